@@ -1,0 +1,126 @@
+/* vieo_hot.h -- C-ABI of the MI355X-native VIEO_SLAM hot path (libvieo_hot.so).
+ *
+ * The reference has no FFI layer: its boundary is three C++ classes.  Each entry
+ * point below names the reference interface it replaces (file:line relative to the reference
+ * root); INTEGRATION.md shows the C++ shim (VIEO_SLAM::ORBextractor / ORBmatcher / Optimizer with
+ * the reference signatures) that forwards to these.  Plain pointers and sizes only; no C++ /
+ * torch / OpenCV types.  Every function returns an int status: VIEO_OK (0) or a negative
+ * VIEO_E_* code, unless stated otherwise.  Nothing here falls back to a CPU implementation: when
+ * no gfx950 device (or no kernel image for it) is present, create() fails with VIEO_E_NO_DEVICE.
+ *
+ * Pointer naming: h_* = host memory, d_* = device (HBM) memory.
+ */
+#ifndef VIEO_HOT_H
+#define VIEO_HOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIEO_OK 0
+#define VIEO_E_INVALID (-1)    /* bad argument */
+#define VIEO_E_NO_DEVICE (-2)  /* no HIP device / kernels unavailable: there is NO CPU fallback */
+#define VIEO_E_HIP (-3)        /* a HIP runtime call failed; see vieo_last_error() */
+#define VIEO_E_CAPACITY (-4)   /* caller buffer too small; required size reported */
+#define VIEO_E_EMPTY (-5)      /* empty image (reference: operator() returns -1) */
+
+const char* vieo_last_error(void);
+/* 1 if a usable gfx950 device is visible, 0 otherwise (never throws, never computes). */
+int vieo_device_available(void);
+const char* vieo_version(void);
+
+/* ---- device memory / stream helpers (so a C, C++ or ctypes host needs no other runtime) ---- */
+int vieo_dev_malloc(void** d_ptr, size_t bytes);
+int vieo_dev_free(void* d_ptr);
+int vieo_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int vieo_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int vieo_device_synchronize(void);
+
+/* ---------------------------------------------------------------- ORB extractor ------------
+ * Replaces VIEO_SLAM::ORBextractor (include/ORBextractor.h:27-80, src/ORBextractor.cc:391-1081).
+ */
+
+/* Same memory layout as cv::KeyPoint (28 bytes): the C++ shim memcpy's. */
+typedef struct vieo_keypoint {
+  float x, y;     /* level-0 pixel coordinates */
+  float size;     /* 31 * scale[octave] truncated (ORBextractor.cc:787) */
+  float angle;    /* degrees, cv::fastAtan2 of the intensity centroid */
+  float response; /* FAST score */
+  int32_t octave;
+  int32_t class_id; /* always -1 */
+} vieo_keypoint;
+
+typedef struct vieo_orb vieo_orb; /* opaque */
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (ORBextractor.cc:391-456).  Device buffers are sized lazily at the first extract call. */
+int vieo_orb_create(vieo_orb** out, int nfeatures, float scale_factor, int nlevels,
+                    int ini_th_fast, int min_th_fast);
+void vieo_orb_destroy(vieo_orb* e);
+
+/* Getters of include/ORBextractor.h:42-52 (tables are float[nlevels]). */
+int vieo_orb_levels(const vieo_orb* e);
+float vieo_orb_scale_factor(const vieo_orb* e);
+int vieo_orb_scale_factors(const vieo_orb* e, float* h_out);
+int vieo_orb_inv_scale_factors(const vieo_orb* e, float* h_out);
+int vieo_orb_level_sigma2(const vieo_orb* e, float* h_out);
+int vieo_orb_inv_level_sigma2(const vieo_orb* e, float* h_out);
+int vieo_orb_features_per_level(const vieo_orb* e, int* h_out);
+/* Upper bound on keypoints one image can return (nfeatures + 3*nlevels + slack). */
+int vieo_orb_max_keypoints(const vieo_orb* e);
+
+/* int ORBextractor::operator()(image, mask, keypoints, descriptors, pvLappingArea)
+ * (ORBextractor.cc:968-1058), host buffers in/out, synchronous.
+ *   h_image: 8-bit grey, `stride` bytes per row.        h_lapping: NULL or int[2].
+ *   h_keypoints[capacity], h_descriptors[capacity*32].
+ *   *n_keypoints = number written; *mono_index = the reference's return value (0 without
+ *   lapping area).  Returns VIEO_E_EMPTY for an empty image (reference returns -1). */
+int vieo_orb_extract(vieo_orb* e, const uint8_t* h_image, int width, int height, int stride,
+                     const int* h_lapping, vieo_keypoint* h_keypoints, uint8_t* h_descriptors,
+                     int capacity, int* n_keypoints, int* mono_index);
+
+/* Batched, device-resident form of the same call: n_images frames of identical size, image i at
+ * d_images + i*image_pitch_bytes.  Asynchronous on the extractor's stream; outputs stay in HBM:
+ *   d_keypoints  [n_images][capacity]      d_descriptors [n_images][capacity][32]
+ *   d_counts     [n_images][2] int32 = {n_keypoints, mono_index}
+ * This is the form the frame-sharded throughput path (bench.py) uses. */
+int vieo_orb_extract_batch_device(vieo_orb* e, const uint8_t* d_images, int n_images, int width,
+                                  int height, int stride, size_t image_pitch_bytes,
+                                  const int* h_lapping, vieo_keypoint* d_keypoints,
+                                  uint8_t* d_descriptors, int capacity, int32_t* d_counts);
+int vieo_orb_sync(vieo_orb* e);
+
+/* mvImagePyramid (include/ORBextractor.h:54, read by Frame.cc:457,536-557): size and pixels of
+ * pyramid level `level` of image `image_index` of the LAST call, valid until the next call.
+ * with_border != 0 returns the (w+38)x(h+38) plane with the 19-px BORDER_REFLECT_101 frame that
+ * ComputePyramid builds (ORBextractor.cc:1060-1081); the ROI origin is then at (+19,+19). */
+int vieo_orb_level_size(const vieo_orb* e, int level, int* width, int* height);
+int vieo_orb_get_level(vieo_orb* e, int image_index, int level, int with_border, uint8_t* h_dst,
+                       int dst_stride);
+/* Device view of the same plane (borderless): pointer + pitch, for device-side consumers
+ * (the rectified stereo matcher reads it in place). */
+int vieo_orb_level_device(vieo_orb* e, int image_index, int level, const uint8_t** d_ptr,
+                          int* pitch);
+
+/* Wall-clock-free timing of the kernels of the last batch call, measured with HIP events on the
+ * extractor's own stream: milliseconds for {pyramid, fast, quadtree, blur, describe, total}. */
+#define VIEO_ORB_NSTAGES 6
+int vieo_orb_last_stage_ms(vieo_orb* e, float* h_ms /*[VIEO_ORB_NSTAGES]*/);
+int vieo_orb_enable_timing(vieo_orb* e, int on);
+
+/* ---- test taps (parity tests only; not part of the drop-in surface) ---- */
+/* which: 1 = blurred level.  FAST candidates: int32 triplets (x, y, response) in
+ * vToDistributeKeys order; level keys: vieo_keypoint in DistributeOctTree output order. */
+int vieo_orb_tap_plane(vieo_orb* e, int image_index, int level, int which, uint8_t* h_dst,
+                       int dst_stride);
+int vieo_orb_tap_candidates(vieo_orb* e, int image_index, int level, int32_t* h_dst, int cap);
+int vieo_orb_tap_level_keys(vieo_orb* e, int image_index, int level, vieo_keypoint* h_dst,
+                            int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIEO_HOT_H */
