@@ -1,0 +1,160 @@
+"""ctypes wrapper of the CPU oracle (oracle/_build/liboracle.so).  Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+
+def build(native=False):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"),
+                           "NATIVE=%d" % int(native)])
+    name = "liboracle_native.so" if native else "liboracle.so"
+    return os.path.join(ROOT, "oracle", "_build", name)
+
+
+class Oracle:
+    def __init__(self, path):
+        L = ctypes.CDLL(path)
+        L.vo_orb_create.restype = P
+        L.vo_orb_create.argtypes = [I, F, I, I, I]
+        L.vo_orb_destroy.argtypes = [P]
+        L.vo_orb_extract.argtypes = [P, P, I, I, I, P, P, P, I, P]
+        L.vo_orb_features_per_level.argtypes = [P, I]
+        L.vo_orb_scale_factor.argtypes = [P, I]
+        L.vo_orb_scale_factor.restype = F
+        L.vo_orb_umax.argtypes = [P, I]
+        L.vo_orb_tie_count.argtypes = [P]
+        L.vo_orb_tie_count.restype = ctypes.c_long
+        L.vo_orb_level_size.argtypes = [P, I, P, P]
+        L.vo_orb_get_plane.argtypes = [P, I, I, P]
+        L.vo_orb_get_candidates.argtypes = [P, I, P, I]
+        L.vo_orb_get_level_keys.argtypes = [P, I, P, I]
+        L.vo_resize_linear_u8.argtypes = [P, I, I, P, I, I]
+        L.vo_gaussian_blur7.argtypes = [P, I, I, P]
+        L.vo_fast.argtypes = [P, I, I, I, P, I]
+        L.vo_fast_atan2.argtypes = [F, F]
+        L.vo_fast_atan2.restype = F
+        L.vo_cv_round_f.argtypes = [F]
+        L.vo_sincos_ref.argtypes = [F, P, P]
+        L.vo_distribute_octtree.argtypes = [P, I, I, I, I, I, I, P, I]
+        self.L = L
+
+    # ---- primitives
+    def resize(self, src, dw, dh):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros((dh, dw), np.uint8)
+        self.L.vo_resize_linear_u8(src.ctypes.data, src.shape[1], src.shape[0], dst.ctypes.data, dw, dh)
+        return dst
+
+    def blur(self, src):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros_like(src)
+        self.L.vo_gaussian_blur7(src.ctypes.data, src.shape[1], src.shape[0], dst.ctypes.data)
+        return dst
+
+    def fast(self, src, threshold, cap=100000):
+        src = np.ascontiguousarray(src, np.uint8)
+        out = np.zeros((cap, 3), np.int32)
+        n = self.L.vo_fast(src.ctypes.data, src.shape[1], src.shape[0], threshold, out.ctypes.data, cap)
+        assert n >= 0
+        return out[:n].copy()
+
+    def fast_atan2(self, y, x):
+        return self.L.vo_fast_atan2(y, x)
+
+    def cv_round(self, v):
+        return self.L.vo_cv_round_f(v)
+
+    def sincos(self, angle_deg):
+        c, s = F(), F()
+        self.L.vo_sincos_ref(angle_deg, ctypes.byref(c), ctypes.byref(s))
+        return c.value, s.value
+
+    def distribute(self, xyr, minX, maxX, minY, maxY, N):
+        xyr = np.ascontiguousarray(xyr, np.int32)
+        out = np.zeros((N + 64, 3), np.int32)
+        n = self.L.vo_distribute_octtree(xyr.ctypes.data, len(xyr), minX, maxX, minY, maxY, N,
+                                         out.ctypes.data, N + 64)
+        assert n >= 0, n
+        return out[:n].copy()
+
+    def extractor(self, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7):
+        return OracleExtractor(self.L, nfeatures, scale, nlevels, ini, mn)
+
+
+class OracleExtractor:
+    def __init__(self, L, nfeatures, scale, nlevels, ini, mn):
+        self.L = L
+        self.nlevels = nlevels
+        self.h = P(L.vo_orb_create(nfeatures, scale, nlevels, ini, mn))
+
+    def __del__(self):
+        try:
+            self.L.vo_orb_destroy(self.h)
+        except Exception:
+            pass
+
+    def __call__(self, image, lapping=None, cap=20000):
+        img = np.ascontiguousarray(image, np.uint8)
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = I()
+        lap = None
+        if lapping is not None:
+            lap = (I * 2)(int(lapping[0]), int(lapping[1]))
+        r = self.L.vo_orb_extract(self.h, img.ctypes.data, img.shape[1], img.shape[0], img.strides[0],
+                                  lap, kps.ctypes.data, desc.ctypes.data, cap, ctypes.byref(n))
+        assert r != -2, "oracle capacity"
+        if r == -1:
+            return -1, kps[:0], desc[:0]
+        return r, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def features_per_level(self):
+        return [self.L.vo_orb_features_per_level(self.h, l) for l in range(self.nlevels)]
+
+    def scale_factors(self):
+        return [self.L.vo_orb_scale_factor(self.h, l) for l in range(self.nlevels)]
+
+    def tie_count(self):
+        return self.L.vo_orb_tie_count(self.h)
+
+    def level_size(self, l):
+        w, h = I(), I()
+        self.L.vo_orb_level_size(self.h, l, ctypes.byref(w), ctypes.byref(h))
+        return w.value, h.value
+
+    def plane(self, l, which=0):
+        w, h = self.level_size(l)
+        if which == 2:
+            w, h = w + 38, h + 38
+        out = np.zeros((h, w), np.uint8)
+        self.L.vo_orb_get_plane(self.h, l, which, out.ctypes.data)
+        return out
+
+    def candidates(self, l, cap=200000):
+        out = np.zeros((cap, 3), np.int32)
+        n = self.L.vo_orb_get_candidates(self.h, l, out.ctypes.data, cap)
+        assert n >= 0
+        return out[:n].copy()
+
+    def level_keys(self, l, cap=20000):
+        out = np.zeros(cap, KEYPOINT_DTYPE)
+        n = self.L.vo_orb_get_level_keys(self.h, l, out.ctypes.data, cap)
+        assert n >= 0
+        return out[:n].copy()
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is None:
+        _cached = Oracle(build())
+    return _cached

@@ -1,0 +1,118 @@
+"""ctypes binding of libvieo_hot.so (the C-ABI of include/vieo_hot.h).
+
+There is no CPU fallback: if the shared object is missing, or no gfx950 device is visible when a
+compute entry point is used, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvieo_hot.so")
+
+VIEO_OK = 0
+VIEO_E_INVALID, VIEO_E_NO_DEVICE, VIEO_E_HIP, VIEO_E_CAPACITY, VIEO_E_EMPTY = -1, -2, -3, -4, -5
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+P = ctypes.POINTER
+
+_SIGS = {
+    "vieo_last_error": (ctypes.c_char_p, []),
+    "vieo_device_available": (c_i, []),
+    "vieo_version": (ctypes.c_char_p, []),
+    "vieo_dev_malloc": (c_i, [P(c_p), c_sz]),
+    "vieo_dev_free": (c_i, [c_p]),
+    "vieo_memcpy_h2d": (c_i, [c_p, c_p, c_sz]),
+    "vieo_memcpy_d2h": (c_i, [c_p, c_p, c_sz]),
+    "vieo_device_synchronize": (c_i, []),
+    "vieo_orb_create": (c_i, [P(c_p), c_i, c_f, c_i, c_i, c_i]),
+    "vieo_orb_destroy": (None, [c_p]),
+    "vieo_orb_levels": (c_i, [c_p]),
+    "vieo_orb_scale_factor": (c_f, [c_p]),
+    "vieo_orb_scale_factors": (c_i, [c_p, c_p]),
+    "vieo_orb_inv_scale_factors": (c_i, [c_p, c_p]),
+    "vieo_orb_level_sigma2": (c_i, [c_p, c_p]),
+    "vieo_orb_inv_level_sigma2": (c_i, [c_p, c_p]),
+    "vieo_orb_features_per_level": (c_i, [c_p, c_p]),
+    "vieo_orb_max_keypoints": (c_i, [c_p]),
+    "vieo_orb_extract": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, P(c_i), P(c_i)]),
+    "vieo_orb_extract_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_sz, c_p, c_p, c_p, c_i, c_p]),
+    "vieo_orb_sync": (c_i, [c_p]),
+    "vieo_orb_level_size": (c_i, [c_p, c_i, P(c_i), P(c_i)]),
+    "vieo_orb_get_level": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),
+    "vieo_orb_level_device": (c_i, [c_p, c_i, c_i, P(c_p), P(c_i)]),
+    "vieo_orb_last_stage_ms": (c_i, [c_p, c_p]),
+    "vieo_orb_enable_timing": (c_i, [c_p, c_i]),
+    "vieo_orb_tap_plane": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),
+    "vieo_orb_tap_candidates": (c_i, [c_p, c_i, c_i, c_p, c_i]),
+    "vieo_orb_tap_level_keys": (c_i, [c_p, c_i, c_i, c_p, c_i]),
+}
+
+_lib = None
+
+
+class VieoError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every extern "C" symbol include/vieo_hot.h declares (used by the ABI export test)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VieoError(
+                "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != VIEO_OK:
+        msg = lib().vieo_last_error().decode(errors="replace")
+        raise VieoError("%s failed (%d): %s" % (what, rc, msg))
+
+
+class DeviceBuffer:
+    """Plain HBM allocation owned through the C-ABI (no torch needed)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = c_p()
+        check(lib().vieo_dev_malloc(ctypes.byref(p), self.nbytes), "vieo_dev_malloc")
+        self.ptr = p.value
+
+    def upload(self, arr):
+        import numpy as np
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        check(lib().vieo_memcpy_h2d(self.ptr, a.ctypes.data, a.nbytes), "h2d")
+
+    def download(self, dtype, shape):
+        import numpy as np
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().vieo_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes), "d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().vieo_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

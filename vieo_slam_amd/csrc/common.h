@@ -1,0 +1,53 @@
+// common.h -- shared host-side helpers of libvieo_hot.so (gfx950 only; no CPU fallback paths).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/vieo_hot.h"
+
+namespace vieo {
+
+void set_error(const char* fmt, ...);
+
+#define VIEO_HIP_CHECK(expr)                                                             \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      vieo::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      return VIEO_E_HIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// One growable device allocation.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return VIEO_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    VIEO_HIP_CHECK(hipMalloc(&p, bytes));
+    cap = bytes;
+    return VIEO_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return (T*)p;
+  }
+};
+
+int require_device();  // VIEO_OK or VIEO_E_NO_DEVICE
+
+}  // namespace vieo

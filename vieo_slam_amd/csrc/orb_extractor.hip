@@ -1,0 +1,1165 @@
+// orb_extractor.hip -- MI355X (gfx950) ORB extractor behind the C-ABI of include/vieo_hot.h.
+//
+// Replaces VIEO_SLAM::ORBextractor (reference: src/ORBextractor.cc, include/ORBextractor.h).
+// Frames are processed in batches that stay resident in HBM; per batch the launch sequence is
+//   k_resize x (nlevels-1)  ComputePyramid            (ORBextractor.cc:1060-1081)
+//   k_fast                  per-cell FAST 20/7 + NMS   (:723-779)  one wavefront per cell,
+//                                                       cell tile staged in LDS
+//   k_quadtree              DistributeOctTree          (:518-721)  one workgroup per (image,level)
+//   k_blur                  GaussianBlur 7x7 s=2       (:1012-1015) LDS-tiled separable Q8.8
+//   k_describe              IC_Angle + steered BRIEF   (:55-127, 1024-1054) one wavefront / key
+//   k_lapping               lapping-area reorder       (:1041-1052) only when pvLappingArea
+// All arithmetic is integer or strictly-ordered float (-ffp-contract=off), so keypoints and
+// descriptors are bit-exact against oracle/ (tests/test_orb_parity.py).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/vieo_orb_pattern_31.h"
+#include "common.h"
+#include "sincosf_exact.h"
+
+#define QT_DEVICE
+#include "quadtree.inl"
+
+namespace vieo {
+
+static const int kPatchSize = 31, kHalfPatch = 15, kEdge = 19;
+static const int kMaxLevels = 16;
+static const int kBlurTW = 64, kBlurTH = 32;
+
+struct LevelDesc {
+  int w, h, pitch, off;      // plane geometry; off = byte offset in the per-image pyramid block
+  int boff;                  // byte offset in the per-image blurred block
+  int cell_begin, cell_end;  // range in the cell table
+  int nfeat;                 // mnFeaturesPerLevel
+  int regW, regH, nIni;      // DistributeOctTree region and root nodes
+  float hX;
+  int key_off, key_cap;  // candidate-key arena of this level inside the per-image arena
+  int sel_off, ncap;     // selected-key arena / node capacity
+  int xtab_off, ytab_off;
+  float scale;
+  int patch;
+  int tile_begin, tile_end, tiles_x;
+};
+
+struct OrbParams {
+  int nlevels, cell_cap, ncells, keys_per_image, sel_per_image, kp_cap;
+  int umax[kHalfPatch + 1];
+  LevelDesc lv[kMaxLevels];
+};
+
+struct CellDesc {
+  short level, x0, y0, cw, ch, offx, offy, pad;
+};
+
+struct ImgSet {  // where the planes of a batch live
+  const uint8_t* img0;
+  int stride0;
+  size_t img_pitch;
+  uint8_t* pyr;
+  size_t pyr_img;
+  uint8_t* blur;
+  size_t blur_img;
+};
+
+__device__ __forceinline__ const uint8_t* plane_ptr(const OrbParams& P, const ImgSet& I, int b,
+                                                    int l, int* pitch) {
+  if (l == 0) {
+    *pitch = I.stride0;
+    return I.img0 + (size_t)b * I.img_pitch;
+  }
+  *pitch = P.lv[l].pitch;
+  return I.pyr + (size_t)b * I.pyr_img + P.lv[l].off;
+}
+
+// ------------------------------------------------------------------ pyramid (cv::resize)
+// xtab: {sx0, sx1, a0, a1}; ytab: {sy0, sy1, b0, b1}; INTER_LINEAR 8U fixed point:
+// H = S[sx0]*a0 + S[sx1]*a1 (x2048), D = (((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2.
+__global__ void __launch_bounds__(256)
+k_resize(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab,
+         const short4* __restrict__ ytab) {
+  const LevelDesc& D = P.lv[l];
+  const int b = blockIdx.z;
+  const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+  const int dx4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (dy >= D.h || dx4 >= D.w) return;
+  int spitch;
+  const uint8_t* src = plane_ptr(P, I, b, l - 1, &spitch);
+  const short4 yt = ytab[D.ytab_off + dy];
+  const uint8_t* r0 = src + (size_t)yt.x * spitch;
+  const uint8_t* r1 = src + (size_t)yt.y * spitch;
+  unsigned out = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int dx = dx4 + j;
+    if (dx < D.w) {
+      const short4 xt = xtab[D.xtab_off + dx];
+      const int h0 = r0[xt.x] * xt.z + r0[xt.y] * xt.w;
+      const int h1 = r1[xt.x] * xt.z + r1[xt.y] * xt.w;
+      const int v = (((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2;
+      out |= (unsigned)(v & 0xFF) << (8 * j);
+    }
+  }
+  uint8_t* dst = I.pyr + (size_t)b * I.pyr_img + D.off;
+  *(unsigned*)(dst + (size_t)dy * D.pitch + dx4) = out;
+}
+
+// ------------------------------------------------------------------ FAST-9/16 per cell
+// Threshold-free corner strength r = max over the 16 arcs of 9 contiguous ring pixels of
+// min(v - x) (dark arcs) and of min(x - v) (bright arcs).  cv::FAST(t) declares a corner iff
+// r > t and cornerScore<16> is then r - 1, for every t: one evaluation serves both thresholds.
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+__device__ __forceinline__ int fast_strength(const uint8_t* t, int p) {
+  const int v = t[0];
+  int d[16];
+  d[0] = v - t[3 * p];
+  d[1] = v - t[3 * p + 1];
+  d[2] = v - t[2 * p + 2];
+  d[3] = v - t[p + 3];
+  d[4] = v - t[3];
+  d[5] = v - t[-p + 3];
+  d[6] = v - t[-2 * p + 2];
+  d[7] = v - t[-3 * p + 1];
+  d[8] = v - t[-3 * p];
+  d[9] = v - t[-3 * p - 1];
+  d[10] = v - t[-2 * p - 2];
+  d[11] = v - t[-p - 3];
+  d[12] = v - t[-3];
+  d[13] = v - t[p - 3];
+  d[14] = v - t[2 * p - 2];
+  d[15] = v - t[3 * p - 1];
+  int lo3[16], hi3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+  }
+  int A = -256, B = 256;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    A = max(A, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+    B = min(B, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+  }
+  return max(max(A, -B), 0);
+}
+
+__global__ void __launch_bounds__(64)
+k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __restrict__ cell_keys,
+       int* __restrict__ cell_counts, int iniTh, int minTh, int tpitch, int tile_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const CellDesc cd = cells[c];
+  int pitch;
+  const uint8_t* src = plane_ptr(P, I, b, cd.level, &pitch);
+  uint8_t* tile = smem;
+  uint8_t* sc = smem + tile_bytes;
+  const int x0a = cd.x0 & ~3;
+  const int ndw = ((cd.x0 + cd.cw + 3) >> 2) - (x0a >> 2);
+  const float inv_ndw = 1.0f / (float)ndw;
+  for (int idx = lane; idx < cd.ch * ndw; idx += 64) {
+    int r = (int)((float)idx * inv_ndw);
+    int dcol = idx - r * ndw;
+    if (dcol >= ndw) r++, dcol -= ndw;
+    if (dcol < 0) r--, dcol += ndw;
+    const unsigned v = *(const unsigned*)(src + (size_t)(cd.y0 + r) * pitch + x0a + 4 * dcol);
+    *(unsigned*)(tile + r * tpitch + 4 * dcol) = v;
+  }
+  const int vw = cd.cw - 6, vh = cd.ch - 6;
+  const int npx = (vw > 0 && vh > 0) ? vw * vh : 0;
+  const int sp = vw + 2;
+  if (npx > 0)
+    for (int idx = lane; idx < ((vh + 2) * sp + 3) / 4; idx += 64) ((unsigned*)sc)[idx] = 0;
+  __syncthreads();
+  const int xo = cd.x0 - x0a;
+  const float inv_vw = npx > 0 ? 1.0f / (float)vw : 0.f;
+  for (int p = lane; p < npx; p += 64) {
+    int y = (int)((float)p * inv_vw);
+    int x = p - y * vw;
+    if (x >= vw) y++, x -= vw;
+    if (x < 0) y--, x += vw;
+    const int r = fast_strength(tile + (y + 3) * tpitch + (x + 3 + xo), tpitch);
+    sc[(y + 1) * sp + x + 1] = (uint8_t)r;
+  }
+  __syncthreads();
+  unsigned* out = cell_keys + ((size_t)b * P.ncells + c) * P.cell_cap;
+  int base = 0;
+  for (int pass = 0; pass < 2 && base == 0; pass++) {
+    const int th = pass == 0 ? iniTh : minTh;
+    for (int p0 = 0; p0 < npx; p0 += 64) {
+      const int p = p0 + lane;
+      bool keep = false;
+      unsigned key = 0;
+      if (p < npx) {
+        int y = (int)((float)p * inv_vw);
+        int x = p - y * vw;
+        if (x >= vw) y++, x -= vw;
+        if (x < 0) y--, x += vw;
+        const uint8_t* s = sc + (y + 1) * sp + x + 1;
+        const int r = s[0];
+        if (r > th) {
+          const int sv = r - 1;
+#define NB(o) ((s[o] > th) ? (int)s[o] - 1 : 0)
+          keep = sv > NB(1) && sv > NB(-1) && sv > NB(-sp - 1) && sv > NB(-sp) && sv > NB(-sp + 1) &&
+                 sv > NB(sp - 1) && sv > NB(sp) && sv > NB(sp + 1);
+#undef NB
+          key = (unsigned)(x + 3 + cd.offx) | ((unsigned)(y + 3 + cd.offy) << 12) |
+                ((unsigned)sv << 24);
+        }
+      }
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < P.cell_cap) out[pos] = key;
+      }
+      base += __popcll(m);
+    }
+  }
+  if (lane == 0) cell_counts[(size_t)b * P.ncells + c] = min(base, P.cell_cap);
+}
+
+// ------------------------------------------------------------------ quadtree
+__global__ void __launch_bounds__(256)
+k_quadtree(OrbParams P, const unsigned* __restrict__ cell_keys,
+           const int* __restrict__ cell_counts, unsigned* __restrict__ keys,
+           unsigned short* __restrict__ kslot, unsigned char* __restrict__ kq,
+           unsigned* __restrict__ sel, int* __restrict__ sel_count, int ncap_max, int scap_max) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int l = blockIdx.x, b = blockIdx.y;
+  const LevelDesc& D = P.lv[l];
+  // carve LDS (8-byte items first)
+  uint8_t* q = smem;
+  QtMem m;
+  m.scanA = (unsigned long long*)q;
+  q += sizeof(unsigned long long) * scap_max;
+  m.scanB = (unsigned long long*)q;
+  q += sizeof(unsigned long long) * scap_max;
+  m.cnt = (int*)q;
+  q += 4 * ncap_max;
+  m.cc = (int*)q;
+  q += 16 * ncap_max;
+  m.best = (unsigned*)q;
+  q += 4 * ncap_max;
+  m.cand_size[0] = (int*)q;
+  q += 4 * ncap_max;
+  m.cand_size[1] = (int*)q;
+  q += 4 * ncap_max;
+  m.s = (QtShared*)q;
+  q += 64;
+  m.x0 = (short*)q;
+  q += 2 * ncap_max;
+  m.y0 = (short*)q;
+  q += 2 * ncap_max;
+  m.x1 = (short*)q;
+  q += 2 * ncap_max;
+  m.y1 = (short*)q;
+  q += 2 * ncap_max;
+  m.child = (unsigned short*)q;
+  q += 8 * ncap_max;
+  m.mark = (unsigned short*)q;
+  q += 2 * ncap_max;
+  m.list[0] = (unsigned short*)q;
+  q += 2 * ncap_max;
+  m.list[1] = (unsigned short*)q;
+  q += 2 * ncap_max;
+  m.cand_slot[0] = (unsigned short*)q;
+  q += 2 * ncap_max;
+  m.cand_slot[1] = (unsigned short*)q;
+  q += 2 * ncap_max;
+  m.order = (unsigned short*)q;
+  q += 2 * ncap_max;
+  m.flag = (unsigned char*)q;
+  m.ncap = D.ncap;
+  m.scap = scap_max;
+
+  const int tid = threadIdx.x;
+  const int ncell = D.cell_end - D.cell_begin;
+  const int* cnts = cell_counts + (size_t)b * P.ncells + D.cell_begin;
+  // ---- concatenate the per-cell lists in cell order = vToDistributeKeys order
+  for (int i = tid; i < ncell; i += blockDim.x) m.scanA[i] = (unsigned long long)cnts[i];
+  for (int i = tid; i < D.nIni; i += blockDim.x) m.cnt[i] = 0;
+  __syncthreads();
+  unsigned long long* inc = qt_scan(m.scanA, m.scanB, ncell);
+  if (tid == 0) m.s->K = ncell > 0 ? (int)inc[ncell - 1] : 0;
+  __syncthreads();
+  const int K = m.s->K;
+  unsigned* kk = keys + (size_t)b * P.keys_per_image + D.key_off;
+  unsigned short* ks = kslot + (size_t)b * P.keys_per_image + D.key_off;
+  unsigned char* kqq = kq + (size_t)b * P.keys_per_image + D.key_off;
+  {
+    const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
+    for (int c = wave; c < ncell; c += nwaves) {
+      const int cnt = cnts[c];
+      const int base = (int)inc[c] - cnt;
+      const unsigned* src = cell_keys + ((size_t)b * P.ncells + D.cell_begin + c) * P.cell_cap;
+      for (int i = lane; i < cnt; i += 64) {
+        const unsigned key = src[i];
+        kk[base + i] = key;
+        // vpIniNodes[kp.pt.x / hX]  (ORBextractor.cc:549)
+        const int ini = (int)((float)QT_KEY_X(key) / D.hX);
+        ks[base + i] = (unsigned short)ini;
+        atomicAdd(&m.cnt[ini], 1);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned* out = sel + (size_t)b * P.sel_per_image + D.sel_off;
+  const int n = qt_distribute(m, kk, ks, kqq, D.regW, D.regH, D.nIni, D.hX, D.nfeat, out);
+  if (tid == 0) sel_count[b * kMaxLevels + l] = m.s->error ? -1 : n;
+}
+
+// ------------------------------------------------------------------ Gaussian blur 7x7, sigma 2
+// Q8.8 kernel {18,34,48,56,48,34,18}: horizontal pass exact in 16 bits, vertical pass
+// (sum + 2^15) >> 16; BORDER_REFLECT_101 on the level itself.
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * (len - 1) - p;
+  return p;
+}
+
+struct BlurTile {
+  short level, tx, ty, pad;
+};
+
+__global__ void __launch_bounds__(256)
+k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles) {
+  __shared__ uint8_t s_src[(kBlurTH + 6) * (kBlurTW + 8)];
+  __shared__ unsigned short s_h[(kBlurTH + 6) * kBlurTW];
+  const BlurTile t = tiles[blockIdx.x];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const LevelDesc& D = P.lv[t.level];
+  int pitch;
+  const uint8_t* src = plane_ptr(P, I, b, t.level, &pitch);
+  const int ox = t.tx * kBlurTW, oy = t.ty * kBlurTH;
+  const int SW = kBlurTW + 6, SP = kBlurTW + 8, SH = kBlurTH + 6;
+  for (int idx = tid; idx < SH * SW; idx += 256) {
+    const int r = idx / SW, c = idx - r * SW;
+    const int gy = reflect101(min(oy + r - 3, D.h + 2), D.h);
+    const int gx = reflect101(min(ox + c - 3, D.w + 2), D.w);
+    s_src[r * SP + c] = src[(size_t)gy * pitch + gx];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < SH * kBlurTW; idx += 256) {
+    const int r = idx / kBlurTW, c = idx - r * kBlurTW;
+    const uint8_t* s = s_src + r * SP + c;
+    const int v = 18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 48 * (s[2] + s[4]) + 56 * s[3];
+    s_h[r * kBlurTW + c] = (unsigned short)v;
+  }
+  __syncthreads();
+  uint8_t* dst = I.blur + (size_t)b * I.blur_img + D.boff;
+  for (int idx = tid; idx < kBlurTH * kBlurTW / 4; idx += 256) {
+    const int r = idx / (kBlurTW / 4), c4 = (idx - r * (kBlurTW / 4)) * 4;
+    const int gy = oy + r, gx = ox + c4;
+    if (gy >= D.h || gx >= D.w) continue;
+    unsigned outv = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned short* h = s_h + r * kBlurTW + c4 + j;
+      const unsigned v = 18u * (h[0] + h[6 * kBlurTW]) + 34u * (h[kBlurTW] + h[5 * kBlurTW]) +
+                         48u * (h[2 * kBlurTW] + h[4 * kBlurTW]) + 56u * h[3 * kBlurTW];
+      outv |= (((v + (1u << 15)) >> 16) & 0xFFu) << (8 * j);
+    }
+    *(unsigned*)(dst + (size_t)gy * D.pitch + gx) = outv;
+  }
+}
+
+// ------------------------------------------------------------------ orientation + descriptor
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// cv::fastAtan2 (degrees), float arithmetic in the published order
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+  const float eps = (float)2.2204460492503131e-16;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + eps);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + eps);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__global__ void __launch_bounds__(256)
+k_describe(OrbParams P, ImgSet I, const unsigned* __restrict__ sel,
+           const int* __restrict__ sel_count, const int* __restrict__ pattern,
+           vieo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int out_cap,
+           int* __restrict__ counts, int write_counts) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // level of keypoint g in the level-concatenated order (ORBextractor.cc:1005-1054)
+  int level = -1, idx = 0, total = 0;
+  for (int l = 0; l < P.nlevels; l++) {
+    const int n = max(sel_count[b * kMaxLevels + l], 0);
+    if (level < 0 && g < total + n) {
+      level = l;
+      idx = g - total;
+    }
+    total += n;
+  }
+  if (g == 0 && lane == 0 && write_counts) {
+    counts[2 * b] = min(total, out_cap);
+    counts[2 * b + 1] = 0;
+  }
+  if (level < 0 || g >= out_cap) return;
+  const LevelDesc& D = P.lv[level];
+  const unsigned key = sel[(size_t)b * P.sel_per_image + D.sel_off + idx];
+  const int cx = QT_KEY_X(key) + (kEdge - 3), cy = QT_KEY_Y(key) + (kEdge - 3);
+  int pitch;
+  const uint8_t* img = plane_ptr(P, I, b, level, &pitch);
+  // ---- IC_Angle: two lanes per row of the radius-15 disc
+  int m10 = 0, m01 = 0;
+  if (lane < 62) {
+    const int v = (lane >> 1) - kHalfPatch;
+    const int d = P.umax[v < 0 ? -v : v];
+    const uint8_t* row = img + (size_t)(cy + v) * pitch + cx;
+    const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
+    int sI = 0;
+    for (int u = u0; u <= u1; u++) {
+      const int val = row[u];
+      m10 += u * val;
+      sI += val;
+    }
+    m01 = v * sI;
+  }
+  m10 = wave_sum(m10);
+  m01 = wave_sum(m01);
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  // ---- steered BRIEF on the blurred plane (ORBextractor.cc:83-127)
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float a, bsin;
+  vieo_sincosf_exact(angle * factorPI, &bsin, &a);
+  const uint8_t* bl = I.blur + (size_t)b * I.blur_img + D.boff + (size_t)cy * D.pitch + cx;
+  const int bp = D.pitch;
+  unsigned long long bits[4];
+#pragma unroll
+  for (int gq = 0; gq < 4; gq++) {
+    const int pt = pattern[gq * 64 + lane];  // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
+    const float x0 = (float)(signed char)(pt & 0xFF), y0 = (float)(signed char)((pt >> 8) & 0xFF);
+    const float x1 = (float)(signed char)((pt >> 16) & 0xFF), y1 = (float)(signed char)((pt >> 24) & 0xFF);
+    const int t0 = bl[__float2int_rn(x0 * bsin + y0 * a) * bp + __float2int_rn(x0 * a - y0 * bsin)];
+    const int t1 = bl[__float2int_rn(x1 * bsin + y1 * a) * bp + __float2int_rn(x1 * a - y1 * bsin)];
+    bits[gq] = __ballot(t0 < t1);
+  }
+  if (lane < 4) ((unsigned long long*)(desc_out + ((size_t)b * out_cap + g) * 32))[lane] = bits[lane];
+  if (lane == 0) {
+    vieo_keypoint k;
+    const float fx = (float)cx, fy = (float)cy;
+    k.x = level ? fx * D.scale : fx;
+    k.y = level ? fy * D.scale : fy;
+    k.size = (float)D.patch;
+    k.angle = angle;
+    k.response = (float)QT_KEY_R(key);
+    k.octave = level;
+    k.class_id = -1;
+    kp_out[(size_t)b * out_cap + g] = k;
+  }
+}
+
+// ------------------------------------------------------------------ lapping-area reorder
+// ORBextractor.cc:1041-1052: keys with lap0 <= x <= lap1 fill the output from the back, the
+// others from the front, both in level-concatenated order.  One workgroup per image.
+__global__ void __launch_bounds__(256)
+k_lapping(const vieo_keypoint* __restrict__ kin, const uint8_t* __restrict__ din, int in_cap,
+          vieo_keypoint* __restrict__ kout, uint8_t* __restrict__ dout, int out_cap,
+          const int* __restrict__ tmp_counts, int* __restrict__ counts, int lap0, int lap1) {
+  __shared__ int s_part[256];
+  __shared__ int s_total;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = tmp_counts[2 * b];
+  const int per = (n + 255) / 256;
+  const int i0 = tid * per, i1 = min(n, i0 + per);
+  int mono = 0;
+  for (int i = i0; i < i1; i++) {
+    const float x = kin[(size_t)b * in_cap + i].x;
+    mono += !(x >= (float)lap0 && x <= (float)lap1);
+  }
+  s_part[tid] = mono;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int t = 0; t < 256; t++) {
+      const int v = s_part[t];
+      s_part[t] = acc;
+      acc += v;
+    }
+    s_total = acc;
+  }
+  __syncthreads();
+  int mi = s_part[tid];
+  for (int i = i0; i < i1; i++) {
+    const vieo_keypoint k = kin[(size_t)b * in_cap + i];
+    const bool st = (k.x >= (float)lap0 && k.x <= (float)lap1);
+    const int pos = st ? (n - 1 - (i - mi)) : mi;
+    if (!st) mi++;
+    if (pos < out_cap) {
+      kout[(size_t)b * out_cap + pos] = k;
+      const uint4* s = (const uint4*)(din + ((size_t)b * in_cap + i) * 32);
+      uint4* d = (uint4*)(dout + ((size_t)b * out_cap + pos) * 32);
+      d[0] = s[0];
+      d[1] = s[1];
+    }
+  }
+  if (tid == 0) {
+    counts[2 * b] = min(n, out_cap);
+    counts[2 * b + 1] = s_total;
+  }
+}
+
+// ================================================================== host side
+struct Timing {
+  bool on = false;
+  hipEvent_t ev[VIEO_ORB_NSTAGES + 1] = {};
+  bool valid = false;
+};
+
+}  // namespace vieo
+
+using namespace vieo;
+
+struct vieo_orb {
+  int nfeatures, nlevels, iniTh, minTh;
+  double scaleFactor;  // ORBextractor.h:67 keeps the float argument in a double member
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> feats;
+  int umax[kHalfPatch + 1];
+  hipStream_t stream = nullptr;
+  // geometry the buffers are currently sized for
+  int w = 0, h = 0, B = 0;
+  OrbParams P;
+  std::vector<CellDesc> cells;
+  std::vector<BlurTile> tiles;
+  int tpitch = 0, tile_bytes = 0, fast_lds = 0, qt_lds = 0, ncap_max = 0, scap_max = 0;
+  size_t pyr_img = 0, blur_img = 0;
+  DevBuf d_pyr, d_blur, d_cells, d_tiles, d_xtab, d_ytab, d_cell_keys, d_cell_counts, d_keys,
+      d_kslot, d_kq, d_sel, d_sel_count, d_pattern, d_in, d_kp, d_desc, d_counts, d_tmp_kp,
+      d_tmp_desc, d_tmp_counts;
+  int out_cap = 0;  // capacity of the internal (host-API) output buffers
+  int last_B = 0;
+  ImgSet last_imgs{};
+  Timing tm;
+};
+
+namespace vieo {
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }  // cvRound: half-to-even
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+static inline int cv_floor_d(double v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+static inline int cv_ceil_d(double v) {
+  int i = (int)v;
+  return i + (i < v);
+}
+
+// cv::resize coefficient tables for one axis (INTER_LINEAR, 8U: 11-bit fixed point).
+static void resize_axis_table(int ssize, int dsize, bool horizontal, std::vector<short>& tab) {
+  const double inv_scale = (double)dsize / ssize;
+  const double sc = 1. / inv_scale;
+  tab.resize((size_t)dsize * 4);
+  for (int d = 0; d < dsize; d++) {
+    float f = (float)((d + 0.5) * sc - 0.5);
+    int s = cv_floor_d(f);
+    f -= s;
+    int s0, s1;
+    if (horizontal) {
+      if (s < 0) f = 0, s = 0;
+      if (s >= ssize - 1) f = 0, s = ssize - 1;
+      s0 = s;
+      s1 = std::min(s + 1, ssize - 1);
+    } else {
+      s0 = std::min(std::max(s, 0), ssize - 1);
+      s1 = std::min(std::max(s + 1, 0), ssize - 1);
+    }
+    short a0 = (short)cv_round_f((1.f - f) * 2048);
+    short a1 = (short)cv_round_f(f * 2048);
+    if (horizontal && s >= ssize - 1) a0 = 2048, a1 = 0;
+    tab[d * 4 + 0] = (short)s0;
+    tab[d * 4 + 1] = (short)s1;
+    tab[d * 4 + 2] = a0;
+    tab[d * 4 + 3] = a1;
+  }
+}
+
+static int plan_geometry(vieo_orb* e, int w, int h, int B) {
+  OrbParams& P = e->P;
+  memset(&P, 0, sizeof(P));
+  P.nlevels = e->nlevels;
+  for (int i = 0; i <= kHalfPatch; i++) P.umax[i] = e->umax[i];
+  e->cells.clear();
+  e->tiles.clear();
+  std::vector<short> xtab, ytab;
+  size_t pyr_off = 0, blur_off = 0;
+  int max_cw = 0, max_ch = 0, key_off = 0, sel_off = 0, ncap_max = 0, max_ncell = 0;
+  for (int l = 0; l < e->nlevels; l++) {
+    LevelDesc& D = P.lv[l];
+    const float s = e->inv_scale[l];
+    D.w = cv_round_f((float)w * s);  // ORBextractor.cc:1063
+    D.h = cv_round_f((float)h * s);
+    if (D.w >= 4096 || D.h >= 4096) {
+      set_error("image level %d (%dx%d) exceeds the 4095-pixel key packing", l, D.w, D.h);
+      return VIEO_E_INVALID;
+    }
+    D.pitch = align_up(D.w, 16);
+    if (l > 0) {
+      D.off = (int)pyr_off;
+      pyr_off += (size_t)D.pitch * D.h;
+      pyr_off = align_up_sz(pyr_off, 256);
+    }
+    D.boff = (int)blur_off;
+    blur_off += (size_t)D.pitch * D.h;
+    blur_off = align_up_sz(blur_off, 256);
+    D.nfeat = e->feats[l];
+    D.scale = e->scale[l];
+    D.patch = (int)(kPatchSize * e->scale[l]);  // ORBextractor.cc:787
+    // ---- cells (ORBextractor.cc:729-760)
+    const int minB = kEdge - 3;
+    const int maxBX = D.w - kEdge + 3, maxBY = D.h - kEdge + 3;
+    D.regW = maxBX - minB;
+    D.regH = maxBY - minB;
+    D.cell_begin = (int)e->cells.size();
+    if (D.regW >= 35 && D.regH >= 35) {
+      const float W = 35;
+      const float width = (float)D.regW, height = (float)D.regH;
+      const int nCols = (int)(width / W), nRows = (int)(height / W);
+      const int wCell = (int)ceilf(width / nCols), hCell = (int)ceilf(height / nRows);
+      for (int i = 0; i < nRows; i++) {
+        const float iniY = minB + i * hCell;
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBY - 3) continue;
+        if (maxY > maxBY) maxY = maxBY;
+        for (int j = 0; j < nCols; j++) {
+          const float iniX = minB + j * wCell;
+          float maxX = iniX + wCell + 6;
+          if (iniX >= maxBX - 6) continue;
+          if (maxX > maxBX) maxX = maxBX;
+          CellDesc c;
+          c.level = (short)l;
+          c.x0 = (short)iniX, c.y0 = (short)iniY;
+          c.cw = (short)((int)maxX - (int)iniX), c.ch = (short)((int)maxY - (int)iniY);
+          c.offx = (short)(j * wCell), c.offy = (short)(i * hCell);
+          c.pad = 0;
+          e->cells.push_back(c);
+          max_cw = std::max(max_cw, (int)c.cw);
+          max_ch = std::max(max_ch, (int)c.ch);
+        }
+      }
+      D.nIni = (int)roundf((float)D.regW / (float)D.regH);  // ORBextractor.cc:524
+      if (D.nIni < 1) {
+        set_error("level %d region %dx%d too tall for DistributeOctTree (nIni=0)", l, D.regW, D.regH);
+        return VIEO_E_INVALID;
+      }
+      D.hX = (float)D.regW / (float)D.nIni;
+    } else {
+      set_error("image too small: level %d is %dx%d", l, D.w, D.h);
+      return VIEO_E_INVALID;
+    }
+    D.cell_end = (int)e->cells.size();
+    max_ncell = std::max(max_ncell, D.cell_end - D.cell_begin);
+    D.ncap = std::max(D.nfeat, 4 * D.nIni) + 8;
+    ncap_max = std::max(ncap_max, D.ncap);
+    D.sel_off = sel_off;
+    sel_off += D.ncap;
+    // ---- resize tables
+    if (l > 0) {
+      std::vector<short> t;
+      D.xtab_off = (int)(xtab.size() / 4);
+      resize_axis_table(P.lv[l - 1].w, D.w, true, t);
+      xtab.insert(xtab.end(), t.begin(), t.end());
+      D.ytab_off = (int)(ytab.size() / 4);
+      resize_axis_table(P.lv[l - 1].h, D.h, false, t);
+      ytab.insert(ytab.end(), t.begin(), t.end());
+    }
+    // ---- blur tiles
+    D.tile_begin = (int)e->tiles.size();
+    D.tiles_x = (D.w + kBlurTW - 1) / kBlurTW;
+    for (int ty = 0; ty < (D.h + kBlurTH - 1) / kBlurTH; ty++)
+      for (int tx = 0; tx < D.tiles_x; tx++) e->tiles.push_back({(short)l, (short)tx, (short)ty, 0});
+    D.tile_end = (int)e->tiles.size();
+  }
+  P.ncells = (int)e->cells.size();
+  // strict 8-neighbour local maxima cannot be adjacent: at most ceil(vw/2)*ceil(vh/2) per cell
+  P.cell_cap = std::max(16, ((max_cw - 6 + 1) / 2) * ((max_ch - 6 + 1) / 2));
+  for (int l = 0; l < e->nlevels; l++) {
+    LevelDesc& D = P.lv[l];
+    D.key_off = key_off;
+    D.key_cap = (D.cell_end - D.cell_begin) * P.cell_cap;
+    key_off += D.key_cap;
+    if (D.key_cap >= (1 << 24)) {
+      set_error("too many candidate keys per level");
+      return VIEO_E_INVALID;
+    }
+  }
+  P.keys_per_image = key_off;
+  P.sel_per_image = sel_off;
+  P.kp_cap = sel_off;
+  e->ncap_max = ncap_max;
+  e->scap_max = std::max(2 * ncap_max, max_ncell);
+  e->pyr_img = align_up_sz(pyr_off, 256);
+  e->blur_img = align_up_sz(blur_off, 256);
+  // FAST LDS: cell tile (dword-aligned columns) + strength tile
+  e->tpitch = align_up(max_cw + 3, 4) + 4;
+  e->tile_bytes = align_up(e->tpitch * max_ch, 16);
+  e->fast_lds = e->tile_bytes + align_up((max_cw - 4) * (max_ch - 4), 16) + 16;
+  e->qt_lds = 16 * e->scap_max + (4 + 16 + 4 + 4 + 4) * ncap_max + 64 + (2 * 4 + 8 + 2 * 6) * ncap_max +
+              ncap_max + 64;
+  // ---- device buffers
+  int rc;
+#define ENS(buf, bytes)                 \
+  if ((rc = (buf).ensure(bytes)) != VIEO_OK) return rc
+  ENS(e->d_pyr, e->pyr_img * B);
+  ENS(e->d_blur, e->blur_img * B);
+  ENS(e->d_cells, e->cells.size() * sizeof(CellDesc));
+  ENS(e->d_tiles, e->tiles.size() * sizeof(BlurTile));
+  ENS(e->d_xtab, std::max<size_t>(xtab.size() * 2, 8));
+  ENS(e->d_ytab, std::max<size_t>(ytab.size() * 2, 8));
+  ENS(e->d_cell_keys, (size_t)B * P.ncells * P.cell_cap * 4);
+  ENS(e->d_cell_counts, (size_t)B * P.ncells * 4);
+  ENS(e->d_keys, (size_t)B * P.keys_per_image * 4);
+  ENS(e->d_kslot, (size_t)B * P.keys_per_image * 2);
+  ENS(e->d_kq, (size_t)B * P.keys_per_image);
+  ENS(e->d_sel, (size_t)B * P.sel_per_image * 4);
+  ENS(e->d_sel_count, (size_t)B * kMaxLevels * 4);
+  ENS(e->d_tmp_kp, (size_t)B * P.kp_cap * sizeof(vieo_keypoint));
+  ENS(e->d_tmp_desc, (size_t)B * P.kp_cap * 32);
+  ENS(e->d_tmp_counts, (size_t)B * 2 * 4);
+#undef ENS
+  VIEO_HIP_CHECK(hipMemcpyAsync(e->d_cells.p, e->cells.data(), e->cells.size() * sizeof(CellDesc),
+                                hipMemcpyHostToDevice, e->stream));
+  VIEO_HIP_CHECK(hipMemcpyAsync(e->d_tiles.p, e->tiles.data(), e->tiles.size() * sizeof(BlurTile),
+                                hipMemcpyHostToDevice, e->stream));
+  if (!xtab.empty()) {
+    VIEO_HIP_CHECK(hipMemcpyAsync(e->d_xtab.p, xtab.data(), xtab.size() * 2, hipMemcpyHostToDevice,
+                                  e->stream));
+    VIEO_HIP_CHECK(hipMemcpyAsync(e->d_ytab.p, ytab.data(), ytab.size() * 2, hipMemcpyHostToDevice,
+                                  e->stream));
+  }
+  VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));  // host vectors go out of scope
+  if (e->qt_lds > 64 * 1024)
+    VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, e->qt_lds));
+  if (e->qt_lds > 160 * 1024) {
+    set_error("nfeatures too large for the LDS quadtree (%d bytes)", e->qt_lds);
+    return VIEO_E_INVALID;
+  }
+  e->w = w;
+  e->h = h;
+  e->B = B;
+  return VIEO_OK;
+}
+
+static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, int stride,
+                     size_t image_pitch, const int* lapping, vieo_keypoint* d_kp, uint8_t* d_desc,
+                     int capacity, int32_t* d_counts) {
+  int rc;
+  if (w != e->w || h != e->h || B > e->B) {
+    if ((rc = plan_geometry(e, w, h, std::max(B, (w == e->w && h == e->h) ? e->B : 0))) != VIEO_OK)
+      return rc;
+  }
+  if ((stride & 3) || ((uintptr_t)d_images & 3) || (image_pitch & 3)) {
+    set_error("device images need 4-byte aligned base, stride and pitch");
+    return VIEO_E_INVALID;
+  }
+  const OrbParams& P = e->P;
+  ImgSet I;
+  I.img0 = d_images;
+  I.stride0 = stride;
+  I.img_pitch = image_pitch;
+  I.pyr = e->d_pyr.as<uint8_t>();
+  I.pyr_img = e->pyr_img;
+  I.blur = e->d_blur.as<uint8_t>();
+  I.blur_img = e->blur_img;
+  e->last_imgs = I;
+  e->last_B = B;
+  hipStream_t st = e->stream;
+  Timing& T = e->tm;
+  int evi = 0;
+#define STAMP()                                                  \
+  if (T.on) VIEO_HIP_CHECK(hipEventRecord(T.ev[evi++], st))
+  STAMP();
+  for (int l = 1; l < P.nlevels; l++) {
+    const LevelDesc& D = P.lv[l];
+    dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 3) / 4, B);
+    hipLaunchKernelGGL(k_resize, grd, blk, 0, st, P, l, I, e->d_xtab.as<short4>(),
+                       e->d_ytab.as<short4>());
+  }
+  STAMP();
+  hipLaunchKernelGGL(k_fast, dim3(P.ncells, B), dim3(64), e->fast_lds, st, P, I,
+                     e->d_cells.as<CellDesc>(), e->d_cell_keys.as<unsigned>(),
+                     e->d_cell_counts.as<int>(), e->iniTh, e->minTh, e->tpitch, e->tile_bytes);
+  STAMP();
+  hipLaunchKernelGGL(k_quadtree, dim3(P.nlevels, B), dim3(256), e->qt_lds, st, P,
+                     e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
+                     e->d_keys.as<unsigned>(), e->d_kslot.as<unsigned short>(),
+                     e->d_kq.as<unsigned char>(), e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(),
+                     e->ncap_max, e->scap_max);
+  STAMP();
+  hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), B), dim3(256), 0, st, P, I,
+                     e->d_tiles.as<BlurTile>());
+  STAMP();
+  const int ngroups = (std::min(P.kp_cap, capacity) + 3) / 4;
+  if (!lapping) {
+    hipLaunchKernelGGL(k_describe, dim3(ngroups, B), dim3(256), 0, st, P, I, e->d_sel.as<unsigned>(),
+                       e->d_sel_count.as<int>(), e->d_pattern.as<int>(), d_kp, d_desc, capacity,
+                       d_counts, 1);
+  } else {
+    hipLaunchKernelGGL(k_describe, dim3((P.kp_cap + 3) / 4, B), dim3(256), 0, st, P, I,
+                       e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(), e->d_pattern.as<int>(),
+                       e->d_tmp_kp.as<vieo_keypoint>(), e->d_tmp_desc.as<uint8_t>(), P.kp_cap,
+                       e->d_tmp_counts.as<int>(), 1);
+    hipLaunchKernelGGL(k_lapping, dim3(B), dim3(256), 0, st, e->d_tmp_kp.as<vieo_keypoint>(),
+                       e->d_tmp_desc.as<uint8_t>(), P.kp_cap, d_kp, d_desc, capacity,
+                       e->d_tmp_counts.as<int>(), d_counts, lapping[0], lapping[1]);
+  }
+  STAMP();
+#undef STAMP
+  T.valid = T.on;
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+}  // namespace vieo
+
+extern "C" {
+
+int vieo_orb_create(vieo_orb** out, int nfeatures, float scale_factor, int nlevels, int ini_th,
+                    int min_th) {
+  if (!out || nfeatures <= 0 || nlevels <= 0 || nlevels > kMaxLevels || !(scale_factor > 1.0f)) {
+    set_error("vieo_orb_create: invalid arguments");
+    return VIEO_E_INVALID;
+  }
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  vieo_orb* e = new vieo_orb();
+  e->nfeatures = nfeatures;
+  e->nlevels = nlevels;
+  e->iniTh = std::min(std::max(ini_th, 0), 255);
+  e->minTh = std::min(std::max(min_th, 0), 255);
+  e->scaleFactor = scale_factor;
+  // ORBextractor.cc:397-431
+  e->scale.resize(nlevels);
+  e->sigma2.resize(nlevels);
+  e->inv_scale.resize(nlevels);
+  e->inv_sigma2.resize(nlevels);
+  e->scale[0] = 1.0f;
+  e->sigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) {
+    e->scale[i] = (float)(e->scale[i - 1] * e->scaleFactor);
+    e->sigma2[i] = e->scale[i] * e->scale[i];
+  }
+  for (int i = 0; i < nlevels; i++) {
+    e->inv_scale[i] = 1.0f / e->scale[i];
+    e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+  }
+  e->feats.resize(nlevels);
+  const float factor = (float)(1.0f / e->scaleFactor);
+  float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; l++) {
+    e->feats[l] = cv_round_f(nDesired);
+    sum += e->feats[l];
+    nDesired *= factor;
+  }
+  e->feats[nlevels - 1] = std::max(nfeatures - sum, 0);
+  // ORBextractor.cc:439-455
+  {
+    int v, v0;
+    const int vmax = cv_floor_d(kHalfPatch * sqrt(2.f) / 2 + 1);
+    const int vmin = cv_ceil_d(kHalfPatch * sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= kHalfPatch; v++) e->umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) e->umax[v] = cv_round_d(sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+      while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+      e->umax[v] = v0;
+      ++v0;
+    }
+  }
+  hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (he != hipSuccess) {
+    set_error("hipStreamCreate: %s", hipGetErrorString(he));
+    delete e;
+    return VIEO_E_HIP;
+  }
+  // BRIEF pattern packed as one int32 per test
+  std::vector<int> pat(256);
+  for (int i = 0; i < 256; i++) {
+    const signed char* p = VIEO_ORB_PATTERN_31 + i * 4;
+    pat[i] = (int)((unsigned)(uint8_t)p[0] | ((unsigned)(uint8_t)p[1] << 8) |
+                   ((unsigned)(uint8_t)p[2] << 16) | ((unsigned)(uint8_t)p[3] << 24));
+  }
+  if ((rc = e->d_pattern.ensure(1024)) != VIEO_OK) {
+    delete e;
+    return rc;
+  }
+  he = hipMemcpy(e->d_pattern.p, pat.data(), 1024, hipMemcpyHostToDevice);
+  if (he != hipSuccess) {
+    set_error("pattern upload: %s", hipGetErrorString(he));
+    delete e;
+    return VIEO_E_HIP;
+  }
+  for (auto& ev : e->tm.ev) (void)hipEventCreate(&ev);
+  *out = e;
+  return VIEO_OK;
+}
+
+void vieo_orb_destroy(vieo_orb* e) {
+  if (!e) return;
+  (void)hipStreamSynchronize(e->stream);
+  DevBuf* bufs[] = {&e->d_pyr,   &e->d_blur,      &e->d_cells,    &e->d_tiles,      &e->d_xtab,
+                    &e->d_ytab,  &e->d_cell_keys, &e->d_cell_counts, &e->d_keys,    &e->d_kslot,
+                    &e->d_kq,    &e->d_sel,       &e->d_sel_count, &e->d_pattern,   &e->d_in,
+                    &e->d_kp,    &e->d_desc,      &e->d_counts,   &e->d_tmp_kp,     &e->d_tmp_desc,
+                    &e->d_tmp_counts};
+  for (DevBuf* b : bufs) b->release();
+  for (auto& ev : e->tm.ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int vieo_orb_levels(const vieo_orb* e) { return e->nlevels; }
+float vieo_orb_scale_factor(const vieo_orb* e) { return (float)e->scaleFactor; }
+static int copy_tab(const std::vector<float>& v, float* out) {
+  if (!out) return VIEO_E_INVALID;
+  memcpy(out, v.data(), v.size() * sizeof(float));
+  return VIEO_OK;
+}
+int vieo_orb_scale_factors(const vieo_orb* e, float* o) { return copy_tab(e->scale, o); }
+int vieo_orb_inv_scale_factors(const vieo_orb* e, float* o) { return copy_tab(e->inv_scale, o); }
+int vieo_orb_level_sigma2(const vieo_orb* e, float* o) { return copy_tab(e->sigma2, o); }
+int vieo_orb_inv_level_sigma2(const vieo_orb* e, float* o) { return copy_tab(e->inv_sigma2, o); }
+int vieo_orb_features_per_level(const vieo_orb* e, int* o) {
+  if (!o) return VIEO_E_INVALID;
+  memcpy(o, e->feats.data(), e->feats.size() * sizeof(int));
+  return VIEO_OK;
+}
+int vieo_orb_max_keypoints(const vieo_orb* e) {
+  // DistributeOctTree stops at >= N nodes and one split adds at most 3; root nodes up to 4*nIni
+  int s = 0;
+  for (int l = 0; l < e->nlevels; l++) s += std::max(e->feats[l], 16) + 8;
+  return s;
+}
+
+int vieo_orb_extract_batch_device(vieo_orb* e, const uint8_t* d_images, int n_images, int width,
+                                  int height, int stride, size_t image_pitch_bytes,
+                                  const int* h_lapping, vieo_keypoint* d_keypoints,
+                                  uint8_t* d_descriptors, int capacity, int32_t* d_counts) {
+  if (!e || !d_images || n_images <= 0 || !d_keypoints || !d_descriptors || !d_counts ||
+      capacity <= 0) {
+    set_error("vieo_orb_extract_batch_device: invalid arguments");
+    return VIEO_E_INVALID;
+  }
+  if (width <= 0 || height <= 0) return VIEO_E_EMPTY;
+  return run_batch(e, d_images, n_images, width, height, stride, image_pitch_bytes, h_lapping,
+                   d_keypoints, d_descriptors, capacity, d_counts);
+}
+
+int vieo_orb_sync(vieo_orb* e) {
+  VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return VIEO_OK;
+}
+
+int vieo_orb_extract(vieo_orb* e, const uint8_t* h_image, int width, int height, int stride,
+                     const int* h_lapping, vieo_keypoint* h_keypoints, uint8_t* h_descriptors,
+                     int capacity, int* n_keypoints, int* mono_index) {
+  if (!e || !n_keypoints) return VIEO_E_INVALID;
+  if (!h_image || width <= 0 || height <= 0) return VIEO_E_EMPTY;  // ORBextractor.cc:970
+  int rc;
+  const int pitch = align_up(width, 16);
+  const int cap = vieo_orb_max_keypoints(e);
+  if ((rc = e->d_in.ensure((size_t)pitch * height)) != VIEO_OK) return rc;
+  if ((rc = e->d_kp.ensure((size_t)cap * sizeof(vieo_keypoint))) != VIEO_OK) return rc;
+  if ((rc = e->d_desc.ensure((size_t)cap * 32)) != VIEO_OK) return rc;
+  if ((rc = e->d_counts.ensure(8)) != VIEO_OK) return rc;
+  VIEO_HIP_CHECK(hipMemcpy2DAsync(e->d_in.p, pitch, h_image, stride, width, height,
+                                  hipMemcpyHostToDevice, e->stream));
+  rc = run_batch(e, e->d_in.as<uint8_t>(), 1, width, height, pitch, (size_t)pitch * height,
+                 h_lapping, e->d_kp.as<vieo_keypoint>(), e->d_desc.as<uint8_t>(), cap,
+                 e->d_counts.as<int32_t>());
+  if (rc != VIEO_OK) return rc;
+  int cnt[2];
+  VIEO_HIP_CHECK(hipMemcpyAsync(cnt, e->d_counts.p, 8, hipMemcpyDeviceToHost, e->stream));
+  VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  *n_keypoints = cnt[0];
+  if (mono_index) *mono_index = cnt[1];
+  if (cnt[0] > capacity) {
+    set_error("vieo_orb_extract: %d keypoints, capacity %d", cnt[0], capacity);
+    return VIEO_E_CAPACITY;
+  }
+  if (cnt[0] > 0) {
+    if (!h_keypoints || !h_descriptors) return VIEO_E_INVALID;
+    VIEO_HIP_CHECK(hipMemcpyAsync(h_keypoints, e->d_kp.p, (size_t)cnt[0] * sizeof(vieo_keypoint),
+                                  hipMemcpyDeviceToHost, e->stream));
+    VIEO_HIP_CHECK(hipMemcpyAsync(h_descriptors, e->d_desc.p, (size_t)cnt[0] * 32,
+                                  hipMemcpyDeviceToHost, e->stream));
+    VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  }
+  return VIEO_OK;
+}
+
+int vieo_orb_level_size(const vieo_orb* e, int level, int* width, int* height) {
+  if (!e || level < 0 || level >= e->nlevels || e->w == 0) return VIEO_E_INVALID;
+  if (width) *width = e->P.lv[level].w;
+  if (height) *height = e->P.lv[level].h;
+  return VIEO_OK;
+}
+
+int vieo_orb_level_device(vieo_orb* e, int image_index, int level, const uint8_t** d_ptr,
+                          int* pitch) {
+  if (!e || level < 0 || level >= e->nlevels || image_index < 0 || image_index >= e->last_B)
+    return VIEO_E_INVALID;
+  const ImgSet& I = e->last_imgs;
+  if (level == 0) {
+    *d_ptr = I.img0 + (size_t)image_index * I.img_pitch;
+    *pitch = I.stride0;
+  } else {
+    *d_ptr = I.pyr + (size_t)image_index * I.pyr_img + e->P.lv[level].off;
+    *pitch = e->P.lv[level].pitch;
+  }
+  return VIEO_OK;
+}
+
+static int fetch_plane(vieo_orb* e, const uint8_t* d_ptr, int pitch, int w, int h, int border,
+                       uint8_t* h_dst, int dst_stride) {
+  VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  if (!border) {
+    VIEO_HIP_CHECK(hipMemcpy2D(h_dst, dst_stride, d_ptr, pitch, w, h, hipMemcpyDeviceToHost));
+    return VIEO_OK;
+  }
+  // copyMakeBorder(BORDER_REFLECT_101) of the ROI (ORBextractor.cc:1072-1077): the border is a
+  // pure function of the ROI, so it is synthesised while copying out.
+  std::vector<uint8_t> tmp((size_t)w * h);
+  VIEO_HIP_CHECK(hipMemcpy2D(tmp.data(), w, d_ptr, pitch, w, h, hipMemcpyDeviceToHost));
+  auto refl = [](int p, int len) {
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return p;
+  };
+  for (int y = 0; y < h + 2 * kEdge; y++) {
+    const uint8_t* s = tmp.data() + (size_t)refl(y - kEdge, h) * w;
+    uint8_t* d = h_dst + (size_t)y * dst_stride;
+    for (int x = 0; x < w + 2 * kEdge; x++) d[x] = s[refl(x - kEdge, w)];
+  }
+  return VIEO_OK;
+}
+
+int vieo_orb_get_level(vieo_orb* e, int image_index, int level, int with_border, uint8_t* h_dst,
+                       int dst_stride) {
+  const uint8_t* p;
+  int pitch;
+  int rc = vieo_orb_level_device(e, image_index, level, &p, &pitch);
+  if (rc != VIEO_OK || !h_dst) return VIEO_E_INVALID;
+  return fetch_plane(e, p, pitch, e->P.lv[level].w, e->P.lv[level].h, with_border, h_dst,
+                     dst_stride);
+}
+
+int vieo_orb_enable_timing(vieo_orb* e, int on) {
+  e->tm.on = on != 0;
+  e->tm.valid = false;
+  return VIEO_OK;
+}
+
+int vieo_orb_last_stage_ms(vieo_orb* e, float* h_ms) {
+  if (!e->tm.valid) {
+    set_error("timing not enabled or no batch run yet");
+    return VIEO_E_INVALID;
+  }
+  VIEO_HIP_CHECK(hipEventSynchronize(e->tm.ev[VIEO_ORB_NSTAGES - 1]));
+  for (int i = 0; i < VIEO_ORB_NSTAGES - 1; i++)
+    VIEO_HIP_CHECK(hipEventElapsedTime(&h_ms[i], e->tm.ev[i], e->tm.ev[i + 1]));
+  VIEO_HIP_CHECK(hipEventElapsedTime(&h_ms[VIEO_ORB_NSTAGES - 1], e->tm.ev[0],
+                                     e->tm.ev[VIEO_ORB_NSTAGES - 1]));
+  return VIEO_OK;
+}
+
+// ---------------------------------------------------------------- test taps
+int vieo_orb_tap_plane(vieo_orb* e, int image_index, int level, int which, uint8_t* h_dst,
+                       int dst_stride) {
+  if (!e || which != 1 || level < 0 || level >= e->nlevels || image_index < 0 ||
+      image_index >= e->last_B)
+    return VIEO_E_INVALID;
+  const LevelDesc& D = e->P.lv[level];
+  const uint8_t* p = e->last_imgs.blur + (size_t)image_index * e->blur_img + D.boff;
+  return fetch_plane(e, p, D.pitch, D.w, D.h, 0, h_dst, dst_stride);
+}
+
+int vieo_orb_tap_candidates(vieo_orb* e, int image_index, int level, int32_t* h_dst, int cap) {
+  if (!e || level < 0 || level >= e->nlevels || image_index < 0 || image_index >= e->last_B)
+    return VIEO_E_INVALID;
+  VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  const OrbParams& P = e->P;
+  const LevelDesc& D = P.lv[level];
+  const int ncell = D.cell_end - D.cell_begin;
+  std::vector<int> cnt(ncell);
+  std::vector<unsigned> keys((size_t)ncell * P.cell_cap);
+  VIEO_HIP_CHECK(hipMemcpy(cnt.data(),
+                           e->d_cell_counts.as<int>() + (size_t)image_index * P.ncells + D.cell_begin,
+                           ncell * 4, hipMemcpyDeviceToHost));
+  VIEO_HIP_CHECK(hipMemcpy(
+      keys.data(),
+      e->d_cell_keys.as<unsigned>() + ((size_t)image_index * P.ncells + D.cell_begin) * P.cell_cap,
+      keys.size() * 4, hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int c = 0; c < ncell; c++)
+    for (int i = 0; i < cnt[c]; i++) {
+      if (n < cap) {
+        const unsigned k = keys[(size_t)c * P.cell_cap + i];
+        h_dst[n * 3] = QT_KEY_X(k);
+        h_dst[n * 3 + 1] = QT_KEY_Y(k);
+        h_dst[n * 3 + 2] = QT_KEY_R(k);
+      }
+      n++;
+    }
+  return n;
+}
+
+int vieo_orb_tap_level_keys(vieo_orb* e, int image_index, int level, vieo_keypoint* h_dst, int cap) {
+  if (!e || level < 0 || level >= e->nlevels || image_index < 0 || image_index >= e->last_B)
+    return VIEO_E_INVALID;
+  VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  const OrbParams& P = e->P;
+  const LevelDesc& D = P.lv[level];
+  int n = 0;
+  VIEO_HIP_CHECK(hipMemcpy(&n, e->d_sel_count.as<int>() + image_index * kMaxLevels + level, 4,
+                           hipMemcpyDeviceToHost));
+  if (n < 0) {
+    set_error("quadtree capacity overflow at level %d", level);
+    return VIEO_E_CAPACITY;
+  }
+  std::vector<unsigned> keys(std::max(n, 1));
+  VIEO_HIP_CHECK(hipMemcpy(keys.data(),
+                           e->d_sel.as<unsigned>() + (size_t)image_index * P.sel_per_image + D.sel_off,
+                           (size_t)n * 4, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n && i < cap; i++) {
+    vieo_keypoint k;
+    k.x = (float)(QT_KEY_X(keys[i]) + kEdge - 3);
+    k.y = (float)(QT_KEY_Y(keys[i]) + kEdge - 3);
+    k.size = (float)D.patch;
+    k.angle = -1.f;
+    k.response = (float)QT_KEY_R(keys[i]);
+    k.octave = level;
+    k.class_id = -1;
+    h_dst[i] = k;
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// runtime.hip -- error reporting, device probing and the small memory helpers of the C-ABI.
+#include <mutex>
+
+#include "common.h"
+
+namespace vieo {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no HIP device visible (%s); libvieo_hot has no CPU fallback",
+              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return VIEO_E_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    set_error("cannot query HIP device");
+    return VIEO_E_NO_DEVICE;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device arch %s is not gfx950; kernels are built for gfx950 only", prop.gcnArchName);
+    return VIEO_E_NO_DEVICE;
+  }
+  return VIEO_OK;
+}
+
+}  // namespace vieo
+
+extern "C" {
+
+const char* vieo_last_error(void) { return vieo::g_err; }
+const char* vieo_version(void) { return "vieo_hot 0.1 (gfx950)"; }
+
+int vieo_device_available(void) { return vieo::require_device() == VIEO_OK ? 1 : 0; }
+
+int vieo_dev_malloc(void** d_ptr, size_t bytes) {
+  if (!d_ptr) return VIEO_E_INVALID;
+  int rc = vieo::require_device();
+  if (rc != VIEO_OK) return rc;
+  VIEO_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 1));
+  return VIEO_OK;
+}
+int vieo_dev_free(void* d_ptr) {
+  if (d_ptr) VIEO_HIP_CHECK(hipFree(d_ptr));
+  return VIEO_OK;
+}
+int vieo_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  VIEO_HIP_CHECK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return VIEO_OK;
+}
+int vieo_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  VIEO_HIP_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return VIEO_OK;
+}
+int vieo_device_synchronize(void) {
+  VIEO_HIP_CHECK(hipDeviceSynchronize());
+  return VIEO_OK;
+}
+
+}  // extern "C"
