@@ -108,8 +108,12 @@ int vieo_orb_level_device(vieo_orb* e, int image_index, int level, const uint8_t
 /* Wall-clock-free timing of the kernels of the last batch call, measured with HIP events on the
  * extractor's own stream: milliseconds for {pyramid, fast, quadtree, blur, describe, total}. */
 #define VIEO_ORB_NSTAGES 6
+int vieo_orb_enable_timing(vieo_orb* e, int on); /* also resets the step counter */
 int vieo_orb_last_stage_ms(vieo_orb* e, float* h_ms /*[VIEO_ORB_NSTAGES]*/);
-int vieo_orb_enable_timing(vieo_orb* e, int on);
+/* The stamps of the last 64 batch calls are kept, so K steps can be timed with no host sync in
+ * between: steps_back = 0 is the most recent call. */
+int vieo_orb_timed_steps(vieo_orb* e);
+int vieo_orb_stage_ms(vieo_orb* e, int steps_back, float* h_ms /*[VIEO_ORB_NSTAGES]*/);
 
 /* ---- test taps (parity tests only; not part of the drop-in surface) ---- */
 /* which: 1 = blurred level.  FAST candidates: int32 triplets (x, y, response) in

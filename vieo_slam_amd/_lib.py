@@ -45,6 +45,8 @@ _SIGS = {
     "vieo_orb_level_device": (c_i, [c_p, c_i, c_i, P(c_p), P(c_i)]),
     "vieo_orb_last_stage_ms": (c_i, [c_p, c_p]),
     "vieo_orb_enable_timing": (c_i, [c_p, c_i]),
+    "vieo_orb_timed_steps": (c_i, [c_p]),
+    "vieo_orb_stage_ms": (c_i, [c_p, c_i, c_p]),
     "vieo_orb_tap_plane": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_candidates": (c_i, [c_p, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_level_keys": (c_i, [c_p, c_i, c_i, c_p, c_i]),

@@ -523,10 +523,13 @@ k_lapping(const vieo_keypoint* __restrict__ kin, const uint8_t* __restrict__ din
 }
 
 // ================================================================== host side
+// HIP-event stamps around every stage of a batch call, on the extractor's own stream.  A ring of
+// kTimingRing steps is kept so a bench can time K steps without a host sync in between.
+static const int kTimingRing = 64;
 struct Timing {
   bool on = false;
-  hipEvent_t ev[VIEO_ORB_NSTAGES + 1] = {};
-  bool valid = false;
+  hipEvent_t ev[kTimingRing][VIEO_ORB_NSTAGES] = {};
+  long steps = 0;  // batch calls stamped since timing was enabled
 };
 
 }  // namespace vieo
@@ -791,8 +794,9 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
   hipStream_t st = e->stream;
   Timing& T = e->tm;
   int evi = 0;
+  hipEvent_t* evs = T.ev[T.steps % kTimingRing];
 #define STAMP()                                                  \
-  if (T.on) VIEO_HIP_CHECK(hipEventRecord(T.ev[evi++], st))
+  if (T.on) VIEO_HIP_CHECK(hipEventRecord(evs[evi++], st))
   STAMP();
   for (int l = 1; l < P.nlevels; l++) {
     const LevelDesc& D = P.lv[l];
@@ -830,7 +834,7 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
   }
   STAMP();
 #undef STAMP
-  T.valid = T.on;
+  if (T.on) T.steps++;
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
@@ -915,7 +919,8 @@ int vieo_orb_create(vieo_orb** out, int nfeatures, float scale_factor, int nleve
     delete e;
     return VIEO_E_HIP;
   }
-  for (auto& ev : e->tm.ev) (void)hipEventCreate(&ev);
+  for (auto& set : e->tm.ev)
+    for (auto& ev : set) (void)hipEventCreate(&ev);
   *out = e;
   return VIEO_OK;
 }
@@ -929,8 +934,9 @@ void vieo_orb_destroy(vieo_orb* e) {
                     &e->d_kp,    &e->d_desc,      &e->d_counts,   &e->d_tmp_kp,     &e->d_tmp_desc,
                     &e->d_tmp_counts};
   for (DevBuf* b : bufs) b->release();
-  for (auto& ev : e->tm.ev)
-    if (ev) (void)hipEventDestroy(ev);
+  for (auto& set : e->tm.ev)
+    for (auto& ev : set)
+      if (ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1073,22 +1079,27 @@ int vieo_orb_get_level(vieo_orb* e, int image_index, int level, int with_border,
 
 int vieo_orb_enable_timing(vieo_orb* e, int on) {
   e->tm.on = on != 0;
-  e->tm.valid = false;
+  e->tm.steps = 0;
   return VIEO_OK;
 }
 
-int vieo_orb_last_stage_ms(vieo_orb* e, float* h_ms) {
-  if (!e->tm.valid) {
-    set_error("timing not enabled or no batch run yet");
+int vieo_orb_timed_steps(vieo_orb* e) { return (int)std::min<long>(e->tm.steps, kTimingRing); }
+
+// steps_back = 0 is the most recent stamped batch call
+int vieo_orb_stage_ms(vieo_orb* e, int steps_back, float* h_ms) {
+  if (steps_back < 0 || steps_back >= vieo_orb_timed_steps(e)) {
+    set_error("timing not enabled or step %d not recorded", steps_back);
     return VIEO_E_INVALID;
   }
-  VIEO_HIP_CHECK(hipEventSynchronize(e->tm.ev[VIEO_ORB_NSTAGES - 1]));
+  hipEvent_t* ev = e->tm.ev[(e->tm.steps - 1 - steps_back) % kTimingRing];
+  VIEO_HIP_CHECK(hipEventSynchronize(ev[VIEO_ORB_NSTAGES - 1]));
   for (int i = 0; i < VIEO_ORB_NSTAGES - 1; i++)
-    VIEO_HIP_CHECK(hipEventElapsedTime(&h_ms[i], e->tm.ev[i], e->tm.ev[i + 1]));
-  VIEO_HIP_CHECK(hipEventElapsedTime(&h_ms[VIEO_ORB_NSTAGES - 1], e->tm.ev[0],
-                                     e->tm.ev[VIEO_ORB_NSTAGES - 1]));
+    VIEO_HIP_CHECK(hipEventElapsedTime(&h_ms[i], ev[i], ev[i + 1]));
+  VIEO_HIP_CHECK(hipEventElapsedTime(&h_ms[VIEO_ORB_NSTAGES - 1], ev[0], ev[VIEO_ORB_NSTAGES - 1]));
   return VIEO_OK;
 }
+
+int vieo_orb_last_stage_ms(vieo_orb* e, float* h_ms) { return vieo_orb_stage_ms(e, 0, h_ms); }
 
 // ---------------------------------------------------------------- test taps
 int vieo_orb_tap_plane(vieo_orb* e, int image_index, int level, int which, uint8_t* h_dst,

@@ -123,6 +123,16 @@ class ORBextractor:
         check(lib().vieo_orb_last_stage_ms(self._h, ms.ctypes.data), "last_stage_ms")
         return dict(zip(STAGES, ms.tolist()))
 
+    def stage_ms_all(self):
+        """per-stage milliseconds of every stamped batch call (oldest first)."""
+        n = lib().vieo_orb_timed_steps(self._h)
+        out = []
+        for back in range(n - 1, -1, -1):
+            ms = np.zeros(len(STAGES), np.float32)
+            check(lib().vieo_orb_stage_ms(self._h, back, ms.ctypes.data), "stage_ms")
+            out.append(dict(zip(STAGES, ms.tolist())))
+        return out
+
     # ---- test taps
     def tap_blurred(self, level, image_index=0):
         w, h = self.level_size(level)

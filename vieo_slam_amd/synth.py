@@ -34,25 +34,30 @@ def synth_image_f32(seed, w=EUROC_W, h=EUROC_H, n_shapes=400):
     img = np.full((h, w), 128.0, np.float32)
     for cell, amp in ((64, 50.0), (16, 25.0), (4, 10.0)):
         img += _value_noise(rng, w, h, cell, amp)
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
     for _ in range(n_shapes):
         kind = rng.integers(0, 3)
         cx, cy = rng.uniform(0, w), rng.uniform(0, h)
         grey = rng.uniform(10, 245)
+        rw, rh = rng.uniform(4, 40), rng.uniform(4, 40)
+        t = rng.uniform(0, np.pi)
+        r = rng.uniform(3, 25)
+        ext = int(np.ceil(max(np.hypot(rw, rh), r))) + 1
+        xa, xb = max(0, int(cx) - ext), min(w, int(cx) + ext + 1)
+        ya, yb = max(0, int(cy) - ext), min(h, int(cy) + ext + 1)
+        if xa >= xb or ya >= yb:
+            continue
+        yy, xx = np.mgrid[ya:yb, xa:xb].astype(np.float32)
         if kind == 0:  # axis-aligned rectangle
-            rw, rh = rng.uniform(4, 40), rng.uniform(4, 40)
             m = (np.abs(xx - cx) < rw) & (np.abs(yy - cy) < rh)
         elif kind == 1:  # rotated rectangle
-            rw, rh = rng.uniform(4, 40), rng.uniform(4, 40)
-            t = rng.uniform(0, np.pi)
             c, s = np.cos(t), np.sin(t)
             u = (xx - cx) * c + (yy - cy) * s
             v = -(xx - cx) * s + (yy - cy) * c
             m = (np.abs(u) < rw) & (np.abs(v) < rh)
         else:  # disc
-            r = rng.uniform(3, 25)
             m = (xx - cx) ** 2 + (yy - cy) ** 2 < r * r
-        img[m] = grey + 0.15 * (img[m] - 128.0)
+        sub = img[ya:yb, xa:xb]
+        sub[m] = grey + 0.15 * (sub[m] - 128.0)
     return img
 
 
