@@ -115,6 +115,45 @@ int vieo_orb_last_stage_ms(vieo_orb* e, float* h_ms /*[VIEO_ORB_NSTAGES]*/);
 int vieo_orb_timed_steps(vieo_orb* e);
 int vieo_orb_stage_ms(vieo_orb* e, int steps_back, float* h_ms /*[VIEO_ORB_NSTAGES]*/);
 
+/* ---------------------------------------------------------------- Hamming matching ---------
+ * Replaces the descriptor searches of src/Frame.cc (stereo) on top of
+ * ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1645-1667: Hamming distance of 32-byte rows).
+ */
+
+/* cv::BFMatcher(cv::NORM_HAMMING).knnMatch(query, train, matches, 2) as called by
+ * Frame::ComputeStereoFishEyeMatches (src/Frame.cc:18,620-628): for every query row the two
+ * nearest train rows, ascending distance, ties -> lower train index first.
+ * idx/dist are [nq][2] int32; a missing neighbour is (-1, INT_MAX). */
+int vieo_hamming_knn2(const uint8_t* h_query, int nq, const uint8_t* h_train, int nt,
+                      int32_t* h_idx, int32_t* h_dist);
+/* Batched device form over the output arrays of vieo_orb_extract_batch_device: pair p searches
+ * image h_pairs[2p] (query) against image h_pairs[2p+1] (train), both restricted to rows
+ * [mono_index, n) like the reference (descriptors.rowRange(num_mono, n)); h_counts is the host
+ * copy of d_counts.  Results of pair p start at row p*capacity; indices are relative to the
+ * train sub-matrix.  Asynchronous on `stream` (a hipStream_t, may be NULL). */
+int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* h_counts,
+                                   int capacity, const int32_t* h_pairs, int n_pairs,
+                                   int32_t* d_idx, int32_t* d_dist, void* stream);
+
+/* void Frame::ComputeStereoMatches() (src/Frame.cc:451-611), rectified stereo: row-band Hamming
+ * search (octave +-1, disparity window [0, bf/baseline]), 11 SADs of 11x11 patches on the
+ * left key's pyramid level, parabola sub-pixel fit, rejection above 1.5*1.4*median SAD.
+ * Outputs stereoinfo_.vuright_ / vdepth_ (-1 = no match).  `left`/`right` are the two
+ * extractors that just processed the frame's images (their mvImagePyramid is read in place on
+ * the device); `baseline` = stereoinfo_.baseline_bf_[0], `bf` = baseline_bf_[1]. */
+int vieo_stereo_match_rectified(vieo_orb* left, vieo_orb* right, const vieo_keypoint* h_kpL,
+                                const uint8_t* h_descL, int nL, const vieo_keypoint* h_kpR,
+                                const uint8_t* h_descR, int nR, float baseline, float bf,
+                                float* h_uright, float* h_depth);
+/* Batched device form: the extractor's last batch holds 2*n_frames images, image 2f = left and
+ * 2f+1 = right camera of frame f; keypoints/descriptors/counts are that batch's outputs.
+ * d_uright / d_depth are [n_frames][capacity].  Asynchronous on the extractor's stream. */
+int vieo_stereo_match_rectified_batch_device(vieo_orb* e, int n_frames,
+                                             const vieo_keypoint* d_keypoints,
+                                             const uint8_t* d_descriptors, const int32_t* d_counts,
+                                             int capacity, float baseline, float bf,
+                                             float* d_uright, float* d_depth);
+
 /* ---- test taps (parity tests only; not part of the drop-in surface) ---- */
 /* which: 1 = blurred level.  FAST candidates: int32 triplets (x, y, response) in
  * vToDistributeKeys order; level keys: vieo_keypoint in DistributeOctTree output order. */

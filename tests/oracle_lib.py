@@ -43,7 +43,39 @@ class Oracle:
         L.vo_cv_round_f.argtypes = [F]
         L.vo_sincos_ref.argtypes = [F, P, P]
         L.vo_distribute_octtree.argtypes = [P, I, I, I, I, I, I, P, I]
+        L.vo_descriptor_distance.argtypes = [P, P]
+        L.vo_knn2_hamming.argtypes = [P, I, P, I, P, P]
+        L.vo_stereo_match_rectified.argtypes = [P, P, I, P, I, P, P, I, P, P, P, F, F, P, P]
         self.L = L
+
+    # ---- matching
+    def descriptor_distance(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return self.L.vo_descriptor_distance(a.ctypes.data, b.ctypes.data)
+
+    def knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.zeros((len(q), 2), np.int32)
+        dist = np.zeros((len(q), 2), np.int32)
+        self.L.vo_knn2_hamming(q.ctypes.data, len(q), t.ctypes.data, len(t), idx.ctypes.data,
+                               dist.ctypes.data)
+        return idx, dist
+
+    def stereo_match(self, extL, extR, kl, dl, kr, dr, baseline, bf):
+        """extL/extR: OracleExtractor objects that just processed the left/right image."""
+        kl, kr = np.ascontiguousarray(kl), np.ascontiguousarray(kr)
+        dl, dr = np.ascontiguousarray(dl, np.uint8), np.ascontiguousarray(dr, np.uint8)
+        sc = np.array(extL.scale_factors(), np.float32)
+        inv = (np.float32(1.0) / sc).astype(np.float32)
+        ur = np.zeros(len(kl), np.float32)
+        dp = np.zeros(len(kl), np.float32)
+        self.L.vo_stereo_match_rectified(extL.h, extR.h, extL.nlevels, kl.ctypes.data, len(kl),
+                                         dl.ctypes.data, kr.ctypes.data, len(kr), dr.ctypes.data,
+                                         sc.ctypes.data, inv.ctypes.data, baseline, bf,
+                                         ur.ctypes.data, dp.ctypes.data)
+        return ur, dp
 
     # ---- primitives
     def resize(self, src, dw, dh):

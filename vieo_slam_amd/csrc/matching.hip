@@ -1,0 +1,433 @@
+// matching.hip -- Hamming matching kernels of the hot path (gfx950).
+//
+//   k_knn2            cv::BFMatcher(NORM_HAMMING).knnMatch(k=2)  (reference: src/Frame.cc:18,620-628,
+//                     the dense N x N search of ComputeStereoFishEyeMatches)
+//   k_stereo_rect     Frame::ComputeStereoMatches                (src/Frame.cc:451-597)
+//   k_stereo_median   its median-SAD outlier rejection           (src/Frame.cc:599-610)
+//   ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1645-1667) is xor + v_bcnt_u32_b32 on the
+//   8 dwords of a 32-byte row.
+// One wavefront per query / left key; the 32-byte train rows are streamed through L2 (a frame's
+// descriptor matrix is 38 KB).  Integer work: results are bit-exact against oracle/matching.cc.
+#include <climits>
+
+#include "orb_internal.h"
+
+namespace vieo {
+
+static const int TH_HIGH = 100, TH_LOW = 50;  // ORBmatcher.cc:20-21
+
+__device__ __forceinline__ int hamming32(const uint4 a0, const uint4 a1, const uint8_t* b) {
+  const uint4 b0 = ((const uint4*)b)[0], b1 = ((const uint4*)b)[1];
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// lexicographic (dist, idx) ordering == cv::batchDistance's stable insertion order
+__device__ __forceinline__ bool lex_less(int d0, int i0, int d1, int i1) {
+  return d0 < d1 || (d0 == d1 && i0 < i1);
+}
+
+struct Knn2Job {
+  const uint8_t* q;  // query rows
+  const uint8_t* t;  // train rows
+  int nq, nt;
+  int out_off;  // row offset into idx/dist outputs
+};
+
+// grid (ceil(max_nq/4), n_jobs); one wave per query row.
+__global__ void __launch_bounds__(256)
+k_knn2(const Knn2Job* __restrict__ jobs, const int* __restrict__ counts, int32_t* __restrict__ idx,
+       int32_t* __restrict__ dist) {
+  Knn2Job J = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= J.nq) return;
+  const uint4 a0 = ((const uint4*)(J.q + (size_t)qi * 32))[0];
+  const uint4 a1 = ((const uint4*)(J.q + (size_t)qi * 32))[1];
+  int d0 = INT_MAX, i0 = INT_MAX, d1 = INT_MAX, i1 = INT_MAX;  // best, second (idx MAX = empty)
+  for (int j = lane; j < J.nt; j += 64) {
+    const int d = hamming32(a0, a1, J.t + (size_t)j * 32);
+    if (lex_less(d, j, d0, i0)) {
+      d1 = d0, i1 = i0;
+      d0 = d, i0 = j;
+    } else if (lex_less(d, j, d1, i1)) {
+      d1 = d, i1 = j;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int e0 = __shfl_xor(d0, o), j0 = __shfl_xor(i0, o);
+    const int e1 = __shfl_xor(d1, o), j1 = __shfl_xor(i1, o);
+    // merge two sorted pairs, keep the two smallest
+    if (lex_less(e0, j0, d0, i0)) {
+      if (lex_less(d0, i0, e1, j1)) {
+        d1 = d0, i1 = i0;
+      } else {
+        d1 = e1, i1 = j1;
+      }
+      d0 = e0, i0 = j0;
+    } else if (lex_less(e0, j0, d1, i1)) {
+      d1 = e0, i1 = j0;
+    }
+  }
+  if (lane == 0) {
+    int32_t* oi = idx + ((size_t)J.out_off + qi) * 2;
+    int32_t* od = dist + ((size_t)J.out_off + qi) * 2;
+    oi[0] = i0 == INT_MAX ? -1 : i0;
+    od[0] = d0;
+    oi[1] = i1 == INT_MAX ? -1 : i1;
+    od[1] = d1;
+  }
+}
+
+// ------------------------------------------------------------------ rectified stereo
+struct StereoArgs {
+  OrbParams P;     // level geometry (both cameras identical)
+  ImgSet IL, IR;   // planes of the left / right extractor batch
+  int l_first, l_step, r_first, r_step;  // image index of frame f inside each batch
+  const vieo_keypoint *kpL, *kpR;        // [image][cap]
+  const uint8_t *descL, *descR;          // [image][cap][32]
+  const int *cntL, *cntR;                // [image][2]
+  int capL, capR;
+  float baseline, bf;
+  float* uright;  // [frame][capL]
+  float* depth;   // [frame][capL]
+  int* sad;       // [frame][capL]  best SAD of accepted matches, -1 otherwise
+};
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// grid (ceil(capL/4), n_frames); one wave per left key.
+__global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63;
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int imL = A.l_first + f * A.l_step, imR = A.r_first + f * A.r_step;
+  const int N = min(A.cntL[2 * imL], A.capL), Nr = min(A.cntR[2 * imR], A.capR);
+  if (iL >= N) return;
+  float* o_ur = A.uright + (size_t)f * A.capL + iL;
+  float* o_dp = A.depth + (size_t)f * A.capL + iL;
+  int* o_sad = A.sad + (size_t)f * A.capL + iL;
+  if (lane == 0) *o_ur = -1.0f, *o_dp = -1.0f, *o_sad = -1;
+  const vieo_keypoint kL = A.kpL[(size_t)imL * A.capL + iL];
+  const int levelL = kL.octave;
+  const float vL = kL.y, uL = kL.x;
+  const int rowL = (int)vL;  // vRowIndices[vL]
+  const float minD = 0.f, maxD = A.bf / A.baseline;
+  const float minU = uL - maxD, maxU = uL - minD;
+  if (maxU < 0) return;
+  const uint8_t* dL = A.descL + ((size_t)imL * A.capL + iL) * 32;
+  const uint4 a0 = ((const uint4*)dL)[0], a1 = ((const uint4*)dL)[1];
+  const vieo_keypoint* KR = A.kpR + (size_t)imR * A.capR;
+  const uint8_t* DR = A.descR + (size_t)imR * A.capR * 32;
+  int bestDist = TH_HIGH, bestIdx = INT_MAX;
+  for (int j = lane; j < Nr; j += 64) {
+    const vieo_keypoint kR = KR[j];
+    const float r = 2.0f * A.P.lv[kR.octave].scale;
+    const int maxr = (int)ceilf(kR.y + r), minr = (int)floorf(kR.y - r);
+    if (rowL < minr || rowL > maxr) continue;
+    if (kR.octave < levelL - 1 || kR.octave > levelL + 1) continue;
+    if (!(kR.x >= minU && kR.x <= maxU)) continue;
+    const int d = hamming32(a0, a1, DR + (size_t)j * 32);
+    if (d < TH_HIGH && lex_less(d, j, bestDist, bestIdx)) bestDist = d, bestIdx = j;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int e = __shfl_xor(bestDist, o), j = __shfl_xor(bestIdx, o);
+    if (lex_less(e, j, bestDist, bestIdx)) bestDist = e, bestIdx = j;
+  }
+  if (bestIdx == INT_MAX || bestDist >= (TH_HIGH + TH_LOW) / 2) return;
+  // ---- sub-pixel refinement by 11 SADs of 11x11 patches at the key's pyramid level
+  const float uR0 = KR[bestIdx].x;
+  const float sF = 1.0f / A.P.lv[levelL].scale;  // mvInvScaleFactors[octave]
+  const float scaleduL = roundf(kL.x * sF), scaledvL = roundf(kL.y * sF);
+  const float scaleduR0 = roundf(uR0 * sF);
+  const int w = 5, L = 5;
+  const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+  if (iniu < 0 || endu >= (float)A.P.lv[levelL].w) return;
+  int pitchL, pitchR;
+  const uint8_t* PL = plane_ptr(A.P, A.IL, imL, levelL, &pitchL);
+  const uint8_t* PR = plane_ptr(A.P, A.IR, imR, levelL, &pitchR);
+  const int r0 = (int)(scaledvL - w), cL0 = (int)(scaleduL - w), cR0 = (int)(scaleduR0 - w);
+  const int cvL = PL[(size_t)(r0 + w) * pitchL + cL0 + w];
+  // each lane owns up to two of the 121 patch positions
+  int py[2], px[2], il[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int p = lane + 64 * k;
+    py[k] = p / 11, px[k] = p - py[k] * 11;
+    il[k] = p < 121 ? (int)PL[(size_t)(r0 + py[k]) * pitchL + cL0 + px[k]] - cvL : 0;
+  }
+  int bestS = INT_MAX, bestInc = 0, sads[11];
+#pragma unroll
+  for (int inc = -L; inc <= L; inc++) {
+    const int cvR = PR[(size_t)(r0 + w) * pitchR + cR0 + inc + w];
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      if (lane + 64 * k < 121) {
+        const int ir = (int)PR[(size_t)(r0 + py[k]) * pitchR + cR0 + inc + px[k]] - cvR;
+        acc += abs(il[k] - ir);
+      }
+    }
+    acc = wave_sum_i(acc);
+    sads[inc + L] = acc;
+    if (acc < bestS) bestS = acc, bestInc = inc;
+  }
+  if (bestInc == -L || bestInc == L) return;
+  float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+  for (int k = 1; k < 10; k++)
+    if (k == bestInc + L) dist1 = (float)sads[k - 1], dist2 = (float)sads[k], dist3 = (float)sads[k + 1];
+  const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+  if (deltaR < -1 || deltaR > 1) return;
+  float bestuR = A.P.lv[levelL].scale * ((float)scaleduR0 + (float)bestInc + deltaR);
+  float disparity = uL - bestuR;
+  if (disparity >= minD && disparity < maxD) {
+    if (disparity <= 0) {
+      disparity = 0.01f;
+      bestuR = (float)((double)uL - 0.01);
+    }
+    if (lane == 0) {
+      *o_dp = A.bf / disparity;
+      *o_ur = bestuR;
+      *o_sad = bestS;
+    }
+  }
+}
+
+// Frame.cc:599-610: median of the accepted SADs (element size/2 of the sorted list), reject
+// matches with SAD >= 1.5*1.4*median.  One workgroup per frame; the k-th smallest is found by a
+// 17-step bisection on the value (SADs are integers below 2^17).
+__global__ void __launch_bounds__(256) k_stereo_median(StereoArgs A) {
+  __shared__ int s_cnt[256];
+  __shared__ int s_n;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int imL = A.l_first + f * A.l_step;
+  const int N = min(A.cntL[2 * imL], A.capL);
+  int* sad = A.sad + (size_t)f * A.capL;
+  int c = 0;
+  for (int i = tid; i < N; i += 256) c += sad[i] >= 0;
+  s_cnt[tid] = c;
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int t = 0; t < 256; t++) n += s_cnt[t];
+    s_n = n;
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) return;
+  const int k = n / 2;  // 0-based rank of the median element
+  int lo = 0, hi = (1 << 17) - 1;  // smallest v with count(sad <= v) >= k+1
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    int cc = 0;
+    for (int i = tid; i < N; i += 256) {
+      const int s = sad[i];
+      cc += (s >= 0 && s <= mid);
+    }
+    __syncthreads();
+    s_cnt[tid] = cc;
+    __syncthreads();
+    if (tid == 0) {
+      int t2 = 0;
+      for (int t = 0; t < 256; t++) t2 += s_cnt[t];
+      s_n = t2;
+    }
+    __syncthreads();
+    if (s_n >= k + 1)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  const float median = (float)lo;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = tid; i < N; i += 256) {
+    const int s = sad[i];
+    if (s >= 0 && !((float)s < thDist)) {
+      A.uright[(size_t)f * A.capL + i] = -1;
+      A.depth[(size_t)f * A.capL + i] = -1;
+    }
+  }
+}
+
+static int launch_stereo(const StereoArgs& A, int n_frames, hipStream_t st) {
+  hipLaunchKernelGGL(k_stereo_rect, dim3((A.capL + 3) / 4, n_frames), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_stereo_median, dim3(n_frames), dim3(256), 0, st, A);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+static int same_geometry(const vieo_orb* a, const vieo_orb* b) {
+  if (a->w != b->w || a->h != b->h || a->nlevels != b->nlevels || a->w == 0) return 0;
+  for (int l = 0; l < a->nlevels; l++)
+    if (a->P.lv[l].w != b->P.lv[l].w || a->P.lv[l].h != b->P.lv[l].h ||
+        a->P.lv[l].scale != b->P.lv[l].scale)
+      return 0;
+  return 1;
+}
+
+// scratch shared by the host-pointer entry points (serialised by a mutex-free single stream use)
+struct MatchScratch {
+  DevBuf kpL, kpR, dL, dR, cL, cR, ur, dp, sad, jobs, idx, dist;
+};
+static thread_local MatchScratch g_ms;
+
+}  // namespace vieo
+
+using namespace vieo;
+
+extern "C" {
+
+int vieo_stereo_match_rectified_batch_device(vieo_orb* e, int n_frames,
+                                             const vieo_keypoint* d_keypoints,
+                                             const uint8_t* d_descriptors, const int32_t* d_counts,
+                                             int capacity, float baseline, float bf,
+                                             float* d_uright, float* d_depth) {
+  if (!e || n_frames <= 0 || 2 * n_frames > e->last_B || !d_keypoints || !d_descriptors ||
+      !d_counts || !d_uright || !d_depth || !(baseline > 0) || !(bf > 0)) {
+    set_error("vieo_stereo_match_rectified_batch_device: invalid arguments (the extractor's last "
+              "batch must hold 2*n_frames images, left/right interleaved)");
+    return VIEO_E_INVALID;
+  }
+  int rc;
+  static thread_local DevBuf sad;
+  if ((rc = sad.ensure((size_t)n_frames * capacity * 4)) != VIEO_OK) return rc;
+  StereoArgs A;
+  A.P = e->P;
+  A.IL = A.IR = e->last_imgs;
+  A.l_first = 0, A.l_step = 2, A.r_first = 1, A.r_step = 2;
+  A.kpL = A.kpR = d_keypoints;
+  A.descL = A.descR = d_descriptors;
+  A.cntL = A.cntR = d_counts;
+  A.capL = A.capR = capacity;
+  A.baseline = baseline;
+  A.bf = bf;
+  A.uright = d_uright;
+  A.depth = d_depth;
+  A.sad = sad.as<int>();
+  return launch_stereo(A, n_frames, e->stream);
+}
+
+int vieo_stereo_match_rectified(vieo_orb* left, vieo_orb* right, const vieo_keypoint* h_kpL,
+                                const uint8_t* h_descL, int nL, const vieo_keypoint* h_kpR,
+                                const uint8_t* h_descR, int nR, float baseline, float bf,
+                                float* h_uright, float* h_depth) {
+  if (!left || !right || nL < 0 || nR < 0 || !h_uright || !h_depth || !(baseline > 0) || !(bf > 0))
+    return VIEO_E_INVALID;
+  if (left->last_B < 1 || right->last_B < 1 || !same_geometry(left, right)) {
+    set_error("vieo_stereo_match_rectified: both extractors must have processed equally sized "
+              "images (their pyramids are read in place)");
+    return VIEO_E_INVALID;
+  }
+  if (nL == 0) return VIEO_OK;
+  int rc;
+  MatchScratch& S = g_ms;
+  const int capL = nL, capR = std::max(nR, 1);
+#define ENS(b, n) \
+  if ((rc = (b).ensure(n)) != VIEO_OK) return rc
+  ENS(S.kpL, (size_t)capL * sizeof(vieo_keypoint));
+  ENS(S.kpR, (size_t)capR * sizeof(vieo_keypoint));
+  ENS(S.dL, (size_t)capL * 32);
+  ENS(S.dR, (size_t)capR * 32);
+  ENS(S.cL, 8);
+  ENS(S.cR, 8);
+  ENS(S.ur, (size_t)capL * 4);
+  ENS(S.dp, (size_t)capL * 4);
+  ENS(S.sad, (size_t)capL * 4);
+#undef ENS
+  hipStream_t st = left->stream;
+  VIEO_HIP_CHECK(hipStreamSynchronize(right->stream));  // right pyramid complete
+  const int cl[2] = {nL, 0}, cr[2] = {nR, 0};
+  VIEO_HIP_CHECK(hipMemcpyAsync(S.kpL.p, h_kpL, (size_t)nL * sizeof(vieo_keypoint), hipMemcpyHostToDevice, st));
+  VIEO_HIP_CHECK(hipMemcpyAsync(S.dL.p, h_descL, (size_t)nL * 32, hipMemcpyHostToDevice, st));
+  if (nR > 0) {
+    VIEO_HIP_CHECK(hipMemcpyAsync(S.kpR.p, h_kpR, (size_t)nR * sizeof(vieo_keypoint), hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemcpyAsync(S.dR.p, h_descR, (size_t)nR * 32, hipMemcpyHostToDevice, st));
+  }
+  VIEO_HIP_CHECK(hipMemcpyAsync(S.cL.p, cl, 8, hipMemcpyHostToDevice, st));
+  VIEO_HIP_CHECK(hipMemcpyAsync(S.cR.p, cr, 8, hipMemcpyHostToDevice, st));
+  StereoArgs A;
+  A.P = left->P;
+  A.IL = left->last_imgs;
+  A.IR = right->last_imgs;
+  A.l_first = 0, A.l_step = 0, A.r_first = 0, A.r_step = 0;
+  A.kpL = S.kpL.as<vieo_keypoint>(), A.kpR = S.kpR.as<vieo_keypoint>();
+  A.descL = S.dL.as<uint8_t>(), A.descR = S.dR.as<uint8_t>();
+  A.cntL = S.cL.as<int>(), A.cntR = S.cR.as<int>();
+  A.capL = capL, A.capR = capR;
+  A.baseline = baseline, A.bf = bf;
+  A.uright = S.ur.as<float>(), A.depth = S.dp.as<float>(), A.sad = S.sad.as<int>();
+  if ((rc = launch_stereo(A, 1, st)) != VIEO_OK) return rc;
+  VIEO_HIP_CHECK(hipMemcpyAsync(h_uright, S.ur.p, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+  VIEO_HIP_CHECK(hipMemcpyAsync(h_depth, S.dp.p, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+  VIEO_HIP_CHECK(hipStreamSynchronize(st));
+  return VIEO_OK;
+}
+
+int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* h_counts,
+                                   int capacity, const int32_t* h_pairs, int n_pairs,
+                                   int32_t* d_idx, int32_t* d_dist, void* stream) {
+  if (!d_descriptors || !h_counts || !h_pairs || n_pairs <= 0 || !d_idx || !d_dist || capacity <= 0)
+    return VIEO_E_INVALID;
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  std::vector<Knn2Job> jobs(n_pairs);
+  int max_nq = 0;
+  for (int p = 0; p < n_pairs; p++) {
+    const int qi = h_pairs[2 * p], ti = h_pairs[2 * p + 1];
+    // descriptors[num_mono:] of both cameras (Frame.cc:620-628)
+    const int qm = h_counts[2 * qi + 1], tm = h_counts[2 * ti + 1];
+    jobs[p].q = d_descriptors + ((size_t)qi * capacity + qm) * 32;
+    jobs[p].t = d_descriptors + ((size_t)ti * capacity + tm) * 32;
+    jobs[p].nq = std::max(h_counts[2 * qi] - qm, 0);
+    jobs[p].nt = std::max(h_counts[2 * ti] - tm, 0);
+    jobs[p].out_off = p * capacity;
+    max_nq = std::max(max_nq, jobs[p].nq);
+  }
+  MatchScratch& S = g_ms;
+  if ((rc = S.jobs.ensure(jobs.size() * sizeof(Knn2Job))) != VIEO_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  VIEO_HIP_CHECK(hipMemcpyAsync(S.jobs.p, jobs.data(), jobs.size() * sizeof(Knn2Job),
+                                hipMemcpyHostToDevice, st));
+  VIEO_HIP_CHECK(hipStreamSynchronize(st));  // jobs vector goes out of scope
+  if (max_nq > 0)
+    hipLaunchKernelGGL(k_knn2, dim3((max_nq + 3) / 4, n_pairs), dim3(256), 0, st,
+                       S.jobs.as<Knn2Job>(), nullptr, d_idx, d_dist);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_hamming_knn2(const uint8_t* h_query, int nq, const uint8_t* h_train, int nt,
+                      int32_t* h_idx, int32_t* h_dist) {
+  if (nq < 0 || nt < 0 || (nq > 0 && (!h_query || !h_idx || !h_dist))) return VIEO_E_INVALID;
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  if (nq == 0) return VIEO_OK;
+  MatchScratch& S = g_ms;
+#define ENS(b, n) \
+  if ((rc = (b).ensure(n)) != VIEO_OK) return rc
+  ENS(S.dL, (size_t)nq * 32);
+  ENS(S.dR, (size_t)std::max(nt, 1) * 32);
+  ENS(S.idx, (size_t)nq * 8);
+  ENS(S.dist, (size_t)nq * 8);
+  ENS(S.jobs, sizeof(Knn2Job));
+#undef ENS
+  VIEO_HIP_CHECK(hipMemcpy(S.dL.p, h_query, (size_t)nq * 32, hipMemcpyHostToDevice));
+  if (nt > 0) VIEO_HIP_CHECK(hipMemcpy(S.dR.p, h_train, (size_t)nt * 32, hipMemcpyHostToDevice));
+  Knn2Job j;
+  j.q = S.dL.as<uint8_t>(), j.t = S.dR.as<uint8_t>(), j.nq = nq, j.nt = nt, j.out_off = 0;
+  VIEO_HIP_CHECK(hipMemcpy(S.jobs.p, &j, sizeof(j), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4, 1), dim3(256), 0, 0, S.jobs.as<Knn2Job>(), nullptr,
+                     S.idx.as<int32_t>(), S.dist.as<int32_t>());
+  VIEO_HIP_CHECK(hipGetLastError());
+  VIEO_HIP_CHECK(hipMemcpy(h_idx, S.idx.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
+  VIEO_HIP_CHECK(hipMemcpy(h_dist, S.dist.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
+  return VIEO_OK;
+}
+
+}  // extern "C"

@@ -22,56 +22,9 @@
 #define QT_DEVICE
 #include "quadtree.inl"
 
+#include "orb_internal.h"
+
 namespace vieo {
-
-static const int kPatchSize = 31, kHalfPatch = 15, kEdge = 19;
-static const int kMaxLevels = 16;
-static const int kBlurTW = 64, kBlurTH = 32;
-
-struct LevelDesc {
-  int w, h, pitch, off;      // plane geometry; off = byte offset in the per-image pyramid block
-  int boff;                  // byte offset in the per-image blurred block
-  int cell_begin, cell_end;  // range in the cell table
-  int nfeat;                 // mnFeaturesPerLevel
-  int regW, regH, nIni;      // DistributeOctTree region and root nodes
-  float hX;
-  int key_off, key_cap;  // candidate-key arena of this level inside the per-image arena
-  int sel_off, ncap;     // selected-key arena / node capacity
-  int xtab_off, ytab_off;
-  float scale;
-  int patch;
-  int tile_begin, tile_end, tiles_x;
-};
-
-struct OrbParams {
-  int nlevels, cell_cap, ncells, keys_per_image, sel_per_image, kp_cap;
-  int umax[kHalfPatch + 1];
-  LevelDesc lv[kMaxLevels];
-};
-
-struct CellDesc {
-  short level, x0, y0, cw, ch, offx, offy, pad;
-};
-
-struct ImgSet {  // where the planes of a batch live
-  const uint8_t* img0;
-  int stride0;
-  size_t img_pitch;
-  uint8_t* pyr;
-  size_t pyr_img;
-  uint8_t* blur;
-  size_t blur_img;
-};
-
-__device__ __forceinline__ const uint8_t* plane_ptr(const OrbParams& P, const ImgSet& I, int b,
-                                                    int l, int* pitch) {
-  if (l == 0) {
-    *pitch = I.stride0;
-    return I.img0 + (size_t)b * I.img_pitch;
-  }
-  *pitch = P.lv[l].pitch;
-  return I.pyr + (size_t)b * I.pyr_img + P.lv[l].off;
-}
 
 // ------------------------------------------------------------------ pyramid (cv::resize)
 // xtab: {sx0, sx1, a0, a1}; ytab: {sy0, sy1, b0, b1}; INTER_LINEAR 8U fixed point:
@@ -319,9 +272,6 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
-struct BlurTile {
-  short level, tx, ty, pad;
-};
 
 __global__ void __launch_bounds__(256)
 k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles) {
@@ -522,43 +472,11 @@ k_lapping(const vieo_keypoint* __restrict__ kin, const uint8_t* __restrict__ din
   }
 }
 
-// ================================================================== host side
-// HIP-event stamps around every stage of a batch call, on the extractor's own stream.  A ring of
-// kTimingRing steps is kept so a bench can time K steps without a host sync in between.
-static const int kTimingRing = 64;
-struct Timing {
-  bool on = false;
-  hipEvent_t ev[kTimingRing][VIEO_ORB_NSTAGES] = {};
-  long steps = 0;  // batch calls stamped since timing was enabled
-};
-
 }  // namespace vieo
 
 using namespace vieo;
 
-struct vieo_orb {
-  int nfeatures, nlevels, iniTh, minTh;
-  double scaleFactor;  // ORBextractor.h:67 keeps the float argument in a double member
-  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
-  std::vector<int> feats;
-  int umax[kHalfPatch + 1];
-  hipStream_t stream = nullptr;
-  // geometry the buffers are currently sized for
-  int w = 0, h = 0, B = 0;
-  OrbParams P;
-  std::vector<CellDesc> cells;
-  std::vector<BlurTile> tiles;
-  int tpitch = 0, tile_bytes = 0, fast_lds = 0, qt_lds = 0, ncap_max = 0, scap_max = 0;
-  size_t pyr_img = 0, blur_img = 0;
-  DevBuf d_pyr, d_blur, d_cells, d_tiles, d_xtab, d_ytab, d_cell_keys, d_cell_counts, d_keys,
-      d_kslot, d_kq, d_sel, d_sel_count, d_pattern, d_in, d_kp, d_desc, d_counts, d_tmp_kp,
-      d_tmp_desc, d_tmp_counts;
-  int out_cap = 0;  // capacity of the internal (host-API) output buffers
-  int last_B = 0;
-  ImgSet last_imgs{};
-  Timing tm;
-};
-
+// ================================================================== host side
 namespace vieo {
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }  // cvRound: half-to-even
