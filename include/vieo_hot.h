@@ -154,6 +154,60 @@ int vieo_stereo_match_rectified_batch_device(vieo_orb* e, int n_frames,
                                              int capacity, float baseline, float bf,
                                              float* d_uright, float* d_depth);
 
+/* ---------------------------------------------------------------- pose optimisation --------
+ * Replaces Optimizer::PoseOptimization (motion-only BA with fixed map points).  The host shim
+ * flattens Frame / MapPoint objects into the POD structs below and writes the results back
+ * (mvbOutlier, NavState, pose) exactly where the reference does (Optimizer.cc:1716,1824-1871).
+ */
+
+/* VIEO_SLAM::NavState (src/Odom/NavState.h:18-85): 22 doubles. */
+typedef struct vieo_navstate {
+  double p[3];  /* mpwb */
+  double q[4];  /* mRwb as unit quaternion (w, x, y, z) */
+  double v[3];  /* mvwb */
+  double bg[3], ba[3], dbg[3], dba[3];
+} vieo_navstate;
+
+/* One 3D-2D correspondence = one EdgeReprojectPR / PRStereo (src/Odom/g2otypes.h:321-547). */
+typedef struct vieo_pose_obs {
+  float Xw[3];      /* MapPoint::mWorldPos, stored as float32 (include/MapPoint.h:52-53) */
+  float u, v, ur;   /* mvKeysUn[i].pt and stereoinfo_.vuright_[i]; ur < 0 => monocular edge */
+  float inv_sigma2; /* scalepyrinfo_.vinvlevelsigma2_[octave] */
+  int32_t flags;    /* bit 0: close point (track_depth_ < max(10, ThDepth)), VIO variant only */
+} vieo_pose_obs;    /* 32 bytes */
+
+typedef struct vieo_pose_frame {
+  vieo_navstate nav;     /* initial estimate (Frame::mNavState after UpdateNavStatePVRFromTcw) */
+  double Rcb[9], tcb[3]; /* FrameBase::meigRcb (row-major) / meigtcb */
+  float fx, fy, cx, cy;  /* pinhole intrinsics, float like camm::Camera::parameters_ */
+  float bf;              /* stereoinfo_.baseline_bf_[1] */
+  int32_t obs_begin;     /* first observation of this frame in the flat obs array */
+  int32_t n_obs;
+  int32_t reserved;
+} vieo_pose_frame;
+
+#define VIEO_POSE_OK 0
+#define VIEO_POSE_TOO_FEW 1 /* < 3 correspondences: the reference returns 0 and leaves the pose */
+typedef struct vieo_pose_result {
+  vieo_navstate nav;  /* optimised state (p, q updated; other fields copied) */
+  int32_t n_inliers;  /* return value of the reference: nInitialCorrespondences - nBad */
+  int32_t status;     /* VIEO_POSE_* */
+  int32_t lm_iterations; /* total LM iterations executed over the 4 rounds (diagnostic) */
+  int32_t reserved;
+} vieo_pose_result;
+
+/* int Optimizer::PoseOptimization(Frame* pFrame, Frame* pLastF = NULL) (src/Optimizer.cc:1611-1874),
+ * vision-only motion BA without the optional encoder edge: 4 rounds of optimize(10) from the
+ * initial estimate, chi2 classification 5.991 / 7.815 after each round, Huber off after round 3.
+ * h_outlier[n_obs] receives mvbOutlier of the matched keypoints. */
+int vieo_pose_optimization(const vieo_pose_frame* h_frame, const vieo_pose_obs* h_obs,
+                           uint8_t* h_outlier, vieo_pose_result* h_result);
+/* Batched device form: one workgroup per frame, the whole 4x10 LM loop runs on the device.
+ * d_obs / d_outlier are flat arrays indexed by obs_begin + i.  Asynchronous on `stream`. */
+int vieo_pose_optimization_batch_device(const vieo_pose_frame* d_frames, int n_frames,
+                                        const vieo_pose_obs* d_obs, uint8_t* d_outlier,
+                                        vieo_pose_result* d_results, void* stream);
+
 /* ---- test taps (parity tests only; not part of the drop-in surface) ---- */
 /* which: 1 = blurred level.  FAST candidates: int32 triplets (x, y, response) in
  * vToDistributeKeys order; level keys: vieo_keypoint in DistributeOctTree output order. */

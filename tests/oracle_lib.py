@@ -46,7 +46,51 @@ class Oracle:
         L.vo_descriptor_distance.argtypes = [P, P]
         L.vo_knn2_hamming.argtypes = [P, I, P, I, P, P]
         L.vo_stereo_match_rectified.argtypes = [P, P, I, P, I, P, P, I, P, P, P, F, F, P, P]
+        L.vo_pose_optimization.argtypes = [P, P, P, P]
+        L.vo_pose_edge_eval.argtypes = [P, P, P, P, P]
+        L.vo_so3_exp.argtypes = [P, P]
+        L.vo_so3_log.argtypes = [P, P]
+        L.vo_so3_jr.argtypes = [P, P, I]
         self.L = L
+
+    # ---- pose optimisation
+    def pose_optimization(self, frame, obs):
+        from vieo_slam_amd.ba_types import POSE_RESULT_DTYPE
+        frame = np.ascontiguousarray(frame)
+        obs = np.ascontiguousarray(obs)
+        outl = np.zeros(len(obs), np.uint8)
+        res = np.zeros(1, POSE_RESULT_DTYPE)
+        self.L.vo_pose_optimization(frame.ctypes.data, obs.ctypes.data, outl.ctypes.data,
+                                    res.ctypes.data)
+        return res[0], outl
+
+    def pose_edge_eval(self, frame, ob, delta=None, want_jac=True):
+        err = np.zeros(3)
+        J = np.zeros((3, 6))
+        d = None if delta is None else np.ascontiguousarray(delta, np.float64)
+        self.L.vo_pose_edge_eval(np.ascontiguousarray(frame).ctypes.data,
+                                 np.ascontiguousarray(ob).ctypes.data,
+                                 None if d is None else d.ctypes.data, err.ctypes.data,
+                                 J.ctypes.data if want_jac else None)
+        return err, J
+
+    def so3_exp(self, w):
+        w = np.ascontiguousarray(w, np.float64)
+        q = np.zeros(4)
+        self.L.vo_so3_exp(w.ctypes.data, q.ctypes.data)
+        return q
+
+    def so3_log(self, q):
+        q = np.ascontiguousarray(q, np.float64)
+        w = np.zeros(3)
+        self.L.vo_so3_log(q.ctypes.data, w.ctypes.data)
+        return w
+
+    def so3_jr(self, w, inverse=False):
+        w = np.ascontiguousarray(w, np.float64)
+        J = np.zeros((3, 3))
+        self.L.vo_so3_jr(w.ctypes.data, J.ctypes.data, int(inverse))
+        return J
 
     # ---- matching
     def descriptor_distance(self, a, b):

@@ -1,0 +1,23 @@
+"""Host-side mirror of VIEO_SLAM::Optimizer (reference include/Optimizer.h:55-101) for the
+functions on the hot path, over flattened problems (ba_types.py) instead of Frame/MapPoint
+pointer graphs."""
+import numpy as np
+
+from ._lib import check, lib
+from .ba_types import POSE_FRAME_DTYPE, POSE_OBS_DTYPE, POSE_RESULT_DTYPE
+
+
+class Optimizer:
+    @staticmethod
+    def PoseOptimization(frame, obs):
+        """int Optimizer::PoseOptimization(Frame*, Frame* = NULL) (Optimizer.cc:1611-1874).
+        frame: POSE_FRAME_DTYPE[1]; obs: POSE_OBS_DTYPE[n].
+        returns (result POSE_RESULT_DTYPE record, outlier uint8[n]); result['n_inliers'] is the
+        reference's return value."""
+        fr = np.ascontiguousarray(frame, POSE_FRAME_DTYPE).reshape(1)
+        ob = np.ascontiguousarray(obs, POSE_OBS_DTYPE)
+        outl = np.zeros(max(len(ob), 1), np.uint8)
+        res = np.zeros(1, POSE_RESULT_DTYPE)
+        check(lib().vieo_pose_optimization(fr.ctypes.data, ob.ctypes.data, outl.ctypes.data,
+                                           res.ctypes.data), "vieo_pose_optimization")
+        return res[0], outl[:len(ob)]
