@@ -154,6 +154,72 @@ int vieo_stereo_match_rectified_batch_device(vieo_orb* e, int n_frames,
                                              int capacity, float baseline, float bf,
                                              float* d_uright, float* d_depth);
 
+/* ---------------------------------------------------------------- projection search ---------
+ * Replaces the tracking-side ORBmatcher::SearchByProjection overloads (src/ORBmatcher.cc:230-335
+ * and :1303-1467) on flattened inputs.  The window query is FrameBase::GetFeaturesInArea
+ * (src/FrameBase.cpp:95-141, 64x48 grid order: cell column, cell row, key index).
+ */
+typedef struct vieo_proj_query { /* one map point projected into one camera: 64 bytes */
+  float u, v, ur;                /* projection; ur is compared with stereo keypoints only */
+  float radius;                  /* window half-size in pixels (th * scale already applied) */
+  int32_t level_min, level_max;  /* GetFeaturesInArea(minlevel, maxlevel); level_max < 0: no max */
+  float angle;                   /* angle of the query's own keypoint (rotation check, a12) */
+  int32_t flags;                 /* bit0: valid; bit1: the map point has Observations() > 0 */
+  uint8_t desc[32];              /* MapPoint::GetDescriptor() */
+} vieo_proj_query;
+
+typedef struct vieo_last_frame_point { /* LastFrame.mvpMapPoints[i] flattened: 64 bytes */
+  float Xw[3];       /* MapPoint::GetWorldPos() */
+  int32_t octave;    /* LastFrame.mvKeys[i].octave */
+  float angle;       /* LastFrame.mvKeys[i].angle */
+  int32_t flags;     /* bit0: pMP != NULL && !LastFrame.mvbOutlier[i]; bit1: Observations() > 0 */
+  int32_t reserved[2];
+  uint8_t desc[32];
+} vieo_last_frame_point;
+
+typedef struct vieo_sbp_camera {
+  double Tcw_cur[12], Tcw_last[12]; /* 3x4 row-major [R|t] of CurrentFrame / LastFrame */
+  float fx, fy, cx, cy;
+  float bounds[4];                  /* gridinfo_.minmax_xy_: min_x, max_x, min_y, max_y */
+  float bf, baseline;               /* stereoinfo_.baseline_bf_[1], [0] */
+  float th, th_far;                 /* window threshold; far-point cut (<= 0: off) */
+  int32_t mono, nlevels;
+  float scale[16];                  /* scalepyrinfo_.vscalefactor_ */
+} vieo_sbp_camera;
+
+#define VIEO_SBP_LAST_FRAME 0 /* accept best <= TH_HIGH, rotation histogram (ORBmatcher.cc:1303-1467) */
+#define VIEO_SBP_LOCAL_MAP 1  /* best/second ratio test when same level (ORBmatcher.cc:230-335) */
+#define VIEO_SBP_UNCHANGED (-1)
+#define VIEO_SBP_ERASED (-2)
+
+/* Projection part of SearchByProjection(Frame&, const Frame&, th, bMono, th_far)
+ * (ORBmatcher.cc:1313-1378): last frame's valid map points -> window queries. */
+int vieo_sbp_project_last_frame(const vieo_last_frame_point* h_points, int n,
+                                const vieo_sbp_camera* h_cam, vieo_proj_query* h_queries);
+/* The search + sequential assignment of both overloads.  h_taken[i] != 0 when keypoint i already
+ * holds a map point with Observations() > 0.  h_assign[n_keys]: VIEO_SBP_UNCHANGED, VIEO_SBP_ERASED
+ * (EraseMapPointMatch by the rotation check) or the index of the query whose map point
+ * AddMapPoint() put there.  *nmatches = the reference's return value. */
+int vieo_search_by_projection(int mode, const vieo_proj_query* h_queries, int nq,
+                              const vieo_keypoint* h_keys, const float* h_uright,
+                              const uint8_t* h_desc, const uint8_t* h_taken, int n_keys,
+                              const float* h_bounds /*[4]*/, float nn_ratio, int check_orientation,
+                              int32_t* h_assign, int32_t* nmatches);
+/* Batched device form: frame f owns queries [f*q_cap, f*q_cap + d_nq[f]) and the key arrays of
+ * image img_first + f*img_step of an extractor batch (d_counts as written by the extractor). */
+int vieo_search_by_projection_batch_device(int mode, const vieo_proj_query* d_queries,
+                                           const int32_t* d_nq, int q_cap, int n_frames,
+                                           const vieo_keypoint* d_keys, const float* d_uright,
+                                           const uint8_t* d_desc, const uint8_t* d_taken,
+                                           const int32_t* d_counts, int key_cap, int img_first,
+                                           int img_step, const float* h_bounds, float nn_ratio,
+                                           int check_orientation, int32_t* d_assign,
+                                           int32_t* d_nmatches, void* stream);
+int vieo_sbp_project_last_frame_batch_device(const vieo_last_frame_point* d_points,
+                                             const int32_t* d_n, int p_cap, int n_frames,
+                                             const vieo_sbp_camera* d_cams,
+                                             vieo_proj_query* d_queries, void* stream);
+
 /* ---------------------------------------------------------------- pose optimisation --------
  * Replaces Optimizer::PoseOptimization (motion-only BA with fixed map points).  The host shim
  * flattens Frame / MapPoint objects into the POD structs below and writes the results back

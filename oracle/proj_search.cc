@@ -1,0 +1,244 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see ocv_prims.hpp header).  PARITY UNPINNED.
+//
+// CPU restatement of the tracking-side projection searches on flattened inputs:
+//   FrameBase::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea / IsInImage   src/FrameBase.cpp:95-174
+//   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono, th_far)       src/ORBmatcher.cc:1303-1467
+//   ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, th_far)        src/ORBmatcher.cc:230-335
+//   ORBmatcher::ComputeThreeMaxima                                                src/ORBmatcher.cc:1608-1641
+// The sequential dependence of the reference (a later query sees the keypoints earlier queries
+// claimed through AddMapPoint) is kept literally.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/vieo_hot.h"
+
+extern "C" int vo_descriptor_distance(const uint8_t* a, const uint8_t* b);
+
+namespace vo {
+
+static const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;  // FrameBase.h:224-225
+static const int TH_HIGH_ = 100, HISTO_LENGTH = 30;           // ORBmatcher.cc:20-22
+
+struct FrameFeat {
+  const vieo_keypoint* keys;
+  const float* uright;
+  const uint8_t* desc;
+  int N;
+  float minx, maxx, miny, maxy, winv, hinv;
+  std::vector<std::vector<size_t>> grid;
+  // mvpMapPoints state during a search: -1 none, -3 pre-existing observed map point,
+  // >= 0 query index placed by AddMapPoint in this call
+  std::vector<int> mp;
+  std::vector<uint8_t> mp_observed;  // Observations() > 0 of the map point currently there
+
+  void build(const float* bounds) {
+    minx = bounds[0], maxx = bounds[1], miny = bounds[2], maxy = bounds[3];
+    winv = FRAME_GRID_COLS / (maxx - minx);  // FrameBase.cpp:214-217
+    hinv = FRAME_GRID_ROWS / (maxy - miny);
+    grid.assign(FRAME_GRID_COLS * FRAME_GRID_ROWS, {});
+    for (int i = 0; i < N; ++i) {  // AssignFeaturesToGrid + PosInGrid
+      int posX = (int)round((keys[i].x - minx) * winv);
+      int posY = (int)round((keys[i].y - miny) * hinv);
+      if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) continue;
+      grid[posX * FRAME_GRID_ROWS + posY].push_back(i);
+    }
+  }
+  bool IsInImage(float x, float y) const { return x >= minx && x < maxx && y >= miny && y < maxy; }
+
+  // FrameBase.cpp:95-141
+  std::vector<size_t> GetFeaturesInArea(float x, float y, float r, int minlevel, int maxlevel) const {
+    std::vector<size_t> vIndices;
+    const int min_cellx = std::max(0, (int)floor((x - minx - r) * winv));
+    if (min_cellx >= FRAME_GRID_COLS) return vIndices;
+    const int max_cellx = std::min((int)FRAME_GRID_COLS - 1, (int)ceil((x - minx + r) * winv));
+    if (max_cellx < 0) return vIndices;
+    const int min_celly = std::max(0, (int)floor((y - miny - r) * hinv));
+    if (min_celly >= FRAME_GRID_ROWS) return vIndices;
+    const int max_celly = std::min((int)FRAME_GRID_ROWS - 1, (int)ceil((y - miny + r) * hinv));
+    if (max_celly < 0) return vIndices;
+    const bool bchecklevel = (minlevel > 0) || (maxlevel >= 0);
+    for (int ix = min_cellx; ix <= max_cellx; ++ix)
+      for (int iy = min_celly; iy <= max_celly; ++iy) {
+        const std::vector<size_t>& vCell = grid[ix * FRAME_GRID_ROWS + iy];
+        for (size_t j = 0, jend = vCell.size(); j < jend; ++j) {
+          const vieo_keypoint& kpUn = keys[vCell[j]];
+          if (bchecklevel) {
+            if (kpUn.octave < minlevel) continue;
+            if (maxlevel >= 0)
+              if (kpUn.octave > maxlevel) continue;
+          }
+          const float distx = kpUn.x - x;
+          const float disty = kpUn.y - y;
+          if (fabs(distx) < r && fabs(disty) < r) vIndices.push_back(vCell[j]);
+        }
+      }
+    return vIndices;
+  }
+};
+
+// ORBmatcher.cc:1608-1641
+static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) {
+      max3 = max2, max2 = max1, max1 = s;
+      ind3 = ind2, ind2 = ind1, ind1 = i;
+    } else if (s > max2) {
+      max3 = max2, max2 = s;
+      ind3 = ind2, ind2 = i;
+    } else if (s > max3) {
+      max3 = s, ind3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) {
+    ind2 = -1, ind3 = -1;
+  } else if (max3 < 0.1f * (float)max1) {
+    ind3 = -1;
+  }
+}
+
+static int search(int mode, const vieo_proj_query* Q, int nq, FrameFeat& F, const uint8_t* taken,
+                  float nnratio, bool checkOri, int32_t* assign) {
+  int nmatches = 0;
+  F.mp.assign(F.N, -1);
+  F.mp_observed.assign(F.N, 0);
+  for (int i = 0; i < F.N; i++) {
+    assign[i] = VIEO_SBP_UNCHANGED;
+    if (taken && taken[i]) F.mp[i] = -3, F.mp_observed[i] = 1;
+  }
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int q = 0; q < nq; q++) {
+    const vieo_proj_query& p = Q[q];
+    if (!(p.flags & 1)) continue;
+    const std::vector<size_t> vIndices = F.GetFeaturesInArea(p.u, p.v, p.radius, p.level_min, p.level_max);
+    if (vIndices.empty()) continue;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (size_t k = 0; k < vIndices.size(); k++) {
+      const size_t idx = vIndices[k];
+      if (F.mp[idx] != -1)
+        if (F.mp_observed[idx]) continue;
+      if (F.uright[idx] > 0) {
+        const float er = fabs(p.ur - F.uright[idx]);
+        if (er > p.radius) continue;
+      }
+      const int dist = vo_descriptor_distance(p.desc, F.desc + idx * 32);
+      if (mode == VIEO_SBP_LAST_FRAME) {
+        if (dist < bestDist) {
+          bestDist = dist;
+          bestIdx = (int)idx;
+        }
+      } else {
+        if (dist < bestDist) {
+          bestDist2 = bestDist;
+          bestDist = dist;
+          bestLevel2 = bestLevel;
+          bestLevel = F.keys[idx].octave;
+          bestIdx = (int)idx;
+        } else if (dist < bestDist2) {
+          bestLevel2 = F.keys[idx].octave;
+          bestDist2 = dist;
+        }
+      }
+    }
+    if (bestDist <= TH_HIGH_) {
+      if (mode == VIEO_SBP_LOCAL_MAP)
+        if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      // AddMapPoint(pMP, bestIdx)
+      F.mp[bestIdx] = q;
+      F.mp_observed[bestIdx] = (p.flags & 2) ? 1 : 0;
+      assign[bestIdx] = q;
+      nmatches++;
+      if (mode == VIEO_SBP_LAST_FRAME && checkOri) {
+        float rot = p.angle - F.keys[bestIdx].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx);
+      }
+    }
+  }
+  if (mode == VIEO_SBP_LAST_FRAME && checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+          assign[rotHist[i][j]] = VIEO_SBP_ERASED;  // EraseMapPointMatch
+          nmatches--;
+        }
+  }
+  return nmatches;
+}
+
+// ORBmatcher.cc:1313-1378: projection of the last frame's map points -> queries
+static void project_last_frame(const vieo_last_frame_point* P, int n, const vieo_sbp_camera& C,
+                               vieo_proj_query* Q) {
+  // Tlrcr = Tlrw * Tcrw^-1 ; translation = tlrw - Rlrw * Rcrw^T * tcrw
+  const double* Tc = C.Tcw_cur;
+  const double* Tl = C.Tcw_last;
+  double Rlc[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      Rlc[i * 3 + j] = Tl[i * 4] * Tc[j * 4] + Tl[i * 4 + 1] * Tc[j * 4 + 1] + Tl[i * 4 + 2] * Tc[j * 4 + 2];
+  const double tz = Tl[2 * 4 + 3] - (Rlc[6] * Tc[3] + Rlc[7] * Tc[7] + Rlc[8] * Tc[11]);
+  const bool bForward = tz > C.baseline && !C.mono;
+  const bool bBackward = -tz > C.baseline && !C.mono;
+  for (int i = 0; i < n; i++) {
+    vieo_proj_query& q = Q[i];
+    memset(&q, 0, sizeof(q));
+    const vieo_last_frame_point& p = P[i];
+    if (!(p.flags & 1)) continue;
+    const double X = p.Xw[0], Y = p.Xw[1], Z = p.Xw[2];
+    const double x3 = Tc[0] * X + Tc[1] * Y + Tc[2] * Z + Tc[3];
+    const double y3 = Tc[4] * X + Tc[5] * Y + Tc[6] * Z + Tc[7];
+    const double z3 = Tc[8] * X + Tc[9] * Y + Tc[10] * Z + Tc[11];
+    if (C.th_far > 0 && z3 > C.th_far) continue;
+    const float xc = x3, yc = y3;
+    const float invzc = 1.0 / z3;
+    if (invzc < 0) continue;
+    // uv = K.cast<float>() * (xc*invzc, yc*invzc, 1)
+    const float pnx = xc * invzc, pny = yc * invzc;
+    const float u = C.fx * pnx + 0.f * pny + C.cx * 1.f;
+    const float v = 0.f * pnx + C.fy * pny + C.cy * 1.f;
+    if (!(u >= C.bounds[0] && u < C.bounds[1] && v >= C.bounds[2] && v < C.bounds[3])) continue;
+    const int nLastOctave = p.octave;
+    q.u = u, q.v = v;
+    q.ur = u - C.bf * invzc;
+    q.radius = C.th * C.scale[nLastOctave];
+    if (bForward)
+      q.level_min = 0, q.level_max = nLastOctave;
+    else if (bBackward)
+      q.level_min = nLastOctave, q.level_max = -1;
+    else
+      q.level_min = nLastOctave - 1, q.level_max = nLastOctave + 1;
+    q.angle = p.angle;
+    q.flags = 1 | (p.flags & 2);
+    memcpy(q.desc, p.desc, 32);
+  }
+}
+
+}  // namespace vo
+
+extern "C" {
+
+void vo_sbp_project_last_frame(const vieo_last_frame_point* pts, int n, const vieo_sbp_camera* cam,
+                               vieo_proj_query* queries) {
+  vo::project_last_frame(pts, n, *cam, queries);
+}
+
+int vo_search_by_projection(int mode, const vieo_proj_query* queries, int nq,
+                            const vieo_keypoint* keys, const float* uright, const uint8_t* desc,
+                            const uint8_t* taken, int n_keys, const float* bounds, float nn_ratio,
+                            int check_orientation, int32_t* assign) {
+  vo::FrameFeat F;
+  F.keys = keys, F.uright = uright, F.desc = desc, F.N = n_keys;
+  F.build(bounds);
+  return vo::search(mode, queries, nq, F, taken, nn_ratio, check_orientation != 0, assign);
+}
+
+}  // extern "C"

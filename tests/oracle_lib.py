@@ -46,12 +46,38 @@ class Oracle:
         L.vo_descriptor_distance.argtypes = [P, P]
         L.vo_knn2_hamming.argtypes = [P, I, P, I, P, P]
         L.vo_stereo_match_rectified.argtypes = [P, P, I, P, I, P, P, I, P, P, P, F, F, P, P]
+        L.vo_sbp_project_last_frame.argtypes = [P, I, P, P]
+        L.vo_search_by_projection.argtypes = [I, P, I, P, P, P, P, I, P, F, I, P]
         L.vo_pose_optimization.argtypes = [P, P, P, P]
         L.vo_pose_edge_eval.argtypes = [P, P, P, P, P]
         L.vo_so3_exp.argtypes = [P, P]
         L.vo_so3_log.argtypes = [P, P]
         L.vo_so3_jr.argtypes = [P, P, I]
         self.L = L
+
+    # ---- projection search
+    def sbp_project_last_frame(self, pts, cam):
+        from vieo_slam_amd.ba_types import PROJ_QUERY_DTYPE
+        pts = np.ascontiguousarray(pts)
+        cam = np.ascontiguousarray(cam)
+        q = np.zeros(len(pts), PROJ_QUERY_DTYPE)
+        self.L.vo_sbp_project_last_frame(pts.ctypes.data, len(pts), cam.ctypes.data, q.ctypes.data)
+        return q
+
+    def search_by_projection(self, mode, queries, keys, uright, desc, taken, bounds, nn_ratio=0.6,
+                             check_ori=True):
+        queries = np.ascontiguousarray(queries)
+        keys = np.ascontiguousarray(keys)
+        uright = np.ascontiguousarray(uright, np.float32)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+        b = np.ascontiguousarray(bounds, np.float32)
+        assign = np.zeros(max(len(keys), 1), np.int32)
+        n = self.L.vo_search_by_projection(mode, queries.ctypes.data, len(queries), keys.ctypes.data,
+                                           uright.ctypes.data, desc.ctypes.data,
+                                           None if tk is None else tk.ctypes.data, len(keys),
+                                           b.ctypes.data, nn_ratio, int(check_ori), assign.ctypes.data)
+        return n, assign[:len(keys)]
 
     # ---- pose optimisation
     def pose_optimization(self, frame, obs):

@@ -1,0 +1,159 @@
+"""Projection search (tracking-side ORBmatcher::SearchByProjection): CPU known-answer tests of
+the oracle and GPU parity tests (bit-exact assignments)."""
+import numpy as np
+import pytest
+
+from vieo_slam_amd import frontend, synth
+from vieo_slam_amd.ba_types import PROJ_QUERY_DTYPE
+
+K = (synth.EUROC_FX, synth.EUROC_FX, 367.4517211914062, 252.2008514404297)
+BF, BASELINE = synth.EUROC_BF, synth.EUROC_BF / synth.EUROC_FX
+BOUNDS = np.array([0, 752, 0, 480], np.float32)
+
+
+def _frame(oracle, seed):
+    """keys/desc/uright/depth of a synthetic stereo frame (via the oracle)."""
+    left, right, _ = synth.synth_stereo_pair(seed)
+    eL, eR = oracle.extractor(1200), oracle.extractor(1200)
+    _, kl, dl = eL(left)
+    _, kr, dr = eR(right)
+    ur, dp = oracle.stereo_match(eL, eR, kl, dl, kr, dr, BASELINE, BF)
+    return kl, dl, ur, dp, np.array(eL.scale_factors(), np.float32)
+
+
+def _scenario(oracle, seed, th=7.0, dt=(0.02, -0.01, 0.03), observed=True):
+    """current frame = stereo frame `seed`; 'last frame' = the same keys unprojected with the
+    identity pose, current pose = small translation -> projections land near their keys."""
+    kl, dl, ur, dp, sc = _frame(oracle, seed)
+    Xw, ok = frontend.unproject_stereo(kl, dp, K, np.eye(3), np.zeros(3))
+    pts = frontend.make_last_frame_points(kl, dl, Xw, ok, observed)
+    Tl = frontend.pose_to_Tcw(np.eye(3), np.zeros(3))
+    Tc = frontend.pose_to_Tcw(np.eye(3), np.array(dt))
+    cam = frontend.make_sbp_camera(Tc, Tl, K, BOUNDS, BF, BASELINE, th, sc)
+    return kl, dl, ur, pts, cam
+
+
+def test_oracle_sbp_last_frame_finds_own_keys(oracle):
+    kl, dl, ur, pts, cam = _scenario(oracle, 1000, dt=(0.0, 0.0, 0.0))
+    q = oracle.sbp_project_last_frame(pts, cam)
+    valid = (q["flags"] & 1) > 0
+    assert valid.sum() > 300
+    # zero motion: every valid query projects onto its own key (float32 round trip)
+    assert np.max(np.abs(q["u"][valid] - kl["x"][valid])) < 1e-2
+    n, assign = oracle.search_by_projection(0, q, kl, ur, dl, None, BOUNDS)
+    got = np.nonzero(assign >= 0)[0]
+    assert n == len(got) and n > 0.9 * valid.sum()
+    assert np.mean(assign[got] == got) > 0.98  # matched to itself (distance 0)
+    assert np.all(q["level_min"][valid] == kl["octave"][valid] - 1)
+
+
+def test_oracle_sbp_forward_backward_levels(oracle):
+    kl, dl, ur, pts, cam = _scenario(oracle, 1001, dt=(0, 0, 0.0))
+    for tz, lo, hi in ((0.5, "zero", "oct"), (-0.5, "oct", "none")):
+        Tc = frontend.pose_to_Tcw(np.eye(3), np.array([0, 0, tz]))
+        cam[0]["Tcw_cur"] = Tc.reshape(-1)
+        q = oracle.sbp_project_last_frame(pts, cam)
+        v = (q["flags"] & 1) > 0
+        # camera moved along +z of the last frame: tlrcr.z = +tz (Tlrcr = Tlrw * Tcrw^-1)
+        if lo == "zero":
+            assert np.all(q["level_min"][v] == 0) and np.all(q["level_max"][v] == pts["octave"][v])
+        else:
+            assert np.all(q["level_min"][v] == pts["octave"][v]) and np.all(q["level_max"][v] == -1)
+
+
+def test_oracle_sequential_claiming_and_rotation_filter(oracle):
+    kl, dl, ur, pts, cam = _scenario(oracle, 1002)
+    q = oracle.sbp_project_last_frame(pts, cam)
+    n, a = oracle.search_by_projection(0, q, kl, ur, dl, None, BOUNDS)
+    used = a[a >= 0]
+    assert len(used) == len(set(used.tolist()))  # a query is placed at most once
+    # rotation check off: no erasures, count >= the filtered count
+    n2, a2 = oracle.search_by_projection(0, q, kl, ur, dl, None, BOUNDS, check_ori=False)
+    assert not np.any(a2 == -2) and n2 >= n
+    # pre-claimed keypoints are never overwritten
+    taken = np.zeros(len(kl), np.uint8)
+    taken[::3] = 1
+    n3, a3 = oracle.search_by_projection(0, q, kl, ur, dl, taken, BOUNDS)
+    assert np.all(a3[::3] == -1)
+    # unobserved (temporal) map points do not claim: later queries may overwrite the slot
+    pts0 = pts.copy()
+    pts0["flags"] = (pts0["flags"] & 1)
+    q0 = oracle.sbp_project_last_frame(pts0, cam)
+    n4, a4 = oracle.search_by_projection(0, q0, kl, ur, dl, None, BOUNDS, check_ori=False)
+    assert n4 >= n2
+
+
+def test_oracle_local_map_ratio_rule(oracle):
+    kl, dl, ur, pts, cam = _scenario(oracle, 1003)
+    q = oracle.sbp_project_last_frame(pts, cam)
+    q["level_min"] = pts["octave"] - 1  # isInFrustum-style windows: levels [L-1, L]
+    q["level_max"] = pts["octave"]
+    n_loose, _ = oracle.search_by_projection(1, q, kl, ur, dl, None, BOUNDS, nn_ratio=1.0)
+    n_tight, _ = oracle.search_by_projection(1, q, kl, ur, dl, None, BOUNDS, nn_ratio=0.3)
+    assert n_loose >= n_tight > 0
+
+
+# ------------------------------------------------------------------ GPU parity
+def _hip_matcher(nn=0.6, ori=True):
+    from vieo_slam_amd.matching import ORBmatcher
+    return ORBmatcher(nn, ori)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th,dt", [(1000, 7.0, (0.02, -0.01, 0.03)), (1001, 15.0, (0.05, 0.02, 0.3)),
+                                        (1002, 7.0, (0.0, 0.0, -0.4)), (1003, 14.0, (-0.1, 0.05, 0.0))])
+def test_gpu_sbp_last_frame_parity(oracle, seed, th, dt):
+    kl, dl, ur, pts, cam = _scenario(oracle, seed, th, dt)
+    oq = oracle.sbp_project_last_frame(pts, cam)
+    m = _hip_matcher()
+    hq = m.project_last_frame(pts, cam)
+    assert np.array_equal(oq.view(np.uint8), hq.view(np.uint8))
+    for taken in (None, (np.arange(len(kl)) % 5 == 0).astype(np.uint8)):
+        on, oa = oracle.search_by_projection(0, oq, kl, ur, dl, taken, BOUNDS)
+        hn, ha = m.SearchByProjectionLastFrame(hq, kl, ur, dl, taken, BOUNDS)
+        assert on == hn and np.array_equal(oa, ha)
+        assert on > 100
+    on, oa = oracle.search_by_projection(0, oq, kl, ur, dl, None, BOUNDS, check_ori=False)
+    hn, ha = _hip_matcher(0.6, False).SearchByProjectionLastFrame(hq, kl, ur, dl, None, BOUNDS)
+    assert on == hn and np.array_equal(oa, ha)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,nn", [(1004, 0.8), (1005, 0.6), (1006, 0.9)])
+def test_gpu_sbp_local_map_parity(oracle, seed, nn):
+    kl, dl, ur, pts, cam = _scenario(oracle, seed, th=1.0)
+    q = oracle.sbp_project_last_frame(pts, cam)
+    rng = np.random.default_rng(seed)
+    q["level_min"] = pts["octave"] - 1
+    q["level_max"] = pts["octave"]
+    q["radius"] = np.where(rng.random(len(q)) < 0.5, 2.5, 4.0).astype(np.float32) * cam[0]["scale"][pts["octave"]] * 3
+    q = q[rng.permutation(len(q))]  # local map points come in arbitrary order
+    for taken in (None, (rng.random(len(kl)) < 0.3).astype(np.uint8)):
+        on, oa = oracle.search_by_projection(1, q, kl, ur, dl, taken, BOUNDS, nn_ratio=nn)
+        hn, ha = _hip_matcher(nn).SearchByProjectionLocalMap(q, kl, ur, dl, taken, BOUNDS)
+        assert on == hn and np.array_equal(oa, ha)
+        assert on > 50
+
+
+@pytest.mark.gpu
+def test_gpu_sbp_edge_cases(oracle):
+    kl, dl, ur, pts, cam = _scenario(oracle, 1007)
+    m = _hip_matcher()
+    q = oracle.sbp_project_last_frame(pts, cam)
+    # no queries / no valid queries / all keys claimed
+    hn, ha = m.SearchByProjectionLastFrame(q[:0], kl, ur, dl, None, BOUNDS)
+    assert hn == 0 and np.all(ha == -1)
+    q0 = q.copy()
+    q0["flags"] = 0
+    hn, ha = m.SearchByProjectionLastFrame(q0, kl, ur, dl, None, BOUNDS)
+    assert hn == 0 and np.all(ha == -1)
+    taken = np.ones(len(kl), np.uint8)
+    on, oa = oracle.search_by_projection(0, q, kl, ur, dl, taken, BOUNDS)
+    hn, ha = m.SearchByProjectionLastFrame(q, kl, ur, dl, taken, BOUNDS)
+    assert on == hn == 0 and np.array_equal(oa, ha)
+    # windows hanging over the image border
+    q2 = q.copy()
+    q2["u"] = np.where(np.arange(len(q)) % 2 == 0, 2.0, 750.0)
+    on, oa = oracle.search_by_projection(0, q2, kl, ur, dl, None, BOUNDS)
+    hn, ha = m.SearchByProjectionLastFrame(q2, kl, ur, dl, None, BOUNDS)
+    assert on == hn and np.array_equal(oa, ha)

@@ -51,6 +51,10 @@ _SIGS = {
     "vieo_hamming_knn2_batch_device": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
     "vieo_stereo_match_rectified": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_f, c_p, c_p]),
     "vieo_stereo_match_rectified_batch_device": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p]),
+    "vieo_sbp_project_last_frame": (c_i, [c_p, c_i, c_p, c_p]),
+    "vieo_search_by_projection": (c_i, [c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_f, c_i, c_p, c_p]),
+    "vieo_search_by_projection_batch_device": (c_i, [c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_i, c_p, c_p, c_p]),
+    "vieo_sbp_project_last_frame_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "vieo_pose_optimization": (c_i, [c_p, c_p, c_p, c_p]),
     "vieo_pose_optimization_batch_device": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p]),
     "vieo_orb_tap_plane": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),

@@ -13,3 +13,16 @@ POSE_RESULT_DTYPE = np.dtype([("nav", NAVSTATE_DTYPE), ("n_inliers", "<i4"), ("s
                               ("lm_iterations", "<i4"), ("reserved", "<i4")], align=True)
 assert NAVSTATE_DTYPE.itemsize == 176 and POSE_OBS_DTYPE.itemsize == 32
 assert POSE_FRAME_DTYPE.itemsize == 304 and POSE_RESULT_DTYPE.itemsize == 192
+
+PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"),
+                             ("level_min", "<i4"), ("level_max", "<i4"), ("angle", "<f4"),
+                             ("flags", "<i4"), ("desc", "u1", 32)], align=True)
+LAST_FRAME_POINT_DTYPE = np.dtype([("Xw", "<f4", 3), ("octave", "<i4"), ("angle", "<f4"),
+                                   ("flags", "<i4"), ("reserved", "<i4", 2), ("desc", "u1", 32)],
+                                  align=True)
+SBP_CAMERA_DTYPE = np.dtype([("Tcw_cur", "<f8", 12), ("Tcw_last", "<f8", 12), ("fx", "<f4"),
+                             ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("bounds", "<f4", 4),
+                             ("bf", "<f4"), ("baseline", "<f4"), ("th", "<f4"), ("th_far", "<f4"),
+                             ("mono", "<i4"), ("nlevels", "<i4"), ("scale", "<f4", 16)], align=True)
+assert PROJ_QUERY_DTYPE.itemsize == 64 and LAST_FRAME_POINT_DTYPE.itemsize == 64
+assert SBP_CAMERA_DTYPE.itemsize == 312

@@ -28,3 +28,52 @@ def compute_stereo_matches(ext_left, ext_right, kps_l, desc_l, kps_r, desc_r, ba
                                             len(kr), baseline, bf, ur.ctypes.data, dp.ctypes.data),
           "vieo_stereo_match_rectified")
     return ur, dp
+
+
+class ORBmatcher:
+    """ORBmatcher(nnratio=0.6, checkOri=True) (reference include/ORBmatcher.h:25-101), tracking-side
+    searches on flattened inputs (ba_types.PROJ_QUERY_DTYPE etc.)."""
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+    SBP_LAST_FRAME, SBP_LOCAL_MAP = 0, 1
+
+    def __init__(self, nnratio=0.6, checkOri=True):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+
+    @staticmethod
+    def project_last_frame(points, cam):
+        from .ba_types import PROJ_QUERY_DTYPE
+        pts = np.ascontiguousarray(points)
+        cam = np.ascontiguousarray(cam)
+        q = np.zeros(len(pts), PROJ_QUERY_DTYPE)
+        check(lib().vieo_sbp_project_last_frame(pts.ctypes.data, len(pts), cam.ctypes.data,
+                                                q.ctypes.data), "vieo_sbp_project_last_frame")
+        return q
+
+    def _search(self, mode, queries, keys, uright, desc, taken, bounds):
+        import ctypes
+        queries = np.ascontiguousarray(queries)
+        keys = np.ascontiguousarray(keys)
+        uright = np.ascontiguousarray(uright, np.float32)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+        b = np.ascontiguousarray(bounds, np.float32)
+        assign = np.zeros(max(len(keys), 1), np.int32)
+        n = ctypes.c_int32()
+        check(lib().vieo_search_by_projection(mode, queries.ctypes.data, len(queries),
+                                              keys.ctypes.data, uright.ctypes.data, desc.ctypes.data,
+                                              None if tk is None else tk.ctypes.data, len(keys),
+                                              b.ctypes.data, self.mfNNratio,
+                                              int(self.mbCheckOrientation), assign.ctypes.data,
+                                              ctypes.byref(n)), "vieo_search_by_projection")
+        return n.value, assign[:len(keys)]
+
+    def SearchByProjectionLastFrame(self, queries, keys, uright, desc, taken, bounds):
+        """SearchByProjection(Frame&, const Frame&, th, bMono, th_far) (ORBmatcher.cc:1303-1467)
+        after project_last_frame(); returns (nmatches, assign[n_keys])."""
+        return self._search(self.SBP_LAST_FRAME, queries, keys, uright, desc, taken, bounds)
+
+    def SearchByProjectionLocalMap(self, queries, keys, uright, desc, taken, bounds):
+        """SearchByProjection(Frame&, vector<MapPoint*>&, th, th_far) (ORBmatcher.cc:230-335) on
+        queries prepared by Frame::isInFrustum."""
+        return self._search(self.SBP_LOCAL_MAP, queries, keys, uright, desc, taken, bounds)
