@@ -274,6 +274,50 @@ int vieo_pose_optimization_batch_device(const vieo_pose_frame* d_frames, int n_f
                                         const vieo_pose_obs* d_obs, uint8_t* d_outlier,
                                         vieo_pose_result* d_results, void* stream);
 
+/* ---- visual-inertial variant --------------------------------------------------------------
+ * template<class KeyFrame> int Optimizer::PoseOptimization(Frame*, KeyFrame* pLastKF,
+ *     const cv::Mat& gw, bool bComputeMarg = false, bool bNoMPs = false)
+ * (include/Optimizer.h:208-816), instantiated for Frame and KeyFrame by Tracking.cc:321,333,475,479.
+ * Vertices: PVR_j (9) + Bias_j (6) free; PVR_i + Bias_i of the last (key)frame fixed unless it
+ * carries a prior (mbPrior).  Edges: EdgeNavStatePVR (IMU pre-integration, g2otypes.h:703-884),
+ * EdgeNavStateBias (g2otypes.cpp:14-34), EdgeNavStatePriorPVRBias (g2otypes.cpp:84-124),
+ * EdgeReprojectPVR / PVRStereo per correspondence.  No encoder edge. */
+typedef struct vieo_imu_preint { /* IMUPreIntegratorBase (src/Odom/OdomPreIntegrator.h:108-147) */
+  double dt;                     /* mdeltatij; 0 => no IMU edge */
+  double Rij[9];                 /* mRij, row-major */
+  double vij[3], pij[3];         /* mvij, mpij */
+  double JgR[9], Jgv[9], Jav[9], Jgp[9], Jap[9]; /* bias Jacobians, row-major */
+  double Sigma[81];              /* mSigmaij, order (p, v, Phi), row-major */
+} vieo_imu_preint;
+
+typedef struct vieo_vio_frame {
+  vieo_pose_frame base;     /* current frame: nav = nsj, extrinsics, camera, observations */
+  vieo_navstate nav_last;   /* pLastKF->GetNavState() */
+  vieo_navstate nav_prior;  /* pLastKF->mNavStatePrior   (used when last_has_prior) */
+  double H_prior[225];      /* pLastKF->mMargCovInv, 15x15 row-major, order (p, v, Phi, bg, ba) */
+  vieo_imu_preint imu;      /* pFrame->GetIMUPreInt() */
+  double gw[3];             /* gravity in the world frame */
+  double inv_sigma_bg2, inv_sigma_ba2; /* IMUDataBase::mInvSigmabg2 / mInvSigmaba2 */
+  double dt_frames;         /* pFrame->ftimestamp_ - pLastKF->ftimestamp_ (used when imu.dt == 0) */
+  float th_depth;           /* pFrame->mThDepth: close points use the 1.5x chi2 gate */
+  int32_t last_has_prior;   /* pLastKF->mbPrior: last state is optimised too (30-dim system) */
+  int32_t compute_marg;     /* bComputeMarg */
+  int32_t no_mps;           /* bNoMPs */
+} vieo_vio_frame;
+
+typedef struct vieo_vio_result {
+  vieo_pose_result base;   /* nav: p, q, v, dbg, dba updated */
+  double H_marg[225];      /* pFrame->mMargCovInv when compute_marg (nav is then mNavStatePrior) */
+  int32_t has_marg;        /* pFrame->mbPrior set */
+  int32_t reserved;
+} vieo_vio_result;
+
+int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_obs* h_obs,
+                               uint8_t* h_outlier, vieo_vio_result* h_result);
+int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int n_frames,
+                                            const vieo_pose_obs* d_obs, uint8_t* d_outlier,
+                                            vieo_vio_result* d_results, void* stream);
+
 /* ---- test taps (parity tests only; not part of the drop-in surface) ---- */
 /* which: 1 = blurred level.  FAST candidates: int32 triplets (x, y, response) in
  * vToDistributeKeys order; level keys: vieo_keypoint in DistributeOctTree output order. */

@@ -49,6 +49,9 @@ class Oracle:
         L.vo_sbp_project_last_frame.argtypes = [P, I, P, P]
         L.vo_search_by_projection.argtypes = [I, P, I, P, P, P, P, I, P, F, I, P]
         L.vo_pose_optimization.argtypes = [P, P, P, P]
+        L.vo_pose_optimization_vio.argtypes = [P, P, P, P]
+        L.vo_imu_edge_eval.argtypes = [P, P, P, P, P, P, P]
+        L.vo_navstate_inc.argtypes = [P, P, P]
         L.vo_pose_edge_eval.argtypes = [P, P, P, P, P]
         L.vo_so3_exp.argtypes = [P, P]
         L.vo_so3_log.argtypes = [P, P]
@@ -89,6 +92,33 @@ class Oracle:
         self.L.vo_pose_optimization(frame.ctypes.data, obs.ctypes.data, outl.ctypes.data,
                                     res.ctypes.data)
         return res[0], outl
+
+    def pose_optimization_vio(self, frame, obs):
+        from vieo_slam_amd.ba_types import VIO_RESULT_DTYPE
+        frame = np.ascontiguousarray(frame)
+        obs = np.ascontiguousarray(obs)
+        outl = np.zeros(max(len(obs), 1), np.uint8)
+        res = np.zeros(1, VIO_RESULT_DTYPE)
+        self.L.vo_pose_optimization_vio(frame.ctypes.data, obs.ctypes.data, outl.ctypes.data,
+                                        res.ctypes.data)
+        return res[0], outl[:len(obs)]
+
+    def imu_edge_eval(self, frame, nsi, nsj, want_jac=True):
+        err = np.zeros(9)
+        Ji, Jj, JB = np.zeros((9, 9)), np.zeros((9, 9)), np.zeros((9, 6))
+        nsi, nsj = np.ascontiguousarray(nsi), np.ascontiguousarray(nsj)
+        self.L.vo_imu_edge_eval(np.ascontiguousarray(frame).ctypes.data, nsi.ctypes.data,
+                                nsj.ctypes.data, err.ctypes.data,
+                                Ji.ctypes.data if want_jac else None, Jj.ctypes.data, JB.ctypes.data)
+        return err, Ji, Jj, JB
+
+    def navstate_inc(self, ns, dpvr=None, dbias=None):
+        out = np.ascontiguousarray(ns).copy()
+        a = None if dpvr is None else np.ascontiguousarray(dpvr, np.float64)
+        b = None if dbias is None else np.ascontiguousarray(dbias, np.float64)
+        self.L.vo_navstate_inc(out.ctypes.data, None if a is None else a.ctypes.data,
+                               None if b is None else b.ctypes.data)
+        return out
 
     def pose_edge_eval(self, frame, ob, delta=None, want_jac=True):
         err = np.zeros(3)

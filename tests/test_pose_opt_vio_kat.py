@@ -1,0 +1,90 @@
+"""CPU known-answer tests pinning the visual-inertial pose-optimisation oracle."""
+import numpy as np
+
+from vieo_slam_amd import synth_ba
+from vieo_slam_amd.ba_types import VIO_FRAME_DTYPE, VIO_RESULT_DTYPE
+
+
+def _nav_arr(rec):
+    return np.array([rec])
+
+
+def test_imu_residual_zero_for_clean_measurement_and_jacobians(oracle):
+    F, obs, gt = synth_ba.make_vio_problem(11)
+    nsi = _nav_arr(F[0]["nav_last"])
+    nsj = _nav_arr(F[0]["base"]["nav"])
+    nsj[0]["p"], nsj[0]["q"], nsj[0]["v"] = gt["p"], gt["q"], gt["v"]
+    err, Ji, Jj, JB = oracle.imu_edge_eval(F, nsi, nsj)
+    assert np.abs(err).max() < 5e-3  # only sensor noise left at ground truth
+    # numerical Jacobians through the reference's own retractions (IncSmall / IncSmallBias)
+    h = 1e-6
+    for k in range(9):
+        d = np.zeros(9)
+        d[k] = h
+        ep, *_ = oracle.imu_edge_eval(F, oracle.navstate_inc(nsi, d), nsj, want_jac=False)
+        em, *_ = oracle.imu_edge_eval(F, oracle.navstate_inc(nsi, -d), nsj, want_jac=False)
+        assert np.allclose((ep - em) / (2 * h), Ji[:, k], atol=2e-5), ("Ji", k)
+        ep, *_ = oracle.imu_edge_eval(F, nsi, oracle.navstate_inc(nsj, d), want_jac=False)
+        em, *_ = oracle.imu_edge_eval(F, nsi, oracle.navstate_inc(nsj, -d), want_jac=False)
+        assert np.allclose((ep - em) / (2 * h), Jj[:, k], atol=2e-5), ("Jj", k)
+    for k in range(6):
+        d = np.zeros(6)
+        d[k] = h
+        ep, *_ = oracle.imu_edge_eval(F, oracle.navstate_inc(nsi, None, d), nsj, want_jac=False)
+        em, *_ = oracle.imu_edge_eval(F, oracle.navstate_inc(nsi, None, -d), nsj, want_jac=False)
+        assert np.allclose((ep - em) / (2 * h), JB[:, k], atol=2e-5), ("JB", k)
+
+
+def test_vio_fixed_last_converges_and_marginal_is_spd(oracle):
+    for seed in range(3):
+        F, obs, gt = synth_ba.make_vio_problem(seed, compute_marg=True)
+        res, outl = oracle.pose_optimization_vio(F, obs)
+        e1 = synth_ba.pose_error(res["base"]["nav"], gt)
+        assert e1[0] < 2e-3 and e1[1] < 2e-3
+        assert np.linalg.norm(res["base"]["nav"]["v"] - gt["v"]) < 0.02
+        assert res["has_marg"] == 1
+        H = res["H_marg"].reshape(15, 15)
+        assert np.allclose(H, H.T, rtol=1e-9, atol=1e-6 * np.abs(H).max())
+        assert np.linalg.eigvalsh((H + H.T) / 2).min() > 0
+        assert np.all(H[:9, 9:] == 0)  # fixed last: PVR and bias blocks are independent
+        assert outl[gt["is_outlier"]].mean() > 0.85
+
+
+def test_vio_chained_prior_free_last_state(oracle):
+    # frame k-1 -> k with a fixed last state produces the prior used by frame k -> k+1
+    F0, obs0, gt0 = synth_ba.make_vio_problem(40, compute_marg=True)
+    r0, _ = oracle.pose_optimization_vio(F0, obs0)
+    F1, obs1, gt1 = synth_ba.make_vio_problem(41, compute_marg=True)
+    # graft the prior onto problem 41's last state (small perturbation of its true last state)
+    nav_last = F1[0]["nav_last"].copy()
+    nav_prior = nav_last.copy()
+    nav_last["p"] += 0.005
+    nav_last["v"] += 0.02
+    F1b, _, _ = synth_ba.make_vio_problem(41, compute_marg=True,
+                                          prior=(nav_prior, r0["H_marg"].reshape(15, 15), nav_last))
+    r1, outl1 = oracle.pose_optimization_vio(F1b, obs1)
+    e1 = synth_ba.pose_error(r1["base"]["nav"], gt1)
+    assert e1[0] < 5e-3 and e1[1] < 2e-3
+    H = r1["H_marg"].reshape(15, 15)
+    assert np.isfinite(H).all() and np.abs(H[:9, 9:]).max() > 0  # Schur complement couples blocks
+    assert np.linalg.eigvalsh((H + H.T) / 2).min() > -1e-6 * np.abs(H).max()
+
+
+def test_vio_edge_cases(oracle):
+    F, obs, _ = synth_ba.make_vio_problem(50, n_obs=2)
+    r, _ = oracle.pose_optimization_vio(F, obs)
+    assert r["base"]["n_inliers"] == 0 and r["base"]["status"] == 1
+    # no IMU measurement: behaves like vision-only (estimate reset every round)
+    F, obs, gt = synth_ba.make_vio_problem(51)
+    F[0]["imu"]["dt"] = 0
+    r, _ = oracle.pose_optimization_vio(F, obs)
+    e = synth_ba.pose_error(r["base"]["nav"], gt)
+    assert e[0] < 1e-2 and e[1] < 3e-3
+    # few inliers -> rescue pass (chi2 18 / 24)
+    F, obs, gt = synth_ba.make_vio_problem(52, n_obs=40, outlier_frac=0.5)
+    r, outl = oracle.pose_optimization_vio(F, obs)
+    assert r["base"]["n_inliers"] <= 40
+
+
+def test_vio_struct_sizes():
+    assert VIO_FRAME_DTYPE.itemsize == 3656 and VIO_RESULT_DTYPE.itemsize == 2000

@@ -26,3 +26,15 @@ SBP_CAMERA_DTYPE = np.dtype([("Tcw_cur", "<f8", 12), ("Tcw_last", "<f8", 12), ("
                              ("mono", "<i4"), ("nlevels", "<i4"), ("scale", "<f4", 16)], align=True)
 assert PROJ_QUERY_DTYPE.itemsize == 64 and LAST_FRAME_POINT_DTYPE.itemsize == 64
 assert SBP_CAMERA_DTYPE.itemsize == 312
+
+IMU_PREINT_DTYPE = np.dtype([("dt", "<f8"), ("Rij", "<f8", 9), ("vij", "<f8", 3), ("pij", "<f8", 3),
+                             ("JgR", "<f8", 9), ("Jgv", "<f8", 9), ("Jav", "<f8", 9),
+                             ("Jgp", "<f8", 9), ("Jap", "<f8", 9), ("Sigma", "<f8", 81)], align=True)
+VIO_FRAME_DTYPE = np.dtype([("base", POSE_FRAME_DTYPE), ("nav_last", NAVSTATE_DTYPE),
+                            ("nav_prior", NAVSTATE_DTYPE), ("H_prior", "<f8", 225),
+                            ("imu", IMU_PREINT_DTYPE), ("gw", "<f8", 3), ("inv_sigma_bg2", "<f8"),
+                            ("inv_sigma_ba2", "<f8"), ("dt_frames", "<f8"), ("th_depth", "<f4"),
+                            ("last_has_prior", "<i4"), ("compute_marg", "<i4"), ("no_mps", "<i4")],
+                           align=True)
+VIO_RESULT_DTYPE = np.dtype([("base", POSE_RESULT_DTYPE), ("H_marg", "<f8", 225),
+                             ("has_marg", "<i4"), ("reserved", "<i4")], align=True)

@@ -89,3 +89,169 @@ def make_pose_problem(seed, n_obs=300, outlier_frac=0.10, stereo_frac=0.70, nois
     f["fx"], f["fy"], f["cx"], f["cy"], f["bf"] = FX, FY, CX, CY, BF
     f["obs_begin"], f["n_obs"] = 0, n_obs
     return frame, obs, {"p": p_gt, "q": q_gt, "is_outlier": is_out}
+
+
+# ----------------------------------------------------------------------------------------------
+# Visual-inertial problems.  The IMU measurement is produced by a numpy restatement of
+# IMUPreIntegratorBase::update (reference src/Odom/OdomPreIntegrator.h:432-506, mid-point samples as
+# in PreIntegration :403-424) so that Delta R/v/p, the bias Jacobians and Sigma_ij are consistent.
+IMU_SIGMA = (1.6968e-4, 2.0e-3, 1.9393e-5, 3.0e-3)  # EuRoC_VIO.yaml:13-17 (gyro, acc, bg walk, ba walk)
+IMU_FREQ = 200.0
+GRAVITY = np.array([0.0, 0.0, -9.81])
+
+
+def so3_exp(w):
+    return quat_to_R(quat_from_rotvec(np.asarray(w, float)))
+
+
+def so3_hat(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def so3_Jr(w):
+    th = np.linalg.norm(w)
+    O = so3_hat(w)
+    if th < 1e-5:
+        return np.eye(3) - 0.5 * O + O @ O / 6.0
+    K = so3_hat(w / th)
+    return np.eye(3) - (1 - np.cos(th)) / th * K + (1 - np.sin(th) / th) * K @ K
+
+
+class Preintegrator:
+    def __init__(self):
+        self.R = np.eye(3)
+        self.v = np.zeros(3)
+        self.p = np.zeros(3)
+        self.Sigma = np.zeros((9, 9))  # order p, v, Phi (mSigmaij)
+        self.JgR = np.zeros((3, 3))
+        self.Jgv = np.zeros((3, 3))
+        self.Jav = np.zeros((3, 3))
+        self.Jgp = np.zeros((3, 3))
+        self.Jap = np.zeros((3, 3))
+        self.dt = 0.0
+        # dt_cov_noise_fix = 1: Sigma_g/a are multiplied by freq once (OdomData.h:48-52)
+        self.Sg = np.eye(3) * IMU_SIGMA[0] ** 2 * IMU_FREQ
+        self.Sa = np.eye(3) * IMU_SIGMA[1] ** 2 * IMU_FREQ
+
+    def update(self, omega, acc, dt):
+        dt2 = dt * dt / 2
+        dR = so3_exp(omega * dt)
+        Jr = so3_Jr(omega * dt)
+        sk = so3_hat(acc)
+        A = np.eye(9)
+        A[6:9, 6:9] = dR.T
+        A[3:6, 6:9] = -self.R @ sk * dt
+        A[0:3, 6:9] = -self.R @ sk * dt2
+        A[0:3, 3:6] = np.eye(3) * dt
+        Bg = np.zeros((9, 3))
+        Bg[6:9] = Jr * dt
+        Ba = np.zeros((9, 3))
+        Ba[3:6] = self.R * dt
+        Ba[0:3] = self.R * dt2
+        self.Sigma = A @ self.Sigma @ A.T + Bg @ self.Sg @ Bg.T + Ba @ self.Sa @ Ba.T
+        self.Jap += self.Jav * dt - self.R * dt2
+        self.Jgp += self.Jgv * dt - self.R @ sk @ self.JgR * dt2
+        self.Jav += -self.R * dt
+        self.Jgv += -self.R @ sk @ self.JgR * dt
+        self.JgR = dR.T @ self.JgR - Jr * dt
+        self.p = self.p + self.v * dt + self.R @ (acc * dt2)
+        self.v = self.v + self.R @ (acc * dt)
+        R = self.R @ dR
+        u, _, vt = np.linalg.svd(R)
+        self.R = u @ vt
+        self.dt += dt
+
+
+def _nav(rec, p, q, v, bg, ba):
+    rec["p"], rec["q"], rec["v"], rec["bg"], rec["ba"] = p, q, v, bg, ba
+    rec["dbg"] = 0
+    rec["dba"] = 0
+
+
+def make_vio_problem(seed, n_obs=300, dt_frame=0.05, compute_marg=False, prior=None, **kw):
+    """returns (vio_frame[1] VIO_FRAME_DTYPE, obs, truth).  prior = None -> last state fixed;
+    prior = (nav_prior record, H_prior 15x15, nav_last record) -> last state optimised too."""
+    from .ba_types import VIO_FRAME_DTYPE
+    frame, obs, gt = make_pose_problem(seed, n_obs=n_obs, **kw)
+    rng = np.random.default_rng(seed + 909)
+    F = np.zeros(1, VIO_FRAME_DTYPE)
+    f = F[0]
+    f["base"] = frame[0]
+    # ground-truth state j comes from make_pose_problem; integrate BACKWARDS to get state i
+    Rj, pj = quat_to_R(gt["q"]), gt["p"]
+    omega = rng.normal(0, 0.4, 3)             # body angular rate (rad/s)
+    a_w = rng.normal(0, 1.0, 3)               # world acceleration (m/s^2)
+    vi = rng.normal(0, 0.8, 3)
+    bg, ba = rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)
+    n_imu = int(round(dt_frame * IMU_FREQ))
+    h = dt_frame / n_imu
+    # noise-free samples along a constant-omega / constant-a_w motion starting at R_i = I frame
+    ts = np.arange(n_imu + 1) * h
+    Rrel = [so3_exp(omega * t) for t in ts]   # R_i^T R(t)
+    # choose R_i so that R_i * DeltaR_true = R_j after the discrete integration
+    clean = Preintegrator()
+    for k in range(n_imu):
+        w_mid = omega
+        a_k = Rrel[k].T @ np.zeros(3)  # placeholder, filled below once R_i is known
+    # two-pass: first the rotation only (independent of acceleration), to get R_i
+    rot = Preintegrator()
+    for k in range(n_imu):
+        rot.update(omega, np.zeros(3), h)
+    Ri = Rj @ rot.R.T
+    acc_true = [(Ri @ Rrel[k]).T @ (a_w - GRAVITY) for k in range(n_imu + 1)]
+    clean = Preintegrator()
+    for k in range(n_imu):
+        clean.update(omega, (acc_true[k] + acc_true[k + 1]) / 2, h)
+    # state i such that the clean measurement has zero residual at (i, j)
+    vj = vi + GRAVITY * dt_frame + Ri @ clean.v
+    pi = pj - (vi * dt_frame + GRAVITY * dt_frame ** 2 / 2 + Ri @ clean.p)
+    # noisy measurement (what the optimiser sees): samples carry bias + white noise
+    sg = IMU_SIGMA[0] * np.sqrt(IMU_FREQ)
+    sa = IMU_SIGMA[1] * np.sqrt(IMU_FREQ)
+    gyr = [omega + bg + rng.normal(0, sg, 3) for _ in range(n_imu + 1)]
+    acc = [acc_true[k] + ba + rng.normal(0, sa, 3) for k in range(n_imu + 1)]
+    meas = Preintegrator()
+    for k in range(n_imu):
+        meas.update((gyr[k] + gyr[k + 1]) / 2 - bg, (acc[k] + acc[k + 1]) / 2 - ba, h)
+    im = f["imu"]
+    im["dt"] = meas.dt
+    im["Rij"], im["vij"], im["pij"] = meas.R.reshape(-1), meas.v, meas.p
+    for name in ("JgR", "Jgv", "Jav", "Jgp", "Jap"):
+        im[name] = getattr(meas, name).reshape(-1)
+    im["Sigma"] = meas.Sigma.reshape(-1)
+    qi = _R_to_quat(Ri)
+    # current frame: keep the perturbed p/q from make_pose_problem, add v and biases
+    f["base"]["nav"]["v"] = vj + rng.normal(0, 0.05, 3)
+    f["base"]["nav"]["bg"], f["base"]["nav"]["ba"] = bg, ba
+    _nav(f["nav_last"], pi, qi, vi, bg, ba)
+    f["gw"] = GRAVITY
+    f["inv_sigma_bg2"] = 1.0 / IMU_SIGMA[2] ** 2
+    f["inv_sigma_ba2"] = 1.0 / IMU_SIGMA[3] ** 2
+    f["dt_frames"] = dt_frame
+    f["th_depth"] = 35.0 * BF / FX * 0 + 35.0
+    f["compute_marg"] = int(compute_marg)
+    if prior is not None:
+        nav_prior, H_prior, nav_last = prior
+        f["nav_prior"] = nav_prior
+        f["H_prior"] = np.asarray(H_prior).reshape(-1)
+        f["nav_last"] = nav_last
+        f["last_has_prior"] = 1
+    gt = dict(gt, v=vj, p_i=pi, q_i=qi, v_i=vi, bg=bg, ba=ba)
+    return F, obs, gt
+
+
+def _R_to_quat(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    return q / np.linalg.norm(q)
