@@ -1,0 +1,94 @@
+"""GPU parity: visual-inertial PoseOptimization (15- and 30-dim systems, marginal prior) vs the
+CPU oracle; 1e-4 on SE(3) (BASELINE.json), identical inlier decisions."""
+import numpy as np
+import pytest
+
+from vieo_slam_amd import synth_ba
+from vieo_slam_amd._lib import DeviceBuffer, check, lib
+from vieo_slam_amd.ba_types import VIO_FRAME_DTYPE, VIO_RESULT_DTYPE
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _cmp(oracle, F, obs, marg_rtol=1e-5):
+    from vieo_slam_amd.optimizer import Optimizer
+    o, oo = oracle.pose_optimization_vio(F, obs)
+    h, ho = Optimizer.PoseOptimizationVIO(F, obs)
+    dt, dr = synth_ba.pose_error(o["base"]["nav"], h["base"]["nav"])
+    assert dt < TOL and dr < TOL, (dt, dr)
+    assert np.linalg.norm(o["base"]["nav"]["v"] - h["base"]["nav"]["v"]) < 1e-4
+    assert np.linalg.norm(o["base"]["nav"]["dbg"] - h["base"]["nav"]["dbg"]) < 1e-6
+    assert np.linalg.norm(o["base"]["nav"]["dba"] - h["base"]["nav"]["dba"]) < 1e-5
+    assert o["base"]["status"] == h["base"]["status"]
+    assert o["base"]["n_inliers"] == h["base"]["n_inliers"]
+    assert np.array_equal(oo, ho)
+    assert o["has_marg"] == h["has_marg"]
+    if o["has_marg"]:
+        Ho, Hh = o["H_marg"].reshape(15, 15), h["H_marg"].reshape(15, 15)
+        assert np.allclose(Ho, Hh, rtol=marg_rtol, atol=marg_rtol * np.abs(Ho).max())
+    return o, h
+
+
+@pytest.mark.parametrize("seed,n,marg", [(0, 300, False), (1, 300, True), (2, 80, True),
+                                         (3, 900, True), (4, 25, False)])
+def test_vio_fixed_last_parity(oracle, seed, n, marg):
+    F, obs, gt = synth_ba.make_vio_problem(seed, n_obs=n, compute_marg=marg)
+    o, h = _cmp(oracle, F, obs)
+    assert abs(int(o["base"]["lm_iterations"]) - int(h["base"]["lm_iterations"])) <= 2
+
+
+@pytest.mark.parametrize("seed", [40, 42, 44])
+def test_vio_free_last_with_prior_parity(oracle, seed):
+    F0, obs0, _ = synth_ba.make_vio_problem(seed, compute_marg=True)
+    r0, _ = oracle.pose_optimization_vio(F0, obs0)
+    F1, obs1, _ = synth_ba.make_vio_problem(seed + 1, compute_marg=True)
+    nav_last = F1[0]["nav_last"].copy()
+    nav_prior = nav_last.copy()
+    nav_last["p"] += 0.004
+    nav_last["v"] += 0.015
+    F1b, _, _ = synth_ba.make_vio_problem(seed + 1, compute_marg=True,
+                                          prior=(nav_prior, r0["H_marg"].reshape(15, 15), nav_last))
+    _cmp(oracle, F1b, obs1, marg_rtol=1e-4)
+
+
+def test_vio_edge_cases_parity(oracle):
+    from vieo_slam_amd.optimizer import Optimizer
+    F, obs, _ = synth_ba.make_vio_problem(50, n_obs=2)
+    h, _ = Optimizer.PoseOptimizationVIO(F, obs)
+    assert h["base"]["n_inliers"] == 0 and h["base"]["status"] == 1
+    F, obs, _ = synth_ba.make_vio_problem(51)  # no IMU measurement -> estimate reset per round
+    F[0]["imu"]["dt"] = 0
+    _cmp(oracle, F, obs)
+    F, obs, _ = synth_ba.make_vio_problem(52, n_obs=40, outlier_frac=0.5, compute_marg=True)
+    _cmp(oracle, F, obs)  # rescue pass
+    F, obs, _ = synth_ba.make_vio_problem(53, n_obs=6, outlier_frac=0.0)  # < 10 edges: one round
+    _cmp(oracle, F, obs)
+
+
+def test_vio_batch_device(oracle):
+    B = 12
+    frames = np.zeros(B, VIO_FRAME_DTYPE)
+    all_obs, begin = [], 0
+    for i in range(B):
+        F, obs, _ = synth_ba.make_vio_problem(200 + i, n_obs=120 + 41 * i, compute_marg=(i % 2 == 0))
+        frames[i] = F[0]
+        frames[i]["base"]["obs_begin"] = begin
+        begin += len(obs)
+        all_obs.append(obs)
+    obs = np.concatenate(all_obs)
+    dF, dO = DeviceBuffer(frames.nbytes), DeviceBuffer(obs.nbytes)
+    dU, dR = DeviceBuffer(len(obs)), DeviceBuffer(B * VIO_RESULT_DTYPE.itemsize)
+    dF.upload(frames)
+    dO.upload(obs)
+    check(lib().vieo_pose_optimization_vio_batch_device(dF.ptr, B, dO.ptr, dU.ptr, dR.ptr, None))
+    check(lib().vieo_device_synchronize())
+    res = dR.download(VIO_RESULT_DTYPE, (B,))
+    outl = dU.download(np.uint8, (len(obs),))
+    for i in range(B):
+        b, n = frames[i]["base"]["obs_begin"], frames[i]["base"]["n_obs"]
+        o, oo = oracle.pose_optimization_vio(frames[i:i + 1], obs)
+        dt, dr = synth_ba.pose_error(o["base"]["nav"], res[i]["base"]["nav"])
+        assert dt < TOL and dr < TOL
+        assert res[i]["base"]["n_inliers"] == o["base"]["n_inliers"]
+        assert np.array_equal(oo[b:b + n], outl[b:b + n])

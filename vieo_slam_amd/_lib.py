@@ -57,6 +57,8 @@ _SIGS = {
     "vieo_sbp_project_last_frame_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "vieo_pose_optimization": (c_i, [c_p, c_p, c_p, c_p]),
     "vieo_pose_optimization_batch_device": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p]),
+    "vieo_pose_optimization_vio": (c_i, [c_p, c_p, c_p, c_p]),
+    "vieo_pose_optimization_vio_batch_device": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p]),
     "vieo_orb_tap_plane": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_candidates": (c_i, [c_p, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_level_keys": (c_i, [c_p, c_i, c_i, c_p, c_i]),

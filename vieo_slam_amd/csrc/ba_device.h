@@ -1,0 +1,172 @@
+// ba_device.h -- device helpers shared by the bundle-adjustment kernels (pose_opt.hip,
+// pose_opt_vio.hip): NavState retractions, the reprojection edge (EdgeReproject<DE,DV,2>,
+// reference src/Odom/g2otypes.h:321-547 with PinholeCamera::Project's float rounding,
+// common/camera_models/camera_pinhole.h:70-106), Huber kernel and block reductions.
+#pragma once
+#include <cfloat>
+
+#include "common.h"
+
+namespace vieo {
+
+struct Est {
+  double p[3];
+  double qw, qx, qy, qz;
+};
+
+struct CamD {
+  double fx, fy, cx, cy, bf;  // float parameters widened once
+  double Rcb[9], tcb[3];
+};
+
+__device__ __forceinline__ void quat_to_R(const Est& s, double* R) {
+  const double tx = 2 * s.qx, ty = 2 * s.qy, tz = 2 * s.qz;
+  const double twx = tx * s.qw, twy = ty * s.qw, twz = tz * s.qw;
+  const double txx = tx * s.qx, txy = ty * s.qx, txz = tz * s.qx;
+  const double tyy = ty * s.qy, tyz = tz * s.qy, tzz = tz * s.qz;
+  R[0] = 1 - (tyy + tzz), R[1] = txy - twz, R[2] = txz + twy;
+  R[3] = txy + twz, R[4] = 1 - (txx + tzz), R[5] = tyz - twx;
+  R[6] = txz - twy, R[7] = tyz + twx, R[8] = 1 - (txx + tyy);
+}
+
+// NavState::IncSmall (NavState.h:47-58): p += Rwb*dp ; Rwb *= Exp(dphi), SO3ex::exp
+// (so3_extra.h:121-142) with its 1e-5 small-angle branch.
+__device__ __forceinline__ void inc_small_pr(Est& s, const double* d) {
+  double R[9];
+  quat_to_R(s, R);
+  for (int i = 0; i < 3; i++) s.p[i] += R[i * 3] * d[0] + R[i * 3 + 1] * d[1] + R[i * 3 + 2] * d[2];
+  const double theta = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+  double imag, real;
+  if (theta < 1e-5) {
+    const double t2 = theta * theta;
+    imag = 0.5 - t2 / 48.;
+    real = 1.0 - t2 / 8.;
+  } else {
+    const double half = 0.5 * theta;
+    imag = sin(half) / theta;
+    real = cos(half);
+  }
+  double ew = real, ex = imag * d[3], ey = imag * d[4], ez = imag * d[5];
+  double n = sqrt(ew * ew + ex * ex + ey * ey + ez * ez);
+  ew /= n, ex /= n, ey /= n, ez /= n;
+  const double w = s.qw * ew - s.qx * ex - s.qy * ey - s.qz * ez;
+  const double x = s.qw * ex + s.qx * ew + s.qy * ez - s.qz * ey;
+  const double y = s.qw * ey + s.qy * ew + s.qz * ex - s.qx * ez;
+  const double z = s.qw * ez + s.qz * ew + s.qx * ey - s.qy * ex;
+  n = sqrt(w * w + x * x + y * y + z * z);
+  s.qw = w / n, s.qx = x / n, s.qy = y / n, s.qz = z / n;
+}
+
+struct PoseXf {  // per-estimate transforms shared by all edges
+  double Rcw[9], tcw[3], Rwb[9];
+};
+
+__device__ __forceinline__ void make_xf(const CamD& c, const Est& s, PoseXf& X) {
+  quat_to_R(s, X.Rwb);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)  // Rcw = Rcb * Rwb^T
+      X.Rcw[i * 3 + j] = c.Rcb[i * 3] * X.Rwb[j * 3] + c.Rcb[i * 3 + 1] * X.Rwb[j * 3 + 1] +
+                         c.Rcb[i * 3 + 2] * X.Rwb[j * 3 + 2];
+  for (int i = 0; i < 3; i++)
+    X.tcw[i] = -(X.Rcw[i * 3] * s.p[0] + X.Rcw[i * 3 + 1] * s.p[1] + X.Rcw[i * 3 + 2] * s.p[2]) + c.tcb[i];
+}
+
+// EdgeReproject::computeError (g2otypes.h:400-406) with PinholeCamera::Project's float rounding
+// (camera_pinhole.h:70-84).  Returns chi2 = e . (info * e).
+__device__ __forceinline__ double edge_error(const CamD& c, const PoseXf& X, const vieo_pose_obs& o,
+                                             double* err, double* Pc) {
+  const double Xw0 = o.Xw[0], Xw1 = o.Xw[1], Xw2 = o.Xw[2];
+  for (int i = 0; i < 3; i++)
+    Pc[i] = X.Rcw[i * 3] * Xw0 + X.Rcw[i * 3 + 1] * Xw1 + X.Rcw[i * 3 + 2] * Xw2 + X.tcw[i];
+  const double invz = 1. / Pc[2];
+  const double u = (double)(float)(c.fx * Pc[0] * invz + c.cx);
+  const double v = (double)(float)(c.fy * Pc[1] * invz + c.cy);
+  err[0] = (double)o.u - u;
+  err[1] = (double)o.v - v;
+  const double info = (double)o.inv_sigma2;
+  double chi2 = err[0] * (info * err[0]) + err[1] * (info * err[1]);
+  if (o.ur >= 0) {
+    err[2] = (double)o.ur - (u - c.bf / Pc[2]);
+    chi2 += err[2] * (info * err[2]);
+  } else
+    err[2] = 0;
+  return chi2;
+}
+
+// RobustKernelHuber::robustify (robust_kernel_impl.cpp:78-91): rho[0], rho[1]
+__device__ __forceinline__ void huber(double e, double delta, double dsqr, double* r0, double* r1) {
+  if (e <= dsqr) {
+    *r0 = e, *r1 = 1.;
+  } else {
+    const double sq = sqrt(e);
+    *r0 = 2 * sq * delta - dsqr;
+    *r1 = delta / sq;
+  }
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// all threads receive the identical block-wide sums of vals[0..n)
+template <int N>
+__device__ __forceinline__ void block_sum(double* vals, double* s_red, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < N; i++) vals[i] = wave_sum_d(vals[i]);
+  __syncthreads();  // previous readers of s_red are done
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < N; i++) s_red[wave * N + i] = vals[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; i++) vals[i] = (s_red[i] + s_red[N + i]) + (s_red[2 * N + i] + s_red[3 * N + i]);
+}
+
+
+// EdgeReproject::linearizeOplus (g2otypes.h:439-498): Jacobian of the (up to 3) residual rows
+// w.r.t. (dp, dphi) of the body pose, J[r*6 + 0..2] = d/dp, J[r*6 + 3..5] = d/dphi.
+__device__ __forceinline__ void visual_jacobian(const CamD& c, const PoseXf& X, const double* p,
+                                                const vieo_pose_obs& o, const double* Pc, double* J) {
+  const double invz = 1 / Pc[2], invz2 = invz * invz;
+  double Jp[9];
+  Jp[0] = -(c.fx * invz), Jp[1] = 0, Jp[2] = -(-c.fx * Pc[0] * invz2);
+  Jp[3] = 0, Jp[4] = -(c.fy * invz), Jp[5] = -(-c.fy * Pc[1] * invz2);
+  Jp[6] = Jp[0], Jp[7] = Jp[1], Jp[8] = Jp[2] - c.bf * invz2;
+  const double dP0 = (double)o.Xw[0] - p[0], dP1 = (double)o.Xw[1] - p[1], dP2 = (double)o.Xw[2] - p[2];
+  double Pa[3];
+  for (int m = 0; m < 3; m++) Pa[m] = X.Rwb[m] * dP0 + X.Rwb[3 + m] * dP1 + X.Rwb[6 + m] * dP2;
+  double RH[9];  // Rcb * hat(Rwb^T (Xw - pwb))
+  for (int m = 0; m < 3; m++) {
+    const double a = c.Rcb[m * 3], b = c.Rcb[m * 3 + 1], d = c.Rcb[m * 3 + 2];
+    RH[m * 3 + 0] = b * Pa[2] - d * Pa[1];
+    RH[m * 3 + 1] = -a * Pa[2] + d * Pa[0];
+    RH[m * 3 + 2] = a * Pa[1] - b * Pa[0];
+  }
+  for (int r = 0; r < 3; r++)
+    for (int q = 0; q < 3; q++) {
+      J[r * 6 + q] = -(Jp[r * 3] * c.Rcb[q] + Jp[r * 3 + 1] * c.Rcb[3 + q] + Jp[r * 3 + 2] * c.Rcb[6 + q]);
+      J[r * 6 + 3 + q] = Jp[r * 3] * RH[q] + Jp[r * 3 + 1] * RH[3 + q] + Jp[r * 3 + 2] * RH[6 + q];
+    }
+}
+
+// accumulate J^T (w*info) J (21 upper entries) and J^T (-(info*err)*w) (6) of one edge
+__device__ __forceinline__ void visual_accumulate(const double* J, const double* err, double info,
+                                                  double r1, bool stereo, double* acc) {
+  const double w = r1 * info;
+  int t = 0;
+  for (int a = 0; a < 6; a++) {
+    for (int b = a; b < 6; b++, t++) {
+      double s = J[a] * w * J[b] + J[6 + a] * w * J[6 + b];
+      if (stereo) s += J[12 + a] * w * J[12 + b];
+      acc[t] += s;
+    }
+    double s = J[a] * (-(info * err[0]) * r1) + J[6 + a] * (-(info * err[1]) * r1);
+    if (stereo) s += J[12 + a] * (-(info * err[2]) * r1);
+    acc[21 + a] += s;
+  }
+}
+
+}  // namespace vieo

@@ -1,0 +1,909 @@
+// pose_opt_vio.hip -- visual-inertial motion BA on gfx950:
+//   template<class KeyFrame> int Optimizer::PoseOptimization(Frame*, KeyFrame*, gw, bComputeMarg, bNoMPs)
+//   (reference include/Optimizer.h:208-816; marginal prior FillCovInv :126-206; edges
+//   src/Odom/g2otypes.h:703-884 (EdgeNavStatePVR), g2otypes.cpp:14-34,84-124).
+//
+// One persistent workgroup per frame, as in pose_opt.hip.  The system is 15-dim (last state
+// fixed) or 30-dim (last state carries a prior and is optimised too) and lives in LDS:
+//   * visual edges: every thread evaluates its edges, wave + LDS reduction of 27 doubles;
+//   * IMU / bias / prior edges: one lane evaluates the residual + Jacobians (a few hundred
+//     flops), all threads then form J^T (rho' Omega) J entry-parallel;
+//   * (H + lambda I) x = b by a right-looking LDL^T run by one wavefront on the LDS copy;
+//   * LM control flow is evaluated redundantly by every thread from the same LDS scalars.
+// FP64 throughout; parity with oracle/pose_opt_vio.cc <= 1e-4 on SE(3).
+#include "ba_device.h"
+
+namespace vieo {
+
+struct NSd {
+  double p[3], v[3], qw, qx, qy, qz, bg[3], ba[3], dbg[3], dba[3];
+};
+
+__device__ __forceinline__ void ns_load(NSd& s, const vieo_navstate& n) {
+  for (int i = 0; i < 3; i++) {
+    s.p[i] = n.p[i], s.v[i] = n.v[i], s.bg[i] = n.bg[i], s.ba[i] = n.ba[i];
+    s.dbg[i] = n.dbg[i], s.dba[i] = n.dba[i];
+  }
+  s.qw = n.q[0], s.qx = n.q[1], s.qy = n.q[2], s.qz = n.q[3];
+}
+__device__ __forceinline__ void ns_store(const NSd& s, vieo_navstate& n) {
+  for (int i = 0; i < 3; i++) {
+    n.p[i] = s.p[i], n.v[i] = s.v[i], n.bg[i] = s.bg[i], n.ba[i] = s.ba[i];
+    n.dbg[i] = s.dbg[i], n.dba[i] = s.dba[i];
+  }
+  n.q[0] = s.qw, n.q[1] = s.qx, n.q[2] = s.qy, n.q[3] = s.qz;
+}
+
+struct Qd {
+  double w, x, y, z;
+};
+__device__ __forceinline__ Qd q_of(const NSd& s) { return Qd{s.qw, s.qx, s.qy, s.qz}; }
+__device__ __forceinline__ Qd q_norm(Qd q) {
+  const double n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  return Qd{q.w / n, q.x / n, q.y / n, q.z / n};
+}
+__device__ __forceinline__ Qd q_mul(const Qd& a, const Qd& b) {
+  return Qd{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ Qd q_conj(const Qd& q) { return Qd{q.w, -q.x, -q.y, -q.z}; }
+__device__ __forceinline__ void q_to_R(const Qd& q, double* R) {
+  Est e;
+  e.qw = q.w, e.qx = q.x, e.qy = q.y, e.qz = q.z;
+  quat_to_R(e, R);
+}
+__device__ __forceinline__ Qd R_to_q(const double* R) {  // Eigen Quaternion(Matrix3) + normalize
+  Qd q;
+  double t = R[0] + R[4] + R[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (R[7] - R[5]) * t, q.y = (R[2] - R[6]) * t, q.z = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+    double v[3];
+    v[i] = 0.5 * t;
+    t = 0.5 / t;
+    q.w = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    q.x = v[0], q.y = v[1], q.z = v[2];
+  }
+  return q_norm(q);
+}
+// SO3ex::exp / log / JacobianR / JacobianRInv (common/so3_extra.h:121-190,254-288)
+__device__ __forceinline__ Qd so3_exp_q(const double* w) {
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  double imag, real;
+  if (th < 1e-5) {
+    const double t2 = th * th;
+    imag = 0.5 - t2 / 48., real = 1.0 - t2 / 8.;
+  } else {
+    const double h = 0.5 * th;
+    imag = sin(h) / th, real = cos(h);
+  }
+  return q_norm(Qd{real, imag * w[0], imag * w[1], imag * w[2]});
+}
+__device__ __forceinline__ void so3_log_q(const Qd& q, double* out) {
+  const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z), w = q.w, sw = w * w;
+  double f;
+  if (n < 1e-5) {
+    f = 2. / w - 2. / 3 * (n * n) / (w * sw);
+  } else if (fabs(w) < 1e-5) {
+    f = (w > 0 ? M_PI : -M_PI) / n;
+    const double n2 = n * n, n4 = n2 * n2;
+    f -= 2 * w / n2 - 2. / 3 * (w * sw) / n4;
+  } else
+    f = 2 * atan(n / w) / n;
+  out[0] = f * q.x, out[1] = f * q.y, out[2] = f * q.z;
+}
+__device__ __forceinline__ void hat3(const double* w, double* O) {
+  O[0] = 0, O[1] = -w[2], O[2] = w[1], O[3] = w[2], O[4] = 0, O[5] = -w[0], O[6] = -w[1], O[7] = w[0], O[8] = 0;
+}
+__device__ __forceinline__ void mm3(const double* A, const double* B, double* C) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+  for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+__device__ __forceinline__ void mv3(const double* A, const double* v, double* r) {
+  const double a = A[0] * v[0] + A[1] * v[1] + A[2] * v[2], b = A[3] * v[0] + A[4] * v[1] + A[5] * v[2],
+               c = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+  r[0] = a, r[1] = b, r[2] = c;
+}
+__device__ __forceinline__ void mTv3(const double* A, const double* v, double* r) {
+  const double a = A[0] * v[0] + A[3] * v[1] + A[6] * v[2], b = A[1] * v[0] + A[4] * v[1] + A[7] * v[2],
+               c = A[2] * v[0] + A[5] * v[1] + A[8] * v[2];
+  r[0] = a, r[1] = b, r[2] = c;
+}
+__device__ __forceinline__ void so3_Jr_d(const double* w, double* J) {
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  double O[9], O2[9];
+  if (th < 1e-5) {
+    hat3(w, O);
+    mm3(O, O, O2);
+    for (int i = 0; i < 9; i++) J[i] = ((i % 4) == 0 ? 1.0 : 0.0) - 0.5 * O[i] + O2[i] / 6.;
+  } else {
+    const double k[3] = {w[0] / th, w[1] / th, w[2] / th};
+    hat3(k, O);
+    mm3(O, O, O2);
+    const double a = (1 - cos(th)) / th, b = 1 - sin(th) / th;
+    for (int i = 0; i < 9; i++) J[i] = ((i % 4) == 0 ? 1.0 : 0.0) - a * O[i] + b * O2[i];
+  }
+}
+__device__ __forceinline__ void so3_JrInv_d(const double* w, double* J) {
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  double O[9], O2[9];
+  hat3(w, O);
+  if (th < 1e-5) {
+    mm3(O, O, O2);
+    for (int i = 0; i < 9; i++) J[i] = ((i % 4) == 0 ? 1.0 : 0.0) + 0.5 * O[i] + (1. / 12.) * O2[i];
+  } else {
+    const double k[3] = {w[0] / th, w[1] / th, w[2] / th};
+    double K[9];
+    hat3(k, K);
+    mm3(K, K, O2);
+    const double c = 1.0 - (1.0 + cos(th)) * th / (2.0 * sin(th));
+    for (int i = 0; i < 9; i++) J[i] = ((i % 4) == 0 ? 1.0 : 0.0) + 0.5 * O[i] + c * O2[i];
+  }
+}
+
+// NavState::IncSmall(dPVR) + IncSmallBias (NavState.h:64-83)
+__device__ __forceinline__ void ns_inc(NSd& s, const double* d, const double* db) {
+  double R[9], Rd[3];
+  q_to_R(q_of(s), R);
+  mv3(R, d, Rd);
+  for (int i = 0; i < 3; i++) s.p[i] += Rd[i], s.v[i] += d[3 + i];
+  const Qd q = q_norm(q_mul(q_of(s), so3_exp_q(d + 6)));
+  s.qw = q.w, s.qx = q.x, s.qy = q.y, s.qz = q.z;
+  for (int i = 0; i < 3; i++) s.dbg[i] += db[i], s.dba[i] += db[3 + i];
+}
+
+// EdgeNavStatePVR::computeError (g2otypes.h:733-776): err = [rp, rv, rR]
+__device__ void imu_error(const vieo_imu_preint& M, const double* gw, const NSd& si, const NSd& sj,
+                          double* err) {
+  double Ri[9], t[3], r[3], Jb[3], Ja[3];
+  q_to_R(q_of(si), Ri);
+  const double dt = M.dt;
+  for (int k = 0; k < 3; k++) t[k] = sj.p[k] - si.p[k] - si.v[k] * dt - gw[k] * (dt * dt / 2);
+  mTv3(Ri, t, r);
+  mv3(M.Jgp, si.dbg, Jb);
+  mv3(M.Jap, si.dba, Ja);
+  for (int k = 0; k < 3; k++) err[k] = r[k] - (M.pij[k] + Jb[k] + Ja[k]);
+  double w[3];
+  mv3(M.JgR, si.dbg, w);
+  const Qd qa = q_norm(q_mul(R_to_q(M.Rij), so3_exp_q(w)));
+  const Qd qb = q_norm(q_mul(q_conj(q_of(si)), q_of(sj)));
+  so3_log_q(q_norm(q_mul(q_conj(qa), qb)), err + 6);
+  for (int k = 0; k < 3; k++) t[k] = sj.v[k] - si.v[k] - gw[k] * dt;
+  mTv3(Ri, t, r);
+  mv3(M.Jgv, si.dbg, Jb);
+  mv3(M.Jav, si.dba, Ja);
+  for (int k = 0; k < 3; k++) err[3 + k] = r[k] - (M.vij[k] + Jb[k] + Ja[k]);
+}
+
+__device__ __forceinline__ void set3(double* J, int ld, int r0, int c0, const double* M, double s) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) J[(r0 + i) * ld + c0 + j] = s * M[i * 3 + j];
+}
+
+// EdgeNavStatePVR::linearizeOplus (g2otypes.h:777-884).  J is 9 x 24:
+// columns 0..8 = PVR_j, 9..17 = PVR_i, 18..23 = Bias_i.
+__device__ void imu_linearize(const vieo_imu_preint& M, const double* gw, const NSd& si, const NSd& sj,
+                              const double* err, double* J) {
+  const int ld = 24, cj = 0, ci = 9, cb = 18, idR = 6, idV = 3;
+  for (int i = 0; i < 9 * 24; i++) J[i] = 0;
+  double Ri[9], RiT[9], Rj[9], t[3], r[3], Hm[9], I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tmp[9], tmp2[9];
+  q_to_R(q_of(si), Ri);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RiT[i * 3 + j] = Ri[j * 3 + i];
+  q_to_R(q_of(sj), Rj);
+  const double dt = M.dt;
+  for (int k = 0; k < 3; k++) t[k] = sj.p[k] - si.p[k] - si.v[k] * dt - gw[k] * (dt * dt / 2);
+  mv3(RiT, t, r);
+  hat3(r, Hm);
+  set3(J, ld, 0, ci + idR, Hm, 1.0);
+  set3(J, ld, 0, ci + 0, I3, -1.0);
+  set3(J, ld, 0, ci + idV, RiT, -dt);
+  set3(J, ld, 0, cb + 0, M.Jgp, -1.0);
+  set3(J, ld, 0, cb + 3, M.Jap, -1.0);
+  mm3(RiT, Rj, tmp);
+  set3(J, ld, 0, cj + 0, tmp, 1.0);
+  for (int k = 0; k < 3; k++) t[k] = sj.v[k] - si.v[k] - gw[k] * dt;
+  mv3(RiT, t, r);
+  hat3(r, Hm);
+  set3(J, ld, idV, ci + idR, Hm, 1.0);
+  set3(J, ld, idV, ci + idV, RiT, -1.0);
+  set3(J, ld, idV, cb + 0, M.Jgv, -1.0);
+  set3(J, ld, idV, cb + 3, M.Jav, -1.0);
+  set3(J, ld, idV, cj + idV, RiT, 1.0);
+  double Jrinv[9], Rji[9];
+  const double* eR = err + idR;
+  so3_JrInv_d(eR, Jrinv);
+  q_to_R(q_norm(q_mul(q_conj(q_of(sj)), q_of(si))), Rji);
+  mm3(Jrinv, Rji, tmp);
+  set3(J, ld, idR, ci + idR, tmp, -1.0);
+  const double meR[3] = {-eR[0], -eR[1], -eR[2]};
+  double E[9], w[3], Jr[9];
+  q_to_R(so3_exp_q(meR), E);
+  mv3(M.JgR, si.dbg, w);
+  so3_Jr_d(w, Jr);
+  mm3(Jrinv, E, tmp);
+  mm3(tmp, Jr, tmp2);
+  mm3(tmp2, M.JgR, tmp);
+  set3(J, ld, idR, cb + 0, tmp, -1.0);
+  set3(J, ld, idR, cj + idR, Jrinv, 1.0);
+}
+
+// EdgeNavStatePriorPVRBias (g2otypes.cpp:84-124); J is 15 x 15: cols 0..8 PVR_i, 9..14 Bias_i
+__device__ void prior_error(const NSd& pr, const NSd& si, double* err) {
+  double Rb[9], d[3];
+  q_to_R(q_of(pr), Rb);
+  for (int k = 0; k < 3; k++) d[k] = si.p[k] - pr.p[k];
+  mTv3(Rb, d, err);
+  so3_log_q(q_norm(q_mul(q_conj(q_of(pr)), q_of(si))), err + 6);
+  for (int k = 0; k < 3; k++) {
+    err[3 + k] = si.v[k] - pr.v[k];
+    err[9 + k] = si.bg[k] + si.dbg[k] - (pr.bg[k] + pr.dbg[k]);
+    err[12 + k] = si.ba[k] + si.dba[k] - (pr.ba[k] + pr.dba[k]);
+  }
+}
+__device__ void prior_linearize(const NSd& pr, const NSd& si, const double* err, double* J) {
+  for (int i = 0; i < 225; i++) J[i] = 0;
+  double Rb[9], Ri[9], RbT[9], tmp[9], I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Jrinv[9];
+  q_to_R(q_of(pr), Rb);
+  q_to_R(q_of(si), Ri);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RbT[i * 3 + j] = Rb[j * 3 + i];
+  mm3(RbT, Ri, tmp);
+  set3(J, 15, 0, 0, tmp, 1.0);
+  set3(J, 15, 3, 3, I3, 1.0);
+  so3_JrInv_d(err + 6, Jrinv);
+  set3(J, 15, 6, 6, Jrinv, 1.0);
+  set3(J, 15, 9, 9, I3, 1.0);
+  set3(J, 15, 12, 12, I3, 1.0);
+}
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Right-looking LDL^T of the n x n matrix A (LDS, row-major, overwritten) and solve A x = b,
+// executed by ONE wavefront (lane = threadIdx & 63).  Returns false on a non-positive pivot.
+__device__ bool wave_ldlt_solve(double* A, const double* b, double* x, double* col, double* D,
+                                int n, int lane) {
+  bool ok = true;
+  for (int j = 0; j < n; j++) {
+    const double d = A[j * n + j];
+    if (!(d > 0)) {
+      ok = false;
+      break;
+    }
+    for (int i = j + 1 + lane; i < n; i += 64) col[i] = A[i * n + j];
+    if (lane == 0) D[j] = d;
+    wave_sync();
+    const int m = n - j - 1;
+    for (int e = lane; e < m * m; e += 64) {
+      const int i = j + 1 + e / m, k = j + 1 + e % m;
+      A[i * n + k] -= (col[i] / d) * col[k];
+    }
+    for (int i = j + 1 + lane; i < n; i += 64) A[i * n + j] = col[i] / d;  // L(i,j)
+    wave_sync();
+  }
+  if (!ok) return false;
+  // forward: y = L^-1 b (column oriented)
+  for (int i = lane; i < n; i += 64) x[i] = b[i];
+  wave_sync();
+  for (int j = 0; j < n; j++) {
+    const double yj = x[j];
+    for (int i = j + 1 + lane; i < n; i += 64) x[i] -= A[i * n + j] * yj;
+    wave_sync();
+  }
+  for (int i = lane; i < n; i += 64) x[i] /= D[i];
+  wave_sync();
+  for (int j = n - 1; j >= 0; j--) {
+    const double xj = x[j];
+    for (int i = lane; i < j; i += 64) x[i] -= A[j * n + i] * xj;
+    wave_sync();
+  }
+  return true;
+}
+
+static const int kVioMaxEPT = 8;
+
+struct VioShared {
+  NSd nsj, nsi, bkj, bki, prior;
+  double H[900], L[900], b[32], x[32], col[32], D[32];
+  double red[4 * 28];
+  double errI[9], errB[6], errP[15], wI[9], wP[15];
+  double JI[9 * 24], JP[225], InfoI[81], T[15 * 24];
+  double cov[225], C[225], E[225], Cinv[225 * 2];
+  int ok;
+};
+
+__global__ void __launch_bounds__(256)
+k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
+               uint8_t* __restrict__ outlier_all, vieo_vio_result* __restrict__ results) {
+  __shared__ VioShared S;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const vieo_vio_frame& F = frames[f];
+  const int N = F.base.n_obs;
+  const vieo_pose_obs* obs = obs_all + F.base.obs_begin;
+  uint8_t* outl = outlier_all + F.base.obs_begin;
+  vieo_vio_result* R = results + f;
+  if ((N < 3 && !F.no_mps) || N > 256 * kVioMaxEPT) {  // Optimizer.h:499-503
+    for (int i = tid; i < N; i += 256) outl[i] = 0;
+    for (int i = tid; i < 225; i += 256) R->H_marg[i] = 0;
+    if (tid == 0) {
+      R->base.nav = F.base.nav;
+      R->base.n_inliers = 0;
+      R->base.status = N > 256 * kVioMaxEPT ? VIEO_E_CAPACITY : VIEO_POSE_TOO_FEW;
+      R->base.lm_iterations = 0;
+      R->base.reserved = 0;
+      R->has_marg = 0;
+      R->reserved = 0;
+    }
+    return;
+  }
+  CamD c;
+  c.fx = F.base.fx, c.fy = F.base.fy, c.cx = F.base.cx, c.cy = F.base.cy, c.bf = F.base.bf;
+  for (int i = 0; i < 9; i++) c.Rcb[i] = F.base.Rcb[i];
+  for (int i = 0; i < 3; i++) c.tcb[i] = F.base.tcb[i];
+  const bool fixedLast = !F.last_has_prior, hasImu = F.imu.dt != 0;
+  const int n = fixedLast ? 15 : 30;
+  const bool bodom = hasImu;
+  const double gw[3] = {F.gw[0], F.gw[1], F.gw[2]};
+  // ---- constant edge data
+  if (tid == 0) {
+    ns_load(S.nsj, F.base.nav);
+    ns_load(S.nsi, F.nav_last);
+    ns_load(S.prior, F.nav_prior);
+  }
+  // IMU information = Sigma^-1 (x 1e-2 when the last state is fixed): Gauss-Jordan by one wave
+  if (hasImu && wave == 0) {
+    double* M = S.Cinv;  // 9 x 18 augmented
+    for (int e = lane; e < 9 * 18; e += 64) {
+      const int i = e / 18, j = e % 18;
+      M[e] = j < 9 ? F.imu.Sigma[i * 9 + j] : (j - 9 == i ? 1.0 : 0.0);
+    }
+    wave_sync();
+    for (int cidx = 0; cidx < 9; cidx++) {
+      int piv = cidx;
+      double best = fabs(M[cidx * 18 + cidx]);
+      for (int r = cidx + 1; r < 9; r++)
+        if (fabs(M[r * 18 + cidx]) > best) best = fabs(M[r * 18 + cidx]), piv = r;
+      if (piv != cidx) {
+        if (lane < 18) {
+          const double t = M[cidx * 18 + lane];
+          M[cidx * 18 + lane] = M[piv * 18 + lane];
+          M[piv * 18 + lane] = t;
+        }
+        wave_sync();
+      }
+      const double d = M[cidx * 18 + cidx];
+      wave_sync();
+      if (lane < 18) M[cidx * 18 + lane] /= d;
+      wave_sync();
+      double fr[3];
+      for (int h = 0; h < 3; h++) {
+        const int e = lane + 64 * h;
+        fr[h] = e < 162 ? M[(e / 18) * 18 + cidx] : 0;
+      }
+      wave_sync();
+      for (int h = 0; h < 3; h++) {
+        const int e = lane + 64 * h;
+        if (e < 162 && e / 18 != cidx) M[e] -= fr[h] * M[cidx * 18 + e % 18];
+      }
+      wave_sync();
+    }
+    for (int e = lane; e < 81; e += 64) S.InfoI[e] = M[(e / 9) * 18 + 9 + e % 9] * (fixedLast ? 1e-2 : 1.0);
+  }
+  __syncthreads();
+  const double deltatij = F.imu.dt ? F.imu.dt : F.dt_frames;
+  const double infoBg = F.inv_sigma_bg2 / deltatij * (fixedLast ? 1e-2 : 1.0);
+  const double infoBa = F.inv_sigma_ba2 / deltatij * (fixedLast ? 1e-2 : 1.0);
+  const double dI = sqrt(16.919), dB = sqrt(12.592), dP = sqrt(25.0);
+  const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+  const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+  const NSd nsj0 = S.nsj, nsi0 = S.nsi;
+  unsigned levelmask = 0;
+  bool vis_robust = true;
+  int nBad = 0, total_iters = 0;
+  const int n_edges_total = N + (hasImu ? 1 : 0) + 1 + (fixedLast ? 0 : 1);
+
+  // generic-edge errors at the current LDS state; returns (robust chi2 sum, rho' of I, B, P)
+  auto generic_errors = [&](double* rhoI, double* rhoB, double* rhoP) -> double {
+    if (tid == 0 && hasImu) imu_error(F.imu, gw, S.nsi, S.nsj, S.errI);
+    if (tid == 64 && !fixedLast) prior_error(S.prior, S.nsi, S.errP);
+    if (tid == 128)
+      for (int k = 0; k < 3; k++) {
+        S.errB[k] = (S.nsj.bg[k] + S.nsj.dbg[k]) - (S.nsi.bg[k] + S.nsi.dbg[k]);
+        S.errB[3 + k] = (S.nsj.ba[k] + S.nsj.dba[k]) - (S.nsi.ba[k] + S.nsi.dba[k]);
+      }
+    __syncthreads();
+    if (hasImu && tid < 9) {
+      double t = 0;
+      for (int j = 0; j < 9; j++) t += S.InfoI[tid * 9 + j] * S.errI[j];
+      S.wI[tid] = t;
+    }
+    if (!fixedLast && tid >= 64 && tid < 79) {
+      const int i = tid - 64;
+      double t = 0;
+      for (int j = 0; j < 15; j++) t += F.H_prior[i * 15 + j] * S.errP[j];
+      S.wP[i] = t;
+    }
+    __syncthreads();
+    double chi = 0;
+    *rhoI = *rhoB = *rhoP = 1.0;
+    if (hasImu) {
+      double e = 0;
+      for (int i = 0; i < 9; i++) e += S.errI[i] * S.wI[i];
+      double r0 = e;
+      if (fixedLast) huber(e, dI, dI * dI, &r0, rhoI);
+      chi += r0;
+    }
+    {
+      double e = 0;
+      for (int i = 0; i < 3; i++) e += S.errB[i] * (infoBg * S.errB[i]);
+      for (int i = 3; i < 6; i++) e += S.errB[i] * (infoBa * S.errB[i]);
+      double r0 = e;
+      if (fixedLast) huber(e, dB, dB * dB, &r0, rhoB);
+      chi += r0;
+    }
+    if (!fixedLast) {
+      double e = 0;
+      for (int i = 0; i < 15; i++) e += S.errP[i] * S.wP[i];
+      double r0 = e;
+      huber(e, dP, dP * dP, &r0, rhoP);
+      chi += r0;
+    }
+    return chi;
+  };
+  // robust chi2 of the active visual edges at the LDS state
+  auto visual_chi = [&]() -> double {
+    Est e;
+    e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
+    e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
+    PoseXf X;
+    make_xf(c, e, X);
+    double tc[1] = {0};
+    for (int k = 0, i = tid; i < N; k++, i += 256) {
+      if ((levelmask >> k) & 1) continue;
+      const vieo_pose_obs o = obs[i];
+      double err[3], Pc[3];
+      const double chi2 = edge_error(c, X, o, err, Pc);
+      double r0 = chi2, r1 = 1.;
+      if (vis_robust) {
+        const double dl = o.ur >= 0 ? deltaStereo : deltaMono;
+        huber(chi2, dl, dl * dl, &r0, &r1);
+      }
+      tc[0] += r0;
+    }
+    block_sum<1>(tc, S.red, tid);
+    return tc[0];
+  };
+
+  for (int it = 0; it < 4; it++) {
+    __syncthreads();
+    if (!bodom && tid == 0) {  // Optimizer.h:538-545
+      S.nsj = nsj0;
+      if (!fixedLast) S.nsi = nsi0;
+    }
+    __syncthreads();
+    double lambda = -1, ni = 2;
+    int nBadLM = 0;
+    for (int iter = 0; iter < 10; iter++) {
+      total_iters++;
+      // ---- computeActiveErrors + activeRobustChi2 + buildSystem
+      double rhoI, rhoB, rhoP;
+      const double chiG = generic_errors(&rhoI, &rhoB, &rhoP);
+      Est e;
+      e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
+      e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
+      PoseXf X;
+      make_xf(c, e, X);
+      double acc[28];
+#pragma unroll
+      for (int i = 0; i < 28; i++) acc[i] = 0;
+      for (int k = 0, i = tid; i < N; k++, i += 256) {
+        if ((levelmask >> k) & 1) continue;
+        const vieo_pose_obs o = obs[i];
+        double err[3], Pc[3];
+        const double chi2 = edge_error(c, X, o, err, Pc);
+        const bool stereo = o.ur >= 0;
+        double r0 = chi2, r1 = 1.;
+        if (vis_robust) {
+          const double dl = stereo ? deltaStereo : deltaMono;
+          huber(chi2, dl, dl * dl, &r0, &r1);
+        }
+        acc[27] += r0;
+        double J[18];
+        visual_jacobian(c, X, e.p, o, Pc, J);
+        visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
+      }
+      block_sum<28>(acc, S.red, tid);
+      double currentChi = chiG + acc[27];
+      const double iniChi = currentChi;
+      // generic Jacobians
+      if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
+      if (tid == 64 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
+      for (int i = tid; i < n * n; i += 256) S.H[i] = 0;
+      if (tid < n) S.b[tid] = 0;
+      __syncthreads();
+      // visual block: (dp, dphi) -> system rows/cols {0,1,2,6,7,8}
+      if (tid < 36) {
+        const int a = tid / 6, bq = tid % 6;
+        const int lo = a < bq ? a : bq, hi = a < bq ? bq : a;
+        const int t = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
+        const int ra = a < 3 ? a : a + 3, rb = bq < 3 ? bq : bq + 3;
+        S.H[ra * n + rb] = acc[t];
+      }
+      if (tid >= 64 && tid < 70) {
+        const int a = tid - 64;
+        S.b[a < 3 ? a : a + 3] = acc[21 + a];
+      }
+      __syncthreads();
+      if (hasImu) {  // T = (rho' Info) J  (9 x 24), then H += J^T T
+        const int nc = fixedLast ? 9 : 24;
+        for (int eidx = tid; eidx < 9 * nc; eidx += 256) {
+          const int a = eidx / nc, cc = eidx % nc;
+          double t = 0;
+          for (int q = 0; q < 9; q++) t += (rhoI * S.InfoI[a * 9 + q]) * S.JI[q * 24 + cc];
+          S.T[a * 24 + cc] = t;
+        }
+        __syncthreads();
+        for (int eidx = tid; eidx < nc * nc; eidx += 256) {
+          const int c1 = eidx / nc, c2 = eidx % nc;
+          double t = 0;
+          for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c1] * S.T[a * 24 + c2];
+          const int s1 = c1 < 9 ? c1 : c1 + 6, s2 = c2 < 9 ? c2 : c2 + 6;
+          S.H[s1 * n + s2] += t;
+        }
+        if (tid < nc) {
+          double t = 0;
+          for (int a = 0; a < 9; a++) t += S.JI[a * 24 + tid] * (-S.wI[a] * rhoI);
+          S.b[tid < 9 ? tid : tid + 6] += t;
+        }
+        __syncthreads();
+      }
+      if (!fixedLast) {  // prior: T = (rho' H_prior) J (15 x 15), H[15.., 15..] += J^T T
+        for (int eidx = tid; eidx < 225; eidx += 256) {
+          const int a = eidx / 15, cc = eidx % 15;
+          double t = 0;
+          for (int q = 0; q < 15; q++) t += (rhoP * F.H_prior[a * 15 + q]) * S.JP[q * 15 + cc];
+          S.T[a * 15 + cc] = t;
+        }
+        __syncthreads();
+        for (int eidx = tid; eidx < 225; eidx += 256) {
+          const int c1 = eidx / 15, c2 = eidx % 15;
+          double t = 0;
+          for (int a = 0; a < 15; a++) t += S.JP[a * 15 + c1] * S.T[a * 15 + c2];
+          S.H[(15 + c1) * n + 15 + c2] += t;
+        }
+        if (tid < 15) {
+          double t = 0;
+          for (int a = 0; a < 15; a++) t += S.JP[a * 15 + tid] * (-S.wP[a] * rhoP);
+          S.b[15 + tid] += t;
+        }
+        __syncthreads();
+      }
+      if (tid < 6) {  // bias edge: J_j = +I (cols 9..14), J_i = -I (cols 24..29)
+        const double w = (tid < 3 ? infoBg : infoBa) * rhoB;
+        const double we = (tid < 3 ? infoBg : infoBa) * S.errB[tid] * rhoB;
+        S.H[(9 + tid) * n + 9 + tid] += w;
+        S.b[9 + tid] += -we;
+        if (!fixedLast) {
+          S.H[(24 + tid) * n + 24 + tid] += w;
+          S.H[(9 + tid) * n + 24 + tid] -= w;
+          S.H[(24 + tid) * n + 9 + tid] -= w;
+          S.b[24 + tid] += we;
+        }
+      }
+      __syncthreads();
+      if (iter == 0) {
+        double mx = 0;
+        for (int j = 0; j < n; j++) mx = fmax(fabs(S.H[j * n + j]), mx);
+        lambda = 1e-5 * mx;
+        ni = 2;
+        nBadLM = 0;
+      }
+      double rho = 0;
+      int qmax = 0;
+      do {
+        __syncthreads();
+        if (tid == 0) S.bkj = S.nsj, S.bki = S.nsi;
+        for (int i = tid; i < n * n; i += 256) S.L[i] = S.H[i] + ((i / n) == (i % n) ? lambda : 0.0);
+        __syncthreads();
+        if (wave == 0) {
+          const bool ok = wave_ldlt_solve(S.L, S.b, S.x, S.col, S.D, n, lane);
+          if (lane == 0) S.ok = ok ? 1 : 0;
+        }
+        __syncthreads();
+        const bool ok2 = S.ok != 0;
+        if (tid == 0) {
+          if (!ok2)
+            for (int i = 0; i < n; i++) S.x[i] = 0;
+          ns_inc(S.nsj, S.x, S.x + 9);
+          if (!fixedLast) ns_inc(S.nsi, S.x + 15, S.x + 24);
+        }
+        __syncthreads();
+        double r1, r2, r3;
+        double tempChi = generic_errors(&r1, &r2, &r3);
+        tempChi += visual_chi();
+        if (!ok2) tempChi = DBL_MAX;
+        rho = currentChi - tempChi;
+        double scale = 0;
+        for (int j = 0; j < n; j++) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && isfinite(tempChi)) {
+          double alpha = 1. - pow(2 * rho - 1, 3);
+          alpha = fmin(alpha, 2. / 3.);
+          lambda *= fmax(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+        } else {
+          lambda *= ni;
+          ni *= 2;
+          __syncthreads();
+          if (tid == 0) S.nsj = S.bkj, S.nsi = S.bki;
+        }
+        qmax++;
+      } while (rho < 0 && qmax < 10);
+      __syncthreads();
+      if (qmax == 10 || rho == 0) break;
+      if ((iniChi - currentChi) * 1e3 < iniChi)
+        nBadLM++;
+      else
+        nBadLM = 0;
+      if (nBadLM >= 3) break;
+    }
+    // ---- classification at the current estimate (Optimizer.h:554-611)
+    __syncthreads();
+    Est e;
+    e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
+    e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
+    PoseXf X;
+    make_xf(c, e, X);
+    const float chi2close = (float)(1.5 * (double)chi2Mono);
+    double nb[1] = {0};
+    for (int k = 0, i = tid; i < N; k++, i += 256) {
+      const vieo_pose_obs o = obs[i];
+      double err[3], Pc[3];
+      const float chi2 = (float)edge_error(c, X, o, err, Pc);
+      bool bad;
+      if (o.ur < 0)
+        bad = chi2 > ((o.flags & 1) ? chi2close : chi2Mono) || !(Pc[2] > 0.);
+      else
+        bad = chi2 > chi2Stereo;
+      if (bad) {
+        levelmask |= (1u << k);
+        nb[0] += 1;
+      } else
+        levelmask &= ~(1u << k);
+    }
+    block_sum<1>(nb, S.red, tid);
+    nBad = (int)nb[0];
+    if (it == 2) vis_robust = false;
+    if (n_edges_total < 10) break;
+  }
+  unsigned outmask = levelmask;  // mvbOutlier
+  if (N - nBad < 30) {           // rescue pass, Optimizer.h:621-648
+    Est e;
+    e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
+    e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
+    PoseXf X;
+    make_xf(c, e, X);
+    double nb[1] = {0};
+    for (int k = 0, i = tid; i < N; k++, i += 256) {
+      const vieo_pose_obs o = obs[i];
+      double err[3], Pc[3];
+      const double chi2 = edge_error(c, X, o, err, Pc);
+      if (chi2 < (double)(o.ur < 0 ? 18.f : 24.f)) {
+        levelmask &= ~(1u << k);
+        outmask &= ~(1u << k);
+      } else
+        nb[0] += 1;
+    }
+    block_sum<1>(nb, S.red, tid);
+    nBad = (int)nb[0];
+  }
+  for (int k = 0, i = tid; i < N; k++, i += 256) outl[i] = (outmask >> k) & 1;
+  // ---- marginal prior (Optimizer.h:663-813, FillCovInv :126-206, exact_mode = kExactRobust)
+  if (F.compute_marg) {
+    double rhoI, rhoB, rhoP;
+    generic_errors(&rhoI, &rhoB, &rhoP);
+    Est e;
+    e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
+    e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
+    PoseXf X;
+    make_xf(c, e, X);
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) acc[i] = 0;
+    for (int k = 0, i = tid; i < N; k++, i += 256) {
+      if ((levelmask >> k) & 1) continue;
+      const vieo_pose_obs o = obs[i];
+      double err[3], Pc[3];
+      const double chi2 = edge_error(c, X, o, err, Pc);
+      const bool stereo = o.ur >= 0;
+      double r0 = chi2, r1 = 1.;
+      if (vis_robust) {
+        const double dl = stereo ? deltaStereo : deltaMono;
+        huber(chi2, dl, dl * dl, &r0, &r1);
+      }
+      double J[18];
+      visual_jacobian(c, X, e.p, o, Pc, J);
+      visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
+    }
+    block_sum<27>(acc, S.red, tid);
+    if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
+    if (tid == 64 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
+    for (int i = tid; i < 225; i += 256) S.cov[i] = 0, S.C[i] = 0, S.E[i] = 0;
+    __syncthreads();
+    if (tid < 36) {
+      const int a = tid / 6, bq = tid % 6;
+      const int lo = a < bq ? a : bq, hi = a < bq ? bq : a;
+      const int t = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
+      S.cov[(a < 3 ? a : a + 3) * 15 + (bq < 3 ? bq : bq + 3)] = acc[t];
+    }
+    __syncthreads();
+    if (hasImu) {
+      for (int eidx = tid; eidx < 9 * 24; eidx += 256) {
+        const int a = eidx / 24, cc = eidx % 24;
+        double t = 0;
+        for (int q = 0; q < 9; q++) t += (rhoI * S.InfoI[a * 9 + q]) * S.JI[q * 24 + cc];
+        S.T[a * 24 + cc] = t;
+      }
+      __syncthreads();
+      for (int eidx = tid; eidx < 24 * 24; eidx += 256) {
+        const int c1 = eidx / 24, c2 = eidx % 24;
+        double t = 0;
+        for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c1] * S.T[a * 24 + c2];
+        if (c1 < 9 && c2 < 9) S.cov[c1 * 15 + c2] += t;                         // B: (cur, cur)
+        if (c1 >= 9 && c2 >= 9) S.C[(c1 - 9) * 15 + (c2 - 9)] += t;             // C: (last, last)
+        if (c1 < 9 && c2 >= 9) S.E[c1 * 15 + (c2 - 9)] += t;                    // E: (cur, last)
+      }
+      __syncthreads();
+    }
+    if (tid < 6) {
+      const double w = (tid < 3 ? infoBg : infoBa) * rhoB;
+      S.cov[(9 + tid) * 15 + 9 + tid] = w;
+      S.C[(9 + tid) * 15 + 9 + tid] += w;
+      S.E[(9 + tid) * 15 + 9 + tid] = -w;
+    }
+    __syncthreads();
+    if (!fixedLast) {
+      for (int eidx = tid; eidx < 225; eidx += 256) {
+        const int a = eidx / 15, cc = eidx % 15;
+        double t = 0;
+        for (int q = 0; q < 15; q++) t += (rhoP * F.H_prior[a * 15 + q]) * S.JP[q * 15 + cc];
+        S.T[a * 15 + cc] = t;
+      }
+      __syncthreads();
+      for (int eidx = tid; eidx < 225; eidx += 256) {
+        const int c1 = eidx / 15, c2 = eidx % 15;
+        double t = 0;
+        for (int a = 0; a < 15; a++) t += S.JP[a * 15 + c1] * S.T[a * 15 + c2];
+        S.C[c1 * 15 + c2] += t;
+      }
+      __syncthreads();
+      // C^-1 by Gauss-Jordan with partial pivoting (one wave), then cov -= E C^-1 E^T
+      if (wave == 0) {
+        double* M = S.Cinv;  // 15 x 30
+        for (int eidx = lane; eidx < 450; eidx += 64) {
+          const int i = eidx / 30, j = eidx % 30;
+          M[eidx] = j < 15 ? S.C[i * 15 + j] : (j - 15 == i ? 1.0 : 0.0);
+        }
+        wave_sync();
+        for (int cidx = 0; cidx < 15; cidx++) {
+          int piv = cidx;
+          double best = fabs(M[cidx * 30 + cidx]);
+          for (int r = cidx + 1; r < 15; r++)
+            if (fabs(M[r * 30 + cidx]) > best) best = fabs(M[r * 30 + cidx]), piv = r;
+          if (piv != cidx) {
+            if (lane < 30) {
+              const double t = M[cidx * 30 + lane];
+              M[cidx * 30 + lane] = M[piv * 30 + lane];
+              M[piv * 30 + lane] = t;
+            }
+            wave_sync();
+          }
+          const double d = M[cidx * 30 + cidx];
+          wave_sync();
+          if (lane < 30) M[cidx * 30 + lane] /= d;
+          wave_sync();
+          double fr[8];
+          for (int h = 0; h < 8; h++) {
+            const int eidx = lane + 64 * h;
+            fr[h] = eidx < 450 ? M[(eidx / 30) * 30 + cidx] : 0;
+          }
+          wave_sync();
+          for (int h = 0; h < 8; h++) {
+            const int eidx = lane + 64 * h;
+            if (eidx < 450 && eidx / 30 != cidx) M[eidx] -= fr[h] * M[cidx * 30 + eidx % 30];
+          }
+          wave_sync();
+        }
+      }
+      __syncthreads();
+      for (int eidx = tid; eidx < 225; eidx += 256) {  // T = E * C^-1
+        const int i = eidx / 15, j = eidx % 15;
+        double t = 0;
+        for (int k = 0; k < 15; k++) t += S.E[i * 15 + k] * S.Cinv[k * 30 + 15 + j];
+        S.T[i * 15 + j] = t;
+      }
+      __syncthreads();
+      for (int eidx = tid; eidx < 225; eidx += 256) {
+        const int i = eidx / 15, j = eidx % 15;
+        double t = 0;
+        for (int k = 0; k < 15; k++) t += S.T[i * 15 + k] * S.E[j * 15 + k];
+        S.cov[eidx] -= t;
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < 225; i += 256) R->H_marg[i] = S.cov[i];
+  } else {
+    for (int i = tid; i < 225; i += 256) R->H_marg[i] = 0;
+  }
+  if (tid == 0) {
+    R->base.nav = F.base.nav;
+    ns_store(S.nsj, R->base.nav);
+    R->base.n_inliers = N - nBad;
+    R->base.status = VIEO_POSE_OK;
+    R->base.lm_iterations = total_iters;
+    R->base.reserved = 0;
+    R->has_marg = F.compute_marg ? 1 : 0;
+    R->reserved = 0;
+  }
+}
+
+}  // namespace vieo
+
+using namespace vieo;
+
+extern "C" {
+
+int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int n_frames,
+                                            const vieo_pose_obs* d_obs, uint8_t* d_outlier,
+                                            vieo_vio_result* d_results, void* stream) {
+  if (!d_frames || n_frames <= 0 || !d_obs || !d_outlier || !d_results) return VIEO_E_INVALID;
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  hipLaunchKernelGGL(k_pose_opt_vio, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames,
+                     d_obs, d_outlier, d_results);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_obs* h_obs,
+                               uint8_t* h_outlier, vieo_vio_result* h_result) {
+  if (!h_frame || !h_result || (h_frame->base.n_obs > 0 && (!h_obs || !h_outlier))) return VIEO_E_INVALID;
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  static thread_local DevBuf dF, dO, dU, dR;
+  const int n = h_frame->base.n_obs;
+  if ((rc = dF.ensure(sizeof(vieo_vio_frame))) != VIEO_OK) return rc;
+  if ((rc = dO.ensure((size_t)std::max(n, 1) * sizeof(vieo_pose_obs))) != VIEO_OK) return rc;
+  if ((rc = dU.ensure(std::max(n, 1))) != VIEO_OK) return rc;
+  if ((rc = dR.ensure(sizeof(vieo_vio_result))) != VIEO_OK) return rc;
+  vieo_vio_frame F = *h_frame;
+  const vieo_pose_obs* src = h_obs + h_frame->base.obs_begin;
+  F.base.obs_begin = 0;
+  VIEO_HIP_CHECK(hipMemcpy(dF.p, &F, sizeof(F), hipMemcpyHostToDevice));
+  if (n > 0) VIEO_HIP_CHECK(hipMemcpy(dO.p, src, (size_t)n * sizeof(vieo_pose_obs), hipMemcpyHostToDevice));
+  rc = vieo_pose_optimization_vio_batch_device(dF.as<vieo_vio_frame>(), 1, dO.as<vieo_pose_obs>(),
+                                               dU.as<uint8_t>(), dR.as<vieo_vio_result>(), nullptr);
+  if (rc != VIEO_OK) return rc;
+  VIEO_HIP_CHECK(hipMemcpy(h_result, dR.p, sizeof(vieo_vio_result), hipMemcpyDeviceToHost));
+  if (n > 0) VIEO_HIP_CHECK(hipMemcpy(h_outlier + h_frame->base.obs_begin, dU.p, n, hipMemcpyDeviceToHost));
+  return VIEO_OK;
+}
+
+}  // extern "C"

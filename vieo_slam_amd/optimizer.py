@@ -4,7 +4,8 @@ pointer graphs."""
 import numpy as np
 
 from ._lib import check, lib
-from .ba_types import POSE_FRAME_DTYPE, POSE_OBS_DTYPE, POSE_RESULT_DTYPE
+from .ba_types import (POSE_FRAME_DTYPE, POSE_OBS_DTYPE, POSE_RESULT_DTYPE, VIO_FRAME_DTYPE,
+                       VIO_RESULT_DTYPE)
 
 
 class Optimizer:
@@ -20,4 +21,17 @@ class Optimizer:
         res = np.zeros(1, POSE_RESULT_DTYPE)
         check(lib().vieo_pose_optimization(fr.ctypes.data, ob.ctypes.data, outl.ctypes.data,
                                            res.ctypes.data), "vieo_pose_optimization")
+        return res[0], outl[:len(ob)]
+
+    @staticmethod
+    def PoseOptimizationVIO(vio_frame, obs):
+        """template<class KeyFrame> int Optimizer::PoseOptimization(Frame*, KeyFrame* pLastKF, gw,
+        bComputeMarg, bNoMPs) (include/Optimizer.h:208-816).  vio_frame: VIO_FRAME_DTYPE[1].
+        returns (VIO_RESULT_DTYPE record, outlier uint8[n])."""
+        fr = np.ascontiguousarray(vio_frame, VIO_FRAME_DTYPE).reshape(1)
+        ob = np.ascontiguousarray(obs, POSE_OBS_DTYPE)
+        outl = np.zeros(max(len(ob), 1), np.uint8)
+        res = np.zeros(1, VIO_RESULT_DTYPE)
+        check(lib().vieo_pose_optimization_vio(fr.ctypes.data, ob.ctypes.data, outl.ctypes.data,
+                                               res.ctypes.data), "vieo_pose_optimization_vio")
         return res[0], outl[:len(ob)]
