@@ -318,6 +318,34 @@ int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int 
                                             const vieo_pose_obs* d_obs, uint8_t* d_outlier,
                                             vieo_vio_result* d_results, void* stream);
 
+/* ---- replay glue (device-resident batches) -------------------------------------------------
+ * What Tracking.cc does between the calls above, on flattened arrays, so a batch of frames runs
+ * extract -> stereo -> search -> pose optimisation with no host round trip (bench.py):
+ * keypoint -> point bookkeeping (Frame::mvpMapPoints), the observation gathering at the top of
+ * PoseOptimization (Optimizer.cc:1704-1786), "Discard outliers" (Tracking.cc:1903-1921).
+ * d_mp_ref[f][key_cap]: index into frame f's point table d_point_xyz[f][p_cap][3], -1 = none. */
+int vieo_track_merge_assign_batch_device(const int32_t* d_assign, int32_t* d_mp_ref,
+                                         const int32_t* d_counts, int key_cap, int n_frames,
+                                         int img_first, int img_step, int point_offset, int reset,
+                                         void* stream);
+/* Fills d_obs[f][key_cap] / d_obs_key and writes n_obs, obs_begin (= f*key_cap) into the frame
+ * structs (vieo_pose_frame or vieo_vio_frame array). */
+int vieo_track_build_obs_batch_device(const int32_t* d_mp_ref, const float* d_point_xyz, int p_cap,
+                                      const vieo_keypoint* d_keys, const float* d_uright,
+                                      const int32_t* d_counts, int key_cap, int n_frames,
+                                      int img_first, int img_step, const float* d_inv_sigma2,
+                                      vieo_pose_obs* d_obs, int32_t* d_obs_key, void* d_frames,
+                                      int frames_are_vio, void* stream);
+/* Drops outlier matches from d_mp_ref, exports d_taken (may be NULL) for the next search and
+ * copies the optimised NavState into d_next_frames[f].nav (may be NULL). */
+int vieo_track_after_pose_batch_device(int32_t* d_mp_ref, const int32_t* d_obs_key,
+                                       const uint8_t* d_outlier, const void* d_frames,
+                                       const void* d_results, int frames_are_vio, int key_cap,
+                                       int n_frames, void* d_next_frames, uint8_t* d_taken,
+                                       void* stream);
+/* The extractor's own hipStream_t, so the calls above can be chained on it. */
+void* vieo_orb_stream(vieo_orb* e);
+
 /* ---- test taps (parity tests only; not part of the drop-in surface) ---- */
 /* which: 1 = blurred level.  FAST candidates: int32 triplets (x, y, response) in
  * vToDistributeKeys order; level keys: vieo_keypoint in DistributeOctTree output order. */

@@ -896,6 +896,8 @@ int vieo_orb_extract_batch_device(vieo_orb* e, const uint8_t* d_images, int n_im
                    d_keypoints, d_descriptors, capacity, d_counts);
 }
 
+void* vieo_orb_stream(vieo_orb* e) { return e ? (void*)e->stream : nullptr; }
+
 int vieo_orb_sync(vieo_orb* e) {
   VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));
   return VIEO_OK;

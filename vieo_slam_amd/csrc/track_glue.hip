@@ -1,0 +1,163 @@
+// track_glue.hip -- device-side glue of the per-frame replay (what Tracking.cc does between the
+// hot-path calls), so a batch of frames can run extract -> stereo -> search -> pose optimisation
+// without a host round trip.  Mirrors, on flattened arrays:
+//   * Frame::mvpMapPoints bookkeeping after a search (AddMapPoint / EraseMapPointMatch results)
+//   * the observation gathering at the top of PoseOptimization (Optimizer.cc:1704-1786,
+//     Optimizer.h:406-490)
+//   * "Discard outliers" after PoseOptimization (Tracking.cc:1903-1921) and the
+//     Observations()>0 test of the next search (ORBmatcher.cc:289-291).
+#include "common.h"
+
+namespace vieo {
+
+// mp_ref[f][key_cap]: index of the point held by keypoint i in the frame's point table, -1 none
+__global__ void __launch_bounds__(256)
+k_track_merge_assign(const int* __restrict__ assign, int* __restrict__ mp_ref,
+                     const int* __restrict__ counts, int key_cap, int img_first, int img_step,
+                     int point_offset, int reset) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const int img = img_first + f * img_step;
+  if (i >= key_cap) return;
+  int* m = mp_ref + (size_t)f * key_cap + i;
+  if (i >= min(counts[2 * img], key_cap)) {
+    *m = -1;
+    return;
+  }
+  int cur = reset ? -1 : *m;
+  const int a = assign[(size_t)f * key_cap + i];
+  if (a >= 0)
+    cur = point_offset + a;
+  else if (a == VIEO_SBP_ERASED)
+    cur = -1;
+  *m = cur;
+}
+
+// one workgroup per frame: compact the held points into observations, in keypoint order
+__global__ void __launch_bounds__(256)
+k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ point_xyz, int p_cap,
+                  const vieo_keypoint* __restrict__ keys, const float* __restrict__ uright,
+                  const int* __restrict__ counts, int key_cap, int img_first, int img_step,
+                  const float* __restrict__ inv_sigma2, float close_depth,
+                  vieo_pose_obs* __restrict__ obs, int* __restrict__ obs_key, uint8_t* frames_base,
+                  size_t frame_stride, size_t nobs_offset, size_t obsbegin_offset) {
+  __shared__ int s_wsum[4];
+  __shared__ int s_base;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int img = img_first + f * img_step;
+  const int N = min(counts[2 * img], key_cap);
+  const int* m = mp_ref + (size_t)f * key_cap;
+  const vieo_keypoint* K = keys + (size_t)img * key_cap;
+  const float* ur = uright + (size_t)f * key_cap;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < N; i0 += 256) {
+    const int i = i0 + tid;
+    const bool has = i < N && m[i] >= 0;
+    const unsigned long long bal = __ballot(has);
+    if (lane == 0) s_wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wsum[w];
+    if (has) {
+      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+      const float* X = point_xyz + ((size_t)f * p_cap + m[i]) * 3;
+      vieo_pose_obs o;
+      o.Xw[0] = X[0], o.Xw[1] = X[1], o.Xw[2] = X[2];
+      const vieo_keypoint k = K[i];
+      o.u = k.x, o.v = k.y, o.ur = ur[i];
+      o.inv_sigma2 = inv_sigma2[k.octave];
+      o.flags = 0;
+      obs[(size_t)f * key_cap + pos] = o;
+      obs_key[(size_t)f * key_cap + pos] = i;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    uint8_t* fr = frames_base + (size_t)f * frame_stride;
+    *(int*)(fr + nobs_offset) = s_base;
+    *(int*)(fr + obsbegin_offset) = f * key_cap;
+  }
+  (void)close_depth;
+}
+
+// after PoseOptimization: drop outlier matches, export the "claimed" flags of the next search,
+// chain the optimised state into the next problem (nav block copied verbatim)
+__global__ void __launch_bounds__(256)
+k_track_after_pose(int* __restrict__ mp_ref, const int* __restrict__ obs_key,
+                   const uint8_t* __restrict__ outlier, const uint8_t* frames_base,
+                   size_t frame_stride, size_t nobs_offset, int key_cap,
+                   const uint8_t* results_base, size_t result_stride, uint8_t* next_frames_base,
+                   size_t next_frame_stride, uint8_t* __restrict__ taken) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int n = *(const int*)(frames_base + (size_t)f * frame_stride + nobs_offset);
+  int* m = mp_ref + (size_t)f * key_cap;
+  for (int j = tid; j < n; j += 256)
+    if (outlier[(size_t)f * key_cap + j]) m[obs_key[(size_t)f * key_cap + j]] = -1;
+  __syncthreads();
+  if (taken)
+    for (int i = tid; i < key_cap; i += 256) taken[(size_t)f * key_cap + i] = m[i] >= 0 ? 1 : 0;
+  if (next_frames_base) {
+    const double* src = (const double*)(results_base + (size_t)f * result_stride);
+    double* dst = (double*)(next_frames_base + (size_t)f * next_frame_stride);
+    for (int i = tid; i < (int)(sizeof(vieo_navstate) / 8); i += 256) dst[i] = src[i];
+  }
+}
+
+}  // namespace vieo
+
+using namespace vieo;
+
+extern "C" {
+
+int vieo_track_merge_assign_batch_device(const int32_t* d_assign, int32_t* d_mp_ref,
+                                         const int32_t* d_counts, int key_cap, int n_frames,
+                                         int img_first, int img_step, int point_offset, int reset,
+                                         void* stream) {
+  if (!d_assign || !d_mp_ref || !d_counts || key_cap <= 0 || n_frames <= 0) return VIEO_E_INVALID;
+  hipLaunchKernelGGL(k_track_merge_assign, dim3((key_cap + 255) / 256, n_frames), dim3(256), 0,
+                     (hipStream_t)stream, d_assign, d_mp_ref, d_counts, key_cap, img_first, img_step,
+                     point_offset, reset);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_build_obs_batch_device(const int32_t* d_mp_ref, const float* d_point_xyz, int p_cap,
+                                      const vieo_keypoint* d_keys, const float* d_uright,
+                                      const int32_t* d_counts, int key_cap, int n_frames,
+                                      int img_first, int img_step, const float* d_inv_sigma2,
+                                      vieo_pose_obs* d_obs, int32_t* d_obs_key, void* d_frames,
+                                      int frames_are_vio, void* stream) {
+  if (!d_mp_ref || !d_point_xyz || !d_keys || !d_uright || !d_counts || !d_inv_sigma2 || !d_obs ||
+      !d_obs_key || !d_frames || key_cap <= 0 || n_frames <= 0)
+    return VIEO_E_INVALID;
+  const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
+  const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
+                     d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
+                     d_inv_sigma2, 0.f, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
+                     base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin));
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_after_pose_batch_device(int32_t* d_mp_ref, const int32_t* d_obs_key,
+                                       const uint8_t* d_outlier, const void* d_frames,
+                                       const void* d_results, int frames_are_vio, int key_cap,
+                                       int n_frames, void* d_next_frames, uint8_t* d_taken,
+                                       void* stream) {
+  if (!d_mp_ref || !d_obs_key || !d_outlier || !d_frames || !d_results || key_cap <= 0 || n_frames <= 0)
+    return VIEO_E_INVALID;
+  const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
+  const size_t rstride = frames_are_vio ? sizeof(vieo_vio_result) : sizeof(vieo_pose_result);
+  hipLaunchKernelGGL(k_track_after_pose, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
+                     d_obs_key, d_outlier, (const uint8_t*)d_frames, stride,
+                     (frames_are_vio ? offsetof(vieo_vio_frame, base) : 0) + offsetof(vieo_pose_frame, n_obs),
+                     key_cap, (const uint8_t*)d_results, rstride, (uint8_t*)d_next_frames, stride,
+                     d_taken);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+}  // extern "C"

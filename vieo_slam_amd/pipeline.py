@@ -1,0 +1,179 @@
+"""Device-resident replay of the per-frame front end for a BATCH of independent stereo-inertial
+frames, in the reference's call order (Tracking::TrackWithIMU + TrackLocalMapWithIMU):
+
+  ORBextractor x2 -> ComputeStereoMatches -> SearchByProjection(last frame) -> PoseOptimization(VIO)
+  -> SearchByProjection(local map) -> PoseOptimization(VIO, bComputeMarg)
+
+All stages are the C-ABI batch entry points chained on the extractor's HIP stream; nothing returns
+to the host between them.  Inputs that the hot path does not produce itself (last frame's map
+points, local-map queries from Frame::isInFrustum, IMU pre-integration, predicted state) are
+prepared once on the host and stay resident in HBM."""
+import ctypes
+
+import numpy as np
+
+from . import frontend, synth, synth_ba
+from . import synth_scene as sc
+from ._lib import DeviceBuffer, check, lib
+from .ba_types import (LAST_FRAME_POINT_DTYPE, POSE_OBS_DTYPE, PROJ_QUERY_DTYPE, SBP_CAMERA_DTYPE,
+                       VIO_FRAME_DTYPE, VIO_RESULT_DTYPE)
+from .orb_extractor import KEYPOINT_DTYPE, ORBextractor
+
+W, H = sc.W, sc.H
+K = (sc.FX, sc.FY, sc.CX, sc.CY)
+BOUNDS = np.array([0, W, 0, H], np.float32)
+NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH = 1200, 1.2, 8, 20, 7  # EuRoC_VIO.yaml:138-151
+
+
+def make_cases(n_base, seed0=1, verbose=False):
+    scene = sc.Scene(seed0)
+    return [sc.make_tracking_case(seed0 + i, scene=scene) for i in range(n_base)]
+
+
+class FramePipeline:
+    STAGES = ("extract", "stereo", "sbp_last", "pose1", "sbp_local", "pose2", "total")
+
+    def __init__(self, cases, batch, seed=0, noise=True):
+        self.B = B = batch
+        self.ext = ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
+        self.stream = lib().vieo_orb_stream(self.ext._h)
+        self.cap = cap = self.ext.max_keypoints()
+        ext0 = [ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH) for _ in range(2)]
+        scf = self.ext.GetScaleFactors()
+        self.inv_sigma2 = (np.float32(1.0) / (scf * scf)).astype(np.float32)
+        rng = np.random.default_rng(seed)
+        imgs = np.zeros((B, 2, H, W), np.uint8)
+        pts = np.zeros((B, cap), LAST_FRAME_POINT_DTYPE)
+        npts = np.zeros(B, np.int32)
+        cams = np.zeros(B, SBP_CAMERA_DTYPE)
+        q2 = np.zeros((B, cap), PROJ_QUERY_DTYPE)
+        xyz = np.zeros((B, 2 * cap, 3), np.float32)
+        f1 = np.zeros(B, VIO_FRAME_DTYPE)
+        self.truth = []
+        from .matching import compute_stereo_matches
+        for b in range(B):
+            case = cases[b % len(cases)]
+
+            def jitter(im):
+                if not noise or b < len(cases):
+                    return im
+                return np.clip(im.astype(np.int16) + rng.integers(-2, 3, im.shape), 0, 255).astype(np.uint8)
+            L0, R0 = [jitter(x) for x in case["images0"]]
+            imgs[b, 0], imgs[b, 1] = [jitter(x) for x in case["images1"]]
+            # ---- frame t0 (the "last frame"): its keys with stereo depth become map points
+            _, k0, d0 = ext0[0](L0)
+            _, k0r, d0r = ext0[1](R0)
+            ur0, dp0 = compute_stereo_matches(ext0[0], ext0[1], k0, d0, k0r, d0r, sc.BASELINE, sc.BF)
+            Ri, pi, Rwc0, twc0 = case["pose0"]
+            Xw, valid = frontend.unproject_stereo(k0, dp0, K, Rwc0, twc0)
+            n0 = len(k0)
+            pts[b, :n0] = frontend.make_last_frame_points(k0, d0, Xw, valid, True)
+            npts[b] = n0
+            xyz[b, :n0] = Xw
+            xyz[b, cap:cap + n0] = Xw
+            # ---- predicted state of frame t1 = truth + small error (PredictNavStateByIMU)
+            F = case["vio"].copy()
+            F[0]["base"]["nav"]["p"] += rng.normal(0, 0.01, 3)
+            F[0]["base"]["nav"]["q"] = synth_ba.quat_mul(
+                F[0]["base"]["nav"]["q"], synth_ba.quat_from_rotvec(rng.normal(0, 0.003, 3)))
+            f1[b] = F[0]
+            Rwb = synth_ba.quat_to_R(F[0]["base"]["nav"]["q"])
+            Tbc = synth_ba.EUROC_TBC
+            Rwc = Rwb @ Tbc[:3, :3]
+            twc = F[0]["base"]["nav"]["p"] + Rwb @ Tbc[:3, 3]
+            Tcw = frontend.pose_to_Tcw(Rwc, twc)
+            cams[b] = frontend.make_sbp_camera(Tcw, frontend.pose_to_Tcw(Rwc0, twc0), K, BOUNDS,
+                                               sc.BF, sc.BASELINE, 7.0, scf)[0]
+            # ---- local-map queries (what Frame::isInFrustum hands to the second search):
+            # the same world points seen again, window 4.0 * scale[level], levels [L-1, L]
+            Xc = Xw.astype(np.float64) @ Tcw[:, :3].T + Tcw[:, 3]
+            z = np.where(Xc[:, 2] > 0.1, Xc[:, 2], 1.0)
+            u = (sc.FX * Xc[:, 0] / z + sc.CX).astype(np.float32)
+            v = (sc.FY * Xc[:, 1] / z + sc.CY).astype(np.float32)
+            inimg = valid & (Xc[:, 2] > 0.1) & (u >= 0) & (u < W) & (v >= 0) & (v < H)
+            q = q2[b, :n0]
+            q["u"], q["v"] = u, v
+            q["ur"] = u - np.float32(sc.BF) / z.astype(np.float32)
+            q["radius"] = np.float32(4.0) * scf[k0["octave"]]
+            q["level_min"], q["level_max"] = k0["octave"] - 1, k0["octave"]
+            q["angle"] = k0["angle"]
+            q["flags"] = inimg.astype(np.int32) * 3
+            q["desc"] = d0
+            self.truth.append(case["truth"])
+        f2 = f1.copy()
+        f2["compute_marg"] = 1
+        self.imgs_host = imgs
+        self.n_img = 2 * B
+        D = DeviceBuffer
+        self.d_img = D(imgs.nbytes)
+        self.d_img.upload(imgs)
+        self.d_kp, self.d_desc, self.d_cnt = D(2 * B * cap * 28), D(2 * B * cap * 32), D(2 * B * 8)
+        self.d_ur, self.d_dp = D(B * cap * 4), D(B * cap * 4)
+        self.d_pts, self.d_npts, self.d_cams = D(pts.nbytes), D(npts.nbytes), D(cams.nbytes)
+        self.d_pts.upload(pts), self.d_npts.upload(npts), self.d_cams.upload(cams)
+        self.d_q1, self.d_q2 = D(B * cap * 64), D(q2.nbytes)
+        self.d_q2.upload(q2)
+        self.d_assign, self.d_nm = D(B * cap * 4), D(B * 4)
+        self.d_mpref, self.d_taken = D(B * cap * 4), D(B * cap)
+        self.d_xyz, self.d_isig = D(xyz.nbytes), D(self.inv_sigma2.nbytes)
+        self.d_xyz.upload(xyz), self.d_isig.upload(self.inv_sigma2)
+        self.d_obs, self.d_obskey, self.d_outl = D(B * cap * 32), D(B * cap * 4), D(B * cap)
+        self.d_f1, self.d_f2 = D(f1.nbytes), D(f2.nbytes)
+        self.d_f1.upload(f1), self.d_f2.upload(f2)
+        self.d_r1, self.d_r2 = D(B * VIO_RESULT_DTYPE.itemsize), D(B * VIO_RESULT_DTYPE.itemsize)
+        self.bounds = (ctypes.c_float * 4)(*BOUNDS.tolist())
+        self.f1_host, self.pts_host, self.q2_host = f1, pts, q2
+        check(lib().vieo_device_synchronize())
+
+    def step(self):
+        L, B, cap, st = lib(), self.B, self.cap, self.stream
+        self.ext.extract_batch_device(self.d_img.ptr, self.n_img, W, H, W, W * H, self.d_kp.ptr,
+                                      self.d_desc.ptr, cap, self.d_cnt.ptr)
+        check(L.vieo_stereo_match_rectified_batch_device(self.ext._h, B, self.d_kp.ptr, self.d_desc.ptr,
+                                                         self.d_cnt.ptr, cap, sc.BASELINE, sc.BF,
+                                                         self.d_ur.ptr, self.d_dp.ptr), "stereo")
+        check(L.vieo_sbp_project_last_frame_batch_device(self.d_pts.ptr, self.d_npts.ptr, cap, B,
+                                                         self.d_cams.ptr, self.d_q1.ptr, st), "project")
+        check(L.vieo_search_by_projection_batch_device(0, self.d_q1.ptr, self.d_npts.ptr, cap, B,
+                                                       self.d_kp.ptr, self.d_ur.ptr, self.d_desc.ptr,
+                                                       None, self.d_cnt.ptr, cap, 0, 2, self.bounds, 0.9,
+                                                       1, self.d_assign.ptr, self.d_nm.ptr, st), "sbp1")
+        check(L.vieo_track_merge_assign_batch_device(self.d_assign.ptr, self.d_mpref.ptr, self.d_cnt.ptr,
+                                                     cap, B, 0, 2, 0, 1, st))
+        check(L.vieo_track_build_obs_batch_device(self.d_mpref.ptr, self.d_xyz.ptr, 2 * cap, self.d_kp.ptr,
+                                                  self.d_ur.ptr, self.d_cnt.ptr, cap, B, 0, 2,
+                                                  self.d_isig.ptr, self.d_obs.ptr, self.d_obskey.ptr,
+                                                  self.d_f1.ptr, 1, st))
+        check(L.vieo_pose_optimization_vio_batch_device(self.d_f1.ptr, B, self.d_obs.ptr, self.d_outl.ptr,
+                                                        self.d_r1.ptr, st), "pose1")
+        check(L.vieo_track_after_pose_batch_device(self.d_mpref.ptr, self.d_obskey.ptr, self.d_outl.ptr,
+                                                   self.d_f1.ptr, self.d_r1.ptr, 1, cap, B, self.d_f2.ptr,
+                                                   self.d_taken.ptr, st))
+        check(L.vieo_search_by_projection_batch_device(1, self.d_q2.ptr, self.d_npts.ptr, cap, B,
+                                                       self.d_kp.ptr, self.d_ur.ptr, self.d_desc.ptr,
+                                                       self.d_taken.ptr, self.d_cnt.ptr, cap, 0, 2,
+                                                       self.bounds, 0.8, 1, self.d_assign.ptr,
+                                                       self.d_nm.ptr, st), "sbp2")
+        check(L.vieo_track_merge_assign_batch_device(self.d_assign.ptr, self.d_mpref.ptr, self.d_cnt.ptr,
+                                                     cap, B, 0, 2, cap, 0, st))
+        check(L.vieo_track_build_obs_batch_device(self.d_mpref.ptr, self.d_xyz.ptr, 2 * cap, self.d_kp.ptr,
+                                                  self.d_ur.ptr, self.d_cnt.ptr, cap, B, 0, 2,
+                                                  self.d_isig.ptr, self.d_obs.ptr, self.d_obskey.ptr,
+                                                  self.d_f2.ptr, 1, st))
+        check(L.vieo_pose_optimization_vio_batch_device(self.d_f2.ptr, B, self.d_obs.ptr, self.d_outl.ptr,
+                                                        self.d_r2.ptr, st), "pose2")
+
+    def sync(self):
+        self.ext.sync()
+
+    def results(self):
+        self.sync()
+        B, cap = self.B, self.cap
+        return dict(r1=self.d_r1.download(VIO_RESULT_DTYPE, (B,)),
+                    r2=self.d_r2.download(VIO_RESULT_DTYPE, (B,)),
+                    counts=self.d_cnt.download(np.int32, (2 * B, 2)),
+                    f2=self.d_f2.download(VIO_FRAME_DTYPE, (B,)),
+                    mp_ref=self.d_mpref.download(np.int32, (B, cap)),
+                    uright=self.d_ur.download(np.float32, (B, cap)),
+                    kps=self.d_kp.download(KEYPOINT_DTYPE, (2 * B, cap)),
+                    desc=self.d_desc.download(np.uint8, (2 * B, cap, 32)))

@@ -162,6 +162,48 @@ class Preintegrator:
         self.dt += dt
 
 
+def imu_motion(rng, pj, Rj, dt_frame):
+    """Random smooth motion ending at pose (pj, Rj): constant body rate and world acceleration
+    over dt_frame, sampled at IMU_FREQ.  State i is defined so that the NOISE-FREE discrete
+    pre-integration has zero residual between (i, j); the returned measurement carries sensor
+    noise and bias.  returns (pi, Ri, vi, vj, bg, ba, Preintegrator)."""
+    omega = rng.normal(0, 0.4, 3)             # body angular rate (rad/s)
+    a_w = rng.normal(0, 1.0, 3)               # world acceleration (m/s^2)
+    vi = rng.normal(0, 0.8, 3)
+    bg, ba = rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)
+    n_imu = int(round(dt_frame * IMU_FREQ))
+    h = dt_frame / n_imu
+    ts = np.arange(n_imu + 1) * h
+    Rrel = [so3_exp(omega * t) for t in ts]   # R_i^T R(t)
+    rot = Preintegrator()
+    for k in range(n_imu):
+        rot.update(omega, np.zeros(3), h)
+    Ri = Rj @ rot.R.T
+    acc_true = [(Ri @ Rrel[k]).T @ (a_w - GRAVITY) for k in range(n_imu + 1)]
+    clean = Preintegrator()
+    for k in range(n_imu):
+        clean.update(omega, (acc_true[k] + acc_true[k + 1]) / 2, h)
+    vj = vi + GRAVITY * dt_frame + Ri @ clean.v
+    pi = pj - (vi * dt_frame + GRAVITY * dt_frame ** 2 / 2 + Ri @ clean.p)
+    sg = IMU_SIGMA[0] * np.sqrt(IMU_FREQ)
+    sa = IMU_SIGMA[1] * np.sqrt(IMU_FREQ)
+    gyr = [omega + bg + rng.normal(0, sg, 3) for _ in range(n_imu + 1)]
+    acc = [acc_true[k] + ba + rng.normal(0, sa, 3) for k in range(n_imu + 1)]
+    meas = Preintegrator()
+    for k in range(n_imu):
+        meas.update((gyr[k] + gyr[k + 1]) / 2 - bg, (acc[k] + acc[k + 1]) / 2 - ba, h)
+    return pi, Ri, vi, vj, bg, ba, meas
+
+
+def fill_imu(im, meas):
+    im["dt"] = meas.dt
+    im["Rij"], im["vij"], im["pij"] = meas.R.reshape(-1), meas.v, meas.p
+    for name in ("JgR", "Jgv", "Jav", "Jgp", "Jap"):
+        im[name] = getattr(meas, name).reshape(-1)
+    im["Sigma"] = meas.Sigma.reshape(-1)
+
+
+
 def _nav(rec, p, q, v, bg, ba):
     rec["p"], rec["q"], rec["v"], rec["bg"], rec["ba"] = p, q, v, bg, ba
     rec["dbg"] = 0
@@ -179,46 +221,8 @@ def make_vio_problem(seed, n_obs=300, dt_frame=0.05, compute_marg=False, prior=N
     f["base"] = frame[0]
     # ground-truth state j comes from make_pose_problem; integrate BACKWARDS to get state i
     Rj, pj = quat_to_R(gt["q"]), gt["p"]
-    omega = rng.normal(0, 0.4, 3)             # body angular rate (rad/s)
-    a_w = rng.normal(0, 1.0, 3)               # world acceleration (m/s^2)
-    vi = rng.normal(0, 0.8, 3)
-    bg, ba = rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)
-    n_imu = int(round(dt_frame * IMU_FREQ))
-    h = dt_frame / n_imu
-    # noise-free samples along a constant-omega / constant-a_w motion starting at R_i = I frame
-    ts = np.arange(n_imu + 1) * h
-    Rrel = [so3_exp(omega * t) for t in ts]   # R_i^T R(t)
-    # choose R_i so that R_i * DeltaR_true = R_j after the discrete integration
-    clean = Preintegrator()
-    for k in range(n_imu):
-        w_mid = omega
-        a_k = Rrel[k].T @ np.zeros(3)  # placeholder, filled below once R_i is known
-    # two-pass: first the rotation only (independent of acceleration), to get R_i
-    rot = Preintegrator()
-    for k in range(n_imu):
-        rot.update(omega, np.zeros(3), h)
-    Ri = Rj @ rot.R.T
-    acc_true = [(Ri @ Rrel[k]).T @ (a_w - GRAVITY) for k in range(n_imu + 1)]
-    clean = Preintegrator()
-    for k in range(n_imu):
-        clean.update(omega, (acc_true[k] + acc_true[k + 1]) / 2, h)
-    # state i such that the clean measurement has zero residual at (i, j)
-    vj = vi + GRAVITY * dt_frame + Ri @ clean.v
-    pi = pj - (vi * dt_frame + GRAVITY * dt_frame ** 2 / 2 + Ri @ clean.p)
-    # noisy measurement (what the optimiser sees): samples carry bias + white noise
-    sg = IMU_SIGMA[0] * np.sqrt(IMU_FREQ)
-    sa = IMU_SIGMA[1] * np.sqrt(IMU_FREQ)
-    gyr = [omega + bg + rng.normal(0, sg, 3) for _ in range(n_imu + 1)]
-    acc = [acc_true[k] + ba + rng.normal(0, sa, 3) for k in range(n_imu + 1)]
-    meas = Preintegrator()
-    for k in range(n_imu):
-        meas.update((gyr[k] + gyr[k + 1]) / 2 - bg, (acc[k] + acc[k + 1]) / 2 - ba, h)
-    im = f["imu"]
-    im["dt"] = meas.dt
-    im["Rij"], im["vij"], im["pij"] = meas.R.reshape(-1), meas.v, meas.p
-    for name in ("JgR", "Jgv", "Jav", "Jgp", "Jap"):
-        im[name] = getattr(meas, name).reshape(-1)
-    im["Sigma"] = meas.Sigma.reshape(-1)
+    pi, Ri, vi, vj, bg, ba, meas = imu_motion(rng, pj, Rj, dt_frame)
+    fill_imu(f["imu"], meas)
     qi = _R_to_quat(Ri)
     # current frame: keep the perturbed p/q from make_pose_problem, add v and biases
     f["base"]["nav"]["v"] = vj + rng.normal(0, 0.05, 3)
