@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X hot path on EuRoC-shaped synthetic stereo frames.
+"""bench.py -- throughput of the MI355X hot path on EuRoC-shaped synthetic stereo-inertial frames.
 
     python bench.py --gpus N --steps K --warmup W [--batch B]
 
-One process per GPU (the driver launches N>1 through torch.distributed.run).  A *step* is one pass
-of the hot path over one batch of B stereo frames that already sits in HBM; frames are independent,
-so ranks shard them with no data-path collective ("weak" scaling: B frames per rank per step).
-Rank 0 prints ONE JSON line.  The stages inside the timed region are listed in config.workload --
-stages of BASELINE.json's metric that are not built yet are named there as missing, never faked.
+Workload (BASELINE.json configs[1]: "EuRoC MH05 stereo-VIO, 1200 feats, 1xMI355X, PoseOptimization
+only"): per stereo frame, in the reference's call order
+    ORBextractor x2 -> ComputeStereoMatches -> SearchByProjection(last frame) -> PoseOptimization(VIO)
+    -> SearchByProjection(local map) -> PoseOptimization(VIO, bComputeMarg)
+LocalBundleAdjustment is NOT in the timed region (not built yet) -- stated in config.workload.
 
-roofline: per-kernel time is measured live with HIP events on the library's own stream across the
-timed steps (vieo_orb_stage_ms); achieved = algorithmic bytes per launch / that time.
-cpu_baseline: the CPU oracle (a port of the reference path, oracle/) rebuilt -O3 -march=native on
-this host and timed on a bounded sample of the same frames, threaded like the reference (one thread
-per camera, src/Frame.cc:259-278).
+One process per GPU (the driver launches N>1 through torch.distributed.run).  A *step* is one pass
+of that path over a batch of B independent frames that already sit in HBM; ranks shard frames
+with no data-path collective ("weak" scaling: B frames per rank per step).  Rank 0 prints ONE
+JSON line.
+
+roofline: stage/kernel time is measured live with HIP events on the library's own stream across
+the timed steps; achieved = algorithmic bytes per launch / average launch duration of
+the dominant kernel.  cpu_baseline: the CPU oracle (a port of the reference path, oracle/) rebuilt
+-O3 -march=native on this host and timed on a bounded sample of the same frames, threaded like the
+reference (one thread per camera for extraction, src/Frame.cc:259-278; the rest on one thread).
 """
 import argparse
 import json
@@ -30,72 +35,92 @@ sys.path.insert(0, ROOT)
 W, H = 752, 480          # EuRoC (Examples/Stereo/EuRoC/EuRoC_VIO.yaml:68-69)
 NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH = 1200, 1.2, 8, 20, 7   # EuRoC_VIO.yaml:138-151
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BOUNDS = np.array([0, W, 0, H], np.float32)
 
 
 def level_sizes():
-    s, out = np.float32(1.0), []
-    inv = []
-    for l in range(NLEVELS):
+    s, inv = np.float32(1.0), []
+    for _ in range(NLEVELS):
         inv.append(np.float32(1.0) / s)
         s = np.float32(s * np.float64(np.float32(SCALE)))
-    for l in range(NLEVELS):
-        out.append((int(np.rint(np.float32(W) * inv[l])), int(np.rint(np.float32(H) * inv[l]))))
-    return out
+    return [(int(np.rint(np.float32(W) * i)), int(np.rint(np.float32(H) * i))) for i in inv]
 
 
 def algorithmic_bytes_per_image():
-    """DESIGN.md 'algorithmic bytes': what each kernel must move per camera image."""
+    """DESIGN.md 'algorithmic bytes': what each extractor kernel must move per camera image."""
     px = [w * h for w, h in level_sizes()]
-    n_kp = NFEAT
     return {
         "pyramid": sum(px[l - 1] + px[l] for l in range(1, NLEVELS)),   # read l-1, write l
         "fast": sum(px),                                                # every level read once
         "blur": 2 * sum(px),                                            # read + write every level
         "quadtree": 0,                                                  # candidate lists, L2-resident
-        "describe": n_kp * (709 + 512 + 28 + 32),                       # disc + 512 taps + outputs
-        # SURVEY 8d whole-extractor figure: input + levels 1.. + outputs
-        "total": px[0] + sum(px[1:]) + n_kp * 60,
+        "describe": NFEAT * (709 + 512 + 28 + 32),                      # disc + 512 taps + outputs
+        "total": px[0] + sum(px[1:]) + NFEAT * 60,                      # SURVEY 8d whole-extractor figure
     }
 
 
-def make_frames(n_pairs, seed0=1000):
-    from vieo_slam_amd import synth
-    base = min(n_pairs, 8)
-    pairs = [synth.synth_stereo_pair(seed0 + i, W, H)[:2] for i in range(base)]
-    imgs = np.empty((n_pairs, 2, H, W), np.uint8)
-    for i in range(n_pairs):
-        l, r = pairs[i % base]
-        if i >= base:  # cheap distinct variants: shifted content + fresh sensor noise
-            sh = 3 * (i // base)
-            rng = np.random.default_rng(seed0 + 7000 + i)
-            l = np.clip(np.roll(l, sh, 1).astype(np.int16) + rng.integers(-2, 3, l.shape), 0, 255)
-            r = np.clip(np.roll(r, sh, 1).astype(np.int16) + rng.integers(-2, 3, r.shape), 0, 255)
-        imgs[i, 0], imgs[i, 1] = l, r
-    return imgs
-
-
-def cpu_baseline(imgs, budget_s=12.0):
-    """Reference-shaped CPU timing: one thread per camera runs the oracle extractor."""
+def cpu_baseline(P, budget_s=15.0):
+    """The same chain on the host with the CPU oracle: 2 threads for extraction, 1 for the rest."""
     from tests import oracle_lib
+    from vieo_slam_amd import synth_scene as sc
+    from vieo_slam_amd.ba_types import POSE_OBS_DTYPE, SBP_CAMERA_DTYPE
     try:
         path = oracle_lib.build(native=True)
     except Exception:
         path = oracle_lib.build(native=False)
     orc = oracle_lib.Oracle(path)
     ex = [orc.extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH) for _ in range(2)]
+    cams = P.d_cams.download(SBP_CAMERA_DTYPE, (P.B,))
+    xyz = P.d_xyz.download(np.float32, (P.B, 2 * P.cap, 3))
+    cap = P.cap
+
+    def obs_from(mp, b, k, ur):
+        idx = np.nonzero(mp >= 0)[0]
+        o = np.zeros(len(idx), POSE_OBS_DTYPE)
+        o["Xw"] = xyz[b][mp[idx]]
+        o["u"], o["v"], o["ur"] = k["x"][idx], k["y"][idx], ur[idx]
+        o["inv_sigma2"] = P.inv_sigma2[k["octave"][idx]]
+        return o, idx
+
     n_done, t0 = 0, time.perf_counter()
-    while n_done < len(imgs):
-        pair = imgs[n_done]
-        th = [threading.Thread(target=ex[c], args=(pair[c],)) for c in range(2)]
+    while n_done < P.B:
+        b = n_done
+        out = [None, None]
+
+        def run(c):
+            out[c] = ex[c](P.imgs_host[b, c])
+        th = [threading.Thread(target=run, args=(c,)) for c in range(2)]
         [t.start() for t in th]
         [t.join() for t in th]
+        (_, k1, d1), (_, kr, dr) = out
+        ur, _ = orc.stereo_match(ex[0], ex[1], k1, d1, kr, dr, sc.BASELINE, sc.BF)
+        n0 = int(P.f1_host[b]["base"]["n_obs"] * 0 + np.count_nonzero(np.any(P.pts_host[b]["desc"] != 0, axis=1)))
+        q1 = orc.sbp_project_last_frame(P.pts_host[b][:n0], cams[b:b + 1])
+        _, a1 = orc.search_by_projection(0, q1, k1, ur, d1, None, BOUNDS)
+        mp = np.where(a1 >= 0, a1, -1)
+        o1, i1 = obs_from(mp, b, k1, ur)
+        F1 = P.f1_host[b:b + 1].copy()
+        F1[0]["base"]["n_obs"] = len(o1)
+        r1, ol1 = orc.pose_optimization_vio(F1, o1)
+        mp[i1[ol1 != 0]] = -1
+        taken = (mp >= 0).astype(np.uint8)
+        _, a2 = orc.search_by_projection(1, P.q2_host[b][:n0], k1, ur, d1, taken, BOUNDS, nn_ratio=0.8)
+        mp = np.where(a2 >= 0, cap + a2, mp)
+        o2, _ = obs_from(mp, b, k1, ur)
+        F2 = F1.copy()
+        F2[0]["base"]["nav"] = r1["base"]["nav"]
+        F2[0]["base"]["n_obs"] = len(o2)
+        F2[0]["compute_marg"] = 1
+        orc.pose_optimization_vio(F2, o2)
         n_done += 1
         if time.perf_counter() - t0 > budget_s and n_done >= 4:
             break
     dt = time.perf_counter() - t0
     return {"value": n_done / dt, "unit": "frames/s", "cores": 2, "kind": "port",
-            "sample": "%d synthetic stereo frames 752x480, ORB extraction x2 cameras, oracle "
-                      "-O3 -march=native, 1 thread per camera (nproc=%d)" % (n_done, os.cpu_count())}
+            "sample": "%d of the benchmark's stereo frames through the same chain with the CPU oracle "
+                      "(-O3 -march=native): extraction on 1 thread per camera, stereo match / "
+                      "projection searches / 2x PoseOptimization on one thread (nproc=%d)"
+                      % (n_done, os.cpu_count())}
 
 
 def main():
@@ -104,6 +129,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="stereo frames per GPU per step")
+    ap.add_argument("--base-cases", type=int, default=8, help="distinct rendered scenes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -116,34 +142,28 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from vieo_slam_amd._lib import DeviceBuffer
-    from vieo_slam_amd.orb_extractor import ORBextractor, STAGES
+    from vieo_slam_amd.orb_extractor import STAGES as ORB_STAGES
+    from vieo_slam_amd.pipeline import FramePipeline, make_cases
 
     B = a.batch
-    imgs = make_frames(B, seed0=1000 + 100000 * rank)
+    cases = make_cases(min(a.base_cases, B), seed0=1 + 1000 * rank)
+    P = FramePipeline(cases, B, seed=rank)
     n_img = 2 * B
-    ext = ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
-    cap = ext.max_keypoints()
-    d_img = DeviceBuffer(imgs.nbytes)
-    d_img.upload(imgs)
-    d_kp, d_desc, d_cnt = DeviceBuffer(n_img * cap * 28), DeviceBuffer(n_img * cap * 32), DeviceBuffer(n_img * 8)
-
-    def step():
-        ext.extract_batch_device(d_img.ptr, n_img, W, H, W, W * H, d_kp.ptr, d_desc.ptr, cap, d_cnt.ptr)
 
     def sync_all():
-        ext.sync()
+        P.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
     for _ in range(a.warmup):
-        step()
-    ext.enable_timing(True)
+        P.step()
+    P.enable_timing(True)
+    P.ext.enable_timing(True)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        P.step()
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -151,13 +171,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    stage = ext.stage_ms_all()
-    cnt = d_cnt.download(np.int32, (n_img, 2))
+    stage = P.stage_ms_all()
+    orb = P.ext.stage_ms_all()
+    res = P.results()
     if rank == 0:
-        avg = {k: float(np.mean([s[k] for s in stage])) for k in STAGES}
+        avg = {k: float(np.mean([s[k] for s in stage])) for k in P.STAGES}
+        oavg = {k: float(np.mean([s[k] for s in orb])) for k in ORB_STAGES}
         ab = algorithmic_bytes_per_image()
-        dom = max((k for k in STAGES if k != "total"), key=lambda k: avg[k])
-        achieved = ab[dom] * n_img / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
+        kern = {("orb." + k): v for k, v in oavg.items() if k != "total"}
+        dom = max(kern, key=kern.get)
+        dk = dom.split(".")[1]
+        achieved = ab[dk] * n_img / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
+        r2 = res["r2"]
+        perr = [np.linalg.norm(r2[b]["base"]["nav"]["p"] - P.truth[b]["p"]) for b in range(B)]
         out = {
             "metric": "frontend+localBA frames/sec on EuRoC MH05 stereo-VIO; ATE vs ref",
             "value": B * a.steps * world / dt,
@@ -165,22 +191,28 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8 (extract/match) + f64 (pose optimisation)", "data": "synthetic",
             "config": {
-                "workload": "EuRoC-shaped synthetic stereo 752x480, 1200 feats, 1.2x8 levels, FAST 20/7: "
-                            "ORBextractor x2 cameras per frame ONLY; stereo match, projection search, "
-                            "PoseOptimization and LocalBA are NOT yet in the timed region",
-                "stereo_frames_per_gpu_per_step": B, "parallelism": "frames sharded 1 batch/GPU, no collective",
-                "mean_keypoints_per_image": float(cnt[:, 0].mean()),
+                "workload": "BASELINE configs[1] 'EuRoC MH05 stereo-VIO, 1200 feats, PoseOptimization only': "
+                            "synthetic rendered stereo-inertial frames 752x480, 1.2x8 levels, FAST 20/7; per "
+                            "frame ORBextractor x2 + ComputeStereoMatches + SearchByProjection(last frame) + "
+                            "PoseOptimization(VIO) + SearchByProjection(local map) + PoseOptimization(VIO, marg). "
+                            "LocalBundleAdjustment is NOT in the timed region (not built yet)",
+                "stereo_frames_per_gpu_per_step": B,
+                "parallelism": "frames sharded, one batch per GPU, no collective",
+                "mean_keypoints_per_image": float(res["counts"][:, 0].mean()),
+                "mean_pose_inliers": float(np.mean(r2["base"]["n_inliers"])),
+                "median_position_error_vs_truth_m": float(np.median(perr)),
             },
             "stage_ms_per_step": avg,
+            "extractor_kernel_ms_per_step": oavg,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": ab[dom] * n_img,
-                         "avg_launch_ms": avg[dom]},
+                         "algorithmic_bytes_per_launch": ab[dk] * n_img,
+                         "avg_launch_ms": kern[dom]},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(imgs)
+            out["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

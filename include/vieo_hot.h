@@ -38,6 +38,11 @@ int vieo_dev_free(void* d_ptr);
 int vieo_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int vieo_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 int vieo_device_synchronize(void);
+/* HIP events on a given stream (NULL = default): kernel timing without any other runtime. */
+int vieo_event_create(void** ev);
+int vieo_event_destroy(void* ev);
+int vieo_event_record(void* ev, void* stream);
+int vieo_event_elapsed_ms(void* ev0, void* ev1, float* ms);
 
 /* ---------------------------------------------------------------- ORB extractor ------------
  * Replaces VIEO_SLAM::ORBextractor (include/ORBextractor.h:27-80, src/ORBextractor.cc:391-1081).

@@ -27,6 +27,10 @@ _SIGS = {
     "vieo_memcpy_h2d": (c_i, [c_p, c_p, c_sz]),
     "vieo_memcpy_d2h": (c_i, [c_p, c_p, c_sz]),
     "vieo_device_synchronize": (c_i, []),
+    "vieo_event_create": (c_i, [P(c_p)]),
+    "vieo_event_destroy": (c_i, [c_p]),
+    "vieo_event_record": (c_i, [c_p, c_p]),
+    "vieo_event_elapsed_ms": (c_i, [c_p, c_p, P(c_f)]),
     "vieo_orb_create": (c_i, [P(c_p), c_i, c_f, c_i, c_i, c_i]),
     "vieo_orb_destroy": (None, [c_p]),
     "vieo_orb_levels": (c_i, [c_p]),

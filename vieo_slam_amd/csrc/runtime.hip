@@ -63,6 +63,26 @@ int vieo_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
   VIEO_HIP_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
   return VIEO_OK;
 }
+int vieo_event_create(void** ev) {
+  if (!ev) return VIEO_E_INVALID;
+  hipEvent_t e;
+  VIEO_HIP_CHECK(hipEventCreate(&e));
+  *ev = (void*)e;
+  return VIEO_OK;
+}
+int vieo_event_destroy(void* ev) {
+  if (ev) VIEO_HIP_CHECK(hipEventDestroy((hipEvent_t)ev));
+  return VIEO_OK;
+}
+int vieo_event_record(void* ev, void* stream) {
+  VIEO_HIP_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+  return VIEO_OK;
+}
+int vieo_event_elapsed_ms(void* ev0, void* ev1, float* ms) {
+  VIEO_HIP_CHECK(hipEventSynchronize((hipEvent_t)ev1));
+  VIEO_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)ev0, (hipEvent_t)ev1));
+  return VIEO_OK;
+}
 int vieo_device_synchronize(void) {
   VIEO_HIP_CHECK(hipDeviceSynchronize());
   return VIEO_OK;

@@ -125,19 +125,57 @@ class FramePipeline:
         self.f1_host, self.pts_host, self.q2_host = f1, pts, q2
         check(lib().vieo_device_synchronize())
 
+    # ---- HIP-event stamps between stage groups (ring of 64 steps), on the pipeline's stream
+    def enable_timing(self, on=True):
+        self._ev = None
+        self._ev_steps = 0
+        if on:
+            self._ev = []
+            for _ in range(64):
+                row = []
+                for _ in range(len(self.STAGES)):
+                    e = ctypes.c_void_p()
+                    check(lib().vieo_event_create(ctypes.byref(e)))
+                    row.append(e)
+                self._ev.append(row)
+
+    def _stamp(self, k):
+        if getattr(self, "_ev", None):
+            check(lib().vieo_event_record(self._ev[self._ev_steps % 64][k], self.stream))
+
+    def stage_ms_all(self):
+        out = []
+        n = min(self._ev_steps, 64)
+        for s in range(self._ev_steps - n, self._ev_steps):
+            row = self._ev[s % 64]
+            ms = {}
+            for k, name in enumerate(self.STAGES[:-1]):
+                v = ctypes.c_float()
+                check(lib().vieo_event_elapsed_ms(row[k], row[k + 1], ctypes.byref(v)))
+                ms[name] = v.value
+            v = ctypes.c_float()
+            check(lib().vieo_event_elapsed_ms(row[0], row[-1], ctypes.byref(v)))
+            ms["total"] = v.value
+            out.append(ms)
+        return out
+
     def step(self):
         L, B, cap, st = lib(), self.B, self.cap, self.stream
+        self._stamp(0)
         self.ext.extract_batch_device(self.d_img.ptr, self.n_img, W, H, W, W * H, self.d_kp.ptr,
                                       self.d_desc.ptr, cap, self.d_cnt.ptr)
+        self._stamp(1)
         check(L.vieo_stereo_match_rectified_batch_device(self.ext._h, B, self.d_kp.ptr, self.d_desc.ptr,
                                                          self.d_cnt.ptr, cap, sc.BASELINE, sc.BF,
                                                          self.d_ur.ptr, self.d_dp.ptr), "stereo")
+        self._stamp(2)
         check(L.vieo_sbp_project_last_frame_batch_device(self.d_pts.ptr, self.d_npts.ptr, cap, B,
                                                          self.d_cams.ptr, self.d_q1.ptr, st), "project")
         check(L.vieo_search_by_projection_batch_device(0, self.d_q1.ptr, self.d_npts.ptr, cap, B,
                                                        self.d_kp.ptr, self.d_ur.ptr, self.d_desc.ptr,
                                                        None, self.d_cnt.ptr, cap, 0, 2, self.bounds, 0.9,
                                                        1, self.d_assign.ptr, self.d_nm.ptr, st), "sbp1")
+        self._stamp(3)
         check(L.vieo_track_merge_assign_batch_device(self.d_assign.ptr, self.d_mpref.ptr, self.d_cnt.ptr,
                                                      cap, B, 0, 2, 0, 1, st))
         check(L.vieo_track_build_obs_batch_device(self.d_mpref.ptr, self.d_xyz.ptr, 2 * cap, self.d_kp.ptr,
@@ -146,6 +184,7 @@ class FramePipeline:
                                                   self.d_f1.ptr, 1, st))
         check(L.vieo_pose_optimization_vio_batch_device(self.d_f1.ptr, B, self.d_obs.ptr, self.d_outl.ptr,
                                                         self.d_r1.ptr, st), "pose1")
+        self._stamp(4)
         check(L.vieo_track_after_pose_batch_device(self.d_mpref.ptr, self.d_obskey.ptr, self.d_outl.ptr,
                                                    self.d_f1.ptr, self.d_r1.ptr, 1, cap, B, self.d_f2.ptr,
                                                    self.d_taken.ptr, st))
@@ -154,6 +193,7 @@ class FramePipeline:
                                                        self.d_taken.ptr, self.d_cnt.ptr, cap, 0, 2,
                                                        self.bounds, 0.8, 1, self.d_assign.ptr,
                                                        self.d_nm.ptr, st), "sbp2")
+        self._stamp(5)
         check(L.vieo_track_merge_assign_batch_device(self.d_assign.ptr, self.d_mpref.ptr, self.d_cnt.ptr,
                                                      cap, B, 0, 2, cap, 0, st))
         check(L.vieo_track_build_obs_batch_device(self.d_mpref.ptr, self.d_xyz.ptr, 2 * cap, self.d_kp.ptr,
@@ -162,6 +202,9 @@ class FramePipeline:
                                                   self.d_f2.ptr, 1, st))
         check(L.vieo_pose_optimization_vio_batch_device(self.d_f2.ptr, B, self.d_obs.ptr, self.d_outl.ptr,
                                                         self.d_r2.ptr, st), "pose2")
+        self._stamp(6)
+        if getattr(self, "_ev", None):
+            self._ev_steps += 1
 
     def sync(self):
         self.ext.sync()
