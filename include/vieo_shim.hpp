@@ -1,0 +1,93 @@
+// vieo_shim.hpp -- VIEO_SLAM::ORBextractor with the reference's public interface
+// (include/ORBextractor.h:27-80) implemented on the C-ABI of vieo_hot.h, so src/Frame.cc and
+// src/Tracking.cc compile and behave unchanged when this header replaces include/ORBextractor.h
+// and libvieo_hot.so replaces src/ORBextractor.cc.  Needs OpenCV headers (cv::Mat, cv::KeyPoint);
+// where they are absent (this repository's image) the file compiles to nothing.
+// ORBmatcher / Optimizer forwarding is shown in INTEGRATION.md.
+#pragma once
+#if defined(__has_include)
+#if __has_include(<opencv2/core/core.hpp>)
+#define VIEO_SHIM_HAVE_OPENCV 1
+#endif
+#endif
+
+#ifdef VIEO_SHIM_HAVE_OPENCV
+#include <opencv2/core/core.hpp>
+
+#include <cassert>
+#include <stdexcept>
+#include <vector>
+
+#include "vieo_hot.h"
+
+namespace VIEO_SLAM {
+
+class ORBextractor {
+ public:
+  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+      : nlevels_(nlevels) {
+    if (vieo_orb_create(&h_, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) != VIEO_OK)
+      throw std::runtime_error(vieo_last_error());  // no CPU fallback
+    mvImagePyramid.resize(nlevels);
+  }
+  ~ORBextractor() { vieo_orb_destroy(h_); }
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
+
+  // ORBextractor.cc:968-1058; mask is ignored as in the reference
+  int operator()(cv::InputArray _image, cv::InputArray, std::vector<cv::KeyPoint>& keypoints,
+                 cv::OutputArray descriptors, const std::vector<int>* pvLappingArea = nullptr) {
+    if (_image.empty()) return -1;
+    cv::Mat image = _image.getMat();
+    assert(image.type() == CV_8UC1);
+    const int cap = vieo_orb_max_keypoints(h_);
+    static_assert(sizeof(cv::KeyPoint) == sizeof(vieo_keypoint), "cv::KeyPoint layout");
+    keypoints.resize(cap);
+    cv::Mat desc(cap, 32, CV_8U);
+    int n = 0, mono = 0;
+    const int rc = vieo_orb_extract(h_, image.data, image.cols, image.rows, (int)image.step,
+                                    pvLappingArea ? pvLappingArea->data() : nullptr,
+                                    reinterpret_cast<vieo_keypoint*>(keypoints.data()), desc.data, cap,
+                                    &n, &mono);
+    if (rc == VIEO_E_EMPTY) return -1;
+    if (rc != VIEO_OK) throw std::runtime_error(vieo_last_error());
+    keypoints.resize(n);
+    if (n == 0)
+      descriptors.release();
+    else
+      desc.rowRange(0, n).copyTo(descriptors);
+    // mvImagePyramid (ORBextractor.h:54): ROI views into bordered planes, valid until the next call
+    for (int l = 0; l < nlevels_; ++l) {
+      int w, h;
+      vieo_orb_level_size(h_, l, &w, &h);
+      cv::Mat temp(h + 38, w + 38, CV_8UC1);
+      vieo_orb_get_level(h_, 0, l, 1, temp.data, (int)temp.step);
+      mvImagePyramid[l] = temp(cv::Rect(19, 19, w, h));
+    }
+    return mono;
+  }
+
+  int inline GetLevels() { return vieo_orb_levels(h_); }
+  float inline GetScaleFactor() { return vieo_orb_scale_factor(h_); }
+  std::vector<float> inline GetScaleFactors() { return tab(vieo_orb_scale_factors); }
+  std::vector<float> inline GetInverseScaleFactors() { return tab(vieo_orb_inv_scale_factors); }
+  std::vector<float> inline GetScaleSigmaSquares() { return tab(vieo_orb_level_sigma2); }
+  std::vector<float> inline GetInverseScaleSigmaSquares() { return tab(vieo_orb_inv_level_sigma2); }
+
+  std::vector<cv::Mat> mvImagePyramid;
+  vieo_orb* handle() { return h_; }  // for the device-side stereo matcher
+
+ private:
+  std::vector<float> tab(int (*fn)(const vieo_orb*, float*)) {
+    std::vector<float> v(nlevels_);
+    fn(h_, v.data());
+    return v;
+  }
+  vieo_orb* h_ = nullptr;
+  int nlevels_;
+};
+
+}  // namespace VIEO_SLAM
+#endif  // VIEO_SHIM_HAVE_OPENCV
