@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Runs only the batched extractor a few times (for rocprofv3 counter passes)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from vieo_slam_amd import synth
+from vieo_slam_amd._lib import DeviceBuffer
+from vieo_slam_amd.orb_extractor import ORBextractor
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+base = [synth.synth_image(1000 + i) for i in range(8)]
+imgs = np.stack([base[i % 8] for i in range(B)])
+e = ORBextractor(1200, 1.2, 8, 20, 7)
+cap = e.max_keypoints()
+d_img = DeviceBuffer(imgs.nbytes); d_img.upload(imgs)
+d_kp, d_desc, d_cnt = DeviceBuffer(B * cap * 28), DeviceBuffer(B * cap * 32), DeviceBuffer(B * 8)
+e.enable_timing(True)
+for _ in range(reps):
+    e.extract_batch_device(d_img.ptr, B, 752, 480, 752, 752 * 480, d_kp.ptr, d_desc.ptr, cap, d_cnt.ptr)
+e.sync()
+ms = e.stage_ms_all()
+print({k: round(float(np.mean([m[k] for m in ms[1:]])), 4) for k in ms[0]})

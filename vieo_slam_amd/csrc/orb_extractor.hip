@@ -99,9 +99,28 @@ __device__ __forceinline__ int fast_strength(const uint8_t* t, int p) {
   return max(max(A, -B), 0);
 }
 
+// Necessary condition for strength > t, evaluated on the 8 even ring positions: an arc of 9
+// contiguous ring pixels always contains >= 4 consecutive even positions, so 4 consecutive even
+// positions must all be darker (v - x > t) or all brighter (x - v > t).
+__device__ __forceinline__ bool fast_quick(const uint8_t* t, int p, int th) {
+  const int v = t[0];
+  const int e0 = v - t[3 * p], e1 = v - t[2 * p + 2], e2 = v - t[3], e3 = v - t[-2 * p + 2];
+  const int e4 = v - t[-3 * p], e5 = v - t[-2 * p - 2], e6 = v - t[-3], e7 = v - t[2 * p - 2];
+  unsigned dk = (e0 > th) | ((e1 > th) << 1) | ((e2 > th) << 2) | ((e3 > th) << 3) |
+                ((e4 > th) << 4) | ((e5 > th) << 5) | ((e6 > th) << 6) | ((e7 > th) << 7);
+  unsigned br = (e0 < -th) | ((e1 < -th) << 1) | ((e2 < -th) << 2) | ((e3 < -th) << 3) |
+                ((e4 < -th) << 4) | ((e5 < -th) << 5) | ((e6 < -th) << 6) | ((e7 < -th) << 7);
+  dk |= dk << 8;
+  br |= br << 8;
+  const unsigned a = dk & (dk >> 1) & (dk >> 2) & (dk >> 3);
+  const unsigned b = br & (br >> 1) & (br >> 2) & (br >> 3);
+  return ((a | b) & 0xFFu) != 0;
+}
+
 __global__ void __launch_bounds__(64)
 k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __restrict__ cell_keys,
-       int* __restrict__ cell_counts, int iniTh, int minTh, int tpitch, int tile_bytes) {
+       int* __restrict__ cell_counts, int iniTh, int minTh, int tpitch, int tile_bytes,
+       int score_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const CellDesc cd = cells[c];
@@ -109,6 +128,7 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
   const uint8_t* src = plane_ptr(P, I, b, cd.level, &pitch);
   uint8_t* tile = smem;
   uint8_t* sc = smem + tile_bytes;
+  unsigned short* cand = (unsigned short*)(smem + tile_bytes + score_bytes);
   const int x0a = cd.x0 & ~3;
   const int ndw = ((cd.x0 + cd.cw + 3) >> 2) - (x0a >> 2);
   const float inv_ndw = 1.0f / (float)ndw;
@@ -128,7 +148,27 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
   __syncthreads();
   const int xo = cd.x0 - x0a;
   const float inv_vw = npx > 0 ? 1.0f / (float)vw : 0.f;
-  for (int p = lane; p < npx; p += 64) {
+  // ---- pass A: high-speed test, ordered compaction of the surviving pixel indices
+  const int tq = min(iniTh, minTh);
+  int nc = 0;
+  for (int p0 = 0; p0 < npx; p0 += 64) {
+    const int p = p0 + lane;
+    bool pass = false;
+    if (p < npx) {
+      int y = (int)((float)p * inv_vw);
+      int x = p - y * vw;
+      if (x >= vw) y++, x -= vw;
+      if (x < 0) y--, x += vw;
+      pass = fast_quick(tile + (y + 3) * tpitch + (x + 3 + xo), tpitch, tq);
+    }
+    const unsigned long long m = __ballot(pass);
+    if (pass) cand[nc + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+    nc += __popcll(m);
+  }
+  __syncthreads();
+  // ---- pass B: exact strength of the candidates only
+  for (int i = lane; i < nc; i += 64) {
+    const int p = cand[i];
     int y = (int)((float)p * inv_vw);
     int x = p - y * vw;
     if (x >= vw) y++, x -= vw;
@@ -137,15 +177,17 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
     sc[(y + 1) * sp + x + 1] = (uint8_t)r;
   }
   __syncthreads();
+  // ---- pass C: 3x3 non-maximum suppression over the candidates (still in row-major order)
   unsigned* out = cell_keys + ((size_t)b * P.ncells + c) * P.cell_cap;
   int base = 0;
   for (int pass = 0; pass < 2 && base == 0; pass++) {
     const int th = pass == 0 ? iniTh : minTh;
-    for (int p0 = 0; p0 < npx; p0 += 64) {
-      const int p = p0 + lane;
+    for (int i0 = 0; i0 < nc; i0 += 64) {
+      const int i = i0 + lane;
       bool keep = false;
       unsigned key = 0;
-      if (p < npx) {
+      if (i < nc) {
+        const int p = cand[i];
         int y = (int)((float)p * inv_vw);
         int x = p - y * vw;
         if (x >= vw) y++, x -= vw;
@@ -273,44 +315,75 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 
+// Tile = 64 x 32 outputs.  The source tile (38 rows x 72 bytes, column 0 <-> x = ox - 4) is staged
+// as dwords; the horizontal pass produces 4 outputs per work item with v_alignbyte + 2x
+// v_dot4_u32_u8 each (exact 16-bit results, stored packed), the vertical pass 4 outputs per work
+// item from 7 x 8-byte LDS reads.  The sum is the same integer as OpenCV's, only the order of the
+// two exact passes' additions differs.
 __global__ void __launch_bounds__(256)
 k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles) {
-  __shared__ uint8_t s_src[(kBlurTH + 6) * (kBlurTW + 8)];
-  __shared__ unsigned short s_h[(kBlurTH + 6) * kBlurTW];
+  constexpr int SP = 72, SH = kBlurTH + 6;  // source pitch (bytes), rows
+  __shared__ __attribute__((aligned(16))) uint8_t s_src[SH * SP];
+  __shared__ __attribute__((aligned(16))) unsigned short s_h[SH * kBlurTW];
   const BlurTile t = tiles[blockIdx.x];
   const int b = blockIdx.y, tid = threadIdx.x;
   const LevelDesc& D = P.lv[t.level];
   int pitch;
   const uint8_t* src = plane_ptr(P, I, b, t.level, &pitch);
   const int ox = t.tx * kBlurTW, oy = t.ty * kBlurTH;
-  const int SW = kBlurTW + 6, SP = kBlurTW + 8, SH = kBlurTH + 6;
-  for (int idx = tid; idx < SH * SW; idx += 256) {
-    const int r = idx / SW, c = idx - r * SW;
-    const int gy = reflect101(min(oy + r - 3, D.h + 2), D.h);
-    const int gx = reflect101(min(ox + c - 3, D.w + 2), D.w);
-    s_src[r * SP + c] = src[(size_t)gy * pitch + gx];
+  const bool interior = ox >= 4 && ox + 68 <= D.w && oy >= 3 && oy + kBlurTH + 3 <= D.h &&
+                        ((pitch & 3) == 0) && ((((uintptr_t)src) & 3) == 0);
+  if (interior) {
+    for (int idx = tid; idx < SH * (SP / 4); idx += 256) {
+      const int r = idx / (SP / 4), c4 = idx - r * (SP / 4);
+      ((unsigned*)s_src)[idx] = *(const unsigned*)(src + (size_t)(oy + r - 3) * pitch + ox - 4 + 4 * c4);
+    }
+  } else {
+    for (int idx = tid; idx < SH * SP; idx += 256) {
+      const int r = idx / SP, c = idx - r * SP;
+      const int gy = reflect101(min(oy + r - 3, D.h + 2), D.h);
+      const int gx = reflect101(min(ox + c - 4, D.w + 2), D.w);
+      s_src[idx] = src[(size_t)gy * pitch + gx];
+    }
   }
   __syncthreads();
-  for (int idx = tid; idx < SH * kBlurTW; idx += 256) {
-    const int r = idx / kBlurTW, c = idx - r * kBlurTW;
-    const uint8_t* s = s_src + r * SP + c;
-    const int v = 18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 48 * (s[2] + s[4]) + 56 * s[3];
-    s_h[r * kBlurTW + c] = (unsigned short)v;
+  const unsigned K0123 = 18u | (34u << 8) | (48u << 16) | (56u << 24);
+  const unsigned K456 = 48u | (34u << 8) | (18u << 16);
+  for (int idx = tid; idx < SH * (kBlurTW / 4); idx += 256) {
+    const int r = idx / (kBlurTW / 4), g = idx - r * (kBlurTW / 4);
+    const unsigned* w = (const unsigned*)(s_src + r * SP) + g;
+    const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+    // output column c = 4g + j uses source bytes 4g + 1 + j .. 4g + 7 + j
+    const unsigned a0 = __builtin_amdgcn_alignbyte(w1, w0, 1), b0 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+    const unsigned a1 = __builtin_amdgcn_alignbyte(w1, w0, 2), b1 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+    const unsigned a2 = __builtin_amdgcn_alignbyte(w1, w0, 3), b2 = __builtin_amdgcn_alignbyte(w2, w1, 3);
+    const unsigned h0 = __builtin_amdgcn_udot4(b0, K456, __builtin_amdgcn_udot4(a0, K0123, 0u, false), false);
+    const unsigned h1 = __builtin_amdgcn_udot4(b1, K456, __builtin_amdgcn_udot4(a1, K0123, 0u, false), false);
+    const unsigned h2 = __builtin_amdgcn_udot4(b2, K456, __builtin_amdgcn_udot4(a2, K0123, 0u, false), false);
+    const unsigned h3 = __builtin_amdgcn_udot4(w2, K456, __builtin_amdgcn_udot4(w1, K0123, 0u, false), false);
+    uint2 o;
+    o.x = h0 | (h1 << 16);
+    o.y = h2 | (h3 << 16);
+    *(uint2*)(s_h + r * kBlurTW + 4 * g) = o;
   }
   __syncthreads();
   uint8_t* dst = I.blur + (size_t)b * I.blur_img + D.boff;
-  for (int idx = tid; idx < kBlurTH * kBlurTW / 4; idx += 256) {
+  for (int idx = tid; idx < kBlurTH * (kBlurTW / 4); idx += 256) {
     const int r = idx / (kBlurTW / 4), c4 = (idx - r * (kBlurTW / 4)) * 4;
     const int gy = oy + r, gx = ox + c4;
     if (gy >= D.h || gx >= D.w) continue;
-    unsigned outv = 0;
+    unsigned acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    const int kk[7] = {18, 34, 48, 56, 48, 34, 18};
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const unsigned short* h = s_h + r * kBlurTW + c4 + j;
-      const unsigned v = 18u * (h[0] + h[6 * kBlurTW]) + 34u * (h[kBlurTW] + h[5 * kBlurTW]) +
-                         48u * (h[2 * kBlurTW] + h[4 * kBlurTW]) + 56u * h[3 * kBlurTW];
-      outv |= (((v + (1u << 15)) >> 16) & 0xFFu) << (8 * j);
+    for (int k = 0; k < 7; k++) {
+      const uint2 v = *(const uint2*)(s_h + (r + k) * kBlurTW + c4);
+      acc0 += kk[k] * (v.x & 0xFFFFu);
+      acc1 += kk[k] * (v.x >> 16);
+      acc2 += kk[k] * (v.y & 0xFFFFu);
+      acc3 += kk[k] * (v.y >> 16);
     }
+    const unsigned outv = (((acc0 + (1u << 15)) >> 16) & 0xFFu) | ((((acc1 + (1u << 15)) >> 16) & 0xFFu) << 8) |
+                          ((((acc2 + (1u << 15)) >> 16) & 0xFFu) << 16) | ((((acc3 + (1u << 15)) >> 16) & 0xFFu) << 24);
     *(unsigned*)(dst + (size_t)gy * D.pitch + gx) = outv;
   }
 }
@@ -638,7 +711,8 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
   // FAST LDS: cell tile (dword-aligned columns) + strength tile
   e->tpitch = align_up(max_cw + 3, 4) + 4;
   e->tile_bytes = align_up(e->tpitch * max_ch, 16);
-  e->fast_lds = e->tile_bytes + align_up((max_cw - 4) * (max_ch - 4), 16) + 16;
+  e->score_bytes = align_up((max_cw - 4) * (max_ch - 4), 16) + 16;
+  e->fast_lds = e->tile_bytes + e->score_bytes + align_up(2 * (max_cw - 6) * (max_ch - 6), 16) + 16;
   e->qt_lds = 16 * e->scap_max + (4 + 16 + 4 + 4 + 4) * ncap_max + 64 + (2 * 4 + 8 + 2 * 6) * ncap_max +
               ncap_max + 64;
   // ---- device buffers
@@ -725,7 +799,8 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
   STAMP();
   hipLaunchKernelGGL(k_fast, dim3(P.ncells, B), dim3(64), e->fast_lds, st, P, I,
                      e->d_cells.as<CellDesc>(), e->d_cell_keys.as<unsigned>(),
-                     e->d_cell_counts.as<int>(), e->iniTh, e->minTh, e->tpitch, e->tile_bytes);
+                     e->d_cell_counts.as<int>(), e->iniTh, e->minTh, e->tpitch, e->tile_bytes,
+                     e->score_bytes);
   STAMP();
   hipLaunchKernelGGL(k_quadtree, dim3(P.nlevels, B), dim3(256), e->qt_lds, st, P,
                      e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
