@@ -323,6 +323,56 @@ int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int 
                                             const vieo_pose_obs* d_obs, uint8_t* d_outlier,
                                             vieo_vio_result* d_results, void* stream);
 
+/* ---------------------------------------------------------------- local bundle adjustment ---
+ * void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int Nlocal)
+ * (src/Optimizer.cc:1876-2307), vision-only LBA without encoder edges.  The host shim collects the
+ * window exactly as the reference does (:1880-1953) and flattens it:
+ *   key frames  : local (free unless nid_ == 0) first, then the fixed observers;
+ *   map points  : lLocalMapPoints order; XYZ float32 as stored by MapPoint;
+ *   observations: in the reference's edge insertion order = per map point, per observing key frame
+ *                 (so a point's edges are contiguous: obs must be sorted by mp).
+ * BlockSolver_6_3 semantics: points are marginalised (Schur complement, block_solver.hpp:353-486),
+ * LM as in g2o, optimize(its0=5) -> chi2 / depth outlier levels, Huber off -> optimize(its1=10).
+ * Outputs: optimised NavStates of the free key frames, float32 points, and h_erase[n_obs] = 1 for
+ * the observations the reference puts in vToErase (chi2 > 5.991 / 7.815 or non-positive depth). */
+typedef struct vieo_lba_keyframe {
+  vieo_navstate nav;
+  int32_t fixed;
+  int32_t reserved;
+} vieo_lba_keyframe;
+
+typedef struct vieo_lba_obs {
+  int32_t kf, mp;   /* indices into the key-frame / point arrays */
+  float u, v, ur;   /* ur < 0 => monocular edge */
+  float inv_sigma2;
+} vieo_lba_obs;
+
+typedef struct vieo_lba_params {
+  double Rcb[9], tcb[3];
+  float fx, fy, cx, cy, bf;
+  int32_t its0, its1;     /* 5 and 10 in the reference */
+  int32_t reserved;
+} vieo_lba_params;
+
+#define VIEO_LBA_OK 0
+#define VIEO_LBA_ABORTED 1       /* *stop was set (Optimizer.cc:2174-2186) */
+#define VIEO_LBA_NO_FREE_POSE 2  /* Optimizer.cc:1993 */
+typedef struct vieo_lba_result {
+  int32_t status;
+  int32_t n_erase;
+  int32_t lm_iterations;
+  int32_t lm_trials;
+  double chi2_initial, chi2_final; /* robust chi2 at the first / after the last accepted step */
+} vieo_lba_result;
+
+/* Host-pointer entry (synchronous).  `stop` may be NULL; it is polled before the first
+ * optimisation, between the two optimisations and between LM iterations. */
+int vieo_local_bundle_adjustment(const vieo_lba_params* params, const vieo_lba_keyframe* h_kfs,
+                                 int n_kf, const float* h_points, int n_mp,
+                                 const vieo_lba_obs* h_obs, int n_obs, volatile const int* stop,
+                                 vieo_navstate* h_navs_out, float* h_points_out, uint8_t* h_erase,
+                                 vieo_lba_result* h_result);
+
 /* ---- replay glue (device-resident batches) -------------------------------------------------
  * What Tracking.cc does between the calls above, on flattened arrays, so a batch of frames runs
  * extract -> stereo -> search -> pose optimisation with no host round trip (bench.py):

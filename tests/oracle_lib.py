@@ -48,6 +48,7 @@ class Oracle:
         L.vo_stereo_match_rectified.argtypes = [P, P, I, P, I, P, P, I, P, P, P, F, F, P, P]
         L.vo_sbp_project_last_frame.argtypes = [P, I, P, P]
         L.vo_search_by_projection.argtypes = [I, P, I, P, P, P, P, I, P, F, I, P]
+        L.vo_local_bundle_adjustment.argtypes = [P, P, I, P, I, P, I, P, P, P, P, P]
         L.vo_pose_optimization.argtypes = [P, P, P, P]
         L.vo_pose_optimization_vio.argtypes = [P, P, P, P]
         L.vo_imu_edge_eval.argtypes = [P, P, P, P, P, P, P]
@@ -81,6 +82,22 @@ class Oracle:
                                            None if tk is None else tk.ctypes.data, len(keys),
                                            b.ctypes.data, nn_ratio, int(check_ori), assign.ctypes.data)
         return n, assign[:len(keys)]
+
+    # ---- local bundle adjustment
+    def local_ba(self, params, kfs, points, obs, stop=None):
+        from vieo_slam_amd.ba_types import LBA_RESULT_DTYPE, NAVSTATE_DTYPE
+        params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
+        points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+        navs = np.zeros(len(kfs), NAVSTATE_DTYPE)
+        pts = np.zeros_like(points)
+        erase = np.zeros(max(len(obs), 1), np.uint8)
+        res = np.zeros(1, LBA_RESULT_DTYPE)
+        st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        self.L.vo_local_bundle_adjustment(params.ctypes.data, kfs.ctypes.data, len(kfs),
+                                          points.ctypes.data, len(points), obs.ctypes.data, len(obs),
+                                          None if st is None else st.ctypes.data, navs.ctypes.data,
+                                          pts.ctypes.data, erase.ctypes.data, res.ctypes.data)
+        return navs, pts, erase[:len(obs)], res[0]
 
     # ---- pose optimisation
     def pose_optimization(self, frame, obs):

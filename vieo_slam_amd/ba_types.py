@@ -38,3 +38,13 @@ VIO_FRAME_DTYPE = np.dtype([("base", POSE_FRAME_DTYPE), ("nav_last", NAVSTATE_DT
                            align=True)
 VIO_RESULT_DTYPE = np.dtype([("base", POSE_RESULT_DTYPE), ("H_marg", "<f8", 225),
                              ("has_marg", "<i4"), ("reserved", "<i4")], align=True)
+
+LBA_KEYFRAME_DTYPE = np.dtype([("nav", NAVSTATE_DTYPE), ("fixed", "<i4"), ("reserved", "<i4")], align=True)
+LBA_OBS_DTYPE = np.dtype([("kf", "<i4"), ("mp", "<i4"), ("u", "<f4"), ("v", "<f4"), ("ur", "<f4"),
+                          ("inv_sigma2", "<f4")], align=True)
+LBA_PARAMS_DTYPE = np.dtype([("Rcb", "<f8", 9), ("tcb", "<f8", 3), ("fx", "<f4"), ("fy", "<f4"),
+                             ("cx", "<f4"), ("cy", "<f4"), ("bf", "<f4"), ("its0", "<i4"),
+                             ("its1", "<i4"), ("reserved", "<i4")], align=True)
+LBA_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_erase", "<i4"), ("lm_iterations", "<i4"),
+                             ("lm_trials", "<i4"), ("chi2_initial", "<f8"), ("chi2_final", "<f8")],
+                            align=True)

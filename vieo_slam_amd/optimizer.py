@@ -4,7 +4,7 @@ pointer graphs."""
 import numpy as np
 
 from ._lib import check, lib
-from .ba_types import (POSE_FRAME_DTYPE, POSE_OBS_DTYPE, POSE_RESULT_DTYPE, VIO_FRAME_DTYPE,
+from .ba_types import (LBA_RESULT_DTYPE, NAVSTATE_DTYPE, POSE_FRAME_DTYPE, POSE_OBS_DTYPE, POSE_RESULT_DTYPE, VIO_FRAME_DTYPE,
                        VIO_RESULT_DTYPE)
 
 
@@ -35,3 +35,22 @@ class Optimizer:
         check(lib().vieo_pose_optimization_vio(fr.ctypes.data, ob.ctypes.data, outl.ctypes.data,
                                                res.ctypes.data), "vieo_pose_optimization_vio")
         return res[0], outl[:len(ob)]
+
+    @staticmethod
+    def LocalBundleAdjustment(params, kfs, points, obs, stop=None):
+        """void Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int Nlocal)
+        (src/Optimizer.cc:1876-2307) on a flattened window (ba_types.LBA_*).
+        returns (navs[n_kf], points float32[n_mp,3], erase uint8[n_obs], result record)."""
+        params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
+        points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+        navs = np.zeros(len(kfs), NAVSTATE_DTYPE)
+        pts = np.zeros_like(points)
+        erase = np.zeros(max(len(obs), 1), np.uint8)
+        res = np.zeros(1, LBA_RESULT_DTYPE)
+        st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        check(lib().vieo_local_bundle_adjustment(params.ctypes.data, kfs.ctypes.data, len(kfs),
+                                                 points.ctypes.data, len(points), obs.ctypes.data,
+                                                 len(obs), None if st is None else st.ctypes.data,
+                                                 navs.ctypes.data, pts.ctypes.data, erase.ctypes.data,
+                                                 res.ctypes.data), "vieo_local_bundle_adjustment")
+        return navs, pts, erase[:len(obs)], res[0]

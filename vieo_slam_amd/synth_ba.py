@@ -259,3 +259,93 @@ def _R_to_quat(R):
         q[1 + j] = (R[j, i] + R[i, j]) / s
         q[1 + k] = (R[k, i] + R[i, k]) / s
     return q / np.linalg.norm(q)
+
+
+# ----------------------------------------------------------------------------------------------
+def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.03, stereo_frac=0.7,
+                     noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_x=0.02, first_fixed=False):
+    """Seeded local-BA window: key frames on a smooth trajectory looking at a cloud
+    of points 2-12 m ahead; every point is observed by the key frames that see it.
+    returns (params[1], kfs[n_kf], points float32[n_mp,3], obs[n_obs] sorted by mp, truth)."""
+    from .ba_types import LBA_KEYFRAME_DTYPE, LBA_OBS_DTYPE, LBA_PARAMS_DTYPE
+    rng = np.random.default_rng(seed)
+    Tcb = np.linalg.inv(EUROC_TBC)
+    Rcb, tcb = Tcb[:3, :3], Tcb[:3, 3]
+    n_kf = n_local + n_fixed
+    # trajectory: fixed key frames first in time (older), then the local window; stored local first
+    R0 = quat_to_R(quat_from_rotvec(rng.normal(0, 0.5, 3)))
+    p0 = rng.uniform(-2, 2, 3)
+    vel = R0 @ np.array([0.0, 0.0, 0.0]) + rng.normal(0, 0.25, 3)
+    omega = rng.normal(0, 0.08, 3)
+    poses = []
+    for k in range(n_kf):
+        t = 0.5 * k
+        Rk = R0 @ so3_exp(omega * t)
+        pk = p0 + vel * t + 0.02 * np.array([np.sin(t), np.cos(1.3 * t), np.sin(0.7 * t)])
+        poses.append((Rk, pk))
+    order = list(range(n_fixed, n_kf)) + list(range(n_fixed))  # local (newest block) first
+    poses = [poses[i] for i in order]
+    # points in front of the middle camera
+    Rm, pm = poses[n_local // 2]
+    Rwc_m = Rm @ EUROC_TBC[:3, :3]
+    twc_m = pm + Rm @ EUROC_TBC[:3, 3]
+    z = rng.uniform(2.0, 12.0, n_points)
+    u = rng.uniform(-150, W + 150, n_points)
+    v = rng.uniform(-100, H + 100, n_points)
+    Xc = np.stack([(u - CX) / FX * z, (v - CY) / FY * z, z], 1)
+    Xw = Xc @ Rwc_m.T + twc_m
+    obs_list = []
+    for m in range(n_points):
+        for k, (Rk, pk) in enumerate(poses):
+            Xck = Rcb @ (Rk.T @ (Xw[m] - pk)) + tcb
+            if Xck[2] < 0.5:
+                continue
+            uu = FX * Xck[0] / Xck[2] + CX
+            vv = FY * Xck[1] / Xck[2] + CY
+            if not (10 < uu < W - 10 and 10 < vv < H - 10):
+                continue
+            lvl = int(rng.integers(0, 8))
+            sig = 1.2 ** lvl
+            uo = uu + rng.normal(0, noise) * sig
+            vo = vv + rng.normal(0, noise) * sig
+            ur = uu - BF / Xck[2] + rng.normal(0, noise) * sig
+            if rng.random() < outlier_frac:
+                uo += rng.uniform(-40, 40)
+                vo += rng.uniform(-40, 40)
+            mono = rng.random() >= stereo_frac
+            obs_list.append((k, m, uo, vo, -1.0 if mono else ur, 1.0 / (np.float32(1.2) ** lvl) ** 2))
+    # keep points with >= 2 observations and at least one local observer; renumber
+    obs_arr = np.array(obs_list, dtype=np.float64)
+    keep = np.zeros(n_points, bool)
+    for m in np.unique(obs_arr[:, 1].astype(int)):
+        sel = obs_arr[:, 1] == m
+        if sel.sum() >= 2 and (obs_arr[sel, 0] < n_local).any():
+            keep[m] = True
+    remap = -np.ones(n_points, int)
+    remap[keep] = np.arange(keep.sum())
+    obs_arr = obs_arr[keep[obs_arr[:, 1].astype(int)]]
+    obs = np.zeros(len(obs_arr), LBA_OBS_DTYPE)
+    obs["kf"] = obs_arr[:, 0].astype(np.int32)
+    obs["mp"] = remap[obs_arr[:, 1].astype(int)]
+    obs["u"], obs["v"], obs["ur"], obs["inv_sigma2"] = obs_arr[:, 2], obs_arr[:, 3], obs_arr[:, 4], obs_arr[:, 5]
+    obs = obs[np.argsort(obs["mp"], kind="stable")]
+    Xw = Xw[keep]
+    kfs = np.zeros(n_kf, LBA_KEYFRAME_DTYPE)
+    truth_p, truth_q = [], []
+    for k, (Rk, pk) in enumerate(poses):
+        q = _R_to_quat(Rk)
+        truth_p.append(pk), truth_q.append(q)
+        is_fixed = k >= n_local or (first_fixed and k == 0)
+        kfs[k]["fixed"] = int(is_fixed)
+        if is_fixed:
+            kfs[k]["nav"]["p"], kfs[k]["nav"]["q"] = pk, q
+        else:
+            kfs[k]["nav"]["p"] = pk + rng.normal(0, 1, 3) / np.sqrt(3) * pert_t
+            kfs[k]["nav"]["q"] = quat_mul(q, quat_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) *
+                                                              np.deg2rad(pert_r_deg)))
+    pts = (Xw + rng.normal(0, pert_x, Xw.shape)).astype(np.float32)
+    params = np.zeros(1, LBA_PARAMS_DTYPE)
+    params[0]["Rcb"], params[0]["tcb"] = Rcb.reshape(-1), tcb
+    params[0]["fx"], params[0]["fy"], params[0]["cx"], params[0]["cy"], params[0]["bf"] = FX, FY, CX, CY, BF
+    params[0]["its0"], params[0]["its1"] = 5, 10
+    return params, kfs, pts, obs, dict(p=np.array(truth_p), q=np.array(truth_q), X=Xw)
