@@ -260,14 +260,18 @@ k_lba_pose(LbaDev D, const int* __restrict__ kf_list, const int* __restrict__ kf
 typedef double double4_t __attribute__((ext_vector_type(4)));
 static const int kSchurMaxObs = 32;  // free observers of one landmark handled by the MFMA tiling
 
-__global__ void __launch_bounds__(256) k_lba_schur(LbaDev D, double lambda, int lds_np, int* overflow) {
+// use_lds = 0: windows whose reduced system does not fit LDS accumulate straight into global memory.
+__global__ void __launch_bounds__(256)
+k_lba_schur(LbaDev D, double lambda, int lds_np, int* overflow, int use_lds) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* sH = smem;                               // [lds_np][lds_np] accumulated -(B D^-1 B^T)
-  double* sb = sH + (size_t)lds_np * lds_np;       // [lds_np]
-  double* stage = sb + lds_np;                     // per wave: A rows [192][4], B rows [192][4], cols [192]
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int np = D.np;
-  for (int i = threadIdx.x; i < lds_np * lds_np + lds_np; i += 256) sH[i] = 0;
+  double* sH = use_lds ? smem : D.Hs;              // [ld][ld] accumulated -(B D^-1 B^T)
+  double* sb = use_lds ? smem + (size_t)lds_np * lds_np : D.bs;
+  double* stage = use_lds ? smem + (size_t)lds_np * lds_np + lds_np : smem;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (!use_lds) lds_np = np;
+  if (use_lds)
+    for (int i = threadIdx.x; i < lds_np * lds_np + lds_np; i += 256) sH[i] = 0;
   __syncthreads();
   double* sA = stage + (size_t)wave * (192 * 4 * 2 + 192);
   double* sB = sA + 192 * 4;
@@ -353,6 +357,7 @@ __global__ void __launch_bounds__(256) k_lba_schur(LbaDev D, double lambda, int 
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
+  if (!use_lds) return;
   for (int i = threadIdx.x; i < np * np; i += 256) {
     const double v = sH[(i / np) * lds_np + (i % np)];
     if (v != 0.0) atomicAdd(&D.Hs[i], v);
@@ -626,11 +631,10 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
     VIEO_HIP_CHECK(hipMemcpy(S.kf_list.p, kf_list.data(), kf_list.size() * 4, hipMemcpyHostToDevice));
     D.np = np;
     const int lds_np = np | 1;  // odd leading dimension: spreads the LDS atomics over banks
-    const size_t schur_lds = ((size_t)lds_np * lds_np + lds_np) * 8 + 4 * (192 * 4 * 2 + 192) * 8 + 64;
-    if (schur_lds > 160 * 1024) {
-      set_error("local BA window too large for the LDS Schur accumulator (%d pose dims)", np);
-      return VIEO_E_CAPACITY;
-    }
+    const size_t stage_lds = 4 * (192 * 4 * 2 + 192) * 8 + 64;
+    size_t schur_lds = ((size_t)lds_np * lds_np + lds_np) * 8 + stage_lds;
+    const int use_lds = schur_lds <= 150 * 1024;
+    if (!use_lds) schur_lds = stage_lds;
     VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_schur, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)schur_lds));
     const int schur_blocks = std::max(1, std::min(256, (n_mp + 3) / 4));
@@ -673,7 +677,7 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
         hipLaunchKernelGGL(k_lba_init_reduced, dim3((np * np + 255) / 256), dim3(256), 0, st, D, lambda);
         VIEO_HIP_CHECK(hipMemsetAsync(S.flags.p, 0, 16, st));
         hipLaunchKernelGGL(k_lba_schur, dim3(schur_blocks), dim3(256), schur_lds, st, D, lambda, lds_np,
-                           S.flags.as<int>() + 1);
+                           S.flags.as<int>() + 1, use_lds);
         hipLaunchKernelGGL(k_lba_ldlt, dim3(1), dim3(256), 0, st, D.Hs, D.bs, D.xp, np, S.flags.as<int>());
         hipLaunchKernelGGL(k_lba_update_points, dim3(nblk_m), dim3(256), 0, st, D, lambda);
         hipLaunchKernelGGL(k_lba_update_poses, dim3((n_kf + 63) / 64), dim3(64), 0, st, D);
