@@ -3,11 +3,14 @@
 
     python bench.py --gpus N --steps K --warmup W [--batch B]
 
-Workload (BASELINE.json configs[1]: "EuRoC MH05 stereo-VIO, 1200 feats, 1xMI355X, PoseOptimization
-only"): per stereo frame, in the reference's call order
+Workload (BASELINE.json configs[1]/[2]: "EuRoC MH05 stereo-VIO, 1200 feats, 1xMI355X"): per stereo
+frame, in the reference's call order
     ORBextractor x2 -> ComputeStereoMatches -> SearchByProjection(last frame) -> PoseOptimization(VIO)
     -> SearchByProjection(local map) -> PoseOptimization(VIO, bComputeMarg)
-LocalBundleAdjustment is NOT in the timed region (not built yet) -- stated in config.workload.
+plus one LocalBundleAdjustment per `--lba-every` frames (a key frame every <= 10 frames at 20 Hz,
+SURVEY.md 8d), issued from host threads like the reference's LocalMapping thread.  The LBA built so
+far is the vision-only variant (Optimizer.cc:1876-2307) on a 10+6 key-frame window; the IMU variant
+LocalBundleAdjustmentNavStatePRV is not built yet -- stated in config.workload.
 
 One process per GPU (the driver launches N>1 through torch.distributed.run).  A *step* is one pass
 of that path over a batch of B independent frames that already sit in HBM; ranks shard frames
@@ -59,8 +62,11 @@ def algorithmic_bytes_per_image():
     }
 
 
-def cpu_baseline(P, budget_s=15.0):
-    """The same chain on the host with the CPU oracle: 2 threads for extraction, 1 for the rest."""
+def cpu_baseline(P, lba_problems, lba_every, budget_s=20.0):
+    """The same chain on the host with the CPU oracle, threaded like the reference: 2 threads for
+    extraction, the tracking thread for the rest, and a LocalMapping thread running one LBA per
+    `lba_every` frames concurrently."""
+    import queue
     from tests import oracle_lib
     from vieo_slam_amd import synth_scene as sc
     from vieo_slam_amd.ba_types import POSE_OBS_DTYPE, SBP_CAMERA_DTYPE
@@ -82,6 +88,17 @@ def cpu_baseline(P, budget_s=15.0):
         o["inv_sigma2"] = P.inv_sigma2[k["octave"][idx]]
         return o, idx
 
+    lq = queue.Queue()
+
+    def local_mapping():
+        while True:
+            i = lq.get()
+            if i is None:
+                return
+            orc.local_ba(*lba_problems[i % len(lba_problems)])
+    lm_thread = threading.Thread(target=local_mapping)
+    if lba_every > 0 and lba_problems:
+        lm_thread.start()
     n_done, t0 = 0, time.perf_counter()
     while n_done < P.B:
         b = n_done
@@ -113,14 +130,20 @@ def cpu_baseline(P, budget_s=15.0):
         F2[0]["compute_marg"] = 1
         orc.pose_optimization_vio(F2, o2)
         n_done += 1
+        if lba_every > 0 and lba_problems and n_done % lba_every == 0:
+            lq.put(n_done // lba_every)
         if time.perf_counter() - t0 > budget_s and n_done >= 4:
             break
+    if lm_thread.is_alive() or (lba_every > 0 and lba_problems):
+        lq.put(None)
+        lm_thread.join()
     dt = time.perf_counter() - t0
-    return {"value": n_done / dt, "unit": "frames/s", "cores": 2, "kind": "port",
+    return {"value": n_done / dt, "unit": "frames/s", "cores": 3, "kind": "port",
             "sample": "%d of the benchmark's stereo frames through the same chain with the CPU oracle "
-                      "(-O3 -march=native): extraction on 1 thread per camera, stereo match / "
-                      "projection searches / 2x PoseOptimization on one thread (nproc=%d)"
-                      % (n_done, os.cpu_count())}
+                      "(-O3 -march=native), threaded like the reference: extraction on 1 thread per "
+                      "camera, stereo match / projection searches / 2x PoseOptimization on the tracking "
+                      "thread, one LocalBundleAdjustment per %d frames on a LocalMapping thread (nproc=%d)"
+                      % (n_done, lba_every, os.cpu_count())}
 
 
 def main():
@@ -133,6 +156,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="independent frame pipelines per GPU, each on its own HIP stream (the batch "
                          "is split between them so latency-bound stages overlap extraction)")
+    ap.add_argument("--lba-every", type=int, default=10, help="frames per LocalBundleAdjustment (0 = none)")
+    ap.add_argument("--lba-threads", type=int, default=16, help="host threads issuing LBA windows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -156,6 +181,21 @@ def main():
     P = pipes[0]
     n_img = 2 * P.B
 
+    # ---- local BA windows (one per `lba_every` frames), issued by host threads
+    from concurrent.futures import ThreadPoolExecutor
+    from vieo_slam_amd import synth_ba
+    from vieo_slam_amd.optimizer import Optimizer
+    n_lba = (B + a.lba_every - 1) // a.lba_every if a.lba_every > 0 else 0
+    lba_problems = [synth_ba.make_lba_problem(500 + 7 * rank + i)[:4] for i in range(min(8, n_lba))]
+    pool = ThreadPoolExecutor(max_workers=max(1, a.lba_threads))
+    lba_ms = []
+
+    def run_lba(i):
+        t = time.perf_counter()
+        r = Optimizer.LocalBundleAdjustment(*lba_problems[i % len(lba_problems)])
+        lba_ms.append((time.perf_counter() - t) * 1e3)
+        return r[3]
+
     def sync_all():
         for q in pipes:
             q.sync()
@@ -166,13 +206,19 @@ def main():
     for _ in range(a.warmup):
         for q in pipes:
             q.step()
+    if n_lba:
+        list(pool.map(run_lba, range(2 * a.lba_threads)))  # every worker thread creates its stream
+    lba_ms.clear()
     P.enable_timing(True)
     P.ext.enable_timing(True)
     sync_all()
     t0 = time.perf_counter()
+    futs = []
     for _ in range(a.steps):
         for q in pipes:
             q.step()
+        futs += [pool.submit(run_lba, i) for i in range(n_lba)]
+    lba_res = [f.result() for f in futs]
     sync_all()
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dist, dt, device="cuda")
@@ -202,8 +248,13 @@ def main():
                 "workload": "BASELINE configs[1] 'EuRoC MH05 stereo-VIO, 1200 feats, PoseOptimization only': "
                             "synthetic rendered stereo-inertial frames 752x480, 1.2x8 levels, FAST 20/7; per "
                             "frame ORBextractor x2 + ComputeStereoMatches + SearchByProjection(last frame) + "
-                            "PoseOptimization(VIO) + SearchByProjection(local map) + PoseOptimization(VIO, marg). "
-                            "LocalBundleAdjustment is NOT in the timed region (not built yet)",
+                            "PoseOptimization(VIO) + SearchByProjection(local map) + PoseOptimization(VIO, marg); "
+                            "plus one vision-only LocalBundleAdjustment (10 free + 6 fixed key frames, ~1500 "
+                            "points, ~14k observations) per %d frames from %d host threads.  The IMU variant "
+                            "LocalBundleAdjustmentNavStatePRV is not built yet" % (a.lba_every, a.lba_threads),
+                "local_ba_windows_per_step": n_lba,
+                "local_ba_ms_per_call_mean": float(np.mean(lba_ms)) if lba_ms else None,
+                "local_ba_lm_iterations_mean": float(np.mean([r["lm_iterations"] for r in lba_res])) if lba_res else None,
                 "stereo_frames_per_gpu_per_step": B,
                 "hip_streams_per_gpu": S,
                 "parallelism": "frames sharded, one batch per GPU split over %d HIP stream(s), no collective" % S,
@@ -219,7 +270,7 @@ def main():
                          "avg_launch_ms": kern[dom]},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P)
+            out["cpu_baseline"] = cpu_baseline(P, lba_problems, a.lba_every)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -474,13 +474,22 @@ struct LbaHost {
       Dinv, xp, xl, part, kf_list, kf_edge_first, kf_edge_idx, flags, erase;
 };
 static thread_local LbaHost g_lba;
+static thread_local hipStream_t g_lba_stream = nullptr;
+
+// synchronous copy on the calling thread's own stream (so concurrent LBA calls from several host
+// threads, and the frame pipelines on their streams, do not serialise on the null stream)
+static inline hipError_t lba_copy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, n, kind, g_lba_stream);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(g_lba_stream);
+}
 
 #define LBA_ENS(b, n) \
   if ((rc = (b).ensure(std::max<size_t>((n), 8))) != VIEO_OK) return rc
 
 static int sum_partials(LbaHost& S, int n, double* out) {
   std::vector<double> h(n);
-  VIEO_HIP_CHECK(hipMemcpy(h.data(), S.part.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  VIEO_HIP_CHECK(lba_copy(h.data(), S.part.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   double s = 0;
   for (double v : h) s += v;
   *out = s;
@@ -502,6 +511,7 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
     return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
+  if (!g_lba_stream) VIEO_HIP_CHECK(hipStreamCreateWithFlags(&g_lba_stream, hipStreamNonBlocking));
   memset(R, 0, sizeof(*R));
   for (int k = 0; k < n_kf; k++) h_navs_out[k] = h_kfs[k].nav;
   memcpy(h_points_out, h_points, (size_t)n_mp * 12);
@@ -569,14 +579,14 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
   LBA_ENS(S.kf_edge_first, (size_t)(n_kf + 1) * 4);
   LBA_ENS(S.kf_edge_idx, (size_t)n_obs * 4);
   LBA_ENS(S.flags, 16);
-  VIEO_HIP_CHECK(hipMemcpy(S.obs.p, h_obs, (size_t)n_obs * sizeof(vieo_lba_obs), hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.X.p, X.data(), X.size() * 8, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.mp_first.p, mp_first.data(), (size_t)n_mp * 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.mp_count.p, mp_count.data(), (size_t)n_mp * 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.kf_edge_first.p, kf_edge_first.data(), (size_t)(n_kf + 1) * 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.kf_edge_idx.p, kf_edge_idx.data(), (size_t)n_obs * 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemset(S.level.p, 0, n_obs));
-  VIEO_HIP_CHECK(hipMemset(S.err.p, 0, (size_t)n_obs * 24));
+  VIEO_HIP_CHECK(lba_copy(S.obs.p, h_obs, (size_t)n_obs * sizeof(vieo_lba_obs), hipMemcpyHostToDevice));
+  VIEO_HIP_CHECK(lba_copy(S.X.p, X.data(), X.size() * 8, hipMemcpyHostToDevice));
+  VIEO_HIP_CHECK(lba_copy(S.mp_first.p, mp_first.data(), (size_t)n_mp * 4, hipMemcpyHostToDevice));
+  VIEO_HIP_CHECK(lba_copy(S.mp_count.p, mp_count.data(), (size_t)n_mp * 4, hipMemcpyHostToDevice));
+  VIEO_HIP_CHECK(lba_copy(S.kf_edge_first.p, kf_edge_first.data(), (size_t)(n_kf + 1) * 4, hipMemcpyHostToDevice));
+  VIEO_HIP_CHECK(lba_copy(S.kf_edge_idx.p, kf_edge_idx.data(), (size_t)n_obs * 4, hipMemcpyHostToDevice));
+  VIEO_HIP_CHECK(hipMemsetAsync(S.level.p, 0, n_obs, g_lba_stream));
+  VIEO_HIP_CHECK(hipMemsetAsync(S.err.p, 0, (size_t)n_obs * 24, g_lba_stream));
   LbaDev D;
   D.obs = S.obs.as<vieo_lba_obs>();
   D.n_obs = n_obs, D.n_mp = n_mp, D.n_kf = n_kf, D.np = 0;
@@ -593,7 +603,7 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
   memcpy(D.cam.tcb, P->tcb, 24);
   D.robust = 1;
   D.dMono = (double)(float)sqrt(5.991), D.dStereo = (double)(float)sqrt(7.815);
-  hipStream_t st = nullptr;
+  hipStream_t st = g_lba_stream;
   std::vector<unsigned char> level(n_obs, 0), mp_act(n_mp);
   std::vector<int> kf_list;
 
@@ -622,13 +632,13 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
     // keep the device poses, refresh only the column map
     std::vector<LbaKf> cur(n_kf);
     if (!first) {
-      VIEO_HIP_CHECK(hipMemcpy(cur.data(), S.kf.p, (size_t)n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
+      VIEO_HIP_CHECK(lba_copy(cur.data(), S.kf.p, (size_t)n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
       for (int k = 0; k < n_kf; k++) cur[k].col = kf[k].col;
     } else
       cur = kf;
-    VIEO_HIP_CHECK(hipMemcpy(S.kf.p, cur.data(), (size_t)n_kf * sizeof(LbaKf), hipMemcpyHostToDevice));
-    VIEO_HIP_CHECK(hipMemcpy(S.mp_act.p, mp_act.data(), n_mp, hipMemcpyHostToDevice));
-    VIEO_HIP_CHECK(hipMemcpy(S.kf_list.p, kf_list.data(), kf_list.size() * 4, hipMemcpyHostToDevice));
+    VIEO_HIP_CHECK(lba_copy(S.kf.p, cur.data(), (size_t)n_kf * sizeof(LbaKf), hipMemcpyHostToDevice));
+    VIEO_HIP_CHECK(lba_copy(S.mp_act.p, mp_act.data(), n_mp, hipMemcpyHostToDevice));
+    VIEO_HIP_CHECK(lba_copy(S.kf_list.p, kf_list.data(), kf_list.size() * 4, hipMemcpyHostToDevice));
     D.np = np;
     const int lds_np = np | 1;  // odd leading dimension: spreads the LDS atomics over banks
     const size_t stage_lds = 4 * (192 * 4 * 2 + 192) * 8 + 64;
@@ -655,8 +665,8 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
                          S.kf_list.as<int>(), S.kf_edge_first.as<int>(), S.kf_edge_idx.as<int>());
       if (it == 0) {  // computeLambdaInit: tau * max diagonal over poses and landmarks
         std::vector<double> Hpp((size_t)np * np), Hll((size_t)n_mp * 9);
-        VIEO_HIP_CHECK(hipMemcpy(Hpp.data(), S.Hpp.p, Hpp.size() * 8, hipMemcpyDeviceToHost));
-        VIEO_HIP_CHECK(hipMemcpy(Hll.data(), S.Hll.p, Hll.size() * 8, hipMemcpyDeviceToHost));
+        VIEO_HIP_CHECK(lba_copy(Hpp.data(), S.Hpp.p, Hpp.size() * 8, hipMemcpyDeviceToHost));
+        VIEO_HIP_CHECK(lba_copy(Hll.data(), S.Hll.p, Hll.size() * 8, hipMemcpyDeviceToHost));
         double mx = 0;
         for (int j = 0; j < np; j++) mx = std::max(std::fabs(Hpp[(size_t)j * np + j]), mx);
         for (int m = 0; m < n_mp; m++)
@@ -667,7 +677,7 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
         nBad = 0;
       }
       std::vector<double> bp(np);
-      VIEO_HIP_CHECK(hipMemcpy(bp.data(), S.bp.p, (size_t)np * 8, hipMemcpyDeviceToHost));
+      VIEO_HIP_CHECK(lba_copy(bp.data(), S.bp.p, (size_t)np * 8, hipMemcpyDeviceToHost));
       double rho = 0;
       int qmax = 0;
       do {
@@ -685,8 +695,8 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
         if ((rc = sum_partials(S, nblk_m, &scale_l)) != VIEO_OK) return rc;
         int flags[2];
         std::vector<double> xp(np);
-        VIEO_HIP_CHECK(hipMemcpy(flags, S.flags.p, 8, hipMemcpyDeviceToHost));
-        VIEO_HIP_CHECK(hipMemcpy(xp.data(), S.xp.p, (size_t)np * 8, hipMemcpyDeviceToHost));
+        VIEO_HIP_CHECK(lba_copy(flags, S.flags.p, 8, hipMemcpyDeviceToHost));
+        VIEO_HIP_CHECK(lba_copy(xp.data(), S.xp.p, (size_t)np * 8, hipMemcpyDeviceToHost));
         if (flags[1]) {
           set_error("local BA: a map point has more than %d free observers", kSchurMaxObs);
           return VIEO_E_CAPACITY;
@@ -732,17 +742,17 @@ extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo
   if ((rc = optimize(P->its0, true)) != VIEO_OK) return rc;
   if (!(stop && *stop)) {
     hipLaunchKernelGGL(k_lba_classify, dim3(nblk_e), dim3(256), 0, st, D, 0, S.erase.as<unsigned char>());
-    VIEO_HIP_CHECK(hipMemcpy(level.data(), S.level.p, n_obs, hipMemcpyDeviceToHost));
+    VIEO_HIP_CHECK(lba_copy(level.data(), S.level.p, n_obs, hipMemcpyDeviceToHost));
     D.robust = 0;
     if ((rc = optimize(P->its1, false)) != VIEO_OK) return rc;
   } else
     R->status = VIEO_LBA_ABORTED;
   hipLaunchKernelGGL(k_lba_classify, dim3(nblk_e), dim3(256), 0, st, D, 1, S.erase.as<unsigned char>());
-  VIEO_HIP_CHECK(hipMemcpy(h_erase, S.erase.p, n_obs, hipMemcpyDeviceToHost));
+  VIEO_HIP_CHECK(lba_copy(h_erase, S.erase.p, n_obs, hipMemcpyDeviceToHost));
   for (int i = 0; i < n_obs; i++) R->n_erase += h_erase[i];
   std::vector<LbaKf> out(n_kf);
-  VIEO_HIP_CHECK(hipMemcpy(out.data(), S.kf.p, (size_t)n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
-  VIEO_HIP_CHECK(hipMemcpy(X.data(), S.X.p, X.size() * 8, hipMemcpyDeviceToHost));
+  VIEO_HIP_CHECK(lba_copy(out.data(), S.kf.p, (size_t)n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
+  VIEO_HIP_CHECK(lba_copy(X.data(), S.X.p, X.size() * 8, hipMemcpyDeviceToHost));
   for (int k = 0; k < n_kf; k++) {
     if (h_kfs[k].fixed) continue;
     memcpy(h_navs_out[k].p, out[k].p, 24);
