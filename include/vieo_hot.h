@@ -373,6 +373,18 @@ int vieo_local_bundle_adjustment(const vieo_lba_params* params, const vieo_lba_k
                                  vieo_navstate* h_navs_out, float* h_points_out, uint8_t* h_erase,
                                  vieo_lba_result* h_result);
 
+/* Several independent windows (one per map / per LocalMapping thread of a multi-session server)
+ * advanced in lock step: every kernel launch covers all windows and the host reads one small
+ * record per window and LM trial.  Each array argument has n_windows entries; per-window results
+ * are identical to n_windows calls of vieo_local_bundle_adjustment.  `stop` is shared. */
+int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* const* params,
+                                       const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                       const float* const* h_points, const int* n_mp,
+                                       const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                       volatile const int* stop, vieo_navstate* const* h_navs_out,
+                                       float* const* h_points_out, uint8_t* const* h_erase,
+                                       vieo_lba_result* h_results);
+
 /* ---- replay glue (device-resident batches) -------------------------------------------------
  * What Tracking.cc does between the calls above, on flattened arrays, so a batch of frames runs
  * extract -> stereo -> search -> pose optimisation with no host round trip (bench.py):

@@ -68,6 +68,8 @@ _SIGS = {
     "vieo_track_after_pose_batch_device": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "vieo_orb_stream": (c_p, [c_p]),
     "vieo_local_bundle_adjustment": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "vieo_local_bundle_adjustment_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                                  c_p]),
     "vieo_orb_tap_plane": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_candidates": (c_i, [c_p, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_level_keys": (c_i, [c_p, c_i, c_i, c_p, c_i]),

@@ -28,9 +28,33 @@ struct LbaKf {
   int pad;
 };
 
+// control word of a window for one round of the lock-step batch driver
+enum {
+  LBA_TRIAL = 1,    // solve + update + evaluate one lambda trial
+  LBA_BUILD = 2,    // re-linearise (start of an LM iteration)
+  LBA_RESTORE = 4,  // last trial was rejected: restore the backed-up estimates first
+  LBA_ERROR = 8,    // residual pass only (start of an optimize())
+  LBA_CLASS0 = 16,  // chi2 / depth gates -> level 1 (between the two optimisations)
+  LBA_CLASS1 = 32,  // final erase flags
+};
+struct WinCtl {
+  int flags, pad;
+  double lambda;
+};
+struct WinOut {
+  double chi2, scale_l, scale_p, maxdiag;
+  int ok, overflow;
+};
+
 struct LbaDev {
   const vieo_lba_obs* obs;
   int n_obs, n_mp, n_kf, np;
+  int n_free, pad0;
+  const int *kf_list, *kf_edge_first, *kf_edge_idx;
+  LbaKf* kf_bak;
+  double* X_bak;
+  double* part_m;          // per-block partial sums of the point pass
+  unsigned char* erase;
   LbaKf* kf;
   double* X;               // [n_mp][3]
   double* err;             // [n_obs][3]
@@ -105,10 +129,18 @@ __device__ __forceinline__ void lba_jacobians(const CamD& c, const PoseXf& X, co
     }
 }
 
-// ---- residuals + robust chi2 of the active edges; mode 1: classify (level) instead
-__global__ void __launch_bounds__(256) k_lba_error(LbaDev D) {
+// Every kernel below is launched for ALL windows of a batch (blockIdx.y / .z / .x = window) and
+// returns at once for windows whose control word does not ask for that step.
+
+// ---- residuals + robust chi2 of the active edges
+__global__ void __launch_bounds__(256)
+k_lba_error(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   __shared__ double s_red[4];
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & (LBA_TRIAL | LBA_ERROR))) return;
+  const LbaDev& D = devs[w];
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= D.n_obs) return;
   double v[1] = {0};
   if (i < D.n_obs && D.level[i] == 0) {
     const vieo_lba_obs o = D.obs[i];
@@ -128,9 +160,28 @@ __global__ void __launch_bounds__(256) k_lba_error(LbaDev D) {
   if (threadIdx.x == 0) D.part[blockIdx.x] = v[0];
 }
 
-// chi2 (from the STORED error, as the reference does) / depth classification.
-// what = 0: set level 1 for outliers (Optimizer.cc:2191-2212); what = 1: write erase flags
-__global__ void __launch_bounds__(256) k_lba_classify(LbaDev D, int what, unsigned char* erase) {
+// one workgroup per window: fold the per-block partials into the window's output record
+__global__ void __launch_bounds__(256)
+k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+  __shared__ double s_red[4 * 2];
+  const int w = blockIdx.x, fl = ctl[w].flags;
+  if (!(fl & (LBA_TRIAL | LBA_ERROR))) return;
+  const LbaDev& D = devs[w];
+  double v[2] = {0, 0};
+  for (int i = threadIdx.x; i < (D.n_obs + 255) / 256; i += 256) v[0] += D.part[i];
+  if (fl & LBA_TRIAL)
+    for (int i = threadIdx.x; i < (D.n_mp + 255) / 256; i += 256) v[1] += D.part_m[i];
+  block_sum<2>(v, s_red, threadIdx.x);
+  if (threadIdx.x == 0) out[w].chi2 = v[0], out[w].scale_l = v[1];
+}
+
+// chi2 (from the STORED error, as the reference does) / depth classification
+// (Optimizer.cc:2191-2212 -> level 1; :2227-2249 -> vToErase)
+__global__ void __launch_bounds__(256)
+k_lba_classify(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y, fl = ctl[w].flags;
+  if (!(fl & (LBA_CLASS0 | LBA_CLASS1))) return;
+  const LbaDev& D = devs[w];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= D.n_obs) return;
   const vieo_lba_obs o = D.obs[i];
@@ -143,14 +194,42 @@ __global__ void __launch_bounds__(256) k_lba_classify(LbaDev D, int what, unsign
   const double* Xw = D.X + 3 * (size_t)o.mp;
   const double z = X.Rcw[6] * Xw[0] + X.Rcw[7] * Xw[1] + X.Rcw[8] * Xw[2] + X.tcw[2];
   const bool bad = chi2 > (o.ur >= 0 ? 7.815 : 5.991) || !(z > 0.);
-  if (what == 0) {
+  if (fl & LBA_CLASS0) {
     if (bad) D.level[i] = 1;
   } else
-    erase[i] = bad ? 1 : 0;
+    D.erase[i] = bad ? 1 : 0;
+}
+
+// ---- backup (before a trial) / restore (after a rejected trial) of poses and points
+__global__ void __launch_bounds__(256)
+k_lba_backup_restore(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int restore) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & (restore ? LBA_RESTORE : LBA_TRIAL))) return;
+  const LbaDev& D = devs[w];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < D.n_mp * 3) {
+    if (restore)
+      D.X[i] = D.X_bak[i];
+    else
+      D.X_bak[i] = D.X[i];
+  }
+  if (i < D.n_kf) {
+    if (restore) {
+      const int col = D.kf[i].col;
+      D.kf[i] = D.kf_bak[i];
+      D.kf[i].col = col;
+    } else
+      D.kf_bak[i] = D.kf[i];
+  }
 }
 
 // ---- landmark-parallel linearisation: 16 lanes per landmark
-__global__ void __launch_bounds__(256) k_lba_linearize(LbaDev D) {
+__global__ void __launch_bounds__(256)
+k_lba_linearize(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_BUILD)) return;
+  const LbaDev& D = devs[w];
+  if (blockIdx.x * 16 >= D.n_mp) return;
   const int sub = threadIdx.x & 15;
   const int m = blockIdx.x * 16 + (threadIdx.x >> 4);
   const bool valid_m = m < D.n_mp && D.mp_act[m];
@@ -177,13 +256,13 @@ __global__ void __launch_bounds__(256) k_lba_linearize(LbaDev D) {
       }
       double Jp[18], Jx[9];
       lba_jacobians(D.cam, X, k.p, Xw, Pc, Jp, Jx);
-      const double info = (double)o.inv_sigma2, w = r1 * info;
+      const double info = (double)o.inv_sigma2, ww = r1 * info;
       const int de = stereo ? 3 : 2;
       int t = 0;
       for (int a = 0; a < 3; a++) {
         for (int b = a; b < 3; b++, t++) {
           double s = 0;
-          for (int r = 0; r < de; r++) s += Jx[r * 3 + a] * w * Jx[r * 3 + b];
+          for (int r = 0; r < de; r++) s += Jx[r * 3 + a] * ww * Jx[r * 3 + b];
           acc[t] += s;
         }
         double s = 0;
@@ -195,7 +274,7 @@ __global__ void __launch_bounds__(256) k_lba_linearize(LbaDev D) {
         for (int a = 0; a < 6; a++)
           for (int b = 0; b < 3; b++) {
             double s = 0;
-            for (int r = 0; r < de; r++) s += Jp[r * 6 + a] * w * Jx[r * 3 + b];
+            for (int r = 0; r < de; r++) s += Jp[r * 6 + a] * ww * Jx[r * 3 + b];
             B[a * 3 + b] = s;
           }
     }
@@ -212,21 +291,35 @@ __global__ void __launch_bounds__(256) k_lba_linearize(LbaDev D) {
   }
 }
 
-// ---- key-frame-parallel Hpp / bp.  grid (chunks, n_free); edge lists sorted by key frame
+// Hpp = 0, bp = 0 of the windows that re-linearise
 __global__ void __launch_bounds__(256)
-k_lba_pose(LbaDev D, const int* __restrict__ kf_list, const int* __restrict__ kf_edge_first,
-           const int* __restrict__ kf_edge_idx) {
+k_lba_zero_pose(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_BUILD)) return;
+  const LbaDev& D = devs[w];
+  const int i = blockIdx.x * 256 + threadIdx.x, np = D.np;
+  if (i < np * np) D.Hpp[i] = 0;
+  if (i < np) D.bp[i] = 0;
+}
+
+// ---- key-frame-parallel Hpp / bp.  grid (chunks, max free key frames, windows)
+__global__ void __launch_bounds__(256)
+k_lba_pose(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   __shared__ double s_red[4 * 27];
-  const int kfi = kf_list[blockIdx.y];
+  const int w = blockIdx.z;
+  if (!(ctl[w].flags & LBA_BUILD)) return;
+  const LbaDev& D = devs[w];
+  if ((int)blockIdx.y >= D.n_free) return;
+  const int kfi = D.kf_list[blockIdx.y];
   const LbaKf k = D.kf[kfi];
-  const int first = kf_edge_first[kfi], cnt = kf_edge_first[kfi + 1] - first;
+  const int first = D.kf_edge_first[kfi], cnt = D.kf_edge_first[kfi + 1] - first;
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0;
   PoseXf X;
   kf_xf(D.cam, k, X);
   for (int j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += gridDim.x * 256) {
-    const int i = kf_edge_idx[first + j];
+    const int i = D.kf_edge_idx[first + j];
     if (D.level[i]) continue;
     const vieo_lba_obs o = D.obs[i];
     const double* Xw = D.X + 3 * (size_t)o.mp;
@@ -256,22 +349,50 @@ k_lba_pose(LbaDev D, const int* __restrict__ kf_list, const int* __restrict__ kf
   }
 }
 
+// computeLambdaInit: max |diagonal| over the pose and landmark blocks (one workgroup per window)
+__global__ void __launch_bounds__(256)
+k_lba_maxdiag(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+  __shared__ double s_m[256];
+  const int w = blockIdx.x;
+  if (!(ctl[w].flags & LBA_ERROR)) return;
+  const LbaDev& D = devs[w];
+  double mx = 0;
+  for (int j = threadIdx.x; j < D.np; j += 256) mx = fmax(mx, fabs(D.Hpp[(size_t)j * D.np + j]));
+  for (int m = threadIdx.x; m < D.n_mp; m += 256)
+    if (D.mp_act[m])
+      for (int a = 0; a < 3; a++) mx = fmax(mx, fabs(D.Hll[9 * (size_t)m + 4 * a]));
+  s_m[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s_m[threadIdx.x] = fmax(s_m[threadIdx.x], s_m[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[w].maxdiag = s_m[0];
+}
+
 // ---- Schur complement: one wavefront per landmark, FP64 MFMA for the block contraction.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 static const int kSchurMaxObs = 32;  // free observers of one landmark handled by the MFMA tiling
 
 // use_lds = 0: windows whose reduced system does not fit LDS accumulate straight into global memory.
 __global__ void __launch_bounds__(256)
-k_lba_schur(LbaDev D, double lambda, int lds_np, int* overflow, int use_lds) {
+k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out,
+            int lds_np_max, int use_lds) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  const double lambda = ctl[w].lambda;
   const int np = D.np;
-  double* sH = use_lds ? smem : D.Hs;              // [ld][ld] accumulated -(B D^-1 B^T)
-  double* sb = use_lds ? smem + (size_t)lds_np * lds_np : D.bs;
-  double* stage = use_lds ? smem + (size_t)lds_np * lds_np + lds_np : smem;
+  int lds_np = use_lds ? (np | 1) : np;
+  double* sH = use_lds ? smem : D.Hs;  // [ld][ld] accumulated -(B D^-1 B^T)
+  double* sb = use_lds ? smem + (size_t)lds_np_max * lds_np_max : D.bs;
+  double* stage = use_lds ? smem + (size_t)lds_np_max * lds_np_max + lds_np_max : smem;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (!use_lds) lds_np = np;
-  if (use_lds)
-    for (int i = threadIdx.x; i < lds_np * lds_np + lds_np; i += 256) sH[i] = 0;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < lds_np * lds_np; i += 256) sH[i] = 0;
+    for (int i = threadIdx.x; i < np; i += 256) sb[i] = 0;
+  }
   __syncthreads();
   double* sA = stage + (size_t)wave * (192 * 4 * 2 + 192);
   double* sB = sA + 192 * 4;
@@ -319,27 +440,25 @@ k_lba_schur(LbaDev D, double lambda, int lds_np, int* overflow, int use_lds) {
             sA[row * 4 + 2] = b0 * Di[2] + b1 * Di[5] + b2 * Di[8];
             sA[row * 4 + 3] = 0;
             sC[row] = col + a;
-            // bschur -= B * (D^-1 bl)
-            atomicAdd(&sb[col + a], -(b0 * db0 + b1 * db1 + b2 * db2));
+            atomicAdd(&sb[col + a], -(b0 * db0 + b1 * db1 + b2 * db2));  // bschur -= B (D^-1 bl)
           }
         }
       }
       k += __popcll(bal);
     }
     if (k > kSchurMaxObs) {
-      if (lane == 0) atomicExch(overflow, 1);
+      if (lane == 0) atomicExch(&out[w].overflow, 1);
       k = kSchurMaxObs;
     }
     const int rows = 6 * k, nt = (rows + 15) >> 4;
-    // zero-pad the last tile
-    for (int r = rows + lane; r < nt * 16; r += 64) {
+    for (int r = rows + lane; r < nt * 16; r += 64) {  // zero-pad the last tile
       sA[r * 4] = sA[r * 4 + 1] = sA[r * 4 + 2] = sA[r * 4 + 3] = 0;
       sB[r * 4] = sB[r * 4 + 1] = sB[r * 4 + 2] = sB[r * 4 + 3] = 0;
       sC[r] = -1;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // C(ti, tj) = A_ti (16x4) * B_tj^T (4x16) on the matrix core; scatter -C into the LDS system
+    // C(ti, tj) = A_ti (16x4) * B_tj^T (4x16) on the matrix core; scatter -C into the system
     for (int ti = 0; ti < nt; ti++)
       for (int tj = 0; tj < nt; tj++) {
         const double av = sA[(ti * 16 + (lane & 15)) * 4 + (lane >> 4)];
@@ -367,18 +486,32 @@ k_lba_schur(LbaDev D, double lambda, int lds_np, int* overflow, int use_lds) {
 }
 
 // Hs = Hpp + lambda I ; bs = bp
-__global__ void __launch_bounds__(256) k_lba_init_reduced(LbaDev D, double lambda) {
+__global__ void __launch_bounds__(256)
+k_lba_init_reduced(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  const double lambda = ctl[w].lambda;
   const int i = blockIdx.x * 256 + threadIdx.x, np = D.np;
   if (i < np * np) D.Hs[i] = D.Hpp[i] + ((i / np) == (i % np) ? lambda : 0.0);
   if (i < np) D.bs[i] = D.bp[i];
+  if (i == 0) out[w].overflow = 0;
 }
 
-// ---- dense LDL^T solve of the reduced system by one workgroup (matrix in global memory / L2)
-__global__ void __launch_bounds__(256) k_lba_ldlt(double* A, const double* b, double* x, int n, int* ok_out) {
+// ---- dense LDL^T solve of the reduced system, one workgroup per window (matrix in L2)
+__global__ void __launch_bounds__(256)
+k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
   __shared__ double s_col[512];
   __shared__ double s_D[512];
+  __shared__ double s_red[4];
   __shared__ int s_ok;
-  const int tid = threadIdx.x;
+  const int w = blockIdx.x;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  double* A = D.Hs;
+  const double* b = D.bs;
+  double* x = D.xp;
+  const int n = D.np, tid = threadIdx.x;
   if (tid == 0) s_ok = 1;
   __syncthreads();
   for (int j = 0; j < n; j++) {
@@ -401,7 +534,7 @@ __global__ void __launch_bounds__(256) k_lba_ldlt(double* A, const double* b, do
   __syncthreads();
   if (!s_ok) {
     for (int i = tid; i < n; i += 256) x[i] = 0;
-    if (tid == 0) *ok_out = 0;
+    if (tid == 0) out[w].ok = 0, out[w].scale_p = 0;
     return;
   }
   double* y = s_col;
@@ -419,13 +552,25 @@ __global__ void __launch_bounds__(256) k_lba_ldlt(double* A, const double* b, do
     for (int i = tid; i < j; i += 256) y[i] -= A[(size_t)j * n + i] * xj;
     __syncthreads();
   }
-  for (int i = tid; i < n; i += 256) x[i] = y[i];
-  if (tid == 0) *ok_out = 1;
+  double sp[1] = {0};
+  const double lambda = ctl[w].lambda;
+  for (int i = tid; i < n; i += 256) {
+    x[i] = y[i];
+    sp[0] += y[i] * (lambda * y[i] + D.bp[i]);  // pose part of computeScale()
+  }
+  block_sum<1>(sp, s_red, tid);
+  if (tid == 0) out[w].ok = 1, out[w].scale_p = sp[0];
 }
 
-// ---- back-substitution + update of the points, scale terms of the LM gain ratio
-__global__ void __launch_bounds__(256) k_lba_update_points(LbaDev D, double lambda) {
+// ---- back-substitution + update of the points, landmark part of the LM gain-ratio scale
+__global__ void __launch_bounds__(256)
+k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   __shared__ double s_red[4];
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  if (blockIdx.x * 256 >= D.n_mp) return;
+  const double lambda = ctl[w].lambda;
   const int m = blockIdx.x * 256 + threadIdx.x;
   double sc[1] = {0};
   if (m < D.n_mp && D.mp_act[m]) {
@@ -451,10 +596,14 @@ __global__ void __launch_bounds__(256) k_lba_update_points(LbaDev D, double lamb
     }
   }
   block_sum<1>(sc, s_red, threadIdx.x);
-  if (threadIdx.x == 0) D.part[blockIdx.x] = sc[0];
+  if (threadIdx.x == 0) D.part_m[blockIdx.x] = sc[0];
 }
 
-__global__ void k_lba_update_poses(LbaDev D) {
+__global__ void __launch_bounds__(64)
+k_lba_update_poses(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= D.n_kf) return;
   LbaKf kf = D.kf[k];
@@ -468,298 +617,400 @@ __global__ void k_lba_update_poses(LbaDev D) {
   D.kf[k] = kf;
 }
 
-// ================================================================== host-side LM driver
-struct LbaHost {
-  DevBuf obs, kf, kf_bak, X, X_bak, err, level, mp_first, mp_count, mp_act, Bpl, Hll, bl, Hpp, bp, Hs, bs,
-      Dinv, xp, xl, part, kf_list, kf_edge_first, kf_edge_idx, flags, erase;
-};
-static thread_local LbaHost g_lba;
+// ================================================================== host-side lock-step LM driver
 static thread_local hipStream_t g_lba_stream = nullptr;
+static thread_local DevBuf g_arena, g_devs, g_ctl, g_out;
 
-// synchronous copy on the calling thread's own stream (so concurrent LBA calls from several host
-// threads, and the frame pipelines on their streams, do not serialise on the null stream)
+// synchronous copy on the calling thread's own stream (concurrent callers and the frame pipelines
+// on their streams do not serialise on the null stream)
 static inline hipError_t lba_copy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
   hipError_t e = hipMemcpyAsync(dst, src, n, kind, g_lba_stream);
   if (e != hipSuccess) return e;
   return hipStreamSynchronize(g_lba_stream);
 }
 
-#define LBA_ENS(b, n) \
-  if ((rc = (b).ensure(std::max<size_t>((n), 8))) != VIEO_OK) return rc
-
-static int sum_partials(LbaHost& S, int n, double* out) {
-  std::vector<double> h(n);
-  VIEO_HIP_CHECK(lba_copy(h.data(), S.part.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-  double s = 0;
-  for (double v : h) s += v;
-  *out = s;
-  return VIEO_OK;
-}
+struct WinHost {  // per-window LM state machine, exactly g2o's (optimization_algorithm_levenberg.cpp)
+  const vieo_lba_params* P;
+  const vieo_lba_keyframe* kfs;
+  const vieo_lba_obs* obs;
+  const float* points;
+  int n_kf, n_mp, n_obs;
+  LbaDev D;                 // device view (host copy)
+  std::vector<int> mp_first, mp_count, kf_edge_first, kf_edge_idx, kf_list;
+  std::vector<unsigned char> level, mp_act;
+  std::vector<LbaKf> kf;
+  // device sub-allocations that change between the two optimisations
+  int *d_kf_list;
+  unsigned char* d_mp_act;
+  // state
+  int stage = 0;            // 0: optimize(its0), 1: optimize(its1), 2: finished
+  int it = 0, iters = 0;    // iteration inside the current optimize()
+  int phase = 0;            // 0: needs the initial error pass, 1: in trials
+  double lambda = -1, ni = 2, currentChi = 0, iniChi = 0;
+  int nBad = 0, qmax = 0;
+  bool need_build = false, need_restore = false, skip = false;
+  vieo_lba_result* R;
+};
 
 }  // namespace vieo
 
 using namespace vieo;
 
-extern "C" int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo_lba_keyframe* h_kfs,
-                                            int n_kf, const float* h_points, int n_mp,
-                                            const vieo_lba_obs* h_obs, int n_obs,
-                                            volatile const int* stop, vieo_navstate* h_navs_out,
-                                            float* h_points_out, uint8_t* h_erase,
-                                            vieo_lba_result* R) {
-  if (!P || !h_kfs || n_kf <= 0 || !h_points || n_mp <= 0 || !h_obs || n_obs <= 0 || !h_navs_out ||
-      !h_points_out || !h_erase || !R)
+extern "C" {
+
+int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* const* params,
+                                       const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                       const float* const* h_points, const int* n_mp,
+                                       const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                       volatile const int* stop, vieo_navstate* const* h_navs_out,
+                                       float* const* h_points_out, uint8_t* const* h_erase,
+                                       vieo_lba_result* h_results) {
+  if (n_windows <= 0 || !params || !h_kfs || !n_kf || !h_points || !n_mp || !h_obs || !n_obs ||
+      !h_navs_out || !h_points_out || !h_erase || !h_results)
     return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
   if (!g_lba_stream) VIEO_HIP_CHECK(hipStreamCreateWithFlags(&g_lba_stream, hipStreamNonBlocking));
-  memset(R, 0, sizeof(*R));
-  for (int k = 0; k < n_kf; k++) h_navs_out[k] = h_kfs[k].nav;
-  memcpy(h_points_out, h_points, (size_t)n_mp * 12);
-  memset(h_erase, 0, n_obs);
-  bool any_free = false;
-  for (int k = 0; k < n_kf; k++) any_free |= !h_kfs[k].fixed;
-  if (!any_free) {
-    R->status = VIEO_LBA_NO_FREE_POSE;  // Optimizer.cc:1993
-    return VIEO_OK;
-  }
-  // ---- index structures (observations must be grouped by map point)
-  std::vector<int> mp_first(n_mp, 0), mp_count(n_mp, 0), kf_cnt(n_kf + 1, 0);
-  for (int i = 0; i < n_obs; i++) {
-    const int m = h_obs[i].mp, k = h_obs[i].kf;
-    if (m < 0 || m >= n_mp || k < 0 || k >= n_kf || (i > 0 && m < h_obs[i - 1].mp)) {
-      set_error("vieo_local_bundle_adjustment: observations must be sorted by map point");
-      return VIEO_E_INVALID;
-    }
-    if (mp_count[m] == 0) mp_first[m] = i;
-    mp_count[m]++;
-    kf_cnt[k + 1]++;
-  }
-  std::vector<int> kf_edge_first(n_kf + 1, 0), kf_edge_idx(n_obs), fill(n_kf, 0);
-  for (int k = 0; k < n_kf; k++) kf_edge_first[k + 1] = kf_edge_first[k] + kf_cnt[k + 1];
-  for (int i = 0; i < n_obs; i++) kf_edge_idx[kf_edge_first[h_obs[i].kf] + fill[h_obs[i].kf]++] = i;
-  std::vector<LbaKf> kf(n_kf);
-  for (int k = 0; k < n_kf; k++) {
-    memcpy(kf[k].p, h_kfs[k].nav.p, 24);
-    kf[k].qw = h_kfs[k].nav.q[0], kf[k].qx = h_kfs[k].nav.q[1], kf[k].qy = h_kfs[k].nav.q[2],
-    kf[k].qz = h_kfs[k].nav.q[3];
-    kf[k].col = -1, kf[k].pad = 0;
-  }
-  std::vector<double> X((size_t)n_mp * 3);
-  for (int i = 0; i < n_mp * 3; i++) X[i] = (double)h_points[i];
-  LbaHost& S = g_lba;
-  const int nblk_e = (n_obs + 255) / 256, nblk_m = (n_mp + 255) / 256;
-  const int np_max = 6 * n_kf;
-  if (np_max > 512) {
-    set_error("local BA: more than 85 key frames");
-    return VIEO_E_CAPACITY;
-  }
-  LBA_ENS(S.obs, (size_t)n_obs * sizeof(vieo_lba_obs));
-  LBA_ENS(S.kf, (size_t)n_kf * sizeof(LbaKf));
-  LBA_ENS(S.kf_bak, (size_t)n_kf * sizeof(LbaKf));
-  LBA_ENS(S.X, (size_t)n_mp * 24);
-  LBA_ENS(S.X_bak, (size_t)n_mp * 24);
-  LBA_ENS(S.err, (size_t)n_obs * 24);
-  LBA_ENS(S.level, (size_t)n_obs);
-  LBA_ENS(S.erase, (size_t)n_obs);
-  LBA_ENS(S.mp_first, (size_t)n_mp * 4);
-  LBA_ENS(S.mp_count, (size_t)n_mp * 4);
-  LBA_ENS(S.mp_act, (size_t)n_mp);
-  LBA_ENS(S.Bpl, (size_t)n_obs * 18 * 8);
-  LBA_ENS(S.Hll, (size_t)n_mp * 72);
-  LBA_ENS(S.bl, (size_t)n_mp * 24);
-  LBA_ENS(S.Dinv, (size_t)n_mp * 72);
-  LBA_ENS(S.xl, (size_t)n_mp * 24);
-  LBA_ENS(S.Hpp, (size_t)np_max * np_max * 8);
-  LBA_ENS(S.Hs, (size_t)np_max * np_max * 8);
-  LBA_ENS(S.bp, (size_t)np_max * 8);
-  LBA_ENS(S.bs, (size_t)np_max * 8);
-  LBA_ENS(S.xp, (size_t)np_max * 8);
-  LBA_ENS(S.part, (size_t)std::max(nblk_e, nblk_m) * 8);
-  LBA_ENS(S.kf_list, (size_t)n_kf * 4);
-  LBA_ENS(S.kf_edge_first, (size_t)(n_kf + 1) * 4);
-  LBA_ENS(S.kf_edge_idx, (size_t)n_obs * 4);
-  LBA_ENS(S.flags, 16);
-  VIEO_HIP_CHECK(lba_copy(S.obs.p, h_obs, (size_t)n_obs * sizeof(vieo_lba_obs), hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(lba_copy(S.X.p, X.data(), X.size() * 8, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(lba_copy(S.mp_first.p, mp_first.data(), (size_t)n_mp * 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(lba_copy(S.mp_count.p, mp_count.data(), (size_t)n_mp * 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(lba_copy(S.kf_edge_first.p, kf_edge_first.data(), (size_t)(n_kf + 1) * 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(lba_copy(S.kf_edge_idx.p, kf_edge_idx.data(), (size_t)n_obs * 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemsetAsync(S.level.p, 0, n_obs, g_lba_stream));
-  VIEO_HIP_CHECK(hipMemsetAsync(S.err.p, 0, (size_t)n_obs * 24, g_lba_stream));
-  LbaDev D;
-  D.obs = S.obs.as<vieo_lba_obs>();
-  D.n_obs = n_obs, D.n_mp = n_mp, D.n_kf = n_kf, D.np = 0;
-  D.kf = S.kf.as<LbaKf>(), D.X = S.X.as<double>(), D.err = S.err.as<double>();
-  D.level = S.level.as<unsigned char>();
-  D.mp_first = S.mp_first.as<int>(), D.mp_count = S.mp_count.as<int>();
-  D.mp_act = S.mp_act.as<unsigned char>();
-  D.Bpl = S.Bpl.as<double>(), D.Hll = S.Hll.as<double>(), D.bl = S.bl.as<double>();
-  D.Hpp = S.Hpp.as<double>(), D.bp = S.bp.as<double>(), D.Hs = S.Hs.as<double>(), D.bs = S.bs.as<double>();
-  D.Dinv = S.Dinv.as<double>(), D.xp = S.xp.as<double>(), D.xl = S.xl.as<double>();
-  D.part = S.part.as<double>();
-  D.cam.fx = P->fx, D.cam.fy = P->fy, D.cam.cx = P->cx, D.cam.cy = P->cy, D.cam.bf = P->bf;
-  memcpy(D.cam.Rcb, P->Rcb, 72);
-  memcpy(D.cam.tcb, P->tcb, 24);
-  D.robust = 1;
-  D.dMono = (double)(float)sqrt(5.991), D.dStereo = (double)(float)sqrt(7.815);
   hipStream_t st = g_lba_stream;
-  std::vector<unsigned char> level(n_obs, 0), mp_act(n_mp);
-  std::vector<int> kf_list;
-
-  auto robust_chi2 = [&](double* out) -> int {
-    hipLaunchKernelGGL(k_lba_error, dim3(nblk_e), dim3(256), 0, st, D);
-    return sum_partials(S, nblk_e, out);
+  const int W = n_windows;
+  std::vector<WinHost> win(W);
+  // ---- host-side index structures + arena layout
+  size_t arena = 0;
+  auto take = [&](size_t bytes) {
+    const size_t off = arena;
+    arena += (bytes + 255) / 256 * 256;
+    return off;
   };
-  // one SparseOptimizer::optimize(iterations)
-  auto optimize = [&](int iterations, bool first) -> int {
-    // initializeOptimization(0): active edges -> active vertices -> reduced-system columns
-    std::vector<char> kf_act(n_kf, 0);
-    std::fill(mp_act.begin(), mp_act.end(), 0);
-    bool any = false;
-    for (int i = 0; i < n_obs; i++)
-      if (!level[i]) kf_act[h_obs[i].kf] = 1, mp_act[h_obs[i].mp] = 1, any = true;
-    int np = 0;
-    kf_list.clear();
-    for (int k = 0; k < n_kf; k++) {
-      if (!h_kfs[k].fixed && kf_act[k]) {
-        kf[k].col = np, np += 6;
-        kf_list.push_back(k);
-      } else
-        kf[k].col = -1;
+  struct Off {
+    size_t obs, kf, kf_bak, X, X_bak, err, level, erase, mp_first, mp_count, mp_act, Bpl, Hll, bl, Dinv, xl,
+        Hpp, Hs, bp, bs, xp, part, part_m, kf_list, kf_edge_first, kf_edge_idx;
+  };
+  std::vector<Off> off(W);
+  int max_obs = 0, max_mp = 0, max_kf = 0, max_np = 0;
+  for (int w = 0; w < W; w++) {
+    WinHost& H = win[w];
+    H.P = params[w], H.kfs = h_kfs[w], H.obs = h_obs[w], H.points = h_points[w];
+    H.n_kf = n_kf[w], H.n_mp = n_mp[w], H.n_obs = n_obs[w];
+    H.R = &h_results[w];
+    memset(H.R, 0, sizeof(*H.R));
+    if (!H.P || !H.kfs || H.n_kf <= 0 || !H.points || H.n_mp <= 0 || !H.obs || H.n_obs <= 0) return VIEO_E_INVALID;
+    for (int k = 0; k < H.n_kf; k++) h_navs_out[w][k] = H.kfs[k].nav;
+    memcpy(h_points_out[w], H.points, (size_t)H.n_mp * 12);
+    memset(h_erase[w], 0, H.n_obs);
+    bool any_free = false;
+    for (int k = 0; k < H.n_kf; k++) any_free |= !H.kfs[k].fixed;
+    if (!any_free) {
+      H.R->status = VIEO_LBA_NO_FREE_POSE;  // Optimizer.cc:1993
+      H.skip = true, H.stage = 2;
     }
-    if (!any || np == 0) return VIEO_OK;
-    // keep the device poses, refresh only the column map
-    std::vector<LbaKf> cur(n_kf);
-    if (!first) {
-      VIEO_HIP_CHECK(lba_copy(cur.data(), S.kf.p, (size_t)n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
-      for (int k = 0; k < n_kf; k++) cur[k].col = kf[k].col;
-    } else
-      cur = kf;
-    VIEO_HIP_CHECK(lba_copy(S.kf.p, cur.data(), (size_t)n_kf * sizeof(LbaKf), hipMemcpyHostToDevice));
-    VIEO_HIP_CHECK(lba_copy(S.mp_act.p, mp_act.data(), n_mp, hipMemcpyHostToDevice));
-    VIEO_HIP_CHECK(lba_copy(S.kf_list.p, kf_list.data(), kf_list.size() * 4, hipMemcpyHostToDevice));
-    D.np = np;
-    const int lds_np = np | 1;  // odd leading dimension: spreads the LDS atomics over banks
-    const size_t stage_lds = 4 * (192 * 4 * 2 + 192) * 8 + 64;
-    size_t schur_lds = ((size_t)lds_np * lds_np + lds_np) * 8 + stage_lds;
-    const int use_lds = schur_lds <= 150 * 1024;
-    if (!use_lds) schur_lds = stage_lds;
-    VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_schur, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)schur_lds));
-    const int schur_blocks = std::max(1, std::min(256, (n_mp + 3) / 4));
-    double lambda = -1, ni = 2;
-    int nBad = 0;
-    for (int it = 0; it < iterations; it++) {
-      if (stop && *stop) break;
-      R->lm_iterations++;
-      double currentChi;
-      if ((rc = robust_chi2(&currentChi)) != VIEO_OK) return rc;
-      if (first && it == 0) R->chi2_initial = currentChi;
-      const double iniChi = currentChi;
-      // ---- buildSystem
-      VIEO_HIP_CHECK(hipMemsetAsync(S.Hpp.p, 0, (size_t)np * np * 8, st));
-      VIEO_HIP_CHECK(hipMemsetAsync(S.bp.p, 0, (size_t)np * 8, st));
-      hipLaunchKernelGGL(k_lba_linearize, dim3((n_mp + 15) / 16), dim3(256), 0, st, D);
-      hipLaunchKernelGGL(k_lba_pose, dim3(8, (unsigned)kf_list.size()), dim3(256), 0, st, D,
-                         S.kf_list.as<int>(), S.kf_edge_first.as<int>(), S.kf_edge_idx.as<int>());
-      if (it == 0) {  // computeLambdaInit: tau * max diagonal over poses and landmarks
-        std::vector<double> Hpp((size_t)np * np), Hll((size_t)n_mp * 9);
-        VIEO_HIP_CHECK(lba_copy(Hpp.data(), S.Hpp.p, Hpp.size() * 8, hipMemcpyDeviceToHost));
-        VIEO_HIP_CHECK(lba_copy(Hll.data(), S.Hll.p, Hll.size() * 8, hipMemcpyDeviceToHost));
-        double mx = 0;
-        for (int j = 0; j < np; j++) mx = std::max(std::fabs(Hpp[(size_t)j * np + j]), mx);
-        for (int m = 0; m < n_mp; m++)
-          if (mp_act[m])
-            for (int a = 0; a < 3; a++) mx = std::max(std::fabs(Hll[(size_t)m * 9 + a * 4]), mx);
-        lambda = 1e-5 * mx;
-        ni = 2;
-        nBad = 0;
+    if (6 * H.n_kf > 512) {
+      set_error("local BA: more than 85 key frames in a window");
+      return VIEO_E_CAPACITY;
+    }
+    H.mp_first.assign(H.n_mp, 0), H.mp_count.assign(H.n_mp, 0);
+    std::vector<int> kf_cnt(H.n_kf + 1, 0), fill(H.n_kf, 0);
+    for (int i = 0; i < H.n_obs; i++) {
+      const int m = H.obs[i].mp, k = H.obs[i].kf;
+      if (m < 0 || m >= H.n_mp || k < 0 || k >= H.n_kf || (i > 0 && m < H.obs[i - 1].mp)) {
+        set_error("vieo_local_bundle_adjustment: observations must be sorted by map point");
+        return VIEO_E_INVALID;
       }
-      std::vector<double> bp(np);
-      VIEO_HIP_CHECK(lba_copy(bp.data(), S.bp.p, (size_t)np * 8, hipMemcpyDeviceToHost));
-      double rho = 0;
-      int qmax = 0;
-      do {
-        R->lm_trials++;
-        VIEO_HIP_CHECK(hipMemcpyAsync(S.kf_bak.p, S.kf.p, (size_t)n_kf * sizeof(LbaKf), hipMemcpyDeviceToDevice, st));
-        VIEO_HIP_CHECK(hipMemcpyAsync(S.X_bak.p, S.X.p, (size_t)n_mp * 24, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_lba_init_reduced, dim3((np * np + 255) / 256), dim3(256), 0, st, D, lambda);
-        VIEO_HIP_CHECK(hipMemsetAsync(S.flags.p, 0, 16, st));
-        hipLaunchKernelGGL(k_lba_schur, dim3(schur_blocks), dim3(256), schur_lds, st, D, lambda, lds_np,
-                           S.flags.as<int>() + 1, use_lds);
-        hipLaunchKernelGGL(k_lba_ldlt, dim3(1), dim3(256), 0, st, D.Hs, D.bs, D.xp, np, S.flags.as<int>());
-        hipLaunchKernelGGL(k_lba_update_points, dim3(nblk_m), dim3(256), 0, st, D, lambda);
-        hipLaunchKernelGGL(k_lba_update_poses, dim3((n_kf + 63) / 64), dim3(64), 0, st, D);
-        double scale_l;
-        if ((rc = sum_partials(S, nblk_m, &scale_l)) != VIEO_OK) return rc;
-        int flags[2];
-        std::vector<double> xp(np);
-        VIEO_HIP_CHECK(lba_copy(flags, S.flags.p, 8, hipMemcpyDeviceToHost));
-        VIEO_HIP_CHECK(lba_copy(xp.data(), S.xp.p, (size_t)np * 8, hipMemcpyDeviceToHost));
-        if (flags[1]) {
-          set_error("local BA: a map point has more than %d free observers", kSchurMaxObs);
-          return VIEO_E_CAPACITY;
-        }
-        const bool ok2 = flags[0] != 0;
-        double tempChi;
-        if ((rc = robust_chi2(&tempChi)) != VIEO_OK) return rc;
-        if (!ok2) tempChi = DBL_MAX;
-        rho = currentChi - tempChi;
-        double scale = ok2 ? scale_l : 0.0;
-        for (int j = 0; j < np; j++) scale += xp[j] * (lambda * xp[j] + bp[j]);
-        scale += 1e-3;
-        rho /= scale;
-        if (rho > 0 && std::isfinite(tempChi)) {
-          double alpha = 1. - std::pow(2 * rho - 1, 3);
-          alpha = std::min(alpha, 2. / 3.);
-          lambda *= std::max(1. / 3., alpha);
-          ni = 2;
-          currentChi = tempChi;
-        } else {
-          lambda *= ni;
-          ni *= 2;
-          VIEO_HIP_CHECK(hipMemcpyAsync(S.kf.p, S.kf_bak.p, (size_t)n_kf * sizeof(LbaKf), hipMemcpyDeviceToDevice, st));
-          VIEO_HIP_CHECK(hipMemcpyAsync(S.X.p, S.X_bak.p, (size_t)n_mp * 24, hipMemcpyDeviceToDevice, st));
-        }
-        qmax++;
-      } while (rho < 0 && qmax < 10 && !(stop && *stop));
-      R->chi2_final = currentChi;
-      if (qmax == 10 || rho == 0) break;
-      if ((iniChi - currentChi) * 1e3 < iniChi)
-        nBad++;
-      else
-        nBad = 0;
-      if (nBad >= 3) break;
+      if (H.mp_count[m] == 0) H.mp_first[m] = i;
+      H.mp_count[m]++;
+      kf_cnt[k + 1]++;
     }
-    return VIEO_OK;
+    H.kf_edge_first.assign(H.n_kf + 1, 0);
+    H.kf_edge_idx.resize(H.n_obs);
+    for (int k = 0; k < H.n_kf; k++) H.kf_edge_first[k + 1] = H.kf_edge_first[k] + kf_cnt[k + 1];
+    for (int i = 0; i < H.n_obs; i++) H.kf_edge_idx[H.kf_edge_first[H.obs[i].kf] + fill[H.obs[i].kf]++] = i;
+    H.kf.resize(H.n_kf);
+    for (int k = 0; k < H.n_kf; k++) {
+      memcpy(H.kf[k].p, H.kfs[k].nav.p, 24);
+      H.kf[k].qw = H.kfs[k].nav.q[0], H.kf[k].qx = H.kfs[k].nav.q[1];
+      H.kf[k].qy = H.kfs[k].nav.q[2], H.kf[k].qz = H.kfs[k].nav.q[3];
+      H.kf[k].col = -1, H.kf[k].pad = 0;
+    }
+    H.level.assign(H.n_obs, 0), H.mp_act.assign(H.n_mp, 0);
+    const int npm = 6 * H.n_kf;
+    Off& o = off[w];
+    o.obs = take((size_t)H.n_obs * sizeof(vieo_lba_obs));
+    o.kf = take((size_t)H.n_kf * sizeof(LbaKf)), o.kf_bak = take((size_t)H.n_kf * sizeof(LbaKf));
+    o.X = take((size_t)H.n_mp * 24), o.X_bak = take((size_t)H.n_mp * 24);
+    o.err = take((size_t)H.n_obs * 24), o.level = take(H.n_obs), o.erase = take(H.n_obs);
+    o.mp_first = take((size_t)H.n_mp * 4), o.mp_count = take((size_t)H.n_mp * 4), o.mp_act = take(H.n_mp);
+    o.Bpl = take((size_t)H.n_obs * 144), o.Hll = take((size_t)H.n_mp * 72), o.bl = take((size_t)H.n_mp * 24);
+    o.Dinv = take((size_t)H.n_mp * 72), o.xl = take((size_t)H.n_mp * 24);
+    o.Hpp = take((size_t)npm * npm * 8), o.Hs = take((size_t)npm * npm * 8);
+    o.bp = take((size_t)npm * 8), o.bs = take((size_t)npm * 8), o.xp = take((size_t)npm * 8);
+    o.part = take((size_t)((H.n_obs + 255) / 256) * 8), o.part_m = take((size_t)((H.n_mp + 255) / 256) * 8);
+    o.kf_list = take((size_t)H.n_kf * 4), o.kf_edge_first = take((size_t)(H.n_kf + 1) * 4);
+    o.kf_edge_idx = take((size_t)H.n_obs * 4);
+    max_obs = std::max(max_obs, H.n_obs), max_mp = std::max(max_mp, H.n_mp);
+    max_kf = std::max(max_kf, H.n_kf), max_np = std::max(max_np, npm);
+  }
+  if ((rc = g_arena.ensure(arena)) != VIEO_OK) return rc;
+  if ((rc = g_devs.ensure((size_t)W * sizeof(LbaDev))) != VIEO_OK) return rc;
+  if ((rc = g_ctl.ensure((size_t)W * sizeof(WinCtl))) != VIEO_OK) return rc;
+  if ((rc = g_out.ensure((size_t)W * sizeof(WinOut))) != VIEO_OK) return rc;
+  uint8_t* base = g_arena.as<uint8_t>();
+  for (int w = 0; w < W; w++) {
+    WinHost& H = win[w];
+    const Off& o = off[w];
+    LbaDev& D = H.D;
+    memset(&D, 0, sizeof(D));
+    D.obs = (const vieo_lba_obs*)(base + o.obs);
+    D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.np = 0, D.n_free = 0;
+    D.kf = (LbaKf*)(base + o.kf), D.kf_bak = (LbaKf*)(base + o.kf_bak);
+    D.X = (double*)(base + o.X), D.X_bak = (double*)(base + o.X_bak), D.err = (double*)(base + o.err);
+    D.level = base + o.level, D.erase = base + o.erase;
+    D.mp_first = (const int*)(base + o.mp_first), D.mp_count = (const int*)(base + o.mp_count);
+    D.mp_act = base + o.mp_act;
+    H.d_mp_act = base + o.mp_act, H.d_kf_list = (int*)(base + o.kf_list);
+    D.Bpl = (double*)(base + o.Bpl), D.Hll = (double*)(base + o.Hll), D.bl = (double*)(base + o.bl);
+    D.Dinv = (double*)(base + o.Dinv), D.xl = (double*)(base + o.xl);
+    D.Hpp = (double*)(base + o.Hpp), D.Hs = (double*)(base + o.Hs), D.bp = (double*)(base + o.bp);
+    D.bs = (double*)(base + o.bs), D.xp = (double*)(base + o.xp);
+    D.part = (double*)(base + o.part), D.part_m = (double*)(base + o.part_m);
+    D.kf_list = (const int*)(base + o.kf_list), D.kf_edge_first = (const int*)(base + o.kf_edge_first);
+    D.kf_edge_idx = (const int*)(base + o.kf_edge_idx);
+    D.cam.fx = H.P->fx, D.cam.fy = H.P->fy, D.cam.cx = H.P->cx, D.cam.cy = H.P->cy, D.cam.bf = H.P->bf;
+    memcpy(D.cam.Rcb, H.P->Rcb, 72);
+    memcpy(D.cam.tcb, H.P->tcb, 24);
+    D.robust = 1;
+    D.dMono = (double)(float)sqrt(5.991), D.dStereo = (double)(float)sqrt(7.815);
+    std::vector<double> X((size_t)H.n_mp * 3);
+    for (int i = 0; i < H.n_mp * 3; i++) X[i] = (double)H.points[i];
+    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.obs, H.obs, (size_t)H.n_obs * sizeof(vieo_lba_obs), hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.X, X.data(), X.size() * 8, hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.mp_first, H.mp_first.data(), (size_t)H.n_mp * 4, hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.mp_count, H.mp_count.data(), (size_t)H.n_mp * 4, hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.kf_edge_first, H.kf_edge_first.data(), (size_t)(H.n_kf + 1) * 4, hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.kf_edge_idx, H.kf_edge_idx.data(), (size_t)H.n_obs * 4, hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemsetAsync(base + o.level, 0, H.n_obs, st));
+    VIEO_HIP_CHECK(hipMemsetAsync(base + o.err, 0, (size_t)H.n_obs * 24, st));
+    VIEO_HIP_CHECK(hipStreamSynchronize(st));  // X goes out of scope
+  }
+  const int lds_np_max = max_np | 1;
+  const size_t stage_lds = 4 * (192 * 4 * 2 + 192) * 8 + 64;
+  size_t schur_lds = ((size_t)lds_np_max * lds_np_max + lds_np_max) * 8 + stage_lds;
+  const int use_lds = schur_lds <= 150 * 1024;
+  if (!use_lds) schur_lds = stage_lds;
+  VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_schur, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)schur_lds));
+  std::vector<WinCtl> ctl(W);
+  std::vector<WinOut> out(W);
+  std::vector<LbaDev> devs(W);
+  bool first_upload = true;
+
+  // initializeOptimization(0) for a window: active vertices, reduced-system columns
+  auto begin_optimize = [&](WinHost& H, int iterations) -> int {
+    std::vector<char> kf_act(H.n_kf, 0);
+    std::fill(H.mp_act.begin(), H.mp_act.end(), 0);
+    bool any = false;
+    for (int i = 0; i < H.n_obs; i++)
+      if (!H.level[i]) kf_act[H.obs[i].kf] = 1, H.mp_act[H.obs[i].mp] = 1, any = true;
+    int np = 0;
+    H.kf_list.clear();
+    for (int k = 0; k < H.n_kf; k++) {
+      if (!H.kfs[k].fixed && kf_act[k]) {
+        H.kf[k].col = np, np += 6;
+        H.kf_list.push_back(k);
+      } else
+        H.kf[k].col = -1;
+    }
+    H.D.np = np, H.D.n_free = (int)H.kf_list.size();
+    H.it = 0, H.iters = iterations, H.phase = 0, H.need_restore = false;
+    std::vector<LbaKf> cur(H.n_kf);
+    if (H.stage == 0)
+      cur = H.kf;
+    else {
+      VIEO_HIP_CHECK(lba_copy(cur.data(), H.D.kf, (size_t)H.n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
+      for (int k = 0; k < H.n_kf; k++) cur[k].col = H.kf[k].col;
+    }
+    VIEO_HIP_CHECK(hipMemcpyAsync(H.D.kf, cur.data(), (size_t)H.n_kf * sizeof(LbaKf), hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemcpyAsync(H.d_mp_act, H.mp_act.data(), H.n_mp, hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemcpyAsync(H.d_kf_list, H.kf_list.data(), H.kf_list.size() * 4, hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipStreamSynchronize(st));
+    return (!any || np == 0 || iterations <= 0) ? 1 : 0;  // 1: nothing to optimise
   };
 
-  if (stop && *stop) {
-    R->status = VIEO_LBA_ABORTED;
-    return VIEO_OK;
+  const bool stopped0 = stop && *stop;
+  for (int w = 0; w < W; w++) {
+    WinHost& H = win[w];
+    if (H.skip) continue;
+    if (stopped0) {
+      H.R->status = VIEO_LBA_ABORTED, H.stage = 2;
+      continue;
+    }
+    int r = begin_optimize(H, H.P->its0);
+    if (r < 0) return r;
+    if (r == 1) H.phase = 2;  // empty optimisation: go straight to the stage transition
   }
-  if ((rc = optimize(P->its0, true)) != VIEO_OK) return rc;
-  if (!(stop && *stop)) {
-    hipLaunchKernelGGL(k_lba_classify, dim3(nblk_e), dim3(256), 0, st, D, 0, S.erase.as<unsigned char>());
-    VIEO_HIP_CHECK(lba_copy(level.data(), S.level.p, n_obs, hipMemcpyDeviceToHost));
-    D.robust = 0;
-    if ((rc = optimize(P->its1, false)) != VIEO_OK) return rc;
-  } else
-    R->status = VIEO_LBA_ABORTED;
-  hipLaunchKernelGGL(k_lba_classify, dim3(nblk_e), dim3(256), 0, st, D, 1, S.erase.as<unsigned char>());
-  VIEO_HIP_CHECK(lba_copy(h_erase, S.erase.p, n_obs, hipMemcpyDeviceToHost));
-  for (int i = 0; i < n_obs; i++) R->n_erase += h_erase[i];
-  std::vector<LbaKf> out(n_kf);
-  VIEO_HIP_CHECK(lba_copy(out.data(), S.kf.p, (size_t)n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
-  VIEO_HIP_CHECK(lba_copy(X.data(), S.X.p, X.size() * 8, hipMemcpyDeviceToHost));
-  for (int k = 0; k < n_kf; k++) {
-    if (h_kfs[k].fixed) continue;
-    memcpy(h_navs_out[k].p, out[k].p, 24);
-    h_navs_out[k].q[0] = out[k].qw, h_navs_out[k].q[1] = out[k].qx, h_navs_out[k].q[2] = out[k].qy,
-    h_navs_out[k].q[3] = out[k].qz;
+
+  // ---- lock-step rounds
+  for (int guard = 0; guard < 400; guard++) {
+    bool any_work = false, any_class = false;
+    for (int w = 0; w < W; w++) {
+      WinHost& H = win[w];
+      WinCtl& c = ctl[w];
+      c.flags = 0, c.pad = 0, c.lambda = H.lambda;
+      if (H.stage >= 2) continue;
+      if (H.phase == 2) {  // optimize() finished -> stage transition handled below
+        continue;
+      }
+      if (H.phase == 0) {
+        c.flags = LBA_ERROR | LBA_BUILD;  // computeActiveErrors + buildSystem of iteration 0
+      } else {
+        c.flags = LBA_TRIAL | (H.need_build ? LBA_BUILD : 0) | (H.need_restore ? LBA_RESTORE : 0);
+      }
+      any_work = true;
+    }
+    // stage transitions (classification) for windows whose optimize() ended
+    for (int w = 0; w < W; w++) {
+      WinHost& H = win[w];
+      if (H.stage < 2 && H.phase == 2) {
+        ctl[w].flags = (H.stage == 0 && !(stop && *stop)) ? LBA_CLASS0 : LBA_CLASS1;
+        if (H.need_restore) ctl[w].flags |= LBA_RESTORE;
+        any_class = true;
+      }
+    }
+    if (!any_work && !any_class) break;
+    for (int w = 0; w < W; w++) devs[w] = win[w].D;
+    VIEO_HIP_CHECK(hipMemcpyAsync(g_devs.p, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
+    VIEO_HIP_CHECK(hipMemcpyAsync(g_ctl.p, ctl.data(), (size_t)W * sizeof(WinCtl), hipMemcpyHostToDevice, st));
+    (void)first_upload;
+    const LbaDev* dD = g_devs.as<LbaDev>();
+    const WinCtl* dC = g_ctl.as<WinCtl>();
+    WinOut* dO = g_out.as<WinOut>();
+    const int ge = (max_obs + 255) / 256, gm = (max_mp + 255) / 256;
+    const int gx = std::max((max_mp * 3 + 255) / 256, (max_kf + 255) / 256);
+    hipLaunchKernelGGL(k_lba_backup_restore, dim3(gx, W), dim3(256), 0, st, dD, dC, 1);
+    if (any_class) hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC);
+    if (any_work) {
+      // phase-0 windows: residuals first (their chi2 is the iteration's currentChi)
+      hipLaunchKernelGGL(k_lba_zero_pose, dim3((max_np * max_np + 255) / 256, W), dim3(256), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_linearize, dim3((max_mp + 15) / 16, W), dim3(256), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_pose, dim3(8, max_kf, W), dim3(256), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_maxdiag, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_backup_restore, dim3(gx, W), dim3(256), 0, st, dD, dC, 0);
+      hipLaunchKernelGGL(k_lba_init_reduced, dim3((max_np * max_np + 255) / 256, W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_schur, dim3(std::max(1, std::min(std::max(16, 512 / W), (max_mp + 3) / 4)), W), dim3(256),
+                         schur_lds, st, dD, dC, dO, lds_np_max, use_lds);
+      hipLaunchKernelGGL(k_lba_ldlt, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_update_poses, dim3((max_kf + 63) / 64, W), dim3(64), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      VIEO_HIP_CHECK(lba_copy(out.data(), g_out.p, (size_t)W * sizeof(WinOut), hipMemcpyDeviceToHost));
+    }
+    VIEO_HIP_CHECK(hipGetLastError());
+    // ---- per-window policy (optimization_algorithm_levenberg.cpp:61-164)
+    for (int w = 0; w < W; w++) {
+      WinHost& H = win[w];
+      const int fl = ctl[w].flags;
+      if (fl & (LBA_CLASS0 | LBA_CLASS1)) {
+        H.need_restore = false;
+        if (fl & LBA_CLASS0) {
+          VIEO_HIP_CHECK(lba_copy(H.level.data(), H.D.level, H.n_obs, hipMemcpyDeviceToHost));
+          H.stage = 1;
+          H.D.robust = 0;
+          int r = begin_optimize(H, H.P->its1);
+          if (r < 0) return r;
+          H.phase = r == 1 ? 2 : 0;
+        } else {
+          if (H.stage == 0) H.R->status = VIEO_LBA_ABORTED;  // stop flag between the two stages
+          H.stage = 2;
+        }
+        continue;
+      }
+      if (fl & LBA_ERROR) {  // start of an optimize(): error pass + first linearisation are done
+        H.R->lm_iterations++;
+        H.currentChi = out[w].chi2;
+        if (H.stage == 0) H.R->chi2_initial = H.currentChi;
+        H.iniChi = H.currentChi;
+        H.lambda = 1e-5 * out[w].maxdiag;  // computeLambdaInit
+        H.ni = 2, H.nBad = 0, H.qmax = 0;
+        H.phase = 1, H.need_build = false, H.need_restore = false;
+        continue;
+      }
+      if (!(fl & LBA_TRIAL)) continue;
+      if (out[w].overflow) {
+        set_error("local BA: a map point has more than %d free observers", kSchurMaxObs);
+        return VIEO_E_CAPACITY;
+      }
+      H.R->lm_trials++;
+      H.need_build = false;
+      const bool ok2 = out[w].ok != 0;
+      double tempChi = ok2 ? out[w].chi2 : DBL_MAX;
+      double rho = H.currentChi - tempChi;
+      double scale = (ok2 ? out[w].scale_l + out[w].scale_p : 0.0) + 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow(2 * rho - 1, 3);
+        alpha = std::min(alpha, 2. / 3.);
+        H.lambda *= std::max(1. / 3., alpha);
+        H.ni = 2;
+        H.currentChi = tempChi;
+        H.need_restore = false;
+      } else {
+        H.lambda *= H.ni;
+        H.ni *= 2;
+        H.need_restore = true;
+      }
+      H.qmax++;
+      H.R->chi2_final = H.currentChi;
+      const bool again = rho < 0 && H.qmax < 10 && !(stop && *stop);
+      if (again) continue;  // next lambda trial of the same iteration
+      // ---- the iteration is over
+      bool terminate = (H.qmax == 10 || rho == 0);
+      if (!terminate) {
+        if ((H.iniChi - H.currentChi) * 1e3 < H.iniChi)
+          H.nBad++;
+        else
+          H.nBad = 0;
+        if (H.nBad >= 3) terminate = true;
+      }
+      H.it++;
+      if (terminate || H.it >= H.iters || (stop && *stop)) {
+        H.phase = 2;
+      } else {
+        H.R->lm_iterations++;
+        H.iniChi = H.currentChi;
+        H.qmax = 0;
+        H.need_build = true;  // buildSystem at the accepted state (errors there are already stored)
+      }
+    }
   }
-  for (int i = 0; i < n_mp * 3; i++) h_points_out[i] = (float)X[i];  // SetWorldPos(cast<float>)
-  VIEO_HIP_CHECK(hipGetLastError());
+  // ---- results
+  for (int w = 0; w < W; w++) {
+    WinHost& H = win[w];
+    if (H.skip || (stopped0)) continue;
+    VIEO_HIP_CHECK(lba_copy(h_erase[w], H.D.erase, H.n_obs, hipMemcpyDeviceToHost));
+    for (int i = 0; i < H.n_obs; i++) H.R->n_erase += h_erase[w][i];
+    std::vector<LbaKf> o(H.n_kf);
+    std::vector<double> X((size_t)H.n_mp * 3);
+    VIEO_HIP_CHECK(lba_copy(o.data(), H.D.kf, (size_t)H.n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
+    VIEO_HIP_CHECK(lba_copy(X.data(), H.D.X, X.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < H.n_kf; k++) {
+      if (H.kfs[k].fixed) continue;
+      memcpy(h_navs_out[w][k].p, o[k].p, 24);
+      h_navs_out[w][k].q[0] = o[k].qw, h_navs_out[w][k].q[1] = o[k].qx;
+      h_navs_out[w][k].q[2] = o[k].qy, h_navs_out[w][k].q[3] = o[k].qz;
+    }
+    for (int i = 0; i < H.n_mp * 3; i++) h_points_out[w][i] = (float)X[i];  // SetWorldPos(cast<float>)
+  }
   return VIEO_OK;
 }
+
+int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo_lba_keyframe* h_kfs, int n_kf,
+                                 const float* h_points, int n_mp, const vieo_lba_obs* h_obs, int n_obs,
+                                 volatile const int* stop, vieo_navstate* h_navs_out,
+                                 float* h_points_out, uint8_t* h_erase, vieo_lba_result* R) {
+  if (!P || !h_kfs || n_kf <= 0 || !h_points || n_mp <= 0 || !h_obs || n_obs <= 0 || !h_navs_out ||
+      !h_points_out || !h_erase || !R)
+    return VIEO_E_INVALID;
+  return vieo_local_bundle_adjustment_batch(1, &P, &h_kfs, &n_kf, &h_points, &n_mp, &h_obs, &n_obs, stop,
+                                            &h_navs_out, &h_points_out, &h_erase, R);
+}
+
+}  // extern "C"

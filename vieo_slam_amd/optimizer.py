@@ -54,3 +54,32 @@ class Optimizer:
                                                  navs.ctypes.data, pts.ctypes.data, erase.ctypes.data,
                                                  res.ctypes.data), "vieo_local_bundle_adjustment")
         return navs, pts, erase[:len(obs)], res[0]
+
+    @staticmethod
+    def LocalBundleAdjustmentBatch(windows, stop=None):
+        """Several independent LocalBundleAdjustment windows in lock step (one launch sequence for
+        all of them).  windows: list of (params, kfs, points, obs) as for LocalBundleAdjustment.
+        returns a list of (navs, points, erase, result) in the same order."""
+        W = len(windows)
+        keep, outs = [], []
+        ptrs = [np.zeros(W, np.uint64) for _ in range(7)]  # params kfs points obs navs pts erase
+        cnt = [np.zeros(W, np.int32) for _ in range(3)]    # n_kf n_mp n_obs
+        res = np.zeros(W, LBA_RESULT_DTYPE)
+        for w, (params, kfs, points, obs) in enumerate(windows):
+            params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
+            points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+            navs = np.zeros(len(kfs), NAVSTATE_DTYPE)
+            pts = np.zeros_like(points)
+            erase = np.zeros(max(len(obs), 1), np.uint8)
+            keep.append((params, kfs, points, obs))
+            outs.append((navs, pts, erase, len(obs)))
+            for a, arr in zip(ptrs, (params, kfs, points, obs, navs, pts, erase)):
+                a[w] = arr.ctypes.data
+            cnt[0][w], cnt[1][w], cnt[2][w] = len(kfs), len(points), len(obs)
+        st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        check(lib().vieo_local_bundle_adjustment_batch(
+            W, ptrs[0].ctypes.data, ptrs[1].ctypes.data, cnt[0].ctypes.data, ptrs[2].ctypes.data,
+            cnt[1].ctypes.data, ptrs[3].ctypes.data, cnt[2].ctypes.data,
+            None if st is None else st.ctypes.data, ptrs[4].ctypes.data, ptrs[5].ctypes.data,
+            ptrs[6].ctypes.data, res.ctypes.data), "vieo_local_bundle_adjustment_batch")
+        return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
