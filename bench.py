@@ -157,7 +157,9 @@ def main():
                     help="independent frame pipelines per GPU, each on its own HIP stream (the batch "
                          "is split between them so latency-bound stages overlap extraction)")
     ap.add_argument("--lba-every", type=int, default=10, help="frames per LocalBundleAdjustment (0 = none)")
-    ap.add_argument("--lba-threads", type=int, default=16, help="host threads issuing LBA windows")
+    ap.add_argument("--lba-threads", type=int, default=2, help="host threads issuing LBA batches")
+    ap.add_argument("--lba-batch", type=int, default=0,
+                    help="windows per lock-step LBA call (0 = all windows of a step in one call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -190,11 +192,14 @@ def main():
     pool = ThreadPoolExecutor(max_workers=max(1, a.lba_threads))
     lba_ms = []
 
-    def run_lba(i):
+    lba_chunk = a.lba_batch if a.lba_batch > 0 else max(1, n_lba)
+    chunks = [list(range(i, min(i + lba_chunk, n_lba))) for i in range(0, n_lba, lba_chunk)]
+
+    def run_lba(idx):
         t = time.perf_counter()
-        r = Optimizer.LocalBundleAdjustment(*lba_problems[i % len(lba_problems)])
-        lba_ms.append((time.perf_counter() - t) * 1e3)
-        return r[3]
+        r = Optimizer.LocalBundleAdjustmentBatch([lba_problems[i % len(lba_problems)] for i in idx])
+        lba_ms.append((time.perf_counter() - t) * 1e3 / len(idx))
+        return [x[3] for x in r]
 
     def sync_all():
         for q in pipes:
@@ -207,7 +212,7 @@ def main():
         for q in pipes:
             q.step()
     if n_lba:
-        list(pool.map(run_lba, range(2 * a.lba_threads)))  # every worker thread creates its stream
+        list(pool.map(run_lba, chunks * (2 * a.lba_threads)))  # every worker thread creates its stream
     lba_ms.clear()
     P.enable_timing(True)
     P.ext.enable_timing(True)
@@ -217,8 +222,8 @@ def main():
     for _ in range(a.steps):
         for q in pipes:
             q.step()
-        futs += [pool.submit(run_lba, i) for i in range(n_lba)]
-    lba_res = [f.result() for f in futs]
+        futs += [pool.submit(run_lba, c) for c in chunks]
+    lba_res = [r for f in futs for r in f.result()]
     sync_all()
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dist, dt, device="cuda")
@@ -250,10 +255,11 @@ def main():
                             "frame ORBextractor x2 + ComputeStereoMatches + SearchByProjection(last frame) + "
                             "PoseOptimization(VIO) + SearchByProjection(local map) + PoseOptimization(VIO, marg); "
                             "plus one vision-only LocalBundleAdjustment (10 free + 6 fixed key frames, ~1500 "
-                            "points, ~14k observations) per %d frames from %d host threads.  The IMU variant "
-                            "LocalBundleAdjustmentNavStatePRV is not built yet" % (a.lba_every, a.lba_threads),
+                            "points, ~14k observations) per %d frames, the windows of a step advanced in lock step "
+                            "(%d per call, %d host threads).  The IMU variant "
+                            "LocalBundleAdjustmentNavStatePRV is not built yet" % (a.lba_every, lba_chunk, a.lba_threads),
                 "local_ba_windows_per_step": n_lba,
-                "local_ba_ms_per_call_mean": float(np.mean(lba_ms)) if lba_ms else None,
+                "local_ba_ms_per_window_mean": float(np.mean(lba_ms)) if lba_ms else None,
                 "local_ba_lm_iterations_mean": float(np.mean([r["lm_iterations"] for r in lba_res])) if lba_res else None,
                 "stereo_frames_per_gpu_per_step": B,
                 "hip_streams_per_gpu": S,

@@ -2,20 +2,26 @@
 // g2o BlockSolver<6,3> with Schur complement, block_solver.hpp:353-589; LM
 // optimization_algorithm_levenberg.cpp:61-207; edges src/Odom/g2otypes.h:321-547).
 //
-// Device side (all FP64):
-//   k_lba_error     edge-parallel residuals + robust chi2 (per-block partial sums)
-//   k_lba_linearize landmark-parallel (16 lanes per landmark, observations of a point are
-//                   contiguous): Jacobians, H_ll (3x3), b_l, and the 6x3 block B = Jp^T W Jx of every
-//                   observation
-//   k_lba_pose      key-frame-parallel H_pp (6x6) and b_p over each key frame's edge list
-//   k_lba_schur     one wavefront per landmark: D^-1, then the dense landmark-block contraction
-//                   [B_1 D^-1; ...; B_k D^-1] x [B_1; ...; B_k]^T on the FP64 matrix cores
-//                   (v_mfma_f64_16x16x4_f64, K = 3 padded to 4, 6k rows tiled by 16), accumulated into a
-//                   per-workgroup LDS copy of the reduced pose system, flushed with one atomic pass
-//   k_lba_ldlt      one workgroup: dense LDL^T of the reduced system (<= 6 x #free key frames)
-//   k_lba_update    back-substitution x_l = D^-1 (b_l - B^T x_p), point / pose retraction, scale terms
-// The Levenberg-Marquardt control flow (lambda policy, accept / reject, stop flag polling) runs on
-// the host exactly as g2o's does; it only reads a handful of scalars per trial.
+// Several independent windows advance in lock step; every kernel covers all windows of the batch
+// (grid y / x = window) and returns at once for windows whose control word does not ask for the step.
+// Device side (all FP64, no floating-point atomics: every sum has a fixed order, so a window's result
+// does not depend on what it is batched with):
+//   k_lba_begin      initializeOptimization(): active key frames / points from the edge levels, the
+//                    reduced-system column of every free key frame, the (free kf, point) -> edge table
+//   k_lba_error      edge-parallel residuals + robust chi2 (per-block partial sums)
+//   k_lba_linearize  landmark-parallel (16 lanes per landmark, the observations of a point are
+//                    contiguous): Jacobians, H_ll (3x3), b_l and the 6x3 block B = Jp^T W Jx per edge
+//   k_lba_pose       one workgroup per free key frame: H_pp (6x6) and b_p over its edge list
+//   k_lba_lambda     computeLambdaInit (tau * max diagonal) for windows starting an optimize()
+//   k_lba_schur      one workgroup per pair of free key frames (a <= b): the 6x6 block
+//                    H_pp[a,b] + lambda I - sum_m B_ma (H_ll,m + lambda I)^-1 B_mb^T over the points both
+//                    observe, gathered through the table; the diagonal pairs also reduce b_p
+//   k_lba_ldlt       one workgroup per window: LDL^T of the reduced system in LDS, solve, pose
+//                    retraction (with backup) and the pose part of the gain-ratio scale
+//   k_lba_update_points  back-substitution x_l = D^-1 (b_l - B^T x_p), point update (with backup)
+//   k_lba_restore / k_lba_classify  rejected-step rollback; chi2 / depth gates
+// The Levenberg-Marquardt policy (lambda, accept / reject, termination, stop flag) runs on the host
+// exactly as g2o's does, from one 56-byte record per window and round.
 #include <vector>
 
 #include "ba_device.h"
@@ -24,48 +30,44 @@ namespace vieo {
 
 struct LbaKf {
   double p[3], qw, qx, qy, qz;
-  int col;  // offset in the reduced pose system, -1 = fixed / inactive
-  int pad;
+  int col;    // offset in the reduced pose system, -1 = fixed / inactive
+  int fixed;
 };
 
-// control word of a window for one round of the lock-step batch driver
+// control word of a window for one round of the lock-step driver
 enum {
   LBA_TRIAL = 1,    // solve + update + evaluate one lambda trial
   LBA_BUILD = 2,    // re-linearise (start of an LM iteration)
-  LBA_RESTORE = 4,  // last trial was rejected: restore the backed-up estimates first
-  LBA_ERROR = 8,    // residual pass only (start of an optimize())
+  LBA_RESTORE = 4,  // the last trial was rejected: restore the backed-up estimates first
+  LBA_BEGIN = 8,    // start of an optimize(): active sets, initial chi2, lambda init
   LBA_CLASS0 = 16,  // chi2 / depth gates -> level 1 (between the two optimisations)
   LBA_CLASS1 = 32,  // final erase flags
+  LBA_ROBUST = 64,  // Huber kernels on (first optimisation)
 };
 struct WinCtl {
   int flags, pad;
-  double lambda;
+  double lambda;  // < 0: take the device-computed initial lambda
 };
 struct WinOut {
-  double chi2, scale_l, scale_p, maxdiag;
-  int ok, overflow;
+  double chi0, chi2, scale_l, scale_p, lambda;
+  int ok, np;
 };
 
 struct LbaDev {
   const vieo_lba_obs* obs;
-  int n_obs, n_mp, n_kf, np;
-  int n_free, pad0;
-  const int *kf_list, *kf_edge_first, *kf_edge_idx;
-  LbaKf* kf_bak;
-  double* X_bak;
-  double* part_m;          // per-block partial sums of the point pass
-  unsigned char* erase;
-  LbaKf* kf;
-  double* X;               // [n_mp][3]
-  double* err;             // [n_obs][3]
-  unsigned char* level;    // [n_obs]
-  const int* mp_first;     // [n_mp]
-  const int* mp_count;     // [n_mp]
-  const unsigned char* mp_act;  // [n_mp]
-  double *Bpl, *Hll, *bl, *Hpp, *bp, *Hs, *bs, *Dinv, *xp, *xl;
-  double* part;            // per-block partial sums
+  int n_obs, n_mp, n_kf, nf_cap;  // nf_cap: non-fixed key frames = rows of `tab`
+  int np, n_free;                 // written by k_lba_begin
+  int* kf_list;                   // [n_free] free + active key frames in column order
+  const int *kf_edge_first, *kf_edge_idx;
+  int* tab;                       // [nf_cap][n_mp] edge of (free kf ordinal, point), -1 = none
+  LbaKf *kf, *kf_bak;
+  double *X, *X_bak;              // [n_mp][3]
+  double* err;                    // [n_obs][3]
+  unsigned char *level, *erase, *mp_act;
+  const int *mp_first, *mp_count;  // [n_mp]
+  double *Bpl, *Hll, *bl, *Hpp, *bp, *Hs, *bs, *xp;
+  double *part0, *part, *part_m, *pmax;  // per-block partials
   CamD cam;
-  int robust;
   double dMono, dStereo;
 };
 
@@ -74,14 +76,6 @@ __device__ __forceinline__ void kf_xf(const CamD& c, const LbaKf& k, PoseXf& X) 
   e.p[0] = k.p[0], e.p[1] = k.p[1], e.p[2] = k.p[2];
   e.qw = k.qw, e.qx = k.qx, e.qy = k.qy, e.qz = k.qz;
   make_xf(c, e, X);
-}
-
-__device__ __forceinline__ vieo_pose_obs as_pose_obs(const vieo_lba_obs& o, const double* X) {
-  vieo_pose_obs p;
-  p.Xw[0] = 0, p.Xw[1] = 0, p.Xw[2] = 0;  // double position passed separately
-  p.u = o.u, p.v = o.v, p.ur = o.ur, p.inv_sigma2 = o.inv_sigma2, p.flags = 0;
-  (void)X;
-  return p;
 }
 
 // residual with a double-precision point (the LBA point vertex is double, unlike PoseOpt's)
@@ -129,50 +123,32 @@ __device__ __forceinline__ void lba_jacobians(const CamD& c, const PoseXf& X, co
     }
 }
 
-// Every kernel below is launched for ALL windows of a batch (blockIdx.y / .z / .x = window) and
-// returns at once for windows whose control word does not ask for that step.
 
-// ---- residuals + robust chi2 of the active edges
-__global__ void __launch_bounds__(256)
-k_lba_error(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
-  __shared__ double s_red[4];
-  const int w = blockIdx.y;
-  if (!(ctl[w].flags & (LBA_TRIAL | LBA_ERROR))) return;
-  const LbaDev& D = devs[w];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= D.n_obs) return;
-  double v[1] = {0};
-  if (i < D.n_obs && D.level[i] == 0) {
-    const vieo_lba_obs o = D.obs[i];
-    PoseXf X;
-    kf_xf(D.cam, D.kf[o.kf], X);
-    double err[3], Pc[3];
-    const double chi2 = lba_edge_error(D.cam, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
-    D.err[3 * (size_t)i] = err[0], D.err[3 * (size_t)i + 1] = err[1], D.err[3 * (size_t)i + 2] = err[2];
-    double r0 = chi2, r1;
-    if (D.robust) {
-      const double dl = o.ur >= 0 ? D.dStereo : D.dMono;
-      huber(chi2, dl, dl * dl, &r0, &r1);
-    }
-    v[0] = r0;
-  }
-  block_sum<1>(v, s_red, threadIdx.x);
-  if (threadIdx.x == 0) D.part[blockIdx.x] = v[0];
+__device__ __forceinline__ double win_lambda(const WinCtl& c, const WinOut& o) {
+  return c.lambda >= 0 ? c.lambda : o.lambda;
 }
 
-// one workgroup per window: fold the per-block partials into the window's output record
+// (H_ll + lambda I)^-1 of one landmark
+__device__ __forceinline__ void landmark_dinv(const double* H, double lambda, double* Di) {
+  const double a00 = H[0] + lambda, a01 = H[1], a02 = H[2], a10 = H[3], a11 = H[4] + lambda, a12 = H[5],
+               a20 = H[6], a21 = H[7], a22 = H[8] + lambda;
+  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
+  Di[0] = c00 * id, Di[1] = (a02 * a21 - a01 * a22) * id, Di[2] = (a01 * a12 - a02 * a11) * id;
+  Di[3] = c01 * id, Di[4] = (a00 * a22 - a02 * a20) * id, Di[5] = (a02 * a10 - a00 * a12) * id;
+  Di[6] = c02 * id, Di[7] = (a01 * a20 - a00 * a21) * id, Di[8] = (a00 * a11 - a01 * a10) * id;
+}
+
+// ---- rollback of a rejected trial (g2o pop()): only what the trial changed
 __global__ void __launch_bounds__(256)
-k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
-  __shared__ double s_red[4 * 2];
-  const int w = blockIdx.x, fl = ctl[w].flags;
-  if (!(fl & (LBA_TRIAL | LBA_ERROR))) return;
+k_lba_restore(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_RESTORE)) return;
   const LbaDev& D = devs[w];
-  double v[2] = {0, 0};
-  for (int i = threadIdx.x; i < (D.n_obs + 255) / 256; i += 256) v[0] += D.part[i];
-  if (fl & LBA_TRIAL)
-    for (int i = threadIdx.x; i < (D.n_mp + 255) / 256; i += 256) v[1] += D.part_m[i];
-  block_sum<2>(v, s_red, threadIdx.x);
-  if (threadIdx.x == 0) out[w].chi2 = v[0], out[w].scale_l = v[1];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < D.n_mp && D.mp_act[i])
+    for (int a = 0; a < 3; a++) D.X[3 * (size_t)i + a] = D.X_bak[3 * (size_t)i + a];
+  if (i < D.n_kf && D.kf[i].col >= 0) D.kf[i] = D.kf_bak[i];
 }
 
 // chi2 (from the STORED error, as the reference does) / depth classification
@@ -200,39 +176,105 @@ k_lba_classify(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) 
     D.erase[i] = bad ? 1 : 0;
 }
 
-// ---- backup (before a trial) / restore (after a rejected trial) of poses and points
+// ---- initializeOptimization(0): one workgroup per window
 __global__ void __launch_bounds__(256)
-k_lba_backup_restore(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int restore) {
-  const int w = blockIdx.y;
-  if (!(ctl[w].flags & (restore ? LBA_RESTORE : LBA_TRIAL))) return;
+k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+  __shared__ int s_act[128];
+  const int w = blockIdx.x, tid = threadIdx.x;
+  if (!(ctl[w].flags & LBA_BEGIN)) return;
+  LbaDev& D = devs[w];
+  const int n_mp = D.n_mp, n_obs = D.n_obs, n_kf = D.n_kf;
+  if (tid < 128) s_act[tid] = 0;
+  for (int m = tid; m < n_mp; m += 256) D.mp_act[m] = 0;
+  for (size_t i = tid; i < (size_t)D.nf_cap * n_mp; i += 256) D.tab[i] = -1;
+  __syncthreads();
+  for (int i = tid; i < n_obs; i += 256)
+    if (D.level[i] == 0) {
+      const vieo_lba_obs o = D.obs[i];
+      s_act[o.kf] = 1;
+      D.mp_act[o.mp] = 1;
+    }
+  __syncthreads();
+  if (tid == 0) {
+    int np = 0, nf = 0;
+    for (int k = 0; k < n_kf; k++) {
+      if (!D.kf[k].fixed && s_act[k]) {
+        D.kf[k].col = np, np += 6;
+        D.kf_list[nf++] = k;
+      } else
+        D.kf[k].col = -1;
+    }
+    D.np = np, D.n_free = nf;
+    out[w].np = np;
+  }
+  __syncthreads();
+  for (int i = tid; i < n_obs; i += 256)
+    if (D.level[i] == 0) {
+      const vieo_lba_obs o = D.obs[i];
+      const int c = D.kf[o.kf].col;
+      if (c >= 0) D.tab[(size_t)(c / 6) * n_mp + o.mp] = i;
+    }
+}
+
+// ---- residuals + robust chi2 of the active edges.  which = 0: at the start of an optimize()
+// (computeActiveErrors before the first iteration), which = 1: after a trial step
+__global__ void __launch_bounds__(256)
+k_lba_error(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int which) {
+  __shared__ double s_red[4];
+  const int w = blockIdx.y, fl = ctl[w].flags;
+  if (!(fl & (which ? LBA_TRIAL : LBA_BEGIN))) return;
   const LbaDev& D = devs[w];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < D.n_mp * 3) {
-    if (restore)
-      D.X[i] = D.X_bak[i];
-    else
-      D.X_bak[i] = D.X[i];
+  if (blockIdx.x * 256 >= D.n_obs || D.np == 0) return;  // np == 0: optimize() returns before any error pass
+  double v[1] = {0};
+  if (i < D.n_obs && D.level[i] == 0) {
+    const vieo_lba_obs o = D.obs[i];
+    PoseXf X;
+    kf_xf(D.cam, D.kf[o.kf], X);
+    double err[3], Pc[3];
+    const double chi2 = lba_edge_error(D.cam, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
+    D.err[3 * (size_t)i] = err[0], D.err[3 * (size_t)i + 1] = err[1], D.err[3 * (size_t)i + 2] = err[2];
+    double r0 = chi2, r1;
+    if (fl & LBA_ROBUST) {
+      const double dl = o.ur >= 0 ? D.dStereo : D.dMono;
+      huber(chi2, dl, dl * dl, &r0, &r1);
+    }
+    v[0] = r0;
   }
-  if (i < D.n_kf) {
-    if (restore) {
-      const int col = D.kf[i].col;
-      D.kf[i] = D.kf_bak[i];
-      D.kf[i].col = col;
-    } else
-      D.kf_bak[i] = D.kf[i];
+  block_sum<1>(v, s_red, threadIdx.x);
+  if (threadIdx.x == 0) (which ? D.part : D.part0)[blockIdx.x] = v[0];
+}
+
+// one workgroup per window: fold the per-block partials into the window's output record
+__global__ void __launch_bounds__(256)
+k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+  __shared__ double s_red[4 * 3];
+  const int w = blockIdx.x, fl = ctl[w].flags;
+  if (!(fl & (LBA_TRIAL | LBA_BEGIN))) return;
+  const LbaDev& D = devs[w];
+  double v[3] = {0, 0, 0};
+  if ((fl & LBA_BEGIN) && D.np > 0)
+    for (int i = threadIdx.x; i < (D.n_obs + 255) / 256; i += 256) v[0] += D.part0[i];
+  if ((fl & LBA_TRIAL) && D.np > 0) {
+    for (int i = threadIdx.x; i < (D.n_obs + 255) / 256; i += 256) v[1] += D.part[i];
+    for (int i = threadIdx.x; i < (D.n_mp + 255) / 256; i += 256) v[2] += D.part_m[i];
   }
+  block_sum<3>(v, s_red, threadIdx.x);
+  if (threadIdx.x == 0) out[w].chi0 = v[0], out[w].chi2 = v[1], out[w].scale_l = v[2];
 }
 
 // ---- landmark-parallel linearisation: 16 lanes per landmark
 __global__ void __launch_bounds__(256)
 k_lba_linearize(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
-  const int w = blockIdx.y;
-  if (!(ctl[w].flags & LBA_BUILD)) return;
+  __shared__ double s_mx[16];
+  const int w = blockIdx.y, fl = ctl[w].flags;
+  if (!(fl & LBA_BUILD)) return;
   const LbaDev& D = devs[w];
   if (blockIdx.x * 16 >= D.n_mp) return;
   const int sub = threadIdx.x & 15;
   const int m = blockIdx.x * 16 + (threadIdx.x >> 4);
   const bool valid_m = m < D.n_mp && D.mp_act[m];
+  const bool robust = fl & LBA_ROBUST;
   double acc[9];  // Hll upper (6) + bl (3)
 #pragma unroll
   for (int i = 0; i < 9; i++) acc[i] = 0;
@@ -250,7 +292,7 @@ k_lba_linearize(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl)
       const double chi2 = lba_edge_error(D.cam, X, o, Xw, err, Pc);
       const bool stereo = o.ur >= 0;
       double r0, r1 = 1.;
-      if (D.robust) {
+      if (robust) {
         const double dl = stereo ? D.dStereo : D.dMono;
         huber(chi2, dl, dl * dl, &r0, &r1);
       }
@@ -282,43 +324,45 @@ k_lba_linearize(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl)
 #pragma unroll
   for (int i = 0; i < 9; i++)
     for (int o = 8; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o, 16);
-  if (valid_m && sub == 0) {
-    double* H = D.Hll + 9 * (size_t)m;
-    H[0] = acc[0], H[1] = acc[1], H[2] = acc[2];
-    H[3] = acc[1], H[4] = acc[3], H[5] = acc[4];
-    H[6] = acc[2], H[7] = acc[4], H[8] = acc[5];
-    D.bl[3 * (size_t)m] = acc[6], D.bl[3 * (size_t)m + 1] = acc[7], D.bl[3 * (size_t)m + 2] = acc[8];
+  if (sub == 0) {
+    double mx = 0;
+    if (valid_m) {
+      double* H = D.Hll + 9 * (size_t)m;
+      H[0] = acc[0], H[1] = acc[1], H[2] = acc[2];
+      H[3] = acc[1], H[4] = acc[3], H[5] = acc[4];
+      H[6] = acc[2], H[7] = acc[4], H[8] = acc[5];
+      D.bl[3 * (size_t)m] = acc[6], D.bl[3 * (size_t)m + 1] = acc[7], D.bl[3 * (size_t)m + 2] = acc[8];
+      mx = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+    }
+    s_mx[threadIdx.x >> 4] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mx = 0;
+    for (int i = 0; i < 16; i++) mx = fmax(mx, s_mx[i]);
+    D.pmax[blockIdx.x] = mx;  // landmark part of computeLambdaInit
   }
 }
 
-// Hpp = 0, bp = 0 of the windows that re-linearise
-__global__ void __launch_bounds__(256)
-k_lba_zero_pose(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
-  const int w = blockIdx.y;
-  if (!(ctl[w].flags & LBA_BUILD)) return;
-  const LbaDev& D = devs[w];
-  const int i = blockIdx.x * 256 + threadIdx.x, np = D.np;
-  if (i < np * np) D.Hpp[i] = 0;
-  if (i < np) D.bp[i] = 0;
-}
-
-// ---- key-frame-parallel Hpp / bp.  grid (chunks, max free key frames, windows)
+// ---- H_pp / b_p: one workgroup per free key frame (grid: key-frame ordinal, window)
 __global__ void __launch_bounds__(256)
 k_lba_pose(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   __shared__ double s_red[4 * 27];
-  const int w = blockIdx.z;
-  if (!(ctl[w].flags & LBA_BUILD)) return;
+  const int w = blockIdx.y, fl = ctl[w].flags;
+  if (!(fl & LBA_BUILD)) return;
   const LbaDev& D = devs[w];
-  if ((int)blockIdx.y >= D.n_free) return;
-  const int kfi = D.kf_list[blockIdx.y];
+  const int a = blockIdx.x;
+  if (a >= D.n_free) return;
+  const int kfi = D.kf_list[a];
   const LbaKf k = D.kf[kfi];
   const int first = D.kf_edge_first[kfi], cnt = D.kf_edge_first[kfi + 1] - first;
+  const bool robust = fl & LBA_ROBUST;
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0;
   PoseXf X;
   kf_xf(D.cam, k, X);
-  for (int j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += gridDim.x * 256) {
+  for (int j = threadIdx.x; j < cnt; j += 256) {
     const int i = D.kf_edge_idx[first + j];
     if (D.level[i]) continue;
     const vieo_lba_obs o = D.obs[i];
@@ -327,7 +371,7 @@ k_lba_pose(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
     const double chi2 = lba_edge_error(D.cam, X, o, Xw, err, Pc);
     const bool stereo = o.ur >= 0;
     double r0, r1 = 1.;
-    if (D.robust) {
+    if (robust) {
       const double dl = stereo ? D.dStereo : D.dMono;
       huber(chi2, dl, dl * dl, &r0, &r1);
     }
@@ -337,240 +381,196 @@ k_lba_pose(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   }
   block_sum<27>(acc, s_red, threadIdx.x);
   if (threadIdx.x < 27) {
-    const int c = k.col, np = D.np;
     if (threadIdx.x < 21) {
-      int a = 0, t = threadIdx.x;
-      while (t >= 6 - a) t -= 6 - a, a++;
-      const int b = a + t;
-      atomicAdd(&D.Hpp[(size_t)(c + a) * np + c + b], acc[threadIdx.x]);
-      if (a != b) atomicAdd(&D.Hpp[(size_t)(c + b) * np + c + a], acc[threadIdx.x]);
+      int r = 0, t = threadIdx.x;
+      while (t >= 6 - r) t -= 6 - r, r++;
+      const int c = r + t;
+      D.Hpp[36 * (size_t)a + r * 6 + c] = acc[threadIdx.x];
+      D.Hpp[36 * (size_t)a + c * 6 + r] = acc[threadIdx.x];
     } else
-      atomicAdd(&D.bp[c + threadIdx.x - 21], acc[threadIdx.x]);
+      D.bp[6 * a + threadIdx.x - 21] = acc[threadIdx.x];
   }
 }
 
-// computeLambdaInit: max |diagonal| over the pose and landmark blocks (one workgroup per window)
+// computeLambdaInit: tau * max |diagonal| over the pose and landmark blocks (one workgroup per window)
 __global__ void __launch_bounds__(256)
-k_lba_maxdiag(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+k_lba_lambda(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
   __shared__ double s_m[256];
   const int w = blockIdx.x;
-  if (!(ctl[w].flags & LBA_ERROR)) return;
+  if (!(ctl[w].flags & LBA_BEGIN)) return;
   const LbaDev& D = devs[w];
   double mx = 0;
-  for (int j = threadIdx.x; j < D.np; j += 256) mx = fmax(mx, fabs(D.Hpp[(size_t)j * D.np + j]));
-  for (int m = threadIdx.x; m < D.n_mp; m += 256)
-    if (D.mp_act[m])
-      for (int a = 0; a < 3; a++) mx = fmax(mx, fabs(D.Hll[9 * (size_t)m + 4 * a]));
+  for (int j = threadIdx.x; j < D.np; j += 256) mx = fmax(mx, fabs(D.Hpp[36 * (size_t)(j / 6) + 7 * (j % 6)]));
+  for (int b = threadIdx.x; b < (D.n_mp + 15) / 16; b += 256) mx = fmax(mx, D.pmax[b]);
   s_m[threadIdx.x] = mx;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) s_m[threadIdx.x] = fmax(s_m[threadIdx.x], s_m[threadIdx.x + o]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[w].maxdiag = s_m[0];
+  if (threadIdx.x == 0) out[w].lambda = 1e-5 * s_m[0];
 }
 
-// ---- Schur complement: one wavefront per landmark, FP64 MFMA for the block contraction.
-typedef double double4_t __attribute__((ext_vector_type(4)));
-static const int kSchurMaxObs = 32;  // free observers of one landmark handled by the MFMA tiling
-
-// use_lds = 0: windows whose reduced system does not fit LDS accumulate straight into global memory.
+// ---- reduced system: one workgroup per key-frame pair (a <= b) gathers
+//   Hs[a,b] = [a == b] (Hpp[a] + lambda I) - sum_m B_ma D_m^-1 B_mb^T,   bs[a] = bp[a] - sum_m B_ma D_m^-1 bl_m
 __global__ void __launch_bounds__(256)
-k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out,
-            int lds_np_max, int use_lds) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out) {
+  __shared__ double s_red[4 * 42];
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
-  const double lambda = ctl[w].lambda;
-  const int np = D.np;
-  int lds_np = use_lds ? (np | 1) : np;
-  double* sH = use_lds ? smem : D.Hs;  // [ld][ld] accumulated -(B D^-1 B^T)
-  double* sb = use_lds ? smem + (size_t)lds_np_max * lds_np_max : D.bs;
-  double* stage = use_lds ? smem + (size_t)lds_np_max * lds_np_max + lds_np_max : smem;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (use_lds) {
-    for (int i = threadIdx.x; i < lds_np * lds_np; i += 256) sH[i] = 0;
-    for (int i = threadIdx.x; i < np; i += 256) sb[i] = 0;
-  }
-  __syncthreads();
-  double* sA = stage + (size_t)wave * (192 * 4 * 2 + 192);
-  double* sB = sA + 192 * 4;
-  int* sC = (int*)(sB + 192 * 4);
-  for (int m = blockIdx.x * 4 + wave; m < D.n_mp; m += gridDim.x * 4) {
-    if (!D.mp_act[m]) continue;
-    // D^-1 = (Hll + lambda I)^-1 (every lane redundantly)
-    const double* H = D.Hll + 9 * (size_t)m;
-    const double a00 = H[0] + lambda, a01 = H[1], a02 = H[2], a10 = H[3], a11 = H[4] + lambda, a12 = H[5],
-                 a20 = H[6], a21 = H[7], a22 = H[8] + lambda;
-    const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
-    const double id = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
-    double Di[9];
-    Di[0] = c00 * id, Di[1] = (a02 * a21 - a01 * a22) * id, Di[2] = (a01 * a12 - a02 * a11) * id;
-    Di[3] = c01 * id, Di[4] = (a00 * a22 - a02 * a20) * id, Di[5] = (a02 * a10 - a00 * a12) * id;
-    Di[6] = c02 * id, Di[7] = (a01 * a20 - a00 * a21) * id, Di[8] = (a00 * a11 - a01 * a10) * id;
-    if (lane < 9) D.Dinv[9 * (size_t)m + lane] = Di[lane];
-    const double* blm = D.bl + 3 * (size_t)m;
-    const double db0 = Di[0] * blm[0] + Di[1] * blm[1] + Di[2] * blm[2];
-    const double db1 = Di[3] * blm[0] + Di[4] * blm[1] + Di[5] * blm[2];
-    const double db2 = Di[6] * blm[0] + Di[7] * blm[1] + Di[8] * blm[2];
-    // gather the free, active observers of this landmark (ordered compaction)
-    const int first = D.mp_first[m], cnt = D.mp_count[m];
-    int k = 0;
-    for (int j0 = 0; j0 < cnt; j0 += 64) {
-      const int j = j0 + lane;
-      bool use = false;
-      int col = -1;
-      if (j < cnt) {
-        const int i = first + j;
-        col = D.kf[D.obs[i].kf].col;
-        use = D.level[i] == 0 && col >= 0;
-      }
-      const unsigned long long bal = __ballot(use);
-      if (use) {
-        const int pos = k + __popcll(bal & ((1ull << lane) - 1ull));
-        if (pos < kSchurMaxObs) {
-          const double* B = D.Bpl + 18 * (size_t)(first + j);
-          for (int a = 0; a < 6; a++) {
-            const double b0 = B[a * 3], b1 = B[a * 3 + 1], b2 = B[a * 3 + 2];
-            const int row = pos * 6 + a;
-            sB[row * 4 + 0] = b0, sB[row * 4 + 1] = b1, sB[row * 4 + 2] = b2, sB[row * 4 + 3] = 0;
-            sA[row * 4 + 0] = b0 * Di[0] + b1 * Di[3] + b2 * Di[6];
-            sA[row * 4 + 1] = b0 * Di[1] + b1 * Di[4] + b2 * Di[7];
-            sA[row * 4 + 2] = b0 * Di[2] + b1 * Di[5] + b2 * Di[8];
-            sA[row * 4 + 3] = 0;
-            sC[row] = col + a;
-            atomicAdd(&sb[col + a], -(b0 * db0 + b1 * db1 + b2 * db2));  // bschur -= B (D^-1 bl)
-          }
-        }
-      }
-      k += __popcll(bal);
-    }
-    if (k > kSchurMaxObs) {
-      if (lane == 0) atomicExch(&out[w].overflow, 1);
-      k = kSchurMaxObs;
-    }
-    const int rows = 6 * k, nt = (rows + 15) >> 4;
-    for (int r = rows + lane; r < nt * 16; r += 64) {  // zero-pad the last tile
-      sA[r * 4] = sA[r * 4 + 1] = sA[r * 4 + 2] = sA[r * 4 + 3] = 0;
-      sB[r * 4] = sB[r * 4 + 1] = sB[r * 4 + 2] = sB[r * 4 + 3] = 0;
-      sC[r] = -1;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    // C(ti, tj) = A_ti (16x4) * B_tj^T (4x16) on the matrix core; scatter -C into the system
-    for (int ti = 0; ti < nt; ti++)
-      for (int tj = 0; tj < nt; tj++) {
-        const double av = sA[(ti * 16 + (lane & 15)) * 4 + (lane >> 4)];
-        const double bv = sB[(tj * 16 + (lane & 15)) * 4 + (lane >> 4)];
-        double4_t c = {0, 0, 0, 0};
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
-        const int gc = sC[tj * 16 + (lane & 15)];
+  const int nf = D.n_free;
+  int a = 0, t = blockIdx.x;
+  if (t >= nf * (nf + 1) / 2) return;
+  while (t >= nf - a) t -= nf - a, a++;
+  const int b = a + t;
+  const double lambda = win_lambda(ctl[w], out[w]);
+  const int n_mp = D.n_mp;
+  const int* ta = D.tab + (size_t)a * n_mp;
+  const int* tb = D.tab + (size_t)b * n_mp;
+  double acc[42];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int gr = sC[ti * 16 + (lane >> 4) + 4 * r];  // f64 C/D map: row = (lane>>4) + 4*reg
-          if (gr >= 0 && gc >= 0) atomicAdd(&sH[gr * lds_np + gc], -c[r]);
-        }
-      }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+  for (int i = 0; i < 42; i++) acc[i] = 0;
+  for (int m = threadIdx.x; m < n_mp; m += 256) {
+    const int ia = ta[m];
+    if (ia < 0) continue;
+    const int ib = tb[m];
+    if (ib < 0) continue;
+    double Di[9];
+    landmark_dinv(D.Hll + 9 * (size_t)m, lambda, Di);
+    const double* Ba = D.Bpl + 18 * (size_t)ia;
+    const double* Bb = D.Bpl + 18 * (size_t)ib;
+    double T[18];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double b0 = Ba[r * 3], b1 = Ba[r * 3 + 1], b2 = Ba[r * 3 + 2];
+      T[r * 3 + 0] = b0 * Di[0] + b1 * Di[3] + b2 * Di[6];
+      T[r * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2 * Di[7];
+      T[r * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2 * Di[8];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const double b0 = Bb[c * 3], b1 = Bb[c * 3 + 1], b2 = Bb[c * 3 + 2];
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc[r * 6 + c] += T[r * 3] * b0 + T[r * 3 + 1] * b1 + T[r * 3 + 2] * b2;
+    }
+    if (a == b) {
+      const double* bl = D.bl + 3 * (size_t)m;
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc[36 + r] += T[r * 3] * bl[0] + T[r * 3 + 1] * bl[1] + T[r * 3 + 2] * bl[2];
+    }
   }
-  __syncthreads();
-  if (!use_lds) return;
-  for (int i = threadIdx.x; i < np * np; i += 256) {
-    const double v = sH[(i / np) * lds_np + (i % np)];
-    if (v != 0.0) atomicAdd(&D.Hs[i], v);
-  }
-  for (int i = threadIdx.x; i < np; i += 256)
-    if (sb[i] != 0.0) atomicAdd(&D.bs[i], sb[i]);
+  block_sum<42>(acc, s_red, threadIdx.x);
+  const int np = D.np, tid = threadIdx.x;
+  if (tid < 36) {
+    const int r = tid / 6, c = tid % 6;
+    double v = -acc[tid];
+    if (a == b) v += D.Hpp[36 * (size_t)a + tid] + (r == c ? lambda : 0.0);
+    D.Hs[(size_t)(6 * a + r) * np + 6 * b + c] = v;
+    if (a != b) D.Hs[(size_t)(6 * b + c) * np + 6 * a + r] = v;
+  } else if (tid < 42 && a == b)
+    D.bs[6 * a + tid - 36] = D.bp[6 * a + tid - 36] - acc[tid];
 }
 
-// Hs = Hpp + lambda I ; bs = bp
+// ---- dense LDL^T solve of the reduced system + pose update, one workgroup per window.
+// use_lds: the matrix is factorised in LDS (dynamic), otherwise in place in global memory (L2).
 __global__ void __launch_bounds__(256)
-k_lba_init_reduced(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
-  const int w = blockIdx.y;
-  if (!(ctl[w].flags & LBA_TRIAL)) return;
-  const LbaDev& D = devs[w];
-  const double lambda = ctl[w].lambda;
-  const int i = blockIdx.x * 256 + threadIdx.x, np = D.np;
-  if (i < np * np) D.Hs[i] = D.Hpp[i] + ((i / np) == (i % np) ? lambda : 0.0);
-  if (i < np) D.bs[i] = D.bp[i];
-  if (i == 0) out[w].overflow = 0;
-}
-
-// ---- dense LDL^T solve of the reduced system, one workgroup per window (matrix in L2)
-__global__ void __launch_bounds__(256)
-k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out,
+           int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) double s_A[];
   __shared__ double s_col[512];
+  __shared__ double s_l[512];
   __shared__ double s_D[512];
   __shared__ double s_red[4];
-  __shared__ int s_ok;
   const int w = blockIdx.x;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
-  double* A = D.Hs;
-  const double* b = D.bs;
-  double* x = D.xp;
   const int n = D.np, tid = threadIdx.x;
-  if (tid == 0) s_ok = 1;
-  __syncthreads();
-  for (int j = 0; j < n; j++) {
-    const double d = A[(size_t)j * n + j];
-    if (!(d > 0)) {
-      if (tid == 0) s_ok = 0;
-      break;
-    }
-    for (int i = j + 1 + tid; i < n; i += 256) s_col[i] = A[(size_t)i * n + j];
-    if (tid == 0) s_D[j] = d;
-    __syncthreads();
-    const int m = n - j - 1;
-    for (int e = tid; e < m * m; e += 256) {
-      const int i = j + 1 + e / m, k = j + 1 + e % m;
-      A[(size_t)i * n + k] -= (s_col[i] / d) * s_col[k];
-    }
-    for (int i = j + 1 + tid; i < n; i += 256) A[(size_t)i * n + j] = s_col[i] / d;
-    __syncthreads();
-  }
-  __syncthreads();
-  if (!s_ok) {
-    for (int i = tid; i < n; i += 256) x[i] = 0;
-    if (tid == 0) out[w].ok = 0, out[w].scale_p = 0;
+  if (n == 0) {
+    if (tid == 0) out[w].ok = 1, out[w].scale_p = 0;
     return;
   }
-  double* y = s_col;
-  for (int i = tid; i < n; i += 256) y[i] = b[i];
-  __syncthreads();
-  for (int j = 0; j < n; j++) {
-    const double yj = y[j];
-    for (int i = j + 1 + tid; i < n; i += 256) y[i] -= A[(size_t)i * n + j] * yj;
+  const double lambda = win_lambda(ctl[w], out[w]);
+  double* A = use_lds ? s_A : D.Hs;
+  if (use_lds) {
+    for (int i = tid; i < n * n; i += 256) A[i] = D.Hs[i];
     __syncthreads();
   }
-  for (int i = tid; i < n; i += 256) y[i] /= s_D[i];
-  __syncthreads();
-  for (int j = n - 1; j >= 0; j--) {
-    const double xj = y[j];
-    for (int i = tid; i < j; i += 256) y[i] -= A[(size_t)j * n + i] * xj;
+  const int ti = tid >> 4, tk = tid & 15;
+  bool ok = true;
+  for (int j = 0; j < n; j++) {
+    const double d = A[(size_t)j * n + j];  // same address for all threads: uniform branch
+    if (!(d > 0)) {
+      ok = false;
+      break;
+    }
+    for (int i = j + 1 + tid; i < n; i += 256) {
+      const double c = A[(size_t)i * n + j];
+      s_col[i] = c, s_l[i] = c / d;
+    }
+    if (tid == 0) s_D[j] = d;
+    __syncthreads();
+    for (int i = j + 1 + ti; i < n; i += 16) {
+      const double li = s_l[i];
+      for (int k = j + 1 + tk; k <= i; k += 16) A[(size_t)i * n + k] -= li * s_col[k];
+    }
+    for (int i = j + 1 + tid; i < n; i += 256) A[(size_t)i * n + j] = s_l[i];
+    __syncthreads();
+  }
+  double* y = s_col;
+  if (ok) {
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) y[i] = D.bs[i];
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+      const double yj = y[j];
+      for (int i = j + 1 + tid; i < n; i += 256) y[i] -= A[(size_t)i * n + j] * yj;
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) y[i] /= s_D[i];
+    __syncthreads();
+    for (int j = n - 1; j >= 0; j--) {
+      const double xj = y[j];
+      for (int i = tid; i < j; i += 256) y[i] -= A[(size_t)j * n + i] * xj;
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) y[i] = 0;
     __syncthreads();
   }
   double sp[1] = {0};
-  const double lambda = ctl[w].lambda;
   for (int i = tid; i < n; i += 256) {
-    x[i] = y[i];
+    D.xp[i] = y[i];
     sp[0] += y[i] * (lambda * y[i] + D.bp[i]);  // pose part of computeScale()
   }
   block_sum<1>(sp, s_red, tid);
-  if (tid == 0) out[w].ok = 1, out[w].scale_p = sp[0];
+  if (tid == 0) out[w].ok = ok ? 1 : 0, out[w].scale_p = ok ? sp[0] : 0.0;
+  // oplus on the free key frames (push() first)
+  for (int k = tid; k < D.n_kf; k += 256) {
+    LbaKf kf = D.kf[k];
+    if (kf.col < 0) continue;
+    D.kf_bak[k] = kf;
+    Est e;
+    e.p[0] = kf.p[0], e.p[1] = kf.p[1], e.p[2] = kf.p[2];
+    e.qw = kf.qw, e.qx = kf.qx, e.qy = kf.qy, e.qz = kf.qz;
+    inc_small_pr(e, y + kf.col);
+    kf.p[0] = e.p[0], kf.p[1] = e.p[1], kf.p[2] = e.p[2];
+    kf.qw = e.qw, kf.qx = e.qx, kf.qy = e.qy, kf.qz = e.qz;
+    D.kf[k] = kf;
+  }
 }
 
 // ---- back-substitution + update of the points, landmark part of the LM gain-ratio scale
 __global__ void __launch_bounds__(256)
-k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl,
+                    const WinOut* __restrict__ out) {
   __shared__ double s_red[4];
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
-  if (blockIdx.x * 256 >= D.n_mp) return;
-  const double lambda = ctl[w].lambda;
+  if (blockIdx.x * 256 >= D.n_mp || D.np == 0) return;
+  const double lambda = win_lambda(ctl[w], out[w]);
   const int m = blockIdx.x * 256 + threadIdx.x;
   double sc[1] = {0};
   if (m < D.n_mp && D.mp_act[m]) {
@@ -587,11 +587,13 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
         cl[0] -= B[a * 3] * xa, cl[1] -= B[a * 3 + 1] * xa, cl[2] -= B[a * 3 + 2] * xa;
       }
     }
-    const double* Di = D.Dinv + 9 * (size_t)m;
+    double Di[9];
+    landmark_dinv(D.Hll + 9 * (size_t)m, lambda, Di);
     for (int a = 0; a < 3; a++) {
       const double x = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2];
-      D.xl[3 * (size_t)m + a] = x;
-      D.X[3 * (size_t)m + a] += x;
+      const double old = D.X[3 * (size_t)m + a];
+      D.X_bak[3 * (size_t)m + a] = old;
+      D.X[3 * (size_t)m + a] = old + x;
       sc[0] += x * (lambda * x + D.bl[3 * (size_t)m + a]);
     }
   }
@@ -599,57 +601,35 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
   if (threadIdx.x == 0) D.part_m[blockIdx.x] = sc[0];
 }
 
-__global__ void __launch_bounds__(64)
-k_lba_update_poses(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
-  const int w = blockIdx.y;
-  if (!(ctl[w].flags & LBA_TRIAL)) return;
-  const LbaDev& D = devs[w];
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= D.n_kf) return;
-  LbaKf kf = D.kf[k];
-  if (kf.col < 0) return;
-  Est e;
-  e.p[0] = kf.p[0], e.p[1] = kf.p[1], e.p[2] = kf.p[2];
-  e.qw = kf.qw, e.qx = kf.qx, e.qy = kf.qy, e.qz = kf.qz;
-  inc_small_pr(e, D.xp + kf.col);
-  kf.p[0] = e.p[0], kf.p[1] = e.p[1], kf.p[2] = e.p[2];
-  kf.qw = e.qw, kf.qx = e.qx, kf.qy = e.qy, kf.qz = e.qz;
-  D.kf[k] = kf;
-}
-
 // ================================================================== host-side lock-step LM driver
 static thread_local hipStream_t g_lba_stream = nullptr;
-static thread_local DevBuf g_arena, g_devs, g_ctl, g_out;
-
-// synchronous copy on the calling thread's own stream (concurrent callers and the frame pipelines
-// on their streams do not serialise on the null stream)
-static inline hipError_t lba_copy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
-  hipError_t e = hipMemcpyAsync(dst, src, n, kind, g_lba_stream);
-  if (e != hipSuccess) return e;
-  return hipStreamSynchronize(g_lba_stream);
-}
+static thread_local DevBuf g_arena, g_small;
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return VIEO_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+    bytes += bytes / 2;
+    VIEO_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
+    return VIEO_OK;
+  }
+};
+static thread_local PinnedBuf g_stage, g_small_h;
 
 struct WinHost {  // per-window LM state machine, exactly g2o's (optimization_algorithm_levenberg.cpp)
   const vieo_lba_params* P;
-  const vieo_lba_keyframe* kfs;
-  const vieo_lba_obs* obs;
-  const float* points;
   int n_kf, n_mp, n_obs;
-  LbaDev D;                 // device view (host copy)
-  std::vector<int> mp_first, mp_count, kf_edge_first, kf_edge_idx, kf_list;
-  std::vector<unsigned char> level, mp_act;
-  std::vector<LbaKf> kf;
-  // device sub-allocations that change between the two optimisations
-  int *d_kf_list;
-  unsigned char* d_mp_act;
-  // state
-  int stage = 0;            // 0: optimize(its0), 1: optimize(its1), 2: finished
-  int it = 0, iters = 0;    // iteration inside the current optimize()
-  int phase = 0;            // 0: needs the initial error pass, 1: in trials
+  int stage = 0;  // 0: optimize(its0), 1: optimize(its1), 2: finished
+  int phase = 0;  // 0: the next round starts an optimize(), 1: in trials, 2: optimize() is over
+  int it = 0, iters = 0;
   double lambda = -1, ni = 2, currentChi = 0, iniChi = 0;
   int nBad = 0, qmax = 0;
   bool need_build = false, need_restore = false, skip = false;
   vieo_lba_result* R;
+  size_t o_kf, o_X, o_erase;  // offsets of the results in the staging buffer
 };
 
 }  // namespace vieo
@@ -674,7 +654,44 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
   hipStream_t st = g_lba_stream;
   const int W = n_windows;
   std::vector<WinHost> win(W);
-  // ---- host-side index structures + arena layout
+  std::vector<LbaDev> devs(W);
+  const bool stopped0 = stop && *stop;
+  int n_live = 0;
+  for (int w = 0; w < W; w++) {
+    WinHost& H = win[w];
+    H.P = params[w], H.n_kf = n_kf[w], H.n_mp = n_mp[w], H.n_obs = n_obs[w];
+    H.R = &h_results[w];
+    if (!H.P || !h_kfs[w] || H.n_kf <= 0 || !h_points[w] || H.n_mp <= 0 || !h_obs[w] || H.n_obs <= 0 ||
+        !h_navs_out[w] || !h_points_out[w] || !h_erase[w])
+      return VIEO_E_INVALID;
+    memset(H.R, 0, sizeof(*H.R));
+    if (H.n_kf > 85) {
+      set_error("local BA: more than 85 key frames in a window");
+      return VIEO_E_CAPACITY;
+    }
+    for (int k = 0; k < H.n_kf; k++) h_navs_out[w][k] = h_kfs[w][k].nav;
+    memcpy(h_points_out[w], h_points[w], (size_t)H.n_mp * 12);
+    memset(h_erase[w], 0, H.n_obs);
+    bool any_free = false;
+    for (int k = 0; k < H.n_kf; k++) any_free |= !h_kfs[w][k].fixed;
+    if (!any_free) {
+      H.R->status = VIEO_LBA_NO_FREE_POSE;  // Optimizer.cc:1993
+      H.skip = true, H.stage = 2;
+    } else if (stopped0) {
+      H.R->status = VIEO_LBA_ABORTED;
+      H.skip = true, H.stage = 2;
+    } else
+      n_live++;
+    const vieo_lba_obs* ob = h_obs[w];
+    for (int i = 0; i < H.n_obs; i++)
+      if (ob[i].mp < 0 || ob[i].mp >= H.n_mp || ob[i].kf < 0 || ob[i].kf >= H.n_kf ||
+          (i > 0 && ob[i].mp < ob[i - 1].mp)) {
+        set_error("vieo_local_bundle_adjustment: observations must be sorted by map point");
+        return VIEO_E_INVALID;
+      }
+  }
+  if (!n_live) return VIEO_OK;
+  // ---- arena layout: [inputs | results (kf, X, erase) | zero-initialised | scratch]
   size_t arena = 0;
   auto take = [&](size_t bytes) {
     const size_t off = arena;
@@ -682,268 +699,218 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     return off;
   };
   struct Off {
-    size_t obs, kf, kf_bak, X, X_bak, err, level, erase, mp_first, mp_count, mp_act, Bpl, Hll, bl, Dinv, xl,
-        Hpp, Hs, bp, bs, xp, part, part_m, kf_list, kf_edge_first, kf_edge_idx;
+    size_t obs, mp_first, mp_count, kf_edge_first, kf_edge_idx, kf, X, erase, level, err;
   };
   std::vector<Off> off(W);
-  int max_obs = 0, max_mp = 0, max_kf = 0, max_np = 0;
   for (int w = 0; w < W; w++) {
-    WinHost& H = win[w];
-    H.P = params[w], H.kfs = h_kfs[w], H.obs = h_obs[w], H.points = h_points[w];
-    H.n_kf = n_kf[w], H.n_mp = n_mp[w], H.n_obs = n_obs[w];
-    H.R = &h_results[w];
-    memset(H.R, 0, sizeof(*H.R));
-    if (!H.P || !H.kfs || H.n_kf <= 0 || !H.points || H.n_mp <= 0 || !H.obs || H.n_obs <= 0) return VIEO_E_INVALID;
-    for (int k = 0; k < H.n_kf; k++) h_navs_out[w][k] = H.kfs[k].nav;
-    memcpy(h_points_out[w], H.points, (size_t)H.n_mp * 12);
-    memset(h_erase[w], 0, H.n_obs);
-    bool any_free = false;
-    for (int k = 0; k < H.n_kf; k++) any_free |= !H.kfs[k].fixed;
-    if (!any_free) {
-      H.R->status = VIEO_LBA_NO_FREE_POSE;  // Optimizer.cc:1993
-      H.skip = true, H.stage = 2;
-    }
-    if (6 * H.n_kf > 512) {
-      set_error("local BA: more than 85 key frames in a window");
-      return VIEO_E_CAPACITY;
-    }
-    H.mp_first.assign(H.n_mp, 0), H.mp_count.assign(H.n_mp, 0);
-    std::vector<int> kf_cnt(H.n_kf + 1, 0), fill(H.n_kf, 0);
-    for (int i = 0; i < H.n_obs; i++) {
-      const int m = H.obs[i].mp, k = H.obs[i].kf;
-      if (m < 0 || m >= H.n_mp || k < 0 || k >= H.n_kf || (i > 0 && m < H.obs[i - 1].mp)) {
-        set_error("vieo_local_bundle_adjustment: observations must be sorted by map point");
-        return VIEO_E_INVALID;
-      }
-      if (H.mp_count[m] == 0) H.mp_first[m] = i;
-      H.mp_count[m]++;
-      kf_cnt[k + 1]++;
-    }
-    H.kf_edge_first.assign(H.n_kf + 1, 0);
-    H.kf_edge_idx.resize(H.n_obs);
-    for (int k = 0; k < H.n_kf; k++) H.kf_edge_first[k + 1] = H.kf_edge_first[k] + kf_cnt[k + 1];
-    for (int i = 0; i < H.n_obs; i++) H.kf_edge_idx[H.kf_edge_first[H.obs[i].kf] + fill[H.obs[i].kf]++] = i;
-    H.kf.resize(H.n_kf);
-    for (int k = 0; k < H.n_kf; k++) {
-      memcpy(H.kf[k].p, H.kfs[k].nav.p, 24);
-      H.kf[k].qw = H.kfs[k].nav.q[0], H.kf[k].qx = H.kfs[k].nav.q[1];
-      H.kf[k].qy = H.kfs[k].nav.q[2], H.kf[k].qz = H.kfs[k].nav.q[3];
-      H.kf[k].col = -1, H.kf[k].pad = 0;
-    }
-    H.level.assign(H.n_obs, 0), H.mp_act.assign(H.n_mp, 0);
-    const int npm = 6 * H.n_kf;
+    const WinHost& H = win[w];
+    if (H.skip) continue;
     Off& o = off[w];
     o.obs = take((size_t)H.n_obs * sizeof(vieo_lba_obs));
-    o.kf = take((size_t)H.n_kf * sizeof(LbaKf)), o.kf_bak = take((size_t)H.n_kf * sizeof(LbaKf));
-    o.X = take((size_t)H.n_mp * 24), o.X_bak = take((size_t)H.n_mp * 24);
-    o.err = take((size_t)H.n_obs * 24), o.level = take(H.n_obs), o.erase = take(H.n_obs);
-    o.mp_first = take((size_t)H.n_mp * 4), o.mp_count = take((size_t)H.n_mp * 4), o.mp_act = take(H.n_mp);
-    o.Bpl = take((size_t)H.n_obs * 144), o.Hll = take((size_t)H.n_mp * 72), o.bl = take((size_t)H.n_mp * 24);
-    o.Dinv = take((size_t)H.n_mp * 72), o.xl = take((size_t)H.n_mp * 24);
-    o.Hpp = take((size_t)npm * npm * 8), o.Hs = take((size_t)npm * npm * 8);
-    o.bp = take((size_t)npm * 8), o.bs = take((size_t)npm * 8), o.xp = take((size_t)npm * 8);
-    o.part = take((size_t)((H.n_obs + 255) / 256) * 8), o.part_m = take((size_t)((H.n_mp + 255) / 256) * 8);
-    o.kf_list = take((size_t)H.n_kf * 4), o.kf_edge_first = take((size_t)(H.n_kf + 1) * 4);
-    o.kf_edge_idx = take((size_t)H.n_obs * 4);
-    max_obs = std::max(max_obs, H.n_obs), max_mp = std::max(max_mp, H.n_mp);
-    max_kf = std::max(max_kf, H.n_kf), max_np = std::max(max_np, npm);
+    o.mp_first = take((size_t)H.n_mp * 4), o.mp_count = take((size_t)H.n_mp * 4);
+    o.kf_edge_first = take((size_t)(H.n_kf + 1) * 4), o.kf_edge_idx = take((size_t)H.n_obs * 4);
   }
-  if ((rc = g_arena.ensure(arena)) != VIEO_OK) return rc;
-  if ((rc = g_devs.ensure((size_t)W * sizeof(LbaDev))) != VIEO_OK) return rc;
-  if ((rc = g_ctl.ensure((size_t)W * sizeof(WinCtl))) != VIEO_OK) return rc;
-  if ((rc = g_out.ensure((size_t)W * sizeof(WinOut))) != VIEO_OK) return rc;
-  uint8_t* base = g_arena.as<uint8_t>();
-  for (int w = 0; w < W; w++) {
-    WinHost& H = win[w];
-    const Off& o = off[w];
-    LbaDev& D = H.D;
-    memset(&D, 0, sizeof(D));
-    D.obs = (const vieo_lba_obs*)(base + o.obs);
-    D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.np = 0, D.n_free = 0;
-    D.kf = (LbaKf*)(base + o.kf), D.kf_bak = (LbaKf*)(base + o.kf_bak);
-    D.X = (double*)(base + o.X), D.X_bak = (double*)(base + o.X_bak), D.err = (double*)(base + o.err);
-    D.level = base + o.level, D.erase = base + o.erase;
-    D.mp_first = (const int*)(base + o.mp_first), D.mp_count = (const int*)(base + o.mp_count);
-    D.mp_act = base + o.mp_act;
-    H.d_mp_act = base + o.mp_act, H.d_kf_list = (int*)(base + o.kf_list);
-    D.Bpl = (double*)(base + o.Bpl), D.Hll = (double*)(base + o.Hll), D.bl = (double*)(base + o.bl);
-    D.Dinv = (double*)(base + o.Dinv), D.xl = (double*)(base + o.xl);
-    D.Hpp = (double*)(base + o.Hpp), D.Hs = (double*)(base + o.Hs), D.bp = (double*)(base + o.bp);
-    D.bs = (double*)(base + o.bs), D.xp = (double*)(base + o.xp);
-    D.part = (double*)(base + o.part), D.part_m = (double*)(base + o.part_m);
-    D.kf_list = (const int*)(base + o.kf_list), D.kf_edge_first = (const int*)(base + o.kf_edge_first);
-    D.kf_edge_idx = (const int*)(base + o.kf_edge_idx);
-    D.cam.fx = H.P->fx, D.cam.fy = H.P->fy, D.cam.cx = H.P->cx, D.cam.cy = H.P->cy, D.cam.bf = H.P->bf;
-    memcpy(D.cam.Rcb, H.P->Rcb, 72);
-    memcpy(D.cam.tcb, H.P->tcb, 24);
-    D.robust = 1;
-    D.dMono = (double)(float)sqrt(5.991), D.dStereo = (double)(float)sqrt(7.815);
-    std::vector<double> X((size_t)H.n_mp * 3);
-    for (int i = 0; i < H.n_mp * 3; i++) X[i] = (double)H.points[i];
-    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.obs, H.obs, (size_t)H.n_obs * sizeof(vieo_lba_obs), hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.X, X.data(), X.size() * 8, hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.mp_first, H.mp_first.data(), (size_t)H.n_mp * 4, hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.mp_count, H.mp_count.data(), (size_t)H.n_mp * 4, hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.kf_edge_first, H.kf_edge_first.data(), (size_t)(H.n_kf + 1) * 4, hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(base + o.kf_edge_idx, H.kf_edge_idx.data(), (size_t)H.n_obs * 4, hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemsetAsync(base + o.level, 0, H.n_obs, st));
-    VIEO_HIP_CHECK(hipMemsetAsync(base + o.err, 0, (size_t)H.n_obs * 24, st));
-    VIEO_HIP_CHECK(hipStreamSynchronize(st));  // X goes out of scope
-  }
-  const int lds_np_max = max_np | 1;
-  const size_t stage_lds = 4 * (192 * 4 * 2 + 192) * 8 + 64;
-  size_t schur_lds = ((size_t)lds_np_max * lds_np_max + lds_np_max) * 8 + stage_lds;
-  const int use_lds = schur_lds <= 150 * 1024;
-  if (!use_lds) schur_lds = stage_lds;
-  VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_schur, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)schur_lds));
-  std::vector<WinCtl> ctl(W);
-  std::vector<WinOut> out(W);
-  std::vector<LbaDev> devs(W);
-  bool first_upload = true;
-
-  // initializeOptimization(0) for a window: active vertices, reduced-system columns
-  auto begin_optimize = [&](WinHost& H, int iterations) -> int {
-    std::vector<char> kf_act(H.n_kf, 0);
-    std::fill(H.mp_act.begin(), H.mp_act.end(), 0);
-    bool any = false;
-    for (int i = 0; i < H.n_obs; i++)
-      if (!H.level[i]) kf_act[H.obs[i].kf] = 1, H.mp_act[H.obs[i].mp] = 1, any = true;
-    int np = 0;
-    H.kf_list.clear();
-    for (int k = 0; k < H.n_kf; k++) {
-      if (!H.kfs[k].fixed && kf_act[k]) {
-        H.kf[k].col = np, np += 6;
-        H.kf_list.push_back(k);
-      } else
-        H.kf[k].col = -1;
-    }
-    H.D.np = np, H.D.n_free = (int)H.kf_list.size();
-    H.it = 0, H.iters = iterations, H.phase = 0, H.need_restore = false;
-    std::vector<LbaKf> cur(H.n_kf);
-    if (H.stage == 0)
-      cur = H.kf;
-    else {
-      VIEO_HIP_CHECK(lba_copy(cur.data(), H.D.kf, (size_t)H.n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
-      for (int k = 0; k < H.n_kf; k++) cur[k].col = H.kf[k].col;
-    }
-    VIEO_HIP_CHECK(hipMemcpyAsync(H.D.kf, cur.data(), (size_t)H.n_kf * sizeof(LbaKf), hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(H.d_mp_act, H.mp_act.data(), H.n_mp, hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(H.d_kf_list, H.kf_list.data(), H.kf_list.size() * 4, hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipStreamSynchronize(st));
-    return (!any || np == 0 || iterations <= 0) ? 1 : 0;  // 1: nothing to optimise
-  };
-
-  const bool stopped0 = stop && *stop;
+  const size_t res_begin = arena;
   for (int w = 0; w < W; w++) {
     WinHost& H = win[w];
     if (H.skip) continue;
-    if (stopped0) {
-      H.R->status = VIEO_LBA_ABORTED, H.stage = 2;
-      continue;
-    }
-    int r = begin_optimize(H, H.P->its0);
-    if (r < 0) return r;
-    if (r == 1) H.phase = 2;  // empty optimisation: go straight to the stage transition
+    Off& o = off[w];
+    o.kf = take((size_t)H.n_kf * sizeof(LbaKf)), o.X = take((size_t)H.n_mp * 24), o.erase = take(H.n_obs);
+    H.o_kf = o.kf, H.o_X = o.X, H.o_erase = o.erase;
   }
+  const size_t res_end = arena;
+  for (int w = 0; w < W; w++) {
+    const WinHost& H = win[w];
+    if (H.skip) continue;
+    off[w].level = take(H.n_obs), off[w].err = take((size_t)H.n_obs * 24);
+  }
+  const size_t zero_end = arena;
+  if ((rc = g_stage.ensure(res_end)) != VIEO_OK) return rc;
+  uint8_t* hs = (uint8_t*)g_stage.p;
+  int max_obs = 0, max_mp = 0, max_kf = 0, max_nf = 0;
+  std::vector<size_t> scratch_off(W);
+  struct Scr {
+    size_t kf_bak, X_bak, mp_act, Bpl, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab;
+  };
+  std::vector<Scr> scr(W);
+  for (int w = 0; w < W; w++) {
+    WinHost& H = win[w];
+    if (H.skip) continue;
+    const Off& o = off[w];
+    const vieo_lba_obs* ob = h_obs[w];
+    const vieo_lba_keyframe* kfs = h_kfs[w];
+    // host-side index structures, written straight into the pinned staging copy of the arena
+    memcpy(hs + o.obs, ob, (size_t)H.n_obs * sizeof(vieo_lba_obs));
+    int* mp_first = (int*)(hs + o.mp_first);
+    int* mp_count = (int*)(hs + o.mp_count);
+    int* kf_first = (int*)(hs + o.kf_edge_first);
+    int* kf_idx = (int*)(hs + o.kf_edge_idx);
+    memset(mp_first, 0, (size_t)H.n_mp * 4), memset(mp_count, 0, (size_t)H.n_mp * 4);
+    memset(kf_first, 0, (size_t)(H.n_kf + 1) * 4);
+    for (int i = 0; i < H.n_obs; i++) {
+      const int m = ob[i].mp;
+      if (mp_count[m] == 0) mp_first[m] = i;
+      mp_count[m]++;
+      kf_first[ob[i].kf + 1]++;
+    }
+    for (int k = 0; k < H.n_kf; k++) kf_first[k + 1] += kf_first[k];
+    int fill[86];
+    for (int k = 0; k < H.n_kf; k++) fill[k] = kf_first[k];
+    for (int i = 0; i < H.n_obs; i++) kf_idx[fill[ob[i].kf]++] = i;
+    LbaKf* kf = (LbaKf*)(hs + o.kf);
+    int nf = 0;
+    for (int k = 0; k < H.n_kf; k++) {
+      memcpy(kf[k].p, kfs[k].nav.p, 24);
+      kf[k].qw = kfs[k].nav.q[0], kf[k].qx = kfs[k].nav.q[1];
+      kf[k].qy = kfs[k].nav.q[2], kf[k].qz = kfs[k].nav.q[3];
+      kf[k].col = -1, kf[k].fixed = kfs[k].fixed ? 1 : 0;
+      nf += !kfs[k].fixed;
+    }
+    double* X = (double*)(hs + o.X);
+    for (int i = 0; i < H.n_mp * 3; i++) X[i] = (double)h_points[w][i];
+    memset(hs + o.erase, 0, H.n_obs);
+    // scratch
+    Scr& s = scr[w];
+    const int npm = 6 * nf;
+    s.kf_bak = take((size_t)H.n_kf * sizeof(LbaKf)), s.X_bak = take((size_t)H.n_mp * 24);
+    s.mp_act = take(H.n_mp);
+    s.Bpl = take((size_t)H.n_obs * 144), s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
+    s.Hpp = take((size_t)nf * 36 * 8), s.Hs = take((size_t)npm * npm * 8);
+    s.bp = take((size_t)npm * 8), s.bs = take((size_t)npm * 8), s.xp = take((size_t)npm * 8);
+    s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
+    s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 15) / 16) * 8);
+    s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)nf * H.n_mp * 4);
+    LbaDev& D = devs[w];
+    memset(&D, 0, sizeof(D));
+    D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.nf_cap = nf;
+    D.cam.fx = H.P->fx, D.cam.fy = H.P->fy, D.cam.cx = H.P->cx, D.cam.cy = H.P->cy, D.cam.bf = H.P->bf;
+    memcpy(D.cam.Rcb, H.P->Rcb, 72);
+    memcpy(D.cam.tcb, H.P->tcb, 24);
+    D.dMono = (double)(float)sqrt(5.991), D.dStereo = (double)(float)sqrt(7.815);
+    max_obs = std::max(max_obs, H.n_obs), max_mp = std::max(max_mp, H.n_mp);
+    max_kf = std::max(max_kf, H.n_kf), max_nf = std::max(max_nf, nf);
+    H.iters = H.P->its0;
+    H.phase = H.iters > 0 ? 0 : 2;
+  }
+  const size_t small_bytes = (size_t)W * (sizeof(LbaDev) + sizeof(WinCtl) + sizeof(WinOut));
+  if ((rc = g_arena.ensure(arena)) != VIEO_OK) return rc;
+  if ((rc = g_small.ensure(small_bytes)) != VIEO_OK) return rc;
+  if ((rc = g_small_h.ensure((size_t)W * (sizeof(WinCtl) + sizeof(WinOut)))) != VIEO_OK) return rc;
+  uint8_t* base = g_arena.as<uint8_t>();
+  for (int w = 0; w < W; w++) {
+    if (win[w].skip) continue;
+    const Off& o = off[w];
+    const Scr& s = scr[w];
+    LbaDev& D = devs[w];
+    D.obs = (const vieo_lba_obs*)(base + o.obs);
+    D.mp_first = (const int*)(base + o.mp_first), D.mp_count = (const int*)(base + o.mp_count);
+    D.kf_edge_first = (const int*)(base + o.kf_edge_first), D.kf_edge_idx = (const int*)(base + o.kf_edge_idx);
+    D.kf = (LbaKf*)(base + o.kf), D.X = (double*)(base + o.X), D.erase = base + o.erase;
+    D.level = base + o.level, D.err = (double*)(base + o.err);
+    D.kf_bak = (LbaKf*)(base + s.kf_bak), D.X_bak = (double*)(base + s.X_bak), D.mp_act = base + s.mp_act;
+    D.Bpl = (double*)(base + s.Bpl), D.Hll = (double*)(base + s.Hll), D.bl = (double*)(base + s.bl);
+    D.Hpp = (double*)(base + s.Hpp), D.Hs = (double*)(base + s.Hs), D.bp = (double*)(base + s.bp);
+    D.bs = (double*)(base + s.bs), D.xp = (double*)(base + s.xp);
+    D.part0 = (double*)(base + s.part0), D.part = (double*)(base + s.part);
+    D.part_m = (double*)(base + s.part_m), D.pmax = (double*)(base + s.pmax);
+    D.kf_list = (int*)(base + s.kf_list), D.tab = (int*)(base + s.tab);
+  }
+  LbaDev* dD = g_small.as<LbaDev>();
+  WinCtl* dC = (WinCtl*)(dD + W);
+  WinOut* dO = (WinOut*)(dC + W);
+  WinCtl* ctl = (WinCtl*)g_small_h.p;
+  WinOut* out = (WinOut*)(ctl + W);
+  VIEO_HIP_CHECK(hipMemcpyAsync(base, hs, res_end, hipMemcpyHostToDevice, st));
+  VIEO_HIP_CHECK(hipMemsetAsync(base + res_end, 0, zero_end - res_end, st));
+  VIEO_HIP_CHECK(hipMemcpyAsync(dD, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
+  VIEO_HIP_CHECK(hipMemsetAsync(dO, 0, (size_t)W * sizeof(WinOut), st));
+  const int n_max = 6 * max_nf;
+  const size_t ldlt_lds = (size_t)n_max * n_max * 8;
+  const int use_lds = ldlt_lds <= 140 * 1024;
+  if (use_lds)
+    VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldlt, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)ldlt_lds));
+  const int ge = (max_obs + 255) / 256, gm = (max_mp + 255) / 256;
+  const int gr = std::max(gm, (max_kf + 255) / 256);
+  const int n_pairs = max_nf * (max_nf + 1) / 2;
 
   // ---- lock-step rounds
-  for (int guard = 0; guard < 400; guard++) {
-    bool any_work = false, any_class = false;
+  for (;;) {
+    const bool stop_now = stop && *stop;
+    int any = 0;
     for (int w = 0; w < W; w++) {
       WinHost& H = win[w];
-      WinCtl& c = ctl[w];
-      c.flags = 0, c.pad = 0, c.lambda = H.lambda;
-      if (H.stage >= 2) continue;
-      if (H.phase == 2) {  // optimize() finished -> stage transition handled below
-        continue;
+      int f = 0;
+      double lam = H.lambda;
+      if (H.stage < 2 && H.phase == 2) {  // an optimize() is over
+        if (H.need_restore) f |= LBA_RESTORE, H.need_restore = false;
+        if (H.stage == 0 && !stop_now) {
+          f |= LBA_CLASS0;
+          H.stage = 1, H.iters = H.P->its1, H.phase = H.iters > 0 ? 0 : 2;
+        } else {
+          if (H.stage == 0) H.R->status = VIEO_LBA_ABORTED;  // stop flag between the two stages
+          f |= LBA_CLASS1;
+          H.stage = 2;
+        }
       }
-      if (H.phase == 0) {
-        c.flags = LBA_ERROR | LBA_BUILD;  // computeActiveErrors + buildSystem of iteration 0
-      } else {
-        c.flags = LBA_TRIAL | (H.need_build ? LBA_BUILD : 0) | (H.need_restore ? LBA_RESTORE : 0);
+      if (H.stage < 2 && H.phase == 0) {
+        f |= LBA_BEGIN | LBA_BUILD | LBA_TRIAL | (H.stage == 0 ? LBA_ROBUST : 0);
+        lam = -1;
+      } else if (H.stage < 2 && H.phase == 1) {
+        f |= LBA_TRIAL | (H.stage == 0 ? LBA_ROBUST : 0);
+        if (H.need_build) f |= LBA_BUILD;
+        if (H.need_restore) f |= LBA_RESTORE, H.need_restore = false;
       }
-      any_work = true;
+      ctl[w].flags = f, ctl[w].pad = 0, ctl[w].lambda = lam;
+      any |= f;
     }
-    // stage transitions (classification) for windows whose optimize() ended
-    for (int w = 0; w < W; w++) {
-      WinHost& H = win[w];
-      if (H.stage < 2 && H.phase == 2) {
-        ctl[w].flags = (H.stage == 0 && !(stop && *stop)) ? LBA_CLASS0 : LBA_CLASS1;
-        if (H.need_restore) ctl[w].flags |= LBA_RESTORE;
-        any_class = true;
-      }
+    if (!any) break;
+    VIEO_HIP_CHECK(hipMemcpyAsync(dC, ctl, (size_t)W * sizeof(WinCtl), hipMemcpyHostToDevice, st));
+    if (any & LBA_RESTORE) hipLaunchKernelGGL(k_lba_restore, dim3(gr, W), dim3(256), 0, st, dD, dC);
+    if (any & (LBA_CLASS0 | LBA_CLASS1)) hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC);
+    if (any & LBA_BEGIN) {
+      hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0);
     }
-    if (!any_work && !any_class) break;
-    for (int w = 0; w < W; w++) devs[w] = win[w].D;
-    VIEO_HIP_CHECK(hipMemcpyAsync(g_devs.p, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(g_ctl.p, ctl.data(), (size_t)W * sizeof(WinCtl), hipMemcpyHostToDevice, st));
-    (void)first_upload;
-    const LbaDev* dD = g_devs.as<LbaDev>();
-    const WinCtl* dC = g_ctl.as<WinCtl>();
-    WinOut* dO = g_out.as<WinOut>();
-    const int ge = (max_obs + 255) / 256, gm = (max_mp + 255) / 256;
-    const int gx = std::max((max_mp * 3 + 255) / 256, (max_kf + 255) / 256);
-    hipLaunchKernelGGL(k_lba_backup_restore, dim3(gx, W), dim3(256), 0, st, dD, dC, 1);
-    if (any_class) hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC);
-    if (any_work) {
-      // phase-0 windows: residuals first (their chi2 is the iteration's currentChi)
-      hipLaunchKernelGGL(k_lba_zero_pose, dim3((max_np * max_np + 255) / 256, W), dim3(256), 0, st, dD, dC);
+    if (any & LBA_BUILD) {
       hipLaunchKernelGGL(k_lba_linearize, dim3((max_mp + 15) / 16, W), dim3(256), 0, st, dD, dC);
-      hipLaunchKernelGGL(k_lba_pose, dim3(8, max_kf, W), dim3(256), 0, st, dD, dC);
-      hipLaunchKernelGGL(k_lba_maxdiag, dim3(W), dim3(256), 0, st, dD, dC, dO);
-      hipLaunchKernelGGL(k_lba_backup_restore, dim3(gx, W), dim3(256), 0, st, dD, dC, 0);
-      hipLaunchKernelGGL(k_lba_init_reduced, dim3((max_np * max_np + 255) / 256, W), dim3(256), 0, st, dD, dC, dO);
-      hipLaunchKernelGGL(k_lba_schur, dim3(std::max(1, std::min(std::max(16, 512 / W), (max_mp + 3) / 4)), W), dim3(256),
-                         schur_lds, st, dD, dC, dO, lds_np_max, use_lds);
-      hipLaunchKernelGGL(k_lba_ldlt, dim3(W), dim3(256), 0, st, dD, dC, dO);
-      hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC);
-      hipLaunchKernelGGL(k_lba_update_poses, dim3((max_kf + 63) / 64, W), dim3(64), 0, st, dD, dC);
-      hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_pose, dim3(max_nf, W), dim3(256), 0, st, dD, dC);
+    }
+    if (any & LBA_BEGIN) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);
+    if (any & LBA_TRIAL) {
+      hipLaunchKernelGGL(k_lba_schur, dim3(n_pairs, W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_ldlt, dim3(W), dim3(256), use_lds ? ldlt_lds : 0, st, dD, dC, dO, use_lds);
+      hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
       hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
-      VIEO_HIP_CHECK(lba_copy(out.data(), g_out.p, (size_t)W * sizeof(WinOut), hipMemcpyDeviceToHost));
+      VIEO_HIP_CHECK(hipMemcpyAsync(out, dO, (size_t)W * sizeof(WinOut), hipMemcpyDeviceToHost, st));
     }
     VIEO_HIP_CHECK(hipGetLastError());
+    VIEO_HIP_CHECK(hipStreamSynchronize(st));
     // ---- per-window policy (optimization_algorithm_levenberg.cpp:61-164)
     for (int w = 0; w < W; w++) {
       WinHost& H = win[w];
       const int fl = ctl[w].flags;
-      if (fl & (LBA_CLASS0 | LBA_CLASS1)) {
-        H.need_restore = false;
-        if (fl & LBA_CLASS0) {
-          VIEO_HIP_CHECK(lba_copy(H.level.data(), H.D.level, H.n_obs, hipMemcpyDeviceToHost));
-          H.stage = 1;
-          H.D.robust = 0;
-          int r = begin_optimize(H, H.P->its1);
-          if (r < 0) return r;
-          H.phase = r == 1 ? 2 : 0;
-        } else {
-          if (H.stage == 0) H.R->status = VIEO_LBA_ABORTED;  // stop flag between the two stages
-          H.stage = 2;
+      if (!(fl & LBA_TRIAL)) continue;
+      if (fl & LBA_BEGIN) {
+        if (out[w].np == 0) {  // no active free vertex: optimize() returns at once
+          H.phase = 2;
+          continue;
         }
-        continue;
-      }
-      if (fl & LBA_ERROR) {  // start of an optimize(): error pass + first linearisation are done
         H.R->lm_iterations++;
-        H.currentChi = out[w].chi2;
+        H.currentChi = out[w].chi0;
         if (H.stage == 0) H.R->chi2_initial = H.currentChi;
         H.iniChi = H.currentChi;
-        H.lambda = 1e-5 * out[w].maxdiag;  // computeLambdaInit
-        H.ni = 2, H.nBad = 0, H.qmax = 0;
-        H.phase = 1, H.need_build = false, H.need_restore = false;
-        continue;
-      }
-      if (!(fl & LBA_TRIAL)) continue;
-      if (out[w].overflow) {
-        set_error("local BA: a map point has more than %d free observers", kSchurMaxObs);
-        return VIEO_E_CAPACITY;
+        H.lambda = out[w].lambda;
+        H.ni = 2, H.nBad = 0, H.qmax = 0, H.it = 0;
+        H.phase = 1;
       }
       H.R->lm_trials++;
       H.need_build = false;
       const bool ok2 = out[w].ok != 0;
-      double tempChi = ok2 ? out[w].chi2 : DBL_MAX;
+      const double tempChi = ok2 ? out[w].chi2 : DBL_MAX;
       double rho = H.currentChi - tempChi;
-      double scale = (ok2 ? out[w].scale_l + out[w].scale_p : 0.0) + 1e-3;
+      const double scale = (ok2 ? out[w].scale_l + out[w].scale_p : 0.0) + 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {
         double alpha = 1. - std::pow(2 * rho - 1, 3);
@@ -951,7 +918,6 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
         H.lambda *= std::max(1. / 3., alpha);
         H.ni = 2;
         H.currentChi = tempChi;
-        H.need_restore = false;
       } else {
         H.lambda *= H.ni;
         H.ni *= 2;
@@ -959,40 +925,39 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
       }
       H.qmax++;
       H.R->chi2_final = H.currentChi;
-      const bool again = rho < 0 && H.qmax < 10 && !(stop && *stop);
-      if (again) continue;  // next lambda trial of the same iteration
-      // ---- the iteration is over
-      bool terminate = (H.qmax == 10 || rho == 0);
+      const bool stopped = stop && *stop;
+      if (rho < 0 && H.qmax < 10 && !stopped) continue;  // next lambda trial of the same iteration
+      bool terminate = H.qmax == 10 || rho == 0;
       if (!terminate) {
         if ((H.iniChi - H.currentChi) * 1e3 < H.iniChi)
           H.nBad++;
         else
           H.nBad = 0;
-        if (H.nBad >= 3) terminate = true;
+        terminate = H.nBad >= 3;
       }
       H.it++;
-      if (terminate || H.it >= H.iters || (stop && *stop)) {
+      if (terminate || H.it >= H.iters || stopped)
         H.phase = 2;
-      } else {
+      else {
         H.R->lm_iterations++;
         H.iniChi = H.currentChi;
         H.qmax = 0;
-        H.need_build = true;  // buildSystem at the accepted state (errors there are already stored)
+        H.need_build = true;  // buildSystem at the accepted state
       }
     }
   }
-  // ---- results
+  // ---- results: one copy for all windows
+  VIEO_HIP_CHECK(hipMemcpyAsync(hs + res_begin, base + res_begin, res_end - res_begin, hipMemcpyDeviceToHost, st));
+  VIEO_HIP_CHECK(hipStreamSynchronize(st));
   for (int w = 0; w < W; w++) {
     WinHost& H = win[w];
-    if (H.skip || (stopped0)) continue;
-    VIEO_HIP_CHECK(lba_copy(h_erase[w], H.D.erase, H.n_obs, hipMemcpyDeviceToHost));
+    if (H.skip) continue;
+    memcpy(h_erase[w], hs + H.o_erase, H.n_obs);
     for (int i = 0; i < H.n_obs; i++) H.R->n_erase += h_erase[w][i];
-    std::vector<LbaKf> o(H.n_kf);
-    std::vector<double> X((size_t)H.n_mp * 3);
-    VIEO_HIP_CHECK(lba_copy(o.data(), H.D.kf, (size_t)H.n_kf * sizeof(LbaKf), hipMemcpyDeviceToHost));
-    VIEO_HIP_CHECK(lba_copy(X.data(), H.D.X, X.size() * 8, hipMemcpyDeviceToHost));
+    const LbaKf* o = (const LbaKf*)(hs + H.o_kf);
+    const double* X = (const double*)(hs + H.o_X);
     for (int k = 0; k < H.n_kf; k++) {
-      if (H.kfs[k].fixed) continue;
+      if (h_kfs[w][k].fixed) continue;
       memcpy(h_navs_out[w][k].p, o[k].p, 24);
       h_navs_out[w][k].q[0] = o[k].qw, h_navs_out[w][k].q[1] = o[k].qx;
       h_navs_out[w][k].q[2] = o[k].qy, h_navs_out[w][k].q[3] = o[k].qz;
