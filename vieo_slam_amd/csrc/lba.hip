@@ -9,13 +9,16 @@
 //   k_lba_begin      initializeOptimization(): active key frames / points from the edge levels, the
 //                    reduced-system column of every free key frame, the (free kf, point) -> edge table
 //   k_lba_error      edge-parallel residuals + robust chi2 (per-block partial sums)
-//   k_lba_linearize  landmark-parallel (16 lanes per landmark, the observations of a point are
-//                    contiguous): Jacobians, H_ll (3x3), b_l and the 6x3 block B = Jp^T W Jx per edge
-//   k_lba_pose       one workgroup per free key frame: H_pp (6x6) and b_p over its edge list
+//   k_lba_build      buildSystem: one thread per point over its observations (H_ll, b_l); one
+//                    workgroup per free key frame over its edge list (H_pp, b_p) which also writes the
+//                    key frame's rows of the dense matrix BB [6 x free key frames][3 x points],
+//                    B = Jp^T W Jx per edge, zero where a key frame does not see a point
 //   k_lba_lambda     computeLambdaInit (tau * max diagonal) for windows starting an optimize()
-//   k_lba_schur      one workgroup per pair of free key frames (a <= b): the 6x6 block
-//                    H_pp[a,b] + lambda I - sum_m B_ma (H_ll,m + lambda I)^-1 B_mb^T over the points both
-//                    observe, gathered through the table; the diagonal pairs also reduce b_p
+//   k_lba_schur      the Schur complement as what it is, a GEMM: (BB D^-1) x [BB; b_l]^T with
+//                    D = blockdiag(H_ll + lambda I), K = 3 x points split over workgroups, 64x64 output
+//                    tiles on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), D^-1 applied while the
+//                    K-chunk is staged through LDS; per-split partial products
+//   k_lba_assemble   Hs = H_pp + lambda I - sum of the partials (fixed order), bs likewise
 //   k_lba_ldlt       one workgroup per window: LDL^T of the reduced system in LDS, solve, pose
 //                    retraction (with backup) and the pose part of the gain-ratio scale
 //   k_lba_update_points  back-substitution x_l = D^-1 (b_l - B^T x_p), point update (with backup)
@@ -57,15 +60,19 @@ struct LbaDev {
   const vieo_lba_obs* obs;
   int n_obs, n_mp, n_kf, nf_cap;  // nf_cap: non-fixed key frames = rows of `tab`
   int np, n_free;                 // written by k_lba_begin
+  int ldB, ldS;                   // leading dimensions of BB (3 x points, padded) and of a partial
   int* kf_list;                   // [n_free] free + active key frames in column order
-  const int *kf_edge_first, *kf_edge_idx;
+  const int *kf_edge_first, *kf_edge_idx;  // edges grouped by key frame
   int* tab;                       // [nf_cap][n_mp] edge of (free kf ordinal, point), -1 = none
   LbaKf *kf, *kf_bak;
   double *X, *X_bak;              // [n_mp][3]
   double* err;                    // [n_obs][3]
   unsigned char *level, *erase, *mp_act;
   const int *mp_first, *mp_count;  // [n_mp]
-  double *Bpl, *Hll, *bl, *Hpp, *bp, *Hs, *bs, *xp;
+  double* BB;                     // [6 nf_cap][ldB]
+  double* Sp;                     // [ksplit][sp_rows][ldS] partial Schur products
+  size_t sp_stride;
+  double *Hll, *bl, *Hpp, *bp, *Hs, *bs, *xp;
   double *part0, *part, *part_m, *pmax;  // per-block partials
   CamD cam;
   double dMono, dStereo;
@@ -176,6 +183,18 @@ k_lba_classify(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) 
     D.erase[i] = bad ? 1 : 0;
 }
 
+// BB = 0, tab = -1 for the windows that start an optimize()
+__global__ void __launch_bounds__(256)
+k_lba_zero(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_BEGIN)) return;
+  const LbaDev& D = devs[w];
+  const size_t nb = (size_t)6 * D.nf_cap * D.ldB, nt = (size_t)D.nf_cap * D.n_mp;
+  const size_t step = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += step) D.BB[i] = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nt; i += step) D.tab[i] = -1;
+}
+
 // ---- initializeOptimization(0): one workgroup per window
 __global__ void __launch_bounds__(256)
 k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
@@ -186,7 +205,6 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
   const int n_mp = D.n_mp, n_obs = D.n_obs, n_kf = D.n_kf;
   if (tid < 128) s_act[tid] = 0;
   for (int m = tid; m < n_mp; m += 256) D.mp_act[m] = 0;
-  for (size_t i = tid; i < (size_t)D.nf_cap * n_mp; i += 256) D.tab[i] = -1;
   __syncthreads();
   for (int i = tid; i < n_obs; i += 256)
     if (D.level[i] == 0) {
@@ -263,70 +281,71 @@ k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   if (threadIdx.x == 0) out[w].chi0 = v[0], out[w].chi2 = v[1], out[w].scale_l = v[2];
 }
 
-// ---- landmark-parallel linearisation: 16 lanes per landmark
+// ---- buildSystem (block_solver.hpp:451-520 with EdgeReprojectPR[Stereo]::linearizeOplus).
+// blocks [0, gm): four lanes per point over its (contiguous) observations -> H_ll, b_l;
+// blocks [gm, gm + free key frames): one workgroup per key frame over its edge list -> H_pp, b_p and the
+// rows of BB = Jp^T W Jx it owns.  Every sum has a fixed order.
 __global__ void __launch_bounds__(256)
-k_lba_linearize(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
-  __shared__ double s_mx[16];
+k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int gm) {
+  const int bx = blockIdx.x;
+  __shared__ double s_red[4 * 27];
   const int w = blockIdx.y, fl = ctl[w].flags;
   if (!(fl & LBA_BUILD)) return;
   const LbaDev& D = devs[w];
-  if (blockIdx.x * 16 >= D.n_mp) return;
-  const int sub = threadIdx.x & 15;
-  const int m = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const bool valid_m = m < D.n_mp && D.mp_act[m];
+  if (D.np == 0) return;
   const bool robust = fl & LBA_ROBUST;
-  double acc[9];  // Hll upper (6) + bl (3)
-#pragma unroll
-  for (int i = 0; i < 9; i++) acc[i] = 0;
-  if (valid_m) {
-    const int first = D.mp_first[m], cnt = D.mp_count[m];
-    const double* Xw = D.X + 3 * (size_t)m;
-    for (int j = sub; j < cnt; j += 16) {
-      const int i = first + j;
-      if (D.level[i]) continue;
-      const vieo_lba_obs o = D.obs[i];
-      const LbaKf k = D.kf[o.kf];
-      PoseXf X;
-      kf_xf(D.cam, k, X);
-      double err[3], Pc[3];
-      const double chi2 = lba_edge_error(D.cam, X, o, Xw, err, Pc);
-      const bool stereo = o.ur >= 0;
-      double r0, r1 = 1.;
-      if (robust) {
-        const double dl = stereo ? D.dStereo : D.dMono;
-        huber(chi2, dl, dl * dl, &r0, &r1);
-      }
-      double Jp[18], Jx[9];
-      lba_jacobians(D.cam, X, k.p, Xw, Pc, Jp, Jx);
-      const double info = (double)o.inv_sigma2, ww = r1 * info;
-      const int de = stereo ? 3 : 2;
-      int t = 0;
-      for (int a = 0; a < 3; a++) {
-        for (int b = a; b < 3; b++, t++) {
-          double s = 0;
-          for (int r = 0; r < de; r++) s += Jx[r * 3 + a] * ww * Jx[r * 3 + b];
-          acc[t] += s;
-        }
-        double s = 0;
-        for (int r = 0; r < de; r++) s += Jx[r * 3 + a] * (-(info * err[r]) * r1);
-        acc[6 + a] += s;
-      }
-      double* B = D.Bpl + 18 * (size_t)i;
-      if (k.col >= 0)
-        for (int a = 0; a < 6; a++)
-          for (int b = 0; b < 3; b++) {
-            double s = 0;
-            for (int r = 0; r < de; r++) s += Jp[r * 6 + a] * ww * Jx[r * 3 + b];
-            B[a * 3 + b] = s;
-          }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 9; i++)
-    for (int o = 8; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o, 16);
-  if (sub == 0) {
+  if (bx < gm) {
+    if (bx * 64 >= D.n_mp) return;
+    const int m = bx * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;  // 4 lanes per point
+    const bool act = m < D.n_mp && D.mp_act[m];
     double mx = 0;
-    if (valid_m) {
+    double acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[t] = 0;
+    if (act) {
+      const double Xw[3] = {D.X[3 * (size_t)m], D.X[3 * (size_t)m + 1], D.X[3 * (size_t)m + 2]};
+      const int first = D.mp_first[m], cnt = D.mp_count[m];
+      for (int j = sub; j < cnt; j += 4) {
+        const int i = first + j;
+        if (D.level[i]) continue;
+        const vieo_lba_obs o = D.obs[i];
+        PoseXf X;
+        kf_xf(D.cam, D.kf[o.kf], X);
+        double err[3], Pc[3];
+        const double chi2 = lba_edge_error(D.cam, X, o, Xw, err, Pc);
+        const bool stereo = o.ur >= 0;
+        double r0, r1 = 1.;
+        if (robust) {
+          const double dl = stereo ? D.dStereo : D.dMono;
+          huber(chi2, dl, dl * dl, &r0, &r1);
+        }
+        const double invz = 1 / Pc[2], invz2 = invz * invz;
+        double J[9], Jx[9];
+        J[0] = -(D.cam.fx * invz), J[1] = 0, J[2] = -(-D.cam.fx * Pc[0] * invz2);
+        J[3] = 0, J[4] = -(D.cam.fy * invz), J[5] = -(-D.cam.fy * Pc[1] * invz2);
+        J[6] = J[0], J[7] = J[1], J[8] = J[2] - D.cam.bf * invz2;
+        for (int r = 0; r < 3; r++)
+          for (int q = 0; q < 3; q++)
+            Jx[r * 3 + q] = J[r * 3] * X.Rcw[q] + J[r * 3 + 1] * X.Rcw[3 + q] + J[r * 3 + 2] * X.Rcw[6 + q];
+        const double info = (double)o.inv_sigma2, ww = r1 * info;
+        if (!stereo) Jx[6] = Jx[7] = Jx[8] = 0;  // monocular edge: no third row (err[2] is 0 already)
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+#pragma unroll
+          for (int b = a; b < 3; b++, t++)
+            acc[t] += Jx[a] * ww * Jx[b] + Jx[3 + a] * ww * Jx[3 + b] + Jx[6 + a] * ww * Jx[6 + b];
+          acc[6 + a] += Jx[a] * (-(info * err[0]) * r1) + Jx[3 + a] * (-(info * err[1]) * r1) +
+                        Jx[6 + a] * (-(info * err[2]) * r1);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      acc[t] += __shfl_xor(acc[t], 1);
+      acc[t] += __shfl_xor(acc[t], 2);
+    }
+    if (act && sub == 0) {
       double* H = D.Hll + 9 * (size_t)m;
       H[0] = acc[0], H[1] = acc[1], H[2] = acc[2];
       H[3] = acc[1], H[4] = acc[3], H[5] = acc[4];
@@ -334,34 +353,24 @@ k_lba_linearize(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl)
       D.bl[3 * (size_t)m] = acc[6], D.bl[3 * (size_t)m + 1] = acc[7], D.bl[3 * (size_t)m + 2] = acc[8];
       mx = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
     }
-    s_mx[threadIdx.x >> 4] = mx;
+    // landmark part of computeLambdaInit: block maximum
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) D.pmax[bx] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    return;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double mx = 0;
-    for (int i = 0; i < 16; i++) mx = fmax(mx, s_mx[i]);
-    D.pmax[blockIdx.x] = mx;  // landmark part of computeLambdaInit
-  }
-}
-
-// ---- H_pp / b_p: one workgroup per free key frame (grid: key-frame ordinal, window)
-__global__ void __launch_bounds__(256)
-k_lba_pose(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
-  __shared__ double s_red[4 * 27];
-  const int w = blockIdx.y, fl = ctl[w].flags;
-  if (!(fl & LBA_BUILD)) return;
-  const LbaDev& D = devs[w];
-  const int a = blockIdx.x;
+  const int a = bx - gm;
   if (a >= D.n_free) return;
   const int kfi = D.kf_list[a];
   const LbaKf k = D.kf[kfi];
   const int first = D.kf_edge_first[kfi], cnt = D.kf_edge_first[kfi + 1] - first;
-  const bool robust = fl & LBA_ROBUST;
   double acc[27];
 #pragma unroll
-  for (int i = 0; i < 27; i++) acc[i] = 0;
+  for (int t = 0; t < 27; t++) acc[t] = 0;
   PoseXf X;
   kf_xf(D.cam, k, X);
+  double* Brow = D.BB + (size_t)k.col * D.ldB;
   for (int j = threadIdx.x; j < cnt; j += 256) {
     const int i = D.kf_edge_idx[first + j];
     if (D.level[i]) continue;
@@ -377,18 +386,30 @@ k_lba_pose(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
     }
     double Jp[18], Jx[9];
     lba_jacobians(D.cam, X, k.p, Xw, Pc, Jp, Jx);
-    visual_accumulate(Jp, err, (double)o.inv_sigma2, r1, stereo, acc);
+    const double info = (double)o.inv_sigma2, ww = r1 * info;
+    visual_accumulate(Jp, err, info, r1, stereo, acc);
+    if (!stereo) Jx[6] = Jx[7] = Jx[8] = 0;
+    double* B = Brow + 3 * (size_t)o.mp;
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+#pragma unroll
+      for (int b = 0; b < 3; b++)
+        B[(size_t)q * D.ldB + b] = Jp[q] * ww * Jx[b] + Jp[6 + q] * ww * Jx[3 + b] + Jp[12 + q] * ww * Jx[6 + b];
   }
   block_sum<27>(acc, s_red, threadIdx.x);
   if (threadIdx.x < 27) {
+    double v = 0;
+#pragma unroll
+    for (int t = 0; t < 27; t++)  // select, not acc[threadIdx.x]: keeps the sums in registers
+      if ((int)threadIdx.x == t) v = acc[t];
     if (threadIdx.x < 21) {
       int r = 0, t = threadIdx.x;
       while (t >= 6 - r) t -= 6 - r, r++;
       const int c = r + t;
-      D.Hpp[36 * (size_t)a + r * 6 + c] = acc[threadIdx.x];
-      D.Hpp[36 * (size_t)a + c * 6 + r] = acc[threadIdx.x];
+      D.Hpp[36 * (size_t)a + r * 6 + c] = v;
+      D.Hpp[36 * (size_t)a + c * 6 + r] = v;
     } else
-      D.bp[6 * a + threadIdx.x - 21] = acc[threadIdx.x];
+      D.bp[6 * a + threadIdx.x - 21] = v;
   }
 }
 
@@ -401,7 +422,7 @@ k_lba_lambda(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   const LbaDev& D = devs[w];
   double mx = 0;
   for (int j = threadIdx.x; j < D.np; j += 256) mx = fmax(mx, fabs(D.Hpp[36 * (size_t)(j / 6) + 7 * (j % 6)]));
-  for (int b = threadIdx.x; b < (D.n_mp + 15) / 16; b += 256) mx = fmax(mx, D.pmax[b]);
+  for (int b = threadIdx.x; b < (D.n_mp + 63) / 64; b += 256) mx = fmax(mx, D.pmax[b]);
   s_m[threadIdx.x] = mx;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -411,65 +432,123 @@ k_lba_lambda(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   if (threadIdx.x == 0) out[w].lambda = 1e-5 * s_m[0];
 }
 
-// ---- reduced system: one workgroup per key-frame pair (a <= b) gathers
-//   Hs[a,b] = [a == b] (Hpp[a] + lambda I) - sum_m B_ma D_m^-1 B_mb^T,   bs[a] = bp[a] - sum_m B_ma D_m^-1 bl_m
+// ---- Schur complement GEMM.  S = (BB D^-1) [BB; bl]^T, S is np x (np + 1), tiled 64 x 64 (upper
+// block-tiles only), K = 3 x points cut into chunks of 16 points; grid x = block-tile * ksplit + split.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+static const int kChunkLm = 16, kLd = 3 * kChunkLm + 2;  // +2: conflict-free b64 fragment reads
+
 __global__ void __launch_bounds__(256)
-k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out) {
-  __shared__ double s_red[4 * 42];
+k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out,
+            int ksplit) {
+  __shared__ __attribute__((aligned(16))) double sT[64 * kLd];
+  __shared__ __attribute__((aligned(16))) double sB[64 * kLd];
+  __shared__ double sDi[kChunkLm * 9];
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
-  const int nf = D.n_free;
-  int a = 0, t = blockIdx.x;
-  if (t >= nf * (nf + 1) / 2) return;
-  while (t >= nf - a) t -= nf - a, a++;
-  const int b = a + t;
+  const int np = D.np;
+  if (np == 0) return;
+  const int RB = (np + 63) >> 6, CB = (np + 64) >> 6;  // CB covers the extra column bl
+  int bt = blockIdx.x / ksplit;
+  const int split = blockIdx.x % ksplit;
+  int bi = 0;
+  while (bi < RB && bt >= CB - bi) bt -= CB - bi, bi++;
+  if (bi >= RB) return;
+  const int bj = bi + bt;
+  const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
+  const int c0 = split * cps, c1 = min(nchunks, c0 + cps);
+  if (c0 >= c1) return;  // k_lba_assemble uses the same split arithmetic
   const double lambda = win_lambda(ctl[w], out[w]);
-  const int n_mp = D.n_mp;
-  const int* ta = D.tab + (size_t)a * n_mp;
-  const int* tb = D.tab + (size_t)b * n_mp;
-  double acc[42];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const size_t ldB = D.ldB;
+  double4_t acc[4];
 #pragma unroll
-  for (int i = 0; i < 42; i++) acc[i] = 0;
-  for (int m = threadIdx.x; m < n_mp; m += 256) {
-    const int ia = ta[m];
-    if (ia < 0) continue;
-    const int ib = tb[m];
-    if (ib < 0) continue;
-    double Di[9];
-    landmark_dinv(D.Hll + 9 * (size_t)m, lambda, Di);
-    const double* Ba = D.Bpl + 18 * (size_t)ia;
-    const double* Bb = D.Bpl + 18 * (size_t)ib;
-    double T[18];
+  for (int q = 0; q < 4; q++) acc[q] = (double4_t){0, 0, 0, 0};
+  for (int ch = c0; ch < c1; ch++) {
+    __syncthreads();  // the previous chunk's fragments have been read
+    if (tid < kChunkLm) {
+      const int m = ch * kChunkLm + tid;
+      double Di[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < D.n_mp && D.mp_act[m]) landmark_dinv(D.Hll + 9 * (size_t)m, lambda, Di);
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const double b0 = Ba[r * 3], b1 = Ba[r * 3 + 1], b2 = Ba[r * 3 + 2];
-      T[r * 3 + 0] = b0 * Di[0] + b1 * Di[3] + b2 * Di[6];
-      T[r * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2 * Di[7];
-      T[r * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2 * Di[8];
+      for (int t = 0; t < 9; t++) sDi[tid * 9 + t] = Di[t];
     }
+    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
-      const double b0 = Bb[c * 3], b1 = Bb[c * 3 + 1], b2 = Bb[c * 3 + 2];
-#pragma unroll
-      for (int r = 0; r < 6; r++) acc[r * 6 + c] += T[r * 3] * b0 + T[r * 3 + 1] * b1 + T[r * 3 + 2] * b2;
+    for (int it = 0; it < 4; it++) {
+      const int item = tid + 256 * it, r = item >> 4, j = item & 15;
+      const int m = ch * kChunkLm + j;
+      const int gr = bi * 64 + r, gc = bj * 64 + r;
+      double b0 = 0, b1 = 0, b2 = 0;
+      if (gr < np) {
+        const double* p = D.BB + (size_t)gr * ldB + 3 * (size_t)m;
+        b0 = p[0], b1 = p[1], b2 = p[2];
+      }
+      const double* Di = sDi + j * 9;
+      sT[r * kLd + 3 * j + 0] = b0 * Di[0] + b1 * Di[3] + b2 * Di[6];
+      sT[r * kLd + 3 * j + 1] = b0 * Di[1] + b1 * Di[4] + b2 * Di[7];
+      sT[r * kLd + 3 * j + 2] = b0 * Di[2] + b1 * Di[5] + b2 * Di[8];
+      if (bj != bi) {
+        b0 = b1 = b2 = 0;
+        if (gc < np) {
+          const double* p = D.BB + (size_t)gc * ldB + 3 * (size_t)m;
+          b0 = p[0], b1 = p[1], b2 = p[2];
+        }
+      }
+      if (gc == np) {  // the extra column: b_l
+        b0 = b1 = b2 = 0;
+        if (m < D.n_mp && D.mp_act[m]) {
+          const double* p = D.bl + 3 * (size_t)m;
+          b0 = p[0], b1 = p[1], b2 = p[2];
+        }
+      }
+      sB[r * kLd + 3 * j + 0] = b0, sB[r * kLd + 3 * j + 1] = b1, sB[r * kLd + 3 * j + 2] = b2;
     }
-    if (a == b) {
-      const double* bl = D.bl + 3 * (size_t)m;
+    __syncthreads();
+    const double* pa = sT + (wv * 16 + (lane & 15)) * kLd + (lane >> 4);
+    const double* pb = sB + (lane & 15) * kLd + (lane >> 4);
 #pragma unroll
-      for (int r = 0; r < 6; r++) acc[36 + r] += T[r * 3] * bl[0] + T[r * 3 + 1] * bl[1] + T[r * 3 + 2] * bl[2];
+    for (int ks = 0; ks < 3 * kChunkLm / 4; ks++) {
+      const double av = pa[ks * 4];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[q * 16 * kLd + ks * 4], acc[q], 0, 0, 0);
     }
   }
-  block_sum<42>(acc, s_red, threadIdx.x);
-  const int np = D.np, tid = threadIdx.x;
-  if (tid < 36) {
-    const int r = tid / 6, c = tid % 6;
-    double v = -acc[tid];
-    if (a == b) v += D.Hpp[36 * (size_t)a + tid] + (r == c ? lambda : 0.0);
-    D.Hs[(size_t)(6 * a + r) * np + 6 * b + c] = v;
-    if (a != b) D.Hs[(size_t)(6 * b + c) * np + 6 * a + r] = v;
-  } else if (tid < 42 && a == b)
-    D.bs[6 * a + tid - 36] = D.bp[6 * a + tid - 36] - acc[tid];
+  // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+  double* S = D.Sp + (size_t)split * D.sp_stride;
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      S[(size_t)(bi * 64 + wv * 16 + (lane >> 4) + 4 * r) * D.ldS + bj * 64 + q * 16 + (lane & 15)] = acc[q][r];
+}
+
+// Hs = Hpp + lambda I - S (both triangles from the upper block-tiles), bs = bp - S[:, np]
+__global__ void __launch_bounds__(256)
+k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out,
+               int ksplit) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  const int np = D.np, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= np * np) return;
+  const double lambda = win_lambda(ctl[w], out[w]);
+  const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
+  const int ns = (nchunks + cps - 1) / cps;
+  const int r = e / np, c = e % np;
+  const int rr = min(r, c), cc = max(r, c);
+  double s = 0;
+  for (int k = 0; k < ns; k++) s += D.Sp[(size_t)k * D.sp_stride + (size_t)rr * D.ldS + cc];
+  double v = -s;
+  if (r / 6 == c / 6) v += D.Hpp[36 * (size_t)(r / 6) + (r % 6) * 6 + c % 6];
+  if (r == c) v += lambda;
+  D.Hs[e] = v;
+  if (c == 0) {
+    double t = 0;
+    for (int k = 0; k < ns; k++) t += D.Sp[(size_t)k * D.sp_stride + (size_t)r * D.ldS + np];
+    D.bs[r] = D.bp[r] - t;
+  }
 }
 
 // ---- dense LDL^T solve of the reduced system + pose update, one workgroup per window.
@@ -574,17 +653,13 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
   const int m = blockIdx.x * 256 + threadIdx.x;
   double sc[1] = {0};
   if (m < D.n_mp && D.mp_act[m]) {
-    const int first = D.mp_first[m], cnt = D.mp_count[m];
     double cl[3] = {D.bl[3 * (size_t)m], D.bl[3 * (size_t)m + 1], D.bl[3 * (size_t)m + 2]};
-    for (int j = 0; j < cnt; j++) {
-      const int i = first + j;
-      if (D.level[i]) continue;
-      const int col = D.kf[D.obs[i].kf].col;
-      if (col < 0) continue;
-      const double* B = D.Bpl + 18 * (size_t)i;
-      for (int a = 0; a < 6; a++) {
-        const double xa = D.xp[col + a];
-        cl[0] -= B[a * 3] * xa, cl[1] -= B[a * 3 + 1] * xa, cl[2] -= B[a * 3 + 2] * xa;
+    for (int a = 0; a < D.n_free; a++) {
+      if (D.tab[(size_t)a * D.n_mp + m] < 0) continue;
+      const double* B = D.BB + (size_t)(6 * a) * D.ldB + 3 * (size_t)m;
+      for (int r = 0; r < 6; r++, B += D.ldB) {
+        const double xa = D.xp[6 * a + r];
+        cl[0] -= B[0] * xa, cl[1] -= B[1] * xa, cl[2] -= B[2] * xa;
       }
     }
     double Di[9];
@@ -728,9 +803,21 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
   if ((rc = g_stage.ensure(res_end)) != VIEO_OK) return rc;
   uint8_t* hs = (uint8_t*)g_stage.p;
   int max_obs = 0, max_mp = 0, max_kf = 0, max_nf = 0;
+  for (int w = 0; w < W; w++) {
+    if (win[w].skip) continue;
+    int nf = 0;
+    for (int k = 0; k < win[w].n_kf; k++) nf += !h_kfs[w][k].fixed;
+    max_nf = std::max(max_nf, nf), max_mp = std::max(max_mp, win[w].n_mp);
+  }
+  // Schur GEMM decomposition: 64x64 block-tiles (upper) x K splits, about 768 workgroups in flight
+  const int np_cap_max = 6 * max_nf;
+  const int RBm = (np_cap_max + 63) / 64, CBm = (np_cap_max + 64) / 64;
+  const int nbt_max = RBm * CBm - RBm * (RBm - 1) / 2;
+  const int nchunks_max = (max_mp + kChunkLm - 1) / kChunkLm;
+  const int ksplit = std::max(1, std::min(std::min(nchunks_max, 16), 768 / std::max(1, n_live * nbt_max)));
   std::vector<size_t> scratch_off(W);
   struct Scr {
-    size_t kf_bak, X_bak, mp_act, Bpl, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab;
+    size_t kf_bak, X_bak, mp_act, BB, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab;
   };
   std::vector<Scr> scr(W);
   for (int w = 0; w < W; w++) {
@@ -774,15 +861,20 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     const int npm = 6 * nf;
     s.kf_bak = take((size_t)H.n_kf * sizeof(LbaKf)), s.X_bak = take((size_t)H.n_mp * 24);
     s.mp_act = take(H.n_mp);
-    s.Bpl = take((size_t)H.n_obs * 144), s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
+    const int ldB = (H.n_mp + kChunkLm - 1) / kChunkLm * (3 * kChunkLm);
+    const int sp_rows = (npm + 63) / 64 * 64, ldS = (npm + 64) / 64 * 64;
+    s.BB = take((size_t)npm * ldB * 8);
+    s.Sp = take((size_t)ksplit * sp_rows * ldS * 8);
+    s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
     s.Hpp = take((size_t)nf * 36 * 8), s.Hs = take((size_t)npm * npm * 8);
     s.bp = take((size_t)npm * 8), s.bs = take((size_t)npm * 8), s.xp = take((size_t)npm * 8);
     s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
-    s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 15) / 16) * 8);
+    s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
     s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)nf * H.n_mp * 4);
     LbaDev& D = devs[w];
     memset(&D, 0, sizeof(D));
     D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.nf_cap = nf;
+    D.ldB = ldB, D.ldS = ldS, D.sp_stride = (size_t)sp_rows * ldS;
     D.cam.fx = H.P->fx, D.cam.fy = H.P->fy, D.cam.cx = H.P->cx, D.cam.cy = H.P->cy, D.cam.bf = H.P->bf;
     memcpy(D.cam.Rcb, H.P->Rcb, 72);
     memcpy(D.cam.tcb, H.P->tcb, 24);
@@ -808,7 +900,8 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     D.kf = (LbaKf*)(base + o.kf), D.X = (double*)(base + o.X), D.erase = base + o.erase;
     D.level = base + o.level, D.err = (double*)(base + o.err);
     D.kf_bak = (LbaKf*)(base + s.kf_bak), D.X_bak = (double*)(base + s.X_bak), D.mp_act = base + s.mp_act;
-    D.Bpl = (double*)(base + s.Bpl), D.Hll = (double*)(base + s.Hll), D.bl = (double*)(base + s.bl);
+    D.BB = (double*)(base + s.BB), D.Sp = (double*)(base + s.Sp);
+    D.Hll = (double*)(base + s.Hll), D.bl = (double*)(base + s.bl);
     D.Hpp = (double*)(base + s.Hpp), D.Hs = (double*)(base + s.Hs), D.bp = (double*)(base + s.bp);
     D.bs = (double*)(base + s.bs), D.xp = (double*)(base + s.xp);
     D.part0 = (double*)(base + s.part0), D.part = (double*)(base + s.part);
@@ -830,9 +923,8 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
   if (use_lds)
     VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldlt, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)ldlt_lds));
-  const int ge = (max_obs + 255) / 256, gm = (max_mp + 255) / 256;
+  const int ge = (max_obs + 255) / 256, gm = (max_mp + 255) / 256, gq = (max_mp + 63) / 64;
   const int gr = std::max(gm, (max_kf + 255) / 256);
-  const int n_pairs = max_nf * (max_nf + 1) / 2;
 
   // ---- lock-step rounds
   for (;;) {
@@ -869,16 +961,18 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     if (any & LBA_RESTORE) hipLaunchKernelGGL(k_lba_restore, dim3(gr, W), dim3(256), 0, st, dD, dC);
     if (any & (LBA_CLASS0 | LBA_CLASS1)) hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC);
     if (any & LBA_BEGIN) {
+      hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC);
       hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO);
       hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0);
     }
     if (any & LBA_BUILD) {
-      hipLaunchKernelGGL(k_lba_linearize, dim3((max_mp + 15) / 16, W), dim3(256), 0, st, dD, dC);
-      hipLaunchKernelGGL(k_lba_pose, dim3(max_nf, W), dim3(256), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_build, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq);
     }
     if (any & LBA_BEGIN) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);
     if (any & LBA_TRIAL) {
-      hipLaunchKernelGGL(k_lba_schur, dim3(n_pairs, W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_schur, dim3(nbt_max * ksplit, W), dim3(256), 0, st, dD, dC, dO, ksplit);
+      hipLaunchKernelGGL(k_lba_assemble, dim3((np_cap_max * np_cap_max + 255) / 256, W), dim3(256), 0, st, dD, dC,
+                         dO, ksplit);
       hipLaunchKernelGGL(k_lba_ldlt, dim3(W), dim3(256), use_lds ? ldlt_lds : 0, st, dD, dC, dO, use_lds);
       hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO);
       hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
