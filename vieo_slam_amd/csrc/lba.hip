@@ -552,14 +552,14 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
 }
 
 // ---- dense LDL^T solve of the reduced system + pose update, one workgroup per window.
-// use_lds: the matrix is factorised in LDS (dynamic), otherwise in place in global memory (L2).
+// Right-looking, one 6-column panel (= one key frame) per step: every thread factorises the 6x6
+// diagonal block in registers, one thread per row below forms its 6 multipliers, then the trailing
+// matrix takes the six rank-1 updates in sequence -- the arithmetic of the column-by-column algorithm
+// with a sixth of its barriers.  use_lds: the matrix lives in LDS, otherwise in place in global memory.
 __global__ void __launch_bounds__(256)
 k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out,
-           int use_lds) {
-  extern __shared__ __attribute__((aligned(16))) double s_A[];
-  __shared__ double s_col[512];
-  __shared__ double s_l[512];
-  __shared__ double s_D[512];
+           int use_lds, int n_max) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   __shared__ double s_red[4];
   const int w = blockIdx.x;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
@@ -570,51 +570,130 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
     return;
   }
   const double lambda = win_lambda(ctl[w], out[w]);
-  double* A = use_lds ? s_A : D.Hs;
+  double* sW = s_dyn;               // [n][6] un-normalised panel columns
+  double* y = sW + 6 * (size_t)n_max;  // [n]
+  double* sD = y + n_max;           // [n]
+  double* A = use_lds ? sD + n_max : D.Hs;
   if (use_lds) {
     for (int i = tid; i < n * n; i += 256) A[i] = D.Hs[i];
-    __syncthreads();
   }
+  __syncthreads();
   const int ti = tid >> 4, tk = tid & 15;
   bool ok = true;
-  for (int j = 0; j < n; j++) {
-    const double d = A[(size_t)j * n + j];  // same address for all threads: uniform branch
-    if (!(d > 0)) {
-      ok = false;
-      break;
+  for (int j0 = 0; j0 < n && ok; j0 += 6) {
+    // 6x6 diagonal block, every thread: a[r][c] (r >= c), Wd = un-normalised columns, Dd = pivots
+    double a[6][6], Wd[6][6], Dd[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) a[r][c] = A[(size_t)(j0 + r) * n + j0 + c];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const double d = a[c][c];
+      if (!(d > 0)) ok = false;
+      Dd[c] = d;
+#pragma unroll
+      for (int r = c + 1; r < 6; r++) Wd[r][c] = a[r][c];
+#pragma unroll
+      for (int r = c + 1; r < 6; r++) {
+        const double l = Wd[r][c] / d;
+#pragma unroll
+        for (int k = c + 1; k <= r; k++) a[r][k] -= l * Wd[k][c];
+        a[r][c] = l;
+      }
     }
-    for (int i = j + 1 + tid; i < n; i += 256) {
-      const double c = A[(size_t)i * n + j];
-      s_col[i] = c, s_l[i] = c / d;
+    if (!ok) break;  // uniform: every thread factorised the same block
+    if (tid < 6) {
+      sD[j0 + tid] = Dd[0];
+#pragma unroll
+      for (int c = 1; c < 6; c++)
+        if (tid == c) sD[j0 + tid] = Dd[c];
     }
-    if (tid == 0) s_D[j] = d;
+    // rows below the panel: multipliers
+    for (int i = j0 + 6 + tid; i < n; i += 256) {
+      double ai[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) ai[c] = A[(size_t)i * n + j0 + c];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const double col = ai[c], l = col / Dd[c];
+        sW[i * 6 + c] = col;
+#pragma unroll
+        for (int k = c + 1; k < 6; k++) ai[k] -= l * Wd[k][c];
+        ai[c] = l;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) A[(size_t)i * n + j0 + c] = ai[c];
+    }
     __syncthreads();
-    for (int i = j + 1 + ti; i < n; i += 16) {
-      const double li = s_l[i];
-      for (int k = j + 1 + tk; k <= i; k += 16) A[(size_t)i * n + k] -= li * s_col[k];
+    if (tid == 0) {  // after the barrier: every thread has read the unfactorised diagonal block
+#pragma unroll
+      for (int r = 1; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < r; c++) A[(size_t)(j0 + r) * n + j0 + c] = a[r][c];
     }
-    for (int i = j + 1 + tid; i < n; i += 256) A[(size_t)i * n + j] = s_l[i];
+    // trailing matrix (lower triangle)
+    for (int i = j0 + 6 + ti; i < n; i += 16) {
+      double li[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) li[c] = A[(size_t)i * n + j0 + c];
+      for (int k = j0 + 6 + tk; k <= i; k += 16) {
+        double v = A[(size_t)i * n + k];
+#pragma unroll
+        for (int c = 0; c < 6; c++) v -= li[c] * sW[k * 6 + c];
+        A[(size_t)i * n + k] = v;
+      }
+    }
     __syncthreads();
   }
-  double* y = s_col;
   if (ok) {
-    __syncthreads();
     for (int i = tid; i < n; i += 256) y[i] = D.bs[i];
     __syncthreads();
-    for (int j = 0; j < n; j++) {
-      const double yj = y[j];
-      for (int i = j + 1 + tid; i < n; i += 256) y[i] -= A[(size_t)i * n + j] * yj;
+    // forward substitution L y = b, panel by panel
+    for (int j0 = 0; j0 < n; j0 += 6) {
+      double yp[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) yp[c] = y[j0 + c];
+#pragma unroll
+      for (int c = 0; c < 6; c++)
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) yp[r] -= A[(size_t)(j0 + r) * n + j0 + c] * yp[c];
+      __syncthreads();  // everyone has read y[j0 .. j0+5]
+      if (tid == 0)
+#pragma unroll
+        for (int c = 1; c < 6; c++) y[j0 + c] = yp[c];
+      for (int i = j0 + 6 + tid; i < n; i += 256) {
+        double v = y[i];
+#pragma unroll
+        for (int c = 0; c < 6; c++) v -= A[(size_t)i * n + j0 + c] * yp[c];
+        y[i] = v;
+      }
       __syncthreads();
     }
-    for (int i = tid; i < n; i += 256) y[i] /= s_D[i];
+    for (int i = tid; i < n; i += 256) y[i] /= sD[i];
     __syncthreads();
-    for (int j = n - 1; j >= 0; j--) {
-      const double xj = y[j];
-      for (int i = tid; i < j; i += 256) y[i] -= A[(size_t)j * n + i] * xj;
+    // backward substitution L^T x = y
+    for (int j0 = n - 6; j0 >= 0; j0 -= 6) {
+      double xp[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) xp[c] = y[j0 + c];
+#pragma unroll
+      for (int c = 5; c > 0; c--)
+#pragma unroll
+        for (int r = c - 1; r >= 0; r--) xp[r] -= A[(size_t)(j0 + c) * n + j0 + r] * xp[c];
+      __syncthreads();
+      if (tid == 0)
+#pragma unroll
+        for (int c = 0; c < 5; c++) y[j0 + c] = xp[c];
+      for (int i = tid; i < j0; i += 256) {
+        double v = y[i];
+#pragma unroll
+        for (int c = 5; c >= 0; c--) v -= A[(size_t)(j0 + c) * n + i] * xp[c];
+        y[i] = v;
+      }
       __syncthreads();
     }
   } else {
-    __syncthreads();
     for (int i = tid; i < n; i += 256) y[i] = 0;
     __syncthreads();
   }
@@ -918,11 +997,11 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
   VIEO_HIP_CHECK(hipMemcpyAsync(dD, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
   VIEO_HIP_CHECK(hipMemsetAsync(dO, 0, (size_t)W * sizeof(WinOut), st));
   const int n_max = 6 * max_nf;
-  const size_t ldlt_lds = (size_t)n_max * n_max * 8;
-  const int use_lds = ldlt_lds <= 140 * 1024;
-  if (use_lds)
-    VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldlt, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)ldlt_lds));
+  const size_t ldlt_small = (size_t)8 * n_max * 8;  // panel columns, rhs, pivots
+  const int use_lds = (size_t)n_max * n_max * 8 + ldlt_small <= 150 * 1024;
+  const size_t ldlt_lds = ldlt_small + (use_lds ? (size_t)n_max * n_max * 8 : 0);
+  VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldlt, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)ldlt_lds));
   const int ge = (max_obs + 255) / 256, gm = (max_mp + 255) / 256, gq = (max_mp + 63) / 64;
   const int gr = std::max(gm, (max_kf + 255) / 256);
 
@@ -973,7 +1052,7 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
       hipLaunchKernelGGL(k_lba_schur, dim3(nbt_max * ksplit, W), dim3(256), 0, st, dD, dC, dO, ksplit);
       hipLaunchKernelGGL(k_lba_assemble, dim3((np_cap_max * np_cap_max + 255) / 256, W), dim3(256), 0, st, dD, dC,
                          dO, ksplit);
-      hipLaunchKernelGGL(k_lba_ldlt, dim3(W), dim3(256), use_lds ? ldlt_lds : 0, st, dD, dC, dO, use_lds);
+      hipLaunchKernelGGL(k_lba_ldlt, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
       hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO);
       hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
       hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
