@@ -92,3 +92,55 @@ def test_vio_batch_device(oracle):
         assert dt < TOL and dr < TOL
         assert res[i]["base"]["n_inliers"] == o["base"]["n_inliers"]
         assert np.array_equal(oo[b:b + n], outl[b:b + n])
+
+
+def test_vio_large_batch_one_wavefront_per_frame(oracle):
+    """More than 256 frames take the one-wavefront-per-frame kernel: every frame must still equal the
+    oracle (distinct problems incl. free last state + prior, marginalisation, rescue pass, few edges)."""
+    protos = []
+    for i in range(10):
+        kw = dict(n_obs=60 + 97 * i, compute_marg=(i % 2 == 0))
+        if i == 7:
+            kw.update(n_obs=40, outlier_frac=0.5)
+        if i == 9:
+            kw.update(n_obs=6, outlier_frac=0.0)
+        if i % 3 == 1:  # last state free, with a marginal prior (30-dim system)
+            F0, obs0, _ = synth_ba.make_vio_problem(400 + i, compute_marg=True)
+            r0, _ = oracle.pose_optimization_vio(F0, obs0)
+            F1, obs1, _ = synth_ba.make_vio_problem(300 + i, **kw)
+            nav_last = F1[0]["nav_last"].copy()
+            nav_prior = nav_last.copy()
+            nav_last["p"] += 0.004
+            nav_last["v"] += 0.015
+            kw["prior"] = (nav_prior, r0["H_marg"].reshape(15, 15), nav_last)
+        protos.append(synth_ba.make_vio_problem(300 + i, **kw)[:2])
+    B = 300
+    frames = np.zeros(B, VIO_FRAME_DTYPE)
+    all_obs, begin = [], 0
+    for i in range(B):
+        F, obs = protos[i % len(protos)]
+        frames[i] = F[0]
+        frames[i]["base"]["obs_begin"] = begin
+        begin += len(obs)
+        all_obs.append(obs)
+    obs = np.concatenate(all_obs)
+    dF, dO = DeviceBuffer(frames.nbytes), DeviceBuffer(obs.nbytes)
+    dU, dR = DeviceBuffer(len(obs)), DeviceBuffer(B * VIO_RESULT_DTYPE.itemsize)
+    dF.upload(frames)
+    dO.upload(obs)
+    check(lib().vieo_pose_optimization_vio_batch_device(dF.ptr, B, dO.ptr, dU.ptr, dR.ptr, None))
+    check(lib().vieo_device_synchronize())
+    res = dR.download(VIO_RESULT_DTYPE, (B,))
+    outl = dU.download(np.uint8, (len(obs),))
+    ref = [oracle.pose_optimization_vio(F, o) for F, o in protos]
+    for i in range(B):
+        b, n = frames[i]["base"]["obs_begin"], frames[i]["base"]["n_obs"]
+        o, oo = ref[i % len(protos)]
+        dt, dr = synth_ba.pose_error(o["base"]["nav"], res[i]["base"]["nav"])
+        assert dt < TOL and dr < TOL, (i, dt, dr)
+        assert res[i]["base"]["n_inliers"] == o["base"]["n_inliers"] and res[i]["base"]["status"] == o["base"]["status"]
+        assert np.array_equal(oo[:n], outl[b:b + n])
+        assert res[i]["has_marg"] == o["has_marg"]
+        if o["has_marg"]:
+            Ho = o["H_marg"].reshape(15, 15)
+            assert np.allclose(Ho, res[i]["H_marg"].reshape(15, 15), rtol=1e-4, atol=1e-4 * np.abs(Ho).max())

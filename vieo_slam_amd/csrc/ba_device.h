@@ -125,6 +125,15 @@ __device__ __forceinline__ void block_sum(double* vals, double* s_red, int tid) 
   for (int i = 0; i < N; i++) vals[i] = (s_red[i] + s_red[N + i]) + (s_red[2 * N + i] + s_red[3 * N + i]);
 }
 
+// the same for a workgroup of BS threads (BS = 64: one wavefront, no LDS round trip)
+template <int N, int BS>
+__device__ __forceinline__ void block_sum_bs(double* vals, double* s_red, int tid) {
+  if (BS == 64) {
+#pragma unroll
+    for (int i = 0; i < N; i++) vals[i] = wave_sum_d(vals[i]);
+  } else
+    block_sum<N>(vals, s_red, tid);
+}
 
 // EdgeReproject::linearizeOplus (g2otypes.h:439-498): Jacobian of the (up to 3) residual rows
 // w.r.t. (dp, dphi) of the body pose, J[r*6 + 0..2] = d/dp, J[r*6 + 3..5] = d/dphi.

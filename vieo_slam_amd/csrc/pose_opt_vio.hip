@@ -288,10 +288,9 @@ __device__ bool wave_ldlt_solve(double* A, const double* b, double* x, double* c
     for (int i = j + 1 + lane; i < n; i += 64) col[i] = A[i * n + j];
     if (lane == 0) D[j] = d;
     wave_sync();
-    const int m = n - j - 1;
-    for (int e = lane; e < m * m; e += 64) {
-      const int i = j + 1 + e / m, k = j + 1 + e % m;
-      A[i * n + k] -= (col[i] / d) * col[k];
+    for (int i = j + 1 + (lane >> 3); i < n; i += 8) {  // lower triangle, 8 x 8 lanes
+      const double li = col[i] / d;
+      for (int k = j + 1 + (lane & 7); k <= i; k += 8) A[i * n + k] -= li * col[k];
     }
     for (int i = j + 1 + lane; i < n; i += 64) A[i * n + j] = col[i] / d;  // L(i,j)
     wave_sync();
@@ -315,35 +314,39 @@ __device__ bool wave_ldlt_solve(double* A, const double* b, double* x, double* c
   return true;
 }
 
-static const int kVioMaxEPT = 8;
+static const int kVioMaxObs = 2048;  // 32 edges per lane at 64 threads, 8 at 256 (bit masks per lane)
 
 struct VioShared {
   NSd nsj, nsi, bkj, bki, prior;
   double H[900], L[900], b[32], x[32], col[32], D[32];
-  double red[4 * 28];
+  double red[4 * 28], vis[28];
   double errI[9], errB[6], errP[15], wI[9], wP[15];
   double JI[9 * 24], JP[225], InfoI[81], T[15 * 24];
   double cov[225], C[225], E[225], Cinv[225 * 2];
   int ok;
 };
 
-__global__ void __launch_bounds__(256)
+// BS threads per frame: 256 (four wavefronts share a frame: lowest latency for a few frames) or 64
+// (one wavefront per frame, four frames per CU in flight: highest throughput for large batches)
+template <int BS>
+__global__ void __launch_bounds__(BS)
 k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
                uint8_t* __restrict__ outlier_all, vieo_vio_result* __restrict__ results) {
   __shared__ VioShared S;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T1 = BS > 64 ? 64 : 0, T2 = BS > 128 ? 128 : 0;  // lanes of the second / third serial role
   const vieo_vio_frame& F = frames[f];
   const int N = F.base.n_obs;
   const vieo_pose_obs* obs = obs_all + F.base.obs_begin;
   uint8_t* outl = outlier_all + F.base.obs_begin;
   vieo_vio_result* R = results + f;
-  if ((N < 3 && !F.no_mps) || N > 256 * kVioMaxEPT) {  // Optimizer.h:499-503
-    for (int i = tid; i < N; i += 256) outl[i] = 0;
-    for (int i = tid; i < 225; i += 256) R->H_marg[i] = 0;
+  if ((N < 3 && !F.no_mps) || N > kVioMaxObs) {  // Optimizer.h:499-503
+    for (int i = tid; i < N; i += BS) outl[i] = 0;
+    for (int i = tid; i < 225; i += BS) R->H_marg[i] = 0;
     if (tid == 0) {
       R->base.nav = F.base.nav;
       R->base.n_inliers = 0;
-      R->base.status = N > 256 * kVioMaxEPT ? VIEO_E_CAPACITY : VIEO_POSE_TOO_FEW;
+      R->base.status = N > kVioMaxObs ? VIEO_E_CAPACITY : VIEO_POSE_TOO_FEW;
       R->base.lm_iterations = 0;
       R->base.reserved = 0;
       R->has_marg = 0;
@@ -420,8 +423,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   // generic-edge errors at the current LDS state; returns (robust chi2 sum, rho' of I, B, P)
   auto generic_errors = [&](double* rhoI, double* rhoB, double* rhoP) -> double {
     if (tid == 0 && hasImu) imu_error(F.imu, gw, S.nsi, S.nsj, S.errI);
-    if (tid == 64 && !fixedLast) prior_error(S.prior, S.nsi, S.errP);
-    if (tid == 128)
+    if (tid == T1 && !fixedLast) prior_error(S.prior, S.nsi, S.errP);
+    if (tid == T2)
       for (int k = 0; k < 3; k++) {
         S.errB[k] = (S.nsj.bg[k] + S.nsj.dbg[k]) - (S.nsi.bg[k] + S.nsi.dbg[k]);
         S.errB[3 + k] = (S.nsj.ba[k] + S.nsj.dba[k]) - (S.nsi.ba[k] + S.nsi.dba[k]);
@@ -432,8 +435,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       for (int j = 0; j < 9; j++) t += S.InfoI[tid * 9 + j] * S.errI[j];
       S.wI[tid] = t;
     }
-    if (!fixedLast && tid >= 64 && tid < 79) {
-      const int i = tid - 64;
+    if (!fixedLast && tid >= T1 && tid < T1 + 15) {
+      const int i = tid - T1;
       double t = 0;
       for (int j = 0; j < 15; j++) t += F.H_prior[i * 15 + j] * S.errP[j];
       S.wP[i] = t;
@@ -473,7 +476,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     PoseXf X;
     make_xf(c, e, X);
     double tc[1] = {0};
-    for (int k = 0, i = tid; i < N; k++, i += 256) {
+    for (int k = 0, i = tid; i < N; k++, i += BS) {
       if ((levelmask >> k) & 1) continue;
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
@@ -485,7 +488,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       }
       tc[0] += r0;
     }
-    block_sum<1>(tc, S.red, tid);
+    block_sum_bs<1, BS>(tc, S.red, tid);
     return tc[0];
   };
 
@@ -511,7 +514,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       double acc[28];
 #pragma unroll
       for (int i = 0; i < 28; i++) acc[i] = 0;
-      for (int k = 0, i = tid; i < N; k++, i += 256) {
+      for (int k = 0, i = tid; i < N; k++, i += BS) {
         if ((levelmask >> k) & 1) continue;
         const vieo_pose_obs o = obs[i];
         double err[3], Pc[3];
@@ -527,13 +530,21 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         visual_jacobian(c, X, e.p, o, Pc, J);
         visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
       }
-      block_sum<28>(acc, S.red, tid);
+      block_sum_bs<28, BS>(acc, S.red, tid);
+      __syncthreads();
+      if (tid < 28) {  // publish the sums (select, not acc[tid]: the sums stay in registers)
+        double v = 0;
+#pragma unroll
+        for (int t = 0; t < 28; t++)
+          if (tid == t) v = acc[t];
+        S.vis[tid] = v;
+      }
       double currentChi = chiG + acc[27];
       const double iniChi = currentChi;
       // generic Jacobians
       if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
-      if (tid == 64 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
-      for (int i = tid; i < n * n; i += 256) S.H[i] = 0;
+      if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
+      for (int i = tid; i < n * n; i += BS) S.H[i] = 0;
       if (tid < n) S.b[tid] = 0;
       __syncthreads();
       // visual block: (dp, dphi) -> system rows/cols {0,1,2,6,7,8}
@@ -542,23 +553,23 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         const int lo = a < bq ? a : bq, hi = a < bq ? bq : a;
         const int t = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
         const int ra = a < 3 ? a : a + 3, rb = bq < 3 ? bq : bq + 3;
-        S.H[ra * n + rb] = acc[t];
+        S.H[ra * n + rb] = S.vis[t];
       }
-      if (tid >= 64 && tid < 70) {
-        const int a = tid - 64;
-        S.b[a < 3 ? a : a + 3] = acc[21 + a];
+      if (tid >= T1 && tid < T1 + 6) {
+        const int a = tid - T1;
+        S.b[a < 3 ? a : a + 3] = S.vis[21 + a];
       }
       __syncthreads();
       if (hasImu) {  // T = (rho' Info) J  (9 x 24), then H += J^T T
         const int nc = fixedLast ? 9 : 24;
-        for (int eidx = tid; eidx < 9 * nc; eidx += 256) {
+        for (int eidx = tid; eidx < 9 * nc; eidx += BS) {
           const int a = eidx / nc, cc = eidx % nc;
           double t = 0;
           for (int q = 0; q < 9; q++) t += (rhoI * S.InfoI[a * 9 + q]) * S.JI[q * 24 + cc];
           S.T[a * 24 + cc] = t;
         }
         __syncthreads();
-        for (int eidx = tid; eidx < nc * nc; eidx += 256) {
+        for (int eidx = tid; eidx < nc * nc; eidx += BS) {
           const int c1 = eidx / nc, c2 = eidx % nc;
           double t = 0;
           for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c1] * S.T[a * 24 + c2];
@@ -573,14 +584,14 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         __syncthreads();
       }
       if (!fixedLast) {  // prior: T = (rho' H_prior) J (15 x 15), H[15.., 15..] += J^T T
-        for (int eidx = tid; eidx < 225; eidx += 256) {
+        for (int eidx = tid; eidx < 225; eidx += BS) {
           const int a = eidx / 15, cc = eidx % 15;
           double t = 0;
           for (int q = 0; q < 15; q++) t += (rhoP * F.H_prior[a * 15 + q]) * S.JP[q * 15 + cc];
           S.T[a * 15 + cc] = t;
         }
         __syncthreads();
-        for (int eidx = tid; eidx < 225; eidx += 256) {
+        for (int eidx = tid; eidx < 225; eidx += BS) {
           const int c1 = eidx / 15, c2 = eidx % 15;
           double t = 0;
           for (int a = 0; a < 15; a++) t += S.JP[a * 15 + c1] * S.T[a * 15 + c2];
@@ -618,7 +629,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       do {
         __syncthreads();
         if (tid == 0) S.bkj = S.nsj, S.bki = S.nsi;
-        for (int i = tid; i < n * n; i += 256) S.L[i] = S.H[i] + ((i / n) == (i % n) ? lambda : 0.0);
+        for (int i = tid; i < n * n; i += BS) S.L[i] = S.H[i] + ((i / n) == (i % n) ? lambda : 0.0);
         __syncthreads();
         if (wave == 0) {
           const bool ok = wave_ldlt_solve(S.L, S.b, S.x, S.col, S.D, n, lane);
@@ -673,7 +684,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     make_xf(c, e, X);
     const float chi2close = (float)(1.5 * (double)chi2Mono);
     double nb[1] = {0};
-    for (int k = 0, i = tid; i < N; k++, i += 256) {
+    for (int k = 0, i = tid; i < N; k++, i += BS) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
       const float chi2 = (float)edge_error(c, X, o, err, Pc);
@@ -688,7 +699,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       } else
         levelmask &= ~(1u << k);
     }
-    block_sum<1>(nb, S.red, tid);
+    block_sum_bs<1, BS>(nb, S.red, tid);
     nBad = (int)nb[0];
     if (it == 2) vis_robust = false;
     if (n_edges_total < 10) break;
@@ -701,7 +712,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     PoseXf X;
     make_xf(c, e, X);
     double nb[1] = {0};
-    for (int k = 0, i = tid; i < N; k++, i += 256) {
+    for (int k = 0, i = tid; i < N; k++, i += BS) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
       const double chi2 = edge_error(c, X, o, err, Pc);
@@ -711,10 +722,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       } else
         nb[0] += 1;
     }
-    block_sum<1>(nb, S.red, tid);
+    block_sum_bs<1, BS>(nb, S.red, tid);
     nBad = (int)nb[0];
   }
-  for (int k = 0, i = tid; i < N; k++, i += 256) outl[i] = (outmask >> k) & 1;
+  for (int k = 0, i = tid; i < N; k++, i += BS) outl[i] = (outmask >> k) & 1;
   // ---- marginal prior (Optimizer.h:663-813, FillCovInv :126-206, exact_mode = kExactRobust)
   if (F.compute_marg) {
     double rhoI, rhoB, rhoP;
@@ -727,7 +738,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
-    for (int k = 0, i = tid; i < N; k++, i += 256) {
+    for (int k = 0, i = tid; i < N; k++, i += BS) {
       if ((levelmask >> k) & 1) continue;
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
@@ -742,27 +753,35 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       visual_jacobian(c, X, e.p, o, Pc, J);
       visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
     }
-    block_sum<27>(acc, S.red, tid);
+    block_sum_bs<27, BS>(acc, S.red, tid);
+    __syncthreads();
+    if (tid < 27) {
+      double v = 0;
+#pragma unroll
+      for (int t = 0; t < 27; t++)
+        if (tid == t) v = acc[t];
+      S.vis[tid] = v;
+    }
     if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
-    if (tid == 64 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
-    for (int i = tid; i < 225; i += 256) S.cov[i] = 0, S.C[i] = 0, S.E[i] = 0;
+    if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
+    for (int i = tid; i < 225; i += BS) S.cov[i] = 0, S.C[i] = 0, S.E[i] = 0;
     __syncthreads();
     if (tid < 36) {
       const int a = tid / 6, bq = tid % 6;
       const int lo = a < bq ? a : bq, hi = a < bq ? bq : a;
       const int t = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
-      S.cov[(a < 3 ? a : a + 3) * 15 + (bq < 3 ? bq : bq + 3)] = acc[t];
+      S.cov[(a < 3 ? a : a + 3) * 15 + (bq < 3 ? bq : bq + 3)] = S.vis[t];
     }
     __syncthreads();
     if (hasImu) {
-      for (int eidx = tid; eidx < 9 * 24; eidx += 256) {
+      for (int eidx = tid; eidx < 9 * 24; eidx += BS) {
         const int a = eidx / 24, cc = eidx % 24;
         double t = 0;
         for (int q = 0; q < 9; q++) t += (rhoI * S.InfoI[a * 9 + q]) * S.JI[q * 24 + cc];
         S.T[a * 24 + cc] = t;
       }
       __syncthreads();
-      for (int eidx = tid; eidx < 24 * 24; eidx += 256) {
+      for (int eidx = tid; eidx < 24 * 24; eidx += BS) {
         const int c1 = eidx / 24, c2 = eidx % 24;
         double t = 0;
         for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c1] * S.T[a * 24 + c2];
@@ -780,14 +799,14 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     }
     __syncthreads();
     if (!fixedLast) {
-      for (int eidx = tid; eidx < 225; eidx += 256) {
+      for (int eidx = tid; eidx < 225; eidx += BS) {
         const int a = eidx / 15, cc = eidx % 15;
         double t = 0;
         for (int q = 0; q < 15; q++) t += (rhoP * F.H_prior[a * 15 + q]) * S.JP[q * 15 + cc];
         S.T[a * 15 + cc] = t;
       }
       __syncthreads();
-      for (int eidx = tid; eidx < 225; eidx += 256) {
+      for (int eidx = tid; eidx < 225; eidx += BS) {
         const int c1 = eidx / 15, c2 = eidx % 15;
         double t = 0;
         for (int a = 0; a < 15; a++) t += S.JP[a * 15 + c1] * S.T[a * 15 + c2];
@@ -833,14 +852,14 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         }
       }
       __syncthreads();
-      for (int eidx = tid; eidx < 225; eidx += 256) {  // T = E * C^-1
+      for (int eidx = tid; eidx < 225; eidx += BS) {  // T = E * C^-1
         const int i = eidx / 15, j = eidx % 15;
         double t = 0;
         for (int k = 0; k < 15; k++) t += S.E[i * 15 + k] * S.Cinv[k * 30 + 15 + j];
         S.T[i * 15 + j] = t;
       }
       __syncthreads();
-      for (int eidx = tid; eidx < 225; eidx += 256) {
+      for (int eidx = tid; eidx < 225; eidx += BS) {
         const int i = eidx / 15, j = eidx % 15;
         double t = 0;
         for (int k = 0; k < 15; k++) t += S.T[i * 15 + k] * S.E[j * 15 + k];
@@ -848,9 +867,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       }
       __syncthreads();
     }
-    for (int i = tid; i < 225; i += 256) R->H_marg[i] = S.cov[i];
+    for (int i = tid; i < 225; i += BS) R->H_marg[i] = S.cov[i];
   } else {
-    for (int i = tid; i < 225; i += 256) R->H_marg[i] = 0;
+    for (int i = tid; i < 225; i += BS) R->H_marg[i] = 0;
   }
   if (tid == 0) {
     R->base.nav = F.base.nav;
@@ -876,8 +895,18 @@ int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int 
   if (!d_frames || n_frames <= 0 || !d_obs || !d_outlier || !d_results) return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
-  hipLaunchKernelGGL(k_pose_opt_vio, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames,
-                     d_obs, d_outlier, d_results);
+  // one CU holds four wavefront-sized frames; below that a frame gets four wavefronts.
+  // VIEO_POSE_THREADS=64|256 overrides the choice (tuning / tests).
+  static const int forced = [] {
+    const char* e = getenv("VIEO_POSE_THREADS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 64 || (forced != 256 && n_frames > 256))
+    hipLaunchKernelGGL(k_pose_opt_vio<64>, dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames, d_obs,
+                       d_outlier, d_results);
+  else
+    hipLaunchKernelGGL(k_pose_opt_vio<256>, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames, d_obs,
+                       d_outlier, d_results);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
