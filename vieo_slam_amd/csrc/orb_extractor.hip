@@ -99,22 +99,15 @@ __device__ __forceinline__ int fast_strength(const uint8_t* t, int p) {
   return max(max(A, -B), 0);
 }
 
-// Necessary condition for strength > t, evaluated on the 8 even ring positions: an arc of 9
-// contiguous ring pixels always contains >= 4 consecutive even positions, so 4 consecutive even
-// positions must all be darker (v - x > t) or all brighter (x - v > t).
-__device__ __forceinline__ bool fast_quick(const uint8_t* t, int p, int th) {
-  const int v = t[0];
-  const int e0 = v - t[3 * p], e1 = v - t[2 * p + 2], e2 = v - t[3], e3 = v - t[-2 * p + 2];
-  const int e4 = v - t[-3 * p], e5 = v - t[-2 * p - 2], e6 = v - t[-3], e7 = v - t[2 * p - 2];
-  unsigned dk = (e0 > th) | ((e1 > th) << 1) | ((e2 > th) << 2) | ((e3 > th) << 3) |
-                ((e4 > th) << 4) | ((e5 > th) << 5) | ((e6 > th) << 6) | ((e7 > th) << 7);
-  unsigned br = (e0 < -th) | ((e1 < -th) << 1) | ((e2 < -th) << 2) | ((e3 < -th) << 3) |
-                ((e4 < -th) << 4) | ((e5 < -th) << 5) | ((e6 < -th) << 6) | ((e7 < -th) << 7);
-  dk |= dk << 8;
-  br |= br << 8;
-  const unsigned a = dk & (dk >> 1) & (dk >> 2) & (dk >> 3);
-  const unsigned b = br & (br >> 1) & (br >> 2) & (br >> 3);
-  return ((a | b) & 0xFFu) != 0;
+// Necessary condition for strength > t on the 4 compass points of the ring (positions 0, 4, 8, 12):
+// an arc of 9 contiguous ring pixels contains position 0 or 8 and position 4 or 12, all of one
+// polarity.  Darker: x < v - t, brighter: x > v + t.  Each comparison is one v_cmp into a lane mask.
+__device__ __forceinline__ bool fast_compass(const uint8_t* t, int p, int th) {
+  const int v = t[0], lo = v - th, hi = v + th;
+  const int x0 = t[3 * p], x4 = t[3], x8 = t[-3 * p], x12 = t[-3];
+  const bool dk = ((x0 < lo) | (x8 < lo)) & ((x4 < lo) | (x12 < lo));
+  const bool br = ((x0 > hi) | (x8 > hi)) & ((x4 > hi) | (x12 > hi));
+  return dk | br;
 }
 
 __global__ void __launch_bounds__(64)
@@ -131,14 +124,17 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
   unsigned short* cand = (unsigned short*)(smem + tile_bytes + score_bytes);
   const int x0a = cd.x0 & ~3;
   const int ndw = ((cd.x0 + cd.cw + 3) >> 2) - (x0a >> 2);
-  const float inv_ndw = 1.0f / (float)ndw;
-  for (int idx = lane; idx < cd.ch * ndw; idx += 64) {
-    int r = (int)((float)idx * inv_ndw);
-    int dcol = idx - r * ndw;
-    if (dcol >= ndw) r++, dcol -= ndw;
-    if (dcol < 0) r--, dcol += ndw;
-    const unsigned v = *(const unsigned*)(src + (size_t)(cd.y0 + r) * pitch + x0a + 4 * dcol);
-    *(unsigned*)(tile + r * tpitch + 4 * dcol) = v;
+  {  // ndw <= 17: 16 dword columns x 4 rows per step, the odd 17th column afterwards
+    const int dc = lane & 15, dr = lane >> 4;
+    for (int r = dr; r < cd.ch; r += 4) {
+      const uint8_t* row = src + (size_t)(cd.y0 + r) * pitch + x0a;
+      if (dc < ndw) *(unsigned*)(tile + r * tpitch + 4 * dc) = *(const unsigned*)(row + 4 * dc);
+    }
+    for (int idx = lane; idx < cd.ch * (ndw - 16); idx += 64) {  // columns 16.. (cells wider than 61)
+      const int r = idx / (ndw - 16), dcol = 16 + idx % (ndw - 16);
+      *(unsigned*)(tile + r * tpitch + 4 * dcol) =
+          *(const unsigned*)(src + (size_t)(cd.y0 + r) * pitch + x0a + 4 * dcol);
+    }
   }
   const int vw = cd.cw - 6, vh = cd.ch - 6;
   const int npx = (vw > 0 && vh > 0) ? vw * vh : 0;
@@ -147,51 +143,55 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
     for (int idx = lane; idx < ((vh + 2) * sp + 3) / 4; idx += 64) ((unsigned*)sc)[idx] = 0;
   __syncthreads();
   const int xo = cd.x0 - x0a;
-  const float inv_vw = npx > 0 ? 1.0f / (float)vw : 0.f;
-  // ---- pass A: high-speed test, ordered compaction of the surviving pixel indices
-  const int tq = min(iniTh, minTh);
-  int nc = 0;
-  for (int p0 = 0; p0 < npx; p0 += 64) {
-    const int p = p0 + lane;
-    bool pass = false;
-    if (p < npx) {
-      int y = (int)((float)p * inv_vw);
-      int x = p - y * vw;
-      if (x >= vw) y++, x -= vw;
-      if (x < 0) y--, x += vw;
-      pass = fast_quick(tile + (y + 3) * tpitch + (x + 3 + xo), tpitch, tq);
-    }
-    const unsigned long long m = __ballot(pass);
-    if (pass) cand[nc + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
-    nc += __popcll(m);
-  }
-  __syncthreads();
-  // ---- pass B: exact strength of the candidates only
-  for (int i = lane; i < nc; i += 64) {
-    const int p = cand[i];
-    int y = (int)((float)p * inv_vw);
-    int x = p - y * vw;
-    if (x >= vw) y++, x -= vw;
-    if (x < 0) y--, x += vw;
-    const int r = fast_strength(tile + (y + 3) * tpitch + (x + 3 + xo), tpitch);
-    sc[(y + 1) * sp + x + 1] = (uint8_t)r;
-  }
-  __syncthreads();
-  // ---- pass C: 3x3 non-maximum suppression over the candidates (still in row-major order)
+  // lanes tile the cell interior row-major: vwp (32 or 64) lanes per row, 64 / vwp rows per step
+  const int sh = vw <= 32 ? 5 : 6, rows_per = 64 >> sh;
+  const int lx = lane & ((1 << sh) - 1), ly = lane >> sh;
   unsigned* out = cell_keys + ((size_t)b * P.ncells + c) * P.cell_cap;
   int base = 0;
-  for (int pass = 0; pass < 2 && base == 0; pass++) {
-    const int th = pass == 0 ? iniTh : minTh;
+  // cv::FAST at iniThFAST, and only for a cell without any corner again at minThFAST
+  // (ORBextractor.cc:752-762).  The strengths are threshold-free, so the second round only adds
+  // the pixels between the two thresholds.
+  for (int round = 0; round < 2 && base == 0; round++) {
+    if (round == 1 && minTh >= iniTh) break;
+    const int th = round == 0 ? iniTh : minTh;
+    // ---- pass A: compass test, ordered compaction of the surviving pixels (y << 6 | x)
+    int na = 0;
+    if (npx > 0)
+      for (int y0 = 0; y0 < vh; y0 += rows_per) {
+        const int y = y0 + ly;
+        bool pass = false;
+        if (lx < vw && y < vh) pass = fast_compass(tile + (y + 3) * tpitch + (lx + 3 + xo), tpitch, th);
+        const unsigned long long m = __ballot(pass);
+        if (pass) cand[na + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((y << 6) | lx);
+        na += __popcll(m);
+      }
+    __syncthreads();
+    // ---- pass B: exact strength of the survivors; those above the threshold are compacted in
+    // place (still row-major: a wavefront reads its 64 entries before it writes any)
+    int nc = 0;
+    for (int i0 = 0; i0 < na; i0 += 64) {
+      const int i = i0 + lane;
+      bool pass = false;
+      int p = 0;
+      if (i < na) {
+        p = cand[i];
+        const int y = p >> 6, x = p & 63;
+        const int r = fast_strength(tile + (y + 3) * tpitch + (x + 3 + xo), tpitch);
+        sc[(y + 1) * sp + x + 1] = (uint8_t)r;
+        pass = r > th;
+      }
+      const unsigned long long m = __ballot(pass);
+      if (pass) cand[nc + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+      nc += __popcll(m);
+    }
+    __syncthreads();
+    // ---- pass C: 3x3 non-maximum suppression over the candidates (still in row-major order)
     for (int i0 = 0; i0 < nc; i0 += 64) {
       const int i = i0 + lane;
       bool keep = false;
       unsigned key = 0;
       if (i < nc) {
-        const int p = cand[i];
-        int y = (int)((float)p * inv_vw);
-        int x = p - y * vw;
-        if (x >= vw) y++, x -= vw;
-        if (x < 0) y--, x += vw;
+        const int p = cand[i], y = p >> 6, x = p & 63;
         const uint8_t* s = sc + (y + 1) * sp + x + 1;
         const int r = s[0];
         if (r > th) {
@@ -211,6 +211,7 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
       }
       base += __popcll(m);
     }
+    __syncthreads();
   }
   if (lane == 0) cell_counts[(size_t)b * P.ncells + c] = min(base, P.cell_cap);
 }
@@ -689,6 +690,10 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
     D.tile_end = (int)e->tiles.size();
   }
   P.ncells = (int)e->cells.size();
+  if (max_cw - 6 > 64 || max_ch - 6 > 1023) {  // k_fast: one lane per interior column, y << 6 | x keys
+    set_error("FAST cell wider than 64 pixels (image narrower than one 30-pixel cell?)");
+    return VIEO_E_INVALID;
+  }
   // strict 8-neighbour local maxima cannot be adjacent: at most ceil(vw/2)*ceil(vh/2) per cell
   P.cell_cap = std::max(16, ((max_cw - 6 + 1) / 2) * ((max_ch - 6 + 1) / 2));
   for (int l = 0; l < e->nlevels; l++) {
