@@ -29,33 +29,49 @@ namespace vieo {
 // ------------------------------------------------------------------ pyramid (cv::resize)
 // xtab: {sx0, sx1, a0, a1}; ytab: {sy0, sy1, b0, b1}; INTER_LINEAR 8U fixed point:
 // H = S[sx0]*a0 + S[sx1]*a1 (x2048), D = (((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2.
+// One workgroup = 256 output columns x kResizeRows output rows.  The source rows it needs are staged
+// in LDS with coalesced dword loads (the 4 taps per pixel then cost LDS byte reads, not global ones).
+static const int kResizeRows = 32;
+
 __global__ void __launch_bounds__(256)
 k_resize(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab,
-         const short4* __restrict__ ytab) {
+         const short4* __restrict__ ytab, int lds_pitch) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const LevelDesc& D = P.lv[l];
-  const int b = blockIdx.z;
-  const int dy = blockIdx.y * blockDim.y + threadIdx.y;
-  const int dx4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (dy >= D.h || dx4 >= D.w) return;
+  const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dy0 = blockIdx.y * kResizeRows, dy1 = min(dy0 + kResizeRows, D.h);
+  const int dx0 = blockIdx.x * 256, dx1 = min(dx0 + 256, D.w);
   int spitch;
   const uint8_t* src = plane_ptr(P, I, b, l - 1, &spitch);
-  const short4 yt = ytab[D.ytab_off + dy];
-  const uint8_t* r0 = src + (size_t)yt.x * spitch;
-  const uint8_t* r1 = src + (size_t)yt.y * spitch;
-  unsigned out = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int dx = dx4 + j;
-    if (dx < D.w) {
-      const short4 xt = xtab[D.xtab_off + dx];
-      const int h0 = r0[xt.x] * xt.z + r0[xt.y] * xt.w;
-      const int h1 = r1[xt.x] * xt.z + r1[xt.y] * xt.w;
-      const int v = (((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2;
-      out |= (unsigned)(v & 0xFF) << (8 * j);
-    }
+  const short4* xt = xtab + D.xtab_off;
+  const short4* yt = ytab + D.ytab_off;
+  const int sy_lo = yt[dy0].x, nrows = yt[dy1 - 1].y - sy_lo + 1;
+  const int sx_lo = xt[dx0].x & ~3, ndw = ((xt[dx1 - 1].y + 4) >> 2) - (sx_lo >> 2);
+  for (int r = wave; r < nrows; r += 4) {
+    const unsigned* row = (const unsigned*)(src + (size_t)(sy_lo + r) * spitch + sx_lo);
+    for (int c = lane; c < ndw; c += 64) *(unsigned*)(smem + r * lds_pitch + 4 * c) = row[c];
   }
+  __syncthreads();
+  const int dx4 = dx0 + lane * 4;
+  if (dx4 >= D.w) return;
+  short4 t[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) t[j] = xt[min(dx4 + j, D.w - 1)];
   uint8_t* dst = I.pyr + (size_t)b * I.pyr_img + D.off;
-  *(unsigned*)(dst + (size_t)dy * D.pitch + dx4) = out;
+  for (int dy = dy0 + wave; dy < dy1; dy += 4) {
+    const short4 y = yt[dy];
+    const uint8_t* r0 = smem + (y.x - sy_lo) * lds_pitch - sx_lo;
+    const uint8_t* r1 = smem + (y.y - sy_lo) * lds_pitch - sx_lo;
+    unsigned out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int h0 = r0[t[j].x] * t[j].z + r0[t[j].y] * t[j].w;
+      const int h1 = r1[t[j].x] * t[j].z + r1[t[j].y] * t[j].w;
+      const int v = (((y.z * (h0 >> 4)) >> 16) + ((y.w * (h1 >> 4)) >> 16) + 2) >> 2;
+      if (dx4 + j < D.w) out |= (unsigned)(v & 0xFF) << (8 * j);
+    }
+    *(unsigned*)(dst + (size_t)dy * D.pitch + dx4) = out;
+  }
 }
 
 // ------------------------------------------------------------------ FAST-9/16 per cell
@@ -601,6 +617,7 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
   e->cells.clear();
   e->tiles.clear();
   std::vector<short> xtab, ytab;
+  int resize_rows = 1, resize_dw = 1;
   size_t pyr_off = 0, blur_off = 0;
   int max_cw = 0, max_ch = 0, key_off = 0, sel_off = 0, ncap_max = 0, max_ncell = 0;
   for (int l = 0; l < e->nlevels; l++) {
@@ -681,6 +698,13 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
       D.ytab_off = (int)(ytab.size() / 4);
       resize_axis_table(P.lv[l - 1].h, D.h, false, t);
       ytab.insert(ytab.end(), t.begin(), t.end());
+      // LDS footprint of one k_resize workgroup at this level
+      const short* xt = xtab.data() + 4 * (size_t)D.xtab_off;
+      const short* yt = ytab.data() + 4 * (size_t)D.ytab_off;
+      for (int y0 = 0; y0 < D.h; y0 += kResizeRows)
+        resize_rows = std::max(resize_rows, yt[4 * (std::min(y0 + kResizeRows, D.h) - 1) + 1] - yt[4 * y0] + 1);
+      for (int x0 = 0; x0 < D.w; x0 += 256)
+        resize_dw = std::max(resize_dw, ((xt[4 * (std::min(x0 + 256, D.w) - 1) + 1] + 4) >> 2) - (xt[4 * x0] >> 2));
     }
     // ---- blur tiles
     D.tile_begin = (int)e->tiles.size();
@@ -713,6 +737,8 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
   e->scap_max = std::max(2 * ncap_max, max_ncell);
   e->pyr_img = align_up_sz(pyr_off, 256);
   e->blur_img = align_up_sz(blur_off, 256);
+  e->resize_pitch = 4 * resize_dw + 4;  // bytes; +4 keeps consecutive rows on different banks
+  e->resize_lds = resize_rows * e->resize_pitch;
   // FAST LDS: cell tile (dword-aligned columns) + strength tile
   e->tpitch = align_up(max_cw + 3, 4) + 4;
   e->tile_bytes = align_up(e->tpitch * max_ch, 16);
@@ -797,9 +823,9 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
   STAMP();
   for (int l = 1; l < P.nlevels; l++) {
     const LevelDesc& D = P.lv[l];
-    dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 3) / 4, B);
-    hipLaunchKernelGGL(k_resize, grd, blk, 0, st, P, l, I, e->d_xtab.as<short4>(),
-                       e->d_ytab.as<short4>());
+    dim3 grd((D.w + 255) / 256, (D.h + kResizeRows - 1) / kResizeRows, B);
+    hipLaunchKernelGGL(k_resize, grd, dim3(256), e->resize_lds, st, P, l, I, e->d_xtab.as<short4>(),
+                       e->d_ytab.as<short4>(), e->resize_pitch);
   }
   STAMP();
   hipLaunchKernelGGL(k_fast, dim3(P.ncells, B), dim3(64), e->fast_lds, st, P, I,

@@ -84,6 +84,7 @@ struct vieo_orb {  // global-scope tag declared in include/vieo_hot.h
   std::vector<vieo::CellDesc> cells;
   std::vector<vieo::BlurTile> tiles;
   int tpitch = 0, tile_bytes = 0, score_bytes = 0, fast_lds = 0, qt_lds = 0, ncap_max = 0, scap_max = 0;
+  int resize_pitch = 0, resize_lds = 0;
   size_t pyr_img = 0, blur_img = 0;
   vieo::DevBuf d_pyr, d_blur, d_cells, d_tiles, d_xtab, d_ytab, d_cell_keys, d_cell_counts, d_keys,
       d_kslot, d_kq, d_sel, d_sel_count, d_pattern, d_in, d_kp, d_desc, d_counts, d_tmp_kp,
