@@ -332,7 +332,7 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 
-// Tile = 64 x 32 outputs.  The source tile (38 rows x 72 bytes, column 0 <-> x = ox - 4) is staged
+// Tile = 64 x kBlurTH outputs.  The source tile (kBlurTH + 6 rows x 72 bytes, column 0 <-> x = ox - 4) is staged
 // as dwords; the horizontal pass produces 4 outputs per work item with v_alignbyte + 2x
 // v_dot4_u32_u8 each (exact 16-bit results, stored packed), the vertical pass 4 outputs per work
 // item from 7 x 8-byte LDS reads.  The sum is the same integer as OpenCV's, only the order of the
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256)
 k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles) {
   constexpr int SP = 72, SH = kBlurTH + 6;  // source pitch (bytes), rows
   __shared__ __attribute__((aligned(16))) uint8_t s_src[SH * SP];
-  __shared__ __attribute__((aligned(16))) unsigned short s_h[SH * kBlurTW];
+  __shared__ __attribute__((aligned(16))) unsigned s_h[(SH / 2) * kBlurTW];  // row pairs, see below
   const BlurTile t = tiles[blockIdx.x];
   const int b = blockIdx.y, tid = threadIdx.x;
   const LevelDesc& D = P.lv[t.level];
@@ -366,42 +366,58 @@ k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles) {
   __syncthreads();
   const unsigned K0123 = 18u | (34u << 8) | (48u << 16) | (56u << 24);
   const unsigned K456 = 48u | (34u << 8) | (18u << 16);
-  for (int idx = tid; idx < SH * (kBlurTW / 4); idx += 256) {
-    const int r = idx / (kBlurTW / 4), g = idx - r * (kBlurTW / 4);
-    const unsigned* w = (const unsigned*)(s_src + r * SP) + g;
-    const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
-    // output column c = 4g + j uses source bytes 4g + 1 + j .. 4g + 7 + j
-    const unsigned a0 = __builtin_amdgcn_alignbyte(w1, w0, 1), b0 = __builtin_amdgcn_alignbyte(w2, w1, 1);
-    const unsigned a1 = __builtin_amdgcn_alignbyte(w1, w0, 2), b1 = __builtin_amdgcn_alignbyte(w2, w1, 2);
-    const unsigned a2 = __builtin_amdgcn_alignbyte(w1, w0, 3), b2 = __builtin_amdgcn_alignbyte(w2, w1, 3);
-    const unsigned h0 = __builtin_amdgcn_udot4(b0, K456, __builtin_amdgcn_udot4(a0, K0123, 0u, false), false);
-    const unsigned h1 = __builtin_amdgcn_udot4(b1, K456, __builtin_amdgcn_udot4(a1, K0123, 0u, false), false);
-    const unsigned h2 = __builtin_amdgcn_udot4(b2, K456, __builtin_amdgcn_udot4(a2, K0123, 0u, false), false);
-    const unsigned h3 = __builtin_amdgcn_udot4(w2, K456, __builtin_amdgcn_udot4(w1, K0123, 0u, false), false);
-    uint2 o;
-    o.x = h0 | (h1 << 16);
-    o.y = h2 | (h3 << 16);
-    *(uint2*)(s_h + r * kBlurTW + 4 * g) = o;
+  // horizontal pass: one item = two source rows x four columns; the 16-bit row sums of vertically
+  // adjacent rows share a dword (row 2p low half, row 2p+1 high half) so the vertical pass can use
+  // v_dot2_u32_u16
+  for (int idx = tid; idx < (SH / 2) * (kBlurTW / 4); idx += 256) {
+    const int pr = idx / (kBlurTW / 4), g = idx - pr * (kBlurTW / 4);
+    unsigned h[2][4];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const unsigned* w = (const unsigned*)(s_src + (2 * pr + q) * SP) + g;
+      const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+      // output column c = 4g + j uses source bytes 4g + 1 + j .. 4g + 7 + j
+      const unsigned a0 = __builtin_amdgcn_alignbyte(w1, w0, 1), b0 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+      const unsigned a1 = __builtin_amdgcn_alignbyte(w1, w0, 2), b1 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+      const unsigned a2 = __builtin_amdgcn_alignbyte(w1, w0, 3), b2 = __builtin_amdgcn_alignbyte(w2, w1, 3);
+      h[q][0] = __builtin_amdgcn_udot4(b0, K456, __builtin_amdgcn_udot4(a0, K0123, 0u, false), false);
+      h[q][1] = __builtin_amdgcn_udot4(b1, K456, __builtin_amdgcn_udot4(a1, K0123, 0u, false), false);
+      h[q][2] = __builtin_amdgcn_udot4(b2, K456, __builtin_amdgcn_udot4(a2, K0123, 0u, false), false);
+      h[q][3] = __builtin_amdgcn_udot4(w2, K456, __builtin_amdgcn_udot4(w1, K0123, 0u, false), false);
+    }
+    uint4 o;
+    o.x = h[0][0] | (h[1][0] << 16), o.y = h[0][1] | (h[1][1] << 16);
+    o.z = h[0][2] | (h[1][2] << 16), o.w = h[0][3] | (h[1][3] << 16);
+    *(uint4*)(s_h + pr * kBlurTW + 4 * g) = o;
   }
   __syncthreads();
+  // vertical pass: one item = two output rows x four columns (exactly one item per thread)
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   uint8_t* dst = I.blur + (size_t)b * I.blur_img + D.boff;
-  for (int idx = tid; idx < kBlurTH * (kBlurTW / 4); idx += 256) {
-    const int r = idx / (kBlurTW / 4), c4 = (idx - r * (kBlurTW / 4)) * 4;
-    const int gy = oy + r, gx = ox + c4;
+  for (int idx = tid; idx < (kBlurTH / 2) * (kBlurTW / 4); idx += 256) {
+    const int q = idx / (kBlurTW / 4), c4 = (idx - q * (kBlurTW / 4)) * 4;
+    const int gy = oy + 2 * q, gx = ox + c4;
     if (gy >= D.h || gx >= D.w) continue;
-    unsigned acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-    const int kk[7] = {18, 34, 48, 56, 48, 34, 18};
+    // even row 2q: source rows 2q .. 2q+6; odd row 2q+1: source rows 2q+1 .. 2q+7
+    const unsigned We[4] = {18u | (34u << 16), 48u | (56u << 16), 48u | (34u << 16), 18u};
+    const unsigned Wo[4] = {18u << 16, 34u | (48u << 16), 56u | (48u << 16), 34u | (18u << 16)};
+    unsigned e[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15}, o[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-      const uint2 v = *(const uint2*)(s_h + (r + k) * kBlurTW + c4);
-      acc0 += kk[k] * (v.x & 0xFFFFu);
-      acc1 += kk[k] * (v.x >> 16);
-      acc2 += kk[k] * (v.y & 0xFFFFu);
-      acc3 += kk[k] * (v.y >> 16);
+    for (int k = 0; k < 4; k++) {
+      const uint4 v = *(const uint4*)(s_h + (q + k) * kBlurTW + c4);
+      const unsigned vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        e[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, vv[j]), __builtin_bit_cast(us2, We[k]), e[j], false);
+        o[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, vv[j]), __builtin_bit_cast(us2, Wo[k]), o[j], false);
+      }
     }
-    const unsigned outv = (((acc0 + (1u << 15)) >> 16) & 0xFFu) | ((((acc1 + (1u << 15)) >> 16) & 0xFFu) << 8) |
-                          ((((acc2 + (1u << 15)) >> 16) & 0xFFu) << 16) | ((((acc3 + (1u << 15)) >> 16) & 0xFFu) << 24);
-    *(unsigned*)(dst + (size_t)gy * D.pitch + gx) = outv;
+    const unsigned oe = ((e[0] >> 16) & 0xFFu) | (((e[1] >> 16) & 0xFFu) << 8) | (((e[2] >> 16) & 0xFFu) << 16) |
+                        (((e[3] >> 16) & 0xFFu) << 24);
+    const unsigned oo = ((o[0] >> 16) & 0xFFu) | (((o[1] >> 16) & 0xFFu) << 8) | (((o[2] >> 16) & 0xFFu) << 16) |
+                        (((o[3] >> 16) & 0xFFu) << 24);
+    *(unsigned*)(dst + (size_t)gy * D.pitch + gx) = oe;
+    if (gy + 1 < D.h) *(unsigned*)(dst + (size_t)(gy + 1) * D.pitch + gx) = oo;
   }
 }
 

@@ -9,7 +9,7 @@ namespace vieo {
 
 static const int kPatchSize = 31, kHalfPatch = 15, kEdge = 19;
 static const int kMaxLevels = 16;
-static const int kBlurTW = 64, kBlurTH = 32;
+static const int kBlurTW = 64, kBlurTH = 64;
 
 struct LevelDesc {
   int w, h, pitch, off;      // plane geometry; off = byte offset in the per-image pyramid block
