@@ -479,12 +479,38 @@ k_describe(OrbParams P, ImgSet I, const unsigned* __restrict__ sel,
   const int cx = QT_KEY_X(key) + (kEdge - 3), cy = QT_KEY_Y(key) + (kEdge - 3);
   int pitch;
   const uint8_t* img = plane_ptr(P, I, b, level, &pitch);
+  // The two patches a key point reads -- 31 x 31 of the level image for the orientation, 39 x 39 of
+  // the blurred level for the steered pattern (|rotated offset| <= 19 = EDGE_THRESHOLD) -- are
+  // staged in this wavefront's LDS slice as whole dwords, row by row.
+  constexpr int AP = 40, BR = 19, BP = 44;
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][31 * AP + (2 * BR + 1) * BP];
+  uint8_t* sa = s_patch[threadIdx.x >> 6];
+  uint8_t* sb = sa + 31 * AP;
+  const int xa = (cx - kHalfPatch) & ~3, xb = (cx - BR) & ~3;
+  const uint8_t* bl0 = I.blur + (size_t)b * I.blur_img + D.boff;
+  const int bp = D.pitch;
+  {  // 16 dword columns x 4 rows per step
+    const int c = lane & 15, r0 = lane >> 4;
+    const uint8_t* ga = img + (size_t)(cy - kHalfPatch + r0) * pitch + xa + 4 * c;
+    const uint8_t* gb = bl0 + (size_t)(cy - BR + r0) * bp + xb + 4 * c;
+    if (c < 9)
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (r0 + 4 * k < 31) *(unsigned*)(sa + (r0 + 4 * k) * AP + 4 * c) = *(const unsigned*)(ga + (size_t)(4 * k) * pitch);
+    if (c < 11)
+#pragma unroll
+      for (int k = 0; k < 10; k++)
+        if (r0 + 4 * k < 2 * BR + 1)
+          *(unsigned*)(sb + (r0 + 4 * k) * BP + 4 * c) = *(const unsigned*)(gb + (size_t)(4 * k) * bp);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
   // ---- IC_Angle: two lanes per row of the radius-15 disc
   int m10 = 0, m01 = 0;
   if (lane < 62) {
     const int v = (lane >> 1) - kHalfPatch;
     const int d = P.umax[v < 0 ? -v : v];
-    const uint8_t* row = img + (size_t)(cy + v) * pitch + cx;
+    const uint8_t* row = sa + (v + kHalfPatch) * AP + (cx - xa);
     const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
     int sI = 0;
     for (int u = u0; u <= u1; u++) {
@@ -501,16 +527,15 @@ k_describe(OrbParams P, ImgSet I, const unsigned* __restrict__ sel,
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   float a, bsin;
   vieo_sincosf_exact(angle * factorPI, &bsin, &a);
-  const uint8_t* bl = I.blur + (size_t)b * I.blur_img + D.boff + (size_t)cy * D.pitch + cx;
-  const int bp = D.pitch;
+  const uint8_t* bl = sb + BR * BP + (cx - xb);
   unsigned long long bits[4];
 #pragma unroll
   for (int gq = 0; gq < 4; gq++) {
     const int pt = pattern[gq * 64 + lane];  // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
     const float x0 = (float)(signed char)(pt & 0xFF), y0 = (float)(signed char)((pt >> 8) & 0xFF);
     const float x1 = (float)(signed char)((pt >> 16) & 0xFF), y1 = (float)(signed char)((pt >> 24) & 0xFF);
-    const int t0 = bl[__float2int_rn(x0 * bsin + y0 * a) * bp + __float2int_rn(x0 * a - y0 * bsin)];
-    const int t1 = bl[__float2int_rn(x1 * bsin + y1 * a) * bp + __float2int_rn(x1 * a - y1 * bsin)];
+    const int t0 = bl[__float2int_rn(x0 * bsin + y0 * a) * BP + __float2int_rn(x0 * a - y0 * bsin)];
+    const int t1 = bl[__float2int_rn(x1 * bsin + y1 * a) * BP + __float2int_rn(x1 * a - y1 * bsin)];
     bits[gq] = __ballot(t0 < t1);
   }
   if (lane < 4) ((unsigned long long*)(desc_out + ((size_t)b * out_cap + g) * 32))[lane] = bits[lane];
