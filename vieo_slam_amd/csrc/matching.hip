@@ -93,12 +93,71 @@ struct StereoArgs {
   float* uright;  // [frame][capL]
   float* depth;   // [frame][capL]
   int* sad;       // [frame][capL]  best SAD of accepted matches, -1 otherwise
+  int* row_start; // [frame][H + 1]  vRowIndices as CSR: right keys whose row band covers row y
+  int* row_list;  // [frame][list_cap]
+  int H, list_cap;
 };
 
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
+}
+
+// vRowIndices (Frame.cc:461-480): for every image row the right keys whose band
+// [floor(y - r), ceil(y + r)], r = 2 * scale(octave), covers it.  One workgroup per frame: LDS
+// histogram, prefix sum, fill.  The order inside a row is irrelevant: the best match is the
+// minimum of (distance, index).
+__global__ void __launch_bounds__(256) k_stereo_rows(StereoArgs A) {
+  extern __shared__ int s_rows[];  // cnt[H + 1], then fill cursor[H]
+  __shared__ int s_part[256];
+  const int f = blockIdx.x, tid = threadIdx.x, H = A.H;
+  int* cnt = s_rows;
+  int* cur = s_rows + H + 1;
+  const int imR = A.r_first + f * A.r_step;
+  const int Nr = min(A.cntR[2 * imR], A.capR);
+  const vieo_keypoint* KR = A.kpR + (size_t)imR * A.capR;
+  for (int y = tid; y <= H; y += 256) cnt[y] = 0;
+  __syncthreads();
+  for (int j = tid; j < Nr; j += 256) {
+    const float y = KR[j].y, r = 2.0f * A.P.lv[KR[j].octave].scale;
+    const int maxr = min((int)ceilf(y + r), H - 1), minr = max((int)floorf(y - r), 0);
+    for (int yi = minr; yi <= maxr; yi++) atomicAdd(&cnt[yi], 1);
+  }
+  __syncthreads();
+  // exclusive prefix sum of cnt[0..H)
+  const int per = (H + 255) / 256, y0 = tid * per, y1 = min(H, y0 + per);
+  int sum = 0;
+  for (int y = y0; y < y1; y++) sum += cnt[y];
+  s_part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int t = 0; t < 256; t++) {
+      const int v = s_part[t];
+      s_part[t] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  int acc = s_part[tid];
+  int* rs = A.row_start + (size_t)f * (H + 1);
+  for (int y = y0; y < y1; y++) {
+    const int v = cnt[y];
+    rs[y] = acc, cur[y] = acc;
+    acc += v;
+  }
+  if (y1 == H && y0 < H) rs[H] = acc;
+  __syncthreads();
+  int* list = A.row_list + (size_t)f * A.list_cap;
+  for (int j = tid; j < Nr; j += 256) {
+    const float y = KR[j].y, r = 2.0f * A.P.lv[KR[j].octave].scale;
+    const int maxr = min((int)ceilf(y + r), H - 1), minr = max((int)floorf(y - r), 0);
+    for (int yi = minr; yi <= maxr; yi++) {
+      const int pos = atomicAdd(&cur[yi], 1);
+      if (pos < A.list_cap) list[pos] = j;
+    }
+  }
 }
 
 // grid (ceil(capL/4), n_frames); one wave per left key.
@@ -124,11 +183,14 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
   const vieo_keypoint* KR = A.kpR + (size_t)imR * A.capR;
   const uint8_t* DR = A.descR + (size_t)imR * A.capR * 32;
   int bestDist = TH_HIGH, bestIdx = INT_MAX;
-  for (int j = lane; j < Nr; j += 64) {
+  if (rowL < 0 || rowL >= A.H) return;
+  const int* rs = A.row_start + (size_t)f * (A.H + 1);
+  const int* list = A.row_list + (size_t)f * A.list_cap;
+  const int c0 = rs[rowL], c1 = min(rs[rowL + 1], A.list_cap);
+  (void)Nr;
+  for (int c = c0 + lane; c < c1; c += 64) {
+    const int j = list[c];
     const vieo_keypoint kR = KR[j];
-    const float r = 2.0f * A.P.lv[kR.octave].scale;
-    const int maxr = (int)ceilf(kR.y + r), minr = (int)floorf(kR.y - r);
-    if (rowL < minr || rowL > maxr) continue;
     if (kR.octave < levelL - 1 || kR.octave > levelL + 1) continue;
     if (!(kR.x >= minU && kR.x <= maxU)) continue;
     const int d = hamming32(a0, a1, DR + (size_t)j * 32);
@@ -255,7 +317,18 @@ __global__ void __launch_bounds__(256) k_stereo_median(StereoArgs A) {
   }
 }
 
-static int launch_stereo(const StereoArgs& A, int n_frames, hipStream_t st) {
+static thread_local DevBuf g_row_start, g_row_list;
+
+static int launch_stereo(StereoArgs A, int n_frames, hipStream_t st) {
+  int rc;
+  float smax = 1.f;
+  for (int l = 0; l < A.P.nlevels; l++) smax = std::max(smax, A.P.lv[l].scale);
+  A.H = A.P.lv[0].h;
+  A.list_cap = A.capR * (2 * (int)ceilf(2.0f * smax) + 3);
+  if ((rc = g_row_start.ensure((size_t)n_frames * (A.H + 1) * 4)) != VIEO_OK) return rc;
+  if ((rc = g_row_list.ensure((size_t)n_frames * A.list_cap * 4)) != VIEO_OK) return rc;
+  A.row_start = g_row_start.as<int>(), A.row_list = g_row_list.as<int>();
+  hipLaunchKernelGGL(k_stereo_rows, dim3(n_frames), dim3(256), (size_t)(2 * A.H + 1) * 4, st, A);
   hipLaunchKernelGGL(k_stereo_rect, dim3((A.capL + 3) / 4, n_frames), dim3(256), 0, st, A);
   hipLaunchKernelGGL(k_stereo_median, dim3(n_frames), dim3(256), 0, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
