@@ -91,6 +91,8 @@ struct SbpArgs {
   float minx, maxx, miny, maxy;
   float nn_ratio;
   int check_ori;
+  const int* cell_start;            // [frame][kGridCols * kGridRows + 1]  Frame::mGrid as CSR
+  const unsigned short* cell_list;  // [frame][key_cap] key indices, ascending inside a cell
   unsigned* cand;      // [frame][q_cap][kCandCap]  idx | dist<<12 | level<<21
   int* cand_n;         // [frame][q_cap]   (-1: overflow)
   int* assign;         // [frame][key_cap]
@@ -103,10 +105,86 @@ __device__ __forceinline__ int hamming32q(const uint4 a0, const uint4 a1, const 
          __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-// grid (ceil(q_cap/4), n_frames): one wave per query
+// Frame::AssignFeaturesToGrid (Frame.cc / FrameBase.cpp:60-93) as a CSR: one workgroup per frame,
+// LDS histogram over the 64 x 48 cells, prefix sum, fill, then every cell's short list is put in
+// ascending key order (= the reference's push_back order).
+static const int kGridCells = kGridCols * kGridRows;
+
+__global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ cell_start,
+                                                  unsigned short* __restrict__ cell_list) {
+  __shared__ int s_cnt[kGridCells + 1];
+  __shared__ int s_cur[kGridCells];
+  __shared__ unsigned short s_list[kMaxKeys];
+  __shared__ int s_part[256];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int img = A.img_first + f * A.img_step;
+  const int N = min(A.counts[2 * img], A.key_cap);
+  const vieo_keypoint* K = A.keys + (size_t)img * A.key_cap;
+  const float winv = (float)kGridCols / (A.maxx - A.minx), hinv = (float)kGridRows / (A.maxy - A.miny);
+  for (int c = tid; c <= kGridCells; c += 256) s_cnt[c] = 0;
+  __syncthreads();
+  for (int j = tid; j < N; j += 256) {
+    const int posX = (int)roundf((K[j].x - A.minx) * winv), posY = (int)roundf((K[j].y - A.miny) * hinv);
+    if (posX >= 0 && posX < kGridCols && posY >= 0 && posY < kGridRows) atomicAdd(&s_cnt[posX * kGridRows + posY], 1);
+  }
+  __syncthreads();
+  const int per = kGridCells / 256, c0 = tid * per;  // 3072 = 256 * 12
+  int sum = 0;
+  for (int c = c0; c < c0 + per; c++) sum += s_cnt[c];
+  s_part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int t = 0; t < 256; t++) {
+      const int v = s_part[t];
+      s_part[t] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  int acc = s_part[tid];
+  int* cs = cell_start + (size_t)f * (kGridCells + 1);
+  for (int c = c0; c < c0 + per; c++) {
+    const int v = s_cnt[c];
+    cs[c] = acc, s_cur[c] = acc;
+    acc += v;
+  }
+  if (tid == 255) cs[kGridCells] = acc;
+  __syncthreads();
+  for (int j = tid; j < N; j += 256) {
+    const int posX = (int)roundf((K[j].x - A.minx) * winv), posY = (int)roundf((K[j].y - A.miny) * hinv);
+    if (posX >= 0 && posX < kGridCols && posY >= 0 && posY < kGridRows)
+      s_list[atomicAdd(&s_cur[posX * kGridRows + posY], 1)] = (unsigned short)j;
+  }
+  __syncthreads();
+  unsigned short* out = cell_list + (size_t)f * A.key_cap;
+  for (int c = c0; c < c0 + per; c++) {
+    const int e = s_cur[c], b = e - s_cnt[c];
+    for (int i = b + 1; i < e; i++) {  // insertion sort, lists are a handful of entries
+      const unsigned short v = s_list[i];
+      int k = i - 1;
+      while (k >= b && s_list[k] > v) s_list[k + 1] = s_list[k], k--;
+      s_list[k + 1] = v;
+    }
+    for (int i = b; i < e; i++) out[i] = s_list[i];
+  }
+}
+
+__device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int* total) {
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  *total = __shfl(x, 63);
+  return x - v;
+}
+
+// grid (ceil(q_cap/4), n_frames): one wave per query.  GetFeaturesInArea (FrameBase.cpp:95-174):
+// the lanes take the cells of the window in (ix, iy) order, so the candidates come out in the
+// reference's order without a sort.
 __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
-  __shared__ unsigned s_key[4][kCandCap];
-  __shared__ unsigned s_val[4][kCandCap];
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + wave;
   if (q >= A.q_cap) return;
@@ -117,7 +195,6 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   }
   const vieo_proj_query& Q = A.queries[(size_t)f * A.q_cap + q];
   const int img = A.img_first + f * A.img_step;
-  const int N = min(A.counts[2 * img], A.key_cap);
   if (!(Q.flags & 1)) {
     if (lane == 0) *out_n = 0;
     return;
@@ -129,7 +206,8 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   const int max_cellx = min(kGridCols - 1, (int)ceilf((x - A.minx + r) * winv));
   const int min_celly = max(0, (int)floorf((y - A.miny - r) * hinv));
   const int max_celly = min(kGridRows - 1, (int)ceilf((y - A.miny + r) * hinv));
-  if (min_cellx >= kGridCols || max_cellx < 0 || min_celly >= kGridRows || max_celly < 0) {
+  if (min_cellx >= kGridCols || max_cellx < 0 || min_celly >= kGridRows || max_celly < 0 ||
+      min_cellx > max_cellx || min_celly > max_celly) {
     if (lane == 0) *out_n = 0;
     return;
   }
@@ -138,51 +216,49 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   const uint4 a0 = ((const uint4*)Q.desc)[0], a1 = ((const uint4*)Q.desc)[1];
   const vieo_keypoint* K = A.keys + (size_t)img * A.key_cap;
   const uint8_t* D = A.desc + (size_t)img * A.key_cap * 32;
+  const int* cs = A.cell_start + (size_t)f * (kGridCells + 1);
+  const unsigned short* cl = A.cell_list + (size_t)f * A.key_cap;
+  unsigned* dst = A.cand + ((size_t)f * A.q_cap + q) * kCandCap;
+  const int ny = max_celly - min_celly + 1, ncell = (max_cellx - min_cellx + 1) * ny;
   int n = 0;
-  for (int j0 = 0; j0 < N; j0 += 64) {
-    const int j = j0 + lane;
-    bool pass = false;
-    unsigned skey = 0, sval = 0;
-    if (j < N) {
-      const vieo_keypoint k = K[j];
-      const int posX = (int)roundf((k.x - A.minx) * winv), posY = (int)roundf((k.y - A.miny) * hinv);
-      pass = posX >= min_cellx && posX <= max_cellx && posY >= min_celly && posY <= max_celly &&
-             posX >= 0 && posX < kGridCols && posY >= 0 && posY < kGridRows;
-      if (pass && bchecklevel) {
+  for (int c0 = 0; c0 < ncell; c0 += 64) {
+    const int c = c0 + lane;
+    int s = 0, e = 0;
+    if (c < ncell) {
+      const int cx = c / ny, cell = (min_cellx + cx) * kGridRows + min_celly + (c - cx * ny);
+      s = cs[cell], e = cs[cell + 1];
+    }
+    int cnt = 0;
+    for (int t = s; t < e; t++) {
+      const vieo_keypoint& k = K[cl[t]];
+      bool pass = true;
+      if (bchecklevel) {
+        if (k.octave < minlevel) pass = false;
+        if (maxlevel >= 0 && k.octave > maxlevel) pass = false;
+      }
+      if (pass) pass = fabsf(k.x - x) < r && fabsf(k.y - y) < r;
+      cnt += pass;
+    }
+    int total;
+    int w = n + wave_excl_scan_i(cnt, lane, &total);
+    for (int t = s; t < e && cnt > 0; t++) {
+      const int j = cl[t];
+      const vieo_keypoint& k = K[j];
+      bool pass = true;
+      if (bchecklevel) {
         if (k.octave < minlevel) pass = false;
         if (maxlevel >= 0 && k.octave > maxlevel) pass = false;
       }
       if (pass) pass = fabsf(k.x - x) < r && fabsf(k.y - y) < r;
       if (pass) {
         const int d = hamming32q(a0, a1, D + (size_t)j * 32);
-        skey = (unsigned)(posX * kGridRows + posY) * kMaxKeys + (unsigned)j;
-        sval = (unsigned)j | ((unsigned)d << 12) | ((unsigned)(k.octave & 15) << 21);
+        if (w < kCandCap) dst[w] = (unsigned)j | ((unsigned)d << 12) | ((unsigned)(k.octave & 15) << 21);
+        w++;
       }
     }
-    const unsigned long long m = __ballot(pass);
-    if (pass) {
-      const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < kCandCap) s_key[wave][pos] = skey, s_val[wave][pos] = sval;
-    }
-    n += __popcll(m);
+    n += total;
   }
-  if (n > kCandCap) {
-    if (lane == 0) *out_n = -1;
-    return;
-  }
-  // wave-private LDS region: only intra-wave ordering is needed (no block barrier: other waves
-  // of the block may already have returned)
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // rank sort by (cell, index) = the order GetFeaturesInArea returns
-  unsigned* dst = A.cand + ((size_t)f * A.q_cap + q) * kCandCap;
-  for (int e = lane; e < n; e += 64) {
-    const unsigned ke = s_key[wave][e];
-    int rank = 0;
-    for (int o = 0; o < n; o++) rank += s_key[wave][o] < ke;
-    dst[rank] = s_val[wave][e];
-  }
-  if (lane == 0) *out_n = n;
+  if (lane == 0) *out_n = n > kCandCap ? -1 : n;
 }
 
 // one wave per frame
@@ -310,7 +386,7 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
 }
 
 struct SbpScratch {
-  DevBuf cand, cand_n, q, nq, keys, ur, desc, taken, counts, assign, nm, pts, cam;
+  DevBuf cand, cand_n, q, nq, keys, ur, desc, taken, counts, assign, nm, pts, cam, cell_start, cell_list;
 };
 static thread_local SbpScratch g_sbp;
 
@@ -325,6 +401,11 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
     set_error("search_by_projection: more than %d keypoints per frame", kMaxKeys);
     return VIEO_E_CAPACITY;
   }
+  if ((rc = S.cell_start.ensure((size_t)n_frames * (kGridCells + 1) * 4)) != VIEO_OK) return rc;
+  if ((rc = S.cell_list.ensure((size_t)n_frames * A.key_cap * 2)) != VIEO_OK) return rc;
+  A.cell_start = S.cell_start.as<int>(), A.cell_list = S.cell_list.as<unsigned short>();
+  hipLaunchKernelGGL(k_sbp_grid, dim3(n_frames), dim3(256), 0, st, A, S.cell_start.as<int>(),
+                     S.cell_list.as<unsigned short>());
   hipLaunchKernelGGL(k_sbp_candidates, dim3((A.q_cap + 3) / 4, n_frames), dim3(256), 0, st, A);
   hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), 0, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
