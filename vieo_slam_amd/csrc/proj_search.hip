@@ -4,10 +4,12 @@
 // The reference is sequential over map points because a later query must skip keypoints that an
 // earlier query already claimed (AddMapPoint).  Split accordingly:
 //   k_sbp_project     (a12 only) last frame's map points -> window queries           [parallel]
-//   k_sbp_candidates  one wavefront per query: window + octave test over the frame's keys,
-//                     Hamming distances, candidates put in GetFeaturesInArea order     [parallel]
-//   k_sbp_assign      one wavefront per frame replays the queries in order against the
-//                     "claimed" flags kept in LDS: best / second-best, accept rules,
+//   k_sbp_grid        Frame::mGrid (64 x 48 cells) as a CSR, built per frame            [parallel]
+//   k_sbp_candidates  one wavefront per query: the window's cells in GetFeaturesInArea order,
+//                     octave / window / stereo-coordinate tests, Hamming distance and rotation
+//                     bin per candidate, appended to the frame's candidate pool        [parallel]
+//   k_sbp_assign      one wavefront per frame copies the pool to LDS and replays the queries in
+//                     order against the "claimed" flags: best / second-best, accept rules,
 //                     rotation histogram + ComputeThreeMaxima                          [sequential]
 // Integer/index work: results are bit-exact against oracle/proj_search.cc.
 #include <climits>
@@ -92,9 +94,12 @@ struct SbpArgs {
   float nn_ratio;
   int check_ori;
   const int* cell_start;            // [frame][kGridCols * kGridRows + 1]  Frame::mGrid as CSR
-  const unsigned short* cell_list;  // [frame][key_cap] key indices, ascending inside a cell
-  unsigned* cand;      // [frame][q_cap][kCandCap]  idx | dist<<12 | level<<21
-  int* cand_n;         // [frame][q_cap]   (-1: overflow)
+  const float4* cell_rec;           // [frame][key_cap] keys in cell order: x, y, uright, idx | octave << 16
+  const float* cell_ang;            // [frame][key_cap] their angles
+  unsigned* pool;      // [frame][pool_cap] candidates of all queries: idx | dist<<12 | level<<21 | bin<<25
+  int* cursor;         // [frame] entries used in the pool
+  int2* qrec;          // [frame][q_cap] {offset in the pool, count (-1: overflow) | has-observations << 16}
+  int pool_cap, pool_lds;
   int* assign;         // [frame][key_cap]
   int* nmatches;       // [frame]
 };
@@ -111,7 +116,8 @@ __device__ __forceinline__ int hamming32q(const uint4 a0, const uint4 a1, const 
 static const int kGridCells = kGridCols * kGridRows;
 
 __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ cell_start,
-                                                  unsigned short* __restrict__ cell_list) {
+                                                  float4* __restrict__ cell_rec,
+                                                  float* __restrict__ cell_ang) {
   __shared__ int s_cnt[kGridCells + 1];
   __shared__ int s_cur[kGridCells];
   __shared__ unsigned short s_list[kMaxKeys];
@@ -149,7 +155,7 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
     cs[c] = acc, s_cur[c] = acc;
     acc += v;
   }
-  if (tid == 255) cs[kGridCells] = acc;
+  if (tid == 255) cs[kGridCells] = acc, A.cursor[f] = 0;
   __syncthreads();
   for (int j = tid; j < N; j += 256) {
     const int posX = (int)roundf((K[j].x - A.minx) * winv), posY = (int)roundf((K[j].y - A.miny) * hinv);
@@ -157,7 +163,6 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
       s_list[atomicAdd(&s_cur[posX * kGridRows + posY], 1)] = (unsigned short)j;
   }
   __syncthreads();
-  unsigned short* out = cell_list + (size_t)f * A.key_cap;
   for (int c = c0; c < c0 + per; c++) {
     const int e = s_cur[c], b = e - s_cnt[c];
     for (int i = b + 1; i < e; i++) {  // insertion sort, lists are a handful of entries
@@ -166,7 +171,18 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
       while (k >= b && s_list[k] > v) s_list[k + 1] = s_list[k], k--;
       s_list[k + 1] = v;
     }
-    for (int i = b; i < e; i++) out[i] = s_list[i];
+  }
+  __syncthreads();
+  // the keys in cell order, with everything a window test reads in one 16-byte record
+  const int n_in = s_cur[kGridCells - 1];
+  const float* uright = A.uright + (size_t)f * A.key_cap;
+  float4* rec = cell_rec + (size_t)f * A.key_cap;
+  float* ang = cell_ang + (size_t)f * A.key_cap;
+  for (int i = tid; i < n_in; i += 256) {
+    const int j = s_list[i];
+    const vieo_keypoint k = K[j];
+    rec[i] = make_float4(k.x, k.y, uright[j], __int_as_float(j | (k.octave << 16)));
+    ang[i] = k.angle;
   }
 }
 
@@ -181,88 +197,160 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int* total) {
   return x - v;
 }
 
-// grid (ceil(q_cap/4), n_frames): one wave per query.  GetFeaturesInArea (FrameBase.cpp:95-174):
-// the lanes take the cells of the window in (ix, iy) order, so the candidates come out in the
-// reference's order without a sort.
+// grid (kSbpBlocks, n_frames), 4 wavefronts per workgroup, each walking the frame's queries with a
+// stride; the frame's cell offsets sit in LDS, the next query is fetched while the current one is
+// processed.  GetFeaturesInArea (FrameBase.cpp:95-174): cells of one grid column are consecutive in
+// the CSR, so a window is nx contiguous runs of records, already in the reference's order (ix outer,
+// iy inner, key index inside a cell) -- no sort.
+static const int kSbpBlocks = 8;
+
 __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
+  __shared__ int s_cs[kGridCells + 1];
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + wave;
-  if (q >= A.q_cap) return;
-  int* out_n = A.cand_n + (size_t)f * A.q_cap + q;
-  if (q >= A.nq[f]) {
-    if (lane == 0) *out_n = 0;
-    return;
-  }
-  const vieo_proj_query& Q = A.queries[(size_t)f * A.q_cap + q];
+  const int nq = min(A.nq[f], A.q_cap);
   const int img = A.img_first + f * A.img_step;
-  if (!(Q.flags & 1)) {
-    if (lane == 0) *out_n = 0;
-    return;
+  {
+    const int* cs = A.cell_start + (size_t)f * (kGridCells + 1);
+    for (int i = threadIdx.x; i <= kGridCells; i += 256) s_cs[i] = cs[i];
   }
-  const float x = Q.u, y = Q.v, r = Q.radius;
+  // queries past nq: empty records (the replay never reads them, but keep the buffer defined)
+  for (int q = nq + blockIdx.x * 256 + threadIdx.x; q < A.q_cap; q += kSbpBlocks * 256)
+    A.qrec[(size_t)f * A.q_cap + q] = make_int2(0, 0);
+  __syncthreads();
   const float winv = (float)kGridCols / (A.maxx - A.minx), hinv = (float)kGridRows / (A.maxy - A.miny);
-  // FrameBase.cpp:102-115
-  const int min_cellx = max(0, (int)floorf((x - A.minx - r) * winv));
-  const int max_cellx = min(kGridCols - 1, (int)ceilf((x - A.minx + r) * winv));
-  const int min_celly = max(0, (int)floorf((y - A.miny - r) * hinv));
-  const int max_celly = min(kGridRows - 1, (int)ceilf((y - A.miny + r) * hinv));
-  if (min_cellx >= kGridCols || max_cellx < 0 || min_celly >= kGridRows || max_celly < 0 ||
-      min_cellx > max_cellx || min_celly > max_celly) {
-    if (lane == 0) *out_n = 0;
-    return;
-  }
-  const int minlevel = Q.level_min, maxlevel = Q.level_max;
-  const bool bchecklevel = (minlevel > 0) || (maxlevel >= 0);
-  const uint4 a0 = ((const uint4*)Q.desc)[0], a1 = ((const uint4*)Q.desc)[1];
-  const vieo_keypoint* K = A.keys + (size_t)img * A.key_cap;
   const uint8_t* D = A.desc + (size_t)img * A.key_cap * 32;
-  const int* cs = A.cell_start + (size_t)f * (kGridCells + 1);
-  const unsigned short* cl = A.cell_list + (size_t)f * A.key_cap;
-  unsigned* dst = A.cand + ((size_t)f * A.q_cap + q) * kCandCap;
-  const int ny = max_celly - min_celly + 1, ncell = (max_cellx - min_cellx + 1) * ny;
-  int n = 0;
-  for (int c0 = 0; c0 < ncell; c0 += 64) {
-    const int c = c0 + lane;
-    int s = 0, e = 0;
-    if (c < ncell) {
-      const int cx = c / ny, cell = (min_cellx + cx) * kGridRows + min_celly + (c - cx * ny);
-      s = cs[cell], e = cs[cell + 1];
+  const float4* rec = A.cell_rec + (size_t)f * A.key_cap;
+  const float* ang = A.cell_ang + (size_t)f * A.key_cap;
+  unsigned* pool = A.pool + (size_t)f * A.pool_cap;
+  const float factor = 1.0f / kHistoLen;
+  const int stride = kSbpBlocks * 4;
+  const uint4* QQ = (const uint4*)(A.queries + (size_t)f * A.q_cap);
+  int q = blockIdx.x * 4 + wave;
+  uint4 h0 = {0, 0, 0, 0}, a0 = h0, a1 = h0;
+  if (q < nq) h0 = QQ[4 * (size_t)q], a0 = QQ[4 * (size_t)q + 2], a1 = QQ[4 * (size_t)q + 3];
+  uint4 h1 = {0, 0, 0, 0};
+  if (q < nq) h1 = QQ[4 * (size_t)q + 1];
+  for (; q < nq; q += stride) {
+    // current query in registers; fetch the next one now
+    const float x = __uint_as_float(h0.x), y = __uint_as_float(h0.y), q_ur = __uint_as_float(h0.z);
+    const float r = __uint_as_float(h0.w);
+    const int minlevel = (int)h1.x, maxlevel = (int)h1.y, flags = (int)h1.w;
+    const float q_angle = __uint_as_float(h1.z);
+    const uint4 d0 = a0, d1 = a1;
+    const int qn = q + stride;
+    if (qn < nq) {
+      h0 = QQ[4 * (size_t)qn], h1 = QQ[4 * (size_t)qn + 1];
+      a0 = QQ[4 * (size_t)qn + 2], a1 = QQ[4 * (size_t)qn + 3];
     }
-    int cnt = 0;
-    for (int t = s; t < e; t++) {
-      const vieo_keypoint& k = K[cl[t]];
-      bool pass = true;
+    int2* out = A.qrec + (size_t)f * A.q_cap + q;
+    if (!(flags & 1)) {
+      if (lane == 0) *out = make_int2(0, 0);
+      continue;
+    }
+    // FrameBase.cpp:102-115
+    const int min_cellx = max(0, (int)floorf((x - A.minx - r) * winv));
+    const int max_cellx = min(kGridCols - 1, (int)ceilf((x - A.minx + r) * winv));
+    const int min_celly = max(0, (int)floorf((y - A.miny - r) * hinv));
+    const int max_celly = min(kGridRows - 1, (int)ceilf((y - A.miny + r) * hinv));
+    if (min_cellx >= kGridCols || max_cellx < 0 || min_celly >= kGridRows || max_celly < 0 ||
+        min_cellx > max_cellx || min_celly > max_celly) {
+      if (lane == 0) *out = make_int2(0, 0);
+      continue;
+    }
+    const bool bchecklevel = (minlevel > 0) || (maxlevel >= 0);
+    const int nx = max_cellx - min_cellx + 1;
+    int seg_s = 0, seg_l = 0;
+    if (lane < nx) {
+      const int col = (min_cellx + lane) * kGridRows;
+      seg_s = s_cs[col + min_celly];
+      seg_l = s_cs[col + max_celly + 1] - seg_s;
+    }
+    int n_ent;
+    const int seg_o = wave_excl_scan_i(seg_l, lane, &n_ent);  // first window entry of the run
+    // entry t of the window -> record, tests.  A key inside the window is a candidate unless its
+    // stereo coordinate disagrees with the query's (ORBmatcher.cc:1421-1426 / :278-283) -- the one test of
+    // the inner loop that does not depend on what earlier queries claimed, so it is applied here.
+    auto test = [&](int t, int* slot, int* packed) -> bool {
+      int sl = -1;
+      for (int i = 0; i < nx; i++) {
+        const int o = __shfl(seg_o, i), l = __shfl(seg_l, i), s0 = __shfl(seg_s, i);
+        if (t >= o && t < o + l) sl = s0 + (t - o);
+      }
+      *slot = sl;
+      if (t >= n_ent || sl < 0) return false;
+      const float4 k = rec[sl];
+      const int pk = __float_as_int(k.w), oct = pk >> 16;
+      *packed = pk;
       if (bchecklevel) {
-        if (k.octave < minlevel) pass = false;
-        if (maxlevel >= 0 && k.octave > maxlevel) pass = false;
+        if (oct < minlevel) return false;
+        if (maxlevel >= 0 && oct > maxlevel) return false;
       }
-      if (pass) pass = fabsf(k.x - x) < r && fabsf(k.y - y) < r;
-      cnt += pass;
+      if (!(fabsf(k.x - x) < r && fabsf(k.y - y) < r)) return false;
+      if (k.z > 0 && fabsf(q_ur - k.z) > r) return false;
+      return true;
+    };
+    auto encode = [&](int slot, int packed) -> unsigned {
+      const int j = packed & 0xFFFF, oct = packed >> 16;
+      const int d = hamming32q(d0, d1, D + (size_t)j * 32);
+      float rot = q_angle - ang[slot];  // ORBmatcher.cc:1453-1460, used only with mbCheckOrientation
+      if (rot < 0.0f) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == kHistoLen) bin = 0;
+      return (unsigned)j | ((unsigned)d << 12) | ((unsigned)(oct & 15) << 21) | ((unsigned)(bin & 31) << 25);
+    };
+    const int obs_bit = (flags & 2) ? 1 << 16 : 0;
+    if (n_ent <= 64) {  // the usual case: one evaluation
+      int slot, packed = 0;
+      const bool pass = test(lane, &slot, &packed);
+      const unsigned long long m = __ballot(pass);
+      const int total = __popcll(m);
+      if (total == 0) {
+        if (lane == 0) *out = make_int2(0, 0);
+        continue;
+      }
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&A.cursor[f], total);
+      base = __shfl(base, 0);
+      if (base + total > A.pool_cap) {
+        if (lane == 0) *out = make_int2(0, -1);
+        continue;
+      }
+      if (pass) pool[base + __popcll(m & ((1ull << lane) - 1ull))] = encode(slot, packed);
+      if (lane == 0) *out = make_int2(base, total | obs_bit);
+      continue;
     }
-    int total;
-    int w = n + wave_excl_scan_i(cnt, lane, &total);
-    for (int t = s; t < e && cnt > 0; t++) {
-      const int j = cl[t];
-      const vieo_keypoint& k = K[j];
-      bool pass = true;
-      if (bchecklevel) {
-        if (k.octave < minlevel) pass = false;
-        if (maxlevel >= 0 && k.octave > maxlevel) pass = false;
-      }
-      if (pass) pass = fabsf(k.x - x) < r && fabsf(k.y - y) < r;
-      if (pass) {
-        const int d = hamming32q(a0, a1, D + (size_t)j * 32);
-        if (w < kCandCap) dst[w] = (unsigned)j | ((unsigned)d << 12) | ((unsigned)(k.octave & 15) << 21);
-        w++;
-      }
+    int total = 0;
+    for (int t0 = 0; t0 < n_ent; t0 += 64) {
+      int slot, packed = 0;
+      total += __popcll(__ballot(test(t0 + lane, &slot, &packed)));
     }
-    n += total;
+    if (total == 0 || total > kCandCap) {
+      if (lane == 0) *out = make_int2(0, total == 0 ? 0 : -1);
+      continue;
+    }
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&A.cursor[f], total);
+    base = __shfl(base, 0);
+    if (base + total > A.pool_cap) {
+      if (lane == 0) *out = make_int2(0, -1);
+      continue;
+    }
+    int w = base;
+    for (int t0 = 0; t0 < n_ent; t0 += 64) {
+      int slot, packed = 0;
+      const bool pass = test(t0 + lane, &slot, &packed);
+      const unsigned long long m = __ballot(pass);
+      if (pass) pool[w + __popcll(m & ((1ull << lane) - 1ull))] = encode(slot, packed);
+      w += __popcll(m);
+    }
+    if (lane == 0) *out = make_int2(base, total | obs_bit);
   }
-  if (lane == 0) *out_n = n > kCandCap ? -1 : n;
 }
 
-// one wave per frame
+// one wave per frame: the frame's candidate pool is copied to LDS once, after that the replay of
+// the queries touches no global memory except the accepted assignments
 __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
+  extern __shared__ unsigned s_pool[];
   __shared__ uint8_t s_state[kMaxKeys];  // bit0: holds a map point, bit1: it has Observations()>0
   __shared__ unsigned short s_log_idx[kMaxKeys];
   __shared__ uint8_t s_log_bin[kMaxKeys];
@@ -273,8 +361,10 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
   const int nq = min(A.nq[f], A.q_cap);
   int* assign = A.assign + (size_t)f * A.key_cap;
   const uint8_t* taken = A.taken ? A.taken + (size_t)f * A.key_cap : nullptr;
-  const float* uright = A.uright + (size_t)f * A.key_cap;
-  const vieo_keypoint* K = A.keys + (size_t)img * A.key_cap;
+  const unsigned* pool = A.pool + (size_t)f * A.pool_cap;
+  const int2* qrec = A.qrec + (size_t)f * A.q_cap;
+  const int n_lds = min(min(A.cursor[f], A.pool_cap), A.pool_lds);
+  for (int i = lane; i < n_lds; i += 64) s_pool[i] = pool[i];
   for (int i = lane; i < N; i += 64) {
     assign[i] = VIEO_SBP_UNCHANGED;
     s_state[i] = (taken && taken[i]) ? 3 : 0;
@@ -282,77 +372,76 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
   if (lane < kHistoLen) s_hist[lane] = 0;
   __syncthreads();
   int nmatches = 0, nlog = 0, overflow = 0;
-  const float factor = 1.0f / kHistoLen;
-  for (int q = 0; q < nq; q++) {
-    const int n = A.cand_n[(size_t)f * A.q_cap + q];
-    if (n == 0) continue;
-    if (n < 0) {
-      overflow = 1;
-      continue;
-    }
-    const vieo_proj_query& Q = A.queries[(size_t)f * A.q_cap + q];
-    const unsigned* cand = A.cand + ((size_t)f * A.q_cap + q) * kCandCap;
-    // two smallest (dist, order) among usable candidates; lane owns positions lane, lane+64
-    unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;  // dist<<20 | pos<<12... packed below
+  const bool ori = A.mode == VIEO_SBP_LAST_FRAME && A.check_ori;
+  for (int q0 = 0; q0 < nq; q0 += 64) {
+    const int2 mine = q0 + lane < nq ? qrec[q0 + lane] : make_int2(0, 0);
+    const int qn = min(64, nq - q0);
+    for (int qq = 0; qq < qn; qq++) {
+      const int off = __shfl(mine.x, qq), ny = __shfl(mine.y, qq);
+      if (ny == 0) continue;
+      if (ny < 0) {
+        overflow = 1;
+        continue;
+      }
+      const int n = ny & 0xFFFF, q = q0 + qq;
+      // two smallest (dist, order) among usable candidates; lane owns positions lane, lane+64
+      unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu, c0 = 0, c1 = 0;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int pos = lane + 64 * h;
-      if (pos < n) {
-        const unsigned c = cand[pos];
-        const int idx = c & 0xFFF, d = (c >> 12) & 0x1FF;
-        bool use = !((s_state[idx] & 1) && (s_state[idx] & 2));
-        if (use && uright[idx] > 0) {
-          const float er = fabsf(Q.ur - uright[idx]);
-          if (er > Q.radius) use = false;
-        }
-        if (use) {
-          const unsigned key = ((unsigned)d << 8) | (unsigned)pos;  // (dist, order)
-          if (key < b0) {
-            b1 = b0;
-            b0 = key;
-          } else if (key < b1)
-            b1 = key;
+      for (int h = 0; h < 2; h++) {
+        const int pos = lane + 64 * h;
+        if (pos < n) {
+          const unsigned c = off + pos < n_lds ? s_pool[off + pos] : pool[off + pos];
+          const int idx = c & 0xFFF, d = (c >> 12) & 0x1FF;
+          const int st = s_state[idx];
+          if (!((st & 1) && (st & 2))) {
+            const unsigned key = ((unsigned)d << 8) | (unsigned)pos;  // (dist, order)
+            if (key < b0) {
+              b1 = b0, c1 = c0;
+              b0 = key, c0 = c;
+            } else if (key < b1)
+              b1 = key, c1 = c;
+          }
         }
       }
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned e0 = __shfl_xor(b0, o), e1 = __shfl_xor(b1, o);
-      if (e0 < b0) {
-        b1 = min(b0, e1);
-        b0 = e0;
-      } else
-        b1 = min(b1, e0);
-    }
-    if (b0 == 0xFFFFFFFFu) continue;
-    const int bestDist = b0 >> 8, bestPos = b0 & 0xFF;
-    const unsigned cb = cand[bestPos];
-    const int bestIdx = cb & 0xFFF, bestLevel = (cb >> 21) & 15;
-    if (bestDist > kThHigh) continue;
-    if (A.mode == VIEO_SBP_LOCAL_MAP && b1 != 0xFFFFFFFFu) {
-      const int bestDist2 = b1 >> 8;
-      const int bestLevel2 = (cand[b1 & 0xFF] >> 21) & 15;
-      if (bestLevel == bestLevel2 && (float)bestDist > A.nn_ratio * (float)bestDist2) continue;
-    }
-    // AddMapPoint(pMP, bestIdx)
-    if (lane == 0) {
-      s_state[bestIdx] = 1 | ((Q.flags & 2) ? 2 : 0);
-      assign[bestIdx] = q;
-    }
-    nmatches++;
-    if (A.mode == VIEO_SBP_LAST_FRAME && A.check_ori) {
-      float rot = Q.angle - K[bestIdx].angle;
-      if (rot < 0.0f) rot += 360.0f;
-      int bin = (int)roundf(rot * factor);
-      if (bin == kHistoLen) bin = 0;
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned e0 = __shfl_xor(b0, o), e1 = __shfl_xor(b1, o);
+        const unsigned g0 = __shfl_xor(c0, o), g1 = __shfl_xor(c1, o);
+        if (e0 < b0) {
+          if (b0 < e1)
+            b1 = b0, c1 = c0;
+          else
+            b1 = e1, c1 = g1;
+          b0 = e0, c0 = g0;
+        } else if (e0 < b1)
+          b1 = e0, c1 = g0;
+      }
+      if (b0 == 0xFFFFFFFFu) continue;
+      const int bestDist = b0 >> 8;
+      const int bestIdx = c0 & 0xFFF, bestLevel = (c0 >> 21) & 15;
+      if (bestDist > kThHigh) continue;
+      if (A.mode == VIEO_SBP_LOCAL_MAP && b1 != 0xFFFFFFFFu) {
+        const int bestDist2 = b1 >> 8;
+        const int bestLevel2 = (c1 >> 21) & 15;
+        if (bestLevel == bestLevel2 && (float)bestDist > A.nn_ratio * (float)bestDist2) continue;
+      }
+      // AddMapPoint(pMP, bestIdx)
       if (lane == 0) {
-        s_log_idx[nlog] = (unsigned short)bestIdx;
-        s_log_bin[nlog] = (uint8_t)bin;
-        s_hist[bin]++;
+        s_state[bestIdx] = 1 | ((ny >> 16) ? 2 : 0);
+        assign[bestIdx] = q;
       }
-      nlog++;
+      nmatches++;
+      if (ori) {
+        const int bin = (c0 >> 25) & 31;
+        if (lane == 0) {
+          s_log_idx[nlog] = (unsigned short)bestIdx;
+          s_log_bin[nlog] = (uint8_t)bin;
+          s_hist[bin]++;
+        }
+        nlog++;
+      }
+      __syncthreads();  // single wave: orders the LDS state update before the next query
     }
-    __syncthreads();  // single wave: orders the LDS state update before the next query
   }
   if (A.mode == VIEO_SBP_LAST_FRAME && A.check_ori) {
     __syncthreads();
@@ -386,28 +475,40 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
 }
 
 struct SbpScratch {
-  DevBuf cand, cand_n, q, nq, keys, ur, desc, taken, counts, assign, nm, pts, cam, cell_start, cell_list;
+  DevBuf pool, cursor, qrec, q, nq, keys, ur, desc, taken, counts, assign, nm, pts, cam, cell_start, cell_rec, cell_ang;
 };
 static thread_local SbpScratch g_sbp;
 
 static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
   int rc;
   SbpScratch& S = g_sbp;
-  if ((rc = S.cand.ensure((size_t)n_frames * A.q_cap * kCandCap * 4)) != VIEO_OK) return rc;
-  if ((rc = S.cand_n.ensure((size_t)n_frames * A.q_cap * 4)) != VIEO_OK) return rc;
-  A.cand = S.cand.as<unsigned>();
-  A.cand_n = S.cand_n.as<int>();
+  // candidate pool: 32 per query on average (a single query may hold up to kCandCap)
+  A.pool_cap = std::max(A.q_cap * 32, 2 * kCandCap);
+  static const int pool_lds_env = [] {
+    const char* e = getenv("VIEO_SBP_POOL_LDS");
+    return e ? atoi(e) : 0;
+  }();
+  A.pool_lds = std::min(A.pool_cap, pool_lds_env > 0 ? pool_lds_env : 5120);  // 20 KB + 16 KB static: 4 frames / CU
+  if ((rc = S.pool.ensure((size_t)n_frames * A.pool_cap * 4)) != VIEO_OK) return rc;
+  if ((rc = S.cursor.ensure((size_t)n_frames * 4)) != VIEO_OK) return rc;
+  if ((rc = S.qrec.ensure((size_t)n_frames * A.q_cap * sizeof(int2))) != VIEO_OK) return rc;
+  A.pool = S.pool.as<unsigned>(), A.cursor = S.cursor.as<int>(), A.qrec = S.qrec.as<int2>();
+  if (A.q_cap > kMaxKeys) {
+    set_error("search_by_projection: more than %d queries per frame", kMaxKeys);
+    return VIEO_E_CAPACITY;
+  }
   if (A.key_cap > kMaxKeys) {
     set_error("search_by_projection: more than %d keypoints per frame", kMaxKeys);
     return VIEO_E_CAPACITY;
   }
   if ((rc = S.cell_start.ensure((size_t)n_frames * (kGridCells + 1) * 4)) != VIEO_OK) return rc;
-  if ((rc = S.cell_list.ensure((size_t)n_frames * A.key_cap * 2)) != VIEO_OK) return rc;
-  A.cell_start = S.cell_start.as<int>(), A.cell_list = S.cell_list.as<unsigned short>();
+  if ((rc = S.cell_rec.ensure((size_t)n_frames * A.key_cap * sizeof(float4))) != VIEO_OK) return rc;
+  if ((rc = S.cell_ang.ensure((size_t)n_frames * A.key_cap * 4)) != VIEO_OK) return rc;
+  A.cell_start = S.cell_start.as<int>(), A.cell_rec = S.cell_rec.as<float4>(), A.cell_ang = S.cell_ang.as<float>();
   hipLaunchKernelGGL(k_sbp_grid, dim3(n_frames), dim3(256), 0, st, A, S.cell_start.as<int>(),
-                     S.cell_list.as<unsigned short>());
-  hipLaunchKernelGGL(k_sbp_candidates, dim3((A.q_cap + 3) / 4, n_frames), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), 0, st, A);
+                     S.cell_rec.as<float4>(), S.cell_ang.as<float>());
+  hipLaunchKernelGGL(k_sbp_candidates, dim3(kSbpBlocks, n_frames), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), (size_t)A.pool_lds * 4, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
