@@ -269,14 +269,16 @@ __device__ void prior_linearize(const NSd& pr, const NSd& si, const double* err,
   set3(J, 15, 12, 12, I3, 1.0);
 }
 
+// LDS hand-over between the lanes of one wavefront
 __device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
-// Right-looking LDL^T of the n x n matrix A (LDS, row-major, overwritten) and solve A x = b,
+// Right-looking LDL^T of the n x n matrix A (LDS, row-major, overwritten; n <= 64) and solve A x = b,
 // executed by ONE wavefront (lane = threadIdx & 63).  Returns false on a non-positive pivot.
-__device__ bool wave_ldlt_solve(double* A, const double* b, double* x, double* col, double* D,
+// col = un-normalised column j, lcol = multipliers col / d (one division per row, all rows at once).
+__device__ bool wave_ldlt_solve(double* A, const double* b, double* x, double* col, double* lcol, double* D,
                                 int n, int lane) {
   bool ok = true;
   for (int j = 0; j < n; j++) {
@@ -285,14 +287,17 @@ __device__ bool wave_ldlt_solve(double* A, const double* b, double* x, double* c
       ok = false;
       break;
     }
-    for (int i = j + 1 + lane; i < n; i += 64) col[i] = A[i * n + j];
+    if (lane > j && lane < n) {
+      const double c = A[lane * n + j];
+      col[lane] = c, lcol[lane] = c / d;
+    }
     if (lane == 0) D[j] = d;
     wave_sync();
     for (int i = j + 1 + (lane >> 3); i < n; i += 8) {  // lower triangle, 8 x 8 lanes
-      const double li = col[i] / d;
+      const double li = lcol[i];
       for (int k = j + 1 + (lane & 7); k <= i; k += 8) A[i * n + k] -= li * col[k];
     }
-    for (int i = j + 1 + lane; i < n; i += 64) A[i * n + j] = col[i] / d;  // L(i,j)
+    if (lane > j && lane < n) A[lane * n + j] = lcol[lane];  // L(i,j)
     wave_sync();
   }
   if (!ok) return false;
@@ -301,14 +306,14 @@ __device__ bool wave_ldlt_solve(double* A, const double* b, double* x, double* c
   wave_sync();
   for (int j = 0; j < n; j++) {
     const double yj = x[j];
-    for (int i = j + 1 + lane; i < n; i += 64) x[i] -= A[i * n + j] * yj;
+    if (lane > j && lane < n) x[lane] -= A[lane * n + j] * yj;
     wave_sync();
   }
-  for (int i = lane; i < n; i += 64) x[i] /= D[i];
+  if (lane < n) x[lane] /= D[lane];
   wave_sync();
   for (int j = n - 1; j >= 0; j--) {
     const double xj = x[j];
-    for (int i = lane; i < j; i += 64) x[i] -= A[j * n + i] * xj;
+    if (lane < j) x[lane] -= A[j * n + lane] * xj;
     wave_sync();
   }
   return true;
@@ -318,7 +323,7 @@ static const int kVioMaxObs = 2048;  // 32 edges per lane at 64 threads, 8 at 25
 
 struct VioShared {
   NSd nsj, nsi, bkj, bki, prior;
-  double H[900], L[900], b[32], x[32], col[32], D[32];
+  double H[900], L[900], b[32], x[32], col[32], lcol[32], D[32];
   double red[4 * 28], vis[28];
   double errI[9], errB[6], errP[15], wI[9], wP[15];
   double JI[9 * 24], JP[225], InfoI[81], T[15 * 24];
@@ -632,7 +637,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         for (int i = tid; i < n * n; i += BS) S.L[i] = S.H[i] + ((i / n) == (i % n) ? lambda : 0.0);
         __syncthreads();
         if (wave == 0) {
-          const bool ok = wave_ldlt_solve(S.L, S.b, S.x, S.col, S.D, n, lane);
+          const bool ok = wave_ldlt_solve(S.L, S.b, S.x, S.col, S.lcol, S.D, n, lane);
           if (lane == 0) S.ok = ok ? 1 : 0;
         }
         __syncthreads();
