@@ -319,6 +319,72 @@ __device__ bool wave_ldlt_solve(double* A, const double* b, double* x, double* c
   return true;
 }
 
+// The same factorisation with the matrix in registers: lane i owns row i of (H + lambda I), column
+// values travel by v_readlane (the column index is a compile-time constant after unrolling), so the
+// N pivot steps need no LDS round trip and no barrier.  Same operations in the same order as above:
+// l = c / d, then a_ik -= l_i * c_k.  L is written to Ls (row-major N x N) for the back substitution,
+// whose column reads are all issued up front.
+__device__ __forceinline__ double readlane_d(double v, int srclane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int N>
+__device__ bool wave_ldlt_solve_reg(const double* H, double lambda, const double* b, double* x, double* Ls,
+                                    int lane) {
+  double a[N];
+  const int row = lane < N ? lane : 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) a[k] = H[row * N + k] + (k == row ? lambda : 0.0);
+  double Dd[N];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const double d = readlane_d(a[j], j);
+    Dd[j] = d;
+    if (!(d > 0)) ok = false;
+    const double c = a[j];          // un-normalised column entry of this row
+    const double l = c / d;
+#pragma unroll
+    for (int k = j + 1; k < N; k++) {
+      const double ck = readlane_d(a[j], k);  // A[k][j]
+      if (lane > j) a[k] -= l * ck;
+    }
+    if (lane > j) a[j] = l;
+  }
+  if (!ok) return false;
+  // forward: y = L^-1 b (column oriented)
+  double y = lane < N ? b[lane] : 0.0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const double yj = readlane_d(y, j);
+    if (lane > j && lane < N) y -= a[j] * yj;
+  }
+  double dd = 1.0;
+#pragma unroll
+  for (int j = 0; j < N; j++)
+    if (lane == j) dd = Dd[j];
+  y /= dd;
+  // L -> LDS, then lane i fetches column i (rows below it)
+  if (lane < N)
+#pragma unroll
+    for (int k = 0; k < N; k++) Ls[lane * N + k] = a[k];
+  wave_sync();
+  double ccol[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) ccol[j] = Ls[j * N + row];
+#pragma unroll
+  for (int j = N - 1; j >= 0; j--) {
+    const double xj = readlane_d(y, j);
+    if (lane < j) y -= ccol[j] * xj;
+  }
+  if (lane < N) x[lane] = y;
+  wave_sync();
+  return true;
+}
+
 static const int kVioMaxObs = 2048;  // 32 edges per lane at 64 threads, 8 at 256 (bit masks per lane)
 
 struct VioShared {
@@ -634,10 +700,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       do {
         __syncthreads();
         if (tid == 0) S.bkj = S.nsj, S.bki = S.nsi;
-        for (int i = tid; i < n * n; i += BS) S.L[i] = S.H[i] + ((i / n) == (i % n) ? lambda : 0.0);
         __syncthreads();
         if (wave == 0) {
-          const bool ok = wave_ldlt_solve(S.L, S.b, S.x, S.col, S.lcol, S.D, n, lane);
+          const bool ok = n == 15 ? wave_ldlt_solve_reg<15>(S.H, lambda, S.b, S.x, S.L, lane)
+                                  : wave_ldlt_solve_reg<30>(S.H, lambda, S.b, S.x, S.L, lane);
           if (lane == 0) S.ok = ok ? 1 : 0;
         }
         __syncthreads();
