@@ -142,9 +142,11 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
   const int ndw = ((cd.x0 + cd.cw + 3) >> 2) - (x0a >> 2);
   {  // ndw <= 17: 16 dword columns x 4 rows per step, the odd 17th column afterwards
     const int dc = lane & 15, dr = lane >> 4;
-    for (int r = dr; r < cd.ch; r += 4) {
-      const uint8_t* row = src + (size_t)(cd.y0 + r) * pitch + x0a;
-      if (dc < ndw) *(unsigned*)(tile + r * tpitch + 4 * dc) = *(const unsigned*)(row + 4 * dc);
+    if (dc < ndw) {
+      const uint8_t* g = src + (size_t)(cd.y0 + dr) * pitch + x0a + 4 * dc;
+      uint8_t* t = tile + dr * tpitch + 4 * dc;
+      const int gstep = 4 * pitch, tstep = 4 * tpitch;
+      for (int r = dr; r < cd.ch; r += 4, g += gstep, t += tstep) *(unsigned*)t = *(const unsigned*)g;
     }
     for (int idx = lane; idx < cd.ch * (ndw - 16); idx += 64) {  // columns 16.. (cells wider than 61)
       const int r = idx / (ndw - 16), dcol = 16 + idx % (ndw - 16);
@@ -155,8 +157,8 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
   const int vw = cd.cw - 6, vh = cd.ch - 6;
   const int npx = (vw > 0 && vh > 0) ? vw * vh : 0;
   const int sp = vw + 2;
-  if (npx > 0)
-    for (int idx = lane; idx < ((vh + 2) * sp + 3) / 4; idx += 64) ((unsigned*)sc)[idx] = 0;
+  if (npx > 0)  // score_bytes is a multiple of 16 and covers (vh + 2) * sp
+    for (int idx = lane; idx < ((vh + 2) * sp + 15) / 16; idx += 64) ((uint4*)sc)[idx] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   const int xo = cd.x0 - x0a;
   // lanes tile the cell interior row-major: vwp (32 or 64) lanes per row, 64 / vwp rows per step
