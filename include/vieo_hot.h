@@ -385,6 +385,54 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
                                        float* const* h_points_out, uint8_t* const* h_erase,
                                        vieo_lba_result* h_results);
 
+/* ---- LocalBundleAdjustmentNavStatePRV (a18) -----------------------------------------------------
+ * void Optimizer::LocalBundleAdjustmentNavStatePRV(KeyFrame*, int Nlocal, bool* pbStopFlag, Map*,
+ *   cv::Mat gw, bool bLarge, bool bRecInit, float th_dist_far) (src/Optimizer.cc:21-769), the local BA
+ * of the visual-inertial configurations.  Per local key frame three vertices PR (6) + V (3) + Bias (6)
+ * (g2otypes.h:287-288,553-567); between consecutive key frames an EdgeNavStatePRV (g2otypes.h:703-884,
+ * residual order p, Phi, v) and an EdgeNavStateBias (g2otypes.cpp:14-34); the same EdgeReprojectPR /
+ * PRStereo edges and marginalised points as the vision-only LBA; Chi2LargeSetLevel pre-pass
+ * (optimizer_ba/g2o_graph_operator.h:23-40); user lambda init; divergence check (:660-666).
+ * Key frames: local ones first, oldest to newest (= lLocalKeyFrames order), then the fixed observers;
+ * the key frame before the window (pKFPrevLocal) is a fixed one whose full nav state is used.
+ * Not covered: encoder edges, th_dist_far (the default INFINITY is assumed). */
+typedef struct vieo_lba_imu_edge {
+  int32_t kf_i, kf_j;  /* previous / current key frame of the pre-integration (indices) */
+  double dt_kf;        /* pKF1->ftimestamp_ - pKF0->ftimestamp_, used when imu.dt == 0 */
+  vieo_imu_preint imu; /* GetIMUPreInt() of kf_j; Sigma = mSigmaijPRV, order (p, Phi, v) */
+} vieo_lba_imu_edge;
+
+typedef struct vieo_lba_vio_params {
+  vieo_lba_params base;  /* extrinsics, camera, its0 / its1 = optit[0] / optit[1] (4 and 6; 2 and 2 if bLarge) */
+  double gw[3];
+  double inv_sigma_bg2, inv_sigma_ba2; /* IMUDataBase::mInvSigmabg2 / mInvSigmaba2 */
+  double lambda_init;    /* setUserLambdaInit: 1e0, 1e-2 if bLarge (Optimizer.cc:131-138) */
+  int32_t rec_init;      /* bRecInit: Huber kernels on the inertial edges of free key frames too */
+  int32_t large;         /* bLarge: the divergence check is skipped */
+} vieo_lba_vio_params;
+
+#define VIEO_LBA_DIVERGED 3 /* 2*err < err_end or NaN: returns without write-back (Optimizer.cc:660-666) */
+
+/* h_close[n_mp]: 1 where pMP->GetTrackInfoRef().track_depth_ < thresh_depth_close (chi2 gate x1.5 for
+ * monocular edges, Optimizer.cc:603-611,677-681).  h_navs_out[k] of a free key frame carries p, q, v,
+ * dbg, dba of the optimised vertices (bg, ba unchanged); result.chi2_initial / chi2_final = err / err_end. */
+int vieo_local_bundle_adjustment_vio(const vieo_lba_vio_params* params, const vieo_lba_keyframe* h_kfs,
+                                     int n_kf, const float* h_points, const uint8_t* h_close, int n_mp,
+                                     const vieo_lba_obs* h_obs, int n_obs,
+                                     const vieo_lba_imu_edge* h_imu, int n_imu, volatile const int* stop,
+                                     vieo_navstate* h_navs_out, float* h_points_out, uint8_t* h_erase,
+                                     vieo_lba_result* h_result);
+
+/* several windows in lock step, see vieo_local_bundle_adjustment_batch */
+int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_params* const* params,
+                                           const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                           const float* const* h_points, const uint8_t* const* h_close,
+                                           const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                           const vieo_lba_imu_edge* const* h_imu, const int* n_imu,
+                                           volatile const int* stop, vieo_navstate* const* h_navs_out,
+                                           float* const* h_points_out, uint8_t* const* h_erase,
+                                           vieo_lba_result* h_results);
+
 /* ---- replay glue (device-resident batches) -------------------------------------------------
  * What Tracking.cc does between the calls above, on flattened arrays, so a batch of frames runs
  * extract -> stereo -> search -> pose optimisation with no host round trip (bench.py):

@@ -99,6 +99,47 @@ class Oracle:
                                           pts.ctypes.data, erase.ctypes.data, res.ctypes.data)
         return navs, pts, erase[:len(obs)], res[0]
 
+    def local_ba_vio(self, params, kfs, points, close, obs, imu, stop=None):
+        from vieo_slam_amd.ba_types import LBA_RESULT_DTYPE, NAVSTATE_DTYPE
+        params, kfs, imu = np.ascontiguousarray(params), np.ascontiguousarray(kfs), np.ascontiguousarray(imu)
+        points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+        close = np.ascontiguousarray(close, np.uint8)
+        navs = np.zeros(len(kfs), NAVSTATE_DTYPE)
+        pts = np.zeros_like(points)
+        erase = np.zeros(max(len(obs), 1), np.uint8)
+        res = np.zeros(1, LBA_RESULT_DTYPE)
+        st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        P = ctypes.c_void_p
+        self.L.vo_local_bundle_adjustment_vio.argtypes = [P, P, ctypes.c_int, P, P, ctypes.c_int, P, ctypes.c_int,
+                                                          P, ctypes.c_int, P, P, P, P, P]
+        self.L.vo_local_bundle_adjustment_vio(params.ctypes.data, kfs.ctypes.data, len(kfs), points.ctypes.data,
+                                              close.ctypes.data, len(points), obs.ctypes.data, len(obs),
+                                              imu.ctypes.data, len(imu), None if st is None else st.ctypes.data,
+                                              navs.ctypes.data, pts.ctypes.data, erase.ctypes.data, res.ctypes.data)
+        return navs, pts, erase[:len(obs)], res[0]
+
+    def lba_imu_edge_eval(self, params, edge, nsi, nsj, jac=True):
+        err = np.zeros(15)
+        J = np.zeros((9, 24))
+        P = ctypes.c_void_p
+        self.L.vo_lba_imu_edge_eval.argtypes = [P] * 6
+        a, b = np.zeros(1, nsi.dtype), np.zeros(1, nsj.dtype)
+        a[0], b[0] = nsi, nsj
+        nsi, nsj = a, b
+        params, edge = np.ascontiguousarray(params), np.ascontiguousarray(edge)
+        self.L.vo_lba_imu_edge_eval(params.ctypes.data, edge.ctypes.data, nsi.ctypes.data, nsj.ctypes.data,
+                                    err.ctypes.data, J.ctypes.data if jac else None)
+        return err, J
+
+    def lba_navstate_inc(self, ns, d15):
+        out = np.zeros(1, ns.dtype)  # (np.array(np.void) would alias the caller's record)
+        out[0] = ns
+        d = np.ascontiguousarray(d15, np.float64)
+        P = ctypes.c_void_p
+        self.L.vo_lba_navstate_inc.argtypes = [P, P]
+        self.L.vo_lba_navstate_inc(out.ctypes.data, d.ctypes.data)
+        return out[0]
+
     # ---- pose optimisation
     def pose_optimization(self, frame, obs):
         from vieo_slam_amd.ba_types import POSE_RESULT_DTYPE

@@ -48,3 +48,10 @@ LBA_PARAMS_DTYPE = np.dtype([("Rcb", "<f8", 9), ("tcb", "<f8", 3), ("fx", "<f4")
 LBA_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_erase", "<i4"), ("lm_iterations", "<i4"),
                              ("lm_trials", "<i4"), ("chi2_initial", "<f8"), ("chi2_final", "<f8")],
                             align=True)
+
+LBA_IMU_EDGE_DTYPE = np.dtype([("kf_i", "<i4"), ("kf_j", "<i4"), ("dt_kf", "<f8"), ("imu", IMU_PREINT_DTYPE)],
+                              align=True)
+LBA_VIO_PARAMS_DTYPE = np.dtype([("base", LBA_PARAMS_DTYPE), ("gw", "<f8", 3), ("inv_sigma_bg2", "<f8"),
+                                 ("inv_sigma_ba2", "<f8"), ("lambda_init", "<f8"), ("rec_init", "<i4"),
+                                 ("large", "<i4")], align=True)
+assert LBA_IMU_EDGE_DTYPE.itemsize == 1152 and LBA_VIO_PARAMS_DTYPE.itemsize == 184

@@ -349,3 +349,152 @@ def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.
     params[0]["fx"], params[0]["fy"], params[0]["cx"], params[0]["cy"], params[0]["bf"] = FX, FY, CX, CY, BF
     params[0]["its0"], params[0]["its1"] = 5, 10
     return params, kfs, pts, obs, dict(p=np.array(truth_p), q=np.array(truth_q), X=Xw)
+
+
+# ----------------------------------------------------------------------------------------------
+def imu_forward(rng, pi, Ri, vi, dt_kf, bg, ba, omega_sigma=0.08, acc_sigma=0.3, noise_scale=1.0):
+    """One key-frame interval forward in time: constant body rate and world acceleration, sampled at
+    IMU_FREQ.  State j is defined so that the NOISE-FREE discrete pre-integration has zero residual;
+    the returned measurement carries sensor noise and was integrated with the biases (bg, ba)
+    removed.  returns (pj, Rj, vj, Preintegrator)."""
+    omega = rng.normal(0, omega_sigma, 3)
+    a_w = rng.normal(0, acc_sigma, 3)
+    n_imu = int(round(dt_kf * IMU_FREQ))
+    h = dt_kf / n_imu
+    ts = np.arange(n_imu + 1) * h
+    Rrel = [so3_exp(omega * t) for t in ts]
+    acc_true = [(Ri @ Rrel[k]).T @ (a_w - GRAVITY) for k in range(n_imu + 1)]
+    clean = Preintegrator()
+    for k in range(n_imu):
+        clean.update(omega, (acc_true[k] + acc_true[k + 1]) / 2, h)
+    Rj = Ri @ clean.R
+    vj = vi + GRAVITY * dt_kf + Ri @ clean.v
+    pj = pi + vi * dt_kf + GRAVITY * dt_kf ** 2 / 2 + Ri @ clean.p
+    sg = IMU_SIGMA[0] * np.sqrt(IMU_FREQ) * noise_scale
+    sa = IMU_SIGMA[1] * np.sqrt(IMU_FREQ) * noise_scale
+    gyr = [omega + bg + rng.normal(0, sg, 3) for _ in range(n_imu + 1)]
+    acc = [acc_true[k] + ba + rng.normal(0, sa, 3) for k in range(n_imu + 1)]
+    meas = Preintegrator()
+    for k in range(n_imu):
+        meas.update((gyr[k] + gyr[k + 1]) / 2 - bg, (acc[k] + acc[k + 1]) / 2 - ba, h)
+    return pj, Rj, vj, meas
+
+
+_PVR_TO_PRV = np.r_[0:3, 6:9, 3:6]  # Sigma order (p, v, Phi) -> (p, Phi, v)
+
+
+def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_frac=0.03, stereo_frac=0.7,
+                         noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_v=0.03, pert_x=0.02, dt_kf=0.5,
+                         first_fixed=False, imu_noise=1.0, with_prev=True):
+    """Seeded visual-inertial local-BA window: a chain prev-local -> n_local key frames
+    integrated forward with consistent IMU pre-integrations, n_fixed older covisible key frames,
+    points 2-12 m ahead.  Key-frame order: local (oldest..newest), prev-local (fixed, full nav state),
+    other fixed.  returns (params[1], kfs, points f32, close u8, obs sorted by mp, imu edges, truth)."""
+    from .ba_types import (LBA_IMU_EDGE_DTYPE, LBA_KEYFRAME_DTYPE, LBA_OBS_DTYPE, LBA_VIO_PARAMS_DTYPE)
+    rng = np.random.default_rng(seed)
+    Tcb = np.linalg.inv(EUROC_TBC)
+    Rcb, tcb = Tcb[:3, :3], Tcb[:3, 3]
+    bg, ba = rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)
+    # chain: index 0 = prev-local, 1..n_local = local window
+    R = quat_to_R(quat_from_rotvec(rng.normal(0, 0.5, 3)))
+    p = rng.uniform(-2, 2, 3)
+    v = rng.normal(0, 0.25, 3)
+    chain = [(R, p, v)]
+    meas = []
+    for k in range(n_local):
+        p, R, v, m = imu_forward(rng, chain[-1][1], chain[-1][0], chain[-1][2], dt_kf, bg, ba,
+                                 noise_scale=imu_noise)
+        chain.append((R, p, v))
+        meas.append(m)
+    # older fixed key frames: extrapolate backwards on a smooth path
+    R0, p0, v0 = chain[0]
+    older = []
+    for k in range(1, n_fixed):
+        t = -dt_kf * k
+        older.append((R0 @ so3_exp(rng.normal(0, 0.03, 3) * k), p0 + v0 * t + rng.normal(0, 0.02, 3), np.zeros(3)))
+    n_prev = 1 if with_prev else 0
+    local = chain[1:]
+    fixed = ([chain[0]] if with_prev else []) + older
+    poses = local + fixed
+    n_kf = len(poses)
+    Rm, pm, _ = local[n_local // 2]
+    Rwc_m = Rm @ EUROC_TBC[:3, :3]
+    twc_m = pm + Rm @ EUROC_TBC[:3, 3]
+    z = rng.uniform(2.0, 12.0, n_points)
+    u = rng.uniform(-150, W + 150, n_points)
+    vv_ = rng.uniform(-100, H + 100, n_points)
+    Xc = np.stack([(u - CX) / FX * z, (vv_ - CY) / FY * z, z], 1)
+    Xw = Xc @ Rwc_m.T + twc_m
+    obs_list = []
+    for m in range(n_points):
+        for k, (Rk, pk, _) in enumerate(poses):
+            Xck = Rcb @ (Rk.T @ (Xw[m] - pk)) + tcb
+            if Xck[2] < 0.5:
+                continue
+            uu = FX * Xck[0] / Xck[2] + CX
+            vv = FY * Xck[1] / Xck[2] + CY
+            if not (10 < uu < W - 10 and 10 < vv < H - 10):
+                continue
+            lvl = int(rng.integers(0, 8))
+            sig = 1.2 ** lvl
+            uo = uu + rng.normal(0, noise) * sig
+            vo = vv + rng.normal(0, noise) * sig
+            ur = uu - BF / Xck[2] + rng.normal(0, noise) * sig
+            if rng.random() < outlier_frac:
+                uo += rng.uniform(-40, 40)
+                vo += rng.uniform(-40, 40)
+            mono = rng.random() >= stereo_frac
+            obs_list.append((k, m, uo, vo, -1.0 if mono else ur, 1.0 / (np.float32(1.2) ** lvl) ** 2))
+    obs_arr = np.array(obs_list, dtype=np.float64)
+    keep = np.zeros(n_points, bool)
+    for m in np.unique(obs_arr[:, 1].astype(int)):
+        sel = obs_arr[:, 1] == m
+        if sel.sum() >= 2 and (obs_arr[sel, 0] < n_local).any():
+            keep[m] = True
+    remap = -np.ones(n_points, int)
+    remap[keep] = np.arange(keep.sum())
+    obs_arr = obs_arr[keep[obs_arr[:, 1].astype(int)]]
+    obs = np.zeros(len(obs_arr), LBA_OBS_DTYPE)
+    obs["kf"] = obs_arr[:, 0].astype(np.int32)
+    obs["mp"] = remap[obs_arr[:, 1].astype(int)]
+    obs["u"], obs["v"], obs["ur"], obs["inv_sigma2"] = obs_arr[:, 2], obs_arr[:, 3], obs_arr[:, 4], obs_arr[:, 5]
+    obs = obs[np.argsort(obs["mp"], kind="stable")]
+    Xw = Xw[keep]
+    close = (z[keep] < 8.0).astype(np.uint8)  # track_depth_ < thresh_depth_close
+    kfs = np.zeros(n_kf, LBA_KEYFRAME_DTYPE)
+    tp, tq, tv = [], [], []
+    for k, (Rk, pk, vk) in enumerate(poses):
+        q = _R_to_quat(Rk)
+        tp.append(pk), tq.append(q), tv.append(vk)
+        is_fixed = k >= n_local or (first_fixed and k == 0)
+        kfs[k]["fixed"] = int(is_fixed)
+        _nav(kfs[k]["nav"], pk, q, vk, bg, ba)
+        if not is_fixed:
+            kfs[k]["nav"]["p"] = pk + rng.normal(0, 1, 3) / np.sqrt(3) * pert_t
+            kfs[k]["nav"]["q"] = quat_mul(q, quat_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) *
+                                                              np.deg2rad(pert_r_deg)))
+            kfs[k]["nav"]["v"] = vk + rng.normal(0, pert_v, 3)
+    imu = np.zeros(n_local - (0 if with_prev else 1), LBA_IMU_EDGE_DTYPE)
+    t = 0
+    for k in range(n_local):
+        if k == 0 and not with_prev:
+            continue
+        imu[t]["kf_i"] = (n_local if k == 0 else k - 1)
+        imu[t]["kf_j"] = k
+        imu[t]["dt_kf"] = dt_kf
+        fill_imu(imu[t]["imu"], meas[k])
+        S = meas[k].Sigma[np.ix_(_PVR_TO_PRV, _PVR_TO_PRV)]
+        imu[t]["imu"]["Sigma"] = S.reshape(-1)
+        t += 1
+    pts = (Xw + rng.normal(0, pert_x, Xw.shape)).astype(np.float32)
+    params = np.zeros(1, LBA_VIO_PARAMS_DTYPE)
+    b = params[0]["base"]
+    b["Rcb"], b["tcb"] = Rcb.reshape(-1), tcb
+    b["fx"], b["fy"], b["cx"], b["cy"], b["bf"] = FX, FY, CX, CY, BF
+    b["its0"], b["its1"] = 4, 6
+    params[0]["gw"] = GRAVITY
+    params[0]["inv_sigma_bg2"] = 1.0 / IMU_SIGMA[2] ** 2
+    params[0]["inv_sigma_ba2"] = 1.0 / IMU_SIGMA[3] ** 2
+    params[0]["lambda_init"] = 1.0
+    return params, kfs, pts, close, obs, imu, dict(p=np.array(tp), q=np.array(tq), v=np.array(tv), X=Xw,
+                                                    bg=bg, ba=ba, n_local=n_local)
