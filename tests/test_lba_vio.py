@@ -88,3 +88,53 @@ def test_oracle_vio_lba_edge_cases(oracle):
         11, n_local=4, n_fixed=2, n_points=300, first_fixed=True, with_prev=False)
     navs, pout, erase, res = oracle.local_ba_vio(params, kfs, pts, close, obs, imu)
     assert np.array_equal(navs[0]["p"], kfs[0]["nav"]["p"]) and res["lm_iterations"] > 0
+
+
+def _parity(oracle, win, hres):
+    params, kfs, pts, close, obs, imu = win
+    on, op, oe, ores = oracle.local_ba_vio(params, kfs, pts, close, obs, imu)
+    hn, hp, he, hr = hres
+    assert hr["status"] == ores["status"]
+    if ores["status"] != 0:
+        assert np.array_equal(hp, pts) and not he.any()
+        return
+    for k in range(len(kfs)):
+        dt, dr = synth_ba.pose_error(on[k], hn[k])
+        assert dt < 1e-4 and dr < 1e-4, (k, dt, dr)
+        assert np.linalg.norm(on[k]["v"] - hn[k]["v"]) < 1e-4
+        assert np.linalg.norm(on[k]["dbg"] - hn[k]["dbg"]) < 1e-6
+        assert np.linalg.norm(on[k]["dba"] - hn[k]["dba"]) < 1e-5
+    assert np.abs(op - hp).max() < 5e-2 and np.median(np.abs(op - hp)) < 2e-5
+    assert (oe != he).mean() < 0.002
+    assert abs(hr["chi2_final"] - ores["chi2_final"]) < 1e-5 * ores["chi2_final"] + 1e-2
+    assert abs(hr["chi2_initial"] - ores["chi2_initial"]) < 1e-5 * ores["chi2_initial"]
+    assert hr["lm_trials"] == ores["lm_trials"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", [(20, {}), (21, dict(n_points=800)),
+                                     (22, dict(n_local=5, n_fixed=3, n_points=400, stereo_frac=0.0)),
+                                     (23, dict(n_local=4, n_fixed=2, n_points=300, first_fixed=True, with_prev=False)),
+                                     (24, dict(n_local=13, n_fixed=6, n_points=1200))])
+def test_gpu_vio_lba_parity(oracle, seed, kw):
+    from vieo_slam_amd.optimizer import Optimizer
+    win = synth_ba.make_lba_vio_problem(seed, **kw)[:6]
+    _parity(oracle, win, Optimizer.LocalBundleAdjustmentNavStatePRV(*win))
+
+
+@pytest.mark.gpu
+def test_gpu_vio_lba_batch_and_edge_cases(oracle):
+    from vieo_slam_amd.optimizer import Optimizer
+    wins = [synth_ba.make_lba_vio_problem(30 + i, n_local=4 + 3 * i, n_fixed=3, n_points=300 + 200 * i)[:6]
+            for i in range(4)]
+    frozen = wins[3][1].copy()
+    frozen["fixed"] = 1
+    wins[3] = (wins[3][0], frozen) + wins[3][2:]
+    rec = wins[2][0].copy()
+    rec[0]["rec_init"] = 1  # bRecInit: robust kernels on every inertial edge
+    wins[2] = (rec,) + wins[2][1:]
+    outs = Optimizer.LocalBundleAdjustmentNavStatePRVBatch(wins)
+    for win, h in zip(wins, outs):
+        _parity(oracle, win, h)
+    hn, hp, he, hr = Optimizer.LocalBundleAdjustmentNavStatePRV(*wins[0], stop=np.array([1], np.int32))
+    assert hr["status"] == 1 and hr["lm_iterations"] == 0 and np.array_equal(hp, wins[0][2])

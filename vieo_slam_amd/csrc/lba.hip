@@ -27,14 +27,24 @@
 // exactly as g2o's does, from one 56-byte record per window and round.
 #include <vector>
 
-#include "ba_device.h"
+#include "imu_device.h"
 
 namespace vieo {
 
 struct LbaKf {
   double p[3], qw, qx, qy, qz;
-  int col;    // offset in the reduced pose system, -1 = fixed / inactive
+  int col;    // offset of the key frame's block in the reduced pose system, -1 = fixed / inactive
   int fixed;
+  double v[3], dbg[3], dba[3], bg[3], ba[3];  // visual-inertial windows (a18) only
+};
+
+// one key-frame pair of a visual-inertial window: EdgeNavStatePRV + EdgeNavStateBias
+struct LbaImu {
+  int i, j;          // key frames (kf_i = previous)
+  int has_imu, robust;
+  double InfoI[81];  // Sigma_PRV^-1, x 1e-2 when kf_i is fixed (Optimizer.cc:247-259)
+  double infoBg, infoBa;
+  vieo_imu_preint M;
 };
 
 // control word of a window for one round of the lock-step driver
@@ -46,6 +56,7 @@ enum {
   LBA_CLASS0 = 16,  // chi2 / depth gates -> level 1 (between the two optimisations)
   LBA_CLASS1 = 32,  // final erase flags
   LBA_ROBUST = 64,  // Huber kernels on (first optimisation)
+  LBA_PRELEVEL = 128,  // GraphOperator::Chi2LargeSetLevel before the first optimisation (a18)
 };
 struct WinCtl {
   int flags, pad;
@@ -59,7 +70,18 @@ struct WinOut {
 struct LbaDev {
   const vieo_lba_obs* obs;
   int n_obs, n_mp, n_kf, nf_cap;  // nf_cap: non-fixed key frames = rows of `tab`
-  int np, n_free;                 // written by k_lba_begin
+  int np, n_free, npv;            // written by k_lba_begin: np = pd * n_free, npv = 6 * n_free
+  int pd;                         // reduced-system dims per free key frame: 6 (PR) or 15 (PR + V + Bias)
+  int n_imu;
+  const LbaImu* imu;              // [n_imu]
+  const int *kf_in, *kf_out;      // [n_kf] inertial edge ending / starting at the key frame, -1 = none
+  double* Ae;                     // [n_imu][930] generic Hessian 30x30 + gradient 30, local order
+                                  //   [kf_i: PR V Bias | kf_j: PR V Bias]
+  double *gchi0, *gchi;           // [n_imu] robust chi2 of the inertial edges (at linearisation / after a trial)
+  double* bfull;                  // [np] gradient of the pose block (visual + inertial)
+  const unsigned char* close;     // [n_mp] bClose flags or null
+  double thMono, thMonoClose, thStereo;  // chi2 gates of the classification
+  double gw[3];
   int ldB, ldS;                   // leading dimensions of BB (3 x points, padded) and of a partial
   int* kf_list;                   // [n_free] free + active key frames in column order
   const int *kf_edge_first, *kf_edge_idx;  // edges grouped by key frame
@@ -176,11 +198,31 @@ k_lba_classify(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) 
   kf_xf(D.cam, D.kf[o.kf], X);
   const double* Xw = D.X + 3 * (size_t)o.mp;
   const double z = X.Rcw[6] * Xw[0] + X.Rcw[7] * Xw[1] + X.Rcw[8] * Xw[2] + X.tcw[2];
-  const bool bad = chi2 > (o.ur >= 0 ? 7.815 : 5.991) || !(z > 0.);
+  const double th = o.ur >= 0 ? D.thStereo : ((D.close && D.close[o.mp]) ? D.thMonoClose : D.thMono);
+  const bool bad = chi2 > th || !(z > 0.);
   if (fl & LBA_CLASS0) {
     if (bad) D.level[i] = 1;
   } else
     D.erase[i] = bad ? 1 : 0;
+}
+
+// GraphOperator::Chi2LargeSetLevel(edges, dim, 100.f, false) (g2o_graph_operator.h:23-40): every edge's
+// error is computed and stored; chi2 > 100 * chi2_95(dim) puts the edge on level 1
+__global__ void __launch_bounds__(256)
+k_lba_prelevel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_PRELEVEL)) return;
+  const LbaDev& D = devs[w];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= D.n_obs) return;
+  const vieo_lba_obs o = D.obs[i];
+  PoseXf X;
+  kf_xf(D.cam, D.kf[o.kf], X);
+  double err[3], Pc[3];
+  const double chi2 = lba_edge_error(D.cam, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
+  D.err[3 * (size_t)i] = err[0], D.err[3 * (size_t)i + 1] = err[1], D.err[3 * (size_t)i + 2] = err[2];
+  const float th = 100.f * (o.ur >= 0 ? 7.815f : 5.991f);
+  if (chi2 > (double)th) D.level[i] = 1;
 }
 
 // BB = 0, tab = -1 for the windows that start an optimize()
@@ -214,15 +256,18 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
     }
   __syncthreads();
   if (tid == 0) {
+    // vision-only window: free key frames with an active edge; visual-inertial window: the inertial
+    // edges keep every free key frame active
     int np = 0, nf = 0;
+    const int pd = D.pd;
     for (int k = 0; k < n_kf; k++) {
-      if (!D.kf[k].fixed && s_act[k]) {
-        D.kf[k].col = np, np += 6;
+      if (!D.kf[k].fixed && (s_act[k] || pd == 15)) {
+        D.kf[k].col = np, np += pd;
         D.kf_list[nf++] = k;
       } else
         D.kf[k].col = -1;
     }
-    D.np = np, D.n_free = nf;
+    D.np = np, D.n_free = nf, D.npv = 6 * nf;
     out[w].np = np;
   }
   __syncthreads();
@@ -230,7 +275,7 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
     if (D.level[i] == 0) {
       const vieo_lba_obs o = D.obs[i];
       const int c = D.kf[o.kf].col;
-      if (c >= 0) D.tab[(size_t)(c / 6) * n_mp + o.mp] = i;
+      if (c >= 0) D.tab[(size_t)(c / D.pd) * n_mp + o.mp] = i;
     }
 }
 
@@ -278,7 +323,11 @@ k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
     for (int i = threadIdx.x; i < (D.n_mp + 255) / 256; i += 256) v[2] += D.part_m[i];
   }
   block_sum<3>(v, s_red, threadIdx.x);
-  if (threadIdx.x == 0) out[w].chi0 = v[0], out[w].chi2 = v[1], out[w].scale_l = v[2];
+  if (threadIdx.x == 0) {
+    double g0 = 0, g1 = 0;  // inertial edges, fixed order
+    for (int e = 0; e < D.n_imu; e++) g0 += D.gchi0[e], g1 += D.gchi[e];
+    out[w].chi0 = v[0] + g0, out[w].chi2 = v[1] + ((fl & LBA_TRIAL) ? g1 : 0.0), out[w].scale_l = v[2];
+  }
 }
 
 // ---- buildSystem (block_solver.hpp:451-520 with EdgeReprojectPR[Stereo]::linearizeOplus).
@@ -370,7 +419,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   for (int t = 0; t < 27; t++) acc[t] = 0;
   PoseXf X;
   kf_xf(D.cam, k, X);
-  double* Brow = D.BB + (size_t)k.col * D.ldB;
+  double* Brow = D.BB + (size_t)(6 * a) * D.ldB;
   for (int j = threadIdx.x; j < cnt; j += 256) {
     const int i = D.kf_edge_idx[first + j];
     if (D.level[i]) continue;
@@ -421,7 +470,7 @@ k_lba_lambda(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   if (!(ctl[w].flags & LBA_BEGIN)) return;
   const LbaDev& D = devs[w];
   double mx = 0;
-  for (int j = threadIdx.x; j < D.np; j += 256) mx = fmax(mx, fabs(D.Hpp[36 * (size_t)(j / 6) + 7 * (j % 6)]));
+  for (int j = threadIdx.x; j < D.npv; j += 256) mx = fmax(mx, fabs(D.Hpp[36 * (size_t)(j / 6) + 7 * (j % 6)]));
   for (int b = threadIdx.x; b < (D.n_mp + 63) / 64; b += 256) mx = fmax(mx, D.pmax[b]);
   s_m[threadIdx.x] = mx;
   __syncthreads();
@@ -446,7 +495,7 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
-  const int np = D.np;
+  const int np = D.npv;  // the landmarks touch the PR blocks only
   if (np == 0) return;
   const int RB = (np + 63) >> 6, CB = (np + 64) >> 6;  // CB covers the extra column bl
   int bt = blockIdx.x / ksplit;
@@ -524,38 +573,171 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
       S[(size_t)(bi * 64 + wv * 16 + (lane >> 4) + 4 * r) * D.ldS + bj * 64 + q * 16 + (lane & 15)] = acc[q][r];
 }
 
-// Hs = Hpp + lambda I - S (both triangles from the upper block-tiles), bs = bp - S[:, np]
+// Reduced pose system.  PR x PR entries: Hpp + lambda I - S (both triangles from the upper block-tiles of
+// the Schur partials); visual-inertial windows add the inertial edges' 30x30 blocks, gathered per entry
+// (a key frame has at most one inertial edge in and one out).  bs = b - S[:, npv], bfull = b.
 __global__ void __launch_bounds__(256)
 k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out,
                int ksplit) {
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
-  const int np = D.np, e = blockIdx.x * 256 + threadIdx.x;
+  const int np = D.np, npv = D.npv, pd = D.pd, e = blockIdx.x * 256 + threadIdx.x;
   if (e >= np * np) return;
   const double lambda = win_lambda(ctl[w], out[w]);
   const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
   const int ns = (nchunks + cps - 1) / cps;
   const int r = e / np, c = e % np;
-  const int rr = min(r, c), cc = max(r, c);
-  double s = 0;
-  for (int k = 0; k < ns; k++) s += D.Sp[(size_t)k * D.sp_stride + (size_t)rr * D.ldS + cc];
-  double v = -s;
-  if (r / 6 == c / 6) v += D.Hpp[36 * (size_t)(r / 6) + (r % 6) * 6 + c % 6];
+  const int a = r / pd, ra = r - a * pd, b = c / pd, cb = c - b * pd;
+  double v = 0;
+  if (ra < 6 && cb < 6) {
+    const int vr = 6 * a + ra, vc = 6 * b + cb, rr = min(vr, vc), cc = max(vr, vc);
+    double s = 0;
+    for (int k = 0; k < ns; k++) s += D.Sp[(size_t)k * D.sp_stride + (size_t)rr * D.ldS + cc];
+    v = -s;
+    if (a == b) v += D.Hpp[36 * (size_t)a + ra * 6 + cb];
+  }
+  int ein = -1, eout = -1;
+  if (pd == 15) {
+    const int ka = D.kf_list[a], kb = D.kf_list[b];
+    ein = D.kf_in[ka], eout = D.kf_out[ka];
+    if (a == b) {
+      if (ein >= 0) v += D.Ae[930 * (size_t)ein + (15 + ra) * 30 + 15 + cb];
+      if (eout >= 0) v += D.Ae[930 * (size_t)eout + ra * 30 + cb];
+    } else {
+      if (eout >= 0 && D.imu[eout].j == kb) v += D.Ae[930 * (size_t)eout + ra * 30 + 15 + cb];
+      if (ein >= 0 && D.imu[ein].i == kb) v += D.Ae[930 * (size_t)ein + (15 + ra) * 30 + cb];
+    }
+  }
   if (r == c) v += lambda;
   D.Hs[e] = v;
   if (c == 0) {
-    double t = 0;
-    for (int k = 0; k < ns; k++) t += D.Sp[(size_t)k * D.sp_stride + (size_t)r * D.ldS + np];
-    D.bs[r] = D.bp[r] - t;
+    double g = 0, t = 0;
+    if (ra < 6) {
+      g = D.bp[6 * a + ra];
+      for (int k = 0; k < ns; k++) t += D.Sp[(size_t)k * D.sp_stride + (size_t)(6 * a + ra) * D.ldS + npv];
+    }
+    if (ein >= 0) g += D.Ae[930 * (size_t)ein + 900 + 15 + ra];
+    if (eout >= 0) g += D.Ae[930 * (size_t)eout + 900 + ra];
+    D.bfull[r] = g;
+    D.bs[r] = g - t;
+  }
+}
+
+// ---- inertial edges of a visual-inertial window: one wavefront per key-frame pair.
+// mode 0: linearise at the current state (30x30 block J^T (rho' Omega) J and gradient, both edges of the
+// pair) and robust chi2 -> gchi0; mode 1: robust chi2 after a trial -> gchi.
+__global__ void __launch_bounds__(64)
+k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int mode) {
+  __shared__ double sJ[9 * 30], sT[9 * 30], sErr[9 + 6], sWe[9], sRho[2];
+  const int w = blockIdx.y, fl = ctl[w].flags;
+  if (!(fl & (mode ? LBA_TRIAL : LBA_BUILD))) return;
+  const LbaDev& D = devs[w];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= D.n_imu) return;
+  const LbaImu& E = D.imu[e];
+  const double dI = (double)(float)sqrt(16.919), dB = (double)(float)sqrt(12.592);  // Optimizer.cc:219-222
+  if (lane == 0) {
+    NSd si, sj;
+    const LbaKf &ki = D.kf[E.i], &kj = D.kf[E.j];
+    for (int k = 0; k < 3; k++) {
+      si.p[k] = ki.p[k], si.v[k] = ki.v[k], si.bg[k] = ki.bg[k], si.ba[k] = ki.ba[k];
+      si.dbg[k] = ki.dbg[k], si.dba[k] = ki.dba[k];
+      sj.p[k] = kj.p[k], sj.v[k] = kj.v[k], sj.bg[k] = kj.bg[k], sj.ba[k] = kj.ba[k];
+      sj.dbg[k] = kj.dbg[k], sj.dba[k] = kj.dba[k];
+    }
+    si.qw = ki.qw, si.qx = ki.qx, si.qy = ki.qy, si.qz = ki.qz;
+    sj.qw = kj.qw, sj.qx = kj.qx, sj.qy = kj.qy, sj.qz = kj.qz;
+    double chi = 0, rI = 1.0, rB = 1.0;
+    if (E.has_imu) {
+      imu_error(E.M, D.gw, si, sj, sErr, 3);
+      double c2 = 0;
+      for (int a = 0; a < 9; a++) {
+        double t = 0;
+        for (int b = 0; b < 9; b++) t += E.InfoI[a * 9 + b] * sErr[b];
+        sWe[a] = t;
+        c2 += sErr[a] * t;
+      }
+      double r0 = c2;
+      if (E.robust) huber(c2, dI, dI * dI, &r0, &rI);
+      chi += r0;
+    }
+    for (int k = 0; k < 3; k++) {
+      sErr[9 + k] = (sj.bg[k] + sj.dbg[k]) - (si.bg[k] + si.dbg[k]);
+      sErr[12 + k] = (sj.ba[k] + sj.dba[k]) - (si.ba[k] + si.dba[k]);
+    }
+    {
+      double c2 = 0;
+      for (int k = 0; k < 3; k++) c2 += sErr[9 + k] * (E.infoBg * sErr[9 + k]);
+      for (int k = 3; k < 6; k++) c2 += sErr[9 + k] * (E.infoBa * sErr[9 + k]);
+      double r0 = c2;
+      if (E.robust) huber(c2, dB, dB * dB, &r0, &rB);
+      chi += r0;
+    }
+    (mode ? D.gchi : D.gchi0)[e] = chi;
+    sRho[0] = rI, sRho[1] = rB;
+    if (mode == 0 && E.has_imu) {
+      // J (9 x 24, [PRV_j | PRV_i | Bias_i]) -> local order [i: PR V Bias | j: PR V Bias]
+      double J24[9 * 24];
+      imu_linearize(E.M, D.gw, si, sj, sErr, J24, 3, 6);
+      for (int a = 0; a < 9; a++) {
+        for (int c = 0; c < 30; c++) sJ[a * 30 + c] = 0;
+        for (int c = 0; c < 9; c++) sJ[a * 30 + 15 + c] = J24[a * 24 + c];       // state j: PR, V
+        for (int c = 0; c < 9; c++) sJ[a * 30 + c] = J24[a * 24 + 9 + c];        // state i: PR, V
+        for (int c = 0; c < 6; c++) sJ[a * 30 + 9 + c] = J24[a * 24 + 18 + c];   // Bias_i
+      }
+    }
+  }
+  if (mode) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double* A = D.Ae + 930 * (size_t)e;
+  const double rI = sRho[0], rB = sRho[1];
+  if (E.has_imu) {
+    for (int t = lane; t < 270; t += 64) {  // T = (rho' Info) J
+      const int a = t / 30, c = t - a * 30;
+      double u = 0;
+      for (int q = 0; q < 9; q++) u += (rI * E.InfoI[a * 9 + q]) * sJ[q * 30 + c];
+      sT[t] = u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int t = lane; t < 900; t += 64) {
+    const int c1 = t / 30, c2 = t - c1 * 30;
+    double u = 0;
+    if (E.has_imu)
+      for (int a = 0; a < 9; a++) u += sJ[a * 30 + c1] * sT[a * 30 + c2];
+    // bias edge: J_i = -I on rows/cols 9..14, J_j = +I on 24..29
+    const int b1 = c1 >= 24 ? c1 - 24 : (c1 >= 9 && c1 < 15 ? c1 - 9 : -1);
+    const int b2 = c2 >= 24 ? c2 - 24 : (c2 >= 9 && c2 < 15 ? c2 - 9 : -1);
+    if (b1 >= 0 && b1 == b2) {
+      const double wgt = (b1 < 3 ? E.infoBg : E.infoBa) * rB;
+      u += ((c1 >= 24) == (c2 >= 24)) ? wgt : -wgt;
+    }
+    A[t] = u;
+  }
+  if (lane < 30) {
+    double u = 0;
+    if (E.has_imu)
+      for (int a = 0; a < 9; a++) u += sJ[a * 30 + lane] * (-sWe[a] * rI);
+    const int b1 = lane >= 24 ? lane - 24 : (lane >= 9 && lane < 15 ? lane - 9 : -1);
+    if (b1 >= 0) {
+      const double we = (b1 < 3 ? E.infoBg : E.infoBa) * sErr[9 + b1] * rB;
+      u += lane >= 24 ? -we : we;
+    }
+    A[900 + lane] = u;
   }
 }
 
 // ---- dense LDL^T solve of the reduced system + pose update, one workgroup per window.
-// Right-looking, one 6-column panel (= one key frame) per step: every thread factorises the 6x6
-// diagonal block in registers, one thread per row below forms its 6 multipliers, then the trailing
-// matrix takes the six rank-1 updates in sequence -- the arithmetic of the column-by-column algorithm
-// with a sixth of its barriers.  use_lds: the matrix lives in LDS, otherwise in place in global memory.
+// Right-looking, one PW-column panel per step (PW = 6: one key frame of a vision-only window; PW = 5: a
+// third of a visual-inertial key-frame block): every thread factorises the PW x PW diagonal block in
+// registers, one thread per row below forms its multipliers, then the trailing matrix takes the PW
+// rank-1 updates in sequence -- the arithmetic of the column-by-column algorithm with 1/PW of its
+// barriers.  use_lds: the lower triangle lives packed in LDS (n <= ~186), otherwise the matrix is
+// factorised in place in global memory.
+template <int PW>
 __global__ void __launch_bounds__(256)
 k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out,
            int use_lds, int n_max) {
@@ -570,32 +752,37 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
     return;
   }
   const double lambda = win_lambda(ctl[w], out[w]);
-  double* sW = s_dyn;               // [n][6] un-normalised panel columns
-  double* y = sW + 6 * (size_t)n_max;  // [n]
-  double* sD = y + n_max;           // [n]
+  double* sW = s_dyn;                   // [n][PW] un-normalised panel columns
+  double* y = sW + PW * (size_t)n_max;  // [n]
+  double* sD = y + n_max;               // [n]
   double* A = use_lds ? sD + n_max : D.Hs;
+  // element (i, k), k <= i
+#define LA(i, k) A[use_lds ? ((size_t)(i) * ((i) + 1) / 2 + (k)) : ((size_t)(i) * n + (k))]
   if (use_lds) {
-    for (int i = tid; i < n * n; i += 256) A[i] = D.Hs[i];
+    for (int i = tid; i < n * n; i += 256) {
+      const int r = i / n, c = i - r * n;
+      if (c <= r) LA(r, c) = D.Hs[i];
+    }
   }
   __syncthreads();
   const int ti = tid >> 4, tk = tid & 15;
   bool ok = true;
-  for (int j0 = 0; j0 < n && ok; j0 += 6) {
-    // 6x6 diagonal block, every thread: a[r][c] (r >= c), Wd = un-normalised columns, Dd = pivots
-    double a[6][6], Wd[6][6], Dd[6];
+  for (int j0 = 0; j0 < n && ok; j0 += PW) {
+    // PW x PW diagonal block, every thread: a[r][c] (r >= c), Wd = un-normalised columns, Dd = pivots
+    double a[PW][PW], Wd[PW][PW], Dd[PW];
 #pragma unroll
-    for (int r = 0; r < 6; r++)
+    for (int r = 0; r < PW; r++)
 #pragma unroll
-      for (int c = 0; c <= r; c++) a[r][c] = A[(size_t)(j0 + r) * n + j0 + c];
+      for (int c = 0; c <= r; c++) a[r][c] = LA(j0 + r, j0 + c);
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
+    for (int c = 0; c < PW; c++) {
       const double d = a[c][c];
       if (!(d > 0)) ok = false;
       Dd[c] = d;
 #pragma unroll
-      for (int r = c + 1; r < 6; r++) Wd[r][c] = a[r][c];
+      for (int r = c + 1; r < PW; r++) Wd[r][c] = a[r][c];
 #pragma unroll
-      for (int r = c + 1; r < 6; r++) {
+      for (int r = c + 1; r < PW; r++) {
         const double l = Wd[r][c] / d;
 #pragma unroll
         for (int k = c + 1; k <= r; k++) a[r][k] -= l * Wd[k][c];
@@ -603,45 +790,46 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
       }
     }
     if (!ok) break;  // uniform: every thread factorised the same block
-    if (tid < 6) {
-      sD[j0 + tid] = Dd[0];
+    if (tid < PW) {
+      double dv = Dd[0];
 #pragma unroll
-      for (int c = 1; c < 6; c++)
-        if (tid == c) sD[j0 + tid] = Dd[c];
+      for (int c = 1; c < PW; c++)
+        if (tid == c) dv = Dd[c];
+      sD[j0 + tid] = dv;
     }
     // rows below the panel: multipliers
-    for (int i = j0 + 6 + tid; i < n; i += 256) {
-      double ai[6];
+    for (int i = j0 + PW + tid; i < n; i += 256) {
+      double ai[PW];
 #pragma unroll
-      for (int c = 0; c < 6; c++) ai[c] = A[(size_t)i * n + j0 + c];
+      for (int c = 0; c < PW; c++) ai[c] = LA(i, j0 + c);
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
+      for (int c = 0; c < PW; c++) {
         const double col = ai[c], l = col / Dd[c];
-        sW[i * 6 + c] = col;
+        sW[i * PW + c] = col;
 #pragma unroll
-        for (int k = c + 1; k < 6; k++) ai[k] -= l * Wd[k][c];
+        for (int k = c + 1; k < PW; k++) ai[k] -= l * Wd[k][c];
         ai[c] = l;
       }
 #pragma unroll
-      for (int c = 0; c < 6; c++) A[(size_t)i * n + j0 + c] = ai[c];
+      for (int c = 0; c < PW; c++) LA(i, j0 + c) = ai[c];
     }
     __syncthreads();
     if (tid == 0) {  // after the barrier: every thread has read the unfactorised diagonal block
 #pragma unroll
-      for (int r = 1; r < 6; r++)
+      for (int r = 1; r < PW; r++)
 #pragma unroll
-        for (int c = 0; c < r; c++) A[(size_t)(j0 + r) * n + j0 + c] = a[r][c];
+        for (int c = 0; c < r; c++) LA(j0 + r, j0 + c) = a[r][c];
     }
     // trailing matrix (lower triangle)
-    for (int i = j0 + 6 + ti; i < n; i += 16) {
-      double li[6];
+    for (int i = j0 + PW + ti; i < n; i += 16) {
+      double li[PW];
 #pragma unroll
-      for (int c = 0; c < 6; c++) li[c] = A[(size_t)i * n + j0 + c];
-      for (int k = j0 + 6 + tk; k <= i; k += 16) {
-        double v = A[(size_t)i * n + k];
+      for (int c = 0; c < PW; c++) li[c] = LA(i, j0 + c);
+      for (int k = j0 + PW + tk; k <= i; k += 16) {
+        double v = LA(i, k);
 #pragma unroll
-        for (int c = 0; c < 6; c++) v -= li[c] * sW[k * 6 + c];
-        A[(size_t)i * n + k] = v;
+        for (int c = 0; c < PW; c++) v -= li[c] * sW[k * PW + c];
+        LA(i, k) = v;
       }
     }
     __syncthreads();
@@ -650,22 +838,22 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
     for (int i = tid; i < n; i += 256) y[i] = D.bs[i];
     __syncthreads();
     // forward substitution L y = b, panel by panel
-    for (int j0 = 0; j0 < n; j0 += 6) {
-      double yp[6];
+    for (int j0 = 0; j0 < n; j0 += PW) {
+      double yp[PW];
 #pragma unroll
-      for (int c = 0; c < 6; c++) yp[c] = y[j0 + c];
+      for (int c = 0; c < PW; c++) yp[c] = y[j0 + c];
 #pragma unroll
-      for (int c = 0; c < 6; c++)
+      for (int c = 0; c < PW; c++)
 #pragma unroll
-        for (int r = c + 1; r < 6; r++) yp[r] -= A[(size_t)(j0 + r) * n + j0 + c] * yp[c];
-      __syncthreads();  // everyone has read y[j0 .. j0+5]
+        for (int r = c + 1; r < PW; r++) yp[r] -= LA(j0 + r, j0 + c) * yp[c];
+      __syncthreads();  // everyone has read y[j0 .. j0+PW-1]
       if (tid == 0)
 #pragma unroll
-        for (int c = 1; c < 6; c++) y[j0 + c] = yp[c];
-      for (int i = j0 + 6 + tid; i < n; i += 256) {
+        for (int c = 1; c < PW; c++) y[j0 + c] = yp[c];
+      for (int i = j0 + PW + tid; i < n; i += 256) {
         double v = y[i];
 #pragma unroll
-        for (int c = 0; c < 6; c++) v -= A[(size_t)i * n + j0 + c] * yp[c];
+        for (int c = 0; c < PW; c++) v -= LA(i, j0 + c) * yp[c];
         y[i] = v;
       }
       __syncthreads();
@@ -673,22 +861,22 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
     for (int i = tid; i < n; i += 256) y[i] /= sD[i];
     __syncthreads();
     // backward substitution L^T x = y
-    for (int j0 = n - 6; j0 >= 0; j0 -= 6) {
-      double xp[6];
+    for (int j0 = n - PW; j0 >= 0; j0 -= PW) {
+      double xp[PW];
 #pragma unroll
-      for (int c = 0; c < 6; c++) xp[c] = y[j0 + c];
+      for (int c = 0; c < PW; c++) xp[c] = y[j0 + c];
 #pragma unroll
-      for (int c = 5; c > 0; c--)
+      for (int c = PW - 1; c > 0; c--)
 #pragma unroll
-        for (int r = c - 1; r >= 0; r--) xp[r] -= A[(size_t)(j0 + c) * n + j0 + r] * xp[c];
+        for (int r = c - 1; r >= 0; r--) xp[r] -= LA(j0 + c, j0 + r) * xp[c];
       __syncthreads();
       if (tid == 0)
 #pragma unroll
-        for (int c = 0; c < 5; c++) y[j0 + c] = xp[c];
+        for (int c = 0; c < PW - 1; c++) y[j0 + c] = xp[c];
       for (int i = tid; i < j0; i += 256) {
         double v = y[i];
 #pragma unroll
-        for (int c = 5; c >= 0; c--) v -= A[(size_t)(j0 + c) * n + i] * xp[c];
+        for (int c = PW - 1; c >= 0; c--) v -= LA(j0 + c, i) * xp[c];
         y[i] = v;
       }
       __syncthreads();
@@ -697,14 +885,15 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
     for (int i = tid; i < n; i += 256) y[i] = 0;
     __syncthreads();
   }
+#undef LA
   double sp[1] = {0};
   for (int i = tid; i < n; i += 256) {
     D.xp[i] = y[i];
-    sp[0] += y[i] * (lambda * y[i] + D.bp[i]);  // pose part of computeScale()
+    sp[0] += y[i] * (lambda * y[i] + D.bfull[i]);  // pose part of computeScale()
   }
   block_sum<1>(sp, s_red, tid);
   if (tid == 0) out[w].ok = ok ? 1 : 0, out[w].scale_p = ok ? sp[0] : 0.0;
-  // oplus on the free key frames (push() first)
+  // oplus on the free key frames (push() first): VertexNavStatePR (+ V, Bias in a visual-inertial window)
   for (int k = tid; k < D.n_kf; k += 256) {
     LbaKf kf = D.kf[k];
     if (kf.col < 0) continue;
@@ -715,6 +904,9 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
     inc_small_pr(e, y + kf.col);
     kf.p[0] = e.p[0], kf.p[1] = e.p[1], kf.p[2] = e.p[2];
     kf.qw = e.qw, kf.qx = e.qx, kf.qy = e.qy, kf.qz = e.qz;
+    if (D.pd == 15)
+      for (int a = 0; a < 3; a++)
+        kf.v[a] += y[kf.col + 6 + a], kf.dbg[a] += y[kf.col + 9 + a], kf.dba[a] += y[kf.col + 12 + a];
     D.kf[k] = kf;
   }
 }
@@ -737,7 +929,7 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
       if (D.tab[(size_t)a * D.n_mp + m] < 0) continue;
       const double* B = D.BB + (size_t)(6 * a) * D.ldB + 3 * (size_t)m;
       for (int r = 0; r < 6; r++, B += D.ldB) {
-        const double xa = D.xp[6 * a + r];
+        const double xa = D.xp[D.pd * a + r];
         cl[0] -= B[0] * xa, cl[1] -= B[1] * xa, cl[2] -= B[2] * xa;
       }
     }
@@ -775,7 +967,10 @@ static thread_local PinnedBuf g_stage, g_small_h;
 
 struct WinHost {  // per-window LM state machine, exactly g2o's (optimization_algorithm_levenberg.cpp)
   const vieo_lba_params* P;
-  int n_kf, n_mp, n_obs;
+  const vieo_lba_vio_params* VP = nullptr;  // visual-inertial window (a18)
+  int n_kf, n_mp, n_obs, n_imu = 0;
+  double lastTrialChi = 0;  // activeRobustChi2 of the errors left in the edges (err_end)
+  bool prelevel_pending = false;
   int stage = 0;  // 0: optimize(its0), 1: optimize(its1), 2: finished
   int phase = 0;  // 0: the next round starts an optimize(), 1: in trials, 2: optimize() is over
   int it = 0, iters = 0;
@@ -786,21 +981,45 @@ struct WinHost {  // per-window LM state machine, exactly g2o's (optimization_al
   size_t o_kf, o_X, o_erase;  // offsets of the results in the staging buffer
 };
 
-}  // namespace vieo
+// 9x9 inverse by Gauss-Jordan with partial pivoting (GetProcessedInfoijPRV: mSigmaijPRV.inverse())
+static bool inverse9(const double* A, double* Ainv) {
+  double M[9][18];
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j < 9; j++) M[i][j] = A[i * 9 + j], M[i][9 + j] = (i == j);
+  for (int c = 0; c < 9; c++) {
+    int piv = c;
+    for (int r = c + 1; r < 9; r++)
+      if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+    if (M[piv][c] == 0) return false;
+    if (piv != c)
+      for (int j = 0; j < 18; j++) std::swap(M[c][j], M[piv][j]);
+    const double d = M[c][c];
+    for (int j = 0; j < 18; j++) M[c][j] /= d;
+    for (int r = 0; r < 9; r++)
+      if (r != c) {
+        const double f = M[r][c];
+        if (f != 0)
+          for (int j = 0; j < 18; j++) M[r][j] -= f * M[c][j];
+      }
+  }
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j < 9; j++) Ainv[i * 9 + j] = M[i][9 + j];
+  return true;
+}
 
-using namespace vieo;
-
-extern "C" {
-
-int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* const* params,
-                                       const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
-                                       const float* const* h_points, const int* n_mp,
-                                       const vieo_lba_obs* const* h_obs, const int* n_obs,
-                                       volatile const int* stop, vieo_navstate* const* h_navs_out,
-                                       float* const* h_points_out, uint8_t* const* h_erase,
-                                       vieo_lba_result* h_results) {
-  if (n_windows <= 0 || !params || !h_kfs || !n_kf || !h_points || !n_mp || !h_obs || !n_obs ||
-      !h_navs_out || !h_points_out || !h_erase || !h_results)
+// Both local BAs: vparams == nullptr -> Optimizer::LocalBundleAdjustment (params), otherwise
+// LocalBundleAdjustmentNavStatePRV (vparams, h_close, h_imu, n_imu).
+static int lba_run(int n_windows, const vieo_lba_params* const* params,
+                   const vieo_lba_vio_params* const* vparams, const vieo_lba_keyframe* const* h_kfs,
+                   const int* n_kf, const float* const* h_points, const uint8_t* const* h_close,
+                   const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
+                   const vieo_lba_imu_edge* const* h_imu, const int* n_imu, volatile const int* stop,
+                   vieo_navstate* const* h_navs_out, float* const* h_points_out, uint8_t* const* h_erase,
+                   vieo_lba_result* h_results) {
+  const bool vio = vparams != nullptr;
+  const int pd = vio ? 15 : 6;
+  if (n_windows <= 0 || (!vio && !params) || !h_kfs || !n_kf || !h_points || !n_mp || !h_obs || !n_obs ||
+      !h_navs_out || !h_points_out || !h_erase || !h_results || (vio && (!h_close || !h_imu || !n_imu)))
     return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
@@ -813,15 +1032,37 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
   int n_live = 0;
   for (int w = 0; w < W; w++) {
     WinHost& H = win[w];
-    H.P = params[w], H.n_kf = n_kf[w], H.n_mp = n_mp[w], H.n_obs = n_obs[w];
+    if (vio) {
+      if (!vparams[w] || !h_close[w] || n_imu[w] < 0 || (n_imu[w] > 0 && !h_imu[w])) return VIEO_E_INVALID;
+      H.VP = vparams[w], H.P = &vparams[w]->base, H.n_imu = n_imu[w];
+    } else
+      H.P = params[w];
+    H.n_kf = n_kf[w], H.n_mp = n_mp[w], H.n_obs = n_obs[w];
     H.R = &h_results[w];
     if (!H.P || !h_kfs[w] || H.n_kf <= 0 || !h_points[w] || H.n_mp <= 0 || !h_obs[w] || H.n_obs <= 0 ||
         !h_navs_out[w] || !h_points_out[w] || !h_erase[w])
       return VIEO_E_INVALID;
     memset(H.R, 0, sizeof(*H.R));
-    if (H.n_kf > 85) {
-      set_error("local BA: more than 85 key frames in a window");
+    if (H.n_kf > 85 * 6 / pd + (vio ? 200 : 0)) {
+      set_error("local BA: too many key frames in a window");
       return VIEO_E_CAPACITY;
+    }
+    if (vio) {  // a chain: at most one pre-integration into and one out of every key frame
+      std::vector<char> in(H.n_kf, 0), outk(H.n_kf, 0);
+      int n_free = 0;
+      for (int k = 0; k < H.n_kf; k++) n_free += !h_kfs[w][k].fixed;
+      if (15 * n_free > 510) {
+        set_error("visual-inertial local BA: more than 34 free key frames");
+        return VIEO_E_CAPACITY;
+      }
+      for (int t = 0; t < H.n_imu; t++) {
+        const int a = h_imu[w][t].kf_i, b = h_imu[w][t].kf_j;
+        if (a < 0 || a >= H.n_kf || b < 0 || b >= H.n_kf || a == b || outk[a] || in[b]) {
+          set_error("visual-inertial local BA: the inertial edges must chain the key frames");
+          return VIEO_E_INVALID;
+        }
+        outk[a] = 1, in[b] = 1;
+      }
     }
     for (int k = 0; k < H.n_kf; k++) h_navs_out[w][k] = h_kfs[w][k].nav;
     memcpy(h_points_out[w], h_points[w], (size_t)H.n_mp * 12);
@@ -853,7 +1094,7 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     return off;
   };
   struct Off {
-    size_t obs, mp_first, mp_count, kf_edge_first, kf_edge_idx, kf, X, erase, level, err;
+    size_t obs, mp_first, mp_count, kf_edge_first, kf_edge_idx, imu, kf_in, kf_out, close, kf, X, erase, level, err;
   };
   std::vector<Off> off(W);
   for (int w = 0; w < W; w++) {
@@ -863,6 +1104,10 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     o.obs = take((size_t)H.n_obs * sizeof(vieo_lba_obs));
     o.mp_first = take((size_t)H.n_mp * 4), o.mp_count = take((size_t)H.n_mp * 4);
     o.kf_edge_first = take((size_t)(H.n_kf + 1) * 4), o.kf_edge_idx = take((size_t)H.n_obs * 4);
+    if (vio) {
+      o.imu = take((size_t)std::max(H.n_imu, 1) * sizeof(LbaImu));
+      o.kf_in = take((size_t)H.n_kf * 4), o.kf_out = take((size_t)H.n_kf * 4), o.close = take(H.n_mp);
+    }
   }
   const size_t res_begin = arena;
   for (int w = 0; w < W; w++) {
@@ -881,7 +1126,7 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
   const size_t zero_end = arena;
   if ((rc = g_stage.ensure(res_end)) != VIEO_OK) return rc;
   uint8_t* hs = (uint8_t*)g_stage.p;
-  int max_obs = 0, max_mp = 0, max_kf = 0, max_nf = 0;
+  int max_obs = 0, max_mp = 0, max_kf = 0, max_nf = 0, max_imu = 0;
   for (int w = 0; w < W; w++) {
     if (win[w].skip) continue;
     int nf = 0;
@@ -896,7 +1141,8 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
   const int ksplit = std::max(1, std::min(std::min(nchunks_max, 16), 768 / std::max(1, n_live * nbt_max)));
   std::vector<size_t> scratch_off(W);
   struct Scr {
-    size_t kf_bak, X_bak, mp_act, BB, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab;
+    size_t kf_bak, X_bak, mp_act, BB, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
+        gchi, bfull;
   };
   std::vector<Scr> scr(W);
   for (int w = 0; w < W; w++) {
@@ -930,7 +1176,38 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
       kf[k].qw = kfs[k].nav.q[0], kf[k].qx = kfs[k].nav.q[1];
       kf[k].qy = kfs[k].nav.q[2], kf[k].qz = kfs[k].nav.q[3];
       kf[k].col = -1, kf[k].fixed = kfs[k].fixed ? 1 : 0;
+      memcpy(kf[k].v, kfs[k].nav.v, 24), memcpy(kf[k].dbg, kfs[k].nav.dbg, 24), memcpy(kf[k].dba, kfs[k].nav.dba, 24);
+      memcpy(kf[k].bg, kfs[k].nav.bg, 24), memcpy(kf[k].ba, kfs[k].nav.ba, 24);
       nf += !kfs[k].fixed;
+    }
+    if (vio) {  // inertial edges (Optimizer.cc:226-311)
+      LbaImu* im = (LbaImu*)(hs + o.imu);
+      int* kin = (int*)(hs + o.kf_in);
+      int* kout = (int*)(hs + o.kf_out);
+      for (int k = 0; k < H.n_kf; k++) kin[k] = kout[k] = -1;
+      for (int t = 0; t < H.n_imu; t++) {
+        const vieo_lba_imu_edge& e = h_imu[w][t];
+        LbaImu& d = im[t];
+        d.i = e.kf_i, d.j = e.kf_j, d.M = e.imu;
+        const bool bfixedkf = kfs[e.kf_i].fixed != 0;
+        d.has_imu = e.imu.dt != 0, d.robust = bfixedkf || H.VP->rec_init;
+        memset(d.InfoI, 0, sizeof(d.InfoI));
+        if (d.has_imu) {
+          if (!inverse9(e.imu.Sigma, d.InfoI)) {
+            set_error("visual-inertial local BA: singular pre-integration covariance");
+            return VIEO_E_INVALID;
+          }
+          if (bfixedkf)
+            for (int q = 0; q < 81; q++) d.InfoI[q] *= 1e-2;
+        }
+        double deltatij = e.imu.dt ? e.imu.dt : e.dt_kf;
+        const float EPS_MIN_DT = 1e-6f;
+        if (deltatij <= EPS_MIN_DT) deltatij = 15;  // Optimizer.cc:271-275
+        d.infoBg = H.VP->inv_sigma_bg2 / deltatij * (bfixedkf ? 1e-2 : 1.0);
+        d.infoBa = H.VP->inv_sigma_ba2 / deltatij * (bfixedkf ? 1e-2 : 1.0);
+        kout[e.kf_i] = t, kin[e.kf_j] = t;
+      }
+      memcpy(hs + o.close, h_close[w], H.n_mp);
     }
     double* X = (double*)(hs + o.X);
     for (int i = 0; i < H.n_mp * 3; i++) X[i] = (double)h_points[w][i];
@@ -945,8 +1222,12 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     s.BB = take((size_t)npm * ldB * 8);
     s.Sp = take((size_t)ksplit * sp_rows * ldS * 8);
     s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
-    s.Hpp = take((size_t)nf * 36 * 8), s.Hs = take((size_t)npm * npm * 8);
-    s.bp = take((size_t)npm * 8), s.bs = take((size_t)npm * 8), s.xp = take((size_t)npm * 8);
+    const int npf = pd * nf;  // full reduced system
+    s.Hpp = take((size_t)nf * 36 * 8), s.Hs = take((size_t)npf * npf * 8);
+    s.bp = take((size_t)npm * 8), s.bs = take((size_t)npf * 8), s.xp = take((size_t)npf * 8);
+    s.bfull = take((size_t)npf * 8);
+    s.Ae = take((size_t)std::max(H.n_imu, 1) * 930 * 8);
+    s.gchi0 = take((size_t)std::max(H.n_imu, 1) * 8), s.gchi = take((size_t)std::max(H.n_imu, 1) * 8);
     s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
     s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
     s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)nf * H.n_mp * 4);
@@ -958,6 +1239,14 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     memcpy(D.cam.Rcb, H.P->Rcb, 72);
     memcpy(D.cam.tcb, H.P->tcb, 24);
     D.dMono = (double)(float)sqrt(5.991), D.dStereo = (double)(float)sqrt(7.815);
+    D.pd = pd, D.n_imu = H.n_imu;
+    if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
+      D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
+      memcpy(D.gw, H.VP->gw, 24);
+      H.prelevel_pending = true;
+    } else
+      D.thMono = D.thMonoClose = 5.991, D.thStereo = 7.815;
+    max_imu = std::max(max_imu, H.n_imu);
     max_obs = std::max(max_obs, H.n_obs), max_mp = std::max(max_mp, H.n_mp);
     max_kf = std::max(max_kf, H.n_kf), max_nf = std::max(max_nf, nf);
     H.iters = H.P->its0;
@@ -986,6 +1275,12 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     D.part0 = (double*)(base + s.part0), D.part = (double*)(base + s.part);
     D.part_m = (double*)(base + s.part_m), D.pmax = (double*)(base + s.pmax);
     D.kf_list = (int*)(base + s.kf_list), D.tab = (int*)(base + s.tab);
+    D.bfull = (double*)(base + s.bfull), D.Ae = (double*)(base + s.Ae);
+    D.gchi0 = (double*)(base + s.gchi0), D.gchi = (double*)(base + s.gchi);
+    if (vio) {
+      D.imu = (const LbaImu*)(base + o.imu), D.close = base + o.close;
+      D.kf_in = (const int*)(base + o.kf_in), D.kf_out = (const int*)(base + o.kf_out);
+    }
   }
   LbaDev* dD = g_small.as<LbaDev>();
   WinCtl* dC = (WinCtl*)(dD + W);
@@ -996,12 +1291,13 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
   VIEO_HIP_CHECK(hipMemsetAsync(base + res_end, 0, zero_end - res_end, st));
   VIEO_HIP_CHECK(hipMemcpyAsync(dD, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
   VIEO_HIP_CHECK(hipMemsetAsync(dO, 0, (size_t)W * sizeof(WinOut), st));
-  const int n_max = 6 * max_nf;
+  const int n_max = pd * max_nf;
   const size_t ldlt_small = (size_t)8 * n_max * 8;  // panel columns, rhs, pivots
-  const int use_lds = (size_t)n_max * n_max * 8 + ldlt_small <= 150 * 1024;
-  const size_t ldlt_lds = ldlt_small + (use_lds ? (size_t)n_max * n_max * 8 : 0);
-  VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldlt, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)ldlt_lds));
+  const size_t tri = (size_t)n_max * (n_max + 1) / 2 * 8;  // packed lower triangle
+  const int use_lds = tri + ldlt_small <= 150 * 1024;
+  const size_t ldlt_lds = ldlt_small + (use_lds ? tri : 0);
+  const void* ldlt_fn = vio ? (const void*)k_lba_ldlt<5> : (const void*)k_lba_ldlt<6>;
+  VIEO_HIP_CHECK(hipFuncSetAttribute(ldlt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
   const int ge = (max_obs + 255) / 256, gm = (max_mp + 255) / 256, gq = (max_mp + 63) / 64;
   const int gr = std::max(gm, (max_kf + 255) / 256);
 
@@ -1026,7 +1322,8 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
       }
       if (H.stage < 2 && H.phase == 0) {
         f |= LBA_BEGIN | LBA_BUILD | LBA_TRIAL | (H.stage == 0 ? LBA_ROBUST : 0);
-        lam = -1;
+        lam = vio ? H.VP->lambda_init : -1;  // setUserLambdaInit (Optimizer.cc:131-138)
+        if (H.prelevel_pending) f |= LBA_PRELEVEL, H.prelevel_pending = false;
       } else if (H.stage < 2 && H.phase == 1) {
         f |= LBA_TRIAL | (H.stage == 0 ? LBA_ROBUST : 0);
         if (H.need_build) f |= LBA_BUILD;
@@ -1039,6 +1336,7 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     VIEO_HIP_CHECK(hipMemcpyAsync(dC, ctl, (size_t)W * sizeof(WinCtl), hipMemcpyHostToDevice, st));
     if (any & LBA_RESTORE) hipLaunchKernelGGL(k_lba_restore, dim3(gr, W), dim3(256), 0, st, dD, dC);
     if (any & (LBA_CLASS0 | LBA_CLASS1)) hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC);
+    if (any & LBA_PRELEVEL) hipLaunchKernelGGL(k_lba_prelevel, dim3(ge, W), dim3(256), 0, st, dD, dC);
     if (any & LBA_BEGIN) {
       hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC);
       hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO);
@@ -1046,15 +1344,20 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
     }
     if (any & LBA_BUILD) {
       hipLaunchKernelGGL(k_lba_build, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq);
+      if (vio && max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0);
     }
     if (any & LBA_BEGIN) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);
     if (any & LBA_TRIAL) {
       hipLaunchKernelGGL(k_lba_schur, dim3(nbt_max * ksplit, W), dim3(256), 0, st, dD, dC, dO, ksplit);
-      hipLaunchKernelGGL(k_lba_assemble, dim3((np_cap_max * np_cap_max + 255) / 256, W), dim3(256), 0, st, dD, dC,
-                         dO, ksplit);
-      hipLaunchKernelGGL(k_lba_ldlt, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
+      hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO,
+                         ksplit);
+      if (vio)
+        hipLaunchKernelGGL(k_lba_ldlt<5>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
+      else
+        hipLaunchKernelGGL(k_lba_ldlt<6>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
       hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO);
       hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
+      if (vio && max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
       hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
       VIEO_HIP_CHECK(hipMemcpyAsync(out, dO, (size_t)W * sizeof(WinOut), hipMemcpyDeviceToHost, st));
     }
@@ -1074,13 +1377,14 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
         H.currentChi = out[w].chi0;
         if (H.stage == 0) H.R->chi2_initial = H.currentChi;
         H.iniChi = H.currentChi;
-        H.lambda = out[w].lambda;
+        H.lambda = vio ? H.VP->lambda_init : out[w].lambda;
         H.ni = 2, H.nBad = 0, H.qmax = 0, H.it = 0;
         H.phase = 1;
       }
       H.R->lm_trials++;
       H.need_build = false;
       const bool ok2 = out[w].ok != 0;
+      H.lastTrialChi = out[w].chi2;
       const double tempChi = ok2 ? out[w].chi2 : DBL_MAX;
       double rho = H.currentChi - tempChi;
       const double scale = (ok2 ? out[w].scale_l + out[w].scale_p : 0.0) + 1e-3;
@@ -1125,6 +1429,14 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
   for (int w = 0; w < W; w++) {
     WinHost& H = win[w];
     if (H.skip) continue;
+    if (vio) {  // float err / err_end and the divergence guard (Optimizer.cc:531-533,655-666)
+      const float err = (float)H.R->chi2_initial, err_end = (float)H.lastTrialChi;
+      H.R->chi2_initial = err, H.R->chi2_final = err_end;
+      if ((2 * err < err_end || std::isnan(err) || std::isnan(err_end)) && !H.VP->large) {
+        H.R->status = VIEO_LBA_DIVERGED;
+        continue;  // returns without write-back: outputs stay equal to the inputs
+      }
+    }
     memcpy(h_erase[w], hs + H.o_erase, H.n_obs);
     for (int i = 0; i < H.n_obs; i++) H.R->n_erase += h_erase[w][i];
     const LbaKf* o = (const LbaKf*)(hs + H.o_kf);
@@ -1134,10 +1446,31 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
       memcpy(h_navs_out[w][k].p, o[k].p, 24);
       h_navs_out[w][k].q[0] = o[k].qw, h_navs_out[w][k].q[1] = o[k].qx;
       h_navs_out[w][k].q[2] = o[k].qy, h_navs_out[w][k].q[3] = o[k].qz;
+      if (vio) {  // ns_recov: v of the V vertex, dbg / dba of the Bias vertex (Optimizer.cc:716-733)
+        memcpy(h_navs_out[w][k].v, o[k].v, 24);
+        memcpy(h_navs_out[w][k].dbg, o[k].dbg, 24), memcpy(h_navs_out[w][k].dba, o[k].dba, 24);
+      }
     }
     for (int i = 0; i < H.n_mp * 3; i++) h_points_out[w][i] = (float)X[i];  // SetWorldPos(cast<float>)
   }
   return VIEO_OK;
+}
+
+}  // namespace vieo
+
+using namespace vieo;
+
+extern "C" {
+
+int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* const* params,
+                                       const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                       const float* const* h_points, const int* n_mp,
+                                       const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                       volatile const int* stop, vieo_navstate* const* h_navs_out,
+                                       float* const* h_points_out, uint8_t* const* h_erase,
+                                       vieo_lba_result* h_results) {
+  return lba_run(n_windows, params, nullptr, h_kfs, n_kf, h_points, nullptr, n_mp, h_obs, n_obs, nullptr, nullptr,
+                 stop, h_navs_out, h_points_out, h_erase, h_results);
 }
 
 int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo_lba_keyframe* h_kfs, int n_kf,
@@ -1149,6 +1482,31 @@ int vieo_local_bundle_adjustment(const vieo_lba_params* P, const vieo_lba_keyfra
     return VIEO_E_INVALID;
   return vieo_local_bundle_adjustment_batch(1, &P, &h_kfs, &n_kf, &h_points, &n_mp, &h_obs, &n_obs, stop,
                                             &h_navs_out, &h_points_out, &h_erase, R);
+}
+
+int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_params* const* params,
+                                           const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                           const float* const* h_points, const uint8_t* const* h_close,
+                                           const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                           const vieo_lba_imu_edge* const* h_imu, const int* n_imu,
+                                           volatile const int* stop, vieo_navstate* const* h_navs_out,
+                                           float* const* h_points_out, uint8_t* const* h_erase,
+                                           vieo_lba_result* h_results) {
+  if (!params) return VIEO_E_INVALID;
+  return lba_run(n_windows, nullptr, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu, n_imu,
+                 stop, h_navs_out, h_points_out, h_erase, h_results);
+}
+
+int vieo_local_bundle_adjustment_vio(const vieo_lba_vio_params* P, const vieo_lba_keyframe* h_kfs, int n_kf,
+                                     const float* h_points, const uint8_t* h_close, int n_mp,
+                                     const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_imu_edge* h_imu,
+                                     int n_imu, volatile const int* stop, vieo_navstate* h_navs_out,
+                                     float* h_points_out, uint8_t* h_erase, vieo_lba_result* R) {
+  if (!P || !h_kfs || n_kf <= 0 || !h_points || !h_close || n_mp <= 0 || !h_obs || n_obs <= 0 || n_imu < 0 ||
+      (n_imu > 0 && !h_imu) || !h_navs_out || !h_points_out || !h_erase || !R)
+    return VIEO_E_INVALID;
+  return vieo_local_bundle_adjustment_vio_batch(1, &P, &h_kfs, &n_kf, &h_points, &h_close, &n_mp, &h_obs, &n_obs,
+                                                &h_imu, &n_imu, stop, &h_navs_out, &h_points_out, &h_erase, R);
 }
 
 }  // extern "C"

@@ -83,3 +83,41 @@ class Optimizer:
             None if st is None else st.ctypes.data, ptrs[4].ctypes.data, ptrs[5].ctypes.data,
             ptrs[6].ctypes.data, res.ctypes.data), "vieo_local_bundle_adjustment_batch")
         return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
+
+    @staticmethod
+    def LocalBundleAdjustmentNavStatePRV(params, kfs, points, close, obs, imu, stop=None):
+        """void Optimizer::LocalBundleAdjustmentNavStatePRV(KeyFrame*, int Nlocal, bool* pbStopFlag, Map*,
+        cv::Mat gw, bool bLarge, bool bRecInit, float th_dist_far) (src/Optimizer.cc:21-769) on a flattened
+        window (ba_types.LBA_VIO_PARAMS / LBA_KEYFRAME / LBA_OBS / LBA_IMU_EDGE).
+        returns (navs[n_kf], points float32[n_mp,3], erase uint8[n_obs], result record)."""
+        return Optimizer.LocalBundleAdjustmentNavStatePRVBatch([(params, kfs, points, close, obs, imu)], stop)[0]
+
+    @staticmethod
+    def LocalBundleAdjustmentNavStatePRVBatch(windows, stop=None):
+        """Several independent visual-inertial windows in lock step.
+        windows: list of (params, kfs, points, close, obs, imu)."""
+        W = len(windows)
+        keep, outs = [], []
+        ptrs = [np.zeros(W, np.uint64) for _ in range(9)]  # params kfs points close obs imu navs pts erase
+        cnt = [np.zeros(W, np.int32) for _ in range(4)]    # n_kf n_mp n_obs n_imu
+        res = np.zeros(W, LBA_RESULT_DTYPE)
+        for w, (params, kfs, points, close, obs, imu) in enumerate(windows):
+            params, kfs, imu = np.ascontiguousarray(params), np.ascontiguousarray(kfs), np.ascontiguousarray(imu)
+            points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+            close = np.ascontiguousarray(close, np.uint8)
+            navs = np.zeros(len(kfs), NAVSTATE_DTYPE)
+            pts = np.zeros_like(points)
+            erase = np.zeros(max(len(obs), 1), np.uint8)
+            keep.append((params, kfs, points, close, obs, imu))
+            outs.append((navs, pts, erase, len(obs)))
+            for a, arr in zip(ptrs, (params, kfs, points, close, obs, imu, navs, pts, erase)):
+                a[w] = arr.ctypes.data
+            cnt[0][w], cnt[1][w], cnt[2][w], cnt[3][w] = len(kfs), len(points), len(obs), len(imu)
+        st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        check(lib().vieo_local_bundle_adjustment_vio_batch(
+            W, ptrs[0].ctypes.data, ptrs[1].ctypes.data, cnt[0].ctypes.data, ptrs[2].ctypes.data,
+            ptrs[3].ctypes.data, cnt[1].ctypes.data, ptrs[4].ctypes.data, cnt[2].ctypes.data,
+            ptrs[5].ctypes.data, cnt[3].ctypes.data, None if st is None else st.ctypes.data,
+            ptrs[6].ctypes.data, ptrs[7].ctypes.data, ptrs[8].ctypes.data, res.ctypes.data),
+            "vieo_local_bundle_adjustment_vio_batch")
+        return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
