@@ -7,10 +7,11 @@ Workload (BASELINE.json configs[1]/[2]: "EuRoC MH05 stereo-VIO, 1200 feats, 1xMI
 frame, in the reference's call order
     ORBextractor x2 -> ComputeStereoMatches -> SearchByProjection(last frame) -> PoseOptimization(VIO)
     -> SearchByProjection(local map) -> PoseOptimization(VIO, bComputeMarg)
-plus one LocalBundleAdjustment per `--lba-every` frames (a key frame every <= 10 frames at 20 Hz,
-SURVEY.md 8d), issued from host threads like the reference's LocalMapping thread.  The LBA built so
-far is the vision-only variant (Optimizer.cc:1876-2307) on a 10+6 key-frame window; the IMU variant
-LocalBundleAdjustmentNavStatePRV is not built yet -- stated in config.workload.
+plus one LocalBundleAdjustmentNavStatePRV (Optimizer.cc:21-769: 10 local key frames with PR + V + Bias
+vertices chained by IMU pre-integrations, the key frame before the window and 5 more fixed observers,
+2000 points) per `--lba-every` frames (a key frame every <= 10 frames at 20 Hz), the
+windows of a step issued as one lock-step batch from a host thread like the reference's LocalMapping
+thread.
 
 One process per GPU (the driver launches N>1 through torch.distributed.run).  A *step* is one pass
 of that path over a batch of B independent frames that already sit in HBM; ranks shard frames
@@ -95,7 +96,7 @@ def cpu_baseline(P, lba_problems, lba_every, budget_s=20.0):
             i = lq.get()
             if i is None:
                 return
-            orc.local_ba(*lba_problems[i % len(lba_problems)])
+            orc.local_ba_vio(*lba_problems[i % len(lba_problems)])
     lm_thread = threading.Thread(target=local_mapping)
     if lba_every > 0 and lba_problems:
         lm_thread.start()
@@ -142,7 +143,7 @@ def cpu_baseline(P, lba_problems, lba_every, budget_s=20.0):
             "sample": "%d of the benchmark's stereo frames through the same chain with the CPU oracle "
                       "(-O3 -march=native), threaded like the reference: extraction on 1 thread per "
                       "camera, stereo match / projection searches / 2x PoseOptimization on the tracking "
-                      "thread, one LocalBundleAdjustment per %d frames on a LocalMapping thread (nproc=%d)"
+                      "thread, one LocalBundleAdjustmentNavStatePRV per %d frames on a LocalMapping thread (nproc=%d)"
                       % (n_done, lba_every, os.cpu_count())}
 
 
@@ -188,7 +189,8 @@ def main():
     from vieo_slam_amd import synth_ba
     from vieo_slam_amd.optimizer import Optimizer
     n_lba = (B + a.lba_every - 1) // a.lba_every if a.lba_every > 0 else 0
-    lba_problems = [synth_ba.make_lba_problem(500 + 7 * rank + i)[:4] for i in range(min(8, n_lba))]
+    lba_problems = [synth_ba.make_lba_vio_problem(500 + 7 * rank + i, n_local=10, n_fixed=6, n_points=2000)[:6]
+                    for i in range(min(8, n_lba))]
     pool = ThreadPoolExecutor(max_workers=max(1, a.lba_threads))
     lba_ms = []
 
@@ -197,7 +199,7 @@ def main():
 
     def run_lba(idx):
         t = time.perf_counter()
-        r = Optimizer.LocalBundleAdjustmentBatch([lba_problems[i % len(lba_problems)] for i in idx])
+        r = Optimizer.LocalBundleAdjustmentNavStatePRVBatch([lba_problems[i % len(lba_problems)] for i in idx])
         lba_ms.append((time.perf_counter() - t) * 1e3 / len(idx))
         return [x[3] for x in r]
 
@@ -254,10 +256,10 @@ def main():
                             "synthetic rendered stereo-inertial frames 752x480, 1.2x8 levels, FAST 20/7; per "
                             "frame ORBextractor x2 + ComputeStereoMatches + SearchByProjection(last frame) + "
                             "PoseOptimization(VIO) + SearchByProjection(local map) + PoseOptimization(VIO, marg); "
-                            "plus one vision-only LocalBundleAdjustment (10 free + 6 fixed key frames, ~1500 "
-                            "points, ~14k observations) per %d frames, the windows of a step advanced in lock step "
-                            "(%d per call, %d host threads).  The IMU variant "
-                            "LocalBundleAdjustmentNavStatePRV is not built yet" % (a.lba_every, lba_chunk, a.lba_threads),
+                            "plus one LocalBundleAdjustmentNavStatePRV (10 local key frames with PR+V+Bias "
+                            "vertices and IMU pre-integration edges, 6 fixed, ~1500 points, ~12k observations) per "
+                            "%d frames, the windows of a step advanced in lock step (%d per call, %d host "
+                            "threads)" % (a.lba_every, lba_chunk, a.lba_threads),
                 "local_ba_windows_per_step": n_lba,
                 "local_ba_ms_per_window_mean": float(np.mean(lba_ms)) if lba_ms else None,
                 "local_ba_lm_iterations_mean": float(np.mean([r["lm_iterations"] for r in lba_res])) if lba_res else None,
