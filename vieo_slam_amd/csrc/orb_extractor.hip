@@ -74,6 +74,17 @@ k_resize(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab,
   }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Neighbouring
+// cells / tiles share 128-byte lines of the plane, so they should share an L2: the launch index is
+// mapped so that runs of G consecutive items stay on one XCD while the runs themselves are still
+// interleaved over the XCDs (a contiguous eighth per XCD would unbalance them: pyramid levels differ
+// in work per cell).  The grid holds 8 * G * ceil(n / (8 G)) blocks.
+static const int kXcdRun = 32;
+__device__ __forceinline__ int xcd_grouped(int bid, int G) {
+  const int xcd = bid & 7, q = bid >> 3;
+  return ((q / G) * 8 + xcd) * G + q % G;
+}
+
 // ------------------------------------------------------------------ FAST-9/16 per cell
 // Threshold-free corner strength r = max over the 16 arcs of 9 contiguous ring pixels of
 // min(v - x) (dark arcs) and of min(x - v) (bright arcs).  cv::FAST(t) declares a corner iff
@@ -129,9 +140,11 @@ __device__ __forceinline__ bool fast_compass(const uint8_t* t, int p, int th) {
 __global__ void __launch_bounds__(64)
 k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __restrict__ cell_keys,
        int* __restrict__ cell_counts, int iniTh, int minTh, int tpitch, int tile_bytes,
-       int score_bytes) {
+       int score_bytes, int n_images) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int item = xcd_grouped(blockIdx.x, kXcdRun), lane = threadIdx.x;  // item = image * ncells + cell
+  if (item >= P.ncells * n_images) return;
+  const int b = item / P.ncells, c = item - b * P.ncells;
   const CellDesc cd = cells[c];
   int pitch;
   const uint8_t* src = plane_ptr(P, I, b, cd.level, &pitch);
@@ -340,12 +353,15 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // item from 7 x 8-byte LDS reads.  The sum is the same integer as OpenCV's, only the order of the
 // two exact passes' additions differs.
 __global__ void __launch_bounds__(256)
-k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles) {
+k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles, int n_tiles, int n_images) {
   constexpr int SP = 72, SH = kBlurTH + 6;  // source pitch (bytes), rows
   __shared__ __attribute__((aligned(16))) uint8_t s_src[SH * SP];
   __shared__ __attribute__((aligned(16))) unsigned s_h[(SH / 2) * kBlurTW];  // row pairs, see below
-  const BlurTile t = tiles[blockIdx.x];
-  const int b = blockIdx.y, tid = threadIdx.x;
+  const int item = xcd_grouped(blockIdx.x, kXcdRun);  // item = image * n_tiles + tile
+  if (item >= n_tiles * n_images) return;
+  const int b = item / n_tiles;
+  const BlurTile t = tiles[item - b * n_tiles];
+  const int tid = threadIdx.x;
   const LevelDesc& D = P.lv[t.level];
   int pitch;
   const uint8_t* src = plane_ptr(P, I, b, t.level, &pitch);
@@ -871,10 +887,17 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
                        e->d_ytab.as<short4>(), e->resize_pitch);
   }
   STAMP();
-  hipLaunchKernelGGL(k_fast, dim3(P.ncells, B), dim3(64), e->fast_lds, st, P, I,
+  const auto xcd_grid = [](long long items) {
+    return (unsigned)((items + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun));
+  };
+  if ((long long)P.ncells * B > 0x7FFF0000LL || (long long)e->tiles.size() * B > 0x7FFF0000LL) {
+    set_error("batch too large for one launch");
+    return VIEO_E_CAPACITY;
+  }
+  hipLaunchKernelGGL(k_fast, dim3(xcd_grid((long long)P.ncells * B)), dim3(64), e->fast_lds, st, P, I,
                      e->d_cells.as<CellDesc>(), e->d_cell_keys.as<unsigned>(),
                      e->d_cell_counts.as<int>(), e->iniTh, e->minTh, e->tpitch, e->tile_bytes,
-                     e->score_bytes);
+                     e->score_bytes, B);
   STAMP();
   hipLaunchKernelGGL(k_quadtree, dim3(P.nlevels, B), dim3(256), e->qt_lds, st, P,
                      e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
@@ -882,8 +905,8 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
                      e->d_kq.as<unsigned char>(), e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(),
                      e->ncap_max, e->scap_max);
   STAMP();
-  hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), B), dim3(256), 0, st, P, I,
-                     e->d_tiles.as<BlurTile>());
+  hipLaunchKernelGGL(k_blur, dim3(xcd_grid((long long)e->tiles.size() * B)), dim3(256), 0, st, P, I,
+                     e->d_tiles.as<BlurTile>(), (int)e->tiles.size(), B);
   STAMP();
   const int ngroups = (std::min(P.kp_cap, capacity) + 3) / 4;
   if (!lapping) {
