@@ -63,6 +63,21 @@ def algorithmic_bytes_per_image():
     }
 
 
+def pmc_traffic(kernel, n_img):
+    """HBM bytes per launch of the kernel from the committed PMC passes (profiles/r1_pmc_extractor.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same launch shape, gfx950 correction
+    FETCH x 2), scaled to this run's images per launch; None if the file is not there."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_extractor.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        k = d["kernels"][kernel]
+        per_img = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0 * k.get("launches", 1) / d["images_per_launch"]
+        return per_img * n_img
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(P, lba_problems, lba_every, budget_s=20.0):
     """The same chain on the host with the CPU oracle, threaded like the reference: 2 threads for
     extraction, the tracking thread for the rest, and a LocalMapping thread running one LBA per
@@ -273,7 +288,7 @@ def main():
             "stage_ms_per_step_stream0": avg,
             "extractor_kernel_ms_per_step_stream0": oavg,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dk, n_img),
                          "algorithmic_bytes_per_launch": ab[dk] * n_img,
                          "avg_launch_ms": kern[dom]},
         }

@@ -473,10 +473,13 @@ __global__ void __launch_bounds__(256)
 k_describe(OrbParams P, ImgSet I, const unsigned* __restrict__ sel,
            const int* __restrict__ sel_count, const int* __restrict__ pattern,
            vieo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int out_cap,
-           int* __restrict__ counts, int write_counts) {
-  const int b = blockIdx.y;
+           int* __restrict__ counts, int write_counts, int groups_per_image, int n_images) {
+  // all key points of an image on one XCD: their overlapping patches then share that XCD's L2
+  const int item = xcd_grouped(blockIdx.x, groups_per_image);
+  const int b = item / groups_per_image;
+  if (b >= n_images) return;
   const int lane = threadIdx.x & 63;
-  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int g = (item - b * groups_per_image) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   // level of keypoint g in the level-concatenated order (ORBextractor.cc:1005-1054)
   int level = -1, idx = 0, total = 0;
   for (int l = 0; l < P.nlevels; l++) {
@@ -910,14 +913,15 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
   STAMP();
   const int ngroups = (std::min(P.kp_cap, capacity) + 3) / 4;
   if (!lapping) {
-    hipLaunchKernelGGL(k_describe, dim3(ngroups, B), dim3(256), 0, st, P, I, e->d_sel.as<unsigned>(),
-                       e->d_sel_count.as<int>(), e->d_pattern.as<int>(), d_kp, d_desc, capacity,
-                       d_counts, 1);
+    hipLaunchKernelGGL(k_describe, dim3((unsigned)ngroups * 8 * ((B + 7) / 8)), dim3(256), 0, st, P, I,
+                       e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(), e->d_pattern.as<int>(), d_kp, d_desc,
+                       capacity, d_counts, 1, ngroups, B);
   } else {
-    hipLaunchKernelGGL(k_describe, dim3((P.kp_cap + 3) / 4, B), dim3(256), 0, st, P, I,
+    const int ng = (P.kp_cap + 3) / 4;
+    hipLaunchKernelGGL(k_describe, dim3((unsigned)ng * 8 * ((B + 7) / 8)), dim3(256), 0, st, P, I,
                        e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(), e->d_pattern.as<int>(),
                        e->d_tmp_kp.as<vieo_keypoint>(), e->d_tmp_desc.as<uint8_t>(), P.kp_cap,
-                       e->d_tmp_counts.as<int>(), 1);
+                       e->d_tmp_counts.as<int>(), 1, ng, B);
     hipLaunchKernelGGL(k_lapping, dim3(B), dim3(256), 0, st, e->d_tmp_kp.as<vieo_keypoint>(),
                        e->d_tmp_desc.as<uint8_t>(), P.kp_cap, d_kp, d_desc, capacity,
                        e->d_tmp_counts.as<int>(), d_counts, lapping[0], lapping[1]);
