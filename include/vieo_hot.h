@@ -433,6 +433,29 @@ int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_par
                                            float* const* h_points_out, uint8_t* const* h_erase,
                                            vieo_lba_result* h_results);
 
+/* ---- one window over several GPUs ---------------------------------------------------
+ * Landmark-sharded LocalBundleAdjustmentNavStatePRV: every rank passes ALL key frames and inertial
+ * edges of a window but only ITS share of the points (and their observations).  Per LM trial the ranks
+ * exchange exactly one thing, the sum of their visual contributions to the reduced pose system (Schur
+ * product, H_pp, b_p), and once more three scalars (chi2 before / after, gain-ratio scale); everything
+ * else -- inertial edges, the dense solve, the LM policy -- is replicated and therefore identical on all
+ * ranks.  `allreduce(ctx, d_buf, n)` must return 0 after the IN-PLACE sum over all ranks of the n
+ * doubles at device pointer d_buf has completed (RCCL: ncclAllReduce(sum, f64) + stream synchronise).
+ * d_reduce_buf: device memory of at least vieo_lba_sharded_buffer_doubles(...) doubles.  Key-frame
+ * outputs are identical on all ranks, h_points_out / h_erase cover the rank's own points.  No stop flag
+ * (the ranks must take the same decisions). */
+typedef int (*vieo_allreduce_sum_f64_fn)(void* ctx, double* d_buf, size_t n);
+size_t vieo_lba_sharded_buffer_doubles(int n_windows, const int* n_free_kf);
+int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_params* const* params,
+                                             const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                             const float* const* h_points, const uint8_t* const* h_close,
+                                             const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                             const vieo_lba_imu_edge* const* h_imu, const int* n_imu,
+                                             double* d_reduce_buf, size_t reduce_cap_doubles,
+                                             vieo_allreduce_sum_f64_fn allreduce, void* ctx,
+                                             vieo_navstate* const* h_navs_out, float* const* h_points_out,
+                                             uint8_t* const* h_erase, vieo_lba_result* h_results);
+
 /* ---- replay glue (device-resident batches) -------------------------------------------------
  * What Tracking.cc does between the calls above, on flattened arrays, so a batch of frames runs
  * extract -> stereo -> search -> pose optimisation with no host round trip (bench.py):

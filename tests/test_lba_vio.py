@@ -138,3 +138,61 @@ def test_gpu_vio_lba_batch_and_edge_cases(oracle):
         _parity(oracle, win, h)
     hn, hp, he, hr = Optimizer.LocalBundleAdjustmentNavStatePRV(*wins[0], stop=np.array([1], np.int32))
     assert hr["status"] == 1 and hr["lm_iterations"] == 0 and np.array_equal(hp, wins[0][2])
+
+
+@pytest.mark.gpu
+def test_gpu_vio_lba_landmark_sharded_two_ranks_on_one_gpu(oracle):
+    """Two 'ranks' (threads, each with its own stream and reduction buffer) run the landmark-sharded LBA
+    of one window; the reduction callback sums the two buffers through the host.  The result must be the
+    unsharded one (key frames identical on both ranks, each rank's points / erase flags = its shard)."""
+    import threading
+    from vieo_slam_amd import sharding
+    from vieo_slam_amd._lib import DeviceBuffer, check, lib
+    from vieo_slam_amd.optimizer import Optimizer
+    win = synth_ba.make_lba_vio_problem(50, n_local=6, n_fixed=3, n_points=600)[:6]
+    on, op, oe, ores = oracle.local_ba_vio(*win)
+    world = 2
+    shards = [sharding.shard_window(win, r, world) for r in range(world)]
+    n = Optimizer.sharded_buffer_doubles([shards[0][0]])
+    bufs = [DeviceBuffer(8 * n) for _ in range(world)]
+    barrier = threading.Barrier(world)
+    stage = [None] * world
+    results = [None] * world
+
+    def make_cb(rank):
+        def cb(offset, count):
+            h = np.empty(count)
+            check(lib().vieo_memcpy_d2h(h.ctypes.data, bufs[rank].ptr + 8 * offset, 8 * count))
+            stage[rank] = h
+            barrier.wait()
+            total = stage[0] + stage[1]
+            barrier.wait()
+            check(lib().vieo_memcpy_h2d(bufs[rank].ptr + 8 * offset, total.ctypes.data, 8 * count))
+            return 0
+        return cb
+
+    def run(rank):
+        results[rank] = Optimizer.LocalBundleAdjustmentNavStatePRVSharded([shards[rank][0]], bufs[rank].ptr, n,
+                                                                          make_cb(rank))[0]
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert all(r is not None for r in results)
+    for rank in range(world):
+        hn, hp, he, hr = results[rank]
+        mine = shards[rank][1]
+        assert hr["status"] == 0 and hr["lm_trials"] == ores["lm_trials"]
+        for k in range(len(win[1])):
+            dt, dr = synth_ba.pose_error(on[k], hn[k])
+            assert dt < 1e-4 and dr < 1e-4 and np.linalg.norm(on[k]["v"] - hn[k]["v"]) < 1e-4
+        assert np.abs(op[mine] - hp).max() < 5e-2 and np.median(np.abs(op[mine] - hp)) < 2e-5
+        sel = np.isin(win[4]["mp"], mine)
+        assert (oe[sel] != he).mean() < 0.004
+        assert abs(hr["chi2_final"] - ores["chi2_final"]) < 1e-5 * ores["chi2_final"] + 1e-2
+    assert results[0][0].tobytes() == results[1][0].tobytes()  # replicated solve: bit-identical key frames
+    # world = 1: the sharded entry with a no-op reduction equals the plain call
+    n1 = Optimizer.sharded_buffer_doubles([win])
+    b1 = DeviceBuffer(8 * n1)
+    s1 = Optimizer.LocalBundleAdjustmentNavStatePRVSharded([win], b1.ptr, n1, lambda off, cnt: 0)[0]
+    p1 = Optimizer.LocalBundleAdjustmentNavStatePRV(*win)
+    assert s1[0].tobytes() == p1[0].tobytes() and np.array_equal(s1[1], p1[1]) and np.array_equal(s1[2], p1[2])

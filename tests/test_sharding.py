@@ -61,3 +61,54 @@ def test_frame_range_properties():
             assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
             sizes = [e - b for b, e in rs]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- landmark-sharded LocalBundleAdjustmentNavStatePRV ---------------------------------
+def test_shard_window_partitions_points_and_observations():
+    import numpy as np
+    from vieo_slam_amd import synth_ba
+    win = synth_ba.make_lba_vio_problem(40, n_local=4, n_fixed=2, n_points=200)[:6]
+    params, kfs, pts, close, obs, imu = win
+    for world in (1, 2, 3):
+        seen_pts, seen_obs = [], 0
+        for r in range(world):
+            (p2, k2, pts2, close2, obs2, imu2), mine = sharding.shard_window(win, r, world)
+            assert k2 is kfs and imu2 is imu  # key frames and inertial edges replicated
+            assert np.array_equal(pts2, pts[mine]) and np.array_equal(close2, np.asarray(close)[mine])
+            assert len(obs2) and obs2["mp"].min() == 0 and obs2["mp"].max() == len(mine) - 1
+            assert (np.diff(obs2["mp"]) >= 0).all()  # still grouped by point
+            # the shard's observations are exactly the window's observations of its points
+            back = obs[np.isin(obs["mp"], mine)]
+            assert np.array_equal(back["u"], obs2["u"]) and np.array_equal(mine[obs2["mp"]], back["mp"])
+            seen_pts.append(mine)
+            seen_obs += len(obs2)
+        assert np.array_equal(np.sort(np.concatenate(seen_pts)), np.arange(len(pts))) and seen_obs == len(obs)
+
+
+def _reduce_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    buf = torch.arange(20, dtype=torch.float64) * (rank + 1)
+    fn = sharding.torch_allreduce(buf)
+    assert fn(0, 12) == 0   # the system part ...
+    assert fn(16, 4) == 0   # ... and the scalars, as the library calls it
+    q.put((rank, buf.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_reduction_callback_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_reduce_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    out = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    for r in range(world):
+        v = out[r]
+        for i in range(20):
+            summed = i < 12 or i >= 16
+            assert v[i] == (i * 3 if summed else i * (r + 1))

@@ -65,6 +65,7 @@ struct WinCtl {
 struct WinOut {
   double chi0, chi2, scale_l, scale_p, lambda;
   int ok, np;
+  double chig0, chig;  // landmark-sharded windows: the (replicated) inertial part, kept out of the reduction
 };
 
 struct LbaDev {
@@ -79,6 +80,8 @@ struct LbaDev {
                                   //   [kf_i: PR V Bias | kf_j: PR V Bias]
   double *gchi0, *gchi;           // [n_imu] robust chi2 of the inertial edges (at linearisation / after a trial)
   double* bfull;                  // [np] gradient of the pose block (visual + inertial)
+  double* red;                    // landmark-sharded window: [S npv x (npv+1) | Hpp | bp], summed over the ranks
+  double* red_sc;                 //   and its scalars [chi0, chi2, scale_l, pad]
   const unsigned char* close;     // [n_mp] bClose flags or null
   double thMono, thMonoClose, thStereo;  // chi2 gates of the classification
   double gw[3];
@@ -326,7 +329,12 @@ k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   if (threadIdx.x == 0) {
     double g0 = 0, g1 = 0;  // inertial edges, fixed order
     for (int e = 0; e < D.n_imu; e++) g0 += D.gchi0[e], g1 += D.gchi[e];
-    out[w].chi0 = v[0] + g0, out[w].chi2 = v[1] + ((fl & LBA_TRIAL) ? g1 : 0.0), out[w].scale_l = v[2];
+    if (D.red) {  // visual parts go through the all-reduce, the inertial part is the same on every rank
+      double* sc = D.red_sc;
+      sc[0] = v[0], sc[1] = v[1], sc[2] = v[2], sc[3] = 0;
+      out[w].chig0 = g0, out[w].chig = (fl & LBA_TRIAL) ? g1 : 0.0;
+    } else
+      out[w].chi0 = v[0] + g0, out[w].chi2 = v[1] + ((fl & LBA_TRIAL) ? g1 : 0.0), out[w].scale_l = v[2];
   }
 }
 
@@ -573,6 +581,32 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
       S[(size_t)(bi * 64 + wv * 16 + (lane >> 4) + 4 * r) * D.ldS + bj * 64 + q * 16 + (lane & 15)] = acc[q][r];
 }
 
+// Landmark-sharded window: this rank's part of everything the ranks have to sum -- the
+// Schur product over its landmarks (K-split partials folded in fixed order), H_pp and b_p of its edges
+// -- packed contiguously for ONE all-reduce.
+__global__ void __launch_bounds__(256)
+k_lba_pack(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int ksplit) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  if (!D.red) return;
+  const int npv = D.npv, nS = npv * (npv + 1), nH = 36 * D.n_free;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= nS + nH + npv) return;
+  if (e < nS) {
+    const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
+    const int ns = (nchunks + cps - 1) / cps;
+    const int r = e / (npv + 1), c = e - r * (npv + 1);
+    const int rr = c < npv ? min(r, c) : r, cc = c < npv ? max(r, c) : npv;
+    double s = 0;
+    for (int k = 0; k < ns; k++) s += D.Sp[(size_t)k * D.sp_stride + (size_t)rr * D.ldS + cc];
+    D.red[e] = s;
+  } else if (e < nS + nH)
+    D.red[e] = D.Hpp[e - nS];
+  else
+    D.red[e] = D.bp[e - nS - nH];
+}
+
 // Reduced pose system.  PR x PR entries: Hpp + lambda I - S (both triangles from the upper block-tiles of
 // the Schur partials); visual-inertial windows add the inertial edges' 30x30 blocks, gathered per entry
 // (a key frame has at most one inertial edge in and one out).  bs = b - S[:, npv], bfull = b.
@@ -590,12 +624,18 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
   const int r = e / np, c = e % np;
   const int a = r / pd, ra = r - a * pd, b = c / pd, cb = c - b * pd;
   double v = 0;
+  const double* redS = D.red;  // sums over the K splits and over the ranks, see k_lba_pack
+  const double* redH = D.red ? D.red + (size_t)npv * (npv + 1) : D.Hpp;
+  const double* redb = D.red ? redH + 36 * (size_t)D.n_free : D.bp;
   if (ra < 6 && cb < 6) {
     const int vr = 6 * a + ra, vc = 6 * b + cb, rr = min(vr, vc), cc = max(vr, vc);
     double s = 0;
-    for (int k = 0; k < ns; k++) s += D.Sp[(size_t)k * D.sp_stride + (size_t)rr * D.ldS + cc];
+    if (redS)
+      s = redS[(size_t)rr * (npv + 1) + cc];
+    else
+      for (int k = 0; k < ns; k++) s += D.Sp[(size_t)k * D.sp_stride + (size_t)rr * D.ldS + cc];
     v = -s;
-    if (a == b) v += D.Hpp[36 * (size_t)a + ra * 6 + cb];
+    if (a == b) v += redH[36 * (size_t)a + ra * 6 + cb];
   }
   int ein = -1, eout = -1;
   if (pd == 15) {
@@ -614,8 +654,11 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
   if (c == 0) {
     double g = 0, t = 0;
     if (ra < 6) {
-      g = D.bp[6 * a + ra];
-      for (int k = 0; k < ns; k++) t += D.Sp[(size_t)k * D.sp_stride + (size_t)(6 * a + ra) * D.ldS + npv];
+      g = redb[6 * a + ra];
+      if (redS)
+        t = redS[(size_t)(6 * a + ra) * (npv + 1) + npv];
+      else
+        for (int k = 0; k < ns; k++) t += D.Sp[(size_t)k * D.sp_stride + (size_t)(6 * a + ra) * D.ldS + npv];
     }
     if (ein >= 0) g += D.Ae[930 * (size_t)ein + 900 + 15 + ra];
     if (eout >= 0) g += D.Ae[930 * (size_t)eout + 900 + ra];
@@ -1007,9 +1050,19 @@ static bool inverse9(const double* A, double* Ainv) {
   return true;
 }
 
+struct LbaShard {  // landmark-sharded run: every rank holds all key frames and its share of the points
+  vieo_allreduce_sum_f64_fn fn;
+  void* ctx;
+  double* d_buf;
+  size_t cap;
+};
+
+static size_t shard_sys_doubles(int nf) { return (size_t)6 * nf * (6 * nf + 1) + 36 * (size_t)nf + 6 * (size_t)nf; }
+
 // Both local BAs: vparams == nullptr -> Optimizer::LocalBundleAdjustment (params), otherwise
-// LocalBundleAdjustmentNavStatePRV (vparams, h_close, h_imu, n_imu).
-static int lba_run(int n_windows, const vieo_lba_params* const* params,
+// LocalBundleAdjustmentNavStatePRV (vparams, h_close, h_imu, n_imu).  sh != nullptr: this process is one
+// rank of a landmark-sharded run.
+static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* const* params,
                    const vieo_lba_vio_params* const* vparams, const vieo_lba_keyframe* const* h_kfs,
                    const int* n_kf, const float* const* h_points, const uint8_t* const* h_close,
                    const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
@@ -1018,6 +1071,10 @@ static int lba_run(int n_windows, const vieo_lba_params* const* params,
                    vieo_lba_result* h_results) {
   const bool vio = vparams != nullptr;
   const int pd = vio ? 15 : 6;
+  if (sh && (!vio || !sh->fn || !sh->d_buf || (stop && *stop))) {
+    set_error("sharded local BA: visual-inertial windows only, with a reduction callback and buffer");
+    return VIEO_E_INVALID;
+  }
   if (n_windows <= 0 || (!vio && !params) || !h_kfs || !n_kf || !h_points || !n_mp || !h_obs || !n_obs ||
       !h_navs_out || !h_points_out || !h_erase || !h_results || (vio && (!h_close || !h_imu || !n_imu)))
     return VIEO_E_INVALID;
@@ -1255,7 +1312,7 @@ static int lba_run(int n_windows, const vieo_lba_params* const* params,
   const size_t small_bytes = (size_t)W * (sizeof(LbaDev) + sizeof(WinCtl) + sizeof(WinOut));
   if ((rc = g_arena.ensure(arena)) != VIEO_OK) return rc;
   if ((rc = g_small.ensure(small_bytes)) != VIEO_OK) return rc;
-  if ((rc = g_small_h.ensure((size_t)W * (sizeof(WinCtl) + sizeof(WinOut)))) != VIEO_OK) return rc;
+  if ((rc = g_small_h.ensure((size_t)W * (sizeof(WinCtl) + sizeof(WinOut) + 32))) != VIEO_OK) return rc;
   uint8_t* base = g_arena.as<uint8_t>();
   for (int w = 0; w < W; w++) {
     if (win[w].skip) continue;
@@ -1282,11 +1339,25 @@ static int lba_run(int n_windows, const vieo_lba_params* const* params,
       D.kf_in = (const int*)(base + o.kf_in), D.kf_out = (const int*)(base + o.kf_out);
     }
   }
+  size_t shard_sys = 0;
+  if (sh) {
+    for (int w = 0; w < W; w++) {
+      if (win[w].skip) continue;
+      devs[w].red = sh->d_buf + shard_sys;
+      shard_sys += shard_sys_doubles(devs[w].nf_cap);
+    }
+    if (shard_sys + 4 * (size_t)W > sh->cap) {
+      set_error("sharded local BA: reduction buffer too small (%zu doubles needed)", shard_sys + 4 * (size_t)W);
+      return VIEO_E_CAPACITY;
+    }
+    for (int w = 0; w < W; w++) devs[w].red_sc = sh->d_buf + shard_sys + 4 * (size_t)w;
+  }
   LbaDev* dD = g_small.as<LbaDev>();
   WinCtl* dC = (WinCtl*)(dD + W);
   WinOut* dO = (WinOut*)(dC + W);
   WinCtl* ctl = (WinCtl*)g_small_h.p;
   WinOut* out = (WinOut*)(ctl + W);
+  double* h_sc = (double*)(out + W);  // reduced scalars of a sharded run
   VIEO_HIP_CHECK(hipMemcpyAsync(base, hs, res_end, hipMemcpyHostToDevice, st));
   VIEO_HIP_CHECK(hipMemsetAsync(base + res_end, 0, zero_end - res_end, st));
   VIEO_HIP_CHECK(hipMemcpyAsync(dD, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
@@ -1349,6 +1420,16 @@ static int lba_run(int n_windows, const vieo_lba_params* const* params,
     if (any & LBA_BEGIN) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);
     if (any & LBA_TRIAL) {
       hipLaunchKernelGGL(k_lba_schur, dim3(nbt_max * ksplit, W), dim3(256), 0, st, dD, dC, dO, ksplit);
+      if (sh) {  // the one exchange step of the path: sum the reduced visual system over the ranks
+        const int nv = 6 * max_nf;
+        hipLaunchKernelGGL(k_lba_pack, dim3((nv * (nv + 1) + 36 * max_nf + nv + 255) / 256, W), dim3(256), 0, st,
+                           dD, dC, ksplit);
+        VIEO_HIP_CHECK(hipStreamSynchronize(st));
+        if (sh->fn(sh->ctx, sh->d_buf, shard_sys) != 0) {
+          set_error("sharded local BA: the all-reduce callback failed");
+          return VIEO_E_INVALID;
+        }
+      }
       hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO,
                          ksplit);
       if (vio)
@@ -1359,6 +1440,14 @@ static int lba_run(int n_windows, const vieo_lba_params* const* params,
       hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
       if (vio && max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
       hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      if (sh) {  // chi2 and the landmark part of the gain-ratio scale
+        VIEO_HIP_CHECK(hipStreamSynchronize(st));
+        if (sh->fn(sh->ctx, sh->d_buf + shard_sys, 4 * (size_t)W) != 0) {
+          set_error("sharded local BA: the all-reduce callback failed");
+          return VIEO_E_INVALID;
+        }
+        VIEO_HIP_CHECK(hipMemcpyAsync(h_sc, sh->d_buf + shard_sys, 32 * (size_t)W, hipMemcpyDeviceToHost, st));
+      }
       VIEO_HIP_CHECK(hipMemcpyAsync(out, dO, (size_t)W * sizeof(WinOut), hipMemcpyDeviceToHost, st));
     }
     VIEO_HIP_CHECK(hipGetLastError());
@@ -1368,6 +1457,9 @@ static int lba_run(int n_windows, const vieo_lba_params* const* params,
       WinHost& H = win[w];
       const int fl = ctl[w].flags;
       if (!(fl & LBA_TRIAL)) continue;
+      if (sh)  // totals = all ranks' visual edges + the inertial edges
+        out[w].chi0 = h_sc[4 * w] + out[w].chig0, out[w].chi2 = h_sc[4 * w + 1] + out[w].chig,
+        out[w].scale_l = h_sc[4 * w + 2];
       if (fl & LBA_BEGIN) {
         if (out[w].np == 0) {  // no active free vertex: optimize() returns at once
           H.phase = 2;
@@ -1469,7 +1561,7 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
                                        volatile const int* stop, vieo_navstate* const* h_navs_out,
                                        float* const* h_points_out, uint8_t* const* h_erase,
                                        vieo_lba_result* h_results) {
-  return lba_run(n_windows, params, nullptr, h_kfs, n_kf, h_points, nullptr, n_mp, h_obs, n_obs, nullptr, nullptr,
+  return lba_run(nullptr, n_windows, params, nullptr, h_kfs, n_kf, h_points, nullptr, n_mp, h_obs, n_obs, nullptr, nullptr,
                  stop, h_navs_out, h_points_out, h_erase, h_results);
 }
 
@@ -1493,8 +1585,29 @@ int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_par
                                            float* const* h_points_out, uint8_t* const* h_erase,
                                            vieo_lba_result* h_results) {
   if (!params) return VIEO_E_INVALID;
-  return lba_run(n_windows, nullptr, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu, n_imu,
+  return lba_run(nullptr, n_windows, nullptr, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu, n_imu,
                  stop, h_navs_out, h_points_out, h_erase, h_results);
+}
+
+size_t vieo_lba_sharded_buffer_doubles(int n_windows, const int* n_free_kf) {
+  size_t n = 0;
+  for (int w = 0; w < n_windows; w++) n += shard_sys_doubles(n_free_kf ? n_free_kf[w] : 0) + 4;
+  return n;
+}
+
+int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_params* const* params,
+                                             const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                             const float* const* h_points, const uint8_t* const* h_close,
+                                             const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                             const vieo_lba_imu_edge* const* h_imu, const int* n_imu,
+                                             double* d_reduce_buf, size_t reduce_cap_doubles,
+                                             vieo_allreduce_sum_f64_fn allreduce, void* ctx,
+                                             vieo_navstate* const* h_navs_out, float* const* h_points_out,
+                                             uint8_t* const* h_erase, vieo_lba_result* h_results) {
+  if (!params) return VIEO_E_INVALID;
+  LbaShard sh{allreduce, ctx, d_reduce_buf, reduce_cap_doubles};
+  return lba_run(&sh, n_windows, nullptr, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu,
+                 n_imu, nullptr, h_navs_out, h_points_out, h_erase, h_results);
 }
 
 int vieo_local_bundle_adjustment_vio(const vieo_lba_vio_params* P, const vieo_lba_keyframe* h_kfs, int n_kf,

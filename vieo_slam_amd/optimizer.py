@@ -121,3 +121,53 @@ class Optimizer:
             ptrs[6].ctypes.data, ptrs[7].ctypes.data, ptrs[8].ctypes.data, res.ctypes.data),
             "vieo_local_bundle_adjustment_vio_batch")
         return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
+
+    @staticmethod
+    def sharded_buffer_doubles(windows):
+        """Doubles the reduction buffer of LocalBundleAdjustmentNavStatePRVSharded needs."""
+        nf = np.array([int((np.asarray(w[1]["fixed"]) == 0).sum()) for w in windows], np.int32)
+        return int(lib().vieo_lba_sharded_buffer_doubles(len(windows), nf.ctypes.data))
+
+    @staticmethod
+    def LocalBundleAdjustmentNavStatePRVSharded(windows, reduce_ptr, reduce_doubles, allreduce):
+        """This rank's part of landmark-sharded visual-inertial windows.  windows: the
+        rank's shards (sharding.shard_window); reduce_ptr: device pointer of a float64 buffer of
+        reduce_doubles entries; allreduce(offset, n): in-place sum over the ranks of entries
+        [offset, offset + n) of that buffer, complete on return (sharding.torch_allreduce).  Returns per window
+        (navs, points, erase, result)."""
+        import ctypes
+        W = len(windows)
+        keep, outs = [], []
+        ptrs = [np.zeros(W, np.uint64) for _ in range(9)]
+        cnt = [np.zeros(W, np.int32) for _ in range(4)]
+        res = np.zeros(W, LBA_RESULT_DTYPE)
+        for w, (params, kfs, points, close, obs, imu) in enumerate(windows):
+            params, kfs, imu = np.ascontiguousarray(params), np.ascontiguousarray(kfs), np.ascontiguousarray(imu)
+            points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+            close = np.ascontiguousarray(close, np.uint8)
+            navs = np.zeros(len(kfs), NAVSTATE_DTYPE)
+            pts = np.zeros_like(points)
+            erase = np.zeros(max(len(obs), 1), np.uint8)
+            keep.append((params, kfs, points, close, obs, imu))
+            outs.append((navs, pts, erase, len(obs)))
+            for a, arr in zip(ptrs, (params, kfs, points, close, obs, imu, navs, pts, erase)):
+                a[w] = arr.ctypes.data
+            cnt[0][w], cnt[1][w], cnt[2][w], cnt[3][w] = len(kfs), len(points), len(obs), len(imu)
+        CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+        base = int(reduce_ptr)
+
+        def _cb(ctx, d_buf, n):
+            try:
+                return int(allreduce((int(d_buf) - base) // 8, int(n)))
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = CB(_cb)
+        check(lib().vieo_local_bundle_adjustment_vio_sharded(
+            W, ptrs[0].ctypes.data, ptrs[1].ctypes.data, cnt[0].ctypes.data, ptrs[2].ctypes.data,
+            ptrs[3].ctypes.data, cnt[1].ctypes.data, ptrs[4].ctypes.data, cnt[2].ctypes.data,
+            ptrs[5].ctypes.data, cnt[3].ctypes.data, ctypes.c_void_p(base), reduce_doubles,
+            ctypes.cast(cb, ctypes.c_void_p), None, ptrs[6].ctypes.data, ptrs[7].ctypes.data,
+            ptrs[8].ctypes.data, res.ctypes.data), "vieo_local_bundle_adjustment_vio_sharded")
+        return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]

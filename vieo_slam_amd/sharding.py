@@ -34,3 +34,37 @@ def max_over_ranks(dist, value, device=None):
 def aggregate_throughput(frames_per_rank_per_step, steps, world, elapsed_max_s):
     """Whole-job frames/s: all ranks' frames over the slowest rank's time."""
     return frames_per_rank_per_step * steps * world / elapsed_max_s
+
+
+# ---- one LocalBundleAdjustmentNavStatePRV window over several GPUs (SURVEY.md 8e) ----------------
+def shard_window(window, rank, world):
+    """Landmark shard of a visual-inertial window (params, kfs, points, close, obs, imu): the points
+    with index % world == rank and their observations (renumbered, still grouped by point); key
+    frames and inertial edges are replicated.  Returns (window_shard, point_index) where point_index
+    maps the shard's points back to the window's."""
+    import numpy as np
+    params, kfs, points, close, obs, imu = window
+    mine = np.nonzero(np.arange(len(points)) % world == rank)[0]
+    remap = -np.ones(len(points), np.int64)
+    remap[mine] = np.arange(len(mine))
+    sel = remap[obs["mp"]] >= 0
+    o = obs[sel].copy()
+    o["mp"] = remap[o["mp"]]
+    return (params, kfs, np.ascontiguousarray(points[mine]), np.ascontiguousarray(np.asarray(close)[mine]), o,
+            imu), mine
+
+
+def torch_allreduce(buf):
+    """Reduction callback for Optimizer.LocalBundleAdjustmentNavStatePRVSharded on top of
+    torch.distributed (backend nccl = RCCL over xGMI; gloo with a CPU tensor in the tests): `buf` is the
+    float64 tensor whose storage was handed to the C-ABI as the reduction buffer."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(offset, n):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(buf[offset:offset + n], op=dist.ReduceOp.SUM)
+        if buf.is_cuda:
+            torch.cuda.synchronize(buf.device)
+        return 0
+    return fn
