@@ -194,6 +194,11 @@ typedef struct vieo_sbp_camera {
 
 #define VIEO_SBP_LAST_FRAME 0 /* accept best <= TH_HIGH, rotation histogram (ORBmatcher.cc:1303-1467) */
 #define VIEO_SBP_LOCAL_MAP 1  /* best/second ratio test when same level (ORBmatcher.cc:230-335) */
+#define VIEO_SBP_RELOC 2      /* a14 ORBmatcher.cc:1471-1606: SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th,
+                                * ORBdist): keys holding ANY map point are skipped, no stereo gate, best only,
+                                * accepted if dist <= ORBdist (passed in nn_ratio), rotation histogram as mode 0;
+                                * queries = the key frame's map points (not in sAlreadyFound) projected with
+                                * levels [L-1, L+1], radius th*scale[L], angle = pKF->mvKeys[i].angle */
 #define VIEO_SBP_UNCHANGED (-1)
 #define VIEO_SBP_ERASED (-2)
 

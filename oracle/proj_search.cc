@@ -120,14 +120,16 @@ static int search(int mode, const vieo_proj_query* Q, int nq, FrameFeat& F, cons
     int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
     for (size_t k = 0; k < vIndices.size(); k++) {
       const size_t idx = vIndices[k];
-      if (F.mp[idx] != -1)
+      if (mode == VIEO_SBP_RELOC) {
+        if (F.mp[idx] != -1) continue;  // if (curfmps[i2]) continue;  ORBmatcher.cc:1553-1555
+      } else if (F.mp[idx] != -1)
         if (F.mp_observed[idx]) continue;
-      if (F.uright[idx] > 0) {
+      if (mode != VIEO_SBP_RELOC && F.uright[idx] > 0) {
         const float er = fabs(p.ur - F.uright[idx]);
         if (er > p.radius) continue;
       }
       const int dist = vo_descriptor_distance(p.desc, F.desc + idx * 32);
-      if (mode == VIEO_SBP_LAST_FRAME) {
+      if (mode != VIEO_SBP_LOCAL_MAP) {
         if (dist < bestDist) {
           bestDist = dist;
           bestIdx = (int)idx;
@@ -145,7 +147,7 @@ static int search(int mode, const vieo_proj_query* Q, int nq, FrameFeat& F, cons
         }
       }
     }
-    if (bestDist <= TH_HIGH_) {
+    if (bestDist <= (mode == VIEO_SBP_RELOC ? (int)nnratio : TH_HIGH_)) {  // ORBdist, ORBmatcher.cc:1571
       if (mode == VIEO_SBP_LOCAL_MAP)
         if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
       // AddMapPoint(pMP, bestIdx)
@@ -153,7 +155,7 @@ static int search(int mode, const vieo_proj_query* Q, int nq, FrameFeat& F, cons
       F.mp_observed[bestIdx] = (p.flags & 2) ? 1 : 0;
       assign[bestIdx] = q;
       nmatches++;
-      if (mode == VIEO_SBP_LAST_FRAME && checkOri) {
+      if (mode != VIEO_SBP_LOCAL_MAP && checkOri) {
         float rot = p.angle - F.keys[bestIdx].angle;
         if (rot < 0.0) rot += 360.0f;
         int bin = (int)round(rot * factor);
@@ -162,7 +164,7 @@ static int search(int mode, const vieo_proj_query* Q, int nq, FrameFeat& F, cons
       }
     }
   }
-  if (mode == VIEO_SBP_LAST_FRAME && checkOri) {
+  if (mode != VIEO_SBP_LOCAL_MAP && checkOri) {
     int ind1 = -1, ind2 = -1, ind3 = -1;
     ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
     for (int i = 0; i < HISTO_LENGTH; i++)

@@ -157,3 +157,38 @@ def test_gpu_sbp_edge_cases(oracle):
     on, oa = oracle.search_by_projection(0, q2, kl, ur, dl, None, BOUNDS)
     hn, ha = m.SearchByProjectionLastFrame(q2, kl, ur, dl, None, BOUNDS)
     assert on == hn and np.array_equal(oa, ha)
+
+
+def test_oracle_reloc_variant_rules(oracle):
+    """a14 (ORBmatcher.cc:1471-1606): keys holding any map point are skipped even when that point has no
+    observations, the stereo coordinate is not checked, acceptance is dist <= ORBdist."""
+    kl, dl, ur, pts, cam = _scenario(oracle, 1010, observed=False)
+    q = oracle.sbp_project_last_frame(pts, cam)
+    q["level_min"], q["level_max"] = pts["octave"] - 1, pts["octave"] + 1
+    n0, a0 = oracle.search_by_projection(2, q, kl, ur, dl, None, BOUNDS, nn_ratio=100.0)
+    assert n0 > 100
+    # mode 0 lets a second query re-claim a key whose holder has no observations; mode 2 never does
+    claimed = a0[a0 >= 0]
+    assert len(np.unique(claimed)) == len(claimed)
+    # a stricter ORBdist only removes matches
+    n1, a1 = oracle.search_by_projection(2, q, kl, ur, dl, None, BOUNDS, nn_ratio=30.0, check_ori=False)
+    n2, a2 = oracle.search_by_projection(2, q, kl, ur, dl, None, BOUNDS, nn_ratio=100.0, check_ori=False)
+    assert n1 <= n2 and np.all((a1 < 0) | (a1 == a2))
+    # ruining the stereo coordinates changes nothing (no gate in this variant)
+    n3, a3 = oracle.search_by_projection(2, q, kl, np.full_like(ur, 5.0), dl, None, BOUNDS, nn_ratio=100.0)
+    assert n3 == n0 and np.array_equal(a3, a0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,orbdist", [(1011, 100), (1012, 64), (1013, 50)])
+def test_gpu_sbp_reloc_parity(oracle, seed, orbdist):
+    kl, dl, ur, pts, cam = _scenario(oracle, seed, th=10.0, observed=(seed % 2 == 0))
+    q = oracle.sbp_project_last_frame(pts, cam)
+    q["level_min"], q["level_max"] = pts["octave"] - 1, pts["octave"] + 1
+    rng = np.random.default_rng(seed)
+    m = _hip_matcher()
+    for taken in (None, (rng.random(len(kl)) < 0.4).astype(np.uint8)):
+        on, oa = oracle.search_by_projection(2, q, kl, ur, dl, taken, BOUNDS, nn_ratio=float(orbdist))
+        hn, ha = m.SearchByProjectionKeyFrame(q, kl, ur, dl, taken, BOUNDS, orbdist)
+        assert on == hn and np.array_equal(oa, ha)
+        assert on > 30

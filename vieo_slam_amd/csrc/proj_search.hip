@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
         if (maxlevel >= 0 && oct > maxlevel) return false;
       }
       if (!(fabsf(k.x - x) < r && fabsf(k.y - y) < r)) return false;
-      if (k.z > 0 && fabsf(q_ur - k.z) > r) return false;
+      if (A.mode != VIEO_SBP_RELOC && k.z > 0 && fabsf(q_ur - k.z) > r) return false;
       return true;
     };
     auto encode = [&](int slot, int packed) -> unsigned {
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
   if (lane < kHistoLen) s_hist[lane] = 0;
   __syncthreads();
   int nmatches = 0, nlog = 0, overflow = 0;
-  const bool ori = A.mode == VIEO_SBP_LAST_FRAME && A.check_ori;
+  const bool ori = A.mode != VIEO_SBP_LOCAL_MAP && A.check_ori;
   for (int q0 = 0; q0 < nq; q0 += 64) {
     const int2 mine = q0 + lane < nq ? qrec[q0 + lane] : make_int2(0, 0);
     const int qn = min(64, nq - q0);
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
           const unsigned c = off + pos < n_lds ? s_pool[off + pos] : pool[off + pos];
           const int idx = c & 0xFFF, d = (c >> 12) & 0x1FF;
           const int st = s_state[idx];
-          if (!((st & 1) && (st & 2))) {
+          if (A.mode == VIEO_SBP_RELOC ? !(st & 1) : !((st & 1) && (st & 2))) {
             const unsigned key = ((unsigned)d << 8) | (unsigned)pos;  // (dist, order)
             if (key < b0) {
               b1 = b0, c1 = c0;
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
       if (b0 == 0xFFFFFFFFu) continue;
       const int bestDist = b0 >> 8;
       const int bestIdx = c0 & 0xFFF, bestLevel = (c0 >> 21) & 15;
-      if (bestDist > kThHigh) continue;
+      if (bestDist > (A.mode == VIEO_SBP_RELOC ? (int)A.nn_ratio : kThHigh)) continue;
       if (A.mode == VIEO_SBP_LOCAL_MAP && b1 != 0xFFFFFFFFu) {
         const int bestDist2 = b1 >> 8;
         const int bestLevel2 = (c1 >> 21) & 15;
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
       __syncthreads();  // single wave: orders the LDS state update before the next query
     }
   }
-  if (A.mode == VIEO_SBP_LAST_FRAME && A.check_ori) {
+  if (ori) {
     __syncthreads();
     // ComputeThreeMaxima (ORBmatcher.cc:1608-1641), evaluated redundantly by every lane
     int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -542,7 +542,7 @@ int vieo_search_by_projection_batch_device(int mode, const vieo_proj_query* d_qu
                                            int32_t* d_nmatches, void* stream) {
   if (!d_queries || !d_nq || q_cap <= 0 || n_frames <= 0 || !d_keys || !d_uright || !d_desc ||
       !d_counts || !h_bounds || !d_assign || !d_nmatches ||
-      (mode != VIEO_SBP_LAST_FRAME && mode != VIEO_SBP_LOCAL_MAP))
+      (mode != VIEO_SBP_LAST_FRAME && mode != VIEO_SBP_LOCAL_MAP && mode != VIEO_SBP_RELOC))
     return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;

@@ -34,7 +34,7 @@ class ORBmatcher:
     """ORBmatcher(nnratio=0.6, checkOri=True) (reference include/ORBmatcher.h:25-101), tracking-side
     searches on flattened inputs (ba_types.PROJ_QUERY_DTYPE etc.)."""
     TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
-    SBP_LAST_FRAME, SBP_LOCAL_MAP = 0, 1
+    SBP_LAST_FRAME, SBP_LOCAL_MAP, SBP_RELOC = 0, 1, 2
 
     def __init__(self, nnratio=0.6, checkOri=True):
         self.mfNNratio = float(nnratio)
@@ -50,7 +50,7 @@ class ORBmatcher:
                                                 q.ctypes.data), "vieo_sbp_project_last_frame")
         return q
 
-    def _search(self, mode, queries, keys, uright, desc, taken, bounds):
+    def _search(self, mode, queries, keys, uright, desc, taken, bounds, ratio=None):
         import ctypes
         queries = np.ascontiguousarray(queries)
         keys = np.ascontiguousarray(keys)
@@ -63,7 +63,7 @@ class ORBmatcher:
         check(lib().vieo_search_by_projection(mode, queries.ctypes.data, len(queries),
                                               keys.ctypes.data, uright.ctypes.data, desc.ctypes.data,
                                               None if tk is None else tk.ctypes.data, len(keys),
-                                              b.ctypes.data, self.mfNNratio,
+                                              b.ctypes.data, self.mfNNratio if ratio is None else float(ratio),
                                               int(self.mbCheckOrientation), assign.ctypes.data,
                                               ctypes.byref(n)), "vieo_search_by_projection")
         return n.value, assign[:len(keys)]
@@ -72,6 +72,12 @@ class ORBmatcher:
         """SearchByProjection(Frame&, const Frame&, th, bMono, th_far) (ORBmatcher.cc:1303-1467)
         after project_last_frame(); returns (nmatches, assign[n_keys])."""
         return self._search(self.SBP_LAST_FRAME, queries, keys, uright, desc, taken, bounds)
+
+    def SearchByProjectionKeyFrame(self, queries, keys, uright, desc, taken, bounds, ORBdist):
+        """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist, th_far) (ORBmatcher.cc:1471-1606,
+        relocalisation) on the key frame's projected map points; `taken` marks the keys that already hold
+        a map point.  returns (nmatches, assign[n_keys])."""
+        return self._search(self.SBP_RELOC, queries, keys, uright, desc, taken, bounds, ratio=ORBdist)
 
     def SearchByProjectionLocalMap(self, queries, keys, uright, desc, taken, bounds):
         """SearchByProjection(Frame&, vector<MapPoint*>&, th, th_far) (ORBmatcher.cc:230-335) on
