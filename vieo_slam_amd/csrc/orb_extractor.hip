@@ -174,9 +174,6 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
     for (int idx = lane; idx < ((vh + 2) * sp + 15) / 16; idx += 64) ((uint4*)sc)[idx] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   const int xo = cd.x0 - x0a;
-  // lanes tile the cell interior row-major: vwp (32 or 64) lanes per row, 64 / vwp rows per step
-  const int sh = vw <= 32 ? 5 : 6, rows_per = 64 >> sh;
-  const int lx = lane & ((1 << sh) - 1), ly = lane >> sh;
   unsigned* out = cell_keys + ((size_t)b * P.ncells + c) * P.cell_cap;
   int base = 0;
   // cv::FAST at iniThFAST, and only for a cell without any corner again at minThFAST
@@ -185,17 +182,71 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
   for (int round = 0; round < 2 && base == 0; round++) {
     if (round == 1 && minTh >= iniTh) break;
     const int th = round == 0 ? iniTh : minTh;
-    // ---- pass A: compass test, ordered compaction of the surviving pixels (y << 6 | x)
+    // ---- pass A: compass test (see fast_compass) on FOUR horizontally adjacent pixels per lane: the
+    // centre row and the rows 3 above / below are read as dwords, realigned with v_alignbyte (the byte
+    // offset is the same for every lane), widened to 16-bit pairs and compared with packed min / max:
+    //   dark  <=> min(max(eU, eD), max(eL, eR)) >  t,   bright <=> max(min(eU, eD), min(eL, eR)) < -t,
+    // e = centre - ring.  Ordered compaction of the surviving pixels (y << 6 | x), 4 rows per step.
     int na = 0;
-    if (npx > 0)
-      for (int y0 = 0; y0 < vh; y0 += rows_per) {
-        const int y = y0 + ly;
-        bool pass = false;
-        if (lx < vw && y < vh) pass = fast_compass(tile + (y + 3) * tpitch + (lx + 3 + xo), tpitch, th);
-        const unsigned long long m = __ballot(pass);
-        if (pass) cand[na + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((y << 6) | lx);
-        na += __popcll(m);
+    if (npx > 0) {
+      typedef short s2 __attribute__((ext_vector_type(2)));
+      const int s = (3 + xo) & 3, kq = (3 + xo) >> 2;  // centre byte of pixel x sits at 4 * (lx4 + kq) + s
+      const int lx4 = lane & 15, ly4 = lane >> 4;
+      const int x0 = 4 * lx4;
+      const unsigned th1 = (unsigned)(th + 1) * 0x00010001u, thp = (unsigned)th * 0x00010001u;
+      for (int y0 = 0; y0 < vh; y0 += 4) {
+        const int y = y0 + ly4;
+        unsigned m4 = 0;
+        if (x0 < vw && y < vh) {
+          const unsigned* rc = (const unsigned*)(tile + (y + 3) * tpitch) + lx4 + kq;
+          const unsigned* ru = (const unsigned*)(tile + y * tpitch) + lx4 + kq;
+          const unsigned* rd = (const unsigned*)(tile + (y + 6) * tpitch) + lx4 + kq;
+          const unsigned wm = rc[-1], w0 = rc[0], w1 = rc[1], w2 = rc[2];
+          const unsigned u0 = ru[0], u1 = ru[1], d0 = rd[0], d1 = rd[1];
+          unsigned C, L, R, U, D;
+          if (s == 0)
+            C = w0, U = u0, D = d0, L = __builtin_amdgcn_alignbyte(w0, wm, 1), R = __builtin_amdgcn_alignbyte(w1, w0, 3);
+          else if (s == 1)
+            C = __builtin_amdgcn_alignbyte(w1, w0, 1), U = __builtin_amdgcn_alignbyte(u1, u0, 1),
+            D = __builtin_amdgcn_alignbyte(d1, d0, 1), L = __builtin_amdgcn_alignbyte(w0, wm, 2), R = w1;
+          else if (s == 2)
+            C = __builtin_amdgcn_alignbyte(w1, w0, 2), U = __builtin_amdgcn_alignbyte(u1, u0, 2),
+            D = __builtin_amdgcn_alignbyte(d1, d0, 2), L = __builtin_amdgcn_alignbyte(w0, wm, 3),
+            R = __builtin_amdgcn_alignbyte(w2, w1, 1);
+          else
+            C = __builtin_amdgcn_alignbyte(w1, w0, 3), U = __builtin_amdgcn_alignbyte(u1, u0, 3),
+            D = __builtin_amdgcn_alignbyte(d1, d0, 3), L = w0, R = __builtin_amdgcn_alignbyte(w2, w1, 2);
+          unsigned pk[2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const unsigned sel = h ? 0x0C030C02u : 0x0C010C00u;  // bytes (2h, 2h+1) -> two 16-bit lanes
+            const s2 c = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, C, sel));
+            const s2 eU = c - __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, U, sel));
+            const s2 eD = c - __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, D, sel));
+            const s2 eL = c - __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, L, sel));
+            const s2 eR = c - __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, R, sel));
+            const s2 mk = __builtin_elementwise_min(__builtin_elementwise_max(eU, eD), __builtin_elementwise_max(eL, eR));
+            const s2 nk = __builtin_elementwise_max(__builtin_elementwise_min(eU, eD), __builtin_elementwise_min(eL, eR));
+            // dark: mk - (t + 1) >= 0 (sign bit clear); bright: nk + t < 0 (sign bit set)
+            const unsigned t = __builtin_bit_cast(unsigned, mk - __builtin_bit_cast(s2, th1));
+            const unsigned u = __builtin_bit_cast(unsigned, nk + __builtin_bit_cast(s2, thp));
+            pk[h] = (~t | u) & 0x80008000u;
+          }
+          m4 = ((pk[0] >> 15) & 1u) | ((pk[0] >> 30) & 2u) | ((pk[1] >> 13) & 4u) | ((pk[1] >> 28) & 8u);
+          m4 &= (1u << min(vw - x0, 4)) - 1u;
+        }
+        // positions: exclusive prefix over the lanes of popcount(m4) from the ballots of its bits
+        const int cnt = __popc(m4);
+        const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int pos = na + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+        const unsigned key = (unsigned)((y << 6) | x0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (m4 & (1u << j)) cand[pos++] = (unsigned short)(key + j);
+        na += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
       }
+    }
     __syncthreads();
     // ---- pass B: exact strength of the survivors; those above the threshold are compacted in
     // place (still row-major: a wavefront reads its 64 entries before it writes any)
