@@ -212,7 +212,10 @@ def main():
     lba_chunk = a.lba_batch if a.lba_batch > 0 else max(1, n_lba)
     chunks = [list(range(i, min(i + lba_chunk, n_lba))) for i in range(0, n_lba, lba_chunk)]
 
+    from vieo_slam_amd._lib import check as _check, lib as _lib
+
     def run_lba(idx):
+        _check(_lib().vieo_set_device(local), "vieo_set_device")  # worker threads start on device 0
         t = time.perf_counter()
         r = Optimizer.LocalBundleAdjustmentNavStatePRVBatch([lba_problems[i % len(lba_problems)] for i in idx])
         lba_ms.append((time.perf_counter() - t) * 1e3 / len(idx))

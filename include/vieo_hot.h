@@ -30,6 +30,10 @@ extern "C" {
 const char* vieo_last_error(void);
 /* 1 if a usable gfx950 device is visible, 0 otherwise (never throws, never computes). */
 int vieo_device_available(void);
+/* One process per GPU: every host thread that calls into the library selects the process's GPU first
+ * (the HIP current device is per thread; torch.cuda.set_device covers only the calling thread). */
+int vieo_set_device(int device);
+int vieo_get_device(void);
 const char* vieo_version(void);
 
 /* ---- device memory / stream helpers (so a C, C++ or ctypes host needs no other runtime) ---- */

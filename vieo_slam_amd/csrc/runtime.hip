@@ -44,6 +44,23 @@ const char* vieo_version(void) { return "vieo_hot 0.1 (gfx950)"; }
 
 int vieo_device_available(void) { return vieo::require_device() == VIEO_OK ? 1 : 0; }
 
+// The HIP "current device" is a per-thread setting: a host thread that did not create the process's
+// context (a LocalMapping-side worker) starts on device 0 and must select its GPU itself.
+int vieo_set_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+    vieo::set_error("vieo_set_device: device %d of %d", device, n);
+    return VIEO_E_INVALID;
+  }
+  VIEO_HIP_CHECK(hipSetDevice(device));
+  return VIEO_OK;
+}
+
+int vieo_get_device(void) {
+  int dev = -1;
+  return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+
 int vieo_dev_malloc(void** d_ptr, size_t bytes) {
   if (!d_ptr) return VIEO_E_INVALID;
   int rc = vieo::require_device();
