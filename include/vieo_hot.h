@@ -356,11 +356,28 @@ typedef struct vieo_lba_obs {
   float inv_sigma2;
 } vieo_lba_obs;
 
+/* camm::Camera of one physical camera as an EdgeReproject sees it (a20: common/camera_models/
+ * camera_pinhole.h:70-106, camera_radtan.h:61-129, camera_kb8.h:68-157), with EdgeReproject::SetParams
+ * (g2otypes.h:409-416) already applied to the extrinsics: Rcb = Rccr * Rcrb, tcb = Rccr * tcrb + tcr. */
+#define VIEO_CAM_PINHOLE 0
+#define VIEO_CAM_RADTAN 1
+#define VIEO_CAM_KB8 2
+typedef struct vieo_camera {
+  int32_t model;   /* VIEO_CAM_* */
+  int32_t num_k;   /* Radtan: number of radial coefficients (parameters.size() - 6), else unused */
+  float fx, fy, cx, cy;
+  float dist[8];   /* Radtan: k1..k_num_k, p1, p2;  KB8: k1..k4 */
+  double Rcb[9], tcb[3];
+} vieo_camera;
+
 typedef struct vieo_lba_params {
   double Rcb[9], tcb[3];
   float fx, fy, cx, cy, bf;
   int32_t its0, its1;     /* 5 and 10 in the reference */
-  int32_t reserved;
+  int32_t n_cams;         /* 0: one rectified pinhole camera = the fields above (Frame::usedistort_ == false);
+                           * 1..4: `cams`, and bits 24..27 of vieo_lba_obs.kf select the observation's camera
+                           * (get<0>(pKFi->mapn2in_[idx])); distorted observations are monocular (ur < 0) */
+  const vieo_camera* cams; /* host pointer, n_cams entries */
 } vieo_lba_params;
 
 #define VIEO_LBA_OK 0

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../include/vieo_hot.h"
+#include "cam_models.hpp"
 #include "smallmat.hpp"
 
 namespace vo {
@@ -33,7 +34,7 @@ struct KFState {
 };
 
 struct LEdge {
-  int kf, mp, de, level = 0;
+  int kf, mp, de, level = 0, cam = 0;
   double obs[3], info, delta, dsqr;
   bool robust = true;
   double err[3] = {0, 0, 0};
@@ -41,6 +42,7 @@ struct LEdge {
 
 struct LBA {
   const vieo_lba_params* P;
+  OCam cams[4];
   std::vector<KFState> kf;
   std::vector<double> X;  // points, 3 per mp
   std::vector<LEdge> E;
@@ -48,17 +50,18 @@ struct LBA {
 
   void project(const LEdge& e, double* proj, double* Pc_out, double* Rcw_out) const {
     const KFState& s = kf[e.kf];
+    const OCam& C = cams[e.cam];
     double Rwb[9], Rbw[9], Rcw[9], t[3], Pc[3];
     quat_to_R(s.q, Rwb);
     m3_T(Rwb, Rbw);
-    m3_mul(P->Rcb, Rbw, Rcw);
+    m3_mul(C.Rcb, Rbw, Rcw);
     m3_v(Rcw, s.p, t);
     m3_v(Rcw, &X[3 * e.mp], Pc);
-    for (int i = 0; i < 3; i++) Pc[i] += -t[i] + P->tcb[i];
-    const double invz = 1. / Pc[2];
-    proj[0] = (float)((double)P->fx * Pc[0] * invz + P->cx);
-    proj[1] = (float)((double)P->fy * Pc[1] * invz + P->cy);
-    if (e.de > 2) proj[2] = proj[0] - (double)P->bf / Pc[2];
+    for (int i = 0; i < 3; i++) Pc[i] += -t[i] + C.tcb[i];
+    float uv[2];
+    ocam_project(C, Pc, uv, nullptr);
+    proj[0] = uv[0], proj[1] = uv[1];
+    if (e.de > 2) proj[2] = proj[0] - (double)C.bf / Pc[2];
     if (Pc_out) memcpy(Pc_out, Pc, 24);
     if (Rcw_out) memcpy(Rcw_out, Rcw, 72);
   }
@@ -82,22 +85,23 @@ struct LBA {
     double proj[3], Pc[3], Rcw[9];
     project(e, proj, Pc, Rcw);
     const KFState& s = kf[e.kf];
+    const OCam& C = cams[e.cam];
     const double invz = 1 / Pc[2], invz_2 = invz * invz;
-    double J[9] = {0};
-    J[0] = -(P->fx * invz), J[2] = -(-P->fx * Pc[0] * invz_2);
-    J[4] = -(P->fy * invz), J[5] = -(-P->fy * Pc[1] * invz_2);
-    if (e.de > 2) J[6] = J[0], J[7] = J[1], J[8] = J[2] - (double)P->bf * invz_2;
+    double J[9] = {0}, Jc[6];
+    ocam_project(C, Pc, nullptr, Jc);  // Jproj = -Jproj_tmp (g2otypes.h:453-459)
+    for (int i = 0; i < 6; i++) J[i] = -Jc[i];
+    if (e.de > 2) J[6] = J[0], J[7] = J[1], J[8] = J[2] - (double)C.bf * invz_2;
     double Rwb[9], dP[3], Paux[3], H[9], RcbH[9];
     quat_to_R(s.q, Rwb);
     for (int i = 0; i < 3; i++) dP[i] = X[3 * e.mp + i] - s.p[i];
     m3T_v(Rwb, dP, Paux);
     hat(Paux, H);
-    m3_mul(P->Rcb, H, RcbH);
+    m3_mul(C.Rcb, H, RcbH);
     for (int r = 0; r < e.de; r++)
       for (int k = 0; k < 3; k++) {
         double a = 0, b = 0, c = 0;
         for (int m = 0; m < 3; m++) {
-          a += J[r * 3 + m] * (-P->Rcb[m * 3 + k]);
+          a += J[r * 3 + m] * (-C.Rcb[m * 3 + k]);
           b += J[r * 3 + m] * RcbH[m * 3 + k];
           c += J[r * 3 + m] * Rcw[m * 3 + k];  // _jacobianOplus[0] = Jproj * Rcw
         }
@@ -349,6 +353,7 @@ static void local_ba(const vieo_lba_params& P, const vieo_lba_keyframe* kfs, int
   memset(erase, 0, n_obs);
   LBA B;
   B.P = &P;
+  ocams_from_params(P, B.cams);
   B.kf.resize(n_kf);
   bool any_free = false;
   for (int k = 0; k < n_kf; k++) {
@@ -370,7 +375,7 @@ static void local_ba(const vieo_lba_params& P, const vieo_lba_keyframe* kfs, int
   const float thHuberMono = sqrt(5.991), thHuberStereo = sqrt(7.815);
   for (int i = 0; i < n_obs; i++) {
     LEdge& e = B.E[i];
-    e.kf = obs[i].kf, e.mp = obs[i].mp;
+    e.kf = obs[i].kf & 0xFFFFFF, e.cam = (obs[i].kf >> 24) & 15, e.mp = obs[i].mp;
     e.obs[0] = obs[i].u, e.obs[1] = obs[i].v, e.obs[2] = obs[i].ur;
     e.de = obs[i].ur < 0 ? 2 : 3;
     e.info = (double)obs[i].inv_sigma2;
@@ -416,4 +421,14 @@ extern "C" void vo_local_bundle_adjustment(const vieo_lba_params* params, const 
                                            vieo_navstate* navs_out, float* points_out, uint8_t* erase,
                                            vieo_lba_result* result) {
   vo::local_ba(*params, kfs, n_kf, points, n_mp, obs, n_obs, stop, navs_out, points_out, erase, *result);
+}
+
+// test hook: camm::Camera::Project of one camera (image point as float, 2x3 Jacobian)
+extern "C" void vo_cam_project(const vieo_camera* cam, const double* P, float* uv, double* J) {
+  vieo_lba_params prm;
+  memset(&prm, 0, sizeof(prm));
+  prm.n_cams = 1, prm.cams = cam;
+  vo::OCam c[4];
+  vo::ocams_from_params(prm, c);
+  vo::ocam_project(c[0], P, uv, J);
 }

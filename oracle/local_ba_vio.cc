@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../include/vieo_hot.h"
+#include "cam_models.hpp"
 #include "smallmat.hpp"
 
 namespace vov {
@@ -32,7 +33,7 @@ struct KF {
 };
 
 struct VEdge {
-  int kf, mp, de, level = 0;
+  int kf, mp, de, level = 0, cam = 0;
   double obs[3], info, delta, dsqr;
   bool robust = true;
   double err[3] = {0, 0, 0};
@@ -102,6 +103,7 @@ static bool mat_inverse(const double* A, double* Ainv, int n) {
 
 struct W {
   const vieo_lba_vio_params* P;
+  OCam cams[4];
   std::vector<KF> kf;
   std::vector<double> X;
   std::vector<VEdge> E;
@@ -111,7 +113,7 @@ struct W {
   // ---- visual edge (identical to the vision-only LBA)
   void project(const VEdge& e, double* proj, double* Pc_out, double* Rcw_out) const {
     const KF& s = kf[e.kf];
-    const vieo_lba_params& C = P->base;
+    const OCam& C = cams[e.cam];
     double Rwb[9], Rbw[9], Rcw[9], t[3], Pc[3];
     quat_to_R(s.q, Rwb);
     m3_T(Rwb, Rbw);
@@ -119,9 +121,9 @@ struct W {
     m3_v(Rcw, s.p, t);
     m3_v(Rcw, &X[3 * e.mp], Pc);
     for (int i = 0; i < 3; i++) Pc[i] += -t[i] + C.tcb[i];
-    const double invz = 1. / Pc[2];
-    proj[0] = (float)((double)C.fx * Pc[0] * invz + C.cx);
-    proj[1] = (float)((double)C.fy * Pc[1] * invz + C.cy);
+    float uv[2];
+    ocam_project(C, Pc, uv, nullptr);
+    proj[0] = uv[0], proj[1] = uv[1];
     if (e.de > 2) proj[2] = proj[0] - (double)C.bf / Pc[2];
     if (Pc_out) memcpy(Pc_out, Pc, 24);
     if (Rcw_out) memcpy(Rcw_out, Rcw, 72);
@@ -142,14 +144,14 @@ struct W {
     return Pc[2] > 0.;
   }
   void v_linearize(const VEdge& e, double* Jp, double* Jx) const {
-    const vieo_lba_params& C = P->base;
+    const OCam& C = cams[e.cam];
     double proj[3], Pc[3], Rcw[9];
     project(e, proj, Pc, Rcw);
     const KF& s = kf[e.kf];
     const double invz = 1 / Pc[2], invz_2 = invz * invz;
-    double J[9] = {0};
-    J[0] = -(C.fx * invz), J[2] = -(-C.fx * Pc[0] * invz_2);
-    J[4] = -(C.fy * invz), J[5] = -(-C.fy * Pc[1] * invz_2);
+    double J[9] = {0}, Jc[6];
+    ocam_project(C, Pc, nullptr, Jc);
+    for (int i = 0; i < 6; i++) J[i] = -Jc[i];
     if (e.de > 2) J[6] = J[0], J[7] = J[1], J[8] = J[2] - (double)C.bf * invz_2;
     double Rwb[9], dP[3], Paux[3], H[9], RcbH[9];
     quat_to_R(s.q, Rwb);
@@ -564,6 +566,7 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
   memset(erase, 0, n_obs);
   W B;
   B.P = &P;
+  ocams_from_params(P.base, B.cams);
   B.kf.resize(n_kf);
   bool any_free = false;
   for (int k = 0; k < n_kf; k++) {
@@ -608,7 +611,7 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
   const float thHuberMono = sqrt(chi2Mono), thHuberStereo = sqrt(7.815);
   for (int i = 0; i < n_obs; i++) {
     VEdge& e = B.E[i];
-    e.kf = obs[i].kf, e.mp = obs[i].mp;
+    e.kf = obs[i].kf & 0xFFFFFF, e.cam = (obs[i].kf >> 24) & 15, e.mp = obs[i].mp;
     e.obs[0] = obs[i].u, e.obs[1] = obs[i].v, e.obs[2] = obs[i].ur;
     e.de = obs[i].ur < 0 ? 2 : 3;
     e.info = (double)obs[i].inv_sigma2;

@@ -140,6 +140,16 @@ class Oracle:
         self.L.vo_lba_navstate_inc(out.ctypes.data, d.ctypes.data)
         return out[0]
 
+    def cam_project(self, cam, P, jac=True):
+        cam = np.ascontiguousarray(cam).reshape(1)
+        P = np.ascontiguousarray(P, np.float64)
+        uv = np.zeros(2, np.float32)
+        J = np.zeros((2, 3))
+        V = ctypes.c_void_p
+        self.L.vo_cam_project.argtypes = [V, V, V, V]
+        self.L.vo_cam_project(cam.ctypes.data, P.ctypes.data, uv.ctypes.data, J.ctypes.data if jac else None)
+        return uv, J
+
     # ---- pose optimisation
     def pose_optimization(self, frame, obs):
         from vieo_slam_amd.ba_types import POSE_RESULT_DTYPE

@@ -196,3 +196,13 @@ def test_gpu_vio_lba_landmark_sharded_two_ranks_on_one_gpu(oracle):
     s1 = Optimizer.LocalBundleAdjustmentNavStatePRVSharded([win], b1.ptr, n1, lambda off, cnt: 0)[0]
     p1 = Optimizer.LocalBundleAdjustmentNavStatePRV(*win)
     assert s1[0].tobytes() == p1[0].tobytes() and np.array_equal(s1[1], p1[1]) and np.array_equal(s1[2], p1[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rig,seed", [("radtan", 70), ("kb8", 71)])
+def test_gpu_vio_lba_distorted_rig_parity(oracle, rig, seed):
+    """a18 on a distorted multi-camera rig (a20): per-observation camera, Radtan / KB8 projection."""
+    from vieo_slam_amd.optimizer import Optimizer
+    w = synth_ba.make_lba_vio_problem(seed, n_local=6, n_fixed=3, n_points=500, rig=rig)
+    win = w[:6]
+    _parity(oracle, win, Optimizer.LocalBundleAdjustmentNavStatePRV(*win))

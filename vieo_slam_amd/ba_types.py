@@ -42,9 +42,14 @@ VIO_RESULT_DTYPE = np.dtype([("base", POSE_RESULT_DTYPE), ("H_marg", "<f8", 225)
 LBA_KEYFRAME_DTYPE = np.dtype([("nav", NAVSTATE_DTYPE), ("fixed", "<i4"), ("reserved", "<i4")], align=True)
 LBA_OBS_DTYPE = np.dtype([("kf", "<i4"), ("mp", "<i4"), ("u", "<f4"), ("v", "<f4"), ("ur", "<f4"),
                           ("inv_sigma2", "<f4")], align=True)
+CAMERA_DTYPE = np.dtype([("model", "<i4"), ("num_k", "<i4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"),
+                         ("cy", "<f4"), ("dist", "<f4", 8), ("Rcb", "<f8", 9), ("tcb", "<f8", 3)], align=True)
+assert CAMERA_DTYPE.itemsize == 152
+# "cams" is a host pointer (array.ctypes.data of a CAMERA_DTYPE array the caller keeps alive)
 LBA_PARAMS_DTYPE = np.dtype([("Rcb", "<f8", 9), ("tcb", "<f8", 3), ("fx", "<f4"), ("fy", "<f4"),
                              ("cx", "<f4"), ("cy", "<f4"), ("bf", "<f4"), ("its0", "<i4"),
-                             ("its1", "<i4"), ("reserved", "<i4")], align=True)
+                             ("its1", "<i4"), ("n_cams", "<i4"), ("cams", "<u8")], align=True)
+assert LBA_PARAMS_DTYPE.itemsize == 136
 LBA_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_erase", "<i4"), ("lm_iterations", "<i4"),
                              ("lm_trials", "<i4"), ("chi2_initial", "<f8"), ("chi2_final", "<f8")],
                             align=True)
@@ -54,4 +59,4 @@ LBA_IMU_EDGE_DTYPE = np.dtype([("kf_i", "<i4"), ("kf_j", "<i4"), ("dt_kf", "<f8"
 LBA_VIO_PARAMS_DTYPE = np.dtype([("base", LBA_PARAMS_DTYPE), ("gw", "<f8", 3), ("inv_sigma_bg2", "<f8"),
                                  ("inv_sigma_ba2", "<f8"), ("lambda_init", "<f8"), ("rec_init", "<i4"),
                                  ("large", "<i4")], align=True)
-assert LBA_IMU_EDGE_DTYPE.itemsize == 1152 and LBA_VIO_PARAMS_DTYPE.itemsize == 184
+assert LBA_IMU_EDGE_DTYPE.itemsize == 1152 and LBA_VIO_PARAMS_DTYPE.itemsize == 192

@@ -17,7 +17,85 @@ struct Est {
 struct CamD {
   double fx, fy, cx, cy, bf;  // float parameters widened once
   double Rcb[9], tcb[3];
+  int model = 0, num_k = 0;   // VIEO_CAM_*; distortion coefficients (float, widened)
+  double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+
+// camm::{Pinhole,Radtan,KB8}Camera::Project (common/camera_models/camera_*.h): the image point as the
+// FLOAT the reference returns (Vec2data), and the 2x3 Jacobian d(u, v)/dPc when J != nullptr.
+// Parameters are float (Tdata), the arithmetic double (Tcalc).
+__device__ __forceinline__ void cam_project(const CamD& c, const double* P, double* uv, double* J) {
+  const double x = P[0], y = P[1], z = P[2];
+  if (c.model == 1) {  // Radtan, camera_radtan.h:61-129
+    const double invz = 1 / z;
+    double xn = x * invz, yn = y * invz;
+    const double x2 = xn * xn, y2 = yn * yn, xy = xn * yn, r2 = x2 + y2;
+    const double* kk = c.k;
+    const double* pp = c.k + c.num_k;
+    double fd = 1, term_r = 1;
+    for (int i = 0; i < c.num_k; ++i) {
+      term_r *= r2;
+      fd += kk[i] * term_r;
+    }
+    if (J) {
+      double fd2 = 0, coeff2 = 0;
+      term_r = 1;
+      for (int i = 2; i < c.num_k; ++i) {
+        coeff2 += 2;
+        fd2 += coeff2 * kk[i] * term_r;
+        term_r *= r2;
+      }
+      const double du_dx = c.fx * invz * (fd + fd2 * x2 + 2 * (pp[0] * yn + 3 * pp[1] * xn));
+      const double du_dy = c.fx * invz * (fd2 * xy + 2 * (pp[0] * xn + pp[1] * yn));
+      const double du_dz = -(xn * du_dx + yn * du_dy);
+      const double dv_dx = du_dy * c.fy / c.fx;
+      const double dv_dy = c.fy * invz * (fd + fd2 * y2 + 2 * (pp[1] * xn + 3 * pp[0] * yn));
+      const double dv_dz = -(xn * dv_dx + yn * dv_dy);
+      J[0] = du_dx, J[1] = du_dy, J[2] = du_dz, J[3] = dv_dx, J[4] = dv_dy, J[5] = dv_dz;
+    }
+    const double xd = xn * fd + 2 * pp[0] * xy + pp[1] * (r2 + 2 * x2);
+    const double yd = yn * fd + 2 * pp[1] * xy + pp[0] * (r2 + 2 * y2);
+    uv[0] = (double)(float)(c.fx * xd * (1. / 1.) + c.cx);
+    uv[1] = (double)(float)(c.fy * yd * (1. / 1.) + c.cy);
+    return;
+  }
+  if (c.model == 2) {  // KB8, camera_kb8.h:68-157
+    const double x2 = x * x, y2 = y * y, r2 = x2 + y2, r = sqrt(r2);
+    if (r > (double)1e-5f) {
+      const double theta = atan2(r, z), theta2 = theta * theta;
+      double thetad = c.k[3] * theta2;
+      thetad += c.k[2], thetad *= theta2, thetad += c.k[1], thetad *= theta2, thetad += c.k[0];
+      thetad *= theta2, thetad += 1, thetad *= theta;
+      const double mx = x * thetad / r, my = y * thetad / r;
+      uv[0] = (double)(float)(c.fx * mx * (1. / 1.) + c.cx);
+      uv[1] = (double)(float)(c.fy * my * (1. / 1.) + c.cy);
+      if (J) {
+        const double invr = 1. / r, d_r_d_x = x * invr, d_r_d_y = y * invr;
+        const double tmp = 1. / (z * z + r2);
+        const double d_thetad_x = d_r_d_x * z * tmp, d_thetad_y = d_r_d_y * z * tmp;
+        double dd = 9.0 * c.k[3] * theta2;
+        dd += 7.0 * c.k[2], dd *= theta2, dd += 5.0 * c.k[1], dd *= theta2, dd += 3.0 * c.k[0];
+        dd *= theta2, dd += 1.0;
+        const double invr2 = invr * invr;
+        J[0] = c.fx * (x * r * dd * d_thetad_x + y2 * thetad / r) * invr2;
+        J[1] = c.fx * x * (dd * d_thetad_y * r - y * thetad / r) * invr2;
+        J[2] = -c.fx * x * dd * tmp;
+        J[3] = J[1] * c.fy / c.fx;
+        J[4] = c.fy * (y * r * dd * d_thetad_y + x2 * thetad / r) * invr2;
+        J[5] = -c.fy * y * dd * tmp;
+      }
+      return;
+    }
+  }
+  const double invz = 1. / z;  // pinhole (also KB8's degenerate case)
+  uv[0] = (double)(float)(c.fx * x * invz + c.cx);
+  uv[1] = (double)(float)(c.fy * y * invz + c.cy);
+  if (J) {
+    const double invz2 = invz * invz;
+    J[0] = c.fx * invz, J[1] = 0, J[2] = -c.fx * x * invz2;
+    J[3] = 0, J[4] = c.fy * invz, J[5] = -c.fy * y * invz2;
+  }
+}
 
 __device__ __forceinline__ void quat_to_R(const Est& s, double* R) {
   const double tx = 2 * s.qx, ty = 2 * s.qy, tz = 2 * s.qz;

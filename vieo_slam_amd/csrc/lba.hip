@@ -99,9 +99,14 @@ struct LbaDev {
   size_t sp_stride;
   double *Hll, *bl, *Hpp, *bp, *Hs, *bs, *xp;
   double *part0, *part, *part_m, *pmax;  // per-block partials
-  CamD cam;
+  CamD cam;                       // the single rectified pinhole camera (n_cams == 0) ...
+  CamD cams[4];                   // ... or the physical cameras of a distorted multi-camera rig
+  int n_cams;
+  const unsigned char* ocam;      // [n_obs] camera of every observation (n_cams > 0)
   double dMono, dStereo;
 };
+
+__device__ __forceinline__ const CamD& obs_cam(const LbaDev& D, int i) { return D.n_cams ? D.cams[D.ocam[i]] : D.cam; }
 
 __device__ __forceinline__ void kf_xf(const CamD& c, const LbaKf& k, PoseXf& X) {
   Est e;
@@ -115,9 +120,9 @@ __device__ __forceinline__ double lba_edge_error(const CamD& c, const PoseXf& X,
                                                  const double* Xw, double* err, double* Pc) {
   for (int i = 0; i < 3; i++)
     Pc[i] = X.Rcw[i * 3] * Xw[0] + X.Rcw[i * 3 + 1] * Xw[1] + X.Rcw[i * 3 + 2] * Xw[2] + X.tcw[i];
-  const double invz = 1. / Pc[2];
-  const double u = (double)(float)(c.fx * Pc[0] * invz + c.cx);
-  const double v = (double)(float)(c.fy * Pc[1] * invz + c.cy);
+  double uv[2];
+  cam_project(c, Pc, uv, nullptr);
+  const double u = uv[0], v = uv[1];
   err[0] = (double)o.u - u;
   err[1] = (double)o.v - v;
   const double info = (double)o.inv_sigma2;
@@ -134,9 +139,10 @@ __device__ __forceinline__ double lba_edge_error(const CamD& c, const PoseXf& X,
 __device__ __forceinline__ void lba_jacobians(const CamD& c, const PoseXf& X, const double* kfp,
                                               const double* Xw, const double* Pc, double* Jp, double* Jx) {
   const double invz = 1 / Pc[2], invz2 = invz * invz;
-  double J[9];
-  J[0] = -(c.fx * invz), J[1] = 0, J[2] = -(-c.fx * Pc[0] * invz2);
-  J[3] = 0, J[4] = -(c.fy * invz), J[5] = -(-c.fy * Pc[1] * invz2);
+  double J[9], Jc[6], uv[2];
+  cam_project(c, Pc, uv, Jc);  // Jproj = -d(u, v)/dPc (g2otypes.h:453-459)
+  J[0] = -Jc[0], J[1] = -Jc[1], J[2] = -Jc[2];
+  J[3] = -Jc[3], J[4] = -Jc[4], J[5] = -Jc[5];
   J[6] = J[0], J[7] = J[1], J[8] = J[2] - c.bf * invz2;
   const double d0 = Xw[0] - kfp[0], d1 = Xw[1] - kfp[1], d2 = Xw[2] - kfp[2];
   double Pa[3], RH[9];
@@ -198,7 +204,7 @@ k_lba_classify(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) 
   double chi2 = e[0] * (info * e[0]) + e[1] * (info * e[1]);
   if (o.ur >= 0) chi2 += e[2] * (info * e[2]);
   PoseXf X;
-  kf_xf(D.cam, D.kf[o.kf], X);
+  kf_xf(obs_cam(D, i), D.kf[o.kf], X);
   const double* Xw = D.X + 3 * (size_t)o.mp;
   const double z = X.Rcw[6] * Xw[0] + X.Rcw[7] * Xw[1] + X.Rcw[8] * Xw[2] + X.tcw[2];
   const double th = o.ur >= 0 ? D.thStereo : ((D.close && D.close[o.mp]) ? D.thMonoClose : D.thMono);
@@ -220,9 +226,10 @@ k_lba_prelevel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) 
   if (i >= D.n_obs) return;
   const vieo_lba_obs o = D.obs[i];
   PoseXf X;
-  kf_xf(D.cam, D.kf[o.kf], X);
+  const CamD& C = obs_cam(D, i);
+  kf_xf(C, D.kf[o.kf], X);
   double err[3], Pc[3];
-  const double chi2 = lba_edge_error(D.cam, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
+  const double chi2 = lba_edge_error(C, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
   D.err[3 * (size_t)i] = err[0], D.err[3 * (size_t)i + 1] = err[1], D.err[3 * (size_t)i + 2] = err[2];
   const float th = 100.f * (o.ur >= 0 ? 7.815f : 5.991f);
   if (chi2 > (double)th) D.level[i] = 1;
@@ -296,9 +303,10 @@ k_lba_error(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   if (i < D.n_obs && D.level[i] == 0) {
     const vieo_lba_obs o = D.obs[i];
     PoseXf X;
-    kf_xf(D.cam, D.kf[o.kf], X);
+    const CamD& C = obs_cam(D, i);
+    kf_xf(C, D.kf[o.kf], X);
     double err[3], Pc[3];
-    const double chi2 = lba_edge_error(D.cam, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
+    const double chi2 = lba_edge_error(C, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
     D.err[3 * (size_t)i] = err[0], D.err[3 * (size_t)i + 1] = err[1], D.err[3 * (size_t)i + 2] = err[2];
     double r0 = chi2, r1;
     if (fl & LBA_ROBUST) {
@@ -338,10 +346,39 @@ k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   }
 }
 
+// 6x3 block Jp^T (rho' Omega) Jx of one active edge (multi-camera rigs: a key frame can see a point in
+// several cameras, the (key frame, point) block of BB is the sum over those edges)
+__device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& k, bool robust, double* B) {
+  const vieo_lba_obs o = D.obs[i];
+  const CamD& C = obs_cam(D, i);
+  PoseXf X;
+  kf_xf(C, k, X);
+  const double* Xw = D.X + 3 * (size_t)o.mp;
+  double err[3], Pc[3];
+  const double chi2 = lba_edge_error(C, X, o, Xw, err, Pc);
+  const bool stereo = o.ur >= 0;
+  double r0, r1 = 1.;
+  if (robust) {
+    const double dl = stereo ? D.dStereo : D.dMono;
+    huber(chi2, dl, dl * dl, &r0, &r1);
+  }
+  double Jp[18], Jx[9];
+  lba_jacobians(C, X, k.p, Xw, Pc, Jp, Jx);
+  const double ww = r1 * (double)o.inv_sigma2;
+  if (!stereo) Jx[6] = Jx[7] = Jx[8] = 0;
+#pragma unroll
+  for (int q = 0; q < 6; q++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) B[q * 3 + b] = Jp[q] * ww * Jx[b] + Jp[6 + q] * ww * Jx[3 + b] + Jp[12 + q] * ww * Jx[6 + b];
+}
+
 // ---- buildSystem (block_solver.hpp:451-520 with EdgeReprojectPR[Stereo]::linearizeOplus).
 // blocks [0, gm): four lanes per point over its (contiguous) observations -> H_ll, b_l;
 // blocks [gm, gm + free key frames): one workgroup per key frame over its edge list -> H_pp, b_p and the
 // rows of BB = Jp^T W Jx it owns.  Every sum has a fixed order.
+// MULTICAM: windows with several (distorted) cameras per key frame; the single rectified camera keeps the
+// lean instantiation.
+template <bool MULTICAM>
 __global__ void __launch_bounds__(256)
 k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int gm) {
   const int bx = blockIdx.x;
@@ -367,9 +404,10 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
         if (D.level[i]) continue;
         const vieo_lba_obs o = D.obs[i];
         PoseXf X;
-        kf_xf(D.cam, D.kf[o.kf], X);
+        const CamD& C = obs_cam(D, i);
+        kf_xf(C, D.kf[o.kf], X);
         double err[3], Pc[3];
-        const double chi2 = lba_edge_error(D.cam, X, o, Xw, err, Pc);
+        const double chi2 = lba_edge_error(C, X, o, Xw, err, Pc);
         const bool stereo = o.ur >= 0;
         double r0, r1 = 1.;
         if (robust) {
@@ -377,10 +415,11 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
           huber(chi2, dl, dl * dl, &r0, &r1);
         }
         const double invz = 1 / Pc[2], invz2 = invz * invz;
-        double J[9], Jx[9];
-        J[0] = -(D.cam.fx * invz), J[1] = 0, J[2] = -(-D.cam.fx * Pc[0] * invz2);
-        J[3] = 0, J[4] = -(D.cam.fy * invz), J[5] = -(-D.cam.fy * Pc[1] * invz2);
-        J[6] = J[0], J[7] = J[1], J[8] = J[2] - D.cam.bf * invz2;
+        double J[9], Jx[9], Jc[6], uv[2];
+        cam_project(C, Pc, uv, Jc);
+        J[0] = -Jc[0], J[1] = -Jc[1], J[2] = -Jc[2];
+        J[3] = -Jc[3], J[4] = -Jc[4], J[5] = -Jc[5];
+        J[6] = J[0], J[7] = J[1], J[8] = J[2] - C.bf * invz2;
         for (int r = 0; r < 3; r++)
           for (int q = 0; q < 3; q++)
             Jx[r * 3 + q] = J[r * 3] * X.Rcw[q] + J[r * 3 + 1] * X.Rcw[3 + q] + J[r * 3 + 2] * X.Rcw[6 + q];
@@ -426,32 +465,62 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
 #pragma unroll
   for (int t = 0; t < 27; t++) acc[t] = 0;
   PoseXf X;
-  kf_xf(D.cam, k, X);
+  kf_xf(D.cam, k, X);  // one camera: the transform is the same for all edges of the key frame
   double* Brow = D.BB + (size_t)(6 * a) * D.ldB;
   for (int j = threadIdx.x; j < cnt; j += 256) {
     const int i = D.kf_edge_idx[first + j];
-    if (D.level[i]) continue;
     const vieo_lba_obs o = D.obs[i];
-    const double* Xw = D.X + 3 * (size_t)o.mp;
-    double err[3], Pc[3];
-    const double chi2 = lba_edge_error(D.cam, X, o, Xw, err, Pc);
-    const bool stereo = o.ur >= 0;
-    double r0, r1 = 1.;
-    if (robust) {
-      const double dl = stereo ? D.dStereo : D.dMono;
-      huber(chi2, dl, dl * dl, &r0, &r1);
+    const bool active = !D.level[i];
+    double Bk[18];
+#pragma unroll
+    for (int t = 0; t < 18; t++) Bk[t] = 0;
+    if (active) {
+      const double* Xw = D.X + 3 * (size_t)o.mp;
+      double err[3], Pc[3];
+      const CamD& C = obs_cam(D, i);
+      if (MULTICAM && D.n_cams) kf_xf(C, k, X);
+      const double chi2 = lba_edge_error(C, X, o, Xw, err, Pc);
+      const bool stereo = o.ur >= 0;
+      double r0, r1 = 1.;
+      if (robust) {
+        const double dl = stereo ? D.dStereo : D.dMono;
+        huber(chi2, dl, dl * dl, &r0, &r1);
+      }
+      double Jp[18], Jx[9];
+      lba_jacobians(C, X, k.p, Xw, Pc, Jp, Jx);
+      const double info = (double)o.inv_sigma2, ww = r1 * info;
+      visual_accumulate(Jp, err, info, r1, stereo, acc);
+      if (!stereo) Jx[6] = Jx[7] = Jx[8] = 0;
+#pragma unroll
+      for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+          Bk[q * 3 + b] = Jp[q] * ww * Jx[b] + Jp[6 + q] * ww * Jx[3 + b] + Jp[12 + q] * ww * Jx[6 + b];
     }
-    double Jp[18], Jx[9];
-    lba_jacobians(D.cam, X, k.p, Xw, Pc, Jp, Jx);
-    const double info = (double)o.inv_sigma2, ww = r1 * info;
-    visual_accumulate(Jp, err, info, r1, stereo, acc);
-    if (!stereo) Jx[6] = Jx[7] = Jx[8] = 0;
-    double* B = Brow + 3 * (size_t)o.mp;
+    bool write = active;
+    if (MULTICAM && D.n_cams) {
+      // edges of one (key frame, point) pair are adjacent in the list: the first one sums the run
+      if (j > 0 && D.obs[D.kf_edge_idx[first + j - 1]].mp == o.mp)
+        write = false;
+      else
+        for (int jj = j + 1; jj < cnt; jj++) {
+          const int i2 = D.kf_edge_idx[first + jj];
+          if (D.obs[i2].mp != o.mp) break;
+          if (D.level[i2]) continue;
+          double B2[18];
+          lba_edge_B(D, i2, k, robust, B2);
 #pragma unroll
-    for (int q = 0; q < 6; q++)
+          for (int t = 0; t < 18; t++) Bk[t] += B2[t];
+          write = true;
+        }
+    }
+    if (write) {
+      double* B = Brow + 3 * (size_t)o.mp;
 #pragma unroll
-      for (int b = 0; b < 3; b++)
-        B[(size_t)q * D.ldB + b] = Jp[q] * ww * Jx[b] + Jp[6 + q] * ww * Jx[3 + b] + Jp[12 + q] * ww * Jx[6 + b];
+      for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) B[(size_t)q * D.ldB + b] = Bk[q * 3 + b];
+    }
   }
   block_sum<27>(acc, s_red, threadIdx.x);
   if (threadIdx.x < 27) {
@@ -1135,12 +1204,20 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     } else
       n_live++;
     const vieo_lba_obs* ob = h_obs[w];
-    for (int i = 0; i < H.n_obs; i++)
-      if (ob[i].mp < 0 || ob[i].mp >= H.n_mp || ob[i].kf < 0 || ob[i].kf >= H.n_kf ||
-          (i > 0 && ob[i].mp < ob[i - 1].mp)) {
-        set_error("vieo_local_bundle_adjustment: observations must be sorted by map point");
+    const int nc = H.P->n_cams;
+    if (nc < 0 || nc > 4 || (nc > 0 && !H.P->cams)) {
+      set_error("local BA: n_cams must be 0..4");
+      return VIEO_E_INVALID;
+    }
+    for (int i = 0; i < H.n_obs; i++) {
+      const int kfi = ob[i].kf & 0xFFFFFF, ci = (ob[i].kf >> 24) & 15;
+      if (ob[i].mp < 0 || ob[i].mp >= H.n_mp || ob[i].kf < 0 || kfi >= H.n_kf || (i > 0 && ob[i].mp < ob[i - 1].mp) ||
+          (nc == 0 ? ci != 0 : (ci >= nc || ob[i].ur >= 0))) {
+        set_error("vieo_local_bundle_adjustment: observations must be sorted by map point, key frame and camera "
+                  "indices in range, distorted observations monocular");
         return VIEO_E_INVALID;
       }
+    }
   }
   if (!n_live) return VIEO_OK;
   // ---- arena layout: [inputs | results (kf, X, erase) | zero-initialised | scratch]
@@ -1151,7 +1228,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     return off;
   };
   struct Off {
-    size_t obs, mp_first, mp_count, kf_edge_first, kf_edge_idx, imu, kf_in, kf_out, close, kf, X, erase, level, err;
+    size_t obs, mp_first, mp_count, kf_edge_first, kf_edge_idx, imu, kf_in, kf_out, close, ocam, kf, X, erase, level, err;
   };
   std::vector<Off> off(W);
   for (int w = 0; w < W; w++) {
@@ -1161,6 +1238,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     o.obs = take((size_t)H.n_obs * sizeof(vieo_lba_obs));
     o.mp_first = take((size_t)H.n_mp * 4), o.mp_count = take((size_t)H.n_mp * 4);
     o.kf_edge_first = take((size_t)(H.n_kf + 1) * 4), o.kf_edge_idx = take((size_t)H.n_obs * 4);
+    o.ocam = take(H.n_obs);
     if (vio) {
       o.imu = take((size_t)std::max(H.n_imu, 1) * sizeof(LbaImu));
       o.kf_in = take((size_t)H.n_kf * 4), o.kf_out = take((size_t)H.n_kf * 4), o.close = take(H.n_mp);
@@ -1184,6 +1262,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
   if ((rc = g_stage.ensure(res_end)) != VIEO_OK) return rc;
   uint8_t* hs = (uint8_t*)g_stage.p;
   int max_obs = 0, max_mp = 0, max_kf = 0, max_nf = 0, max_imu = 0;
+  bool any_multicam = false;
   for (int w = 0; w < W; w++) {
     if (win[w].skip) continue;
     int nf = 0;
@@ -1209,7 +1288,15 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     const vieo_lba_obs* ob = h_obs[w];
     const vieo_lba_keyframe* kfs = h_kfs[w];
     // host-side index structures, written straight into the pinned staging copy of the arena
-    memcpy(hs + o.obs, ob, (size_t)H.n_obs * sizeof(vieo_lba_obs));
+    {  // the device sees plain key-frame indices; the camera index travels in its own byte array
+      vieo_lba_obs* so = (vieo_lba_obs*)(hs + o.obs);
+      for (int i = 0; i < H.n_obs; i++) {
+        so[i] = ob[i];
+        so[i].kf = ob[i].kf & 0xFFFFFF;
+        hs[o.ocam + i] = (uint8_t)((ob[i].kf >> 24) & 15);
+      }
+      ob = so;
+    }
     int* mp_first = (int*)(hs + o.mp_first);
     int* mp_count = (int*)(hs + o.mp_count);
     int* kf_first = (int*)(hs + o.kf_edge_first);
@@ -1295,6 +1382,20 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     D.cam.fx = H.P->fx, D.cam.fy = H.P->fy, D.cam.cx = H.P->cx, D.cam.cy = H.P->cy, D.cam.bf = H.P->bf;
     memcpy(D.cam.Rcb, H.P->Rcb, 72);
     memcpy(D.cam.tcb, H.P->tcb, 24);
+    D.n_cams = H.P->n_cams;
+    any_multicam |= H.P->n_cams > 0;
+    for (int ci = 0; ci < H.P->n_cams; ci++) {
+      const vieo_camera& c = H.P->cams[ci];
+      CamD& d = D.cams[ci];
+      d.fx = c.fx, d.fy = c.fy, d.cx = c.cx, d.cy = c.cy, d.bf = 0;
+      memcpy(d.Rcb, c.Rcb, 72), memcpy(d.tcb, c.tcb, 24);
+      d.model = c.model, d.num_k = c.model == VIEO_CAM_RADTAN ? c.num_k : 0;
+      if (c.model < 0 || c.model > 2 || (c.model == VIEO_CAM_RADTAN && (c.num_k < 2 || c.num_k > 6))) {
+        set_error("local BA: camera %d has an unknown model or coefficient count", ci);
+        return VIEO_E_INVALID;
+      }
+      for (int q = 0; q < 8; q++) d.k[q] = (double)c.dist[q];
+    }
     D.dMono = (double)(float)sqrt(5.991), D.dStereo = (double)(float)sqrt(7.815);
     D.pd = pd, D.n_imu = H.n_imu;
     if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
@@ -1324,6 +1425,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     D.kf_edge_first = (const int*)(base + o.kf_edge_first), D.kf_edge_idx = (const int*)(base + o.kf_edge_idx);
     D.kf = (LbaKf*)(base + o.kf), D.X = (double*)(base + o.X), D.erase = base + o.erase;
     D.level = base + o.level, D.err = (double*)(base + o.err);
+    D.ocam = base + o.ocam;
     D.kf_bak = (LbaKf*)(base + s.kf_bak), D.X_bak = (double*)(base + s.X_bak), D.mp_act = base + s.mp_act;
     D.BB = (double*)(base + s.BB), D.Sp = (double*)(base + s.Sp);
     D.Hll = (double*)(base + s.Hll), D.bl = (double*)(base + s.bl);
@@ -1414,7 +1516,10 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
       hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0);
     }
     if (any & LBA_BUILD) {
-      hipLaunchKernelGGL(k_lba_build, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq);
+      if (any_multicam)
+        hipLaunchKernelGGL(k_lba_build<true>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq);
+      else
+        hipLaunchKernelGGL(k_lba_build<false>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq);
       if (vio && max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0);
     }
     if (any & LBA_BEGIN) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);

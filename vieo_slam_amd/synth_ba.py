@@ -261,9 +261,49 @@ def _R_to_quat(R):
     return q / np.linalg.norm(q)
 
 
+def _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig=None):
+    """Observations (kf [| cam << 24], mp, u, v, ur, inv_sigma2) of the points from the key frames.
+    rig = None: the rectified pinhole stereo camera; otherwise (cams, (width, height)) from camera_rig():
+    monocular observations in every camera that sees the point."""
+    obs_list = []
+    for m in range(len(Xw)):
+        for k, pose in enumerate(poses):
+            Rk, pk = pose[0], pose[1]
+            Xb = Rk.T @ (Xw[m] - pk)
+            if rig is None:
+                views = [(0, Rcb @ Xb + tcb, None)]
+            else:
+                views = [(ci, c["Rcb"].reshape(3, 3) @ Xb + c["tcb"], c) for ci, c in enumerate(rig[0])]
+            for ci, Xck, c in views:
+                if Xck[2] < 0.5:
+                    continue
+                if c is None:
+                    uu, vv = FX * Xck[0] / Xck[2] + CX, FY * Xck[1] / Xck[2] + CY
+                    w_, h_ = W, H
+                else:
+                    uu, vv = project_camera(c, Xck)
+                    w_, h_ = rig[1]
+                    if np.hypot(Xck[0], Xck[1]) / Xck[2] > (0.9 if c["model"] == 1 else 2.0):
+                        continue  # outside the field of view the distortion model is meant for
+                if not (10 < uu < w_ - 10 and 10 < vv < h_ - 10):
+                    continue
+                lvl = int(rng.integers(0, 8))
+                sig = 1.2 ** lvl
+                uo = uu + rng.normal(0, noise) * sig
+                vo = vv + rng.normal(0, noise) * sig
+                ur = uu - BF / Xck[2] + rng.normal(0, noise) * sig
+                if rng.random() < outlier_frac:
+                    uo += rng.uniform(-40, 40)
+                    vo += rng.uniform(-40, 40)
+                mono = rng.random() >= stereo_frac or c is not None
+                obs_list.append((k | (ci << 24), m, uo, vo, -1.0 if mono else ur,
+                                 1.0 / (np.float32(1.2) ** lvl) ** 2))
+    return obs_list
+
+
 # ----------------------------------------------------------------------------------------------
 def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.03, stereo_frac=0.7,
-                     noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_x=0.02, first_fixed=False):
+                     noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_x=0.02, first_fixed=False, rig=None):
     """Seeded local-BA window: key frames on a smooth trajectory looking at a cloud
     of points 2-12 m ahead; every point is observed by the key frames that see it.
     returns (params[1], kfs[n_kf], points float32[n_mp,3], obs[n_obs] sorted by mp, truth)."""
@@ -294,32 +334,14 @@ def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.
     v = rng.uniform(-100, H + 100, n_points)
     Xc = np.stack([(u - CX) / FX * z, (v - CY) / FY * z, z], 1)
     Xw = Xc @ Rwc_m.T + twc_m
-    obs_list = []
-    for m in range(n_points):
-        for k, (Rk, pk) in enumerate(poses):
-            Xck = Rcb @ (Rk.T @ (Xw[m] - pk)) + tcb
-            if Xck[2] < 0.5:
-                continue
-            uu = FX * Xck[0] / Xck[2] + CX
-            vv = FY * Xck[1] / Xck[2] + CY
-            if not (10 < uu < W - 10 and 10 < vv < H - 10):
-                continue
-            lvl = int(rng.integers(0, 8))
-            sig = 1.2 ** lvl
-            uo = uu + rng.normal(0, noise) * sig
-            vo = vv + rng.normal(0, noise) * sig
-            ur = uu - BF / Xck[2] + rng.normal(0, noise) * sig
-            if rng.random() < outlier_frac:
-                uo += rng.uniform(-40, 40)
-                vo += rng.uniform(-40, 40)
-            mono = rng.random() >= stereo_frac
-            obs_list.append((k, m, uo, vo, -1.0 if mono else ur, 1.0 / (np.float32(1.2) ** lvl) ** 2))
+    rig_c = camera_rig(rig) if rig else None
+    obs_list = _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig_c)
     # keep points with >= 2 observations and at least one local observer; renumber
     obs_arr = np.array(obs_list, dtype=np.float64)
     keep = np.zeros(n_points, bool)
     for m in np.unique(obs_arr[:, 1].astype(int)):
         sel = obs_arr[:, 1] == m
-        if sel.sum() >= 2 and (obs_arr[sel, 0] < n_local).any():
+        if sel.sum() >= 2 and ((obs_arr[sel, 0].astype(np.int64) & 0xFFFFFF) < n_local).any():
             keep[m] = True
     remap = -np.ones(n_points, int)
     remap[keep] = np.arange(keep.sum())
@@ -348,7 +370,11 @@ def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.
     params[0]["Rcb"], params[0]["tcb"] = Rcb.reshape(-1), tcb
     params[0]["fx"], params[0]["fy"], params[0]["cx"], params[0]["cy"], params[0]["bf"] = FX, FY, CX, CY, BF
     params[0]["its0"], params[0]["its1"] = 5, 10
-    return params, kfs, pts, obs, dict(p=np.array(truth_p), q=np.array(truth_q), X=Xw)
+    gt = dict(p=np.array(truth_p), q=np.array(truth_q), X=Xw)
+    if rig_c is not None:  # keep the camera array alive with the truth record
+        params[0]["n_cams"], params[0]["cams"] = len(rig_c[0]), rig_c[0].ctypes.data
+        gt["cams"] = rig_c[0]
+    return params, kfs, pts, obs, gt
 
 
 # ----------------------------------------------------------------------------------------------
@@ -385,7 +411,7 @@ _PVR_TO_PRV = np.r_[0:3, 6:9, 3:6]  # Sigma order (p, v, Phi) -> (p, Phi, v)
 
 def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_frac=0.03, stereo_frac=0.7,
                          noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_v=0.03, pert_x=0.02, dt_kf=0.5,
-                         first_fixed=False, imu_noise=1.0, with_prev=True):
+                         first_fixed=False, imu_noise=1.0, with_prev=True, rig=None):
     """Seeded visual-inertial local-BA window: a chain prev-local -> n_local key frames
     integrated forward with consistent IMU pre-integrations, n_fixed older covisible key frames,
     points 2-12 m ahead.  Key-frame order: local (oldest..newest), prev-local (fixed, full nav state),
@@ -425,31 +451,13 @@ def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_fra
     vv_ = rng.uniform(-100, H + 100, n_points)
     Xc = np.stack([(u - CX) / FX * z, (vv_ - CY) / FY * z, z], 1)
     Xw = Xc @ Rwc_m.T + twc_m
-    obs_list = []
-    for m in range(n_points):
-        for k, (Rk, pk, _) in enumerate(poses):
-            Xck = Rcb @ (Rk.T @ (Xw[m] - pk)) + tcb
-            if Xck[2] < 0.5:
-                continue
-            uu = FX * Xck[0] / Xck[2] + CX
-            vv = FY * Xck[1] / Xck[2] + CY
-            if not (10 < uu < W - 10 and 10 < vv < H - 10):
-                continue
-            lvl = int(rng.integers(0, 8))
-            sig = 1.2 ** lvl
-            uo = uu + rng.normal(0, noise) * sig
-            vo = vv + rng.normal(0, noise) * sig
-            ur = uu - BF / Xck[2] + rng.normal(0, noise) * sig
-            if rng.random() < outlier_frac:
-                uo += rng.uniform(-40, 40)
-                vo += rng.uniform(-40, 40)
-            mono = rng.random() >= stereo_frac
-            obs_list.append((k, m, uo, vo, -1.0 if mono else ur, 1.0 / (np.float32(1.2) ** lvl) ** 2))
+    rig_c = camera_rig(rig) if rig else None
+    obs_list = _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig_c)
     obs_arr = np.array(obs_list, dtype=np.float64)
     keep = np.zeros(n_points, bool)
     for m in np.unique(obs_arr[:, 1].astype(int)):
         sel = obs_arr[:, 1] == m
-        if sel.sum() >= 2 and (obs_arr[sel, 0] < n_local).any():
+        if sel.sum() >= 2 and ((obs_arr[sel, 0].astype(np.int64) & 0xFFFFFF) < n_local).any():
             keep[m] = True
     remap = -np.ones(n_points, int)
     remap[keep] = np.arange(keep.sum())
@@ -496,5 +504,71 @@ def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_fra
     params[0]["inv_sigma_bg2"] = 1.0 / IMU_SIGMA[2] ** 2
     params[0]["inv_sigma_ba2"] = 1.0 / IMU_SIGMA[3] ** 2
     params[0]["lambda_init"] = 1.0
-    return params, kfs, pts, close, obs, imu, dict(p=np.array(tp), q=np.array(tq), v=np.array(tv), X=Xw,
-                                                    bg=bg, ba=ba, n_local=n_local)
+    gt = dict(p=np.array(tp), q=np.array(tq), v=np.array(tv), X=Xw, bg=bg, ba=ba, n_local=n_local)
+    if rig_c is not None:
+        b["n_cams"], b["cams"] = len(rig_c[0]), rig_c[0].ctypes.data
+        gt["cams"] = rig_c[0]
+    return params, kfs, pts, close, obs, imu, gt
+
+
+# ---- distorted multi-camera rigs (a20: Radtan / KB8 models, per-observation camera) --------------
+def camera_rig(name):
+    """(CAMERA_DTYPE array, (width, height)) of a rig as the BA edges see it: EdgeReproject::SetParams
+    already applied (Rcb = Rccr * Rcrb, tcb = Rccr * tcrb + tcr).  'radtan': the two EuRoC cameras
+    (k1 k2 p1 p2); 'kb8': four TUM-VI-like fisheye cameras (k1..k4)."""
+    from .ba_types import CAMERA_DTYPE
+    Tcb = np.linalg.inv(EUROC_TBC)
+    Rcrb, tcrb = Tcb[:3, :3], Tcb[:3, 3]
+    if name == "radtan":
+        intr = [(458.654, 457.296, 367.215, 248.375, [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05]),
+                (457.587, 456.134, 379.999, 255.238, [-0.28368365, 0.07451284, -0.00010473, -3.55590700e-05])]
+        Tcr = [np.eye(4), np.eye(4)]
+        Tcr[1][:3, :3] = so3_exp(np.array([0.002, -0.012, 0.001]))
+        Tcr[1][:3, 3] = [-0.110, 0.0004, -0.0008]
+        model, num_k, size = 1, 2, (752, 480)
+    elif name == "kb8":
+        k = [0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673]
+        intr = [(190.978, 190.973, 254.93, 256.90, k), (190.442, 190.434, 252.60, 254.92, k),
+                (191.1, 191.0, 255.5, 255.9, k), (190.7, 190.8, 256.2, 254.1, k)]
+        Tcr = [np.eye(4) for _ in range(4)]
+        for i, (rv, t) in enumerate([((0, 0, 0), (0, 0, 0)), ((0.003, 0.01, -0.002), (-0.101, 0.001, -0.001)),
+                                     ((0.0, 0.35, 0.0), (0.05, 0.0, -0.02)), ((0.0, -0.35, 0.0), (-0.15, 0.0, -0.02))]):
+            Tcr[i][:3, :3] = so3_exp(np.array(rv, float))
+            Tcr[i][:3, 3] = t
+        model, num_k, size = 2, 0, (512, 512)
+    else:
+        raise ValueError(name)
+    cams = np.zeros(len(intr), CAMERA_DTYPE)
+    for i, (fx, fy, cx, cy, d) in enumerate(intr):
+        c = cams[i]
+        c["model"], c["num_k"] = model, num_k
+        c["fx"], c["fy"], c["cx"], c["cy"] = fx, fy, cx, cy
+        c["dist"][:len(d)] = d
+        Rccr, tcr = Tcr[i][:3, :3], Tcr[i][:3, 3]
+        c["Rcb"] = (Rccr @ Rcrb).reshape(-1)
+        c["tcb"] = Rccr @ tcrb + tcr
+    return cams, size
+
+
+def project_camera(cam, Pc):
+    """float64 python restatement of the three Project functions (image point only)."""
+    x, y, z = Pc
+    fx, fy, cx, cy = float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"])
+    d = cam["dist"].astype(np.float64)
+    if cam["model"] == 1:
+        nk = int(cam["num_k"])
+        xn, yn = x / z, y / z
+        r2 = xn * xn + yn * yn
+        fd = 1 + sum(d[i] * r2 ** (i + 1) for i in range(nk))
+        p1, p2 = d[nk], d[nk + 1]
+        xd = xn * fd + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)
+        yd = yn * fd + 2 * p2 * xn * yn + p1 * (r2 + 2 * yn * yn)
+        return fx * xd + cx, fy * yd + cy
+    if cam["model"] == 2:
+        r = np.hypot(x, y)
+        if r > 1e-5:
+            th = np.arctan2(r, z)
+            t2 = th * th
+            thd = th * (1 + t2 * (d[0] + t2 * (d[1] + t2 * (d[2] + t2 * d[3]))))
+            return fx * x * thd / r + cx, fy * y * thd / r + cy
+    return fx * x / z + cx, fy * y / z + cy
