@@ -80,3 +80,33 @@ def test_pose_batch_device(oracle):
         assert dt < TOL and dr < TOL
         assert res[i]["n_inliers"] == ores["n_inliers"]
         assert np.array_equal(ooutl[b:b + n], outl[b:b + n])
+
+
+def test_pose_large_batch_one_wavefront_per_frame(oracle):
+    """More than 256 frames take the one-wavefront-per-frame kernel; every frame still equals the oracle."""
+    protos = [synth_ba.make_pose_problem(400 + i, n_obs=40 + 83 * i)[:2] for i in range(8)]
+    B = 280
+    frames = np.zeros(B, POSE_FRAME_DTYPE)
+    all_obs, begin = [], 0
+    for i in range(B):
+        fr, obs = protos[i % len(protos)]
+        frames[i] = fr[0]
+        frames[i]["obs_begin"] = begin
+        begin += len(obs)
+        all_obs.append(obs)
+    obs = np.concatenate(all_obs)
+    dF, dO = DeviceBuffer(frames.nbytes), DeviceBuffer(obs.nbytes)
+    dU, dR = DeviceBuffer(len(obs)), DeviceBuffer(B * POSE_RESULT_DTYPE.itemsize)
+    dF.upload(frames)
+    dO.upload(obs)
+    check(lib().vieo_pose_optimization_batch_device(dF.ptr, B, dO.ptr, dU.ptr, dR.ptr, None))
+    check(lib().vieo_device_synchronize())
+    res = dR.download(POSE_RESULT_DTYPE, (B,))
+    outl = dU.download(np.uint8, (len(obs),))
+    ref = [oracle.pose_optimization(fr, ob) for fr, ob in protos]
+    for i in range(B):
+        b, n = frames[i]["obs_begin"], frames[i]["n_obs"]
+        ores, ooutl = ref[i % len(protos)]
+        dt, dr = synth_ba.pose_error(ores["nav"], res[i]["nav"])
+        assert dt < TOL and dr < TOL, (i, dt, dr)
+        assert res[i]["n_inliers"] == ores["n_inliers"] and np.array_equal(ooutl[:n], outl[b:b + n])

@@ -43,9 +43,12 @@ __device__ __forceinline__ bool ldlt6(const double* H, const double* b, double* 
   return true;
 }
 
-static const int kMaxEPT = 8;  // edges per thread: n_obs <= 2048
+static const int kMaxObs = 2048;  // 32 edges per lane at 64 threads per frame, 8 at 256 (bit mask per lane)
 
-__global__ void __launch_bounds__(256)
+// BS threads per frame: 256 for a few frames (lowest latency), 64 = one wavefront per frame for large
+// batches (four frames per CU in flight), as in pose_opt_vio.hip
+template <int BS>
+__global__ void __launch_bounds__(BS)
 k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
            uint8_t* __restrict__ outlier_all, vieo_pose_result* __restrict__ results) {
   __shared__ double s_red[4 * 27];
@@ -55,8 +58,8 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
   const vieo_pose_obs* obs = obs_all + F.obs_begin;
   uint8_t* outl = outlier_all + F.obs_begin;
   vieo_pose_result* R = results + f;
-  if (N < 3 || N > 256 * kMaxEPT) {  // Optimizer.cc:1789
-    for (int i = tid; i < N; i += 256) outl[i] = 0;
+  if (N < 3 || N > kMaxObs) {  // Optimizer.cc:1789
+    for (int i = tid; i < N; i += BS) outl[i] = 0;
     if (tid == 0) {
       R->nav = F.nav;
       R->n_inliers = 0;
@@ -84,8 +87,8 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
     const bool robust = it < 3;
     // active-edge count decides whether optimize() does anything
     double cnt[1] = {0};
-    for (int k = 0, i = tid; i < N; k++, i += 256) cnt[0] += ((levelmask >> k) & 1) ? 0. : 1.;
-    block_sum<1>(cnt, s_red, tid);
+    for (int k = 0, i = tid; i < N; k++, i += BS) cnt[0] += ((levelmask >> k) & 1) ? 0. : 1.;
+    block_sum_bs<1, BS>(cnt, s_red, tid);
     Est est_err = est;  // estimate at the last computeActiveErrors (g2o does not pop edge errors)
     if (cnt[0] > 0) {
       double lambda = -1, ni = 2;
@@ -99,7 +102,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] = 0;
         double chi = 0;
-        for (int k = 0, i = tid; i < N; k++, i += 256) {
+        for (int k = 0, i = tid; i < N; k++, i += BS) {
           if ((levelmask >> k) & 1) continue;
           const vieo_pose_obs o = obs[i];
           double err[3], Pc[3];
@@ -116,9 +119,9 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
           visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
         }
         est_err = est;
-        block_sum<27>(acc, s_red, tid);
+        block_sum_bs<27, BS>(acc, s_red, tid);
         double c1[1] = {chi};
-        block_sum<1>(c1, s_red, tid);
+        block_sum_bs<1, BS>(c1, s_red, tid);
         double currentChi = c1[0];
         const double iniChi = currentChi;
         double H[36], b[6];
@@ -147,7 +150,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
           PoseXf X2;
           make_xf(c, est, X2);
           double tc[1] = {0};
-          for (int k = 0, i = tid; i < N; k++, i += 256) {
+          for (int k = 0, i = tid; i < N; k++, i += BS) {
             if ((levelmask >> k) & 1) continue;
             const vieo_pose_obs o = obs[i];
             double err[3], Pc[3];
@@ -160,7 +163,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
             tc[0] += r0;
           }
           est_err = est;
-          block_sum<1>(tc, s_red, tid);
+          block_sum_bs<1, BS>(tc, s_red, tid);
           double tempChi = tc[0];
           if (!ok2) tempChi = DBL_MAX;
           rho = currentChi - tempChi;
@@ -195,7 +198,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
     make_xf(c, est_err, Xe);  // inliers keep the error of the last computeActiveErrors
     make_xf(c, est, Xc);      // outliers are re-evaluated at the current estimate
     double nb[1] = {0};
-    for (int k = 0, i = tid; i < N; k++, i += 256) {
+    for (int k = 0, i = tid; i < N; k++, i += BS) {
       const vieo_pose_obs o = obs[i];
       const bool was_out = (levelmask >> k) & 1;
       double err[3], Pc[3];
@@ -207,11 +210,11 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
       } else
         levelmask &= ~(1u << k);
     }
-    block_sum<1>(nb, s_red, tid);
+    block_sum_bs<1, BS>(nb, s_red, tid);
     nBad = (int)nb[0];
     if (N < 10) break;  // optimizer.edges().size() < 10
   }
-  for (int k = 0, i = tid; i < N; k++, i += 256) outl[i] = (levelmask >> k) & 1;
+  for (int k = 0, i = tid; i < N; k++, i += BS) outl[i] = (levelmask >> k) & 1;
   if (tid == 0) {
     R->nav = F.nav;
     R->nav.p[0] = est.p[0], R->nav.p[1] = est.p[1], R->nav.p[2] = est.p[2];
@@ -235,8 +238,16 @@ int vieo_pose_optimization_batch_device(const vieo_pose_frame* d_frames, int n_f
   if (!d_frames || n_frames <= 0 || !d_obs || !d_outlier || !d_results) return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
-  hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames, d_obs,
-                     d_outlier, d_results);
+  static const int forced = [] {  // VIEO_POSE_THREADS=64|256 overrides the choice (tuning / tests)
+    const char* e = getenv("VIEO_POSE_THREADS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 64 || (forced != 256 && n_frames > 256))
+    hipLaunchKernelGGL(k_pose_opt<64>, dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames, d_obs, d_outlier,
+                       d_results);
+  else
+    hipLaunchKernelGGL(k_pose_opt<256>, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames, d_obs,
+                       d_outlier, d_results);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
