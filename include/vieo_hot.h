@@ -248,6 +248,20 @@ typedef struct vieo_navstate {
   double bg[3], ba[3], dbg[3], dba[3];
 } vieo_navstate;
 
+/* camm::Camera of one physical camera as an EdgeReproject sees it (a20: common/camera_models/
+ * camera_pinhole.h:70-106, camera_radtan.h:61-129, camera_kb8.h:68-157), with EdgeReproject::SetParams
+ * (g2otypes.h:409-416) already applied to the extrinsics: Rcb = Rccr * Rcrb, tcb = Rccr * tcrb + tcr. */
+#define VIEO_CAM_PINHOLE 0
+#define VIEO_CAM_RADTAN 1
+#define VIEO_CAM_KB8 2
+typedef struct vieo_camera {
+  int32_t model;   /* VIEO_CAM_* */
+  int32_t num_k;   /* Radtan: number of radial coefficients (parameters.size() - 6), else unused */
+  float fx, fy, cx, cy;
+  float dist[8];   /* Radtan: k1..k_num_k, p1, p2;  KB8: k1..k4 */
+  double Rcb[9], tcb[3];
+} vieo_camera;
+
 /* One 3D-2D correspondence = one EdgeReprojectPR / PRStereo (src/Odom/g2otypes.h:321-547). */
 typedef struct vieo_pose_obs {
   float Xw[3];      /* MapPoint::mWorldPos, stored as float32 (include/MapPoint.h:52-53) */
@@ -263,8 +277,19 @@ typedef struct vieo_pose_frame {
   float bf;              /* stereoinfo_.baseline_bf_[1] */
   int32_t obs_begin;     /* first observation of this frame in the flat obs array */
   int32_t n_obs;
-  int32_t reserved;
+  int32_t n_cams;        /* 0: the rectified pinhole camera above; 1..4: `cams` (a20, Frame::usedistort_), and
+                          * bits 8..11 of vieo_pose_obs.flags select the observation's camera (monocular edges) */
+  const vieo_camera* cams; /* host pointer for the host entry points, device pointer for *_batch_device */
 } vieo_pose_frame;
+
+/* The batched device forms cannot see n_cams from the host, so by default they launch both kernel instances
+ * (rectified pinhole frames, camera-rig frames); each instance skips the other's frames.  A caller whose
+ * frames are all of one kind says so once and saves the empty launch; a frame of the other kind then
+ * comes back with status VIEO_E_INVALID instead of being optimised. */
+#define VIEO_POSE_CAMS_AUTO 0
+#define VIEO_POSE_CAMS_RECTIFIED 1 /* every frame has n_cams == 0 (Frame::usedistort_ false) */
+#define VIEO_POSE_CAMS_RIG 2       /* every frame has n_cams > 0 */
+int vieo_pose_set_camera_mode(int mode);
 
 #define VIEO_POSE_OK 0
 #define VIEO_POSE_TOO_FEW 1 /* < 3 correspondences: the reference returns 0 and leaves the pose */
@@ -355,20 +380,6 @@ typedef struct vieo_lba_obs {
   float u, v, ur;   /* ur < 0 => monocular edge */
   float inv_sigma2;
 } vieo_lba_obs;
-
-/* camm::Camera of one physical camera as an EdgeReproject sees it (a20: common/camera_models/
- * camera_pinhole.h:70-106, camera_radtan.h:61-129, camera_kb8.h:68-157), with EdgeReproject::SetParams
- * (g2otypes.h:409-416) already applied to the extrinsics: Rcb = Rccr * Rcrb, tcb = Rccr * tcrb + tcr. */
-#define VIEO_CAM_PINHOLE 0
-#define VIEO_CAM_RADTAN 1
-#define VIEO_CAM_KB8 2
-typedef struct vieo_camera {
-  int32_t model;   /* VIEO_CAM_* */
-  int32_t num_k;   /* Radtan: number of radial coefficients (parameters.size() - 6), else unused */
-  float fx, fy, cx, cy;
-  float dist[8];   /* Radtan: k1..k_num_k, p1, p2;  KB8: k1..k4 */
-  double Rcb[9], tcb[3];
-} vieo_camera;
 
 typedef struct vieo_lba_params {
   double Rcb[9], tcb[3];

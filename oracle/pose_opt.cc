@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../include/vieo_hot.h"
+#include "cam_models.hpp"
 #include "smallmat.hpp"
 
 namespace vo {
@@ -55,17 +56,18 @@ struct ReprojEdge {
   double delta, dsqr;  // RobustKernelHuber
   double err[3] = {0, 0, 0};
   int idx;  // keypoint slot
+  int cam = 0;  // camera of the observation (bits 8..11 of vieo_pose_obs.flags)
 };
 
+// the cameras of a frame (a20): cams[0] is the rectified pinhole camera of vieo_pose_frame when n_cams == 0
 struct Cam {
-  float fx, fy, cx, cy;
-  double bf;
-  double Rcb[9], tcb[3];
+  OCam cams[4];
 };
 
 // EdgeReproject::GetTcw_wX + cam_project (g2otypes.h:338-406), NV=2, MODE 0
-static void edge_project(const Cam& c, const PoseState& s, const double* Xw, int de, double* proj,
-                         double* Pc_out, double* Rcw_out) {
+static void edge_project(const Cam& cc, const PoseState& s, const double* Xw, int de, double* proj,
+                         double* Pc_out, double* Rcw_out, int ci = 0) {
+  const OCam& c = cc.cams[ci];
   double Rwb[9], Rbw[9], Rcw[9], t[3], tcw[3], Pc[3];
   quat_to_R(s.q, Rwb);
   m3_T(Rwb, Rbw);
@@ -74,20 +76,19 @@ static void edge_project(const Cam& c, const PoseState& s, const double* Xw, int
   for (int i = 0; i < 3; i++) tcw[i] = -t[i] + c.tcb[i];
   m3_v(Rcw, Xw, Pc);
   for (int i = 0; i < 3; i++) Pc[i] += tcw[i];
-  // PinholeCamera::Project: (Tdata)((Tcalc)fx * x * invz + cx), Tdata = float
-  const double invz = 1. / Pc[2];
-  const float u = (float)((double)c.fx * Pc[0] * invz + c.cx);
-  const float v = (float)((double)c.fy * Pc[1] * invz + c.cy);
-  proj[0] = u;
-  proj[1] = v;
-  if (de > 2) proj[2] = proj[0] - c.bf / Pc[2];
+  // camm::Camera::Project: image point as float (Tdata)
+  float uv[2];
+  ocam_project(c, Pc, uv, nullptr);
+  proj[0] = uv[0];
+  proj[1] = uv[1];
+  if (de > 2) proj[2] = proj[0] - (double)c.bf / Pc[2];
   if (Pc_out) memcpy(Pc_out, Pc, 24);
   if (Rcw_out) memcpy(Rcw_out, Rcw, 72);
 }
 
 static void edge_compute_error(const Cam& c, const PoseState& s, ReprojEdge& e) {
   double proj[3];
-  edge_project(c, s, e.Xw, e.de, proj, nullptr, nullptr);
+  edge_project(c, s, e.Xw, e.de, proj, nullptr, nullptr, e.cam);
   for (int i = 0; i < e.de; i++) e.err[i] = e.obs[i] - proj[i];
 }
 
@@ -109,25 +110,21 @@ static void huber(double e, double delta, double dsqr, double* rho) {  // robust
 }
 
 // EdgeReproject::linearizeOplus (g2otypes.h:439-541), Jacobian w.r.t. the PR vertex (de x 6)
-static void edge_linearize(const Cam& c, const PoseState& s, const ReprojEdge& e, double* J) {
+static void edge_linearize(const Cam& cc, const PoseState& s, const ReprojEdge& e, double* J) {
+  const OCam& c = cc.cams[e.cam];
   double proj[3], Pc[3], Rcw[9];
-  edge_project(c, s, e.Xw, e.de, proj, Pc, Rcw);
+  edge_project(cc, s, e.Xw, e.de, proj, Pc, Rcw, e.cam);
   const double invz = 1 / Pc[2], invz_2 = invz * invz;
   double Jproj[9] = {0};
-  {  // PinholeCamera::Project Jacobian, then Jproj = -J
-    const double x = Pc[0], y = Pc[1];
-    const double invz2 = invz * invz;
-    double Jt[6] = {0};
-    Jt[0] = c.fx * invz;
-    Jt[2] = -c.fx * x * invz2;
-    Jt[4] = c.fy * invz;
-    Jt[5] = -c.fy * y * invz2;
+  {  // Project Jacobian of the edge's camera, then Jproj = -J
+    double Jt[6];
+    ocam_project(c, Pc, nullptr, Jt);
     for (int i = 0; i < 6; i++) Jproj[i] = -Jt[i];
   }
   if (e.de > 2) {
     Jproj[6] = Jproj[0];
     Jproj[7] = Jproj[1];
-    Jproj[8] = Jproj[2] - c.bf * invz_2;
+    Jproj[8] = Jproj[2] - (double)c.bf * invz_2;
   }
   // JdPwb = Jproj * (-Rcb)
   double Rwb[9], dP[3], Paux[3], H[9], RcbH[9];
@@ -254,10 +251,14 @@ static void pose_optimization(const vieo_pose_frame& F, const vieo_pose_obs* obs
   R.status = VIEO_POSE_OK;
   R.lm_iterations = 0;
   Cam c;
-  c.fx = F.fx, c.fy = F.fy, c.cx = F.cx, c.cy = F.cy;
-  c.bf = F.bf;
-  memcpy(c.Rcb, F.Rcb, 72);
-  memcpy(c.tcb, F.tcb, 24);
+  {
+    vieo_lba_params prm;
+    memset(&prm, 0, sizeof(prm));
+    memcpy(prm.Rcb, F.Rcb, 72), memcpy(prm.tcb, F.tcb, 24);
+    prm.fx = F.fx, prm.fy = F.fy, prm.cx = F.cx, prm.cy = F.cy, prm.bf = F.bf;
+    prm.n_cams = F.n_cams, prm.cams = F.cams;
+    ocams_from_params(prm, c.cams);
+  }
   const int N = F.n_obs;
   std::vector<ReprojEdge> edges(N);
   const float deltaMono = sqrt(5.991), deltaStereo = sqrt(7.815);
@@ -272,6 +273,7 @@ static void pose_optimization(const vieo_pose_frame& F, const vieo_pose_obs* obs
     e.delta = e.de == 2 ? (double)deltaMono : (double)deltaStereo;
     e.dsqr = e.delta * e.delta;
     e.idx = i;
+    e.cam = (o.flags >> 8) & 15;
     ++nInitialCorrespondences;
     outlier[i] = 0;
   }
@@ -339,10 +341,15 @@ void vo_pose_optimization(const vieo_pose_frame* frame, const vieo_pose_obs* obs
 // test helpers: residual + analytic Jacobian of one edge, for finite-difference checks
 void vo_pose_edge_eval(const vieo_pose_frame* F, const vieo_pose_obs* o, const double* delta6,
                        double* err3, double* J18) {
-  vo::Cam c;
-  c.fx = F->fx, c.fy = F->fy, c.cx = F->cx, c.cy = F->cy, c.bf = F->bf;
-  memcpy(c.Rcb, F->Rcb, 72);
-  memcpy(c.tcb, F->tcb, 24);
+  vo::Cam cc;
+  {
+    vieo_lba_params prm;
+    memset(&prm, 0, sizeof(prm));
+    memcpy(prm.Rcb, F->Rcb, 72), memcpy(prm.tcb, F->tcb, 24);
+    prm.fx = F->fx, prm.fy = F->fy, prm.cx = F->cx, prm.cy = F->cy, prm.bf = F->bf;
+    vo::ocams_from_params(prm, cc.cams);
+  }
+  const vo::OCam& c = cc.cams[0];
   vo::PoseState s;
   memcpy(s.p, F->nav.p, 24);
   s.q.w = F->nav.q[0], s.q.x = F->nav.q[1], s.q.y = F->nav.q[2], s.q.z = F->nav.q[3];
@@ -363,7 +370,7 @@ void vo_pose_edge_eval(const vieo_pose_frame* F, const vieo_pose_obs* o, const d
   err3[0] = e.obs[0] - ((double)c.fx * Pc[0] / Pc[2] + c.cx);
   err3[1] = e.obs[1] - ((double)c.fy * Pc[1] / Pc[2] + c.cy);
   err3[2] = e.de > 2 ? e.obs[2] - (((double)c.fx * Pc[0] / Pc[2] + c.cx) - c.bf / Pc[2]) : 0;
-  if (J18) vo::edge_linearize(c, s, e, J18);
+  if (J18) vo::edge_linearize(cc, s, e, J18);
 }
 
 void vo_so3_exp(const double* w, double* q4) {

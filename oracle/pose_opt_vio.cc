@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../include/vieo_hot.h"
+#include "cam_models.hpp"
 #include "smallmat.hpp"
 
 namespace vo {
@@ -130,7 +131,7 @@ static void huber2(double e, double delta, double dsqr, double* rho) {
 
 struct VisEdge {
   double Xw[3], obs[3], info;
-  int de, level = 0, idx;
+  int de, level = 0, idx, cam = 0;
   bool robust = true, close = false;
   double delta, dsqr;
   double err[3] = {0, 0, 0};
@@ -138,8 +139,7 @@ struct VisEdge {
 
 struct Problem {
   const vieo_vio_frame* F;
-  double Rcb[9], tcb[3], bf;
-  float fx, fy, cx, cy;
+  OCam cams[4];  // cams[0] = the rectified pinhole camera when n_cams == 0 (a20)
   NS nsj, nsi;       // current estimates
   NS prior;          // measurement of the prior edge
   bool fixedLast, hasImu;
@@ -149,25 +149,27 @@ struct Problem {
   int ndim;  // 15 or 30
 
   // ---- visual edge (EdgeReprojectPVR[Stereo])
-  void vis_project(const double* Xw, int de, double* proj, double* Pc_out, double* Rcw_out) const {
+  void vis_project(const double* Xw, int de, double* proj, double* Pc_out, double* Rcw_out, int ci = 0) const {
+    const OCam& C = cams[ci];
     double Rwb[9], Rbw[9], Rcw[9], t[3], tcw[3], Pc[3];
     quat_to_R(nsj.q, Rwb);
     m3_T(Rwb, Rbw);
-    m3_mul(Rcb, Rbw, Rcw);
+    m3_mul(C.Rcb, Rbw, Rcw);
     m3_v(Rcw, nsj.p, t);
-    for (int i = 0; i < 3; i++) tcw[i] = -t[i] + tcb[i];
+    for (int i = 0; i < 3; i++) tcw[i] = -t[i] + C.tcb[i];
     m3_v(Rcw, Xw, Pc);
     for (int i = 0; i < 3; i++) Pc[i] += tcw[i];
-    const double invz = 1. / Pc[2];
-    proj[0] = (float)((double)fx * Pc[0] * invz + cx);
-    proj[1] = (float)((double)fy * Pc[1] * invz + cy);
-    if (de > 2) proj[2] = proj[0] - bf / Pc[2];
+    float uv[2];
+    ocam_project(C, Pc, uv, nullptr);
+    proj[0] = uv[0];
+    proj[1] = uv[1];
+    if (de > 2) proj[2] = proj[0] - (double)C.bf / Pc[2];
     if (Pc_out) memcpy(Pc_out, Pc, 24);
     if (Rcw_out) memcpy(Rcw_out, Rcw, 72);
   }
   void vis_error(VisEdge& e) const {
     double proj[3];
-    vis_project(e.Xw, e.de, proj, nullptr, nullptr);
+    vis_project(e.Xw, e.de, proj, nullptr, nullptr, e.cam);
     for (int i = 0; i < e.de; i++) e.err[i] = e.obs[i] - proj[i];
   }
   static double vis_chi2(const VisEdge& e) {
@@ -177,17 +179,20 @@ struct Problem {
   }
   bool vis_depth_positive(const VisEdge& e) const {  // g2otypes.h:421-427
     double proj[3], Pc[3];
-    vis_project(e.Xw, e.de, proj, Pc, nullptr);
+    vis_project(e.Xw, e.de, proj, Pc, nullptr, e.cam);
     return Pc[2] > 0.;
   }
   void vis_linearize(const VisEdge& e, double* J /* de x 9 */) const {
     double proj[3], Pc[3], Rcw[9];
-    vis_project(e.Xw, e.de, proj, Pc, Rcw);
+    vis_project(e.Xw, e.de, proj, Pc, Rcw, e.cam);
+    const OCam& C = cams[e.cam];
+    const double* Rcb = C.Rcb;
     const double invz = 1 / Pc[2], invz_2 = invz * invz;
-    double Jp[9] = {0};
-    Jp[0] = -(fx * invz), Jp[2] = -(-fx * Pc[0] * invz_2);
-    Jp[4] = -(fy * invz), Jp[5] = -(-fy * Pc[1] * invz_2);
-    if (e.de > 2) Jp[6] = Jp[0], Jp[7] = Jp[1], Jp[8] = Jp[2] - bf * invz_2;
+    double Jp[9] = {0}, Jc[6];
+    ocam_project(C, Pc, nullptr, Jc);
+    for (int i = 0; i < 6; i++) Jp[i] = -Jc[i];
+    if (e.de > 2) Jp[6] = Jp[0], Jp[7] = Jp[1], Jp[8] = Jp[2] - (double)C.bf * invz_2;
+    (void)invz;
     double Rwb[9], dP[3], Paux[3], H[9], RcbH[9];
     quat_to_R(nsj.q, Rwb);
     for (int i = 0; i < 3; i++) dP[i] = e.Xw[i] - nsj.p[i];
@@ -544,10 +549,14 @@ static void pose_optimization_vio(const vieo_vio_frame& F, const vieo_pose_obs* 
   R.base.status = VIEO_POSE_OK;
   Problem P;
   P.F = &F;
-  memcpy(P.Rcb, F.base.Rcb, 72);
-  memcpy(P.tcb, F.base.tcb, 24);
-  P.fx = F.base.fx, P.fy = F.base.fy, P.cx = F.base.cx, P.cy = F.base.cy;
-  P.bf = F.base.bf;
+  {
+    vieo_lba_params prm;
+    memset(&prm, 0, sizeof(prm));
+    memcpy(prm.Rcb, F.base.Rcb, 72), memcpy(prm.tcb, F.base.tcb, 24);
+    prm.fx = F.base.fx, prm.fy = F.base.fy, prm.cx = F.base.cx, prm.cy = F.base.cy, prm.bf = F.base.bf;
+    prm.n_cams = F.base.n_cams, prm.cams = F.base.cams;
+    ocams_from_params(prm, P.cams);
+  }
   P.fixedLast = !F.last_has_prior;  // Optimizer.h:212-213
   P.hasImu = F.imu.dt != 0;
   P.ndim = P.fixedLast ? 15 : 30;
@@ -620,6 +629,7 @@ static void pose_optimization_vio(const vieo_vio_frame& F, const vieo_pose_obs* 
     e.dsqr = e.delta * e.delta;
     e.idx = i;
     e.close = (o.flags & 1) != 0;
+    e.cam = (o.flags >> 8) & 15;
     nInitialCorrespondences++;
     outlier[i] = 0;
   }

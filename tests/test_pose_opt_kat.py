@@ -1,5 +1,6 @@
 """CPU known-answer tests pinning the pose-optimisation oracle (oracle/pose_opt.cc)."""
 import numpy as np
+import pytest
 
 from vieo_slam_amd import synth_ba
 from vieo_slam_amd.ba_types import POSE_FRAME_DTYPE, POSE_OBS_DTYPE
@@ -54,6 +55,22 @@ def test_noiseless_scene_recovers_ground_truth(oracle):
     assert res["n_inliers"] == 200 and not outl.any()
 
 
+@pytest.mark.parametrize("name", ["radtan", "kb8"])
+def test_noiseless_rig_scene_recovers_ground_truth(oracle, name):
+    """a20: distorted cameras of a rig; the projection used to make the data is the float64 python
+    restatement (synth_ba.project_camera), independent of the oracle's C++ one."""
+    rig = synth_ba.camera_rig(name)
+    fr, obs, gt = synth_ba.make_pose_problem(9, n_obs=200, outlier_frac=0.0, noise=0.0, rig=rig)
+    res, outl = oracle.pose_optimization(fr, obs)
+    dt, dr = synth_ba.pose_error(res["nav"], gt)
+    assert dt < 5e-5 and dr < 2e-5, (dt, dr)
+    assert res["n_inliers"] == 200 and not outl.any()
+    Fv, obsv, gtv = synth_ba.make_vio_problem(9, n_obs=200, outlier_frac=0.0, noise=0.0, rig=rig)
+    resv, outlv = oracle.pose_optimization_vio(Fv, obsv)
+    dt, dr = synth_ba.pose_error(resv["base"]["nav"], gtv)
+    assert dt < 2e-3 and dr < 5e-4 and not outlv.any(), (dt, dr)
+
+
 def test_outliers_are_rejected_and_pose_improves(oracle):
     for seed in range(4):
         fr, obs, gt = synth_ba.make_pose_problem(seed)
@@ -78,4 +95,4 @@ def test_too_few_correspondences_and_small_problem(oracle):
 
 
 def test_struct_sizes_match_header():
-    assert POSE_OBS_DTYPE.itemsize == 32 and POSE_FRAME_DTYPE.itemsize == 304
+    assert POSE_OBS_DTYPE.itemsize == 32 and POSE_FRAME_DTYPE.itemsize == 312

@@ -110,3 +110,50 @@ def test_pose_large_batch_one_wavefront_per_frame(oracle):
         dt, dr = synth_ba.pose_error(ores["nav"], res[i]["nav"])
         assert dt < TOL and dr < TOL, (i, dt, dr)
         assert res[i]["n_inliers"] == ores["n_inliers"] and np.array_equal(ooutl[:n], outl[b:b + n])
+
+
+@pytest.mark.parametrize("name,seed", [("radtan", 50), ("radtan", 51), ("kb8", 52), ("kb8", 53)])
+def test_pose_camera_rig(oracle, name, seed):
+    """a20: monocular observations in the distorted cameras of a rig (Radtan stereo pair, four KB8 fisheyes)."""
+    rig = synth_ba.camera_rig(name)
+    fr, obs, gt = synth_ba.make_pose_problem(seed, n_obs=300, rig=rig)
+    assert len(set((obs["flags"] >> 8).tolist())) == len(rig[0])
+    ores, hres, dt, dr = _check(oracle, fr, obs)
+    assert ores["n_inliers"] > 200
+    gdt = float(np.linalg.norm(hres["nav"]["p"] - gt["p"]))  # and the optimum is the true pose
+    gdr = 2 * np.arccos(min(1.0, abs(float(np.dot(hres["nav"]["q"], gt["q"])))))
+    assert gdt < 0.05 and gdr < 0.02
+
+
+def test_pose_camera_mode_switch(oracle):
+    """vieo_pose_set_camera_mode: a mixed batch needs AUTO; under RECTIFIED a rig frame is refused loudly."""
+    rig = synth_ba.camera_rig("kb8")
+    fa, oa, _ = synth_ba.make_pose_problem(60, n_obs=200)
+    fb, ob, gt = synth_ba.make_pose_problem(61, n_obs=200, rig=rig)
+    dC = DeviceBuffer(rig[0].nbytes)
+    dC.upload(rig[0])
+    frames = np.concatenate([fa, fb])
+    frames[1]["obs_begin"] = len(oa)
+    frames[1]["cams"] = dC.ptr
+    obs = np.concatenate([oa, ob])
+    dF, dO = DeviceBuffer(frames.nbytes), DeviceBuffer(obs.nbytes)
+    dU, dR = DeviceBuffer(len(obs)), DeviceBuffer(2 * POSE_RESULT_DTYPE.itemsize)
+    dF.upload(frames)
+    dO.upload(obs)
+    try:
+        for mode in (0, 1, 2):
+            check(lib().vieo_pose_set_camera_mode(mode))
+            check(lib().vieo_pose_optimization_batch_device(dF.ptr, 2, dO.ptr, dU.ptr, dR.ptr, None))
+            check(lib().vieo_device_synchronize())
+            res = dR.download(POSE_RESULT_DTYPE, (2,))
+            for i, (fr, ob_) in enumerate(((fa, oa), (fb, ob))):
+                handled = mode == 0 or mode == i + 1
+                if handled:
+                    ores, _ = oracle.pose_optimization(fr, ob_)
+                    dt, dr = synth_ba.pose_error(ores["nav"], res[i]["nav"])
+                    assert dt < TOL and dr < TOL and res[i]["n_inliers"] == ores["n_inliers"]
+                else:
+                    assert res[i]["status"] < 0 and res[i]["n_inliers"] == 0
+        assert lib().vieo_pose_set_camera_mode(7) != 0
+    finally:
+        check(lib().vieo_pose_set_camera_mode(0))

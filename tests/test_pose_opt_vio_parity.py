@@ -144,3 +144,13 @@ def test_vio_large_batch_one_wavefront_per_frame(oracle):
         if o["has_marg"]:
             Ho = o["H_marg"].reshape(15, 15)
             assert np.allclose(Ho, res[i]["H_marg"].reshape(15, 15), rtol=1e-4, atol=1e-4 * np.abs(Ho).max())
+
+
+@pytest.mark.parametrize("name,seed,marg", [("radtan", 70, True), ("kb8", 71, True), ("kb8", 72, False)])
+def test_vio_camera_rig_parity(oracle, name, seed, marg):
+    """a20: the visual edges of a distorted multi-camera rig (camera index in bits 8..11 of obs.flags)."""
+    rig = synth_ba.camera_rig(name)
+    F, obs, gt = synth_ba.make_vio_problem(seed, n_obs=300, compute_marg=marg, rig=rig)
+    assert F[0]["base"]["n_cams"] == len(rig[0])
+    o, h = _cmp(oracle, F, obs)
+    assert o["base"]["n_inliers"] > 200

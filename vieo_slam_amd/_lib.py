@@ -22,6 +22,7 @@ _SIGS = {
     "vieo_last_error": (ctypes.c_char_p, []),
     "vieo_device_available": (c_i, []),
     "vieo_set_device": (c_i, [c_i]),
+    "vieo_pose_set_camera_mode": (c_i, [c_i]),
     "vieo_get_device": (c_i, []),
     "vieo_version": (ctypes.c_char_p, []),
     "vieo_dev_malloc": (c_i, [P(c_p), c_sz]),

@@ -8,11 +8,11 @@ POSE_OBS_DTYPE = np.dtype([("Xw", "<f4", 3), ("u", "<f4"), ("v", "<f4"), ("ur", 
 POSE_FRAME_DTYPE = np.dtype([("nav", NAVSTATE_DTYPE), ("Rcb", "<f8", 9), ("tcb", "<f8", 3),
                              ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"),
                              ("bf", "<f4"), ("obs_begin", "<i4"), ("n_obs", "<i4"),
-                             ("reserved", "<i4")], align=True)
+                             ("n_cams", "<i4"), ("cams", "<u8")], align=True)  # cams: pointer, see vieo_hot.h
 POSE_RESULT_DTYPE = np.dtype([("nav", NAVSTATE_DTYPE), ("n_inliers", "<i4"), ("status", "<i4"),
                               ("lm_iterations", "<i4"), ("reserved", "<i4")], align=True)
 assert NAVSTATE_DTYPE.itemsize == 176 and POSE_OBS_DTYPE.itemsize == 32
-assert POSE_FRAME_DTYPE.itemsize == 304 and POSE_RESULT_DTYPE.itemsize == 192
+assert POSE_FRAME_DTYPE.itemsize == 312 and POSE_RESULT_DTYPE.itemsize == 192
 
 PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"),
                              ("level_min", "<i4"), ("level_max", "<i4"), ("angle", "<f4"),

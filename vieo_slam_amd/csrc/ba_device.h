@@ -239,6 +239,75 @@ __device__ __forceinline__ void visual_jacobian(const CamD& c, const PoseXf& X, 
     }
 }
 
+// ---- a20: frames of a distorted multi-camera rig (Frame::usedistort_) ----------------------------
+// vieo_camera -> CamD (parameters widened once); false when the model / coefficient count is unknown
+__device__ __host__ inline bool cam_from_abi(const vieo_camera& c, CamD& d) {
+  d.fx = c.fx, d.fy = c.fy, d.cx = c.cx, d.cy = c.cy, d.bf = 0;
+  for (int i = 0; i < 9; i++) d.Rcb[i] = c.Rcb[i];
+  for (int i = 0; i < 3; i++) d.tcb[i] = c.tcb[i];
+  d.model = c.model, d.num_k = c.model == VIEO_CAM_RADTAN ? c.num_k : 0;
+  for (int q = 0; q < 8; q++) d.k[q] = (double)c.dist[q];
+  return !(c.model < 0 || c.model > 2 || (c.model == VIEO_CAM_RADTAN && (c.num_k < 2 || c.num_k > 6)));
+}
+
+// One reprojection edge of a pose optimisation: error (and the Jacobian rows when J != nullptr).
+// MC = false: the frame's single rectified pinhole camera c0 with the per-estimate transforms X0.
+// MC = true: the observation's own camera cams[(flags >> 8) & 15] (Radtan / KB8 / pinhole, monocular
+// edges), whose Rcw / tcw are formed per edge from X0.Rwb and the body position p.
+template <bool MC>
+__device__ __forceinline__ double edge_eval(const CamD& c0, const CamD* cams, const PoseXf& X0, const double* p,
+                                            const vieo_pose_obs& o, double* err, double* Pc, double* J) {
+  if (!MC) {
+    const double chi2 = edge_error(c0, X0, o, err, Pc);
+    if (J) visual_jacobian(c0, X0, p, o, Pc, J);
+    return chi2;
+  }
+  const CamD& c = cams[(o.flags >> 8) & 3];
+  double Rcw[9], tcw[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      Rcw[i * 3 + j] = c.Rcb[i * 3] * X0.Rwb[j * 3] + c.Rcb[i * 3 + 1] * X0.Rwb[j * 3 + 1] +
+                       c.Rcb[i * 3 + 2] * X0.Rwb[j * 3 + 2];
+  for (int i = 0; i < 3; i++)
+    tcw[i] = -(Rcw[i * 3] * p[0] + Rcw[i * 3 + 1] * p[1] + Rcw[i * 3 + 2] * p[2]) + c.tcb[i];
+  const double Xw0 = o.Xw[0], Xw1 = o.Xw[1], Xw2 = o.Xw[2];
+  for (int i = 0; i < 3; i++) Pc[i] = Rcw[i * 3] * Xw0 + Rcw[i * 3 + 1] * Xw1 + Rcw[i * 3 + 2] * Xw2 + tcw[i];
+  double uv[2], Jc[6];
+  cam_project(c, Pc, uv, J ? Jc : nullptr);
+  err[0] = (double)o.u - uv[0];
+  err[1] = (double)o.v - uv[1];
+  const double info = (double)o.inv_sigma2;
+  double chi2 = err[0] * (info * err[0]) + err[1] * (info * err[1]);
+  const bool stereo = o.ur >= 0;
+  if (stereo) {
+    err[2] = (double)o.ur - (uv[0] - c.bf / Pc[2]);
+    chi2 += err[2] * (info * err[2]);
+  } else
+    err[2] = 0;
+  if (J) {
+    const double invz = 1 / Pc[2], invz2 = invz * invz;
+    double Jp[9];
+    for (int i = 0; i < 6; i++) Jp[i] = -Jc[i];
+    Jp[6] = Jp[0], Jp[7] = Jp[1], Jp[8] = Jp[2] - c.bf * invz2;
+    const double dP0 = Xw0 - p[0], dP1 = Xw1 - p[1], dP2 = Xw2 - p[2];
+    double Pa[3];
+    for (int m = 0; m < 3; m++) Pa[m] = X0.Rwb[m] * dP0 + X0.Rwb[3 + m] * dP1 + X0.Rwb[6 + m] * dP2;
+    double RH[9];
+    for (int m = 0; m < 3; m++) {
+      const double a = c.Rcb[m * 3], b = c.Rcb[m * 3 + 1], d = c.Rcb[m * 3 + 2];
+      RH[m * 3 + 0] = b * Pa[2] - d * Pa[1];
+      RH[m * 3 + 1] = -a * Pa[2] + d * Pa[0];
+      RH[m * 3 + 2] = a * Pa[1] - b * Pa[0];
+    }
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++) {
+        J[r * 6 + q] = -(Jp[r * 3] * c.Rcb[q] + Jp[r * 3 + 1] * c.Rcb[3 + q] + Jp[r * 3 + 2] * c.Rcb[6 + q]);
+        J[r * 6 + 3 + q] = Jp[r * 3] * RH[q] + Jp[r * 3 + 1] * RH[3 + q] + Jp[r * 3 + 2] * RH[6 + q];
+      }
+  }
+  return chi2;
+}
+
 // accumulate J^T (w*info) J (21 upper entries) and J^T (-(info*err)*w) (6) of one edge
 __device__ __forceinline__ void visual_accumulate(const double* J, const double* err, double info,
                                                   double r1, bool stereo, double* acc) {

@@ -49,5 +49,8 @@ struct DevBuf {
 };
 
 int require_device();  // VIEO_OK or VIEO_E_NO_DEVICE
+// which pose-optimisation kernels a *_batch_device call launches: bit 0 the rectified-pinhole instance,
+// bit 1 the multi-camera-rig instance (vieo_pose_set_camera_mode)
+int pose_rig_launches();
 
 }  // namespace vieo

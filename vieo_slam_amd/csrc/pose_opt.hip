@@ -47,17 +47,32 @@ static const int kMaxObs = 2048;  // 32 edges per lane at 64 threads per frame, 
 
 // BS threads per frame: 256 for a few frames (lowest latency), 64 = one wavefront per frame for large
 // batches (four frames per CU in flight), as in pose_opt_vio.hip
-template <int BS>
+// MC = true handles the frames of a distorted multi-camera rig (n_cams > 0, a20), MC = false all others;
+// each instance leaves the other's frames alone, so a mixed batch takes both launches.
+template <int BS, bool MC>
 __global__ void __launch_bounds__(BS)
 k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
-           uint8_t* __restrict__ outlier_all, vieo_pose_result* __restrict__ results) {
+           uint8_t* __restrict__ outlier_all, vieo_pose_result* __restrict__ results, int other_launched) {
   __shared__ double s_red[4 * 27];
+  __shared__ __align__(8) unsigned char s_cam_store[sizeof(CamD) * (MC ? 4 : 1)];  // CamD has initialisers
+  CamD* s_cams = reinterpret_cast<CamD*>(s_cam_store);
+  __shared__ int s_bad;
   const int f = blockIdx.x, tid = threadIdx.x;
   const vieo_pose_frame& F = frames[f];
   const int N = F.n_obs;
   const vieo_pose_obs* obs = obs_all + F.obs_begin;
   uint8_t* outl = outlier_all + F.obs_begin;
   vieo_pose_result* R = results + f;
+  if ((F.n_cams > 0) != MC) {
+    if (!other_launched) {  // vieo_pose_set_camera_mode promised frames of the other kind only
+      for (int i = tid; i < N; i += BS) outl[i] = 0;
+      if (tid == 0) {
+        R->nav = F.nav;
+        R->n_inliers = 0, R->status = VIEO_E_INVALID, R->lm_iterations = 0, R->reserved = 0;
+      }
+    }
+    return;
+  }
   if (N < 3 || N > kMaxObs) {  // Optimizer.cc:1789
     for (int i = tid; i < N; i += BS) outl[i] = 0;
     if (tid == 0) {
@@ -73,6 +88,23 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
   c.fx = F.fx, c.fy = F.fy, c.cx = F.cx, c.cy = F.cy, c.bf = F.bf;
   for (int i = 0; i < 9; i++) c.Rcb[i] = F.Rcb[i];
   for (int i = 0; i < 3; i++) c.tcb[i] = F.tcb[i];
+  if (MC) {
+    if (tid == 0) s_bad = F.n_cams > 4 || !F.cams;
+    __syncthreads();
+    if (tid < 4 && !s_bad) {
+      const bool ok = cam_from_abi(F.cams[tid < F.n_cams ? tid : 0], s_cams[tid]);
+      if (!ok) s_bad = 1;
+    }
+    __syncthreads();
+    if (s_bad) {
+      for (int i = tid; i < N; i += BS) outl[i] = 0;
+      if (tid == 0) {
+        R->nav = F.nav;
+        R->n_inliers = 0, R->status = VIEO_E_INVALID, R->lm_iterations = 0, R->reserved = 0;
+      }
+      return;
+    }
+  }
   // `const float deltaMono = sqrt(5.991)`: double sqrt rounded to float (Optimizer.cc:1689-1690)
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
@@ -106,7 +138,8 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
           if ((levelmask >> k) & 1) continue;
           const vieo_pose_obs o = obs[i];
           double err[3], Pc[3];
-          const double chi2 = edge_error(c, X, o, err, Pc);
+          double J[18];
+          const double chi2 = edge_eval<MC>(c, s_cams, X, est.p, o, err, Pc, J);
           const bool stereo = o.ur >= 0;
           double r0 = chi2, r1 = 1.;
           if (robust) {
@@ -114,8 +147,6 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
             huber(chi2, dl, dl * dl, &r0, &r1);
           }
           chi += r0;
-          double J[18];
-          visual_jacobian(c, X, est.p, o, Pc, J);
           visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
         }
         est_err = est;
@@ -154,7 +185,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
             if ((levelmask >> k) & 1) continue;
             const vieo_pose_obs o = obs[i];
             double err[3], Pc[3];
-            const double chi2 = edge_error(c, X2, o, err, Pc);
+            const double chi2 = edge_eval<MC>(c, s_cams, X2, est.p, o, err, Pc, nullptr);
             double r0 = chi2, r1 = 1.;
             if (robust) {
               const double dl = o.ur >= 0 ? deltaStereo : deltaMono;
@@ -202,7 +233,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
       const vieo_pose_obs o = obs[i];
       const bool was_out = (levelmask >> k) & 1;
       double err[3], Pc[3];
-      const float chi2 = (float)edge_error(c, was_out ? Xc : Xe, o, err, Pc);
+      const float chi2 = (float)edge_eval<MC>(c, s_cams, was_out ? Xc : Xe, was_out ? est.p : est_err.p, o, err, Pc, nullptr);
       const float th = o.ur >= 0 ? chi2Stereo : chi2Mono;
       if (chi2 > th) {
         levelmask |= (1u << k);
@@ -232,9 +263,8 @@ using namespace vieo;
 
 extern "C" {
 
-int vieo_pose_optimization_batch_device(const vieo_pose_frame* d_frames, int n_frames,
-                                        const vieo_pose_obs* d_obs, uint8_t* d_outlier,
-                                        vieo_pose_result* d_results, void* stream) {
+static int pose_launch(const vieo_pose_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
+                       uint8_t* d_outlier, vieo_pose_result* d_results, int which, void* stream) {
   if (!d_frames || n_frames <= 0 || !d_obs || !d_outlier || !d_results) return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
@@ -242,14 +272,32 @@ int vieo_pose_optimization_batch_device(const vieo_pose_frame* d_frames, int n_f
     const char* e = getenv("VIEO_POSE_THREADS");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 64 || (forced != 256 && n_frames > 256))
-    hipLaunchKernelGGL(k_pose_opt<64>, dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames, d_obs, d_outlier,
-                       d_results);
-  else
-    hipLaunchKernelGGL(k_pose_opt<256>, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames, d_obs,
-                       d_outlier, d_results);
+  const bool narrow = forced == 64 || (forced != 256 && n_frames > 256);
+  const int both = which == 3;
+  if (which & 1) {
+    if (narrow)
+      hipLaunchKernelGGL((k_pose_opt<64, false>), dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames, d_obs,
+                         d_outlier, d_results, both);
+    else
+      hipLaunchKernelGGL((k_pose_opt<256, false>), dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames,
+                         d_obs, d_outlier, d_results, both);
+  }
+  if (which & 2) {
+    if (narrow)
+      hipLaunchKernelGGL((k_pose_opt<64, true>), dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames, d_obs,
+                         d_outlier, d_results, both);
+    else
+      hipLaunchKernelGGL((k_pose_opt<256, true>), dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames,
+                         d_obs, d_outlier, d_results, both);
+  }
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
+}
+
+int vieo_pose_optimization_batch_device(const vieo_pose_frame* d_frames, int n_frames,
+                                        const vieo_pose_obs* d_obs, uint8_t* d_outlier,
+                                        vieo_pose_result* d_results, void* stream) {
+  return pose_launch(d_frames, n_frames, d_obs, d_outlier, d_results, vieo::pose_rig_launches(), stream);
 }
 
 int vieo_pose_optimization(const vieo_pose_frame* h_frame, const vieo_pose_obs* h_obs,
@@ -257,19 +305,28 @@ int vieo_pose_optimization(const vieo_pose_frame* h_frame, const vieo_pose_obs* 
   if (!h_frame || !h_result || (h_frame->n_obs > 0 && (!h_obs || !h_outlier))) return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
-  static thread_local DevBuf dF, dO, dU, dR;
-  const int n = h_frame->n_obs;
+  static thread_local DevBuf dF, dO, dU, dR, dC;
+  const int n = h_frame->n_obs, nc = h_frame->n_cams;
+  if (nc < 0 || nc > 4 || (nc > 0 && !h_frame->cams)) {
+    set_error("PoseOptimization: n_cams = %d (0..4) needs `cams`", nc);
+    return VIEO_E_INVALID;
+  }
   if ((rc = dF.ensure(sizeof(vieo_pose_frame))) != VIEO_OK) return rc;
+  if ((rc = dC.ensure(4 * sizeof(vieo_camera))) != VIEO_OK) return rc;
   if ((rc = dO.ensure((size_t)std::max(n, 1) * sizeof(vieo_pose_obs))) != VIEO_OK) return rc;
   if ((rc = dU.ensure(std::max(n, 1))) != VIEO_OK) return rc;
   if ((rc = dR.ensure(sizeof(vieo_pose_result))) != VIEO_OK) return rc;
   vieo_pose_frame F = *h_frame;
   const vieo_pose_obs* src = h_obs + h_frame->obs_begin;
   F.obs_begin = 0;
+  if (nc > 0) {
+    VIEO_HIP_CHECK(hipMemcpy(dC.p, h_frame->cams, (size_t)nc * sizeof(vieo_camera), hipMemcpyHostToDevice));
+    F.cams = dC.as<vieo_camera>();
+  }
   VIEO_HIP_CHECK(hipMemcpy(dF.p, &F, sizeof(F), hipMemcpyHostToDevice));
   if (n > 0) VIEO_HIP_CHECK(hipMemcpy(dO.p, src, (size_t)n * sizeof(vieo_pose_obs), hipMemcpyHostToDevice));
-  rc = vieo_pose_optimization_batch_device(dF.as<vieo_pose_frame>(), 1, dO.as<vieo_pose_obs>(),
-                                           dU.as<uint8_t>(), dR.as<vieo_pose_result>(), nullptr);
+  rc = pose_launch(dF.as<vieo_pose_frame>(), 1, dO.as<vieo_pose_obs>(), dU.as<uint8_t>(),
+                   dR.as<vieo_pose_result>(), nc > 0 ? 2 : 1, nullptr);
   if (rc != VIEO_OK) return rc;
   VIEO_HIP_CHECK(hipMemcpy(h_result, dR.p, sizeof(vieo_pose_result), hipMemcpyDeviceToHost));
   if (n > 0) VIEO_HIP_CHECK(hipMemcpy(h_outlier + h_frame->obs_begin, dU.p, n, hipMemcpyDeviceToHost));

@@ -174,11 +174,14 @@ struct VioShared {
 
 // BS threads per frame: 256 (four wavefronts share a frame: lowest latency for a few frames) or 64
 // (one wavefront per frame, four frames per CU in flight: highest throughput for large batches)
-template <int BS>
+// MC as in pose_opt.hip: the instance for frames of a distorted multi-camera rig (n_cams > 0, a20)
+template <int BS, bool MC>
 __global__ void __launch_bounds__(BS)
 k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
-               uint8_t* __restrict__ outlier_all, vieo_vio_result* __restrict__ results) {
+               uint8_t* __restrict__ outlier_all, vieo_vio_result* __restrict__ results, int other_launched) {
   __shared__ VioShared S;
+  __shared__ __align__(8) unsigned char s_cam_store[sizeof(CamD) * (MC ? 4 : 1)];  // CamD has initialisers
+  CamD* s_cams = reinterpret_cast<CamD*>(s_cam_store);
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T1 = BS > 64 ? 64 : 0, T2 = BS > 128 ? 128 : 0;  // lanes of the second / third serial role
   const vieo_vio_frame& F = frames[f];
@@ -186,13 +189,25 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const vieo_pose_obs* obs = obs_all + F.base.obs_begin;
   uint8_t* outl = outlier_all + F.base.obs_begin;
   vieo_vio_result* R = results + f;
-  if ((N < 3 && !F.no_mps) || N > kVioMaxObs) {  // Optimizer.h:499-503
+  const bool other_kind = (F.base.n_cams > 0) != MC;
+  if (other_kind && other_launched) return;
+  bool bad_cams = other_kind;  // vieo_pose_set_camera_mode promised frames of the other kind only
+  if (MC && !other_kind) {
+    if (tid == 0) S.ok = !(F.base.n_cams > 4 || !F.base.cams);
+    __syncthreads();
+    if (tid < 4 && S.ok)
+      if (!cam_from_abi(F.base.cams[tid < F.base.n_cams ? tid : 0], s_cams[tid])) S.ok = 0;
+    __syncthreads();
+    bad_cams = !S.ok;
+    __syncthreads();
+  }
+  if (bad_cams || (N < 3 && !F.no_mps) || N > kVioMaxObs) {  // Optimizer.h:499-503
     for (int i = tid; i < N; i += BS) outl[i] = 0;
     for (int i = tid; i < 225; i += BS) R->H_marg[i] = 0;
     if (tid == 0) {
       R->base.nav = F.base.nav;
       R->base.n_inliers = 0;
-      R->base.status = N > kVioMaxObs ? VIEO_E_CAPACITY : VIEO_POSE_TOO_FEW;
+      R->base.status = bad_cams ? VIEO_E_INVALID : N > kVioMaxObs ? VIEO_E_CAPACITY : VIEO_POSE_TOO_FEW;
       R->base.lm_iterations = 0;
       R->base.reserved = 0;
       R->has_marg = 0;
@@ -326,7 +341,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       if ((levelmask >> k) & 1) continue;
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
-      const double chi2 = edge_error(c, X, o, err, Pc);
+      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr);
       double r0 = chi2, r1 = 1.;
       if (vis_robust) {
         const double dl = o.ur >= 0 ? deltaStereo : deltaMono;
@@ -364,7 +379,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         if ((levelmask >> k) & 1) continue;
         const vieo_pose_obs o = obs[i];
         double err[3], Pc[3];
-        const double chi2 = edge_error(c, X, o, err, Pc);
+        double J[18];
+        const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J);
         const bool stereo = o.ur >= 0;
         double r0 = chi2, r1 = 1.;
         if (vis_robust) {
@@ -372,8 +388,6 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           huber(chi2, dl, dl * dl, &r0, &r1);
         }
         acc[27] += r0;
-        double J[18];
-        visual_jacobian(c, X, e.p, o, Pc, J);
         visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
       }
       block_sum_bs<28, BS>(acc, S.red, tid);
@@ -533,7 +547,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     for (int k = 0, i = tid; i < N; k++, i += BS) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
-      const float chi2 = (float)edge_error(c, X, o, err, Pc);
+      const float chi2 = (float)edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr);
       bool bad;
       if (o.ur < 0)
         bad = chi2 > ((o.flags & 1) ? chi2close : chi2Mono) || !(Pc[2] > 0.);
@@ -561,7 +575,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     for (int k = 0, i = tid; i < N; k++, i += BS) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
-      const double chi2 = edge_error(c, X, o, err, Pc);
+      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr);
       if (chi2 < (double)(o.ur < 0 ? 18.f : 24.f)) {
         levelmask &= ~(1u << k);
         outmask &= ~(1u << k);
@@ -588,15 +602,14 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       if ((levelmask >> k) & 1) continue;
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
-      const double chi2 = edge_error(c, X, o, err, Pc);
+      double J[18];
+      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J);
       const bool stereo = o.ur >= 0;
       double r0 = chi2, r1 = 1.;
       if (vis_robust) {
         const double dl = stereo ? deltaStereo : deltaMono;
         huber(chi2, dl, dl * dl, &r0, &r1);
       }
-      double J[18];
-      visual_jacobian(c, X, e.p, o, Pc, J);
       visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
     }
     block_sum_bs<27, BS>(acc, S.red, tid);
@@ -735,9 +748,8 @@ using namespace vieo;
 
 extern "C" {
 
-int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int n_frames,
-                                            const vieo_pose_obs* d_obs, uint8_t* d_outlier,
-                                            vieo_vio_result* d_results, void* stream) {
+static int vio_launch(const vieo_vio_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
+                      uint8_t* d_outlier, vieo_vio_result* d_results, int which, void* stream) {
   if (!d_frames || n_frames <= 0 || !d_obs || !d_outlier || !d_results) return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
@@ -747,14 +759,32 @@ int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int 
     const char* e = getenv("VIEO_POSE_THREADS");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 64 || (forced != 256 && n_frames > 256))
-    hipLaunchKernelGGL(k_pose_opt_vio<64>, dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames, d_obs,
-                       d_outlier, d_results);
-  else
-    hipLaunchKernelGGL(k_pose_opt_vio<256>, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames, d_obs,
-                       d_outlier, d_results);
+  const bool narrow = forced == 64 || (forced != 256 && n_frames > 256);
+  const int both = which == 3;
+  if (which & 1) {
+    if (narrow)
+      hipLaunchKernelGGL((k_pose_opt_vio<64, false>), dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames,
+                         d_obs, d_outlier, d_results, both);
+    else
+      hipLaunchKernelGGL((k_pose_opt_vio<256, false>), dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames,
+                         d_obs, d_outlier, d_results, both);
+  }
+  if (which & 2) {
+    if (narrow)
+      hipLaunchKernelGGL((k_pose_opt_vio<64, true>), dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames,
+                         d_obs, d_outlier, d_results, both);
+    else
+      hipLaunchKernelGGL((k_pose_opt_vio<256, true>), dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames,
+                         d_obs, d_outlier, d_results, both);
+  }
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
+}
+
+int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int n_frames,
+                                            const vieo_pose_obs* d_obs, uint8_t* d_outlier,
+                                            vieo_vio_result* d_results, void* stream) {
+  return vio_launch(d_frames, n_frames, d_obs, d_outlier, d_results, vieo::pose_rig_launches(), stream);
 }
 
 int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_obs* h_obs,
@@ -762,19 +792,28 @@ int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_ob
   if (!h_frame || !h_result || (h_frame->base.n_obs > 0 && (!h_obs || !h_outlier))) return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
-  static thread_local DevBuf dF, dO, dU, dR;
-  const int n = h_frame->base.n_obs;
+  static thread_local DevBuf dF, dO, dU, dR, dC;
+  const int n = h_frame->base.n_obs, nc = h_frame->base.n_cams;
+  if (nc < 0 || nc > 4 || (nc > 0 && !h_frame->base.cams)) {
+    set_error("PoseOptimization (VIO): n_cams = %d (0..4) needs `cams`", nc);
+    return VIEO_E_INVALID;
+  }
   if ((rc = dF.ensure(sizeof(vieo_vio_frame))) != VIEO_OK) return rc;
+  if ((rc = dC.ensure(4 * sizeof(vieo_camera))) != VIEO_OK) return rc;
   if ((rc = dO.ensure((size_t)std::max(n, 1) * sizeof(vieo_pose_obs))) != VIEO_OK) return rc;
   if ((rc = dU.ensure(std::max(n, 1))) != VIEO_OK) return rc;
   if ((rc = dR.ensure(sizeof(vieo_vio_result))) != VIEO_OK) return rc;
   vieo_vio_frame F = *h_frame;
   const vieo_pose_obs* src = h_obs + h_frame->base.obs_begin;
   F.base.obs_begin = 0;
+  if (nc > 0) {
+    VIEO_HIP_CHECK(hipMemcpy(dC.p, h_frame->base.cams, (size_t)nc * sizeof(vieo_camera), hipMemcpyHostToDevice));
+    F.base.cams = dC.as<vieo_camera>();
+  }
   VIEO_HIP_CHECK(hipMemcpy(dF.p, &F, sizeof(F), hipMemcpyHostToDevice));
   if (n > 0) VIEO_HIP_CHECK(hipMemcpy(dO.p, src, (size_t)n * sizeof(vieo_pose_obs), hipMemcpyHostToDevice));
-  rc = vieo_pose_optimization_vio_batch_device(dF.as<vieo_vio_frame>(), 1, dO.as<vieo_pose_obs>(),
-                                               dU.as<uint8_t>(), dR.as<vieo_vio_result>(), nullptr);
+  rc = vio_launch(dF.as<vieo_vio_frame>(), 1, dO.as<vieo_pose_obs>(), dU.as<uint8_t>(),
+                  dR.as<vieo_vio_result>(), nc > 0 ? 2 : 1, nullptr);
   if (rc != VIEO_OK) return rc;
   VIEO_HIP_CHECK(hipMemcpy(h_result, dR.p, sizeof(vieo_vio_result), hipMemcpyDeviceToHost));
   if (n > 0) VIEO_HIP_CHECK(hipMemcpy(h_outlier + h_frame->base.obs_begin, dU.p, n, hipMemcpyDeviceToHost));

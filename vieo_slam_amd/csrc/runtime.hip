@@ -1,4 +1,5 @@
 // runtime.hip -- error reporting, device probing and the small memory helpers of the C-ABI.
+#include <atomic>
 #include <mutex>
 
 #include "common.h"
@@ -35,6 +36,12 @@ int require_device() {
   return VIEO_OK;
 }
 
+std::atomic<int> g_pose_cams_mode{VIEO_POSE_CAMS_AUTO};
+int pose_rig_launches() {
+  const int m = g_pose_cams_mode.load();
+  return m == VIEO_POSE_CAMS_RECTIFIED ? 1 : m == VIEO_POSE_CAMS_RIG ? 2 : 3;
+}
+
 }  // namespace vieo
 
 extern "C" {
@@ -53,6 +60,12 @@ int vieo_set_device(int device) {
     return VIEO_E_INVALID;
   }
   VIEO_HIP_CHECK(hipSetDevice(device));
+  return VIEO_OK;
+}
+
+int vieo_pose_set_camera_mode(int mode) {
+  if (mode < VIEO_POSE_CAMS_AUTO || mode > VIEO_POSE_CAMS_RIG) return VIEO_E_INVALID;
+  vieo::g_pose_cams_mode.store(mode);
   return VIEO_OK;
 }
 

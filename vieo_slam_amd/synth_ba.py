@@ -46,9 +46,13 @@ def pose_error(nav_a, nav_b):
 
 
 def make_pose_problem(seed, n_obs=300, outlier_frac=0.10, stereo_frac=0.70, noise=1.0,
-                      pert_t=0.03, pert_r_deg=1.0):
-    """returns (frame[1] POSE_FRAME_DTYPE, obs[n] POSE_OBS_DTYPE, truth dict)."""
+                      pert_t=0.03, pert_r_deg=1.0, rig=None):
+    """returns (frame[1] POSE_FRAME_DTYPE, obs[n] POSE_OBS_DTYPE, truth dict).
+    rig = (cams, size) from camera_rig(): monocular observations spread over the distorted cameras of the rig
+    (Frame::usedistort_), camera index in bits 8..11 of obs.flags; truth["cams"] keeps the array alive."""
     rng = np.random.default_rng(seed)
+    if rig is not None:
+        return _make_pose_problem_rig(rng, n_obs, outlier_frac, noise, pert_t, pert_r_deg, rig)
     Tcb = np.linalg.inv(EUROC_TBC)
     Rcb, tcb = Tcb[:3, :3], Tcb[:3, 3]
     q_gt = quat_from_rotvec(rng.normal(0, 0.6, 3))
@@ -89,6 +93,46 @@ def make_pose_problem(seed, n_obs=300, outlier_frac=0.10, stereo_frac=0.70, nois
     f["fx"], f["fy"], f["cx"], f["cy"], f["bf"] = FX, FY, CX, CY, BF
     f["obs_begin"], f["n_obs"] = 0, n_obs
     return frame, obs, {"p": p_gt, "q": q_gt, "is_outlier": is_out}
+
+
+def _make_pose_problem_rig(rng, n_obs, outlier_frac, noise, pert_t, pert_r_deg, rig):
+    cams, _ = rig
+    q_gt = quat_from_rotvec(rng.normal(0, 0.6, 3))
+    p_gt = rng.uniform(-5, 5, 3)
+    Rwb = quat_to_R(q_gt)
+    ci = rng.integers(0, len(cams), n_obs)
+    z = rng.uniform(1.0, 15.0, n_obs)
+    xn, yn = rng.uniform(-0.7, 0.7, n_obs), rng.uniform(-0.45, 0.45, n_obs)
+    obs = np.zeros(n_obs, POSE_OBS_DTYPE)
+    level = rng.integers(0, 8, n_obs)
+    sig = 1.2 ** level
+    is_out = rng.random(n_obs) < outlier_frac
+    for i in range(n_obs):
+        c = cams[ci[i]]
+        Rcb, tcb = c["Rcb"].reshape(3, 3), c["tcb"]
+        Xc = np.array([xn[i] * z[i], yn[i] * z[i], z[i]])
+        Xw32 = (Rwb @ (Rcb.T @ (Xc - tcb)) + p_gt).astype(np.float32)
+        Xc2 = Rcb @ (Rwb.T @ (Xw32.astype(np.float64) - p_gt)) + tcb
+        u, v = project_camera(c, Xc2)
+        u += rng.normal(0, noise) * sig[i]
+        v += rng.normal(0, noise) * sig[i]
+        if is_out[i]:
+            u += rng.uniform(-60, 60)
+            v += rng.uniform(-60, 60)
+        o = obs[i]
+        o["Xw"], o["u"], o["v"], o["ur"] = Xw32, u, v, -1.0
+        o["flags"] = int(Xc2[2] < 35.0) | (int(ci[i]) << 8)
+    obs["inv_sigma2"] = (np.float32(1.0) / (np.float32(1.2) ** level).astype(np.float32) ** 2)
+    frame = np.zeros(1, POSE_FRAME_DTYPE)
+    f = frame[0]
+    dq = quat_from_rotvec(rng.normal(0, 1, 3) / np.sqrt(3) * np.deg2rad(pert_r_deg))
+    f["nav"]["p"] = p_gt + rng.normal(0, 1, 3) / np.sqrt(3) * pert_t
+    f["nav"]["q"] = quat_mul(q_gt, dq)
+    f["Rcb"], f["tcb"] = cams[0]["Rcb"], cams[0]["tcb"]
+    f["fx"], f["fy"], f["cx"], f["cy"], f["bf"] = cams[0]["fx"], cams[0]["fy"], cams[0]["cx"], cams[0]["cy"], 0
+    f["obs_begin"], f["n_obs"] = 0, n_obs
+    f["n_cams"], f["cams"] = len(cams), cams.ctypes.data
+    return frame, obs, {"p": p_gt, "q": q_gt, "is_outlier": is_out, "cams": cams}
 
 
 # ----------------------------------------------------------------------------------------------
