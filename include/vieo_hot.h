@@ -144,6 +144,37 @@ int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* 
                                    int capacity, const int32_t* h_pairs, int n_pairs,
                                    int32_t* d_idx, int32_t* d_dist, void* stream);
 
+/* void Frame::ComputeStereoFishEyeMatches(const float th_far_pts) (src/Frame.cc:613-779), the stereo stage of
+ * the distorted multi-camera configurations: dense knn-2 between every camera pair (rows [num_mono, n)),
+ * Lowe ratio 0.7 / (<75 and 0.9) (:661-663), camm::GeometricCamera::FillMatchesFromPair with
+ * USE_STRATEGY_MIN_DIST (common/config.h:12; camera_base.h:408-574: UnProject, parallax gate, DLT triangulation
+ * :576-608, positive depth, reprojection chi2 5.991*sigma2), the second pass with the far-point parallax
+ * threshold when fewer than 30 matches survive, the all-camera re-triangulation of every group when
+ * n_cams > 2 (:704-737), and vdepth_ of the concatenated key list (:742-764).
+ *   device: the knn-2 searches, every pair / group triangulation.
+ *   host (inside the library): the order-dependent group bookkeeping, as in the reference.
+ * Outputs: h_depth / h_key_group [sum n_keys] in mvKeys order (camera-major): depth in the key's own camera
+ * (-1: none) and mapcamidx2idxs_ (-1: none); the groups mvidxsMatches (h_group_idx [n_groups][n_cams], -1:
+ * none), goodmatches_, v3dpoints_ (reference-camera frame).  VIEO_E_CAPACITY when more than group_capacity
+ * groups form. */
+typedef struct vieo_fisheye_params {
+  int32_t n_cams;   /* 2..4 */
+  int32_t n_levels; /* entries of level_sigma2 */
+  float bf;         /* stereoinfo_.baseline_bf_[1] */
+  float th_far_pts; /* <= 0: the two parallax thresholds stay 0.9998 and 1 - 1e-6 */
+  const struct vieo_camera* cams; /* model + float parameters of mpCameras[i] (Rcb / tcb unused here) */
+  const double* Trc;         /* [n_cams][12] row-major 3x4 of mpCameras[i]->GetTrc().cast<double>() */
+  const double* Tcr;         /* [n_cams][12] row-major 3x4 of mpCameras[i]->GetTcr().cast<double>() */
+  const float* level_sigma2; /* scalepyrinfo_.vlevelsigma2_ */
+} vieo_fisheye_params;
+
+int vieo_stereo_fisheye_match(const vieo_fisheye_params* params, const vieo_keypoint* const* h_keys /*[n_cams]*/,
+                              const uint8_t* const* h_descriptors /*[n_cams] rows of 32 bytes*/,
+                              const int32_t* n_keys /*[n_cams]*/, const int32_t* num_mono /*[n_cams]*/,
+                              int32_t group_capacity, float* h_depth, int32_t* h_key_group,
+                              int32_t* h_group_idx, uint8_t* h_group_good, double* h_group_p3d,
+                              int32_t* n_groups, int32_t* n_matches);
+
 /* void Frame::ComputeStereoMatches() (src/Frame.cc:451-611), rectified stereo: row-band Hamming
  * search (octave +-1, disparity window [0, bf/baseline]), 11 SADs of 11x11 patches on the
  * left key's pyramid level, parabola sub-pixel fit, rejection above 1.5*1.4*median SAD.

@@ -55,6 +55,7 @@ _SIGS = {
     "vieo_orb_timed_steps": (c_i, [c_p]),
     "vieo_orb_stage_ms": (c_i, [c_p, c_i, c_p]),
     "vieo_hamming_knn2": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
+    "vieo_stereo_fisheye_match": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "vieo_hamming_knn2_batch_device": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
     "vieo_stereo_match_rectified": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_f, c_p, c_p]),
     "vieo_stereo_match_rectified_batch_device": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p]),

@@ -1,6 +1,7 @@
 """Host-side mirrors of the reference's stereo descriptor searches on top of the C-ABI:
   knn_match2(query, train)             cv::BFMatcher(NORM_HAMMING).knnMatch(k=2)  (Frame.cc:620-628)
   compute_stereo_matches(extL, extR..) Frame::ComputeStereoMatches                (Frame.cc:451-611)
+  compute_stereo_fisheye_matches(..)   Frame::ComputeStereoFishEyeMatches         (Frame.cc:613-779)
 """
 import numpy as np
 
@@ -28,6 +29,39 @@ def compute_stereo_matches(ext_left, ext_right, kps_l, desc_l, kps_r, desc_r, ba
                                             len(kr), baseline, bf, ur.ctypes.data, dp.ctypes.data),
           "vieo_stereo_match_rectified")
     return ur, dp
+
+
+def fisheye_call(fn, params, keys, descs, num_mono, group_capacity=None):
+    """Marshals one ComputeStereoFishEyeMatches call for `fn` (the C-ABI entry, or the test oracle's function of
+    the same signature).  params: FISHEYE_PARAMS_DTYPE[1]; keys[c]: KEYPOINT_DTYPE[n_c]; descs[c]: uint8[n_c, 32].
+    returns dict(depth float32[N], key_group int32[N], group_idx int32[G, n_cams], group_good bool[G],
+    group_p3d float64[G, 3], n_matches) with N = sum n_c in mvKeys (camera-major) order."""
+    import ctypes
+    nc = int(params[0]["n_cams"])
+    keys = [np.ascontiguousarray(k) for k in keys]
+    descs = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in descs]
+    n_keys = np.array([len(k) for k in keys], np.int32)
+    mono = np.ascontiguousarray(num_mono, np.int32)
+    kp = (ctypes.c_void_p * nc)(*[k.ctypes.data for k in keys])
+    dp = (ctypes.c_void_p * nc)(*[d.ctypes.data for d in descs])
+    N = int(n_keys.sum())
+    cap = int(group_capacity if group_capacity is not None else max(N, 1))
+    depth, kg = np.zeros(max(N, 1), np.float32), np.zeros(max(N, 1), np.int32)
+    gidx, good = np.zeros((cap, nc), np.int32), np.zeros(cap, np.uint8)
+    p3d, ng, nm = np.zeros((cap, 3), np.float64), np.zeros(1, np.int32), np.zeros(1, np.int32)
+    rc = fn(params.ctypes.data, ctypes.cast(kp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p),
+            n_keys.ctypes.data, mono.ctypes.data, cap, depth.ctypes.data, kg.ctypes.data, gidx.ctypes.data,
+            good.ctypes.data, p3d.ctypes.data, ng.ctypes.data, nm.ctypes.data)
+    g = int(ng[0])
+    return rc, dict(depth=depth[:N], key_group=kg[:N], group_idx=gidx[:g], group_good=good[:g].astype(bool),
+                    group_p3d=p3d[:g], n_matches=int(nm[0]))
+
+
+def compute_stereo_fisheye_matches(params, keys, descs, num_mono, group_capacity=None):
+    """void Frame::ComputeStereoFishEyeMatches(th_far_pts) (Frame.cc:613-779); see fisheye_call for the result."""
+    rc, out = fisheye_call(lib().vieo_stereo_fisheye_match, params, keys, descs, num_mono, group_capacity)
+    check(rc, "vieo_stereo_fisheye_match")
+    return out
 
 
 class ORBmatcher:

@@ -556,10 +556,11 @@ def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_fra
 
 
 # ---- distorted multi-camera rigs (a20: Radtan / KB8 models, per-observation camera) --------------
-def camera_rig(name):
+def camera_rig(name, with_tcr=False):
     """(CAMERA_DTYPE array, (width, height)) of a rig as the BA edges see it: EdgeReproject::SetParams
     already applied (Rcb = Rccr * Rcrb, tcb = Rccr * tcrb + tcr).  'radtan': the two EuRoC cameras
-    (k1 k2 p1 p2); 'kb8': four TUM-VI-like fisheye cameras (k1..k4)."""
+    (k1 k2 p1 p2); 'kb8': four TUM-VI-like fisheye cameras (k1..k4).
+    with_tcr: also the list of 4x4 Tcr (reference camera -> camera i)."""
     from .ba_types import CAMERA_DTYPE
     Tcb = np.linalg.inv(EUROC_TBC)
     Rcrb, tcrb = Tcb[:3, :3], Tcb[:3, 3]
@@ -591,6 +592,8 @@ def camera_rig(name):
         Rccr, tcr = Tcr[i][:3, :3], Tcr[i][:3, 3]
         c["Rcb"] = (Rccr @ Rcrb).reshape(-1)
         c["tcb"] = Rccr @ tcrb + tcr
+    if with_tcr:
+        return cams, size, Tcr
     return cams, size
 
 
