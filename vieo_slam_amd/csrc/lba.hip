@@ -87,6 +87,7 @@ struct LbaDev {
   double gw[3];
   int ldB, ldS;                   // leading dimensions of BB (3 x points, padded) and of a partial
   int* kf_list;                   // [n_free] free + active key frames in column order
+  int* kf_act;                    // [n_kf] scratch of k_lba_begin: the key frame has an active edge
   const int *kf_edge_first, *kf_edge_idx;  // edges grouped by key frame
   int* tab;                       // [nf_cap][n_mp] edge of (free kf ordinal, point), -1 = none
   LbaKf *kf, *kf_bak;
@@ -98,6 +99,9 @@ struct LbaDev {
   double* Sp;                     // [ksplit][sp_rows][ldS] partial Schur products
   size_t sp_stride;
   double *Hll, *bl, *Hpp, *bp, *Hs, *bs, *xp;
+  double *Hb, *Wp;                // tiled solve of a large reduced system: padded copy [nb][nb], panel [nb][64]
+  int* big_fail;                  //   and its "not positive definite" flag
+  int nb;
   double *part0, *part, *part_m, *pmax;  // per-block partials
   CamD cam;                       // the single rectified pinhole camera (n_cams == 0) ...
   CamD cams[4];                   // ... or the physical cameras of a distorted multi-camera rig
@@ -250,12 +254,12 @@ k_lba_zero(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
 // ---- initializeOptimization(0): one workgroup per window
 __global__ void __launch_bounds__(256)
 k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
-  __shared__ int s_act[128];
   const int w = blockIdx.x, tid = threadIdx.x;
   if (!(ctl[w].flags & LBA_BEGIN)) return;
   LbaDev& D = devs[w];
   const int n_mp = D.n_mp, n_obs = D.n_obs, n_kf = D.n_kf;
-  if (tid < 128) s_act[tid] = 0;
+  int* s_act = D.kf_act;
+  for (int k = tid; k < n_kf; k += 256) s_act[k] = 0;
   for (int m = tid; m < n_mp; m += 256) D.mp_act[m] = 0;
   __syncthreads();
   for (int i = tid; i < n_obs; i += 256)
@@ -849,6 +853,36 @@ k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, i
 // rank-1 updates in sequence -- the arithmetic of the column-by-column algorithm with 1/PW of its
 // barriers.  use_lds: the lower triangle lives packed in LDS (n <= ~186), otherwise the matrix is
 // factorised in place in global memory.
+// The end of a solve, shared by the single-workgroup LDL^T and the tiled one: x -> D.xp, the pose part of
+// computeScale(), push() + oplus on the free key frames.  y: the solution (LDS or global), 256 threads.
+__device__ __forceinline__ void lba_apply_step(const LbaDev& D, const double* y, double lambda, bool ok, WinOut& o,
+                                               double* s_red, int tid) {
+  const int n = D.np;
+  double sp[1] = {0};
+  for (int i = tid; i < n; i += 256) {
+    D.xp[i] = y[i];
+    sp[0] += y[i] * (lambda * y[i] + D.bfull[i]);  // pose part of computeScale()
+  }
+  block_sum<1>(sp, s_red, tid);
+  if (tid == 0) o.ok = ok ? 1 : 0, o.scale_p = ok ? sp[0] : 0.0;
+  // oplus on the free key frames (push() first): VertexNavStatePR (+ V, Bias in a visual-inertial window)
+  for (int k = tid; k < D.n_kf; k += 256) {
+    LbaKf kf = D.kf[k];
+    if (kf.col < 0) continue;
+    D.kf_bak[k] = kf;
+    Est e;
+    e.p[0] = kf.p[0], e.p[1] = kf.p[1], e.p[2] = kf.p[2];
+    e.qw = kf.qw, e.qx = kf.qx, e.qy = kf.qy, e.qz = kf.qz;
+    inc_small_pr(e, y + kf.col);
+    kf.p[0] = e.p[0], kf.p[1] = e.p[1], kf.p[2] = e.p[2];
+    kf.qw = e.qw, kf.qx = e.qx, kf.qy = e.qy, kf.qz = e.qz;
+    if (D.pd == 15)
+      for (int a = 0; a < 3; a++)
+        kf.v[a] += y[kf.col + 6 + a], kf.dbg[a] += y[kf.col + 9 + a], kf.dba[a] += y[kf.col + 12 + a];
+    D.kf[k] = kf;
+  }
+}
+
 template <int PW>
 __global__ void __launch_bounds__(256)
 k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out,
@@ -998,29 +1032,195 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
     __syncthreads();
   }
 #undef LA
-  double sp[1] = {0};
-  for (int i = tid; i < n; i += 256) {
-    D.xp[i] = y[i];
-    sp[0] += y[i] * (lambda * y[i] + D.bfull[i]);  // pose part of computeScale()
+  lba_apply_step(D, y, lambda, ok, out[w], s_red, tid);
+}
+
+// ---- tiled LDL^T for reduced systems that do not fit one workgroup (global BA: hundreds of key frames).
+// Right-looking over 64-column panels of the padded lower triangle Hb [nb][nb]; row np carries the right-hand
+// side, so the forward substitution falls out of the factorisation (its row of L is D^-1 L^-1 b).
+//   k_big_init   Hb <- Hs, bs; identity on the padding
+//   k_big_panel  step k: every workgroup factorises the 64 x 64 diagonal tile in LDS (redundantly: 87 kflop) and
+//                solves its own 256 rows below it, one row per lane held in registers: W = A L_kk^-T -> Wp
+//                (un-normalised), L = W D^-1 in place
+//   k_big_syrk   A_ij -= W_ik L_jk^T for the tiles right of the panel: FP64 MFMA, 64 x 64 x 64 per workgroup
+//   k_big_back   one workgroup: L^T x = z block by block from the bottom, then lba_apply_step
+static const int kNB = 64, kBigLd = kNB + 2;
+
+__global__ void __launch_bounds__(256)
+k_big_init(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  const int n = D.np, nb = D.nb;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e == 0) *D.big_fail = 0;
+  if (n == 0 || e >= (size_t)nb * nb) return;
+  const int r = (int)(e / nb), c = (int)(e - (size_t)r * nb);
+  if (c > r) return;
+  double v = r == c ? (r == n ? 1e300 : 1.0) : 0.0;  // the right-hand-side row never limits a pivot
+  if (r < n)
+    v = D.Hs[(size_t)r * n + c];
+  else if (r == n && c < n)
+    v = D.bs[c];
+  D.Hb[e] = v;
+}
+
+__global__ void __launch_bounds__(256)
+k_big_panel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int k) {
+  __shared__ double sA[kNB * kBigLd];  // the diagonal tile, then its unit-lower factor
+  __shared__ double sD[kNB];
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  const int n = D.np, nb = D.nb, tid = threadIdx.x;
+  const int r0 = (k + 1) * kNB + blockIdx.x * 256 - 256;  // block 0: the diagonal tile itself, then 256 rows each
+  if (n == 0 || k * kNB >= nb || (blockIdx.x > 0 && r0 >= nb)) return;
+  double* Hb = D.Hb;
+  const size_t ld = nb;
+  for (int i = tid; i < kNB * kNB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    sA[r * kBigLd + c] = c <= r ? Hb[(size_t)(k * kNB + r) * ld + k * kNB + c] : 0.0;
   }
-  block_sum<1>(sp, s_red, tid);
-  if (tid == 0) out[w].ok = ok ? 1 : 0, out[w].scale_p = ok ? sp[0] : 0.0;
-  // oplus on the free key frames (push() first): VertexNavStatePR (+ V, Bias in a visual-inertial window)
-  for (int k = tid; k < D.n_kf; k += 256) {
-    LbaKf kf = D.kf[k];
-    if (kf.col < 0) continue;
-    D.kf_bak[k] = kf;
-    Est e;
-    e.p[0] = kf.p[0], e.p[1] = kf.p[1], e.p[2] = kf.p[2];
-    e.qw = kf.qw, e.qx = kf.qx, e.qy = kf.qy, e.qz = kf.qz;
-    inc_small_pr(e, y + kf.col);
-    kf.p[0] = e.p[0], kf.p[1] = e.p[1], kf.p[2] = e.p[2];
-    kf.qw = e.qw, kf.qx = e.qx, kf.qy = e.qy, kf.qz = e.qz;
-    if (D.pd == 15)
-      for (int a = 0; a < 3; a++)
-        kf.v[a] += y[kf.col + 6 + a], kf.dbg[a] += y[kf.col + 9 + a], kf.dba[a] += y[kf.col + 12 + a];
-    D.kf[k] = kf;
+  __syncthreads();
+  bool bad = false;
+  for (int c = 0; c < kNB; c++) {
+    const double d = sA[c * kBigLd + c];
+    if (!(d > 0) && k * kNB + c < n) bad = true;  // the right-hand-side row and the padding are not pivots
+    // rows below c: l = a / d; trailing a[r][q] -= l[r] * a[q][c] for c < q <= r (a[q][c] still un-normalised)
+    for (int i = tid; i < (kNB - 1 - c) * (kNB - 1 - c); i += 256) {
+      const int r = c + 1 + i / (kNB - 1 - c), q = c + 1 + i % (kNB - 1 - c);
+      if (q <= r) sA[r * kBigLd + q] -= sA[r * kBigLd + c] / d * sA[q * kBigLd + c];
+    }
+    __syncthreads();
+    if (tid > c && tid < kNB) sA[tid * kBigLd + c] /= d;
+    if (tid == c) sD[c] = d;
+    __syncthreads();
   }
+  if (blockIdx.x == 0) {
+    if (bad && tid == 0) *D.big_fail = 1;
+    for (int i = tid; i < kNB * kNB; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      if (c < r) Hb[(size_t)(k * kNB + r) * ld + k * kNB + c] = sA[r * kBigLd + c];
+      if (c == r) Hb[(size_t)(k * kNB + r) * ld + k * kNB + c] = sD[c];
+    }
+    return;
+  }
+  const int row = r0 + tid;
+  if (row >= nb) return;
+  double a[kNB];
+  double* src = Hb + (size_t)row * ld + k * kNB;
+#pragma unroll
+  for (int c = 0; c < kNB; c++) a[c] = src[c];
+  // W L_kk^T = A: W[c] = A[c] - sum_{m < c} W[m] L_kk[c][m]   (LDS reads are broadcasts)
+#pragma unroll
+  for (int c = 1; c < kNB; c++) {
+    double v = a[c];
+#pragma unroll
+    for (int m = 0; m < c; m++) v -= a[m] * sA[c * kBigLd + m];
+    a[c] = v;
+  }
+  double* wp = D.Wp + (size_t)row * kNB;
+#pragma unroll
+  for (int c = 0; c < kNB; c++) {
+    wp[c] = a[c];
+    src[c] = a[c] / sD[c];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_big_syrk(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int k) {
+  __shared__ __attribute__((aligned(16))) double sW[kNB * kBigLd];
+  __shared__ __attribute__((aligned(16))) double sL[kNB * kBigLd];
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  const int nb = D.nb, nt = nb / kNB, m = nt - k - 1;
+  if (D.np == 0 || m <= 0) return;
+  int t = blockIdx.x, ti = 0;  // tile (k + 1 + ti, k + 1 + tj), tj <= ti, row-major over the lower triangle
+  if (t >= m * (m + 1) / 2) return;
+  while (t > ti) t -= ti + 1, ti++;
+  const int bi = k + 1 + ti, bj = k + 1 + t;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const size_t ld = nb;
+  for (int i = tid; i < kNB * kNB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    sW[r * kBigLd + c] = D.Wp[(size_t)(bi * kNB + r) * kNB + c];
+    sL[r * kBigLd + c] = D.Hb[(size_t)(bj * kNB + r) * ld + k * kNB + c];
+  }
+  __syncthreads();
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  double4_t acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) acc[q] = (double4_t){0, 0, 0, 0};
+  const double* pa = sW + (wv * 16 + (lane & 15)) * kBigLd + (lane >> 4);
+  const double* pb = sL + (lane & 15) * kBigLd + (lane >> 4);
+#pragma unroll
+  for (int ks = 0; ks < kNB / 4; ks++) {
+    const double av = pa[ks * 4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[q * 16 * kBigLd + ks * 4], acc[q], 0, 0, 0);
+  }
+  // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int gr = bi * kNB + wv * 16 + (lane >> 4) + 4 * r, gc = bj * kNB + q * 16 + (lane & 15);
+      if (gc <= gr) D.Hb[(size_t)gr * ld + gc] -= acc[q][r];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_big_back(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+  __shared__ double sA[kNB * kBigLd];
+  __shared__ double sx[kNB];
+  __shared__ double s_red[4];
+  const int w = blockIdx.x;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  const int n = D.np, nb = D.nb, tid = threadIdx.x;
+  if (n == 0) {
+    if (tid == 0) out[w].ok = 1, out[w].scale_p = 0;
+    return;
+  }
+  const double lambda = win_lambda(ctl[w], out[w]);
+  const bool ok = *D.big_fail == 0;
+  const size_t ld = nb;
+  double* x = D.xp;
+  if (ok) {
+    for (int i = tid; i < n; i += 256) x[i] = D.Hb[(size_t)n * ld + i];  // z = D^-1 L^-1 b
+    __syncthreads();
+    for (int kb = (n - 1) / kNB; kb >= 0; kb--) {
+      const int c0 = kb * kNB, cn = min(kNB, n - c0);
+      for (int i = tid; i < kNB * kNB; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        sA[r * kBigLd + c] = (c < r && r < cn) ? D.Hb[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
+      }
+      if (tid < kNB) sx[tid] = tid < cn ? x[c0 + tid] : 0.0;
+      __syncthreads();
+      if (tid < kNB)  // one wavefront: x[r] is final once the rows above... below it have been applied
+        for (int r = cn - 1; r > 0; r--) {
+          const double xr = sx[r];
+          if (tid < r) sx[tid] -= sA[r * kBigLd + tid] * xr;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      __syncthreads();
+      if (tid < cn) x[c0 + tid] = sx[tid];
+      // z[0 .. c0) -= L[c0 + r][.] x[r]
+      for (int c = tid; c < c0; c += 256) {
+        double v = x[c];
+        for (int r = 0; r < cn; r++) v -= D.Hb[(size_t)(c0 + r) * ld + c] * sx[r];
+        x[c] = v;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int i = tid; i < n; i += 256) x[i] = 0;
+    __syncthreads();
+  }
+  lba_apply_step(D, x, lambda, ok, out[w], s_red, tid);
 }
 
 // ---- back-substitution + update of the points, landmark part of the LM gain-ratio scale
@@ -1131,6 +1331,17 @@ static size_t shard_sys_doubles(int nf) { return (size_t)6 * nf * (6 * nf + 1) +
 // Both local BAs: vparams == nullptr -> Optimizer::LocalBundleAdjustment (params), otherwise
 // LocalBundleAdjustmentNavStatePRV (vparams, h_close, h_imu, n_imu).  sh != nullptr: this process is one
 // rank of a landmark-sharded run.
+
+// reduced systems beyond one workgroup's LDL^T take the tiled solve (VIEO_LBA_BIG_SOLVE=1 forces it: tests)
+static const int kSmallSolveMax = 510, kBigSolveMax = 16320;
+static bool big_solve(int n) {
+  static const int forced = [] {
+    const char* e = getenv("VIEO_LBA_BIG_SOLVE");
+    return e ? atoi(e) : 0;
+  }();
+  return forced > 0 || n > kSmallSolveMax;
+}
+
 static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* const* params,
                    const vieo_lba_vio_params* const* vparams, const vieo_lba_keyframe* const* h_kfs,
                    const int* n_kf, const float* const* h_points, const uint8_t* const* h_close,
@@ -1169,18 +1380,17 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
         !h_navs_out[w] || !h_points_out[w] || !h_erase[w])
       return VIEO_E_INVALID;
     memset(H.R, 0, sizeof(*H.R));
-    if (H.n_kf > 85 * 6 / pd + (vio ? 200 : 0)) {
-      set_error("local BA: too many key frames in a window");
-      return VIEO_E_CAPACITY;
+    {
+      int n_free = 0;
+      for (int k = 0; k < H.n_kf; k++) n_free += !h_kfs[w][k].fixed;
+      if (pd * n_free > kBigSolveMax || H.n_kf >= (1 << 24)) {
+        set_error("bundle adjustment: %d free key frames exceed the reduced-system limit of %d unknowns", n_free,
+                  kBigSolveMax);
+        return VIEO_E_CAPACITY;
+      }
     }
     if (vio) {  // a chain: at most one pre-integration into and one out of every key frame
       std::vector<char> in(H.n_kf, 0), outk(H.n_kf, 0);
-      int n_free = 0;
-      for (int k = 0; k < H.n_kf; k++) n_free += !h_kfs[w][k].fixed;
-      if (15 * n_free > 510) {
-        set_error("visual-inertial local BA: more than 34 free key frames");
-        return VIEO_E_CAPACITY;
-      }
       for (int t = 0; t < H.n_imu; t++) {
         const int a = h_imu[w][t].kf_i, b = h_imu[w][t].kf_j;
         if (a < 0 || a >= H.n_kf || b < 0 || b >= H.n_kf || a == b || outk[a] || in[b]) {
@@ -1278,7 +1488,8 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
   std::vector<size_t> scratch_off(W);
   struct Scr {
     size_t kf_bak, X_bak, mp_act, BB, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
-        gchi, bfull;
+        gchi, bfull, Hb, Wp, big_fail, kf_act;
+    int nb;
   };
   std::vector<Scr> scr(W);
   for (int w = 0; w < W; w++) {
@@ -1310,8 +1521,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
       kf_first[ob[i].kf + 1]++;
     }
     for (int k = 0; k < H.n_kf; k++) kf_first[k + 1] += kf_first[k];
-    int fill[86];
-    for (int k = 0; k < H.n_kf; k++) fill[k] = kf_first[k];
+    std::vector<int> fill(kf_first, kf_first + H.n_kf);
     for (int i = 0; i < H.n_obs; i++) kf_idx[fill[ob[i].kf]++] = i;
     LbaKf* kf = (LbaKf*)(hs + o.kf);
     int nf = 0;
@@ -1368,6 +1578,11 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
     const int npf = pd * nf;  // full reduced system
     s.Hpp = take((size_t)nf * 36 * 8), s.Hs = take((size_t)npf * npf * 8);
+    s.nb = (npf + 1 + kNB - 1) / kNB * kNB;  // + the right-hand-side row
+    s.Hb = s.Wp = s.big_fail = 0;
+    if (big_solve(pd * nf)) {
+      s.Hb = take((size_t)s.nb * s.nb * 8), s.Wp = take((size_t)s.nb * kNB * 8), s.big_fail = take(256);
+    }
     s.bp = take((size_t)npm * 8), s.bs = take((size_t)npf * 8), s.xp = take((size_t)npf * 8);
     s.bfull = take((size_t)npf * 8);
     s.Ae = take((size_t)std::max(H.n_imu, 1) * 930 * 8);
@@ -1375,6 +1590,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
     s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
     s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)nf * H.n_mp * 4);
+    s.kf_act = take((size_t)H.n_kf * 4);
     LbaDev& D = devs[w];
     memset(&D, 0, sizeof(D));
     D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.nf_cap = nf;
@@ -1430,10 +1646,13 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     D.BB = (double*)(base + s.BB), D.Sp = (double*)(base + s.Sp);
     D.Hll = (double*)(base + s.Hll), D.bl = (double*)(base + s.bl);
     D.Hpp = (double*)(base + s.Hpp), D.Hs = (double*)(base + s.Hs), D.bp = (double*)(base + s.bp);
+    D.Hb = (double*)(base + s.Hb), D.Wp = (double*)(base + s.Wp), D.big_fail = (int*)(base + s.big_fail);
+    D.nb = s.nb;
     D.bs = (double*)(base + s.bs), D.xp = (double*)(base + s.xp);
     D.part0 = (double*)(base + s.part0), D.part = (double*)(base + s.part);
     D.part_m = (double*)(base + s.part_m), D.pmax = (double*)(base + s.pmax);
     D.kf_list = (int*)(base + s.kf_list), D.tab = (int*)(base + s.tab);
+    D.kf_act = (int*)(base + s.kf_act);
     D.bfull = (double*)(base + s.bfull), D.Ae = (double*)(base + s.Ae);
     D.gchi0 = (double*)(base + s.gchi0), D.gchi = (double*)(base + s.gchi);
     if (vio) {
@@ -1465,8 +1684,9 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
   VIEO_HIP_CHECK(hipMemcpyAsync(dD, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
   VIEO_HIP_CHECK(hipMemsetAsync(dO, 0, (size_t)W * sizeof(WinOut), st));
   const int n_max = pd * max_nf;
-  const size_t ldlt_small = (size_t)8 * n_max * 8;  // panel columns, rhs, pivots
-  const size_t tri = (size_t)n_max * (n_max + 1) / 2 * 8;  // packed lower triangle
+  const bool big = big_solve(n_max);
+  const size_t ldlt_small = big ? 0 : (size_t)8 * n_max * 8;  // panel columns, rhs, pivots
+  const size_t tri = big ? 0 : (size_t)n_max * (n_max + 1) / 2 * 8;  // packed lower triangle
   const int use_lds = tri + ldlt_small <= 150 * 1024;
   const size_t ldlt_lds = ldlt_small + (use_lds ? tri : 0);
   const void* ldlt_fn = vio ? (const void*)k_lba_ldlt<5> : (const void*)k_lba_ldlt<6>;
@@ -1537,7 +1757,16 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
       }
       hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO,
                          ksplit);
-      if (vio)
+      if (big) {
+        const int nbm = (n_max + 1 + kNB - 1) / kNB * kNB, ntm = nbm / kNB;
+        hipLaunchKernelGGL(k_big_init, dim3((unsigned)(((size_t)nbm * nbm + 255) / 256), W), dim3(256), 0, st, dD, dC);
+        for (int k = 0; k < ntm; k++) {
+          const int below = nbm - (k + 1) * kNB, m = ntm - k - 1;
+          hipLaunchKernelGGL(k_big_panel, dim3(1 + (below + 255) / 256, W), dim3(256), 0, st, dD, dC, k);
+          if (m > 0) hipLaunchKernelGGL(k_big_syrk, dim3(m * (m + 1) / 2, W), dim3(256), 0, st, dD, dC, k);
+        }
+        hipLaunchKernelGGL(k_big_back, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      } else if (vio)
         hipLaunchKernelGGL(k_lba_ldlt<5>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
       else
         hipLaunchKernelGGL(k_lba_ldlt<6>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
