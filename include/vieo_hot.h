@@ -501,6 +501,27 @@ int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_par
                                            float* const* h_points_out, uint8_t* const* h_erase,
                                            vieo_lba_result* h_results);
 
+/* void Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust, bEnc = false)
+ * (src/Optimizer.cc:1353-1609; GlobalBundleAdjustment :1346-1351 passes the whole map) and
+ * int Optimizer::GlobalBundleAdjustmentNavStatePRV(pMap, gw, nIterations, pbStopFlag, nLoopKF, bRobust,
+ * bScaleOpt = false, pimu_initiator = nullptr) (:771-1345) -- "full BA" -- on the flattened layout of the local
+ * BAs: every key frame free except the flagged ones (nid_ == 0), ONE optimize(n_iterations) with g2o's own
+ * initial lambda, Huber kernels (sqrt(5.99) / sqrt(7.815); sqrt(16.919) / sqrt(12.592) on the inertial / bias
+ * edges) on every edge iff `robust`, no outlier classification, every point written back.  The visual-inertial
+ * form weighs the inertial and bias edges leaving a fixed key frame by 1e-2 like the reference.  Reduced systems
+ * beyond 510 unknowns are factorised by the tiled LDL^T (FP64 matrix cores); up to 16320 unknowns.
+ * params->its0 / its1 (and lambda_init / rec_init / large of the VIO params) are ignored.  Not covered: the scale
+ * vertex (bScaleOpt), the gravity vertex of the IMU initialiser, encoder edges. */
+int vieo_bundle_adjustment(const vieo_lba_params* params, int n_iterations, int robust,
+                           const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
+                           const vieo_lba_obs* h_obs, int n_obs, volatile const int* stop, vieo_navstate* h_navs_out,
+                           float* h_points_out, vieo_lba_result* h_result);
+int vieo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_iterations, int robust,
+                                      const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
+                                      const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_imu_edge* h_imu, int n_imu,
+                                      volatile const int* stop, vieo_navstate* h_navs_out, float* h_points_out,
+                                      vieo_lba_result* h_result);
+
 /* ---- one window over several GPUs ---------------------------------------------------
  * Landmark-sharded LocalBundleAdjustmentNavStatePRV: every rank passes ALL key frames and inertial
  * edges of a window but only ITS share of the points (and their observations).  Per LM trial the ranks

@@ -343,10 +343,13 @@ static int optimize(LBA& B, int iterations, volatile const int* stop, vieo_lba_r
   return done;
 }
 
+// gba_iterations >= 0: Optimizer::BundleAdjustment (Optimizer.cc:1353-1609) instead -- one optimize(), Huber
+// (sqrt(5.99) / sqrt(7.815), :1445-1446) iff gba_robust, no classification, every point written back
 static void local_ba(const vieo_lba_params& P, const vieo_lba_keyframe* kfs, int n_kf,
                      const float* points, int n_mp, const vieo_lba_obs* obs, int n_obs,
                      volatile const int* stop, vieo_navstate* navs_out, float* points_out,
-                     uint8_t* erase, vieo_lba_result& R) {
+                     uint8_t* erase, vieo_lba_result& R, int gba_iterations = -1, bool gba_robust = false) {
+  const bool gba = gba_iterations >= 0;
   memset(&R, 0, sizeof(R));
   for (int k = 0; k < n_kf; k++) navs_out[k] = kfs[k].nav;
   memcpy(points_out, points, (size_t)n_mp * 12);
@@ -372,9 +375,10 @@ static void local_ba(const vieo_lba_params& P, const vieo_lba_keyframe* kfs, int
   B.E.resize(n_obs);
   B.mp_first.assign(n_mp, 0);
   B.mp_count.assign(n_mp, 0);
-  const float thHuberMono = sqrt(5.991), thHuberStereo = sqrt(7.815);
+  const float thHuberMono = sqrt(gba ? 5.99 : 5.991), thHuberStereo = sqrt(7.815);
   for (int i = 0; i < n_obs; i++) {
     LEdge& e = B.E[i];
+    if (gba) e.robust = gba_robust;
     e.kf = obs[i].kf & 0xFFFFFF, e.cam = (obs[i].kf >> 24) & 15, e.mp = obs[i].mp;
     e.obs[0] = obs[i].u, e.obs[1] = obs[i].v, e.obs[2] = obs[i].ur;
     e.de = obs[i].ur < 0 ? 2 : 3;
@@ -388,9 +392,10 @@ static void local_ba(const vieo_lba_params& P, const vieo_lba_keyframe* kfs, int
     R.status = VIEO_LBA_ABORTED;
     return;
   }
-  optimize(B, P.its0, stop, R, true);
+  optimize(B, gba ? gba_iterations : P.its0, stop, R, true);
   bool bDoMore = !(stop && *stop);
-  if (bDoMore) {
+  if (gba) {
+  } else if (bDoMore) {
     for (auto& e : B.E) {
       const double th = e.de == 2 ? 5.991 : 7.815;
       if (LBA::chi2(e) > th || !B.depth_positive(e)) e.level = 1;
@@ -399,7 +404,7 @@ static void local_ba(const vieo_lba_params& P, const vieo_lba_keyframe* kfs, int
     optimize(B, P.its1, stop, R, false);
   } else
     R.status = VIEO_LBA_ABORTED;
-  for (int i = 0; i < n_obs; i++) {
+  for (int i = 0; i < n_obs && !gba; i++) {
     const LEdge& e = B.E[i];
     const double th = e.de == 2 ? 5.991 : 7.815;
     if (LBA::chi2(e) > th || !B.depth_positive(e)) erase[i] = 1, R.n_erase++;
@@ -431,4 +436,13 @@ extern "C" void vo_cam_project(const vieo_camera* cam, const double* P, float* u
   vo::OCam c[4];
   vo::ocams_from_params(prm, c);
   vo::ocam_project(c[0], P, uv, J);
+}
+
+extern "C" void vo_bundle_adjustment(const vieo_lba_params* params, int n_iterations, int robust,
+                                     const vieo_lba_keyframe* kfs, int n_kf, const float* points, int n_mp,
+                                     const vieo_lba_obs* obs, int n_obs, const int* stop, vieo_navstate* navs_out,
+                                     float* points_out, vieo_lba_result* result) {
+  std::vector<uint8_t> erase((size_t)n_obs + 1);
+  vo::local_ba(*params, kfs, n_kf, points, n_mp, obs, n_obs, stop, navs_out, points_out, erase.data(), *result,
+               n_iterations, robust != 0);
 }

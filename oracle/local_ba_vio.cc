@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -103,6 +105,7 @@ static bool mat_inverse(const double* A, double* Ainv, int n) {
 
 struct W {
   const vieo_lba_vio_params* P;
+  bool gba = false;  // GlobalBundleAdjustmentNavStatePRV: g2o's own initial lambda
   OCam cams[4];
   std::vector<KF> kf;
   std::vector<double> X;
@@ -450,6 +453,14 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
     }
     if (it == 0) {
       lambda = B.P->lambda_init;  // computeLambdaInit: _userLambdaInit > 0
+      if (B.gba) {  // tau * max |diagonal| over the pose-side and the landmark blocks
+        double maxDiag = 0;
+        for (int j = 0; j < np; j++) maxDiag = std::max(std::fabs(H[(size_t)j * np + j]), maxDiag);
+        for (int m = 0; m < nm; m++)
+          if (mp_act[m])
+            for (int a = 0; a < 3; a++) maxDiag = std::max(std::fabs(Hll[(size_t)m * 9 + a * 4]), maxDiag);
+        lambda = 1e-5 * maxDiag;
+      }
       ni = 2;
       nBad = 0;
     }
@@ -556,16 +567,23 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
   }
 }
 
+// gba_iterations >= 0: Optimizer::GlobalBundleAdjustmentNavStatePRV (Optimizer.cc:771-1345; no scale / gravity
+// vertex, no encoder edges) instead -- one optimize(), Huber on every edge iff gba_robust (sqrt(5.99) /
+// sqrt(7.815) :1063-1064, sqrt(16.919) / sqrt(12.592) :910-911), no Chi2LargeSetLevel, no classification, no
+// divergence guard
 static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* kfs, int n_kf,
                          const float* points, const uint8_t* close, int n_mp, const vieo_lba_obs* obs,
                          int n_obs, const vieo_lba_imu_edge* imu, int n_imu, volatile const int* stop,
-                         vieo_navstate* navs_out, float* points_out, uint8_t* erase, vieo_lba_result& R) {
+                         vieo_navstate* navs_out, float* points_out, uint8_t* erase, vieo_lba_result& R,
+                         int gba_iterations = -1, bool gba_robust = false) {
+  const bool gba = gba_iterations >= 0;
   memset(&R, 0, sizeof(R));
   for (int k = 0; k < n_kf; k++) navs_out[k] = kfs[k].nav;
   memcpy(points_out, points, (size_t)n_mp * 12);
   memset(erase, 0, n_obs);
   W B;
   B.P = &P;
+  B.gba = gba;
   ocams_from_params(P.base, B.cams);
   B.kf.resize(n_kf);
   bool any_free = false;
@@ -591,7 +609,7 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
     e.i = imu[t].kf_i, e.j = imu[t].kf_j, e.M = &imu[t].imu;
     const bool bfixedkf = B.kf[e.i].fixed;
     e.has_imu = e.M->dt != 0;
-    e.robust = bfixedkf || P.rec_init;
+    e.robust = gba ? gba_robust : (bfixedkf || P.rec_init);
     if (e.has_imu) {
       mat_inverse(e.M->Sigma, e.InfoI, 9);  // GetProcessedInfoijPRV
       if (bfixedkf)
@@ -608,9 +626,10 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
   B.mp_first.assign(n_mp, 0);
   B.mp_count.assign(n_mp, 0);
   const float chi2Mono = 5.991;
-  const float thHuberMono = sqrt(chi2Mono), thHuberStereo = sqrt(7.815);
+  const float thHuberMono = gba ? (float)sqrt(5.99) : sqrt(chi2Mono), thHuberStereo = sqrt(7.815);
   for (int i = 0; i < n_obs; i++) {
     VEdge& e = B.E[i];
+    if (gba) e.robust = gba_robust;
     e.kf = obs[i].kf & 0xFFFFFF, e.cam = (obs[i].kf >> 24) & 15, e.mp = obs[i].mp;
     e.obs[0] = obs[i].u, e.obs[1] = obs[i].v, e.obs[2] = obs[i].ur;
     e.de = obs[i].ur < 0 ? 2 : 3;
@@ -626,12 +645,13 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
   }
   // Chi2LargeSetLevel (rat_vis_check = 100): chi2_sig5_[2] = 5.991f, [3] = 7.815f, float product
   for (auto& e : B.E) {
+    if (gba) break;
     B.v_error(e);
     const float th = 100.f * (e.de == 2 ? 5.991f : 7.815f);
     if (W::v_chi2(e) > th) e.level = 1;
   }
   Sums S;
-  optimize(B, P.base.its0, stop, R, true, S);
+  optimize(B, gba ? gba_iterations : P.base.its0, stop, R, true, S);
   const float err = (float)R.chi2_initial;
   bool bDoMore = !(stop && *stop);
   auto bad = [&](const VEdge& e) {
@@ -639,7 +659,7 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
       return W::v_chi2(e) > (close[e.mp] ? 1.5 * chi2Mono : chi2Mono) || !B.depth_positive(e);
     return W::v_chi2(e) > 7.815 || !B.depth_positive(e);
   };
-  if (bDoMore) {
+  if (bDoMore && !gba) {
     for (auto& e : B.E) {
       if (bad(e)) e.level = 1;
       e.robust = false;
@@ -649,11 +669,11 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
   const float err_end = (float)S.last_trial_chi;
   R.chi2_final = err_end;
   R.chi2_initial = err;
-  if ((2 * err < err_end || std::isnan(err) || std::isnan(err_end)) && !P.large) {  // Optimizer.cc:660-666
+  if ((2 * err < err_end || std::isnan(err) || std::isnan(err_end)) && !P.large && !gba) {  // Optimizer.cc:660-666
     R.status = VIEO_LBA_DIVERGED;
     return;
   }
-  for (int i = 0; i < n_obs; i++)
+  for (int i = 0; i < n_obs && !gba; i++)
     if (bad(B.E[i])) erase[i] = 1, R.n_erase++;
   for (int k = 0; k < n_kf; k++) {
     const KF& s = B.kf[k];
@@ -679,6 +699,16 @@ void vo_local_bundle_adjustment_vio(const vieo_lba_vio_params* params, const vie
 }
 
 // test hook: error (9 + 6) and Jacobian (9 x 24) of one inertial edge at the given states
+void vo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_iterations, int robust,
+                                     const vieo_lba_keyframe* kfs, int n_kf, const float* points, int n_mp,
+                                     const vieo_lba_obs* obs, int n_obs, const vieo_lba_imu_edge* imu, int n_imu,
+                                     const int* stop, vieo_navstate* navs_out, float* points_out,
+                                     vieo_lba_result* result) {
+  std::vector<uint8_t> erase((size_t)n_obs + 1), close((size_t)n_mp + 1, 0);
+  vov::local_ba_vio(*params, kfs, n_kf, points, close.data(), n_mp, obs, n_obs, imu, n_imu, stop, navs_out,
+                    points_out, erase.data(), *result, n_iterations, robust != 0);
+}
+
 void vo_lba_imu_edge_eval(const vieo_lba_vio_params* params, const vieo_lba_imu_edge* edge,
                           const vieo_navstate* nsi, const vieo_navstate* nsj, double* err15, double* J) {
   vov::W B;

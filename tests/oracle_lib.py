@@ -99,6 +99,35 @@ class Oracle:
                                           pts.ctypes.data, erase.ctypes.data, res.ctypes.data)
         return navs, pts, erase[:len(obs)], res[0]
 
+    def bundle_adjustment(self, params, kfs, points, obs, n_iterations=5, robust=True, stop=None):
+        from vieo_slam_amd.ba_types import LBA_RESULT_DTYPE, NAVSTATE_DTYPE
+        params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
+        points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+        navs, pts, res = np.zeros(len(kfs), NAVSTATE_DTYPE), np.zeros_like(points), np.zeros(1, LBA_RESULT_DTYPE)
+        st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        P, I = ctypes.c_void_p, ctypes.c_int
+        self.L.vo_bundle_adjustment.argtypes = [P, I, I, P, I, P, I, P, I, P, P, P, P]
+        self.L.vo_bundle_adjustment(params.ctypes.data, int(n_iterations), int(bool(robust)), kfs.ctypes.data,
+                                    len(kfs), points.ctypes.data, len(points), obs.ctypes.data, len(obs),
+                                    None if st is None else st.ctypes.data, navs.ctypes.data, pts.ctypes.data,
+                                    res.ctypes.data)
+        return navs, pts, res[0]
+
+    def global_ba_vio(self, params, kfs, points, obs, imu, n_iterations=5, robust=True, stop=None):
+        from vieo_slam_amd.ba_types import LBA_RESULT_DTYPE, NAVSTATE_DTYPE
+        params, kfs, imu = np.ascontiguousarray(params), np.ascontiguousarray(kfs), np.ascontiguousarray(imu)
+        points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+        navs, pts, res = np.zeros(len(kfs), NAVSTATE_DTYPE), np.zeros_like(points), np.zeros(1, LBA_RESULT_DTYPE)
+        st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        P, I = ctypes.c_void_p, ctypes.c_int
+        self.L.vo_global_bundle_adjustment_vio.argtypes = [P, I, I, P, I, P, I, P, I, P, I, P, P, P, P]
+        self.L.vo_global_bundle_adjustment_vio(params.ctypes.data, int(n_iterations), int(bool(robust)),
+                                               kfs.ctypes.data, len(kfs), points.ctypes.data, len(points),
+                                               obs.ctypes.data, len(obs), imu.ctypes.data, len(imu),
+                                               None if st is None else st.ctypes.data, navs.ctypes.data,
+                                               pts.ctypes.data, res.ctypes.data)
+        return navs, pts, res[0]
+
     def local_ba_vio(self, params, kfs, points, close, obs, imu, stop=None):
         from vieo_slam_amd.ba_types import LBA_RESULT_DTYPE, NAVSTATE_DTYPE
         params, kfs, imu = np.ascontiguousarray(params), np.ascontiguousarray(kfs), np.ascontiguousarray(imu)

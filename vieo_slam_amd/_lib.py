@@ -23,6 +23,9 @@ _SIGS = {
     "vieo_device_available": (c_i, []),
     "vieo_set_device": (c_i, [c_i]),
     "vieo_pose_set_camera_mode": (c_i, [c_i]),
+    "vieo_bundle_adjustment": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "vieo_global_bundle_adjustment_vio": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p,
+                                                c_p]),
     "vieo_get_device": (c_i, []),
     "vieo_version": (ctypes.c_char_p, []),
     "vieo_dev_malloc": (c_i, [P(c_p), c_sz]),

@@ -551,7 +551,18 @@ k_lba_lambda(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   if (!(ctl[w].flags & LBA_BEGIN)) return;
   const LbaDev& D = devs[w];
   double mx = 0;
-  for (int j = threadIdx.x; j < D.npv; j += 256) mx = fmax(mx, fabs(D.Hpp[36 * (size_t)(j / 6) + 7 * (j % 6)]));
+  if (D.pd == 6) {
+    for (int j = threadIdx.x; j < D.npv; j += 256) mx = fmax(mx, fabs(D.Hpp[36 * (size_t)(j / 6) + 7 * (j % 6)]));
+  } else {  // PR + V + Bias vertices: visual block + the inertial edges' diagonal (as k_lba_assemble adds them)
+    for (int j = threadIdx.x; j < D.np; j += 256) {
+      const int a = j / 15, ra = j - a * 15, ka = D.kf_list[a];
+      const int ein = D.kf_in[ka], eout = D.kf_out[ka];
+      double v = ra < 6 ? D.Hpp[36 * (size_t)a + 7 * ra] : 0.0;
+      if (ein >= 0) v += D.Ae[930 * (size_t)ein + (15 + ra) * 30 + 15 + ra];
+      if (eout >= 0) v += D.Ae[930 * (size_t)eout + ra * 30 + ra];
+      mx = fmax(mx, fabs(v));
+    }
+  }
   for (int b = threadIdx.x; b < (D.n_mp + 63) / 64; b += 256) mx = fmax(mx, D.pmax[b]);
   s_m[threadIdx.x] = mx;
   __syncthreads();
@@ -1342,7 +1353,14 @@ static bool big_solve(int n) {
   return forced > 0 || n > kSmallSolveMax;
 }
 
-static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* const* params,
+// Optimizer::BundleAdjustment / GlobalBundleAdjustmentNavStatePRV (Optimizer.cc:1353-1609, 771-1345) on the same
+// engine: ONE optimize(iterations), Huber kernels on every edge iff `robust`, no chi2 classification, no
+// Chi2LargeSetLevel, g2o's own initial lambda, no divergence guard.
+struct GbaMode {
+  int iterations, robust;
+};
+
+static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const vieo_lba_params* const* params,
                    const vieo_lba_vio_params* const* vparams, const vieo_lba_keyframe* const* h_kfs,
                    const int* n_kf, const float* const* h_points, const uint8_t* const* h_close,
                    const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
@@ -1370,7 +1388,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
   for (int w = 0; w < W; w++) {
     WinHost& H = win[w];
     if (vio) {
-      if (!vparams[w] || !h_close[w] || n_imu[w] < 0 || (n_imu[w] > 0 && !h_imu[w])) return VIEO_E_INVALID;
+      if (!vparams[w] || (!h_close[w] && !gba) || n_imu[w] < 0 || (n_imu[w] > 0 && !h_imu[w])) return VIEO_E_INVALID;
       H.VP = vparams[w], H.P = &vparams[w]->base, H.n_imu = n_imu[w];
     } else
       H.P = params[w];
@@ -1544,7 +1562,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
         LbaImu& d = im[t];
         d.i = e.kf_i, d.j = e.kf_j, d.M = e.imu;
         const bool bfixedkf = kfs[e.kf_i].fixed != 0;
-        d.has_imu = e.imu.dt != 0, d.robust = bfixedkf || H.VP->rec_init;
+        d.has_imu = e.imu.dt != 0, d.robust = gba ? gba->robust != 0 : (bfixedkf || H.VP->rec_init);
         memset(d.InfoI, 0, sizeof(d.InfoI));
         if (d.has_imu) {
           if (!inverse9(e.imu.Sigma, d.InfoI)) {
@@ -1561,7 +1579,10 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
         d.infoBa = H.VP->inv_sigma_ba2 / deltatij * (bfixedkf ? 1e-2 : 1.0);
         kout[e.kf_i] = t, kin[e.kf_j] = t;
       }
-      memcpy(hs + o.close, h_close[w], H.n_mp);
+      if (h_close[w])
+        memcpy(hs + o.close, h_close[w], H.n_mp);
+      else
+        memset(hs + o.close, 0, H.n_mp);
     }
     double* X = (double*)(hs + o.X);
     for (int i = 0; i < H.n_mp * 3; i++) X[i] = (double)h_points[w][i];
@@ -1612,18 +1633,19 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
       }
       for (int q = 0; q < 8; q++) d.k[q] = (double)c.dist[q];
     }
-    D.dMono = (double)(float)sqrt(5.991), D.dStereo = (double)(float)sqrt(7.815);
+    // thHuberMono = sqrt(5.991) in the local BAs, thHuber2D = sqrt(5.99) in the global ones (Optimizer.cc:1063,1445)
+    D.dMono = (double)(float)sqrt(gba ? 5.99 : 5.991), D.dStereo = (double)(float)sqrt(7.815);
     D.pd = pd, D.n_imu = H.n_imu;
     if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
       D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
       memcpy(D.gw, H.VP->gw, 24);
-      H.prelevel_pending = true;
+      H.prelevel_pending = !gba;
     } else
       D.thMono = D.thMonoClose = 5.991, D.thStereo = 7.815;
     max_imu = std::max(max_imu, H.n_imu);
     max_obs = std::max(max_obs, H.n_obs), max_mp = std::max(max_mp, H.n_mp);
     max_kf = std::max(max_kf, H.n_kf), max_nf = std::max(max_nf, nf);
-    H.iters = H.P->its0;
+    H.iters = gba ? gba->iterations : H.P->its0;
     H.phase = H.iters > 0 ? 0 : 2;
   }
   const size_t small_bytes = (size_t)W * (sizeof(LbaDev) + sizeof(WinCtl) + sizeof(WinOut));
@@ -1704,7 +1726,9 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
       double lam = H.lambda;
       if (H.stage < 2 && H.phase == 2) {  // an optimize() is over
         if (H.need_restore) f |= LBA_RESTORE, H.need_restore = false;
-        if (H.stage == 0 && !stop_now) {
+        if (gba)
+          H.stage = 2;
+        else if (H.stage == 0 && !stop_now) {
           f |= LBA_CLASS0;
           H.stage = 1, H.iters = H.P->its1, H.phase = H.iters > 0 ? 0 : 2;
         } else {
@@ -1714,11 +1738,11 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
         }
       }
       if (H.stage < 2 && H.phase == 0) {
-        f |= LBA_BEGIN | LBA_BUILD | LBA_TRIAL | (H.stage == 0 ? LBA_ROBUST : 0);
-        lam = vio ? H.VP->lambda_init : -1;  // setUserLambdaInit (Optimizer.cc:131-138)
+        f |= LBA_BEGIN | LBA_BUILD | LBA_TRIAL | ((gba ? gba->robust != 0 : H.stage == 0) ? LBA_ROBUST : 0);
+        lam = vio && !gba ? H.VP->lambda_init : -1;  // setUserLambdaInit (Optimizer.cc:131-138)
         if (H.prelevel_pending) f |= LBA_PRELEVEL, H.prelevel_pending = false;
       } else if (H.stage < 2 && H.phase == 1) {
-        f |= LBA_TRIAL | (H.stage == 0 ? LBA_ROBUST : 0);
+        f |= LBA_TRIAL | ((gba ? gba->robust != 0 : H.stage == 0) ? LBA_ROBUST : 0);
         if (H.need_build) f |= LBA_BUILD;
         if (H.need_restore) f |= LBA_RESTORE, H.need_restore = false;
       }
@@ -1803,7 +1827,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
         H.currentChi = out[w].chi0;
         if (H.stage == 0) H.R->chi2_initial = H.currentChi;
         H.iniChi = H.currentChi;
-        H.lambda = vio ? H.VP->lambda_init : out[w].lambda;
+        H.lambda = vio && !gba ? H.VP->lambda_init : out[w].lambda;
         H.ni = 2, H.nBad = 0, H.qmax = 0, H.it = 0;
         H.phase = 1;
       }
@@ -1858,7 +1882,7 @@ static int lba_run(const LbaShard* sh, int n_windows, const vieo_lba_params* con
     if (vio) {  // float err / err_end and the divergence guard (Optimizer.cc:531-533,655-666)
       const float err = (float)H.R->chi2_initial, err_end = (float)H.lastTrialChi;
       H.R->chi2_initial = err, H.R->chi2_final = err_end;
-      if ((2 * err < err_end || std::isnan(err) || std::isnan(err_end)) && !H.VP->large) {
+      if ((2 * err < err_end || std::isnan(err) || std::isnan(err_end)) && !H.VP->large && !gba) {
         H.R->status = VIEO_LBA_DIVERGED;
         continue;  // returns without write-back: outputs stay equal to the inputs
       }
@@ -1895,7 +1919,7 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
                                        volatile const int* stop, vieo_navstate* const* h_navs_out,
                                        float* const* h_points_out, uint8_t* const* h_erase,
                                        vieo_lba_result* h_results) {
-  return lba_run(nullptr, n_windows, params, nullptr, h_kfs, n_kf, h_points, nullptr, n_mp, h_obs, n_obs, nullptr, nullptr,
+  return lba_run(nullptr, nullptr, n_windows, params, nullptr, h_kfs, n_kf, h_points, nullptr, n_mp, h_obs, n_obs, nullptr, nullptr,
                  stop, h_navs_out, h_points_out, h_erase, h_results);
 }
 
@@ -1919,7 +1943,7 @@ int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_par
                                            float* const* h_points_out, uint8_t* const* h_erase,
                                            vieo_lba_result* h_results) {
   if (!params) return VIEO_E_INVALID;
-  return lba_run(nullptr, n_windows, nullptr, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu, n_imu,
+  return lba_run(nullptr, nullptr, n_windows, nullptr, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu, n_imu,
                  stop, h_navs_out, h_points_out, h_erase, h_results);
 }
 
@@ -1940,7 +1964,7 @@ int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_p
                                              uint8_t* const* h_erase, vieo_lba_result* h_results) {
   if (!params) return VIEO_E_INVALID;
   LbaShard sh{allreduce, ctx, d_reduce_buf, reduce_cap_doubles};
-  return lba_run(&sh, n_windows, nullptr, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu,
+  return lba_run(&sh, nullptr, n_windows, nullptr, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu,
                  n_imu, nullptr, h_navs_out, h_points_out, h_erase, h_results);
 }
 
@@ -1954,6 +1978,32 @@ int vieo_local_bundle_adjustment_vio(const vieo_lba_vio_params* P, const vieo_lb
     return VIEO_E_INVALID;
   return vieo_local_bundle_adjustment_vio_batch(1, &P, &h_kfs, &n_kf, &h_points, &h_close, &n_mp, &h_obs, &n_obs,
                                                 &h_imu, &n_imu, stop, &h_navs_out, &h_points_out, &h_erase, R);
+}
+
+int vieo_bundle_adjustment(const vieo_lba_params* params, int n_iterations, int robust,
+                           const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
+                           const vieo_lba_obs* h_obs, int n_obs, volatile const int* stop, vieo_navstate* h_navs_out,
+                           float* h_points_out, vieo_lba_result* h_result) {
+  if (!params || n_iterations < 0 || !h_result || n_obs < 0) return VIEO_E_INVALID;
+  const GbaMode g = {n_iterations, robust};
+  std::vector<uint8_t> erase((size_t)std::max(n_obs, 1));
+  uint8_t* er = erase.data();
+  return lba_run(nullptr, &g, 1, &params, nullptr, &h_kfs, &n_kf, &h_points, nullptr, &n_mp, &h_obs, &n_obs, nullptr,
+                 nullptr, stop, &h_navs_out, &h_points_out, &er, h_result);
+}
+
+int vieo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_iterations, int robust,
+                                      const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
+                                      const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_imu_edge* h_imu, int n_imu,
+                                      volatile const int* stop, vieo_navstate* h_navs_out, float* h_points_out,
+                                      vieo_lba_result* h_result) {
+  if (!params || n_iterations < 0 || !h_result || n_obs < 0) return VIEO_E_INVALID;
+  const GbaMode g = {n_iterations, robust};
+  std::vector<uint8_t> erase((size_t)std::max(n_obs, 1));
+  uint8_t* er = erase.data();
+  const uint8_t* no_close = nullptr;
+  return lba_run(nullptr, &g, 1, nullptr, &params, &h_kfs, &n_kf, &h_points, &no_close, &n_mp, &h_obs, &n_obs, &h_imu,
+                 &n_imu, stop, &h_navs_out, &h_points_out, &er, h_result);
 }
 
 }  // extern "C"

@@ -171,3 +171,34 @@ class Optimizer:
             ctypes.cast(cb, ctypes.c_void_p), None, ptrs[6].ctypes.data, ptrs[7].ctypes.data,
             ptrs[8].ctypes.data, res.ctypes.data), "vieo_local_bundle_adjustment_vio_sharded")
         return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
+
+    @staticmethod
+    def BundleAdjustment(params, kfs, points, obs, nIterations=5, bRobust=True, stop=None):
+        """void Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust, bEnc=false)
+        (src/Optimizer.cc:1353-1609) -- GlobalBundleAdjustment passes the whole map -- on the flattened layout of
+        LocalBundleAdjustment.  returns (navs[n_kf], points float32[n_mp,3], result record)."""
+        params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
+        points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+        navs, pts, res = np.zeros(len(kfs), NAVSTATE_DTYPE), np.zeros_like(points), np.zeros(1, LBA_RESULT_DTYPE)
+        st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        check(lib().vieo_bundle_adjustment(params.ctypes.data, int(nIterations), int(bool(bRobust)), kfs.ctypes.data,
+                                           len(kfs), points.ctypes.data, len(points), obs.ctypes.data, len(obs),
+                                           None if st is None else st.ctypes.data, navs.ctypes.data,
+                                           pts.ctypes.data, res.ctypes.data), "vieo_bundle_adjustment")
+        return navs, pts, res[0]
+
+    @staticmethod
+    def GlobalBundleAdjustmentNavStatePRV(params, kfs, points, obs, imu, nIterations=5, bRobust=True, stop=None):
+        """int Optimizer::GlobalBundleAdjustmentNavStatePRV(pMap, gw, nIterations, pbStopFlag, nLoopKF, bRobust,
+        bScaleOpt=false, pimu_initiator=nullptr) (src/Optimizer.cc:771-1345) on the flattened layout of
+        LocalBundleAdjustmentNavStatePRV.  returns (navs[n_kf], points float32[n_mp,3], result record)."""
+        params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
+        points, obs, imu = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs), np.ascontiguousarray(imu)
+        navs, pts, res = np.zeros(len(kfs), NAVSTATE_DTYPE), np.zeros_like(points), np.zeros(1, LBA_RESULT_DTYPE)
+        st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        check(lib().vieo_global_bundle_adjustment_vio(
+            params.ctypes.data, int(nIterations), int(bool(bRobust)), kfs.ctypes.data, len(kfs), points.ctypes.data,
+            len(points), obs.ctypes.data, len(obs), imu.ctypes.data, len(imu),
+            None if st is None else st.ctypes.data, navs.ctypes.data, pts.ctypes.data, res.ctypes.data),
+            "vieo_global_bundle_adjustment_vio")
+        return navs, pts, res[0]

@@ -346,8 +346,27 @@ def _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig=Non
 
 
 # ----------------------------------------------------------------------------------------------
+def _scene_points(rng, local_poses, n_points, anchors):
+    """points 2-12 m in front of `anchors` cameras spread evenly over the local key frames (1: the middle one,
+    the local-BA windows; more: maps that cover a long trajectory, the global BAs).  returns (Xw, z)."""
+    n_local = len(local_poses)
+    ids = [n_local // 2] if anchors <= 1 else [int(round(a)) for a in np.linspace(0, n_local - 1, anchors)]
+    z = rng.uniform(2.0, 12.0, n_points)
+    u = rng.uniform(-150, W + 150, n_points)
+    v = rng.uniform(-100, H + 100, n_points)
+    Xc = np.stack([(u - CX) / FX * z, (v - CY) / FY * z, z], 1)
+    Xw = np.zeros_like(Xc)
+    which = np.arange(n_points) % len(ids)
+    for t, a in enumerate(ids):
+        Rm, pm = local_poses[a][0], local_poses[a][1]
+        Rwc_m = Rm @ EUROC_TBC[:3, :3]
+        twc_m = pm + Rm @ EUROC_TBC[:3, 3]
+        Xw[which == t] = Xc[which == t] @ Rwc_m.T + twc_m
+    return Xw, z
+
+
 def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.03, stereo_frac=0.7,
-                     noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_x=0.02, first_fixed=False, rig=None):
+                     noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_x=0.02, first_fixed=False, rig=None, anchors=1):
     """Seeded local-BA window: key frames on a smooth trajectory looking at a cloud
     of points 2-12 m ahead; every point is observed by the key frames that see it.
     returns (params[1], kfs[n_kf], points float32[n_mp,3], obs[n_obs] sorted by mp, truth)."""
@@ -369,15 +388,8 @@ def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.
         poses.append((Rk, pk))
     order = list(range(n_fixed, n_kf)) + list(range(n_fixed))  # local (newest block) first
     poses = [poses[i] for i in order]
-    # points in front of the middle camera
-    Rm, pm = poses[n_local // 2]
-    Rwc_m = Rm @ EUROC_TBC[:3, :3]
-    twc_m = pm + Rm @ EUROC_TBC[:3, 3]
-    z = rng.uniform(2.0, 12.0, n_points)
-    u = rng.uniform(-150, W + 150, n_points)
-    v = rng.uniform(-100, H + 100, n_points)
-    Xc = np.stack([(u - CX) / FX * z, (v - CY) / FY * z, z], 1)
-    Xw = Xc @ Rwc_m.T + twc_m
+    # points in front of the middle camera (or of several anchors)
+    Xw, z = _scene_points(rng, poses[:n_local], n_points, anchors)
     rig_c = camera_rig(rig) if rig else None
     obs_list = _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig_c)
     # keep points with >= 2 observations and at least one local observer; renumber
@@ -455,7 +467,7 @@ _PVR_TO_PRV = np.r_[0:3, 6:9, 3:6]  # Sigma order (p, v, Phi) -> (p, Phi, v)
 
 def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_frac=0.03, stereo_frac=0.7,
                          noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_v=0.03, pert_x=0.02, dt_kf=0.5,
-                         first_fixed=False, imu_noise=1.0, with_prev=True, rig=None):
+                         first_fixed=False, imu_noise=1.0, with_prev=True, rig=None, anchors=1):
     """Seeded visual-inertial local-BA window: a chain prev-local -> n_local key frames
     integrated forward with consistent IMU pre-integrations, n_fixed older covisible key frames,
     points 2-12 m ahead.  Key-frame order: local (oldest..newest), prev-local (fixed, full nav state),
@@ -487,14 +499,7 @@ def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_fra
     fixed = ([chain[0]] if with_prev else []) + older
     poses = local + fixed
     n_kf = len(poses)
-    Rm, pm, _ = local[n_local // 2]
-    Rwc_m = Rm @ EUROC_TBC[:3, :3]
-    twc_m = pm + Rm @ EUROC_TBC[:3, 3]
-    z = rng.uniform(2.0, 12.0, n_points)
-    u = rng.uniform(-150, W + 150, n_points)
-    vv_ = rng.uniform(-100, H + 100, n_points)
-    Xc = np.stack([(u - CX) / FX * z, (vv_ - CY) / FY * z, z], 1)
-    Xw = Xc @ Rwc_m.T + twc_m
+    Xw, z = _scene_points(rng, local, n_points, anchors)
     rig_c = camera_rig(rig) if rig else None
     obs_list = _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig_c)
     obs_arr = np.array(obs_list, dtype=np.float64)
