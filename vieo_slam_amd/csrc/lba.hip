@@ -99,6 +99,7 @@ struct LbaDev {
   double* Sp;                     // [ksplit][sp_rows][ldS] partial Schur products
   size_t sp_stride;
   double *Hll, *bl, *Hpp, *bp, *Hs, *bs, *xp;
+  unsigned char* occ;             // [(npv + 64) / 64][chunks of 16 landmarks]: the row tile has an edge in the chunk
   double *Hb, *Wp;                // tiled solve of a large reduced system: padded copy [nb][nb], panel [nb][64]
   int* big_fail;                  //   and its "not positive definite" flag
   int nb;
@@ -578,6 +579,30 @@ k_lba_lambda(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
 typedef double double4_t __attribute__((ext_vector_type(4)));
 static const int kChunkLm = 16, kLd = 3 * kChunkLm + 2;  // +2: conflict-free b64 fragment reads
 
+// Which 16-landmark chunks a 64-row tile of BB touches (from `tab`, rebuilt at every optimize()): the Schur
+// GEMM skips the all-zero ones -- a map of hundreds of key frames is block-sparse, a local window is dense.
+__global__ void __launch_bounds__(256)
+k_lba_occ(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_BEGIN)) return;
+  const LbaDev& D = devs[w];
+  const int np = D.npv, CB = (np + 64) >> 6, nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (np == 0 || e >= CB * nchunks) return;
+  const int bi = e / nchunks, ch = e - bi * nchunks;
+  const int a0 = bi * 64 / 6, a1 = min((bi * 64 + 63) / 6, D.n_free - 1);
+  int any = 0;
+  for (int a = a0; a <= a1 && !any; a++)
+    for (int j = 0; j < kChunkLm; j++) {
+      const int m = ch * kChunkLm + j;
+      if (m < D.n_mp && D.tab[(size_t)a * D.n_mp + m] >= 0) {
+        any = 1;
+        break;
+      }
+    }
+  D.occ[e] = (unsigned char)any;
+}
+
 __global__ void __launch_bounds__(256)
 k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out,
             int ksplit) {
@@ -605,7 +630,11 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   double4_t acc[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) acc[q] = (double4_t){0, 0, 0, 0};
+  const unsigned char* occ_i = D.occ + (size_t)bi * nchunks;
+  const unsigned char* occ_j = D.occ + (size_t)bj * nchunks;
+  const bool has_bl = np >= bj * 64 && np < bj * 64 + 64;  // this column tile carries b_l: dense
   for (int ch = c0; ch < c1; ch++) {
+    if (!occ_i[ch] || (!has_bl && !occ_j[ch])) continue;  // a zero factor: nothing to add (workgroup-uniform)
     __syncthreads();  // the previous chunk's fragments have been read
     if (tid < kChunkLm) {
       const int m = ch * kChunkLm + tid;
@@ -1054,7 +1083,7 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
 //                solves its own 256 rows below it, one row per lane held in registers: W = A L_kk^-T -> Wp
 //                (un-normalised), L = W D^-1 in place
 //   k_big_syrk   A_ij -= W_ik L_jk^T for the tiles right of the panel: FP64 MFMA, 64 x 64 x 64 per workgroup
-//   k_big_back   one workgroup: L^T x = z block by block from the bottom, then lba_apply_step
+//   k_big_back_step  L^T x = z, one 64-row block per launch from the bottom; k_big_finish: lba_apply_step
 static const int kNB = 64, kBigLd = kNB + 2;
 
 __global__ void __launch_bounds__(256)
@@ -1094,18 +1123,20 @@ k_big_panel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   }
   __syncthreads();
   bool bad = false;
-  for (int c = 0; c < kNB; c++) {
-    const double d = sA[c * kBigLd + c];
-    if (!(d > 0) && k * kNB + c < n) bad = true;  // the right-hand-side row and the padding are not pivots
-    // rows below c: l = a / d; trailing a[r][q] -= l[r] * a[q][c] for c < q <= r (a[q][c] still un-normalised)
-    for (int i = tid; i < (kNB - 1 - c) * (kNB - 1 - c); i += 256) {
-      const int r = c + 1 + i / (kNB - 1 - c), q = c + 1 + i % (kNB - 1 - c);
-      if (q <= r) sA[r * kBigLd + q] -= sA[r * kBigLd + c] / d * sA[q * kBigLd + c];
+  {  // thread (row r, column class g): a[r][q] -= (a[r][c] / d) a[q][c] for c < q <= r, q = g (mod 4)
+    const int r = tid & 63, g = tid >> 6;
+    for (int c = 0; c < kNB; c++) {
+      const double d = sA[c * kBigLd + c];
+      if (!(d > 0) && k * kNB + c < n) bad = true;  // the right-hand-side row and the padding are not pivots
+      if (r > c) {
+        const double l = sA[r * kBigLd + c] / d;
+        for (int q = c + 1 + ((g - c - 1) & 3); q <= r; q += 4) sA[r * kBigLd + q] -= l * sA[q * kBigLd + c];
+      }
+      __syncthreads();
+      if (g == 0 && r > c) sA[r * kBigLd + c] /= d;
+      if (tid == c) sD[c] = d;
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid > c && tid < kNB) sA[tid * kBigLd + c] /= d;
-    if (tid == c) sD[c] = d;
-    __syncthreads();
   }
   if (blockIdx.x == 0) {
     if (bad && tid == 0) *D.big_fail = 1;
@@ -1182,56 +1213,66 @@ k_big_syrk(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int 
     }
 }
 
+// step s of L^T x = z from the bottom: block kb = last - s.  Every workgroup solves the 64 x 64 block in LDS
+// (one wavefront, redundantly); workgroup 0 publishes x of the block, the others fold it into their 256 columns
+// of z (kept in Wp, free after the factorisation): z[c] -= sum_r L[c0 + r][c] x[r].
 __global__ void __launch_bounds__(256)
-k_big_back(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+k_big_back_step(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int s) {
   __shared__ double sA[kNB * kBigLd];
   __shared__ double sx[kNB];
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  const int n = D.np, nb = D.nb, tid = threadIdx.x;
+  if (n == 0) return;
+  const int kb = (n - 1) / kNB - s;
+  if (kb < 0) return;
+  const int c0 = kb * kNB, cn = min(kNB, n - c0);
+  if (blockIdx.x > 0 && (int)(blockIdx.x - 1) * 256 >= c0) return;
+  const size_t ld = nb;
+  const double* z = s == 0 ? D.Hb + (size_t)n * ld : D.Wp;  // z = D^-1 L^-1 b: the right-hand-side row of L
+  for (int i = tid; i < kNB * kNB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    sA[r * kBigLd + c] = (c < r && r < cn) ? D.Hb[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
+  }
+  if (tid < kNB) sx[tid] = tid < cn ? z[c0 + tid] : 0.0;
+  __syncthreads();
+  if (tid < kNB)  // x[r] is final once the rows below it have been applied
+    for (int r = cn - 1; r > 0; r--) {
+      const double xr = sx[r];
+      if (tid < r) sx[tid] -= sA[r * kBigLd + tid] * xr;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (tid < cn) D.xp[c0 + tid] = sx[tid];
+    return;
+  }
+  const int c = (blockIdx.x - 1) * 256 + tid;
+  if (c >= c0) return;
+  double v = z[c];
+  for (int r = 0; r < cn; r++) v -= D.Hb[(size_t)(c0 + r) * ld + c] * sx[r];
+  D.Wp[c] = v;
+}
+
+__global__ void __launch_bounds__(256)
+k_big_finish(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
   __shared__ double s_red[4];
   const int w = blockIdx.x;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
-  const int n = D.np, nb = D.nb, tid = threadIdx.x;
+  const int n = D.np, tid = threadIdx.x;
   if (n == 0) {
     if (tid == 0) out[w].ok = 1, out[w].scale_p = 0;
     return;
   }
-  const double lambda = win_lambda(ctl[w], out[w]);
   const bool ok = *D.big_fail == 0;
-  const size_t ld = nb;
-  double* x = D.xp;
-  if (ok) {
-    for (int i = tid; i < n; i += 256) x[i] = D.Hb[(size_t)n * ld + i];  // z = D^-1 L^-1 b
-    __syncthreads();
-    for (int kb = (n - 1) / kNB; kb >= 0; kb--) {
-      const int c0 = kb * kNB, cn = min(kNB, n - c0);
-      for (int i = tid; i < kNB * kNB; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        sA[r * kBigLd + c] = (c < r && r < cn) ? D.Hb[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
-      }
-      if (tid < kNB) sx[tid] = tid < cn ? x[c0 + tid] : 0.0;
-      __syncthreads();
-      if (tid < kNB)  // one wavefront: x[r] is final once the rows above... below it have been applied
-        for (int r = cn - 1; r > 0; r--) {
-          const double xr = sx[r];
-          if (tid < r) sx[tid] -= sA[r * kBigLd + tid] * xr;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-        }
-      __syncthreads();
-      if (tid < cn) x[c0 + tid] = sx[tid];
-      // z[0 .. c0) -= L[c0 + r][.] x[r]
-      for (int c = tid; c < c0; c += 256) {
-        double v = x[c];
-        for (int r = 0; r < cn; r++) v -= D.Hb[(size_t)(c0 + r) * ld + c] * sx[r];
-        x[c] = v;
-      }
-      __syncthreads();
-    }
-  } else {
-    for (int i = tid; i < n; i += 256) x[i] = 0;
+  if (!ok) {
+    for (int i = tid; i < n; i += 256) D.xp[i] = 0;
     __syncthreads();
   }
-  lba_apply_step(D, x, lambda, ok, out[w], s_red, tid);
+  lba_apply_step(D, D.xp, win_lambda(ctl[w], out[w]), ok, out[w], s_red, tid);
 }
 
 // ---- back-substitution + update of the points, landmark part of the LM gain-ratio scale
@@ -1506,7 +1547,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   std::vector<size_t> scratch_off(W);
   struct Scr {
     size_t kf_bak, X_bak, mp_act, BB, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
-        gchi, bfull, Hb, Wp, big_fail, kf_act;
+        gchi, bfull, Hb, Wp, big_fail, kf_act, occ;
     int nb;
   };
   std::vector<Scr> scr(W);
@@ -1612,6 +1653,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
     s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)nf * H.n_mp * 4);
     s.kf_act = take((size_t)H.n_kf * 4);
+    s.occ = take((size_t)((npm + 64) / 64) * ((H.n_mp + kChunkLm - 1) / kChunkLm));
     LbaDev& D = devs[w];
     memset(&D, 0, sizeof(D));
     D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.nf_cap = nf;
@@ -1674,7 +1716,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.part0 = (double*)(base + s.part0), D.part = (double*)(base + s.part);
     D.part_m = (double*)(base + s.part_m), D.pmax = (double*)(base + s.pmax);
     D.kf_list = (int*)(base + s.kf_list), D.tab = (int*)(base + s.tab);
-    D.kf_act = (int*)(base + s.kf_act);
+    D.kf_act = (int*)(base + s.kf_act), D.occ = base + s.occ;
     D.bfull = (double*)(base + s.bfull), D.Ae = (double*)(base + s.Ae);
     D.gchi0 = (double*)(base + s.gchi0), D.gchi = (double*)(base + s.gchi);
     if (vio) {
@@ -1706,6 +1748,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   VIEO_HIP_CHECK(hipMemcpyAsync(dD, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
   VIEO_HIP_CHECK(hipMemsetAsync(dO, 0, (size_t)W * sizeof(WinOut), st));
   const int n_max = pd * max_nf;
+  const int occ_max = ((6 * max_nf + 64) / 64) * ((max_mp + kChunkLm - 1) / kChunkLm);
   const bool big = big_solve(n_max);
   const size_t ldlt_small = big ? 0 : (size_t)8 * n_max * 8;  // panel columns, rhs, pivots
   const size_t tri = big ? 0 : (size_t)n_max * (n_max + 1) / 2 * 8;  // packed lower triangle
@@ -1757,6 +1800,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (any & LBA_BEGIN) {
       hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC);
       hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_occ, dim3((occ_max + 255) / 256, W), dim3(256), 0, st, dD, dC);
       hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0);
     }
     if (any & LBA_BUILD) {
@@ -1789,7 +1833,9 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
           hipLaunchKernelGGL(k_big_panel, dim3(1 + (below + 255) / 256, W), dim3(256), 0, st, dD, dC, k);
           if (m > 0) hipLaunchKernelGGL(k_big_syrk, dim3(m * (m + 1) / 2, W), dim3(256), 0, st, dD, dC, k);
         }
-        hipLaunchKernelGGL(k_big_back, dim3(W), dim3(256), 0, st, dD, dC, dO);
+        for (int sb = 0; sb < (n_max + kNB - 1) / kNB; sb++)
+          hipLaunchKernelGGL(k_big_back_step, dim3(1 + (n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, sb);
+        hipLaunchKernelGGL(k_big_finish, dim3(W), dim3(256), 0, st, dD, dC, dO);
       } else if (vio)
         hipLaunchKernelGGL(k_lba_ldlt<5>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
       else

@@ -345,6 +345,45 @@ def _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig=Non
     return obs_list
 
 
+def _keep_points(obs_arr, n_points, n_local):
+    """points with >= 2 observations and at least one local observer"""
+    m = obs_arr[:, 1].astype(np.int64)
+    cnt = np.bincount(m, minlength=n_points)
+    loc = np.bincount(m, weights=((obs_arr[:, 0].astype(np.int64) & 0xFFFFFF) < n_local), minlength=n_points)
+    return (cnt >= 2) & (loc > 0)
+
+
+def _observe_span(rng, poses, Xw, anchor, span, n_local, Rcb, tcb, noise, outlier_frac, stereo_frac):
+    """_observe for large maps, vectorised per key frame (rectified pinhole only): a point is looked for in the
+    local key frames within `span` indices of its anchor and in the non-local (fixed) ones -- the covisibility
+    a SLAM map has, instead of every key frame seeing everything along a slow trajectory."""
+    rows = []
+    for k, pose in enumerate(poses):
+        Rk, pk = pose[0], pose[1]
+        cand = np.nonzero(np.abs(anchor - k) <= span)[0] if k < n_local else np.arange(len(Xw))
+        if len(cand) == 0:
+            continue
+        Xc = (Xw[cand] - pk) @ Rk @ Rcb.T + tcb
+        ok = Xc[:, 2] >= 0.5
+        uu = FX * Xc[:, 0] / np.where(ok, Xc[:, 2], 1) + CX
+        vv = FY * Xc[:, 1] / np.where(ok, Xc[:, 2], 1) + CY
+        ok &= (uu > 10) & (uu < W - 10) & (vv > 10) & (vv < H - 10)
+        cand, Xc, uu, vv = cand[ok], Xc[ok], uu[ok], vv[ok]
+        n = len(cand)
+        lvl = rng.integers(0, 8, n)
+        sig = 1.2 ** lvl
+        uo = uu + rng.normal(0, noise, n) * sig
+        vo = vv + rng.normal(0, noise, n) * sig
+        ur = uu - BF / Xc[:, 2] + rng.normal(0, noise, n) * sig
+        out = rng.random(n) < outlier_frac
+        uo[out] += rng.uniform(-40, 40, out.sum())
+        vo[out] += rng.uniform(-40, 40, out.sum())
+        mono = rng.random(n) >= stereo_frac
+        isig = 1.0 / (np.float32(1.2) ** lvl).astype(np.float64) ** 2
+        rows.append(np.stack([np.full(n, k, float), cand.astype(float), uo, vo, np.where(mono, -1.0, ur), isig], 1))
+    return np.concatenate(rows) if rows else np.zeros((0, 6))
+
+
 # ----------------------------------------------------------------------------------------------
 def _scene_points(rng, local_poses, n_points, anchors):
     """points 2-12 m in front of `anchors` cameras spread evenly over the local key frames (1: the middle one,
@@ -362,11 +401,12 @@ def _scene_points(rng, local_poses, n_points, anchors):
         Rwc_m = Rm @ EUROC_TBC[:3, :3]
         twc_m = pm + Rm @ EUROC_TBC[:3, 3]
         Xw[which == t] = Xc[which == t] @ Rwc_m.T + twc_m
+    _scene_points.anchor = np.asarray(ids)[which]  # anchor key frame of every point (for _observe_span)
     return Xw, z
 
 
 def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.03, stereo_frac=0.7,
-                     noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_x=0.02, first_fixed=False, rig=None, anchors=1):
+                     noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_x=0.02, first_fixed=False, rig=None, anchors=1, span=None):
     """Seeded local-BA window: key frames on a smooth trajectory looking at a cloud
     of points 2-12 m ahead; every point is observed by the key frames that see it.
     returns (params[1], kfs[n_kf], points float32[n_mp,3], obs[n_obs] sorted by mp, truth)."""
@@ -391,14 +431,14 @@ def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.
     # points in front of the middle camera (or of several anchors)
     Xw, z = _scene_points(rng, poses[:n_local], n_points, anchors)
     rig_c = camera_rig(rig) if rig else None
-    obs_list = _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig_c)
+    if span is None:
+        obs_list = _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig_c)
+        obs_arr = np.array(obs_list, dtype=np.float64)
+    else:
+        obs_arr = _observe_span(rng, poses, Xw, _scene_points.anchor, span, n_local, Rcb, tcb, noise, outlier_frac,
+                                stereo_frac)
     # keep points with >= 2 observations and at least one local observer; renumber
-    obs_arr = np.array(obs_list, dtype=np.float64)
-    keep = np.zeros(n_points, bool)
-    for m in np.unique(obs_arr[:, 1].astype(int)):
-        sel = obs_arr[:, 1] == m
-        if sel.sum() >= 2 and ((obs_arr[sel, 0].astype(np.int64) & 0xFFFFFF) < n_local).any():
-            keep[m] = True
+    keep = _keep_points(obs_arr, n_points, n_local)
     remap = -np.ones(n_points, int)
     remap[keep] = np.arange(keep.sum())
     obs_arr = obs_arr[keep[obs_arr[:, 1].astype(int)]]
@@ -467,7 +507,7 @@ _PVR_TO_PRV = np.r_[0:3, 6:9, 3:6]  # Sigma order (p, v, Phi) -> (p, Phi, v)
 
 def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_frac=0.03, stereo_frac=0.7,
                          noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_v=0.03, pert_x=0.02, dt_kf=0.5,
-                         first_fixed=False, imu_noise=1.0, with_prev=True, rig=None, anchors=1):
+                         first_fixed=False, imu_noise=1.0, with_prev=True, rig=None, anchors=1, span=None):
     """Seeded visual-inertial local-BA window: a chain prev-local -> n_local key frames
     integrated forward with consistent IMU pre-integrations, n_fixed older covisible key frames,
     points 2-12 m ahead.  Key-frame order: local (oldest..newest), prev-local (fixed, full nav state),
@@ -501,13 +541,13 @@ def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_fra
     n_kf = len(poses)
     Xw, z = _scene_points(rng, local, n_points, anchors)
     rig_c = camera_rig(rig) if rig else None
-    obs_list = _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig_c)
-    obs_arr = np.array(obs_list, dtype=np.float64)
-    keep = np.zeros(n_points, bool)
-    for m in np.unique(obs_arr[:, 1].astype(int)):
-        sel = obs_arr[:, 1] == m
-        if sel.sum() >= 2 and ((obs_arr[sel, 0].astype(np.int64) & 0xFFFFFF) < n_local).any():
-            keep[m] = True
+    if span is None:
+        obs_list = _observe(rng, poses, Xw, Rcb, tcb, noise, outlier_frac, stereo_frac, rig_c)
+        obs_arr = np.array(obs_list, dtype=np.float64)
+    else:
+        obs_arr = _observe_span(rng, poses, Xw, _scene_points.anchor, span, n_local, Rcb, tcb, noise, outlier_frac,
+                                stereo_frac)
+    keep = _keep_points(obs_arr, n_points, n_local)
     remap = -np.ones(n_points, int)
     remap[keep] = np.arange(keep.sum())
     obs_arr = obs_arr[keep[obs_arr[:, 1].astype(int)]]
