@@ -1086,6 +1086,13 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
 //   k_big_back_step  L^T x = z, one 64-row block per launch from the bottom; k_big_finish: lba_apply_step
 static const int kNB = 64, kBigLd = kNB + 2;
 
+__device__ __forceinline__ double big_readlane(double v, int srclane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __global__ void __launch_bounds__(256)
 k_big_init(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const int w = blockIdx.y;
@@ -1122,24 +1129,31 @@ k_big_panel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
     sA[r * kBigLd + c] = c <= r ? Hb[(size_t)(k * kNB + r) * ld + k * kNB + c] : 0.0;
   }
   __syncthreads();
+  // LDL^T of the tile by ONE wavefront, register resident: lane r holds row r, column c is broadcast with
+  // v_readlane (no LDS traffic, no barriers); lanes r <= c carry don't-care values in a[q], q > r.
   bool bad = false;
-  {  // thread (row r, column class g): a[r][q] -= (a[r][c] / d) a[q][c] for c < q <= r, q = g (mod 4)
-    const int r = tid & 63, g = tid >> 6;
+  if (tid < kNB) {
+    double a[kNB];
+#pragma unroll
+    for (int c = 0; c < kNB; c++) a[c] = sA[tid * kBigLd + c];
+#pragma unroll
     for (int c = 0; c < kNB; c++) {
-      const double d = sA[c * kBigLd + c];
+      const double d = big_readlane(a[c], c);
       if (!(d > 0) && k * kNB + c < n) bad = true;  // the right-hand-side row and the padding are not pivots
-      if (r > c) {
-        const double l = sA[r * kBigLd + c] / d;
-        for (int q = c + 1 + ((g - c - 1) & 3); q <= r; q += 4) sA[r * kBigLd + q] -= l * sA[q * kBigLd + c];
-      }
-      __syncthreads();
-      if (g == 0 && r > c) sA[r * kBigLd + c] /= d;
-      if (tid == c) sD[c] = d;
-      __syncthreads();
+      const double l = a[c] / d;
+#pragma unroll
+      for (int q = c + 1; q < kNB; q++) a[q] -= l * big_readlane(a[c], q);  // w_q = A[q][c], un-normalised
+      if (tid > c) a[c] = l;
     }
+#pragma unroll
+    for (int c = 0; c < kNB; c++) {
+      if (c < tid) sA[tid * kBigLd + c] = a[c];
+      if (c == tid) sD[c] = a[c];
+    }
+    if (bad && blockIdx.x == 0) *D.big_fail = 1;
   }
+  __syncthreads();
   if (blockIdx.x == 0) {
-    if (bad && tid == 0) *D.big_fail = 1;
     for (int i = tid; i < kNB * kNB; i += 256) {
       const int r = i >> 6, c = i & 63;
       if (c < r) Hb[(size_t)(k * kNB + r) * ld + k * kNB + c] = sA[r * kBigLd + c];
