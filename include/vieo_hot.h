@@ -582,6 +582,60 @@ int vieo_orb_tap_candidates(vieo_orb* e, int image_index, int level, int32_t* h_
 int vieo_orb_tap_level_keys(vieo_orb* e, int image_index, int level, vieo_keypoint* h_dst,
                             int cap);
 
+/* ---------------------------------------------------------------- map-point side --------------
+ * The per-point steps either side of SearchByProjection(local map) and of the local BA write-back. */
+
+/* bool Frame::isInFrustum(MapPoint* pMP, float viewingCosLimit) (src/Frame.cc:335-416) for a batch of points:
+ * per camera positive depth, image bounds, distance inside [0.8 mfMinDistance, 1.2 mfMaxDistance], viewing
+ * cosine against the mean normal, MapPoint::PredictScale (src/MapPoint.cc:491-509).  All float, as the
+ * reference computes it; Sophus SE3f products are taken through their 3x4 matrices. */
+typedef struct vieo_frustum_frame {
+  float Rcrw[9], tcrw[3]; /* Tcw_ rotation (row-major) and mtcw, cast to float (Frame.cc:348-351) */
+  float Ow[3];            /* mOw */
+  int32_t n_cams;         /* 1..4 */
+  int32_t use_distort;    /* Frame::usedistort_: 0 -> K * (x/z, y/z, 1) in float, 1 -> camera Project() */
+  const struct vieo_camera* cams; /* host pointer, n_cams entries (Rcb / tcb unused) */
+  float Tcr[4][12];       /* mpCameras[i]->GetTcr().matrix3x4() row-major (identity for camera 0) */
+  float trc[4][3];        /* mpCameras[i]->GetTrc().translation() */
+  float bounds[4][4];     /* gridinfo_.minmax_xy_[i] = {min_x, max_x, min_y, max_y} */
+  float bf;               /* stereoinfo_.baseline_bf_[1] */
+  float log_scale_factor; /* scalepyrinfo_.flogscalefactor_ */
+  int32_t n_levels;
+  float viewing_cos_limit;
+} vieo_frustum_frame;
+
+typedef struct vieo_frustum_point {
+  float Xw[3], normal[3];           /* GetWorldPos(), GetNormal() */
+  float max_distance, min_distance; /* mfMaxDistance, mfMinDistance (the 1.2 / 0.8 factors are applied here) */
+} vieo_frustum_point;               /* 32 bytes */
+
+typedef struct vieo_track_info {    /* MapPoint::_TrackFastMatchInfo after the call */
+  float u[4], v[4], ur[4], viewcos[4]; /* vtrack_proj_[0..2], vtrack_viewcos_ (entries 0..n-1, push order) */
+  int32_t level[4], cam[4];         /* vtrack_scalelevel_, vtrack_cami_ */
+  int32_t n;                        /* cameras that see the point; btrack_inview_ = n > 0 */
+  float track_depth;                /* mean dist3D over those cameras; -1 when n == 0 (the member keeps its value) */
+} vieo_track_info;                  /* 104 bytes */
+
+int vieo_is_in_frustum_batch(const vieo_frustum_frame* h_frame, const vieo_frustum_point* h_points, int n_points,
+                             vieo_track_info* h_info);
+
+/* void MapPoint::ComputeDistinctiveDescriptors() (src/MapPoint.cc:314-378) for a batch of points: point p owns
+ * the descriptor rows [h_first[p], h_first[p + 1]) of h_descriptors (its observations in map order); h_best[p]
+ * receives the row (relative to h_first[p]) with the least median Hamming distance to the others, first such
+ * row on ties; -1 for a point without observations.  At most 128 observations per point. */
+int vieo_distinctive_descriptors_batch(const uint8_t* h_descriptors, const int32_t* h_first, int n_points,
+                                       int32_t* h_best);
+
+/* void MapPoint::UpdateNormalAndDepth() (src/MapPoint.cc:424-480) for a batch of points: observation i of point
+ * p looks from the camera centre h_centres[h_obs_centre[i]] (twc of the (key frame, camera) pair, float[3]);
+ * outputs the mean viewing direction and mfMaxDistance / mfMinDistance from the reference key frame
+ * (h_ref_centre[p] index into h_centres, h_ref_scale[p] = vscalefactor_[octave of the key in it]). */
+int vieo_update_normal_and_depth_batch(const float* h_points /*[n][3]*/, const int32_t* h_first,
+                                       const int32_t* h_obs_centre, const float* h_centres, int n_centres,
+                                       const int32_t* h_ref_centre, const float* h_ref_scale,
+                                       float scale_last_level, int n_points, float* h_normal /*[n][3]*/,
+                                       float* h_max_distance, float* h_min_distance);
+
 #ifdef __cplusplus
 }
 #endif

@@ -259,6 +259,28 @@ class Oracle:
         assert rc == 0, rc
         return out
 
+    def is_in_frustum(self, frame, points):
+        from vieo_slam_amd.map_point import frustum_call
+        P = ctypes.c_void_p
+        self.L.vo_is_in_frustum_batch.argtypes = [P, P, ctypes.c_int, P]
+        self.L.vo_is_in_frustum_batch.restype = None
+        return frustum_call(self.L.vo_is_in_frustum_batch, frame, points)[1]
+
+    def distinctive_descriptors(self, descriptors, first):
+        from vieo_slam_amd.map_point import distinctive_call
+        P = ctypes.c_void_p
+        self.L.vo_distinctive_descriptors_batch.argtypes = [P, P, ctypes.c_int, P]
+        self.L.vo_distinctive_descriptors_batch.restype = None
+        return distinctive_call(self.L.vo_distinctive_descriptors_batch, descriptors, first)[1]
+
+    def update_normal_and_depth(self, points, first, obs_centre, centres, ref_centre, ref_scale, scale_last):
+        from vieo_slam_amd.map_point import normal_depth_call
+        P = ctypes.c_void_p
+        self.L.vo_update_normal_and_depth_batch.argtypes = [P, P, P, P, P, P, ctypes.c_float, ctypes.c_int, P, P, P]
+        self.L.vo_update_normal_and_depth_batch.restype = None
+        return normal_depth_call(self.L.vo_update_normal_and_depth_batch, points, first, obs_centre, centres,
+                                 ref_centre, ref_scale, scale_last, oracle=True)[1:]
+
     def fisheye_branch_counts(self, reset=True):
         """(new group, extension, member replaced, contradiction kept, contradiction swapped) since the last reset"""
         out = (ctypes.c_long * 5)()

@@ -1,0 +1,177 @@
+"""Map-point steps next to the hot path: Frame::isInFrustum, ComputeDistinctiveDescriptors,
+UpdateNormalAndDepth.  Oracle known-answer tests (CPU) and HIP-vs-oracle parity (GPU; float results bit-equal:
+both sides evaluate the same float expressions in the same order)."""
+import numpy as np
+import pytest
+
+from vieo_slam_amd import synth_ba
+from vieo_slam_amd.map_point import FRUSTUM_FRAME_DTYPE, FRUSTUM_POINT_DTYPE
+
+
+def _frame(rng, rig=None):
+    """a frame at a random pose; rig = None: one rectified pinhole camera, else the distorted cameras of a rig"""
+    F = np.zeros(1, FRUSTUM_FRAME_DTYPE)
+    f = F[0]
+    Rcw = synth_ba.quat_to_R(synth_ba.quat_from_rotvec(rng.normal(0, 0.4, 3)))
+    tcw = rng.uniform(-1, 1, 3)
+    f["Rcrw"], f["tcrw"], f["Ow"] = Rcw.reshape(-1), tcw, -Rcw.T @ tcw
+    if rig is None:
+        from vieo_slam_amd.ba_types import CAMERA_DTYPE
+        cams = np.zeros(1, CAMERA_DTYPE)
+        cams[0]["fx"], cams[0]["fy"], cams[0]["cx"], cams[0]["cy"] = synth_ba.FX, synth_ba.FY, synth_ba.CX, synth_ba.CY
+        size, Tcr = (synth_ba.W, synth_ba.H), [np.eye(4)]
+        f["use_distort"] = 0
+    else:
+        cams, size, Tcr = synth_ba.camera_rig(rig, with_tcr=True)
+        f["use_distort"] = 1
+    f["n_cams"], f["cams"] = len(cams), cams.ctypes.data
+    for c, T in enumerate(Tcr):
+        f["Tcr"][c] = T[:3, :].reshape(-1)
+        f["trc"][c] = np.linalg.inv(T)[:3, 3]
+        f["bounds"][c] = (0, size[0], 0, size[1])
+    f["bf"], f["n_levels"], f["viewing_cos_limit"] = synth_ba.BF, 8, 0.5
+    f["log_scale_factor"] = np.float32(np.log(np.float32(1.2)))
+    return F, cams, Rcw, tcw
+
+
+def _points(rng, Rcw, tcw, n):
+    P = np.zeros(n, FRUSTUM_POINT_DTYPE)
+    Xc = np.stack([rng.uniform(-8, 8, n), rng.uniform(-5, 5, n), rng.uniform(-2, 14, n)], 1)
+    Xw = (Xc - tcw) @ Rcw  # Rcw^T (Xc - tcw)
+    P["Xw"] = Xw
+    Ow = -Rcw.T @ tcw
+    d = np.linalg.norm(Xw - Ow, axis=1)
+    nrm = (Xw - Ow) / d[:, None] + rng.normal(0, 0.5, (n, 3))
+    P["normal"] = nrm / np.linalg.norm(nrm, axis=1)[:, None]
+    lvl = rng.integers(0, 8, n)
+    ref_dist = d * rng.uniform(0.4, 2.5, n)  # distance at which the point was created
+    P["max_distance"] = ref_dist * 1.2 ** lvl
+    P["min_distance"] = P["max_distance"] / np.float32(1.2 ** 7)
+    return P
+
+
+def _obs_problem(rng, n_points, n_centres=40, max_obs=20):
+    pts = rng.uniform(-5, 5, (n_points, 3)).astype(np.float32)
+    centres = rng.uniform(-6, 6, (n_centres, 3)).astype(np.float32)
+    cnt = rng.integers(0, max_obs + 1, n_points)
+    cnt[0] = 0
+    first = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    obs_centre = rng.integers(0, n_centres, first[-1]).astype(np.int32)
+    ref_centre = np.array([obs_centre[first[p]] if cnt[p] else 0 for p in range(n_points)], np.int32)
+    ref_scale = (np.float32(1.2) ** rng.integers(0, 8, n_points)).astype(np.float32)
+    return pts, first, obs_centre, centres, ref_centre, ref_scale
+
+
+# ------------------------------------------------------------------ oracle (CPU)
+def test_oracle_frustum_gates(oracle):
+    rng = np.random.default_rng(1)
+    F, cams, Rcw, tcw = _frame(rng)
+    P = _points(rng, Rcw, tcw, 4000)
+    info = oracle.is_in_frustum(F, P)
+    Xc = P["Xw"].astype(np.float64) @ Rcw.T + tcw
+    u = synth_ba.FX * Xc[:, 0] / Xc[:, 2] + synth_ba.CX
+    v = synth_ba.FY * Xc[:, 1] / Xc[:, 2] + synth_ba.CY
+    d = np.linalg.norm(P["Xw"] - F[0]["Ow"], axis=1)
+    cosv = ((P["Xw"] - F[0]["Ow"]) * P["normal"]).sum(1) / d
+    exp = ((Xc[:, 2] >= 0) & (u >= 0) & (u <= synth_ba.W) & (v >= 0) & (v <= synth_ba.H) &
+           (d >= 0.8 * P["min_distance"]) & (d <= 1.2 * P["max_distance"]) & (cosv >= 0.5))
+    near = ((np.abs(u) < 1e-2) | (np.abs(u - synth_ba.W) < 1e-2) | (np.abs(v) < 1e-2) | (np.abs(v - synth_ba.H) < 1e-2)
+            | (np.abs(cosv - 0.5) < 1e-5) | (np.abs(d / (0.8 * P["min_distance"]) - 1) < 1e-5)
+            | (np.abs(d / (1.2 * P["max_distance"]) - 1) < 1e-5))
+    got = info["n"] > 0
+    assert (got == exp)[~near].all() and 200 < got.sum() < 3000
+    k = got & ~near
+    assert np.allclose(info["u"][k, 0], u[k], atol=2e-3) and np.allclose(info["ur"][k, 0], u[k] - synth_ba.BF / Xc[k, 2], atol=2e-3)
+    assert np.allclose(info["track_depth"][k], d[k], rtol=1e-6) and (info["track_depth"][~got] == -1).all()
+    # PredictScale: ceil(log(max/d) / log 1.2) clamped to [0, 7]
+    lv = np.clip(np.ceil(np.log(P["max_distance"][k].astype(np.float64) / d[k]) / np.log(1.2)), 0, 7)
+    assert (np.abs(info["level"][k, 0] - lv) <= 1).all() and (info["level"][k, 0] == lv).mean() > 0.999
+
+
+def test_oracle_distinctive_descriptor_is_the_medoid(oracle):
+    rng = np.random.default_rng(2)
+    first, rows, expect = [0], [], []
+    for p in range(60):
+        N = int(rng.integers(0, 40)) if p else 0
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        D = np.repeat(base[None], N, 0)
+        for i in range(N):
+            for b in rng.integers(0, 256, rng.integers(0, 80)):
+                D[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        rows.append(D)
+        first.append(first[-1] + N)
+        if N:
+            dist = np.unpackbits(D[:, None] ^ D[None], axis=2).sum(2)
+            med = np.sort(dist, 1)[:, int(0.5 * (N - 1))]
+            expect.append(int(np.argmin(med)))  # first minimum
+        else:
+            expect.append(-1)
+    best = oracle.distinctive_descriptors(np.concatenate(rows), first)
+    assert best.tolist() == expect
+
+
+def test_oracle_normal_and_depth(oracle):
+    rng = np.random.default_rng(3)
+    pts, first, oc, centres, rc, rs = _obs_problem(rng, 300)
+    nrm, mx, mn = oracle.update_normal_and_depth(pts, first, oc, centres, rc, rs, np.float32(1.2) ** 7)
+    for p in (1, 7, 100, 299):
+        if first[p + 1] == first[p]:
+            continue
+        d = pts[p] - centres[oc[first[p]:first[p + 1]]]
+        e = (d / np.linalg.norm(d, axis=1)[:, None]).mean(0)
+        assert np.allclose(nrm[p], e, atol=1e-5)
+        dist = np.linalg.norm(pts[p] - centres[rc[p]])
+        assert np.isclose(mx[p], dist * rs[p], rtol=1e-6) and np.isclose(mn[p], mx[p] / 1.2 ** 7, rtol=1e-6)
+    assert mx[0] == -1 and (nrm[0] == 0).all()  # no observations: members untouched
+
+
+# ------------------------------------------------------------------ parity (GPU)
+@pytest.mark.gpu
+@pytest.mark.parametrize("rig", [None, "radtan", "kb8"])
+def test_frustum_parity(oracle, rig):
+    from vieo_slam_amd.map_point import is_in_frustum
+    rng = np.random.default_rng(11)
+    F, cams, Rcw, tcw = _frame(rng, rig)
+    P = _points(rng, Rcw, tcw, 20000)
+    o, h = oracle.is_in_frustum(F, P), is_in_frustum(F, P)
+    assert o["n"].sum() > 1000
+    if rig is None:
+        assert o.tobytes() == h.tobytes()  # float expressions in the same order: bit-equal records
+    else:  # the distorted projection goes through double sin / atan2: libm vs device, last float bit at most
+        assert np.array_equal(o["n"], h["n"]) and np.array_equal(o["cam"], h["cam"]) and np.array_equal(o["level"], h["level"])
+        for k in ("u", "v", "ur", "viewcos", "track_depth"):
+            assert np.allclose(o[k], h[k], rtol=1e-6, atol=1e-4)
+    if rig == "kb8":
+        assert (o["n"] > 1).any()  # some points are seen by several cameras of the rig
+
+
+@pytest.mark.gpu
+def test_distinctive_parity(oracle):
+    from vieo_slam_amd._lib import lib
+    from vieo_slam_amd.map_point import compute_distinctive_descriptors, distinctive_call
+    rng = np.random.default_rng(12)
+    cnt = rng.integers(0, 129, 3000)
+    cnt[:4] = (0, 1, 2, 128)
+    first = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    base = rng.integers(0, 256, (len(cnt), 32), dtype=np.uint8)
+    D = np.repeat(base, cnt, 0)
+    flip = rng.random(D.shape) < 0.08  # near-duplicates: many equal medians, ties resolved by the first row
+    D ^= (flip * (1 << rng.integers(0, 8, D.shape))).astype(np.uint8)
+    o = oracle.distinctive_descriptors(D, first)
+    h = compute_distinctive_descriptors(D, first)
+    assert np.array_equal(o, h) and (h[cnt == 0] == -1).all()
+    first2 = np.array([0, 129], np.int32)
+    rc, _ = distinctive_call(lib().vieo_distinctive_descriptors_batch, np.zeros((129, 32), np.uint8), first2)
+    assert rc != 0  # capacity
+
+
+@pytest.mark.gpu
+def test_normal_depth_parity(oracle):
+    from vieo_slam_amd.map_point import update_normal_and_depth
+    rng = np.random.default_rng(13)
+    pts, first, oc, centres, rc, rs = _obs_problem(rng, 50000, n_centres=300, max_obs=30)
+    s7 = float(np.float32(1.2) ** 7)
+    o = oracle.update_normal_and_depth(pts, first, oc, centres, rc, rs, s7)
+    h = update_normal_and_depth(pts, first, oc, centres, rc, rs, s7)
+    for a, b in zip(o, h):
+        assert a.tobytes() == b.tobytes()

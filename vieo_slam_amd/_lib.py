@@ -23,6 +23,10 @@ _SIGS = {
     "vieo_device_available": (c_i, []),
     "vieo_set_device": (c_i, [c_i]),
     "vieo_pose_set_camera_mode": (c_i, [c_i]),
+    "vieo_is_in_frustum_batch": (c_i, [c_p, c_p, c_i, c_p]),
+    "vieo_distinctive_descriptors_batch": (c_i, [c_p, c_p, c_i, c_p]),
+    "vieo_update_normal_and_depth_batch": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, ctypes.c_float, c_i, c_p, c_p,
+                                                 c_p]),
     "vieo_bundle_adjustment": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "vieo_global_bundle_adjustment_vio": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p,
                                                 c_p]),
