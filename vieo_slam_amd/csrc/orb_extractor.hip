@@ -425,11 +425,23 @@ k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles, int n_tiles, i
       ((unsigned*)s_src)[idx] = *(const unsigned*)(src + (size_t)(oy + r - 3) * pitch + ox - 4 + 4 * c4);
     }
   } else {
-    for (int idx = tid; idx < SH * SP; idx += 256) {
-      const int r = idx / SP, c = idx - r * SP;
+    // border tiles (a third of all tiles over the pyramid): whole dwords wherever the four columns lie inside
+    // the image, REFLECT_101 byte by byte only for the dwords that straddle a border
+    const bool aligned = ((pitch & 3) == 0) && ((((uintptr_t)src) & 3) == 0);
+    for (int idx = tid; idx < SH * (SP / 4); idx += 256) {
+      const int r = idx / (SP / 4), c4 = idx - r * (SP / 4);
       const int gy = reflect101(min(oy + r - 3, D.h + 2), D.h);
-      const int gx = reflect101(min(ox + c - 4, D.w + 2), D.w);
-      s_src[idx] = src[(size_t)gy * pitch + gx];
+      const int gx0 = ox - 4 + 4 * c4;
+      const uint8_t* row = src + (size_t)gy * pitch;
+      unsigned v;
+      if (aligned && gx0 >= 0 && gx0 + 4 <= D.w)
+        v = *(const unsigned*)(row + gx0);
+      else {
+        v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v |= (unsigned)row[reflect101(min(gx0 + j, D.w + 2), D.w)] << (8 * j);
+      }
+      ((unsigned*)s_src)[idx] = v;
     }
   }
   __syncthreads();
