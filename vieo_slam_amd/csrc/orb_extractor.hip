@@ -191,10 +191,13 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
     if (npx > 0) {
       typedef short s2 __attribute__((ext_vector_type(2)));
       const int s = (3 + xo) & 3, kq = (3 + xo) >> 2;  // centre byte of pixel x sits at 4 * (lx4 + kq) + s
-      const int lx4 = lane & 15, ly4 = lane >> 4;
+      // a 30 .. 32 pixel wide cell (the three largest levels) needs 8 four-pixel groups per row, so a step
+      // covers 8 rows with every lane busy; wider cells take 16 groups x 4 rows
+      const int gsh = vw <= 32 ? 3 : 4;
+      const int lx4 = lane & ((1 << gsh) - 1), ly4 = lane >> gsh, rows_per_step = 64 >> gsh;
       const int x0 = 4 * lx4;
       const unsigned th1 = (unsigned)(th + 1) * 0x00010001u, thp = (unsigned)th * 0x00010001u;
-      for (int y0 = 0; y0 < vh; y0 += 4) {
+      for (int y0 = 0; y0 < vh; y0 += rows_per_step) {
         const int y = y0 + ly4;
         unsigned m4 = 0;
         if (x0 < vw && y < vh) {
