@@ -47,9 +47,26 @@ k_resize(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab,
   const short4* yt = ytab + D.ytab_off;
   const int sy_lo = yt[dy0].x, nrows = yt[dy1 - 1].y - sy_lo + 1;
   const int sx_lo = xt[dx0].x & ~3, ndw = ((xt[dx1 - 1].y + 4) >> 2) - (sx_lo >> 2);
-  for (int r = wave; r < nrows; r += 4) {
-    const unsigned* row = (const unsigned*)(src + (size_t)(sy_lo + r) * spitch + sx_lo);
-    for (int c = lane; c < ndw; c += 64) *(unsigned*)(smem + r * lds_pitch + 4 * c) = row[c];
+  {  // all source rows of the band in flight at once (12 rows x 2 dword columns per lane), then the stores: a
+     // dependent load -> store loop costs one HBM round trip per row
+    unsigned v[12][2];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const int r = wave + 4 * k;
+      const unsigned* row = (const unsigned*)(src + (size_t)(sy_lo + r) * spitch + sx_lo);
+      if (r < nrows && lane < ndw) v[k][0] = row[lane];
+      if (r < nrows && lane + 64 < ndw) v[k][1] = row[lane + 64];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const int r = wave + 4 * k;
+      if (r < nrows && lane < ndw) *(unsigned*)(smem + r * lds_pitch + 4 * lane) = v[k][0];
+      if (r < nrows && lane + 64 < ndw) *(unsigned*)(smem + r * lds_pitch + 4 * (lane + 64)) = v[k][1];
+    }
+    for (int r = wave; r < nrows; r += 4) {  // whatever a wider / taller band leaves over
+      const unsigned* row = (const unsigned*)(src + (size_t)(sy_lo + r) * spitch + sx_lo);
+      for (int c = lane + (r < 48 ? 128 : 0); c < ndw; c += 64) *(unsigned*)(smem + r * lds_pitch + 4 * c) = row[c];
+    }
   }
   __syncthreads();
   const int dx4 = dx0 + lane * 4;
@@ -159,7 +176,17 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
       const uint8_t* g = src + (size_t)(cd.y0 + dr) * pitch + x0a + 4 * dc;
       uint8_t* t = tile + dr * tpitch + 4 * dc;
       const int gstep = 4 * pitch, tstep = 4 * tpitch;
-      for (int r = dr; r < cd.ch; r += 4, g += gstep, t += tstep) *(unsigned*)t = *(const unsigned*)g;
+      // every row of the cell in flight at once (a dependent load -> store loop costs one HBM round trip per
+      // four rows); cells taller than 64 rows finish in the loop
+      unsigned v[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (dr + 4 * k < cd.ch) v[k] = *(const unsigned*)(g + (size_t)k * gstep);
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (dr + 4 * k < cd.ch) *(unsigned*)(t + k * tstep) = v[k];
+      g += (size_t)16 * gstep, t += 16 * tstep;
+      for (int r = dr + 64; r < cd.ch; r += 4, g += gstep, t += tstep) *(unsigned*)t = *(const unsigned*)g;
     }
     for (int idx = lane; idx < cd.ch * (ndw - 16); idx += 64) {  // columns 16.. (cells wider than 61)
       const int r = idx / (ndw - 16), dcol = 16 + idx % (ndw - 16);
@@ -423,29 +450,41 @@ k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles, int n_tiles, i
   const bool interior = ox >= 4 && ox + 68 <= D.w && oy >= 3 && oy + kBlurTH + 3 <= D.h &&
                         ((pitch & 3) == 0) && ((((uintptr_t)src) & 3) == 0);
   if (interior) {
-    for (int idx = tid; idx < SH * (SP / 4); idx += 256) {
-      const int r = idx / (SP / 4), c4 = idx - r * (SP / 4);
-      ((unsigned*)s_src)[idx] = *(const unsigned*)(src + (size_t)(oy + r - 3) * pitch + ox - 4 + 4 * c4);
+    constexpr int NIT = (SH * (SP / 4) + 255) / 256;  // all loads of the tile in flight, then the stores
+    unsigned v[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      const int idx = tid + 256 * k, r = idx / (SP / 4), c4 = idx - r * (SP / 4);
+      if (idx < SH * (SP / 4)) v[k] = *(const unsigned*)(src + (size_t)(oy + r - 3) * pitch + ox - 4 + 4 * c4);
     }
+#pragma unroll
+    for (int k = 0; k < NIT; k++)
+      if (tid + 256 * k < SH * (SP / 4)) ((unsigned*)s_src)[tid + 256 * k] = v[k];
   } else {
     // border tiles (a third of all tiles over the pyramid): whole dwords wherever the four columns lie inside
     // the image, REFLECT_101 byte by byte only for the dwords that straddle a border
     const bool aligned = ((pitch & 3) == 0) && ((((uintptr_t)src) & 3) == 0);
-    for (int idx = tid; idx < SH * (SP / 4); idx += 256) {
-      const int r = idx / (SP / 4), c4 = idx - r * (SP / 4);
-      const int gy = reflect101(min(oy + r - 3, D.h + 2), D.h);
-      const int gx0 = ox - 4 + 4 * c4;
-      const uint8_t* row = src + (size_t)gy * pitch;
-      unsigned v;
-      if (aligned && gx0 >= 0 && gx0 + 4 <= D.w)
-        v = *(const unsigned*)(row + gx0);
-      else {
-        v = 0;
+    constexpr int NIT = (SH * (SP / 4) + 255) / 256;
+    unsigned v[NIT];
 #pragma unroll
-        for (int j = 0; j < 4; j++) v |= (unsigned)row[reflect101(min(gx0 + j, D.w + 2), D.w)] << (8 * j);
+    for (int k = 0; k < NIT; k++) {
+      const int idx = tid + 256 * k, r = idx / (SP / 4), c4 = idx - r * (SP / 4);
+      v[k] = 0;
+      if (idx < SH * (SP / 4)) {
+        const int gy = reflect101(min(oy + r - 3, D.h + 2), D.h);
+        const int gx0 = ox - 4 + 4 * c4;
+        const uint8_t* row = src + (size_t)gy * pitch;
+        if (aligned && gx0 >= 0 && gx0 + 4 <= D.w)
+          v[k] = *(const unsigned*)(row + gx0);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[k] |= (unsigned)row[reflect101(min(gx0 + j, D.w + 2), D.w)] << (8 * j);
+        }
       }
-      ((unsigned*)s_src)[idx] = v;
     }
+#pragma unroll
+    for (int k = 0; k < NIT; k++)
+      if (tid + 256 * k < SH * (SP / 4)) ((unsigned*)s_src)[tid + 256 * k] = v[k];
   }
   __syncthreads();
   const unsigned K0123 = 18u | (34u << 8) | (48u << 16) | (56u << 24);
