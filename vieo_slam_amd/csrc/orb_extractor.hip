@@ -619,15 +619,20 @@ k_describe(OrbParams P, ImgSet I, const unsigned* __restrict__ sel,
     const int c = lane & 15, r0 = lane >> 4;
     const uint8_t* ga = img + (size_t)(cy - kHalfPatch + r0) * pitch + xa + 4 * c;
     const uint8_t* gb = bl0 + (size_t)(cy - BR + r0) * bp + xb + 4 * c;
-    if (c < 9)
+    // both patches in flight at once, then the LDS stores (one memory round trip instead of two)
+    unsigned va[8], vb[10];
 #pragma unroll
-      for (int k = 0; k < 8; k++)
-        if (r0 + 4 * k < 31) *(unsigned*)(sa + (r0 + 4 * k) * AP + 4 * c) = *(const unsigned*)(ga + (size_t)(4 * k) * pitch);
-    if (c < 11)
+    for (int k = 0; k < 8; k++)
+      if (c < 9 && r0 + 4 * k < 31) va[k] = *(const unsigned*)(ga + (size_t)(4 * k) * pitch);
 #pragma unroll
-      for (int k = 0; k < 10; k++)
-        if (r0 + 4 * k < 2 * BR + 1)
-          *(unsigned*)(sb + (r0 + 4 * k) * BP + 4 * c) = *(const unsigned*)(gb + (size_t)(4 * k) * bp);
+    for (int k = 0; k < 10; k++)
+      if (c < 11 && r0 + 4 * k < 2 * BR + 1) vb[k] = *(const unsigned*)(gb + (size_t)(4 * k) * bp);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (c < 9 && r0 + 4 * k < 31) *(unsigned*)(sa + (r0 + 4 * k) * AP + 4 * c) = va[k];
+#pragma unroll
+    for (int k = 0; k < 10; k++)
+      if (c < 11 && r0 + 4 * k < 2 * BR + 1) *(unsigned*)(sb + (r0 + 4 * k) * BP + 4 * c) = vb[k];
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();

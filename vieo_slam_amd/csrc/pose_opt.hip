@@ -134,9 +134,11 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] = 0;
         double chi = 0;
+        vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
         for (int k = 0, i = tid; i < N; k++, i += BS) {
+          const vieo_pose_obs o = o_next;
+          if (i + BS < N) o_next = obs[i + BS];
           if ((levelmask >> k) & 1) continue;
-          const vieo_pose_obs o = obs[i];
           double err[3], Pc[3];
           double J[18];
           const double chi2 = edge_eval<MC>(c, s_cams, X, est.p, o, err, Pc, J);
@@ -181,9 +183,11 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
           PoseXf X2;
           make_xf(c, est, X2);
           double tc[1] = {0};
+          vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
           for (int k = 0, i = tid; i < N; k++, i += BS) {
+            const vieo_pose_obs o = o_next;
+            if (i + BS < N) o_next = obs[i + BS];
             if ((levelmask >> k) & 1) continue;
-            const vieo_pose_obs o = obs[i];
             double err[3], Pc[3];
             const double chi2 = edge_eval<MC>(c, s_cams, X2, est.p, o, err, Pc, nullptr);
             double r0 = chi2, r1 = 1.;

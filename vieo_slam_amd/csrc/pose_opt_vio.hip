@@ -337,9 +337,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     PoseXf X;
     make_xf(c, e, X);
     double tc[1] = {0};
+    vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
     for (int k = 0, i = tid; i < N; k++, i += BS) {
+      const vieo_pose_obs o = o_next;
+      if (i + BS < N) o_next = obs[i + BS];
       if ((levelmask >> k) & 1) continue;
-      const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
       const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr);
       double r0 = chi2, r1 = 1.;
@@ -375,9 +377,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       double acc[28];
 #pragma unroll
       for (int i = 0; i < 28; i++) acc[i] = 0;
+      vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
       for (int k = 0, i = tid; i < N; k++, i += BS) {
+        const vieo_pose_obs o = o_next;
+        if (i + BS < N) o_next = obs[i + BS];
         if ((levelmask >> k) & 1) continue;
-        const vieo_pose_obs o = obs[i];
         double err[3], Pc[3];
         double J[18];
         const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J);
@@ -598,9 +602,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
+    vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
     for (int k = 0, i = tid; i < N; k++, i += BS) {
+      const vieo_pose_obs o = o_next;
+      if (i + BS < N) o_next = obs[i + BS];
       if ((levelmask >> k) & 1) continue;
-      const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
       double J[18];
       const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J);
