@@ -223,15 +223,25 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
     py[k] = p / 11, px[k] = p - py[k] * 11;
     il[k] = p < 121 ? (int)PL[(size_t)(r0 + py[k]) * pitchL + cL0 + px[k]] - cvL : 0;
   }
+  // the right-image bytes of all 11 shifts in flight at once (33 loads), then the sums: interleaved with the
+  // wavefront reductions they cost one memory round trip per shift
+  int cvRv[11], irv[2][11];
+#pragma unroll
+  for (int inc = -L; inc <= L; inc++) {
+    cvRv[inc + L] = PR[(size_t)(r0 + w) * pitchR + cR0 + inc + w];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      irv[k][inc + L] = lane + 64 * k < 121 ? (int)PR[(size_t)(r0 + py[k]) * pitchR + cR0 + inc + px[k]] : 0;
+  }
   int bestS = INT_MAX, bestInc = 0, sads[11];
 #pragma unroll
   for (int inc = -L; inc <= L; inc++) {
-    const int cvR = PR[(size_t)(r0 + w) * pitchR + cR0 + inc + w];
+    const int cvR = cvRv[inc + L];
     int acc = 0;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       if (lane + 64 * k < 121) {
-        const int ir = (int)PR[(size_t)(r0 + py[k]) * pitchR + cR0 + inc + px[k]] - cvR;
+        const int ir = irv[k][inc + L] - cvR;
         acc += abs(il[k] - ir);
       }
     }
