@@ -396,19 +396,39 @@ k_quadtree(OrbParams P, const unsigned* __restrict__ cell_keys,
   unsigned* kk = keys + (size_t)b * P.keys_per_image + D.key_off;
   unsigned short* ks = kslot + (size_t)b * P.keys_per_image + D.key_off;
   unsigned char* kqq = kq + (size_t)b * P.keys_per_image + D.key_off;
-  {
-    const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
-    for (int c = wave; c < ncell; c += nwaves) {
-      const int cnt = cnts[c];
-      const int base = (int)inc[c] - cnt;
-      const unsigned* src = cell_keys + ((size_t)b * P.ncells + D.cell_begin + c) * P.cell_cap;
-      for (int i = lane; i < cnt; i += 64) {
-        const unsigned key = src[i];
-        kk[base + i] = key;
-        // vpIniNodes[kp.pt.x / hX]  (ORBextractor.cc:549)
-        const int ini = (int)((float)QT_KEY_X(key) / D.hX);
-        ks[base + i] = (unsigned short)ini;
-        atomicAdd(&m.cnt[ini], 1);
+  {  // one thread per output key, four keys in flight: the cell of key t is found by bisection on the inclusive
+     // scan in LDS (a wavefront per cell walked ~90 cells one dependent HBM round trip after the other)
+    const unsigned* cells0 = cell_keys + ((size_t)b * P.ncells + D.cell_begin) * P.cell_cap;
+    const int nth = blockDim.x;
+    for (int t0 = tid; t0 < K; t0 += 4 * nth) {
+      unsigned key[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int t = t0 + u * nth;
+        key[u] = 0;
+        if (t < K) {
+          int lo = 0, hi = ncell - 1;  // first cell with inc[c] > t
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)inc[mid] > t)
+              hi = mid;
+            else
+              lo = mid + 1;
+          }
+          const int first = lo ? (int)inc[lo - 1] : 0;
+          key[u] = cells0[(size_t)lo * P.cell_cap + (t - first)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int t = t0 + u * nth;
+        if (t < K) {
+          kk[t] = key[u];
+          // vpIniNodes[kp.pt.x / hX]  (ORBextractor.cc:549)
+          const int ini = (int)((float)QT_KEY_X(key[u]) / D.hX);
+          ks[t] = (unsigned short)ini;
+          atomicAdd(&m.cnt[ini], 1);
+        }
       }
     }
   }
