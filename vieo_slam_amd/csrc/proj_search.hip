@@ -364,10 +364,24 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
   const unsigned* pool = A.pool + (size_t)f * A.pool_cap;
   const int2* qrec = A.qrec + (size_t)f * A.q_cap;
   const int n_lds = min(min(A.cursor[f], A.pool_cap), A.pool_lds);
-  for (int i = lane; i < n_lds; i += 64) s_pool[i] = pool[i];
-  for (int i = lane; i < N; i += 64) {
-    assign[i] = VIEO_SBP_UNCHANGED;
-    s_state[i] = (taken && taken[i]) ? 3 : 0;
+  for (int i0 = lane; i0 < n_lds; i0 += 16 * 64) {  // 16 loads in flight per lane, then the LDS stores
+    unsigned v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = i0 + 64 * u < n_lds ? pool[i0 + 64 * u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (i0 + 64 * u < n_lds) s_pool[i0 + 64 * u] = v[u];
+  }
+  for (int i0 = lane; i0 < N; i0 += 8 * 64) {
+    uint8_t t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = (taken && i0 + 64 * u < N) ? taken[i0 + 64 * u] : (uint8_t)0;
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i0 + 64 * u < N) {
+        assign[i0 + 64 * u] = VIEO_SBP_UNCHANGED;
+        s_state[i0 + 64 * u] = t[u] ? 3 : 0;
+      }
   }
   if (lane < kHistoLen) s_hist[lane] = 0;
   __syncthreads();
