@@ -636,6 +636,40 @@ int vieo_update_normal_and_depth_batch(const float* h_points /*[n][3]*/, const i
                                        float scale_last_level, int n_points, float* h_normal /*[n][3]*/,
                                        float* h_max_distance, float* h_min_distance);
 
+/* The search of ORBmatcher::SearchByProjectionBase (src/ORBmatcher.cc:26-227) -- what ORBmatcher::Fuse (:1152-1165,
+ * LocalMapping::SearchInNeighbors) and the Sim3 / loop-closing callers run per map point: projection into every
+ * camera of the key frame (positive depth, FrameBase::IsInImage, scale-invariance distances, optional 60 degree
+ * viewing cone), MapPoint::PredictScale, FrameBase::GetFeaturesInArea (FrameBase.cpp:95-141) with radius
+ * th_radius * scale[level], octave in [level-1, level], the chi2 gate on the reprojection error (7.8 stereo /
+ * 5.99 mono, only when use_bf), best Hamming distance (first minimum in the reference's candidate order).
+ * Per (point, camera): h_best_idx (index into that camera's keys, -1: none) and h_best_dist.  The thresholds on
+ * the distance, KeyFrame::FuseMP and the only-one-match bookkeeping (:195-224) stay with the caller: they are
+ * order-dependent mutations of the map.  A point whose skip_mask has bit 31 set is not searched at all
+ * (isBad / IsInKeyFrame), bit c skips camera c (pvbAlreadyMatched1). */
+typedef struct vieo_fuse_frame {
+  vieo_frustum_frame base;     /* Rcrw, tcrw, Ow = GetCameraCenter(), cameras, bounds, bf, log scale factor, n_levels */
+  float scale_factors[16];     /* scalepyrinfo_.vscalefactor_ */
+  float inv_level_sigma2[16];  /* scalepyrinfo_.vinvlevelsigma2_ */
+  float th_radius;
+  int32_t check_viewing_angle; /* bCheckViewingAngle */
+  int32_t use_bf;              /* pbf != nullptr: chi2 gate with the stereo coordinate */
+  int32_t reserved;
+} vieo_fuse_frame;
+
+typedef struct vieo_fuse_point {
+  float Xw[3], normal[3];
+  float max_distance, min_distance; /* mfMaxDistance, mfMinDistance */
+  uint8_t desc[32];                 /* GetDescriptor() */
+  int32_t skip_mask;
+  int32_t reserved;
+} vieo_fuse_point;                  /* 72 bytes */
+
+int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const* h_keys /*[n_cams]*/,
+                     const float* const* h_uright /*[n_cams], may be NULL entries: all monocular*/,
+                     const uint8_t* const* h_descriptors /*[n_cams]*/, const int32_t* n_keys /*[n_cams]*/,
+                     const vieo_fuse_point* h_points, int n_points, int32_t* h_best_idx /*[n_points][n_cams]*/,
+                     int32_t* h_best_dist /*[n_points][n_cams]*/);
+
 #ifdef __cplusplus
 }
 #endif

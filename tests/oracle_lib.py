@@ -281,6 +281,13 @@ class Oracle:
         return normal_depth_call(self.L.vo_update_normal_and_depth_batch, points, first, obs_centre, centres,
                                  ref_centre, ref_scale, scale_last, oracle=True)[1:]
 
+    def fuse_search(self, frame, keys, uright, descs, points):
+        from vieo_slam_amd.map_point import fuse_call
+        P = ctypes.c_void_p
+        self.L.vo_fuse_search.argtypes = [P, P, P, P, P, P, ctypes.c_int, P, P]
+        self.L.vo_fuse_search.restype = None
+        return fuse_call(self.L.vo_fuse_search, frame, keys, uright, descs, points)[1:]
+
     def fisheye_branch_counts(self, reset=True):
         """(new group, extension, member replaced, contradiction kept, contradiction swapped) since the last reset"""
         out = (ctypes.c_long * 5)()

@@ -175,3 +175,93 @@ def test_normal_depth_parity(oracle):
     h = update_normal_and_depth(pts, first, oc, centres, rc, rs, s7)
     for a, b in zip(o, h):
         assert a.tobytes() == b.tobytes()
+
+
+# ------------------------------------------------------------------ SearchByProjectionBase / Fuse
+def _fuse_case(rng, rig, n_points=3000, use_bf=True, check_angle=True):
+    """a key frame whose keys are the (noisy) projections of part of the map points + distractors"""
+    from vieo_slam_amd.map_point import FUSE_FRAME_DTYPE, FUSE_POINT_DTYPE
+    from vieo_slam_amd.orb_extractor import KEYPOINT_DTYPE
+    F0, cams, Rcw, tcw = _frame(rng, rig)
+    FF = np.zeros(1, FUSE_FRAME_DTYPE)
+    FF[0]["base"] = F0[0]
+    sc = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    FF[0]["scale_factors"][:8], FF[0]["inv_level_sigma2"][:8] = sc, 1.0 / (sc * sc)
+    FF[0]["th_radius"], FF[0]["check_viewing_angle"], FF[0]["use_bf"] = 3.0, int(check_angle), int(use_bf)
+    P0 = _points(rng, Rcw, tcw, n_points)
+    P = np.zeros(n_points, FUSE_POINT_DTYPE)
+    for k in ("Xw", "normal", "max_distance", "min_distance"):
+        P[k] = P0[k]
+    P["desc"] = rng.integers(0, 256, (n_points, 32), dtype=np.uint8)
+    P["skip_mask"] = np.where(rng.random(n_points) < 0.05, np.int32(-2 ** 31), 0) | np.where(rng.random(n_points) < 0.05, 1, 0)
+    nc = len(cams)
+    keys, urs, descs = [], [], []
+    for c in range(nc):
+        Tcr = FF[0]["base"]["Tcr"][c].reshape(3, 4).astype(np.float64)
+        kk, uu, dd = [], [], []
+        for m in range(n_points):
+            Pc = Tcr[:, :3] @ (Rcw @ P["Xw"][m].astype(np.float64) + tcw) + Tcr[:, 3]
+            if Pc[2] < 0.3 or rng.random() < 0.4:
+                continue
+            if rig is None:
+                u, v = synth_ba.FX * Pc[0] / Pc[2] + synth_ba.CX, synth_ba.FY * Pc[1] / Pc[2] + synth_ba.CY
+            else:
+                if np.hypot(Pc[0], Pc[1]) / Pc[2] > (0.9 if cams[c]["model"] == 1 else 2.0):
+                    continue
+                u, v = synth_ba.project_camera(cams[c], Pc)
+            b = FF[0]["base"]["bounds"][c]
+            if not (b[0] + 1 < u < b[1] - 1 and b[2] + 1 < v < b[3] - 1):
+                continue
+            d3 = np.linalg.norm(P["Xw"][m] - FF[0]["base"]["Ow"])
+            lvl = int(np.clip(np.ceil(np.log(P["max_distance"][m] / d3) / np.log(1.2)), 0, 7)) - int(rng.integers(0, 2))
+            lvl = max(lvl, 0)
+            s = 1.2 ** lvl
+            d = P["desc"][m].copy()
+            for bit in rng.integers(0, 256, rng.integers(0, 30)):
+                d[bit >> 3] ^= np.uint8(1 << (bit & 7))
+            ku, kv = u + rng.normal(0, 0.8) * s, v + rng.normal(0, 0.8) * s
+            kk.append((ku, kv, 31 * s, 0, 20, lvl, -1))
+            uu.append(ku - synth_ba.BF / Pc[2] + rng.normal(0, 0.8) * s if (rig is None and rng.random() < 0.7) else -1.0)
+            dd.append(d)
+        for _ in range(len(kk) // 2 + 5):  # distractors
+            b = FF[0]["base"]["bounds"][c]
+            kk.append((rng.uniform(b[0], b[1]), rng.uniform(b[2], b[3]), 31, 0, 20, int(rng.integers(0, 8)), -1))
+            uu.append(-1.0)
+            dd.append(rng.integers(0, 256, 32, dtype=np.uint8))
+        order = rng.permutation(len(kk))[:4000]
+        keys.append(np.array([kk[i] for i in order], KEYPOINT_DTYPE))
+        urs.append(np.array([uu[i] for i in order], np.float32))
+        descs.append(np.stack([dd[i] for i in order]).astype(np.uint8))
+    return FF, keys, urs, descs, P, cams
+
+
+def test_oracle_fuse_search_finds_the_projected_keys(oracle):
+    rng = np.random.default_rng(21)
+    FF, keys, urs, descs, P, cams = _fuse_case(rng, None, n_points=1500)
+    bi, bd = oracle.fuse_search(FF, keys, urs, descs, P)
+    found = bi[:, 0] >= 0
+    assert 150 < found.sum() < 1200
+    # a found key is inside the window and carries the point's signature (<= 30 flipped bits) far more often than not
+    assert (bd[found, 0] <= 30).mean() > 0.85
+    assert (bi[P["skip_mask"] < 0, 0] == -1).all() and (bi[(P["skip_mask"] & 1) != 0, 0] == -1).all()
+    # without the chi2 gate / viewing cone at least as many points find a key
+    FF2 = FF.copy()
+    FF2[0]["use_bf"], FF2[0]["check_viewing_angle"] = 0, 0
+    bi2, _ = oracle.fuse_search(FF2, keys, urs, descs, P)
+    assert (bi2[:, 0] >= 0).sum() >= found.sum() and ((bi2[:, 0] >= 0) | ~found).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rig,use_bf,angle", [(None, True, True), (None, False, False), ("radtan", True, True),
+                                              ("kb8", True, False)])
+def test_fuse_search_parity(oracle, rig, use_bf, angle):
+    from vieo_slam_amd.map_point import fuse_search
+    rng = np.random.default_rng(22)
+    FF, keys, urs, descs, P, cams = _fuse_case(rng, rig, n_points=4000, use_bf=use_bf, check_angle=angle)
+    oi, od = oracle.fuse_search(FF, keys, urs, descs, P)
+    hi, hd = fuse_search(FF, keys, urs, descs, P)
+    assert (oi >= 0).sum() > 300
+    if rig is None:
+        assert np.array_equal(oi, hi) and np.array_equal(od, hd)
+    else:  # distorted projection through libm / device trigonometry: a window edge may flip once in a while
+        assert (oi != hi).mean() < 2e-3 and (od != hd).mean() < 2e-3

@@ -14,7 +14,7 @@
 // Integer/index work: results are bit-exact against oracle/proj_search.cc.
 #include <climits>
 
-#include "common.h"
+#include "ba_device.h"
 
 namespace vieo {
 
@@ -488,6 +488,113 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
   if (lane == 0) A.nmatches[f] = overflow ? -1 : nmatches;
 }
 
+// ---------------------------------------------------------------- SearchByProjectionBase (Fuse) -------------
+// ORBmatcher.cc:26-193 per (map point, camera): one wavefront per point; the projection and its gates are
+// evaluated by every lane (cheap, uniform), the window is walked column by column over the CSR grid with the
+// lanes across a column's run, best (distance, position in the reference's candidate order) reduced over the
+// wavefront.  The mutations that follow in the reference (FuseMP, only-one-match) are the caller's.
+struct FuseDev {
+  vieo_fuse_frame F;
+  CamD cams[4];
+};
+
+__global__ void __launch_bounds__(256)
+k_fuse_search(const FuseDev* __restrict__ fd, int cami, const int* __restrict__ cell_start,
+              const float4* __restrict__ cell_rec, const uint8_t* __restrict__ desc,
+              const vieo_fuse_point* __restrict__ pts, int n, int32_t* __restrict__ best_idx,
+              int32_t* __restrict__ best_dist) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= n) return;
+  const vieo_fuse_frame& FF = fd->F;
+  const vieo_frustum_frame& F = FF.base;
+  const int nc = F.n_cams;
+  int32_t* oi = best_idx + (size_t)m * nc + cami;
+  int32_t* od = best_dist + (size_t)m * nc + cami;
+  if (lane == 0) *oi = -1, *od = INT_MAX;
+  const vieo_fuse_point& P = pts[m];
+  const int skip = P.skip_mask;
+  if ((skip & (1u << 31)) || (skip & (1 << cami))) return;
+  const float X0 = P.Xw[0], X1 = P.Xw[1], X2 = P.Xw[2];
+  const float* R = F.Rcrw;
+  float Pcr[3];
+  for (int r = 0; r < 3; ++r) Pcr[r] = (R[r * 3] * X0 + R[r * 3 + 1] * X1 + R[r * 3 + 2] * X2) + F.tcrw[r];
+  const float* Tc = F.Tcr[cami];
+  float Pc[3], twc[3];
+  for (int r = 0; r < 3; ++r) Pc[r] = (Tc[r * 4] * Pcr[0] + Tc[r * 4 + 1] * Pcr[1] + Tc[r * 4 + 2] * Pcr[2]) + Tc[r * 4 + 3];
+  const float* t = F.trc[cami];
+  for (int r = 0; r < 3; ++r) twc[r] = F.Ow[r] + (R[r] * t[0] + R[3 + r] * t[1] + R[6 + r] * t[2]);
+  if (Pc[2] <= 0.0f) return;
+  const float invz = 1.0f / Pc[2];
+  float u, v;
+  const CamD& C = fd->cams[cami];
+  if (!F.use_distort) {
+    const float p0 = Pc[0] * invz, p1 = Pc[1] * invz;
+    u = ((float)C.fx * p0 + 0.f * p1) + (float)C.cx * 1.f;
+    v = (0.f * p0 + (float)C.fy * p1) + (float)C.cy * 1.f;
+  } else {
+    const double Pd[3] = {Pc[0], Pc[1], Pc[2]};
+    double uv[2];
+    cam_project(C, Pd, uv, nullptr);
+    u = (float)uv[0], v = (float)uv[1];
+  }
+  const float* b = F.bounds[cami];
+  if (!(u >= b[0] && u < b[1] && v >= b[2] && v < b[3])) return;  // FrameBase::IsInImage
+  const float PO[3] = {X0 - twc[0], X1 - twc[1], X2 - twc[2]};
+  const float dist3D = sqrtf(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+  if (dist3D < 0.8f * P.min_distance || dist3D > 1.2f * P.max_distance) return;
+  if (FF.check_viewing_angle &&
+      (double)(PO[0] * P.normal[0] + PO[1] * P.normal[1] + PO[2] * P.normal[2]) < 0.5 * (double)dist3D)
+    return;
+  const float ratio = P.max_distance / dist3D;
+  int lvl = (int)ceilf((float)log((double)ratio) / F.log_scale_factor);  // PredictScale, see oracle/mappoint.cc
+  if (lvl < 0)
+    lvl = 0;
+  else if (lvl >= F.n_levels)
+    lvl = F.n_levels - 1;
+  const float radius = FF.th_radius * FF.scale_factors[lvl];
+  const float winv = (float)kGridCols / (b[1] - b[0]), hinv = (float)kGridRows / (b[3] - b[2]);
+  const int min_cellx = max(0, (int)floorf((u - b[0] - radius) * winv));
+  const int max_cellx = min(kGridCols - 1, (int)ceilf((u - b[0] + radius) * winv));
+  const int min_celly = max(0, (int)floorf((v - b[2] - radius) * hinv));
+  const int max_celly = min(kGridRows - 1, (int)ceilf((v - b[2] + radius) * hinv));
+  if (min_cellx >= kGridCols || max_cellx < 0 || min_celly >= kGridRows || max_celly < 0) return;
+  const uint4 d0 = ((const uint4*)P.desc)[0], d1 = ((const uint4*)P.desc)[1];
+  unsigned best = 0xFFFFFFFFu;  // dist << 20 | position in the candidate order
+  int bidx = -1, order = 0;
+  for (int ix = min_cellx; ix <= max_cellx; ++ix) {
+    const int s0 = cell_start[ix * kGridRows + min_celly], s1 = cell_start[ix * kGridRows + max_celly + 1];
+    for (int e0 = s0; e0 < s1; e0 += 64) {
+      const int e = e0 + lane;
+      if (e < s1) {
+        const float4 k = cell_rec[e];
+        const int pk = __float_as_int(k.w), j = pk & 0xFFFF, oct = pk >> 16;
+        bool ok = fabsf(k.x - u) < radius && fabsf(k.y - v) < radius && oct >= lvl - 1 && oct <= lvl;
+        if (ok && FF.use_bf) {
+          const float ex = u - k.x, ey = v - k.y;
+          if (k.z >= 0) {
+            const float er = (u - F.bf * invz) - k.z;
+            ok = !((double)((ex * ex + ey * ey + er * er) * FF.inv_level_sigma2[oct]) > 7.8);
+          } else
+            ok = !((double)((ex * ex + ey * ey) * FF.inv_level_sigma2[oct]) > 5.99);
+        }
+        if (ok) {
+          const unsigned d = (unsigned)hamming32q(d0, d1, desc + (size_t)j * 32);
+          const unsigned key = (d << 20) | (unsigned)min(order + (e - s0), (1 << 20) - 1);
+          if (key < best) best = key, bidx = j;
+        }
+      }
+    }
+    order += s1 - s0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned e = __shfl_xor(best, o);
+    const int j = __shfl_xor(bidx, o);
+    if (e < best) best = e, bidx = j;
+  }
+  if (lane == 0 && bidx >= 0) *oi = bidx, *od = (int)(best >> 20);
+}
+
 struct SbpScratch {
   DevBuf pool, cursor, qrec, q, nq, keys, ur, desc, taken, counts, assign, nm, pts, cam, cell_start, cell_rec, cell_ang;
 };
@@ -638,6 +745,88 @@ int vieo_search_by_projection(int mode, const vieo_proj_query* h_queries, int nq
     set_error("search_by_projection: more than %d window candidates for one query", kCandCap);
     return VIEO_E_CAPACITY;
   }
+  return VIEO_OK;
+}
+
+int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const* h_keys,
+                     const float* const* h_uright, const uint8_t* const* h_desc, const int32_t* n_keys,
+                     const vieo_fuse_point* h_points, int n_points, int32_t* h_best_idx, int32_t* h_best_dist) {
+  if (!h_frame || !h_keys || !h_desc || !n_keys || n_points < 0 || (n_points > 0 && (!h_points || !h_best_idx || !h_best_dist)))
+    return VIEO_E_INVALID;
+  const vieo_frustum_frame& F = h_frame->base;
+  const int nc = F.n_cams;
+  if (nc < 1 || nc > 4 || !F.cams || F.n_levels <= 0 || F.n_levels > 16) {
+    set_error("SearchByProjectionBase: n_cams = %d (1..4) with cameras, n_levels = %d (1..16)", nc, F.n_levels);
+    return VIEO_E_INVALID;
+  }
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  if (n_points == 0) return VIEO_OK;
+  FuseDev fd;
+  memset(&fd, 0, sizeof(fd));
+  fd.F = *h_frame;
+  fd.F.base.cams = nullptr;
+  int cap = 1;
+  for (int c = 0; c < nc; ++c) {
+    if (!cam_from_abi(F.cams[c], fd.cams[c])) {
+      set_error("SearchByProjectionBase: camera %d has an unknown model or coefficient count", c);
+      return VIEO_E_INVALID;
+    }
+    if (n_keys[c] < 0 || n_keys[c] > kMaxKeys || (n_keys[c] > 0 && (!h_keys[c] || !h_desc[c]))) {
+      set_error("SearchByProjectionBase: camera %d has %d keys (limit %d)", c, n_keys[c], kMaxKeys);
+      return n_keys[c] > kMaxKeys ? VIEO_E_CAPACITY : VIEO_E_INVALID;
+    }
+    cap = std::max(cap, n_keys[c]);
+  }
+  static thread_local DevBuf dF, dP, dI, dD;
+  SbpScratch& S = g_sbp;
+#define ENS(b, n) \
+  if ((rc = (b).ensure(n)) != VIEO_OK) return rc
+  ENS(dF, sizeof(FuseDev));
+  ENS(dP, (size_t)n_points * sizeof(vieo_fuse_point));
+  ENS(dI, (size_t)n_points * nc * 4);
+  ENS(dD, (size_t)n_points * nc * 4);
+  ENS(S.keys, (size_t)cap * sizeof(vieo_keypoint));
+  ENS(S.ur, (size_t)cap * 4);
+  ENS(S.desc, (size_t)cap * 32);
+  ENS(S.counts, 8);
+  ENS(S.cursor, 4);
+  ENS(S.cell_start, (size_t)(kGridCells + 1) * 4);
+  ENS(S.cell_rec, (size_t)cap * 16);
+  ENS(S.cell_ang, (size_t)cap * 4);
+#undef ENS
+  VIEO_HIP_CHECK(hipMemcpy(dF.p, &fd, sizeof(fd), hipMemcpyHostToDevice));
+  VIEO_HIP_CHECK(hipMemcpy(dP.p, h_points, (size_t)n_points * sizeof(vieo_fuse_point), hipMemcpyHostToDevice));
+  std::vector<float> mono;
+  for (int c = 0; c < nc; ++c) {
+    if (n_keys[c] > 0) {
+      VIEO_HIP_CHECK(hipMemcpy(S.keys.p, h_keys[c], (size_t)n_keys[c] * sizeof(vieo_keypoint), hipMemcpyHostToDevice));
+      VIEO_HIP_CHECK(hipMemcpy(S.desc.p, h_desc[c], (size_t)n_keys[c] * 32, hipMemcpyHostToDevice));
+      const float* ur = h_uright ? h_uright[c] : nullptr;
+      if (!ur) {
+        mono.assign(n_keys[c], -1.f);
+        ur = mono.data();
+      }
+      VIEO_HIP_CHECK(hipMemcpy(S.ur.p, ur, (size_t)n_keys[c] * 4, hipMemcpyHostToDevice));
+    }
+    const int cnt[2] = {n_keys[c], 0};
+    VIEO_HIP_CHECK(hipMemcpy(S.counts.p, cnt, 8, hipMemcpyHostToDevice));
+    SbpArgs A;
+    memset(&A, 0, sizeof(A));
+    A.keys = S.keys.as<vieo_keypoint>(), A.uright = S.ur.as<float>(), A.counts = S.counts.as<int>();
+    A.key_cap = cap, A.img_first = 0, A.img_step = 0;
+    A.minx = F.bounds[c][0], A.maxx = F.bounds[c][1], A.miny = F.bounds[c][2], A.maxy = F.bounds[c][3];
+    A.cursor = S.cursor.as<int>();
+    hipLaunchKernelGGL(k_sbp_grid, dim3(1), dim3(256), 0, 0, A, S.cell_start.as<int>(), S.cell_rec.as<float4>(),
+                       S.cell_ang.as<float>());
+    hipLaunchKernelGGL(k_fuse_search, dim3((n_points + 3) / 4), dim3(256), 0, 0, dF.as<FuseDev>(), c,
+                       S.cell_start.as<int>(), S.cell_rec.as<float4>(), S.desc.as<uint8_t>(),
+                       dP.as<vieo_fuse_point>(), n_points, dI.as<int32_t>(), dD.as<int32_t>());
+    VIEO_HIP_CHECK(hipGetLastError());
+    VIEO_HIP_CHECK(hipDeviceSynchronize());  // the per-camera staging buffers are reused
+  }
+  VIEO_HIP_CHECK(hipMemcpy(h_best_idx, dI.p, (size_t)n_points * nc * 4, hipMemcpyDeviceToHost));
+  VIEO_HIP_CHECK(hipMemcpy(h_best_dist, dD.p, (size_t)n_points * nc * 4, hipMemcpyDeviceToHost));
   return VIEO_OK;
 }
 

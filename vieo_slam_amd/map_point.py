@@ -73,3 +73,42 @@ def update_normal_and_depth(points, first, obs_centre, centres, ref_centre, ref_
                                         centres, ref_centre, ref_scale, scale_last_level)
     check(rc, "vieo_update_normal_and_depth_batch")
     return nrm, mx, mn
+
+
+FUSE_FRAME_DTYPE = np.dtype([("base", FRUSTUM_FRAME_DTYPE), ("scale_factors", "<f4", 16),
+                             ("inv_level_sigma2", "<f4", 16), ("th_radius", "<f4"), ("check_viewing_angle", "<i4"),
+                             ("use_bf", "<i4"), ("reserved", "<i4")], align=True)
+FUSE_POINT_DTYPE = np.dtype([("Xw", "<f4", 3), ("normal", "<f4", 3), ("max_distance", "<f4"),
+                             ("min_distance", "<f4"), ("desc", "u1", 32), ("skip_mask", "<i4"), ("reserved", "<i4")])
+assert FUSE_FRAME_DTYPE.itemsize == 544 and FUSE_POINT_DTYPE.itemsize == 72
+
+
+def fuse_call(fn, frame, keys, uright, descs, points):
+    """One SearchByProjectionBase search for `fn` (the C-ABI entry or the oracle's function of the same
+    signature).  keys[c]: KEYPOINT_DTYPE[n_c], uright[c]: float32[n_c] or None, descs[c]: uint8[n_c, 32].
+    returns (rc, best_idx int32[n, n_cams], best_dist int32[n, n_cams])."""
+    import ctypes
+    fr = np.ascontiguousarray(frame, FUSE_FRAME_DTYPE).reshape(1)
+    nc = int(fr[0]["base"]["n_cams"])
+    keys = [np.ascontiguousarray(k) for k in keys]
+    descs = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in descs]
+    urs = [None if u is None else np.ascontiguousarray(u, np.float32) for u in uright]
+    n_keys = np.array([len(k) for k in keys], np.int32)
+    kp = (ctypes.c_void_p * nc)(*[k.ctypes.data for k in keys])
+    dp = (ctypes.c_void_p * nc)(*[d.ctypes.data for d in descs])
+    up = (ctypes.c_void_p * nc)(*[None if u is None else u.ctypes.data for u in urs])
+    pts = np.ascontiguousarray(points, FUSE_POINT_DTYPE)
+    bi = np.zeros((max(len(pts), 1), nc), np.int32)
+    bd = np.zeros((max(len(pts), 1), nc), np.int32)
+    rc = fn(fr.ctypes.data, ctypes.cast(kp, ctypes.c_void_p), ctypes.cast(up, ctypes.c_void_p),
+            ctypes.cast(dp, ctypes.c_void_p), n_keys.ctypes.data, pts.ctypes.data, len(pts), bi.ctypes.data,
+            bd.ctypes.data)
+    return rc, bi[:len(pts)], bd[:len(pts)]
+
+
+def fuse_search(frame, keys, uright, descs, points):
+    """The search of ORBmatcher::SearchByProjectionBase / Fuse (ORBmatcher.cc:26-193): per (point, camera) the
+    best key (index into that camera's keys, -1: none) and its Hamming distance."""
+    rc, bi, bd = fuse_call(lib().vieo_fuse_search, frame, keys, uright, descs, points)
+    check(rc, "vieo_fuse_search")
+    return bi, bd
