@@ -670,6 +670,32 @@ int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const*
                      const vieo_fuse_point* h_points, int n_points, int32_t* h_best_idx /*[n_points][n_cams]*/,
                      int32_t* h_best_dist /*[n_points][n_cams]*/);
 
+/* ---------------------------------------------------------------- IMU pre-integration ----------
+ * int IMUPreIntegratorBase::PreIntegration(timeStampi, timeStampj, bgi_bar, bai_bar, iterBegin, iterEnd, breset =
+ * true) + update() (src/Odom/OdomPreIntegrator.h:226-506; mid-point samples, the partial intervals at both ends
+ * interpolated as the reference does, USE_PREINT_EULA off) for a batch of intervals, one lane per interval:
+ * delta R / v / p, the five bias Jacobians, Sigma in both orders (mSigmaij: p v Phi; mSigmaijPRV: p Phi v).
+ * Interval k owns the samples [h_first[k], h_first[k + 1]) (time-ordered).  h_status[k]: */
+#define VIEO_PREINT_OK 0
+#define VIEO_PREINT_EMPTY 1       /* no samples: PreIntegration() does nothing (outputs zeroed, dt = 0) */
+#define VIEO_PREINT_GAP 2         /* |dt| > 1.5 s between samples: "CheckIMU", mdeltatij = 0, returns -1 */
+#define VIEO_PREINT_UNSUPPORTED 3 /* timeStampi > timeStampj (map-reuse backward order): not built */
+typedef struct vieo_imu_sample {
+  double t;            /* IMUData::mtm */
+  double w[3], a[3];   /* mw, ma */
+} vieo_imu_sample;     /* 56 bytes */
+typedef struct vieo_imu_noise {
+  double sigma_g[9], sigma_a[9]; /* IMUDataBase::mSigmag, mSigmaa (row-major) */
+  double freq_ref;               /* IMUDataBase::mFreqRef */
+  int32_t dt_cov_noise_fixed;    /* IMUDataBase::mdt_cov_noise_fixed */
+  int32_t reserved;
+} vieo_imu_noise;
+int vieo_imu_preintegrate_batch(const vieo_imu_noise* noise, const vieo_imu_sample* h_samples,
+                                const int32_t* h_first, const double* h_ti, const double* h_tj,
+                                const double* h_bg /*[n][3]*/, const double* h_ba /*[n][3]*/, int n,
+                                vieo_imu_preint* h_out, double* h_sigma_prv /*[n][81], may be NULL*/,
+                                int32_t* h_status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,6 +288,13 @@ class Oracle:
         self.L.vo_fuse_search.restype = None
         return fuse_call(self.L.vo_fuse_search, frame, keys, uright, descs, points)[1:]
 
+    def imu_preintegrate(self, noise, sample_lists, ti, tj, bg, ba):
+        from vieo_slam_amd.imu import preint_call
+        P = ctypes.c_void_p
+        self.L.vo_imu_preintegrate_batch.argtypes = [P, P, P, P, P, P, P, ctypes.c_int, P, P, P]
+        self.L.vo_imu_preintegrate_batch.restype = None
+        return preint_call(self.L.vo_imu_preintegrate_batch, noise, sample_lists, ti, tj, bg, ba)[1:]
+
     def fisheye_branch_counts(self, reset=True):
         """(new group, extension, member replaced, contradiction kept, contradiction swapped) since the last reset"""
         out = (ctypes.c_long * 5)()

@@ -24,6 +24,7 @@ _SIGS = {
     "vieo_set_device": (c_i, [c_i]),
     "vieo_pose_set_camera_mode": (c_i, [c_i]),
     "vieo_is_in_frustum_batch": (c_i, [c_p, c_p, c_i, c_p]),
+    "vieo_imu_preintegrate_batch": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     "vieo_fuse_search": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     "vieo_distinctive_descriptors_batch": (c_i, [c_p, c_p, c_i, c_p]),
     "vieo_update_normal_and_depth_batch": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, ctypes.c_float, c_i, c_p, c_p,
