@@ -1433,7 +1433,16 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
-  if (!g_lba_stream) VIEO_HIP_CHECK(hipStreamCreateWithFlags(&g_lba_stream, hipStreamNonBlocking));
+  if (!g_lba_stream) {
+    // VIEO_LBA_PRIORITY = -1 / 1: lowest / highest stream priority for the bundle-adjustment stream (default 0)
+    int lo = 0, hi = 0;
+    const char* e = getenv("VIEO_LBA_PRIORITY");
+    const int want = e ? atoi(e) : 0;
+    if (want == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi)
+      VIEO_HIP_CHECK(hipStreamCreateWithFlags(&g_lba_stream, hipStreamNonBlocking));
+    else
+      VIEO_HIP_CHECK(hipStreamCreateWithPriority(&g_lba_stream, hipStreamNonBlocking, want < 0 ? lo : hi));
+  }
   hipStream_t st = g_lba_stream;
   const int W = n_windows;
   std::vector<WinHost> win(W);
