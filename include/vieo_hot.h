@@ -544,6 +544,16 @@ int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_p
                                              vieo_allreduce_sum_f64_fn allreduce, void* ctx,
                                              vieo_navstate* const* h_navs_out, float* const* h_points_out,
                                              uint8_t* const* h_erase, vieo_lba_result* h_results);
+/* The same exchange for the full BA (BASELINE configs[4]: "full BA with RCCL pose-Hessian all-reduce"): this rank's
+ * landmark shard of GlobalBundleAdjustmentNavStatePRV; per LM trial one all-reduce of the packed reduced visual
+ * system ((6n)(6n+1) + 42n doubles for n free key frames) and one of three scalars. */
+int vieo_global_bundle_adjustment_vio_sharded(const vieo_lba_vio_params* params, int n_iterations, int robust,
+                                              const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points,
+                                              int n_mp, const vieo_lba_obs* h_obs, int n_obs,
+                                              const vieo_lba_imu_edge* h_imu, int n_imu, double* d_reduce_buf,
+                                              size_t reduce_cap_doubles, vieo_allreduce_sum_f64_fn allreduce,
+                                              void* ctx, vieo_navstate* h_navs_out, float* h_points_out,
+                                              vieo_lba_result* h_result);
 
 /* ---- replay glue (device-resident batches) -------------------------------------------------
  * What Tracking.cc does between the calls above, on flattened arrays, so a batch of frames runs

@@ -112,3 +112,50 @@ def test_gba_stop_flag_and_no_free_pose(oracle):
     k2["fixed"] = 1
     hn, hp, hres = Optimizer.BundleAdjustment(P, k2, pts, obs, 5, True)
     assert hres["status"] == 2
+
+
+@pytest.mark.gpu
+def test_vio_gba_landmark_sharded_two_ranks_on_one_gpu(oracle):
+    """BASELINE configs[4] in small: the full BA of 44 key frames (660 unknowns, tiled LDL^T) with its landmarks
+    split over two 'ranks' (threads with their own reduction buffers; the callback sums through the host)."""
+    import threading
+    from vieo_slam_amd import sharding
+    from vieo_slam_amd._lib import DeviceBuffer, check, lib
+    from vieo_slam_amd.optimizer import Optimizer
+    params, kfs, pts, close, obs, imu, gt = synth_ba.make_lba_vio_problem(41, n_local=44, n_fixed=1, n_points=4000,
+                                                                          anchors=22, span=5)
+    win = (params, kfs, pts, close, obs, imu)
+    on, op, ores = oracle.global_ba_vio(params, kfs, pts, obs, imu, 4, True)
+    world = 2
+    shards = [sharding.shard_window(win, r, world) for r in range(world)]
+    n = Optimizer.sharded_buffer_doubles([win])
+    bufs = [DeviceBuffer(8 * n) for _ in range(world)]
+    barrier = threading.Barrier(world)
+    stage, results = [None] * world, [None] * world
+
+    def make_cb(rank):
+        def cb(offset, count):
+            h = np.empty(count)
+            check(lib().vieo_memcpy_d2h(h.ctypes.data, bufs[rank].ptr + 8 * offset, 8 * count))
+            stage[rank] = h
+            barrier.wait()
+            total = stage[0] + stage[1]
+            barrier.wait()
+            check(lib().vieo_memcpy_h2d(bufs[rank].ptr + 8 * offset, total.ctypes.data, 8 * count))
+            return 0
+        return cb
+
+    def run(rank):
+        results[rank] = Optimizer.GlobalBundleAdjustmentNavStatePRVSharded(shards[rank][0], bufs[rank].ptr, n,
+                                                                           make_cb(rank), 4, True)
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert all(r is not None for r in results)
+    for rank in range(world):
+        hn, hp, hr = results[rank]
+        assert hr["status"] == 0 and hr["lm_trials"] == ores["lm_trials"]
+        dt, dr = _pose_diff(on, hn, 44)
+        assert dt < TOL and dr < TOL, (dt, dr)
+        assert np.abs(op[shards[rank][1]] - hp).max() < 1e-3
+    assert results[0][0].tobytes() == results[1][0].tobytes()  # replicated solve: bit-identical key frames

@@ -87,6 +87,8 @@ _SIGS = {
                                                 c_p, c_p]),
     "vieo_local_bundle_adjustment_vio_batch": (c_i, [c_i] + [c_p] * 15),
     "vieo_lba_sharded_buffer_doubles": (ctypes.c_size_t, [c_i, c_p]),
+    "vieo_global_bundle_adjustment_vio_sharded": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p,
+                                                        ctypes.c_size_t, c_p, c_p, c_p, c_p, c_p]),
     "vieo_local_bundle_adjustment_vio_sharded": (c_i, [c_i] + [c_p] * 10 + [c_p, ctypes.c_size_t, c_p, c_p] +
                                                  [c_p] * 4),
     "vieo_orb_tap_plane": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),

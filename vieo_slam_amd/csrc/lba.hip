@@ -2037,6 +2037,23 @@ int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_p
                  n_imu, nullptr, h_navs_out, h_points_out, h_erase, h_results);
 }
 
+int vieo_global_bundle_adjustment_vio_sharded(const vieo_lba_vio_params* params, int n_iterations, int robust,
+                                              const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points,
+                                              int n_mp, const vieo_lba_obs* h_obs, int n_obs,
+                                              const vieo_lba_imu_edge* h_imu, int n_imu, double* d_reduce_buf,
+                                              size_t reduce_cap_doubles, vieo_allreduce_sum_f64_fn allreduce,
+                                              void* ctx, vieo_navstate* h_navs_out, float* h_points_out,
+                                              vieo_lba_result* h_result) {
+  if (!params || n_iterations < 0 || !h_result || n_obs < 0) return VIEO_E_INVALID;
+  const GbaMode g = {n_iterations, robust};
+  LbaShard sh{allreduce, ctx, d_reduce_buf, reduce_cap_doubles};
+  std::vector<uint8_t> erase((size_t)std::max(n_obs, 1));
+  uint8_t* er = erase.data();
+  const uint8_t* no_close = nullptr;
+  return lba_run(&sh, &g, 1, nullptr, &params, &h_kfs, &n_kf, &h_points, &no_close, &n_mp, &h_obs, &n_obs, &h_imu,
+                 &n_imu, nullptr, &h_navs_out, &h_points_out, &er, h_result);
+}
+
 int vieo_local_bundle_adjustment_vio(const vieo_lba_vio_params* P, const vieo_lba_keyframe* h_kfs, int n_kf,
                                      const float* h_points, const uint8_t* h_close, int n_mp,
                                      const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_imu_edge* h_imu,

@@ -202,3 +202,32 @@ class Optimizer:
             None if st is None else st.ctypes.data, navs.ctypes.data, pts.ctypes.data, res.ctypes.data),
             "vieo_global_bundle_adjustment_vio")
         return navs, pts, res[0]
+
+    @staticmethod
+    def GlobalBundleAdjustmentNavStatePRVSharded(shard, reduce_ptr, reduce_doubles, allreduce, nIterations=5,
+                                                 bRobust=True):
+        """This rank's landmark shard (sharding.shard_window of (params, kfs, points, close, obs, imu)) of a full
+        BA; reduce_ptr / allreduce as in LocalBundleAdjustmentNavStatePRVSharded.  returns (navs, points, result)."""
+        import ctypes
+        params, kfs, points, close, obs, imu = shard
+        params, kfs, imu = np.ascontiguousarray(params), np.ascontiguousarray(kfs), np.ascontiguousarray(imu)
+        points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
+        navs, pts, res = np.zeros(len(kfs), NAVSTATE_DTYPE), np.zeros_like(points), np.zeros(1, LBA_RESULT_DTYPE)
+        CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+        base = int(reduce_ptr)
+
+        def _cb(ctx, d_buf, n):
+            try:
+                return int(allreduce((int(d_buf) - base) // 8, int(n)))
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = CB(_cb)
+        check(lib().vieo_global_bundle_adjustment_vio_sharded(
+            params.ctypes.data, int(nIterations), int(bool(bRobust)), kfs.ctypes.data, len(kfs), points.ctypes.data,
+            len(points), obs.ctypes.data, len(obs), imu.ctypes.data, len(imu), ctypes.c_void_p(base),
+            reduce_doubles, ctypes.cast(cb, ctypes.c_void_p), None, navs.ctypes.data, pts.ctypes.data,
+            res.ctypes.data), "vieo_global_bundle_adjustment_vio_sharded")
+        return navs, pts, res[0]
+
