@@ -1124,9 +1124,18 @@ k_big_panel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   if (n == 0 || k * kNB >= nb || (blockIdx.x > 0 && r0 >= nb)) return;
   double* Hb = D.Hb;
   const size_t ld = nb;
-  for (int i = tid; i < kNB * kNB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    sA[r * kBigLd + c] = c <= r ? Hb[(size_t)(k * kNB + r) * ld + k * kNB + c] : 0.0;
+  {  // the 16 loads of a thread in flight, then the LDS stores
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int i = tid + 256 * u, r = i >> 6, c = i & 63;
+      v[u] = c <= r ? Hb[(size_t)(k * kNB + r) * ld + k * kNB + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int i = tid + 256 * u;
+      sA[(i >> 6) * kBigLd + (i & 63)] = v[u];
+    }
   }
   __syncthreads();
   // LDL^T of the tile by ONE wavefront, register resident: lane r holds row r, column c is broadcast with
@@ -1198,10 +1207,20 @@ k_big_syrk(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int 
   const int bi = k + 1 + ti, bj = k + 1 + t;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const size_t ld = nb;
-  for (int i = tid; i < kNB * kNB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    sW[r * kBigLd + c] = D.Wp[(size_t)(bi * kNB + r) * kNB + c];
-    sL[r * kBigLd + c] = D.Hb[(size_t)(bj * kNB + r) * ld + k * kNB + c];
+  {  // both tiles in flight (32 loads per thread), then the LDS stores
+    double vw[16], vl[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int i = tid + 256 * u, r = i >> 6, c = i & 63;
+      vw[u] = D.Wp[(size_t)(bi * kNB + r) * kNB + c];
+      vl[u] = D.Hb[(size_t)(bj * kNB + r) * ld + k * kNB + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int i = tid + 256 * u, r = i >> 6, c = i & 63;
+      sW[r * kBigLd + c] = vw[u];
+      sL[r * kBigLd + c] = vl[u];
+    }
   }
   __syncthreads();
   typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -1245,9 +1264,18 @@ k_big_back_step(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl,
   if (blockIdx.x > 0 && (int)(blockIdx.x - 1) * 256 >= c0) return;
   const size_t ld = nb;
   const double* z = s == 0 ? D.Hb + (size_t)n * ld : D.Wp;  // z = D^-1 L^-1 b: the right-hand-side row of L
-  for (int i = tid; i < kNB * kNB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    sA[r * kBigLd + c] = (c < r && r < cn) ? D.Hb[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
+  {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int i = tid + 256 * u, r = i >> 6, c = i & 63;
+      v[u] = (c < r && r < cn) ? D.Hb[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int i = tid + 256 * u;
+      sA[(i >> 6) * kBigLd + (i & 63)] = v[u];
+    }
   }
   if (tid < kNB) sx[tid] = tid < cn ? z[c0 + tid] : 0.0;
   __syncthreads();
@@ -1266,7 +1294,14 @@ k_big_back_step(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl,
   const int c = (blockIdx.x - 1) * 256 + tid;
   if (c >= c0) return;
   double v = z[c];
-  for (int r = 0; r < cn; r++) v -= D.Hb[(size_t)(c0 + r) * ld + c] * sx[r];
+  for (int r0 = 0; r0 < cn; r0 += 16) {  // 16 rows in flight; the subtraction order stays r ascending
+    double l[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) l[u] = r0 + u < cn ? D.Hb[(size_t)(c0 + r0 + u) * ld + c] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (r0 + u < cn) v -= l[u] * sx[r0 + u];
+  }
   D.Wp[c] = v;
 }
 
