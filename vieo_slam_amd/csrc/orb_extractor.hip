@@ -594,18 +594,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
+// (key, level) of every selected key point in the level-concatenated order (ORBextractor.cc:1005-1054), and the
+// per-image counts: k_describe then starts from ONE record load.
 __global__ void __launch_bounds__(256)
-k_describe(OrbParams P, ImgSet I, const unsigned* __restrict__ sel,
-           const int* __restrict__ sel_count, const int* __restrict__ pattern,
-           vieo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int out_cap,
-           int* __restrict__ counts, int write_counts, int groups_per_image, int n_images) {
-  // all key points of an image on one XCD: their overlapping patches then share that XCD's L2
-  const int item = xcd_grouped(blockIdx.x, groups_per_image);
-  const int b = item / groups_per_image;
-  if (b >= n_images) return;
-  const int lane = threadIdx.x & 63;
-  const int g = (item - b * groups_per_image) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  // level of keypoint g in the level-concatenated order (ORBextractor.cc:1005-1054)
+k_desc_index(OrbParams P, const unsigned* __restrict__ sel, const int* __restrict__ sel_count,
+             uint2* __restrict__ krec, int out_cap, int* __restrict__ counts) {
+  const int b = blockIdx.y, g = blockIdx.x * 256 + threadIdx.x;
   int level = -1, idx = 0, total = 0;
   for (int l = 0; l < P.nlevels; l++) {
     const int n = max(sel_count[b * kMaxLevels + l], 0);
@@ -615,13 +609,33 @@ k_describe(OrbParams P, ImgSet I, const unsigned* __restrict__ sel,
     }
     total += n;
   }
-  if (g == 0 && lane == 0 && write_counts) {
+  if (g == 0) {
     counts[2 * b] = min(total, out_cap);
     counts[2 * b + 1] = 0;
   }
-  if (level < 0 || g >= out_cap) return;
+  if (g >= P.kp_cap) return;
+  unsigned key = 0;
+  if (level >= 0) key = sel[(size_t)b * P.sel_per_image + P.lv[level].sel_off + idx];
+  krec[(size_t)b * P.kp_cap + g] = make_uint2(key, (unsigned)level);
+}
+
+__global__ void __launch_bounds__(256)
+k_describe(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __restrict__ pattern,
+           vieo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int out_cap,
+           int groups_per_image, int n_images) {
+  // all key points of an image on one XCD: their overlapping patches then share that XCD's L2
+  const int item = xcd_grouped(blockIdx.x, groups_per_image);
+  const int b = item / groups_per_image;
+  if (b >= n_images) return;
+  const int lane = threadIdx.x & 63;
+  const int g = (item - b * groups_per_image) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= min(P.kp_cap, out_cap)) return;
+  // (key, level) of key point g, written by k_desc_index: one load instead of the level search + the key load
+  const uint2 kr = krec[(size_t)b * P.kp_cap + g];
+  const int level = (int)kr.y;
+  if (level < 0) return;
+  const unsigned key = kr.x;
   const LevelDesc& D = P.lv[level];
-  const unsigned key = sel[(size_t)b * P.sel_per_image + D.sel_off + idx];
   const int cx = QT_KEY_X(key) + (kEdge - 3), cy = QT_KEY_Y(key) + (kEdge - 3);
   int pitch;
   const uint8_t* img = plane_ptr(P, I, b, level, &pitch);
@@ -958,6 +972,7 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
   ENS(e->d_tmp_kp, (size_t)B * P.kp_cap * sizeof(vieo_keypoint));
   ENS(e->d_tmp_desc, (size_t)B * P.kp_cap * 32);
   ENS(e->d_tmp_counts, (size_t)B * 2 * 4);
+  ENS(e->d_krec, (size_t)B * P.kp_cap * 8);
 #undef ENS
   VIEO_HIP_CHECK(hipMemcpyAsync(e->d_cells.p, e->cells.data(), e->cells.size() * sizeof(CellDesc),
                                 hipMemcpyHostToDevice, e->stream));
@@ -1043,15 +1058,17 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
   STAMP();
   const int ngroups = (std::min(P.kp_cap, capacity) + 3) / 4;
   if (!lapping) {
+    hipLaunchKernelGGL(k_desc_index, dim3((P.kp_cap + 255) / 256, B), dim3(256), 0, st, P, e->d_sel.as<unsigned>(),
+                       e->d_sel_count.as<int>(), e->d_krec.as<uint2>(), capacity, d_counts);
     hipLaunchKernelGGL(k_describe, dim3((unsigned)ngroups * 8 * ((B + 7) / 8)), dim3(256), 0, st, P, I,
-                       e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(), e->d_pattern.as<int>(), d_kp, d_desc,
-                       capacity, d_counts, 1, ngroups, B);
+                       e->d_krec.as<uint2>(), e->d_pattern.as<int>(), d_kp, d_desc, capacity, ngroups, B);
   } else {
     const int ng = (P.kp_cap + 3) / 4;
+    hipLaunchKernelGGL(k_desc_index, dim3((P.kp_cap + 255) / 256, B), dim3(256), 0, st, P, e->d_sel.as<unsigned>(),
+                       e->d_sel_count.as<int>(), e->d_krec.as<uint2>(), P.kp_cap, e->d_tmp_counts.as<int>());
     hipLaunchKernelGGL(k_describe, dim3((unsigned)ng * 8 * ((B + 7) / 8)), dim3(256), 0, st, P, I,
-                       e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(), e->d_pattern.as<int>(),
-                       e->d_tmp_kp.as<vieo_keypoint>(), e->d_tmp_desc.as<uint8_t>(), P.kp_cap,
-                       e->d_tmp_counts.as<int>(), 1, ng, B);
+                       e->d_krec.as<uint2>(), e->d_pattern.as<int>(), e->d_tmp_kp.as<vieo_keypoint>(),
+                       e->d_tmp_desc.as<uint8_t>(), P.kp_cap, ng, B);
     hipLaunchKernelGGL(k_lapping, dim3(B), dim3(256), 0, st, e->d_tmp_kp.as<vieo_keypoint>(),
                        e->d_tmp_desc.as<uint8_t>(), P.kp_cap, d_kp, d_desc, capacity,
                        e->d_tmp_counts.as<int>(), d_counts, lapping[0], lapping[1]);

@@ -88,7 +88,7 @@ struct vieo_orb {  // global-scope tag declared in include/vieo_hot.h
   size_t pyr_img = 0, blur_img = 0;
   vieo::DevBuf d_pyr, d_blur, d_cells, d_tiles, d_xtab, d_ytab, d_cell_keys, d_cell_counts, d_keys,
       d_kslot, d_kq, d_sel, d_sel_count, d_pattern, d_in, d_kp, d_desc, d_counts, d_tmp_kp,
-      d_tmp_desc, d_tmp_counts;
+      d_tmp_desc, d_tmp_counts, d_krec;  // d_krec: [image][kp_cap] (key, level) in output order
   int out_cap = 0;  // capacity of the internal (host-API) output buffers
   int last_B = 0;
   vieo::ImgSet last_imgs{};
