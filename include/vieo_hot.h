@@ -477,6 +477,9 @@ typedef struct vieo_lba_vio_params {
   double lambda_init;    /* setUserLambdaInit: 1e0, 1e-2 if bLarge (Optimizer.cc:131-138) */
   int32_t rec_init;      /* bRecInit: Huber kernels on the inertial edges of free key frames too */
   int32_t large;         /* bLarge: the divergence check is skipped */
+  float th_dist_far;     /* th_dist_far (Optimizer.cc:395,454,513-517): a point none of whose monocular edges sees it
+                          * closer than this has all its monocular edges excluded; <= 0 or inf: no such rule */
+  int32_t reserved;
 } vieo_lba_vio_params;
 
 #define VIEO_LBA_DIVERGED 3 /* 2*err < err_end or NaN: returns without write-back (Optimizer.cc:660-666) */

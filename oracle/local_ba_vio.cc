@@ -643,6 +643,24 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
     R.status = VIEO_LBA_ABORTED;
     return;
   }
+  // th_dist_far (Optimizer.cc:395,454,513-517): a point without a monocular edge closer than the limit loses its
+  // monocular edges (level 1); GetDepth() = third row of Rcw * Xw + tcw at the initial estimates
+  if (!gba && P.th_dist_far > 0 && std::isfinite(P.th_dist_far)) {
+    for (int m = 0; m < n_mp; m++) {
+      bool ok = false, any_mono = false;
+      for (int i = B.mp_first[m]; i < B.mp_first[m] + B.mp_count[m]; i++) {
+        VEdge& e = B.E[i];
+        if (e.de != 2) continue;
+        any_mono = true;
+        double proj[3], Pc[3];
+        B.project(e, proj, Pc, nullptr);
+        if (Pc[2] < (double)P.th_dist_far) ok = true;
+      }
+      if (any_mono && !ok)
+        for (int i = B.mp_first[m]; i < B.mp_first[m] + B.mp_count[m]; i++)
+          if (B.E[i].de == 2) B.E[i].level = 1;
+    }
+  }
   // Chi2LargeSetLevel (rat_vis_check = 100): chi2_sig5_[2] = 5.991f, [3] = 7.815f, float product
   for (auto& e : B.E) {
     if (gba) break;

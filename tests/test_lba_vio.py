@@ -206,3 +206,35 @@ def test_gpu_vio_lba_distorted_rig_parity(oracle, rig, seed):
     w = synth_ba.make_lba_vio_problem(seed, n_local=6, n_fixed=3, n_points=500, rig=rig)
     win = w[:6]
     _parity(oracle, win, Optimizer.LocalBundleAdjustmentNavStatePRV(*win))
+
+
+def test_oracle_th_dist_far_excludes_far_monocular_points(oracle):
+    """th_dist_far (Optimizer.cc:395,454,513-517): points no monocular edge sees closer than the limit lose their
+    monocular edges; chi2 of the first linearisation drops with the excluded edges, stereo-only windows are untouched."""
+    import numpy as np
+    win = synth_ba.make_lba_vio_problem(31, n_points=600, stereo_frac=0.3)[:6]
+    base = oracle.local_ba_vio(*win)[3]
+    far = [w.copy() if hasattr(w, "copy") else w for w in win]
+    far[0][0]["th_dist_far"] = 5.0
+    r5 = oracle.local_ba_vio(*far)[3]
+    far[0][0]["th_dist_far"] = 1e-3  # nothing is that close: every monocular edge goes
+    r0 = oracle.local_ba_vio(*far)[3]
+    far[0][0]["th_dist_far"] = np.inf
+    rinf = oracle.local_ba_vio(*far)[3]
+    assert r0["chi2_initial"] < r5["chi2_initial"] < base["chi2_initial"]
+    assert rinf["chi2_initial"] == base["chi2_initial"]
+    st = list(synth_ba.make_lba_vio_problem(32, n_points=400, stereo_frac=1.0)[:6])
+    st[4] = st[4].copy()
+    st[4]["ur"] = np.abs(st[4]["ur"])  # (a stereo coordinate left of the image would make the edge monocular)
+    a = oracle.local_ba_vio(*st)[3]
+    st[0][0]["th_dist_far"] = 3.0
+    assert oracle.local_ba_vio(*st)[3]["chi2_initial"] == a["chi2_initial"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("th", [3.0, 6.0, 1e-3])
+def test_gpu_vio_lba_th_dist_far_parity(oracle, th):
+    from vieo_slam_amd.optimizer import Optimizer
+    win = list(synth_ba.make_lba_vio_problem(33, n_points=700, stereo_frac=0.4)[:6])
+    win[0][0]["th_dist_far"] = th
+    _parity(oracle, win, Optimizer.LocalBundleAdjustmentNavStatePRV(*win))

@@ -85,6 +85,7 @@ struct LbaDev {
   const unsigned char* close;     // [n_mp] bClose flags or null
   double thMono, thMonoClose, thStereo;  // chi2 gates of the classification
   double gw[3];
+  double th_dist_far;             // > 0: the far-point rule of the visual-inertial local BA is on
   int ldB, ldS;                   // leading dimensions of BB (3 x points, padded) and of a partial
   int* kf_list;                   // [n_free] free + active key frames in column order
   int* kf_act;                    // [n_kf] scratch of k_lba_begin: the key frame has an active edge
@@ -223,19 +224,33 @@ k_lba_classify(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) 
 // GraphOperator::Chi2LargeSetLevel(edges, dim, 100.f, false) (g2o_graph_operator.h:23-40): every edge's
 // error is computed and stored; chi2 > 100 * chi2_95(dim) puts the edge on level 1
 __global__ void __launch_bounds__(256)
-k_lba_prelevel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+k_lba_prelevel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int phase) {
+  // phase 0: clear the per-point marks (mp_act is free until k_lba_begin); phase 1: Chi2LargeSetLevel, and mark the
+  // points a monocular edge sees closer than th_dist_far; phase 2: th_dist_far (Optimizer.cc:395,454,513-517) --
+  // the monocular edges of an unmarked point go to level 1
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_PRELEVEL)) return;
   const LbaDev& D = devs[w];
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool far_rule = D.th_dist_far > 0;
+  if (phase == 0) {
+    if (far_rule)
+      for (int m = i; m < D.n_mp; m += gridDim.x * 256) D.mp_act[m] = 0;
+    return;
+  }
   if (i >= D.n_obs) return;
   const vieo_lba_obs o = D.obs[i];
+  if (phase == 2) {
+    if (far_rule && o.ur < 0 && !D.mp_act[o.mp]) D.level[i] = 1;
+    return;
+  }
   PoseXf X;
   const CamD& C = obs_cam(D, i);
   kf_xf(C, D.kf[o.kf], X);
   double err[3], Pc[3];
   const double chi2 = lba_edge_error(C, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
   D.err[3 * (size_t)i] = err[0], D.err[3 * (size_t)i + 1] = err[1], D.err[3 * (size_t)i + 2] = err[2];
+  if (far_rule && o.ur < 0 && Pc[2] < D.th_dist_far) D.mp_act[o.mp] = 1;  // same value from every writer
   const float th = 100.f * (o.ur >= 0 ? 7.815f : 5.991f);
   if (chi2 > (double)th) D.level[i] = 1;
 }
@@ -1739,6 +1754,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
       D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
       memcpy(D.gw, H.VP->gw, 24);
+      D.th_dist_far = (!gba && H.VP->th_dist_far > 0 && std::isfinite(H.VP->th_dist_far)) ? (double)H.VP->th_dist_far : 0.0;
       H.prelevel_pending = !gba;
     } else
       D.thMono = D.thMonoClose = 5.991, D.thStereo = 7.815;
@@ -1854,7 +1870,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     VIEO_HIP_CHECK(hipMemcpyAsync(dC, ctl, (size_t)W * sizeof(WinCtl), hipMemcpyHostToDevice, st));
     if (any & LBA_RESTORE) hipLaunchKernelGGL(k_lba_restore, dim3(gr, W), dim3(256), 0, st, dD, dC);
     if (any & (LBA_CLASS0 | LBA_CLASS1)) hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC);
-    if (any & LBA_PRELEVEL) hipLaunchKernelGGL(k_lba_prelevel, dim3(ge, W), dim3(256), 0, st, dD, dC);
+    if (any & LBA_PRELEVEL)
+      for (int ph = 0; ph < 3; ph++) hipLaunchKernelGGL(k_lba_prelevel, dim3(ge, W), dim3(256), 0, st, dD, dC, ph);
     if (any & LBA_BEGIN) {
       hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC);
       hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO);
