@@ -463,11 +463,17 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
  * (optimizer_ba/g2o_graph_operator.h:23-40); user lambda init; divergence check (:660-666).
  * Key frames: local ones first, oldest to newest (= lLocalKeyFrames order), then the fixed observers;
  * the key frame before the window (pKFPrevLocal) is a fixed one whose full nav state is used.
- * Not covered: encoder edges, th_dist_far (the default INFINITY is assumed). */
+ * Encoder edges (EdgeEncNavStatePR, g2otypes.h:591-668; Optimizer.cc:323-347): one per pair whose enc.dt != 0. */
+typedef struct vieo_enc_preint { /* EncPreIntegrator (src/Odom/OdomPreIntegrator.h:66-100) */
+  double dt;          /* mdeltatij; 0 => no encoder edge */
+  double delx[6];     /* mdelxEij: delta~Phi_ij (3), delta~p_ij (3) */
+  double Sigma[36];   /* mSigmaEij, row-major */
+} vieo_enc_preint;    /* 344 bytes */
 typedef struct vieo_lba_imu_edge {
   int32_t kf_i, kf_j;  /* previous / current key frame of the pre-integration (indices) */
   double dt_kf;        /* pKF1->ftimestamp_ - pKF0->ftimestamp_, used when imu.dt == 0 */
   vieo_imu_preint imu; /* GetIMUPreInt() of kf_j; Sigma = mSigmaijPRV, order (p, Phi, v) */
+  vieo_enc_preint enc; /* GetEncPreInt() of kf_j */
 } vieo_lba_imu_edge;
 
 typedef struct vieo_lba_vio_params {
@@ -480,6 +486,7 @@ typedef struct vieo_lba_vio_params {
   float th_dist_far;     /* th_dist_far (Optimizer.cc:395,454,513-517): a point none of whose monocular edges sees it
                           * closer than this has all its monocular edges excluded; <= 0 or inf: no such rule */
   int32_t reserved;
+  double qRbe[4], pbe[3]; /* Tbe = Frame::mTbc * Frame::mTce: rotation (w, x, y, z) and translation (encoder edges) */
 } vieo_lba_vio_params;
 
 #define VIEO_LBA_DIVERGED 3 /* 2*err < err_end or NaN: returns without write-back (Optimizer.cc:660-666) */

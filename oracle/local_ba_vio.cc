@@ -22,6 +22,7 @@
 
 #include "../include/vieo_hot.h"
 #include "cam_models.hpp"
+#include "enc_edge.hpp"
 #include "smallmat.hpp"
 
 namespace vov {
@@ -49,6 +50,9 @@ struct IEdge {  // EdgeNavStatePRV + EdgeNavStateBias of one key-frame pair
   double infoBg, infoBa;
   double errI[9], errB[6];
   double J[9 * 24];  // columns: PR_i 0..5, PR_j 6..11, V_i 12..14, V_j 15..17, Bias_i 18..23
+  // EdgeEncNavStatePR of the same pair (Optimizer.cc:323-347)
+  bool has_enc = false, enc_robust = true;
+  double measE[6], InfoE[36], errE[6], JEi[36], JEj[36];
 };
 
 static Quat qconj(const Quat& q) {
@@ -177,8 +181,27 @@ struct W {
   }
 
   // ---- EdgeNavStatePRV::computeError (g2otypes.h:733-776, idR = 3) + EdgeNavStateBias
+  void enc_eval(IEdge& e, bool jac) const {
+    const KF &si = kf[e.i], &sj = kf[e.j];
+    EncPose a, b;
+    memcpy(a.p, si.p, 24), memcpy(b.p, sj.p, 24);
+    a.q = si.q, b.q = sj.q;
+    Quat qbe;
+    qbe.w = P->qRbe[0], qbe.x = P->qRbe[1], qbe.y = P->qRbe[2], qbe.z = P->qRbe[3];
+    enc_edge_eval(a, b, e.measE, qbe, P->pbe, e.errE, jac ? e.JEi : nullptr, jac ? e.JEj : nullptr);
+  }
+  static double chi2_E(const IEdge& e) {
+    double s = 0;
+    for (int a = 0; a < 6; a++) {
+      double t = 0;
+      for (int b = 0; b < 6; b++) t += e.InfoE[a * 6 + b] * e.errE[b];
+      s += e.errE[a] * t;
+    }
+    return s;
+  }
   void i_error(IEdge& e) const {
     const KF &si = kf[e.i], &sj = kf[e.j];
+    if (e.has_enc) enc_eval(e, false);
     if (e.has_imu) {
       const vieo_imu_preint& M = *e.M;
       double Ri[9], RiT[9];
@@ -347,6 +370,14 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
         chi += rho[0];
       } else
         chi += c;
+      if (e.has_enc) {
+        const double ce = W::chi2_E(e);
+        if (e.enc_robust) {
+          hub(ce, (double)thB, (double)thB * (double)thB, rho);  // sqrt(12.592), Optimizer.cc:343
+          chi += rho[0];
+        } else
+          chi += ce;
+      }
     }
     return chi;
   };
@@ -448,6 +479,36 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
           if (ri >= 0) H[(size_t)ri * np + ri] += w, b[ri] += we;
           if (rj >= 0) H[(size_t)rj * np + rj] += w, b[rj] += -we;
           if (ri >= 0 && rj >= 0) H[(size_t)ri * np + rj] -= w, H[(size_t)rj * np + ri] -= w;
+        }
+      }
+      if (e.has_enc) {  // encoder edge: 6 rows, columns PR_i (map 0..5) and PR_j (map 6..11)
+        B.enc_eval(e, true);
+        double rho[2] = {0, 1.0};
+        if (e.enc_robust) hub(W::chi2_E(e), (double)thB, (double)thB * (double)thB, rho);
+        double JE[6 * 12], TE[6 * 12], weE[6];
+        for (int a = 0; a < 6; a++)
+          for (int c = 0; c < 6; c++) JE[a * 12 + c] = e.JEi[a * 6 + c], JE[a * 12 + 6 + c] = e.JEj[a * 6 + c];
+        for (int a = 0; a < 6; a++) {
+          double t = 0;
+          for (int q = 0; q < 6; q++) t += e.InfoE[a * 6 + q] * e.errE[q];
+          weE[a] = -t * rho[1];
+          for (int c = 0; c < 12; c++) {
+            double u = 0;
+            for (int q = 0; q < 6; q++) u += (rho[1] * e.InfoE[a * 6 + q]) * JE[q * 12 + c];
+            TE[a * 12 + c] = u;
+          }
+        }
+        for (int c1 = 0; c1 < 12; c1++) {
+          if (map[c1] < 0) continue;
+          for (int c2 = 0; c2 < 12; c2++) {
+            if (map[c2] < 0) continue;
+            double t = 0;
+            for (int a = 0; a < 6; a++) t += JE[a * 12 + c1] * TE[a * 12 + c2];
+            H[(size_t)map[c1] * np + map[c2]] += t;
+          }
+          double t = 0;
+          for (int a = 0; a < 6; a++) t += JE[a * 12 + c1] * weE[a];
+          b[map[c1]] += t;
         }
       }
     }
@@ -621,6 +682,15 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
     e.infoBg = P.inv_sigma_bg2 / deltatij * (bfixedkf ? 1e-2 : 1.0);
     e.infoBa = P.inv_sigma_ba2 / deltatij * (bfixedkf ? 1e-2 : 1.0);
     memset(e.errI, 0, sizeof(e.errI)), memset(e.errB, 0, sizeof(e.errB));
+    e.has_enc = imu[t].enc.dt != 0;
+    if (e.has_enc) {
+      memcpy(e.measE, imu[t].enc.delx, 48);
+      mat_inverse(imu[t].enc.Sigma, e.InfoE, 6);
+      if (bfixedkf)
+        for (int k = 0; k < 36; k++) e.InfoE[k] *= 1e-2;
+      e.enc_robust = gba ? gba_robust : true;
+      memset(e.errE, 0, sizeof(e.errE));
+    }
   }
   B.E.resize(n_obs);
   B.mp_first.assign(n_mp, 0);
@@ -725,6 +795,17 @@ void vo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_it
   std::vector<uint8_t> erase((size_t)n_obs + 1), close((size_t)n_mp + 1, 0);
   vov::local_ba_vio(*params, kfs, n_kf, points, close.data(), n_mp, obs, n_obs, imu, n_imu, stop, navs_out,
                     points_out, erase.data(), *result, n_iterations, robust != 0);
+}
+
+void vo_enc_edge_eval(const vieo_navstate* nsi, const vieo_navstate* nsj, const double* meas6, const double* qRbe4,
+                      const double* pbe3, double* err6, double* Ji36, double* Jj36) {
+  vo::EncPose a, b;
+  memcpy(a.p, nsi->p, 24), memcpy(b.p, nsj->p, 24);
+  a.q.w = nsi->q[0], a.q.x = nsi->q[1], a.q.y = nsi->q[2], a.q.z = nsi->q[3];
+  b.q.w = nsj->q[0], b.q.x = nsj->q[1], b.q.y = nsj->q[2], b.q.z = nsj->q[3];
+  vo::Quat qbe;
+  qbe.w = qRbe4[0], qbe.x = qRbe4[1], qbe.y = qRbe4[2], qbe.z = qRbe4[3];
+  vo::enc_edge_eval(a, b, meas6, qbe, pbe3, err6, Ji36, Jj36);
 }
 
 void vo_lba_imu_edge_eval(const vieo_lba_vio_params* params, const vieo_lba_imu_edge* edge,

@@ -295,6 +295,18 @@ class Oracle:
         self.L.vo_imu_preintegrate_batch.restype = None
         return preint_call(self.L.vo_imu_preintegrate_batch, noise, sample_lists, ti, tj, bg, ba)[1:]
 
+    def enc_edge_eval(self, nsi, nsj, meas, qRbe, pbe, jac=True):
+        a, b = np.zeros(1, nsi.dtype), np.zeros(1, nsj.dtype)
+        a[0], b[0] = nsi, nsj
+        meas, qRbe, pbe = (np.ascontiguousarray(x, np.float64) for x in (meas, qRbe, pbe))
+        err, Ji, Jj = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+        P = ctypes.c_void_p
+        self.L.vo_enc_edge_eval.argtypes = [P] * 8
+        self.L.vo_enc_edge_eval.restype = None
+        self.L.vo_enc_edge_eval(a.ctypes.data, b.ctypes.data, meas.ctypes.data, qRbe.ctypes.data, pbe.ctypes.data,
+                                err.ctypes.data, Ji.ctypes.data if jac else None, Jj.ctypes.data if jac else None)
+        return err, Ji, Jj
+
     def fisheye_branch_counts(self, reset=True):
         """(new group, extension, member replaced, contradiction kept, contradiction swapped) since the last reset"""
         out = (ctypes.c_long * 5)()

@@ -238,3 +238,71 @@ def test_gpu_vio_lba_th_dist_far_parity(oracle, th):
     win = list(synth_ba.make_lba_vio_problem(33, n_points=700, stereo_frac=0.4)[:6])
     win[0][0]["th_dist_far"] = th
     _parity(oracle, win, Optimizer.LocalBundleAdjustmentNavStatePRV(*win))
+
+
+# ------------------------------------------------------------------ encoder edges (EdgeEncNavStatePR)
+def test_oracle_encoder_edge_residual_and_jacobians(oracle):
+    """g2otypes.h:606-665: zero residual for a consistent measurement; Jacobians against central differences of
+    computeError through the PR vertex's oplus (p += R dp, R *= Exp(dphi))."""
+    import numpy as np
+    params, kfs, pts, close, obs, imu, gt = synth_ba.make_lba_vio_problem(3, n_local=3, n_fixed=2, n_points=60,
+                                                                          enc=True)
+    e = imu[1]
+    qbe, pbe = params[0]["qRbe"], params[0]["pbe"]
+    nsi, nsj = kfs["nav"][e["kf_i"]].copy(), kfs["nav"][e["kf_j"]].copy()
+    # at the true states the residual is the measurement noise
+    ti, tj = nsi.copy(), nsj.copy()
+    ti["p"], ti["q"], tj["p"], tj["q"] = gt["p"][e["kf_i"]], gt["q"][e["kf_i"]], gt["p"][e["kf_j"]], gt["q"][e["kf_j"]]
+    err, _, _ = oracle.enc_edge_eval(ti, tj, e["enc"]["delx"], qbe, pbe, jac=False)
+    assert np.abs(err[:3]).max() < 0.01 and np.abs(err[3:]).max() < 0.03
+    err0, Ji, Jj = oracle.enc_edge_eval(nsi, nsj, e["enc"]["delx"], qbe, pbe)
+    h = 1e-6
+    for who, J in (("i", Ji), ("j", Jj)):
+        for k in range(6):
+            d = np.zeros(15)
+            d[k] = h
+            if who == "i":
+                ep, _, _ = oracle.enc_edge_eval(oracle.lba_navstate_inc(nsi, d), nsj, e["enc"]["delx"], qbe, pbe, False)
+                em, _, _ = oracle.enc_edge_eval(oracle.lba_navstate_inc(nsi, -d), nsj, e["enc"]["delx"], qbe, pbe, False)
+            else:
+                ep, _, _ = oracle.enc_edge_eval(nsi, oracle.lba_navstate_inc(nsj, d), e["enc"]["delx"], qbe, pbe, False)
+                em, _, _ = oracle.enc_edge_eval(nsi, oracle.lba_navstate_inc(nsj, -d), e["enc"]["delx"], qbe, pbe, False)
+            assert np.allclose((ep - em) / (2 * h), J[:, k], atol=2e-6, rtol=1e-5), (who, k)
+
+
+def test_oracle_vio_lba_with_encoder_edges(oracle):
+    win = synth_ba.make_lba_vio_problem(41, n_points=500, enc=True)
+    navs, pout, erase, res = oracle.local_ba_vio(*win[:6])
+    dp, dr, dv = _errs(navs, win[6])
+    dp0, dr0, dv0 = _errs(win[1]["nav"], win[6])
+    assert res["status"] == 0 and dr.mean() < 0.5 * dr0.mean() and res["chi2_final"] < 0.1 * res["chi2_initial"]
+    # the edges take part: dropping them changes the cost
+    no = list(win[:6])
+    no[5] = no[5].copy()
+    no[5]["enc"]["dt"] = 0
+    assert oracle.local_ba_vio(*no)[3]["chi2_initial"] < res["chi2_initial"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", [(42, {}), (43, dict(n_local=5, n_fixed=3, n_points=400, with_prev=False,
+                                                         first_fixed=True))])
+def test_gpu_vio_lba_encoder_parity(oracle, seed, kw):
+    from vieo_slam_amd.optimizer import Optimizer
+    win = synth_ba.make_lba_vio_problem(seed, enc=True, **kw)[:6]
+    _parity(oracle, win, Optimizer.LocalBundleAdjustmentNavStatePRV(*win))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robust", [True, False])
+def test_gpu_vio_gba_encoder_parity(oracle, robust):
+    import numpy as np
+    from vieo_slam_amd.optimizer import Optimizer
+    params, kfs, pts, close, obs, imu, gt = synth_ba.make_lba_vio_problem(44, n_local=40, n_fixed=1, n_points=3000,
+                                                                          anchors=20, span=5, enc=True)
+    on, op, ores = oracle.global_ba_vio(params, kfs, pts, obs, imu, 5, robust)
+    hn, hp, hres = Optimizer.GlobalBundleAdjustmentNavStatePRV(params, kfs, pts, obs, imu, 5, robust)
+    for k in range(40):
+        dt, dr = synth_ba.pose_error(on[k], hn[k])
+        assert dt < 1e-4 and dr < 1e-4, (k, dt, dr)
+    assert hres["lm_trials"] == ores["lm_trials"]
+    assert abs(hres["chi2_final"] - ores["chi2_final"]) <= 1e-6 * ores["chi2_final"]

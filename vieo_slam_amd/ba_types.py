@@ -54,12 +54,15 @@ LBA_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_erase", "<i4"), ("lm_iterati
                              ("lm_trials", "<i4"), ("chi2_initial", "<f8"), ("chi2_final", "<f8")],
                             align=True)
 
-LBA_IMU_EDGE_DTYPE = np.dtype([("kf_i", "<i4"), ("kf_j", "<i4"), ("dt_kf", "<f8"), ("imu", IMU_PREINT_DTYPE)],
-                              align=True)
+ENC_PREINT_DTYPE = np.dtype([("dt", "<f8"), ("delx", "<f8", 6), ("Sigma", "<f8", 36)], align=True)
+LBA_IMU_EDGE_DTYPE = np.dtype([("kf_i", "<i4"), ("kf_j", "<i4"), ("dt_kf", "<f8"), ("imu", IMU_PREINT_DTYPE),
+                               ("enc", ENC_PREINT_DTYPE)], align=True)
 LBA_VIO_PARAMS_DTYPE = np.dtype([("base", LBA_PARAMS_DTYPE), ("gw", "<f8", 3), ("inv_sigma_bg2", "<f8"),
                                  ("inv_sigma_ba2", "<f8"), ("lambda_init", "<f8"), ("rec_init", "<i4"),
-                                 ("large", "<i4"), ("th_dist_far", "<f4"), ("reserved", "<i4")], align=True)
-assert LBA_IMU_EDGE_DTYPE.itemsize == 1152 and LBA_VIO_PARAMS_DTYPE.itemsize == 200
+                                 ("large", "<i4"), ("th_dist_far", "<f4"), ("reserved", "<i4"), ("qRbe", "<f8", 4),
+                                 ("pbe", "<f8", 3)], align=True)
+assert ENC_PREINT_DTYPE.itemsize == 344
+assert LBA_IMU_EDGE_DTYPE.itemsize == 1496 and LBA_VIO_PARAMS_DTYPE.itemsize == 256
 
 # vieo_fisheye_params: cams / Trc / Tcr / level_sigma2 are host pointers the caller keeps alive
 FISHEYE_PARAMS_DTYPE = np.dtype([("n_cams", "<i4"), ("n_levels", "<i4"), ("bf", "<f4"), ("th_far_pts", "<f4"),

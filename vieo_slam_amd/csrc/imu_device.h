@@ -232,4 +232,50 @@ static __device__ void imu_linearize(const vieo_imu_preint& M, const double* gw,
   set3(J, ld, idR, cj + idR, Jrinv, 1.0);
 }
 
+// EdgeEncNavState<DV>::computeError / linearizeOplus (g2otypes.h:606-665, USE_P_PLUS_RDP on): the 6-row encoder
+// edge between the PR parts of two states.  err = (eR, ep); Ji / Jj: 6 x 6, columns (dp, dphi); J may be null.
+static __device__ void enc_edge_eval(const NSd& si, const NSd& sj, const double* meas, const double* qRbe4,
+                                     const double* pbe, double* err, double* Ji, double* Jj) {
+  const Qd qi = q_of(si), qj = q_of(sj), qbe = Qd{qRbe4[0], qRbe4[1], qRbe4[2], qRbe4[3]};
+  const Qd qRiw = q_conj(qi), qReb = q_conj(qbe);
+  const Qd qRij = q_mul(qRiw, qj);
+  const Qd qe = q_norm(q_mul(q_mul(qReb, qRij), qbe));
+  const Qd ql = q_norm(q_mul(q_conj(so3_exp_q(meas)), qe));
+  so3_log_q(ql, err);
+  double Riw[9], Rij[9], Reb[9];
+  q_to_R(qRiw, Riw), q_to_R(qRij, Rij), q_to_R(qReb, Reb);
+  const double dpw[3] = {sj.p[0] - si.p[0], sj.p[1] - si.p[1], sj.p[2] - si.p[2]};
+  double a[3], b[3], c[3], dp[3];
+  mv3(Riw, dpw, a);
+  mv3(Rij, pbe, b);
+  for (int k = 0; k < 3; k++) c[k] = a[k] - pbe[k] + b[k];
+  mv3(Reb, c, dp);
+  for (int k = 0; k < 3; k++) err[3 + k] = dp[k] - meas[3 + k];
+  if (!Ji) return;
+  double JrInv[9], RijT[9], T[9], T2[9], RebRiw[9], Rwi[9], Rwj[9], hv[9], v[3], RebRij[9];
+  so3_JrInv_d(err, JrInv);
+  for (int r = 0; r < 3; r++)
+    for (int q = 0; q < 3; q++) RijT[r * 3 + q] = Rij[q * 3 + r];
+  for (int k = 0; k < 36; k++) Ji[k] = 0, Jj[k] = 0;
+  mm3(JrInv, Reb, T);
+  mm3(T, RijT, T2);
+  set3(Ji, 6, 0, 3, T2, -1.0);       // JeR_dphii = -Jrinv(eR) Reb Rij^T
+  mm3(Reb, Riw, RebRiw);
+  q_to_R(qi, Rwi), q_to_R(qj, Rwj);
+  mm3(RebRiw, Rwi, T);
+  set3(Ji, 6, 3, 0, T, -1.0);        // Jep_dpi = -Reb Rbiw Rwbi
+  for (int k = 0; k < 3; k++) v[k] = b[k] + a[k];
+  hat3(v, hv);
+  mm3(Reb, hv, T);
+  set3(Ji, 6, 3, 3, T, 1.0);         // Jep_dphii = Reb [Rij pbe + Riw (pwj - pwi)]^
+  mm3(JrInv, Reb, T);
+  set3(Jj, 6, 0, 3, T, 1.0);         // JeR_dphij = Jrinv(eR) Reb
+  mm3(RebRiw, Rwj, T);
+  set3(Jj, 6, 3, 0, T, 1.0);         // Jep_dpj = Reb Rbiw Rwbj
+  mm3(Reb, Rij, RebRij);
+  hat3(pbe, hv);
+  mm3(RebRij, hv, T);
+  set3(Jj, 6, 3, 3, T, -1.0);        // Jep_dphij = -Reb Rij pbe^
+}
+
 }  // namespace vieo

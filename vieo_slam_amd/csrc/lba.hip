@@ -45,6 +45,8 @@ struct LbaImu {
   double InfoI[81];  // Sigma_PRV^-1, x 1e-2 when kf_i is fixed (Optimizer.cc:247-259)
   double infoBg, infoBa;
   vieo_imu_preint M;
+  int has_enc, enc_robust;  // EdgeEncNavStatePR of the pair (Optimizer.cc:323-347)
+  double measE[6], InfoE[36];
 };
 
 // control word of a window for one round of the lock-step driver
@@ -86,6 +88,7 @@ struct LbaDev {
   double thMono, thMonoClose, thStereo;  // chi2 gates of the classification
   double gw[3];
   double th_dist_far;             // > 0: the far-point rule of the visual-inertial local BA is on
+  double qRbe[4], pbe[3];         // body <- encoder extrinsics of the encoder edges
   int ldB, ldS;                   // leading dimensions of BB (3 x points, padded) and of a partial
   int* kf_list;                   // [n_free] free + active key frames in column order
   int* kf_act;                    // [n_kf] scratch of k_lba_begin: the key frame has an active edge
@@ -800,7 +803,8 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
 // pair) and robust chi2 -> gchi0; mode 1: robust chi2 after a trial -> gchi.
 __global__ void __launch_bounds__(64)
 k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int mode) {
-  __shared__ double sJ[9 * 30], sT[9 * 30], sErr[9 + 6], sWe[9], sRho[2];
+  __shared__ double sJ[9 * 30], sT[9 * 30], sErr[9 + 6], sWe[9], sRho[3];
+  __shared__ double sJE[6 * 30], sTE[6 * 30], sWeE[6];  // encoder edge: J in the local order, (rho' Info) J, Info e
   const int w = blockIdx.y, fl = ctl[w].flags;
   if (!(fl & (mode ? LBA_TRIAL : LBA_BUILD))) return;
   const LbaDev& D = devs[w];
@@ -845,8 +849,28 @@ k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, i
       if (E.robust) huber(c2, dB, dB * dB, &r0, &rB);
       chi += r0;
     }
+    double rE = 1.0;
+    if (E.has_enc) {
+      double errE[6], JEi[36], JEj[36];
+      enc_edge_eval(si, sj, E.measE, D.qRbe, D.pbe, errE, mode == 0 ? JEi : nullptr, mode == 0 ? JEj : nullptr);
+      double c2 = 0;
+      for (int a = 0; a < 6; a++) {
+        double t = 0;
+        for (int b = 0; b < 6; b++) t += E.InfoE[a * 6 + b] * errE[b];
+        sWeE[a] = t;
+        c2 += errE[a] * t;
+      }
+      double r0 = c2;
+      if (E.enc_robust) huber(c2, dB, dB * dB, &r0, &rE);  // sqrt(12.592), Optimizer.cc:343
+      chi += r0;
+      if (mode == 0)
+        for (int a = 0; a < 6; a++) {
+          for (int c = 0; c < 30; c++) sJE[a * 30 + c] = 0;
+          for (int c = 0; c < 6; c++) sJE[a * 30 + c] = JEi[a * 6 + c], sJE[a * 30 + 15 + c] = JEj[a * 6 + c];
+        }
+    }
     (mode ? D.gchi : D.gchi0)[e] = chi;
-    sRho[0] = rI, sRho[1] = rB;
+    sRho[0] = rI, sRho[1] = rB, sRho[2] = rE;
     if (mode == 0 && E.has_imu) {
       // J (9 x 24, [PRV_j | PRV_i | Bias_i]) -> local order [i: PR V Bias | j: PR V Bias]
       double J24[9 * 24];
@@ -863,7 +887,15 @@ k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, i
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   double* A = D.Ae + 930 * (size_t)e;
-  const double rI = sRho[0], rB = sRho[1];
+  const double rI = sRho[0], rB = sRho[1], rE = sRho[2];
+  if (E.has_enc) {
+    for (int t = lane; t < 180; t += 64) {
+      const int a = t / 30, c = t - a * 30;
+      double u = 0;
+      for (int q = 0; q < 6; q++) u += (rE * E.InfoE[a * 6 + q]) * sJE[q * 30 + c];
+      sTE[t] = u;
+    }
+  }
   if (E.has_imu) {
     for (int t = lane; t < 270; t += 64) {  // T = (rho' Info) J
       const int a = t / 30, c = t - a * 30;
@@ -871,14 +903,16 @@ k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, i
       for (int q = 0; q < 9; q++) u += (rI * E.InfoI[a * 9 + q]) * sJ[q * 30 + c];
       sT[t] = u;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   for (int t = lane; t < 900; t += 64) {
     const int c1 = t / 30, c2 = t - c1 * 30;
     double u = 0;
     if (E.has_imu)
       for (int a = 0; a < 9; a++) u += sJ[a * 30 + c1] * sT[a * 30 + c2];
+    if (E.has_enc)
+      for (int a = 0; a < 6; a++) u += sJE[a * 30 + c1] * sTE[a * 30 + c2];
     // bias edge: J_i = -I on rows/cols 9..14, J_j = +I on 24..29
     const int b1 = c1 >= 24 ? c1 - 24 : (c1 >= 9 && c1 < 15 ? c1 - 9 : -1);
     const int b2 = c2 >= 24 ? c2 - 24 : (c2 >= 9 && c2 < 15 ? c2 - 9 : -1);
@@ -892,6 +926,8 @@ k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, i
     double u = 0;
     if (E.has_imu)
       for (int a = 0; a < 9; a++) u += sJ[a * 30 + lane] * (-sWe[a] * rI);
+    if (E.has_enc)
+      for (int a = 0; a < 6; a++) u += sJE[a * 30 + lane] * (-sWeE[a] * rE);
     const int b1 = lane >= 24 ? lane - 24 : (lane >= 9 && lane < 15 ? lane - 9 : -1);
     if (b1 >= 0) {
       const double we = (b1 < 3 ? E.infoBg : E.infoBa) * sErr[9 + b1] * rB;
@@ -1435,6 +1471,32 @@ static bool inverse9(const double* A, double* Ainv) {
   return true;
 }
 
+// the same elimination for an n x n block (n <= 9): the encoder covariance
+static bool inverse_n(const double* A, double* Ainv, int n) {
+  double M[9][18];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) M[i][j] = A[i * n + j], M[i][n + j] = (i == j);
+  for (int c = 0; c < n; c++) {
+    int piv = c;
+    for (int r = c + 1; r < n; r++)
+      if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+    if (M[piv][c] == 0) return false;
+    if (piv != c)
+      for (int j = 0; j < 2 * n; j++) std::swap(M[c][j], M[piv][j]);
+    const double d = M[c][c];
+    for (int j = 0; j < 2 * n; j++) M[c][j] /= d;
+    for (int r = 0; r < n; r++)
+      if (r != c) {
+        const double f = M[r][c];
+        if (f != 0)
+          for (int j = 0; j < 2 * n; j++) M[r][j] -= f * M[c][j];
+      }
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) Ainv[i * n + j] = M[i][n + j];
+  return true;
+}
+
 struct LbaShard {  // landmark-sharded run: every rank holds all key frames and its share of the points
   vieo_allreduce_sum_f64_fn fn;
   void* ctx;
@@ -1691,6 +1753,17 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         if (deltatij <= EPS_MIN_DT) deltatij = 15;  // Optimizer.cc:271-275
         d.infoBg = H.VP->inv_sigma_bg2 / deltatij * (bfixedkf ? 1e-2 : 1.0);
         d.infoBa = H.VP->inv_sigma_ba2 / deltatij * (bfixedkf ? 1e-2 : 1.0);
+        d.has_enc = e.enc.dt != 0, d.enc_robust = gba ? gba->robust != 0 : 1;
+        memset(d.InfoE, 0, sizeof(d.InfoE)), memset(d.measE, 0, sizeof(d.measE));
+        if (d.has_enc) {
+          memcpy(d.measE, e.enc.delx, 48);
+          if (!inverse_n(e.enc.Sigma, d.InfoE, 6)) {
+            set_error("visual-inertial local BA: singular encoder covariance");
+            return VIEO_E_INVALID;
+          }
+          if (bfixedkf)
+            for (int q = 0; q < 36; q++) d.InfoE[q] *= 1e-2;
+        }
         kout[e.kf_i] = t, kin[e.kf_j] = t;
       }
       if (h_close[w])
@@ -1754,6 +1827,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
       D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
       memcpy(D.gw, H.VP->gw, 24);
+      memcpy(D.qRbe, H.VP->qRbe, 32), memcpy(D.pbe, H.VP->pbe, 24);
       D.th_dist_far = (!gba && H.VP->th_dist_far > 0 && std::isfinite(H.VP->th_dist_far)) ? (double)H.VP->th_dist_far : 0.0;
       H.prelevel_pending = !gba;
     } else

@@ -148,6 +148,16 @@ def so3_exp(w):
     return quat_to_R(quat_from_rotvec(np.asarray(w, float)))
 
 
+ENC_PBE = np.array([0.10, 0.02, -0.05])  # body <- encoder extrinsics of the synthetic wheel odometry
+
+
+def so3_log_np(R):
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    th = np.arccos(c)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+    return w if th < 1e-8 else w * th / np.sin(th)
+
+
 def so3_hat(w):
     return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
 
@@ -507,7 +517,7 @@ _PVR_TO_PRV = np.r_[0:3, 6:9, 3:6]  # Sigma order (p, v, Phi) -> (p, Phi, v)
 
 def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_frac=0.03, stereo_frac=0.7,
                          noise=1.0, pert_t=0.01, pert_r_deg=0.3, pert_v=0.03, pert_x=0.02, dt_kf=0.5,
-                         first_fixed=False, imu_noise=1.0, with_prev=True, rig=None, anchors=1, span=None):
+                         first_fixed=False, imu_noise=1.0, with_prev=True, rig=None, anchors=1, span=None, enc=False):
     """Seeded visual-inertial local-BA window: a chain prev-local -> n_local key frames
     integrated forward with consistent IMU pre-integrations, n_fixed older covisible key frames,
     points 2-12 m ahead.  Key-frame order: local (oldest..newest), prev-local (fixed, full nav state),
@@ -582,6 +592,17 @@ def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_fra
         fill_imu(imu[t]["imu"], meas[k])
         S = meas[k].Sigma[np.ix_(_PVR_TO_PRV, _PVR_TO_PRV)]
         imu[t]["imu"]["Sigma"] = S.reshape(-1)
+        if enc:  # wheel-odometry pre-integration of the same pair (EncPreIntegrator: delta Phi, delta p in the
+            #       encoder frame), consistent with the true poses
+            (Ri, pi_, _), (Rj, pj_, _) = (chain[0] if k == 0 else local[k - 1]), local[k]
+            Reb = ENC_RBE.T
+            dR = Reb @ Ri.T @ Rj @ ENC_RBE
+            dp = Reb @ (Ri.T @ (pj_ - pi_) - ENC_PBE + Ri.T @ Rj @ ENC_PBE)
+            sphi, sp = 2e-3, 5e-3
+            imu[t]["enc"]["dt"] = dt_kf
+            imu[t]["enc"]["delx"][:3] = so3_log_np(dR) + rng.normal(0, sphi, 3)
+            imu[t]["enc"]["delx"][3:] = dp + rng.normal(0, sp, 3)
+            imu[t]["enc"]["Sigma"] = np.diag([sphi ** 2] * 3 + [sp ** 2] * 3).reshape(-1)
         t += 1
     pts = (Xw + rng.normal(0, pert_x, Xw.shape)).astype(np.float32)
     params = np.zeros(1, LBA_VIO_PARAMS_DTYPE)
@@ -593,11 +614,15 @@ def make_lba_vio_problem(seed, n_local=10, n_fixed=5, n_points=1500, outlier_fra
     params[0]["inv_sigma_bg2"] = 1.0 / IMU_SIGMA[2] ** 2
     params[0]["inv_sigma_ba2"] = 1.0 / IMU_SIGMA[3] ** 2
     params[0]["lambda_init"] = 1.0
+    params[0]["qRbe"], params[0]["pbe"] = _R_to_quat(ENC_RBE), ENC_PBE
     gt = dict(p=np.array(tp), q=np.array(tq), v=np.array(tv), X=Xw, bg=bg, ba=ba, n_local=n_local)
     if rig_c is not None:
         b["n_cams"], b["cams"] = len(rig_c[0]), rig_c[0].ctypes.data
         gt["cams"] = rig_c[0]
     return params, kfs, pts, close, obs, imu, gt
+
+
+ENC_RBE = so3_exp(np.array([0.02, -0.03, 0.5]))
 
 
 # ---- distorted multi-camera rigs (a20: Radtan / KB8 models, per-observation camera) --------------
