@@ -301,6 +301,19 @@ typedef struct vieo_pose_obs {
   int32_t flags;    /* bit 0: close point (track_depth_ < max(10, ThDepth)), VIO variant only */
 } vieo_pose_obs;    /* 32 bytes */
 
+typedef struct vieo_enc_preint { /* EncPreIntegrator (src/Odom/OdomPreIntegrator.h:66-100) */
+  double dt;          /* mdeltatij; 0 => no encoder edge */
+  double delx[6];     /* mdelxEij: delta~Phi_ij (3), delta~p_ij (3) */
+  double Sigma[36];   /* mSigmaEij, row-major */
+} vieo_enc_preint;    /* 344 bytes */
+/* The optional encoder edge of the pose optimisations (EdgeEncNavStatePR / PVR between the last frame and the
+ * current one, Optimizer.cc:1650-1674, Optimizer.h:345-372): measurement, extrinsics, and the last frame's pose. */
+typedef struct vieo_pose_enc {
+  vieo_enc_preint enc;     /* pFrame->GetEncPreInt() */
+  double qRbe[4], pbe[3];  /* Tbe = Frame::mTbc * Frame::mTce: rotation (w, x, y, z), translation */
+  double p_last[3], q_last[4]; /* pLastF->GetNavStateRef(): mpwb, mRwb (w, x, y, z) -- the fixed vertex of a15 */
+} vieo_pose_enc;           /* 456 bytes */
+
 typedef struct vieo_pose_frame {
   vieo_navstate nav;     /* initial estimate (Frame::mNavState after UpdateNavStatePVRFromTcw) */
   double Rcb[9], tcb[3]; /* FrameBase::meigRcb (row-major) / meigtcb */
@@ -311,6 +324,7 @@ typedef struct vieo_pose_frame {
   int32_t n_cams;        /* 0: the rectified pinhole camera above; 1..4: `cams` (a20, Frame::usedistort_), and
                           * bits 8..11 of vieo_pose_obs.flags select the observation's camera (monocular edges) */
   const vieo_camera* cams; /* host pointer for the host entry points, device pointer for *_batch_device */
+  const vieo_pose_enc* enc; /* NULL or enc->enc.dt == 0: no encoder edge; host / device pointer like `cams` */
 } vieo_pose_frame;
 
 /* The batched device forms cannot see n_cams from the host, so by default they launch both kernel instances
@@ -464,11 +478,6 @@ int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* con
  * Key frames: local ones first, oldest to newest (= lLocalKeyFrames order), then the fixed observers;
  * the key frame before the window (pKFPrevLocal) is a fixed one whose full nav state is used.
  * Encoder edges (EdgeEncNavStatePR, g2otypes.h:591-668; Optimizer.cc:323-347): one per pair whose enc.dt != 0. */
-typedef struct vieo_enc_preint { /* EncPreIntegrator (src/Odom/OdomPreIntegrator.h:66-100) */
-  double dt;          /* mdeltatij; 0 => no encoder edge */
-  double delx[6];     /* mdelxEij: delta~Phi_ij (3), delta~p_ij (3) */
-  double Sigma[36];   /* mSigmaEij, row-major */
-} vieo_enc_preint;    /* 344 bytes */
 typedef struct vieo_lba_imu_edge {
   int32_t kf_i, kf_j;  /* previous / current key frame of the pre-integration (indices) */
   double dt_kf;        /* pKF1->ftimestamp_ - pKF0->ftimestamp_, used when imu.dt == 0 */

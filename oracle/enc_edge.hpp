@@ -1,9 +1,38 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY.  EdgeEncNavState<DV>::computeError / linearizeOplus (reference
 // src/Odom/g2otypes.h:606-665, USE_P_PLUS_RDP on: NavState.h:8) restated on the closed forms of smallmat.hpp.
 #pragma once
+#include <cmath>
+#include <utility>
+
 #include "smallmat.hpp"
 
 namespace vo {
+
+// inverse of a small dense matrix, Gauss-Jordan with partial pivoting (n <= 9)
+static inline bool gj_inverse(const double* A, double* Ainv, int n) {
+  double M[9][18];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) M[i][j] = A[i * n + j], M[i][n + j] = (i == j);
+  for (int c = 0; c < n; c++) {
+    int piv = c;
+    for (int r = c + 1; r < n; r++)
+      if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+    if (M[piv][c] == 0) return false;
+    if (piv != c)
+      for (int j = 0; j < 2 * n; j++) std::swap(M[c][j], M[piv][j]);
+    const double d = M[c][c];
+    for (int j = 0; j < 2 * n; j++) M[c][j] /= d;
+    for (int r = 0; r < n; r++)
+      if (r != c) {
+        const double f = M[r][c];
+        if (f != 0)
+          for (int j = 0; j < 2 * n; j++) M[r][j] -= f * M[c][j];
+      }
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) Ainv[i * n + j] = M[i][n + j];
+  return true;
+}
 
 struct EncPose {  // the PR part of a NavState
   double p[3];

@@ -26,6 +26,7 @@
 
 #include "../include/vieo_hot.h"
 #include "cam_models.hpp"
+#include "enc_edge.hpp"
 #include "smallmat.hpp"
 
 namespace vo {
@@ -146,6 +147,32 @@ static void edge_linearize(const Cam& cc, const PoseState& s, const ReprojEdge& 
   }
 }
 
+// the optional EdgeEncNavStatePR between the fixed last frame (vertex i) and the frame (vertex j)
+// (Optimizer.cc:1650-1674): Huber sqrt(12.592) in all four rounds
+struct EncEdge {
+  bool on = false;
+  EncPose last;
+  Quat qRbe;
+  double pbe[3], meas[6], Info[36], err[6], Jj[36];
+  double chi2() const {
+    double s = 0;
+    for (int a = 0; a < 6; a++) {
+      double t = 0;
+      for (int b = 0; b < 6; b++) t += Info[a * 6 + b] * err[b];
+      s += err[a] * t;
+    }
+    return s;
+  }
+  void eval(const PoseState& s, bool jac) {
+    EncPose cur;
+    memcpy(cur.p, s.p, 24);
+    cur.q = s.q;
+    double Ji[36];
+    enc_edge_eval(last, cur, meas, qRbe, pbe, err, jac ? Ji : nullptr, jac ? Jj : nullptr);
+  }
+};
+static const float kThEnc = std::sqrt(12.592);
+
 struct LMState {
   double lambda = -1, ni = 2;
   int nBad = 0;
@@ -153,9 +180,10 @@ struct LMState {
 
 // one OptimizationAlgorithmLevenberg::solve(iteration); returns 0 OK, 1 Terminate
 static int lm_solve(const Cam& c, PoseState& est, std::vector<ReprojEdge*>& active, int iteration,
-                    LMState& lm) {
+                    LMState& lm, EncEdge& enc) {
   auto computeActiveErrors = [&]() {
     for (auto* e : active) edge_compute_error(c, est, *e);
+    if (enc.on) enc.eval(est, false);
   };
   auto activeRobustChi2 = [&]() {
     double chi = 0, rho[3];
@@ -165,6 +193,10 @@ static int lm_solve(const Cam& c, PoseState& est, std::vector<ReprojEdge*>& acti
         chi += rho[0];
       } else
         chi += edge_chi2(*e);
+    }
+    if (enc.on) {
+      huber(enc.chi2(), (double)kThEnc, (double)kThEnc * (double)kThEnc, rho);
+      chi += rho[0];
     }
     return chi;
   };
@@ -193,6 +225,32 @@ static int lm_solve(const Cam& c, PoseState& est, std::vector<ReprojEdge*>& acti
       double s = 0;
       for (int r = 0; r < e->de; r++) s += J[r * 6 + i] * (-(w * e->err[r]) * wr);
       b[i] += s;
+    }
+  }
+  if (enc.on) {
+    enc.eval(est, true);
+    double rho[3];
+    huber(enc.chi2(), (double)kThEnc, (double)kThEnc * (double)kThEnc, rho);
+    double T[36], we[6];
+    for (int a = 0; a < 6; a++) {
+      double t = 0;
+      for (int q = 0; q < 6; q++) t += enc.Info[a * 6 + q] * enc.err[q];
+      we[a] = -t * rho[1];
+      for (int c2 = 0; c2 < 6; c2++) {
+        double u = 0;
+        for (int q = 0; q < 6; q++) u += (rho[1] * enc.Info[a * 6 + q]) * enc.Jj[q * 6 + c2];
+        T[a * 6 + c2] = u;
+      }
+    }
+    for (int i = 0; i < 6; i++) {
+      for (int j = 0; j < 6; j++) {
+        double s2 = 0;
+        for (int a = 0; a < 6; a++) s2 += enc.Jj[a * 6 + i] * T[a * 6 + j];
+        H[i * 6 + j] += s2;
+      }
+      double s2 = 0;
+      for (int a = 0; a < 6; a++) s2 += enc.Jj[a * 6 + i] * we[a];
+      b[i] += s2;
     }
   }
   if (iteration == 0) {  // computeLambdaInit: tau * max diagonal
@@ -244,7 +302,7 @@ static int lm_solve(const Cam& c, PoseState& est, std::vector<ReprojEdge*>& acti
   return 0;
 }
 
-// Optimizer::PoseOptimization(Frame*, Frame*) without encoder edge (Optimizer.cc:1611-1874)
+// Optimizer::PoseOptimization(Frame*, Frame*) (Optimizer.cc:1611-1874)
 static void pose_optimization(const vieo_pose_frame& F, const vieo_pose_obs* obs, uint8_t* outlier,
                               vieo_pose_result& R) {
   R.nav = F.nav;
@@ -289,6 +347,17 @@ static void pose_optimization(const vieo_pose_frame& F, const vieo_pose_obs* obs
   memcpy(init.p, F.nav.p, 24);
   init.q.w = F.nav.q[0], init.q.x = F.nav.q[1], init.q.y = F.nav.q[2], init.q.z = F.nav.q[3];
   PoseState est = init;
+  EncEdge enc;
+  if (F.enc && F.enc->enc.dt != 0) {  // Optimizer.cc:1650-1674
+    const vieo_pose_enc& E = *F.enc;
+    enc.on = true;
+    memcpy(enc.last.p, E.p_last, 24);
+    enc.last.q.w = E.q_last[0], enc.last.q.x = E.q_last[1], enc.last.q.y = E.q_last[2], enc.last.q.z = E.q_last[3];
+    enc.qRbe.w = E.qRbe[0], enc.qRbe.x = E.qRbe[1], enc.qRbe.y = E.qRbe[2], enc.qRbe.z = E.qRbe[3];
+    memcpy(enc.pbe, E.pbe, 24), memcpy(enc.meas, E.enc.delx, 48);
+    gj_inverse(E.enc.Sigma, enc.Info, 6);
+    memset(enc.err, 0, sizeof(enc.err));
+  }
   int nBad = 0;
   for (size_t it = 0; it < 4; it++) {
     est = init;  // vns->setEstimate(pFrame->GetNavStateRef())
@@ -296,10 +365,10 @@ static void pose_optimization(const vieo_pose_frame& F, const vieo_pose_obs* obs
     for (auto& e : edges)
       if (e.level == 0) active.push_back(&e);
     // optimizer.optimize(its[it])
-    if (!active.empty()) {
+    if (!active.empty() || enc.on) {
       LMState lm;
       for (int i = 0; i < its[it]; i++) {
-        int res = lm_solve(c, est, active, i, lm);
+        int res = lm_solve(c, est, active, i, lm, enc);
         R.lm_iterations++;
         if (res != 0) break;
       }
@@ -322,7 +391,7 @@ static void pose_optimization(const vieo_pose_frame& F, const vieo_pose_obs* obs
         }
         if (it == 2) e.robust = false;
       }
-    if (edges.size() < 10) break;
+    if (edges.size() + (enc.on ? 1 : 0) < 10) break;
   }
   memcpy(R.nav.p, est.p, 24);
   R.nav.q[0] = est.q.w, R.nav.q[1] = est.q.x, R.nav.q[2] = est.q.y, R.nav.q[3] = est.q.z;

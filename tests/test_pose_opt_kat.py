@@ -95,4 +95,23 @@ def test_too_few_correspondences_and_small_problem(oracle):
 
 
 def test_struct_sizes_match_header():
-    assert POSE_OBS_DTYPE.itemsize == 32 and POSE_FRAME_DTYPE.itemsize == 312
+    assert POSE_OBS_DTYPE.itemsize == 32 and POSE_FRAME_DTYPE.itemsize == 320
+
+
+def test_encoder_edge_constrains_a_weak_visual_problem(oracle):
+    """Optimizer.cc:1650-1674: with few, noisy correspondences the EdgeEncNavStatePR to the last frame pulls the
+    estimate towards the odometry; the edge counts in `edges().size() < 10`."""
+    e0 = e1 = 0
+    for seed in range(6):
+        fr, obs, gt = synth_ba.make_pose_problem(seed, n_obs=30, noise=2.5, outlier_frac=0.0)
+        r0, _ = oracle.pose_optimization(fr, obs)
+        fr, obs, gt = synth_ba.make_pose_problem(seed, n_obs=30, noise=2.5, outlier_frac=0.0, enc=True)
+        r1, _ = oracle.pose_optimization(fr, obs)
+        e0 += synth_ba.pose_error(r0["nav"], gt)[0]
+        e1 += synth_ba.pose_error(r1["nav"], gt)[0]
+    assert e1 < 0.6 * e0
+    fr, obs, gt = synth_ba.make_pose_problem(7, n_obs=9, outlier_frac=0.0)
+    a, _ = oracle.pose_optimization(fr, obs)       # 9 edges: one round
+    fr, obs, gt = synth_ba.make_pose_problem(7, n_obs=9, outlier_frac=0.0, enc=True)
+    b, _ = oracle.pose_optimization(fr, obs)       # 10 edges with the encoder edge: four rounds
+    assert b["lm_iterations"] > a["lm_iterations"]

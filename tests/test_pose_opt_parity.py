@@ -157,3 +157,44 @@ def test_pose_camera_mode_switch(oracle):
         assert lib().vieo_pose_set_camera_mode(7) != 0
     finally:
         check(lib().vieo_pose_set_camera_mode(0))
+
+
+@pytest.mark.parametrize("seed,n,kw", [(70, 300, {}), (71, 40, dict(noise=2.5)), (72, 9, dict(outlier_frac=0.0)),
+                                       (73, 300, dict(outlier_frac=0.5))])
+def test_pose_encoder_edge_parity(oracle, seed, n, kw):
+    """a15 with its optional EdgeEncNavStatePR to the last frame (Optimizer.cc:1650-1674)."""
+    fr, obs, gt = synth_ba.make_pose_problem(seed, n_obs=n, enc=True, **kw)
+    _check(oracle, fr, obs)
+
+
+def test_pose_encoder_edge_in_a_device_batch(oracle):
+    from vieo_slam_amd.ba_types import POSE_ENC_DTYPE
+    B = 6
+    frames = np.zeros(B, POSE_FRAME_DTYPE)
+    encs = np.zeros(B, POSE_ENC_DTYPE)
+    all_obs, begin, cases = [], 0, []
+    for i in range(B):
+        fr, obs, gt = synth_ba.make_pose_problem(80 + i, n_obs=60 + 40 * i, enc=(i % 2 == 0))
+        cases.append((fr.copy(), obs, gt))
+        frames[i] = fr[0]
+        frames[i]["obs_begin"] = begin
+        if i % 2 == 0:
+            encs[i] = gt["enc"][0]
+        begin += len(obs)
+        all_obs.append(obs)
+    obs = np.concatenate(all_obs)
+    dE = DeviceBuffer(encs.nbytes)
+    dE.upload(encs)
+    for i in range(B):
+        frames[i]["enc"] = dE.ptr + i * POSE_ENC_DTYPE.itemsize if i % 2 == 0 else 0
+    dF, dO = DeviceBuffer(frames.nbytes), DeviceBuffer(obs.nbytes)
+    dU, dR = DeviceBuffer(len(obs)), DeviceBuffer(B * POSE_RESULT_DTYPE.itemsize)
+    dF.upload(frames)
+    dO.upload(obs)
+    check(lib().vieo_pose_optimization_batch_device(dF.ptr, B, dO.ptr, dU.ptr, dR.ptr, None))
+    check(lib().vieo_device_synchronize())
+    res = dR.download(POSE_RESULT_DTYPE, (B,))
+    for i, (fr, ob, gt) in enumerate(cases):
+        ores, _ = oracle.pose_optimization(fr, ob)
+        dt, dr = synth_ba.pose_error(ores["nav"], res[i]["nav"])
+        assert dt < TOL and dr < TOL and res[i]["n_inliers"] == ores["n_inliers"], (i, dt, dr)

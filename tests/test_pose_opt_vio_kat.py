@@ -87,4 +87,4 @@ def test_vio_edge_cases(oracle):
 
 
 def test_vio_struct_sizes():
-    assert VIO_FRAME_DTYPE.itemsize == 3664 and VIO_RESULT_DTYPE.itemsize == 2000
+    assert VIO_FRAME_DTYPE.itemsize == 3672 and VIO_RESULT_DTYPE.itemsize == 2000

@@ -8,11 +8,16 @@ POSE_OBS_DTYPE = np.dtype([("Xw", "<f4", 3), ("u", "<f4"), ("v", "<f4"), ("ur", 
 POSE_FRAME_DTYPE = np.dtype([("nav", NAVSTATE_DTYPE), ("Rcb", "<f8", 9), ("tcb", "<f8", 3),
                              ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"),
                              ("bf", "<f4"), ("obs_begin", "<i4"), ("n_obs", "<i4"),
-                             ("n_cams", "<i4"), ("cams", "<u8")], align=True)  # cams: pointer, see vieo_hot.h
+                             ("n_cams", "<i4"), ("cams", "<u8"), ("enc", "<u8")],
+                            align=True)  # cams / enc: pointers, see vieo_hot.h
+ENC_PREINT_DTYPE = np.dtype([("dt", "<f8"), ("delx", "<f8", 6), ("Sigma", "<f8", 36)], align=True)
+POSE_ENC_DTYPE = np.dtype([("enc", ENC_PREINT_DTYPE), ("qRbe", "<f8", 4), ("pbe", "<f8", 3), ("p_last", "<f8", 3),
+                           ("q_last", "<f8", 4)], align=True)
 POSE_RESULT_DTYPE = np.dtype([("nav", NAVSTATE_DTYPE), ("n_inliers", "<i4"), ("status", "<i4"),
                               ("lm_iterations", "<i4"), ("reserved", "<i4")], align=True)
 assert NAVSTATE_DTYPE.itemsize == 176 and POSE_OBS_DTYPE.itemsize == 32
-assert POSE_FRAME_DTYPE.itemsize == 312 and POSE_RESULT_DTYPE.itemsize == 192
+assert POSE_FRAME_DTYPE.itemsize == 320 and POSE_RESULT_DTYPE.itemsize == 192
+assert ENC_PREINT_DTYPE.itemsize == 344 and POSE_ENC_DTYPE.itemsize == 456
 
 PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"),
                              ("level_min", "<i4"), ("level_max", "<i4"), ("angle", "<f4"),
@@ -54,14 +59,12 @@ LBA_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_erase", "<i4"), ("lm_iterati
                              ("lm_trials", "<i4"), ("chi2_initial", "<f8"), ("chi2_final", "<f8")],
                             align=True)
 
-ENC_PREINT_DTYPE = np.dtype([("dt", "<f8"), ("delx", "<f8", 6), ("Sigma", "<f8", 36)], align=True)
 LBA_IMU_EDGE_DTYPE = np.dtype([("kf_i", "<i4"), ("kf_j", "<i4"), ("dt_kf", "<f8"), ("imu", IMU_PREINT_DTYPE),
                                ("enc", ENC_PREINT_DTYPE)], align=True)
 LBA_VIO_PARAMS_DTYPE = np.dtype([("base", LBA_PARAMS_DTYPE), ("gw", "<f8", 3), ("inv_sigma_bg2", "<f8"),
                                  ("inv_sigma_ba2", "<f8"), ("lambda_init", "<f8"), ("rec_init", "<i4"),
                                  ("large", "<i4"), ("th_dist_far", "<f4"), ("reserved", "<i4"), ("qRbe", "<f8", 4),
                                  ("pbe", "<f8", 3)], align=True)
-assert ENC_PREINT_DTYPE.itemsize == 344
 assert LBA_IMU_EDGE_DTYPE.itemsize == 1496 and LBA_VIO_PARAMS_DTYPE.itemsize == 256
 
 # vieo_fisheye_params: cams / Trc / Tcr / level_sigma2 are host pointers the caller keeps alive

@@ -11,7 +11,7 @@
 // identical 27 doubles of J^T W J / J^T W e, and every thread then solves the 6x6 system
 // redundantly (uniform control flow, no broadcast needed).
 // FP64 throughout; parity with oracle/pose_opt.cc is <= 1e-4 on SE(3) (summation order differs).
-#include "ba_device.h"
+#include "imu_device.h"
 
 namespace vieo {
 
@@ -43,6 +43,77 @@ __device__ __forceinline__ bool ldlt6(const double* H, const double* b, double* 
   return true;
 }
 
+// ---- the optional encoder edge (EdgeEncNavStatePR between the fixed last frame and the frame, Optimizer.cc:1650-1674,
+// Huber sqrt(12.592) in all four rounds).  One 6-row edge: thread 0 evaluates it out of line (the visual loops keep
+// their registers) and publishes chi2 and its J^T (rho' Omega) J, J^T (-rho' Omega e) through LDS.
+struct PoseEncShared {
+  double Info[36], H[36], b[6], chi;
+};
+
+__device__ __noinline__ void pose_enc_setup(const vieo_pose_enc* pe, PoseEncShared* S) {
+  double M[6][12];  // Gauss-Jordan with partial pivoting, as the host does for the BA edges
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) M[i][j] = pe->enc.Sigma[i * 6 + j], M[i][6 + j] = (i == j) ? 1.0 : 0.0;
+  for (int c = 0; c < 6; c++) {
+    int piv = c;
+    for (int r = c + 1; r < 6; r++)
+      if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < 12; j++) {
+        const double t = M[c][j];
+        M[c][j] = M[piv][j], M[piv][j] = t;
+      }
+    const double d = M[c][c];
+    for (int j = 0; j < 12; j++) M[c][j] /= d;
+    for (int r = 0; r < 6; r++)
+      if (r != c) {
+        const double f = M[r][c];
+        if (f != 0)
+          for (int j = 0; j < 12; j++) M[r][j] -= f * M[c][j];
+      }
+  }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) S->Info[i * 6 + j] = M[i][6 + j];
+}
+
+__device__ __noinline__ void pose_enc_eval(const vieo_pose_enc* pe, PoseEncShared* S, const Est* est, int jac) {
+  NSd si, sj;
+  for (int k = 0; k < 3; k++) si.p[k] = pe->p_last[k], sj.p[k] = est->p[k];
+  si.qw = pe->q_last[0], si.qx = pe->q_last[1], si.qy = pe->q_last[2], si.qz = pe->q_last[3];
+  sj.qw = est->qw, sj.qx = est->qx, sj.qy = est->qy, sj.qz = est->qz;
+  double err[6], Ji[36], Jj[36];
+  enc_edge_eval(si, sj, pe->enc.delx, pe->qRbe, pe->pbe, err, jac ? Ji : nullptr, jac ? Jj : nullptr);
+  double we[6], c2 = 0;
+  for (int a = 0; a < 6; a++) {
+    double t = 0;
+    for (int q = 0; q < 6; q++) t += S->Info[a * 6 + q] * err[q];
+    we[a] = t;
+    c2 += err[a] * t;
+  }
+  const double dE = (double)(float)sqrt(12.592);
+  double r0, r1;
+  huber(c2, dE, dE * dE, &r0, &r1);
+  S->chi = r0;
+  if (!jac) return;
+  double T[36];
+  for (int a = 0; a < 6; a++)
+    for (int c = 0; c < 6; c++) {
+      double u = 0;
+      for (int q = 0; q < 6; q++) u += (r1 * S->Info[a * 6 + q]) * Jj[q * 6 + c];
+      T[a * 6 + c] = u;
+    }
+  for (int i = 0; i < 6; i++) {
+    for (int j = 0; j < 6; j++) {
+      double u = 0;
+      for (int a = 0; a < 6; a++) u += Jj[a * 6 + i] * T[a * 6 + j];
+      S->H[i * 6 + j] = u;
+    }
+    double u = 0;
+    for (int a = 0; a < 6; a++) u += Jj[a * 6 + i] * (-we[a] * r1);
+    S->b[i] = u;
+  }
+}
+
 static const int kMaxObs = 2048;  // 32 edges per lane at 64 threads per frame, 8 at 256 (bit mask per lane)
 
 // BS threads per frame: 256 for a few frames (lowest latency), 64 = one wavefront per frame for large
@@ -57,6 +128,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
   __shared__ __align__(8) unsigned char s_cam_store[sizeof(CamD) * (MC ? 4 : 1)];  // CamD has initialisers
   CamD* s_cams = reinterpret_cast<CamD*>(s_cam_store);
   __shared__ int s_bad;
+  __shared__ PoseEncShared s_enc;
   const int f = blockIdx.x, tid = threadIdx.x;
   const vieo_pose_frame& F = frames[f];
   const int N = F.n_obs;
@@ -105,6 +177,12 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
       return;
     }
   }
+  const vieo_pose_enc* pe = F.enc;
+  const bool has_enc = pe != nullptr && pe->enc.dt != 0;
+  if (has_enc) {
+    if (tid == 0) pose_enc_setup(pe, &s_enc);
+    __syncthreads();
+  }
   // `const float deltaMono = sqrt(5.991)`: double sqrt rounded to float (Optimizer.cc:1689-1690)
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
@@ -122,7 +200,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
     for (int k = 0, i = tid; i < N; k++, i += BS) cnt[0] += ((levelmask >> k) & 1) ? 0. : 1.;
     block_sum_bs<1, BS>(cnt, s_red, tid);
     Est est_err = est;  // estimate at the last computeActiveErrors (g2o does not pop edge errors)
-    if (cnt[0] > 0) {
+    if (cnt[0] > 0 || has_enc) {
       double lambda = -1, ni = 2;
       int nBadLM = 0;
       for (int iter = 0; iter < 10; iter++) {
@@ -156,7 +234,6 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
         double c1[1] = {chi};
         block_sum_bs<1, BS>(c1, s_red, tid);
         double currentChi = c1[0];
-        const double iniChi = currentChi;
         double H[36], b[6];
         {
           int t = 0;
@@ -164,6 +241,15 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
             for (int bb = a; bb < 6; bb++, t++) H[a * 6 + bb] = H[bb * 6 + a] = acc[t];
           for (int a = 0; a < 6; a++) b[a] = acc[21 + a];
         }
+        if (has_enc) {
+          __syncthreads();
+          if (tid == 0) pose_enc_eval(pe, &s_enc, &est, 1);
+          __syncthreads();
+          currentChi += s_enc.chi;
+          for (int a = 0; a < 36; a++) H[a] += s_enc.H[a];
+          for (int a = 0; a < 6; a++) b[a] += s_enc.b[a];
+        }
+        const double iniChi = currentChi;
         if (iter == 0) {  // computeLambdaInit
           double mx = 0;
           for (int j = 0; j < 6; j++) mx = fmax(fabs(H[j * 6 + j]), mx);
@@ -200,6 +286,12 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
           est_err = est;
           block_sum_bs<1, BS>(tc, s_red, tid);
           double tempChi = tc[0];
+          if (has_enc) {
+            __syncthreads();
+            if (tid == 0) pose_enc_eval(pe, &s_enc, &est, 0);
+            __syncthreads();
+            tempChi += s_enc.chi;
+          }
           if (!ok2) tempChi = DBL_MAX;
           rho = currentChi - tempChi;
           double scale = 0;
@@ -247,7 +339,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
     }
     block_sum_bs<1, BS>(nb, s_red, tid);
     nBad = (int)nb[0];
-    if (N < 10) break;  // optimizer.edges().size() < 10
+    if (N + (has_enc ? 1 : 0) < 10) break;  // optimizer.edges().size() < 10
   }
   for (int k = 0, i = tid; i < N; k++, i += BS) outl[i] = (levelmask >> k) & 1;
   if (tid == 0) {
@@ -326,6 +418,12 @@ int vieo_pose_optimization(const vieo_pose_frame* h_frame, const vieo_pose_obs* 
   if (nc > 0) {
     VIEO_HIP_CHECK(hipMemcpy(dC.p, h_frame->cams, (size_t)nc * sizeof(vieo_camera), hipMemcpyHostToDevice));
     F.cams = dC.as<vieo_camera>();
+  }
+  if (h_frame->enc) {
+    static thread_local DevBuf dE;
+    if ((rc = dE.ensure(sizeof(vieo_pose_enc))) != VIEO_OK) return rc;
+    VIEO_HIP_CHECK(hipMemcpy(dE.p, h_frame->enc, sizeof(vieo_pose_enc), hipMemcpyHostToDevice));
+    F.enc = dE.as<vieo_pose_enc>();
   }
   VIEO_HIP_CHECK(hipMemcpy(dF.p, &F, sizeof(F), hipMemcpyHostToDevice));
   if (n > 0) VIEO_HIP_CHECK(hipMemcpy(dO.p, src, (size_t)n * sizeof(vieo_pose_obs), hipMemcpyHostToDevice));

@@ -46,8 +46,9 @@ def pose_error(nav_a, nav_b):
 
 
 def make_pose_problem(seed, n_obs=300, outlier_frac=0.10, stereo_frac=0.70, noise=1.0,
-                      pert_t=0.03, pert_r_deg=1.0, rig=None):
+                      pert_t=0.03, pert_r_deg=1.0, rig=None, enc=False):
     """returns (frame[1] POSE_FRAME_DTYPE, obs[n] POSE_OBS_DTYPE, truth dict).
+    enc: attach an encoder edge to the last frame (truth["enc"] keeps the record alive).
     rig = (cams, size) from camera_rig(): monocular observations spread over the distorted cameras of the rig
     (Frame::usedistort_), camera index in bits 8..11 of obs.flags; truth["cams"] keeps the array alive."""
     rng = np.random.default_rng(seed)
@@ -92,7 +93,33 @@ def make_pose_problem(seed, n_obs=300, outlier_frac=0.10, stereo_frac=0.70, nois
     f["tcb"] = tcb
     f["fx"], f["fy"], f["cx"], f["cy"], f["bf"] = FX, FY, CX, CY, BF
     f["obs_begin"], f["n_obs"] = 0, n_obs
-    return frame, obs, {"p": p_gt, "q": q_gt, "is_outlier": is_out}
+    gt = {"p": p_gt, "q": q_gt, "is_outlier": is_out}
+    if enc:
+        gt["enc"] = make_pose_enc(np.random.default_rng(seed + 4242), p_gt, q_gt)
+        f["enc"] = gt["enc"].ctypes.data
+    return frame, obs, gt
+
+
+def make_pose_enc(rng, p_cur, q_cur, noise=1.0):
+    """vieo_pose_enc for a frame whose TRUE pose is (p_cur, q_cur): a last frame 0.05 s earlier on a smooth motion
+    and the wheel-odometry pre-integration between the two (consistent up to the sensor noise)."""
+    from .ba_types import POSE_ENC_DTYPE
+    E = np.zeros(1, POSE_ENC_DTYPE)
+    Rj = quat_to_R(q_cur)
+    Ri = Rj @ so3_exp(rng.normal(0, 0.02, 3)).T
+    pi_ = p_cur - Rj @ rng.normal(0, 0.03, 3)
+    Reb = ENC_RBE.T
+    dR = Reb @ Ri.T @ Rj @ ENC_RBE
+    dp = Reb @ (Ri.T @ (p_cur - pi_) - ENC_PBE + Ri.T @ Rj @ ENC_PBE)
+    sphi, sp = 2e-3, 5e-3
+    e = E[0]
+    e["enc"]["dt"] = 0.05
+    e["enc"]["delx"][:3] = so3_log_np(dR) + rng.normal(0, sphi, 3) * noise
+    e["enc"]["delx"][3:] = dp + rng.normal(0, sp, 3) * noise
+    e["enc"]["Sigma"] = np.diag([sphi ** 2] * 3 + [sp ** 2] * 3).reshape(-1)
+    e["qRbe"], e["pbe"] = _R_to_quat(ENC_RBE), ENC_PBE
+    e["p_last"], e["q_last"] = pi_, _R_to_quat(Ri)
+    return E
 
 
 def _make_pose_problem_rig(rng, n_obs, outlier_frac, noise, pert_t, pert_r_deg, rig):
