@@ -347,7 +347,7 @@ typedef struct vieo_pose_result {
 } vieo_pose_result;
 
 /* int Optimizer::PoseOptimization(Frame* pFrame, Frame* pLastF = NULL) (src/Optimizer.cc:1611-1874),
- * vision-only motion BA without the optional encoder edge: 4 rounds of optimize(10) from the
+ * vision-only motion BA (the optional encoder edge to the last frame: `enc`): 4 rounds of optimize(10) from the
  * initial estimate, chi2 classification 5.991 / 7.815 after each round, Huber off after round 3.
  * h_outlier[n_obs] receives mvbOutlier of the matched keypoints. */
 int vieo_pose_optimization(const vieo_pose_frame* h_frame, const vieo_pose_obs* h_obs,
@@ -365,7 +365,8 @@ int vieo_pose_optimization_batch_device(const vieo_pose_frame* d_frames, int n_f
  * Vertices: PVR_j (9) + Bias_j (6) free; PVR_i + Bias_i of the last (key)frame fixed unless it
  * carries a prior (mbPrior).  Edges: EdgeNavStatePVR (IMU pre-integration, g2otypes.h:703-884),
  * EdgeNavStateBias (g2otypes.cpp:14-34), EdgeNavStatePriorPVRBias (g2otypes.cpp:84-124),
- * EdgeReprojectPVR / PVRStereo per correspondence.  No encoder edge. */
+ * EdgeReprojectPVR / PVRStereo per correspondence.  The encoder edge of THIS variant (EdgeEncNavStatePVR, which also
+ * enters the marginal prior) is not built: base.enc must be NULL or carry dt == 0. */
 typedef struct vieo_imu_preint { /* IMUPreIntegratorBase (src/Odom/OdomPreIntegrator.h:108-147) */
   double dt;                     /* mdeltatij; 0 => no IMU edge */
   double Rij[9];                 /* mRij, row-major */
@@ -530,7 +531,8 @@ int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_par
  * form weighs the inertial and bias edges leaving a fixed key frame by 1e-2 like the reference.  Reduced systems
  * beyond 510 unknowns are factorised by the tiled LDL^T (FP64 matrix cores); up to 16320 unknowns.
  * params->its0 / its1 (and lambda_init / rec_init / large of the VIO params) are ignored.  Not covered: the scale
- * vertex (bScaleOpt), the gravity vertex of the IMU initialiser, encoder edges. */
+ * vertex (bScaleOpt), the gravity vertex of the IMU initialiser; encoder edges only in the visual-inertial form
+ * (vieo_lba_imu_edge.enc), not in vieo_bundle_adjustment (bEnc). */
 int vieo_bundle_adjustment(const vieo_lba_params* params, int n_iterations, int robust,
                            const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
                            const vieo_lba_obs* h_obs, int n_obs, volatile const int* stop, vieo_navstate* h_navs_out,
