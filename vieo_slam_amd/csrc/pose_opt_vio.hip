@@ -804,6 +804,10 @@ int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_ob
     set_error("PoseOptimization (VIO): n_cams = %d (0..4) needs `cams`", nc);
     return VIEO_E_INVALID;
   }
+  if (h_frame->base.enc && h_frame->base.enc->enc.dt != 0) {
+    set_error("PoseOptimization (VIO): the encoder edge of this variant is not built (base.enc must be NULL)");
+    return VIEO_E_INVALID;
+  }
   if ((rc = dF.ensure(sizeof(vieo_vio_frame))) != VIEO_OK) return rc;
   if ((rc = dC.ensure(4 * sizeof(vieo_camera))) != VIEO_OK) return rc;
   if ((rc = dO.ensure((size_t)std::max(n, 1) * sizeof(vieo_pose_obs))) != VIEO_OK) return rc;
