@@ -335,6 +335,13 @@ typedef struct vieo_pose_frame {
 #define VIEO_POSE_CAMS_RECTIFIED 1 /* every frame has n_cams == 0 (Frame::usedistort_ false) */
 #define VIEO_POSE_CAMS_RIG 2       /* every frame has n_cams > 0 */
 int vieo_pose_set_camera_mode(int mode);
+/* The same for the encoder edge of vieo_pose_optimization_vio_batch_device (EdgeEncNavStatePVR, Optimizer.h:345-363):
+ * frames with base.enc->enc.dt != 0 run in their own kernel instance.  (The vision-only kernel branches at run
+ * time and ignores this mode.) */
+#define VIEO_POSE_ENC_AUTO 0
+#define VIEO_POSE_ENC_NONE 1 /* no frame carries an encoder measurement (Frame::GetEncPreInt().mdeltatij == 0) */
+#define VIEO_POSE_ENC_ALL 2  /* every frame carries one */
+int vieo_pose_set_encoder_mode(int mode);
 
 #define VIEO_POSE_OK 0
 #define VIEO_POSE_TOO_FEW 1 /* < 3 correspondences: the reference returns 0 and leaves the pose */
@@ -365,8 +372,10 @@ int vieo_pose_optimization_batch_device(const vieo_pose_frame* d_frames, int n_f
  * Vertices: PVR_j (9) + Bias_j (6) free; PVR_i + Bias_i of the last (key)frame fixed unless it
  * carries a prior (mbPrior).  Edges: EdgeNavStatePVR (IMU pre-integration, g2otypes.h:703-884),
  * EdgeNavStateBias (g2otypes.cpp:14-34), EdgeNavStatePriorPVRBias (g2otypes.cpp:84-124),
- * EdgeReprojectPVR / PVRStereo per correspondence.  The encoder edge of THIS variant (EdgeEncNavStatePVR, which also
- * enters the marginal prior) is not built: base.enc must be NULL or carry dt == 0. */
+ * EdgeReprojectPVR / PVRStereo per correspondence, and EdgeEncNavStatePVR (g2otypes.h:591-668, Optimizer.h:345-363)
+ * when base.enc carries a measurement: between PVR_i and PVR_j (base.enc->p_last / q_last are not read here, the
+ * last state is nav_last), Huber sqrt(12.592), information Sigma_E^-1; it also enters the marginal prior
+ * (FillCovInv, Optimizer.h:195-204) and counts as the odometry edge that keeps the estimate between the rounds. */
 typedef struct vieo_imu_preint { /* IMUPreIntegratorBase (src/Odom/OdomPreIntegrator.h:108-147) */
   double dt;                     /* mdeltatij; 0 => no IMU edge */
   double Rij[9];                 /* mRij, row-major */

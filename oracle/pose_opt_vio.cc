@@ -9,7 +9,8 @@
 //   EdgeNavStatePriorPVRBias                src/Odom/g2otypes.cpp:84-124
 //   EdgeReprojectPVR / PVRStereo            src/Odom/g2otypes.h:321-547
 //   NavState::IncSmall(dPVR), IncSmallBias  src/Odom/NavState.h:64-83
-// and the g2o machinery as in pose_opt.cc (LM, Huber, dense LDLT).  No encoder edge.
+//   EdgeEncNavState<9> = EdgeEncNavStatePVR src/Odom/g2otypes.h:591-668   (enc_edge.hpp; Optimizer.h:345-363)
+// and the g2o machinery as in pose_opt.cc (LM, Huber, dense LDLT).
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -20,6 +21,7 @@
 
 #include "../include/vieo_hot.h"
 #include "cam_models.hpp"
+#include "enc_edge.hpp"
 #include "smallmat.hpp"
 
 namespace vo {
@@ -144,7 +146,10 @@ struct Problem {
   NS prior;          // measurement of the prior edge
   bool fixedLast, hasImu;
   double InfoI[81];  // IMU information (already scaled)
-  GEdge eI, eB, eP;
+  GEdge eI, eB, eP, eE;
+  bool hasEnc = false;  // EdgeEncNavStatePVR between PVRi (vertex 0 of the edge) and PVRj
+  Quat qRbe;
+  double pbe[3], measE[6];
   std::vector<VisEdge> vis;
   int ndim;  // 15 or 30
 
@@ -350,21 +355,39 @@ struct Problem {
       inc_bias(nsi, x + 24);
     }
   }
+  // ---- encoder edge: enc_edge.hpp gives (dp, dphi) columns; PVR vertices hold them at 0..2 and 6..8
+  void enc_eval(bool jac) {
+    EncPose si, sj;
+    memcpy(si.p, nsi.p, 24), memcpy(sj.p, nsj.p, 24);
+    si.q = nsi.q, sj.q = nsj.q;
+    double Ji[36], Jj[36];
+    enc_edge_eval(si, sj, measE, qRbe, pbe, eE.err.data(), jac ? Ji : nullptr, jac ? Jj : nullptr);
+    if (!jac) return;
+    eE.J[0] = Dense(6, 9), eE.J[1] = Dense(6, 9);
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 3; c++) {
+        eE.J[0](r, c) = Ji[r * 6 + c], eE.J[0](r, 6 + c) = Ji[r * 6 + 3 + c];
+        eE.J[1](r, c) = Jj[r * 6 + c], eE.J[1](r, 6 + c) = Jj[r * 6 + 3 + c];
+      }
+  }
   std::vector<GEdge*> generic_edges() {
     std::vector<GEdge*> g;
     if (hasImu) g.push_back(&eI);
     g.push_back(&eB);
     if (!fixedLast) g.push_back(&eP);
+    if (hasEnc) g.push_back(&eE);
     return g;
   }
   void compute_generic_errors() {
     if (hasImu) imu_error();
     bias_error();
     if (!fixedLast) prior_error();
+    if (hasEnc) enc_eval(false);
   }
   void linearize_generic() {
     if (hasImu) imu_linearize();
     if (!fixedLast) prior_linearize();
+    if (hasEnc) enc_eval(true);
   }
 };
 
@@ -611,6 +634,24 @@ static void pose_optimization_vio(const vieo_vio_frame& F, const vieo_pose_obs* 
     e.delta = sqrt(25);
     e.dsqr = e.delta * e.delta;
   }
+  if (F.base.enc && F.base.enc->enc.dt != 0) {  // ---- encoder edge (Optimizer.h:345-363)
+    bodom_edge = true;
+    P.hasEnc = true;
+    const vieo_pose_enc& pe = *F.base.enc;
+    GEdge& e = P.eE;
+    e.D = 6, e.nv = 2;
+    e.vid[0] = 2, e.vid[1] = 0;
+    e.err.assign(6, 0.0);
+    e.info = Dense(6, 6);
+    double Inv[36];
+    gj_inverse(pe.enc.Sigma, Inv, 6);
+    for (int i = 0; i < 36; i++) e.info.a[i] = Inv[i];
+    memcpy(P.measE, pe.enc.delx, 48), memcpy(P.pbe, pe.pbe, 24);
+    P.qRbe.w = pe.qRbe[0], P.qRbe.x = pe.qRbe[1], P.qRbe.y = pe.qRbe[2], P.qRbe.z = pe.qRbe[3];
+    e.robust = true;
+    e.delta = sqrt(12.592);
+    e.dsqr = e.delta * e.delta;
+  }
   // ---- visual edges
   const int N = F.base.n_obs;
   P.vis.resize(N);
@@ -641,7 +682,7 @@ static void pose_optimization_vio(const vieo_vio_frame& F, const vieo_pose_obs* 
   }
   const float chi2Mono[4] = {5.991, 5.991, 5.991, 5.991};
   const float chi2Stereo[4] = {7.815, 7.815, 7.815, 7.815};
-  const int n_edges_total = N + (P.hasImu ? 1 : 0) + 1 + (P.fixedLast ? 0 : 1);
+  const int n_edges_total = N + (P.hasImu ? 1 : 0) + 1 + (P.fixedLast ? 0 : 1) + (P.hasEnc ? 1 : 0);
   for (size_t it = 0; it < 4; it++) {
     if (!bodom_edge) {  // Optimizer.h:538-545
       P.nsj = nsj0;
@@ -704,6 +745,14 @@ static void pose_optimization_vio(const vieo_vio_frame& F, const vieo_pose_obs* 
     double cov[225] = {0};
     if (P.hasImu) P.imu_error();
     P.bias_error();
+    if (P.hasEnc) P.enc_eval(true);  // Optimizer.h:672 computeError; the Jacobians depend on the state only
+    double encXj[81], encXi[81], encXji[81];
+    if (P.hasEnc) {  // getHessianXj / Xi / Xji of FillCovInv :195-204
+      const double w = edge_rho1(P.eE);
+      JtWK(P.eE.J[1], P.eE.info, w, P.eE.J[1], encXj, 9, false);
+      JtWK(P.eE.J[0], P.eE.info, w, P.eE.J[0], encXi, 9, false);
+      JtWK(P.eE.J[1], P.eE.info, w, P.eE.J[0], encXji, 9, false);
+    }
     // FillCovInv(schur_bec = 0)
     if (P.hasImu) {
       P.imu_linearize();
@@ -733,6 +782,9 @@ static void pose_optimization_vio(const vieo_vio_frame& F, const vieo_pose_obs* 
             cov[i * 15 + j] += s;
           }
       }
+    if (P.hasEnc)
+      for (int i = 0; i < 9; i++)
+        for (int j = 0; j < 9; j++) cov[i * 15 + j] += encXj[i * 9 + j];
     if (!P.fixedLast) {
       double C[225] = {0}, E[225] = {0};
       P.prior_error();
@@ -771,6 +823,9 @@ static void pose_optimization_vio(const vieo_vio_frame& F, const vieo_pose_obs* 
         for (int i = 0; i < 9; i++)
           for (int j = 0; j < 6; j++) C[(9 + j) * 15 + i] = C[i * 15 + 9 + j];
       }
+      if (P.hasEnc)
+        for (int i = 0; i < 9; i++)
+          for (int j = 0; j < 9; j++) C[i * 15 + j] += encXi[i * 9 + j];
       // schur_bec = 1 : cross block (cur, last)
       if (P.hasImu) {
         const double w = edge_rho1(P.eI);
@@ -787,6 +842,9 @@ static void pose_optimization_vio(const vieo_vio_frame& F, const vieo_pose_obs* 
         for (int i = 0; i < 6; i++)
           for (int j = 0; j < 6; j++) E[(9 + i) * 15 + 9 + j] = -(w * P.eB.info(i, j));
       }
+      if (P.hasEnc)
+        for (int i = 0; i < 9; i++)
+          for (int j = 0; j < 9; j++) E[i * 15 + j] += encXji[i * 9 + j];
       // margH = B - E C^-1 E^T  (C^-1 through the SVD pseudo-inverse without threshold = inverse)
       double Cinv[225], T[225];
       mat_inverse(C, Cinv, 15);

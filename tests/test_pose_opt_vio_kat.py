@@ -86,5 +86,54 @@ def test_vio_edge_cases(oracle):
     assert r["base"]["n_inliers"] <= 40
 
 
+def test_vio_encoder_edge(oracle):
+    """EdgeEncNavStatePVR (Optimizer.h:345-363, g2otypes.h:591-668): the wheel odometry constrains a weak visual
+    problem; it adds its Hessians to the three blocks of the marginal prior (FillCovInv :195-204); without an IMU
+    measurement it is the odometry edge that keeps the estimate between the rounds (bodom_edge)."""
+    e0 = e1 = 0
+    for seed in range(6):
+        kw = dict(n_obs=25, noise=2.5, outlier_frac=0.0, imu=False)
+        F, obs, gt = synth_ba.make_vio_problem(seed, **kw)
+        r0, _ = oracle.pose_optimization_vio(F, obs)
+        F, obs, gt = synth_ba.make_vio_problem(seed, enc=True, **kw)
+        r1, _ = oracle.pose_optimization_vio(F, obs)
+        e0 += synth_ba.pose_error(r0["base"]["nav"], gt)[0]
+        e1 += synth_ba.pose_error(r1["base"]["nav"], gt)[0]
+    assert e1 < 0.6 * e0, (e0, e1)
+    # marginal prior, last state fixed: B gains Jj^T W Jj on the (p, phi) rows only -- the difference to the run
+    # without the edge at (nearly) the same estimate is positive semi-definite and leaves the V rows alone
+    F, obs, gt = synth_ba.make_vio_problem(3, compute_marg=True, noise=0.0, outlier_frac=0.0)
+    a, _ = oracle.pose_optimization_vio(F, obs)
+    F, obs, gt = synth_ba.make_vio_problem(3, compute_marg=True, noise=0.0, outlier_frac=0.0, enc=True)
+    b, _ = oracle.pose_optimization_vio(F, obs)
+    D = (b["H_marg"] - a["H_marg"]).reshape(15, 15)
+    pr = [0, 1, 2, 6, 7, 8]
+    assert np.linalg.eigvalsh(D[np.ix_(pr, pr)]).max() > 1e3          # information of a 2 mrad / 5 mm sensor
+    scale = np.abs(D[np.ix_(pr, pr)]).max()
+    assert np.abs(D[3:6, :]).max() < 1e-3 * scale and np.abs(D[9:, 9:]).max() < 1e-3 * scale
+    assert np.linalg.eigvalsh((D + D.T)[np.ix_(pr, pr)] / 2).min() > -1e-3 * scale
+    # free last state + prior: finite, symmetric, and still different from the run without the edge
+    F0, obs0, _ = synth_ba.make_vio_problem(40, compute_marg=True)
+    r0, _ = oracle.pose_optimization_vio(F0, obs0)
+    F1, obs1, gt1 = synth_ba.make_vio_problem(41, compute_marg=True)
+    nav_last = F1[0]["nav_last"].copy()
+    prior = (nav_last.copy(), r0["H_marg"].reshape(15, 15), nav_last)
+    Fa, _, _ = synth_ba.make_vio_problem(41, compute_marg=True, prior=prior)
+    Fb, _, gtb = synth_ba.make_vio_problem(41, compute_marg=True, prior=prior, enc=True)
+    ra, _ = oracle.pose_optimization_vio(Fa, obs1)
+    rb, _ = oracle.pose_optimization_vio(Fb, obs1)
+    Ha, Hb = ra["H_marg"].reshape(15, 15), rb["H_marg"].reshape(15, 15)
+    assert np.isfinite(Hb).all() and np.allclose(Hb, Hb.T, rtol=1e-6, atol=1e-6 * np.abs(Hb).max())
+    assert np.abs(Hb - Ha).max() > 1e2  # (most of the gain cancels in B - E C^-1 E^T: both ends carry the edge)
+    e = synth_ba.pose_error(rb["base"]["nav"], gtb)
+    assert e[0] < 5e-3 and e[1] < 2e-3
+    # the edge counts in `edges().size() < 10`: 7 visual + bias + IMU = 9 edges stop after one round, 10 do not
+    F, obs, _ = synth_ba.make_vio_problem(53, n_obs=7, outlier_frac=0.0)
+    a, _ = oracle.pose_optimization_vio(F, obs)
+    F, obs, _ = synth_ba.make_vio_problem(53, n_obs=7, outlier_frac=0.0, enc=True)
+    b, _ = oracle.pose_optimization_vio(F, obs)
+    assert b["base"]["lm_iterations"] > a["base"]["lm_iterations"]
+
+
 def test_vio_struct_sizes():
     assert VIO_FRAME_DTYPE.itemsize == 3672 and VIO_RESULT_DTYPE.itemsize == 2000

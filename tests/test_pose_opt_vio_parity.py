@@ -154,3 +154,93 @@ def test_vio_camera_rig_parity(oracle, name, seed, marg):
     assert F[0]["base"]["n_cams"] == len(rig[0])
     o, h = _cmp(oracle, F, obs)
     assert o["base"]["n_inliers"] > 200
+
+
+@pytest.mark.parametrize("seed,n,kw", [(80, 300, dict(compute_marg=True)), (81, 60, dict(compute_marg=True, noise=2.0)),
+                                       (82, 200, dict(imu=False, compute_marg=True)),
+                                       (83, 40, dict(outlier_frac=0.5, compute_marg=True)),
+                                       (84, 7, dict(outlier_frac=0.0))])
+def test_vio_encoder_edge_parity(oracle, seed, n, kw):
+    """a16: EdgeEncNavStatePVR between the last frame and the current one (Optimizer.h:345-363), also inside the
+    marginal prior (FillCovInv :195-204); without an IMU measurement it is the only odometry edge."""
+    F, obs, gt = synth_ba.make_vio_problem(seed, n_obs=n, enc=True, **kw)
+    o, h = _cmp(oracle, F, obs)
+    F0, _, _ = synth_ba.make_vio_problem(seed, n_obs=n, **kw)
+    from vieo_slam_amd.optimizer import Optimizer
+    h0, _ = Optimizer.PoseOptimizationVIO(F0, obs)
+    assert not np.array_equal(h0["base"]["nav"]["p"], h["base"]["nav"]["p"])  # the edge is in the system
+
+
+@pytest.mark.parametrize("rigname", [None, "kb8"])
+def test_vio_encoder_edge_free_last_parity(oracle, rigname):
+    """30-dim system: the encoder edge couples the two PVR vertices and enters B, C and E of the Schur complement."""
+    kw = dict(rig=synth_ba.camera_rig(rigname)) if rigname else {}
+    F0, obs0, _ = synth_ba.make_vio_problem(90, compute_marg=True)
+    r0, _ = oracle.pose_optimization_vio(F0, obs0)
+    F1, obs1, _ = synth_ba.make_vio_problem(91, compute_marg=True, **kw)
+    nav_last = F1[0]["nav_last"].copy()
+    nav_prior = nav_last.copy()
+    nav_last["p"] += 0.004
+    nav_last["v"] += 0.015
+    F1b, _, gt = synth_ba.make_vio_problem(91, compute_marg=True, enc=True,
+                                           prior=(nav_prior, r0["H_marg"].reshape(15, 15), nav_last), **kw)
+    _cmp(oracle, F1b, obs1, marg_rtol=1e-4)
+
+
+def test_vio_encoder_mode_and_mixed_device_batch(oracle):
+    """vieo_pose_set_encoder_mode: a batch that mixes frames with and without an encoder measurement (and, here,
+    rectified and rig frames) needs AUTO -- four kernel instances, each skips the others' frames; under NONE a
+    frame that carries a measurement is refused loudly (status VIEO_E_INVALID), never optimised without it."""
+    from vieo_slam_amd.ba_types import POSE_ENC_DTYPE
+    rig = synth_ba.camera_rig("radtan")
+    B = 8
+    frames = np.zeros(B, VIO_FRAME_DTYPE)
+    encs = np.zeros(B, POSE_ENC_DTYPE)
+    keep, all_obs, begin = [], [], 0
+    for i in range(B):
+        F, obs, gt = synth_ba.make_vio_problem(500 + i, n_obs=100 + 30 * i, compute_marg=(i % 3 == 0), enc=(i % 2 == 0),
+                                               **(dict(rig=rig) if i % 4 >= 2 else {}))
+        keep.append((F, obs, gt))
+        frames[i] = F[0]
+        frames[i]["base"]["obs_begin"] = begin
+        begin += len(obs)
+        all_obs.append(obs)
+        if i % 2 == 0:
+            encs[i] = gt["enc"][0]
+    obs = np.concatenate(all_obs)
+    dC, dE = DeviceBuffer(rig[0].nbytes), DeviceBuffer(encs.nbytes)
+    dC.upload(rig[0])
+    dE.upload(encs)
+    for i in range(B):
+        frames[i]["base"]["enc"] = dE.ptr + i * POSE_ENC_DTYPE.itemsize if i % 2 == 0 else 0
+        frames[i]["base"]["cams"] = dC.ptr if i % 4 >= 2 else 0
+    dF, dO = DeviceBuffer(frames.nbytes), DeviceBuffer(obs.nbytes)
+    dU, dR = DeviceBuffer(len(obs)), DeviceBuffer(B * VIO_RESULT_DTYPE.itemsize)
+    dF.upload(frames)
+    dO.upload(obs)
+    try:
+        for mode in (0, 1, 2):
+            check(lib().vieo_pose_set_encoder_mode(mode))
+            dR.upload(np.zeros(B, VIO_RESULT_DTYPE))
+            check(lib().vieo_pose_optimization_vio_batch_device(dF.ptr, B, dO.ptr, dU.ptr, dR.ptr, None))
+            check(lib().vieo_device_synchronize())
+            res = dR.download(VIO_RESULT_DTYPE, (B,))
+            outl = dU.download(np.uint8, (len(obs),))
+            for i in range(B):
+                has = i % 2 == 0
+                if (mode == 1 and has) or (mode == 2 and not has):
+                    assert res[i]["base"]["status"] < 0 and res[i]["base"]["n_inliers"] == 0, (mode, i)
+                    continue
+                F, ob, _ = keep[i]
+                o, oo = oracle.pose_optimization_vio(F, ob)
+                b, n = frames[i]["base"]["obs_begin"], frames[i]["base"]["n_obs"]
+                dt, dr = synth_ba.pose_error(o["base"]["nav"], res[i]["base"]["nav"])
+                assert dt < TOL and dr < TOL, (mode, i, dt, dr)
+                assert res[i]["base"]["n_inliers"] == o["base"]["n_inliers"] and res[i]["base"]["status"] == 0
+                assert np.array_equal(oo, outl[b:b + n])
+                if o["has_marg"]:
+                    Ho = o["H_marg"].reshape(15, 15)
+                    assert np.allclose(Ho, res[i]["H_marg"].reshape(15, 15), rtol=1e-4, atol=1e-4 * np.abs(Ho).max())
+        assert lib().vieo_pose_set_encoder_mode(3) != 0
+    finally:
+        check(lib().vieo_pose_set_encoder_mode(0))

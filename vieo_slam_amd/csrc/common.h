@@ -52,5 +52,8 @@ int require_device();  // VIEO_OK or VIEO_E_NO_DEVICE
 // which pose-optimisation kernels a *_batch_device call launches: bit 0 the rectified-pinhole instance,
 // bit 1 the multi-camera-rig instance (vieo_pose_set_camera_mode)
 int pose_rig_launches();
+// the same for the visual-inertial kernel's encoder instances: bit 0 frames without an encoder measurement,
+// bit 1 frames with one (vieo_pose_set_encoder_mode)
+int pose_enc_launches();
 
 }  // namespace vieo

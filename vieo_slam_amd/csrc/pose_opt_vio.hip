@@ -172,16 +172,70 @@ struct VioShared {
   int ok;
 };
 
+// EdgeEncNavStatePVR (g2otypes.h:591-668, Optimizer.h:345-363) of the ENC instance: one lane evaluates the
+// 6-row edge, the block folds J = [Jj | Ji] (columns (dp, dphi) of the two PVR vertices) into the system.
+struct VioEncShared {
+  double Info[36], err[6], we[6], chi, J[6 * 12], T[6 * 12];
+};
+
+__device__ __noinline__ void vio_enc_setup(const vieo_pose_enc* pe, VioEncShared* S) {
+  double M[6][12];  // Sigma_E^-1 by Gauss-Jordan with partial pivoting
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) M[i][j] = pe->enc.Sigma[i * 6 + j], M[i][6 + j] = (i == j) ? 1.0 : 0.0;
+  for (int c = 0; c < 6; c++) {
+    int piv = c;
+    for (int r = c + 1; r < 6; r++)
+      if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < 12; j++) {
+        const double t = M[c][j];
+        M[c][j] = M[piv][j], M[piv][j] = t;
+      }
+    const double d = M[c][c];
+    for (int j = 0; j < 12; j++) M[c][j] /= d;
+    for (int r = 0; r < 6; r++)
+      if (r != c) {
+        const double f = M[r][c];
+        if (f != 0)
+          for (int j = 0; j < 12; j++) M[r][j] -= f * M[c][j];
+      }
+  }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) S->Info[i * 6 + j] = M[i][6 + j];
+}
+
+__device__ __noinline__ void vio_enc_eval(const vieo_pose_enc* pe, VioEncShared* S, const NSd* nsi, const NSd* nsj,
+                                          int jac) {
+  const NSd si = *nsi, sj = *nsj;
+  double err[6], Ji[36], Jj[36];
+  enc_edge_eval(si, sj, pe->enc.delx, pe->qRbe, pe->pbe, err, jac ? Ji : nullptr, jac ? Jj : nullptr);
+  double c2 = 0;
+  for (int a = 0; a < 6; a++) {
+    double t = 0;
+    for (int q = 0; q < 6; q++) t += S->Info[a * 6 + q] * err[q];
+    S->err[a] = err[a], S->we[a] = t;
+    c2 += err[a] * t;
+  }
+  S->chi = c2;
+  if (!jac) return;
+  for (int a = 0; a < 6; a++)
+    for (int q = 0; q < 6; q++) S->J[a * 12 + q] = Jj[a * 6 + q], S->J[a * 12 + 6 + q] = Ji[a * 6 + q];
+}
+
 // BS threads per frame: 256 (four wavefronts share a frame: lowest latency for a few frames) or 64
 // (one wavefront per frame, four frames per CU in flight: highest throughput for large batches)
 // MC as in pose_opt.hip: the instance for frames of a distorted multi-camera rig (n_cams > 0, a20)
-template <int BS, bool MC>
+// ENC: the instance for frames that carry an encoder measurement (base.enc with dt != 0, a16)
+// other_launched: bit 0 the other camera kind, bit 1 the other encoder kind has its own launch in this batch
+template <int BS, bool MC, bool ENC>
 __global__ void __launch_bounds__(BS)
 k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
                uint8_t* __restrict__ outlier_all, vieo_vio_result* __restrict__ results, int other_launched) {
   __shared__ VioShared S;
   __shared__ __align__(8) unsigned char s_cam_store[sizeof(CamD) * (MC ? 4 : 1)];  // CamD has initialisers
   CamD* s_cams = reinterpret_cast<CamD*>(s_cam_store);
+  __shared__ __align__(8) unsigned char s_enc_store[ENC ? sizeof(VioEncShared) : 8];
+  VioEncShared* SE = reinterpret_cast<VioEncShared*>(s_enc_store);
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T1 = BS > 64 ? 64 : 0, T2 = BS > 128 ? 128 : 0;  // lanes of the second / third serial role
   const vieo_vio_frame& F = frames[f];
@@ -189,9 +243,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const vieo_pose_obs* obs = obs_all + F.base.obs_begin;
   uint8_t* outl = outlier_all + F.base.obs_begin;
   vieo_vio_result* R = results + f;
-  const bool other_kind = (F.base.n_cams > 0) != MC;
-  if (other_kind && other_launched) return;
-  bool bad_cams = other_kind;  // vieo_pose_set_camera_mode promised frames of the other kind only
+  const vieo_pose_enc* pe = F.base.enc;
+  const bool cam_other = (F.base.n_cams > 0) != MC, enc_other = (pe != nullptr && pe->enc.dt != 0) != ENC;
+  if ((cam_other && (other_launched & 1)) || (enc_other && (other_launched & 2))) return;
+  const bool other_kind = cam_other || enc_other;
+  bool bad_cams = other_kind;  // vieo_pose_set_camera_mode / _encoder_mode promised frames of the other kind only
   if (MC && !other_kind) {
     if (tid == 0) S.ok = !(F.base.n_cams > 4 || !F.base.cams);
     __syncthreads();
@@ -221,7 +277,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   for (int i = 0; i < 3; i++) c.tcb[i] = F.base.tcb[i];
   const bool fixedLast = !F.last_has_prior, hasImu = F.imu.dt != 0;
   const int n = fixedLast ? 15 : 30;
-  const bool bodom = hasImu;
+  const bool bodom = hasImu || ENC;
   const double gw[3] = {F.gw[0], F.gw[1], F.gw[2]};
   // ---- constant edge data
   if (tid == 0) {
@@ -229,6 +285,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     ns_load(S.nsi, F.nav_last);
     ns_load(S.prior, F.nav_prior);
   }
+  if (ENC && tid == T2) vio_enc_setup(pe, SE);
   // IMU information = Sigma^-1 (x 1e-2 when the last state is fixed): Gauss-Jordan by one wave
   if (hasImu && wave == 0) {
     double* M = S.Cinv;  // 9 x 18 augmented
@@ -272,24 +329,27 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const double deltatij = F.imu.dt ? F.imu.dt : F.dt_frames;
   const double infoBg = F.inv_sigma_bg2 / deltatij * (fixedLast ? 1e-2 : 1.0);
   const double infoBa = F.inv_sigma_ba2 / deltatij * (fixedLast ? 1e-2 : 1.0);
-  const double dI = sqrt(16.919), dB = sqrt(12.592), dP = sqrt(25.0);
+  const double dI = sqrt(16.919), dB = sqrt(12.592), dP = sqrt(25.0), dE = sqrt(12.592);
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
   const NSd nsj0 = S.nsj, nsi0 = S.nsi;
   unsigned levelmask = 0;
   bool vis_robust = true;
   int nBad = 0, total_iters = 0;
-  const int n_edges_total = N + (hasImu ? 1 : 0) + 1 + (fixedLast ? 0 : 1);
+  const int n_edges_total = N + (hasImu ? 1 : 0) + 1 + (fixedLast ? 0 : 1) + (ENC ? 1 : 0);
+  double rhoE = 1.0;  // rho' of the encoder edge at the last generic_errors()
 
   // generic-edge errors at the current LDS state; returns (robust chi2 sum, rho' of I, B, P)
   auto generic_errors = [&](double* rhoI, double* rhoB, double* rhoP) -> double {
     if (tid == 0 && hasImu) imu_error(F.imu, gw, S.nsi, S.nsj, S.errI);
     if (tid == T1 && !fixedLast) prior_error(S.prior, S.nsi, S.errP);
-    if (tid == T2)
+    if (tid == T2) {
       for (int k = 0; k < 3; k++) {
         S.errB[k] = (S.nsj.bg[k] + S.nsj.dbg[k]) - (S.nsi.bg[k] + S.nsi.dbg[k]);
         S.errB[3 + k] = (S.nsj.ba[k] + S.nsj.dba[k]) - (S.nsi.ba[k] + S.nsi.dba[k]);
       }
+      if (ENC) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 0);
+    }
     __syncthreads();
     if (hasImu && tid < 9) {
       double t = 0;
@@ -325,6 +385,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       for (int i = 0; i < 15; i++) e += S.errP[i] * S.wP[i];
       double r0 = e;
       huber(e, dP, dP * dP, &r0, rhoP);
+      chi += r0;
+    }
+    if (ENC) {
+      double r0;
+      huber(SE->chi, dE, dE * dE, &r0, &rhoE);
       chi += r0;
     }
     return chi;
@@ -408,6 +473,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       // generic Jacobians
       if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
       if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
+      if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
+      const double rhoE0 = rhoE;  // the trial evaluations below overwrite rhoE
       for (int i = tid; i < n * n; i += BS) S.H[i] = 0;
       if (tid < n) S.b[tid] = 0;
       __syncthreads();
@@ -465,6 +532,29 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           double t = 0;
           for (int a = 0; a < 15; a++) t += S.JP[a * 15 + tid] * (-S.wP[a] * rhoP);
           S.b[15 + tid] += t;
+        }
+        __syncthreads();
+      }
+      if (ENC) {  // T = (rho' Info) [Jj | Ji], H += J^T T on the (p, phi) rows of the PVR vertices
+        const int nc = fixedLast ? 6 : 12;
+        for (int eidx = tid; eidx < 72; eidx += BS) {
+          const int a = eidx / 12, cc = eidx % 12;
+          double t = 0;
+          for (int q = 0; q < 6; q++) t += (rhoE0 * SE->Info[a * 6 + q]) * SE->J[q * 12 + cc];
+          SE->T[eidx] = t;
+        }
+        __syncthreads();
+        for (int eidx = tid; eidx < nc * nc; eidx += BS) {
+          const int c1 = eidx / nc, c2 = eidx % nc;
+          double t = 0;
+          for (int a = 0; a < 6; a++) t += SE->J[a * 12 + c1] * SE->T[a * 12 + c2];
+          const int s1 = (c1 < 6 ? 0 : 9) + c1 + (c1 % 6 < 3 ? 0 : 3), s2 = (c2 < 6 ? 0 : 9) + c2 + (c2 % 6 < 3 ? 0 : 3);
+          S.H[s1 * n + s2] += t;
+        }
+        if (tid < nc) {
+          double t = 0;
+          for (int a = 0; a < 6; a++) t += SE->J[a * 12 + tid] * (-SE->we[a] * rhoE0);
+          S.b[(tid < 6 ? 0 : 9) + tid + (tid % 6 < 3 ? 0 : 3)] += t;
         }
         __syncthreads();
       }
@@ -629,6 +719,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     }
     if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
     if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
+    if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
     for (int i = tid; i < 225; i += BS) S.cov[i] = 0, S.C[i] = 0, S.E[i] = 0;
     __syncthreads();
     if (tid < 36) {
@@ -663,6 +754,26 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       S.E[(9 + tid) * 15 + 9 + tid] = -w;
     }
     __syncthreads();
+    if (ENC) {  // getHessianXj -> B, Xi -> C, Xji -> E (FillCovInv :195-204)
+      for (int eidx = tid; eidx < 72; eidx += BS) {
+        const int a = eidx / 12, cc = eidx % 12;
+        double t = 0;
+        for (int q = 0; q < 6; q++) t += (rhoE * SE->Info[a * 6 + q]) * SE->J[q * 12 + cc];
+        SE->T[eidx] = t;
+      }
+      __syncthreads();
+      for (int eidx = tid; eidx < 144; eidx += BS) {
+        const int c1 = eidx / 12, c2 = eidx % 12;
+        double t = 0;
+        for (int a = 0; a < 6; a++) t += SE->J[a * 12 + c1] * SE->T[a * 12 + c2];
+        const int k1 = c1 % 6, k2 = c2 % 6;
+        const int d = (k1 < 3 ? k1 : k1 + 3) * 15 + (k2 < 3 ? k2 : k2 + 3);
+        if (c1 < 6 && c2 < 6) S.cov[d] += t;
+        if (c1 >= 6 && c2 >= 6) S.C[d] += t;
+        if (c1 < 6 && c2 >= 6) S.E[d] += t;
+      }
+      __syncthreads();
+    }
     if (!fixedLast) {
       for (int eidx = tid; eidx < 225; eidx += BS) {
         const int a = eidx / 15, cc = eidx % 15;
@@ -752,10 +863,22 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
 
 using namespace vieo;
 
+template <bool MC, bool ENC>
+static void vio_launch_kind(bool narrow, const vieo_vio_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
+                            uint8_t* d_outlier, vieo_vio_result* d_results, int others, hipStream_t stream) {
+  if (narrow)
+    hipLaunchKernelGGL((k_pose_opt_vio<64, MC, ENC>), dim3(n_frames), dim3(64), 0, stream, d_frames, d_obs,
+                       d_outlier, d_results, others);
+  else
+    hipLaunchKernelGGL((k_pose_opt_vio<256, MC, ENC>), dim3(n_frames), dim3(256), 0, stream, d_frames, d_obs,
+                       d_outlier, d_results, others);
+}
+
 extern "C" {
 
+// which / which_enc: bit 0 the rectified / encoder-less instance, bit 1 the rig / encoder instance
 static int vio_launch(const vieo_vio_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
-                      uint8_t* d_outlier, vieo_vio_result* d_results, int which, void* stream) {
+                      uint8_t* d_outlier, vieo_vio_result* d_results, int which, int which_enc, void* stream) {
   if (!d_frames || n_frames <= 0 || !d_obs || !d_outlier || !d_results) return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
@@ -766,23 +889,12 @@ static int vio_launch(const vieo_vio_frame* d_frames, int n_frames, const vieo_p
     return e ? atoi(e) : 0;
   }();
   const bool narrow = forced == 64 || (forced != 256 && n_frames > 256);
-  const int both = which == 3;
-  if (which & 1) {
-    if (narrow)
-      hipLaunchKernelGGL((k_pose_opt_vio<64, false>), dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames,
-                         d_obs, d_outlier, d_results, both);
-    else
-      hipLaunchKernelGGL((k_pose_opt_vio<256, false>), dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames,
-                         d_obs, d_outlier, d_results, both);
-  }
-  if (which & 2) {
-    if (narrow)
-      hipLaunchKernelGGL((k_pose_opt_vio<64, true>), dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames,
-                         d_obs, d_outlier, d_results, both);
-    else
-      hipLaunchKernelGGL((k_pose_opt_vio<256, true>), dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_frames,
-                         d_obs, d_outlier, d_results, both);
-  }
+  const int others = (which == 3 ? 1 : 0) | (which_enc == 3 ? 2 : 0);
+  hipStream_t st = (hipStream_t)stream;
+  if ((which & 1) && (which_enc & 1)) vio_launch_kind<false, false>(narrow, d_frames, n_frames, d_obs, d_outlier, d_results, others, st);
+  if ((which & 2) && (which_enc & 1)) vio_launch_kind<true, false>(narrow, d_frames, n_frames, d_obs, d_outlier, d_results, others, st);
+  if ((which & 1) && (which_enc & 2)) vio_launch_kind<false, true>(narrow, d_frames, n_frames, d_obs, d_outlier, d_results, others, st);
+  if ((which & 2) && (which_enc & 2)) vio_launch_kind<true, true>(narrow, d_frames, n_frames, d_obs, d_outlier, d_results, others, st);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
@@ -790,7 +902,8 @@ static int vio_launch(const vieo_vio_frame* d_frames, int n_frames, const vieo_p
 int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int n_frames,
                                             const vieo_pose_obs* d_obs, uint8_t* d_outlier,
                                             vieo_vio_result* d_results, void* stream) {
-  return vio_launch(d_frames, n_frames, d_obs, d_outlier, d_results, vieo::pose_rig_launches(), stream);
+  return vio_launch(d_frames, n_frames, d_obs, d_outlier, d_results, vieo::pose_rig_launches(),
+                    vieo::pose_enc_launches(), stream);
 }
 
 int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_obs* h_obs,
@@ -798,16 +911,14 @@ int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_ob
   if (!h_frame || !h_result || (h_frame->base.n_obs > 0 && (!h_obs || !h_outlier))) return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
-  static thread_local DevBuf dF, dO, dU, dR, dC;
+  static thread_local DevBuf dF, dO, dU, dR, dC, dE;
   const int n = h_frame->base.n_obs, nc = h_frame->base.n_cams;
   if (nc < 0 || nc > 4 || (nc > 0 && !h_frame->base.cams)) {
     set_error("PoseOptimization (VIO): n_cams = %d (0..4) needs `cams`", nc);
     return VIEO_E_INVALID;
   }
-  if (h_frame->base.enc && h_frame->base.enc->enc.dt != 0) {
-    set_error("PoseOptimization (VIO): the encoder edge of this variant is not built (base.enc must be NULL)");
-    return VIEO_E_INVALID;
-  }
+  const bool has_enc = h_frame->base.enc && h_frame->base.enc->enc.dt != 0;
+  if ((rc = dE.ensure(sizeof(vieo_pose_enc))) != VIEO_OK) return rc;
   if ((rc = dF.ensure(sizeof(vieo_vio_frame))) != VIEO_OK) return rc;
   if ((rc = dC.ensure(4 * sizeof(vieo_camera))) != VIEO_OK) return rc;
   if ((rc = dO.ensure((size_t)std::max(n, 1) * sizeof(vieo_pose_obs))) != VIEO_OK) return rc;
@@ -820,10 +931,15 @@ int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_ob
     VIEO_HIP_CHECK(hipMemcpy(dC.p, h_frame->base.cams, (size_t)nc * sizeof(vieo_camera), hipMemcpyHostToDevice));
     F.base.cams = dC.as<vieo_camera>();
   }
+  F.base.enc = nullptr;
+  if (has_enc) {
+    VIEO_HIP_CHECK(hipMemcpy(dE.p, h_frame->base.enc, sizeof(vieo_pose_enc), hipMemcpyHostToDevice));
+    F.base.enc = dE.as<vieo_pose_enc>();
+  }
   VIEO_HIP_CHECK(hipMemcpy(dF.p, &F, sizeof(F), hipMemcpyHostToDevice));
   if (n > 0) VIEO_HIP_CHECK(hipMemcpy(dO.p, src, (size_t)n * sizeof(vieo_pose_obs), hipMemcpyHostToDevice));
   rc = vio_launch(dF.as<vieo_vio_frame>(), 1, dO.as<vieo_pose_obs>(), dU.as<uint8_t>(),
-                  dR.as<vieo_vio_result>(), nc > 0 ? 2 : 1, nullptr);
+                  dR.as<vieo_vio_result>(), nc > 0 ? 2 : 1, has_enc ? 2 : 1, nullptr);
   if (rc != VIEO_OK) return rc;
   VIEO_HIP_CHECK(hipMemcpy(h_result, dR.p, sizeof(vieo_vio_result), hipMemcpyDeviceToHost));
   if (n > 0) VIEO_HIP_CHECK(hipMemcpy(h_outlier + h_frame->base.obs_begin, dU.p, n, hipMemcpyDeviceToHost));

@@ -41,6 +41,11 @@ int pose_rig_launches() {
   const int m = g_pose_cams_mode.load();
   return m == VIEO_POSE_CAMS_RECTIFIED ? 1 : m == VIEO_POSE_CAMS_RIG ? 2 : 3;
 }
+std::atomic<int> g_pose_enc_mode{VIEO_POSE_ENC_AUTO};
+int pose_enc_launches() {
+  const int m = g_pose_enc_mode.load();
+  return m == VIEO_POSE_ENC_NONE ? 1 : m == VIEO_POSE_ENC_ALL ? 2 : 3;
+}
 
 }  // namespace vieo
 
@@ -66,6 +71,12 @@ int vieo_set_device(int device) {
 int vieo_pose_set_camera_mode(int mode) {
   if (mode < VIEO_POSE_CAMS_AUTO || mode > VIEO_POSE_CAMS_RIG) return VIEO_E_INVALID;
   vieo::g_pose_cams_mode.store(mode);
+  return VIEO_OK;
+}
+
+int vieo_pose_set_encoder_mode(int mode) {
+  if (mode < VIEO_POSE_ENC_AUTO || mode > VIEO_POSE_ENC_ALL) return VIEO_E_INVALID;
+  vieo::g_pose_enc_mode.store(mode);
   return VIEO_OK;
 }
 

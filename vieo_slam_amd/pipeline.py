@@ -39,6 +39,7 @@ class FramePipeline:
         self.stream = lib().vieo_orb_stream(self.ext._h)
         # every frame here is a rectified stereo frame (Frame::usedistort_ false): skip the camera-rig instance
         check(lib().vieo_pose_set_camera_mode(1))
+        check(lib().vieo_pose_set_encoder_mode(1))
         self.cap = cap = self.ext.max_keypoints()
         ext0 = [ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH) for _ in range(2)]
         scf = self.ext.GetScaleFactors()

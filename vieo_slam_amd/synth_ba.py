@@ -103,17 +103,22 @@ def make_pose_problem(seed, n_obs=300, outlier_frac=0.10, stereo_frac=0.70, nois
 def make_pose_enc(rng, p_cur, q_cur, noise=1.0):
     """vieo_pose_enc for a frame whose TRUE pose is (p_cur, q_cur): a last frame 0.05 s earlier on a smooth motion
     and the wheel-odometry pre-integration between the two (consistent up to the sensor noise)."""
-    from .ba_types import POSE_ENC_DTYPE
-    E = np.zeros(1, POSE_ENC_DTYPE)
     Rj = quat_to_R(q_cur)
     Ri = Rj @ so3_exp(rng.normal(0, 0.02, 3)).T
     pi_ = p_cur - Rj @ rng.normal(0, 0.03, 3)
+    return enc_between(rng, pi_, Ri, p_cur, Rj, noise)
+
+
+def enc_between(rng, pi_, Ri, pj, Rj, noise=1.0, dt=0.05):
+    """vieo_pose_enc: the wheel-odometry pre-integration between the true poses (pi, Ri) and (pj, Rj)."""
+    from .ba_types import POSE_ENC_DTYPE
+    E = np.zeros(1, POSE_ENC_DTYPE)
     Reb = ENC_RBE.T
     dR = Reb @ Ri.T @ Rj @ ENC_RBE
-    dp = Reb @ (Ri.T @ (p_cur - pi_) - ENC_PBE + Ri.T @ Rj @ ENC_PBE)
+    dp = Reb @ (Ri.T @ (pj - pi_) - ENC_PBE + Ri.T @ Rj @ ENC_PBE)
     sphi, sp = 2e-3, 5e-3
     e = E[0]
-    e["enc"]["dt"] = 0.05
+    e["enc"]["dt"] = dt
     e["enc"]["delx"][:3] = so3_log_np(dR) + rng.normal(0, sphi, 3) * noise
     e["enc"]["delx"][3:] = dp + rng.normal(0, sp, 3) * noise
     e["enc"]["Sigma"] = np.diag([sphi ** 2] * 3 + [sp ** 2] * 3).reshape(-1)
@@ -291,9 +296,11 @@ def _nav(rec, p, q, v, bg, ba):
     rec["dba"] = 0
 
 
-def make_vio_problem(seed, n_obs=300, dt_frame=0.05, compute_marg=False, prior=None, **kw):
+def make_vio_problem(seed, n_obs=300, dt_frame=0.05, compute_marg=False, prior=None, enc=False, imu=True, **kw):
     """returns (vio_frame[1] VIO_FRAME_DTYPE, obs, truth).  prior = None -> last state fixed;
-    prior = (nav_prior record, H_prior 15x15, nav_last record) -> last state optimised too."""
+    prior = (nav_prior record, H_prior 15x15, nav_last record) -> last state optimised too.
+    enc: attach the wheel-odometry edge between the last and the current frame (truth["enc"] keeps the record
+    alive); imu = False drops the IMU edge (dt = 0), e.g. to leave the encoder as the only odometry."""
     from .ba_types import VIO_FRAME_DTYPE
     frame, obs, gt = make_pose_problem(seed, n_obs=n_obs, **kw)
     rng = np.random.default_rng(seed + 909)
@@ -304,6 +311,8 @@ def make_vio_problem(seed, n_obs=300, dt_frame=0.05, compute_marg=False, prior=N
     Rj, pj = quat_to_R(gt["q"]), gt["p"]
     pi, Ri, vi, vj, bg, ba, meas = imu_motion(rng, pj, Rj, dt_frame)
     fill_imu(f["imu"], meas)
+    if not imu:
+        f["imu"]["dt"] = 0
     qi = _R_to_quat(Ri)
     # current frame: keep the perturbed p/q from make_pose_problem, add v and biases
     f["base"]["nav"]["v"] = vj + rng.normal(0, 0.05, 3)
@@ -322,6 +331,9 @@ def make_vio_problem(seed, n_obs=300, dt_frame=0.05, compute_marg=False, prior=N
         f["nav_last"] = nav_last
         f["last_has_prior"] = 1
     gt = dict(gt, v=vj, p_i=pi, q_i=qi, v_i=vi, bg=bg, ba=ba)
+    if enc:
+        gt["enc"] = enc_between(np.random.default_rng(seed + 4243), pi, Ri, pj, Rj, dt=dt_frame)
+        f["base"]["enc"] = gt["enc"].ctypes.data
     return F, obs, gt
 
 
