@@ -530,6 +530,32 @@ int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_par
                                            float* const* h_points_out, uint8_t* const* h_erase,
                                            vieo_lba_result* h_results);
 
+/* Encoder edges of the vision-only BAs: EdgeEncNavStatePR (g2otypes.h:591-668) between pKF1->GetPrevKeyFrame() and
+ * pKF1 for every pair with GetEncPreInt().mdeltatij != 0 (LocalBundleAdjustment: Optimizer.cc:2008-2042, local key
+ * frames only; BundleAdjustment with bEnc: :1401-1438).  Both key frames must be in the window (indices), the edges
+ * chain the key frames (at most one into and one out of each).  Information Sigma_E^-1, x 1e-2 when kf_i is fixed;
+ * Huber sqrt(12.592) -- always in the local BA (kept through both optimisations), iff `robust` in the full BA. */
+typedef struct vieo_lba_enc_edge {
+  int32_t kf_i, kf_j;  /* previous / current key frame (indices into the key-frame array) */
+  vieo_enc_preint enc; /* GetEncPreInt() of kf_j */
+} vieo_lba_enc_edge;   /* 352 bytes */
+typedef struct vieo_lba_enc {
+  int32_t n_edges, reserved;
+  const vieo_lba_enc_edge* edges; /* host pointer */
+  double qRbe[4], pbe[3];         /* Tbe = Frame::mTbc * Frame::mTce: rotation (w, x, y, z), translation */
+} vieo_lba_enc;                   /* 72 bytes */
+/* vieo_local_bundle_adjustment / vieo_bundle_adjustment with those edges; enc == NULL or n_edges == 0: identical to
+ * the plain entries. */
+int vieo_local_bundle_adjustment_enc(const vieo_lba_params* params, const vieo_lba_keyframe* h_kfs, int n_kf,
+                                     const float* h_points, int n_mp, const vieo_lba_obs* h_obs, int n_obs,
+                                     const vieo_lba_enc* enc, volatile const int* stop, vieo_navstate* h_navs_out,
+                                     float* h_points_out, uint8_t* h_erase, vieo_lba_result* h_result);
+int vieo_bundle_adjustment_enc(const vieo_lba_params* params, int n_iterations, int robust,
+                               const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
+                               const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_enc* enc,
+                               volatile const int* stop, vieo_navstate* h_navs_out, float* h_points_out,
+                               vieo_lba_result* h_result);
+
 /* void Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust, bEnc = false)
  * (src/Optimizer.cc:1353-1609; GlobalBundleAdjustment :1346-1351 passes the whole map) and
  * int Optimizer::GlobalBundleAdjustmentNavStatePRV(pMap, gw, nIterations, pbStopFlag, nLoopKF, bRobust,
@@ -540,8 +566,8 @@ int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_par
  * form weighs the inertial and bias edges leaving a fixed key frame by 1e-2 like the reference.  Reduced systems
  * beyond 510 unknowns are factorised by the tiled LDL^T (FP64 matrix cores); up to 16320 unknowns.
  * params->its0 / its1 (and lambda_init / rec_init / large of the VIO params) are ignored.  Not covered: the scale
- * vertex (bScaleOpt), the gravity vertex of the IMU initialiser; encoder edges only in the visual-inertial form
- * (vieo_lba_imu_edge.enc), not in vieo_bundle_adjustment (bEnc). */
+ * vertex (bScaleOpt), the gravity vertex of the IMU initialiser.  Encoder edges: vieo_lba_imu_edge.enc in the
+ * visual-inertial form, vieo_bundle_adjustment_enc (bEnc = true) in the vision-only one. */
 int vieo_bundle_adjustment(const vieo_lba_params* params, int n_iterations, int robust,
                            const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
                            const vieo_lba_obs* h_obs, int n_obs, volatile const int* stop, vieo_navstate* h_navs_out,

@@ -1,8 +1,9 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see ocv_prims.hpp header).  PARITY UNPINNED.
 //
-// CPU restatement of Optimizer::LocalBundleAdjustment (vision-only, no encoder edges;
-// reference: src/Optimizer.cc:1876-2307) on a flattened window, with the vendored g2o pieces it
-// runs through:
+// CPU restatement of Optimizer::LocalBundleAdjustment (vision-only; reference: src/Optimizer.cc:1876-2307)
+// on a flattened window, with the vendored g2o pieces it runs through:
+//   EdgeEncNavStatePR between consecutive key frames       src/Odom/g2otypes.h:591-668 (enc_edge.hpp),
+//     Optimizer.cc:2008-2042 (local BA), :1401-1438 (BundleAdjustment, bEnc)
 //   EdgeReprojectPR / PRStereo incl. the point Jacobian   src/Odom/g2otypes.h:400-541
 //   BlockSolver<6,3>::buildSystem / setLambda / solve     g2o/core/block_solver.hpp:501-589,353-486
 //     (Hpp, Hll, Hpl blocks; Schur complement  Hschur = Hpp - sum_l B D^-1 B^T,
@@ -22,6 +23,7 @@
 
 #include "../include/vieo_hot.h"
 #include "cam_models.hpp"
+#include "enc_edge.hpp"
 #include "smallmat.hpp"
 
 namespace vo {
@@ -40,8 +42,33 @@ struct LEdge {
   double err[3] = {0, 0, 0};
 };
 
+struct PairEdge {  // EdgeEncNavStatePR: vertex 0 = kf i (previous), vertex 1 = kf j
+  int i, j;
+  double meas[6], Info[36], err[6] = {0, 0, 0, 0, 0, 0};
+  bool robust = true;
+  double chi2() const {
+    double s = 0;
+    for (int a = 0; a < 6; a++) {
+      double t = 0;
+      for (int b = 0; b < 6; b++) t += Info[a * 6 + b] * err[b];
+      s += err[a] * t;
+    }
+    return s;
+  }
+};
+static const double kDeltaEnc = std::sqrt(12.592);
+
 struct LBA {
   const vieo_lba_params* P;
+  std::vector<PairEdge> G;
+  Quat qRbe;
+  double pbe[3];
+  void enc_eval(PairEdge& g, double* Ji, double* Jj) const {
+    EncPose si, sj;
+    memcpy(si.p, kf[g.i].p, 24), memcpy(sj.p, kf[g.j].p, 24);
+    si.q = kf[g.i].q, sj.q = kf[g.j].q;
+    enc_edge_eval(si, sj, g.meas, qRbe, pbe, g.err, Ji, Jj);
+  }
   OCam cams[4];
   std::vector<KFState> kf;
   std::vector<double> X;  // points, 3 per mp
@@ -155,6 +182,7 @@ static int optimize(LBA& B, int iterations, volatile const int* stop, vieo_lba_r
     if (B.E[i].level == 0) act.push_back((int)i);
   std::vector<char> kf_act(nk, 0), mp_act(nm, 0);
   for (int i : act) kf_act[B.E[i].kf] = 1, mp_act[B.E[i].mp] = 1;
+  for (const PairEdge& g : B.G) kf_act[g.i] = kf_act[g.j] = 1;  // level-0 edges: their vertices are active
   int np = 0;
   for (int k = 0; k < nk; k++) {
     if (!B.kf[k].fixed && kf_act[k])
@@ -165,6 +193,7 @@ static int optimize(LBA& B, int iterations, volatile const int* stop, vieo_lba_r
   if (np == 0 || act.empty()) return 0;
   auto computeActiveErrors = [&]() {
     for (int i : act) B.compute_error(B.E[i]);
+    for (PairEdge& g : B.G) B.enc_eval(g, nullptr, nullptr);
   };
   auto activeRobustChi2 = [&]() {
     double chi = 0, rho[2];
@@ -175,6 +204,13 @@ static int optimize(LBA& B, int iterations, volatile const int* stop, vieo_lba_r
         chi += rho[0];
       } else
         chi += LBA::chi2(e);
+    }
+    for (const PairEdge& g : B.G) {
+      if (g.robust) {
+        hub(g.chi2(), kDeltaEnc, kDeltaEnc * kDeltaEnc, rho);
+        chi += rho[0];
+      } else
+        chi += g.chi2();
     }
     return chi;
   };
@@ -229,6 +265,43 @@ static int optimize(LBA& B, int iterations, volatile const int* stop, vieo_lba_r
             for (int r = 0; r < e.de; r++) t += Jp[r * 6 + a] * w * Jx[r * 3 + b2];
             Bpl[(size_t)i * 18 + a * 3 + b2] = t;
           }
+        }
+      }
+    }
+    for (PairEdge& g : B.G) {  // J^T (rho' Omega) J of the pair, both blocks and the cross block
+      double J[2][36];
+      B.enc_eval(g, J[0], J[1]);
+      double wr = 1.0;
+      if (g.robust) {
+        double rho[2];
+        hub(g.chi2(), kDeltaEnc, kDeltaEnc * kDeltaEnc, rho);
+        wr = rho[1];
+      }
+      double we[6];
+      for (int a = 0; a < 6; a++) {
+        we[a] = 0;
+        for (int q = 0; q < 6; q++) we[a] += g.Info[a * 6 + q] * g.err[q];
+      }
+      const int col[2] = {B.kf[g.i].col, B.kf[g.j].col};
+      for (int u = 0; u < 2; u++) {
+        if (col[u] < 0) continue;
+        for (int a = 0; a < 6; a++) {
+          double sb = 0;
+          for (int r = 0; r < 6; r++) sb += J[u][r * 6 + a] * (-we[r] * wr);
+          bp[col[u] + a] += sb;
+        }
+        for (int v = 0; v < 2; v++) {
+          if (col[v] < 0) continue;
+          for (int a = 0; a < 6; a++)
+            for (int b2 = 0; b2 < 6; b2++) {
+              double sH = 0;
+              for (int r = 0; r < 6; r++) {
+                double t = 0;
+                for (int q = 0; q < 6; q++) t += (wr * g.Info[r * 6 + q]) * J[v][q * 6 + b2];
+                sH += J[u][r * 6 + a] * t;
+              }
+              Hpp[(size_t)(col[u] + a) * np + col[v] + b2] += sH;
+            }
         }
       }
     }
@@ -348,7 +421,8 @@ static int optimize(LBA& B, int iterations, volatile const int* stop, vieo_lba_r
 static void local_ba(const vieo_lba_params& P, const vieo_lba_keyframe* kfs, int n_kf,
                      const float* points, int n_mp, const vieo_lba_obs* obs, int n_obs,
                      volatile const int* stop, vieo_navstate* navs_out, float* points_out,
-                     uint8_t* erase, vieo_lba_result& R, int gba_iterations = -1, bool gba_robust = false) {
+                     uint8_t* erase, vieo_lba_result& R, int gba_iterations = -1, bool gba_robust = false,
+                     const vieo_lba_enc* enc = nullptr) {
   const bool gba = gba_iterations >= 0;
   memset(&R, 0, sizeof(R));
   for (int k = 0; k < n_kf; k++) navs_out[k] = kfs[k].nav;
@@ -387,6 +461,22 @@ static void local_ba(const vieo_lba_params& P, const vieo_lba_keyframe* kfs, int
     e.dsqr = e.delta * e.delta;
     if (B.mp_count[e.mp] == 0) B.mp_first[e.mp] = i;
     B.mp_count[e.mp]++;
+  }
+  if (enc) {
+    B.qRbe.w = enc->qRbe[0], B.qRbe.x = enc->qRbe[1], B.qRbe.y = enc->qRbe[2], B.qRbe.z = enc->qRbe[3];
+    memcpy(B.pbe, enc->pbe, 24);
+    for (int t = 0; t < enc->n_edges; t++) {
+      const vieo_lba_enc_edge& e = enc->edges[t];
+      if (e.enc.dt == 0) continue;
+      PairEdge g;
+      g.i = e.kf_i, g.j = e.kf_j;
+      memcpy(g.meas, e.enc.delx, 48);
+      gj_inverse(e.enc.Sigma, g.Info, 6);
+      if (B.kf[g.i].fixed)
+        for (int q = 0; q < 36; q++) g.Info[q] *= 1e-2;
+      g.robust = gba ? gba_robust : true;
+      B.G.push_back(g);
+    }
   }
   if (stop && *stop) {
     R.status = VIEO_LBA_ABORTED;
@@ -445,4 +535,21 @@ extern "C" void vo_bundle_adjustment(const vieo_lba_params* params, int n_iterat
   std::vector<uint8_t> erase((size_t)n_obs + 1);
   vo::local_ba(*params, kfs, n_kf, points, n_mp, obs, n_obs, stop, navs_out, points_out, erase.data(), *result,
                n_iterations, robust != 0);
+}
+
+extern "C" void vo_local_bundle_adjustment_enc(const vieo_lba_params* params, const vieo_lba_keyframe* kfs, int n_kf,
+                                               const float* points, int n_mp, const vieo_lba_obs* obs, int n_obs,
+                                               const vieo_lba_enc* enc, const int* stop, vieo_navstate* navs_out,
+                                               float* points_out, uint8_t* erase, vieo_lba_result* result) {
+  vo::local_ba(*params, kfs, n_kf, points, n_mp, obs, n_obs, stop, navs_out, points_out, erase, *result, -1, false,
+               enc);
+}
+
+extern "C" void vo_bundle_adjustment_enc(const vieo_lba_params* params, int n_iterations, int robust,
+                                         const vieo_lba_keyframe* kfs, int n_kf, const float* points, int n_mp,
+                                         const vieo_lba_obs* obs, int n_obs, const vieo_lba_enc* enc, const int* stop,
+                                         vieo_navstate* navs_out, float* points_out, vieo_lba_result* result) {
+  std::vector<uint8_t> erase((size_t)n_obs + 1);
+  vo::local_ba(*params, kfs, n_kf, points, n_mp, obs, n_obs, stop, navs_out, points_out, erase.data(), *result,
+               n_iterations, robust != 0, enc);
 }

@@ -84,7 +84,7 @@ class Oracle:
         return n, assign[:len(keys)]
 
     # ---- local bundle adjustment
-    def local_ba(self, params, kfs, points, obs, stop=None):
+    def local_ba(self, params, kfs, points, obs, stop=None, enc=None):
         from vieo_slam_amd.ba_types import LBA_RESULT_DTYPE, NAVSTATE_DTYPE
         params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
         points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
@@ -93,19 +93,36 @@ class Oracle:
         erase = np.zeros(max(len(obs), 1), np.uint8)
         res = np.zeros(1, LBA_RESULT_DTYPE)
         st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        if enc is not None:
+            P, I = ctypes.c_void_p, ctypes.c_int
+            self.L.vo_local_bundle_adjustment_enc.argtypes = [P, P, I, P, I, P, I, P, P, P, P, P, P]
+            self.L.vo_local_bundle_adjustment_enc(params.ctypes.data, kfs.ctypes.data, len(kfs), points.ctypes.data,
+                                                  len(points), obs.ctypes.data, len(obs),
+                                                  np.ascontiguousarray(enc).ctypes.data,
+                                                  None if st is None else st.ctypes.data, navs.ctypes.data,
+                                                  pts.ctypes.data, erase.ctypes.data, res.ctypes.data)
+            return navs, pts, erase[:len(obs)], res[0]
         self.L.vo_local_bundle_adjustment(params.ctypes.data, kfs.ctypes.data, len(kfs),
                                           points.ctypes.data, len(points), obs.ctypes.data, len(obs),
                                           None if st is None else st.ctypes.data, navs.ctypes.data,
                                           pts.ctypes.data, erase.ctypes.data, res.ctypes.data)
         return navs, pts, erase[:len(obs)], res[0]
 
-    def bundle_adjustment(self, params, kfs, points, obs, n_iterations=5, robust=True, stop=None):
+    def bundle_adjustment(self, params, kfs, points, obs, n_iterations=5, robust=True, stop=None, enc=None):
         from vieo_slam_amd.ba_types import LBA_RESULT_DTYPE, NAVSTATE_DTYPE
         params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
         points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
         navs, pts, res = np.zeros(len(kfs), NAVSTATE_DTYPE), np.zeros_like(points), np.zeros(1, LBA_RESULT_DTYPE)
         st = None if stop is None else np.ascontiguousarray(stop, np.int32)
         P, I = ctypes.c_void_p, ctypes.c_int
+        if enc is not None:
+            self.L.vo_bundle_adjustment_enc.argtypes = [P, I, I, P, I, P, I, P, I, P, P, P, P, P]
+            self.L.vo_bundle_adjustment_enc(params.ctypes.data, int(n_iterations), int(bool(robust)), kfs.ctypes.data,
+                                            len(kfs), points.ctypes.data, len(points), obs.ctypes.data, len(obs),
+                                            np.ascontiguousarray(enc).ctypes.data,
+                                            None if st is None else st.ctypes.data, navs.ctypes.data, pts.ctypes.data,
+                                            res.ctypes.data)
+            return navs, pts, res[0]
         self.L.vo_bundle_adjustment.argtypes = [P, I, I, P, I, P, I, P, I, P, P, P, P]
         self.L.vo_bundle_adjustment(params.ctypes.data, int(n_iterations), int(bool(robust)), kfs.ctypes.data,
                                     len(kfs), points.ctypes.data, len(points), obs.ctypes.data, len(obs),

@@ -159,3 +159,37 @@ def test_vio_gba_landmark_sharded_two_ranks_on_one_gpu(oracle):
         assert dt < TOL and dr < TOL, (dt, dr)
         assert np.abs(op[shards[rank][1]] - hp).max() < 1e-3
     assert results[0][0].tobytes() == results[1][0].tobytes()  # replicated solve: bit-identical key frames
+
+
+def test_oracle_vision_gba_encoder_edges(oracle):
+    """BundleAdjustment(bEnc = true) (Optimizer.cc:1401-1438): noiseless odometry between every pair leaves the
+    noiseless optimum where it is; the kernel is on the pair edges iff bRobust."""
+    P, kfs, pts, obs, gt = synth_ba.make_lba_problem(5, n_local=12, n_fixed=1, n_points=800, outlier_frac=0.0, noise=0.0,
+                                                     stereo_frac=1.0, anchors=3)
+    enc, edges = synth_ba.make_lba_enc(5, gt, synth_ba.lba_enc_pairs(12, 13), noise=0.0)
+    assert len(edges) == 12
+    navs, pout, res = oracle.bundle_adjustment(P, kfs, pts, obs, 10, True, enc=enc)
+    dt, dr = _gt_err(navs, gt, 12)
+    assert dt.max() < 5e-4 and dr.max() < 1e-4
+    # a gross odometry error on one pair: with the kernel its pull is bounded
+    edges[5]["enc"]["delx"][3:] += 0.5
+    r1 = oracle.bundle_adjustment(P, kfs, pts, obs, 10, True, enc=enc)
+    r0 = oracle.bundle_adjustment(P, kfs, pts, obs, 10, False, enc=enc)
+    assert _gt_err(r1[0], gt, 12)[0].max() < _gt_err(r0[0], gt, 12)[0].max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_local,n_points,robust,iters", [(21, 30, 2500, True, 8), (22, 100, 6000, False, 5)])
+def test_vision_gba_encoder_edges_parity(oracle, seed, n_local, n_points, robust, iters):
+    from vieo_slam_amd.optimizer import Optimizer
+    P, kfs, pts, obs, gt = synth_ba.make_lba_problem(seed, n_local=n_local, n_fixed=1, n_points=n_points,
+                                                     anchors=max(2, n_local // 6))
+    enc, edges = synth_ba.make_lba_enc(seed, gt, synth_ba.lba_enc_pairs(n_local, n_local + 1))
+    on, op, ores = oracle.bundle_adjustment(P, kfs, pts, obs, iters, robust, enc=enc)
+    hn, hp, hres = Optimizer.BundleAdjustment(P, kfs, pts, obs, iters, robust, enc=enc)
+    dt, dr = _pose_diff(on, hn, n_local)
+    assert dt < TOL and dr < TOL, (dt, dr)
+    assert hres["status"] == ores["status"] == 0
+    assert abs(hres["chi2_final"] - ores["chi2_final"]) <= 1e-6 * ores["chi2_final"]
+    plain = Optimizer.BundleAdjustment(P, kfs, pts, obs, iters, robust)
+    assert not np.array_equal(plain[0]["p"], hn["p"])

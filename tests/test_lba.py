@@ -177,3 +177,76 @@ def test_gpu_lba_distorted_rig_parity(oracle, rig, seed):
     assert np.abs(op - hp).max() < 5e-2 and np.median(np.abs(op - hp)) < 5e-5
     assert (oe != he).mean() < 0.003
     assert abs(hres["chi2_final"] - ores["chi2_final"]) < 1e-6 * ores["chi2_final"] + 1e-3
+
+
+def _enc_of(seed, kfs, gt, **kw):
+    nl = int((kfs["fixed"] == 0).sum())
+    return synth_ba.make_lba_enc(seed, gt, synth_ba.lba_enc_pairs(nl, len(kfs)), **kw)
+
+
+def test_oracle_lba_encoder_edges(oracle):
+    """a17: EdgeEncNavStatePR between consecutive key frames (Optimizer.cc:2008-2042).  An empty edge list changes
+    nothing; with few, noisy, monocular-heavy observations the wheel odometry tightens the window; a key frame that
+    lost every visual edge stays in the system through its encoder edges."""
+    params, kfs, pts, obs, gt = synth_ba.make_lba_problem(20, n_local=6, n_fixed=3, n_points=120, noise=2.5,
+                                                          stereo_frac=0.2, outlier_frac=0.0)
+    a = oracle.local_ba(params, kfs, pts, obs)
+    enc0, e0 = synth_ba.make_lba_enc(20, gt, [])
+    b = oracle.local_ba(params, kfs, pts, obs, enc=enc0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    enc, edges = _enc_of(20, kfs, gt)
+    assert len(edges) == 6 and edges[0]["kf_i"] == len(kfs) - 1  # the key frame before the window is a fixed one
+    c = oracle.local_ba(params, kfs, pts, obs, enc=enc)
+    ea, ec = _pose_errs(a[0], gt, 6), _pose_errs(c[0], gt, 6)
+    assert ec[:, 0].mean() < 0.7 * ea[:, 0].mean() and ec[:, 1].mean() < 0.7 * ea[:, 1].mean(), (ea.mean(0), ec.mean(0))
+    assert c[3]["chi2_initial"] > a[3]["chi2_initial"]  # the pair edges count in the robust chi2
+    # a local key frame without observations: only the encoder edges move it (without them it stays put)
+    params, kfs, pts, obs, gt = synth_ba.make_lba_problem(21, n_local=6, n_fixed=3, n_points=300, pert_t=0.05,
+                                                          pert_r_deg=2.0)
+    enc, edges = _enc_of(21, kfs, gt)
+    lone = 2
+    obs2 = obs[(obs["kf"] & 0xFFFFFF) != lone]
+    d0 = oracle.local_ba(params, kfs, pts, obs2)
+    assert np.array_equal(d0[0][lone]["p"], kfs[lone]["nav"]["p"])
+    d1 = oracle.local_ba(params, kfs, pts, obs2, enc=enc)
+    e_before = synth_ba.pose_error(kfs[lone]["nav"], dict(p=gt["p"][lone], q=gt["q"][lone]))
+    e_after = synth_ba.pose_error(d1[0][lone], dict(p=gt["p"][lone], q=gt["q"][lone]))
+    assert e_after[0] < 0.5 * e_before[0] and e_after[1] < 0.5 * e_before[1], (e_before, e_after)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", [(30, {}), (31, dict(n_local=6, n_fixed=3, n_points=120, noise=2.5, stereo_frac=0.2)),
+                                     (32, dict(n_local=25, n_fixed=10, n_points=2500)),
+                                     (33, dict(n_local=4, n_fixed=0, n_points=300, first_fixed=True))])
+def test_gpu_lba_encoder_edges_parity(oracle, seed, kw):
+    from vieo_slam_amd.optimizer import Optimizer
+    params, kfs, pts, obs, gt = synth_ba.make_lba_problem(seed, **kw)
+    enc, edges = _enc_of(seed, kfs, gt)
+    on, op, oe, ores = oracle.local_ba(params, kfs, pts, obs, enc=enc)
+    hn, hp, he, hres = Optimizer.LocalBundleAdjustment(params, kfs, pts, obs, enc=enc)
+    assert hres["status"] == ores["status"] == 0
+    for k in range(len(kfs)):
+        dt, dr = synth_ba.pose_error(on[k], hn[k])
+        assert dt < 1e-4 and dr < 1e-4, (k, dt, dr)
+    assert (oe != he).mean() < 0.002
+    assert abs(hres["chi2_final"] - ores["chi2_final"]) < 1e-6 * ores["chi2_final"] + 1e-3
+    assert abs(hres["chi2_initial"] - ores["chi2_initial"]) < 1e-6 * ores["chi2_initial"]
+    plain = Optimizer.LocalBundleAdjustment(params, kfs, pts, obs)
+    assert not np.array_equal(plain[0]["p"], hn["p"])  # the edges are in the system
+    none = Optimizer.LocalBundleAdjustment(params, kfs, pts, obs, enc=synth_ba.make_lba_enc(0, gt, [])[0])
+    assert np.array_equal(none[0], plain[0]) and np.array_equal(none[2], plain[2])
+
+
+@pytest.mark.gpu
+def test_gpu_lba_encoder_only_key_frame(oracle):
+    """A local key frame whose observations are all gone joins the reduced system through its encoder edges."""
+    from vieo_slam_amd.optimizer import Optimizer
+    params, kfs, pts, obs, gt = synth_ba.make_lba_problem(34, n_local=6, n_fixed=3, n_points=200)
+    enc, edges = _enc_of(34, kfs, gt)
+    obs2 = obs[(obs["kf"] & 0xFFFFFF) != 2]
+    on, op, oe, ores = oracle.local_ba(params, kfs, pts, obs2, enc=enc)
+    hn, hp, he, hres = Optimizer.LocalBundleAdjustment(params, kfs, pts, obs2, enc=enc)
+    assert not np.array_equal(hn[2]["p"], kfs[2]["nav"]["p"])
+    for k in range(len(kfs)):
+        dt, dr = synth_ba.pose_error(on[k], hn[k])
+        assert dt < 1e-4 and dr < 1e-4, (k, dt, dr)

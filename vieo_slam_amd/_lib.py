@@ -31,6 +31,8 @@ _SIGS = {
     "vieo_update_normal_and_depth_batch": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, ctypes.c_float, c_i, c_p, c_p,
                                                  c_p]),
     "vieo_bundle_adjustment": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "vieo_bundle_adjustment_enc": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "vieo_local_bundle_adjustment_enc": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "vieo_global_bundle_adjustment_vio": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p,
                                                 c_p]),
     "vieo_get_device": (c_i, []),

@@ -66,6 +66,11 @@ LBA_VIO_PARAMS_DTYPE = np.dtype([("base", LBA_PARAMS_DTYPE), ("gw", "<f8", 3), (
                                  ("large", "<i4"), ("th_dist_far", "<f4"), ("reserved", "<i4"), ("qRbe", "<f8", 4),
                                  ("pbe", "<f8", 3)], align=True)
 assert LBA_IMU_EDGE_DTYPE.itemsize == 1496 and LBA_VIO_PARAMS_DTYPE.itemsize == 256
+# encoder edges of the vision-only BAs (vieo_lba_enc_edge / vieo_lba_enc)
+LBA_ENC_EDGE_DTYPE = np.dtype([("kf_i", "<i4"), ("kf_j", "<i4"), ("enc", ENC_PREINT_DTYPE)], align=True)
+LBA_ENC_DTYPE = np.dtype([("n_edges", "<i4"), ("reserved", "<i4"), ("edges", "<u8"), ("qRbe", "<f8", 4),
+                          ("pbe", "<f8", 3)], align=True)
+assert LBA_ENC_EDGE_DTYPE.itemsize == 352 and LBA_ENC_DTYPE.itemsize == 72
 
 # vieo_fisheye_params: cams / Trc / Tcr / level_sigma2 are host pointers the caller keeps alive
 FISHEYE_PARAMS_DTYPE = np.dtype([("n_cams", "<i4"), ("n_levels", "<i4"), ("bf", "<f4"), ("th_far_pts", "<f4"),

@@ -287,6 +287,8 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
       s_act[o.kf] = 1;
       D.mp_act[o.mp] = 1;
     }
+  if (D.pd == 6)  // encoder edges of a vision-only window are active edges too (their vertices join the system)
+    for (int e = tid; e < D.n_imu; e += 256) s_act[D.imu[e].i] = 1, s_act[D.imu[e].j] = 1;
   __syncthreads();
   if (tid == 0) {
     // vision-only window: free key frames with an active edge; visual-inertial window: the inertial
@@ -570,11 +572,11 @@ k_lba_lambda(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   if (!(ctl[w].flags & LBA_BEGIN)) return;
   const LbaDev& D = devs[w];
   double mx = 0;
-  if (D.pd == 6) {
+  if (D.pd == 6 && D.n_imu == 0) {
     for (int j = threadIdx.x; j < D.npv; j += 256) mx = fmax(mx, fabs(D.Hpp[36 * (size_t)(j / 6) + 7 * (j % 6)]));
   } else {  // PR + V + Bias vertices: visual block + the inertial edges' diagonal (as k_lba_assemble adds them)
     for (int j = threadIdx.x; j < D.np; j += 256) {
-      const int a = j / 15, ra = j - a * 15, ka = D.kf_list[a];
+      const int pd = D.pd, a = j / pd, ra = j - a * pd, ka = D.kf_list[a];
       const int ein = D.kf_in[ka], eout = D.kf_out[ka];
       double v = ra < 6 ? D.Hpp[36 * (size_t)a + 7 * ra] : 0.0;
       if (ein >= 0) v += D.Ae[930 * (size_t)ein + (15 + ra) * 30 + 15 + ra];
@@ -769,7 +771,7 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
     if (a == b) v += redH[36 * (size_t)a + ra * 6 + cb];
   }
   int ein = -1, eout = -1;
-  if (pd == 15) {
+  if (pd == 15 || D.n_imu > 0) {  // pair edges: inertial (+ encoder) of a 15-dim window, encoder only of a 6-dim one
     const int ka = D.kf_list[a], kb = D.kf_list[b];
     ein = D.kf_in[ka], eout = D.kf_out[ka];
     if (a == b) {
@@ -1432,6 +1434,7 @@ static thread_local PinnedBuf g_stage, g_small_h;
 struct WinHost {  // per-window LM state machine, exactly g2o's (optimization_algorithm_levenberg.cpp)
   const vieo_lba_params* P;
   const vieo_lba_vio_params* VP = nullptr;  // visual-inertial window (a18)
+  const vieo_lba_enc* ENC = nullptr;        // encoder edges of a vision-only window (a17)
   int n_kf, n_mp, n_obs, n_imu = 0;
   double lastTrialChi = 0;  // activeRobustChi2 of the errors left in the edges (err_end)
   bool prelevel_pending = false;
@@ -1533,7 +1536,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
                    const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
                    const vieo_lba_imu_edge* const* h_imu, const int* n_imu, volatile const int* stop,
                    vieo_navstate* const* h_navs_out, float* const* h_points_out, uint8_t* const* h_erase,
-                   vieo_lba_result* h_results) {
+                   vieo_lba_result* h_results, const vieo_lba_enc* const* encs = nullptr) {
   const bool vio = vparams != nullptr;
   const int pd = vio ? 15 : 6;
   if (sh && (!vio || !sh->fn || !sh->d_buf || (stop && *stop))) {
@@ -1566,8 +1569,13 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (vio) {
       if (!vparams[w] || (!h_close[w] && !gba) || n_imu[w] < 0 || (n_imu[w] > 0 && !h_imu[w])) return VIEO_E_INVALID;
       H.VP = vparams[w], H.P = &vparams[w]->base, H.n_imu = n_imu[w];
-    } else
+    } else {
       H.P = params[w];
+      if (encs && encs[w]) {  // EdgeEncNavStatePR of a vision-only window (Optimizer.cc:2008-2042, 1401-1438)
+        if (encs[w]->n_edges < 0 || (encs[w]->n_edges > 0 && !encs[w]->edges)) return VIEO_E_INVALID;
+        H.ENC = encs[w], H.n_imu = encs[w]->n_edges;
+      }
+    }
     H.n_kf = n_kf[w], H.n_mp = n_mp[w], H.n_obs = n_obs[w];
     H.R = &h_results[w];
     if (!H.P || !h_kfs[w] || H.n_kf <= 0 || !h_points[w] || H.n_mp <= 0 || !h_obs[w] || H.n_obs <= 0 ||
@@ -1583,12 +1591,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         return VIEO_E_CAPACITY;
       }
     }
-    if (vio) {  // a chain: at most one pre-integration into and one out of every key frame
+    if (vio || H.ENC) {  // a chain: at most one pre-integration into and one out of every key frame
       std::vector<char> in(H.n_kf, 0), outk(H.n_kf, 0);
       for (int t = 0; t < H.n_imu; t++) {
-        const int a = h_imu[w][t].kf_i, b = h_imu[w][t].kf_j;
+        const int a = vio ? h_imu[w][t].kf_i : H.ENC->edges[t].kf_i, b = vio ? h_imu[w][t].kf_j : H.ENC->edges[t].kf_j;
         if (a < 0 || a >= H.n_kf || b < 0 || b >= H.n_kf || a == b || outk[a] || in[b]) {
-          set_error("visual-inertial local BA: the inertial edges must chain the key frames");
+          set_error("local BA: the inertial / encoder edges must chain the key frames");
           return VIEO_E_INVALID;
         }
         outk[a] = 1, in[b] = 1;
@@ -1643,7 +1651,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     o.mp_first = take((size_t)H.n_mp * 4), o.mp_count = take((size_t)H.n_mp * 4);
     o.kf_edge_first = take((size_t)(H.n_kf + 1) * 4), o.kf_edge_idx = take((size_t)H.n_obs * 4);
     o.ocam = take(H.n_obs);
-    if (vio) {
+    if (vio || H.ENC) {
       o.imu = take((size_t)std::max(H.n_imu, 1) * sizeof(LbaImu));
       o.kf_in = take((size_t)H.n_kf * 4), o.kf_out = take((size_t)H.n_kf * 4), o.close = take(H.n_mp);
     }
@@ -1770,6 +1778,29 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         memcpy(hs + o.close, h_close[w], H.n_mp);
       else
         memset(hs + o.close, 0, H.n_mp);
+    } else if (H.ENC) {  // encoder edges only: no inertial residual, no bias random walk
+      LbaImu* im = (LbaImu*)(hs + o.imu);
+      int* kin = (int*)(hs + o.kf_in);
+      int* kout = (int*)(hs + o.kf_out);
+      for (int k = 0; k < H.n_kf; k++) kin[k] = kout[k] = -1;
+      for (int t = 0; t < H.n_imu; t++) {
+        const vieo_lba_enc_edge& e = H.ENC->edges[t];
+        LbaImu& d = im[t];
+        memset(&d, 0, sizeof(d));
+        d.i = e.kf_i, d.j = e.kf_j;
+        d.has_enc = e.enc.dt != 0, d.enc_robust = gba ? gba->robust != 0 : 1;
+        if (d.has_enc) {
+          memcpy(d.measE, e.enc.delx, 48);
+          if (!inverse_n(e.enc.Sigma, d.InfoE, 6)) {
+            set_error("local BA: singular encoder covariance");
+            return VIEO_E_INVALID;
+          }
+          if (kfs[e.kf_i].fixed)  // Optimizer.cc:2030-2033
+            for (int q = 0; q < 36; q++) d.InfoE[q] *= 1e-2;
+        }
+        kout[e.kf_i] = t, kin[e.kf_j] = t;
+      }
+      memset(hs + o.close, 0, H.n_mp);
     }
     double* X = (double*)(hs + o.X);
     for (int i = 0; i < H.n_mp * 3; i++) X[i] = (double)h_points[w][i];
@@ -1830,8 +1861,10 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       memcpy(D.qRbe, H.VP->qRbe, 32), memcpy(D.pbe, H.VP->pbe, 24);
       D.th_dist_far = (!gba && H.VP->th_dist_far > 0 && std::isfinite(H.VP->th_dist_far)) ? (double)H.VP->th_dist_far : 0.0;
       H.prelevel_pending = !gba;
-    } else
+    } else {
       D.thMono = D.thMonoClose = 5.991, D.thStereo = 7.815;
+      if (H.ENC) memcpy(D.qRbe, H.ENC->qRbe, 32), memcpy(D.pbe, H.ENC->pbe, 24);
+    }
     max_imu = std::max(max_imu, H.n_imu);
     max_obs = std::max(max_obs, H.n_obs), max_mp = std::max(max_mp, H.n_mp);
     max_kf = std::max(max_kf, H.n_kf), max_nf = std::max(max_nf, nf);
@@ -1867,7 +1900,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.kf_act = (int*)(base + s.kf_act), D.occ = base + s.occ;
     D.bfull = (double*)(base + s.bfull), D.Ae = (double*)(base + s.Ae);
     D.gchi0 = (double*)(base + s.gchi0), D.gchi = (double*)(base + s.gchi);
-    if (vio) {
+    if (vio || win[w].ENC) {
       D.imu = (const LbaImu*)(base + o.imu), D.close = base + o.close;
       D.kf_in = (const int*)(base + o.kf_in), D.kf_out = (const int*)(base + o.kf_out);
     }
@@ -1957,7 +1990,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         hipLaunchKernelGGL(k_lba_build<true>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq);
       else
         hipLaunchKernelGGL(k_lba_build<false>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq);
-      if (vio && max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0);
+      if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0);
     }
     if (any & LBA_BEGIN) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);
     if (any & LBA_TRIAL) {
@@ -1991,7 +2024,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         hipLaunchKernelGGL(k_lba_ldlt<6>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
       hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO);
       hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
-      if (vio && max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
+      if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
       hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
       if (sh) {  // chi2 and the landmark part of the gain-ratio scale
         VIEO_HIP_CHECK(hipStreamSynchronize(st));
@@ -2202,6 +2235,30 @@ int vieo_bundle_adjustment(const vieo_lba_params* params, int n_iterations, int 
   uint8_t* er = erase.data();
   return lba_run(nullptr, &g, 1, &params, nullptr, &h_kfs, &n_kf, &h_points, nullptr, &n_mp, &h_obs, &n_obs, nullptr,
                  nullptr, stop, &h_navs_out, &h_points_out, &er, h_result);
+}
+
+int vieo_local_bundle_adjustment_enc(const vieo_lba_params* P, const vieo_lba_keyframe* h_kfs, int n_kf,
+                                     const float* h_points, int n_mp, const vieo_lba_obs* h_obs, int n_obs,
+                                     const vieo_lba_enc* enc, volatile const int* stop, vieo_navstate* h_navs_out,
+                                     float* h_points_out, uint8_t* h_erase, vieo_lba_result* R) {
+  if (!P || !h_kfs || n_kf <= 0 || !h_points || n_mp <= 0 || !h_obs || n_obs <= 0 || !h_navs_out ||
+      !h_points_out || !h_erase || !R)
+    return VIEO_E_INVALID;
+  return lba_run(nullptr, nullptr, 1, &P, nullptr, &h_kfs, &n_kf, &h_points, nullptr, &n_mp, &h_obs, &n_obs, nullptr,
+                 nullptr, stop, &h_navs_out, &h_points_out, &h_erase, R, &enc);
+}
+
+int vieo_bundle_adjustment_enc(const vieo_lba_params* params, int n_iterations, int robust,
+                               const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
+                               const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_enc* enc,
+                               volatile const int* stop, vieo_navstate* h_navs_out, float* h_points_out,
+                               vieo_lba_result* h_result) {
+  if (!params || n_iterations < 0 || !h_result || n_obs < 0) return VIEO_E_INVALID;
+  const GbaMode g = {n_iterations, robust};
+  std::vector<uint8_t> erase((size_t)std::max(n_obs, 1));
+  uint8_t* er = erase.data();
+  return lba_run(nullptr, &g, 1, &params, nullptr, &h_kfs, &n_kf, &h_points, nullptr, &n_mp, &h_obs, &n_obs, nullptr,
+                 nullptr, stop, &h_navs_out, &h_points_out, &er, h_result, &enc);
 }
 
 int vieo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_iterations, int robust,

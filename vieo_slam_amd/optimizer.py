@@ -37,9 +37,10 @@ class Optimizer:
         return res[0], outl[:len(ob)]
 
     @staticmethod
-    def LocalBundleAdjustment(params, kfs, points, obs, stop=None):
+    def LocalBundleAdjustment(params, kfs, points, obs, stop=None, enc=None):
         """void Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int Nlocal)
-        (src/Optimizer.cc:1876-2307) on a flattened window (ba_types.LBA_*).
+        (src/Optimizer.cc:1876-2307) on a flattened window (ba_types.LBA_*).  enc: LBA_ENC_DTYPE[1] with the
+        EdgeEncNavStatePR pairs (:2008-2042) or None.
         returns (navs[n_kf], points float32[n_mp,3], erase uint8[n_obs], result record)."""
         params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
         points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
@@ -48,6 +49,13 @@ class Optimizer:
         erase = np.zeros(max(len(obs), 1), np.uint8)
         res = np.zeros(1, LBA_RESULT_DTYPE)
         st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        if enc is not None:
+            enc = np.ascontiguousarray(enc)
+            check(lib().vieo_local_bundle_adjustment_enc(
+                params.ctypes.data, kfs.ctypes.data, len(kfs), points.ctypes.data, len(points), obs.ctypes.data,
+                len(obs), enc.ctypes.data, None if st is None else st.ctypes.data, navs.ctypes.data, pts.ctypes.data,
+                erase.ctypes.data, res.ctypes.data), "vieo_local_bundle_adjustment_enc")
+            return navs, pts, erase[:len(obs)], res[0]
         check(lib().vieo_local_bundle_adjustment(params.ctypes.data, kfs.ctypes.data, len(kfs),
                                                  points.ctypes.data, len(points), obs.ctypes.data,
                                                  len(obs), None if st is None else st.ctypes.data,
@@ -173,7 +181,7 @@ class Optimizer:
         return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
 
     @staticmethod
-    def BundleAdjustment(params, kfs, points, obs, nIterations=5, bRobust=True, stop=None):
+    def BundleAdjustment(params, kfs, points, obs, nIterations=5, bRobust=True, stop=None, enc=None):
         """void Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust, bEnc=false)
         (src/Optimizer.cc:1353-1609) -- GlobalBundleAdjustment passes the whole map -- on the flattened layout of
         LocalBundleAdjustment.  returns (navs[n_kf], points float32[n_mp,3], result record)."""
@@ -181,6 +189,13 @@ class Optimizer:
         points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
         navs, pts, res = np.zeros(len(kfs), NAVSTATE_DTYPE), np.zeros_like(points), np.zeros(1, LBA_RESULT_DTYPE)
         st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        if enc is not None:  # bEnc = true: EdgeEncNavStatePR pairs (Optimizer.cc:1401-1438), LBA_ENC_DTYPE[1]
+            enc = np.ascontiguousarray(enc)
+            check(lib().vieo_bundle_adjustment_enc(
+                params.ctypes.data, int(nIterations), int(bool(bRobust)), kfs.ctypes.data, len(kfs), points.ctypes.data,
+                len(points), obs.ctypes.data, len(obs), enc.ctypes.data, None if st is None else st.ctypes.data,
+                navs.ctypes.data, pts.ctypes.data, res.ctypes.data), "vieo_bundle_adjustment_enc")
+            return navs, pts, res[0]
         check(lib().vieo_bundle_adjustment(params.ctypes.data, int(nIterations), int(bool(bRobust)), kfs.ctypes.data,
                                            len(kfs), points.ctypes.data, len(points), obs.ctypes.data, len(obs),
                                            None if st is None else st.ctypes.data, navs.ctypes.data,

@@ -522,6 +522,31 @@ def make_lba_problem(seed, n_local=10, n_fixed=6, n_points=2000, outlier_frac=0.
     return params, kfs, pts, obs, gt
 
 
+def make_lba_enc(seed, truth, pairs, dt=0.5, noise=1.0):
+    """vieo_lba_enc (LBA_ENC_DTYPE[1]) + its edge array for the key-frame pairs (i = previous, j) of a window whose
+    TRUE poses are truth["p"], truth["q"]: wheel-odometry pre-integrations consistent with them up to sensor noise.
+    Keep both returned arrays alive while the record is in use."""
+    from .ba_types import LBA_ENC_DTYPE, LBA_ENC_EDGE_DTYPE
+    rng = np.random.default_rng(seed + 31337)
+    edges = np.zeros(len(pairs), LBA_ENC_EDGE_DTYPE)
+    for t, (i, j) in enumerate(pairs):
+        e = enc_between(rng, truth["p"][i], quat_to_R(truth["q"][i]), truth["p"][j], quat_to_R(truth["q"][j]), noise, dt)
+        edges[t]["kf_i"], edges[t]["kf_j"], edges[t]["enc"] = i, j, e[0]["enc"]
+    enc = np.zeros(1, LBA_ENC_DTYPE)
+    enc[0]["n_edges"], enc[0]["edges"] = len(pairs), edges.ctypes.data
+    enc[0]["qRbe"], enc[0]["pbe"] = _R_to_quat(ENC_RBE), ENC_PBE
+    return enc, edges
+
+
+def lba_enc_pairs(n_local, n_kf, with_prev=True):
+    """(previous, current) key-frame pairs of make_lba_problem's window: local key frames are stored oldest first,
+    the key frame before the window is the last (newest) fixed one."""
+    pairs = [(k - 1, k) for k in range(1, n_local)]
+    if with_prev and n_kf > n_local:
+        pairs.insert(0, (n_kf - 1, 0))
+    return pairs
+
+
 # ----------------------------------------------------------------------------------------------
 def imu_forward(rng, pi, Ri, vi, dt_kf, bg, ba, omega_sigma=0.08, acc_sigma=0.3, noise_scale=1.0):
     """One key-frame interval forward in time: constant body rate and world acceleration, sampled at
