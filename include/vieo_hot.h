@@ -550,6 +550,14 @@ int vieo_local_bundle_adjustment_enc(const vieo_lba_params* params, const vieo_l
                                      const float* h_points, int n_mp, const vieo_lba_obs* h_obs, int n_obs,
                                      const vieo_lba_enc* enc, volatile const int* stop, vieo_navstate* h_navs_out,
                                      float* h_points_out, uint8_t* h_erase, vieo_lba_result* h_result);
+/* lock-step batch: encs[w] may be NULL (a window without encoder edges); encs itself may be NULL */
+int vieo_local_bundle_adjustment_batch_enc(int n_windows, const vieo_lba_params* const* params,
+                                           const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                           const float* const* h_points, const int* n_mp,
+                                           const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                           const vieo_lba_enc* const* encs, volatile const int* stop,
+                                           vieo_navstate* const* h_navs_out, float* const* h_points_out,
+                                           uint8_t* const* h_erase, vieo_lba_result* h_results);
 int vieo_bundle_adjustment_enc(const vieo_lba_params* params, int n_iterations, int robust,
                                const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
                                const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_enc* enc,

@@ -250,3 +250,24 @@ def test_gpu_lba_encoder_only_key_frame(oracle):
     for k in range(len(kfs)):
         dt, dr = synth_ba.pose_error(on[k], hn[k])
         assert dt < 1e-4 and dr < 1e-4, (k, dt, dr)
+
+
+@pytest.mark.gpu
+def test_gpu_lba_batch_with_and_without_encoder_edges(oracle):
+    """Lock-step batch in which only some windows carry encoder edges (encs[w] = NULL for the others)."""
+    from vieo_slam_amd.optimizer import Optimizer
+    wins, encs, keep = [], [], []
+    for i in range(5):
+        w = synth_ba.make_lba_problem(40 + i, n_local=4 + 3 * i, n_fixed=2 + i, n_points=300 + 200 * i)
+        wins.append(w[:4])
+        e = _enc_of(40 + i, w[1], w[4]) if i % 2 == 0 else None
+        keep.append(e)
+        encs.append(None if e is None else e[0])
+    outs = Optimizer.LocalBundleAdjustmentBatch(wins, encs=encs)
+    for w, (win, enc) in enumerate(zip(wins, encs)):
+        on, op, oe, ores = oracle.local_ba(*win, enc=enc)
+        hn, hp, he, hres = outs[w]
+        for k in range(len(win[1])):
+            dt, dr = synth_ba.pose_error(on[k], hn[k])
+            assert dt < 1e-4 and dr < 1e-4, (w, k, dt, dr)
+        assert hres["lm_trials"] == ores["lm_trials"] and (oe != he).mean() < 0.002

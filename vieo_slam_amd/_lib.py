@@ -32,6 +32,8 @@ _SIGS = {
                                                  c_p]),
     "vieo_bundle_adjustment": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "vieo_bundle_adjustment_enc": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "vieo_local_bundle_adjustment_batch_enc": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                                      c_p]),
     "vieo_local_bundle_adjustment_enc": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "vieo_global_bundle_adjustment_vio": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p,
                                                 c_p]),

@@ -64,9 +64,10 @@ class Optimizer:
         return navs, pts, erase[:len(obs)], res[0]
 
     @staticmethod
-    def LocalBundleAdjustmentBatch(windows, stop=None):
+    def LocalBundleAdjustmentBatch(windows, stop=None, encs=None):
         """Several independent LocalBundleAdjustment windows in lock step (one launch sequence for
-        all of them).  windows: list of (params, kfs, points, obs) as for LocalBundleAdjustment.
+        all of them).  windows: list of (params, kfs, points, obs) as for LocalBundleAdjustment; encs: None or
+        one LBA_ENC_DTYPE[1] / None per window.
         returns a list of (navs, points, erase, result) in the same order."""
         W = len(windows)
         keep, outs = [], []
@@ -85,6 +86,15 @@ class Optimizer:
                 a[w] = arr.ctypes.data
             cnt[0][w], cnt[1][w], cnt[2][w] = len(kfs), len(points), len(obs)
         st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        if encs is not None:
+            encs = [None if e is None else np.ascontiguousarray(e) for e in encs]
+            pe = np.array([0 if e is None else e.ctypes.data for e in encs], np.uint64)
+            check(lib().vieo_local_bundle_adjustment_batch_enc(
+                W, ptrs[0].ctypes.data, ptrs[1].ctypes.data, cnt[0].ctypes.data, ptrs[2].ctypes.data,
+                cnt[1].ctypes.data, ptrs[3].ctypes.data, cnt[2].ctypes.data, pe.ctypes.data,
+                None if st is None else st.ctypes.data, ptrs[4].ctypes.data, ptrs[5].ctypes.data,
+                ptrs[6].ctypes.data, res.ctypes.data), "vieo_local_bundle_adjustment_batch_enc")
+            return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
         check(lib().vieo_local_bundle_adjustment_batch(
             W, ptrs[0].ctypes.data, ptrs[1].ctypes.data, cnt[0].ctypes.data, ptrs[2].ctypes.data,
             cnt[1].ctypes.data, ptrs[3].ctypes.data, cnt[2].ctypes.data,
