@@ -175,6 +175,38 @@ int vieo_stereo_fisheye_match(const vieo_fisheye_params* params, const vieo_keyp
                               int32_t* h_group_idx, uint8_t* h_group_good, double* h_group_p3d,
                               int32_t* n_groups, int32_t* n_matches);
 
+/* int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vMatchedPairs, bOnlyStereo)
+ * (src/ORBmatcher.cc:896-1150; LocalMapping::CreateNewMapPoints, LocalMapping.cc:709) for key frames with one
+ * undistorted pinhole camera each (usedistort_ false): per shared vocabulary node, every unmatched key of pKF1 against
+ * the unmatched keys of pKF2 -- Hamming <= TH_LOW (50), the epipole gate for two monocular keys, the epipolar
+ * constraint (GeometricCamera::epipolarConstrain, camera_base.h:287-406, fundamental-matrix branch, 3.84 sigma2)
+ * -- then FillMatchesFromPair (USE_STRATEGY_MIN_DIST) and the rotation-histogram filter.
+ *   device: all gates of all (key1, key2) pairs of the shared nodes, for a batch of pKF2 at once;
+ *   host (inside the library): the order-dependent part (skip keys already taken, best distance, group tables).
+ * mFeatVec is the caller's (DBoW2 transform needs the vocabulary): nodes ascending, CSR over feature indices.
+ * Distorted multi-camera key frames are refused (VIEO_E_INVALID). */
+typedef struct vieo_tri_keyframe {
+  double Tcw[12];              /* GetTcw(): row-major 3x4 */
+  float fx, fy, cx, cy;        /* mpCameras[0] (pinhole) */
+  int32_t n_keys, n_nodes;
+  const vieo_keypoint* keys;   /* mvKeysUn (pt, angle, octave) */
+  const uint8_t* descriptors;  /* mDescriptors, 32 bytes per key */
+  const float* uright;         /* stereoinfo_.vuright_ (< 0: monocular key) */
+  const uint8_t* has_mappoint; /* GetMapPoint(idx) != NULL */
+  const uint32_t* node_id;     /* mFeatVec: node ids, ascending */
+  const int32_t* node_first;   /* [n_nodes + 1] offsets into node_feat */
+  const int32_t* node_feat;    /* feature indices of each node, in the vector's order */
+  const float* scale_factor;   /* scalepyrinfo_.vscalefactor_ */
+  const float* level_sigma2;   /* scalepyrinfo_.vlevelsigma2_ */
+  int32_t n_levels, reserved;
+} vieo_tri_keyframe;           /* 200 bytes */
+/* kf2s[n_kf2]: the neighbours of kf1, each an independent call of the reference.  Outputs per neighbour p:
+ * h_pairs[p * pair_capacity ..][2] = (idx1, idx2) of vMatchedPairs in its order, h_n_pairs[p] their count,
+ * h_n_matches[p] the reference's return value.  VIEO_E_CAPACITY when a neighbour has more pairs. */
+int vieo_search_for_triangulation(const vieo_tri_keyframe* kf1, const vieo_tri_keyframe* kf2s, int n_kf2,
+                                  int only_stereo, int check_orientation, int32_t pair_capacity, int32_t* h_pairs,
+                                  int32_t* h_n_pairs, int32_t* h_n_matches);
+
 /* void Frame::ComputeStereoMatches() (src/Frame.cc:451-611), rectified stereo: row-band Hamming
  * search (octave +-1, disparity window [0, bf/baseline]), 11 SADs of 11x11 patches on the
  * left key's pyramid level, parabola sub-pixel fit, rejection above 1.5*1.4*median SAD.

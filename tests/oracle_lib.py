@@ -84,6 +84,22 @@ class Oracle:
         return n, assign[:len(keys)]
 
     # ---- local bundle adjustment
+    def search_for_triangulation(self, kf1, kf2s, only_stereo=False, check_orientation=True, pair_capacity=None):
+        from vieo_slam_amd.tri_search import tri_call
+        P, I = ctypes.c_void_p, ctypes.c_int
+        self.L.vo_search_for_triangulation.argtypes = [P, P, I, I, I, I, P, P, P]
+        self.L.vo_search_for_triangulation.restype = None
+        rc, out = tri_call(self.L.vo_search_for_triangulation, kf1, kf2s, only_stereo, check_orientation, pair_capacity)
+        return out
+
+    def tri_gates(self, kf1, kf2, idx1, idx2):
+        P, I = ctypes.c_void_p, ctypes.c_int
+        self.L.vo_tri_gates.argtypes = [P, P, I, I, P]
+        self.L.vo_tri_gates.restype = I
+        ep = np.zeros(2, np.float32)
+        d = self.L.vo_tri_gates(kf1.rec.ctypes.data, kf2.rec.ctypes.data, int(idx1), int(idx2), ep.ctypes.data)
+        return d, ep
+
     def local_ba(self, params, kfs, points, obs, stop=None, enc=None):
         from vieo_slam_amd.ba_types import LBA_RESULT_DTYPE, NAVSTATE_DTYPE
         params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)

@@ -1,0 +1,115 @@
+"""ORBmatcher::SearchForTriangulation: known-answer tests of the oracle on seeded key-frame pairs, GPU
+parity of the HIP gates + host bookkeeping (pairs bit-equal, in the reference's order)."""
+import numpy as np
+import pytest
+
+from vieo_slam_amd import tri_search
+
+
+def _epi_dist2(kf1, kf2, i1, i2):
+    """squared distance of key 2 from the epipolar line of key 1, float64, from the poses (independent of the oracle)"""
+    T1, T2 = kf1.rec[0]["Tcw"].reshape(3, 4), kf2.rec[0]["Tcw"].reshape(3, 4)
+    R12 = T1[:, :3] @ T2[:, :3].T
+    t12 = T1[:, 3] - R12 @ T2[:, 3]
+    K = lambda k: np.array([[k.rec[0]["fx"], 0, k.rec[0]["cx"]], [0, k.rec[0]["fy"], k.rec[0]["cy"]], [0, 0, 1.0]])
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    F = np.linalg.inv(K(kf1)).T @ tx @ R12 @ np.linalg.inv(K(kf2))
+    l = np.array([kf1.keys[i1]["x"], kf1.keys[i1]["y"], 1.0]) @ F
+    return (l @ np.array([kf2.keys[i2]["x"], kf2.keys[i2]["y"], 1.0])) ** 2 / (l[0] ** 2 + l[1] ** 2)
+
+
+def test_oracle_gates_known_answers(oracle):
+    kf1, kf2s, truth = tri_search.make_tri_scene(3, n_points=400, n_neighbours=1, stereo_frac=0.0, pixel_noise=0.3)
+    kf2 = kf2s[0]
+    # the epipole = projection of camera 1's centre into image 2
+    T1, T2 = kf1.rec[0]["Tcw"].reshape(3, 4), kf2.rec[0]["Tcw"].reshape(3, 4)
+    C2 = T2[:, :3] @ (-T1[:, :3].T @ T1[:, 3]) + T2[:, 3]
+    _, ep = oracle.tri_gates(kf1, kf2, 0, 0)
+    assert abs(ep[0] - (kf2.rec[0]["fx"] * C2[0] / C2[2] + kf2.rec[0]["cx"])) < 1e-2 * max(1, abs(ep[0]) * 1e-4)
+    n_true = n_pass = 0
+    for (i1, i2), pt in list(truth[0].items())[:150]:
+        d = oracle.tri_gates(kf1, kf2, i1, i2)[0]
+        ham = int(np.unpackbits(kf1.desc[i1] ^ kf2.desc[i2]).sum())
+        e2 = _epi_dist2(kf1, kf2, i1, i2)
+        th = 3.84 * kf2.sigma2[kf2.keys[i2]["octave"]]
+        far = (ep[0] - kf2.keys[i2]["x"]) ** 2 + (ep[1] - kf2.keys[i2]["y"]) ** 2 >= 100 * kf2.scale[kf2.keys[i2]["octave"]]
+        if abs(e2 - th) < 1e-3 * th:
+            continue
+        assert (d >= 0) == (ham <= 50 and e2 < th and far), (i1, i2, d, ham, e2, th)
+        assert d in (-1, ham)
+        n_true += 1
+        n_pass += d >= 0
+    assert n_pass > 0.8 * n_true  # 0.3 px of noise against a 1.96 sigma gate
+    # a wrong partner (same descriptor, another place) fails the epipolar gate nearly always
+    rng = np.random.default_rng(0)
+    wrong = 0
+    pairs = list(truth[0])
+    for k in range(200):
+        (i1, _), (_, j2) = pairs[rng.integers(len(pairs))], pairs[rng.integers(len(pairs))]
+        kf2.desc[j2] = kf1.desc[i1]
+        wrong += oracle.tri_gates(kf1, kf2, i1, j2)[0] >= 0 and (i1, j2) not in truth[0]
+    assert wrong < 30
+
+
+def test_oracle_search_recovers_true_pairs(oracle):
+    for seed in range(3):
+        kf1, kf2s, truth = tri_search.make_tri_scene(seed)
+        out = oracle.search_for_triangulation(kf1, kf2s)
+        for (pairs, nm), tr, kf2 in zip(out, truth, kf2s):
+            hit = sum((int(a), int(b)) in tr for a, b in pairs)
+            assert hit >= 0.97 * len(pairs) and len(pairs) > 0.8 * len(tr)
+            assert len(set(pairs[:, 0])) == len(pairs) and len(set(pairs[:, 1])) == len(pairs)  # one to one
+            assert not kf1.has_mp[pairs[:, 0]].any() and not kf2.has_mp[pairs[:, 1]].any()
+            assert nm == len(pairs)
+        only = oracle.search_for_triangulation(kf1, kf2s, only_stereo=True)
+        for (pairs, nm), kf2 in zip(only, kf2s):
+            assert (kf1.uright[pairs[:, 0]] >= 0).all() and (kf2.uright[pairs[:, 1]] >= 0).all() and len(pairs) > 10
+        # without the rotation histogram the 5 % keys with a random angle stay in
+        free = oracle.search_for_triangulation(kf1, kf2s, check_orientation=False)
+        assert all(len(f[0]) >= len(o[0]) for f, o in zip(free, out)) and sum(len(f[0]) for f in free) > sum(len(o[0]) for o in out)
+
+
+def test_oracle_lookalikes_stay_one_to_one(oracle):
+    kf1, kf2s, truth = tri_search.make_tri_scene(7, n_nodes=60, dup_frac=0.5, flip_bits=4)
+    out = oracle.search_for_triangulation(kf1, kf2s)
+    for (pairs, nm), tr in zip(out, truth):
+        assert len(set(pairs[:, 0])) == len(pairs) and len(set(pairs[:, 1])) == len(pairs)
+        hit = sum((int(a), int(b)) in tr for a, b in pairs)
+        assert 0.5 * len(pairs) < hit < len(pairs)  # look-alikes on the same epipolar line do get confused
+
+
+def test_struct_size():
+    assert tri_search.TRI_KEYFRAME_DTYPE.itemsize == 200
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw,flags", [(0, {}, (False, True)), (1, {}, (True, True)), (2, {}, (False, False)),
+                                           (7, dict(n_nodes=60, dup_frac=0.5, flip_bits=4), (False, True)),
+                                           (8, dict(n_points=3000, n_neighbours=8, n_nodes=40, dup_frac=0.3), (False, True)),
+                                           (9, dict(n_points=50, n_neighbours=2, n_nodes=500), (False, True))])
+def test_gpu_search_for_triangulation_parity(oracle, seed, kw, flags):
+    kf1, kf2s, truth = tri_search.make_tri_scene(seed, **kw)
+    ref = oracle.search_for_triangulation(kf1, kf2s, *flags)
+    got = tri_search.SearchForTriangulation(kf1, kf2s, *flags)
+    assert len(ref) == len(got) == len(kf2s)
+    for (rp, rn), (gp, gn) in zip(ref, got):
+        assert rn == gn and np.array_equal(rp, gp)
+
+
+@pytest.mark.gpu
+def test_gpu_search_for_triangulation_edge_cases(oracle):
+    from vieo_slam_amd._lib import lib
+    kf1, kf2s, _ = tri_search.make_tri_scene(4, n_neighbours=2)
+    # no shared node / everything already mapped / capacity
+    lonely = tri_search.TriKeyFrame(np.eye(4), (458.0, 457.0, 367.0, 248.0), kf2s[0].keys, kf2s[0].desc, kf2s[0].uright,
+                                    kf2s[0].has_mp, [(100000, [0, 1, 2])], kf2s[0].scale, kf2s[0].sigma2)
+    got = tri_search.SearchForTriangulation(kf1, [lonely, kf2s[1]])
+    assert len(got[0][0]) == 0 and got[0][1] == 0 and len(got[1][0]) > 0
+    kf2s[0].has_mp[:] = 1
+    assert len(tri_search.SearchForTriangulation(kf1, kf2s)[0][0]) == 0
+    rc, _ = tri_search.tri_call(lib().vieo_search_for_triangulation, kf1, kf2s, pair_capacity=5)
+    assert rc == -3 or rc != 0
+    bad = tri_search.TriKeyFrame(np.eye(4), (458.0, 457.0, 367.0, 248.0), kf1.keys, kf1.desc, kf1.uright, kf1.has_mp,
+                                 [(5, [0]), (3, [1])], kf1.scale, kf1.sigma2)  # nodes not ascending
+    rc, _ = tri_search.tri_call(lib().vieo_search_for_triangulation, bad, kf2s)
+    assert rc != 0
