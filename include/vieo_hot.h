@@ -176,20 +176,21 @@ int vieo_stereo_fisheye_match(const vieo_fisheye_params* params, const vieo_keyp
                               int32_t* n_groups, int32_t* n_matches);
 
 /* int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vMatchedPairs, bOnlyStereo)
- * (src/ORBmatcher.cc:896-1150; LocalMapping::CreateNewMapPoints, LocalMapping.cc:709) for key frames with one
- * undistorted pinhole camera each (usedistort_ false): per shared vocabulary node, every unmatched key of pKF1 against
- * the unmatched keys of pKF2 -- Hamming <= TH_LOW (50), the epipole gate for two monocular keys, the epipolar
- * constraint (GeometricCamera::epipolarConstrain, camera_base.h:287-406, fundamental-matrix branch, 3.84 sigma2)
- * -- then FillMatchesFromPair (USE_STRATEGY_MIN_DIST) and the rotation-histogram filter.
+ * (src/ORBmatcher.cc:896-1150; LocalMapping::CreateNewMapPoints, LocalMapping.cc:709): per shared vocabulary node,
+ * every unmatched key of pKF1 against the unmatched keys of pKF2 -- Hamming <= TH_LOW (50), best per image of pKF2,
+ * the epipole gate for two monocular keys, the epipolar constraint (GeometricCamera::epipolarConstrain,
+ * camera_base.h:287-406, fundamental-matrix branch, 3.84 sigma2; distorted keys are un-projected first) -- then
+ * FillMatchesFromPair (USE_STRATEGY_MIN_DIST) and the rotation-histogram filter.
  *   device: all gates of all (key1, key2) pairs of the shared nodes, for a batch of pKF2 at once;
  *   host (inside the library): the order-dependent part (skip keys already taken, best distance, group tables).
  * mFeatVec is the caller's (DBoW2 transform needs the vocabulary): nodes ascending, CSR over feature indices.
- * Distorted multi-camera key frames are refused (VIEO_E_INVALID). */
+ * Both key frames of a pair are of one kind: n_cams == 0 (usedistort_ false: one undistorted pinhole camera, keys =
+ * mvKeysUn) or n_cams 1..4 (a distorted rig: keys = mvKeys, camera-major). */
 typedef struct vieo_tri_keyframe {
-  double Tcw[12];              /* GetTcw(): row-major 3x4 */
-  float fx, fy, cx, cy;        /* mpCameras[0] (pinhole) */
+  double Tcw[12];              /* GetTcw() of the reference camera: row-major 3x4 */
+  float fx, fy, cx, cy;        /* mpCameras[0] (pinhole), n_cams == 0 */
   int32_t n_keys, n_nodes;
-  const vieo_keypoint* keys;   /* mvKeysUn (pt, angle, octave) */
+  const vieo_keypoint* keys;   /* mvKeysUn / mvKeys (pt, angle, octave) */
   const uint8_t* descriptors;  /* mDescriptors, 32 bytes per key */
   const float* uright;         /* stereoinfo_.vuright_ (< 0: monocular key) */
   const uint8_t* has_mappoint; /* GetMapPoint(idx) != NULL */
@@ -198,14 +199,20 @@ typedef struct vieo_tri_keyframe {
   const int32_t* node_feat;    /* feature indices of each node, in the vector's order */
   const float* scale_factor;   /* scalepyrinfo_.vscalefactor_ */
   const float* level_sigma2;   /* scalepyrinfo_.vlevelsigma2_ */
-  int32_t n_levels, reserved;
-} vieo_tri_keyframe;           /* 200 bytes */
+  int32_t n_levels, n_cams;
+  const struct vieo_camera* cams; /* [n_cams] model + parameters of mpCameras[i] (Rcb / tcb unused here) */
+  const double* Tcr;           /* [n_cams][12] mpCameras[i]->GetTcr() as row-major 3x4 */
+  const double* Trc;           /* [n_cams][12] mpCameras[i]->GetTrc() */
+  const uint8_t* key_cam;      /* [n_keys] get<0>(mapn2in_[idx]): the camera of each key */
+} vieo_tri_keyframe;           /* 232 bytes */
 /* kf2s[n_kf2]: the neighbours of kf1, each an independent call of the reference.  Outputs per neighbour p:
- * h_pairs[p * pair_capacity ..][2] = (idx1, idx2) of vMatchedPairs in its order, h_n_pairs[p] their count,
- * h_n_matches[p] the reference's return value.  VIEO_E_CAPACITY when a neighbour has more pairs. */
+ * h_pairs[(p * pair_capacity + m) * pair_stride + c] = the key of camera c in match m of vMatchedPairs (its
+ * order; cameras of pKF1 first, then those of pKF2; -1: none; pair_stride >= the number of cameras of the pair,
+ * 2 for undistorted key frames), h_n_pairs[p] their count, h_n_matches[p] the reference's return value.
+ * VIEO_E_CAPACITY when a neighbour has more matches than pair_capacity. */
 int vieo_search_for_triangulation(const vieo_tri_keyframe* kf1, const vieo_tri_keyframe* kf2s, int n_kf2,
-                                  int only_stereo, int check_orientation, int32_t pair_capacity, int32_t* h_pairs,
-                                  int32_t* h_n_pairs, int32_t* h_n_matches);
+                                  int only_stereo, int check_orientation, int32_t pair_capacity, int32_t pair_stride,
+                                  int32_t* h_pairs, int32_t* h_n_pairs, int32_t* h_n_matches);
 
 /* void Frame::ComputeStereoMatches() (src/Frame.cc:451-611), rectified stereo: row-band Hamming
  * search (octave +-1, disparity window [0, bf/baseline]), 11 SADs of 11x11 patches on the

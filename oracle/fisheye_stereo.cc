@@ -26,74 +26,6 @@ extern "C" void vo_knn2_hamming(const uint8_t* q, int nq, const uint8_t* t, int 
 
 namespace vo {
 
-// Base (pinhole) UnProject to the plane z = 1
-static void unproject_pinhole(const OCam& c, const float* uv, double* P) {
-  P[0] = ((double)uv[0] - c.cx) / c.fx;
-  P[1] = ((double)uv[1] - c.cy) / c.fy;
-  P[2] = 1.0;
-}
-
-static void ocam_unproject(const OCam& c, const float* uv, double* P) {
-  const int max_iter = 10;
-  const float precision = 1e-8f;
-  if (c.model == VIEO_CAM_RADTAN) {
-    double t[3];
-    unproject_pinhole(c, uv, t);
-    const double y0 = t[0], y1 = t[1];
-    double yb0 = y0, yb1 = y1;
-    const double precision2 = precision * precision;
-    for (int i = 0; i < max_iter; ++i) {
-      const double Pn[3] = {yb0, yb1, 1.};
-      float y2f[2];
-      double Jc[6];
-      ocam_project(c, Pn, y2f, Jc);
-      unproject_pinhole(c, y2f, t);
-      const double F00 = Jc[0] / c.fx, F01 = Jc[1] / c.fx, F10 = F01, F11 = Jc[4] / c.fy;
-      const double e0 = y0 - t[0], e1 = y1 - t[1];
-      // du = (F^T F)^-1 F^T e, 2x2 closed-form inverse
-      const double A00 = F00 * F00 + F10 * F10, A01 = F00 * F01 + F10 * F11, A11 = F01 * F01 + F11 * F11;
-      const double det = A00 * A11 - A01 * A01, inv = 1. / det;
-      const double I00 = A11 * inv, I01 = -A01 * inv, I11 = A00 * inv;
-      // (A^-1 F^T) e, evaluated as Eigen does: ((A^-1 * F^T) * e)
-      const double M00 = I00 * F00 + I01 * F01, M01 = I00 * F10 + I01 * F11;
-      const double M10 = I01 * F00 + I11 * F01, M11 = I01 * F10 + I11 * F11;
-      yb0 += M00 * e0 + M01 * e1;
-      yb1 += M10 * e0 + M11 * e1;
-      if (e0 * e0 + e1 * e1 < precision2) break;
-    }
-    P[0] = (double)(float)yb0, P[1] = (double)(float)yb1, P[2] = 1.0;
-    return;
-  }
-  if (c.model == VIEO_CAM_KB8) {
-    double t[3];
-    unproject_pinhole(c, uv, t);
-    const double mx = t[0], my = t[1];
-    double theta = 0, sin_theta = 0, cos_theta = 1, scaling = 1.0;
-    double thetad = std::sqrt(mx * mx + my * my);
-    thetad = std::min(std::max(-M_PI / 2., thetad), M_PI / 2.);
-    if (thetad > precision) {
-      const float k1 = c.dist[0], k2 = c.dist[1], k3 = c.dist[2], k4 = c.dist[3];
-      theta = thetad;
-      for (int i = 0; i < max_iter; ++i) {  // SolveTheta
-        const double theta2 = theta * theta;
-        double func = k4 * theta2;
-        func += k3, func *= theta2, func += k2, func *= theta2, func += k1, func *= theta2, func += 1, func *= theta;
-        double d = 9 * k4 * theta2;
-        d += 7 * k3, d *= theta2, d += 5 * k2, d *= theta2, d += 3 * k1, d *= theta2, d += 1;
-        const double fix = (thetad - func) / d;
-        theta += fix;
-        if (std::fabs(fix) < precision) break;
-      }
-      sin_theta = std::tan(theta);
-      cos_theta = 1.;
-      scaling = sin_theta / thetad;
-    }
-    P[0] = mx * scaling, P[1] = my * scaling, P[2] = cos_theta;
-    return;
-  }
-  unproject_pinhole(c, uv, P);
-}
-
 // right singular vector of the smallest singular value of A (m x 4, row-major), one-sided Jacobi
 static void null_vector4(const double* A_in, int m, double* x4) {
   double A[8 * 4], V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};

@@ -87,8 +87,8 @@ class Oracle:
     def search_for_triangulation(self, kf1, kf2s, only_stereo=False, check_orientation=True, pair_capacity=None):
         from vieo_slam_amd.tri_search import tri_call
         P, I = ctypes.c_void_p, ctypes.c_int
-        self.L.vo_search_for_triangulation.argtypes = [P, P, I, I, I, I, P, P, P]
-        self.L.vo_search_for_triangulation.restype = None
+        self.L.vo_search_for_triangulation.argtypes = [P, P, I, I, I, I, I, P, P, P]
+        self.L.vo_search_for_triangulation.restype = I
         rc, out = tri_call(self.L.vo_search_for_triangulation, kf1, kf2s, only_stereo, check_orientation, pair_capacity)
         return out
 

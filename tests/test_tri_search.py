@@ -78,15 +78,44 @@ def test_oracle_lookalikes_stay_one_to_one(oracle):
         assert 0.5 * len(pairs) < hit < len(pairs)  # look-alikes on the same epipolar line do get confused
 
 
+@pytest.mark.parametrize("rig", ["radtan", "kb8"])
+def test_oracle_search_in_a_distorted_rig(oracle, rig):
+    """usedistort_: keys of several cameras per key frame; a match row holds one key (or -1) per camera of pKF1, then
+    of pKF2.  Every (key of pKF1, key of pKF2) combination inside a row must be a true correspondence."""
+    kf1, kf2s, truth = tri_search.make_tri_scene(1, rig=rig, n_points=700)
+    nc1 = kf1.n_cams
+    out = oracle.search_for_triangulation(kf1, kf2s)
+    for (rows, nm), tr, kf2 in zip(out, truth, kf2s):
+        assert rows.shape[1] == nc1 + kf2.n_cams and len(rows) > 100 and nm >= len(rows)
+        good = tot = 0
+        for row in rows:
+            assert (row >= 0).sum() >= 2
+            for c1 in range(nc1):
+                for c2 in range(kf2.n_cams):
+                    i1, i2 = row[c1], row[nc1 + c2]
+                    if i1 >= 0 and i2 >= 0:
+                        assert kf1.key_cam[i1] == c1 and kf2.key_cam[i2] == c2
+                        tot += 1
+                        good += (c1, int(i1), c2, int(i2)) in tr
+        assert good >= 0.97 * tot and tot > 0.5 * len(tr)
+        for c in range(rows.shape[1]):  # a key belongs to one row at most
+            col = rows[:, c][rows[:, c] >= 0]
+            assert len(set(col)) == len(col)
+
+
 def test_struct_size():
-    assert tri_search.TRI_KEYFRAME_DTYPE.itemsize == 200
+    assert tri_search.TRI_KEYFRAME_DTYPE.itemsize == 232
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,kw,flags", [(0, {}, (False, True)), (1, {}, (True, True)), (2, {}, (False, False)),
                                            (7, dict(n_nodes=60, dup_frac=0.5, flip_bits=4), (False, True)),
                                            (8, dict(n_points=3000, n_neighbours=8, n_nodes=40, dup_frac=0.3), (False, True)),
-                                           (9, dict(n_points=50, n_neighbours=2, n_nodes=500), (False, True))])
+                                           (9, dict(n_points=50, n_neighbours=2, n_nodes=500), (False, True)),
+                                           (10, dict(rig="radtan", n_points=700), (False, True)),
+                                           (11, dict(rig="kb8", n_points=600, n_neighbours=4), (False, True)),
+                                           (12, dict(rig="kb8", n_points=500, n_nodes=40, dup_frac=0.4, flip_bits=4), (False, False)),
+                                           (13, dict(rig="radtan", n_points=500), (True, True))])
 def test_gpu_search_for_triangulation_parity(oracle, seed, kw, flags):
     kf1, kf2s, truth = tri_search.make_tri_scene(seed, **kw)
     ref = oracle.search_for_triangulation(kf1, kf2s, *flags)
@@ -109,6 +138,9 @@ def test_gpu_search_for_triangulation_edge_cases(oracle):
     assert len(tri_search.SearchForTriangulation(kf1, kf2s)[0][0]) == 0
     rc, _ = tri_search.tri_call(lib().vieo_search_for_triangulation, kf1, kf2s, pair_capacity=5)
     assert rc == -3 or rc != 0
+    rigged, _, _ = tri_search.make_tri_scene(4, n_neighbours=1, rig="radtan", n_points=100)
+    rc, _ = tri_search.tri_call(lib().vieo_search_for_triangulation, rigged, kf2s)  # a rig against undistorted key frames
+    assert rc != 0
     bad = tri_search.TriKeyFrame(np.eye(4), (458.0, 457.0, 367.0, 248.0), kf1.keys, kf1.desc, kf1.uright, kf1.has_mp,
                                  [(5, [0]), (3, [1])], kf1.scale, kf1.sigma2)  # nodes not ascending
     rc, _ = tri_search.tri_call(lib().vieo_search_for_triangulation, bad, kf2s)

@@ -18,7 +18,7 @@ struct FeGroups {
   std::vector<float> last;     // [g][nc], INFINITY: none    (lastdists)
   std::vector<uint8_t> good;   //                            (goodmatches_)
   std::vector<double> p3d;     // [g][3]                     (v3dpoints_)
-  std::vector<int32_t> key2g[4];  // (camera, key) -> group, -1: none   (mapcamidx2idxs_)
+  std::vector<int32_t> key2g[8];  // (camera, key) -> group, -1: none   (mapcamidx2idxs_)
   void reset(int n_cams, const int32_t* n_keys) {
     nc = n_cams;
     idxs.clear(), last.clear(), good.clear(), p3d.clear();
