@@ -3,7 +3,7 @@ oracle's, or the HIP product's) to the arrays that are pinned.  Shared by make_b
 the oracle) and tests/test_golden_ba.py (re-runs the oracle on CPU, the HIP path on the GPU box)."""
 import numpy as np
 
-from vieo_slam_amd import synth_ba, synth_fisheye
+from vieo_slam_amd import synth_ba, synth_fisheye, tri_search
 
 
 def nav_vec(nav):
@@ -42,3 +42,19 @@ def cases(api):
     yield "fisheye_groups", o["group_idx"].astype(np.int32), 0
     yield "fisheye_good", o["group_good"].astype(np.uint8), 0
     yield "fisheye_depth", o["depth"].astype(np.float32), 1e-4
+    # encoder edges (a15-a18) and the triangulation search (8f-2), added after the first fixture set
+    F, obs, _ = synth_ba.make_vio_problem(15, n_obs=200, compute_marg=True, enc=True)
+    res, outl = api["pose_vio"](F, obs)
+    yield "vio_enc_nav", nav_vec(res["base"]["nav"]), 1e-4
+    yield "vio_enc_marg_diag", np.diag(res["H_marg"].reshape(15, 15)) / np.abs(res["H_marg"]).max(), 1e-5
+    w = synth_ba.make_lba_problem(16, n_local=5, n_fixed=3, n_points=400)
+    enc, edges = synth_ba.make_lba_enc(16, w[4], synth_ba.lba_enc_pairs(5, 8))
+    navs, pts, erase, r = api["lba"](*w[:4], enc=enc)
+    yield "lba_enc_nav", nav_vec(navs)[:, :7], 1e-4
+    kf1, kf2s, _ = tri_search.make_tri_scene(17, n_points=400, n_neighbours=2, dup_frac=0.2)
+    for p, (rows, nm) in enumerate(api["tri"](kf1, kf2s)):
+        yield "tri_pairs_%d" % p, rows.astype(np.int32), 0
+    kf1, kf2s, _ = tri_search.make_tri_scene(18, n_points=300, n_neighbours=1, rig="kb8")
+    rows, nm = api["tri"](kf1, kf2s)[0]
+    yield "tri_rig_rows", rows.astype(np.int32), 0
+    yield "tri_rig_nmatches", np.array([nm], np.int32), 0

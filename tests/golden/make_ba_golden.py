@@ -17,7 +17,8 @@ from tests.golden import ba_cases  # noqa: E402
 
 def oracle_api(o):
     return {"pose": o.pose_optimization, "pose_vio": o.pose_optimization_vio, "lba": o.local_ba,
-            "lba_vio": o.local_ba_vio, "gba_vio": o.global_ba_vio, "fisheye": o.stereo_fisheye}
+            "lba_vio": o.local_ba_vio, "gba_vio": o.global_ba_vio, "fisheye": o.stereo_fisheye,
+            "tri": o.search_for_triangulation}
 
 
 if __name__ == "__main__":

@@ -36,7 +36,8 @@ def test_oracle_reproduces_committed_ba_golden(oracle):
 def test_hip_matches_committed_ba_golden():
     from vieo_slam_amd.matching import compute_stereo_fisheye_matches
     from vieo_slam_amd.optimizer import Optimizer as O
+    from vieo_slam_amd.tri_search import SearchForTriangulation
     api = {"pose": O.PoseOptimization, "pose_vio": O.PoseOptimizationVIO, "lba": O.LocalBundleAdjustment,
            "lba_vio": O.LocalBundleAdjustmentNavStatePRV, "gba_vio": O.GlobalBundleAdjustmentNavStatePRV,
-           "fisheye": compute_stereo_fisheye_matches}
+           "fisheye": compute_stereo_fisheye_matches, "tri": SearchForTriangulation}
     _compare(api, tight=False)
