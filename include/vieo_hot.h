@@ -792,7 +792,7 @@ int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const*
 #define VIEO_PREINT_OK 0
 #define VIEO_PREINT_EMPTY 1       /* no samples: PreIntegration() does nothing (outputs zeroed, dt = 0) */
 #define VIEO_PREINT_GAP 2         /* |dt| > 1.5 s between samples: "CheckIMU", mdeltatij = 0, returns -1 */
-#define VIEO_PREINT_UNSUPPORTED 3 /* timeStampi > timeStampj (map-reuse backward order): not built */
+#define VIEO_PREINT_UNSUPPORTED 3 /* (not returned any more: the backward order of map reuse, timeStampi > timeStampj, is built) */
 typedef struct vieo_imu_sample {
   double t;            /* IMUData::mtm */
   double w[3], a[3];   /* mw, ma */

@@ -114,8 +114,9 @@ static int preintegrate(const vieo_imu_noise& N, const vieo_imu_sample* L, int K
                         const double* bg, const double* ba, PreInt& P) {
   P.reset();
   if (K <= 0) return VIEO_PREINT_EMPTY;
-  if (ti > tj) return VIEO_PREINT_UNSUPPORTED;
-  const double timemin = ti, timemax = tj;
+  // timeStampi > timeStampj (map reuse): the samples are walked backwards with negative steps (:241-262)
+  const bool back = ti > tj;
+  const double timemin = back ? tj : ti, timemax = back ? ti : tj;
   int iter_start = 0, iter_stop = K;
   for (int j = 0; j != K && L[j].t <= timemin; iter_start = j++) {
   }
@@ -124,9 +125,19 @@ static int preintegrate(const vieo_imu_noise& N, const vieo_imu_sample* L, int K
     if (L[j].t >= timemax) continue;
     break;
   }
+  if (back) {
+    if (iter_stop == K) --iter_stop;
+    std::swap(iter_start, iter_stop);
+    if (L[iter_stop].t > timemin) iter_stop = K;  // assert(iter_stop == iterBegin): run down to the first sample
+  }
   for (int j = iter_start; j != iter_stop;) {
     const int jm1 = j;
-    ++j;
+    if (!back)
+      ++j;
+    else if (j == 0)
+      j = iter_stop;
+    else
+      --j;
     const double tj_1 = jm1 == iter_start ? ti : L[jm1].t;
     const double tjj = j == iter_stop ? tj : L[j].t;
     double dt = tjj - tj_1;
@@ -139,7 +150,7 @@ static int preintegrate(const vieo_imu_noise& N, const vieo_imu_sample* L, int K
     if (j != K) {
       if (j == iter_stop) {
         const double dt_tmp = L[j].t - tj;
-        if (dt_tmp > 0) {
+        if (back ? dt_tmp < 0 : dt_tmp > 0) {
           const double rat = dt_tmp / (L[j].t - L[jm1].t);
           for (int a = 0; a < 3; a++)
             imu_now.w[a] = rat * imu.w[a] + (1 - rat) * imu_now.w[a], imu_now.a[a] = rat * imu.a[a] + (1 - rat) * imu_now.a[a];
@@ -147,7 +158,7 @@ static int preintegrate(const vieo_imu_noise& N, const vieo_imu_sample* L, int K
       }
       if (jm1 == iter_start) {
         const double dt_tmp = ti - L[jm1].t;
-        if (dt_tmp > 0) {
+        if (back ? dt_tmp < 0 : dt_tmp > 0) {
           const double rat = dt_tmp / (L[j].t - L[jm1].t);
           for (int a = 0; a < 3; a++)
             imu.w[a] = (1 - rat) * imu.w[a] + rat * imu_now.w[a], imu.a[a] = (1 - rat) * imu.a[a] + rat * imu_now.a[a];
@@ -157,7 +168,7 @@ static int preintegrate(const vieo_imu_noise& N, const vieo_imu_sample* L, int K
     double w[3], a[3];
     if (jm1 == iter_start) {
       const double dt_comple = L[jm1].t - ti;
-      if (dt_comple > 0) {
+      if (back ? dt_comple < 0 : dt_comple > 0) {
         for (int q = 0; q < 3; q++) w[q] = imu.w[q] - bg[q], a[q] = imu.a[q] - ba[q];
         update(P, N, w, a, dt_comple);
         dt -= dt_comple;
@@ -167,11 +178,11 @@ static int preintegrate(const vieo_imu_noise& N, const vieo_imu_sample* L, int K
     double dt_comple_stop = 0;
     if (j == iter_stop) {
       dt_comple_stop = tj - imu_now.t;
-      if (dt_comple_stop > 0) dt -= dt_comple_stop;
+      if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) dt -= dt_comple_stop;
     }
     for (int q = 0; q < 3; q++) w[q] = (imu_now.w[q] + imu.w[q]) / 2 - bg[q], a[q] = (imu_now.a[q] + imu.a[q]) / 2 - ba[q];
     update(P, N, w, a, dt);
-    if (dt_comple_stop > 0) {
+    if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) {
       for (int q = 0; q < 3; q++) w[q] = imu_now.w[q] - bg[q], a[q] = imu_now.a[q] - ba[q];
       update(P, N, w, a, dt_comple_stop);
     }

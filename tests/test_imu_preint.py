@@ -59,16 +59,49 @@ def test_oracle_partial_intervals_and_status(oracle):
     # the window may start before the first and end after the last sample
     out2, _, st2 = oracle.imu_preintegrate(_noise(), [s[5:15]], [s["t"][5] - 0.003], [s["t"][14] + 0.004], [bg], [ba])
     assert st2[0] == 0 and abs(out2[0]["dt"] - (s["t"][14] + 0.004 - s["t"][5] + 0.003)) < 1e-12
-    # statuses: no samples / a 2 s hole / backward order
+    # statuses: no samples / a 2 s hole
     hole = s.copy()
     hole["t"][15:] += 2.0
-    _, _, st3 = oracle.imu_preintegrate(_noise(), [s[:0], hole, s], [5.0, hole["t"][0], s["t"][20]],
-                                        [5.1, hole["t"][-1], s["t"][2]], [bg] * 3, [ba] * 3)
-    assert st3.tolist() == [1, 2, 3]
+    _, _, st3 = oracle.imu_preintegrate(_noise(), [s[:0], hole], [5.0, hole["t"][0]], [5.1, hole["t"][-1]], [bg] * 2,
+                                        [ba] * 2)
+    assert st3.tolist() == [1, 2]
     # noise model: per-sample 1/dt scaling equals the fixed one at the reference rate
     a, _, _ = oracle.imu_preintegrate(_noise(1), [s], [s["t"][0]], [s["t"][-1]], [bg], [ba])
     b, _, _ = oracle.imu_preintegrate(_noise(0), [s], [s["t"][0]], [s["t"][-1]], [bg], [ba])
     assert np.allclose(a[0]["Sigma"], b[0]["Sigma"], rtol=1e-6)
+
+
+def test_oracle_backward_order(oracle):
+    """timeStampi > timeStampj (map reuse, OdomPreIntegrator.h:241-262): the samples are walked backwards with
+    negative steps.  Constant measurements have closed forms whatever the splitting: R = Exp(w T), and with w = 0
+    v = a T, p = a T^2 / 2 (T = tj - ti < 0); the forward run over the same span mirrors them."""
+    rng = np.random.default_rng(4)
+    s = _samples(rng, 5.0, 30)
+    bg = ba = np.zeros(3)
+    for ti, tj in ((s["t"][24] + 0.001, s["t"][3] + 0.002),   # both ends inside a sample interval
+                   (s["t"][29] + 0.004, s["t"][0] - 0.003),   # beyond both ends of the list
+                   (s["t"][20], s["t"][5]),                   # on samples
+                   (s["t"][7] + 0.0031, s["t"][7] + 0.0012)):  # inside one interval
+        c = s.copy()
+        c["w"], c["a"] = s["w"][0], 0.0
+        out, _, st = oracle.imu_preintegrate(_noise(), [c], [ti], [tj], [bg], [ba])
+        T = tj - ti
+        assert st[0] == 0 and T < 0 and abs(out[0]["dt"] - T) < 1e-12, (ti, tj, out[0]["dt"])
+        assert np.allclose(out[0]["Rij"].reshape(3, 3), synth_ba.so3_exp(s["w"][0] * T), atol=1e-12)
+        c["w"], c["a"] = 0.0, s["a"][0]
+        out, _, st = oracle.imu_preintegrate(_noise(), [c], [ti], [tj], [bg], [ba])
+        assert np.allclose(out[0]["vij"], s["a"][0] * T, atol=1e-12) and np.allclose(out[0]["pij"], s["a"][0] * T * T / 2, atol=1e-12)
+    # varying measurements: forward over [a, b] then backward over [b, a] compose to (nearly) the identity rotation
+    a, b = s["t"][2] + 0.001, s["t"][26] + 0.003
+    f, _, _ = oracle.imu_preintegrate(_noise(), [s], [a], [b], [bg], [ba])
+    r, _, st = oracle.imu_preintegrate(_noise(), [s], [b], [a], [bg], [ba])
+    assert st[0] == 0 and abs(f[0]["dt"] + r[0]["dt"]) < 1e-12
+    assert np.abs(f[0]["Rij"].reshape(3, 3) @ r[0]["Rij"].reshape(3, 3) - np.eye(3)).max() < 1e-5
+    # a hole is still refused
+    hole = s.copy()
+    hole["t"][15:] += 2.0
+    _, _, st = oracle.imu_preintegrate(_noise(), [hole], [hole["t"][-1]], [hole["t"][0]], [bg], [ba])
+    assert st[0] == 2
 
 
 @pytest.mark.gpu
@@ -85,6 +118,8 @@ def test_preintegration_parity(oracle):
         if n:
             ti.append(s["t"][0] + rng.uniform(-0.004, 0.012))
             tj.append(s["t"][-1] + rng.uniform(-0.012, 0.004))
+            if k % 3 == 2:  # backward order (map reuse)
+                ti[-1], tj[-1] = tj[-1], ti[-1]
         else:
             ti.append(0.0), tj.append(1.0)
     bg, ba = rng.normal(0, 0.01, (700, 3)), rng.normal(0, 0.05, (700, 3))

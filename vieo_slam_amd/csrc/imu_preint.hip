@@ -119,20 +119,32 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
   int st = VIEO_PREINT_OK;
   if (K <= 0)
     st = VIEO_PREINT_EMPTY;
-  else if (ti > tj)
-    st = VIEO_PREINT_UNSUPPORTED;
   else {
+    // timeStampi > timeStampj (map reuse): the samples are walked backwards with negative steps (:241-262)
+    const bool back = ti > tj;
+    const double timemin = back ? tj : ti, timemax = back ? ti : tj;
     int iter_start = 0, iter_stop = K;
-    for (int j = 0; j != K && L[j].t <= ti; iter_start = j++) {
+    for (int j = 0; j != K && L[j].t <= timemin; iter_start = j++) {
     }
     for (int j = K; j != 0;) {
       iter_stop = j--;
-      if (L[j].t >= tj) continue;
+      if (L[j].t >= timemax) continue;
       break;
+    }
+    if (back) {
+      if (iter_stop == K) --iter_stop;
+      const int t = iter_start;
+      iter_start = iter_stop, iter_stop = t;
+      if (L[iter_stop].t > timemin) iter_stop = K;  // (only at the first sample) run down to it, then stop
     }
     for (int j = iter_start; j != iter_stop;) {
       const int jm1 = j;
-      ++j;
+      if (!back)
+        ++j;
+      else if (j == 0)
+        j = iter_stop;
+      else
+        --j;
       const double tj_1 = jm1 == iter_start ? ti : L[jm1].t;
       const double tjj = j == iter_stop ? tj : L[j].t;
       double dt = tjj - tj_1;
@@ -146,7 +158,7 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
       if (j != K) {
         if (j == iter_stop) {
           const double dt_tmp = L[j].t - tj;
-          if (dt_tmp > 0) {
+          if (back ? dt_tmp < 0 : dt_tmp > 0) {
             const double rat = dt_tmp / (L[j].t - L[jm1].t);
             for (int a = 0; a < 3; a++)
               imu_now.w[a] = rat * imu.w[a] + (1 - rat) * imu_now.w[a], imu_now.a[a] = rat * imu.a[a] + (1 - rat) * imu_now.a[a];
@@ -154,7 +166,7 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
         }
         if (jm1 == iter_start) {
           const double dt_tmp = ti - L[jm1].t;
-          if (dt_tmp > 0) {
+          if (back ? dt_tmp < 0 : dt_tmp > 0) {
             const double rat = dt_tmp / (L[j].t - L[jm1].t);
             for (int a = 0; a < 3; a++)
               imu.w[a] = (1 - rat) * imu.w[a] + rat * imu_now.w[a], imu.a[a] = (1 - rat) * imu.a[a] + rat * imu_now.a[a];
@@ -164,7 +176,7 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
       double w[3], a[3];
       if (jm1 == iter_start) {
         const double dt_comple = L[jm1].t - ti;
-        if (dt_comple > 0) {
+        if (back ? dt_comple < 0 : dt_comple > 0) {
           for (int q = 0; q < 3; q++) w[q] = imu.w[q] - bg[q], a[q] = imu.a[q] - ba[q];
           preint_update(P, N, w, a, dt_comple);
           dt -= dt_comple;
@@ -174,11 +186,11 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
       double dt_comple_stop = 0;
       if (j == iter_stop) {
         dt_comple_stop = tj - imu_now.t;
-        if (dt_comple_stop > 0) dt -= dt_comple_stop;
+        if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) dt -= dt_comple_stop;
       }
       for (int q = 0; q < 3; q++) w[q] = (imu_now.w[q] + imu.w[q]) / 2 - bg[q], a[q] = (imu_now.a[q] + imu.a[q]) / 2 - ba[q];
       preint_update(P, N, w, a, dt);
-      if (dt_comple_stop > 0) {
+      if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) {
         for (int q = 0; q < 3; q++) w[q] = imu_now.w[q] - bg[q], a[q] = imu_now.a[q] - ba[q];
         preint_update(P, N, w, a, dt_comple_stop);
       }
