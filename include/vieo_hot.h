@@ -788,7 +788,8 @@ int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const*
  * true) + update() (src/Odom/OdomPreIntegrator.h:226-506; mid-point samples, the partial intervals at both ends
  * interpolated as the reference does, USE_PREINT_EULA off) for a batch of intervals, one lane per interval:
  * delta R / v / p, the five bias Jacobians, Sigma in both orders (mSigmaij: p v Phi; mSigmaijPRV: p Phi v).
- * Interval k owns the samples [h_first[k], h_first[k + 1]) (time-ordered).  h_status[k]: */
+ * Interval k owns the samples [h_first[k], h_first[k + 1]) (time-ordered).  h_ti[k] > h_tj[k] is the reference's
+ * backward order (map reuse, :241-262): the samples are walked from the end with negative steps.  h_status[k]: */
 #define VIEO_PREINT_OK 0
 #define VIEO_PREINT_EMPTY 1       /* no samples: PreIntegration() does nothing (outputs zeroed, dt = 0) */
 #define VIEO_PREINT_GAP 2         /* |dt| > 1.5 s between samples: "CheckIMU", mdeltatij = 0, returns -1 */
