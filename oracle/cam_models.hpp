@@ -1,4 +1,4 @@
-// ORACLE -- TEST INFRASTRUCTURE ONLY.  camm::{Pinhole,Radtan,KB8}Camera::Project restated
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.  camm::{Pinhole,Radtan,KB8}Camera::Project restated
 // (common/camera_models/camera_pinhole.h:70-106, camera_radtan.h:61-129, camera_kb8.h:68-157):
 // float parameters (Tdata), double arithmetic (Tcalc), image point returned as float (Vec2data).
 #pragma once

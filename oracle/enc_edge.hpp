@@ -1,4 +1,4 @@
-// ORACLE -- TEST INFRASTRUCTURE ONLY.  EdgeEncNavState<DV>::computeError / linearizeOplus (reference
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.  EdgeEncNavState<DV>::computeError / linearizeOplus (reference
 // src/Odom/g2otypes.h:606-665, USE_P_PLUS_RDP on: NavState.h:8) restated on the closed forms of smallmat.hpp.
 #pragma once
 #include <cmath>

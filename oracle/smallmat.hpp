@@ -1,4 +1,4 @@
-// ORACLE -- TEST INFRASTRUCTURE ONLY.  Tiny dense linear algebra + SO(3) helpers for the BA oracle.
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.  Tiny dense linear algebra + SO(3) helpers for the BA oracle.
 // The reference uses Eigen 3.3.7 and Sophus (third-party, absent here); these restate the few
 // closed-form operations it needs.  SO(3) functions follow common/so3_extra.h line by line.
 #pragma once
