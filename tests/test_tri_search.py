@@ -138,6 +138,13 @@ def test_gpu_search_for_triangulation_edge_cases(oracle):
     assert len(tri_search.SearchForTriangulation(kf1, kf2s)[0][0]) == 0
     rc, _ = tri_search.tri_call(lib().vieo_search_for_triangulation, kf1, kf2s, pair_capacity=5)
     assert rc == -3 or rc != 0
+    empty = tri_search.TriKeyFrame(np.eye(4), (458.0, 457.0, 367.0, 248.0), kf1.keys[:0], kf1.desc[:0], kf1.uright[:0],
+                                   kf1.has_mp[:0], [], kf1.scale, kf1.sigma2)  # a key frame without keys / nodes
+    got = tri_search.SearchForTriangulation(kf1, [empty, kf2s[1]])
+    assert len(got[0][0]) == 0 and len(got[1][0]) > 0
+    assert all(len(g[0]) == 0 for g in tri_search.SearchForTriangulation(empty, kf2s))
+    ref = oracle.search_for_triangulation(kf1, [empty, kf2s[1]])
+    assert np.array_equal(ref[1][0], got[1][0])
     rigged, _, _ = tri_search.make_tri_scene(4, n_neighbours=1, rig="radtan", n_points=100)
     rc, _ = tri_search.tri_call(lib().vieo_search_for_triangulation, rigged, kf2s)  # a rig against undistorted key frames
     assert rc != 0
