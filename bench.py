@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="stereo frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=2048, help="stereo frames per GPU per step")
     ap.add_argument("--base-cases", type=int, default=8, help="distinct rendered scenes per GPU")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent frame pipelines per GPU, each on its own HIP stream (the batch "
