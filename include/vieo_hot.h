@@ -233,6 +233,20 @@ int vieo_stereo_match_rectified_batch_device(vieo_orb* e, int n_frames,
                                              int capacity, float baseline, float bf,
                                              float* d_uright, float* d_depth);
 
+/* camm::Camera of one physical camera as an EdgeReproject sees it (a20: common/camera_models/
+ * camera_pinhole.h:70-106, camera_radtan.h:61-129, camera_kb8.h:68-157), with EdgeReproject::SetParams
+ * (g2otypes.h:409-416) already applied to the extrinsics: Rcb = Rccr * Rcrb, tcb = Rccr * tcrb + tcr. */
+#define VIEO_CAM_PINHOLE 0
+#define VIEO_CAM_RADTAN 1
+#define VIEO_CAM_KB8 2
+typedef struct vieo_camera {
+  int32_t model;   /* VIEO_CAM_* */
+  int32_t num_k;   /* Radtan: number of radial coefficients (parameters.size() - 6), else unused */
+  float fx, fy, cx, cy;
+  float dist[8];   /* Radtan: k1..k_num_k, p1, p2;  KB8: k1..k4 */
+  double Rcb[9], tcb[3];
+} vieo_camera;
+
 /* ---------------------------------------------------------------- projection search ---------
  * Replaces the tracking-side ORBmatcher::SearchByProjection overloads (src/ORBmatcher.cc:230-335
  * and :1303-1467) on flattened inputs.  The window query is FrameBase::GetFeaturesInArea
@@ -243,7 +257,8 @@ typedef struct vieo_proj_query { /* one map point projected into one camera: 64 
   float radius;                  /* window half-size in pixels (th * scale already applied) */
   int32_t level_min, level_max;  /* GetFeaturesInArea(minlevel, maxlevel); level_max < 0: no max */
   float angle;                   /* angle of the query's own keypoint (rotation check, a12) */
-  int32_t flags;                 /* bit0: valid; bit1: the map point has Observations() > 0 */
+  int32_t flags;                 /* bit0: valid; bit1: the map point has Observations() > 0;
+                                  * bits 8..11: camera of a rig frame (0 for the single-camera entries) */
   uint8_t desc[32];              /* MapPoint::GetDescriptor() */
 } vieo_proj_query;
 
@@ -304,6 +319,67 @@ int vieo_sbp_project_last_frame_batch_device(const vieo_last_frame_point* d_poin
                                              const vieo_sbp_camera* d_cams,
                                              vieo_proj_query* d_queries, void* stream);
 
+/* ---- the same searches for frames of a camera rig (Frame::mpCameras.size() cameras, distorted or not) -------
+ * The reference loops the cameras inside every overload: SearchByProjection(Frame&, const Frame&) projects each
+ * last-frame point into every camera camj with mpCameras[camj]->GetTcr() and, when Frame::usedistort_, the camera
+ * model's Project() (ORBmatcher.cc:1339-1366); the local-map overload walks the point's vtrack_cami_ list
+ * (:257-266); the relocalisation overload loops cami (:1491-1543).  Every (point, camera) pair is one query, in
+ * point-major order -- that is the order in which keys are claimed -- and its camera travels in bits 8..11 of
+ * vieo_proj_query.flags.  The window query is GetFeaturesInArea(cami, ...) on that camera's 64 x 48 grid
+ * (FrameBase.cpp:95-141); the frame's keys are mvKeys in camera-major order (Frame.cc:738-764), camera c owning
+ * the keys [cam_first[c], cam_first[c + 1]).  One rotation histogram is shared by all cameras. */
+typedef struct vieo_sbp_rig {
+  int32_t n_cams;      /* 1..4 */
+  int32_t use_distort; /* Frame::usedistort_: 1 -> mpCameras[c]->Project(), 0 -> K * (x/z, y/z, 1) in float */
+  vieo_camera cams[4]; /* model + float parameters of mpCameras[c] (Rcb / tcb unused here) */
+  double Tcr[4][12];   /* mpCameras[c]->GetTcr().cast<double>(), row-major 3x4 (identity for the reference camera) */
+  double trc[4][3];    /* mpCameras[c]->GetTrc().translation().cast<double>() (camera centre, relocalisation variant) */
+  float bounds[4][4];  /* gridinfo_.minmax_xy_[c]: min_x, max_x, min_y, max_y */
+} vieo_sbp_rig;        /* 1160 bytes */
+
+/* pKF->GetMapPointMatches()[i] of the relocalisation overload, flattened: 64 bytes, the layout of
+ * vieo_last_frame_point with the two distances in place of `reserved`. */
+typedef struct vieo_keyframe_point {
+  float Xw[3];       /* MapPoint::GetWorldPos() */
+  int32_t octave;    /* unused (the level is predicted from the distance) */
+  float angle;       /* pKF->mvKeys[i].angle */
+  int32_t flags;     /* bit0: pMP != NULL && !isBad() && not in sAlreadyFound; bit1: Observations() > 0 */
+  float max_distance, min_distance; /* mfMaxDistance, mfMinDistance (the 1.2 / 0.8 factors are applied here) */
+  uint8_t desc[32];
+} vieo_keyframe_point;
+
+/* ORBmatcher.cc:1313-1378 with the camera loop: h_queries[i * n_cams + camj].  h_cam supplies the poses, bf,
+ * baseline, th, th_far, mono and the scale factors; its fx..cy / bounds are not read (h_rig has them). */
+int vieo_sbp_project_last_frame_rig(const vieo_last_frame_point* h_points, int n, const vieo_sbp_camera* h_cam,
+                                    const vieo_sbp_rig* h_rig, vieo_proj_query* h_queries /*[n * n_cams]*/);
+/* Projection part of SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist, th_far)
+ * (ORBmatcher.cc:1487-1543): Tcr, Project / K, IsInImage, the scale-invariance distances, MapPoint::PredictScale,
+ * window th * scale[level], levels [L-1, L+1].  h_cam: Tcw_cur, th, th_far, nlevels, scale;
+ * log_scale_factor = scalepyrinfo_.flogscalefactor_.  h_rig == NULL: the one rectified camera of h_cam. */
+int vieo_sbp_project_keyframe(const vieo_keyframe_point* h_points, int n, const vieo_sbp_camera* h_cam,
+                              const vieo_sbp_rig* h_rig, float log_scale_factor,
+                              vieo_proj_query* h_queries /*[n * n_cams]*/);
+/* vieo_search_by_projection on the camera-major key list of a rig frame.  h_bounds: [n_cams][4]. */
+int vieo_search_by_projection_rig(int mode, const vieo_proj_query* h_queries, int nq, const vieo_keypoint* h_keys,
+                                  const float* h_uright, const uint8_t* h_desc, const uint8_t* h_taken, int n_keys,
+                                  const int32_t* h_cam_first /*[n_cams + 1]*/, const float* h_bounds, int n_cams,
+                                  float nn_ratio, int check_orientation, int32_t* h_assign, int32_t* nmatches);
+/* Batched device forms.  Frame f owns the queries [f * q_cap, f * q_cap + d_nq[f]) and the key arrays
+ * [f * key_cap, f * key_cap + d_cam_first[f * (n_cams + 1) + n_cams]) (already concatenated camera-major);
+ * d_rigs: one vieo_sbp_rig per frame; h_bounds [n_cams][4] shared by all frames. */
+int vieo_sbp_project_last_frame_rig_batch_device(const vieo_last_frame_point* d_points, const int32_t* d_n,
+                                                 int p_cap, int n_frames, const vieo_sbp_camera* d_cams,
+                                                 const vieo_sbp_rig* d_rigs, int n_cams,
+                                                 vieo_proj_query* d_queries /*[n_frames][p_cap * n_cams]*/,
+                                                 void* stream);
+int vieo_search_by_projection_rig_batch_device(int mode, const vieo_proj_query* d_queries, const int32_t* d_nq,
+                                               int q_cap, int n_frames, const vieo_keypoint* d_keys,
+                                               const float* d_uright, const uint8_t* d_desc,
+                                               const uint8_t* d_taken, const int32_t* d_cam_first, int key_cap,
+                                               const float* h_bounds, int n_cams, float nn_ratio,
+                                               int check_orientation, int32_t* d_assign, int32_t* d_nmatches,
+                                               void* stream);
+
 /* ---------------------------------------------------------------- pose optimisation --------
  * Replaces Optimizer::PoseOptimization (motion-only BA with fixed map points).  The host shim
  * flattens Frame / MapPoint objects into the POD structs below and writes the results back
@@ -318,19 +394,6 @@ typedef struct vieo_navstate {
   double bg[3], ba[3], dbg[3], dba[3];
 } vieo_navstate;
 
-/* camm::Camera of one physical camera as an EdgeReproject sees it (a20: common/camera_models/
- * camera_pinhole.h:70-106, camera_radtan.h:61-129, camera_kb8.h:68-157), with EdgeReproject::SetParams
- * (g2otypes.h:409-416) already applied to the extrinsics: Rcb = Rccr * Rcrb, tcb = Rccr * tcrb + tcr. */
-#define VIEO_CAM_PINHOLE 0
-#define VIEO_CAM_RADTAN 1
-#define VIEO_CAM_KB8 2
-typedef struct vieo_camera {
-  int32_t model;   /* VIEO_CAM_* */
-  int32_t num_k;   /* Radtan: number of radial coefficients (parameters.size() - 6), else unused */
-  float fx, fy, cx, cy;
-  float dist[8];   /* Radtan: k1..k_num_k, p1, p2;  KB8: k1..k4 */
-  double Rcb[9], tcb[3];
-} vieo_camera;
 
 /* One 3D-2D correspondence = one EdgeReprojectPR / PRStereo (src/Odom/g2otypes.h:321-547). */
 typedef struct vieo_pose_obs {

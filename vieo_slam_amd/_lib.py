@@ -75,6 +75,12 @@ _SIGS = {
     "vieo_stereo_match_rectified": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_f, c_p, c_p]),
     "vieo_stereo_match_rectified_batch_device": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p]),
     "vieo_sbp_project_last_frame": (c_i, [c_p, c_i, c_p, c_p]),
+    "vieo_sbp_project_last_frame_rig": (c_i, [c_p, c_i, c_p, c_p, c_p]),
+    "vieo_sbp_project_keyframe": (c_i, [c_p, c_i, c_p, c_p, c_f, c_p]),
+    "vieo_search_by_projection_rig": (c_i, [c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_i, c_p, c_p]),
+    "vieo_sbp_project_last_frame_rig_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
+    "vieo_search_by_projection_rig_batch_device": (c_i, [c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i,
+                                                          c_f, c_i, c_p, c_p, c_p]),
     "vieo_search_by_projection": (c_i, [c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_f, c_i, c_p, c_p]),
     "vieo_search_by_projection_batch_device": (c_i, [c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_i, c_p, c_p, c_p]),
     "vieo_sbp_project_last_frame_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),

@@ -31,6 +31,9 @@ SBP_CAMERA_DTYPE = np.dtype([("Tcw_cur", "<f8", 12), ("Tcw_last", "<f8", 12), ("
                              ("mono", "<i4"), ("nlevels", "<i4"), ("scale", "<f4", 16)], align=True)
 assert PROJ_QUERY_DTYPE.itemsize == 64 and LAST_FRAME_POINT_DTYPE.itemsize == 64
 assert SBP_CAMERA_DTYPE.itemsize == 312
+KEYFRAME_POINT_DTYPE = np.dtype([("Xw", "<f4", 3), ("octave", "<i4"), ("angle", "<f4"), ("flags", "<i4"),
+                                 ("max_distance", "<f4"), ("min_distance", "<f4"), ("desc", "u1", 32)], align=True)
+assert KEYFRAME_POINT_DTYPE.itemsize == 64
 
 IMU_PREINT_DTYPE = np.dtype([("dt", "<f8"), ("Rij", "<f8", 9), ("vij", "<f8", 3), ("pij", "<f8", 3),
                              ("JgR", "<f8", 9), ("Jgv", "<f8", 9), ("Jav", "<f8", 9),
@@ -50,6 +53,10 @@ LBA_OBS_DTYPE = np.dtype([("kf", "<i4"), ("mp", "<i4"), ("u", "<f4"), ("v", "<f4
 CAMERA_DTYPE = np.dtype([("model", "<i4"), ("num_k", "<i4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"),
                          ("cy", "<f4"), ("dist", "<f4", 8), ("Rcb", "<f8", 9), ("tcb", "<f8", 3)], align=True)
 assert CAMERA_DTYPE.itemsize == 152
+# vieo_sbp_rig: the cameras of a rig frame as the tracking-side projection searches use them
+SBP_RIG_DTYPE = np.dtype([("n_cams", "<i4"), ("use_distort", "<i4"), ("cams", CAMERA_DTYPE, 4),
+                          ("Tcr", "<f8", (4, 12)), ("trc", "<f8", (4, 3)), ("bounds", "<f4", (4, 4))], align=True)
+assert SBP_RIG_DTYPE.itemsize == 1160
 # "cams" is a host pointer (array.ctypes.data of a CAMERA_DTYPE array the caller keeps alive)
 LBA_PARAMS_DTYPE = np.dtype([("Rcb", "<f8", 9), ("tcb", "<f8", 3), ("fx", "<f4"), ("fy", "<f4"),
                              ("cx", "<f4"), ("cy", "<f4"), ("bf", "<f4"), ("its0", "<i4"),

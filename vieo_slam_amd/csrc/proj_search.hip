@@ -21,18 +21,39 @@ namespace vieo {
 static const int kGridRows = 48, kGridCols = 64;  // FrameBase.h:224-225
 static const int kThHigh = 100, kHistoLen = 30;   // ORBmatcher.cc:20-22
 static const int kCandCap = 128;                  // candidates kept per query (2 per lane)
-static const int kMaxKeys = 4096;                 // 12-bit key index packing
+static const int kMaxKeys = 8192;                 // 13-bit key index packing (4 cameras x 1500 features fit)
+static const int kMaxCams = 4;
 
-// ORBmatcher.cc:1313-1378
+// the cameras of a rig frame on the device (vieo_sbp_rig widened once per thread block user)
+__device__ __forceinline__ void rig_uv(const vieo_sbp_rig& R, int cam, const double* x3Dc, float invzc, float* u, float* v) {
+  const vieo_camera& c = R.cams[cam];
+  if (R.use_distort) {
+    CamD d;
+    cam_from_abi(c, d);
+    double uv[2];
+    cam_project(d, x3Dc, uv, nullptr);
+    *u = (float)uv[0], *v = (float)uv[1];
+  } else {
+    const float xc = (float)x3Dc[0], yc = (float)x3Dc[1];
+    const float pnx = xc * invzc, pny = yc * invzc;
+    *u = c.fx * pnx + 0.f * pny + c.cx * 1.f;
+    *v = 0.f * pnx + c.fy * pny + c.cy * 1.f;
+  }
+}
+
+// ORBmatcher.cc:1313-1378.  One thread per (last-frame point, camera): rigs == nullptr is the single rectified
+// camera of vieo_sbp_camera (n_cams = 1), otherwise query (i, camj) goes to out[i * n_cams + camj].
 __global__ void __launch_bounds__(256)
 k_sbp_project(const vieo_last_frame_point* __restrict__ pts, const int* __restrict__ n_pts,
-              int p_cap, const vieo_sbp_camera* __restrict__ cams, vieo_proj_query* __restrict__ out) {
+              int p_cap, const vieo_sbp_camera* __restrict__ cams, const vieo_sbp_rig* __restrict__ rigs,
+              int n_cams, vieo_proj_query* __restrict__ out) {
   const int f = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p_cap) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p_cap * n_cams) return;
+  const int i = t / n_cams, camj = t - i * n_cams;
   vieo_proj_query q;
   memset(&q, 0, sizeof(q));
-  vieo_proj_query* dst = out + (size_t)f * p_cap + i;
+  vieo_proj_query* dst = out + (size_t)f * p_cap * n_cams + t;
   if (i >= n_pts[f]) {
     *dst = q;
     return;
@@ -50,17 +71,31 @@ k_sbp_project(const vieo_last_frame_point* __restrict__ pts, const int* __restri
   const bool bForward = tz > C.baseline && !C.mono;
   const bool bBackward = -tz > C.baseline && !C.mono;
   const double X = p.Xw[0], Y = p.Xw[1], Z = p.Xw[2];
-  const double x3 = Tc[0] * X + Tc[1] * Y + Tc[2] * Z + Tc[3];
-  const double y3 = Tc[4] * X + Tc[5] * Y + Tc[6] * Z + Tc[7];
-  const double z3 = Tc[8] * X + Tc[9] * Y + Tc[10] * Z + Tc[11];
-  if (C.th_far > 0 && z3 > C.th_far) ok = false;
-  const float xc = (float)x3, yc = (float)y3;
-  const float invzc = (float)(1.0 / z3);
+  double x3[3];
+  x3[0] = Tc[0] * X + Tc[1] * Y + Tc[2] * Z + Tc[3];
+  x3[1] = Tc[4] * X + Tc[5] * Y + Tc[6] * Z + Tc[7];
+  x3[2] = Tc[8] * X + Tc[9] * Y + Tc[10] * Z + Tc[11];
+  if (C.th_far > 0 && x3[2] > C.th_far) ok = false;
+  float u, v, invzc;
+  const float* bnd = C.bounds;
+  if (!rigs) {
+    const float xc = (float)x3[0], yc = (float)x3[1];
+    invzc = (float)(1.0 / x3[2]);
+    const float pnx = xc * invzc, pny = yc * invzc;
+    u = C.fx * pnx + 0.f * pny + C.cx * 1.f;
+    v = 0.f * pnx + C.fy * pny + C.cy * 1.f;
+  } else {
+    const vieo_sbp_rig& R = rigs[f];
+    const double* T = R.Tcr[camj];
+    double xc[3];
+    for (int r = 0; r < 3; ++r) xc[r] = T[r * 4] * x3[0] + T[r * 4 + 1] * x3[1] + T[r * 4 + 2] * x3[2] + T[r * 4 + 3];
+    invzc = (float)(1.0 / xc[2]);
+    u = v = 0.f;
+    if (!(invzc < 0)) rig_uv(R, camj, xc, invzc, &u, &v);
+    bnd = R.bounds[camj];
+  }
   if (invzc < 0) ok = false;
-  const float pnx = xc * invzc, pny = yc * invzc;
-  const float u = C.fx * pnx + 0.f * pny + C.cx * 1.f;
-  const float v = 0.f * pnx + C.fy * pny + C.cy * 1.f;
-  if (!(u >= C.bounds[0] && u < C.bounds[1] && v >= C.bounds[2] && v < C.bounds[3])) ok = false;
+  if (!(u >= bnd[0] && u < bnd[1] && v >= bnd[2] && v < bnd[3])) ok = false;
   if (ok) {
     const int oct = p.octave;
     q.u = u, q.v = v;
@@ -73,10 +108,71 @@ k_sbp_project(const vieo_last_frame_point* __restrict__ pts, const int* __restri
     else
       q.level_min = oct - 1, q.level_max = oct + 1;
     q.angle = p.angle;
-    q.flags = 1 | (p.flags & 2);
+    q.flags = 1 | (p.flags & 2) | (camj << 8);
     for (int k = 0; k < 32; k++) q.desc[k] = p.desc[k];
   }
   *dst = q;
+}
+
+// ORBmatcher.cc:1487-1543, the projection of the relocalisation overload (see oracle/proj_search.cc)
+__global__ void __launch_bounds__(256)
+k_sbp_project_kf(const vieo_keyframe_point* __restrict__ pts, int n, const vieo_sbp_camera* __restrict__ cam,
+                 const vieo_sbp_rig* __restrict__ rig, int n_cams, float log_scale_factor,
+                 vieo_proj_query* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * n_cams) return;
+  const int i = t / n_cams, cami = t - i * n_cams;
+  vieo_proj_query q;
+  memset(&q, 0, sizeof(q));
+  const vieo_sbp_camera& C = *cam;
+  const vieo_keyframe_point p = pts[i];
+  bool ok = p.flags & 1;
+  const double* Tc = C.Tcw_cur;
+  const double Xw[3] = {p.Xw[0], p.Xw[1], p.Xw[2]};
+  double x3[3];
+  for (int r = 0; r < 3; ++r) x3[r] = Tc[r * 4] * Xw[0] + Tc[r * 4 + 1] * Xw[1] + Tc[r * 4 + 2] * Xw[2] + Tc[r * 4 + 3];
+  if (C.th_far > 0 && x3[2] > C.th_far) ok = false;
+  // Twcr = Tcrw.inverse()
+  double tw[3];
+  for (int r = 0; r < 3; ++r) tw[r] = Tc[r] * (Tc[3] * -1.0) + Tc[4 + r] * (Tc[7] * -1.0) + Tc[8 + r] * (Tc[11] * -1.0);
+  double Pc[3], twc[3];
+  float u, v, invzc;
+  const float* bnd = C.bounds;
+  if (!rig) {
+    for (int r = 0; r < 3; ++r) Pc[r] = x3[r], twc[r] = tw[r];  // identity Tcr, zero trc
+    invzc = (float)(1.0 / Pc[2]);
+    const float xc = (float)Pc[0], yc = (float)Pc[1];
+    const float pnx = xc * invzc, pny = yc * invzc;
+    u = C.fx * pnx + 0.f * pny + C.cx * 1.f;
+    v = 0.f * pnx + C.fy * pny + C.cy * 1.f;
+  } else {
+    const double* T = rig->Tcr[cami];
+    for (int r = 0; r < 3; ++r) Pc[r] = T[r * 4] * x3[0] + T[r * 4 + 1] * x3[1] + T[r * 4 + 2] * x3[2] + T[r * 4 + 3];
+    const double* tr = rig->trc[cami];
+    for (int r = 0; r < 3; ++r) twc[r] = tw[r] + (Tc[r] * tr[0] + Tc[4 + r] * tr[1] + Tc[8 + r] * tr[2]);
+    invzc = (float)(1.0 / Pc[2]);
+    rig_uv(*rig, cami, Pc, invzc, &u, &v);
+    bnd = rig->bounds[cami];
+  }
+  if (!(u >= bnd[0] && u < bnd[1] && v >= bnd[2] && v < bnd[3])) ok = false;
+  const double PO[3] = {Xw[0] - twc[0], Xw[1] - twc[1], Xw[2] - twc[2]};
+  const float dist3D = (float)sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+  if (dist3D < 0.8f * p.min_distance || dist3D > 1.2f * p.max_distance) ok = false;
+  if (ok) {
+    const float ratio = p.max_distance / dist3D;
+    int lvl = (int)ceilf((float)log((double)ratio) / log_scale_factor);  // PredictScale, see oracle/mappoint.cc
+    if (lvl < 0)
+      lvl = 0;
+    else if (lvl >= C.nlevels)
+      lvl = C.nlevels - 1;
+    q.u = u, q.v = v, q.ur = u - C.bf * invzc;
+    q.radius = C.th * C.scale[lvl];
+    q.level_min = lvl - 1, q.level_max = lvl + 1;
+    q.angle = p.angle;
+    q.flags = 1 | (p.flags & 2) | (cami << 8);
+    for (int k = 0; k < 32; k++) q.desc[k] = p.desc[k];
+  }
+  out[t] = q;
 }
 
 struct SbpArgs {
@@ -90,13 +186,15 @@ struct SbpArgs {
   const uint8_t* taken;            // [frame][key_cap] or null
   const int* counts;               // [image][2]
   int key_cap, img_first, img_step;
-  float minx, maxx, miny, maxy;
+  int n_cams;                       // cameras of a frame (1 for the single-camera entries)
+  const int* cam_first;             // [frame][n_cams + 1] key ranges of the cameras, or null: one camera, N = counts
+  float bounds[kMaxCams][4];        // gridinfo_.minmax_xy_[cam]
   float nn_ratio;
   int check_ori;
-  const int* cell_start;            // [frame][kGridCols * kGridRows + 1]  Frame::mGrid as CSR
-  const float4* cell_rec;           // [frame][key_cap] keys in cell order: x, y, uright, idx | octave << 16
+  const int* cell_start;            // [frame][cam][kGridCols * kGridRows + 1]  vgrids_[cam] as CSR (camera-local offsets)
+  const float4* cell_rec;           // [frame][key_cap] keys in (camera, cell) order: x, y, uright, idx | octave << 16
   const float* cell_ang;            // [frame][key_cap] their angles
-  unsigned* pool;      // [frame][pool_cap] candidates of all queries: idx | dist<<12 | level<<21 | bin<<25
+  unsigned* pool;      // [frame][pool_cap] candidates of all queries: idx | dist<<13 | level<<22 | bin<<26
   int* cursor;         // [frame] entries used in the pool
   int2* qrec;          // [frame][q_cap] {offset in the pool, count (-1: overflow) | has-observations << 16}
   int pool_cap, pool_lds;
@@ -115,6 +213,16 @@ __device__ __forceinline__ int hamming32q(const uint4 a0, const uint4 a1, const 
 // ascending key order (= the reference's push_back order).
 static const int kGridCells = kGridCols * kGridRows;
 
+// keys [k0, k1) of camera `cam` of frame f
+__device__ __forceinline__ void cam_range(const SbpArgs& A, int f, int cam, int* k0, int* k1) {
+  if (A.cam_first) {
+    const int* cf = A.cam_first + (size_t)f * (A.n_cams + 1);
+    *k0 = min(cf[cam], A.key_cap), *k1 = min(cf[cam + 1], A.key_cap);
+  } else {
+    *k0 = 0, *k1 = min(A.counts[2 * (A.img_first + f * A.img_step)], A.key_cap);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ cell_start,
                                                   float4* __restrict__ cell_rec,
                                                   float* __restrict__ cell_ang) {
@@ -122,15 +230,18 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
   __shared__ int s_cur[kGridCells];
   __shared__ unsigned short s_list[kMaxKeys];
   __shared__ int s_part[256];
-  const int f = blockIdx.x, tid = threadIdx.x;
+  const int f = blockIdx.x / A.n_cams, cam = blockIdx.x - f * A.n_cams, tid = threadIdx.x;
   const int img = A.img_first + f * A.img_step;
-  const int N = min(A.counts[2 * img], A.key_cap);
-  const vieo_keypoint* K = A.keys + (size_t)img * A.key_cap;
-  const float winv = (float)kGridCols / (A.maxx - A.minx), hinv = (float)kGridRows / (A.maxy - A.miny);
+  int k0, k1;
+  cam_range(A, f, cam, &k0, &k1);
+  const int N = k1 - k0;
+  const vieo_keypoint* K = A.keys + (size_t)img * A.key_cap + k0;
+  const float minx = A.bounds[cam][0], miny = A.bounds[cam][2];
+  const float winv = (float)kGridCols / (A.bounds[cam][1] - minx), hinv = (float)kGridRows / (A.bounds[cam][3] - miny);
   for (int c = tid; c <= kGridCells; c += 256) s_cnt[c] = 0;
   __syncthreads();
   for (int j = tid; j < N; j += 256) {
-    const int posX = (int)roundf((K[j].x - A.minx) * winv), posY = (int)roundf((K[j].y - A.miny) * hinv);
+    const int posX = (int)roundf((K[j].x - minx) * winv), posY = (int)roundf((K[j].y - miny) * hinv);
     if (posX >= 0 && posX < kGridCols && posY >= 0 && posY < kGridRows) atomicAdd(&s_cnt[posX * kGridRows + posY], 1);
   }
   __syncthreads();
@@ -149,16 +260,19 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
   }
   __syncthreads();
   int acc = s_part[tid];
-  int* cs = cell_start + (size_t)f * (kGridCells + 1);
+  int* cs = cell_start + (size_t)blockIdx.x * (kGridCells + 1);
   for (int c = c0; c < c0 + per; c++) {
     const int v = s_cnt[c];
     cs[c] = acc, s_cur[c] = acc;
     acc += v;
   }
-  if (tid == 255) cs[kGridCells] = acc, A.cursor[f] = 0;
+  if (tid == 255) {
+    cs[kGridCells] = acc;
+    if (cam == 0) A.cursor[f] = 0;
+  }
   __syncthreads();
   for (int j = tid; j < N; j += 256) {
-    const int posX = (int)roundf((K[j].x - A.minx) * winv), posY = (int)roundf((K[j].y - A.miny) * hinv);
+    const int posX = (int)roundf((K[j].x - minx) * winv), posY = (int)roundf((K[j].y - miny) * hinv);
     if (posX >= 0 && posX < kGridCols && posY >= 0 && posY < kGridRows)
       s_list[atomicAdd(&s_cur[posX * kGridRows + posY], 1)] = (unsigned short)j;
   }
@@ -173,15 +287,16 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
     }
   }
   __syncthreads();
-  // the keys in cell order, with everything a window test reads in one 16-byte record
+  // the keys in cell order, with everything a window test reads in one 16-byte record; the index is the key's
+  // position in the frame's list (mvKeys), i.e. camera-local + k0
   const int n_in = s_cur[kGridCells - 1];
-  const float* uright = A.uright + (size_t)f * A.key_cap;
-  float4* rec = cell_rec + (size_t)f * A.key_cap;
-  float* ang = cell_ang + (size_t)f * A.key_cap;
+  const float* uright = A.uright + (size_t)f * A.key_cap + k0;
+  float4* rec = cell_rec + (size_t)f * A.key_cap + k0;
+  float* ang = cell_ang + (size_t)f * A.key_cap + k0;
   for (int i = tid; i < n_in; i += 256) {
     const int j = s_list[i];
     const vieo_keypoint k = K[j];
-    rec[i] = make_float4(k.x, k.y, uright[j], __int_as_float(j | (k.octave << 16)));
+    rec[i] = make_float4(k.x, k.y, uright[j], __int_as_float((j + k0) | (k.octave << 16)));
     ang[i] = k.angle;
   }
 }
@@ -205,22 +320,21 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int* total) {
 static const int kSbpBlocks = 8;
 
 __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
-  __shared__ int s_cs[kGridCells + 1];
+  extern __shared__ unsigned short s_cs[];  // [n_cams][kGridCells + 1] camera-local offsets (< kMaxKeys: 16 bits)
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nq = min(A.nq[f], A.q_cap);
   const int img = A.img_first + f * A.img_step;
   {
-    const int* cs = A.cell_start + (size_t)f * (kGridCells + 1);
-    for (int i = threadIdx.x; i <= kGridCells; i += 256) s_cs[i] = cs[i];
+    const int* cs = A.cell_start + (size_t)f * A.n_cams * (kGridCells + 1);
+    for (int i = threadIdx.x; i < A.n_cams * (kGridCells + 1); i += 256) s_cs[i] = (unsigned short)cs[i];
   }
   // queries past nq: empty records (the replay never reads them, but keep the buffer defined)
   for (int q = nq + blockIdx.x * 256 + threadIdx.x; q < A.q_cap; q += kSbpBlocks * 256)
     A.qrec[(size_t)f * A.q_cap + q] = make_int2(0, 0);
   __syncthreads();
-  const float winv = (float)kGridCols / (A.maxx - A.minx), hinv = (float)kGridRows / (A.maxy - A.miny);
   const uint8_t* D = A.desc + (size_t)img * A.key_cap * 32;
-  const float4* rec = A.cell_rec + (size_t)f * A.key_cap;
-  const float* ang = A.cell_ang + (size_t)f * A.key_cap;
+  const float4* rec_f = A.cell_rec + (size_t)f * A.key_cap;
+  const float* ang_f = A.cell_ang + (size_t)f * A.key_cap;
   unsigned* pool = A.pool + (size_t)f * A.pool_cap;
   const float factor = 1.0f / kHistoLen;
   const int stride = kSbpBlocks * 4;
@@ -243,15 +357,24 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
       a0 = QQ[4 * (size_t)qn + 2], a1 = QQ[4 * (size_t)qn + 3];
     }
     int2* out = A.qrec + (size_t)f * A.q_cap + q;
-    if (!(flags & 1)) {
+    const int cam = (flags >> 8) & 15;
+    if (!(flags & 1) || cam >= A.n_cams) {
       if (lane == 0) *out = make_int2(0, 0);
       continue;
     }
+    // the query's camera: bounds, its slice of the records (camera c's records start at its first key)
+    const float minx = A.bounds[cam][0], miny = A.bounds[cam][2];
+    const float winv = (float)kGridCols / (A.bounds[cam][1] - minx), hinv = (float)kGridRows / (A.bounds[cam][3] - miny);
+    int k0 = 0;
+    if (A.cam_first) k0 = min(A.cam_first[(size_t)f * (A.n_cams + 1) + cam], A.key_cap);
+    const float4* rec = rec_f + k0;
+    const float* ang = ang_f + k0;
+    const unsigned short* cs = s_cs + cam * (kGridCells + 1);
     // FrameBase.cpp:102-115
-    const int min_cellx = max(0, (int)floorf((x - A.minx - r) * winv));
-    const int max_cellx = min(kGridCols - 1, (int)ceilf((x - A.minx + r) * winv));
-    const int min_celly = max(0, (int)floorf((y - A.miny - r) * hinv));
-    const int max_celly = min(kGridRows - 1, (int)ceilf((y - A.miny + r) * hinv));
+    const int min_cellx = max(0, (int)floorf((x - minx - r) * winv));
+    const int max_cellx = min(kGridCols - 1, (int)ceilf((x - minx + r) * winv));
+    const int min_celly = max(0, (int)floorf((y - miny - r) * hinv));
+    const int max_celly = min(kGridRows - 1, (int)ceilf((y - miny + r) * hinv));
     if (min_cellx >= kGridCols || max_cellx < 0 || min_celly >= kGridRows || max_celly < 0 ||
         min_cellx > max_cellx || min_celly > max_celly) {
       if (lane == 0) *out = make_int2(0, 0);
@@ -262,8 +385,8 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
     int seg_s = 0, seg_l = 0;
     if (lane < nx) {
       const int col = (min_cellx + lane) * kGridRows;
-      seg_s = s_cs[col + min_celly];
-      seg_l = s_cs[col + max_celly + 1] - seg_s;
+      seg_s = cs[col + min_celly];
+      seg_l = cs[col + max_celly + 1] - seg_s;
     }
     int n_ent;
     const int seg_o = wave_excl_scan_i(seg_l, lane, &n_ent);  // first window entry of the run
@@ -296,7 +419,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
       if (rot < 0.0f) rot += 360.0f;
       int bin = (int)roundf(rot * factor);
       if (bin == kHistoLen) bin = 0;
-      return (unsigned)j | ((unsigned)d << 12) | ((unsigned)(oct & 15) << 21) | ((unsigned)(bin & 31) << 25);
+      return (unsigned)j | ((unsigned)d << 13) | ((unsigned)(oct & 15) << 22) | ((unsigned)(bin & 31) << 26);
     };
     const int obs_bit = (flags & 2) ? 1 << 16 : 0;
     if (n_ent <= 64) {  // the usual case: one evaluation
@@ -350,14 +473,19 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
 // one wave per frame: the frame's candidate pool is copied to LDS once, after that the replay of
 // the queries touches no global memory except the accepted assignments
 __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
+  // dynamic LDS: pool copy (pool_lds words) | log of accepted keys (q_cap u16) | key state (key_cap bytes) |
+  // log bins (q_cap bytes)
   extern __shared__ unsigned s_pool[];
-  __shared__ uint8_t s_state[kMaxKeys];  // bit0: holds a map point, bit1: it has Observations()>0
-  __shared__ unsigned short s_log_idx[kMaxKeys];
-  __shared__ uint8_t s_log_bin[kMaxKeys];
+  unsigned short* s_log_idx = (unsigned short*)(s_pool + A.pool_lds);
+  uint8_t* s_state = (uint8_t*)(s_log_idx + A.q_cap);  // bit0: holds a map point, bit1: it has Observations()>0
+  uint8_t* s_log_bin = s_state + A.key_cap;
   __shared__ int s_hist[kHistoLen];
   const int f = blockIdx.x, lane = threadIdx.x;
-  const int img = A.img_first + f * A.img_step;
-  const int N = min(A.counts[2 * img], A.key_cap);
+  int N;
+  {
+    int k0;
+    cam_range(A, f, A.n_cams - 1, &k0, &N);  // end of the last camera = number of keys of the frame
+  }
   const int nq = min(A.nq[f], A.q_cap);
   int* assign = A.assign + (size_t)f * A.key_cap;
   const uint8_t* taken = A.taken ? A.taken + (size_t)f * A.key_cap : nullptr;
@@ -405,7 +533,7 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
         const int pos = lane + 64 * h;
         if (pos < n) {
           const unsigned c = off + pos < n_lds ? s_pool[off + pos] : pool[off + pos];
-          const int idx = c & 0xFFF, d = (c >> 12) & 0x1FF;
+          const int idx = c & 0x1FFF, d = (c >> 13) & 0x1FF;
           const int st = s_state[idx];
           if (A.mode == VIEO_SBP_RELOC ? !(st & 1) : !((st & 1) && (st & 2))) {
             const unsigned key = ((unsigned)d << 8) | (unsigned)pos;  // (dist, order)
@@ -432,11 +560,11 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
       }
       if (b0 == 0xFFFFFFFFu) continue;
       const int bestDist = b0 >> 8;
-      const int bestIdx = c0 & 0xFFF, bestLevel = (c0 >> 21) & 15;
+      const int bestIdx = c0 & 0x1FFF, bestLevel = (c0 >> 22) & 15;
       if (bestDist > (A.mode == VIEO_SBP_RELOC ? (int)A.nn_ratio : kThHigh)) continue;
       if (A.mode == VIEO_SBP_LOCAL_MAP && b1 != 0xFFFFFFFFu) {
         const int bestDist2 = b1 >> 8;
-        const int bestLevel2 = (c1 >> 21) & 15;
+        const int bestLevel2 = (c1 >> 22) & 15;
         if (bestLevel == bestLevel2 && (float)bestDist > A.nn_ratio * (float)bestDist2) continue;
       }
       // AddMapPoint(pMP, bestIdx)
@@ -446,7 +574,7 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
       }
       nmatches++;
       if (ori) {
-        const int bin = (c0 >> 25) & 31;
+        const int bin = (c0 >> 26) & 31;
         if (lane == 0) {
           s_log_idx[nlog] = (unsigned short)bestIdx;
           s_log_bin[nlog] = (uint8_t)bin;
@@ -603,13 +731,17 @@ static thread_local SbpScratch g_sbp;
 static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
   int rc;
   SbpScratch& S = g_sbp;
+  if (A.n_cams < 1 || A.n_cams > kMaxCams) {
+    set_error("search_by_projection: n_cams = %d (1..%d)", A.n_cams, kMaxCams);
+    return VIEO_E_INVALID;
+  }
   // candidate pool: 32 per query on average (a single query may hold up to kCandCap)
   A.pool_cap = std::max(A.q_cap * 32, 2 * kCandCap);
   static const int pool_lds_env = [] {
     const char* e = getenv("VIEO_SBP_POOL_LDS");
     return e ? atoi(e) : 0;
   }();
-  A.pool_lds = std::min(A.pool_cap, pool_lds_env > 0 ? pool_lds_env : 5120);  // 20 KB + 16 KB static: 4 frames / CU
+  A.pool_lds = std::min(A.pool_cap, pool_lds_env > 0 ? pool_lds_env : 5120);  // 20 KB + ~5 KB of state: 4+ frames / CU
   if ((rc = S.pool.ensure((size_t)n_frames * A.pool_cap * 4)) != VIEO_OK) return rc;
   if ((rc = S.cursor.ensure((size_t)n_frames * 4)) != VIEO_OK) return rc;
   if ((rc = S.qrec.ensure((size_t)n_frames * A.q_cap * sizeof(int2))) != VIEO_OK) return rc;
@@ -622,14 +754,16 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
     set_error("search_by_projection: more than %d keypoints per frame", kMaxKeys);
     return VIEO_E_CAPACITY;
   }
-  if ((rc = S.cell_start.ensure((size_t)n_frames * (kGridCells + 1) * 4)) != VIEO_OK) return rc;
+  if ((rc = S.cell_start.ensure((size_t)n_frames * A.n_cams * (kGridCells + 1) * 4)) != VIEO_OK) return rc;
   if ((rc = S.cell_rec.ensure((size_t)n_frames * A.key_cap * sizeof(float4))) != VIEO_OK) return rc;
   if ((rc = S.cell_ang.ensure((size_t)n_frames * A.key_cap * 4)) != VIEO_OK) return rc;
   A.cell_start = S.cell_start.as<int>(), A.cell_rec = S.cell_rec.as<float4>(), A.cell_ang = S.cell_ang.as<float>();
-  hipLaunchKernelGGL(k_sbp_grid, dim3(n_frames), dim3(256), 0, st, A, S.cell_start.as<int>(),
+  hipLaunchKernelGGL(k_sbp_grid, dim3(n_frames * A.n_cams), dim3(256), 0, st, A, S.cell_start.as<int>(),
                      S.cell_rec.as<float4>(), S.cell_ang.as<float>());
-  hipLaunchKernelGGL(k_sbp_candidates, dim3(kSbpBlocks, n_frames), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), (size_t)A.pool_lds * 4, st, A);
+  hipLaunchKernelGGL(k_sbp_candidates, dim3(kSbpBlocks, n_frames), dim3(256),
+                     (size_t)A.n_cams * (kGridCells + 1) * sizeof(unsigned short), st, A);
+  const size_t lds = (size_t)A.pool_lds * 4 + (size_t)A.q_cap * 3 + (size_t)A.key_cap;
+  hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), lds, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
@@ -640,17 +774,51 @@ using namespace vieo;
 
 extern "C" {
 
+int vieo_sbp_project_last_frame_rig_batch_device(const vieo_last_frame_point* d_points, const int32_t* d_n,
+                                                 int p_cap, int n_frames, const vieo_sbp_camera* d_cams,
+                                                 const vieo_sbp_rig* d_rigs, int n_cams,
+                                                 vieo_proj_query* d_queries, void* stream) {
+  if (!d_points || !d_n || p_cap <= 0 || n_frames <= 0 || !d_cams || !d_queries || n_cams < 1 || n_cams > kMaxCams ||
+      (!d_rigs && n_cams != 1))
+    return VIEO_E_INVALID;
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  hipLaunchKernelGGL(k_sbp_project, dim3((p_cap * n_cams + 255) / 256, n_frames), dim3(256), 0,
+                     (hipStream_t)stream, d_points, d_n, p_cap, d_cams, d_rigs, n_cams, d_queries);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
 int vieo_sbp_project_last_frame_batch_device(const vieo_last_frame_point* d_points,
                                              const int32_t* d_n, int p_cap, int n_frames,
                                              const vieo_sbp_camera* d_cams,
                                              vieo_proj_query* d_queries, void* stream) {
-  if (!d_points || !d_n || p_cap <= 0 || n_frames <= 0 || !d_cams || !d_queries) return VIEO_E_INVALID;
+  return vieo_sbp_project_last_frame_rig_batch_device(d_points, d_n, p_cap, n_frames, d_cams, nullptr, 1, d_queries,
+                                                      stream);
+}
+
+static int search_batch(int mode, const vieo_proj_query* d_queries, const int32_t* d_nq, int q_cap, int n_frames,
+                        const vieo_keypoint* d_keys, const float* d_uright, const uint8_t* d_desc,
+                        const uint8_t* d_taken, const int32_t* d_counts, const int32_t* d_cam_first, int key_cap,
+                        int img_first, int img_step, const float* h_bounds, int n_cams, float nn_ratio,
+                        int check_orientation, int32_t* d_assign, int32_t* d_nmatches, void* stream) {
+  if (!d_queries || !d_nq || q_cap <= 0 || n_frames <= 0 || !d_keys || !d_uright || !d_desc ||
+      (!d_counts && !d_cam_first) || !h_bounds || !d_assign || !d_nmatches || key_cap <= 0 ||
+      (mode != VIEO_SBP_LAST_FRAME && mode != VIEO_SBP_LOCAL_MAP && mode != VIEO_SBP_RELOC))
+    return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
-  hipLaunchKernelGGL(k_sbp_project, dim3((p_cap + 255) / 256, n_frames), dim3(256), 0,
-                     (hipStream_t)stream, d_points, d_n, p_cap, d_cams, d_queries);
-  VIEO_HIP_CHECK(hipGetLastError());
-  return VIEO_OK;
+  SbpArgs A;
+  memset(&A, 0, sizeof(A));
+  A.mode = mode;
+  A.queries = d_queries, A.nq = d_nq, A.q_cap = q_cap;
+  A.keys = d_keys, A.uright = d_uright, A.desc = d_desc, A.taken = d_taken, A.counts = d_counts;
+  A.key_cap = key_cap, A.img_first = img_first, A.img_step = img_step;
+  A.n_cams = n_cams, A.cam_first = d_cam_first;
+  if (n_cams >= 1 && n_cams <= kMaxCams) memcpy(A.bounds, h_bounds, sizeof(float) * 4 * n_cams);
+  A.nn_ratio = nn_ratio, A.check_ori = check_orientation;
+  A.assign = d_assign, A.nmatches = d_nmatches;
+  return run_search(A, n_frames, (hipStream_t)stream);
 }
 
 int vieo_search_by_projection_batch_device(int mode, const vieo_proj_query* d_queries,
@@ -661,58 +829,114 @@ int vieo_search_by_projection_batch_device(int mode, const vieo_proj_query* d_qu
                                            int img_step, const float* h_bounds, float nn_ratio,
                                            int check_orientation, int32_t* d_assign,
                                            int32_t* d_nmatches, void* stream) {
-  if (!d_queries || !d_nq || q_cap <= 0 || n_frames <= 0 || !d_keys || !d_uright || !d_desc ||
-      !d_counts || !h_bounds || !d_assign || !d_nmatches ||
-      (mode != VIEO_SBP_LAST_FRAME && mode != VIEO_SBP_LOCAL_MAP && mode != VIEO_SBP_RELOC))
-    return VIEO_E_INVALID;
-  int rc = require_device();
-  if (rc != VIEO_OK) return rc;
-  SbpArgs A;
-  A.mode = mode;
-  A.queries = d_queries, A.nq = d_nq, A.q_cap = q_cap;
-  A.keys = d_keys, A.uright = d_uright, A.desc = d_desc, A.taken = d_taken, A.counts = d_counts;
-  A.key_cap = key_cap, A.img_first = img_first, A.img_step = img_step;
-  A.minx = h_bounds[0], A.maxx = h_bounds[1], A.miny = h_bounds[2], A.maxy = h_bounds[3];
-  A.nn_ratio = nn_ratio, A.check_ori = check_orientation;
-  A.assign = d_assign, A.nmatches = d_nmatches;
-  return run_search(A, n_frames, (hipStream_t)stream);
+  if (!d_counts) return VIEO_E_INVALID;
+  return search_batch(mode, d_queries, d_nq, q_cap, n_frames, d_keys, d_uright, d_desc, d_taken, d_counts, nullptr,
+                      key_cap, img_first, img_step, h_bounds, 1, nn_ratio, check_orientation, d_assign, d_nmatches,
+                      stream);
 }
 
-int vieo_sbp_project_last_frame(const vieo_last_frame_point* h_points, int n,
-                                const vieo_sbp_camera* h_cam, vieo_proj_query* h_queries) {
+int vieo_search_by_projection_rig_batch_device(int mode, const vieo_proj_query* d_queries, const int32_t* d_nq,
+                                               int q_cap, int n_frames, const vieo_keypoint* d_keys,
+                                               const float* d_uright, const uint8_t* d_desc,
+                                               const uint8_t* d_taken, const int32_t* d_cam_first, int key_cap,
+                                               const float* h_bounds, int n_cams, float nn_ratio,
+                                               int check_orientation, int32_t* d_assign, int32_t* d_nmatches,
+                                               void* stream) {
+  if (!d_cam_first) return VIEO_E_INVALID;
+  return search_batch(mode, d_queries, d_nq, q_cap, n_frames, d_keys, d_uright, d_desc, d_taken, nullptr, d_cam_first,
+                      key_cap, 0, 1, h_bounds, n_cams, nn_ratio, check_orientation, d_assign, d_nmatches, stream);
+}
+
+// host-pointer form of the three projections: last frame (rig or not) and key frame
+static int project_host(const void* h_points, int n, const vieo_sbp_camera* h_cam, const vieo_sbp_rig* h_rig,
+                        int keyframe, float log_scale_factor, vieo_proj_query* h_queries) {
   if (n < 0 || !h_cam || (n > 0 && (!h_points || !h_queries))) return VIEO_E_INVALID;
+  const int nc = h_rig ? h_rig->n_cams : 1;
+  if (nc < 1 || nc > kMaxCams) {
+    set_error("sbp_project: n_cams = %d (1..%d)", nc, kMaxCams);
+    return VIEO_E_INVALID;
+  }
+  if (h_rig)
+    for (int c = 0; c < nc; ++c) {
+      CamD d;
+      if (!cam_from_abi(h_rig->cams[c], d)) {
+        set_error("sbp_project: camera %d has an unknown model or coefficient count", c);
+        return VIEO_E_INVALID;
+      }
+    }
+  if (h_cam->nlevels < 1 || h_cam->nlevels > 16) {
+    set_error("sbp_project: nlevels = %d (1..16)", h_cam->nlevels);
+    return VIEO_E_INVALID;
+  }
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
   if (n == 0) return VIEO_OK;
   SbpScratch& S = g_sbp;
-  if ((rc = S.pts.ensure((size_t)n * sizeof(vieo_last_frame_point))) != VIEO_OK) return rc;
+  static thread_local DevBuf dRig;
+  if ((rc = S.pts.ensure((size_t)n * 64)) != VIEO_OK) return rc;
   if ((rc = S.cam.ensure(sizeof(vieo_sbp_camera))) != VIEO_OK) return rc;
-  if ((rc = S.q.ensure((size_t)n * sizeof(vieo_proj_query))) != VIEO_OK) return rc;
+  if ((rc = S.q.ensure((size_t)n * nc * sizeof(vieo_proj_query))) != VIEO_OK) return rc;
   if ((rc = S.nq.ensure(4)) != VIEO_OK) return rc;
-  VIEO_HIP_CHECK(hipMemcpy(S.pts.p, h_points, (size_t)n * sizeof(vieo_last_frame_point), hipMemcpyHostToDevice));
+  if ((rc = dRig.ensure(sizeof(vieo_sbp_rig))) != VIEO_OK) return rc;
+  VIEO_HIP_CHECK(hipMemcpy(S.pts.p, h_points, (size_t)n * 64, hipMemcpyHostToDevice));
   VIEO_HIP_CHECK(hipMemcpy(S.cam.p, h_cam, sizeof(vieo_sbp_camera), hipMemcpyHostToDevice));
   VIEO_HIP_CHECK(hipMemcpy(S.nq.p, &n, 4, hipMemcpyHostToDevice));
-  rc = vieo_sbp_project_last_frame_batch_device(S.pts.as<vieo_last_frame_point>(), S.nq.as<int>(), n, 1,
-                                                S.cam.as<vieo_sbp_camera>(), S.q.as<vieo_proj_query>(),
-                                                nullptr);
-  if (rc != VIEO_OK) return rc;
-  VIEO_HIP_CHECK(hipMemcpy(h_queries, S.q.p, (size_t)n * sizeof(vieo_proj_query), hipMemcpyDeviceToHost));
+  if (h_rig) VIEO_HIP_CHECK(hipMemcpy(dRig.p, h_rig, sizeof(vieo_sbp_rig), hipMemcpyHostToDevice));
+  const vieo_sbp_rig* d_rig = h_rig ? dRig.as<vieo_sbp_rig>() : nullptr;
+  if (keyframe) {
+    hipLaunchKernelGGL(k_sbp_project_kf, dim3((n * nc + 255) / 256), dim3(256), 0, 0, S.pts.as<vieo_keyframe_point>(),
+                       n, S.cam.as<vieo_sbp_camera>(), d_rig, nc, log_scale_factor, S.q.as<vieo_proj_query>());
+    VIEO_HIP_CHECK(hipGetLastError());
+  } else {
+    rc = vieo_sbp_project_last_frame_rig_batch_device(S.pts.as<vieo_last_frame_point>(), S.nq.as<int>(), n, 1,
+                                                      S.cam.as<vieo_sbp_camera>(), d_rig, nc,
+                                                      S.q.as<vieo_proj_query>(), nullptr);
+    if (rc != VIEO_OK) return rc;
+  }
+  VIEO_HIP_CHECK(hipMemcpy(h_queries, S.q.p, (size_t)n * nc * sizeof(vieo_proj_query), hipMemcpyDeviceToHost));
   return VIEO_OK;
 }
 
-int vieo_search_by_projection(int mode, const vieo_proj_query* h_queries, int nq,
-                              const vieo_keypoint* h_keys, const float* h_uright,
-                              const uint8_t* h_desc, const uint8_t* h_taken, int n_keys,
-                              const float* h_bounds, float nn_ratio, int check_orientation,
-                              int32_t* h_assign, int32_t* nmatches) {
-  if (nq < 0 || n_keys < 0 || !h_bounds || !nmatches || (n_keys > 0 && (!h_keys || !h_uright || !h_desc || !h_assign)))
+int vieo_sbp_project_last_frame(const vieo_last_frame_point* h_points, int n,
+                                const vieo_sbp_camera* h_cam, vieo_proj_query* h_queries) {
+  return project_host(h_points, n, h_cam, nullptr, 0, 0.f, h_queries);
+}
+
+int vieo_sbp_project_last_frame_rig(const vieo_last_frame_point* h_points, int n, const vieo_sbp_camera* h_cam,
+                                    const vieo_sbp_rig* h_rig, vieo_proj_query* h_queries) {
+  if (!h_rig) return VIEO_E_INVALID;
+  return project_host(h_points, n, h_cam, h_rig, 0, 0.f, h_queries);
+}
+
+int vieo_sbp_project_keyframe(const vieo_keyframe_point* h_points, int n, const vieo_sbp_camera* h_cam,
+                              const vieo_sbp_rig* h_rig, float log_scale_factor, vieo_proj_query* h_queries) {
+  if (!(log_scale_factor > 0)) return VIEO_E_INVALID;
+  return project_host(h_points, n, h_cam, h_rig, 1, log_scale_factor, h_queries);
+}
+
+int vieo_search_by_projection_rig(int mode, const vieo_proj_query* h_queries, int nq, const vieo_keypoint* h_keys,
+                                  const float* h_uright, const uint8_t* h_desc, const uint8_t* h_taken, int n_keys,
+                                  const int32_t* h_cam_first, const float* h_bounds, int n_cams, float nn_ratio,
+                                  int check_orientation, int32_t* h_assign, int32_t* nmatches) {
+  if (nq < 0 || n_keys < 0 || !h_bounds || !nmatches || n_cams < 1 || n_cams > kMaxCams || !h_cam_first ||
+      (n_keys > 0 && (!h_keys || !h_uright || !h_desc || !h_assign)) || (nq > 0 && !h_queries))
     return VIEO_E_INVALID;
+  if (h_cam_first[0] != 0 || h_cam_first[n_cams] != n_keys) {
+    set_error("search_by_projection: cam_first must run from 0 to n_keys");
+    return VIEO_E_INVALID;
+  }
+  for (int c = 0; c < n_cams; ++c)
+    if (h_cam_first[c] > h_cam_first[c + 1]) {
+      set_error("search_by_projection: cam_first is not ascending");
+      return VIEO_E_INVALID;
+    }
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
   *nmatches = 0;
   for (int i = 0; i < n_keys; i++) h_assign[i] = VIEO_SBP_UNCHANGED;
   if (nq == 0 || n_keys == 0) return VIEO_OK;
   SbpScratch& S = g_sbp;
+  static thread_local DevBuf dCf;
 #define ENS(b, n) \
   if ((rc = (b).ensure(n)) != VIEO_OK) return rc
   ENS(S.q, (size_t)nq * sizeof(vieo_proj_query));
@@ -721,23 +945,21 @@ int vieo_search_by_projection(int mode, const vieo_proj_query* h_queries, int nq
   ENS(S.ur, (size_t)n_keys * 4);
   ENS(S.desc, (size_t)n_keys * 32);
   ENS(S.taken, (size_t)n_keys);
-  ENS(S.counts, 8);
+  ENS(dCf, 8 * 4);
   ENS(S.assign, (size_t)n_keys * 4);
   ENS(S.nm, 4);
 #undef ENS
-  const int cnt[2] = {n_keys, 0};
   VIEO_HIP_CHECK(hipMemcpy(S.q.p, h_queries, (size_t)nq * sizeof(vieo_proj_query), hipMemcpyHostToDevice));
   VIEO_HIP_CHECK(hipMemcpy(S.nq.p, &nq, 4, hipMemcpyHostToDevice));
   VIEO_HIP_CHECK(hipMemcpy(S.keys.p, h_keys, (size_t)n_keys * sizeof(vieo_keypoint), hipMemcpyHostToDevice));
   VIEO_HIP_CHECK(hipMemcpy(S.ur.p, h_uright, (size_t)n_keys * 4, hipMemcpyHostToDevice));
   VIEO_HIP_CHECK(hipMemcpy(S.desc.p, h_desc, (size_t)n_keys * 32, hipMemcpyHostToDevice));
   if (h_taken) VIEO_HIP_CHECK(hipMemcpy(S.taken.p, h_taken, (size_t)n_keys, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.counts.p, cnt, 8, hipMemcpyHostToDevice));
-  rc = vieo_search_by_projection_batch_device(
-      mode, S.q.as<vieo_proj_query>(), S.nq.as<int>(), nq, 1, S.keys.as<vieo_keypoint>(),
-      S.ur.as<float>(), S.desc.as<uint8_t>(), h_taken ? S.taken.as<uint8_t>() : nullptr,
-      S.counts.as<int>(), n_keys, 0, 0, h_bounds, nn_ratio, check_orientation, S.assign.as<int>(),
-      S.nm.as<int>(), nullptr);
+  VIEO_HIP_CHECK(hipMemcpy(dCf.p, h_cam_first, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice));
+  rc = vieo_search_by_projection_rig_batch_device(
+      mode, S.q.as<vieo_proj_query>(), S.nq.as<int>(), nq, 1, S.keys.as<vieo_keypoint>(), S.ur.as<float>(),
+      S.desc.as<uint8_t>(), h_taken ? S.taken.as<uint8_t>() : nullptr, dCf.as<int32_t>(), n_keys, h_bounds, n_cams,
+      nn_ratio, check_orientation, S.assign.as<int>(), S.nm.as<int>(), nullptr);
   if (rc != VIEO_OK) return rc;
   VIEO_HIP_CHECK(hipMemcpy(h_assign, S.assign.p, (size_t)n_keys * 4, hipMemcpyDeviceToHost));
   VIEO_HIP_CHECK(hipMemcpy(nmatches, S.nm.p, 4, hipMemcpyDeviceToHost));
@@ -746,6 +968,16 @@ int vieo_search_by_projection(int mode, const vieo_proj_query* h_queries, int nq
     return VIEO_E_CAPACITY;
   }
   return VIEO_OK;
+}
+
+int vieo_search_by_projection(int mode, const vieo_proj_query* h_queries, int nq,
+                              const vieo_keypoint* h_keys, const float* h_uright,
+                              const uint8_t* h_desc, const uint8_t* h_taken, int n_keys,
+                              const float* h_bounds, float nn_ratio, int check_orientation,
+                              int32_t* h_assign, int32_t* nmatches) {
+  const int32_t cam_first[2] = {0, n_keys};
+  return vieo_search_by_projection_rig(mode, h_queries, nq, h_keys, h_uright, h_desc, h_taken, n_keys, cam_first,
+                                       h_bounds, 1, nn_ratio, check_orientation, h_assign, nmatches);
 }
 
 int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const* h_keys,
@@ -815,7 +1047,8 @@ int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const*
     memset(&A, 0, sizeof(A));
     A.keys = S.keys.as<vieo_keypoint>(), A.uright = S.ur.as<float>(), A.counts = S.counts.as<int>();
     A.key_cap = cap, A.img_first = 0, A.img_step = 0;
-    A.minx = F.bounds[c][0], A.maxx = F.bounds[c][1], A.miny = F.bounds[c][2], A.maxy = F.bounds[c][3];
+    A.n_cams = 1;
+    for (int q = 0; q < 4; ++q) A.bounds[0][q] = F.bounds[c][q];
     A.cursor = S.cursor.as<int>();
     hipLaunchKernelGGL(k_sbp_grid, dim3(1), dim3(256), 0, 0, A, S.cell_start.as<int>(), S.cell_rec.as<float4>(),
                        S.cell_ang.as<float>());

@@ -53,3 +53,31 @@ def build_pose_obs(assign, query_Xw, keys, uright, inv_sigma2):
     obs["ur"] = uright[idx]
     obs["inv_sigma2"] = inv_sigma2[keys["octave"][idx]]
     return obs, idx
+
+
+def queries_from_track_info(info, desc, th, scale, observed=None, th_far=0.0):
+    """The head of SearchByProjection(Frame&, vector<MapPoint*>&, th, th_far) (ORBmatcher.cc:237-266): one window
+    query per (map point in view, camera of vtrack_cami_), point-major.  info: TRACK_INFO_DTYPE[n] from
+    Frame::isInFrustum, desc uint8[n, 32], scale = scalepyrinfo_.vscalefactor_ (float32).
+    returns (queries PROJ_QUERY_DTYPE[m], point index of every query int32[m])."""
+    from .ba_types import PROJ_QUERY_DTYPE
+    rows, owner = [], []
+    bFactor = th != 1.0
+    for i in range(len(info)):
+        T = info[i]
+        if T["n"] <= 0:
+            continue
+        if th_far > 0 and T["track_depth"] > th_far:
+            continue
+        for k in range(int(T["n"])):
+            lvl = int(T["level"][k])
+            r = np.float32(2.5) if T["viewcos"][k] > np.float32(0.998) else np.float32(4.0)  # RadiusByViewingCos
+            if bFactor:
+                r = np.float32(r * np.float32(th))
+            rows.append((T["u"][k], T["v"][k], T["ur"][k], np.float32(r * scale[lvl]), lvl - 1, lvl, 0.0,
+                         1 | (2 if (observed is None or observed[i]) else 0) | (int(T["cam"][k]) << 8), desc[i]))
+            owner.append(i)
+    q = np.zeros(len(rows), PROJ_QUERY_DTYPE)
+    for j, r in enumerate(rows):
+        q[j] = r
+    return q, np.array(owner, np.int32)

@@ -75,16 +75,40 @@ class ORBmatcher:
         self.mbCheckOrientation = bool(checkOri)
 
     @staticmethod
-    def project_last_frame(points, cam):
+    def project_last_frame(points, cam, rig=None):
+        """ORBmatcher.cc:1313-1378: rig = None -> one query per point (the rectified camera of `cam`);
+        rig = SBP_RIG_DTYPE[1] -> queries[i * n_cams + camj]."""
         from .ba_types import PROJ_QUERY_DTYPE
         pts = np.ascontiguousarray(points)
         cam = np.ascontiguousarray(cam)
-        q = np.zeros(len(pts), PROJ_QUERY_DTYPE)
-        check(lib().vieo_sbp_project_last_frame(pts.ctypes.data, len(pts), cam.ctypes.data,
-                                                q.ctypes.data), "vieo_sbp_project_last_frame")
+        if rig is None:
+            q = np.zeros(len(pts), PROJ_QUERY_DTYPE)
+            check(lib().vieo_sbp_project_last_frame(pts.ctypes.data, len(pts), cam.ctypes.data,
+                                                    q.ctypes.data), "vieo_sbp_project_last_frame")
+            return q
+        rig = np.ascontiguousarray(rig)
+        q = np.zeros(len(pts) * int(rig[0]["n_cams"]), PROJ_QUERY_DTYPE)
+        check(lib().vieo_sbp_project_last_frame_rig(pts.ctypes.data, len(pts), cam.ctypes.data, rig.ctypes.data,
+                                                    q.ctypes.data), "vieo_sbp_project_last_frame_rig")
         return q
 
-    def _search(self, mode, queries, keys, uright, desc, taken, bounds, ratio=None):
+    @staticmethod
+    def project_keyframe(points, cam, rig, log_scale_factor):
+        """Projection of SearchByProjection(Frame&, KeyFrame*, ...) (ORBmatcher.cc:1487-1543);
+        points: KEYFRAME_POINT_DTYPE, rig may be None (the rectified camera of `cam`)."""
+        from .ba_types import PROJ_QUERY_DTYPE
+        pts = np.ascontiguousarray(points)
+        cam = np.ascontiguousarray(cam)
+        nc = 1 if rig is None else int(rig[0]["n_cams"])
+        rig = None if rig is None else np.ascontiguousarray(rig)
+        q = np.zeros(len(pts) * nc, PROJ_QUERY_DTYPE)
+        check(lib().vieo_sbp_project_keyframe(pts.ctypes.data, len(pts), cam.ctypes.data,
+                                              None if rig is None else rig.ctypes.data, float(log_scale_factor),
+                                              q.ctypes.data), "vieo_sbp_project_keyframe")
+        return q
+
+    def _search(self, mode, queries, keys, uright, desc, taken, bounds, ratio=None, cam_first=None):
+        """bounds: float32[4], or [n_cams][4] with cam_first int32[n_cams + 1] for the key list of a rig frame."""
         import ctypes
         queries = np.ascontiguousarray(queries)
         keys = np.ascontiguousarray(keys)
@@ -94,26 +118,36 @@ class ORBmatcher:
         b = np.ascontiguousarray(bounds, np.float32)
         assign = np.zeros(max(len(keys), 1), np.int32)
         n = ctypes.c_int32()
-        check(lib().vieo_search_by_projection(mode, queries.ctypes.data, len(queries),
-                                              keys.ctypes.data, uright.ctypes.data, desc.ctypes.data,
-                                              None if tk is None else tk.ctypes.data, len(keys),
-                                              b.ctypes.data, self.mfNNratio if ratio is None else float(ratio),
-                                              int(self.mbCheckOrientation), assign.ctypes.data,
-                                              ctypes.byref(n)), "vieo_search_by_projection")
+        r = self.mfNNratio if ratio is None else float(ratio)
+        if cam_first is None:
+            check(lib().vieo_search_by_projection(mode, queries.ctypes.data, len(queries),
+                                                  keys.ctypes.data, uright.ctypes.data, desc.ctypes.data,
+                                                  None if tk is None else tk.ctypes.data, len(keys),
+                                                  b.ctypes.data, r, int(self.mbCheckOrientation), assign.ctypes.data,
+                                                  ctypes.byref(n)), "vieo_search_by_projection")
+        else:
+            cf = np.ascontiguousarray(cam_first, np.int32)
+            check(lib().vieo_search_by_projection_rig(mode, queries.ctypes.data, len(queries), keys.ctypes.data,
+                                                      uright.ctypes.data, desc.ctypes.data,
+                                                      None if tk is None else tk.ctypes.data, len(keys),
+                                                      cf.ctypes.data, b.ctypes.data, len(cf) - 1, r,
+                                                      int(self.mbCheckOrientation), assign.ctypes.data,
+                                                      ctypes.byref(n)), "vieo_search_by_projection_rig")
         return n.value, assign[:len(keys)]
 
-    def SearchByProjectionLastFrame(self, queries, keys, uright, desc, taken, bounds):
+    def SearchByProjectionLastFrame(self, queries, keys, uright, desc, taken, bounds, cam_first=None):
         """SearchByProjection(Frame&, const Frame&, th, bMono, th_far) (ORBmatcher.cc:1303-1467)
         after project_last_frame(); returns (nmatches, assign[n_keys])."""
-        return self._search(self.SBP_LAST_FRAME, queries, keys, uright, desc, taken, bounds)
+        return self._search(self.SBP_LAST_FRAME, queries, keys, uright, desc, taken, bounds, cam_first=cam_first)
 
-    def SearchByProjectionKeyFrame(self, queries, keys, uright, desc, taken, bounds, ORBdist):
+    def SearchByProjectionKeyFrame(self, queries, keys, uright, desc, taken, bounds, ORBdist, cam_first=None):
         """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist, th_far) (ORBmatcher.cc:1471-1606,
         relocalisation) on the key frame's projected map points; `taken` marks the keys that already hold
         a map point.  returns (nmatches, assign[n_keys])."""
-        return self._search(self.SBP_RELOC, queries, keys, uright, desc, taken, bounds, ratio=ORBdist)
+        return self._search(self.SBP_RELOC, queries, keys, uright, desc, taken, bounds, ratio=ORBdist,
+                            cam_first=cam_first)
 
-    def SearchByProjectionLocalMap(self, queries, keys, uright, desc, taken, bounds):
+    def SearchByProjectionLocalMap(self, queries, keys, uright, desc, taken, bounds, cam_first=None):
         """SearchByProjection(Frame&, vector<MapPoint*>&, th, th_far) (ORBmatcher.cc:230-335) on
         queries prepared by Frame::isInFrustum."""
-        return self._search(self.SBP_LOCAL_MAP, queries, keys, uright, desc, taken, bounds)
+        return self._search(self.SBP_LOCAL_MAP, queries, keys, uright, desc, taken, bounds, cam_first=cam_first)

@@ -690,11 +690,13 @@ ENC_RBE = so3_exp(np.array([0.02, -0.03, 0.5]))
 
 
 # ---- distorted multi-camera rigs (a20: Radtan / KB8 models, per-observation camera) --------------
-def camera_rig(name, with_tcr=False):
+def camera_rig(name, with_tcr=False, n_cams=None):
     """(CAMERA_DTYPE array, (width, height)) of a rig as the BA edges see it: EdgeReproject::SetParams
     already applied (Rcb = Rccr * Rcrb, tcb = Rccr * tcrb + tcr).  'radtan': the two EuRoC cameras
     (k1 k2 p1 p2); 'kb8': four TUM-VI-like fisheye cameras (k1..k4).
-    with_tcr: also the list of 4x4 Tcr (reference camera -> camera i)."""
+    with_tcr: also the list of 4x4 Tcr (reference camera -> camera i).
+    n_cams: None = the rig as described; 2 or 4 = that many cameras (the radtan rig grows two side cameras, the kb8
+    rig keeps its first two)."""
     from .ba_types import CAMERA_DTYPE
     Tcb = np.linalg.inv(EUROC_TBC)
     Rcrb, tcrb = Tcb[:3, :3], Tcb[:3, 3]
@@ -704,6 +706,13 @@ def camera_rig(name, with_tcr=False):
         Tcr = [np.eye(4), np.eye(4)]
         Tcr[1][:3, :3] = so3_exp(np.array([0.002, -0.012, 0.001]))
         Tcr[1][:3, 3] = [-0.110, 0.0004, -0.0008]
+        if n_cams == 4:
+            intr += [(458.1, 457.0, 370.2, 250.1, intr[0][4]), (457.9, 456.6, 375.3, 252.7, intr[1][4])]
+            for rv, t in (((0.0, 0.30, 0.0), (0.05, 0.0, -0.02)), ((0.0, -0.30, 0.0), (-0.16, 0.0, -0.02))):
+                T = np.eye(4)
+                T[:3, :3] = so3_exp(np.array(rv, float))
+                T[:3, 3] = t
+                Tcr.append(T)
         model, num_k, size = 1, 2, (752, 480)
     elif name == "kb8":
         k = [0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673]
@@ -714,6 +723,8 @@ def camera_rig(name, with_tcr=False):
                                      ((0.0, 0.35, 0.0), (0.05, 0.0, -0.02)), ((0.0, -0.35, 0.0), (-0.15, 0.0, -0.02))]):
             Tcr[i][:3, :3] = so3_exp(np.array(rv, float))
             Tcr[i][:3, 3] = t
+        if n_cams == 2:
+            intr, Tcr = intr[:2], Tcr[:2]
         model, num_k, size = 2, 0, (512, 512)
     else:
         raise ValueError(name)
