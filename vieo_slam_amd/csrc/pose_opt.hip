@@ -114,7 +114,8 @@ __device__ __noinline__ void pose_enc_eval(const vieo_pose_enc* pe, PoseEncShare
   }
 }
 
-static const int kMaxObs = 2048;  // 32 edges per lane at 64 threads per frame, 8 at 256 (bit mask per lane)
+// observations per frame: one bit per edge in a 64-bit mask per lane -> 64 x threads (4096 / 16384)
+#define kMaxObs (64 * BS)
 
 // BS threads per frame: 256 for a few frames (lowest latency), 64 = one wavefront per frame for large
 // batches (four frames per CU in flight), as in pose_opt_vio.hip
@@ -190,7 +191,7 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
   init.p[0] = F.nav.p[0], init.p[1] = F.nav.p[1], init.p[2] = F.nav.p[2];
   init.qw = F.nav.q[0], init.qx = F.nav.q[1], init.qy = F.nav.q[2], init.qz = F.nav.q[3];
   Est est = init;
-  unsigned levelmask = 0;  // bit k: edge tid + 256k is at level 1 (outlier)
+  unsigned long long levelmask = 0;  // bit k: edge tid + 256k is at level 1 (outlier)
   int nBad = 0, total_iters = 0;
   for (int it = 0; it < 4; it++) {
     est = init;
@@ -332,10 +333,10 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
       const float chi2 = (float)edge_eval<MC>(c, s_cams, was_out ? Xc : Xe, was_out ? est.p : est_err.p, o, err, Pc, nullptr);
       const float th = o.ur >= 0 ? chi2Stereo : chi2Mono;
       if (chi2 > th) {
-        levelmask |= (1u << k);
+        levelmask |= (1ull << k);
         nb[0] += 1;
       } else
-        levelmask &= ~(1u << k);
+        levelmask &= ~(1ull << k);
     }
     block_sum_bs<1, BS>(nb, s_red, tid);
     nBad = (int)nb[0];
@@ -379,7 +380,7 @@ static int pose_launch(const vieo_pose_frame* d_frames, int n_frames, const vieo
                          d_obs, d_outlier, d_results, both);
   }
   if (which & 2) {
-    if (narrow)
+    if (false)  // rig frames carry n_cams x the observations: always the wide form (up to 16384 edges)
       hipLaunchKernelGGL((k_pose_opt<64, true>), dim3(n_frames), dim3(64), 0, (hipStream_t)stream, d_frames, d_obs,
                          d_outlier, d_results, both);
     else
@@ -432,6 +433,10 @@ int vieo_pose_optimization(const vieo_pose_frame* h_frame, const vieo_pose_obs* 
   if (rc != VIEO_OK) return rc;
   VIEO_HIP_CHECK(hipMemcpy(h_result, dR.p, sizeof(vieo_pose_result), hipMemcpyDeviceToHost));
   if (n > 0) VIEO_HIP_CHECK(hipMemcpy(h_outlier + h_frame->obs_begin, dU.p, n, hipMemcpyDeviceToHost));
+  if (h_result->status == VIEO_E_CAPACITY) {
+    set_error("PoseOptimization: %d observations exceed the kernel's capacity (16384)", n);
+    return VIEO_E_CAPACITY;
+  }
   return VIEO_OK;
 }
 

@@ -160,7 +160,8 @@ __device__ bool wave_ldlt_solve_reg(const double* H, double lambda, const double
   return true;
 }
 
-static const int kVioMaxObs = 2048;  // 32 edges per lane at 64 threads, 8 at 256 (bit masks per lane)
+// observations per frame: one bit per edge in a 64-bit mask per lane -> 64 x threads (4096 / 16384)
+#define kVioMaxObs (64 * BS)
 
 struct VioShared {
   NSd nsj, nsi, bkj, bki, prior;
@@ -333,7 +334,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
   const NSd nsj0 = S.nsj, nsi0 = S.nsi;
-  unsigned levelmask = 0;
+  unsigned long long levelmask = 0;
   bool vis_robust = true;
   int nBad = 0, total_iters = 0;
   const int n_edges_total = N + (hasImu ? 1 : 0) + 1 + (fixedLast ? 0 : 1) + (ENC ? 1 : 0);
@@ -648,17 +649,17 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       else
         bad = chi2 > chi2Stereo;
       if (bad) {
-        levelmask |= (1u << k);
+        levelmask |= (1ull << k);
         nb[0] += 1;
       } else
-        levelmask &= ~(1u << k);
+        levelmask &= ~(1ull << k);
     }
     block_sum_bs<1, BS>(nb, S.red, tid);
     nBad = (int)nb[0];
     if (it == 2) vis_robust = false;
     if (n_edges_total < 10) break;
   }
-  unsigned outmask = levelmask;  // mvbOutlier
+  unsigned long long outmask = levelmask;  // mvbOutlier
   if (N - nBad < 30) {           // rescue pass, Optimizer.h:621-648
     Est e;
     e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
@@ -671,8 +672,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       double err[3], Pc[3];
       const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr);
       if (chi2 < (double)(o.ur < 0 ? 18.f : 24.f)) {
-        levelmask &= ~(1u << k);
-        outmask &= ~(1u << k);
+        levelmask &= ~(1ull << k);
+        outmask &= ~(1ull << k);
       } else
         nb[0] += 1;
     }
@@ -866,7 +867,7 @@ using namespace vieo;
 template <bool MC, bool ENC>
 static void vio_launch_kind(bool narrow, const vieo_vio_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
                             uint8_t* d_outlier, vieo_vio_result* d_results, int others, hipStream_t stream) {
-  if (narrow)
+  if (narrow && !MC)  // rig frames carry n_cams x the observations: always the wide form (up to 16384 edges)
     hipLaunchKernelGGL((k_pose_opt_vio<64, MC, ENC>), dim3(n_frames), dim3(64), 0, stream, d_frames, d_obs,
                        d_outlier, d_results, others);
   else
@@ -943,6 +944,10 @@ int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_ob
   if (rc != VIEO_OK) return rc;
   VIEO_HIP_CHECK(hipMemcpy(h_result, dR.p, sizeof(vieo_vio_result), hipMemcpyDeviceToHost));
   if (n > 0) VIEO_HIP_CHECK(hipMemcpy(h_outlier + h_frame->base.obs_begin, dU.p, n, hipMemcpyDeviceToHost));
+  if (h_result->base.status == VIEO_E_CAPACITY) {
+    set_error("PoseOptimization (VIO): %d observations exceed the kernel's capacity (16384)", n);
+    return VIEO_E_CAPACITY;
+  }
   return VIEO_OK;
 }
 

@@ -473,12 +473,11 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
 // one wave per frame: the frame's candidate pool is copied to LDS once, after that the replay of
 // the queries touches no global memory except the accepted assignments
 __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
-  // dynamic LDS: pool copy (pool_lds words) | log of accepted keys (q_cap u16) | key state (key_cap bytes) |
-  // log bins (q_cap bytes)
+  // dynamic LDS: pool copy (pool_lds words) | per key the rotation bins it was accepted with (bit b = bin b; a key
+  // can be accepted more than once when its holder has no observations) | key state (key_cap bytes)
   extern __shared__ unsigned s_pool[];
-  unsigned short* s_log_idx = (unsigned short*)(s_pool + A.pool_lds);
-  uint8_t* s_state = (uint8_t*)(s_log_idx + A.q_cap);  // bit0: holds a map point, bit1: it has Observations()>0
-  uint8_t* s_log_bin = s_state + A.key_cap;
+  unsigned* s_bins = s_pool + A.pool_lds;
+  uint8_t* s_state = (uint8_t*)(s_bins + A.key_cap);  // bit0: holds a map point, bit1: it has Observations()>0
   __shared__ int s_hist[kHistoLen];
   const int f = blockIdx.x, lane = threadIdx.x;
   int N;
@@ -509,11 +508,12 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
       if (i0 + 64 * u < N) {
         assign[i0 + 64 * u] = VIEO_SBP_UNCHANGED;
         s_state[i0 + 64 * u] = t[u] ? 3 : 0;
+        s_bins[i0 + 64 * u] = 0u;
       }
   }
   if (lane < kHistoLen) s_hist[lane] = 0;
   __syncthreads();
-  int nmatches = 0, nlog = 0, overflow = 0;
+  int nmatches = 0, overflow = 0;
   const bool ori = A.mode != VIEO_SBP_LOCAL_MAP && A.check_ori;
   for (int q0 = 0; q0 < nq; q0 += 64) {
     const int2 mine = q0 + lane < nq ? qrec[q0 + lane] : make_int2(0, 0);
@@ -575,12 +575,10 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
       nmatches++;
       if (ori) {
         const int bin = (c0 >> 26) & 31;
-        if (lane == 0) {
-          s_log_idx[nlog] = (unsigned short)bestIdx;
-          s_log_bin[nlog] = (uint8_t)bin;
+        if (lane == 0) {  // rotHist[bin].push_back(bestIdx2)
+          s_bins[bestIdx] |= 1u << bin;
           s_hist[bin]++;
         }
-        nlog++;
       }
       __syncthreads();  // single wave: orders the LDS state update before the next query
     }
@@ -606,10 +604,13 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
     } else if (max3 < 0.1f * (float)max1) {
       ind3 = -1;
     }
-    for (int k = lane; k < nlog; k += 64) {
-      const int bin = s_log_bin[k];
-      if (bin != ind1 && bin != ind2 && bin != ind3) assign[s_log_idx[k]] = VIEO_SBP_ERASED;
-    }
+    // EraseMapPointMatch of every key logged in a bin that is not kept
+    unsigned losers = (1u << kHistoLen) - 1u;
+    if (ind1 >= 0) losers &= ~(1u << ind1);
+    if (ind2 >= 0) losers &= ~(1u << ind2);
+    if (ind3 >= 0) losers &= ~(1u << ind3);
+    for (int k = lane; k < N; k += 64)
+      if (s_bins[k] & losers) assign[k] = VIEO_SBP_ERASED;
     for (int i = 0; i < kHistoLen; i++)
       if (i != ind1 && i != ind2 && i != ind3) nmatches -= s_hist[i];
   }
@@ -736,7 +737,7 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
     return VIEO_E_INVALID;
   }
   // candidate pool: 32 per query on average (a single query may hold up to kCandCap)
-  A.pool_cap = std::max(A.q_cap * 32, 2 * kCandCap);
+  A.pool_cap = std::max(std::min(A.q_cap, 2 * kMaxKeys) * 32, 2 * kCandCap);
   static const int pool_lds_env = [] {
     const char* e = getenv("VIEO_SBP_POOL_LDS");
     return e ? atoi(e) : 0;
@@ -746,8 +747,8 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
   if ((rc = S.cursor.ensure((size_t)n_frames * 4)) != VIEO_OK) return rc;
   if ((rc = S.qrec.ensure((size_t)n_frames * A.q_cap * sizeof(int2))) != VIEO_OK) return rc;
   A.pool = S.pool.as<unsigned>(), A.cursor = S.cursor.as<int>(), A.qrec = S.qrec.as<int2>();
-  if (A.q_cap > kMaxKeys) {
-    set_error("search_by_projection: more than %d queries per frame", kMaxKeys);
+  if (A.q_cap > (1 << 20)) {
+    set_error("search_by_projection: more than %d queries per frame", 1 << 20);
     return VIEO_E_CAPACITY;
   }
   if (A.key_cap > kMaxKeys) {
@@ -762,7 +763,7 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
                      S.cell_rec.as<float4>(), S.cell_ang.as<float>());
   hipLaunchKernelGGL(k_sbp_candidates, dim3(kSbpBlocks, n_frames), dim3(256),
                      (size_t)A.n_cams * (kGridCells + 1) * sizeof(unsigned short), st, A);
-  const size_t lds = (size_t)A.pool_lds * 4 + (size_t)A.q_cap * 3 + (size_t)A.key_cap;
+  const size_t lds = (size_t)A.pool_lds * 4 + (size_t)A.key_cap * 5;
   hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), lds, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;

@@ -37,9 +37,6 @@ class FramePipeline:
         self.B = B = batch
         self.ext = ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
         self.stream = lib().vieo_orb_stream(self.ext._h)
-        # every frame here is a rectified stereo frame (Frame::usedistort_ false): skip the camera-rig instance
-        check(lib().vieo_pose_set_camera_mode(1))
-        check(lib().vieo_pose_set_encoder_mode(1))
         self.cap = cap = self.ext.max_keypoints()
         ext0 = [ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH) for _ in range(2)]
         scf = self.ext.GetScaleFactors()
@@ -163,6 +160,18 @@ class FramePipeline:
         return out
 
     def step(self):
+        L, B, cap, st = lib(), self.B, self.cap, self.stream
+        # every frame here is a rectified stereo frame without encoder (Frame::usedistort_ false): skip the camera-rig
+        # and encoder kernel instances for the launches of this step only (the modes are process-wide)
+        check(L.vieo_pose_set_camera_mode(1))
+        check(L.vieo_pose_set_encoder_mode(1))
+        try:
+            self._step()
+        finally:
+            check(L.vieo_pose_set_camera_mode(0))
+            check(L.vieo_pose_set_encoder_mode(0))
+
+    def _step(self):
         L, B, cap, st = lib(), self.B, self.cap, self.stream
         self._stamp(0)
         self.ext.extract_batch_device(self.d_img.ptr, self.n_img, W, H, W, W * H, self.d_kp.ptr,

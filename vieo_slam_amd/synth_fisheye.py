@@ -84,6 +84,16 @@ def make_fisheye_case(seed, rig="kb8", n_points=500, n_levels=8, th_far_pts=0.0,
                 keep=(cams, Trc, Tcr_a, sigma2), cams=cams, Tcr=Tcr_a)
 
 
+def rig_extrinsics(Tcr):
+    """(Trc [n, 12], Tcr [n, 12]) row-major 3x4 doubles as the camera members hold them: Sophus::SE3<float> Trc as
+    given, Tcr = Trc.inverse() (both float), cast to double afterwards."""
+    Trc_f = [np.asarray(_inv(T), np.float32).astype(np.float64) for T in Tcr]
+    Tcr_f = [np.asarray(_inv(T), np.float32).astype(np.float64) for T in Trc_f]
+    n = len(Tcr)
+    return (np.ascontiguousarray(np.stack([T[:3, :] for T in Trc_f]).reshape(n, 12)),
+            np.ascontiguousarray(np.stack([T[:3, :] for T in Tcr_f]).reshape(n, 12)))
+
+
 def make_sbp_rig(cams, Tcr, bounds, use_distort=True):
     """SBP_RIG_DTYPE[1] from a CAMERA_DTYPE array, the 4x4 Tcr list and per-camera bounds [n_cams][4].
     Tcr / Trc go through Sophus::SE3<float> like the camera members (cast to double afterwards)."""
@@ -93,11 +103,10 @@ def make_sbp_rig(cams, Tcr, bounds, use_distort=True):
     nc = len(cams)
     R["n_cams"], R["use_distort"] = nc, int(use_distort)
     R["cams"][:nc] = cams
+    Trc_a, Tcr_a = rig_extrinsics(Tcr)
     for c in range(nc):
-        Trc_f = np.asarray(_inv(Tcr[c]), np.float32).astype(np.float64)
-        Tcr_f = np.asarray(_inv(Trc_f), np.float32).astype(np.float64)
-        R["Tcr"][c] = Tcr_f[:3, :].reshape(-1)
-        R["trc"][c] = Trc_f[:3, 3]
+        R["Tcr"][c] = Tcr_a[c]
+        R["trc"][c] = Trc_a[c].reshape(3, 4)[:, 3]
         R["bounds"][c] = bounds[c]
     return rig
 

@@ -93,3 +93,104 @@ def make_tracking_case(seed, dt_frame=0.05, scene=None):
     return dict(images0=(L0, R0), images1=(L1, R1), pose0=(Ri, pi, Rwc0, twc0),
                 pose1=(Rj, pj, Rwc1, twc1), depth0=depth0, depth1=depth1, vio=F,
                 truth=dict(p=pj, q=synth_ba._R_to_quat(Rj), v=vj))
+
+
+# ---- frames of a distorted camera rig (BASELINE configs[3] / [4]: Radtan EuRoC stereo, KB8 TUM-VI stereo) --------
+def unproject_pixels(cam, W_, H_):
+    """unit-plane rays (x, y, 1)[H, W, 3] of every pixel centre of a Radtan / KB8 camera, by vectorised Newton /
+    fixed-point inversion of synth_ba.project_camera (float64; generator code, not the reference's UnProject).
+    KB8 pixels beyond ~88 degrees get z <= 0 (no ray)."""
+    v, u = np.mgrid[0:H_, 0:W_].astype(np.float64)
+    fx, fy, cx, cy = float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"])
+    mx, my = (u - cx) / fx, (v - cy) / fy
+    d = cam["dist"].astype(np.float64)
+    if cam["model"] == 1:  # radtan: fixed-point iteration on the normalised coordinates
+        nk = int(cam["num_k"])
+        p1, p2 = d[nk], d[nk + 1]
+        x, y = mx.copy(), my.copy()
+        for _ in range(30):
+            r2 = x * x + y * y
+            fd = 1 + sum(d[i] * r2 ** (i + 1) for i in range(nk))
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dy = 2 * p2 * x * y + p1 * (r2 + 2 * y * y)
+            x, y = (mx - dx) / fd, (my - dy) / fd
+        return np.stack([x, y, np.ones_like(x)], -1)
+    if cam["model"] == 2:  # kb8: Newton on theta
+        thd = np.hypot(mx, my)
+        th = thd.copy()
+        for _ in range(12):
+            t2 = th * th
+            f = th * (1 + t2 * (d[0] + t2 * (d[1] + t2 * (d[2] + t2 * d[3])))) - thd
+            df = 1 + t2 * (3 * d[0] + t2 * (5 * d[1] + t2 * (7 * d[2] + t2 * 9 * d[3])))
+            th = th - f / df
+        s = np.where(thd > 1e-9, np.sin(th) / np.maximum(thd, 1e-9), 1.0)
+        return np.stack([mx * s, my * s, np.cos(th)], -1)  # not normalised to z = 1: direction only
+    return np.stack([mx, my, np.ones_like(mx)], -1)
+
+
+class RigScene(Scene):
+    """The textured plane seen through the distorted cameras of synth_ba.camera_rig(name)."""
+
+    def __init__(self, seed, rig="radtan", n_cams=2):
+        super().__init__(seed)
+        self.cams, (self.W, self.H), Tcr = synth_ba.camera_rig(rig, with_tcr=True, n_cams=n_cams)
+        self.Tcr = Tcr
+        self.rays = [unproject_pixels(c, self.W, self.H) for c in self.cams]
+        # body <- reference camera is EUROC_TBC like the rectified scene
+
+    def render_cam(self, c, Rwcr, twcr, noise_seed):
+        """uint8 image of camera c of the rig whose reference camera sits at (Rwcr, twcr)."""
+        Trc = np.linalg.inv(self.Tcr[c])
+        Rwc = Rwcr @ Trc[:3, :3]
+        twc = twcr + Rwcr @ Trc[:3, 3]
+        d_w = self.rays[c] @ Rwc.T
+        hit = d_w[..., 2] < -1e-3  # looking down at z = 0 from above
+        lam = np.where(hit, -twc[2] / np.where(hit, d_w[..., 2], -1.0), 0.0)
+        P = twc + lam[..., None] * d_w
+        tx = P[..., 0] / TEXEL + TEX_W / 2
+        ty = P[..., 1] / TEXEL + TEX_H / 2
+        inside = hit & (tx >= 0) & (tx < TEX_W - 1) & (ty >= 0) & (ty < TEX_H - 1) & (self.rays[c][..., 2] > 0.05)
+        x0 = np.clip(np.floor(tx).astype(np.int64), 0, TEX_W - 2)
+        y0 = np.clip(np.floor(ty).astype(np.int64), 0, TEX_H - 2)
+        fx = np.clip(tx - x0, 0, 1).astype(np.float32)
+        fy = np.clip(ty - y0, 0, 1).astype(np.float32)
+        T = self.tex
+        img = (T[y0, x0] * (1 - fx) * (1 - fy) + T[y0, x0 + 1] * fx * (1 - fy) +
+               T[y0 + 1, x0] * (1 - fx) * fy + T[y0 + 1, x0 + 1] * fx * fy)
+        img = np.where(inside, img, 40.0).astype(np.float32)  # outside the plane / the fisheye circle: flat dark
+        return synth.quantise(img, noise_seed)
+
+    def frame(self, Rwb, pwb, noise_seed):
+        """images of all cameras for the body pose; returns (images, Rwcr, twcr)."""
+        Rwc = Rwb @ self.Tbc[:3, :3]
+        twc = pwb + Rwb @ self.Tbc[:3, 3]
+        return [self.render_cam(c, Rwc, twc, noise_seed + c) for c in range(len(self.cams))], Rwc, twc
+
+
+def make_rig_tracking_case(seed, scene, dt_frame=0.05, height=(2.4, 3.0)):
+    """Two consecutive rig frames with IMU between them (the rig counterpart of make_tracking_case)."""
+    rng = np.random.default_rng(seed + 4242)
+    Rj, pj = look_down_pose(rng)
+    pj = pj.copy()
+    pj[2] += rng.uniform(*height) - 4.5
+    pi, Ri, vi, vj, bg, ba, meas = synth_ba.imu_motion(rng, pj, Rj, dt_frame)
+    im0, Rwc0, twc0 = scene.frame(Ri, pi, 10 * seed)
+    im1, Rwc1, twc1 = scene.frame(Rj, pj, 10 * seed + 5)
+    F = np.zeros(1, VIO_FRAME_DTYPE)
+    f = F[0]
+    Tcb = scene.Tcb
+    b = f["base"]
+    b["Rcb"] = Tcb[:3, :3].reshape(-1)
+    b["tcb"] = Tcb[:3, 3]
+    c0 = scene.cams[0]
+    b["fx"], b["fy"], b["cx"], b["cy"], b["bf"] = c0["fx"], c0["fy"], c0["cx"], c0["cy"], 0.11 * float(c0["fx"])
+    synth_ba._nav(b["nav"], pj, synth_ba._R_to_quat(Rj), vj, bg, ba)
+    synth_ba._nav(f["nav_last"], pi, synth_ba._R_to_quat(Ri), vi, bg, ba)
+    synth_ba.fill_imu(f["imu"], meas)
+    f["gw"] = synth_ba.GRAVITY
+    f["inv_sigma_bg2"] = 1.0 / synth_ba.IMU_SIGMA[2] ** 2
+    f["inv_sigma_ba2"] = 1.0 / synth_ba.IMU_SIGMA[3] ** 2
+    f["dt_frames"] = dt_frame
+    f["th_depth"] = 35.0
+    return dict(images0=im0, images1=im1, pose0=(Ri, pi, Rwc0, twc0), pose1=(Rj, pj, Rwc1, twc1), vio=F,
+                truth=dict(p=pj, q=synth_ba._R_to_quat(Rj), v=vj))
