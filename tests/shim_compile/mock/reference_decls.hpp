@@ -1,0 +1,252 @@
+// TEST DOUBLE -- the declarations of the reference's classes that shim/*.cc touches, reduced to those members (same
+// names and types as leavesnight/VIEO_SLAM: include/FrameBase.h, Frame.h, KeyFrame.h, MapPoint.h, Map.h, ORBmatcher.h,
+// Optimizer.h, FrameBase_impl.h, src/Odom/NavState.h, OdomPreIntegrator.h, OdomData.h, common/camera_models/
+// camera_base.h).  Lets `g++ -fsyntax-only` type-check the shims where the real tree cannot be compiled (no OpenCV /
+// Eigen / Sophus in the image).  Declarations only; nothing is linked or run; no parity evidence.
+#pragma once
+#include <array>
+#include <cmath>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "third_party_decls.hpp"
+
+namespace DBoW2 {
+typedef unsigned int NodeId;
+class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {};
+}  // namespace DBoW2
+
+namespace VIEO_SLAM {
+using std::set;
+using std::vector;
+using Eigen::Matrix;
+typedef Eigen::Matrix<double, 6, 1> Vector6d;
+typedef Eigen::Matrix<double, 6, 6> Matrix6d;
+typedef Eigen::Matrix<double, 9, 9> Matrix9d;
+
+class NavState {
+ public:
+  Sophus::SO3exd mRwb;
+  Eigen::Vector3d mpwb, mvwb, mbg, mba, mdbg, mdba;
+};
+
+class IMUDataBase {
+ public:
+  static double mInvSigmabg2, mInvSigmaba2;
+};
+class EncPreIntegrator {
+ public:
+  double mdeltatij;
+  Vector6d mdelxEij;
+  Matrix6d mSigmaEij;
+};
+class IMUPreintegrator {
+ public:
+  double mdeltatij;
+  Eigen::Matrix3d mRij;
+  Eigen::Vector3d mvij, mpij;
+  Matrix9d mSigmaijPRV, mSigmaij;
+  Eigen::Matrix3d mJgpij, mJapij, mJgvij, mJavij, mJgRij;
+};
+
+namespace camm {
+class GeometricCamera {
+ public:
+  typedef std::shared_ptr<GeometricCamera> Ptr;
+  enum CameraModel { kUnknown = -1, kPinhole, kRadtan, kKB8 };
+  const Sophus::SE3<float>& GetTrc() const;
+  const Sophus::SE3<float>& GetTcr() const;
+  const std::vector<float>& GetParameters() const;
+  const CameraModel& camera_model() const;
+};
+using Camera = GeometricCamera;
+}  // namespace camm
+
+class MapPoint;
+class KeyFrame;
+class Frame;
+class Map;
+
+class FrameBase {
+ public:
+  virtual ~FrameBase();
+  virtual const Sophus::SE3d GetTwc();
+  virtual const Sophus::SE3d GetTcw();
+  virtual void AddMapPoint(MapPoint* pMP, const size_t& idx);
+  virtual void EraseMapPointMatch(const size_t& idx);
+  virtual vector<MapPoint*> GetMapPointMatches();
+  virtual NavState GetNavState(void);
+  virtual void SetNavState(const NavState& ns);
+  virtual EncPreIntegrator GetEncPreInt(void);
+  virtual IMUPreintegrator GetIMUPreInt(void);
+  virtual bool isBad();
+  double timestamp_, ftimestamp_;
+  static cv::Mat mTbc, mTce;
+  static Eigen::Matrix3d meigRcb;
+  static Eigen::Vector3d meigtcb;
+  static bool usedistort_;
+  vector<camm::Camera::Ptr> mpCameras;
+  int N;
+  vector<cv::KeyPoint> mvKeys, mvKeysUn;
+  vector<std::pair<size_t, size_t>> mapn2in_;
+  unsigned long nid_;
+  float mThDepth;
+  cv::Mat mDescriptors;
+  DBoW2::FeatureVector mFeatVec;
+  struct StereoInfo {
+    vector<float> vdepth_, vuright_;
+    float baseline_bf_[2];
+  } stereoinfo_;
+  struct ScalePyramidInfo {
+    vector<float> vscalefactor_;
+    float fscalefactor_, flogscalefactor_;
+    vector<float> vlevelsigma2_, vinvlevelsigma2_;
+  } scalepyrinfo_;
+
+ protected:
+  const Sophus::SE3d GetTcwCst() const;
+  struct GridInfo {
+    vector<std::array<float, 4>> minmax_xy_;
+  };
+  static GridInfo gridinfo_;
+  vector<MapPoint*> mvpMapPoints;
+};
+
+class Frame : public FrameBase {
+ public:
+  Matrix<double, 15, 15> mMargCovInv;
+  NavState mNavStatePrior;
+  bool mbPrior;
+  const vector<MapPoint*>& GetMapPointMatches() const;
+  const NavState& GetNavState() const;
+  NavState& GetNavStateRef();
+  const EncPreIntegrator& GetEncPreInt(void) const;
+  const IMUPreintegrator& GetIMUPreInt(void) const;
+  void UpdatePoseFromNS();
+  void UpdateNavStatePVRFromTcw();
+  vector<MapPoint*>& GetMapPointsRef();
+  vector<bool> mvbOutlier;
+  cv::Mat& GetTcwRef();
+  const Sophus::SE3d GetTcwCst() const;
+};
+
+class KeyFrame : public FrameBase {
+ public:
+  NavState mNavStatePrior;
+  Matrix<double, 15, 15> mMargCovInv;
+  const bool mbPrior = false;
+  NavState GetNavState(void) override;
+  void SetNavState(const NavState& ns) override;
+  EncPreIntegrator GetEncPreInt(void) override;
+  IMUPreintegrator GetIMUPreInt(void) override;
+  KeyFrame* GetPrevKeyFrame(void);
+  const Sophus::SE3d GetTwc() override;
+  const Sophus::SE3d GetTcw() override;
+  cv::Mat GetCameraCenter();
+  cv::Mat GetRotation();
+  cv::Mat GetTranslation();
+  bool isBad() override;
+  void EraseMapPointMatch(const size_t& idx) override;
+  void EraseMapPointMatch(MapPoint* pMP);
+  vector<MapPoint*> GetMapPointMatches() override;
+  MapPoint* GetMapPoint(const size_t& idx);
+  void FuseMP(size_t idx, MapPoint* pMP);
+  vector<KeyFrame*> GetVectorCovisibleKeyFrames();
+  unsigned long mnBALocalForKF, mnBAFixedForKF;
+};
+
+class MapPoint {
+ protected:
+  typedef struct _TrackFastMatchInfo {
+    float track_depth_ = INFINITY;
+    bool btrack_inview_;
+    static constexpr int NUM_PROJ = 3;
+    std::list<float> vtrack_proj_[NUM_PROJ];
+    std::list<size_t> vtrack_cami_;
+    std::list<float> vtrack_viewcos_;
+    std::list<int> vtrack_scalelevel_;
+  } TrackFastMatchInfo;
+  TrackFastMatchInfo trackinfo_;
+
+ public:
+  using Tdata = float;
+  using Vector3data = Eigen::Matrix<Tdata, 3, 1>;
+  MapPoint(const Vector3data& Pos, KeyFrame* pRefKF, Map* pMap);
+  Vector3data GetWorldPos();
+  void SetWorldPos(const Vector3data& Pos, bool block = true);
+  std::map<KeyFrame*, std::set<size_t>> GetObservations();
+  void EraseObservation(KeyFrame* pKF, size_t idx = -1);
+  std::set<size_t> GetIndexInKeyFrame(KeyFrame* pKF);
+  int Observations();
+  bool IsInKeyFrame(KeyFrame* pKF, size_t idx = -1, size_t cami = -1);
+  bool isBad();
+  void UpdateNormalAndDepth();
+  Vector3data GetNormal();
+  cv::Mat GetDescriptor();
+  TrackFastMatchInfo& GetTrackInfoRef();
+  unsigned long mnId, mnBALocalForKF;
+  static std::mutex mGlobalMutex;
+
+ protected:
+  float mfMinDistance, mfMaxDistance;
+};
+
+class Map {
+ public:
+  void InformNewChange();
+  std::mutex mMutexMapUpdate;
+};
+
+void ErasePairObs(KeyFrame* pFBi, MapPoint* pMPi, size_t idx = -1);
+
+class ORBmatcher {
+ public:
+  static const int TH_LOW, TH_HIGH, HISTO_LENGTH;
+  enum ModeSBP { SBPFuseLater = 0x1, SBPMatchMultiCam = 0x2 };
+  ORBmatcher(float nnratio = 0.6, bool checkOri = true);
+  static void SearchByProjectionBase(const vector<MapPoint*>& vpMapPoints1, cv::Mat Rcrw, cv::Mat tcrw, KeyFrame* pKF,
+                                     const float th_radius, const float th_bestdist, bool bCheckViewingAngle = false,
+                                     const float* pbf = nullptr, int* pnfused = nullptr,
+                                     char mode = (char)SBPMatchMultiCam,
+                                     vector<vector<bool>>* pvbAlreadyMatched1 = nullptr,
+                                     vector<set<int>>* pvnMatch1 = nullptr);
+  int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3,
+                         const float th_far_pts = 0);
+  int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono,
+                         const float th_far_pts = 0);
+  int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
+                         const int ORBdist, const float th_far_pts = 0);
+  int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<vector<vector<size_t>>>& vMatchedPairs,
+                             const bool bOnlyStereo);
+  int Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th = 3.0);
+
+ protected:
+  float RadiusByViewingCos(const float& viewCos);
+  float mfNNratio;
+  bool mbCheckOrientation;
+};
+
+class Optimizer {
+ public:
+  template <class KeyFrame>
+  int static PoseOptimization(Frame* pFrame, KeyFrame* pLastKF, const cv::Mat& gw, const bool bComputeMarg = false,
+                              const bool bNoMPs = false);
+  void static LocalBundleAdjustmentNavStatePRV(KeyFrame* pKF, int Nlocal, bool* pbStopFlag, Map* pMap, cv::Mat gw,
+                                               bool bLarge = false, bool bRecInit = false,
+                                               float th_dist_far = INFINITY);
+  void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int Nlocal = 0);
+  int static PoseOptimization(Frame* pFrame, Frame* pLastF = NULL);
+};
+// what INTEGRATION.md section 4 adds to include/Optimizer.h in place of the template's body
+template <>
+int Optimizer::PoseOptimization<Frame>(Frame*, Frame*, const cv::Mat&, const bool, const bool);
+template <>
+int Optimizer::PoseOptimization<KeyFrame>(Frame*, KeyFrame*, const cv::Mat&, const bool, const bool);
+
+}  // namespace VIEO_SLAM
