@@ -18,6 +18,14 @@ of that path over a batch of B independent frames that already sit in HBM; ranks
 with no data-path collective ("weak" scaling: B frames per rank per step).  Rank 0 prints ONE
 JSON line.
 
+Besides the batched headline the line carries
+  single_stream: the SEQUENTIAL replay of vieo_slam_amd/replay.py (frame t's pose, map points and marginal prior feed
+      frame t+1, one LocalBundleAdjustmentNavStatePRV per 10 frames with write-back) on ONE stream of frames through
+      the host-pointer C-ABI entry points (every call carries its own H2D / D2H): ms per frame, frames/s, and the ATE of
+      that trajectory against the same replay run on the CPU oracle (BASELINE configs[2]: "ATE within 1e-4 of ref");
+  pcie_inclusive: the batched step again with the step's images arriving from pinned host memory on a copy stream
+      (double-buffered, overlapped with the previous step's kernels).
+
 roofline: stage/kernel time is measured live with HIP events on the library's own stream across
 the timed steps; achieved = algorithmic bytes per launch / average launch duration of
 the dominant kernel.  cpu_baseline: the CPU oracle (a port of the reference path, oracle/) rebuilt
@@ -162,6 +170,103 @@ def cpu_baseline(P, lba_problems, lba_every, budget_s=20.0):
                       % (n_done, lba_every, os.cpu_count())}
 
 
+def single_stream_leg(seq, n_frames):
+    """The sequential replay on the C-ABI (see the module docstring); the oracle's run of the same replay is part of
+    the cpu_baseline leg, which fills in the ATE."""
+    from vieo_slam_amd import replay, synth_ba
+    for k in range(n_frames):
+        seq.images(k)  # rendering is not part of either timing
+    Rh = replay.Replay(seq, replay.HipStages())
+    Rh.run(min(12, n_frames))  # warm-up: kernels loaded, scratch buffers allocated
+    Rh = replay.Replay(seq, replay.HipStages())
+    t0 = time.perf_counter()
+    th = Rh.run(n_frames)
+    t_hip = time.perf_counter() - t0
+    err = max(synth_ba.pose_error(th[k], seq.truth(k))[0] for k in range(n_frames))
+    ms_f, ms_l = np.array(Rh.stats["ms_frames"]), np.array(Rh.stats["ms_lba"])
+    return {
+        "frames": n_frames, "local_bas": int(Rh.stats["lba"]),
+        "ms_per_frame": 1e3 * t_hip / (n_frames - 1),
+        "frames_per_s": (n_frames - 1) / t_hip,
+        "latency_ms_per_frame_tracking_median": float(np.median(ms_f)),
+        "latency_ms_per_frame_tracking_p95": float(np.percentile(ms_f, 95)),
+        "ms_per_local_ba_mean": float(ms_l.mean()) if len(ms_l) else None,
+        "ate_vs_oracle_m": None, "max_position_difference_vs_oracle_m": None,
+        "max_position_error_vs_truth_m": float(err),
+        "path": "host-pointer C-ABI entry points, one call per stage, synchronous H2D / D2H inside every call "
+                "(PCIe-inclusive); single host thread; includes the host glue of the replay driver (numpy)",
+    }, th
+
+
+def cpu_replay(seq, n_frames):
+    """cpu_baseline, single-stream form: the same sequential replay on the CPU oracle (one thread)."""
+    from tests import oracle_lib
+    from tests.replay_oracle import OracleStages
+    from vieo_slam_amd import replay
+    try:
+        path = oracle_lib.build(native=True)
+    except Exception:
+        path = oracle_lib.build(native=False)
+    Ro = replay.Replay(seq, OracleStages(oracle_lib.Oracle(path)))
+    t0 = time.perf_counter()
+    to = Ro.run(n_frames)
+    dt = time.perf_counter() - t0
+    return {"value": (n_frames - 1) / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "the %d-frame sequential replay of the single_stream leg (tracking + one local BA per 10 frames) "
+                      "on the CPU oracle, one thread" % n_frames}, to
+
+
+def pcie_leg(P, steps, warmup):
+    """The batched step with its images uploaded from pinned host memory on a copy stream, double-buffered: while
+    step s runs on the pipeline's stream, step s+1's images travel over PCIe."""
+    import ctypes
+    from vieo_slam_amd._lib import DeviceBuffer, check, lib
+    L = lib()
+    nbytes = P.imgs_host.nbytes
+    pin = ctypes.c_void_p()
+    check(L.vieo_host_alloc_pinned(ctypes.byref(pin), nbytes), "pinned")
+    ctypes.memmove(pin.value, P.imgs_host.ctypes.data, nbytes)
+    bufs = [P.d_img, DeviceBuffer(nbytes)]
+    cs = ctypes.c_void_p()
+    check(L.vieo_stream_create(ctypes.byref(cs)), "stream")
+    ev_up = [ctypes.c_void_p(), ctypes.c_void_p()]
+    ev_done = [ctypes.c_void_p(), ctypes.c_void_p()]
+    for e in ev_up + ev_done:
+        check(L.vieo_event_create(ctypes.byref(e)))
+    d_img0 = P.d_img
+
+    def upload(i):  # images of the step that will read buffer i
+        check(L.vieo_stream_wait_event(cs, ev_done[i]))  # the step that last read this buffer has finished
+        check(L.vieo_memcpy_h2d_async(bufs[i].ptr, pin, nbytes, cs))
+        check(L.vieo_event_record(ev_up[i], cs))
+
+    for i in range(2):
+        check(L.vieo_event_record(ev_done[i], P.stream))
+    upload(0)
+    t0 = None
+    for s_ in range(warmup + steps):
+        if s_ == warmup:
+            P.sync()
+            check(L.vieo_stream_synchronize(cs))
+            t0 = time.perf_counter()
+        i = s_ % 2
+        upload(1 - i)                                  # next step's images travel now
+        check(L.vieo_stream_wait_event(P.stream, ev_up[i]))
+        P.d_img = bufs[i]
+        P.step()
+        check(L.vieo_event_record(ev_done[i], P.stream))
+    P.sync()
+    check(L.vieo_stream_synchronize(cs))
+    dt = time.perf_counter() - t0
+    P.d_img = d_img0
+    check(L.vieo_stream_destroy(cs))
+    check(L.vieo_host_free_pinned(pin))
+    return {"value": P.B * steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps,
+            "h2d_bytes_per_step": nbytes, "h2d_GBps_sustained": nbytes * (steps + 1) / dt / 1e9,
+            "note": "front end only (no LocalBA threads), images from pinned host memory on a copy stream, "
+                    "double-buffered against the step's kernels"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +282,9 @@ def main():
     ap.add_argument("--lba-batch", type=int, default=0,
                     help="windows per lock-step LBA call (0 = all windows of a step in one call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream-frames", type=int, default=100,
+                    help="frames of the sequential replay leg (0 = skip); rank 0 at N = 1 only")
+    ap.add_argument("--no-pcie-leg", action="store_true")
     a = ap.parse_args()
 
     from vieo_slam_amd import sharding
@@ -273,7 +381,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (extract/match) + f64 (pose optimisation)", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1] 'EuRoC MH05 stereo-VIO, 1200 feats, PoseOptimization only': "
+                "workload": "BASELINE configs[2] 'EuRoC MH05 stereo-VIO + LocalBundleAdjustment' (= configs[1] plus the "
+                            "local BA; --lba-every 0 is configs[1] alone): "
                             "synthetic rendered stereo-inertial frames 752x480, 1.2x8 levels, FAST 20/7; per "
                             "frame ORBextractor x2 + ComputeStereoMatches + SearchByProjection(last frame) + "
                             "PoseOptimization(VIO) + SearchByProjection(local map) + PoseOptimization(VIO, marg); "
@@ -299,8 +408,20 @@ def main():
                          "algorithmic_bytes_per_launch": ab[dk] * n_img,
                          "avg_launch_ms": kern[dom]},
         }
+        if world == 1 and not a.no_pcie_leg:
+            out["pcie_inclusive"] = pcie_leg(P, max(3, min(a.steps, 10)), 2)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, lba_problems, a.lba_every)
+        if world == 1 and a.single_stream_frames > 1:
+            from vieo_slam_amd import replay
+            seq = replay.Sequence(1, a.single_stream_frames)
+            out["single_stream"], th = single_stream_leg(seq, a.single_stream_frames)
+            if not a.no_cpu_baseline:  # the oracle's run of the same replay: baseline and checker
+                cb, to = cpu_replay(seq, a.single_stream_frames)
+                out["cpu_baseline"]["single_stream"] = cb
+                out["single_stream"]["ate_vs_oracle_m"] = replay.ate_between(th, to)
+                out["single_stream"]["max_position_difference_vs_oracle_m"] = float(
+                    np.linalg.norm(th["p"] - to["p"], axis=1).max())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

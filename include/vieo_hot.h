@@ -47,6 +47,16 @@ int vieo_event_create(void** ev);
 int vieo_event_destroy(void* ev);
 int vieo_event_record(void* ev, void* stream);
 int vieo_event_elapsed_ms(void* ev0, void* ev1, float* ms);
+/* Streams (hipStream_t, non-blocking), pinned host memory and asynchronous copies: frames travel over PCIe on a copy
+ * stream while the previous batch is processed; vieo_stream_wait_event orders the two streams. */
+int vieo_stream_create(void** stream);
+int vieo_stream_destroy(void* stream);
+int vieo_stream_synchronize(void* stream);
+int vieo_stream_wait_event(void* stream, void* ev);
+int vieo_host_alloc_pinned(void** h_ptr, size_t bytes);
+int vieo_host_free_pinned(void* h_ptr);
+int vieo_memcpy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int vieo_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------- ORB extractor ------------
  * Replaces VIEO_SLAM::ORBextractor (include/ORBextractor.h:27-80, src/ORBextractor.cc:391-1081).

@@ -45,6 +45,14 @@ _SIGS = {
     "vieo_memcpy_h2d": (c_i, [c_p, c_p, c_sz]),
     "vieo_memcpy_d2h": (c_i, [c_p, c_p, c_sz]),
     "vieo_device_synchronize": (c_i, []),
+    "vieo_stream_create": (c_i, [P(c_p)]),
+    "vieo_stream_destroy": (c_i, [c_p]),
+    "vieo_stream_synchronize": (c_i, [c_p]),
+    "vieo_stream_wait_event": (c_i, [c_p, c_p]),
+    "vieo_host_alloc_pinned": (c_i, [P(c_p), c_sz]),
+    "vieo_host_free_pinned": (c_i, [c_p]),
+    "vieo_memcpy_h2d_async": (c_i, [c_p, c_p, c_sz, c_p]),
+    "vieo_memcpy_d2h_async": (c_i, [c_p, c_p, c_sz, c_p]),
     "vieo_event_create": (c_i, [P(c_p)]),
     "vieo_event_destroy": (c_i, [c_p]),
     "vieo_event_record": (c_i, [c_p, c_p]),

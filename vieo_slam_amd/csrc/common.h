@@ -24,17 +24,27 @@ void set_error(const char* fmt, ...);
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// One growable device allocation.
+// One growable device allocation.  It remembers the device it lives on: the thread_local scratch caches of the
+// entry points are re-created when the calling thread has moved to another GPU (vieo_set_device).
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  int dev = -1;
   int ensure(size_t bytes) {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (p && dev != cur) {  // allocated on another device: free it there, start again here
+      (void)hipSetDevice(dev);
+      (void)hipFree(p);
+      (void)hipSetDevice(cur);
+      p = nullptr, cap = 0;
+    }
     if (bytes <= cap) return VIEO_OK;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
     VIEO_HIP_CHECK(hipMalloc(&p, bytes));
-    cap = bytes;
+    cap = bytes, dev = cur;
     return VIEO_OK;
   }
   void release() {

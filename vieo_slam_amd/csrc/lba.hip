@@ -1415,6 +1415,7 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
 
 // ================================================================== host-side lock-step LM driver
 static thread_local hipStream_t g_lba_stream = nullptr;
+static thread_local int g_lba_stream_dev = -1;  // the device the stream was created on
 static thread_local DevBuf g_arena, g_small;
 struct PinnedBuf {
   void* p = nullptr;
@@ -1548,6 +1549,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
+  {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (g_lba_stream && g_lba_stream_dev != cur) g_lba_stream = nullptr;  // the thread moved to another GPU
+    g_lba_stream_dev = cur;
+  }
   if (!g_lba_stream) {
     // VIEO_LBA_PRIORITY = -1 / 1: lowest / highest stream priority for the bundle-adjustment stream (default 0)
     int lo = 0, hi = 0;

@@ -15,7 +15,12 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// The arch check is cached per device id: the per-step *_batch_device launches call this on the hot path.
 int require_device() {
+  static std::atomic<int> ok_dev[64];  // 0 unknown, 1 gfx950
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && ok_dev[dev].load(std::memory_order_relaxed) == 1)
+    return VIEO_OK;
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -24,7 +29,6 @@ int require_device() {
     return VIEO_E_NO_DEVICE;
   }
   hipDeviceProp_t prop;
-  int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
     set_error("cannot query HIP device");
     return VIEO_E_NO_DEVICE;
@@ -33,6 +37,7 @@ int require_device() {
     set_error("device arch %s is not gfx950; kernels are built for gfx950 only", prop.gcnArchName);
     return VIEO_E_NO_DEVICE;
   }
+  if (dev >= 0 && dev < 64) ok_dev[dev].store(1, std::memory_order_relaxed);
   return VIEO_OK;
 }
 
@@ -126,6 +131,49 @@ int vieo_event_elapsed_ms(void* ev0, void* ev1, float* ms) {
 }
 int vieo_device_synchronize(void) {
   VIEO_HIP_CHECK(hipDeviceSynchronize());
+  return VIEO_OK;
+}
+
+// ---- streams, pinned host memory and asynchronous copies: what a host needs to feed frames over PCIe while the
+// previous batch is being processed (bench.py's PCIe-inclusive leg, the single-stream replay)
+int vieo_stream_create(void** stream) {
+  if (!stream) return VIEO_E_INVALID;
+  int rc = vieo::require_device();
+  if (rc != VIEO_OK) return rc;
+  hipStream_t s;
+  VIEO_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void*)s;
+  return VIEO_OK;
+}
+int vieo_stream_destroy(void* stream) {
+  if (stream) VIEO_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  return VIEO_OK;
+}
+int vieo_stream_synchronize(void* stream) {
+  VIEO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return VIEO_OK;
+}
+int vieo_stream_wait_event(void* stream, void* ev) {
+  VIEO_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+  return VIEO_OK;
+}
+int vieo_host_alloc_pinned(void** h_ptr, size_t bytes) {
+  if (!h_ptr) return VIEO_E_INVALID;
+  int rc = vieo::require_device();
+  if (rc != VIEO_OK) return rc;
+  VIEO_HIP_CHECK(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return VIEO_OK;
+}
+int vieo_host_free_pinned(void* h_ptr) {
+  if (h_ptr) VIEO_HIP_CHECK(hipHostFree(h_ptr));
+  return VIEO_OK;
+}
+int vieo_memcpy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stream) {
+  VIEO_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return VIEO_OK;
+}
+int vieo_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream) {
+  VIEO_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return VIEO_OK;
 }
 
