@@ -20,3 +20,14 @@ for _ in range(reps):
 e.sync()
 ms = e.stage_ms_all()
 print({k: round(float(np.mean([m[k] for m in ms[1:]])), 4) for k in ms[0]})
+import zlib
+from vieo_slam_amd.orb_extractor import KEYPOINT_DTYPE
+cnt = d_cnt.download(np.int32, (B, 2))
+kp = d_kp.download(KEYPOINT_DTYPE, (B, cap))
+ds = d_desc.download(np.uint8, (B, cap, 32))
+crc = 0
+for b in range(min(B, 16)):
+    n = cnt[b, 0]
+    crc = zlib.crc32(kp[b, :n].tobytes(), crc)
+    crc = zlib.crc32(ds[b, :n].tobytes(), crc)
+print("keys", int(cnt[:, 0].sum()), "crc %08x" % crc)

@@ -154,52 +154,26 @@ __device__ __forceinline__ bool fast_compass(const uint8_t* t, int p, int th) {
   return dk | br;
 }
 
-__global__ void __launch_bounds__(64)
-k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __restrict__ cell_keys,
-       int* __restrict__ cell_counts, int iniTh, int minTh, int tpitch, int tile_bytes,
-       int score_bytes, int n_images) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int item = xcd_grouped(blockIdx.x, kXcdRun), lane = threadIdx.x;  // item = image * ncells + cell
-  if (item >= P.ncells * n_images) return;
-  const int b = item / P.ncells, c = item - b * P.ncells;
-  const CellDesc cd = cells[c];
-  int pitch;
-  const uint8_t* src = plane_ptr(P, I, b, cd.level, &pitch);
-  uint8_t* tile = smem;
-  uint8_t* sc = smem + tile_bytes;
-  unsigned short* cand = (unsigned short*)(smem + tile_bytes + score_bytes);
+// Ordering point for ONE wavefront working on its own slice of LDS: its LDS operations complete in order, so all that
+// is needed is that earlier stores have been issued and waited for before later loads are scheduled.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The three passes of one cell on its tile in LDS (the tile must be complete and visible): compass test +
+// compaction, exact strength of the survivors, 3x3 non-maximum suppression; writes the cell's keys and count.
+__device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd, int b, int c, uint8_t* tile, uint8_t* sc,
+                                          unsigned short* cand, int tpitch, int iniTh, int minTh, int lane,
+                                          unsigned* __restrict__ cell_keys, int* __restrict__ cell_counts) {
   const int x0a = cd.x0 & ~3;
-  const int ndw = ((cd.x0 + cd.cw + 3) >> 2) - (x0a >> 2);
-  {  // ndw <= 17: 16 dword columns x 4 rows per step, the odd 17th column afterwards
-    const int dc = lane & 15, dr = lane >> 4;
-    if (dc < ndw) {
-      const uint8_t* g = src + (size_t)(cd.y0 + dr) * pitch + x0a + 4 * dc;
-      uint8_t* t = tile + dr * tpitch + 4 * dc;
-      const int gstep = 4 * pitch, tstep = 4 * tpitch;
-      // every row of the cell in flight at once (a dependent load -> store loop costs one HBM round trip per
-      // four rows); cells taller than 64 rows finish in the loop
-      unsigned v[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++)
-        if (dr + 4 * k < cd.ch) v[k] = *(const unsigned*)(g + (size_t)k * gstep);
-#pragma unroll
-      for (int k = 0; k < 16; k++)
-        if (dr + 4 * k < cd.ch) *(unsigned*)(t + k * tstep) = v[k];
-      g += (size_t)16 * gstep, t += 16 * tstep;
-      for (int r = dr + 64; r < cd.ch; r += 4, g += gstep, t += tstep) *(unsigned*)t = *(const unsigned*)g;
-    }
-    for (int idx = lane; idx < cd.ch * (ndw - 16); idx += 64) {  // columns 16.. (cells wider than 61)
-      const int r = idx / (ndw - 16), dcol = 16 + idx % (ndw - 16);
-      *(unsigned*)(tile + r * tpitch + 4 * dcol) =
-          *(const unsigned*)(src + (size_t)(cd.y0 + r) * pitch + x0a + 4 * dcol);
-    }
-  }
   const int vw = cd.cw - 6, vh = cd.ch - 6;
   const int npx = (vw > 0 && vh > 0) ? vw * vh : 0;
   const int sp = vw + 2;
   if (npx > 0)  // score_bytes is a multiple of 16 and covers (vh + 2) * sp
     for (int idx = lane; idx < ((vh + 2) * sp + 15) / 16; idx += 64) ((uint4*)sc)[idx] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
+  wave_sync();
   const int xo = cd.x0 - x0a;
   unsigned* out = cell_keys + ((size_t)b * P.ncells + c) * P.cell_cap;
   int base = 0;
@@ -209,25 +183,34 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
   for (int round = 0; round < 2 && base == 0; round++) {
     if (round == 1 && minTh >= iniTh) break;
     const int th = round == 0 ? iniTh : minTh;
-    // ---- pass A: compass test (see fast_compass) on FOUR horizontally adjacent pixels per lane: the
-    // centre row and the rows 3 above / below are read as dwords, realigned with v_alignbyte (the byte
-    // offset is the same for every lane), widened to 16-bit pairs and compared with packed min / max:
-    //   dark  <=> min(max(eU, eD), max(eL, eR)) >  t,   bright <=> max(min(eU, eD), min(eL, eR)) < -t,
-    // e = centre - ring.  Ordered compaction of the surviving pixels (y << 6 | x), 4 rows per step.
+    // ---- pass A: compass test (see fast_compass) on FOUR horizontally adjacent pixels per lane.  The groups of
+    // four are numbered row-major over the cell (g = y * ng + x / 4) and a step takes 64 consecutive ones, so all
+    // lanes are busy whatever the cell width (a 36-pixel cell has 9 groups per row, not a power of two).  The
+    // centre row and the rows 3 above / below are read as dwords and realigned with v_alignbyte (the byte offset
+    // is the same for every lane); the test itself stays on whole dwords, four pixels per operation, with the
+    // full-rate 32-bit add / and / bitop3 (measured, tools/ubench/valu_rate.hip: the packed 16-bit, perm, min / max
+    // and three-operand forms issue at half that rate on gfx950):
+    //   lo = C -sat t, hi = C +sat t per byte;  dark <=> (U < lo | D < lo) & (L < lo | R < lo),
+    //   bright <=> (U > hi | D > hi) & (L > hi | R > hi);  bytewise unsigned a < b from d = (a | H) - (b & ~H):
+    //   bit 7 of the byte = (~a & b) | (~(a ^ b) & ~d), one v_bitop3 (H = 0x80808080).
+    // Ordered compaction of the surviving pixels (y << 6 | x).
     int na = 0;
     if (npx > 0) {
-      typedef short s2 __attribute__((ext_vector_type(2)));
       const int s = (3 + xo) & 3, kq = (3 + xo) >> 2;  // centre byte of pixel x sits at 4 * (lx4 + kq) + s
-      // a 30 .. 32 pixel wide cell (the three largest levels) needs 8 four-pixel groups per row, so a step
-      // covers 8 rows with every lane busy; wider cells take 16 groups x 4 rows
-      const int gsh = vw <= 32 ? 3 : 4;
-      const int lx4 = lane & ((1 << gsh) - 1), ly4 = lane >> gsh, rows_per_step = 64 >> gsh;
-      const int x0 = 4 * lx4;
-      const unsigned th1 = (unsigned)(th + 1) * 0x00010001u, thp = (unsigned)th * 0x00010001u;
-      for (int y0 = 0; y0 < vh; y0 += rows_per_step) {
-        const int y = y0 + ly4;
+      const int ng = (vw + 3) >> 2, G = ng * vh;
+      const int qy = 64 / ng, rx = 64 - qy * ng;        // a step of 64 groups = qy rows and rx groups
+      int y = lane / ng, lx4 = lane - y * ng;
+      const unsigned H = 0x80808080u, T = (unsigned)th * 0x01010101u;
+      const unsigned Tl = T & ~H;
+      // bytewise a < b (bit 7 of every byte): see above; 0x4D = truth table of (~a & b) | (~(a ^ b) & ~d) over (a, b, d)
+      auto ltu = [&](unsigned a, unsigned bb) -> unsigned {
+        const unsigned d = (a | H) - (bb & ~H);
+        return __builtin_amdgcn_bitop3_b32(a, bb, d, 0x4D);
+      };
+      for (int g0 = 0; g0 < G; g0 += 64) {
         unsigned m4 = 0;
-        if (x0 < vw && y < vh) {
+        const int x0 = 4 * lx4;
+        if (g0 + lane < G) {
           const unsigned* rc = (const unsigned*)(tile + (y + 3) * tpitch) + lx4 + kq;
           const unsigned* ru = (const unsigned*)(tile + y * tpitch) + lx4 + kq;
           const unsigned* rd = (const unsigned*)(tile + (y + 6) * tpitch) + lx4 + kq;
@@ -246,38 +229,39 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
           else
             C = __builtin_amdgcn_alignbyte(w1, w0, 3), U = __builtin_amdgcn_alignbyte(u1, u0, 3),
             D = __builtin_amdgcn_alignbyte(d1, d0, 3), L = w0, R = __builtin_amdgcn_alignbyte(w2, w1, 2);
-          unsigned pk[2];
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const unsigned sel = h ? 0x0C030C02u : 0x0C010C00u;  // bytes (2h, 2h+1) -> two 16-bit lanes
-            const s2 c = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, C, sel));
-            const s2 eU = c - __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, U, sel));
-            const s2 eD = c - __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, D, sel));
-            const s2 eL = c - __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, L, sel));
-            const s2 eR = c - __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, R, sel));
-            const s2 mk = __builtin_elementwise_min(__builtin_elementwise_max(eU, eD), __builtin_elementwise_max(eL, eR));
-            const s2 nk = __builtin_elementwise_max(__builtin_elementwise_min(eU, eD), __builtin_elementwise_min(eL, eR));
-            // dark: mk - (t + 1) >= 0 (sign bit clear); bright: nk + t < 0 (sign bit set)
-            const unsigned t = __builtin_bit_cast(unsigned, mk - __builtin_bit_cast(s2, th1));
-            const unsigned u = __builtin_bit_cast(unsigned, nk + __builtin_bit_cast(s2, thp));
-            pk[h] = (~t | u) & 0x80008000u;
-          }
-          m4 = ((pk[0] >> 15) & 1u) | ((pk[0] >> 30) & 2u) | ((pk[1] >> 13) & 4u) | ((pk[1] >> 28) & 8u);
+          // lo = C -sat t: bytes with C >= t keep C - t, the others become 0
+          const unsigned ge = ~ltu(C, T) & H;                 // bit 7: C >= t
+          const unsigned gem = (ge - (ge >> 7)) | ge;          // 0xFF in those bytes
+          const unsigned dif = ((C | H) - Tl) ^ ((C ^ ~T) & H);  // bytewise C - t (mod 256)
+          const unsigned lo = dif & gem;
+          // hi = C +sat t: bytes whose sum carries become 255
+          const unsigned suml = (C & ~H) + Tl;                 // low 7 bits + carry into bit 7
+          const unsigned sum = suml ^ ((C ^ T) & H);           // bytewise C + t (mod 256)
+          const unsigned cy = __builtin_amdgcn_bitop3_b32(C, T, suml, 0xE8) & H;  // carry out = majority(C7, t7, carry in)
+          const unsigned hi = sum | ((cy - (cy >> 7)) | cy);
+          const unsigned dk = (ltu(U, lo) | ltu(D, lo)) & (ltu(L, lo) | ltu(R, lo));
+          const unsigned br = (ltu(hi, U) | ltu(hi, D)) & (ltu(hi, L) | ltu(hi, R));
+          const unsigned f = (dk | br) & H;                    // bit 7 of byte j: pixel x0 + j passes
+          m4 = ((f >> 7) | (f >> 14) | (f >> 21) | (f >> 28)) & 15u;
           m4 &= (1u << min(vw - x0, 4)) - 1u;
         }
         // positions: exclusive prefix over the lanes of popcount(m4) from the ballots of its bits
         const int cnt = __popc(m4);
         const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        int pos = na + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+        int pos = na + __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0)) +
+                  2 * __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0)) +
+                  4 * __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
         const unsigned key = (unsigned)((y << 6) | x0);
 #pragma unroll
         for (int j = 0; j < 4; j++)
           if (m4 & (1u << j)) cand[pos++] = (unsigned short)(key + j);
         na += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+        // the next 64 groups
+        lx4 += rx, y += qy;
+        if (lx4 >= ng) lx4 -= ng, y++;
       }
     }
-    __syncthreads();
+    wave_sync();
     // ---- pass B: exact strength of the survivors; those above the threshold are compacted in
     // place (still row-major: a wavefront reads its 64 entries before it writes any)
     int nc = 0;
@@ -296,7 +280,7 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
       if (pass) cand[nc + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
       nc += __popcll(m);
     }
-    __syncthreads();
+    wave_sync();
     // ---- pass C: 3x3 non-maximum suppression over the candidates (still in row-major order)
     for (int i0 = 0; i0 < nc; i0 += 64) {
       const int i = i0 + lane;
@@ -323,9 +307,70 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
       }
       base += __popcll(m);
     }
-    __syncthreads();
+    wave_sync();
   }
   if (lane == 0) cell_counts[(size_t)b * P.ncells + c] = min(base, P.cell_cap);
+}
+
+// WPB wavefronts per workgroup, each with its own cell and its own slice of LDS (no workgroup barrier anywhere): the
+// CU holds at most 16 workgroups, so one-wavefront workgroups cap the occupancy at 4 wavefronts per SIMD.
+template <int WPB>
+__global__ void __launch_bounds__(64 * WPB)
+k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __restrict__ cell_keys,
+       int* __restrict__ cell_counts, int iniTh, int minTh, int tpitch, int tile_bytes,
+       int score_bytes, int n_images, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* smem = smem_all + wave * lds_per_wave;
+  const int item = xcd_grouped(blockIdx.x, kXcdRun) * WPB + wave;  // item = image * ncells + cell
+  if (item >= P.ncells * n_images) return;
+  const int b = item / P.ncells, c = item - b * P.ncells;
+  const CellDesc cd = cells[c];
+  int pitch;
+  const uint8_t* src = plane_ptr(P, I, b, cd.level, &pitch);
+  uint8_t* tile = smem;
+  uint8_t* sc = smem + tile_bytes;
+  unsigned short* cand = (unsigned short*)(smem + tile_bytes + score_bytes);
+  const int x0a = cd.x0 & ~3;
+  const int ndw = ((cd.x0 + cd.cw + 3) >> 2) - (x0a >> 2);
+  {  // ndw <= 17: 16 dword columns x 4 rows per step, the odd 17th column afterwards
+    const int dc = lane & 15, dr = lane >> 4;
+    // Every row of the cell in flight at once (a dependent load -> store loop costs one HBM round trip per four
+    // rows).  Addresses are a uniform base (scalar registers) plus a 32-bit lane offset that grows by one add per
+    // step, and the steps that lie wholly inside the cell are taken on a uniform condition: per-step 64-bit
+    // address arithmetic and lane masks were 120 of this kernel's vector instructions.
+    const uint8_t* gbase = src + (size_t)cd.y0 * pitch + x0a;  // uniform
+    const unsigned gstep = 4u * (unsigned)pitch, tstep = 4u * (unsigned)tpitch;
+    unsigned goff = (unsigned)dr * (unsigned)pitch + 4u * dc;
+    uint8_t* t = tile + dr * tpitch + 4 * dc;
+    const int kfull = cd.ch >> 2;  // steps whose four rows all exist (uniform)
+    if (dc < ndw) {
+      unsigned v[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        if (k < kfull)
+          v[k] = *(const unsigned*)(gbase + goff);
+        else if (dr + 4 * k < cd.ch)
+          v[k] = *(const unsigned*)(gbase + goff);
+        goff += gstep;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        if (k < kfull)
+          *(unsigned*)t = v[k];
+        else if (dr + 4 * k < cd.ch)
+          *(unsigned*)t = v[k];
+        t += tstep;
+      }
+      for (int r = dr + 64; r < cd.ch; r += 4, goff += gstep, t += tstep) *(unsigned*)t = *(const unsigned*)(gbase + goff);
+    }
+    for (int idx = lane; idx < cd.ch * (ndw - 16); idx += 64) {  // columns 16.. (cells wider than 61)
+      const int r = idx / (ndw - 16), dcol = 16 + idx % (ndw - 16);
+      *(unsigned*)(tile + r * tpitch + 4 * dcol) =
+          *(const unsigned*)(src + (size_t)(cd.y0 + r) * pitch + x0a + 4 * dcol);
+    }
+  }
+  fast_cell(P, cd, b, c, tile, sc, cand, tpitch, iniTh, minTh, lane, cell_keys, cell_counts);
 }
 
 // ------------------------------------------------------------------ quadtree
@@ -1042,10 +1087,16 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
     set_error("batch too large for one launch");
     return VIEO_E_CAPACITY;
   }
-  hipLaunchKernelGGL(k_fast, dim3(xcd_grid((long long)P.ncells * B)), dim3(64), e->fast_lds, st, P, I,
-                     e->d_cells.as<CellDesc>(), e->d_cell_keys.as<unsigned>(),
-                     e->d_cell_counts.as<int>(), e->iniTh, e->minTh, e->tpitch, e->tile_bytes,
-                     e->score_bytes, B);
+  // one wavefront per cell.  Measured alternatives that were slower and are gone: a persistent form with the next
+  // cell's tile prefetched in registers (2.4 - 3.3 ms against 2.0 ms per 1024 images: the extra registers cost
+  // occupancy, and the prologue latency it hides is not what bounds the kernel), 2 / 4 independent wavefronts per
+  // workgroup (2.05 - 2.09 ms)
+  {
+    const int lds_w = align_up(e->fast_lds, 16);
+    hipLaunchKernelGGL((k_fast<1>), dim3(xcd_grid((long long)P.ncells * B)), dim3(64), (size_t)lds_w, st, P, I,
+                       e->d_cells.as<CellDesc>(), e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
+                       e->iniTh, e->minTh, e->tpitch, e->tile_bytes, e->score_bytes, B, lds_w);
+  }
   STAMP();
   hipLaunchKernelGGL(k_quadtree, dim3(P.nlevels, B), dim3(256), e->qt_lds, st, P,
                      e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
