@@ -710,6 +710,15 @@ int vieo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_i
  * outputs are identical on all ranks, h_points_out / h_erase cover the rank's own points.  No stop flag
  * (the ranks must take the same decisions). */
 typedef int (*vieo_allreduce_sum_f64_fn)(void* ctx, double* d_buf, size_t n);
+/* In-library RCCL (north_star: "RCCL all-reduce over xGMI on the pose-block Hessian"): librccl.so is loaded with dlopen at
+ * first use.  Rank 0 draws the 128-byte unique id, the host carries it to the other ranks (torch.distributed broadcast,
+ * MPI, ...), every rank creates its communicator on its own GPU.  Passing allreduce == NULL and ctx == that communicator to
+ * the sharded entries makes the library issue ncclAllReduce(sum, f64) itself on its bundle-adjustment stream, between the
+ * pack and the assemble kernels, with no host synchronisation in between. */
+int vieo_rccl_available(void);
+int vieo_rccl_unique_id(uint8_t* id128);
+int vieo_rccl_comm_create(void** comm, const uint8_t* id128, int n_ranks, int rank);
+int vieo_rccl_comm_destroy(void* comm);
 size_t vieo_lba_sharded_buffer_doubles(int n_windows, const int* n_free_kf);
 int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_params* const* params,
                                              const vieo_lba_keyframe* const* h_kfs, const int* n_kf,

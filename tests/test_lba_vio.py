@@ -198,6 +198,94 @@ def test_gpu_vio_lba_landmark_sharded_two_ranks_on_one_gpu(oracle):
     assert s1[0].tobytes() == p1[0].tobytes() and np.array_equal(s1[1], p1[1]) and np.array_equal(s1[2], p1[2])
 
 
+def _run_ranks(world, shards, n, bad_rank=None):
+    """world 'ranks' as host threads on one GPU; the reduction callback sums their buffers through the host"""
+    import threading
+    from vieo_slam_amd._lib import DeviceBuffer, VieoError, check, lib
+    from vieo_slam_amd.optimizer import Optimizer
+    bufs = [DeviceBuffer(8 * n) for _ in range(world)]
+    barrier = threading.Barrier(world)
+    stage, results = [None] * world, [None] * world
+
+    def make_cb(rank):
+        def cb(offset, count):
+            h = np.empty(count)
+            check(lib().vieo_memcpy_d2h(h.ctypes.data, bufs[rank].ptr + 8 * offset, 8 * count))
+            stage[rank] = h
+            barrier.wait(60)
+            total = sum(stage[r] for r in range(world))
+            barrier.wait(60)
+            check(lib().vieo_memcpy_h2d(bufs[rank].ptr + 8 * offset, total.ctypes.data, 8 * count))
+            return 0
+        return cb
+
+    def run(rank):
+        try:
+            results[rank] = Optimizer.LocalBundleAdjustmentNavStatePRVSharded([shards[rank]], bufs[rank].ptr, n,
+                                                                              make_cb(rank))[0]
+        except VieoError as e:
+            results[rank] = e
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a rank hangs in the exchange"
+    return results
+
+
+@pytest.mark.gpu
+def test_gpu_vio_lba_sharded_empty_shard_and_collective_abort(oracle):
+    """A rank may own no point of a window (more ranks than points, or points without observations): it contributes
+    zeros and still takes part in every exchange.  And when one rank's arguments are invalid, ALL ranks return
+    VIEO_E_INVALID together instead of leaving the others waiting in the all-reduce."""
+    from vieo_slam_amd import sharding
+    from vieo_slam_amd._lib import VieoError
+    from vieo_slam_amd.optimizer import Optimizer
+    win = synth_ba.make_lba_vio_problem(52, n_local=5, n_fixed=2, n_points=300)[:6]
+    ref = Optimizer.LocalBundleAdjustmentNavStatePRV(*win)
+    two = [sharding.shard_window(win, r, 2) for r in range(2)]
+    params, kfs, points, close, obs, imu = win
+    empty = (params, kfs, points[:0].copy(), np.asarray(close)[:0].copy(), obs[:0].copy(), imu)
+    shards = [two[0][0], two[1][0], empty]
+    n = Optimizer.sharded_buffer_doubles([two[0][0]])
+    res = _run_ranks(3, shards, n)
+    assert all(not isinstance(r, Exception) for r in res), res
+    for rank in range(3):
+        hn, hp, he, hr = res[rank]
+        assert hr["status"] == 0 and hr["lm_trials"] == ref[3]["lm_trials"]
+        for k in range(len(kfs)):
+            dt, dr = synth_ba.pose_error(ref[0][k], hn[k])
+            assert dt < 1e-6 and dr < 1e-6
+    assert res[0][0].tobytes() == res[1][0].tobytes() == res[2][0].tobytes()
+    assert len(res[2][1]) == 0 and len(res[2][2]) == 0
+    # rank 1 hands in unsorted observations: every rank comes back with an error, nobody hangs
+    bad = list(two[1][0])
+    bad[4] = bad[4][::-1].copy()
+    res = _run_ranks(2, [two[0][0], tuple(bad)], n)
+    assert all(isinstance(r, VieoError) for r in res), res
+    assert "another rank" in str(res[0]) and "this rank" in str(res[1])
+
+
+@pytest.mark.gpu
+def test_gpu_vio_lba_in_library_rccl_single_rank():
+    """The dlopen'ed RCCL path (vieo_rccl_*): a one-rank communicator, ncclAllReduce issued by the library on its own
+    stream between the pack and assemble kernels; with one rank the result is the plain call's, bit for bit."""
+    from vieo_slam_amd import sharding
+    from vieo_slam_amd._lib import DeviceBuffer, lib
+    from vieo_slam_amd.optimizer import Optimizer
+    assert lib().vieo_rccl_available() == 1
+    win = synth_ba.make_lba_vio_problem(53, n_local=6, n_fixed=3, n_points=500)[:6]
+    comm = sharding.RcclComm(0, 1)
+    try:
+        n = Optimizer.sharded_buffer_doubles([win])
+        buf = DeviceBuffer(8 * n)
+        s = Optimizer.LocalBundleAdjustmentNavStatePRVSharded([win], buf.ptr, n, comm=comm.handle)[0]
+        p = Optimizer.LocalBundleAdjustmentNavStatePRV(*win)
+        assert s[3]["status"] == 0 and s[0].tobytes() == p[0].tobytes()
+        assert np.array_equal(s[1], p[1]) and np.array_equal(s[2], p[2])
+    finally:
+        comm.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rig,seed", [("radtan", 70), ("kb8", 71)])
 def test_gpu_vio_lba_distorted_rig_parity(oracle, rig, seed):

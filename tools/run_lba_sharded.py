@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--fixed", type=int, default=6)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--gba", type=int, default=0, help="full BA with this many LM iterations instead of the local BA")
+    ap.add_argument("--callback", action="store_true",
+                    help="exchange through the torch.distributed callback (two host synchronisations per LM trial) "
+                         "instead of the in-library RCCL all-reduce on the bundle-adjustment stream")
     a = ap.parse_args()
     rank, world, local = sharding.env_rank()
     torch.cuda.set_device(local)
@@ -46,12 +49,14 @@ def main():
 
     def call():
         if a.gba:
-            navs, pts, res = Optimizer.GlobalBundleAdjustmentNavStatePRVSharded(shard, buf.data_ptr(), n, cb, a.gba, True)
+            navs, pts, res = Optimizer.GlobalBundleAdjustmentNavStatePRVSharded(shard, buf.data_ptr(), n, cb, a.gba, True,
+                                                                                comm=comm)
             return navs, pts, None, res
-        return Optimizer.LocalBundleAdjustmentNavStatePRVSharded([shard], buf.data_ptr(), n, cb)[0]
+        return Optimizer.LocalBundleAdjustmentNavStatePRVSharded([shard], buf.data_ptr(), n, cb, comm=comm)[0]
 
     buf = torch.zeros(n, dtype=torch.float64, device="cuda")
-    cb = sharding.torch_allreduce(buf)
+    cb = sharding.torch_allreduce(buf) if a.callback else None
+    comm = None if a.callback else sharding.RcclComm(rank, world).handle
     out = None
     for i in range(a.reps + 1):
         if world > 1:
@@ -72,7 +77,8 @@ def main():
         dmax = max(max(synth_ba.pose_error(ref[0][k], out[0][k])) for k in range(len(win[1])))
         print({"mode": "full BA" if a.gba else "local BA", "ranks": world, "points_total": len(win[2]), "points_this_rank": len(mine),
                "observations_total": len(win[4]), "ms_per_call": 1e3 * float(np.mean(times)),
-               "lm_trials": int(out[3]["lm_trials"]), "max_pose_diff_vs_unsharded": dmax})
+               "lm_trials": int(out[3]["lm_trials"]), "max_pose_diff_vs_unsharded": dmax,
+               "exchange": "torch.distributed callback" if a.callback else "in-library RCCL on the BA stream"})
     if world > 1:
         dist.destroy_process_group()
 

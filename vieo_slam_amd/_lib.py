@@ -107,6 +107,10 @@ _SIGS = {
                                                 c_p, c_p]),
     "vieo_local_bundle_adjustment_vio_batch": (c_i, [c_i] + [c_p] * 15),
     "vieo_lba_sharded_buffer_doubles": (ctypes.c_size_t, [c_i, c_p]),
+    "vieo_rccl_available": (c_i, []),
+    "vieo_rccl_unique_id": (c_i, [c_p]),
+    "vieo_rccl_comm_create": (c_i, [P(c_p), c_p, c_i, c_i]),
+    "vieo_rccl_comm_destroy": (c_i, [c_p]),
     "vieo_global_bundle_adjustment_vio_sharded": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p,
                                                         ctypes.c_size_t, c_p, c_p, c_p, c_p, c_p]),
     "vieo_local_bundle_adjustment_vio_sharded": (c_i, [c_i] + [c_p] * 10 + [c_p, ctypes.c_size_t, c_p, c_p] +

@@ -25,9 +25,11 @@
 //   k_lba_restore / k_lba_classify  rejected-step rollback; chi2 / depth gates
 // The Levenberg-Marquardt policy (lambda, accept / reject, termination, stop flag) runs on the host
 // exactly as g2o's does, from one 56-byte record per window and round.
+#include <chrono>
 #include <vector>
 
 #include "imu_device.h"
+#include "rccl_dl.h"
 
 namespace vieo {
 
@@ -1508,6 +1510,20 @@ struct LbaShard {  // landmark-sharded run: every rank holds all key frames and 
   size_t cap;
 };
 
+// one exchange of a sharded run: the caller's callback (complete on return; the stream is drained first) or, with
+// fn == nullptr, ncclAllReduce on the stream itself (ctx = the communicator of vieo_rccl_comm_create)
+static int shard_exchange(const LbaShard* sh, double* d_buf, size_t n, hipStream_t st) {
+  if (sh->fn) {
+    VIEO_HIP_CHECK(hipStreamSynchronize(st));
+    if (sh->fn(sh->ctx, d_buf, n) != 0) {
+      set_error("sharded local BA: the all-reduce callback failed");
+      return VIEO_E_INVALID;
+    }
+    return VIEO_OK;
+  }
+  return rccl_allreduce_sum_f64(sh->ctx, d_buf, n, st);
+}
+
 static size_t shard_sys_doubles(int nf) { return (size_t)6 * nf * (6 * nf + 1) + 36 * (size_t)nf + 6 * (size_t)nf; }
 
 // Both local BAs: vparams == nullptr -> Optimizer::LocalBundleAdjustment (params), otherwise
@@ -1531,6 +1547,49 @@ struct GbaMode {
   int iterations, robust;
 };
 
+// The argument checks of lba_run without side effects.  A landmark-sharded run calls it first and lets all ranks agree
+// on the outcome with one all-reduce: a rank that returned early on its own while the others were already waiting in
+// the collective would hang them.  `sharded`: a rank may own no point (or no observation) of a window.
+static bool lba_args_ok(bool sharded, bool vio, bool gba, int W, const vieo_lba_params* const* params,
+                        const vieo_lba_vio_params* const* vparams, const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                        const float* const* h_points, const uint8_t* const* h_close, const int* n_mp,
+                        const vieo_lba_obs* const* h_obs, const int* n_obs, const vieo_lba_imu_edge* const* h_imu,
+                        const int* n_imu, vieo_navstate* const* h_navs_out, float* const* h_points_out,
+                        uint8_t* const* h_erase, const vieo_lba_result* h_results, int pd) {
+  if (W <= 0 || (!vio && !params) || !h_kfs || !n_kf || !h_points || !n_mp || !h_obs || !n_obs || !h_navs_out ||
+      !h_points_out || !h_erase || !h_results || (vio && (!h_close || !h_imu || !n_imu)))
+    return false;
+  for (int w = 0; w < W; w++) {
+    const vieo_lba_params* P = vio ? (vparams[w] ? &vparams[w]->base : nullptr) : params[w];
+    if (!P || !h_kfs[w] || n_kf[w] <= 0 || n_mp[w] < 0 || n_obs[w] < 0 || !h_navs_out[w]) return false;
+    if (!sharded && (n_mp[w] == 0 || n_obs[w] == 0)) return false;
+    if (n_mp[w] > 0 && (!h_points[w] || !h_points_out[w])) return false;
+    if (n_obs[w] > 0 && (!h_obs[w] || !h_erase[w])) return false;
+    if (vio && ((!h_close[w] && !gba && n_mp[w] > 0) || n_imu[w] < 0 || (n_imu[w] > 0 && !h_imu[w]))) return false;
+    int n_free = 0;
+    for (int k = 0; k < n_kf[w]; k++) n_free += !h_kfs[w][k].fixed;
+    if (pd * n_free > kBigSolveMax || n_kf[w] >= (1 << 24)) return false;
+    if (vio) {
+      std::vector<char> in(n_kf[w], 0), outk(n_kf[w], 0);
+      for (int t = 0; t < n_imu[w]; t++) {
+        const int a = h_imu[w][t].kf_i, b = h_imu[w][t].kf_j;
+        if (a < 0 || a >= n_kf[w] || b < 0 || b >= n_kf[w] || a == b || outk[a] || in[b]) return false;
+        outk[a] = 1, in[b] = 1;
+      }
+    }
+    const int nc = P->n_cams;
+    if (nc < 0 || nc > 4 || (nc > 0 && !P->cams)) return false;
+    const vieo_lba_obs* ob = h_obs[w];
+    for (int i = 0; i < n_obs[w]; i++) {
+      const int kfi = ob[i].kf & 0xFFFFFF, ci = (ob[i].kf >> 24) & 15;
+      if (ob[i].mp < 0 || ob[i].mp >= n_mp[w] || ob[i].kf < 0 || kfi >= n_kf[w] || (i > 0 && ob[i].mp < ob[i - 1].mp) ||
+          (nc == 0 ? ci != 0 : (ci >= nc || ob[i].ur >= 0)))
+        return false;
+    }
+  }
+  return true;
+}
+
 static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const vieo_lba_params* const* params,
                    const vieo_lba_vio_params* const* vparams, const vieo_lba_keyframe* const* h_kfs,
                    const int* n_kf, const float* const* h_points, const uint8_t* const* h_close,
@@ -1540,9 +1599,32 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
                    vieo_lba_result* h_results, const vieo_lba_enc* const* encs = nullptr) {
   const bool vio = vparams != nullptr;
   const int pd = vio ? 15 : 6;
-  if (sh && (!vio || !sh->fn || !sh->d_buf || (stop && *stop))) {
+  if (sh && (!vio || (!sh->fn && !sh->ctx) || !sh->d_buf || (stop && *stop))) {
     set_error("sharded local BA: visual-inertial windows only, with a reduction callback and buffer");
     return VIEO_E_INVALID;
+  }
+  if (sh) {
+    // every rank reaches this collective whatever its own arguments look like; the sum of the failure flags decides
+    // for all of them (needs a device: a rank without one cannot take part in the job at all)
+    int rcd = require_device();
+    if (rcd != VIEO_OK) return rcd;
+    const bool ok = sh->cap >= 1 && lba_args_ok(true, vio, gba != nullptr, n_windows, params, vparams, h_kfs, n_kf,
+                                                h_points, h_close, n_mp, h_obs, n_obs, h_imu, n_imu, h_navs_out,
+                                                h_points_out, h_erase, h_results, pd);
+    const double flag = ok ? 0.0 : 1.0;
+    double sum = 1.0;
+    if (sh->cap >= 1) {
+      VIEO_HIP_CHECK(hipMemcpy(sh->d_buf, &flag, 8, hipMemcpyHostToDevice));
+      const int xrc = shard_exchange(sh, sh->d_buf, 1, nullptr);
+      if (xrc != VIEO_OK) return xrc;
+      VIEO_HIP_CHECK(hipStreamSynchronize(nullptr));
+      VIEO_HIP_CHECK(hipMemcpy(&sum, sh->d_buf, 8, hipMemcpyDeviceToHost));
+    }
+    if (sum != 0.0) {
+      set_error(ok ? "sharded local BA: another rank rejected its arguments, all ranks return"
+                   : "sharded local BA: invalid arguments on this rank (all ranks return)");
+      return VIEO_E_INVALID;
+    }
   }
   if (n_windows <= 0 || (!vio && !params) || !h_kfs || !n_kf || !h_points || !n_mp || !h_obs || !n_obs ||
       !h_navs_out || !h_points_out || !h_erase || !h_results || (vio && (!h_close || !h_imu || !n_imu)))
@@ -1566,6 +1648,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       VIEO_HIP_CHECK(hipStreamCreateWithPriority(&g_lba_stream, hipStreamNonBlocking, want < 0 ? lo : hi));
   }
   hipStream_t st = g_lba_stream;
+  // VIEO_LBA_TIMING=1: host phases of a call on stderr (staging, rounds, results)
+  static const bool host_timing = getenv("VIEO_LBA_TIMING") != nullptr;
+  const auto t_enter = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
   const int W = n_windows;
   std::vector<WinHost> win(W);
   std::vector<LbaDev> devs(W);
@@ -1585,9 +1673,10 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     }
     H.n_kf = n_kf[w], H.n_mp = n_mp[w], H.n_obs = n_obs[w];
     H.R = &h_results[w];
-    if (!H.P || !h_kfs[w] || H.n_kf <= 0 || !h_points[w] || H.n_mp <= 0 || !h_obs[w] || H.n_obs <= 0 ||
-        !h_navs_out[w] || !h_points_out[w] || !h_erase[w])
-      return VIEO_E_INVALID;
+    if (!H.P || !h_kfs[w] || H.n_kf <= 0 || H.n_mp < 0 || H.n_obs < 0 || !h_navs_out[w] ||
+        (!sh && (H.n_mp == 0 || H.n_obs == 0)) || (H.n_mp > 0 && (!h_points[w] || !h_points_out[w])) ||
+        (H.n_obs > 0 && (!h_obs[w] || !h_erase[w])))
+      return VIEO_E_INVALID;  // a rank of a sharded run may own no point of a window: it still takes part in every exchange
     memset(H.R, 0, sizeof(*H.R));
     {
       int n_free = 0;
@@ -1610,8 +1699,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       }
     }
     for (int k = 0; k < H.n_kf; k++) h_navs_out[w][k] = h_kfs[w][k].nav;
-    memcpy(h_points_out[w], h_points[w], (size_t)H.n_mp * 12);
-    memset(h_erase[w], 0, H.n_obs);
+    if (H.n_mp > 0) memcpy(h_points_out[w], h_points[w], (size_t)H.n_mp * 12);
+    if (H.n_obs > 0) memset(h_erase[w], 0, H.n_obs);
     bool any_free = false;
     for (int k = 0; k < H.n_kf; k++) any_free |= !h_kfs[w][k].fixed;
     if (!any_free) {
@@ -1944,11 +2033,17 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   const size_t ldlt_lds = ldlt_small + (use_lds ? tri : 0);
   const void* ldlt_fn = vio ? (const void*)k_lba_ldlt<5> : (const void*)k_lba_ldlt<6>;
   VIEO_HIP_CHECK(hipFuncSetAttribute(ldlt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
-  const int ge = (max_obs + 255) / 256, gm = (max_mp + 255) / 256, gq = (max_mp + 63) / 64;
+  // (at least one workgroup each: an empty landmark shard still launches everything)
+  const int ge = std::max(1, (max_obs + 255) / 256), gm = std::max(1, (max_mp + 255) / 256), gq = std::max(1, (max_mp + 63) / 64);
   const int gr = std::max(gm, (max_kf + 255) / 256);
 
   // ---- lock-step rounds
+  const double ms_staged = ms_since(t_enter);
+  const auto t_rounds = std::chrono::steady_clock::now();
+  int n_rounds = 0;
+  double ms_wait = 0;
   for (;;) {
+    n_rounds++;
     const bool stop_now = stop && *stop;
     int any = 0;
     for (int w = 0; w < W; w++) {
@@ -1989,7 +2084,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (any & LBA_BEGIN) {
       hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC);
       hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO);
-      hipLaunchKernelGGL(k_lba_occ, dim3((occ_max + 255) / 256, W), dim3(256), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_occ, dim3(std::max(1, (occ_max + 255) / 256), W), dim3(256), 0, st, dD, dC);
       hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0);
     }
     if (any & LBA_BUILD) {
@@ -2006,11 +2101,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         const int nv = 6 * max_nf;
         hipLaunchKernelGGL(k_lba_pack, dim3((nv * (nv + 1) + 36 * max_nf + nv + 255) / 256, W), dim3(256), 0, st,
                            dD, dC, ksplit);
-        VIEO_HIP_CHECK(hipStreamSynchronize(st));
-        if (sh->fn(sh->ctx, sh->d_buf, shard_sys) != 0) {
-          set_error("sharded local BA: the all-reduce callback failed");
-          return VIEO_E_INVALID;
-        }
+        if ((rc = shard_exchange(sh, sh->d_buf, shard_sys, st)) != VIEO_OK) return rc;
       }
       hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO,
                          ksplit);
@@ -2034,17 +2125,17 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
       hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
       if (sh) {  // chi2 and the landmark part of the gain-ratio scale
-        VIEO_HIP_CHECK(hipStreamSynchronize(st));
-        if (sh->fn(sh->ctx, sh->d_buf + shard_sys, 4 * (size_t)W) != 0) {
-          set_error("sharded local BA: the all-reduce callback failed");
-          return VIEO_E_INVALID;
-        }
+        if ((rc = shard_exchange(sh, sh->d_buf + shard_sys, 4 * (size_t)W, st)) != VIEO_OK) return rc;
         VIEO_HIP_CHECK(hipMemcpyAsync(h_sc, sh->d_buf + shard_sys, 32 * (size_t)W, hipMemcpyDeviceToHost, st));
       }
       VIEO_HIP_CHECK(hipMemcpyAsync(out, dO, (size_t)W * sizeof(WinOut), hipMemcpyDeviceToHost, st));
     }
     VIEO_HIP_CHECK(hipGetLastError());
-    VIEO_HIP_CHECK(hipStreamSynchronize(st));
+    {
+      const auto t_w = std::chrono::steady_clock::now();
+      VIEO_HIP_CHECK(hipStreamSynchronize(st));
+      ms_wait += ms_since(t_w);
+    }
     // ---- per-window policy (optimization_algorithm_levenberg.cpp:61-164)
     for (int w = 0; w < W; w++) {
       WinHost& H = win[w];
@@ -2109,8 +2200,13 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     }
   }
   // ---- results: one copy for all windows
+  const double ms_rounds = ms_since(t_rounds);
+  const auto t_res = std::chrono::steady_clock::now();
   VIEO_HIP_CHECK(hipMemcpyAsync(hs + res_begin, base + res_begin, res_end - res_begin, hipMemcpyDeviceToHost, st));
   VIEO_HIP_CHECK(hipStreamSynchronize(st));
+  if (host_timing)
+    fprintf(stderr, "lba_run: %d windows, staging %.3f ms, %d rounds %.3f ms (of which waiting for the stream %.3f), "
+                    "results copy %.3f ms\n", W, ms_staged, n_rounds, ms_rounds, ms_wait, ms_since(t_res));
   for (int w = 0; w < W; w++) {
     WinHost& H = win[w];
     if (H.skip) continue;
@@ -2122,7 +2218,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         continue;  // returns without write-back: outputs stay equal to the inputs
       }
     }
-    memcpy(h_erase[w], hs + H.o_erase, H.n_obs);
+    if (H.n_obs > 0) memcpy(h_erase[w], hs + H.o_erase, H.n_obs);
     for (int i = 0; i < H.n_obs; i++) H.R->n_erase += h_erase[w][i];
     const LbaKf* o = (const LbaKf*)(hs + H.o_kf);
     const double* X = (const double*)(hs + H.o_X);

@@ -147,12 +147,13 @@ class Optimizer:
         return int(lib().vieo_lba_sharded_buffer_doubles(len(windows), nf.ctypes.data))
 
     @staticmethod
-    def LocalBundleAdjustmentNavStatePRVSharded(windows, reduce_ptr, reduce_doubles, allreduce):
+    def LocalBundleAdjustmentNavStatePRVSharded(windows, reduce_ptr, reduce_doubles, allreduce=None, comm=None):
         """This rank's part of landmark-sharded visual-inertial windows.  windows: the
         rank's shards (sharding.shard_window); reduce_ptr: device pointer of a float64 buffer of
         reduce_doubles entries; allreduce(offset, n): in-place sum over the ranks of entries
-        [offset, offset + n) of that buffer, complete on return (sharding.torch_allreduce).  Returns per window
-        (navs, points, erase, result)."""
+        [offset, offset + n) of that buffer, complete on return (sharding.torch_allreduce) -- or comm: the in-library
+        RCCL communicator of sharding.RcclComm (the library then issues ncclAllReduce on its own stream).  Returns per
+        window (navs, points, erase, result)."""
         import ctypes
         W = len(windows)
         keep, outs = [], []
@@ -182,11 +183,12 @@ class Optimizer:
                 traceback.print_exc()
                 return 1
         cb = CB(_cb)
+        fn_ptr, ctx = (ctypes.cast(cb, ctypes.c_void_p), None) if comm is None else (None, ctypes.c_void_p(int(comm)))
         check(lib().vieo_local_bundle_adjustment_vio_sharded(
             W, ptrs[0].ctypes.data, ptrs[1].ctypes.data, cnt[0].ctypes.data, ptrs[2].ctypes.data,
             ptrs[3].ctypes.data, cnt[1].ctypes.data, ptrs[4].ctypes.data, cnt[2].ctypes.data,
             ptrs[5].ctypes.data, cnt[3].ctypes.data, ctypes.c_void_p(base), reduce_doubles,
-            ctypes.cast(cb, ctypes.c_void_p), None, ptrs[6].ctypes.data, ptrs[7].ctypes.data,
+            fn_ptr, ctx, ptrs[6].ctypes.data, ptrs[7].ctypes.data,
             ptrs[8].ctypes.data, res.ctypes.data), "vieo_local_bundle_adjustment_vio_sharded")
         return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
 
@@ -229,8 +231,8 @@ class Optimizer:
         return navs, pts, res[0]
 
     @staticmethod
-    def GlobalBundleAdjustmentNavStatePRVSharded(shard, reduce_ptr, reduce_doubles, allreduce, nIterations=5,
-                                                 bRobust=True):
+    def GlobalBundleAdjustmentNavStatePRVSharded(shard, reduce_ptr, reduce_doubles, allreduce=None, nIterations=5,
+                                                 bRobust=True, comm=None):
         """This rank's landmark shard (sharding.shard_window of (params, kfs, points, close, obs, imu)) of a full
         BA; reduce_ptr / allreduce as in LocalBundleAdjustmentNavStatePRVSharded.  returns (navs, points, result)."""
         import ctypes
@@ -252,7 +254,8 @@ class Optimizer:
         check(lib().vieo_global_bundle_adjustment_vio_sharded(
             params.ctypes.data, int(nIterations), int(bool(bRobust)), kfs.ctypes.data, len(kfs), points.ctypes.data,
             len(points), obs.ctypes.data, len(obs), imu.ctypes.data, len(imu), ctypes.c_void_p(base),
-            reduce_doubles, ctypes.cast(cb, ctypes.c_void_p), None, navs.ctypes.data, pts.ctypes.data,
+            reduce_doubles, None if comm is not None else ctypes.cast(cb, ctypes.c_void_p),
+            None if comm is None else ctypes.c_void_p(int(comm)), navs.ctypes.data, pts.ctypes.data,
             res.ctypes.data), "vieo_global_bundle_adjustment_vio_sharded")
         return navs, pts, res[0]
 

@@ -68,3 +68,37 @@ def torch_allreduce(buf):
             torch.cuda.synchronize(buf.device)
         return 0
     return fn
+
+
+class RcclComm:
+    """In-library RCCL communicator (vieo_rccl_*): rank 0 draws the unique id, `bcast(bytes_or_None) -> bytes`
+    carries it to the other ranks (default: torch.distributed broadcast of a uint8 tensor), every rank creates its
+    communicator on its current GPU.  `.handle` goes to the sharded Optimizer entries as `comm=`."""
+
+    def __init__(self, rank, world, bcast=None):
+        import ctypes
+        import numpy as np
+        from ._lib import check, lib
+        if not lib().vieo_rccl_available():
+            raise RuntimeError("librccl.so could not be loaded")
+        ident = np.zeros(128, np.uint8)
+        if rank == 0:
+            check(lib().vieo_rccl_unique_id(ident.ctypes.data), "vieo_rccl_unique_id")
+        if world > 1:
+            if bcast is None:
+                import torch
+                import torch.distributed as dist
+                t = torch.from_numpy(ident).cuda() if dist.get_backend() == "nccl" else torch.from_numpy(ident)
+                dist.broadcast(t, src=0)
+                ident = t.cpu().numpy()
+            else:
+                ident = np.frombuffer(bcast(ident.tobytes() if rank == 0 else None), np.uint8).copy()
+        h = ctypes.c_void_p()
+        check(lib().vieo_rccl_comm_create(ctypes.byref(h), ident.ctypes.data, world, rank), "vieo_rccl_comm_create")
+        self.handle = h.value
+
+    def close(self):
+        from ._lib import lib
+        if getattr(self, "handle", None):
+            lib().vieo_rccl_comm_destroy(self.handle)
+            self.handle = None
