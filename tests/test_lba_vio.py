@@ -123,6 +123,21 @@ def test_gpu_vio_lba_parity(oracle, seed, kw):
 
 
 @pytest.mark.gpu
+def test_gpu_vio_lba_large_window_parity(oracle):
+    """bLarge (Optimizer.cc:41-49, 131-138): Nlocal x 2.5 = 25 local key frames (375 unknowns: the reduced system no
+    longer fits the LDS-resident solver's 132-dim panel form), optimize(2) + optimize(2), lambda_init 1e-2, no
+    divergence guard"""
+    from vieo_slam_amd.optimizer import Optimizer
+    win = list(synth_ba.make_lba_vio_problem(26, n_local=25, n_fixed=8, n_points=2000, dt_kf=0.25)[:6])
+    P = win[0].copy()
+    P[0]["large"], P[0]["lambda_init"] = 1, 1e-2
+    P[0]["base"]["its0"], P[0]["base"]["its1"] = 2, 2
+    win[0] = P
+    assert (win[1]["fixed"] == 0).sum() == 25
+    _parity(oracle, tuple(win), Optimizer.LocalBundleAdjustmentNavStatePRV(*win))
+
+
+@pytest.mark.gpu
 def test_gpu_vio_lba_batch_and_edge_cases(oracle):
     from vieo_slam_amd.optimizer import Optimizer
     wins = [synth_ba.make_lba_vio_problem(30 + i, n_local=4 + 3 * i, n_fixed=3, n_points=300 + 200 * i)[:6]

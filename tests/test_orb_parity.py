@@ -149,8 +149,19 @@ def test_matches_committed_golden():
         assert np.array_equal(desc, g[tag + "_desc"])
 
 
-def test_device_sincos_exhaustive_sample():
-    """The device runs the same text as tests/emul/sincos_emul.c; here the descriptor parity above
-    already exercises it.  Extra guard: descriptors of a frame rotated by 90 degrees still match
-    the oracle (angles spread over all quadrants)."""
-    pass
+def test_rotated_frames_cover_all_quadrants(oracle):
+    """The steered-BRIEF path (IC angle -> cos / sin of sincosf_exact.h -> 256 rotated taps) on frames whose key-point
+    angles fill every quadrant: a frame, its 90 / 180 / 270 degree rotations and its mirror image.  Descriptors and
+    angles stay bit-equal to the oracle, and the angles of the four rotations together populate all 12 bins of 30
+    degrees (a synthetic frame alone leaves some nearly empty)."""
+    base = synth.synth_image(1042, 640, 480)
+    frames = [base, np.ascontiguousarray(np.rot90(base, 1)), np.ascontiguousarray(np.rot90(base, 2)),
+              np.ascontiguousarray(np.rot90(base, 3)), np.ascontiguousarray(base[:, ::-1])]
+    hist = np.zeros(12, int)
+    for img in frames:
+        o, h = oracle.extractor(1000), _hip(1000)
+        ref, got = o(img), h(img)
+        _assert_same(ref, got)
+        assert len(ref[1]) > 800
+        hist += np.bincount((ref[1]["angle"] // 30).astype(int) % 12, minlength=12)
+    assert hist.min() > 100, hist
