@@ -19,6 +19,20 @@ def test_oracle_replay_tracks_the_truth(oracle):
     assert min(R.stats["n_inliers"]) > 150
     # the second frame after a key frame runs against the last frame with the marginal prior of the first one
     assert R.last.prior is not None and np.abs(R.last.prior[1]).max() > 0
+    # the map the run built, through the reference's binary map file and back
+    import io
+    from vieo_slam_amd import map_io
+    m = map_io.map_from_replay(R)
+    f = io.BytesIO()
+    map_io.save_map(f, m)
+    r = map_io.load_map(f.getvalue())
+    assert len(r["keyframes"]) == 3 and len(r["mappoints"]) == len(m["mappoints"]) > 500
+    assert r["keyframes"][2]["nav"].tobytes() == np.asarray(R.kfs[2].nav, r["keyframes"][2]["nav"].dtype).tobytes()
+    assert np.array_equal(r["keyframes"][1]["descriptors"], R.kfs[1].desc)
+    seen = {p["id"]: p for p in r["mappoints"]}
+    k2 = r["keyframes"][2]
+    held = k2["matches"][k2["matches"] != map_io.ULONG_MAX]
+    assert len(held) > 100 and all(int(i) in seen for i in held)
 
 
 @pytest.mark.gpu
