@@ -19,13 +19,15 @@
 //                    tiles on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), D^-1 applied while the
 //                    K-chunk is staged through LDS; per-split partial products
 //   k_lba_assemble   Hs = H_pp + lambda I - sum of the partials (fixed order), bs likewise
-//   k_lba_ldlt       one workgroup per window: LDL^T of the reduced system in LDS, solve, pose
+//   k_lba_ldlt16     one workgroup per window: blocked LDL^T (FP64 MFMA) of the reduced system in LDS, solve, pose
 //                    retraction (with backup) and the pose part of the gain-ratio scale
+//   k_lba_ldlt       the same with column panels, for systems of 160 .. 510 unknowns
 //   k_lba_update_points  back-substitution x_l = D^-1 (b_l - B^T x_p), point update (with backup)
 //   k_lba_restore / k_lba_classify  rejected-step rollback; chi2 / depth gates
 // The Levenberg-Marquardt policy (lambda, accept / reject, termination, stop flag) runs on the host
 // exactly as g2o's does, from one 56-byte record per window and round.
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "imu_device.h"
@@ -950,16 +952,28 @@ k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, i
 // factorised in place in global memory.
 // The end of a solve, shared by the single-workgroup LDL^T and the tiled one: x -> D.xp, the pose part of
 // computeScale(), push() + oplus on the free key frames.  y: the solution (LDS or global), 256 threads.
+// NT: threads of the workgroup; the first 256 do the work (and sum in the same order whatever NT is).
+template <int NT = 256>
 __device__ __forceinline__ void lba_apply_step(const LbaDev& D, const double* y, double lambda, bool ok, WinOut& o,
                                                double* s_red, int tid) {
   const int n = D.np;
   double sp[1] = {0};
-  for (int i = tid; i < n; i += 256) {
-    D.xp[i] = y[i];
-    sp[0] += y[i] * (lambda * y[i] + D.bfull[i]);  // pose part of computeScale()
+  if (tid < 256)
+    for (int i = tid; i < n; i += 256) {
+      D.xp[i] = y[i];
+      sp[0] += y[i] * (lambda * y[i] + D.bfull[i]);  // pose part of computeScale()
+    }
+  if (NT == 256)
+    block_sum<1>(sp, s_red, tid);
+  else {
+    sp[0] = wave_sum_d(sp[0]);
+    __syncthreads();
+    if ((tid & 63) == 0 && tid < 256) s_red[tid >> 6] = sp[0];
+    __syncthreads();
+    sp[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   }
-  block_sum<1>(sp, s_red, tid);
   if (tid == 0) o.ok = ok ? 1 : 0, o.scale_p = ok ? sp[0] : 0.0;
+  if (tid >= 256) return;
   // oplus on the free key frames (push() first): VertexNavStatePR (+ V, Bias in a visual-inertial window)
   for (int k = tid; k < D.n_kf; k += 256) {
     LbaKf kf = D.kf[k];
@@ -1130,6 +1144,212 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
   lba_apply_step(D, y, lambda, ok, out[w], s_red, tid);
 }
 
+__device__ __forceinline__ double big_readlane(double v, int srclane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// block t of a lower triangle counted row by row -> (row, column)
+struct TriMap {
+  unsigned char i[64], j[64];
+  constexpr TriMap() : i(), j() {
+    int t = 0;
+    for (int r = 0; r < 11 && t < 64; r++)
+      for (int c = 0; c <= r && t < 64; c++, t++) i[t] = (unsigned char)r, j[t] = (unsigned char)c;
+  }
+};
+__constant__ TriMap kTriMap;
+
+// ---- the same solve for reduced systems of up to 159 unknowns (ten key frames of a visual-inertial window, 26 of a
+// vision-only one), blocked by 16 on the FP64 matrix cores.  The lower triangle of [H b; b^T 1] lives in LDS as
+// 16 x 16 blocks (row pitch 17): row n carries the right-hand side, so the forward substitution falls out of the
+// factorisation.  Per block column k, two phases with a barrier each:
+//   panel      one thread per row below: W = A_ik L_kk^-T (un-normalised, kept in sWp), L_ik = W D_k^-1 in place
+//   trailing   A_ij -= W_ik L_jk^T, one v_mfma_f64_16x16x4_f64 chain of four per block, blocks dealt over the
+//              four wavefronts; wavefront 0 takes A_(k+1)(k+1) first and factorises it in registers right after
+//              (one lane per row, v_readlane for the column broadcasts), hidden behind the other wavefronts' blocks
+// then L^T x = z from the bottom block up (wavefront 0 solves the 16 x 16 triangle, the others fold the block into
+// the earlier entries of z).
+// Measured (MI355X, 150 unknowns, s_memtime inside the kernel): 75 us per solve against 200 us for the column-panel
+// kernel above -- load 8.5, per block column 1.9 (panel) + 3.2 .. 5.2 (diagonal factor 2.7 on the critical path),
+// back substitution 7.8, pose update 4.3.  What did NOT help: DPP row_newbcast instead of v_readlane in the
+// diagonal factor (5.8 us instead of 2.9), letting every wavefront walk the whole block list and skip the blocks
+// of the others (the scalar loop of 16 wavefronts serialises on the CU's scalar unit: +3.5 us at k = 0).
+static const int kLdP = 17, kLdBlk = 16 * kLdP, kLd16MaxBlocks = 10, kLd16Threads = 1024;
+
+__device__ __forceinline__ int ld16_blk(int i, int j) { return (i * (i + 1) / 2 + j) * kLdBlk; }
+
+static size_t ld16_lds_bytes(int nbm) { return ((size_t)(nbm * (nbm + 1) / 2 + nbm) * kLdBlk + 16 + nbm * 16) * 8; }
+
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_lba_ldlt16(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out, int nb_max) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  __shared__ double s_red[4];
+  __shared__ int s_bad;
+  constexpr int NW = NT / 64;
+  const int w = blockIdx.x;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  const int n = D.np, tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform for the compiler: the MFMA blocks of the other wavefronts must be branched over, not masked
+  // (v_mfma ignores EXEC and would run its passes anyway)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (n == 0) {
+    if (tid == 0) out[w].ok = 1, out[w].scale_p = 0;
+    return;
+  }
+  const double lambda = win_lambda(ctl[w], out[w]);
+  const int nb = (n + 16) >> 4;  // blocks of the bordered matrix, n + 1 rows
+  double* sA = s_dyn;
+  double* sWp = sA + (size_t)(nb_max * (nb_max + 1) / 2) * kLdBlk;
+  double* sD = sWp + (size_t)nb_max * kLdBlk;
+  double* y = sD + 16;
+  if (tid == 0) s_bad = 0;
+  {  // H, coalesced: the blocks on and below the diagonal
+    const float inv_n = 1.0f / (float)n;
+#pragma unroll 8
+    for (int i = tid; i < n * n; i += NT) {
+      const int r = (int)(((float)i + 0.5f) * inv_n), c = i - r * n;  // exact: n * n < 2^15
+      if ((c >> 4) <= (r >> 4)) sA[ld16_blk(r >> 4, c >> 4) + (r & 15) * kLdP + (c & 15)] = D.Hs[i];
+    }
+    // border: row n = b^T with pivot 1, identity padding below
+    const int rows = nb * 16 - n;
+    for (int i = tid; i < rows * nb * 16; i += NT) {
+      const int r = n + i / (nb * 16), c = i % (nb * 16);
+      if ((c >> 4) > (r >> 4)) continue;
+      const double v = r == n ? (c < n ? D.bs[c] : (c == n ? 1.0 : 0.0)) : (r == c ? 1.0 : 0.0);
+      sA[ld16_blk(r >> 4, c >> 4) + (r & 15) * kLdP + (c & 15)] = v;
+    }
+    // columns >= n of the rows above the border in the last block column
+    for (int i = tid; i < 16 * 16; i += NT) {
+      const int r = (n >> 4) * 16 + (i >> 4), c = (n >> 4) * 16 + (i & 15);
+      if (r < n && c >= n) sA[ld16_blk(n >> 4, n >> 4) + (r & 15) * kLdP + (c & 15)] = 0.0;
+    }
+  }
+  __syncthreads();
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  // A_kk = L D L^T in the registers of wavefront 0 (lanes 16..63 mirror lanes 0..15 so that the readlanes stay
+  // wave-uniform); 1 / d_c (v_rcp_f64 + two Newton steps) goes to sD for the panel
+  auto factor_diag = [&](int k) {
+    double* Akk = sA + ld16_blk(k, k);
+    const int r = lane & 15;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) a[c] = Akk[r * kLdP + c];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const double d = big_readlane(a[c], c);
+      if (!(d > 0) && k * 16 + c < n) bad = true;  // the right-hand-side row and the padding are not pivots
+      double inv = __builtin_amdgcn_rcp(d);
+      inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+      inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+      const double l = a[c] * inv;
+#pragma unroll
+      for (int q = c + 1; q < 16; q++) a[q] -= l * big_readlane(a[c], q);  // w_q = A[q][c], un-normalised
+      if (r > c) a[c] = l;
+      if (r == c) a[c] = inv;
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < r) Akk[r * kLdP + c] = a[c];
+        if (c == r) sD[c] = a[c];
+      }
+      if (bad) s_bad = 1;
+    }
+  };
+  if (wv == 0) factor_diag(0);
+  __syncthreads();
+  bool ok = true;
+  for (int k = 0; k < nb; k++) {
+    if (s_bad) {
+      ok = false;
+      break;
+    }
+    const double* Akk = sA + ld16_blk(k, k);
+    if (tid < (nb - k - 1) * 16) {
+      const int i = k + 1 + (tid >> 4), r = tid & 15;
+      double* src = sA + ld16_blk(i, k) + r * kLdP;
+      double a[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[c] = src[c];
+      // W L_kk^T = A: W[c] = A[c] - sum_{m < c} W[m] L_kk[c][m]   (LDS reads are broadcasts)
+#pragma unroll
+      for (int c = 1; c < 16; c++) {
+        double v = a[c];
+#pragma unroll
+        for (int m = 0; m < c; m++) v -= a[m] * Akk[c * kLdP + m];
+        a[c] = v;
+      }
+      double* wp = sWp + i * kLdBlk + r * kLdP;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        wp[c] = a[c];
+        src[c] = a[c] * sD[c];
+      }
+    }
+    __syncthreads();
+    // trailing update; the wavefront that owns A_(k+1)(k+1) factorises it straight away, one step ahead
+    const int m = nb - k - 1;
+    for (int t = wv; t < m * (m + 1) / 2; t += NW) {
+      const int i = k + 1 + kTriMap.i[t], j = k + 1 + kTriMap.j[t];
+      double* C = sA + ld16_blk(i, j) + (lane >> 4) * kLdP + (lane & 15);
+      double4_t acc;
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[q] = C[q * 4 * kLdP];
+      const double* pa = sWp + i * kLdBlk + (lane & 15) * kLdP + (lane >> 4);
+      const double* pb = sA + ld16_blk(j, k) + (lane & 15) * kLdP + (lane >> 4);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[ks * 4], pb[ks * 4], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) C[q * 4 * kLdP] = acc[q];
+      if (t == 0) factor_diag(k + 1);  // wavefront 0; its own LDS traffic is in order
+    }
+    __syncthreads();
+  }
+  if (ok) {
+    // z = D^-1 L^-1 b is row n of the factor; L^T x = z from the bottom block up.  Wavefront 0 folds x of block
+    // kb + 1 into block kb and solves its triangle at once, the others fold it into the entries above.
+    for (int i = tid; i < nb * 16; i += NT) y[i] = i < n ? sA[ld16_blk(n >> 4, i >> 4) + (n & 15) * kLdP + (i & 15)] : 0.0;
+    __syncthreads();
+    const int top = (n - 1) >> 4;
+    for (int kb = top; kb >= 0; kb--) {
+      if (wv == 0) {
+        const int r = lane & 15, j = kb * 16 + r;
+        double s = y[j];
+        if (kb < top) {
+          const double* blk = sA + ld16_blk(kb + 1, kb) + r;
+#pragma unroll
+          for (int q = 0; q < 16; q++) s -= blk[q * kLdP] * y[(kb + 1) * 16 + q];  // entries >= n are zero
+        }
+        const double* Akk = sA + ld16_blk(kb, kb);
+        double Lc[16];
+#pragma unroll
+        for (int rr = 1; rr < 16; rr++) Lc[rr] = (r < rr && kb * 16 + rr < n) ? Akk[rr * kLdP + r] : 0.0;
+#pragma unroll
+        for (int rr = 15; rr >= 1; rr--) s -= Lc[rr] * big_readlane(s, rr);
+        if (lane < 16 && j < n) y[j] = s;
+      } else if (kb < top && tid - 64 < kb * 16) {
+        const int j = tid - 64;
+        const double* blk = sA + ld16_blk(kb + 1, j >> 4) + (j & 15);
+        double v = y[j];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v -= blk[q * kLdP] * y[(kb + 1) * 16 + q];
+        y[j] = v;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int i = tid; i < n; i += NT) y[i] = 0;
+    __syncthreads();
+  }
+  lba_apply_step<NT>(D, y, lambda, ok, out[w], s_red, tid);
+}
+
 // ---- tiled LDL^T for reduced systems that do not fit one workgroup (global BA: hundreds of key frames).
 // Right-looking over 64-column panels of the padded lower triangle Hb [nb][nb]; row np carries the right-hand
 // side, so the forward substitution falls out of the factorisation (its row of L is D^-1 L^-1 b).
@@ -1140,13 +1360,6 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
 //   k_big_syrk   A_ij -= W_ik L_jk^T for the tiles right of the panel: FP64 MFMA, 64 x 64 x 64 per workgroup
 //   k_big_back_step  L^T x = z, one 64-row block per launch from the bottom; k_big_finish: lba_apply_step
 static const int kNB = 64, kBigLd = kNB + 2;
-
-__device__ __forceinline__ double big_readlane(double v, int srclane) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)b, srclane);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 
 __global__ void __launch_bounds__(256)
 k_big_init(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
@@ -1532,6 +1745,14 @@ static size_t shard_sys_doubles(int nf) { return (size_t)6 * nf * (6 * nf + 1) +
 
 // reduced systems beyond one workgroup's LDL^T take the tiled solve (VIEO_LBA_BIG_SOLVE=1 forces it: tests)
 static const int kSmallSolveMax = 510, kBigSolveMax = 16320;
+static bool ldlt16_disabled() {  // VIEO_LBA_LDLT16=0: the column-panel kernel instead (A/B runs)
+  static const int off = [] {
+    const char* e = getenv("VIEO_LBA_LDLT16");
+    return e && atoi(e) == 0;
+  }();
+  return off;
+}
+
 static bool big_solve(int n) {
   static const int forced = [] {
     const char* e = getenv("VIEO_LBA_BIG_SOLVE");
@@ -1717,15 +1938,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       set_error("local BA: n_cams must be 0..4");
       return VIEO_E_INVALID;
     }
-    for (int i = 0; i < H.n_obs; i++) {
-      const int kfi = ob[i].kf & 0xFFFFFF, ci = (ob[i].kf >> 24) & 15;
-      if (ob[i].mp < 0 || ob[i].mp >= H.n_mp || ob[i].kf < 0 || kfi >= H.n_kf || (i > 0 && ob[i].mp < ob[i - 1].mp) ||
-          (nc == 0 ? ci != 0 : (ci >= nc || ob[i].ur >= 0))) {
-        set_error("vieo_local_bundle_adjustment: observations must be sorted by map point, key frame and camera "
-                  "indices in range, distorted observations monocular");
-        return VIEO_E_INVALID;
-      }
-    }
+    (void)ob;  // the observations are checked while they are staged (fill_window)
   }
   if (!n_live) return VIEO_OK;
   // ---- arena layout: [inputs | results (kf, X, erase) | zero-initialised | scratch]
@@ -1790,19 +2003,102 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     int nb;
   };
   std::vector<Scr> scr(W);
+  // ---- staging, part 1 (sequential, cheap): scratch layout of every window and the scalar part of its descriptor
   for (int w = 0; w < W; w++) {
     WinHost& H = win[w];
     if (H.skip) continue;
+    const vieo_lba_keyframe* kfs = h_kfs[w];
+    int nf = 0;
+    for (int k = 0; k < H.n_kf; k++) nf += !kfs[k].fixed;
+    // scratch
+    Scr& s = scr[w];
+    const int npm = 6 * nf;
+    s.kf_bak = take((size_t)H.n_kf * sizeof(LbaKf)), s.X_bak = take((size_t)H.n_mp * 24);
+    s.mp_act = take(H.n_mp);
+    const int ldB = (H.n_mp + kChunkLm - 1) / kChunkLm * (3 * kChunkLm);
+    const int sp_rows = (npm + 63) / 64 * 64, ldS = (npm + 64) / 64 * 64;
+    s.BB = take((size_t)npm * ldB * 8);
+    s.Sp = take((size_t)ksplit * sp_rows * ldS * 8);
+    s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
+    const int npf = pd * nf;  // full reduced system
+    s.Hpp = take((size_t)nf * 36 * 8), s.Hs = take((size_t)npf * npf * 8);
+    s.nb = (npf + 1 + kNB - 1) / kNB * kNB;  // + the right-hand-side row
+    s.Hb = s.Wp = s.big_fail = 0;
+    if (big_solve(pd * nf)) {
+      s.Hb = take((size_t)s.nb * s.nb * 8), s.Wp = take((size_t)s.nb * kNB * 8), s.big_fail = take(256);
+    }
+    s.bp = take((size_t)npm * 8), s.bs = take((size_t)npf * 8), s.xp = take((size_t)npf * 8);
+    s.bfull = take((size_t)npf * 8);
+    s.Ae = take((size_t)std::max(H.n_imu, 1) * 930 * 8);
+    s.gchi0 = take((size_t)std::max(H.n_imu, 1) * 8), s.gchi = take((size_t)std::max(H.n_imu, 1) * 8);
+    s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
+    s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
+    s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)nf * H.n_mp * 4);
+    s.kf_act = take((size_t)H.n_kf * 4);
+    s.occ = take((size_t)((npm + 64) / 64) * ((H.n_mp + kChunkLm - 1) / kChunkLm));
+    LbaDev& D = devs[w];
+    memset(&D, 0, sizeof(D));
+    D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.nf_cap = nf;
+    D.ldB = ldB, D.ldS = ldS, D.sp_stride = (size_t)sp_rows * ldS;
+    D.cam.fx = H.P->fx, D.cam.fy = H.P->fy, D.cam.cx = H.P->cx, D.cam.cy = H.P->cy, D.cam.bf = H.P->bf;
+    memcpy(D.cam.Rcb, H.P->Rcb, 72);
+    memcpy(D.cam.tcb, H.P->tcb, 24);
+    D.n_cams = H.P->n_cams;
+    any_multicam |= H.P->n_cams > 0;
+    for (int ci = 0; ci < H.P->n_cams; ci++) {
+      const vieo_camera& c = H.P->cams[ci];
+      CamD& d = D.cams[ci];
+      d.fx = c.fx, d.fy = c.fy, d.cx = c.cx, d.cy = c.cy, d.bf = 0;
+      memcpy(d.Rcb, c.Rcb, 72), memcpy(d.tcb, c.tcb, 24);
+      d.model = c.model, d.num_k = c.model == VIEO_CAM_RADTAN ? c.num_k : 0;
+      if (c.model < 0 || c.model > 2 || (c.model == VIEO_CAM_RADTAN && (c.num_k < 2 || c.num_k > 6))) {
+        set_error("local BA: camera %d has an unknown model or coefficient count", ci);
+        return VIEO_E_INVALID;
+      }
+      for (int q = 0; q < 8; q++) d.k[q] = (double)c.dist[q];
+    }
+    // thHuberMono = sqrt(5.991) in the local BAs, thHuber2D = sqrt(5.99) in the global ones (Optimizer.cc:1063,1445)
+    D.dMono = (double)(float)sqrt(gba ? 5.99 : 5.991), D.dStereo = (double)(float)sqrt(7.815);
+    D.pd = pd, D.n_imu = H.n_imu;
+    if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
+      D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
+      memcpy(D.gw, H.VP->gw, 24);
+      memcpy(D.qRbe, H.VP->qRbe, 32), memcpy(D.pbe, H.VP->pbe, 24);
+      D.th_dist_far = (!gba && H.VP->th_dist_far > 0 && std::isfinite(H.VP->th_dist_far)) ? (double)H.VP->th_dist_far : 0.0;
+      H.prelevel_pending = !gba;
+    } else {
+      D.thMono = D.thMonoClose = 5.991, D.thStereo = 7.815;
+      if (H.ENC) memcpy(D.qRbe, H.ENC->qRbe, 32), memcpy(D.pbe, H.ENC->pbe, 24);
+    }
+    max_imu = std::max(max_imu, H.n_imu);
+    max_obs = std::max(max_obs, H.n_obs), max_mp = std::max(max_mp, H.n_mp);
+    max_kf = std::max(max_kf, H.n_kf), max_nf = std::max(max_nf, nf);
+    H.iters = gba ? gba->iterations : H.P->its0;
+    H.phase = H.iters > 0 ? 0 : 2;
+  }
+  // ---- staging, part 2: the inputs of every window into the pinned copy of the arena (index structures, key frames,
+  // inertial edges with their information matrices, points).  Windows are independent and the work is memory copies,
+  // so a large batch is split over a few host threads (6.6 ms on one thread for the 103 windows of a bench step).
+  auto fill_window = [&](int w) -> int {
+    WinHost& H = win[w];
     const Off& o = off[w];
     const vieo_lba_obs* ob = h_obs[w];
     const vieo_lba_keyframe* kfs = h_kfs[w];
     // host-side index structures, written straight into the pinned staging copy of the arena
     {  // the device sees plain key-frame indices; the camera index travels in its own byte array
       vieo_lba_obs* so = (vieo_lba_obs*)(hs + o.obs);
+      const int nc = H.P->n_cams;
       for (int i = 0; i < H.n_obs; i++) {
+        const int kfi = ob[i].kf & 0xFFFFFF, ci = (ob[i].kf >> 24) & 15;
+        if (ob[i].mp < 0 || ob[i].mp >= H.n_mp || ob[i].kf < 0 || kfi >= H.n_kf || (i > 0 && ob[i].mp < ob[i - 1].mp) ||
+            (nc == 0 ? ci != 0 : (ci >= nc || ob[i].ur >= 0))) {
+          set_error("vieo_local_bundle_adjustment: observations must be sorted by map point, key frame and camera "
+                    "indices in range, distorted observations monocular");
+          return VIEO_E_INVALID;
+        }
         so[i] = ob[i];
-        so[i].kf = ob[i].kf & 0xFFFFFF;
-        hs[o.ocam + i] = (uint8_t)((ob[i].kf >> 24) & 15);
+        so[i].kf = kfi;
+        hs[o.ocam + i] = (uint8_t)ci;
       }
       ob = so;
     }
@@ -1901,71 +2197,28 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     double* X = (double*)(hs + o.X);
     for (int i = 0; i < H.n_mp * 3; i++) X[i] = (double)h_points[w][i];
     memset(hs + o.erase, 0, H.n_obs);
-    // scratch
-    Scr& s = scr[w];
-    const int npm = 6 * nf;
-    s.kf_bak = take((size_t)H.n_kf * sizeof(LbaKf)), s.X_bak = take((size_t)H.n_mp * 24);
-    s.mp_act = take(H.n_mp);
-    const int ldB = (H.n_mp + kChunkLm - 1) / kChunkLm * (3 * kChunkLm);
-    const int sp_rows = (npm + 63) / 64 * 64, ldS = (npm + 64) / 64 * 64;
-    s.BB = take((size_t)npm * ldB * 8);
-    s.Sp = take((size_t)ksplit * sp_rows * ldS * 8);
-    s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
-    const int npf = pd * nf;  // full reduced system
-    s.Hpp = take((size_t)nf * 36 * 8), s.Hs = take((size_t)npf * npf * 8);
-    s.nb = (npf + 1 + kNB - 1) / kNB * kNB;  // + the right-hand-side row
-    s.Hb = s.Wp = s.big_fail = 0;
-    if (big_solve(pd * nf)) {
-      s.Hb = take((size_t)s.nb * s.nb * 8), s.Wp = take((size_t)s.nb * kNB * 8), s.big_fail = take(256);
-    }
-    s.bp = take((size_t)npm * 8), s.bs = take((size_t)npf * 8), s.xp = take((size_t)npf * 8);
-    s.bfull = take((size_t)npf * 8);
-    s.Ae = take((size_t)std::max(H.n_imu, 1) * 930 * 8);
-    s.gchi0 = take((size_t)std::max(H.n_imu, 1) * 8), s.gchi = take((size_t)std::max(H.n_imu, 1) * 8);
-    s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
-    s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
-    s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)nf * H.n_mp * 4);
-    s.kf_act = take((size_t)H.n_kf * 4);
-    s.occ = take((size_t)((npm + 64) / 64) * ((H.n_mp + kChunkLm - 1) / kChunkLm));
-    LbaDev& D = devs[w];
-    memset(&D, 0, sizeof(D));
-    D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.nf_cap = nf;
-    D.ldB = ldB, D.ldS = ldS, D.sp_stride = (size_t)sp_rows * ldS;
-    D.cam.fx = H.P->fx, D.cam.fy = H.P->fy, D.cam.cx = H.P->cx, D.cam.cy = H.P->cy, D.cam.bf = H.P->bf;
-    memcpy(D.cam.Rcb, H.P->Rcb, 72);
-    memcpy(D.cam.tcb, H.P->tcb, 24);
-    D.n_cams = H.P->n_cams;
-    any_multicam |= H.P->n_cams > 0;
-    for (int ci = 0; ci < H.P->n_cams; ci++) {
-      const vieo_camera& c = H.P->cams[ci];
-      CamD& d = D.cams[ci];
-      d.fx = c.fx, d.fy = c.fy, d.cx = c.cx, d.cy = c.cy, d.bf = 0;
-      memcpy(d.Rcb, c.Rcb, 72), memcpy(d.tcb, c.tcb, 24);
-      d.model = c.model, d.num_k = c.model == VIEO_CAM_RADTAN ? c.num_k : 0;
-      if (c.model < 0 || c.model > 2 || (c.model == VIEO_CAM_RADTAN && (c.num_k < 2 || c.num_k > 6))) {
-        set_error("local BA: camera %d has an unknown model or coefficient count", ci);
-        return VIEO_E_INVALID;
-      }
-      for (int q = 0; q < 8; q++) d.k[q] = (double)c.dist[q];
-    }
-    // thHuberMono = sqrt(5.991) in the local BAs, thHuber2D = sqrt(5.99) in the global ones (Optimizer.cc:1063,1445)
-    D.dMono = (double)(float)sqrt(gba ? 5.99 : 5.991), D.dStereo = (double)(float)sqrt(7.815);
-    D.pd = pd, D.n_imu = H.n_imu;
-    if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
-      D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
-      memcpy(D.gw, H.VP->gw, 24);
-      memcpy(D.qRbe, H.VP->qRbe, 32), memcpy(D.pbe, H.VP->pbe, 24);
-      D.th_dist_far = (!gba && H.VP->th_dist_far > 0 && std::isfinite(H.VP->th_dist_far)) ? (double)H.VP->th_dist_far : 0.0;
-      H.prelevel_pending = !gba;
+    return VIEO_OK;
+  };
+  {
+    std::vector<int> live;
+    for (int w = 0; w < W; w++)
+      if (!win[w].skip) live.push_back(w);
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = std::max(1, std::min(std::min(8, hw > 0 ? hw : 1), (int)live.size() / 8));
+    std::vector<int> rcs(live.size(), VIEO_OK);
+    if (nt <= 1) {
+      for (size_t i = 0; i < live.size(); i++)
+        if ((rcs[i] = fill_window(live[i])) != VIEO_OK) return rcs[i];
     } else {
-      D.thMono = D.thMonoClose = 5.991, D.thStereo = 7.815;
-      if (H.ENC) memcpy(D.qRbe, H.ENC->qRbe, 32), memcpy(D.pbe, H.ENC->pbe, 24);
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+          for (size_t i = t; i < live.size(); i += nt) rcs[i] = fill_window(live[i]);
+        });
+      for (auto& x : th) x.join();
+      for (size_t i = 0; i < live.size(); i++)
+        if (rcs[i] != VIEO_OK) return fill_window(live[i]);  // again on this thread: the error text is thread-local
     }
-    max_imu = std::max(max_imu, H.n_imu);
-    max_obs = std::max(max_obs, H.n_obs), max_mp = std::max(max_mp, H.n_mp);
-    max_kf = std::max(max_kf, H.n_kf), max_nf = std::max(max_nf, nf);
-    H.iters = gba ? gba->iterations : H.P->its0;
-    H.phase = H.iters > 0 ? 0 : 2;
   }
   const size_t small_bytes = (size_t)W * (sizeof(LbaDev) + sizeof(WinCtl) + sizeof(WinOut));
   if ((rc = g_arena.ensure(arena)) != VIEO_OK) return rc;
@@ -2033,6 +2286,11 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   const size_t ldlt_lds = ldlt_small + (use_lds ? tri : 0);
   const void* ldlt_fn = vio ? (const void*)k_lba_ldlt<5> : (const void*)k_lba_ldlt<6>;
   VIEO_HIP_CHECK(hipFuncSetAttribute(ldlt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
+  const int nb16 = (n_max + 16) >> 4;
+  const bool ldlt16 = !big && nb16 <= kLd16MaxBlocks && !ldlt16_disabled();
+  if (ldlt16)
+    VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldlt16<kLd16Threads>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)ld16_lds_bytes(nb16)));
   // (at least one workgroup each: an empty landmark shard still launches everything)
   const int ge = std::max(1, (max_obs + 255) / 256), gm = std::max(1, (max_mp + 255) / 256), gq = std::max(1, (max_mp + 63) / 64);
   const int gr = std::max(gm, (max_kf + 255) / 256);
@@ -2116,7 +2374,9 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         for (int sb = 0; sb < (n_max + kNB - 1) / kNB; sb++)
           hipLaunchKernelGGL(k_big_back_step, dim3(1 + (n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, sb);
         hipLaunchKernelGGL(k_big_finish, dim3(W), dim3(256), 0, st, dD, dC, dO);
-      } else if (vio)
+      } else if (ldlt16)
+        hipLaunchKernelGGL(k_lba_ldlt16<kLd16Threads>, dim3(W), dim3(kLd16Threads), ld16_lds_bytes(nb16), st, dD, dC, dO, nb16);
+      else if (vio)
         hipLaunchKernelGGL(k_lba_ldlt<5>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
       else
         hipLaunchKernelGGL(k_lba_ldlt<6>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
