@@ -71,11 +71,26 @@ def algorithmic_bytes_per_image():
     }
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (dense) peak, v_mfma_f64_16x16x4_f64
+
+
+def _latest_profile(suffix):
+    """Newest committed profiles/r<N>*<suffix> (the PMC passes are separate rocprofv3 runs, MI355X_MICROARCH.md)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix)):
+        m = re.match(r"r(\d+)", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) >= best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 def pmc_traffic(kernel, n_img):
-    """HBM bytes per launch of the kernel from the committed PMC passes (profiles/r1_pmc_extractor.json:
+    """HBM bytes per launch of the kernel from the committed PMC passes (profiles/r*_pmc_extractor.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same launch shape, gfx950 correction
     FETCH x 2), scaled to this run's images per launch; None if the file is not there."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_extractor.json")
+    path = _latest_profile("_pmc_extractor.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -83,6 +98,18 @@ def pmc_traffic(kernel, n_img):
         per_img = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0 * k.get("launches", 1) / d["images_per_launch"]
         return per_img * n_img
     except (OSError, KeyError, ValueError):
+        return None
+
+
+def mfma_busy():
+    """SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES of k_lba_schur from the committed counter pass
+    (profiles/r*_pmc_lba_schur.json, collected by tools/pmc_lba_schur.sh in its own rocprofv3 --pmc run); None if
+    absent."""
+    path = _latest_profile("_pmc_lba_schur.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, TypeError, ValueError):
         return None
 
 
@@ -344,6 +371,7 @@ def main():
     lba_ms.clear()
     P.enable_timing(True)
     P.ext.enable_timing(True)
+    Optimizer.enable_kernel_timing(True)
     sync_all()
     t0 = time.perf_counter()
     futs = []
@@ -363,10 +391,27 @@ def main():
         avg = {k: float(np.mean([s[k] for s in stage])) for k in P.STAGES}
         oavg = {k: float(np.mean([s[k] for s in orb])) for k in ORB_STAGES}
         ab = algorithmic_bytes_per_image()
+        # every kernel (class) of the path, ms per step: the extractor's kernels and the front-end stages from the
+        # events of stream 0, the bundle-adjustment kernels from the engine's own events on its streams
+        lba_k, schur_flops = Optimizer.kernel_times()
         kern = {("orb." + k): v for k, v in oavg.items() if k != "total"}
+        kern.update({("frontend." + k): v for k, v in avg.items() if k not in ("extract", "total")})
+        kern.update({k: v["ms"] / a.steps for k, v in lba_k.items()})
         dom = max(kern, key=kern.get)
-        dk = dom.split(".")[1]
-        achieved = ab[dk] * n_img / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
+        launches = lba_k[dom]["launches"] / a.steps if dom in lba_k else 1
+        # algorithmic bytes per launch of the kernels that are HBM-bound by design
+        nfree, nmp_w, nobs_w = 10, np.mean([len(p[2]) for p in lba_problems]) if lba_problems else 0, \
+            np.mean([len(p[4]) for p in lba_problems]) if lba_problems else 0
+        lba_ab = {"lba.build": n_lba * (6 * nfree * 3 * nmp_w * 8 + 40 * nobs_w + 96 * nmp_w)}  # dense BB + edges + H_ll, b_l
+        if dom.startswith("orb."):
+            dk = dom.split(".")[1]
+            alg_bytes = ab[dk] * n_img
+        else:
+            dk, alg_bytes = None, lba_ab.get(dom)
+        launch_ms = kern[dom] / launches if launches else 0.0
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if (alg_bytes and launch_ms > 0) else None
+        sch = lba_k.get("lba.schur", {"ms": 0.0, "launches": 0})
+        sch_tf = schur_flops / (sch["ms"] * 1e-3) / 1e12 if sch["ms"] > 0 else None
         r2 = res["r2"]
         perr = [np.linalg.norm(r2[b]["base"]["nav"]["p"] - P.truth[b]["p"]) for b in range(P.B)]
         from vieo_slam_amd import trajectory  # the metric's "ATE vs ref": Horn-aligned RMSE of the step's frame positions
@@ -403,10 +448,23 @@ def main():
             },
             "stage_ms_per_step_stream0": avg,
             "extractor_kernel_ms_per_step_stream0": oavg,
+            "kernel_ms_per_step_all": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dk, n_img),
-                         "algorithmic_bytes_per_launch": ab[dk] * n_img,
-                         "avg_launch_ms": kern[dom]},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                         "traffic": pmc_traffic(dk, n_img) if dk else None,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": launch_ms,
+                         "chosen_over": "all kernels of the path: extractor kernels, front-end stages (1-3 kernels each) "
+                                        "and bundle-adjustment kernel classes, by ms per step"},
+            # the one dense contraction of the path: the Schur complement of the local BA on the FP64 matrix cores
+            "roofline_mfma": {"bound": "mfma", "kernel": "lba.schur (k_lba_schur, v_mfma_f64_16x16x4_f64)",
+                              "achieved": sch_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": sch_tf / FP64_MFMA_PEAK_TFLOPS if sch_tf else None,
+                              "flops_per_launch": schur_flops / sch["launches"] if sch["launches"] else None,
+                              "flops": "dense 2 np (np + 1) 3 n_mp per window and LM trial (np = 6 x free key frames)",
+                              "avg_launch_ms": sch["ms"] / sch["launches"] if sch["launches"] else None,
+                              "launches_per_step": sch["launches"] / a.steps,
+                              "mfma_busy": mfma_busy()},
         }
         if world == 1 and not a.no_pcie_leg:
             out["pcie_inclusive"] = pcie_leg(P, max(3, min(a.steps, 10)), 2)

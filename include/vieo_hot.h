@@ -720,6 +720,15 @@ int vieo_rccl_unique_id(uint8_t* id128);
 int vieo_rccl_comm_create(void** comm, const uint8_t* id128, int n_ranks, int rank);
 int vieo_rccl_comm_destroy(void* comm);
 size_t vieo_lba_sharded_buffer_doubles(int n_windows, const int* n_free_kf);
+
+/* Measurement hook of the bundle-adjustment engine (no reference counterpart): with timing on, every kernel launch
+ * of the local / full BA entries is bracketed by HIP events on the engine's own stream and folded into process-wide
+ * totals per kernel class (vieo_lba_kernel_class_name: "lba.build", "lba.schur", ...).  enable(on) also clears the
+ * totals.  schur_flops: dense FLOPs 2 np (np + 1) 3 n_mp of the windows the timed k_lba_schur launches worked on. */
+void vieo_lba_enable_timing(int on);
+int vieo_lba_kernel_classes(void);
+const char* vieo_lba_kernel_class_name(int i);
+void vieo_lba_kernel_times(double* ms /*[classes]*/, long long* launches /*[classes]*/, double* schur_flops);
 int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_params* const* params,
                                              const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
                                              const float* const* h_points, const uint8_t* const* h_close,

@@ -26,7 +26,9 @@
 //   k_lba_restore / k_lba_classify  rejected-step rollback; chi2 / depth gates
 // The Levenberg-Marquardt policy (lambda, accept / reject, termination, stop flag) runs on the host
 // exactly as g2o's does, from one 56-byte record per window and round.
+#include <atomic>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -1745,6 +1747,61 @@ static size_t shard_sys_doubles(int nf) { return (size_t)6 * nf * (6 * nf + 1) +
 
 // reduced systems beyond one workgroup's LDL^T take the tiled solve (VIEO_LBA_BIG_SOLVE=1 forces it: tests)
 static const int kSmallSolveMax = 510, kBigSolveMax = 16320;
+// ---- optional kernel-class timing (vieo_lba_enable_timing): HIP events around every launch on the BA stream, folded
+// into process-wide totals after each round's synchronisation.  bench.py reads them for the roofline of the whole path.
+enum LbaKClass { KC_BUILD, KC_GENERIC, KC_SCHUR, KC_ASSEMBLE, KC_LDLT, KC_UPDATE, KC_ERROR, KC_BEGIN, KC_OTHER, KC_N };
+static const char* const kLbaKClassName[KC_N] = {"lba.build", "lba.generic", "lba.schur", "lba.assemble", "lba.ldlt",
+                                                 "lba.update_points", "lba.error", "lba.begin", "lba.other"};
+static std::atomic<int> g_lba_ktiming{0};
+static std::mutex g_lba_kt_mutex;
+static double g_lba_kt_ms[KC_N];
+static long long g_lba_kt_launches[KC_N];
+static double g_lba_kt_schur_flops;  // dense FLOPs of the timed k_lba_schur launches
+
+struct LbaKTimer {
+  bool on = false;
+  hipStream_t st = nullptr;
+  std::vector<hipEvent_t> pool;
+  std::vector<int> cls;  // class of pair i (events 2i, 2i + 1)
+  void begin(hipStream_t s) {
+    on = g_lba_ktiming.load() != 0;
+    st = s;
+    cls.clear();
+  }
+  template <class F>
+  void launch(int c, F&& f) {
+    if (!on) {
+      f();
+      return;
+    }
+    const size_t i = cls.size();
+    while (pool.size() < 2 * (i + 1)) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) {
+        on = false;
+        f();
+        return;
+      }
+      pool.push_back(e);
+    }
+    (void)hipEventRecord(pool[2 * i], st);
+    f();
+    (void)hipEventRecord(pool[2 * i + 1], st);
+    cls.push_back(c);
+  }
+  void fold(double schur_flops_per_launch) {  // after the stream was synchronised
+    if (!on || cls.empty()) return;
+    std::lock_guard<std::mutex> g(g_lba_kt_mutex);
+    for (size_t i = 0; i < cls.size(); i++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pool[2 * i], pool[2 * i + 1]) != hipSuccess) continue;
+      g_lba_kt_ms[cls[i]] += ms, g_lba_kt_launches[cls[i]]++;
+      if (cls[i] == KC_SCHUR) g_lba_kt_schur_flops += schur_flops_per_launch;
+    }
+    cls.clear();
+  }
+};
+
 static bool ldlt16_disabled() {  // VIEO_LBA_LDLT16=0: the column-panel kernel instead (A/B runs)
   static const int off = [] {
     const char* e = getenv("VIEO_LBA_LDLT16");
@@ -1859,10 +1916,13 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     g_lba_stream_dev = cur;
   }
   if (!g_lba_stream) {
-    // VIEO_LBA_PRIORITY = -1 / 1: lowest / highest stream priority for the bundle-adjustment stream (default 0)
+    // VIEO_LBA_PRIORITY = -1 / 0 / 1: lowest / default / highest stream priority for the bundle-adjustment stream.
+    // Highest by default: its kernels are short (<= 0.3 ms for 205 windows) and many; next to a batched front end
+    // on another stream they otherwise wait behind thousands of queued workgroups per launch (k_lba_build 2.8 ms
+    // instead of 0.9 per launch in the bench step, same frames/s either way).
     int lo = 0, hi = 0;
     const char* e = getenv("VIEO_LBA_PRIORITY");
-    const int want = e ? atoi(e) : 0;
+    const int want = e ? atoi(e) : 1;
     if (want == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi)
       VIEO_HIP_CHECK(hipStreamCreateWithFlags(&g_lba_stream, hipStreamNonBlocking));
     else
@@ -2300,6 +2360,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   const auto t_rounds = std::chrono::steady_clock::now();
   int n_rounds = 0;
   double ms_wait = 0;
+  static thread_local LbaKTimer KT;
+  KT.begin(st);
+  // dense count 2 np (np + 1) 3 n_mp of the visual part of a window's Schur complement
+  auto schur_flops_of = [&](int w) {
+    return win[w].skip ? 0.0 : 2.0 * (6 * devs[w].nf_cap) * (6 * devs[w].nf_cap + 1) * 3.0 * devs[w].n_mp;
+  };
   for (;;) {
     n_rounds++;
     const bool stop_now = stop && *stop;
@@ -2335,55 +2401,55 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     }
     if (!any) break;
     VIEO_HIP_CHECK(hipMemcpyAsync(dC, ctl, (size_t)W * sizeof(WinCtl), hipMemcpyHostToDevice, st));
-    if (any & LBA_RESTORE) hipLaunchKernelGGL(k_lba_restore, dim3(gr, W), dim3(256), 0, st, dD, dC);
-    if (any & (LBA_CLASS0 | LBA_CLASS1)) hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC);
+    if (any & LBA_RESTORE) KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_restore, dim3(gr, W), dim3(256), 0, st, dD, dC); });
+    if (any & (LBA_CLASS0 | LBA_CLASS1)) KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC); });
     if (any & LBA_PRELEVEL)
-      for (int ph = 0; ph < 3; ph++) hipLaunchKernelGGL(k_lba_prelevel, dim3(ge, W), dim3(256), 0, st, dD, dC, ph);
+      for (int ph = 0; ph < 3; ph++) KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_prelevel, dim3(ge, W), dim3(256), 0, st, dD, dC, ph); });
     if (any & LBA_BEGIN) {
-      hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC);
-      hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO);
-      hipLaunchKernelGGL(k_lba_occ, dim3(std::max(1, (occ_max + 255) / 256), W), dim3(256), 0, st, dD, dC);
-      hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0);
+      KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC); });
+      KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO); });
+      KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_occ, dim3(std::max(1, (occ_max + 255) / 256), W), dim3(256), 0, st, dD, dC); });
+      KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0); });
     }
     if (any & LBA_BUILD) {
       if (any_multicam)
-        hipLaunchKernelGGL(k_lba_build<true>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq);
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL(k_lba_build<true>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
       else
-        hipLaunchKernelGGL(k_lba_build<false>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq);
-      if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0);
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL(k_lba_build<false>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
+      if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0); });
     }
-    if (any & LBA_BEGIN) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);
+    if (any & LBA_BEGIN) KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO); });
     if (any & LBA_TRIAL) {
-      hipLaunchKernelGGL(k_lba_schur, dim3(nbt_max * ksplit, W), dim3(256), 0, st, dD, dC, dO, ksplit);
+      KT.launch(KC_SCHUR, [&] { hipLaunchKernelGGL(k_lba_schur, dim3(nbt_max * ksplit, W), dim3(256), 0, st, dD, dC, dO, ksplit); });
       if (sh) {  // the one exchange step of the path: sum the reduced visual system over the ranks
         const int nv = 6 * max_nf;
-        hipLaunchKernelGGL(k_lba_pack, dim3((nv * (nv + 1) + 36 * max_nf + nv + 255) / 256, W), dim3(256), 0, st,
-                           dD, dC, ksplit);
+        KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_pack, dim3((nv * (nv + 1) + 36 * max_nf + nv + 255) / 256, W), dim3(256), 0, st,
+                           dD, dC, ksplit); });
         if ((rc = shard_exchange(sh, sh->d_buf, shard_sys, st)) != VIEO_OK) return rc;
       }
-      hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO,
-                         ksplit);
+      KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO,
+                         ksplit); });
       if (big) {
         const int nbm = (n_max + 1 + kNB - 1) / kNB * kNB, ntm = nbm / kNB;
-        hipLaunchKernelGGL(k_big_init, dim3((unsigned)(((size_t)nbm * nbm + 255) / 256), W), dim3(256), 0, st, dD, dC);
+        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_init, dim3((unsigned)(((size_t)nbm * nbm + 255) / 256), W), dim3(256), 0, st, dD, dC); });
         for (int k = 0; k < ntm; k++) {
           const int below = nbm - (k + 1) * kNB, m = ntm - k - 1;
-          hipLaunchKernelGGL(k_big_panel, dim3(1 + (below + 255) / 256, W), dim3(256), 0, st, dD, dC, k);
-          if (m > 0) hipLaunchKernelGGL(k_big_syrk, dim3(m * (m + 1) / 2, W), dim3(256), 0, st, dD, dC, k);
+          KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_panel, dim3(1 + (below + 255) / 256, W), dim3(256), 0, st, dD, dC, k); });
+          if (m > 0) KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_syrk, dim3(m * (m + 1) / 2, W), dim3(256), 0, st, dD, dC, k); });
         }
         for (int sb = 0; sb < (n_max + kNB - 1) / kNB; sb++)
-          hipLaunchKernelGGL(k_big_back_step, dim3(1 + (n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, sb);
-        hipLaunchKernelGGL(k_big_finish, dim3(W), dim3(256), 0, st, dD, dC, dO);
+          KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_back_step, dim3(1 + (n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, sb); });
+        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_finish, dim3(W), dim3(256), 0, st, dD, dC, dO); });
       } else if (ldlt16)
-        hipLaunchKernelGGL(k_lba_ldlt16<kLd16Threads>, dim3(W), dim3(kLd16Threads), ld16_lds_bytes(nb16), st, dD, dC, dO, nb16);
+        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt16<kLd16Threads>, dim3(W), dim3(kLd16Threads), ld16_lds_bytes(nb16), st, dD, dC, dO, nb16); });
       else if (vio)
-        hipLaunchKernelGGL(k_lba_ldlt<5>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
+        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt<5>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max); });
       else
-        hipLaunchKernelGGL(k_lba_ldlt<6>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max);
-      hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO);
-      hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
-      if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
-      hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
+        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt<6>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max); });
+      KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO); });
+      KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1); });
+      if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1); });
+      KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO); });
       if (sh) {  // chi2 and the landmark part of the gain-ratio scale
         if ((rc = shard_exchange(sh, sh->d_buf + shard_sys, 4 * (size_t)W, st)) != VIEO_OK) return rc;
         VIEO_HIP_CHECK(hipMemcpyAsync(h_sc, sh->d_buf + shard_sys, 32 * (size_t)W, hipMemcpyDeviceToHost, st));
@@ -2395,6 +2461,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       const auto t_w = std::chrono::steady_clock::now();
       VIEO_HIP_CHECK(hipStreamSynchronize(st));
       ms_wait += ms_since(t_w);
+    }
+    if (KT.on) {
+      double fl = 0;  // the windows this round's k_lba_schur launch worked on
+      for (int w = 0; w < W; w++)
+        if (ctl[w].flags & LBA_TRIAL) fl += schur_flops_of(w);
+      KT.fold(fl);
     }
     // ---- per-window policy (optimization_algorithm_levenberg.cpp:61-164)
     for (int w = 0; w < W; w++) {
@@ -2649,4 +2721,19 @@ int vieo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_i
                  &n_imu, stop, &h_navs_out, &h_points_out, &er, h_result);
 }
 
+
+// Kernel-class timing of the bundle-adjustment engine (bench.py's roofline over the whole path).
+void vieo_lba_enable_timing(int on) {
+  std::lock_guard<std::mutex> g(vieo::g_lba_kt_mutex);
+  vieo::g_lba_ktiming.store(on ? 1 : 0);
+  for (int i = 0; i < vieo::KC_N; i++) vieo::g_lba_kt_ms[i] = 0, vieo::g_lba_kt_launches[i] = 0;
+  vieo::g_lba_kt_schur_flops = 0;
+}
+int vieo_lba_kernel_classes(void) { return vieo::KC_N; }
+const char* vieo_lba_kernel_class_name(int i) { return i >= 0 && i < vieo::KC_N ? vieo::kLbaKClassName[i] : ""; }
+void vieo_lba_kernel_times(double* ms, long long* launches, double* schur_flops) {
+  std::lock_guard<std::mutex> g(vieo::g_lba_kt_mutex);
+  for (int i = 0; i < vieo::KC_N; i++) ms[i] = vieo::g_lba_kt_ms[i], launches[i] = vieo::g_lba_kt_launches[i];
+  *schur_flops = vieo::g_lba_kt_schur_flops;
+}
 }  // extern "C"

@@ -141,6 +141,22 @@ class Optimizer:
         return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
 
     @staticmethod
+    def enable_kernel_timing(on=True):
+        """HIP-event timing of every bundle-adjustment kernel launch, per kernel class (vieo_lba_enable_timing);
+        also clears the totals."""
+        lib().vieo_lba_enable_timing(1 if on else 0)
+
+    @staticmethod
+    def kernel_times():
+        """({class: {"ms": total, "launches": n}}, dense FLOPs of the timed k_lba_schur launches) since
+        enable_kernel_timing()."""
+        n = lib().vieo_lba_kernel_classes()
+        ms, cnt, fl = np.zeros(n), np.zeros(n, np.int64), np.zeros(1)
+        lib().vieo_lba_kernel_times(ms.ctypes.data, cnt.ctypes.data, fl.ctypes.data)
+        names = [lib().vieo_lba_kernel_class_name(i).decode() for i in range(n)]
+        return {k: {"ms": float(ms[i]), "launches": int(cnt[i])} for i, k in enumerate(names)}, float(fl[0])
+
+    @staticmethod
     def sharded_buffer_doubles(windows):
         """Doubles the reduction buffer of LocalBundleAdjustmentNavStatePRVSharded needs."""
         nf = np.array([int((np.asarray(w[1]["fixed"]) == 0).sum()) for w in windows], np.int32)
