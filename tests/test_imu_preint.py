@@ -136,3 +136,27 @@ def test_preintegration_parity(oracle):
             a, b = np.nan_to_num(a), np.nan_to_num(b)
             scale = np.abs(a).max(1, keepdims=True) + 1e-300
             assert (np.abs(a - b) / scale).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_wave_and_lane_instantiations_agree_bitwise():
+    """A call with fewer than 1024 intervals gives every interval a wavefront (the 9 x 9 products spread over the lanes),
+    a larger one a lane: every entry is summed by one lane in the same order, so the two must agree bit for bit."""
+    from vieo_slam_amd.imu import imu_preintegrate
+    rng = np.random.default_rng(11)
+    lists, ti, tj = [], [], []
+    for k in range(1100):
+        n = int(rng.integers(2, 120))
+        s = _samples(rng, 50.0 + k, n, jitter=0.001)
+        lists.append(s)
+        ti.append(s["t"][0] + rng.uniform(-0.004, 0.012))
+        tj.append(s["t"][-1] + rng.uniform(-0.012, 0.004))
+        if k % 4 == 3:
+            ti[-1], tj[-1] = tj[-1], ti[-1]
+    bg, ba = rng.normal(0, 0.01, (1100, 3)), rng.normal(0, 0.05, (1100, 3))
+    for fixed in (1, 0):
+        big, bigp, bigs = imu_preintegrate(_noise(fixed), lists, ti, tj, bg, ba)               # lane per interval
+        sm, smp, sms = imu_preintegrate(_noise(fixed), lists[:40], ti[:40], tj[:40], bg[:40], ba[:40])  # wavefront each
+        assert np.array_equal(bigs[:40], sms)
+        assert big[:40].tobytes() == sm.tobytes()
+        assert np.asarray(bigp)[:40].tobytes() == np.asarray(smp).tobytes()

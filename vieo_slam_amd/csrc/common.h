@@ -58,6 +58,21 @@ struct DevBuf {
   }
 };
 
+// pinned host staging (grows by half again, never shrinks): one H2D / D2H per call instead of one per array
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return VIEO_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+    bytes += bytes / 2;
+    VIEO_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
+    return VIEO_OK;
+  }
+};
+
 int require_device();  // VIEO_OK or VIEO_E_NO_DEVICE
 // which pose-optimisation kernels a *_batch_device call launches: bit 0 the rectified-pinhole instance,
 // bit 1 the multi-camera-rig instance (vieo_pose_set_camera_mode)

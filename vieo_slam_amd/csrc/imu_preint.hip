@@ -3,13 +3,80 @@
 // samples (the recursion over samples is sequential; the batch is the parallel axis), FP64 throughout.  The
 // 9 x 9 covariance recursions exploit nothing: A Sigma A^T is formed densely in the lane's private arrays -- a few
 // thousand flops per sample, the input producer of the pose optimisations, not a throughput kernel.
+// A single interval (the sequential replay: one call per frame) is latency, not throughput: for fewer intervals than
+// kWaveBelow the WAVE instantiation gives each interval a wavefront, keeps the two covariances in LDS and spreads
+// the 81 entries of every 9 x 9 product over the lanes -- every entry still summed by one lane in the scalar
+// version's order, so the result is bit-identical (2.1 -> 0.4 ms per call of ~100 samples).
+#include <cstring>
 #include "imu_device.h"
 
 namespace vieo {
 
 struct PreIntD {
-  double R[9], v[3], p[3], JgR[9], Jgv[9], Jav[9], Jgp[9], Jap[9], S[81], Sprv[81], dt;
+  double R[9], v[3], p[3], JgR[9], Jgv[9], Jav[9], Jgp[9], Jap[9], dt;
+  double *S, *Sprv;  // 9 x 9 covariances: the lane's private arrays, or the wavefront's LDS (WAVE)
+  double* lds;       // WAVE: A[81] | T[81] | Bg[27] | Ba[27] | TB[27]
+  int lane;
 };
+
+__device__ __forceinline__ void preint_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the covariance step of one pass on a wavefront: entries e = lane, lane + 64 of every 9 x 9 result
+__device__ void preint_cov_wave(PreIntD& P, double* S, int iR, int iV, const double* dRt, const double* Rsk,
+                                const double* Jr, const double* Ng, const double* Na, double dt, double dt2div2) {
+  double* A = P.lds;
+  double* T = A + 81;
+  double* Bg = T + 81;
+  double* Ba = Bg + 27;
+  double* TB = Ba + 27;
+  const int lane = P.lane;
+  for (int e = lane; e < 81; e += 64) A[e] = (e % 10) == 0 ? 1.0 : 0.0;
+  if (lane < 27) Bg[lane] = 0, Ba[lane] = 0;
+  preint_wave_sync();
+  if (lane < 9) {
+    const int i = lane / 3, j = lane - 3 * i;
+    A[(iR + i) * 9 + iR + j] = dRt[lane] * 1.0;
+    A[(iV + i) * 9 + iR + j] = Rsk[lane] * -dt;
+    A[i * 9 + iR + j] = Rsk[lane] * -dt2div2;
+    A[i * 9 + iV + j] = (i == j ? 1.0 : 0.0) * dt;
+    Bg[(iR + i) * 3 + j] = Jr[lane] * dt;
+    Ba[(iV + i) * 3 + j] = P.R[lane] * dt;
+    Ba[i * 3 + j] = P.R[lane] * dt2div2;
+  }
+  preint_wave_sync();
+  for (int e = lane; e < 81; e += 64) {
+    const int i = e / 9, j = e - 9 * i;
+    double s = 0;
+    for (int k = 0; k < 9; k++) s += A[i * 9 + k] * S[k * 9 + j];
+    T[e] = s;
+  }
+  preint_wave_sync();
+  for (int e = lane; e < 81; e += 64) {
+    const int i = e / 9, j = e - 9 * i;
+    double s = 0;
+    for (int k = 0; k < 9; k++) s += T[i * 9 + k] * A[j * 9 + k];
+    S[e] = s;
+  }
+  preint_wave_sync();
+  for (int which = 0; which < 2; which++) {  // S += Bg Ng Bg^T, then S += Ba Na Ba^T
+    const double* B = which ? Ba : Bg;
+    const double* N = which ? Na : Ng;
+    if (lane < 27) {
+      const int i = lane / 3, j = lane - 3 * i;
+      TB[lane] = B[i * 3] * N[j] + B[i * 3 + 1] * N[3 + j] + B[i * 3 + 2] * N[6 + j];
+    }
+    preint_wave_sync();
+    for (int e = lane; e < 81; e += 64) {
+      const int i = e / 9, j = e - 9 * i;
+      S[e] += TB[i * 3] * B[j * 3] + TB[i * 3 + 1] * B[j * 3 + 1] + TB[i * 3 + 2] * B[j * 3 + 2];
+    }
+    preint_wave_sync();
+  }
+}
 
 __device__ void preint_sandwich(const double* A, double* S) {  // S <- A S A^T
   double T[81];
@@ -39,7 +106,11 @@ __device__ __forceinline__ void preint_block(double* M, int ld, int r0, int c0, 
 }
 
 // IMUPreIntegratorBase::update (OdomPreIntegrator.h:430-506)
-__device__ void preint_update(PreIntD& P, const vieo_imu_noise& N, const double* omega, const double* acc, double dt) {
+// (noinline: three inlined copies per kernel made the lane-per-interval instantiation drop the partial first step of
+// some intervals -- caught by tests/test_imu_preint.py::test_wave_and_lane_instantiations_agree_bitwise; the
+// out-of-line call is what round 1 shipped and what the parity test pins)
+template <bool WAVE>
+__device__ __attribute__((noinline)) void preint_update(PreIntD& P, const vieo_imu_noise& N, const double* omega, const double* acc, double dt) {
   const double dt2div2 = dt * dt / 2;
   const double wdt[3] = {omega[0] * dt, omega[1] * dt, omega[2] * dt};
   double dR[9], Jr[9], skewa[9], dRt[9], Rsk[9];
@@ -61,6 +132,10 @@ __device__ void preint_update(PreIntD& P, const vieo_imu_noise& N, const double*
   const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   for (int pass = 0; pass < 2; pass++) {  // mSigmaijPRV (p, Phi, v), then mSigmaij (p, v, Phi)
     const int iR = pass == 0 ? 3 : 6, iV = pass == 0 ? 6 : 3;
+    if (WAVE) {
+      preint_cov_wave(P, pass == 0 ? P.Sprv : P.S, iR, iV, dRt, Rsk, Jr, Ng, Na, dt, dt2div2);
+      continue;
+    }
     double A[81], Bg[27], Ba[27];
     for (int i = 0; i < 81; i++) A[i] = (i % 10) == 0 ? 1.0 : 0.0;
     for (int i = 0; i < 27; i++) Bg[i] = 0, Ba[i] = 0;
@@ -99,22 +174,31 @@ __device__ void preint_update(PreIntD& P, const vieo_imu_noise& N, const double*
   P.dt += dt;
 }
 
+template <bool WAVE>
 __global__ void __launch_bounds__(64)
 k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __restrict__ samples,
              const int32_t* __restrict__ first, const double* __restrict__ ti_, const double* __restrict__ tj_,
              const double* __restrict__ bg_, const double* __restrict__ ba_, int n, vieo_imu_preint* __restrict__ out,
              double* __restrict__ sigma_prv, int32_t* __restrict__ status) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
+  const int k = WAVE ? blockIdx.x : blockIdx.x * 64 + threadIdx.x;
   if (k >= n) return;
+  __shared__ double s_cov[WAVE ? 2 * 81 + 81 + 81 + 27 * 3 : 1];
+  double S_priv[WAVE ? 1 : 81], Sprv_priv[WAVE ? 1 : 81];
   const vieo_imu_noise N = *noise;
   const vieo_imu_sample* L = samples + first[k];
   const int K = first[k + 1] - first[k];
   const double ti = ti_[k], tj = tj_[k];
   const double bg[3] = {bg_[3 * k], bg_[3 * k + 1], bg_[3 * k + 2]}, ba[3] = {ba_[3 * k], ba_[3 * k + 1], ba_[3 * k + 2]};
   PreIntD P;
+  P.lane = threadIdx.x;
+  P.S = WAVE ? s_cov : S_priv, P.Sprv = WAVE ? s_cov + 81 : Sprv_priv, P.lds = s_cov + 162;
   for (int i = 0; i < 9; i++) P.R[i] = (i % 4) == 0 ? 1.0 : 0.0, P.JgR[i] = P.Jgv[i] = P.Jav[i] = P.Jgp[i] = P.Jap[i] = 0;
   for (int i = 0; i < 3; i++) P.v[i] = P.p[i] = 0;
-  for (int i = 0; i < 81; i++) P.S[i] = P.Sprv[i] = 0;
+  if (WAVE) {
+    for (int i = threadIdx.x; i < 162; i += 64) s_cov[i] = 0;
+    preint_wave_sync();
+  } else
+    for (int i = 0; i < 81; i++) P.S[i] = P.Sprv[i] = 0;
   P.dt = 0;
   int st = VIEO_PREINT_OK;
   if (K <= 0)
@@ -178,7 +262,7 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
         const double dt_comple = L[jm1].t - ti;
         if (back ? dt_comple < 0 : dt_comple > 0) {
           for (int q = 0; q < 3; q++) w[q] = imu.w[q] - bg[q], a[q] = imu.a[q] - ba[q];
-          preint_update(P, N, w, a, dt_comple);
+          preint_update<WAVE>(P, N, w, a, dt_comple);
           dt -= dt_comple;
           if (!dt) continue;
         }
@@ -189,22 +273,32 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
         if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) dt -= dt_comple_stop;
       }
       for (int q = 0; q < 3; q++) w[q] = (imu_now.w[q] + imu.w[q]) / 2 - bg[q], a[q] = (imu_now.a[q] + imu.a[q]) / 2 - ba[q];
-      preint_update(P, N, w, a, dt);
+      preint_update<WAVE>(P, N, w, a, dt);
       if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) {
         for (int q = 0; q < 3; q++) w[q] = imu_now.w[q] - bg[q], a[q] = imu_now.a[q] - ba[q];
-        preint_update(P, N, w, a, dt_comple_stop);
+        preint_update<WAVE>(P, N, w, a, dt_comple_stop);
       }
     }
+  }
+  if (WAVE) {
+    for (int i = threadIdx.x; i < 81; i += 64) {
+      out[k].Sigma[i] = P.S[i];
+      if (sigma_prv) sigma_prv[81 * (size_t)k + i] = P.Sprv[i];
+    }
+    if (threadIdx.x != 0) return;
   }
   status[k] = st;
   vieo_imu_preint& o = out[k];
   o.dt = P.dt;
   for (int i = 0; i < 9; i++) o.Rij[i] = P.R[i], o.JgR[i] = P.JgR[i], o.Jgv[i] = P.Jgv[i], o.Jav[i] = P.Jav[i], o.Jgp[i] = P.Jgp[i], o.Jap[i] = P.Jap[i];
   for (int i = 0; i < 3; i++) o.vij[i] = P.v[i], o.pij[i] = P.p[i];
+  if (WAVE) return;
   for (int i = 0; i < 81; i++) o.Sigma[i] = P.S[i];
   if (sigma_prv)
     for (int i = 0; i < 81; i++) sigma_prv[81 * (size_t)k + i] = P.Sprv[i];
 }
+
+static const int kWaveBelow = 1024;  // intervals per call below which every interval gets a wavefront
 
 }  // namespace vieo
 
@@ -223,35 +317,41 @@ extern "C" int vieo_imu_preintegrate_batch(const vieo_imu_noise* noise, const vi
   if (total < 0 || (total > 0 && !h_samples)) return VIEO_E_INVALID;
   for (int k = 0; k < n; k++)
     if (h_first[k + 1] < h_first[k]) return VIEO_E_INVALID;
-  static thread_local DevBuf dN, dS, dF, dT, dB, dO, dP, dSt;
-#define ENS(b, bytes) \
-  if ((rc = (b).ensure(std::max<size_t>(bytes, 8))) != VIEO_OK) return rc
-  ENS(dN, sizeof(vieo_imu_noise));
-  ENS(dS, (size_t)total * sizeof(vieo_imu_sample));
-  ENS(dF, (size_t)(n + 1) * 4);
-  ENS(dT, (size_t)n * 16);
-  ENS(dB, (size_t)n * 48);
-  ENS(dO, (size_t)n * sizeof(vieo_imu_preint));
-  ENS(dP, (size_t)n * 81 * 8);
-  ENS(dSt, (size_t)n * 4);
-#undef ENS
-  VIEO_HIP_CHECK(hipMemcpy(dN.p, noise, sizeof(vieo_imu_noise), hipMemcpyHostToDevice));
-  if (total > 0) VIEO_HIP_CHECK(hipMemcpy(dS.p, h_samples, (size_t)total * sizeof(vieo_imu_sample), hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(dF.p, h_first, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
-  double* dti = dT.as<double>();
-  double* dtj = dti + n;
-  double* dbg = dB.as<double>();
-  double* dba = dbg + 3 * (size_t)n;
-  VIEO_HIP_CHECK(hipMemcpy(dti, h_ti, (size_t)n * 8, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(dtj, h_tj, (size_t)n * 8, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(dbg, h_bg, (size_t)n * 24, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(dba, h_ba, (size_t)n * 24, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_imu_preint, dim3((n + 63) / 64), dim3(64), 0, 0, dN.as<vieo_imu_noise>(),
-                     dS.as<vieo_imu_sample>(), dF.as<int32_t>(), dti, dtj, dbg, dba, n, dO.as<vieo_imu_preint>(),
-                     dP.as<double>(), dSt.as<int32_t>());
+  // one device block, one pinned staging block: [noise | ti | tj | bg | ba | first | samples] up,
+  // [out | sigma_prv | status] down (ten synchronous copies of pageable memory were 2 ms per call)
+  static thread_local DevBuf dev;
+  static thread_local PinnedBuf pin;
+  auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t o_noise = 0, o_ti = al(sizeof(vieo_imu_noise)), o_tj = o_ti + al((size_t)n * 8);
+  const size_t o_bg = o_tj + al((size_t)n * 8), o_ba = o_bg + al((size_t)n * 24), o_first = o_ba + al((size_t)n * 24);
+  const size_t o_samples = o_first + al((size_t)(n + 1) * 4);
+  const size_t up = o_samples + al((size_t)total * sizeof(vieo_imu_sample));
+  const size_t o_out = up, o_prv = o_out + al((size_t)n * sizeof(vieo_imu_preint));
+  const size_t o_st = o_prv + al((size_t)n * 81 * 8), all = o_st + al((size_t)n * 4);
+  if ((rc = dev.ensure(all)) != VIEO_OK || (rc = pin.ensure(all)) != VIEO_OK) return rc;
+  uint8_t* h = (uint8_t*)pin.p;
+  uint8_t* d = (uint8_t*)dev.p;
+  memcpy(h + o_noise, noise, sizeof(vieo_imu_noise));
+  memcpy(h + o_ti, h_ti, (size_t)n * 8), memcpy(h + o_tj, h_tj, (size_t)n * 8);
+  memcpy(h + o_bg, h_bg, (size_t)n * 24), memcpy(h + o_ba, h_ba, (size_t)n * 24);
+  memcpy(h + o_first, h_first, (size_t)(n + 1) * 4);
+  if (total > 0) memcpy(h + o_samples, h_samples, (size_t)total * sizeof(vieo_imu_sample));
+  VIEO_HIP_CHECK(hipMemcpyAsync(d, h, up, hipMemcpyHostToDevice, 0));
+  if (n < kWaveBelow)
+    hipLaunchKernelGGL(k_imu_preint<true>, dim3(n), dim3(64), 0, 0, (const vieo_imu_noise*)(d + o_noise),
+                       (const vieo_imu_sample*)(d + o_samples), (const int32_t*)(d + o_first), (const double*)(d + o_ti),
+                       (const double*)(d + o_tj), (const double*)(d + o_bg), (const double*)(d + o_ba), n,
+                       (vieo_imu_preint*)(d + o_out), (double*)(d + o_prv), (int32_t*)(d + o_st));
+  else
+    hipLaunchKernelGGL(k_imu_preint<false>, dim3((n + 63) / 64), dim3(64), 0, 0, (const vieo_imu_noise*)(d + o_noise),
+                       (const vieo_imu_sample*)(d + o_samples), (const int32_t*)(d + o_first), (const double*)(d + o_ti),
+                       (const double*)(d + o_tj), (const double*)(d + o_bg), (const double*)(d + o_ba), n,
+                       (vieo_imu_preint*)(d + o_out), (double*)(d + o_prv), (int32_t*)(d + o_st));
   VIEO_HIP_CHECK(hipGetLastError());
-  VIEO_HIP_CHECK(hipMemcpy(h_out, dO.p, (size_t)n * sizeof(vieo_imu_preint), hipMemcpyDeviceToHost));
-  if (h_sigma_prv) VIEO_HIP_CHECK(hipMemcpy(h_sigma_prv, dP.p, (size_t)n * 81 * 8, hipMemcpyDeviceToHost));
-  VIEO_HIP_CHECK(hipMemcpy(h_status, dSt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  VIEO_HIP_CHECK(hipMemcpyAsync(h + o_out, d + o_out, all - o_out, hipMemcpyDeviceToHost, 0));
+  VIEO_HIP_CHECK(hipStreamSynchronize(0));
+  memcpy(h_out, h + o_out, (size_t)n * sizeof(vieo_imu_preint));
+  if (h_sigma_prv) memcpy(h_sigma_prv, h + o_prv, (size_t)n * 81 * 8);
+  memcpy(h_status, h + o_st, (size_t)n * 4);
   return VIEO_OK;
 }

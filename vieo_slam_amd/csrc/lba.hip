@@ -1634,19 +1634,6 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
 static thread_local hipStream_t g_lba_stream = nullptr;
 static thread_local int g_lba_stream_dev = -1;  // the device the stream was created on
 static thread_local DevBuf g_arena, g_small;
-struct PinnedBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  int ensure(size_t bytes) {
-    if (bytes <= cap) return VIEO_OK;
-    if (p) (void)hipHostFree(p);
-    p = nullptr, cap = 0;
-    bytes += bytes / 2;
-    VIEO_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
-    cap = bytes;
-    return VIEO_OK;
-  }
-};
 static thread_local PinnedBuf g_stage, g_small_h;
 
 struct WinHost {  // per-window LM state machine, exactly g2o's (optimization_algorithm_levenberg.cpp)
