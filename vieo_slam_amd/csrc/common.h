@@ -73,6 +73,54 @@ struct PinnedBuf {
   }
 };
 
+// Several host arrays -> one pinned block -> one device block: ONE asynchronous copy up and one back per call.  The
+// host-pointer entry points of the small per-frame calls (one frame's search, one pose optimisation) spent a third of
+// their time in five to nine synchronous copies of pageable memory.
+struct Staging {
+  PinnedBuf pin;
+  DevBuf dev;
+  struct Item {
+    const void* src;
+    size_t bytes, off;
+  };
+  Item items[16];
+  int n = 0;
+  size_t used = 0, in_end = 0;
+  static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+  void reset() { n = 0, used = 0, in_end = 0; }
+  size_t in(const void* src, size_t bytes) {  // inputs first, in call order
+    const size_t off = used;
+    items[n++] = Item{src, bytes, off};
+    used += al(bytes);
+    in_end = used;
+    return off;
+  }
+  size_t out(size_t bytes) {  // device-written regions, after the inputs
+    const size_t off = used;
+    used += al(bytes);
+    return off;
+  }
+  int upload(hipStream_t st) {
+    int rc;
+    if ((rc = pin.ensure(used)) != VIEO_OK || (rc = dev.ensure(used)) != VIEO_OK) return rc;
+    for (int i = 0; i < n; i++)
+      if (items[i].bytes) memcpy((uint8_t*)pin.p + items[i].off, items[i].src, items[i].bytes);
+    if (in_end) VIEO_HIP_CHECK(hipMemcpyAsync(dev.p, pin.p, in_end, hipMemcpyHostToDevice, st));
+    return VIEO_OK;
+  }
+  int download(size_t from, hipStream_t st) {  // [from, used) back to the pinned block, then wait
+    if (used > from)
+      VIEO_HIP_CHECK(hipMemcpyAsync((uint8_t*)pin.p + from, (uint8_t*)dev.p + from, used - from, hipMemcpyDeviceToHost, st));
+    VIEO_HIP_CHECK(hipStreamSynchronize(st));
+    return VIEO_OK;
+  }
+  template <class T>
+  T* d(size_t off) const {
+    return (T*)((uint8_t*)dev.p + off);
+  }
+  const void* h(size_t off) const { return (const uint8_t*)pin.p + off; }
+};
+
 int require_device();  // VIEO_OK or VIEO_E_NO_DEVICE
 // which pose-optimisation kernels a *_batch_device call launches: bit 0 the rectified-pinhole instance,
 // bit 1 the multi-camera-rig instance (vieo_pose_set_camera_mode)

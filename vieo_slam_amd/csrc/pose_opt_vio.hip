@@ -912,38 +912,34 @@ int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_ob
   if (!h_frame || !h_result || (h_frame->base.n_obs > 0 && (!h_obs || !h_outlier))) return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
-  static thread_local DevBuf dF, dO, dU, dR, dC, dE;
   const int n = h_frame->base.n_obs, nc = h_frame->base.n_cams;
   if (nc < 0 || nc > 4 || (nc > 0 && !h_frame->base.cams)) {
     set_error("PoseOptimization (VIO): n_cams = %d (0..4) needs `cams`", nc);
     return VIEO_E_INVALID;
   }
   const bool has_enc = h_frame->base.enc && h_frame->base.enc->enc.dt != 0;
-  if ((rc = dE.ensure(sizeof(vieo_pose_enc))) != VIEO_OK) return rc;
-  if ((rc = dF.ensure(sizeof(vieo_vio_frame))) != VIEO_OK) return rc;
-  if ((rc = dC.ensure(4 * sizeof(vieo_camera))) != VIEO_OK) return rc;
-  if ((rc = dO.ensure((size_t)std::max(n, 1) * sizeof(vieo_pose_obs))) != VIEO_OK) return rc;
-  if ((rc = dU.ensure(std::max(n, 1))) != VIEO_OK) return rc;
-  if ((rc = dR.ensure(sizeof(vieo_vio_result))) != VIEO_OK) return rc;
+  // one block up (frame, cameras, encoder edge, observations), one back (result, outlier flags).  The device
+  // pointers inside the frame record are only known once the block is placed, so the record is patched in the
+  // pinned copy before the upload.
+  static thread_local Staging G;
+  G.reset();
   vieo_vio_frame F = *h_frame;
-  const vieo_pose_obs* src = h_obs + h_frame->base.obs_begin;
   F.base.obs_begin = 0;
-  if (nc > 0) {
-    VIEO_HIP_CHECK(hipMemcpy(dC.p, h_frame->base.cams, (size_t)nc * sizeof(vieo_camera), hipMemcpyHostToDevice));
-    F.base.cams = dC.as<vieo_camera>();
-  }
-  F.base.enc = nullptr;
-  if (has_enc) {
-    VIEO_HIP_CHECK(hipMemcpy(dE.p, h_frame->base.enc, sizeof(vieo_pose_enc), hipMemcpyHostToDevice));
-    F.base.enc = dE.as<vieo_pose_enc>();
-  }
-  VIEO_HIP_CHECK(hipMemcpy(dF.p, &F, sizeof(F), hipMemcpyHostToDevice));
-  if (n > 0) VIEO_HIP_CHECK(hipMemcpy(dO.p, src, (size_t)n * sizeof(vieo_pose_obs), hipMemcpyHostToDevice));
-  rc = vio_launch(dF.as<vieo_vio_frame>(), 1, dO.as<vieo_pose_obs>(), dU.as<uint8_t>(),
-                  dR.as<vieo_vio_result>(), nc > 0 ? 2 : 1, has_enc ? 2 : 1, nullptr);
+  const size_t o_f = G.in(&F, sizeof(F));
+  const size_t o_c = G.in(h_frame->base.cams, nc > 0 ? (size_t)nc * sizeof(vieo_camera) : 0);
+  const size_t o_e = G.in(h_frame->base.enc, has_enc ? sizeof(vieo_pose_enc) : 0);
+  const size_t o_o = G.in(h_obs ? h_obs + h_frame->base.obs_begin : nullptr, (size_t)std::max(n, 0) * sizeof(vieo_pose_obs));
+  const size_t o_r = G.out(sizeof(vieo_vio_result)), o_u = G.out((size_t)std::max(n, 1));
+  if ((rc = G.pin.ensure(G.used)) != VIEO_OK || (rc = G.dev.ensure(G.used)) != VIEO_OK) return rc;
+  F.base.cams = nc > 0 ? G.d<vieo_camera>(o_c) : nullptr;
+  F.base.enc = has_enc ? G.d<vieo_pose_enc>(o_e) : nullptr;
+  if ((rc = G.upload(nullptr)) != VIEO_OK) return rc;
+  rc = vio_launch(G.d<vieo_vio_frame>(o_f), 1, G.d<vieo_pose_obs>(o_o), G.d<uint8_t>(o_u), G.d<vieo_vio_result>(o_r),
+                  nc > 0 ? 2 : 1, has_enc ? 2 : 1, nullptr);
   if (rc != VIEO_OK) return rc;
-  VIEO_HIP_CHECK(hipMemcpy(h_result, dR.p, sizeof(vieo_vio_result), hipMemcpyDeviceToHost));
-  if (n > 0) VIEO_HIP_CHECK(hipMemcpy(h_outlier + h_frame->base.obs_begin, dU.p, n, hipMemcpyDeviceToHost));
+  if ((rc = G.download(o_r, nullptr)) != VIEO_OK) return rc;
+  memcpy(h_result, G.h(o_r), sizeof(vieo_vio_result));
+  if (n > 0) memcpy(h_outlier + h_frame->base.obs_begin, G.h(o_u), n);
   if (h_result->base.status == VIEO_E_CAPACITY) {
     set_error("PoseOptimization (VIO): %d observations exceed the kernel's capacity (16384)", n);
     return VIEO_E_CAPACITY;

@@ -936,34 +936,23 @@ int vieo_search_by_projection_rig(int mode, const vieo_proj_query* h_queries, in
   *nmatches = 0;
   for (int i = 0; i < n_keys; i++) h_assign[i] = VIEO_SBP_UNCHANGED;
   if (nq == 0 || n_keys == 0) return VIEO_OK;
-  SbpScratch& S = g_sbp;
-  static thread_local DevBuf dCf;
-#define ENS(b, n) \
-  if ((rc = (b).ensure(n)) != VIEO_OK) return rc
-  ENS(S.q, (size_t)nq * sizeof(vieo_proj_query));
-  ENS(S.nq, 4);
-  ENS(S.keys, (size_t)n_keys * sizeof(vieo_keypoint));
-  ENS(S.ur, (size_t)n_keys * 4);
-  ENS(S.desc, (size_t)n_keys * 32);
-  ENS(S.taken, (size_t)n_keys);
-  ENS(dCf, 8 * 4);
-  ENS(S.assign, (size_t)n_keys * 4);
-  ENS(S.nm, 4);
-#undef ENS
-  VIEO_HIP_CHECK(hipMemcpy(S.q.p, h_queries, (size_t)nq * sizeof(vieo_proj_query), hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.nq.p, &nq, 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.keys.p, h_keys, (size_t)n_keys * sizeof(vieo_keypoint), hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.ur.p, h_uright, (size_t)n_keys * 4, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(S.desc.p, h_desc, (size_t)n_keys * 32, hipMemcpyHostToDevice));
-  if (h_taken) VIEO_HIP_CHECK(hipMemcpy(S.taken.p, h_taken, (size_t)n_keys, hipMemcpyHostToDevice));
-  VIEO_HIP_CHECK(hipMemcpy(dCf.p, h_cam_first, (size_t)(n_cams + 1) * 4, hipMemcpyHostToDevice));
+  static thread_local Staging G;
+  G.reset();
+  const size_t o_q = G.in(h_queries, (size_t)nq * sizeof(vieo_proj_query)), o_nq = G.in(&nq, 4);
+  const size_t o_keys = G.in(h_keys, (size_t)n_keys * sizeof(vieo_keypoint)), o_ur = G.in(h_uright, (size_t)n_keys * 4);
+  const size_t o_desc = G.in(h_desc, (size_t)n_keys * 32);
+  const size_t o_taken = G.in(h_taken, h_taken ? (size_t)n_keys : 0);
+  const size_t o_cf = G.in(h_cam_first, (size_t)(n_cams + 1) * 4);
+  const size_t o_assign = G.out((size_t)n_keys * 4), o_nm = G.out(4);
+  if ((rc = G.upload(nullptr)) != VIEO_OK) return rc;
   rc = vieo_search_by_projection_rig_batch_device(
-      mode, S.q.as<vieo_proj_query>(), S.nq.as<int>(), nq, 1, S.keys.as<vieo_keypoint>(), S.ur.as<float>(),
-      S.desc.as<uint8_t>(), h_taken ? S.taken.as<uint8_t>() : nullptr, dCf.as<int32_t>(), n_keys, h_bounds, n_cams,
-      nn_ratio, check_orientation, S.assign.as<int>(), S.nm.as<int>(), nullptr);
+      mode, G.d<vieo_proj_query>(o_q), G.d<int>(o_nq), nq, 1, G.d<vieo_keypoint>(o_keys), G.d<float>(o_ur),
+      G.d<uint8_t>(o_desc), h_taken ? G.d<uint8_t>(o_taken) : nullptr, G.d<int32_t>(o_cf), n_keys, h_bounds, n_cams,
+      nn_ratio, check_orientation, G.d<int>(o_assign), G.d<int>(o_nm), nullptr);
   if (rc != VIEO_OK) return rc;
-  VIEO_HIP_CHECK(hipMemcpy(h_assign, S.assign.p, (size_t)n_keys * 4, hipMemcpyDeviceToHost));
-  VIEO_HIP_CHECK(hipMemcpy(nmatches, S.nm.p, 4, hipMemcpyDeviceToHost));
+  if ((rc = G.download(o_assign, nullptr)) != VIEO_OK) return rc;
+  memcpy(h_assign, G.h(o_assign), (size_t)n_keys * 4);
+  memcpy(nmatches, G.h(o_nm), 4);
   if (*nmatches < 0) {
     set_error("search_by_projection: more than %d window candidates for one query", kCandCap);
     return VIEO_E_CAPACITY;

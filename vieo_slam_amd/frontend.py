@@ -61,23 +61,24 @@ def queries_from_track_info(info, desc, th, scale, observed=None, th_far=0.0):
     Frame::isInFrustum, desc uint8[n, 32], scale = scalepyrinfo_.vscalefactor_ (float32).
     returns (queries PROJ_QUERY_DTYPE[m], point index of every query int32[m])."""
     from .ba_types import PROJ_QUERY_DTYPE
-    rows, owner = [], []
-    bFactor = th != 1.0
-    for i in range(len(info)):
-        T = info[i]
-        if T["n"] <= 0:
-            continue
-        if th_far > 0 and T["track_depth"] > th_far:
-            continue
-        for k in range(int(T["n"])):
-            lvl = int(T["level"][k])
-            r = np.float32(2.5) if T["viewcos"][k] > np.float32(0.998) else np.float32(4.0)  # RadiusByViewingCos
-            if bFactor:
-                r = np.float32(r * np.float32(th))
-            rows.append((T["u"][k], T["v"][k], T["ur"][k], np.float32(r * scale[lvl]), lvl - 1, lvl, 0.0,
-                         1 | (2 if (observed is None or observed[i]) else 0) | (int(T["cam"][k]) << 8), desc[i]))
-            owner.append(i)
-    q = np.zeros(len(rows), PROJ_QUERY_DTYPE)
-    for j, r in enumerate(rows):
-        q[j] = r
-    return q, np.array(owner, np.int32)
+    info = np.asarray(info)
+    n = len(info)
+    kmax = info["level"].shape[1] if n else 0
+    cnt = np.clip(info["n"].astype(np.int64), 0, kmax)
+    if th_far > 0:
+        cnt = np.where(info["track_depth"] > th_far, 0, cnt)
+    # (point, slot) pairs, point-major
+    sel = np.arange(kmax)[None, :] < cnt[:, None]
+    owner, slot = np.nonzero(sel)
+    lvl = info["level"][owner, slot].astype(np.int32)
+    r = np.where(info["viewcos"][owner, slot] > np.float32(0.998), np.float32(2.5), np.float32(4.0)).astype(np.float32)
+    if th != 1.0:  # RadiusByViewingCos, then the factor, then the level's scale: three float32 products
+        r = (r * np.float32(th)).astype(np.float32)
+    q = np.zeros(len(owner), PROJ_QUERY_DTYPE)
+    q["u"], q["v"], q["ur"] = info["u"][owner, slot], info["v"][owner, slot], info["ur"][owner, slot]
+    q["radius"] = (r * np.asarray(scale, np.float32)[lvl]).astype(np.float32)
+    q["level_min"], q["level_max"], q["angle"] = lvl - 1, lvl, 0.0
+    obs = np.ones(len(owner), bool) if observed is None else np.asarray(observed, bool)[owner]
+    q["flags"] = 1 | np.where(obs, 2, 0) | (info["cam"][owner, slot].astype(np.int32) << 8)
+    q["desc"] = np.asarray(desc)[owner]
+    return q, owner.astype(np.int32)
