@@ -303,7 +303,9 @@ def main():
     ap.add_argument("--base-cases", type=int, default=8, help="distinct rendered scenes per GPU")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent frame pipelines per GPU, each on its own HIP stream (the batch "
-                         "is split between them so latency-bound stages overlap extraction)")
+                         "is split between them so latency-bound stages overlap extraction: 2 streams give "
+                         "+3..5 %% frames/s, but then the per-kernel event times of stream 0 include the other "
+                         "stream's kernels, so the default keeps the roofline attribution clean)")
     ap.add_argument("--lba-every", type=int, default=10, help="frames per LocalBundleAdjustment (0 = none)")
     ap.add_argument("--lba-threads", type=int, default=2, help="host threads issuing LBA batches")
     ap.add_argument("--lba-batch", type=int, default=0,
@@ -394,11 +396,13 @@ def main():
         # every kernel (class) of the path, ms per step: the extractor's kernels and the front-end stages from the
         # events of stream 0, the bundle-adjustment kernels from the engine's own events on its streams
         lba_k, schur_flops = Optimizer.kernel_times()
-        kern = {("orb." + k): v for k, v in oavg.items() if k != "total"}
-        kern.update({("frontend." + k): v for k, v in avg.items() if k not in ("extract", "total")})
+        # (stream 0 carries P.B of the step's B frames: its launch times are scaled to the whole step for the ranking)
+        share = B / float(P.B)
+        kern = {("orb." + k): v * share for k, v in oavg.items() if k != "total"}
+        kern.update({("frontend." + k): v * share for k, v in avg.items() if k not in ("extract", "total")})
         kern.update({k: v["ms"] / a.steps for k, v in lba_k.items()})
         dom = max(kern, key=kern.get)
-        launches = lba_k[dom]["launches"] / a.steps if dom in lba_k else 1
+        launches = lba_k[dom]["launches"] / a.steps if dom in lba_k else share
         # algorithmic bytes per launch of the kernels that are HBM-bound by design
         nfree, nmp_w, nobs_w = 10, np.mean([len(p[2]) for p in lba_problems]) if lba_problems else 0, \
             np.mean([len(p[4]) for p in lba_problems]) if lba_problems else 0
