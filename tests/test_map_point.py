@@ -159,9 +159,16 @@ def test_distinctive_parity(oracle):
     o = oracle.distinctive_descriptors(D, first)
     h = compute_distinctive_descriptors(D, first)
     assert np.array_equal(o, h) and (h[cnt == 0] == -1).all()
-    first2 = np.array([0, 129], np.int32)
-    rc, _ = distinctive_call(lib().vieo_distinctive_descriptors_batch, np.zeros((129, 32), np.uint8), first2)
-    assert rc != 0  # capacity
+    # more than 128 observations of one point (4-camera rigs, long sessions): no limit in the reference; the kernel
+    # switches from the N x N table in LDS to per-lane histograms, and the other points of the batch are unaffected
+    cnt2 = np.array([129, 5, 700, 0, 128, 301], np.int64)
+    first2 = np.concatenate([[0], np.cumsum(cnt2)]).astype(np.int32)
+    D2 = np.repeat(rng.integers(0, 256, (len(cnt2), 32), dtype=np.uint8), cnt2, 0)
+    D2 ^= ((rng.random(D2.shape) < 0.1) * (1 << rng.integers(0, 8, D2.shape))).astype(np.uint8)
+    assert np.array_equal(oracle.distinctive_descriptors(D2, first2), compute_distinctive_descriptors(D2, first2))
+    # small batches ask for small LDS (the table of the largest point, not 128 KB)
+    small = np.array([0, 3, 7], np.int32)
+    assert np.array_equal(oracle.distinctive_descriptors(D2[:7], small), compute_distinctive_descriptors(D2[:7], small))
 
 
 @pytest.mark.gpu

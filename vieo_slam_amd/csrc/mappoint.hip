@@ -84,12 +84,22 @@ k_in_frustum(const FrustumDev* __restrict__ fd, const vieo_frustum_point* __rest
   out[m] = T;
 }
 
-static const int kMaxObsPerPoint = 128;
+static const int kMaxObsLds = 128;      // rows of the N x N distance table a wavefront keeps in LDS
+static const int kMaxObsPerPoint = 65535;  // bins are 16 bits wide
 
-// one wavefront per point: lane i owns rows i, i + 64; distances as uint16 in LDS; the median of a row is its
-// k-th smallest value (k = int(0.5 (N - 1))), found by bisection on the value (0..256) with counting
+__device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// one wavefront per point: lane i owns rows i, i + 64, ...; the median of a row is its k-th smallest value
+// (k = int(0.5 (N - 1))).  N <= cap: the distances as uint16 in LDS, the k-th smallest by bisection on the value
+// (0..256) with counting.  N > cap (no limit in the reference, reachable with rigs and long sessions): the lane keeps
+// a 257-bin histogram of its row in LDS instead and walks the cumulative count -- same value, no N x N table.
+// slice: uint16 entries of LDS per wavefront (>= cap * cap, and >= 64 * 258 when a point of the batch needs bins).
 __global__ void __launch_bounds__(256)
-k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ first, int n, int32_t* __restrict__ best) {
+k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ first, int n, int32_t* __restrict__ best,
+              int cap, int slice) {
   extern __shared__ unsigned short s_all[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + wv;
@@ -99,31 +109,47 @@ k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ firs
     if (lane == 0) best[p] = -1;
     return;
   }
-  unsigned short* sd = s_all + (size_t)wv * kMaxObsPerPoint * kMaxObsPerPoint;
+  unsigned short* sd = s_all + (size_t)wv * slice;
   const uint8_t* D = desc + (size_t)first[p] * 32;
-  for (int i = lane; i < N; i += 64) {
-    const uint4 a0 = ((const uint4*)(D + (size_t)i * 32))[0], a1 = ((const uint4*)(D + (size_t)i * 32))[1];
-    for (int j = 0; j < N; ++j) {
-      const uint4 b0 = ((const uint4*)(D + (size_t)j * 32))[0], b1 = ((const uint4*)(D + (size_t)j * 32))[1];
-      const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
-                    __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-      sd[i * N + j] = (unsigned short)d;
-    }
-  }
   const int k = (int)(0.5 * (N - 1));
   int bm = INT_MAX, bi = INT_MAX;
-  for (int i = lane; i < N; i += 64) {
-    int lo = 0, hi = 256;  // smallest v with #{d <= v} >= k + 1
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      int c = 0;
-      for (int j = 0; j < N; ++j) c += sd[i * N + j] <= mid;
-      if (c >= k + 1)
-        hi = mid;
-      else
-        lo = mid + 1;
+  if (N <= cap) {
+    for (int i = lane; i < N; i += 64) {
+      const uint4 a0 = ((const uint4*)(D + (size_t)i * 32))[0], a1 = ((const uint4*)(D + (size_t)i * 32))[1];
+      for (int j = 0; j < N; ++j) {
+        const uint4 b0 = ((const uint4*)(D + (size_t)j * 32))[0], b1 = ((const uint4*)(D + (size_t)j * 32))[1];
+        sd[i * N + j] = (unsigned short)hamming256(a0, a1, b0, b1);
+      }
     }
-    if (lo < bm) bm = lo, bi = i;  // rows ascend within a lane: the first minimum stays
+    for (int i = lane; i < N; i += 64) {
+      int lo = 0, hi = 256;  // smallest v with #{d <= v} >= k + 1
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        int c = 0;
+        for (int j = 0; j < N; ++j) c += sd[i * N + j] <= mid;
+        if (c >= k + 1)
+          hi = mid;
+        else
+          lo = mid + 1;
+      }
+      if (lo < bm) bm = lo, bi = i;  // rows ascend within a lane: the first minimum stays
+    }
+  } else {
+    unsigned short* h = sd + lane * 258;
+    for (int i = lane; i < N; i += 64) {
+      for (int v = 0; v < 257; ++v) h[v] = 0;
+      const uint4 a0 = ((const uint4*)(D + (size_t)i * 32))[0], a1 = ((const uint4*)(D + (size_t)i * 32))[1];
+      for (int j = 0; j < N; ++j) {
+        const uint4 b0 = ((const uint4*)(D + (size_t)j * 32))[0], b1 = ((const uint4*)(D + (size_t)j * 32))[1];
+        h[hamming256(a0, a1, b0, b1)]++;
+      }
+      int c = 0, v = 0;
+      for (; v < 257; ++v) {
+        c += h[v];
+        if (c >= k + 1) break;
+      }
+      if (v < bm) bm = v, bi = i;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -219,6 +245,7 @@ int vieo_distinctive_descriptors_batch(const uint8_t* h_descriptors, const int32
   if (n_points == 0) return VIEO_OK;
   const int total = h_first[n_points];
   if (total < 0 || (total > 0 && !h_descriptors)) return VIEO_E_INVALID;
+  int n_max = 0;
   for (int p = 0; p < n_points; ++p) {
     const int N = h_first[p + 1] - h_first[p];
     if (N < 0) return VIEO_E_INVALID;
@@ -226,6 +253,7 @@ int vieo_distinctive_descriptors_batch(const uint8_t* h_descriptors, const int32
       set_error("ComputeDistinctiveDescriptors: point %d has %d observations (limit %d)", p, N, kMaxObsPerPoint);
       return VIEO_E_CAPACITY;
     }
+    n_max = std::max(n_max, N);
   }
   MpScratch& S = g_mp;
   ENS(S.a, (size_t)total * 32);
@@ -233,10 +261,13 @@ int vieo_distinctive_descriptors_batch(const uint8_t* h_descriptors, const int32
   ENS(S.c, (size_t)n_points * 4);
   H2D(S.a, h_descriptors, (size_t)total * 32);
   H2D(S.b, h_first, (size_t)(n_points + 1) * 4);
-  const size_t lds = (size_t)4 * kMaxObsPerPoint * kMaxObsPerPoint * sizeof(unsigned short);  // 128 KB
+  // LDS from the batch's largest point: its N x N table, or the per-lane bins when a point exceeds kMaxObsLds
+  const int cap = std::min(n_max, kMaxObsLds);
+  const int slice = std::max(cap * cap, n_max > kMaxObsLds ? 64 * 258 : 0);
+  const size_t lds = (size_t)4 * slice * sizeof(unsigned short);  // <= 132 KB
   VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_distinctive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_distinctive, dim3((n_points + 3) / 4), dim3(256), lds, 0, S.a.as<uint8_t>(),
-                     S.b.as<int32_t>(), n_points, S.c.as<int32_t>());
+                     S.b.as<int32_t>(), n_points, S.c.as<int32_t>(), cap, slice);
   VIEO_HIP_CHECK(hipGetLastError());
   VIEO_HIP_CHECK(hipMemcpy(h_best, S.c.p, (size_t)n_points * 4, hipMemcpyDeviceToHost));
   return VIEO_OK;
