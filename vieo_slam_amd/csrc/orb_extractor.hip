@@ -71,23 +71,39 @@ k_resize(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab,
   __syncthreads();
   const int dx4 = dx0 + lane * 4;
   if (dx4 >= D.w) return;
-  short4 t[4];
+  // per lane: the four columns' taps as LDS offsets inside a band row, and which of the four bytes exist
+  int x0[4], x1[4], a0[4], a1[4];
+  unsigned keep = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) t[j] = xt[min(dx4 + j, D.w - 1)];
+  for (int j = 0; j < 4; j++) {
+    const short4 t = xt[min(dx4 + j, D.w - 1)];
+    x0[j] = t.x - sx_lo, x1[j] = t.y - sx_lo, a0[j] = t.z, a1[j] = t.w;
+    if (dx4 + j < D.w) keep |= 0xFFu << (8 * j);
+  }
   uint8_t* dst = I.pyr + (size_t)b * I.pyr_img + D.off;
-  for (int dy = dy0 + wave; dy < dy1; dy += 4) {
+  // the row's table entry is the same for the whole wavefront: with a wave-uniform row index it is a scalar load
+  // (a per-lane global load followed by its wait was one L2 round trip per output row)
+  // the row's table entry is the same for the whole wavefront: with a wave-uniform row index it is a scalar load
+  // (a per-lane global load followed by its wait was one L2 round trip per output row).  Measured and dropped:
+  // consecutive rows per wavefront with the horizontal sums of the last two source rows kept in registers (a source
+  // row serves 1.67 output rows) -- 0.81 ms per 1024 images against 0.78 for this form, whose 16 LDS reads per row
+  // are all in flight at once.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  for (int dy = dy0 + wave_u; dy < dy1; dy += 4) {
     const short4 y = yt[dy];
-    const uint8_t* r0 = smem + (y.x - sy_lo) * lds_pitch - sx_lo;
-    const uint8_t* r1 = smem + (y.y - sy_lo) * lds_pitch - sx_lo;
+    const uint8_t* r0 = smem + (y.x - sy_lo) * lds_pitch;
+    const uint8_t* r1 = smem + (y.y - sy_lo) * lds_pitch;
+    const int b0 = y.z, b1 = y.w;
     unsigned out = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int h0 = r0[t[j].x] * t[j].z + r0[t[j].y] * t[j].w;
-      const int h1 = r1[t[j].x] * t[j].z + r1[t[j].y] * t[j].w;
-      const int v = (((y.z * (h0 >> 4)) >> 16) + ((y.w * (h1 >> 4)) >> 16) + 2) >> 2;
-      if (dx4 + j < D.w) out |= (unsigned)(v & 0xFF) << (8 * j);
+      const int h0 = r0[x0[j]] * a0[j] + r0[x1[j]] * a1[j];
+      const int h1 = r1[x0[j]] * a0[j] + r1[x1[j]] * a1[j];
+      // h >> 4 <= 255 * 2048 / 16 fits 16 bits: saying so lets the compiler use the 24-bit multiply (v_mul_lo_u32 is quarter rate)
+      const int v = (((b0 * (int)(unsigned short)(h0 >> 4)) >> 16) + ((b1 * (int)(unsigned short)(h1 >> 4)) >> 16) + 2) >> 2;
+      out |= (unsigned)(v & 0xFF) << (8 * j);
     }
-    *(unsigned*)(dst + (size_t)dy * D.pitch + dx4) = out;
+    *(unsigned*)(dst + (size_t)dy * D.pitch + dx4) = out & keep;
   }
 }
 
