@@ -161,6 +161,29 @@ def test_vio_gba_landmark_sharded_two_ranks_on_one_gpu(oracle):
     assert results[0][0].tobytes() == results[1][0].tobytes()  # replicated solve: bit-identical key frames
 
 
+@pytest.mark.gpu
+def test_vio_gba_in_library_rccl_single_rank():
+    """BASELINE configs[4]'s exchange step through the dlopen'ed RCCL (vieo_rccl_*): a one-rank communicator, the
+    all-reduce of the reduced visual system issued by the library on the BA stream; equal to the unsharded call."""
+    from vieo_slam_amd import sharding
+    from vieo_slam_amd._lib import DeviceBuffer, lib
+    from vieo_slam_amd.optimizer import Optimizer
+    assert lib().vieo_rccl_available() == 1
+    params, kfs, pts, close, obs, imu, gt = synth_ba.make_lba_vio_problem(43, n_local=36, n_fixed=1, n_points=3000,
+                                                                          anchors=18, span=5)
+    win = (params, kfs, pts, close, obs, imu)
+    comm = sharding.RcclComm(0, 1)
+    try:
+        n = Optimizer.sharded_buffer_doubles([win])
+        buf = DeviceBuffer(8 * n)
+        sn, sp, sr = Optimizer.GlobalBundleAdjustmentNavStatePRVSharded(win, buf.ptr, n, None, 4, True, comm=comm.handle)
+        pn, pp, pr = Optimizer.GlobalBundleAdjustmentNavStatePRV(params, kfs, pts, obs, imu, 4, True)
+        assert sr["status"] == 0 and sr["lm_trials"] == pr["lm_trials"]
+        assert sn.tobytes() == pn.tobytes() and np.array_equal(sp, pp)
+    finally:
+        comm.close()
+
+
 def test_oracle_vision_gba_encoder_edges(oracle):
     """BundleAdjustment(bEnc = true) (Optimizer.cc:1401-1438): noiseless odometry between every pair leaves the
     noiseless optimum where it is; the kernel is on the pair edges iff bRobust."""
