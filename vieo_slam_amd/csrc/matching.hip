@@ -163,7 +163,9 @@ __global__ void __launch_bounds__(256) k_stereo_rows(StereoArgs A) {
 // grid (ceil(capL/4), n_frames); one wave per left key.
 __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
   const int f = blockIdx.y, lane = threadIdx.x & 63;
-  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // wave-uniform key index: the key, its descriptor, its level's descriptor and later the best right key then come
+  // through scalar loads instead of chains of per-lane global loads of the same address
+  const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int imL = A.l_first + f * A.l_step, imR = A.r_first + f * A.r_step;
   const int N = min(A.cntL[2 * imL], A.capL), Nr = min(A.cntR[2 * imR], A.capR);
   if (iL >= N) return;
@@ -201,6 +203,7 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
     const int e = __shfl_xor(bestDist, o), j = __shfl_xor(bestIdx, o);
     if (lex_less(e, j, bestDist, bestIdx)) bestDist = e, bestIdx = j;
   }
+  bestIdx = __builtin_amdgcn_readfirstlane(bestIdx), bestDist = __builtin_amdgcn_readfirstlane(bestDist);
   if (bestIdx == INT_MAX || bestDist >= (TH_HIGH + TH_LOW) / 2) return;
   // ---- sub-pixel refinement by 11 SADs of 11x11 patches at the key's pyramid level
   const float uR0 = KR[bestIdx].x;

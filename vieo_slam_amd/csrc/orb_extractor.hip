@@ -689,7 +689,10 @@ k_describe(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __r
   const int b = item / groups_per_image;
   if (b >= n_images) return;
   const int lane = threadIdx.x & 63;
-  const int g = (item - b * groups_per_image) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // wave-uniform for the compiler: the key's record, its level and the level's descriptor then come through scalar
+  // loads instead of three dependent per-lane global loads
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = (item - b * groups_per_image) * (blockDim.x >> 6) + wv;
   if (g >= min(P.kp_cap, out_cap)) return;
   // (key, level) of key point g, written by k_desc_index: one load instead of the level search + the key load
   const uint2 kr = krec[(size_t)b * P.kp_cap + g];
@@ -705,7 +708,7 @@ k_describe(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __r
   // staged in this wavefront's LDS slice as whole dwords, row by row.
   constexpr int AP = 40, BR = 19, BP = 44;
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][31 * AP + (2 * BR + 1) * BP];
-  uint8_t* sa = s_patch[threadIdx.x >> 6];
+  uint8_t* sa = s_patch[wv];
   uint8_t* sb = sa + 31 * AP;
   const int xa = (cx - kHalfPatch) & ~3, xb = (cx - BR) & ~3;
   const uint8_t* bl0 = I.blur + (size_t)b * I.blur_img + D.boff;

@@ -321,7 +321,8 @@ static const int kSbpBlocks = 8;
 
 __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   extern __shared__ unsigned short s_cs[];  // [n_cams][kGridCells + 1] camera-local offsets (< kMaxKeys: 16 bits)
-  const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // (wave-uniform wavefront index: the query walk then runs on scalar registers and scalar loads)
+  const int f = blockIdx.y, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int nq = min(A.nq[f], A.q_cap);
   const int img = A.img_first + f * A.img_step;
   {
