@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256)
 k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ first, int n, int32_t* __restrict__ best,
               int cap, int slice) {
   extern __shared__ unsigned short s_all[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // wave-uniform
   const int p = blockIdx.x * 4 + wv;
   if (p >= n) return;
   const int N = first[p + 1] - first[p];

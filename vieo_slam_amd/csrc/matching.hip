@@ -40,7 +40,7 @@ k_knn2(const Knn2Job* __restrict__ jobs, const int* __restrict__ counts, int32_t
        int32_t* __restrict__ dist) {
   Knn2Job J = jobs[blockIdx.y];
   const int lane = threadIdx.x & 63;
-  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int qi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform
   if (qi >= J.nq) return;
   const uint4 a0 = ((const uint4*)(J.q + (size_t)qi * 32))[0];
   const uint4 a1 = ((const uint4*)(J.q + (size_t)qi * 32))[1];

@@ -1109,7 +1109,7 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
   // one wavefront per cell.  Measured alternatives that were slower and are gone: a persistent form with the next
   // cell's tile prefetched in registers (2.4 - 3.3 ms against 2.0 ms per 1024 images: the extra registers cost
   // occupancy, and the prologue latency it hides is not what bounds the kernel), 2 / 4 independent wavefronts per
-  // workgroup (2.05 - 2.09 ms)
+  // workgroup (2.05 - 2.09 ms; again 2.06 / 1.99 against 1.95 with the wavefront index made wave-uniform)
   {
     const int lds_w = align_up(e->fast_lds, 16);
     hipLaunchKernelGGL((k_fast<1>), dim3(xcd_grid((long long)P.ncells * B)), dim3(64), (size_t)lds_w, st, P, I,

@@ -633,7 +633,7 @@ k_fuse_search(const FuseDev* __restrict__ fd, int cami, const int* __restrict__ 
               const float4* __restrict__ cell_rec, const uint8_t* __restrict__ desc,
               const vieo_fuse_point* __restrict__ pts, int n, int32_t* __restrict__ best_idx,
               int32_t* __restrict__ best_dist) {
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // wave-uniform
   if (m >= n) return;
   const vieo_fuse_frame& FF = fd->F;
   const vieo_frustum_frame& F = FF.base;
