@@ -27,6 +27,7 @@
 
 #ifdef QT_DEVICE
 #define QT_FN __device__ __forceinline__
+#define QT_MEM __device__ __forceinline__
 #define QT_NT ((int)blockDim.x)
 #define QT_PHASE for (int tid = (int)threadIdx.x, qt_once_ = 1; qt_once_; qt_once_ = 0)
 #define QT_SYNC() __syncthreads()
@@ -34,6 +35,7 @@
 #define QT_ATOMIC_MAX(p, v) atomicMax((p), (v))
 #else
 #define QT_FN static inline
+#define QT_MEM inline
 #define QT_NT 256
 #define QT_PHASE for (int tid = 0; tid < QT_NT; ++tid)
 #define QT_SYNC() ((void)0)
@@ -90,6 +92,11 @@ struct QtMem {
   int* cand_size[2];
   unsigned short* order;  // [ncap] processing order -> candidate index
   int ncap, scap;
+  // the ping-pong halves by (uniform) index WITHOUT indexing the pointer arrays dynamically: a dynamic index forces
+  // the whole struct into scratch memory and every use of a pointer becomes a scratch load inside the round loops
+  QT_MEM unsigned short* list_(int i) const { return i ? list[1] : list[0]; }
+  QT_MEM unsigned short* cslot(int i) const { return i ? cand_slot[1] : cand_slot[0]; }
+  QT_MEM int* csize(int i) const { return i ? cand_size[1] : cand_size[0]; }
 };
 
 // Inclusive Hillis-Steele scan of a[0..n) (4 x 16-bit packed counters); result ends in the
@@ -134,8 +141,8 @@ QT_FN void qt_apply_round(const QtMem& m, int mode, int cur, int cb, const unsig
                           unsigned short* kslot, unsigned char* kq) {
   QtShared* s = m.s;
   const int n = s->n;
-  const unsigned short* L = m.list[cur];
-  unsigned short* Ln = m.list[cur ^ 1];
+  const unsigned short* L = m.list_(cur);
+  unsigned short* Ln = m.list_(cur ^ 1);
   // ---- per list position: is the node split in this round?  packed counters:
   //  bits 0..15 pushes (children), 16..31 retained, 32..47 expandable children
   QT_PHASE {
@@ -208,8 +215,8 @@ QT_FN void qt_apply_round(const QtMem& m, int mode, int cur, int cb, const unsig
             m.child[sl * 4 + q] = (unsigned short)slot;
             Ln[P - 1 - (pushbase + t)] = (unsigned short)slot;
             if (c[q] > 1) {
-              m.cand_slot[cb ^ 1][ebase + te] = (unsigned short)slot;
-              m.cand_size[cb ^ 1][ebase + te] = c[q];
+              m.cslot(cb ^ 1)[ebase + te] = (unsigned short)slot;
+              m.csize(cb ^ 1)[ebase + te] = c[q];
               te++;
             }
             t++;
@@ -237,7 +244,7 @@ QT_FN void qt_apply_round(const QtMem& m, int mode, int cur, int cb, const unsig
     unsigned long long* pa = inc;  // free now
     QT_PHASE {
       for (int j = tid; j < cbsz; j += QT_NT) {
-        const int sl = m.cand_slot[cb][m.order[j]];
+        const int sl = m.cslot(cb)[m.order[j]];
         int nch = 0, ne = 0;
         for (int q = 0; q < 4; q++) {
           nch += m.cc[sl * 4 + q] > 0;
@@ -270,7 +277,7 @@ QT_FN void qt_apply_round(const QtMem& m, int mode, int cur, int cb, const unsig
     }
     QT_PHASE {
       for (int j = tid; j < cbsz; j += QT_NT) {
-        const int sl = m.cand_slot[cb][m.order[j]];
+        const int sl = m.cslot(cb)[m.order[j]];
         const unsigned long long in = pinc[j];
         int c[4];
         int nch = 0, ne = 0;
@@ -295,8 +302,8 @@ QT_FN void qt_apply_round(const QtMem& m, int mode, int cur, int cb, const unsig
           m.child[sl * 4 + q] = (unsigned short)slot;
           Ln[P - 1 - (pushbase + t)] = (unsigned short)slot;
           if (c[q] > 1) {
-            m.cand_slot[cb ^ 1][ebase + te] = (unsigned short)slot;
-            m.cand_size[cb ^ 1][ebase + te] = c[q];
+            m.cslot(cb ^ 1)[ebase + te] = (unsigned short)slot;
+            m.csize(cb ^ 1)[ebase + te] = c[q];
             te++;
           }
           t++;
@@ -339,7 +346,7 @@ QT_FN void qt_count_children(const QtMem& m, int mode, int cur, const unsigned* 
                              const unsigned short* kslot, unsigned char* kq) {
   QtShared* s = m.s;
   const int n = s->n, K = s->K;
-  const unsigned short* L = m.list[cur];
+  const unsigned short* L = m.list_(cur);
   QT_PHASE {
     for (int i = tid; i < n; i += QT_NT) {
       const int sl = L[i];
@@ -417,10 +424,10 @@ QT_FN int qt_distribute(const QtMem& m, const unsigned* keys, unsigned short* ks
         // processing order: descending (size, push index)
         QT_PHASE {
           for (int a = tid; a < mc; a += QT_NT) {
-            const int sa = m.cand_size[cb][a];
+            const int sa = m.csize(cb)[a];
             int rank = 0;
             for (int b = 0; b < mc; b++) {
-              const int sb = m.cand_size[cb][b];
+              const int sb = m.csize(cb)[b];
               rank += (sb > sa) || (sb == sa && b > a);
             }
             m.order[rank] = (unsigned short)a;
@@ -429,7 +436,7 @@ QT_FN int qt_distribute(const QtMem& m, const unsigned* keys, unsigned short* ks
         QT_SYNC();
         QT_PHASE {
           for (int j = tid; j < mc; j += QT_NT)
-            m.mark[m.cand_slot[cb][m.order[j]]] = (unsigned short)(j + 1);
+            m.mark[m.cslot(cb)[m.order[j]]] = (unsigned short)(j + 1);
           if (tid == 0) s->jstar = mc - 1;
         }
         QT_SYNC();
@@ -437,7 +444,7 @@ QT_FN int qt_distribute(const QtMem& m, const unsigned* keys, unsigned short* ks
         // growth prefix in processing order -> break index
         QT_PHASE {
           for (int j = tid; j < mc; j += QT_NT) {
-            const int sl = m.cand_slot[cb][m.order[j]];
+            const int sl = m.cslot(cb)[m.order[j]];
             int nch = 0;
             for (int q = 0; q < 4; q++) nch += m.cc[sl * 4 + q] > 0;
             m.scanA[j] = (unsigned long long)(nch - 1);
@@ -456,7 +463,7 @@ QT_FN int qt_distribute(const QtMem& m, const unsigned* keys, unsigned short* ks
         qt_apply_round(m, 1, cur, cb, keys, kslot, kq);
         // clear marks of this round's candidates
         QT_PHASE {
-          for (int j = tid; j < mc; j += QT_NT) m.mark[m.cand_slot[cb][m.order[j]]] = 0;
+          for (int j = tid; j < mc; j += QT_NT) m.mark[m.cslot(cb)[m.order[j]]] = 0;
         }
         QT_SYNC();
         cur ^= 1;
@@ -469,7 +476,7 @@ QT_FN int qt_distribute(const QtMem& m, const unsigned* keys, unsigned short* ks
   }
   // ---- best key per node (ORBextractor.cc:697-718): max response, first in key order wins
   const int n = s->n, K = s->K;
-  const unsigned short* L = m.list[cur];
+  const unsigned short* L = m.list_(cur);
   QT_PHASE {
     for (int i = tid; i < n; i += QT_NT) m.best[L[i]] = 0u;
   }
