@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvieo_hot.so")
+LIB_PATH = os.environ.get("VIEO_LIB_PATH") or os.path.join(_HERE, "libvieo_hot.so")  # (the override: A/B runs of two builds)
 
 VIEO_OK = 0
 VIEO_E_INVALID, VIEO_E_NO_DEVICE, VIEO_E_HIP, VIEO_E_CAPACITY, VIEO_E_EMPTY = -1, -2, -3, -4, -5

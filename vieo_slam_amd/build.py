@@ -13,7 +13,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
-]
+] + os.environ.get("VIEO_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DVIEO_FAST_PROBE for tools/probe_fast.py
 
 
 def sources():

@@ -13,6 +13,7 @@
 // descriptors are bit-exact against oracle/ (tests/test_orb_parity.py).
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/vieo_orb_pattern_31.h"
@@ -181,7 +182,7 @@ __device__ __forceinline__ void wave_sync() {
 // The three passes of one cell on its tile in LDS (the tile must be complete and visible): compass test +
 // compaction, exact strength of the survivors, 3x3 non-maximum suppression; writes the cell's keys and count.
 __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd, int b, int c, uint8_t* tile, uint8_t* sc,
-                                          unsigned short* cand, int tpitch, int iniTh, int minTh, int lane,
+                                          unsigned short* cand, int cand_cap, int tpitch, int iniTh, int minTh, int lane,
                                           unsigned* __restrict__ cell_keys, int* __restrict__ cell_counts) {
   const int x0a = cd.x0 & ~3;
   const int vw = cd.cw - 6, vh = cd.ch - 6;
@@ -199,6 +200,30 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
   for (int round = 0; round < 2 && base == 0; round++) {
     if (round == 1 && minTh >= iniTh) break;
     const int th = round == 0 ? iniTh : minTh;
+    int na = 0, nc = 0;  // cand[0, nc): corners (strength > th); cand[nc, na): compass survivors still to be scored
+    bool overflow = false;
+    // ---- pass B: exact strength of the pending survivors cand[nc, na); those above the threshold are compacted
+    // in place behind the corners already there (still row-major: a wavefront reads its 64 entries before it writes
+    // any).  Runs once after pass A, and inside pass A whenever the list is about to exceed its LDS capacity.
+    auto pass_b = [&]() {
+      int w = nc;
+      for (int i0 = nc; i0 < na; i0 += 64) {
+        const int i = i0 + lane;
+        bool pass = false;
+        int p = 0;
+        if (i < na) {
+          p = cand[i];
+          const int y = p >> 6, x = p & 63;
+          const int r = fast_strength(tile + (y + 3) * tpitch + (x + 3 + xo), tpitch);
+          sc[(y + 1) * sp + x + 1] = (uint8_t)r;
+          pass = r > th;
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) cand[w + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+        w += __popcll(m);
+      }
+      nc = na = w;
+    };
     // ---- pass A: compass test (see fast_compass) on FOUR horizontally adjacent pixels per lane.  The groups of
     // four are numbered row-major over the cell (g = y * ng + x / 4) and a step takes 64 consecutive ones, so all
     // lanes are busy whatever the cell width (a 36-pixel cell has 9 groups per row, not a power of two).  The
@@ -210,12 +235,12 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
     //   bright <=> (U > hi | D > hi) & (L > hi | R > hi);  bytewise unsigned a < b from d = (a | H) - (b & ~H):
     //   bit 7 of the byte = (~a & b) | (~(a ^ b) & ~d), one v_bitop3 (H = 0x80808080).
     // Ordered compaction of the surviving pixels (y << 6 | x).
-    int na = 0;
     if (npx > 0) {
-      const int s = (3 + xo) & 3, kq = (3 + xo) >> 2;  // centre byte of pixel x sits at 4 * (lx4 + kq) + s
+      // centre byte of pixel x sits at 4 * (lx4 + kq) + s; s is the same for the whole cell: one copy of the loop per
+      // value, chosen by a scalar branch (as a lane value it cost a chain of exec-mask branches per step)
+      const int s = __builtin_amdgcn_readfirstlane((3 + xo) & 3), kq = (3 + xo) >> 2;
       const int ng = (vw + 3) >> 2, G = ng * vh;
       const int qy = 64 / ng, rx = 64 - qy * ng;        // a step of 64 groups = qy rows and rx groups
-      int y = lane / ng, lx4 = lane - y * ng;
       const unsigned H = 0x80808080u, T = (unsigned)th * 0x01010101u;
       const unsigned Tl = T & ~H;
       // bytewise a < b (bit 7 of every byte): see above; 0x4D = truth table of (~a & b) | (~(a ^ b) & ~d) over (a, b, d)
@@ -223,87 +248,110 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
         const unsigned d = (a | H) - (bb & ~H);
         return __builtin_amdgcn_bitop3_b32(a, bb, d, 0x4D);
       };
-      for (int g0 = 0; g0 < G; g0 += 64) {
-        unsigned m4 = 0;
-        const int x0 = 4 * lx4;
-        if (g0 + lane < G) {
-          const unsigned* rc = (const unsigned*)(tile + (y + 3) * tpitch) + lx4 + kq;
-          const unsigned* ru = (const unsigned*)(tile + y * tpitch) + lx4 + kq;
-          const unsigned* rd = (const unsigned*)(tile + (y + 6) * tpitch) + lx4 + kq;
-          const unsigned wm = rc[-1], w0 = rc[0], w1 = rc[1], w2 = rc[2];
-          const unsigned u0 = ru[0], u1 = ru[1], d0 = rd[0], d1 = rd[1];
-          unsigned C, L, R, U, D;
-          if (s == 0)
-            C = w0, U = u0, D = d0, L = __builtin_amdgcn_alignbyte(w0, wm, 1), R = __builtin_amdgcn_alignbyte(w1, w0, 3);
-          else if (s == 1)
-            C = __builtin_amdgcn_alignbyte(w1, w0, 1), U = __builtin_amdgcn_alignbyte(u1, u0, 1),
-            D = __builtin_amdgcn_alignbyte(d1, d0, 1), L = __builtin_amdgcn_alignbyte(w0, wm, 2), R = w1;
-          else if (s == 2)
-            C = __builtin_amdgcn_alignbyte(w1, w0, 2), U = __builtin_amdgcn_alignbyte(u1, u0, 2),
-            D = __builtin_amdgcn_alignbyte(d1, d0, 2), L = __builtin_amdgcn_alignbyte(w0, wm, 3),
-            R = __builtin_amdgcn_alignbyte(w2, w1, 1);
-          else
-            C = __builtin_amdgcn_alignbyte(w1, w0, 3), U = __builtin_amdgcn_alignbyte(u1, u0, 3),
-            D = __builtin_amdgcn_alignbyte(d1, d0, 3), L = w0, R = __builtin_amdgcn_alignbyte(w2, w1, 2);
-          // lo = C -sat t: bytes with C >= t keep C - t, the others become 0
-          const unsigned ge = ~ltu(C, T) & H;                 // bit 7: C >= t
-          const unsigned gem = (ge - (ge >> 7)) | ge;          // 0xFF in those bytes
-          const unsigned dif = ((C | H) - Tl) ^ ((C ^ ~T) & H);  // bytewise C - t (mod 256)
-          const unsigned lo = dif & gem;
-          // hi = C +sat t: bytes whose sum carries become 255
-          const unsigned suml = (C & ~H) + Tl;                 // low 7 bits + carry into bit 7
-          const unsigned sum = suml ^ ((C ^ T) & H);           // bytewise C + t (mod 256)
-          const unsigned cy = __builtin_amdgcn_bitop3_b32(C, T, suml, 0xE8) & H;  // carry out = majority(C7, t7, carry in)
-          const unsigned hi = sum | ((cy - (cy >> 7)) | cy);
-          const unsigned dk = (ltu(U, lo) | ltu(D, lo)) & (ltu(L, lo) | ltu(R, lo));
-          const unsigned br = (ltu(hi, U) | ltu(hi, D)) & (ltu(hi, L) | ltu(hi, R));
-          const unsigned f = (dk | br) & H;                    // bit 7 of byte j: pixel x0 + j passes
-          m4 = ((f >> 7) | (f >> 14) | (f >> 21) | (f >> 28)) & 15u;
-          m4 &= (1u << min(vw - x0, 4)) - 1u;
-        }
-        // positions: exclusive prefix over the lanes of popcount(m4) from the ballots of its bits
-        const int cnt = __popc(m4);
-        const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
-        int pos = na + __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0)) +
-                  2 * __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0)) +
-                  4 * __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
-        const unsigned key = (unsigned)((y << 6) | x0);
+      auto pass_a = [&](auto SC) {
+        constexpr int S = decltype(SC)::value;
+        int y = lane / ng, lx4 = lane - y * ng;
+        for (int g0 = 0; g0 < G; g0 += 64) {
+          if (na + 256 > cand_cap) {  // a step appends up to 256 entries: score what is pending first (uniform branch)
+            wave_sync();
+            pass_b();
+            wave_sync();
+            if (na + 256 > cand_cap) {
+              overflow = true;
+              break;
+            }
+          }
+          unsigned m4 = 0;
+          const int x0 = 4 * lx4;
+          if (g0 + lane < G) {
+            const unsigned* rc = (const unsigned*)(tile + (y + 3) * tpitch) + lx4 + kq;
+            const unsigned* ru = (const unsigned*)(tile + y * tpitch) + lx4 + kq;
+            const unsigned* rd = (const unsigned*)(tile + (y + 6) * tpitch) + lx4 + kq;
+            unsigned C, L, R, U, D;
+            if constexpr (S == 0) {
+              const unsigned wm = rc[-1], w0 = rc[0], w1 = rc[1];
+              C = w0, U = ru[0], D = rd[0], L = __builtin_amdgcn_alignbyte(w0, wm, 1), R = __builtin_amdgcn_alignbyte(w1, w0, 3);
+            } else if constexpr (S == 1) {
+              const unsigned wm = rc[-1], w0 = rc[0], w1 = rc[1];
+              C = __builtin_amdgcn_alignbyte(w1, w0, 1), U = __builtin_amdgcn_alignbyte(ru[1], ru[0], 1),
+              D = __builtin_amdgcn_alignbyte(rd[1], rd[0], 1), L = __builtin_amdgcn_alignbyte(w0, wm, 2), R = w1;
+            } else if constexpr (S == 2) {
+              const unsigned wm = rc[-1], w0 = rc[0], w1 = rc[1], w2 = rc[2];
+              C = __builtin_amdgcn_alignbyte(w1, w0, 2), U = __builtin_amdgcn_alignbyte(ru[1], ru[0], 2),
+              D = __builtin_amdgcn_alignbyte(rd[1], rd[0], 2), L = __builtin_amdgcn_alignbyte(w0, wm, 3),
+              R = __builtin_amdgcn_alignbyte(w2, w1, 1);
+            } else {
+              const unsigned w0 = rc[0], w1 = rc[1], w2 = rc[2];
+              C = __builtin_amdgcn_alignbyte(w1, w0, 3), U = __builtin_amdgcn_alignbyte(ru[1], ru[0], 3),
+              D = __builtin_amdgcn_alignbyte(rd[1], rd[0], 3), L = w0, R = __builtin_amdgcn_alignbyte(w2, w1, 2);
+            }
+            // lo = C -sat t: bytes with C >= t keep C - t, the others become 0
+            const unsigned ge = ~ltu(C, T) & H;                 // bit 7: C >= t
+            const unsigned gem = (ge - (ge >> 7)) | ge;          // 0xFF in those bytes
+            const unsigned dif = ((C | H) - Tl) ^ ((C ^ ~T) & H);  // bytewise C - t (mod 256)
+            const unsigned lo = dif & gem;
+            // hi = C +sat t: bytes whose sum carries become 255
+            const unsigned suml = (C & ~H) + Tl;                 // low 7 bits + carry into bit 7
+            const unsigned sum = suml ^ ((C ^ T) & H);           // bytewise C + t (mod 256)
+            const unsigned cy = __builtin_amdgcn_bitop3_b32(C, T, suml, 0xE8) & H;  // carry out = majority(C7, t7, carry in)
+            const unsigned hi = sum | ((cy - (cy >> 7)) | cy);
+            const unsigned dk = (ltu(U, lo) | ltu(D, lo)) & (ltu(L, lo) | ltu(R, lo));
+            const unsigned br = (ltu(hi, U) | ltu(hi, D)) & (ltu(hi, L) | ltu(hi, R));
+            const unsigned f = (dk | br) & H;                    // bit 7 of byte j: pixel x0 + j passes
+            m4 = ((f >> 7) | (f >> 14) | (f >> 21) | (f >> 28)) & 15u;
+            m4 &= (1u << min(vw - x0, 4)) - 1u;
+          }
+          // positions: exclusive prefix over the lanes of popcount(m4) from the ballots of its bits
+          const int cnt = __popc(m4);
+          const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+          int pos = na + __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0)) +
+                    2 * __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0)) +
+                    4 * __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
+          const unsigned key = (unsigned)((y << 6) | x0);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (m4 & (1u << j)) cand[pos++] = (unsigned short)(key + j);
-        na += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-        // the next 64 groups
-        lx4 += rx, y += qy;
-        if (lx4 >= ng) lx4 -= ng, y++;
+          for (int j = 0; j < 4; j++)
+            if (m4 & (1u << j)) cand[pos++] = (unsigned short)(key + j);
+          na += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+          // the next 64 groups
+          lx4 += rx, y += qy;
+          if (lx4 >= ng) lx4 -= ng, y++;
+        }
+      };
+      if (s == 0) pass_a(std::integral_constant<int, 0>());
+      else if (s == 1) pass_a(std::integral_constant<int, 1>());
+      else if (s == 2) pass_a(std::integral_constant<int, 2>());
+      else pass_a(std::integral_constant<int, 3>());
+    }
+    wave_sync();
+    if (!overflow) pass_b();
+    else {
+      // More corners than the list holds (noise, synthetic patterns: never a camera image).  The list is dropped and
+      // the strength of EVERY pixel of the cell is evaluated; pass C then scans the strength tile itself.  Same
+      // result: the compass test is a necessary condition, so the pixels it removes have strength <= th, which
+      // pass C reads as 0 either way.
+      for (int i0 = 0; i0 < npx; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < npx) {
+          const int y = i / vw, x = i - y * vw;
+          sc[(y + 1) * sp + x + 1] = (uint8_t)fast_strength(tile + (y + 3) * tpitch + (x + 3 + xo), tpitch);
+        }
       }
     }
     wave_sync();
-    // ---- pass B: exact strength of the survivors; those above the threshold are compacted in
-    // place (still row-major: a wavefront reads its 64 entries before it writes any)
-    int nc = 0;
-    for (int i0 = 0; i0 < na; i0 += 64) {
-      const int i = i0 + lane;
-      bool pass = false;
-      int p = 0;
-      if (i < na) {
-        p = cand[i];
-        const int y = p >> 6, x = p & 63;
-        const int r = fast_strength(tile + (y + 3) * tpitch + (x + 3 + xo), tpitch);
-        sc[(y + 1) * sp + x + 1] = (uint8_t)r;
-        pass = r > th;
-      }
-      const unsigned long long m = __ballot(pass);
-      if (pass) cand[nc + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
-      nc += __popcll(m);
-    }
-    wave_sync();
-    // ---- pass C: 3x3 non-maximum suppression over the candidates (still in row-major order)
-    for (int i0 = 0; i0 < nc; i0 += 64) {
+    // ---- pass C: 3x3 non-maximum suppression over the corners (still in row-major order)
+    const int nC = overflow ? npx : nc;
+    for (int i0 = 0; i0 < nC; i0 += 64) {
       const int i = i0 + lane;
       bool keep = false;
       unsigned key = 0;
-      if (i < nc) {
-        const int p = cand[i], y = p >> 6, x = p & 63;
+      if (i < nC) {
+        int x, y;
+        if (overflow) {
+          y = i / vw, x = i - y * vw;
+        } else {
+          const int p = cand[i];
+          y = p >> 6, x = p & 63;
+        }
         const uint8_t* s = sc + (y + 1) * sp + x + 1;
         const int r = s[0];
         if (r > th) {
@@ -328,17 +376,18 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
   if (lane == 0) cell_counts[(size_t)b * P.ncells + c] = min(base, P.cell_cap);
 }
 
-// WPB wavefronts per workgroup, each with its own cell and its own slice of LDS (no workgroup barrier anywhere): the
-// CU holds at most 16 workgroups, so one-wavefront workgroups cap the occupancy at 4 wavefronts per SIMD.
-template <int WPB>
-__global__ void __launch_bounds__(64 * WPB)
+// One wavefront (= one workgroup) per cell, no workgroup barrier anywhere.  What the kernel lives on is the number of
+// resident wavefronts: it is a chain of short dependent phases (record -> plane -> tile -> three passes), and a CU takes
+// as many of these workgroups as their LDS allows.  Measured on 1024 images: 6.5 KB of LDS per cell (candidate list
+// sized for the worst case) 2.05 ms, 4.8 KB (list capped, see fast_cell) 1.78 ms, 8.8 KB 2.2 - 2.4 ms -- which is also
+// why a second tile buffer for prefetching the next cell (by LDS-DMA or through registers) lost more than it hid.
+__global__ void __launch_bounds__(64)
 k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __restrict__ cell_keys,
        int* __restrict__ cell_counts, int iniTh, int minTh, int tpitch, int tile_bytes,
-       int score_bytes, int n_images, int lds_per_wave) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint8_t* smem = smem_all + wave * lds_per_wave;
-  const int item = xcd_grouped(blockIdx.x, kXcdRun) * WPB + wave;  // item = image * ncells + cell
+       int score_bytes, int cand_cap, int n_images) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  const int item = xcd_grouped(blockIdx.x, kXcdRun);  // item = image * ncells + cell
   if (item >= P.ncells * n_images) return;
   const int b = item / P.ncells, c = item - b * P.ncells;
   const CellDesc cd = cells[c];
@@ -386,7 +435,7 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
           *(const unsigned*)(src + (size_t)(cd.y0 + r) * pitch + x0a + 4 * dcol);
     }
   }
-  fast_cell(P, cd, b, c, tile, sc, cand, tpitch, iniTh, minTh, lane, cell_keys, cell_counts);
+  fast_cell(P, cd, b, c, tile, sc, cand, cand_cap, tpitch, iniTh, minTh, lane, cell_keys, cell_counts);
 }
 
 // ------------------------------------------------------------------ quadtree
@@ -1013,7 +1062,11 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
   e->tpitch = align_up(max_cw + 3, 4) + 4;
   e->tile_bytes = align_up(e->tpitch * max_ch, 16);
   e->score_bytes = align_up((max_cw - 4) * (max_ch - 4), 16) + 16;
-  e->fast_lds = e->tile_bytes + e->score_bytes + align_up(2 * (max_cw - 6) * (max_ch - 6), 16) + 16;
+  // candidate list: at most 512 entries in LDS (fast_cell scores the pending ones when it fills up and falls back to a
+  // dense evaluation of the cell when even the corners alone do not fit); VIEO_FAST_CAND_CAP lets the tests force both
+  e->fast_cand_cap = std::min((max_cw - 6) * (max_ch - 6), 512);
+  if (const char* cc = getenv("VIEO_FAST_CAND_CAP")) e->fast_cand_cap = std::max(256, atoi(cc));
+  e->fast_lds = e->tile_bytes + e->score_bytes + align_up(2 * e->fast_cand_cap, 16) + 16;
   e->qt_lds = 16 * e->scap_max + (4 + 16 + 4 + 4 + 4) * ncap_max + 64 + (2 * 4 + 8 + 2 * 6) * ncap_max +
               ncap_max + 64;
   // ---- device buffers
@@ -1106,16 +1159,9 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
     set_error("batch too large for one launch");
     return VIEO_E_CAPACITY;
   }
-  // one wavefront per cell.  Measured alternatives that were slower and are gone: a persistent form with the next
-  // cell's tile prefetched in registers (2.4 - 3.3 ms against 2.0 ms per 1024 images: the extra registers cost
-  // occupancy, and the prologue latency it hides is not what bounds the kernel), 2 / 4 independent wavefronts per
-  // workgroup (2.05 - 2.09 ms; again 2.06 / 1.99 against 1.95 with the wavefront index made wave-uniform)
-  {
-    const int lds_w = align_up(e->fast_lds, 16);
-    hipLaunchKernelGGL((k_fast<1>), dim3(xcd_grid((long long)P.ncells * B)), dim3(64), (size_t)lds_w, st, P, I,
-                       e->d_cells.as<CellDesc>(), e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
-                       e->iniTh, e->minTh, e->tpitch, e->tile_bytes, e->score_bytes, B, lds_w);
-  }
+  hipLaunchKernelGGL(k_fast, dim3(xcd_grid((long long)P.ncells * B)), dim3(64), (size_t)align_up(e->fast_lds, 16), st, P, I,
+                     e->d_cells.as<CellDesc>(), e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
+                     e->iniTh, e->minTh, e->tpitch, e->tile_bytes, e->score_bytes, e->fast_cand_cap, B);
   STAMP();
   hipLaunchKernelGGL(k_quadtree, dim3(P.nlevels, B), dim3(256), e->qt_lds, st, P,
                      e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),

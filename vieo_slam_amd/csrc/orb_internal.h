@@ -83,7 +83,7 @@ struct vieo_orb {  // global-scope tag declared in include/vieo_hot.h
   vieo::OrbParams P;
   std::vector<vieo::CellDesc> cells;
   std::vector<vieo::BlurTile> tiles;
-  int tpitch = 0, tile_bytes = 0, score_bytes = 0, fast_lds = 0, qt_lds = 0, ncap_max = 0, scap_max = 0;
+  int tpitch = 0, fast_cand_cap = 0, tile_bytes = 0, score_bytes = 0, fast_lds = 0, qt_lds = 0, ncap_max = 0, scap_max = 0;
   int resize_pitch = 0, resize_lds = 0;
   size_t pyr_img = 0, blur_img = 0;
   vieo::DevBuf d_pyr, d_blur, d_cells, d_tiles, d_xtab, d_ytab, d_cell_keys, d_cell_counts, d_keys,
