@@ -774,6 +774,21 @@ int vieo_track_after_pose_batch_device(int32_t* d_mp_ref, const int32_t* d_obs_k
                                        const void* d_results, int frames_are_vio, int key_cap,
                                        int n_frames, void* d_next_frames, uint8_t* d_taken,
                                        void* stream);
+/* The same with the `close` bit of the observations (vieo_pose_obs.flags bit 0) taken from the depth at which the
+ * point was tracked: d_point_depth[f][p_cap] < close_depth (Frame::mvpMapPoints[i]->mTrackDepth against
+ * max(10, ThDepth), the stereo chi2 gate of the visual-inertial PoseOptimization, include/Optimizer.h:406-490). */
+int vieo_track_build_obs_depth_batch_device(const int32_t* d_mp_ref, const float* d_point_xyz,
+                                            const float* d_point_depth, float close_depth, int p_cap,
+                                            const vieo_keypoint* d_keys, const float* d_uright,
+                                            const int32_t* d_counts, int key_cap, int n_frames,
+                                            int img_first, int img_step, const float* d_inv_sigma2,
+                                            vieo_pose_obs* d_obs, int32_t* d_obs_key, void* d_frames,
+                                            int frames_are_vio, void* stream);
+/* d_held[f][p_cap] = 1 for the entries of frame f's point table that a key holds (the points
+ * Tracking::SearchLocalPoints takes out of the local-map search, src/Tracking.cc:2318-2334). */
+int vieo_track_mark_held_batch_device(const int32_t* d_mp_ref, const int32_t* d_counts, int key_cap,
+                                      int n_frames, int img_first, int img_step, uint8_t* d_held, int p_cap,
+                                      void* stream);
 /* The extractor's own hipStream_t, so the calls above can be chained on it. */
 void* vieo_orb_stream(vieo_orb* e);
 
@@ -822,6 +837,21 @@ typedef struct vieo_track_info {    /* MapPoint::_TrackFastMatchInfo after the c
 
 int vieo_is_in_frustum_batch(const vieo_frustum_frame* h_frame, const vieo_frustum_point* h_points, int n_points,
                              vieo_track_info* h_info);
+/* The head of Tracking::SearchLocalPoints (src/Tracking.cc:2308-2370) for ONE frame whose pose is still in HBM, so
+ * that TrackWithIMU -> TrackLocalMapWithIMU runs as one chain of launches (no host round trip between the first
+ * PoseOptimization and the local-map search): the pose is d_result->base.nav when d_result->base.status == 0, else
+ * d_frame->base.nav, with d_frame->base.Rcb / tcb (h_frame's Rcrw / tcrw / Ow are ignored, the rest of h_frame is used
+ * as in vieo_is_in_frustum_batch); isInFrustum of the n_points candidates; their window queries in the order of
+ * SearchByProjection(Frame&, vector<MapPoint*>&, th, th_far) (src/ORBmatcher.cc:237-266): d_queries[p * n_cams + k]
+ * is the k-th camera that sees candidate p (flags = 0 in the unused slots), *d_nq = n_points * n_cams.
+ * d_alias[p] >= 0 (may be NULL): candidate p is the same map point as entry d_alias[p] of the frame's point table;
+ * it gets no query when d_held[d_alias[p]] != 0 (vieo_track_mark_held_batch_device).  d_track_depth[p] = mTrackDepth
+ * (-1 when no camera sees the point).  d_scale: scalepyrinfo_.vscalefactor_ (n_levels floats). */
+int vieo_track_local_queries_device(const vieo_frustum_frame* h_frame, const vieo_vio_frame* d_frame,
+                                    const vieo_vio_result* d_result, const vieo_frustum_point* d_points,
+                                    const uint8_t* d_desc, const int32_t* d_alias, const uint8_t* d_held, int n_points,
+                                    float th, float th_far, const float* d_scale, vieo_proj_query* d_queries,
+                                    float* d_track_depth, int32_t* d_nq, void* stream);
 
 /* void MapPoint::ComputeDistinctiveDescriptors() (src/MapPoint.cc:314-378) for a batch of points: point p owns
  * the descriptor rows [h_first[p], h_first[p + 1]) of h_descriptors (its observations in map order); h_best[p]

@@ -61,3 +61,34 @@ def test_gpu_replay_ate_vs_oracle(oracle):
     assert (io == ih).mean() > 0.97 and np.abs(io - ih).max() <= 3, np.abs(io - ih).max()
     print("replay: ATE vs oracle %.3e m (max %.3e), max err vs truth %.2e m, %d / %d frames with equal inlier counts"
           % (ate, dmax, err, int((io == ih).sum()), n - 1))
+
+
+@pytest.mark.gpu
+def test_gpu_chained_replay_one_sync_per_frame(oracle):
+    """The frame as one chain of launches (replay.ChainedReplay: one copy up, extraction ... second PoseOptimization
+    back to back on the device entry points with isInFrustum / query construction reading the first optimisation's
+    pose in HBM, one copy back) against the oracle's stage-by-stage run and against the stage-by-stage run on the C-ABI."""
+    from tests.replay_oracle import OracleStages
+    n = 100
+    seq = replay.Sequence(1, n)
+    Ro = replay.Replay(seq, OracleStages(oracle))
+    to = Ro.run(n)
+    Rh = replay.Replay(seq, replay.HipStages())
+    th = Rh.run(n)
+    Rc = replay.ChainedReplay(seq, replay.HipStages())
+    tc = Rc.run(n)
+    assert len(tc) == n and Rc.stats["lba"] == Ro.stats["lba"] == 9
+    assert Rc.stats["fallbacks"] == 0  # no frame needed the stage-by-stage path
+    ate = replay.ate_between(tc, to)
+    dmax = np.linalg.norm(tc["p"] - to["p"], axis=1).max()
+    assert ate <= 1e-4 and dmax <= 1e-4, (ate, dmax)
+    rot = max(synth_ba.pose_error(tc[k], to[k])[1] for k in range(n))
+    assert rot <= 1e-4, rot
+    # against the stage-by-stage run on the same kernels: the same decisions on (nearly) every frame
+    mh, mc = np.array(Rh.stats["n_matches"]), np.array(Rc.stats["n_matches"])
+    ih, ic = np.array(Rh.stats["n_inliers"]), np.array(Rc.stats["n_inliers"])
+    assert (mh == mc).all(1).mean() > 0.97 and np.abs(mh - mc).max() <= 3, (mh - mc)
+    assert (ih == ic).mean() > 0.97 and np.abs(ih - ic).max() <= 3, (ih - ic)
+    assert replay.ate_between(tc, th) <= 1e-5
+    print("chained replay: ATE vs oracle %.3e m, vs stage-by-stage %.3e m, %.2f ms per frame (stage-by-stage %.2f)"
+          % (ate, replay.ate_between(tc, th), np.mean(Rc.stats["ms_frames"]), np.mean(Rh.stats["ms_frames"])))

@@ -16,14 +16,9 @@ struct FrustumDev {
   CamD cams[4];
 };
 
-__global__ void __launch_bounds__(256)
-k_in_frustum(const FrustumDev* __restrict__ fd, const vieo_frustum_point* __restrict__ pts, int n,
-             vieo_track_info* __restrict__ out) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= n) return;
-  const vieo_frustum_frame& F = fd->F;
-  const vieo_frustum_point P = pts[m];
-  vieo_track_info T;
+// Frame::isInFrustum for one point (Frame.cc:335-416): the cameras that see it, in push order
+__device__ __forceinline__ void frustum_eval(const vieo_frustum_frame& F, const CamD* cams, const vieo_frustum_point& P,
+                                             vieo_track_info& T) {
   memset(&T, 0, sizeof(T));
   const float maxDistance = 1.2f * P.max_distance, minDistance = 0.8f * P.min_distance;
   const float* R = F.Rcrw;
@@ -42,7 +37,7 @@ k_in_frustum(const FrustumDev* __restrict__ fd, const vieo_frustum_point* __rest
     if (PcZ < 0.0f) continue;
     const float invz = 1.0f / PcZ;
     float u, v;
-    const CamD& C = fd->cams[cami];
+    const CamD& C = cams[cami];
     if (!F.use_distort) {
       const float fx = (float)C.fx, fy = (float)C.fy, cx = (float)C.cx, cy = (float)C.cy;
       const float p0 = Pc[0] * invz, p1 = Pc[1] * invz;
@@ -81,7 +76,92 @@ k_in_frustum(const FrustumDev* __restrict__ fd, const vieo_frustum_point* __rest
   }
   T.n = cnt;
   T.track_depth = cnt ? sum_depth / cnt : -1.f;
+}
+
+__global__ void __launch_bounds__(256)
+k_in_frustum(const FrustumDev* __restrict__ fd, const vieo_frustum_point* __restrict__ pts, int n,
+             vieo_track_info* __restrict__ out) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= n) return;
+  const vieo_frustum_point P = pts[m];
+  vieo_track_info T;
+  frustum_eval(fd->F, fd->cams, P, T);
   out[m] = T;
+}
+
+// The head of Tracking::SearchLocalPoints (src/Tracking.cc:2308-2370) for a frame whose pose is still in HBM: the
+// pose of the first PoseOptimization (its result when it succeeded, the frame's own estimate otherwise) -> Tcw in
+// float as Frame::isInFrustum reads it -> isInFrustum of every candidate -> the window queries of
+// SearchByProjection(Frame&, vector<MapPoint*>&) (ORBmatcher.cc:237-266), point-major with n_cams slots per point
+// (slots of cameras that do not see the point carry flags = 0).  A candidate that aliases an entry of the frame's
+// point table which a key already holds (mbTrackInView = false for points matched in the frame, Tracking.cc:2318-
+// 2334) gets no query.  One lane per point.
+__global__ void __launch_bounds__(256)
+k_track_local_queries(FrustumDev tmpl, const vieo_vio_frame* __restrict__ frame, const vieo_vio_result* __restrict__ result,
+                      const vieo_frustum_point* __restrict__ pts, const uint8_t* __restrict__ desc,
+                      const int32_t* __restrict__ alias, const uint8_t* __restrict__ held, int n, float th, float th_far,
+                      const float* __restrict__ scale, vieo_proj_query* __restrict__ queries,
+                      float* __restrict__ track_depth, int32_t* __restrict__ nq) {
+  __shared__ vieo_frustum_frame sF;
+  if (threadIdx.x == 0) {
+    sF = tmpl.F;
+    const vieo_navstate& nav = result->base.status == 0 ? result->base.nav : frame->base.nav;
+    // Tcw = Tcb * Twb^-1 in double, cast to float (Frame.cc:348-351 reads Tcw_ as float)
+    double Rwb[9];
+    {
+      const double qw = nav.q[0], qx = nav.q[1], qy = nav.q[2], qz = nav.q[3];
+      const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+      const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx;
+      const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+      Rwb[0] = 1 - (tyy + tzz), Rwb[1] = txy - twz, Rwb[2] = txz + twy;
+      Rwb[3] = txy + twz, Rwb[4] = 1 - (txx + tzz), Rwb[5] = tyz - twx;
+      Rwb[6] = txz - twy, Rwb[7] = tyz + twx, Rwb[8] = 1 - (txx + tyy);
+    }
+    const double* Rcb = frame->base.Rcb;
+    double Rcw[9], tcw[3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Rcw[r * 3 + c] = Rcb[r * 3] * Rwb[c * 3] + Rcb[r * 3 + 1] * Rwb[c * 3 + 1] + Rcb[r * 3 + 2] * Rwb[c * 3 + 2];
+    for (int r = 0; r < 3; ++r)
+      tcw[r] = frame->base.tcb[r] - (Rcw[r * 3] * nav.p[0] + Rcw[r * 3 + 1] * nav.p[1] + Rcw[r * 3 + 2] * nav.p[2]);
+    for (int i = 0; i < 9; ++i) sF.Rcrw[i] = (float)Rcw[i];
+    for (int r = 0; r < 3; ++r) {
+      sF.tcrw[r] = (float)tcw[r];
+      sF.Ow[r] = (float)(-(Rcw[r] * tcw[0] + Rcw[3 + r] * tcw[1] + Rcw[6 + r] * tcw[2]));
+    }
+    if (blockIdx.x == 0) *nq = n * tmpl.F.n_cams;
+  }
+  __syncthreads();
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= n) return;
+  const vieo_frustum_point P = pts[m];
+  vieo_track_info T;
+  frustum_eval(sF, tmpl.cams, P, T);
+  const int S = sF.n_cams;
+  int cnt = T.n;
+  if (th_far > 0.f && T.track_depth > th_far) cnt = 0;
+  if (alias && alias[m] >= 0 && held[alias[m]]) cnt = 0;
+  track_depth[m] = T.track_depth;
+  const uint4* d = (const uint4*)(desc + (size_t)m * 32);
+  const uint4 d0 = d[0], d1 = d[1];
+  for (int k = 0; k < S; ++k) {
+    vieo_proj_query q;
+    memset(&q, 0, sizeof(q));
+    if (k < cnt) {
+      float u = 0, v = 0, ur = 0, vc = 0;
+      int lvl = 0, cam = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j == k) u = T.u[j], v = T.v[j], ur = T.ur[j], vc = T.viewcos[j], lvl = T.level[j], cam = T.cam[j];
+      float r = vc > 0.998f ? 2.5f : 4.0f;  // RadiusByViewingCos, then the factor, then the level's scale
+      if (th != 1.0f) r = r * th;
+      q.u = u, q.v = v, q.ur = ur;
+      q.radius = r * scale[lvl];
+      q.level_min = lvl - 1, q.level_max = lvl, q.angle = 0.f;
+      q.flags = 3 | (cam << 8);
+      ((uint4*)q.desc)[0] = d0, ((uint4*)q.desc)[1] = d1;
+    }
+    queries[(size_t)m * S + k] = q;
+  }
 }
 
 static const int kMaxObsLds = 128;      // rows of the N x N distance table a wavefront keeps in LDS
@@ -234,6 +314,36 @@ int vieo_is_in_frustum_batch(const vieo_frustum_frame* h_frame, const vieo_frust
                      S.b.as<vieo_frustum_point>(), n_points, S.c.as<vieo_track_info>());
   VIEO_HIP_CHECK(hipGetLastError());
   VIEO_HIP_CHECK(hipMemcpy(h_info, S.c.p, (size_t)n_points * sizeof(vieo_track_info), hipMemcpyDeviceToHost));
+  return VIEO_OK;
+}
+
+int vieo_track_local_queries_device(const vieo_frustum_frame* h_frame, const vieo_vio_frame* d_frame,
+                                    const vieo_vio_result* d_result, const vieo_frustum_point* d_points,
+                                    const uint8_t* d_desc, const int32_t* d_alias, const uint8_t* d_held, int n_points,
+                                    float th, float th_far, const float* d_scale, vieo_proj_query* d_queries,
+                                    float* d_track_depth, int32_t* d_nq, void* stream) {
+  if (!h_frame || !d_frame || !d_result || n_points < 0 || !d_scale || !d_nq ||
+      (n_points > 0 && (!d_points || !d_desc || !d_queries || !d_track_depth)) || (d_alias && !d_held))
+    return VIEO_E_INVALID;
+  if (h_frame->n_cams < 1 || h_frame->n_cams > 4 || !h_frame->cams || h_frame->n_levels <= 0) {
+    set_error("SearchLocalPoints: n_cams = %d (1..4) with cameras and n_levels > 0", h_frame->n_cams);
+    return VIEO_E_INVALID;
+  }
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  FrustumDev fd;
+  memset(&fd, 0, sizeof(fd));
+  fd.F = *h_frame;
+  fd.F.cams = nullptr;
+  for (int c = 0; c < h_frame->n_cams; ++c)
+    if (!cam_from_abi(h_frame->cams[c], fd.cams[c])) {
+      set_error("SearchLocalPoints: camera %d has an unknown model or coefficient count", c);
+      return VIEO_E_INVALID;
+    }
+  hipLaunchKernelGGL(k_track_local_queries, dim3(std::max(1, (n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fd,
+                     d_frame, d_result, d_points, d_desc, d_alias, d_held, n_points, th, th_far, d_scale, d_queries,
+                     d_track_depth, d_nq);
+  VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
 

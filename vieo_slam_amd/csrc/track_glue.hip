@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256)
 k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ point_xyz, int p_cap,
                   const vieo_keypoint* __restrict__ keys, const float* __restrict__ uright,
                   const int* __restrict__ counts, int key_cap, int img_first, int img_step,
-                  const float* __restrict__ inv_sigma2, float close_depth,
+                  const float* __restrict__ inv_sigma2, const float* __restrict__ point_depth, float close_depth,
                   vieo_pose_obs* __restrict__ obs, int* __restrict__ obs_key, uint8_t* frames_base,
                   size_t frame_stride, size_t nobs_offset, size_t obsbegin_offset) {
   __shared__ int s_wsum[4];
@@ -66,7 +66,9 @@ k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ poin
       const vieo_keypoint k = K[i];
       o.u = k.x, o.v = k.y, o.ur = ur[i];
       o.inv_sigma2 = inv_sigma2[k.octave];
-      o.flags = 0;
+      // bit 0: the point was tracked at less than close_depth (the stereo chi2 gate of the visual-inertial
+      // PoseOptimization, Optimizer.h:406-490 / mTrackDepth)
+      o.flags = point_depth ? (point_depth[(size_t)f * p_cap + m[i]] < close_depth ? 1 : 0) : 0;
       obs[(size_t)f * key_cap + pos] = o;
       obs_key[(size_t)f * key_cap + pos] = i;
     }
@@ -79,7 +81,21 @@ k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ poin
     *(int*)(fr + nobs_offset) = s_base;
     *(int*)(fr + obsbegin_offset) = f * key_cap;
   }
-  (void)close_depth;
+}
+
+// held[f][p_cap]: 1 for every entry of the frame's point table that a key holds (after the outliers of the last
+// PoseOptimization were dropped).  One workgroup per frame.
+__global__ void __launch_bounds__(256)
+k_track_mark_held(const int* __restrict__ mp_ref, const int* __restrict__ counts, int key_cap, int img_first,
+                  int img_step, uint8_t* __restrict__ held, int p_cap) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  uint8_t* h = held + (size_t)f * p_cap;
+  for (int i = tid; i < p_cap; i += 256) h[i] = 0;
+  __syncthreads();
+  const int N = min(counts[2 * (img_first + f * img_step)], key_cap);
+  const int* m = mp_ref + (size_t)f * key_cap;
+  for (int i = tid; i < N; i += 256)
+    if (m[i] >= 0 && m[i] < p_cap) h[m[i]] = 1;
 }
 
 // after PoseOptimization: drop outlier matches, export the "claimed" flags of the next search,
@@ -136,8 +152,38 @@ int vieo_track_build_obs_batch_device(const int32_t* d_mp_ref, const float* d_po
   const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
   hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
                      d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
-                     d_inv_sigma2, 0.f, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
+                     d_inv_sigma2, (const float*)nullptr, 0.f, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
                      base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin));
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_build_obs_depth_batch_device(const int32_t* d_mp_ref, const float* d_point_xyz,
+                                            const float* d_point_depth, float close_depth, int p_cap,
+                                            const vieo_keypoint* d_keys, const float* d_uright,
+                                            const int32_t* d_counts, int key_cap, int n_frames,
+                                            int img_first, int img_step, const float* d_inv_sigma2,
+                                            vieo_pose_obs* d_obs, int32_t* d_obs_key, void* d_frames,
+                                            int frames_are_vio, void* stream) {
+  if (!d_mp_ref || !d_point_xyz || !d_point_depth || !d_keys || !d_uright || !d_counts || !d_inv_sigma2 || !d_obs ||
+      !d_obs_key || !d_frames || key_cap <= 0 || n_frames <= 0)
+    return VIEO_E_INVALID;
+  const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
+  const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
+                     d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
+                     d_inv_sigma2, d_point_depth, close_depth, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
+                     base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin));
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_mark_held_batch_device(const int32_t* d_mp_ref, const int32_t* d_counts, int key_cap,
+                                      int n_frames, int img_first, int img_step, uint8_t* d_held, int p_cap,
+                                      void* stream) {
+  if (!d_mp_ref || !d_counts || !d_held || key_cap <= 0 || n_frames <= 0 || p_cap <= 0) return VIEO_E_INVALID;
+  hipLaunchKernelGGL(k_track_mark_held, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref, d_counts,
+                     key_cap, img_first, img_step, d_held, p_cap);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }

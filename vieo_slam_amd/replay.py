@@ -486,8 +486,12 @@ class Replay:
         self.map_updated = False
         self.stats["n_matches"].append((int(n1), int(n2)))
         self.stats["n_inliers"].append(int(r2["base"]["n_inliers"]))
-        # ---- NeedNewKeyFrame / CreateNewKeyFrame / LocalMapping (single-threaded: runs before the next frame)
-        self.kf_imu = getattr(self, "kf_imu", None)
+        return self._finish_frame(k, f, t0)
+
+    # ---- NeedNewKeyFrame / CreateNewKeyFrame / LocalMapping (single-threaded: runs before the next frame)
+    def _finish_frame(self, k, f, t0):
+        S = self.S
+        n1, n2 = self.stats["n_matches"][-1]
         if k % self.kf_every == 0:
             kf_prev = self.kfs[-1]
             im_kf, prv_kf, st = S.preintegrate(self.seq.noise, self.seq.imu_between(kf_prev.t, f.t), kf_prev.t, f.t,
@@ -531,6 +535,241 @@ class Replay:
             self.step(k)
         return np.array(self.traj, NAVSTATE_DTYPE)
 
+
+# ---------------------------------------------------------------- one frame as ONE chain of launches
+class _Arena:
+    """A pinned host block and its device twin with the same layout: fields are carved out once, the block travels
+    in one asynchronous copy."""
+
+    def __init__(self, nbytes):
+        import ctypes
+        from ._lib import DeviceBuffer, check, lib
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        check(lib().vieo_host_alloc_pinned(ctypes.byref(p), self.nbytes), "pinned")
+        self.h_ptr = p.value
+        self.h = np.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(self.h_ptr))
+        self.dev = DeviceBuffer(self.nbytes)
+        self.d_ptr = self.dev.ptr
+        self.off = 0
+
+    def field(self, dtype, count):
+        dtype = np.dtype(dtype)
+        self.off = (self.off + 255) & ~255
+        nb = dtype.itemsize * int(count)
+        assert self.off + nb <= self.nbytes, "arena too small"
+        view = self.h[self.off:self.off + nb].view(dtype)
+        dptr = self.d_ptr + self.off
+        self.off += nb
+        return view, dptr
+
+    def free(self):
+        from ._lib import lib
+        if self.h_ptr:
+            lib().vieo_host_free_pinned(self.h_ptr)
+            self.h_ptr = None
+            self.dev.free()
+
+
+class ChainedReplay(Replay):
+    """The same replay with a frame's tracking as ONE chain of launches on one stream: the frame's inputs go up in one
+    copy from pinned memory, extraction (both images) -> ComputeStereoMatches -> SearchByProjection(last frame) ->
+    PoseOptimization -> isInFrustum + query construction from the optimised pose (vieo_track_local_queries_device) ->
+    SearchByProjection(local map) -> PoseOptimization(bComputeMarg) run back to back on the device-pointer entry
+    points with the bookkeeping between them in the vieo_track_* glue kernels, and the results come back in one copy;
+    the host synchronises once per frame.  The local-map candidates are all points of the local key frames (the ones a
+    key of the frame already holds are taken out on the device, as Tracking::SearchLocalPoints does).  Two rare
+    branches are not worth a device form and re-run the frame through the stage-by-stage path of the base class: fewer
+    than 20 matches in the first search (the wider window of Tracking.cc:301-309) and a failed first optimisation."""
+
+    CCAP = 16384  # local-map candidates per frame
+
+    def __init__(self, seq, stages, **kw):
+        super().__init__(seq, stages, **kw)
+        import ctypes
+        from ._lib import check, lib
+        from .ba_types import PROJ_QUERY_DTYPE, SBP_CAMERA_DTYPE, VIO_RESULT_DTYPE
+        from .orb_extractor import KEYPOINT_DTYPE, ORBextractor
+        self.L = lib()
+        self.ext = ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
+        self.stream = self.L.vieo_orb_stream(self.ext._h)
+        self.cap = cap = self.ext.max_keypoints()
+        ccap = self.CCAP
+        self.pcap = cap + ccap
+        A = self.ain = _Arena(2 * W * H + 64 * cap + 3672 * 2 + 12 * self.pcap + 4 * self.pcap + (32 + 32 + 4) * ccap + (1 << 16))
+        self.h_img, self.d_img = A.field(np.uint8, 2 * W * H)
+        self.h_pts, self.d_pts = A.field(LAST_FRAME_POINT_DTYPE, cap)
+        self.h_npts, self.d_npts = A.field(np.int32, 4)
+        self.h_cam, self.d_cam = A.field(SBP_CAMERA_DTYPE, 1)
+        self.h_f1, self.d_f1 = A.field(VIO_FRAME_DTYPE, 1)
+        self.h_f2, self.d_f2 = A.field(VIO_FRAME_DTYPE, 1)
+        self.h_xyz, self.d_xyz = A.field(np.float32, 3 * self.pcap)
+        self.h_dep, self.d_dep = A.field(np.float32, self.pcap)
+        self.h_cpt, self.d_cpt = A.field(FRUSTUM_POINT_DTYPE, ccap)
+        self.h_cdesc, self.d_cdesc = A.field(np.uint8, 32 * ccap)
+        self.h_alias, self.d_alias = A.field(np.int32, ccap)
+        self.h_const, self.d_const = A.field(np.float32, 32)  # inv_sigma2[16], scale[16]
+        self.h_const[:NLEVELS] = self.inv_sigma2
+        self.h_const[16:16 + NLEVELS] = self.scale
+        self.d_isig, self.d_scale = self.d_const, self.d_const + 64
+        O = self.aout = _Arena((28 + 32) * 2 * cap + 16 * cap + 2 * VIO_RESULT_DTYPE.itemsize + 3672 + 4 * self.pcap + (1 << 14))
+        self.o_cnt, self.d_cnt = O.field(np.int32, 4)
+        self.o_kp, self.d_kp = O.field(KEYPOINT_DTYPE, 2 * cap)
+        self.o_desc, self.d_desc = O.field(np.uint8, 2 * cap * 32)
+        self.o_ur, self.d_ur = O.field(np.float32, cap)
+        self.o_dp, self.d_dp = O.field(np.float32, cap)
+        self.o_mpref, self.d_mpref = O.field(np.int32, cap)
+        self.o_obskey, self.d_obskey = O.field(np.int32, cap)
+        self.o_outl, self.d_outl = O.field(np.uint8, cap)
+        self.o_r1, self.d_r1 = O.field(VIO_RESULT_DTYPE, 1)
+        self.o_r2, self.d_r2 = O.field(VIO_RESULT_DTYPE, 1)
+        self.o_nm, self.d_nm = O.field(np.int32, 4)
+        self.o_f2, self.d_f2out = O.field(VIO_FRAME_DTYPE, 1)
+        self.o_cdep, self.d_cdep = O.field(np.float32, ccap)
+        self.o_nq, self.d_nq = O.field(np.int32, 4)
+        from ._lib import DeviceBuffer
+        self.d_q1, self.d_q2 = DeviceBuffer(64 * cap), DeviceBuffer(64 * ccap)
+        self.d_assign, self.d_taken, self.d_held = DeviceBuffer(4 * cap), DeviceBuffer(cap), DeviceBuffer(self.pcap)
+        self.d_obs = DeviceBuffer(32 * cap)
+        self.bounds = (ctypes.c_float * 4)(*BOUNDS.tolist())
+        self.ff = np.zeros(1, FRUSTUM_FRAME_DTYPE)
+        ff = self.ff[0]
+        ff["n_cams"], ff["use_distort"], ff["cams"] = 1, 0, self._pinhole().ctypes.data
+        ff["Tcr"][0] = np.eye(4)[:3].reshape(-1)
+        ff["bounds"][0] = BOUNDS
+        ff["bf"], ff["n_levels"], ff["viewing_cos_limit"] = sc.BF, NLEVELS, 0.5
+        ff["log_scale_factor"] = np.float32(np.log(np.float32(SCALE)))
+        self.stats["fallbacks"] = 0
+
+    def _all_local_points(self):
+        out, seen = [], set()
+        for k in self.kfs[-self.n_local_kfs:]:
+            for m in k.mp_ref[k.mp_ref >= 0]:
+                m = int(m)
+                if m not in seen and not self.mp_bad[m]:
+                    seen.add(m)
+                    out.append(m)
+        return np.array(out, np.int64)
+
+    def step(self, k):
+        from ._lib import check
+        t0 = time.perf_counter()
+        L, last, cap, st = self.L, self.last, self.cap, self.stream
+        ref_nav = self.kfs[-1].nav if self.map_updated else last.nav
+        prior = None if self.map_updated else last.prior
+        t_ref = self.kfs[-1].t if self.map_updated else last.t
+        t = self.seq.time(k)
+        im, prv, stt = self.S.preintegrate(self.seq.noise, self.seq.imu_between(t_ref, t), t_ref, t, ref_nav["bg"],
+                                           ref_nav["ba"])
+        assert stt == 0, "IMU pre-integration failed"
+        nav_pred = self.predict(ref_nav, im)
+        Tcw, _, _ = _Tcw_of(nav_pred, self.Tbc)
+        Tcw_last, _, _ = _Tcw_of(last.nav, self.Tbc)
+        # ---- the frame's inputs, written straight into the pinned block
+        Li, Ri = self.seq.images(k)
+        self.h_img[:W * H] = Li.reshape(-1)
+        self.h_img[W * H:] = Ri.reshape(-1)
+        has = (last.mp_ref >= 0) & ~last.outlier
+        has[has] &= ~self.mp_bad[last.mp_ref[has]]
+        nl = last.N
+        Xw = np.zeros((nl, 3), np.float32)
+        Xw[has] = self.mp_X[last.mp_ref[has]]
+        pts = frontend.make_last_frame_points(last.keys, np.zeros((nl, 32), np.uint8), Xw, has, True)
+        pts["desc"][has] = self.mp_desc[last.mp_ref[has]]
+        self.h_pts[:nl] = pts
+        self.h_npts[0] = nl
+        self.h_cam[0] = frontend.make_sbp_camera(Tcw, Tcw_last, K, BOUNDS, sc.BF, sc.BASELINE, self.th_last, self.scale)[0]
+        self.h_f1[0] = self._vio_frame(nav_pred, ref_nav, im, prior, t - t_ref, False)[0]
+        self.h_f2[0] = self._vio_frame(nav_pred, ref_nav, im, prior, t - t_ref, True)[0]
+        xyz = self.h_xyz.reshape(-1, 3)
+        xyz[:nl] = Xw
+        self.h_dep[:nl] = last.track_depth
+        cand = self._all_local_points()
+        nc = len(cand)
+        assert nc <= self.CCAP, "more local-map candidates than the chained replay holds"
+        if nc:
+            xyz[cap:cap + nc] = self.mp_X[cand]
+            cp = self.h_cpt[:nc]
+            cp["Xw"], cp["normal"] = self.mp_X[cand], self.mp_normal[cand]
+            cp["max_distance"], cp["min_distance"] = self.mp_maxd[cand], self.mp_mind[cand]
+            self.h_cdesc[:32 * nc] = self.mp_desc[cand].reshape(-1)
+            where = np.full(len(self.mp_X), -1, np.int32)  # map point -> entry of the last frame's table
+            lk = np.nonzero(has)[0]
+            where[last.mp_ref[lk[::-1]]] = lk[::-1]
+            self.h_alias[:nc] = where[cand]
+        # ---- one copy up, the chain, one copy back
+        t1 = time.perf_counter()
+        check(L.vieo_memcpy_h2d_async(self.ain.d_ptr, self.ain.h_ptr, self.ain.off, st))
+        check(L.vieo_pose_set_camera_mode(1))
+        check(L.vieo_pose_set_encoder_mode(1))
+        try:
+            self.ext.extract_batch_device(self.d_img, 2, W, H, W, W * H, self.d_kp, self.d_desc, cap, self.d_cnt)
+            check(L.vieo_stereo_match_rectified_batch_device(self.ext._h, 1, self.d_kp, self.d_desc, self.d_cnt, cap,
+                                                             sc.BASELINE, sc.BF, self.d_ur, self.d_dp), "stereo")
+            check(L.vieo_sbp_project_last_frame_batch_device(self.d_pts, self.d_npts, cap, 1, self.d_cam, self.d_q1.ptr, st))
+            check(L.vieo_search_by_projection_batch_device(0, self.d_q1.ptr, self.d_npts, cap, 1, self.d_kp, self.d_ur,
+                                                           self.d_desc, None, self.d_cnt, cap, 0, 2, self.bounds, 0.9, 1,
+                                                           self.d_assign.ptr, self.d_nm, st), "sbp1")
+            check(L.vieo_track_merge_assign_batch_device(self.d_assign.ptr, self.d_mpref, self.d_cnt, cap, 1, 0, 2, 0, 1, st))
+            close = float(max(10.0, TH_DEPTH))
+            check(L.vieo_track_build_obs_depth_batch_device(self.d_mpref, self.d_xyz, self.d_dep, close, self.pcap, self.d_kp,
+                                                            self.d_ur, self.d_cnt, cap, 1, 0, 2, self.d_isig, self.d_obs.ptr,
+                                                            self.d_obskey, self.d_f1, 1, st))
+            check(L.vieo_pose_optimization_vio_batch_device(self.d_f1, 1, self.d_obs.ptr, self.d_outl, self.d_r1, st), "pose1")
+            check(L.vieo_track_after_pose_batch_device(self.d_mpref, self.d_obskey, self.d_outl, self.d_f1, self.d_r1, 1, cap,
+                                                       1, self.d_f2, self.d_taken.ptr, st))
+            check(L.vieo_track_mark_held_batch_device(self.d_mpref, self.d_cnt, cap, 1, 0, 2, self.d_held.ptr, self.pcap, st))
+            check(L.vieo_track_local_queries_device(self.ff.ctypes.data, self.d_f1, self.d_r1, self.d_cpt, self.d_cdesc,
+                                                    self.d_alias, self.d_held.ptr, nc, self.th_local, 0.0, self.d_scale,
+                                                    self.d_q2.ptr, self.d_dep + 4 * cap, self.d_nq, st), "local queries")
+            check(L.vieo_search_by_projection_batch_device(1, self.d_q2.ptr, self.d_nq, self.CCAP, 1, self.d_kp, self.d_ur,
+                                                           self.d_desc, self.d_taken.ptr, self.d_cnt, cap, 0, 2, self.bounds,
+                                                           0.8, 1, self.d_assign.ptr, self.d_nm + 4, st), "sbp2")
+            check(L.vieo_track_merge_assign_batch_device(self.d_assign.ptr, self.d_mpref, self.d_cnt, cap, 1, 0, 2, cap, 0, st))
+            check(L.vieo_track_build_obs_depth_batch_device(self.d_mpref, self.d_xyz, self.d_dep, close, self.pcap, self.d_kp,
+                                                            self.d_ur, self.d_cnt, cap, 1, 0, 2, self.d_isig, self.d_obs.ptr,
+                                                            self.d_obskey, self.d_f2, 1, st))
+            check(L.vieo_pose_optimization_vio_batch_device(self.d_f2, 1, self.d_obs.ptr, self.d_outl, self.d_r2, st), "pose2")
+        finally:
+            check(L.vieo_pose_set_camera_mode(0))
+            check(L.vieo_pose_set_encoder_mode(0))
+        check(L.vieo_memcpy_d2h_async(self.aout.h_ptr, self.aout.d_ptr, self.aout.off, st))
+        check(L.vieo_memcpy_d2h_async(self.o_f2.ctypes.data, self.d_f2, VIO_FRAME_DTYPE.itemsize, st))
+        check(L.vieo_memcpy_d2h_async(self.o_cdep.ctypes.data, self.d_dep + 4 * cap, 4 * max(nc, 1), st))
+        t2 = time.perf_counter()
+        check(L.vieo_stream_synchronize(st))
+        t3 = time.perf_counter()
+        self.stats.setdefault("ms_chain", []).append((1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)))
+        # ---- the frame as the stage-by-stage path leaves it
+        r1, r2 = self.o_r1[0], self.o_r2[0]
+        n1, n2 = int(self.o_nm[0]), int(self.o_nm[1])
+        if n1 < 20 or int(r1["base"]["status"]) != 0:
+            self.stats["fallbacks"] += 1
+            return super().step(k)
+        f = _Frame()
+        f.k, f.t = k, t
+        N = f.N = int(min(self.o_cnt[0], cap))
+        f.keys, f.desc = self.o_kp[:N].copy(), self.o_desc[:32 * N].reshape(N, 32).copy()
+        f.uright, f.depth = self.o_ur[:N].copy(), self.o_dp[:N].copy()
+        tab = self.o_mpref[:N]
+        f.mp_ref = np.full(N, -1, np.int64)
+        f.track_depth = np.full(N, np.inf, np.float32)
+        a = np.nonzero((tab >= 0) & (tab < cap))[0]
+        f.mp_ref[a] = last.mp_ref[tab[a]]
+        f.track_depth[a] = last.track_depth[tab[a]]
+        b = np.nonzero(tab >= cap)[0]
+        f.mp_ref[b] = cand[tab[b] - cap]
+        f.track_depth[b] = self.o_cdep[tab[b] - cap]
+        nobs = int(self.o_f2[0]["base"]["n_obs"])
+        f.outlier = np.zeros(N, bool)
+        f.outlier[self.o_obskey[:nobs][self.o_outl[:nobs] != 0]] = True
+        nav1 = r1["base"]["nav"]
+        f.nav = (r2["base"]["nav"] if int(r2["base"]["status"]) == 0 else nav1).copy()
+        f.prior = (f.nav.copy(), r2["H_marg"].copy()) if int(r2["has_marg"]) else None
+        self.map_updated = False
+        self.stats["n_matches"].append((n1, n2))
+        self.stats["n_inliers"].append(int(r2["base"]["n_inliers"]))
+        return self._finish_frame(k, f, t0)
 
 def ate_between(traj_a, traj_b):
     """RMSE of the position differences of two trajectories of the same frames (no alignment: same world frame)"""
