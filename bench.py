@@ -21,7 +21,7 @@ JSON line.
 Besides the batched headline the line carries
   single_stream: the SEQUENTIAL replay of vieo_slam_amd/replay.py (frame t's pose, map points and marginal prior feed
       frame t+1, one LocalBundleAdjustmentNavStatePRV per 10 frames with write-back) on ONE stream of frames through
-      the host-pointer C-ABI entry points (every call carries its own H2D / D2H): ms per frame, frames/s, and the ATE of
+      the C-ABI, a frame's tracking as one chain of launches (one copy up, one back): ms per frame, frames/s, and the ATE of
       that trajectory against the same replay run on the CPU oracle (BASELINE configs[2]: "ATE within 1e-4 of ref");
   pcie_inclusive: the batched step again with the step's images arriving from pinned host memory on a copy stream
       (double-buffered, overlapped with the previous step's kernels).
@@ -198,30 +198,45 @@ def cpu_baseline(P, lba_problems, lba_every, budget_s=20.0):
 
 
 def single_stream_leg(seq, n_frames):
-    """The sequential replay on the C-ABI (see the module docstring); the oracle's run of the same replay is part of
-    the cpu_baseline leg, which fills in the ATE."""
+    """The sequential replay on the C-ABI (see the module docstring), a frame's tracking as one chain of launches
+    (replay.ChainedReplay); the stage-by-stage form (one synchronous call per stage) is timed beside it.  The
+    oracle's run of the same replay is part of the cpu_baseline leg, which fills in the ATE."""
     from vieo_slam_amd import replay, synth_ba
     for k in range(n_frames):
         seq.images(k)  # rendering is not part of either timing
-    Rh = replay.Replay(seq, replay.HipStages())
-    Rh.run(min(12, n_frames))  # warm-up: kernels loaded, scratch buffers allocated
-    Rh = replay.Replay(seq, replay.HipStages())
-    t0 = time.perf_counter()
-    th = Rh.run(n_frames)
-    t_hip = time.perf_counter() - t0
+    out = {}
+    for name, cls in (("stage_by_stage", replay.Replay), ("chained", replay.ChainedReplay)):
+        R = cls(seq, replay.HipStages())
+        R.run(min(12, n_frames))  # warm-up: kernels loaded, scratch buffers allocated
+        R = cls(seq, replay.HipStages())
+        t0 = time.perf_counter()
+        th = R.run(n_frames)
+        out[name] = (R, th, time.perf_counter() - t0)
+    Rs, _, t_s = out["stage_by_stage"]
+    Rh, th, t_hip = out["chained"]
     err = max(synth_ba.pose_error(th[k], seq.truth(k))[0] for k in range(n_frames))
     ms_f, ms_l = np.array(Rh.stats["ms_frames"]), np.array(Rh.stats["ms_lba"])
+    chain = np.array(Rh.stats["ms_chain"])
     return {
         "frames": n_frames, "local_bas": int(Rh.stats["lba"]),
         "ms_per_frame": 1e3 * t_hip / (n_frames - 1),
         "frames_per_s": (n_frames - 1) / t_hip,
         "latency_ms_per_frame_tracking_median": float(np.median(ms_f)),
         "latency_ms_per_frame_tracking_p95": float(np.percentile(ms_f, 95)),
+        "ms_per_frame_host_prepare_launch_wait": [float(x) for x in chain.mean(0)],
+        "host_syncs_per_frame": 2, "frames_through_the_stage_by_stage_path": int(Rh.stats["fallbacks"]),
         "ms_per_local_ba_mean": float(ms_l.mean()) if len(ms_l) else None,
         "ate_vs_oracle_m": None, "max_position_difference_vs_oracle_m": None,
         "max_position_error_vs_truth_m": float(err),
-        "path": "host-pointer C-ABI entry points, one call per stage, synchronous H2D / D2H inside every call "
-                "(PCIe-inclusive); single host thread; includes the host glue of the replay driver (numpy)",
+        "stage_by_stage": {"ms_per_frame": 1e3 * t_s / (n_frames - 1),
+                           "latency_ms_per_frame_tracking_median": float(np.median(Rs.stats["ms_frames"]))},
+        "path": "a frame's tracking as ONE chain of launches on one stream: inputs in one copy from pinned memory, "
+                "extraction x2 -> stereo -> SearchByProjection(last frame) -> PoseOptimization -> isInFrustum + queries "
+                "from the optimised pose in HBM -> SearchByProjection(local map) -> PoseOptimization(marg) on the "
+                "device-pointer entry points, results in one copy back; the host synchronises twice per frame (IMU "
+                "pre-integration, end of the chain); one host thread; includes the host glue of the replay driver "
+                "(numpy: map bookkeeping, local-BA window assembly); stage_by_stage = the same replay with one synchronous "
+                "host-pointer call per stage",
     }, th
 
 

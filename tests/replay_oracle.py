@@ -41,3 +41,6 @@ class OracleStages:
 
     def lba_vio(self, params, kfs, pts, close, obs, imu):
         return self.o.local_ba_vio(params, kfs, pts, close, obs, imu)
+
+    def update_normal_depth(self, points, first, obs_centre, centres, ref_centre, ref_scale, scale_last):
+        return self.o.update_normal_and_depth(points, first, obs_centre, centres, ref_centre, ref_scale, scale_last)

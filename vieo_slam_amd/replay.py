@@ -152,6 +152,10 @@ class HipStages:
         from .optimizer import Optimizer
         return Optimizer.LocalBundleAdjustmentNavStatePRV(params, kfs, pts, close, obs, imu)
 
+    def update_normal_depth(self, points, first, obs_centre, centres, ref_centre, ref_scale, scale_last):
+        from .map_point import update_normal_and_depth
+        return update_normal_and_depth(points, first, obs_centre, centres, ref_centre, ref_scale, scale_last)
+
 
 # ---------------------------------------------------------------- the driver
 class _Frame:
@@ -218,25 +222,22 @@ class Replay:
         kf.mp_ref[idx] = n0 + np.arange(len(idx))
 
     def _update_normal_depth(self, ids):
-        """MapPoint::UpdateNormalAndDepth (MapPoint.cc:424-480) for the given points"""
-        kf_by_id = {k.id: k for k in self.kfs}
-        for m in ids:
-            obs = self.mp_obs[m]
-            if self.mp_bad[m] or not obs:
-                continue
-            X = self.mp_X[m].astype(np.float32)
-            nrm = np.zeros(3, np.float32)
-            for kid in sorted(obs):
-                Ow = kf_by_id[kid].twc.astype(np.float32)
-                d = X - Ow
-                nrm = nrm + d / np.float32(np.sqrt(np.float32(d @ d)))
-            ref = kf_by_id[min(obs)]
-            PC = X - ref.twc.astype(np.float32)
-            dist = np.float32(np.sqrt(np.float32(PC @ PC)))
-            lvl = ref.keys["octave"][obs[ref.id]]
-            self.mp_maxd[m] = dist * self.scale[lvl]
-            self.mp_mind[m] = self.mp_maxd[m] / self.scale[NLEVELS - 1]
-            self.mp_normal[m] = nrm / np.float32(len(obs))
+        """MapPoint::UpdateNormalAndDepth (MapPoint.cc:424-480) for the given points, one batched call: observations in
+        key-frame order, the reference key frame = the oldest observer"""
+        ids = [m for m in ids if not self.mp_bad[m] and self.mp_obs[m]]
+        if not ids:
+            return
+        kids = [sorted(self.mp_obs[m]) for m in ids]
+        first = np.zeros(len(ids) + 1, np.int32)
+        first[1:] = np.cumsum([len(k) for k in kids])
+        obs_centre = np.fromiter((k for ks in kids for k in ks), np.int32, int(first[-1]))
+        centres = np.array([k.twc for k in self.kfs], np.float32)
+        ref = np.array([ks[0] for ks in kids], np.int32)
+        ref_scale = np.array([self.scale[self.kfs[ks[0]].keys["octave"][self.mp_obs[m][ks[0]]]] for m, ks in zip(ids, kids)],
+                             np.float32)
+        nrm, mx, mn = self.S.update_normal_depth(self.mp_X[ids], first, obs_centre, centres, ref, ref_scale,
+                                                 self.scale[NLEVELS - 1])
+        self.mp_normal[ids], self.mp_maxd[ids], self.mp_mind[ids] = nrm, mx, mn
 
     # ---- Tracking::CreateNewKeyFrame + LocalMapping::ProcessNewKeyFrame
     def insert_keyframe(self, f, nav, imu_edge):
