@@ -11,6 +11,7 @@
 #include <climits>
 
 #include "orb_internal.h"
+#include "wave_ops.h"
 
 namespace vieo {
 
@@ -98,11 +99,7 @@ struct StereoArgs {
   int H, list_cap;
 };
 
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ int wave_sum_i(int v) { return wave_sum_i32(v); }
 
 // vRowIndices (Frame.cc:461-480): for every image row the right keys whose band
 // [floor(y - r), ceil(y + r)], r = 2 * scale(octave), covers it.  One workgroup per frame: LDS
@@ -198,12 +195,11 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
     const int d = hamming32(a0, a1, DR + (size_t)j * 32);
     if (d < TH_HIGH && lex_less(d, j, bestDist, bestIdx)) bestDist = d, bestIdx = j;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int e = __shfl_xor(bestDist, o), j = __shfl_xor(bestIdx, o);
-    if (lex_less(e, j, bestDist, bestIdx)) bestDist = e, bestIdx = j;
+  {  // lexicographic minimum of (distance, index) as ONE key (distance <= 256, index < 2^20)
+    const unsigned m = wave_min_u32(bestIdx == INT_MAX ? 0xFFFFFFFFu : ((unsigned)bestDist << 20) | (unsigned)bestIdx);
+    bestIdx = m == 0xFFFFFFFFu ? INT_MAX : (int)(m & 0xFFFFF);
+    bestDist = m == 0xFFFFFFFFu ? INT_MAX : (int)(m >> 20);
   }
-  bestIdx = __builtin_amdgcn_readfirstlane(bestIdx), bestDist = __builtin_amdgcn_readfirstlane(bestDist);
   if (bestIdx == INT_MAX || bestDist >= (TH_HIGH + TH_LOW) / 2) return;
   // ---- sub-pixel refinement by 11 SADs of 11x11 patches at the key's pyramid level
   const float uR0 = KR[bestIdx].x;

@@ -19,6 +19,7 @@
 #include "../../include/vieo_orb_pattern_31.h"
 #include "common.h"
 #include "sincosf_exact.h"
+#include "wave_ops.h"
 
 #define QT_DEVICE
 #include "quadtree.inl"
@@ -675,11 +676,7 @@ k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles, int n_tiles, i
 }
 
 // ------------------------------------------------------------------ orientation + descriptor
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ int wave_sum(int v) { return wave_sum_i32(v); }
 
 // cv::fastAtan2 (degrees), float arithmetic in the published order
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {

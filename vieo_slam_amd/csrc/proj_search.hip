@@ -15,6 +15,7 @@
 #include <climits>
 
 #include "ba_device.h"
+#include "wave_ops.h"
 
 namespace vieo {
 
@@ -302,13 +303,16 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
 }
 
 __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int* total) {
+  // inclusive scan on DPP: four shifted adds inside a row of 16 lanes (zeros shift in), then the two row broadcasts
   int x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(x, o);
-    if (lane >= o) x += y;
-  }
-  *total = __shfl(x, 63);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
+  x += VIEO_DPP(0, x, VIEO_DPP_ROW_BCAST15, 0xA);
+  x += VIEO_DPP(0, x, VIEO_DPP_ROW_BCAST31, 0xC);
+  (void)lane;
+  *total = __builtin_amdgcn_readlane(x, 63);
   return x - v;
 }
 
@@ -397,7 +401,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
     auto test = [&](int t, int* slot, int* packed) -> bool {
       int sl = -1;
       for (int i = 0; i < nx; i++) {
-        const int o = __shfl(seg_o, i), l = __shfl(seg_l, i), s0 = __shfl(seg_s, i);
+        const int o = __builtin_amdgcn_readlane(seg_o, i), l = __builtin_amdgcn_readlane(seg_l, i), s0 = __builtin_amdgcn_readlane(seg_s, i);
         if (t >= o && t < o + l) sl = s0 + (t - o);
       }
       *slot = sl;
@@ -434,7 +438,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
       }
       int base = 0;
       if (lane == 0) base = atomicAdd(&A.cursor[f], total);
-      base = __shfl(base, 0);
+      base = __builtin_amdgcn_readfirstlane(base);
       if (base + total > A.pool_cap) {
         if (lane == 0) *out = make_int2(0, -1);
         continue;
@@ -454,7 +458,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
     }
     int base = 0;
     if (lane == 0) base = atomicAdd(&A.cursor[f], total);
-    base = __shfl(base, 0);
+    base = __builtin_amdgcn_readfirstlane(base);
     if (base + total > A.pool_cap) {
       if (lane == 0) *out = make_int2(0, -1);
       continue;
@@ -520,15 +524,17 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
     const int2 mine = q0 + lane < nq ? qrec[q0 + lane] : make_int2(0, 0);
     const int qn = min(64, nq - q0);
     for (int qq = 0; qq < qn; qq++) {
-      const int off = __shfl(mine.x, qq), ny = __shfl(mine.y, qq);
+      const int off = __builtin_amdgcn_readlane(mine.x, qq), ny = __builtin_amdgcn_readlane(mine.y, qq);  // qq is uniform
       if (ny == 0) continue;
       if (ny < 0) {
         overflow = 1;
         continue;
       }
       const int n = ny & 0xFFFF, q = q0 + qq;
-      // two smallest (dist, order) among usable candidates; lane owns positions lane, lane+64
-      unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu, c0 = 0, c1 = 0;
+      // two smallest (dist, order) among usable candidates; lane owns positions lane, lane+64.  The keys are unique
+      // (they carry the position), so the second smallest is the minimum once the winner's lane puts its other key
+      // forward; the winners' candidate words are read back from the pool by position.
+      unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int pos = lane + 64 * h;
@@ -538,26 +544,24 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
           const int st = s_state[idx];
           if (A.mode == VIEO_SBP_RELOC ? !(st & 1) : !((st & 1) && (st & 2))) {
             const unsigned key = ((unsigned)d << 8) | (unsigned)pos;  // (dist, order)
-            if (key < b0) {
-              b1 = b0, c1 = c0;
-              b0 = key, c0 = c;
-            } else if (key < b1)
-              b1 = key, c1 = c;
+            if (key < b0)
+              b1 = b0, b0 = key;
+            else
+              b1 = key;
           }
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned e0 = __shfl_xor(b0, o), e1 = __shfl_xor(b1, o);
-        const unsigned g0 = __shfl_xor(c0, o), g1 = __shfl_xor(c1, o);
-        if (e0 < b0) {
-          if (b0 < e1)
-            b1 = b0, c1 = c0;
-          else
-            b1 = e1, c1 = g1;
-          b0 = e0, c0 = g0;
-        } else if (e0 < b1)
-          b1 = e0, c1 = g0;
+      const unsigned m0 = wave_min_u32(b0);
+      const unsigned m1 = wave_min_u32(b0 == m0 ? b1 : b0);
+      b0 = m0, b1 = m1;
+      unsigned c0 = 0, c1 = 0;
+      if (b0 != 0xFFFFFFFFu) {
+        const int p0 = off + (int)(b0 & 0xFF);
+        c0 = p0 < n_lds ? s_pool[p0] : pool[p0];
+      }
+      if (b1 != 0xFFFFFFFFu) {
+        const int p1 = off + (int)(b1 & 0xFF);
+        c1 = p1 < n_lds ? s_pool[p1] : pool[p1];
       }
       if (b0 == 0xFFFFFFFFu) continue;
       const int bestDist = b0 >> 8;
