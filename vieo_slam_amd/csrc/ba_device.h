@@ -6,6 +6,7 @@
 #include <cfloat>
 
 #include "common.h"
+#include "wave_ops.h"
 
 namespace vieo {
 
@@ -182,7 +183,10 @@ __device__ __forceinline__ void huber(double e, double delta, double dsqr, doubl
   }
 }
 
-__device__ __forceinline__ double wave_sum_d(double v) {
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64(v); }  // DPP, fixed association order
+// the xor butterfly through ds_bpermute: kept for the one-wavefront-per-frame instances of the pose kernels (with the
+// DPP form those instances, at ~390 registers, abort on the device; the four-wavefront instances are fine)
+__device__ __forceinline__ double wave_sum_d_bfly(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
@@ -208,7 +212,7 @@ template <int N, int BS>
 __device__ __forceinline__ void block_sum_bs(double* vals, double* s_red, int tid) {
   if (BS == 64) {
 #pragma unroll
-    for (int i = 0; i < N; i++) vals[i] = wave_sum_d(vals[i]);
+    for (int i = 0; i < N; i++) vals[i] = wave_sum_d_bfly(vals[i]);
   } else
     block_sum<N>(vals, s_red, tid);
 }

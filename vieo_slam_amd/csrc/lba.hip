@@ -468,10 +468,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
       }
     }
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-      acc[t] += __shfl_xor(acc[t], 1);
-      acc[t] += __shfl_xor(acc[t], 2);
-    }
+    for (int t = 0; t < 9; t++) acc[t] = quad_sum_f64(acc[t]);
     if (act && sub == 0) {
       double* H = D.Hll + 9 * (size_t)m;
       H[0] = acc[0], H[1] = acc[1], H[2] = acc[2];
@@ -481,7 +478,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
       mx = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
     }
     // landmark part of computeLambdaInit: block maximum
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    mx = wave_max_f64(mx);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) D.pmax[bx] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));

@@ -62,4 +62,34 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// sum over the four lanes of a quad (every lane of the quad receives it); same association as two xor butterflies
+__device__ __forceinline__ double quad_sum_f64(double v) {
+  {
+    const int l2 = VIEO_DPP(0, __double2loint(v), VIEO_DPP_QUAD_XOR1, 0xF), h2 = VIEO_DPP(0, __double2hiint(v), VIEO_DPP_QUAD_XOR1, 0xF);
+    v += __hiloint2double(h2, l2);
+  }
+  {
+    const int l2 = VIEO_DPP(0, __double2loint(v), VIEO_DPP_QUAD_XOR2, 0xF), h2 = VIEO_DPP(0, __double2hiint(v), VIEO_DPP_QUAD_XOR2, 0xF);
+    v += __hiloint2double(h2, l2);
+  }
+  return v;
+}
+
+__device__ __forceinline__ double wave_max_f64(double v) {
+#define VIEO_DPP_MAX_F64(ctrl, row_mask)                                                      \
+  {                                                                                           \
+    const int lo = __double2loint(v), hi = __double2hiint(v);                                 \
+    const int l2 = VIEO_DPP(lo, lo, ctrl, row_mask), h2 = VIEO_DPP(hi, hi, ctrl, row_mask);   \
+    v = fmax(v, __hiloint2double(h2, l2));                                                    \
+  }
+  VIEO_DPP_MAX_F64(VIEO_DPP_QUAD_XOR1, 0xF)
+  VIEO_DPP_MAX_F64(VIEO_DPP_QUAD_XOR2, 0xF)
+  VIEO_DPP_MAX_F64(VIEO_DPP_ROW_HALF_MIRROR, 0xF)
+  VIEO_DPP_MAX_F64(VIEO_DPP_ROW_MIRROR, 0xF)
+  VIEO_DPP_MAX_F64(VIEO_DPP_ROW_BCAST15, 0xA)
+  VIEO_DPP_MAX_F64(VIEO_DPP_ROW_BCAST31, 0xC)
+#undef VIEO_DPP_MAX_F64
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 }  // namespace vieo
