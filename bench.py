@@ -485,6 +485,20 @@ def main():
                               "launches_per_step": sch["launches"] / a.steps,
                               "mfma_busy": mfma_busy()},
         }
+        if dk:
+            # the same kernel with the GPU to itself (no bundle-adjustment stream beside it): a few more launches of the
+            # extractor after the timed region, same events.  `achieved` / `frac` above stay the in-situ figures.
+            for _ in range(4):
+                P.ext.extract_batch_device(P.d_img.ptr, P.n_img, 752, 480, 752, 752 * 480, P.d_kp.ptr, P.d_desc.ptr,
+                                           P.cap, P.d_cnt.ptr)
+            P.sync()
+            alone = P.ext.stage_ms_all()[-3:]
+            ms_alone = float(np.mean([m[dk] for m in alone]))
+            out["roofline"]["alone"] = {"avg_launch_ms": ms_alone, "achieved": ab[dk] * P.n_img / (ms_alone * 1e-3) / 1e9,
+                                        "frac": ab[dk] * P.n_img / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "extractor_kernel_ms": {k: float(np.mean([m[k] for m in alone])) for k in ORB_STAGES},
+                                        "note": "same launch without the bundle-adjustment stream beside it (its short "
+                                                "high-priority kernels take CUs from the front end in the timed region)"}
         if world == 1 and not a.no_pcie_leg:
             out["pcie_inclusive"] = pcie_leg(P, max(3, min(a.steps, 10)), 2)
         if world == 1 and not a.no_cpu_baseline:

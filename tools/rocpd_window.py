@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel totals of a rocprofv3 rocpd database restricted to the steady-state window: from the
-start of the N-th last launch of an anchor kernel to the end of the trace.
-Usage: tools/rocpd_window.py results.db anchor_kernel_substring n_steps [launches_per_step]"""
+start of the N-th last launch of an anchor kernel to the end of the trace (or, with skip_last, to the start of the
+skip_last-th last anchor launch: bench.py runs a few more extractor launches alone after the timed steps).
+Usage: tools/rocpd_window.py results.db anchor_kernel_substring n_steps [launches_per_step [skip_last]]"""
 import sqlite3
 import sys
 
@@ -9,17 +10,19 @@ import sys
 def main():
     path, anchor, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
     per = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    skip = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     cur = sqlite3.connect(path).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = cur.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
     anc = [r for r in rows if anchor in r[0]]
-    t0 = anc[-n * per][1]
+    t0 = anc[-(n + skip) * per][1]
+    t1 = anc[-skip * per][1] if skip else rows[-1][2] + 1
     agg = {}
     for name, s, e in rows:
-        if s >= t0:
+        if t0 <= s < t1:
             agg.setdefault(name.split("(")[0], []).append(e - s)
-    span = (rows[-1][2] - t0) / 1e6
+    span = ((t1 if skip else rows[-1][2]) - t0) / 1e6
     print("window: %.3f ms, %d steps -> %.3f ms/step" % (span, n, span / n))
     print("| kernel | launches/step | ms/step | avg_us |")
     print("|---|---|---|---|")
