@@ -269,3 +269,65 @@ def test_fuse_search_parity(oracle, rig, use_bf, angle):
     assert (oi >= 0).sum() > 300
     # index work: exact for distorted rigs too (see test_frustum_parity)
     assert np.array_equal(oi, hi) and np.array_equal(od, hd), (int((oi != hi).sum()), int((od != hd).sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rig", [None, "kb8"])
+def test_track_local_queries_device(oracle, rig):
+    """vieo_track_local_queries_device (the head of Tracking::SearchLocalPoints for a frame whose pose is still in
+    HBM): pose taken from a PoseOptimization result on the device -> isInFrustum -> window queries, against
+    isInFrustum of the oracle + the host's query construction on the same pose."""
+    import ctypes
+    from vieo_slam_amd import frontend
+    from vieo_slam_amd._lib import DeviceBuffer, check, lib
+    from vieo_slam_amd.ba_types import PROJ_QUERY_DTYPE, VIO_FRAME_DTYPE, VIO_RESULT_DTYPE
+    rng = np.random.default_rng(21)
+    F, cams, _, _ = _frame(rng, rig)
+    # the pose as the optimiser leaves it: body state + camera extrinsics; Tcw = Tcb * Twb^-1
+    q = synth_ba.quat_from_rotvec(rng.normal(0, 0.4, 3))
+    p = rng.uniform(-1, 1, 3)
+    Rcb = synth_ba.quat_to_R(synth_ba.quat_from_rotvec(rng.normal(0, 0.2, 3)))
+    tcb = rng.uniform(-0.1, 0.1, 3)
+    Rcw = Rcb @ synth_ba.quat_to_R(q).T
+    tcw = tcb - Rcw @ p
+    F[0]["Rcrw"], F[0]["tcrw"], F[0]["Ow"] = Rcw.reshape(-1), tcw, -Rcw.T @ tcw
+    n = 6000
+    P = _points(rng, Rcw, tcw, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    th = 2.0
+    S = int(F[0]["n_cams"])
+    for status in (0, 1):  # result usable / not: then the frame's own estimate is the pose
+        fr, res = np.zeros(1, VIO_FRAME_DTYPE), np.zeros(1, VIO_RESULT_DTYPE)
+        fr[0]["base"]["Rcb"], fr[0]["base"]["tcb"] = Rcb.reshape(-1), tcb
+        good, junk = (res, fr) if status == 0 else (fr, res)
+        good[0]["base"]["nav"]["q"], good[0]["base"]["nav"]["p"] = q, p
+        junk[0]["base"]["nav"]["q"], junk[0]["base"]["nav"]["p"] = (1, 0, 0, 0), (50, 50, 50)
+        res[0]["base"]["status"] = status
+        alias = np.where(rng.random(n) < 0.3, rng.integers(0, 500, n), -1).astype(np.int32)
+        held = (rng.random(500) < 0.5).astype(np.uint8)
+        D = DeviceBuffer
+        d_fr, d_res, d_P, d_desc = D(fr.nbytes), D(res.nbytes), D(P.nbytes), D(desc.nbytes)
+        d_alias, d_held, d_scale = D(alias.nbytes), D(held.nbytes), D(64)
+        d_q, d_dep, d_nq = D(64 * n * S), D(4 * n), D(16)
+        for b, a in ((d_fr, fr), (d_res, res), (d_P, P), (d_desc, desc), (d_alias, alias), (d_held, held), (d_scale, scale)):
+            b.upload(a)
+        Fz = F.copy()
+        Fz[0]["Rcrw"], Fz[0]["tcrw"], Fz[0]["Ow"] = 0, 0, 0  # ignored by the device entry
+        check(lib().vieo_track_local_queries_device(Fz.ctypes.data, d_fr.ptr, d_res.ptr, d_P.ptr, d_desc.ptr, d_alias.ptr,
+                                                    d_held.ptr, n, th, 0.0, d_scale.ptr, d_q.ptr, d_dep.ptr, d_nq.ptr, None))
+        check(lib().vieo_device_synchronize())
+        got = d_q.download(PROJ_QUERY_DTYPE, (n * S,))
+        dep = d_dep.download(np.float32, (n,))
+        assert int(d_nq.download(np.int32, (4,))[0]) == n * S
+        info = oracle.is_in_frustum(F, P)
+        assert np.array_equal(dep, info["track_depth"])
+        excluded = (alias >= 0) & (held[np.maximum(alias, 0)] != 0)
+        info_x = info.copy()
+        info_x["n"][excluded] = 0
+        ref, owner = frontend.queries_from_track_info(info_x, desc, th, scale)
+        valid = np.nonzero(got["flags"] & 1)[0]
+        assert len(ref) > 300 and len(valid) == len(ref)
+        assert got[valid].tobytes() == ref.tobytes()
+        assert np.array_equal(valid // S, owner)
+        assert not got[(got["flags"] & 1) == 0].view(np.uint8).any()  # unused slots are zero
