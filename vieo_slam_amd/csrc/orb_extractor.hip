@@ -252,6 +252,15 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
       auto pass_a = [&](auto SC) {
         constexpr int S = decltype(SC)::value;
         int y = lane / ng, lx4 = lane - y * ng;
+        // byte offset of the lane's group in the tile, advanced by adds (a step = qy rows + rx groups, one more row
+        // when the group index wraps); the three rows it reads are uniform bases + this offset
+        int toff = y * tpitch + 4 * lx4;
+        const int step_off = qy * tpitch + 4 * rx, wrap_off = tpitch - 4 * ng;
+        const uint8_t* base_u = tile + 4 * kq;
+        const uint8_t* base_c = base_u + 3 * tpitch;
+        const uint8_t* base_d = base_u + 6 * tpitch;
+        // the last group of a row may hang over the cell: its bytes beyond the last pixel never pass
+        const unsigned Htail = (unsigned)(0x80808080ull & ((1ull << (8 * (vw - 4 * (ng - 1)))) - 1ull));
         for (int g0 = 0; g0 < G; g0 += 64) {
           if (na + 256 > cand_cap) {  // a step appends up to 256 entries: score what is pending first (uniform branch)
             wave_sync();
@@ -265,9 +274,9 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
           unsigned m4 = 0;
           const int x0 = 4 * lx4;
           if (g0 + lane < G) {
-            const unsigned* rc = (const unsigned*)(tile + (y + 3) * tpitch) + lx4 + kq;
-            const unsigned* ru = (const unsigned*)(tile + y * tpitch) + lx4 + kq;
-            const unsigned* rd = (const unsigned*)(tile + (y + 6) * tpitch) + lx4 + kq;
+            const unsigned* rc = (const unsigned*)(base_c + toff);
+            const unsigned* ru = (const unsigned*)(base_u + toff);
+            const unsigned* rd = (const unsigned*)(base_d + toff);
             unsigned C, L, R, U, D;
             if constexpr (S == 0) {
               const unsigned wm = rc[-1], w0 = rc[0], w1 = rc[1];
@@ -298,24 +307,29 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
             const unsigned hi = sum | ((cy - (cy >> 7)) | cy);
             const unsigned dk = (ltu(U, lo) | ltu(D, lo)) & (ltu(L, lo) | ltu(R, lo));
             const unsigned br = (ltu(hi, U) | ltu(hi, D)) & (ltu(hi, L) | ltu(hi, R));
-            const unsigned f = (dk | br) & H;                    // bit 7 of byte j: pixel x0 + j passes
-            m4 = ((f >> 7) | (f >> 14) | (f >> 21) | (f >> 28)) & 15u;
-            m4 &= (1u << min(vw - x0, 4)) - 1u;
+            const unsigned f = (dk | br) & (lx4 == ng - 1 ? Htail : H);  // bit 7 of byte j: pixel x0 + j passes
+            // bits 7, 15, 23, 31 -> bits 0..3: one multiply (the partial products land on distinct bits, no carries)
+            m4 = ((f >> 7) * 0x01020408u) >> 24;
           }
-          // positions: exclusive prefix over the lanes of popcount(m4) from the ballots of its bits
+          // positions: inclusive scan of the lanes' counts on DPP (four shifted adds inside a row of 16 lanes, zeros
+          // shift in; two row broadcasts), minus the lane's own count
           const int cnt = __popc(m4);
-          const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
-          int pos = na + __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0)) +
-                    2 * __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0)) +
-                    4 * __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
+          int inc = cnt;
+          inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);  // row_shr:1
+          inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);  // row_shr:2
+          inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);  // row_shr:4
+          inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);  // row_shr:8
+          inc += VIEO_DPP(0, inc, VIEO_DPP_ROW_BCAST15, 0xA);
+          inc += VIEO_DPP(0, inc, VIEO_DPP_ROW_BCAST31, 0xC);
+          int pos = na + inc - cnt;
           const unsigned key = (unsigned)((y << 6) | x0);
 #pragma unroll
           for (int j = 0; j < 4; j++)
             if (m4 & (1u << j)) cand[pos++] = (unsigned short)(key + j);
-          na += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+          na += __builtin_amdgcn_readlane(inc, 63);
           // the next 64 groups
-          lx4 += rx, y += qy;
-          if (lx4 >= ng) lx4 -= ng, y++;
+          lx4 += rx, y += qy, toff += step_off;
+          if (lx4 >= ng) lx4 -= ng, y++, toff += wrap_off;
         }
       };
       if (s == 0) pass_a(std::integral_constant<int, 0>());
