@@ -1901,12 +1901,14 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   }
   if (!g_lba_stream) {
     // VIEO_LBA_PRIORITY = -1 / 0 / 1: lowest / default / highest stream priority for the bundle-adjustment stream.
-    // Highest by default: its kernels are short (<= 0.3 ms for 205 windows) and many; next to a batched front end
-    // on another stream they otherwise wait behind thousands of queued workgroups per launch (k_lba_build 2.8 ms
-    // instead of 0.9 per launch in the bench step, same frames/s either way).
+    // Lowest by default: local mapping is the background thread of the reference and tracking must not wait for
+    // it.  Next to a batched front end on another stream the bench step measured (30 steps, 205 windows per step):
+    // highest 48.9 k frames/s with k_fast at 9.3 ms per launch and 0.17 ms per window; default 50.1 k / 7.6 / 0.79;
+    // lowest 53.0 k / 7.7 (what k_fast takes alone) / 0.73 -- the windows' kernels are short and many and fill what the
+    // front end leaves free instead of taking CUs from it.
     int lo = 0, hi = 0;
     const char* e = getenv("VIEO_LBA_PRIORITY");
-    const int want = e ? atoi(e) : 1;
+    const int want = e ? atoi(e) : -1;
     if (want == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi)
       VIEO_HIP_CHECK(hipStreamCreateWithFlags(&g_lba_stream, hipStreamNonBlocking));
     else
