@@ -2,7 +2,9 @@
 """Per-kernel totals of a rocprofv3 rocpd database restricted to the steady-state window: from the
 start of the N-th last launch of an anchor kernel to the end of the trace (or, with skip_last, to the start of the
 skip_last-th last anchor launch: bench.py runs a few more extractor launches alone after the timed steps).
-Usage: tools/rocpd_window.py results.db anchor_kernel_substring n_steps [launches_per_step [skip_last]]"""
+With end_anchor the window closes at the end of the last launch of that kernel before the window's nominal end (the
+front end's last kernel of the timed steps: what follows is the drain of the low-priority bundle-adjustment stream).
+Usage: tools/rocpd_window.py results.db anchor_kernel_substring n_steps [launches_per_step [skip_last [end_anchor]]]"""
 import sqlite3
 import sys
 
@@ -18,6 +20,10 @@ def main():
     anc = [r for r in rows if anchor in r[0]]
     t0 = anc[-(n + skip) * per][1]
     t1 = anc[-skip * per][1] if skip else rows[-1][2] + 1
+    if len(sys.argv) > 6:
+        ends = [r[2] for r in rows if sys.argv[6] in r[0] and r[1] < t1]
+        t1 = ends[-1] + 1
+        skip = 1  # the span below runs to t1
     agg = {}
     for name, s, e in rows:
         if t0 <= s < t1:
