@@ -771,6 +771,10 @@ k_describe(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __r
   uint8_t* sa = s_patch[wv];
   uint8_t* sb = sa + 31 * AP;
   const int xa = (cx - kHalfPatch) & ~3, xb = (cx - BR) & ~3;
+  // the lane's four pattern words: issued ahead of the patch loads, so that they are there when the angle is
+  int pt4[4];
+#pragma unroll
+  for (int gq = 0; gq < 4; gq++) pt4[gq] = pattern[gq * 64 + lane];  // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
   const uint8_t* bl0 = I.blur + (size_t)b * I.blur_img + D.boff;
   const int bp = D.pitch;
   {  // 16 dword columns x 4 rows per step
@@ -802,10 +806,16 @@ k_describe(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __r
     const uint8_t* row = sa + (v + kHalfPatch) * AP + (cx - xa);
     const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
     int sI = 0;
-    for (int u = u0; u <= u1; u++) {
-      const int val = row[u];
-      m10 += u * val;
-      sI += val;
+    // at most 16 pixels per lane (d <= 15): unrolled, so the byte reads are all issued before the first one is used
+    // (as a loop with a lane-dependent trip count every iteration waited for its own LDS read)
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int u = u0 + t;
+      if (u <= u1) {
+        const int val = row[u];
+        m10 += u * val;
+        sI += val;
+      }
     }
     m01 = v * sI;
   }
@@ -820,7 +830,7 @@ k_describe(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __r
   unsigned long long bits[4];
 #pragma unroll
   for (int gq = 0; gq < 4; gq++) {
-    const int pt = pattern[gq * 64 + lane];  // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
+    const int pt = pt4[gq];
     const float x0 = (float)(signed char)(pt & 0xFF), y0 = (float)(signed char)((pt >> 8) & 0xFF);
     const float x1 = (float)(signed char)((pt >> 16) & 0xFF), y1 = (float)(signed char)((pt >> 24) & 0xFF);
     const int t0 = bl[__float2int_rn(x0 * bsin + y0 * a) * BP + __float2int_rn(x0 * a - y0 * bsin)];
