@@ -222,15 +222,33 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
     py[k] = p / 11, px[k] = p - py[k] * 11;
     il[k] = p < 121 ? (int)PL[(size_t)(r0 + py[k]) * pitchL + cL0 + px[k]] - cvL : 0;
   }
-  // the right-image bytes of all 11 shifts in flight at once (33 loads), then the sums: interleaved with the
-  // wavefront reductions they cost one memory round trip per shift
+  // The 11 shifted 11 x 11 windows of the right image overlap: together they are one 11 x 21 strip (231 bytes).  The
+  // wavefront loads the strip once (4 byte loads per lane) into its LDS slice and every lane reads its 22 window bytes
+  // and the 11 centre values from there.  As 33 global byte loads per lane (11 rows under every instruction) the
+  // kernel was bound by the address path of the vector memory unit: 2.8 ms per step of 2048 frames.
+  __shared__ uint8_t s_strip[4][11 * 21 + 25];
+  uint8_t* strip = s_strip[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  {
+    unsigned v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = lane + 64 * k, row = p / 21, col = p - row * 21;
+      v[k] = p < 231 ? PR[(size_t)(r0 + row) * pitchR + cR0 - L + col] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (lane + 64 * k < 231) strip[lane + 64 * k] = (uint8_t)v[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   int cvRv[11], irv[2][11];
 #pragma unroll
   for (int inc = -L; inc <= L; inc++) {
-    cvRv[inc + L] = PR[(size_t)(r0 + w) * pitchR + cR0 + inc + w];
+    cvRv[inc + L] = strip[w * 21 + inc + L + w];
 #pragma unroll
     for (int k = 0; k < 2; k++)
-      irv[k][inc + L] = lane + 64 * k < 121 ? (int)PR[(size_t)(r0 + py[k]) * pitchR + cR0 + inc + px[k]] : 0;
+      irv[k][inc + L] = lane + 64 * k < 121 ? (int)strip[py[k] * 21 + inc + L + px[k]] : 0;
   }
   int bestS = INT_MAX, bestInc = 0, sads[11];
 #pragma unroll
