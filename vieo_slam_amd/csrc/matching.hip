@@ -95,7 +95,7 @@ struct StereoArgs {
   float* depth;   // [frame][capL]
   int* sad;       // [frame][capL]  best SAD of accepted matches, -1 otherwise
   int* row_start; // [frame][H + 1]  vRowIndices as CSR: right keys whose row band covers row y
-  int* row_list;  // [frame][list_cap]
+  int2* row_list;  // [frame][list_cap]: {right key | octave << 20, its x as float bits}: the candidate loop needs no key record
   int H, list_cap;
 };
 
@@ -146,13 +146,14 @@ __global__ void __launch_bounds__(256) k_stereo_rows(StereoArgs A) {
   }
   if (y1 == H && y0 < H) rs[H] = acc;
   __syncthreads();
-  int* list = A.row_list + (size_t)f * A.list_cap;
+  int2* list = A.row_list + (size_t)f * A.list_cap;
   for (int j = tid; j < Nr; j += 256) {
-    const float y = KR[j].y, r = 2.0f * A.P.lv[KR[j].octave].scale;
+    const vieo_keypoint kj = KR[j];
+    const float y = kj.y, r = 2.0f * A.P.lv[kj.octave].scale;
     const int maxr = min((int)ceilf(y + r), H - 1), minr = max((int)floorf(y - r), 0);
     for (int yi = minr; yi <= maxr; yi++) {
       const int pos = atomicAdd(&cur[yi], 1);
-      if (pos < A.list_cap) list[pos] = j;
+      if (pos < A.list_cap) list[pos] = make_int2(j | (kj.octave << 20), __float_as_int(kj.x));
     }
   }
 }
@@ -184,14 +185,15 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
   int bestDist = TH_HIGH, bestIdx = INT_MAX;
   if (rowL < 0 || rowL >= A.H) return;
   const int* rs = A.row_start + (size_t)f * (A.H + 1);
-  const int* list = A.row_list + (size_t)f * A.list_cap;
+  const int2* list = A.row_list + (size_t)f * A.list_cap;
   const int c0 = rs[rowL], c1 = min(rs[rowL + 1], A.list_cap);
   (void)Nr;
   for (int c = c0 + lane; c < c1; c += 64) {
-    const int j = list[c];
-    const vieo_keypoint kR = KR[j];
-    if (kR.octave < levelL - 1 || kR.octave > levelL + 1) continue;
-    if (!(kR.x >= minU && kR.x <= maxU)) continue;
+    const int2 e = list[c];  // the key's octave and column travel with the list entry
+    const int j = e.x & 0xFFFFF, octR = e.x >> 20;
+    const float xR = __int_as_float(e.y);
+    if (octR < levelL - 1 || octR > levelL + 1) continue;
+    if (!(xR >= minU && xR <= maxU)) continue;
     const int d = hamming32(a0, a1, DR + (size_t)j * 32);
     if (d < TH_HIGH && lex_less(d, j, bestDist, bestIdx)) bestDist = d, bestIdx = j;
   }
@@ -351,10 +353,14 @@ static int launch_stereo(StereoArgs A, int n_frames, hipStream_t st) {
   float smax = 1.f;
   for (int l = 0; l < A.P.nlevels; l++) smax = std::max(smax, A.P.lv[l].scale);
   A.H = A.P.lv[0].h;
+  if (A.capR >= (1 << 20)) {  // the row lists carry the key index in 20 bits
+    set_error("ComputeStereoMatches: more than 2^20 keys per image");
+    return VIEO_E_CAPACITY;
+  }
   A.list_cap = A.capR * (2 * (int)ceilf(2.0f * smax) + 3);
   if ((rc = g_row_start.ensure((size_t)n_frames * (A.H + 1) * 4)) != VIEO_OK) return rc;
-  if ((rc = g_row_list.ensure((size_t)n_frames * A.list_cap * 4)) != VIEO_OK) return rc;
-  A.row_start = g_row_start.as<int>(), A.row_list = g_row_list.as<int>();
+  if ((rc = g_row_list.ensure((size_t)n_frames * A.list_cap * 8)) != VIEO_OK) return rc;
+  A.row_start = g_row_start.as<int>(), A.row_list = g_row_list.as<int2>();
   hipLaunchKernelGGL(k_stereo_rows, dim3(n_frames), dim3(256), (size_t)(2 * A.H + 1) * 4, st, A);
   hipLaunchKernelGGL(k_stereo_rect, dim3((A.capL + 3) / 4, n_frames), dim3(256), 0, st, A);
   hipLaunchKernelGGL(k_stereo_median, dim3(n_frames), dim3(256), 0, st, A);
