@@ -99,8 +99,54 @@ struct QtMem {
   QT_MEM int* csize(int i) const { return i ? cand_size[1] : cand_size[0]; }
 };
 
-// Inclusive Hillis-Steele scan of a[0..n) (4 x 16-bit packed counters); result ends in the
-// returned buffer (a or b).
+// Inclusive scan of a[0..n) (4 x 16-bit packed counters); result ends in the returned buffer (a or b).
+#ifdef QT_DEVICE
+// Device form: every thread scans a contiguous chunk, the chunk totals are scanned inside the wavefront on DPP (the two
+// 32-bit halves separately: the counters are 16 bits wide and never carry into one another), the wavefront totals go
+// through LDS.  Two barriers whatever n is; the Hillis-Steele form below took log2(n) of them (ten at n = 540) and was
+// two thirds of the barriers of a quadtree workgroup.
+QT_FN unsigned long long* qt_scan(unsigned long long* a, unsigned long long* b, int n) {
+  __shared__ unsigned long long s_qt_tot[16];
+  const int tid = (int)threadIdx.x, NT = (int)blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + NT - 1) / NT, i0 = tid * per;
+  unsigned long long run = 0;
+  for (int k = 0; k < per; k++)
+    if (i0 + k < n) {
+      run += a[i0 + k];
+      b[i0 + k] = run;
+    }
+  int lo = (int)(unsigned)run, hi = (int)(unsigned)(run >> 32);
+#define QT_DPP_SCAN(x)                                               \
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);     \
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);     \
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);     \
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);     \
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);    \
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  QT_DPP_SCAN(lo)
+  QT_DPP_SCAN(hi)
+#undef QT_DPP_SCAN
+  const unsigned long long inc = (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
+  if (lane == 63) s_qt_tot[wave] = inc;
+  __syncthreads();
+  // exclusive over the wavefront's chunks (per half: no borrow between them)
+  unsigned long long off = (unsigned long long)(unsigned)((unsigned)inc - (unsigned)run) |
+        ((unsigned long long)(unsigned)((unsigned)(inc >> 32) - (unsigned)(run >> 32)) << 32);
+  for (int w = 0; w < wave; w++) {
+    const unsigned long long t = s_qt_tot[w];
+    off = (unsigned long long)(unsigned)((unsigned)off + (unsigned)t) |
+          ((unsigned long long)(unsigned)((unsigned)(off >> 32) + (unsigned)(t >> 32)) << 32);
+  }
+  for (int k = 0; k < per; k++)
+    if (i0 + k < n) {
+      const unsigned long long v = b[i0 + k];
+      b[i0 + k] = (unsigned long long)(unsigned)((unsigned)v + (unsigned)off) |
+                  ((unsigned long long)(unsigned)((unsigned)(v >> 32) + (unsigned)(off >> 32)) << 32);
+    }
+  __syncthreads();
+  return b;
+}
+#else
 QT_FN unsigned long long* qt_scan(unsigned long long* a, unsigned long long* b, int n) {
   unsigned long long* src = a;
   unsigned long long* dst = b;
@@ -115,6 +161,7 @@ QT_FN unsigned long long* qt_scan(unsigned long long* a, unsigned long long* b, 
   }
   return src;
 }
+#endif
 
 QT_FN int qt_quadrant(int x, int y, int x0, int y0, int x1, int y1) {
   // DivideNode: halfX = ceil((UR.x-UL.x)/2.f), halfY = ceil((BR.y-UL.y)/2.f)
