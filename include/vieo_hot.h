@@ -845,12 +845,13 @@ int vieo_is_in_frustum_batch(const vieo_frustum_frame* h_frame, const vieo_frust
  * SearchByProjection(Frame&, vector<MapPoint*>&, th, th_far) (src/ORBmatcher.cc:237-266): d_queries[p * n_cams + k]
  * is the k-th camera that sees candidate p (flags = 0 in the unused slots), *d_nq = n_points * n_cams.
  * d_alias[p] >= 0 (may be NULL): candidate p is the same map point as entry d_alias[p] of the frame's point table;
- * it gets no query when d_held[d_alias[p]] != 0 (vieo_track_mark_held_batch_device).  d_track_depth[p] = mTrackDepth
+ * it gets no query when d_held[d_alias[p]] != 0 (vieo_track_mark_held_batch_device; d_held has held_cap entries,
+ * larger indices count as not held).  d_track_depth[p] = mTrackDepth
  * (-1 when no camera sees the point).  d_scale: scalepyrinfo_.vscalefactor_ (n_levels floats). */
 int vieo_track_local_queries_device(const vieo_frustum_frame* h_frame, const vieo_vio_frame* d_frame,
                                     const vieo_vio_result* d_result, const vieo_frustum_point* d_points,
-                                    const uint8_t* d_desc, const int32_t* d_alias, const uint8_t* d_held, int n_points,
-                                    float th, float th_far, const float* d_scale, vieo_proj_query* d_queries,
+                                    const uint8_t* d_desc, const int32_t* d_alias, const uint8_t* d_held, int held_cap,
+                                    int n_points, float th, float th_far, const float* d_scale, vieo_proj_query* d_queries,
                                     float* d_track_depth, int32_t* d_nq, void* stream);
 
 /* void MapPoint::ComputeDistinctiveDescriptors() (src/MapPoint.cc:314-378) for a batch of points: point p owns

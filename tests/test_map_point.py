@@ -315,7 +315,7 @@ def test_track_local_queries_device(oracle, rig):
         Fz = F.copy()
         Fz[0]["Rcrw"], Fz[0]["tcrw"], Fz[0]["Ow"] = 0, 0, 0  # ignored by the device entry
         check(lib().vieo_track_local_queries_device(Fz.ctypes.data, d_fr.ptr, d_res.ptr, d_P.ptr, d_desc.ptr, d_alias.ptr,
-                                                    d_held.ptr, n, th, 0.0, d_scale.ptr, d_q.ptr, d_dep.ptr, d_nq.ptr, None))
+                                                    d_held.ptr, len(held), n, th, 0.0, d_scale.ptr, d_q.ptr, d_dep.ptr, d_nq.ptr, None))
         check(lib().vieo_device_synchronize())
         got = d_q.download(PROJ_QUERY_DTYPE, (n * S,))
         dep = d_dep.download(np.float32, (n,))

@@ -99,7 +99,7 @@ k_in_frustum(const FrustumDev* __restrict__ fd, const vieo_frustum_point* __rest
 __global__ void __launch_bounds__(256)
 k_track_local_queries(FrustumDev tmpl, const vieo_vio_frame* __restrict__ frame, const vieo_vio_result* __restrict__ result,
                       const vieo_frustum_point* __restrict__ pts, const uint8_t* __restrict__ desc,
-                      const int32_t* __restrict__ alias, const uint8_t* __restrict__ held, int n, float th, float th_far,
+                      const int32_t* __restrict__ alias, const uint8_t* __restrict__ held, int held_cap, int n, float th, float th_far,
                       const float* __restrict__ scale, vieo_proj_query* __restrict__ queries,
                       float* __restrict__ track_depth, int32_t* __restrict__ nq) {
   __shared__ vieo_frustum_frame sF;
@@ -139,7 +139,7 @@ k_track_local_queries(FrustumDev tmpl, const vieo_vio_frame* __restrict__ frame,
   const int S = sF.n_cams;
   int cnt = T.n;
   if (th_far > 0.f && T.track_depth > th_far) cnt = 0;
-  if (alias && alias[m] >= 0 && held[alias[m]]) cnt = 0;
+  if (alias && alias[m] >= 0 && alias[m] < held_cap && held[alias[m]]) cnt = 0;
   track_depth[m] = T.track_depth;
   const uint4* d = (const uint4*)(desc + (size_t)m * 32);
   const uint4 d0 = d[0], d1 = d[1];
@@ -319,11 +319,11 @@ int vieo_is_in_frustum_batch(const vieo_frustum_frame* h_frame, const vieo_frust
 
 int vieo_track_local_queries_device(const vieo_frustum_frame* h_frame, const vieo_vio_frame* d_frame,
                                     const vieo_vio_result* d_result, const vieo_frustum_point* d_points,
-                                    const uint8_t* d_desc, const int32_t* d_alias, const uint8_t* d_held, int n_points,
-                                    float th, float th_far, const float* d_scale, vieo_proj_query* d_queries,
+                                    const uint8_t* d_desc, const int32_t* d_alias, const uint8_t* d_held, int held_cap,
+                                    int n_points, float th, float th_far, const float* d_scale, vieo_proj_query* d_queries,
                                     float* d_track_depth, int32_t* d_nq, void* stream) {
   if (!h_frame || !d_frame || !d_result || n_points < 0 || !d_scale || !d_nq ||
-      (n_points > 0 && (!d_points || !d_desc || !d_queries || !d_track_depth)) || (d_alias && !d_held))
+      (n_points > 0 && (!d_points || !d_desc || !d_queries || !d_track_depth)) || (d_alias && (!d_held || held_cap <= 0)))
     return VIEO_E_INVALID;
   if (h_frame->n_cams < 1 || h_frame->n_cams > 4 || !h_frame->cams || h_frame->n_levels <= 0) {
     set_error("SearchLocalPoints: n_cams = %d (1..4) with cameras and n_levels > 0", h_frame->n_cams);
@@ -341,7 +341,7 @@ int vieo_track_local_queries_device(const vieo_frustum_frame* h_frame, const vie
       return VIEO_E_INVALID;
     }
   hipLaunchKernelGGL(k_track_local_queries, dim3(std::max(1, (n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fd,
-                     d_frame, d_result, d_points, d_desc, d_alias, d_held, n_points, th, th_far, d_scale, d_queries,
+                     d_frame, d_result, d_points, d_desc, d_alias, d_held, held_cap, n_points, th, th_far, d_scale, d_queries,
                      d_track_depth, d_nq);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;

@@ -7,6 +7,9 @@
 // refinement, the block sums of the pose optimisations and of the local BA) spent a large part of their time there.
 // The DPP forms below need no LDS and no address: 4 steps inside a row of 16 lanes (two quad permutes, the two row
 // mirrors), two row broadcasts, one v_readlane.
+//
+// All 64 lanes must be active at the call (the result is read from lane 63, and a DPP read of an inactive lane returns
+// the `old` operand): call them in wave-uniform control flow only.
 #pragma once
 #include <hip/hip_runtime.h>
 

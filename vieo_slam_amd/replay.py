@@ -642,6 +642,18 @@ class ChainedReplay(Replay):
         ff["log_scale_factor"] = np.float32(np.log(np.float32(SCALE)))
         self.stats["fallbacks"] = 0
 
+    def close(self):
+        for a in (getattr(self, "ain", None), getattr(self, "aout", None)):
+            if a is not None:
+                a.free()
+        self.ain = self.aout = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _all_local_points(self):
         out, seen = [], set()
         for k in self.kfs[-self.n_local_kfs:]:
@@ -721,7 +733,7 @@ class ChainedReplay(Replay):
                                                        1, self.d_f2, self.d_taken.ptr, st))
             check(L.vieo_track_mark_held_batch_device(self.d_mpref, self.d_cnt, cap, 1, 0, 2, self.d_held.ptr, self.pcap, st))
             check(L.vieo_track_local_queries_device(self.ff.ctypes.data, self.d_f1, self.d_r1, self.d_cpt, self.d_cdesc,
-                                                    self.d_alias, self.d_held.ptr, nc, self.th_local, 0.0, self.d_scale,
+                                                    self.d_alias, self.d_held.ptr, self.pcap, nc, self.th_local, 0.0, self.d_scale,
                                                     self.d_q2.ptr, self.d_dep + 4 * cap, self.d_nq, st), "local queries")
             check(L.vieo_search_by_projection_batch_device(1, self.d_q2.ptr, self.d_nq, self.CCAP, 1, self.d_kp, self.d_ur,
                                                            self.d_desc, self.d_taken.ptr, self.d_cnt, cap, 0, 2, self.bounds,
