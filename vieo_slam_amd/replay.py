@@ -655,6 +655,14 @@ class ChainedReplay(Replay):
             pass
 
     def _all_local_points(self):
+        # the local key frames and their points change only when a key frame is inserted / a local BA has run
+        key = (len(self.kfs), self.stats["lba"])
+        if getattr(self, "_lp_key", None) == key:
+            return self._lp
+        self._lp_key, self._lp = key, self._all_local_points_now()
+        return self._lp
+
+    def _all_local_points_now(self):
         out, seen = [], set()
         for k in self.kfs[-self.n_local_kfs:]:
             for m in k.mp_ref[k.mp_ref >= 0]:
