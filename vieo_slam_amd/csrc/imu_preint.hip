@@ -33,20 +33,27 @@ __device__ void preint_cov_wave(PreIntD& P, double* S, int iR, int iV, const dou
   double* Bg = T + 81;
   double* Ba = Bg + 27;
   double* TB = Ba + 27;
+  double* NgL = TB + 27;  // the noise matrices in LDS: they are indexed by lane below
+  double* NaL = NgL + 9;
   const int lane = P.lane;
   for (int e = lane; e < 81; e += 64) A[e] = (e % 10) == 0 ? 1.0 : 0.0;
   if (lane < 27) Bg[lane] = 0, Ba[lane] = 0;
   preint_wave_sync();
-  if (lane < 9) {
-    const int i = lane / 3, j = lane - 3 * i;
-    A[(iR + i) * 9 + iR + j] = dRt[lane] * 1.0;
-    A[(iV + i) * 9 + iR + j] = Rsk[lane] * -dt;
-    A[i * 9 + iR + j] = Rsk[lane] * -dt2div2;
-    A[i * 9 + iV + j] = (i == j ? 1.0 : 0.0) * dt;
-    Bg[(iR + i) * 3 + j] = Jr[lane] * dt;
-    Ba[(iV + i) * 3 + j] = P.R[lane] * dt;
-    Ba[i * 3 + j] = P.R[lane] * dt2div2;
-  }
+  // lane e writes element e of the 3 x 3 blocks: compile-time element indices (dRt[lane] & co. would put the
+  // arrays, which every lane holds in registers, into scratch memory)
+#pragma unroll
+  for (int e = 0; e < 9; e++)
+    if (lane == e) {
+      const int i = e / 3, j = e - 3 * i;
+      A[(iR + i) * 9 + iR + j] = dRt[e] * 1.0;
+      A[(iV + i) * 9 + iR + j] = Rsk[e] * -dt;
+      A[i * 9 + iR + j] = Rsk[e] * -dt2div2;
+      A[i * 9 + iV + j] = (i == j ? 1.0 : 0.0) * dt;
+      Bg[(iR + i) * 3 + j] = Jr[e] * dt;
+      Ba[(iV + i) * 3 + j] = P.R[e] * dt;
+      Ba[i * 3 + j] = P.R[e] * dt2div2;
+      NgL[e] = Ng[e], NaL[e] = Na[e];
+    }
   preint_wave_sync();
   for (int e = lane; e < 81; e += 64) {
     const int i = e / 9, j = e - 9 * i;
@@ -64,7 +71,7 @@ __device__ void preint_cov_wave(PreIntD& P, double* S, int iR, int iV, const dou
   preint_wave_sync();
   for (int which = 0; which < 2; which++) {  // S += Bg Ng Bg^T, then S += Ba Na Ba^T
     const double* B = which ? Ba : Bg;
-    const double* N = which ? Na : Ng;
+    const double* N = which ? NaL : NgL;
     if (lane < 27) {
       const int i = lane / 3, j = lane - 3 * i;
       TB[lane] = B[i * 3] * N[j] + B[i * 3 + 1] * N[3 + j] + B[i * 3 + 2] * N[6 + j];
@@ -110,7 +117,7 @@ __device__ __forceinline__ void preint_block(double* M, int ld, int r0, int c0, 
 // some intervals -- caught by tests/test_imu_preint.py::test_wave_and_lane_instantiations_agree_bitwise; the
 // out-of-line call is what round 1 shipped and what the parity test pins)
 template <bool WAVE>
-__device__ __attribute__((noinline)) void preint_update(PreIntD& P, const vieo_imu_noise& N, const double* omega, const double* acc, double dt) {
+__device__ __forceinline__ void preint_update_body(PreIntD& P, const vieo_imu_noise& N, const double* omega, const double* acc, double dt) {
   const double dt2div2 = dt * dt / 2;
   const double wdt[3] = {omega[0] * dt, omega[1] * dt, omega[2] * dt};
   double dR[9], Jr[9], skewa[9], dRt[9], Rsk[9];
@@ -174,6 +181,20 @@ __device__ __attribute__((noinline)) void preint_update(PreIntD& P, const vieo_i
   P.dt += dt;
 }
 
+// The lane-per-interval instantiation calls the update out of line (see above); the wavefront-per-interval one inlines it:
+// out of line the integrator state `P` lives in scratch memory and every access inside the (serial) recursion is a
+// memory round trip -- 265 us for one interval of ten samples.
+__device__ __attribute__((noinline)) void preint_update_lane(PreIntD& P, const vieo_imu_noise& N, const double* omega, const double* acc, double dt) {
+  preint_update_body<false>(P, N, omega, acc, dt);
+}
+template <bool WAVE>
+__device__ __forceinline__ void preint_update(PreIntD& P, const vieo_imu_noise& N, const double* omega, const double* acc, double dt) {
+  if constexpr (WAVE)
+    preint_update_body<true>(P, N, omega, acc, dt);
+  else
+    preint_update_lane(P, N, omega, acc, dt);
+}
+
 template <bool WAVE>
 __global__ void __launch_bounds__(64)
 k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __restrict__ samples,
@@ -182,7 +203,7 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
              double* __restrict__ sigma_prv, int32_t* __restrict__ status) {
   const int k = WAVE ? blockIdx.x : blockIdx.x * 64 + threadIdx.x;
   if (k >= n) return;
-  __shared__ double s_cov[WAVE ? 2 * 81 + 81 + 81 + 27 * 3 : 1];
+  __shared__ double s_cov[WAVE ? 2 * 81 + 81 + 81 + 27 * 3 + 18 : 1];
   double S_priv[WAVE ? 1 : 81], Sprv_priv[WAVE ? 1 : 81];
   const vieo_imu_noise N = *noise;
   const vieo_imu_sample* L = samples + first[k];
@@ -257,26 +278,46 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
           }
         }
       }
-      double w[3], a[3];
+      // up to three updates per sample pair (partial first step, the mid-point step, partial last step), collected
+      // first and run by ONE loop body: three inlined copies of the update were 100 KB of code for a single wavefront
+      double wq[3][3], aq[3][3], dtq[3];
+      int nsub = 0;
       if (jm1 == iter_start) {
         const double dt_comple = L[jm1].t - ti;
         if (back ? dt_comple < 0 : dt_comple > 0) {
-          for (int q = 0; q < 3; q++) w[q] = imu.w[q] - bg[q], a[q] = imu.a[q] - ba[q];
-          preint_update<WAVE>(P, N, w, a, dt_comple);
+          for (int q = 0; q < 3; q++) wq[0][q] = imu.w[q] - bg[q], aq[0][q] = imu.a[q] - ba[q];
+          dtq[0] = dt_comple;
+          nsub = 1;
           dt -= dt_comple;
-          if (!dt) continue;
         }
       }
-      double dt_comple_stop = 0;
-      if (j == iter_stop) {
-        dt_comple_stop = tj - imu_now.t;
-        if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) dt -= dt_comple_stop;
+      if (dt != 0 || nsub == 0) {
+        double dt_comple_stop = 0;
+        if (j == iter_stop) {
+          dt_comple_stop = tj - imu_now.t;
+          if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) dt -= dt_comple_stop;
+        }
+        for (int q = 0; q < 3; q++) {
+          const double wm = (imu_now.w[q] + imu.w[q]) / 2 - bg[q], am = (imu_now.a[q] + imu.a[q]) / 2 - ba[q];
+          if (nsub == 0) wq[0][q] = wm, aq[0][q] = am; else wq[1][q] = wm, aq[1][q] = am;
+        }
+        if (nsub == 0) dtq[0] = dt; else dtq[1] = dt;
+        nsub++;
+        if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) {
+          for (int q = 0; q < 3; q++) {
+            const double wl = imu_now.w[q] - bg[q], al = imu_now.a[q] - ba[q];
+            if (nsub == 1) wq[1][q] = wl, aq[1][q] = al; else wq[2][q] = wl, aq[2][q] = al;
+          }
+          if (nsub == 1) dtq[1] = dt_comple_stop; else dtq[2] = dt_comple_stop;
+          nsub++;
+        }
       }
-      for (int q = 0; q < 3; q++) w[q] = (imu_now.w[q] + imu.w[q]) / 2 - bg[q], a[q] = (imu_now.a[q] + imu.a[q]) / 2 - ba[q];
-      preint_update<WAVE>(P, N, w, a, dt);
-      if (back ? dt_comple_stop < 0 : dt_comple_stop > 0) {
-        for (int q = 0; q < 3; q++) w[q] = imu_now.w[q] - bg[q], a[q] = imu_now.a[q] - ba[q];
-        preint_update<WAVE>(P, N, w, a, dt_comple_stop);
+#pragma nounroll
+      for (int u = 0; u < nsub; u++) {
+        double w[3], a[3];
+        for (int q = 0; q < 3; q++) w[q] = u == 0 ? wq[0][q] : u == 1 ? wq[1][q] : wq[2][q], a[q] = u == 0 ? aq[0][q] : u == 1 ? aq[1][q] : aq[2][q];
+        const double dtu = u == 0 ? dtq[0] : u == 1 ? dtq[1] : dtq[2];
+        preint_update<WAVE>(P, N, w, a, dtu);
       }
     }
   }
