@@ -533,13 +533,15 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
       const int n = ny & 0xFFFF, q = q0 + qq;
       // two smallest (dist, order) among usable candidates; lane owns positions lane, lane+64.  The keys are unique
       // (they carry the position), so the second smallest is the minimum once the winner's lane puts its other key
-      // forward; the winners' candidate words are read back from the pool by position.
+      // forward; the winners' candidate words are read back from their lanes' registers.
       unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
+      unsigned cand2[2] = {0u, 0u};  // the lane's candidate words: the winners are read back from here
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int pos = lane + 64 * h;
         if (pos < n) {
           const unsigned c = off + pos < n_lds ? s_pool[off + pos] : pool[off + pos];
+          cand2[h] = c;
           const int idx = c & 0x1FFF, d = (c >> 13) & 0x1FF;
           const int st = s_state[idx];
           if (A.mode == VIEO_SBP_RELOC ? !(st & 1) : !((st & 1) && (st & 2))) {
@@ -554,15 +556,10 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
       const unsigned m0 = wave_min_u32(b0);
       const unsigned m1 = wave_min_u32(b0 == m0 ? b1 : b0);
       b0 = m0, b1 = m1;
+      // (uniform position -> that lane's register: v_readlane instead of another LDS round trip)
       unsigned c0 = 0, c1 = 0;
-      if (b0 != 0xFFFFFFFFu) {
-        const int p0 = off + (int)(b0 & 0xFF);
-        c0 = p0 < n_lds ? s_pool[p0] : pool[p0];
-      }
-      if (b1 != 0xFFFFFFFFu) {
-        const int p1 = off + (int)(b1 & 0xFF);
-        c1 = p1 < n_lds ? s_pool[p1] : pool[p1];
-      }
+      if (b0 != 0xFFFFFFFFu) c0 = (unsigned)__builtin_amdgcn_readlane((int)((b0 & 64u) ? cand2[1] : cand2[0]), (int)(b0 & 63u));
+      if (b1 != 0xFFFFFFFFu) c1 = (unsigned)__builtin_amdgcn_readlane((int)((b1 & 64u) ? cand2[1] : cand2[0]), (int)(b1 & 63u));
       if (b0 == 0xFFFFFFFFu) continue;
       const int bestDist = b0 >> 8;
       const int bestIdx = c0 & 0x1FFF, bestLevel = (c0 >> 22) & 15;
