@@ -186,50 +186,58 @@ __device__ __forceinline__ void set3(double* J, int ld, int r0, int c0, const do
 // EdgeNavStateI<NV>::linearizeOplus (g2otypes.h:777-884).  J is 9 x 24:
 // columns 0..8 = state j, 9..17 = state i (each p, then R at idR, V at idV), 18..23 = Bias_i;
 // rows as in imu_error.  (idR, idV) = (6, 3) for PVR, (3, 6) for PRV.
+// part: 0 = the whole Jacobian (J is cleared first); 1 = the position and velocity rows, 2 = the rotation rows -- the two
+// halves share no intermediate, so two lanes of different wavefronts can form them side by side (the caller clears J).
 static __device__ void imu_linearize(const vieo_imu_preint& M, const double* gw, const NSd& si, const NSd& sj,
-                              const double* err, double* J, int idR = 6, int idV = 3) {
+                              const double* err, double* J, int idR = 6, int idV = 3, int part = 0) {
   const int ld = 24, cj = 0, ci = 9, cb = 18;
-  for (int i = 0; i < 9 * 24; i++) J[i] = 0;
-  double Ri[9], RiT[9], Rj[9], t[3], r[3], Hm[9], I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tmp[9], tmp2[9];
-  q_to_R(q_of(si), Ri);
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) RiT[i * 3 + j] = Ri[j * 3 + i];
-  q_to_R(q_of(sj), Rj);
-  const double dt = M.dt;
-  for (int k = 0; k < 3; k++) t[k] = sj.p[k] - si.p[k] - si.v[k] * dt - gw[k] * (dt * dt / 2);
-  mv3(RiT, t, r);
-  hat3(r, Hm);
-  set3(J, ld, 0, ci + idR, Hm, 1.0);
-  set3(J, ld, 0, ci + 0, I3, -1.0);
-  set3(J, ld, 0, ci + idV, RiT, -dt);
-  set3(J, ld, 0, cb + 0, M.Jgp, -1.0);
-  set3(J, ld, 0, cb + 3, M.Jap, -1.0);
-  mm3(RiT, Rj, tmp);
-  set3(J, ld, 0, cj + 0, tmp, 1.0);
-  for (int k = 0; k < 3; k++) t[k] = sj.v[k] - si.v[k] - gw[k] * dt;
-  mv3(RiT, t, r);
-  hat3(r, Hm);
-  set3(J, ld, idV, ci + idR, Hm, 1.0);
-  set3(J, ld, idV, ci + idV, RiT, -1.0);
-  set3(J, ld, idV, cb + 0, M.Jgv, -1.0);
-  set3(J, ld, idV, cb + 3, M.Jav, -1.0);
-  set3(J, ld, idV, cj + idV, RiT, 1.0);
-  double Jrinv[9], Rji[9];
-  const double* eR = err + idR;
-  so3_JrInv_d(eR, Jrinv);
-  q_to_R(q_norm(q_mul(q_conj(q_of(sj)), q_of(si))), Rji);
-  mm3(Jrinv, Rji, tmp);
-  set3(J, ld, idR, ci + idR, tmp, -1.0);
-  const double meR[3] = {-eR[0], -eR[1], -eR[2]};
-  double E[9], w[3], Jr[9];
-  q_to_R(so3_exp_q(meR), E);
-  mv3(M.JgR, si.dbg, w);
-  so3_Jr_d(w, Jr);
-  mm3(Jrinv, E, tmp);
-  mm3(tmp, Jr, tmp2);
-  mm3(tmp2, M.JgR, tmp);
-  set3(J, ld, idR, cb + 0, tmp, -1.0);
-  set3(J, ld, idR, cj + idR, Jrinv, 1.0);
+  if (part == 0)
+    for (int i = 0; i < 9 * 24; i++) J[i] = 0;
+  double tmp[9], tmp2[9];
+  if (part != 2) {
+    double Ri[9], RiT[9], Rj[9], t[3], r[3], Hm[9], I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    q_to_R(q_of(si), Ri);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) RiT[i * 3 + j] = Ri[j * 3 + i];
+    q_to_R(q_of(sj), Rj);
+    const double dt = M.dt;
+    for (int k = 0; k < 3; k++) t[k] = sj.p[k] - si.p[k] - si.v[k] * dt - gw[k] * (dt * dt / 2);
+    mv3(RiT, t, r);
+    hat3(r, Hm);
+    set3(J, ld, 0, ci + idR, Hm, 1.0);
+    set3(J, ld, 0, ci + 0, I3, -1.0);
+    set3(J, ld, 0, ci + idV, RiT, -dt);
+    set3(J, ld, 0, cb + 0, M.Jgp, -1.0);
+    set3(J, ld, 0, cb + 3, M.Jap, -1.0);
+    mm3(RiT, Rj, tmp);
+    set3(J, ld, 0, cj + 0, tmp, 1.0);
+    for (int k = 0; k < 3; k++) t[k] = sj.v[k] - si.v[k] - gw[k] * dt;
+    mv3(RiT, t, r);
+    hat3(r, Hm);
+    set3(J, ld, idV, ci + idR, Hm, 1.0);
+    set3(J, ld, idV, ci + idV, RiT, -1.0);
+    set3(J, ld, idV, cb + 0, M.Jgv, -1.0);
+    set3(J, ld, idV, cb + 3, M.Jav, -1.0);
+    set3(J, ld, idV, cj + idV, RiT, 1.0);
+  }
+  if (part != 1) {
+    double Jrinv[9], Rji[9];
+    const double* eR = err + idR;
+    so3_JrInv_d(eR, Jrinv);
+    q_to_R(q_norm(q_mul(q_conj(q_of(sj)), q_of(si))), Rji);
+    mm3(Jrinv, Rji, tmp);
+    set3(J, ld, idR, ci + idR, tmp, -1.0);
+    const double meR[3] = {-eR[0], -eR[1], -eR[2]};
+    double E[9], w[3], Jr[9];
+    q_to_R(so3_exp_q(meR), E);
+    mv3(M.JgR, si.dbg, w);
+    so3_Jr_d(w, Jr);
+    mm3(Jrinv, E, tmp);
+    mm3(tmp, Jr, tmp2);
+    mm3(tmp2, M.JgR, tmp);
+    set3(J, ld, idR, cb + 0, tmp, -1.0);
+    set3(J, ld, idR, cj + idR, Jrinv, 1.0);
+  }
 }
 
 // EdgeEncNavState<DV>::computeError / linearizeOplus (g2otypes.h:606-665, USE_P_PLUS_RDP on): the 6-row encoder

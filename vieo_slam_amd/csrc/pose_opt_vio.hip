@@ -239,6 +239,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   VioEncShared* SE = reinterpret_cast<VioEncShared*>(s_enc_store);
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T1 = BS > 64 ? 64 : 0, T2 = BS > 128 ? 128 : 0;  // lanes of the second / third serial role
+  const int T3 = BS > 192 ? 192 : 0;  // fourth: the rotation rows of the inertial Jacobian (its two halves are independent)
   const vieo_vio_frame& F = frames[f];
   const int N = F.base.n_obs;
   const vieo_pose_obs* obs = obs_all + F.base.obs_begin;
@@ -461,6 +462,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
       }
       block_sum_bs<28, BS>(acc, S.red, tid);
+      if (BS > 192)
+        for (int i = tid; i < 9 * 24; i += BS) S.JI[i] = 0;  // cleared by everybody; its halves are filled below
       __syncthreads();
       if (tid < 28) {  // publish the sums (select, not acc[tid]: the sums stay in registers)
         double v = 0;
@@ -472,7 +475,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       double currentChi = chiG + acc[27];
       const double iniChi = currentChi;
       // generic Jacobians
-      if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
+      if (BS > 192) {  // position / velocity rows on wavefront 0, rotation rows on wavefront 3, side by side
+        if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
+        if (tid == T3 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2);
+      } else if (tid == 0 && hasImu)
+        imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
       if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
       if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
       const double rhoE0 = rhoE;  // the trial evaluations below overwrite rhoE
@@ -710,6 +717,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
     }
     block_sum_bs<27, BS>(acc, S.red, tid);
+    if (BS > 192)
+      for (int i = tid; i < 9 * 24; i += BS) S.JI[i] = 0;
     __syncthreads();
     if (tid < 27) {
       double v = 0;
@@ -718,7 +727,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         if (tid == t) v = acc[t];
       S.vis[tid] = v;
     }
-    if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
+    if (BS > 192) {
+      if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
+      if (tid == T3 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2);
+    } else if (tid == 0 && hasImu)
+      imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
     if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
     if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
     for (int i = tid; i < 225; i += BS) S.cov[i] = 0, S.C[i] = 0, S.E[i] = 0;
