@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
   const vieo_keypoint* KR = A.kpR + (size_t)imR * A.capR;
   const uint8_t* DR = A.descR + (size_t)imR * A.capR * 32;
   int bestDist = TH_HIGH, bestIdx = INT_MAX;
+  float bestX = 0.f;  // column of the lane's best right key (it travels with the row list)
   if (rowL < 0 || rowL >= A.H) return;
   const int* rs = A.row_start + (size_t)f * (A.H + 1);
   const int2* list = A.row_list + (size_t)f * A.list_cap;
@@ -195,8 +196,9 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
     if (octR < levelL - 1 || octR > levelL + 1) continue;
     if (!(xR >= minU && xR <= maxU)) continue;
     const int d = hamming32(a0, a1, DR + (size_t)j * 32);
-    if (d < TH_HIGH && lex_less(d, j, bestDist, bestIdx)) bestDist = d, bestIdx = j;
+    if (d < TH_HIGH && lex_less(d, j, bestDist, bestIdx)) bestDist = d, bestIdx = j, bestX = xR;
   }
+  const int myIdx = bestIdx;
   {  // lexicographic minimum of (distance, index) as ONE key (distance <= 256, index < 2^20)
     const unsigned m = wave_min_u32(bestIdx == INT_MAX ? 0xFFFFFFFFu : ((unsigned)bestDist << 20) | (unsigned)bestIdx);
     bestIdx = m == 0xFFFFFFFFu ? INT_MAX : (int)(m & 0xFFFFF);
@@ -204,7 +206,9 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
   }
   if (bestIdx == INT_MAX || bestDist >= (TH_HIGH + TH_LOW) / 2) return;
   // ---- sub-pixel refinement by 11 SADs of 11x11 patches at the key's pyramid level
-  const float uR0 = KR[bestIdx].x;
+  // the winner's column from the lane that found it (one dependent load less than KR[bestIdx].x)
+  const unsigned long long own = __ballot(myIdx == bestIdx);
+  const float uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bestX), __builtin_ffsll((long long)own) - 1));
   const float sF = 1.0f / A.P.lv[levelL].scale;  // mvInvScaleFactors[octave]
   const float scaleduL = roundf(kL.x * sF), scaledvL = roundf(kL.y * sF);
   const float scaleduR0 = roundf(uR0 * sF);
