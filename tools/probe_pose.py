@@ -1,0 +1,16 @@
+import sys, ctypes, numpy as np
+sys.path.insert(0, "/root/repo")
+from vieo_slam_amd import replay, _lib
+n = 40
+seq = replay.Sequence(1, n)
+Rc = replay.ChainedReplay(seq, replay.HipStages())
+Rc.run(n)
+out = (ctypes.c_ulonglong * 16)()
+L = _lib.lib()
+f = ctypes.CDLL(_lib.LIB_PATH).vieo_debug_pose_probe
+f(out)
+v = np.array(list(out), float)
+names = ["loop/bookkeeping", "generic_errors", "visual linearize loop", "block_sum", "publish + imu/prior linearize", "H assembly", "backup + ldlt", "ns_inc", "generic_errors (trial)", "visual_chi (trial)", "iteration tail"]
+tot = v[:11].sum()
+for i, nm in enumerate(names): print("%-32s %6.1f %%  %9.0f cycles per pose call" % (nm, 100 * v[i] / tot, v[i] / (2 * (n - 1))))
+print("total cycles per pose call %.0f = %.0f us at 2.4 GHz" % (tot / (2 * (n - 1)), tot / (2 * (n - 1)) / 2400))

@@ -228,6 +228,12 @@ __device__ __noinline__ void vio_enc_eval(const vieo_pose_enc* pe, VioEncShared*
 // MC as in pose_opt.hip: the instance for frames of a distorted multi-camera rig (n_cams > 0, a20)
 // ENC: the instance for frames that carry an encoder measurement (base.enc with dt != 0, a16)
 // other_launched: bit 0 the other camera kind, bit 1 the other encoder kind has its own launch in this batch
+#ifdef VIEO_POSE_PROBE
+__device__ unsigned long long g_pose_probe[16];
+#define PP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_pose_probe[i], t_ - pp_last); pp_last = t_; } } while (0)
+#else
+#define PP(i)
+#endif
 template <int BS, bool MC, bool ENC>
 __global__ void __launch_bounds__(BS)
 k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
@@ -422,6 +428,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     return tc[0];
   };
 
+#ifdef VIEO_POSE_PROBE
+  unsigned long long pp_last = __builtin_amdgcn_s_memtime();
+#endif
   for (int it = 0; it < 4; it++) {
     __syncthreads();
     if (!bodom && tid == 0) {  // Optimizer.h:538-545
@@ -435,7 +444,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       total_iters++;
       // ---- computeActiveErrors + activeRobustChi2 + buildSystem
       double rhoI, rhoB, rhoP;
+      PP(0);
       const double chiG = generic_errors(&rhoI, &rhoB, &rhoP);
+      PP(1);
       Est e;
       e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
       e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
@@ -461,7 +472,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         acc[27] += r0;
         visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
       }
+      PP(2);
       block_sum_bs<28, BS>(acc, S.red, tid);
+      PP(3);
       if (BS > 192)
         for (int i = tid; i < 9 * 24; i += BS) S.JI[i] = 0;  // cleared by everybody; its halves are filled below
       __syncthreads();
@@ -482,6 +495,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
       if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
       if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
+      PP(4);
       const double rhoE0 = rhoE;  // the trial evaluations below overwrite rhoE
       for (int i = tid; i < n * n; i += BS) S.H[i] = 0;
       if (tid < n) S.b[tid] = 0;
@@ -579,6 +593,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         }
       }
       __syncthreads();
+      PP(5);
       if (iter == 0) {
         double mx = 0;
         for (int j = 0; j < n; j++) mx = fmax(fabs(S.H[j * n + j]), mx);
@@ -598,6 +613,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           if (lane == 0) S.ok = ok ? 1 : 0;
         }
         __syncthreads();
+        PP(6);
         const bool ok2 = S.ok != 0;
         if (tid == 0) {
           if (!ok2)
@@ -606,9 +622,12 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           if (!fixedLast) ns_inc(S.nsi, S.x + 15, S.x + 24);
         }
         __syncthreads();
+        PP(7);
         double r1, r2, r3;
         double tempChi = generic_errors(&r1, &r2, &r3);
+        PP(8);
         tempChi += visual_chi();
+        PP(9);
         if (!ok2) tempChi = DBL_MAX;
         rho = currentChi - tempChi;
         double scale = 0;
@@ -637,6 +656,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         nBadLM = 0;
       if (nBadLM >= 3) break;
     }
+    PP(10);
     // ---- classification at the current estimate (Optimizer.h:554-611)
     __syncthreads();
     Est e;
@@ -961,3 +981,13 @@ int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_ob
 }
 
 }  // extern "C"
+
+#ifdef VIEO_POSE_PROBE
+extern "C" int vieo_debug_pose_probe(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vieo::g_pose_probe), sizeof(unsigned long long) * 16);
+  unsigned long long z[16] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(vieo::g_pose_probe), z, sizeof(z));
+  return 0;
+}
+#endif
