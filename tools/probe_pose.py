@@ -1,3 +1,6 @@
+"""Phase times of k_pose_opt_vio<256> on the chained sequential replay from s_memtime probes inside the kernel.
+Needs a library built with the probes: VIEO_EXTRA_HIPCC_FLAGS=-DVIEO_POSE_PROBE (touch csrc/pose_opt_vio.hip first: the
+build only looks at modification times).  Output of round 2: profiles/r2g_pose_probe.txt."""
 import sys, ctypes, numpy as np
 sys.path.insert(0, "/root/repo")
 from vieo_slam_amd import replay, _lib

@@ -1,3 +1,5 @@
+"""Chained sequential replay (replay.ChainedReplay): ms per frame split into host preparation / launches / GPU wait, and a
+cProfile of the driver; run under rocprofv3 --kernel-trace for the per-kernel times (profiles/r2g_chained_frame.md)."""
 import sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
 from vieo_slam_amd import replay

@@ -1,3 +1,4 @@
+"""cProfile of the host side of the chained sequential replay (where the Python driver spends its time per frame)."""
 import sys, time, numpy as np, cProfile, pstats
 sys.path.insert(0, "/root/repo")
 from vieo_slam_amd import replay
