@@ -92,3 +92,19 @@ def test_gpu_chained_replay_one_sync_per_frame(oracle):
     assert replay.ate_between(tc, th) <= 1e-5
     print("chained replay: ATE vs oracle %.3e m, vs stage-by-stage %.3e m, %.2f ms per frame (stage-by-stage %.2f)"
           % (ate, replay.ate_between(tc, th), np.mean(Rc.stats["ms_frames"]), np.mean(Rh.stats["ms_frames"])))
+
+
+@pytest.mark.gpu
+def test_gpu_chained_replay_falls_back_stage_by_stage():
+    """The two branches the chain does not have (fewer than 20 matches in the first search -> the wider window of
+    Tracking.cc:301-309) re-run the frame through the stage-by-stage path: with a first-search window too small to find
+    20 matches every frame takes it, and the trajectory equals the stage-by-stage replay's."""
+    n = 24
+    seq = replay.Sequence(3, n)
+    Rh = replay.Replay(seq, replay.HipStages(), th_last=0.12)
+    th = Rh.run(n)
+    Rc = replay.ChainedReplay(seq, replay.HipStages(), th_last=0.12)
+    tc = Rc.run(n)
+    assert Rc.stats["fallbacks"] > 0
+    assert np.array_equal(Rh.stats["n_matches"], Rc.stats["n_matches"])
+    assert replay.ate_between(tc, th) <= 1e-9
