@@ -685,8 +685,9 @@ int vieo_bundle_adjustment_enc(const vieo_lba_params* params, int n_iterations, 
  * edges) on every edge iff `robust`, no outlier classification, every point written back.  The visual-inertial
  * form weighs the inertial and bias edges leaving a fixed key frame by 1e-2 like the reference.  Reduced systems
  * beyond 510 unknowns are factorised by the tiled LDL^T (FP64 matrix cores); up to 16320 unknowns.
- * params->its0 / its1 (and lambda_init / rec_init / large of the VIO params) are ignored.  Not covered: the scale
- * vertex (bScaleOpt), the gravity vertex of the IMU initialiser.  Encoder edges: vieo_lba_imu_edge.enc in the
+ * params->its0 / its1 (and lambda_init / rec_init / large of the VIO params) are ignored.  Not covered: the gravity
+ * vertex of the IMU initialiser (pimu_initiator, SURVEY 2 row 14: out of scope).  bScaleOpt: the _scale entries
+ * below.  Encoder edges: vieo_lba_imu_edge.enc in the
  * visual-inertial form, vieo_bundle_adjustment_enc (bEnc = true) in the vision-only one. */
 int vieo_bundle_adjustment(const vieo_lba_params* params, int n_iterations, int robust,
                            const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
@@ -697,6 +698,19 @@ int vieo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_i
                                       const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_imu_edge* h_imu, int n_imu,
                                       volatile const int* stop, vieo_navstate* h_navs_out, float* h_points_out,
                                       vieo_lba_result* h_result);
+/* The full BA as System::FinalGBA runs it (src/System.cc:24-33: bScaleOpt = true; Examples/Stereo/stereo_euroc.cc:334-351
+ * "FullBA"), BASELINE configs[4].  scale_opt != 0 adds the VertexScale (src/Odom/g2otypes.h:292-311; estimate 1, id after
+ * every key-frame vertex, src/Optimizer.cc:842-851) and turns every visual edge into the three-vertex EdgeReprojectPRS /
+ * EdgeReprojectPRSStereo (g2otypes.h:321-541 with MODE_OPT_VAR == 1, typedefs :548-550; Optimizer.cc:1131-1137,
+ * 1190-1196): the edge projects s * Xh, the point vertex stays unscaled.  Write-back as the reference's
+ * (Optimizer.cc:1256-1335): points = (float)s * (float)Xh, key-frame states unscaled; *h_scale_out (may be NULL) = s.
+ * With the scale vertex a map whose key frames are all fixed is still optimised (bdimPoses, :850).
+ * scale_opt == 0: identical to vieo_global_bundle_adjustment_vio. */
+int vieo_global_bundle_adjustment_vio_scale(const vieo_lba_vio_params* params, int n_iterations, int robust, int scale_opt,
+                                            const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
+                                            const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_imu_edge* h_imu,
+                                            int n_imu, volatile const int* stop, vieo_navstate* h_navs_out,
+                                            float* h_points_out, vieo_lba_result* h_result, double* h_scale_out);
 
 /* ---- one window over several GPUs ---------------------------------------------------
  * Landmark-sharded LocalBundleAdjustmentNavStatePRV: every rank passes ALL key frames and inertial
@@ -748,6 +762,15 @@ int vieo_global_bundle_adjustment_vio_sharded(const vieo_lba_vio_params* params,
                                               size_t reduce_cap_doubles, vieo_allreduce_sum_f64_fn allreduce,
                                               void* ctx, vieo_navstate* h_navs_out, float* h_points_out,
                                               vieo_lba_result* h_result);
+/* ... and of System::FinalGBA's form (scale_opt, see vieo_global_bundle_adjustment_vio_scale): the scale vertex's row of
+ * the reduced visual system and its H_ps / H_ss / b_s travel in the same all-reduce ((6n+1)(6n+2) + 48n + 2 doubles). */
+int vieo_global_bundle_adjustment_vio_sharded_scale(const vieo_lba_vio_params* params, int n_iterations, int robust,
+                                                    int scale_opt, const vieo_lba_keyframe* h_kfs, int n_kf,
+                                                    const float* h_points, int n_mp, const vieo_lba_obs* h_obs, int n_obs,
+                                                    const vieo_lba_imu_edge* h_imu, int n_imu, double* d_reduce_buf,
+                                                    size_t reduce_cap_doubles, vieo_allreduce_sum_f64_fn allreduce,
+                                                    void* ctx, vieo_navstate* h_navs_out, float* h_points_out,
+                                                    vieo_lba_result* h_result, double* h_scale_out);
 
 /* ---- replay glue (device-resident batches) -------------------------------------------------
  * What Tracking.cc does between the calls above, on flattened arrays, so a batch of frames runs

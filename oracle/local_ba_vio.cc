@@ -10,6 +10,11 @@
 //   BlockSolverX Schur complement, LM with user lambda init g2o/core/block_solver.hpp, optimization_algorithm_levenberg.cpp
 //   LinearSolverEigen -> dense LDL^T of the reduced (15 per key frame) system, same solution up to rounding.
 // Reduced-system order: key frames in window order, [PR (dp, dphi), V, Bias (dbg, dba)] each.
+// Full BA with bScaleOpt (System::FinalGBA, src/System.cc:24-33 -> Optimizer.cc:842-851,1131-1137,1190-1196,1256-1335):
+//   VertexScale (g2otypes.h:292-311, 1 dim, s <- s + ds, id after every key-frame vertex = last column of the pose
+//   system) and EdgeReprojectPRS / PRSStereo = EdgeReproject<DE, 6, 3, MODE_OPT_VAR = 1> (g2otypes.h:321-541,548-550):
+//   Xw = s * Xh with the point vertex unscaled, J_s = (Jproj Rcw) Xh, J_Xh = s (Jproj Rcw); the points are written back
+//   as s * Xh, the key frames as they are (the rescaling of p_wb is commented out in the reference, :1286-1289).
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -110,6 +115,8 @@ static bool mat_inverse(const double* A, double* Ainv, int n) {
 struct W {
   const vieo_lba_vio_params* P;
   bool gba = false;  // GlobalBundleAdjustmentNavStatePRV: g2o's own initial lambda
+  bool scale_opt = false;  // bScaleOpt: VertexScale + EdgeReprojectPRS[Stereo]
+  double scale = 1.0;      // VertexScale::estimate(), setEstimate(1.) (Optimizer.cc:845)
   OCam cams[4];
   std::vector<KF> kf;
   std::vector<double> X;
@@ -126,7 +133,8 @@ struct W {
     m3_T(Rwb, Rbw);
     m3_mul(C.Rcb, Rbw, Rcw);
     m3_v(Rcw, s.p, t);
-    m3_v(Rcw, &X[3 * e.mp], Pc);
+    const double Xw[3] = {X[3 * e.mp] * scale, X[3 * e.mp + 1] * scale, X[3 * e.mp + 2] * scale};  // g2otypes.h:376
+    m3_v(Rcw, Xw, Pc);
     for (int i = 0; i < 3; i++) Pc[i] += -t[i] + C.tcb[i];
     float uv[2];
     ocam_project(C, Pc, uv, nullptr);
@@ -150,7 +158,9 @@ struct W {
     project(e, proj, Pc, nullptr);
     return Pc[2] > 0.;
   }
-  void v_linearize(const VEdge& e, double* Jp, double* Jx) const {
+  // Js (de x 1, may be null): Jacobian w.r.t. the scale vertex, _jacobianOplus[0] * Ph_unscale before the point block
+  // is multiplied by the scale (g2otypes.h:514-518)
+  void v_linearize(const VEdge& e, double* Jp, double* Jx, double* Js = nullptr) const {
     const OCam& C = cams[e.cam];
     double proj[3], Pc[3], Rcw[9];
     project(e, proj, Pc, Rcw);
@@ -162,7 +172,7 @@ struct W {
     if (e.de > 2) J[6] = J[0], J[7] = J[1], J[8] = J[2] - (double)C.bf * invz_2;
     double Rwb[9], dP[3], Paux[3], H[9], RcbH[9];
     quat_to_R(s.q, Rwb);
-    for (int i = 0; i < 3; i++) dP[i] = X[3 * e.mp + i] - s.p[i];
+    for (int i = 0; i < 3; i++) dP[i] = X[3 * e.mp + i] * scale - s.p[i];  // Pw = s * Xh
     m3T_v(Rwb, dP, Paux);
     hat(Paux, H);
     m3_mul(C.Rcb, H, RcbH);
@@ -178,6 +188,12 @@ struct W {
         Jp[r * 6 + 3 + k] = b;
         Jx[r * 3 + k] = c;
       }
+    if (Js)
+      for (int r = 0; r < e.de; r++)
+        Js[r] = Jx[r * 3] * X[3 * e.mp] + Jx[r * 3 + 1] * X[3 * e.mp + 1] + Jx[r * 3 + 2] * X[3 * e.mp + 2];
+    if (scale_opt)
+      for (int r = 0; r < e.de; r++)
+        for (int k = 0; k < 3; k++) Jx[r * 3 + k] *= scale;
   }
 
   // ---- EdgeNavStatePRV::computeError (g2otypes.h:733-776, idR = 3) + EdgeNavStateBias
@@ -338,9 +354,10 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
     else
       B.kf[k].col = -1;
   }
+  // VertexScale: id_scale = maxKFid + 1 (Optimizer.cc:846), i.e. the last non-marginalised vertex
+  const int sc = B.scale_opt ? np : -1;
+  if (B.scale_opt) np += 1;
   if (np == 0) return;
-  const int npv = np;  // visual blocks live inside the same system
-  (void)npv;
   auto computeActiveErrors = [&]() {
     for (int i : act) B.v_error(B.E[i]);
     for (auto& e : B.I) B.i_error(e);
@@ -394,10 +411,11 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
     // ---- buildSystem
     std::vector<double> H((size_t)np * np, 0.0), b(np, 0.0), Hll((size_t)nm * 9, 0.0), bl((size_t)nm * 3, 0.0);
     std::vector<double> Bpl(B.E.size() * 18, 0.0);
+    std::vector<double> Bsl(sc >= 0 ? (size_t)nm * 3 : 0, 0.0);  // (scale, point) block, summed over the point's edges
     for (int i : act) {
       const VEdge& e = B.E[i];
-      double Jp[18], Jx[9];
-      B.v_linearize(e, Jp, Jx);
+      double Jp[18], Jx[9], Js[3] = {0, 0, 0};
+      B.v_linearize(e, Jp, Jx, sc >= 0 ? Js : nullptr);
       double wr = 1.0;
       if (e.robust) {
         double rho[2];
@@ -415,6 +433,24 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
         double s = 0;
         for (int r = 0; r < e.de; r++) s += Jx[r * 3 + a] * (-(e.info * e.err[r]) * wr);
         bl[(size_t)e.mp * 3 + a] += s;
+      }
+      if (sc >= 0) {  // BaseMultiEdge::constructQuadraticForm over (point, PR, scale): the scale's own blocks
+        double hss = 0, g = 0;
+        for (int r = 0; r < e.de; r++) hss += Js[r] * w * Js[r], g += Js[r] * (-(e.info * e.err[r]) * wr);
+        H[(size_t)sc * np + sc] += hss;
+        b[sc] += g;
+        for (int b2 = 0; b2 < 3; b2++) {
+          double t = 0;
+          for (int r = 0; r < e.de; r++) t += Js[r] * w * Jx[r * 3 + b2];
+          Bsl[(size_t)e.mp * 3 + b2] += t;
+        }
+        if (c >= 0)
+          for (int a = 0; a < 6; a++) {
+            double t = 0;
+            for (int r = 0; r < e.de; r++) t += Jp[r * 6 + a] * w * Js[r];
+            H[(size_t)(c + a) * np + sc] += t;
+            H[(size_t)sc * np + c + a] += t;
+          }
       }
       if (c >= 0) {
         for (int a = 0; a < 6; a++) {
@@ -531,6 +567,7 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
       R.lm_trials++;
       std::vector<KF> bk = B.kf;
       std::vector<double> bX = B.X;
+      const double bscale = B.scale;
       std::vector<double> Hs = H, bs = b, Dinv((size_t)nm * 9, 0.0), xp(np, 0.0);
       for (int j = 0; j < np; j++) Hs[(size_t)j * np + j] += lambda;
       for (int m = 0; m < nm; m++) {
@@ -542,6 +579,13 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
         const double* Di = &Dinv[(size_t)m * 9];
         double db[3];
         m3_v(Di, &bl[(size_t)m * 3], db);
+        double SD[3] = {0, 0, 0};
+        if (sc >= 0) {  // the scale vertex sees every point
+          const double* Bs = &Bsl[(size_t)m * 3];
+          for (int b2 = 0; b2 < 3; b2++) SD[b2] = Bs[0] * Di[b2] + Bs[1] * Di[3 + b2] + Bs[2] * Di[6 + b2];
+          Hs[(size_t)sc * np + sc] -= SD[0] * Bs[0] + SD[1] * Bs[1] + SD[2] * Bs[2];
+          bs[sc] -= Bs[0] * db[0] + Bs[1] * db[1] + Bs[2] * db[2];
+        }
         for (int i1 = B.mp_first[m]; i1 < B.mp_first[m] + B.mp_count[m]; i1++) {
           const VEdge& e1 = B.E[i1];
           const int c1 = B.kf[e1.kf].col;
@@ -553,6 +597,12 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
               BD[a * 3 + b2] = B1[a * 3] * Di[b2] + B1[a * 3 + 1] * Di[3 + b2] + B1[a * 3 + 2] * Di[6 + b2];
           for (int a = 0; a < 6; a++)
             bs[c1 + a] -= B1[a * 3] * db[0] + B1[a * 3 + 1] * db[1] + B1[a * 3 + 2] * db[2];
+          if (sc >= 0)
+            for (int a = 0; a < 6; a++) {
+              const double t = B1[a * 3] * SD[0] + B1[a * 3 + 1] * SD[1] + B1[a * 3 + 2] * SD[2];
+              Hs[(size_t)(c1 + a) * np + sc] -= t;
+              Hs[(size_t)sc * np + c1 + a] -= t;
+            }
           for (int i2 = B.mp_first[m]; i2 < B.mp_first[m] + B.mp_count[m]; i2++) {
             const VEdge& e2 = B.E[i2];
             const int c2 = B.kf[e2.kf].col;
@@ -579,6 +629,8 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
             for (int b2 = 0; b2 < 3; b2++)
               for (int a = 0; a < 6; a++) cl[b2] -= B1[a * 3 + b2] * xp[c1 + a];
           }
+          if (sc >= 0)
+            for (int b2 = 0; b2 < 3; b2++) cl[b2] -= Bsl[(size_t)m * 3 + b2] * xp[sc];
           m3_v(&Dinv[(size_t)m * 9], cl, &xl[(size_t)m * 3]);
         }
       }
@@ -589,6 +641,7 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
         for (int a = 0; a < 3; a++) s.v[a] += xp[s.col + 6 + a];
         for (int a = 0; a < 3; a++) s.dbg[a] += xp[s.col + 9 + a], s.dba[a] += xp[s.col + 12 + a];
       }
+      if (sc >= 0) B.scale += xp[sc];  // VertexScale::oplusImpl (g2otypes.h:310)
       for (int m = 0; m < nm; m++)
         if (mp_act[m])
           for (int a = 0; a < 3; a++) B.X[(size_t)m * 3 + a] += xl[(size_t)m * 3 + a];
@@ -616,6 +669,7 @@ static void optimize(W& B, int iterations, volatile const int* stop, vieo_lba_re
         ni *= 2;
         B.kf = bk;
         B.X = bX;
+        B.scale = bscale;
       }
       qmax++;
     } while (rho < 0 && qmax < 10 && !(stop && *stop));
@@ -636,8 +690,10 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
                          const float* points, const uint8_t* close, int n_mp, const vieo_lba_obs* obs,
                          int n_obs, const vieo_lba_imu_edge* imu, int n_imu, volatile const int* stop,
                          vieo_navstate* navs_out, float* points_out, uint8_t* erase, vieo_lba_result& R,
-                         int gba_iterations = -1, bool gba_robust = false) {
+                         int gba_iterations = -1, bool gba_robust = false, bool scale_opt = false,
+                         double* scale_out = nullptr) {
   const bool gba = gba_iterations >= 0;
+  if (scale_out) *scale_out = 1.;
   memset(&R, 0, sizeof(R));
   for (int k = 0; k < n_kf; k++) navs_out[k] = kfs[k].nav;
   memcpy(points_out, points, (size_t)n_mp * 12);
@@ -645,6 +701,7 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
   W B;
   B.P = &P;
   B.gba = gba;
+  B.scale_opt = gba && scale_opt;
   ocams_from_params(P.base, B.cams);
   B.kf.resize(n_kf);
   bool any_free = false;
@@ -657,6 +714,7 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
     s.fixed = kfs[k].fixed != 0;
     any_free |= !s.fixed;
   }
+  if (B.scale_opt) any_free = true;  // bdimPoses = true with the scale vertex (Optimizer.cc:850)
   if (!any_free) {  // if (!bdimPoses) return;  Optimizer.cc:178
     R.status = VIEO_LBA_NO_FREE_POSE;
     return;
@@ -770,7 +828,12 @@ static void local_ba_vio(const vieo_lba_vio_params& P, const vieo_lba_keyframe* 
     memcpy(n.p, s.p, 24), memcpy(n.v, s.v, 24), memcpy(n.dbg, s.dbg, 24), memcpy(n.dba, s.dba, 24);
     n.q[0] = s.q.w, n.q[1] = s.q.x, n.q[2] = s.q.y, n.q[3] = s.q.z;
   }
-  for (int i = 0; i < n_mp * 3; i++) points_out[i] = (float)B.X[i];
+  if (B.scale_opt) {  // SetWorldPos(scale * vPoint->estimate().cast<float>()): the scalar meets a float vector
+    const float sf = (float)B.scale;
+    for (int i = 0; i < n_mp * 3; i++) points_out[i] = sf * (float)B.X[i];
+    if (scale_out) *scale_out = B.scale;
+  } else
+    for (int i = 0; i < n_mp * 3; i++) points_out[i] = (float)B.X[i];
 }
 
 }  // namespace vov
@@ -795,6 +858,45 @@ void vo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_it
   std::vector<uint8_t> erase((size_t)n_obs + 1), close((size_t)n_mp + 1, 0);
   vov::local_ba_vio(*params, kfs, n_kf, points, close.data(), n_mp, obs, n_obs, imu, n_imu, stop, navs_out,
                     points_out, erase.data(), *result, n_iterations, robust != 0);
+}
+
+// System::FinalGBA's form (src/System.cc:24-33): bScaleOpt = true.  scale_out: the recovered VertexScale estimate.
+void vo_global_bundle_adjustment_vio_scale(const vieo_lba_vio_params* params, int n_iterations, int robust,
+                                           int scale_opt, const vieo_lba_keyframe* kfs, int n_kf, const float* points,
+                                           int n_mp, const vieo_lba_obs* obs, int n_obs, const vieo_lba_imu_edge* imu,
+                                           int n_imu, const int* stop, vieo_navstate* navs_out, float* points_out,
+                                           vieo_lba_result* result, double* scale_out) {
+  std::vector<uint8_t> erase((size_t)n_obs + 1), close((size_t)n_mp + 1, 0);
+  vov::local_ba_vio(*params, kfs, n_kf, points, close.data(), n_mp, obs, n_obs, imu, n_imu, stop, navs_out,
+                    points_out, erase.data(), *result, n_iterations, robust != 0, scale_opt != 0, scale_out);
+}
+
+// test hook: error and Jacobians of one EdgeReprojectPRS / PRSStereo (ur < 0: 2 rows) at a key-frame state, an
+// unscaled point and a scale.  Jp [3][6] (dp, dphi), Jx [3][3], Js [3]
+void vo_lba_prs_edge_eval(const vieo_lba_vio_params* params, const vieo_navstate* ns, const double* Xh, double scale,
+                          const vieo_lba_obs* obs, double* err3, double* Jp, double* Jx, double* Js) {
+  vov::W B;
+  B.P = params;
+  B.scale_opt = true, B.scale = scale;
+  vov::ocams_from_params(params->base, B.cams);
+  B.kf.resize(1);
+  vov::KF& s = B.kf[0];
+  memcpy(s.p, ns->p, 24);
+  s.q.w = ns->q[0], s.q.x = ns->q[1], s.q.y = ns->q[2], s.q.z = ns->q[3];
+  s.fixed = false, s.col = 0;
+  B.X.assign(Xh, Xh + 3);
+  vov::VEdge e;
+  e.kf = 0, e.mp = 0, e.cam = (obs->kf >> 24) & 15;
+  e.obs[0] = obs->u, e.obs[1] = obs->v, e.obs[2] = obs->ur;
+  e.de = obs->ur < 0 ? 2 : 3;
+  e.info = (double)obs->inv_sigma2;
+  B.v_error(e);
+  memcpy(err3, e.err, 24);
+  if (Jp) {
+    double jp[18] = {0}, jx[9] = {0}, js[3] = {0};
+    B.v_linearize(e, jp, jx, js);
+    memcpy(Jp, jp, sizeof(jp)), memcpy(Jx, jx, sizeof(jx)), memcpy(Js, js, sizeof(js));
+  }
 }
 
 void vo_enc_edge_eval(const vieo_navstate* nsi, const vieo_navstate* nsj, const double* meas6, const double* qRbe4,

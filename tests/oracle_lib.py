@@ -173,13 +173,24 @@ class Oracle:
                                     res.ctypes.data)
         return navs, pts, res[0]
 
-    def global_ba_vio(self, params, kfs, points, obs, imu, n_iterations=5, robust=True, stop=None):
+    def global_ba_vio(self, params, kfs, points, obs, imu, n_iterations=5, robust=True, stop=None, scale_opt=None):
+        """scale_opt is None: (navs, points, result); otherwise bScaleOpt = scale_opt (System::FinalGBA passes true)
+        and the recovered VertexScale estimate comes back as a fourth value."""
         from vieo_slam_amd.ba_types import LBA_RESULT_DTYPE, NAVSTATE_DTYPE
         params, kfs, imu = np.ascontiguousarray(params), np.ascontiguousarray(kfs), np.ascontiguousarray(imu)
         points, obs = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs)
         navs, pts, res = np.zeros(len(kfs), NAVSTATE_DTYPE), np.zeros_like(points), np.zeros(1, LBA_RESULT_DTYPE)
         st = None if stop is None else np.ascontiguousarray(stop, np.int32)
         P, I = ctypes.c_void_p, ctypes.c_int
+        if scale_opt is not None:
+            scale = np.ones(1)
+            self.L.vo_global_bundle_adjustment_vio_scale.argtypes = [P, I, I, I, P, I, P, I, P, I, P, I, P, P, P, P, P]
+            self.L.vo_global_bundle_adjustment_vio_scale(
+                params.ctypes.data, int(n_iterations), int(bool(robust)), int(bool(scale_opt)), kfs.ctypes.data, len(kfs),
+                points.ctypes.data, len(points), obs.ctypes.data, len(obs), imu.ctypes.data, len(imu),
+                None if st is None else st.ctypes.data, navs.ctypes.data, pts.ctypes.data, res.ctypes.data,
+                scale.ctypes.data)
+            return navs, pts, res[0], float(scale[0])
         self.L.vo_global_bundle_adjustment_vio.argtypes = [P, I, I, P, I, P, I, P, I, P, I, P, P, P, P]
         self.L.vo_global_bundle_adjustment_vio(params.ctypes.data, int(n_iterations), int(bool(robust)),
                                                kfs.ctypes.data, len(kfs), points.ctypes.data, len(points),
@@ -206,6 +217,19 @@ class Oracle:
                                               imu.ctypes.data, len(imu), None if st is None else st.ctypes.data,
                                               navs.ctypes.data, pts.ctypes.data, erase.ctypes.data, res.ctypes.data)
         return navs, pts, erase[:len(obs)], res[0]
+
+    def lba_prs_edge_eval(self, params, ns, Xh, scale, ob, jac=True):
+        """EdgeReprojectPRS / PRSStereo at (key-frame state, unscaled point, scale): err[3], Jp[3,6], Jx[3,3], Js[3]."""
+        err, Jp, Jx, Js = np.zeros(3), np.zeros((3, 6)), np.zeros((3, 3)), np.zeros(3)
+        P = ctypes.c_void_p
+        self.L.vo_lba_prs_edge_eval.argtypes = [P, P, P, ctypes.c_double, P, P, P, P, P]
+        params = np.ascontiguousarray(params)
+        a, o = np.zeros(1, ns.dtype), np.zeros(1, ob.dtype)
+        a[0], o[0] = ns, ob
+        X = np.ascontiguousarray(Xh, np.float64)
+        self.L.vo_lba_prs_edge_eval(params.ctypes.data, a.ctypes.data, X.ctypes.data, float(scale), o.ctypes.data,
+                                    err.ctypes.data, Jp.ctypes.data if jac else None, Jx.ctypes.data, Js.ctypes.data)
+        return err, Jp, Jx, Js
 
     def lba_imu_edge_eval(self, params, edge, nsi, nsj, jac=True):
         err = np.zeros(15)

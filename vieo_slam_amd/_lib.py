@@ -38,6 +38,10 @@ _SIGS = {
     "vieo_local_bundle_adjustment_enc": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "vieo_global_bundle_adjustment_vio": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p,
                                                 c_p]),
+    "vieo_global_bundle_adjustment_vio_scale": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p,
+                                                      c_p, c_p, c_p]),
+    "vieo_global_bundle_adjustment_vio_sharded_scale": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i,
+                                                              c_p, ctypes.c_size_t, c_p, c_p, c_p, c_p, c_p, c_p]),
     "vieo_get_device": (c_i, []),
     "vieo_version": (ctypes.c_char_p, []),
     "vieo_dev_malloc": (c_i, [P(c_p), c_sz]),

@@ -26,6 +26,13 @@
 //   k_lba_restore / k_lba_classify  rejected-step rollback; chi2 / depth gates
 // The Levenberg-Marquardt policy (lambda, accept / reject, termination, stop flag) runs on the host
 // exactly as g2o's does, from one 56-byte record per window and round.
+//
+// Full BA with bScaleOpt (System::FinalGBA, src/System.cc:24-33; Optimizer.cc:842-851,1131-1137,1190-1196,1256-1335):
+// the VertexScale (g2otypes.h:292-311) is one more 1-dim column at the END of the pose system and the visual edges are
+// EdgeReprojectPRS / PRSStereo (g2otypes.h:321-541, MODE_OPT_VAR == 1): Xw = s Xh, J_s = (Jproj Rcw) Xh,
+// J_Xh = s (Jproj Rcw).  The scale sees every point, so it is one more (dense) row of BB -- row 6 x free key frames --
+// and the Schur GEMM, the pack / all-reduce and the solves take it like any other row; its own blocks (H_ss, b_s,
+// H_ps) are summed in fixed order by k_lba_build / k_lba_scale_fold and gathered by k_lba_assemble.
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -119,7 +126,18 @@ struct LbaDev {
   int n_cams;
   const unsigned char* ocam;      // [n_obs] camera of every observation (n_cams > 0)
   double dMono, dStereo;
+  int scale_opt;                  // bScaleOpt: the VertexScale is the last column of the pose system
+  double* scl;                    // [2] VertexScale estimate, its backup (push / pop)
+  double* sc_sys;                 // [6 nf_cap + 2] H_ps per free key frame (Jp^T W Js), then H_ss, b_s
+  double* psc;                    // [blocks of 64 points][2] partial sums of H_ss, b_s
 };
+
+__device__ __forceinline__ double win_scale(const LbaDev& D) { return D.scale_opt ? D.scl[0] : 1.0; }
+// s * Xh: the point the edges project (g2otypes.h:376; s == 1 without the scale vertex)
+__device__ __forceinline__ void scaled_point(const LbaDev& D, int m, double* Xs) {
+  const double s = win_scale(D);
+  Xs[0] = D.X[3 * (size_t)m] * s, Xs[1] = D.X[3 * (size_t)m + 1] * s, Xs[2] = D.X[3 * (size_t)m + 2] * s;
+}
 
 __device__ __forceinline__ const CamD& obs_cam(const LbaDev& D, int i) { return D.n_cams ? D.cams[D.ocam[i]] : D.cam; }
 
@@ -202,6 +220,7 @@ k_lba_restore(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   if (i < D.n_mp && D.mp_act[i])
     for (int a = 0; a < 3; a++) D.X[3 * (size_t)i + a] = D.X_bak[3 * (size_t)i + a];
   if (i < D.n_kf && D.kf[i].col >= 0) D.kf[i] = D.kf_bak[i];
+  if (i == 0 && D.scale_opt) D.scl[0] = D.scl[1];
 }
 
 // chi2 (from the STORED error, as the reference does) / depth classification
@@ -220,7 +239,8 @@ k_lba_classify(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) 
   if (o.ur >= 0) chi2 += e[2] * (info * e[2]);
   PoseXf X;
   kf_xf(obs_cam(D, i), D.kf[o.kf], X);
-  const double* Xw = D.X + 3 * (size_t)o.mp;
+  double Xw[3];
+  scaled_point(D, o.mp, Xw);
   const double z = X.Rcw[6] * Xw[0] + X.Rcw[7] * Xw[1] + X.Rcw[8] * Xw[2] + X.tcw[2];
   const double th = o.ur >= 0 ? D.thStereo : ((D.close && D.close[o.mp]) ? D.thMonoClose : D.thMono);
   const bool bad = chi2 > th || !(z > 0.);
@@ -256,8 +276,9 @@ k_lba_prelevel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
   PoseXf X;
   const CamD& C = obs_cam(D, i);
   kf_xf(C, D.kf[o.kf], X);
-  double err[3], Pc[3];
-  const double chi2 = lba_edge_error(C, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
+  double err[3], Pc[3], Xs[3];
+  scaled_point(D, o.mp, Xs);
+  const double chi2 = lba_edge_error(C, X, o, Xs, err, Pc);
   D.err[3 * (size_t)i] = err[0], D.err[3 * (size_t)i + 1] = err[1], D.err[3 * (size_t)i + 2] = err[2];
   if (far_rule && o.ur < 0 && Pc[2] < D.th_dist_far) D.mp_act[o.mp] = 1;  // same value from every writer
   const float th = 100.f * (o.ur >= 0 ? 7.815f : 5.991f);
@@ -270,7 +291,7 @@ k_lba_zero(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_BEGIN)) return;
   const LbaDev& D = devs[w];
-  const size_t nb = (size_t)6 * D.nf_cap * D.ldB, nt = (size_t)D.nf_cap * D.n_mp;
+  const size_t nb = ((size_t)6 * D.nf_cap + (D.scale_opt ? 1 : 0)) * D.ldB, nt = (size_t)D.nf_cap * D.n_mp;
   const size_t step = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += step) D.BB[i] = 0.0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nt; i += step) D.tab[i] = -1;
@@ -308,7 +329,8 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
       } else
         D.kf[k].col = -1;
     }
-    D.np = np, D.n_free = nf, D.npv = 6 * nf;
+    if (D.scale_opt) np += 1;  // id_scale = maxKFid + 1: after every key-frame vertex
+    D.np = np, D.n_free = nf, D.npv = 6 * nf + (D.scale_opt ? 1 : 0);
     out[w].np = np;
   }
   __syncthreads();
@@ -336,8 +358,9 @@ k_lba_error(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
     PoseXf X;
     const CamD& C = obs_cam(D, i);
     kf_xf(C, D.kf[o.kf], X);
-    double err[3], Pc[3];
-    const double chi2 = lba_edge_error(C, X, o, D.X + 3 * (size_t)o.mp, err, Pc);
+    double err[3], Pc[3], Xs[3];
+    scaled_point(D, o.mp, Xs);
+    const double chi2 = lba_edge_error(C, X, o, Xs, err, Pc);
     D.err[3 * (size_t)i] = err[0], D.err[3 * (size_t)i + 1] = err[1], D.err[3 * (size_t)i + 2] = err[2];
     double r0 = chi2, r1;
     if (fl & LBA_ROBUST) {
@@ -384,7 +407,9 @@ __device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& 
   const CamD& C = obs_cam(D, i);
   PoseXf X;
   kf_xf(C, k, X);
-  const double* Xw = D.X + 3 * (size_t)o.mp;
+  double Xw[3];
+  scaled_point(D, o.mp, Xw);
+  const double sc = win_scale(D);
   double err[3], Pc[3];
   const double chi2 = lba_edge_error(C, X, o, Xw, err, Pc);
   const bool stereo = o.ur >= 0;
@@ -397,6 +422,8 @@ __device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& 
   lba_jacobians(C, X, k.p, Xw, Pc, Jp, Jx);
   const double ww = r1 * (double)o.inv_sigma2;
   if (!stereo) Jx[6] = Jx[7] = Jx[8] = 0;
+  if (D.scale_opt)
+    for (int t = 0; t < 9; t++) Jx[t] *= sc;  // J_Xh = s (Jproj Rcw)
 #pragma unroll
   for (int q = 0; q < 6; q++)
 #pragma unroll
@@ -408,8 +435,10 @@ __device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& 
 // blocks [gm, gm + free key frames): one workgroup per key frame over its edge list -> H_pp, b_p and the
 // rows of BB = Jp^T W Jx it owns.  Every sum has a fixed order.
 // MULTICAM: windows with several (distorted) cameras per key frame; the single rectified camera keeps the
-// lean instantiation.
-template <bool MULTICAM>
+// lean instantiation.  SCALE: a batch with a scale-vertex window (EdgeReprojectPRS[Stereo]): the point half also forms
+// the point's entry of the scale row of BB (sum over its edges of Js^T W Jx) and its terms of H_ss / b_s, the key-frame
+// half H_ps = sum Jp^T W Js.
+template <bool MULTICAM, bool SCALE>
 __global__ void __launch_bounds__(256)
 k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int gm) {
   const int bx = blockIdx.x;
@@ -427,8 +456,12 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
     double acc[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = 0;
+    double asc[5] = {0, 0, 0, 0, 0};  // SCALE: Bs[3], H_ss, b_s of the point
+    const bool scl = SCALE && D.scale_opt;
+    const double sc = scl ? D.scl[0] : 1.0;
     if (act) {
-      const double Xw[3] = {D.X[3 * (size_t)m], D.X[3 * (size_t)m + 1], D.X[3 * (size_t)m + 2]};
+      const double Xh[3] = {D.X[3 * (size_t)m], D.X[3 * (size_t)m + 1], D.X[3 * (size_t)m + 2]};
+      const double Xw[3] = {Xh[0] * sc, Xh[1] * sc, Xh[2] * sc};
       const int first = D.mp_first[m], cnt = D.mp_count[m];
       for (int j = sub; j < cnt; j += 4) {
         const int i = first + j;
@@ -456,6 +489,17 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
             Jx[r * 3 + q] = J[r * 3] * X.Rcw[q] + J[r * 3 + 1] * X.Rcw[3 + q] + J[r * 3 + 2] * X.Rcw[6 + q];
         const double info = (double)o.inv_sigma2, ww = r1 * info;
         if (!stereo) Jx[6] = Jx[7] = Jx[8] = 0;  // monocular edge: no third row (err[2] is 0 already)
+        if (scl) {  // _jacobianOplus[scale] = _jacobianOplus[0] * Ph_unscale, then _jacobianOplus[0] *= scale
+          double Js[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) Js[r] = Jx[r * 3] * Xh[0] + Jx[r * 3 + 1] * Xh[1] + Jx[r * 3 + 2] * Xh[2];
+#pragma unroll
+          for (int q = 0; q < 9; q++) Jx[q] *= sc;
+#pragma unroll
+          for (int b = 0; b < 3; b++) asc[b] += Js[0] * ww * Jx[b] + Js[1] * ww * Jx[3 + b] + Js[2] * ww * Jx[6 + b];
+          asc[3] += Js[0] * ww * Js[0] + Js[1] * ww * Js[1] + Js[2] * ww * Js[2];
+          asc[4] += Js[0] * (-(info * err[0]) * r1) + Js[1] * (-(info * err[1]) * r1) + Js[2] * (-(info * err[2]) * r1);
+        }
         int t = 0;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -477,6 +521,17 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
       D.bl[3 * (size_t)m] = acc[6], D.bl[3 * (size_t)m + 1] = acc[7], D.bl[3 * (size_t)m + 2] = acc[8];
       mx = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
     }
+    if (scl) {
+#pragma unroll
+      for (int t = 0; t < 5; t++) asc[t] = quad_sum_f64(asc[t]);
+      if (m < D.n_mp && sub == 0) {  // the scale's row of BB: zero for a point without an active edge
+        double* B = D.BB + (size_t)(D.npv - 1) * D.ldB + 3 * (size_t)m;
+        B[0] = asc[0], B[1] = asc[1], B[2] = asc[2];
+      }
+      double v[2] = {sub == 0 ? asc[3] : 0.0, sub == 0 ? asc[4] : 0.0};
+      block_sum<2>(v, s_red + 8, threadIdx.x);
+      if (threadIdx.x == 0) D.psc[2 * bx] = v[0], D.psc[2 * bx + 1] = v[1];
+    }
     // landmark part of computeLambdaInit: block maximum
     mx = wave_max_f64(mx);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
@@ -492,6 +547,9 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   double acc[27];
 #pragma unroll
   for (int t = 0; t < 27; t++) acc[t] = 0;
+  double aps[6] = {0, 0, 0, 0, 0, 0};  // SCALE: H_ps = sum Jp^T W Js
+  const bool scl = SCALE && D.scale_opt;
+  const double sc = scl ? D.scl[0] : 1.0;
   PoseXf X;
   kf_xf(D.cam, k, X);  // one camera: the transform is the same for all edges of the key frame
   double* Brow = D.BB + (size_t)(6 * a) * D.ldB;
@@ -503,7 +561,8 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
 #pragma unroll
     for (int t = 0; t < 18; t++) Bk[t] = 0;
     if (active) {
-      const double* Xw = D.X + 3 * (size_t)o.mp;
+      const double* Xh = D.X + 3 * (size_t)o.mp;
+      const double Xw[3] = {Xh[0] * sc, Xh[1] * sc, Xh[2] * sc};
       double err[3], Pc[3];
       const CamD& C = obs_cam(D, i);
       if (MULTICAM && D.n_cams) kf_xf(C, k, X);
@@ -519,6 +578,19 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
       const double info = (double)o.inv_sigma2, ww = r1 * info;
       visual_accumulate(Jp, err, info, r1, stereo, acc);
       if (!stereo) Jx[6] = Jx[7] = Jx[8] = 0;
+      if (scl) {
+        double Js[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) Js[r] = Jx[r * 3] * Xh[0] + Jx[r * 3 + 1] * Xh[1] + Jx[r * 3 + 2] * Xh[2];
+#pragma unroll
+        for (int q = 0; q < 9; q++) Jx[q] *= sc;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          double t = Jp[q] * ww * Js[0] + Jp[6 + q] * ww * Js[1];
+          if (stereo) t += Jp[12 + q] * ww * Js[2];
+          aps[q] += t;
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 6; q++)
 #pragma unroll
@@ -565,6 +637,30 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
     } else
       D.bp[6 * a + threadIdx.x - 21] = v;
   }
+  if (scl) {
+    block_sum<6>(aps, s_red, threadIdx.x);
+    if (threadIdx.x < 6) {
+      double v = 0;
+#pragma unroll
+      for (int t = 0; t < 6; t++)
+        if ((int)threadIdx.x == t) v = aps[t];
+      D.sc_sys[6 * a + threadIdx.x] = v;
+    }
+  }
+}
+
+// H_ss, b_s of the scale vertex: the per-block partials of k_lba_build in fixed order (one workgroup per window)
+__global__ void __launch_bounds__(256)
+k_lba_scale_fold(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  __shared__ double s_red[4 * 2];
+  const int w = blockIdx.x;
+  if (!(ctl[w].flags & LBA_BUILD)) return;
+  const LbaDev& D = devs[w];
+  if (!D.scale_opt || D.np == 0) return;
+  double v[2] = {0, 0};
+  for (int i = threadIdx.x; i < (D.n_mp + 63) / 64; i += 256) v[0] += D.psc[2 * i], v[1] += D.psc[2 * i + 1];
+  block_sum<2>(v, s_red, threadIdx.x);
+  if (threadIdx.x == 0) D.sc_sys[6 * D.n_free] = v[0], D.sc_sys[6 * D.n_free + 1] = v[1];
 }
 
 // computeLambdaInit: tau * max |diagonal| over the pose and landmark blocks (one workgroup per window)
@@ -575,10 +671,11 @@ k_lba_lambda(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   if (!(ctl[w].flags & LBA_BEGIN)) return;
   const LbaDev& D = devs[w];
   double mx = 0;
+  if (D.scale_opt && threadIdx.x == 0) mx = fabs(D.sc_sys[6 * D.n_free]);  // H_ss
   if (D.pd == 6 && D.n_imu == 0) {
-    for (int j = threadIdx.x; j < D.npv; j += 256) mx = fmax(mx, fabs(D.Hpp[36 * (size_t)(j / 6) + 7 * (j % 6)]));
+    for (int j = threadIdx.x; j < 6 * D.n_free; j += 256) mx = fmax(mx, fabs(D.Hpp[36 * (size_t)(j / 6) + 7 * (j % 6)]));
   } else {  // PR + V + Bias vertices: visual block + the inertial edges' diagonal (as k_lba_assemble adds them)
-    for (int j = threadIdx.x; j < D.np; j += 256) {
+    for (int j = threadIdx.x; j < D.pd * D.n_free; j += 256) {
       const int pd = D.pd, a = j / pd, ra = j - a * pd, ka = D.kf_list[a];
       const int ein = D.kf_in[ka], eout = D.kf_out[ka];
       double v = ra < 6 ? D.Hpp[36 * (size_t)a + 7 * ra] : 0.0;
@@ -614,7 +711,7 @@ k_lba_occ(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   if (np == 0 || e >= CB * nchunks) return;
   const int bi = e / nchunks, ch = e - bi * nchunks;
   const int a0 = bi * 64 / 6, a1 = min((bi * 64 + 63) / 6, D.n_free - 1);
-  int any = 0;
+  int any = D.scale_opt && (np - 1) >= bi * 64 && (np - 1) < bi * 64 + 64;  // the scale's row sees every point
   for (int a = a0; a <= a1 && !any; a++)
     for (int j = 0; j < kChunkLm; j++) {
       const int m = ch * kChunkLm + j;
@@ -726,9 +823,9 @@ k_lba_pack(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int 
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
   if (!D.red) return;
-  const int npv = D.npv, nS = npv * (npv + 1), nH = 36 * D.n_free;
+  const int npv = D.npv, nS = npv * (npv + 1), nH = 36 * D.n_free, nb = 6 * D.n_free;
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= nS + nH + npv) return;
+  if (e >= nS + nH + nb + (D.scale_opt ? nb + 2 : 0)) return;
   if (e < nS) {
     const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
     const int ns = (nchunks + cps - 1) / cps;
@@ -739,8 +836,10 @@ k_lba_pack(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int 
     D.red[e] = s;
   } else if (e < nS + nH)
     D.red[e] = D.Hpp[e - nS];
-  else
+  else if (e < nS + nH + nb)
     D.red[e] = D.bp[e - nS - nH];
+  else
+    D.red[e] = D.sc_sys[e - nS - nH - nb];  // H_ps, H_ss, b_s of the scale vertex
 }
 
 // Reduced pose system.  PR x PR entries: Hpp + lambda I - S (both triangles from the upper block-tiles of
@@ -758,43 +857,57 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
   const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
   const int ns = (nchunks + cps - 1) / cps;
   const int r = e / np, c = e % np;
+  // the scale vertex (bScaleOpt) is the last row / column; its row of the visual system is the last one as well
+  const bool rs = D.scale_opt && r == np - 1, cs = D.scale_opt && c == np - 1;
   const int a = r / pd, ra = r - a * pd, b = c / pd, cb = c - b * pd;
+  const int vr = rs ? npv - 1 : (ra < 6 ? 6 * a + ra : -1), vc = cs ? npv - 1 : (cb < 6 ? 6 * b + cb : -1);
   double v = 0;
   const double* redS = D.red;  // sums over the K splits and over the ranks, see k_lba_pack
   const double* redH = D.red ? D.red + (size_t)npv * (npv + 1) : D.Hpp;
   const double* redb = D.red ? redH + 36 * (size_t)D.n_free : D.bp;
-  if (ra < 6 && cb < 6) {
-    const int vr = 6 * a + ra, vc = 6 * b + cb, rr = min(vr, vc), cc = max(vr, vc);
+  const double* redsc = D.red ? redb + 6 * (size_t)D.n_free : D.sc_sys;
+  if (vr >= 0 && vc >= 0) {
+    const int rr = min(vr, vc), cc = max(vr, vc);
     double s = 0;
     if (redS)
       s = redS[(size_t)rr * (npv + 1) + cc];
     else
       for (int k = 0; k < ns; k++) s += D.Sp[(size_t)k * D.sp_stride + (size_t)rr * D.ldS + cc];
     v = -s;
-    if (a == b) v += redH[36 * (size_t)a + ra * 6 + cb];
+    if (rs && cs)
+      v += redsc[6 * D.n_free];  // H_ss
+    else if (rs)
+      v += redsc[6 * b + cb];  // H_ps^T
+    else if (cs)
+      v += redsc[6 * a + ra];
+    else if (a == b)
+      v += redH[36 * (size_t)a + ra * 6 + cb];
   }
   int ein = -1, eout = -1;
-  if (pd == 15 || D.n_imu > 0) {  // pair edges: inertial (+ encoder) of a 15-dim window, encoder only of a 6-dim one
-    const int ka = D.kf_list[a], kb = D.kf_list[b];
+  if ((pd == 15 || D.n_imu > 0) && !rs) {  // pair edges: inertial (+ encoder) of a 15-dim window, encoder only of a 6-dim one
+    const int ka = D.kf_list[a];
     ein = D.kf_in[ka], eout = D.kf_out[ka];
-    if (a == b) {
-      if (ein >= 0) v += D.Ae[930 * (size_t)ein + (15 + ra) * 30 + 15 + cb];
-      if (eout >= 0) v += D.Ae[930 * (size_t)eout + ra * 30 + cb];
-    } else {
-      if (eout >= 0 && D.imu[eout].j == kb) v += D.Ae[930 * (size_t)eout + ra * 30 + 15 + cb];
-      if (ein >= 0 && D.imu[ein].i == kb) v += D.Ae[930 * (size_t)ein + (15 + ra) * 30 + cb];
+    if (!cs) {
+      const int kb = D.kf_list[b];
+      if (a == b) {
+        if (ein >= 0) v += D.Ae[930 * (size_t)ein + (15 + ra) * 30 + 15 + cb];
+        if (eout >= 0) v += D.Ae[930 * (size_t)eout + ra * 30 + cb];
+      } else {
+        if (eout >= 0 && D.imu[eout].j == kb) v += D.Ae[930 * (size_t)eout + ra * 30 + 15 + cb];
+        if (ein >= 0 && D.imu[ein].i == kb) v += D.Ae[930 * (size_t)ein + (15 + ra) * 30 + cb];
+      }
     }
   }
   if (r == c) v += lambda;
   D.Hs[e] = v;
   if (c == 0) {
     double g = 0, t = 0;
-    if (ra < 6) {
-      g = redb[6 * a + ra];
+    if (vr >= 0) {
+      g = rs ? redsc[6 * D.n_free + 1] : redb[6 * a + ra];
       if (redS)
-        t = redS[(size_t)(6 * a + ra) * (npv + 1) + npv];
+        t = redS[(size_t)vr * (npv + 1) + npv];
       else
-        for (int k = 0; k < ns; k++) t += D.Sp[(size_t)k * D.sp_stride + (size_t)(6 * a + ra) * D.ldS + npv];
+        for (int k = 0; k < ns; k++) t += D.Sp[(size_t)k * D.sp_stride + (size_t)vr * D.ldS + npv];
     }
     if (ein >= 0) g += D.Ae[930 * (size_t)ein + 900 + 15 + ra];
     if (eout >= 0) g += D.Ae[930 * (size_t)eout + 900 + ra];
@@ -971,7 +1084,10 @@ __device__ __forceinline__ void lba_apply_step(const LbaDev& D, const double* y,
     __syncthreads();
     sp[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   }
-  if (tid == 0) o.ok = ok ? 1 : 0, o.scale_p = ok ? sp[0] : 0.0;
+  if (tid == 0) {
+    o.ok = ok ? 1 : 0, o.scale_p = ok ? sp[0] : 0.0;
+    if (D.scale_opt) D.scl[1] = D.scl[0], D.scl[0] += y[n - 1];  // push(), VertexScale::oplusImpl (g2otypes.h:310)
+  }
   if (tid >= 256) return;
   // oplus on the free key frames (push() first): VertexNavStatePR (+ V, Bias in a visual-inertial window)
   for (int k = tid; k < D.n_kf; k += 256) {
@@ -1613,6 +1729,11 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
         cl[0] -= B[0] * xa, cl[1] -= B[1] * xa, cl[2] -= B[2] * xa;
       }
     }
+    if (D.scale_opt) {  // the (scale, point) block
+      const double* B = D.BB + (size_t)(D.npv - 1) * D.ldB + 3 * (size_t)m;
+      const double xa = D.xp[D.np - 1];
+      cl[0] -= B[0] * xa, cl[1] -= B[1] * xa, cl[2] -= B[2] * xa;
+    }
     double Di[9];
     landmark_dinv(D.Hll + 9 * (size_t)m, lambda, Di);
     for (int a = 0; a < 3; a++) {
@@ -1647,7 +1768,7 @@ struct WinHost {  // per-window LM state machine, exactly g2o's (optimization_al
   int nBad = 0, qmax = 0;
   bool need_build = false, need_restore = false, skip = false;
   vieo_lba_result* R;
-  size_t o_kf, o_X, o_erase;  // offsets of the results in the staging buffer
+  size_t o_kf, o_X, o_erase, o_scl;  // offsets of the results in the staging buffer
 };
 
 // 9x9 inverse by Gauss-Jordan with partial pivoting (GetProcessedInfoijPRV: mSigmaijPRV.inverse())
@@ -1723,7 +1844,12 @@ static int shard_exchange(const LbaShard* sh, double* d_buf, size_t n, hipStream
   return rccl_allreduce_sum_f64(sh->ctx, d_buf, n, st);
 }
 
-static size_t shard_sys_doubles(int nf) { return (size_t)6 * nf * (6 * nf + 1) + 36 * (size_t)nf + 6 * (size_t)nf; }
+// packed reduced visual system of a window with nf free key frames (k_lba_pack); sc: with the scale vertex's row,
+// H_ps, H_ss, b_s
+static size_t shard_sys_doubles(int nf, int sc = 0) {
+  const size_t nv = (size_t)6 * nf + (sc ? 1 : 0);
+  return nv * (nv + 1) + 36 * (size_t)nf + 6 * (size_t)nf + (sc ? 6 * (size_t)nf + 2 : 0);
+}
 
 // Both local BAs: vparams == nullptr -> Optimizer::LocalBundleAdjustment (params), otherwise
 // LocalBundleAdjustmentNavStatePRV (vparams, h_close, h_imu, n_imu).  sh != nullptr: this process is one
@@ -1807,6 +1933,8 @@ static bool big_solve(int n) {
 // Chi2LargeSetLevel, g2o's own initial lambda, no divergence guard.
 struct GbaMode {
   int iterations, robust;
+  int scale_opt = 0;          // bScaleOpt (System::FinalGBA): VertexScale + EdgeReprojectPRS[Stereo]
+  double* scale_out = nullptr;  // the recovered scale (1 when the call returns early)
 };
 
 // The argument checks of lba_run without side effects.  A landmark-sharded run calls it first and lets all ranks agree
@@ -1830,7 +1958,7 @@ static bool lba_args_ok(bool sharded, bool vio, bool gba, int W, const vieo_lba_
     if (vio && ((!h_close[w] && !gba && n_mp[w] > 0) || n_imu[w] < 0 || (n_imu[w] > 0 && !h_imu[w]))) return false;
     int n_free = 0;
     for (int k = 0; k < n_kf[w]; k++) n_free += !h_kfs[w][k].fixed;
-    if (pd * n_free > kBigSolveMax || n_kf[w] >= (1 << 24)) return false;
+    if (pd * n_free + 1 > kBigSolveMax || n_kf[w] >= (1 << 24)) return false;
     if (vio) {
       std::vector<char> in(n_kf[w], 0), outk(n_kf[w], 0);
       for (int t = 0; t < n_imu[w]; t++) {
@@ -1861,6 +1989,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
                    vieo_lba_result* h_results, const vieo_lba_enc* const* encs = nullptr) {
   const bool vio = vparams != nullptr;
   const int pd = vio ? 15 : 6;
+  const int sco = gba && gba->scale_opt ? 1 : 0;
+  if (gba && gba->scale_out) *gba->scale_out = 1.0;
   if (sh && (!vio || (!sh->fn && !sh->ctx) || !sh->d_buf || (stop && *stop))) {
     set_error("sharded local BA: visual-inertial windows only, with a reduction callback and buffer");
     return VIEO_E_INVALID;
@@ -1948,7 +2078,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     {
       int n_free = 0;
       for (int k = 0; k < H.n_kf; k++) n_free += !h_kfs[w][k].fixed;
-      if (pd * n_free > kBigSolveMax || H.n_kf >= (1 << 24)) {
+      if (pd * n_free + sco > kBigSolveMax || H.n_kf >= (1 << 24)) {
         set_error("bundle adjustment: %d free key frames exceed the reduced-system limit of %d unknowns", n_free,
                   kBigSolveMax);
         return VIEO_E_CAPACITY;
@@ -1970,6 +2100,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (H.n_obs > 0) memset(h_erase[w], 0, H.n_obs);
     bool any_free = false;
     for (int k = 0; k < H.n_kf; k++) any_free |= !h_kfs[w][k].fixed;
+    if (sco) any_free = true;  // bdimPoses = true with the scale vertex (Optimizer.cc:850)
     if (!any_free) {
       H.R->status = VIEO_LBA_NO_FREE_POSE;  // Optimizer.cc:1993
       H.skip = true, H.stage = 2;
@@ -1995,7 +2126,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     return off;
   };
   struct Off {
-    size_t obs, mp_first, mp_count, kf_edge_first, kf_edge_idx, imu, kf_in, kf_out, close, ocam, kf, X, erase, level, err;
+    size_t obs, mp_first, mp_count, kf_edge_first, kf_edge_idx, imu, kf_in, kf_out, close, ocam, kf, X, erase, scl, level, err;
   };
   std::vector<Off> off(W);
   for (int w = 0; w < W; w++) {
@@ -2017,7 +2148,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (H.skip) continue;
     Off& o = off[w];
     o.kf = take((size_t)H.n_kf * sizeof(LbaKf)), o.X = take((size_t)H.n_mp * 24), o.erase = take(H.n_obs);
-    H.o_kf = o.kf, H.o_X = o.X, H.o_erase = o.erase;
+    o.scl = take(16);
+    H.o_kf = o.kf, H.o_X = o.X, H.o_erase = o.erase, H.o_scl = o.scl;
   }
   const size_t res_end = arena;
   for (int w = 0; w < W; w++) {
@@ -2037,7 +2169,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     max_nf = std::max(max_nf, nf), max_mp = std::max(max_mp, win[w].n_mp);
   }
   // Schur GEMM decomposition: 64x64 block-tiles (upper) x K splits, about 768 workgroups in flight
-  const int np_cap_max = 6 * max_nf;
+  const int np_cap_max = 6 * max_nf + sco;
   const int RBm = (np_cap_max + 63) / 64, CBm = (np_cap_max + 64) / 64;
   const int nbt_max = RBm * CBm - RBm * (RBm - 1) / 2;
   const int nchunks_max = (max_mp + kChunkLm - 1) / kChunkLm;
@@ -2045,7 +2177,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   std::vector<size_t> scratch_off(W);
   struct Scr {
     size_t kf_bak, X_bak, mp_act, BB, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
-        gchi, bfull, Hb, Wp, big_fail, kf_act, occ;
+        gchi, bfull, Hb, Wp, big_fail, kf_act, occ, sc_sys, psc;
     int nb;
   };
   std::vector<Scr> scr(W);
@@ -2058,7 +2190,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     for (int k = 0; k < H.n_kf; k++) nf += !kfs[k].fixed;
     // scratch
     Scr& s = scr[w];
-    const int npm = 6 * nf;
+    const int npm = 6 * nf + sco;  // rows of the visual system: PR blocks (+ the scale vertex)
     s.kf_bak = take((size_t)H.n_kf * sizeof(LbaKf)), s.X_bak = take((size_t)H.n_mp * 24);
     s.mp_act = take(H.n_mp);
     const int ldB = (H.n_mp + kChunkLm - 1) / kChunkLm * (3 * kChunkLm);
@@ -2066,11 +2198,11 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     s.BB = take((size_t)npm * ldB * 8);
     s.Sp = take((size_t)ksplit * sp_rows * ldS * 8);
     s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
-    const int npf = pd * nf;  // full reduced system
-    s.Hpp = take((size_t)nf * 36 * 8), s.Hs = take((size_t)npf * npf * 8);
+    const int npf = pd * nf + sco;  // full reduced system
+    s.Hpp = take((size_t)std::max(nf, 1) * 36 * 8), s.Hs = take((size_t)npf * npf * 8);
     s.nb = (npf + 1 + kNB - 1) / kNB * kNB;  // + the right-hand-side row
     s.Hb = s.Wp = s.big_fail = 0;
-    if (big_solve(pd * nf)) {
+    if (big_solve(npf) || (sco && ((npf + 16) >> 4) > kLd16MaxBlocks)) {
       s.Hb = take((size_t)s.nb * s.nb * 8), s.Wp = take((size_t)s.nb * kNB * 8), s.big_fail = take(256);
     }
     s.bp = take((size_t)npm * 8), s.bs = take((size_t)npf * 8), s.xp = take((size_t)npf * 8);
@@ -2079,7 +2211,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     s.gchi0 = take((size_t)std::max(H.n_imu, 1) * 8), s.gchi = take((size_t)std::max(H.n_imu, 1) * 8);
     s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
     s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
-    s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)nf * H.n_mp * 4);
+    s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)std::max(nf, 1) * H.n_mp * 4);
+    s.sc_sys = take((size_t)(6 * nf + 2) * 8), s.psc = take((size_t)((H.n_mp + 63) / 64) * 16);
     s.kf_act = take((size_t)H.n_kf * 4);
     s.occ = take((size_t)((npm + 64) / 64) * ((H.n_mp + kChunkLm - 1) / kChunkLm));
     LbaDev& D = devs[w];
@@ -2106,6 +2239,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     // thHuberMono = sqrt(5.991) in the local BAs, thHuber2D = sqrt(5.99) in the global ones (Optimizer.cc:1063,1445)
     D.dMono = (double)(float)sqrt(gba ? 5.99 : 5.991), D.dStereo = (double)(float)sqrt(7.815);
     D.pd = pd, D.n_imu = H.n_imu;
+    D.scale_opt = sco;
     if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
       D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
       memcpy(D.gw, H.VP->gw, 24);
@@ -2243,6 +2377,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     double* X = (double*)(hs + o.X);
     for (int i = 0; i < H.n_mp * 3; i++) X[i] = (double)h_points[w][i];
     memset(hs + o.erase, 0, H.n_obs);
+    ((double*)(hs + o.scl))[0] = ((double*)(hs + o.scl))[1] = 1.0;  // pvScale->setEstimate(1.) (Optimizer.cc:845)
     return VIEO_OK;
   };
   {
@@ -2295,6 +2430,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.kf_act = (int*)(base + s.kf_act), D.occ = base + s.occ;
     D.bfull = (double*)(base + s.bfull), D.Ae = (double*)(base + s.Ae);
     D.gchi0 = (double*)(base + s.gchi0), D.gchi = (double*)(base + s.gchi);
+    D.scl = (double*)(base + o.scl), D.sc_sys = (double*)(base + s.sc_sys), D.psc = (double*)(base + s.psc);
     if (vio || win[w].ENC) {
       D.imu = (const LbaImu*)(base + o.imu), D.close = base + o.close;
       D.kf_in = (const int*)(base + o.kf_in), D.kf_out = (const int*)(base + o.kf_out);
@@ -2305,7 +2441,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     for (int w = 0; w < W; w++) {
       if (win[w].skip) continue;
       devs[w].red = sh->d_buf + shard_sys;
-      shard_sys += shard_sys_doubles(devs[w].nf_cap);
+      shard_sys += shard_sys_doubles(devs[w].nf_cap, sco);
     }
     if (shard_sys + 4 * (size_t)W > sh->cap) {
       set_error("sharded local BA: reduction buffer too small (%zu doubles needed)", shard_sys + 4 * (size_t)W);
@@ -2323,9 +2459,11 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   VIEO_HIP_CHECK(hipMemsetAsync(base + res_end, 0, zero_end - res_end, st));
   VIEO_HIP_CHECK(hipMemcpyAsync(dD, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
   VIEO_HIP_CHECK(hipMemsetAsync(dO, 0, (size_t)W * sizeof(WinOut), st));
-  const int n_max = pd * max_nf;
-  const int occ_max = ((6 * max_nf + 64) / 64) * ((max_mp + kChunkLm - 1) / kChunkLm);
-  const bool big = big_solve(n_max);
+  const int n_max = pd * max_nf + sco;
+  const int occ_max = ((6 * max_nf + sco + 64) / 64) * ((max_mp + kChunkLm - 1) / kChunkLm);
+  // the column-panel kernel needs a system size divisible by its panel width: with the scale vertex the blocked
+  // kernel (any size up to 159) or the tiled solve take the system
+  const bool big = big_solve(n_max) || (sco && ((n_max + 16) >> 4) > kLd16MaxBlocks);
   const size_t ldlt_small = big ? 0 : (size_t)8 * n_max * 8;  // panel columns, rhs, pivots
   const size_t tri = big ? 0 : (size_t)n_max * (n_max + 1) / 2 * 8;  // packed lower triangle
   const int use_lds = tri + ldlt_small <= 150 * 1024;
@@ -2333,7 +2471,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   const void* ldlt_fn = vio ? (const void*)k_lba_ldlt<5> : (const void*)k_lba_ldlt<6>;
   VIEO_HIP_CHECK(hipFuncSetAttribute(ldlt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
   const int nb16 = (n_max + 16) >> 4;
-  const bool ldlt16 = !big && nb16 <= kLd16MaxBlocks && !ldlt16_disabled();
+  const bool ldlt16 = !big && nb16 <= kLd16MaxBlocks && (sco || !ldlt16_disabled());
   if (ldlt16)
     VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldlt16<kLd16Threads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)ld16_lds_bytes(nb16)));
@@ -2398,19 +2536,26 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0); });
     }
     if (any & LBA_BUILD) {
-      if (any_multicam)
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL(k_lba_build<true>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
+      if (sco) {
+        if (any_multicam)
+          KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<true, true>), dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
+        else
+          KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<false, true>), dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL(k_lba_scale_fold, dim3(W), dim3(256), 0, st, dD, dC); });
+      } else if (any_multicam)
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<true, false>), dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
       else
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL(k_lba_build<false>, dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<false, false>), dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
       if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0); });
     }
     if (any & LBA_BEGIN) KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO); });
     if (any & LBA_TRIAL) {
       KT.launch(KC_SCHUR, [&] { hipLaunchKernelGGL(k_lba_schur, dim3(nbt_max * ksplit, W), dim3(256), 0, st, dD, dC, dO, ksplit); });
       if (sh) {  // the one exchange step of the path: sum the reduced visual system over the ranks
-        const int nv = 6 * max_nf;
-        KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_pack, dim3((nv * (nv + 1) + 36 * max_nf + nv + 255) / 256, W), dim3(256), 0, st,
+        const int nv = 6 * max_nf + sco;
+        KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_pack, dim3((unsigned)((shard_sys_doubles(max_nf, sco) + 255) / 256), W), dim3(256), 0, st,
                            dD, dC, ksplit); });
+        (void)nv;
         if ((rc = shard_exchange(sh, sh->d_buf, shard_sys, st)) != VIEO_OK) return rc;
       }
       KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO,
@@ -2550,7 +2695,13 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         memcpy(h_navs_out[w][k].dbg, o[k].dbg, 24), memcpy(h_navs_out[w][k].dba, o[k].dba, 24);
       }
     }
-    for (int i = 0; i < H.n_mp * 3; i++) h_points_out[w][i] = (float)X[i];  // SetWorldPos(cast<float>)
+    if (sco) {  // SetWorldPos(scale * vPoint->estimate().cast<float>()) (Optimizer.cc:1321): a float product
+      const double scale = *(const double*)(hs + H.o_scl);
+      const float sf = (float)scale;
+      for (int i = 0; i < H.n_mp * 3; i++) h_points_out[w][i] = sf * (float)X[i];
+      if (gba->scale_out) *gba->scale_out = scale;
+    } else
+      for (int i = 0; i < H.n_mp * 3; i++) h_points_out[w][i] = (float)X[i];  // SetWorldPos(cast<float>)
   }
   return VIEO_OK;
 }
@@ -2598,7 +2749,7 @@ int vieo_local_bundle_adjustment_vio_batch(int n_windows, const vieo_lba_vio_par
 
 size_t vieo_lba_sharded_buffer_doubles(int n_windows, const int* n_free_kf) {
   size_t n = 0;
-  for (int w = 0; w < n_windows; w++) n += shard_sys_doubles(n_free_kf ? n_free_kf[w] : 0) + 4;
+  for (int w = 0; w < n_windows; w++) n += shard_sys_doubles(n_free_kf ? n_free_kf[w] : 0, 1) + 4;  // (room for the scale vertex)
   return n;
 }
 
@@ -2617,6 +2768,24 @@ int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_p
                  n_imu, nullptr, h_navs_out, h_points_out, h_erase, h_results);
 }
 
+int vieo_global_bundle_adjustment_vio_sharded_scale(const vieo_lba_vio_params* params, int n_iterations, int robust,
+                                                    int scale_opt, const vieo_lba_keyframe* h_kfs, int n_kf,
+                                                    const float* h_points, int n_mp, const vieo_lba_obs* h_obs, int n_obs,
+                                                    const vieo_lba_imu_edge* h_imu, int n_imu, double* d_reduce_buf,
+                                                    size_t reduce_cap_doubles, vieo_allreduce_sum_f64_fn allreduce,
+                                                    void* ctx, vieo_navstate* h_navs_out, float* h_points_out,
+                                                    vieo_lba_result* h_result, double* h_scale_out) {
+  if (!params || n_iterations < 0 || !h_result || n_obs < 0) return VIEO_E_INVALID;
+  GbaMode g = {n_iterations, robust};
+  g.scale_opt = scale_opt != 0, g.scale_out = h_scale_out;
+  LbaShard sh{allreduce, ctx, d_reduce_buf, reduce_cap_doubles};
+  std::vector<uint8_t> erase((size_t)std::max(n_obs, 1));
+  uint8_t* er = erase.data();
+  const uint8_t* no_close = nullptr;
+  return lba_run(&sh, &g, 1, nullptr, &params, &h_kfs, &n_kf, &h_points, &no_close, &n_mp, &h_obs, &n_obs, &h_imu,
+                 &n_imu, nullptr, &h_navs_out, &h_points_out, &er, h_result);
+}
+
 int vieo_global_bundle_adjustment_vio_sharded(const vieo_lba_vio_params* params, int n_iterations, int robust,
                                               const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points,
                                               int n_mp, const vieo_lba_obs* h_obs, int n_obs,
@@ -2624,14 +2793,9 @@ int vieo_global_bundle_adjustment_vio_sharded(const vieo_lba_vio_params* params,
                                               size_t reduce_cap_doubles, vieo_allreduce_sum_f64_fn allreduce,
                                               void* ctx, vieo_navstate* h_navs_out, float* h_points_out,
                                               vieo_lba_result* h_result) {
-  if (!params || n_iterations < 0 || !h_result || n_obs < 0) return VIEO_E_INVALID;
-  const GbaMode g = {n_iterations, robust};
-  LbaShard sh{allreduce, ctx, d_reduce_buf, reduce_cap_doubles};
-  std::vector<uint8_t> erase((size_t)std::max(n_obs, 1));
-  uint8_t* er = erase.data();
-  const uint8_t* no_close = nullptr;
-  return lba_run(&sh, &g, 1, nullptr, &params, &h_kfs, &n_kf, &h_points, &no_close, &n_mp, &h_obs, &n_obs, &h_imu,
-                 &n_imu, nullptr, &h_navs_out, &h_points_out, &er, h_result);
+  return vieo_global_bundle_adjustment_vio_sharded_scale(params, n_iterations, robust, 0, h_kfs, n_kf, h_points, n_mp,
+                                                         h_obs, n_obs, h_imu, n_imu, d_reduce_buf, reduce_cap_doubles,
+                                                         allreduce, ctx, h_navs_out, h_points_out, h_result, nullptr);
 }
 
 int vieo_local_bundle_adjustment_vio(const vieo_lba_vio_params* P, const vieo_lba_keyframe* h_kfs, int n_kf,
@@ -2698,8 +2862,18 @@ int vieo_global_bundle_adjustment_vio(const vieo_lba_vio_params* params, int n_i
                                       const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_imu_edge* h_imu, int n_imu,
                                       volatile const int* stop, vieo_navstate* h_navs_out, float* h_points_out,
                                       vieo_lba_result* h_result) {
+  return vieo_global_bundle_adjustment_vio_scale(params, n_iterations, robust, 0, h_kfs, n_kf, h_points, n_mp, h_obs, n_obs,
+                                                 h_imu, n_imu, stop, h_navs_out, h_points_out, h_result, nullptr);
+}
+
+int vieo_global_bundle_adjustment_vio_scale(const vieo_lba_vio_params* params, int n_iterations, int robust, int scale_opt,
+                                            const vieo_lba_keyframe* h_kfs, int n_kf, const float* h_points, int n_mp,
+                                            const vieo_lba_obs* h_obs, int n_obs, const vieo_lba_imu_edge* h_imu,
+                                            int n_imu, volatile const int* stop, vieo_navstate* h_navs_out,
+                                            float* h_points_out, vieo_lba_result* h_result, double* h_scale_out) {
   if (!params || n_iterations < 0 || !h_result || n_obs < 0) return VIEO_E_INVALID;
-  const GbaMode g = {n_iterations, robust};
+  GbaMode g = {n_iterations, robust};
+  g.scale_opt = scale_opt != 0, g.scale_out = h_scale_out;
   std::vector<uint8_t> erase((size_t)std::max(n_obs, 1));
   uint8_t* er = erase.data();
   const uint8_t* no_close = nullptr;

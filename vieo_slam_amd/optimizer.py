@@ -231,14 +231,24 @@ class Optimizer:
         return navs, pts, res[0]
 
     @staticmethod
-    def GlobalBundleAdjustmentNavStatePRV(params, kfs, points, obs, imu, nIterations=5, bRobust=True, stop=None):
+    def GlobalBundleAdjustmentNavStatePRV(params, kfs, points, obs, imu, nIterations=5, bRobust=True, stop=None,
+                                          bScaleOpt=None):
         """int Optimizer::GlobalBundleAdjustmentNavStatePRV(pMap, gw, nIterations, pbStopFlag, nLoopKF, bRobust,
         bScaleOpt=false, pimu_initiator=nullptr) (src/Optimizer.cc:771-1345) on the flattened layout of
-        LocalBundleAdjustmentNavStatePRV.  returns (navs[n_kf], points float32[n_mp,3], result record)."""
+        LocalBundleAdjustmentNavStatePRV.  returns (navs[n_kf], points float32[n_mp,3], result record); with
+        bScaleOpt given (System::FinalGBA passes true, src/System.cc:24-33) the recovered scale as a fourth value."""
         params, kfs = np.ascontiguousarray(params), np.ascontiguousarray(kfs)
         points, obs, imu = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(obs), np.ascontiguousarray(imu)
         navs, pts, res = np.zeros(len(kfs), NAVSTATE_DTYPE), np.zeros_like(points), np.zeros(1, LBA_RESULT_DTYPE)
         st = None if stop is None else np.ascontiguousarray(stop, np.int32)
+        if bScaleOpt is not None:
+            scale = np.ones(1)
+            check(lib().vieo_global_bundle_adjustment_vio_scale(
+                params.ctypes.data, int(nIterations), int(bool(bRobust)), int(bool(bScaleOpt)), kfs.ctypes.data, len(kfs),
+                points.ctypes.data, len(points), obs.ctypes.data, len(obs), imu.ctypes.data, len(imu),
+                None if st is None else st.ctypes.data, navs.ctypes.data, pts.ctypes.data, res.ctypes.data,
+                scale.ctypes.data), "vieo_global_bundle_adjustment_vio_scale")
+            return navs, pts, res[0], float(scale[0])
         check(lib().vieo_global_bundle_adjustment_vio(
             params.ctypes.data, int(nIterations), int(bool(bRobust)), kfs.ctypes.data, len(kfs), points.ctypes.data,
             len(points), obs.ctypes.data, len(obs), imu.ctypes.data, len(imu),
@@ -248,9 +258,10 @@ class Optimizer:
 
     @staticmethod
     def GlobalBundleAdjustmentNavStatePRVSharded(shard, reduce_ptr, reduce_doubles, allreduce=None, nIterations=5,
-                                                 bRobust=True, comm=None):
+                                                 bRobust=True, comm=None, bScaleOpt=None):
         """This rank's landmark shard (sharding.shard_window of (params, kfs, points, close, obs, imu)) of a full
-        BA; reduce_ptr / allreduce as in LocalBundleAdjustmentNavStatePRVSharded.  returns (navs, points, result)."""
+        BA; reduce_ptr / allreduce as in LocalBundleAdjustmentNavStatePRVSharded.  returns (navs, points, result)
+        (+ the recovered scale when bScaleOpt is given)."""
         import ctypes
         params, kfs, points, close, obs, imu = shard
         params, kfs, imu = np.ascontiguousarray(params), np.ascontiguousarray(kfs), np.ascontiguousarray(imu)
@@ -267,6 +278,15 @@ class Optimizer:
                 traceback.print_exc()
                 return 1
         cb = CB(_cb)
+        if bScaleOpt is not None:
+            scale = np.ones(1)
+            check(lib().vieo_global_bundle_adjustment_vio_sharded_scale(
+                params.ctypes.data, int(nIterations), int(bool(bRobust)), int(bool(bScaleOpt)), kfs.ctypes.data, len(kfs),
+                points.ctypes.data, len(points), obs.ctypes.data, len(obs), imu.ctypes.data, len(imu),
+                ctypes.c_void_p(base), reduce_doubles, None if comm is not None else ctypes.cast(cb, ctypes.c_void_p),
+                None if comm is None else ctypes.c_void_p(int(comm)), navs.ctypes.data, pts.ctypes.data,
+                res.ctypes.data, scale.ctypes.data), "vieo_global_bundle_adjustment_vio_sharded_scale")
+            return navs, pts, res[0], float(scale[0])
         check(lib().vieo_global_bundle_adjustment_vio_sharded(
             params.ctypes.data, int(nIterations), int(bool(bRobust)), kfs.ctypes.data, len(kfs), points.ctypes.data,
             len(points), obs.ctypes.data, len(obs), imu.ctypes.data, len(imu), ctypes.c_void_p(base),
