@@ -58,3 +58,9 @@ def cases(api):
     rows, nm = api["tri"](kf1, kf2s)[0]
     yield "tri_rig_rows", rows.astype(np.int32), 0
     yield "tri_rig_nmatches", np.array([nm], np.int32), 0
+    # System::FinalGBA's form of the full BA (bScaleOpt = true: VertexScale + EdgeReprojectPRS / PRSStereo), round 3
+    w = synth_ba.make_lba_vio_problem(19, n_local=12, n_fixed=1, n_points=800, anchors=4, span=4)
+    navs, pts, r, scale = api["gba_vio"](w[0], w[1], (w[2] / np.float32(1.04)).astype(np.float32), w[4], w[5], 5, True,
+                                         None, True)
+    yield "gba_scale_nav", nav_vec(navs), 1e-4
+    yield "gba_scale_scale", np.array([scale]), 1e-6
