@@ -278,6 +278,17 @@ def test_gpu_vio_lba_sharded_empty_shard_and_collective_abort(oracle):
     res = _run_ranks(2, [two[0][0], tuple(bad)], n)
     assert all(isinstance(r, VieoError) for r in res), res
     assert "another rank" in str(res[0]) and "this rank" in str(res[1])
+    # a failure only one rank runs into AFTER the argument agreement (a singular pre-integration covariance met while
+    # staging): it reports to the second agreement on its way out, the other rank returns too
+    bad = list(two[1][0])
+    bad[5] = bad[5].copy()
+    bad[5]["imu"]["Sigma"][0] = 0.0
+    res = _run_ranks(2, [two[0][0], tuple(bad)], n)
+    assert all(isinstance(r, VieoError) for r in res), res
+    assert "staging" in str(res[0]) and "singular" in str(res[1])
+    # ... and the engine is fine afterwards
+    res = _run_ranks(2, [two[0][0], two[1][0]], n)
+    assert all(not isinstance(r, Exception) for r in res) and res[0][3]["lm_trials"] == ref[3]["lm_trials"]
 
 
 @pytest.mark.gpu

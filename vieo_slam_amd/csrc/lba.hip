@@ -1846,6 +1846,33 @@ static int shard_exchange(const LbaShard* sh, double* d_buf, size_t n, hipStream
 
 // packed reduced visual system of a window with nf free key frames (k_lba_pack); sc: with the scale vertex's row,
 // H_ps, H_ss, b_s
+// All ranks of a sharded run agree on go / no-go: the sum of the ranks' failure flags through the run's own exchange.
+// Every rank must call it the same number of times.  *sum > 0: some rank failed.
+static int shard_agree(const LbaShard* sh, bool ok, double* sum) {
+  const double flag = ok ? 0.0 : 1.0;
+  *sum = 1.0;
+  VIEO_HIP_CHECK(hipMemcpy(sh->d_buf, &flag, 8, hipMemcpyHostToDevice));
+  const int xrc = shard_exchange(sh, sh->d_buf, 1, nullptr);
+  if (xrc != VIEO_OK) return xrc;
+  VIEO_HIP_CHECK(hipStreamSynchronize(nullptr));
+  VIEO_HIP_CHECK(hipMemcpy(sum, sh->d_buf, 8, hipMemcpyDeviceToHost));
+  return VIEO_OK;
+}
+
+// A rank that leaves lba_run between the first agreement and the rounds (a staging error only it ran into: allocation
+// failure, a singular covariance) still takes part in the second agreement -- with a failure flag -- so that the
+// other ranks return too instead of waiting for it in the first all-reduce of the rounds.
+struct ShardStagingGuard {
+  const LbaShard* sh;
+  bool done = false;
+  ~ShardStagingGuard() {
+    if (sh && !done) {
+      double sum;
+      (void)shard_agree(sh, false, &sum);
+    }
+  }
+};
+
 static size_t shard_sys_doubles(int nf, int sc = 0) {
   const size_t nv = (size_t)6 * nf + (sc ? 1 : 0);
   return nv * (nv + 1) + 36 * (size_t)nf + 6 * (size_t)nf + (sc ? 6 * (size_t)nf + 2 : 0);
@@ -1991,10 +2018,13 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   const int pd = vio ? 15 : 6;
   const int sco = gba && gba->scale_opt ? 1 : 0;
   if (gba && gba->scale_out) *gba->scale_out = 1.0;
-  if (sh && (!vio || (!sh->fn && !sh->ctx) || !sh->d_buf || (stop && *stop))) {
+  // (configuration errors, the same on every rank of a job; `stop` is rank-local and asynchronous, so a sharded run
+  // does not look at it at all -- the public sharded entries pass none)
+  if (sh && (!vio || (!sh->fn && !sh->ctx) || !sh->d_buf)) {
     set_error("sharded local BA: visual-inertial windows only, with a reduction callback and buffer");
     return VIEO_E_INVALID;
   }
+  if (sh) stop = nullptr;
   if (sh) {
     // every rank reaches this collective whatever its own arguments look like; the sum of the failure flags decides
     // for all of them (needs a device: a rank without one cannot take part in the job at all)
@@ -2003,14 +2033,10 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     const bool ok = sh->cap >= 1 && lba_args_ok(true, vio, gba != nullptr, n_windows, params, vparams, h_kfs, n_kf,
                                                 h_points, h_close, n_mp, h_obs, n_obs, h_imu, n_imu, h_navs_out,
                                                 h_points_out, h_erase, h_results, pd);
-    const double flag = ok ? 0.0 : 1.0;
     double sum = 1.0;
     if (sh->cap >= 1) {
-      VIEO_HIP_CHECK(hipMemcpy(sh->d_buf, &flag, 8, hipMemcpyHostToDevice));
-      const int xrc = shard_exchange(sh, sh->d_buf, 1, nullptr);
+      const int xrc = shard_agree(sh, ok, &sum);
       if (xrc != VIEO_OK) return xrc;
-      VIEO_HIP_CHECK(hipStreamSynchronize(nullptr));
-      VIEO_HIP_CHECK(hipMemcpy(&sum, sh->d_buf, 8, hipMemcpyDeviceToHost));
     }
     if (sum != 0.0) {
       set_error(ok ? "sharded local BA: another rank rejected its arguments, all ranks return"
@@ -2018,6 +2044,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       return VIEO_E_INVALID;
     }
   }
+  ShardStagingGuard staging_guard{sh};  // from here to the second agreement every early return reports to the other ranks
   if (n_windows <= 0 || (!vio && !params) || !h_kfs || !n_kf || !h_points || !n_mp || !h_obs || !n_obs ||
       !h_navs_out || !h_points_out || !h_erase || !h_results || (vio && (!h_close || !h_imu || !n_imu)))
     return VIEO_E_INVALID;
@@ -2117,7 +2144,10 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     }
     (void)ob;  // the observations are checked while they are staged (fill_window)
   }
-  if (!n_live) return VIEO_OK;
+  if (!n_live) {  // (key frames and stop state are replicated: the ranks of a sharded run all leave here together)
+    staging_guard.done = true;
+    return VIEO_OK;
+  }
   // ---- arena layout: [inputs | results (kf, X, erase) | zero-initialised | scratch]
   size_t arena = 0;
   auto take = [&](size_t bytes) {
@@ -2479,6 +2509,17 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   const int ge = std::max(1, (max_obs + 255) / 256), gm = std::max(1, (max_mp + 255) / 256), gq = std::max(1, (max_mp + 63) / 64);
   const int gr = std::max(gm, (max_kf + 255) / 256);
 
+  if (sh) {  // second agreement: every rank staged its windows (ShardStagingGuard reports the ones that did not)
+    VIEO_HIP_CHECK(hipStreamSynchronize(st));
+    double sum = 1.0;
+    staging_guard.done = true;
+    const int xrc = shard_agree(sh, true, &sum);
+    if (xrc != VIEO_OK) return xrc;
+    if (sum != 0.0) {
+      set_error("sharded local BA: another rank failed while staging its windows, all ranks return");
+      return VIEO_E_INVALID;
+    }
+  }
   // ---- lock-step rounds
   const double ms_staged = ms_since(t_enter);
   const auto t_rounds = std::chrono::steady_clock::now();
