@@ -955,6 +955,106 @@ int vieo_imu_preintegrate_batch(const vieo_imu_noise* noise, const vieo_imu_samp
                                 vieo_imu_preint* h_out, double* h_sigma_prv /*[n][81], may be NULL*/,
                                 int32_t* h_status);
 
+/* Device form of the same call (the chained frame below runs it on its own stream next to the extraction): every
+ * array in HBM, asynchronous on `stream`; n < 1024 intervals get a wavefront each. */
+int vieo_imu_preintegrate_batch_device(const vieo_imu_noise* d_noise, const vieo_imu_sample* d_samples,
+                                       const int32_t* d_first, const double* d_ti, const double* d_tj,
+                                       const double* d_bg, const double* d_ba, int n, vieo_imu_preint* d_out,
+                                       double* d_sigma_prv, int32_t* d_status, void* stream);
+
+/* ---------------------------------------------------------------- one frame's tracking as ONE call -----------
+ * What Tracking::Track does for a stereo-inertial frame in the steady state -- Frame::Frame (ExtractORB x 2,
+ * src/Frame.cc:259-320; ComputeStereoMatches :451-611), PreIntegration + PredictNavStateByIMU (src/Tracking.cc:385-451),
+ * TrackWithIMU (:261-378: SearchByProjection(last frame) -> PoseOptimization), TrackLocalMapWithIMU (:453-488:
+ * SearchLocalPoints :2308-2370 -> PoseOptimization(bComputeMarg)) -- as one chain of launches on one stream: ONE copy
+ * up from pinned memory (two when the local map changed), the kernels of the entries above back to back with the
+ * bookkeeping between them on the device (vieo_track_* glue), the IMU pre-integration on a second stream beside the
+ * extraction, ONE copy back, ONE host synchronisation.  The caller keeps the reference's object graph (Frame /
+ * KeyFrame / MapPoint / Map) and hands over flattened views of what the calls read; outputs point into pinned memory
+ * owned by the tracker and stay valid until its next call.  Thread model: one tracker per tracking thread; other
+ * threads (LocalMapping, LoopClosing) call the other entries concurrently on their own streams.
+ * Rectified stereo + IMU (BASELINE configs[1] / [2]); rigs go through the stage entries (pipeline_rig). */
+typedef struct vieo_tracker vieo_tracker;
+typedef struct vieo_tracker_params {
+  int32_t width, height;                /* image size; both cameras */
+  int32_t n_features, n_levels, ini_th_fast, min_th_fast;
+  float scale_factor;                   /* ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) */
+  float fx, fy, cx, cy, bf, baseline;   /* rectified pinhole, stereoinfo_.baseline_bf_ */
+  float th_depth;                       /* Frame::mThDepth */
+  float th_last, th_local;              /* th of SearchByProjection(last frame) / (local map): Tracking.cc:296,2365 */
+  float nn_last, nn_local;              /* ORBmatcher(nnratio): 0.9 / 0.8 */
+  int32_t max_local_points;             /* capacity of the local-map candidate table */
+  double Rcb[9], tcb[3];                /* camera <- body */
+  double gw[3];                         /* gravity in the world frame */
+  double inv_sigma_bg2, inv_sigma_ba2;  /* IMUDataBase::mInvSigmabg2 / mInvSigmaba2 */
+  vieo_imu_noise noise;
+} vieo_tracker_params;
+
+typedef struct vieo_track_input {
+  const uint8_t *left, *right;          /* 8-bit grey images, `stride` bytes per row (or the tracker's own pinned
+                                         * planes from vieo_tracker_image_buffers: then no host copy is made) */
+  int32_t stride;
+  int32_t n_imu;
+  const vieo_imu_sample* imu;           /* the samples PreIntegration hands over for [t_ref, t_cur] */
+  double t_ref, t_cur;
+  vieo_navstate nav_ref;                /* the state the prediction starts from: the last key frame's after a map update,
+                                         * else the last frame's (Tracking.cc:392-409) */
+  vieo_navstate nav_last;               /* mLastFrame's state (Tcw of the projection search's LastFrame) */
+  const vieo_navstate* nav_prior;       /* mNavStatePrior / mMargCovInv of the reference state, NULL: none (mbPrior) */
+  const double* H_prior;                /* 15 x 15 row-major */
+  int32_t n_last;
+  const vieo_last_frame_point* last_points; /* mLastFrame.mvpMapPoints flattened (n_last = its key count) */
+  const float* last_track_depth;        /* mTrackDepth of those points (inf: unknown) */
+  int32_t n_local;                      /* local-map candidates (all points of the local key frames; the ones the frame
+                                         * already holds are dropped on the device through local_alias) */
+  int32_t local_version;                /* change it whenever the candidate arrays differ from the previous call's:
+                                         * equal versions skip the re-upload (the local map changes per key frame) */
+  const vieo_frustum_point* local_points;
+  const uint8_t* local_desc;            /* [n_local][32] */
+  const int32_t* local_alias;           /* candidate j is last_points[local_alias[j]] (-1: not in the last frame) */
+} vieo_track_input;
+
+#define VIEO_TRACK_OK 0
+#define VIEO_TRACK_PREINT_FAILED 1      /* mdeltatij == 0 / CheckIMU: PredictNavStateByIMU returns false; extraction and
+                                         * stereo outputs are valid, the tracking outputs are not */
+typedef struct vieo_track_output {
+  int32_t status;                       /* VIEO_TRACK_* */
+  int32_t n_keys, key_cap;              /* left image: N, and the offset that separates the two point tables */
+  const vieo_keypoint* keys;            /* [n_keys] */
+  const uint8_t* desc;                  /* [n_keys][32] */
+  const float *uright, *depth;          /* ComputeStereoMatches */
+  const int32_t* point_ref;             /* per key: -1 none; < key_cap: last_points[i]; else local_points[i - key_cap] */
+  const uint8_t* outlier;               /* per key: mvbOutlier after the second optimisation */
+  const float* local_track_depth;       /* [n_local] mTrackDepth of the candidates (isInFrustum) */
+  int32_t n_matches_last, n_matches_local; /* return values of the two searches */
+  int32_t widened;                      /* 1: the first search ran again with 2 * th_last (Tracking.cc:301-309) */
+  vieo_navstate nav_pred;               /* PredictNavStateByIMU */
+  vieo_imu_preint imu;                  /* the pre-integration [t_ref, t_cur] (Sigma in (p, v, Phi) order) */
+  int32_t preint_status;                /* VIEO_PREINT_* */
+  int32_t reserved;
+  vieo_vio_result first, second;        /* TrackWithIMU's / TrackLocalMapWithIMU's PoseOptimization */
+  float ms_gpu;                         /* HIP-event time of the chain, upload to download */
+  float ms_host;                        /* wall time of the call */
+} vieo_track_output;
+
+int vieo_tracker_create(vieo_tracker** out, const vieo_tracker_params* params);
+void vieo_tracker_destroy(vieo_tracker* t);
+/* pinned planes the caller may decode the next frame's images into (stride = width) */
+int vieo_tracker_image_buffers(vieo_tracker* t, uint8_t** left, uint8_t** right);
+int vieo_tracker_scale_factors(const vieo_tracker* t, float* h_out /*[n_levels]*/);
+int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_output* out);
+/* mvImagePyramid of the frame just tracked, lazily (only Frame::ComputeStereoMatches reads it, src/Frame.cc:457,536-557,
+ * and that ran on the device): image 0 = left, 1 = right; see vieo_orb_get_level */
+int vieo_tracker_get_level(vieo_tracker* t, int image_index, int level, int with_border, uint8_t* h_dst, int dst_stride);
+
+/* Per-call form of the kernel-instance choice (vieo_pose_set_camera_mode / _encoder_mode above are per host thread
+ * and kept for old callers): cams_mode VIEO_POSE_CAMS_*, enc_mode VIEO_POSE_ENC_*. */
+int vieo_pose_optimization_vio_batch_device_ex(const vieo_vio_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
+                                               uint8_t* d_outlier, vieo_vio_result* d_results, int cams_mode,
+                                               int enc_mode, void* stream);
+int vieo_pose_optimization_batch_device_ex(const vieo_pose_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
+                                           uint8_t* d_outlier, vieo_pose_result* d_results, int cams_mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

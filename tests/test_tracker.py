@@ -1,0 +1,115 @@
+"""The one-call frame tracker behind the C-ABI (vieo_tracker_*, vieo_track_frame; csrc/tracker.hip): the chained frame
+of replay.ChainedReplay issued from C++ -- one upload, the IMU pre-integration beside the extraction, the state
+prediction and every piece of bookkeeping on the device, one synchronisation."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from vieo_slam_amd import replay, synth_ba
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tracker_structs_match_the_header(tmp_path):
+    """numpy mirrors of vieo_tracker_params / vieo_track_input / vieo_track_output against the C header (gcc)."""
+    from vieo_slam_amd import tracker as tk
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "vieo_hot.h"
+int main(void) {
+  printf("%zu %zu %zu ", sizeof(vieo_tracker_params), sizeof(vieo_track_input), sizeof(vieo_track_output));
+  printf("%zu %zu %zu %zu ", offsetof(vieo_tracker_params, Rcb), offsetof(vieo_tracker_params, noise),
+         offsetof(vieo_track_input, nav_ref), offsetof(vieo_track_input, local_alias));
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(vieo_track_output, nav_pred), offsetof(vieo_track_output, imu),
+         offsetof(vieo_track_output, first), offsetof(vieo_track_output, second), offsetof(vieo_track_output, ms_gpu),
+         offsetof(vieo_track_output, local_track_depth));
+  return 0;
+}''')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    P, I, O = tk.TRACKER_PARAMS_DTYPE, tk.TRACK_INPUT_DTYPE, tk.TRACK_OUTPUT_DTYPE
+    want = [P.itemsize, I.itemsize, O.itemsize, P.fields["Rcb"][1], P.fields["noise"][1], I.fields["nav_ref"][1],
+            I.fields["local_alias"][1], O.fields["nav_pred"][1], O.fields["imu"][1], O.fields["first"][1],
+            O.fields["second"][1], O.fields["ms_gpu"][1], O.fields["local_track_depth"][1]]
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_replay_equals_the_python_chain(oracle):
+    """100 frames, 9 local BAs: the C++ chain against the oracle's stage-by-stage run (BASELINE configs[2]: ATE within
+    1e-4) and against the Python-issued chain (same kernels; the state prediction moved from numpy to the device)."""
+    from tests.replay_oracle import OracleStages
+    from vieo_slam_amd.tracker import TrackerReplay
+    n = 100
+    seq = replay.Sequence(1, n)
+    Ro = replay.Replay(seq, OracleStages(oracle))
+    to = Ro.run(n)
+    Rc = replay.ChainedReplay(seq, replay.HipStages())
+    tc = Rc.run(n)
+    Rt = TrackerReplay(seq, replay.HipStages())
+    tt = Rt.run(n)
+    Rt.close()
+    assert len(tt) == n and Rt.stats["lba"] == Ro.stats["lba"] == 9 and Rt.stats["widened"] == 0
+    ate = replay.ate_between(tt, to)
+    dmax = np.linalg.norm(tt["p"] - to["p"], axis=1).max()
+    assert ate <= 1e-4 and dmax <= 1e-4, (ate, dmax)
+    rot = max(synth_ba.pose_error(tt[k], to[k])[1] for k in range(n))
+    assert rot <= 1e-4, rot
+    mc, mt = np.array(Rc.stats["n_matches"]), np.array(Rt.stats["n_matches"])
+    ic, it = np.array(Rc.stats["n_inliers"]), np.array(Rt.stats["n_inliers"])
+    assert (mc == mt).all(1).mean() > 0.97 and np.abs(mc - mt).max() <= 3, (mc - mt)
+    assert (ic == it).mean() > 0.97 and np.abs(ic - it).max() <= 3, (ic - it)
+    assert replay.ate_between(tt, tc) <= 1e-5
+    ms = np.array(Rt.stats["ms_chain"])
+    print("tracker replay: ATE vs oracle %.3e m, vs the Python chain %.3e m; per frame %.2f ms in the call "
+          "(GPU %.2f), %.2f ms with the driver" % (ate, replay.ate_between(tt, tc), ms[:, 0].mean(), ms[:, 1].mean(),
+                                                     np.mean(Rt.stats["ms_frames"])))
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_wider_window_branch():
+    """Fewer than 20 matches in the first search (Tracking.cc:301-309): the call re-runs the chain from the projection
+    with 2 x th -- the decisions equal the stage-by-stage replay's, which takes the same branch on the host."""
+    from vieo_slam_amd.tracker import TrackerReplay
+    n = 24
+    seq = replay.Sequence(3, n)
+    Rh = replay.Replay(seq, replay.HipStages(), th_last=0.12)
+    th = Rh.run(n)
+    Rt = TrackerReplay(seq, replay.HipStages(), th_last=0.12)
+    tt = Rt.run(n)
+    Rt.close()
+    assert Rt.stats["widened"] > 0
+    mh, mt = np.array(Rh.stats["n_matches"]), np.array(Rt.stats["n_matches"])
+    assert (mh == mt).all(1).mean() > 0.9 and np.abs(mh - mt).max() <= 3, (mh - mt)
+    assert replay.ate_between(tt, th) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_pinned_image_planes_and_local_version():
+    """Images decoded straight into the tracker's pinned planes give the same frame as caller-owned buffers; an unchanged
+    local_version skips the candidate upload and changes nothing."""
+    from vieo_slam_amd.tracker import TrackerReplay
+    seq = replay.Sequence(4, 14)
+    Ra = TrackerReplay(seq, replay.HipStages())
+    ta = Ra.run(14)
+    Ra.close()
+    Rb = TrackerReplay(seq, replay.HipStages())
+    orig = Rb.seq.images
+
+    def into_pinned(k):
+        L, R = orig(k)
+        Rb.trk.left[:], Rb.trk.right[:] = L, R
+        return Rb.trk.left, Rb.trk.right
+    Rb.initialise()
+    for k in range(1, 14):
+        Rb.seq.images = into_pinned if k > 1 else orig
+        Rb.step(k)
+    Rb.seq.images = orig
+    tb = np.array(Rb.traj, ta.dtype)
+    Rb.close()
+    assert ta.tobytes() == tb.tobytes()

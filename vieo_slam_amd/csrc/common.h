@@ -128,5 +128,6 @@ int pose_rig_launches();
 // the same for the visual-inertial kernel's encoder instances: bit 0 frames without an encoder measurement,
 // bit 1 frames with one (vieo_pose_set_encoder_mode)
 int pose_enc_launches();
+int pose_launch_mask(int mode);  // VIEO_POSE_CAMS_* / VIEO_POSE_ENC_* -> bit mask of the kernel instances to launch
 
 }  // namespace vieo

@@ -345,6 +345,23 @@ static const int kWaveBelow = 1024;  // intervals per call below which every int
 
 using namespace vieo;
 
+extern "C" int vieo_imu_preintegrate_batch_device(const vieo_imu_noise* d_noise, const vieo_imu_sample* d_samples,
+                                                  const int32_t* d_first, const double* d_ti, const double* d_tj,
+                                                  const double* d_bg, const double* d_ba, int n, vieo_imu_preint* d_out,
+                                                  double* d_sigma_prv, int32_t* d_status, void* stream) {
+  if (!d_noise || n <= 0 || !d_first || !d_ti || !d_tj || !d_bg || !d_ba || !d_out || !d_status) return VIEO_E_INVALID;
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  if (n < kWaveBelow)
+    hipLaunchKernelGGL(k_imu_preint<true>, dim3(n), dim3(64), 0, (hipStream_t)stream, d_noise, d_samples, d_first, d_ti,
+                       d_tj, d_bg, d_ba, n, d_out, d_sigma_prv, d_status);
+  else
+    hipLaunchKernelGGL(k_imu_preint<false>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_noise, d_samples,
+                       d_first, d_ti, d_tj, d_bg, d_ba, n, d_out, d_sigma_prv, d_status);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
 extern "C" int vieo_imu_preintegrate_batch(const vieo_imu_noise* noise, const vieo_imu_sample* h_samples,
                                            const int32_t* h_first, const double* h_ti, const double* h_tj,
                                            const double* h_bg, const double* h_ba, int n, vieo_imu_preint* h_out,

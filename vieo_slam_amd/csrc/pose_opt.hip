@@ -397,6 +397,12 @@ int vieo_pose_optimization_batch_device(const vieo_pose_frame* d_frames, int n_f
   return pose_launch(d_frames, n_frames, d_obs, d_outlier, d_results, vieo::pose_rig_launches(), stream);
 }
 
+int vieo_pose_optimization_batch_device_ex(const vieo_pose_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
+                                           uint8_t* d_outlier, vieo_pose_result* d_results, int cams_mode, void* stream) {
+  if (cams_mode < VIEO_POSE_CAMS_AUTO || cams_mode > VIEO_POSE_CAMS_RIG) return VIEO_E_INVALID;
+  return pose_launch(d_frames, n_frames, d_obs, d_outlier, d_results, vieo::pose_launch_mask(cams_mode), stream);
+}
+
 int vieo_pose_optimization(const vieo_pose_frame* h_frame, const vieo_pose_obs* h_obs,
                            uint8_t* h_outlier, vieo_pose_result* h_result) {
   if (!h_frame || !h_result || (h_frame->n_obs > 0 && (!h_obs || !h_outlier))) return VIEO_E_INVALID;

@@ -940,6 +940,16 @@ int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int 
                     vieo::pose_enc_launches(), stream);
 }
 
+int vieo_pose_optimization_vio_batch_device_ex(const vieo_vio_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
+                                               uint8_t* d_outlier, vieo_vio_result* d_results, int cams_mode,
+                                               int enc_mode, void* stream) {
+  if (cams_mode < VIEO_POSE_CAMS_AUTO || cams_mode > VIEO_POSE_CAMS_RIG || enc_mode < VIEO_POSE_ENC_AUTO ||
+      enc_mode > VIEO_POSE_ENC_ALL)
+    return VIEO_E_INVALID;
+  return vio_launch(d_frames, n_frames, d_obs, d_outlier, d_results, vieo::pose_launch_mask(cams_mode),
+                    vieo::pose_launch_mask(enc_mode), stream);
+}
+
 int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_obs* h_obs,
                                uint8_t* h_outlier, vieo_vio_result* h_result) {
   if (!h_frame || !h_result || (h_frame->base.n_obs > 0 && (!h_obs || !h_outlier))) return VIEO_E_INVALID;

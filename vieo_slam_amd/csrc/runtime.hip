@@ -41,16 +41,13 @@ int require_device() {
   return VIEO_OK;
 }
 
-std::atomic<int> g_pose_cams_mode{VIEO_POSE_CAMS_AUTO};
-int pose_rig_launches() {
-  const int m = g_pose_cams_mode.load();
-  return m == VIEO_POSE_CAMS_RECTIFIED ? 1 : m == VIEO_POSE_CAMS_RIG ? 2 : 3;
-}
-std::atomic<int> g_pose_enc_mode{VIEO_POSE_ENC_AUTO};
-int pose_enc_launches() {
-  const int m = g_pose_enc_mode.load();
-  return m == VIEO_POSE_ENC_NONE ? 1 : m == VIEO_POSE_ENC_ALL ? 2 : 3;
-}
+// Per HOST THREAD (round 3): as process-wide values a LocalMapping-side call between another thread's set and reset
+// silently skipped that thread's frames of the other kind.  New callers pass the modes per call (the _ex entries).
+static thread_local int g_pose_cams_mode = VIEO_POSE_CAMS_AUTO;
+int pose_launch_mask(int mode) { return mode == 1 ? 1 : mode == 2 ? 2 : 3; }
+int pose_rig_launches() { return pose_launch_mask(g_pose_cams_mode); }
+static thread_local int g_pose_enc_mode = VIEO_POSE_ENC_AUTO;
+int pose_enc_launches() { return pose_launch_mask(g_pose_enc_mode); }
 
 }  // namespace vieo
 
@@ -75,13 +72,13 @@ int vieo_set_device(int device) {
 
 int vieo_pose_set_camera_mode(int mode) {
   if (mode < VIEO_POSE_CAMS_AUTO || mode > VIEO_POSE_CAMS_RIG) return VIEO_E_INVALID;
-  vieo::g_pose_cams_mode.store(mode);
+  vieo::g_pose_cams_mode = mode;
   return VIEO_OK;
 }
 
 int vieo_pose_set_encoder_mode(int mode) {
   if (mode < VIEO_POSE_ENC_AUTO || mode > VIEO_POSE_ENC_ALL) return VIEO_E_INVALID;
-  vieo::g_pose_enc_mode.store(mode);
+  vieo::g_pose_enc_mode = mode;
   return VIEO_OK;
 }
 

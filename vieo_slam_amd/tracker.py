@@ -1,0 +1,236 @@
+"""ctypes mirror of the one-call frame tracker (include/vieo_hot.h: vieo_tracker_*, vieo_track_frame) and a replay
+that drives it: `TrackerReplay` is `replay.Replay` with a frame's tracking done by ONE C-ABI call (the C++ form of
+what `replay.ChainedReplay` issues from Python launch by launch).  The map bookkeeping stays in the driver, as it
+stays in Tracking / LocalMapping in the reference."""
+import ctypes
+import time
+
+import numpy as np
+
+from . import replay as rp
+from . import synth_ba
+from . import synth_scene as sc
+from ._lib import check, lib
+from .ba_types import IMU_PREINT_DTYPE, LAST_FRAME_POINT_DTYPE, NAVSTATE_DTYPE, VIO_RESULT_DTYPE
+from .imu import IMU_NOISE_DTYPE, IMU_SAMPLE_DTYPE
+from .map_point import FRUSTUM_POINT_DTYPE
+from .orb_extractor import KEYPOINT_DTYPE
+
+TRACKER_PARAMS_DTYPE = np.dtype([
+    ("width", "<i4"), ("height", "<i4"), ("n_features", "<i4"), ("n_levels", "<i4"), ("ini_th_fast", "<i4"),
+    ("min_th_fast", "<i4"), ("scale_factor", "<f4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"),
+    ("bf", "<f4"), ("baseline", "<f4"), ("th_depth", "<f4"), ("th_last", "<f4"), ("th_local", "<f4"), ("nn_last", "<f4"),
+    ("nn_local", "<f4"), ("max_local_points", "<i4"), ("Rcb", "<f8", 9), ("tcb", "<f8", 3), ("gw", "<f8", 3),
+    ("inv_sigma_bg2", "<f8"), ("inv_sigma_ba2", "<f8"), ("noise", IMU_NOISE_DTYPE)], align=True)
+TRACK_INPUT_DTYPE = np.dtype([
+    ("left", "<u8"), ("right", "<u8"), ("stride", "<i4"), ("n_imu", "<i4"), ("imu", "<u8"), ("t_ref", "<f8"),
+    ("t_cur", "<f8"), ("nav_ref", NAVSTATE_DTYPE), ("nav_last", NAVSTATE_DTYPE), ("nav_prior", "<u8"), ("H_prior", "<u8"),
+    ("n_last", "<i4"), ("last_points", "<u8"), ("last_track_depth", "<u8"), ("n_local", "<i4"), ("local_version", "<i4"),
+    ("local_points", "<u8"), ("local_desc", "<u8"), ("local_alias", "<u8")], align=True)
+TRACK_OUTPUT_DTYPE = np.dtype([
+    ("status", "<i4"), ("n_keys", "<i4"), ("key_cap", "<i4"), ("keys", "<u8"), ("desc", "<u8"), ("uright", "<u8"),
+    ("depth", "<u8"), ("point_ref", "<u8"), ("outlier", "<u8"), ("local_track_depth", "<u8"), ("n_matches_last", "<i4"),
+    ("n_matches_local", "<i4"), ("widened", "<i4"), ("nav_pred", NAVSTATE_DTYPE), ("imu", IMU_PREINT_DTYPE),
+    ("preint_status", "<i4"), ("reserved", "<i4"), ("first", VIO_RESULT_DTYPE), ("second", VIO_RESULT_DTYPE),
+    ("ms_gpu", "<f4"), ("ms_host", "<f4")], align=True)
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    L = lib()
+    if not _bound:
+        P, I = ctypes.c_void_p, ctypes.c_int
+        L.vieo_tracker_create.argtypes, L.vieo_tracker_create.restype = [ctypes.POINTER(P), P], I
+        L.vieo_tracker_destroy.argtypes, L.vieo_tracker_destroy.restype = [P], None
+        L.vieo_tracker_image_buffers.argtypes, L.vieo_tracker_image_buffers.restype = [P, ctypes.POINTER(P), ctypes.POINTER(P)], I
+        L.vieo_tracker_scale_factors.argtypes, L.vieo_tracker_scale_factors.restype = [P, P], I
+        L.vieo_track_frame.argtypes, L.vieo_track_frame.restype = [P, P, P], I
+        L.vieo_tracker_get_level.argtypes, L.vieo_tracker_get_level.restype = [P, I, I, I, P, I], I
+        _bound = True
+    return L
+
+
+def euroc_params(max_local_points=16384, th_last=7.0, th_local=2.0, noise=None):
+    """vieo_tracker_params of the replay's rendered EuRoC-like stereo rig (synth_scene)."""
+    P = np.zeros(1, TRACKER_PARAMS_DTYPE)
+    p = P[0]
+    p["width"], p["height"] = rp.W, rp.H
+    p["n_features"], p["n_levels"], p["ini_th_fast"], p["min_th_fast"], p["scale_factor"] = (rp.NFEAT, rp.NLEVELS, rp.INI_TH,
+                                                                                             rp.MIN_TH, rp.SCALE)
+    p["fx"], p["fy"], p["cx"], p["cy"], p["bf"], p["baseline"] = sc.FX, sc.FY, sc.CX, sc.CY, sc.BF, sc.BASELINE
+    p["th_depth"], p["th_last"], p["th_local"], p["nn_last"], p["nn_local"] = rp.TH_DEPTH, th_last, th_local, 0.9, 0.8
+    p["max_local_points"] = max_local_points
+    Tcb = np.linalg.inv(synth_ba.EUROC_TBC)
+    p["Rcb"], p["tcb"] = Tcb[:3, :3].reshape(-1), Tcb[:3, 3]
+    p["gw"] = synth_ba.GRAVITY
+    p["inv_sigma_bg2"], p["inv_sigma_ba2"] = 1.0 / synth_ba.IMU_SIGMA[2] ** 2, 1.0 / synth_ba.IMU_SIGMA[3] ** 2
+    if noise is not None:
+        p["noise"] = noise
+    return P
+
+
+class Tracker:
+    """vieo_tracker: one call per frame.  `track` returns the output record plus numpy views of the per-key arrays
+    (valid until the next call)."""
+
+    def __init__(self, params):
+        L = _bind()
+        self.params = np.ascontiguousarray(params, TRACKER_PARAMS_DTYPE).reshape(1)
+        h = ctypes.c_void_p()
+        check(L.vieo_tracker_create(ctypes.byref(h), self.params.ctypes.data), "vieo_tracker_create")
+        self.h = h
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        check(L.vieo_tracker_image_buffers(h, ctypes.byref(a), ctypes.byref(b)))
+        w, hh = int(self.params[0]["width"]), int(self.params[0]["height"])
+        self.left = np.ctypeslib.as_array((ctypes.c_uint8 * (w * hh)).from_address(a.value)).reshape(hh, w)
+        self.right = np.ctypeslib.as_array((ctypes.c_uint8 * (w * hh)).from_address(b.value)).reshape(hh, w)
+        self._ptrs = (a.value, b.value)
+        self.inp = np.zeros(1, TRACK_INPUT_DTYPE)
+        self.out = np.zeros(1, TRACK_OUTPUT_DTYPE)
+
+    def close(self):
+        if self.h:
+            _bind().vieo_tracker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scale_factors(self):
+        s = np.zeros(int(self.params[0]["n_levels"]), np.float32)
+        check(_bind().vieo_tracker_scale_factors(self.h, s.ctypes.data))
+        return s
+
+    def track(self, left, right, imu, t_ref, t_cur, nav_ref, nav_last, prior, last_points, last_track_depth, local_points,
+              local_desc, local_alias, local_version):
+        i = self.inp[0]
+        keep = []
+        for name, img, mine, ptr in (("left", left, self.left, self._ptrs[0]), ("right", right, self.right, self._ptrs[1])):
+            if img is mine:
+                i[name] = ptr
+            else:
+                img = np.ascontiguousarray(img, np.uint8)
+                keep.append(img)
+                i[name] = img.ctypes.data
+        i["stride"] = int(self.params[0]["width"])
+        imu = np.ascontiguousarray(imu, IMU_SAMPLE_DTYPE)
+        i["n_imu"], i["imu"] = len(imu), imu.ctypes.data
+        i["t_ref"], i["t_cur"], i["nav_ref"], i["nav_last"] = t_ref, t_cur, nav_ref, nav_last
+        if prior is not None:
+            pn = np.zeros(1, NAVSTATE_DTYPE)
+            pn[0] = prior[0]
+            pH = np.ascontiguousarray(prior[1], np.float64)
+            keep += [pn, pH]
+            i["nav_prior"], i["H_prior"] = pn.ctypes.data, pH.ctypes.data
+        else:
+            i["nav_prior"] = i["H_prior"] = 0
+        lp = np.ascontiguousarray(last_points, LAST_FRAME_POINT_DTYPE)
+        ld = np.ascontiguousarray(last_track_depth, np.float32)
+        i["n_last"], i["last_points"], i["last_track_depth"] = len(lp), lp.ctypes.data, ld.ctypes.data
+        cp = np.ascontiguousarray(local_points, FRUSTUM_POINT_DTYPE)
+        cd = np.ascontiguousarray(local_desc, np.uint8)
+        ca = np.ascontiguousarray(local_alias, np.int32)
+        i["n_local"], i["local_version"] = len(cp), int(local_version)
+        i["local_points"], i["local_desc"], i["local_alias"] = cp.ctypes.data, cd.ctypes.data, ca.ctypes.data
+        check(_bind().vieo_track_frame(self.h, self.inp.ctypes.data, self.out.ctypes.data), "vieo_track_frame")
+        o = self.out[0]
+        n, nc = int(o["n_keys"]), len(cp)
+
+        def view(ptr, dtype, count):
+            dtype = np.dtype(dtype)
+            if count == 0:
+                return np.zeros(0, dtype)
+            buf = (ctypes.c_uint8 * (dtype.itemsize * count)).from_address(int(ptr))
+            return np.frombuffer(buf, dtype, count)
+        return o, dict(keys=view(o["keys"], KEYPOINT_DTYPE, n), desc=view(o["desc"], np.uint8, 32 * n).reshape(n, 32),
+                       uright=view(o["uright"], np.float32, n), depth=view(o["depth"], np.float32, n),
+                       point_ref=view(o["point_ref"], np.int32, n), outlier=view(o["outlier"], np.uint8, n),
+                       local_track_depth=view(o["local_track_depth"], np.float32, nc))
+
+
+class TrackerReplay(rp.Replay):
+    """The sequential replay with every frame's tracking as ONE vieo_track_frame call."""
+
+    def __init__(self, seq, stages, max_local_points=16384, **kw):
+        super().__init__(seq, stages, **kw)
+        self.trk = Tracker(euroc_params(max_local_points, self.th_last, self.th_local, seq.noise[0]))
+        self._lv = 0
+        self.stats["ms_chain"] = []
+        self.stats["widened"] = 0
+
+    def close(self):
+        self.trk.close()
+
+    def _all_local_points(self):
+        key = (len(self.kfs), self.stats["lba"])
+        if getattr(self, "_lp_key", None) != key:
+            out, seen = [], set()
+            for k in self.kfs[-self.n_local_kfs:]:
+                for m in k.mp_ref[k.mp_ref >= 0]:
+                    m = int(m)
+                    if m not in seen and not self.mp_bad[m]:
+                        seen.add(m)
+                        out.append(m)
+            self._lp_key, self._lp = key, np.array(out, np.int64)
+            self._lv += 1
+            cp = np.zeros(len(out), FRUSTUM_POINT_DTYPE)
+            cp["Xw"], cp["normal"] = self.mp_X[self._lp], self.mp_normal[self._lp]
+            cp["max_distance"], cp["min_distance"] = self.mp_maxd[self._lp], self.mp_mind[self._lp]
+            self._lp_pts, self._lp_desc = cp, self.mp_desc[self._lp].copy()
+        return self._lp
+
+    def step(self, k):
+        from . import frontend
+        t0 = time.perf_counter()
+        last = self.last
+        ref_nav = self.kfs[-1].nav if self.map_updated else last.nav
+        prior = None if self.map_updated else last.prior
+        t_ref = self.kfs[-1].t if self.map_updated else last.t
+        t = self.seq.time(k)
+        Li, Ri = self.seq.images(k)
+        has = (last.mp_ref >= 0) & ~last.outlier
+        has[has] &= ~self.mp_bad[last.mp_ref[has]]
+        nl = last.N
+        Xw = np.zeros((nl, 3), np.float32)
+        Xw[has] = self.mp_X[last.mp_ref[has]]
+        pts = frontend.make_last_frame_points(last.keys, np.zeros((nl, 32), np.uint8), Xw, has, True)
+        pts["desc"][has] = self.mp_desc[last.mp_ref[has]]
+        cand = self._all_local_points()
+        where = np.full(len(self.mp_X), -1, np.int32)
+        lk = np.nonzero(has)[0]
+        where[last.mp_ref[lk[::-1]]] = lk[::-1]
+        alias = where[cand] if len(cand) else np.zeros(0, np.int32)
+        o, v = self.trk.track(Li, Ri, self.seq.imu_between(t_ref, t), t_ref, t, ref_nav, last.nav, prior, pts,
+                              last.track_depth, self._lp_pts, self._lp_desc, alias, self._lv)
+        assert int(o["status"]) == 0, "IMU pre-integration failed"
+        self.stats["ms_chain"].append((float(o["ms_host"]), float(o["ms_gpu"])))
+        self.stats["widened"] += int(o["widened"])
+        cap = int(o["key_cap"])
+        f = rp._Frame()
+        f.k, f.t = k, t
+        N = f.N = int(o["n_keys"])
+        f.keys, f.desc = v["keys"].copy(), v["desc"].copy()
+        f.uright, f.depth = v["uright"].copy(), v["depth"].copy()
+        tab = v["point_ref"]
+        f.mp_ref = np.full(N, -1, np.int64)
+        f.track_depth = np.full(N, np.inf, np.float32)
+        a = np.nonzero((tab >= 0) & (tab < cap))[0]
+        f.mp_ref[a] = last.mp_ref[tab[a]]
+        f.track_depth[a] = last.track_depth[tab[a]]
+        b = np.nonzero(tab >= cap)[0]
+        f.mp_ref[b] = cand[tab[b] - cap]
+        f.track_depth[b] = v["local_track_depth"][tab[b] - cap]
+        f.outlier = v["outlier"].astype(bool)
+        r1, r2 = o["first"], o["second"]
+        nav1 = r1["base"]["nav"]
+        f.nav = (r2["base"]["nav"] if int(r2["base"]["status"]) == 0 else nav1).copy()
+        f.prior = (f.nav.copy(), r2["H_marg"].copy()) if int(r2["has_marg"]) else None
+        self.map_updated = False
+        self.stats["n_matches"].append((int(o["n_matches_last"]), int(o["n_matches_local"])))
+        self.stats["n_inliers"].append(int(r2["base"]["n_inliers"]))
+        return self._finish_frame(k, f, t0)
