@@ -113,3 +113,37 @@ def test_gpu_tracker_pinned_image_planes_and_local_version():
     tb = np.array(Rb.traj, ta.dtype)
     Rb.close()
     assert ta.tobytes() == tb.tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_cpp_replay_without_python(tmp_path):
+    """examples/replay_main.cc: the sequential replay as a C++ program on the C-ABI (vieo_track_frame per frame, local BA
+    per key frame, the map on the host in C++).  Same sequence, same calls as tracker.TrackerReplay -> the same
+    trajectory up to the rounding of the host-side glue (numpy's BLAS product against a plain loop where new map points
+    are unprojected)."""
+    import json
+    from tools.write_sequence import write_sequence
+    from vieo_slam_amd.tracker import TrackerReplay
+    exe = os.path.join(ROOT, "examples", "replay_main")
+    assert os.path.exists(exe), "examples/replay_main is built by __graft_entry__.build()"
+    n = 60
+    seq = replay.Sequence(1, n)
+    path, traj_path = str(tmp_path / "seq.vseq"), str(tmp_path / "traj.bin")
+    write_sequence(path, 1, n, seq)
+    line = subprocess.check_output([exe, path, traj_path, "--quiet"], timeout=600).decode().strip().splitlines()[-1]
+    r = json.loads(line)
+    from vieo_slam_amd.ba_types import NAVSTATE_DTYPE
+    tc = np.fromfile(traj_path, NAVSTATE_DTYPE)
+    Rt = TrackerReplay(seq, replay.HipStages())
+    tt = Rt.run(n)
+    Rt.close()
+    assert len(tc) == len(tt) == n and r["frames"] == n - 1 and r["local_bas"] == Rt.stats["lba"] == 5
+    assert r["key_frames"] == len(Rt.kfs) and r["map_points"] == len(Rt.mp_X)
+    d = np.linalg.norm(tc["p"] - tt["p"], axis=1)
+    assert d.max() <= 1e-6, d.max()
+    rot = max(synth_ba.pose_error(tc[k], tt[k])[1] for k in range(n))
+    assert rot <= 1e-6, rot
+    assert r["max_err_vs_truth_m"] < 1.5e-2
+    print("C++ replay: %.3f ms per frame (tracking call %.3f, its GPU part %.3f, local BA %.2f ms each); "
+          "max |dp| against the Python driver %.2e m" % (r["ms_per_frame"], r["ms_track_call"], r["ms_track_gpu"],
+                                                         r["ms_per_local_ba"], d.max()))
