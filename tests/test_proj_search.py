@@ -192,3 +192,46 @@ def test_gpu_sbp_reloc_parity(oracle, seed, orbdist):
         hn, ha = m.SearchByProjectionKeyFrame(q, kl, ur, dl, taken, BOUNDS, orbdist)
         assert on == hn and np.array_equal(oa, ha)
         assert on > 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gpu_sbp_assignment_dependency_chains(oracle, mode, monkeypatch):
+    """The optimistic-parallel assignment (k_sbp_assign_par) against the sequential semantics where they bite: look-alike
+    descriptors and wide windows make every query want the keys its predecessors take, so the claims settle only after
+    many rounds.  Three ways through the library -- the parallel fixed point, the sequential replay alone
+    (VIEO_SBP_ASSIGN=seq), the parallel form giving up after one round and handing the frame to the replay -- all equal the
+    oracle bit for bit; unobserved points (no blocking) and pre-claimed keys mixed in."""
+    kl, dl, ur, pts, cam = _scenario(oracle, 1020 + mode, th=25.0 if mode != 1 else 6.0)
+    rng = np.random.default_rng(77 + mode)
+    # a few descriptor families: within a family the distances are 0..6 bits, so the order of claims decides who gets what
+    fam = rng.integers(0, 256, (12, 32), dtype=np.uint8)
+    dl2 = fam[rng.integers(0, 12, len(kl))].copy()
+    flip = rng.integers(0, 256, len(kl))
+    dl2[np.arange(len(kl)), flip % 32] ^= (1 << (flip % 8)).astype(np.uint8)
+    pts2 = pts.copy()
+    pts2["desc"] = fam[rng.integers(0, 12, len(pts))]
+    unobs = rng.random(len(pts)) < 0.15
+    pts2["flags"] = np.where(unobs, pts2["flags"] & 1, pts2["flags"])
+    q = oracle.sbp_project_last_frame(pts2, cam)
+    if mode == 1:
+        q["level_min"], q["level_max"] = pts["octave"] - 1, pts["octave"]
+        q["radius"] = (np.float32(4.0) * cam[0]["scale"][pts["octave"]] * 6).astype(np.float32)
+        q = q[rng.permutation(len(q))]
+    elif mode == 2:
+        q["level_min"], q["level_max"] = pts["octave"] - 1, pts["octave"] + 1
+    taken = (rng.random(len(kl)) < 0.1).astype(np.uint8)
+    m = _hip_matcher(0.9 if mode != 1 else 0.95)
+    call = {0: m.SearchByProjectionLastFrame, 1: m.SearchByProjectionLocalMap,
+            2: lambda *a: m.SearchByProjectionKeyFrame(*a, 100)}[mode]
+    on, oa = oracle.search_by_projection(mode, q, kl, ur, dl2, taken, BOUNDS, nn_ratio=(0.9, 0.95, 100.0)[mode])
+    assert on > 100
+    results = {}
+    for name, env in (("parallel", {}), ("sequential", {"VIEO_SBP_ASSIGN": "seq"}), ("fallback", {"VIEO_SBP_MAX_ROUNDS": "1"})):
+        monkeypatch.delenv("VIEO_SBP_ASSIGN", raising=False)
+        monkeypatch.delenv("VIEO_SBP_MAX_ROUNDS", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        results[name] = call(q, kl, ur, dl2, taken, BOUNDS)
+    for name, (hn, ha) in results.items():
+        assert hn == on and np.array_equal(ha, oa), name

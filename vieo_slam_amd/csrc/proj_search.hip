@@ -13,6 +13,7 @@
 //                     rotation histogram + ComputeThreeMaxima                          [sequential]
 // Integer/index work: results are bit-exact against oracle/proj_search.cc.
 #include <climits>
+#include <cstring>
 
 #include "ba_device.h"
 #include "wave_ops.h"
@@ -201,6 +202,9 @@ struct SbpArgs {
   int pool_cap, pool_lds;
   int* assign;         // [frame][key_cap]
   int* nmatches;       // [frame]
+  int* claim;          // [frame][q_cap] scratch of k_sbp_assign_par: the key every query claims (-1 none)
+  int* need_seq;       // [frame] 1: k_sbp_assign_par gave up, the sequential replay (k_sbp_assign) does the frame
+  int max_rounds;      // of the optimistic assignment
 };
 
 __device__ __forceinline__ int hamming32q(const uint4 a0, const uint4 a1, const uint8_t* b) {
@@ -475,8 +479,163 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   }
 }
 
+// ---- the assignment, optimistic-parallel (round 3).  The reference walks the queries in order and a key that an
+// earlier query's map point took (AddMapPoint, Observations() > 0) is skipped by the later ones (ORBmatcher.cc:289-291,
+// 1430-1433), so query q's outcome depends on the queries before it -- but only through the few keys they claim.
+// Fixed-point form: in every round ALL queries pick their best / second candidate in parallel, treating key k as taken
+// iff the PREVIOUS round's claims hold an earlier blocking query on it (min over the claimers, one atomicMin per claim).
+// By induction query j is right from round j + 1 on, and a round that changes no claim is the sequential answer (every
+// query then agrees with the claims of the queries before it); real frames settle in a handful of rounds because the
+// dependency chains are as short as the overlaps of neighbouring search windows.  One workgroup of 1024 threads per
+// frame, one thread per query; the state lives in LDS.  A frame that has not settled after max_rounds is left to the
+// sequential replay below (need_seq).  Same results bit for bit: the candidate order key (distance, position) and the
+// tests are the replay's.
+__global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
+  extern __shared__ unsigned s_pool[];
+  int* s_min0 = (int*)(s_pool + A.pool_lds);  // [key_cap] earliest blocking claimer of the key, previous / current round
+  int* s_min1 = s_min0 + A.key_cap;
+  unsigned* s_bins = (unsigned*)(s_min1 + A.key_cap);
+  uint8_t* s_taken = (uint8_t*)(s_bins + A.key_cap);
+  __shared__ int s_hist[kHistoLen];
+  __shared__ int s_changed[2], s_nm, s_overflow;  // s_changed: one flag per round parity
+  const int f = blockIdx.x, tid = threadIdx.x;
+  int N;
+  {
+    int k0;
+    cam_range(A, f, A.n_cams - 1, &k0, &N);
+  }
+  const int nq = min(A.nq[f], A.q_cap);
+  int* assign = A.assign + (size_t)f * A.key_cap;
+  const uint8_t* taken = A.taken ? A.taken + (size_t)f * A.key_cap : nullptr;
+  const unsigned* pool = A.pool + (size_t)f * A.pool_cap;
+  const int2* qrec = A.qrec + (size_t)f * A.q_cap;
+  int* claim = A.claim + (size_t)f * A.q_cap;
+  const int n_lds = min(min(A.cursor[f], A.pool_cap), A.pool_lds);
+  for (int i = tid; i < n_lds; i += 1024) s_pool[i] = pool[i];
+  for (int i = tid; i < N; i += 1024) {
+    s_taken[i] = taken ? taken[i] : (uint8_t)0;
+    s_min0[i] = INT_MAX, s_min1[i] = INT_MAX, s_bins[i] = 0u;
+    assign[i] = VIEO_SBP_UNCHANGED;
+  }
+  for (int q = tid; q < nq; q += 1024) claim[q] = -1;
+  if (tid < kHistoLen) s_hist[tid] = 0;
+  if (tid == 0) s_nm = 0, s_overflow = 0, s_changed[0] = s_changed[1] = 0;
+  __syncthreads();
+  const bool reloc = A.mode == VIEO_SBP_RELOC;
+  // best / second of query q when key k is blocked iff it was taken at the start or mn[k] < q; returns the claimed
+  // key (-1: no match) and the winner's candidate word
+  auto eval = [&](int q, const int* mn, unsigned* word, int* blocker) -> int {
+    const int2 r = qrec[q];
+    const int off = r.x, ny = r.y;
+    if (ny == 0) return -1;
+    if (ny < 0) {
+      s_overflow = 1;
+      return -1;
+    }
+    const int n = ny & 0xFFFF;
+    unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu, c0 = 0, c1 = 0;
+    for (int pos = 0; pos < n; pos++) {
+      const unsigned c = off + pos < n_lds ? s_pool[off + pos] : pool[off + pos];
+      const int idx = c & 0x1FFF;
+      if (s_taken[idx] || mn[idx] < q) continue;
+      const unsigned key = (((c >> 13) & 0x1FFu) << 8) | (unsigned)pos;  // (dist, order)
+      if (key < b0)
+        b1 = b0, c1 = c0, b0 = key, c0 = c;
+      else if (key < b1)
+        b1 = key, c1 = c;
+    }
+    if (b0 == 0xFFFFFFFFu) return -1;
+    const int bestDist = b0 >> 8, bestLevel = (c0 >> 22) & 15;
+    if (bestDist > (reloc ? (int)A.nn_ratio : kThHigh)) return -1;
+    if (A.mode == VIEO_SBP_LOCAL_MAP && b1 != 0xFFFFFFFFu) {
+      const int bestDist2 = b1 >> 8, bestLevel2 = (c1 >> 22) & 15;
+      if (bestLevel == bestLevel2 && (float)bestDist > A.nn_ratio * (float)bestDist2) return -1;
+    }
+    *word = c0;
+    *blocker = reloc || (ny >> 16);  // its key is closed to later queries (any holder in the relocalisation mode)
+    return (int)(c0 & 0x1FFF);
+  };
+  bool settled = false;
+  for (int round = 0; round < A.max_rounds; round++) {
+    int* prev = (round & 1) ? s_min1 : s_min0;
+    int* cur = (round & 1) ? s_min0 : s_min1;
+    int changed = 0;
+    for (int q = tid; q < nq; q += 1024) {
+      unsigned w;
+      int blk = 0;
+      const int k = eval(q, prev, &w, &blk);
+      if (k != claim[q]) claim[q] = k, changed = 1;
+      if (k >= 0 && blk) atomicMin(&cur[k], q);
+    }
+    if (changed) s_changed[round & 1] = 1;
+    __syncthreads();
+    const int any = s_changed[round & 1];
+    if (tid == 0) s_changed[(round + 1) & 1] = 0;  // (last read a round ago)
+    for (int i = tid; i < N; i += 1024) prev[i] = INT_MAX;  // becomes the next round's `cur`
+    __syncthreads();
+    if (!any) {  // `cur` == the claims everybody just agreed with
+      settled = true;
+      // results: AddMapPoint in query order = the last accepted claimer of a key stays
+      const bool ori = A.mode != VIEO_SBP_LOCAL_MAP && A.check_ori;
+      int* s_asg = prev;  // (free now) -1 == VIEO_SBP_UNCHANGED after the reset below
+      for (int i = tid; i < N; i += 1024) s_asg[i] = -1;
+      __syncthreads();
+      int nm = 0;
+      for (int q = tid; q < nq; q += 1024) {
+        const int k = claim[q];
+        if (k < 0) continue;
+        unsigned w = 0;
+        int blk = 0;
+        (void)eval(q, cur, &w, &blk);  // the winner's word again (rotation bin)
+        atomicMax(&s_asg[k], q);
+        nm++;
+        if (ori) {
+          const int bin = (w >> 26) & 31;
+          atomicOr(&s_bins[k], 1u << bin);
+          atomicAdd(&s_hist[bin], 1);
+        }
+      }
+      if (nm) atomicAdd(&s_nm, nm);
+      __syncthreads();
+      int nmatches = s_nm;
+      unsigned losers = 0;
+      if (ori) {  // ComputeThreeMaxima (ORBmatcher.cc:1608-1641), evaluated redundantly by every thread
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < kHistoLen; i++) {
+          const int sv = s_hist[i];
+          if (sv > max1) {
+            max3 = max2, max2 = max1, max1 = sv;
+            ind3 = ind2, ind2 = ind1, ind1 = i;
+          } else if (sv > max2) {
+            max3 = max2, max2 = sv;
+            ind3 = ind2, ind2 = i;
+          } else if (sv > max3) {
+            max3 = sv, ind3 = i;
+          }
+        }
+        if (max2 < 0.1f * (float)max1) {
+          ind2 = -1, ind3 = -1;
+        } else if (max3 < 0.1f * (float)max1) {
+          ind3 = -1;
+        }
+        losers = (1u << kHistoLen) - 1u;
+        if (ind1 >= 0) losers &= ~(1u << ind1);
+        if (ind2 >= 0) losers &= ~(1u << ind2);
+        if (ind3 >= 0) losers &= ~(1u << ind3);
+        for (int i = 0; i < kHistoLen; i++)
+          if (i != ind1 && i != ind2 && i != ind3) nmatches -= s_hist[i];
+      }
+      for (int k = tid; k < N; k += 1024) assign[k] = (s_bins[k] & losers) ? VIEO_SBP_ERASED : s_asg[k];
+      if (tid == 0) A.nmatches[f] = s_overflow ? -1 : nmatches;
+      break;
+    }
+  }
+  if (tid == 0) A.need_seq[f] = settled ? 0 : 1;
+}
+
 // one wave per frame: the frame's candidate pool is copied to LDS once, after that the replay of
-// the queries touches no global memory except the accepted assignments
+// the queries touches no global memory except the accepted assignments.  Since round 3 the fallback of
+// k_sbp_assign_par (frames whose claims did not settle) and the reference form for the tests (VIEO_SBP_ASSIGN=seq).
 __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
   // dynamic LDS: pool copy (pool_lds words) | per key the rotation bins it was accepted with (bit b = bin b; a key
   // can be accepted more than once when its holder has no observations) | key state (key_cap bytes)
@@ -485,6 +644,7 @@ __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
   uint8_t* s_state = (uint8_t*)(s_bins + A.key_cap);  // bit0: holds a map point, bit1: it has Observations()>0
   __shared__ int s_hist[kHistoLen];
   const int f = blockIdx.x, lane = threadIdx.x;
+  if (A.need_seq && !A.need_seq[f]) return;  // the parallel assignment settled this frame
   int N;
   {
     int k0;
@@ -727,7 +887,7 @@ k_fuse_search(const FuseDev* __restrict__ fd, int cami, const int* __restrict__ 
 }
 
 struct SbpScratch {
-  DevBuf pool, cursor, qrec, q, nq, keys, ur, desc, taken, counts, assign, nm, pts, cam, cell_start, cell_rec, cell_ang;
+  DevBuf pool, cursor, qrec, q, nq, keys, ur, desc, taken, counts, assign, nm, pts, cam, cell_start, cell_rec, cell_ang, claim, need;
 };
 static thread_local SbpScratch g_sbp;
 
@@ -765,7 +925,29 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
                      S.cell_rec.as<float4>(), S.cell_ang.as<float>());
   hipLaunchKernelGGL(k_sbp_candidates, dim3(kSbpBlocks, n_frames), dim3(256),
                      (size_t)A.n_cams * (kGridCells + 1) * sizeof(unsigned short), st, A);
+  // VIEO_SBP_ASSIGN=seq: only the sequential replay (A/B runs, tests); VIEO_SBP_MAX_ROUNDS: rounds before a frame is
+  // handed to it (1 = every frame with any dependency falls back)
+  // (read at every call: the tests switch them in-process)
+  const char* e_mode = getenv("VIEO_SBP_ASSIGN");
+  const bool seq_only = e_mode && !strcmp(e_mode, "seq");
+  const char* e_rounds = getenv("VIEO_SBP_MAX_ROUNDS");
+  const int max_rounds = e_rounds && atoi(e_rounds) > 0 ? atoi(e_rounds) : 48;
   const size_t lds = (size_t)A.pool_lds * 4 + (size_t)A.key_cap * 5;
+  A.need_seq = nullptr, A.claim = nullptr, A.max_rounds = max_rounds;
+  if (!seq_only) {
+    if ((rc = S.claim.ensure((size_t)n_frames * A.q_cap * 4)) != VIEO_OK) return rc;
+    if ((rc = S.need.ensure((size_t)n_frames * 4)) != VIEO_OK) return rc;
+    A.claim = S.claim.as<int>(), A.need_seq = S.need.as<int>();
+    SbpArgs P = A;
+    size_t lds_par = (size_t)P.pool_lds * 4 + (size_t)P.key_cap * 13;
+    if (lds_par > 150 * 1024) P.pool_lds = 0, lds_par = (size_t)P.key_cap * 13;  // many-camera frames: the pool stays in L2
+    static thread_local size_t lds_set = 0;
+    if (lds_par > lds_set) {
+      VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_sbp_assign_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_par));
+      lds_set = lds_par;
+    }
+    hipLaunchKernelGGL(k_sbp_assign_par, dim3(n_frames), dim3(1024), lds_par, st, P);
+  }
   hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), lds, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
