@@ -118,10 +118,14 @@ __device__ bool wave_ldlt_solve_reg(const double* H, double lambda, const double
 #pragma unroll
   for (int j = 0; j < N; j++) {
     const double d = readlane_d(a[j], j);
-    Dd[j] = d;
     if (!(d > 0)) ok = false;
+    // 1 / d once per column (v_rcp_f64 + two Newton steps, as k_lba_ldlt16 does) instead of a division per row
+    double inv = __builtin_amdgcn_rcp(d);
+    inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+    inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+    Dd[j] = inv;
     const double c = a[j];          // un-normalised column entry of this row
-    const double l = c / d;
+    const double l = c * inv;
 #pragma unroll
     for (int k = j + 1; k < N; k++) {
       const double ck = readlane_d(a[j], k);  // A[k][j]
@@ -141,7 +145,7 @@ __device__ bool wave_ldlt_solve_reg(const double* H, double lambda, const double
 #pragma unroll
   for (int j = 0; j < N; j++)
     if (lane == j) dd = Dd[j];
-  y /= dd;
+  y *= dd;
   // L -> LDS, then lane i fetches column i (rows below it)
   if (lane < N)
 #pragma unroll
@@ -440,12 +444,20 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     __syncthreads();
     double lambda = -1, ni = 2;
     int nBadLM = 0;
+    // an iteration after the first starts at the state its predecessor's last trial was ACCEPTED at (a rejected last
+    // trial ends the optimize()), and that trial evaluated the generic edges there: errors, weights and rho' are still
+    // in LDS / registers, computing them again gives the same bits
+    double accChi = 0, accI = 1, accB = 1, accP = 1, accE = 1;
     for (int iter = 0; iter < 10; iter++) {
       total_iters++;
       // ---- computeActiveErrors + activeRobustChi2 + buildSystem
       double rhoI, rhoB, rhoP;
       PP(0);
-      const double chiG = generic_errors(&rhoI, &rhoB, &rhoP);
+      double chiG;
+      if (iter == 0)
+        chiG = generic_errors(&rhoI, &rhoB, &rhoP);
+      else
+        chiG = accChi, rhoI = accI, rhoB = accB, rhoP = accP, rhoE = accE;
       PP(1);
       Est e;
       e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
@@ -615,16 +627,18 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         __syncthreads();
         PP(6);
         const bool ok2 = S.ok != 0;
-        if (tid == 0) {
-          if (!ok2)
-            for (int i = 0; i < n; i++) S.x[i] = 0;
-          ns_inc(S.nsj, S.x, S.x + 9);
-          if (!fixedLast) ns_inc(S.nsi, S.x + 15, S.x + 24);
+        if (!ok2) {  // (uniform)
+          if (tid < n) S.x[tid] = 0;
+          __syncthreads();
         }
+        // the two states are retracted side by side on different wavefronts (one lane each)
+        if (tid == 0) ns_inc(S.nsj, S.x, S.x + 9);
+        if (tid == T1 && !fixedLast) ns_inc(S.nsi, S.x + 15, S.x + 24);
         __syncthreads();
         PP(7);
         double r1, r2, r3;
-        double tempChi = generic_errors(&r1, &r2, &r3);
+        const double tempChiG = generic_errors(&r1, &r2, &r3);
+        double tempChi = tempChiG;
         PP(8);
         tempChi += visual_chi();
         PP(9);
@@ -640,6 +654,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           lambda *= fmax(1. / 3., alpha);
           ni = 2;
           currentChi = tempChi;
+          accChi = tempChiG, accI = r1, accB = r2, accP = r3, accE = rhoE;
         } else {
           lambda *= ni;
           ni *= 2;
