@@ -19,10 +19,12 @@ with no data-path collective ("weak" scaling: B frames per rank per step).  Rank
 JSON line.
 
 Besides the batched headline the line carries
-  single_stream: the SEQUENTIAL replay of vieo_slam_amd/replay.py (frame t's pose, map points and marginal prior feed
-      frame t+1, one LocalBundleAdjustmentNavStatePRV per 10 frames with write-back) on ONE stream of frames through
-      the C-ABI, a frame's tracking as one chain of launches (one copy up, one back): ms per frame, frames/s, and the ATE of
-      that trajectory against the same replay run on the CPU oracle (BASELINE configs[2]: "ATE within 1e-4 of ref");
+  single_stream: the SEQUENTIAL replay (frame t's pose, map points and marginal prior feed frame t+1, one
+      LocalBundleAdjustmentNavStatePRV per 10 frames with write-back) on ONE stream of frames, run by the C++ program
+      examples/replay_main on the C-ABI (vieo_track_frame: a frame's tracking as one chain of launches, one copy up, one
+      back, one synchronisation): ms per frame, frames/s, the ratio to the same replay on the CPU oracle
+      (vs_cpu_single_stream), the reference's own published front-end figure beside it (reference_readme_anchor), and the
+      ATE of that trajectory against the oracle's (BASELINE configs[2]: "ATE within 1e-4 of ref");
   pcie_inclusive: the batched step again with the step's images arriving from pinned host memory on a copy stream
       (double-buffered, overlapped with the previous step's kernels).
 
@@ -197,45 +199,65 @@ def cpu_baseline(P, lba_problems, lba_every, budget_s=20.0):
                       % (n_done, lba_every, os.cpu_count())}
 
 
+README_FRONTEND_MS = {"value": 35.0, "source": "/root/reference/README.md:60 'Final MH05 mean time cost per frame of "
+                      "frontend(ms): 43.X -> 11.X -- 35.X' (i9-14900HX virtual box, 16 cores, 2024/9/9); the reference's own "
+                      "published figure for the front end of this configuration, NOT measured here"}
+
+
 def single_stream_leg(seq, n_frames):
-    """The sequential replay on the C-ABI (see the module docstring), a frame's tracking as one chain of launches
-    (replay.ChainedReplay); the stage-by-stage form (one synchronous call per stage) is timed beside it.  The
-    oracle's run of the same replay is part of the cpu_baseline leg, which fills in the ATE."""
+    """The sequential replay on the C-ABI (see the module docstring).  Headline: examples/replay_main, the replay as a
+    C++ program WITHOUT Python -- vieo_track_frame per frame (one chain of launches, one synchronisation), local BA per
+    key frame, the map on the host in C++.  Beside it the same replay driven from Python stage by stage (one synchronous
+    host-pointer call per stage).  The oracle's run of the same replay is part of the cpu_baseline leg, which fills in
+    the ATE."""
+    import subprocess
+    import tempfile
+    from tools.write_sequence import write_sequence
     from vieo_slam_amd import replay, synth_ba
+    from vieo_slam_amd.ba_types import NAVSTATE_DTYPE
     for k in range(n_frames):
         seq.images(k)  # rendering is not part of either timing
-    out = {}
-    for name, cls in (("stage_by_stage", replay.Replay), ("chained", replay.ChainedReplay)):
-        R = cls(seq, replay.HipStages())
-        R.run(min(12, n_frames))  # warm-up: kernels loaded, scratch buffers allocated
-        R = cls(seq, replay.HipStages())
-        t0 = time.perf_counter()
-        th = R.run(n_frames)
-        out[name] = (R, th, time.perf_counter() - t0)
-    Rs, _, t_s = out["stage_by_stage"]
-    Rh, th, t_hip = out["chained"]
+    exe = os.path.join(ROOT, "examples", "replay_main")
+    if not os.path.exists(exe):
+        raise RuntimeError("examples/replay_main is missing: run __graft_entry__.build()")
+    with tempfile.TemporaryDirectory() as tmp:
+        path, traj = os.path.join(tmp, "seq.vseq"), os.path.join(tmp, "traj.bin")
+        write_sequence(path, seq.seed, n_frames, seq)
+        runs = []
+        for _ in range(3):  # the best of three: a fresh box has noisy first seconds
+            line = subprocess.check_output([exe, path, traj, "--warmup", "16", "--quiet"], timeout=900).decode().strip()
+            runs.append(json.loads(line.splitlines()[-1]))
+        r = min(runs, key=lambda x: x["ms_per_frame"])
+        th = np.fromfile(traj, NAVSTATE_DTYPE)
+    Rs = replay.Replay(seq, replay.HipStages())
+    Rs.run(min(12, n_frames))
+    Rs = replay.Replay(seq, replay.HipStages())
+    t0 = time.perf_counter()
+    ts = Rs.run(n_frames)
+    t_s = time.perf_counter() - t0
     err = max(synth_ba.pose_error(th[k], seq.truth(k))[0] for k in range(n_frames))
-    ms_f, ms_l = np.array(Rh.stats["ms_frames"]), np.array(Rh.stats["ms_lba"])
-    chain = np.array(Rh.stats["ms_chain"])
     return {
-        "frames": n_frames, "local_bas": int(Rh.stats["lba"]),
-        "ms_per_frame": 1e3 * t_hip / (n_frames - 1),
-        "frames_per_s": (n_frames - 1) / t_hip,
-        "latency_ms_per_frame_tracking_median": float(np.median(ms_f)),
-        "latency_ms_per_frame_tracking_p95": float(np.percentile(ms_f, 95)),
-        "ms_per_frame_host_prepare_launch_wait": [float(x) for x in chain.mean(0)],
-        "host_syncs_per_frame": 2, "frames_through_the_stage_by_stage_path": int(Rh.stats["fallbacks"]),
-        "ms_per_local_ba_mean": float(ms_l.mean()) if len(ms_l) else None,
-        "ate_vs_oracle_m": None, "max_position_difference_vs_oracle_m": None,
+        "frames": n_frames, "local_bas": r["local_bas"],
+        "ms_per_frame": r["ms_per_frame"], "frames_per_s": r["frames_per_s"],
+        "ms_per_frame_all_runs": [x["ms_per_frame"] for x in runs],
+        "ms_per_frame_tracking_call": r["ms_track_call"], "ms_per_frame_tracking_call_gpu": r["ms_track_gpu"],
+        "ms_per_frame_without_local_ba": r["ms_frame_without_local_ba"], "ms_per_local_ba_mean": r["ms_per_local_ba"],
+        "host_syncs_per_frame": 1, "frames_with_the_wider_search_window": r["widened"],
+        "key_frames": r["key_frames"], "map_points": r["map_points"],
+        "ate_vs_oracle_m": None, "max_position_difference_vs_oracle_m": None, "vs_cpu_single_stream": None,
         "max_position_error_vs_truth_m": float(err),
+        "max_position_difference_vs_stage_by_stage_m": float(np.linalg.norm(th["p"] - ts["p"], axis=1).max()),
+        "reference_readme_anchor": dict(README_FRONTEND_MS, ratio_to_this_ms_per_frame=README_FRONTEND_MS["value"] / r["ms_per_frame"],
+                                        ms_per_frame_for_30x=README_FRONTEND_MS["value"] / 30.0),
         "stage_by_stage": {"ms_per_frame": 1e3 * t_s / (n_frames - 1),
                            "latency_ms_per_frame_tracking_median": float(np.median(Rs.stats["ms_frames"]))},
-        "path": "a frame's tracking as ONE chain of launches on one stream: inputs in one copy from pinned memory, "
-                "extraction x2 -> stereo -> SearchByProjection(last frame) -> PoseOptimization -> isInFrustum + queries "
-                "from the optimised pose in HBM -> SearchByProjection(local map) -> PoseOptimization(marg) on the "
-                "device-pointer entry points, results in one copy back; the host synchronises twice per frame (IMU "
-                "pre-integration, end of the chain); one host thread; includes the host glue of the replay driver "
-                "(numpy: map bookkeeping, local-BA window assembly); stage_by_stage = the same replay with one synchronous "
+        "path": "examples/replay_main (C++, no Python): per frame ONE vieo_track_frame call = one copy up from pinned "
+                "memory, IMU pre-integration on a second stream beside extraction x2 -> stereo, PredictNavStateByIMU on the "
+                "device, SearchByProjection(last frame) -> PoseOptimization -> isInFrustum + queries from the optimised pose "
+                "in HBM -> SearchByProjection(local map) -> PoseOptimization(marg), one copy back, ONE host synchronisation; "
+                "per key frame (every 10 frames) vieo_imu_preintegrate_batch + vieo_local_bundle_adjustment_vio + "
+                "vieo_update_normal_and_depth_batch; ms_per_frame is wall time of the whole loop incl. the C++ map "
+                "bookkeeping and the local BAs; stage_by_stage = the same replay driven from Python with one synchronous "
                 "host-pointer call per stage",
     }, th
 
@@ -534,6 +556,7 @@ def main():
             if not a.no_cpu_baseline:  # the oracle's run of the same replay: baseline and checker
                 cb, to = cpu_replay(seq, a.single_stream_frames)
                 out["cpu_baseline"]["single_stream"] = cb
+                out["single_stream"]["vs_cpu_single_stream"] = out["single_stream"]["frames_per_s"] / cb["value"]
                 out["single_stream"]["ate_vs_oracle_m"] = replay.ate_between(th, to)
                 out["single_stream"]["max_position_difference_vs_oracle_m"] = float(
                     np.linalg.norm(th["p"] - to["p"], axis=1).max())
