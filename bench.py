@@ -337,7 +337,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2048, help="stereo frames per GPU per step")
-    ap.add_argument("--base-cases", type=int, default=8, help="distinct rendered scenes per GPU")
+    ap.add_argument("--workload", choices=("r3", "r2"), default="r3",
+                    help="r3 (default): SURVEY 8d as written -- 64 distinct cases with non-planar depth and low-contrast "
+                         "patches, isInFrustum + query construction for 4-5 k local-map candidates per frame inside the step, "
+                         "local-BA windows with 40 fixed key frames (~21 k edges), every 4th one bLarge (25 local key "
+                         "frames); r2: the shape of rounds 1-2 (8 views of one textured plane, host-precomputed local-map "
+                         "queries, 6 fixed key frames / ~12 k edges), kept so that the numbers stay comparable")
+    ap.add_argument("--base-cases", type=int, default=0, help="distinct rendered cases per GPU (0: 64 for r3, 8 for r2)")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent frame pipelines per GPU, each on its own HIP stream (the batch "
                          "is split between them so latency-bound stages overlap extraction: 2 streams give "
@@ -368,9 +374,10 @@ def main():
 
     B = a.batch
     S = max(1, min(a.streams, B))
-    cases = make_cases(min(a.base_cases, B), seed0=sharding.rank_seed(rank))
+    n_base = a.base_cases if a.base_cases > 0 else (64 if a.workload == "r3" else 8)
+    cases = make_cases(min(n_base, B), seed0=sharding.rank_seed(rank), workload=a.workload)
     sizes = [B // S + (1 if i < B % S else 0) for i in range(S)]
-    pipes = [FramePipeline(cases[i % len(cases):] + cases[:i % len(cases)], sizes[i], seed=rank * 16 + i)
+    pipes = [FramePipeline(cases[i % len(cases):] + cases[:i % len(cases)], sizes[i], seed=rank * 16 + i, workload=a.workload)
              for i in range(S)]
     P = pipes[0]
     n_img = 2 * P.B
@@ -380,8 +387,18 @@ def main():
     from vieo_slam_amd import synth_ba
     from vieo_slam_amd.optimizer import Optimizer
     n_lba = (B + a.lba_every - 1) // a.lba_every if a.lba_every > 0 else 0
-    lba_problems = [synth_ba.make_lba_vio_problem(500 + 7 * rank + i, n_local=10, n_fixed=6, n_points=2000)[:6]
-                    for i in range(min(8, n_lba))]
+    if a.workload == "r3":  # 10 local + 40 fixed key frames, ~1600 points / ~21 k edges; every 4th window bLarge
+        lba_problems = []
+        for i in range(min(8, n_lba)):
+            large = i % 4 == 3
+            w = synth_ba.make_lba_vio_problem(500 + 7 * rank + i, n_local=25 if large else 10, n_fixed=40, n_points=2000)[:6]
+            w[0][0]["large"] = int(large)
+            if large:  # ORB3_STRATEGY_OPT_WIDER: Nlocal *= 2.5, optit = {2, 2} (Optimizer.cc:45-52)
+                w[0][0]["base"]["its0"], w[0][0]["base"]["its1"] = 2, 2
+            lba_problems.append(w)
+    else:
+        lba_problems = [synth_ba.make_lba_vio_problem(500 + 7 * rank + i, n_local=10, n_fixed=6, n_points=2000)[:6]
+                        for i in range(min(8, n_lba))]
     pool = ThreadPoolExecutor(max_workers=max(1, a.lba_threads))
     lba_ms = []
 
@@ -459,7 +476,8 @@ def main():
         dom = max(kern, key=kern.get)
         launches = lba_k[dom]["launches"] / a.steps if dom in lba_k else share
         # algorithmic bytes per launch of the kernels that are HBM-bound by design
-        nfree, nmp_w, nobs_w = 10, np.mean([len(p[2]) for p in lba_problems]) if lba_problems else 0, \
+        nfree = float(np.mean([int((p[1]["fixed"] == 0).sum()) for p in lba_problems])) if lba_problems else 0
+        nmp_w, nobs_w = np.mean([len(p[2]) for p in lba_problems]) if lba_problems else 0, \
             np.mean([len(p[4]) for p in lba_problems]) if lba_problems else 0
         lba_ab = {"lba.build": n_lba * (6 * nfree * 3 * nmp_w * 8 + 40 * nobs_w + 96 * nmp_w)}  # dense BB + edges + H_ll, b_l
         if dom.startswith("orb."):
@@ -489,11 +507,19 @@ def main():
                             "local BA; --lba-every 0 is configs[1] alone): "
                             "synthetic rendered stereo-inertial frames 752x480, 1.2x8 levels, FAST 20/7; per "
                             "frame ORBextractor x2 + ComputeStereoMatches + SearchByProjection(last frame) + "
-                            "PoseOptimization(VIO) + SearchByProjection(local map) + PoseOptimization(VIO, marg); "
-                            "plus one LocalBundleAdjustmentNavStatePRV (10 local key frames with PR+V+Bias "
-                            "vertices and IMU pre-integration edges, 6 fixed, ~1500 points, ~12k observations) per "
+                            "PoseOptimization(VIO) + SearchByProjection(local map) + PoseOptimization(VIO, marg); " +
+                            ("workload r3 (SURVEY 8d): %d distinct cases (8 textures with low-contrast patches x sheet "
+                             "layouts: non-planar depth) x noise replicas; Frame::isInFrustum + query construction for "
+                             "%d local-map candidates per frame inside the step; plus one LocalBundleAdjustmentNavStatePRV "
+                             "(10 local key frames with PR+V+Bias vertices and IMU edges, 40 fixed, ~%d points, ~%d "
+                             "observations; every 4th window bLarge with 25 local key frames) per "
+                             % (len(cases), int(np.mean(P.ncand_host)), int(nmp_w), int(nobs_w)) if a.workload == "r3" else
+                             "workload r2: 8 views of one textured plane, local-map queries precomputed on the host; plus one "
+                             "LocalBundleAdjustmentNavStatePRV (10 local key frames with PR+V+Bias vertices and IMU "
+                             "pre-integration edges, 6 fixed, ~1500 points, ~12k observations) per ") +
                             "%d frames, the windows of a step advanced in lock step (%d per call, %d host "
                             "threads)" % (a.lba_every, lba_chunk, a.lba_threads),
+                "workload_id": a.workload,
                 "local_ba_windows_per_step": n_lba,
                 "local_ba_ms_per_window_mean": float(np.mean(lba_ms)) if lba_ms else None,
                 "local_ba_lm_iterations_mean": float(np.mean([r["lm_iterations"] for r in lba_res])) if lba_res else None,

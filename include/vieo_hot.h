@@ -877,6 +877,16 @@ int vieo_track_local_queries_device(const vieo_frustum_frame* h_frame, const vie
                                     int n_points, float th, float th_far, const float* d_scale, vieo_proj_query* d_queries,
                                     float* d_track_depth, int32_t* d_nq, void* stream);
 
+/* The same for a batch of frames (bench.py's batched step): frame f reads d_frames[f] / d_results[f], its candidates
+ * d_points / d_desc / d_alias [f][p_cap] (d_counts[f] of them), d_held [f][held_cap]; writes d_queries [f][p_cap * n_cams],
+ * d_track_depth + f * depth_stride, d_nq[f] = d_counts[f] * n_cams. */
+int vieo_track_local_queries_batch_device(const vieo_frustum_frame* h_frame, const vieo_vio_frame* d_frames,
+                                          const vieo_vio_result* d_results, int n_frames, const vieo_frustum_point* d_points,
+                                          const uint8_t* d_desc, const int32_t* d_alias, const int32_t* d_counts, int p_cap,
+                                          const uint8_t* d_held, int held_cap, float th, float th_far, const float* d_scale,
+                                          vieo_proj_query* d_queries, float* d_track_depth, size_t depth_stride,
+                                          int32_t* d_nq, void* stream);
+
 /* void MapPoint::ComputeDistinctiveDescriptors() (src/MapPoint.cc:314-378) for a batch of points: point p owns
  * the descriptor rows [h_first[p], h_first[p + 1]) of h_descriptors (its observations in map order); h_best[p]
  * receives the row (relative to h_first[p]) with the least median Hamming distance to the others, first such

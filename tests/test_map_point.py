@@ -331,3 +331,60 @@ def test_track_local_queries_device(oracle, rig):
         assert got[valid].tobytes() == ref.tobytes()
         assert np.array_equal(valid // S, owner)
         assert not got[(got["flags"] & 1) == 0].view(np.uint8).any()  # unused slots are zero
+
+
+@pytest.mark.gpu
+def test_track_local_queries_batch_equals_single_frame_calls():
+    """vieo_track_local_queries_batch_device (bench.py's batched step): every frame of the batch gets exactly what the
+    one-frame entry gives for its pose / candidates / held table, ragged candidate counts included."""
+    from vieo_slam_amd._lib import DeviceBuffer, check, lib
+    from vieo_slam_amd.ba_types import PROJ_QUERY_DTYPE, VIO_FRAME_DTYPE, VIO_RESULT_DTYPE
+    rng = np.random.default_rng(31)
+    F, cams, _, _ = _frame(rng, None)
+    B, pcap, hcap = 3, 2500, 400
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    fr, res = np.zeros(B, VIO_FRAME_DTYPE), np.zeros(B, VIO_RESULT_DTYPE)
+    counts = np.array([2500, 1700, 0], np.int32)
+    P = np.zeros((B, pcap), _points(rng, np.eye(3), np.zeros(3), 1).dtype)
+    desc = rng.integers(0, 256, (B, pcap, 32), dtype=np.uint8)
+    alias = np.where(rng.random((B, pcap)) < 0.3, rng.integers(0, hcap, (B, pcap)), -1).astype(np.int32)
+    held = (rng.random((B, hcap)) < 0.5).astype(np.uint8)
+    for b in range(B):
+        q = synth_ba.quat_from_rotvec(rng.normal(0, 0.4, 3))
+        p = rng.uniform(-1, 1, 3)
+        Rcb = synth_ba.quat_to_R(synth_ba.quat_from_rotvec(rng.normal(0, 0.2, 3)))
+        tcb = rng.uniform(-0.1, 0.1, 3)
+        Rcw = Rcb @ synth_ba.quat_to_R(q).T
+        fr[b]["base"]["Rcb"], fr[b]["base"]["tcb"] = Rcb.reshape(-1), tcb
+        res[b]["base"]["nav"]["q"], res[b]["base"]["nav"]["p"] = q, p
+        P[b] = _points(rng, Rcw, tcb - Rcw @ p, pcap)
+    D = DeviceBuffer
+    bufs = {}
+    for name, a in (("fr", fr), ("res", res), ("P", P), ("desc", desc), ("alias", alias), ("held", held), ("scale", scale),
+                    ("counts", counts)):
+        bufs[name] = D(a.nbytes)
+        bufs[name].upload(a)
+    d_q, d_dep, d_nq = D(64 * B * pcap), D(4 * B * pcap), D(4 * B)
+    check(lib().vieo_track_local_queries_batch_device(F.ctypes.data, bufs["fr"].ptr, bufs["res"].ptr, B, bufs["P"].ptr,
+                                                      bufs["desc"].ptr, bufs["alias"].ptr, bufs["counts"].ptr, pcap,
+                                                      bufs["held"].ptr, hcap, 2.0, 0.0, bufs["scale"].ptr, d_q.ptr, d_dep.ptr,
+                                                      pcap, d_nq.ptr, None))
+    check(lib().vieo_device_synchronize())
+    got_q = d_q.download(PROJ_QUERY_DTYPE, (B, pcap))
+    got_d = d_dep.download(np.float32, (B, pcap))
+    got_n = d_nq.download(np.int32, (B,))
+    assert got_n.tolist() == counts.tolist()
+    s_q, s_dep, s_nq = D(64 * pcap), D(4 * pcap), D(16)
+    for b in range(B):
+        n = int(counts[b])
+        if n == 0:
+            continue
+        check(lib().vieo_track_local_queries_device(F.ctypes.data, bufs["fr"].ptr + b * fr.itemsize,
+                                                    bufs["res"].ptr + b * res.itemsize, bufs["P"].ptr + b * pcap * P.itemsize,
+                                                    bufs["desc"].ptr + b * pcap * 32, bufs["alias"].ptr + 4 * b * pcap,
+                                                    bufs["held"].ptr + b * hcap, hcap, n, 2.0, 0.0, bufs["scale"].ptr,
+                                                    s_q.ptr, s_dep.ptr, s_nq.ptr, None))
+        check(lib().vieo_device_synchronize())
+        assert s_q.download(PROJ_QUERY_DTYPE, (pcap,))[:n].tobytes() == got_q[b, :n].tobytes()
+        assert np.array_equal(s_dep.download(np.float32, (pcap,))[:n], got_d[b, :n])
+        assert (got_q[b, :n]["flags"] & 1).sum() > 100

@@ -42,6 +42,10 @@ _SIGS = {
                                                       c_p, c_p, c_p]),
     "vieo_global_bundle_adjustment_vio_sharded_scale": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i,
                                                               c_p, ctypes.c_size_t, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "vieo_track_local_queries_batch_device": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_p,
+                                                    c_p, c_sz, c_p, c_p]),
+    "vieo_pose_optimization_vio_batch_device_ex": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "vieo_pose_optimization_batch_device_ex": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_p]),
     "vieo_get_device": (c_i, []),
     "vieo_version": (ctypes.c_char_p, []),
     "vieo_dev_malloc": (c_i, [P(c_p), c_sz]),

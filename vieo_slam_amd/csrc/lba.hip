@@ -126,6 +126,8 @@ struct LbaDev {
   int n_cams;
   const unsigned char* ocam;      // [n_obs] camera of every observation (n_cams > 0)
   double dMono, dStereo;
+  int solver;                     // which solve kernel owns the window in a mixed batch: 0 blocked LDS (<= 159 unknowns),
+                                  // 1 column panels (LDS up to ~186 unknowns), 2 tiled multi-workgroup LDL^T
   int scale_opt;                  // bScaleOpt: the VertexScale is the last column of the pose system
   double* scl;                    // [2] VertexScale estimate, its backup (push / pop)
   double* sc_sys;                 // [6 nf_cap + 2] H_ps per free key frame (Jp^T W Js), then H_ss, b_s
@@ -1116,6 +1118,7 @@ k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
   const int w = blockIdx.x;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
+  if (D.solver != 1) return;
   const int n = D.np, tid = threadIdx.x;
   if (n == 0) {
     if (tid == 0) out[w].ok = 1, out[w].scale_p = 0;
@@ -1308,6 +1311,7 @@ k_lba_ldlt16(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   const int w = blockIdx.x;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
+  if (D.solver != 0) return;
   const int n = D.np, tid = threadIdx.x, lane = tid & 63;
   // wave-uniform for the compiler: the MFMA blocks of the other wavefronts must be branched over, not masked
   // (v_mfma ignores EXEC and would run its passes anyway)
@@ -1481,6 +1485,7 @@ k_big_init(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
+  if (D.solver != 2) return;
   const int n = D.np, nb = D.nb;
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e == 0) *D.big_fail = 0;
@@ -1502,6 +1507,7 @@ k_big_panel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
+  if (D.solver != 2) return;
   const int n = D.np, nb = D.nb, tid = threadIdx.x;
   const int r0 = (k + 1) * kNB + blockIdx.x * 256 - 256;  // block 0: the diagonal tile itself, then 256 rows each
   if (n == 0 || k * kNB >= nb || (blockIdx.x > 0 && r0 >= nb)) return;
@@ -1582,6 +1588,7 @@ k_big_syrk(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int 
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
+  if (D.solver != 2) return;
   const int nb = D.nb, nt = nb / kNB, m = nt - k - 1;
   if (D.np == 0 || m <= 0) return;
   int t = blockIdx.x, ti = 0;  // tile (k + 1 + ti, k + 1 + tj), tj <= ti, row-major over the lower triangle
@@ -1639,6 +1646,7 @@ k_big_back_step(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl,
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
+  if (D.solver != 2) return;
   const int n = D.np, nb = D.nb, tid = threadIdx.x;
   if (n == 0) return;
   const int kb = (n - 1) / kNB - s;
@@ -1694,6 +1702,7 @@ k_big_finish(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
   const int w = blockIdx.x;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
+  if (D.solver != 2) return;
   const int n = D.np, tid = threadIdx.x;
   if (n == 0) {
     if (tid == 0) out[w].ok = 1, out[w].scale_p = 0;
@@ -1953,6 +1962,25 @@ static bool big_solve(int n) {
     return e ? atoi(e) : 0;
   }();
   return forced > 0 || n > kSmallSolveMax;
+}
+
+// The solve kernel of a window with n unknowns (sco: with the scale vertex, whose odd size the column-panel kernel
+// cannot take).  Windows of different classes share a lock-step batch: every class's kernel is launched and skips the
+// others' windows (a bLarge window of 25 key frames next to ordinary ones of 10 is the usual LocalMapping mix).
+//   0  k_lba_ldlt16   n <= 159: blocked on the matrix cores, whole triangle in LDS
+//   1  k_lba_ldlt     n <= kPanelLdsMax: column panels, packed triangle in LDS (VIEO_LBA_PANEL_MAX raises the limit;
+//                     beyond the LDS size it factorises in L2, one workgroup crawling: 2.4 ms at 375 unknowns)
+//   2  k_big_*        the tiled LDL^T over many workgroups
+static const int kPanelLdsMax = 186;
+static int solver_class(int n, int sco) {
+  static const int panel_max = [] {
+    const char* e = getenv("VIEO_LBA_PANEL_MAX");
+    return e ? atoi(e) : kPanelLdsMax;
+  }();
+  if (big_solve(n)) return 2;
+  if (((n + 16) >> 4) <= kLd16MaxBlocks && (sco || !ldlt16_disabled())) return 0;
+  if (sco) return 2;
+  return n <= panel_max ? 1 : 2;
 }
 
 // Optimizer::BundleAdjustment / GlobalBundleAdjustmentNavStatePRV (Optimizer.cc:1353-1609, 771-1345) on the same
@@ -2232,7 +2260,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     s.Hpp = take((size_t)std::max(nf, 1) * 36 * 8), s.Hs = take((size_t)npf * npf * 8);
     s.nb = (npf + 1 + kNB - 1) / kNB * kNB;  // + the right-hand-side row
     s.Hb = s.Wp = s.big_fail = 0;
-    if (big_solve(npf) || (sco && ((npf + 16) >> 4) > kLd16MaxBlocks)) {
+    if (solver_class(npf, sco) == 2) {
       s.Hb = take((size_t)s.nb * s.nb * 8), s.Wp = take((size_t)s.nb * kNB * 8), s.big_fail = take(256);
     }
     s.bp = take((size_t)npm * 8), s.bs = take((size_t)npf * 8), s.xp = take((size_t)npf * 8);
@@ -2270,6 +2298,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.dMono = (double)(float)sqrt(gba ? 5.99 : 5.991), D.dStereo = (double)(float)sqrt(7.815);
     D.pd = pd, D.n_imu = H.n_imu;
     D.scale_opt = sco;
+    D.solver = solver_class(npf, sco);
     if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
       D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
       memcpy(D.gw, H.VP->gw, 24);
@@ -2491,17 +2520,19 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   VIEO_HIP_CHECK(hipMemsetAsync(dO, 0, (size_t)W * sizeof(WinOut), st));
   const int n_max = pd * max_nf + sco;
   const int occ_max = ((6 * max_nf + sco + 64) / 64) * ((max_mp + kChunkLm - 1) / kChunkLm);
-  // the column-panel kernel needs a system size divisible by its panel width: with the scale vertex the blocked
-  // kernel (any size up to 159) or the tiled solve take the system
-  const bool big = big_solve(n_max) || (sco && ((n_max + 16) >> 4) > kLd16MaxBlocks);
-  const size_t ldlt_small = big ? 0 : (size_t)8 * n_max * 8;  // panel columns, rhs, pivots
-  const size_t tri = big ? 0 : (size_t)n_max * (n_max + 1) / 2 * 8;  // packed lower triangle
+  // per solver class: the largest system of the class in this batch (0: the class is empty)
+  int cls_max[3] = {0, 0, 0};
+  for (int w = 0; w < W; w++)
+    if (!win[w].skip) cls_max[devs[w].solver] = std::max(cls_max[devs[w].solver], pd * devs[w].nf_cap + sco);
+  const bool big = cls_max[2] > 0, ldlt16 = cls_max[0] > 0, panels = cls_max[1] > 0;
+  const int n_max_p = cls_max[1], n_max_b = cls_max[2];
+  const size_t ldlt_small = (size_t)8 * n_max_p * 8;  // panel columns, rhs, pivots
+  const size_t tri = (size_t)n_max_p * (n_max_p + 1) / 2 * 8;  // packed lower triangle
   const int use_lds = tri + ldlt_small <= 150 * 1024;
   const size_t ldlt_lds = ldlt_small + (use_lds ? tri : 0);
   const void* ldlt_fn = vio ? (const void*)k_lba_ldlt<5> : (const void*)k_lba_ldlt<6>;
-  VIEO_HIP_CHECK(hipFuncSetAttribute(ldlt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
-  const int nb16 = (n_max + 16) >> 4;
-  const bool ldlt16 = !big && nb16 <= kLd16MaxBlocks && (sco || !ldlt16_disabled());
+  if (panels) VIEO_HIP_CHECK(hipFuncSetAttribute(ldlt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
+  const int nb16 = (cls_max[0] + 16) >> 4;
   if (ldlt16)
     VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldlt16<kLd16Threads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)ld16_lds_bytes(nb16)));
@@ -2602,22 +2633,23 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO,
                          ksplit); });
       if (big) {
-        const int nbm = (n_max + 1 + kNB - 1) / kNB * kNB, ntm = nbm / kNB;
+        const int nbm = (n_max_b + 1 + kNB - 1) / kNB * kNB, ntm = nbm / kNB;
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_init, dim3((unsigned)(((size_t)nbm * nbm + 255) / 256), W), dim3(256), 0, st, dD, dC); });
         for (int k = 0; k < ntm; k++) {
           const int below = nbm - (k + 1) * kNB, m = ntm - k - 1;
           KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_panel, dim3(1 + (below + 255) / 256, W), dim3(256), 0, st, dD, dC, k); });
           if (m > 0) KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_syrk, dim3(m * (m + 1) / 2, W), dim3(256), 0, st, dD, dC, k); });
         }
-        for (int sb = 0; sb < (n_max + kNB - 1) / kNB; sb++)
-          KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_back_step, dim3(1 + (n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, sb); });
+        for (int sb = 0; sb < (n_max_b + kNB - 1) / kNB; sb++)
+          KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_back_step, dim3(1 + (n_max_b + 255) / 256, W), dim3(256), 0, st, dD, dC, sb); });
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_finish, dim3(W), dim3(256), 0, st, dD, dC, dO); });
-      } else if (ldlt16)
+      }
+      if (ldlt16)
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt16<kLd16Threads>, dim3(W), dim3(kLd16Threads), ld16_lds_bytes(nb16), st, dD, dC, dO, nb16); });
-      else if (vio)
-        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt<5>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max); });
-      else
-        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt<6>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max); });
+      if (panels && vio)
+        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt<5>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max_p); });
+      else if (panels)
+        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt<6>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max_p); });
       KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO); });
       KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1); });
       if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1); });

@@ -96,13 +96,25 @@ k_in_frustum(const FrustumDev* __restrict__ fd, const vieo_frustum_point* __rest
 // (slots of cameras that do not see the point carry flags = 0).  A candidate that aliases an entry of the frame's
 // point table which a key already holds (mbTrackInView = false for points matched in the frame, Tracking.cc:2318-
 // 2334) gets no query.  One lane per point.
+// Batched form: grid y = frame; frame f reads frames[f] / results[f], candidates [f][p_cap], its own count counts[f]
+// (null: n for every frame), writes queries [f][p_cap * n_cams], depths at track_depth + f * depth_stride, nq[f].
 __global__ void __launch_bounds__(256)
 k_track_local_queries(FrustumDev tmpl, const vieo_vio_frame* __restrict__ frame, const vieo_vio_result* __restrict__ result,
                       const vieo_frustum_point* __restrict__ pts, const uint8_t* __restrict__ desc,
                       const int32_t* __restrict__ alias, const uint8_t* __restrict__ held, int held_cap, int n, float th, float th_far,
                       const float* __restrict__ scale, vieo_proj_query* __restrict__ queries,
-                      float* __restrict__ track_depth, int32_t* __restrict__ nq) {
+                      float* __restrict__ track_depth, int32_t* __restrict__ nq, int p_cap, const int32_t* __restrict__ counts,
+                      size_t depth_stride) {
   __shared__ vieo_frustum_frame sF;
+  {
+    const size_t f = blockIdx.y;
+    frame += f, result += f, nq += f;
+    pts += f * p_cap, desc += f * p_cap * 32;
+    if (alias) alias += f * p_cap, held += f * held_cap;
+    queries += f * p_cap * tmpl.F.n_cams, track_depth += f * depth_stride;
+    if (counts) n = min(counts[f], p_cap);
+    if (blockIdx.x * 256 >= (unsigned)max(n, 1)) return;
+  }
   if (threadIdx.x == 0) {
     sF = tmpl.F;
     const vieo_navstate& nav = result->base.status == 0 ? result->base.nav : frame->base.nav;
@@ -342,7 +354,38 @@ int vieo_track_local_queries_device(const vieo_frustum_frame* h_frame, const vie
     }
   hipLaunchKernelGGL(k_track_local_queries, dim3(std::max(1, (n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fd,
                      d_frame, d_result, d_points, d_desc, d_alias, d_held, held_cap, n_points, th, th_far, d_scale, d_queries,
-                     d_track_depth, d_nq);
+                     d_track_depth, d_nq, n_points, (const int32_t*)nullptr, (size_t)0);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_local_queries_batch_device(const vieo_frustum_frame* h_frame, const vieo_vio_frame* d_frames,
+                                          const vieo_vio_result* d_results, int n_frames, const vieo_frustum_point* d_points,
+                                          const uint8_t* d_desc, const int32_t* d_alias, const int32_t* d_counts, int p_cap,
+                                          const uint8_t* d_held, int held_cap, float th, float th_far, const float* d_scale,
+                                          vieo_proj_query* d_queries, float* d_track_depth, size_t depth_stride,
+                                          int32_t* d_nq, void* stream) {
+  if (!h_frame || !d_frames || !d_results || n_frames <= 0 || p_cap <= 0 || !d_counts || !d_scale || !d_nq || !d_points ||
+      !d_desc || !d_queries || !d_track_depth || (d_alias && (!d_held || held_cap <= 0)))
+    return VIEO_E_INVALID;
+  if (h_frame->n_cams < 1 || h_frame->n_cams > 4 || !h_frame->cams || h_frame->n_levels <= 0) {
+    set_error("SearchLocalPoints: n_cams = %d (1..4) with cameras and n_levels > 0", h_frame->n_cams);
+    return VIEO_E_INVALID;
+  }
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  FrustumDev fd;
+  memset(&fd, 0, sizeof(fd));
+  fd.F = *h_frame;
+  fd.F.cams = nullptr;
+  for (int c = 0; c < h_frame->n_cams; ++c)
+    if (!cam_from_abi(h_frame->cams[c], fd.cams[c])) {
+      set_error("SearchLocalPoints: camera %d has an unknown model or coefficient count", c);
+      return VIEO_E_INVALID;
+    }
+  hipLaunchKernelGGL(k_track_local_queries, dim3((p_cap + 255) / 256, n_frames), dim3(256), 0, (hipStream_t)stream, fd, d_frames,
+                     d_results, d_points, d_desc, d_alias, d_held, held_cap, 0, th, th_far, d_scale, d_queries, d_track_depth,
+                     d_nq, p_cap, d_counts, depth_stride);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }

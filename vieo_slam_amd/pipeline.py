@@ -7,7 +7,14 @@ frames, in the reference's call order (SURVEY.md 3.1, Tracking::TrackWithIMU + T
 All stages are the C-ABI batch entry points chained on the extractor's HIP stream; nothing returns
 to the host between them.  Inputs that the hot path does not produce itself (last frame's map
 points, local-map queries from Frame::isInFrustum, IMU pre-integration, predicted state) are
-prepared once on the host and stay resident in HBM."""
+prepared once on the host and stay resident in HBM.
+
+Two workloads.  "r2" (rounds 1-2): 8 views of one textured plane, the second search's queries precomputed on the host
+from the last frame's own points.  "r3" (SURVEY.md 8d as written): 64 distinct cases over 8 textures with non-planar
+depth (floating sheets) and low-contrast patches (cells that need minThFAST), and the head of SearchLocalPoints INSIDE
+the step: Frame::isInFrustum + query construction for 4-5 k local-map candidates per frame on the device from the first
+optimisation's pose in HBM (vieo_track_local_queries_batch_device), the frame's own matches dropped through the held
+table -- the stage Tracking.cc:2308-2370 runs between the two optimisations."""
 import ctypes
 
 import numpy as np
@@ -25,15 +32,29 @@ BOUNDS = np.array([0, W, 0, H], np.float32)
 NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH = 1200, 1.2, 8, 20, 7  # EuRoC_VIO.yaml:138-151
 
 
-def make_cases(n_base, seed0=1, verbose=False):
-    scene = sc.Scene(seed0)
-    return [sc.make_tracking_case(seed0 + i, scene=scene) for i in range(n_base)]
+def make_cases(n_base, seed0=1, verbose=False, workload="r2"):
+    if workload == "r2":
+        scene = sc.Scene(seed0)
+        return [sc.make_tracking_case(seed0 + i, scene=scene) for i in range(n_base)]
+    # r3: 8 textures with dull patches x as many sheet layouts as needed; every case its own layout and pose
+    n_tex = min(8, n_base)
+    texs = [sc.Scene(seed0 + 100 * t, relief=(seed0 + 100 * t, 12), low_contrast=True) for t in range(n_tex)]
+    cases = []
+    for i in range(n_base):
+        scene = texs[i % n_tex] if i < n_tex else texs[i % n_tex].with_relief((seed0 + 7 * i, 12))
+        c = sc.make_tracking_case(seed0 + i, scene=scene)
+        c["scene"] = scene
+        cases.append(c)
+    return cases
+
+N_EXTRA = 3072  # synthetic local-map candidates per frame on top of the last frame's own points (r3)
 
 
 class FramePipeline:
     STAGES = ("extract", "stereo", "sbp_last", "pose1", "sbp_local", "pose2", "total")
 
-    def __init__(self, cases, batch, seed=0, noise=True):
+    def __init__(self, cases, batch, seed=0, noise=True, workload="r2"):
+        self.workload = workload
         self.B = B = batch
         self.ext = ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
         self.stream = lib().vieo_orb_stream(self.ext._h)
@@ -100,6 +121,8 @@ class FramePipeline:
             q["flags"] = inimg.astype(np.int32) * 3
             q["desc"] = d0
             self.truth.append(case["truth"])
+        if workload == "r3":
+            self._local_candidates(cases, pts, npts, xyz_last=xyz, rng=rng)
         f2 = f1.copy()
         f2["compute_marg"] = 1
         self.imgs_host = imgs
@@ -111,10 +134,15 @@ class FramePipeline:
         self.d_ur, self.d_dp = D(B * cap * 4), D(B * cap * 4)
         self.d_pts, self.d_npts, self.d_cams = D(pts.nbytes), D(npts.nbytes), D(cams.nbytes)
         self.d_pts.upload(pts), self.d_npts.upload(npts), self.d_cams.upload(cams)
-        self.d_q1, self.d_q2 = D(B * cap * 64), D(q2.nbytes)
-        self.d_q2.upload(q2)
+        if workload == "r3":
+            self.d_q1, self.d_q2 = D(B * cap * 64), D(B * self.ccap * 64)
+        else:
+            self.d_q1, self.d_q2 = D(B * cap * 64), D(q2.nbytes)
+            self.d_q2.upload(q2)
         self.d_assign, self.d_nm = D(B * cap * 4), D(B * 4)
         self.d_mpref, self.d_taken = D(B * cap * 4), D(B * cap)
+        if workload == "r3":
+            xyz = self.xyz3
         self.d_xyz, self.d_isig = D(xyz.nbytes), D(self.inv_sigma2.nbytes)
         self.d_xyz.upload(xyz), self.d_isig.upload(self.inv_sigma2)
         self.d_obs, self.d_obskey, self.d_outl = D(B * cap * 32), D(B * cap * 4), D(B * cap)
@@ -124,6 +152,66 @@ class FramePipeline:
         self.bounds = (ctypes.c_float * 4)(*BOUNDS.tolist())
         self.f1_host, self.pts_host, self.q2_host = f1, pts, q2
         check(lib().vieo_device_synchronize())
+
+    # ---- r3: the local-map candidates of every frame (what UpdateLocalMap hands to SearchLocalPoints)
+    def _local_candidates(self, cases, pts, npts, xyz_last, rng):
+        from .ba_types import CAMERA_DTYPE
+        from .map_point import FRUSTUM_FRAME_DTYPE, FRUSTUM_POINT_DTYPE
+        B, cap = self.B, self.cap
+        self.ccap = ccap = cap + N_EXTRA
+        self.pcap = cap + ccap
+        scf = self.ext.GetScaleFactors()
+        cpt = np.zeros((B, ccap), FRUSTUM_POINT_DTYPE)
+        cdesc = np.zeros((B, ccap, 32), np.uint8)
+        alias = np.full((B, ccap), -1, np.int32)
+        ncand = np.zeros(B, np.int32)
+        self.xyz3 = np.zeros((B, self.pcap, 3), np.float32)
+        for b in range(B):
+            case = cases[b % len(cases)]
+            n0 = int(npts[b])
+            Xw = pts[b, :n0]["Xw"].astype(np.float64)
+            valid = (pts[b, :n0]["flags"] & 1) > 0
+            Ow0 = case["pose0"][3]
+            d = Xw - Ow0
+            dist = np.linalg.norm(d, axis=1)
+            dist = np.where(valid, dist, 1.0)
+            c = cpt[b, :n0]
+            c["Xw"], c["normal"] = Xw, (d / dist[:, None])
+            maxd = (dist * scf[pts[b, :n0]["octave"]]).astype(np.float32)
+            c["max_distance"] = np.where(valid, maxd, 0)  # a key without a point: outside every distance range
+            c["min_distance"] = np.where(valid, maxd / scf[NLEVELS - 1], 0)
+            cdesc[b, :n0] = pts[b, :n0]["desc"]
+            alias[b, :n0] = np.arange(n0)
+            # points of the local key frames the frame does not hold: true surface points (they project where the
+            # scene is) seen from about here, with descriptors of their own
+            Xe = case["scene"].surface_points(rng, N_EXTRA)
+            Ow1 = case["pose1"][3]
+            de = Xe - Ow1
+            diste = np.linalg.norm(de, axis=1)
+            e = cpt[b, n0:n0 + N_EXTRA]
+            e["Xw"], e["normal"] = Xe, de / diste[:, None]
+            md = (diste * scf[rng.integers(0, NLEVELS, N_EXTRA)]).astype(np.float32)
+            e["max_distance"], e["min_distance"] = md, md / scf[NLEVELS - 1]
+            cdesc[b, n0:n0 + N_EXTRA] = rng.integers(0, 256, (N_EXTRA, 32), dtype=np.uint8)
+            ncand[b] = n0 + N_EXTRA
+            self.xyz3[b, :n0] = xyz_last[b, :n0]
+            self.xyz3[b, cap:cap + n0 + N_EXTRA] = cpt[b, :n0 + N_EXTRA]["Xw"]
+        D = DeviceBuffer
+        self.d_cpt, self.d_cdesc, self.d_alias, self.d_ncand = D(cpt.nbytes), D(cdesc.nbytes), D(alias.nbytes), D(ncand.nbytes)
+        self.d_cpt.upload(cpt), self.d_cdesc.upload(cdesc), self.d_alias.upload(alias), self.d_ncand.upload(ncand)
+        self.d_held, self.d_cdep, self.d_nq = D(B * self.pcap), D(B * ccap * 4), D(B * 4)
+        self.d_scale = D(scf.nbytes)
+        self.d_scale.upload(np.ascontiguousarray(scf, np.float32))
+        self._cam = np.zeros(1, CAMERA_DTYPE)
+        self._cam[0]["fx"], self._cam[0]["fy"], self._cam[0]["cx"], self._cam[0]["cy"] = sc.FX, sc.FY, sc.CX, sc.CY
+        self.ff = np.zeros(1, FRUSTUM_FRAME_DTYPE)
+        ff = self.ff[0]
+        ff["n_cams"], ff["use_distort"], ff["cams"] = 1, 0, self._cam.ctypes.data
+        ff["Tcr"][0] = np.eye(4)[:3].reshape(-1)
+        ff["bounds"][0] = BOUNDS
+        ff["bf"], ff["n_levels"], ff["viewing_cos_limit"] = sc.BF, NLEVELS, 0.5
+        ff["log_scale_factor"] = np.float32(np.log(np.float32(SCALE)))
+        self.ncand_host = ncand
 
     # ---- HIP-event stamps between stage groups (ring of 64 steps), on the pipeline's stream
     def enable_timing(self, on=True):
@@ -160,16 +248,10 @@ class FramePipeline:
         return out
 
     def step(self):
-        L, B, cap, st = lib(), self.B, self.cap, self.stream
-        # every frame here is a rectified stereo frame without encoder (Frame::usedistort_ false): skip the camera-rig
-        # and encoder kernel instances for the launches of this step only (the modes are process-wide)
-        check(L.vieo_pose_set_camera_mode(1))
-        check(L.vieo_pose_set_encoder_mode(1))
-        try:
-            self._step()
-        finally:
-            check(L.vieo_pose_set_camera_mode(0))
-            check(L.vieo_pose_set_encoder_mode(0))
+        # every frame here is a rectified stereo frame without encoder (Frame::usedistort_ false): the camera-rig and
+        # encoder kernel instances are skipped by the per-call modes of the _ex entries (VIEO_POSE_CAMS_RECTIFIED = 1,
+        # VIEO_POSE_ENC_NONE = 1)
+        self._step()
 
     def _step(self):
         L, B, cap, st = lib(), self.B, self.cap, self.stream
@@ -190,17 +272,29 @@ class FramePipeline:
         self._stamp(3)
         check(L.vieo_track_merge_assign_batch_device(self.d_assign.ptr, self.d_mpref.ptr, self.d_cnt.ptr,
                                                      cap, B, 0, 2, 0, 1, st))
-        check(L.vieo_track_build_obs_batch_device(self.d_mpref.ptr, self.d_xyz.ptr, 2 * cap, self.d_kp.ptr,
+        check(L.vieo_track_build_obs_batch_device(self.d_mpref.ptr, self.d_xyz.ptr,
+                                                  self.pcap if self.workload == "r3" else 2 * cap, self.d_kp.ptr,
                                                   self.d_ur.ptr, self.d_cnt.ptr, cap, B, 0, 2,
                                                   self.d_isig.ptr, self.d_obs.ptr, self.d_obskey.ptr,
                                                   self.d_f1.ptr, 1, st))
-        check(L.vieo_pose_optimization_vio_batch_device(self.d_f1.ptr, B, self.d_obs.ptr, self.d_outl.ptr,
-                                                        self.d_r1.ptr, st), "pose1")
+        check(L.vieo_pose_optimization_vio_batch_device_ex(self.d_f1.ptr, B, self.d_obs.ptr, self.d_outl.ptr,
+                                                           self.d_r1.ptr, 1, 1, st), "pose1")
         self._stamp(4)
         check(L.vieo_track_after_pose_batch_device(self.d_mpref.ptr, self.d_obskey.ptr, self.d_outl.ptr,
                                                    self.d_f1.ptr, self.d_r1.ptr, 1, cap, B, self.d_f2.ptr,
                                                    self.d_taken.ptr, st))
-        check(L.vieo_search_by_projection_batch_device(1, self.d_q2.ptr, self.d_npts.ptr, cap, B,
+        if self.workload == "r3":  # SearchLocalPoints' head on the device: held points, isInFrustum, window queries
+            check(L.vieo_track_mark_held_batch_device(self.d_mpref.ptr, self.d_cnt.ptr, cap, B, 0, 2, self.d_held.ptr,
+                                                      self.pcap, st))
+            check(L.vieo_track_local_queries_batch_device(self.ff.ctypes.data, self.d_f1.ptr, self.d_r1.ptr, B, self.d_cpt.ptr,
+                                                          self.d_cdesc.ptr, self.d_alias.ptr, self.d_ncand.ptr, self.ccap,
+                                                          self.d_held.ptr, self.pcap, 2.0, 0.0, self.d_scale.ptr,
+                                                          self.d_q2.ptr, self.d_cdep.ptr, self.ccap, self.d_nq.ptr, st),
+                  "local queries")
+            nq, qcap, ptab = self.d_nq.ptr, self.ccap, self.pcap
+        else:
+            nq, qcap, ptab = self.d_npts.ptr, cap, 2 * cap
+        check(L.vieo_search_by_projection_batch_device(1, self.d_q2.ptr, nq, qcap, B,
                                                        self.d_kp.ptr, self.d_ur.ptr, self.d_desc.ptr,
                                                        self.d_taken.ptr, self.d_cnt.ptr, cap, 0, 2,
                                                        self.bounds, 0.8, 1, self.d_assign.ptr,
@@ -208,12 +302,12 @@ class FramePipeline:
         self._stamp(5)
         check(L.vieo_track_merge_assign_batch_device(self.d_assign.ptr, self.d_mpref.ptr, self.d_cnt.ptr,
                                                      cap, B, 0, 2, cap, 0, st))
-        check(L.vieo_track_build_obs_batch_device(self.d_mpref.ptr, self.d_xyz.ptr, 2 * cap, self.d_kp.ptr,
+        check(L.vieo_track_build_obs_batch_device(self.d_mpref.ptr, self.d_xyz.ptr, ptab, self.d_kp.ptr,
                                                   self.d_ur.ptr, self.d_cnt.ptr, cap, B, 0, 2,
                                                   self.d_isig.ptr, self.d_obs.ptr, self.d_obskey.ptr,
                                                   self.d_f2.ptr, 1, st))
-        check(L.vieo_pose_optimization_vio_batch_device(self.d_f2.ptr, B, self.d_obs.ptr, self.d_outl.ptr,
-                                                        self.d_r2.ptr, st), "pose2")
+        check(L.vieo_pose_optimization_vio_batch_device_ex(self.d_f2.ptr, B, self.d_obs.ptr, self.d_outl.ptr,
+                                                           self.d_r2.ptr, 1, 1, st), "pose2")
         self._stamp(6)
         if getattr(self, "_ev", None):
             self._ev_steps += 1

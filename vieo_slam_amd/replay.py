@@ -721,9 +721,7 @@ class ChainedReplay(Replay):
         # ---- one copy up, the chain, one copy back
         t1 = time.perf_counter()
         check(L.vieo_memcpy_h2d_async(self.ain.d_ptr, self.ain.h_ptr, self.ain.off, st))
-        check(L.vieo_pose_set_camera_mode(1))
-        check(L.vieo_pose_set_encoder_mode(1))
-        try:
+        try:  # (rectified stereo frames without encoder: the per-call modes 1, 1 of the _ex entries)
             self.ext.extract_batch_device(self.d_img, 2, W, H, W, W * H, self.d_kp, self.d_desc, cap, self.d_cnt)
             check(L.vieo_stereo_match_rectified_batch_device(self.ext._h, 1, self.d_kp, self.d_desc, self.d_cnt, cap,
                                                              sc.BASELINE, sc.BF, self.d_ur, self.d_dp), "stereo")
@@ -736,7 +734,7 @@ class ChainedReplay(Replay):
             check(L.vieo_track_build_obs_depth_batch_device(self.d_mpref, self.d_xyz, self.d_dep, close, self.pcap, self.d_kp,
                                                             self.d_ur, self.d_cnt, cap, 1, 0, 2, self.d_isig, self.d_obs.ptr,
                                                             self.d_obskey, self.d_f1, 1, st))
-            check(L.vieo_pose_optimization_vio_batch_device(self.d_f1, 1, self.d_obs.ptr, self.d_outl, self.d_r1, st), "pose1")
+            check(L.vieo_pose_optimization_vio_batch_device_ex(self.d_f1, 1, self.d_obs.ptr, self.d_outl, self.d_r1, 1, 1, st), "pose1")
             check(L.vieo_track_after_pose_batch_device(self.d_mpref, self.d_obskey, self.d_outl, self.d_f1, self.d_r1, 1, cap,
                                                        1, self.d_f2, self.d_taken.ptr, st))
             check(L.vieo_track_mark_held_batch_device(self.d_mpref, self.d_cnt, cap, 1, 0, 2, self.d_held.ptr, self.pcap, st))
@@ -750,10 +748,9 @@ class ChainedReplay(Replay):
             check(L.vieo_track_build_obs_depth_batch_device(self.d_mpref, self.d_xyz, self.d_dep, close, self.pcap, self.d_kp,
                                                             self.d_ur, self.d_cnt, cap, 1, 0, 2, self.d_isig, self.d_obs.ptr,
                                                             self.d_obskey, self.d_f2, 1, st))
-            check(L.vieo_pose_optimization_vio_batch_device(self.d_f2, 1, self.d_obs.ptr, self.d_outl, self.d_r2, st), "pose2")
+            check(L.vieo_pose_optimization_vio_batch_device_ex(self.d_f2, 1, self.d_obs.ptr, self.d_outl, self.d_r2, 1, 1, st), "pose2")
         finally:
-            check(L.vieo_pose_set_camera_mode(0))
-            check(L.vieo_pose_set_encoder_mode(0))
+            pass
         check(L.vieo_memcpy_d2h_async(self.aout.h_ptr, self.aout.d_ptr, self.aout.off, st))
         check(L.vieo_memcpy_d2h_async(self.o_f2.ctypes.data, self.d_f2, VIO_FRAME_DTYPE.itemsize, st))
         check(L.vieo_memcpy_d2h_async(self.o_cdep.ctypes.data, self.d_dep + 4 * cap, 4 * max(nc, 1), st))

@@ -16,12 +16,54 @@ TEX_W, TEX_H = 2304, 1728
 
 
 class Scene:
-    """Plane z = 0 of the world, textured; cameras look at it from above."""
+    """Plane z = 0 of the world, textured; cameras look at it from above.
+    relief = (layout seed, n): n thin textured sheets (0.7 - 1.6 m squares) float 0.25 - 1.4 m above the plane around
+    the origin, so that depth is not planar and views occlude differently (a floating sheet is a consistent 3-D scene
+    for every viewpoint); low_contrast: the texture's contrast falls to 15 - 45 % in smooth patches -- corners there
+    have FAST strengths between minThFAST and iniThFAST, the cells that need the second threshold (ORBextractor.cc:
+    752-762)."""
 
-    def __init__(self, seed):
-        self.tex = synth.synth_image_f32(seed, TEX_W, TEX_H, n_shapes=2600)
+    def __init__(self, seed, relief=None, low_contrast=False, tex=None):
+        self.tex = synth.synth_image_f32(seed, TEX_W, TEX_H, n_shapes=2600) if tex is None else tex
+        if low_contrast:
+            rng = np.random.default_rng(seed + 4242)
+            g = rng.uniform(0, 1, (TEX_H // 192 + 2, TEX_W // 192 + 2))
+            c = np.where(g < 0.3, rng.uniform(0.15, 0.45, g.shape), 1.0)  # 30 % of the 1.5 m patches are dull
+            yy, xx = np.mgrid[0:TEX_H, 0:TEX_W]
+            fy, fx = yy / 192.0, xx / 192.0
+            y0, x0 = fy.astype(int), fx.astype(int)
+            wy, wx = (fy - y0).astype(np.float32), (fx - x0).astype(np.float32)
+            cm = (c[y0, x0] * (1 - wx) * (1 - wy) + c[y0, x0 + 1] * wx * (1 - wy) + c[y0 + 1, x0] * (1 - wx) * wy +
+                  c[y0 + 1, x0 + 1] * wx * wy).astype(np.float32)
+            m = np.float32(self.tex.mean())
+            self.tex = (m + cm * (self.tex - m)).astype(np.float32)
         self.Tcb = np.linalg.inv(synth_ba.EUROC_TBC)
         self.Tbc = synth_ba.EUROC_TBC
+        self.sheets = []
+        if relief:
+            rng = np.random.default_rng(1000 + relief[0])
+            for _ in range(relief[1]):
+                half = rng.uniform(0.35, 0.8, 2)
+                self.sheets.append(dict(c=rng.uniform(-2.6, 2.6, 2), half=half, z=rng.uniform(0.25, 1.4),
+                                        toff=rng.uniform(-600, 600, 2)))
+
+    def with_relief(self, relief):
+        """the same texture with another sheet layout (the texture is the expensive part)"""
+        s = Scene.__new__(Scene)
+        s.tex, s.Tcb, s.Tbc, s.sheets = self.tex, self.Tcb, self.Tbc, []
+        s.__init__(0, relief=relief, tex=self.tex)
+        return s
+
+    def _sample(self, P, off=(0.0, 0.0)):
+        tx = P[..., 0] / TEXEL + TEX_W / 2 + off[0]
+        ty = P[..., 1] / TEXEL + TEX_H / 2 + off[1]
+        x0 = np.clip(np.floor(tx).astype(np.int64), 0, TEX_W - 2)
+        y0 = np.clip(np.floor(ty).astype(np.int64), 0, TEX_H - 2)
+        fx = np.clip(tx - x0, 0, 1).astype(np.float32)
+        fy = np.clip(ty - y0, 0, 1).astype(np.float32)
+        T = self.tex
+        return (T[y0, x0] * (1 - fx) * (1 - fy) + T[y0, x0 + 1] * fx * (1 - fy) +
+                T[y0 + 1, x0] * (1 - fx) * fy + T[y0 + 1, x0 + 1] * fx * fy)
 
     def render(self, Rwc, twc, noise_seed):
         """uint8 image of the pinhole camera at (Rwc, twc), plus per-pixel camera depth."""
@@ -29,17 +71,39 @@ class Scene:
         d_c = np.stack([(u - CX) / FX, (v - CY) / FY, np.ones_like(u)], -1)
         d_w = d_c @ Rwc.T
         lam = -twc[2] / d_w[..., 2]  # plane z = 0
-        P = twc + lam[..., None] * d_w
-        tx = P[..., 0] / TEXEL + TEX_W / 2
-        ty = P[..., 1] / TEXEL + TEX_H / 2
-        x0 = np.clip(np.floor(tx).astype(np.int64), 0, TEX_W - 2)
-        y0 = np.clip(np.floor(ty).astype(np.int64), 0, TEX_H - 2)
-        fx = np.clip(tx - x0, 0, 1).astype(np.float32)
-        fy = np.clip(ty - y0, 0, 1).astype(np.float32)
-        T = self.tex
-        img = (T[y0, x0] * (1 - fx) * (1 - fy) + T[y0, x0 + 1] * fx * (1 - fy) +
-               T[y0 + 1, x0] * (1 - fx) * fy + T[y0 + 1, x0 + 1] * fx * fy)
+        img = self._sample(twc + lam[..., None] * d_w)
+        Rcw = Rwc.T
+        for sh in self.sheets:  # nearest surface along the ray: only inside the sheet's projected bounding box
+            cx, cy, hx, hy, z = sh["c"][0], sh["c"][1], sh["half"][0], sh["half"][1], sh["z"]
+            cor = np.array([[cx - hx, cy - hy, z], [cx + hx, cy - hy, z], [cx + hx, cy + hy, z], [cx - hx, cy + hy, z]])
+            pc = (cor - twc) @ Rcw.T
+            if np.any(pc[:, 2] < 0.2):
+                continue
+            uu, vv = FX * pc[:, 0] / pc[:, 2] + CX, FY * pc[:, 1] / pc[:, 2] + CY
+            u0, u1 = int(max(0, np.floor(uu.min()))), int(min(W, np.ceil(uu.max()) + 1))
+            v0, v1 = int(max(0, np.floor(vv.min()))), int(min(H, np.ceil(vv.max()) + 1))
+            if u0 >= u1 or v0 >= v1:
+                continue
+            dw = d_w[v0:v1, u0:u1]
+            l2 = (z - twc[2]) / dw[..., 2]
+            P2 = twc + l2[..., None] * dw
+            hit = (np.abs(P2[..., 0] - cx) <= hx) & (np.abs(P2[..., 1] - cy) <= hy) & (l2 > 0) & (l2 < lam[v0:v1, u0:u1])
+            if not hit.any():
+                continue
+            col = self._sample(P2, sh["toff"])
+            sub = img[v0:v1, u0:u1]
+            sub[hit] = col[hit]
+            lam[v0:v1, u0:u1][hit] = l2[hit]
         return synth.quantise(img.astype(np.float32), noise_seed), lam
+
+    def surface_points(self, rng, n):
+        """n points on the visible surfaces (plane or sheet tops) around the origin, with their upward normal."""
+        P = np.zeros((n, 3))
+        P[:, :2] = rng.uniform(-4.0, 4.0, (n, 2))
+        for sh in self.sheets:  # later sheets win where they overlap; a point under a sheet is simply occluded from above
+            ins = (np.abs(P[:, 0] - sh["c"][0]) <= sh["half"][0]) & (np.abs(P[:, 1] - sh["c"][1]) <= sh["half"][1])
+            P[ins, 2] = np.maximum(P[ins, 2], sh["z"])
+        return P
 
     def stereo(self, Rwb, pwb, noise_seed):
         """(left, right, depth_left) for the body pose (Rwb, pwb)."""
