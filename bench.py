@@ -280,6 +280,115 @@ def cpu_replay(seq, n_frames):
                       "on the CPU oracle, one thread" % n_frames}, to
 
 
+def multi_gpu_legs(rank, world, dist, torch, reps=3):
+    """SURVEY 8e "report both modes": besides the replica mode of the headline, what the driver's --gpus N runs measure
+    in the same process group (and what --gpus 1 exercises with a one-rank communicator):
+      sharded_local_ba / sharded_full_ba: ONE window / ONE full BA in System::FinalGBA's form (scale vertex) with its
+          landmarks spread over the ranks, the reduced pose system summed by the in-library RCCL all-reduce on the
+          bundle-adjustment stream (sharding.RcclComm -> vieo_rccl_*), rank 0's poses against the unsharded call on its
+          own GPU, and the time of a torch.distributed all-reduce of the same size for scale;
+      rig_replicas: BASELINE configs[3] -- a 4-camera distorted (KB8) rig chain, one sequence of frames per rank, no
+          collective: extract x 4 -> ComputeStereoFishEyeMatches -> SearchByProjection x 2 -> PoseOptimization x 2."""
+    from vieo_slam_amd import sharding, synth_ba
+    from vieo_slam_amd import synth_scene as sc
+    from vieo_slam_amd._lib import DeviceBuffer
+    from vieo_slam_amd.optimizer import Optimizer
+    from vieo_slam_amd.pipeline_rig import RigFrontEnd
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def mx(v):
+        return sharding.max_over_ranks(dist, v, device="cuda")
+
+    out = {"rccl_ranks": world}
+    comm = sharding.RcclComm(rank, world)
+    try:
+        for name, gba in (("sharded_local_ba", False), ("sharded_full_ba", True)):
+            if gba:
+                win = synth_ba.make_lba_vio_problem(901, n_local=60, n_fixed=1, n_points=6000, anchors=30, span=5)[:6]
+                win = (win[0], win[1], (win[2] / np.float32(1.03)).astype(np.float32)) + tuple(win[3:])
+            else:
+                win = synth_ba.make_lba_vio_problem(900, n_local=10, n_fixed=40, n_points=2000)[:6]
+            shard, mine = sharding.shard_window(win, rank, world)
+            n = Optimizer.sharded_buffer_doubles([shard])
+            buf = DeviceBuffer(8 * n)
+
+            def call():
+                if gba:
+                    return Optimizer.GlobalBundleAdjustmentNavStatePRVSharded(shard, buf.ptr, n, None, 5, True, comm=comm.handle,
+                                                                              bScaleOpt=True)
+                return Optimizer.LocalBundleAdjustmentNavStatePRVSharded([shard], buf.ptr, n, None, comm=comm.handle)[0]
+            times = []
+            for i in range(reps + 1):
+                barrier()
+                t = time.perf_counter()
+                r = call()
+                barrier()
+                if i:
+                    times.append(mx(time.perf_counter() - t))
+            nf = int((win[1]["fixed"] == 0).sum())
+            n_sys = (6 * nf + (1 if gba else 0)) * (6 * nf + 1 + (1 if gba else 0)) + 42 * nf + ((6 * nf + 2) if gba else 0)
+            tt = torch.zeros(n_sys, dtype=torch.float64, device="cuda")
+            us = None
+            if world > 1:
+                for _ in range(5):
+                    dist.all_reduce(tt)
+                barrier()
+                t = time.perf_counter()
+                for _ in range(50):
+                    dist.all_reduce(tt)
+                torch.cuda.synchronize()
+                us = mx(time.perf_counter() - t) / 50 * 1e6
+            leg = {"ms_per_call": 1e3 * float(np.mean(times)), "key_frames": len(win[1]), "free_key_frames": nf,
+                   "points_total": len(win[2]), "points_this_rank": len(mine), "observations_total": len(win[4]),
+                   "lm_trials": int((r[2] if gba else r[3])["lm_trials"]),
+                   "allreduce_doubles_per_trial": n_sys,
+                   "torch_allreduce_of_that_size_us": us,
+                   "exchange": "in-library ncclAllReduce(sum, f64) on the bundle-adjustment stream (vieo_rccl_*), one per LM "
+                               "trial + one of 4 scalars"}
+            if rank == 0:
+                if gba:
+                    ref = Optimizer.GlobalBundleAdjustmentNavStatePRV(win[0], win[1], win[2], win[4], win[5], 5, True, bScaleOpt=True)
+                    t = time.perf_counter()
+                    Optimizer.GlobalBundleAdjustmentNavStatePRV(win[0], win[1], win[2], win[4], win[5], 5, True, bScaleOpt=True)
+                    leg["recovered_scale"], leg["recovered_scale_unsharded"] = r[3], ref[3]
+                else:
+                    ref = Optimizer.LocalBundleAdjustmentNavStatePRV(*win)
+                    t = time.perf_counter()
+                    Optimizer.LocalBundleAdjustmentNavStatePRV(*win)
+                leg["ms_per_call_unsharded_one_gpu"] = 1e3 * (time.perf_counter() - t)
+                leg["max_pose_difference_vs_unsharded"] = float(max(max(synth_ba.pose_error(ref[0][k], r[0][k]))
+                                                                    for k in range(len(win[1]))))
+            barrier()
+            buf.free()
+            out[name] = leg
+    finally:
+        comm.close()
+    # ---- configs[3]: rig replicas
+    seed = 300 + rank
+    scene = sc.RigScene(seed, "kb8", 4)
+    cases = [sc.make_rig_tracking_case(seed + 10 * i, scene) for i in range(3)]
+    fe = RigFrontEnd(scene, 1500)
+    fe.track(cases[0], np.random.default_rng(0))  # warm-up
+    barrier()
+    t = time.perf_counter()
+    errs = []
+    for i, c in enumerate(cases):
+        o = fe.track(c, np.random.default_rng(i))
+        errs.append(synth_ba.pose_error(o["r2"]["base"]["nav"], c["truth"])[0])
+    barrier()
+    dt = mx(time.perf_counter() - t)
+    out["rig_replicas"] = {"config": "BASELINE configs[3]: 4-camera KB8 rig, 1500 features per camera, one sequence per rank, "
+                                     "stage-by-stage host-pointer calls (each track = the frame pair t0, t1: 8 extractions, "
+                                     "2 fisheye stereo matches, 2 searches, 2 pose optimisations)",
+                           "rig_frames_per_s_all_ranks": 2 * len(cases) * world / dt, "ms_per_rig_frame": 1e3 * dt / (2 * len(cases)),
+                           "max_position_error_vs_truth_m_rank0": float(max(errs))}
+    return out
+
+
 def pcie_leg(P, steps, warmup):
     """The batched step with its images uploaded from pinned host memory on a copy stream, double-buffered: while
     step s runs on the pipeline's stream, step s+1's images travel over PCIe."""
@@ -359,6 +468,9 @@ def main():
     ap.add_argument("--single-stream-frames", type=int, default=100,
                     help="frames of the sequential replay leg (0 = skip); rank 0 at N = 1 only")
     ap.add_argument("--no-pcie-leg", action="store_true")
+    ap.add_argument("--no-multi-gpu-legs", action="store_true",
+                    help="skip the landmark-sharded local / full BA and the configs[3] rig-replica legs (they run on every "
+                         "rank after the timed region, with a one-rank communicator at --gpus 1)")
     a = ap.parse_args()
 
     from vieo_slam_amd import sharding
@@ -445,6 +557,12 @@ def main():
     stage = P.stage_ms_all()
     orb = P.ext.stage_ms_all()
     res = P.results()
+    mg = None
+    if not a.no_multi_gpu_legs:
+        try:
+            mg = multi_gpu_legs(rank, world, dist, torch)
+        except Exception as e:  # a leg must not take the headline down with it
+            mg = {"error": repr(e)}
     if rank == 0:
         avg = {k: float(np.mean([s[k] for s in stage])) for k in P.STAGES}
         oavg = {k: float(np.mean([s[k] for s in orb])) for k in ORB_STAGES}
@@ -571,6 +689,8 @@ def main():
                                         "extractor_kernel_ms": {k: float(np.mean([m[k] for m in alone])) for k in ORB_STAGES},
                                         "note": "same launch without the bundle-adjustment stream beside it (its short "
                                                 "high-priority kernels take CUs from the front end in the timed region)"}
+        if mg is not None:
+            out["multi_gpu"] = mg
         if world == 1 and not a.no_pcie_leg:
             out["pcie_inclusive"] = pcie_leg(P, max(3, min(a.steps, 10)), 2)
         if world == 1 and not a.no_cpu_baseline:
@@ -586,7 +706,10 @@ def main():
                 out["single_stream"]["ate_vs_oracle_m"] = replay.ate_between(th, to)
                 out["single_stream"]["max_position_difference_vs_oracle_m"] = float(
                     np.linalg.norm(th["p"] - to["p"], axis=1).max())
-        print(json.dumps(out))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # (RCCL's version banner sits in C stdio's buffer: out with it BEFORE the line)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

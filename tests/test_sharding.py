@@ -112,3 +112,47 @@ def test_two_rank_reduction_callback_gloo():
         for i in range(20):
             summed = i < 12 or i >= 16
             assert v[i] == (i * 3 if summed else i * (r + 1))
+
+
+def _reduce8_worker(rank, world, port, q):
+    """One rank of an 8-rank landmark-sharded window whose point count is below the world size: some ranks own no
+    point.  Everything the sharded entry needs from the host side: the shard (possibly empty), the buffer size every
+    rank computes alike, the reduction callback summing over all ranks -- empty ranks included -- in both exchanges."""
+    import numpy as np
+    from vieo_slam_amd import synth_ba
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    win = synth_ba.make_lba_vio_problem(44, n_local=3, n_fixed=1, n_points=40)[:6]
+    params, kfs, pts, close, obs, imu = win
+    keep = np.arange(5)  # a window of five points over eight ranks
+    sel = np.isin(obs["mp"], keep)
+    small = (params, kfs, pts[:5], np.asarray(close)[:5], obs[sel], imu)
+    (p2, k2, pts2, close2, obs2, imu2), mine = sharding.shard_window(small, rank, world)
+    assert len(pts2) == (1 if rank < 5 else 0) and len(obs2) == int(np.isin(small[4]["mp"], mine).sum())
+    assert k2 is kfs and imu2 is imu
+    nf = int((kfs["fixed"] == 0).sum())
+    n_sys = 6 * nf * (6 * nf + 1) + 42 * nf  # the packed reduced visual system (DESIGN.md section 6)
+    buf = torch.zeros(n_sys + 4, dtype=torch.float64)
+    buf[:n_sys] = float(len(pts2))       # a rank without points contributes zeros
+    buf[n_sys:n_sys + 3] = float(rank)
+    fn = sharding.torch_allreduce(buf)
+    assert fn(0, n_sys) == 0 and fn(n_sys, 4) == 0
+    q.put((rank, float(buf[0]), float(buf[n_sys - 1]), float(buf[n_sys]), len(pts2)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_reduction_with_empty_shards_gloo():
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_reduce8_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert [o[0] for o in out] == list(range(8)) and sum(o[4] for o in out) == 5
+    for r, first, last, sc, npts in out:
+        assert first == last == 5.0      # five ranks own one point each, three none: the sum is the same everywhere
+        assert sc == float(sum(range(8)))

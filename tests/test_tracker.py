@@ -147,3 +147,66 @@ def test_gpu_cpp_replay_without_python(tmp_path):
     print("C++ replay: %.3f ms per frame (tracking call %.3f, its GPU part %.3f, local BA %.2f ms each); "
           "max |dp| against the Python driver %.2e m" % (r["ms_per_frame"], r["ms_track_call"], r["ms_track_gpu"],
                                                          r["ms_per_local_ba"], d.max()))
+
+
+@pytest.mark.gpu
+def test_gpu_three_host_threads_concurrently(oracle):
+    """the back end must be re-entrant across >= 3 host threads.  Tracking (vieo_track_frame per frame, with
+    its key-frame local BAs), LocalMapping-style work (visual-inertial local BAs and a vision-only pose optimisation that
+    needs the OTHER kernel instances: a distorted rig) and LoopClosing-style work (Fuse searches) run at the same
+    time, each on its own thread and streams; every thread's results equal the ones it gets alone.  The kernel-instance
+    modes are per call / per thread now, so the rig optimisation of thread 2 cannot be skipped by the tracker's choice."""
+    import threading
+    from tests.test_map_point import _fuse_case
+    from vieo_slam_amd.map_point import fuse_search
+    from vieo_slam_amd.optimizer import Optimizer
+    from vieo_slam_amd.tracker import TrackerReplay
+    n = 30
+    seq = replay.Sequence(6, n)
+    for k in range(n):
+        seq.images(k)
+
+    def track():
+        R = TrackerReplay(seq, replay.HipStages())
+        t = R.run(n)
+        R.close()
+        return t.tobytes()
+
+    win = synth_ba.make_lba_vio_problem(61, n_local=8, n_fixed=4, n_points=900)[:6]
+    fr, ob, _ = synth_ba.make_pose_problem(62, n_obs=300, rig=synth_ba.camera_rig("kb8"))
+
+    def mapping():
+        out = []
+        for _ in range(6):
+            navs, pts, erase, res = Optimizer.LocalBundleAdjustmentNavStatePRV(*win)
+            r, o = Optimizer.PoseOptimization(fr, ob)
+            out.append((navs.tobytes(), pts.tobytes(), erase.tobytes(), r["nav"].tobytes(), o.tobytes()))
+        return out
+
+    rng = np.random.default_rng(63)
+    FF, keys, urs, descs, P, cams = _fuse_case(rng, None, n_points=3000)
+
+    def fusing():
+        out = []
+        for _ in range(12):
+            bi, bd = fuse_search(FF, keys, urs, descs, P)
+            out.append((bi.tobytes(), bd.tobytes()))
+        return out
+
+    alone = [track(), mapping(), fusing()]
+    assert int(np.frombuffer(alone[1][0][4], np.uint8).size) == len(ob)
+    got, errs = [None] * 3, []
+
+    def run(i, fn):
+        try:
+            got[i] = fn()
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, e))
+    ts = [threading.Thread(target=run, args=(i, fn)) for i, fn in enumerate((track, mapping, fusing))]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errs, errs
+    assert not any(t.is_alive() for t in ts)
+    assert got[0] == alone[0], "the tracked trajectory changed under concurrent local mapping / fusing"
+    assert got[1] == alone[1] and got[2] == alone[2]
+    assert all(x == alone[1][0] for x in got[1]) and all(x == alone[2][0] for x in got[2])
