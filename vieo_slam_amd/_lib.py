@@ -134,6 +134,13 @@ _SIGS = {
     "vieo_orb_tap_plane": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_candidates": (c_i, [c_p, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_level_keys": (c_i, [c_p, c_i, c_i, c_p, c_i]),
+    "vieo_imu_preintegrate_batch_device": (c_i, [c_p] * 7 + [c_i] + [c_p] * 4),
+    "vieo_tracker_create": (c_i, [P(c_p), c_p]),
+    "vieo_tracker_destroy": (None, [c_p]),
+    "vieo_tracker_image_buffers": (c_i, [c_p, P(c_p), P(c_p)]),
+    "vieo_tracker_scale_factors": (c_i, [c_p, c_p]),
+    "vieo_track_frame": (c_i, [c_p, c_p, c_p]),
+    "vieo_tracker_get_level": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),
 }
 
 _lib = None

@@ -115,6 +115,7 @@ struct LbaDev {
   double* BB;                     // [6 nf_cap][ldB]
   double* Sp;                     // [ksplit][sp_rows][ldS] partial Schur products
   size_t sp_stride;
+  int ksplit;                     // K splits of this window's Schur GEMM (a function of the window alone)
   double *Hll, *bl, *Hpp, *bp, *Hs, *bs, *xp;
   unsigned char* occ;             // [(npv + 64) / 64][chunks of 16 landmarks]: the row tile has an edge in the chunk
   double *Hb, *Wp;                // tiled solve of a large reduced system: padded copy [nb][nb], panel [nb][64]
@@ -726,8 +727,7 @@ k_lba_occ(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
 }
 
 __global__ void __launch_bounds__(256)
-k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out,
-            int ksplit) {
+k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) double sT[64 * kLd];
   __shared__ __attribute__((aligned(16))) double sB[64 * kLd];
   __shared__ double sDi[kChunkLm * 9];
@@ -737,6 +737,7 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   const int np = D.npv;  // the landmarks touch the PR blocks only
   if (np == 0) return;
   const int RB = (np + 63) >> 6, CB = (np + 64) >> 6;  // CB covers the extra column bl
+  const int ksplit = D.ksplit;
   int bt = blockIdx.x / ksplit;
   const int split = blockIdx.x % ksplit;
   int bi = 0;
@@ -820,7 +821,7 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
 // Schur product over its landmarks (K-split partials folded in fixed order), H_pp and b_p of its edges
 // -- packed contiguously for ONE all-reduce.
 __global__ void __launch_bounds__(256)
-k_lba_pack(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int ksplit) {
+k_lba_pack(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
@@ -829,6 +830,7 @@ k_lba_pack(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int 
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= nS + nH + nb + (D.scale_opt ? nb + 2 : 0)) return;
   if (e < nS) {
+    const int ksplit = D.ksplit;
     const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
     const int ns = (nchunks + cps - 1) / cps;
     const int r = e / (npv + 1), c = e - r * (npv + 1);
@@ -848,14 +850,14 @@ k_lba_pack(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int 
 // the Schur partials); visual-inertial windows add the inertial edges' 30x30 blocks, gathered per entry
 // (a key frame has at most one inertial edge in and one out).  bs = b - S[:, npv], bfull = b.
 __global__ void __launch_bounds__(256)
-k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out,
-               int ksplit) {
+k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out) {
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
   const int np = D.np, npv = D.npv, pd = D.pd, e = blockIdx.x * 256 + threadIdx.x;
   if (e >= np * np) return;
   const double lambda = win_lambda(ctl[w], out[w]);
+  const int ksplit = D.ksplit;
   const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
   const int ns = (nchunks + cps - 1) / cps;
   const int r = e / np, c = e % np;
@@ -2226,12 +2228,25 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     for (int k = 0; k < win[w].n_kf; k++) nf += !h_kfs[w][k].fixed;
     max_nf = std::max(max_nf, nf), max_mp = std::max(max_mp, win[w].n_mp);
   }
-  // Schur GEMM decomposition: 64x64 block-tiles (upper) x K splits, about 768 workgroups in flight
-  const int np_cap_max = 6 * max_nf + sco;
-  const int RBm = (np_cap_max + 63) / 64, CBm = (np_cap_max + 64) / 64;
-  const int nbt_max = RBm * CBm - RBm * (RBm - 1) / 2;
-  const int nchunks_max = (max_mp + kChunkLm - 1) / kChunkLm;
-  const int ksplit = std::max(1, std::min(std::min(nchunks_max, 16), 768 / std::max(1, n_live * nbt_max)));
+  // Schur GEMM decomposition: 64x64 block-tiles (upper) x K splits.  The number of splits is a function of the window
+  // alone (about kSchurCps chunks of 16 landmarks per workgroup, VIEO_LBA_CPS), so that the summation order -- and with
+  // it the window's result -- does not depend on what the window is batched with; a mixed batch (ordinary windows of
+  // one tile next to bLarge ones of six) launches the largest tile x split count and the others' workgroups exit.
+  // The full BA keeps few splits: its tiles are many and mostly skipped (k_lba_occ).
+  static const int cps_target = [] {
+    const char* e = getenv("VIEO_LBA_CPS");
+    return e && atoi(e) > 0 ? atoi(e) : 6;
+  }();
+  auto schur_tiles = [&](int nf) {
+    const int npm = 6 * nf + sco, RB = (npm + 63) / 64, CB = (npm + 64) / 64;
+    return RB * CB - RB * (RB - 1) / 2;
+  };
+  auto schur_ksplit = [&](int nf, int nmp) {
+    const int nch = (nmp + kChunkLm - 1) / kChunkLm, nbt = std::max(1, schur_tiles(nf));
+    if (gba) return std::max(1, std::min(std::min(nch, 16), 768 / nbt));
+    return std::max(1, std::min(std::min((nch + cps_target - 1) / cps_target, 32), std::max(1, 512 / nbt)));
+  };
+  int schur_grid = 1;
   std::vector<size_t> scratch_off(W);
   struct Scr {
     size_t kf_bak, X_bak, mp_act, BB, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
@@ -2254,6 +2269,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     const int ldB = (H.n_mp + kChunkLm - 1) / kChunkLm * (3 * kChunkLm);
     const int sp_rows = (npm + 63) / 64 * 64, ldS = (npm + 64) / 64 * 64;
     s.BB = take((size_t)npm * ldB * 8);
+    const int ksplit = schur_ksplit(nf, H.n_mp);
+    schur_grid = std::max(schur_grid, schur_tiles(nf) * ksplit);
     s.Sp = take((size_t)ksplit * sp_rows * ldS * 8);
     s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
     const int npf = pd * nf + sco;  // full reduced system
@@ -2276,7 +2293,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     LbaDev& D = devs[w];
     memset(&D, 0, sizeof(D));
     D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.nf_cap = nf;
-    D.ldB = ldB, D.ldS = ldS, D.sp_stride = (size_t)sp_rows * ldS;
+    D.ldB = ldB, D.ldS = ldS, D.sp_stride = (size_t)sp_rows * ldS, D.ksplit = ksplit;
     D.cam.fx = H.P->fx, D.cam.fy = H.P->fy, D.cam.cx = H.P->cx, D.cam.cy = H.P->cy, D.cam.bf = H.P->bf;
     memcpy(D.cam.Rcb, H.P->Rcb, 72);
     memcpy(D.cam.tcb, H.P->tcb, 24);
@@ -2622,16 +2639,15 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     }
     if (any & LBA_BEGIN) KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO); });
     if (any & LBA_TRIAL) {
-      KT.launch(KC_SCHUR, [&] { hipLaunchKernelGGL(k_lba_schur, dim3(nbt_max * ksplit, W), dim3(256), 0, st, dD, dC, dO, ksplit); });
+      KT.launch(KC_SCHUR, [&] { hipLaunchKernelGGL(k_lba_schur, dim3(schur_grid, W), dim3(256), 0, st, dD, dC, dO); });
       if (sh) {  // the one exchange step of the path: sum the reduced visual system over the ranks
         const int nv = 6 * max_nf + sco;
         KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_pack, dim3((unsigned)((shard_sys_doubles(max_nf, sco) + 255) / 256), W), dim3(256), 0, st,
-                           dD, dC, ksplit); });
+                           dD, dC); });
         (void)nv;
         if ((rc = shard_exchange(sh, sh->d_buf, shard_sys, st)) != VIEO_OK) return rc;
       }
-      KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO,
-                         ksplit); });
+      KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO); });
       if (big) {
         const int nbm = (n_max_b + 1 + kNB - 1) / kNB * kNB, ntm = nbm / kNB;
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_init, dim3((unsigned)(((size_t)nbm * nbm + 255) / 256), W), dim3(256), 0, st, dD, dC); });

@@ -34,22 +34,8 @@ TRACK_OUTPUT_DTYPE = np.dtype([
     ("preint_status", "<i4"), ("reserved", "<i4"), ("first", VIO_RESULT_DTYPE), ("second", VIO_RESULT_DTYPE),
     ("ms_gpu", "<f4"), ("ms_host", "<f4")], align=True)
 
-_bound = False
-
-
 def _bind():
-    global _bound
-    L = lib()
-    if not _bound:
-        P, I = ctypes.c_void_p, ctypes.c_int
-        L.vieo_tracker_create.argtypes, L.vieo_tracker_create.restype = [ctypes.POINTER(P), P], I
-        L.vieo_tracker_destroy.argtypes, L.vieo_tracker_destroy.restype = [P], None
-        L.vieo_tracker_image_buffers.argtypes, L.vieo_tracker_image_buffers.restype = [P, ctypes.POINTER(P), ctypes.POINTER(P)], I
-        L.vieo_tracker_scale_factors.argtypes, L.vieo_tracker_scale_factors.restype = [P, P], I
-        L.vieo_track_frame.argtypes, L.vieo_track_frame.restype = [P, P, P], I
-        L.vieo_tracker_get_level.argtypes, L.vieo_tracker_get_level.restype = [P, I, I, I, P, I], I
-        _bound = True
-    return L
+    return lib()  # signatures: _lib._SIGS
 
 
 def euroc_params(max_local_points=16384, th_last=7.0, th_local=2.0, noise=None):
