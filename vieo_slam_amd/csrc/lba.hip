@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(256)
 k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) double sT[64 * kLd];
   __shared__ __attribute__((aligned(16))) double sB[64 * kLd];
-  __shared__ double sDi[kChunkLm * 9];
+  __shared__ double sDi[2][kChunkLm * 9];
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
@@ -750,37 +750,35 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   const double lambda = win_lambda(ctl[w], out[w]);
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const size_t ldB = D.ldB;
+  const int n_mp = D.n_mp;
   double4_t acc[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) acc[q] = (double4_t){0, 0, 0, 0};
   const unsigned char* occ_i = D.occ + (size_t)bi * nchunks;
   const unsigned char* occ_j = D.occ + (size_t)bj * nchunks;
   const bool has_bl = np >= bj * 64 && np < bj * 64 + 64;  // this column tile carries b_l: dense
-  for (int ch = c0; ch < c1; ch++) {
-    if (!occ_i[ch] || (!has_bl && !occ_j[ch])) continue;  // a zero factor: nothing to add (workgroup-uniform)
-    __syncthreads();  // the previous chunk's fragments have been read
-    if (tid < kChunkLm) {
-      const int m = ch * kChunkLm + tid;
-      double Di[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (m < D.n_mp && D.mp_act[m]) landmark_dinv(D.Hll + 9 * (size_t)m, lambda, Di);
-#pragma unroll
-      for (int t = 0; t < 9; t++) sDi[tid * 9 + t] = Di[t];
-    }
-    __syncthreads();
+  // the chunks this workgroup works on: a zero factor adds nothing (workgroup-uniform)
+  auto next_chunk = [&](int ch) {
+    while (ch < c1 && (!occ_i[ch] || (!has_bl && !occ_j[ch]))) ch++;
+    return ch;
+  };
+  // Software pipeline over the chunks: the operands of chunk c + 1 (the two 64 x 48 slabs of BB, 12 + 12 doubles per
+  // thread, and H_ll of its 16 landmarks on the first 16 threads) are loaded into registers before the MFMAs of chunk
+  // c are issued, (H_ll + lambda I)^-1 of chunk c + 1 is formed after them into the other half of sDi; per chunk the
+  // workgroup then pays two barriers, the LDS stores and 48 MFMAs per wavefront instead of two global round trips.
+  const int r_it = tid >> 4, j_it = tid & 15;  // item it of a thread: row r_it + 16 it, landmark j_it of the chunk
+  double ta[12], tb[12], hl[9];
+  auto load_chunk = [&](int ch) {
+    const int m = ch * kChunkLm + j_it;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
-      const int item = tid + 256 * it, r = item >> 4, j = item & 15;
-      const int m = ch * kChunkLm + j;
-      const int gr = bi * 64 + r, gc = bj * 64 + r;
+      const int r = r_it + 16 * it, gr = bi * 64 + r, gc = bj * 64 + r;
       double b0 = 0, b1 = 0, b2 = 0;
       if (gr < np) {
         const double* p = D.BB + (size_t)gr * ldB + 3 * (size_t)m;
         b0 = p[0], b1 = p[1], b2 = p[2];
       }
-      const double* Di = sDi + j * 9;
-      sT[r * kLd + 3 * j + 0] = b0 * Di[0] + b1 * Di[3] + b2 * Di[6];
-      sT[r * kLd + 3 * j + 1] = b0 * Di[1] + b1 * Di[4] + b2 * Di[7];
-      sT[r * kLd + 3 * j + 2] = b0 * Di[2] + b1 * Di[5] + b2 * Di[8];
+      ta[3 * it] = b0, ta[3 * it + 1] = b1, ta[3 * it + 2] = b2;
       if (bj != bi) {
         b0 = b1 = b2 = 0;
         if (gc < np) {
@@ -790,14 +788,55 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
       }
       if (gc == np) {  // the extra column: b_l
         b0 = b1 = b2 = 0;
-        if (m < D.n_mp && D.mp_act[m]) {
+        if (m < n_mp && D.mp_act[m]) {
           const double* p = D.bl + 3 * (size_t)m;
           b0 = p[0], b1 = p[1], b2 = p[2];
         }
       }
-      sB[r * kLd + 3 * j + 0] = b0, sB[r * kLd + 3 * j + 1] = b1, sB[r * kLd + 3 * j + 2] = b2;
+      tb[3 * it] = b0, tb[3 * it + 1] = b1, tb[3 * it + 2] = b2;
+    }
+  };
+  bool hl_act = false;
+  auto load_hll = [&](int ch) {  // threads 0..15
+    const int m = ch * kChunkLm + tid;
+    hl_act = m < n_mp && D.mp_act[m];
+    if (hl_act) {
+#pragma unroll
+      for (int t = 0; t < 9; t++) hl[t] = D.Hll[9 * (size_t)m + t];
+    }
+  };
+  auto store_dinv = [&](int buf) {  // threads 0..15
+    double Di[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hl_act) landmark_dinv(hl, lambda, Di);
+#pragma unroll
+    for (int t = 0; t < 9; t++) sDi[buf][tid * 9 + t] = Di[t];
+  };
+  int ch = next_chunk(c0), buf = 0;
+  if (ch < c1) {
+    load_chunk(ch);
+    if (tid < kChunkLm) load_hll(ch), store_dinv(0);
+  }
+  while (ch < c1) {
+    __syncthreads();  // the previous chunk's fragments have been read; sDi[buf] is complete
+    {
+      const double* Di = sDi[buf] + j_it * 9;
+      const double d0 = Di[0], d1 = Di[1], d2 = Di[2], d3 = Di[3], d4 = Di[4], d5 = Di[5], d6 = Di[6], d7 = Di[7], d8 = Di[8];
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = r_it + 16 * it;
+        const double b0 = ta[3 * it], b1 = ta[3 * it + 1], b2 = ta[3 * it + 2];
+        sT[r * kLd + 3 * j_it + 0] = b0 * d0 + b1 * d3 + b2 * d6;
+        sT[r * kLd + 3 * j_it + 1] = b0 * d1 + b1 * d4 + b2 * d7;
+        sT[r * kLd + 3 * j_it + 2] = b0 * d2 + b1 * d5 + b2 * d8;
+        sB[r * kLd + 3 * j_it + 0] = tb[3 * it], sB[r * kLd + 3 * j_it + 1] = tb[3 * it + 1], sB[r * kLd + 3 * j_it + 2] = tb[3 * it + 2];
+      }
     }
     __syncthreads();
+    const int nx = next_chunk(ch + 1);
+    if (nx < c1) {
+      load_chunk(nx);
+      if (tid < kChunkLm) load_hll(nx);
+    }
     const double* pa = sT + (wv * 16 + (lane & 15)) * kLd + (lane >> 4);
     const double* pb = sB + (lane & 15) * kLd + (lane >> 4);
 #pragma unroll
@@ -807,6 +846,8 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
       for (int q = 0; q < 4; q++)
         acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[q * 16 * kLd + ks * 4], acc[q], 0, 0, 0);
     }
+    if (nx < c1 && tid < kChunkLm) store_dinv(buf ^ 1);
+    buf ^= 1, ch = nx;
   }
   // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
   double* S = D.Sp + (size_t)split * D.sp_stride;
@@ -1059,13 +1100,7 @@ k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, i
   }
 }
 
-// ---- dense LDL^T solve of the reduced system + pose update, one workgroup per window.
-// Right-looking, one PW-column panel per step (PW = 6: one key frame of a vision-only window; PW = 5: a
-// third of a visual-inertial key-frame block): every thread factorises the PW x PW diagonal block in
-// registers, one thread per row below forms its multipliers, then the trailing matrix takes the PW
-// rank-1 updates in sequence -- the arithmetic of the column-by-column algorithm with 1/PW of its
-// barriers.  use_lds: the lower triangle lives packed in LDS (n <= ~186), otherwise the matrix is
-// factorised in place in global memory.
+// ---- dense LDL^T solve of the reduced system + pose update.
 // The end of a solve, shared by the single-workgroup LDL^T and the tiled one: x -> D.xp, the pose part of
 // computeScale(), push() + oplus on the free key frames.  y: the solution (LDS or global), 256 threads.
 // NT: threads of the workgroup; the first 256 do the work (and sum in the same order whatever NT is).
@@ -1109,159 +1144,6 @@ __device__ __forceinline__ void lba_apply_step(const LbaDev& D, const double* y,
         kf.v[a] += y[kf.col + 6 + a], kf.dbg[a] += y[kf.col + 9 + a], kf.dba[a] += y[kf.col + 12 + a];
     D.kf[k] = kf;
   }
-}
-
-template <int PW>
-__global__ void __launch_bounds__(256)
-k_lba_ldlt(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out,
-           int use_lds, int n_max) {
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  __shared__ double s_red[4];
-  const int w = blockIdx.x;
-  if (!(ctl[w].flags & LBA_TRIAL)) return;
-  const LbaDev& D = devs[w];
-  if (D.solver != 1) return;
-  const int n = D.np, tid = threadIdx.x;
-  if (n == 0) {
-    if (tid == 0) out[w].ok = 1, out[w].scale_p = 0;
-    return;
-  }
-  const double lambda = win_lambda(ctl[w], out[w]);
-  double* sW = s_dyn;                   // [n][PW] un-normalised panel columns
-  double* y = sW + PW * (size_t)n_max;  // [n]
-  double* sD = y + n_max;               // [n]
-  double* A = use_lds ? sD + n_max : D.Hs;
-  // element (i, k), k <= i
-#define LA(i, k) A[use_lds ? ((size_t)(i) * ((i) + 1) / 2 + (k)) : ((size_t)(i) * n + (k))]
-  if (use_lds) {
-    for (int i = tid; i < n * n; i += 256) {
-      const int r = i / n, c = i - r * n;
-      if (c <= r) LA(r, c) = D.Hs[i];
-    }
-  }
-  __syncthreads();
-  const int ti = tid >> 4, tk = tid & 15;
-  bool ok = true;
-  for (int j0 = 0; j0 < n && ok; j0 += PW) {
-    // PW x PW diagonal block, every thread: a[r][c] (r >= c), Wd = un-normalised columns, Dd = pivots
-    double a[PW][PW], Wd[PW][PW], Dd[PW];
-#pragma unroll
-    for (int r = 0; r < PW; r++)
-#pragma unroll
-      for (int c = 0; c <= r; c++) a[r][c] = LA(j0 + r, j0 + c);
-#pragma unroll
-    for (int c = 0; c < PW; c++) {
-      const double d = a[c][c];
-      if (!(d > 0)) ok = false;
-      Dd[c] = d;
-#pragma unroll
-      for (int r = c + 1; r < PW; r++) Wd[r][c] = a[r][c];
-#pragma unroll
-      for (int r = c + 1; r < PW; r++) {
-        const double l = Wd[r][c] / d;
-#pragma unroll
-        for (int k = c + 1; k <= r; k++) a[r][k] -= l * Wd[k][c];
-        a[r][c] = l;
-      }
-    }
-    if (!ok) break;  // uniform: every thread factorised the same block
-    if (tid < PW) {
-      double dv = Dd[0];
-#pragma unroll
-      for (int c = 1; c < PW; c++)
-        if (tid == c) dv = Dd[c];
-      sD[j0 + tid] = dv;
-    }
-    // rows below the panel: multipliers
-    for (int i = j0 + PW + tid; i < n; i += 256) {
-      double ai[PW];
-#pragma unroll
-      for (int c = 0; c < PW; c++) ai[c] = LA(i, j0 + c);
-#pragma unroll
-      for (int c = 0; c < PW; c++) {
-        const double col = ai[c], l = col / Dd[c];
-        sW[i * PW + c] = col;
-#pragma unroll
-        for (int k = c + 1; k < PW; k++) ai[k] -= l * Wd[k][c];
-        ai[c] = l;
-      }
-#pragma unroll
-      for (int c = 0; c < PW; c++) LA(i, j0 + c) = ai[c];
-    }
-    __syncthreads();
-    if (tid == 0) {  // after the barrier: every thread has read the unfactorised diagonal block
-#pragma unroll
-      for (int r = 1; r < PW; r++)
-#pragma unroll
-        for (int c = 0; c < r; c++) LA(j0 + r, j0 + c) = a[r][c];
-    }
-    // trailing matrix (lower triangle)
-    for (int i = j0 + PW + ti; i < n; i += 16) {
-      double li[PW];
-#pragma unroll
-      for (int c = 0; c < PW; c++) li[c] = LA(i, j0 + c);
-      for (int k = j0 + PW + tk; k <= i; k += 16) {
-        double v = LA(i, k);
-#pragma unroll
-        for (int c = 0; c < PW; c++) v -= li[c] * sW[k * PW + c];
-        LA(i, k) = v;
-      }
-    }
-    __syncthreads();
-  }
-  if (ok) {
-    for (int i = tid; i < n; i += 256) y[i] = D.bs[i];
-    __syncthreads();
-    // forward substitution L y = b, panel by panel
-    for (int j0 = 0; j0 < n; j0 += PW) {
-      double yp[PW];
-#pragma unroll
-      for (int c = 0; c < PW; c++) yp[c] = y[j0 + c];
-#pragma unroll
-      for (int c = 0; c < PW; c++)
-#pragma unroll
-        for (int r = c + 1; r < PW; r++) yp[r] -= LA(j0 + r, j0 + c) * yp[c];
-      __syncthreads();  // everyone has read y[j0 .. j0+PW-1]
-      if (tid == 0)
-#pragma unroll
-        for (int c = 1; c < PW; c++) y[j0 + c] = yp[c];
-      for (int i = j0 + PW + tid; i < n; i += 256) {
-        double v = y[i];
-#pragma unroll
-        for (int c = 0; c < PW; c++) v -= LA(i, j0 + c) * yp[c];
-        y[i] = v;
-      }
-      __syncthreads();
-    }
-    for (int i = tid; i < n; i += 256) y[i] /= sD[i];
-    __syncthreads();
-    // backward substitution L^T x = y
-    for (int j0 = n - PW; j0 >= 0; j0 -= PW) {
-      double xp[PW];
-#pragma unroll
-      for (int c = 0; c < PW; c++) xp[c] = y[j0 + c];
-#pragma unroll
-      for (int c = PW - 1; c > 0; c--)
-#pragma unroll
-        for (int r = c - 1; r >= 0; r--) xp[r] -= LA(j0 + c, j0 + r) * xp[c];
-      __syncthreads();
-      if (tid == 0)
-#pragma unroll
-        for (int c = 0; c < PW - 1; c++) y[j0 + c] = xp[c];
-      for (int i = tid; i < j0; i += 256) {
-        double v = y[i];
-#pragma unroll
-        for (int c = PW - 1; c >= 0; c--) v -= LA(j0 + c, i) * xp[c];
-        y[i] = v;
-      }
-      __syncthreads();
-    }
-  } else {
-    for (int i = tid; i < n; i += 256) y[i] = 0;
-    __syncthreads();
-  }
-#undef LA
-  lba_apply_step(D, y, lambda, ok, out[w], s_red, tid);
 }
 
 __device__ __forceinline__ double big_readlane(double v, int srclane) {
@@ -1461,6 +1343,229 @@ k_lba_ldlt16(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
 #pragma unroll
         for (int q = 0; q < 16; q++) v -= blk[q * kLdP] * y[(kb + 1) * 16 + q];
         y[j] = v;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int i = tid; i < n; i += NT) y[i] = 0;
+    __syncthreads();
+  }
+  lba_apply_step<NT>(D, y, lambda, ok, out[w], s_red, tid);
+}
+
+// ---- the same solve for reduced systems of 160 .. 639 unknowns (a bLarge window: 25 key frames x 15 = 375; a vision-only
+// window of up to 106 key frames), one workgroup per window.  The lower triangle no longer fits LDS (567 KB at 375), so
+// the factor lives in global memory -- L2-resident, 1.2 MB -- as 16 x 16 blocks stored COLUMN-major: lane l of a
+// v_mfma_f64_16x16x4_f64 operand is element [l & 15][4 ks + (l >> 4)] of its block, i.e. double ks * 64 + l, so every
+// operand load of a wavefront is one contiguous 512-byte read.  LEFT-looking by block column k:
+//   gather     A_ik - sum_{j<k} W_ij L_kj^T for the row blocks i >= k: a chain of 4 k MFMAs per block with the
+//              accumulator in registers (nothing is written back until the block is final; the right-looking form
+//              would read and write every trailing block at every step).  What bounds it is the L2 round trip per
+//              operand group, so a wavefront takes up to three row blocks at a time and shares the L_kj operands
+//              between them; results go to LDS in row layout
+//   diagonal   wavefront 0 gathers A_kk alone and factorises it in registers while the others still gather (row per
+//              lane, v_readlane broadcasts)
+//   panel      one thread per row below: W = A L_kk^-T (un-normalised) and L = W D_k^-1 -> global, column-major blocks
+// Row n of the bordered matrix [H b; b^T 1] carries the right-hand side (forward substitution for free); L^T x = z from
+// the bottom block up as in k_lba_ldlt16.  Same-workgroup visibility of the global writes: the wavefronts of a
+// workgroup share the CU's vector L1 (write-through), so the barrier's workgroup-scope fence is enough.
+// It replaces the multi-workgroup tiled solve for this size class (6 x k_big_panel + 5 x k_big_syrk + 6 x k_big_back_step
+// per trial: 1.1 ms for the 51 bLarge windows of a bench step) and the column-panel kernel crawling in L2 (2.4 ms).
+static const int kLdGMaxBlocks = 40, kLdGThreads = 512;
+static size_t ldg_lds_bytes(int nbm) { return ((size_t)(nbm + 1) * kLdBlk + 16 + (size_t)nbm * 16) * 8; }
+static size_t ldg_scratch_doubles(int nbm) { return (size_t)nbm * (nbm + 1) / 2 * 256 * 2; }
+
+// element (row, col), col <= row's block, of the bordered matrix [H b; b^T 1] with identity padding
+__device__ __forceinline__ double ldg_bordered(const LbaDev& D, int n, int row, int col) {
+  if (row < n) return col < n ? D.Hs[(size_t)row * n + col] : 0.0;
+  if (row == n) return col < n ? D.bs[col] : (col == n ? 1.0 : 0.0);
+  return row == col ? 1.0 : 0.0;
+}
+
+// CNT row blocks i0, i0 + step, ... of block column k: A_ik - sum_{j<k} W_ij L_kj^T -> sP (row layout).  Four j per
+// round trip to L2: the 16 operand loads of L_kj serve all CNT blocks, the CNT x 16 of W_ij go out with them, then
+// 16 CNT MFMAs on 2 CNT independent accumulators.
+template <int CNT>
+__device__ __forceinline__ void ldg_gather(const LbaDev& D, int n, int k, int i0, int step, const double* Wg,
+                                           const double* Lg, double* sP, int lane) {
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  double4_t acc[CNT][2];
+  const double* pw[CNT];
+#pragma unroll
+  for (int c = 0; c < CNT; c++) {
+    const int i = i0 + c * step;
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[c][0][q] = ldg_bordered(D, n, i * 16 + (lane >> 4) + 4 * q, k * 16 + (lane & 15));
+    acc[c][1] = (double4_t){0, 0, 0, 0};
+    pw[c] = Wg + (size_t)(i * (i + 1) / 2) * 256 + lane;
+  }
+  const double* pl = Lg + (size_t)(k * (k + 1) / 2) * 256 + lane;
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    double b[16], a[CNT][16];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool in = j0 + u < k;
+      const size_t o = (size_t)(in ? j0 + u : 0) * 256;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        b[u * 4 + ks] = in ? pl[o + ks * 64] : 0.0;
+#pragma unroll
+        for (int c = 0; c < CNT; c++) a[c][u * 4 + ks] = in ? pw[c][o + ks * 64] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int c = 0; c < CNT; c++)
+          acc[c][u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[c][u * 4 + ks], b[u * 4 + ks], acc[c][u & 1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int c = 0; c < CNT; c++) {
+    double* C = sP + (size_t)(i0 + c * step) * kLdBlk + (lane >> 4) * kLdP + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < 4; q++) C[q * 4 * kLdP] = acc[c][0][q] + acc[c][1][q];
+  }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_lba_ldltg(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out, int nb_max) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  __shared__ double s_red[4];
+  __shared__ int s_bad;
+  constexpr int NW = NT / 64;
+  const int w = blockIdx.x;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  if (D.solver != 1) return;
+  const int n = D.np, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: MFMA blocks are branched over, not masked
+  if (n == 0) {
+    if (tid == 0) out[w].ok = 1, out[w].scale_p = 0;
+    return;
+  }
+  const double lambda = win_lambda(ctl[w], out[w]);
+  const int nb = (n + 16) >> 4;  // blocks of the bordered matrix, n + 1 rows
+  double* sP = s_dyn;                         // [nb] the block column after the gather, row layout, pitch kLdP
+  double* sKK = sP + (size_t)nb_max * kLdBlk;  // L_kk (unit lower)
+  double* sD = sKK + kLdBlk;                   // 1 / d of the block's pivots
+  double* y = sD + 16;
+  double* Wg = D.Hb;                                           // un-normalised W = L D, blocks (i, j), j <= i
+  double* Lg = Wg + (size_t)D.nb * (D.nb + 1) / 2 * 256;      // L (D.nb: block capacity of the window)
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  bool ok = true;
+  for (int k = 0; k < nb; k++) {
+    // ---- gather: wavefront 0 takes the diagonal block alone and factorises it at once; the others share the row
+    // blocks below, up to three at a time with the L_kj operands loaded once for all of them
+    if (wv == 0) {
+      ldg_gather<1>(D, n, k, k, 0, Wg, Lg, sP, lane);
+      // ---- diagonal block: A_kk = L D L^T in the registers of wavefront 0 (lanes 16..63 mirror lanes 0..15 so
+      // that the readlanes stay wave-uniform); its own LDS traffic is in order
+      const double* Akk = sP + (size_t)k * kLdBlk;
+      const int r = lane & 15;
+      double a[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[c] = Akk[r * kLdP + c];
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const double d = big_readlane(a[c], c);
+        if (!(d > 0) && k * 16 + c < n) bad = true;  // the right-hand-side row and the padding are not pivots
+        double inv = __builtin_amdgcn_rcp(d);
+        inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+        inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+        const double l = a[c] * inv;
+#pragma unroll
+        for (int q = c + 1; q < 16; q++) a[q] -= l * big_readlane(a[c], q);  // w_q = A[q][c], un-normalised
+        if (r > c) a[c] = l;
+        if (r == c) a[c] = inv;
+      }
+      if (lane < 16) {
+        double* Lkk = Lg + (size_t)(k * (k + 1) / 2 + k) * 256;
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          if (c < r) sKK[r * kLdP + c] = a[c], Lkk[c * 16 + r] = a[c];
+          if (c == r) sD[c] = a[c];
+        }
+        if (bad) s_bad = 1;
+      }
+    } else {
+      for (int i0 = k + wv; i0 < nb; i0 += 3 * (NW - 1)) {
+        const int cnt = (nb - i0 + NW - 2) / (NW - 1);  // row blocks i0, i0 + NW - 1, ... below nb
+        if (cnt >= 3)
+          ldg_gather<3>(D, n, k, i0, NW - 1, Wg, Lg, sP, lane);
+        else if (cnt == 2)
+          ldg_gather<2>(D, n, k, i0, NW - 1, Wg, Lg, sP, lane);
+        else
+          ldg_gather<1>(D, n, k, i0, NW - 1, Wg, Lg, sP, lane);
+      }
+    }
+    __syncthreads();
+    if (s_bad) {
+      ok = false;
+      break;
+    }
+    // ---- panel: one thread per row below the diagonal block
+    for (int t = tid; t < (nb - k - 1) * 16; t += NT) {
+      const int i = k + 1 + (t >> 4), r = t & 15;
+      const double* src = sP + (size_t)i * kLdBlk + r * kLdP;
+      double a[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[c] = src[c];
+      // W L_kk^T = A: W[c] = A[c] - sum_{m < c} W[m] L_kk[c][m]   (LDS reads are broadcasts)
+#pragma unroll
+      for (int c = 1; c < 16; c++) {
+        double v = a[c];
+#pragma unroll
+        for (int m = 0; m < c; m++) v -= a[m] * sKK[c * kLdP + m];
+        a[c] = v;
+      }
+      double* wg = Wg + (size_t)(i * (i + 1) / 2 + k) * 256 + r;
+      double* lg = Lg + (size_t)(i * (i + 1) / 2 + k) * 256 + r;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        wg[c * 16] = a[c];
+        lg[c * 16] = a[c] * sD[c];
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (ok) {
+    // z = D^-1 L^-1 b is row n of the factor; L^T x = z from the bottom block up
+    const int bn = n >> 4, rn = n & 15;
+    for (int i = tid; i < nb * 16; i += NT)
+      y[i] = i < n ? Lg[(size_t)(bn * (bn + 1) / 2 + (i >> 4)) * 256 + (i & 15) * 16 + rn] : 0.0;
+    __syncthreads();
+    const int top = (n - 1) >> 4;
+    for (int kb = top; kb >= 0; kb--) {
+      if (wv == 0) {
+        const int r = lane & 15, j = kb * 16 + r;
+        double s = y[j];
+        if (kb < top) {
+          const double* blk = Lg + (size_t)((kb + 1) * (kb + 2) / 2 + kb) * 256 + r * 16;
+#pragma unroll
+          for (int q = 0; q < 16; q++) s -= blk[q] * y[(kb + 1) * 16 + q];  // entries >= n are zero
+        }
+        const double* Lkk = Lg + (size_t)(kb * (kb + 1) / 2 + kb) * 256 + r * 16;
+        double Lc[16];
+#pragma unroll
+        for (int rr = 1; rr < 16; rr++) Lc[rr] = (r < rr && kb * 16 + rr < n) ? Lkk[rr] : 0.0;
+#pragma unroll
+        for (int rr = 15; rr >= 1; rr--) s -= Lc[rr] * big_readlane(s, rr);
+        if (lane < 16 && j < n) y[j] = s;
+      } else if (kb < top) {
+        for (int j = tid - 64; j < kb * 16; j += NT - 64) {
+          const double* blk = Lg + (size_t)((kb + 1) * (kb + 2) / 2 + (j >> 4)) * 256 + (j & 15) * 16;
+          double v = y[j];
+#pragma unroll
+          for (int q = 0; q < 16; q++) v -= blk[q] * y[(kb + 1) * 16 + q];
+          y[j] = v;
+        }
       }
       __syncthreads();
     }
@@ -1894,7 +1999,7 @@ static size_t shard_sys_doubles(int nf, int sc = 0) {
 // rank of a landmark-sharded run.
 
 // reduced systems beyond one workgroup's LDL^T take the tiled solve (VIEO_LBA_BIG_SOLVE=1 forces it: tests)
-static const int kSmallSolveMax = 510, kBigSolveMax = 16320;
+static const int kSmallSolveMax = 16 * kLdGMaxBlocks - 1, kBigSolveMax = 16320;
 // ---- optional kernel-class timing (vieo_lba_enable_timing): HIP events around every launch on the BA stream, folded
 // into process-wide totals after each round's synchronisation.  bench.py reads them for the roofline of the whole path.
 enum LbaKClass { KC_BUILD, KC_GENERIC, KC_SCHUR, KC_ASSEMBLE, KC_LDLT, KC_UPDATE, KC_ERROR, KC_BEGIN, KC_OTHER, KC_N };
@@ -1966,23 +2071,16 @@ static bool big_solve(int n) {
   return forced > 0 || n > kSmallSolveMax;
 }
 
-// The solve kernel of a window with n unknowns (sco: with the scale vertex, whose odd size the column-panel kernel
-// cannot take).  Windows of different classes share a lock-step batch: every class's kernel is launched and skips the
-// others' windows (a bLarge window of 25 key frames next to ordinary ones of 10 is the usual LocalMapping mix).
+// The solve kernel of a window with n unknowns.  Windows of different classes share a lock-step batch: every class's
+// kernel is launched (when one of its windows takes a trial this round) and skips the others' windows (a bLarge
+// window of 25 key frames next to ordinary ones of 10 is the usual LocalMapping mix).
 //   0  k_lba_ldlt16   n <= 159: blocked on the matrix cores, whole triangle in LDS
-//   1  k_lba_ldlt     n <= kPanelLdsMax: column panels, packed triangle in LDS (VIEO_LBA_PANEL_MAX raises the limit;
-//                     beyond the LDS size it factorises in L2, one workgroup crawling: 2.4 ms at 375 unknowns)
-//   2  k_big_*        the tiled LDL^T over many workgroups
-static const int kPanelLdsMax = 186;
-static int solver_class(int n, int sco) {
-  static const int panel_max = [] {
-    const char* e = getenv("VIEO_LBA_PANEL_MAX");
-    return e ? atoi(e) : kPanelLdsMax;
-  }();
+//   1  k_lba_ldltg    n <= 639: one workgroup, left-looking, the factor in L2 as column-major 16 x 16 blocks
+//   2  k_big_*        the tiled LDL^T over many workgroups (full BA: hundreds of key frames)
+static int solver_class(int n) {
   if (big_solve(n)) return 2;
-  if (((n + 16) >> 4) <= kLd16MaxBlocks && (sco || !ldlt16_disabled())) return 0;
-  if (sco) return 2;
-  return n <= panel_max ? 1 : 2;
+  if (((n + 16) >> 4) <= kLd16MaxBlocks && !ldlt16_disabled()) return 0;
+  return 1;
 }
 
 // Optimizer::BundleAdjustment / GlobalBundleAdjustmentNavStatePRV (Optimizer.cc:1353-1609, 771-1345) on the same
@@ -2277,8 +2375,11 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     s.Hpp = take((size_t)std::max(nf, 1) * 36 * 8), s.Hs = take((size_t)npf * npf * 8);
     s.nb = (npf + 1 + kNB - 1) / kNB * kNB;  // + the right-hand-side row
     s.Hb = s.Wp = s.big_fail = 0;
-    if (solver_class(npf, sco) == 2) {
+    if (solver_class(npf) == 2) {
       s.Hb = take((size_t)s.nb * s.nb * 8), s.Wp = take((size_t)s.nb * kNB * 8), s.big_fail = take(256);
+    } else if (solver_class(npf) == 1) {
+      s.nb = (npf + 16) >> 4;  // 16 x 16 blocks of the bordered matrix
+      s.Hb = take(ldg_scratch_doubles(s.nb) * 8);
     }
     s.bp = take((size_t)npm * 8), s.bs = take((size_t)npf * 8), s.xp = take((size_t)npf * 8);
     s.bfull = take((size_t)npf * 8);
@@ -2315,7 +2416,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.dMono = (double)(float)sqrt(gba ? 5.99 : 5.991), D.dStereo = (double)(float)sqrt(7.815);
     D.pd = pd, D.n_imu = H.n_imu;
     D.scale_opt = sco;
-    D.solver = solver_class(npf, sco);
+    D.solver = solver_class(npf);
     if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
       D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
       memcpy(D.gw, H.VP->gw, 24);
@@ -2542,13 +2643,11 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   for (int w = 0; w < W; w++)
     if (!win[w].skip) cls_max[devs[w].solver] = std::max(cls_max[devs[w].solver], pd * devs[w].nf_cap + sco);
   const bool big = cls_max[2] > 0, ldlt16 = cls_max[0] > 0, panels = cls_max[1] > 0;
-  const int n_max_p = cls_max[1], n_max_b = cls_max[2];
-  const size_t ldlt_small = (size_t)8 * n_max_p * 8;  // panel columns, rhs, pivots
-  const size_t tri = (size_t)n_max_p * (n_max_p + 1) / 2 * 8;  // packed lower triangle
-  const int use_lds = tri + ldlt_small <= 150 * 1024;
-  const size_t ldlt_lds = ldlt_small + (use_lds ? tri : 0);
-  const void* ldlt_fn = vio ? (const void*)k_lba_ldlt<5> : (const void*)k_lba_ldlt<6>;
-  if (panels) VIEO_HIP_CHECK(hipFuncSetAttribute(ldlt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
+  const int n_max_b = cls_max[2];
+  const int nbg = (cls_max[1] + 16) >> 4;
+  if (panels)
+    VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldltg<kLdGThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)ldg_lds_bytes(nbg)));
   const int nb16 = (cls_max[0] + 16) >> 4;
   if (ldlt16)
     VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba_ldlt16<kLd16Threads>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2583,6 +2682,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     n_rounds++;
     const bool stop_now = stop && *stop;
     int any = 0;
+    bool cls_trial[3] = {false, false, false};  // which solve kernels have a window this round
     for (int w = 0; w < W; w++) {
       WinHost& H = win[w];
       int f = 0;
@@ -2611,6 +2711,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       }
       ctl[w].flags = f, ctl[w].pad = 0, ctl[w].lambda = lam;
       any |= f;
+      if ((f & LBA_TRIAL) && !H.skip) cls_trial[devs[w].solver] = true;
     }
     if (!any) break;
     VIEO_HIP_CHECK(hipMemcpyAsync(dC, ctl, (size_t)W * sizeof(WinCtl), hipMemcpyHostToDevice, st));
@@ -2648,7 +2749,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         if ((rc = shard_exchange(sh, sh->d_buf, shard_sys, st)) != VIEO_OK) return rc;
       }
       KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO); });
-      if (big) {
+      if (big && cls_trial[2]) {
         const int nbm = (n_max_b + 1 + kNB - 1) / kNB * kNB, ntm = nbm / kNB;
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_init, dim3((unsigned)(((size_t)nbm * nbm + 255) / 256), W), dim3(256), 0, st, dD, dC); });
         for (int k = 0; k < ntm; k++) {
@@ -2660,12 +2761,10 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
           KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_back_step, dim3(1 + (n_max_b + 255) / 256, W), dim3(256), 0, st, dD, dC, sb); });
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_finish, dim3(W), dim3(256), 0, st, dD, dC, dO); });
       }
-      if (ldlt16)
+      if (ldlt16 && cls_trial[0])
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt16<kLd16Threads>, dim3(W), dim3(kLd16Threads), ld16_lds_bytes(nb16), st, dD, dC, dO, nb16); });
-      if (panels && vio)
-        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt<5>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max_p); });
-      else if (panels)
-        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt<6>, dim3(W), dim3(256), ldlt_lds, st, dD, dC, dO, use_lds, n_max_p); });
+      if (panels && cls_trial[1])
+        KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldltg<kLdGThreads>, dim3(W), dim3(kLdGThreads), ldg_lds_bytes(nbg), st, dD, dC, dO, nbg); });
       KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO); });
       KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1); });
       if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1); });
