@@ -541,7 +541,7 @@ def main():
     lba_ms.clear()
     P.enable_timing(True)
     P.ext.enable_timing(True)
-    Optimizer.enable_kernel_timing(True)
+    Optimizer.enable_kernel_timing(2 if os.environ.get("VIEO_BENCH_LBA_COUNT_ONLY") else True)
     sync_all()
     t0 = time.perf_counter()
     futs = []

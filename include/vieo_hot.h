@@ -738,7 +738,8 @@ size_t vieo_lba_sharded_buffer_doubles(int n_windows, const int* n_free_kf);
 /* Measurement hook of the bundle-adjustment engine (no reference counterpart): with timing on, every kernel launch
  * of the local / full BA entries is bracketed by HIP events on the engine's own stream and folded into process-wide
  * totals per kernel class (vieo_lba_kernel_class_name: "lba.build", "lba.schur", ...).  enable(on) also clears the
- * totals.  schur_flops: dense FLOPs 2 np (np + 1) 3 n_mp of the windows the timed k_lba_schur launches worked on. */
+ * totals; on == 2 counts the launches (and the Schur FLOPs) per class without recording events, for a timed region
+ * that must not carry the events' markers on the stream.  schur_flops: dense FLOPs 2 np (np + 1) 3 n_mp of the windows the timed k_lba_schur launches worked on. */
 void vieo_lba_enable_timing(int on);
 int vieo_lba_kernel_classes(void);
 const char* vieo_lba_kernel_class_name(int i);

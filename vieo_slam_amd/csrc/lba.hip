@@ -11,13 +11,14 @@
 //   k_lba_error      edge-parallel residuals + robust chi2 (per-block partial sums)
 //   k_lba_build      buildSystem: one thread per point over its observations (H_ll, b_l); one
 //                    workgroup per free key frame over its edge list (H_pp, b_p) which also writes the
-//                    key frame's rows of the dense matrix BB [6 x free key frames][3 x points],
-//                    B = Jp^T W Jx per edge, zero where a key frame does not see a point
+//                    6 x 3 blocks B = Jp^T W Jx of its edges, COMPACT: one 144-byte block per observation
+//                    (CB[edge]); `tab` maps (free key frame, point) to the edge that carries the block
 //   k_lba_lambda     computeLambdaInit (tau * max diagonal) for windows starting an optimize()
 //   k_lba_schur      the Schur complement as what it is, a GEMM: (BB D^-1) x [BB; b_l]^T with
 //                    D = blockdiag(H_ll + lambda I), K = 3 x points split over workgroups, 64x64 output
-//                    tiles on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), D^-1 applied while the
-//                    K-chunk is staged through LDS; per-split partial products
+//                    tiles on the FP64 matrix cores (v_mfma_f64_16x16x4_f64); the dense operand tiles exist
+//                    only in LDS: a K-chunk is staged from the compact blocks through `tab` (zeros where a key
+//                    frame does not see a point), D^-1 applied on the way; per-split partial products
 //   k_lba_assemble   Hs = H_pp + lambda I - sum of the partials (fixed order), bs likewise
 //   k_lba_ldlt16     one workgroup per window: blocked LDL^T (FP64 MFMA) of the reduced system in LDS, solve, pose
 //                    retraction (with backup) and the pose part of the gain-ratio scale
@@ -102,7 +103,7 @@ struct LbaDev {
   double gw[3];
   double th_dist_far;             // > 0: the far-point rule of the visual-inertial local BA is on
   double qRbe[4], pbe[3];         // body <- encoder extrinsics of the encoder edges
-  int ldB, ldS;                   // leading dimensions of BB (3 x points, padded) and of a partial
+  int ldS;                        // leading dimension of a partial Schur product
   int* kf_list;                   // [n_free] free + active key frames in column order
   int* kf_act;                    // [n_kf] scratch of k_lba_begin: the key frame has an active edge
   const int *kf_edge_first, *kf_edge_idx;  // edges grouped by key frame
@@ -112,12 +113,14 @@ struct LbaDev {
   double* err;                    // [n_obs][3]
   unsigned char *level, *erase, *mp_act;
   const int *mp_first, *mp_count;  // [n_mp]
-  double* BB;                     // [6 nf_cap][ldB]
+  double* CB;                     // [n_obs][18] B = Jp^T W Jx of an edge (6 x 3, row-major); valid where `tab` points
+  double* Bs;                     // [n_mp][3] the scale vertex's row (bScaleOpt): it sees every point
   double* Sp;                     // [ksplit][sp_rows][ldS] partial Schur products
   size_t sp_stride;
   int ksplit;                     // K splits of this window's Schur GEMM (a function of the window alone)
   double *Hll, *bl, *Hpp, *bp, *Hs, *bs, *xp;
   unsigned char* occ;             // [(npv + 64) / 64][chunks of 16 landmarks]: the row tile has an edge in the chunk
+  int use_occ;                    // full BA only: a local window is dense at that granularity, its Schur GEMM does not look
   double *Hb, *Wp;                // tiled solve of a large reduced system: padded copy [nb][nb], panel [nb][64]
   int* big_fail;                  //   and its "not positive definite" flag
   int nb;
@@ -288,15 +291,14 @@ k_lba_prelevel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
   if (chi2 > (double)th) D.level[i] = 1;
 }
 
-// BB = 0, tab = -1 for the windows that start an optimize()
+// tab = -1 for the windows that start an optimize()
 __global__ void __launch_bounds__(256)
 k_lba_zero(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_BEGIN)) return;
   const LbaDev& D = devs[w];
-  const size_t nb = ((size_t)6 * D.nf_cap + (D.scale_opt ? 1 : 0)) * D.ldB, nt = (size_t)D.nf_cap * D.n_mp;
+  const size_t nt = (size_t)D.nf_cap * D.n_mp;
   const size_t step = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += step) D.BB[i] = 0.0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nt; i += step) D.tab[i] = -1;
 }
 
@@ -528,7 +530,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
 #pragma unroll
       for (int t = 0; t < 5; t++) asc[t] = quad_sum_f64(asc[t]);
       if (m < D.n_mp && sub == 0) {  // the scale's row of BB: zero for a point without an active edge
-        double* B = D.BB + (size_t)(D.npv - 1) * D.ldB + 3 * (size_t)m;
+        double* B = D.Bs + 3 * (size_t)m;
         B[0] = asc[0], B[1] = asc[1], B[2] = asc[2];
       }
       double v[2] = {sub == 0 ? asc[3] : 0.0, sub == 0 ? asc[4] : 0.0};
@@ -555,7 +557,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   const double sc = scl ? D.scl[0] : 1.0;
   PoseXf X;
   kf_xf(D.cam, k, X);  // one camera: the transform is the same for all edges of the key frame
-  double* Brow = D.BB + (size_t)(6 * a) * D.ldB;
+  const int* tab_a = D.tab + (size_t)a * D.n_mp;
   for (int j = threadIdx.x; j < cnt; j += 256) {
     const int i = D.kf_edge_idx[first + j];
     const vieo_lba_obs o = D.obs[i];
@@ -600,29 +602,41 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
         for (int b = 0; b < 3; b++)
           Bk[q * 3 + b] = Jp[q] * ww * Jx[b] + Jp[6 + q] * ww * Jx[3 + b] + Jp[12 + q] * ww * Jx[6 + b];
     }
+    // the (key frame, point) block lives at the edge `tab` points to; with several cameras per key frame that edge
+    // sums the run of the pair's edges (adjacent in the list) in list order
     bool write = active;
     if (MULTICAM && D.n_cams) {
-      // edges of one (key frame, point) pair are adjacent in the list: the first one sums the run
-      if (j > 0 && D.obs[D.kf_edge_idx[first + j - 1]].mp == o.mp)
-        write = false;
-      else
-        for (int jj = j + 1; jj < cnt; jj++) {
+      write = false;
+      if (tab_a[o.mp] == i) {
+        int js = j;
+        while (js > 0 && D.obs[D.kf_edge_idx[first + js - 1]].mp == o.mp) js--;
+        double Bsum[18];
+#pragma unroll
+        for (int t = 0; t < 18; t++) Bsum[t] = 0;
+        bool first_term = true;
+        for (int jj = js; jj < cnt; jj++) {
           const int i2 = D.kf_edge_idx[first + jj];
           if (D.obs[i2].mp != o.mp) break;
           if (D.level[i2]) continue;
           double B2[18];
-          lba_edge_B(D, i2, k, robust, B2);
+          if (jj == j) {
 #pragma unroll
-          for (int t = 0; t < 18; t++) Bk[t] += B2[t];
+            for (int t = 0; t < 18; t++) B2[t] = Bk[t];
+          } else
+            lba_edge_B(D, i2, k, robust, B2);
+#pragma unroll
+          for (int t = 0; t < 18; t++) Bsum[t] = first_term ? B2[t] : Bsum[t] + B2[t];
+          first_term = false;
           write = true;
         }
+#pragma unroll
+        for (int t = 0; t < 18; t++) Bk[t] = Bsum[t];
+      }
     }
     if (write) {
-      double* B = Brow + 3 * (size_t)o.mp;
+      double* B = D.CB + 18 * (size_t)i;
 #pragma unroll
-      for (int q = 0; q < 6; q++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) B[(size_t)q * D.ldB + b] = Bk[q * 3 + b];
+      for (int t = 0; t < 18; t++) B[t] = Bk[t];
     }
   }
   block_sum<27>(acc, s_red, threadIdx.x);
@@ -701,6 +715,9 @@ k_lba_lambda(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
 // block-tiles only), K = 3 x points cut into chunks of 16 points; grid x = block-tile * ksplit + split.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 static const int kChunkLm = 16, kLd = 3 * kChunkLm + 2;  // +2: conflict-free b64 fragment reads
+#ifndef VIEO_SCHUR_AB
+#define VIEO_SCHUR_AB 0  // timing experiments only (wrong results): 1 no MFMAs, 2 no LDS staging, 4 no block loads
+#endif
 
 // Which 16-landmark chunks a 64-row tile of BB touches (from `tab`, rebuilt at every optimize()): the Schur
 // GEMM skips the all-zero ones -- a map of hundreds of key frames is block-sparse, a local window is dense.
@@ -709,6 +726,7 @@ k_lba_occ(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_BEGIN)) return;
   const LbaDev& D = devs[w];
+  if (!D.use_occ) return;
   const int np = D.npv, CB = (np + 64) >> 6, nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (np == 0 || e >= CB * nchunks) return;
@@ -726,7 +744,7 @@ k_lba_occ(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   D.occ[e] = (unsigned char)any;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)  // three wavefronts per SIMD = the three workgroups a CU's LDS holds
 k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) double sT[64 * kLd];
   __shared__ __attribute__((aligned(16))) double sB[64 * kLd];
@@ -749,7 +767,6 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   if (c0 >= c1) return;  // k_lba_assemble uses the same split arithmetic
   const double lambda = win_lambda(ctl[w], out[w]);
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const size_t ldB = D.ldB;
   const int n_mp = D.n_mp;
   double4_t acc[4];
 #pragma unroll
@@ -758,44 +775,56 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   const unsigned char* occ_j = D.occ + (size_t)bj * nchunks;
   const bool has_bl = np >= bj * 64 && np < bj * 64 + 64;  // this column tile carries b_l: dense
   // the chunks this workgroup works on: a zero factor adds nothing (workgroup-uniform)
+  // (local windows: every chunk -- the flag bytes would be one more dependent global load per chunk)
+  const bool use_occ = D.use_occ != 0;
   auto next_chunk = [&](int ch) {
-    while (ch < c1 && (!occ_i[ch] || (!has_bl && !occ_j[ch]))) ch++;
+    if (use_occ)
+      while (ch < c1 && (!occ_i[ch] || (!has_bl && !occ_j[ch]))) ch++;
     return ch;
   };
-  // Software pipeline over the chunks: the operands of chunk c + 1 (the two 64 x 48 slabs of BB, 12 + 12 doubles per
-  // thread, and H_ll of its 16 landmarks on the first 16 threads) are loaded into registers before the MFMAs of chunk
-  // c are issued, (H_ll + lambda I)^-1 of chunk c + 1 is formed after them into the other half of sDi; per chunk the
-  // workgroup then pays two barriers, the LDS stores and 48 MFMAs per wavefront instead of two global round trips.
-  const int r_it = tid >> 4, j_it = tid & 15;  // item it of a thread: row r_it + 16 it, landmark j_it of the chunk
-  double ta[12], tb[12], hl[9];
-  auto load_chunk = [&](int ch) {
-    const int m = ch * kChunkLm + j_it;
+  // Staging.  The operand tiles T = (BB D^-1)[rows of tile bi] and B = [BB; b_l][rows of tile bj], 64 x 48 per chunk
+  // of 16 landmarks, exist only in LDS.  One thread per (key-frame slot of the tile, landmark of the chunk) pair --
+  // 12 slots cover the 64 rows whatever 6 a mod 64 is -- looks the pair's edge up in `tab` and writes its 6 x 3 block
+  // or zeros: nothing to clear, two barriers per chunk.  The slot after the last free key frame carries the scale
+  // vertex's row (bScaleOpt) and, on the B side, the extra column b_l.
+  // Software pipeline: the blocks of chunk c + 1 (18 + 18 doubles per thread, and H_ll of its 16 landmarks on the first
+  // 16 threads) are loaded into registers before the MFMAs of chunk c are issued, their `tab` entries one chunk earlier
+  // still; (H_ll + lambda I)^-1 of chunk c + 1 is formed after the MFMAs into the other half of sDi.
+  const int ps = tid >> 4, pj = tid & 15;
+  const bool pair_thr = tid < 192;
+  const int nfree = D.n_free, q_bl = D.scale_opt ? 1 : 0;
+  const int aT = (64 * bi) / 6 + ps, aB = (64 * bj) / 6 + ps;
+  const int rT = 6 * aT - 64 * bi, rB = 6 * aB - 64 * bj;  // tile row of the pair's first row (-5 .. 66)
+  auto tab_of = [&](int a, int ch) -> int {
+    const int m = ch * kChunkLm + pj;
+    return (pair_thr && ch < c1 && a < nfree && m < n_mp) ? D.tab[(size_t)a * n_mp + m] : -1;
+  };
+  auto load_blk = [&](int a, int e, int ch, double* v) {
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int r = r_it + 16 * it, gr = bi * 64 + r, gc = bj * 64 + r;
-      double b0 = 0, b1 = 0, b2 = 0;
-      if (gr < np) {
-        const double* p = D.BB + (size_t)gr * ldB + 3 * (size_t)m;
-        b0 = p[0], b1 = p[1], b2 = p[2];
-      }
-      ta[3 * it] = b0, ta[3 * it + 1] = b1, ta[3 * it + 2] = b2;
-      if (bj != bi) {
-        b0 = b1 = b2 = 0;
-        if (gc < np) {
-          const double* p = D.BB + (size_t)gc * ldB + 3 * (size_t)m;
-          b0 = p[0], b1 = p[1], b2 = p[2];
+    for (int t = 0; t < 18; t++) v[t] = 0.0;
+    if (!pair_thr) return;
+    const int m = ch * kChunkLm + pj;
+    if (a < nfree) {
+      if (e >= 0 && !(VIEO_SCHUR_AB & 4)) {
+        const double2* p = (const double2*)(D.CB + 18 * (size_t)e);
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+          const double2 x = p[t];
+          v[2 * t] = x.x, v[2 * t + 1] = x.y;
         }
       }
-      if (gc == np) {  // the extra column: b_l
-        b0 = b1 = b2 = 0;
-        if (m < n_mp && D.mp_act[m]) {
-          const double* p = D.bl + 3 * (size_t)m;
-          b0 = p[0], b1 = p[1], b2 = p[2];
-        }
+    } else if (a == nfree && m < n_mp) {
+      if (D.scale_opt) v[0] = D.Bs[3 * (size_t)m], v[1] = D.Bs[3 * (size_t)m + 1], v[2] = D.Bs[3 * (size_t)m + 2];
+      if (D.mp_act[m]) {
+        const double* q = D.bl + 3 * (size_t)m;  // (no runtime index into v: it must stay in registers)
+        if (q_bl)
+          v[3] = q[0], v[4] = q[1], v[5] = q[2];
+        else
+          v[0] = q[0], v[1] = q[1], v[2] = q[2];
       }
-      tb[3 * it] = b0, tb[3 * it + 1] = b1, tb[3 * it + 2] = b2;
     }
   };
+  double ta[18], tb[18], hl[9];
   bool hl_act = false;
   auto load_hll = [&](int ch) {  // threads 0..15
     const int m = ch * kChunkLm + tid;
@@ -811,43 +840,82 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
 #pragma unroll
     for (int t = 0; t < 9; t++) sDi[buf][tid * 9 + t] = Di[t];
   };
+  const bool offdiag = bj != bi;
   int ch = next_chunk(c0), buf = 0;
+  int nx = ch < c1 ? next_chunk(ch + 1) : c1;
+  int eT = -1, eB = -1;
   if (ch < c1) {
-    load_chunk(ch);
+    load_blk(aT, tab_of(aT, ch), ch, ta);
+    if (offdiag) load_blk(aB, tab_of(aB, ch), ch, tb);
+    eT = tab_of(aT, nx);
+    if (offdiag) eB = tab_of(aB, nx);
     if (tid < kChunkLm) load_hll(ch), store_dinv(0);
   }
   while (ch < c1) {
     __syncthreads();  // the previous chunk's fragments have been read; sDi[buf] is complete
-    {
-      const double* Di = sDi[buf] + j_it * 9;
+    if (pair_thr && !(VIEO_SCHUR_AB & 2)) {
+      const double* Di = sDi[buf] + pj * 9;
       const double d0 = Di[0], d1 = Di[1], d2 = Di[2], d3 = Di[3], d4 = Di[4], d5 = Di[5], d6 = Di[6], d7 = Di[7], d8 = Di[8];
 #pragma unroll
-      for (int it = 0; it < 4; it++) {
-        const int r = r_it + 16 * it;
-        const double b0 = ta[3 * it], b1 = ta[3 * it + 1], b2 = ta[3 * it + 2];
-        sT[r * kLd + 3 * j_it + 0] = b0 * d0 + b1 * d3 + b2 * d6;
-        sT[r * kLd + 3 * j_it + 1] = b0 * d1 + b1 * d4 + b2 * d7;
-        sT[r * kLd + 3 * j_it + 2] = b0 * d2 + b1 * d5 + b2 * d8;
-        sB[r * kLd + 3 * j_it + 0] = tb[3 * it], sB[r * kLd + 3 * j_it + 1] = tb[3 * it + 1], sB[r * kLd + 3 * j_it + 2] = tb[3 * it + 2];
+      for (int q = 0; q < 6; q++) {
+        const int r = rT + q;
+        if (r >= 0 && r < 64) {
+          double b0 = ta[3 * q], b1 = ta[3 * q + 1], b2 = ta[3 * q + 2];
+          if (aT == nfree && q == q_bl) b0 = b1 = b2 = 0.0;  // b_l is a column of the right factor only
+          sT[r * kLd + 3 * pj + 0] = b0 * d0 + b1 * d3 + b2 * d6;
+          sT[r * kLd + 3 * pj + 1] = b0 * d1 + b1 * d4 + b2 * d7;
+          sT[r * kLd + 3 * pj + 2] = b0 * d2 + b1 * d5 + b2 * d8;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const int r = rB + q;
+        if (r >= 0 && r < 64) {
+          sB[r * kLd + 3 * pj + 0] = offdiag ? tb[3 * q] : ta[3 * q];
+          sB[r * kLd + 3 * pj + 1] = offdiag ? tb[3 * q + 1] : ta[3 * q + 1];
+          sB[r * kLd + 3 * pj + 2] = offdiag ? tb[3 * q + 2] : ta[3 * q + 2];
+        }
       }
     }
     __syncthreads();
-    const int nx = next_chunk(ch + 1);
     if (nx < c1) {
-      load_chunk(nx);
+      const int nx2 = next_chunk(nx + 1);
+      load_blk(aT, eT, nx, ta);
+      if (offdiag) load_blk(aB, eB, nx, tb);
+      eT = tab_of(aT, nx2);
+      if (offdiag) eB = tab_of(aB, nx2);
       if (tid < kChunkLm) load_hll(nx);
-    }
-    const double* pa = sT + (wv * 16 + (lane & 15)) * kLd + (lane >> 4);
-    const double* pb = sB + (lane & 15) * kLd + (lane >> 4);
+      const double* pa = sT + (wv * 16 + (lane & 15)) * kLd + (lane >> 4);
+      const double* pb = sB + (lane & 15) * kLd + (lane >> 4);
+#if !(VIEO_SCHUR_AB & 1)
 #pragma unroll
-    for (int ks = 0; ks < 3 * kChunkLm / 4; ks++) {
-      const double av = pa[ks * 4];
+      for (int ks = 0; ks < 3 * kChunkLm / 4; ks++) {
+        const double av = pa[ks * 4];
 #pragma unroll
-      for (int q = 0; q < 4; q++)
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[q * 16 * kLd + ks * 4], acc[q], 0, 0, 0);
+        for (int q = 0; q < 4; q++)
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[q * 16 * kLd + ks * 4], acc[q], 0, 0, 0);
+      }
+#else
+      acc[0][0] += pa[0] + pb[0];
+#endif
+      if (tid < kChunkLm) store_dinv(buf ^ 1);
+      buf ^= 1, ch = nx, nx = nx2;
+    } else {
+      const double* pa = sT + (wv * 16 + (lane & 15)) * kLd + (lane >> 4);
+      const double* pb = sB + (lane & 15) * kLd + (lane >> 4);
+#if !(VIEO_SCHUR_AB & 1)
+#pragma unroll
+      for (int ks = 0; ks < 3 * kChunkLm / 4; ks++) {
+        const double av = pa[ks * 4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[q * 16 * kLd + ks * 4], acc[q], 0, 0, 0);
+      }
+#else
+      acc[0][0] += pa[0] + pb[0];
+#endif
+      ch = c1;
     }
-    if (nx < c1 && tid < kChunkLm) store_dinv(buf ^ 1);
-    buf ^= 1, ch = nx;
   }
   // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
   double* S = D.Sp + (size_t)split * D.sp_stride;
@@ -895,13 +963,17 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
-  const int np = D.np, npv = D.npv, pd = D.pd, e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= np * np) return;
+  const int np = D.np, npv = D.npv, pd = D.pd;
   const double lambda = win_lambda(ctl[w], out[w]);
   const int ksplit = D.ksplit;
   const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
   const int ns = (nchunks + cps - 1) / cps;
+  // (a fixed grid that walks the window's entries: sizing the grid for the largest window of a mixed batch launched
+  // 112 k workgroups of which the ordinary windows' 90 % returned at once; the solve kernels read the 16 x 16 blocks
+  // on and below the diagonal only)
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < np * np; e += gridDim.x * 256) {
   const int r = e / np, c = e % np;
+  if ((c >> 4) > (r >> 4)) continue;
   // the scale vertex (bScaleOpt) is the last row / column; its row of the visual system is the last one as well
   const bool rs = D.scale_opt && r == np - 1, cs = D.scale_opt && c == np - 1;
   const int a = r / pd, ra = r - a * pd, b = c / pd, cb = c - b * pd;
@@ -958,6 +1030,7 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
     if (eout >= 0) g += D.Ae[930 * (size_t)eout + 900 + ra];
     D.bfull[r] = g;
     D.bs[r] = g - t;
+  }
   }
 }
 
@@ -1456,7 +1529,6 @@ k_lba_ldltg(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Win
   double* Lg = Wg + (size_t)D.nb * (D.nb + 1) / 2 * 256;      // L (D.nb: block capacity of the window)
   if (tid == 0) s_bad = 0;
   __syncthreads();
-  typedef double double4_t __attribute__((ext_vector_type(4)));
   bool ok = true;
   for (int k = 0; k < nb; k++) {
     // ---- gather: wavefront 0 takes the diagonal block alone and factorises it at once; the others share the row
@@ -1838,15 +1910,16 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
   if (m < D.n_mp && D.mp_act[m]) {
     double cl[3] = {D.bl[3 * (size_t)m], D.bl[3 * (size_t)m + 1], D.bl[3 * (size_t)m + 2]};
     for (int a = 0; a < D.n_free; a++) {
-      if (D.tab[(size_t)a * D.n_mp + m] < 0) continue;
-      const double* B = D.BB + (size_t)(6 * a) * D.ldB + 3 * (size_t)m;
-      for (int r = 0; r < 6; r++, B += D.ldB) {
+      const int e = D.tab[(size_t)a * D.n_mp + m];
+      if (e < 0) continue;
+      const double* B = D.CB + 18 * (size_t)e;
+      for (int r = 0; r < 6; r++, B += 3) {
         const double xa = D.xp[D.pd * a + r];
         cl[0] -= B[0] * xa, cl[1] -= B[1] * xa, cl[2] -= B[2] * xa;
       }
     }
     if (D.scale_opt) {  // the (scale, point) block
-      const double* B = D.BB + (size_t)(D.npv - 1) * D.ldB + 3 * (size_t)m;
+      const double* B = D.Bs + 3 * (size_t)m;
       const double xa = D.xp[D.np - 1];
       cl[0] -= B[0] * xa, cl[1] -= B[1] * xa, cl[2] -= B[2] * xa;
     }
@@ -2012,12 +2085,13 @@ static long long g_lba_kt_launches[KC_N];
 static double g_lba_kt_schur_flops;  // dense FLOPs of the timed k_lba_schur launches
 
 struct LbaKTimer {
-  bool on = false;
+  bool on = false, count_only = false;  // count_only (mode 2): launches per class without events
   hipStream_t st = nullptr;
   std::vector<hipEvent_t> pool;
   std::vector<int> cls;  // class of pair i (events 2i, 2i + 1)
   void begin(hipStream_t s) {
-    on = g_lba_ktiming.load() != 0;
+    const int mode = g_lba_ktiming.load();
+    on = mode != 0, count_only = mode == 2;
     st = s;
     cls.clear();
   }
@@ -2025,6 +2099,11 @@ struct LbaKTimer {
   void launch(int c, F&& f) {
     if (!on) {
       f();
+      return;
+    }
+    if (count_only) {
+      f();
+      cls.push_back(c);
       return;
     }
     const size_t i = cls.size();
@@ -2047,7 +2126,7 @@ struct LbaKTimer {
     std::lock_guard<std::mutex> g(g_lba_kt_mutex);
     for (size_t i = 0; i < cls.size(); i++) {
       float ms = 0;
-      if (hipEventElapsedTime(&ms, pool[2 * i], pool[2 * i + 1]) != hipSuccess) continue;
+      if (!count_only && hipEventElapsedTime(&ms, pool[2 * i], pool[2 * i + 1]) != hipSuccess) continue;
       g_lba_kt_ms[cls[i]] += ms, g_lba_kt_launches[cls[i]]++;
       if (cls[i] == KC_SCHUR) g_lba_kt_schur_flops += schur_flops_per_launch;
     }
@@ -2194,7 +2273,13 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     int lo = 0, hi = 0;
     const char* e = getenv("VIEO_LBA_PRIORITY");
     const int want = e ? atoi(e) : -1;
-    if (want == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi)
+    const char* cm = getenv("VIEO_LBA_CU_MASK");  // experiment: "first,count" -> the engine's stream on those CUs only
+    int cu_first = 0, cu_count = 0;
+    if (cm && sscanf(cm, "%d,%d", &cu_first, &cu_count) == 2 && cu_count > 0) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = cu_first; i < cu_first + cu_count && i < 256; i++) mask[i >> 5] |= 1u << (i & 31);
+      VIEO_HIP_CHECK(hipExtStreamCreateWithCUMask(&g_lba_stream, 8, mask));
+    } else if (want == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi)
       VIEO_HIP_CHECK(hipStreamCreateWithFlags(&g_lba_stream, hipStreamNonBlocking));
     else
       VIEO_HIP_CHECK(hipStreamCreateWithPriority(&g_lba_stream, hipStreamNonBlocking, want < 0 ? lo : hi));
@@ -2347,7 +2432,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   int schur_grid = 1;
   std::vector<size_t> scratch_off(W);
   struct Scr {
-    size_t kf_bak, X_bak, mp_act, BB, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
+    size_t kf_bak, X_bak, mp_act, BB, Bs, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
         gchi, bfull, Hb, Wp, big_fail, kf_act, occ, sc_sys, psc;
     int nb;
   };
@@ -2364,9 +2449,9 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     const int npm = 6 * nf + sco;  // rows of the visual system: PR blocks (+ the scale vertex)
     s.kf_bak = take((size_t)H.n_kf * sizeof(LbaKf)), s.X_bak = take((size_t)H.n_mp * 24);
     s.mp_act = take(H.n_mp);
-    const int ldB = (H.n_mp + kChunkLm - 1) / kChunkLm * (3 * kChunkLm);
     const int sp_rows = (npm + 63) / 64 * 64, ldS = (npm + 64) / 64 * 64;
-    s.BB = take((size_t)npm * ldB * 8);
+    s.BB = take((size_t)std::max(H.n_obs, 1) * 144);
+    s.Bs = sco ? take((size_t)std::max(H.n_mp, 1) * 24) : 0;
     const int ksplit = schur_ksplit(nf, H.n_mp);
     schur_grid = std::max(schur_grid, schur_tiles(nf) * ksplit);
     s.Sp = take((size_t)ksplit * sp_rows * ldS * 8);
@@ -2394,7 +2479,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     LbaDev& D = devs[w];
     memset(&D, 0, sizeof(D));
     D.n_obs = H.n_obs, D.n_mp = H.n_mp, D.n_kf = H.n_kf, D.nf_cap = nf;
-    D.ldB = ldB, D.ldS = ldS, D.sp_stride = (size_t)sp_rows * ldS, D.ksplit = ksplit;
+    D.ldS = ldS, D.sp_stride = (size_t)sp_rows * ldS, D.ksplit = ksplit;
     D.cam.fx = H.P->fx, D.cam.fy = H.P->fy, D.cam.cx = H.P->cx, D.cam.cy = H.P->cy, D.cam.bf = H.P->bf;
     memcpy(D.cam.Rcb, H.P->Rcb, 72);
     memcpy(D.cam.tcb, H.P->tcb, 24);
@@ -2416,6 +2501,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.dMono = (double)(float)sqrt(gba ? 5.99 : 5.991), D.dStereo = (double)(float)sqrt(7.815);
     D.pd = pd, D.n_imu = H.n_imu;
     D.scale_opt = sco;
+    D.use_occ = gba ? 1 : 0;
     D.solver = solver_class(npf);
     if (vio) {  // const float chi2Mono = 5.991; 1.5 * chi2Mono; literal 7.815 (Optimizer.cc:347,603-620)
       D.thMono = (double)5.991f, D.thMonoClose = 1.5 * (double)5.991f, D.thStereo = 7.815;
@@ -2475,7 +2561,6 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     std::vector<int> fill(kf_first, kf_first + H.n_kf);
     for (int i = 0; i < H.n_obs; i++) kf_idx[fill[ob[i].kf]++] = i;
     LbaKf* kf = (LbaKf*)(hs + o.kf);
-    int nf = 0;
     for (int k = 0; k < H.n_kf; k++) {
       memcpy(kf[k].p, kfs[k].nav.p, 24);
       kf[k].qw = kfs[k].nav.q[0], kf[k].qx = kfs[k].nav.q[1];
@@ -2483,7 +2568,6 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       kf[k].col = -1, kf[k].fixed = kfs[k].fixed ? 1 : 0;
       memcpy(kf[k].v, kfs[k].nav.v, 24), memcpy(kf[k].dbg, kfs[k].nav.dbg, 24), memcpy(kf[k].dba, kfs[k].nav.dba, 24);
       memcpy(kf[k].bg, kfs[k].nav.bg, 24), memcpy(kf[k].ba, kfs[k].nav.ba, 24);
-      nf += !kfs[k].fixed;
     }
     if (vio) {  // inertial edges (Optimizer.cc:226-311)
       LbaImu* im = (LbaImu*)(hs + o.imu);
@@ -2595,7 +2679,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.level = base + o.level, D.err = (double*)(base + o.err);
     D.ocam = base + o.ocam;
     D.kf_bak = (LbaKf*)(base + s.kf_bak), D.X_bak = (double*)(base + s.X_bak), D.mp_act = base + s.mp_act;
-    D.BB = (double*)(base + s.BB), D.Sp = (double*)(base + s.Sp);
+    D.CB = (double*)(base + s.BB), D.Bs = (double*)(base + s.Bs), D.Sp = (double*)(base + s.Sp);
     D.Hll = (double*)(base + s.Hll), D.bl = (double*)(base + s.bl);
     D.Hpp = (double*)(base + s.Hpp), D.Hs = (double*)(base + s.Hs), D.bp = (double*)(base + s.bp);
     D.Hb = (double*)(base + s.Hb), D.Wp = (double*)(base + s.Wp), D.big_fail = (int*)(base + s.big_fail);
@@ -2722,7 +2806,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (any & LBA_BEGIN) {
       KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC); });
       KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO); });
-      KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_occ, dim3(std::max(1, (occ_max + 255) / 256), W), dim3(256), 0, st, dD, dC); });
+      if (gba) KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_occ, dim3(std::max(1, (occ_max + 255) / 256), W), dim3(256), 0, st, dD, dC); });
       KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0); });
     }
     if (any & LBA_BUILD) {
@@ -2748,7 +2832,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         (void)nv;
         if ((rc = shard_exchange(sh, sh->d_buf, shard_sys, st)) != VIEO_OK) return rc;
       }
-      KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3((n_max * n_max + 255) / 256, W), dim3(256), 0, st, dD, dC, dO); });
+      KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3(std::min((n_max * n_max + 255) / 256, std::max(96, 8192 / W)), W), dim3(256), 0, st, dD, dC, dO); });
       if (big && cls_trial[2]) {
         const int nbm = (n_max_b + 1 + kNB - 1) / kNB * kNB, ntm = nbm / kNB;
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_init, dim3((unsigned)(((size_t)nbm * nbm + 255) / 256), W), dim3(256), 0, st, dD, dC); });
@@ -3073,7 +3157,7 @@ int vieo_global_bundle_adjustment_vio_scale(const vieo_lba_vio_params* params, i
 // Kernel-class timing of the bundle-adjustment engine (bench.py's roofline over the whole path).
 void vieo_lba_enable_timing(int on) {
   std::lock_guard<std::mutex> g(vieo::g_lba_kt_mutex);
-  vieo::g_lba_ktiming.store(on ? 1 : 0);
+  vieo::g_lba_ktiming.store(on == 2 ? 2 : (on ? 1 : 0));
   for (int i = 0; i < vieo::KC_N; i++) vieo::g_lba_kt_ms[i] = 0, vieo::g_lba_kt_launches[i] = 0;
   vieo::g_lba_kt_schur_flops = 0;
 }

@@ -143,8 +143,8 @@ class Optimizer:
     @staticmethod
     def enable_kernel_timing(on=True):
         """HIP-event timing of every bundle-adjustment kernel launch, per kernel class (vieo_lba_enable_timing);
-        also clears the totals."""
-        lib().vieo_lba_enable_timing(1 if on else 0)
+        also clears the totals.  on == 2: count the launches per class only (no events on the stream)."""
+        lib().vieo_lba_enable_timing(2 if on == 2 else (1 if on else 0))
 
     @staticmethod
     def kernel_times():
