@@ -103,6 +103,34 @@ def pmc_traffic(kernel, n_img):
         return None
 
 
+def valu_issue(kernel, n_img, launch_ms):
+    """VALU-issue view of an extractor kernel: its vector instruction count per SIMD from the committed SQ counter pass
+    (profiles/r*_pmc_fast.json, tools/pmc_fast.sh: SQ_INSTS_VALU in its own rocprofv3 --pmc run), scaled to this run's
+    images per launch, against the issue slots of THIS run's launch duration: the fraction of a SIMD's vector issue
+    the kernel fills if all its instructions were full-rate (1.9 cycles per wave instruction on gfx950) and if all were
+    half-rate (3.4); the kernel's mix lies between.  None if the file is absent or describes another kernel."""
+    path = _latest_profile("_pmc_fast.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("kernel") != "k_" + kernel or launch_ms <= 0:
+            return None
+        insts = d["valu_insts_per_simd"] * n_img / d["images_per_launch"]
+        cyc = launch_ms * 1e-3 * 2.4e9
+        c = d["issue_cycles_per_valu_inst"]
+        return {"valu_insts_per_simd_per_launch": insts, "launch_cycles_at_2p4_ghz": cyc,
+                "valu_insts_per_cycle_per_simd": insts / cyc,
+                "issue_fraction_if_all_full_rate": insts * c["full_rate"] / cyc,
+                "issue_fraction_if_all_half_rate": insts * c["half_rate"] / cyc,
+                "lane_fill": d.get("lane_fill"),
+                "source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))) + " (" + d["source"] + ")",
+                "note": "the kernel moves its algorithmic bytes once (traffic / algorithmic bytes ~ 1.1) and is bound by "
+                        "vector instruction issue and resident wavefronts, not by HBM: `frac` above is reported against "
+                        "the HBM peak because SURVEY 8(d) prices this kernel in bytes"}
+    except (OSError, KeyError, TypeError, ValueError):
+        return None
+
+
 def mfma_busy():
     """SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES of k_lba_schur from the committed counter pass
     (profiles/r*_pmc_lba_schur.json, collected by tools/pmc_lba_schur.sh in its own rocprofv3 --pmc run); None if
@@ -605,6 +633,20 @@ def main():
             dk, alg_bytes = None, lba_ab.get(dom)
         launch_ms = kern[dom] / launches if launches else 0.0
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if (alg_bytes and launch_ms > 0) else None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                "traffic": pmc_traffic(dk, n_img) if dk else None, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": launch_ms}
+        if dk:
+            roof["valu_issue"] = valu_issue(dk, n_img, launch_ms)
+        if dom == "lba.schur" and schur_alone:  # the one MFMA kernel of the path: priced in FLOPs, not bytes
+            roof = {"bound": "mfma", "kernel": dom, "achieved": schur_alone["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": schur_alone["frac"], "traffic": None,
+                    "flops": "dense 2 np (np + 1) 3 n_mp per window and LM trial", "avg_launch_ms": launch_ms,
+                    "note": "duration of the launch alone (the bundle-adjustment stream has the lowest priority; in situ "
+                            "its events mostly measure waiting, see roofline_mfma)"}
+        roof["chosen_over"] = ("all kernels of the path: extractor kernels, front-end stages (1-3 kernels each) and "
+                               "bundle-adjustment kernel classes, by ms per step")
         sch = lba_k.get("lba.schur", {"ms": 0.0, "launches": 0})
         sch_tf = schur_flops / (sch["ms"] * 1e-3) / 1e12 if sch["ms"] > 0 else None
         r2 = res["r2"]
@@ -656,13 +698,7 @@ def main():
                               "step x the duration of the same launch alone (the bundle-adjustment stream runs at the "
                               "lowest priority; its in-situ event times, mostly waiting, are in lba_elapsed_ms_per_step_in_situ)",
             "lba_elapsed_ms_per_step_in_situ": {k: round(v["ms"] / a.steps, 3) for k, v in lba_k.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                         "traffic": pmc_traffic(dk, n_img) if dk else None,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": launch_ms,
-                         "chosen_over": "all kernels of the path: extractor kernels, front-end stages (1-3 kernels each) "
-                                        "and bundle-adjustment kernel classes, by ms per step"},
+            "roofline": roof,
             # the one dense contraction of the path: the Schur complement of the local BA on the FP64 matrix cores
             "roofline_mfma": {"bound": "mfma", "kernel": "lba.schur (k_lba_schur, v_mfma_f64_16x16x4_f64)",
                               "achieved": sch_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -315,7 +315,9 @@ int vieo_search_by_projection(int mode, const vieo_proj_query* h_queries, int nq
                               const float* h_bounds /*[4]*/, float nn_ratio, int check_orientation,
                               int32_t* h_assign, int32_t* nmatches);
 /* Batched device form: frame f owns queries [f*q_cap, f*q_cap + d_nq[f]) and the key arrays of
- * image img_first + f*img_step of an extractor batch (d_counts as written by the extractor). */
+ * image img_first + f*img_step of an extractor batch (d_counts as written by the extractor).
+ * The search entries keep their scratch (candidate pool, cursors, grid CSRs) per HOST THREAD, not per stream: a thread
+ * issues its searches on ONE stream, or synchronises between searches it issues on different streams. */
 int vieo_search_by_projection_batch_device(int mode, const vieo_proj_query* d_queries,
                                            const int32_t* d_nq, int q_cap, int n_frames,
                                            const vieo_keypoint* d_keys, const float* d_uright,
@@ -520,6 +522,11 @@ typedef struct vieo_vio_result {
 
 int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_obs* h_obs,
                                uint8_t* h_outlier, vieo_vio_result* h_result);
+/* Capacity: a frame's edges are one bit per edge in a 64-bit mask per lane.  The host entry above always runs the
+ * 256-thread instance (16384 observations per frame).  The batched device entry picks its instance from the batch
+ * size -- more than 256 non-rig frames per call run one wavefront per frame (4096 observations per frame), smaller
+ * batches and rig frames the 256-thread instance (16384) -- and reports a frame beyond the limit through that
+ * frame's status (VIEO_E_CAPACITY), not through the return value. */
 int vieo_pose_optimization_vio_batch_device(const vieo_vio_frame* d_frames, int n_frames,
                                             const vieo_pose_obs* d_obs, uint8_t* d_outlier,
                                             vieo_vio_result* d_results, void* stream);

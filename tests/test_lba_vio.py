@@ -138,6 +138,48 @@ def test_gpu_vio_lba_large_window_parity(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_local", [11, 21, 32, 42])
+def test_gpu_vio_lba_solver_classes_parity(oracle, n_local):
+    """The one-workgroup L2-resident blocked LDL^T (k_lba_ldltg, 160 .. 639 unknowns): its smallest system (11 key
+    frames = 165 unknowns, 11 blocks), a visual system whose last key frame straddles two 64-row Schur tiles (21 key
+    frames: rows 126..131), 32 key frames (480 unknowns: more row blocks than gather wavefronts x 3) and its largest
+    (42 key frames = 630 unknowns, 40 blocks)."""
+    from vieo_slam_amd.optimizer import Optimizer
+    win = list(synth_ba.make_lba_vio_problem(80 + n_local, n_local=n_local, n_fixed=6, n_points=1500, dt_kf=0.25)[:6])
+    P = win[0].copy()
+    P[0]["large"], P[0]["lambda_init"] = 1, 1e-2
+    P[0]["base"]["its0"], P[0]["base"]["its1"] = 2, 2
+    win[0] = P
+    assert (win[1]["fixed"] == 0).sum() == n_local
+    _parity(oracle, tuple(win), Optimizer.LocalBundleAdjustmentNavStatePRV(*win))
+
+
+@pytest.mark.gpu
+def test_gpu_vio_lba_mixed_batch_equals_single_calls():
+    """Ordinary and bLarge windows in one lock-step batch (different Schur tile counts, K splits and solve kernels per
+    window): every window's result is bit-identical to its own single-window call -- the summation orders are
+    functions of the window alone."""
+    from vieo_slam_amd.optimizer import Optimizer
+    wins = []
+    for i, n_local in enumerate([10, 25, 10, 12, 25]):
+        w = list(synth_ba.make_lba_vio_problem(90 + i, n_local=n_local, n_fixed=8, n_points=900 + 150 * i, dt_kf=0.25)[:6])
+        if n_local == 25:
+            P = w[0].copy()
+            P[0]["large"], P[0]["lambda_init"] = 1, 1e-2
+            P[0]["base"]["its0"], P[0]["base"]["its1"] = 2, 2
+            w[0] = P
+        wins.append(tuple(w))
+    outs = Optimizer.LocalBundleAdjustmentNavStatePRVBatch(wins)
+    for win, (hn, hp, he, hr) in zip(wins, outs):
+        sn, sp, se, sr = Optimizer.LocalBundleAdjustmentNavStatePRV(*win)
+        assert hr["lm_trials"] == sr["lm_trials"] and hr["status"] == sr["status"]
+        assert np.array_equal(hp, sp) and np.array_equal(he, se)
+        for k in range(len(hn)):
+            assert np.array_equal(hn[k]["p"], sn[k]["p"]) and np.array_equal(hn[k]["q"], sn[k]["q"])
+            assert np.array_equal(hn[k]["v"], sn[k]["v"])
+
+
+@pytest.mark.gpu
 def test_gpu_vio_lba_batch_and_edge_cases(oracle):
     from vieo_slam_amd.optimizer import Optimizer
     wins = [synth_ba.make_lba_vio_problem(30 + i, n_local=4 + 3 * i, n_fixed=3, n_points=300 + 200 * i)[:6]

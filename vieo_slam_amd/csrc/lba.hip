@@ -303,24 +303,24 @@ k_lba_zero(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
 }
 
 // ---- initializeOptimization(0): one workgroup per window
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
   const int w = blockIdx.x, tid = threadIdx.x;
   if (!(ctl[w].flags & LBA_BEGIN)) return;
   LbaDev& D = devs[w];
   const int n_mp = D.n_mp, n_obs = D.n_obs, n_kf = D.n_kf;
   int* s_act = D.kf_act;
-  for (int k = tid; k < n_kf; k += 256) s_act[k] = 0;
-  for (int m = tid; m < n_mp; m += 256) D.mp_act[m] = 0;
+  for (int k = tid; k < n_kf; k += 1024) s_act[k] = 0;
+  for (int m = tid; m < n_mp; m += 1024) D.mp_act[m] = 0;
   __syncthreads();
-  for (int i = tid; i < n_obs; i += 256)
+  for (int i = tid; i < n_obs; i += 1024)
     if (D.level[i] == 0) {
       const vieo_lba_obs o = D.obs[i];
       s_act[o.kf] = 1;
       D.mp_act[o.mp] = 1;
     }
   if (D.pd == 6)  // encoder edges of a vision-only window are active edges too (their vertices join the system)
-    for (int e = tid; e < D.n_imu; e += 256) s_act[D.imu[e].i] = 1, s_act[D.imu[e].j] = 1;
+    for (int e = tid; e < D.n_imu; e += 1024) s_act[D.imu[e].i] = 1, s_act[D.imu[e].j] = 1;
   __syncthreads();
   if (tid == 0) {
     // vision-only window: free key frames with an active edge; visual-inertial window: the inertial
@@ -339,7 +339,7 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
     out[w].np = np;
   }
   __syncthreads();
-  for (int i = tid; i < n_obs; i += 256)
+  for (int i = tid; i < n_obs; i += 1024)
     if (D.level[i] == 0) {
       const vieo_lba_obs o = D.obs[i];
       const int c = D.kf[o.kf].col;
@@ -443,9 +443,11 @@ __device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& 
 // lean instantiation.  SCALE: a batch with a scale-vertex window (EdgeReprojectPRS[Stereo]): the point half also forms
 // the point's entry of the scale row of BB (sum over its edges of Js^T W Jx) and its terms of H_ss / b_s, the key-frame
 // half H_ps = sum Jp^T W Js.
-template <bool MULTICAM, bool SCALE>
-__global__ void __launch_bounds__(256)
-k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int gm) {
+// The two halves are two launches (KFHALF): the point half needs 162 registers, the key-frame half 254, and in one
+// kernel the point half's 64 % of the workgroups ran at the key-frame half's two wavefronts per SIMD.
+template <bool MULTICAM, bool SCALE, bool KFHALF>
+__global__ void __launch_bounds__(256, KFHALF ? 2 : 3)
+k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const int bx = blockIdx.x;
   __shared__ double s_red[4 * 27];
   const int w = blockIdx.y, fl = ctl[w].flags;
@@ -453,7 +455,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   const LbaDev& D = devs[w];
   if (D.np == 0) return;
   const bool robust = fl & LBA_ROBUST;
-  if (bx < gm) {
+  if (!KFHALF) {
     if (bx * 64 >= D.n_mp) return;
     const int m = bx * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;  // 4 lanes per point
     const bool act = m < D.n_mp && D.mp_act[m];
@@ -544,7 +546,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
     if (threadIdx.x == 0) D.pmax[bx] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
     return;
   }
-  const int a = bx - gm;
+  const int a = bx;
   if (a >= D.n_free) return;
   const int kfi = D.kf_list[a];
   const LbaKf k = D.kf[kfi];
@@ -2805,21 +2807,26 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       for (int ph = 0; ph < 3; ph++) KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_prelevel, dim3(ge, W), dim3(256), 0, st, dD, dC, ph); });
     if (any & LBA_BEGIN) {
       KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC); });
-      KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(256), 0, st, dD, dC, dO); });
+      KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(1024), 0, st, dD, dC, dO); });
       if (gba) KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_occ, dim3(std::max(1, (occ_max + 255) / 256), W), dim3(256), 0, st, dD, dC); });
       KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0); });
     }
     if (any & LBA_BUILD) {
+      auto build2 = [&](auto mc, auto sc) {  // point half, key-frame half
+        constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC); });
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(std::max(1, max_nf), W), dim3(256), 0, st, dD, dC); });
+      };
       if (sco) {
         if (any_multicam)
-          KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<true, true>), dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
+          build2(std::true_type(), std::true_type());
         else
-          KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<false, true>), dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
+          build2(std::false_type(), std::true_type());
         KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL(k_lba_scale_fold, dim3(W), dim3(256), 0, st, dD, dC); });
       } else if (any_multicam)
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<true, false>), dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
+        build2(std::true_type(), std::false_type());
       else
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<false, false>), dim3(gq + max_nf, W), dim3(256), 0, st, dD, dC, gq); });
+        build2(std::false_type(), std::false_type());
       if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0); });
     }
     if (any & LBA_BEGIN) KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO); });

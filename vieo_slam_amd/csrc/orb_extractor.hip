@@ -1085,7 +1085,8 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
   e->score_bytes = align_up((max_cw - 4) * (max_ch - 4), 16) + 16;
   // candidate list: at most 512 entries in LDS (fast_cell scores the pending ones when it fills up and falls back to a
   // dense evaluation of the cell when even the corners alone do not fit); VIEO_FAST_CAND_CAP lets the tests force both
-  e->fast_cand_cap = std::min((max_cw - 6) * (max_ch - 6), 512);
+  // (at least 256: pass A appends up to 256 entries per step and would otherwise drop to the dense fallback at once)
+  e->fast_cand_cap = std::max(256, std::min((max_cw - 6) * (max_ch - 6), 512));
   if (const char* cc = getenv("VIEO_FAST_CAND_CAP")) e->fast_cand_cap = std::max(256, atoi(cc));
   e->fast_lds = e->tile_bytes + e->score_bytes + align_up(2 * e->fast_cand_cap, 16) + 16;
   e->qt_lds = 16 * e->scap_max + (4 + 16 + 4 + 4 + 4) * ncap_max + 64 + (2 * 4 + 8 + 2 * 6) * ncap_max +
