@@ -792,48 +792,59 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   // Software pipeline: the blocks of chunk c + 1 (18 + 18 doubles per thread, and H_ll of its 16 landmarks on the first
   // 16 threads) are loaded into registers before the MFMAs of chunk c are issued, their `tab` entries one chunk earlier
   // still; (H_ll + lambda I)^-1 of chunk c + 1 is formed after the MFMAs into the other half of sDi.
+  // What the staging phase must NOT contain (measured: it does not overlap with the other workgroups' MFMAs, its
+  // instructions add to the launch): generic-address loads (the window's arrays are GLOBAL: a flat load also takes an
+  // LDS-counter slot and every LDS wait then waits for it), selects between the two register sets (a uniform branch).
+  // (A dummy LDS row for the rows outside the tile, instead of masking them, costs the third workgroup per CU: 54.3 KB.)
+  typedef const double __attribute__((address_space(1)))* gdp;
+  typedef double dbl2_t __attribute__((ext_vector_type(2)));
+  typedef const dbl2_t __attribute__((address_space(1)))* gd2p;
+  typedef const int __attribute__((address_space(1)))* gip;
+  typedef const unsigned char __attribute__((address_space(1)))* gbp;
+  const gd2p gCB = (gd2p)D.CB;
+  const gdp gBs = (gdp)D.Bs, gbl = (gdp)D.bl, gHll = (gdp)D.Hll;
+  const gip gtab = (gip)D.tab;
+  const gbp gact = (gbp)D.mp_act;
   const int ps = tid >> 4, pj = tid & 15;
   const bool pair_thr = tid < 192;
-  const int nfree = D.n_free, q_bl = D.scale_opt ? 1 : 0;
+  const int nfree = D.n_free;
+  const bool sc_opt = D.scale_opt != 0;
   const int aT = (64 * bi) / 6 + ps, aB = (64 * bj) / 6 + ps;
   const int rT = 6 * aT - 64 * bi, rB = 6 * aB - 64 * bj;  // tile row of the pair's first row (-5 .. 66)
   auto tab_of = [&](int a, int ch) -> int {
     const int m = ch * kChunkLm + pj;
-    return (pair_thr && ch < c1 && a < nfree && m < n_mp) ? D.tab[(size_t)a * n_mp + m] : -1;
+    return (pair_thr && ch < c1 && a < nfree && m < n_mp) ? gtab[(size_t)a * n_mp + m] : -1;
   };
-  auto load_blk = [&](int a, int e, int ch, double* v) {
+  // v: the pair's block (zeros without an edge; the scale vertex's row for the slot after the last key frame);
+  // blv: b_l of the landmark for that slot on the B side, zeros elsewhere
+  auto load_blk = [&](int a, int e, int ch, bool with_bl, double* v, double* blv) {
 #pragma unroll
     for (int t = 0; t < 18; t++) v[t] = 0.0;
+    if (with_bl) blv[0] = blv[1] = blv[2] = 0.0;
     if (!pair_thr) return;
     const int m = ch * kChunkLm + pj;
     if (a < nfree) {
       if (e >= 0 && !(VIEO_SCHUR_AB & 4)) {
-        const double2* p = (const double2*)(D.CB + 18 * (size_t)e);
+        const gd2p p = gCB + 9 * (size_t)e;
 #pragma unroll
         for (int t = 0; t < 9; t++) {
-          const double2 x = p[t];
-          v[2 * t] = x.x, v[2 * t + 1] = x.y;
+          const dbl2_t x = p[t];
+          v[2 * t] = x[0], v[2 * t + 1] = x[1];
         }
       }
     } else if (a == nfree && m < n_mp) {
-      if (D.scale_opt) v[0] = D.Bs[3 * (size_t)m], v[1] = D.Bs[3 * (size_t)m + 1], v[2] = D.Bs[3 * (size_t)m + 2];
-      if (D.mp_act[m]) {
-        const double* q = D.bl + 3 * (size_t)m;  // (no runtime index into v: it must stay in registers)
-        if (q_bl)
-          v[3] = q[0], v[4] = q[1], v[5] = q[2];
-        else
-          v[0] = q[0], v[1] = q[1], v[2] = q[2];
-      }
+      if (sc_opt) v[0] = gBs[3 * (size_t)m], v[1] = gBs[3 * (size_t)m + 1], v[2] = gBs[3 * (size_t)m + 2];
+      if (with_bl && gact[m]) blv[0] = gbl[3 * (size_t)m], blv[1] = gbl[3 * (size_t)m + 1], blv[2] = gbl[3 * (size_t)m + 2];
     }
   };
-  double ta[18], tb[18], hl[9];
+  double ta[18], tb[18], blv[3], hl[9];
   bool hl_act = false;
   auto load_hll = [&](int ch) {  // threads 0..15
     const int m = ch * kChunkLm + tid;
-    hl_act = m < n_mp && D.mp_act[m];
+    hl_act = m < n_mp && gact[m];
     if (hl_act) {
 #pragma unroll
-      for (int t = 0; t < 9; t++) hl[t] = D.Hll[9 * (size_t)m + t];
+      for (int t = 0; t < 9; t++) hl[t] = gHll[9 * (size_t)m + t];
     }
   };
   auto store_dinv = [&](int buf) {  // threads 0..15
@@ -842,13 +853,40 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
 #pragma unroll
     for (int t = 0; t < 9; t++) sDi[buf][tid * 9 + t] = Di[t];
   };
+  // rows of the pair -> LDS (a slot that straddles the tile's edge has rows outside it)
+  auto stage_T = [&](const double* v, const double* Di) {
+    const double d0 = Di[0], d1 = Di[1], d2 = Di[2], d3 = Di[3], d4 = Di[4], d5 = Di[5], d6 = Di[6], d7 = Di[7], d8 = Di[8];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const unsigned r = (unsigned)(rT + q);
+      if (r < 64u) {
+        const double b0 = v[3 * q], b1 = v[3 * q + 1], b2 = v[3 * q + 2];
+        double* d = sT + r * kLd + 3 * pj;
+        d[0] = __builtin_fma(b2, d6, __builtin_fma(b1, d3, b0 * d0));
+        d[1] = __builtin_fma(b2, d7, __builtin_fma(b1, d4, b0 * d1));
+        d[2] = __builtin_fma(b2, d8, __builtin_fma(b1, d5, b0 * d2));
+      }
+    }
+  };
+  auto stage_B = [&](const double* v) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const unsigned r = (unsigned)(rB + q);
+      if (r < 64u) {
+        double* d = sB + r * kLd + 3 * pj;
+        double b0 = v[3 * q], b1 = v[3 * q + 1], b2 = v[3 * q + 2];
+        if (q < 2 && (q == 1) == sc_opt) b0 += blv[0], b1 += blv[1], b2 += blv[2];  // (uniform) the b_l column's row
+        d[0] = b0, d[1] = b1, d[2] = b2;
+      }
+    }
+  };
   const bool offdiag = bj != bi;
   int ch = next_chunk(c0), buf = 0;
   int nx = ch < c1 ? next_chunk(ch + 1) : c1;
   int eT = -1, eB = -1;
   if (ch < c1) {
-    load_blk(aT, tab_of(aT, ch), ch, ta);
-    if (offdiag) load_blk(aB, tab_of(aB, ch), ch, tb);
+    load_blk(aT, tab_of(aT, ch), ch, !offdiag, ta, blv);
+    if (offdiag) load_blk(aB, tab_of(aB, ch), ch, true, tb, blv);
     eT = tab_of(aT, nx);
     if (offdiag) eB = tab_of(aB, nx);
     if (tid < kChunkLm) load_hll(ch), store_dinv(0);
@@ -856,68 +894,39 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   while (ch < c1) {
     __syncthreads();  // the previous chunk's fragments have been read; sDi[buf] is complete
     if (pair_thr && !(VIEO_SCHUR_AB & 2)) {
-      const double* Di = sDi[buf] + pj * 9;
-      const double d0 = Di[0], d1 = Di[1], d2 = Di[2], d3 = Di[3], d4 = Di[4], d5 = Di[5], d6 = Di[6], d7 = Di[7], d8 = Di[8];
-#pragma unroll
-      for (int q = 0; q < 6; q++) {
-        const int r = rT + q;
-        if (r >= 0 && r < 64) {
-          double b0 = ta[3 * q], b1 = ta[3 * q + 1], b2 = ta[3 * q + 2];
-          if (aT == nfree && q == q_bl) b0 = b1 = b2 = 0.0;  // b_l is a column of the right factor only
-          sT[r * kLd + 3 * pj + 0] = b0 * d0 + b1 * d3 + b2 * d6;
-          sT[r * kLd + 3 * pj + 1] = b0 * d1 + b1 * d4 + b2 * d7;
-          sT[r * kLd + 3 * pj + 2] = b0 * d2 + b1 * d5 + b2 * d8;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 6; q++) {
-        const int r = rB + q;
-        if (r >= 0 && r < 64) {
-          sB[r * kLd + 3 * pj + 0] = offdiag ? tb[3 * q] : ta[3 * q];
-          sB[r * kLd + 3 * pj + 1] = offdiag ? tb[3 * q + 1] : ta[3 * q + 1];
-          sB[r * kLd + 3 * pj + 2] = offdiag ? tb[3 * q + 2] : ta[3 * q + 2];
-        }
-      }
+      stage_T(ta, sDi[buf] + pj * 9);
+      if (offdiag)
+        stage_B(tb);
+      else
+        stage_B(ta);
     }
     __syncthreads();
-    if (nx < c1) {
-      const int nx2 = next_chunk(nx + 1);
-      load_blk(aT, eT, nx, ta);
-      if (offdiag) load_blk(aB, eB, nx, tb);
+    const bool more = nx < c1;
+    const int nx2 = more ? next_chunk(nx + 1) : c1;
+    if (more) {
+      load_blk(aT, eT, nx, !offdiag, ta, blv);
+      if (offdiag) load_blk(aB, eB, nx, true, tb, blv);
       eT = tab_of(aT, nx2);
       if (offdiag) eB = tab_of(aB, nx2);
       if (tid < kChunkLm) load_hll(nx);
-      const double* pa = sT + (wv * 16 + (lane & 15)) * kLd + (lane >> 4);
-      const double* pb = sB + (lane & 15) * kLd + (lane >> 4);
-#if !(VIEO_SCHUR_AB & 1)
-#pragma unroll
-      for (int ks = 0; ks < 3 * kChunkLm / 4; ks++) {
-        const double av = pa[ks * 4];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[q * 16 * kLd + ks * 4], acc[q], 0, 0, 0);
-      }
-#else
-      acc[0][0] += pa[0] + pb[0];
-#endif
-      if (tid < kChunkLm) store_dinv(buf ^ 1);
-      buf ^= 1, ch = nx, nx = nx2;
-    } else {
-      const double* pa = sT + (wv * 16 + (lane & 15)) * kLd + (lane >> 4);
-      const double* pb = sB + (lane & 15) * kLd + (lane >> 4);
-#if !(VIEO_SCHUR_AB & 1)
-#pragma unroll
-      for (int ks = 0; ks < 3 * kChunkLm / 4; ks++) {
-        const double av = pa[ks * 4];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[q * 16 * kLd + ks * 4], acc[q], 0, 0, 0);
-      }
-#else
-      acc[0][0] += pa[0] + pb[0];
-#endif
-      ch = c1;
     }
+    {
+      const double* pa = sT + (wv * 16 + (lane & 15)) * kLd + (lane >> 4);
+      const double* pb = sB + (lane & 15) * kLd + (lane >> 4);
+#if !(VIEO_SCHUR_AB & 1)
+#pragma unroll
+      for (int ks = 0; ks < 3 * kChunkLm / 4; ks++) {
+        const double av = pa[ks * 4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[q * 16 * kLd + ks * 4], acc[q], 0, 0, 0);
+      }
+#else
+      acc[0][0] += pa[0] + pb[0];
+#endif
+    }
+    if (more && tid < kChunkLm) store_dinv(buf ^ 1);
+    buf ^= 1, ch = nx, nx = nx2;
   }
   // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
   double* S = D.Sp + (size_t)split * D.sp_stride;
