@@ -1536,6 +1536,7 @@ k_lba_ldltg(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Win
   double* sKK = sP + (size_t)nb_max * kLdBlk;  // L_kk (unit lower)
   double* sD = sKK + kLdBlk;                   // 1 / d of the block's pivots
   double* y = sD + 16;
+  // (plain generic pointers on purpose: with address_space(1) loads the kernel measured 523 instead of 405 us)
   double* Wg = D.Hb;                                           // un-normalised W = L D, blocks (i, j), j <= i
   double* Lg = Wg + (size_t)D.nb * (D.nb + 1) / 2 * 256;      // L (D.nb: block capacity of the window)
   if (tid == 0) s_bad = 0;
