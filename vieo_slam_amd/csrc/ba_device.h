@@ -212,7 +212,11 @@ template <int N, int BS>
 __device__ __forceinline__ void block_sum_bs(double* vals, double* s_red, int tid) {
   if (BS == 64) {
 #pragma unroll
+#ifdef VIEO_POSE_DPP64  // experiment: the DPP sums in the one-wavefront instances (tools/probe_dpp64.sh)
+    for (int i = 0; i < N; i++) vals[i] = wave_sum_d(vals[i]);
+#else
     for (int i = 0; i < N; i++) vals[i] = wave_sum_d_bfly(vals[i]);
+#endif
   } else
     block_sum<N>(vals, s_red, tid);
 }
