@@ -585,6 +585,24 @@ def main():
     stage = P.stage_ms_all()
     orb = P.ext.stage_ms_all()
     res = P.results()
+    # every bundle-adjustment kernel class of the timed region (the engine's own events on its streams), then -- the
+    # engine's stream has the lowest priority, so those events mostly measure waiting -- the duration of the same
+    # launches ALONE: one more batch of the step's windows.  Both before the multi-GPU legs, which run the same kernels.
+    lba_k, schur_flops = Optimizer.kernel_times()
+    lba_alone, schur_alone = {}, None
+    if n_lba:
+        run_lba(chunks[0])
+        k1, f1 = Optimizer.kernel_times()
+        for k, v in k1.items():
+            dn, dm = v["launches"] - lba_k[k]["launches"], v["ms"] - lba_k[k]["ms"]
+            lba_alone[k] = dm / dn if dn > 0 else 0.0
+        ds = k1["lba.schur"]["ms"] - lba_k["lba.schur"]["ms"]
+        if ds > 0:
+            tf = (f1 - schur_flops) / (ds * 1e-3) / 1e12
+            schur_alone = {"achieved": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": lba_alone["lba.schur"],
+                           "windows_per_launch": len(chunks[0]),
+                           "note": "one lock-step batch of the step's windows after the timed region"}
+    Optimizer.enable_kernel_timing(False)
     mg = None
     if not a.no_multi_gpu_legs:
         try:
@@ -596,24 +614,7 @@ def main():
         oavg = {k: float(np.mean([s[k] for s in orb])) for k in ORB_STAGES}
         ab = algorithmic_bytes_per_image()
         # every kernel (class) of the path, ms per step: the extractor's kernels and the front-end stages from the
-        # events of stream 0, the bundle-adjustment kernels from the engine's own events on its streams
-        lba_k, schur_flops = Optimizer.kernel_times()
-        # The bundle-adjustment stream has the lowest priority: what its events measure in the timed region is mostly
-        # the time a launch waited for the front end.  For the ranking its kernel classes count with the duration of
-        # the same launches alone -- one more batch of the step's windows, issued after the timed region.
-        lba_alone, schur_alone = {}, None
-        if n_lba:
-            run_lba(chunks[0])
-            k1, f1 = Optimizer.kernel_times()
-            for k, v in k1.items():
-                dn, dm = v["launches"] - lba_k[k]["launches"], v["ms"] - lba_k[k]["ms"]
-                lba_alone[k] = dm / dn if dn > 0 else 0.0
-            ds = k1["lba.schur"]["ms"] - lba_k["lba.schur"]["ms"]
-            if ds > 0:
-                tf = (f1 - schur_flops) / (ds * 1e-3) / 1e12
-                schur_alone = {"achieved": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": lba_alone["lba.schur"],
-                               "windows_per_launch": len(chunks[0]),
-                               "note": "one lock-step batch of the step's windows after the timed region"}
+        # events of stream 0, the bundle-adjustment kernel classes as collected above
         # (stream 0 carries P.B of the step's B frames: its launch times are scaled to the whole step for the ranking)
         share = B / float(P.B)
         kern = {("orb." + k): v * share for k, v in oavg.items() if k != "total"}
