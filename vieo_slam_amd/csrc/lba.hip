@@ -970,8 +970,9 @@ k_lba_pack(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
 // the Schur partials); visual-inertial windows add the inertial edges' 30x30 blocks, gathered per entry
 // (a key frame has at most one inertial edge in and one out).  bs = b - S[:, npv], bfull = b.
 __global__ void __launch_bounds__(256)
-k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out) {
-  const int w = blockIdx.y;
+k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out,
+               const int* __restrict__ wins) {
+  const int w = wins[blockIdx.y];  // the windows of one solver class: the grid is sized for that class's systems
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
   const int np = D.np, npv = D.npv, pd = D.pd;
@@ -979,9 +980,10 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
   const int ksplit = D.ksplit;
   const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
   const int ns = (nchunks + cps - 1) / cps;
-  // (a fixed grid that walks the window's entries: sizing the grid for the largest window of a mixed batch launched
-  // 112 k workgroups of which the ordinary windows' 90 % returned at once; the solve kernels read the 16 x 16 blocks
-  // on and below the diagonal only)
+  // (one launch per solver class, over that class's windows only: sizing one grid for the largest window of a mixed
+  // batch launched 112 k workgroups of which the ordinary windows' 90 % returned at once, a small fixed grid left the
+  // bLarge windows' threads nine dependent gathers each.  The solve kernels read the 16 x 16 blocks on and below the
+  // diagonal only.)
   for (int e = blockIdx.x * 256 + threadIdx.x; e < np * np; e += gridDim.x * 256) {
   const int r = e / np, c = e % np;
   if ((c >> 4) > (r >> 4)) continue;
@@ -2424,13 +2426,15 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     max_nf = std::max(max_nf, nf), max_mp = std::max(max_mp, win[w].n_mp);
   }
   // Schur GEMM decomposition: 64x64 block-tiles (upper) x K splits.  The number of splits is a function of the window
-  // alone (about kSchurCps chunks of 16 landmarks per workgroup, VIEO_LBA_CPS), so that the summation order -- and with
-  // it the window's result -- does not depend on what the window is batched with; a mixed batch (ordinary windows of
-  // one tile next to bLarge ones of six) launches the largest tile x split count and the others' workgroups exit.
-  // The full BA keeps few splits: its tiles are many and mostly skipped (k_lba_occ).
+  // alone (about 8 chunks of 16 landmarks per workgroup, VIEO_LBA_CPS), so that the summation order -- and with it the
+  // window's result -- does not depend on what the window is batched with; a mixed batch (ordinary windows of one
+  // tile next to bLarge ones of six) launches the largest tile x split count and the others' workgroups exit.
+  // Measured per call of 205 windows, VIEO_LBA_CPS = 3 / 6 / 12 / 24: Schur 4.9 / 4.6 / 4.7 / 6.1 ms, k_lba_assemble
+  // (which sums the partials) 2.1 / 1.6 / 1.2 / 1.1 ms.  The full BA keeps few splits: its tiles are many and
+  // mostly skipped (k_lba_occ).
   static const int cps_target = [] {
     const char* e = getenv("VIEO_LBA_CPS");
-    return e && atoi(e) > 0 ? atoi(e) : 6;
+    return e && atoi(e) > 0 ? atoi(e) : 8;
   }();
   auto schur_tiles = [&](int nf) {
     const int npm = 6 * nf + sco, RB = (npm + 63) / 64, CB = (npm + 64) / 64;
@@ -2674,7 +2678,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         if (rcs[i] != VIEO_OK) return fill_window(live[i]);  // again on this thread: the error text is thread-local
     }
   }
-  const size_t small_bytes = (size_t)W * (sizeof(LbaDev) + sizeof(WinCtl) + sizeof(WinOut));
+  const size_t small_bytes = (size_t)W * (sizeof(LbaDev) + sizeof(WinCtl) + sizeof(WinOut) + sizeof(int));
   if ((rc = g_arena.ensure(arena)) != VIEO_OK) return rc;
   if ((rc = g_small.ensure(small_bytes)) != VIEO_OK) return rc;
   if ((rc = g_small_h.ensure((size_t)W * (sizeof(WinCtl) + sizeof(WinOut) + 32))) != VIEO_OK) return rc;
@@ -2725,6 +2729,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   LbaDev* dD = g_small.as<LbaDev>();
   WinCtl* dC = (WinCtl*)(dD + W);
   WinOut* dO = (WinOut*)(dC + W);
+  int* dWins = (int*)(dO + W);  // the windows grouped by solver class: [class 0 | class 1 | class 2]
   WinCtl* ctl = (WinCtl*)g_small_h.p;
   WinOut* out = (WinOut*)(ctl + W);
   double* h_sc = (double*)(out + W);  // reduced scalars of a sharded run
@@ -2739,6 +2744,16 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   for (int w = 0; w < W; w++)
     if (!win[w].skip) cls_max[devs[w].solver] = std::max(cls_max[devs[w].solver], pd * devs[w].nf_cap + sco);
   const bool big = cls_max[2] > 0, ldlt16 = cls_max[0] > 0, panels = cls_max[1] > 0;
+  int cls_first[4] = {0, 0, 0, 0};
+  std::vector<int> cls_order;  // (alive until the call returns: the copy below is asynchronous)
+  for (int c = 0; c < 3; c++) {
+    cls_first[c] = (int)cls_order.size();
+    for (int w = 0; w < W; w++)
+      if (!win[w].skip && devs[w].solver == c) cls_order.push_back(w);
+  }
+  cls_first[3] = (int)cls_order.size();
+  if (!cls_order.empty())
+    VIEO_HIP_CHECK(hipMemcpyAsync(dWins, cls_order.data(), cls_order.size() * sizeof(int), hipMemcpyHostToDevice, st));
   const int n_max_b = cls_max[2];
   const int nbg = (cls_max[1] + 16) >> 4;
   if (panels)
@@ -2849,7 +2864,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         (void)nv;
         if ((rc = shard_exchange(sh, sh->d_buf, shard_sys, st)) != VIEO_OK) return rc;
       }
-      KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3(std::min((n_max * n_max + 255) / 256, std::max(96, 8192 / W)), W), dim3(256), 0, st, dD, dC, dO); });
+      for (int c = 0; c < 3; c++) {
+        const int nw = cls_first[c + 1] - cls_first[c];
+        if (nw <= 0 || !cls_trial[c]) continue;
+        const unsigned gx = (unsigned)(((size_t)cls_max[c] * cls_max[c] + 255) / 256);
+        KT.launch(KC_ASSEMBLE, [&] { hipLaunchKernelGGL(k_lba_assemble, dim3(gx, nw), dim3(256), 0, st, dD, dC, dO, dWins + cls_first[c]); });
+      }
       if (big && cls_trial[2]) {
         const int nbm = (n_max_b + 1 + kNB - 1) / kNB * kNB, ntm = nbm / kNB;
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_big_init, dim3((unsigned)(((size_t)nbm * nbm + 255) / 256), W), dim3(256), 0, st, dD, dC); });

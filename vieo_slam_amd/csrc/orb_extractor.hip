@@ -637,7 +637,10 @@ k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles, int n_tiles, i
   // horizontal pass: one item = two source rows x four columns; the 16-bit row sums of vertically
   // adjacent rows share a dword (row 2p low half, row 2p+1 high half) so the vertical pass can use
   // v_dot2_u32_u16
-  for (int idx = tid; idx < (SH / 2) * (kBlurTW / 4); idx += 256) {
+#ifndef VIEO_BLUR_AB
+#define VIEO_BLUR_AB 0  // timing experiment only (wrong results): 1 = no arithmetic, the tile goes from LDS straight out
+#endif
+  for (int idx = tid; idx < ((VIEO_BLUR_AB & 1) ? 0 : (SH / 2) * (kBlurTW / 4)); idx += 256) {
     const int pr = idx / (kBlurTW / 4), g = idx - pr * (kBlurTW / 4);
     unsigned h[2][4];
 #pragma unroll
@@ -666,6 +669,11 @@ k_blur(OrbParams P, ImgSet I, const BlurTile* __restrict__ tiles, int n_tiles, i
     const int q = idx / (kBlurTW / 4), c4 = (idx - q * (kBlurTW / 4)) * 4;
     const int gy = oy + 2 * q, gx = ox + c4;
     if (gy >= D.h || gx >= D.w) continue;
+#if VIEO_BLUR_AB & 1
+    *(unsigned*)(dst + (size_t)gy * D.pitch + gx) = *(const unsigned*)(s_src + (2 * q + 3) * SP + c4 + 4);
+    if (gy + 1 < D.h) *(unsigned*)(dst + (size_t)(gy + 1) * D.pitch + gx) = *(const unsigned*)(s_src + (2 * q + 4) * SP + c4 + 4);
+    continue;
+#endif
     // even row 2q: source rows 2q .. 2q+6; odd row 2q+1: source rows 2q+1 .. 2q+7
     const unsigned We[4] = {18u | (34u << 16), 48u | (56u << 16), 48u | (34u << 16), 18u};
     const unsigned Wo[4] = {18u << 16, 34u | (48u << 16), 56u | (48u << 16), 34u | (18u << 16)};
