@@ -701,7 +701,7 @@ def main():
             "lba_elapsed_ms_per_step_in_situ": {k: round(v["ms"] / a.steps, 3) for k, v in lba_k.items()},
             "roofline": roof,
             # the one dense contraction of the path: the Schur complement of the local BA on the FP64 matrix cores
-            "roofline_mfma": {"bound": "mfma", "kernel": "lba.schur (k_lba_schur, v_mfma_f64_16x16x4_f64)",
+            "roofline_mfma": {"bound": "mfma", "kernel": "lba.schur (k_lba_schur<diagonal tiles> + <off-diagonal tiles>: two launches per LM trial round, v_mfma_f64_16x16x4_f64)",
                               "achieved": sch_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": sch_tf / FP64_MFMA_PEAK_TFLOPS if sch_tf else None,
                               "flops_per_launch": schur_flops / sch["launches"] if sch["launches"] else None,

@@ -291,7 +291,7 @@ k_lba_prelevel(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
   if (chi2 > (double)th) D.level[i] = 1;
 }
 
-// tab = -1 for the windows that start an optimize()
+// tab = -1 (and the zero block of CB) for the windows that start an optimize()
 __global__ void __launch_bounds__(256)
 k_lba_zero(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const int w = blockIdx.y;
@@ -299,6 +299,7 @@ k_lba_zero(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const LbaDev& D = devs[w];
   const size_t nt = (size_t)D.nf_cap * D.n_mp;
   const size_t step = (size_t)gridDim.x * 256;
+  if (blockIdx.x == 0 && threadIdx.x < 18) D.CB[18 * (size_t)D.n_obs + threadIdx.x] = 0.0;  // the zero block of absent pairs
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nt; i += step) D.tab[i] = -1;
 }
 
@@ -746,7 +747,11 @@ k_lba_occ(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   D.occ[e] = (unsigned char)any;
 }
 
-__global__ void __launch_bounds__(256, 3)  // three wavefronts per SIMD = the three workgroups a CU's LDS holds
+// Two instances: the diagonal tiles (bi == bj: one register set of blocks, three wavefronts per SIMD = the three
+// workgroups a CU's LDS holds) and the off-diagonal ones (two register sets; at 168 registers they spilled the blocks
+// they had just loaded, i.e. waited for them at once: two wavefronts per SIMD).  An ordinary window is one diagonal tile.
+template <bool OFFDIAG>
+__global__ void __launch_bounds__(256, OFFDIAG ? 2 : 3)
 k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, const WinOut* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) double sT[64 * kLd];
   __shared__ __attribute__((aligned(16))) double sB[64 * kLd];
@@ -760,15 +765,21 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   const int ksplit = D.ksplit;
   int bt = blockIdx.x / ksplit;
   const int split = blockIdx.x % ksplit;
-  int bi = 0;
-  while (bi < RB && bt >= CB - bi) bt -= CB - bi, bi++;
-  if (bi >= RB) return;
-  const int bj = bi + bt;
+  int bi = 0, bj;
+  if (OFFDIAG) {  // tiles (bi, bj), bi < bj < CB, row by row
+    while (bi < RB && bt >= CB - bi - 1) bt -= CB - bi - 1, bi++;
+    if (bi >= RB) return;
+    bj = bi + 1 + bt;
+  } else {
+    if (bt >= RB) return;
+    bi = bj = bt;
+  }
   const int nchunks = (D.n_mp + kChunkLm - 1) / kChunkLm, cps = (nchunks + ksplit - 1) / ksplit;
   const int c0 = split * cps, c1 = min(nchunks, c0 + cps);
   if (c0 >= c1) return;  // k_lba_assemble uses the same split arithmetic
   const double lambda = win_lambda(ctl[w], out[w]);
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_mp = D.n_mp;
   double4_t acc[4];
 #pragma unroll
@@ -786,19 +797,19 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   };
   // Staging.  The operand tiles T = (BB D^-1)[rows of tile bi] and B = [BB; b_l][rows of tile bj], 64 x 48 per chunk
   // of 16 landmarks, exist only in LDS.  One thread per (key-frame slot of the tile, landmark of the chunk) pair --
-  // 12 slots cover the 64 rows whatever 6 a mod 64 is -- looks the pair's edge up in `tab` and writes its 6 x 3 block
-  // or zeros: nothing to clear, two barriers per chunk.  The slot after the last free key frame carries the scale
-  // vertex's row (bScaleOpt) and, on the B side, the extra column b_l.
-  // Software pipeline: the blocks of chunk c + 1 (18 + 18 doubles per thread, and H_ll of its 16 landmarks on the first
-  // 16 threads) are loaded into registers before the MFMAs of chunk c are issued, their `tab` entries one chunk earlier
-  // still; (H_ll + lambda I)^-1 of chunk c + 1 is formed after the MFMAs into the other half of sDi.
-  // What the staging phase must NOT contain (measured: it does not overlap with the other workgroups' MFMAs, its
-  // instructions add to the launch): generic-address loads (the window's arrays are GLOBAL: a flat load also takes an
-  // LDS-counter slot and every LDS wait then waits for it), selects between the two register sets (a uniform branch).
-  // (A dummy LDS row for the rows outside the tile, instead of masking them, costs the third workgroup per CU: 54.3 KB.)
-  typedef const double __attribute__((address_space(1)))* gdp;
+  // 12 slots cover the 64 rows whatever 6 a mod 64 is: wavefronts 0..2 -- looks the pair's edge up in `tab` and writes
+  // its 6 x 3 block or zeros: nothing to clear, two barriers per chunk.  The slot after the last free key frame carries
+  // the scale vertex's row (bScaleOpt) and, on the B side, the extra column b_l.  Wavefront 3 has no pairs: its first
+  // 16 lanes form (H_ll + lambda I)^-1 of the NEXT chunk's landmarks while the others stage the current one.
+  // Software pipeline: blocks of chunk c + 1 in registers, `tab` entries of chunk c + 2, H_ll of chunk c + 2.
+  // The loop has NO load whose address or predicate depends on another load of the same iteration (s_memtime probes,
+  // tools/probe_schur.sh: such a chain -- activity byte -> H_ll, tab entry -> "edge present?" branch -> block -- put a
+  // full vmcnt(0) wait, i.e. the whole HBM latency, into every chunk: 16.5 k cycles per chunk against 2.9 k of MFMAs).
+  // Absent pairs read a zero block (CB[n_obs], cleared by k_lba_zero) instead of branching, indices are clamped
+  // instead of guarded, predicates are applied to the VALUES.
   typedef double dbl2_t __attribute__((ext_vector_type(2)));
   typedef const dbl2_t __attribute__((address_space(1)))* gd2p;
+  typedef const double __attribute__((address_space(1)))* gdp;
   typedef const int __attribute__((address_space(1)))* gip;
   typedef const unsigned char __attribute__((address_space(1)))* gbp;
   const gd2p gCB = (gd2p)D.CB;
@@ -806,52 +817,56 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
   const gip gtab = (gip)D.tab;
   const gbp gact = (gbp)D.mp_act;
   const int ps = tid >> 4, pj = tid & 15;
-  const bool pair_thr = tid < 192;
-  const int nfree = D.n_free;
+  const int nfree = D.n_free, n_obs = D.n_obs;
   const bool sc_opt = D.scale_opt != 0;
+  constexpr bool offdiag = OFFDIAG;
   const int aT = (64 * bi) / 6 + ps, aB = (64 * bj) / 6 + ps;
   const int rT = 6 * aT - 64 * bi, rB = 6 * aB - 64 * bj;  // tile row of the pair's first row (-5 .. 66)
-  auto tab_of = [&](int a, int ch) -> int {
+  const int aTc = min(aT, max(nfree, 1) - 1), aBc = min(aB, max(nfree, 1) - 1);
+  // does this wavefront hold the slot after the last key frame (per side)?  wave-uniform
+  const bool spT = wv < 3 && nfree >= (64 * bi) / 6 + 4 * wv && nfree < (64 * bi) / 6 + 4 * wv + 4;
+  const bool spB = wv < 3 && nfree >= (64 * bj) / 6 + 4 * wv && nfree < (64 * bj) / 6 + 4 * wv + 4;
+  auto tab_of = [&](int a, int ac, int ch) -> int {  // unconditional load, the predicate picks the value
     const int m = ch * kChunkLm + pj;
-    return (pair_thr && ch < c1 && a < nfree && m < n_mp) ? gtab[(size_t)a * n_mp + m] : -1;
+    const int t = gtab[(size_t)ac * n_mp + min(m, n_mp - 1)];
+    return (ch < c1 && a < nfree && m < n_mp) ? t : -1;
   };
-  // v: the pair's block (zeros without an edge; the scale vertex's row for the slot after the last key frame);
-  // blv: b_l of the landmark for that slot on the B side, zeros elsewhere
-  auto load_blk = [&](int a, int e, int ch, bool with_bl, double* v, double* blv) {
+  auto load_blk = [&](int e, double* v) {  // e < 0: the zero block
+    const gd2p p = gCB + 9 * (size_t)min((unsigned)e, (unsigned)n_obs);
 #pragma unroll
-    for (int t = 0; t < 18; t++) v[t] = 0.0;
-    if (with_bl) blv[0] = blv[1] = blv[2] = 0.0;
-    if (!pair_thr) return;
-    const int m = ch * kChunkLm + pj;
-    if (a < nfree) {
-      if (e >= 0 && !(VIEO_SCHUR_AB & 4)) {
-        const gd2p p = gCB + 9 * (size_t)e;
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
-          const dbl2_t x = p[t];
-          v[2 * t] = x[0], v[2 * t + 1] = x[1];
-        }
-      }
-    } else if (a == nfree && m < n_mp) {
-      if (sc_opt) v[0] = gBs[3 * (size_t)m], v[1] = gBs[3 * (size_t)m + 1], v[2] = gBs[3 * (size_t)m + 2];
-      if (with_bl && gact[m]) blv[0] = gbl[3 * (size_t)m], blv[1] = gbl[3 * (size_t)m + 1], blv[2] = gbl[3 * (size_t)m + 2];
+    for (int t = 0; t < 9; t++) {
+      const dbl2_t x = p[t];
+      v[2 * t] = x[0], v[2 * t + 1] = x[1];
     }
   };
-  double ta[18], tb[18], blv[3], hl[9];
-  bool hl_act = false;
-  auto load_hll = [&](int ch) {  // threads 0..15
-    const int m = ch * kChunkLm + tid;
-    hl_act = m < n_mp && gact[m];
-    if (hl_act) {
-#pragma unroll
-      for (int t = 0; t < 9; t++) hl[t] = gHll[9 * (size_t)m + t];
+  // the slot after the last key frame: the scale vertex's row and b_l of the landmark (zeros for the other threads)
+  auto load_special = [&](int a, int ch, bool with_bl, double* sp, double* blv) {
+    const int m = ch * kChunkLm + pj, mc = min(m, n_mp - 1);
+    const bool mine = a == nfree && m < n_mp && ch < c1;
+    double s0 = 0, s1 = 0, s2 = 0;
+    if (sc_opt) s0 = gBs[3 * (size_t)mc], s1 = gBs[3 * (size_t)mc + 1], s2 = gBs[3 * (size_t)mc + 2];
+    sp[0] = mine ? s0 : 0.0, sp[1] = mine ? s1 : 0.0, sp[2] = mine ? s2 : 0.0;
+    if (with_bl) {
+      const double b0 = gbl[3 * (size_t)mc], b1 = gbl[3 * (size_t)mc + 1], b2 = gbl[3 * (size_t)mc + 2];
+      const bool on = mine && gact[mc] != 0;
+      blv[0] = on ? b0 : 0.0, blv[1] = on ? b1 : 0.0, blv[2] = on ? b2 : 0.0;
     }
   };
-  auto store_dinv = [&](int buf) {  // threads 0..15
-    double Di[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (hl_act) landmark_dinv(hl, lambda, Di);
+  double ta[18], tb[18], spT3[3] = {0, 0, 0}, spB3[3] = {0, 0, 0}, blv[3] = {0, 0, 0}, hl[9];
+  unsigned char hl_on = 0;
+  auto load_hll = [&](int ch) {  // wavefront 3, lanes 0..15 (the others load the same clamped landmark)
+    const int m = ch * kChunkLm + (lane & 15), mc = min(m, n_mp - 1);
 #pragma unroll
-    for (int t = 0; t < 9; t++) sDi[buf][tid * 9 + t] = Di[t];
+    for (int t = 0; t < 9; t++) hl[t] = gHll[9 * (size_t)mc + t];
+    hl_on = (ch < c1 && m < n_mp) ? gact[mc] : (unsigned char)0;
+  };
+  auto store_dinv = [&](int buf) {  // wavefront 3, lanes 0..15
+    double Di[9];
+    landmark_dinv(hl, lambda, Di);
+    if (lane < kChunkLm) {
+#pragma unroll
+      for (int t = 0; t < 9; t++) sDi[buf][lane * 9 + t] = hl_on ? Di[t] : 0.0;
+    }
   };
   // rows of the pair -> LDS (a slot that straddles the tile's edge has rows outside it)
   auto stage_T = [&](const double* v, const double* Di) {
@@ -860,7 +875,8 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
     for (int q = 0; q < 6; q++) {
       const unsigned r = (unsigned)(rT + q);
       if (r < 64u) {
-        const double b0 = v[3 * q], b1 = v[3 * q + 1], b2 = v[3 * q + 2];
+        double b0 = v[3 * q], b1 = v[3 * q + 1], b2 = v[3 * q + 2];
+        if (q == 0) b0 += spT3[0], b1 += spT3[1], b2 += spT3[2];  // the scale vertex's row (zeros elsewhere)
         double* d = sT + r * kLd + 3 * pj;
         d[0] = __builtin_fma(b2, d6, __builtin_fma(b1, d3, b0 * d0));
         d[1] = __builtin_fma(b2, d7, __builtin_fma(b1, d4, b0 * d1));
@@ -868,48 +884,69 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
       }
     }
   };
-  auto stage_B = [&](const double* v) {
+  auto stage_B = [&](const double* v, const double* sp) {
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       const unsigned r = (unsigned)(rB + q);
       if (r < 64u) {
         double* d = sB + r * kLd + 3 * pj;
         double b0 = v[3 * q], b1 = v[3 * q + 1], b2 = v[3 * q + 2];
+        if (q == 0) b0 += sp[0], b1 += sp[1], b2 += sp[2];
         if (q < 2 && (q == 1) == sc_opt) b0 += blv[0], b1 += blv[1], b2 += blv[2];  // (uniform) the b_l column's row
         d[0] = b0, d[1] = b1, d[2] = b2;
       }
     }
   };
-  const bool offdiag = bj != bi;
+#ifdef VIEO_SCHUR_PROBE
+  long long tp[6] = {0, 0, 0, 0, 0, 0}, t0 = __builtin_readcyclecounter(), t1;
+#define SCHUR_TICK(i) t1 = __builtin_readcyclecounter(), tp[i] += t1 - t0, t0 = t1;
+#else
+#define SCHUR_TICK(i)
+#endif
   int ch = next_chunk(c0), buf = 0;
   int nx = ch < c1 ? next_chunk(ch + 1) : c1;
+  int nx2 = nx < c1 ? next_chunk(nx + 1) : c1;
   int eT = -1, eB = -1;
-  if (ch < c1) {
-    load_blk(aT, tab_of(aT, ch), ch, !offdiag, ta, blv);
-    if (offdiag) load_blk(aB, tab_of(aB, ch), ch, true, tb, blv);
-    eT = tab_of(aT, nx);
-    if (offdiag) eB = tab_of(aB, nx);
-    if (tid < kChunkLm) load_hll(ch), store_dinv(0);
+  if (wv < 3) {
+    load_blk(tab_of(aT, aTc, ch), ta);
+    if (offdiag) load_blk(tab_of(aB, aBc, ch), tb);
+    if (spT) load_special(aT, ch, !offdiag, spT3, blv);
+    if (offdiag && spB) load_special(aB, ch, true, spB3, blv);
+    eT = tab_of(aT, aTc, nx);
+    if (offdiag) eB = tab_of(aB, aBc, nx);
+  } else {
+    load_hll(ch);
+    store_dinv(0);
+    load_hll(nx);
   }
   while (ch < c1) {
     __syncthreads();  // the previous chunk's fragments have been read; sDi[buf] is complete
-    if (pair_thr && !(VIEO_SCHUR_AB & 2)) {
-      stage_T(ta, sDi[buf] + pj * 9);
-      if (offdiag)
-        stage_B(tb);
-      else
-        stage_B(ta);
+    SCHUR_TICK(0)
+    if (wv < 3) {
+      if (!(VIEO_SCHUR_AB & 2)) {
+        stage_T(ta, sDi[buf] + pj * 9);
+        if (offdiag)
+          stage_B(tb, spB3);
+        else
+          stage_B(ta, spT3);
+      }
+    } else {
+      store_dinv(buf ^ 1);  // chunk nx, from the H_ll loaded an iteration ago
+      load_hll(nx2);
     }
+    SCHUR_TICK(1)
     __syncthreads();
-    const bool more = nx < c1;
-    const int nx2 = more ? next_chunk(nx + 1) : c1;
-    if (more) {
-      load_blk(aT, eT, nx, !offdiag, ta, blv);
-      if (offdiag) load_blk(aB, eB, nx, true, tb, blv);
-      eT = tab_of(aT, nx2);
-      if (offdiag) eB = tab_of(aB, nx2);
-      if (tid < kChunkLm) load_hll(nx);
+    SCHUR_TICK(2)
+    const int nx3 = nx2 < c1 ? next_chunk(nx2 + 1) : c1;
+    if (wv < 3 && nx < c1) {
+      load_blk(eT, ta);
+      if (offdiag) load_blk(eB, tb);
+      if (spT) load_special(aT, nx, !offdiag, spT3, blv);
+      if (offdiag && spB) load_special(aB, nx, true, spB3, blv);
+      eT = tab_of(aT, aTc, nx2);
+      if (offdiag) eB = tab_of(aB, aBc, nx2);
     }
+    SCHUR_TICK(3)
     {
       const double* pa = sT + (wv * 16 + (lane & 15)) * kLd + (lane >> 4);
       const double* pb = sB + (lane & 15) * kLd + (lane >> 4);
@@ -925,9 +962,14 @@ k_lba_schur(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, con
       acc[0][0] += pa[0] + pb[0];
 #endif
     }
-    if (more && tid < kChunkLm) store_dinv(buf ^ 1);
-    buf ^= 1, ch = nx, nx = nx2;
+    SCHUR_TICK(4)
+    buf ^= 1, ch = nx, nx = nx2, nx2 = nx3;
   }
+#ifdef VIEO_SCHUR_PROBE
+  if ((blockIdx.x == 3 || blockIdx.x == 40) && (blockIdx.y == 0 || blockIdx.y == 3) && (tid == 0 || tid == 64 || tid == 200))
+    printf("schur probe w %d bx %d tid %d tile (%d,%d) chunks %d: wait_A %lld stage %lld wait_B %lld issue_loads %lld mfma %lld\n",
+           w, (int)blockIdx.x, tid, bi, bj, c1 - c0, tp[0], tp[1], tp[2], tp[3], tp[4]);
+#endif
   // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
   double* S = D.Sp + (size_t)split * D.sp_stride;
 #pragma unroll
@@ -2138,11 +2180,12 @@ struct LbaKTimer {
   void fold(double schur_flops_per_launch) {  // after the stream was synchronised
     if (!on || cls.empty()) return;
     std::lock_guard<std::mutex> g(g_lba_kt_mutex);
+    bool schur_seen = false;  // a round's Schur complement is two launches (diagonal / off-diagonal tiles): FLOPs once
     for (size_t i = 0; i < cls.size(); i++) {
       float ms = 0;
       if (!count_only && hipEventElapsedTime(&ms, pool[2 * i], pool[2 * i + 1]) != hipSuccess) continue;
       g_lba_kt_ms[cls[i]] += ms, g_lba_kt_launches[cls[i]]++;
-      if (cls[i] == KC_SCHUR) g_lba_kt_schur_flops += schur_flops_per_launch;
+      if (cls[i] == KC_SCHUR && !schur_seen) g_lba_kt_schur_flops += schur_flops_per_launch, schur_seen = true;
     }
     cls.clear();
   }
@@ -2445,7 +2488,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (gba) return std::max(1, std::min(std::min(nch, 16), 768 / nbt));
     return std::max(1, std::min(std::min((nch + cps_target - 1) / cps_target, 32), std::max(1, 512 / nbt)));
   };
-  int schur_grid = 1;
+  int schur_grid = 0, schur_grid_off = 0;  // diagonal / off-diagonal tiles x splits, largest over the windows
   std::vector<size_t> scratch_off(W);
   struct Scr {
     size_t kf_bak, X_bak, mp_act, BB, Bs, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
@@ -2466,10 +2509,14 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     s.kf_bak = take((size_t)H.n_kf * sizeof(LbaKf)), s.X_bak = take((size_t)H.n_mp * 24);
     s.mp_act = take(H.n_mp);
     const int sp_rows = (npm + 63) / 64 * 64, ldS = (npm + 64) / 64 * 64;
-    s.BB = take((size_t)std::max(H.n_obs, 1) * 144);
+    s.BB = take(((size_t)H.n_obs + 1) * 144);  // + the zero block
     s.Bs = sco ? take((size_t)std::max(H.n_mp, 1) * 24) : 0;
     const int ksplit = schur_ksplit(nf, H.n_mp);
-    schur_grid = std::max(schur_grid, schur_tiles(nf) * ksplit);
+    {
+      const int RBw = (npm + 63) / 64;
+      schur_grid = std::max(schur_grid, RBw * ksplit);
+      schur_grid_off = std::max(schur_grid_off, (schur_tiles(nf) - RBw) * ksplit);
+    }
     s.Sp = take((size_t)ksplit * sp_rows * ldS * 8);
     s.Hll = take((size_t)H.n_mp * 72), s.bl = take((size_t)H.n_mp * 24);
     const int npf = pd * nf + sco;  // full reduced system
@@ -2856,7 +2903,9 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     }
     if (any & LBA_BEGIN) KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO); });
     if (any & LBA_TRIAL) {
-      KT.launch(KC_SCHUR, [&] { hipLaunchKernelGGL(k_lba_schur, dim3(schur_grid, W), dim3(256), 0, st, dD, dC, dO); });
+      KT.launch(KC_SCHUR, [&] { hipLaunchKernelGGL(k_lba_schur<false>, dim3(std::max(1, schur_grid), W), dim3(256), 0, st, dD, dC, dO); });
+      if (schur_grid_off > 0)
+        KT.launch(KC_SCHUR, [&] { hipLaunchKernelGGL(k_lba_schur<true>, dim3(schur_grid_off, W), dim3(256), 0, st, dD, dC, dO); });
       if (sh) {  // the one exchange step of the path: sum the reduced visual system over the ranks
         const int nv = 6 * max_nf + sco;
         KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_pack, dim3((unsigned)((shard_sys_doubles(max_nf, sco) + 255) / 256), W), dim3(256), 0, st,
