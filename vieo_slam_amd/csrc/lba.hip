@@ -447,7 +447,7 @@ __device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& 
 // The two halves are two launches (KFHALF): the point half needs 162 registers, the key-frame half 254, and in one
 // kernel the point half's 64 % of the workgroups ran at the key-frame half's two wavefronts per SIMD.
 template <bool MULTICAM, bool SCALE, bool KFHALF>
-__global__ void __launch_bounds__(256, KFHALF ? 2 : 3)
+__global__ void __launch_bounds__(256, 2)
 k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   const int bx = blockIdx.x;
   __shared__ double s_red[4 * 27];
@@ -471,13 +471,37 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
       const double Xh[3] = {D.X[3 * (size_t)m], D.X[3 * (size_t)m + 1], D.X[3 * (size_t)m + 2]};
       const double Xw[3] = {Xh[0] * sc, Xh[1] * sc, Xh[2] * sc};
       const int first = D.mp_first[m], cnt = D.mp_count[m];
-      for (int j = sub; j < cnt; j += 4) {
-        const int i = first + j;
-        if (D.level[i]) continue;
-        const vieo_lba_obs o = D.obs[i];
+      // A lane's edges four at a time: their records and level bytes first, then the four key-frame poses, then the
+      // arithmetic -- three dependent round trips per FOUR edges instead of per edge (level -> record -> key frame).
+      // Same edges in the same order per lane, so the sums are bit-identical.
+      for (int j0 = sub; j0 < cnt; j0 += 16) {
+        vieo_lba_obs ou[4];
+        unsigned char lv[4], oc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = first + min(j0 + 4 * u, cnt - 1);
+          ou[u] = D.obs[i], lv[u] = D.level[i];
+          oc[u] = (MULTICAM && D.n_cams) ? D.ocam[i] : (unsigned char)0;
+        }
+        double kp[4][7];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const LbaKf& K = D.kf[ou[u].kf];
+          kp[u][0] = K.p[0], kp[u][1] = K.p[1], kp[u][2] = K.p[2];
+          kp[u][3] = K.qw, kp[u][4] = K.qx, kp[u][5] = K.qy, kp[u][6] = K.qz;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+        if (j0 + 4 * u >= cnt || lv[u]) continue;
+        const vieo_lba_obs o = ou[u];
         PoseXf X;
-        const CamD& C = obs_cam(D, i);
-        kf_xf(C, D.kf[o.kf], X);
+        const CamD& C = (MULTICAM && D.n_cams) ? D.cams[oc[u]] : D.cam;
+        {
+          Est e;
+          e.p[0] = kp[u][0], e.p[1] = kp[u][1], e.p[2] = kp[u][2];
+          e.qw = kp[u][3], e.qx = kp[u][4], e.qy = kp[u][5], e.qz = kp[u][6];
+          make_xf(C, e, X);
+        }
         double err[3], Pc[3];
         const double chi2 = lba_edge_error(C, X, o, Xw, err, Pc);
         const bool stereo = o.ur >= 0;
@@ -516,6 +540,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
             acc[t] += Jx[a] * ww * Jx[b] + Jx[3 + a] * ww * Jx[3 + b] + Jx[6 + a] * ww * Jx[6 + b];
           acc[6 + a] += Jx[a] * (-(info * err[0]) * r1) + Jx[3 + a] * (-(info * err[1]) * r1) +
                         Jx[6 + a] * (-(info * err[2]) * r1);
+        }
         }
       }
     }
