@@ -348,6 +348,21 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   const float factor = 1.0f / kHistoLen;
   const int stride = kSbpBlocks * 4;
   const uint4* QQ = (const uint4*)(A.queries + (size_t)f * A.q_cap);
+  // Pool space comes in slabs of kCandCap entries per wavefront (a query keeps at most kCandCap candidates): one global
+  // atomic per slab instead of one per query -- the atomic's round trip was one of the three dependent ones of every
+  // query (window records -> reservation -> descriptors).  The tail of a slab stays unused; the queries' records carry
+  // their own base, nothing reads the pool front to back.
+  int slab_cur = 0, slab_end = 0;  // wave-uniform
+  auto reserve = [&](int total) -> int {
+    if (slab_cur + total > slab_end) {
+      int b = 0;
+      if (lane == 0) b = atomicAdd(&A.cursor[f], kCandCap);
+      slab_cur = __builtin_amdgcn_readfirstlane(b), slab_end = slab_cur + kCandCap;
+    }
+    const int base = slab_cur;
+    slab_cur += total;
+    return base;
+  };
   int q = blockIdx.x * 4 + wave;
   uint4 h0 = {0, 0, 0, 0}, a0 = h0, a1 = h0;
   if (q < nq) h0 = QQ[4 * (size_t)q], a0 = QQ[4 * (size_t)q + 2], a1 = QQ[4 * (size_t)q + 3];
@@ -440,9 +455,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
         if (lane == 0) *out = make_int2(0, 0);
         continue;
       }
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&A.cursor[f], total);
-      base = __builtin_amdgcn_readfirstlane(base);
+      const int base = reserve(total);
       if (base + total > A.pool_cap) {
         if (lane == 0) *out = make_int2(0, -1);
         continue;
@@ -460,9 +473,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
       if (lane == 0) *out = make_int2(0, total == 0 ? 0 : -1);
       continue;
     }
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&A.cursor[f], total);
-    base = __builtin_amdgcn_readfirstlane(base);
+    const int base = reserve(total);
     if (base + total > A.pool_cap) {
       if (lane == 0) *out = make_int2(0, -1);
       continue;
@@ -898,8 +909,9 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
     set_error("search_by_projection: n_cams = %d (1..%d)", A.n_cams, kMaxCams);
     return VIEO_E_INVALID;
   }
-  // candidate pool: 32 per query on average (a single query may hold up to kCandCap)
-  A.pool_cap = std::max(std::min(A.q_cap, 2 * kMaxKeys) * 32, 2 * kCandCap);
+  // candidate pool: 32 per query on average (a single query may hold up to kCandCap), plus the unused tail of one slab
+  // per wavefront of k_sbp_candidates
+  A.pool_cap = std::max(std::min(A.q_cap, 2 * kMaxKeys) * 32, 2 * kCandCap) + kSbpBlocks * 4 * kCandCap;
   static const int pool_lds_env = [] {
     const char* e = getenv("VIEO_SBP_POOL_LDS");
     return e ? atoi(e) : 0;
