@@ -329,6 +329,10 @@ static const int kSbpBlocks = 8;
 
 __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   extern __shared__ unsigned short s_cs[];  // [n_cams][kGridCells + 1] camera-local offsets (< kMaxKeys: 16 bits)
+  constexpr int kBigCap = 1024;
+  __shared__ int s_big[kBigCap];  // the queries pass 1 leaves to pass 2
+  __shared__ int s_nbig;
+  if (threadIdx.x == 0) s_nbig = 0;
   // (wave-uniform wavefront index: the query walk then runs on scalar registers and scalar loads)
   const int f = blockIdx.y, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int nq = min(A.nq[f], A.q_cap);
@@ -363,29 +367,168 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
     slab_cur += total;
     return base;
   };
-  int q = blockIdx.x * 4 + wave;
-  uint4 h0 = {0, 0, 0, 0}, a0 = h0, a1 = h0;
-  if (q < nq) h0 = QQ[4 * (size_t)q], a0 = QQ[4 * (size_t)q + 2], a1 = QQ[4 * (size_t)q + 3];
-  uint4 h1 = {0, 0, 0, 0};
-  if (q < nq) h1 = QQ[4 * (size_t)q + 1];
-  for (; q < nq; q += stride) {
-    // current query in registers; fetch the next one now
+  // ---- pass 1: FOUR queries per wavefront, one per row of 16 lanes.  A window holds a handful of keys (1200 keys over
+  // 3072 cells), so with a wavefront per query most lanes idled through three dependent round trips per query (window
+  // records -> reservation -> descriptors) and a wavefront walked ~134 queries one after the other.  A row takes a query
+  // whose window spans at most 16 grid columns and 64 entries (`small`, four steps of 16); the others are left to pass 2, the
+  // wavefront-per-query form below, which recomputes the same predicate and skips the small ones.
+  {
+    const int g = lane >> 4, gl = lane & 15;
+    const int stride4 = kSbpBlocks * 16;
+    uint4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0;  // the next iteration's record, fetched an iteration ahead
+    {
+      const int qf = (blockIdx.x * 4 + wave) * 4 + g;
+      if (qf < nq) n0 = QQ[4 * (size_t)qf], n1 = QQ[4 * (size_t)qf + 1], n2 = QQ[4 * (size_t)qf + 2], n3 = QQ[4 * (size_t)qf + 3];
+    }
+    for (int q0 = (blockIdx.x * 4 + wave) * 4; q0 < nq; q0 += stride4) {
+      const int qg = q0 + g;
+      const bool qin = qg < nq;
+      const uint4 g0 = n0, g1 = n1, e0 = n2, e1 = n3;
+      {
+        const int qn = qg + stride4;
+        if (qn < nq) n0 = QQ[4 * (size_t)qn], n1 = QQ[4 * (size_t)qn + 1], n2 = QQ[4 * (size_t)qn + 2], n3 = QQ[4 * (size_t)qn + 3];
+      }
+      const float x = __uint_as_float(g0.x), y = __uint_as_float(g0.y), q_ur = __uint_as_float(g0.z);
+      const float r = __uint_as_float(g0.w);
+      const int minlevel = (int)g1.x, maxlevel = (int)g1.y, flags = (int)g1.w;
+      const float q_angle = __uint_as_float(g1.z);
+      const int cam = (flags >> 8) & 15;
+      bool valid = qin && (flags & 1) && cam < A.n_cams;
+      const int camc = valid ? cam : 0;
+      const float minx = A.bounds[camc][0], miny = A.bounds[camc][2];
+      const float winv = (float)kGridCols / (A.bounds[camc][1] - minx), hinv = (float)kGridRows / (A.bounds[camc][3] - miny);
+      int k0 = 0;
+      if (A.cam_first) k0 = min(A.cam_first[(size_t)f * (A.n_cams + 1) + camc], A.key_cap);
+      const unsigned short* cs = s_cs + camc * (kGridCells + 1);
+      const int min_cellx = max(0, (int)floorf((x - minx - r) * winv));
+      const int max_cellx = min(kGridCols - 1, (int)ceilf((x - minx + r) * winv));
+      const int min_celly = max(0, (int)floorf((y - miny - r) * hinv));
+      const int max_celly = min(kGridRows - 1, (int)ceilf((y - miny + r) * hinv));
+      const bool empty = min_cellx >= kGridCols || max_cellx < 0 || min_celly >= kGridRows || max_celly < 0 ||
+                         min_cellx > max_cellx || min_celly > max_celly;
+      const int nx = max_cellx - min_cellx + 1;
+      const bool narrow = valid && !empty && nx <= 16;
+      int seg_s = 0, seg_l = 0;
+      if (narrow && gl < nx) {
+        const int col = (min_cellx + gl) * kGridRows;
+        seg_s = cs[col + min_celly];
+        seg_l = cs[col + max_celly + 1] - seg_s;
+      }
+      // inclusive scan inside the row of 16 lanes (zeros shift in)
+      int inc = seg_l;
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);  // row_shr:1
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);  // row_shr:2
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);  // row_shr:4
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);  // row_shr:8
+      const int n_ent = __builtin_amdgcn_ds_bpermute((g * 16 + 15) * 4, inc);
+      const bool small = narrow && n_ent <= 64;
+      // up to four steps of 16 entries (uniform trip count: the largest small window of the four)
+      const int ne_s = small ? n_ent : 0;
+      const int ne_max = max(max(__builtin_amdgcn_readlane(ne_s, 0), __builtin_amdgcn_readlane(ne_s, 16)),
+                             max(__builtin_amdgcn_readlane(ne_s, 32), __builtin_amdgcn_readlane(ne_s, 48)));
+      const int nit = (ne_max + 15) >> 4;
+      const float4* rec = rec_f + k0;
+      const bool bchecklevel = (minlevel > 0) || (maxlevel >= 0);
+      int sl_it[4], pk_it[4];
+      unsigned long long m_it[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        sl_it[it] = 0, pk_it[it] = 0;
+        if (it >= nit) continue;  // uniform
+        // entry t of the window: the run it falls into = the number of runs that end at or before t (their inclusive
+        // ends come round the row on DPP rotations; lanes past nx hold n_ent, which is > t for an entry)
+        const int t = it * 16 + gl;
+        int idx = (inc <= t) ? 1 : 0;
+#define VIEO_ROR(n) idx += (__builtin_amdgcn_update_dpp(0, inc, 0x120 + (n), 0xF, 0xF, false) <= t) ? 1 : 0;
+        VIEO_ROR(1) VIEO_ROR(2) VIEO_ROR(3) VIEO_ROR(4) VIEO_ROR(5) VIEO_ROR(6) VIEO_ROR(7) VIEO_ROR(8)
+        VIEO_ROR(9) VIEO_ROR(10) VIEO_ROR(11) VIEO_ROR(12) VIEO_ROR(13) VIEO_ROR(14) VIEO_ROR(15)
+#undef VIEO_ROR
+        idx = min(idx, 15);
+        const int src = (g * 16 + idx) * 4;
+        const int run_s = __builtin_amdgcn_ds_bpermute(src, seg_s), run_inc = __builtin_amdgcn_ds_bpermute(src, inc),
+                  run_l = __builtin_amdgcn_ds_bpermute(src, seg_l);
+        const int sl = run_s + (t - (run_inc - run_l));
+        bool pass = small && t < n_ent;
+        if (pass) {
+          const float4 k = rec[sl];
+          const int pk = __float_as_int(k.w), oct = pk >> 16;
+          pk_it[it] = pk;
+          if (bchecklevel && (oct < minlevel || (maxlevel >= 0 && oct > maxlevel))) pass = false;
+          if (!(fabsf(k.x - x) < r && fabsf(k.y - y) < r)) pass = false;
+          if (A.mode != VIEO_SBP_RELOC && k.z > 0 && fabsf(q_ur - k.z) > r) pass = false;
+        }
+        sl_it[it] = sl;
+        m_it[it] = __ballot(pass);
+      }
+      // totals per row (query) and the rows' offsets inside one reservation
+      const int sh = 16 * g;
+      int tg[4], tot_g = 0;
+#pragma unroll
+      for (int it = 0; it < 4; it++) tg[it] = __popc((unsigned)((m_it[it] >> sh) & 0xFFFFull)), tot_g += tg[it];
+      const int T0 = __builtin_amdgcn_readlane(tot_g, 0), T1 = __builtin_amdgcn_readlane(tot_g, 16),
+                T2 = __builtin_amdgcn_readlane(tot_g, 32), T3 = __builtin_amdgcn_readlane(tot_g, 48);
+      // (a row whose window holds more than kCandCap candidates cannot happen here: at most 64 entries)
+      const int tot_all = T0 + T1 + T2 + T3;
+      const int off_g = g == 0 ? 0 : (g == 1 ? T0 : (g == 2 ? T0 + T1 : T0 + T1 + T2));
+      int base = 0;
+      bool over = false;
+      if (tot_all > 0) {  // (uniform) one reservation for the four queries; 4 x 64 entries at most = two slabs
+        if (tot_all > kCandCap) {  // larger than a slab: its own reservation
+          int bb = 0;
+          if (lane == 0) bb = atomicAdd(&A.cursor[f], tot_all);
+          base = __builtin_amdgcn_readfirstlane(bb);
+        } else
+          base = reserve(tot_all);
+        over = base + tot_all > A.pool_cap;
+      }
+      int wpos = base + off_g;
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        if (it >= nit) continue;
+        const unsigned gm = (unsigned)((m_it[it] >> sh) & 0xFFFFull);
+        if (((gm >> gl) & 1u) && !over) {
+          const int packed = pk_it[it], sl = sl_it[it];
+          const int j = packed & 0xFFFF, oct = packed >> 16;
+          const int d = hamming32q(e0, e1, D + (size_t)j * 32);
+          float rot = q_angle - (ang_f + k0)[sl];
+          if (rot < 0.0f) rot += 360.0f;
+          int bin = (int)roundf(rot * factor);
+          if (bin == kHistoLen) bin = 0;
+          pool[wpos + __popc(gm & ((1u << gl) - 1u))] =
+              (unsigned)j | ((unsigned)d << 13) | ((unsigned)(oct & 15) << 22) | ((unsigned)(bin & 31) << 26);
+        }
+        wpos += tg[it];
+      }
+      if (gl == 0 && qin) {
+        int2* out = A.qrec + (size_t)f * A.q_cap + qg;
+        if (!valid || empty)
+          *out = make_int2(0, 0);
+        else if (small)
+          *out = tot_g == 0 ? make_int2(0, 0) : (over ? make_int2(0, -1) : make_int2(base + off_g, tot_g | ((flags & 2) ? 1 << 16 : 0)));
+        else {  // a wide or crowded window: pass 2
+          const int k = atomicAdd(&s_nbig, 1);
+          if (k < kBigCap) s_big[k] = qg;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: a wavefront per query for the windows pass 1 left (more than 16 columns or 64 entries)
+  // (the block's own list of them; if it overflowed, every query of the stride is looked at again and the small ones skipped)
+  const int nbig = s_nbig;
+  const bool listed = nbig <= kBigCap;
+  const int n2 = listed ? nbig : nq;
+  for (int k2 = listed ? wave : blockIdx.x * 4 + wave; k2 < n2; k2 += listed ? 4 : stride) {
+    const int q = listed ? s_big[k2] : k2;
+    const uint4 h0 = QQ[4 * (size_t)q], h1 = QQ[4 * (size_t)q + 1];
+    const uint4 d0 = QQ[4 * (size_t)q + 2], d1 = QQ[4 * (size_t)q + 3];
     const float x = __uint_as_float(h0.x), y = __uint_as_float(h0.y), q_ur = __uint_as_float(h0.z);
     const float r = __uint_as_float(h0.w);
     const int minlevel = (int)h1.x, maxlevel = (int)h1.y, flags = (int)h1.w;
     const float q_angle = __uint_as_float(h1.z);
-    const uint4 d0 = a0, d1 = a1;
-    const int qn = q + stride;
-    if (qn < nq) {
-      h0 = QQ[4 * (size_t)qn], h1 = QQ[4 * (size_t)qn + 1];
-      a0 = QQ[4 * (size_t)qn + 2], a1 = QQ[4 * (size_t)qn + 3];
-    }
     int2* out = A.qrec + (size_t)f * A.q_cap + q;
     const int cam = (flags >> 8) & 15;
-    if (!(flags & 1) || cam >= A.n_cams) {
-      if (lane == 0) *out = make_int2(0, 0);
-      continue;
-    }
+    if (!(flags & 1) || cam >= A.n_cams) continue;  // pass 1 wrote its empty record
     // the query's camera: bounds, its slice of the records (camera c's records start at its first key)
     const float minx = A.bounds[cam][0], miny = A.bounds[cam][2];
     const float winv = (float)kGridCols / (A.bounds[cam][1] - minx), hinv = (float)kGridRows / (A.bounds[cam][3] - miny);
@@ -400,10 +543,8 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
     const int min_celly = max(0, (int)floorf((y - miny - r) * hinv));
     const int max_celly = min(kGridRows - 1, (int)ceilf((y - miny + r) * hinv));
     if (min_cellx >= kGridCols || max_cellx < 0 || min_celly >= kGridRows || max_celly < 0 ||
-        min_cellx > max_cellx || min_celly > max_celly) {
-      if (lane == 0) *out = make_int2(0, 0);
-      continue;
-    }
+        min_cellx > max_cellx || min_celly > max_celly)
+      continue;  // (pass 1 wrote its empty record)
     const bool bchecklevel = (minlevel > 0) || (maxlevel >= 0);
     const int nx = max_cellx - min_cellx + 1;
     int seg_s = 0, seg_l = 0;
@@ -414,6 +555,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
     }
     int n_ent;
     const int seg_o = wave_excl_scan_i(seg_l, lane, &n_ent);  // first window entry of the run
+    if (nx <= 16 && n_ent <= 64) continue;  // pass 1 did it
     // entry t of the window -> record, tests.  A key inside the window is a candidate unless its
     // stereo coordinate disagrees with the query's (ORBmatcher.cc:1421-1426 / :278-283) -- the one test of
     // the inner loop that does not depend on what earlier queries claimed, so it is applied here.
