@@ -396,13 +396,18 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
 // as many of these workgroups as their LDS allows.  Measured on 1024 images: 6.5 KB of LDS per cell (candidate list
 // sized for the worst case) 2.05 ms, 4.8 KB (list capped, see fast_cell) 1.78 ms, 8.8 KB 2.2 - 2.4 ms -- which is also
 // why a second tile buffer for prefetching the next cell (by LDS-DMA or through registers) lost more than it hid.
-__global__ void __launch_bounds__(64)
+#ifndef VIEO_FAST_WAVES
+#define VIEO_FAST_WAVES 1  // wavefronts (= cells) per workgroup; each keeps its own LDS slice, no workgroup barrier
+#endif
+__global__ void __launch_bounds__(64 * VIEO_FAST_WAVES)
 k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __restrict__ cell_keys,
        int* __restrict__ cell_counts, int iniTh, int minTh, int tpitch, int tile_bytes,
-       int score_bytes, int cand_cap, int n_images) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int lane = threadIdx.x;
-  const int item = xcd_grouped(blockIdx.x, kXcdRun);  // item = image * ncells + cell
+       int score_bytes, int cand_cap, int n_images, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* smem = smem_all + wave_in_wg * lds_per_wave;
+  const int item = xcd_grouped(blockIdx.x, kXcdRun) * VIEO_FAST_WAVES + wave_in_wg;  // item = image * ncells + cell
   if (item >= P.ncells * n_images) return;
   const int b = item / P.ncells, c = item - b * P.ncells;
   const CellDesc cd = cells[c];
@@ -1189,9 +1194,11 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
     set_error("batch too large for one launch");
     return VIEO_E_CAPACITY;
   }
-  hipLaunchKernelGGL(k_fast, dim3(xcd_grid((long long)P.ncells * B)), dim3(64), (size_t)align_up(e->fast_lds, 16), st, P, I,
+  hipLaunchKernelGGL(k_fast, dim3(xcd_grid(((long long)P.ncells * B + VIEO_FAST_WAVES - 1) / VIEO_FAST_WAVES)), dim3(64 * VIEO_FAST_WAVES),
+                     (size_t)align_up(e->fast_lds, 16) * VIEO_FAST_WAVES, st, P, I,
                      e->d_cells.as<CellDesc>(), e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
-                     e->iniTh, e->minTh, e->tpitch, e->tile_bytes, e->score_bytes, e->fast_cand_cap, B);
+                     e->iniTh, e->minTh, e->tpitch, e->tile_bytes, e->score_bytes, e->fast_cand_cap, B,
+                     (int)align_up(e->fast_lds, 16));
   STAMP();
   hipLaunchKernelGGL(k_quadtree, dim3(P.nlevels, B), dim3(256), e->qt_lds, st, P,
                      e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
