@@ -58,7 +58,9 @@ def test_oracle_lba_edge_cases(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,kw", [(0, {}), (1, {}), (2, dict(n_local=25, n_fixed=10, n_points=2500)),
                                      (6, dict(n_local=4, n_fixed=0, n_points=300, first_fixed=True)),
-                                     (7, dict(n_local=3, n_fixed=2, n_points=150, stereo_frac=0.0))])
+                                     (7, dict(n_local=3, n_fixed=2, n_points=150, stereo_frac=0.0)),
+                                     # 30 key frames x 6 = 180 unknowns: the L2-resident one-workgroup solver with 6-dim blocks
+                                     (8, dict(n_local=30, n_fixed=8, n_points=2500))])
 def test_gpu_lba_parity(oracle, seed, kw):
     from vieo_slam_amd.optimizer import Optimizer
     params, kfs, pts, obs, gt = synth_ba.make_lba_problem(seed, **kw)
