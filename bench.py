@@ -573,9 +573,11 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     futs = []
+    skip_fe = bool(os.environ.get("VIEO_BENCH_SKIP_FE"))  # experiment: the bundle-adjustment engine's capacity alone
     for _ in range(a.steps):
         for q in pipes:
-            q.step()
+            if not skip_fe:
+                q.step()
         futs += [pool.submit(run_lba, c) for c in chunks]
     lba_res = [r for f in futs for r in f.result()]
     sync_all()
