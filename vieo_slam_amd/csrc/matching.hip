@@ -158,121 +158,151 @@ __global__ void __launch_bounds__(256) k_stereo_rows(StereoArgs A) {
   }
 }
 
-// grid (ceil(capL/4), n_frames); one wave per left key.
+// grid (ceil(capL/16), n_frames); FOUR left keys per wavefront, one per row of 16 lanes (round 3).  A key's row holds
+// about 20 candidates and its refinement is 121 + 231 bytes of patches: with a wavefront per key most lanes idled through
+// a chain of four dependent round trips (key -> row list -> descriptors -> patches) and 2.5 M wavefronts queued for
+// them.  Same arithmetic: the best match is the minimum of (distance, index), the SADs are integer sums.
+__device__ __forceinline__ unsigned row_min_u32(unsigned v) {  // minimum over the lane's row of 16
+  v = min(v, (unsigned)VIEO_DPP(v, v, VIEO_DPP_QUAD_XOR1, 0xF));
+  v = min(v, (unsigned)VIEO_DPP(v, v, VIEO_DPP_QUAD_XOR2, 0xF));
+  v = min(v, (unsigned)VIEO_DPP(v, v, VIEO_DPP_ROW_HALF_MIRROR, 0xF));
+  v = min(v, (unsigned)VIEO_DPP(v, v, VIEO_DPP_ROW_MIRROR, 0xF));
+  return v;
+}
+__device__ __forceinline__ int row_sum_i32(int v) {  // sum over the lane's row of 16 (every lane receives it)
+  v += VIEO_DPP(0, v, VIEO_DPP_QUAD_XOR1, 0xF);
+  v += VIEO_DPP(0, v, VIEO_DPP_QUAD_XOR2, 0xF);
+  v += VIEO_DPP(0, v, VIEO_DPP_ROW_HALF_MIRROR, 0xF);
+  v += VIEO_DPP(0, v, VIEO_DPP_ROW_MIRROR, 0xF);
+  return v;
+}
+
 __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
-  const int f = blockIdx.y, lane = threadIdx.x & 63;
-  // wave-uniform key index: the key, its descriptor, its level's descriptor and later the best right key then come
-  // through scalar loads instead of chains of per-lane global loads of the same address
-  const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int f = blockIdx.y, lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int iL = (blockIdx.x * 4 + wave) * 4 + g;
   const int imL = A.l_first + f * A.l_step, imR = A.r_first + f * A.r_step;
-  const int N = min(A.cntL[2 * imL], A.capL), Nr = min(A.cntR[2 * imR], A.capR);
-  if (iL >= N) return;
-  float* o_ur = A.uright + (size_t)f * A.capL + iL;
-  float* o_dp = A.depth + (size_t)f * A.capL + iL;
-  int* o_sad = A.sad + (size_t)f * A.capL + iL;
-  if (lane == 0) *o_ur = -1.0f, *o_dp = -1.0f, *o_sad = -1;
-  const vieo_keypoint kL = A.kpL[(size_t)imL * A.capL + iL];
+  const int N = min(A.cntL[2 * imL], A.capL);
+  bool alive = iL < N;
+  const int iLc = alive ? iL : 0;
+  float* o_ur = A.uright + (size_t)f * A.capL + iLc;
+  float* o_dp = A.depth + (size_t)f * A.capL + iLc;
+  int* o_sad = A.sad + (size_t)f * A.capL + iLc;
+  if (alive && gl == 0) *o_ur = -1.0f, *o_dp = -1.0f, *o_sad = -1;
+  if (!__any(alive)) return;
+  const vieo_keypoint kL = A.kpL[(size_t)imL * A.capL + iLc];
   const int levelL = kL.octave;
   const float vL = kL.y, uL = kL.x;
   const int rowL = (int)vL;  // vRowIndices[vL]
   const float minD = 0.f, maxD = A.bf / A.baseline;
   const float minU = uL - maxD, maxU = uL - minD;
-  if (maxU < 0) return;
-  const uint8_t* dL = A.descL + ((size_t)imL * A.capL + iL) * 32;
+  alive = alive && !(maxU < 0) && rowL >= 0 && rowL < A.H;
+  const int rowc = min(max(rowL, 0), A.H - 1);
+  const uint8_t* dL = A.descL + ((size_t)imL * A.capL + iLc) * 32;
   const uint4 a0 = ((const uint4*)dL)[0], a1 = ((const uint4*)dL)[1];
-  const vieo_keypoint* KR = A.kpR + (size_t)imR * A.capR;
   const uint8_t* DR = A.descR + (size_t)imR * A.capR * 32;
   int bestDist = TH_HIGH, bestIdx = INT_MAX;
   float bestX = 0.f;  // column of the lane's best right key (it travels with the row list)
-  if (rowL < 0 || rowL >= A.H) return;
   const int* rs = A.row_start + (size_t)f * (A.H + 1);
   const int2* list = A.row_list + (size_t)f * A.list_cap;
-  const int c0 = rs[rowL], c1 = min(rs[rowL + 1], A.list_cap);
-  (void)Nr;
-  for (int c = c0 + lane; c < c1; c += 64) {
-    const int2 e = list[c];  // the key's octave and column travel with the list entry
-    const int j = e.x & 0xFFFFF, octR = e.x >> 20;
-    const float xR = __int_as_float(e.y);
-    if (octR < levelL - 1 || octR > levelL + 1) continue;
-    if (!(xR >= minU && xR <= maxU)) continue;
-    const int d = hamming32(a0, a1, DR + (size_t)j * 32);
-    if (d < TH_HIGH && lex_less(d, j, bestDist, bestIdx)) bestDist = d, bestIdx = j, bestX = xR;
+  const int c0 = rs[rowc], c1 = alive ? min(rs[rowc + 1], A.list_cap) : c0;
+  // two list entries per lane and pass (32 candidates per key), both entries and then both descriptors in flight
+  for (int cb = c0; __any(cb < c1); cb += 32) {
+    int2 e[2];
+    bool in[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int c = cb + gl + 16 * u;
+      in[u] = c < c1;
+      e[u] = in[u] ? list[c] : make_int2(0, 0);
+    }
+    int dd[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int j = e[u].x & 0xFFFFF, octR = e[u].x >> 20;
+      const float xR = __int_as_float(e[u].y);
+      in[u] = in[u] && !(octR < levelL - 1 || octR > levelL + 1) && (xR >= minU && xR <= maxU);
+      dd[u] = in[u] ? hamming32(a0, a1, DR + (size_t)j * 32) : TH_HIGH;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int j = e[u].x & 0xFFFFF;
+      if (in[u] && dd[u] < TH_HIGH && lex_less(dd[u], j, bestDist, bestIdx))
+        bestDist = dd[u], bestIdx = j, bestX = __int_as_float(e[u].y);
+    }
   }
   const int myIdx = bestIdx;
-  {  // lexicographic minimum of (distance, index) as ONE key (distance <= 256, index < 2^20)
-    const unsigned m = wave_min_u32(bestIdx == INT_MAX ? 0xFFFFFFFFu : ((unsigned)bestDist << 20) | (unsigned)bestIdx);
+  {  // lexicographic minimum of (distance, index) as ONE key (distance <= 256, index < 2^20), per row of 16 lanes
+    const unsigned m = row_min_u32(bestIdx == INT_MAX ? 0xFFFFFFFFu : ((unsigned)bestDist << 20) | (unsigned)bestIdx);
     bestIdx = m == 0xFFFFFFFFu ? INT_MAX : (int)(m & 0xFFFFF);
     bestDist = m == 0xFFFFFFFFu ? INT_MAX : (int)(m >> 20);
   }
-  if (bestIdx == INT_MAX || bestDist >= (TH_HIGH + TH_LOW) / 2) return;
+  alive = alive && bestIdx != INT_MAX && bestDist < (TH_HIGH + TH_LOW) / 2;
   // ---- sub-pixel refinement by 11 SADs of 11x11 patches at the key's pyramid level
-  // the winner's column from the lane that found it (one dependent load less than KR[bestIdx].x)
-  const unsigned long long own = __ballot(myIdx == bestIdx);
-  const float uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bestX), __builtin_ffsll((long long)own) - 1));
+  // the winner's column from the lane of the row that found it
+  const unsigned long long own = __ballot(alive && myIdx == bestIdx);
+  const unsigned own_g = (unsigned)((own >> (16 * g)) & 0xFFFFull);
+  const int src_lane = g * 16 + (own_g ? __builtin_ffs((int)own_g) - 1 : 0);
+  const float uR0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(bestX)));
   const float sF = 1.0f / A.P.lv[levelL].scale;  // mvInvScaleFactors[octave]
   const float scaleduL = roundf(kL.x * sF), scaledvL = roundf(kL.y * sF);
   const float scaleduR0 = roundf(uR0 * sF);
   const int w = 5, L = 5;
   const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
-  if (iniu < 0 || endu >= (float)A.P.lv[levelL].w) return;
+  const int lvw = A.P.lv[levelL].w, lvh = A.P.lv[levelL].h;
+  alive = alive && !(iniu < 0 || endu >= (float)lvw);
+  if (!__any(alive)) return;
   int pitchL, pitchR;
   const uint8_t* PL = plane_ptr(A.P, A.IL, imL, levelL, &pitchL);
   const uint8_t* PR = plane_ptr(A.P, A.IR, imR, levelL, &pitchR);
   const int r0 = (int)(scaledvL - w), cL0 = (int)(scaleduL - w), cR0 = (int)(scaleduR0 - w);
-  const int cvL = PL[(size_t)(r0 + w) * pitchL + cL0 + w];
-  // each lane owns up to two of the 121 patch positions
-  int py[2], px[2], il[2];
+  // (addresses of rows that are not refined are clamped into the plane; their values are never used)
+  auto clampy = [&](int yy) { return min(max(yy, 0), lvh - 1); };
+  auto clampx = [&](int xx) { return min(max(xx, 0), lvw - 1); };
+  const int cvL = alive ? (int)PL[(size_t)(r0 + w) * pitchL + cL0 + w] : 0;
+  // each lane owns up to eight of the 121 patch positions
+  int py[8], px[8], il[8];
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int p = lane + 64 * k;
+  for (int k = 0; k < 8; k++) {
+    const int p = gl + 16 * k;
     py[k] = p / 11, px[k] = p - py[k] * 11;
-    il[k] = p < 121 ? (int)PL[(size_t)(r0 + py[k]) * pitchL + cL0 + px[k]] - cvL : 0;
+    il[k] = (alive && p < 121) ? (int)PL[(size_t)clampy(r0 + py[k]) * pitchL + clampx(cL0 + px[k])] - cvL : 0;
   }
-  // The 11 shifted 11 x 11 windows of the right image overlap: together they are one 11 x 21 strip (231 bytes).  The
-  // wavefront loads the strip once (4 byte loads per lane) into its LDS slice and every lane reads its 22 window bytes
-  // and the 11 centre values from there.  As 33 global byte loads per lane (11 rows under every instruction) the
-  // kernel was bound by the address path of the vector memory unit: 2.8 ms per step of 2048 frames.
-  __shared__ uint8_t s_strip[4][11 * 21 + 25];
-  uint8_t* strip = s_strip[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  // The 11 shifted 11 x 11 windows of the right image overlap: together they are one 11 x 21 strip (231 bytes); the row
+  // of lanes loads it once (15 byte loads per lane) into its LDS slice
+  __shared__ uint8_t s_strip[16][11 * 21 + 25];
+  uint8_t* strip = s_strip[wave * 4 + g];
   {
-    unsigned v[4];
+    unsigned v[15];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int p = lane + 64 * k, row = p / 21, col = p - row * 21;
-      v[k] = p < 231 ? PR[(size_t)(r0 + row) * pitchR + cR0 - L + col] : 0;
+    for (int k = 0; k < 15; k++) {
+      const int p = gl + 16 * k, row = p / 21, col = p - row * 21;
+      v[k] = (alive && p < 231) ? PR[(size_t)clampy(r0 + row) * pitchR + clampx(cR0 - L + col)] : 0;
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (lane + 64 * k < 231) strip[lane + 64 * k] = (uint8_t)v[k];
+    for (int k = 0; k < 15; k++)
+      if (gl + 16 * k < 231) strip[gl + 16 * k] = (uint8_t)v[k];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  int cvRv[11], irv[2][11];
-#pragma unroll
-  for (int inc = -L; inc <= L; inc++) {
-    cvRv[inc + L] = strip[w * 21 + inc + L + w];
-#pragma unroll
-    for (int k = 0; k < 2; k++)
-      irv[k][inc + L] = lane + 64 * k < 121 ? (int)strip[py[k] * 21 + inc + L + px[k]] : 0;
-  }
   int bestS = INT_MAX, bestInc = 0, sads[11];
 #pragma unroll
   for (int inc = -L; inc <= L; inc++) {
-    const int cvR = cvRv[inc + L];
+    const int cvR = strip[w * 21 + inc + L + w];
     int acc = 0;
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      if (lane + 64 * k < 121) {
-        const int ir = irv[k][inc + L] - cvR;
+    for (int k = 0; k < 8; k++) {
+      if (gl + 16 * k < 121) {
+        const int ir = (int)strip[py[k] * 21 + inc + L + px[k]] - cvR;
         acc += abs(il[k] - ir);
       }
     }
-    acc = wave_sum_i(acc);
+    acc = row_sum_i32(acc);
     sads[inc + L] = acc;
     if (acc < bestS) bestS = acc, bestInc = inc;
   }
-  if (bestInc == -L || bestInc == L) return;
+  if (!alive || bestInc == -L || bestInc == L) return;
   float dist1 = 0, dist2 = 0, dist3 = 0;
 #pragma unroll
   for (int k = 1; k < 10; k++)
@@ -286,7 +316,7 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
       disparity = 0.01f;
       bestuR = (float)((double)uL - 0.01);
     }
-    if (lane == 0) {
+    if (gl == 0) {
       *o_dp = A.bf / disparity;
       *o_ur = bestuR;
       *o_sad = bestS;
@@ -366,7 +396,7 @@ static int launch_stereo(StereoArgs A, int n_frames, hipStream_t st) {
   if ((rc = g_row_list.ensure((size_t)n_frames * A.list_cap * 8)) != VIEO_OK) return rc;
   A.row_start = g_row_start.as<int>(), A.row_list = g_row_list.as<int2>();
   hipLaunchKernelGGL(k_stereo_rows, dim3(n_frames), dim3(256), (size_t)(2 * A.H + 1) * 4, st, A);
-  hipLaunchKernelGGL(k_stereo_rect, dim3((A.capL + 3) / 4, n_frames), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_stereo_rect, dim3((A.capL + 15) / 16, n_frames), dim3(256), 0, st, A);
   hipLaunchKernelGGL(k_stereo_median, dim3(n_frames), dim3(256), 0, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
