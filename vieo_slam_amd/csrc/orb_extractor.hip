@@ -753,10 +753,14 @@ k_desc_index(OrbParams P, const unsigned* __restrict__ sel, const int* __restric
   krec[(size_t)b * P.kp_cap + g] = make_uint2(key, (unsigned)level);
 }
 
+#ifndef VIEO_DESC_KPW
+#define VIEO_DESC_KPW 1  // key points per wavefront (records, then ALL patches in flight together): 1 / 2 / 3 / 4 measured 0.93 / 0.95 / 1.11 / 1.32 ms per 1024 images -- the kernel is not waiting for its two round trips
+#endif
 __global__ void __launch_bounds__(256)
 k_describe(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __restrict__ pattern,
            vieo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int out_cap,
            int groups_per_image, int n_images) {
+  constexpr int KPW = VIEO_DESC_KPW;
   // all key points of an image on one XCD: their overlapping patches then share that XCD's L2
   const int item = xcd_grouped(blockIdx.x, groups_per_image);
   const int b = item / groups_per_image;
@@ -765,103 +769,126 @@ k_describe(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __r
   // wave-uniform for the compiler: the key's record, its level and the level's descriptor then come through scalar
   // loads instead of three dependent per-lane global loads
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int g = (item - b * groups_per_image) * (blockDim.x >> 6) + wv;
-  if (g >= min(P.kp_cap, out_cap)) return;
-  // (key, level) of key point g, written by k_desc_index: one load instead of the level search + the key load
-  const uint2 kr = krec[(size_t)b * P.kp_cap + g];
-  const int level = (int)kr.y;
-  if (level < 0) return;
-  const unsigned key = kr.x;
-  const LevelDesc& D = P.lv[level];
-  const int cx = QT_KEY_X(key) + (kEdge - 3), cy = QT_KEY_Y(key) + (kEdge - 3);
-  int pitch;
-  const uint8_t* img = plane_ptr(P, I, b, level, &pitch);
+  const int g0 = ((item - b * groups_per_image) * (blockDim.x >> 6) + wv) * KPW;
+  const int gmax = min(P.kp_cap, out_cap);
+  if (g0 >= gmax) return;
+  // (key, level) of the key points, written by k_desc_index: one load instead of the level search + the key load.
+  // A wavefront takes KPW consecutive key points: the chain record -> patches -> arithmetic is two dependent round
+  // trips per WAVEFRONT, and with one key point each 4.9 M wavefronts per step queued for them.
+  uint2 kr[KPW];
+#pragma unroll
+  for (int u = 0; u < KPW; u++) kr[u] = g0 + u < gmax ? krec[(size_t)b * P.kp_cap + g0 + u] : make_uint2(0, 0xFFFFFFFFu);
   // The two patches a key point reads -- 31 x 31 of the level image for the orientation, 39 x 39 of
   // the blurred level for the steered pattern (|rotated offset| <= 19 = EDGE_THRESHOLD) -- are
   // staged in this wavefront's LDS slice as whole dwords, row by row.
   constexpr int AP = 40, BR = 19, BP = 44;
-  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][31 * AP + (2 * BR + 1) * BP];
-  uint8_t* sa = s_patch[wv];
-  uint8_t* sb = sa + 31 * AP;
-  const int xa = (cx - kHalfPatch) & ~3, xb = (cx - BR) & ~3;
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][KPW][31 * AP + (2 * BR + 1) * BP];
   // the lane's four pattern words: issued ahead of the patch loads, so that they are there when the angle is
   int pt4[4];
 #pragma unroll
   for (int gq = 0; gq < 4; gq++) pt4[gq] = pattern[gq * 64 + lane];  // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
-  const uint8_t* bl0 = I.blur + (size_t)b * I.blur_img + D.boff;
-  const int bp = D.pitch;
-  {  // 16 dword columns x 4 rows per step
-    const int c = lane & 15, r0 = lane >> 4;
+  int cxs[KPW], cys[KPW], xas[KPW], xbs[KPW];
+  unsigned va[KPW][8], vb[KPW][10];
+  const int c = lane & 15, r0 = lane >> 4;  // 16 dword columns x 4 rows per step
+#pragma unroll
+  for (int u = 0; u < KPW; u++) {
+    const int level = (int)kr[u].y;
+    if (level < 0) continue;  // (wave-uniform)
+    const unsigned key = kr[u].x;
+    const LevelDesc& D = P.lv[level];
+    const int cx = QT_KEY_X(key) + (kEdge - 3), cy = QT_KEY_Y(key) + (kEdge - 3);
+    int pitch;
+    const uint8_t* img = plane_ptr(P, I, b, level, &pitch);
+    const int xa = (cx - kHalfPatch) & ~3, xb = (cx - BR) & ~3;
+    cxs[u] = cx, cys[u] = cy, xas[u] = xa, xbs[u] = xb;
+    const uint8_t* bl0 = I.blur + (size_t)b * I.blur_img + D.boff;
+    const int bp = D.pitch;
     const uint8_t* ga = img + (size_t)(cy - kHalfPatch + r0) * pitch + xa + 4 * c;
     const uint8_t* gb = bl0 + (size_t)(cy - BR + r0) * bp + xb + 4 * c;
     // both patches in flight at once, then the LDS stores (one memory round trip instead of two)
-    unsigned va[8], vb[10];
 #pragma unroll
     for (int k = 0; k < 8; k++)
-      if (c < 9 && r0 + 4 * k < 31) va[k] = *(const unsigned*)(ga + (size_t)(4 * k) * pitch);
+      if (c < 9 && r0 + 4 * k < 31) va[u][k] = *(const unsigned*)(ga + (size_t)(4 * k) * pitch);
 #pragma unroll
     for (int k = 0; k < 10; k++)
-      if (c < 11 && r0 + 4 * k < 2 * BR + 1) vb[k] = *(const unsigned*)(gb + (size_t)(4 * k) * bp);
+      if (c < 11 && r0 + 4 * k < 2 * BR + 1) vb[u][k] = *(const unsigned*)(gb + (size_t)(4 * k) * bp);
+  }
+#pragma unroll
+  for (int u = 0; u < KPW; u++) {
+    if ((int)kr[u].y < 0) continue;
+    uint8_t* sa = s_patch[wv][u];
+    uint8_t* sb = sa + 31 * AP;
 #pragma unroll
     for (int k = 0; k < 8; k++)
-      if (c < 9 && r0 + 4 * k < 31) *(unsigned*)(sa + (r0 + 4 * k) * AP + 4 * c) = va[k];
+      if (c < 9 && r0 + 4 * k < 31) *(unsigned*)(sa + (r0 + 4 * k) * AP + 4 * c) = va[u][k];
 #pragma unroll
     for (int k = 0; k < 10; k++)
-      if (c < 11 && r0 + 4 * k < 2 * BR + 1) *(unsigned*)(sb + (r0 + 4 * k) * BP + 4 * c) = vb[k];
+      if (c < 11 && r0 + 4 * k < 2 * BR + 1) *(unsigned*)(sb + (r0 + 4 * k) * BP + 4 * c) = vb[u][k];
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  // ---- IC_Angle: two lanes per row of the radius-15 disc
-  int m10 = 0, m01 = 0;
-  if (lane < 62) {
-    const int v = (lane >> 1) - kHalfPatch;
-    const int d = P.umax[v < 0 ? -v : v];
-    const uint8_t* row = sa + (v + kHalfPatch) * AP + (cx - xa);
-    const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
-    int sI = 0;
-    // at most 16 pixels per lane (d <= 15): unrolled, so the byte reads are all issued before the first one is used
-    // (as a loop with a lane-dependent trip count every iteration waited for its own LDS read)
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const int u = u0 + t;
-      if (u <= u1) {
-        const int val = row[u];
-        m10 += u * val;
-        sI += val;
+  for (int u = 0; u < KPW; u++) {
+    const int level = (int)kr[u].y;
+    if (level < 0) continue;
+    const int g = g0 + u;
+    const unsigned key = kr[u].x;
+    const LevelDesc& D = P.lv[level];
+    const int cx = cxs[u], cy = cys[u], xa = xas[u], xb = xbs[u];
+    const uint8_t* sa = s_patch[wv][u];
+    const uint8_t* sb = sa + 31 * AP;
+    // ---- IC_Angle: two lanes per row of the radius-15 disc
+    int m10 = 0, m01 = 0;
+    if (lane < 62) {
+      const int v = (lane >> 1) - kHalfPatch;
+      const int d = P.umax[v < 0 ? -v : v];
+      const uint8_t* row = sa + (v + kHalfPatch) * AP + (cx - xa);
+      const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
+      int sI = 0;
+      // at most 16 pixels per lane (d <= 15): unrolled, so the byte reads are all issued before the first one is used
+      // (as a loop with a lane-dependent trip count every iteration waited for its own LDS read)
+#pragma unroll
+      for (int t = 0; t < 16; t++) {
+        const int uu = u0 + t;
+        if (uu <= u1) {
+          const int val = row[uu];
+          m10 += uu * val;
+          sI += val;
+        }
       }
+      m01 = v * sI;
     }
-    m01 = v * sI;
-  }
-  m10 = wave_sum(m10);
-  m01 = wave_sum(m01);
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-  // ---- steered BRIEF on the blurred plane (ORBextractor.cc:83-127)
-  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-  float a, bsin;
-  vieo_sincosf_exact(angle * factorPI, &bsin, &a);
-  const uint8_t* bl = sb + BR * BP + (cx - xb);
-  unsigned long long bits[4];
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // ---- steered BRIEF on the blurred plane (ORBextractor.cc:83-127)
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, bsin;
+    vieo_sincosf_exact(angle * factorPI, &bsin, &a);
+    const uint8_t* bl = sb + BR * BP + (cx - xb);
+    unsigned long long bits[4];
 #pragma unroll
-  for (int gq = 0; gq < 4; gq++) {
-    const int pt = pt4[gq];
-    const float x0 = (float)(signed char)(pt & 0xFF), y0 = (float)(signed char)((pt >> 8) & 0xFF);
-    const float x1 = (float)(signed char)((pt >> 16) & 0xFF), y1 = (float)(signed char)((pt >> 24) & 0xFF);
-    const int t0 = bl[__float2int_rn(x0 * bsin + y0 * a) * BP + __float2int_rn(x0 * a - y0 * bsin)];
-    const int t1 = bl[__float2int_rn(x1 * bsin + y1 * a) * BP + __float2int_rn(x1 * a - y1 * bsin)];
-    bits[gq] = __ballot(t0 < t1);
-  }
-  if (lane < 4) ((unsigned long long*)(desc_out + ((size_t)b * out_cap + g) * 32))[lane] = bits[lane];
-  if (lane == 0) {
-    vieo_keypoint k;
-    const float fx = (float)cx, fy = (float)cy;
-    k.x = level ? fx * D.scale : fx;
-    k.y = level ? fy * D.scale : fy;
-    k.size = (float)D.patch;
-    k.angle = angle;
-    k.response = (float)QT_KEY_R(key);
-    k.octave = level;
-    k.class_id = -1;
-    kp_out[(size_t)b * out_cap + g] = k;
+    for (int gq = 0; gq < 4; gq++) {
+      const int pt = pt4[gq];
+      const float x0 = (float)(signed char)(pt & 0xFF), y0 = (float)(signed char)((pt >> 8) & 0xFF);
+      const float x1 = (float)(signed char)((pt >> 16) & 0xFF), y1 = (float)(signed char)((pt >> 24) & 0xFF);
+      const int t0 = bl[__float2int_rn(x0 * bsin + y0 * a) * BP + __float2int_rn(x0 * a - y0 * bsin)];
+      const int t1 = bl[__float2int_rn(x1 * bsin + y1 * a) * BP + __float2int_rn(x1 * a - y1 * bsin)];
+      bits[gq] = __ballot(t0 < t1);
+    }
+    if (lane < 4) ((unsigned long long*)(desc_out + ((size_t)b * out_cap + g) * 32))[lane] = bits[lane];
+    if (lane == 0) {
+      vieo_keypoint k;
+      const float fx = (float)cx, fy = (float)cy;
+      k.x = level ? fx * D.scale : fx;
+      k.y = level ? fy * D.scale : fy;
+      k.size = (float)D.patch;
+      k.angle = angle;
+      k.response = (float)QT_KEY_R(key);
+      k.octave = level;
+      k.class_id = -1;
+      kp_out[(size_t)b * out_cap + g] = k;
+    }
   }
 }
 
@@ -1209,14 +1236,14 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
   hipLaunchKernelGGL(k_blur, dim3(xcd_grid((long long)e->tiles.size() * B)), dim3(256), 0, st, P, I,
                      e->d_tiles.as<BlurTile>(), (int)e->tiles.size(), B);
   STAMP();
-  const int ngroups = (std::min(P.kp_cap, capacity) + 3) / 4;
+  const int ngroups = (std::min(P.kp_cap, capacity) + 4 * VIEO_DESC_KPW - 1) / (4 * VIEO_DESC_KPW);
   if (!lapping) {
     hipLaunchKernelGGL(k_desc_index, dim3((P.kp_cap + 255) / 256, B), dim3(256), 0, st, P, e->d_sel.as<unsigned>(),
                        e->d_sel_count.as<int>(), e->d_krec.as<uint2>(), capacity, d_counts);
     hipLaunchKernelGGL(k_describe, dim3((unsigned)ngroups * 8 * ((B + 7) / 8)), dim3(256), 0, st, P, I,
                        e->d_krec.as<uint2>(), e->d_pattern.as<int>(), d_kp, d_desc, capacity, ngroups, B);
   } else {
-    const int ng = (P.kp_cap + 3) / 4;
+    const int ng = (P.kp_cap + 4 * VIEO_DESC_KPW - 1) / (4 * VIEO_DESC_KPW);
     hipLaunchKernelGGL(k_desc_index, dim3((P.kp_cap + 255) / 256, B), dim3(256), 0, st, P, e->d_sel.as<unsigned>(),
                        e->d_sel_count.as<int>(), e->d_krec.as<uint2>(), P.kp_cap, e->d_tmp_counts.as<int>());
     hipLaunchKernelGGL(k_describe, dim3((unsigned)ng * 8 * ((B + 7) / 8)), dim3(256), 0, st, P, I,
