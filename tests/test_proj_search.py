@@ -195,6 +195,30 @@ def test_gpu_sbp_reloc_parity(oracle, seed, orbdist):
 
 
 @pytest.mark.gpu
+def test_gpu_sbp_window_size_classes_and_tiny_batches(oracle):
+    """k_sbp_candidates takes four queries per wavefront when a window spans at most 16 grid columns and 64 entries and
+    a wavefront per query otherwise: one frame that mixes narrow windows, windows wider than 16 columns and windows
+    with more than 64 entries, then query counts that do not fill a wavefront's four rows (1, 3, 17)."""
+    kl, dl, ur, pts, cam = _scenario(oracle, 1030, th=7.0)
+    q = oracle.sbp_project_last_frame(pts, cam)
+    rng = np.random.default_rng(1030)
+    kind = rng.integers(0, 3, len(q))
+    # narrow windows over every level / 13 columns with the projection's own level range (more than 64 entries, a
+    # third of them candidates) / 18 columns likewise (the library keeps at most 128 candidates per query)
+    q["level_min"] = np.where(kind == 0, 0, q["level_min"])
+    q["level_max"] = np.where(kind == 0, -1, q["level_max"])
+    q["radius"] = np.where(kind == 0, 6.0, np.where(kind == 1, 70.0, 100.0)).astype(np.float32)
+    m = _hip_matcher(0.9)
+    on, oa = oracle.search_by_projection(0, q, kl, ur, dl, None, BOUNDS, nn_ratio=0.9)
+    hn, ha = m.SearchByProjectionLastFrame(q, kl, ur, dl, None, BOUNDS)
+    assert on == hn and np.array_equal(oa, ha) and on > 50
+    for n in (1, 3, 17):
+        on, oa = oracle.search_by_projection(0, q[:n], kl, ur, dl, None, BOUNDS, nn_ratio=0.9)
+        hn, ha = m.SearchByProjectionLastFrame(q[:n], kl, ur, dl, None, BOUNDS)
+        assert on == hn and np.array_equal(oa, ha)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gpu_sbp_assignment_dependency_chains(oracle, mode, monkeypatch):
     """The optimistic-parallel assignment (k_sbp_assign_par) against the sequential semantics where they bite: look-alike
