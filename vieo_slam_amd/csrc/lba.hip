@@ -391,7 +391,7 @@ k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
     for (int i = threadIdx.x; i < (D.n_obs + 255) / 256; i += 256) v[0] += D.part0[i];
   if ((fl & LBA_TRIAL) && D.np > 0) {
     for (int i = threadIdx.x; i < (D.n_obs + 255) / 256; i += 256) v[1] += D.part[i];
-    for (int i = threadIdx.x; i < (D.n_mp + 255) / 256; i += 256) v[2] += D.part_m[i];
+    for (int i = threadIdx.x; i < (D.n_mp + 63) / 64; i += 256) v[2] += D.part_m[i];
   }
   block_sum<3>(v, s_red, threadIdx.x);
   if (threadIdx.x == 0) {
@@ -1984,13 +1984,18 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
   const int w = blockIdx.y;
   if (!(ctl[w].flags & LBA_TRIAL)) return;
   const LbaDev& D = devs[w];
-  if (blockIdx.x * 256 >= D.n_mp || D.np == 0) return;
+  if (blockIdx.x * 64 >= D.n_mp || D.np == 0) return;
   const double lambda = win_lambda(ctl[w], out[w]);
-  const int m = blockIdx.x * 256 + threadIdx.x;
+  // FOUR lanes per point, each over every fourth free key frame: a point's chain was one dependent `tab` -> block round
+  // trip per free key frame (10 .. 25 of them, 73 us per launch whatever the batch); the quad's partial sums are added
+  // in a fixed order
+  const int m = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const bool act = m < D.n_mp && D.mp_act[m];
   double sc[1] = {0};
-  if (m < D.n_mp && D.mp_act[m]) {
-    double cl[3] = {D.bl[3 * (size_t)m], D.bl[3 * (size_t)m + 1], D.bl[3 * (size_t)m + 2]};
-    for (int a = 0; a < D.n_free; a++) {
+  double cl[3] = {0, 0, 0};
+  if (act) {
+    if (sub == 0) cl[0] = D.bl[3 * (size_t)m], cl[1] = D.bl[3 * (size_t)m + 1], cl[2] = D.bl[3 * (size_t)m + 2];
+    for (int a = sub; a < D.n_free; a += 4) {
       const int e = D.tab[(size_t)a * D.n_mp + m];
       if (e < 0) continue;
       const double* B = D.CB + 18 * (size_t)e;
@@ -1999,11 +2004,15 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
         cl[0] -= B[0] * xa, cl[1] -= B[1] * xa, cl[2] -= B[2] * xa;
       }
     }
-    if (D.scale_opt) {  // the (scale, point) block
+    if (D.scale_opt && sub == 0) {  // the (scale, point) block
       const double* B = D.Bs + 3 * (size_t)m;
       const double xa = D.xp[D.np - 1];
       cl[0] -= B[0] * xa, cl[1] -= B[1] * xa, cl[2] -= B[2] * xa;
     }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) cl[k] = quad_sum_f64(cl[k]);
+  if (act && sub == 0) {
     double Di[9];
     landmark_dinv(D.Hll + 9 * (size_t)m, lambda, Di);
     for (int a = 0; a < 3; a++) {
@@ -2015,7 +2024,7 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
     }
   }
   block_sum<1>(sc, s_red, threadIdx.x);
-  if (threadIdx.x == 0) D.part_m[blockIdx.x] = sc[0];
+  if (threadIdx.x == 0) D.part_m[blockIdx.x] = sc[0];  // one partial per 64 points (k_lba_reduce)
 }
 
 // ================================================================== host-side lock-step LM driver
@@ -2559,7 +2568,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     s.Ae = take((size_t)std::max(H.n_imu, 1) * 930 * 8);
     s.gchi0 = take((size_t)std::max(H.n_imu, 1) * 8), s.gchi = take((size_t)std::max(H.n_imu, 1) * 8);
     s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
-    s.part_m = take((size_t)((H.n_mp + 255) / 256) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
+    s.part_m = take((size_t)((H.n_mp + 63) / 64) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
     s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)std::max(nf, 1) * H.n_mp * 4);
     s.sc_sys = take((size_t)(6 * nf + 2) * 8), s.psc = take((size_t)((H.n_mp + 63) / 64) * 16);
     s.kf_act = take((size_t)H.n_kf * 4);
@@ -2960,7 +2969,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt16<kLd16Threads>, dim3(W), dim3(kLd16Threads), ld16_lds_bytes(nb16), st, dD, dC, dO, nb16); });
       if (panels && cls_trial[1])
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldltg<kLdGThreads>, dim3(W), dim3(kLdGThreads), ldg_lds_bytes(nbg), st, dD, dC, dO, nbg); });
-      KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_update_points, dim3(gm, W), dim3(256), 0, st, dD, dC, dO); });
+      KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_update_points, dim3(gq, W), dim3(256), 0, st, dD, dC, dO); });
       KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1); });
       if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1); });
       KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO); });
