@@ -586,15 +586,35 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   PoseXf X;
   kf_xf(D.cam, k, X);  // one camera: the transform is the same for all edges of the key frame
   const int* tab_a = D.tab + (size_t)a * D.n_mp;
-  for (int j = threadIdx.x; j < cnt; j += 256) {
-    const int i = D.kf_edge_idx[first + j];
-    const vieo_lba_obs o = D.obs[i];
-    const bool active = !D.level[i];
+  // A thread's edges two at a time: both list entries, then both records and level bytes, then both points are loaded
+  // before the arithmetic (three dependent round trips per PAIR of edges instead of per edge; a key frame's ~600 edges are
+  // 2.3 per thread).  Same edges in the same order per thread: the sums are bit-identical.
+  for (int j0 = threadIdx.x; j0 < cnt; j0 += 512) {
+    int ii[2];
+    vieo_lba_obs oo[2];
+    unsigned char lvv[2];
+    double Xp[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; u++) ii[u] = D.kf_edge_idx[first + min(j0 + 256 * u, cnt - 1)];
+#pragma unroll
+    for (int u = 0; u < 2; u++) oo[u] = D.obs[ii[u]], lvv[u] = D.level[ii[u]];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const double* q = D.X + 3 * (size_t)oo[u].mp;
+      Xp[u][0] = q[0], Xp[u][1] = q[1], Xp[u][2] = q[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+    const int j = j0 + 256 * u;
+    if (j >= cnt) continue;
+    const int i = ii[u];
+    const vieo_lba_obs o = oo[u];
+    const bool active = !lvv[u];
     double Bk[18];
 #pragma unroll
     for (int t = 0; t < 18; t++) Bk[t] = 0;
     if (active) {
-      const double* Xh = D.X + 3 * (size_t)o.mp;
+      const double* Xh = Xp[u];
       const double Xw[3] = {Xh[0] * sc, Xh[1] * sc, Xh[2] * sc};
       double err[3], Pc[3];
       const CamD& C = obs_cam(D, i);
@@ -665,6 +685,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
       double* B = D.CB + 18 * (size_t)i;
 #pragma unroll
       for (int t = 0; t < 18; t++) B[t] = Bk[t];
+    }
     }
   }
   block_sum<27>(acc, s_red, threadIdx.x);
