@@ -9,7 +9,10 @@ namespace vieo {
 
 static const int kPatchSize = 31, kHalfPatch = 15, kEdge = 19;
 static const int kMaxLevels = 16;
-static const int kBlurTW = 64, kBlurTH = 64;
+#ifndef VIEO_BLUR_TH
+#define VIEO_BLUR_TH 96  // rows of a blur tile (even): 32 / 64 / 96 / 128 measured 1.18 / 1.02 / 0.96 / 1.00 ms per 1024 images (tools/ab_blur_th.sh)
+#endif
+static const int kBlurTW = 64, kBlurTH = VIEO_BLUR_TH;
 
 struct LevelDesc {
   int w, h, pitch, off;      // plane geometry; off = byte offset in the per-image pyramid block
