@@ -33,7 +33,10 @@ namespace vieo {
 // H = S[sx0]*a0 + S[sx1]*a1 (x2048), D = (((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2.
 // One workgroup = 256 output columns x kResizeRows output rows.  The source rows it needs are staged
 // in LDS with coalesced dword loads (the 4 taps per pixel then cost LDS byte reads, not global ones).
-static const int kResizeRows = 32;
+#ifndef VIEO_RESIZE_ROWS
+#define VIEO_RESIZE_ROWS 32
+#endif
+static const int kResizeRows = VIEO_RESIZE_ROWS;
 
 __global__ void __launch_bounds__(256, 8)  // 51 instead of 74 registers, no spills: 8 wavefronts per SIMD
 k_resize(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab,
@@ -114,7 +117,10 @@ k_resize(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab,
 // mapped so that runs of G consecutive items stay on one XCD while the runs themselves are still
 // interleaved over the XCDs (a contiguous eighth per XCD would unbalance them: pyramid levels differ
 // in work per cell).  The grid holds 8 * G * ceil(n / (8 G)) blocks.
-static const int kXcdRun = 32;
+#ifndef VIEO_XCD_RUN
+#define VIEO_XCD_RUN 32
+#endif
+static const int kXcdRun = VIEO_XCD_RUN;
 __device__ __forceinline__ int xcd_grouped(int bid, int G) {
   const int xcd = bid & 7, q = bid >> 3;
   return ((q / G) * 8 + xcd) * G + q % G;
