@@ -37,6 +37,9 @@ namespace vieo {
 #define VIEO_RESIZE_ROWS 32
 #endif
 static const int kResizeRows = VIEO_RESIZE_ROWS;
+#ifndef VIEO_QT_GROUPS
+#define VIEO_QT_GROUPS {1, 64}  // k_quadtree: level 0 and levels 1.. are two launches, each with its own LDS size ({64} 0.37, {1,64} 0.28, {1,3,64} 0.31, a launch per level 0.37 ms per 1024 images: tools/ab_qt_split.sh)
+#endif
 
 __global__ void __launch_bounds__(256, 8)  // 51 instead of 74 registers, no spills: 8 wavefronts per SIMD
 k_resize(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab,
@@ -469,9 +472,9 @@ __global__ void __launch_bounds__(256)
 k_quadtree(OrbParams P, const unsigned* __restrict__ cell_keys,
            const int* __restrict__ cell_counts, unsigned* __restrict__ keys,
            unsigned short* __restrict__ kslot, unsigned char* __restrict__ kq,
-           unsigned* __restrict__ sel, int* __restrict__ sel_count, int ncap_max, int scap_max) {
+           unsigned* __restrict__ sel, int* __restrict__ sel_count, int ncap_max, int scap_max, int l0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int l = blockIdx.x, b = blockIdx.y;
+  const int l = l0 + blockIdx.x, b = blockIdx.y;
   const LevelDesc& D = P.lv[l];
   // carve LDS (8-byte items first)
   uint8_t* q = smem;
@@ -1233,11 +1236,30 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
                      e->iniTh, e->minTh, e->tpitch, e->tile_bytes, e->score_bytes, e->fast_cand_cap, B,
                      (int)align_up(e->fast_lds, 16));
   STAMP();
-  hipLaunchKernelGGL(k_quadtree, dim3(P.nlevels, B), dim3(256), e->qt_lds, st, P,
-                     e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
-                     e->d_keys.as<unsigned>(), e->d_kslot.as<unsigned short>(),
-                     e->d_kq.as<unsigned char>(), e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(),
-                     e->ncap_max, e->scap_max);
+  // Several launches over groups of levels: the LDS a workgroup carves is sized by its level's node / cell capacities,
+  // and sized for level 0 (25 KB) the smaller levels ran six workgroups per CU instead of eight (one launch 0.37 ms per
+  // 1024 images, split after level 0: 0.28)
+  {
+    static const int bounds[] = VIEO_QT_GROUPS;  // level group boundaries, ascending, the last one >= nlevels
+    auto qt_caps = [&](int la, int lb, int* ncap, int* scap) {
+      int nc = 1, mc = 1;
+      for (int l = la; l < lb; l++) nc = std::max(nc, P.lv[l].ncap), mc = std::max(mc, P.lv[l].cell_end - P.lv[l].cell_begin);
+      *ncap = nc, *scap = std::max(2 * nc, mc);
+    };
+    int la = 0;
+    for (size_t gi = 0; gi < sizeof(bounds) / sizeof(bounds[0]) && la < P.nlevels; gi++) {
+      const int lb = std::min(bounds[gi], P.nlevels);
+      if (lb <= la) continue;
+      int nc, sc;
+      qt_caps(la, lb, &nc, &sc);
+      const size_t lds = (size_t)16 * sc + (4 + 16 + 4 + 4 + 4) * nc + 64 + (2 * 4 + 8 + 2 * 6) * nc + nc + 64;
+      hipLaunchKernelGGL(k_quadtree, dim3(lb - la, B), dim3(256), lds, st, P,
+                         e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
+                         e->d_keys.as<unsigned>(), e->d_kslot.as<unsigned short>(),
+                         e->d_kq.as<unsigned char>(), e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(), nc, sc, la);
+      la = lb;
+    }
+  }
   STAMP();
   hipLaunchKernelGGL(k_blur, dim3(xcd_grid((long long)e->tiles.size() * B)), dim3(256), 0, st, P, I,
                      e->d_tiles.as<BlurTile>(), (int)e->tiles.size(), B);
