@@ -490,6 +490,8 @@ def main():
     ap.add_argument("--lba-threads", type=int, default=4,
                     help="host threads issuing LBA batches (each call = the windows of one step; with the bundle-adjustment "
                          "stream at the lowest priority up to four calls are in flight behind the front end)")
+    ap.add_argument("--lba-mixed", action="store_true",
+                    help="one lock-step call per step with ordinary and bLarge windows mixed (default: one call per class)")
     ap.add_argument("--lba-batch", type=int, default=0,
                     help="windows per lock-step LBA call (0 = all windows of a step in one call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -544,6 +546,17 @@ def main():
 
     lba_chunk = a.lba_batch if a.lba_batch > 0 else max(1, n_lba)
     chunks = [list(range(i, min(i + lba_chunk, n_lba))) for i in range(0, n_lba, lba_chunk)]
+    # Windows of one solver class per lock-step call (a call advances at the pace of its slowest class: the bLarge
+    # windows' four heavy rounds -- one-workgroup solves of 0.4 ms, off-diagonal Schur tiles -- held the ordinary windows'
+    # seventeen light ones back and vice versa).  --lba-mixed keeps the one mixed call per step.
+    if a.workload == "r3" and not a.lba_mixed and a.lba_batch <= 0:
+        is_large = [int(lba_problems[i % len(lba_problems)][0][0]["large"]) != 0 for i in range(n_lba)]
+        small = [i for i in range(n_lba) if not is_large[i]]
+        large = [i for i in range(n_lba) if is_large[i]]
+        ns = max(1, int(os.environ.get("VIEO_BENCH_LBA_SMALL_CALLS", "1")))
+        per = (len(small) + ns - 1) // ns if small else 0
+        chunks = [small[k:k + per] for k in range(0, len(small), per)] if small else []
+        chunks = [c for c in chunks + [large] if c]
 
     from vieo_slam_amd._lib import check as _check, lib as _lib
 
@@ -593,7 +606,8 @@ def main():
     lba_k, schur_flops = Optimizer.kernel_times()
     lba_alone, schur_alone = {}, None
     if n_lba:
-        run_lba(chunks[0])
+        for c_ in chunks:  # the step's calls one after the other, alone on the GPU
+            run_lba(c_)
         k1, f1 = Optimizer.kernel_times()
         for k, v in k1.items():
             dn, dm = v["launches"] - lba_k[k]["launches"], v["ms"] - lba_k[k]["ms"]
@@ -602,7 +616,7 @@ def main():
         if ds > 0:
             tf = (f1 - schur_flops) / (ds * 1e-3) / 1e12
             schur_alone = {"achieved": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": lba_alone["lba.schur"],
-                           "windows_per_launch": len(chunks[0]),
+                           "windows_per_launch": "/".join(str(len(c_)) for c_ in chunks),
                            "note": "one lock-step batch of the step's windows after the timed region"}
     Optimizer.enable_kernel_timing(False)
     mg = None
@@ -680,8 +694,10 @@ def main():
                              "workload r2: 8 views of one textured plane, local-map queries precomputed on the host; plus one "
                              "LocalBundleAdjustmentNavStatePRV (10 local key frames with PR+V+Bias vertices and IMU "
                              "pre-integration edges, 6 fixed, ~1500 points, ~12k observations) per ") +
-                            "%d frames, the windows of a step advanced in lock step (%d per call, %d host "
-                            "threads)" % (a.lba_every, lba_chunk, a.lba_threads),
+                            "%d frames, the windows of a step advanced in lock step (calls of %s windows%s; %d host threads)"
+                            % (a.lba_every, " + ".join(str(len(c)) for c in chunks),
+                               "" if (a.lba_mixed or a.lba_batch > 0 or a.workload != "r3") else
+                               ": one call per solver class, i.e. ordinary / bLarge windows apart", a.lba_threads),
                 "workload_id": a.workload,
                 "local_ba_windows_per_step": n_lba,
                 "local_ba_ms_per_window_mean": float(np.mean(lba_ms)) if lba_ms else None,
