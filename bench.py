@@ -556,7 +556,7 @@ def main():
         ns = max(1, int(os.environ.get("VIEO_BENCH_LBA_SMALL_CALLS", "1")))
         per = (len(small) + ns - 1) // ns if small else 0
         chunks = [small[k:k + per] for k in range(0, len(small), per)] if small else []
-        chunks = [c for c in chunks + [large] if c]
+        chunks = [c for c in ([large] + chunks if os.environ.get("VIEO_BENCH_LBA_LARGE_FIRST") else chunks + [large]) if c]
 
     from vieo_slam_amd._lib import check as _check, lib as _lib
 
