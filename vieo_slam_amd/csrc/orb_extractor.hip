@@ -1240,14 +1240,19 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
   // and sized for level 0 (25 KB) the smaller levels ran six workgroups per CU instead of eight (one launch 0.37 ms per
   // 1024 images, split after level 0: 0.28)
   {
-    static const int bounds[] = VIEO_QT_GROUPS;  // level group boundaries, ascending, the last one >= nlevels
+    static const int bounds_batch[] = VIEO_QT_GROUPS;  // level group boundaries, ascending, the last one >= nlevels
+    static const int bounds_one[] = {64};
+    // (a few images -- the single-stream frame -- are latency: one launch, 39 us, instead of two of 39 us each)
+    const bool batch = B >= 32;
+    const int* bounds = batch ? bounds_batch : bounds_one;
+    const size_t n_bounds = batch ? sizeof(bounds_batch) / sizeof(bounds_batch[0]) : 1;
     auto qt_caps = [&](int la, int lb, int* ncap, int* scap) {
       int nc = 1, mc = 1;
       for (int l = la; l < lb; l++) nc = std::max(nc, P.lv[l].ncap), mc = std::max(mc, P.lv[l].cell_end - P.lv[l].cell_begin);
       *ncap = nc, *scap = std::max(2 * nc, mc);
     };
     int la = 0;
-    for (size_t gi = 0; gi < sizeof(bounds) / sizeof(bounds[0]) && la < P.nlevels; gi++) {
+    for (size_t gi = 0; gi < n_bounds && la < P.nlevels; gi++) {
       const int lb = std::min(bounds[gi], P.nlevels);
       if (lb <= la) continue;
       int nc, sc;
