@@ -1350,7 +1350,15 @@ int vieo_orb_create(vieo_orb** out, int nfeatures, float scale_factor, int nleve
       ++v0;
     }
   }
-  hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  hipError_t he;
+  {  // VIEO_ORB_PRIORITY=1: the extractor's (= the frame pipeline's) stream at the highest priority (A/B runs)
+    const char* pe = getenv("VIEO_ORB_PRIORITY");
+    int lo = 0, hi = 0;
+    if (pe && atoi(pe) > 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      he = hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, hi);
+    else
+      he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  }
   if (he != hipSuccess) {
     set_error("hipStreamCreate: %s", hipGetErrorString(he));
     delete e;
