@@ -276,7 +276,11 @@ def single_stream_leg(seq, n_frames):
         "max_position_error_vs_truth_m": float(err),
         "max_position_difference_vs_stage_by_stage_m": float(np.linalg.norm(th["p"] - ts["p"], axis=1).max()),
         "reference_readme_anchor": dict(README_FRONTEND_MS, ratio_to_this_ms_per_frame=README_FRONTEND_MS["value"] / r["ms_per_frame"],
-                                        ms_per_frame_for_30x=README_FRONTEND_MS["value"] / 30.0),
+                                        ms_per_frame_for_30x=README_FRONTEND_MS["value"] / 30.0,
+                                        # the README figure is the FRONT END's time per frame (the tracking thread; local
+                                        # mapping runs beside it in the reference): like for like it is this replay's
+                                        # tracking call, not its whole loop with the local BAs in line
+                                        ratio_to_this_tracking_call=README_FRONTEND_MS["value"] / r["ms_track_call"]),
         "stage_by_stage": {"ms_per_frame": 1e3 * t_s / (n_frames - 1),
                            "latency_ms_per_frame_tracking_median": float(np.median(Rs.stats["ms_frames"]))},
         "path": "examples/replay_main (C++, no Python): per frame ONE vieo_track_frame call = one copy up from pinned "
