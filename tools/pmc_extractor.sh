@@ -25,7 +25,7 @@ def read(c):
     return out
 F, W = read("FETCH_SIZE"), read("WRITE_SIZE")
 names = {"fast": "k_fast", "blur": "k_blur", "pyramid": "k_resize", "describe": "k_describe", "quadtree": "k_quadtree"}
-launches = {"pyramid": 7}
+launches = {"pyramid": 7, "quadtree": 2}  # k_quadtree: level 0 and the other levels are two launches (batches)
 # one counter row per launch (rocprofv3 sums the instances): the average over the rows is KB per launch
 kern = {}
 for short, kn in names.items():
