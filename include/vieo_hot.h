@@ -161,8 +161,8 @@ int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* 
  * :576-608, positive depth, reprojection chi2 5.991*sigma2), the second pass with the far-point parallax
  * threshold when fewer than 30 matches survive, the all-camera re-triangulation of every group when
  * n_cams > 2 (:704-737), and vdepth_ of the concatenated key list (:742-764).
- *   device: the knn-2 searches, every pair / group triangulation.
- *   host (inside the library): the order-dependent group bookkeeping, as in the reference.
+ *   device: everything -- the knn-2 searches, every pair / group triangulation and (round 4) the order-dependent group
+ *   bookkeeping; this host-pointer form is one upload, the device stage below, one download.
  * Outputs: h_depth / h_key_group [sum n_keys] in mvKeys order (camera-major): depth in the key's own camera
  * (-1: none) and mapcamidx2idxs_ (-1: none); the groups mvidxsMatches (h_group_idx [n_groups][n_cams], -1:
  * none), goodmatches_, v3dpoints_ (reference-camera frame).  VIEO_E_CAPACITY when more than group_capacity
@@ -184,6 +184,30 @@ int vieo_stereo_fisheye_match(const vieo_fisheye_params* params, const vieo_keyp
                               int32_t group_capacity, float* h_depth, int32_t* h_key_group,
                               int32_t* h_group_idx, uint8_t* h_group_good, double* h_group_p3d,
                               int32_t* n_groups, int32_t* n_matches);
+
+/* Device-resident form (round 4): the whole stage -- knn-2 of every camera pair, ratio test + pair triangulation, the
+ * group tables of FillMatchesFromPair, the all-camera re-triangulation, mvKeys / mDescriptors / vdepth_ -- as five
+ * launches on `stream` with no host round trip: the key counts are read on the device, and the order-dependent group
+ * bookkeeping runs as a speculative-parallel walk on one wavefront per frame (rows that touch disjoint keys / groups
+ * are applied 64 at a time with the sequential result; fisheye_stereo.hip).  A handle carries the rig's constants and
+ * the scratch for up to max_frames frames of key_cap_per_camera (<= 8191) keys per camera.
+ * Inputs are the extractor's batch arrays: d_keys / d_desc [n_frames][n_cams][key_cap_per_camera], d_counts
+ * [n_frames][n_cams][2] = {n, num_mono} (vieo_orb_extract_batch_device with n_images = n_frames * n_cams).
+ * Outputs, per frame: d_keys_cat / d_desc_cat / d_depth / d_uright / d_key_group [n_cams * key_cap_per_camera] in mvKeys
+ * (camera-major) order, d_cam_first [n_cams + 1]; the groups d_group_idx [gcap][n_cams], d_group_good [gcap],
+ * d_group_p3d [gcap][3] with gcap = vieo_fisheye_group_capacity(); d_hdr [8] = {n_groups, n_matches, threshold used
+ * (0 / 1), status (1: more than gcap groups, the frame's tables are void), -, rows walked, wavefront steps, -}. */
+typedef struct vieo_fisheye vieo_fisheye;
+int vieo_fisheye_create(vieo_fisheye** out, const vieo_fisheye_params* params, int key_cap_per_camera, int max_frames);
+void vieo_fisheye_destroy(vieo_fisheye* h);
+int vieo_fisheye_group_capacity(const vieo_fisheye* h);
+int vieo_stereo_fisheye_match_batch_device(vieo_fisheye* h, const vieo_keypoint* d_keys, const uint8_t* d_desc,
+                                           const int32_t* d_counts, int n_frames, vieo_keypoint* d_keys_cat,
+                                           uint8_t* d_desc_cat, int32_t* d_cam_first, float* d_depth, float* d_uright,
+                                           int32_t* d_key_group, int32_t* d_group_idx, uint8_t* d_group_good,
+                                           double* d_group_p3d, int32_t* d_hdr, void* stream);
+/* test tap: rows walked / wavefront steps of this thread's last vieo_stereo_fisheye_match */
+void vieo_fisheye_last_walk(int32_t* rows, int32_t* steps);
 
 /* int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vMatchedPairs, bOnlyStereo)
  * (src/ORBmatcher.cc:896-1150; LocalMapping::CreateNewMapPoints, LocalMapping.cc:709): per shared vocabulary node,

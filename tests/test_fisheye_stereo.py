@@ -157,3 +157,40 @@ def test_fisheye_stereo_edge_cases(oracle):
     rc, _ = fisheye_call(lib().vieo_stereo_fisheye_match, case["params"], case["keys"], case["descs"],
                          case["num_mono"], group_capacity=3)
     assert rc != 0
+
+
+@pytest.mark.gpu
+def test_fisheye_device_batch_matches_oracle_and_walks_in_parallel(oracle):
+    """The device-resident stage (vieo_stereo_fisheye_match_batch_device) on a batch of different rig frames at once --
+    2-camera Radtan, 4-camera KB8, frames with look-alike descriptors (replacement / contradiction branches) -- against
+    the oracle frame by frame, mvKeys / mDescriptors included; the speculative-parallel walk of the group tables must
+    take far fewer wavefront steps than rows on ordinary frames."""
+    from vieo_slam_amd.matching import FisheyeStereoDevice, compute_stereo_fisheye_matches, fisheye_last_walk
+    for rig, seeds, kws in (("radtan", (31, 32, 33), ({}, dict(duplicates=0.3), dict(n_points=900, distractors=0.5))),
+                            ("kb8", (34, 35, 36), ({}, dict(flip_bits=60, duplicates=0.4), dict(num_mono=[5, 0, 17, 3])))):
+        cases = [synth_fisheye.make_fisheye_case(s, rig=rig, **kw) for s, kw in zip(seeds, kws)]
+        cap = max(len(k) for c in cases for k in c["keys"]) + 7
+        dev = FisheyeStereoDevice(cases[0]["params"], cap, max_frames=len(cases))
+        outs = dev.match_batch([(c["keys"], c["descs"], c["num_mono"]) for c in cases])
+        for c, h in zip(cases, outs):
+            o = oracle.stereo_fisheye(c["params"], c["keys"], c["descs"], c["num_mono"])
+            assert h["hdr"][3] == 0
+            assert np.array_equal(o["group_idx"], h["group_idx"]) and np.array_equal(o["group_good"], h["group_good"])
+            assert np.array_equal(o["key_group"], h["key_group"]) and o["n_matches"] == h["n_matches"]
+            good = o["group_good"]
+            if good.any():
+                a, b = o["group_p3d"][good], h["group_p3d"][good]
+                assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max())
+            assert np.array_equal(o["depth"] < 0, h["depth"] < 0) and np.allclose(o["depth"], h["depth"], rtol=1e-6, atol=0)
+            assert np.array_equal(h["keys"].view(np.uint8), np.concatenate(c["keys"]).view(np.uint8))
+            assert np.array_equal(h["desc"], np.concatenate(c["descs"])) and (h["uright"] == -1).all()
+            assert np.array_equal(h["cam_first"], np.concatenate([[0], np.cumsum([len(k) for k in c["keys"]])]))
+        # an ordinary frame: most rows are independent
+        rows, steps = outs[0]["hdr"][5], outs[0]["hdr"][6]
+        assert rows > 100 and steps <= rows // 8 + 8, (rig, rows, steps)
+        dev.close()
+    # the host-pointer entry reports its walk as well
+    c = synth_fisheye.make_fisheye_case(37, rig="kb8")
+    compute_stereo_fisheye_matches(c["params"], c["keys"], c["descs"], c["num_mono"])
+    rows, steps = fisheye_last_walk()
+    assert rows > 100 and 0 < steps < rows

@@ -259,3 +259,37 @@ def test_gpu_sbp_assignment_dependency_chains(oracle, mode, monkeypatch):
         results[name] = call(q, kl, ur, dl2, taken, BOUNDS)
     for name, (hn, ha) in results.items():
         assert hn == on and np.array_equal(ha, oa), name
+
+
+@pytest.mark.gpu
+def test_gpu_sbp_more_wide_windows_than_a_block_lists(oracle, monkeypatch):
+    """k_sbp_candidates leaves wide / crowded windows to a second pass through a per-block list of 1024 entries; a frame
+    with more of them than the eight blocks can list (relocalisation-size windows, rig local maps with p_cap * n_cams
+    queries) makes every block walk ITS OWN share of the queries again.  10 800 queries, all of them wider than 16 grid
+    columns, against the oracle and against the sequential replay."""
+    kl, dl, ur, pts, cam = _scenario(oracle, 1040, th=7.0)
+    q1 = oracle.sbp_project_last_frame(pts, cam)
+    rng = np.random.default_rng(1040)
+    q = np.tile(q1, 9)
+    q["u"] += rng.uniform(-30, 30, len(q)).astype(np.float32)
+    q["v"] += rng.uniform(-30, 30, len(q)).astype(np.float32)
+    q["radius"] = rng.uniform(96.0, 110.0, len(q)).astype(np.float32)
+    oc = np.tile(pts["octave"], 9)
+    q["level_min"], q["level_max"] = oc, oc           # one level: ~20 candidates out of a window of ~130 keys
+    q["flags"] = np.where(rng.random(len(q)) < 0.5, q["flags"] & ~2, q["flags"])
+    assert len(q) > 8 * 1024 + 2000 and ((q["flags"] & 1) > 0).sum() > 8 * 1024
+    m = _hip_matcher(0.9)
+    on, oa = oracle.search_by_projection(0, q, kl, ur, dl, None, BOUNDS, nn_ratio=0.9)
+    assert on > 100
+    for env in ({}, {"VIEO_SBP_ASSIGN": "seq"}):
+        monkeypatch.delenv("VIEO_SBP_ASSIGN", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hn, ha = m.SearchByProjectionLastFrame(q, kl, ur, dl, None, BOUNDS)
+        assert hn == on and np.array_equal(ha, oa), env
+    # and with only three of the eight blocks over their list (block b owns the queries with (q >> 4) % 8 == b)
+    q2 = q.copy()
+    q2["radius"] = np.where(((np.arange(len(q)) >> 4) % 8) < 3, q["radius"], 6.0).astype(np.float32)
+    on, oa = oracle.search_by_projection(0, q2, kl, ur, dl, None, BOUNDS, nn_ratio=0.9)
+    hn, ha = m.SearchByProjectionLastFrame(q2, kl, ur, dl, None, BOUNDS)
+    assert hn == on and np.array_equal(ha, oa)

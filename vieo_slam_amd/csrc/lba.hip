@@ -2291,7 +2291,7 @@ static bool lba_args_ok(bool sharded, bool vio, bool gba, int W, const vieo_lba_
                         const float* const* h_points, const uint8_t* const* h_close, const int* n_mp,
                         const vieo_lba_obs* const* h_obs, const int* n_obs, const vieo_lba_imu_edge* const* h_imu,
                         const int* n_imu, vieo_navstate* const* h_navs_out, float* const* h_points_out,
-                        uint8_t* const* h_erase, const vieo_lba_result* h_results, int pd) {
+                        uint8_t* const* h_erase, const vieo_lba_result* h_results, int pd, int sco) {
   if (W <= 0 || (!vio && !params) || !h_kfs || !n_kf || !h_points || !n_mp || !h_obs || !n_obs || !h_navs_out ||
       !h_points_out || !h_erase || !h_results || (vio && (!h_close || !h_imu || !n_imu)))
     return false;
@@ -2304,7 +2304,7 @@ static bool lba_args_ok(bool sharded, bool vio, bool gba, int W, const vieo_lba_
     if (vio && ((!h_close[w] && !gba && n_mp[w] > 0) || n_imu[w] < 0 || (n_imu[w] > 0 && !h_imu[w]))) return false;
     int n_free = 0;
     for (int k = 0; k < n_kf[w]; k++) n_free += !h_kfs[w][k].fixed;
-    if (pd * n_free + 1 > kBigSolveMax || n_kf[w] >= (1 << 24)) return false;
+    if (pd * n_free + sco > kBigSolveMax || n_kf[w] >= (1 << 24)) return false;
     if (vio) {
       std::vector<char> in(n_kf[w], 0), outk(n_kf[w], 0);
       for (int t = 0; t < n_imu[w]; t++) {
@@ -2351,7 +2351,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (rcd != VIEO_OK) return rcd;
     const bool ok = sh->cap >= 1 && lba_args_ok(true, vio, gba != nullptr, n_windows, params, vparams, h_kfs, n_kf,
                                                 h_points, h_close, n_mp, h_obs, n_obs, h_imu, n_imu, h_navs_out,
-                                                h_points_out, h_erase, h_results, pd);
+                                                h_points_out, h_erase, h_results, pd, sco);
     double sum = 1.0;
     if (sh->cap >= 1) {
       const int xrc = shard_agree(sh, ok, &sum);

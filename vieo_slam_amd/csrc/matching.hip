@@ -35,50 +35,94 @@ struct Knn2Job {
   int out_off;  // row offset into idx/dist outputs
 };
 
-// grid (ceil(max_nq/4), n_jobs); one wave per query row.
+// Where the jobs of a launch come from: a table in HBM (host-built), or the extractor's arrays of a batch of camera-rig
+// frames -- pair p of frame f searches camera pi[p]'s rows [num_mono, n) in camera pj[p]'s, the counts read on the
+// device (Frame.cc:620-628), so that a rig frame's stereo stage needs no host round trip.
+struct Knn2Src {
+  const Knn2Job* jobs;     // non-NULL: job blockIdx.y of the table
+  const uint8_t* desc;     // [frame][n_cams][cap][32]
+  const int32_t* counts;   // [frame][n_cams][2] = {n, num_mono}
+  int cap, n_cams, n_pairs;
+  signed char pi[6], pj[6];
+};
+
+// grid (ceil(max_nq / 64), n_jobs | n_pairs, n_frames), 256 threads.  A lane owns one query row (8 dwords in registers);
+// the train rows pass through LDS in tiles of 256 (one coalesced copy per workgroup instead of one 32-byte gather per
+// (query, train) pair and lane), wavefront w walks rows w*64.. of every tile with wave-uniform LDS addresses (a
+// broadcast read, no bank conflicts).  best / second travel as ONE packed word (distance << 16 | train index): the
+// lexicographic order of (distance, index) == cv::batchDistance's stable insertion order is the order of the words, so
+// an update is a v_med3_u32 and a v_min_u32, and the four wavefronts' pairs merge with min / max.
 __global__ void __launch_bounds__(256)
-k_knn2(const Knn2Job* __restrict__ jobs, const int* __restrict__ counts, int32_t* __restrict__ idx,
-       int32_t* __restrict__ dist) {
-  Knn2Job J = jobs[blockIdx.y];
-  const int lane = threadIdx.x & 63;
-  const int qi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform
-  if (qi >= J.nq) return;
-  const uint4 a0 = ((const uint4*)(J.q + (size_t)qi * 32))[0];
-  const uint4 a1 = ((const uint4*)(J.q + (size_t)qi * 32))[1];
-  int d0 = INT_MAX, i0 = INT_MAX, d1 = INT_MAX, i1 = INT_MAX;  // best, second (idx MAX = empty)
-  for (int j = lane; j < J.nt; j += 64) {
-    const int d = hamming32(a0, a1, J.t + (size_t)j * 32);
-    if (lex_less(d, j, d0, i0)) {
-      d1 = d0, i1 = i0;
-      d0 = d, i0 = j;
-    } else if (lex_less(d, j, d1, i1)) {
-      d1 = d, i1 = j;
+k_knn2(Knn2Src S, int32_t* __restrict__ idx, int32_t* __restrict__ dist) {
+  __shared__ uint4 s_t[256 * 2];
+  __shared__ unsigned s_m[3][64][2];
+  Knn2Job J;
+  if (S.jobs)
+    J = S.jobs[blockIdx.y];
+  else {
+    const int f = blockIdx.z, p = blockIdx.y, ci = S.pi[p], cj = S.pj[p];
+    const int32_t* c = S.counts + (size_t)f * S.n_cams * 2;
+    const int ni = c[2 * ci], mi = c[2 * ci + 1], nj = c[2 * cj], mj = c[2 * cj + 1];
+    const bool skip = mi >= ni || mj >= nj;  // Frame.cc:623
+    J.q = S.desc + (((size_t)f * S.n_cams + ci) * S.cap + mi) * 32;
+    J.t = S.desc + (((size_t)f * S.n_cams + cj) * S.cap + mj) * 32;
+    J.nq = skip ? 0 : min(ni, S.cap) - mi, J.nt = skip ? 0 : min(nj, S.cap) - mj;
+    J.out_off = ((int)f * S.n_pairs + p) * S.cap;
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= J.nq) return;  // (uniform over the workgroup)
+  const int qi = q0 + lane;
+  uint4 a0 = {0, 0, 0, 0}, a1 = a0;
+  if (qi < J.nq) a0 = ((const uint4*)(J.q + (size_t)qi * 32))[0], a1 = ((const uint4*)(J.q + (size_t)qi * 32))[1];
+  unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;  // best, second: distance << 16 | train row
+  const uint4* T = (const uint4*)J.t;
+  for (int t0 = 0; t0 < J.nt; t0 += 256) {
+    __syncthreads();
+    const int rows = min(256, J.nt - t0);
+    for (int e = threadIdx.x; e < rows * 2; e += 256) s_t[e] = T[(size_t)t0 * 2 + e];
+    __syncthreads();
+    const int r1 = min(rows, wave * 64 + 64);
+    for (int r = wave * 64; r < r1; r++) {
+      const uint4 b0 = s_t[2 * r], b1 = s_t[2 * r + 1];
+      const unsigned d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+      const unsigned key = (d << 16) | (unsigned)(t0 + r);
+      k1 = min(max(key, k0), k1);  // second smallest of {key, k0 <= k1} (v_med3_u32)
+      k0 = min(k0, key);
     }
   }
+  if (wave > 0) s_m[wave - 1][lane][0] = k0, s_m[wave - 1][lane][1] = k1;
+  __syncthreads();
+  if (wave == 0 && qi < J.nq) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int e0 = __shfl_xor(d0, o), j0 = __shfl_xor(i0, o);
-    const int e1 = __shfl_xor(d1, o), j1 = __shfl_xor(i1, o);
-    // merge two sorted pairs, keep the two smallest
-    if (lex_less(e0, j0, d0, i0)) {
-      if (lex_less(d0, i0, e1, j1)) {
-        d1 = d0, i1 = i0;
-      } else {
-        d1 = e1, i1 = j1;
-      }
-      d0 = e0, i0 = j0;
-    } else if (lex_less(e0, j0, d1, i1)) {
-      d1 = e0, i1 = j0;
+    for (int w = 0; w < 3; w++) {
+      const unsigned b0 = s_m[w][lane][0], b1 = s_m[w][lane][1];
+      const unsigned lo = min(k0, b0), hi = max(k0, b0);
+      k1 = min(hi, min(k1, b1));
+      k0 = lo;
     }
-  }
-  if (lane == 0) {
     int32_t* oi = idx + ((size_t)J.out_off + qi) * 2;
     int32_t* od = dist + ((size_t)J.out_off + qi) * 2;
-    oi[0] = i0 == INT_MAX ? -1 : i0;
-    od[0] = d0;
-    oi[1] = i1 == INT_MAX ? -1 : i1;
-    od[1] = d1;
+    oi[0] = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 & 0xFFFF), od[0] = k0 == 0xFFFFFFFFu ? INT_MAX : (int)(k0 >> 16);
+    oi[1] = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 & 0xFFFF), od[1] = k1 == 0xFFFFFFFFu ? INT_MAX : (int)(k1 >> 16);
   }
+}
+
+// the rig form for the device-resident stereo stage of camera-rig frames (fisheye_stereo.hip)
+int knn2_rig_launch(const uint8_t* d_desc, const int32_t* d_counts, int cap, int n_cams, int n_frames, int32_t* d_idx,
+                    int32_t* d_dist, hipStream_t st) {
+  Knn2Src S;
+  memset(&S, 0, sizeof(S));
+  S.desc = d_desc, S.counts = d_counts, S.cap = cap, S.n_cams = n_cams;
+  int p = 0;
+  for (int i = 0; i < n_cams - 1; i++)
+    for (int j = i + 1; j < n_cams; j++, p++) S.pi[p] = (signed char)i, S.pj[p] = (signed char)j;
+  S.n_pairs = p;
+  if (p == 0 || n_frames <= 0) return VIEO_OK;
+  hipLaunchKernelGGL(k_knn2, dim3((cap + 63) / 64, p, n_frames), dim3(256), 0, st, S, d_idx, d_dist);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
 }
 
 // ------------------------------------------------------------------ rectified stereo
@@ -512,7 +556,7 @@ int vieo_stereo_match_rectified(vieo_orb* left, vieo_orb* right, const vieo_keyp
 int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* h_counts,
                                    int capacity, const int32_t* h_pairs, int n_pairs,
                                    int32_t* d_idx, int32_t* d_dist, void* stream) {
-  if (!d_descriptors || !h_counts || !h_pairs || n_pairs <= 0 || !d_idx || !d_dist || capacity <= 0)
+  if (!d_descriptors || !h_counts || !h_pairs || n_pairs <= 0 || !d_idx || !d_dist || capacity <= 0 || capacity > 65535)
     return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
@@ -535,9 +579,12 @@ int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* 
   VIEO_HIP_CHECK(hipMemcpyAsync(S.jobs.p, jobs.data(), jobs.size() * sizeof(Knn2Job),
                                 hipMemcpyHostToDevice, st));
   VIEO_HIP_CHECK(hipStreamSynchronize(st));  // jobs vector goes out of scope
-  if (max_nq > 0)
-    hipLaunchKernelGGL(k_knn2, dim3((max_nq + 3) / 4, n_pairs), dim3(256), 0, st,
-                       S.jobs.as<Knn2Job>(), nullptr, d_idx, d_dist);
+  if (max_nq > 0) {
+    Knn2Src K;
+    memset(&K, 0, sizeof(K));
+    K.jobs = S.jobs.as<Knn2Job>();
+    hipLaunchKernelGGL(k_knn2, dim3((max_nq + 63) / 64, n_pairs), dim3(256), 0, st, K, d_idx, d_dist);
+  }
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
@@ -548,6 +595,10 @@ int vieo_hamming_knn2(const uint8_t* h_query, int nq, const uint8_t* h_train, in
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
   if (nq == 0) return VIEO_OK;
+  if (nt > 65535) {  // the packed (distance, index) word of k_knn2
+    set_error("vieo_hamming_knn2: %d train rows, at most 65535", nt);
+    return VIEO_E_CAPACITY;
+  }
   MatchScratch& S = g_ms;
 #define ENS(b, n) \
   if ((rc = (b).ensure(n)) != VIEO_OK) return rc
@@ -562,8 +613,10 @@ int vieo_hamming_knn2(const uint8_t* h_query, int nq, const uint8_t* h_train, in
   Knn2Job j;
   j.q = S.dL.as<uint8_t>(), j.t = S.dR.as<uint8_t>(), j.nq = nq, j.nt = nt, j.out_off = 0;
   VIEO_HIP_CHECK(hipMemcpy(S.jobs.p, &j, sizeof(j), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4, 1), dim3(256), 0, 0, S.jobs.as<Knn2Job>(), nullptr,
-                     S.idx.as<int32_t>(), S.dist.as<int32_t>());
+  Knn2Src K;
+  memset(&K, 0, sizeof(K));
+  K.jobs = S.jobs.as<Knn2Job>();
+  hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64, 1), dim3(256), 0, 0, K, S.idx.as<int32_t>(), S.dist.as<int32_t>());
   VIEO_HIP_CHECK(hipGetLastError());
   VIEO_HIP_CHECK(hipMemcpy(h_idx, S.idx.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
   VIEO_HIP_CHECK(hipMemcpy(h_dist, S.dist.p, (size_t)nq * 8, hipMemcpyDeviceToHost));

@@ -350,7 +350,6 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   const float* ang_f = A.cell_ang + (size_t)f * A.key_cap;
   unsigned* pool = A.pool + (size_t)f * A.pool_cap;
   const float factor = 1.0f / kHistoLen;
-  const int stride = kSbpBlocks * 4;
   const uint4* QQ = (const uint4*)(A.queries + (size_t)f * A.q_cap);
   // Pool space comes in slabs of kCandCap entries per wavefront (a query keeps at most kCandCap candidates): one global
   // atomic per slab instead of one per query -- the atomic's round trip was one of the three dependent ones of every
@@ -515,11 +514,22 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   __syncthreads();
   // ---- pass 2: a wavefront per query for the windows pass 1 left (more than 16 columns or 64 entries)
   // (the block's own list of them; if it overflowed, every query of the stride is looked at again and the small ones skipped)
+  // The fallback walks exactly the queries pass 1 gave this wavefront (groups of four, kSbpBlocks * 16 apart): pass 1
+  // wrote no record for their wide ones and no other block looks at them.
   const int nbig = s_nbig;
   const bool listed = nbig <= kBigCap;
-  const int n2 = listed ? nbig : nq;
-  for (int k2 = listed ? wave : blockIdx.x * 4 + wave; k2 < n2; k2 += listed ? 4 : stride) {
-    const int q = listed ? s_big[k2] : k2;
+  const int own0 = (blockIdx.x * 4 + wave) * 4;
+  for (int k2 = listed ? wave : 0;; k2 += listed ? 4 : 1) {
+    int q;
+    if (listed) {
+      if (k2 >= nbig) break;
+      q = s_big[k2];
+    } else {
+      const int q0 = own0 + (k2 >> 2) * (kSbpBlocks * 16);
+      if (q0 >= nq) break;
+      q = q0 + (k2 & 3);
+      if (q >= nq) continue;
+    }
     const uint4 h0 = QQ[4 * (size_t)q], h1 = QQ[4 * (size_t)q + 1];
     const uint4 d0 = QQ[4 * (size_t)q + 2], d1 = QQ[4 * (size_t)q + 3];
     const float x = __uint_as_float(h0.x), y = __uint_as_float(h0.y), q_ur = __uint_as_float(h0.z);
@@ -1095,11 +1105,10 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
     SbpArgs P = A;
     size_t lds_par = (size_t)P.pool_lds * 4 + (size_t)P.key_cap * 13;
     if (lds_par > 150 * 1024) P.pool_lds = 0, lds_par = (size_t)P.key_cap * 13;  // many-camera frames: the pool stays in L2
-    static thread_local size_t lds_set = 0;
-    if (lds_par > lds_set) {
-      VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_sbp_assign_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_par));
-      lds_set = lds_par;
-    }
+    // (the attribute belongs to the function on the device, not to the calling thread, and a set overwrites it: every
+    // launch asks for the one fixed ceiling, so concurrent tracker threads with different key_cap cannot lower each other's)
+    if (lds_par > 64 * 1024)
+      VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_sbp_assign_par, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     hipLaunchKernelGGL(k_sbp_assign_par, dim3(n_frames), dim3(1024), lds_par, st, P);
   }
   hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), lds, st, A);

@@ -64,6 +64,83 @@ def compute_stereo_fisheye_matches(params, keys, descs, num_mono, group_capacity
     return out
 
 
+class FisheyeStereoDevice:
+    """Handle of the device-resident stereo stage of camera-rig frames (vieo_fisheye_*): `match_batch` takes the
+    extractor-layout arrays of n_frames rig frames ([frame][camera][cap]) already in HBM (DeviceBuffer) or as numpy
+    arrays (uploaded here, test convenience) and returns the per-frame outputs downloaded as numpy arrays."""
+
+    def __init__(self, params, key_cap, max_frames=1):
+        import ctypes
+        self.params = np.ascontiguousarray(params)
+        self.nc, self.cap, self.max_frames = int(params[0]["n_cams"]), int(key_cap), int(max_frames)
+        h = ctypes.c_void_p()
+        check(lib().vieo_fisheye_create(ctypes.byref(h), self.params.ctypes.data, self.cap, self.max_frames),
+              "vieo_fisheye_create")
+        self.h = h
+        self.gcap = lib().vieo_fisheye_group_capacity(self.h)
+
+    def close(self):
+        if self.h:
+            lib().vieo_fisheye_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def match_batch(self, frames):
+        """frames: list of (keys [n_cams] KEYPOINT_DTYPE arrays, descs [n_cams], num_mono).  returns a list of dicts
+        like fisheye_call's plus keys / desc (mvKeys order), cam_first, hdr."""
+        from ._lib import DeviceBuffer
+        from .orb_extractor import KEYPOINT_DTYPE
+        nf, nc, cap, gcap = len(frames), self.nc, self.cap, self.gcap
+        kc = nc * cap
+        K = np.zeros((nf, nc, cap), KEYPOINT_DTYPE)
+        D = np.zeros((nf, nc, cap, 32), np.uint8)
+        C = np.zeros((nf, nc, 2), np.int32)
+        for f, (keys, descs, mono) in enumerate(frames):
+            for c in range(nc):
+                n = len(keys[c])
+                K[f, c, :n], D[f, c, :n] = keys[c], np.asarray(descs[c]).reshape(-1, 32)
+                C[f, c] = (n, mono[c])
+        bufs = {}
+        for name, arr in (("K", K), ("D", D), ("C", C)):
+            bufs[name] = DeviceBuffer(max(arr.nbytes, 16))
+            bufs[name].upload(arr)
+        outs = dict(kcat=(KEYPOINT_DTYPE, (nf, kc)), dcat=(np.uint8, (nf, kc, 32)), first=(np.int32, (nf, nc + 1)),
+                    depth=(np.float32, (nf, kc)), ur=(np.float32, (nf, kc)), kg=(np.int32, (nf, kc)),
+                    gidx=(np.int32, (nf, gcap, nc)), good=(np.uint8, (nf, gcap)), p3d=(np.float64, (nf, gcap, 3)),
+                    hdr=(np.int32, (nf, 8)))
+        for name, (dt, shp) in outs.items():
+            bufs[name] = DeviceBuffer(max(int(np.prod(shp)) * np.dtype(dt).itemsize, 16))
+        check(lib().vieo_stereo_fisheye_match_batch_device(
+            self.h, bufs["K"].ptr, bufs["D"].ptr, bufs["C"].ptr, nf, bufs["kcat"].ptr, bufs["dcat"].ptr, bufs["first"].ptr,
+            bufs["depth"].ptr, bufs["ur"].ptr, bufs["kg"].ptr, bufs["gidx"].ptr, bufs["good"].ptr, bufs["p3d"].ptr,
+            bufs["hdr"].ptr, None), "vieo_stereo_fisheye_match_batch_device")
+        check(lib().vieo_device_synchronize(), "sync")
+        got = {name: bufs[name].download(dt, shp) for name, (dt, shp) in outs.items()}
+        res = []
+        for f in range(nf):
+            N, g = int(got["first"][f, nc]), int(got["hdr"][f, 0])
+            res.append(dict(depth=got["depth"][f, :N], key_group=got["kg"][f, :N], group_idx=got["gidx"][f, :g],
+                            group_good=got["good"][f, :g].astype(bool), group_p3d=got["p3d"][f, :g],
+                            n_matches=int(got["hdr"][f, 1]), keys=got["kcat"][f, :N], desc=got["dcat"][f, :N],
+                            uright=got["ur"][f, :N], cam_first=got["first"][f], hdr=got["hdr"][f]))
+        for b in bufs.values():
+            b.free()
+        return res
+
+
+def fisheye_last_walk():
+    """(rows walked, wavefront steps) of this thread's last compute_stereo_fisheye_matches (test tap)."""
+    import ctypes
+    a, b = ctypes.c_int32(), ctypes.c_int32()
+    lib().vieo_fisheye_last_walk(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
 class ORBmatcher:
     """ORBmatcher(nnratio=0.6, checkOri=True) (reference include/ORBmatcher.h:25-101), tracking-side
     searches on flattened inputs (ba_types.PROJ_QUERY_DTYPE etc.)."""
