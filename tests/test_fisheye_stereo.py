@@ -186,8 +186,8 @@ def test_fisheye_device_batch_matches_oracle_and_walks_in_parallel(oracle):
             assert np.array_equal(h["desc"], np.concatenate(c["descs"])) and (h["uright"] == -1).all()
             assert np.array_equal(h["cam_first"], np.concatenate([[0], np.cumsum([len(k) for k in c["keys"]])]))
         # an ordinary frame: most rows are independent
-        rows, steps = outs[0]["hdr"][5], outs[0]["hdr"][6]
-        assert rows > 100 and steps <= rows // 8 + 8, (rig, rows, steps)
+        rows, steps = int(outs[0]["hdr"][5]), int(outs[0]["hdr"][6])
+        assert rows >= 30 and 0 < steps <= rows // 8 + 8, (rig, rows, steps)
         dev.close()
     # the host-pointer entry reports its walk as well
     c = synth_fisheye.make_fisheye_case(37, rig="kb8")

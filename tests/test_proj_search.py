@@ -265,19 +265,19 @@ def test_gpu_sbp_assignment_dependency_chains(oracle, mode, monkeypatch):
 def test_gpu_sbp_more_wide_windows_than_a_block_lists(oracle, monkeypatch):
     """k_sbp_candidates leaves wide / crowded windows to a second pass through a per-block list of 1024 entries; a frame
     with more of them than the eight blocks can list (relocalisation-size windows, rig local maps with p_cap * n_cams
-    queries) makes every block walk ITS OWN share of the queries again.  10 800 queries, all of them wider than 16 grid
+    queries) makes every block walk ITS OWN share of the queries again.  19 000 queries, all of them wider than 16 grid
     columns, against the oracle and against the sequential replay."""
     kl, dl, ur, pts, cam = _scenario(oracle, 1040, th=7.0)
     q1 = oracle.sbp_project_last_frame(pts, cam)
     rng = np.random.default_rng(1040)
-    q = np.tile(q1, 9)
+    q = np.tile(q1, 16)
     q["u"] += rng.uniform(-30, 30, len(q)).astype(np.float32)
     q["v"] += rng.uniform(-30, 30, len(q)).astype(np.float32)
     q["radius"] = rng.uniform(96.0, 110.0, len(q)).astype(np.float32)
-    oc = np.tile(pts["octave"], 9)
+    oc = np.tile(pts["octave"], 16)
     q["level_min"], q["level_max"] = oc, oc           # one level: ~20 candidates out of a window of ~130 keys
     q["flags"] = np.where(rng.random(len(q)) < 0.5, q["flags"] & ~2, q["flags"])
-    assert len(q) > 8 * 1024 + 2000 and ((q["flags"] & 1) > 0).sum() > 8 * 1024
+    assert ((q["flags"] & 1) > 0).sum() > 8 * 1024 + 1500
     m = _hip_matcher(0.9)
     on, oa = oracle.search_by_projection(0, q, kl, ur, dl, None, BOUNDS, nn_ratio=0.9)
     assert on > 100
