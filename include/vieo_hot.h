@@ -194,7 +194,8 @@ int vieo_stereo_fisheye_match(const vieo_fisheye_params* params, const vieo_keyp
  * Inputs are the extractor's batch arrays: d_keys / d_desc [n_frames][n_cams][key_cap_per_camera], d_counts
  * [n_frames][n_cams][2] = {n, num_mono} (vieo_orb_extract_batch_device with n_images = n_frames * n_cams).
  * Outputs, per frame: d_keys_cat / d_desc_cat / d_depth / d_uright / d_key_group [n_cams * key_cap_per_camera] in mvKeys
- * (camera-major) order, d_cam_first [n_cams + 1]; the groups d_group_idx [gcap][n_cams], d_group_good [gcap],
+ * (camera-major) order, d_cam_first [n_cams + 1], d_frame_counts [2] = {N, 0} (the counts layout the vieo_track_* glue
+ * reads); the groups d_group_idx [gcap][n_cams], d_group_good [gcap],
  * d_group_p3d [gcap][3] with gcap = vieo_fisheye_group_capacity(); d_hdr [8] = {n_groups, n_matches, threshold used
  * (0 / 1), status (1: more than gcap groups, the frame's tables are void), -, rows walked, wavefront steps, -}. */
 typedef struct vieo_fisheye vieo_fisheye;
@@ -203,8 +204,8 @@ void vieo_fisheye_destroy(vieo_fisheye* h);
 int vieo_fisheye_group_capacity(const vieo_fisheye* h);
 int vieo_stereo_fisheye_match_batch_device(vieo_fisheye* h, const vieo_keypoint* d_keys, const uint8_t* d_desc,
                                            const int32_t* d_counts, int n_frames, vieo_keypoint* d_keys_cat,
-                                           uint8_t* d_desc_cat, int32_t* d_cam_first, float* d_depth, float* d_uright,
-                                           int32_t* d_key_group, int32_t* d_group_idx, uint8_t* d_group_good,
+                                           uint8_t* d_desc_cat, int32_t* d_cam_first, int32_t* d_frame_counts,
+                                           float* d_depth, float* d_uright, int32_t* d_key_group, int32_t* d_group_idx, uint8_t* d_group_good,
                                            double* d_group_p3d, int32_t* d_hdr, void* stream);
 /* test tap: rows walked / wavefront steps of this thread's last vieo_stereo_fisheye_match */
 void vieo_fisheye_last_walk(int32_t* rows, int32_t* steps);
@@ -301,7 +302,8 @@ typedef struct vieo_last_frame_point { /* LastFrame.mvpMapPoints[i] flattened: 6
   int32_t octave;    /* LastFrame.mvKeys[i].octave */
   float angle;       /* LastFrame.mvKeys[i].angle */
   int32_t flags;     /* bit0: pMP != NULL && !LastFrame.mvbOutlier[i]; bit1: Observations() > 0 */
-  int32_t reserved[2];
+  int32_t reserved[2]; /* [0]: read by the frame tracker only -- 1 + the index of the FIRST key of LastFrame that holds the
+                        * same MapPoint (a rig frame's point is held by one key per camera), 0: this key */
   uint8_t desc[32];
 } vieo_last_frame_point;
 
@@ -842,6 +844,21 @@ int vieo_track_build_obs_depth_batch_device(const int32_t* d_mp_ref, const float
                                             int img_first, int img_step, const float* d_inv_sigma2,
                                             vieo_pose_obs* d_obs, int32_t* d_obs_key, void* d_frames,
                                             int frames_are_vio, void* stream);
+/* The two glue steps for camera-rig frames: a search's query (point i, camera c) is i * query_div + c (query_div =
+ * n_cams), and an observation carries its key's camera in bits 8..11 of vieo_pose_obs.flags (mapn2in_,
+ * include/Optimizer.h:424-426) -- the camera found from d_cam_first [f][n_cams + 1]; keys [f][key_cap] camera-major,
+ * d_counts [f][2] = {N, -} (d_frame_counts of vieo_stereo_fisheye_match_batch_device); d_point_depth may be NULL. */
+int vieo_track_merge_assign_rig_batch_device(const int32_t* d_assign, int32_t* d_mp_ref, const int32_t* d_counts,
+                                             int key_cap, int n_frames, int img_first, int img_step, int point_offset,
+                                             int reset, int query_div,
+                                             const vieo_last_frame_point* d_same_point /*[f][key_cap] or NULL: reserved[0]
+                                             > 0 names (1 +) the first point-table entry of the same MapPoint*/, void* stream);
+int vieo_track_build_obs_rig_batch_device(const int32_t* d_mp_ref, const float* d_point_xyz,
+                                          const float* d_point_depth, float close_depth, int p_cap,
+                                          const vieo_keypoint* d_keys, const float* d_uright,
+                                          const int32_t* d_counts, const int32_t* d_cam_first, int n_cams, int key_cap,
+                                          int n_frames, const float* d_inv_sigma2, vieo_pose_obs* d_obs,
+                                          int32_t* d_obs_key, void* d_frames, int frames_are_vio, void* stream);
 /* d_held[f][p_cap] = 1 for the entries of frame f's point table that a key holds (the points
  * Tracking::SearchLocalPoints takes out of the local-map search, src/Tracking.cc:2318-2334). */
 int vieo_track_mark_held_batch_device(const int32_t* d_mp_ref, const int32_t* d_counts, int key_cap,
@@ -1018,7 +1035,13 @@ int vieo_imu_preintegrate_batch_device(const vieo_imu_noise* d_noise, const vieo
  * KeyFrame / MapPoint / Map) and hands over flattened views of what the calls read; outputs point into pinned memory
  * owned by the tracker and stay valid until its next call.  Thread model: one tracker per tracking thread; other
  * threads (LocalMapping, LoopClosing) call the other entries concurrently on their own streams.
- * Rectified stereo + IMU (BASELINE configs[1] / [2]); rigs go through the stage entries (pipeline_rig). */
+ * Three kinds of tracker (round 4): rectified stereo + IMU (BASELINE configs[1] / [2]; vieo_tracker_create); a distorted
+ * camera rig of 2..4 cameras + IMU (the reference's default EuRoC_VIO_dist* set-up, configs[3] / [4];
+ * vieo_tracker_create_rig): ExtractORB x n_cams with the KB8 lapping area, Frame::ComputeStereoFishEyeMatches
+ * (Frame.cc:613-779) instead of the rectified matcher, the camera loop in both searches, the rig instances of the
+ * optimiser; and rectified stereo WITHOUT the IMU (configs[0]; params.vision_only): Tracking::TrackWithMotionModel
+ * (Tracking.cc:1844-1928) + TrackLocalMap (:1930-1945) with Optimizer::PoseOptimization(Frame*, Frame*)
+ * (Optimizer.cc:1611-1874); the predicted pose (mVelocity * mLastFrame.Tcw, a 4x4 product) is the caller's. */
 typedef struct vieo_tracker vieo_tracker;
 typedef struct vieo_tracker_params {
   int32_t width, height;                /* image size; both cameras */
@@ -1033,7 +1056,24 @@ typedef struct vieo_tracker_params {
   double gw[3];                         /* gravity in the world frame */
   double inv_sigma_bg2, inv_sigma_ba2;  /* IMUDataBase::mInvSigmabg2 / mInvSigmaba2 */
   vieo_imu_noise noise;
+  int32_t vision_only;                  /* 1: no IMU -- nav_ref of the input is the PREDICTED state of the frame (p, q; the
+                                         * rest is carried along), imu / prior inputs are ignored, the two optimisations are
+                                         * the vision-only ones and `first` / `second` hold their vieo_pose_result in .base */
+  int32_t reserved;
 } vieo_tracker_params;
+
+/* The rig of a distorted multi-camera tracker (Frame::usedistort_, mpCameras).  params.fx..cy are not read (camera 0's
+ * are used where the reference takes mpCameras[0]->toK()); params.Rcb / tcb: body -> reference camera; params.bf /
+ * baseline: stereoinfo_.baseline_bf_. */
+typedef struct vieo_tracker_rig {
+  int32_t n_cams;                       /* 2..4 */
+  int32_t use_lapping;                  /* KB8 cameras hand their lapping area to ExtractORB (Frame.cc:269-273) */
+  int32_t lapping[2];                   /* GetvLappingArea() */
+  float th_far_pts;                     /* mpLocalMapper->th_far_pts_ (<= 0: off) */
+  float reserved;
+  vieo_camera cams[4];                  /* model + parameters; Rcb / tcb: body -> camera c (pose optimisation) */
+  double Trc[4][12], Tcr[4][12];        /* mpCameras[c]->GetTrc() / GetTcr() (Sophus::SE3<float>) cast to double, 3x4 */
+} vieo_tracker_rig;
 
 typedef struct vieo_track_input {
   const uint8_t *left, *right;          /* 8-bit grey images, `stride` bytes per row (or the tracker's own pinned
@@ -1057,11 +1097,18 @@ typedef struct vieo_track_input {
   const vieo_frustum_point* local_points;
   const uint8_t* local_desc;            /* [n_local][32] */
   const int32_t* local_alias;           /* candidate j is last_points[local_alias[j]] (-1: not in the last frame) */
+  const uint8_t* images[4];             /* rig trackers: camera c's image (left / right are not read); n_last then counts
+                                         * mLastFrame's keys in mvKeys (camera-major) order, up to vieo_tracker_key_capacity */
 } vieo_track_input;
 
 #define VIEO_TRACK_OK 0
 #define VIEO_TRACK_PREINT_FAILED 1      /* mdeltatij == 0 / CheckIMU: PredictNavStateByIMU returns false; extraction and
                                          * stereo outputs are valid, the tracking outputs are not */
+#define VIEO_TRACK_LOST 2               /* fewer than 10 (vision-only: 20) matches after the widened search: TrackWithIMU /
+                                         * TrackWithMotionModel return false before the optimisations (Tracking.cc:311,1878);
+                                         * extraction, stereo and search outputs are valid, `first` / `second` are not.
+                                         * (The inlier gates behind the optimisations -- nmatchesMap, mnMatchesInliers --
+                                         * need MapPoint::Observations() and stay with the caller.) */
 typedef struct vieo_track_output {
   int32_t status;                       /* VIEO_TRACK_* */
   int32_t n_keys, key_cap;              /* left image: N, and the offset that separates the two point tables */
@@ -1080,12 +1127,25 @@ typedef struct vieo_track_output {
   vieo_vio_result first, second;        /* TrackWithIMU's / TrackLocalMapWithIMU's PoseOptimization */
   float ms_gpu;                         /* HIP-event time of the chain, upload to download */
   float ms_host;                        /* wall time of the call */
+  /* rig trackers: keys / desc / uright (-1) / depth / point_ref / outlier are in mvKeys order (camera-major) */
+  int32_t cam_first[5];                 /* first key of camera c, [n_cams] = n_keys (mapn2in_) */
+  int32_t mono_index[4];                /* num_mono of ExtractORB per camera */
+  int32_t stereo_status;                /* != 0: more stereo groups than vieo_tracker_group_capacity, no depths */
+  int32_t n_groups, n_stereo_matches;   /* ComputeStereoFishEyeMatches: mvidxsMatches.size(), nMatches */
+  const int32_t* key_group;             /* [n_keys] mapcamidx2idxs_ (-1: none) */
+  const int32_t* group_idx;             /* [n_groups][n_cams] mvidxsMatches */
+  const uint8_t* group_good;            /* [n_groups] goodmatches_ */
+  const double* group_p3d;              /* [n_groups][3] v3dpoints_ (reference-camera frame) */
 } vieo_track_output;
 
 int vieo_tracker_create(vieo_tracker** out, const vieo_tracker_params* params);
+int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* params, const vieo_tracker_rig* rig /*NULL: rectified*/);
 void vieo_tracker_destroy(vieo_tracker* t);
+int vieo_tracker_key_capacity(const vieo_tracker* t);   /* keys of a frame at most (n_cams x the extractor's capacity) */
+int vieo_tracker_group_capacity(const vieo_tracker* t); /* stereo groups of a rig frame at most */
 /* pinned planes the caller may decode the next frame's images into (stride = width) */
 int vieo_tracker_image_buffers(vieo_tracker* t, uint8_t** left, uint8_t** right);
+int vieo_tracker_image_buffer(vieo_tracker* t, int image_index, uint8_t** plane);
 int vieo_tracker_scale_factors(const vieo_tracker* t, float* h_out /*[n_levels]*/);
 int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_output* out);
 /* mvImagePyramid of the frame just tracked, lazily (only Frame::ComputeStereoMatches reads it, src/Frame.cc:457,536-557,

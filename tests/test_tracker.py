@@ -22,6 +22,8 @@ def test_tracker_structs_match_the_header(tmp_path):
 #include "vieo_hot.h"
 int main(void) {
   printf("%zu %zu %zu ", sizeof(vieo_tracker_params), sizeof(vieo_track_input), sizeof(vieo_track_output));
+  printf("%zu %zu %zu %zu %zu %zu ", sizeof(vieo_tracker_rig), offsetof(vieo_tracker_rig, cams), offsetof(vieo_tracker_rig, Tcr),
+         offsetof(vieo_tracker_params, vision_only), offsetof(vieo_track_input, images), offsetof(vieo_track_output, group_p3d));
   printf("%zu %zu %zu %zu ", offsetof(vieo_tracker_params, Rcb), offsetof(vieo_tracker_params, noise),
          offsetof(vieo_track_input, nav_ref), offsetof(vieo_track_input, local_alias));
   printf("%zu %zu %zu %zu %zu %zu\n", offsetof(vieo_track_output, nav_pred), offsetof(vieo_track_output, imu),
@@ -33,7 +35,9 @@ int main(void) {
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     P, I, O = tk.TRACKER_PARAMS_DTYPE, tk.TRACK_INPUT_DTYPE, tk.TRACK_OUTPUT_DTYPE
-    want = [P.itemsize, I.itemsize, O.itemsize, P.fields["Rcb"][1], P.fields["noise"][1], I.fields["nav_ref"][1],
+    G = tk.TRACKER_RIG_DTYPE
+    want = [P.itemsize, I.itemsize, O.itemsize, G.itemsize, G.fields["cams"][1], G.fields["Tcr"][1],
+            P.fields["vision_only"][1], I.fields["images"][1], O.fields["group_p3d"][1], P.fields["Rcb"][1], P.fields["noise"][1], I.fields["nav_ref"][1],
             I.fields["local_alias"][1], O.fields["nav_pred"][1], O.fields["imu"][1], O.fields["first"][1],
             O.fields["second"][1], O.fields["ms_gpu"][1], O.fields["local_track_depth"][1]]
     assert got == want

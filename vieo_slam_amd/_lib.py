@@ -90,7 +90,10 @@ _SIGS = {
     "vieo_fisheye_create": (c_i, [P(c_p), c_p, c_i, c_i]),
     "vieo_fisheye_destroy": (None, [c_p]),
     "vieo_fisheye_group_capacity": (c_i, [c_p]),
-    "vieo_stereo_fisheye_match_batch_device": (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_p] * 11),
+    "vieo_stereo_fisheye_match_batch_device": (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_p] * 12),
+    "vieo_track_merge_assign_rig_batch_device": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "vieo_track_build_obs_rig_batch_device": (c_i, [c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p,
+                                                     c_p, c_i, c_p]),
     "vieo_fisheye_last_walk": (None, [c_p, c_p]),
     "vieo_hamming_knn2_batch_device": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
     "vieo_stereo_match_rectified": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_f, c_p, c_p]),
@@ -141,6 +144,10 @@ _SIGS = {
     "vieo_orb_tap_level_keys": (c_i, [c_p, c_i, c_i, c_p, c_i]),
     "vieo_imu_preintegrate_batch_device": (c_i, [c_p] * 7 + [c_i] + [c_p] * 4),
     "vieo_tracker_create": (c_i, [P(c_p), c_p]),
+    "vieo_tracker_create_rig": (c_i, [P(c_p), c_p, c_p]),
+    "vieo_tracker_key_capacity": (c_i, [c_p]),
+    "vieo_tracker_group_capacity": (c_i, [c_p]),
+    "vieo_tracker_image_buffer": (c_i, [c_p, c_i, P(c_p)]),
     "vieo_tracker_destroy": (None, [c_p]),
     "vieo_tracker_image_buffers": (c_i, [c_p, P(c_p), P(c_p)]),
     "vieo_tracker_scale_factors": (c_i, [c_p, c_p]),

@@ -169,6 +169,7 @@ struct FeBatch {
   vieo_keypoint* keys_cat;     // [frame][key_cap] mvKeys (camera-major)
   uint8_t* desc_cat;           // [frame][key_cap][32] mDescriptors
   int32_t* cam_first;          // [frame][n_cams + 1]
+  int32_t* frame_counts;       // [frame][2] = {N, 0}: the frame's key count in the layout the tracking glue reads
   float* depth;                // [frame][key_cap] vdepth_
   float* uright;               // [frame][key_cap] vuright_ (-1)
   int32_t* key_group;          // [frame][key_cap] mapcamidx2idxs_ in mvKeys order
@@ -515,6 +516,7 @@ k_fe_finish(FeBatch B) {
   int32_t* hdr = B.hdr + (size_t)f * 8;
   if (n == 0) {
     for (int c = 0; c <= nc; c++) B.cam_first[(size_t)f * (nc + 1) + c] = first[c];
+    B.frame_counts[2 * (size_t)f] = min(first[nc], B.key_cap), B.frame_counts[2 * (size_t)f + 1] = 0;
     if (nc > 2) hdr[1] = hdr[4];  // Frame.cc:705: nMatches counts the re-triangulated groups
   }
   if (n >= first[nc] || n >= B.key_cap) return;
@@ -640,11 +642,12 @@ int vieo_fisheye_group_capacity(const vieo_fisheye* h) { return h ? h->gcap : 0;
 
 int vieo_stereo_fisheye_match_batch_device(vieo_fisheye* h, const vieo_keypoint* d_keys, const uint8_t* d_desc,
                                            const int32_t* d_counts, int n_frames, vieo_keypoint* d_keys_cat,
-                                           uint8_t* d_desc_cat, int32_t* d_cam_first, float* d_depth, float* d_uright,
+                                           uint8_t* d_desc_cat, int32_t* d_cam_first, int32_t* d_frame_counts,
+                                           float* d_depth, float* d_uright,
                                            int32_t* d_key_group, int32_t* d_group_idx, uint8_t* d_group_good,
                                            double* d_group_p3d, int32_t* d_hdr, void* stream) {
   if (!h || !d_keys || !d_desc || !d_counts || n_frames <= 0 || n_frames > h->max_frames || !d_keys_cat || !d_desc_cat ||
-      !d_cam_first || !d_depth || !d_uright || !d_key_group || !d_group_idx || !d_group_good || !d_group_p3d || !d_hdr)
+      !d_cam_first || !d_frame_counts || !d_depth || !d_uright || !d_key_group || !d_group_idx || !d_group_good || !d_group_p3d || !d_hdr)
     return VIEO_E_INVALID;
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
@@ -661,6 +664,7 @@ int vieo_stereo_fisheye_match_batch_device(vieo_fisheye* h, const vieo_keypoint*
   B.hdr = d_hdr, B.group_idx = d_group_idx, B.group_good = d_group_good, B.group_p3d = d_group_p3d;
   B.key_group_cam = h->kgc.as<int32_t>();
   B.keys_cat = d_keys_cat, B.desc_cat = d_desc_cat, B.cam_first = d_cam_first, B.depth = d_depth, B.uright = d_uright;
+  B.frame_counts = d_frame_counts;
   B.key_group = d_key_group;
   B.cap = cap, B.gcap = h->gcap, B.n_cams = nc, B.n_pairs = h->n_pairs, B.tries = h->tries, B.key_cap = nc * cap;
   for (int i = 0, p = 0; i < nc - 1; ++i)
@@ -738,14 +742,13 @@ int vieo_stereo_fisheye_match(const vieo_fisheye_params* P, const vieo_keypoint*
   const size_t i_keys = S.in(keys.data(), keys.size() * sizeof(vieo_keypoint)), i_desc = S.in(desc.data(), desc.size());
   const size_t i_cnt = S.in(counts, sizeof(counts));
   const size_t o_kcat = S.out((size_t)kc * sizeof(vieo_keypoint)), o_dcat = S.out((size_t)kc * 32), o_first = S.out(5 * 4);
-  const size_t o_first_dl = o_first;
+  const size_t o_fcnt = S.out(8);
   const size_t o_depth = S.out((size_t)kc * 4), o_ur = S.out((size_t)kc * 4), o_kg = S.out((size_t)kc * 4);
   const size_t o_gidx = S.out((size_t)gcap * nc * 4), o_good = S.out(gcap), o_p3d = S.out((size_t)gcap * 24), o_hdr = S.out(32);
-  (void)o_first_dl;
   rc = S.upload(nullptr);
   if (rc == VIEO_OK)
     rc = vieo_stereo_fisheye_match_batch_device(h, S.d<vieo_keypoint>(i_keys), S.d<uint8_t>(i_desc), S.d<int32_t>(i_cnt), 1,
-                                                S.d<vieo_keypoint>(o_kcat), S.d<uint8_t>(o_dcat), S.d<int32_t>(o_first),
+                                                S.d<vieo_keypoint>(o_kcat), S.d<uint8_t>(o_dcat), S.d<int32_t>(o_first), S.d<int32_t>(o_fcnt),
                                                 S.d<float>(o_depth), S.d<float>(o_ur), S.d<int32_t>(o_kg), S.d<int32_t>(o_gidx),
                                                 S.d<uint8_t>(o_good), S.d<double>(o_p3d), S.d<int32_t>(o_hdr), nullptr);
   if (rc == VIEO_OK) rc = S.download(o_depth, nullptr);

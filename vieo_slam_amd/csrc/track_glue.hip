@@ -14,7 +14,7 @@ namespace vieo {
 __global__ void __launch_bounds__(256)
 k_track_merge_assign(const int* __restrict__ assign, int* __restrict__ mp_ref,
                      const int* __restrict__ counts, int key_cap, int img_first, int img_step,
-                     int point_offset, int reset) {
+                     int point_offset, int reset, int query_div, const vieo_last_frame_point* __restrict__ pts) {
   const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   const int img = img_first + f * img_step;
   if (i >= key_cap) return;
@@ -25,8 +25,15 @@ k_track_merge_assign(const int* __restrict__ assign, int* __restrict__ mp_ref,
   }
   int cur = reset ? -1 : *m;
   const int a = assign[(size_t)f * key_cap + i];
-  if (a >= 0)
-    cur = point_offset + a;
+  if (a >= 0) {
+    int pi = query_div > 1 ? a / query_div : a;  // a rig's query (point i, camera c) is i * n_cams + c
+    // a rig frame's map point is held by one key per camera: all of them stand for the first one's table entry
+    if (pts) {
+      const int rep = pts[(size_t)f * key_cap + pi].reserved[0];
+      if (rep > 0) pi = rep - 1;
+    }
+    cur = point_offset + pi;
+  }
   else if (a == VIEO_SBP_ERASED)
     cur = -1;
   *m = cur;
@@ -39,7 +46,8 @@ k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ poin
                   const int* __restrict__ counts, int key_cap, int img_first, int img_step,
                   const float* __restrict__ inv_sigma2, const float* __restrict__ point_depth, float close_depth,
                   vieo_pose_obs* __restrict__ obs, int* __restrict__ obs_key, uint8_t* frames_base,
-                  size_t frame_stride, size_t nobs_offset, size_t obsbegin_offset) {
+                  size_t frame_stride, size_t nobs_offset, size_t obsbegin_offset,
+                  const int* __restrict__ cam_first, int n_cams) {
   __shared__ int s_wsum[4];
   __shared__ int s_base;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,6 +77,13 @@ k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ poin
       // bit 0: the point was tracked at less than close_depth (the stereo chi2 gate of the visual-inertial
       // PoseOptimization, Optimizer.h:406-490 / mTrackDepth)
       o.flags = point_depth ? (point_depth[(size_t)f * p_cap + m[i]] < close_depth ? 1 : 0) : 0;
+      if (cam_first) {  // bits 8..11: the key's camera (mapn2in_, Optimizer.h:424-426)
+        const int* cf = cam_first + (size_t)f * (n_cams + 1);
+        int c = 0;
+        for (int t = 1; t < n_cams; t++)
+          if (i >= cf[t]) c = t;
+        o.flags |= c << 8;
+      }
       obs[(size_t)f * key_cap + pos] = o;
       obs_key[(size_t)f * key_cap + pos] = i;
     }
@@ -134,7 +149,19 @@ int vieo_track_merge_assign_batch_device(const int32_t* d_assign, int32_t* d_mp_
   if (!d_assign || !d_mp_ref || !d_counts || key_cap <= 0 || n_frames <= 0) return VIEO_E_INVALID;
   hipLaunchKernelGGL(k_track_merge_assign, dim3((key_cap + 255) / 256, n_frames), dim3(256), 0,
                      (hipStream_t)stream, d_assign, d_mp_ref, d_counts, key_cap, img_first, img_step,
-                     point_offset, reset);
+                     point_offset, reset, 1, (const vieo_last_frame_point*)nullptr);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_merge_assign_rig_batch_device(const int32_t* d_assign, int32_t* d_mp_ref, const int32_t* d_counts,
+                                             int key_cap, int n_frames, int img_first, int img_step, int point_offset,
+                                             int reset, int query_div, const vieo_last_frame_point* d_same_point,
+                                             void* stream) {
+  if (!d_assign || !d_mp_ref || !d_counts || key_cap <= 0 || n_frames <= 0 || query_div < 1) return VIEO_E_INVALID;
+  hipLaunchKernelGGL(k_track_merge_assign, dim3((key_cap + 255) / 256, n_frames), dim3(256), 0,
+                     (hipStream_t)stream, d_assign, d_mp_ref, d_counts, key_cap, img_first, img_step,
+                     point_offset, reset, query_div, d_same_point);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
@@ -153,7 +180,8 @@ int vieo_track_build_obs_batch_device(const int32_t* d_mp_ref, const float* d_po
   hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
                      d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
                      d_inv_sigma2, (const float*)nullptr, 0.f, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
-                     base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin));
+                     base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
+                     (const int*)nullptr, 0);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
@@ -173,7 +201,28 @@ int vieo_track_build_obs_depth_batch_device(const int32_t* d_mp_ref, const float
   hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
                      d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
                      d_inv_sigma2, d_point_depth, close_depth, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
-                     base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin));
+                     base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
+                     (const int*)nullptr, 0);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_build_obs_rig_batch_device(const int32_t* d_mp_ref, const float* d_point_xyz,
+                                          const float* d_point_depth, float close_depth, int p_cap,
+                                          const vieo_keypoint* d_keys, const float* d_uright,
+                                          const int32_t* d_counts, const int32_t* d_cam_first, int n_cams, int key_cap,
+                                          int n_frames, const float* d_inv_sigma2, vieo_pose_obs* d_obs,
+                                          int32_t* d_obs_key, void* d_frames, int frames_are_vio, void* stream) {
+  if (!d_mp_ref || !d_point_xyz || !d_keys || !d_uright || !d_counts || !d_cam_first || n_cams < 1 || n_cams > 4 ||
+      !d_inv_sigma2 || !d_obs || !d_obs_key || !d_frames || key_cap <= 0 || n_frames <= 0)
+    return VIEO_E_INVALID;
+  const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
+  const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
+                     d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, 0, 1,
+                     d_inv_sigma2, d_point_depth, close_depth, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
+                     base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
+                     d_cam_first, n_cams);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }

@@ -26,19 +26,20 @@ namespace vieo {
 
 // upload header: everything small the chain reads, one struct so that it travels with the images in one copy
 struct TrkHdr {
-  vieo_sbp_camera cam;       // Tcw_cur / Tcw_last are written by k_track_predict
+  vieo_sbp_camera cam;       // Tcw_cur / Tcw_last are written by k_track_predict / k_track_set_pose
   vieo_vio_frame f1, f2;     // base.nav / imu written by k_track_predict, n_obs / obs_begin by k_track_build_obs
+                             // (vision-only trackers use f1.base / f2.base as the vieo_pose_frames)
   vieo_navstate nav_ref, nav_last;
   vieo_imu_noise noise;
   double ti, tj, bg[3], ba[3];
   int32_t first[2];
-  int32_t npts[4];           // [0] = n_last
+  int32_t npts[4];           // [0] = n_last, [1] = n_last * n_cams (queries of the first search)
   float consts[32];          // inv_sigma2[16], scale[16]
 };
 
 // download header
 struct TrkOut {
-  int32_t cnt[4];            // extractor counts: {n_left, mono_left, n_right, mono_right}
+  int32_t cnt[8];            // extractor counts per image: {n, mono}
   int32_t nm[4];             // [0] matches of the first search, [1] of the second
   int32_t nq[4];
   int32_t preint_status[4];
@@ -47,6 +48,9 @@ struct TrkOut {
   vieo_imu_preint imu;
   double sigma_prv[81];
   int32_t nobs2[4];          // observations of the second optimisation
+  int32_t fe_hdr[8];         // rig: header of the stereo stage (groups, matches, threshold, status, ...)
+  int32_t cam_first[8];      // rig: first key of every camera in mvKeys, [n_cams] = N
+  int32_t fcnt[2];           // rig: {N, 0}
 };
 
 // PredictNavStateByIMU (Tracking.cc:385-451) from the pre-integration in HBM; fills the two optimiser problems and
@@ -120,6 +124,32 @@ k_track_predict(TrkHdr* __restrict__ H, TrkOut* __restrict__ O, const vieo_imu_p
   for (int i = lane; i < 81; i += 64) O->sigma_prv[i] = sigma_prv[i];
 }
 
+// The vision-only tracker's prediction comes from the host (mVelocity * mLastFrame.Tcw, Tracking.cc:1852): the two
+// optimiser problems start from it, the projection search gets Tcw of it and of the last frame.
+__global__ void __launch_bounds__(64)
+k_track_set_pose(TrkHdr* __restrict__ H, TrkOut* __restrict__ O) {
+  const int lane = threadIdx.x;
+  if (lane < 2) {
+    const vieo_navstate& n = lane == 0 ? H->nav_ref : H->nav_last;
+    const Qd q{n.q[0], n.q[1], n.q[2], n.q[3]};
+    double Rwb[9];
+    q_to_R(q, Rwb);
+    const double* Rcb = H->f1.base.Rcb;
+    double* T = lane == 0 ? H->cam.Tcw_cur : H->cam.Tcw_last;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++)
+        T[r * 4 + c] = Rcb[r * 3] * Rwb[c * 3] + Rcb[r * 3 + 1] * Rwb[c * 3 + 1] + Rcb[r * 3 + 2] * Rwb[c * 3 + 2];
+      T[r * 4 + 3] = H->f1.base.tcb[r] - (T[r * 4] * n.p[0] + T[r * 4 + 1] * n.p[1] + T[r * 4 + 2] * n.p[2]);
+    }
+  }
+  const double* sn = (const double*)&H->nav_ref;
+  for (int i = lane; i < (int)(sizeof(vieo_navstate) / 8); i += 64) {
+    ((double*)&H->f1.base.nav)[i] = sn[i], ((double*)&H->f2.base.nav)[i] = sn[i];
+    ((double*)&O->nav_pred)[i] = sn[i];
+  }
+  if (lane == 0) O->preint_status[0] = 0;
+}
+
 // per-key outlier flags of the second optimisation (mvbOutlier), and its observation count for the host
 __global__ void __launch_bounds__(256)
 k_track_finish(const int32_t* __restrict__ obs_key, const uint8_t* __restrict__ outl, const vieo_vio_frame* __restrict__ f2,
@@ -138,27 +168,35 @@ using namespace vieo;
 
 struct vieo_tracker {
   vieo_tracker_params P;
+  vieo_tracker_rig R;
+  bool rig = false, vision = false;
+  int n_img = 2;     // images per frame
+  int nc = 1;        // cameras the searches loop over (1: the rectified pair's left camera)
+  int kc = 0;        // key capacity of a frame: cap, or n_cams * cap of a rig (mvKeys)
   vieo_orb* ext = nullptr;
+  vieo_fisheye* fe = nullptr;
   hipStream_t st = nullptr, st_imu = nullptr;
   hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
-  int cap = 0, ccap = 0, pcap = 0, imu_cap = 512;
+  int cap = 0, ccap = 0, pcap = 0, gcap = 0, imu_cap = 512;
   int local_version = -1, n_local_dev = 0;
   float scale[16], inv_sigma2[16];
   vieo_camera pin_cam;
   vieo_frustum_frame ff;
+  float bounds[4][4];
   // pinned blocks and their device twins (same layout)
   uint8_t *h_up = nullptr, *d_up = nullptr;      // per-frame upload
   uint8_t *h_loc = nullptr, *d_loc = nullptr;    // local-map candidates (uploaded when they change)
   uint8_t *h_out = nullptr, *d_out = nullptr;    // download
   uint8_t* d_work = nullptr;                     // device-only scratch
+  uint8_t* d_const = nullptr;                    // rig: vieo_sbp_rig | vieo_camera[4]
   // offsets in the upload block
   size_t o_hdr, o_imu, o_img, o_pts, o_xyz, o_dep, o_alias, up_fixed;
   // offsets in the local block
   size_t l_cpt, l_cdesc, l_xyz;
   // offsets in the download block
-  size_t q_hdr, q_ur, q_dp, q_mpref, q_outl, q_kp, q_desc, q_cdep, out_bytes;
+  size_t q_hdr, q_ur, q_dp, q_mpref, q_outl, q_kg, q_gidx, q_good, q_p3d, q_small_end, q_kp, q_desc, q_cdep, out_bytes;
   // offsets in the work block
-  size_t w_kp, w_desc, w_q1, w_q2, w_assign, w_taken, w_held, w_obs, w_obskey, w_outl, w_xyz, w_dep, w_pre, w_prv, w_pst;
+  size_t w_kp, w_desc, w_kcat, w_dcat, w_q1, w_q2, w_assign, w_taken, w_held, w_obs, w_obskey, w_outl, w_xyz, w_dep, w_pre, w_prv, w_pst;
 };
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -173,31 +211,53 @@ void vieo_tracker_destroy(vieo_tracker* t) {
     if (e) (void)hipEventDestroy(e);
   for (uint8_t* p : {t->h_up, t->h_loc, t->h_out})
     if (p) (void)hipHostFree(p);
-  for (uint8_t* p : {t->d_up, t->d_loc, t->d_out, t->d_work})
+  for (uint8_t* p : {t->d_up, t->d_loc, t->d_out, t->d_work, t->d_const})
     if (p) (void)hipFree(p);
+  if (t->fe) vieo_fisheye_destroy(t->fe);
   if (t->ext) vieo_orb_destroy(t->ext);
   delete t;
 }
 
-int vieo_tracker_create(vieo_tracker** out, const vieo_tracker_params* P) {
+int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, const vieo_tracker_rig* R) {
   if (!out || !P || P->width <= 0 || P->height <= 0 || P->n_levels < 1 || P->n_levels > 16 || P->max_local_points < 0)
     return VIEO_E_INVALID;
+  if (R && (R->n_cams < 2 || R->n_cams > 4 || P->vision_only)) {
+    set_error("vieo_tracker_create_rig: %d cameras (2..4), visual-inertial", R->n_cams);
+    return VIEO_E_INVALID;
+  }
   int rc = require_device();
   if (rc != VIEO_OK) return rc;
   vieo_tracker* t = new vieo_tracker();
   t->P = *P;
+  t->rig = R != nullptr, t->vision = P->vision_only != 0;
+  if (R) t->R = *R;
+  t->n_img = R ? R->n_cams : 2, t->nc = R ? R->n_cams : 1;
   if ((rc = vieo_orb_create(&t->ext, P->n_features, P->scale_factor, P->n_levels, P->ini_th_fast, P->min_th_fast)) != VIEO_OK) {
     delete t;
     return rc;
   }
   t->st = (hipStream_t)vieo_orb_stream(t->ext);
   t->cap = vieo_orb_max_keypoints(t->ext);
+  t->kc = t->nc * t->cap;
   t->ccap = std::max(P->max_local_points, 64);
-  t->pcap = t->cap + t->ccap;
+  t->pcap = t->kc + t->ccap;
   vieo_orb_scale_factors(t->ext, t->scale);
   vieo_orb_inv_level_sigma2(t->ext, t->inv_sigma2);
+  if (R) {
+    float sig2[16];
+    vieo_orb_level_sigma2(t->ext, sig2);
+    vieo_fisheye_params fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.n_cams = R->n_cams, fp.n_levels = P->n_levels, fp.bf = P->bf, fp.th_far_pts = R->th_far_pts;
+    fp.cams = R->cams, fp.Trc = &R->Trc[0][0], fp.Tcr = &R->Tcr[0][0], fp.level_sigma2 = sig2;
+    if ((rc = vieo_fisheye_create(&t->fe, &fp, t->cap, 1)) != VIEO_OK) {
+      vieo_tracker_destroy(t);
+      return rc;
+    }
+    t->gcap = vieo_fisheye_group_capacity(t->fe);
+  }
   const size_t npx = (size_t)P->width * P->height;
-  const int cap = t->cap, ccap = t->ccap;
+  const int cap = t->cap, ccap = t->ccap, kc = t->kc, nc = t->nc;
   size_t o = 0;
   auto take = [&](size_t bytes) {
     const size_t r = o;
@@ -205,9 +265,9 @@ int vieo_tracker_create(vieo_tracker** out, const vieo_tracker_params* P) {
     return r;
   };
   // ---- upload block: [header | IMU samples | images | last points | their xyz | their depth | alias]
-  t->o_hdr = take(sizeof(TrkHdr)), t->o_imu = take((size_t)t->imu_cap * sizeof(vieo_imu_sample)), t->o_img = take(2 * npx);
-  t->o_pts = take((size_t)cap * sizeof(vieo_last_frame_point));
-  t->o_xyz = take((size_t)cap * 12), t->o_dep = take((size_t)cap * 4), t->o_alias = take((size_t)ccap * 4);
+  t->o_hdr = take(sizeof(TrkHdr)), t->o_imu = take((size_t)t->imu_cap * sizeof(vieo_imu_sample)), t->o_img = take(t->n_img * npx);
+  t->o_pts = take((size_t)kc * sizeof(vieo_last_frame_point));
+  t->o_xyz = take((size_t)kc * 12), t->o_dep = take((size_t)kc * 4), t->o_alias = take((size_t)ccap * 4);
   t->up_fixed = t->o_alias;
   const size_t up_bytes = o;
   o = 0;
@@ -215,22 +275,32 @@ int vieo_tracker_create(vieo_tracker** out, const vieo_tracker_params* P) {
   const size_t loc_bytes = o;
   o = 0;
   t->q_hdr = take(sizeof(TrkOut));
-  t->q_ur = take((size_t)cap * 4), t->q_dp = take((size_t)cap * 4), t->q_mpref = take((size_t)cap * 4), t->q_outl = take(cap);
-  t->q_kp = take((size_t)cap * sizeof(vieo_keypoint)), t->q_desc = take((size_t)cap * 32), t->q_cdep = take((size_t)ccap * 4);
+  t->q_ur = take((size_t)kc * 4), t->q_dp = take((size_t)kc * 4), t->q_mpref = take((size_t)kc * 4), t->q_outl = take(kc);
+  t->q_kg = t->q_gidx = t->q_good = t->q_p3d = o;
+  if (R) {
+    t->q_kg = take((size_t)kc * 4), t->q_gidx = take((size_t)t->gcap * nc * 4), t->q_good = take(t->gcap);
+    t->q_p3d = take((size_t)t->gcap * 24);
+  }
+  t->q_small_end = o;
+  t->q_kp = take((size_t)kc * sizeof(vieo_keypoint)), t->q_desc = take((size_t)kc * 32), t->q_cdep = take((size_t)ccap * 4);
   t->out_bytes = o;
   o = 0;
-  t->w_kp = take((size_t)2 * cap * sizeof(vieo_keypoint)), t->w_desc = take((size_t)2 * cap * 32);
-  t->w_q1 = take((size_t)cap * sizeof(vieo_proj_query)), t->w_q2 = take((size_t)ccap * sizeof(vieo_proj_query));
-  t->w_assign = take((size_t)cap * 4), t->w_taken = take(cap), t->w_held = take(t->pcap);
-  t->w_obs = take((size_t)cap * sizeof(vieo_pose_obs)), t->w_obskey = take((size_t)cap * 4), t->w_outl = take(cap);
+  t->w_kp = take((size_t)t->n_img * cap * sizeof(vieo_keypoint)), t->w_desc = take((size_t)t->n_img * cap * 32);
+  t->w_kcat = t->w_kp, t->w_dcat = t->w_desc;
+  if (R) t->w_kcat = take((size_t)kc * sizeof(vieo_keypoint)), t->w_dcat = take((size_t)kc * 32);
+  t->w_q1 = take((size_t)kc * nc * sizeof(vieo_proj_query)), t->w_q2 = take((size_t)ccap * nc * sizeof(vieo_proj_query));
+  t->w_assign = take((size_t)kc * 4), t->w_taken = take(kc), t->w_held = take(t->pcap);
+  t->w_obs = take((size_t)kc * sizeof(vieo_pose_obs)), t->w_obskey = take((size_t)kc * 4), t->w_outl = take(kc);
   t->w_xyz = take((size_t)t->pcap * 12), t->w_dep = take((size_t)t->pcap * 4);
   t->w_pre = take(sizeof(vieo_imu_preint)), t->w_prv = take(81 * 8), t->w_pst = take(16);
   const size_t work_bytes = o;
+  const size_t const_bytes = al256(sizeof(vieo_sbp_rig)) + al256(sizeof(vieo_camera) * 4);
   bool ok = hipHostMalloc((void**)&t->h_up, up_bytes, hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&t->h_loc, loc_bytes, hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&t->h_out, t->out_bytes, hipHostMallocDefault) == hipSuccess &&
             hipMalloc((void**)&t->d_up, up_bytes) == hipSuccess && hipMalloc((void**)&t->d_loc, loc_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_out, t->out_bytes) == hipSuccess && hipMalloc((void**)&t->d_work, work_bytes) == hipSuccess &&
+            hipMalloc((void**)&t->d_const, const_bytes) == hipSuccess &&
             hipStreamCreateWithFlags(&t->st_imu, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_up, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_imu, hipEventDisableTiming) == hipSuccess &&
@@ -245,14 +315,20 @@ int vieo_tracker_create(vieo_tracker** out, const vieo_tracker_params* P) {
   (void)hipMemsetAsync(t->d_out, 0, t->out_bytes, t->st);
   // constant parts of the header
   TrkHdr& H = *(TrkHdr*)(t->h_up + t->o_hdr);
-  H.cam.fx = P->fx, H.cam.fy = P->fy, H.cam.cx = P->cx, H.cam.cy = P->cy;
+  const vieo_camera* c0 = R ? &R->cams[0] : nullptr;
+  const float fx = c0 ? c0->fx : P->fx, fy = c0 ? c0->fy : P->fy, cx = c0 ? c0->cx : P->cx, cy = c0 ? c0->cy : P->cy;
+  H.cam.fx = fx, H.cam.fy = fy, H.cam.cx = cx, H.cam.cy = cy;
   H.cam.bounds[0] = 0, H.cam.bounds[1] = (float)P->width, H.cam.bounds[2] = 0, H.cam.bounds[3] = (float)P->height;
-  H.cam.bf = P->bf, H.cam.baseline = P->baseline, H.cam.th = P->th_last, H.cam.th_far = 0;
+  H.cam.bf = P->bf, H.cam.baseline = P->baseline, H.cam.th = P->th_last, H.cam.th_far = R ? R->th_far_pts : 0;
   H.cam.mono = 0, H.cam.nlevels = P->n_levels;
   for (int l = 0; l < P->n_levels; l++) H.cam.scale[l] = t->scale[l], H.consts[l] = t->inv_sigma2[l], H.consts[16 + l] = t->scale[l];
+  for (int c = 0; c < 4; c++)
+    t->bounds[c][0] = 0, t->bounds[c][1] = (float)P->width, t->bounds[c][2] = 0, t->bounds[c][3] = (float)P->height;
+  vieo_camera* d_cams = (vieo_camera*)(t->d_const + al256(sizeof(vieo_sbp_rig)));
   for (vieo_vio_frame* f : {&H.f1, &H.f2}) {
     memcpy(f->base.Rcb, P->Rcb, 72), memcpy(f->base.tcb, P->tcb, 24);
-    f->base.fx = P->fx, f->base.fy = P->fy, f->base.cx = P->cx, f->base.cy = P->cy, f->base.bf = P->bf;
+    f->base.fx = fx, f->base.fy = fy, f->base.cx = cx, f->base.cy = cy, f->base.bf = P->bf;
+    if (R) f->base.n_cams = R->n_cams, f->base.cams = d_cams;
     memcpy(f->gw, P->gw, 24);
     f->inv_sigma_bg2 = P->inv_sigma_bg2, f->inv_sigma_ba2 = P->inv_sigma_ba2, f->th_depth = P->th_depth;
   }
@@ -263,17 +339,45 @@ int vieo_tracker_create(vieo_tracker** out, const vieo_tracker_params* P) {
   memset(&t->ff, 0, sizeof(t->ff));
   t->ff.n_cams = 1, t->ff.use_distort = 0, t->ff.cams = &t->pin_cam;
   t->ff.Tcr[0][0] = t->ff.Tcr[0][5] = t->ff.Tcr[0][10] = 1.f;
-  t->ff.bounds[0][0] = 0, t->ff.bounds[0][1] = (float)P->width, t->ff.bounds[0][2] = 0, t->ff.bounds[0][3] = (float)P->height;
+  for (int c = 0; c < 4; c++) memcpy(t->ff.bounds[c], t->bounds[c], 16);
   t->ff.bf = P->bf, t->ff.n_levels = P->n_levels, t->ff.viewing_cos_limit = 0.5f;
   t->ff.log_scale_factor = logf(P->scale_factor);
+  if (R) {
+    // the searches' rig (Tcr / trc cast to double as mpCameras[c]->GetTcr().cast<double>()) and the cameras, once
+    vieo_sbp_rig sr;
+    memset(&sr, 0, sizeof(sr));
+    sr.n_cams = R->n_cams, sr.use_distort = 1;
+    t->ff.n_cams = R->n_cams, t->ff.use_distort = 1, t->ff.cams = t->R.cams;
+    for (int c = 0; c < R->n_cams; c++) {
+      sr.cams[c] = R->cams[c];
+      memcpy(sr.Tcr[c], R->Tcr[c], 96);
+      for (int r = 0; r < 3; r++) sr.trc[c][r] = R->Trc[c][r * 4 + 3], t->ff.trc[c][r] = (float)R->Trc[c][r * 4 + 3];
+      for (int i = 0; i < 12; i++) t->ff.Tcr[c][i] = (float)R->Tcr[c][i];
+      memcpy(sr.bounds[c], t->bounds[c], 16);
+    }
+    if (hipMemcpy(t->d_const, &sr, sizeof(sr), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_cams, R->cams, sizeof(vieo_camera) * R->n_cams, hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("vieo_tracker_create: constant upload failed");
+      vieo_tracker_destroy(t);
+      return VIEO_E_HIP;
+    }
+  }
   *out = t;
   return VIEO_OK;
 }
+
+int vieo_tracker_create(vieo_tracker** out, const vieo_tracker_params* P) { return vieo_tracker_create_rig(out, P, nullptr); }
 
 int vieo_tracker_image_buffers(vieo_tracker* t, uint8_t** left, uint8_t** right) {
   if (!t || !left || !right) return VIEO_E_INVALID;
   *left = t->h_up + t->o_img;
   *right = *left + (size_t)t->P.width * t->P.height;
+  return VIEO_OK;
+}
+
+int vieo_tracker_image_buffer(vieo_tracker* t, int image_index, uint8_t** plane) {
+  if (!t || !plane || image_index < 0 || image_index >= t->n_img) return VIEO_E_INVALID;
+  *plane = t->h_up + t->o_img + (size_t)image_index * t->P.width * t->P.height;
   return VIEO_OK;
 }
 
@@ -283,24 +387,28 @@ int vieo_tracker_scale_factors(const vieo_tracker* t, float* h_out) {
   return VIEO_OK;
 }
 
+int vieo_tracker_key_capacity(const vieo_tracker* t) { return t ? t->kc : 0; }
+int vieo_tracker_group_capacity(const vieo_tracker* t) { return t ? t->gcap : 0; }
+
 int vieo_tracker_get_level(vieo_tracker* t, int image_index, int level, int with_border, uint8_t* h_dst, int dst_stride) {
   if (!t) return VIEO_E_INVALID;
   return vieo_orb_get_level(t->ext, image_index, level, with_border, h_dst, dst_stride);
 }
 
 // the part of the chain behind the prediction: both searches and both optimisations
-static int track_chain_tail(vieo_tracker* t, int nc) {
+static int track_chain_tail(vieo_tracker* t, int nc_local) {
   const vieo_tracker_params& P = t->P;
-  const int cap = t->cap;
+  const int kc = t->kc, nc = t->nc;
   hipStream_t st = t->st;
   TrkHdr* dH = (TrkHdr*)(t->d_up + t->o_hdr);
   TrkOut* dO = (TrkOut*)(t->d_out + t->q_hdr);
   uint8_t* W = t->d_work;
-  vieo_keypoint* d_kp = (vieo_keypoint*)(W + t->w_kp);
-  uint8_t* d_desc = W + t->w_desc;
+  const vieo_keypoint* d_kp = (const vieo_keypoint*)(W + t->w_kcat);  // mvKeys of the frame
+  const uint8_t* d_desc = W + t->w_dcat;
   float* d_ur = (float*)(t->d_out + t->q_ur);
   int32_t* d_mpref = (int32_t*)(t->d_out + t->q_mpref);
-  int32_t* d_cnt = dO->cnt;
+  // the frame's key count in the {n, -} layout the glue reads: the left image's counts / the rig's {N, 0}
+  const int32_t* d_cnt = t->rig ? dO->fcnt : dO->cnt;
   vieo_proj_query* d_q1 = (vieo_proj_query*)(W + t->w_q1);
   vieo_proj_query* d_q2 = (vieo_proj_query*)(W + t->w_q2);
   int32_t* d_assign = (int32_t*)(W + t->w_assign);
@@ -311,52 +419,96 @@ static int track_chain_tail(vieo_tracker* t, int nc) {
   uint8_t* d_outl = W + t->w_outl;
   float* d_xyz = (float*)(W + t->w_xyz);
   float* d_dep = (float*)(W + t->w_dep);
-  const float bounds[4] = {0.f, (float)P.width, 0.f, (float)P.height};
+  const vieo_sbp_rig* d_rig = (const vieo_sbp_rig*)t->d_const;
   const float close = std::max(10.0f, P.th_depth);
+  const int vio = t->vision ? 0 : 1;
+  void* f1 = t->vision ? (void*)&dH->f1.base : (void*)&dH->f1;
+  void* f2 = t->vision ? (void*)&dH->f2.base : (void*)&dH->f2;
+  void* r1 = t->vision ? (void*)&dO->r1.base : (void*)&dO->r1;
   int rc;
 #define TRK(call)                       \
   do {                                  \
     if ((rc = (call)) != VIEO_OK) return rc; \
   } while (0)
-  TRK(vieo_sbp_project_last_frame_batch_device((const vieo_last_frame_point*)(t->d_up + t->o_pts), dH->npts, cap, 1, &dH->cam, d_q1, st));
-  TRK(vieo_search_by_projection_batch_device(VIEO_SBP_LAST_FRAME, d_q1, dH->npts, cap, 1, d_kp, d_ur, d_desc, nullptr, d_cnt, cap, 0, 2,
-                                             bounds, P.nn_last, 1, d_assign, dO->nm, st));
-  TRK(vieo_track_merge_assign_batch_device(d_assign, d_mpref, d_cnt, cap, 1, 0, 2, 0, 1, st));
-  TRK(vieo_track_build_obs_depth_batch_device(d_mpref, d_xyz, d_dep, close, t->pcap, d_kp, d_ur, d_cnt, cap, 1, 0, 2, dH->consts,
-                                              d_obs, d_obskey, &dH->f1, 1, st));
-  TRK(vieo_pose_optimization_vio_batch_device_ex(&dH->f1, 1, d_obs, d_outl, &dO->r1, VIEO_POSE_CAMS_RECTIFIED, VIEO_POSE_ENC_NONE, st));
-  TRK(vieo_track_after_pose_batch_device(d_mpref, d_obskey, d_outl, &dH->f1, &dO->r1, 1, cap, 1, &dH->f2, d_taken, st));
-  TRK(vieo_track_mark_held_batch_device(d_mpref, d_cnt, cap, 1, 0, 2, d_held, t->pcap, st));
-  TRK(vieo_track_local_queries_device(&t->ff, &dH->f1, &dO->r1, (const vieo_frustum_point*)(t->d_loc + t->l_cpt), t->d_loc + t->l_cdesc,
-                                      (const int32_t*)(t->d_up + t->o_alias), d_held, t->pcap, nc, P.th_local, 0.f, dH->consts + 16, d_q2,
-                                      d_dep + cap, dO->nq, st));
-  TRK(vieo_search_by_projection_batch_device(VIEO_SBP_LOCAL_MAP, d_q2, dO->nq, t->ccap, 1, d_kp, d_ur, d_desc, d_taken, d_cnt, cap, 0, 2,
-                                             bounds, P.nn_local, 1, d_assign, dO->nm + 1, st));
-  TRK(vieo_track_merge_assign_batch_device(d_assign, d_mpref, d_cnt, cap, 1, 0, 2, cap, 0, st));
-  TRK(vieo_track_build_obs_depth_batch_device(d_mpref, d_xyz, d_dep, close, t->pcap, d_kp, d_ur, d_cnt, cap, 1, 0, 2, dH->consts,
-                                              d_obs, d_obskey, &dH->f2, 1, st));
-  TRK(vieo_pose_optimization_vio_batch_device_ex(&dH->f2, 1, d_obs, d_outl, &dO->r2, VIEO_POSE_CAMS_RECTIFIED, VIEO_POSE_ENC_NONE, st));
+  auto search = [&](int mode, const vieo_proj_query* q, const int32_t* d_nq, int q_cap, const uint8_t* taken, float nn, int32_t* d_nm) {
+    if (t->rig)
+      return vieo_search_by_projection_rig_batch_device(mode, q, d_nq, q_cap, 1, d_kp, d_ur, d_desc, taken, dO->cam_first, kc,
+                                                        &t->bounds[0][0], nc, nn, 1, d_assign, d_nm, st);
+    return vieo_search_by_projection_batch_device(mode, q, d_nq, q_cap, 1, d_kp, d_ur, d_desc, taken, d_cnt, kc, 0, 2,
+                                                  t->bounds[0], nn, 1, d_assign, d_nm, st);
+  };
+  auto build_obs = [&](void* frame) {
+    if (t->rig)
+      return vieo_track_build_obs_rig_batch_device(d_mpref, d_xyz, d_dep, close, t->pcap, d_kp, d_ur, d_cnt, dO->cam_first, nc, kc,
+                                                   1, dH->consts, d_obs, d_obskey, frame, vio, st);
+    if (t->vision)  // (the vision-only optimisation has no close-point gate)
+      return vieo_track_build_obs_batch_device(d_mpref, d_xyz, t->pcap, d_kp, d_ur, d_cnt, kc, 1, 0, 2, dH->consts, d_obs, d_obskey,
+                                               frame, 0, st);
+    return vieo_track_build_obs_depth_batch_device(d_mpref, d_xyz, d_dep, close, t->pcap, d_kp, d_ur, d_cnt, kc, 1, 0, 2, dH->consts,
+                                                   d_obs, d_obskey, frame, 1, st);
+  };
+  auto pose = [&](void* frame, void* result) {
+    if (t->vision)
+      return vieo_pose_optimization_batch_device_ex((const vieo_pose_frame*)frame, 1, d_obs, d_outl, (vieo_pose_result*)result,
+                                                    VIEO_POSE_CAMS_RECTIFIED, st);
+    return vieo_pose_optimization_vio_batch_device_ex((const vieo_vio_frame*)frame, 1, d_obs, d_outl, (vieo_vio_result*)result,
+                                                      t->rig ? VIEO_POSE_CAMS_RIG : VIEO_POSE_CAMS_RECTIFIED, VIEO_POSE_ENC_NONE, st);
+  };
+  if (t->rig)
+    TRK(vieo_sbp_project_last_frame_rig_batch_device((const vieo_last_frame_point*)(t->d_up + t->o_pts), dH->npts, kc, 1, &dH->cam,
+                                                     d_rig, nc, d_q1, st));
+  else
+    TRK(vieo_sbp_project_last_frame_batch_device((const vieo_last_frame_point*)(t->d_up + t->o_pts), dH->npts, kc, 1, &dH->cam, d_q1, st));
+  TRK(search(VIEO_SBP_LAST_FRAME, d_q1, dH->npts + 1, kc * nc, nullptr, P.nn_last, dO->nm));
+  TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, 0, 1, nc,
+                                               t->rig ? (const vieo_last_frame_point*)(t->d_up + t->o_pts) : nullptr, st));
+  TRK(build_obs(f1));
+  TRK(pose(f1, r1));
+  TRK(vieo_track_after_pose_batch_device(d_mpref, d_obskey, d_outl, f1, r1, vio, kc, 1, f2, d_taken, st));
+  TRK(vieo_track_mark_held_batch_device(d_mpref, d_cnt, kc, 1, 0, 2, d_held, t->pcap, st));
+  // (the kernel reads only the leading vieo_pose_frame / vieo_pose_result of its two arguments)
+  TRK(vieo_track_local_queries_device(&t->ff, (const vieo_vio_frame*)f1, (const vieo_vio_result*)r1,
+                                      (const vieo_frustum_point*)(t->d_loc + t->l_cpt), t->d_loc + t->l_cdesc,
+                                      (const int32_t*)(t->d_up + t->o_alias), d_held, t->pcap, nc_local, P.th_local,
+                                      t->rig ? t->R.th_far_pts : 0.f, dH->consts + 16, d_q2, d_dep + kc, dO->nq, st));
+  TRK(search(VIEO_SBP_LOCAL_MAP, d_q2, dO->nq, t->ccap * nc, d_taken, P.nn_local, dO->nm + 1));
+  TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, kc, 0, nc, nullptr, st));
+  TRK(build_obs(f2));
+  TRK(pose(f2, t->vision ? (void*)&dO->r2.base : (void*)&dO->r2));
 #undef TRK
-  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(256), 0, st, d_obskey, d_outl, &dH->f2, t->d_out + t->q_outl, cap, dO);
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(256), 0, st, d_obskey, d_outl, &dH->f2, t->d_out + t->q_outl, kc, dO);
   VIEO_HIP_CHECK(hipGetLastError());
-  // results: [header | uright | depth | point_ref | outlier] and the candidates' depths (the left keys / descriptors are
-  // copied by the caller, once)
-  VIEO_HIP_CHECK(hipMemcpyAsync(t->h_out, t->d_out, t->q_kp, hipMemcpyDeviceToHost, st));
-  if (nc > 0) VIEO_HIP_CHECK(hipMemcpyAsync(t->h_out + t->q_cdep, d_dep + cap, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
+  // results: [header | uright | depth | point_ref | outlier | (rig: key -> group, the groups)] and the candidates' depths
+  // (the keys / descriptors are copied by the caller, once)
+  VIEO_HIP_CHECK(hipMemcpyAsync(t->h_out, t->d_out, t->q_small_end, hipMemcpyDeviceToHost, st));
+  if (nc_local > 0) VIEO_HIP_CHECK(hipMemcpyAsync(t->h_out + t->q_cdep, d_dep + kc, (size_t)nc_local * 4, hipMemcpyDeviceToHost, st));
   return VIEO_OK;
 }
 
+// an error in the middle of the chain: work queued on the two streams still reads the pinned blocks, which the next
+// call would overwrite -- wait for it before handing the error back
+static int track_fail(vieo_tracker* t, int rc) {
+  (void)hipStreamSynchronize(t->st_imu);
+  (void)hipStreamSynchronize(t->st);
+  return rc;
+}
+
 int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_output* out) {
-  if (!t || !in || !out || !in->left || !in->right || in->stride < t->P.width || in->n_imu < 0 || (in->n_imu > 0 && !in->imu) ||
+  if (!t || !in || !out || in->stride < t->P.width || in->n_imu < 0 || (in->n_imu > 0 && !in->imu) ||
       in->n_last < 0 || (in->n_last > 0 && (!in->last_points || !in->last_track_depth)) || in->n_local < 0 ||
       (in->n_local > 0 && !in->local_alias))
     return VIEO_E_INVALID;
+  const uint8_t* imgs[4] = {in->left, in->right, nullptr, nullptr};
+  if (t->rig)
+    for (int c = 0; c < 4; c++) imgs[c] = in->images[c];
+  for (int c = 0; c < t->n_img; c++)
+    if (!imgs[c]) return VIEO_E_INVALID;
   const auto t_enter = std::chrono::steady_clock::now();
   const vieo_tracker_params& P = t->P;
-  const int cap = t->cap, W = P.width, Hh = P.height;
-  if (in->n_last > cap || in->n_local > t->ccap || in->n_imu > t->imu_cap) {
+  const int cap = t->cap, kc = t->kc, W = P.width, Hh = P.height;
+  if (in->n_last > kc || in->n_local > t->ccap || in->n_imu > t->imu_cap) {
     set_error("vieo_track_frame: %d last-frame points / %d local points / %d IMU samples exceed the capacities %d / %d / %d",
-              in->n_last, in->n_local, in->n_imu, cap, t->ccap, t->imu_cap);
+              in->n_last, in->n_local, in->n_imu, kc, t->ccap, t->imu_cap);
     return VIEO_E_CAPACITY;
   }
   int rc = require_device();
@@ -378,11 +530,11 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   H.ti = in->t_ref, H.tj = in->t_cur;
   for (int k = 0; k < 3; k++) H.bg[k] = in->nav_ref.bg[k], H.ba[k] = in->nav_ref.ba[k];
   H.first[0] = 0, H.first[1] = in->n_imu;
-  H.npts[0] = nl;
+  H.npts[0] = nl, H.npts[1] = nl * t->nc;
   if (in->n_imu) memcpy(t->h_up + t->o_imu, in->imu, (size_t)in->n_imu * sizeof(vieo_imu_sample));
   uint8_t* img = t->h_up + t->o_img;
-  for (int c = 0; c < 2; c++) {
-    const uint8_t* src = c == 0 ? in->left : in->right;
+  for (int c = 0; c < t->n_img; c++) {
+    const uint8_t* src = imgs[c];
     uint8_t* dst = img + c * npx;
     if (src == dst) continue;  // decoded straight into the pinned plane
     if (in->stride == W)
@@ -413,62 +565,100 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   }
   // ---- one copy up (+ the local map when it changed), the chain, the copies back
   uint8_t* Wk = t->d_work;
-  VIEO_HIP_CHECK(hipEventRecord(t->ev_t0, st));
-  VIEO_HIP_CHECK(hipMemcpyAsync(t->d_up, t->h_up, t->up_fixed + (size_t)nc * 4, hipMemcpyHostToDevice, st));
-  VIEO_HIP_CHECK(hipEventRecord(t->ev_up, st));
+#define TRK_HIP(expr)                                                                                 \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      vieo::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));           \
+      return track_fail(t, VIEO_E_HIP);                                                               \
+    }                                                                                                 \
+  } while (0)
+  TRK_HIP(hipEventRecord(t->ev_t0, st));
+  TRK_HIP(hipMemcpyAsync(t->d_up, t->h_up, t->up_fixed + (size_t)nc * 4, hipMemcpyHostToDevice, st));
+  TRK_HIP(hipEventRecord(t->ev_up, st));
   TrkHdr* dH = (TrkHdr*)(t->d_up + t->o_hdr);
   TrkOut* dO = (TrkOut*)(t->d_out + t->q_hdr);
-  // the pre-integration beside the extraction
-  VIEO_HIP_CHECK(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
-  if ((rc = vieo_imu_preintegrate_batch_device(&dH->noise, (const vieo_imu_sample*)(t->d_up + t->o_imu), dH->first, &dH->ti, &dH->tj,
-                                               dH->bg, dH->ba, 1, (vieo_imu_preint*)(Wk + t->w_pre), (double*)(Wk + t->w_prv),
-                                               (int32_t*)(Wk + t->w_pst), t->st_imu)) != VIEO_OK)
-    return rc;
-  VIEO_HIP_CHECK(hipEventRecord(t->ev_imu, t->st_imu));
+  if (!t->vision) {
+    // the pre-integration beside the extraction
+    TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
+    if ((rc = vieo_imu_preintegrate_batch_device(&dH->noise, (const vieo_imu_sample*)(t->d_up + t->o_imu), dH->first, &dH->ti, &dH->tj,
+                                                 dH->bg, dH->ba, 1, (vieo_imu_preint*)(Wk + t->w_pre), (double*)(Wk + t->w_prv),
+                                                 (int32_t*)(Wk + t->w_pst), t->st_imu)) != VIEO_OK)
+      return track_fail(t, rc);
+    TRK_HIP(hipEventRecord(t->ev_imu, t->st_imu));
+  }
   if (new_local) {
-    VIEO_HIP_CHECK(hipMemcpyAsync(t->d_loc + t->l_cpt, t->h_loc + t->l_cpt, (size_t)nc * sizeof(vieo_frustum_point), hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(t->d_loc + t->l_cdesc, t->h_loc + t->l_cdesc, (size_t)nc * 32, hipMemcpyHostToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(Wk + t->w_xyz + (size_t)cap * 12, t->h_loc + t->l_xyz, (size_t)nc * 12, hipMemcpyHostToDevice, st));
+    TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cpt, t->h_loc + t->l_cpt, (size_t)nc * sizeof(vieo_frustum_point), hipMemcpyHostToDevice, st));
+    TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cdesc, t->h_loc + t->l_cdesc, (size_t)nc * 32, hipMemcpyHostToDevice, st));
+    TRK_HIP(hipMemcpyAsync(Wk + t->w_xyz + (size_t)kc * 12, t->h_loc + t->l_xyz, (size_t)nc * 12, hipMemcpyHostToDevice, st));
     t->local_version = in->local_version, t->n_local_dev = nc;
   }
   // the last frame's part of the two point tables
   if (nl) {
-    VIEO_HIP_CHECK(hipMemcpyAsync(Wk + t->w_xyz, t->d_up + t->o_xyz, (size_t)nl * 12, hipMemcpyDeviceToDevice, st));
-    VIEO_HIP_CHECK(hipMemcpyAsync(Wk + t->w_dep, t->d_up + t->o_dep, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
+    TRK_HIP(hipMemcpyAsync(Wk + t->w_xyz, t->d_up + t->o_xyz, (size_t)nl * 12, hipMemcpyDeviceToDevice, st));
+    TRK_HIP(hipMemcpyAsync(Wk + t->w_dep, t->d_up + t->o_dep, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
   }
   vieo_keypoint* d_kp = (vieo_keypoint*)(Wk + t->w_kp);
   uint8_t* d_desc = Wk + t->w_desc;
-  if ((rc = vieo_orb_extract_batch_device(t->ext, t->d_up + t->o_img, 2, W, Hh, W, npx, nullptr, d_kp, d_desc, cap, dO->cnt)) != VIEO_OK)
-    return rc;
-  if ((rc = vieo_stereo_match_rectified_batch_device(t->ext, 1, d_kp, d_desc, dO->cnt, cap, P.baseline, P.bf, (float*)(t->d_out + t->q_ur),
-                                                     (float*)(t->d_out + t->q_dp))) != VIEO_OK)
-    return rc;
-  VIEO_HIP_CHECK(hipStreamWaitEvent(st, t->ev_imu, 0));
-  hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(64), 0, st, dH, dO, (const vieo_imu_preint*)(Wk + t->w_pre),
-                     (const double*)(Wk + t->w_prv), (const int32_t*)(Wk + t->w_pst));
-  VIEO_HIP_CHECK(hipGetLastError());
-  if ((rc = track_chain_tail(t, nc)) != VIEO_OK) return rc;
-  // the left image's keys / descriptors (the extractor's arrays hold both images)
-  VIEO_HIP_CHECK(hipMemcpyAsync(t->h_out + t->q_kp, d_kp, (size_t)cap * sizeof(vieo_keypoint), hipMemcpyDeviceToHost, st));
-  VIEO_HIP_CHECK(hipMemcpyAsync(t->h_out + t->q_desc, d_desc, (size_t)cap * 32, hipMemcpyDeviceToHost, st));
-  VIEO_HIP_CHECK(hipEventRecord(t->ev_t1, st));
-  VIEO_HIP_CHECK(hipStreamSynchronize(st));
+  const int* lapping = t->rig && t->R.use_lapping ? t->R.lapping : nullptr;
+  if ((rc = vieo_orb_extract_batch_device(t->ext, t->d_up + t->o_img, t->n_img, W, Hh, W, npx, lapping, d_kp, d_desc, cap, dO->cnt)) != VIEO_OK)
+    return track_fail(t, rc);
+  if (t->rig) {
+    // ComputeStereoFishEyeMatches (Frame.cc:613-779) into mvKeys order: keys / descriptors in the work block, the tables in
+    // the download block
+    rc = vieo_stereo_fisheye_match_batch_device(t->fe, d_kp, d_desc, dO->cnt, 1, (vieo_keypoint*)(Wk + t->w_kcat), Wk + t->w_dcat,
+                                                dO->cam_first, dO->fcnt, (float*)(t->d_out + t->q_dp), (float*)(t->d_out + t->q_ur),
+                                                (int32_t*)(t->d_out + t->q_kg), (int32_t*)(t->d_out + t->q_gidx), t->d_out + t->q_good,
+                                                (double*)(t->d_out + t->q_p3d), dO->fe_hdr, st);
+  } else
+    rc = vieo_stereo_match_rectified_batch_device(t->ext, 1, d_kp, d_desc, dO->cnt, cap, P.baseline, P.bf, (float*)(t->d_out + t->q_ur),
+                                                  (float*)(t->d_out + t->q_dp));
+  if (rc != VIEO_OK) return track_fail(t, rc);
+  if (t->vision)
+    hipLaunchKernelGGL(k_track_set_pose, dim3(1), dim3(64), 0, st, dH, dO);
+  else {
+    TRK_HIP(hipStreamWaitEvent(st, t->ev_imu, 0));
+    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(64), 0, st, dH, dO, (const vieo_imu_preint*)(Wk + t->w_pre),
+                       (const double*)(Wk + t->w_prv), (const int32_t*)(Wk + t->w_pst));
+  }
+  TRK_HIP(hipGetLastError());
+  if ((rc = track_chain_tail(t, nc)) != VIEO_OK) return track_fail(t, rc);
+  // the frame's keys / descriptors (mvKeys / mDescriptors: the left image's, or the rig's concatenation)
+  TRK_HIP(hipMemcpyAsync(t->h_out + t->q_kp, Wk + t->w_kcat, (size_t)kc * sizeof(vieo_keypoint), hipMemcpyDeviceToHost, st));
+  TRK_HIP(hipMemcpyAsync(t->h_out + t->q_desc, Wk + t->w_dcat, (size_t)kc * 32, hipMemcpyDeviceToHost, st));
+  TRK_HIP(hipEventRecord(t->ev_t1, st));
+  TRK_HIP(hipStreamSynchronize(st));
   const TrkOut* O = (const TrkOut*)(t->h_out + t->q_hdr);
+  const bool pre_ok = t->vision || (O->preint_status[0] == 0 && O->imu.dt != 0);
   int widened = 0;
-  if (O->nm[0] < 20 && O->preint_status[0] == 0 && O->imu.dt != 0) {
-    // Tracking.cc:301-309: the wider window.  Only the search threshold changes; everything before the projection is
-    // still in HBM
+  if (O->nm[0] < 20 && pre_ok) {
+    // Tracking.cc:301-309 / :1869-1876: the wider window.  Only the search threshold changes; everything before the
+    // projection is still in HBM
     widened = 1;
     const float th2 = 2 * P.th_last;
-    VIEO_HIP_CHECK(hipMemcpyAsync(&dH->cam.th, &th2, 4, hipMemcpyHostToDevice, st));
-    if ((rc = track_chain_tail(t, nc)) != VIEO_OK) return rc;
-    VIEO_HIP_CHECK(hipEventRecord(t->ev_t1, st));
-    VIEO_HIP_CHECK(hipStreamSynchronize(st));
+    TRK_HIP(hipMemcpyAsync(&dH->cam.th, &th2, 4, hipMemcpyHostToDevice, st));
+    if ((rc = track_chain_tail(t, nc)) != VIEO_OK) return track_fail(t, rc);
+    TRK_HIP(hipEventRecord(t->ev_t1, st));
+    TRK_HIP(hipStreamSynchronize(st));
   }
+#undef TRK_HIP
   memset(out, 0, sizeof(*out));
   out->preint_status = O->preint_status[0];
-  out->status = (O->preint_status[0] != 0 || O->imu.dt == 0) ? VIEO_TRACK_PREINT_FAILED : VIEO_TRACK_OK;
-  out->n_keys = std::min(O->cnt[0], cap), out->key_cap = cap;
+  // Tracking.cc:311 (fewer than 10 matches with the IMU) / :1878 (fewer than 20 without): the reference returns before
+  // the optimisations; here they have run, their outputs are to be ignored
+  out->status = !pre_ok ? VIEO_TRACK_PREINT_FAILED : (O->nm[0] < (t->vision ? 20 : 10) ? VIEO_TRACK_LOST : VIEO_TRACK_OK);
+  if (t->rig) {
+    out->n_keys = std::min(O->cam_first[t->nc], kc);
+    for (int c = 0; c <= t->nc; c++) out->cam_first[c] = O->cam_first[c];
+    for (int c = 0; c < t->nc; c++) out->mono_index[c] = O->cnt[2 * c + 1];
+    out->stereo_status = O->fe_hdr[3], out->n_groups = O->fe_hdr[3] ? 0 : O->fe_hdr[0], out->n_stereo_matches = O->fe_hdr[1];
+    out->key_group = (const int32_t*)(t->h_out + t->q_kg), out->group_idx = (const int32_t*)(t->h_out + t->q_gidx);
+    out->group_good = t->h_out + t->q_good, out->group_p3d = (const double*)(t->h_out + t->q_p3d);
+  } else {
+    out->n_keys = std::min(O->cnt[0], cap);
+    out->cam_first[1] = out->n_keys;
+  }
+  out->key_cap = kc;
   out->keys = (const vieo_keypoint*)(t->h_out + t->q_kp), out->desc = t->h_out + t->q_desc;
   out->uright = (const float*)(t->h_out + t->q_ur), out->depth = (const float*)(t->h_out + t->q_dp);
   out->point_ref = (const int32_t*)(t->h_out + t->q_mpref), out->outlier = t->h_out + t->q_outl;

@@ -110,6 +110,7 @@ class FisheyeStereoDevice:
             bufs[name] = DeviceBuffer(max(arr.nbytes, 16))
             bufs[name].upload(arr)
         outs = dict(kcat=(KEYPOINT_DTYPE, (nf, kc)), dcat=(np.uint8, (nf, kc, 32)), first=(np.int32, (nf, nc + 1)),
+                    fcnt=(np.int32, (nf, 2)),
                     depth=(np.float32, (nf, kc)), ur=(np.float32, (nf, kc)), kg=(np.int32, (nf, kc)),
                     gidx=(np.int32, (nf, gcap, nc)), good=(np.uint8, (nf, gcap)), p3d=(np.float64, (nf, gcap, 3)),
                     hdr=(np.int32, (nf, 8)))
@@ -117,7 +118,7 @@ class FisheyeStereoDevice:
             bufs[name] = DeviceBuffer(max(int(np.prod(shp)) * np.dtype(dt).itemsize, 16))
         check(lib().vieo_stereo_fisheye_match_batch_device(
             self.h, bufs["K"].ptr, bufs["D"].ptr, bufs["C"].ptr, nf, bufs["kcat"].ptr, bufs["dcat"].ptr, bufs["first"].ptr,
-            bufs["depth"].ptr, bufs["ur"].ptr, bufs["kg"].ptr, bufs["gidx"].ptr, bufs["good"].ptr, bufs["p3d"].ptr,
+            bufs["fcnt"].ptr, bufs["depth"].ptr, bufs["ur"].ptr, bufs["kg"].ptr, bufs["gidx"].ptr, bufs["good"].ptr, bufs["p3d"].ptr,
             bufs["hdr"].ptr, None), "vieo_stereo_fisheye_match_batch_device")
         check(lib().vieo_device_synchronize(), "sync")
         got = {name: bufs[name].download(dt, shp) for name, (dt, shp) in outs.items()}

@@ -138,13 +138,17 @@ class RigFrontEnd:
         return frontend.make_sbp_camera(Tcw, Tcw_last, self.K0, self.bounds[0], self.bf, self.bf / self.K0[0], th,
                                         self.scale), Tcw
 
-    def _obs(self, fr, mp_ref, mps):
+    def _obs(self, fr, mp_ref, mps, track_depth=None, th_depth=35.0):
+        """track_depth: mTrackDepth per map point -> the close bit of the observation (bClose of the visual-inertial
+        PoseOptimization, include/Optimizer.h:561: track_depth_ < max(10, mThDepth)); None: no close bits."""
         idx = np.nonzero(mp_ref >= 0)[0]
         obs = np.zeros(len(idx), POSE_OBS_DTYPE)
         obs["Xw"] = mps["Xw"][mp_ref[idx]]
         obs["u"], obs["v"], obs["ur"] = fr.keys["x"][idx], fr.keys["y"][idx], -1.0
         obs["inv_sigma2"] = self.inv_sigma2[fr.keys["octave"][idx]]
         obs["flags"] = fr.key_cam[idx] << 8
+        if track_depth is not None:
+            obs["flags"] |= (track_depth[mp_ref[idx]] < np.float32(max(10.0, th_depth))).astype(np.int32)
         return obs, idx
 
     def _frustum(self, Tcw, mps, pose0):
@@ -166,8 +170,11 @@ class RigFrontEnd:
         return F, P
 
     # ---- Tracking::TrackWithIMU + TrackLocalMapWithIMU for one frame
-    def track(self, case, rng=None):
-        """case: synth_scene.make_rig_tracking_case.  returns dict(r1, r2, mp_ref, frame, map points)."""
+    def track(self, case, rng=None, pred=None, track_depth=None):
+        """case: synth_scene.make_rig_tracking_case.  returns dict(r1, r2, mp_ref, frame, map points).
+        pred = (NavState, IMU pre-integration record): the predicted state and the measurement of the optimiser problems
+        (default: truth + a small error, the case's own pre-integration); track_depth: mTrackDepth of the last frame's map
+        points -> close bits on the observations (default: none, also none for the local-map candidates)."""
         self.trace = []
         rng = rng or np.random.default_rng(0)
         fr0 = self.make_frame(case["images0"])
@@ -177,8 +184,13 @@ class RigFrontEnd:
         # predicted state of the current frame = truth + a small error (PredictNavStateByIMU)
         F1 = case["vio"].copy()
         b = F1[0]["base"]
-        b["nav"]["p"] += rng.normal(0, 0.01, 3)
-        b["nav"]["q"] = synth_ba.quat_mul(b["nav"]["q"], synth_ba.quat_from_rotvec(rng.normal(0, 0.003, 3)))
+        if pred is None:
+            b["nav"]["p"] += rng.normal(0, 0.01, 3)
+            b["nav"]["q"] = synth_ba.quat_mul(b["nav"]["q"], synth_ba.quat_from_rotvec(rng.normal(0, 0.003, 3)))
+        else:
+            b["nav"], F1[0]["imu"] = pred
+        th_depth = float(F1[0]["th_depth"])
+        td = None if track_depth is None else np.array(track_depth, np.float32)
         b["n_cams"], b["cams"] = self.nc, self.scene.cams.ctypes.data
         cam, Tcw = self._sbp_cam(b["nav"], frontend.pose_to_Tcw(Rwc0, twc0), self.th_last)
         pts = self.last_frame_points(fr0, mps)
@@ -188,7 +200,7 @@ class RigFrontEnd:
         mp_ref = np.full(fr1.N, -1, np.int32)
         ok = a1 >= 0
         mp_ref[ok] = mps["key_mp"][a1[ok] // self.nc]  # query (i, camj) belongs to last-frame key i
-        obs1, idx1 = self._obs(fr1, mp_ref, mps)
+        obs1, idx1 = self._obs(fr1, mp_ref, mps, td, th_depth)
         F1[0]["base"]["n_obs"] = len(obs1)
         r1, o1 = self._rec("pose_vio", dict(F=F1, obs=obs1), self.S.pose_vio(F1, obs1))
         mp_ref[idx1[o1 != 0]] = -1  # "Discard outliers" (Tracking.cc:1903-1921)
@@ -207,10 +219,13 @@ class RigFrontEnd:
                                          self.nn_local))
         ok = a2 >= 0
         mp_ref[ok] = cand[owner[a2[ok]]]
-        obs2, idx2 = self._obs(fr1, mp_ref, mps)
+        if td is not None:
+            td[cand] = info["track_depth"]  # isInFrustum sets mTrackDepth of every candidate it sees
+        obs2, idx2 = self._obs(fr1, mp_ref, mps, td, th_depth)
         F2 = F1.copy()
         F2[0]["base"]["nav"] = nav1
         F2[0]["base"]["n_obs"] = len(obs2)
         F2[0]["compute_marg"] = 1
         r2, o2 = self._rec("pose_vio", dict(F=F2, obs=obs2), self.S.pose_vio(F2, obs2))
-        return dict(r1=r1, r2=r2, o2=o2, mp_ref=mp_ref, fr0=fr0, fr1=fr1, mps=mps, n1=n1, n2=n2, obs2=obs2)
+        return dict(r1=r1, r2=r2, o2=o2, mp_ref=mp_ref, fr0=fr0, fr1=fr1, mps=mps, n1=n1, n2=n2, obs2=obs2, idx2=idx2,
+                    frustum_points=P, cand=cand)

@@ -278,6 +278,7 @@ def imu_motion(rng, pj, Rj, dt_frame):
     meas = Preintegrator()
     for k in range(n_imu):
         meas.update((gyr[k] + gyr[k + 1]) / 2 - bg, (acc[k] + acc[k + 1]) / 2 - ba, h)
+    meas.samples = (ts, np.array(gyr), np.array(acc))  # the raw samples on [0, dt_frame] (IMUData: t, w, a)
     return pi, Ri, vi, vj, bg, ba, meas
 
 

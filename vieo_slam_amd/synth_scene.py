@@ -256,5 +256,9 @@ def make_rig_tracking_case(seed, scene, dt_frame=0.05, height=(2.4, 3.0)):
     f["inv_sigma_ba2"] = 1.0 / synth_ba.IMU_SIGMA[3] ** 2
     f["dt_frames"] = dt_frame
     f["th_depth"] = 35.0
+    from .imu import IMU_SAMPLE_DTYPE
+    ts, gyr, acc = meas.samples
+    samples = np.zeros(len(ts), IMU_SAMPLE_DTYPE)
+    samples["t"], samples["w"], samples["a"] = ts, gyr, acc
     return dict(images0=im0, images1=im1, pose0=(Ri, pi, Rwc0, twc0), pose1=(Rj, pj, Rwc1, twc1), vio=F,
-                truth=dict(p=pj, q=synth_ba._R_to_quat(Rj), v=vj))
+                truth=dict(p=pj, q=synth_ba._R_to_quat(Rj), v=vj), imu_samples=samples, dt_frame=dt_frame)

@@ -11,7 +11,7 @@ from . import replay as rp
 from . import synth_ba
 from . import synth_scene as sc
 from ._lib import check, lib
-from .ba_types import IMU_PREINT_DTYPE, LAST_FRAME_POINT_DTYPE, NAVSTATE_DTYPE, VIO_RESULT_DTYPE
+from .ba_types import CAMERA_DTYPE, IMU_PREINT_DTYPE, LAST_FRAME_POINT_DTYPE, NAVSTATE_DTYPE, VIO_RESULT_DTYPE
 from .imu import IMU_NOISE_DTYPE, IMU_SAMPLE_DTYPE
 from .map_point import FRUSTUM_POINT_DTYPE
 from .orb_extractor import KEYPOINT_DTYPE
@@ -21,18 +21,24 @@ TRACKER_PARAMS_DTYPE = np.dtype([
     ("min_th_fast", "<i4"), ("scale_factor", "<f4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"),
     ("bf", "<f4"), ("baseline", "<f4"), ("th_depth", "<f4"), ("th_last", "<f4"), ("th_local", "<f4"), ("nn_last", "<f4"),
     ("nn_local", "<f4"), ("max_local_points", "<i4"), ("Rcb", "<f8", 9), ("tcb", "<f8", 3), ("gw", "<f8", 3),
-    ("inv_sigma_bg2", "<f8"), ("inv_sigma_ba2", "<f8"), ("noise", IMU_NOISE_DTYPE)], align=True)
+    ("inv_sigma_bg2", "<f8"), ("inv_sigma_ba2", "<f8"), ("noise", IMU_NOISE_DTYPE), ("vision_only", "<i4"),
+    ("reserved", "<i4")], align=True)
+TRACKER_RIG_DTYPE = np.dtype([
+    ("n_cams", "<i4"), ("use_lapping", "<i4"), ("lapping", "<i4", 2), ("th_far_pts", "<f4"), ("reserved", "<f4"),
+    ("cams", CAMERA_DTYPE, 4), ("Trc", "<f8", (4, 12)), ("Tcr", "<f8", (4, 12))], align=True)
 TRACK_INPUT_DTYPE = np.dtype([
     ("left", "<u8"), ("right", "<u8"), ("stride", "<i4"), ("n_imu", "<i4"), ("imu", "<u8"), ("t_ref", "<f8"),
     ("t_cur", "<f8"), ("nav_ref", NAVSTATE_DTYPE), ("nav_last", NAVSTATE_DTYPE), ("nav_prior", "<u8"), ("H_prior", "<u8"),
     ("n_last", "<i4"), ("last_points", "<u8"), ("last_track_depth", "<u8"), ("n_local", "<i4"), ("local_version", "<i4"),
-    ("local_points", "<u8"), ("local_desc", "<u8"), ("local_alias", "<u8")], align=True)
+    ("local_points", "<u8"), ("local_desc", "<u8"), ("local_alias", "<u8"), ("images", "<u8", 4)], align=True)
 TRACK_OUTPUT_DTYPE = np.dtype([
     ("status", "<i4"), ("n_keys", "<i4"), ("key_cap", "<i4"), ("keys", "<u8"), ("desc", "<u8"), ("uright", "<u8"),
     ("depth", "<u8"), ("point_ref", "<u8"), ("outlier", "<u8"), ("local_track_depth", "<u8"), ("n_matches_last", "<i4"),
     ("n_matches_local", "<i4"), ("widened", "<i4"), ("nav_pred", NAVSTATE_DTYPE), ("imu", IMU_PREINT_DTYPE),
     ("preint_status", "<i4"), ("reserved", "<i4"), ("first", VIO_RESULT_DTYPE), ("second", VIO_RESULT_DTYPE),
-    ("ms_gpu", "<f4"), ("ms_host", "<f4")], align=True)
+    ("ms_gpu", "<f4"), ("ms_host", "<f4"), ("cam_first", "<i4", 5), ("mono_index", "<i4", 4), ("stereo_status", "<i4"),
+    ("n_groups", "<i4"), ("n_stereo_matches", "<i4"), ("key_group", "<u8"), ("group_idx", "<u8"), ("group_good", "<u8"),
+    ("group_p3d", "<u8")], align=True)
 
 def _bind():
     return lib()  # signatures: _lib._SIGS
@@ -57,22 +63,72 @@ def euroc_params(max_local_points=16384, th_last=7.0, th_local=2.0, noise=None):
     return P
 
 
+def rig_params(scene, nfeatures, max_local_points=8192, th_last=7.0, th_local=2.0, noise=None, th_depth=35.0):
+    """(vieo_tracker_params, vieo_tracker_rig) of a synth_scene.RigScene (the configuration pipeline_rig.RigFrontEnd runs
+    stage by stage): KB8 cameras hand over their lapping area, bf = 0.11 * fx of camera 0."""
+    from . import synth_fisheye as sf
+    P = np.zeros(1, TRACKER_PARAMS_DTYPE)
+    p = P[0]
+    c0 = scene.cams[0]
+    p["width"], p["height"] = scene.W, scene.H
+    p["n_features"], p["n_levels"], p["ini_th_fast"], p["min_th_fast"], p["scale_factor"] = nfeatures, 8, 20, 7, 1.2
+    p["fx"], p["fy"], p["cx"], p["cy"] = c0["fx"], c0["fy"], c0["cx"], c0["cy"]
+    p["bf"] = 0.11 * float(c0["fx"])
+    p["baseline"] = p["bf"] / np.float32(c0["fx"])
+    p["th_depth"], p["th_last"], p["th_local"], p["nn_last"], p["nn_local"] = th_depth, th_last, th_local, 0.9, 0.8
+    p["max_local_points"] = max_local_points
+    p["Rcb"], p["tcb"] = scene.Tcb[:3, :3].reshape(-1), scene.Tcb[:3, 3]
+    p["gw"] = synth_ba.GRAVITY
+    p["inv_sigma_bg2"], p["inv_sigma_ba2"] = 1.0 / synth_ba.IMU_SIGMA[2] ** 2, 1.0 / synth_ba.IMU_SIGMA[3] ** 2
+    if noise is not None:
+        p["noise"] = noise
+    else:  # EuRoC sigmas, as replay.Sequence builds them
+        p["noise"]["sigma_g"] = (np.eye(3) * synth_ba.IMU_SIGMA[0] ** 2 * synth_ba.IMU_FREQ).reshape(-1)
+        p["noise"]["sigma_a"] = (np.eye(3) * synth_ba.IMU_SIGMA[1] ** 2 * synth_ba.IMU_FREQ).reshape(-1)
+        p["noise"]["freq_ref"], p["noise"]["dt_cov_noise_fixed"] = synth_ba.IMU_FREQ, 1
+    R = np.zeros(1, TRACKER_RIG_DTYPE)
+    r = R[0]
+    nc = len(scene.cams)
+    r["n_cams"] = nc
+    if int(c0["model"]) == 2:
+        r["use_lapping"], r["lapping"] = 1, (0, scene.W - 1)
+    r["cams"][:nc] = scene.cams
+    Trc, Tcr = sf.rig_extrinsics(scene.Tcr)
+    r["Trc"][:nc], r["Tcr"][:nc] = Trc, Tcr
+    return P, R
+
+
+def _view(ptr, dtype, count):
+    dtype = np.dtype(dtype)
+    if count == 0 or not ptr:
+        return np.zeros(0, dtype)
+    buf = (ctypes.c_uint8 * (dtype.itemsize * count)).from_address(int(ptr))
+    return np.frombuffer(buf, dtype, count)
+
+
 class Tracker:
     """vieo_tracker: one call per frame.  `track` returns the output record plus numpy views of the per-key arrays
-    (valid until the next call)."""
+    (valid until the next call).  rig: TRACKER_RIG_DTYPE[1] -> a distorted camera-rig tracker (images = one per camera);
+    params["vision_only"] = 1 -> the stereo tracker without IMU (nav_ref = the predicted state)."""
 
-    def __init__(self, params):
+    def __init__(self, params, rig=None):
         L = _bind()
         self.params = np.ascontiguousarray(params, TRACKER_PARAMS_DTYPE).reshape(1)
+        self.rig = None if rig is None else np.ascontiguousarray(rig, TRACKER_RIG_DTYPE).reshape(1)
+        self.n_img = 2 if rig is None else int(self.rig[0]["n_cams"])
         h = ctypes.c_void_p()
-        check(L.vieo_tracker_create(ctypes.byref(h), self.params.ctypes.data), "vieo_tracker_create")
+        check(L.vieo_tracker_create_rig(ctypes.byref(h), self.params.ctypes.data,
+                                        None if rig is None else self.rig.ctypes.data), "vieo_tracker_create_rig")
         self.h = h
-        a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        check(L.vieo_tracker_image_buffers(h, ctypes.byref(a), ctypes.byref(b)))
         w, hh = int(self.params[0]["width"]), int(self.params[0]["height"])
-        self.left = np.ctypeslib.as_array((ctypes.c_uint8 * (w * hh)).from_address(a.value)).reshape(hh, w)
-        self.right = np.ctypeslib.as_array((ctypes.c_uint8 * (w * hh)).from_address(b.value)).reshape(hh, w)
-        self._ptrs = (a.value, b.value)
+        self.planes, self._ptrs = [], []
+        for c in range(self.n_img):
+            a = ctypes.c_void_p()
+            check(L.vieo_tracker_image_buffer(h, c, ctypes.byref(a)))
+            self.planes.append(np.ctypeslib.as_array((ctypes.c_uint8 * (w * hh)).from_address(a.value)).reshape(hh, w))
+            self._ptrs.append(a.value)
+        self.left, self.right = self.planes[0], self.planes[1]
+        self.key_cap = L.vieo_tracker_key_capacity(h)
         self.inp = np.zeros(1, TRACK_INPUT_DTYPE)
         self.out = np.zeros(1, TRACK_OUTPUT_DTYPE)
 
@@ -93,16 +149,23 @@ class Tracker:
         return s
 
     def track(self, left, right, imu, t_ref, t_cur, nav_ref, nav_last, prior, last_points, last_track_depth, local_points,
-              local_desc, local_alias, local_version):
+              local_desc, local_alias, local_version, images=None):
         i = self.inp[0]
         keep = []
-        for name, img, mine, ptr in (("left", left, self.left, self._ptrs[0]), ("right", right, self.right, self._ptrs[1])):
-            if img is mine:
-                i[name] = ptr
+        imgs = [left, right] if images is None else list(images)
+        assert len(imgs) == self.n_img
+        ptrs = []
+        for c, img in enumerate(imgs):
+            if img is self.planes[c]:
+                ptrs.append(self._ptrs[c])
             else:
                 img = np.ascontiguousarray(img, np.uint8)
                 keep.append(img)
-                i[name] = img.ctypes.data
+                ptrs.append(img.ctypes.data)
+        i["left"], i["right"] = ptrs[0], ptrs[1]
+        i["images"] = 0
+        if self.rig is not None:
+            i["images"][:self.n_img] = ptrs
         i["stride"] = int(self.params[0]["width"])
         imu = np.ascontiguousarray(imu, IMU_SAMPLE_DTYPE)
         i["n_imu"], i["imu"] = len(imu), imu.ctypes.data
@@ -126,17 +189,17 @@ class Tracker:
         check(_bind().vieo_track_frame(self.h, self.inp.ctypes.data, self.out.ctypes.data), "vieo_track_frame")
         o = self.out[0]
         n, nc = int(o["n_keys"]), len(cp)
-
-        def view(ptr, dtype, count):
-            dtype = np.dtype(dtype)
-            if count == 0:
-                return np.zeros(0, dtype)
-            buf = (ctypes.c_uint8 * (dtype.itemsize * count)).from_address(int(ptr))
-            return np.frombuffer(buf, dtype, count)
-        return o, dict(keys=view(o["keys"], KEYPOINT_DTYPE, n), desc=view(o["desc"], np.uint8, 32 * n).reshape(n, 32),
-                       uright=view(o["uright"], np.float32, n), depth=view(o["depth"], np.float32, n),
-                       point_ref=view(o["point_ref"], np.int32, n), outlier=view(o["outlier"], np.uint8, n),
-                       local_track_depth=view(o["local_track_depth"], np.float32, nc))
+        v = dict(keys=_view(o["keys"], KEYPOINT_DTYPE, n), desc=_view(o["desc"], np.uint8, 32 * n).reshape(n, 32),
+                 uright=_view(o["uright"], np.float32, n), depth=_view(o["depth"], np.float32, n),
+                 point_ref=_view(o["point_ref"], np.int32, n), outlier=_view(o["outlier"], np.uint8, n),
+                 local_track_depth=_view(o["local_track_depth"], np.float32, nc))
+        if self.rig is not None:
+            g, ncam = int(o["n_groups"]), self.n_img
+            v.update(key_group=_view(o["key_group"], np.int32, n),
+                     group_idx=_view(o["group_idx"], np.int32, g * ncam).reshape(g, ncam),
+                     group_good=_view(o["group_good"], np.uint8, g).astype(bool),
+                     group_p3d=_view(o["group_p3d"], np.float64, g * 3).reshape(g, 3))
+        return o, v
 
 
 class TrackerReplay(rp.Replay):
