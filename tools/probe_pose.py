@@ -5,12 +5,20 @@ import sys, ctypes, numpy as np
 sys.path.insert(0, "/root/repo")
 from vieo_slam_amd import replay, _lib
 n = 40
-seq = replay.Sequence(1, n)
-Rc = replay.ChainedReplay(seq, replay.HipStages())
-Rc.run(n)
-out = (ctypes.c_ulonglong * 16)()
 L = _lib.lib()
 f = ctypes.CDLL(_lib.LIB_PATH).vieo_debug_pose_probe
+out = (ctypes.c_ulonglong * 16)()
+if len(sys.argv) > 1 and sys.argv[1] == "rig":  # the rig instance: 20 calls of the one-call rig tracker
+    sys.argv = [sys.argv[0]] + sys.argv[2:]
+    sys.path.insert(0, "/root/repo/tools")
+    import run_rig_tracker
+    f(out)  # (reset)
+    run_rig_tracker.main()
+    n = int(sys.argv[4]) + 1
+else:
+    seq = replay.Sequence(1, n)
+    Rc = replay.ChainedReplay(seq, replay.HipStages())
+    Rc.run(n)
 f(out)
 v = np.array(list(out), float)
 names = ["loop/bookkeeping", "generic_errors", "visual linearize loop", "block_sum", "publish + imu/prior linearize", "H assembly", "backup + ldlt", "ns_inc", "generic_errors (trial)", "visual_chi (trial)", "iteration tail"]

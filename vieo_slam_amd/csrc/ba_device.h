@@ -217,8 +217,30 @@ __device__ __forceinline__ void block_sum_bs(double* vals, double* s_red, int ti
 #else
     for (int i = 0; i < N; i++) vals[i] = wave_sum_d_bfly(vals[i]);
 #endif
-  } else
+  } else if (BS == 256)
     block_sum<N>(vals, s_red, tid);
+  else {  // BS / 64 wavefronts: the same two steps, the partial sums added in a fixed tree order (s_red: BS / 64 x N)
+    constexpr int W = BS / 64;
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < N; i++) vals[i] = wave_sum_d(vals[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+      for (int i = 0; i < N; i++) s_red[wave * N + i] = vals[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      double t[W];
+#pragma unroll
+      for (int w = 0; w < W; w++) t[w] = s_red[w * N + i];
+#pragma unroll
+      for (int h = W / 2; h > 0; h >>= 1)
+#pragma unroll
+        for (int w = 0; w < h; w++) t[w] = t[w] + t[w + h];
+      vals[i] = t[0];
+    }
+  }
 }
 
 // EdgeReproject::linearizeOplus (g2otypes.h:439-498): Jacobian of the (up to 3) residual rows

@@ -28,9 +28,12 @@ struct Qd {
   double w, x, y, z;
 };
 __device__ __forceinline__ Qd q_of(const NSd& s) { return Qd{s.qw, s.qx, s.qy, s.qz}; }
+// (one division and four products instead of four divisions: a wavefront issues a double-precision operation every 8
+// cycles and a division is a dozen of them; the results differ from Eigen's normalize() in the last bit, far inside the
+// 1e-4 parity tolerance of the optimisers)
 __device__ __forceinline__ Qd q_norm(Qd q) {
-  const double n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  return Qd{q.w / n, q.x / n, q.y / n, q.z / n};
+  const double r = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  return Qd{q.w * r, q.x * r, q.y * r, q.z * r};
 }
 __device__ __forceinline__ Qd q_mul(const Qd& a, const Qd& b) {
   return Qd{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,

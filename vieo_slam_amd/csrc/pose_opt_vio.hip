@@ -11,6 +11,11 @@
 //   * (H + lambda I) x = b by a right-looking LDL^T run by one wavefront on the LDS copy;
 //   * LM control flow is evaluated redundantly by every thread from the same LDS scalars.
 // FP64 throughout; parity with oracle/pose_opt_vio.cc <= 1e-4 on SE(3).
+// This translation unit lets the compiler fuse a * b + c (the library is otherwise built with -ffp-contract=off for the
+// bit-exact integer / float paths): the optimiser's parity bar is 1e-4 on SE(3), the kernel runs long single-wavefront
+// chains where every double-precision instruction costs 8 issue cycles, and a fused multiply-add is one instead of two.
+#pragma clang fp contract(fast)
+
 #include "imu_device.h"
 
 namespace vieo {
@@ -106,60 +111,100 @@ __device__ __forceinline__ double readlane_d(double v, int srclane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int N>
-__device__ bool wave_ldlt_solve_reg(const double* H, double lambda, const double* b, double* x, double* Ls,
-                                    int lane) {
-  double a[N];
-  const int row = lane < N ? lane : 0;
+// The system's structure (round 4): the bias of the current state (unknowns 9..14) meets the rest of the system only
+// through the random-walk edge, one diagonal entry w_t per component and -w_t towards the last state's bias (24 + t) when
+// that is free -- the inertial edge's Jacobian has no column for it, the visual, prior and encoder edges neither.  Its six
+// unknowns are eliminated in closed form (pivot d_t = w_t + lambda) and the factorisation runs on the remaining NR = 24
+// (last state free) or 9 (last state fixed) unknowns: 0.65x / 0.25x of the dependent pivot chain of the 30 / 15-dim form.
+// Reduced index r -> system index: r < 9 ? r : r + 6.  Lane r owns row r; 1 / d per column is kept in LDS (Dl), the
+// factor L goes through LDS (Ls) for the back substitution.
+template <int NR>
+__device__ bool wave_solve_vio(const double* H, int n, double lambda, const double* b, double* x, double* Ls, double* Dl,
+                               int lane) {
+  double a[NR];
+  const int row = lane < NR ? lane : 0;
+  const int frow = row < 9 ? row : row + 6;
 #pragma unroll
-  for (int k = 0; k < N; k++) a[k] = H[row * N + k] + (k == row ? lambda : 0.0);
-  double Dd[N];
+  for (int k = 0; k < NR; k++) a[k] = H[frow * n + (k < 9 ? k : k + 6)] + (k == row ? lambda : 0.0);
+  double y = lane < NR ? b[frow] : 0.0;
   bool ok = true;
+  // the six eliminated unknowns: lane t < 6 keeps its pivot's reciprocal, lanes 18 + t of the 24-dim form take the update
+  double dbias = 1.0, off = 0.0;
+  {
+    const int t = NR == 24 ? (lane >= 18 && lane < 24 ? lane - 18 : (lane < 6 ? lane : 0)) : (lane < 6 ? lane : 0);
+    const double d = H[(9 + t) * n + 9 + t] + lambda;
+    if (!(d > 0)) ok = false;
+    double inv = __builtin_amdgcn_rcp(d);
+    inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+    inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+    dbias = inv;
+    if (NR == 24) {
+      off = H[(9 + t) * n + 24 + t];
+      if (lane >= 18 && lane < 24) {
+        const double l = off * inv;
 #pragma unroll
-  for (int j = 0; j < N; j++) {
-    const double d = readlane_d(a[j], j);
+        for (int k = 18; k < 24; k++)
+          if (k == lane) a[k] -= l * off;
+        y -= l * b[9 + t];
+      }
+    }
+  }
+  ok = __all(ok);
+  // Column j travels to the other rows through LDS (one ds_write per lane, then wave-uniform -- broadcast -- reads, two
+  // values per instruction) instead of two v_readlane per value: a wavefront issues one instruction every 4 (8 for double
+  // precision) cycles whatever the number of useful lanes, so the count of instructions is the cost, and this form has
+  // a quarter of them.  The reciprocal's Newton chain sits between the write and the reads (hides the LDS turn-around).
+  double* colbuf = Ls + NR * NR;  // 2 x 32 doubles behind L
+#pragma unroll
+  for (int j = 0; j < NR; j++) {
+    const double c = a[j];  // un-normalised column entry of this row
+    double* col = colbuf + (j & 1) * 32;
+    if (lane < 32) col[lane] = c;
+    const double d = readlane_d(c, j);
     if (!(d > 0)) ok = false;
     // 1 / d once per column (v_rcp_f64 + two Newton steps, as k_lba_ldlt16 does) instead of a division per row
     double inv = __builtin_amdgcn_rcp(d);
     inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
     inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
-    Dd[j] = inv;
-    const double c = a[j];          // un-normalised column entry of this row
+    if (lane == j) Dl[j] = inv;
     const double l = c * inv;
+    wave_sync();
+    // (rows <= j take the update as well: their entries right of the diagonal are never read again)
 #pragma unroll
-    for (int k = j + 1; k < N; k++) {
-      const double ck = readlane_d(a[j], k);  // A[k][j]
-      if (lane > j) a[k] -= l * ck;
-    }
-    if (lane > j) a[j] = l;
+    for (int k = j + 1; k < NR; k++) a[k] = __builtin_fma(-l, col[k], a[k]);
+    a[j] = l;
   }
   if (!ok) return false;
   // forward: y = L^-1 b (column oriented)
-  double y = lane < N ? b[lane] : 0.0;
 #pragma unroll
-  for (int j = 0; j < N; j++) {
+  for (int j = 0; j < NR; j++) {
     const double yj = readlane_d(y, j);
-    if (lane > j && lane < N) y -= a[j] * yj;
+    if (lane > j && lane < NR) y -= a[j] * yj;
   }
-  double dd = 1.0;
-#pragma unroll
-  for (int j = 0; j < N; j++)
-    if (lane == j) dd = Dd[j];
-  y *= dd;
   // L -> LDS, then lane i fetches column i (rows below it)
-  if (lane < N)
+  if (lane < NR)
 #pragma unroll
-    for (int k = 0; k < N; k++) Ls[lane * N + k] = a[k];
+    for (int k = 0; k < NR; k++) Ls[lane * NR + k] = a[k];
   wave_sync();
-  double ccol[N];
+  y *= Dl[row];
 #pragma unroll
-  for (int j = 0; j < N; j++) ccol[j] = Ls[j * N + row];
-#pragma unroll
-  for (int j = N - 1; j >= 0; j--) {
+  for (int j = NR - 1; j >= 0; j--) {
     const double xj = readlane_d(y, j);
-    if (lane < j) y -= ccol[j] * xj;
+    if (lane < j) y -= Ls[j * NR + row] * xj;
   }
-  if (lane < N) x[lane] = y;
+  if (lane < NR) x[frow] = y;
+  // the eliminated unknowns: x_(9+t) = (b_(9+t) - off_t x_(24+t)) / d_t
+  {
+    double xb = 0.0;
+    if (NR == 24) {
+#pragma unroll
+      for (int t = 0; t < 6; t++) {
+        const double v = readlane_d(y, 18 + t);
+        if (lane == t) xb = v;
+      }
+    }
+    if (lane < 6) x[9 + lane] = (b[9 + lane] - off * xb) * dbias;
+  }
   wave_sync();
   return true;
 }
@@ -170,7 +215,7 @@ __device__ bool wave_ldlt_solve_reg(const double* H, double lambda, const double
 struct VioShared {
   NSd nsj, nsi, bkj, bki, prior;
   double H[900], L[900], b[32], x[32], col[32], lcol[32], D[32];
-  double red[4 * 28], vis[28];
+  double red[16 * 28], vis[28];
   double errI[9], errB[6], errP[15], wI[9], wP[15];
   double JI[9 * 24], JP[225], InfoI[81], T[15 * 24];
   double cov[225], C[225], E[225], Cinv[225 * 2];
@@ -344,7 +389,6 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const double dI = sqrt(16.919), dB = sqrt(12.592), dP = sqrt(25.0), dE = sqrt(12.592);
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
-  const NSd nsj0 = S.nsj, nsi0 = S.nsi;
   unsigned long long levelmask = 0;
   bool vis_robust = true;
   int nBad = 0, total_iters = 0;
@@ -438,8 +482,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   for (int it = 0; it < 4; it++) {
     __syncthreads();
     if (!bodom && tid == 0) {  // Optimizer.h:538-545
-      S.nsj = nsj0;
-      if (!fixedLast) S.nsi = nsi0;
+      ns_load(S.nsj, F.base.nav);
+      if (!fixedLast) ns_load(S.nsi, F.nav_last);
     }
     __syncthreads();
     double lambda = -1, ni = 2;
@@ -617,11 +661,17 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       int qmax = 0;
       do {
         __syncthreads();
-        if (tid == 0) S.bkj = S.nsj, S.bki = S.nsi;
-        __syncthreads();
+        // the two states' backup (a lane per double) on the last wavefront, beside the factorisation on the first
+        if (tid >= BS - 64) {
+          constexpr int kNs = (int)(sizeof(NSd) / 8);
+          if (lane < kNs) ((double*)&S.bkj)[lane] = ((const double*)&S.nsj)[lane];
+          if (lane < kNs && BS == 64) ((double*)&S.bki)[lane] = ((const double*)&S.nsi)[lane];
+          if (BS > 64 && lane >= 32 && lane < 32 + kNs) ((double*)&S.bki)[lane - 32] = ((const double*)&S.nsi)[lane - 32];
+        }
+        if (BS == 64) wave_sync();
         if (wave == 0) {
-          const bool ok = n == 15 ? wave_ldlt_solve_reg<15>(S.H, lambda, S.b, S.x, S.L, lane)
-                                  : wave_ldlt_solve_reg<30>(S.H, lambda, S.b, S.x, S.L, lane);
+          const bool ok = n == 15 ? wave_solve_vio<9>(S.H, n, lambda, S.b, S.x, S.L, S.D, lane)
+                                  : wave_solve_vio<24>(S.H, n, lambda, S.b, S.x, S.L, S.D, lane);
           if (lane == 0) S.ok = ok ? 1 : 0;
         }
         __syncthreads();
@@ -659,7 +709,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           lambda *= ni;
           ni *= 2;
           __syncthreads();
-          if (tid == 0) S.nsj = S.bkj, S.nsi = S.bki;
+          {
+            constexpr int kNs = (int)(sizeof(NSd) / 8);
+            if (tid < kNs) ((double*)&S.nsj)[tid] = ((const double*)&S.bkj)[tid];
+            if (tid >= 32 && tid < 32 + kNs) ((double*)&S.nsi)[tid - 32] = ((const double*)&S.bki)[tid - 32];
+          }
         }
         qmax++;
       } while (rho < 0 && qmax < 10);
