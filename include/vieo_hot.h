@@ -852,7 +852,14 @@ int vieo_track_merge_assign_rig_batch_device(const int32_t* d_assign, int32_t* d
                                              int key_cap, int n_frames, int img_first, int img_step, int point_offset,
                                              int reset, int query_div,
                                              const vieo_last_frame_point* d_same_point /*[f][key_cap] or NULL: reserved[0]
-                                             > 0 names (1 +) the first point-table entry of the same MapPoint*/, void* stream);
+                                             > 0 names (1 +) the first point-table entry of the same MapPoint*/,
+                                             const int32_t* d_query_src /*[f][q_cap] or NULL: the searched list was
+                                             compacted, entry a came from query d_query_src[a]*/, int q_cap, void* stream);
+/* The valid queries (flags bit 0) of every frame moved to the front of d_queries_out in their order, d_src[f][k] = the
+ * index the k-th one had, d_nq_out[f] = their number.  A rig frame's first search holds one query per (last-frame key,
+ * camera) pair and most of them project outside their camera; the search walks the list several times. */
+int vieo_track_compact_queries_batch_device(const vieo_proj_query* d_queries, const int32_t* d_nq, int q_cap, int n_frames,
+                                            vieo_proj_query* d_queries_out, int32_t* d_src, int32_t* d_nq_out, void* stream);
 int vieo_track_build_obs_rig_batch_device(const int32_t* d_mp_ref, const float* d_point_xyz,
                                           const float* d_point_depth, float close_depth, int p_cap,
                                           const vieo_keypoint* d_keys, const float* d_uright,

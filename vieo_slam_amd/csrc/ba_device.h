@@ -122,8 +122,10 @@ __device__ __forceinline__ void inc_small_pr(Est& s, const double* d) {
     real = 1.0 - t2 / 8.;
   } else {
     const double half = 0.5 * theta;
-    imag = sin(half) / theta;
-    real = cos(half);
+    double sh, ch;
+    sincos(half, &sh, &ch);
+    imag = sh / theta;
+    real = ch;
   }
   double ew = real, ex = imag * d[3], ey = imag * d[4], ez = imag * d[5];
   double n = sqrt(ew * ew + ex * ex + ey * ey + ez * ez);

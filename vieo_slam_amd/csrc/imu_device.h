@@ -78,7 +78,9 @@ __device__ __forceinline__ Qd so3_exp_q(const double* w) {
     imag = 0.5 - t2 / 48., real = 1.0 - t2 / 8.;
   } else {
     const double h = 0.5 * th;
-    imag = sin(h) / th, real = cos(h);
+    double sh, ch;
+    sincos(h, &sh, &ch);  // one argument reduction for both
+    imag = sh / th, real = ch;
   }
   return q_norm(Qd{real, imag * w[0], imag * w[1], imag * w[2]});
 }
@@ -125,7 +127,9 @@ __device__ __forceinline__ void so3_Jr_d(const double* w, double* J) {
     const double k[3] = {w[0] / th, w[1] / th, w[2] / th};
     hat3(k, O);
     mm3(O, O, O2);
-    const double a = (1 - cos(th)) / th, b = 1 - sin(th) / th;
+    double sth, cth;
+    sincos(th, &sth, &cth);
+    const double a = (1 - cth) / th, b = 1 - sth / th;
     for (int i = 0; i < 9; i++) J[i] = ((i % 4) == 0 ? 1.0 : 0.0) - a * O[i] + b * O2[i];
   }
 }
@@ -141,7 +145,9 @@ __device__ __forceinline__ void so3_JrInv_d(const double* w, double* J) {
     double K[9];
     hat3(k, K);
     mm3(K, K, O2);
-    const double c = 1.0 - (1.0 + cos(th)) * th / (2.0 * sin(th));
+    double sth, cth;
+    sincos(th, &sth, &cth);
+    const double c = 1.0 - (1.0 + cth) * th / (2.0 * sth);
     for (int i = 0; i < 9; i++) J[i] = ((i % 4) == 0 ? 1.0 : 0.0) + 0.5 * O[i] + c * O2[i];
   }
 }
@@ -159,26 +165,32 @@ __device__ __forceinline__ void ns_inc(NSd& s, const double* d, const double* db
 
 // EdgeNavStateI<NV>::computeError (g2otypes.h:733-776): rows [r_p, then r_R at idR, r_v at 9 - idR]
 // (idR = 6: EdgeNavStatePVR of PoseOptimization; idR = 3: EdgeNavStatePRV of the local BA)
+// part: 0 = all nine rows; 1 = the position and velocity rows, 2 = the rotation rows (the quaternion chain with its exp /
+// log) -- the two halves share nothing but the inputs, so two lanes of different wavefronts evaluate them side by side.
 static __device__ void imu_error(const vieo_imu_preint& M, const double* gw, const NSd& si, const NSd& sj,
-                          double* err, int idR = 6) {
-  double Ri[9], t[3], r[3], Jb[3], Ja[3];
-  q_to_R(q_of(si), Ri);
-  const double dt = M.dt;
-  for (int k = 0; k < 3; k++) t[k] = sj.p[k] - si.p[k] - si.v[k] * dt - gw[k] * (dt * dt / 2);
-  mTv3(Ri, t, r);
-  mv3(M.Jgp, si.dbg, Jb);
-  mv3(M.Jap, si.dba, Ja);
-  for (int k = 0; k < 3; k++) err[k] = r[k] - (M.pij[k] + Jb[k] + Ja[k]);
-  double w[3];
-  mv3(M.JgR, si.dbg, w);
-  const Qd qa = q_norm(q_mul(R_to_q(M.Rij), so3_exp_q(w)));
-  const Qd qb = q_norm(q_mul(q_conj(q_of(si)), q_of(sj)));
-  so3_log_q(q_norm(q_mul(q_conj(qa), qb)), err + idR);
-  for (int k = 0; k < 3; k++) t[k] = sj.v[k] - si.v[k] - gw[k] * dt;
-  mTv3(Ri, t, r);
-  mv3(M.Jgv, si.dbg, Jb);
-  mv3(M.Jav, si.dba, Ja);
-  for (int k = 0; k < 3; k++) err[9 - idR + k] = r[k] - (M.vij[k] + Jb[k] + Ja[k]);
+                          double* err, int idR = 6, int part = 0) {
+  if (part != 2) {
+    double Ri[9], t[3], r[3], Jb[3], Ja[3];
+    q_to_R(q_of(si), Ri);
+    const double dt = M.dt;
+    for (int k = 0; k < 3; k++) t[k] = sj.p[k] - si.p[k] - si.v[k] * dt - gw[k] * (dt * dt / 2);
+    mTv3(Ri, t, r);
+    mv3(M.Jgp, si.dbg, Jb);
+    mv3(M.Jap, si.dba, Ja);
+    for (int k = 0; k < 3; k++) err[k] = r[k] - (M.pij[k] + Jb[k] + Ja[k]);
+    for (int k = 0; k < 3; k++) t[k] = sj.v[k] - si.v[k] - gw[k] * dt;
+    mTv3(Ri, t, r);
+    mv3(M.Jgv, si.dbg, Jb);
+    mv3(M.Jav, si.dba, Ja);
+    for (int k = 0; k < 3; k++) err[9 - idR + k] = r[k] - (M.vij[k] + Jb[k] + Ja[k]);
+  }
+  if (part != 1) {
+    double w[3];
+    mv3(M.JgR, si.dbg, w);
+    const Qd qa = q_norm(q_mul(R_to_q(M.Rij), so3_exp_q(w)));
+    const Qd qb = q_norm(q_mul(q_conj(q_of(si)), q_of(sj)));
+    so3_log_q(q_norm(q_mul(q_conj(qa), qb)), err + idR);
+  }
 }
 
 __device__ __forceinline__ void set3(double* J, int ld, int r0, int c0, const double* M, double s) {

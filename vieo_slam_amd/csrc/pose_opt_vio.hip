@@ -397,7 +397,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
 
   // generic-edge errors at the current LDS state; returns (robust chi2 sum, rho' of I, B, P)
   auto generic_errors = [&](double* rhoI, double* rhoB, double* rhoP) -> double {
-    if (tid == 0 && hasImu) imu_error(F.imu, gw, S.nsi, S.nsj, S.errI);
+    if (BS > 192) {  // the rotation rows on wavefront 0, the position / velocity rows on wavefront 3, side by side
+      if (tid == 0 && hasImu) imu_error(F.imu, gw, S.nsi, S.nsj, S.errI, 6, 2);
+      if (tid == T3 && hasImu) imu_error(F.imu, gw, S.nsi, S.nsj, S.errI, 6, 1);
+    } else if (tid == 0 && hasImu)
+      imu_error(F.imu, gw, S.nsi, S.nsj, S.errI);
     if (tid == T1 && !fixedLast) prior_error(S.prior, S.nsi, S.errP);
     if (tid == T2) {
       for (int k = 0; k < 3; k++) {

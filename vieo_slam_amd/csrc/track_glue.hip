@@ -14,7 +14,8 @@ namespace vieo {
 __global__ void __launch_bounds__(256)
 k_track_merge_assign(const int* __restrict__ assign, int* __restrict__ mp_ref,
                      const int* __restrict__ counts, int key_cap, int img_first, int img_step,
-                     int point_offset, int reset, int query_div, const vieo_last_frame_point* __restrict__ pts) {
+                     int point_offset, int reset, int query_div, const vieo_last_frame_point* __restrict__ pts,
+                     const int* __restrict__ query_src, int q_cap) {
   const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   const int img = img_first + f * img_step;
   if (i >= key_cap) return;
@@ -26,7 +27,8 @@ k_track_merge_assign(const int* __restrict__ assign, int* __restrict__ mp_ref,
   int cur = reset ? -1 : *m;
   const int a = assign[(size_t)f * key_cap + i];
   if (a >= 0) {
-    int pi = query_div > 1 ? a / query_div : a;  // a rig's query (point i, camera c) is i * n_cams + c
+    const int q = query_src ? query_src[(size_t)f * q_cap + a] : a;  // compacted query list: back to (point, camera)
+    int pi = query_div > 1 ? q / query_div : q;  // a rig's query (point i, camera c) is i * n_cams + c
     // a rig frame's map point is held by one key per camera: all of them stand for the first one's table entry
     if (pts) {
       const int rep = pts[(size_t)f * key_cap + pi].reserved[0];
@@ -136,6 +138,50 @@ k_track_after_pose(int* __restrict__ mp_ref, const int* __restrict__ obs_key,
   }
 }
 
+// The valid queries of a frame moved to the front, order kept (the order is the order in which keys are claimed).  A rig
+// frame's first search asks for every (last-frame key, camera) pair, most of which project outside their camera: the
+// search kernels walk the list several times, so a list a fifth as long is worth one pass.  One workgroup per frame.
+__global__ void __launch_bounds__(1024)
+k_track_compact_queries(const vieo_proj_query* __restrict__ q_in, const int* __restrict__ nq_in, int q_cap,
+                        vieo_proj_query* __restrict__ q_out, int* __restrict__ src, int* __restrict__ nq_out) {
+  __shared__ int s_w[16];
+  __shared__ int s_base;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(nq_in[f], q_cap);
+  const uint4* in = (const uint4*)(q_in + (size_t)f * q_cap);
+  uint4* out = (uint4*)(q_out + (size_t)f * q_cap);
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    uint4 r0 = {0, 0, 0, 0}, r1 = r0, r2 = r0, r3 = r0;
+    bool has = false;
+    if (i < n) {
+      r1 = in[4 * (size_t)i + 1];
+      has = (r1.w & 1u) != 0;  // flags: the last word of the second quarter
+      if (has) r0 = in[4 * (size_t)i], r2 = in[4 * (size_t)i + 2], r3 = in[4 * (size_t)i + 3];
+    }
+    const unsigned long long bal = __ballot(has);
+    if (lane == 0) s_w[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_w[w];
+    if (has) {
+      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+      out[4 * (size_t)pos] = r0, out[4 * (size_t)pos + 1] = r1, out[4 * (size_t)pos + 2] = r2, out[4 * (size_t)pos + 3] = r3;
+      src[(size_t)f * q_cap + pos] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; w++) t += s_w[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) nq_out[f] = s_base;
+}
+
 }  // namespace vieo
 
 using namespace vieo;
@@ -149,7 +195,7 @@ int vieo_track_merge_assign_batch_device(const int32_t* d_assign, int32_t* d_mp_
   if (!d_assign || !d_mp_ref || !d_counts || key_cap <= 0 || n_frames <= 0) return VIEO_E_INVALID;
   hipLaunchKernelGGL(k_track_merge_assign, dim3((key_cap + 255) / 256, n_frames), dim3(256), 0,
                      (hipStream_t)stream, d_assign, d_mp_ref, d_counts, key_cap, img_first, img_step,
-                     point_offset, reset, 1, (const vieo_last_frame_point*)nullptr);
+                     point_offset, reset, 1, (const vieo_last_frame_point*)nullptr, (const int*)nullptr, 0);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
@@ -157,11 +203,20 @@ int vieo_track_merge_assign_batch_device(const int32_t* d_assign, int32_t* d_mp_
 int vieo_track_merge_assign_rig_batch_device(const int32_t* d_assign, int32_t* d_mp_ref, const int32_t* d_counts,
                                              int key_cap, int n_frames, int img_first, int img_step, int point_offset,
                                              int reset, int query_div, const vieo_last_frame_point* d_same_point,
-                                             void* stream) {
+                                             const int32_t* d_query_src, int q_cap, void* stream) {
   if (!d_assign || !d_mp_ref || !d_counts || key_cap <= 0 || n_frames <= 0 || query_div < 1) return VIEO_E_INVALID;
   hipLaunchKernelGGL(k_track_merge_assign, dim3((key_cap + 255) / 256, n_frames), dim3(256), 0,
                      (hipStream_t)stream, d_assign, d_mp_ref, d_counts, key_cap, img_first, img_step,
-                     point_offset, reset, query_div, d_same_point);
+                     point_offset, reset, query_div, d_same_point, d_query_src, q_cap);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_compact_queries_batch_device(const vieo_proj_query* d_queries, const int32_t* d_nq, int q_cap, int n_frames,
+                                            vieo_proj_query* d_queries_out, int32_t* d_src, int32_t* d_nq_out, void* stream) {
+  if (!d_queries || !d_nq || q_cap <= 0 || n_frames <= 0 || !d_queries_out || !d_src || !d_nq_out) return VIEO_E_INVALID;
+  hipLaunchKernelGGL(k_track_compact_queries, dim3(n_frames), dim3(1024), 0, (hipStream_t)stream, d_queries, d_nq, q_cap,
+                     d_queries_out, d_src, d_nq_out);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }

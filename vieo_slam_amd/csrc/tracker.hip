@@ -196,7 +196,7 @@ struct vieo_tracker {
   // offsets in the download block
   size_t q_hdr, q_ur, q_dp, q_mpref, q_outl, q_kg, q_gidx, q_good, q_p3d, q_small_end, q_kp, q_desc, q_cdep, out_bytes;
   // offsets in the work block
-  size_t w_kp, w_desc, w_kcat, w_dcat, w_q1, w_q2, w_assign, w_taken, w_held, w_obs, w_obskey, w_outl, w_xyz, w_dep, w_pre, w_prv, w_pst;
+  size_t w_kp, w_desc, w_kcat, w_dcat, w_q1, w_q1c, w_qsrc, w_q2, w_assign, w_taken, w_held, w_obs, w_obskey, w_outl, w_xyz, w_dep, w_pre, w_prv, w_pst;
 };
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -289,6 +289,8 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
   t->w_kcat = t->w_kp, t->w_dcat = t->w_desc;
   if (R) t->w_kcat = take((size_t)kc * sizeof(vieo_keypoint)), t->w_dcat = take((size_t)kc * 32);
   t->w_q1 = take((size_t)kc * nc * sizeof(vieo_proj_query)), t->w_q2 = take((size_t)ccap * nc * sizeof(vieo_proj_query));
+  t->w_q1c = t->w_q1, t->w_qsrc = 0;
+  if (R) t->w_q1c = take((size_t)kc * nc * sizeof(vieo_proj_query)), t->w_qsrc = take((size_t)kc * nc * 4);
   t->w_assign = take((size_t)kc * 4), t->w_taken = take(kc), t->w_held = take(t->pcap);
   t->w_obs = take((size_t)kc * sizeof(vieo_pose_obs)), t->w_obskey = take((size_t)kc * 4), t->w_outl = take(kc);
   t->w_xyz = take((size_t)t->pcap * 12), t->w_dep = take((size_t)t->pcap * 4);
@@ -459,9 +461,18 @@ static int track_chain_tail(vieo_tracker* t, int nc_local) {
                                                      d_rig, nc, d_q1, st));
   else
     TRK(vieo_sbp_project_last_frame_batch_device((const vieo_last_frame_point*)(t->d_up + t->o_pts), dH->npts, kc, 1, &dH->cam, d_q1, st));
-  TRK(search(VIEO_SBP_LAST_FRAME, d_q1, dH->npts + 1, kc * nc, nullptr, P.nn_last, dO->nm));
-  TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, 0, 1, nc,
-                                               t->rig ? (const vieo_last_frame_point*)(t->d_up + t->o_pts) : nullptr, st));
+  if (t->rig) {
+    // one query per (last-frame key, camera): most project outside their camera -- the search walks the valid ones only
+    vieo_proj_query* d_q1c = (vieo_proj_query*)(W + t->w_q1c);
+    int32_t* d_qsrc = (int32_t*)(W + t->w_qsrc);
+    TRK(vieo_track_compact_queries_batch_device(d_q1, dH->npts + 1, kc * nc, 1, d_q1c, d_qsrc, dO->nq + 1, st));
+    TRK(search(VIEO_SBP_LAST_FRAME, d_q1c, dO->nq + 1, kc * nc, nullptr, P.nn_last, dO->nm));
+    TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, 0, 1, nc,
+                                                 (const vieo_last_frame_point*)(t->d_up + t->o_pts), d_qsrc, kc * nc, st));
+  } else {
+    TRK(search(VIEO_SBP_LAST_FRAME, d_q1, dH->npts + 1, kc * nc, nullptr, P.nn_last, dO->nm));
+    TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, 0, 1, nc, nullptr, nullptr, 0, st));
+  }
   TRK(build_obs(f1));
   TRK(pose(f1, r1));
   TRK(vieo_track_after_pose_batch_device(d_mpref, d_obskey, d_outl, f1, r1, vio, kc, 1, f2, d_taken, st));
@@ -472,7 +483,7 @@ static int track_chain_tail(vieo_tracker* t, int nc_local) {
                                       (const int32_t*)(t->d_up + t->o_alias), d_held, t->pcap, nc_local, P.th_local,
                                       t->rig ? t->R.th_far_pts : 0.f, dH->consts + 16, d_q2, d_dep + kc, dO->nq, st));
   TRK(search(VIEO_SBP_LOCAL_MAP, d_q2, dO->nq, t->ccap * nc, d_taken, P.nn_local, dO->nm + 1));
-  TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, kc, 0, nc, nullptr, st));
+  TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, kc, 0, nc, nullptr, nullptr, 0, st));
   TRK(build_obs(f2));
   TRK(pose(f2, t->vision ? (void*)&dO->r2.base : (void*)&dO->r2));
 #undef TRK
