@@ -267,6 +267,7 @@ def test_gpu_sbp_more_wide_windows_than_a_block_lists(oracle, monkeypatch):
     with more of them than the eight blocks can list (relocalisation-size windows, rig local maps with p_cap * n_cams
     queries) makes every block walk ITS OWN share of the queries again.  19 000 queries, all of them wider than 16 grid
     columns, against the oracle and against the sequential replay."""
+    monkeypatch.setenv("VIEO_SBP_BLOCKS", "8")  # (a single frame would get 32 blocks: 33 000 wide queries to overflow)
     kl, dl, ur, pts, cam = _scenario(oracle, 1040, th=7.0)
     q1 = oracle.sbp_project_last_frame(pts, cam)
     rng = np.random.default_rng(1040)

@@ -78,11 +78,13 @@ __device__ __forceinline__ void cam_project(const CamD& c, const double* P, doub
         dd += 7.0 * c.k[2], dd *= theta2, dd += 5.0 * c.k[1], dd *= theta2, dd += 3.0 * c.k[0];
         dd *= theta2, dd += 1.0;
         const double invr2 = invr * invr;
-        J[0] = c.fx * (x * r * dd * d_thetad_x + y2 * thetad / r) * invr2;
-        J[1] = c.fx * x * (dd * d_thetad_y * r - y * thetad / r) * invr2;
+        const double tr = thetad * invr;  // thetad / r once (a double-precision division is a dozen instructions)
+        const double jxy = x * (dd * d_thetad_y * r - y * tr) * invr2;
+        J[0] = c.fx * (x * r * dd * d_thetad_x + y2 * tr) * invr2;
+        J[1] = c.fx * jxy;
         J[2] = -c.fx * x * dd * tmp;
-        J[3] = J[1] * c.fy / c.fx;
-        J[4] = c.fy * (y * r * dd * d_thetad_y + x2 * thetad / r) * invr2;
+        J[3] = c.fy * jxy;  // = J[1] * fy / fx
+        J[4] = c.fy * (y * r * dd * d_thetad_y + x2 * tr) * invr2;
         J[5] = -c.fy * y * dd * tmp;
       }
       return;
@@ -286,22 +288,36 @@ __device__ __host__ inline bool cam_from_abi(const vieo_camera& c, CamD& d) {
 // MC = false: the frame's single rectified pinhole camera c0 with the per-estimate transforms X0.
 // MC = true: the observation's own camera cams[(flags >> 8) & 15] (Radtan / KB8 / pinhole, monocular
 // edges), whose Rcw / tcw are formed per edge from X0.Rwb and the body position p.
+// camera c's world -> camera transform at the estimate X0 / p: xf[0..8] = Rcw = Rcb Rwb^T, xf[9..11] = tcw
+__device__ __forceinline__ void rig_cam_xf(const CamD& c, const PoseXf& X0, const double* p, double* xf) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      xf[i * 3 + j] = c.Rcb[i * 3] * X0.Rwb[j * 3] + c.Rcb[i * 3 + 1] * X0.Rwb[j * 3 + 1] + c.Rcb[i * 3 + 2] * X0.Rwb[j * 3 + 2];
+  for (int i = 0; i < 3; i++) xf[9 + i] = -(xf[i * 3] * p[0] + xf[i * 3 + 1] * p[1] + xf[i * 3 + 2] * p[2]) + c.tcb[i];
+}
+
+// cam_xf: the rig's per-camera transforms [n_cams][12] formed once per pass (rig_cam_xf, in LDS), or null: per edge
 template <bool MC>
 __device__ __forceinline__ double edge_eval(const CamD& c0, const CamD* cams, const PoseXf& X0, const double* p,
-                                            const vieo_pose_obs& o, double* err, double* Pc, double* J) {
+                                            const vieo_pose_obs& o, double* err, double* Pc, double* J,
+                                            const double* cam_xf = nullptr) {
   if (!MC) {
     const double chi2 = edge_error(c0, X0, o, err, Pc);
     if (J) visual_jacobian(c0, X0, p, o, Pc, J);
     return chi2;
   }
-  const CamD& c = cams[(o.flags >> 8) & 3];
+  const int ci = (o.flags >> 8) & 3;
+  const CamD& c = cams[ci];
   double Rcw[9], tcw[3];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++)
-      Rcw[i * 3 + j] = c.Rcb[i * 3] * X0.Rwb[j * 3] + c.Rcb[i * 3 + 1] * X0.Rwb[j * 3 + 1] +
-                       c.Rcb[i * 3 + 2] * X0.Rwb[j * 3 + 2];
-  for (int i = 0; i < 3; i++)
-    tcw[i] = -(Rcw[i * 3] * p[0] + Rcw[i * 3 + 1] * p[1] + Rcw[i * 3 + 2] * p[2]) + c.tcb[i];
+  if (cam_xf) {
+    for (int i = 0; i < 9; i++) Rcw[i] = cam_xf[ci * 12 + i];
+    for (int i = 0; i < 3; i++) tcw[i] = cam_xf[ci * 12 + 9 + i];
+  } else {
+    double xf[12];
+    rig_cam_xf(c, X0, p, xf);
+    for (int i = 0; i < 9; i++) Rcw[i] = xf[i];
+    for (int i = 0; i < 3; i++) tcw[i] = xf[9 + i];
+  }
   const double Xw0 = o.Xw[0], Xw1 = o.Xw[1], Xw2 = o.Xw[2];
   for (int i = 0; i < 3; i++) Pc[i] = Rcw[i * 3] * Xw0 + Rcw[i * 3 + 1] * Xw1 + Rcw[i * 3 + 2] * Xw2 + tcw[i];
   double uv[2], Jc[6];

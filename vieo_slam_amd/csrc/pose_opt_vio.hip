@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(BS)
 k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
                uint8_t* __restrict__ outlier_all, vieo_vio_result* __restrict__ results, int other_launched) {
   __shared__ VioShared S;
+  __shared__ double s_xf[MC ? 48 : 1];  // rig: every camera's Rcw | tcw at the estimate of the current pass
   __shared__ __align__(8) unsigned char s_cam_store[sizeof(CamD) * (MC ? 4 : 1)];  // CamD has initialisers
   CamD* s_cams = reinterpret_cast<CamD*>(s_cam_store);
   __shared__ __align__(8) unsigned char s_enc_store[ENC ? sizeof(VioEncShared) : 8];
@@ -333,6 +334,14 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   for (int i = 0; i < 9; i++) c.Rcb[i] = F.base.Rcb[i];
   for (int i = 0; i < 3; i++) c.tcb[i] = F.base.tcb[i];
   const bool fixedLast = !F.last_has_prior, hasImu = F.imu.dt != 0;
+  // rig frames: the cameras' transforms at the estimate of a pass, once (a lane per camera) instead of once per edge
+  auto rig_xf = [&](const PoseXf& X, const double* p) {
+    if (MC) {
+      __syncthreads();  // the previous pass's readers are done
+      if (tid < F.base.n_cams) rig_cam_xf(s_cams[tid], X, p, s_xf + 12 * tid);
+      __syncthreads();
+    }
+  };
   const int n = fixedLast ? 15 : 30;
   const bool bodom = hasImu || ENC;
   const double gw[3] = {F.gw[0], F.gw[1], F.gw[2]};
@@ -461,6 +470,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
     PoseXf X;
     make_xf(c, e, X);
+    rig_xf(X, e.p);
     double tc[1] = {0};
     vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
     for (int k = 0, i = tid; i < N; k++, i += BS) {
@@ -468,7 +478,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       if (i + BS < N) o_next = obs[i + BS];
       if ((levelmask >> k) & 1) continue;
       double err[3], Pc[3];
-      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr);
+      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
       double r0 = chi2, r1 = 1.;
       if (vis_robust) {
         const double dl = o.ur >= 0 ? deltaStereo : deltaMono;
@@ -512,6 +522,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
       PoseXf X;
       make_xf(c, e, X);
+      rig_xf(X, e.p);
       double acc[28];
 #pragma unroll
       for (int i = 0; i < 28; i++) acc[i] = 0;
@@ -522,7 +533,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         if ((levelmask >> k) & 1) continue;
         double err[3], Pc[3];
         double J[18];
-        const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J);
+        const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J, MC ? s_xf : nullptr);
         const bool stereo = o.ur >= 0;
         double r0 = chi2, r1 = 1.;
         if (vis_robust) {
@@ -737,12 +748,13 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
     PoseXf X;
     make_xf(c, e, X);
+    rig_xf(X, e.p);
     const float chi2close = (float)(1.5 * (double)chi2Mono);
     double nb[1] = {0};
     for (int k = 0, i = tid; i < N; k++, i += BS) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
-      const float chi2 = (float)edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr);
+      const float chi2 = (float)edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
       bool bad;
       if (o.ur < 0)
         bad = chi2 > ((o.flags & 1) ? chi2close : chi2Mono) || !(Pc[2] > 0.);
@@ -766,11 +778,12 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
     PoseXf X;
     make_xf(c, e, X);
+    rig_xf(X, e.p);
     double nb[1] = {0};
     for (int k = 0, i = tid; i < N; k++, i += BS) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
-      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr);
+      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
       if (chi2 < (double)(o.ur < 0 ? 18.f : 24.f)) {
         levelmask &= ~(1ull << k);
         outmask &= ~(1ull << k);
@@ -790,6 +803,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
     PoseXf X;
     make_xf(c, e, X);
+    rig_xf(X, e.p);
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
@@ -800,7 +814,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       if ((levelmask >> k) & 1) continue;
       double err[3], Pc[3];
       double J[18];
-      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J);
+      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J, MC ? s_xf : nullptr);
       const bool stereo = o.ur >= 0;
       double r0 = chi2, r1 = 1.;
       if (vis_robust) {

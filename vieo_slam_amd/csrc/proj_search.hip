@@ -325,7 +325,8 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int* total) {
 // processed.  GetFeaturesInArea (FrameBase.cpp:95-174): cells of one grid column are consecutive in
 // the CSR, so a window is nx contiguous runs of records, already in the reference's order (ix outer,
 // iy inner, key index inside a cell) -- no sort.
-static const int kSbpBlocks = 8;
+static const int kSbpBlocks = 8;      // workgroups per frame of a batch
+static const int kSbpBlocksFew = 32;  // ... of a call with a frame or two (the one-call tracker): latency, not occupancy
 
 __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   extern __shared__ unsigned short s_cs[];  // [n_cams][kGridCells + 1] camera-local offsets (< kMaxKeys: 16 bits)
@@ -342,7 +343,8 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
     for (int i = threadIdx.x; i < A.n_cams * (kGridCells + 1); i += 256) s_cs[i] = (unsigned short)cs[i];
   }
   // queries past nq: empty records (the replay never reads them, but keep the buffer defined)
-  for (int q = nq + blockIdx.x * 256 + threadIdx.x; q < A.q_cap; q += kSbpBlocks * 256)
+  const int n_blocks = gridDim.x;
+  for (int q = nq + blockIdx.x * 256 + threadIdx.x; q < A.q_cap; q += n_blocks * 256)
     A.qrec[(size_t)f * A.q_cap + q] = make_int2(0, 0);
   __syncthreads();
   const uint8_t* D = A.desc + (size_t)img * A.key_cap * 32;
@@ -373,7 +375,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   // wavefront-per-query form below, which recomputes the same predicate and skips the small ones.
   {
     const int g = lane >> 4, gl = lane & 15;
-    const int stride4 = kSbpBlocks * 16;
+    const int stride4 = n_blocks * 16;
     uint4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0;  // the next iteration's record, fetched an iteration ahead
     {
       const int qf = (blockIdx.x * 4 + wave) * 4 + g;
@@ -525,7 +527,7 @@ __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
       if (k2 >= nbig) break;
       q = s_big[k2];
     } else {
-      const int q0 = own0 + (k2 >> 2) * (kSbpBlocks * 16);
+      const int q0 = own0 + (k2 >> 2) * (n_blocks * 16);
       if (q0 >= nq) break;
       q = q0 + (k2 & 3);
       if (q >= nq) continue;
@@ -1063,7 +1065,7 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
   }
   // candidate pool: 32 per query on average (a single query may hold up to kCandCap), plus the unused tail of one slab
   // per wavefront of k_sbp_candidates
-  A.pool_cap = std::max(std::min(A.q_cap, 2 * kMaxKeys) * 32, 2 * kCandCap) + kSbpBlocks * 4 * kCandCap;
+  A.pool_cap = std::max(std::min(A.q_cap, 2 * kMaxKeys) * 32, 2 * kCandCap) + kSbpBlocksFew * 4 * kCandCap;
   static const int pool_lds_env = [] {
     const char* e = getenv("VIEO_SBP_POOL_LDS");
     return e ? atoi(e) : 0;
@@ -1087,7 +1089,10 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
   A.cell_start = S.cell_start.as<int>(), A.cell_rec = S.cell_rec.as<float4>(), A.cell_ang = S.cell_ang.as<float>();
   hipLaunchKernelGGL(k_sbp_grid, dim3(n_frames * A.n_cams), dim3(256), 0, st, A, S.cell_start.as<int>(),
                      S.cell_rec.as<float4>(), S.cell_ang.as<float>());
-  hipLaunchKernelGGL(k_sbp_candidates, dim3(kSbpBlocks, n_frames), dim3(256),
+  // (VIEO_SBP_BLOCKS: tests pin the block count to reach the per-block list's overflow path with few queries)
+  const char* e_blocks = getenv("VIEO_SBP_BLOCKS");
+  const int n_blocks = e_blocks && atoi(e_blocks) > 0 ? std::min(atoi(e_blocks), kSbpBlocksFew) : (n_frames <= 2 ? kSbpBlocksFew : kSbpBlocks);
+  hipLaunchKernelGGL(k_sbp_candidates, dim3(n_blocks, n_frames), dim3(256),
                      (size_t)A.n_cams * (kGridCells + 1) * sizeof(unsigned short), st, A);
   // VIEO_SBP_ASSIGN=seq: only the sequential replay (A/B runs, tests); VIEO_SBP_MAX_ROUNDS: rounds before a frame is
   // handed to it (1 = every frame with any dependency falls back)
