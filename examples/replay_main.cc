@@ -24,10 +24,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "vieo_hot.h"
@@ -151,7 +154,21 @@ struct Replay {
   std::vector<vieo_navstate> traj;
   FramePtr last;
   bool map_updated = false;
-  int n_lba = 0, lba_version = 0, local_version = 0, widened = 0;
+  int n_lba = 0, n_lba_applied = 0, lba_version = 0, local_version = 0, widened = 0;
+  // LocalMapping beside Tracking (src/LocalMapping.cc:113-139): the local BA of the key frame made at frame k is solved on
+  // its own host thread (the library call is re-entrant, its kernels run on the bundle-adjustment stream below the
+  // tracker's) and its write-back reaches the tracker before frame k + lba_lag; lba_lag = 0: inline, before frame k + 1.
+  int lba_lag = 0, lba_due = -1;
+  struct LbaJob;
+  std::unique_ptr<LbaJob> job;
+  // the LocalMapping thread: ONE persistent host thread (the library keeps its scratch buffers per calling thread; a
+  // thread per job would allocate and free them every key frame)
+  std::thread lba_thread;
+  std::mutex lba_m;
+  std::condition_variable lba_cv;
+  LbaJob* lba_todo = nullptr;
+  bool lba_busy = false, lba_quit = false;
+
   std::vector<long> lp;  // cached local-map candidates
   std::vector<vieo_frustum_point> lp_pts;
   std::vector<uint8_t> lp_desc;
@@ -182,6 +199,14 @@ struct Replay {
     CHECK(vieo_orb_create(&extR, NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH));
   }
   ~Replay() {
+    if (lba_thread.joinable()) {
+      {
+        std::lock_guard<std::mutex> g(lba_m);
+        lba_quit = true;
+      }
+      lba_cv.notify_all();
+      lba_thread.join();
+    }
     vieo_tracker_destroy(trk);
     vieo_orb_destroy(extL), vieo_orb_destroy(extR);
   }
@@ -282,14 +307,33 @@ struct Replay {
     }
   }
 
-  // Optimizer::LocalBundleAdjustmentNavStatePRV on the last n_local key frames
-  void local_ba() {
-    const int nk = (int)kfs.size(), first = std::max(0, nk - n_local);
+  // Optimizer::LocalBundleAdjustmentNavStatePRV on the last n_local key frames: the flattened problem (a snapshot of the
+  // map when the key frame was made), the solve, the write-back
+  struct Row { int kid, key; };
+  struct LbaJob {
     std::vector<int> local;
+    std::vector<long> pts;
+    std::vector<vieo_lba_keyframe> K;
+    std::vector<vieo_lba_obs> obs;
+    std::vector<Row> rows;
+    std::vector<vieo_lba_imu_edge> edges;
+    vieo_lba_vio_params P;
+    std::vector<float> X, Xo;
+    std::vector<uint8_t> close, erase;
+    std::vector<vieo_navstate> navs;
+    vieo_lba_result res;
+    double ms = 0;
+    int rc = 0;
+  };
+  std::unique_ptr<LbaJob> lba_build() {
+    std::unique_ptr<LbaJob> Jp(new LbaJob());
+    LbaJob& J = *Jp;
+    const int nk = (int)kfs.size(), first = std::max(0, nk - n_local);
+    std::vector<int>& local = J.local;
     for (int k = first; k < nk; k++) local.push_back(k);
     std::vector<char> is_local(nk, 0);
     for (int k : local) is_local[k] = 1;
-    std::vector<long> pts;
+    std::vector<long>& pts = J.pts;
     {
       std::vector<char> seen(mp_bad.size(), 0);
       for (int k : local)  // lLocalMapPoints: key frames oldest first, keys in order
@@ -306,15 +350,13 @@ struct Replay {
     order.insert(order.end(), fixed_ids.begin(), fixed_ids.end());
     std::vector<int> index(nk, -1);
     for (size_t i = 0; i < order.size(); i++) index[order[i]] = (int)i;
-    std::vector<vieo_lba_keyframe> K(order.size());
+    std::vector<vieo_lba_keyframe>& K = J.K;
+    K.resize(order.size());
     std::memset(K.data(), 0, K.size() * sizeof(vieo_lba_keyframe));
     for (size_t i = 0; i < order.size(); i++) {
       K[i].nav = kfs[order[i]]->nav;
       K[i].fixed = (i >= local.size() || order[i] == 0) ? 1 : 0;
     }
-    struct Row { int kid, key; };
-    std::vector<vieo_lba_obs> obs;
-    std::vector<Row> rows;
     for (size_t j = 0; j < pts.size(); j++)
       for (const auto& kv : mp_obs[pts[j]])
         if (index[kv.first] >= 0) {
@@ -323,9 +365,8 @@ struct Replay {
           o.kf = index[kv.first], o.mp = (int)j;
           o.u = k.keys[kv.second].x, o.v = k.keys[kv.second].y, o.ur = k.uright[kv.second];
           o.inv_sigma2 = inv_sigma2[k.keys[kv.second].octave];
-          obs.push_back(o), rows.push_back(Row{kv.first, kv.second});
+          J.obs.push_back(o), J.rows.push_back(Row{kv.first, kv.second});
         }
-    std::vector<vieo_lba_imu_edge> edges;
     for (int k : local)
       if (k > 0 && index[k - 1] >= 0 && kfs[k]->has_edge) {
         vieo_lba_imu_edge e;
@@ -333,9 +374,9 @@ struct Replay {
         e.kf_i = index[k - 1], e.kf_j = index[k];
         e.dt_kf = kfs[k]->t - kfs[k - 1]->t;
         e.imu = kfs[k]->edge;
-        edges.push_back(e);
+        J.edges.push_back(e);
       }
-    vieo_lba_vio_params P;
+    vieo_lba_vio_params& P = J.P;
     std::memset(&P, 0, sizeof(P));
     for (int r = 0; r < 3; r++) {
       for (int c = 0; c < 3; c++) P.base.Rcb[r * 3 + c] = Tcb[r * 4 + c];
@@ -347,34 +388,83 @@ struct Replay {
     P.inv_sigma_bg2 = 1.0 / (IMU_SIGMA[2] * IMU_SIGMA[2]), P.inv_sigma_ba2 = 1.0 / (IMU_SIGMA[3] * IMU_SIGMA[3]);
     P.lambda_init = 1.0;
     P.qRbe[0] = 1.0;
-    std::vector<float> X(pts.size() * 3), Xo(pts.size() * 3);
+    J.X.resize(pts.size() * 3), J.Xo.resize(pts.size() * 3);
     for (size_t j = 0; j < pts.size(); j++)
-      for (int r = 0; r < 3; r++) X[3 * j + r] = mp_X[3 * pts[j] + r];
-    std::vector<uint8_t> close(pts.size(), 0), erase(std::max<size_t>(obs.size(), 1), 0);
-    std::vector<vieo_navstate> navs(order.size());
-    vieo_lba_result res;
+      for (int r = 0; r < 3; r++) J.X[3 * j + r] = mp_X[3 * pts[j] + r];
+    J.close.assign(pts.size(), 0), J.erase.assign(std::max<size_t>(J.obs.size(), 1), 0);
+    J.navs.resize(order.size());
+    return Jp;
+  }
+  static void lba_solve(LbaJob* J) {  // (any host thread)
     const auto t0 = std::chrono::steady_clock::now();
-    CHECK(vieo_local_bundle_adjustment_vio(&P, K.data(), (int)K.size(), X.data(), close.data(), (int)pts.size(), obs.data(),
-                                           (int)obs.size(), edges.data(), (int)edges.size(), nullptr, navs.data(), Xo.data(),
-                                           erase.data(), &res));
-    ms_lba += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    n_lba++;
-    if (res.status != 0) return;
-    for (size_t r = 0; r < obs.size(); r++)  // ErasePairObs
-      if (erase[r]) {
-        const long m = pts[obs[r].mp];
-        mp_obs[m].erase(rows[r].kid);
-        kfs[rows[r].kid]->mp_ref[rows[r].key] = -1;
+    J->rc = vieo_local_bundle_adjustment_vio(&J->P, J->K.data(), (int)J->K.size(), J->X.data(), J->close.data(), (int)J->pts.size(),
+                                             J->obs.data(), (int)J->obs.size(), J->edges.data(), (int)J->edges.size(), nullptr,
+                                             J->navs.data(), J->Xo.data(), J->erase.data(), &J->res);
+    J->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  void lba_apply(LbaJob& J) {
+    if (J.rc != 0) std::fprintf(stderr, "local BA failed: %s\n", vieo_last_error()), std::exit(1);
+    ms_lba += J.ms;
+    n_lba_applied++;
+    if (J.res.status != 0) return;
+    for (size_t r = 0; r < J.obs.size(); r++)  // ErasePairObs
+      if (J.erase[r]) {
+        const long m = J.pts[J.obs[r].mp];
+        mp_obs[m].erase(J.rows[r].kid);
+        kfs[J.rows[r].kid]->mp_ref[J.rows[r].key] = -1;
         if (mp_obs[m].empty()) mp_bad[m] = 1;
       }
-    for (size_t i = 0; i < local.size(); i++)
-      if (!K[i].fixed) {
-        kfs[local[i]]->nav = navs[i];
-        pose_of(*kfs[local[i]]);
+    for (size_t i = 0; i < J.local.size(); i++)
+      if (!J.K[i].fixed) {
+        kfs[J.local[i]]->nav = J.navs[i];
+        pose_of(*kfs[J.local[i]]);
       }
-    for (size_t j = 0; j < pts.size(); j++)
-      for (int r = 0; r < 3; r++) mp_X[3 * pts[j] + r] = Xo[3 * j + r];
-    update_normal_depth(pts);
+    for (size_t j = 0; j < J.pts.size(); j++)
+      for (int r = 0; r < 3; r++) mp_X[3 * J.pts[j] + r] = J.Xo[3 * j + r];
+    update_normal_depth(J.pts);
+  }
+  void local_ba() {  // inline: LocalMapping before the next frame
+    std::unique_ptr<LbaJob> J = lba_build();
+    lba_solve(J.get());
+    n_lba++;
+    lba_apply(*J);
+  }
+  void lba_worker() {
+    for (;;) {
+      LbaJob* J;
+      {
+        std::unique_lock<std::mutex> g(lba_m);
+        lba_cv.wait(g, [&] { return lba_todo || lba_quit; });
+        if (lba_quit) return;
+        J = lba_todo, lba_todo = nullptr;
+      }
+      lba_solve(J);
+      {
+        std::lock_guard<std::mutex> g(lba_m);
+        lba_busy = false;
+      }
+      lba_cv.notify_all();
+    }
+  }
+  void lba_submit(LbaJob* J) {
+    if (!lba_thread.joinable()) lba_thread = std::thread(&Replay::lba_worker, this);
+    {
+      std::lock_guard<std::mutex> g(lba_m);
+      lba_todo = J, lba_busy = true;
+    }
+    lba_cv.notify_all();
+  }
+  // the pending write-back reaches the tracker before frame k
+  void before_frame(int k) {
+    if (job && k >= lba_due) {
+      {
+        std::unique_lock<std::mutex> g(lba_m);
+        lba_cv.wait(g, [&] { return !lba_busy; });
+      }
+      lba_apply(*job);
+      job.reset();
+      map_updated = true;
+    }
   }
 
   void initialise() {
@@ -392,8 +482,8 @@ struct Replay {
   }
 
   void local_points() {  // all points of the local key frames (rebuilt when a key frame came in / a local BA ran)
-    if (lp_key_kfs == kfs.size() && lp_key_lba == n_lba) return;
-    lp_key_kfs = kfs.size(), lp_key_lba = n_lba;
+    if (lp_key_kfs == kfs.size() && lp_key_lba == n_lba_applied) return;
+    lp_key_kfs = kfs.size(), lp_key_lba = n_lba_applied;
     lp.clear();
     std::vector<char> seen(mp_bad.size(), 0);
     for (size_t k = kfs.size() > (size_t)n_local_kfs ? kfs.size() - n_local_kfs : 0; k < kfs.size(); k++)
@@ -485,10 +575,18 @@ struct Replay {
       for (int i = 0; i < f->N; i++)
         if (f->outlier[i]) f->mp_ref[i] = -1;
       insert_keyframe(f, f->nav, &im);
-      local_ba();
-      f->nav = kfs.back()->nav;  // mLastFrame follows its reference key frame (UpdateLastFrame)
+      if (lba_lag <= 0) {
+        local_ba();
+        f->nav = kfs.back()->nav;  // mLastFrame follows its reference key frame (UpdateLastFrame)
+        map_updated = true;
+      } else {
+        before_frame(k + lba_lag + kf_every);  // (a job still pending is applied first)
+        job = lba_build();
+        n_lba++;
+        lba_due = k + lba_lag;
+        lba_submit(job.get());
+      }
       std::fill(f->outlier.begin(), f->outlier.end(), 0);
-      map_updated = true;
     }
     last = f;
     traj.push_back(f->nav);
@@ -499,17 +597,19 @@ struct Replay {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::fprintf(stderr, "usage: %s seq.vseq [traj.bin] [--frames N] [--warmup M] [--quiet]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s seq.vseq [traj.bin] [--frames N] [--warmup M] [--lba-lag L] [--quiet]\n", argv[0]);
     return 2;
   }
   const char* traj_path = nullptr;
-  int n_frames = -1, warmup = 0;
+  int n_frames = -1, warmup = 0, lba_lag = 0;
   bool quiet = false;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--frames") && i + 1 < argc)
       n_frames = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--warmup") && i + 1 < argc)
       warmup = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--lba-lag") && i + 1 < argc)
+      lba_lag = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--quiet"))
       quiet = true;
     else
@@ -527,13 +627,17 @@ int main(int argc, char** argv) {
   const int n = n_frames > 0 ? std::min(n_frames, S.n_frames) : S.n_frames;
   if (warmup > 1) {
     Replay Wm(S);
+    Wm.lba_lag = lba_lag;
     Wm.initialise();
-    for (int k = 1; k < std::min(warmup, S.n_frames); k++) Wm.step(k);
+    for (int k = 1; k < std::min(warmup, S.n_frames); k++) Wm.before_frame(k), Wm.step(k);
+    Wm.before_frame(1 << 30);
   }
   Replay R(S);
+  R.lba_lag = lba_lag;
   R.initialise();
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = 1; k < n; k++) {
+    R.before_frame(k);
     R.step(k);
     if (!quiet && k % 10 == 0) {
       const double* tr = &S.truth[(size_t)k * 10];
@@ -543,6 +647,7 @@ int main(int argc, char** argv) {
     }
   }
   const double ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  R.before_frame(1 << 30);  // (a solve still running is waited for outside the timed frames: its frames are not in the run)
   double emax = 0, e2 = 0;
   for (int k = 0; k < n; k++) {
     const double* tr = &S.truth[(size_t)k * 10];
@@ -561,8 +666,8 @@ int main(int argc, char** argv) {
   const int nf = n - 1;
   std::printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"ms_track_call\": %.4f, \"ms_track_gpu\": %.4f, "
               "\"ms_frame_without_local_ba\": %.4f, \"local_bas\": %d, \"ms_per_local_ba\": %.4f, \"key_frames\": %zu, "
-              "\"map_points\": %zu, \"widened\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e}\n",
+              "\"map_points\": %zu, \"widened\": %d, \"lba_lag\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e}\n",
               nf, ms_total / nf, 1e3 * nf / ms_total, R.ms_track / nf, R.ms_gpu / nf, R.ms_frames / nf, R.n_lba,
-              R.n_lba ? R.ms_lba / R.n_lba : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, std::sqrt(e2 / n), emax);
+              R.n_lba ? R.ms_lba / R.n_lba : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, lba_lag, std::sqrt(e2 / n), emax);
   return 0;
 }

@@ -154,6 +154,45 @@ def test_gpu_cpp_replay_without_python(tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_cpp_replay_local_ba_beside_tracking(oracle, tmp_path):
+    """LocalMapping beside Tracking (src/LocalMapping.cc:113-139): examples/replay_main --lba-lag 3 solves a key frame's
+    local BA on its own host thread while the next frames are tracked and applies the write-back before the third frame
+    after the key frame.  The same lag in the Python driver (solve at once, hold the result back) gives the same map for
+    the same frames: the C++ run equals the Python tracker run, and both stay within 1e-4 of the ORACLE replay with
+    that lag -- the trajectory the concurrent run is checked against."""
+    import json
+    from tests.replay_oracle import OracleStages
+    from tools.write_sequence import write_sequence
+    from vieo_slam_amd.ba_types import NAVSTATE_DTYPE
+    from vieo_slam_amd.tracker import TrackerReplay
+    exe = os.path.join(ROOT, "examples", "replay_main")
+    n, lag = 60, 3
+    seq = replay.Sequence(1, n)
+    path, traj_path = str(tmp_path / "seq.vseq"), str(tmp_path / "traj.bin")
+    write_sequence(path, 1, n, seq)
+    line = subprocess.check_output([exe, path, traj_path, "--quiet", "--lba-lag", str(lag)], timeout=600).decode().strip().splitlines()[-1]
+    r = json.loads(line)
+    tc = np.fromfile(traj_path, NAVSTATE_DTYPE)
+    Rt = TrackerReplay(seq, replay.HipStages(), lba_lag=lag)
+    tt = Rt.run(n)
+    Rt.close()
+    Ro = replay.Replay(seq, OracleStages(oracle), lba_lag=lag)
+    to = Ro.run(n)
+    assert r["lba_lag"] == lag and r["local_bas"] == Rt.stats["lba"] == Ro.stats["lba"] == 5
+    d = np.linalg.norm(tc["p"] - tt["p"], axis=1)
+    assert d.max() <= 1e-6, d.max()
+    ate = replay.ate_between(tc, to)
+    assert ate <= 1e-4 and np.linalg.norm(tc["p"] - to["p"], axis=1).max() <= 1e-4, ate
+    # the lag changes the run (the frames between a key frame and its write-back see the old map)
+    R0 = TrackerReplay(seq, replay.HipStages())
+    t0 = R0.run(n)
+    R0.close()
+    assert 1e-7 < np.linalg.norm(t0["p"] - tt["p"], axis=1).max() < 5e-3
+    print("C++ replay, local BA beside tracking (lag %d): %.3f ms per frame (tracking call %.3f), ATE vs the oracle run %.2e m"
+          % (lag, r["ms_per_frame"], r["ms_track_call"], ate))
+
+
+@pytest.mark.gpu
 def test_gpu_three_host_threads_concurrently(oracle):
     """the back end must be re-entrant across >= 3 host threads.  Tracking (vieo_track_frame per frame, with
     its key-frame local BAs), LocalMapping-style work (visual-inertial local BAs and a vision-only pose optimisation that

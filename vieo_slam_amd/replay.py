@@ -169,7 +169,14 @@ def _Tcw_of(nav, Tbc):
 
 
 class Replay:
-    def __init__(self, seq, stages, kf_every=10, n_local=10, n_local_kfs=10, th_last=7.0, th_local=2.0, verbose=False):
+    def __init__(self, seq, stages, kf_every=10, n_local=10, n_local_kfs=10, th_last=7.0, th_local=2.0, verbose=False,
+                 lba_lag=0):
+        # LocalMapping runs beside Tracking in the reference (src/LocalMapping.cc:113-139): the local BA of a key frame
+        # made at frame k works on the map as it was then, and its write-back reaches the tracker some frames later.  A
+        # fixed lag makes that reproducible: lba_lag = 0 applies the result before frame k + 1 (the inline form), lba_lag = L
+        # before frame k + L (the C++ replay overlaps the solve with the L - 1 frames in between; here it is solved at
+        # once and held back, which is the same map for the same frames).
+        self.lba_lag, self._pending = int(lba_lag), None
         self.seq, self.S = seq, stages
         self.kf_every, self.n_local, self.n_local_kfs = kf_every, n_local, n_local_kfs
         self.th_last, self.th_local = th_last, th_local
@@ -188,7 +195,7 @@ class Replay:
         self.mp_mind = np.zeros(0, np.float32)
         self.kfs = []         # key frames: _Frame with id / nav / keys / mp_ref / imu edge from the previous one
         self.traj = []        # optimised NavState per frame
-        self.stats = dict(frames=0, lba=0, ms_frames=[], ms_lba=[], n_matches=[], n_inliers=[])
+        self.stats = dict(frames=0, lba=0, lba_applied=0, ms_frames=[], ms_lba=[], n_matches=[], n_inliers=[])
         self.last = None
         self.map_updated = False
 
@@ -264,7 +271,7 @@ class Replay:
         return kf
 
     # ---- Optimizer::LocalBundleAdjustmentNavStatePRV on the last n_local key frames
-    def local_ba(self):
+    def local_ba(self, apply=True):
         local = self.kfs[-self.n_local:]
         first = local[0].id
         prev = self.kfs[first - 1] if first > 0 else None
@@ -326,6 +333,16 @@ class Replay:
         navs, Xo, erase, res = self.S.lba_vio(P, kfs, X, close, obs, imu)
         self.stats["ms_lba"].append(1e3 * (time.perf_counter() - t0))
         self.stats["lba"] += 1
+        job = dict(local=local, kfs=kfs, pts=pts, rows=rows, navs=navs, Xo=Xo, erase=erase, res=res)
+        if apply:
+            self._lba_apply(job)
+        return job
+
+    def _lba_apply(self, job):
+        """the write-back of Optimizer::LocalBundleAdjustmentNavStatePRV (Optimizer.cc:704-768)"""
+        local, kfs, pts, rows, navs, Xo, erase, res = (job[k] for k in ("local", "kfs", "pts", "rows", "navs", "Xo", "erase",
+                                                                         "res"))
+        self.stats["lba_applied"] += 1
         if int(res["status"]) != 0:
             return res
         for r in np.nonzero(erase)[0]:  # ErasePairObs
@@ -503,10 +520,15 @@ class Replay:
             f.mp_ref[f.outlier] = -1
             kf = self.insert_keyframe(f, f.nav, edge)
             self.stats["ms_frames"].append(1e3 * (time.perf_counter() - t0))
-            res = self.local_ba()
-            f.nav = kf.nav.copy()  # mLastFrame follows its reference key frame (UpdateLastFrame)
+            if self.lba_lag <= 0:
+                res = self.local_ba()["res"]
+                f.nav = kf.nav.copy()  # mLastFrame follows its reference key frame (UpdateLastFrame)
+                self.map_updated = True
+            else:
+                self.before_frame(k + 1)  # (a job still pending from the previous key frame is applied first)
+                job = self.local_ba(apply=False)
+                self._pending, res = (k + self.lba_lag, job), job["res"]
             f.outlier = np.zeros(f.N, bool)
-            self.map_updated = True
             if self.verbose:
                 print("  kf %d: lba status %d, %d trials, chi2 %.1f -> %.1f" % (
                     kf.id, int(res["status"]), int(res["lm_trials"]), res["chi2_initial"], res["chi2_final"]))
@@ -529,10 +551,18 @@ class Replay:
             c["fx"], c["fy"], c["cx"], c["cy"] = sc.FX, sc.FY, sc.CX, sc.CY
         return self._cam
 
+    def before_frame(self, k):
+        """LocalMapping's pending write-back reaches the tracker before frame k (lba_lag)"""
+        if self._pending is not None and k >= self._pending[0]:
+            job, self._pending = self._pending[1], None
+            self._lba_apply(job)
+            self.map_updated = True
+
     def run(self, n_frames=None):
         n = n_frames or self.seq.n_frames
         self.initialise()
         for k in range(1, n):
+            self.before_frame(k)
             self.step(k)
         return np.array(self.traj, NAVSTATE_DTYPE)
 
@@ -656,7 +686,7 @@ class ChainedReplay(Replay):
 
     def _all_local_points(self):
         # the local key frames and their points change only when a key frame is inserted / a local BA has run
-        key = (len(self.kfs), self.stats["lba"])
+        key = (len(self.kfs), self.stats["lba_applied"])
         if getattr(self, "_lp_key", None) == key:
             return self._lp
         self._lp_key, self._lp = key, self._all_local_points_now()

@@ -216,7 +216,7 @@ class TrackerReplay(rp.Replay):
         self.trk.close()
 
     def _all_local_points(self):
-        key = (len(self.kfs), self.stats["lba"])
+        key = (len(self.kfs), self.stats["lba_applied"])
         if getattr(self, "_lp_key", None) != key:
             out, seen = [], set()
             for k in self.kfs[-self.n_local_kfs:]:
