@@ -232,6 +232,248 @@ README_FRONTEND_MS = {"value": 35.0, "source": "/root/reference/README.md:60 'Fi
                       "published figure for the front end of this configuration, NOT measured here"}
 
 
+README_FRONTEND_DIST_MS = {"value": 43.0, "source": "/root/reference/README.md:44-46,60: the same line's first figure, 43.X ms, is the "
+                           "front end of the DEFAULT (distorted stereo, EuRoC_VIO_dist*.yaml) MH05 configuration; NOT measured here"}
+
+
+def _rig_tracker_inputs(fe, fr0, mps, case):
+    """mLastFrame / the local map of the one-call rig tracker from a stage-by-stage frame 0 (as tests/test_tracker_rig.py)"""
+    from vieo_slam_amd.map_point import FRUSTUM_POINT_DTYPE
+    pts = fe.last_frame_points(fr0, mps)
+    has = mps["key_mp"] >= 0
+    pts["reserved"][has, 0] = mps["first_key"][mps["key_mp"][has]] + 1
+    z = fr0.fe["group_p3d"][np.nonzero(fr0.fe["group_good"])[0]][:, 2].astype(np.float32)
+    last_depth = np.full(fr0.N, np.inf, np.float32)
+    last_depth[has] = z[mps["key_mp"][has]]
+    _, P = fe._frustum(np.eye(3, 4), mps, case["pose0"])
+    return pts, last_depth, np.ascontiguousarray(P, FRUSTUM_POINT_DTYPE), mps["first_key"].astype(np.int32)
+
+
+def rig_single_stream(rig, n_cams, nfeat, seed, n_cases=3, reps=10):
+    """One-call tracker of a distorted camera rig (vieo_tracker_create_rig + vieo_track_frame): ms per rig frame over
+    `n_cases` rendered frame pairs x `reps` calls each (the last frame's map points come from a stage-by-stage frame 0,
+    untimed).  There is no rig SEQUENCE driver (map management for rigs is the caller's): this is the tracking call's
+    latency on single frames, the figure the rectified replay reports as ms_per_frame_tracking_call."""
+    from vieo_slam_amd import synth_ba
+    from vieo_slam_amd import synth_scene as sc
+    from vieo_slam_amd.pipeline_rig import RigFrontEnd
+    from vieo_slam_amd.tracker import Tracker, rig_params
+    scene = sc.RigScene(seed, rig, n_cams)
+    fe = RigFrontEnd(scene, nfeat)
+    ms, gpu, errs, keys, m1, m2, inl = [], [], [], [], [], [], []
+    trk = None
+    for i in range(n_cases):
+        case = sc.make_rig_tracking_case(seed + 10 * i, scene)
+        fr0 = fe.make_frame(case["images0"])
+        mps = fe.make_map_points(fr0, case["pose0"][2], case["pose0"][3])
+        pts, ld, P, alias = _rig_tracker_inputs(fe, fr0, mps, case)
+        if trk is None:
+            prm, rg = rig_params(scene, nfeat, max_local_points=4096)
+            trk = Tracker(prm, rg)
+        nav = case["vio"][0]["nav_last"]
+        call = lambda: trk.track(None, None, case["imu_samples"], 0.0, case["dt_frame"], nav, nav, None, pts, ld, P, mps["desc"],
+                                 alias, i + 1, images=case["images1"])
+        call()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            o, v = call()
+            t.append(1e3 * (time.perf_counter() - t0))
+        ms.append(float(np.median(t))), gpu.append(float(o["ms_gpu"]))
+        errs.append(float(synth_ba.pose_error(o["second"]["base"]["nav"], case["truth"])[0]))
+        keys.append(int(o["n_keys"])), m1.append(int(o["n_matches_last"])), m2.append(int(o["n_matches_local"]))
+        inl.append(int(o["second"]["base"]["n_inliers"]))
+    trk.close()
+    v = float(np.mean(ms))
+    return {"config": "%d-camera %s rig, %d features per camera, %dx%d" % (n_cams, rig, nfeat, scene.W, scene.H),
+            "ms_per_rig_frame": v, "rig_frames_per_s": 1e3 / v, "ms_per_rig_frame_gpu": float(np.mean(gpu)),
+            "ms_per_case": ms, "host_syncs_per_frame": 1, "mean_keys_per_frame": float(np.mean(keys)),
+            "mean_matches_last_frame": float(np.mean(m1)), "mean_matches_local_map": float(np.mean(m2)),
+            "mean_pose_inliers": float(np.mean(inl)), "max_position_error_vs_truth_m": float(max(errs)),
+            "path": "ONE vieo_track_frame call per rig frame: one copy up, ExtractORB x n_cams (one batch launch chain) + IMU "
+                    "pre-integration beside it, ComputeStereoFishEyeMatches on the device (knn-2 of every camera pair, pair "
+                    "triangulation, FillMatchesFromPair as a speculative-parallel walk, all-camera re-triangulation), "
+                    "PredictNavStateByIMU, SearchByProjection(last frame, camera loop) -> PoseOptimization(rig) -> isInFrustum + "
+                    "queries -> SearchByProjection(local map) -> PoseOptimization(rig, marg), one copy back, ONE synchronisation"}
+
+
+def rig_frontend_batch(rig="kb8", n_cams=4, nfeat=1500, seed=300, n_frames=64, steps=5):
+    """Frame::Frame of a BATCH of rig frames device-resident (BASELINE configs[3] shape): ExtractORB of n_frames x n_cams
+    images in one batch call, then ComputeStereoFishEyeMatches of all frames as five launches (no host round trip), and
+    the roofline of the stage's dense kernel: k_knn2 = the Hamming brute-force search north_star names."""
+    import ctypes
+    from vieo_slam_amd import synth_scene as sc
+    from vieo_slam_amd import synth_fisheye as sf
+    from vieo_slam_amd._lib import DeviceBuffer, check, lib
+    from vieo_slam_amd.ba_types import FISHEYE_PARAMS_DTYPE
+    from vieo_slam_amd.matching import FisheyeStereoDevice
+    from vieo_slam_amd.orb_extractor import KEYPOINT_DTYPE, ORBextractor
+    L = lib()
+    scene = sc.RigScene(seed, rig, n_cams)
+    frames = []
+    for i in range(3):
+        c = sc.make_rig_tracking_case(seed + 10 * i, scene)
+        frames += [c["images0"], c["images1"]]
+    Wd, Hd = scene.W, scene.H
+    imgs = np.stack([np.stack(frames[f % len(frames)]) for f in range(n_frames)])  # [frame][cam][H][W]
+    ext = ORBextractor(nfeat, 1.2, 8, 20, 7)
+    cap = ext.max_keypoints()
+    lap = [0, Wd - 1] if int(scene.cams[0]["model"]) == 2 else None
+    sig2 = np.ascontiguousarray((np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2, np.float32)
+    Trc, Tcr = sf.rig_extrinsics(scene.Tcr)
+    fp = np.zeros(1, FISHEYE_PARAMS_DTYPE)
+    fp[0]["n_cams"], fp[0]["n_levels"], fp[0]["bf"], fp[0]["th_far_pts"] = n_cams, 8, 0.11 * float(scene.cams[0]["fx"]), 0.0
+    fp[0]["cams"], fp[0]["Trc"], fp[0]["Tcr"], fp[0]["level_sigma2"] = (scene.cams.ctypes.data, Trc.ctypes.data,
+                                                                        Tcr.ctypes.data, sig2.ctypes.data)
+    fe = FisheyeStereoDevice(fp, cap, max_frames=n_frames)
+    gcap, kc, n_img = fe.gcap, n_cams * cap, n_frames * n_cams
+    d_img = DeviceBuffer(imgs.nbytes)
+    d_img.upload(imgs)
+    sizes = dict(kp=n_img * cap * KEYPOINT_DTYPE.itemsize, desc=n_img * cap * 32, cnt=n_img * 8, kcat=n_frames * kc * KEYPOINT_DTYPE.itemsize,
+                 dcat=n_frames * kc * 32, first=n_frames * (n_cams + 1) * 4, fcnt=n_frames * 8, depth=n_frames * kc * 4,
+                 ur=n_frames * kc * 4, kg=n_frames * kc * 4, gidx=n_frames * gcap * n_cams * 4, good=n_frames * gcap,
+                 p3d=n_frames * gcap * 24, hdr=n_frames * 32)
+    d = {k: DeviceBuffer(max(v, 16)) for k, v in sizes.items()}
+    st = ctypes.c_void_p(L.vieo_orb_stream(ext._h))
+
+    def step():
+        ext.extract_batch_device(d_img.ptr, n_img, Wd, Hd, Wd, Wd * Hd, d["kp"].ptr, d["desc"].ptr, cap, d["cnt"].ptr, lapping=lap)
+        check(L.vieo_stereo_fisheye_match_batch_device(fe.h, d["kp"].ptr, d["desc"].ptr, d["cnt"].ptr, n_frames, d["kcat"].ptr,
+                                                       d["dcat"].ptr, d["first"].ptr, d["fcnt"].ptr, d["depth"].ptr, d["ur"].ptr,
+                                                       d["kg"].ptr, d["gidx"].ptr, d["good"].ptr, d["p3d"].ptr, d["hdr"].ptr, st),
+              "vieo_stereo_fisheye_match_batch_device")
+    step()
+    ext.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ext.sync()
+    dt = (time.perf_counter() - t0) / steps
+    hdr = d["hdr"].download(np.int32, (n_frames, 8))
+    cnt = d["cnt"].download(np.int32, (n_frames, n_cams, 2))
+    # ---- k_knn2 alone between two events on the extractor's stream
+    n_pairs = n_cams * (n_cams - 1) // 2
+    d_idx, d_dist = DeviceBuffer(n_frames * n_pairs * cap * 8), DeviceBuffer(n_frames * n_pairs * cap * 8)
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    check(L.vieo_event_create(ctypes.byref(e0))), check(L.vieo_event_create(ctypes.byref(e1)))
+    K = 20
+    for k in range(K + 2):
+        if k == 2:
+            check(L.vieo_event_record(e0, st))
+        check(L.vieo_hamming_knn2_rig_batch_device(d["desc"].ptr, d["cnt"].ptr, cap, n_cams, n_frames, d_idx.ptr, d_dist.ptr, st))
+    check(L.vieo_event_record(e1, st))
+    ext.sync()
+    ms = ctypes.c_float()
+    check(L.vieo_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+    launch_ms = ms.value / K
+    alg, ops = 0.0, 0.0
+    for f in range(n_frames):
+        for i in range(n_cams - 1):
+            for j in range(i + 1, n_cams):
+                ni, mi, nj, mj = cnt[f, i, 0], cnt[f, i, 1], cnt[f, j, 0], cnt[f, j, 1]
+                if mi >= ni or mj >= nj:
+                    continue
+                nq, nt = float(ni - mi), float(nj - mj)
+                alg += (nq + nt) * 32 + nq * 16  # SURVEY 8d: both descriptor matrices once + two (index, distance) pairs per query
+                ops += nq * nt * 8
+    gbs = alg / (launch_ms * 1e-3) / 1e9
+    L.vieo_event_destroy(e0), L.vieo_event_destroy(e1)
+    for b in list(d.values()) + [d_img, d_idx, d_dist]:
+        b.free()
+    fe.close()
+    return {
+        "config": "BASELINE configs[3] shape: %d frames of a %d-camera %s rig, %d features per camera, device-resident: "
+                  "ExtractORB x %d images in one batch + ComputeStereoFishEyeMatches of the batch (5 launches, no host round "
+                  "trip); replicas of 6 rendered rig frames" % (n_frames, n_cams, rig, nfeat, n_img),
+        "rig_frames_per_s": n_frames / dt, "ms_per_step": 1e3 * dt, "camera_images_per_s": n_img / dt,
+        "mean_keys_per_camera": float(cnt[:, :, 0].mean()), "mean_stereo_groups_per_frame": float(hdr[:, 0].mean()),
+        "fill_matches_walk": {"rows_per_frame": float(hdr[:, 5].mean()), "wavefront_steps_per_frame": float(hdr[:, 6].mean()),
+                              "note": "FillMatchesFromPair's order-dependent group tables on the device: rows applied per "
+                                      "speculative-parallel step = rows / steps (sequential form: 1)"},
+        "roofline_knn2": {"bound": "hbm", "kernel": "k_knn2 (cv::BFMatcher knnMatch k = 2 of every camera pair of every frame, one "
+                                                    "launch; query rows in registers, train rows through LDS tiles)",
+                          "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": launch_ms, "traffic": None,
+                          "xor_popcount_word_ops_per_launch": ops, "word_ops_per_s": ops / (launch_ms * 1e-3),
+                          "note": "SURVEY 8d prices the search by its bytes ((N_q + N_t) 32 + N_q 16 per pair): at N = 1500 "
+                                  "that is 120 KB against 18 M word operations, so the kernel is bound by the integer issue "
+                                  "rate (word_ops_per_s), not by HBM; the fraction of the byte roofline is reported as asked"}}
+
+
+def vision_single_stream(n_cases=3, reps=10):
+    """BASELINE configs[0] (stereo, no IMU, 1000 features): the one-call tracker in vision-only mode
+    (TrackWithMotionModel + TrackLocalMap, Optimizer::PoseOptimization(Frame*, Frame*)) on rendered frame pairs."""
+    from vieo_slam_amd import frontend, synth_ba
+    from vieo_slam_amd import synth_scene as sc
+    from vieo_slam_amd.imu import IMU_SAMPLE_DTYPE
+    from vieo_slam_amd.map_point import FRUSTUM_POINT_DTYPE
+    from vieo_slam_amd.matching import compute_stereo_matches
+    from vieo_slam_amd.orb_extractor import ORBextractor
+    from vieo_slam_amd.tracker import Tracker, euroc_params
+    K = (sc.FX, sc.FY, sc.CX, sc.CY)
+    ex = [ORBextractor(1000, 1.2, 8, 20, 7) for _ in range(2)]
+    scf = ex[0].GetScaleFactors()
+    prm = euroc_params(max_local_points=2048)
+    prm[0]["n_features"], prm[0]["vision_only"] = 1000, 1
+    trk = Tracker(prm)
+    ms, errs, m1, inl = [], [], [], []
+    for i in range(n_cases):
+        case = sc.make_tracking_case(20 + i)
+        k0, d0 = ex[0](case["images0"][0])[1:]
+        k0r, d0r = ex[1](case["images0"][1])[1:]
+        _, dp0 = compute_stereo_matches(ex[0], ex[1], k0, d0, k0r, d0r, sc.BASELINE, sc.BF)
+        Ri, pi, Rwc0, twc0 = case["pose0"]
+        Xw, valid = frontend.unproject_stereo(k0, dp0, K, Rwc0, twc0)
+        pts = frontend.make_last_frame_points(k0, d0, Xw, valid, True)
+        P = np.zeros(len(k0), FRUSTUM_POINT_DTYPE)
+        P["Xw"] = Xw
+        dv = Xw.astype(np.float64) - twc0
+        dist = np.maximum(np.linalg.norm(dv, axis=1), 1e-6)
+        P["normal"] = (dv / dist[:, None]).astype(np.float32)
+        P["max_distance"] = (dist * scf[k0["octave"]]).astype(np.float32)
+        P["min_distance"] = P["max_distance"] / scf[7]
+        sel = np.nonzero(valid)[0]
+        rng = np.random.default_rng(i)
+        nav_pred = case["vio"][0]["base"]["nav"].copy()
+        nav_pred["p"] += rng.normal(0, 0.01, 3)
+        nav_pred["q"] = synth_ba.quat_mul(nav_pred["q"], synth_ba.quat_from_rotvec(rng.normal(0, 0.003, 3)))
+        nav_i = case["vio"][0]["nav_last"]
+        none = np.zeros(0, IMU_SAMPLE_DTYPE)
+        inf = np.full(len(pts), np.inf, np.float32)
+        call = lambda: trk.track(case["images1"][0], case["images1"][1], none, 0.0, 0.05, nav_pred, nav_i, None, pts, inf, P[sel],
+                                 pts["desc"][sel], sel.astype(np.int32), i + 1)
+        call()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            o, v = call()
+            t.append(1e3 * (time.perf_counter() - t0))
+        ms.append(float(np.median(t)))
+        errs.append(float(synth_ba.pose_error(o["second"]["base"]["nav"], case["truth"])[0]))
+        m1.append(int(o["n_matches_last"])), inl.append(int(o["second"]["base"]["n_inliers"]))
+    trk.close()
+    v = float(np.mean(ms))
+    return {"config": "BASELINE configs[0]: rectified stereo WITHOUT IMU, 1000 features, 752x480; vieo_track_frame in vision-only "
+                      "mode (TrackWithMotionModel + TrackLocalMap as one chain, vision-only PoseOptimization x 2)",
+            "ms_per_frame": v, "frames_per_s": 1e3 / v, "ms_per_case": ms, "host_syncs_per_frame": 1,
+            "mean_matches_last_frame": float(np.mean(m1)), "mean_pose_inliers": float(np.mean(inl)),
+            "max_position_error_vs_truth_m": float(max(errs))}
+
+
+def schur_useful_flops(window):
+    """SURVEY 8d's sparsity-aware count of the Schur reduction of ONE LM trial of a local-BA window: per landmark with k free
+    observers 60 (3x3 inverse) + 108 k (W Hll^-1) + 216 k (k + 1) / 2 (the landmark's blocks of Hpp) + 36 k (gradient)."""
+    kfs, obs = window[1], window[4]
+    free = kfs["fixed"] == 0
+    kf = obs["kf"] & 0xFFFFFF
+    k = np.bincount(obs["mp"][free[kf]], minlength=len(window[2])).astype(np.float64)
+    k = k[np.bincount(obs["mp"], minlength=len(window[2])) > 0]
+    return float(np.sum(60 + 108 * k + 216 * k * (k + 1) / 2 + 36 * k))
+
+
+LBA_LAG = 6  # frames between a key frame and the write-back of its local BA in the single_stream leg (0: inline)
+
+
 def single_stream_leg(seq, n_frames):
     """The sequential replay on the C-ABI (see the module docstring).  Headline: examples/replay_main, the replay as a
     C++ program WITHOUT Python -- vieo_track_frame per frame (one chain of launches, one synchronisation), local BA per
@@ -253,10 +495,14 @@ def single_stream_leg(seq, n_frames):
         write_sequence(path, seq.seed, n_frames, seq)
         runs = []
         for _ in range(3):  # the best of three: a fresh box has noisy first seconds
-            line = subprocess.check_output([exe, path, traj, "--warmup", "16", "--quiet"], timeout=900).decode().strip()
+            line = subprocess.check_output([exe, path, traj, "--warmup", "16", "--quiet", "--lba-lag", str(LBA_LAG)],
+                                           timeout=900).decode().strip()
             runs.append(json.loads(line.splitlines()[-1]))
         r = min(runs, key=lambda x: x["ms_per_frame"])
+        # (the trajectory of ANY run with this lag is the same: the lag, not the timing, decides which map a frame sees)
         th = np.fromfile(traj, NAVSTATE_DTYPE)
+        line = subprocess.check_output([exe, path, traj + ".inline", "--warmup", "16", "--quiet"], timeout=900).decode().strip()
+        r_inline = json.loads(line.splitlines()[-1])
     Rs = replay.Replay(seq, replay.HipStages())
     Rs.run(min(12, n_frames))
     Rs = replay.Replay(seq, replay.HipStages())
@@ -267,6 +513,11 @@ def single_stream_leg(seq, n_frames):
     return {
         "frames": n_frames, "local_bas": r["local_bas"],
         "ms_per_frame": r["ms_per_frame"], "frames_per_s": r["frames_per_s"],
+        "local_ba": "beside tracking (src/LocalMapping.cc:113-139): solved on its own host thread on the bundle-adjustment "
+                    "stream, write-back before the %d-th frame after the key frame; the oracle replay it is compared with "
+                    "applies the same lag" % LBA_LAG,
+        "lba_lag_frames": LBA_LAG,
+        "ms_per_frame_local_ba_inline": r_inline["ms_per_frame"], "vs_cpu_threaded": None,
         "ms_per_frame_all_runs": [x["ms_per_frame"] for x in runs],
         "ms_per_frame_tracking_call": r["ms_track_call"], "ms_per_frame_tracking_call_gpu": r["ms_track_gpu"],
         "ms_per_frame_without_local_ba": r["ms_frame_without_local_ba"], "ms_per_local_ba_mean": r["ms_per_local_ba"],
@@ -287,14 +538,14 @@ def single_stream_leg(seq, n_frames):
                 "memory, IMU pre-integration on a second stream beside extraction x2 -> stereo, PredictNavStateByIMU on the "
                 "device, SearchByProjection(last frame) -> PoseOptimization -> isInFrustum + queries from the optimised pose "
                 "in HBM -> SearchByProjection(local map) -> PoseOptimization(marg), one copy back, ONE host synchronisation; "
-                "per key frame (every 10 frames) vieo_imu_preintegrate_batch + vieo_local_bundle_adjustment_vio + "
-                "vieo_update_normal_and_depth_batch; ms_per_frame is wall time of the whole loop incl. the C++ map "
-                "bookkeeping and the local BAs; stage_by_stage = the same replay driven from Python with one synchronous "
+                "per key frame (every 10 frames) vieo_imu_preintegrate_batch + vieo_local_bundle_adjustment_vio (on the "
+                "LocalMapping thread) + vieo_update_normal_and_depth_batch; ms_per_frame is wall time of the whole loop incl. "
+                "the C++ map bookkeeping, the write-backs and any wait for a local BA that is not finished at its frame; stage_by_stage = the same replay driven from Python with one synchronous "
                 "host-pointer call per stage",
     }, th
 
 
-def cpu_replay(seq, n_frames):
+def cpu_replay(seq, n_frames, lba_lag=0):
     """cpu_baseline, single-stream form: the same sequential replay on the CPU oracle (one thread)."""
     from tests import oracle_lib
     from tests.replay_oracle import OracleStages
@@ -303,7 +554,7 @@ def cpu_replay(seq, n_frames):
         path = oracle_lib.build(native=True)
     except Exception:
         path = oracle_lib.build(native=False)
-    Ro = replay.Replay(seq, OracleStages(oracle_lib.Oracle(path)))
+    Ro = replay.Replay(seq, OracleStages(oracle_lib.Oracle(path)), lba_lag=lba_lag)
     t0 = time.perf_counter()
     to = Ro.run(n_frames)
     dt = time.perf_counter() - t0
@@ -399,25 +650,25 @@ def multi_gpu_legs(rank, world, dist, torch, reps=3):
             out[name] = leg
     finally:
         comm.close()
-    # ---- configs[3]: rig replicas
-    seed = 300 + rank
-    scene = sc.RigScene(seed, "kb8", 4)
-    cases = [sc.make_rig_tracking_case(seed + 10 * i, scene) for i in range(3)]
-    fe = RigFrontEnd(scene, 1500)
-    fe.track(cases[0], np.random.default_rng(0))  # warm-up
+    # ---- configs[3]: rig replicas, one sequence of rig frames per rank through the ONE-CALL tracker (no collective)
     barrier()
-    t = time.perf_counter()
-    errs = []
-    for i, c in enumerate(cases):
-        o = fe.track(c, np.random.default_rng(i))
-        errs.append(synth_ba.pose_error(o["r2"]["base"]["nav"], c["truth"])[0])
+    leg = rig_single_stream("kb8", 4, 1500, 300 + rank, n_cases=3, reps=5)
     barrier()
-    dt = mx(time.perf_counter() - t)
-    out["rig_replicas"] = {"config": "BASELINE configs[3]: 4-camera KB8 rig, 1500 features per camera, one sequence per rank, "
-                                     "stage-by-stage host-pointer calls (each track = the frame pair t0, t1: 8 extractions, "
-                                     "2 fisheye stereo matches, 2 searches, 2 pose optimisations)",
-                           "rig_frames_per_s_all_ranks": 2 * len(cases) * world / dt, "ms_per_rig_frame": 1e3 * dt / (2 * len(cases)),
-                           "max_position_error_vs_truth_m_rank0": float(max(errs))}
+    ms_max = mx(leg["ms_per_rig_frame"])
+    out["rig_replicas"] = {"config": "BASELINE configs[3]: 4-camera KB8 rig, 1500 features per camera, one sequence per rank, one "
+                                     "vieo_track_frame call per rig frame (vieo_tracker_create_rig)",
+                           "rig_frames_per_s_all_ranks": world * 1e3 / ms_max, "ms_per_rig_frame": ms_max,
+                           "ms_per_rig_frame_gpu_rank0": leg["ms_per_rig_frame_gpu"],
+                           "max_position_error_vs_truth_m_rank0": leg["max_position_error_vs_truth_m"]}
+    # what the driver's 1 -> 8 table needs from THIS run: per mode the figure that scales (replica modes: x N expected;
+    # sharded modes: ms per call, whatever is measured -- SURVEY 8e expects the latency-bound all-reduce to cap them)
+    out["speedup_vs_n1_expected_inputs"] = {
+        "n_gpus": world,
+        "replicas_headline": "value of this line (frames/s, weak scaling: expected N x the N = 1 value)",
+        "rig_replicas_frames_per_s": out["rig_replicas"]["rig_frames_per_s_all_ranks"],
+        "sharded_local_ba_ms_per_call": out.get("sharded_local_ba", {}).get("ms_per_call"),
+        "sharded_full_ba_ms_per_call": out.get("sharded_full_ba", {}).get("ms_per_call"),
+        "note": "divide the N-GPU figure by the N = 1 run's figure of the same key (ms: the other way round)"}
     return out
 
 
@@ -502,6 +753,10 @@ def main():
     ap.add_argument("--single-stream-frames", type=int, default=100,
                     help="frames of the sequential replay leg (0 = skip); rank 0 at N = 1 only")
     ap.add_argument("--no-pcie-leg", action="store_true")
+    ap.add_argument("--no-rig-legs", action="store_true",
+                    help="skip single_stream_rig / rig_frontend_batch / single_stream_vision_only (rank 0 at N = 1 only)")
+    ap.add_argument("--parity-sample", type=int, default=8,
+                    help="frames of the timed batch recomputed on the CPU oracle after the timed region (0 = none)")
     ap.add_argument("--no-multi-gpu-legs", action="store_true",
                     help="skip the landmark-sharded local / full BA and the configs[3] rig-replica legs (they run on every "
                          "rank after the timed region, with a one-rank communicator at --gpus 1)")
@@ -668,6 +923,16 @@ def main():
                             "its events mostly measure waiting, see roofline_mfma)"}
         roof["chosen_over"] = ("all kernels of the path: extractor kernels, front-end stages (1-3 kernels each) and "
                                "bundle-adjustment kernel classes, by ms per step")
+        # useful / dense FLOPs of one LM trial over the windows of a step
+        useful_ratio = None
+        if lba_problems:
+            us = sum(schur_useful_flops(lba_problems[i % len(lba_problems)]) for i in range(n_lba))
+            de = 0.0
+            for i in range(n_lba):
+                w = lba_problems[i % len(lba_problems)]
+                npv = 6.0 * int((w[1]["fixed"] == 0).sum())
+                de += 2 * npv * (npv + 1) * 3 * len(w[2])
+            useful_ratio = us / de if de > 0 else None
         sch = lba_k.get("lba.schur", {"ms": 0.0, "launches": 0})
         sch_tf = schur_flops / (sch["ms"] * 1e-3) / 1e12 if sch["ms"] > 0 else None
         r2 = res["r2"]
@@ -728,11 +993,18 @@ def main():
                               "frac": sch_tf / FP64_MFMA_PEAK_TFLOPS if sch_tf else None,
                               "flops_per_launch": schur_flops / sch["launches"] if sch["launches"] else None,
                               "flops": "dense 2 np (np + 1) 3 n_mp per window and LM trial (np = 6 x free key frames)",
+                              "useful_over_dense": useful_ratio,
+                              "frac_useful": sch_tf * useful_ratio / FP64_MFMA_PEAK_TFLOPS if (sch_tf and useful_ratio) else None,
+                              "useful_flops_per_launch": (schur_flops / sch["launches"] * useful_ratio) if (sch["launches"] and useful_ratio) else None,
+                              "useful_flops": "SURVEY 8d's sparsity-aware count: per landmark with k free observers 60 + 108 k + "
+                                              "216 k (k + 1) / 2 + 36 k, summed over the step's windows (one LM trial each)",
                               "avg_launch_ms": sch["ms"] / sch["launches"] if sch["launches"] else None,
                               "launches_per_step": sch["launches"] / a.steps,
                               "mfma_busy": mfma_busy()},
         }
         if schur_alone:
+            if useful_ratio:
+                schur_alone["frac_useful"] = schur_alone["frac"] * useful_ratio
             out["roofline_mfma"]["alone"] = schur_alone
         if dk:
             # the same kernel with the GPU to itself (no bundle-adjustment stream beside it): a few more launches of the
@@ -752,6 +1024,50 @@ def main():
             out["multi_gpu"] = mg
         if world == 1 and not a.no_pcie_leg:
             out["pcie_inclusive"] = pcie_leg(P, max(3, min(a.steps, 10)), 2)
+        if world == 1 and not a.no_rig_legs:
+            try:  # the other BASELINE configurations on their fast path (a leg must not take the headline down)
+                out["single_stream_rig"] = {
+                    "default_mh05_distorted_stereo": rig_single_stream("radtan", 2, 1200, 210),
+                    "configs3_4cam_kb8": rig_single_stream("kb8", 4, 1500, 300),
+                    "configs4_tumvi_2cam_kb8": rig_single_stream("kb8", 2, 1500, 400),
+                    "reference_readme_anchor": README_FRONTEND_DIST_MS}
+                ss = out["single_stream_rig"]
+                ss["reference_readme_anchor"] = dict(README_FRONTEND_DIST_MS, ratio_to_default_mh05_ms_per_rig_frame=
+                                                     README_FRONTEND_DIST_MS["value"] / ss["default_mh05_distorted_stereo"]["ms_per_rig_frame"])
+                out["rig_frontend_batch"] = rig_frontend_batch()
+                out["single_stream_vision_only"] = vision_single_stream()
+            except Exception as e:
+                out["single_stream_rig"] = {"error": repr(e)}
+        if world == 1 and not a.no_cpu_baseline and a.workload == "r3" and a.parity_sample > 0:
+            # the headline tied to checked outputs: sampled frames of the timed batch and two of the step's local-BA
+            # windows recomputed on the CPU oracle (after the timed region; the oracle is the checker, never the product)
+            try:
+                from tests import oracle_lib
+                from tests.pipeline_check import R3FrameChecker
+                orc = oracle_lib.load()
+                C = R3FrameChecker(P, res, orc)
+                idx = np.unique(np.linspace(0, P.B - 1, a.parity_sample).astype(int))
+                chk = [C.check(int(b)) for b in idx]
+                ps = {"frames_checked": [int(b) for b in idx],
+                      "keypoint_bytes_equal": all(c["keys_equal"] and c["uright_equal"] for c in chk),
+                      "matches_equal": all(c["matches_equal"] for c in chk), "inliers_equal": all(c["inliers_equal"] for c in chk),
+                      "max_se3_error": max(c["max_se3_error"] for c in chk)}
+                lerr = []
+                for wi in range(min(2, len(lba_problems))):
+                    w = lba_problems[-1] if wi else lba_problems[0]  # one ordinary, one bLarge window (every 4th)
+                    on, op, oe, ores = orc.local_ba_vio(*w)
+                    hn, hp, he, hres = Optimizer.LocalBundleAdjustmentNavStatePRV(*w)
+                    lerr.append({"key_frames": len(w[1]), "observations": len(w[4]), "large": int(w[0][0]["large"]),
+                                 "max_se3_error": float(max(max(synth_ba.pose_error(on[k], hn[k])) for k in range(len(on)))),
+                                 "erase_flags_equal": bool(np.array_equal(oe, he)),
+                                 "lm_trials": [int(ores["lm_trials"]), int(hres["lm_trials"])]})
+                ps["local_ba_windows"] = lerr
+                ps["note"] = ("frames of the timed device-resident batch re-evaluated stage by stage on the CPU oracle from the "
+                              "same inputs (tests/pipeline_check.py); local-BA windows of the timed step against the oracle's "
+                              "LocalBundleAdjustmentNavStatePRV; bar: keypoint bytes / matches equal, SE(3) <= 1e-4")
+                out["parity_sample"] = ps
+            except Exception as e:
+                out["parity_sample"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, lba_problems, a.lba_every)
         if world == 1 and a.single_stream_frames > 1:
@@ -759,9 +1075,11 @@ def main():
             seq = replay.Sequence(1, a.single_stream_frames)
             out["single_stream"], th = single_stream_leg(seq, a.single_stream_frames)
             if not a.no_cpu_baseline:  # the oracle's run of the same replay: baseline and checker
-                cb, to = cpu_replay(seq, a.single_stream_frames)
+                cb, to = cpu_replay(seq, a.single_stream_frames, LBA_LAG)
                 out["cpu_baseline"]["single_stream"] = cb
                 out["single_stream"]["vs_cpu_single_stream"] = out["single_stream"]["frames_per_s"] / cb["value"]
+                # against the oracle threaded like the reference (one thread per camera + LocalMapping: cpu_baseline.value)
+                out["single_stream"]["vs_cpu_threaded"] = out["single_stream"]["frames_per_s"] / out["cpu_baseline"]["value"]
                 out["single_stream"]["ate_vs_oracle_m"] = replay.ate_between(th, to)
                 out["single_stream"]["max_position_difference_vs_oracle_m"] = float(
                     np.linalg.norm(th["p"] - to["p"], axis=1).max())

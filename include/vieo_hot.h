@@ -153,6 +153,13 @@ int vieo_hamming_knn2(const uint8_t* h_query, int nq, const uint8_t* h_train, in
 int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* h_counts,
                                    int capacity, const int32_t* h_pairs, int n_pairs,
                                    int32_t* d_idx, int32_t* d_dist, void* stream);
+/* The same search for a batch of camera-rig frames with the counts read ON THE DEVICE (no host copy, no synchronisation):
+ * d_descriptors [n_frames][n_cams][capacity][32], d_counts [n_frames][n_cams][2] = {n, num_mono}; every camera pair
+ * (i < j) of every frame, rows [num_mono, n) of camera i against those of camera j (src/Frame.cc:618-628); results of
+ * (frame f, pair p) start at row (f * n_pairs + p) * capacity, n_pairs = n_cams (n_cams - 1) / 2.  One launch: a lane
+ * owns a query row, the train rows pass through LDS in tiles of 256 (k_knn2, matching.hip). */
+int vieo_hamming_knn2_rig_batch_device(const uint8_t* d_descriptors, const int32_t* d_counts, int capacity, int n_cams,
+                                       int n_frames, int32_t* d_idx, int32_t* d_dist, void* stream);
 
 /* void Frame::ComputeStereoFishEyeMatches(const float th_far_pts) (src/Frame.cc:613-779), the stereo stage of
  * the distorted multi-camera configurations: dense knn-2 between every camera pair (rows [num_mono, n)),

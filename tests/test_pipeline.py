@@ -80,74 +80,21 @@ def _cam(P, b):
 def test_batched_pipeline_r3_local_map_stage_on_device(oracle):
     """The r3 workload of bench.py: non-planar scenes with low-contrast patches, and SearchLocalPoints' head inside the
     step -- isInFrustum + window queries of 4 k candidates per frame from the first optimisation's pose in HBM.  Checked
-    against the same chain on the CPU oracle: is_in_frustum at the oracle's first pose, the host's query construction,
-    the second search, the second optimisation."""
-    from vieo_slam_amd import frontend
-    from vieo_slam_amd.map_point import FRUSTUM_POINT_DTYPE
+    against the same chain on the CPU oracle (tests/pipeline_check.py, the checker bench.py's parity_sample uses too):
+    is_in_frustum at the oracle's first pose, the host's query construction, the second search, the second optimisation."""
+    from tests.pipeline_check import R3FrameChecker
     from vieo_slam_amd.pipeline import FramePipeline, make_cases
     cases = make_cases(2, seed0=5, workload="r3")
     assert len(cases[0]["scene"].sheets) == 12
     B = 3
     P = FramePipeline(cases, B, seed=9, workload="r3")
     P.step()
-    R = P.results()
-    cap, ccap = P.cap, P.ccap
-    xyz = P.d_xyz.download(np.float32, (B, P.pcap, 3))
-    cpt = P.d_cpt.download(FRUSTUM_POINT_DTYPE, (B, ccap))
-    cdesc = P.d_cdesc.download(np.uint8, (B, ccap, 32))
-    scf = np.asarray(P.ext.GetScaleFactors(), np.float32)
-    oL, oR = oracle.extractor(1200), oracle.extractor(1200)
+    C = R3FrameChecker(P, P.results(), oracle)
     retried = 0
     for b in range(B):
-        _, k1, d1 = oL(P.imgs_host[b, 0])
-        _, kr, dr = oR(P.imgs_host[b, 1])
-        n = len(k1)
-        assert R["counts"][2 * b, 0] == n and np.array_equal(R["kps"][2 * b, :n].view(np.uint8), k1.view(np.uint8))
-        retried += int((k1["response"] < 20).sum())  # keys only the second threshold finds (score = strength - 1)
-        ur, _ = oracle.stereo_match(oL, oR, k1, d1, kr, dr, sc.BASELINE, sc.BF)
-        n0 = int(np.count_nonzero(np.any(P.pts_host[b]["desc"] != 0, axis=1)))
-        q1 = oracle.sbp_project_last_frame(P.pts_host[b][:n0], np.array([_cam(P, b)]))
-        _, a1 = oracle.search_by_projection(0, q1, k1, ur, d1, None, BOUNDS)
-        mp = np.where(a1 >= 0, a1, -1)
-        obs1, idx1 = _obs_from(mp, xyz[b], k1, ur, P.inv_sigma2)
-        F1 = np.array([P.f1_host[b]])
-        F1[0]["base"]["n_obs"] = len(obs1)
-        r1, o1 = oracle.pose_optimization_vio(F1, obs1)
-        mp[idx1[o1 != 0]] = -1
-        taken = (mp >= 0).astype(np.uint8)
-        # SearchLocalPoints at the first optimisation's pose
-        nav = r1["base"]["nav"]
-        Rwb = synth_ba.quat_to_R(nav["q"])
-        Rcb, tcb = F1[0]["base"]["Rcb"].reshape(3, 3), F1[0]["base"]["tcb"]
-        Rcw = Rcb @ Rwb.T
-        tcw = tcb - Rcw @ nav["p"]
-        FF = P.ff.copy()
-        FF[0]["Rcrw"], FF[0]["tcrw"], FF[0]["Ow"] = Rcw.reshape(-1), tcw, -Rcw.T @ tcw
-        nc = int(P.ncand_host[b])
-        info = oracle.is_in_frustum(FF, cpt[b, :nc])
-        held = np.zeros(P.pcap, bool)
-        held[mp[mp >= 0]] = True
-        al = np.full(nc, -1)
-        al[:n0] = np.arange(n0)
-        info["n"][(al >= 0) & held[np.maximum(al, 0)]] = 0
-        q2, owner = frontend.queries_from_track_info(info, cdesc[b, :nc], 2.0, scf)
-        assert len(q2) > 500
-        # the device keeps one slot per candidate; same order, the empty slots carry flags = 0
-        full = np.zeros(nc, q2.dtype)
-        full[owner] = q2
-        _, a2 = oracle.search_by_projection(1, full, k1, ur, d1, taken, BOUNDS, nn_ratio=0.8)
-        mp = np.where(a2 >= 0, cap + a2, mp)
-        assert np.array_equal(R["mp_ref"][b, :n], mp)
-        obs2, idx2 = _obs_from(mp, xyz[b], k1, ur, P.inv_sigma2)
-        F2 = F1.copy()
-        F2[0]["base"]["nav"] = r1["base"]["nav"]
-        F2[0]["base"]["n_obs"] = len(obs2)
-        F2[0]["compute_marg"] = 1
-        r2, o2 = oracle.pose_optimization_vio(F2, obs2)
-        for name, ref, got in (("r1", r1, R["r1"][b]), ("r2", r2, R["r2"][b])):
-            dt, dr = synth_ba.pose_error(ref["base"]["nav"], got["base"]["nav"])
-            assert dt < 1e-4 and dr < 1e-4, (name, b, dt, dr)
-            assert ref["base"]["n_inliers"] == got["base"]["n_inliers"], (name, b)
-        gdt, gdr = synth_ba.pose_error(R["r2"][b]["base"]["nav"], P.truth[b])
-        assert gdt < 5e-3 and gdr < 3e-3, (b, gdt, gdr)
+        c = C.check(b)
+        assert c["keys_equal"] and c["uright_equal"] and c["matches_equal"] and c["inliers_equal"], c
+        assert c["max_se3_error"] < 1e-4 and c["n_local_queries"] > 500, c
+        assert c["error_vs_truth"][0] < 5e-3 and c["error_vs_truth"][1] < 3e-3, c
+        retried += c["retried"]
     assert retried > 0, "no cell needed minThFAST: the low-contrast patches are not doing their job"

@@ -87,6 +87,7 @@ _SIGS = {
     "vieo_orb_stage_ms": (c_i, [c_p, c_i, c_p]),
     "vieo_hamming_knn2": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
     "vieo_stereo_fisheye_match": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "vieo_hamming_knn2_rig_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "vieo_fisheye_create": (c_i, [P(c_p), c_p, c_i, c_i]),
     "vieo_fisheye_destroy": (None, [c_p]),
     "vieo_fisheye_group_capacity": (c_i, [c_p]),

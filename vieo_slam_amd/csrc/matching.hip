@@ -589,6 +589,16 @@ int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* 
   return VIEO_OK;
 }
 
+int vieo_hamming_knn2_rig_batch_device(const uint8_t* d_descriptors, const int32_t* d_counts, int capacity, int n_cams,
+                                       int n_frames, int32_t* d_idx, int32_t* d_dist, void* stream) {
+  if (!d_descriptors || !d_counts || capacity <= 0 || capacity > 65535 || n_cams < 2 || n_cams > 4 || n_frames <= 0 || !d_idx ||
+      !d_dist)
+    return VIEO_E_INVALID;
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  return knn2_rig_launch(d_descriptors, d_counts, capacity, n_cams, n_frames, d_idx, d_dist, (hipStream_t)stream);
+}
+
 int vieo_hamming_knn2(const uint8_t* h_query, int nq, const uint8_t* h_train, int nt,
                       int32_t* h_idx, int32_t* h_dist) {
   if (nq < 0 || nt < 0 || (nq > 0 && (!h_query || !h_idx || !h_dist))) return VIEO_E_INVALID;
