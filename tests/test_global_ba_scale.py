@@ -234,3 +234,38 @@ def test_vio_gba_scale_landmark_sharded_two_ranks_on_one_gpu(oracle):
         assert abs(hsc - osc) < 1e-6
         assert np.abs(op[shards[rank][1]] - hp).max() < 1e-3
     assert results[0][0].tobytes() == results[1][0].tobytes() and results[0][3] == results[1][3]
+
+
+@pytest.mark.gpu
+def test_vio_gba_scale_bench_problem_parity(oracle):
+    """bench.py's `sharded_full_ba` problem (60 key frames, 6000 points before culling, System::FinalGBA's form with the
+    scale vertex, map handed over at scale 1 / 1.03) UNSHARDED against the oracle -- the bench compares the sharded run
+    with the unsharded HIP call only."""
+    from vieo_slam_amd.optimizer import Optimizer
+    win = synth_ba.make_lba_vio_problem(901, n_local=60, n_fixed=1, n_points=6000, anchors=30, span=5)[:6]
+    params, kfs, pts, obs, imu = win[0], win[1], (win[2] / np.float32(1.03)).astype(np.float32), win[4], win[5]
+    on, op, ores, osc = oracle.global_ba_vio(params, kfs, pts, obs, imu, 5, True, scale_opt=True)
+    hn, hp, hres, hsc = Optimizer.GlobalBundleAdjustmentNavStatePRV(params, kfs, pts, obs, imu, 5, True, bScaleOpt=True)
+    dt, dr = _pose_diff(on, hn, 60)
+    assert dt < TOL and dr < TOL, (dt, dr)
+    assert abs(osc - hsc) < 1e-6 and abs(hsc - 1.03) < 5e-3, (osc, hsc)
+    assert hres["status"] == ores["status"] == 0 and hres["lm_trials"] == ores["lm_trials"]
+    assert np.abs(op - hp).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_vio_gba_scale_400_key_frames_parity(oracle):
+    """Full BA at BASELINE configs[4] scale -- 400 key frames = 6001 unknowns of the reduced system (tiled LDL^T,
+    block-sparse Schur with the dense scale row) -- against the oracle on a thinned point set (4000 points, ~19 k
+    observations; the oracle's dense solve is what takes the time: two iterations, about a minute of CPU)."""
+    from vieo_slam_amd.optimizer import Optimizer
+    params, kfs, pts, close, obs, imu, gt = synth_ba.make_lba_vio_problem(7, n_local=400, n_fixed=1, n_points=4000,
+                                                                          anchors=200, span=5)
+    pts = (pts / np.float32(1.02)).astype(np.float32)
+    on, op, ores, osc = oracle.global_ba_vio(params, kfs, pts, obs, imu, 2, True, scale_opt=True)
+    hn, hp, hres, hsc = Optimizer.GlobalBundleAdjustmentNavStatePRV(params, kfs, pts, obs, imu, 2, True, bScaleOpt=True)
+    dt, dr = _pose_diff(on, hn, 400)
+    assert dt < TOL and dr < TOL, (dt, dr)
+    assert abs(osc - hsc) < 1e-6, (osc, hsc)
+    assert hres["status"] == ores["status"] == 0 and hres["lm_trials"] == ores["lm_trials"]
+    assert np.linalg.norm(on["v"][:400] - hn["v"][:400], axis=1).max() < 1e-4

@@ -462,3 +462,19 @@ def test_gpu_vio_gba_encoder_parity(oracle, robust):
         assert dt < 1e-4 and dr < 1e-4, (k, dt, dr)
     assert hres["lm_trials"] == ores["lm_trials"]
     assert abs(hres["chi2_final"] - ores["chi2_final"]) <= 1e-6 * ores["chi2_final"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", [0, 3, 7])
+def test_gpu_vio_lba_bench_windows_parity(oracle, i):
+    """The local-BA windows of bench.py's timed step EXACTLY as it builds them (workload r3, SURVEY 8d: 10 local + 40
+    fixed key frames, ~1500 points / ~21 k observations; every 4th window bLarge -- 25 local key frames, optimize(2) +
+    optimize(2)) against the oracle: the shapes the headline is measured on."""
+    from vieo_slam_amd.optimizer import Optimizer
+    large = i % 4 == 3
+    w = synth_ba.make_lba_vio_problem(500 + i, n_local=25 if large else 10, n_fixed=40, n_points=2000)[:6]
+    w[0][0]["large"] = int(large)
+    if large:
+        w[0][0]["base"]["its0"], w[0][0]["base"]["its1"] = 2, 2
+    assert (w[1]["fixed"] != 0).sum() >= 40 and len(w[4]) > 15000
+    _parity(oracle, w, Optimizer.LocalBundleAdjustmentNavStatePRV(*w))
