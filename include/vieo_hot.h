@@ -796,6 +796,19 @@ int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_p
                                              vieo_allreduce_sum_f64_fn allreduce, void* ctx,
                                              vieo_navstate* const* h_navs_out, float* const* h_points_out,
                                              uint8_t* const* h_erase, vieo_lba_result* h_results);
+/* The same with pbStopFlag (src/Optimizer.cc:524-528,570-571,590-592): `stop` is this rank's flag (NULL: none).  A sharded
+ * run never acts on its own copy: the ranks' requests are summed in the exchanges the run makes anyway (the agreement at
+ * entry, the spare fourth scalar of every trial's exchange), so a flag raised on ONE rank aborts the call on ALL ranks at
+ * the same trial -- nobody is left waiting in a collective. */
+int vieo_local_bundle_adjustment_vio_sharded_stop(int n_windows, const vieo_lba_vio_params* const* params,
+                                                  const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                                  const float* const* h_points, const uint8_t* const* h_close,
+                                                  const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                                  const vieo_lba_imu_edge* const* h_imu, const int* n_imu,
+                                                  double* d_reduce_buf, size_t reduce_cap_doubles,
+                                                  vieo_allreduce_sum_f64_fn allreduce, void* ctx, volatile const int* stop,
+                                                  vieo_navstate* const* h_navs_out, float* const* h_points_out,
+                                                  uint8_t* const* h_erase, vieo_lba_result* h_results);
 /* The same exchange for the full BA (BASELINE configs[4]: "full BA with RCCL pose-Hessian all-reduce"): this rank's
  * landmark shard of GlobalBundleAdjustmentNavStatePRV; per LM trial one all-reduce of the packed reduced visual
  * system ((6n)(6n+1) + 42n doubles for n free key frames) and one of three scalars. */

@@ -255,7 +255,7 @@ def test_gpu_vio_lba_landmark_sharded_two_ranks_on_one_gpu(oracle):
     assert s1[0].tobytes() == p1[0].tobytes() and np.array_equal(s1[1], p1[1]) and np.array_equal(s1[2], p1[2])
 
 
-def _run_ranks(world, shards, n, bad_rank=None):
+def _run_ranks(world, shards, n, bad_rank=None, stops=None, on_exchange=None):
     """world 'ranks' as host threads on one GPU; the reduction callback sums their buffers through the host"""
     import threading
     from vieo_slam_amd._lib import DeviceBuffer, VieoError, check, lib
@@ -269,6 +269,8 @@ def _run_ranks(world, shards, n, bad_rank=None):
             h = np.empty(count)
             check(lib().vieo_memcpy_d2h(h.ctypes.data, bufs[rank].ptr + 8 * offset, 8 * count))
             stage[rank] = h
+            if on_exchange:
+                on_exchange(rank, count)
             barrier.wait(60)
             total = sum(stage[r] for r in range(world))
             barrier.wait(60)
@@ -279,7 +281,8 @@ def _run_ranks(world, shards, n, bad_rank=None):
     def run(rank):
         try:
             results[rank] = Optimizer.LocalBundleAdjustmentNavStatePRVSharded([shards[rank]], bufs[rank].ptr, n,
-                                                                              make_cb(rank))[0]
+                                                                              make_cb(rank),
+                                                                              stop=None if stops is None else stops[rank])[0]
         except VieoError as e:
             results[rank] = e
     ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
@@ -478,3 +481,40 @@ def test_gpu_vio_lba_bench_windows_parity(oracle, i):
         w[0][0]["base"]["its0"], w[0][0]["base"]["its1"] = 2, 2
     assert (w[1]["fixed"] != 0).sum() >= 40 and len(w[4]) > 15000
     _parity(oracle, w, Optimizer.LocalBundleAdjustmentNavStatePRV(*w))
+
+
+@pytest.mark.gpu
+def test_gpu_vio_lba_sharded_stop_flag_is_collective(oracle):
+    """pbStopFlag of a landmark-sharded local BA (Optimizer.cc:524-528,570-571): the flag is rank-local, the ranks' requests
+    are summed inside the run's own exchanges -- raised on ONE rank, before the call or in the middle of it, it stops ALL
+    ranks at the same trial (nobody hangs in a collective), with the status and the key frames the same on every rank."""
+    from vieo_slam_amd import sharding
+    from vieo_slam_amd.optimizer import Optimizer
+    win = synth_ba.make_lba_vio_problem(58, n_local=6, n_fixed=3, n_points=600)[:6]
+    world = 3
+    shards = [sharding.shard_window(win, r, world)[0] for r in range(world)]
+    n = Optimizer.sharded_buffer_doubles([shards[0]])
+    full = _run_ranks(world, shards, n)
+    assert all(r[3]["status"] == 0 for r in full)
+    # raised on rank 1 before the call: every rank returns the aborted status with nothing optimised
+    stops = [np.zeros(1, np.int32) for _ in range(world)]
+    stops[1][0] = 1
+    res = _run_ranks(world, shards, n, stops=stops)
+    plain_stop = np.ones(1, np.int32)
+    ref = Optimizer.LocalBundleAdjustmentNavStatePRV(*win, stop=plain_stop)
+    for r in res:
+        assert not isinstance(r, Exception) and int(r[3]["status"]) == int(ref[3]["status"]) != 0
+        assert r[0].tobytes() == ref[0].tobytes() and int(r[3]["lm_trials"]) == 0
+    # raised on rank 2 in the middle (after its 4th trial exchange): all ranks stop together, earlier than the full run
+    stops = [np.zeros(1, np.int32) for _ in range(world)]
+    seen = [0]
+
+    def on_exchange(rank, count):
+        if rank == 2 and count == 4:  # (the 4-scalar exchange of a trial)
+            seen[0] += 1
+            if seen[0] == 4:
+                stops[2][0] = 1
+    res = _run_ranks(world, shards, n, stops=stops, on_exchange=on_exchange)
+    trials = [int(r[3]["lm_trials"]) for r in res]
+    assert len(set(trials)) == 1 and 4 <= trials[0] < int(full[0][3]["lm_trials"]), (trials, int(full[0][3]["lm_trials"]))
+    assert res[0][0].tobytes() == res[1][0].tobytes() == res[2][0].tobytes()

@@ -141,6 +141,8 @@ _SIGS = {
                                                         ctypes.c_size_t, c_p, c_p, c_p, c_p, c_p]),
     "vieo_local_bundle_adjustment_vio_sharded": (c_i, [c_i] + [c_p] * 10 + [c_p, ctypes.c_size_t, c_p, c_p] +
                                                  [c_p] * 4),
+    "vieo_local_bundle_adjustment_vio_sharded_stop": (c_i, [c_i] + [c_p] * 10 + [c_p, ctypes.c_size_t, c_p, c_p, c_p] +
+                                                      [c_p] * 4),
     "vieo_orb_tap_plane": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_candidates": (c_i, [c_p, c_i, c_i, c_p, c_i]),
     "vieo_orb_tap_level_keys": (c_i, [c_p, c_i, c_i, c_p, c_i]),

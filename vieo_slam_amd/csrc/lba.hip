@@ -399,7 +399,8 @@ k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
     for (int e = 0; e < D.n_imu; e++) g0 += D.gchi0[e], g1 += D.gchi[e];
     if (D.red) {  // visual parts go through the all-reduce, the inertial part is the same on every rank
       double* sc = D.red_sc;
-      sc[0] = v[0], sc[1] = v[1], sc[2] = v[2], sc[3] = 0;
+      sc[0] = v[0], sc[1] = v[1], sc[2] = v[2];
+      sc[3] = ctl[w].pad ? 1.0 : 0.0;  // this rank's stop request: summed with the others', every rank sees the same count
       out[w].chig0 = g0, out[w].chig = (fl & LBA_TRIAL) ? g1 : 0.0;
     } else
       out[w].chi0 = v[0] + g0, out[w].chi2 = v[1] + ((fl & LBA_TRIAL) ? g1 : 0.0), out[w].scale_l = v[2];
@@ -2148,14 +2149,20 @@ static int shard_exchange(const LbaShard* sh, double* d_buf, size_t n, hipStream
 // H_ps, H_ss, b_s
 // All ranks of a sharded run agree on go / no-go: the sum of the ranks' failure flags through the run's own exchange.
 // Every rank must call it the same number of times.  *sum > 0: some rank failed.
-static int shard_agree(const LbaShard* sh, bool ok, double* sum) {
-  const double flag = ok ? 0.0 : 1.0;
+// stop / *stop_any: the ranks' stop requests travel in the same number (4096 per request: exact in a double for any
+// realistic job size), so that pbStopFlag raised on one rank aborts the call on all of them together.
+static int shard_agree(const LbaShard* sh, bool ok, double* sum, bool stop = false, bool* stop_any = nullptr) {
+  const double flag = (ok ? 0.0 : 1.0) + (stop ? 4096.0 : 0.0);
   *sum = 1.0;
   VIEO_HIP_CHECK(hipMemcpy(sh->d_buf, &flag, 8, hipMemcpyHostToDevice));
   const int xrc = shard_exchange(sh, sh->d_buf, 1, nullptr);
   if (xrc != VIEO_OK) return xrc;
   VIEO_HIP_CHECK(hipStreamSynchronize(nullptr));
-  VIEO_HIP_CHECK(hipMemcpy(sum, sh->d_buf, 8, hipMemcpyDeviceToHost));
+  double total = 0;
+  VIEO_HIP_CHECK(hipMemcpy(&total, sh->d_buf, 8, hipMemcpyDeviceToHost));
+  const double stops = std::floor(total / 4096.0);
+  if (stop_any) *stop_any = stops > 0;
+  *sum = total - 4096.0 * stops;
   return VIEO_OK;
 }
 
@@ -2337,13 +2344,14 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   const int pd = vio ? 15 : 6;
   const int sco = gba && gba->scale_opt ? 1 : 0;
   if (gba && gba->scale_out) *gba->scale_out = 1.0;
-  // (configuration errors, the same on every rank of a job; `stop` is rank-local and asynchronous, so a sharded run
-  // does not look at it at all -- the public sharded entries pass none)
+  // (configuration errors, the same on every rank of a job; `stop` is rank-local and asynchronous: a sharded run never
+  // acts on its own copy -- the ranks' requests are summed in the exchanges the run makes anyway (the two agreements
+  // at entry, the fourth scalar of every trial), so all ranks take the abort at the same point: Optimizer.cc:524-528,570-571)
   if (sh && (!vio || (!sh->fn && !sh->ctx) || !sh->d_buf)) {
     set_error("sharded local BA: visual-inertial windows only, with a reduction callback and buffer");
     return VIEO_E_INVALID;
   }
-  if (sh) stop = nullptr;
+  bool shard_stop = false;  // a sharded run's collective view of the stop flag (latched)
   if (sh) {
     // every rank reaches this collective whatever its own arguments look like; the sum of the failure flags decides
     // for all of them (needs a device: a rank without one cannot take part in the job at all)
@@ -2354,7 +2362,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
                                                 h_points_out, h_erase, h_results, pd, sco);
     double sum = 1.0;
     if (sh->cap >= 1) {
-      const int xrc = shard_agree(sh, ok, &sum);
+      const int xrc = shard_agree(sh, ok, &sum, stop && *stop, &shard_stop);
       if (xrc != VIEO_OK) return xrc;
     }
     if (sum != 0.0) {
@@ -2406,7 +2414,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   const int W = n_windows;
   std::vector<WinHost> win(W);
   std::vector<LbaDev> devs(W);
-  const bool stopped0 = stop && *stop;
+  const bool stopped0 = sh ? shard_stop : (stop && *stop);
   int n_live = 0;
   for (int w = 0; w < W; w++) {
     WinHost& H = win[w];
@@ -2893,7 +2901,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   };
   for (;;) {
     n_rounds++;
-    const bool stop_now = stop && *stop;
+    const bool stop_now = sh ? shard_stop : (stop && *stop);
+    const int stop_req = stop && *stop ? 1 : 0;  // (sharded: travels as ctl.pad -> the trial's fourth scalar)
     int any = 0;
     bool cls_trial[3] = {false, false, false};  // which solve kernels have a window this round
     for (int w = 0; w < W; w++) {
@@ -2922,7 +2931,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         if (H.need_build) f |= LBA_BUILD;
         if (H.need_restore) f |= LBA_RESTORE, H.need_restore = false;
       }
-      ctl[w].flags = f, ctl[w].pad = 0, ctl[w].lambda = lam;
+      ctl[w].flags = f, ctl[w].pad = sh ? stop_req : 0, ctl[w].lambda = lam;
       any |= f;
       if ((f & LBA_TRIAL) && !H.skip) cls_trial[devs[w].solver] = true;
     }
@@ -3012,14 +3021,18 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         if (ctl[w].flags & LBA_TRIAL) fl += schur_flops_of(w);
       KT.fold(fl);
     }
+    if (sh)  // the ranks' stop requests of this round (the same count in every window that ran a trial)
+      for (int w = 0; w < W; w++)
+        if ((ctl[w].flags & (LBA_TRIAL | LBA_BEGIN)) && h_sc[4 * w + 3] > 0) shard_stop = true;
     // ---- per-window policy (optimization_algorithm_levenberg.cpp:61-164)
     for (int w = 0; w < W; w++) {
       WinHost& H = win[w];
       const int fl = ctl[w].flags;
       if (!(fl & LBA_TRIAL)) continue;
-      if (sh)  // totals = all ranks' visual edges + the inertial edges
+      if (sh) {  // totals = all ranks' visual edges + the inertial edges; the ranks' stop requests
         out[w].chi0 = h_sc[4 * w] + out[w].chig0, out[w].chi2 = h_sc[4 * w + 1] + out[w].chig,
         out[w].scale_l = h_sc[4 * w + 2];
+      }
       if (fl & LBA_BEGIN) {
         if (out[w].np == 0) {  // no active free vertex: optimize() returns at once
           H.phase = 2;
@@ -3054,7 +3067,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       }
       H.qmax++;
       H.R->chi2_final = H.currentChi;
-      const bool stopped = stop && *stop;
+      const bool stopped = sh ? shard_stop : (stop && *stop);
       if (rho < 0 && H.qmax < 10 && !stopped) continue;  // next lambda trial of the same iteration
       bool terminate = H.qmax == 10 || rho == 0;
       if (!terminate) {
@@ -3175,10 +3188,24 @@ int vieo_local_bundle_adjustment_vio_sharded(int n_windows, const vieo_lba_vio_p
                                              vieo_allreduce_sum_f64_fn allreduce, void* ctx,
                                              vieo_navstate* const* h_navs_out, float* const* h_points_out,
                                              uint8_t* const* h_erase, vieo_lba_result* h_results) {
+  return vieo_local_bundle_adjustment_vio_sharded_stop(n_windows, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu,
+                                                       n_imu, d_reduce_buf, reduce_cap_doubles, allreduce, ctx, nullptr, h_navs_out,
+                                                       h_points_out, h_erase, h_results);
+}
+
+int vieo_local_bundle_adjustment_vio_sharded_stop(int n_windows, const vieo_lba_vio_params* const* params,
+                                                  const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
+                                                  const float* const* h_points, const uint8_t* const* h_close,
+                                                  const int* n_mp, const vieo_lba_obs* const* h_obs, const int* n_obs,
+                                                  const vieo_lba_imu_edge* const* h_imu, const int* n_imu,
+                                                  double* d_reduce_buf, size_t reduce_cap_doubles,
+                                                  vieo_allreduce_sum_f64_fn allreduce, void* ctx, volatile const int* stop,
+                                                  vieo_navstate* const* h_navs_out, float* const* h_points_out,
+                                                  uint8_t* const* h_erase, vieo_lba_result* h_results) {
   if (!params) return VIEO_E_INVALID;
   LbaShard sh{allreduce, ctx, d_reduce_buf, reduce_cap_doubles};
   return lba_run(&sh, nullptr, n_windows, nullptr, params, h_kfs, n_kf, h_points, h_close, n_mp, h_obs, n_obs, h_imu,
-                 n_imu, nullptr, h_navs_out, h_points_out, h_erase, h_results);
+                 n_imu, stop, h_navs_out, h_points_out, h_erase, h_results);
 }
 
 int vieo_global_bundle_adjustment_vio_sharded_scale(const vieo_lba_vio_params* params, int n_iterations, int robust,

@@ -163,13 +163,14 @@ class Optimizer:
         return int(lib().vieo_lba_sharded_buffer_doubles(len(windows), nf.ctypes.data))
 
     @staticmethod
-    def LocalBundleAdjustmentNavStatePRVSharded(windows, reduce_ptr, reduce_doubles, allreduce=None, comm=None):
+    def LocalBundleAdjustmentNavStatePRVSharded(windows, reduce_ptr, reduce_doubles, allreduce=None, comm=None, stop=None):
         """This rank's part of landmark-sharded visual-inertial windows.  windows: the
         rank's shards (sharding.shard_window); reduce_ptr: device pointer of a float64 buffer of
         reduce_doubles entries; allreduce(offset, n): in-place sum over the ranks of entries
         [offset, offset + n) of that buffer, complete on return (sharding.torch_allreduce) -- or comm: the in-library
-        RCCL communicator of sharding.RcclComm (the library then issues ncclAllReduce on its own stream).  Returns per
-        window (navs, points, erase, result)."""
+        RCCL communicator of sharding.RcclComm (the library then issues ncclAllReduce on its own stream).  stop: int32[1],
+        this rank's pbStopFlag (the ranks' flags are summed inside the run: one raised flag aborts all ranks together).
+        Returns per window (navs, points, erase, result)."""
         import ctypes
         W = len(windows)
         keep, outs = [], []
@@ -200,11 +201,11 @@ class Optimizer:
                 return 1
         cb = CB(_cb)
         fn_ptr, ctx = (ctypes.cast(cb, ctypes.c_void_p), None) if comm is None else (None, ctypes.c_void_p(int(comm)))
-        check(lib().vieo_local_bundle_adjustment_vio_sharded(
+        check(lib().vieo_local_bundle_adjustment_vio_sharded_stop(
             W, ptrs[0].ctypes.data, ptrs[1].ctypes.data, cnt[0].ctypes.data, ptrs[2].ctypes.data,
             ptrs[3].ctypes.data, cnt[1].ctypes.data, ptrs[4].ctypes.data, cnt[2].ctypes.data,
             ptrs[5].ctypes.data, cnt[3].ctypes.data, ctypes.c_void_p(base), reduce_doubles,
-            fn_ptr, ctx, ptrs[6].ctypes.data, ptrs[7].ctypes.data,
+            fn_ptr, ctx, None if stop is None else stop.ctypes.data, ptrs[6].ctypes.data, ptrs[7].ctypes.data,
             ptrs[8].ctypes.data, res.ctypes.data), "vieo_local_bundle_adjustment_vio_sharded")
         return [(n, p, e[:k], res[w]) for w, (n, p, e, k) in enumerate(outs)]
 
