@@ -726,8 +726,11 @@ int vieo_bundle_adjustment_enc(const vieo_lba_params* params, int n_iterations, 
  * BAs: every key frame free except the flagged ones (nid_ == 0), ONE optimize(n_iterations) with g2o's own
  * initial lambda, Huber kernels (sqrt(5.99) / sqrt(7.815); sqrt(16.919) / sqrt(12.592) on the inertial / bias
  * edges) on every edge iff `robust`, no outlier classification, every point written back.  The visual-inertial
- * form weighs the inertial and bias edges leaving a fixed key frame by 1e-2 like the reference.  Reduced systems
- * beyond 510 unknowns are factorised by the tiled LDL^T (FP64 matrix cores); up to 16320 unknowns.
+ * form weighs the inertial and bias edges leaving a fixed key frame by 1e-2 like the reference.  The reduced
+ * system is factorised by one of three kernels according to its size n (lba.hip solver_class, the same for the local
+ * BAs): n <= 159 k_lba_ldlt16 (one workgroup, whole triangle in LDS, blocked on the FP64 matrix cores), n <= 639
+ * k_lba_ldltg (one workgroup, left-looking, the factor in L2 as 16 x 16 blocks), beyond that the tiled LDL^T over many
+ * workgroups (k_big_*); up to 16320 unknowns (1088 visual-inertial key frames).
  * params->its0 / its1 (and lambda_init / rec_init / large of the VIO params) are ignored.  Not covered: the gravity
  * vertex of the IMU initialiser (pimu_initiator, SURVEY 2 row 14: out of scope).  bScaleOpt: the _scale entries
  * below.  Encoder edges: vieo_lba_imu_edge.enc in the

@@ -60,7 +60,13 @@ def test_oracle_lba_edge_cases(oracle):
                                      (6, dict(n_local=4, n_fixed=0, n_points=300, first_fixed=True)),
                                      (7, dict(n_local=3, n_fixed=2, n_points=150, stereo_frac=0.0)),
                                      # 30 key frames x 6 = 180 unknowns: the L2-resident one-workgroup solver with 6-dim blocks
-                                     (8, dict(n_local=30, n_fixed=8, n_points=2500))])
+                                     (8, dict(n_local=30, n_fixed=8, n_points=2500)),
+                                     # the hand-over between the three solve kernels (lba.hip solver_class): 6-dim blocks,
+                                     # 156 | 162 unknowns (k_lba_ldlt16 | k_lba_ldltg), 636 | 642 (k_lba_ldltg | tiled k_big_*)
+                                     (9, dict(n_local=26, n_fixed=4, n_points=2000)),
+                                     (10, dict(n_local=27, n_fixed=4, n_points=2000)),
+                                     (11, dict(n_local=106, n_fixed=2, n_points=4000)),
+                                     (12, dict(n_local=107, n_fixed=2, n_points=4000))])
 def test_gpu_lba_parity(oracle, seed, kw):
     from vieo_slam_amd.optimizer import Optimizer
     params, kfs, pts, obs, gt = synth_ba.make_lba_problem(seed, **kw)

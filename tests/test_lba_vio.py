@@ -138,12 +138,13 @@ def test_gpu_vio_lba_large_window_parity(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_local", [11, 21, 32, 42])
+@pytest.mark.parametrize("n_local", [10, 11, 21, 32, 42, 43])
 def test_gpu_vio_lba_solver_classes_parity(oracle, n_local):
     """The one-workgroup L2-resident blocked LDL^T (k_lba_ldltg, 160 .. 639 unknowns): its smallest system (11 key
     frames = 165 unknowns, 11 blocks), a visual system whose last key frame straddles two 64-row Schur tiles (21 key
     frames: rows 126..131), 32 key frames (480 unknowns: more row blocks than gather wavefronts x 3) and its largest
-    (42 key frames = 630 unknowns, 40 blocks)."""
+    (42 key frames = 630 unknowns, 40 blocks); and the neighbours across the class boundaries: 10 key frames = 150
+    unknowns (k_lba_ldlt16, LDS-resident) and 43 = 645 (the tiled k_big_* LDL^T over many workgroups)."""
     from vieo_slam_amd.optimizer import Optimizer
     win = list(synth_ba.make_lba_vio_problem(80 + n_local, n_local=n_local, n_fixed=6, n_points=1500, dt_kf=0.25)[:6])
     P = win[0].copy()
