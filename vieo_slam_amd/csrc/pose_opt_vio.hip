@@ -155,12 +155,15 @@ __device__ bool wave_solve_vio(const double* H, int n, double lambda, const doub
   // precision) cycles whatever the number of useful lanes, so the count of instructions is the cost, and this form has
   // a quarter of them.  The reciprocal's Newton chain sits between the write and the reads (hides the LDS turn-around).
   double* colbuf = Ls + NR * NR;  // 2 x 32 doubles behind L
+  // The pivot chain -- d_j -> 1 / d_j (v_rcp_f64 + two Newton steps) -> l -> d_(j+1) -- never waits for LDS: row j + 1's
+  // own update of its diagonal needs only its own two values (A[j+1][j] is its own column entry), so the next pivot is
+  // formed from registers and read by v_readlane while the broadcast of column j is still on its way.
+  double d = readlane_d(a[0], 0);
 #pragma unroll
   for (int j = 0; j < NR; j++) {
     const double c = a[j];  // un-normalised column entry of this row
     double* col = colbuf + (j & 1) * 32;
     if (lane < 32) col[lane] = c;
-    const double d = readlane_d(c, j);
     if (!(d > 0)) ok = false;
     // 1 / d once per column (v_rcp_f64 + two Newton steps, as k_lba_ldlt16 does) instead of a division per row
     double inv = __builtin_amdgcn_rcp(d);
@@ -168,6 +171,7 @@ __device__ bool wave_solve_vio(const double* H, int n, double lambda, const doub
     inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
     if (lane == j) Dl[j] = inv;
     const double l = c * inv;
+    if (j + 1 < NR) d = readlane_d(__builtin_fma(-l, c, a[j + 1 < NR ? j + 1 : j]), j + 1);  // lane j + 1: its new diagonal
     wave_sync();
     // (rows <= j take the update as well: their entries right of the diagonal are never read again)
 #pragma unroll
@@ -684,11 +688,13 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           if (BS > 64 && lane >= 32 && lane < 32 + kNs) ((double*)&S.bki)[lane - 32] = ((const double*)&S.nsi)[lane - 32];
         }
         if (BS == 64) wave_sync();
+        PP(11);
         if (wave == 0) {
           const bool ok = n == 15 ? wave_solve_vio<9>(S.H, n, lambda, S.b, S.x, S.L, S.D, lane)
                                   : wave_solve_vio<24>(S.H, n, lambda, S.b, S.x, S.L, S.D, lane);
           if (lane == 0) S.ok = ok ? 1 : 0;
         }
+        PP(12);
         __syncthreads();
         PP(6);
         const bool ok2 = S.ok != 0;
