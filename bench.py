@@ -297,61 +297,35 @@ def rig_single_stream(rig, n_cams, nfeat, seed, n_cases=3, reps=10):
                     "queries -> SearchByProjection(local map) -> PoseOptimization(rig, marg), one copy back, ONE synchronisation"}
 
 
-def rig_frontend_batch(rig="kb8", n_cams=4, nfeat=1500, seed=300, n_frames=64, steps=5):
-    """Frame::Frame of a BATCH of rig frames device-resident (BASELINE configs[3] shape): ExtractORB of n_frames x n_cams
-    images in one batch call, then ComputeStereoFishEyeMatches of all frames as five launches (no host round trip), and
-    the roofline of the stage's dense kernel: k_knn2 = the Hamming brute-force search north_star names."""
+def rig_frontend_batch(rig="kb8", n_cams=4, nfeat=1500, seed=300, n_frames=256, steps=5):
+    """BASELINE configs[3] shape, batched: B rig frames device-resident through the WHOLE tracking step
+    (pipeline_rig_batch.RigFramePipeline: ExtractORB x B x n_cams in one batch, ComputeStereoFishEyeMatches of the batch as
+    five launches, both projection searches with the camera loop, both rig pose optimisations; no host round trip), and
+    the roofline of the stereo stage's dense kernel: k_knn2 = the Hamming brute-force search north_star names."""
     import ctypes
+    from vieo_slam_amd import synth_ba
     from vieo_slam_amd import synth_scene as sc
-    from vieo_slam_amd import synth_fisheye as sf
     from vieo_slam_amd._lib import DeviceBuffer, check, lib
-    from vieo_slam_amd.ba_types import FISHEYE_PARAMS_DTYPE
-    from vieo_slam_amd.matching import FisheyeStereoDevice
-    from vieo_slam_amd.orb_extractor import KEYPOINT_DTYPE, ORBextractor
+    from vieo_slam_amd.pipeline_rig_batch import RigFramePipeline
     L = lib()
     scene = sc.RigScene(seed, rig, n_cams)
-    frames = []
-    for i in range(3):
-        c = sc.make_rig_tracking_case(seed + 10 * i, scene)
-        frames += [c["images0"], c["images1"]]
-    Wd, Hd = scene.W, scene.H
-    imgs = np.stack([np.stack(frames[f % len(frames)]) for f in range(n_frames)])  # [frame][cam][H][W]
-    ext = ORBextractor(nfeat, 1.2, 8, 20, 7)
-    cap = ext.max_keypoints()
-    lap = [0, Wd - 1] if int(scene.cams[0]["model"]) == 2 else None
-    sig2 = np.ascontiguousarray((np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2, np.float32)
-    Trc, Tcr = sf.rig_extrinsics(scene.Tcr)
-    fp = np.zeros(1, FISHEYE_PARAMS_DTYPE)
-    fp[0]["n_cams"], fp[0]["n_levels"], fp[0]["bf"], fp[0]["th_far_pts"] = n_cams, 8, 0.11 * float(scene.cams[0]["fx"]), 0.0
-    fp[0]["cams"], fp[0]["Trc"], fp[0]["Tcr"], fp[0]["level_sigma2"] = (scene.cams.ctypes.data, Trc.ctypes.data,
-                                                                        Tcr.ctypes.data, sig2.ctypes.data)
-    fe = FisheyeStereoDevice(fp, cap, max_frames=n_frames)
-    gcap, kc, n_img = fe.gcap, n_cams * cap, n_frames * n_cams
-    d_img = DeviceBuffer(imgs.nbytes)
-    d_img.upload(imgs)
-    sizes = dict(kp=n_img * cap * KEYPOINT_DTYPE.itemsize, desc=n_img * cap * 32, cnt=n_img * 8, kcat=n_frames * kc * KEYPOINT_DTYPE.itemsize,
-                 dcat=n_frames * kc * 32, first=n_frames * (n_cams + 1) * 4, fcnt=n_frames * 8, depth=n_frames * kc * 4,
-                 ur=n_frames * kc * 4, kg=n_frames * kc * 4, gidx=n_frames * gcap * n_cams * 4, good=n_frames * gcap,
-                 p3d=n_frames * gcap * 24, hdr=n_frames * 32)
-    d = {k: DeviceBuffer(max(v, 16)) for k, v in sizes.items()}
-    st = ctypes.c_void_p(L.vieo_orb_stream(ext._h))
-
-    def step():
-        ext.extract_batch_device(d_img.ptr, n_img, Wd, Hd, Wd, Wd * Hd, d["kp"].ptr, d["desc"].ptr, cap, d["cnt"].ptr, lapping=lap)
-        check(L.vieo_stereo_fisheye_match_batch_device(fe.h, d["kp"].ptr, d["desc"].ptr, d["cnt"].ptr, n_frames, d["kcat"].ptr,
-                                                       d["dcat"].ptr, d["first"].ptr, d["fcnt"].ptr, d["depth"].ptr, d["ur"].ptr,
-                                                       d["kg"].ptr, d["gidx"].ptr, d["good"].ptr, d["p3d"].ptr, d["hdr"].ptr, st),
-              "vieo_stereo_fisheye_match_batch_device")
-    step()
-    ext.sync()
+    cases = [sc.make_rig_tracking_case(seed + 10 * i, scene) for i in range(3)]
+    P = RigFramePipeline(scene, cases, nfeat, n_frames, seed=seed)
+    P.step()
+    P.sync()
+    P.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
-    ext.sync()
+        P.step()
+    P.sync()
     dt = (time.perf_counter() - t0) / steps
-    hdr = d["hdr"].download(np.int32, (n_frames, 8))
-    cnt = d["cnt"].download(np.int32, (n_frames, n_cams, 2))
-    # ---- k_knn2 alone between two events on the extractor's stream
+    stage = P.stage_ms_all()
+    R = P.results()
+    hdr = R["hdr"]
+    cnt = P.d_cnt.download(np.int32, (n_frames, n_cams, 2))
+    errs = [float(synth_ba.pose_error(R["r2"][b]["base"]["nav"], P.truth[b])[0]) for b in range(n_frames)]
+    # ---- k_knn2 alone between two events on the pipeline's stream
+    st, cap, n_img = P.stream, P.cap, n_frames * n_cams
     n_pairs = n_cams * (n_cams - 1) // 2
     d_idx, d_dist = DeviceBuffer(n_frames * n_pairs * cap * 8), DeviceBuffer(n_frames * n_pairs * cap * 8)
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
@@ -360,9 +334,9 @@ def rig_frontend_batch(rig="kb8", n_cams=4, nfeat=1500, seed=300, n_frames=64, s
     for k in range(K + 2):
         if k == 2:
             check(L.vieo_event_record(e0, st))
-        check(L.vieo_hamming_knn2_rig_batch_device(d["desc"].ptr, d["cnt"].ptr, cap, n_cams, n_frames, d_idx.ptr, d_dist.ptr, st))
+        check(L.vieo_hamming_knn2_rig_batch_device(P.d_desc.ptr, P.d_cnt.ptr, cap, n_cams, n_frames, d_idx.ptr, d_dist.ptr, st))
     check(L.vieo_event_record(e1, st))
-    ext.sync()
+    P.sync()
     ms = ctypes.c_float()
     check(L.vieo_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
     launch_ms = ms.value / K
@@ -378,15 +352,18 @@ def rig_frontend_batch(rig="kb8", n_cams=4, nfeat=1500, seed=300, n_frames=64, s
                 ops += nq * nt * 8
     gbs = alg / (launch_ms * 1e-3) / 1e9
     L.vieo_event_destroy(e0), L.vieo_event_destroy(e1)
-    for b in list(d.values()) + [d_img, d_idx, d_dist]:
-        b.free()
-    fe.close()
+    d_idx.free(), d_dist.free()
+    P.close_all()
     return {
-        "config": "BASELINE configs[3] shape: %d frames of a %d-camera %s rig, %d features per camera, device-resident: "
-                  "ExtractORB x %d images in one batch + ComputeStereoFishEyeMatches of the batch (5 launches, no host round "
-                  "trip); replicas of 6 rendered rig frames" % (n_frames, n_cams, rig, nfeat, n_img),
+        "config": "BASELINE configs[3] shape: %d frames of a %d-camera %s rig, %d features per camera, device-resident, the whole "
+                  "tracking step: ExtractORB x %d images in one batch, ComputeStereoFishEyeMatches of the batch (5 launches), "
+                  "SearchByProjection(last frame) with the camera loop, PoseOptimization(VIO, rig), isInFrustum + queries, "
+                  "SearchByProjection(local map), PoseOptimization(VIO, rig, marg); no host round trip; noise replicas of 3 "
+                  "rendered rig frame pairs" % (n_frames, n_cams, rig, nfeat, n_img),
         "rig_frames_per_s": n_frames / dt, "ms_per_step": 1e3 * dt, "camera_images_per_s": n_img / dt,
+        "stage_ms_per_step": {k: float(np.mean([s_[k] for s_ in stage])) for k in P.STAGES},
         "mean_keys_per_camera": float(cnt[:, :, 0].mean()), "mean_stereo_groups_per_frame": float(hdr[:, 0].mean()),
+        "mean_pose_inliers": float(np.mean(R["r2"]["base"]["n_inliers"])), "median_position_error_vs_truth_m": float(np.median(errs)),
         "fill_matches_walk": {"rows_per_frame": float(hdr[:, 5].mean()), "wavefront_steps_per_frame": float(hdr[:, 6].mean()),
                               "note": "FillMatchesFromPair's order-dependent group tables on the device: rows applied per "
                                       "speculative-parallel step = rows / steps (sequential form: 1)"},
@@ -1034,7 +1011,7 @@ def main():
                 ss = out["single_stream_rig"]
                 ss["reference_readme_anchor"] = dict(README_FRONTEND_DIST_MS, ratio_to_default_mh05_ms_per_rig_frame=
                                                      README_FRONTEND_DIST_MS["value"] / ss["default_mh05_distorted_stereo"]["ms_per_rig_frame"])
-                out["rig_frontend_batch"] = rig_frontend_batch()
+                out["rig_batch"] = rig_frontend_batch()
                 out["single_stream_vision_only"] = vision_single_stream()
             except Exception as e:
                 out["single_stream_rig"] = {"error": repr(e)}

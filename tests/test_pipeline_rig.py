@@ -95,3 +95,44 @@ def test_rig_frontend_chain_stage_by_stage(oracle, rig, nc, nfeat, seed):
     gdt, gdr = synth_ba.pose_error(out["r2"]["base"]["nav"], case["truth"])
     assert gdt < 1e-2 and gdr < 5e-3, (gdt, gdr)
     assert out["r2"]["base"]["n_inliers"] > 60
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rig,nc,nfeat,seed", [("kb8", 4, 1500, 7), ("radtan", 2, 1200, 8)])
+def test_batched_rig_pipeline_equals_the_staged_chain(rig, nc, nfeat, seed):
+    """pipeline_rig_batch.RigFramePipeline -- a batch of rig frames device-resident through the whole tracking chain (what
+    bench.py's batched rig leg times) -- against the stage-by-stage chain of RigFrontEnd on the same inputs (the chain
+    tests/test_tracker_rig.py and the test above tie to the oracle): held map points, both optimisations."""
+    from vieo_slam_amd.pipeline_rig import RigFrontEnd
+    from vieo_slam_amd.pipeline_rig_batch import RigFramePipeline
+    scene = sc.RigScene(seed, rig, nc)
+    cases = [sc.make_rig_tracking_case(seed + 10 * i, scene) for i in range(2)]
+    B = 5  # frames 2.. are noisy replicas of the two base cases
+    P = RigFramePipeline(scene, cases, nfeat, B, seed=3)
+    P.step()
+    P.step()  # a second pass over the resident batch gives the same answer
+    R = P.results()
+    assert (R["hdr"][:, 3] == 0).all()
+    for b in range(2):
+        case, pr = cases[b], P.prep[b]
+        F = P.f1_host[b]
+        fs = RigFrontEnd(scene, nfeat)
+        ref = fs.track(case, pred=(F["base"]["nav"].copy(), F["imu"].copy()), track_depth=pr["z"])
+        fr1 = ref["fr1"]
+        N = int(R["first"][b, nc])
+        assert N == fr1.N and np.array_equal(R["keys"][b, :N].view(np.uint8), fr1.keys.view(np.uint8))
+        assert np.allclose(R["depth"][b, :N], fr1.depth, rtol=1e-6, atol=0)
+        tab = R["mp_ref"][b, :N].astype(np.int64)
+        held = np.full(N, -1, np.int64)
+        a = (tab >= 0) & (tab < P.kc)
+        held[a] = pr["mps"]["key_mp"][tab[a]]
+        held[tab >= P.kc] = tab[tab >= P.kc] - P.kc
+        assert np.array_equal(held, ref["mp_ref"]), b
+        for name, got in (("r1", R["r1"][b]), ("r2", R["r2"][b])):
+            dt, dr = synth_ba.pose_error(ref[name]["base"]["nav"], got["base"]["nav"])
+            assert dt < 1e-4 and dr < 1e-4, (b, name, dt, dr)
+            assert int(ref[name]["base"]["n_inliers"]) == int(got["base"]["n_inliers"]), (b, name)
+    for b in range(B):  # every frame of the batch is tracked
+        gdt, gdr = synth_ba.pose_error(R["r2"][b]["base"]["nav"], P.truth[b])
+        assert gdt < 1e-2 and gdr < 5e-3 and int(R["r2"][b]["base"]["n_inliers"]) > 60, (b, gdt, gdr)
+    P.close_all()
