@@ -425,6 +425,12 @@ int vieo_search_by_projection_rig_batch_device(int mode, const vieo_proj_query* 
                                                int check_orientation, int32_t* d_assign, int32_t* d_nmatches,
                                                void* stream);
 
+/* The window grid of a search (Frame::mGrid as a CSR, built on the device by every *_batch_device search call) depends on
+ * the frame's keys only.  vieo_sbp_keep_grid(1) tells the NEXT search call of this host thread that its key arrays hold what
+ * the previous call's held (same device pointers, geometry and stream are checked, the contents are the caller's promise):
+ * the grid is then not rebuilt -- TrackLocalMap's search after TrackWithIMU's in the one-call tracker.  One call only. */
+int vieo_sbp_keep_grid(int on);
+
 /* ---------------------------------------------------------------- pose optimisation --------
  * Replaces Optimizer::PoseOptimization (motion-only BA with fixed map points).  The host shim
  * flattens Frame / MapPoint objects into the POD structs below and writes the results back

@@ -104,6 +104,7 @@ _SIGS = {
     "vieo_sbp_project_last_frame_rig": (c_i, [c_p, c_i, c_p, c_p, c_p]),
     "vieo_sbp_project_keyframe": (c_i, [c_p, c_i, c_p, c_p, c_f, c_p]),
     "vieo_search_by_projection_rig": (c_i, [c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_i, c_p, c_p]),
+    "vieo_sbp_keep_grid": (c_i, [c_i]),
     "vieo_sbp_project_last_frame_rig_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
     "vieo_search_by_projection_rig_batch_device": (c_i, [c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i,
                                                           c_f, c_i, c_p, c_p, c_p]),

@@ -372,43 +372,46 @@ __global__ void __launch_bounds__(256) k_stereo_rect(StereoArgs A) {
 // matches with SAD >= 1.5*1.4*median.  One workgroup per frame; the k-th smallest is found by a
 // 17-step bisection on the value (SADs are integers below 2^17).
 __global__ void __launch_bounds__(256) k_stereo_median(StereoArgs A) {
-  __shared__ int s_cnt[256];
-  __shared__ int s_n;
-  const int f = blockIdx.x, tid = threadIdx.x;
+  // The frame's SADs stay in registers (8 per thread: 2048 keys; more fall back to re-reading), a bisection round is a
+  // count per thread, one DPP sum per wavefront and four partial sums through LDS -- was: the SADs re-read from HBM and a
+  // 256-entry serial sum by one thread in each of the 17 rounds (31 us for one frame, now a few).
+  __shared__ int s_part[2][4];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int imL = A.l_first + f * A.l_step;
   const int N = min(A.cntL[2 * imL], A.capL);
   int* sad = A.sad + (size_t)f * A.capL;
-  int c = 0;
-  for (int i = tid; i < N; i += 256) c += sad[i] >= 0;
-  s_cnt[tid] = c;
-  __syncthreads();
-  if (tid == 0) {
-    int n = 0;
-    for (int t = 0; t < 256; t++) n += s_cnt[t];
-    s_n = n;
+  constexpr int kR = 8;
+  int v[kR];
+#pragma unroll
+  for (int r = 0; r < kR; r++) {
+    const int i = tid + 256 * r;
+    v[r] = i < N ? sad[i] : -1;
   }
-  __syncthreads();
-  const int n = s_n;
+  const bool spill = N > 256 * kR;
+  auto block_count = [&](int bound, int slot) -> int {  // number of SADs s with 0 <= s <= bound
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < kR; r++) c += (v[r] >= 0 && v[r] <= bound);
+    if (spill)
+      for (int i = tid + 256 * kR; i < N; i += 256) {
+        const int s = sad[i];
+        c += (s >= 0 && s <= bound);
+      }
+    c = wave_sum_i32(c);
+    if (lane == 0) s_part[slot][wave] = c;
+    __syncthreads();
+    return s_part[slot][0] + s_part[slot][1] + s_part[slot][2] + s_part[slot][3];
+  };
+  const int n = block_count((1 << 30), 0);
   if (n == 0) return;
   const int k = n / 2;  // 0-based rank of the median element
   int lo = 0, hi = (1 << 17) - 1;  // smallest v with count(sad <= v) >= k+1
+  int slot = 1;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    int cc = 0;
-    for (int i = tid; i < N; i += 256) {
-      const int s = sad[i];
-      cc += (s >= 0 && s <= mid);
-    }
-    __syncthreads();
-    s_cnt[tid] = cc;
-    __syncthreads();
-    if (tid == 0) {
-      int t2 = 0;
-      for (int t = 0; t < 256; t++) t2 += s_cnt[t];
-      s_n = t2;
-    }
-    __syncthreads();
-    if (s_n >= k + 1)
+    const int cnt = block_count(mid, slot);  // (alternating slots: one barrier per round is enough)
+    slot ^= 1;
+    if (cnt >= k + 1)
       hi = mid;
     else
       lo = mid + 1;

@@ -482,6 +482,7 @@ static int track_chain_tail(vieo_tracker* t, int nc_local) {
                                       (const vieo_frustum_point*)(t->d_loc + t->l_cpt), t->d_loc + t->l_cdesc,
                                       (const int32_t*)(t->d_up + t->o_alias), d_held, t->pcap, nc_local, P.th_local,
                                       t->rig ? t->R.th_far_pts : 0.f, dH->consts + 16, d_q2, d_dep + kc, dO->nq, st));
+  (void)vieo_sbp_keep_grid(1);  // the frame's keys have not changed since the first search
   TRK(search(VIEO_SBP_LOCAL_MAP, d_q2, dO->nq, t->ccap * nc, d_taken, P.nn_local, dO->nm + 1));
   TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, kc, 0, nc, nullptr, nullptr, 0, st));
   TRK(build_obs(f2));
