@@ -194,3 +194,24 @@ def test_fisheye_device_batch_matches_oracle_and_walks_in_parallel(oracle):
     compute_stereo_fisheye_matches(c["params"], c["keys"], c["descs"], c["num_mono"])
     rows, steps = fisheye_last_walk()
     assert rows > 100 and 0 < steps < rows
+
+
+@pytest.mark.gpu
+def test_fisheye_device_batch_ragged_frames(oracle):
+    """One batch whose frames differ in what they have: a full frame, a frame with an empty camera, a frame whose
+    second camera has no usable rows (num_mono >= n) and a frame with a single key in camera 1 (knnMatch returns one
+    neighbour) -- each equals its own oracle run."""
+    from vieo_slam_amd.matching import FisheyeStereoDevice
+    cases = [synth_fisheye.make_fisheye_case(41 + i, rig="kb8", n_points=150) for i in range(4)]
+    cases[1]["keys"][2], cases[1]["descs"][2] = cases[1]["keys"][2][:0], cases[1]["descs"][2][:0]
+    cases[2]["num_mono"] = np.array([0, len(cases[2]["keys"][1]), 0, 0], np.int32)
+    cases[3]["keys"][1], cases[3]["descs"][1] = cases[3]["keys"][1][:1], cases[3]["descs"][1][:1]
+    cap = max(len(k) for c in cases for k in c["keys"]) + 3
+    dev = FisheyeStereoDevice(cases[0]["params"], cap, max_frames=4)
+    outs = dev.match_batch([(c["keys"], c["descs"], c["num_mono"]) for c in cases])
+    for c, h in zip(cases, outs):
+        o = oracle.stereo_fisheye(c["params"], c["keys"], c["descs"], c["num_mono"])
+        assert np.array_equal(o["group_idx"], h["group_idx"]) and np.array_equal(o["group_good"], h["group_good"])
+        assert np.array_equal(o["key_group"], h["key_group"]) and o["n_matches"] == h["n_matches"]
+        assert np.array_equal(o["depth"] < 0, h["depth"] < 0) and np.allclose(o["depth"], h["depth"], rtol=1e-6, atol=0)
+    dev.close()

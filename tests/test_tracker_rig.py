@@ -89,3 +89,34 @@ def test_gpu_rig_tracker_equals_the_staged_chain_and_the_oracle(oracle, rig, nc,
     assert np.array_equal(v2["point_ref"], tab.astype(np.int32)) and o2["second"]["base"]["nav"].tobytes() == o["second"]["base"]["nav"].tobytes()
     print("rig tracker %s x%d: %.2f ms in the call (GPU %.2f)" % (rig, nc, float(o2["ms_host"]), float(o2["ms_gpu"])))
     trk.close()
+
+
+@pytest.mark.gpu
+def test_gpu_rig_tracker_edge_cases(monkeypatch):
+    """No map yet (no last-frame points, no local map): the frame's extraction and stereo outputs are valid, the status is
+    LOST (TrackWithIMU's `nmatches < 10`, Tracking.cc:311) after the widened search.  A stereo group table too small for
+    the frame: stereo_status reports it, no depths, the call itself succeeds."""
+    from vieo_slam_amd.ba_types import LAST_FRAME_POINT_DTYPE
+    from vieo_slam_amd.map_point import FRUSTUM_POINT_DTYPE
+    from vieo_slam_amd.pipeline_rig import RigFrontEnd
+    from vieo_slam_amd.tracker import Tracker, rig_params
+    scene = sc.RigScene(9, "kb8", 2)
+    case = sc.make_rig_tracking_case(9, scene)
+    prm, rg = rig_params(scene, 1500, max_local_points=256)
+    trk = Tracker(prm, rg)
+    nav = case["vio"][0]["nav_last"]
+    none_p, none_c = np.zeros(0, LAST_FRAME_POINT_DTYPE), np.zeros(0, FRUSTUM_POINT_DTYPE)
+    o, v = trk.track(None, None, case["imu_samples"], 0.0, case["dt_frame"], nav, nav, None, none_p, np.zeros(0, np.float32),
+                     none_c, np.zeros((0, 32), np.uint8), np.zeros(0, np.int32), 1, images=case["images1"])
+    assert int(o["status"]) == 2 and int(o["widened"]) == 1 and int(o["n_matches_last"]) == 0
+    fr = RigFrontEnd(scene, 1500).make_frame(case["images1"])
+    assert int(o["n_keys"]) == fr.N and np.array_equal(v["keys"].view(np.uint8), fr.keys.view(np.uint8))
+    assert np.array_equal(v["key_group"], fr.fe["key_group"]) and int(o["n_groups"]) == len(fr.fe["group_good"]) > 100
+    assert (v["point_ref"] == -1).all()
+    trk.close()
+    monkeypatch.setenv("VIEO_FE_GCAP", "64")
+    trk = Tracker(prm, rg)
+    o, v = trk.track(None, None, case["imu_samples"], 0.0, case["dt_frame"], nav, nav, None, none_p, np.zeros(0, np.float32),
+                     none_c, np.zeros((0, 32), np.uint8), np.zeros(0, np.int32), 1, images=case["images1"])
+    assert int(o["stereo_status"]) != 0 and int(o["n_groups"]) == 0 and (v["depth"] < 0).all() and int(o["n_keys"]) == fr.N
+    trk.close()

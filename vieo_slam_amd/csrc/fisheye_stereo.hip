@@ -610,6 +610,8 @@ int vieo_fisheye_create(vieo_fisheye** out, const vieo_fisheye_params* P, int ke
   // groups: as many as keys, or what the LDS tables hold
   const int n_chunks = h->n_pairs * ((h->cap + 63) / 64);
   h->gcap = nc * h->cap;
+  if (const char* e = getenv("VIEO_FE_GCAP"))  // tests: a small table to reach the overflow status
+    if (atoi(e) > 0) h->gcap = std::min(h->gcap, std::max(atoi(e), 64));
   while (h->gcap > 64 && fe_fill_lds(nc, h->cap, h->gcap, n_chunks) > kFeLdsMax) h->gcap -= 64;
   h->lds = fe_fill_lds(nc, h->cap, h->gcap, n_chunks);
   if (h->lds > kFeLdsMax) {
