@@ -324,6 +324,13 @@ struct Replay {
     vieo_lba_result res;
     double ms = 0;
     int rc = 0;
+    // the newest key frame's inertial edge, pre-integrated on the LocalMapping thread too (only the local BA reads it)
+    bool need_edge = false;
+    int edge_kf = -1;
+    std::vector<vieo_imu_sample> samples;
+    vieo_imu_noise noise;
+    double ti = 0, tj = 0, bg[3], ba[3];
+    vieo_imu_preint edge;
   };
   std::unique_ptr<LbaJob> lba_build() {
     std::unique_ptr<LbaJob> Jp(new LbaJob());
@@ -397,13 +404,26 @@ struct Replay {
   }
   static void lba_solve(LbaJob* J) {  // (any host thread)
     const auto t0 = std::chrono::steady_clock::now();
+    if (J->need_edge) {
+      const int32_t first[2] = {0, (int32_t)J->samples.size()};
+      double prv[81];
+      int32_t st = 0;
+      J->rc = vieo_imu_preintegrate_batch(&J->noise, J->samples.data(), first, &J->ti, &J->tj, J->bg, J->ba, 1, &J->edge, prv, &st);
+      if (J->rc != 0 || st != 0) {
+        J->rc = J->rc ? J->rc : -1;
+        return;
+      }
+      std::memcpy(J->edge.Sigma, prv, sizeof(prv));  // mSigmaijPRV for the local BA
+      J->edges.back().imu = J->edge;                 // (the newest key frame's edge is the last one built)
+    }
     J->rc = vieo_local_bundle_adjustment_vio(&J->P, J->K.data(), (int)J->K.size(), J->X.data(), J->close.data(), (int)J->pts.size(),
                                              J->obs.data(), (int)J->obs.size(), J->edges.data(), (int)J->edges.size(), nullptr,
                                              J->navs.data(), J->Xo.data(), J->erase.data(), &J->res);
     J->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   void lba_apply(LbaJob& J) {
-    if (J.rc != 0) std::fprintf(stderr, "local BA failed: %s\n", vieo_last_error()), std::exit(1);
+    if (J.rc != 0) std::fprintf(stderr, "local BA / key-frame pre-integration failed: %s\n", vieo_last_error()), std::exit(1);
+    if (J.need_edge) kfs[J.edge_kf]->edge = J.edge;
     ms_lba += J.ms;
     n_lba_applied++;
     if (J.res.status != 0) return;
@@ -565,23 +585,35 @@ struct Replay {
     if (k % kf_every == 0) {
       const Frame& kp = *kfs.back();
       S.imu_between(kp.t, t, &i0, &ni);
-      const int32_t first[2] = {0, ni};
-      vieo_imu_preint im;
-      double prv[81];
-      int32_t st = 0;
-      CHECK(vieo_imu_preintegrate_batch(&S.noise, S.imu.data() + i0, first, &kp.t, &t, kp.nav.bg, kp.nav.ba, 1, &im, prv, &st));
-      if (st != 0) std::fprintf(stderr, "key-frame pre-integration failed\n"), std::exit(1);
-      std::memcpy(im.Sigma, prv, sizeof(prv));  // mSigmaijPRV for the local BA
       for (int i = 0; i < f->N; i++)
         if (f->outlier[i]) f->mp_ref[i] = -1;
-      insert_keyframe(f, f->nav, &im);
       if (lba_lag <= 0) {
+        const int32_t first[2] = {0, ni};
+        vieo_imu_preint im;
+        double prv[81];
+        int32_t st = 0;
+        CHECK(vieo_imu_preintegrate_batch(&S.noise, S.imu.data() + i0, first, &kp.t, &t, kp.nav.bg, kp.nav.ba, 1, &im, prv, &st));
+        if (st != 0) std::fprintf(stderr, "key-frame pre-integration failed\n"), std::exit(1);
+        std::memcpy(im.Sigma, prv, sizeof(prv));  // mSigmaijPRV for the local BA
+        insert_keyframe(f, f->nav, &im);
         local_ba();
         f->nav = kfs.back()->nav;  // mLastFrame follows its reference key frame (UpdateLastFrame)
         map_updated = true;
       } else {
+        // LocalMapping's work goes to its thread whole: the key-frame-to-key-frame pre-integration (an input of the local
+        // BA only) and the solve; the edge is stored with the write-back
+        const double kp_t = kp.t;
+        double kbg[3], kba[3];
+        std::memcpy(kbg, kp.nav.bg, 24), std::memcpy(kba, kp.nav.ba, 24);
+        vieo_imu_preint placeholder;
+        std::memset(&placeholder, 0, sizeof(placeholder));
+        insert_keyframe(f, f->nav, &placeholder);
         before_frame(k + lba_lag + kf_every);  // (a job still pending is applied first)
         job = lba_build();
+        job->need_edge = true, job->edge_kf = (int)kfs.size() - 1;
+        job->samples.assign(S.imu.begin() + i0, S.imu.begin() + i0 + ni);
+        job->noise = S.noise, job->ti = kp_t, job->tj = t;
+        std::memcpy(job->bg, kbg, 24), std::memcpy(job->ba, kba, 24);
         n_lba++;
         lba_due = k + lba_lag;
         lba_submit(job.get());
