@@ -21,10 +21,11 @@ else:
     Rc.run(n)
 f(out)
 v = np.array(list(out), float)
-names16 = ["", "", "", "", "", "", "", "", "", "", "", "  (11) top of trial: sync + backup", "  (12) solve", "", "", ""]
+names16 = ["", "", "", "", "", "", "", "", "", "", "", "(11) top of trial: sync + backup", "(12) solve", "(13) generic_errors: tid 0's edge",
+           "(14) generic_errors: wait for the other edges", "(15) generic_errors: information products"]
 names = ["loop/bookkeeping", "generic_errors", "visual linearize loop", "block_sum", "publish + imu/prior linearize", "H assembly", "backup + ldlt", "ns_inc", "generic_errors (trial)", "visual_chi (trial)", "iteration tail"]
-tot = v[:11].sum()
-for i, nm in enumerate(names): print("%-32s %6.1f %%  %9.0f cycles per pose call" % (nm, 100 * v[i] / tot, v[i] / (2 * (n - 1))))
-for i in (11, 12):
-    print("%-32s %6.1f %%  %9.0f cycles per pose call" % (names16[i], 100 * v[i] / tot, v[i] / (2 * (n - 1))))
+tot = v.sum()
+for i, nm in enumerate(names): print("%-46s %6.1f %%  %9.0f cycles per pose call" % (nm, 100 * v[i] / tot, v[i] / (2 * (n - 1))))
+for i in (11, 12, 13, 14, 15):
+    print("%-46s %6.1f %%  %9.0f cycles per pose call" % (names16[i], 100 * v[i] / tot, v[i] / (2 * (n - 1))))
 print("total cycles per pose call %.0f = %.0f us at 2.4 GHz" % (tot / (2 * (n - 1)), tot / (2 * (n - 1)) / 2400))

@@ -247,6 +247,43 @@ __device__ __forceinline__ void block_sum_bs(double* vals, double* s_red, int ti
   }
 }
 
+// Block-wide sums of N values per thread through an LDS transpose: out[v] = sum over the BS threads of vals[v].
+// A wavefront issues one instruction per 4 cycles however few lanes are useful, so N butterfly sums cost N x 6 steps x 3
+// instructions per wavefront; here every thread stores its N values (thread-major inside blocks of 32, stride 34
+// doubles: 16-byte aligned, at most 2 lanes per bank), thread (v, part) adds the 32 values of its block with four
+// independent chains, and the BS / 32 parts of a value -- neighbouring lanes -- meet in up to three DPP steps: about
+// 90 instructions per thread for N = 28 instead of about 500.  The association order is fixed (same result every run).
+// tr: N * (BS / 32) * 34 doubles nobody else uses between the two barriers inside; out: N doubles, valid after return.
+template <int N, int BS>
+__device__ __forceinline__ void block_sum_lds(const double* vals, double* tr, double* out, int tid) {
+  constexpr int P = BS / 32, CS = 34;
+  static_assert(N * P <= BS && (P == 2 || P == 4 || P == 8), "one thread per (value, part)");
+  {
+    double* w = tr + (tid >> 5) * CS + (tid & 31);
+#pragma unroll
+    for (int v = 0; v < N; v++) w[v * P * CS] = vals[v];
+  }
+  __syncthreads();
+  if (tid < N * P) {
+    const double* r = tr + tid * CS;  // block (v * P + part) = tid
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) s0 += r[k], s1 += r[k + 1], s2 += r[k + 2], s3 += r[k + 3];
+    double s = (s0 + s1) + (s2 + s3);
+#define VIEO_DPP_ADD(ctrl)                                                                              \
+  {                                                                                                     \
+    const int l2 = VIEO_DPP(0, __double2loint(s), ctrl, 0xF), h2 = VIEO_DPP(0, __double2hiint(s), ctrl, 0xF); \
+    s += __hiloint2double(h2, l2);                                                                      \
+  }
+    VIEO_DPP_ADD(0xB1)               // quad_perm [1, 0, 3, 2]: lane ^ 1
+    if (P >= 4) VIEO_DPP_ADD(0x4E)   // quad_perm [2, 3, 0, 1]: lane ^ 2
+    if (P >= 8) VIEO_DPP_ADD(0x141)  // row_half_mirror: the other quad of the eight
+#undef VIEO_DPP_ADD
+    if ((tid & (P - 1)) == 0) out[tid / P] = s;
+  }
+  __syncthreads();
+}
+
 // EdgeReproject::linearizeOplus (g2otypes.h:439-498): Jacobian of the (up to 3) residual rows
 // w.r.t. (dp, dphi) of the body pose, J[r*6 + 0..2] = d/dp, J[r*6 + 3..5] = d/dphi.
 __device__ __forceinline__ void visual_jacobian(const CamD& c, const PoseXf& X, const double* p,

@@ -116,22 +116,31 @@ __device__ __forceinline__ double readlane_d(double v, int srclane) {
 // that is free -- the inertial edge's Jacobian has no column for it, the visual, prior and encoder edges neither.  Its six
 // unknowns are eliminated in closed form (pivot d_t = w_t + lambda) and the factorisation runs on the remaining NR = 24
 // (last state free) or 9 (last state fixed) unknowns: 0.65x / 0.25x of the dependent pivot chain of the 30 / 15-dim form.
-// Reduced index r -> system index: r < 9 ? r : r + 6.  Lane r owns row r; 1 / d per column is kept in LDS (Dl), the
-// factor L goes through LDS (Ls) for the back substitution.
+// Reduced index r -> system index: r < 9 ? r : r + 6.  Lane r owns row r and keeps 1 / d_r; the columns broadcast during
+// the factorisation stay in LDS (Ls, NR x 34 doubles) and serve the back substitution.
+// (the "TP:" comments mark the phases tools/micro/gen_solve_bench.py puts its s_memtime probes at)
+// The function is out of line (two instances, one call site each); its arrays are named in the LDS address space so that
+// every access is a plain ds_ instruction -- through generic pointers each one carried a 64-bit address add and a null
+// test of the flat -> LDS cast (3 extra instructions per access, about a third of the function).
+typedef __attribute__((address_space(3))) double lds_f64;
 template <int NR>
-__device__ bool wave_solve_vio(const double* H, int n, double lambda, const double* b, double* x, double* Ls, double* Dl,
-                               int lane) {
+__device__ bool wave_solve_vio(const lds_f64* H, int n, double lambda, const lds_f64* b, lds_f64* x, lds_f64* Ls, int lane) {
+  // the lane masks below are formed here, per call: hoisted out of the caller's trial loop they would live in ~100
+  // scalar registers, i.e. be spilled to lanes of a VGPR and read back by v_readlane, two instructions per use
+  asm volatile("" : "+v"(lane));
   double a[NR];
-  const int row = lane < NR ? lane : 0;
+  // lanes 32..63 mirror lanes 0..31 (same row, same values, same LDS addresses): no execution mask anywhere
+  const int l32 = lane & 31;
+  const int row = l32 < NR ? l32 : 0;
   const int frow = row < 9 ? row : row + 6;
 #pragma unroll
-  for (int k = 0; k < NR; k++) a[k] = H[frow * n + (k < 9 ? k : k + 6)] + (k == row ? lambda : 0.0);
-  double y = lane < NR ? b[frow] : 0.0;
+  for (int k = 0; k < NR; k++) a[k] = H[frow * n + (k < 9 ? k : k + 6)];  // lambda joins the pivots as they are read
+  double y = l32 < NR ? b[frow] : 0.0;
   bool ok = true;
   // the six eliminated unknowns: lane t < 6 keeps its pivot's reciprocal, lanes 18 + t of the 24-dim form take the update
   double dbias = 1.0, off = 0.0;
   {
-    const int t = NR == 24 ? (lane >= 18 && lane < 24 ? lane - 18 : (lane < 6 ? lane : 0)) : (lane < 6 ? lane : 0);
+    const int t = NR == 24 ? (l32 >= 18 && l32 < 24 ? l32 - 18 : (l32 < 6 ? l32 : 0)) : (l32 < 6 ? l32 : 0);
     const double d = H[(9 + t) * n + 9 + t] + lambda;
     if (!(d > 0)) ok = false;
     double inv = __builtin_amdgcn_rcp(d);
@@ -140,76 +149,79 @@ __device__ bool wave_solve_vio(const double* H, int n, double lambda, const doub
     dbias = inv;
     if (NR == 24) {
       off = H[(9 + t) * n + 24 + t];
-      if (lane >= 18 && lane < 24) {
-        const double l = off * inv;
+      const double l = l32 >= 18 && l32 < 24 ? off * inv : 0.0;
 #pragma unroll
-        for (int k = 18; k < 24; k++)
-          if (k == lane) a[k] -= l * off;
-        y -= l * b[9 + t];
-      }
+      for (int k = 18; k < 24; k++) a[k] = __builtin_fma(k == l32 ? -l : 0.0, off, a[k]);
+      y = __builtin_fma(-l, b[9 + t], y);
     }
   }
   ok = __all(ok);
+  // TP:factor
   // Column j travels to the other rows through LDS (one ds_write per lane, then wave-uniform -- broadcast -- reads, two
   // values per instruction) instead of two v_readlane per value: a wavefront issues one instruction every 4 (8 for double
   // precision) cycles whatever the number of useful lanes, so the count of instructions is the cost, and this form has
-  // a quarter of them.  The reciprocal's Newton chain sits between the write and the reads (hides the LDS turn-around).
-  double* colbuf = Ls + NR * NR;  // 2 x 32 doubles behind L
+  // a quarter of them.  Every column keeps its own 34 doubles of Ls, zero at and above the diagonal: together they are
+  // L^T un-normalised, which is what the backward substitution reads (lane i its own column i) -- L is never stored.
+  lds_f64* colbuf = Ls;  // NR x kCS doubles: 34 keeps pairs 16-byte aligned and spreads the backward pass's per-lane
+  constexpr int kCS = 34;  // column reads over the banks (32 would put every lane on one bank: 32 passes per read)
   // The pivot chain -- d_j -> 1 / d_j (v_rcp_f64 + two Newton steps) -> l -> d_(j+1) -- never waits for LDS: row j + 1's
   // own update of its diagonal needs only its own two values (A[j+1][j] is its own column entry), so the next pivot is
   // formed from registers and read by v_readlane while the broadcast of column j is still on its way.
-  double d = readlane_d(a[0], 0);
+  // The forward substitution y = L^-1 b rides along (b is one more column of the row: y_j is final once pivot j starts).
+  // The broadcast of column j is consumed one pivot late (cp / lp): its ds_reads are issued at the end of pivot j and
+  // their values first needed after pivot j + 1's reciprocal chain, which covers the LDS round trip (~77 cycles); the
+  // empty asm ties that first use to the chain's result so that the scheduler does not pull the wait up.  The order of
+  // the updates each entry receives is that of the plain right-looking form.
+  double d = readlane_d(a[0], 0) + lambda;
+  double dinv = 1.0;  // lane j < NR: 1 / d_j
+  double cp[NR], lp = 0.0;
 #pragma unroll
   for (int j = 0; j < NR; j++) {
-    const double c = a[j];  // un-normalised column entry of this row
-    double* col = colbuf + (j & 1) * 32;
-    if (lane < 32) col[lane] = c;
+    const double c = l32 > j ? a[j] : 0.0;  // un-normalised column entry of this row; rows <= j are done
+    colbuf[j * kCS + l32] = c;
     if (!(d > 0)) ok = false;
     // 1 / d once per column (v_rcp_f64 + two Newton steps, as k_lba_ldlt16 does) instead of a division per row
     double inv = __builtin_amdgcn_rcp(d);
     inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
     inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
-    if (lane == j) Dl[j] = inv;
+    dinv = l32 == j ? inv : dinv;
     const double l = c * inv;
-    if (j + 1 < NR) d = readlane_d(__builtin_fma(-l, c, a[j + 1 < NR ? j + 1 : j]), j + 1);  // lane j + 1: its new diagonal
+    if (j + 1 < NR) {
+      const int j1 = j + 1 < NR ? j + 1 : j;
+      if (j >= 1) {
+        asm volatile("" : "+v"(cp[j1]) : "v"(inv));
+        a[j1] = __builtin_fma(-lp, cp[j1], a[j1]);  // pivot j - 1's update of column j + 1
+      }
+      // column j + 1 is the NEXT broadcast: its update takes A[j+1][j] by v_readlane, so the next ds_write does not wait
+      // for this column's trip through LDS
+      a[j1] = __builtin_fma(-l, readlane_d(c, j + 1), a[j1]);
+      d = readlane_d(a[j1], j + 1) + lambda;  // lane j + 1: its new diagonal
+    }
+    y = __builtin_fma(-l, readlane_d(y, j), y);
     wave_sync();
-    // (rows <= j take the update as well: their entries right of the diagonal are never read again)
+    if (j >= 1)
 #pragma unroll
-    for (int k = j + 1; k < NR; k++) a[k] = __builtin_fma(-l, col[k], a[k]);
-    a[j] = l;
+      for (int k = j + 2; k < NR; k++) a[k] = __builtin_fma(-lp, cp[k], a[k]);
+#pragma unroll
+    for (int k = j + 2; k < NR; k++) cp[k] = colbuf[j * kCS + k];
+    lp = l;
   }
   if (!ok) return false;
-  // forward: y = L^-1 b (column oriented)
+  // TP:backward
+  // backward: x_i = (y_i - sum_(j > i) A_ji x_j) / d_i with A_ji = colbuf[i][j] (lane i: its own column, fetched up front)
+  double lt[NR];
 #pragma unroll
-  for (int j = 0; j < NR; j++) {
-    const double yj = readlane_d(y, j);
-    if (lane > j && lane < NR) y -= a[j] * yj;
-  }
-  // L -> LDS, then lane i fetches column i (rows below it)
-  if (lane < NR)
+  for (int k = 1; k < NR; k++) lt[k] = colbuf[row * kCS + k] * dinv;
+  y *= dinv;
 #pragma unroll
-    for (int k = 0; k < NR; k++) Ls[lane * NR + k] = a[k];
-  wave_sync();
-  y *= Dl[row];
-#pragma unroll
-  for (int j = NR - 1; j >= 0; j--) {
-    const double xj = readlane_d(y, j);
-    if (lane < j) y -= Ls[j * NR + row] * xj;
-  }
+  for (int j = NR - 1; j > 0; j--) y = __builtin_fma(-lt[j], readlane_d(y, j), y);
+  // TP:write
   if (lane < NR) x[frow] = y;
-  // the eliminated unknowns: x_(9+t) = (b_(9+t) - off_t x_(24+t)) / d_t
-  {
-    double xb = 0.0;
-    if (NR == 24) {
-#pragma unroll
-      for (int t = 0; t < 6; t++) {
-        const double v = readlane_d(y, 18 + t);
-        if (lane == t) xb = v;
-      }
-    }
-    if (lane < 6) x[9 + lane] = (b[9 + lane] - off * xb) * dbias;
-  }
   wave_sync();
+  // the eliminated unknowns: x_(9+t) = (b_(9+t) - off_t x_(24+t)) / d_t
+  if (lane < 6) x[9 + lane] = (b[9 + lane] - (NR == 24 ? off * x[24 + lane] : 0.0)) * dbias;
+  wave_sync();
+  // TP:end
   return true;
 }
 
@@ -218,7 +230,7 @@ __device__ bool wave_solve_vio(const double* H, int n, double lambda, const doub
 
 struct VioShared {
   NSd nsj, nsi, bkj, bki, prior;
-  double H[900], L[900], b[32], x[32], col[32], lcol[32], D[32];
+  double H[900], L[900], b[32], x[32], tr_tail[64];  // (H .. tr_tail: block_sum_lds' buffer of the 64-thread instances)
   double red[16 * 28], vis[28];
   double errI[9], errB[6], errP[15], wI[9], wP[15];
   double JI[9 * 24], JP[225], InfoI[81], T[15 * 24];
@@ -292,6 +304,7 @@ __global__ void __launch_bounds__(BS)
 k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
                uint8_t* __restrict__ outlier_all, vieo_vio_result* __restrict__ results, int other_launched) {
   __shared__ VioShared S;
+  __shared__ double s_tr[BS == 64 ? 1 : 28 * (BS / 32) * 34];  // block_sum_lds' buffer (four wavefronts: 61 KB of its own)
   __shared__ double s_xf[MC ? 48 : 1];  // rig: every camera's Rcw | tcw at the estimate of the current pass
   __shared__ __align__(8) unsigned char s_cam_store[sizeof(CamD) * (MC ? 4 : 1)];  // CamD has initialisers
   CamD* s_cams = reinterpret_cast<CamD*>(s_cam_store);
@@ -408,6 +421,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const int n_edges_total = N + (hasImu ? 1 : 0) + 1 + (fixedLast ? 0 : 1) + (ENC ? 1 : 0);
   double rhoE = 1.0;  // rho' of the encoder edge at the last generic_errors()
 
+#ifdef VIEO_POSE_PROBE
+  unsigned long long pp_last = __builtin_amdgcn_s_memtime();
+#endif
   // generic-edge errors at the current LDS state; returns (robust chi2 sum, rho' of I, B, P)
   auto generic_errors = [&](double* rhoI, double* rhoB, double* rhoP) -> double {
     if (BS > 192) {  // the rotation rows on wavefront 0, the position / velocity rows on wavefront 3, side by side
@@ -423,7 +439,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       }
       if (ENC) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 0);
     }
+    PP(13);
     __syncthreads();
+    PP(14);
     if (hasImu && tid < 9) {
       double t = 0;
       for (int j = 0; j < 9; j++) t += S.InfoI[tid * 9 + j] * S.errI[j];
@@ -436,6 +454,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       S.wP[i] = t;
     }
     __syncthreads();
+    PP(15);
     double chi = 0;
     *rhoI = *rhoB = *rhoP = 1.0;
     if (hasImu) {
@@ -494,9 +513,6 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     return tc[0];
   };
 
-#ifdef VIEO_POSE_PROBE
-  unsigned long long pp_last = __builtin_amdgcn_s_memtime();
-#endif
   for (int it = 0; it < 4; it++) {
     __syncthreads();
     if (!bodom && tid == 0) {  // Optimizer.h:538-545
@@ -548,19 +564,12 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
       }
       PP(2);
-      block_sum_bs<28, BS>(acc, S.red, tid);
-      PP(3);
       if (BS > 192)
         for (int i = tid; i < 9 * 24; i += BS) S.JI[i] = 0;  // cleared by everybody; its halves are filled below
-      __syncthreads();
-      if (tid < 28) {  // publish the sums (select, not acc[tid]: the sums stay in registers)
-        double v = 0;
-#pragma unroll
-        for (int t = 0; t < 28; t++)
-          if (tid == t) v = acc[t];
-        S.vis[tid] = v;
-      }
-      double currentChi = chiG + acc[27];
+      // the 28 sums land in S.vis (the system's visual block) straight from the transpose; H .. tr_tail are dead here
+      block_sum_lds<28, BS>(acc, BS == 64 ? S.H : s_tr, S.vis, tid);
+      PP(3);
+      double currentChi = chiG + S.vis[27];
       const double iniChi = currentChi;
       // generic Jacobians
       if (BS > 192) {  // position / velocity rows on wavefront 0, rotation rows on wavefront 3, side by side
@@ -690,8 +699,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         if (BS == 64) wave_sync();
         PP(11);
         if (wave == 0) {
-          const bool ok = n == 15 ? wave_solve_vio<9>(S.H, n, lambda, S.b, S.x, S.L, S.D, lane)
-                                  : wave_solve_vio<24>(S.H, n, lambda, S.b, S.x, S.L, S.D, lane);
+          const bool ok = n == 15 ? wave_solve_vio<9>((const lds_f64*)S.H, n, lambda, (const lds_f64*)S.b, (lds_f64*)S.x, (lds_f64*)S.L, lane)
+                                  : wave_solve_vio<24>((const lds_f64*)S.H, n, lambda, (const lds_f64*)S.b, (lds_f64*)S.x, (lds_f64*)S.L, lane);
           if (lane == 0) S.ok = ok ? 1 : 0;
         }
         PP(12);
