@@ -7,7 +7,7 @@ from vieo_slam_amd import replay, _lib
 n = 40
 L = _lib.lib()
 f = ctypes.CDLL(_lib.LIB_PATH).vieo_debug_pose_probe
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 24)()
 if len(sys.argv) > 1 and sys.argv[1] == "rig":  # the rig instance: 20 calls of the one-call rig tracker
     sys.argv = [sys.argv[0]] + sys.argv[2:]
     sys.path.insert(0, "/root/repo/tools")
@@ -22,10 +22,11 @@ else:
 f(out)
 v = np.array(list(out), float)
 names16 = ["", "", "", "", "", "", "", "", "", "", "", "(11) top of trial: sync + backup", "(12) solve", "(13) generic_errors: tid 0's edge",
-           "(14) generic_errors: wait for the other edges", "(15) generic_errors: information products"]
+           "(14) generic_errors: wait for the other edges", "(15) generic_errors: information products",
+           "(16) wait for the other lanes' Jacobians"]
 names = ["loop/bookkeeping", "generic_errors", "visual linearize loop", "block_sum", "publish + imu/prior linearize", "H assembly", "backup + ldlt", "ns_inc", "generic_errors (trial)", "visual_chi (trial)", "iteration tail"]
 tot = v.sum()
 for i, nm in enumerate(names): print("%-46s %6.1f %%  %9.0f cycles per pose call" % (nm, 100 * v[i] / tot, v[i] / (2 * (n - 1))))
-for i in (11, 12, 13, 14, 15):
+for i in (11, 12, 13, 14, 15, 16):
     print("%-46s %6.1f %%  %9.0f cycles per pose call" % (names16[i], 100 * v[i] / tot, v[i] / (2 * (n - 1))))
 print("total cycles per pose call %.0f = %.0f us at 2.4 GHz" % (tot / (2 * (n - 1)), tot / (2 * (n - 1)) / 2400))

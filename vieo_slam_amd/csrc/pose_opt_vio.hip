@@ -233,7 +233,7 @@ struct VioShared {
   double H[900], L[900], b[32], x[32], tr_tail[64];  // (H .. tr_tail: block_sum_lds' buffer of the 64-thread instances)
   double red[16 * 28], vis[28];
   double errI[9], errB[6], errP[15], wI[9], wP[15];
-  double JI[9 * 24], JP[225], InfoI[81], T[15 * 24];
+  double JI[9 * 24], JP[225], InfoI[81], T[15 * 24], TP[225], Hp[225];  // Hp: the frame's H_prior, staged once
   double cov[225], C[225], E[225], Cinv[225 * 2];
   int ok;
 };
@@ -294,7 +294,7 @@ __device__ __noinline__ void vio_enc_eval(const vieo_pose_enc* pe, VioEncShared*
 // ENC: the instance for frames that carry an encoder measurement (base.enc with dt != 0, a16)
 // other_launched: bit 0 the other camera kind, bit 1 the other encoder kind has its own launch in this batch
 #ifdef VIEO_POSE_PROBE
-__device__ unsigned long long g_pose_probe[16];
+__device__ unsigned long long g_pose_probe[24];
 #define PP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_pose_probe[i], t_ - pp_last); pp_last = t_; } } while (0)
 #else
 #define PP(i)
@@ -408,6 +408,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     }
     for (int e = lane; e < 81; e += 64) S.InfoI[e] = M[(e / 9) * 18 + 9 + e % 9] * (fixedLast ? 1e-2 : 1.0);
   }
+  if (!fixedLast)
+    for (int e = tid; e < 225; e += BS) S.Hp[e] = F.H_prior[e];
   __syncthreads();
   const double deltatij = F.imu.dt ? F.imu.dt : F.dt_frames;
   const double infoBg = F.inv_sigma_bg2 / deltatij * (fixedLast ? 1e-2 : 1.0);
@@ -450,7 +452,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     if (!fixedLast && tid >= T1 && tid < T1 + 15) {
       const int i = tid - T1;
       double t = 0;
-      for (int j = 0; j < 15; j++) t += F.H_prior[i * 15 + j] * S.errP[j];
+      for (int j = 0; j < 15; j++) t += S.Hp[i * 15 + j] * S.errP[j];
       S.wP[i] = t;
     }
     __syncthreads();
@@ -581,8 +583,61 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
       PP(4);
       const double rhoE0 = rhoE;  // the trial evaluations below overwrite rhoE
-      for (int i = tid; i < n * n; i += BS) S.H[i] = 0;
-      if (tid < n) S.b[tid] = 0;
+      __syncthreads();  // the Jacobians above are complete
+      PP(16);
+      // Three more barriers (were seven): (A) the products (rho' Info) J of the inertial, prior and encoder edges side by side;
+      // (B) every entry of the system is WRITTEN once -- J^T T of the inertial edge over its 24 (9) unknowns, zero on
+      // the rows and columns of the current bias -- so nothing is cleared first; (C) the visual block, the prior and
+      // the bias edge add to entries no other role of this phase touches (the one shared diagonal, prior + bias of the
+      // last state, stays with the prior's thread).  Each entry receives its terms in the order inertial, visual |
+      // prior, bias, i.e. the sums are those of the one-edge-after-the-other form, bit for bit.
+      if (hasImu) {  // T = (rho' Info) J  (9 x 24)
+        const int cnt = fixedLast ? 81 : 216;
+        for (int eidx = tid; eidx < cnt; eidx += BS) {
+          const int a = fixedLast ? eidx / 9 : eidx / 24, cc = eidx - a * (fixedLast ? 9 : 24);
+          double t = 0;
+#pragma unroll
+          for (int q = 0; q < 9; q++) t += (rhoI * S.InfoI[a * 9 + q]) * S.JI[q * 24 + cc];
+          S.T[a * 24 + cc] = t;
+        }
+      }
+      if (!fixedLast)  // T' = (rho' H_prior) J (15 x 15)
+        for (int eidx = tid; eidx < 225; eidx += BS) {
+          const int a = eidx / 15, cc = eidx % 15;
+          double t = 0;
+#pragma unroll
+          for (int q = 0; q < 15; q++) t += (rhoP * S.Hp[a * 15 + q]) * S.JP[q * 15 + cc];
+          S.TP[a * 15 + cc] = t;
+        }
+      if (ENC)  // T'' = (rho' Info) [Jj | Ji]
+        for (int eidx = tid; eidx < 72; eidx += BS) {
+          const int a = eidx / 12, cc = eidx % 12;
+          double t = 0;
+          for (int q = 0; q < 6; q++) t += (rhoE0 * SE->Info[a * 6 + q]) * SE->J[q * 12 + cc];
+          SE->T[eidx] = t;
+        }
+      __syncthreads();
+      for (int i = tid; i < n * n; i += BS) {
+        const int s1 = fixedLast ? i / 15 : i / 30, s2 = i - s1 * n;
+        const bool bias = (s1 >= 9 && s1 < 15) || (s2 >= 9 && s2 < 15);
+        double t = 0;
+        if (hasImu && !bias) {
+          const int c1 = s1 < 9 ? s1 : s1 - 6, c2 = s2 < 9 ? s2 : s2 - 6;
+#pragma unroll
+          for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c1] * S.T[a * 24 + c2];
+        }
+        S.H[i] = 0.0 + t;  // (0 + t: the sign of a zero sum as before)
+      }
+      if (tid < n) {
+        const bool bias = tid >= 9 && tid < 15;
+        double t = 0;
+        if (hasImu && !bias) {
+          const int c = tid < 9 ? tid : tid - 6;
+#pragma unroll
+          for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c] * (-S.wI[a] * rhoI);
+        }
+        S.b[tid] = 0.0 + t;
+      }
       __syncthreads();
       // visual block: (dp, dphi) -> system rows/cols {0,1,2,6,7,8}
       if (tid < 36) {
@@ -590,66 +645,45 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         const int lo = a < bq ? a : bq, hi = a < bq ? bq : a;
         const int t = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
         const int ra = a < 3 ? a : a + 3, rb = bq < 3 ? bq : bq + 3;
-        S.H[ra * n + rb] = S.vis[t];
+        S.H[ra * n + rb] += S.vis[t];
       }
       if (tid >= T1 && tid < T1 + 6) {
         const int a = tid - T1;
-        S.b[a < 3 ? a : a + 3] = S.vis[21 + a];
+        S.b[a < 3 ? a : a + 3] += S.vis[21 + a];
       }
-      __syncthreads();
-      if (hasImu) {  // T = (rho' Info) J  (9 x 24), then H += J^T T
-        const int nc = fixedLast ? 9 : 24;
-        for (int eidx = tid; eidx < 9 * nc; eidx += BS) {
-          const int a = eidx / nc, cc = eidx % nc;
-          double t = 0;
-          for (int q = 0; q < 9; q++) t += (rhoI * S.InfoI[a * 9 + q]) * S.JI[q * 24 + cc];
-          S.T[a * 24 + cc] = t;
-        }
-        __syncthreads();
-        for (int eidx = tid; eidx < nc * nc; eidx += BS) {
-          const int c1 = eidx / nc, c2 = eidx % nc;
-          double t = 0;
-          for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c1] * S.T[a * 24 + c2];
-          const int s1 = c1 < 9 ? c1 : c1 + 6, s2 = c2 < 9 ? c2 : c2 + 6;
-          S.H[s1 * n + s2] += t;
-        }
-        if (tid < nc) {
-          double t = 0;
-          for (int a = 0; a < 9; a++) t += S.JI[a * 24 + tid] * (-S.wI[a] * rhoI);
-          S.b[tid < 9 ? tid : tid + 6] += t;
-        }
-        __syncthreads();
-      }
-      if (!fixedLast) {  // prior: T = (rho' H_prior) J (15 x 15), H[15.., 15..] += J^T T
-        for (int eidx = tid; eidx < 225; eidx += BS) {
-          const int a = eidx / 15, cc = eidx % 15;
-          double t = 0;
-          for (int q = 0; q < 15; q++) t += (rhoP * F.H_prior[a * 15 + q]) * S.JP[q * 15 + cc];
-          S.T[a * 15 + cc] = t;
-        }
-        __syncthreads();
+      if (!fixedLast) {  // prior: H[15.., 15..] += J^T T', with the bias edge's weight on the last state's bias diagonal
         for (int eidx = tid; eidx < 225; eidx += BS) {
           const int c1 = eidx / 15, c2 = eidx % 15;
           double t = 0;
-          for (int a = 0; a < 15; a++) t += S.JP[a * 15 + c1] * S.T[a * 15 + c2];
-          S.H[(15 + c1) * n + 15 + c2] += t;
+#pragma unroll
+          for (int a = 0; a < 15; a++) t += S.JP[a * 15 + c1] * S.TP[a * 15 + c2];
+          double h = S.H[(15 + c1) * n + 15 + c2] + t;
+          if (c1 == c2 && c1 >= 9) h += (c1 < 12 ? infoBg : infoBa) * rhoB;
+          S.H[(15 + c1) * n + 15 + c2] = h;
         }
         if (tid < 15) {
           double t = 0;
+#pragma unroll
           for (int a = 0; a < 15; a++) t += S.JP[a * 15 + tid] * (-S.wP[a] * rhoP);
-          S.b[15 + tid] += t;
+          double h = S.b[15 + tid] + t;
+          if (tid >= 9) h += (tid < 12 ? infoBg : infoBa) * S.errB[tid - 9] * rhoB;
+          S.b[15 + tid] = h;
         }
-        __syncthreads();
       }
-      if (ENC) {  // T = (rho' Info) [Jj | Ji], H += J^T T on the (p, phi) rows of the PVR vertices
-        const int nc = fixedLast ? 6 : 12;
-        for (int eidx = tid; eidx < 72; eidx += BS) {
-          const int a = eidx / 12, cc = eidx % 12;
-          double t = 0;
-          for (int q = 0; q < 6; q++) t += (rhoE0 * SE->Info[a * 6 + q]) * SE->J[q * 12 + cc];
-          SE->T[eidx] = t;
+      if (tid >= T2 && tid < T2 + 6) {  // bias edge: J_j = +I (cols 9..14), J_i = -I (cols 24..29)
+        const int k = tid - T2;
+        const double w = (k < 3 ? infoBg : infoBa) * rhoB;
+        const double we = (k < 3 ? infoBg : infoBa) * S.errB[k] * rhoB;
+        S.H[(9 + k) * n + 9 + k] += w;
+        S.b[9 + k] += -we;
+        if (!fixedLast) {
+          S.H[(9 + k) * n + 24 + k] -= w;
+          S.H[(24 + k) * n + 9 + k] -= w;
         }
-        __syncthreads();
+      }
+      __syncthreads();
+      if (ENC) {  // H += J^T T'' on the (p, phi) rows of the PVR vertices
+        const int nc = fixedLast ? 6 : 12;
         for (int eidx = tid; eidx < nc * nc; eidx += BS) {
           const int c1 = eidx / nc, c2 = eidx % nc;
           double t = 0;
@@ -664,19 +698,6 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         }
         __syncthreads();
       }
-      if (tid < 6) {  // bias edge: J_j = +I (cols 9..14), J_i = -I (cols 24..29)
-        const double w = (tid < 3 ? infoBg : infoBa) * rhoB;
-        const double we = (tid < 3 ? infoBg : infoBa) * S.errB[tid] * rhoB;
-        S.H[(9 + tid) * n + 9 + tid] += w;
-        S.b[9 + tid] += -we;
-        if (!fixedLast) {
-          S.H[(24 + tid) * n + 24 + tid] += w;
-          S.H[(9 + tid) * n + 24 + tid] -= w;
-          S.H[(24 + tid) * n + 9 + tid] -= w;
-          S.b[24 + tid] += we;
-        }
-      }
-      __syncthreads();
       PP(5);
       if (iter == 0) {
         double mx = 0;
@@ -914,7 +935,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       for (int eidx = tid; eidx < 225; eidx += BS) {
         const int a = eidx / 15, cc = eidx % 15;
         double t = 0;
-        for (int q = 0; q < 15; q++) t += (rhoP * F.H_prior[a * 15 + q]) * S.JP[q * 15 + cc];
+        for (int q = 0; q < 15; q++) t += (rhoP * S.Hp[a * 15 + q]) * S.JP[q * 15 + cc];
         S.T[a * 15 + cc] = t;
       }
       __syncthreads();
@@ -1097,8 +1118,8 @@ int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_ob
 #ifdef VIEO_POSE_PROBE
 extern "C" int vieo_debug_pose_probe(unsigned long long* out) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vieo::g_pose_probe), sizeof(unsigned long long) * 16);
-  unsigned long long z[16] = {};
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vieo::g_pose_probe), sizeof(unsigned long long) * 24);
+  unsigned long long z[24] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(vieo::g_pose_probe), z, sizeof(z));
   return 0;
 }
