@@ -38,16 +38,17 @@ def test_vio_fixed_last_parity(oracle, seed, n, marg):
     # 0.1 % improvement stop rule is evaluated on sums accumulated in a different order)
 
 
-@pytest.mark.parametrize("seed", [40, 42, 44])
-def test_vio_free_last_with_prior_parity(oracle, seed):
+# (n: the four-wavefront instance keeps the visual edges on two wavefronts up to 768 edges, on all four beyond)
+@pytest.mark.parametrize("seed,n", [(40, 300), (42, 300), (44, 300), (46, 767), (48, 769), (50, 1500)])
+def test_vio_free_last_with_prior_parity(oracle, seed, n):
     F0, obs0, _ = synth_ba.make_vio_problem(seed, compute_marg=True)
     r0, _ = oracle.pose_optimization_vio(F0, obs0)
-    F1, obs1, _ = synth_ba.make_vio_problem(seed + 1, compute_marg=True)
+    F1, obs1, _ = synth_ba.make_vio_problem(seed + 1, n_obs=n, compute_marg=True)
     nav_last = F1[0]["nav_last"].copy()
     nav_prior = nav_last.copy()
     nav_last["p"] += 0.004
     nav_last["v"] += 0.015
-    F1b, _, _ = synth_ba.make_vio_problem(seed + 1, compute_marg=True,
+    F1b, _, _ = synth_ba.make_vio_problem(seed + 1, n_obs=n, compute_marg=True,
                                           prior=(nav_prior, r0["H_marg"].reshape(15, 15), nav_last))
     _cmp(oracle, F1b, obs1, marg_rtol=1e-4)
 

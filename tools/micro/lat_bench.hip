@@ -50,6 +50,28 @@ __global__ void k(double* out, unsigned long long* t, double seed, int which) {
   } else if (which == 7) {  // v_rcp_f64 chain
 #pragma unroll
     for (int i = 0; i < N; i++) y = __builtin_amdgcn_rcp(y);
+  } else if (which == 8) {
+#pragma unroll 8
+    for (int i = 0; i < N; i++) y = 1.0 / (y + 0.5);
+  } else if (which == 9) {
+#pragma unroll 8
+    for (int i = 0; i < N; i++) y = sqrt(y + 0.5);
+  } else if (which == 10) {
+#pragma unroll 4
+    for (int i = 0; i < N; i++) {
+      double sn, cs;
+      sincos(y * 0.3, &sn, &cs);
+      y = sn + cs;
+    }
+  } else if (which == 11) {
+#pragma unroll 4
+    for (int i = 0; i < N; i++) y = atan(y) + 0.7;
+  } else if (which == 12) {
+#pragma unroll 4
+    for (int i = 0; i < N; i++) y = rsqrt(y + 0.5);
+  } else if (which == 13) {
+#pragma unroll 4
+    for (int i = 0; i < N; i++) y = sin(y * 0.3) + 0.9;
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   out[lane] = y + yf;
@@ -57,15 +79,15 @@ __global__ void k(double* out, unsigned long long* t, double seed, int which) {
 }
 int main() {
   double* out;
-  unsigned long long *t, h[8];
-  hipMalloc(&out, 512), hipMalloc(&t, 64);
+  unsigned long long *t, h[16];
+  hipMalloc(&out, 512), hipMalloc(&t, 128);
   const char* nm[] = {"v_fma_f64 -> v_fma_f64", "v_fma_f64 -> 2 v_readlane -> v_fma_f64", "v_fma_f32 -> v_fma_f32",
                       "v_fma_f32 -> v_readlane -> v_fma_f32", "v_fma_f64 -> ds_write, ds_read -> v_fma_f64",
-                      "v_fma_f64 -> 2 dpp mov -> v_fma_f64", "2 independent v_fma_f64 chains (per pair)", "v_rcp_f64 -> v_rcp_f64"};
-  for (int w = 0; w < 8; w++)
+                      "v_fma_f64 -> 2 dpp mov -> v_fma_f64", "2 independent v_fma_f64 chains (per pair)", "v_rcp_f64 -> v_rcp_f64", "1.0 / x", "sqrt(x)", "sincos(x)", "atan(x)", "rsqrt(x)", "sin(x)"};
+  for (int w = 0; w < 14; w++)
     for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k, 1, 64, 0, 0, out, t, 1.0, w);
   hipDeviceSynchronize();
-  hipMemcpy(h, t, 64, hipMemcpyDeviceToHost);
-  for (int w = 0; w < 8; w++) printf("%-46s %6.1f cycles per link\n", nm[w], (double)h[w] / N);
+  hipMemcpy(h, t, 128, hipMemcpyDeviceToHost);
+  for (int w = 0; w < 14; w++) printf("%-46s %6.1f cycles per link\n", nm[w], (double)h[w] / N);
   return 0;
 }

@@ -23,10 +23,12 @@ f(out)
 v = np.array(list(out), float)
 names16 = ["", "", "", "", "", "", "", "", "", "", "", "(11) top of trial: sync + backup", "(12) solve", "(13) generic_errors: tid 0's edge",
            "(14) generic_errors: wait for the other edges", "(15) generic_errors: information products",
-           "(16) wait for the other lanes' Jacobians"]
-names = ["loop/bookkeeping", "generic_errors", "visual linearize loop", "block_sum", "publish + imu/prior linearize", "H assembly", "backup + ldlt", "ns_inc", "generic_errors (trial)", "visual_chi (trial)", "iteration tail"]
-tot = v.sum()
+           "(16) wait for the other lanes' Jacobians", "[17] imu_error rotation rows (own clock)",
+           "[18] imu_error p, v rows", "[19] prior_error", "[20] imu_linearize p, v rows", "[21] imu_linearize rotation rows",
+           "[22] prior_linearize"]
+names = ["loop/bookkeeping", "generic_errors", "visual linearize loop", "block_sum", "publish + imu/prior linearize", "H assembly", "backup + ldlt", "ns_inc", "(unused)", "trial: errors of all edges", "iteration tail"]
+tot = v[:17].sum()
 for i, nm in enumerate(names): print("%-46s %6.1f %%  %9.0f cycles per pose call" % (nm, 100 * v[i] / tot, v[i] / (2 * (n - 1))))
-for i in (11, 12, 13, 14, 15, 16):
+for i in (11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22):
     print("%-46s %6.1f %%  %9.0f cycles per pose call" % (names16[i], 100 * v[i] / tot, v[i] / (2 * (n - 1))))
 print("total cycles per pose call %.0f = %.0f us at 2.4 GHz" % (tot / (2 * (n - 1)), tot / (2 * (n - 1)) / 2400))

@@ -16,6 +16,8 @@
 // chains where every double-precision instruction costs 8 issue cycles, and a fused multiply-add is one instead of two.
 #pragma clang fp contract(fast)
 
+#include <type_traits>
+
 #include "imu_device.h"
 
 namespace vieo {
@@ -234,6 +236,8 @@ struct VioShared {
   double red[16 * 28], vis[28];
   double errI[9], errB[6], errP[15], wI[9], wP[15];
   double JI[9 * 24], JP[225], InfoI[81], T[15 * 24], TP[225], Hp[225];  // Hp: the frame's H_prior, staged once
+  vieo_imu_preint imu;  // the frame's pre-integration without Sigma, staged once: the single-lane edge evaluations of
+                        // every trial read it, and a trip to L2 per dependent batch of loads was a fifth of their time
   double cov[225], C[225], E[225], Cinv[225 * 2];
   int ok;
 };
@@ -295,9 +299,11 @@ __device__ __noinline__ void vio_enc_eval(const vieo_pose_enc* pe, VioEncShared*
 // other_launched: bit 0 the other camera kind, bit 1 the other encoder kind has its own launch in this batch
 #ifdef VIEO_POSE_PROBE
 __device__ unsigned long long g_pose_probe[24];
+#define RT(i, stmt) do { const unsigned long long a_ = __builtin_amdgcn_s_memtime(); stmt; atomicAdd(&g_pose_probe[i], __builtin_amdgcn_s_memtime() - a_); } while (0)
 #define PP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_pose_probe[i], t_ - pp_last); pp_last = t_; } } while (0)
 #else
 #define PP(i)
+#define RT(i, stmt) stmt
 #endif
 template <int BS, bool MC, bool ENC>
 __global__ void __launch_bounds__(BS)
@@ -315,6 +321,15 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const int T3 = BS > 192 ? 192 : 0;  // fourth: the rotation rows of the inertial Jacobian (its two halves are independent)
   const vieo_vio_frame& F = frames[f];
   const int N = F.base.n_obs;
+  // The visual edges belong to the first VT threads, edge i = tid + k VT <-> bit k of the thread's masks.  Four
+  // wavefronts and up to kVioSplitObs edges (a tracked frame of one stereo pair): the first two wavefronts; the
+  // single-lane edges (inertial, prior, bias, encoder) sit on lanes of the other two and are evaluated WHILE the visual
+  // edges are -- separate instruction streams -- instead of after them.  Beyond that (rig frames: thousands of edges)
+  // the visual passes are the longer part and take all four wavefronts; the single-lane edges then follow on theirs.
+  // (VT is a compile-time constant of the optimisation below, which exists twice in the four-wavefront instances of
+  // one-camera frames -- picked per frame by its number of edges; as a run-time stride it cost 7 % of the kernel.
+  // Rig instances: rig_xf()'s barriers need every thread, and their frames are beyond the limit anyway.)
+  constexpr int kVioSplitObs = 768;
   const vieo_pose_obs* obs = obs_all + F.base.obs_begin;
   uint8_t* outl = outlier_all + F.base.obs_begin;
   vieo_vio_result* R = results + f;
@@ -410,6 +425,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   }
   if (!fixedLast)
     for (int e = tid; e < 225; e += BS) S.Hp[e] = F.H_prior[e];
+  for (int e = tid; e < (int)(offsetof(vieo_imu_preint, Sigma) / 8); e += BS)
+    reinterpret_cast<double*>(&S.imu)[e] = reinterpret_cast<const double*>(&F.imu)[e];
   __syncthreads();
   const double deltatij = F.imu.dt ? F.imu.dt : F.dt_frames;
   const double infoBg = F.inv_sigma_bg2 / deltatij * (fixedLast ? 1e-2 : 1.0);
@@ -417,24 +434,56 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const double dI = sqrt(16.919), dB = sqrt(12.592), dP = sqrt(25.0), dE = sqrt(12.592);
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+  auto optimise = [&](auto vt_c) {
+  constexpr int VT = decltype(vt_c)::value;
+  const int Nv = tid < VT ? N : 0;  // (loop bound of the visual loops: no trip for the other threads)
   unsigned long long levelmask = 0;
   bool vis_robust = true;
   int nBad = 0, total_iters = 0;
   const int n_edges_total = N + (hasImu ? 1 : 0) + 1 + (fixedLast ? 0 : 1) + (ENC ? 1 : 0);
-  double rhoE = 1.0;  // rho' of the encoder edge at the last generic_errors()
+  double rhoE = 1.0;  // rho' of the encoder edge at the last all_errors()
 
 #ifdef VIEO_POSE_PROBE
   unsigned long long pp_last = __builtin_amdgcn_s_memtime();
 #endif
-  // generic-edge errors at the current LDS state; returns (robust chi2 sum, rho' of I, B, P)
-  auto generic_errors = [&](double* rhoI, double* rhoB, double* rhoP) -> double {
-    if (BS > 192) {  // the rotation rows on wavefront 0, the position / velocity rows on wavefront 3, side by side
-      if (tid == 0 && hasImu) imu_error(F.imu, gw, S.nsi, S.nsj, S.errI, 6, 2);
-      if (tid == T3 && hasImu) imu_error(F.imu, gw, S.nsi, S.nsj, S.errI, 6, 1);
+  // Errors of the edges at the LDS state.  The single-lane edges sit on lanes of the wavefronts that hold no visual
+  // edge (four wavefronts: the inertial edge's rotation rows on the fourth, its position / velocity rows, the prior, the
+  // bias and the encoder edge on the third) and are evaluated while the first two wavefronts go through the visual edges
+  // (with_visual: a trial; without: the first linearisation of an optimize(), which sums the visual edges itself).
+  // Returns the robust chi2 of the generic edges (and rho' of I, B, P); *vis = that of the active visual edges.
+  auto all_errors = [&](double* rhoI, double* rhoB, double* rhoP, bool with_visual, double* vis) -> double {
+    if (with_visual && tid < VT) {  // (whole wavefronts)
+      Est e;
+      e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
+      e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
+      PoseXf X;
+      make_xf(c, e, X);
+      rig_xf(X, e.p);
+      double tc = 0;
+      vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
+      for (int k = 0, i = tid; i < Nv; k++, i += VT) {
+        const vieo_pose_obs o = o_next;
+        if (i + VT < N) o_next = obs[i + VT];
+        if ((levelmask >> k) & 1) continue;
+        double err[3], Pc[3];
+        const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
+        double r0 = chi2, r1 = 1.;
+        if (vis_robust) {
+          const double dl = o.ur >= 0 ? deltaStereo : deltaMono;
+          huber(chi2, dl, dl * dl, &r0, &r1);
+        }
+        tc += r0;
+      }
+      tc = BS == 64 ? wave_sum_d_bfly(tc) : wave_sum_d(tc);
+      if (lane == 0) S.red[wave] = tc;  // (S.red's last readers are barriers away)
+    }
+    if (BS > 192) {
+      if (tid == T3 && hasImu) RT(17, imu_error(S.imu, gw, S.nsi, S.nsj, S.errI, 6, 2));
+      if (tid == T2 && hasImu) RT(18, imu_error(S.imu, gw, S.nsi, S.nsj, S.errI, 6, 1));
     } else if (tid == 0 && hasImu)
-      imu_error(F.imu, gw, S.nsi, S.nsj, S.errI);
-    if (tid == T1 && !fixedLast) prior_error(S.prior, S.nsi, S.errP);
+      imu_error(S.imu, gw, S.nsi, S.nsj, S.errI);
     if (tid == T2) {
+      if (!fixedLast) RT(19, prior_error(S.prior, S.nsi, S.errP));
       for (int k = 0; k < 3; k++) {
         S.errB[k] = (S.nsj.bg[k] + S.nsj.dbg[k]) - (S.nsi.bg[k] + S.nsi.dbg[k]);
         S.errB[3 + k] = (S.nsj.ba[k] + S.nsj.dba[k]) - (S.nsi.ba[k] + S.nsi.dba[k]);
@@ -486,33 +535,12 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       huber(SE->chi, dE, dE * dE, &r0, &rhoE);
       chi += r0;
     }
-    return chi;
-  };
-  // robust chi2 of the active visual edges at the LDS state
-  auto visual_chi = [&]() -> double {
-    Est e;
-    e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
-    e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
-    PoseXf X;
-    make_xf(c, e, X);
-    rig_xf(X, e.p);
-    double tc[1] = {0};
-    vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
-    for (int k = 0, i = tid; i < N; k++, i += BS) {
-      const vieo_pose_obs o = o_next;
-      if (i + BS < N) o_next = obs[i + BS];
-      if ((levelmask >> k) & 1) continue;
-      double err[3], Pc[3];
-      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
-      double r0 = chi2, r1 = 1.;
-      if (vis_robust) {
-        const double dl = o.ur >= 0 ? deltaStereo : deltaMono;
-        huber(chi2, dl, dl * dl, &r0, &r1);
-      }
-      tc[0] += r0;
+    if (with_visual) {
+      double v = S.red[0];
+      for (int w = 1; w < VT / 64; w++) v += S.red[w];
+      *vis = v;
     }
-    block_sum_bs<1, BS>(tc, S.red, tid);
-    return tc[0];
+    return chi;
   };
 
   for (int it = 0; it < 4; it++) {
@@ -535,23 +563,24 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       PP(0);
       double chiG;
       if (iter == 0)
-        chiG = generic_errors(&rhoI, &rhoB, &rhoP);
+        chiG = all_errors(&rhoI, &rhoB, &rhoP, false, nullptr);
       else
         chiG = accChi, rhoI = accI, rhoB = accB, rhoP = accP, rhoE = accE;
       PP(1);
+      double acc[28];
+#pragma unroll
+      for (int i = 0; i < 28; i++) acc[i] = 0;
+      if (tid < VT) {  // (whole wavefronts)
       Est e;
       e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
       e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
       PoseXf X;
       make_xf(c, e, X);
       rig_xf(X, e.p);
-      double acc[28];
-#pragma unroll
-      for (int i = 0; i < 28; i++) acc[i] = 0;
       vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
-      for (int k = 0, i = tid; i < N; k++, i += BS) {
+      for (int k = 0, i = tid; i < Nv; k++, i += VT) {
         const vieo_pose_obs o = o_next;
-        if (i + BS < N) o_next = obs[i + BS];
+        if (i + VT < N) o_next = obs[i + VT];
         if ((levelmask >> k) & 1) continue;
         double err[3], Pc[3];
         double J[18];
@@ -565,26 +594,30 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         acc[27] += r0;
         visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
       }
+      }
+      // the single-lane Jacobians, on the wavefronts without visual edges, meanwhile
+      if (BS > 192) {
+        if (wave == 3 && hasImu) {  // both halves of the inertial Jacobian: the wavefront clears it, lane 0 fills it
+          for (int i = lane; i < 9 * 24; i += 64) S.JI[i] = 0;
+          wave_sync();
+          if (lane == 0) {
+            RT(20, imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1));
+            RT(21, imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2));
+          }
+        }
+      } else if (tid == 0 && hasImu)
+        imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
+      if (tid == T2 && !fixedLast) RT(22, prior_linearize(S.prior, S.nsi, S.errP, S.JP));
+      if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
       PP(2);
-      if (BS > 192)
-        for (int i = tid; i < 9 * 24; i += BS) S.JI[i] = 0;  // cleared by everybody; its halves are filled below
-      // the 28 sums land in S.vis (the system's visual block) straight from the transpose; H .. tr_tail are dead here
+      // the 28 sums land in S.vis (the system's visual block) straight from the transpose; H .. tr_tail are dead here.
+      // Its barriers are also where the Jacobians above meet the threads that assemble the system.
       block_sum_lds<28, BS>(acc, BS == 64 ? S.H : s_tr, S.vis, tid);
       PP(3);
       double currentChi = chiG + S.vis[27];
       const double iniChi = currentChi;
-      // generic Jacobians
-      if (BS > 192) {  // position / velocity rows on wavefront 0, rotation rows on wavefront 3, side by side
-        if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
-        if (tid == T3 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2);
-      } else if (tid == 0 && hasImu)
-        imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
-      if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
-      if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
-      PP(4);
       const double rhoE0 = rhoE;  // the trial evaluations below overwrite rhoE
-      __syncthreads();  // the Jacobians above are complete
-      PP(16);
+      PP(4);
       // Three more barriers (were seven): (A) the products (rho' Info) J of the inertial, prior and encoder edges side by side;
       // (B) every entry of the system is WRITTEN once -- J^T T of the inertial edge over its 24 (9) unknowns, zero on
       // the rows and columns of the current bias -- so nothing is cleared first; (C) the visual block, the prior and
@@ -737,11 +770,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         if (tid == T1 && !fixedLast) ns_inc(S.nsi, S.x + 15, S.x + 24);
         __syncthreads();
         PP(7);
-        double r1, r2, r3;
-        const double tempChiG = generic_errors(&r1, &r2, &r3);
-        double tempChi = tempChiG;
-        PP(8);
-        tempChi += visual_chi();
+        double r1, r2, r3, visChi;
+        const double tempChiG = all_errors(&r1, &r2, &r3, true, &visChi);
+        double tempChi = tempChiG + visChi;
         PP(9);
         if (!ok2) tempChi = DBL_MAX;
         rho = currentChi - tempChi;
@@ -750,7 +781,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         scale += 1e-3;
         rho /= scale;
         if (rho > 0 && isfinite(tempChi)) {
-          double alpha = 1. - pow(2 * rho - 1, 3);
+          const double r21 = 2 * rho - 1;
+          double alpha = 1. - r21 * r21 * r21;  // (pow(., 3) of the reference: the last bit of lambda may differ)
           alpha = fmin(alpha, 2. / 3.);
           lambda *= fmax(1. / 3., alpha);
           ni = 2;
@@ -787,7 +819,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     rig_xf(X, e.p);
     const float chi2close = (float)(1.5 * (double)chi2Mono);
     double nb[1] = {0};
-    for (int k = 0, i = tid; i < N; k++, i += BS) {
+    for (int k = 0, i = tid; i < Nv; k++, i += VT) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
       const float chi2 = (float)edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
@@ -816,7 +848,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     make_xf(c, e, X);
     rig_xf(X, e.p);
     double nb[1] = {0};
-    for (int k = 0, i = tid; i < N; k++, i += BS) {
+    for (int k = 0, i = tid; i < Nv; k++, i += VT) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
       const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
@@ -829,11 +861,11 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     block_sum_bs<1, BS>(nb, S.red, tid);
     nBad = (int)nb[0];
   }
-  for (int k = 0, i = tid; i < N; k++, i += BS) outl[i] = (outmask >> k) & 1;
+  for (int k = 0, i = tid; i < Nv; k++, i += VT) outl[i] = (outmask >> k) & 1;
   // ---- marginal prior (Optimizer.h:663-813, FillCovInv :126-206, exact_mode = kExactRobust)
   if (F.compute_marg) {
     double rhoI, rhoB, rhoP;
-    generic_errors(&rhoI, &rhoB, &rhoP);
+    all_errors(&rhoI, &rhoB, &rhoP, false, nullptr);
     Est e;
     e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
     e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
@@ -844,9 +876,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
     vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
-    for (int k = 0, i = tid; i < N; k++, i += BS) {
+    for (int k = 0, i = tid; i < Nv; k++, i += VT) {
       const vieo_pose_obs o = o_next;
-      if (i + BS < N) o_next = obs[i + BS];
+      if (i + VT < N) o_next = obs[i + VT];
       if ((levelmask >> k) & 1) continue;
       double err[3], Pc[3];
       double J[18];
@@ -871,10 +903,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       S.vis[tid] = v;
     }
     if (BS > 192) {
-      if (tid == 0 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
-      if (tid == T3 && hasImu) imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2);
+      if (tid == 0 && hasImu) imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
+      if (tid == T3 && hasImu) imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2);
     } else if (tid == 0 && hasImu)
-      imu_linearize(F.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
+      imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
     if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
     if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
     for (int i = tid; i < 225; i += BS) S.cov[i] = 0, S.C[i] = 0, S.E[i] = 0;
@@ -1014,6 +1046,14 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     R->has_marg = F.compute_marg ? 1 : 0;
     R->reserved = 0;
   }
+  };  // optimise
+  if constexpr (BS == 256 && !MC) {
+    if (N <= kVioSplitObs)
+      optimise(std::integral_constant<int, 128>{});
+    else
+      optimise(std::integral_constant<int, BS>{});
+  } else
+    optimise(std::integral_constant<int, BS>{});
 }
 
 }  // namespace vieo
