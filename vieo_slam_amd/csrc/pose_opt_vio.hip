@@ -232,13 +232,23 @@ __device__ bool wave_solve_vio(const lds_f64* H, int n, double lambda, const lds
 
 struct VioShared {
   NSd nsj, nsi, bkj, bki, prior;
-  double H[900], L[900], b[32], x[32], tr_tail[64];  // (H .. tr_tail: block_sum_lds' buffer of the 64-thread instances)
-  double red[16 * 28], vis[28];
+  // The system and the solver's column buffers | the marginalisation's blocks after the last optimize() (the system
+  // is dead by then).  LDS per frame decides how many one-wavefront frames a CU holds: 32 KB -> 4 (40 KB would be 3).
+  union {
+    struct {
+      double H[900], L[900];
+    };
+    struct {
+      double cov[225], C[225], E[225], Cinv[225 * 2];
+    };
+  };
+  double b[32], x[32], tr_tail[64];  // (H .. tr_tail: block_sum_lds' buffer of the 64-thread instances)
+  double red[4 * 28], vis[28];
   double errI[9], errB[6], errP[15], wI[9], wP[15];
-  double JI[9 * 24], JP[225], InfoI[81], T[15 * 24], TP[225], Hp[225];  // Hp: the frame's H_prior, staged once
+  double JI[9 * 24], JP[225], InfoI[81], T[225], TP[225], Hp[225];  // Hp: the frame's H_prior, staged once
+  double gw[4];         // gravity (a pointer into LDS for the out-of-line edge functions; a local array would sit in scratch)
   vieo_imu_preint imu;  // the frame's pre-integration without Sigma, staged once: the single-lane edge evaluations of
                         // every trial read it, and a trip to L2 per dependent batch of loads was a fifth of their time
-  double cov[225], C[225], E[225], Cinv[225 * 2];
   int ok;
 };
 
@@ -376,7 +386,6 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   };
   const int n = fixedLast ? 15 : 30;
   const bool bodom = hasImu || ENC;
-  const double gw[3] = {F.gw[0], F.gw[1], F.gw[2]};
   // ---- constant edge data
   if (tid == 0) {
     ns_load(S.nsj, F.base.nav);
@@ -425,6 +434,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   }
   if (!fixedLast)
     for (int e = tid; e < 225; e += BS) S.Hp[e] = F.H_prior[e];
+  if (tid < 3) S.gw[tid] = F.gw[tid];
   for (int e = tid; e < (int)(offsetof(vieo_imu_preint, Sigma) / 8); e += BS)
     reinterpret_cast<double*>(&S.imu)[e] = reinterpret_cast<const double*>(&F.imu)[e];
   __syncthreads();
@@ -478,10 +488,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       if (lane == 0) S.red[wave] = tc;  // (S.red's last readers are barriers away)
     }
     if (BS > 192) {
-      if (tid == T3 && hasImu) RT(17, imu_error(S.imu, gw, S.nsi, S.nsj, S.errI, 6, 2));
-      if (tid == T2 && hasImu) RT(18, imu_error(S.imu, gw, S.nsi, S.nsj, S.errI, 6, 1));
+      if (tid == T3 && hasImu) RT(17, imu_error(S.imu, S.gw, S.nsi, S.nsj, S.errI, 6, 2));
+      if (tid == T2 && hasImu) RT(18, imu_error(S.imu, S.gw, S.nsi, S.nsj, S.errI, 6, 1));
     } else if (tid == 0 && hasImu)
-      imu_error(S.imu, gw, S.nsi, S.nsj, S.errI);
+      imu_error(S.imu, S.gw, S.nsi, S.nsj, S.errI);
     if (tid == T2) {
       if (!fixedLast) RT(19, prior_error(S.prior, S.nsi, S.errP));
       for (int k = 0; k < 3; k++) {
@@ -601,12 +611,12 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           for (int i = lane; i < 9 * 24; i += 64) S.JI[i] = 0;
           wave_sync();
           if (lane == 0) {
-            RT(20, imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1));
-            RT(21, imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2));
+            RT(20, imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1));
+            RT(21, imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2));
           }
         }
       } else if (tid == 0 && hasImu)
-        imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
+        imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI);
       if (tid == T2 && !fixedLast) RT(22, prior_linearize(S.prior, S.nsi, S.errP, S.JP));
       if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
       PP(2);
@@ -903,10 +913,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       S.vis[tid] = v;
     }
     if (BS > 192) {
-      if (tid == 0 && hasImu) imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
-      if (tid == T3 && hasImu) imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2);
+      if (tid == 0 && hasImu) imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
+      if (tid == T3 && hasImu) imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2);
     } else if (tid == 0 && hasImu)
-      imu_linearize(S.imu, gw, S.nsi, S.nsj, S.errI, S.JI);
+      imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI);
     if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
     if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
     for (int i = tid; i < 225; i += BS) S.cov[i] = 0, S.C[i] = 0, S.E[i] = 0;
