@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(BS)
 k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
            uint8_t* __restrict__ outlier_all, vieo_pose_result* __restrict__ results, int other_launched) {
   __shared__ double s_red[4 * 27];
+  __shared__ double s_tr[28 * (BS / 32) * 34], s_vis[28];  // block_sum_lds' transposition buffer, the 28 sums of an iteration
   __shared__ __align__(8) unsigned char s_cam_store[sizeof(CamD) * (MC ? 4 : 1)];  // CamD has initialisers
   CamD* s_cams = reinterpret_cast<CamD*>(s_cam_store);
   __shared__ int s_bad;
@@ -209,10 +210,9 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
         PoseXf X;
         make_xf(c, est, X);
         // computeActiveErrors + activeRobustChi2 + buildSystem in one pass
-        double acc[27];
+        double acc[28];  // the system's 21 + 6 sums, the robust chi2
 #pragma unroll
-        for (int i = 0; i < 27; i++) acc[i] = 0;
-        double chi = 0;
+        for (int i = 0; i < 28; i++) acc[i] = 0;
         vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
         for (int k = 0, i = tid; i < N; k++, i += BS) {
           const vieo_pose_obs o = o_next;
@@ -227,20 +227,20 @@ k_pose_opt(const vieo_pose_frame* __restrict__ frames, const vieo_pose_obs* __re
             const double dl = stereo ? deltaStereo : deltaMono;
             huber(chi2, dl, dl * dl, &r0, &r1);
           }
-          chi += r0;
+          acc[27] += r0;
           visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
         }
         est_err = est;
-        block_sum_bs<27, BS>(acc, s_red, tid);
-        double c1[1] = {chi};
-        block_sum_bs<1, BS>(c1, s_red, tid);
-        double currentChi = c1[0];
+        // one LDS transpose for the 28 sums (28 butterfly sums were ~500 instructions per wavefront: ba_device.h);
+        // every thread then reads them back, the 6 x 6 solve below is done by all of them side by side
+        block_sum_lds<28, BS>(acc, s_tr, s_vis, tid);
+        double currentChi = s_vis[27];
         double H[36], b[6];
         {
           int t = 0;
           for (int a = 0; a < 6; a++)
-            for (int bb = a; bb < 6; bb++, t++) H[a * 6 + bb] = H[bb * 6 + a] = acc[t];
-          for (int a = 0; a < 6; a++) b[a] = acc[21 + a];
+            for (int bb = a; bb < 6; bb++, t++) H[a * 6 + bb] = H[bb * 6 + a] = s_vis[t];
+          for (int a = 0; a < 6; a++) b[a] = s_vis[21 + a];
         }
         if (has_enc) {
           __syncthreads();
