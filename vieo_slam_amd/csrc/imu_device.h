@@ -28,8 +28,8 @@ struct Qd {
   double w, x, y, z;
 };
 __device__ __forceinline__ Qd q_of(const NSd& s) { return Qd{s.qw, s.qx, s.qy, s.qz}; }
-// (one division and four products instead of four divisions: a wavefront issues a double-precision operation every 8
-// cycles and a division is a dozen of them; the results differ from Eigen's normalize() in the last bit, far inside the
+// (one division and four products instead of four divisions: a double-precision division is a dozen dependent
+// instructions, ~76 cycles on a single-lane chain (tools/micro/lat_bench.hip); the results differ from Eigen's normalize() in the last bit, far inside the
 // 1e-4 parity tolerance of the optimisers)
 __device__ __forceinline__ Qd q_norm(Qd q) {
   const double r = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);

@@ -13,7 +13,8 @@
 // FP64 throughout; parity with oracle/pose_opt_vio.cc <= 1e-4 on SE(3).
 // This translation unit lets the compiler fuse a * b + c (the library is otherwise built with -ffp-contract=off for the
 // bit-exact integer / float paths): the optimiser's parity bar is 1e-4 on SE(3), the kernel runs long single-wavefront
-// chains where every double-precision instruction costs 8 issue cycles, and a fused multiply-add is one instead of two.
+// chains where every instruction costs its 4 issue cycles and every dependent link ~7, and a fused multiply-add is one of
+// each instead of two.
 #pragma clang fp contract(fast)
 
 #include <type_traits>
@@ -160,9 +161,9 @@ __device__ bool wave_solve_vio(const lds_f64* H, int n, double lambda, const lds
   ok = __all(ok);
   // TP:factor
   // Column j travels to the other rows through LDS (one ds_write per lane, then wave-uniform -- broadcast -- reads, two
-  // values per instruction) instead of two v_readlane per value: a wavefront issues one instruction every 4 (8 for double
-  // precision) cycles whatever the number of useful lanes, so the count of instructions is the cost, and this form has
-  // a quarter of them.  Every column keeps its own 34 doubles of Ls, zero at and above the diagonal: together they are
+  // values per instruction) instead of two v_readlane per value: a wavefront issues one instruction every 4 cycles
+  // (double precision included: tools/micro/lat_bench.hip) whatever the number of useful lanes, so the count of
+  // instructions is the cost, and this form has a quarter of them.  Every column keeps its own 34 doubles of Ls, zero at and above the diagonal: together they are
   // L^T un-normalised, which is what the backward substitution reads (lane i its own column i) -- L is never stored.
   lds_f64* colbuf = Ls;  // NR x kCS doubles: 34 keeps pairs 16-byte aligned and spreads the backward pass's per-lane
   constexpr int kCS = 34;  // column reads over the banks (32 would put every lane on one bank: 32 passes per read)
