@@ -561,6 +561,14 @@ typedef struct vieo_vio_result {
 
 int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_obs* h_obs,
                                uint8_t* h_outlier, vieo_vio_result* h_result);
+/* Rig frames (n_cams > 0) of a call with at most 4 frames -- the one-call tracker's case -- are optimised by 8
+ * workgroups each: replicas that run the same optimisation and share the passes over the visual edges (thousands per
+ * rig frame), exchanging partial sums through device memory; a frame below 700 edges is left to one of them.  The
+ * result differs from the one-workgroup form only in the association order of those sums (1e-12 relative on the
+ * pose); the status VIEO_E_HIP on a frame means a replica never arrived (never on a healthy device).
+ * vieo_pose_set_replicas(0) keeps one workgroup per frame on this host thread (measurements; also the environment
+ * variable VIEO_POSE_REPLICAS=0 at start-up), (1) restores the default.  Returns the previous setting. */
+int vieo_pose_set_replicas(int on);
 /* Capacity: a frame's edges are one bit per edge in a 64-bit mask per lane.  The host entry above always runs the
  * 256-thread instance (16384 observations per frame).  The batched device entry picks its instance from the batch
  * size -- more than 256 non-rig frames per call run one wavefront per frame (4096 observations per frame), smaller

@@ -157,6 +157,85 @@ def test_vio_camera_rig_parity(oracle, name, seed, marg):
     assert o["base"]["n_inliers"] > 200
 
 
+@pytest.mark.parametrize("name,seed,n,free_last", [("kb8", 73, 1500, False), ("radtan", 74, 3200, False),
+                                                   ("kb8", 75, 2400, True), ("kb8", 76, 699, False),
+                                                   ("kb8", 77, 700, False), ("radtan", 78, 9000, False)])
+def test_vio_rig_replicas_parity(oracle, name, seed, n, free_last):
+    """A rig frame of a small call is optimised by 8 replica workgroups that share the visual edges (from 700 edges on;
+    below, one of them takes the frame alone): against the oracle, and against the one-workgroup form of the same
+    kernel (vieo_pose_set_replicas(0)) -- only the association order of the visual sums differs."""
+    from vieo_slam_amd.optimizer import Optimizer
+    rig = synth_ba.camera_rig(name)
+    F, obs, _ = synth_ba.make_vio_problem(seed, n_obs=n, compute_marg=True, rig=rig)
+    if free_last:
+        F0, obs0, _ = synth_ba.make_vio_problem(seed + 100, compute_marg=True)
+        r0, _ = oracle.pose_optimization_vio(F0, obs0)
+        nav_last = F[0]["nav_last"].copy()
+        nav_prior = nav_last.copy()
+        nav_last["p"] += 0.004
+        nav_last["v"] += 0.015
+        F, _, _ = synth_ba.make_vio_problem(seed, n_obs=n, compute_marg=True, rig=rig,
+                                            prior=(nav_prior, r0["H_marg"].reshape(15, 15), nav_last))
+    L = lib()
+    was = L.vieo_pose_set_replicas(1)
+    try:
+        o, h8 = _cmp(oracle, F, obs, marg_rtol=1e-4 if free_last else 1e-5)
+        _, ho8 = Optimizer.PoseOptimizationVIO(F, obs)
+        L.vieo_pose_set_replicas(0)
+        h1, ho1 = Optimizer.PoseOptimizationVIO(F, obs)
+    finally:
+        L.vieo_pose_set_replicas(was)
+    assert h8["base"]["status"] == 0 and h1["base"]["status"] == 0
+    dt, dr = synth_ba.pose_error(h1["base"]["nav"], h8["base"]["nav"])
+    assert dt < 1e-9 and dr < 1e-7, (dt, dr)  # (dr: the angle metric resolves 3e-8)
+    assert np.array_equal(ho1, ho8) and h1["base"]["n_inliers"] == h8["base"]["n_inliers"]
+    H1, H8 = h1["H_marg"].reshape(15, 15), h8["H_marg"].reshape(15, 15)
+    assert np.allclose(H1, H8, rtol=1e-7, atol=1e-7 * np.abs(H1).max())
+
+
+def test_vio_rig_replicas_repeated_launches_and_small_batches(oracle):
+    """The exchange records are reused launch after launch (tags carry the launch number), a call of up to 4 rig frames
+    is replicated frame by frame, a larger one is not: all give the results of single calls."""
+    from vieo_slam_amd.optimizer import Optimizer
+    rig = synth_ba.camera_rig("kb8")
+    probs = [synth_ba.make_vio_problem(300 + i, n_obs=n, compute_marg=(i % 2 == 0), rig=rig)
+             for i, n in enumerate((900, 2000, 650, 1400, 800, 1200))]
+    single = [Optimizer.PoseOptimizationVIO(F, obs) for F, obs, _ in probs]
+    for rep in range(3):  # the same record set again and again
+        for (F, obs, _), (h0, o0) in zip(probs, single):
+            h, o = Optimizer.PoseOptimizationVIO(F, obs)
+            assert np.array_equal(o, o0) and h.tobytes() == h0.tobytes()  # a fixed order of sums: the same bits every time
+    dC = DeviceBuffer(rig[0].nbytes)
+    dC.upload(rig[0])
+    for B in (2, 4, 6):  # 2 and 4: replicated frame by frame; 6: one workgroup per frame; a rectified frame among them
+        frames = np.zeros(B, VIO_FRAME_DTYPE)
+        all_obs, begin = [], 0
+        plain = synth_ba.make_vio_problem(340, n_obs=400)
+        for i in range(B):
+            F, obs, _ = plain if i == 1 else probs[i]
+            frames[i] = F[0]
+            frames[i]["base"]["obs_begin"] = begin
+            frames[i]["base"]["cams"] = 0 if i == 1 else dC.ptr
+            all_obs.append(obs)
+            begin += len(obs)
+        obs_cat = np.concatenate(all_obs)
+        dF, dO = DeviceBuffer(frames.nbytes), DeviceBuffer(obs_cat.nbytes)
+        dU, dR = DeviceBuffer(len(obs_cat)), DeviceBuffer(B * VIO_RESULT_DTYPE.itemsize)
+        dF.upload(frames)
+        dO.upload(obs_cat)
+        check(lib().vieo_pose_optimization_vio_batch_device(dF.ptr, B, dO.ptr, dU.ptr, dR.ptr, None))
+        check(lib().vieo_device_synchronize())
+        res = dR.download(VIO_RESULT_DTYPE, (B,))
+        outl = dU.download(np.uint8, (len(obs_cat),))
+        for i in range(B):
+            h0, o0 = Optimizer.PoseOptimizationVIO(*plain[:2]) if i == 1 else single[i]
+            assert res[i]["base"]["status"] == 0
+            dt, dr = synth_ba.pose_error(h0["base"]["nav"], res[i]["base"]["nav"])
+            assert dt < 1e-9 and dr < 1e-7, (B, i, dt, dr)  # (dr: the angle metric resolves 3e-8)
+            b0 = int(frames[i]["base"]["obs_begin"])
+            assert np.array_equal(outl[b0:b0 + len(o0)], o0)
+
+
 @pytest.mark.parametrize("seed,n,kw", [(80, 300, dict(compute_marg=True)), (81, 60, dict(compute_marg=True, noise=2.0)),
                                        (82, 200, dict(imu=False, compute_marg=True)),
                                        (83, 40, dict(outlier_frac=0.5, compute_marg=True)),

@@ -23,6 +23,7 @@ _SIGS = {
     "vieo_device_available": (c_i, []),
     "vieo_set_device": (c_i, [c_i]),
     "vieo_pose_set_camera_mode": (c_i, [c_i]),
+    "vieo_pose_set_replicas": (c_i, [c_i]),
     "vieo_search_for_triangulation": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "vieo_pose_set_encoder_mode": (c_i, [c_i]),
     "vieo_is_in_frustum_batch": (c_i, [c_p, c_p, c_i, c_p]),

@@ -18,6 +18,7 @@
 #pragma clang fp contract(fast)
 
 #include <type_traits>
+#include <vector>
 
 #include "imu_device.h"
 
@@ -247,6 +248,8 @@ struct VioShared {
   double red[4 * 28], vis[28];
   double errI[9], errB[6], errP[15], wI[9], wP[15];
   double JI[9 * 24], JP[225], InfoI[81], T[225], TP[225], Hp[225];  // Hp: the frame's H_prior, staged once
+  double xv[4];         // a scalar on its way through PoseXchg
+  int xfail;            // an exchange timed out (a replica never arrived): the frame is reported as failed
   double gw[4];         // gravity (a pointer into LDS for the out-of-line edge functions; a local array would sit in scratch)
   vieo_imu_preint imu;  // the frame's pre-integration without Sigma, staged once: the single-lane edge evaluations of
                         // every trial read it, and a trip to L2 per dependent batch of loads was a fifth of their time
@@ -316,13 +319,53 @@ __device__ unsigned long long g_pose_probe[24];
 #define PP(i)
 #define RT(i, stmt) stmt
 #endif
+// A frame on several workgroups (rig frames of a small call: thousands of visual edges, one frame).  The kXG workgroups
+// of a frame are REPLICAS: each runs the whole optimisation -- the same serial mathematics on the same data, hence the
+// same decisions -- but goes through only its share of the visual edges; wherever a sum over the visual edges is taken
+// (28 per linearisation, 1 per trial, 1 per classification) the replicas exchange their partial sums through this record
+// and add them in the same order.  No master, no commands: a workgroup only ever waits for the others to arrive.
+// Protocol (MI355X: the per-XCD L2s are not coherent, a CU's L1 is never refreshed by another CU's stores): every
+// partial sum travels as ONE 16-byte granule (value, tag) written with a system-coherent store and read with
+// system-coherent loads (`sc0 sc1` on both sides: no fence, no counter); tag = (launch number << 32) | exchange number,
+// so a granule is its own "ready" flag and nothing has to be cleared between launches.  A thread publishes its value,
+// then polls the kXG granules of its index until all carry the tag, and adds them in replica order.  Granules are
+// double-buffered by the parity of the exchange (a fast replica may be one exchange ahead, never two: it needs every
+// replica's granule of this exchange before it can leave it).  First form of this exchange -- atomic stores, an arrival
+// counter, polls, atomic loads, three barriers -- cost ~7 us per exchange; this one ~3.
+constexpr int kXG = 8;
+typedef unsigned long long xq_t __attribute__((ext_vector_type(2)));
+struct PoseXchg {
+  xq_t cell[2][kXG][32];
+};
+__device__ __forceinline__ void xq_store(xq_t* p, xq_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// the kXG replicas' granules of one index (512 bytes apart), all in flight at once
+__device__ __forceinline__ void xq_load8(const xq_t* p, xq_t* v) {
+  static_assert(kXG == 8, "eight loads below");
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %8, off offset:512 sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %8, off offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %8, off offset:1536 sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %8, off offset:2048 sc0 sc1\n\t"
+      "global_load_dwordx4 %5, %8, off offset:2560 sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %8, off offset:3072 sc0 sc1\n\t"
+      "global_load_dwordx4 %7, %8, off offset:3584 sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p)
+      : "memory");
+}
 template <int BS, bool MC, bool ENC>
 __global__ void __launch_bounds__(BS)
 k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* __restrict__ obs_all,
-               uint8_t* __restrict__ outlier_all, vieo_vio_result* __restrict__ results, int other_launched) {
+               uint8_t* __restrict__ outlier_all, vieo_vio_result* __restrict__ results, int other_launched,
+               PoseXchg* __restrict__ xchg, unsigned launch_id) {
   __shared__ VioShared S;
   __shared__ double s_tr[BS == 64 ? 1 : 28 * (BS / 32) * 34];  // block_sum_lds' buffer (four wavefronts: 61 KB of its own)
-  __shared__ double s_xf[MC ? 48 : 1];  // rig: every camera's Rcw | tcw at the estimate of the current pass
+  __shared__ double s_xf[MC ? 48 * (BS / 64) : 1];  // rig: every camera's Rcw | tcw at the estimate of the current pass, one
+                                                    // copy per wavefront (formed by its own lanes: no workgroup barrier)
   __shared__ __align__(8) unsigned char s_cam_store[sizeof(CamD) * (MC ? 4 : 1)];  // CamD has initialisers
   CamD* s_cams = reinterpret_cast<CamD*>(s_cam_store);
   __shared__ __align__(8) unsigned char s_enc_store[ENC ? sizeof(VioEncShared) : 8];
@@ -341,6 +384,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   // one-camera frames -- picked per frame by its number of edges; as a run-time stride it cost 7 % of the kernel.
   // Rig instances: rig_xf()'s barriers need every thread, and their frames are beyond the limit anyway.)
   constexpr int kVioSplitObs = 768;
+  constexpr int kVioReplicaMinObs = 700;
   const vieo_pose_obs* obs = obs_all + F.base.obs_begin;
   uint8_t* outl = outlier_all + F.base.obs_begin;
   vieo_vio_result* R = results + f;
@@ -378,13 +422,6 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   for (int i = 0; i < 3; i++) c.tcb[i] = F.base.tcb[i];
   const bool fixedLast = !F.last_has_prior, hasImu = F.imu.dt != 0;
   // rig frames: the cameras' transforms at the estimate of a pass, once (a lane per camera) instead of once per edge
-  auto rig_xf = [&](const PoseXf& X, const double* p) {
-    if (MC) {
-      __syncthreads();  // the previous pass's readers are done
-      if (tid < F.base.n_cams) rig_cam_xf(s_cams[tid], X, p, s_xf + 12 * tid);
-      __syncthreads();
-    }
-  };
   const int n = fixedLast ? 15 : 30;
   const bool bodom = hasImu || ENC;
   // ---- constant edge data
@@ -445,9 +482,66 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const double dI = sqrt(16.919), dB = sqrt(12.592), dP = sqrt(25.0), dE = sqrt(12.592);
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
-  auto optimise = [&](auto vt_c) {
+  auto optimise = [&](auto vt_c, auto g_c) __attribute__((always_inline)) {
   constexpr int VT = decltype(vt_c)::value;
+  constexpr int G = decltype(g_c)::value;  // replicas of the frame (1, or kXG on blockIdx.y)
+  const int g = G > 1 ? (int)blockIdx.y : 0;
   const int Nv = tid < VT ? N : 0;  // (loop bound of the visual loops: no trip for the other threads)
+  const int i0 = g * VT + tid;       // this thread's first visual edge; the next ones GV further
+  constexpr int GV = G * VT;
+  PoseXchg* xb = G > 1 ? xchg + f : nullptr;
+  // Rig: the cameras' transforms at the estimate of a pass.  All threads on the visual edges: lanes 0 .. n_cams - 1 of
+  // the workgroup form them between two barriers.  Visual edges on wavefronts 0-1 only (replicas): every wavefront
+  // forms its own copy between wavefront barriers -- the other wavefronts are busy with the single-lane edges and cannot
+  // come to a workgroup barrier here.  (The copy is named at every use: through a pointer variable the compiler loses
+  // the LDS address space.)
+  auto rig_xf = [&](const PoseXf& X, const double* p) {
+    if (MC && VT == BS) {
+      __syncthreads();  // the previous pass's readers are done
+      if (tid < F.base.n_cams) rig_cam_xf(s_cams[tid], X, p, s_xf + 12 * tid);
+      __syncthreads();
+    } else if (MC) {
+      wave_sync();
+      if (lane < F.base.n_cams) rig_cam_xf(s_cams[lane], X, p, s_xf + 48 * wave + 12 * lane);
+      wave_sync();
+    }
+  };
+  int epoch = 0;
+  if (G > 1) {
+    if (tid == 0) S.xfail = 0;
+    __syncthreads();
+  }
+  // v[0 .. n) in LDS, complete and visible (a barrier has passed) -> the sums over the replicas, in every replica
+  auto grid_sum = [&](double* v, int n) {
+    if (G == 1) return;
+    if (tid < n) {
+      const unsigned long long tag = ((unsigned long long)launch_id << 32) | (unsigned)(epoch + 1);
+      xq_t* cells = &xb->cell[epoch & 1][0][tid];  // replica q's granule: cells + 32 q
+      xq_t mine;
+      mine.x = (unsigned long long)__double_as_longlong(v[tid]), mine.y = tag;
+      xq_store(cells + 32 * g, mine);
+      xq_t in[kXG];
+      int spins = 0;
+      for (;;) {
+        xq_load8(cells, in);
+        bool all = true;
+#pragma unroll
+        for (int q = 0; q < kXG; q++) all = all && in[q].y == tag;
+        if (all) break;
+        if (++spins > (1 << 21)) {  // seconds: a replica is not coming (never on a healthy launch); fail, do not hang
+          S.xfail = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      double t = 0;
+#pragma unroll
+      for (int q = 0; q < kXG; q++) t += __longlong_as_double((long long)in[q].x);  // replica order: the same sum everywhere
+      v[tid] = t;
+    }
+    epoch++;
+    __syncthreads();
+  };
   unsigned long long levelmask = 0;
   bool vis_robust = true;
   int nBad = 0, total_iters = 0;
@@ -471,13 +565,13 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       make_xf(c, e, X);
       rig_xf(X, e.p);
       double tc = 0;
-      vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
-      for (int k = 0, i = tid; i < Nv; k++, i += VT) {
+      vieo_pose_obs o_next = obs[min(i0, N - 1)];  // the next edge's record is in flight while this one is evaluated
+      for (int k = 0, i = i0; i < Nv; k++, i += GV) {
         const vieo_pose_obs o = o_next;
-        if (i + VT < N) o_next = obs[i + VT];
+        if (i + GV < N) o_next = obs[i + GV];
         if ((levelmask >> k) & 1) continue;
         double err[3], Pc[3];
-        const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
+        const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf + (VT == BS ? 0 : 48 * wave) : nullptr);
         double r0 = chi2, r1 = 1.;
         if (vis_robust) {
           const double dl = o.ur >= 0 ? deltaStereo : deltaMono;
@@ -504,6 +598,15 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     PP(13);
     __syncthreads();
     PP(14);
+    if (G > 1 && with_visual) {  // the replicas' shares of the visual chi2
+      if (tid == 0) {
+        double v = S.red[0];
+        for (int w = 1; w < VT / 64; w++) v += S.red[w];
+        S.xv[0] = v;
+      }
+      __syncthreads();
+      grid_sum(S.xv, 1);
+    }
     if (hasImu && tid < 9) {
       double t = 0;
       for (int j = 0; j < 9; j++) t += S.InfoI[tid * 9 + j] * S.errI[j];
@@ -549,7 +652,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     if (with_visual) {
       double v = S.red[0];
       for (int w = 1; w < VT / 64; w++) v += S.red[w];
-      *vis = v;
+      *vis = G > 1 ? S.xv[0] : v;
     }
     return chi;
   };
@@ -588,14 +691,14 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       PoseXf X;
       make_xf(c, e, X);
       rig_xf(X, e.p);
-      vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
-      for (int k = 0, i = tid; i < Nv; k++, i += VT) {
+      vieo_pose_obs o_next = obs[min(i0, N - 1)];  // the next edge's record is in flight while this one is evaluated
+      for (int k = 0, i = i0; i < Nv; k++, i += GV) {
         const vieo_pose_obs o = o_next;
-        if (i + VT < N) o_next = obs[i + VT];
+        if (i + GV < N) o_next = obs[i + GV];
         if ((levelmask >> k) & 1) continue;
         double err[3], Pc[3];
         double J[18];
-        const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J, MC ? s_xf : nullptr);
+        const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J, MC ? s_xf + (VT == BS ? 0 : 48 * wave) : nullptr);
         const bool stereo = o.ur >= 0;
         double r0 = chi2, r1 = 1.;
         if (vis_robust) {
@@ -624,6 +727,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       // the 28 sums land in S.vis (the system's visual block) straight from the transpose; H .. tr_tail are dead here.
       // Its barriers are also where the Jacobians above meet the threads that assemble the system.
       block_sum_lds<28, BS>(acc, BS == 64 ? S.H : s_tr, S.vis, tid);
+      grid_sum(S.vis, 28);
       PP(3);
       double currentChi = chiG + S.vis[27];
       const double iniChi = currentChi;
@@ -830,10 +934,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     rig_xf(X, e.p);
     const float chi2close = (float)(1.5 * (double)chi2Mono);
     double nb[1] = {0};
-    for (int k = 0, i = tid; i < Nv; k++, i += VT) {
+    for (int k = 0, i = i0; i < Nv; k++, i += GV) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
-      const float chi2 = (float)edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
+      const float chi2 = (float)edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf + (VT == BS ? 0 : 48 * wave) : nullptr);
       bool bad;
       if (o.ur < 0)
         bad = chi2 > ((o.flags & 1) ? chi2close : chi2Mono) || !(Pc[2] > 0.);
@@ -846,6 +950,13 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         levelmask &= ~(1ull << k);
     }
     block_sum_bs<1, BS>(nb, S.red, tid);
+    if (G > 1) {
+      __syncthreads();  // (the last trial's readers of xv)
+      if (tid == 0) S.xv[0] = nb[0];
+      __syncthreads();
+      grid_sum(S.xv, 1);
+      nb[0] = S.xv[0];
+    }
     nBad = (int)nb[0];
     if (it == 2) vis_robust = false;
     if (n_edges_total < 10) break;
@@ -859,10 +970,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     make_xf(c, e, X);
     rig_xf(X, e.p);
     double nb[1] = {0};
-    for (int k = 0, i = tid; i < Nv; k++, i += VT) {
+    for (int k = 0, i = i0; i < Nv; k++, i += GV) {
       const vieo_pose_obs o = obs[i];
       double err[3], Pc[3];
-      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf : nullptr);
+      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf + (VT == BS ? 0 : 48 * wave) : nullptr);
       if (chi2 < (double)(o.ur < 0 ? 18.f : 24.f)) {
         levelmask &= ~(1ull << k);
         outmask &= ~(1ull << k);
@@ -870,9 +981,16 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         nb[0] += 1;
     }
     block_sum_bs<1, BS>(nb, S.red, tid);
+    if (G > 1) {
+      __syncthreads();  // (the last trial's readers of xv)
+      if (tid == 0) S.xv[0] = nb[0];
+      __syncthreads();
+      grid_sum(S.xv, 1);
+      nb[0] = S.xv[0];
+    }
     nBad = (int)nb[0];
   }
-  for (int k = 0, i = tid; i < Nv; k++, i += VT) outl[i] = (outmask >> k) & 1;
+  for (int k = 0, i = i0; i < Nv; k++, i += GV) outl[i] = (outmask >> k) & 1;
   // ---- marginal prior (Optimizer.h:663-813, FillCovInv :126-206, exact_mode = kExactRobust)
   if (F.compute_marg) {
     double rhoI, rhoB, rhoP;
@@ -886,14 +1004,14 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
-    vieo_pose_obs o_next = obs[min(tid, N - 1)];  // the next edge's record is in flight while this one is evaluated
-    for (int k = 0, i = tid; i < Nv; k++, i += VT) {
+    vieo_pose_obs o_next = obs[min(i0, N - 1)];  // the next edge's record is in flight while this one is evaluated
+    for (int k = 0, i = i0; i < Nv; k++, i += GV) {
       const vieo_pose_obs o = o_next;
-      if (i + VT < N) o_next = obs[i + VT];
+      if (i + GV < N) o_next = obs[i + GV];
       if ((levelmask >> k) & 1) continue;
       double err[3], Pc[3];
       double J[18];
-      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J, MC ? s_xf : nullptr);
+      const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, J, MC ? s_xf + (VT == BS ? 0 : 48 * wave) : nullptr);
       const bool stereo = o.ur >= 0;
       double r0 = chi2, r1 = 1.;
       if (vis_robust) {
@@ -922,6 +1040,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
     for (int i = tid; i < 225; i += BS) S.cov[i] = 0, S.C[i] = 0, S.E[i] = 0;
     __syncthreads();
+    grid_sum(S.vis, 27);
     if (tid < 36) {
       const int a = tid / 6, bq = tid % 6;
       const int lo = a < bq ? a : bq, hi = a < bq ? bq : a;
@@ -1047,42 +1166,109 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   } else {
     for (int i = tid; i < 225; i += BS) R->H_marg[i] = 0;
   }
-  if (tid == 0) {
+  if (tid == 0 && g == 0) {  // (the replicas hold the same values)
     R->base.nav = F.base.nav;
     ns_store(S.nsj, R->base.nav);
     R->base.n_inliers = N - nBad;
-    R->base.status = VIEO_POSE_OK;
+    R->base.status = (G > 1 && S.xfail) ? VIEO_E_HIP : VIEO_POSE_OK;
     R->base.lm_iterations = total_iters;
     R->base.reserved = 0;
     R->has_marg = F.compute_marg ? 1 : 0;
     R->reserved = 0;
   }
   };  // optimise
+  using one_c = std::integral_constant<int, 1>;
   if constexpr (BS == 256 && !MC) {
     if (N <= kVioSplitObs)
-      optimise(std::integral_constant<int, 128>{});
+      optimise(std::integral_constant<int, 128>{}, one_c{});
     else
-      optimise(std::integral_constant<int, BS>{});
+      optimise(std::integral_constant<int, BS>{}, one_c{});
+  } else if constexpr (BS == 256 && MC) {
+    // a replicated launch: below kVioReplicaMinObs edges the ~36 exchanges (3 us each) cost more than the shared
+    // visual passes save -- replica 0 takes the frame alone; each replica's share is small, so the single-lane edges
+    // run beside the visual ones (128 visual threads x 64 mask bits x kXG replicas >= any frame the kernel accepts).
+    // (ONE call site per instance of the body: called from two it stays out of line, and its by-reference captures --
+    // every local above -- then live in scratch memory: 4-camera frame 2.8 -> 3.3 ms.)
+    bool rep = gridDim.y == (unsigned)kXG && xchg != nullptr;
+    if (rep && N < kVioReplicaMinObs) {
+      if (blockIdx.y != 0) return;
+      rep = false;
+    }
+    if (rep)
+      optimise(std::integral_constant<int, 128>{}, std::integral_constant<int, kXG>{});
+    else
+      optimise(std::integral_constant<int, BS>{}, one_c{});
   } else
-    optimise(std::integral_constant<int, BS>{});
+    optimise(std::integral_constant<int, BS>{}, one_c{});
 }
 
 }  // namespace vieo
 
 using namespace vieo;
 
+// The exchange records of the replicated launches, one set per (host thread, stream): launches on one stream are
+// ordered, so a record is never shared by two kernels in flight.  Zeroed once (tag 0 is never used: launches count from 1).
+static PoseXchg* vio_xchg_records(hipStream_t stream, int n_frames, unsigned* launch_id) {
+  struct Rec {
+    hipStream_t st;
+    PoseXchg* p;
+    int n;
+    unsigned launches;
+  };
+  static thread_local std::vector<Rec> recs;
+  for (Rec& r : recs)
+    if (r.st == stream) {
+      *launch_id = ++r.launches;
+      if (r.n >= n_frames) return r.p;
+      (void)hipStreamSynchronize(stream);
+      (void)hipFree(r.p);
+      r.p = nullptr, r.n = 0;
+      if (hipMalloc(&r.p, sizeof(PoseXchg) * n_frames) != hipSuccess) return nullptr;
+      (void)hipMemset(r.p, 0, sizeof(PoseXchg) * n_frames);
+      r.n = n_frames;
+      return r.p;
+    }
+  Rec r{stream, nullptr, 0, 1};
+  if (hipMalloc(&r.p, sizeof(PoseXchg) * n_frames) != hipSuccess) return nullptr;
+  (void)hipMemset(r.p, 0, sizeof(PoseXchg) * n_frames);
+  r.n = n_frames;
+  recs.push_back(r);
+  *launch_id = 1;
+  return r.p;
+}
+
+// rig frames of a small call (the one-call tracker: one frame): kXG replicas per frame share the visual edges.
+// vieo_pose_set_replicas(0) / VIEO_POSE_REPLICAS=0 keeps one workgroup per frame (measurements, tests of both forms).
+constexpr int kVioReplicaFrames = 4;
+static int& vio_replicas() {
+  static thread_local int on = [] {
+    const char* e = getenv("VIEO_POSE_REPLICAS");
+    return (e && atoi(e) == 0) ? 0 : 1;
+  }();
+  return on;
+}
 template <bool MC, bool ENC>
 static void vio_launch_kind(bool narrow, const vieo_vio_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
                             uint8_t* d_outlier, vieo_vio_result* d_results, int others, hipStream_t stream) {
+  const bool replicas = vio_replicas() != 0;
   if (narrow && !MC)  // rig frames carry n_cams x the observations: always the wide form (up to 16384 edges)
     hipLaunchKernelGGL((k_pose_opt_vio<64, MC, ENC>), dim3(n_frames), dim3(64), 0, stream, d_frames, d_obs,
-                       d_outlier, d_results, others);
-  else
-    hipLaunchKernelGGL((k_pose_opt_vio<256, MC, ENC>), dim3(n_frames), dim3(256), 0, stream, d_frames, d_obs,
-                       d_outlier, d_results, others);
+                       d_outlier, d_results, others, (PoseXchg*)nullptr, 0u);
+  else {
+    unsigned launch_id = 0;
+    PoseXchg* xb = (MC && replicas && n_frames <= kVioReplicaFrames) ? vio_xchg_records(stream, kVioReplicaFrames, &launch_id) : nullptr;
+    hipLaunchKernelGGL((k_pose_opt_vio<256, MC, ENC>), dim3(n_frames, xb ? kXG : 1), dim3(256), 0, stream, d_frames, d_obs,
+                       d_outlier, d_results, others, xb, launch_id);
+  }
 }
 
 extern "C" {
+
+int vieo_pose_set_replicas(int on) {
+  const int was = vio_replicas();
+  vio_replicas() = on ? 1 : 0;
+  return was;
+}
 
 // which / which_enc: bit 0 the rectified / encoder-less instance, bit 1 the rig / encoder instance
 static int vio_launch(const vieo_vio_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
