@@ -689,8 +689,18 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
   const bool reloc = A.mode == VIEO_SBP_RELOC;
   // best / second of query q when key k is blocked iff it was taken at the start or mn[k] < q; returns the claimed
   // key (-1: no match) and the winner's candidate word
-  auto eval = [&](int q, const int* mn, unsigned* word, int* blocker) -> int {
-    const int2 r = qrec[q];
+  // A thread's queries are tid, tid + 1024, ...: the first kQPer of them keep their record and their claim in registers
+  // (a round then touches LDS only: read from HBM every round, they were two dependent round trips per round)
+  constexpr int kQPer = 8;
+  int2 rq[kQPer];
+  int cl[kQPer];
+#pragma unroll
+  for (int j = 0; j < kQPer; j++) {
+    const int q = tid + 1024 * j;
+    rq[j] = q < nq ? qrec[q] : make_int2(0, 0);
+    cl[j] = -1;
+  }
+  auto eval = [&](int q, const int2 r, const int* mn, unsigned* word, int* blocker) -> int {
     const int off = r.x, ny = r.y;
     if (ny == 0) return -1;
     if (ny < 0) {
@@ -725,10 +735,21 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
     int* prev = (round & 1) ? s_min1 : s_min0;
     int* cur = (round & 1) ? s_min0 : s_min1;
     int changed = 0;
-    for (int q = tid; q < nq; q += 1024) {
+#pragma unroll
+    for (int j = 0; j < kQPer; j++) {
+      const int q = tid + 1024 * j;
+      if (q < nq) {
+        unsigned w;
+        int blk = 0;
+        const int k = eval(q, rq[j], prev, &w, &blk);
+        if (k != cl[j]) cl[j] = k, changed = 1;
+        if (k >= 0 && blk) atomicMin(&cur[k], q);
+      }
+    }
+    for (int q = tid + 1024 * kQPer; q < nq; q += 1024) {  // (more than 8192 queries: the rest through memory)
       unsigned w;
       int blk = 0;
-      const int k = eval(q, prev, &w, &blk);
+      const int k = eval(q, qrec[q], prev, &w, &blk);
       if (k != claim[q]) claim[q] = k, changed = 1;
       if (k >= 0 && blk) atomicMin(&cur[k], q);
     }
@@ -746,12 +767,11 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
       for (int i = tid; i < N; i += 1024) s_asg[i] = -1;
       __syncthreads();
       int nm = 0;
-      for (int q = tid; q < nq; q += 1024) {
-        const int k = claim[q];
-        if (k < 0) continue;
+      auto accept = [&](int q, const int2 r, int k) {
+        if (k < 0) return;
         unsigned w = 0;
         int blk = 0;
-        (void)eval(q, cur, &w, &blk);  // the winner's word again (rotation bin)
+        (void)eval(q, r, cur, &w, &blk);  // the winner's word again (rotation bin)
         atomicMax(&s_asg[k], q);
         nm++;
         if (ori) {
@@ -759,7 +779,13 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
           atomicOr(&s_bins[k], 1u << bin);
           atomicAdd(&s_hist[bin], 1);
         }
+      };
+#pragma unroll
+      for (int j = 0; j < kQPer; j++) {
+        const int q = tid + 1024 * j;
+        if (q < nq) accept(q, rq[j], cl[j]);
       }
+      for (int q = tid + 1024 * kQPer; q < nq; q += 1024) accept(q, qrec[q], claim[q]);
       if (nm) atomicAdd(&s_nm, nm);
       __syncthreads();
       int nmatches = s_nm;
