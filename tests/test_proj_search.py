@@ -251,9 +251,14 @@ def test_gpu_sbp_assignment_dependency_chains(oracle, mode, monkeypatch):
     on, oa = oracle.search_by_projection(mode, q, kl, ur, dl2, taken, BOUNDS, nn_ratio=(0.9, 0.95, 100.0)[mode])
     assert on > 100
     results = {}
-    for name, env in (("parallel", {}), ("sequential", {"VIEO_SBP_ASSIGN": "seq"}), ("fallback", {"VIEO_SBP_MAX_ROUNDS": "1"})):
+    # (the parallel form exists twice: flat over the candidate pairs -- the default for a call of few frames and for
+    # rigs -- and one thread per query for large batches; VIEO_SBP_FLAT picks)
+    for name, env in (("parallel", {}), ("flat", {"VIEO_SBP_FLAT": "1"}), ("per query", {"VIEO_SBP_FLAT": "0"}),
+                      ("sequential", {"VIEO_SBP_ASSIGN": "seq"}), ("fallback", {"VIEO_SBP_MAX_ROUNDS": "1"}),
+                      ("fallback per query", {"VIEO_SBP_MAX_ROUNDS": "1", "VIEO_SBP_FLAT": "0"})):
         monkeypatch.delenv("VIEO_SBP_ASSIGN", raising=False)
         monkeypatch.delenv("VIEO_SBP_MAX_ROUNDS", raising=False)
+        monkeypatch.delenv("VIEO_SBP_FLAT", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         results[name] = call(q, kl, ur, dl2, taken, BOUNDS)
@@ -282,12 +287,15 @@ def test_gpu_sbp_more_wide_windows_than_a_block_lists(oracle, monkeypatch):
     m = _hip_matcher(0.9)
     on, oa = oracle.search_by_projection(0, q, kl, ur, dl, None, BOUNDS, nn_ratio=0.9)
     assert on > 100
-    for env in ({}, {"VIEO_SBP_ASSIGN": "seq"}):
+    for env in ({}, {"VIEO_SBP_FLAT": "0"}, {"VIEO_SBP_ASSIGN": "seq"}):  # (19 000 queries: the flat form hands over to the replay)
         monkeypatch.delenv("VIEO_SBP_ASSIGN", raising=False)
+        monkeypatch.delenv("VIEO_SBP_FLAT", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         hn, ha = m.SearchByProjectionLastFrame(q, kl, ur, dl, None, BOUNDS)
         assert hn == on and np.array_equal(ha, oa), env
+    monkeypatch.delenv("VIEO_SBP_ASSIGN", raising=False)
+    monkeypatch.delenv("VIEO_SBP_FLAT", raising=False)
     # and with only three of the eight blocks over their list (block b owns the queries with (q >> 4) % 8 == b)
     q2 = q.copy()
     q2["radius"] = np.where(((np.arange(len(q)) >> 4) % 8) < 3, q["radius"], 6.0).astype(np.float32)

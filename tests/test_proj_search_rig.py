@@ -147,6 +147,49 @@ def test_gpu_rig_last_frame_parity(oracle, rig, nc, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rig,nc", RIGS)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gpu_rig_assignment_forms_agree(oracle, rig, nc, mode, monkeypatch):
+    """The order-dependent assignment of a rig frame, four ways through the library: one workgroup per camera with rounds
+    flat over the candidate pairs (the default; the rotation histogram, which spans the cameras, is finished by the last
+    workgroup to arrive), one workgroup per frame with a thread per query (VIEO_SBP_FLAT=0), the sequential replay alone,
+    and the flat form giving up after one round.  Look-alike descriptors and wide windows make the claims depend on the
+    order; all equal the oracle bit for bit."""
+    C = sf.make_rig_tracking_case(31 + mode, rig, nc, n_points=900 if nc == 4 else 1200, th=20.0)
+    rng = np.random.default_rng(310 + mode)
+    fam = rng.integers(0, 256, (10, 32), dtype=np.uint8)
+    desc = fam[rng.integers(0, 10, len(C["keys"]))].copy()
+    flip = rng.integers(0, 256, len(desc))
+    desc[np.arange(len(desc)), flip % 32] ^= (1 << (flip % 8)).astype(np.uint8)
+    if mode == 0:
+        pts = C["pts"].copy()
+        pts["desc"] = fam[rng.integers(0, 10, len(pts))]
+        pts["flags"] = np.where(rng.random(len(pts)) < 0.15, pts["flags"] & 1, pts["flags"])  # some without observations
+        q = oracle.sbp_project_last_frame(pts, C["cam"], C["rig"])
+        nn = 0.9
+    else:
+        q, _ = _local_map_queries(oracle, C, th=8.0)
+        q["desc"] = fam[rng.integers(0, 10, len(q))]
+        nn = 0.95
+    taken = (rng.random(len(C["keys"])) < 0.1).astype(np.uint8)
+    on, oa = oracle.search_by_projection(mode, q, C["keys"], C["uright"], desc, taken, C["bounds"], nn_ratio=nn,
+                                         cam_first=C["cam_first"])
+    assert on > 100
+    m = _m(nn)
+    call = m.SearchByProjectionLastFrame if mode == 0 else m.SearchByProjectionLocalMap
+    for name, env in (("flat per camera", {}), ("thread per query", {"VIEO_SBP_FLAT": "0"}),
+                      ("sequential", {"VIEO_SBP_ASSIGN": "seq"}), ("fallback", {"VIEO_SBP_MAX_ROUNDS": "1"})):
+        for k in ("VIEO_SBP_FLAT", "VIEO_SBP_ASSIGN", "VIEO_SBP_MAX_ROUNDS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hn, ha = call(q, C["keys"], C["uright"], desc, taken, C["bounds"], C["cam_first"])
+        assert hn == on and np.array_equal(ha, oa), name
+    for k in ("VIEO_SBP_FLAT", "VIEO_SBP_ASSIGN", "VIEO_SBP_MAX_ROUNDS"):
+        monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rig,nc", RIGS)
 def test_gpu_rig_local_map_parity(oracle, rig, nc):
     from vieo_slam_amd.map_point import is_in_frustum
     C = sf.make_rig_tracking_case(21, rig, nc, n_points=1000)

@@ -709,15 +709,31 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
     }
     const int n = ny & 0xFFFF;
     unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu, c0 = 0, c1 = 0;
-    for (int pos = 0; pos < n; pos++) {
-      const unsigned c = off + pos < n_lds ? s_pool[off + pos] : pool[off + pos];
-      const int idx = c & 0x1FFF;
-      if (s_taken[idx] || mn[idx] < q) continue;
-      const unsigned key = (((c >> 13) & 0x1FFu) << 8) | (unsigned)pos;  // (dist, order)
-      if (key < b0)
-        b1 = b0, c1 = c0, b0 = key, c0 = c;
-      else if (key < b1)
-        b1 = key, c1 = c;
+    // eight candidates at a time, each of the three reads issued for all eight before any is used (see k_sbp_assign_cam)
+    for (int p0 = 0; p0 < n; p0 += 8) {
+      unsigned cw[8];
+      int tk[8], mq[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int at = off + min(p0 + u, n - 1);
+        cw[u] = at < n_lds ? s_pool[at] : pool[at];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int idx = cw[u] & 0x1FFF;
+        tk[u] = s_taken[idx], mq[u] = mn[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int pos = p0 + u;
+        if (pos < n && !(tk[u] || mq[u] < q)) {
+          const unsigned c = cw[u], key = (((c >> 13) & 0x1FFu) << 8) | (unsigned)pos;  // (dist, order)
+          if (key < b0)
+            b1 = b0, c1 = c0, b0 = key, c0 = c;
+          else if (key < b1)
+            b1 = key, c1 = c;
+        }
+      }
     }
     if (b0 == 0xFFFFFFFFu) return -1;
     const int bestDist = b0 >> 8, bestLevel = (c0 >> 22) & 15;
@@ -822,6 +838,240 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
     }
   }
   if (tid == 0) A.need_seq[f] = settled ? 0 : 1;
+}
+
+// ---- the same assignment for camera rigs, one workgroup per (frame, camera) (round 4).  A query belongs to one
+// camera and its candidates are keys of that camera, so the order-dependent walk decomposes exactly: the queries of
+// camera c, in their original order, against the keys of camera c.  Two things made the one-workgroup form slow on rig
+// frames (31 us per round of 10 k queries, 8 rounds): (1) 13 bytes of state per key of ALL cameras in LDS left room for
+// 5 k of the frame's 35-45 k candidate words, the rest was read through L2 in every round; (2) one thread per query
+// walks its list candidate by candidate -- three dependent reads each -- and a wavefront waits for its longest list
+// (up to kCandCap = 128 entries where the texture is dense, 3 on average).  Here the camera's lists are copied to LDS
+// once and a round is FLAT over the (query, candidate) pairs: every thread takes the same number of pairs, tests
+// "blocked?" and puts the pair's key (distance, position) into its query's slot with one LDS atomicMin (a second pass
+// for the runner-up where the mode looks at it); the query's owner then applies the tests and claims.  The cameras run
+// side by side on their own CUs.  What spans the cameras -- the rotation histogram (ComputeThreeMaxima over the matches
+// of all cameras, ORBmatcher.cc:1608-1641), the match count, "not settled" -- is finished by the LAST workgroup of the
+// frame to arrive (agent-scope release / acquire around one counter).  fin: [frame][48] ints, zero between launches
+// (the finisher clears it); kbins: [frame][key_cap] rotation bins of the accepted keys.
+// LDS: pairs (word u32, owner u16) x pair_cap | per key 13 bytes x cam_cap | per query of the camera 12 bytes x kCamQ.
+static const int kFinStride = 48, kCamQ = 4096;
+__global__ void __launch_bounds__(1024) k_sbp_assign_cam(SbpArgs A, int cam_cap, int* __restrict__ fin, unsigned* __restrict__ kbins) {
+  extern __shared__ unsigned s_pool[];             // [pool_lds] the camera's candidate words, list after list
+  unsigned* s_best = s_pool + A.pool_lds;          // [kCamQ] smallest unblocked key of the query this round
+  unsigned* s_second = s_best + kCamQ;             // [kCamQ] runner-up (local-map mode)
+  int* s_min0 = (int*)(s_second + kCamQ);          // [cam_cap] earliest blocking claimer of the key, previous / current round
+  int* s_min1 = s_min0 + cam_cap;
+  unsigned* s_bins = (unsigned*)(s_min1 + cam_cap);
+  unsigned short* s_qof = (unsigned short*)(s_bins + cam_cap);  // [pool_lds] pair -> local query
+  unsigned short* s_qid = s_qof + A.pool_lds;      // [kCamQ] local query -> query
+  unsigned short* s_qstart = s_qid + kCamQ;        // [kCamQ] its first pair
+  uint8_t* s_taken = (uint8_t*)(s_qstart + kCamQ);  // [cam_cap]
+  __shared__ int s_hist[kHistoLen];
+  __shared__ int s_changed[2], s_nm, s_overflow, s_fill, s_nql, s_last;
+  const int f = blockIdx.x, cam = blockIdx.y, tid = threadIdx.x;
+  int k0, k1;
+  cam_range(A, f, cam, &k0, &k1);
+  const int Nc = k1 - k0;
+  const int nq = min(A.nq[f], A.q_cap);
+  int* assign = A.assign + (size_t)f * A.key_cap;
+  const uint8_t* taken = A.taken ? A.taken + (size_t)f * A.key_cap : nullptr;
+  const unsigned* pool = A.pool + (size_t)f * A.pool_cap;
+  const int2* qrec = A.qrec + (size_t)f * A.q_cap;
+  int* F = fin + (size_t)f * kFinStride;  // [0, 30) histogram, [32] matches, [33] overflow, [34] not settled, [35] arrivals
+  unsigned* KB = kbins + (size_t)f * A.key_cap;
+  const bool ori = A.mode != VIEO_SBP_LOCAL_MAP && A.check_ori;
+  const bool reloc = A.mode == VIEO_SBP_RELOC, second = A.mode == VIEO_SBP_LOCAL_MAP;
+  constexpr int kQPer = 12;  // queries per thread held in registers: 12 288 per frame
+  bool settled = false;
+  // (a camera with more keys than its share of key_cap, more queries than fit: the sequential replay takes the frame)
+  if (Nc <= cam_cap && nq <= 1024 * kQPer && nq < 65536) {
+    for (int i = tid; i < Nc; i += 1024) {
+      s_taken[i] = taken ? taken[k0 + i] : (uint8_t)0;
+      s_min0[i] = INT_MAX, s_min1[i] = INT_MAX, s_bins[i] = 0u;
+    }
+    for (int i = tid; i < kCamQ; i += 1024) s_best[i] = 0xFFFFFFFFu, s_second[i] = 0xFFFFFFFFu;
+    if (tid < kHistoLen) s_hist[tid] = 0;
+    if (tid == 0) s_nm = 0, s_overflow = 0, s_fill = 0, s_nql = 0, s_changed[0] = s_changed[1] = 0;
+    __syncthreads();
+    // ---- this thread's queries (tid, tid + 1024, ...): which are this camera's (their first candidate is one of its
+    // keys); their lists go to LDS.  lq: the query's slot among the camera's queries (-1: not this camera's).
+    int lq[kQPer], cny[kQPer], cl[kQPer];
+    unsigned wl[kQPer];  // the winner's candidate word at the last round (rotation bin)
+    {
+      int2 rq[kQPer];
+      unsigned first[kQPer];
+#pragma unroll
+      for (int j = 0; j < kQPer; j++) {  // (all records in flight, then all first words)
+        const int q = tid + 1024 * j;
+        rq[j] = q < nq ? qrec[q] : make_int2(0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < kQPer; j++) first[j] = rq[j].y > 0 ? pool[rq[j].x] : 0u;
+#pragma unroll
+      for (int j = 0; j < kQPer; j++) {
+        cl[j] = -1, lq[j] = -1, cny[j] = 0, wl[j] = 0;
+        if (rq[j].y < 0) s_overflow = 1;  // (its camera is unknown: every camera reports it)
+        const int n = rq[j].y > 0 ? (rq[j].y & 0xFFFF) : 0, idx = (int)(first[j] & 0x1FFF);
+        if (n > 0 && idx >= k0 && idx < k1) {
+          const int lo = atomicAdd(&s_fill, n), me = atomicAdd(&s_nql, 1);
+          if (lo + n <= A.pool_lds && me < kCamQ) {
+            lq[j] = me, cny[j] = rq[j].y;
+            s_qid[me] = (unsigned short)(tid + 1024 * j), s_qstart[me] = (unsigned short)lo;
+            for (int p0 = 0; p0 < n; p0 += 8) {  // eight words in flight
+              unsigned cw[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) cw[u] = pool[rq[j].x + min(p0 + u, n - 1)];
+#pragma unroll
+              for (int u = 0; u < 8; u++)
+                if (p0 + u < n) s_pool[lo + p0 + u] = cw[u], s_qof[lo + p0 + u] = (unsigned short)me;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int n_pairs = s_fill;
+    const bool fits = n_pairs <= A.pool_lds && s_nql <= kCamQ && n_pairs < 65536;
+    for (int round = 0; fits && round < A.max_rounds; round++) {
+      int* prev = (round & 1) ? s_min1 : s_min0;
+      int* cur = (round & 1) ? s_min0 : s_min1;
+      // pairs: the key (distance, position) of every unblocked candidate into its query's slot
+      for (int p = tid; p < n_pairs; p += 1024) {
+        const unsigned c = s_pool[p];
+        const int me = s_qof[p], idx = (int)(c & 0x1FFF) - k0;
+        const int q = s_qid[me], pos = p - s_qstart[me];
+        if (!(s_taken[idx] || prev[idx] < q)) atomicMin(&s_best[me], (((c >> 13) & 0x1FFu) << 8) | (unsigned)pos);
+      }
+      __syncthreads();
+      if (second) {  // the runner-up: the smallest key that is not the best
+        for (int p = tid; p < n_pairs; p += 1024) {
+          const unsigned c = s_pool[p];
+          const int me = s_qof[p], idx = (int)(c & 0x1FFF) - k0;
+          const int q = s_qid[me], pos = p - s_qstart[me];
+          const unsigned key = (((c >> 13) & 0x1FFu) << 8) | (unsigned)pos;
+          if (key != s_best[me] && !(s_taken[idx] || prev[idx] < q)) atomicMin(&s_second[me], key);
+        }
+        __syncthreads();
+      }
+      // queries: the tests behind best / second, the claim
+      int changed = 0;
+#pragma unroll
+      for (int j = 0; j < kQPer; j++)
+        if (lq[j] >= 0) {
+          const int me = lq[j], q = tid + 1024 * j, ny = cny[j];
+          const unsigned b0 = s_best[me], b1 = s_second[me];
+          s_best[me] = 0xFFFFFFFFu, s_second[me] = 0xFFFFFFFFu;  // (for the next round)
+          int k = -1;
+          if (b0 != 0xFFFFFFFFu) {
+            const unsigned c0 = s_pool[s_qstart[me] + (b0 & 0xFF)];
+            const int bestDist = b0 >> 8, bestLevel = (c0 >> 22) & 15;
+            bool ok = bestDist <= (reloc ? (int)A.nn_ratio : kThHigh);
+            if (ok && second && b1 != 0xFFFFFFFFu) {
+              const unsigned c1 = s_pool[s_qstart[me] + (b1 & 0xFF)];
+              const int bestDist2 = b1 >> 8, bestLevel2 = (c1 >> 22) & 15;
+              if (bestLevel == bestLevel2 && (float)bestDist > A.nn_ratio * (float)bestDist2) ok = false;
+            }
+            if (ok) k = (int)(c0 & 0x1FFF) - k0, wl[j] = c0;
+          }
+          if (k != cl[j]) cl[j] = k, changed = 1;
+          // its key is closed to later queries when its holder has observations (any holder in the relocalisation mode)
+          if (k >= 0 && (reloc || (ny >> 16))) atomicMin(&cur[k], q);
+        }
+      if (changed) s_changed[round & 1] = 1;
+      __syncthreads();
+      const int any = s_changed[round & 1];
+      if (tid == 0) s_changed[(round + 1) & 1] = 0;  // (last read a round ago)
+      for (int i = tid; i < Nc; i += 1024) prev[i] = INT_MAX;  // becomes the next round's `cur`
+      __syncthreads();
+      if (!any) {  // `cur` == the claims everybody just agreed with
+        settled = true;
+        int* s_asg = prev;  // (free now) -1 == VIEO_SBP_UNCHANGED
+        for (int i = tid; i < Nc; i += 1024) s_asg[i] = -1;
+        __syncthreads();
+        int nm = 0;
+#pragma unroll
+        for (int j = 0; j < kQPer; j++)
+          if (lq[j] >= 0 && cl[j] >= 0) {
+            atomicMax(&s_asg[cl[j]], tid + 1024 * j);  // AddMapPoint in query order = the last accepted claimer of a key stays
+            nm++;
+            if (ori) {
+              const int bin = (wl[j] >> 26) & 31;
+              atomicOr(&s_bins[cl[j]], 1u << bin);
+              atomicAdd(&s_hist[bin], 1);
+            }
+          }
+        if (nm) atomicAdd(&s_nm, nm);
+        __syncthreads();
+        for (int i = tid; i < Nc; i += 1024) assign[k0 + i] = s_asg[i], KB[k0 + i] = s_bins[i];
+        if (ori && tid < kHistoLen && s_hist[tid]) atomicAdd(&F[tid], s_hist[tid]);
+        if (tid == 0 && s_nm) atomicAdd(&F[32], s_nm);
+        break;
+      }
+    }
+    if (tid == 0 && s_overflow == 1) atomicOr(&F[33], 1);
+  }
+  if (tid == 0 && !settled) atomicOr(&F[34], 1);
+  // ---- the frame's last workgroup finishes what spans the cameras
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (A.n_cams > 1) {  // (one camera: this workgroup is the frame's only one -- its own stores are visible to it)
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int old = __hip_atomic_fetch_add(&F[35], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == A.n_cams - 1;
+      if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+  }
+  if (tid < kHistoLen) s_hist[tid] = __hip_atomic_load(&F[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    s_nm = __hip_atomic_load(&F[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_overflow = __hip_atomic_load(&F[33], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_fill = __hip_atomic_load(&F[34], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  int nmatches = s_nm;
+  if (ori && !s_fill) {  // ComputeThreeMaxima (ORBmatcher.cc:1608-1641), evaluated redundantly by every thread
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < kHistoLen; i++) {
+      const int sv = s_hist[i];
+      if (sv > max1) {
+        max3 = max2, max2 = max1, max1 = sv;
+        ind3 = ind2, ind2 = ind1, ind1 = i;
+      } else if (sv > max2) {
+        max3 = max2, max2 = sv;
+        ind3 = ind2, ind2 = i;
+      } else if (sv > max3) {
+        max3 = sv, ind3 = i;
+      }
+    }
+    if (max2 < 0.1f * (float)max1) {
+      ind2 = -1, ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+      ind3 = -1;
+    }
+    unsigned losers = (1u << kHistoLen) - 1u;
+    if (ind1 >= 0) losers &= ~(1u << ind1);
+    if (ind2 >= 0) losers &= ~(1u << ind2);
+    if (ind3 >= 0) losers &= ~(1u << ind3);
+    for (int i = 0; i < kHistoLen; i++)
+      if (i != ind1 && i != ind2 && i != ind3) nmatches -= s_hist[i];
+    int kend;
+    {
+      int kb;
+      cam_range(A, f, A.n_cams - 1, &kb, &kend);
+    }
+    for (int k = tid; k < kend; k += 1024)
+      if (KB[k] & losers) assign[k] = VIEO_SBP_ERASED;
+  }
+  if (tid == 0) {
+    A.nmatches[f] = s_overflow ? -1 : nmatches;
+    A.need_seq[f] = s_fill ? 1 : 0;
+  }
+  if (tid < kFinStride) F[tid] = 0;  // (the next launch on this stream finds it clear)
 }
 
 // one wave per frame: the frame's candidate pool is copied to LDS once, after that the replay of
@@ -1078,7 +1328,7 @@ k_fuse_search(const FuseDev* __restrict__ fd, int cami, const int* __restrict__ 
 }
 
 struct SbpScratch {
-  DevBuf pool, cursor, qrec, q, nq, keys, ur, desc, taken, counts, assign, nm, pts, cam, cell_start, cell_rec, cell_ang, claim, need;
+  DevBuf pool, cursor, qrec, q, nq, keys, ur, desc, taken, counts, assign, nm, pts, cam, cell_start, cell_rec, cell_ang, claim, need, fin, kbins;
 };
 static thread_local SbpScratch g_sbp;
 static thread_local struct {
@@ -1159,7 +1409,25 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
     // launch asks for the one fixed ceiling, so concurrent tracker threads with different key_cap cannot lower each other's)
     if (lds_par > 64 * 1024)
       VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_sbp_assign_par, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    hipLaunchKernelGGL(k_sbp_assign_par, dim3(n_frames), dim3(1024), lds_par, st, P);
+    // rigs, and the few frames of a tracking call: a workgroup per (frame, camera) with the camera's lists in LDS and
+    // rounds flat over the candidate pairs (k_sbp_assign_cam: all of a CU's LDS).  Large batches of one-camera frames
+    // keep the thread-per-query form, three frames per CU.  VIEO_SBP_FLAT=0 / 1 forces one or the other (tests, A/B).
+    const char* e_flat = getenv("VIEO_SBP_FLAT");
+    const bool flat = e_flat ? atoi(e_flat) != 0 : (P.n_cams > 1 || n_frames <= 16);
+    if (flat) {
+      const int cam_cap = (((A.key_cap + A.n_cams - 1) / A.n_cams) + 3) & ~3;
+      const size_t state = (size_t)cam_cap * 13 + (size_t)kCamQ * 12;  // per key | per query of the camera
+      P.pool_lds = (int)(std::min<size_t>((size_t)P.pool_cap, (150 * 1024 - state - 64) / 6) & ~(size_t)1);  // pairs: 6 bytes
+      const size_t lds_cam = (size_t)P.pool_lds * 6 + state;
+      const void* fin_was = S.fin.p;
+      if ((rc = S.fin.ensure((size_t)n_frames * kFinStride * 4)) != VIEO_OK) return rc;
+      if ((rc = S.kbins.ensure((size_t)n_frames * A.key_cap * 4)) != VIEO_OK) return rc;
+      if (S.fin.p != fin_was) VIEO_HIP_CHECK(hipMemsetAsync(S.fin.p, 0, S.fin.cap, st));  // (the kernel leaves it clear)
+      VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_sbp_assign_cam, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      hipLaunchKernelGGL(k_sbp_assign_cam, dim3(n_frames, P.n_cams), dim3(1024), lds_cam, st, P, cam_cap, S.fin.as<int>(),
+                         S.kbins.as<unsigned>());
+    } else
+      hipLaunchKernelGGL(k_sbp_assign_par, dim3(n_frames), dim3(1024), lds_par, st, P);
   }
   hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), lds, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
