@@ -689,18 +689,8 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
   const bool reloc = A.mode == VIEO_SBP_RELOC;
   // best / second of query q when key k is blocked iff it was taken at the start or mn[k] < q; returns the claimed
   // key (-1: no match) and the winner's candidate word
-  // A thread's queries are tid, tid + 1024, ...: the first kQPer of them keep their record and their claim in registers
-  // (a round then touches LDS only: read from HBM every round, they were two dependent round trips per round)
-  constexpr int kQPer = 8;
-  int2 rq[kQPer];
-  int cl[kQPer];
-#pragma unroll
-  for (int j = 0; j < kQPer; j++) {
-    const int q = tid + 1024 * j;
-    rq[j] = q < nq ? qrec[q] : make_int2(0, 0);
-    cl[j] = -1;
-  }
-  auto eval = [&](int q, const int2 r, const int* mn, unsigned* word, int* blocker) -> int {
+  auto eval = [&](int q, const int* mn, unsigned* word, int* blocker) -> int {
+    const int2 r = qrec[q];
     const int off = r.x, ny = r.y;
     if (ny == 0) return -1;
     if (ny < 0) {
@@ -709,31 +699,15 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
     }
     const int n = ny & 0xFFFF;
     unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu, c0 = 0, c1 = 0;
-    // eight candidates at a time, each of the three reads issued for all eight before any is used (see k_sbp_assign_cam)
-    for (int p0 = 0; p0 < n; p0 += 8) {
-      unsigned cw[8];
-      int tk[8], mq[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int at = off + min(p0 + u, n - 1);
-        cw[u] = at < n_lds ? s_pool[at] : pool[at];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int idx = cw[u] & 0x1FFF;
-        tk[u] = s_taken[idx], mq[u] = mn[idx];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int pos = p0 + u;
-        if (pos < n && !(tk[u] || mq[u] < q)) {
-          const unsigned c = cw[u], key = (((c >> 13) & 0x1FFu) << 8) | (unsigned)pos;  // (dist, order)
-          if (key < b0)
-            b1 = b0, c1 = c0, b0 = key, c0 = c;
-          else if (key < b1)
-            b1 = key, c1 = c;
-        }
-      }
+    for (int pos = 0; pos < n; pos++) {
+      const unsigned c = off + pos < n_lds ? s_pool[off + pos] : pool[off + pos];
+      const int idx = c & 0x1FFF;
+      if (s_taken[idx] || mn[idx] < q) continue;
+      const unsigned key = (((c >> 13) & 0x1FFu) << 8) | (unsigned)pos;  // (dist, order)
+      if (key < b0)
+        b1 = b0, c1 = c0, b0 = key, c0 = c;
+      else if (key < b1)
+        b1 = key, c1 = c;
     }
     if (b0 == 0xFFFFFFFFu) return -1;
     const int bestDist = b0 >> 8, bestLevel = (c0 >> 22) & 15;
@@ -751,21 +725,10 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
     int* prev = (round & 1) ? s_min1 : s_min0;
     int* cur = (round & 1) ? s_min0 : s_min1;
     int changed = 0;
-#pragma unroll
-    for (int j = 0; j < kQPer; j++) {
-      const int q = tid + 1024 * j;
-      if (q < nq) {
-        unsigned w;
-        int blk = 0;
-        const int k = eval(q, rq[j], prev, &w, &blk);
-        if (k != cl[j]) cl[j] = k, changed = 1;
-        if (k >= 0 && blk) atomicMin(&cur[k], q);
-      }
-    }
-    for (int q = tid + 1024 * kQPer; q < nq; q += 1024) {  // (more than 8192 queries: the rest through memory)
+    for (int q = tid; q < nq; q += 1024) {
       unsigned w;
       int blk = 0;
-      const int k = eval(q, qrec[q], prev, &w, &blk);
+      const int k = eval(q, prev, &w, &blk);
       if (k != claim[q]) claim[q] = k, changed = 1;
       if (k >= 0 && blk) atomicMin(&cur[k], q);
     }
@@ -783,11 +746,12 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
       for (int i = tid; i < N; i += 1024) s_asg[i] = -1;
       __syncthreads();
       int nm = 0;
-      auto accept = [&](int q, const int2 r, int k) {
-        if (k < 0) return;
+      for (int q = tid; q < nq; q += 1024) {
+        const int k = claim[q];
+        if (k < 0) continue;
         unsigned w = 0;
         int blk = 0;
-        (void)eval(q, r, cur, &w, &blk);  // the winner's word again (rotation bin)
+        (void)eval(q, cur, &w, &blk);  // the winner's word again (rotation bin)
         atomicMax(&s_asg[k], q);
         nm++;
         if (ori) {
@@ -795,13 +759,7 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
           atomicOr(&s_bins[k], 1u << bin);
           atomicAdd(&s_hist[bin], 1);
         }
-      };
-#pragma unroll
-      for (int j = 0; j < kQPer; j++) {
-        const int q = tid + 1024 * j;
-        if (q < nq) accept(q, rq[j], cl[j]);
       }
-      for (int q = tid + 1024 * kQPer; q < nq; q += 1024) accept(q, qrec[q], claim[q]);
       if (nm) atomicAdd(&s_nm, nm);
       __syncthreads();
       int nmatches = s_nm;
