@@ -1371,10 +1371,11 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
     // rounds flat over the candidate pairs (k_sbp_assign_cam: all of a CU's LDS).  Large batches of one-camera frames
     // keep the thread-per-query form, three frames per CU.  VIEO_SBP_FLAT=0 / 1 forces one or the other (tests, A/B).
     const char* e_flat = getenv("VIEO_SBP_FLAT");
-    const bool flat = e_flat ? atoi(e_flat) != 0 : (P.n_cams > 1 || n_frames <= 16);
+    const int cam_cap = (((A.key_cap + A.n_cams - 1) / A.n_cams) + 3) & ~3;
+    const size_t state = (size_t)cam_cap * 13 + (size_t)kCamQ * 12;  // per key | per query of the camera
+    // (a camera of more than ~6 000 keys leaves no room for its lists beside its state: the thread-per-query form)
+    const bool flat = (e_flat ? atoi(e_flat) != 0 : (P.n_cams > 1 || n_frames <= 16)) && state + 64 + 6 * 4096 <= 150 * 1024;
     if (flat) {
-      const int cam_cap = (((A.key_cap + A.n_cams - 1) / A.n_cams) + 3) & ~3;
-      const size_t state = (size_t)cam_cap * 13 + (size_t)kCamQ * 12;  // per key | per query of the camera
       P.pool_lds = (int)(std::min<size_t>((size_t)P.pool_cap, (150 * 1024 - state - 64) / 6) & ~(size_t)1);  // pairs: 6 bytes
       const size_t lds_cam = (size_t)P.pool_lds * 6 + state;
       const void* fin_was = S.fin.p;
