@@ -267,6 +267,32 @@ def test_gpu_sbp_assignment_dependency_chains(oracle, mode, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gpu_sbp_many_keys_in_one_camera(oracle, monkeypatch):
+    """A one-camera frame with ~7 000 keys: its per-key state alone fills the LDS the flat assignment would need for the
+    candidate lists, so the call takes the thread-per-query form even when the flat one is asked for -- same answer."""
+    kl, dl, ur, pts, cam = _scenario(oracle, 1050, th=7.0)
+    reps = max(2, 7000 // len(kl) + 1)
+    rng = np.random.default_rng(1050)
+    kl2, dl2, ur2 = np.tile(kl, reps), np.tile(dl, (reps, 1)), np.tile(ur, reps)
+    kl2["x"] += rng.uniform(-1.5, 1.5, len(kl2)).astype(np.float32)
+    kl2["y"] += rng.uniform(-1.5, 1.5, len(kl2)).astype(np.float32)
+    flip = rng.integers(0, 256, len(dl2))
+    dl2[np.arange(len(dl2)), flip % 32] ^= (1 << (flip % 8)).astype(np.uint8)
+    assert 6500 < len(kl2) <= 8192
+    q = oracle.sbp_project_last_frame(pts, cam)
+    on, oa = oracle.search_by_projection(0, q, kl2, ur2, dl2, None, BOUNDS, nn_ratio=0.9)
+    assert on > 100
+    m = _hip_matcher(0.9)
+    for env in ({}, {"VIEO_SBP_FLAT": "1"}, {"VIEO_SBP_FLAT": "0"}):
+        monkeypatch.delenv("VIEO_SBP_FLAT", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hn, ha = m.SearchByProjectionLastFrame(q, kl2, ur2, dl2, None, BOUNDS)
+        assert hn == on and np.array_equal(ha, oa), env
+    monkeypatch.delenv("VIEO_SBP_FLAT", raising=False)
+
+
+@pytest.mark.gpu
 def test_gpu_sbp_more_wide_windows_than_a_block_lists(oracle, monkeypatch):
     """k_sbp_candidates leaves wide / crowded windows to a second pass through a per-block list of 1024 entries; a frame
     with more of them than the eight blocks can list (relocalisation-size windows, rig local maps with p_cap * n_cams
