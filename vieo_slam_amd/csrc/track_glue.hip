@@ -42,7 +42,7 @@ k_track_merge_assign(const int* __restrict__ assign, int* __restrict__ mp_ref,
 }
 
 // one workgroup per frame: compact the held points into observations, in keypoint order
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ point_xyz, int p_cap,
                   const vieo_keypoint* __restrict__ keys, const float* __restrict__ uright,
                   const int* __restrict__ counts, int key_cap, int img_first, int img_step,
@@ -50,52 +50,56 @@ k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ poin
                   vieo_pose_obs* __restrict__ obs, int* __restrict__ obs_key, uint8_t* frames_base,
                   size_t frame_stride, size_t nobs_offset, size_t obsbegin_offset,
                   const int* __restrict__ cam_first, int n_cams) {
-  __shared__ int s_wsum[4];
-  __shared__ int s_base;
+  __shared__ int s_wsum[16];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int img = img_first + f * img_step;
   const int N = min(counts[2 * img], key_cap);
   const int* m = mp_ref + (size_t)f * key_cap;
   const vieo_keypoint* K = keys + (size_t)img * key_cap;
   const float* ur = uright + (size_t)f * key_cap;
-  if (tid == 0) s_base = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < N; i0 += 256) {
-    const int i = i0 + tid;
-    const bool has = i < N && m[i] >= 0;
-    const unsigned long long bal = __ballot(has);
-    if (lane == 0) s_wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int off = s_base;
-    for (int w = 0; w < wave; w++) off += s_wsum[w];
-    if (has) {
-      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-      const float* X = point_xyz + ((size_t)f * p_cap + m[i]) * 3;
-      vieo_pose_obs o;
-      o.Xw[0] = X[0], o.Xw[1] = X[1], o.Xw[2] = X[2];
-      const vieo_keypoint k = K[i];
-      o.u = k.x, o.v = k.y, o.ur = ur[i];
-      o.inv_sigma2 = inv_sigma2[k.octave];
-      // bit 0: the point was tracked at less than close_depth (the stereo chi2 gate of the visual-inertial
-      // PoseOptimization, Optimizer.h:406-490 / mTrackDepth)
-      o.flags = point_depth ? (point_depth[(size_t)f * p_cap + m[i]] < close_depth ? 1 : 0) : 0;
-      if (cam_first) {  // bits 8..11: the key's camera (mapn2in_, Optimizer.h:424-426)
-        const int* cf = cam_first + (size_t)f * (n_cams + 1);
-        int c = 0;
-        for (int t = 1; t < n_cams; t++)
-          if (i >= cf[t]) c = t;
-        o.flags |= c << 8;
-      }
-      obs[(size_t)f * key_cap + pos] = o;
-      obs_key[(size_t)f * key_cap + pos] = i;
-    }
-    __syncthreads();
-    if (tid == 0) s_base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    __syncthreads();
+  // A thread owns E consecutive keys, so the order of the edges is the order of the keys with ONE scan over the
+  // workgroup: count, scan, write.  (1024 threads for a rig frame's thousands of keys, 256 otherwise.  Chunk after chunk of 256 keys -- a dependent load, three barriers each -- took 30 us
+  // for the 6 000 keys of a 4-camera frame.)
+  const int nt = (int)blockDim.x, E = (N + nt - 1) / nt, i_lo = tid * E, i_hi = min(i_lo + E, N);
+  int cnt = 0;
+#pragma unroll 8
+  for (int i = i_lo; i < i_hi; i++) cnt += m[i] >= 0 ? 1 : 0;
+  int inc = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
   }
-  if (tid == 0) {
+  if (lane == 63) s_wsum[wave] = inc;
+  __syncthreads();
+  int pos = inc - cnt;
+  for (int w = 0; w < wave; w++) pos += s_wsum[w];
+  const int* cf = cam_first ? cam_first + (size_t)f * (n_cams + 1) : nullptr;
+#pragma unroll 4
+  for (int i = i_lo; i < i_hi; i++) {
+    const int mi = m[i];
+    if (mi < 0) continue;
+    const float* X = point_xyz + ((size_t)f * p_cap + mi) * 3;
+    vieo_pose_obs o;
+    o.Xw[0] = X[0], o.Xw[1] = X[1], o.Xw[2] = X[2];
+    const vieo_keypoint k = K[i];
+    o.u = k.x, o.v = k.y, o.ur = ur[i];
+    o.inv_sigma2 = inv_sigma2[k.octave];
+    // bit 0: the point was tracked at less than close_depth (the stereo chi2 gate of the visual-inertial
+    // PoseOptimization, Optimizer.h:406-490 / mTrackDepth)
+    o.flags = point_depth ? (point_depth[(size_t)f * p_cap + mi] < close_depth ? 1 : 0) : 0;
+    if (cf) {  // bits 8..11: the key's camera (mapn2in_, Optimizer.h:424-426)
+      int c = 0;
+      for (int t = 1; t < n_cams; t++)
+        if (i >= cf[t]) c = t;
+      o.flags |= c << 8;
+    }
+    obs[(size_t)f * key_cap + pos] = o;
+    obs_key[(size_t)f * key_cap + pos] = i;
+    pos++;
+  }
+  if (tid == nt - 1) {  // (pos: all edges of the frame)
     uint8_t* fr = frames_base + (size_t)f * frame_stride;
-    *(int*)(fr + nobs_offset) = s_base;
+    *(int*)(fr + nobs_offset) = pos;
     *(int*)(fr + obsbegin_offset) = f * key_cap;
   }
 }
@@ -256,7 +260,7 @@ int vieo_track_build_obs_batch_device(const int32_t* d_mp_ref, const float* d_po
     return VIEO_E_INVALID;
   const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
   const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
-  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, d_mp_ref,
                      d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
                      d_inv_sigma2, (const float*)nullptr, 0.f, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
                      base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
@@ -277,7 +281,7 @@ int vieo_track_build_obs_depth_batch_device(const int32_t* d_mp_ref, const float
     return VIEO_E_INVALID;
   const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
   const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
-  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, d_mp_ref,
                      d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
                      d_inv_sigma2, d_point_depth, close_depth, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
                      base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
@@ -297,7 +301,7 @@ int vieo_track_build_obs_rig_batch_device(const int32_t* d_mp_ref, const float* 
     return VIEO_E_INVALID;
   const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
   const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
-  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref,
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, d_mp_ref,
                      d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, 0, 1,
                      d_inv_sigma2, d_point_depth, close_depth, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
                      base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
