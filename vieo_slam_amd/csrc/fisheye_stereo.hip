@@ -139,6 +139,68 @@ __device__ bool triangulate_matches(const FeRig& R, const int* ci, const float (
   return true;
 }
 
+// The same for a run-time number of cameras n <= 4 (the groups of one wavefront have 2, 3 and 4 members: three
+// instances of the template one after the other were the kernel's time).  The system is padded to 8 rows with zeros,
+// which changes no bit: the Jacobi sums gain terms + 0 * 0 and a rotation leaves a zero row zero.
+__device__ bool triangulate_matches_n(const FeRig& R, int n, const int* ci, const float (*kp)[2], const float* sig,
+                                      bool* gate, double* p3d, float* czs) {
+  double nP[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    nP[i][0] = nP[i][1] = nP[i][2] = 0;
+    if (i < n) cam_unproject(R.cam[ci[i]], kp[i][0], kp[i][1], nP[i]);
+  }
+  bool all_above[2] = {true, true};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i + 1; j < 4; ++j)
+      if (j < n) {
+        const double* Ri = R.Rrc[ci[i]];
+        const double* Rj = R.Rrc[ci[j]];
+        double w[3], v[3];
+        for (int r = 0; r < 3; ++r) w[r] = Rj[r * 3] * nP[j][0] + Rj[r * 3 + 1] * nP[j][1] + Rj[r * 3 + 2] * nP[j][2];
+        for (int r = 0; r < 3; ++r) v[r] = Ri[r] * w[0] + Ri[3 + r] * w[1] + Ri[6 + r] * w[2];
+        const double dot = nP[i][0] * v[0] + nP[i][1] * v[1] + nP[i][2] * v[2];
+        const double ni = sqrt(nP[i][0] * nP[i][0] + nP[i][1] * nP[i][1] + nP[i][2] * nP[i][2]);
+        const double nj = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        const float cosr = (float)(dot / (ni * nj));
+        if (cosr <= R.th[0]) all_above[0] = false;
+        if (cosr <= R.th[1]) all_above[1] = false;
+      }
+  gate[0] = !(R.th[0] < 1.f && all_above[0]);
+  gate[1] = !(R.th[1] < 1.f && all_above[1]);
+  if (!gate[0] && !gate[1]) return false;
+  double A[8][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double* T = R.Tcw[ci[i < n ? i : 0]];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      A[2 * i][c] = i < n ? nP[i][0] * T[8 + c] - T[c] : 0.0;
+      A[2 * i + 1][c] = i < n ? nP[i][1] * T[8 + c] - T[4 + c] : 0.0;
+    }
+  }
+  double x4[4];
+  null_vector4<8>(A, x4);
+  if (!x4[3]) return false;
+  const double X[3] = {x4[0] / x4[3], x4[1] / x4[3], x4[2] / x4[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < n) {
+      const double* T = R.Tcw[ci[i]];
+      czs[i] = (float)(T[8] * X[0] + T[9] * X[1] + T[10] * X[2] + T[11]);
+      if (czs[i] <= 0) return false;
+      double Pc[3], uv[2];
+      for (int r = 0; r < 3; ++r) Pc[r] = (T[r * 4] * X[0] + T[r * 4 + 1] * X[1] + T[r * 4 + 2] * X[2]) + T[r * 4 + 3];
+      cam_project(R.cam[ci[i]], Pc, uv, nullptr);
+      const float e0 = (float)uv[0] - kp[i][0], e1 = (float)uv[1] - kp[i][1];
+      if (e0 * e0 + e1 * e1 > 5.991f * sig[i]) return false;
+    }
+  p3d[0] = X[0], p3d[1] = X[1], p3d[2] = X[2];
+  return true;
+}
+
 struct FePairRec {  // verdict of one knn row
   int32_t idxj;     // absolute key index in camera j, -1: ratio test failed / fewer than two neighbours
   float dist;
@@ -487,12 +549,7 @@ k_fe_groups(FeBatch B) {
   }
   double X[3] = {0, 0, 0};
   bool gate[2] = {false, false}, ok = false;
-  if (n == 2)
-    ok = triangulate_matches<2>(*B.rig, ci, kp, sig, gate, X, czs);
-  else if (n == 3)
-    ok = triangulate_matches<3>(*B.rig, ci, kp, sig, gate, X, czs);
-  else if (n == 4)
-    ok = triangulate_matches<4>(*B.rig, ci, kp, sig, gate, X, czs);
+  if (n >= 2 && n <= 4) ok = triangulate_matches_n(*B.rig, n, ci, kp, sig, gate, X, czs);
   ok = ok && gate[which];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
