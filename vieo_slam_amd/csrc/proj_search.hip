@@ -326,7 +326,7 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int* total) {
 // the CSR, so a window is nx contiguous runs of records, already in the reference's order (ix outer,
 // iy inner, key index inside a cell) -- no sort.
 static const int kSbpBlocks = 8;      // workgroups per frame of a batch
-static const int kSbpBlocksFew = 32;  // ... of a call with a frame or two (the one-call tracker): latency, not occupancy
+static const int kSbpBlocksFew = 128; // ... of a call with a frame or two (the one-call tracker): latency, not occupancy
 
 __global__ void __launch_bounds__(256) k_sbp_candidates(SbpArgs A) {
   extern __shared__ unsigned short s_cs[];  // [n_cams][kGridCells + 1] camera-local offsets (< kMaxKeys: 16 bits)
