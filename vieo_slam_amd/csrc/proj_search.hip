@@ -253,18 +253,17 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
   const int per = kGridCells / 256, c0 = tid * per;  // 3072 = 256 * 12
   int sum = 0;
   for (int c = c0; c < c0 + per; c++) sum += s_cnt[c];
-  s_part[tid] = sum;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int t = 0; t < 256; t++) {
-      const int v = s_part[t];
-      s_part[t] = acc;
-      acc += v;
-    }
+  // exclusive scan of the 256 partial sums: within the wavefronts, then over the four of them (one thread walking the
+  // 256 values was 256 dependent LDS round trips, ~10 us of this kernel's 23)
+  int inc = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if ((tid & 63) >= o) inc += t;
   }
+  if ((tid & 63) == 63) s_part[tid >> 6] = inc;
   __syncthreads();
-  int acc = s_part[tid];
+  int acc = inc - sum;
+  for (int w = 0; w < (tid >> 6); w++) acc += s_part[w];
   int* cs = cell_start + (size_t)blockIdx.x * (kGridCells + 1);
   for (int c = c0; c < c0 + per; c++) {
     const int v = s_cnt[c];
