@@ -228,13 +228,14 @@ __device__ __forceinline__ void cam_range(const SbpArgs& A, int f, int cam, int*
   }
 }
 
-__global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ cell_start,
+__global__ void __launch_bounds__(1024) k_sbp_grid(SbpArgs A, int* __restrict__ cell_start,
                                                   float4* __restrict__ cell_rec,
                                                   float* __restrict__ cell_ang) {
   __shared__ int s_cnt[kGridCells + 1];
   __shared__ int s_cur[kGridCells];
   __shared__ unsigned short s_list[kMaxKeys];
-  __shared__ int s_part[256];
+  __shared__ int s_part[16];
+  constexpr int NT = 1024;  // (256 until round 4: five dependent trips to the keys per pass)
   const int f = blockIdx.x / A.n_cams, cam = blockIdx.x - f * A.n_cams, tid = threadIdx.x;
   const int img = A.img_first + f * A.img_step;
   int k0, k1;
@@ -243,17 +244,17 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
   const vieo_keypoint* K = A.keys + (size_t)img * A.key_cap + k0;
   const float minx = A.bounds[cam][0], miny = A.bounds[cam][2];
   const float winv = (float)kGridCols / (A.bounds[cam][1] - minx), hinv = (float)kGridRows / (A.bounds[cam][3] - miny);
-  for (int c = tid; c <= kGridCells; c += 256) s_cnt[c] = 0;
+  for (int c = tid; c <= kGridCells; c += NT) s_cnt[c] = 0;
   __syncthreads();
-  for (int j = tid; j < N; j += 256) {
+  for (int j = tid; j < N; j += NT) {
     const int posX = (int)roundf((K[j].x - minx) * winv), posY = (int)roundf((K[j].y - miny) * hinv);
     if (posX >= 0 && posX < kGridCols && posY >= 0 && posY < kGridRows) atomicAdd(&s_cnt[posX * kGridRows + posY], 1);
   }
   __syncthreads();
-  const int per = kGridCells / 256, c0 = tid * per;  // 3072 = 256 * 12
+  const int per = kGridCells / NT, c0 = tid * per;  // 3072 = 1024 * 3
   int sum = 0;
   for (int c = c0; c < c0 + per; c++) sum += s_cnt[c];
-  // exclusive scan of the 256 partial sums: within the wavefronts, then over the four of them (one thread walking the
+  // exclusive scan of the partial sums: within the wavefronts, then over the four of them (one thread walking the
   // 256 values was 256 dependent LDS round trips, ~10 us of this kernel's 23)
   int inc = sum;
   for (int o = 1; o < 64; o <<= 1) {
@@ -270,12 +271,12 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
     cs[c] = acc, s_cur[c] = acc;
     acc += v;
   }
-  if (tid == 255) {
+  if (tid == NT - 1) {
     cs[kGridCells] = acc;
     if (cam == 0) A.cursor[f] = 0;
   }
   __syncthreads();
-  for (int j = tid; j < N; j += 256) {
+  for (int j = tid; j < N; j += NT) {
     const int posX = (int)roundf((K[j].x - minx) * winv), posY = (int)roundf((K[j].y - miny) * hinv);
     if (posX >= 0 && posX < kGridCols && posY >= 0 && posY < kGridRows)
       s_list[atomicAdd(&s_cur[posX * kGridRows + posY], 1)] = (unsigned short)j;
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(256) k_sbp_grid(SbpArgs A, int* __restrict__ c
   const float* uright = A.uright + (size_t)f * A.key_cap + k0;
   float4* rec = cell_rec + (size_t)f * A.key_cap + k0;
   float* ang = cell_ang + (size_t)f * A.key_cap + k0;
-  for (int i = tid; i < n_in; i += 256) {
+  for (int i = tid; i < n_in; i += NT) {
     const int j = s_list[i];
     const vieo_keypoint k = K[j];
     rec[i] = make_float4(k.x, k.y, uright[j], __int_as_float((j + k0) | (k.octave << 16)));
@@ -1336,7 +1337,7 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
                     g_grid.rec == S.cell_rec.p;
   g_grid_keep = false;
   if (!same)
-    hipLaunchKernelGGL(k_sbp_grid, dim3(n_frames * A.n_cams), dim3(256), 0, st, A, S.cell_start.as<int>(),
+    hipLaunchKernelGGL(k_sbp_grid, dim3(n_frames * A.n_cams), dim3(1024), 0, st, A, S.cell_start.as<int>(),
                        S.cell_rec.as<float4>(), S.cell_ang.as<float>());
   g_grid.valid = true, g_grid.keys = A.keys, g_grid.ur = A.uright;
   g_grid.counts = A.cam_first ? (const void*)A.cam_first : (const void*)A.counts;
@@ -1668,7 +1669,7 @@ int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const*
     A.n_cams = 1;
     for (int q = 0; q < 4; ++q) A.bounds[0][q] = F.bounds[c][q];
     A.cursor = S.cursor.as<int>();
-    hipLaunchKernelGGL(k_sbp_grid, dim3(1), dim3(256), 0, 0, A, S.cell_start.as<int>(), S.cell_rec.as<float4>(),
+    hipLaunchKernelGGL(k_sbp_grid, dim3(1), dim3(1024), 0, 0, A, S.cell_start.as<int>(), S.cell_rec.as<float4>(),
                        S.cell_ang.as<float>());
     hipLaunchKernelGGL(k_fuse_search, dim3((n_points + 3) / 4), dim3(256), 0, 0, dF.as<FuseDev>(), c,
                        S.cell_start.as<int>(), S.cell_rec.as<float4>(), S.desc.as<uint8_t>(),
