@@ -149,49 +149,47 @@ __device__ __forceinline__ int wave_sum_i(int v) { return wave_sum_i32(v); }
 // [floor(y - r), ceil(y + r)], r = 2 * scale(octave), covers it.  One workgroup per frame: LDS
 // histogram, prefix sum, fill.  The order inside a row is irrelevant: the best match is the
 // minimum of (distance, index).
-__global__ void __launch_bounds__(256) k_stereo_rows(StereoArgs A) {
+__global__ void __launch_bounds__(1024) k_stereo_rows(StereoArgs A) {
+  constexpr int NT = 1024;  // (256 until round 4: five dependent trips to the keys per pass, one thread scanning)
   extern __shared__ int s_rows[];  // cnt[H + 1], then fill cursor[H]
-  __shared__ int s_part[256];
+  __shared__ int s_part[16];
   const int f = blockIdx.x, tid = threadIdx.x, H = A.H;
   int* cnt = s_rows;
   int* cur = s_rows + H + 1;
   const int imR = A.r_first + f * A.r_step;
   const int Nr = min(A.cntR[2 * imR], A.capR);
   const vieo_keypoint* KR = A.kpR + (size_t)imR * A.capR;
-  for (int y = tid; y <= H; y += 256) cnt[y] = 0;
+  for (int y = tid; y <= H; y += NT) cnt[y] = 0;
   __syncthreads();
-  for (int j = tid; j < Nr; j += 256) {
+  for (int j = tid; j < Nr; j += NT) {
     const float y = KR[j].y, r = 2.0f * A.P.lv[KR[j].octave].scale;
     const int maxr = min((int)ceilf(y + r), H - 1), minr = max((int)floorf(y - r), 0);
     for (int yi = minr; yi <= maxr; yi++) atomicAdd(&cnt[yi], 1);
   }
   __syncthreads();
   // exclusive prefix sum of cnt[0..H)
-  const int per = (H + 255) / 256, y0 = tid * per, y1 = min(H, y0 + per);
+  const int per = (H + NT - 1) / NT, y0 = min(H, tid * per), y1 = min(H, y0 + per);
   int sum = 0;
   for (int y = y0; y < y1; y++) sum += cnt[y];
-  s_part[tid] = sum;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int t = 0; t < 256; t++) {
-      const int v = s_part[t];
-      s_part[t] = acc;
-      acc += v;
-    }
+  int inc = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if ((tid & 63) >= o) inc += t;
   }
+  if ((tid & 63) == 63) s_part[tid >> 6] = inc;
   __syncthreads();
-  int acc = s_part[tid];
+  int acc = inc - sum;
+  for (int w = 0; w < (tid >> 6); w++) acc += s_part[w];
   int* rs = A.row_start + (size_t)f * (H + 1);
   for (int y = y0; y < y1; y++) {
     const int v = cnt[y];
     rs[y] = acc, cur[y] = acc;
     acc += v;
   }
-  if (y1 == H && y0 < H) rs[H] = acc;
+  if (tid == NT - 1) rs[H] = acc;  // (the running sum of the last thread: everything)
   __syncthreads();
   int2* list = A.row_list + (size_t)f * A.list_cap;
-  for (int j = tid; j < Nr; j += 256) {
+  for (int j = tid; j < Nr; j += NT) {
     const vieo_keypoint kj = KR[j];
     const float y = kj.y, r = 2.0f * A.P.lv[kj.octave].scale;
     const int maxr = min((int)ceilf(y + r), H - 1), minr = max((int)floorf(y - r), 0);
@@ -442,7 +440,7 @@ static int launch_stereo(StereoArgs A, int n_frames, hipStream_t st) {
   if ((rc = g_row_start.ensure((size_t)n_frames * (A.H + 1) * 4)) != VIEO_OK) return rc;
   if ((rc = g_row_list.ensure((size_t)n_frames * A.list_cap * 8)) != VIEO_OK) return rc;
   A.row_start = g_row_start.as<int>(), A.row_list = g_row_list.as<int2>();
-  hipLaunchKernelGGL(k_stereo_rows, dim3(n_frames), dim3(256), (size_t)(2 * A.H + 1) * 4, st, A);
+  hipLaunchKernelGGL(k_stereo_rows, dim3(n_frames), dim3(1024), (size_t)(2 * A.H + 1) * 4, st, A);
   hipLaunchKernelGGL(k_stereo_rect, dim3((A.capL + 15) / 16, n_frames), dim3(256), 0, st, A);
   hipLaunchKernelGGL(k_stereo_median, dim3(n_frames), dim3(256), 0, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
