@@ -149,8 +149,9 @@ __device__ __forceinline__ int wave_sum_i(int v) { return wave_sum_i32(v); }
 // [floor(y - r), ceil(y + r)], r = 2 * scale(octave), covers it.  One workgroup per frame: LDS
 // histogram, prefix sum, fill.  The order inside a row is irrelevant: the best match is the
 // minimum of (distance, index).
-__global__ void __launch_bounds__(1024) k_stereo_rows(StereoArgs A) {
-  constexpr int NT = 1024;  // (256 until round 4: five dependent trips to the keys per pass, one thread scanning)
+// NT threads: 1024 for a call of a few frames (one or two trips to the keys per pass instead of five), 256 for batches
+template <int NT>
+__global__ void __launch_bounds__(NT) k_stereo_rows(StereoArgs A) {
   extern __shared__ int s_rows[];  // cnt[H + 1], then fill cursor[H]
   __shared__ int s_part[16];
   const int f = blockIdx.x, tid = threadIdx.x, H = A.H;
@@ -440,7 +441,10 @@ static int launch_stereo(StereoArgs A, int n_frames, hipStream_t st) {
   if ((rc = g_row_start.ensure((size_t)n_frames * (A.H + 1) * 4)) != VIEO_OK) return rc;
   if ((rc = g_row_list.ensure((size_t)n_frames * A.list_cap * 8)) != VIEO_OK) return rc;
   A.row_start = g_row_start.as<int>(), A.row_list = g_row_list.as<int2>();
-  hipLaunchKernelGGL(k_stereo_rows, dim3(n_frames), dim3(1024), (size_t)(2 * A.H + 1) * 4, st, A);
+  if (n_frames <= 16)
+    hipLaunchKernelGGL(k_stereo_rows<1024>, dim3(n_frames), dim3(1024), (size_t)(2 * A.H + 1) * 4, st, A);
+  else
+    hipLaunchKernelGGL(k_stereo_rows<256>, dim3(n_frames), dim3(256), (size_t)(2 * A.H + 1) * 4, st, A);
   hipLaunchKernelGGL(k_stereo_rect, dim3((A.capL + 15) / 16, n_frames), dim3(256), 0, st, A);
   hipLaunchKernelGGL(k_stereo_median, dim3(n_frames), dim3(256), 0, st, A);
   VIEO_HIP_CHECK(hipGetLastError());

@@ -468,7 +468,7 @@ k_fast(OrbParams P, ImgSet I, const CellDesc* __restrict__ cells, unsigned* __re
 }
 
 // ------------------------------------------------------------------ quadtree
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_quadtree(OrbParams P, const unsigned* __restrict__ cell_keys,
            const int* __restrict__ cell_counts, unsigned* __restrict__ keys,
            unsigned short* __restrict__ kslot, unsigned char* __restrict__ kq,
@@ -1252,13 +1252,19 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
       *ncap = nc, *scap = std::max(2 * nc, mc);
     };
     int la = 0;
+    // (a few images: latency, a workgroup's passes over its keys on more threads; a batch: four workgroups per CU)
+    static const int qt_env = [] {
+      const char* e = getenv("VIEO_QT_THREADS");
+      return e ? atoi(e) : 0;
+    }();
+    const int qt_threads = qt_env > 0 ? qt_env : (B <= 16 ? 512 : 256);
     for (size_t gi = 0; gi < n_bounds && la < P.nlevels; gi++) {
       const int lb = std::min(bounds[gi], P.nlevels);
       if (lb <= la) continue;
       int nc, sc;
       qt_caps(la, lb, &nc, &sc);
       const size_t lds = (size_t)16 * sc + (4 + 16 + 4 + 4 + 4) * nc + 64 + (2 * 4 + 8 + 2 * 6) * nc + nc + 64;
-      hipLaunchKernelGGL(k_quadtree, dim3(lb - la, B), dim3(256), lds, st, P,
+      hipLaunchKernelGGL(k_quadtree, dim3(lb - la, B), dim3(qt_threads), lds, st, P,
                          e->d_cell_keys.as<unsigned>(), e->d_cell_counts.as<int>(),
                          e->d_keys.as<unsigned>(), e->d_kslot.as<unsigned short>(),
                          e->d_kq.as<unsigned char>(), e->d_sel.as<unsigned>(), e->d_sel_count.as<int>(), nc, sc, la);

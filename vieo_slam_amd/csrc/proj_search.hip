@@ -228,14 +228,15 @@ __device__ __forceinline__ void cam_range(const SbpArgs& A, int f, int cam, int*
   }
 }
 
-__global__ void __launch_bounds__(1024) k_sbp_grid(SbpArgs A, int* __restrict__ cell_start,
+// NT threads: 1024 for a call of a few frames, 256 for batches
+template <int NT>
+__global__ void __launch_bounds__(NT) k_sbp_grid(SbpArgs A, int* __restrict__ cell_start,
                                                   float4* __restrict__ cell_rec,
                                                   float* __restrict__ cell_ang) {
   __shared__ int s_cnt[kGridCells + 1];
   __shared__ int s_cur[kGridCells];
   __shared__ unsigned short s_list[kMaxKeys];
   __shared__ int s_part[16];
-  constexpr int NT = 1024;  // (256 until round 4: five dependent trips to the keys per pass)
   const int f = blockIdx.x / A.n_cams, cam = blockIdx.x - f * A.n_cams, tid = threadIdx.x;
   const int img = A.img_first + f * A.img_step;
   int k0, k1;
@@ -1336,9 +1337,14 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
                     g_grid.n_frames == n_frames && g_grid.key_cap == A.key_cap && g_grid.n_cams == A.n_cams && g_grid.st == st &&
                     g_grid.rec == S.cell_rec.p;
   g_grid_keep = false;
-  if (!same)
-    hipLaunchKernelGGL(k_sbp_grid, dim3(n_frames * A.n_cams), dim3(1024), 0, st, A, S.cell_start.as<int>(),
-                       S.cell_rec.as<float4>(), S.cell_ang.as<float>());
+  if (!same) {
+    if (n_frames * A.n_cams <= 16)
+      hipLaunchKernelGGL(k_sbp_grid<1024>, dim3(n_frames * A.n_cams), dim3(1024), 0, st, A, S.cell_start.as<int>(),
+                         S.cell_rec.as<float4>(), S.cell_ang.as<float>());
+    else
+      hipLaunchKernelGGL(k_sbp_grid<256>, dim3(n_frames * A.n_cams), dim3(256), 0, st, A, S.cell_start.as<int>(),
+                         S.cell_rec.as<float4>(), S.cell_ang.as<float>());
+  }
   g_grid.valid = true, g_grid.keys = A.keys, g_grid.ur = A.uright;
   g_grid.counts = A.cam_first ? (const void*)A.cam_first : (const void*)A.counts;
   g_grid.n_frames = n_frames, g_grid.key_cap = A.key_cap, g_grid.n_cams = A.n_cams, g_grid.st = st, g_grid.rec = S.cell_rec.p;
@@ -1669,7 +1675,7 @@ int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const*
     A.n_cams = 1;
     for (int q = 0; q < 4; ++q) A.bounds[0][q] = F.bounds[c][q];
     A.cursor = S.cursor.as<int>();
-    hipLaunchKernelGGL(k_sbp_grid, dim3(1), dim3(1024), 0, 0, A, S.cell_start.as<int>(), S.cell_rec.as<float4>(),
+    hipLaunchKernelGGL(k_sbp_grid<1024>, dim3(1), dim3(1024), 0, 0, A, S.cell_start.as<int>(), S.cell_rec.as<float4>(),
                        S.cell_ang.as<float>());
     hipLaunchKernelGGL(k_fuse_search, dim3((n_points + 3) / 4), dim3(256), 0, 0, dF.as<FuseDev>(), c,
                        S.cell_start.as<int>(), S.cell_rec.as<float4>(), S.desc.as<uint8_t>(),
