@@ -561,7 +561,7 @@ typedef struct vieo_vio_result {
 
 int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_obs* h_obs,
                                uint8_t* h_outlier, vieo_vio_result* h_result);
-/* Rig frames (n_cams > 0) of a call with at most 4 frames -- the one-call tracker's case -- are optimised by 8
+/* Rig frames (n_cams > 0) of a call with at most 4 frames -- the one-call tracker's case -- are optimised by 16
  * workgroups each: replicas that run the same optimisation and share the passes over the visual edges (thousands per
  * rig frame), exchanging partial sums through device memory; a frame below 700 edges is left to one of them.  The
  * result differs from the one-workgroup form only in the association order of those sums (1e-12 relative on the

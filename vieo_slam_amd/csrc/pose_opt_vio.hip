@@ -332,7 +332,7 @@ __device__ unsigned long long g_pose_probe[24];
 // double-buffered by the parity of the exchange (a fast replica may be one exchange ahead, never two: it needs every
 // replica's granule of this exchange before it can leave it).  First form of this exchange -- atomic stores, an arrival
 // counter, polls, atomic loads, three barriers -- cost ~7 us per exchange; this one ~3.
-constexpr int kXG = 8;
+constexpr int kXG = 16;
 typedef unsigned long long xq_t __attribute__((ext_vector_type(2)));
 struct PoseXchg {
   xq_t cell[2][kXG][32];
@@ -341,20 +341,29 @@ __device__ __forceinline__ void xq_store(xq_t* p, xq_t v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 // the kXG replicas' granules of one index (512 bytes apart), all in flight at once
-__device__ __forceinline__ void xq_load8(const xq_t* p, xq_t* v) {
-  static_assert(kXG == 8, "eight loads below");
+__device__ __forceinline__ void xq_load_all(const xq_t* p, xq_t* v) {
+  static_assert(kXG == 16, "sixteen loads below");
+  const xq_t* p2 = p + 32 * 8;  // (the instruction's offset field ends at 4095)
   asm volatile(
-      "global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
-      "global_load_dwordx4 %1, %8, off offset:512 sc0 sc1\n\t"
-      "global_load_dwordx4 %2, %8, off offset:1024 sc0 sc1\n\t"
-      "global_load_dwordx4 %3, %8, off offset:1536 sc0 sc1\n\t"
-      "global_load_dwordx4 %4, %8, off offset:2048 sc0 sc1\n\t"
-      "global_load_dwordx4 %5, %8, off offset:2560 sc0 sc1\n\t"
-      "global_load_dwordx4 %6, %8, off offset:3072 sc0 sc1\n\t"
-      "global_load_dwordx4 %7, %8, off offset:3584 sc0 sc1\n\t"
+      "global_load_dwordx4 %0, %16, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %16, off offset:512 sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %16, off offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %16, off offset:1536 sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %16, off offset:2048 sc0 sc1\n\t"
+      "global_load_dwordx4 %5, %16, off offset:2560 sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %16, off offset:3072 sc0 sc1\n\t"
+      "global_load_dwordx4 %7, %16, off offset:3584 sc0 sc1\n\t"
+      "global_load_dwordx4 %8, %17, off sc0 sc1\n\t"
+      "global_load_dwordx4 %9, %17, off offset:512 sc0 sc1\n\t"
+      "global_load_dwordx4 %10, %17, off offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %11, %17, off offset:1536 sc0 sc1\n\t"
+      "global_load_dwordx4 %12, %17, off offset:2048 sc0 sc1\n\t"
+      "global_load_dwordx4 %13, %17, off offset:2560 sc0 sc1\n\t"
+      "global_load_dwordx4 %14, %17, off offset:3072 sc0 sc1\n\t"
+      "global_load_dwordx4 %15, %17, off offset:3584 sc0 sc1\n\t"
       "s_waitcnt vmcnt(0)"
-      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-      : "v"(p)
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+      : "v"(p), "v"(p2)
       : "memory");
 }
 template <int BS, bool MC, bool ENC>
@@ -523,7 +532,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       xq_t in[kXG];
       int spins = 0;
       for (;;) {
-        xq_load8(cells, in);
+        xq_load_all(cells, in);
         bool all = true;
 #pragma unroll
         for (int q = 0; q < kXG; q++) all = all && in[q].y == tag;
