@@ -214,6 +214,18 @@ int vieo_stereo_fisheye_match_batch_device(vieo_fisheye* h, const vieo_keypoint*
                                            uint8_t* d_desc_cat, int32_t* d_cam_first, int32_t* d_frame_counts,
                                            float* d_depth, float* d_uright, int32_t* d_key_group, int32_t* d_group_idx, uint8_t* d_group_good,
                                            double* d_group_p3d, int32_t* d_hdr, void* stream);
+/* The same stage in two parts, for a caller that lets the tracking of a frame run beside its stereo bookkeeping: what
+ * tracking reads of a rig frame -- the concatenated keys / descriptors, the cameras' ranges, uright = -1 -- does not
+ * depend on the matches (VIEO_FISHEYE_CONCAT, one short kernel); the matches, the groups and the keys' depths
+ * (VIEO_FISHEYE_GROUPS) are outputs of the frame only and may run on another stream.  CONCAT + GROUPS = ALL. */
+#define VIEO_FISHEYE_ALL 0
+#define VIEO_FISHEYE_CONCAT 1
+#define VIEO_FISHEYE_GROUPS 2
+int vieo_stereo_fisheye_match_batch_device_part(vieo_fisheye* h, const vieo_keypoint* d_keys, const uint8_t* d_desc,
+                                           const int32_t* d_counts, int n_frames, vieo_keypoint* d_keys_cat,
+                                           uint8_t* d_desc_cat, int32_t* d_cam_first, int32_t* d_frame_counts,
+                                           float* d_depth, float* d_uright, int32_t* d_key_group, int32_t* d_group_idx, uint8_t* d_group_good,
+                                           double* d_group_p3d, int32_t* d_hdr, int part, void* stream);
 /* test tap: rows walked / wavefront steps of this thread's last vieo_stereo_fisheye_match */
 void vieo_fisheye_last_walk(int32_t* rows, int32_t* steps);
 

@@ -212,6 +212,7 @@ struct FePairRec {  // verdict of one knn row
 // One batch of camera-rig frames in HBM: inputs = the extractor's arrays ([frame][camera][cap]), everything else is
 // written on the device.  The counts are read where they are needed, so the stage runs without a host round trip.
 struct FeBatch {
+  int part;  // k_fe_finish: 0 everything, 1 the concatenation only (keys, descriptors, ranges, uright), 2 the group part only
   const FeRig* rig;
   const float* level_sigma2;
   const double* Tcr;           // [n_cams][12]
@@ -571,10 +572,13 @@ k_fe_finish(FeBatch B) {
   first[0] = 0;
   for (int c = 0; c < 4; c++) first[c + 1] = first[c] + (c < nc ? fe_count(B, f, c) : 0);
   int32_t* hdr = B.hdr + (size_t)f * 8;
+  const bool cat = B.part != 2, grp = B.part != 1;
   if (n == 0) {
-    for (int c = 0; c <= nc; c++) B.cam_first[(size_t)f * (nc + 1) + c] = first[c];
-    B.frame_counts[2 * (size_t)f] = min(first[nc], B.key_cap), B.frame_counts[2 * (size_t)f + 1] = 0;
-    if (nc > 2) hdr[1] = hdr[4];  // Frame.cc:705: nMatches counts the re-triangulated groups
+    if (cat) {
+      for (int c = 0; c <= nc; c++) B.cam_first[(size_t)f * (nc + 1) + c] = first[c];
+      B.frame_counts[2 * (size_t)f] = min(first[nc], B.key_cap), B.frame_counts[2 * (size_t)f + 1] = 0;
+    }
+    if (grp && nc > 2) hdr[1] = hdr[4];  // Frame.cc:705: nMatches counts the re-triangulated groups
   }
   if (n >= first[nc] || n >= B.key_cap) return;
   int c = 0;
@@ -584,10 +588,14 @@ k_fe_finish(FeBatch B) {
   for (int t = 0; t < 4; t++)
     if (t == c) k = n - first[t];
   const size_t src = ((size_t)f * nc + c) * B.cap + k, dst = (size_t)f * B.key_cap + n;
-  B.keys_cat[dst] = B.keys[src];
-  const uint4* d = (const uint4*)(B.desc + src * 32);
-  uint4* o = (uint4*)(B.desc_cat + dst * 32);
-  o[0] = d[0], o[1] = d[1];
+  if (cat) {
+    B.keys_cat[dst] = B.keys[src];
+    const uint4* d = (const uint4*)(B.desc + src * 32);
+    uint4* o = (uint4*)(B.desc_cat + dst * 32);
+    o[0] = d[0], o[1] = d[1];
+    B.uright[dst] = -1.f;
+  }
+  if (!grp) return;
   const int g = hdr[3] ? -1 : B.key_group_cam[src];
   float z = -1;
   if (g >= 0 && B.group_good[(size_t)f * B.gcap + g]) {
@@ -595,7 +603,7 @@ k_fe_finish(FeBatch B) {
     const double* X = B.group_p3d + ((size_t)f * B.gcap + g) * 3;
     z = (float)(T[8] * X[0] + T[9] * X[1] + T[10] * X[2] + T[11]);
   }
-  B.key_group[dst] = g, B.depth[dst] = z, B.uright[dst] = -1.f;
+  B.key_group[dst] = g, B.depth[dst] = z;
 }
 
 static thread_local int32_t g_fe_last_steps[2] = {0, 0};
@@ -705,6 +713,18 @@ int vieo_stereo_fisheye_match_batch_device(vieo_fisheye* h, const vieo_keypoint*
                                            float* d_depth, float* d_uright,
                                            int32_t* d_key_group, int32_t* d_group_idx, uint8_t* d_group_good,
                                            double* d_group_p3d, int32_t* d_hdr, void* stream) {
+  return vieo_stereo_fisheye_match_batch_device_part(h, d_keys, d_desc, d_counts, n_frames, d_keys_cat, d_desc_cat, d_cam_first,
+                                                     d_frame_counts, d_depth, d_uright, d_key_group, d_group_idx, d_group_good,
+                                                     d_group_p3d, d_hdr, VIEO_FISHEYE_ALL, stream);
+}
+
+int vieo_stereo_fisheye_match_batch_device_part(vieo_fisheye* h, const vieo_keypoint* d_keys, const uint8_t* d_desc,
+                                                const int32_t* d_counts, int n_frames, vieo_keypoint* d_keys_cat,
+                                                uint8_t* d_desc_cat, int32_t* d_cam_first, int32_t* d_frame_counts,
+                                                float* d_depth, float* d_uright, int32_t* d_key_group,
+                                                int32_t* d_group_idx, uint8_t* d_group_good, double* d_group_p3d,
+                                                int32_t* d_hdr, int part, void* stream) {
+  if (part < VIEO_FISHEYE_ALL || part > VIEO_FISHEYE_GROUPS) return VIEO_E_INVALID;
   if (!h || !d_keys || !d_desc || !d_counts || n_frames <= 0 || n_frames > h->max_frames || !d_keys_cat || !d_desc_cat ||
       !d_cam_first || !d_frame_counts || !d_depth || !d_uright || !d_key_group || !d_group_idx || !d_group_good || !d_group_p3d || !d_hdr)
     return VIEO_E_INVALID;
@@ -728,13 +748,16 @@ int vieo_stereo_fisheye_match_batch_device(vieo_fisheye* h, const vieo_keypoint*
   B.cap = cap, B.gcap = h->gcap, B.n_cams = nc, B.n_pairs = h->n_pairs, B.tries = h->tries, B.key_cap = nc * cap;
   for (int i = 0, p = 0; i < nc - 1; ++i)
     for (int j = i + 1; j < nc; ++j, ++p) B.pi[p] = (signed char)i, B.pj[p] = (signed char)j;
-  // brute force between the key points of all image pairs (Frame.cc:618-628), the pairs' verdicts, the group tables
-  if ((rc = knn2_rig_launch(d_desc, d_counts, cap, nc, n_frames, h->idx.as<int32_t>(), h->dist.as<int32_t>(), st)) != VIEO_OK) return rc;
-  hipLaunchKernelGGL(k_fe_pairs, dim3((cap + 63) / 64, h->n_pairs, n_frames), dim3(64), 0, st, B);
-  if (h->lds > 64 * 1024)
-    VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_fe_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFeLdsMax));
-  hipLaunchKernelGGL(k_fe_fill, dim3(n_frames), dim3(256), h->lds, st, B);
-  if (nc > 2) hipLaunchKernelGGL(k_fe_groups, dim3((h->gcap + 63) / 64, n_frames), dim3(64), 0, st, B);
+  B.part = part;
+  if (part != VIEO_FISHEYE_CONCAT) {
+    // brute force between the key points of all image pairs (Frame.cc:618-628), the pairs' verdicts, the group tables
+    if ((rc = knn2_rig_launch(d_desc, d_counts, cap, nc, n_frames, h->idx.as<int32_t>(), h->dist.as<int32_t>(), st)) != VIEO_OK) return rc;
+    hipLaunchKernelGGL(k_fe_pairs, dim3((cap + 63) / 64, h->n_pairs, n_frames), dim3(64), 0, st, B);
+    if (h->lds > 64 * 1024)
+      VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_fe_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFeLdsMax));
+    hipLaunchKernelGGL(k_fe_fill, dim3(n_frames), dim3(256), h->lds, st, B);
+    if (nc > 2) hipLaunchKernelGGL(k_fe_groups, dim3((h->gcap + 63) / 64, n_frames), dim3(64), 0, st, B);
+  }
   hipLaunchKernelGGL(k_fe_finish, dim3((B.key_cap + 255) / 256, n_frames), dim3(256), 0, st, B);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;

@@ -176,7 +176,7 @@ struct vieo_tracker {
   vieo_orb* ext = nullptr;
   vieo_fisheye* fe = nullptr;
   hipStream_t st = nullptr, st_imu = nullptr;
-  hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_ext = nullptr, ev_fe = nullptr;
   int cap = 0, ccap = 0, pcap = 0, gcap = 0, imu_cap = 512;
   int local_version = -1, n_local_dev = 0;
   float scale[16], inv_sigma2[16];
@@ -201,13 +201,24 @@ struct vieo_tracker {
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// The second stream of a tracker (pre-integration, a rig frame's stereo bookkeeping) is created with the HIGH priority:
+// two streams of the same priority may be served by the same hardware queue, where their kernels run one after the
+// other (observed: the "parallel" pre-integration of every frame sat in front of its extraction, 100 us), and streams of
+// different priorities are not.  Its kernels are short and few.
+static hipError_t create_side_stream(hipStream_t* s) {
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 extern "C" {
 
 void vieo_tracker_destroy(vieo_tracker* t) {
   if (!t) return;
   if (t->st) (void)hipStreamSynchronize(t->st);
   if (t->st_imu) (void)hipStreamSynchronize(t->st_imu), (void)hipStreamDestroy(t->st_imu);
-  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1})
+  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe})
     if (e) (void)hipEventDestroy(e);
   for (uint8_t* p : {t->h_up, t->h_loc, t->h_out})
     if (p) (void)hipHostFree(p);
@@ -303,9 +314,11 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
             hipMalloc((void**)&t->d_up, up_bytes) == hipSuccess && hipMalloc((void**)&t->d_loc, loc_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_out, t->out_bytes) == hipSuccess && hipMalloc((void**)&t->d_work, work_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_const, const_bytes) == hipSuccess &&
-            hipStreamCreateWithFlags(&t->st_imu, hipStreamNonBlocking) == hipSuccess &&
+            create_side_stream(&t->st_imu) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_up, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_imu, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&t->ev_ext, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&t->ev_fe, hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&t->ev_t0) == hipSuccess && hipEventCreate(&t->ev_t1) == hipSuccess;
   if (!ok) {
     set_error("vieo_tracker_create: allocation failed (%s)", hipGetErrorString(hipGetLastError()));
@@ -492,6 +505,7 @@ static int track_chain_tail(vieo_tracker* t, int nc_local) {
   VIEO_HIP_CHECK(hipGetLastError());
   // results: [header | uright | depth | point_ref | outlier | (rig: key -> group, the groups)] and the candidates' depths
   // (the keys / descriptors are copied by the caller, once)
+  if (t->rig) VIEO_HIP_CHECK(hipStreamWaitEvent(st, t->ev_fe, 0));  // the stereo groups of the frame (second stream)
   VIEO_HIP_CHECK(hipMemcpyAsync(t->h_out, t->d_out, t->q_small_end, hipMemcpyDeviceToHost, st));
   if (nc_local > 0) VIEO_HIP_CHECK(hipMemcpyAsync(t->h_out + t->q_cdep, d_dep + kc, (size_t)nc_local * 4, hipMemcpyDeviceToHost, st));
   return VIEO_OK;
@@ -618,10 +632,23 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   if (t->rig) {
     // ComputeStereoFishEyeMatches (Frame.cc:613-779) into mvKeys order: keys / descriptors in the work block, the tables in
     // the download block
-    rc = vieo_stereo_fisheye_match_batch_device(t->fe, d_kp, d_desc, dO->cnt, 1, (vieo_keypoint*)(Wk + t->w_kcat), Wk + t->w_dcat,
-                                                dO->cam_first, dO->fcnt, (float*)(t->d_out + t->q_dp), (float*)(t->d_out + t->q_ur),
-                                                (int32_t*)(t->d_out + t->q_kg), (int32_t*)(t->d_out + t->q_gidx), t->d_out + t->q_good,
-                                                (double*)(t->d_out + t->q_p3d), dO->fe_hdr, st);
+    // What tracking reads of it -- the concatenated keys and descriptors, the cameras' ranges, uright = -1 -- does not
+    // depend on the matches: that part stays on this stream (one short kernel), the matches / groups / depths, which are
+    // outputs of the frame only (knn-2, pairs, FillMatchesFromPair's walk, re-triangulation: 0.3 ms of a 4-camera frame),
+    // run on the second stream beside the two searches and optimisations and are joined before the copy back.
+    auto fe_part = [&](int part, hipStream_t s) {
+      return vieo_stereo_fisheye_match_batch_device_part(
+          t->fe, d_kp, d_desc, dO->cnt, 1, (vieo_keypoint*)(Wk + t->w_kcat), Wk + t->w_dcat, dO->cam_first, dO->fcnt,
+          (float*)(t->d_out + t->q_dp), (float*)(t->d_out + t->q_ur), (int32_t*)(t->d_out + t->q_kg),
+          (int32_t*)(t->d_out + t->q_gidx), t->d_out + t->q_good, (double*)(t->d_out + t->q_p3d), dO->fe_hdr, part, s);
+    };
+    TRK_HIP(hipEventRecord(t->ev_ext, st));
+    rc = fe_part(VIEO_FISHEYE_CONCAT, st);
+    if (rc == VIEO_OK) {
+      TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_ext, 0));
+      rc = fe_part(VIEO_FISHEYE_GROUPS, t->st_imu);
+      TRK_HIP(hipEventRecord(t->ev_fe, t->st_imu));
+    }
   } else
     rc = vieo_stereo_match_rectified_batch_device(t->ext, 1, d_kp, d_desc, dO->cnt, cap, P.baseline, P.bf, (float*)(t->d_out + t->q_ur),
                                                   (float*)(t->d_out + t->q_dp));
