@@ -93,6 +93,7 @@ _SIGS = {
     "vieo_fisheye_destroy": (None, [c_p]),
     "vieo_fisheye_group_capacity": (c_i, [c_p]),
     "vieo_stereo_fisheye_match_batch_device": (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_p] * 12),
+    "vieo_stereo_fisheye_match_batch_device_part": (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_p] * 11 + [c_i, c_p]),
     "vieo_track_merge_assign_rig_batch_device": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "vieo_track_compact_queries_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "vieo_track_build_obs_rig_batch_device": (c_i, [c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p,
