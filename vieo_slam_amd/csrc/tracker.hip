@@ -176,7 +176,7 @@ struct vieo_tracker {
   vieo_orb* ext = nullptr;
   vieo_fisheye* fe = nullptr;
   hipStream_t st = nullptr, st_imu = nullptr;
-  hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_ext = nullptr, ev_fe = nullptr;
+  hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_ext = nullptr, ev_fe = nullptr, ev_kd = nullptr;
   int cap = 0, ccap = 0, pcap = 0, gcap = 0, imu_cap = 512;
   int local_version = -1, n_local_dev = 0;
   float scale[16], inv_sigma2[16];
@@ -218,7 +218,7 @@ void vieo_tracker_destroy(vieo_tracker* t) {
   if (!t) return;
   if (t->st) (void)hipStreamSynchronize(t->st);
   if (t->st_imu) (void)hipStreamSynchronize(t->st_imu), (void)hipStreamDestroy(t->st_imu);
-  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe})
+  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe, t->ev_kd})
     if (e) (void)hipEventDestroy(e);
   for (uint8_t* p : {t->h_up, t->h_loc, t->h_out})
     if (p) (void)hipHostFree(p);
@@ -319,6 +319,7 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
             hipEventCreateWithFlags(&t->ev_imu, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_ext, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_fe, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&t->ev_kd, hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&t->ev_t0) == hipSuccess && hipEventCreate(&t->ev_t1) == hipSuccess;
   if (!ok) {
     set_error("vieo_tracker_create: allocation failed (%s)", hipGetErrorString(hipGetLastError()));
@@ -642,9 +643,9 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
           (float*)(t->d_out + t->q_dp), (float*)(t->d_out + t->q_ur), (int32_t*)(t->d_out + t->q_kg),
           (int32_t*)(t->d_out + t->q_gidx), t->d_out + t->q_good, (double*)(t->d_out + t->q_p3d), dO->fe_hdr, part, s);
     };
-    TRK_HIP(hipEventRecord(t->ev_ext, st));
     rc = fe_part(VIEO_FISHEYE_CONCAT, st);
     if (rc == VIEO_OK) {
+      TRK_HIP(hipEventRecord(t->ev_ext, st));  // (the extraction and the concatenation: what the second stream reads)
       TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_ext, 0));
       rc = fe_part(VIEO_FISHEYE_GROUPS, t->st_imu);
       TRK_HIP(hipEventRecord(t->ev_fe, t->st_imu));
@@ -653,6 +654,15 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     rc = vieo_stereo_match_rectified_batch_device(t->ext, 1, d_kp, d_desc, dO->cnt, cap, P.baseline, P.bf, (float*)(t->d_out + t->q_ur),
                                                   (float*)(t->d_out + t->q_dp));
   if (rc != VIEO_OK) return track_fail(t, rc);
+  // the frame's keys / descriptors (mvKeys / mDescriptors: the left image's, or the rig's concatenation) are final here:
+  // their copies back travel on the second stream while the frame is tracked
+  if (!t->rig) {
+    TRK_HIP(hipEventRecord(t->ev_ext, st));
+    TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_ext, 0));
+  }
+  TRK_HIP(hipMemcpyAsync(t->h_out + t->q_kp, Wk + t->w_kcat, (size_t)kc * sizeof(vieo_keypoint), hipMemcpyDeviceToHost, t->st_imu));
+  TRK_HIP(hipMemcpyAsync(t->h_out + t->q_desc, Wk + t->w_dcat, (size_t)kc * 32, hipMemcpyDeviceToHost, t->st_imu));
+  TRK_HIP(hipEventRecord(t->ev_kd, t->st_imu));
   if (t->vision)
     hipLaunchKernelGGL(k_track_set_pose, dim3(1), dim3(64), 0, st, dH, dO);
   else {
@@ -662,9 +672,7 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   }
   TRK_HIP(hipGetLastError());
   if ((rc = track_chain_tail(t, nc)) != VIEO_OK) return track_fail(t, rc);
-  // the frame's keys / descriptors (mvKeys / mDescriptors: the left image's, or the rig's concatenation)
-  TRK_HIP(hipMemcpyAsync(t->h_out + t->q_kp, Wk + t->w_kcat, (size_t)kc * sizeof(vieo_keypoint), hipMemcpyDeviceToHost, st));
-  TRK_HIP(hipMemcpyAsync(t->h_out + t->q_desc, Wk + t->w_dcat, (size_t)kc * 32, hipMemcpyDeviceToHost, st));
+  TRK_HIP(hipStreamWaitEvent(st, t->ev_kd, 0));  // (the keys' / descriptors' copies)
   TRK_HIP(hipEventRecord(t->ev_t1, st));
   TRK_HIP(hipStreamSynchronize(st));
   const TrkOut* O = (const TrkOut*)(t->h_out + t->q_hdr);
