@@ -799,6 +799,151 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
   if (tid == 0) A.need_seq[f] = settled ? 0 : 1;
 }
 
+// (one wavefront: the body is also the tail of k_sbp_assign_cam's last workgroup when a frame did not settle)
+__device__ __forceinline__ void seq_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ void sbp_assign_seq(const SbpArgs& A, int f, unsigned* s_pool, int lane) {
+  // LDS from s_pool on: pool copy (pool_lds words) | per key the rotation bins it was accepted with (bit b = bin b; a key
+  // can be accepted more than once when its holder has no observations) | key state (key_cap bytes)
+  unsigned* s_bins = s_pool + A.pool_lds;
+  uint8_t* s_state = (uint8_t*)(s_bins + A.key_cap);  // bit0: holds a map point, bit1: it has Observations()>0
+  __shared__ int s_hist[kHistoLen];
+  int N;
+  {
+    int k0;
+    cam_range(A, f, A.n_cams - 1, &k0, &N);  // end of the last camera = number of keys of the frame
+  }
+  const int nq = min(A.nq[f], A.q_cap);
+  int* assign = A.assign + (size_t)f * A.key_cap;
+  const uint8_t* taken = A.taken ? A.taken + (size_t)f * A.key_cap : nullptr;
+  const unsigned* pool = A.pool + (size_t)f * A.pool_cap;
+  const int2* qrec = A.qrec + (size_t)f * A.q_cap;
+  const int n_lds = min(min(A.cursor[f], A.pool_cap), A.pool_lds);
+  for (int i0 = lane; i0 < n_lds; i0 += 16 * 64) {  // 16 loads in flight per lane, then the LDS stores
+    unsigned v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = i0 + 64 * u < n_lds ? pool[i0 + 64 * u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (i0 + 64 * u < n_lds) s_pool[i0 + 64 * u] = v[u];
+  }
+  for (int i0 = lane; i0 < N; i0 += 8 * 64) {
+    uint8_t t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = (taken && i0 + 64 * u < N) ? taken[i0 + 64 * u] : (uint8_t)0;
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i0 + 64 * u < N) {
+        assign[i0 + 64 * u] = VIEO_SBP_UNCHANGED;
+        s_state[i0 + 64 * u] = t[u] ? 3 : 0;
+        s_bins[i0 + 64 * u] = 0u;
+      }
+  }
+  if (lane < kHistoLen) s_hist[lane] = 0;
+  seq_sync();
+  int nmatches = 0, overflow = 0;
+  const bool ori = A.mode != VIEO_SBP_LOCAL_MAP && A.check_ori;
+  for (int q0 = 0; q0 < nq; q0 += 64) {
+    const int2 mine = q0 + lane < nq ? qrec[q0 + lane] : make_int2(0, 0);
+    const int qn = min(64, nq - q0);
+    for (int qq = 0; qq < qn; qq++) {
+      const int off = __builtin_amdgcn_readlane(mine.x, qq), ny = __builtin_amdgcn_readlane(mine.y, qq);  // qq is uniform
+      if (ny == 0) continue;
+      if (ny < 0) {
+        overflow = 1;
+        continue;
+      }
+      const int n = ny & 0xFFFF, q = q0 + qq;
+      // two smallest (dist, order) among usable candidates; lane owns positions lane, lane+64.  The keys are unique
+      // (they carry the position), so the second smallest is the minimum once the winner's lane puts its other key
+      // forward; the winners' candidate words are read back from their lanes' registers.
+      unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
+      unsigned cand2[2] = {0u, 0u};  // the lane's candidate words: the winners are read back from here
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int pos = lane + 64 * h;
+        if (pos < n) {
+          const unsigned c = off + pos < n_lds ? s_pool[off + pos] : pool[off + pos];
+          cand2[h] = c;
+          const int idx = c & 0x1FFF, d = (c >> 13) & 0x1FF;
+          const int st = s_state[idx];
+          if (A.mode == VIEO_SBP_RELOC ? !(st & 1) : !((st & 1) && (st & 2))) {
+            const unsigned key = ((unsigned)d << 8) | (unsigned)pos;  // (dist, order)
+            if (key < b0)
+              b1 = b0, b0 = key;
+            else
+              b1 = key;
+          }
+        }
+      }
+      const unsigned m0 = wave_min_u32(b0);
+      const unsigned m1 = wave_min_u32(b0 == m0 ? b1 : b0);
+      b0 = m0, b1 = m1;
+      // (uniform position -> that lane's register: v_readlane instead of another LDS round trip)
+      unsigned c0 = 0, c1 = 0;
+      if (b0 != 0xFFFFFFFFu) c0 = (unsigned)__builtin_amdgcn_readlane((int)((b0 & 64u) ? cand2[1] : cand2[0]), (int)(b0 & 63u));
+      if (b1 != 0xFFFFFFFFu) c1 = (unsigned)__builtin_amdgcn_readlane((int)((b1 & 64u) ? cand2[1] : cand2[0]), (int)(b1 & 63u));
+      if (b0 == 0xFFFFFFFFu) continue;
+      const int bestDist = b0 >> 8;
+      const int bestIdx = c0 & 0x1FFF, bestLevel = (c0 >> 22) & 15;
+      if (bestDist > (A.mode == VIEO_SBP_RELOC ? (int)A.nn_ratio : kThHigh)) continue;
+      if (A.mode == VIEO_SBP_LOCAL_MAP && b1 != 0xFFFFFFFFu) {
+        const int bestDist2 = b1 >> 8;
+        const int bestLevel2 = (c1 >> 22) & 15;
+        if (bestLevel == bestLevel2 && (float)bestDist > A.nn_ratio * (float)bestDist2) continue;
+      }
+      // AddMapPoint(pMP, bestIdx)
+      if (lane == 0) {
+        s_state[bestIdx] = 1 | ((ny >> 16) ? 2 : 0);
+        assign[bestIdx] = q;
+      }
+      nmatches++;
+      if (ori) {
+        const int bin = (c0 >> 26) & 31;
+        if (lane == 0) {  // rotHist[bin].push_back(bestIdx2)
+          s_bins[bestIdx] |= 1u << bin;
+          s_hist[bin]++;
+        }
+      }
+      seq_sync();  // single wave: orders the LDS state update before the next query
+    }
+  }
+  if (ori) {
+    seq_sync();
+    // ComputeThreeMaxima (ORBmatcher.cc:1608-1641), evaluated redundantly by every lane
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < kHistoLen; i++) {
+      const int s = s_hist[i];
+      if (s > max1) {
+        max3 = max2, max2 = max1, max1 = s;
+        ind3 = ind2, ind2 = ind1, ind1 = i;
+      } else if (s > max2) {
+        max3 = max2, max2 = s;
+        ind3 = ind2, ind2 = i;
+      } else if (s > max3) {
+        max3 = s, ind3 = i;
+      }
+    }
+    if (max2 < 0.1f * (float)max1) {
+      ind2 = -1, ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+      ind3 = -1;
+    }
+    // EraseMapPointMatch of every key logged in a bin that is not kept
+    unsigned losers = (1u << kHistoLen) - 1u;
+    if (ind1 >= 0) losers &= ~(1u << ind1);
+    if (ind2 >= 0) losers &= ~(1u << ind2);
+    if (ind3 >= 0) losers &= ~(1u << ind3);
+    for (int k = lane; k < N; k += 64)
+      if (s_bins[k] & losers) assign[k] = VIEO_SBP_ERASED;
+    for (int i = 0; i < kHistoLen; i++)
+      if (i != ind1 && i != ind2 && i != ind3) nmatches -= s_hist[i];
+  }
+  if (lane == 0) A.nmatches[f] = overflow ? -1 : nmatches;
+}
+
 // ---- the same assignment for camera rigs, one workgroup per (frame, camera) (round 4).  A query belongs to one
 // camera and its candidates are keys of that camera, so the order-dependent walk decomposes exactly: the queries of
 // camera c, in their original order, against the keys of camera c.  Two things made the one-workgroup form slow on rig
@@ -815,7 +960,8 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_par(SbpArgs A) {
 // (the finisher clears it); kbins: [frame][key_cap] rotation bins of the accepted keys.
 // LDS: pairs (word u32, owner u16) x pair_cap | per key 13 bytes x cam_cap | per query of the camera 12 bytes x kCamQ.
 static const int kFinStride = 48, kCamQ = 4096;
-__global__ void __launch_bounds__(1024) k_sbp_assign_cam(SbpArgs A, int cam_cap, int* __restrict__ fin, unsigned* __restrict__ kbins) {
+__global__ void __launch_bounds__(1024) k_sbp_assign_cam(SbpArgs A, int cam_cap, int* __restrict__ fin, unsigned* __restrict__ kbins,
+                                                        int lds_bytes) {
   extern __shared__ unsigned s_pool[];             // [pool_lds] the camera's candidate words, list after list
   unsigned* s_best = s_pool + A.pool_lds;          // [kCamQ] smallest unblocked key of the query this round
   unsigned* s_second = s_best + kCamQ;             // [kCamQ] runner-up (local-map mode)
@@ -1026,157 +1172,27 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_cam(SbpArgs A, int cam_cap,
     for (int k = tid; k < kend; k += 1024)
       if (KB[k] & losers) assign[k] = VIEO_SBP_ERASED;
   }
+  const bool replay = s_fill != 0;  // some camera did not settle (or does not fit): the sequential replay, right here
   if (tid == 0) {
     A.nmatches[f] = s_overflow ? -1 : nmatches;
-    A.need_seq[f] = s_fill ? 1 : 0;
+    A.need_seq[f] = 0;
   }
   if (tid < kFinStride) F[tid] = 0;  // (the next launch on this stream finds it clear)
+  __syncthreads();
+  if (replay && tid < 64) {
+    SbpArgs S = A;
+    S.pool_lds = max(0, min(A.pool_cap, (lds_bytes - A.key_cap * 5 - 64) / 4));
+    sbp_assign_seq(S, f, s_pool, tid);
+  }
 }
 
 // one wave per frame: the frame's candidate pool is copied to LDS once, after that the replay of
 // the queries touches no global memory except the accepted assignments.  Since round 3 the fallback of
 // k_sbp_assign_par (frames whose claims did not settle) and the reference form for the tests (VIEO_SBP_ASSIGN=seq).
 __global__ void __launch_bounds__(64) k_sbp_assign(SbpArgs A) {
-  // dynamic LDS: pool copy (pool_lds words) | per key the rotation bins it was accepted with (bit b = bin b; a key
-  // can be accepted more than once when its holder has no observations) | key state (key_cap bytes)
   extern __shared__ unsigned s_pool[];
-  unsigned* s_bins = s_pool + A.pool_lds;
-  uint8_t* s_state = (uint8_t*)(s_bins + A.key_cap);  // bit0: holds a map point, bit1: it has Observations()>0
-  __shared__ int s_hist[kHistoLen];
-  const int f = blockIdx.x, lane = threadIdx.x;
-  if (A.need_seq && !A.need_seq[f]) return;  // the parallel assignment settled this frame
-  int N;
-  {
-    int k0;
-    cam_range(A, f, A.n_cams - 1, &k0, &N);  // end of the last camera = number of keys of the frame
-  }
-  const int nq = min(A.nq[f], A.q_cap);
-  int* assign = A.assign + (size_t)f * A.key_cap;
-  const uint8_t* taken = A.taken ? A.taken + (size_t)f * A.key_cap : nullptr;
-  const unsigned* pool = A.pool + (size_t)f * A.pool_cap;
-  const int2* qrec = A.qrec + (size_t)f * A.q_cap;
-  const int n_lds = min(min(A.cursor[f], A.pool_cap), A.pool_lds);
-  for (int i0 = lane; i0 < n_lds; i0 += 16 * 64) {  // 16 loads in flight per lane, then the LDS stores
-    unsigned v[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) v[u] = i0 + 64 * u < n_lds ? pool[i0 + 64 * u] : 0u;
-#pragma unroll
-    for (int u = 0; u < 16; u++)
-      if (i0 + 64 * u < n_lds) s_pool[i0 + 64 * u] = v[u];
-  }
-  for (int i0 = lane; i0 < N; i0 += 8 * 64) {
-    uint8_t t[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) t[u] = (taken && i0 + 64 * u < N) ? taken[i0 + 64 * u] : (uint8_t)0;
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (i0 + 64 * u < N) {
-        assign[i0 + 64 * u] = VIEO_SBP_UNCHANGED;
-        s_state[i0 + 64 * u] = t[u] ? 3 : 0;
-        s_bins[i0 + 64 * u] = 0u;
-      }
-  }
-  if (lane < kHistoLen) s_hist[lane] = 0;
-  __syncthreads();
-  int nmatches = 0, overflow = 0;
-  const bool ori = A.mode != VIEO_SBP_LOCAL_MAP && A.check_ori;
-  for (int q0 = 0; q0 < nq; q0 += 64) {
-    const int2 mine = q0 + lane < nq ? qrec[q0 + lane] : make_int2(0, 0);
-    const int qn = min(64, nq - q0);
-    for (int qq = 0; qq < qn; qq++) {
-      const int off = __builtin_amdgcn_readlane(mine.x, qq), ny = __builtin_amdgcn_readlane(mine.y, qq);  // qq is uniform
-      if (ny == 0) continue;
-      if (ny < 0) {
-        overflow = 1;
-        continue;
-      }
-      const int n = ny & 0xFFFF, q = q0 + qq;
-      // two smallest (dist, order) among usable candidates; lane owns positions lane, lane+64.  The keys are unique
-      // (they carry the position), so the second smallest is the minimum once the winner's lane puts its other key
-      // forward; the winners' candidate words are read back from their lanes' registers.
-      unsigned b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
-      unsigned cand2[2] = {0u, 0u};  // the lane's candidate words: the winners are read back from here
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int pos = lane + 64 * h;
-        if (pos < n) {
-          const unsigned c = off + pos < n_lds ? s_pool[off + pos] : pool[off + pos];
-          cand2[h] = c;
-          const int idx = c & 0x1FFF, d = (c >> 13) & 0x1FF;
-          const int st = s_state[idx];
-          if (A.mode == VIEO_SBP_RELOC ? !(st & 1) : !((st & 1) && (st & 2))) {
-            const unsigned key = ((unsigned)d << 8) | (unsigned)pos;  // (dist, order)
-            if (key < b0)
-              b1 = b0, b0 = key;
-            else
-              b1 = key;
-          }
-        }
-      }
-      const unsigned m0 = wave_min_u32(b0);
-      const unsigned m1 = wave_min_u32(b0 == m0 ? b1 : b0);
-      b0 = m0, b1 = m1;
-      // (uniform position -> that lane's register: v_readlane instead of another LDS round trip)
-      unsigned c0 = 0, c1 = 0;
-      if (b0 != 0xFFFFFFFFu) c0 = (unsigned)__builtin_amdgcn_readlane((int)((b0 & 64u) ? cand2[1] : cand2[0]), (int)(b0 & 63u));
-      if (b1 != 0xFFFFFFFFu) c1 = (unsigned)__builtin_amdgcn_readlane((int)((b1 & 64u) ? cand2[1] : cand2[0]), (int)(b1 & 63u));
-      if (b0 == 0xFFFFFFFFu) continue;
-      const int bestDist = b0 >> 8;
-      const int bestIdx = c0 & 0x1FFF, bestLevel = (c0 >> 22) & 15;
-      if (bestDist > (A.mode == VIEO_SBP_RELOC ? (int)A.nn_ratio : kThHigh)) continue;
-      if (A.mode == VIEO_SBP_LOCAL_MAP && b1 != 0xFFFFFFFFu) {
-        const int bestDist2 = b1 >> 8;
-        const int bestLevel2 = (c1 >> 22) & 15;
-        if (bestLevel == bestLevel2 && (float)bestDist > A.nn_ratio * (float)bestDist2) continue;
-      }
-      // AddMapPoint(pMP, bestIdx)
-      if (lane == 0) {
-        s_state[bestIdx] = 1 | ((ny >> 16) ? 2 : 0);
-        assign[bestIdx] = q;
-      }
-      nmatches++;
-      if (ori) {
-        const int bin = (c0 >> 26) & 31;
-        if (lane == 0) {  // rotHist[bin].push_back(bestIdx2)
-          s_bins[bestIdx] |= 1u << bin;
-          s_hist[bin]++;
-        }
-      }
-      __syncthreads();  // single wave: orders the LDS state update before the next query
-    }
-  }
-  if (ori) {
-    __syncthreads();
-    // ComputeThreeMaxima (ORBmatcher.cc:1608-1641), evaluated redundantly by every lane
-    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-    for (int i = 0; i < kHistoLen; i++) {
-      const int s = s_hist[i];
-      if (s > max1) {
-        max3 = max2, max2 = max1, max1 = s;
-        ind3 = ind2, ind2 = ind1, ind1 = i;
-      } else if (s > max2) {
-        max3 = max2, max2 = s;
-        ind3 = ind2, ind2 = i;
-      } else if (s > max3) {
-        max3 = s, ind3 = i;
-      }
-    }
-    if (max2 < 0.1f * (float)max1) {
-      ind2 = -1, ind3 = -1;
-    } else if (max3 < 0.1f * (float)max1) {
-      ind3 = -1;
-    }
-    // EraseMapPointMatch of every key logged in a bin that is not kept
-    unsigned losers = (1u << kHistoLen) - 1u;
-    if (ind1 >= 0) losers &= ~(1u << ind1);
-    if (ind2 >= 0) losers &= ~(1u << ind2);
-    if (ind3 >= 0) losers &= ~(1u << ind3);
-    for (int k = lane; k < N; k += 64)
-      if (s_bins[k] & losers) assign[k] = VIEO_SBP_ERASED;
-    for (int i = 0; i < kHistoLen; i++)
-      if (i != ind1 && i != ind2 && i != ind3) nmatches -= s_hist[i];
-  }
-  if (lane == 0) A.nmatches[f] = overflow ? -1 : nmatches;
+  if (A.need_seq && !A.need_seq[blockIdx.x]) return;  // the parallel assignment settled this frame
+  sbp_assign_seq(A, blockIdx.x, s_pool, threadIdx.x);
 }
 
 // ---------------------------------------------------------------- SearchByProjectionBase (Fuse) -------------
@@ -1390,9 +1406,11 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
       if (S.fin.p != fin_was) VIEO_HIP_CHECK(hipMemsetAsync(S.fin.p, 0, S.fin.cap, st));  // (the kernel leaves it clear)
       VIEO_HIP_CHECK(hipFuncSetAttribute((const void*)k_sbp_assign_cam, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       hipLaunchKernelGGL(k_sbp_assign_cam, dim3(n_frames, P.n_cams), dim3(1024), lds_cam, st, P, cam_cap, S.fin.as<int>(),
-                         S.kbins.as<unsigned>());
-    } else
-      hipLaunchKernelGGL(k_sbp_assign_par, dim3(n_frames), dim3(1024), lds_par, st, P);
+                         S.kbins.as<unsigned>(), (int)lds_cam);
+      VIEO_HIP_CHECK(hipGetLastError());
+      return VIEO_OK;  // (a frame that does not settle is replayed by its last workgroup: no second launch)
+    }
+    hipLaunchKernelGGL(k_sbp_assign_par, dim3(n_frames), dim3(1024), lds_par, st, P);
   }
   hipLaunchKernelGGL(k_sbp_assign, dim3(n_frames), dim3(64), lds, st, A);
   VIEO_HIP_CHECK(hipGetLastError());
