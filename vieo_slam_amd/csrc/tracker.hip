@@ -201,15 +201,56 @@ struct vieo_tracker {
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// The second stream of a tracker (pre-integration, a rig frame's stereo bookkeeping) is created with the HIGH priority:
-// two streams of the same priority may be served by the same hardware queue, where their kernels run one after the
-// other (observed: the "parallel" pre-integration of every frame sat in front of its extraction, 100 us), and streams of
-// different priorities are not.  Its kernels are short and few.
-static hipError_t create_side_stream(hipStream_t* s) {
+// The second stream of a tracker (pre-integration, a rig frame's stereo bookkeeping, the copies back) must be served by
+// another hardware queue than the first: on one queue their kernels run one after the other (observed with two streams
+// of equal priority: the "parallel" pre-integration of every frame sat in front of its extraction, 100 us; in a process
+// that holds many streams the assignment is anybody's guess: a 2-camera frame 1.06 -> 1.55 ms with eight idle torch
+// streams around).  HIP does not say which queue a stream gets, so candidates are TRIED: a ~40 us spin kernel on each of
+// the two streams, started together -- a candidate whose kernel ends when the first one's does runs beside it.  High
+// priority first (its own pool of queues where the runtime has one), a handful of attempts, the best one is kept.
+__global__ void k_track_spin(long long cycles) {
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
+static hipError_t create_side_stream(hipStream_t* out, hipStream_t main_stream) {
   int lo = 0, hi = 0;
-  if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
-  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  const bool prio = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
+    for (hipEvent_t e : {e0, e1, e2})
+      if (e) (void)hipEventDestroy(e);
+    return prio ? hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  }
+  const long long spin = 100000;  // ~40 us
+  hipStream_t best = nullptr, held[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float best_ratio = 1e9f;
+  for (int k = 0; k < 6; k++) {
+    hipStream_t c = nullptr;
+    const hipError_t err = (prio && k % 2 == 0) ? hipStreamCreateWithPriority(&c, hipStreamNonBlocking, hi)
+                                                : hipStreamCreateWithFlags(&c, hipStreamNonBlocking);
+    if (err != hipSuccess) break;
+    held[k] = c;  // (kept until the end: a destroyed candidate's queue would be handed to the next one)
+    float both = 0, one = 0;
+    bool ok = true;
+    for (int rep = 0; rep < 2 && ok; rep++) {  // (the first round also creates the candidate's queue)
+      ok = hipEventRecord(e0, main_stream) == hipSuccess && hipStreamWaitEvent(c, e0, 0) == hipSuccess;
+      hipLaunchKernelGGL(k_track_spin, dim3(1), dim3(64), 0, main_stream, spin);
+      hipLaunchKernelGGL(k_track_spin, dim3(1), dim3(64), 0, c, spin);
+      ok = ok && hipEventRecord(e1, main_stream) == hipSuccess && hipEventRecord(e2, c) == hipSuccess &&
+           hipStreamSynchronize(main_stream) == hipSuccess && hipStreamSynchronize(c) == hipSuccess &&
+           hipEventElapsedTime(&one, e0, e1) == hipSuccess && hipEventElapsedTime(&both, e0, e2) == hipSuccess;
+    }
+    if (!ok) continue;
+    const float ratio = both / (one > 0 ? one : 1.f);  // 1: side by side, 2: one after the other
+    if (ratio < best_ratio) best_ratio = ratio, best = c;
+    if (ratio < 1.35f) break;
+  }
+  for (hipStream_t c : held)
+    if (c && c != best) (void)hipStreamDestroy(c);
+  for (hipEvent_t e : {e0, e1, e2}) (void)hipEventDestroy(e);
+  if (!best) return hipErrorUnknown;
+  *out = best;
+  return hipSuccess;
 }
 
 extern "C" {
@@ -314,7 +355,7 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
             hipMalloc((void**)&t->d_up, up_bytes) == hipSuccess && hipMalloc((void**)&t->d_loc, loc_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_out, t->out_bytes) == hipSuccess && hipMalloc((void**)&t->d_work, work_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_const, const_bytes) == hipSuccess &&
-            create_side_stream(&t->st_imu) == hipSuccess &&
+            create_side_stream(&t->st_imu, t->st) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_up, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_imu, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_ext, hipEventDisableTiming) == hipSuccess &&
