@@ -453,7 +453,30 @@ int vieo_tracker_get_level(vieo_tracker* t, int image_index, int level, int with
 }
 
 // the part of the chain behind the prediction: both searches and both optimisations
-static int track_chain_tail(vieo_tracker* t, int nc_local) {
+// the first search's queries from the predicted pose: SearchByProjection's projection of the last frame's points and, for
+// rigs, the compaction of the valid (point, camera) pairs
+static int track_project(vieo_tracker* t, hipStream_t s) {
+  const int kc = t->kc, nc = t->nc;
+  TrkHdr* dH = (TrkHdr*)(t->d_up + t->o_hdr);
+  TrkOut* dO = (TrkOut*)(t->d_out + t->q_hdr);
+  uint8_t* W = t->d_work;
+  vieo_proj_query* d_q1 = (vieo_proj_query*)(W + t->w_q1);
+  int rc;
+  if (t->rig) {
+    if ((rc = vieo_sbp_project_last_frame_rig_batch_device((const vieo_last_frame_point*)(t->d_up + t->o_pts), dH->npts, kc, 1,
+                                                           &dH->cam, (const vieo_sbp_rig*)t->d_const, nc, d_q1, s)) != VIEO_OK)
+      return rc;
+    // one query per (last-frame key, camera): most project outside their camera -- the search walks the valid ones only
+    return vieo_track_compact_queries_batch_device(d_q1, dH->npts + 1, kc * nc, 1, (vieo_proj_query*)(W + t->w_q1c),
+                                                   (int32_t*)(W + t->w_qsrc), dO->nq + 1, s);
+  }
+  return vieo_sbp_project_last_frame_batch_device((const vieo_last_frame_point*)(t->d_up + t->o_pts), dH->npts, kc, 1, &dH->cam,
+                                                  d_q1, s);
+}
+
+// projected: the first search's queries are there already (the prediction, the projection of the last frame's points and,
+// for rigs, their compaction ran on the second stream beside the extraction); false for the repeat with the wider window
+static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected) {
   const vieo_tracker_params& P = t->P;
   const int kc = t->kc, nc = t->nc;
   hipStream_t st = t->st;
@@ -511,16 +534,10 @@ static int track_chain_tail(vieo_tracker* t, int nc_local) {
     return vieo_pose_optimization_vio_batch_device_ex((const vieo_vio_frame*)frame, 1, d_obs, d_outl, (vieo_vio_result*)result,
                                                       t->rig ? VIEO_POSE_CAMS_RIG : VIEO_POSE_CAMS_RECTIFIED, VIEO_POSE_ENC_NONE, st);
   };
-  if (t->rig)
-    TRK(vieo_sbp_project_last_frame_rig_batch_device((const vieo_last_frame_point*)(t->d_up + t->o_pts), dH->npts, kc, 1, &dH->cam,
-                                                     d_rig, nc, d_q1, st));
-  else
-    TRK(vieo_sbp_project_last_frame_batch_device((const vieo_last_frame_point*)(t->d_up + t->o_pts), dH->npts, kc, 1, &dH->cam, d_q1, st));
+  if (!projected) TRK(track_project(t, st));
   if (t->rig) {
-    // one query per (last-frame key, camera): most project outside their camera -- the search walks the valid ones only
     vieo_proj_query* d_q1c = (vieo_proj_query*)(W + t->w_q1c);
     int32_t* d_qsrc = (int32_t*)(W + t->w_qsrc);
-    TRK(vieo_track_compact_queries_batch_device(d_q1, dH->npts + 1, kc * nc, 1, d_q1c, d_qsrc, dO->nq + 1, st));
     TRK(search(VIEO_SBP_LAST_FRAME, d_q1c, dO->nq + 1, kc * nc, nullptr, P.nn_last, dO->nm));
     TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, 0, 1, nc,
                                                  (const vieo_last_frame_point*)(t->d_up + t->o_pts), d_qsrc, kc * nc, st));
@@ -653,8 +670,16 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
                                                  dH->bg, dH->ba, 1, (vieo_imu_preint*)(Wk + t->w_pre), (double*)(Wk + t->w_prv),
                                                  (int32_t*)(Wk + t->w_pst), t->st_imu)) != VIEO_OK)
       return track_fail(t, rc);
-    TRK_HIP(hipEventRecord(t->ev_imu, t->st_imu));
+    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(64), 0, t->st_imu, dH, dO, (const vieo_imu_preint*)(Wk + t->w_pre),
+                       (const double*)(Wk + t->w_prv), (const int32_t*)(Wk + t->w_pst));
+  } else {
+    TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
+    hipLaunchKernelGGL(k_track_set_pose, dim3(1), dim3(64), 0, t->st_imu, dH, dO);
   }
+  // PredictNavStateByIMU and the projection of the last frame's points need nothing of the new images: beside the extraction
+  TRK_HIP(hipGetLastError());
+  if ((rc = track_project(t, t->st_imu)) != VIEO_OK) return track_fail(t, rc);
+  TRK_HIP(hipEventRecord(t->ev_imu, t->st_imu));
   if (new_local) {
     TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cpt, t->h_loc + t->l_cpt, (size_t)nc * sizeof(vieo_frustum_point), hipMemcpyHostToDevice, st));
     TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cdesc, t->h_loc + t->l_cdesc, (size_t)nc * 32, hipMemcpyHostToDevice, st));
@@ -704,15 +729,8 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   TRK_HIP(hipMemcpyAsync(t->h_out + t->q_kp, Wk + t->w_kcat, (size_t)kc * sizeof(vieo_keypoint), hipMemcpyDeviceToHost, t->st_imu));
   TRK_HIP(hipMemcpyAsync(t->h_out + t->q_desc, Wk + t->w_dcat, (size_t)kc * 32, hipMemcpyDeviceToHost, t->st_imu));
   TRK_HIP(hipEventRecord(t->ev_kd, t->st_imu));
-  if (t->vision)
-    hipLaunchKernelGGL(k_track_set_pose, dim3(1), dim3(64), 0, st, dH, dO);
-  else {
-    TRK_HIP(hipStreamWaitEvent(st, t->ev_imu, 0));
-    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(64), 0, st, dH, dO, (const vieo_imu_preint*)(Wk + t->w_pre),
-                       (const double*)(Wk + t->w_prv), (const int32_t*)(Wk + t->w_pst));
-  }
-  TRK_HIP(hipGetLastError());
-  if ((rc = track_chain_tail(t, nc)) != VIEO_OK) return track_fail(t, rc);
+  TRK_HIP(hipStreamWaitEvent(st, t->ev_imu, 0));  // the prediction and the first search's queries (second stream)
+  if ((rc = track_chain_tail(t, nc, true)) != VIEO_OK) return track_fail(t, rc);
   TRK_HIP(hipStreamWaitEvent(st, t->ev_kd, 0));  // (the keys' / descriptors' copies)
   TRK_HIP(hipEventRecord(t->ev_t1, st));
   TRK_HIP(hipStreamSynchronize(st));
@@ -725,7 +743,7 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     widened = 1;
     const float th2 = 2 * P.th_last;
     TRK_HIP(hipMemcpyAsync(&dH->cam.th, &th2, 4, hipMemcpyHostToDevice, st));
-    if ((rc = track_chain_tail(t, nc)) != VIEO_OK) return track_fail(t, rc);
+    if ((rc = track_chain_tail(t, nc, false)) != VIEO_OK) return track_fail(t, rc);
     TRK_HIP(hipEventRecord(t->ev_t1, st));
     TRK_HIP(hipStreamSynchronize(st));
   }
