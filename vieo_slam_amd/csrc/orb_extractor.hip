@@ -170,6 +170,13 @@ __device__ __forceinline__ int fast_strength(const uint8_t* t, int p) {
   return max(max(A, -B), 0);
 }
 
+#ifdef VIEO_FAST_STATS  // tools/fast_stats.py: what the cells of a workload cost (a private build, not the product)
+__device__ unsigned long long g_fast_stats[8];
+#define FAST_STAT(i, v) do { if (lane == 0) atomicAdd(&g_fast_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define FAST_STAT(i, v) do { } while (0)
+#endif
+
 // Necessary condition for strength > t on the 4 compass points of the ring (positions 0, 4, 8, 12):
 // an arc of 9 contiguous ring pixels contains position 0 or 8 and position 4 or 12, all of one
 // polarity.  Darker: x < v - t, brighter: x > v + t.  Each comparison is one v_cmp into a lane mask.
@@ -212,11 +219,14 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
     const int th = round == 0 ? iniTh : minTh;
     int na = 0, nc = 0;  // cand[0, nc): corners (strength > th); cand[nc, na): compass survivors still to be scored
     bool overflow = false;
+    FAST_STAT(round, 1);
     // ---- pass B: exact strength of the pending survivors cand[nc, na); those above the threshold are compacted
     // in place behind the corners already there (still row-major: a wavefront reads its 64 entries before it writes
     // any).  Runs once after pass A, and inside pass A whenever the list is about to exceed its LDS capacity.
     auto pass_b = [&]() {
       int w = nc;
+      FAST_STAT(3, (na - nc + 63) / 64);
+      FAST_STAT(6, na - nc);
       for (int i0 = nc; i0 < na; i0 += 64) {
         const int i = i0 + lane;
         bool pass = false;
@@ -353,6 +363,7 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
       // the strength of EVERY pixel of the cell is evaluated; pass C then scans the strength tile itself.  Same
       // result: the compass test is a necessary condition, so the pixels it removes have strength <= th, which
       // pass C reads as 0 either way.
+      FAST_STAT(2, 1);
       for (int i0 = 0; i0 < npx; i0 += 64) {
         const int i = i0 + lane;
         if (i < npx) {
@@ -364,6 +375,7 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
     wave_sync();
     // ---- pass C: 3x3 non-maximum suppression over the corners (still in row-major order)
     const int nC = overflow ? npx : nc;
+    FAST_STAT(4, (nC + 63) / 64);
     for (int i0 = 0; i0 < nC; i0 += 64) {
       const int i = i0 + lane;
       bool keep = false;
@@ -397,6 +409,7 @@ __device__ __forceinline__ void fast_cell(const OrbParams& P, const CellDesc& cd
     }
     wave_sync();
   }
+  FAST_STAT(7, base);
   if (lane == 0) cell_counts[(size_t)b * P.ncells + c] = min(base, P.cell_cap);
 }
 
@@ -1445,6 +1458,18 @@ int vieo_orb_extract_batch_device(vieo_orb* e, const uint8_t* d_images, int n_im
   return run_batch(e, d_images, n_images, width, height, stride, image_pitch_bytes, h_lapping,
                    d_keypoints, d_descriptors, capacity, d_counts);
 }
+
+#ifdef VIEO_FAST_STATS
+// [0] cells, [1] cells that went on to minThFAST, [2] cells evaluated densely, [3] batches of 64 exact strengths,
+// [4] batches of pass C, [6] compass survivors scored, [7] corners kept; reset on read
+int vieo_fast_stats(unsigned long long* out8) {
+  unsigned long long z[8] = {0};
+  VIEO_HIP_CHECK(hipDeviceSynchronize());
+  VIEO_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(vieo::g_fast_stats), sizeof(z)));
+  VIEO_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(vieo::g_fast_stats), z, sizeof(z)));
+  return VIEO_OK;
+}
+#endif
 
 void* vieo_orb_stream(vieo_orb* e) { return e ? (void*)e->stream : nullptr; }
 
