@@ -663,6 +663,14 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   TRK_HIP(hipEventRecord(t->ev_up, st));
   TrkHdr* dH = (TrkHdr*)(t->d_up + t->o_hdr);
   TrkOut* dO = (TrkOut*)(t->d_out + t->q_hdr);
+  vieo_keypoint* d_kp = (vieo_keypoint*)(Wk + t->w_kp);
+  uint8_t* d_desc = Wk + t->w_desc;
+  const int* lapping = t->rig && t->R.use_lapping ? t->R.lapping : nullptr;
+  if ((rc = vieo_orb_extract_batch_device(t->ext, t->d_up + t->o_img, t->n_img, W, Hh, W, npx, lapping, d_kp, d_desc, cap, dO->cnt)) != VIEO_OK)
+    return track_fail(t, rc);
+  // Everything that needs nothing of the new images goes to the second stream, and is handed to it AFTER the extraction's
+  // launches: those are the head of the critical path (the host spends 20-30 us on the second stream's five to eight
+  // launches, and the first pyramid level used to wait for them).
   if (!t->vision) {
     // the pre-integration beside the extraction
     TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
@@ -679,23 +687,18 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   // PredictNavStateByIMU and the projection of the last frame's points need nothing of the new images: beside the extraction
   TRK_HIP(hipGetLastError());
   if ((rc = track_project(t, t->st_imu)) != VIEO_OK) return track_fail(t, rc);
-  TRK_HIP(hipEventRecord(t->ev_imu, t->st_imu));
   if (new_local) {
-    TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cpt, t->h_loc + t->l_cpt, (size_t)nc * sizeof(vieo_frustum_point), hipMemcpyHostToDevice, st));
-    TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cdesc, t->h_loc + t->l_cdesc, (size_t)nc * 32, hipMemcpyHostToDevice, st));
-    TRK_HIP(hipMemcpyAsync(Wk + t->w_xyz + (size_t)kc * 12, t->h_loc + t->l_xyz, (size_t)nc * 12, hipMemcpyHostToDevice, st));
+    TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cpt, t->h_loc + t->l_cpt, (size_t)nc * sizeof(vieo_frustum_point), hipMemcpyHostToDevice, t->st_imu));
+    TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cdesc, t->h_loc + t->l_cdesc, (size_t)nc * 32, hipMemcpyHostToDevice, t->st_imu));
+    TRK_HIP(hipMemcpyAsync(Wk + t->w_xyz + (size_t)kc * 12, t->h_loc + t->l_xyz, (size_t)nc * 12, hipMemcpyHostToDevice, t->st_imu));
     t->local_version = in->local_version, t->n_local_dev = nc;
   }
-  // the last frame's part of the two point tables
+  // the last frame's part of the two point tables (read by the tail only)
   if (nl) {
-    TRK_HIP(hipMemcpyAsync(Wk + t->w_xyz, t->d_up + t->o_xyz, (size_t)nl * 12, hipMemcpyDeviceToDevice, st));
-    TRK_HIP(hipMemcpyAsync(Wk + t->w_dep, t->d_up + t->o_dep, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
+    TRK_HIP(hipMemcpyAsync(Wk + t->w_xyz, t->d_up + t->o_xyz, (size_t)nl * 12, hipMemcpyDeviceToDevice, t->st_imu));
+    TRK_HIP(hipMemcpyAsync(Wk + t->w_dep, t->d_up + t->o_dep, (size_t)nl * 4, hipMemcpyDeviceToDevice, t->st_imu));
   }
-  vieo_keypoint* d_kp = (vieo_keypoint*)(Wk + t->w_kp);
-  uint8_t* d_desc = Wk + t->w_desc;
-  const int* lapping = t->rig && t->R.use_lapping ? t->R.lapping : nullptr;
-  if ((rc = vieo_orb_extract_batch_device(t->ext, t->d_up + t->o_img, t->n_img, W, Hh, W, npx, lapping, d_kp, d_desc, cap, dO->cnt)) != VIEO_OK)
-    return track_fail(t, rc);
+  TRK_HIP(hipEventRecord(t->ev_imu, t->st_imu));
   if (t->rig) {
     // ComputeStereoFishEyeMatches (Frame.cc:613-779) into mvKeys order: keys / descriptors in the work block, the tables in
     // the download block
