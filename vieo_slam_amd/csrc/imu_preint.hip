@@ -17,6 +17,7 @@ struct PreIntD {
   double *S, *Sprv;  // 9 x 9 covariances: the lane's private arrays, or the wavefront's LDS (WAVE)
   double* lds;       // WAVE: A[81] | T[81] | Bg[27] | Ba[27] | TB[27]
   int lane;
+  const double* sig;  // WAVE: the 18 entries of sigma_g | sigma_a in global memory
 };
 
 __device__ __forceinline__ void preint_wave_sync() {
@@ -52,7 +53,6 @@ __device__ void preint_cov_wave(PreIntD& P, double* S, int iR, int iV, const dou
       Bg[(iR + i) * 3 + j] = Jr[e] * dt;
       Ba[(iV + i) * 3 + j] = P.R[e] * dt;
       Ba[i * 3 + j] = P.R[e] * dt2div2;
-      NgL[e] = Ng[e], NaL[e] = Na[e];
     }
   preint_wave_sync();
   for (int e = lane; e < 81; e += 64) {
@@ -128,14 +128,22 @@ __device__ __forceinline__ void preint_update_body(PreIntD& P, const vieo_imu_no
     for (int j = 0; j < 3; j++) dRt[i * 3 + j] = dR[j * 3 + i];
   mm3(P.R, skewa, Rsk);
   double Ng[9], Na[9];
-  for (int i = 0; i < 9; i++) {
-    if (N.dt_cov_noise_fixed)
-      Ng[i] = N.sigma_g[i], Na[i] = N.sigma_a[i];
-    else if (!N.freq_ref || dt < 1.5 / N.freq_ref)
-      Ng[i] = N.sigma_g[i] / dt, Na[i] = N.sigma_a[i] / dt;
-    else
-      Ng[i] = N.sigma_g[i] * N.freq_ref, Na[i] = N.sigma_a[i] * N.freq_ref;
-  }
+  if (WAVE) {
+    // the step's noise matrices: entry e on lane e (the 18 divisions by dt were 18 x ~30 instructions on every lane),
+    // straight into the wavefront's LDS block, where preint_cov_wave reads them (ordered by its first wave_sync)
+    if (P.lane < 18) {
+      const double sg = P.sig[P.lane];
+      P.lds[81 + 81 + 81 + P.lane] = N.dt_cov_noise_fixed ? sg : (!N.freq_ref || dt < 1.5 / N.freq_ref) ? sg / dt : sg * N.freq_ref;
+    }
+  } else
+    for (int i = 0; i < 9; i++) {
+      if (N.dt_cov_noise_fixed)
+        Ng[i] = N.sigma_g[i], Na[i] = N.sigma_a[i];
+      else if (!N.freq_ref || dt < 1.5 / N.freq_ref)
+        Ng[i] = N.sigma_g[i] / dt, Na[i] = N.sigma_a[i] / dt;
+      else
+        Ng[i] = N.sigma_g[i] * N.freq_ref, Na[i] = N.sigma_a[i] * N.freq_ref;
+    }
   const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   for (int pass = 0; pass < 2; pass++) {  // mSigmaijPRV (p, Phi, v), then mSigmaij (p, v, Phi)
     const int iR = pass == 0 ? 3 : 6, iV = pass == 0 ? 6 : 3;
@@ -195,6 +203,8 @@ __device__ __forceinline__ void preint_update(PreIntD& P, const vieo_imu_noise& 
     preint_update_lane(P, N, omega, acc, dt);
 }
 
+static_assert(offsetof(vieo_imu_noise, sigma_a) == offsetof(vieo_imu_noise, sigma_g) + 9 * sizeof(double), "PreIntD::sig");
+
 template <bool WAVE>
 __global__ void __launch_bounds__(64)
 k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __restrict__ samples,
@@ -212,6 +222,7 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
   const double bg[3] = {bg_[3 * k], bg_[3 * k + 1], bg_[3 * k + 2]}, ba[3] = {ba_[3 * k], ba_[3 * k + 1], ba_[3 * k + 2]};
   PreIntD P;
   P.lane = threadIdx.x;
+  P.sig = noise->sigma_g;  // (sigma_a follows it in vieo_imu_noise)
   P.S = WAVE ? s_cov : S_priv, P.Sprv = WAVE ? s_cov + 81 : Sprv_priv, P.lds = s_cov + 162;
   for (int i = 0; i < 9; i++) P.R[i] = (i % 4) == 0 ? 1.0 : 0.0, P.JgR[i] = P.Jgv[i] = P.Jav[i] = P.Jgp[i] = P.Jap[i] = 0;
   for (int i = 0; i < 3; i++) P.v[i] = P.p[i] = 0;
