@@ -15,7 +15,7 @@ namespace vieo {
 struct PreIntD {
   double R[9], v[3], p[3], JgR[9], Jgv[9], Jav[9], Jgp[9], Jap[9], dt;
   double *S, *Sprv;  // 9 x 9 covariances: the lane's private arrays, or the wavefront's LDS (WAVE)
-  double* lds;       // WAVE: A[81] | T[81] | Bg[27] | Ba[27] | TB[27]
+  double* lds;       // WAVE: see preint_cov_wave
   int lane;
   const double* sig;  // WAVE: the 18 entries of sigma_g | sigma_a in global memory
 };
@@ -26,19 +26,25 @@ __device__ __forceinline__ void preint_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// the covariance step of one pass on a wavefront: entries e = lane, lane + 64 of every 9 x 9 result
-__device__ void preint_cov_wave(PreIntD& P, double* S, int iR, int iV, const double* dRt, const double* Rsk,
-                                const double* Jr, const double* Ng, const double* Na, double dt, double dt2div2) {
-  double* A = P.lds;
-  double* T = A + 81;
-  double* Bg = T + 81;
-  double* Ba = Bg + 27;
-  double* TB = Ba + 27;
-  double* NgL = TB + 27;  // the noise matrices in LDS: they are indexed by lane below
-  double* NaL = NgL + 9;
+// The covariance step on a wavefront, both orderings at once: m = 0 is mSigmaijPRV (p, Phi, v: iR = 3, iV = 6), m = 1
+// mSigmaij (p, v, Phi: iR = 6, iV = 3).  The two are independent, so every stage works on both between two
+// wave_syncs (8 ordering points per step instead of 16, the 2 x 81 entries of a stage in three rounds of 64 lanes
+// instead of four); each entry is the same sum in the same order as one pass after the other.
+// LDS block of matrix m at P.lds + m * kCovSet: A[81] | T[81] | Bg[27] | Ba[27] | TB[27]; the noise matrices
+// NgL[9] | NaL[9] behind both sets (written by the caller, entry e by lane e).
+static const int kCovSet = 81 + 81 + 27 * 3, kCovNoise = 2 * kCovSet;
+__device__ void preint_cov_wave(PreIntD& P, const double* dRt, const double* Rsk, const double* Jr, double dt, double dt2div2) {
   const int lane = P.lane;
-  for (int e = lane; e < 81; e += 64) A[e] = (e % 10) == 0 ? 1.0 : 0.0;
-  if (lane < 27) Bg[lane] = 0, Ba[lane] = 0;
+  const double* NgL = P.lds + kCovNoise;
+  for (int e2 = lane; e2 < 162; e2 += 64) {
+    const int m = e2 >= 81, e = e2 - 81 * m;
+    (P.lds + m * kCovSet)[e] = (e % 10) == 0 ? 1.0 : 0.0;
+  }
+  if (lane < 54) {
+    const int m = lane >= 27, l = lane - 27 * m;
+    double* Bg = P.lds + m * kCovSet + 162;
+    Bg[l] = 0, Bg[27 + l] = 0;
+  }
   preint_wave_sync();
   // lane e writes element e of the 3 x 3 blocks: compile-time element indices (dRt[lane] & co. would put the
   // arrays, which every lane holds in registers, into scratch memory)
@@ -46,23 +52,37 @@ __device__ void preint_cov_wave(PreIntD& P, double* S, int iR, int iV, const dou
   for (int e = 0; e < 9; e++)
     if (lane == e) {
       const int i = e / 3, j = e - 3 * i;
-      A[(iR + i) * 9 + iR + j] = dRt[e] * 1.0;
-      A[(iV + i) * 9 + iR + j] = Rsk[e] * -dt;
-      A[i * 9 + iR + j] = Rsk[e] * -dt2div2;
-      A[i * 9 + iV + j] = (i == j ? 1.0 : 0.0) * dt;
-      Bg[(iR + i) * 3 + j] = Jr[e] * dt;
-      Ba[(iV + i) * 3 + j] = P.R[e] * dt;
-      Ba[i * 3 + j] = P.R[e] * dt2div2;
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        const int iR = m == 0 ? 3 : 6, iV = m == 0 ? 6 : 3;
+        double* A = P.lds + m * kCovSet;
+        double* Bg = A + 162;
+        double* Ba = Bg + 27;
+        A[(iR + i) * 9 + iR + j] = dRt[e] * 1.0;
+        A[(iV + i) * 9 + iR + j] = Rsk[e] * -dt;
+        A[i * 9 + iR + j] = Rsk[e] * -dt2div2;
+        A[i * 9 + iV + j] = (i == j ? 1.0 : 0.0) * dt;
+        Bg[(iR + i) * 3 + j] = Jr[e] * dt;
+        Ba[(iV + i) * 3 + j] = P.R[e] * dt;
+        Ba[i * 3 + j] = P.R[e] * dt2div2;
+      }
     }
   preint_wave_sync();
-  for (int e = lane; e < 81; e += 64) {
+  for (int e2 = lane; e2 < 162; e2 += 64) {
+    const int m = e2 >= 81, e = e2 - 81 * m;
+    const double* A = P.lds + m * kCovSet;
+    const double* S = m == 0 ? P.Sprv : P.S;
     const int i = e / 9, j = e - 9 * i;
     double s = 0;
     for (int k = 0; k < 9; k++) s += A[i * 9 + k] * S[k * 9 + j];
-    T[e] = s;
+    (P.lds + m * kCovSet + 81)[e] = s;
   }
   preint_wave_sync();
-  for (int e = lane; e < 81; e += 64) {
+  for (int e2 = lane; e2 < 162; e2 += 64) {
+    const int m = e2 >= 81, e = e2 - 81 * m;
+    const double* A = P.lds + m * kCovSet;
+    const double* T = A + 81;
+    double* S = m == 0 ? P.Sprv : P.S;
     const int i = e / 9, j = e - 9 * i;
     double s = 0;
     for (int k = 0; k < 9; k++) s += T[i * 9 + k] * A[j * 9 + k];
@@ -70,14 +90,19 @@ __device__ void preint_cov_wave(PreIntD& P, double* S, int iR, int iV, const dou
   }
   preint_wave_sync();
   for (int which = 0; which < 2; which++) {  // S += Bg Ng Bg^T, then S += Ba Na Ba^T
-    const double* B = which ? Ba : Bg;
-    const double* N = which ? NaL : NgL;
-    if (lane < 27) {
-      const int i = lane / 3, j = lane - 3 * i;
-      TB[lane] = B[i * 3] * N[j] + B[i * 3 + 1] * N[3 + j] + B[i * 3 + 2] * N[6 + j];
+    const double* N = NgL + 9 * which;
+    if (lane < 54) {
+      const int m = lane >= 27, l = lane - 27 * m;
+      const double* B = P.lds + m * kCovSet + 162 + 27 * which;
+      const int i = l / 3, j = l - 3 * i;
+      (P.lds + m * kCovSet + 216)[l] = B[i * 3] * N[j] + B[i * 3 + 1] * N[3 + j] + B[i * 3 + 2] * N[6 + j];
     }
     preint_wave_sync();
-    for (int e = lane; e < 81; e += 64) {
+    for (int e2 = lane; e2 < 162; e2 += 64) {
+      const int m = e2 >= 81, e = e2 - 81 * m;
+      const double* B = P.lds + m * kCovSet + 162 + 27 * which;
+      const double* TB = P.lds + m * kCovSet + 216;
+      double* S = m == 0 ? P.Sprv : P.S;
       const int i = e / 9, j = e - 9 * i;
       S[e] += TB[i * 3] * B[j * 3] + TB[i * 3 + 1] * B[j * 3 + 1] + TB[i * 3 + 2] * B[j * 3 + 2];
     }
@@ -133,7 +158,7 @@ __device__ __forceinline__ void preint_update_body(PreIntD& P, const vieo_imu_no
     // straight into the wavefront's LDS block, where preint_cov_wave reads them (ordered by its first wave_sync)
     if (P.lane < 18) {
       const double sg = P.sig[P.lane];
-      P.lds[81 + 81 + 81 + P.lane] = N.dt_cov_noise_fixed ? sg : (!N.freq_ref || dt < 1.5 / N.freq_ref) ? sg / dt : sg * N.freq_ref;
+      P.lds[kCovNoise + P.lane] = N.dt_cov_noise_fixed ? sg : (!N.freq_ref || dt < 1.5 / N.freq_ref) ? sg / dt : sg * N.freq_ref;
     }
   } else
     for (int i = 0; i < 9; i++) {
@@ -145,12 +170,9 @@ __device__ __forceinline__ void preint_update_body(PreIntD& P, const vieo_imu_no
         Ng[i] = N.sigma_g[i] * N.freq_ref, Na[i] = N.sigma_a[i] * N.freq_ref;
     }
   const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  for (int pass = 0; pass < 2; pass++) {  // mSigmaijPRV (p, Phi, v), then mSigmaij (p, v, Phi)
+  if (WAVE) preint_cov_wave(P, dRt, Rsk, Jr, dt, dt2div2);
+  for (int pass = 0; pass < 2 && !WAVE; pass++) {  // mSigmaijPRV (p, Phi, v), then mSigmaij (p, v, Phi)
     const int iR = pass == 0 ? 3 : 6, iV = pass == 0 ? 6 : 3;
-    if (WAVE) {
-      preint_cov_wave(P, pass == 0 ? P.Sprv : P.S, iR, iV, dRt, Rsk, Jr, Ng, Na, dt, dt2div2);
-      continue;
-    }
     double A[81], Bg[27], Ba[27];
     for (int i = 0; i < 81; i++) A[i] = (i % 10) == 0 ? 1.0 : 0.0;
     for (int i = 0; i < 27; i++) Bg[i] = 0, Ba[i] = 0;
@@ -213,7 +235,7 @@ k_imu_preint(const vieo_imu_noise* __restrict__ noise, const vieo_imu_sample* __
              double* __restrict__ sigma_prv, int32_t* __restrict__ status) {
   const int k = WAVE ? blockIdx.x : blockIdx.x * 64 + threadIdx.x;
   if (k >= n) return;
-  __shared__ double s_cov[WAVE ? 2 * 81 + 81 + 81 + 27 * 3 + 18 : 1];
+  __shared__ double s_cov[WAVE ? 2 * 81 + 2 * kCovSet + 18 : 1];
   double S_priv[WAVE ? 1 : 81], Sprv_priv[WAVE ? 1 : 81];
   const vieo_imu_noise N = *noise;
   const vieo_imu_sample* L = samples + first[k];
