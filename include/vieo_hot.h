@@ -443,6 +443,39 @@ int vieo_search_by_projection_rig_batch_device(int mode, const vieo_proj_query* 
  * the grid is then not rebuilt -- TrackLocalMap's search after TrackWithIMU's in the one-call tracker.  One call only. */
 int vieo_sbp_keep_grid(int on);
 
+/* ---- the resident frame: the drop-in path's fast form (round 5) -------------------------------------------------
+ * The reference's callers reach this library one class member at a time -- Frame::Frame -> ExtractORB per camera thread
+ * (src/Frame.cc:259-278) -> ComputeStereoMatches (:451-611) -> ORBmatcher::SearchByProjection (src/Tracking.cc:296, :2599)
+ * -> Optimizer::PoseOptimization (:321,333) -- and every member's signature hands over host objects.  Nothing in those
+ * signatures says the data must travel: vieo_orb_extract LEAVES the image's keys, descriptors and pyramid in HBM, in the
+ * extractor handle the Frame already points at (mpORBextractors[c]), and the entries below read them there.  A call
+ * uploads only what the pointer graph forces (the last frame's map points, the window queries, the taken flags), runs on
+ * the handle's stream and returns behind ONE synchronisation; the frame's window grid (Frame::mGrid as a CSR) is built by
+ * its first search and kept for the later ones.  The shim decides per call with vieo_orb_holds whether the handle still
+ * holds the frame it was given (a Frame copied long ago does not: the host-pointer entries above serve it).
+ * Results are those of the host-pointer entries bit for bit (same kernels, same inputs). */
+/* 1 when the handle's resident frame is the one these keys describe (count + first / last eight keys compared with what
+ * the last vieo_orb_extract of this handle returned), else 0. */
+int vieo_orb_holds(const vieo_orb* e, const vieo_keypoint* h_keys, int n_keys);
+/* number of keys of the resident frame, -1: none */
+int vieo_orb_resident_keys(const vieo_orb* e);
+/* Frame::ComputeStereoMatches (src/Frame.cc:451-611) of the frame the two handles have just extracted.
+ * h_uright / h_depth [vieo_orb_resident_keys(left)]; uright also stays in the left handle for the searches. */
+int vieo_stereo_match_rectified_resident(vieo_orb* left, vieo_orb* right, float baseline, float bf,
+                                         float* h_uright, float* h_depth);
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono, th_far_pts)
+ * (src/ORBmatcher.cc:1303-1467) as one call: vieo_sbp_project_last_frame + vieo_search_by_projection(VIEO_SBP_LAST_FRAME)
+ * on the resident keys.  h_uright: NULL = the resident values of vieo_stereo_match_rectified_resident, else
+ * stereoinfo_.vuright_ of the frame.  h_assign [vieo_orb_resident_keys(frame)] as in vieo_search_by_projection. */
+int vieo_search_by_projection_last_frame_resident(vieo_orb* frame, const vieo_last_frame_point* h_points, int n_points,
+                                                  const vieo_sbp_camera* h_cam, const float* h_uright, float nn_ratio,
+                                                  int check_orientation, int32_t* h_assign, int32_t* nmatches);
+/* vieo_search_by_projection on the resident keys: the local-map overload (src/ORBmatcher.cc:230-335, queries from
+ * MapPoint::GetTrackInfoRef()) and the relocalisation overload (queries from vieo_sbp_project_keyframe). */
+int vieo_search_by_projection_resident(int mode, vieo_orb* frame, const vieo_proj_query* h_queries, int nq,
+                                       const float* h_uright, const uint8_t* h_taken, const float* h_bounds /*[4]*/,
+                                       float nn_ratio, int check_orientation, int32_t* h_assign, int32_t* nmatches);
+
 /* ---------------------------------------------------------------- pose optimisation --------
  * Replaces Optimizer::PoseOptimization (motion-only BA with fixed map points).  The host shim
  * flattens Frame / MapPoint objects into the POD structs below and writes the results back
@@ -1204,6 +1237,24 @@ int vieo_tracker_image_buffers(vieo_tracker* t, uint8_t** left, uint8_t** right)
 int vieo_tracker_image_buffer(vieo_tracker* t, int image_index, uint8_t** plane);
 int vieo_tracker_scale_factors(const vieo_tracker* t, float* h_out /*[n_levels]*/);
 int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_output* out);
+/* What the tracker knows about its two streams and its replicated optimisations.  A tracker runs its frame on two HIP
+ * streams (pre-integration, a rig frame's stereo bookkeeping and the copies back beside the extraction); they overlap only
+ * when the runtime serves them from different hardware queues, which it decides from the streams the PROCESS holds.  The
+ * second stream is therefore chosen by measurement at creation, the measured figure is kept here, and the choice is made
+ * again -- vieo_tracker_reprobe, or by the tracker itself when eight frames in a row take 30 % more GPU time than the
+ * running median of the last 32 -- when streams created later have changed the mapping. */
+typedef struct vieo_tracker_stats {
+  float side_stream_ratio;        /* elapsed(two ~40 us spin kernels started together, one per stream) / elapsed(one):
+                                   * ~1 = side by side, ~2 = one hardware queue; > 1.35: no better stream was to be had */
+  int32_t side_stream_selections; /* times a second stream was chosen (1 = at creation only) */
+  int32_t side_stream_checks;     /* times the ratio was measured again */
+  int32_t replica_repeats;        /* rig frames whose optimisations were repeated on one workgroup because a replica
+                                   * workgroup never became resident (vieo_pose_set_replicas) */
+  float ms_gpu_median;            /* running median of vieo_track_output.ms_gpu (last 32 frames) */
+  int32_t slow_frames_in_a_row;   /* frames in a row above 1.3 x that median */
+} vieo_tracker_stats;
+int vieo_tracker_get_stats(const vieo_tracker* t, vieo_tracker_stats* out);
+int vieo_tracker_reprobe(vieo_tracker* t);
 /* mvImagePyramid of the frame just tracked, lazily (only Frame::ComputeStereoMatches reads it, src/Frame.cc:457,536-557,
  * and that ran on the device): image 0 = left, 1 = right; see vieo_orb_get_level */
 int vieo_tracker_get_level(vieo_tracker* t, int image_index, int level, int with_border, uint8_t* h_dst, int dst_stride);

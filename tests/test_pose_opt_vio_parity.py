@@ -236,6 +236,34 @@ def test_vio_rig_replicas_repeated_launches_and_small_batches(oracle):
             assert np.array_equal(outl[b0:b0 + len(o0)], o0)
 
 
+def test_vio_rig_replica_that_never_arrives_degrades_to_one_workgroup(oracle, monkeypatch):
+    """A replica workgroup that does not become resident (VIEO_POSE_REPLICA_DROP: replica 5 returns at once, as on a device
+    another process fills) must cost ONE time-out, not one per exchange, and must not cost the frame: the waiting replicas
+    poison their slots and finish, the host entry repeats the optimisation on one workgroup and returns its result."""
+    import time
+    from vieo_slam_amd.optimizer import Optimizer
+    rig = synth_ba.camera_rig("kb8")
+    F, obs, _ = synth_ba.make_vio_problem(410, n_obs=1800, compute_marg=True, rig=rig)
+    L = lib()
+    was = L.vieo_pose_set_replicas(0)
+    try:
+        h1, o1 = Optimizer.PoseOptimizationVIO(F, obs)
+        L.vieo_pose_set_replicas(1)
+        h16, o16 = Optimizer.PoseOptimizationVIO(F, obs)
+        monkeypatch.setenv("VIEO_POSE_REPLICA_DROP", "1")
+        t0 = time.perf_counter()
+        hd, od = Optimizer.PoseOptimizationVIO(F, obs)
+        dt_fail = time.perf_counter() - t0
+        monkeypatch.delenv("VIEO_POSE_REPLICA_DROP")
+        h16b, o16b = Optimizer.PoseOptimizationVIO(F, obs)  # the records are usable again (the poison carries the launch number)
+    finally:
+        L.vieo_pose_set_replicas(was)
+    assert hd["base"]["status"] == 0 and hd.tobytes() == h1.tobytes() and np.array_equal(od, o1)
+    assert h16b.tobytes() == h16.tobytes() and np.array_equal(o16b, o16)
+    assert dt_fail < 5.0, dt_fail  # one time-out (~0.5 s), not ~36
+    print("replica drop: the frame came back after %.2f s on one workgroup" % dt_fail)
+
+
 @pytest.mark.parametrize("seed,n,kw", [(80, 300, dict(compute_marg=True)), (81, 60, dict(compute_marg=True, noise=2.0)),
                                        (82, 200, dict(imu=False, compute_marg=True)),
                                        (83, 40, dict(outlier_frac=0.5, compute_marg=True)),

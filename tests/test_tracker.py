@@ -253,3 +253,49 @@ def test_gpu_three_host_threads_concurrently(oracle):
     assert got[0] == alone[0], "the tracked trajectory changed under concurrent local mapping / fusing"
     assert got[1] == alone[1] and got[2] == alone[2]
     assert all(x == alone[1][0] for x in got[1]) and all(x == alone[2][0] for x in got[2])
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_second_stream_is_measured_reported_and_reselected():
+    """The tracker's second stream overlaps the first only when the runtime serves them from different hardware queues.
+    vieo_tracker_get_stats reports the overlap ratio measured when the stream was chosen; streams the process creates (and
+    uses) AFTER the tracker must not slow the frame down -- the frame time is asserted -- and vieo_tracker_reprobe measures
+    again and re-selects when the streams have come to share a queue."""
+    import ctypes
+    from vieo_slam_amd._lib import check, lib
+    from vieo_slam_amd.tracker import TrackerReplay
+    n = 44
+    seq = replay.Sequence(3, n)
+    R = TrackerReplay(seq, replay.HipStages())
+    st0 = R.trk.stats()
+    assert st0["side_stream_selections"] == 1 and 0.5 < st0["side_stream_ratio"] < 2.6, st0
+    R.initialise()
+    for k in range(1, 22):
+        R.before_frame(k), R.step(k)
+    base = float(np.median([g for _, g in R.stats["ms_chain"][8:]]))
+    # eight streams created and used after the tracker (a LocalMapping thread's BA stream, a viewer, a second tracker ...)
+    L = lib()
+    streams = []
+    buf = ctypes.c_void_p()
+    check(L.vieo_dev_malloc(ctypes.byref(buf), 1 << 20))
+    host = np.zeros(1 << 20, np.uint8)
+    for _ in range(8):
+        s = ctypes.c_void_p()
+        check(L.vieo_stream_create(ctypes.byref(s)))
+        check(L.vieo_memcpy_h2d_async(buf, host.ctypes.data, host.nbytes, s))
+        check(L.vieo_stream_synchronize(s))
+        streams.append(s)
+    n_before = len(R.stats["ms_chain"])
+    for k in range(22, n):
+        R.before_frame(k), R.step(k)
+    after = float(np.median([g for _, g in R.stats["ms_chain"][n_before:]]))
+    st1 = R.trk.reprobe()
+    assert st1["side_stream_checks"] >= 1 and st1["ms_gpu_median"] > 0
+    assert st1["side_stream_ratio"] < 1.6, st1          # the two streams run side by side (after a re-selection if needed)
+    assert after <= 1.25 * base + 0.05, (base, after, st0, st1)
+    print("tracker streams: ratio %.2f at creation, %.2f after 8 later streams (%d selections, %d checks); GPU ms per frame %.3f -> %.3f"
+          % (st0["side_stream_ratio"], st1["side_stream_ratio"], st1["side_stream_selections"], st1["side_stream_checks"], base, after))
+    for s in streams:
+        L.vieo_stream_destroy(s)
+    L.vieo_dev_free(buf)
+    R.close()

@@ -120,3 +120,51 @@ def test_gpu_rig_tracker_edge_cases(monkeypatch):
                      none_c, np.zeros((0, 32), np.uint8), np.zeros(0, np.int32), 1, images=case["images1"])
     assert int(o["stereo_status"]) != 0 and int(o["n_groups"]) == 0 and (v["depth"] < 0).all() and int(o["n_keys"]) == fr.N
     trk.close()
+
+
+@pytest.mark.gpu
+def test_gpu_rig_tracker_repeats_the_frame_when_a_replica_never_arrives(monkeypatch):
+    """The two optimisations of a rig frame run on 16 replica workgroups each; one that never becomes resident
+    (VIEO_POSE_REPLICA_DROP) used to fail the frame with VIEO_E_HIP after one time-out per exchange.  Now the waiting
+    replicas give up once, and the tracker repeats the tail of the chain with one workgroup per optimisation: the frame is
+    late, not lost, and carries the one-workgroup result."""
+    import time
+    from vieo_slam_amd._lib import lib
+    from vieo_slam_amd.pipeline_rig import RigFrontEnd
+    from vieo_slam_amd.tracker import Tracker, rig_params
+    seed, rig, nc, nfeat = 5, "kb8", 4, 1500
+    scene = sc.RigScene(seed, rig, nc)
+    case = sc.make_rig_tracking_case(seed, scene)
+    fe = RigFrontEnd(scene, nfeat)
+    fr0 = fe.make_frame(case["images0"])
+    Ri, pi, Rwc0, twc0 = case["pose0"]
+    mps = fe.make_map_points(fr0, Rwc0, twc0)
+    pts, last_depth, z, P, alias = _tracker_inputs(fe, fr0, mps, case)
+    prm, rg = rig_params(scene, nfeat, max_local_points=len(P) + 10, th_depth=float(case["vio"][0]["th_depth"]))
+    nav_i = case["vio"][0]["nav_last"]
+    args = (None, None, case["imu_samples"], 0.0, case["dt_frame"], nav_i, nav_i, None, pts, last_depth, P, mps["desc"], alias, 1)
+    L = lib()
+    was = L.vieo_pose_set_replicas(0)
+    try:
+        trk = Tracker(prm, rg)
+        o1, v1 = trk.track(*args, images=case["images1"])
+        one = (o1["first"].tobytes(), o1["second"].tobytes(), v1["point_ref"].copy(), v1["outlier"].copy())
+        L.vieo_pose_set_replicas(1)
+        monkeypatch.setenv("VIEO_POSE_REPLICA_DROP", "1")
+        t0 = time.perf_counter()
+        od, vd = trk.track(*args, images=case["images1"])
+        dt_fail = time.perf_counter() - t0
+        monkeypatch.delenv("VIEO_POSE_REPLICA_DROP")
+        st = trk.stats()
+        assert int(od["status"]) == 0 and int(od["first"]["base"]["status"]) == 0 and int(od["second"]["base"]["status"]) == 0
+        assert (od["first"].tobytes(), od["second"].tobytes()) == one[:2]
+        assert np.array_equal(vd["point_ref"], one[2]) and np.array_equal(vd["outlier"], one[3])
+        assert st["replica_repeats"] == 1 and dt_fail < 5.0, (st, dt_fail)
+        o16, v16 = trk.track(*args, images=case["images1"])  # and the replicated form works again right after
+        assert int(o16["second"]["base"]["status"]) == 0 and trk.stats()["replica_repeats"] == 1
+        dt, dr = synth_ba.pose_error(o16["second"]["base"]["nav"], o1["second"]["base"]["nav"])
+        assert dt < 1e-9 and dr < 1e-7
+        trk.close()
+    finally:
+        L.vieo_pose_set_replicas(was)
+    print("rig tracker, replica dropped: frame back after %.2f s" % dt_fail)

@@ -107,6 +107,11 @@ _SIGS = {
     "vieo_sbp_project_keyframe": (c_i, [c_p, c_i, c_p, c_p, c_f, c_p]),
     "vieo_search_by_projection_rig": (c_i, [c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_i, c_p, c_p]),
     "vieo_sbp_keep_grid": (c_i, [c_i]),
+    "vieo_orb_holds": (c_i, [c_p, c_p, c_i]),
+    "vieo_orb_resident_keys": (c_i, [c_p]),
+    "vieo_stereo_match_rectified_resident": (c_i, [c_p, c_p, c_f, c_f, c_p, c_p]),
+    "vieo_search_by_projection_last_frame_resident": (c_i, [c_p, c_p, c_i, c_p, c_p, c_f, c_i, c_p, c_p]),
+    "vieo_search_by_projection_resident": (c_i, [c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_p]),
     "vieo_sbp_project_last_frame_rig_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
     "vieo_search_by_projection_rig_batch_device": (c_i, [c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i,
                                                           c_f, c_i, c_p, c_p, c_p]),
@@ -159,6 +164,8 @@ _SIGS = {
     "vieo_tracker_image_buffers": (c_i, [c_p, P(c_p), P(c_p)]),
     "vieo_tracker_scale_factors": (c_i, [c_p, c_p]),
     "vieo_track_frame": (c_i, [c_p, c_p, c_p]),
+    "vieo_tracker_get_stats": (c_i, [c_p, c_p]),
+    "vieo_tracker_reprobe": (c_i, [c_p]),
     "vieo_tracker_get_level": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i]),
 }
 

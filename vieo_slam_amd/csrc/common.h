@@ -71,6 +71,10 @@ struct PinnedBuf {
     cap = bytes;
     return VIEO_OK;
   }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+  }
 };
 
 // Several host arrays -> one pinned block -> one device block: ONE asynchronous copy up and one back per call.  The

@@ -558,6 +558,50 @@ int vieo_stereo_match_rectified(vieo_orb* left, vieo_orb* right, const vieo_keyp
   return VIEO_OK;
 }
 
+// Frame::ComputeStereoMatches (Frame.cc:451-611) of the frame the two handles have just extracted: keys, descriptors
+// and pyramids are read where vieo_orb_extract left them, nothing goes up; uright / depth come back in one block and
+// uright stays in the left handle for the frame's projection searches.
+int vieo_stereo_match_rectified_resident(vieo_orb* left, vieo_orb* right, float baseline, float bf, float* h_uright,
+                                         float* h_depth) {
+  if (!left || !right || !h_uright || !h_depth || !(baseline > 0) || !(bf > 0)) return VIEO_E_INVALID;
+  if (left->res_n < 0 || right->res_n < 0) {
+    set_error("vieo_stereo_match_rectified_resident: a handle holds no frame (vieo_orb_extract first)");
+    return VIEO_E_INVALID;
+  }
+  if (left->last_B < 1 || right->last_B < 1 || !same_geometry(left, right)) {
+    set_error("vieo_stereo_match_rectified_resident: both extractors must have processed equally sized images");
+    return VIEO_E_INVALID;
+  }
+  const int nL = left->res_n, capL = vieo_orb_max_keypoints(left), capR = vieo_orb_max_keypoints(right);
+  int rc;
+  if ((rc = left->d_uright.ensure((size_t)capL * 4)) != VIEO_OK || (rc = left->d_depth.ensure((size_t)capL * 4)) != VIEO_OK ||
+      (rc = left->d_sad.ensure((size_t)capL * 4)) != VIEO_OK || (rc = left->h_io.ensure((size_t)capL * 8)) != VIEO_OK)
+    return rc;
+  left->uright_epoch = left->epoch;
+  if (nL == 0) return VIEO_OK;
+  hipStream_t st = left->stream;
+  VIEO_HIP_CHECK(hipStreamSynchronize(right->stream));  // (its extraction returned synchronised: a formality)
+  StereoArgs A;
+  A.P = left->P;
+  A.IL = left->last_imgs;
+  A.IR = right->last_imgs;
+  A.l_first = 0, A.l_step = 0, A.r_first = 0, A.r_step = 0;
+  A.kpL = left->d_kp.as<vieo_keypoint>(), A.kpR = right->d_kp.as<vieo_keypoint>();
+  A.descL = left->d_desc.as<uint8_t>(), A.descR = right->d_desc.as<uint8_t>();
+  A.cntL = left->d_counts.as<int>(), A.cntR = right->d_counts.as<int>();
+  A.capL = capL, A.capR = capR;
+  A.baseline = baseline, A.bf = bf;
+  A.uright = left->d_uright.as<float>(), A.depth = left->d_depth.as<float>(), A.sad = left->d_sad.as<int>();
+  if ((rc = launch_stereo(A, 1, st)) != VIEO_OK) return rc;
+  float* H = (float*)left->h_io.p;
+  VIEO_HIP_CHECK(hipMemcpyAsync(H, left->d_uright.p, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+  VIEO_HIP_CHECK(hipMemcpyAsync(H + capL, left->d_depth.p, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+  VIEO_HIP_CHECK(hipStreamSynchronize(st));
+  memcpy(h_uright, H, (size_t)nL * 4);
+  memcpy(h_depth, H + capL, (size_t)nL * 4);
+  return VIEO_OK;
+}
+
 int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* h_counts,
                                    int capacity, const int32_t* h_pairs, int n_pairs,
                                    int32_t* d_idx, int32_t* d_dist, void* stream) {

@@ -1266,9 +1266,10 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
     };
     int la = 0;
     // (a few images: latency, a workgroup's passes over its keys on more threads; a batch: four workgroups per CU)
-    static const int qt_env = [] {
+    static const int qt_env = [] {  // (k_quadtree's launch bound is 1024; whole wavefronts)
       const char* e = getenv("VIEO_QT_THREADS");
-      return e ? atoi(e) : 0;
+      const int v = e ? atoi(e) : 0;
+      return v > 0 ? std::min(std::max(v / 64 * 64, 64), 1024) : 0;
     }();
     const int qt_threads = qt_env > 0 ? qt_env : (B <= 16 ? 512 : 256);
     for (size_t gi = 0; gi < n_bounds && la < P.nlevels; gi++) {
@@ -1318,6 +1319,19 @@ extern "C" {
 
 int vieo_orb_create(vieo_orb** out, int nfeatures, float scale_factor, int nlevels, int ini_th,
                     int min_th) {
+  // VIEO_ORB_PRIORITY=1: the extractor's (= the frame pipeline's) stream at the highest priority (A/B runs)
+  const char* pe = getenv("VIEO_ORB_PRIORITY");
+  return vieo::orb_create_with_priority(out, nfeatures, scale_factor, nlevels, ini_th, min_th, pe && atoi(pe) > 0 ? 1 : 0);
+}
+
+}  // extern "C"
+
+// priority 1: the handle's stream comes from the runtime's HIGH-priority queues.  The runtime keeps one pool of hardware
+// queues per priority level, so streams of different priority never share a queue: the one-call tracker puts its main
+// stream there, its second stream at the normal level and the bundle adjustment runs at the lowest -- three chains that
+// cannot end up in series behind each other whatever other streams the process holds.
+int vieo::orb_create_with_priority(vieo_orb** out, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
+                                   int priority) {
   if (!out || nfeatures <= 0 || nlevels <= 0 || nlevels > kMaxLevels || !(scale_factor > 1.0f)) {
     set_error("vieo_orb_create: invalid arguments");
     return VIEO_E_INVALID;
@@ -1370,10 +1384,9 @@ int vieo_orb_create(vieo_orb** out, int nfeatures, float scale_factor, int nleve
     }
   }
   hipError_t he;
-  {  // VIEO_ORB_PRIORITY=1: the extractor's (= the frame pipeline's) stream at the highest priority (A/B runs)
-    const char* pe = getenv("VIEO_ORB_PRIORITY");
+  {
     int lo = 0, hi = 0;
-    if (pe && atoi(pe) > 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+    if (priority > 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
       he = hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, hi);
     else
       he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -1406,6 +1419,8 @@ int vieo_orb_create(vieo_orb** out, int nfeatures, float scale_factor, int nleve
   return VIEO_OK;
 }
 
+extern "C" {
+
 void vieo_orb_destroy(vieo_orb* e) {
   if (!e) return;
   (void)hipStreamSynchronize(e->stream);
@@ -1413,8 +1428,10 @@ void vieo_orb_destroy(vieo_orb* e) {
                     &e->d_ytab,  &e->d_cell_keys, &e->d_cell_counts, &e->d_keys,    &e->d_kslot,
                     &e->d_kq,    &e->d_sel,       &e->d_sel_count, &e->d_pattern,   &e->d_in,
                     &e->d_kp,    &e->d_desc,      &e->d_counts,   &e->d_tmp_kp,     &e->d_tmp_desc,
-                    &e->d_tmp_counts};
+                    &e->d_tmp_counts, &e->d_krec,  &e->d_io,       &e->d_uright,     &e->d_depth,
+                    &e->d_sad,   &e->g_start,     &e->g_rec,      &e->g_ang};
   for (DevBuf* b : bufs) b->release();
+  e->h_in.release(), e->h_res.release(), e->h_io.release();
   for (auto& set : e->tm.ev)
     for (auto& ev : set)
       if (ev) (void)hipEventDestroy(ev);
@@ -1483,38 +1500,72 @@ int vieo_orb_extract(vieo_orb* e, const uint8_t* h_image, int width, int height,
                      int capacity, int* n_keypoints, int* mono_index) {
   if (!e || !n_keypoints) return VIEO_E_INVALID;
   if (!h_image || width <= 0 || height <= 0) return VIEO_E_EMPTY;  // ORBextractor.cc:970
+  if (stride < width) return VIEO_E_INVALID;
   int rc;
   const int pitch = align_up(width, 16);
   const int cap = vieo_orb_max_keypoints(e);
+  e->res_n = -1;  // (whatever happens below, the handle no longer holds the previous frame)
+  e->epoch++;
   if ((rc = e->d_in.ensure((size_t)pitch * height)) != VIEO_OK) return rc;
   if ((rc = e->d_kp.ensure((size_t)cap * sizeof(vieo_keypoint))) != VIEO_OK) return rc;
   if ((rc = e->d_desc.ensure((size_t)cap * 32)) != VIEO_OK) return rc;
   if ((rc = e->d_counts.ensure(8)) != VIEO_OK) return rc;
-  VIEO_HIP_CHECK(hipMemcpy2DAsync(e->d_in.p, pitch, h_image, stride, width, height,
-                                  hipMemcpyHostToDevice, e->stream));
+  // The image goes up through the handle's own pinned plane (a pageable source makes the runtime stage it in chunks, with
+  // a synchronisation per chunk), and counts | keys | descriptors come back as ONE block behind ONE synchronisation
+  // (round 4: the counts first, a synchronisation, then the two arrays and another).
+  const size_t o_kp = 256, o_desc = o_kp + align_up_sz((size_t)cap * sizeof(vieo_keypoint), 256);
+  if ((rc = e->h_in.ensure((size_t)pitch * height)) != VIEO_OK) return rc;
+  if ((rc = e->h_res.ensure(o_desc + (size_t)cap * 32)) != VIEO_OK) return rc;
+  {
+    uint8_t* dst = (uint8_t*)e->h_in.p;
+    if (stride == pitch)
+      memcpy(dst, h_image, (size_t)pitch * (height - 1) + width);
+    else
+      for (int y = 0; y < height; y++) memcpy(dst + (size_t)y * pitch, h_image + (size_t)y * stride, width);
+  }
+  VIEO_HIP_CHECK(hipMemcpyAsync(e->d_in.p, e->h_in.p, (size_t)pitch * height, hipMemcpyHostToDevice, e->stream));
   rc = run_batch(e, e->d_in.as<uint8_t>(), 1, width, height, pitch, (size_t)pitch * height,
                  h_lapping, e->d_kp.as<vieo_keypoint>(), e->d_desc.as<uint8_t>(), cap,
                  e->d_counts.as<int32_t>());
   if (rc != VIEO_OK) return rc;
-  int cnt[2];
-  VIEO_HIP_CHECK(hipMemcpyAsync(cnt, e->d_counts.p, 8, hipMemcpyDeviceToHost, e->stream));
+  uint8_t* R = (uint8_t*)e->h_res.p;
+  VIEO_HIP_CHECK(hipMemcpyAsync(R, e->d_counts.p, 8, hipMemcpyDeviceToHost, e->stream));
+  VIEO_HIP_CHECK(hipMemcpyAsync(R + o_kp, e->d_kp.p, (size_t)cap * sizeof(vieo_keypoint), hipMemcpyDeviceToHost, e->stream));
+  VIEO_HIP_CHECK(hipMemcpyAsync(R + o_desc, e->d_desc.p, (size_t)cap * 32, hipMemcpyDeviceToHost, e->stream));
   VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));
-  *n_keypoints = cnt[0];
+  const int* cnt = (const int*)R;
+  const int n = cnt[0];
+  *n_keypoints = n;
   if (mono_index) *mono_index = cnt[1];
-  if (cnt[0] > capacity) {
-    set_error("vieo_orb_extract: %d keypoints, capacity %d", cnt[0], capacity);
+  if (n > capacity || n > cap) {
+    set_error("vieo_orb_extract: %d keypoints, capacity %d", n, std::min(capacity, cap));
     return VIEO_E_CAPACITY;
   }
-  if (cnt[0] > 0) {
+  if (n > 0) {
     if (!h_keypoints || !h_descriptors) return VIEO_E_INVALID;
-    VIEO_HIP_CHECK(hipMemcpyAsync(h_keypoints, e->d_kp.p, (size_t)cnt[0] * sizeof(vieo_keypoint),
-                                  hipMemcpyDeviceToHost, e->stream));
-    VIEO_HIP_CHECK(hipMemcpyAsync(h_descriptors, e->d_desc.p, (size_t)cnt[0] * 32,
-                                  hipMemcpyDeviceToHost, e->stream));
-    VIEO_HIP_CHECK(hipStreamSynchronize(e->stream));
+    memcpy(h_keypoints, R + o_kp, (size_t)n * sizeof(vieo_keypoint));
+    memcpy(h_descriptors, R + o_desc, (size_t)n * 32);
   }
+  // the frame stays resident: its identity = the count and the first / last eight keys
+  const vieo_keypoint* K = (const vieo_keypoint*)(R + o_kp);
+  memset(e->res_sample, 0, sizeof(e->res_sample));
+  for (int i = 0; i < std::min(n, 8); i++) e->res_sample[i] = K[i], e->res_sample[8 + i] = K[n - 1 - i];
+  e->res_n = n, e->res_mono = cnt[1];
   return VIEO_OK;
 }
+
+// Does the handle still hold THESE keys (the frame a Frame object describes)?  The count and the first / last eight
+// keys are compared with what the last vieo_orb_extract returned: 1 = yes, the *_resident entries may be used for it.
+int vieo_orb_holds(const vieo_orb* e, const vieo_keypoint* h_keys, int n_keys) {
+  if (!e || e->res_n < 0 || n_keys != e->res_n || (n_keys > 0 && !h_keys)) return 0;
+  for (int i = 0; i < std::min(n_keys, 8); i++)
+    if (memcmp(&h_keys[i], &e->res_sample[i], sizeof(vieo_keypoint)) ||
+        memcmp(&h_keys[n_keys - 1 - i], &e->res_sample[8 + i], sizeof(vieo_keypoint)))
+      return 0;
+  return 1;
+}
+
+int vieo_orb_resident_keys(const vieo_orb* e) { return e ? e->res_n : -1; }
 
 int vieo_orb_level_size(const vieo_orb* e, int level, int* width, int* height) {
   if (!e || level < 0 || level >= e->nlevels || e->w == 0) return VIEO_E_INVALID;

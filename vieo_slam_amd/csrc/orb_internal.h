@@ -72,6 +72,8 @@ struct Timing {
   long steps = 0;  // batch calls stamped since timing was enabled
 };
 
+int orb_create_with_priority(vieo_orb** out, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int priority);
+
 }  // namespace vieo
 
 struct vieo_orb {  // global-scope tag declared in include/vieo_hot.h
@@ -96,5 +98,18 @@ struct vieo_orb {  // global-scope tag declared in include/vieo_hot.h
   int last_B = 0;
   vieo::ImgSet last_imgs{};
   vieo::Timing tm;
+  // ---- the resident frame (round 5).  vieo_orb_extract leaves the image's keys, descriptors and pyramid in HBM; the
+  // *_resident entries (stereo matcher, projection searches) read them there instead of taking them back from the host:
+  // Frame::Frame -> ComputeStereoMatches -> SearchByProjection x 2 of one frame upload only what the pointer graph forces
+  // (last-frame points, window queries, taken flags).  `epoch` counts the host-API extractions of this handle.
+  vieo::PinnedBuf h_in, h_res, h_io;  // pinned staging: the image up, counts | keys | descriptors back, small call blocks
+  vieo::DevBuf d_io;                  // device twin of h_io
+  unsigned long long epoch = 0;
+  int res_n = -1, res_mono = 0;       // keys of the resident frame (-1: none)
+  vieo_keypoint res_sample[16];       // its first 8 / last 8 keys: the identity test of vieo_orb_holds
+  vieo::DevBuf d_uright, d_depth, d_sad;  // written by vieo_stereo_match_rectified_resident (uright: read by the searches)
+  unsigned long long uright_epoch = ~0ull;
+  vieo::DevBuf g_start, g_rec, g_ang;  // Frame::mGrid as a CSR, built by the frame's first resident search
+  unsigned long long grid_epoch = ~0ull;
 };
 

@@ -325,14 +325,23 @@ __device__ unsigned long long g_pose_probe[24];
 // (28 per linearisation, 1 per trial, 1 per classification) the replicas exchange their partial sums through this record
 // and add them in the same order.  No master, no commands: a workgroup only ever waits for the others to arrive.
 // Protocol (MI355X: the per-XCD L2s are not coherent, a CU's L1 is never refreshed by another CU's stores): every
-// partial sum travels as ONE 16-byte granule (value, tag) written with a system-coherent store and read with
-// system-coherent loads (`sc0 sc1` on both sides: no fence, no counter); tag = (launch number << 32) | exchange number,
-// so a granule is its own "ready" flag and nothing has to be cleared between launches.  A thread publishes its value,
-// then polls the kXG granules of its index until all carry the tag, and adds them in replica order.  Granules are
+// partial sum travels as ONE 16-byte granule written with a system-coherent store and read with system-coherent loads
+// (`sc0 sc1` on both sides: no fence, no counter).  The granule is two 8-byte halves, each (32 value bits, 32-bit tag),
+// tag = (launch number & 0xFFFFF) << 12 | exchange number: a granule counts as arrived only when BOTH halves carry the
+// tag, so the protocol needs single-copy atomicity of aligned 8-byte stores only -- a 16-byte store that reached memory
+// as two halves shows a stale tag in one of them and is polled again, never read as (fresh tag, stale value).  A granule
+// is its own "ready" flag and nothing is cleared between launches (a slot is rewritten by every launch, so the stale
+// tags a poll can meet are the previous launch's: 20 bits of launch number tell them apart).  A thread publishes its
+// value, then polls the kXG granules of its index until all carry the tag, and adds them in replica order.  Granules are
 // double-buffered by the parity of the exchange (a fast replica may be one exchange ahead, never two: it needs every
-// replica's granule of this exchange before it can leave it).  First form of this exchange -- atomic stores, an arrival
-// counter, polls, atomic loads, three barriers -- cost ~7 us per exchange; this one ~3.
+// replica's granule of this exchange before it can leave it).  A replica that waits in vain (its peers are not
+// resident: another process fills the device) gives up after kXchgSpins polls, POISONS its slots -- tag field all ones
+// under the launch number -- and finishes without exchanging; a replica that meets a poisoned granule does the same at
+// once, so a failed launch costs one time-out, not one per exchange, and the host repeats the frame on one workgroup.
+// First form of this exchange -- atomic stores, an arrival counter, polls, atomic loads, three barriers -- cost ~7 us per
+// exchange; this one ~3.
 constexpr int kXG = 16;
+constexpr int kXchgSpins = 1 << 18;  // polls (each 16 loads in flight + a short sleep: ~0.5 s in all) before a replica gives up
 typedef unsigned long long xq_t __attribute__((ext_vector_type(2)));
 struct PoseXchg {
   xq_t cell[2][kXG][32];
@@ -523,33 +532,52 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   // v[0 .. n) in LDS, complete and visible (a barrier has passed) -> the sums over the replicas, in every replica
   auto grid_sum = [&](double* v, int n) {
     if (G == 1) return;
+    if (S.xfail) return;  // (uniform: set before a barrier below) the launch has failed, the host repeats the frame
     if (tid < n) {
-      const unsigned long long tag = ((unsigned long long)launch_id << 32) | (unsigned)(epoch + 1);
+      const unsigned tag = ((launch_id & 0xFFFFFu) << 12) | (unsigned)((epoch + 1) & 0xFFF);
+      const unsigned poison = ((launch_id & 0xFFFFFu) << 12) | 0xFFFu;  // (an exchange number never reaches 0xFFF)
       xq_t* cells = &xb->cell[epoch & 1][0][tid];  // replica q's granule: cells + 32 q
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(v[tid]);
       xq_t mine;
-      mine.x = (unsigned long long)__double_as_longlong(v[tid]), mine.y = tag;
+      mine.x = (bits & 0xFFFFFFFFull) | ((unsigned long long)tag << 32), mine.y = (bits >> 32) | ((unsigned long long)tag << 32);
       xq_store(cells + 32 * g, mine);
       xq_t in[kXG];
       int spins = 0;
+      bool failed = false;
       for (;;) {
         xq_load_all(cells, in);
         bool all = true;
 #pragma unroll
-        for (int q = 0; q < kXG; q++) all = all && in[q].y == tag;
-        if (all) break;
-        if (++spins > (1 << 21)) {  // seconds: a replica is not coming (never on a healthy launch); fail, do not hang
-          S.xfail = 1;
+        for (int q = 0; q < kXG; q++) {
+          const unsigned tx = (unsigned)(in[q].x >> 32), ty = (unsigned)(in[q].y >> 32);
+          all = all && tx == tag && ty == tag;
+          failed = failed || tx == poison || ty == poison;
+        }
+        if (all && !failed) break;
+        if (failed || ++spins > kXchgSpins || epoch >= 0xFF0) {  // a peer gave up / is not coming: fail, do not hang
+          failed = true;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      double t = 0;
+      if (failed) {
+        S.xfail = 1;
+      } else {
+        double t = 0;
 #pragma unroll
-      for (int q = 0; q < kXG; q++) t += __longlong_as_double((long long)in[q].x);  // replica order: the same sum everywhere
-      v[tid] = t;
+        for (int q = 0; q < kXG; q++)  // replica order: the same sum everywhere
+          t += __longlong_as_double((long long)((in[q].x & 0xFFFFFFFFull) | (in[q].y << 32)));
+        v[tid] = t;
+      }
     }
     epoch++;
     __syncthreads();
+    if (S.xfail && tid < 64) {  // tell the peers: every slot of this replica, both parities
+      const unsigned long long pz = (unsigned long long)(((launch_id & 0xFFFFFu) << 12) | 0xFFFu) << 32;
+      xq_t pq;
+      pq.x = pz, pq.y = pz;
+      xq_store(&xb->cell[tid >> 5][g][tid & 31], pq);
+    }
   };
   unsigned long long levelmask = 0;
   bool vis_robust = true;
@@ -1199,6 +1227,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     // (ONE call site per instance of the body: called from two it stays out of line, and its by-reference captures --
     // every local above -- then live in scratch memory: 4-camera frame 2.8 -> 3.3 ms.)
     bool rep = gridDim.y == (unsigned)kXG && xchg != nullptr;
+    // (test hook, VIEO_POSE_REPLICA_DROP=1: bit 31 of the launch number makes replica 5 stay away, as a workgroup that
+    // never becomes resident would -- the others time out, poison their slots, and the host repeats the frame)
+    if (rep && (launch_id >> 31) && blockIdx.y == 5 && N >= kVioReplicaMinObs) return;
     if (rep && N < kVioReplicaMinObs) {
       if (blockIdx.y != 0) return;
       rep = false;
@@ -1215,40 +1246,62 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
 
 using namespace vieo;
 
-// The exchange records of the replicated launches, one set per (host thread, stream): launches on one stream are
-// ordered, so a record is never shared by two kernels in flight.  Zeroed once (tag 0 is never used: launches count from 1).
+// The exchange records of the replicated launches, one set per (host thread, device, stream): launches on one stream
+// are ordered, so a record is never shared by two kernels in flight.  Zeroed once, on the launch stream (tag 0 is never
+// used: launches count from 1); freed when the host thread ends.
 static PoseXchg* vio_xchg_records(hipStream_t stream, int n_frames, unsigned* launch_id) {
   struct Rec {
     hipStream_t st;
+    int dev;
     PoseXchg* p;
     int n;
     unsigned launches;
   };
-  static thread_local std::vector<Rec> recs;
-  for (Rec& r : recs)
-    if (r.st == stream) {
+  struct Recs {
+    std::vector<Rec> v;
+    ~Recs() {
+      for (Rec& r : v)
+        if (r.p) {
+          int cur = 0;
+          (void)hipGetDevice(&cur);
+          if (cur != r.dev) (void)hipSetDevice(r.dev);
+          (void)hipFree(r.p);
+          if (cur != r.dev) (void)hipSetDevice(cur);
+        }
+    }
+  };
+  static thread_local Recs recs;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto fresh = [&](Rec& r) -> PoseXchg* {
+    r.p = nullptr, r.n = 0;
+    if (hipMalloc(&r.p, sizeof(PoseXchg) * n_frames) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(r.p, 0, sizeof(PoseXchg) * n_frames, stream) != hipSuccess) {
+      (void)hipFree(r.p);
+      r.p = nullptr;
+      return nullptr;
+    }
+    r.n = n_frames;
+    return r.p;
+  };
+  for (Rec& r : recs.v)
+    if (r.st == stream && r.dev == dev) {
       *launch_id = ++r.launches;
       if (r.n >= n_frames) return r.p;
       (void)hipStreamSynchronize(stream);
       (void)hipFree(r.p);
-      r.p = nullptr, r.n = 0;
-      if (hipMalloc(&r.p, sizeof(PoseXchg) * n_frames) != hipSuccess) return nullptr;
-      (void)hipMemset(r.p, 0, sizeof(PoseXchg) * n_frames);
-      r.n = n_frames;
-      return r.p;
+      return fresh(r);
     }
-  Rec r{stream, nullptr, 0, 1};
-  if (hipMalloc(&r.p, sizeof(PoseXchg) * n_frames) != hipSuccess) return nullptr;
-  (void)hipMemset(r.p, 0, sizeof(PoseXchg) * n_frames);
-  r.n = n_frames;
-  recs.push_back(r);
+  Rec r{stream, dev, nullptr, 0, 1};
+  PoseXchg* p = fresh(r);
+  if (!p) return nullptr;
+  recs.v.push_back(r);
   *launch_id = 1;
-  return r.p;
+  return p;
 }
 
 // rig frames of a small call (the one-call tracker: one frame): kXG replicas per frame share the visual edges.
 // vieo_pose_set_replicas(0) / VIEO_POSE_REPLICAS=0 keeps one workgroup per frame (measurements, tests of both forms).
-constexpr int kVioReplicaFrames = 4;
 static int& vio_replicas() {
   static thread_local int on = [] {
     const char* e = getenv("VIEO_POSE_REPLICAS");
@@ -1256,16 +1309,40 @@ static int& vio_replicas() {
   }();
   return on;
 }
+constexpr int kVioReplicaFrames = 4;
+// The replicas of a launch wait for each other, so all of them must be resident at once: n_frames x kXG workgroups against
+// what the device holds of this kernel (occupancy x CUs; a partitioned or smaller device, or a kernel instance that
+// outgrew a CU's LDS, then keeps the one-workgroup form).  Other work on the device can still delay a replica: that is
+// what the time-out + poison + the host's repeat on one workgroup are for.
+template <bool MC, bool ENC>
+static bool vio_replicas_fit(int n_frames) {
+  static thread_local int cached_dev = -1, cached_blocks = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != cached_dev) {
+    int per_cu = 0, cus = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pose_opt_vio<256, MC, ENC>, 256, 0) != hipSuccess) per_cu = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    cached_dev = dev, cached_blocks = per_cu * cus;
+  }
+  return n_frames * kXG <= cached_blocks;
+}
+
 template <bool MC, bool ENC>
 static void vio_launch_kind(bool narrow, const vieo_vio_frame* d_frames, int n_frames, const vieo_pose_obs* d_obs,
                             uint8_t* d_outlier, vieo_vio_result* d_results, int others, hipStream_t stream) {
-  const bool replicas = vio_replicas() != 0;
+  const bool replicas = vio_replicas() != 0 && MC && n_frames <= kVioReplicaFrames && vio_replicas_fit<MC, ENC>(n_frames);
   if (narrow && !MC)  // rig frames carry n_cams x the observations: always the wide form (up to 16384 edges)
     hipLaunchKernelGGL((k_pose_opt_vio<64, MC, ENC>), dim3(n_frames), dim3(64), 0, stream, d_frames, d_obs,
                        d_outlier, d_results, others, (PoseXchg*)nullptr, 0u);
   else {
     unsigned launch_id = 0;
-    PoseXchg* xb = (MC && replicas && n_frames <= kVioReplicaFrames) ? vio_xchg_records(stream, kVioReplicaFrames, &launch_id) : nullptr;
+    PoseXchg* xb = replicas ? vio_xchg_records(stream, kVioReplicaFrames, &launch_id) : nullptr;
+    if (xb) {
+      const char* drop = getenv("VIEO_POSE_REPLICA_DROP");  // (read per call: the test switches it in-process)
+      if (drop && atoi(drop) > 0) launch_id |= 0x80000000u;
+    }
     hipLaunchKernelGGL((k_pose_opt_vio<256, MC, ENC>), dim3(n_frames, xb ? kXG : 1), dim3(256), 0, stream, d_frames, d_obs,
                        d_outlier, d_results, others, xb, launch_id);
   }
@@ -1350,6 +1427,16 @@ int vieo_pose_optimization_vio(const vieo_vio_frame* h_frame, const vieo_pose_ob
                   nc > 0 ? 2 : 1, has_enc ? 2 : 1, nullptr);
   if (rc != VIEO_OK) return rc;
   if ((rc = G.download(o_r, nullptr)) != VIEO_OK) return rc;
+  if (((const vieo_vio_result*)G.h(o_r))->base.status == VIEO_E_HIP && vio_replicas()) {
+    // a replica of the frame never became resident (the device is shared with other work): the same optimisation on
+    // one workgroup -- slower, same result up to the association order of the visual sums
+    const int was = vieo_pose_set_replicas(0);
+    rc = vio_launch(G.d<vieo_vio_frame>(o_f), 1, G.d<vieo_pose_obs>(o_o), G.d<uint8_t>(o_u), G.d<vieo_vio_result>(o_r),
+                    nc > 0 ? 2 : 1, has_enc ? 2 : 1, nullptr);
+    (void)vieo_pose_set_replicas(was);
+    if (rc != VIEO_OK) return rc;
+    if ((rc = G.download(o_r, nullptr)) != VIEO_OK) return rc;
+  }
   memcpy(h_result, G.h(o_r), sizeof(vieo_vio_result));
   if (n > 0) memcpy(h_outlier + h_frame->base.obs_begin, G.h(o_u), n);
   if (h_result->base.status == VIEO_E_CAPACITY) {

@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include "ba_device.h"
+#include "orb_internal.h"
 #include "wave_ops.h"
 
 namespace vieo {
@@ -1311,10 +1312,27 @@ static thread_local struct {
   const void *keys = nullptr, *ur = nullptr, *counts = nullptr, *rec = nullptr;
   int n_frames = 0, key_cap = 0, n_cams = 0;
   hipStream_t st = nullptr;
+  float bounds[kMaxCams][4] = {};
 } g_grid;
 static thread_local bool g_grid_keep = false;
+// the sticky request of vieo_sbp_keep_grid is consumed by the NEXT search call whatever becomes of that call (an early
+// return used to leave it set for the search after it)
+static bool take_grid_keep() {
+  const bool k = g_grid_keep;
+  g_grid_keep = false;
+  return k;
+}
 
-static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
+// A grid that outlives the call: the window grid of a RESIDENT frame (vieo_search_by_projection*_resident) lives in the
+// frame's extractor handle, is built by the frame's first search and read by the later ones.
+struct SbpGridRef {
+  int* cell_start;
+  float4* cell_rec;
+  float* cell_ang;
+  bool built;  // in: already built for these keys; the caller marks it built after a successful call
+};
+
+static int run_search(SbpArgs& A, int n_frames, hipStream_t st, bool keep_grid, SbpGridRef* ext_grid = nullptr) {
   int rc;
   SbpScratch& S = g_sbp;
   if (A.n_cams < 1 || A.n_cams > kMaxCams) {
@@ -1341,29 +1359,36 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st) {
     set_error("search_by_projection: more than %d keypoints per frame", kMaxKeys);
     return VIEO_E_CAPACITY;
   }
-  if ((rc = S.cell_start.ensure((size_t)n_frames * A.n_cams * (kGridCells + 1) * 4)) != VIEO_OK) return rc;
-  if ((rc = S.cell_rec.ensure((size_t)n_frames * A.key_cap * sizeof(float4))) != VIEO_OK) return rc;
-  if ((rc = S.cell_ang.ensure((size_t)n_frames * A.key_cap * 4)) != VIEO_OK) return rc;
-  A.cell_start = S.cell_start.as<int>(), A.cell_rec = S.cell_rec.as<float4>(), A.cell_ang = S.cell_ang.as<float>();
+  if (ext_grid) {
+    A.cell_start = ext_grid->cell_start, A.cell_rec = ext_grid->cell_rec, A.cell_ang = ext_grid->cell_ang;
+  } else {
+    if ((rc = S.cell_start.ensure((size_t)n_frames * A.n_cams * (kGridCells + 1) * 4)) != VIEO_OK) return rc;
+    if ((rc = S.cell_rec.ensure((size_t)n_frames * A.key_cap * sizeof(float4))) != VIEO_OK) return rc;
+    if ((rc = S.cell_ang.ensure((size_t)n_frames * A.key_cap * 4)) != VIEO_OK) return rc;
+    A.cell_start = S.cell_start.as<int>(), A.cell_rec = S.cell_rec.as<float4>(), A.cell_ang = S.cell_ang.as<float>();
+  }
   // The grid (Frame::mGrid as a CSR + the records in cell order) is a function of the frame's keys alone: the second search
   // of a frame (local map after last frame) reuses the first one's when the caller says the keys are the same
   // (vieo_sbp_keep_grid: the one-call tracker) and the arrays, geometry and stream match.
-  const bool same = g_grid_keep && g_grid.valid && g_grid.keys == (const void*)A.keys && g_grid.ur == (const void*)A.uright &&
-                    g_grid.counts == (const void*)(A.cam_first ? (const void*)A.cam_first : (const void*)A.counts) &&
-                    g_grid.n_frames == n_frames && g_grid.key_cap == A.key_cap && g_grid.n_cams == A.n_cams && g_grid.st == st &&
-                    g_grid.rec == S.cell_rec.p;
-  g_grid_keep = false;
+  const bool same = ext_grid ? ext_grid->built
+                             : (keep_grid && g_grid.valid && g_grid.keys == (const void*)A.keys && g_grid.ur == (const void*)A.uright &&
+                                g_grid.counts == (const void*)(A.cam_first ? (const void*)A.cam_first : (const void*)A.counts) &&
+                                g_grid.n_frames == n_frames && g_grid.key_cap == A.key_cap && g_grid.n_cams == A.n_cams &&
+                                g_grid.st == st && g_grid.rec == S.cell_rec.p && !memcmp(g_grid.bounds, A.bounds, sizeof(g_grid.bounds)));
   if (!same) {
     if (n_frames * A.n_cams <= 16)
-      hipLaunchKernelGGL(k_sbp_grid<1024>, dim3(n_frames * A.n_cams), dim3(1024), 0, st, A, S.cell_start.as<int>(),
-                         S.cell_rec.as<float4>(), S.cell_ang.as<float>());
+      hipLaunchKernelGGL(k_sbp_grid<1024>, dim3(n_frames * A.n_cams), dim3(1024), 0, st, A, (int*)A.cell_start, (float4*)A.cell_rec,
+                         (float*)A.cell_ang);
     else
-      hipLaunchKernelGGL(k_sbp_grid<256>, dim3(n_frames * A.n_cams), dim3(256), 0, st, A, S.cell_start.as<int>(),
-                         S.cell_rec.as<float4>(), S.cell_ang.as<float>());
+      hipLaunchKernelGGL(k_sbp_grid<256>, dim3(n_frames * A.n_cams), dim3(256), 0, st, A, (int*)A.cell_start, (float4*)A.cell_rec,
+                         (float*)A.cell_ang);
   }
-  g_grid.valid = true, g_grid.keys = A.keys, g_grid.ur = A.uright;
-  g_grid.counts = A.cam_first ? (const void*)A.cam_first : (const void*)A.counts;
-  g_grid.n_frames = n_frames, g_grid.key_cap = A.key_cap, g_grid.n_cams = A.n_cams, g_grid.st = st, g_grid.rec = S.cell_rec.p;
+  if (!ext_grid) {
+    g_grid.valid = true, g_grid.keys = A.keys, g_grid.ur = A.uright;
+    g_grid.counts = A.cam_first ? (const void*)A.cam_first : (const void*)A.counts;
+    g_grid.n_frames = n_frames, g_grid.key_cap = A.key_cap, g_grid.n_cams = A.n_cams, g_grid.st = st, g_grid.rec = S.cell_rec.p;
+    memcpy(g_grid.bounds, A.bounds, sizeof(g_grid.bounds));
+  }
   // (VIEO_SBP_BLOCKS: tests pin the block count to reach the per-block list's overflow path with few queries)
   const char* e_blocks = getenv("VIEO_SBP_BLOCKS");
   const int n_blocks = e_blocks && atoi(e_blocks) > 0 ? std::min(atoi(e_blocks), kSbpBlocksFew) : (n_frames <= 2 ? kSbpBlocksFew : kSbpBlocks);
@@ -1456,6 +1481,7 @@ static int search_batch(int mode, const vieo_proj_query* d_queries, const int32_
                         const uint8_t* d_taken, const int32_t* d_counts, const int32_t* d_cam_first, int key_cap,
                         int img_first, int img_step, const float* h_bounds, int n_cams, float nn_ratio,
                         int check_orientation, int32_t* d_assign, int32_t* d_nmatches, void* stream) {
+  const bool keep_grid = take_grid_keep();
   if (!d_queries || !d_nq || q_cap <= 0 || n_frames <= 0 || !d_keys || !d_uright || !d_desc ||
       (!d_counts && !d_cam_first) || !h_bounds || !d_assign || !d_nmatches || key_cap <= 0 ||
       (mode != VIEO_SBP_LAST_FRAME && mode != VIEO_SBP_LOCAL_MAP && mode != VIEO_SBP_RELOC))
@@ -1472,7 +1498,7 @@ static int search_batch(int mode, const vieo_proj_query* d_queries, const int32_
   if (n_cams >= 1 && n_cams <= kMaxCams) memcpy(A.bounds, h_bounds, sizeof(float) * 4 * n_cams);
   A.nn_ratio = nn_ratio, A.check_ori = check_orientation;
   A.assign = d_assign, A.nmatches = d_nmatches;
-  return run_search(A, n_frames, (hipStream_t)stream);
+  return run_search(A, n_frames, (hipStream_t)stream, keep_grid);
 }
 
 int vieo_search_by_projection_batch_device(int mode, const vieo_proj_query* d_queries,
@@ -1621,6 +1647,121 @@ int vieo_search_by_projection(int mode, const vieo_proj_query* h_queries, int nq
   const int32_t cam_first[2] = {0, n_keys};
   return vieo_search_by_projection_rig(mode, h_queries, nq, h_keys, h_uright, h_desc, h_taken, n_keys, cam_first,
                                        h_bounds, 1, nn_ratio, check_orientation, h_assign, nmatches);
+}
+
+// ---- the projection searches of a RESIDENT frame (round 5) ---------------------------------------------------------
+// The frame's keys, descriptors and (after vieo_stereo_match_rectified_resident) uright are still in the extractor handle
+// that produced them; a search uploads only what the caller's pointer graph forces -- the last frame's points or the
+// window queries, the taken flags -- in ONE block on the handle's stream, builds the window grid at the frame's first
+// search and keeps it in the handle, and returns behind ONE synchronisation.
+static int resident_common(vieo_orb* fr, const float* h_uright, const char* who) {
+  if (!fr || fr->res_n < 0) {
+    set_error("%s: the handle holds no frame (vieo_orb_extract first)", who);
+    return VIEO_E_INVALID;
+  }
+  if (!h_uright && fr->uright_epoch != fr->epoch) {
+    set_error("%s: no resident uright for this frame (vieo_stereo_match_rectified_resident first, or pass h_uright)", who);
+    return VIEO_E_INVALID;
+  }
+  return require_device();
+}
+
+static int resident_search(int mode, vieo_orb* fr, const vieo_last_frame_point* h_points, const vieo_sbp_camera* h_cam,
+                           const vieo_proj_query* h_queries, int nq, const float* h_uright, const uint8_t* h_taken,
+                           const float* h_bounds, float nn_ratio, int check_orientation, int32_t* h_assign, int32_t* nmatches) {
+  const int n_keys = fr->res_n, cap = vieo_orb_max_keypoints(fr);
+  *nmatches = 0;
+  for (int i = 0; i < n_keys; i++) h_assign[i] = VIEO_SBP_UNCHANGED;
+  if (nq == 0 || n_keys == 0) return VIEO_OK;
+  int rc;
+  // one block: [points or queries | camera | nq | taken | uright] up, [assign | nmatches] back; the projected queries
+  // of the last-frame form are device-only
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t r = o;
+    o = (o + bytes + 255) & ~(size_t)255;
+    return r;
+  };
+  const size_t o_in = take((size_t)nq * 64), o_cam = take(sizeof(vieo_sbp_camera)), o_nq = take(4);
+  const size_t o_taken = take(h_taken ? (size_t)n_keys : 0), o_ur = take(h_uright ? (size_t)n_keys * 4 : 0);
+  const size_t in_end = o;
+  const size_t o_assign = take((size_t)cap * 4), o_nm = take(4);
+  const size_t io_end = o;
+  const size_t o_q = take(h_points ? (size_t)nq * sizeof(vieo_proj_query) : 0);
+  if ((rc = fr->h_io.ensure(io_end)) != VIEO_OK || (rc = fr->d_io.ensure(o)) != VIEO_OK) return rc;
+  if ((rc = fr->g_start.ensure((size_t)(kGridCells + 1) * 4)) != VIEO_OK || (rc = fr->g_rec.ensure((size_t)cap * sizeof(float4))) != VIEO_OK ||
+      (rc = fr->g_ang.ensure((size_t)cap * 4)) != VIEO_OK)
+    return rc;
+  uint8_t* H = (uint8_t*)fr->h_io.p;
+  uint8_t* D = (uint8_t*)fr->d_io.p;
+  memcpy(H + o_in, h_points ? (const void*)h_points : (const void*)h_queries, (size_t)nq * 64);
+  if (h_cam) memcpy(H + o_cam, h_cam, sizeof(vieo_sbp_camera));
+  memcpy(H + o_nq, &nq, 4);
+  if (h_taken) memcpy(H + o_taken, h_taken, n_keys);
+  if (h_uright) memcpy(H + o_ur, h_uright, (size_t)n_keys * 4);
+  hipStream_t st = fr->stream;
+  VIEO_HIP_CHECK(hipMemcpyAsync(D, H, in_end, hipMemcpyHostToDevice, st));
+  const vieo_proj_query* d_q = (const vieo_proj_query*)(D + o_in);
+  if (h_points) {
+    hipLaunchKernelGGL(k_sbp_project, dim3((nq + 255) / 256, 1), dim3(256), 0, st, (const vieo_last_frame_point*)(D + o_in),
+                       (const int*)(D + o_nq), nq, (const vieo_sbp_camera*)(D + o_cam), (const vieo_sbp_rig*)nullptr, 1,
+                       (vieo_proj_query*)(D + o_q));
+    d_q = (const vieo_proj_query*)(D + o_q);
+  }
+  SbpArgs A;
+  memset(&A, 0, sizeof(A));
+  A.mode = mode;
+  A.queries = d_q, A.nq = (const int*)(D + o_nq), A.q_cap = nq;
+  A.keys = fr->d_kp.as<vieo_keypoint>(), A.desc = fr->d_desc.as<uint8_t>(), A.counts = fr->d_counts.as<int>();
+  A.uright = h_uright ? (const float*)(D + o_ur) : fr->d_uright.as<float>();
+  A.taken = h_taken ? D + o_taken : nullptr;
+  A.key_cap = cap, A.img_first = 0, A.img_step = 0, A.n_cams = 1, A.cam_first = nullptr;
+  memcpy(A.bounds[0], h_bounds, 16);
+  A.nn_ratio = nn_ratio, A.check_ori = check_orientation;
+  A.assign = (int*)(D + o_assign), A.nmatches = (int*)(D + o_nm);
+  // the grid holds uright as well: one built from caller-supplied values is not kept
+  SbpGridRef G{fr->g_start.as<int>(), fr->g_rec.as<float4>(), fr->g_ang.as<float>(), !h_uright && fr->grid_epoch == fr->epoch};
+  (void)take_grid_keep();
+  if ((rc = run_search(A, 1, st, false, &G)) != VIEO_OK) return rc;
+  fr->grid_epoch = h_uright ? ~0ull : fr->epoch;
+  VIEO_HIP_CHECK(hipMemcpyAsync(H + o_assign, D + o_assign, io_end - o_assign, hipMemcpyDeviceToHost, st));
+  VIEO_HIP_CHECK(hipStreamSynchronize(st));
+  memcpy(h_assign, H + o_assign, (size_t)n_keys * 4);
+  memcpy(nmatches, H + o_nm, 4);
+  if (*nmatches < 0) {
+    set_error("search_by_projection: more than %d window candidates for one query", kCandCap);
+    return VIEO_E_CAPACITY;
+  }
+  return VIEO_OK;
+}
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono, th_far) (ORBmatcher.cc:1303-1467)
+// as ONE call: the projection of the last frame's points and the search.  h_assign[vieo_orb_resident_keys(frame)].
+int vieo_search_by_projection_last_frame_resident(vieo_orb* frame, const vieo_last_frame_point* h_points, int n_points,
+                                                  const vieo_sbp_camera* h_cam, const float* h_uright, float nn_ratio,
+                                                  int check_orientation, int32_t* h_assign, int32_t* nmatches) {
+  if (n_points < 0 || !h_cam || !nmatches || (n_points > 0 && !h_points) || h_cam->nlevels < 1 || h_cam->nlevels > 16)
+    return VIEO_E_INVALID;
+  int rc = resident_common(frame, h_uright, "vieo_search_by_projection_last_frame_resident");
+  if (rc != VIEO_OK) return rc;
+  if (frame->res_n > 0 && !h_assign) return VIEO_E_INVALID;
+  return resident_search(VIEO_SBP_LAST_FRAME, frame, h_points, h_cam, nullptr, n_points, h_uright, nullptr, h_cam->bounds, nn_ratio,
+                         check_orientation, h_assign, nmatches);
+}
+
+// The search of the other two overloads on queries the caller built (local map: mode VIEO_SBP_LOCAL_MAP from
+// MapPoint::GetTrackInfoRef(); relocalisation: VIEO_SBP_RELOC from vieo_sbp_project_keyframe).
+int vieo_search_by_projection_resident(int mode, vieo_orb* frame, const vieo_proj_query* h_queries, int nq,
+                                       const float* h_uright, const uint8_t* h_taken, const float* h_bounds, float nn_ratio,
+                                       int check_orientation, int32_t* h_assign, int32_t* nmatches) {
+  if (nq < 0 || !h_bounds || !nmatches || (nq > 0 && !h_queries) ||
+      (mode != VIEO_SBP_LAST_FRAME && mode != VIEO_SBP_LOCAL_MAP && mode != VIEO_SBP_RELOC))
+    return VIEO_E_INVALID;
+  int rc = resident_common(frame, h_uright, "vieo_search_by_projection_resident");
+  if (rc != VIEO_OK) return rc;
+  if (frame->res_n > 0 && !h_assign) return VIEO_E_INVALID;
+  return resident_search(mode, frame, nullptr, nullptr, h_queries, nq, h_uright, h_taken, h_bounds, nn_ratio, check_orientation,
+                         h_assign, nmatches);
 }
 
 int vieo_fuse_search(const vieo_fuse_frame* h_frame, const vieo_keypoint* const* h_keys,

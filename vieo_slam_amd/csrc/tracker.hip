@@ -16,11 +16,13 @@
 // The order-free bookkeeping between the stages is the vieo_track_* glue of track_glue.hip; nothing here computes
 // on the host beyond filling the upload block.  The rare wider-window branch (fewer than 20 matches in the first
 // search, Tracking.cc:301-309) re-runs the chain from the projection with 2 x th.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
 
 #include "imu_device.h"
+#include "orb_internal.h"
 
 namespace vieo {
 
@@ -179,6 +181,13 @@ struct vieo_tracker {
   hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_ext = nullptr, ev_fe = nullptr, ev_kd = nullptr;
   int cap = 0, ccap = 0, pcap = 0, gcap = 0, imu_cap = 512;
   int local_version = -1, n_local_dev = 0;
+  int replica_repeats = 0;    // frames whose optimisations were repeated on one workgroup (a replica did not arrive)
+  float side_ratio = 0.f;     // create_side_stream: elapsed(both spin kernels) / elapsed(one): 1 side by side, 2 in series
+  int side_probes = 1, side_checks = 0;
+  // the frames' GPU times: a ring for the running median, and how many frames in a row sat 30 % above it -- the sign that
+  // the two streams have come to share a hardware queue (streams the process created since: the mapping is the runtime's)
+  float gpu_ring[32] = {};
+  int gpu_n = 0, slow_run = 0, frames_since_check = 0;
   float scale[16], inv_sigma2[16];
   vieo_camera pin_cam;
   vieo_frustum_frame ff;
@@ -212,44 +221,54 @@ __global__ void k_track_spin(long long cycles) {
   const long long t0 = __builtin_amdgcn_s_memtime();
   while (__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
 }
-static hipError_t create_side_stream(hipStream_t* out, hipStream_t main_stream) {
+// elapsed(both spin kernels, started together on the two streams) / elapsed(one): ~1 side by side, ~2 one after the other
+static bool side_stream_ratio(hipStream_t main_stream, hipStream_t c, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, float* ratio) {
+  const long long spin = 100000;  // ~40 us
+  float both = 0, one = 0;
+  bool ok = true;
+  for (int rep = 0; rep < 2 && ok; rep++) {  // (the first round also creates the candidate's queue)
+    ok = hipEventRecord(e0, main_stream) == hipSuccess && hipStreamWaitEvent(c, e0, 0) == hipSuccess;
+    hipLaunchKernelGGL(k_track_spin, dim3(1), dim3(64), 0, main_stream, spin);
+    hipLaunchKernelGGL(k_track_spin, dim3(1), dim3(64), 0, c, spin);
+    ok = ok && hipEventRecord(e1, main_stream) == hipSuccess && hipEventRecord(e2, c) == hipSuccess &&
+         hipStreamSynchronize(main_stream) == hipSuccess && hipStreamSynchronize(c) == hipSuccess &&
+         hipEventElapsedTime(&one, e0, e1) == hipSuccess && hipEventElapsedTime(&both, e0, e2) == hipSuccess;
+  }
+  if (ok) *ratio = both / (one > 0 ? one : 1.f);
+  return ok;
+}
+static const float kSideRatioOk = 1.35f;
+// *ratio: what the kept stream measured (reported by vieo_tracker_get_stats; > kSideRatioOk = no candidate ran beside
+// the main stream, the best of them is kept and the frame's second stream is then in series with the first)
+static hipError_t create_side_stream(hipStream_t* out, hipStream_t main_stream, float* ratio_out) {
   int lo = 0, hi = 0;
   const bool prio = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  *ratio_out = 0.f;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
     for (hipEvent_t e : {e0, e1, e2})
       if (e) (void)hipEventDestroy(e);
     return prio ? hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(out, hipStreamNonBlocking);
   }
-  const long long spin = 100000;  // ~40 us
   hipStream_t best = nullptr, held[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float best_ratio = 1e9f;
   for (int k = 0; k < 6; k++) {
     hipStream_t c = nullptr;
-    const hipError_t err = (prio && k % 2 == 0) ? hipStreamCreateWithPriority(&c, hipStreamNonBlocking, hi)
+    // (normal-priority candidates first: the main stream is a high-priority one unless VIEO_TRACKER_PRIORITY=0)
+    const hipError_t err = (prio && k % 2 == 1) ? hipStreamCreateWithPriority(&c, hipStreamNonBlocking, hi)
                                                 : hipStreamCreateWithFlags(&c, hipStreamNonBlocking);
     if (err != hipSuccess) break;
     held[k] = c;  // (kept until the end: a destroyed candidate's queue would be handed to the next one)
-    float both = 0, one = 0;
-    bool ok = true;
-    for (int rep = 0; rep < 2 && ok; rep++) {  // (the first round also creates the candidate's queue)
-      ok = hipEventRecord(e0, main_stream) == hipSuccess && hipStreamWaitEvent(c, e0, 0) == hipSuccess;
-      hipLaunchKernelGGL(k_track_spin, dim3(1), dim3(64), 0, main_stream, spin);
-      hipLaunchKernelGGL(k_track_spin, dim3(1), dim3(64), 0, c, spin);
-      ok = ok && hipEventRecord(e1, main_stream) == hipSuccess && hipEventRecord(e2, c) == hipSuccess &&
-           hipStreamSynchronize(main_stream) == hipSuccess && hipStreamSynchronize(c) == hipSuccess &&
-           hipEventElapsedTime(&one, e0, e1) == hipSuccess && hipEventElapsedTime(&both, e0, e2) == hipSuccess;
-    }
-    if (!ok) continue;
-    const float ratio = both / (one > 0 ? one : 1.f);  // 1: side by side, 2: one after the other
+    float ratio = 0;
+    if (!side_stream_ratio(main_stream, c, e0, e1, e2, &ratio)) continue;
     if (ratio < best_ratio) best_ratio = ratio, best = c;
-    if (ratio < 1.35f) break;
+    if (ratio < kSideRatioOk) break;
   }
   for (hipStream_t c : held)
     if (c && c != best) (void)hipStreamDestroy(c);
   for (hipEvent_t e : {e0, e1, e2}) (void)hipEventDestroy(e);
   if (!best) return hipErrorUnknown;
-  *out = best;
+  *out = best, *ratio_out = best_ratio;
   return hipSuccess;
 }
 
@@ -284,7 +303,14 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
   t->rig = R != nullptr, t->vision = P->vision_only != 0;
   if (R) t->R = *R;
   t->n_img = R ? R->n_cams : 2, t->nc = R ? R->n_cams : 1;
-  if ((rc = vieo_orb_create(&t->ext, P->n_features, P->scale_factor, P->n_levels, P->ini_th_fast, P->min_th_fast)) != VIEO_OK) {
+  // the main stream from the high-priority queues, the second one from the normal ones, the bundle adjustment's at the
+  // lowest level: three queue pools, no sharing (orb_create_with_priority).  VIEO_TRACKER_PRIORITY=0: all normal (A/B).
+  static const int main_prio = [] {
+    const char* e = getenv("VIEO_TRACKER_PRIORITY");
+    return e ? atoi(e) : 1;
+  }();
+  if ((rc = vieo::orb_create_with_priority(&t->ext, P->n_features, P->scale_factor, P->n_levels, P->ini_th_fast, P->min_th_fast,
+                                           main_prio)) != VIEO_OK) {
     delete t;
     return rc;
   }
@@ -355,7 +381,7 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
             hipMalloc((void**)&t->d_up, up_bytes) == hipSuccess && hipMalloc((void**)&t->d_loc, loc_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_out, t->out_bytes) == hipSuccess && hipMalloc((void**)&t->d_work, work_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_const, const_bytes) == hipSuccess &&
-            create_side_stream(&t->st_imu, t->st) == hipSuccess &&
+            create_side_stream(&t->st_imu, t->st, &t->side_ratio) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_up, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_imu, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_ext, hipEventDisableTiming) == hipSuccess &&
@@ -441,6 +467,50 @@ int vieo_tracker_image_buffer(vieo_tracker* t, int image_index, uint8_t** plane)
 int vieo_tracker_scale_factors(const vieo_tracker* t, float* h_out) {
   if (!t || !h_out) return VIEO_E_INVALID;
   for (int l = 0; l < t->P.n_levels; l++) h_out[l] = t->scale[l];
+  return VIEO_OK;
+}
+
+// The second stream again: measured first, replaced only when it no longer runs beside the main one.  Both streams are
+// idle here (every vieo_track_frame returns synchronised).
+int vieo_tracker_reprobe(vieo_tracker* t) {
+  if (!t) return VIEO_E_INVALID;
+  int rc = require_device();
+  if (rc != VIEO_OK) return rc;
+  VIEO_HIP_CHECK(hipStreamSynchronize(t->st));
+  VIEO_HIP_CHECK(hipStreamSynchronize(t->st_imu));
+  hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+  for (auto& ev : e) VIEO_HIP_CHECK(hipEventCreate(&ev));
+  float ratio = 0;
+  const bool ok = side_stream_ratio(t->st, t->st_imu, e[0], e[1], e[2], &ratio);
+  for (auto& ev : e) (void)hipEventDestroy(ev);
+  t->side_checks++;
+  if (ok) t->side_ratio = ratio;
+  if (ok && ratio < kSideRatioOk) return VIEO_OK;
+  hipStream_t fresh = nullptr;
+  float fr = 0;
+  if (create_side_stream(&fresh, t->st, &fr) != hipSuccess) return VIEO_OK;  // (keep what there is)
+  if (ok && fr >= ratio) {  // nothing better to be had
+    (void)hipStreamDestroy(fresh);
+    return VIEO_OK;
+  }
+  (void)hipStreamDestroy(t->st_imu);
+  t->st_imu = fresh, t->side_ratio = fr, t->side_probes++;
+  return VIEO_OK;
+}
+
+int vieo_tracker_get_stats(const vieo_tracker* t, vieo_tracker_stats* out) {
+  if (!t || !out) return VIEO_E_INVALID;
+  memset(out, 0, sizeof(*out));
+  out->side_stream_ratio = t->side_ratio, out->side_stream_selections = t->side_probes, out->side_stream_checks = t->side_checks;
+  out->replica_repeats = t->replica_repeats;
+  const int n = std::min(t->gpu_n, 32);
+  if (n > 0) {
+    float v[32];
+    memcpy(v, t->gpu_ring, sizeof(float) * n);
+    std::nth_element(v, v + n / 2, v + n);
+    out->ms_gpu_median = v[n / 2];
+  }
+  out->slow_frames_in_a_row = t->slow_run;
   return VIEO_OK;
 }
 
@@ -750,6 +820,17 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     TRK_HIP(hipEventRecord(t->ev_t1, st));
     TRK_HIP(hipStreamSynchronize(st));
   }
+  if (t->rig && (O->r1.base.status == VIEO_E_HIP || O->r2.base.status == VIEO_E_HIP)) {
+    // a replica of one of the two optimisations never became resident (vieo_pose_set_replicas in include/vieo_hot.h: the
+    // device is shared with other work): the tail again with one workgroup per optimisation -- the frame is late, not lost
+    const int was = vieo_pose_set_replicas(0);
+    rc = track_chain_tail(t, nc, false);
+    (void)vieo_pose_set_replicas(was);
+    if (rc != VIEO_OK) return track_fail(t, rc);
+    TRK_HIP(hipEventRecord(t->ev_t1, st));
+    TRK_HIP(hipStreamSynchronize(st));
+    t->replica_repeats++;
+  }
 #undef TRK_HIP
   memset(out, 0, sizeof(*out));
   out->preint_status = O->preint_status[0];
@@ -777,6 +858,25 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   out->first = O->r1, out->second = O->r2;
   (void)hipEventElapsedTime(&out->ms_gpu, t->ev_t0, t->ev_t1);
   out->ms_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+  // watch the chain's GPU time: eight frames in a row 30 % above the running median -> look at the second stream again
+  // (at most once per 64 frames; a workload that simply grew moves the median instead)
+  {
+    const int n = std::min(t->gpu_n, 32);
+    float med = 0;
+    if (n >= 16) {
+      float v[32];
+      memcpy(v, t->gpu_ring, sizeof(float) * n);
+      std::nth_element(v, v + n / 2, v + n);
+      med = v[n / 2];
+    }
+    t->slow_run = (med > 0 && out->ms_gpu > 1.3f * med && !widened) ? t->slow_run + 1 : 0;
+    t->gpu_ring[t->gpu_n % 32] = out->ms_gpu, t->gpu_n++;
+    t->frames_since_check++;
+    if (t->slow_run >= 8 && t->frames_since_check >= 64) {
+      (void)vieo_tracker_reprobe(t);
+      t->frames_since_check = 0, t->slow_run = 0, t->gpu_n = 0;
+    }
+  }
   return VIEO_OK;
 }
 

@@ -31,6 +31,18 @@ def compute_stereo_matches(ext_left, ext_right, kps_l, desc_l, kps_r, desc_r, ba
     return ur, dp
 
 
+def compute_stereo_matches_resident(ext_left, ext_right, baseline, bf):
+    """Frame::ComputeStereoMatches of the frame the two extractors have just processed: keys, descriptors and pyramids
+    are read in HBM where ORBextractor.__call__ left them (vieo_stereo_match_rectified_resident)."""
+    n = lib().vieo_orb_resident_keys(ext_left._h)
+    assert n >= 0, "the left extractor holds no frame"
+    ur = np.full(max(n, 1), -1, np.float32)
+    dp = np.full(max(n, 1), -1, np.float32)
+    check(lib().vieo_stereo_match_rectified_resident(ext_left._h, ext_right._h, baseline, bf, ur.ctypes.data,
+                                                     dp.ctypes.data), "vieo_stereo_match_rectified_resident")
+    return ur[:n], dp[:n]
+
+
 def fisheye_call(fn, params, keys, descs, num_mono, group_capacity=None):
     """Marshals one ComputeStereoFishEyeMatches call for `fn` (the C-ABI entry, or the test oracle's function of
     the same signature).  params: FISHEYE_PARAMS_DTYPE[1]; keys[c]: KEYPOINT_DTYPE[n_c]; descs[c]: uint8[n_c, 32].
@@ -212,6 +224,38 @@ class ORBmatcher:
                                                       int(self.mbCheckOrientation), assign.ctypes.data,
                                                       ctypes.byref(n)), "vieo_search_by_projection_rig")
         return n.value, assign[:len(keys)]
+
+    # ---- the same searches on a frame that is still resident in its extractor handle (include/vieo_hot.h "the resident
+    # frame"): nothing of the frame goes up
+    def search_last_frame_resident(self, ext, points, cam, uright=None):
+        """SearchByProjection(Frame&, const Frame&, ...) as one call: projection + search.  returns (nmatches, assign)."""
+        import ctypes
+        n_keys = lib().vieo_orb_resident_keys(ext._h)
+        assert n_keys >= 0, "the extractor holds no frame"
+        pts, cam = np.ascontiguousarray(points), np.ascontiguousarray(cam)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        assign = np.zeros(max(n_keys, 1), np.int32)
+        n = ctypes.c_int32()
+        check(lib().vieo_search_by_projection_last_frame_resident(
+            ext._h, pts.ctypes.data, len(pts), cam.ctypes.data, None if ur is None else ur.ctypes.data, self.mfNNratio,
+            int(self.mbCheckOrientation), assign.ctypes.data, ctypes.byref(n)), "vieo_search_by_projection_last_frame_resident")
+        return n.value, assign[:n_keys]
+
+    def search_resident(self, mode, ext, queries, taken, bounds, uright=None, ratio=None):
+        import ctypes
+        n_keys = lib().vieo_orb_resident_keys(ext._h)
+        assert n_keys >= 0, "the extractor holds no frame"
+        q = np.ascontiguousarray(queries)
+        tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        b = np.ascontiguousarray(bounds, np.float32)
+        assign = np.zeros(max(n_keys, 1), np.int32)
+        n = ctypes.c_int32()
+        check(lib().vieo_search_by_projection_resident(
+            mode, ext._h, q.ctypes.data, len(q), None if ur is None else ur.ctypes.data, None if tk is None else tk.ctypes.data,
+            b.ctypes.data, self.mfNNratio if ratio is None else float(ratio), int(self.mbCheckOrientation), assign.ctypes.data,
+            ctypes.byref(n)), "vieo_search_by_projection_resident")
+        return n.value, assign[:n_keys]
 
     def SearchByProjectionLastFrame(self, queries, keys, uright, desc, taken, bounds, cam_first=None):
         """SearchByProjection(Frame&, const Frame&, th, bMono, th_far) (ORBmatcher.cc:1303-1467)

@@ -74,7 +74,7 @@ class ORBextractor:
         if image is None or image.size == 0:
             return -1, np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
         assert image.dtype == np.uint8 and image.ndim == 2  # CV_8UC1 assert, ORBextractor.cc:973
-        img = np.ascontiguousarray(image)
+        img = image if image.strides[1] == 1 and image.strides[0] >= image.shape[1] else np.ascontiguousarray(image)
         cap = self.max_keypoints()
         kps = np.zeros(cap, KEYPOINT_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
@@ -86,6 +86,14 @@ class ORBextractor:
                                      img.strides[0], lap, kps.ctypes.data, desc.ctypes.data, cap,
                                      ctypes.byref(n), ctypes.byref(mono)), "vieo_orb_extract")
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    # ---- the resident frame (include/vieo_hot.h): does the handle still hold these keys?
+    def holds(self, keypoints):
+        k = np.ascontiguousarray(keypoints)
+        return bool(lib().vieo_orb_holds(self._h, k.ctypes.data, len(k)))
+
+    def resident_keys(self):
+        return lib().vieo_orb_resident_keys(self._h)
 
     # ---- mvImagePyramid (include/ORBextractor.h:54)
     def level_size(self, level):

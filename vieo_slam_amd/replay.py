@@ -109,15 +109,20 @@ class Sequence:
 
 # ---------------------------------------------------------------- the hot-path calls (C-ABI)
 class HipStages:
-    """Every call of the replay that belongs to the hot path, through libvieo_hot.so (host-pointer entry points)."""
+    """Every call of the replay that belongs to the hot path, through libvieo_hot.so (host-pointer entry points).
+    resident=True: the frame's stereo match and its two projection searches read the keys / descriptors / pyramid where
+    the extractions left them (include/vieo_hot.h "the resident frame": the drop-in shims' fast form) whenever the
+    handles still hold the frame they are given -- same results, less traffic."""
     name = "hip"
 
-    def __init__(self):
+    def __init__(self, resident=False):
         from .matching import ORBmatcher
         from .orb_extractor import ORBextractor
         self.extL = ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
         self.extR = ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
         self.M = ORBmatcher
+        self.resident = bool(resident)
+        self.resident_calls = 0
 
     def scale_factors(self):
         return self.extL.GetScaleFactors()
@@ -126,8 +131,20 @@ class HipStages:
         return (self.extL if cam == 0 else self.extR)(image)
 
     def stereo(self, kl, dl, kr, dr):
-        from .matching import compute_stereo_matches
+        from .matching import compute_stereo_matches, compute_stereo_matches_resident
+        if self.resident and self.extL.holds(kl) and self.extR.holds(kr):
+            self.resident_calls += 1
+            return compute_stereo_matches_resident(self.extL, self.extR, sc.BASELINE, sc.BF)
         return compute_stereo_matches(self.extL, self.extR, kl, dl, kr, dr, sc.BASELINE, sc.BF)
+
+    def search_last_frame(self, pts, cam, keys, ur, desc, nn):
+        """SearchByProjection(Frame&, const Frame&, ...): projection + search -> (queries or None, nmatches, assign)"""
+        if self.resident and self.extL.holds(keys):
+            self.resident_calls += 1
+            n, a = self.M(nn, True).search_last_frame_resident(self.extL, pts, cam)
+            return n, a
+        q = self.project_last_frame(pts, cam)
+        return self.search(0, q, keys, ur, desc, None, nn)
 
     def preintegrate(self, noise, samples, ti, tj, bg, ba):
         from .imu import imu_preintegrate
@@ -138,6 +155,9 @@ class HipStages:
         return self.M.project_last_frame(pts, cam)
 
     def search(self, mode, q, keys, ur, desc, taken, nn):
+        if self.resident and self.extL.holds(keys):
+            self.resident_calls += 1
+            return self.M(nn, True).search_resident(mode, self.extL, q, taken, BOUNDS)
         return self.M(nn, True)._search(mode, q, keys, ur, desc, taken, BOUNDS)
 
     def pose_vio(self, F, obs):
@@ -454,12 +474,16 @@ class Replay:
         pts = frontend.make_last_frame_points(last.keys, np.zeros((last.N, 32), np.uint8), Xw, has, True)
         pts["desc"][has] = self.mp_desc[last.mp_ref[has]]
         cam = frontend.make_sbp_camera(Tcw, Tcw_last, K, BOUNDS, sc.BF, sc.BASELINE, self.th_last, self.scale)
-        q1 = S.project_last_frame(pts, cam)
-        n1, a1 = S.search(0, q1, f.keys, f.uright, f.desc, None, 0.9)
+        if hasattr(S, "search_last_frame"):  # (one call: the projection and the search)
+            n1, a1 = S.search_last_frame(pts, cam, f.keys, f.uright, f.desc, 0.9)
+        else:
+            n1, a1 = S.search(0, S.project_last_frame(pts, cam), f.keys, f.uright, f.desc, None, 0.9)
         if n1 < 20:  # the wider window of Tracking.cc:301-309
             cam[0]["th"] = 2 * self.th_last
-            q1 = S.project_last_frame(pts, cam)
-            n1, a1 = S.search(0, q1, f.keys, f.uright, f.desc, None, 0.9)
+            if hasattr(S, "search_last_frame"):
+                n1, a1 = S.search_last_frame(pts, cam, f.keys, f.uright, f.desc, 0.9)
+            else:
+                n1, a1 = S.search(0, S.project_last_frame(pts, cam), f.keys, f.uright, f.desc, None, 0.9)
         ok = a1 >= 0
         f.mp_ref[ok] = last.mp_ref[a1[ok]]
         f.track_depth[ok] = last.track_depth[a1[ok]]

@@ -143,6 +143,19 @@ class Tracker:
         except Exception:
             pass
 
+    STATS_DTYPE = np.dtype([("side_stream_ratio", "<f4"), ("side_stream_selections", "<i4"), ("side_stream_checks", "<i4"),
+                            ("replica_repeats", "<i4"), ("ms_gpu_median", "<f4"), ("slow_frames_in_a_row", "<i4")])
+
+    def stats(self):
+        """vieo_tracker_get_stats: the second stream's measured overlap ratio, re-selections, replica repeats, ..."""
+        st = np.zeros(1, self.STATS_DTYPE)
+        check(_bind().vieo_tracker_get_stats(self.h, st.ctypes.data), "vieo_tracker_get_stats")
+        return {k: st[0][k].item() for k in st.dtype.names}
+
+    def reprobe(self):
+        check(_bind().vieo_tracker_reprobe(self.h), "vieo_tracker_reprobe")
+        return self.stats()
+
     def scale_factors(self):
         s = np.zeros(int(self.params[0]["n_levels"]), np.float32)
         check(_bind().vieo_tracker_scale_factors(self.h, s.ctypes.data))
