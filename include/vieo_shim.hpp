@@ -27,7 +27,7 @@ class ORBextractor {
   enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
 
   ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
-      : nlevels_(nlevels) {
+      : nlevels_(nlevels), nfeatures_(nfeatures), ini_th_(iniThFAST), min_th_(minThFAST) {
     if (vieo_orb_create(&h_, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) != VIEO_OK)
       throw std::runtime_error(vieo_last_error());  // no CPU fallback
     mvImagePyramid.resize(nlevels);
@@ -42,6 +42,12 @@ class ORBextractor {
     if (_image.empty()) return -1;
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1);
+    if (deferred_) {  // shim/Tracking_hot.cc: the frame's extraction happens inside vieo_track_frame
+      deferred_image_ = image;
+      keypoints.clear();
+      descriptors.release();
+      return 0;
+    }
     const int cap = vieo_orb_max_keypoints(h_);
     static_assert(sizeof(cv::KeyPoint) == sizeof(vieo_keypoint), "cv::KeyPoint layout");
     keypoints.resize(cap);
@@ -58,14 +64,14 @@ class ORBextractor {
       descriptors.release();
     else
       desc.rowRange(0, n).copyTo(descriptors);
-    // mvImagePyramid (ORBextractor.h:54): ROI views into bordered planes, valid until the next call
-    for (int l = 0; l < nlevels_; ++l) {
-      int w, h;
-      vieo_orb_level_size(h_, l, &w, &h);
-      cv::Mat temp(h + 38, w + 38, CV_8UC1);
-      vieo_orb_get_level(h_, 0, l, 1, temp.data, (int)temp.step);
-      mvImagePyramid[l] = temp(cv::Rect(19, 19, w, h));
-    }
+    // mvImagePyramid (ORBextractor.h:54) is read by Frame::ComputeStereoMatches only (src/Frame.cc:457,536-557), and
+    // shim/Frame_hot.cc runs that on the device where the planes already are: the eight bordered planes (1.4 MB for a
+    // 752 x 480 image) are copied back only on request -- FetchImagePyramid(), or always with VIEO_SHIM_EAGER_PYRAMID.
+#ifdef VIEO_SHIM_EAGER_PYRAMID
+    FetchImagePyramid();
+#else
+    for (auto& m : mvImagePyramid) m = cv::Mat();
+#endif
     return mono;
   }
 
@@ -77,7 +83,27 @@ class ORBextractor {
   std::vector<float> inline GetInverseScaleSigmaSquares() { return tab(vieo_orb_inv_level_sigma2); }
 
   std::vector<cv::Mat> mvImagePyramid;
-  vieo_orb* handle() { return h_; }  // for the device-side stereo matcher
+  // ROI views into bordered planes (ComputePyramid, ORBextractor.cc:1060-1081) of the last extraction
+  void FetchImagePyramid() {
+    for (int l = 0; l < nlevels_; ++l) {
+      int w, h;
+      vieo_orb_level_size(h_, l, &w, &h);
+      cv::Mat temp(h + 38, w + 38, CV_8UC1);
+      vieo_orb_get_level(h_, 0, l, 1, temp.data, (int)temp.step);
+      mvImagePyramid[l] = temp(cv::Rect(19, 19, w, h));
+    }
+  }
+  vieo_orb* handle() { return h_; }  // the resident frame: shim/Frame_hot.cc, shim/ORBmatcher_hot.cc
+  // One call per frame (shim/Tracking_hot.cc): while deferred, operator() only keeps the image (a cv::Mat header) and
+  // returns no keys -- Frame::Frame then stops after ExtractORB (src/Frame.cc:282 `if (!N) return;`) and the tracker
+  // binding fills the frame from vieo_track_frame's outputs.
+  // (the constructor's arguments, for the binding that creates a tracker with the same extractor)
+  int HotFeatures() const { return nfeatures_; }
+  int HotIniThFAST() const { return ini_th_; }
+  int HotMinThFAST() const { return min_th_; }
+  void Defer(bool on) { deferred_ = on; }
+  bool Deferred() const { return deferred_; }
+  const cv::Mat& DeferredImage() const { return deferred_image_; }
 
  private:
   std::vector<float> tab(int (*fn)(const vieo_orb*, float*)) {
@@ -86,7 +112,9 @@ class ORBextractor {
     return v;
   }
   vieo_orb* h_ = nullptr;
-  int nlevels_;
+  int nlevels_, nfeatures_, ini_th_, min_th_;
+  bool deferred_ = false;
+  cv::Mat deferred_image_;
 };
 
 }  // namespace VIEO_SLAM

@@ -53,32 +53,58 @@ void fill_sbp_camera(const Frame& F, float th, float th_far, bool mono, vieo_sbp
   for (int l = 0; l < C.nlevels && l < 16; ++l) C.scale[l] = F.scalepyrinfo_.vscalefactor_[l];
 }
 
-// vieo_search_by_projection_rig on the current frame + the write-back of the reference (AddMapPoint per accepted
-// query, EraseMapPointMatch for the rotation-histogram losers).  mp_of(q) = the map point of query q.
+// The extractor handle that still holds THIS frame's keys (the resident frame of include/vieo_hot.h), or nullptr: a
+// one-camera key list (rectified stereo, monocular, RGB-D) whose search keys -- mvKeysUn when the frame is undistorted,
+// identical to the extracted keys for pinhole cameras -- are what the frame's first extractor has just returned.  The
+// current frame of Tracking always qualifies; a Frame copied long ago does not and takes the host-pointer entry.
+vieo_orb* resident_handle(const Frame& F, const std::vector<cv::KeyPoint>& keys, int n_cams) {
+  if (n_cams != 1 || F.mpORBextractors.empty() || !F.mpORBextractors[0]) return nullptr;
+  vieo_orb* h = F.mpORBextractors[0]->handle();
+  return vieo_orb_holds(h, reinterpret_cast<const vieo_keypoint*>(keys.data()), F.N) ? h : nullptr;
+}
+
+void taken_flags(const Frame& F, int mode, std::vector<uint8_t>& taken) {
+  const auto& cur = F.GetMapPointMatches();
+  taken.assign(F.N, 0);
+  for (int i = 0; i < F.N; ++i)
+    if (cur[i]) taken[i] = (mode == VIEO_SBP_RELOC) ? 1 : (cur[i]->Observations() > 0 ? 1 : 0);
+}
+
+// the write-back of the reference: AddMapPoint per accepted query, EraseMapPointMatch for the rotation-histogram losers
+template <class MpOf>
+void apply_assign(Frame& F, const std::vector<int32_t>& assign, MpOf mp_of) {
+  for (int i = 0; i < F.N; ++i) {
+    if (assign[i] >= 0)
+      F.AddMapPoint(mp_of(assign[i]), i);
+    else if (assign[i] == VIEO_SBP_ERASED)
+      F.EraseMapPointMatch(i);
+  }
+}
+
+// the search on caller-built queries + the write-back.  mp_of(q) = the map point of query q.  Resident frames: nothing of
+// the frame goes up (vieo_search_by_projection_resident), the window grid of the frame's first search is reused.
 template <class MpOf>
 int search_and_apply(int mode, Frame& F, const std::vector<vieo_proj_query>& q, float ratio, bool check_ori,
                      const vieo_sbp_rig& rig, MpOf mp_of) {
   const int N = F.N, nc = rig.n_cams;
   if (N <= 0 || q.empty()) return 0;
   const std::vector<cv::KeyPoint>& keys = !Frame::usedistort_ ? F.mvKeysUn : F.mvKeys;  // FrameBase.cpp:120
-  const auto& cur = F.GetMapPointMatches();
-  std::vector<uint8_t> taken(N, 0);
-  for (int i = 0; i < N; ++i)
-    if (cur[i]) taken[i] = (mode == VIEO_SBP_RELOC) ? 1 : (cur[i]->Observations() > 0 ? 1 : 0);
-  int32_t cam_first[5];
-  vieo_shim::cam_first_of(F, nc, cam_first);
+  std::vector<uint8_t> taken;
+  taken_flags(F, mode, taken);
   std::vector<int32_t> assign(N);
   int32_t nmatches = 0;
-  HOT_CHECK(vieo_search_by_projection_rig(mode, q.data(), (int)q.size(), reinterpret_cast<const vieo_keypoint*>(keys.data()),
-                                          F.stereoinfo_.vuright_.data(), F.mDescriptors.ptr<unsigned char>(0),
-                                          taken.data(), N, cam_first, &rig.bounds[0][0], nc, ratio, check_ori ? 1 : 0,
-                                          assign.data(), &nmatches));
-  for (int i = 0; i < N; ++i) {
-    if (assign[i] >= 0)
-      F.AddMapPoint(mp_of(assign[i]), i);
-    else if (assign[i] == VIEO_SBP_ERASED)
-      F.EraseMapPointMatch(i);
+  if (vieo_orb* h = resident_handle(F, keys, nc)) {
+    HOT_CHECK(vieo_search_by_projection_resident(mode, h, q.data(), (int)q.size(), F.stereoinfo_.vuright_.data(), taken.data(),
+                                                 &rig.bounds[0][0], ratio, check_ori ? 1 : 0, assign.data(), &nmatches));
+  } else {
+    int32_t cam_first[5];
+    vieo_shim::cam_first_of(F, nc, cam_first);
+    HOT_CHECK(vieo_search_by_projection_rig(mode, q.data(), (int)q.size(), reinterpret_cast<const vieo_keypoint*>(keys.data()),
+                                            F.stereoinfo_.vuright_.data(), F.mDescriptors.ptr<unsigned char>(0),
+                                            taken.data(), N, cam_first, &rig.bounds[0][0], nc, ratio, check_ori ? 1 : 0,
+                                            assign.data(), &nmatches));
   }
+  apply_assign(F, assign, mp_of);
   return nmatches;
 }
 
@@ -106,6 +132,24 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     p.octave = LastFrame.mvKeys[i].octave, p.angle = LastFrame.mvKeys[i].angle;
     p.flags = 1 | (pMP->Observations() > 0 ? 2 : 0);
     copy_desc(pMP->GetDescriptor(), p.desc);
+  }
+  // the resident frame: projection and search as ONE call on the keys still in the extractor handle
+  const std::vector<cv::KeyPoint>& keys = !Frame::usedistort_ ? CurrentFrame.mvKeysUn : CurrentFrame.mvKeys;
+  if (vieo_orb* h = (CurrentFrame.N > 0 && !Frame::usedistort_) ? resident_handle(CurrentFrame, keys, nc) : nullptr) {
+    cam.fx = rig.cams[0].fx, cam.fy = rig.cams[0].fy, cam.cx = rig.cams[0].cx, cam.cy = rig.cams[0].cy;
+    std::memcpy(cam.bounds, rig.bounds[0], sizeof(cam.bounds));
+    std::vector<uint8_t> taken;
+    taken_flags(CurrentFrame, VIEO_SBP_LAST_FRAME, taken);
+    bool any_taken = false;
+    for (uint8_t t : taken) any_taken = any_taken || t;
+    if (!any_taken) {  // (TrackWithIMU / TrackWithMotionModel call with an empty frame; else the two-call form below)
+      std::vector<int32_t> assign(CurrentFrame.N);
+      int32_t nmatches = 0;
+      HOT_CHECK(vieo_search_by_projection_last_frame_resident(h, pts.data(), n, &cam, CurrentFrame.stereoinfo_.vuright_.data(),
+                                                              mfNNratio, mbCheckOrientation ? 1 : 0, assign.data(), &nmatches));
+      apply_assign(CurrentFrame, assign, [&](int k) { return lfmps[k]; });
+      return nmatches;
+    }
   }
   std::vector<vieo_proj_query> q((size_t)n * nc);
   HOT_CHECK(vieo_sbp_project_last_frame_rig(pts.data(), n, &cam, &rig, q.data()));

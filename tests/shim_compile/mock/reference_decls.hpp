@@ -12,19 +12,32 @@
 #include <mutex>
 #include <set>
 #include <tuple>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
 #include "third_party_decls.hpp"
+#include "vieo_shim.hpp"  // VIEO_SLAM::ORBextractor: include/vieo_shim.hpp REPLACES the reference's include/ORBextractor.h
 
 namespace DBoW2 {
 typedef unsigned int NodeId;
 class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {};
 }  // namespace DBoW2
 
+namespace Eigen {
+template <class T>
+using aligned_vector = std::vector<T, Eigen::aligned_allocator<T>>;  // common/eigen_utils.h:20
+template <class T>
+using aligned_list = std::list<T, Eigen::aligned_allocator<T>>;
+}  // namespace Eigen
+
 namespace VIEO_SLAM {
 using std::set;
 using std::vector;
+using Eigen::aligned_list;
+using Eigen::aligned_vector;
+using Eigen::Vector3d;
+class ORBVocabulary;
 using Eigen::Matrix;
 typedef Eigen::Matrix<double, 6, 1> Vector6d;
 typedef Eigen::Matrix<double, 6, 6> Matrix6d;
@@ -38,8 +51,14 @@ class NavState {
 
 class IMUDataBase {
  public:
+  static Eigen::Matrix3d mSigmag, mSigmaa;
   static double mInvSigmabg2, mInvSigmaba2;
+  static int mdt_cov_noise_fixed;
+  static double mFreqRef;
+  double mtm;
+  Eigen::Vector3d mw, ma;
 };
+typedef IMUDataBase IMUData;
 class EncPreIntegrator {
  public:
   double mdeltatij;
@@ -48,6 +67,8 @@ class EncPreIntegrator {
 };
 class IMUPreintegrator {
  public:
+  aligned_list<IMUData>& GetRawDataRef();
+  const aligned_list<IMUData>& GetRawDataRef() const;
   double mdeltatij;
   Eigen::Matrix3d mRij;
   Eigen::Vector3d mvij, mpij;
@@ -64,8 +85,16 @@ class GeometricCamera {
   const Sophus::SE3<float>& GetTcr() const;
   const std::vector<float>& GetParameters() const;
   const CameraModel& camera_model() const;
+  struct PairHash {
+    size_t operator()(const std::pair<size_t, size_t>& p) const;
+  };
+  using MapCamIdx2Idx = std::unordered_map<std::pair<size_t, size_t>, size_t, PairHash>;
 };
 using Camera = GeometricCamera;
+class KB8Camera : public GeometricCamera {
+ public:
+  const std::vector<int>& GetvLappingArea() const;
+};
 }  // namespace camm
 
 class MapPoint;
@@ -86,6 +115,8 @@ class FrameBase {
   virtual EncPreIntegrator GetEncPreInt(void);
   virtual IMUPreintegrator GetIMUPreInt(void);
   virtual bool isBad();
+  void AssignFeaturesToGrid();
+  void ComputeImageBounds(const vector<int>& wid_hei);
   double timestamp_, ftimestamp_;
   static cv::Mat mTbc, mTce;
   static Eigen::Matrix3d meigRcb;
@@ -101,6 +132,9 @@ class FrameBase {
   DBoW2::FeatureVector mFeatVec;
   struct StereoInfo {
     vector<float> vdepth_, vuright_;
+    aligned_vector<Vector3d> v3dpoints_;
+    vector<bool> goodmatches_;
+    camm::Camera::MapCamIdx2Idx mapcamidx2idxs_;
     float baseline_bf_[2];
   } stereoinfo_;
   struct ScalePyramidInfo {
@@ -120,6 +154,21 @@ class FrameBase {
 
 class Frame : public FrameBase {
  public:
+  Frame();
+  Frame(const vector<cv::Mat>& ims, const double& timeStamp, const vector<ORBextractor*>& extractors, ORBVocabulary* voc,
+        const vector<camm::Camera::Ptr>& CamInsts, const float& bf, const float& thDepth,
+        IMUPreintegrator* ppreint_imu_kf = nullptr, EncPreIntegrator* ppreint_enc_kf = nullptr, bool usedistort = true,
+        const float th_far_pts = 0);
+  void ComputeStereoMatches();
+  void ComputeStereoFishEyeMatches(const float th_far_pts = 0);
+  void SetPose(cv::Mat Tcw);
+  vector<ORBextractor*> mpORBextractors;
+  vector<size_t> num_mono;
+  std::vector<std::vector<cv::KeyPoint>> vvkeys_;
+  std::vector<cv::Mat> vdescriptors_;
+  vector<vector<size_t>> mvidxsMatches;
+  vector<size_t> mapidxs2n_;
+  std::vector<std::vector<size_t>> mapin2n_;
   Matrix<double, 15, 15> mMargCovInv;
   NavState mNavStatePrior;
   bool mbPrior;
@@ -171,6 +220,7 @@ class MapPoint {
     std::list<size_t> vtrack_cami_;
     std::list<float> vtrack_viewcos_;
     std::list<int> vtrack_scalelevel_;
+    void Reset(Frame* pf = nullptr);
   } TrackFastMatchInfo;
   TrackFastMatchInfo trackinfo_;
 
@@ -190,6 +240,7 @@ class MapPoint {
   Vector3data GetNormal();
   cv::Mat GetDescriptor();
   TrackFastMatchInfo& GetTrackInfoRef();
+  void IncreaseFound(int n = 1);
   unsigned long mnId, mnBALocalForKF;
   static std::mutex mGlobalMutex;
 
@@ -248,5 +299,55 @@ template <>
 int Optimizer::PoseOptimization<Frame>(Frame*, Frame*, const cv::Mat&, const bool, const bool);
 template <>
 int Optimizer::PoseOptimization<KeyFrame>(Frame*, KeyFrame*, const cv::Mat&, const bool, const bool);
+
+class System {
+ public:
+  enum eSensor { MONOCULAR = 0, STEREO, RGBD, NUM_SUPPORTED_CAM };
+};
+class LocalMapping {
+ public:
+  float th_far_pts_ = 0;
+};
+class IMUInitialization {
+ public:
+  cv::Mat GetGravityVec(void);
+  bool GetVINSInited(void);
+};
+
+// include/Tracking.h, reduced to what shim/Tracking_hot.cc touches
+class Tracking {
+ public:
+  void PreIntegration(const int8_t type = 0);
+  bool TrackWithIMU(bool bMapUpdated);
+  bool PredictNavStateByIMU(bool bMapUpdated, bool preint = true);
+  bool TrackLocalMapWithIMU(bool bMapUpdated);
+  enum eTrackingState { SYSTEM_NOT_READY = -1, NO_IMAGES_YET = 0, NOT_INITIALIZED = 1, OK = 2, LOST = 3, ODOMOK = 4, MAP_REUSE = 5 };
+  eTrackingState mState;
+  int mSensor;
+  Frame mCurrentFrame;
+  bool mbOnlyTracking = false;
+
+ protected:
+  void UpdateLastFrame();
+  bool TrackWithMotionModel();
+  void UpdateLocalMap();
+  bool TrackLocalMap();
+  void SearchLocalPoints();
+  bool mbVO = false;
+  LocalMapping* mpLocalMapper;
+  IMUInitialization* mpIMUInitiator;
+  vector<ORBextractor*> mpORBextractors = vector<ORBextractor*>(1, nullptr);
+  ORBVocabulary* mpORBVocabulary;
+  std::vector<MapPoint*> mvpLocalMapPoints;
+  float mbf;
+  vector<camm::Camera::Ptr> mpCameras;
+  int mMaxFrames;
+  float mThDepth = 10.f;
+  int mnMatchesInliers;
+  KeyFrame* plast_kf_ = nullptr;
+  Frame mLastFrame;
+  unsigned int mnLastRelocFrameId = 0;
+  cv::Mat mVelocity;
+};
 
 }  // namespace VIEO_SLAM

@@ -4,6 +4,9 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <list>
+#include <memory>
+#include <vector>
 
 #define CV_8U 0
 #define CV_8UC1 0
@@ -43,6 +46,8 @@ class Mat {
   Mat operator()(const Rect& roi) const;
   void copyTo(const _OutputArray& dst) const;
 };
+Mat operator*(const Mat& a, const Mat& b);
+void vconcat(const Mat& a, const Mat& b, Mat& dst);
 class _InputArray {
  public:
   _InputArray(const Mat& m);
@@ -69,6 +74,15 @@ class Matrix {
   const T& operator()(int i) const;
   static Matrix Identity();
   static Matrix Zero();
+  Matrix& operator+=(const Matrix& o);
+};
+template <class T>
+class aligned_allocator : public std::allocator<T> {
+ public:
+  template <class U>
+  struct rebind {
+    typedef aligned_allocator<U> other;
+  };
 };
 typedef Matrix<double, 3, 3> Matrix3d;
 typedef Matrix<double, 3, 1> Vector3d;

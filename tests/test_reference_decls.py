@@ -21,10 +21,21 @@ HEADERS = {
     "Map": ["include/Map.h"],
     "ORBmatcher": ["include/ORBmatcher.h"],
     "Optimizer": ["include/Optimizer.h"],
+    "Tracking": ["include/Tracking.h"],
+    "LocalMapping": ["include/LocalMapping.h"],
+    "IMUInitialization": ["src/Odom/IMUInitialization.h"],
+    "IMUDataBase": ["src/Odom/OdomData.h"],
+    "KB8Camera": ["common/camera_models/camera_kb8.h"],
 }
 # members the mock states in a reduced form on purpose, with the reason
 KNOWN = {
     ("KeyFrame", "mbPrior"): "const bool in the reference too; the mock gives it an initialiser so that the class is constructible",
+}
+
+
+# member functions the reference generates with a macro: (class, name) -> the macro invocation that must be in its header
+MACRO_MADE = {
+    ("IMUInitialization", "GetVINSInited"): r"CREATOR_VAR_MULTITHREADS\(\s*VINSInited\s*,\s*bool\b",  # common/macro_creator.h:12-28: bool GetVINSInited(void)
 }
 
 
@@ -37,7 +48,7 @@ def _strip(text):
 
 def _class_body(text, name):
     """the text between the braces of `class name` / `struct name` (first definition), nested braces included"""
-    m = re.search(r"\b(?:class|struct)\s+%s\b[^;{]*\{" % re.escape(name), text)
+    m = re.search(r"\b(?:class|struct)\s+(?:[A-Z_]+\s+)?%s\b[^;{]*\{" % re.escape(name), text)  # (an export macro may sit between)
     if not m:
         return None
     i, depth = m.end(), 1
@@ -108,7 +119,11 @@ def _data_members(body):
     out = {}
     for stmt in flat.split(";"):
         stmt = re.sub(r"\b(?:public|protected|private)\s*:", " ", stmt).strip()
-        if not stmt or "(" in stmt or stmt.startswith(("typedef", "using", "friend", "enum", "template")):
+        if not stmt or stmt.startswith(("typedef", "using", "friend", "enum", "template")):
+            continue
+        if "(" in stmt and re.search(r"\s=\s", stmt.split("(")[0]):
+            stmt = re.sub(r"\s=\s.*$", "", stmt)           # `T name = T(args)`: an initialiser with parentheses
+        if "(" in stmt:
             continue
         stmt = re.sub(r"=\s*[^,]+", "", stmt).strip()        # initialisers
         m = re.match(r"^(.*?[\w>&*\]])\s+((?:[*&]?\s*[A-Za-z_]\w*(?:\s*\[[^\]]*\])?\s*,\s*)*[*&]?\s*[A-Za-z_]\w*(?:\s*\[[^\]]*\])?)$", stmt)
@@ -176,6 +191,10 @@ def test_mock_members_exist_in_the_reference_header(cls):
         if name in (cls, "~" + cls):
             continue
         for ret, ptypes in sigs:
+            if (cls, name) in MACRO_MADE:
+                if not re.search(MACRO_MADE[(cls, name)], ref):
+                    missing.append("%s: the macro line that generates it is gone" % name)
+                continue
             cands = ref_funcs.get(name, [])
             if not any(p == ptypes and (r == ret or not ret) for r, p in cands):
                 missing.append("%s %s(%s)  -- reference has: %s" % (ret, name, ", ".join(ptypes), cands[:3]))

@@ -13,7 +13,7 @@ MOCK = os.path.join(ROOT, "tests", "shim_compile", "mock")
 INC = ["-I" + MOCK, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "shim")]
 
 
-@pytest.mark.parametrize("src", ["shim/ORBmatcher_hot.cc", "shim/Optimizer_hot.cc",
+@pytest.mark.parametrize("src", ["shim/ORBmatcher_hot.cc", "shim/Optimizer_hot.cc", "shim/Frame_hot.cc", "shim/Tracking_hot.cc",
                                  "tests/shim_compile/use_extractor_shim.cc"])
 def test_shim_translation_unit_type_checks(src):
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror"] + INC + [os.path.join(ROOT, src)],
@@ -37,6 +37,18 @@ def test_shims_define_every_replaced_member():
                 "void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int Nlocal)",
                 "MapPoint::mGlobalMutex", "pMap->mMutexMapUpdate", "pbStopFlag"):
         assert sig in o, sig
+    f = open(os.path.join(ROOT, "shim", "Frame_hot.cc")).read()
+    for sig in ("void Frame::ComputeStereoMatches()", "void Frame::ComputeStereoFishEyeMatches(const float th_far_pts)",
+                "vieo_stereo_match_rectified_resident", "vieo_stereo_fisheye_match", "vieo_orb_holds"):
+        assert sig in f, sig
+    t = open(os.path.join(ROOT, "shim", "Tracking_hot.cc")).read()
+    for sig in ("bool Tracking::TrackWithIMU(bool bMapUpdated)", "bool Tracking::TrackLocalMapWithIMU(bool bMapUpdated)",
+                "bool Tracking::TrackWithMotionModel()", "bool Tracking::TrackLocalMap()", "vieo_track_frame",
+                "vieo_tracker_create_rig", "P.vision_only"):
+        assert sig in t, sig
+    # the resident frame is what the matcher shim tries first
+    for sig in ("vieo_search_by_projection_last_frame_resident", "vieo_search_by_projection_resident", "vieo_orb_holds"):
+        assert sig in m, sig
 
 
 def _build_demo():

@@ -578,6 +578,7 @@ int vieo_stereo_match_rectified_resident(vieo_orb* left, vieo_orb* right, float 
       (rc = left->d_sad.ensure((size_t)capL * 4)) != VIEO_OK || (rc = left->h_io.ensure((size_t)capL * 8)) != VIEO_OK)
     return rc;
   left->uright_epoch = left->epoch;
+  left->uright_host.clear();
   if (nL == 0) return VIEO_OK;
   hipStream_t st = left->stream;
   VIEO_HIP_CHECK(hipStreamSynchronize(right->stream));  // (its extraction returned synchronised: a formality)
@@ -599,6 +600,7 @@ int vieo_stereo_match_rectified_resident(vieo_orb* left, vieo_orb* right, float 
   VIEO_HIP_CHECK(hipStreamSynchronize(st));
   memcpy(h_uright, H, (size_t)nL * 4);
   memcpy(h_depth, H + capL, (size_t)nL * 4);
+  left->uright_host.assign(H, H + nL);
   return VIEO_OK;
 }
 

@@ -109,6 +109,7 @@ struct vieo_orb {  // global-scope tag declared in include/vieo_hot.h
   vieo_keypoint res_sample[16];       // its first 8 / last 8 keys: the identity test of vieo_orb_holds
   vieo::DevBuf d_uright, d_depth, d_sad;  // written by vieo_stereo_match_rectified_resident (uright: read by the searches)
   unsigned long long uright_epoch = ~0ull;
+  std::vector<float> uright_host;  // what the resident matcher returned: a caller that passes these values back is resident
   vieo::DevBuf g_start, g_rec, g_ang;  // Frame::mGrid as a CSR, built by the frame's first resident search
   unsigned long long grid_epoch = ~0ull;
 };

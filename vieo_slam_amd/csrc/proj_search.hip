@@ -1654,11 +1654,16 @@ int vieo_search_by_projection(int mode, const vieo_proj_query* h_queries, int nq
 // that produced them; a search uploads only what the caller's pointer graph forces -- the last frame's points or the
 // window queries, the taken flags -- in ONE block on the handle's stream, builds the window grid at the frame's first
 // search and keeps it in the handle, and returns behind ONE synchronisation.
-static int resident_common(vieo_orb* fr, const float* h_uright, const char* who) {
+static int resident_common(vieo_orb* fr, const float*& h_uright, const char* who) {
   if (!fr || fr->res_n < 0) {
     set_error("%s: the handle holds no frame (vieo_orb_extract first)", who);
     return VIEO_E_INVALID;
   }
+  // a caller that hands back the values the resident matcher returned (the shim passes stereoinfo_.vuright_ always) is
+  // served from HBM like one that passes NULL
+  if (h_uright && fr->uright_epoch == fr->epoch && (int)fr->uright_host.size() == fr->res_n &&
+      (fr->res_n == 0 || !memcmp(h_uright, fr->uright_host.data(), (size_t)fr->res_n * 4)))
+    h_uright = nullptr;
   if (!h_uright && fr->uright_epoch != fr->epoch) {
     set_error("%s: no resident uright for this frame (vieo_stereo_match_rectified_resident first, or pass h_uright)", who);
     return VIEO_E_INVALID;
