@@ -25,8 +25,13 @@ Besides the batched headline the line carries
       back, one synchronisation): ms per frame, frames/s, the ratio to the same replay on the CPU oracle
       (vs_cpu_single_stream), the reference's own published front-end figure beside it (reference_readme_anchor), and the
       ATE of that trajectory against the oracle's (BASELINE configs[2]: "ATE within 1e-4 of ref");
+      `drop_in` inside it: examples/dropin_replay, the same replay through the per-member entries behind the reference's own
+      signatures (nothing changes in Tracking.cc); `concurrent_trackers`: 8 / 32 independent sequences on the one GPU;
+  single_stream_rig / single_stream_vision_only: SEQUENCE replays of the other BASELINE configurations (distorted rigs of
+      2 / 4 cameras with the visual-inertial local BA, rectified stereo without IMU with the vision-only local BA), one
+      vieo_track_frame call per frame, ATE against the oracle's replay;
   pcie_inclusive: the batched step again with the step's images arriving from pinned host memory on a copy stream
-      (double-buffered, overlapped with the previous step's kernels).
+      (double-buffered, overlapped with the previous step's kernels); inclusive: the same WITH the step's local BAs.
 
 roofline: stage/kernel time is measured live with HIP events on the library's own stream across
 the timed steps; achieved = algorithmic bytes per launch / average launch duration of
@@ -377,66 +382,6 @@ def rig_frontend_batch(rig="kb8", n_cams=4, nfeat=1500, seed=300, n_frames=256, 
                                   "rate (word_ops_per_s), not by HBM; the fraction of the byte roofline is reported as asked"}}
 
 
-def vision_single_stream(n_cases=3, reps=10):
-    """BASELINE configs[0] (stereo, no IMU, 1000 features): the one-call tracker in vision-only mode
-    (TrackWithMotionModel + TrackLocalMap, Optimizer::PoseOptimization(Frame*, Frame*)) on rendered frame pairs."""
-    from vieo_slam_amd import frontend, synth_ba
-    from vieo_slam_amd import synth_scene as sc
-    from vieo_slam_amd.imu import IMU_SAMPLE_DTYPE
-    from vieo_slam_amd.map_point import FRUSTUM_POINT_DTYPE
-    from vieo_slam_amd.matching import compute_stereo_matches
-    from vieo_slam_amd.orb_extractor import ORBextractor
-    from vieo_slam_amd.tracker import Tracker, euroc_params
-    K = (sc.FX, sc.FY, sc.CX, sc.CY)
-    ex = [ORBextractor(1000, 1.2, 8, 20, 7) for _ in range(2)]
-    scf = ex[0].GetScaleFactors()
-    prm = euroc_params(max_local_points=2048)
-    prm[0]["n_features"], prm[0]["vision_only"] = 1000, 1
-    trk = Tracker(prm)
-    ms, errs, m1, inl = [], [], [], []
-    for i in range(n_cases):
-        case = sc.make_tracking_case(20 + i)
-        k0, d0 = ex[0](case["images0"][0])[1:]
-        k0r, d0r = ex[1](case["images0"][1])[1:]
-        _, dp0 = compute_stereo_matches(ex[0], ex[1], k0, d0, k0r, d0r, sc.BASELINE, sc.BF)
-        Ri, pi, Rwc0, twc0 = case["pose0"]
-        Xw, valid = frontend.unproject_stereo(k0, dp0, K, Rwc0, twc0)
-        pts = frontend.make_last_frame_points(k0, d0, Xw, valid, True)
-        P = np.zeros(len(k0), FRUSTUM_POINT_DTYPE)
-        P["Xw"] = Xw
-        dv = Xw.astype(np.float64) - twc0
-        dist = np.maximum(np.linalg.norm(dv, axis=1), 1e-6)
-        P["normal"] = (dv / dist[:, None]).astype(np.float32)
-        P["max_distance"] = (dist * scf[k0["octave"]]).astype(np.float32)
-        P["min_distance"] = P["max_distance"] / scf[7]
-        sel = np.nonzero(valid)[0]
-        rng = np.random.default_rng(i)
-        nav_pred = case["vio"][0]["base"]["nav"].copy()
-        nav_pred["p"] += rng.normal(0, 0.01, 3)
-        nav_pred["q"] = synth_ba.quat_mul(nav_pred["q"], synth_ba.quat_from_rotvec(rng.normal(0, 0.003, 3)))
-        nav_i = case["vio"][0]["nav_last"]
-        none = np.zeros(0, IMU_SAMPLE_DTYPE)
-        inf = np.full(len(pts), np.inf, np.float32)
-        call = lambda: trk.track(case["images1"][0], case["images1"][1], none, 0.0, 0.05, nav_pred, nav_i, None, pts, inf, P[sel],
-                                 pts["desc"][sel], sel.astype(np.int32), i + 1)
-        call()
-        t = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            o, v = call()
-            t.append(1e3 * (time.perf_counter() - t0))
-        ms.append(float(np.median(t)))
-        errs.append(float(synth_ba.pose_error(o["second"]["base"]["nav"], case["truth"])[0]))
-        m1.append(int(o["n_matches_last"])), inl.append(int(o["second"]["base"]["n_inliers"]))
-    trk.close()
-    v = float(np.mean(ms))
-    return {"config": "BASELINE configs[0]: rectified stereo WITHOUT IMU, 1000 features, 752x480; vieo_track_frame in vision-only "
-                      "mode (TrackWithMotionModel + TrackLocalMap as one chain, vision-only PoseOptimization x 2)",
-            "ms_per_frame": v, "frames_per_s": 1e3 / v, "ms_per_case": ms, "host_syncs_per_frame": 1,
-            "mean_matches_last_frame": float(np.mean(m1)), "mean_pose_inliers": float(np.mean(inl)),
-            "max_position_error_vs_truth_m": float(max(errs))}
-
-
 def schur_useful_flops(window):
     """SURVEY 8d's sparsity-aware count of the Schur reduction of ONE LM trial of a local-BA window: per landmark with k free
     observers 60 (3x3 inverse) + 108 k (W Hll^-1) + 216 k (k + 1) / 2 (the landmark's blocks of Hpp) + 36 k (gradient)."""
@@ -454,9 +399,10 @@ LBA_LAG = 6  # frames between a key frame and the write-back of its local BA in 
 def single_stream_leg(seq, n_frames):
     """The sequential replay on the C-ABI (see the module docstring).  Headline: examples/replay_main, the replay as a
     C++ program WITHOUT Python -- vieo_track_frame per frame (one chain of launches, one synchronisation), local BA per
-    key frame, the map on the host in C++.  Beside it the same replay driven from Python stage by stage (one synchronous
-    host-pointer call per stage).  The oracle's run of the same replay is part of the cpu_baseline leg, which fills in
-    the ATE."""
+    key frame on the LocalMapping thread, the map on the host in C++.  Beside it `drop_in`: examples/dropin_replay, the
+    same replay driven ONLY through the entries behind the reference's own class members (the path that changes nothing
+    in Tracking.cc), and the same replay driven from Python stage by stage.  The oracle's run of the same replay (a worker
+    process of the cpu_baseline leg) fills in the ATE."""
     import subprocess
     import tempfile
     from tools.write_sequence import write_sequence
@@ -465,79 +411,218 @@ def single_stream_leg(seq, n_frames):
     for k in range(n_frames):
         seq.images(k)  # rendering is not part of either timing
     exe = os.path.join(ROOT, "examples", "replay_main")
-    if not os.path.exists(exe):
-        raise RuntimeError("examples/replay_main is missing: run __graft_entry__.build()")
+    exe_d = os.path.join(ROOT, "examples", "dropin_replay")
+    if not os.path.exists(exe) or not os.path.exists(exe_d):
+        raise RuntimeError("examples/replay_main / dropin_replay missing: run __graft_entry__.build()")
+
+    def run(cmd):
+        return json.loads(subprocess.check_output(cmd, timeout=1800).decode().strip().splitlines()[-1])
     with tempfile.TemporaryDirectory() as tmp:
         path, traj = os.path.join(tmp, "seq.vseq"), os.path.join(tmp, "traj.bin")
         write_sequence(path, seq.seed, n_frames, seq)
-        runs = []
-        for _ in range(3):  # the best of three: a fresh box has noisy first seconds
-            line = subprocess.check_output([exe, path, traj, "--warmup", "16", "--quiet", "--lba-lag", str(LBA_LAG)],
-                                           timeout=900).decode().strip()
-            runs.append(json.loads(line.splitlines()[-1]))
-        r = min(runs, key=lambda x: x["ms_per_frame"])
+        runs = [run([exe, path, traj, "--warmup", "16", "--quiet", "--lba-lag", str(LBA_LAG)]) for _ in range(3)]
         # (the trajectory of ANY run with this lag is the same: the lag, not the timing, decides which map a frame sees)
         th = np.fromfile(traj, NAVSTATE_DTYPE)
-        line = subprocess.check_output([exe, path, traj + ".inline", "--warmup", "16", "--quiet"], timeout=900).decode().strip()
-        r_inline = json.loads(line.splitlines()[-1])
+        r_inline = run([exe, path, traj + ".inline", "--warmup", "16", "--quiet"])
+        d_runs = [run([exe_d, path, traj + ".dropin", "--warmup", "16", "--quiet", "--lba-lag", str(LBA_LAG)]) for _ in range(3)]
+        td = np.fromfile(traj + ".dropin", NAVSTATE_DTYPE)
+        d_host = run([exe_d, path, traj + ".dropin0", "--warmup", "16", "--quiet", "--lba-lag", str(LBA_LAG), "--resident", "0"])
+        conc = concurrent_trackers_leg(path)
+    r = runs[int(np.argsort([x["ms_per_frame"] for x in runs])[1])]  # the median run's record; the figure below is the MEAN
+    mean_ms = float(np.mean([x["ms_per_frame"] for x in runs]))
+    d = d_runs[int(np.argsort([x["ms_per_frame"] for x in d_runs])[1])]
+    d_mean = float(np.mean([x["ms_per_frame"] for x in d_runs]))
     Rs = replay.Replay(seq, replay.HipStages())
     Rs.run(min(12, n_frames))
+    n_py = min(n_frames, 100)
     Rs = replay.Replay(seq, replay.HipStages())
     t0 = time.perf_counter()
-    ts = Rs.run(n_frames)
+    ts = Rs.run(n_py)
     t_s = time.perf_counter() - t0
     err = max(synth_ba.pose_error(th[k], seq.truth(k))[0] for k in range(n_frames))
+    drop_in = {
+        "ms_per_frame": d_mean, "frames_per_s": 1e3 / d_mean, "ms_per_frame_all_runs": [x["ms_per_frame"] for x in d_runs],
+        "ms_per_frame_last_200": float(np.mean([x["ms_per_frame_last_200"] for x in d_runs])),
+        "ms_per_frame_host_pointer_form": d_host["ms_per_frame"], "stage_ms_per_frame": d["stage_ms_per_frame"],
+        "sequential_calls_per_frame": d["sequential_calls_per_frame"], "lba_lag_frames": LBA_LAG,
+        "ms_per_local_ba_mean": d["ms_per_local_ba"], "key_frames": d["key_frames"], "map_points": d["map_points"],
+        "ate_vs_oracle_m": None, "max_position_difference_vs_oracle_m": None,
+        "max_position_difference_vs_one_call_path_m": float(np.linalg.norm(td["p"] - th["p"], axis=1).max()),
+        "reference_readme_anchor": dict(README_FRONTEND_MS, ratio_to_this_ms_per_frame=README_FRONTEND_MS["value"] / d_mean),
+        "path": "examples/dropin_replay (C++, no Python): the frame member by member, as Tracking calls them -- "
+                "ORBextractor::operator() per camera on its own host thread (vieo_orb_extract), Frame::ComputeStereoMatches "
+                "(vieo_stereo_match_rectified_resident), FrameBase::PreIntegration (vieo_imu_preintegrate_batch), "
+                "PredictNavStateByIMU on the host, ORBmatcher::SearchByProjection(Frame&, const Frame&) "
+                "(vieo_search_by_projection_last_frame_resident), Optimizer::PoseOptimization (vieo_pose_optimization_vio), "
+                "Frame::isInFrustum (vieo_is_in_frustum_batch), SearchByProjection(Frame&, vector<MapPoint*>&) "
+                "(vieo_search_by_projection_resident), PoseOptimization(bComputeMarg); LocalBundleAdjustmentNavStatePRV on the "
+                "LocalMapping thread.  The resident frame: keys / descriptors / pyramid / uright / window grid stay in the "
+                "extractor handles the Frame points at; ms_per_frame_host_pointer_form re-uploads them in every call "
+                "(round 4's shims).  Nothing in Tracking.cc / LocalMapping.cc changes for this path (shim/*.cc)."}
     return {
         "frames": n_frames, "local_bas": r["local_bas"],
-        "ms_per_frame": r["ms_per_frame"], "frames_per_s": r["frames_per_s"],
+        "ms_per_frame": mean_ms, "frames_per_s": 1e3 / mean_ms,
+        "ms_per_frame_last_200": float(np.mean([x["ms_per_frame_last_200"] for x in runs])),
+        "ms_per_frame_median_frame": r["ms_per_frame_median"], "ms_per_frame_p99_frame": r["ms_per_frame_p99"],
+        "lba_windows": r["lba_windows"],
         "local_ba": "beside tracking (src/LocalMapping.cc:113-139): solved on its own host thread on the bundle-adjustment "
                     "stream, write-back before the %d-th frame after the key frame; the oracle replay it is compared with "
                     "applies the same lag" % LBA_LAG,
         "lba_lag_frames": LBA_LAG,
         "ms_per_frame_local_ba_inline": r_inline["ms_per_frame"], "vs_cpu_threaded": None,
         "ms_per_frame_all_runs": [x["ms_per_frame"] for x in runs],
-        "ms_per_frame_tracking_call": r["ms_track_call"], "ms_per_frame_tracking_call_gpu": r["ms_track_gpu"],
+        "ms_per_frame_tracking_call": float(np.mean([x["ms_track_call"] for x in runs])),
+        "ms_per_frame_tracking_call_gpu": float(np.mean([x["ms_track_gpu"] for x in runs])),
         "ms_per_frame_without_local_ba": r["ms_frame_without_local_ba"], "ms_per_local_ba_mean": r["ms_per_local_ba"],
         "host_syncs_per_frame": 1, "frames_with_the_wider_search_window": r["widened"],
         "key_frames": r["key_frames"], "map_points": r["map_points"],
         "ate_vs_oracle_m": None, "max_position_difference_vs_oracle_m": None, "vs_cpu_single_stream": None,
         "max_position_error_vs_truth_m": float(err),
-        "max_position_difference_vs_stage_by_stage_m": float(np.linalg.norm(th["p"] - ts["p"], axis=1).max()),
-        "reference_readme_anchor": dict(README_FRONTEND_MS, ratio_to_this_ms_per_frame=README_FRONTEND_MS["value"] / r["ms_per_frame"],
+        "max_position_difference_vs_stage_by_stage_m": float(np.linalg.norm(th["p"][:n_py] - ts["p"], axis=1).max()),
+        "reference_readme_anchor": dict(README_FRONTEND_MS, ratio_to_this_ms_per_frame=README_FRONTEND_MS["value"] / mean_ms,
                                         ms_per_frame_for_30x=README_FRONTEND_MS["value"] / 30.0,
                                         # the README figure is the FRONT END's time per frame (the tracking thread; local
                                         # mapping runs beside it in the reference): like for like it is this replay's
                                         # tracking call, not its whole loop with the local BAs in line
-                                        ratio_to_this_tracking_call=README_FRONTEND_MS["value"] / r["ms_track_call"]),
-        "stage_by_stage": {"ms_per_frame": 1e3 * t_s / (n_frames - 1),
+                                        ratio_to_this_tracking_call=README_FRONTEND_MS["value"] / float(np.mean([x["ms_track_call"] for x in runs]))),
+        "drop_in": drop_in,
+        "concurrent_trackers": dict(conc, note="examples/replay_main --trackers N: N independent sequences (each its own host "
+                                               "thread, vieo_tracker, map, LocalMapping thread) on this one GPU, 60 frames each; "
+                                               "frames_per_s_all_trackers = aggregate, ms_per_frame_latency_* = a frame's wall time "
+                                               "inside its own tracker's loop; trajectories asserted identical"),
+        "stage_by_stage": {"ms_per_frame": 1e3 * t_s / (n_py - 1), "frames": n_py,
                            "latency_ms_per_frame_tracking_median": float(np.median(Rs.stats["ms_frames"]))},
         "path": "examples/replay_main (C++, no Python): per frame ONE vieo_track_frame call = one copy up from pinned "
                 "memory, IMU pre-integration on a second stream beside extraction x2 -> stereo, PredictNavStateByIMU on the "
                 "device, SearchByProjection(last frame) -> PoseOptimization -> isInFrustum + queries from the optimised pose "
                 "in HBM -> SearchByProjection(local map) -> PoseOptimization(marg), one copy back, ONE host synchronisation; "
                 "per key frame (every 10 frames) vieo_imu_preintegrate_batch + vieo_local_bundle_adjustment_vio (on the "
-                "LocalMapping thread) + vieo_update_normal_and_depth_batch; ms_per_frame is wall time of the whole loop incl. "
-                "the C++ map bookkeeping, the write-backs and any wait for a local BA that is not finished at its frame; stage_by_stage = the same replay driven from Python with one synchronous "
+                "LocalMapping thread) + vieo_update_normal_and_depth_batch; ms_per_frame is the MEAN of three runs of the wall "
+                "time of the whole loop incl. the C++ map bookkeeping, the write-backs and any wait for a local BA that is not "
+                "finished at its frame; stage_by_stage = the same replay driven from Python with one synchronous "
                 "host-pointer call per stage",
-    }, th
+    }, th, td
 
 
-def cpu_replay(seq, n_frames, lba_lag=0):
-    """cpu_baseline, single-stream form: the same sequential replay on the CPU oracle (one thread)."""
+# ---------------------------------------------------------------- oracle replays in worker processes
+def _oracle_replay_worker(task):
+    """(spawned process, CPU only) renders a sequence and replays it on the CPU oracle: the checker of a sequence leg.
+    task = (kind, seed, n_frames, lag, rig, n_cams, nfeat, oracle_so).  Returns the oracle's trajectory, the seconds its
+    replay took, and the rendered images (the parent's HIP run then needs no second rendering)."""
+    kind, seed, n, lag, rig, nc, nfeat, so = task
     from tests import oracle_lib
-    from tests.replay_oracle import OracleStages
-    from vieo_slam_amd import replay
-    try:
-        path = oracle_lib.build(native=True)
-    except Exception:
-        path = oracle_lib.build(native=False)
-    Ro = replay.Replay(seq, OracleStages(oracle_lib.Oracle(path)), lba_lag=lba_lag)
+    from tests.replay_oracle import OracleRigStages, OracleStages, OracleVisionStages
+    from vieo_slam_amd import replay, replay_modes as rm
+    orc = oracle_lib.Oracle(so)
+    if kind == "vio":
+        seq = replay.Sequence(seed, n)
+        R = replay.Replay(seq, OracleStages(orc), lba_lag=lag)
+    elif kind == "vision":
+        seq = replay.Sequence(seed, n)
+        R = rm.VisionReplay(seq, OracleVisionStages(orc), lba_lag=lag)
+    else:
+        seq = rm.RigSequence(seed, n, rig, nc)
+        R = rm.RigReplay(seq, OracleRigStages(orc, nfeat, nc), nfeat, lba_lag=lag)
+    imgs = [seq.images(k) for k in range(n)]
     t0 = time.perf_counter()
-    to = Ro.run(n_frames)
+    traj = R.run(n)
     dt = time.perf_counter() - t0
-    return {"value": (n_frames - 1) / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "the %d-frame sequential replay of the single_stream leg (tracking + one local BA per 10 frames) "
-                      "on the CPU oracle, one thread" % n_frames}, to
+    return {"task": task[:7], "traj": traj.tobytes(), "seconds": dt, "images": imgs, "lba": R.stats["lba"],
+            "key_frames": len(R.kfs), "map_points": len(R.mp_X),
+            "stats": {"n_matches": [tuple(int(x) for x in m) for m in R.stats["n_matches"]],
+                      "n_inliers": [int(x) for x in R.stats["n_inliers"]]}}
+
+
+class OracleReplays:
+    """The oracle's replays of the sequence legs, started in spawned worker processes right after the timed region and
+    collected when a leg needs them (the GPU box has 256 hardware threads; the workers never touch the GPU)."""
+
+    def __init__(self, tasks):
+        import multiprocessing as mp
+        from tests import oracle_lib
+        try:
+            so = oracle_lib.build(native=True)
+        except Exception:
+            so = oracle_lib.build(native=False)
+        self.pool = mp.get_context("spawn").Pool(min(len(tasks), 6))
+        self.res = {name: self.pool.apply_async(_oracle_replay_worker, (t + (so,),)) for name, t in tasks.items()}
+
+    def get(self, name):
+        from vieo_slam_amd.ba_types import NAVSTATE_DTYPE
+        r = self.res[name].get(timeout=1800)
+        r["traj"] = np.frombuffer(r["traj"], NAVSTATE_DTYPE).copy()
+        return r
+
+    def close(self):
+        self.pool.terminate()
+
+
+def sequence_leg(kind, orc, n, lag, rig=None, nc=None, nfeat=None, seed=1):
+    """A SEQUENCE replay of one of the other BASELINE configurations with the local BA in the loop
+    (vieo_slam_amd/replay_modes.py): map growth from the stereo groups / stereo depths, a key frame every 10 frames, its
+    local BA applied `lag` frames later, one vieo_track_frame call per frame; ATE against the oracle's replay of the same
+    sequence (run in a worker process)."""
+    from vieo_slam_amd import replay, replay_modes as rm, synth_ba
+    if kind == "vision":
+        seq = replay.Sequence(seed, n)
+    else:
+        seq = rm.RigSequence(seed, n, rig, nc)
+    for k, im in enumerate(orc["images"]):
+        seq._img[k] = im
+    mk = (lambda: rm.VisionTrackerReplay(seq, rm.HipVisionStages(), lba_lag=lag)) if kind == "vision" else \
+        (lambda: rm.RigTrackerReplay(seq, rm.HipRigStages(nfeat, nc), nfeat, lba_lag=lag))
+    R = mk()
+    R.run(min(14, n))  # code objects, scratch buffers, the LocalMapping thread's arenas
+    R.close()
+    R = mk()
+    t0 = time.perf_counter()
+    th = R.run(n)
+    dt = time.perf_counter() - t0
+    R.close()
+    to = orc["traj"]
+    # 1e-4 is the bar "for the same inputs": up to the first frame whose integer decisions (matches, inliers) differ from
+    # the oracle's run the two work on the same map; behind it a flipped decision has changed the inputs
+    flip = replay.first_decision_flip(R.stats, orc["stats"])
+    upto = n if flip is None else flip
+    ms = np.array(R.stats["ms_chain"])
+    shapes = np.array(R.stats.get("lba_shapes", [(0, 0, 0, 0)]))
+    err = max(synth_ba.pose_error(th[k], seq.truth(k))[0] for k in range(n))
+    return {
+        "frames": n, "local_bas": R.stats["lba"], "key_frames": len(R.kfs), "map_points": int(len(R.mp_X)), "lba_lag_frames": lag,
+        "ms_per_frame_tracking_call": float(ms[:, 0].mean()), "ms_per_frame_tracking_call_gpu": float(ms[:, 1].mean()),
+        "ms_per_frame_tracking_call_last_half": float(ms[len(ms) // 2:, 0].mean()),
+        "ms_per_frame_python_loop": 1e3 * dt / (n - 1),
+        "ms_per_local_ba_mean": float(np.mean(R.stats["ms_lba"])) if R.stats["ms_lba"] else None,
+        "lba_windows": {"mean_key_frames": float(shapes[:, 0].mean()), "max_key_frames": int(shapes[:, 0].max()),
+                        "max_fixed_key_frames": int(shapes[:, 1].max()), "mean_points": float(shapes[:, 2].mean()),
+                        "mean_observations": float(shapes[:, 3].mean())},
+        "mean_matches_last_frame": float(np.mean([m[0] for m in R.stats["n_matches"]])),
+        "mean_matches_local_map": float(np.mean([m[1] for m in R.stats["n_matches"]])),
+        "mean_pose_inliers": float(np.mean(R.stats["n_inliers"])),
+        "ate_vs_oracle_m": replay.ate_between(th, to),
+        "max_position_difference_vs_oracle_m": float(np.linalg.norm(th["p"] - to["p"], axis=1).max()),
+        "first_frame_with_a_different_integer_decision": flip,
+        "max_position_difference_vs_oracle_until_then_m": float(np.linalg.norm(th["p"][:upto] - to["p"][:upto], axis=1).max()),
+        "oracle_replay_frames_per_s": (n - 1) / orc["seconds"], "oracle_over_tracking_call": orc["seconds"] / (n - 1) * 1e3 / float(ms[:, 0].mean()),
+        "max_position_error_vs_truth_m": float(err), "host_syncs_per_frame": 1,
+        "note": "ms_per_frame_tracking_call = wall time of the ONE vieo_track_frame call per frame (the C entry's own clock); "
+                "ms_per_frame_python_loop adds this driver's numpy map bookkeeping and the local BAs issued from Python "
+                "(the rectified configuration has a C++ driver, examples/replay_main: single_stream)",
+    }
+
+
+def concurrent_trackers_leg(path, n_list=(8, 32), frames=60):
+    """N independent sequences on ONE GPU: examples/replay_main --trackers N (every tracker its own host thread, streams,
+    map and LocalMapping thread, all replaying the same file: identical trajectories are asserted by the program)."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "replay_main")
+    out = {}
+    for nt in n_list:
+        line = subprocess.check_output([exe, path, "--frames", str(frames), "--trackers", str(nt), "--quiet", "--lba-lag", str(LBA_LAG)],
+                                       timeout=900).decode().strip().splitlines()[-1]
+        out["n%d" % nt] = json.loads(line)
+    return out
+
 
 
 def multi_gpu_legs(rank, world, dist, torch, reps=3):
@@ -649,9 +734,10 @@ def multi_gpu_legs(rank, world, dist, torch, reps=3):
     return out
 
 
-def pcie_leg(P, steps, warmup):
+def pcie_leg(P, steps, warmup, lba=None):
     """The batched step with its images uploaded from pinned host memory on a copy stream, double-buffered: while
-    step s runs on the pipeline's stream, step s+1's images travel over PCIe."""
+    step s runs on the pipeline's stream, step s+1's images travel over PCIe.  lba = (pool, run_lba, chunks): the step's
+    local-BA windows are issued beside it exactly as in the headline (the `inclusive` leg: H2D + front end + LocalBA)."""
     import ctypes
     from vieo_slam_amd._lib import DeviceBuffer, check, lib
     L = lib()
@@ -677,6 +763,7 @@ def pcie_leg(P, steps, warmup):
         check(L.vieo_event_record(ev_done[i], P.stream))
     upload(0)
     t0 = None
+    futs = []
     for s_ in range(warmup + steps):
         if s_ == warmup:
             P.sync()
@@ -688,6 +775,10 @@ def pcie_leg(P, steps, warmup):
         P.d_img = bufs[i]
         P.step()
         check(L.vieo_event_record(ev_done[i], P.stream))
+        if lba and s_ >= warmup:
+            futs += [lba[0].submit(lba[1], c) for c in lba[2]]
+    for f in futs:
+        f.result()
     P.sync()
     check(L.vieo_stream_synchronize(cs))
     dt = time.perf_counter() - t0
@@ -696,8 +787,11 @@ def pcie_leg(P, steps, warmup):
     check(L.vieo_host_free_pinned(pin))
     return {"value": P.B * steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps,
             "h2d_bytes_per_step": nbytes, "h2d_GBps_sustained": nbytes * (steps + 1) / dt / 1e9,
-            "note": "front end only (no LocalBA threads), images from pinned host memory on a copy stream, "
-                    "double-buffered against the step's kernels"}
+            "note": ("H2D + front end + LocalBA in one timed region: the step's images from pinned host memory on a copy "
+                     "stream (double-buffered against the step's kernels) and the step's local-BA windows issued from the host "
+                     "threads as in the headline") if lba else
+                    ("front end only (no LocalBA threads), images from pinned host memory on a copy stream, "
+                     "double-buffered against the step's kernels")}
 
 
 def main():
@@ -727,11 +821,14 @@ def main():
     ap.add_argument("--lba-batch", type=int, default=0,
                     help="windows per lock-step LBA call (0 = all windows of a step in one call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--single-stream-frames", type=int, default=100,
-                    help="frames of the sequential replay leg (0 = skip); rank 0 at N = 1 only")
+    ap.add_argument("--single-stream-frames", type=int, default=400,
+                    help="frames of the sequential replay leg (0 = skip); rank 0 at N = 1 only.  400 frames = 40 key frames: "
+                         "the local-BA windows reach 10 free key frames + their fixed observers")
+    ap.add_argument("--sequence-frames", type=int, default=100,
+                    help="frames of the rig / vision-only sequence replays (0 = skip); rank 0 at N = 1 only")
     ap.add_argument("--no-pcie-leg", action="store_true")
     ap.add_argument("--no-rig-legs", action="store_true",
-                    help="skip single_stream_rig / rig_frontend_batch / single_stream_vision_only (rank 0 at N = 1 only)")
+                    help="skip single_stream_rig / rig_batch / single_stream_vision_only (rank 0 at N = 1 only)")
     ap.add_argument("--parity-sample", type=int, default=8,
                     help="frames of the timed batch recomputed on the CPU oracle after the timed region (0 = none)")
     ap.add_argument("--no-multi-gpu-legs", action="store_true",
@@ -1001,20 +1098,26 @@ def main():
             out["multi_gpu"] = mg
         if world == 1 and not a.no_pcie_leg:
             out["pcie_inclusive"] = pcie_leg(P, max(3, min(a.steps, 10)), 2)
+        oracle_runs = None
+        n_seq = a.sequence_frames
+        if world == 1 and not a.no_cpu_baseline:
+            # the oracle's replays of the sequence legs (checker + single-stream CPU baseline): worker processes, from now on
+            tasks = {}
+            if a.single_stream_frames > 1:
+                tasks["vio"] = ("vio", 1, a.single_stream_frames, LBA_LAG, None, 0, 0)
+            if not a.no_rig_legs and n_seq > 1:
+                tasks.update({"radtan2": ("rig", 3, n_seq, LBA_LAG, "radtan", 2, 1200), "kb8_4": ("rig", 5, n_seq, LBA_LAG, "kb8", 4, 1500),
+                              "kb8_2": ("rig", 4, n_seq, LBA_LAG, "kb8", 2, 1500), "vision": ("vision", 2, n_seq, LBA_LAG, None, 0, 0)})
+            if tasks:
+                oracle_runs = OracleReplays(tasks)
+        if world == 1 and not a.no_pcie_leg and n_lba:
+            # H2D + front end + LocalBA in ONE timed region (the headline has the images resident, pcie_inclusive no LocalBA)
+            out["inclusive"] = pcie_leg(P, max(3, min(a.steps, 10)), 2, lba=(pool, run_lba, chunks))
         if world == 1 and not a.no_rig_legs:
             try:  # the other BASELINE configurations on their fast path (a leg must not take the headline down)
-                out["single_stream_rig"] = {
-                    "default_mh05_distorted_stereo": rig_single_stream("radtan", 2, 1200, 210),
-                    "configs3_4cam_kb8": rig_single_stream("kb8", 4, 1500, 300),
-                    "configs4_tumvi_2cam_kb8": rig_single_stream("kb8", 2, 1500, 400),
-                    "reference_readme_anchor": README_FRONTEND_DIST_MS}
-                ss = out["single_stream_rig"]
-                ss["reference_readme_anchor"] = dict(README_FRONTEND_DIST_MS, ratio_to_default_mh05_ms_per_rig_frame=
-                                                     README_FRONTEND_DIST_MS["value"] / ss["default_mh05_distorted_stereo"]["ms_per_rig_frame"])
                 out["rig_batch"] = rig_frontend_batch()
-                out["single_stream_vision_only"] = vision_single_stream()
             except Exception as e:
-                out["single_stream_rig"] = {"error": repr(e)}
+                out["rig_batch"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline and a.workload == "r3" and a.parity_sample > 0:
             # the headline tied to checked outputs: sampled frames of the timed batch and two of the step's local-BA
             # windows recomputed on the CPU oracle (after the timed region; the oracle is the checker, never the product)
@@ -1050,16 +1153,51 @@ def main():
         if world == 1 and a.single_stream_frames > 1:
             from vieo_slam_amd import replay
             seq = replay.Sequence(1, a.single_stream_frames)
-            out["single_stream"], th = single_stream_leg(seq, a.single_stream_frames)
-            if not a.no_cpu_baseline:  # the oracle's run of the same replay: baseline and checker
-                cb, to = cpu_replay(seq, a.single_stream_frames, LBA_LAG)
+            orc = oracle_runs.get("vio") if oracle_runs else None
+            if orc:
+                for k, im in enumerate(orc["images"]):
+                    seq._img[k] = im
+            out["single_stream"], th, td = single_stream_leg(seq, a.single_stream_frames)
+            if orc:  # the oracle's run of the same replay: baseline and checker
+                to = orc["traj"]
+                cb = {"value": (a.single_stream_frames - 1) / orc["seconds"], "unit": "frames/s", "cores": 1, "kind": "port",
+                      "sample": "the %d-frame sequential replay of the single_stream leg (tracking + one local BA per 10 frames) "
+                                "on the CPU oracle, one thread (a worker process beside the other legs)" % a.single_stream_frames}
                 out["cpu_baseline"]["single_stream"] = cb
-                out["single_stream"]["vs_cpu_single_stream"] = out["single_stream"]["frames_per_s"] / cb["value"]
+                ss = out["single_stream"]
+                ss["vs_cpu_single_stream"] = ss["frames_per_s"] / cb["value"]
                 # against the oracle threaded like the reference (one thread per camera + LocalMapping: cpu_baseline.value)
-                out["single_stream"]["vs_cpu_threaded"] = out["single_stream"]["frames_per_s"] / out["cpu_baseline"]["value"]
-                out["single_stream"]["ate_vs_oracle_m"] = replay.ate_between(th, to)
-                out["single_stream"]["max_position_difference_vs_oracle_m"] = float(
-                    np.linalg.norm(th["p"] - to["p"], axis=1).max())
+                ss["vs_cpu_threaded"] = ss["frames_per_s"] / out["cpu_baseline"]["value"]
+                ss["ate_vs_oracle_m"] = replay.ate_between(th, to)
+                ss["max_position_difference_vs_oracle_m"] = float(np.linalg.norm(th["p"] - to["p"], axis=1).max())
+                ss["drop_in"]["ate_vs_oracle_m"] = replay.ate_between(td, to)
+                ss["drop_in"]["max_position_difference_vs_oracle_m"] = float(np.linalg.norm(td["p"] - to["p"], axis=1).max())
+                ss["drop_in"]["vs_cpu_single_stream"] = ss["drop_in"]["frames_per_s"] / cb["value"]
+                n2 = a.single_stream_frames
+                ss["ate_vs_oracle_last_200_m"] = replay.ate_between(th[max(0, n2 - 200):], to[max(0, n2 - 200):])
+        if world == 1 and not a.no_rig_legs and oracle_runs and n_seq > 1:
+            try:  # the other BASELINE configurations as SEQUENCES with their local BA in the loop
+                rigs = {"default_mh05_distorted_stereo": ("radtan2", "radtan", 2, 1200, 3), "configs3_4cam_kb8": ("kb8_4", "kb8", 4, 1500, 5),
+                        "configs4_tumvi_2cam_kb8": ("kb8_2", "kb8", 2, 1500, 4)}
+                ssr = {}
+                for name, (key, rig, nc, nf, seed) in rigs.items():
+                    leg = sequence_leg("rig", oracle_runs.get(key), n_seq, LBA_LAG, rig, nc, nf, seed)
+                    leg["config"] = "%d-camera %s rig, %d features per camera, %s" % (nc, rig, nf, "752x480" if rig == "radtan" else "512x512")
+                    ssr[name] = leg
+                ssr["reference_readme_anchor"] = dict(
+                    README_FRONTEND_DIST_MS, ratio_to_default_mh05_ms_per_frame_tracking_call=
+                    README_FRONTEND_DIST_MS["value"] / ssr["default_mh05_distorted_stereo"]["ms_per_frame_tracking_call"])
+                out["single_stream_rig"] = ssr
+                leg = sequence_leg("vision", oracle_runs.get("vision"), n_seq, LBA_LAG, seed=2)
+                leg["config"] = ("BASELINE configs[0]: rectified stereo WITHOUT IMU, 1000 features, 752x480; TrackWithMotionModel + "
+                                 "TrackLocalMap as one vieo_track_frame call (vision-only PoseOptimization x 2), LocalBundleAdjustment "
+                                 "per key frame")
+                out["single_stream_vision_only"] = leg
+            except Exception as e:
+                import traceback
+                out["single_stream_rig"] = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
+        if oracle_runs:
+            oracle_runs.close()
         import ctypes
         ctypes.CDLL(None).fflush(None)  # (RCCL's version banner sits in C stdio's buffer: out with it BEFORE the line)
         sys.stdout.flush()

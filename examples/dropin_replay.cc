@@ -413,8 +413,10 @@ int main(int argc, char** argv) {
   R.initialise();
   const auto t0 = Clock::now();
   for (int k = 1; k < n; k++) {
+    const auto tk = std::chrono::steady_clock::now();
     R.before_frame(k);
     R.step(k);
+    R.frame_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count());
     if (!quiet && k % 10 == 0) {
       const double* tr = &S.truth[(size_t)k * 10];
       const vieo_navstate& v = R.traj.back();
@@ -446,6 +448,6 @@ int main(int argc, char** argv) {
               nf, resident, ms_total / nf, 1e3 * nf / ms_total, R.ms_frames / nf, R.n_lba, R.n_lba ? R.ms_lba / R.n_lba : 0.0, R.kfs.size(),
               R.mp_bad.size(), R.widened, lba_lag, std::sqrt(e2 / n), emax, 8);
   for (int s = 0; s < ST_N; s++) std::printf("%s\"%s\": %.4f", s ? ", " : "", kStageName[s], R.ms_stage[s] / nf);
-  std::printf("}}\n");
+  std::printf("}, %s}\n", R.run_shape_json().c_str());
   return 0;
 }

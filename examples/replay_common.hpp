@@ -160,6 +160,29 @@ struct ReplayBase {
   int lp_key_lba = -1;
   double ms_track = 0, ms_gpu = 0, ms_lba = 0, ms_frames = 0;
   int n_tracked = 0;
+  // what the run looked like: wall time of every frame of the timed loop (main() fills it), and the local-BA windows'
+  // shapes (key frames, fixed ones among them, points, observations) -- a steady-state run has 10 free key frames plus
+  // the fixed observers of their points
+  std::vector<double> frame_ms;
+  long win_kfs = 0, win_fixed = 0, win_points = 0, win_obs = 0;
+  int win_max_kfs = 0, win_max_fixed = 0;
+  // JSON fragment shared by the two programs' result lines
+  std::string run_shape_json() const {
+    const size_t n = frame_ms.size(), tail = std::min<size_t>(n, 200);
+    double all = 0, last = 0;
+    for (size_t i = 0; i < n; i++) all += frame_ms[i], last += i + tail >= n ? frame_ms[i] : 0.0;
+    std::vector<double> v(frame_ms);
+    std::sort(v.begin(), v.end());
+    char buf[512];
+    std::snprintf(buf, sizeof(buf),
+                  "\"ms_per_frame_last_200\": %.4f, \"frames_in_last_200\": %zu, \"ms_per_frame_median\": %.4f, \"ms_per_frame_p99\": %.4f, "
+                  "\"lba_windows\": {\"mean_key_frames\": %.2f, \"mean_fixed_key_frames\": %.2f, \"max_key_frames\": %d, "
+                  "\"max_fixed_key_frames\": %d, \"mean_points\": %.1f, \"mean_observations\": %.1f}",
+                  tail ? last / tail : 0.0, tail, n ? v[n / 2] : 0.0, n ? v[std::min(n - 1, (size_t)(0.99 * n))] : 0.0,
+                  n_lba ? (double)win_kfs / n_lba : 0.0, n_lba ? (double)win_fixed / n_lba : 0.0, win_max_kfs, win_max_fixed,
+                  n_lba ? (double)win_points / n_lba : 0.0, n_lba ? (double)win_obs / n_lba : 0.0);
+    return buf;
+  }
 
   explicit ReplayBase(const Sequence& s) : S(s) {
     std::memcpy(Tcb, S.Tcb, sizeof(Tcb));
@@ -371,6 +394,10 @@ struct ReplayBase {
       for (int r = 0; r < 3; r++) J.X[3 * j + r] = mp_X[3 * pts[j] + r];
     J.close.assign(pts.size(), 0), J.erase.assign(std::max<size_t>(J.obs.size(), 1), 0);
     J.navs.resize(order.size());
+    int n_fixed = 0;
+    for (const vieo_lba_keyframe& k : K) n_fixed += k.fixed != 0;
+    win_kfs += (long)K.size(), win_fixed += n_fixed, win_points += (long)pts.size(), win_obs += (long)J.obs.size();
+    win_max_kfs = std::max(win_max_kfs, (int)K.size()), win_max_fixed = std::max(win_max_fixed, n_fixed);
     return Jp;
   }
   static void lba_solve(LbaJob* J) {  // (any host thread)

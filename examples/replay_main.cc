@@ -114,15 +114,17 @@ struct Replay : ReplayBase {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::fprintf(stderr, "usage: %s seq.vseq [traj.bin] [--frames N] [--warmup M] [--lba-lag L] [--quiet]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s seq.vseq [traj.bin] [--frames N] [--warmup M] [--lba-lag L] [--trackers T] [--quiet]\n", argv[0]);
     return 2;
   }
   const char* traj_path = nullptr;
-  int n_frames = -1, warmup = 0, lba_lag = 0;
+  int n_frames = -1, warmup = 0, lba_lag = 0, n_trackers = 1;
   bool quiet = false;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--frames") && i + 1 < argc)
       n_frames = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--trackers") && i + 1 < argc)
+      n_trackers = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--warmup") && i + 1 < argc)
       warmup = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--lba-lag") && i + 1 < argc)
@@ -149,13 +151,83 @@ int main(int argc, char** argv) {
     for (int k = 1; k < std::min(warmup, S.n_frames); k++) Wm.before_frame(k), Wm.step(k);
     Wm.before_frame(1 << 30);
   }
+  if (n_trackers > 1) {
+    // N independent sequences on ONE GPU (BASELINE configs[3] "8 sequences": what a GPU of that run serves when it gets
+    // more than one): every tracker has its own host thread, streams, map and LocalMapping thread; all replay the same
+    // file, so every trajectory must equal the first one's bit for bit.
+    std::vector<std::unique_ptr<Replay>> Rs;
+    for (int i = 0; i < n_trackers; i++) {
+      Rs.emplace_back(new Replay(S));
+      Rs.back()->lba_lag = lba_lag;
+      Rs.back()->initialise();
+    }
+    std::mutex m;
+    std::condition_variable cv;
+    int ready = 0;
+    bool go = false;
+    std::vector<double> wall(n_trackers, 0.0);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n_trackers; i++)
+      th.emplace_back([&, i] {
+        {
+          std::unique_lock<std::mutex> g(m);
+          ready++;
+          cv.notify_all();
+          cv.wait(g, [&] { return go; });
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        Replay& R = *Rs[i];
+        for (int k = 1; k < n; k++) {
+          const auto tk = std::chrono::steady_clock::now();
+          R.before_frame(k);
+          R.step(k);
+          R.frame_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count());
+        }
+        wall[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        R.before_frame(1 << 30);
+      });
+    std::chrono::steady_clock::time_point t0;
+    {
+      std::unique_lock<std::mutex> g(m);
+      cv.wait(g, [&] { return ready == n_trackers; });
+      go = true;
+      t0 = std::chrono::steady_clock::now();
+    }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+    const double ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    bool same = true;
+    for (int i = 1; i < n_trackers; i++)
+      same = same && Rs[i]->traj.size() == Rs[0]->traj.size() &&
+             !std::memcmp(Rs[i]->traj.data(), Rs[0]->traj.data(), Rs[0]->traj.size() * sizeof(vieo_navstate));
+    std::vector<double> all;
+    double gpu = 0, call = 0;
+    for (auto& R : Rs) all.insert(all.end(), R->frame_ms.begin(), R->frame_ms.end()), gpu += R->ms_gpu, call += R->ms_track;
+    std::sort(all.begin(), all.end());
+    const double nf = (double)(n - 1);
+    double mean = 0;
+    for (double v : all) mean += v;
+    std::printf("{\"trackers\": %d, \"frames_per_tracker\": %d, \"frames_per_s_all_trackers\": %.2f, \"ms_per_frame_latency_mean\": %.4f, "
+                "\"ms_per_frame_latency_median\": %.4f, \"ms_per_frame_latency_p99\": %.4f, \"ms_track_call_mean\": %.4f, "
+                "\"ms_track_gpu_mean\": %.4f, \"slowest_tracker_ms_per_frame\": %.4f, \"identical_trajectories\": %s, \"lba_lag\": %d}\n",
+                n_trackers, n - 1, 1e3 * n_trackers * nf / ms_total, mean / all.size(), all[all.size() / 2],
+                all[std::min(all.size() - 1, (size_t)(0.99 * all.size()))], call / (n_trackers * nf), gpu / (n_trackers * nf),
+                *std::max_element(wall.begin(), wall.end()) / nf, same ? "true" : "false", lba_lag);
+    if (traj_path) {
+      FILE* f = std::fopen(traj_path, "wb");
+      if (f) std::fwrite(Rs[0]->traj.data(), sizeof(vieo_navstate), Rs[0]->traj.size(), f), std::fclose(f);
+    }
+    return same ? 0 : 1;
+  }
   Replay R(S);
   R.lba_lag = lba_lag;
   R.initialise();
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = 1; k < n; k++) {
+    const auto tk = std::chrono::steady_clock::now();
     R.before_frame(k);
     R.step(k);
+    R.frame_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count());
     if (!quiet && k % 10 == 0) {
       const double* tr = &S.truth[(size_t)k * 10];
       const vieo_navstate& v = R.traj.back();
@@ -183,8 +255,9 @@ int main(int argc, char** argv) {
   const int nf = n - 1;
   std::printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"ms_track_call\": %.4f, \"ms_track_gpu\": %.4f, "
               "\"ms_frame_without_local_ba\": %.4f, \"local_bas\": %d, \"ms_per_local_ba\": %.4f, \"key_frames\": %zu, "
-              "\"map_points\": %zu, \"widened\": %d, \"lba_lag\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e}\n",
+              "\"map_points\": %zu, \"widened\": %d, \"lba_lag\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e, %s}\n",
               nf, ms_total / nf, 1e3 * nf / ms_total, R.ms_track / nf, R.ms_gpu / nf, R.ms_frames / nf, R.n_lba,
-              R.n_lba ? R.ms_lba / R.n_lba : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, lba_lag, std::sqrt(e2 / n), emax);
+              R.n_lba ? R.ms_lba / R.n_lba : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, lba_lag, std::sqrt(e2 / n), emax,
+              R.run_shape_json().c_str());
   return 0;
 }

@@ -108,3 +108,45 @@ def test_gpu_chained_replay_falls_back_stage_by_stage():
     assert Rc.stats["fallbacks"] > 0
     assert np.array_equal(Rh.stats["n_matches"], Rc.stats["n_matches"])
     assert replay.ate_between(tc, th) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+def test_gpu_cpp_replays_at_steady_state_length_vs_oracle(oracle, tmp_path):
+    """400 frames / 40 key frames: the local-BA windows reach 10 free key frames plus the fixed observers of their points and
+    the local map its steady size.  Both C++ programs -- examples/replay_main (one vieo_track_frame call per frame) and
+    examples/dropin_replay (the per-member entries behind the reference's own signatures) -- with LocalMapping on its own
+    thread, against the ORACLE replay with the same hand-over lag."""
+    import json
+    import os
+    import subprocess
+    from tests.replay_oracle import OracleStages
+    from tools.write_sequence import write_sequence
+    from vieo_slam_amd.ba_types import NAVSTATE_DTYPE
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, lag = 400, 6
+    seq = replay.Sequence(1, n)
+    path = str(tmp_path / "seq.vseq")
+    write_sequence(path, 1, n, seq)
+    Ro = replay.Replay(seq, OracleStages(oracle), lba_lag=lag)
+    to = Ro.run(n)
+    assert Ro.stats["lba"] == 39
+    for exe in ("replay_main", "dropin_replay"):
+        traj = str(tmp_path / (exe + ".bin"))
+        line = subprocess.check_output([os.path.join(root, "examples", exe), path, traj, "--quiet", "--lba-lag", str(lag), "--warmup", "12"],
+                                       timeout=900).decode().strip().splitlines()[-1]
+        r = json.loads(line)
+        t = np.fromfile(traj, NAVSTATE_DTYPE)
+        ate = replay.ate_between(t, to)
+        dmax = np.linalg.norm(t["p"] - to["p"], axis=1).max()
+        rot = max(synth_ba.pose_error(t[k], to[k])[1] for k in range(n))
+        assert len(t) == n and r["local_bas"] == 39 and r["key_frames"] == 40, r
+        # the RMSE stays at the parity scale over the whole run; single frames behind a flipped integer decision (a window
+        # candidate on its ratio test, an observation on its chi2 gate: see tests/test_replay_modes._check_vs_oracle) may sit
+        # a few 1e-4 off until the next local BA pulls the maps together again
+        assert ate <= 1e-4 and dmax <= 1e-3 and rot <= 1e-3, (exe, ate, dmax, rot)
+        w = r["lba_windows"]
+        assert w["max_key_frames"] >= 12 and w["max_fixed_key_frames"] >= 2, w  # 10 free + fixed observers
+        assert r["max_err_vs_truth_m"] < 2e-2
+        print("%s, 400 frames: %.3f ms per frame (last 200: %.3f, p99 frame %.3f), windows %s, ATE vs oracle %.2e m (max %.2e)"
+              % (exe, r["ms_per_frame"], r["ms_per_frame_last_200"], r["ms_per_frame_p99"], w, ate, dmax))

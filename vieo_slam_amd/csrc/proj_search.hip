@@ -988,10 +988,15 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_cam(SbpArgs A, int cam_cap,
   unsigned* KB = kbins + (size_t)f * A.key_cap;
   const bool ori = A.mode != VIEO_SBP_LOCAL_MAP && A.check_ori;
   const bool reloc = A.mode == VIEO_SBP_RELOC, second = A.mode == VIEO_SBP_LOCAL_MAP;
-  constexpr int kQPer = 12;  // queries per thread held in registers: 12 288 per frame
+  // A thread OWNS the camera's queries me = tid, tid + 1024, ... (kCamQ / 1024 = 4 slots: their state lives in registers);
+  // which query sits in which slot is decided while the lists are gathered and does not matter -- the order of the walk is
+  // the query number s_qid[me].  (Round 4 kept a register slot for EVERY query of the frame, 12 per thread: a 4-camera
+  // fisheye sequence reaches 14 k valid (point, camera) queries once its map has grown, and every frame beyond 12 288 fell
+  // to the sequential replay, 6 ms instead of 50 us.)
+  constexpr int kOwn = kCamQ / 1024;
   bool settled = false;
   // (a camera with more keys than its share of key_cap, more queries than fit: the sequential replay takes the frame)
-  if (Nc <= cam_cap && nq <= 1024 * kQPer && nq < 65536) {
+  if (Nc <= cam_cap && nq < 65536) {
     for (int i = tid; i < Nc; i += 1024) {
       s_taken[i] = taken ? taken[k0 + i] : (uint8_t)0;
       s_min0[i] = INT_MAX, s_min1[i] = INT_MAX, s_bins[i] = 0u;
@@ -1000,30 +1005,28 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_cam(SbpArgs A, int cam_cap,
     if (tid < kHistoLen) s_hist[tid] = 0;
     if (tid == 0) s_nm = 0, s_overflow = 0, s_fill = 0, s_nql = 0, s_changed[0] = s_changed[1] = 0;
     __syncthreads();
-    // ---- this thread's queries (tid, tid + 1024, ...): which are this camera's (their first candidate is one of its
-    // keys); their lists go to LDS.  lq: the query's slot among the camera's queries (-1: not this camera's).
-    int lq[kQPer], cny[kQPer], cl[kQPer];
-    unsigned wl[kQPer];  // the winner's candidate word at the last round (rotation bin)
-    {
-      int2 rq[kQPer];
-      unsigned first[kQPer];
+    // ---- all queries of the frame, four records in flight per thread: which are this camera's (their first candidate is
+    // one of its keys); those get a slot, their lists go to LDS (s_second keeps the record's count word until the owner
+    // has taken it)
+    for (int q0 = tid; q0 < nq; q0 += 4096) {
+      int2 rq[4];
+      unsigned first[4];
 #pragma unroll
-      for (int j = 0; j < kQPer; j++) {  // (all records in flight, then all first words)
-        const int q = tid + 1024 * j;
+      for (int j = 0; j < 4; j++) {
+        const int q = q0 + 1024 * j;
         rq[j] = q < nq ? qrec[q] : make_int2(0, 0);
       }
 #pragma unroll
-      for (int j = 0; j < kQPer; j++) first[j] = rq[j].y > 0 ? pool[rq[j].x] : 0u;
+      for (int j = 0; j < 4; j++) first[j] = rq[j].y > 0 ? pool[rq[j].x] : 0u;
 #pragma unroll
-      for (int j = 0; j < kQPer; j++) {
-        cl[j] = -1, lq[j] = -1, cny[j] = 0, wl[j] = 0;
+      for (int j = 0; j < 4; j++) {
         if (rq[j].y < 0) s_overflow = 1;  // (its camera is unknown: every camera reports it)
         const int n = rq[j].y > 0 ? (rq[j].y & 0xFFFF) : 0, idx = (int)(first[j] & 0x1FFF);
         if (n > 0 && idx >= k0 && idx < k1) {
           const int lo = atomicAdd(&s_fill, n), me = atomicAdd(&s_nql, 1);
           if (lo + n <= A.pool_lds && me < kCamQ) {
-            lq[j] = me, cny[j] = rq[j].y;
-            s_qid[me] = (unsigned short)(tid + 1024 * j), s_qstart[me] = (unsigned short)lo;
+            s_qid[me] = (unsigned short)(q0 + 1024 * j), s_qstart[me] = (unsigned short)lo;
+            s_second[me] = (unsigned)rq[j].y;
             for (int p0 = 0; p0 < n; p0 += 8) {  // eight words in flight
               unsigned cw[8];
 #pragma unroll
@@ -1034,6 +1037,19 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_cam(SbpArgs A, int cam_cap,
             }
           }
         }
+      }
+    }
+    __syncthreads();
+    // the owners take their queries' records
+    int lq[kOwn], cny[kOwn], cl[kOwn];
+    unsigned wl[kOwn];  // the winner's candidate word at the last round (rotation bin)
+    {
+      const int nql = min(s_nql, kCamQ);
+#pragma unroll
+      for (int j = 0; j < kOwn; j++) {
+        const int me = tid + 1024 * j;
+        cl[j] = -1, wl[j] = 0, lq[j] = me < nql ? me : -1, cny[j] = 0;
+        if (me < nql) cny[j] = (int)s_second[me], s_second[me] = 0xFFFFFFFFu;
       }
     }
     __syncthreads();
@@ -1063,9 +1079,9 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_cam(SbpArgs A, int cam_cap,
       // queries: the tests behind best / second, the claim
       int changed = 0;
 #pragma unroll
-      for (int j = 0; j < kQPer; j++)
+      for (int j = 0; j < kOwn; j++)
         if (lq[j] >= 0) {
-          const int me = lq[j], q = tid + 1024 * j, ny = cny[j];
+          const int me = lq[j], q = s_qid[me], ny = cny[j];
           const unsigned b0 = s_best[me], b1 = s_second[me];
           s_best[me] = 0xFFFFFFFFu, s_second[me] = 0xFFFFFFFFu;  // (for the next round)
           int k = -1;
@@ -1097,9 +1113,9 @@ __global__ void __launch_bounds__(1024) k_sbp_assign_cam(SbpArgs A, int cam_cap,
         __syncthreads();
         int nm = 0;
 #pragma unroll
-        for (int j = 0; j < kQPer; j++)
+        for (int j = 0; j < kOwn; j++)
           if (lq[j] >= 0 && cl[j] >= 0) {
-            atomicMax(&s_asg[cl[j]], tid + 1024 * j);  // AddMapPoint in query order = the last accepted claimer of a key stays
+            atomicMax(&s_asg[cl[j]], (int)s_qid[lq[j]]);  // AddMapPoint in query order = the last accepted claimer of a key stays
             nm++;
             if (ori) {
               const int bin = (wl[j] >> 26) & 31;
@@ -1383,6 +1399,9 @@ static int run_search(SbpArgs& A, int n_frames, hipStream_t st, bool keep_grid, 
       hipLaunchKernelGGL(k_sbp_grid<256>, dim3(n_frames * A.n_cams), dim3(256), 0, st, A, (int*)A.cell_start, (float4*)A.cell_rec,
                          (float*)A.cell_ang);
   }
+  else if (ext_grid)  // the grid kernel is what empties the frames' candidate pools: a resident frame may be searched any
+    VIEO_HIP_CHECK(hipMemsetAsync(A.cursor, 0, (size_t)n_frames * 4, st));  // number of times on one grid (the tracker's
+                                                                            // second search appends behind its first)
   if (!ext_grid) {
     g_grid.valid = true, g_grid.keys = A.keys, g_grid.ur = A.uright;
     g_grid.counts = A.cam_first ? (const void*)A.cam_first : (const void*)A.counts;

@@ -591,6 +591,20 @@ class Replay:
         return np.array(self.traj, NAVSTATE_DTYPE)
 
 
+def first_decision_flip(stats_a, stats_b):
+    """First tracked frame (1-based index into the trajectories) whose INTEGER decisions differ between two runs of the same
+    replay -- matches found by the two searches, inliers kept by the second optimisation -- or None.  Up to that frame the
+    two runs worked on the same inputs and must agree to the parity tolerance; behind it they track different maps (one
+    observation sitting on its chi2 gate or one window candidate on its ratio test is enough), and what can be asked is
+    that both keep tracking."""
+    ma, mb = stats_a["n_matches"], stats_b["n_matches"]
+    ia, ib = stats_a["n_inliers"], stats_b["n_inliers"]
+    for k in range(min(len(ma), len(mb))):
+        if tuple(ma[k]) != tuple(mb[k]) or ia[k] != ib[k]:
+            return k + 1
+    return None
+
+
 # ---------------------------------------------------------------- one frame as ONE chain of launches
 class _Arena:
     """A pinned host block and its device twin with the same layout: fields are carved out once, the block travels
