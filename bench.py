@@ -93,6 +93,24 @@ def _latest_profile(suffix):
     return best[1] if best else None
 
 
+def _counters_match_source(d):
+    """A committed counter file describes the kernels of ONE source text: it records sha256[:16] of the kernel's source
+    file (tools/pmc_round5.sh), and its figures are quoted only while that file is unchanged -- counters of an older
+    kernel are not evidence about this one (round 4 quoted round-3 counters)."""
+    import hashlib
+    shas = d.get("source_sha16")
+    if not isinstance(shas, dict) or not shas:
+        return False
+    for rel, sha in shas.items():
+        try:
+            with open(os.path.join(ROOT, rel), "rb") as f:
+                if hashlib.sha256(f.read()).hexdigest()[:16] != sha:
+                    return False
+        except OSError:
+            return False
+    return True
+
+
 def pmc_traffic(kernel, n_img):
     """HBM bytes per launch of the kernel from the committed PMC passes (profiles/r*_pmc_extractor.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same launch shape, gfx950 correction
@@ -101,6 +119,8 @@ def pmc_traffic(kernel, n_img):
     try:
         with open(path) as f:
             d = json.load(f)
+        if not _counters_match_source(d):
+            return None  # counters of another source text: no traffic figure rather than a stale one
         k = d["kernels"][kernel]
         per_img = (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0 * k.get("launches", 1) / d["images_per_launch"]
         return per_img * n_img
@@ -118,7 +138,7 @@ def valu_issue(kernel, n_img, launch_ms):
     try:
         with open(path) as f:
             d = json.load(f)
-        if d.get("kernel") != "k_" + kernel or launch_ms <= 0:
+        if d.get("kernel") != "k_" + kernel or launch_ms <= 0 or not _counters_match_source(d):
             return None
         insts = d["valu_insts_per_simd"] * n_img / d["images_per_launch"]
         cyc = launch_ms * 1e-3 * 2.4e9

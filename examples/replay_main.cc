@@ -118,13 +118,15 @@ int main(int argc, char** argv) {
     return 2;
   }
   const char* traj_path = nullptr;
-  int n_frames = -1, warmup = 0, lba_lag = 0, n_trackers = 1;
+  int n_frames = -1, warmup = 0, lba_lag = 0, n_trackers = 1, kf_every = 10;
   bool quiet = false;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--frames") && i + 1 < argc)
       n_frames = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--trackers") && i + 1 < argc)
       n_trackers = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--kf-every") && i + 1 < argc)  // (experiments: a huge value = no key frames, no local BA)
+      kf_every = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--warmup") && i + 1 < argc)
       warmup = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--lba-lag") && i + 1 < argc)
@@ -158,7 +160,7 @@ int main(int argc, char** argv) {
     std::vector<std::unique_ptr<Replay>> Rs;
     for (int i = 0; i < n_trackers; i++) {
       Rs.emplace_back(new Replay(S));
-      Rs.back()->lba_lag = lba_lag;
+      Rs.back()->lba_lag = lba_lag, Rs.back()->kf_every = kf_every;
       Rs.back()->initialise();
     }
     std::mutex m;
@@ -220,7 +222,7 @@ int main(int argc, char** argv) {
     return same ? 0 : 1;
   }
   Replay R(S);
-  R.lba_lag = lba_lag;
+  R.lba_lag = lba_lag, R.kf_every = kf_every;
   R.initialise();
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = 1; k < n; k++) {

@@ -1,0 +1,80 @@
+#!/bin/bash
+# Round-5 counter passes (each its own rocprofv3 --pmc run with --kernel-trace only, MI355X_MICROARCH.md):
+#   1. HBM traffic of the batched extractor's kernels (FETCH_SIZE / WRITE_SIZE, 2048 images)       -> r5_pmc_extractor.json
+#   2. VALU issue of k_fast (SQ_INSTS_VALU ..., GRBM_GUI_ACTIVE, 512 images)                        -> r5_pmc_fast.json
+#   3. VALU issue of the round-4 kernels the verdict asked about: k_knn2 and k_sbp_assign_cam (the 4-camera rig sequence
+#      through the one-call tracker) and k_pose_opt_vio (same run)                                  -> r5_pmc_kernels.json
+# Every JSON carries source_sha16 = sha256 of the kernel's source file: bench.py refuses counters of another source.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+export PYTHONPATH=$R
+sha() { sha256sum $R/vieo_slam_amd/csrc/$1 | cut -c1-16; }
+bash $R/tools/pmc_extractor.sh 2048 > $R/gpurun_out/pmc_ext.log 2>&1
+python - $R $(sha orb_extractor.hip) <<'PY'
+import json, sys
+R, sha = sys.argv[1], sys.argv[2]
+d = json.load(open(R + "/gpurun_out/pmc_extractor.json"))
+d["source_sha16"] = {"vieo_slam_amd/csrc/orb_extractor.hip": sha}
+json.dump(d, open(R + "/gpurun_out/r5_pmc_extractor.json", "w"), indent=1)
+tot = sum((2 * v["fetch_kb"] + v["write_kb"]) * v["launches"] for v in d["kernels"].values()) * 1024 / 1e9
+print("extractor HBM traffic per %d images: %.2f GB" % (d["images_per_launch"], tot))
+PY
+run() {  # name, counters..., then "--", then the command
+  name=$1; shift
+  ctr=()
+  while [ "$1" != "--" ]; do ctr+=("$1"); shift; done
+  shift
+  rocprofv3 --pmc "${ctr[@]}" --kernel-trace -d $R/gpurun_out/pmc5_$name -o out -- "$@" > $R/gpurun_out/pmc5_$name.log 2>&1
+  python $R/tools/rocpd_pmc.py $(find $R/gpurun_out/pmc5_$name -name "*.db" | head -1) > $R/gpurun_out/pmc5_$name.txt 2>&1
+}
+run fast_b SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -- python $R/tools/run_extract.py 512 3
+run fast_d GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU -- python $R/tools/run_extract.py 512 3
+run rig_b SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -- python $R/tools/run_rig_sequence.py kb8 4 1500 24 5
+run rig_d GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python $R/tools/run_rig_sequence.py kb8 4 1500 24 5
+python - $R $(sha orb_extractor.hip) $(sha matching.hip) $(sha proj_search.hip) $(sha pose_opt_vio.hip) <<'PY'
+import json, re, sys
+R, s_orb, s_match, s_sbp, s_pose = sys.argv[1:6]
+def read(name):
+    out, k = {}, None
+    for line in open("%s/gpurun_out/pmc5_%s.txt" % (R, name)):
+        if not line.startswith(" "):
+            k = line.strip()
+            out.setdefault(k, {})
+        else:
+            m = re.match(r"\s+(\S+)\s+avg (\S+)\s+\(n=(\d+)\)", line)
+            if m:
+                out[k][m.group(1)] = float(m.group(2))
+    return out
+def pick(d, sub):
+    ks = [k for k in d if sub in k]
+    return d[ks[0]] if ks else {}
+fb, fd = read("fast_b"), read("fast_d")
+c = dict(pick(fb, "k_fast")); c.update(pick(fd, "k_fast"))
+valu = c.get("SQ_INSTS_VALU", 0) / 32.0
+cyc = c.get("GRBM_GUI_ACTIVE", 0)
+fast = {"source": "tools/pmc_round5.sh: rocprofv3 --pmc in separate passes over a 512-image extraction; averages per (XCD, shader engine) "
+                  "counter instance = 8 CUs = 32 SIMDs and per launch",
+        "kernel": "k_fast", "images_per_launch": 512, "counters": c, "valu_insts_per_simd": valu, "kernel_cycles": cyc,
+        "valu_insts_per_cycle_per_simd": valu / cyc if cyc else None,
+        "lane_fill": c.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * c["SQ_ACTIVE_INST_VALU"] * 4 / 4) if c.get("SQ_ACTIVE_INST_VALU") else None,
+        "issue_cycles_per_valu_inst": {"full_rate": 1.9, "half_rate": 3.4, "source": "tools/ubench/valu_rate.hip on gfx950 (profiles/r2_valu_rate.txt)"},
+        "source_sha16": {"vieo_slam_amd/csrc/orb_extractor.hip": s_orb}}
+json.dump(fast, open(R + "/gpurun_out/r5_pmc_fast.json", "w"), indent=1)
+rb, rd = read("rig_b"), read("rig_d")
+ker = {}
+for name, sub, src, sha in (("k_knn2", "k_knn2", "matching.hip", s_match), ("k_sbp_assign_cam", "k_sbp_assign_cam", "proj_search.hip", s_sbp),
+                            ("k_pose_opt_vio<256, rig>", "k_pose_opt_vio", "pose_opt_vio.hip", s_pose), ("k_fe_fill", "k_fe_fill", "fisheye_stereo.hip", "")):
+    c = dict(pick(rb, sub)); c.update(pick(rd, sub))
+    if not c:
+        continue
+    cyc = c.get("GRBM_GUI_ACTIVE", 0)
+    ker[name] = {"counters": c, "source_file": src, "source_sha16": sha,
+                 "valu_insts_per_cycle_per_busy_simd_group": (c.get("SQ_INSTS_VALU", 0) / c["SQ_BUSY_CYCLES"]) if c.get("SQ_BUSY_CYCLES") else None,
+                 "valu_active_over_busy": (c.get("SQ_ACTIVE_INST_VALU", 0) / c["SQ_BUSY_CYCLES"]) if c.get("SQ_BUSY_CYCLES") else None,
+                 "launch_cycles": cyc}
+json.dump({"how": "tools/pmc_round5.sh: the 4-camera KB8 rig sequence (24 frames, one vieo_track_frame call per frame) under rocprofv3 --pmc, "
+                  "two passes; averages per counter instance ((XCD, shader engine) = 32 SIMDs) and per launch; SQ_* count quad-cycles",
+           "kernels": ker}, open(R + "/gpurun_out/r5_pmc_kernels.json", "w"), indent=1)
+print(json.dumps({k: {q: v[q] for q in ("valu_insts_per_cycle_per_busy_simd_group", "valu_active_over_busy", "launch_cycles")} for k, v in ker.items()}, indent=1))
+print("k_fast valu/cycle/simd", fast["valu_insts_per_cycle_per_simd"])
+PY
