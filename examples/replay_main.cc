@@ -25,6 +25,10 @@ namespace {
 
 struct Replay : ReplayBase {
   vieo_tracker* trk = nullptr;
+  // frame pipelining (vieo_track_input.next_left / next_right): a dataset player has frame k + 1's images in hand while
+  // frame k is tracked; their extraction + stereo stage then run beside frame k's searches and optimisations
+  bool prefetch = false, prefetched = false;
+  int last_frame = -1;
 
   explicit Replay(const Sequence& s) : ReplayBase(s) {
     vieo_tracker_params P;
@@ -53,6 +57,11 @@ struct Replay : ReplayBase {
     vieo_track_input in;
     std::memset(&in, 0, sizeof(in));
     in.left = S.image(k, 0), in.right = S.image(k, 1), in.stride = S.W;
+    if (prefetch) {
+      in.use_prefetched = prefetched ? 1 : 0;
+      prefetched = k + 1 <= last_frame;
+      if (prefetched) in.next_left = S.image(k + 1, 0), in.next_right = S.image(k + 1, 1);
+    }
     int i0, ni;
     S.imu_between(ref.t, t, &i0, &ni);
     in.imu = S.imu.data() + i0, in.n_imu = ni;
@@ -114,17 +123,19 @@ struct Replay : ReplayBase {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::fprintf(stderr, "usage: %s seq.vseq [traj.bin] [--frames N] [--warmup M] [--lba-lag L] [--trackers T] [--quiet]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s seq.vseq [traj.bin] [--frames N] [--warmup M] [--lba-lag L] [--prefetch 0|1] [--trackers T] [--quiet]\n", argv[0]);
     return 2;
   }
   const char* traj_path = nullptr;
-  int n_frames = -1, warmup = 0, lba_lag = 0, n_trackers = 1, kf_every = 10;
+  int n_frames = -1, warmup = 0, lba_lag = 0, n_trackers = 1, kf_every = 10, prefetch = 0;
   bool quiet = false;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--frames") && i + 1 < argc)
       n_frames = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--trackers") && i + 1 < argc)
       n_trackers = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--prefetch") && i + 1 < argc)
+      prefetch = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--kf-every") && i + 1 < argc)  // (experiments: a huge value = no key frames, no local BA)
       kf_every = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--warmup") && i + 1 < argc)
@@ -148,7 +159,7 @@ int main(int argc, char** argv) {
   const int n = n_frames > 0 ? std::min(n_frames, S.n_frames) : S.n_frames;
   if (warmup > 1) {
     Replay Wm(S);
-    Wm.lba_lag = lba_lag;
+    Wm.lba_lag = lba_lag, Wm.prefetch = prefetch != 0, Wm.last_frame = std::min(warmup, S.n_frames) - 1;
     Wm.initialise();
     for (int k = 1; k < std::min(warmup, S.n_frames); k++) Wm.before_frame(k), Wm.step(k);
     Wm.before_frame(1 << 30);
@@ -160,7 +171,7 @@ int main(int argc, char** argv) {
     std::vector<std::unique_ptr<Replay>> Rs;
     for (int i = 0; i < n_trackers; i++) {
       Rs.emplace_back(new Replay(S));
-      Rs.back()->lba_lag = lba_lag, Rs.back()->kf_every = kf_every;
+      Rs.back()->lba_lag = lba_lag, Rs.back()->kf_every = kf_every, Rs.back()->prefetch = prefetch != 0, Rs.back()->last_frame = n - 1;
       Rs.back()->initialise();
     }
     std::mutex m;
@@ -222,7 +233,7 @@ int main(int argc, char** argv) {
     return same ? 0 : 1;
   }
   Replay R(S);
-  R.lba_lag = lba_lag, R.kf_every = kf_every;
+  R.lba_lag = lba_lag, R.kf_every = kf_every, R.prefetch = prefetch != 0, R.last_frame = n - 1;
   R.initialise();
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = 1; k < n; k++) {
@@ -257,9 +268,9 @@ int main(int argc, char** argv) {
   const int nf = n - 1;
   std::printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"ms_track_call\": %.4f, \"ms_track_gpu\": %.4f, "
               "\"ms_frame_without_local_ba\": %.4f, \"local_bas\": %d, \"ms_per_local_ba\": %.4f, \"key_frames\": %zu, "
-              "\"map_points\": %zu, \"widened\": %d, \"lba_lag\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e, %s}\n",
+              "\"map_points\": %zu, \"widened\": %d, \"lba_lag\": %d, \"prefetch\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e, %s}\n",
               nf, ms_total / nf, 1e3 * nf / ms_total, R.ms_track / nf, R.ms_gpu / nf, R.ms_frames / nf, R.n_lba,
-              R.n_lba ? R.ms_lba / R.n_lba : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, lba_lag, std::sqrt(e2 / n), emax,
+              R.n_lba ? R.ms_lba / R.n_lba : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, lba_lag, prefetch, std::sqrt(e2 / n), emax,
               R.run_shape_json().c_str());
   return 0;
 }

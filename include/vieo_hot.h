@@ -1188,6 +1188,15 @@ typedef struct vieo_track_input {
   const int32_t* local_alias;           /* candidate j is last_points[local_alias[j]] (-1: not in the last frame) */
   const uint8_t* images[4];             /* rig trackers: camera c's image (left / right are not read); n_last then counts
                                          * mLastFrame's keys in mvKeys (camera-major) order, up to vieo_tracker_key_capacity */
+  /* Frame pipelining (rectified trackers; a replay or any caller that has the NEXT frame's images in hand -- a camera
+   * driver one frame ahead, a dataset player): the next frame's ExtractORB x 2 + ComputeStereoMatches are queued on a
+   * third stream BEHIND this frame's stereo stage and run beside this frame's searches and optimisations (which keep one
+   * CU busy; the extraction wants all of them for ~0.2 ms).  The NEXT call then finds its frame extracted: its
+   * left / right are not read, and it says so with use_prefetched = 1 -- a call with use_prefetched = 0 discards a pending
+   * prefetch.  Outputs are those of the unpipelined call bit for bit (same kernels on the same data).  NULL: off. */
+  const uint8_t *next_left, *next_right; /* `stride` bytes per row like left / right */
+  int32_t use_prefetched;
+  int32_t reserved2;
 } vieo_track_input;
 
 #define VIEO_TRACK_OK 0

@@ -299,3 +299,53 @@ def test_gpu_tracker_second_stream_is_measured_reported_and_reselected():
         L.vieo_stream_destroy(s)
     L.vieo_dev_free(buf)
     R.close()
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_frame_pipelining_is_bit_identical(tmp_path):
+    """vieo_track_input.next_left / next_right: the next frame's ExtractORB x 2 + ComputeStereoMatches run on a third stream
+    beside this frame's searches and optimisations, the next call adopts them (use_prefetched).  Same kernels on the same
+    data: every output of every frame is what the unpipelined tracker returns, from Python and in the C++ replay; a call
+    that does not want a pending prefetch discards it; use_prefetched without one is refused."""
+    import json
+    from tools.write_sequence import write_sequence
+    from vieo_slam_amd._lib import VieoError
+    from vieo_slam_amd.tracker import TrackerReplay
+    n = 34
+    seq = replay.Sequence(5, n)
+    Ra = TrackerReplay(seq, replay.HipStages())
+    ta = Ra.run(n)
+    Rb = TrackerReplay(seq, replay.HipStages(), prefetch=True)
+    tb = Rb.run(n)
+    assert ta.tobytes() == tb.tobytes()
+    assert Ra.stats["n_matches"] == Rb.stats["n_matches"] and Ra.stats["n_inliers"] == Rb.stats["n_inliers"]
+    assert np.array_equal(Ra.last.keys.view(np.uint8), Rb.last.keys.view(np.uint8)) and np.array_equal(Ra.last.uright, Rb.last.uright)
+    ga, gb = np.array(Ra.stats["ms_chain"])[8:, 1].mean(), np.array(Rb.stats["ms_chain"])[8:, 1].mean()
+    # a pending prefetch is discarded by a call that brings its own images; use_prefetched without one is an error
+    Rb2 = TrackerReplay(seq, replay.HipStages(), prefetch=True)
+    Rb2.initialise()
+    Rb2._n_run = n
+    for k in range(1, 6):
+        Rb2.step(k)
+    Rb2._prefetched = False  # frame 6 arrives with its own images although frame 5's call prefetched it
+    for k in range(6, 12):
+        Rb2.step(k)
+    assert np.array(Rb2.traj, ta.dtype).tobytes() == ta[:12].tobytes()
+    Rc = TrackerReplay(seq, replay.HipStages(), prefetch=True)
+    Rc.initialise()
+    Rc._n_run, Rc._prefetched = n, True
+    with pytest.raises(VieoError):
+        Rc.step(1)
+    for R in (Ra, Rb, Rb2, Rc):
+        R.close()
+    exe = os.path.join(ROOT, "examples", "replay_main")
+    path = str(tmp_path / "seq.vseq")
+    write_sequence(path, 5, n, seq)
+    out = {}
+    for pf in (0, 1):
+        traj = str(tmp_path / ("t%d.bin" % pf))
+        line = subprocess.check_output([exe, path, traj, "--quiet", "--lba-lag", "3", "--prefetch", str(pf), "--warmup", "8"], timeout=600).decode().strip().splitlines()[-1]
+        out[pf] = (json.loads(line), open(traj, "rb").read())
+    assert out[0][1] == out[1][1] and out[1][0]["prefetch"] == 1
+    print("frame pipelining: GPU ms per call %.3f -> %.3f (Python driver); C++ replay %.3f -> %.3f ms per frame"
+          % (ga, gb, out[0][0]["ms_per_frame"], out[1][0]["ms_per_frame"]))

@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "imu_device.h"
 #include "orb_internal.h"
@@ -164,6 +165,20 @@ k_track_finish(const int32_t* __restrict__ obs_key, const uint8_t* __restrict__ 
   if (threadIdx.x == 0) O->nobs2[0] = n;
 }
 
+// A prefetched frame becomes the current one: the slot the third stream extracted into -> the arrays the chain reads
+// (both images' keys and descriptors, their counts, uright / depth of the stereo stage).  One launch instead of five copies.
+__global__ void __launch_bounds__(256)
+k_track_adopt(const uint4* __restrict__ s_kp, uint4* __restrict__ d_kp, int n_kp16, const uint4* __restrict__ s_desc,
+              uint4* __restrict__ d_desc, int n_desc16, const uint4* __restrict__ s_ur, uint4* __restrict__ d_ur,
+              const uint4* __restrict__ s_dp, uint4* __restrict__ d_dp, int n_f16, const int32_t* __restrict__ s_cnt,
+              int32_t* __restrict__ d_cnt) {
+  const int stride = gridDim.x * 256;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_kp16; i += stride) d_kp[i] = s_kp[i];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_desc16; i += stride) d_desc[i] = s_desc[i];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_f16; i += stride) d_ur[i] = s_ur[i], d_dp[i] = s_dp[i];
+  if (blockIdx.x == 0 && threadIdx.x < 4) d_cnt[threadIdx.x] = s_cnt[threadIdx.x];
+}
+
 }  // namespace vieo
 
 using namespace vieo;
@@ -177,8 +192,15 @@ struct vieo_tracker {
   int kc = 0;        // key capacity of a frame: cap, or n_cams * cap of a rig (mvKeys)
   vieo_orb* ext = nullptr;
   vieo_fisheye* fe = nullptr;
-  hipStream_t st = nullptr, st_imu = nullptr;
+  hipStream_t st = nullptr, st_imu = nullptr, st_pref = nullptr;
   hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_ext = nullptr, ev_fe = nullptr, ev_kd = nullptr;
+  hipEvent_t ev_head = nullptr, ev_pref = nullptr;  // this frame's stereo stage is done / the next frame is extracted
+  // frame pipelining (vieo_track_input.next_left / next_right): the next frame's images and what its extraction and
+  // stereo stage produce, on the third stream
+  uint8_t *h_next = nullptr, *d_next = nullptr, *d_slot = nullptr;
+  size_t s_kp = 0, s_desc = 0, s_ur = 0, s_dp = 0, s_cnt = 0;
+  bool pref_valid = false;
+  int pref_frames = 0;
   int cap = 0, ccap = 0, pcap = 0, gcap = 0, imu_cap = 512;
   int local_version = -1, n_local_dev = 0;
   int replica_repeats = 0;    // frames whose optimisations were repeated on one workgroup (a replica did not arrive)
@@ -199,7 +221,7 @@ struct vieo_tracker {
   uint8_t* d_work = nullptr;                     // device-only scratch
   uint8_t* d_const = nullptr;                    // rig: vieo_sbp_rig | vieo_camera[4]
   // offsets in the upload block
-  size_t o_hdr, o_imu, o_img, o_pts, o_xyz, o_dep, o_alias, up_fixed;
+  size_t o_hdr, o_imu, o_img, o_pts, o_xyz, o_dep, o_alias, up_fixed, up_small;
   // offsets in the local block
   size_t l_cpt, l_cdesc, l_xyz;
   // offsets in the download block
@@ -272,17 +294,29 @@ static hipError_t create_side_stream(hipStream_t* out, hipStream_t main_stream, 
   return hipSuccess;
 }
 
+// The third stream (the next frame's extraction).  VIEO_PREFETCH_PRIORITY = -1 (lowest: the bundle adjustment's pool of
+// hardware queues), 0 (normal, the default), 1 (highest): A/B runs.
+static hipError_t create_prefetch_stream(hipStream_t* out) {
+  const char* e = getenv("VIEO_PREFETCH_PRIORITY");
+  const int want = e ? atoi(e) : 0;
+  int lo = 0, hi = 0;
+  if (want != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, want < 0 ? lo : hi);
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
 extern "C" {
 
 void vieo_tracker_destroy(vieo_tracker* t) {
   if (!t) return;
   if (t->st) (void)hipStreamSynchronize(t->st);
   if (t->st_imu) (void)hipStreamSynchronize(t->st_imu), (void)hipStreamDestroy(t->st_imu);
-  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe, t->ev_kd})
+  if (t->st_pref) (void)hipStreamSynchronize(t->st_pref), (void)hipStreamDestroy(t->st_pref);
+  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe, t->ev_kd, t->ev_head, t->ev_pref})
     if (e) (void)hipEventDestroy(e);
-  for (uint8_t* p : {t->h_up, t->h_loc, t->h_out})
+  for (uint8_t* p : {t->h_up, t->h_loc, t->h_out, t->h_next})
     if (p) (void)hipHostFree(p);
-  for (uint8_t* p : {t->d_up, t->d_loc, t->d_out, t->d_work, t->d_const})
+  for (uint8_t* p : {t->d_up, t->d_loc, t->d_out, t->d_work, t->d_const, t->d_next, t->d_slot})
     if (p) (void)hipFree(p);
   if (t->fe) vieo_fisheye_destroy(t->fe);
   if (t->ext) vieo_orb_destroy(t->ext);
@@ -342,12 +376,20 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
     o = al256(o + bytes);
     return r;
   };
-  // ---- upload block: [header | IMU samples | images | last points | their xyz | their depth | alias]
-  t->o_hdr = take(sizeof(TrkHdr)), t->o_imu = take((size_t)t->imu_cap * sizeof(vieo_imu_sample)), t->o_img = take(t->n_img * npx);
+  // ---- upload block: [header | IMU samples | last points | their xyz | their depth | alias | images]: the images last, so
+  // that a call whose frame was prefetched uploads the head only
+  t->o_hdr = take(sizeof(TrkHdr)), t->o_imu = take((size_t)t->imu_cap * sizeof(vieo_imu_sample));
   t->o_pts = take((size_t)kc * sizeof(vieo_last_frame_point));
   t->o_xyz = take((size_t)kc * 12), t->o_dep = take((size_t)kc * 4), t->o_alias = take((size_t)ccap * 4);
   t->up_fixed = t->o_alias;
+  t->up_small = o;
+  t->o_img = take(t->n_img * npx);
   const size_t up_bytes = o;
+  // ---- the prefetch slot: both images' keys / descriptors, counts, uright / depth of the left image
+  o = 0;
+  t->s_kp = take((size_t)t->n_img * cap * sizeof(vieo_keypoint)), t->s_desc = take((size_t)t->n_img * cap * 32);
+  t->s_ur = take((size_t)cap * 4 + 16), t->s_dp = take((size_t)cap * 4 + 16), t->s_cnt = take(64);
+  const size_t slot_bytes = o;
   o = 0;
   t->l_cpt = take((size_t)ccap * sizeof(vieo_frustum_point)), t->l_cdesc = take((size_t)ccap * 32), t->l_xyz = take((size_t)ccap * 12);
   const size_t loc_bytes = o;
@@ -381,6 +423,11 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
             hipMalloc((void**)&t->d_up, up_bytes) == hipSuccess && hipMalloc((void**)&t->d_loc, loc_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_out, t->out_bytes) == hipSuccess && hipMalloc((void**)&t->d_work, work_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_const, const_bytes) == hipSuccess &&
+            (R || (hipHostMalloc((void**)&t->h_next, t->n_img * npx, hipHostMallocDefault) == hipSuccess &&
+                   hipMalloc((void**)&t->d_next, t->n_img * npx) == hipSuccess && hipMalloc((void**)&t->d_slot, slot_bytes) == hipSuccess &&
+                   create_prefetch_stream(&t->st_pref) == hipSuccess &&
+                   hipEventCreateWithFlags(&t->ev_pref, hipEventDisableTiming) == hipSuccess)) &&
+            hipEventCreateWithFlags(&t->ev_head, hipEventDisableTiming) == hipSuccess &&
             create_side_stream(&t->st_imu, t->st, &t->side_ratio) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_up, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_imu, hipEventDisableTiming) == hipSuccess &&
@@ -643,6 +690,7 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected) {
 // an error in the middle of the chain: work queued on the two streams still reads the pinned blocks, which the next
 // call would overwrite -- wait for it before handing the error back
 static int track_fail(vieo_tracker* t, int rc) {
+  if (t->st_pref) (void)hipStreamSynchronize(t->st_pref), t->pref_valid = false;
   (void)hipStreamSynchronize(t->st_imu);
   (void)hipStreamSynchronize(t->st);
   return rc;
@@ -671,6 +719,20 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   hipStream_t st = t->st;
   const size_t npx = (size_t)W * Hh;
   const int nl = in->n_last, nc = in->n_local;
+  // frame pipelining: was this frame extracted beside the previous call's tail?
+  if (in->use_prefetched && !t->pref_valid) {
+    set_error("vieo_track_frame: use_prefetched without a pending prefetch (the previous call carried no next_left / next_right)");
+    return VIEO_E_INVALID;
+  }
+  if (in->next_left && (t->rig || !in->next_right)) {
+    set_error("vieo_track_frame: next_left / next_right are for rectified trackers and come as a pair");
+    return VIEO_E_INVALID;
+  }
+  const bool pref = in->use_prefetched != 0;
+  if (!pref && t->pref_valid) {  // a pending prefetch the caller does not want: let it finish, forget it
+    (void)hipStreamSynchronize(t->st_pref);
+    t->pref_valid = false;
+  }
   // ---- the upload block
   TrkHdr& H = *(TrkHdr*)(t->h_up + t->o_hdr);
   H.cam.th = P.th_last;
@@ -688,7 +750,7 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   H.npts[0] = nl, H.npts[1] = nl * t->nc;
   if (in->n_imu) memcpy(t->h_up + t->o_imu, in->imu, (size_t)in->n_imu * sizeof(vieo_imu_sample));
   uint8_t* img = t->h_up + t->o_img;
-  for (int c = 0; c < t->n_img; c++) {
+  for (int c = 0; c < (pref ? 0 : t->n_img); c++) {
     const uint8_t* src = imgs[c];
     uint8_t* dst = img + c * npx;
     if (src == dst) continue;  // decoded straight into the pinned plane
@@ -736,8 +798,20 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   vieo_keypoint* d_kp = (vieo_keypoint*)(Wk + t->w_kp);
   uint8_t* d_desc = Wk + t->w_desc;
   const int* lapping = t->rig && t->R.use_lapping ? t->R.lapping : nullptr;
-  if ((rc = vieo_orb_extract_batch_device(t->ext, t->d_up + t->o_img, t->n_img, W, Hh, W, npx, lapping, d_kp, d_desc, cap, dO->cnt)) != VIEO_OK)
-    return track_fail(t, rc);
+  if (pref) {
+    // the frame was extracted (and its stereo stage run) on the third stream beside the previous call's tail: adopt it
+    TRK_HIP(hipStreamWaitEvent(st, t->ev_pref, 0));
+    const int n_kp16 = (int)(((size_t)t->n_img * cap * sizeof(vieo_keypoint) + 15) / 16), n_desc16 = t->n_img * cap * 2, n_f16 = (cap + 3) / 4;
+    hipLaunchKernelGGL(k_track_adopt, dim3(32), dim3(256), 0, st, (const uint4*)(t->d_slot + t->s_kp), (uint4*)d_kp, n_kp16,
+                       (const uint4*)(t->d_slot + t->s_desc), (uint4*)d_desc, n_desc16, (const uint4*)(t->d_slot + t->s_ur),
+                       (uint4*)(t->d_out + t->q_ur), (const uint4*)(t->d_slot + t->s_dp), (uint4*)(t->d_out + t->q_dp), n_f16,
+                       (const int32_t*)(t->d_slot + t->s_cnt), dO->cnt);
+    t->pref_valid = false;
+  } else {
+    TRK_HIP(hipMemcpyAsync(t->d_up + t->o_img, t->h_up + t->o_img, t->n_img * npx, hipMemcpyHostToDevice, st));
+    if ((rc = vieo_orb_extract_batch_device(t->ext, t->d_up + t->o_img, t->n_img, W, Hh, W, npx, lapping, d_kp, d_desc, cap, dO->cnt)) != VIEO_OK)
+      return track_fail(t, rc);
+  }
   // Everything that needs nothing of the new images goes to the second stream, and is handed to it AFTER the extraction's
   // launches: those are the head of the critical path (the host spends 20-30 us on the second stream's five to eight
   // launches, and the first pyramid level used to wait for them).
@@ -789,10 +863,11 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
       rc = fe_part(VIEO_FISHEYE_GROUPS, t->st_imu);
       TRK_HIP(hipEventRecord(t->ev_fe, t->st_imu));
     }
-  } else
+  } else if (!pref)
     rc = vieo_stereo_match_rectified_batch_device(t->ext, 1, d_kp, d_desc, dO->cnt, cap, P.baseline, P.bf, (float*)(t->d_out + t->q_ur),
                                                   (float*)(t->d_out + t->q_dp));
   if (rc != VIEO_OK) return track_fail(t, rc);
+  TRK_HIP(hipEventRecord(t->ev_head, st));  // the extractor's pyramids and scratch are free from here on
   // the frame's keys / descriptors (mvKeys / mDescriptors: the left image's, or the rig's concatenation) are final here:
   // their copies back travel on the second stream while the frame is tracked
   if (!t->rig) {
@@ -806,6 +881,38 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   if ((rc = track_chain_tail(t, nc, true)) != VIEO_OK) return track_fail(t, rc);
   TRK_HIP(hipStreamWaitEvent(st, t->ev_kd, 0));  // (the keys' / descriptors' copies)
   TRK_HIP(hipEventRecord(t->ev_t1, st));
+  if (in->next_left) {
+    // ---- the NEXT frame's Frame::Frame on the third stream, beside this frame's searches and optimisations (which are
+    // queued by now): copy its images to the pinned planes (the host is otherwise about to wait), up, ExtractORB x 2,
+    // ComputeStereoMatches into the slot the next call adopts
+    const uint8_t* nx[2] = {in->next_left, in->next_right};
+    for (int c = 0; c < 2; c++) {
+      uint8_t* dst = t->h_next + c * npx;
+      if (in->stride == W)
+        memcpy(dst, nx[c], npx);
+      else
+        for (int y = 0; y < Hh; y++) memcpy(dst + (size_t)y * W, nx[c] + (size_t)y * in->stride, W);
+    }
+    hipStream_t sp = t->st_pref;
+    TRK_HIP(hipStreamWaitEvent(sp, t->ev_head, 0));
+    TRK_HIP(hipMemcpyAsync(t->d_next, t->h_next, 2 * npx, hipMemcpyHostToDevice, sp));
+    vieo_keypoint* s_kp = (vieo_keypoint*)(t->d_slot + t->s_kp);
+    uint8_t* s_desc = t->d_slot + t->s_desc;
+    int32_t* s_cnt = (int32_t*)(t->d_slot + t->s_cnt);
+    hipStream_t keep = t->ext->stream;
+    t->ext->stream = sp;  // (the extractor and the stereo matcher launch on the handle's stream)
+    rc = vieo_orb_extract_batch_device(t->ext, t->d_next, 2, W, Hh, W, npx, nullptr, s_kp, s_desc, cap, s_cnt);
+    if (rc == VIEO_OK)
+      rc = vieo_stereo_match_rectified_batch_device(t->ext, 1, s_kp, s_desc, s_cnt, cap, P.baseline, P.bf, (float*)(t->d_slot + t->s_ur),
+                                                    (float*)(t->d_slot + t->s_dp));
+    t->ext->stream = keep;
+    if (rc != VIEO_OK) {
+      (void)hipStreamSynchronize(sp);
+      return track_fail(t, rc);
+    }
+    TRK_HIP(hipEventRecord(t->ev_pref, sp));
+    t->pref_valid = true, t->pref_frames++;
+  }
   TRK_HIP(hipStreamSynchronize(st));
   const TrkOut* O = (const TrkOut*)(t->h_out + t->q_hdr);
   const bool pre_ok = t->vision || (O->preint_status[0] == 0 && O->imu.dt != 0);

@@ -30,7 +30,8 @@ TRACK_INPUT_DTYPE = np.dtype([
     ("left", "<u8"), ("right", "<u8"), ("stride", "<i4"), ("n_imu", "<i4"), ("imu", "<u8"), ("t_ref", "<f8"),
     ("t_cur", "<f8"), ("nav_ref", NAVSTATE_DTYPE), ("nav_last", NAVSTATE_DTYPE), ("nav_prior", "<u8"), ("H_prior", "<u8"),
     ("n_last", "<i4"), ("last_points", "<u8"), ("last_track_depth", "<u8"), ("n_local", "<i4"), ("local_version", "<i4"),
-    ("local_points", "<u8"), ("local_desc", "<u8"), ("local_alias", "<u8"), ("images", "<u8", 4)], align=True)
+    ("local_points", "<u8"), ("local_desc", "<u8"), ("local_alias", "<u8"), ("images", "<u8", 4), ("next_left", "<u8"),
+    ("next_right", "<u8"), ("use_prefetched", "<i4"), ("reserved2", "<i4")], align=True)
 TRACK_OUTPUT_DTYPE = np.dtype([
     ("status", "<i4"), ("n_keys", "<i4"), ("key_cap", "<i4"), ("keys", "<u8"), ("desc", "<u8"), ("uright", "<u8"),
     ("depth", "<u8"), ("point_ref", "<u8"), ("outlier", "<u8"), ("local_track_depth", "<u8"), ("n_matches_last", "<i4"),
@@ -162,11 +163,21 @@ class Tracker:
         return s
 
     def track(self, left, right, imu, t_ref, t_cur, nav_ref, nav_last, prior, last_points, last_track_depth, local_points,
-              local_desc, local_alias, local_version, images=None):
+              local_desc, local_alias, local_version, images=None, next_images=None, use_prefetched=False):
+        """next_images = (left, right) of the frame the NEXT call will track: its extraction + stereo stage run beside this
+        frame's searches and optimisations; that call passes use_prefetched=True (its own images are then not read)."""
         i = self.inp[0]
         keep = []
         imgs = [left, right] if images is None else list(images)
+        if use_prefetched and images is None:
+            imgs = [self.planes[0], self.planes[1]]  # (not read)
         assert len(imgs) == self.n_img
+        i["next_left"] = i["next_right"] = 0
+        i["use_prefetched"] = int(bool(use_prefetched))
+        if next_images is not None:
+            nl, nr = (np.ascontiguousarray(x, np.uint8) for x in next_images)
+            keep += [nl, nr]
+            i["next_left"], i["next_right"] = nl.ctypes.data, nr.ctypes.data
         ptrs = []
         for c, img in enumerate(imgs):
             if img is self.planes[c]:
@@ -218,15 +229,21 @@ class Tracker:
 class TrackerReplay(rp.Replay):
     """The sequential replay with every frame's tracking as ONE vieo_track_frame call."""
 
-    def __init__(self, seq, stages, max_local_points=16384, **kw):
+    def __init__(self, seq, stages, max_local_points=16384, prefetch=False, **kw):
         super().__init__(seq, stages, **kw)
         self.trk = Tracker(euroc_params(max_local_points, self.th_last, self.th_local, seq.noise[0]))
         self._lv = 0
+        # frame pipelining: frame k + 1's images go along with frame k's call (vieo_track_input.next_left / next_right)
+        self.prefetch, self._prefetched, self._n_run = bool(prefetch), False, 0
         self.stats["ms_chain"] = []
         self.stats["widened"] = 0
 
     def close(self):
         self.trk.close()
+
+    def run(self, n_frames=None):
+        self._n_run = n_frames or self.seq.n_frames
+        return super().run(n_frames)
 
     def _all_local_points(self):
         key = (len(self.kfs), self.stats["lba_applied"])
@@ -267,8 +284,12 @@ class TrackerReplay(rp.Replay):
         lk = np.nonzero(has)[0]
         where[last.mp_ref[lk[::-1]]] = lk[::-1]
         alias = where[cand] if len(cand) else np.zeros(0, np.int32)
+        use_pf = self.prefetch and self._prefetched
+        nxt = self.seq.images(k + 1) if (self.prefetch and k + 1 < self._n_run) else None
+        self._prefetched = nxt is not None
         o, v = self.trk.track(Li, Ri, self.seq.imu_between(t_ref, t), t_ref, t, ref_nav, last.nav, prior, pts,
-                              last.track_depth, self._lp_pts, self._lp_desc, alias, self._lv)
+                              last.track_depth, self._lp_pts, self._lp_desc, alias, self._lv, next_images=nxt,
+                              use_prefetched=use_pf)
         assert int(o["status"]) == 0, "IMU pre-integration failed"
         self.stats["ms_chain"].append((float(o["ms_host"]), float(o["ms_gpu"])))
         self.stats["widened"] += int(o["widened"])
