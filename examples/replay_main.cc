@@ -29,6 +29,7 @@ struct Replay : ReplayBase {
   // frame k is tracked; their extraction + stereo stage then run beside frame k's searches and optimisations
   bool prefetch = false, prefetched = false;
   int last_frame = -1;
+  double ms_prep = 0, ms_post = 0, ms_finish = 0;  // the caller's own work per frame: before / after the call, bookkeeping
 
   explicit Replay(const Sequence& s) : ReplayBase(s) {
     vieo_tracker_params P;
@@ -60,7 +61,13 @@ struct Replay : ReplayBase {
     if (prefetch) {
       in.use_prefetched = prefetched ? 1 : 0;
       prefetched = k + 1 <= last_frame;
-      if (prefetched) in.next_left = S.image(k + 1, 0), in.next_right = S.image(k + 1, 1);
+      if (prefetched) {
+        in.next_left = S.image(k + 1, 0), in.next_right = S.image(k + 1, 1);
+        // ... and its pre-integration, which starts at this frame unless the map is updated in between
+        int j0, nj;
+        S.imu_between(t, S.time(k + 1), &j0, &nj);
+        in.next_imu = S.imu.data() + j0, in.next_n_imu = nj, in.next_t_cur = S.time(k + 1);
+      }
     }
     int i0, ni;
     S.imu_between(ref.t, t, &i0, &ni);
@@ -90,7 +97,9 @@ struct Replay : ReplayBase {
     in.n_local = (int)lp.size(), in.local_version = local_version;
     in.local_points = lp_pts.data(), in.local_desc = lp_desc.data(), in.local_alias = alias.data();
     vieo_track_output out;
+    const auto t1 = std::chrono::steady_clock::now();
     CHECK(vieo_track_frame(trk, &in, &out));
+    const auto t2 = std::chrono::steady_clock::now();
     if (out.status != VIEO_TRACK_OK) {
       std::fprintf(stderr, "frame %d: IMU pre-integration failed (%d)\n", k, out.preint_status);
       std::exit(1);
@@ -114,8 +123,11 @@ struct Replay : ReplayBase {
     f->has_prior = out.second.has_marg != 0;
     if (f->has_prior) f->prior_nav = f->nav, std::memcpy(f->H_prior, out.second.H_marg, sizeof(f->H_prior));
     map_updated = false;
-    ms_frames += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const auto t3 = std::chrono::steady_clock::now();
+    ms_frames += std::chrono::duration<double, std::milli>(t3 - t0).count();
     finish_frame(k, f);
+    ms_prep += std::chrono::duration<double, std::milli>(t1 - t0).count(), ms_post += std::chrono::duration<double, std::milli>(t3 - t2).count();
+    ms_finish += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t3).count();
   }
 };
 
@@ -236,9 +248,11 @@ int main(int argc, char** argv) {
   R.lba_lag = lba_lag, R.kf_every = kf_every, R.prefetch = prefetch != 0, R.last_frame = n - 1;
   R.initialise();
   const auto t0 = std::chrono::steady_clock::now();
+  double ms_before = 0;
   for (int k = 1; k < n; k++) {
     const auto tk = std::chrono::steady_clock::now();
     R.before_frame(k);
+    ms_before += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
     R.step(k);
     R.frame_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count());
     if (!quiet && k % 10 == 0) {
@@ -268,9 +282,10 @@ int main(int argc, char** argv) {
   const int nf = n - 1;
   std::printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"ms_track_call\": %.4f, \"ms_track_gpu\": %.4f, "
               "\"ms_frame_without_local_ba\": %.4f, \"local_bas\": %d, \"ms_per_local_ba\": %.4f, \"key_frames\": %zu, "
-              "\"map_points\": %zu, \"widened\": %d, \"lba_lag\": %d, \"prefetch\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e, %s}\n",
+              "\"map_points\": %zu, \"widened\": %d, \"lba_lag\": %d, \"prefetch\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e, "
+              "\"caller_ms_per_frame\": {\"map_write_back\": %.4f, \"before_call\": %.4f, \"after_call\": %.4f, \"key_frame_bookkeeping\": %.4f}, %s}\n",
               nf, ms_total / nf, 1e3 * nf / ms_total, R.ms_track / nf, R.ms_gpu / nf, R.ms_frames / nf, R.n_lba,
               R.n_lba ? R.ms_lba / R.n_lba : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, lba_lag, prefetch, std::sqrt(e2 / n), emax,
-              R.run_shape_json().c_str());
+              ms_before / nf, R.ms_prep / nf, R.ms_post / nf, R.ms_finish / nf, R.run_shape_json().c_str());
   return 0;
 }

@@ -1196,7 +1196,15 @@ typedef struct vieo_track_input {
    * prefetch.  Outputs are those of the unpipelined call bit for bit (same kernels on the same data).  NULL: off. */
   const uint8_t *next_left, *next_right; /* `stride` bytes per row like left / right */
   int32_t use_prefetched;
-  int32_t reserved2;
+  /* ... and the next frame's pre-integration (IMU trackers): with the extraction out of the way it is the 75 us serial
+   * chain at the head of the next call.  next_imu = the samples PreIntegration will hand over for [t_cur, next_t_cur],
+   * i.e. with THIS frame as the next call's reference: they are integrated beside this frame's tail with the bias this
+   * frame's prediction produced (bj_bar = bi_bar + dbi).  The next call uses the result when -- and only when -- its own
+   * t_ref / t_cur / samples / nav_ref.bg / nav_ref.ba are bit for bit what was integrated (after a map update the
+   * reference is the key frame: the comparison fails and the call integrates as usual).  NULL / 0: off. */
+  int32_t next_n_imu;
+  const vieo_imu_sample* next_imu;
+  double next_t_cur;
 } vieo_track_input;
 
 #define VIEO_TRACK_OK 0
@@ -1261,6 +1269,8 @@ typedef struct vieo_tracker_stats {
                                    * workgroup never became resident (vieo_pose_set_replicas) */
   float ms_gpu_median;            /* running median of vieo_track_output.ms_gpu (last 32 frames) */
   int32_t slow_frames_in_a_row;   /* frames in a row above 1.3 x that median */
+  int32_t frames_prefetched;      /* frames extracted ahead (vieo_track_input.next_left / next_right) */
+  int32_t preints_ahead_used;     /* calls that found their pre-integration done by the previous call (next_imu) */
 } vieo_tracker_stats;
 int vieo_tracker_get_stats(const vieo_tracker* t, vieo_tracker_stats* out);
 int vieo_tracker_reprobe(vieo_tracker* t);

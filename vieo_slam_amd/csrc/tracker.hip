@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "imu_device.h"
@@ -40,6 +41,14 @@ struct TrkHdr {
   float consts[32];          // inv_sigma2[16], scale[16]
 };
 
+// The next frame's pre-integration, run ahead (vieo_track_input.next_imu): what goes up for it.  In HBM the block is
+// [SpecImu | samples | bias (6 doubles, written by k_track_predict) | vieo_imu_preint | Sigma_prv (81) | status].
+struct SpecImu {
+  vieo_imu_noise noise;
+  double ti, tj;
+  int32_t first[2];
+};
+
 // download header
 struct TrkOut {
   int32_t cnt[8];            // extractor counts per image: {n, mono}
@@ -56,11 +65,27 @@ struct TrkOut {
   int32_t fcnt[2];           // rig: {N, 0}
 };
 
+// The last frame's part of the tail's two point tables ([last frame's points | local candidates]: positions, track depths)
+// comes up with the header; blocks 1.. of the prediction kernels move it in place (two copies and an event less to hand
+// to the second stream per frame).
+constexpr int kTableBlocks = 16;
+struct TrkTables {
+  const float *xyz_in, *dep_in;
+  float *xyz_out, *dep_out;
+};
+__device__ __forceinline__ void track_fill_tables(const TrkTables& T, int n_last) {
+  const int i0 = (blockIdx.x - 1) * 64 + threadIdx.x, step = kTableBlocks * 64;
+  for (int i = i0; i < 3 * n_last; i += step) T.xyz_out[i] = T.xyz_in[i];
+  for (int i = i0; i < n_last; i += step) T.dep_out[i] = T.dep_in[i];
+}
+
 // PredictNavStateByIMU (Tracking.cc:385-451) from the pre-integration in HBM; fills the two optimiser problems and
 // the projection search's camera.  One wavefront; lane 0 does the (double) arithmetic, all lanes copy.
 __global__ void __launch_bounds__(64)
 k_track_predict(TrkHdr* __restrict__ H, TrkOut* __restrict__ O, const vieo_imu_preint* __restrict__ pre,
-                const double* __restrict__ sigma_prv, const int32_t* __restrict__ status) {
+                const double* __restrict__ sigma_prv, const int32_t* __restrict__ status, double* __restrict__ next_bias,
+                TrkTables tables) {
+  if (blockIdx.x > 0) return track_fill_tables(tables, H->npts[0]);
   __shared__ vieo_navstate s_nav;
   const int lane = threadIdx.x;
   const vieo_imu_preint& M = *pre;
@@ -96,6 +121,8 @@ k_track_predict(TrkHdr* __restrict__ H, TrkOut* __restrict__ O, const vieo_imu_p
       ns.dbg[k] = 0, ns.dba[k] = 0;
     }
     s_nav = ns;
+    // (bj_bar: the bias the NEXT frame's pre-integration runs with when this frame is its reference -- SpecImu below)
+    for (int k = 0; k < 3; k++) next_bias[k] = ns.bg[k], next_bias[3 + k] = ns.ba[k];
     // Tcw = Tcb Twb^-1 of the predicted and of the last frame's state (UpdatePoseFromNS)
     for (int which = 0; which < 2; which++) {
       const vieo_navstate& n = which == 0 ? ns : H->nav_last;
@@ -130,7 +157,8 @@ k_track_predict(TrkHdr* __restrict__ H, TrkOut* __restrict__ O, const vieo_imu_p
 // The vision-only tracker's prediction comes from the host (mVelocity * mLastFrame.Tcw, Tracking.cc:1852): the two
 // optimiser problems start from it, the projection search gets Tcw of it and of the last frame.
 __global__ void __launch_bounds__(64)
-k_track_set_pose(TrkHdr* __restrict__ H, TrkOut* __restrict__ O) {
+k_track_set_pose(TrkHdr* __restrict__ H, TrkOut* __restrict__ O, TrkTables tables) {
+  if (blockIdx.x > 0) return track_fill_tables(tables, H->npts[0]);
   const int lane = threadIdx.x;
   if (lane < 2) {
     const vieo_navstate& n = lane == 0 ? H->nav_ref : H->nav_last;
@@ -195,12 +223,22 @@ struct vieo_tracker {
   hipStream_t st = nullptr, st_imu = nullptr, st_pref = nullptr;
   hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_ext = nullptr, ev_fe = nullptr, ev_kd = nullptr;
   hipEvent_t ev_head = nullptr, ev_pref = nullptr;  // this frame's stereo stage is done / the next frame is extracted
+  hipEvent_t ev_tab = nullptr;                      // a changed local map (second stream) is in place
+  bool tab_pending = false;
   // frame pipelining (vieo_track_input.next_left / next_right): the next frame's images and what its extraction and
   // stereo stage produce, on the third stream
   uint8_t *h_next = nullptr, *d_next = nullptr, *d_slot = nullptr;
   size_t s_kp = 0, s_desc = 0, s_ur = 0, s_dp = 0, s_cnt = 0;
   bool pref_valid = false;
   int pref_frames = 0;
+  // ... and its pre-integration (next_imu): pinned / device blocks, what was integrated (the next call compares), counts
+  uint8_t *h_spec = nullptr, *d_spec = nullptr;
+  size_t sp_samples = 0, sp_bias = 0, sp_pre = 0, sp_prv = 0, sp_pst = 0, sp_up = 0;
+  std::vector<vieo_imu_sample> spec_samples;
+  double spec_ti = 0, spec_tj = 0, spec_bias[6] = {0, 0, 0, 0, 0, 0};
+  int spec_n = 0;
+  bool spec_valid = false;
+  int spec_used = 0;
   int cap = 0, ccap = 0, pcap = 0, gcap = 0, imu_cap = 512;
   int local_version = -1, n_local_dev = 0;
   int replica_repeats = 0;    // frames whose optimisations were repeated on one workgroup (a replica did not arrive)
@@ -312,11 +350,11 @@ void vieo_tracker_destroy(vieo_tracker* t) {
   if (t->st) (void)hipStreamSynchronize(t->st);
   if (t->st_imu) (void)hipStreamSynchronize(t->st_imu), (void)hipStreamDestroy(t->st_imu);
   if (t->st_pref) (void)hipStreamSynchronize(t->st_pref), (void)hipStreamDestroy(t->st_pref);
-  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe, t->ev_kd, t->ev_head, t->ev_pref})
+  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe, t->ev_kd, t->ev_head, t->ev_pref, t->ev_tab})
     if (e) (void)hipEventDestroy(e);
-  for (uint8_t* p : {t->h_up, t->h_loc, t->h_out, t->h_next})
+  for (uint8_t* p : {t->h_up, t->h_loc, t->h_out, t->h_next, t->h_spec})
     if (p) (void)hipHostFree(p);
-  for (uint8_t* p : {t->d_up, t->d_loc, t->d_out, t->d_work, t->d_const, t->d_next, t->d_slot})
+  for (uint8_t* p : {t->d_up, t->d_loc, t->d_out, t->d_work, t->d_const, t->d_next, t->d_slot, t->d_spec})
     if (p) (void)hipFree(p);
   if (t->fe) vieo_fisheye_destroy(t->fe);
   if (t->ext) vieo_orb_destroy(t->ext);
@@ -416,6 +454,11 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
   t->w_xyz = take((size_t)t->pcap * 12), t->w_dep = take((size_t)t->pcap * 4);
   t->w_pre = take(sizeof(vieo_imu_preint)), t->w_prv = take(81 * 8), t->w_pst = take(16);
   const size_t work_bytes = o;
+  o = 0;
+  (void)take(sizeof(SpecImu));
+  t->sp_samples = take((size_t)t->imu_cap * sizeof(vieo_imu_sample)), t->sp_up = o;
+  t->sp_bias = take(6 * 8), t->sp_pre = take(sizeof(vieo_imu_preint)), t->sp_prv = take(81 * 8), t->sp_pst = take(16);
+  const size_t spec_bytes = o;
   const size_t const_bytes = al256(sizeof(vieo_sbp_rig)) + al256(sizeof(vieo_camera) * 4);
   bool ok = hipHostMalloc((void**)&t->h_up, up_bytes, hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&t->h_loc, loc_bytes, hipHostMallocDefault) == hipSuccess &&
@@ -423,11 +466,14 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
             hipMalloc((void**)&t->d_up, up_bytes) == hipSuccess && hipMalloc((void**)&t->d_loc, loc_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_out, t->out_bytes) == hipSuccess && hipMalloc((void**)&t->d_work, work_bytes) == hipSuccess &&
             hipMalloc((void**)&t->d_const, const_bytes) == hipSuccess &&
+            hipHostMalloc((void**)&t->h_spec, t->sp_up, hipHostMallocDefault) == hipSuccess &&
+            hipMalloc((void**)&t->d_spec, spec_bytes) == hipSuccess && hipMemset(t->d_spec, 0, spec_bytes) == hipSuccess &&
             (R || (hipHostMalloc((void**)&t->h_next, t->n_img * npx, hipHostMallocDefault) == hipSuccess &&
                    hipMalloc((void**)&t->d_next, t->n_img * npx) == hipSuccess && hipMalloc((void**)&t->d_slot, slot_bytes) == hipSuccess &&
                    create_prefetch_stream(&t->st_pref) == hipSuccess &&
                    hipEventCreateWithFlags(&t->ev_pref, hipEventDisableTiming) == hipSuccess)) &&
             hipEventCreateWithFlags(&t->ev_head, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&t->ev_tab, hipEventDisableTiming) == hipSuccess &&
             create_side_stream(&t->st_imu, t->st, &t->side_ratio) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_up, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_imu, hipEventDisableTiming) == hipSuccess &&
@@ -550,6 +596,7 @@ int vieo_tracker_get_stats(const vieo_tracker* t, vieo_tracker_stats* out) {
   memset(out, 0, sizeof(*out));
   out->side_stream_ratio = t->side_ratio, out->side_stream_selections = t->side_probes, out->side_stream_checks = t->side_checks;
   out->replica_repeats = t->replica_repeats;
+  out->frames_prefetched = t->pref_frames, out->preints_ahead_used = t->spec_used;
   const int n = std::min(t->gpu_n, 32);
   if (n > 0) {
     float v[32];
@@ -593,7 +640,9 @@ static int track_project(vieo_tracker* t, hipStream_t s) {
 
 // projected: the first search's queries are there already (the prediction, the projection of the last frame's points and,
 // for rigs, their compaction ran on the second stream beside the extraction); false for the repeat with the wider window
-static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected) {
+// side_rest: what the caller still has to hand to the second stream (recorded into ev_tab / ev_kd / ev_fe there); called
+// behind the first optimisation's launch
+static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, const std::function<int()>* side_rest = nullptr) {
   const vieo_tracker_params& P = t->P;
   const int kc = t->kc, nc = t->nc;
   hipStream_t st = t->st;
@@ -664,6 +713,12 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected) {
   }
   TRK(build_obs(f1));
   TRK(pose(f1, r1));
+  // a changed local map travels on the second stream; nothing before this line reads it
+  if (side_rest) TRK((*side_rest)());
+  if (t->tab_pending) {
+    if (hipStreamWaitEvent(st, t->ev_tab, 0) != hipSuccess) return VIEO_E_HIP;
+    t->tab_pending = false;
+  }
   TRK(vieo_track_after_pose_batch_device(d_mpref, d_obskey, d_outl, f1, r1, vio, kc, 1, f2, d_taken, st));
   TRK(vieo_track_mark_held_batch_device(d_mpref, d_cnt, kc, 1, 0, 2, d_held, t->pcap, st));
   // (the kernel reads only the leading vieo_pose_frame / vieo_pose_result of its two arguments)
@@ -691,6 +746,7 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected) {
 // call would overwrite -- wait for it before handing the error back
 static int track_fail(vieo_tracker* t, int rc) {
   if (t->st_pref) (void)hipStreamSynchronize(t->st_pref), t->pref_valid = false;
+  t->spec_valid = false;
   (void)hipStreamSynchronize(t->st_imu);
   (void)hipStreamSynchronize(t->st);
   return rc;
@@ -815,70 +871,101 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   // Everything that needs nothing of the new images goes to the second stream, and is handed to it AFTER the extraction's
   // launches: those are the head of the critical path (the host spends 20-30 us on the second stream's five to eight
   // launches, and the first pyramid level used to wait for them).
+  const TrkTables tables{(const float*)(t->d_up + t->o_xyz), (const float*)(t->d_up + t->o_dep), (float*)(Wk + t->w_xyz), (float*)(Wk + t->w_dep)};
   if (!t->vision) {
-    // the pre-integration beside the extraction
+    // the pre-integration beside the extraction -- or, run ahead by the previous call (next_imu), if what that call
+    // integrated is bit for bit what this call asks for
+    const bool ahead = t->spec_valid && in->n_imu == t->spec_n && in->t_ref == t->spec_ti && in->t_cur == t->spec_tj &&
+                       (in->n_imu == 0 || memcmp(in->imu, t->spec_samples.data(), (size_t)in->n_imu * sizeof(vieo_imu_sample)) == 0) &&
+                       memcmp(in->nav_ref.bg, t->spec_bias, 24) == 0 && memcmp(in->nav_ref.ba, t->spec_bias + 3, 24) == 0;
+    t->spec_valid = false;
+    const uint8_t* pre_at = ahead ? t->d_spec + t->sp_pre : Wk + t->w_pre;
+    const uint8_t* prv_at = ahead ? t->d_spec + t->sp_prv : Wk + t->w_prv;
+    const uint8_t* pst_at = ahead ? t->d_spec + t->sp_pst : Wk + t->w_pst;
     TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
-    if ((rc = vieo_imu_preintegrate_batch_device(&dH->noise, (const vieo_imu_sample*)(t->d_up + t->o_imu), dH->first, &dH->ti, &dH->tj,
-                                                 dH->bg, dH->ba, 1, (vieo_imu_preint*)(Wk + t->w_pre), (double*)(Wk + t->w_prv),
-                                                 (int32_t*)(Wk + t->w_pst), t->st_imu)) != VIEO_OK)
+    if (ahead)
+      t->spec_used++;
+    else if ((rc = vieo_imu_preintegrate_batch_device(&dH->noise, (const vieo_imu_sample*)(t->d_up + t->o_imu), dH->first, &dH->ti,
+                                                      &dH->tj, dH->bg, dH->ba, 1, (vieo_imu_preint*)(Wk + t->w_pre),
+                                                      (double*)(Wk + t->w_prv), (int32_t*)(Wk + t->w_pst), t->st_imu)) != VIEO_OK)
       return track_fail(t, rc);
-    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(64), 0, t->st_imu, dH, dO, (const vieo_imu_preint*)(Wk + t->w_pre),
-                       (const double*)(Wk + t->w_prv), (const int32_t*)(Wk + t->w_pst));
+    hipLaunchKernelGGL(k_track_predict, dim3(1 + kTableBlocks), dim3(64), 0, t->st_imu, dH, dO, (const vieo_imu_preint*)pre_at,
+                       (const double*)prv_at, (const int32_t*)pst_at, (double*)(t->d_spec + t->sp_bias), tables);
   } else {
     TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
-    hipLaunchKernelGGL(k_track_set_pose, dim3(1), dim3(64), 0, t->st_imu, dH, dO);
+    hipLaunchKernelGGL(k_track_set_pose, dim3(1 + kTableBlocks), dim3(64), 0, t->st_imu, dH, dO, tables);
   }
   // PredictNavStateByIMU and the projection of the last frame's points need nothing of the new images: beside the extraction
   TRK_HIP(hipGetLastError());
   if ((rc = track_project(t, t->st_imu)) != VIEO_OK) return track_fail(t, rc);
-  if (new_local) {
-    TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cpt, t->h_loc + t->l_cpt, (size_t)nc * sizeof(vieo_frustum_point), hipMemcpyHostToDevice, t->st_imu));
-    TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cdesc, t->h_loc + t->l_cdesc, (size_t)nc * 32, hipMemcpyHostToDevice, t->st_imu));
-    TRK_HIP(hipMemcpyAsync(Wk + t->w_xyz + (size_t)kc * 12, t->h_loc + t->l_xyz, (size_t)nc * 12, hipMemcpyHostToDevice, t->st_imu));
-    t->local_version = in->local_version, t->n_local_dev = nc;
-  }
-  // the last frame's part of the two point tables (read by the tail only)
-  if (nl) {
-    TRK_HIP(hipMemcpyAsync(Wk + t->w_xyz, t->d_up + t->o_xyz, (size_t)nl * 12, hipMemcpyDeviceToDevice, t->st_imu));
-    TRK_HIP(hipMemcpyAsync(Wk + t->w_dep, t->d_up + t->o_dep, (size_t)nl * 4, hipMemcpyDeviceToDevice, t->st_imu));
-  }
-  TRK_HIP(hipEventRecord(t->ev_imu, t->st_imu));
-  if (t->rig) {
-    // ComputeStereoFishEyeMatches (Frame.cc:613-779) into mvKeys order: keys / descriptors in the work block, the tables in
-    // the download block
-    // What tracking reads of it -- the concatenated keys and descriptors, the cameras' ranges, uright = -1 -- does not
-    // depend on the matches: that part stays on this stream (one short kernel), the matches / groups / depths, which are
-    // outputs of the frame only (knn-2, pairs, FillMatchesFromPair's walk, re-triangulation: 0.3 ms of a 4-camera frame),
-    // run on the second stream beside the two searches and optimisations and are joined before the copy back.
-    auto fe_part = [&](int part, hipStream_t s) {
-      return vieo_stereo_fisheye_match_batch_device_part(
-          t->fe, d_kp, d_desc, dO->cnt, 1, (vieo_keypoint*)(Wk + t->w_kcat), Wk + t->w_dcat, dO->cam_first, dO->fcnt,
-          (float*)(t->d_out + t->q_dp), (float*)(t->d_out + t->q_ur), (int32_t*)(t->d_out + t->q_kg),
-          (int32_t*)(t->d_out + t->q_gidx), t->d_out + t->q_good, (double*)(t->d_out + t->q_p3d), dO->fe_hdr, part, s);
-    };
+  TRK_HIP(hipEventRecord(t->ev_imu, t->st_imu));  // the prediction and the first search's queries: what the search waits for
+  // ComputeStereoFishEyeMatches (Frame.cc:613-779) into mvKeys order: keys / descriptors in the work block, the tables in
+  // the download block.
+  // What tracking reads of it -- the concatenated keys and descriptors, the cameras' ranges, uright = -1 -- does not
+  // depend on the matches: that part stays on this stream (one short kernel), the matches / groups / depths, which are
+  // outputs of the frame only (knn-2, pairs, FillMatchesFromPair's walk, re-triangulation: 0.3 ms of a 4-camera frame),
+  // run on the second stream beside the two searches and optimisations and are joined before the copy back.
+  auto fe_part = [&](int part, hipStream_t s) {
+    return vieo_stereo_fisheye_match_batch_device_part(
+        t->fe, d_kp, d_desc, dO->cnt, 1, (vieo_keypoint*)(Wk + t->w_kcat), Wk + t->w_dcat, dO->cam_first, dO->fcnt,
+        (float*)(t->d_out + t->q_dp), (float*)(t->d_out + t->q_ur), (int32_t*)(t->d_out + t->q_kg),
+        (int32_t*)(t->d_out + t->q_gidx), t->d_out + t->q_good, (double*)(t->d_out + t->q_p3d), dO->fe_hdr, part, s);
+  };
+  if (t->rig)
     rc = fe_part(VIEO_FISHEYE_CONCAT, st);
-    if (rc == VIEO_OK) {
-      TRK_HIP(hipEventRecord(t->ev_ext, st));  // (the extraction and the concatenation: what the second stream reads)
-      TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_ext, 0));
-      rc = fe_part(VIEO_FISHEYE_GROUPS, t->st_imu);
-      TRK_HIP(hipEventRecord(t->ev_fe, t->st_imu));
-    }
-  } else if (!pref)
+  else if (!pref)
     rc = vieo_stereo_match_rectified_batch_device(t->ext, 1, d_kp, d_desc, dO->cnt, cap, P.baseline, P.bf, (float*)(t->d_out + t->q_ur),
                                                   (float*)(t->d_out + t->q_dp));
   if (rc != VIEO_OK) return track_fail(t, rc);
   TRK_HIP(hipEventRecord(t->ev_head, st));  // the extractor's pyramids and scratch are free from here on
   // the frame's keys / descriptors (mvKeys / mDescriptors: the left image's, or the rig's concatenation) are final here:
-  // their copies back travel on the second stream while the frame is tracked
-  if (!t->rig) {
-    TRK_HIP(hipEventRecord(t->ev_ext, st));
+  // what the second stream reads of this one (the rig's groups, the keys' / descriptors' copies back)
+  TRK_HIP(hipEventRecord(t->ev_ext, st));
+  const bool spec = !t->vision && in->next_imu && in->next_n_imu > 0 && in->next_n_imu <= t->imu_cap;
+  // The rest of the second stream's work is read by the tail behind the first optimisation at the earliest: the host hands
+  // it over AFTER that kernel's launch.  (Once the frame was extracted ahead the host's launches are the head of the
+  // critical path: twenty runtime calls at 2-5 us each used to stand between k_track_adopt and the first search kernel;
+  // the first optimisation's 0.25 ms is where the host gets ahead again.)
+  const std::function<int()> side_rest = [&]() -> int {
+    if (new_local) {
+      TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cpt, t->h_loc + t->l_cpt, (size_t)nc * sizeof(vieo_frustum_point), hipMemcpyHostToDevice, t->st_imu));
+      TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cdesc, t->h_loc + t->l_cdesc, (size_t)nc * 32, hipMemcpyHostToDevice, t->st_imu));
+      TRK_HIP(hipMemcpyAsync(Wk + t->w_xyz + (size_t)kc * 12, t->h_loc + t->l_xyz, (size_t)nc * 12, hipMemcpyHostToDevice, t->st_imu));
+      t->local_version = in->local_version, t->n_local_dev = nc;
+      TRK_HIP(hipEventRecord(t->ev_tab, t->st_imu));  // (joined by the tail before the local-map queries)
+      t->tab_pending = true;
+    }
     TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_ext, 0));
-  }
-  TRK_HIP(hipMemcpyAsync(t->h_out + t->q_kp, Wk + t->w_kcat, (size_t)kc * sizeof(vieo_keypoint), hipMemcpyDeviceToHost, t->st_imu));
-  TRK_HIP(hipMemcpyAsync(t->h_out + t->q_desc, Wk + t->w_dcat, (size_t)kc * 32, hipMemcpyDeviceToHost, t->st_imu));
-  TRK_HIP(hipEventRecord(t->ev_kd, t->st_imu));
+    if (t->rig) {
+      const int rc_fe = fe_part(VIEO_FISHEYE_GROUPS, t->st_imu);
+      if (rc_fe != VIEO_OK) return rc_fe;
+      TRK_HIP(hipEventRecord(t->ev_fe, t->st_imu));
+    }
+    if (spec) {  // the next frame's samples go up with this frame's copies (the pinned block is free again when the call returns)
+      SpecImu& S = *(SpecImu*)t->h_spec;
+      S.noise = H.noise, S.ti = in->t_cur, S.tj = in->next_t_cur, S.first[0] = 0, S.first[1] = in->next_n_imu;
+      memcpy(t->h_spec + t->sp_samples, in->next_imu, (size_t)in->next_n_imu * sizeof(vieo_imu_sample));
+      TRK_HIP(hipMemcpyAsync(t->d_spec, t->h_spec, t->sp_samples + (size_t)in->next_n_imu * sizeof(vieo_imu_sample), hipMemcpyHostToDevice, t->st_imu));
+    }
+    TRK_HIP(hipMemcpyAsync(t->h_out + t->q_kp, Wk + t->w_kcat, (size_t)kc * sizeof(vieo_keypoint), hipMemcpyDeviceToHost, t->st_imu));
+    TRK_HIP(hipMemcpyAsync(t->h_out + t->q_desc, Wk + t->w_dcat, (size_t)kc * 32, hipMemcpyDeviceToHost, t->st_imu));
+    TRK_HIP(hipEventRecord(t->ev_kd, t->st_imu));
+    if (spec) {
+      // PreIntegration of [t_cur, next_t_cur] with bj_bar (k_track_predict left it in the block), behind this frame's
+      // copies on the second stream and beside its tail; the next call's k_track_predict is behind it on the same stream
+      SpecImu* dS = (SpecImu*)t->d_spec;
+      const double* bias = (const double*)(t->d_spec + t->sp_bias);
+      const int rc_pre = vieo_imu_preintegrate_batch_device(&dS->noise, (const vieo_imu_sample*)(t->d_spec + t->sp_samples), dS->first,
+                                                            &dS->ti, &dS->tj, bias, bias + 3, 1, (vieo_imu_preint*)(t->d_spec + t->sp_pre),
+                                                            (double*)(t->d_spec + t->sp_prv), (int32_t*)(t->d_spec + t->sp_pst), t->st_imu);
+      if (rc_pre != VIEO_OK) return rc_pre;
+      t->spec_samples.assign(in->next_imu, in->next_imu + in->next_n_imu);
+      t->spec_n = in->next_n_imu, t->spec_ti = in->t_cur, t->spec_tj = in->next_t_cur;
+    }
+    return VIEO_OK;
+  };
   TRK_HIP(hipStreamWaitEvent(st, t->ev_imu, 0));  // the prediction and the first search's queries (second stream)
-  if ((rc = track_chain_tail(t, nc, true)) != VIEO_OK) return track_fail(t, rc);
+  if ((rc = track_chain_tail(t, nc, true, &side_rest)) != VIEO_OK) return track_fail(t, rc);
   TRK_HIP(hipStreamWaitEvent(st, t->ev_kd, 0));  // (the keys' / descriptors' copies)
   TRK_HIP(hipEventRecord(t->ev_t1, st));
   if (in->next_left) {
@@ -939,6 +1026,10 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     t->replica_repeats++;
   }
 #undef TRK_HIP
+  if (spec) {  // (the bias the run-ahead integration used: the next call's nav_ref must carry exactly it)
+    for (int k = 0; k < 3; k++) t->spec_bias[k] = O->nav_pred.bg[k], t->spec_bias[3 + k] = O->nav_pred.ba[k];
+    t->spec_valid = true;
+  }
   memset(out, 0, sizeof(*out));
   out->preint_status = O->preint_status[0];
   // Tracking.cc:311 (fewer than 10 matches with the IMU) / :1878 (fewer than 20 without): the reference returns before

@@ -31,7 +31,8 @@ TRACK_INPUT_DTYPE = np.dtype([
     ("t_cur", "<f8"), ("nav_ref", NAVSTATE_DTYPE), ("nav_last", NAVSTATE_DTYPE), ("nav_prior", "<u8"), ("H_prior", "<u8"),
     ("n_last", "<i4"), ("last_points", "<u8"), ("last_track_depth", "<u8"), ("n_local", "<i4"), ("local_version", "<i4"),
     ("local_points", "<u8"), ("local_desc", "<u8"), ("local_alias", "<u8"), ("images", "<u8", 4), ("next_left", "<u8"),
-    ("next_right", "<u8"), ("use_prefetched", "<i4"), ("reserved2", "<i4")], align=True)
+    ("next_right", "<u8"), ("use_prefetched", "<i4"), ("next_n_imu", "<i4"), ("next_imu", "<u8"), ("next_t_cur", "<f8")],
+    align=True)
 TRACK_OUTPUT_DTYPE = np.dtype([
     ("status", "<i4"), ("n_keys", "<i4"), ("key_cap", "<i4"), ("keys", "<u8"), ("desc", "<u8"), ("uright", "<u8"),
     ("depth", "<u8"), ("point_ref", "<u8"), ("outlier", "<u8"), ("local_track_depth", "<u8"), ("n_matches_last", "<i4"),
@@ -145,7 +146,8 @@ class Tracker:
             pass
 
     STATS_DTYPE = np.dtype([("side_stream_ratio", "<f4"), ("side_stream_selections", "<i4"), ("side_stream_checks", "<i4"),
-                            ("replica_repeats", "<i4"), ("ms_gpu_median", "<f4"), ("slow_frames_in_a_row", "<i4")])
+                            ("replica_repeats", "<i4"), ("ms_gpu_median", "<f4"), ("slow_frames_in_a_row", "<i4"),
+                            ("frames_prefetched", "<i4"), ("preints_ahead_used", "<i4")])
 
     def stats(self):
         """vieo_tracker_get_stats: the second stream's measured overlap ratio, re-selections, replica repeats, ..."""
@@ -163,9 +165,11 @@ class Tracker:
         return s
 
     def track(self, left, right, imu, t_ref, t_cur, nav_ref, nav_last, prior, last_points, last_track_depth, local_points,
-              local_desc, local_alias, local_version, images=None, next_images=None, use_prefetched=False):
+              local_desc, local_alias, local_version, images=None, next_images=None, use_prefetched=False, next_imu=None):
         """next_images = (left, right) of the frame the NEXT call will track: its extraction + stereo stage run beside this
-        frame's searches and optimisations; that call passes use_prefetched=True (its own images are then not read)."""
+        frame's searches and optimisations; that call passes use_prefetched=True (its own images are then not read).
+        next_imu = (samples of [t_cur, t_next], t_next): the next call's pre-integration, run ahead (used by that call only
+        when its reference turns out to be this frame)."""
         i = self.inp[0]
         keep = []
         imgs = [left, right] if images is None else list(images)
@@ -178,6 +182,11 @@ class Tracker:
             nl, nr = (np.ascontiguousarray(x, np.uint8) for x in next_images)
             keep += [nl, nr]
             i["next_left"], i["next_right"] = nl.ctypes.data, nr.ctypes.data
+        i["next_imu"], i["next_n_imu"], i["next_t_cur"] = 0, 0, 0.0
+        if next_imu is not None:
+            ns = np.ascontiguousarray(next_imu[0], IMU_SAMPLE_DTYPE)
+            keep.append(ns)
+            i["next_imu"], i["next_n_imu"], i["next_t_cur"] = ns.ctypes.data, len(ns), float(next_imu[1])
         ptrs = []
         for c, img in enumerate(imgs):
             if img is self.planes[c]:
@@ -287,9 +296,13 @@ class TrackerReplay(rp.Replay):
         use_pf = self.prefetch and self._prefetched
         nxt = self.seq.images(k + 1) if (self.prefetch and k + 1 < self._n_run) else None
         self._prefetched = nxt is not None
+        nxt_imu = None
+        if nxt is not None:
+            t_next = self.seq.time(k + 1)
+            nxt_imu = (self.seq.imu_between(t, t_next), t_next)
         o, v = self.trk.track(Li, Ri, self.seq.imu_between(t_ref, t), t_ref, t, ref_nav, last.nav, prior, pts,
                               last.track_depth, self._lp_pts, self._lp_desc, alias, self._lv, next_images=nxt,
-                              use_prefetched=use_pf)
+                              use_prefetched=use_pf, next_imu=nxt_imu)
         assert int(o["status"]) == 0, "IMU pre-integration failed"
         self.stats["ms_chain"].append((float(o["ms_host"]), float(o["ms_gpu"])))
         self.stats["widened"] += int(o["widened"])
