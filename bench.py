@@ -413,7 +413,9 @@ def schur_useful_flops(window):
     return float(np.sum(60 + 108 * k + 216 * k * (k + 1) / 2 + 36 * k))
 
 
-LBA_LAG = 6  # frames between a key frame and the write-back of its local BA in the single_stream leg (0: inline)
+LBA_LAG = 8  # frames between a key frame and the write-back of its local BA in the single_stream leg (0: inline).
+# (8 since round 5: with frames near 1.05 ms a 5 ms solve plus its window assembly does not fit into 6 of them -- the
+# tracker waited 0.06 ms per frame for the write-back; the figure with 6 is reported beside it)
 
 
 def single_stream_leg(seq, n_frames):
@@ -440,7 +442,10 @@ def single_stream_leg(seq, n_frames):
     with tempfile.TemporaryDirectory() as tmp:
         path, traj = os.path.join(tmp, "seq.vseq"), os.path.join(tmp, "traj.bin")
         write_sequence(path, seq.seed, n_frames, seq)
-        runs = [run([exe, path, traj, "--warmup", "16", "--quiet", "--lba-lag", str(LBA_LAG)]) for _ in range(3)]
+        runs = [run([exe, path, traj, "--warmup", "16", "--quiet", "--lba-lag", str(LBA_LAG), "--prefetch", "1"]) for _ in range(3)]
+        r_plain = run([exe, path, traj + ".plain", "--warmup", "16", "--quiet", "--lba-lag", str(LBA_LAG), "--prefetch", "0"])
+        plain_identical = open(traj, "rb").read() == open(traj + ".plain", "rb").read()
+        r_lag6 = run([exe, path, traj + ".lag6", "--warmup", "16", "--quiet", "--lba-lag", "6", "--prefetch", "1"])
         # (the trajectory of ANY run with this lag is the same: the lag, not the timing, decides which map a frame sees)
         th = np.fromfile(traj, NAVSTATE_DTYPE)
         r_inline = run([exe, path, traj + ".inline", "--warmup", "16", "--quiet"])
@@ -489,6 +494,15 @@ def single_stream_leg(seq, n_frames):
                     "stream, write-back before the %d-th frame after the key frame; the oracle replay it is compared with "
                     "applies the same lag" % LBA_LAG,
         "lba_lag_frames": LBA_LAG,
+        "frame_pipelining": {
+            "on": True, "ms_per_frame_without": r_plain["ms_per_frame"], "ms_per_frame_tracking_call_without": r_plain["ms_track_call"],
+            "trajectory_bytes_identical_without": bool(plain_identical),
+            "ms_per_frame_write_back_6_frames_behind": r_lag6["ms_per_frame"],
+            "note": "vieo_track_input.next_left / next_right / next_imu: frame k + 1's ExtractORB x 2 + ComputeStereoMatches (third "
+                    "stream) and its pre-integration (second stream) run beside frame k's searches and optimisations; the "
+                    "next call adopts them.  A dataset player / a camera driver one frame ahead has the next frame in hand; "
+                    "outputs are bit for bit those of the unpipelined calls"},
+        "caller_ms_per_frame": r.get("caller_ms_per_frame"),
         "ms_per_frame_local_ba_inline": r_inline["ms_per_frame"], "vs_cpu_threaded": None,
         "ms_per_frame_all_runs": [x["ms_per_frame"] for x in runs],
         "ms_per_frame_tracking_call": float(np.mean([x["ms_track_call"] for x in runs])),

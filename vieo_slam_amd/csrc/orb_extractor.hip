@@ -590,6 +590,15 @@ k_quadtree(OrbParams P, const unsigned* __restrict__ cell_keys,
   if (tid == 0) sel_count[b * kMaxLevels + l] = m.s->error ? -1 : n;
 }
 
+// VIEO_ORB_FUSED (default 1): blur + descriptor in one kernel (k_describe_fused), 0: k_blur + k_describe
+static bool orb_fused() {
+  static const bool on = [] {
+    const char* e = getenv("VIEO_ORB_FUSED");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+
 // ------------------------------------------------------------------ Gaussian blur 7x7, sigma 2
 // Q8.8 kernel {18,34,48,56,48,34,18}: horizontal pass exact in 16 bits, vertical pass
 // (sum + 2^15) >> 16; BORDER_REFLECT_101 on the level itself.
@@ -914,6 +923,214 @@ k_describe(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __r
   }
 }
 
+// ------------------------------------------------------------------ orientation + blur + descriptor, one kernel
+// The descriptor reads the blurred level at 512 steered positions within 18 pixels of the key point (the pattern's
+// largest radius is 18.38, cvRound'ed per coordinate): a 37 x 37 patch of the blurred level, which is the 7 x 7 Gaussian
+// of a 43 x 43 patch of the level itself.  A frame's ~1200 key points per image cover about twice the pyramid's pixels
+// that way, so the blur's arithmetic doubles -- but the blurred pyramid (1.1 MB per image written, then gathered back)
+// never exists: the wavefront stages the raw patch once (it holds the orientation's 31 x 31 disc too), blurs it in LDS
+// with k_blur's two exact passes (same integers: Q8.8 rows, (sum + 2^15) >> 16 columns) and samples the result there.
+// Raw pixels outside the level are its REFLECT_101 continuation, which is what GaussianBlur reads at the border of the
+// (borderless) clone the reference blurs (ORBextractor.cc:1128-1131); blurred pixels outside the level -- a key point
+// 16 or 17 pixels from the border whose steered offset reaches 17 or 18 -- are out of bounds of that clone in the
+// reference (it reads whatever lies there); here they are the blur of the continuation.
+#ifndef VIEO_FUSED_AB
+#define VIEO_FUSED_AB 0  // timing experiments only (wrong results): 1 = no blur passes, 2 = no patch loads, 4 = no angle / sampling
+#endif
+constexpr int kFR = 18, kFRaw = kFR + 3;                // blurred / raw patch radius
+constexpr int kFRawRows = 2 * kFRaw + 1, kFRawPitch = 48;  // 43 rows of 12 dwords
+constexpr int kFHPairs = (kFRawRows + 1) / 2, kFHCols = 40;  // horizontal sums: 22 row pairs x 40 columns (dwords)
+constexpr int kFBlRows = 2 * kFR + 1, kFBlPitch = 40;       // blurred patch: 37 rows x 40 bytes
+constexpr int kFWaveLds = kFRawRows * kFRawPitch + 16 + kFHPairs * kFHCols * 4;  // the blurred patch overlays the raw one
+static_assert(kFBlRows * kFBlPitch <= kFRawRows * kFRawPitch, "the blurred patch fits where the raw one was");
+
+__global__ void __launch_bounds__(256)
+k_describe_fused(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __restrict__ pattern,
+                 vieo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int out_cap,
+                 int groups_per_image, int n_images) {
+  // all key points of an image on one XCD: their overlapping patches then share that XCD's L2
+  const int item = xcd_grouped(blockIdx.x, groups_per_image);
+  const int b = item / groups_per_image;
+  if (b >= n_images) return;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = (item - b * groups_per_image) * (blockDim.x >> 6) + wv;
+  const int gmax = min(P.kp_cap, out_cap);
+  if (g >= gmax) return;
+  const uint2 kr = krec[(size_t)b * P.kp_cap + g];
+  __shared__ __attribute__((aligned(16))) uint8_t s_all[4][kFWaveLds];
+  int pt4[4];
+#pragma unroll
+  for (int gq = 0; gq < 4; gq++) pt4[gq] = pattern[gq * 64 + lane];  // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
+  const int level = (int)kr.y;
+  if (level < 0) return;  // (wave-uniform)
+  const unsigned key = kr.x;
+  const LevelDesc& D = P.lv[level];
+  const int cx = QT_KEY_X(key) + (kEdge - 3), cy = QT_KEY_Y(key) + (kEdge - 3);
+  int pitch;
+  const uint8_t* img = plane_ptr(P, I, b, level, &pitch);
+  uint8_t* s_raw = s_all[wv];
+  unsigned* s_h = (unsigned*)(s_raw + kFRawRows * kFRawPitch + 16);
+  const int x_lo = cx - kFRaw, y_lo = cy - kFRaw;
+  const int xa = x_lo & ~3, sh = x_lo - xa;  // the patch's column 0 is byte `sh` of the aligned rows (wave-uniform)
+  // ---- the raw patch: 43 rows, staged so that its column 0 is byte 0 of the LDS row (12 dwords).  A step = 4 rows x 16
+  // lanes: lane c loads dword c of the aligned row (13 of them hold the patch), takes dword c + 1 from its neighbour
+  // (DPP row shift) and stores the two realigned; all loads in flight, then the stores
+  constexpr int NLD = (kFRawRows + 3) / 4;
+  unsigned v[NLD];
+  const int c = lane & 15, r0 = lane >> 4;
+  const bool interior = x_lo >= 0 && y_lo >= 0 && cx + kFRaw < D.w && cy + kFRaw < D.h && xa + 52 <= pitch &&
+                        ((pitch & 3) == 0) && ((((uintptr_t)img) & 3) == 0);
+  if (VIEO_FUSED_AB & 2) {
+#pragma unroll
+    for (int k = 0; k < NLD; k++) v[k] = key + k;
+  } else if (interior) {
+    const uint8_t* g0 = img + (size_t)(y_lo + r0) * pitch + xa + 4 * c;
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      v[k] = 0;
+      if (c < 13 && r0 + 4 * k < kFRawRows) v[k] = *(const unsigned*)(g0 + (size_t)(4 * k) * pitch);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[k], 0x101, 0xF, 0xF, false);  // row_shl:1 = lane + 1's
+      v[k] = __builtin_amdgcn_alignbyte(nxt, v[k], sh);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      v[k] = 0;
+      if (c < 12 && r0 + 4 * k < kFRawRows) {
+        const uint8_t* row = img + (size_t)reflect101(min(max(y_lo + r0 + 4 * k, -(D.h - 1)), 2 * D.h - 2), D.h) * pitch;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int x = min(max(x_lo + 4 * c + j, -(D.w - 1)), 2 * D.w - 2);
+          v[k] |= (unsigned)row[reflect101(x, D.w)] << (8 * j);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NLD; k++)
+    if (c < 12 && r0 + 4 * k < kFRawRows) *(unsigned*)(s_raw + (r0 + 4 * k) * kFRawPitch + 4 * c) = v[k];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- horizontal pass: one item = two raw rows x EIGHT columns from four dwords per row; the seven taps as v_dot4 with
+  // the weights shifted instead of the bytes (20 per row: no realignment), 16-bit sums of vertically adjacent rows packed
+  {
+    constexpr unsigned A0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), A1 = 48u | (34u << 8) | (18u << 16);
+    constexpr unsigned B0 = (18u << 8) | (34u << 16) | (48u << 24), B1 = 56u | (48u << 8) | (34u << 16) | (18u << 24);
+    constexpr unsigned C0 = (18u << 16) | (34u << 24), C1 = 48u | (56u << 8) | (48u << 16) | (34u << 24), C2 = 18u;
+    constexpr unsigned E0 = 18u << 24, E1 = 34u | (48u << 8) | (56u << 16) | (48u << 24), E2 = 34u | (18u << 8);
+    for (int idx = lane; idx < ((VIEO_FUSED_AB & 1) ? 0 : kFHPairs * (kFHCols / 8)); idx += 64) {
+      const int pr = idx / (kFHCols / 8), g8 = idx - pr * (kFHCols / 8);
+      unsigned h[2][8];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int r = min(2 * pr + q, kFRawRows - 1);  // (the 44th row does not exist: its sums are never read)
+        const uint2* w = (const uint2*)(s_raw + r * kFRawPitch + 8 * g8);
+        const uint2 lo = w[0], hi = w[1];
+        const unsigned d0 = lo.x, d1 = lo.y, d2 = hi.x, d3 = hi.y;
+#define DOT4(x, k, acc) __builtin_amdgcn_udot4(x, k, acc, false)
+        h[q][0] = DOT4(d1, A1, DOT4(d0, A0, 0u));
+        h[q][1] = DOT4(d1, B1, DOT4(d0, B0, 0u));
+        h[q][2] = DOT4(d2, C2, DOT4(d1, C1, DOT4(d0, C0, 0u)));
+        h[q][3] = DOT4(d2, E2, DOT4(d1, E1, DOT4(d0, E0, 0u)));
+        h[q][4] = DOT4(d2, A1, DOT4(d1, A0, 0u));
+        h[q][5] = DOT4(d2, B1, DOT4(d1, B0, 0u));
+        h[q][6] = DOT4(d3, C2, DOT4(d2, C1, DOT4(d1, C0, 0u)));
+        h[q][7] = DOT4(d3, E2, DOT4(d2, E1, DOT4(d1, E0, 0u)));
+#undef DOT4
+      }
+      uint4 o0, o1;
+      o0.x = h[0][0] | (h[1][0] << 16), o0.y = h[0][1] | (h[1][1] << 16);
+      o0.z = h[0][2] | (h[1][2] << 16), o0.w = h[0][3] | (h[1][3] << 16);
+      o1.x = h[0][4] | (h[1][4] << 16), o1.y = h[0][5] | (h[1][5] << 16);
+      o1.z = h[0][6] | (h[1][6] << 16), o1.w = h[0][7] | (h[1][7] << 16);
+      uint4* dst = (uint4*)(s_h + pr * kFHCols + 8 * g8);
+      dst[0] = o0, dst[1] = o1;
+    }
+  }
+  // ---- IC_Angle on the raw patch (its centre is row kFRaw, byte kFRaw): two lanes per row of the radius-15 disc
+  int m10 = 0, m01 = 0;
+  if (lane < ((VIEO_FUSED_AB & 4) ? 1 : 62)) {
+    const int vv = (lane >> 1) - kHalfPatch;
+    const int d = P.umax[vv < 0 ? -vv : vv];
+    const uint8_t* row = s_raw + (vv + kFRaw) * kFRawPitch + kFRaw;
+    const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
+    int sI = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int uu = u0 + t;
+      if (uu <= u1) {
+        const int val = row[uu];
+        m10 += uu * val;
+        sI += val;
+      }
+    }
+    m01 = vv * sI;
+  }
+  m10 = wave_sum(m10);
+  m01 = wave_sum(m01);
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- vertical pass (k_blur's): one item = two blurred rows x four columns, into the space the raw patch had
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  uint8_t* s_bl = s_raw;
+  for (int idx = lane; idx < ((VIEO_FUSED_AB & 1) ? 0 : ((kFBlRows + 1) / 2) * (kFBlPitch / 4)); idx += 64) {
+    const int q = idx / (kFBlPitch / 4), c4 = (idx - q * (kFBlPitch / 4)) * 4;
+    const unsigned We[4] = {18u | (34u << 16), 48u | (56u << 16), 48u | (34u << 16), 18u};
+    const unsigned Wo[4] = {18u << 16, 34u | (48u << 16), 56u | (48u << 16), 34u | (18u << 16)};
+    unsigned e[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15}, o[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint4 hv = *(const uint4*)(s_h + (q + k) * kFHCols + c4);
+      const unsigned vv[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        e[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, vv[j]), __builtin_bit_cast(us2, We[k]), e[j], false);
+        o[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, vv[j]), __builtin_bit_cast(us2, Wo[k]), o[j], false);
+      }
+    }
+    // byte 2 of each sum (the sums stay below 2^24): three v_perm per four pixels
+    const unsigned oe = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), 0x05040100u);
+    const unsigned oo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0602u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), 0x05040100u);
+    *(unsigned*)(s_bl + (2 * q) * kFBlPitch + c4) = oe;
+    if (2 * q + 1 < kFBlRows) *(unsigned*)(s_bl + (2 * q + 1) * kFBlPitch + c4) = oo;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- steered BRIEF on the blurred patch (ORBextractor.cc:83-127)
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float a, bsin;
+  vieo_sincosf_exact(angle * factorPI, &bsin, &a);
+  const uint8_t* bl = s_bl + kFR * kFBlPitch + kFR;
+  unsigned long long bits[4];
+#pragma unroll
+  for (int gq = 0; gq < ((VIEO_FUSED_AB & 4) ? 1 : 4); gq++) {
+    const int pt = pt4[gq];
+    const float x0 = (float)(signed char)(pt & 0xFF), y0 = (float)(signed char)((pt >> 8) & 0xFF);
+    const float x1 = (float)(signed char)((pt >> 16) & 0xFF), y1 = (float)(signed char)((pt >> 24) & 0xFF);
+    const int t0 = bl[__float2int_rn(x0 * bsin + y0 * a) * kFBlPitch + __float2int_rn(x0 * a - y0 * bsin)];
+    const int t1 = bl[__float2int_rn(x1 * bsin + y1 * a) * kFBlPitch + __float2int_rn(x1 * a - y1 * bsin)];
+    bits[gq] = __ballot(t0 < t1);
+  }
+  if (lane < 4) ((unsigned long long*)(desc_out + ((size_t)b * out_cap + g) * 32))[lane] = bits[lane];
+  if (lane == 0) {
+    vieo_keypoint k;
+    const float fx = (float)cx, fy = (float)cy;
+    k.x = level ? fx * D.scale : fx;
+    k.y = level ? fy * D.scale : fy;
+    k.size = (float)D.patch;
+    k.angle = angle;
+    k.response = (float)QT_KEY_R(key);
+    k.octave = level;
+    k.class_id = -1;
+    kp_out[(size_t)b * out_cap + g] = k;
+  }
+}
+
 // ------------------------------------------------------------------ lapping-area reorder
 // ORBextractor.cc:1041-1052: keys with lap0 <= x <= lap1 fill the output from the back, the
 // others from the front, both in level-concatenated order.  One workgroup per image.
@@ -1158,7 +1375,7 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
 #define ENS(buf, bytes)                 \
   if ((rc = (buf).ensure(bytes)) != VIEO_OK) return rc
   ENS(e->d_pyr, e->pyr_img * B);
-  ENS(e->d_blur, e->blur_img * B);
+  if (!orb_fused()) ENS(e->d_blur, e->blur_img * B);  // (the fused descriptor kernel has no blurred pyramid)
   ENS(e->d_cells, e->cells.size() * sizeof(CellDesc));
   ENS(e->d_tiles, e->tiles.size() * sizeof(BlurTile));
   ENS(e->d_xtab, std::max<size_t>(xtab.size() * 2, 8));
@@ -1286,22 +1503,36 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
     }
   }
   STAMP();
-  hipLaunchKernelGGL(k_blur, dim3(xcd_grid((long long)e->tiles.size() * B)), dim3(256), 0, st, P, I,
-                     e->d_tiles.as<BlurTile>(), (int)e->tiles.size(), B);
+  // VIEO_ORB_FUSED=0: the two-kernel form (the whole pyramid blurred into HBM, k_describe gathers from it) -- kept for A/B
+  // timing and as the producer of the blurred planes the parity tap reads
+  const bool fused = orb_fused();
+  if (!fused) {
+    int rc_b = e->d_blur.ensure(e->blur_img * (size_t)e->B);
+    if (rc_b != VIEO_OK) return rc_b;
+    I.blur = e->d_blur.as<uint8_t>(), e->last_imgs = I;
+    hipLaunchKernelGGL(k_blur, dim3(xcd_grid((long long)e->tiles.size() * B)), dim3(256), 0, st, P, I,
+                       e->d_tiles.as<BlurTile>(), (int)e->tiles.size(), B);
+  }
   STAMP();
-  const int ngroups = (std::min(P.kp_cap, capacity) + 4 * VIEO_DESC_KPW - 1) / (4 * VIEO_DESC_KPW);
+  const int per_group = fused ? 4 : 4 * VIEO_DESC_KPW;
+  const int ngroups = (std::min(P.kp_cap, capacity) + per_group - 1) / per_group;
+  auto describe = [&](unsigned grid, vieo_keypoint* kp, uint8_t* desc, int cap, int ng) {
+    if (fused)
+      hipLaunchKernelGGL(k_describe_fused, dim3(grid), dim3(256), 0, st, P, I, e->d_krec.as<uint2>(), e->d_pattern.as<int>(), kp, desc,
+                         cap, ng, B);
+    else
+      hipLaunchKernelGGL(k_describe, dim3(grid), dim3(256), 0, st, P, I, e->d_krec.as<uint2>(), e->d_pattern.as<int>(), kp, desc, cap,
+                         ng, B);
+  };
   if (!lapping) {
     hipLaunchKernelGGL(k_desc_index, dim3((P.kp_cap + 255) / 256, B), dim3(256), 0, st, P, e->d_sel.as<unsigned>(),
                        e->d_sel_count.as<int>(), e->d_krec.as<uint2>(), capacity, d_counts);
-    hipLaunchKernelGGL(k_describe, dim3((unsigned)ngroups * 8 * ((B + 7) / 8)), dim3(256), 0, st, P, I,
-                       e->d_krec.as<uint2>(), e->d_pattern.as<int>(), d_kp, d_desc, capacity, ngroups, B);
+    describe((unsigned)ngroups * 8 * ((B + 7) / 8), d_kp, d_desc, capacity, ngroups);
   } else {
-    const int ng = (P.kp_cap + 4 * VIEO_DESC_KPW - 1) / (4 * VIEO_DESC_KPW);
+    const int ng = (P.kp_cap + per_group - 1) / per_group;
     hipLaunchKernelGGL(k_desc_index, dim3((P.kp_cap + 255) / 256, B), dim3(256), 0, st, P, e->d_sel.as<unsigned>(),
                        e->d_sel_count.as<int>(), e->d_krec.as<uint2>(), P.kp_cap, e->d_tmp_counts.as<int>());
-    hipLaunchKernelGGL(k_describe, dim3((unsigned)ng * 8 * ((B + 7) / 8)), dim3(256), 0, st, P, I,
-                       e->d_krec.as<uint2>(), e->d_pattern.as<int>(), e->d_tmp_kp.as<vieo_keypoint>(),
-                       e->d_tmp_desc.as<uint8_t>(), P.kp_cap, ng, B);
+    describe((unsigned)ng * 8 * ((B + 7) / 8), e->d_tmp_kp.as<vieo_keypoint>(), e->d_tmp_desc.as<uint8_t>(), P.kp_cap, ng);
     hipLaunchKernelGGL(k_lapping, dim3(B), dim3(256), 0, st, e->d_tmp_kp.as<vieo_keypoint>(),
                        e->d_tmp_desc.as<uint8_t>(), P.kp_cap, d_kp, d_desc, capacity,
                        e->d_tmp_counts.as<int>(), d_counts, lapping[0], lapping[1]);
@@ -1654,6 +1885,16 @@ int vieo_orb_tap_plane(vieo_orb* e, int image_index, int level, int which, uint8
       image_index >= e->last_B)
     return VIEO_E_INVALID;
   const LevelDesc& D = e->P.lv[level];
+  if (vieo::orb_fused()) {
+    // the extraction did not leave a blurred pyramid behind: blur the last batch's levels now (k_blur, the two-kernel
+    // form's producer; the fused kernel runs the same two passes per key-point patch)
+    int rc = e->d_blur.ensure(e->blur_img * (size_t)e->B);
+    if (rc != VIEO_OK) return rc;
+    e->last_imgs.blur = e->d_blur.as<uint8_t>(), e->last_imgs.blur_img = e->blur_img;
+    hipLaunchKernelGGL(vieo::k_blur, dim3((unsigned)(((long long)e->tiles.size() * e->last_B + 8 * vieo::kXcdRun - 1) / (8 * vieo::kXcdRun) * (8 * vieo::kXcdRun))), dim3(256), 0, e->stream, e->P,
+                       e->last_imgs, e->d_tiles.as<vieo::BlurTile>(), (int)e->tiles.size(), e->last_B);
+    VIEO_HIP_CHECK(hipGetLastError());
+  }
   const uint8_t* p = e->last_imgs.blur + (size_t)image_index * e->blur_img + D.boff;
   return fetch_plane(e, p, D.pitch, D.w, D.h, 0, h_dst, dst_stride);
 }
