@@ -603,12 +603,16 @@ def sequence_leg(kind, orc, n, lag, rig=None, nc=None, nfeat=None, seed=1):
         seq = rm.RigSequence(seed, n, rig, nc)
     for k, im in enumerate(orc["images"]):
         seq._img[k] = im
-    mk = (lambda: rm.VisionTrackerReplay(seq, rm.HipVisionStages(), lba_lag=lag)) if kind == "vision" else \
-        (lambda: rm.RigTrackerReplay(seq, rm.HipRigStages(nfeat, nc), nfeat, lba_lag=lag))
-    R = mk()
+    mk = (lambda pf: rm.VisionTrackerReplay(seq, rm.HipVisionStages(), lba_lag=lag, prefetch=pf)) if kind == "vision" else \
+        (lambda pf: rm.RigTrackerReplay(seq, rm.HipRigStages(nfeat, nc), nfeat, lba_lag=lag, prefetch=pf))
+    R = mk(True)
     R.run(min(14, n))  # code objects, scratch buffers, the LocalMapping thread's arenas
     R.close()
-    R = mk()
+    Rn = mk(False)  # without frame pipelining: the same outputs bit for bit, the extraction inside the call
+    tn = Rn.run(n)
+    Rn.close()
+    ms_plain = np.array(Rn.stats["ms_chain"])
+    R = mk(True)
     t0 = time.perf_counter()
     th = R.run(n)
     dt = time.perf_counter() - t0
@@ -625,6 +629,8 @@ def sequence_leg(kind, orc, n, lag, rig=None, nc=None, nfeat=None, seed=1):
         "frames": n, "local_bas": R.stats["lba"], "key_frames": len(R.kfs), "map_points": int(len(R.mp_X)), "lba_lag_frames": lag,
         "ms_per_frame_tracking_call": float(ms[:, 0].mean()), "ms_per_frame_tracking_call_gpu": float(ms[:, 1].mean()),
         "ms_per_frame_tracking_call_last_half": float(ms[len(ms) // 2:, 0].mean()),
+        "frame_pipelining": {"on": True, "ms_per_frame_tracking_call_without": float(ms_plain[:, 0].mean()),
+                             "trajectory_bytes_identical_without": bool(th.tobytes() == tn.tobytes())},
         "ms_per_frame_python_loop": 1e3 * dt / (n - 1),
         "ms_per_local_ba_mean": float(np.mean(R.stats["ms_lba"])) if R.stats["ms_lba"] else None,
         "lba_windows": {"mean_key_frames": float(shapes[:, 0].mean()), "max_key_frames": int(shapes[:, 0].max()),

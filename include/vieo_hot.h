@@ -1188,7 +1188,7 @@ typedef struct vieo_track_input {
   const int32_t* local_alias;           /* candidate j is last_points[local_alias[j]] (-1: not in the last frame) */
   const uint8_t* images[4];             /* rig trackers: camera c's image (left / right are not read); n_last then counts
                                          * mLastFrame's keys in mvKeys (camera-major) order, up to vieo_tracker_key_capacity */
-  /* Frame pipelining (rectified trackers; a replay or any caller that has the NEXT frame's images in hand -- a camera
+  /* Frame pipelining (a replay or any caller that has the NEXT frame's images in hand -- a camera
    * driver one frame ahead, a dataset player): the next frame's ExtractORB x 2 + ComputeStereoMatches are queued on a
    * third stream BEHIND this frame's stereo stage and run beside this frame's searches and optimisations (which keep one
    * CU busy; the extraction wants all of them for ~0.2 ms).  The NEXT call then finds its frame extracted: its
@@ -1205,6 +1205,8 @@ typedef struct vieo_track_input {
   int32_t next_n_imu;
   const vieo_imu_sample* next_imu;
   double next_t_cur;
+  const uint8_t* next_images[4];        /* rig trackers: the next frame's camera images instead of next_left / next_right
+                                         * (all of them or none); its extraction runs ahead, its stereo stage in its call */
 } vieo_track_input;
 
 #define VIEO_TRACK_OK 0

@@ -63,6 +63,14 @@ def test_gpu_rig_replay_staged_and_one_call_vs_oracle(oracle, rig, nc, nfeat, se
     Rt = rm.RigTrackerReplay(seq, rm.HipRigStages(nfeat, nc), nfeat, lba_lag=lag)
     tt = Rt.run(n)
     Rt.close()
+    # frame pipelining (next_images / next_imu): the next frame's extraction and pre-integration run beside this frame's
+    # tail -- every frame's outputs are those of the unpipelined calls, bit for bit
+    Rp = rm.RigTrackerReplay(seq, rm.HipRigStages(nfeat, nc), nfeat, lba_lag=lag, prefetch=True)
+    tp = Rp.run(n)
+    sp = Rp.trk.stats()
+    Rp.close()
+    assert tp.tobytes() == tt.tobytes() and Rp.stats["n_matches"] == Rt.stats["n_matches"]
+    assert sp["frames_prefetched"] == n - 2 and 0 < sp["preints_ahead_used"] <= n - 2
     assert Ro.stats["lba"] == Rh.stats["lba"] == Rt.stats["lba"] == 3
     for name, t, R in (("staged", th, Rh), ("one call", tt, Rt)):
         _check_vs_oracle(name, t, R, to, Ro, n)
@@ -70,8 +78,10 @@ def test_gpu_rig_replay_staged_and_one_call_vs_oracle(oracle, rig, nc, nfeat, se
     assert err < 4e-2, err  # (the 512 x 512 fisheye cameras have 190-pixel focal lengths: 2.3 cm at worst)
     assert len(Rt.kfs) == len(Ro.kfs) == 4 and abs(len(Rt.mp_X) - len(Ro.mp_X)) <= 3
     ms = np.array(Rt.stats["ms_chain"])
-    print("rig replay %s x%d: ATE vs oracle staged %.2e / one call %.2e m; tracking call %.2f ms (GPU %.2f); windows %s"
-          % (rig, nc, replay.ate_between(th, to), replay.ate_between(tt, to), ms[8:, 0].mean(), ms[8:, 1].mean(), Rt.stats["lba_shapes"][-1]))
+    mp = np.array(Rp.stats["ms_chain"])
+    print("rig replay %s x%d: ATE vs oracle staged %.2e / one call %.2e m; tracking call %.2f ms (GPU %.2f), pipelined %.2f (%.2f); windows %s"
+          % (rig, nc, replay.ate_between(th, to), replay.ate_between(tt, to), ms[8:, 0].mean(), ms[8:, 1].mean(), mp[8:, 0].mean(),
+             mp[8:, 1].mean(), Rt.stats["lba_shapes"][-1]))
 
 
 @pytest.mark.gpu
@@ -86,6 +96,10 @@ def test_gpu_vision_only_replay_staged_and_one_call_vs_oracle(oracle):
     Rt = rm.VisionTrackerReplay(seq, rm.HipVisionStages(), lba_lag=lag)
     tt = Rt.run(n)
     Rt.close()
+    Rp = rm.VisionTrackerReplay(seq, rm.HipVisionStages(), lba_lag=lag, prefetch=True)  # (frame pipelining: bit-identical)
+    tp = Rp.run(n)
+    assert tp.tobytes() == tt.tobytes() and Rp.trk.stats()["frames_prefetched"] == n - 2
+    Rp.close()
     assert Ro.stats["lba"] == Rh.stats["lba"] == Rt.stats["lba"] == 6
     for name, t, R in (("staged", th, Rh), ("one call", tt, Rt)):
         _check_vs_oracle(name, t, R, to, Ro, n)

@@ -59,6 +59,13 @@ fast = {"source": "tools/pmc_round5.sh: rocprofv3 --pmc in separate passes over 
         "lane_fill": c.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * c["SQ_ACTIVE_INST_VALU"] * 4 / 4) if c.get("SQ_ACTIVE_INST_VALU") else None,
         "issue_cycles_per_valu_inst": {"full_rate": 1.9, "half_rate": 3.4, "source": "tools/ubench/valu_rate.hip on gfx950 (profiles/r2_valu_rate.txt)"},
         "source_sha16": {"vieo_slam_amd/csrc/orb_extractor.hip": s_orb}}
+# the same two passes saw the fused blur + descriptor kernel
+cd_ = dict(pick(fb, "k_describe_fused")); cd_.update(pick(fd, "k_describe_fused"))
+if cd_:
+    fast["k_describe_fused"] = {"counters": cd_, "valu_insts_per_simd": cd_.get("SQ_INSTS_VALU", 0) / 32.0,
+                                "kernel_cycles": cd_.get("GRBM_GUI_ACTIVE", 0),
+                                "valu_insts_per_cycle_per_simd": (cd_.get("SQ_INSTS_VALU", 0) / 32.0 / cd_["GRBM_GUI_ACTIVE"]) if cd_.get("GRBM_GUI_ACTIVE") else None,
+                                "lds_insts_per_simd": cd_.get("SQ_INSTS_LDS", 0) / 32.0}
 json.dump(fast, open(R + "/gpurun_out/r5_pmc_fast.json", "w"), indent=1)
 rb, rd = read("rig_b"), read("rig_d")
 ker = {}

@@ -2,7 +2,8 @@
 # rocprofv3 kernel traces of the round's measured paths, summaries under gpurun_out/ (copy to profiles/):
 #   $1_full_step.md      python bench.py (batched step, workload r3), 5 timed steps; rows per (kernel, grid) and the roofline
 #                        lines of the dominant kernels recomputed from the trace alone
-#   $1_cpp_replay.md     examples/replay_main over 60 frames with the local BA beside tracking (the single_stream leg's program)
+#   $1_cpp_replay.md     examples/replay_main over 60 frames with the local BA beside tracking and frame pipelining (the single_stream
+#                        leg's program);  $1_dropin_replay.md: examples/dropin_replay, the same frames member by member
 #   $1_rig_*.md          the one-call rig tracker (tools/prof_rig_tracker.sh)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -13,8 +14,11 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_step -o out -- python $R/
 python $R/tools/rocpd_summary.py $(find $R/gpurun_out/prof_step -name "*.db" | head -1) $R/gpurun_out/${TAG}_full_step.md --min-us 1.0 \
   --bytes k_fast=4576735232@1000000 > /dev/null
 python $R/tools/write_sequence.py /tmp/seq.vseq --frames 60 > /dev/null
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_replay -o out -- $R/examples/replay_main /tmp/seq.vseq --warmup 12 --quiet --lba-lag 6 > $R/gpurun_out/prof_replay.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_replay -o out -- $R/examples/replay_main /tmp/seq.vseq --warmup 12 --quiet --lba-lag 8 --prefetch 1 > $R/gpurun_out/prof_replay.log 2>&1
 python $R/tools/rocpd_summary.py $(find $R/gpurun_out/prof_replay -name "*.db" | head -1) $R/gpurun_out/${TAG}_cpp_replay.md --merge-grids > /dev/null
+# the same sequence member by member (the resident drop-in calls of shim/*.cc)
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_dropin -o out -- $R/examples/dropin_replay /tmp/seq.vseq --warmup 12 --quiet --lba-lag 8 > $R/gpurun_out/prof_dropin.log 2>&1
+python $R/tools/rocpd_summary.py $(find $R/gpurun_out/prof_dropin -name "*.db" | head -1) $R/gpurun_out/${TAG}_dropin_replay.md --merge-grids > /dev/null
 bash $R/tools/prof_rig_tracker.sh $TAG > /dev/null 2>&1
 tail -1 $R/gpurun_out/prof_step.log | cut -c1-300
 tail -1 $R/gpurun_out/prof_replay.log

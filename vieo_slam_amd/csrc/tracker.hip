@@ -199,12 +199,12 @@ __global__ void __launch_bounds__(256)
 k_track_adopt(const uint4* __restrict__ s_kp, uint4* __restrict__ d_kp, int n_kp16, const uint4* __restrict__ s_desc,
               uint4* __restrict__ d_desc, int n_desc16, const uint4* __restrict__ s_ur, uint4* __restrict__ d_ur,
               const uint4* __restrict__ s_dp, uint4* __restrict__ d_dp, int n_f16, const int32_t* __restrict__ s_cnt,
-              int32_t* __restrict__ d_cnt) {
+              int32_t* __restrict__ d_cnt, int n_cnt) {
   const int stride = gridDim.x * 256;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n_kp16; i += stride) d_kp[i] = s_kp[i];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n_desc16; i += stride) d_desc[i] = s_desc[i];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n_f16; i += stride) d_ur[i] = s_ur[i], d_dp[i] = s_dp[i];
-  if (blockIdx.x == 0 && threadIdx.x < 4) d_cnt[threadIdx.x] = s_cnt[threadIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x < n_cnt) d_cnt[threadIdx.x] = s_cnt[threadIdx.x];
 }
 
 }  // namespace vieo
@@ -468,10 +468,10 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
             hipMalloc((void**)&t->d_const, const_bytes) == hipSuccess &&
             hipHostMalloc((void**)&t->h_spec, t->sp_up, hipHostMallocDefault) == hipSuccess &&
             hipMalloc((void**)&t->d_spec, spec_bytes) == hipSuccess && hipMemset(t->d_spec, 0, spec_bytes) == hipSuccess &&
-            (R || (hipHostMalloc((void**)&t->h_next, t->n_img * npx, hipHostMallocDefault) == hipSuccess &&
-                   hipMalloc((void**)&t->d_next, t->n_img * npx) == hipSuccess && hipMalloc((void**)&t->d_slot, slot_bytes) == hipSuccess &&
-                   create_prefetch_stream(&t->st_pref) == hipSuccess &&
-                   hipEventCreateWithFlags(&t->ev_pref, hipEventDisableTiming) == hipSuccess)) &&
+            hipHostMalloc((void**)&t->h_next, t->n_img * npx, hipHostMallocDefault) == hipSuccess &&
+            hipMalloc((void**)&t->d_next, t->n_img * npx) == hipSuccess && hipMalloc((void**)&t->d_slot, slot_bytes) == hipSuccess &&
+            create_prefetch_stream(&t->st_pref) == hipSuccess &&
+            hipEventCreateWithFlags(&t->ev_pref, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_head, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_tab, hipEventDisableTiming) == hipSuccess &&
             create_side_stream(&t->st_imu, t->st, &t->side_ratio) == hipSuccess &&
@@ -780,8 +780,14 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     set_error("vieo_track_frame: use_prefetched without a pending prefetch (the previous call carried no next_left / next_right)");
     return VIEO_E_INVALID;
   }
-  if (in->next_left && (t->rig || !in->next_right)) {
-    set_error("vieo_track_frame: next_left / next_right are for rectified trackers and come as a pair");
+  // the next frame's images, if the caller has them: next_left / next_right (rectified pair) or next_images[c] (rig)
+  const uint8_t* nx[4] = {in->next_left, in->next_right, nullptr, nullptr};
+  if (t->rig)
+    for (int c = 0; c < 4; c++) nx[c] = in->next_images[c];
+  int n_next = 0;
+  for (int c = 0; c < t->n_img; c++) n_next += nx[c] != nullptr;
+  if (n_next != 0 && n_next != t->n_img) {
+    set_error("vieo_track_frame: the next frame's images come complete (%d of %d given)", n_next, t->n_img);
     return VIEO_E_INVALID;
   }
   const bool pref = in->use_prefetched != 0;
@@ -857,11 +863,12 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   if (pref) {
     // the frame was extracted (and its stereo stage run) on the third stream beside the previous call's tail: adopt it
     TRK_HIP(hipStreamWaitEvent(st, t->ev_pref, 0));
-    const int n_kp16 = (int)(((size_t)t->n_img * cap * sizeof(vieo_keypoint) + 15) / 16), n_desc16 = t->n_img * cap * 2, n_f16 = (cap + 3) / 4;
+    const int n_kp16 = (int)(((size_t)t->n_img * cap * sizeof(vieo_keypoint) + 15) / 16), n_desc16 = t->n_img * cap * 2;
+    const int n_f16 = t->rig ? 0 : (cap + 3) / 4;  // (a rig frame's stereo stage runs in the call: it fills mvKeys-order tables)
     hipLaunchKernelGGL(k_track_adopt, dim3(32), dim3(256), 0, st, (const uint4*)(t->d_slot + t->s_kp), (uint4*)d_kp, n_kp16,
                        (const uint4*)(t->d_slot + t->s_desc), (uint4*)d_desc, n_desc16, (const uint4*)(t->d_slot + t->s_ur),
                        (uint4*)(t->d_out + t->q_ur), (const uint4*)(t->d_slot + t->s_dp), (uint4*)(t->d_out + t->q_dp), n_f16,
-                       (const int32_t*)(t->d_slot + t->s_cnt), dO->cnt);
+                       (const int32_t*)(t->d_slot + t->s_cnt), dO->cnt, 2 * t->n_img);
     t->pref_valid = false;
   } else {
     TRK_HIP(hipMemcpyAsync(t->d_up + t->o_img, t->h_up + t->o_img, t->n_img * npx, hipMemcpyHostToDevice, st));
@@ -968,12 +975,11 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   if ((rc = track_chain_tail(t, nc, true, &side_rest)) != VIEO_OK) return track_fail(t, rc);
   TRK_HIP(hipStreamWaitEvent(st, t->ev_kd, 0));  // (the keys' / descriptors' copies)
   TRK_HIP(hipEventRecord(t->ev_t1, st));
-  if (in->next_left) {
+  if (n_next) {
     // ---- the NEXT frame's Frame::Frame on the third stream, beside this frame's searches and optimisations (which are
-    // queued by now): copy its images to the pinned planes (the host is otherwise about to wait), up, ExtractORB x 2,
-    // ComputeStereoMatches into the slot the next call adopts
-    const uint8_t* nx[2] = {in->next_left, in->next_right};
-    for (int c = 0; c < 2; c++) {
+    // queued by now): copy its images to the pinned planes (the host is otherwise about to wait), up, ExtractORB x n_img,
+    // (rectified pairs: ComputeStereoMatches) into the slot the next call adopts
+    for (int c = 0; c < t->n_img; c++) {
       uint8_t* dst = t->h_next + c * npx;
       if (in->stride == W)
         memcpy(dst, nx[c], npx);
@@ -982,14 +988,14 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     }
     hipStream_t sp = t->st_pref;
     TRK_HIP(hipStreamWaitEvent(sp, t->ev_head, 0));
-    TRK_HIP(hipMemcpyAsync(t->d_next, t->h_next, 2 * npx, hipMemcpyHostToDevice, sp));
+    TRK_HIP(hipMemcpyAsync(t->d_next, t->h_next, t->n_img * npx, hipMemcpyHostToDevice, sp));
     vieo_keypoint* s_kp = (vieo_keypoint*)(t->d_slot + t->s_kp);
     uint8_t* s_desc = t->d_slot + t->s_desc;
     int32_t* s_cnt = (int32_t*)(t->d_slot + t->s_cnt);
     hipStream_t keep = t->ext->stream;
     t->ext->stream = sp;  // (the extractor and the stereo matcher launch on the handle's stream)
-    rc = vieo_orb_extract_batch_device(t->ext, t->d_next, 2, W, Hh, W, npx, nullptr, s_kp, s_desc, cap, s_cnt);
-    if (rc == VIEO_OK)
+    rc = vieo_orb_extract_batch_device(t->ext, t->d_next, t->n_img, W, Hh, W, npx, lapping, s_kp, s_desc, cap, s_cnt);
+    if (rc == VIEO_OK && !t->rig)
       rc = vieo_stereo_match_rectified_batch_device(t->ext, 1, s_kp, s_desc, s_cnt, cap, P.baseline, P.bf, (float*)(t->d_slot + t->s_ur),
                                                     (float*)(t->d_slot + t->s_dp));
     t->ext->stream = keep;

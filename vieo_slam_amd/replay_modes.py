@@ -365,18 +365,35 @@ class RigReplay(replay.Replay):
 class RigTrackerReplay(RigReplay):
     """every frame's tracking as ONE vieo_track_frame call on a rig tracker (vieo_tracker_create_rig)"""
 
-    def __init__(self, seq, stages, nfeatures=1200, max_local_points=16384, **kw):
+    def __init__(self, seq, stages, nfeatures=1200, max_local_points=16384, prefetch=False, **kw):
         from .tracker import Tracker, rig_params
         super().__init__(seq, stages, nfeatures, **kw)
         prm, rg = rig_params(self.scene, nfeatures, max_local_points=max_local_points, th_last=self.th_last, th_local=self.th_local,
                              noise=seq.noise[0], th_depth=self.th_depth)
         self.trk = Tracker(prm, rg)
         self._lv = 0
+        # frame pipelining (vieo_track_input.next_images / next_imu): frame k + 1 goes along with frame k's call
+        self.prefetch, self._prefetched, self._n_run = bool(prefetch), False, 0
         self.stats["ms_chain"] = []
         self.stats["widened"] = 0
 
     def close(self):
         self.trk.close()
+
+    def run(self, n_frames=None):
+        self._n_run = n_frames or self.seq.n_frames
+        return super().run(n_frames)
+
+    def _pipelining(self, k, t):
+        """(use_prefetched, next_images, next_imu) of frame k's call"""
+        use = self.prefetch and self._prefetched
+        nxt = self.seq.images(k + 1) if (self.prefetch and k + 1 < self._n_run) else None
+        self._prefetched = nxt is not None
+        nxt_imu = None
+        if nxt is not None and len(self.seq.imu):
+            t_next = self.seq.time(k + 1)
+            nxt_imu = (self.seq.imu_between(t, t_next), t_next)
+        return use, nxt, nxt_imu
 
     def _all_local_points(self):
         key = (len(self.kfs), self.stats["lba_applied"])
@@ -408,8 +425,10 @@ class RigTrackerReplay(RigReplay):
         pts["reserved"][lk, 0] = where[last.mp_ref[lk]] + 1
         cand = self._all_local_points()
         alias = where[cand] if len(cand) else np.zeros(0, np.int32)
+        use_pf, nxt, nxt_imu = self._pipelining(k, t)
         o, v = self.trk.track(None, None, self.seq.imu_between(t_ref, t), t_ref, t, ref_nav, last.nav, prior, pts, last.track_depth,
-                              self._lp_pts, self._lp_desc, alias, self._lv, images=self.seq.images(k))
+                              self._lp_pts, self._lp_desc, alias, self._lv, images=self.seq.images(k), next_images=nxt,
+                              use_prefetched=use_pf, next_imu=nxt_imu)
         assert int(o["status"]) == 0 and int(o["stereo_status"]) == 0, "tracking call failed"
         self.stats["ms_chain"].append((float(o["ms_host"]), float(o["ms_gpu"])))
         self.stats["widened"] += int(o["widened"])
@@ -667,14 +686,19 @@ class VisionReplay(replay.Replay):
 class VisionTrackerReplay(VisionReplay):
     """every frame's tracking as ONE vieo_track_frame call on a vision-only tracker (params.vision_only = 1)"""
 
-    def __init__(self, seq, stages, max_local_points=16384, **kw):
+    def __init__(self, seq, stages, max_local_points=16384, prefetch=False, **kw):
         from .tracker import Tracker, euroc_params
         super().__init__(seq, stages, **kw)
         prm = euroc_params(max_local_points, self.th_last, self.th_local, seq.noise[0])
         prm[0]["n_features"], prm[0]["vision_only"] = NFEAT_VISION, 1
         self.trk = Tracker(prm)
         self._lv = 0
+        self.prefetch, self._prefetched, self._n_run = bool(prefetch), False, 0
         self.stats["ms_chain"] = []
+
+    def run(self, n_frames=None):
+        self._n_run = n_frames or self.seq.n_frames
+        return super().run(n_frames)
 
     def close(self):
         self.trk.close()
@@ -704,8 +728,11 @@ class VisionTrackerReplay(VisionReplay):
         where[last.mp_ref[lk[::-1]]] = lk[::-1]
         alias = where[cand] if len(cand) else np.zeros(0, np.int32)
         t = self.seq.time(k)
+        use_pf = self.prefetch and self._prefetched
+        nxt = self.seq.images(k + 1) if (self.prefetch and k + 1 < self._n_run) else None
+        self._prefetched = nxt is not None
         o, v = self.trk.track(Li, Ri, np.zeros(0, self.seq.imu.dtype), last.t, t, nav_pred, nav_last, None, pts, last.track_depth,
-                              self._lp_pts, self._lp_desc, alias, self._lv)
+                              self._lp_pts, self._lp_desc, alias, self._lv, next_images=nxt, use_prefetched=use_pf)
         assert int(o["status"]) == 0, "TrackWithMotionModel lost the frame"
         self.stats["ms_chain"].append((float(o["ms_host"]), float(o["ms_gpu"])))
         cap = int(o["key_cap"])

@@ -31,7 +31,7 @@ TRACK_INPUT_DTYPE = np.dtype([
     ("t_cur", "<f8"), ("nav_ref", NAVSTATE_DTYPE), ("nav_last", NAVSTATE_DTYPE), ("nav_prior", "<u8"), ("H_prior", "<u8"),
     ("n_last", "<i4"), ("last_points", "<u8"), ("last_track_depth", "<u8"), ("n_local", "<i4"), ("local_version", "<i4"),
     ("local_points", "<u8"), ("local_desc", "<u8"), ("local_alias", "<u8"), ("images", "<u8", 4), ("next_left", "<u8"),
-    ("next_right", "<u8"), ("use_prefetched", "<i4"), ("next_n_imu", "<i4"), ("next_imu", "<u8"), ("next_t_cur", "<f8")],
+    ("next_right", "<u8"), ("use_prefetched", "<i4"), ("next_n_imu", "<i4"), ("next_imu", "<u8"), ("next_t_cur", "<f8"), ("next_images", "<u8", 4)],
     align=True)
 TRACK_OUTPUT_DTYPE = np.dtype([
     ("status", "<i4"), ("n_keys", "<i4"), ("key_cap", "<i4"), ("keys", "<u8"), ("desc", "<u8"), ("uright", "<u8"),
@@ -173,15 +173,20 @@ class Tracker:
         i = self.inp[0]
         keep = []
         imgs = [left, right] if images is None else list(images)
-        if use_prefetched and images is None:
-            imgs = [self.planes[0], self.planes[1]]  # (not read)
+        if use_prefetched:
+            imgs = [self.planes[c] for c in range(self.n_img)]  # (not read)
         assert len(imgs) == self.n_img
         i["next_left"] = i["next_right"] = 0
+        i["next_images"] = 0
         i["use_prefetched"] = int(bool(use_prefetched))
         if next_images is not None:
-            nl, nr = (np.ascontiguousarray(x, np.uint8) for x in next_images)
-            keep += [nl, nr]
-            i["next_left"], i["next_right"] = nl.ctypes.data, nr.ctypes.data
+            nxt = [np.ascontiguousarray(x, np.uint8) for x in next_images]
+            assert len(nxt) == self.n_img
+            keep += nxt
+            if self.rig is not None:
+                i["next_images"][:self.n_img] = [x.ctypes.data for x in nxt]
+            else:
+                i["next_left"], i["next_right"] = nxt[0].ctypes.data, nxt[1].ctypes.data
         i["next_imu"], i["next_n_imu"], i["next_t_cur"] = 0, 0, 0.0
         if next_imu is not None:
             ns = np.ascontiguousarray(next_imu[0], IMU_SAMPLE_DTYPE)
