@@ -392,8 +392,15 @@ def rig_frontend_batch(rig="kb8", n_cams=4, nfeat=1500, seed=300, n_frames=256, 
         "fill_matches_walk": {"rows_per_frame": float(hdr[:, 5].mean()), "wavefront_steps_per_frame": float(hdr[:, 6].mean()),
                               "note": "FillMatchesFromPair's order-dependent group tables on the device: rows applied per "
                                       "speculative-parallel step = rows / steps (sequential form: 1)"},
-        "roofline_knn2": {"bound": "hbm", "kernel": "k_knn2 (cv::BFMatcher knnMatch k = 2 of every camera pair of every frame, one "
-                                                    "launch; query rows in registers, train rows through LDS tiles)",
+        "roofline_knn2": {"bound": "hbm", "kernel": "k_knn2_mfma (cv::BFMatcher knnMatch k = 2 of every camera pair of every frame, one "
+                                                    "launch; Hamming = |a| + |b| - 2 a.b with the bits as int8 0 / 1 on "
+                                                    "v_mfma_i32_32x32x32_i8, 256 queries per workgroup as resident B fragments, "
+                                                    "train tiles expanded once per workgroup in LDS; VIEO_KNN2_MFMA=0: the "
+                                                    "popcount kernel k_knn2)" if os.environ.get("VIEO_KNN2_MFMA", "1") != "0" else
+                                                    "k_knn2 (popcount form: query rows in registers, train rows through LDS tiles)",
+                          "mfma": {"bound": "mfma", "int8_ops_per_launch": ops / 8 * 256 * 2, "achieved": ops / 8 * 256 * 2 / (launch_ms * 1e-3) / 1e12,
+                                   "peak": 4404.0, "unit": "TOP/s", "frac": ops / 8 * 256 * 2 / (launch_ms * 1e-3) / 1e12 / 4404.0,
+                                   "peak_source": "cdna_hip_programming.md: i8 32x32 MFMA, 4404 TOPS measured floor"},
                           "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                           "algorithmic_bytes_per_launch": alg, "avg_launch_ms": launch_ms, "traffic": None,
                           "xor_popcount_word_ops_per_launch": ops, "word_ops_per_s": ops / (launch_ms * 1e-3),

@@ -109,6 +109,150 @@ k_knn2(Knn2Src S, int32_t* __restrict__ idx, int32_t* __restrict__ dist) {
   }
 }
 
+// ---- the same search on the matrix cores (round 5).  Hamming(a, b) = |a| + |b| - 2 a.b with the descriptors' 256 bits as
+// 0 / 1 int8 vectors: a.b for a 32 x 32 block of (train row, query) pairs is eight v_mfma_i32_32x32x32_i8.  The K order is
+// free as long as both operands use the same one, so a lane takes the 16 bytes [16 g, 16 g + 16) of its row (g = lane >> 5)
+// and MFMA m the bits of bytes 2 m, 2 m + 1 of those -- no knowledge of the instruction's K layout is needed, only that the
+// A operand's lane l is row l & 31, the B operand's lane l column l & 31, and D's lane l holds column l & 31, rows
+// (r & 3) + 8 (r >> 2) + 4 (l >> 5) (cdna_hip_programming.md).
+// Work: a workgroup = 256 queries (a wavefront keeps TWO sets of 32 as expanded B fragments, 64 registers, for the whole
+// kernel), the train rows pass in tiles of 32, expanded ONCE per workgroup into LDS in fragment order (a lane's operand of
+// MFMA m is one conflict-free ds_read_b128), double-buffered, one barrier per tile.  The tile also carries one word per
+// row, (|a| + 512) << 16 | row: key = that - (a.b << 17) is the packed (distance - |b| + 512, row) word in ONE v_mad --
+// |b| is the same for all keys of a lane and is added at the end -- and best / second are the v_med3 / v_min of k_knn2.
+// Per 32 x 32 pairs and wavefront: 8 MFMA (~260 cycles of the matrix pipe) against 48 key instructions + a quarter of the
+// tile's expansion; k_knn2 spends 19 vector instructions per PAIR and lane.
+typedef int knn_v16i __attribute__((ext_vector_type(16)));
+typedef int knn_v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned knn_spread4(unsigned nib) { return (nib * 0x00204081u) & 0x01010101u; }  // 4 bits -> 4 bytes 0 / 1
+__device__ __forceinline__ knn_v4i knn_spread16(unsigned h) {
+  knn_v4i r;
+  r[0] = (int)knn_spread4(h & 15u), r[1] = (int)knn_spread4((h >> 4) & 15u);
+  r[2] = (int)knn_spread4((h >> 8) & 15u), r[3] = (int)knn_spread4((h >> 12) & 15u);
+  return r;
+}
+
+__global__ void __launch_bounds__(256)
+k_knn2_mfma(Knn2Src S, int32_t* __restrict__ idx, int32_t* __restrict__ dist) {
+  __shared__ knn_v4i s_a[2][512];  // chunk (m * 2 + g) * 32 + i = the 16 expanded bytes of train row i for MFMA m, half g
+  __shared__ __attribute__((aligned(16))) unsigned s_L[2][32];
+  Knn2Job J;
+  if (S.jobs)
+    J = S.jobs[blockIdx.y];
+  else {
+    const int f = blockIdx.z, p = blockIdx.y, ci = S.pi[p], cj = S.pj[p];
+    const int32_t* c = S.counts + (size_t)f * S.n_cams * 2;
+    const int ni = c[2 * ci], mi = c[2 * ci + 1], nj = c[2 * cj], mj = c[2 * cj + 1];
+    const bool skip = mi >= ni || mj >= nj;  // Frame.cc:623
+    J.q = S.desc + (((size_t)f * S.n_cams + ci) * S.cap + mi) * 32;
+    J.t = S.desc + (((size_t)f * S.n_cams + cj) * S.cap + mj) * 32;
+    J.nq = skip ? 0 : min(ni, S.cap) - mi, J.nt = skip ? 0 : min(nj, S.cap) - mj;
+    J.out_off = ((int)f * S.n_pairs + p) * S.cap;
+  }
+  if ((int)blockIdx.x * 256 >= J.nq) return;  // (uniform over the workgroup)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int q0 = blockIdx.x * 256 + wave * 64;
+  // ---- this wavefront's queries as B fragments
+  knn_v4i B[2][8];
+  unsigned pb[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int qi = q0 + 32 * s + j;
+    uint4 h = {0, 0, 0, 0};
+    if (qi < J.nq) h = ((const uint4*)(J.q + (size_t)qi * 32))[g];
+    const unsigned half = __popc(h.x) + __popc(h.y) + __popc(h.z) + __popc(h.w);
+    pb[s] = half + (unsigned)__shfl_xor((int)half, 32);
+    const unsigned w[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+    for (int m = 0; m < 8; m++) B[s][m] = knn_spread16((w[m >> 1] >> (16 * (m & 1))) & 0xFFFFu);
+  }
+  unsigned k0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, k1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+  // ---- staging roles: thread t expands chunks t and t + 256 of a tile; threads 0..31 its rows' words
+  const int n_tiles = (J.nt + 31) >> 5;
+  unsigned h16[2] = {0, 0};
+  uint4 ra = {0, 0, 0, 0}, rb = ra;
+  auto fetch = [&](int T) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int cc = tid + 256 * u, m = cc >> 6, gg = (cc >> 5) & 1, row = T * 32 + (cc & 31);
+      h16[u] = row < J.nt ? (unsigned)*(const unsigned short*)(J.t + (size_t)row * 32 + 16 * gg + 2 * m) : 0u;
+    }
+    if (tid < 32) {
+      const int row = T * 32 + tid;
+      ra = rb = make_uint4(0, 0, 0, 0);
+      if (row < J.nt) ra = ((const uint4*)(J.t + (size_t)row * 32))[0], rb = ((const uint4*)(J.t + (size_t)row * 32))[1];
+    }
+  };
+  auto stage = [&](int T, int b) {
+    s_a[b][tid] = knn_spread16(h16[0]);
+    s_a[b][tid + 256] = knn_spread16(h16[1]);
+    if (tid < 32) {
+      const int row = T * 32 + tid;
+      const unsigned pa = __popc(ra.x) + __popc(ra.y) + __popc(ra.z) + __popc(ra.w) + __popc(rb.x) + __popc(rb.y) + __popc(rb.z) + __popc(rb.w);
+      s_L[b][tid] = row < J.nt ? ((pa + 512u) << 16) | (unsigned)row : 0xFFFFFFFFu;
+    }
+  };
+  fetch(0);
+  stage(0, 0);
+  __syncthreads();
+  for (int T = 0; T < n_tiles; T++) {
+    const int b = T & 1;
+    if (T + 1 < n_tiles) fetch(T + 1);  // (in flight during this tile's MFMAs)
+    knn_v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const knn_v4i a = s_a[b][(m * 2 + g) * 32 + j];
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[0][m], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[1][m], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) {
+      const uint4 Lw = *(const uint4*)&s_L[b][8 * q4 + 4 * g];
+      const unsigned L[4] = {Lw.x, Lw.y, Lw.z, Lw.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const unsigned ka = L[e] - ((unsigned)acc0[4 * q4 + e] << 17), kb = L[e] - ((unsigned)acc1[4 * q4 + e] << 17);
+        k1[0] = min(max(ka, k0[0]), k1[0]), k0[0] = min(k0[0], ka);
+        k1[1] = min(max(kb, k0[1]), k1[1]), k0[1] = min(k0[1], kb);
+      }
+    }
+    if (T + 1 < n_tiles) stage(T + 1, b ^ 1);
+    __syncthreads();
+  }
+  // ---- the two lanes of a query (rows 4 g .. of every group of 8) merge; |b| joins the distances
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const unsigned o0 = (unsigned)__shfl_xor((int)k0[s], 32), o1 = (unsigned)__shfl_xor((int)k1[s], 32);
+    const unsigned lo = min(k0[s], o0), hi = max(k0[s], o0);
+    const unsigned second = min(hi, min(k1[s], o1));
+    const int qi = q0 + 32 * s + j;
+    if (g == 0 && qi < J.nq) {
+      int32_t* oi = idx + ((size_t)J.out_off + qi) * 2;
+      int32_t* od = dist + ((size_t)J.out_off + qi) * 2;
+      oi[0] = lo == 0xFFFFFFFFu ? -1 : (int)(lo & 0xFFFF), od[0] = lo == 0xFFFFFFFFu ? INT_MAX : (int)(lo >> 16) - 512 + (int)pb[s];
+      oi[1] = second == 0xFFFFFFFFu ? -1 : (int)(second & 0xFFFF);
+      od[1] = second == 0xFFFFFFFFu ? INT_MAX : (int)(second >> 16) - 512 + (int)pb[s];
+    }
+  }
+}
+
+// VIEO_KNN2_MFMA=0: the popcount kernel (A/B timing)
+static bool knn2_mfma() {
+  static const bool on = [] {
+    const char* e = getenv("VIEO_KNN2_MFMA");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+static void knn2_launch(const Knn2Src& S, int max_nq, int ny, int nz, int32_t* d_idx, int32_t* d_dist, hipStream_t st) {
+  if (knn2_mfma())
+    hipLaunchKernelGGL(k_knn2_mfma, dim3((max_nq + 255) / 256, ny, nz), dim3(256), 0, st, S, d_idx, d_dist);
+  else
+    hipLaunchKernelGGL(k_knn2, dim3((max_nq + 63) / 64, ny, nz), dim3(256), 0, st, S, d_idx, d_dist);
+}
+
 // the rig form for the device-resident stereo stage of camera-rig frames (fisheye_stereo.hip)
 int knn2_rig_launch(const uint8_t* d_desc, const int32_t* d_counts, int cap, int n_cams, int n_frames, int32_t* d_idx,
                     int32_t* d_dist, hipStream_t st) {
@@ -120,7 +264,7 @@ int knn2_rig_launch(const uint8_t* d_desc, const int32_t* d_counts, int cap, int
     for (int j = i + 1; j < n_cams; j++, p++) S.pi[p] = (signed char)i, S.pj[p] = (signed char)j;
   S.n_pairs = p;
   if (p == 0 || n_frames <= 0) return VIEO_OK;
-  hipLaunchKernelGGL(k_knn2, dim3((cap + 63) / 64, p, n_frames), dim3(256), 0, st, S, d_idx, d_dist);
+  knn2_launch(S, cap, p, n_frames, d_idx, d_dist, st);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
@@ -634,7 +778,7 @@ int vieo_hamming_knn2_batch_device(const uint8_t* d_descriptors, const int32_t* 
     Knn2Src K;
     memset(&K, 0, sizeof(K));
     K.jobs = S.jobs.as<Knn2Job>();
-    hipLaunchKernelGGL(k_knn2, dim3((max_nq + 63) / 64, n_pairs), dim3(256), 0, st, K, d_idx, d_dist);
+    knn2_launch(K, max_nq, n_pairs, 1, d_idx, d_dist, st);
   }
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
@@ -677,7 +821,7 @@ int vieo_hamming_knn2(const uint8_t* h_query, int nq, const uint8_t* h_train, in
   Knn2Src K;
   memset(&K, 0, sizeof(K));
   K.jobs = S.jobs.as<Knn2Job>();
-  hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64, 1), dim3(256), 0, 0, K, S.idx.as<int32_t>(), S.dist.as<int32_t>());
+  knn2_launch(K, nq, 1, 1, S.idx.as<int32_t>(), S.dist.as<int32_t>(), 0);
   VIEO_HIP_CHECK(hipGetLastError());
   VIEO_HIP_CHECK(hipMemcpy(h_idx, S.idx.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
   VIEO_HIP_CHECK(hipMemcpy(h_dist, S.dist.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
