@@ -944,190 +944,221 @@ constexpr int kFBlRows = 2 * kFR + 1, kFBlPitch = 40;       // blurred patch: 37
 constexpr int kFWaveLds = kFRawRows * kFRawPitch + 16 + kFHPairs * kFHCols * 4;  // the blurred patch overlays the raw one
 static_assert(kFBlRows * kFBlPitch <= kFRawRows * kFRawPitch, "the blurred patch fits where the raw one was");
 
+#ifndef VIEO_FUSED_KPW
+#define VIEO_FUSED_KPW 4  // key points per wavefront, one after the other (the next one's patch loads in flight meanwhile)
+#endif
 __global__ void __launch_bounds__(256)
 k_describe_fused(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __restrict__ pattern,
                  vieo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int out_cap,
                  int groups_per_image, int n_images) {
+  constexpr int KPW = VIEO_FUSED_KPW;
   // all key points of an image on one XCD: their overlapping patches then share that XCD's L2
   const int item = xcd_grouped(blockIdx.x, groups_per_image);
   const int b = item / groups_per_image;
   if (b >= n_images) return;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int g = (item - b * groups_per_image) * (blockDim.x >> 6) + wv;
+  // A wavefront takes KPW consecutive key points one after the other: the wave's start-up, the record and pattern loads
+  // are paid once, and the NEXT key point's patch loads are in flight while this one is blurred and sampled (with one key
+  // point per wavefront 1.7 of the kernel's 5.7 ms were start-up and 0.9 the wait for the patch).
+  const int g0 = ((item - b * groups_per_image) * (blockDim.x >> 6) + wv) * KPW;
   const int gmax = min(P.kp_cap, out_cap);
-  if (g >= gmax) return;
-  const uint2 kr = krec[(size_t)b * P.kp_cap + g];
+  if (g0 >= gmax) return;
   __shared__ __attribute__((aligned(16))) uint8_t s_all[4][kFWaveLds];
   int pt4[4];
 #pragma unroll
   for (int gq = 0; gq < 4; gq++) pt4[gq] = pattern[gq * 64 + lane];  // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
-  const int level = (int)kr.y;
-  if (level < 0) return;  // (wave-uniform)
-  const unsigned key = kr.x;
-  const LevelDesc& D = P.lv[level];
-  const int cx = QT_KEY_X(key) + (kEdge - 3), cy = QT_KEY_Y(key) + (kEdge - 3);
-  int pitch;
-  const uint8_t* img = plane_ptr(P, I, b, level, &pitch);
   uint8_t* s_raw = s_all[wv];
   unsigned* s_h = (unsigned*)(s_raw + kFRawRows * kFRawPitch + 16);
-  const int x_lo = cx - kFRaw, y_lo = cy - kFRaw;
-  const int xa = x_lo & ~3, sh = x_lo - xa;  // the patch's column 0 is byte `sh` of the aligned rows (wave-uniform)
   // ---- the raw patch: 43 rows, staged so that its column 0 is byte 0 of the LDS row (12 dwords).  A step = 4 rows x 16
   // lanes: lane c loads dword c of the aligned row (13 of them hold the patch), takes dword c + 1 from its neighbour
-  // (DPP row shift) and stores the two realigned; all loads in flight, then the stores
+  // (DPP row shift) and stores the two realigned; all loads in flight, then (an iteration later) the stores
   constexpr int NLD = (kFRawRows + 3) / 4;
   unsigned v[NLD];
+  bool interior = false;
+  int sh = 0;
   const int c = lane & 15, r0 = lane >> 4;
-  const bool interior = x_lo >= 0 && y_lo >= 0 && cx + kFRaw < D.w && cy + kFRaw < D.h && xa + 52 <= pitch &&
-                        ((pitch & 3) == 0) && ((((uintptr_t)img) & 3) == 0);
-  if (VIEO_FUSED_AB & 2) {
+  auto rec_of = [&](int u) { return (u < KPW && g0 + u < gmax) ? krec[(size_t)b * P.kp_cap + g0 + u] : make_uint2(0u, 0xFFFFFFFFu); };
+  auto fetch = [&](const uint2 kr) {  // the loads of key point kr's patch (wave-uniform control flow)
+    const int level = (int)kr.y;
+    if (level < 0) return;
+    const LevelDesc& D = P.lv[level];
+    const int cx = QT_KEY_X(kr.x) + (kEdge - 3), cy = QT_KEY_Y(kr.x) + (kEdge - 3);
+    int pitch;
+    const uint8_t* img = plane_ptr(P, I, b, level, &pitch);
+    const int x_lo = cx - kFRaw, y_lo = cy - kFRaw;
+    const int xa = x_lo & ~3;
+    sh = x_lo - xa;  // the patch's column 0 is byte `sh` of the aligned rows
+    interior = x_lo >= 0 && y_lo >= 0 && cx + kFRaw < D.w && cy + kFRaw < D.h && xa + 52 <= pitch && ((pitch & 3) == 0) &&
+               ((((uintptr_t)img) & 3) == 0);
+    if (VIEO_FUSED_AB & 2) {
 #pragma unroll
-    for (int k = 0; k < NLD; k++) v[k] = key + k;
-  } else if (interior) {
-    const uint8_t* g0 = img + (size_t)(y_lo + r0) * pitch + xa + 4 * c;
+      for (int k = 0; k < NLD; k++) v[k] = kr.x + k;
+      interior = false;
+    } else if (interior) {
+      const uint8_t* gp = img + (size_t)(y_lo + r0) * pitch + xa + 4 * c;
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      v[k] = 0;
-      if (c < 13 && r0 + 4 * k < kFRawRows) v[k] = *(const unsigned*)(g0 + (size_t)(4 * k) * pitch);
-    }
+      for (int k = 0; k < NLD; k++) {
+        v[k] = 0;
+        if (c < 13 && r0 + 4 * k < kFRawRows) v[k] = *(const unsigned*)(gp + (size_t)(4 * k) * pitch);
+      }
+    } else {
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[k], 0x101, 0xF, 0xF, false);  // row_shl:1 = lane + 1's
-      v[k] = __builtin_amdgcn_alignbyte(nxt, v[k], sh);
-    }
-  } else {
+      for (int k = 0; k < NLD; k++) {
+        v[k] = 0;
+        if (c < 12 && r0 + 4 * k < kFRawRows) {
+          const uint8_t* row = img + (size_t)reflect101(min(max(y_lo + r0 + 4 * k, -(D.h - 1)), 2 * D.h - 2), D.h) * pitch;
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      v[k] = 0;
-      if (c < 12 && r0 + 4 * k < kFRawRows) {
-        const uint8_t* row = img + (size_t)reflect101(min(max(y_lo + r0 + 4 * k, -(D.h - 1)), 2 * D.h - 2), D.h) * pitch;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int x = min(max(x_lo + 4 * c + j, -(D.w - 1)), 2 * D.w - 2);
-          v[k] |= (unsigned)row[reflect101(x, D.w)] << (8 * j);
+          for (int jj = 0; jj < 4; jj++) {
+            const int x = min(max(x_lo + 4 * c + jj, -(D.w - 1)), 2 * D.w - 2);
+            v[k] |= (unsigned)row[reflect101(x, D.w)] << (8 * jj);
+          }
         }
       }
     }
-  }
+  };
+  uint2 kr = rec_of(0);
+  fetch(kr);
+#pragma unroll 1
+  for (int u = 0; u < KPW; u++) {
+    const uint2 cur = kr;
+    const int level = (int)cur.y;
+    if (level < 0) break;  // (the records behind an image's last key point are all empty)
+    const unsigned key = cur.x;
+    const int g = g0 + u;
+    const LevelDesc& D = P.lv[level];
+    const int cx = QT_KEY_X(key) + (kEdge - 3), cy = QT_KEY_Y(key) + (kEdge - 3);
+    if (interior) {
 #pragma unroll
-  for (int k = 0; k < NLD; k++)
-    if (c < 12 && r0 + 4 * k < kFRawRows) *(unsigned*)(s_raw + (r0 + 4 * k) * kFRawPitch + 4 * c) = v[k];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // ---- horizontal pass: one item = two raw rows x EIGHT columns from four dwords per row; the seven taps as v_dot4 with
-  // the weights shifted instead of the bytes (20 per row: no realignment), 16-bit sums of vertically adjacent rows packed
-  {
-    constexpr unsigned A0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), A1 = 48u | (34u << 8) | (18u << 16);
-    constexpr unsigned B0 = (18u << 8) | (34u << 16) | (48u << 24), B1 = 56u | (48u << 8) | (34u << 16) | (18u << 24);
-    constexpr unsigned C0 = (18u << 16) | (34u << 24), C1 = 48u | (56u << 8) | (48u << 16) | (34u << 24), C2 = 18u;
-    constexpr unsigned E0 = 18u << 24, E1 = 34u | (48u << 8) | (56u << 16) | (48u << 24), E2 = 34u | (18u << 8);
-    for (int idx = lane; idx < ((VIEO_FUSED_AB & 1) ? 0 : kFHPairs * (kFHCols / 8)); idx += 64) {
-      const int pr = idx / (kFHCols / 8), g8 = idx - pr * (kFHCols / 8);
-      unsigned h[2][8];
+      for (int k = 0; k < NLD; k++) {
+        const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[k], 0x101, 0xF, 0xF, false);  // row_shl:1 = lane + 1's
+        v[k] = __builtin_amdgcn_alignbyte(nxt, v[k], sh);
+      }
+    }
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const int r = min(2 * pr + q, kFRawRows - 1);  // (the 44th row does not exist: its sums are never read)
-        const uint2* w = (const uint2*)(s_raw + r * kFRawPitch + 8 * g8);
-        const uint2 lo = w[0], hi = w[1];
-        const unsigned d0 = lo.x, d1 = lo.y, d2 = hi.x, d3 = hi.y;
+    for (int k = 0; k < NLD; k++)
+      if (c < 12 && r0 + 4 * k < kFRawRows) *(unsigned*)(s_raw + (r0 + 4 * k) * kFRawPitch + 4 * c) = v[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    kr = rec_of(u + 1);
+    fetch(kr);  // the next key point's patch: in flight during this one's arithmetic
+    // ---- horizontal pass: one item = two raw rows x EIGHT columns from four dwords per row; the seven taps as v_dot4 with
+    // the weights shifted instead of the bytes (20 per row: no realignment), 16-bit sums of vertically adjacent rows packed
+    {
+      constexpr unsigned A0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), A1 = 48u | (34u << 8) | (18u << 16);
+      constexpr unsigned B0 = (18u << 8) | (34u << 16) | (48u << 24), B1 = 56u | (48u << 8) | (34u << 16) | (18u << 24);
+      constexpr unsigned C0 = (18u << 16) | (34u << 24), C1 = 48u | (56u << 8) | (48u << 16) | (34u << 24), C2 = 18u;
+      constexpr unsigned E0 = 18u << 24, E1 = 34u | (48u << 8) | (56u << 16) | (48u << 24), E2 = 34u | (18u << 8);
+      for (int idx = lane; idx < ((VIEO_FUSED_AB & 1) ? 0 : kFHPairs * (kFHCols / 8)); idx += 64) {
+        const int pr = idx / (kFHCols / 8), g8 = idx - pr * (kFHCols / 8);
+        unsigned h[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int r = min(2 * pr + q, kFRawRows - 1);  // (the 44th row does not exist: its sums are never read)
+          const uint2* w = (const uint2*)(s_raw + r * kFRawPitch + 8 * g8);
+          const uint2 lo = w[0], hi = w[1];
+          const unsigned d0 = lo.x, d1 = lo.y, d2 = hi.x, d3 = hi.y;
 #define DOT4(x, k, acc) __builtin_amdgcn_udot4(x, k, acc, false)
-        h[q][0] = DOT4(d1, A1, DOT4(d0, A0, 0u));
-        h[q][1] = DOT4(d1, B1, DOT4(d0, B0, 0u));
-        h[q][2] = DOT4(d2, C2, DOT4(d1, C1, DOT4(d0, C0, 0u)));
-        h[q][3] = DOT4(d2, E2, DOT4(d1, E1, DOT4(d0, E0, 0u)));
-        h[q][4] = DOT4(d2, A1, DOT4(d1, A0, 0u));
-        h[q][5] = DOT4(d2, B1, DOT4(d1, B0, 0u));
-        h[q][6] = DOT4(d3, C2, DOT4(d2, C1, DOT4(d1, C0, 0u)));
-        h[q][7] = DOT4(d3, E2, DOT4(d2, E1, DOT4(d1, E0, 0u)));
+          h[q][0] = DOT4(d1, A1, DOT4(d0, A0, 0u));
+          h[q][1] = DOT4(d1, B1, DOT4(d0, B0, 0u));
+          h[q][2] = DOT4(d2, C2, DOT4(d1, C1, DOT4(d0, C0, 0u)));
+          h[q][3] = DOT4(d2, E2, DOT4(d1, E1, DOT4(d0, E0, 0u)));
+          h[q][4] = DOT4(d2, A1, DOT4(d1, A0, 0u));
+          h[q][5] = DOT4(d2, B1, DOT4(d1, B0, 0u));
+          h[q][6] = DOT4(d3, C2, DOT4(d2, C1, DOT4(d1, C0, 0u)));
+          h[q][7] = DOT4(d3, E2, DOT4(d2, E1, DOT4(d1, E0, 0u)));
 #undef DOT4
-      }
-      uint4 o0, o1;
-      o0.x = h[0][0] | (h[1][0] << 16), o0.y = h[0][1] | (h[1][1] << 16);
-      o0.z = h[0][2] | (h[1][2] << 16), o0.w = h[0][3] | (h[1][3] << 16);
-      o1.x = h[0][4] | (h[1][4] << 16), o1.y = h[0][5] | (h[1][5] << 16);
-      o1.z = h[0][6] | (h[1][6] << 16), o1.w = h[0][7] | (h[1][7] << 16);
-      uint4* dst = (uint4*)(s_h + pr * kFHCols + 8 * g8);
-      dst[0] = o0, dst[1] = o1;
-    }
-  }
-  // ---- IC_Angle on the raw patch (its centre is row kFRaw, byte kFRaw): two lanes per row of the radius-15 disc
-  int m10 = 0, m01 = 0;
-  if (lane < ((VIEO_FUSED_AB & 4) ? 1 : 62)) {
-    const int vv = (lane >> 1) - kHalfPatch;
-    const int d = P.umax[vv < 0 ? -vv : vv];
-    const uint8_t* row = s_raw + (vv + kFRaw) * kFRawPitch + kFRaw;
-    const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
-    int sI = 0;
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const int uu = u0 + t;
-      if (uu <= u1) {
-        const int val = row[uu];
-        m10 += uu * val;
-        sI += val;
+        }
+        uint4 o0, o1;
+        o0.x = h[0][0] | (h[1][0] << 16), o0.y = h[0][1] | (h[1][1] << 16);
+        o0.z = h[0][2] | (h[1][2] << 16), o0.w = h[0][3] | (h[1][3] << 16);
+        o1.x = h[0][4] | (h[1][4] << 16), o1.y = h[0][5] | (h[1][5] << 16);
+        o1.z = h[0][6] | (h[1][6] << 16), o1.w = h[0][7] | (h[1][7] << 16);
+        uint4* dst = (uint4*)(s_h + pr * kFHCols + 8 * g8);
+        dst[0] = o0, dst[1] = o1;
       }
     }
-    m01 = vv * sI;
-  }
-  m10 = wave_sum(m10);
-  m01 = wave_sum(m01);
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // ---- vertical pass (k_blur's): one item = two blurred rows x four columns, into the space the raw patch had
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  uint8_t* s_bl = s_raw;
-  for (int idx = lane; idx < ((VIEO_FUSED_AB & 1) ? 0 : ((kFBlRows + 1) / 2) * (kFBlPitch / 4)); idx += 64) {
-    const int q = idx / (kFBlPitch / 4), c4 = (idx - q * (kFBlPitch / 4)) * 4;
-    const unsigned We[4] = {18u | (34u << 16), 48u | (56u << 16), 48u | (34u << 16), 18u};
-    const unsigned Wo[4] = {18u << 16, 34u | (48u << 16), 56u | (48u << 16), 34u | (18u << 16)};
-    unsigned e[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15}, o[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
+    // ---- IC_Angle on the raw patch (its centre is row kFRaw, byte kFRaw): two lanes per row of the radius-15 disc
+    int m10 = 0, m01 = 0;
+    if (lane < ((VIEO_FUSED_AB & 4) ? 1 : 62)) {
+      const int vv = (lane >> 1) - kHalfPatch;
+      const int d = P.umax[vv < 0 ? -vv : vv];
+      const uint8_t* row = s_raw + (vv + kFRaw) * kFRawPitch + kFRaw;
+      const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
+      int sI = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint4 hv = *(const uint4*)(s_h + (q + k) * kFHCols + c4);
-      const unsigned vv[4] = {hv.x, hv.y, hv.z, hv.w};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        e[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, vv[j]), __builtin_bit_cast(us2, We[k]), e[j], false);
-        o[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, vv[j]), __builtin_bit_cast(us2, Wo[k]), o[j], false);
+      for (int t = 0; t < 16; t++) {
+        const int uu = u0 + t;
+        if (uu <= u1) {
+          const int val = row[uu];
+          m10 += uu * val;
+          sI += val;
+        }
       }
+      m01 = vv * sI;
     }
-    // byte 2 of each sum (the sums stay below 2^24): three v_perm per four pixels
-    const unsigned oe = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), 0x05040100u);
-    const unsigned oo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0602u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), 0x05040100u);
-    *(unsigned*)(s_bl + (2 * q) * kFBlPitch + c4) = oe;
-    if (2 * q + 1 < kFBlRows) *(unsigned*)(s_bl + (2 * q + 1) * kFBlPitch + c4) = oo;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // ---- steered BRIEF on the blurred patch (ORBextractor.cc:83-127)
-  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-  float a, bsin;
-  vieo_sincosf_exact(angle * factorPI, &bsin, &a);
-  const uint8_t* bl = s_bl + kFR * kFBlPitch + kFR;
-  unsigned long long bits[4];
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- vertical pass (k_blur's): one item = two blurred rows x four columns, into the space the raw patch had
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    uint8_t* s_bl = s_raw;
+    for (int idx = lane; idx < ((VIEO_FUSED_AB & 1) ? 0 : ((kFBlRows + 1) / 2) * (kFBlPitch / 4)); idx += 64) {
+      const int q = idx / (kFBlPitch / 4), c4 = (idx - q * (kFBlPitch / 4)) * 4;
+      const unsigned We[4] = {18u | (34u << 16), 48u | (56u << 16), 48u | (34u << 16), 18u};
+      const unsigned Wo[4] = {18u << 16, 34u | (48u << 16), 56u | (48u << 16), 34u | (18u << 16)};
+      unsigned e[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15}, o[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
 #pragma unroll
-  for (int gq = 0; gq < ((VIEO_FUSED_AB & 4) ? 1 : 4); gq++) {
-    const int pt = pt4[gq];
-    const float x0 = (float)(signed char)(pt & 0xFF), y0 = (float)(signed char)((pt >> 8) & 0xFF);
-    const float x1 = (float)(signed char)((pt >> 16) & 0xFF), y1 = (float)(signed char)((pt >> 24) & 0xFF);
-    const int t0 = bl[__float2int_rn(x0 * bsin + y0 * a) * kFBlPitch + __float2int_rn(x0 * a - y0 * bsin)];
-    const int t1 = bl[__float2int_rn(x1 * bsin + y1 * a) * kFBlPitch + __float2int_rn(x1 * a - y1 * bsin)];
-    bits[gq] = __ballot(t0 < t1);
-  }
-  if (lane < 4) ((unsigned long long*)(desc_out + ((size_t)b * out_cap + g) * 32))[lane] = bits[lane];
-  if (lane == 0) {
-    vieo_keypoint k;
-    const float fx = (float)cx, fy = (float)cy;
-    k.x = level ? fx * D.scale : fx;
-    k.y = level ? fy * D.scale : fy;
-    k.size = (float)D.patch;
-    k.angle = angle;
-    k.response = (float)QT_KEY_R(key);
-    k.octave = level;
-    k.class_id = -1;
-    kp_out[(size_t)b * out_cap + g] = k;
+      for (int k = 0; k < 4; k++) {
+        const uint4 hv = *(const uint4*)(s_h + (q + k) * kFHCols + c4);
+        const unsigned vv[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          e[jj] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, vv[jj]), __builtin_bit_cast(us2, We[k]), e[jj], false);
+          o[jj] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, vv[jj]), __builtin_bit_cast(us2, Wo[k]), o[jj], false);
+        }
+      }
+      // byte 2 of each sum (the sums stay below 2^24): three v_perm per four pixels
+      const unsigned oe = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), 0x05040100u);
+      const unsigned oo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0602u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), 0x05040100u);
+      *(unsigned*)(s_bl + (2 * q) * kFBlPitch + c4) = oe;
+      if (2 * q + 1 < kFBlRows) *(unsigned*)(s_bl + (2 * q + 1) * kFBlPitch + c4) = oo;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- steered BRIEF on the blurred patch (ORBextractor.cc:83-127)
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, bsin;
+    vieo_sincosf_exact(angle * factorPI, &bsin, &a);
+    const uint8_t* bl = s_bl + kFR * kFBlPitch + kFR;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int gq = 0; gq < ((VIEO_FUSED_AB & 4) ? 1 : 4); gq++) {
+      const int pt = pt4[gq];
+      const float x0 = (float)(signed char)(pt & 0xFF), y0 = (float)(signed char)((pt >> 8) & 0xFF);
+      const float x1 = (float)(signed char)((pt >> 16) & 0xFF), y1 = (float)(signed char)((pt >> 24) & 0xFF);
+      const int t0 = bl[__float2int_rn(x0 * bsin + y0 * a) * kFBlPitch + __float2int_rn(x0 * a - y0 * bsin)];
+      const int t1 = bl[__float2int_rn(x1 * bsin + y1 * a) * kFBlPitch + __float2int_rn(x1 * a - y1 * bsin)];
+      bits[gq] = __ballot(t0 < t1);
+    }
+    if (lane < 4) ((unsigned long long*)(desc_out + ((size_t)b * out_cap + g) * 32))[lane] = bits[lane];
+    if (lane == 0) {
+      vieo_keypoint k;
+      const float fx = (float)cx, fy = (float)cy;
+      k.x = level ? fx * D.scale : fx;
+      k.y = level ? fy * D.scale : fy;
+      k.size = (float)D.patch;
+      k.angle = angle;
+      k.response = (float)QT_KEY_R(key);
+      k.octave = level;
+      k.class_id = -1;
+      kp_out[(size_t)b * out_cap + g] = k;
+    }
+    // (the next iteration overwrites the patch this one sampled)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1514,7 +1545,7 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
                        e->d_tiles.as<BlurTile>(), (int)e->tiles.size(), B);
   }
   STAMP();
-  const int per_group = fused ? 4 : 4 * VIEO_DESC_KPW;
+  const int per_group = fused ? 4 * VIEO_FUSED_KPW : 4 * VIEO_DESC_KPW;
   const int ngroups = (std::min(P.kp_cap, capacity) + per_group - 1) / per_group;
   auto describe = [&](unsigned grid, vieo_keypoint* kp, uint8_t* desc, int cap, int ng) {
     if (fused)
