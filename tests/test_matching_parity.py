@@ -14,7 +14,7 @@ def _hip(nfeat=1200):
     return ORBextractor(nfeat, 1.2, 8, 20, 7)
 
 
-@pytest.mark.parametrize("nq,nt", [(1200, 1200), (1500, 1000), (1, 1), (7, 1), (65, 130), (3, 0)])
+@pytest.mark.parametrize("nq,nt", [(1200, 1200), (1500, 1000), (1, 1), (7, 1), (65, 130), (3, 0), (300, 33), (257, 31), (40, 2100)])
 def test_knn2_parity(oracle, nq, nt):
     from vieo_slam_amd.matching import knn_match2
     q = synth.synth_descriptors(nq, seed=7, n_dup=nq // 2)
@@ -26,6 +26,21 @@ def test_knn2_parity(oracle, nq, nt):
                                                np.full((nq, 2), np.iinfo(np.int32).max, np.int32))
     hi, hd = knn_match2(q, t)
     assert np.array_equal(oi, hi) and np.array_equal(od, hd)
+
+
+def test_knn2_extreme_rows(oracle):
+    """all-zero / all-one rows (|a| = 0, 256; a.b = 0, 256) and exact duplicates among the train rows: the matrix-core form
+    computes |a| + |b| - 2 a.b, its packed keys must order exactly like the distances + indices"""
+    from vieo_slam_amd.matching import knn_match2
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (45, 32), dtype=np.uint8)
+    q[0], q[1], q[2] = 0, 255, t[7]
+    t[0], t[1], t[20], t[21], t[44] = 255, 0, t[7], 0, 255
+    oi, od = oracle.knn2(q, t)
+    hi, hd = knn_match2(q, t)
+    assert np.array_equal(oi, hi) and np.array_equal(od, hd)
+    assert od[0, 0] == 0 and oi[0, 0] == 1 and od[1, 0] == 0 and oi[1, 0] == 0 and oi[2].tolist() == [7, 20]
 
 
 def test_knn2_real_descriptors_with_ties(oracle):

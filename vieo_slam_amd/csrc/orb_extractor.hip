@@ -945,13 +945,15 @@ constexpr int kFWaveLds = kFRawRows * kFRawPitch + 16 + kFHPairs * kFHCols * 4; 
 static_assert(kFBlRows * kFBlPitch <= kFRawRows * kFRawPitch, "the blurred patch fits where the raw one was");
 
 #ifndef VIEO_FUSED_KPW
-#define VIEO_FUSED_KPW 4  // key points per wavefront, one after the other (the next one's patch loads in flight meanwhile)
+#define VIEO_FUSED_KPW 4  // key points per wavefront in large batches, one after the other (the next one's patch loads in flight meanwhile)
 #endif
+// (a frame or two at a time -- the one-call tracker, the per-image host entry -- there are fewer key points than wavefront
+// slots: one key point per wavefront then, 604 wavefronts of four were 28 us per stereo frame against 20 for the two kernels)
+static inline int fused_kpw(int n_images) { return n_images >= 32 ? VIEO_FUSED_KPW : 1; }
 __global__ void __launch_bounds__(256)
 k_describe_fused(OrbParams P, ImgSet I, const uint2* __restrict__ krec, const int* __restrict__ pattern,
                  vieo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out, int out_cap,
-                 int groups_per_image, int n_images) {
-  constexpr int KPW = VIEO_FUSED_KPW;
+                 int groups_per_image, int n_images, int KPW) {
   // all key points of an image on one XCD: their overlapping patches then share that XCD's L2
   const int item = xcd_grouped(blockIdx.x, groups_per_image);
   const int b = item / groups_per_image;
@@ -1545,12 +1547,12 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
                        e->d_tiles.as<BlurTile>(), (int)e->tiles.size(), B);
   }
   STAMP();
-  const int per_group = fused ? 4 * VIEO_FUSED_KPW : 4 * VIEO_DESC_KPW;
+  const int per_group = fused ? 4 * fused_kpw(B) : 4 * VIEO_DESC_KPW;
   const int ngroups = (std::min(P.kp_cap, capacity) + per_group - 1) / per_group;
   auto describe = [&](unsigned grid, vieo_keypoint* kp, uint8_t* desc, int cap, int ng) {
     if (fused)
       hipLaunchKernelGGL(k_describe_fused, dim3(grid), dim3(256), 0, st, P, I, e->d_krec.as<uint2>(), e->d_pattern.as<int>(), kp, desc,
-                         cap, ng, B);
+                         cap, ng, B, fused_kpw(B));
     else
       hipLaunchKernelGGL(k_describe, dim3(grid), dim3(256), 0, st, P, I, e->d_krec.as<uint2>(), e->d_pattern.as<int>(), kp, desc, cap,
                          ng, B);

@@ -223,6 +223,8 @@ struct vieo_tracker {
   hipStream_t st = nullptr, st_imu = nullptr, st_pref = nullptr;
   hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_ext = nullptr, ev_fe = nullptr, ev_kd = nullptr;
   hipEvent_t ev_head = nullptr, ev_pref = nullptr;  // this frame's stereo stage is done / the next frame is extracted
+  hipEvent_t ev_h2d = nullptr;                      // the prefetched images have left the pinned planes
+  bool h2d_pending = false;
   hipEvent_t ev_tab = nullptr;                      // a changed local map (second stream) is in place
   bool tab_pending = false;
   // frame pipelining (vieo_track_input.next_left / next_right): the next frame's images and what its extraction and
@@ -350,7 +352,7 @@ void vieo_tracker_destroy(vieo_tracker* t) {
   if (t->st) (void)hipStreamSynchronize(t->st);
   if (t->st_imu) (void)hipStreamSynchronize(t->st_imu), (void)hipStreamDestroy(t->st_imu);
   if (t->st_pref) (void)hipStreamSynchronize(t->st_pref), (void)hipStreamDestroy(t->st_pref);
-  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe, t->ev_kd, t->ev_head, t->ev_pref, t->ev_tab})
+  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe, t->ev_kd, t->ev_head, t->ev_pref, t->ev_tab, t->ev_h2d})
     if (e) (void)hipEventDestroy(e);
   for (uint8_t* p : {t->h_up, t->h_loc, t->h_out, t->h_next, t->h_spec})
     if (p) (void)hipHostFree(p);
@@ -472,6 +474,7 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
             hipMalloc((void**)&t->d_next, t->n_img * npx) == hipSuccess && hipMalloc((void**)&t->d_slot, slot_bytes) == hipSuccess &&
             create_prefetch_stream(&t->st_pref) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_pref, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&t->ev_h2d, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_head, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_tab, hipEventDisableTiming) == hipSuccess &&
             create_side_stream(&t->st_imu, t->st, &t->side_ratio) == hipSuccess &&
@@ -979,6 +982,9 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     // ---- the NEXT frame's Frame::Frame on the third stream, beside this frame's searches and optimisations (which are
     // queued by now): copy its images to the pinned planes (the host is otherwise about to wait), up, ExtractORB x n_img,
     // (rectified pairs: ComputeStereoMatches) into the slot the next call adopts
+    // (the previous prefetch's copy up left these planes long ago -- it was queued behind that frame's stereo stage and this
+    // host thread has waited for that frame's whole chain since --, but nothing in the stream order says so: ask)
+    if (t->h2d_pending) TRK_HIP(hipEventSynchronize(t->ev_h2d));
     for (int c = 0; c < t->n_img; c++) {
       uint8_t* dst = t->h_next + c * npx;
       if (in->stride == W)
@@ -989,6 +995,8 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     hipStream_t sp = t->st_pref;
     TRK_HIP(hipStreamWaitEvent(sp, t->ev_head, 0));
     TRK_HIP(hipMemcpyAsync(t->d_next, t->h_next, t->n_img * npx, hipMemcpyHostToDevice, sp));
+    TRK_HIP(hipEventRecord(t->ev_h2d, sp));
+    t->h2d_pending = true;
     vieo_keypoint* s_kp = (vieo_keypoint*)(t->d_slot + t->s_kp);
     uint8_t* s_desc = t->d_slot + t->s_desc;
     int32_t* s_cnt = (int32_t*)(t->d_slot + t->s_cnt);
