@@ -519,3 +519,20 @@ def test_gpu_vio_lba_sharded_stop_flag_is_collective(oracle):
     trials = [int(r[3]["lm_trials"]) for r in res]
     assert len(set(trials)) == 1 and 4 <= trials[0] < int(full[0][3]["lm_trials"]), (trials, int(full[0][3]["lm_trials"]))
     assert res[0][0].tobytes() == res[1][0].tobytes() == res[2][0].tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_lba_device_policy_parity():
+    """VIEO_LBA_DEVICE_POLICY=1: g2o's LM policy as a kernel (k_lba_policy), rounds queued blind, the host looks at the windows
+    every third round.  The switch is read once per process: the local-BA parity tests again, in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VIEO_LBA_DEVICE_POLICY="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "tests/test_lba.py::test_gpu_lba_parity",
+                        "tests/test_lba.py::test_gpu_lba_edge_cases", "tests/test_lba.py::test_gpu_lba_batch_lockstep_matches_oracle",
+                        "tests/test_lba_vio.py::test_gpu_vio_lba_parity", "tests/test_lba_vio.py::test_gpu_vio_lba_large_window_parity",
+                        "tests/test_lba_vio.py::test_gpu_vio_lba_solver_classes_parity"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]

@@ -2049,6 +2049,119 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
   if (threadIdx.x == 0) D.part_m[blockIdx.x] = sc[0];  // one partial per 64 points (k_lba_reduce)
 }
 
+// ================================================================== g2o's LM policy, per window, on the device
+// What the host loop below does between two rounds (optimization_algorithm_levenberg.cpp:61-164 + the two-stage
+// optimize() sequence of the local BAs), as a kernel: the round trip trial -> copy back -> host decision -> copy up ->
+// next launch (40 us of every ~200 us round of a single window) disappears, the host queues several rounds blind and
+// looks at the windows' state every few rounds.  The arithmetic is the host's line for line; pow() is the device
+// library's (the damping factor may differ from the host's in its last bit: far below the solve's own rounding).
+struct WinPol {
+  int stage, phase, it, iters, its1, nBad, qmax;
+  int need_build, need_restore, prelevel_pending, vio, robust0;
+  int lm_iterations, lm_trials, aborted, pad;
+  double lambda, ni, currentChi, iniChi, lastTrialChi, lambda_init, chi2_initial, chi2_final;
+};
+
+// first: only the next round's flags (the first round).  allow_begin: the round being prepared contains the kernels of a
+// stage start (classification, active sets, initial chi2, lambda); a window that needs them in a round without waits.
+__global__ void __launch_bounds__(64)
+k_lba_policy(WinPol* __restrict__ pol, WinCtl* __restrict__ ctl, const WinOut* __restrict__ out, int W, int first,
+             int allow_begin, int stop_now) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= W) return;
+  WinPol H = pol[w];
+  const int fl = first ? 0 : ctl[w].flags;
+  if (fl & LBA_TRIAL) {
+    bool run = true;
+    if (fl & LBA_BEGIN) {
+      if (out[w].np == 0) {  // no active free vertex: optimize() returns at once
+        H.phase = 2;
+        run = false;
+      } else {
+        H.lm_iterations++;
+        H.currentChi = out[w].chi0;
+        if (H.stage == 0) H.chi2_initial = H.currentChi;
+        H.iniChi = H.currentChi;
+        H.lambda = H.vio ? H.lambda_init : out[w].lambda;
+        H.ni = 2, H.nBad = 0, H.qmax = 0, H.it = 0;
+        H.phase = 1;
+      }
+    }
+    if (run) {
+      H.lm_trials++;
+      H.need_build = 0;
+      const bool ok2 = out[w].ok != 0;
+      H.lastTrialChi = out[w].chi2;
+      const double tempChi = ok2 ? out[w].chi2 : DBL_MAX;
+      double rho = H.currentChi - tempChi;
+      const double scale = (ok2 ? out[w].scale_l + out[w].scale_p : 0.0) + 1e-3;
+      rho /= scale;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow(2 * rho - 1, 3.0);
+        alpha = fmin(alpha, 2. / 3.);
+        H.lambda *= fmax(1. / 3., alpha);
+        H.ni = 2;
+        H.currentChi = tempChi;
+      } else {
+        H.lambda *= H.ni;
+        H.ni *= 2;
+        H.need_restore = 1;
+      }
+      H.qmax++;
+      H.chi2_final = H.currentChi;
+      if (!(rho < 0 && H.qmax < 10 && !stop_now)) {  // (else: the next lambda trial of the same iteration)
+        bool terminate = H.qmax == 10 || rho == 0;
+        if (!terminate) {
+          if ((H.iniChi - H.currentChi) * 1e3 < H.iniChi)
+            H.nBad++;
+          else
+            H.nBad = 0;
+          terminate = H.nBad >= 3;
+        }
+        H.it++;
+        if (terminate || H.it >= H.iters || stop_now)
+          H.phase = 2;
+        else {
+          H.lm_iterations++;
+          H.iniChi = H.currentChi;
+          H.qmax = 0;
+          H.need_build = 1;  // buildSystem at the accepted state
+        }
+      }
+    }
+  }
+  // ---- the next round
+  int f = 0;
+  double lam = H.lambda;
+  const bool starts = H.stage < 2 && (H.phase == 0 || (H.phase == 2 && H.stage == 0 && !stop_now));
+  if (starts && !allow_begin && !first) {
+    // (an optimize() would start in the round being prepared and that round has no stage-start kernels: wait a round)
+  } else {
+    if (H.stage < 2 && H.phase == 2) {  // an optimize() is over
+      if (H.need_restore) f |= LBA_RESTORE, H.need_restore = 0;
+      if (H.stage == 0 && !stop_now) {
+        f |= LBA_CLASS0;
+        H.stage = 1, H.iters = H.its1, H.phase = H.iters > 0 ? 0 : 2;
+      } else {
+        if (H.stage == 0) H.aborted = 1;  // stop flag between the two stages
+        f |= LBA_CLASS1;
+        H.stage = 2;
+      }
+    }
+    if (H.stage < 2 && H.phase == 0) {
+      f |= LBA_BEGIN | LBA_BUILD | LBA_TRIAL | ((H.stage == 0 && H.robust0) ? LBA_ROBUST : 0);
+      lam = H.vio ? H.lambda_init : -1;
+      if (H.prelevel_pending) f |= LBA_PRELEVEL, H.prelevel_pending = 0;
+    } else if (H.stage < 2 && H.phase == 1) {
+      f |= LBA_TRIAL | ((H.stage == 0 && H.robust0) ? LBA_ROBUST : 0);
+      if (H.need_build) f |= LBA_BUILD;
+      if (H.need_restore) f |= LBA_RESTORE, H.need_restore = 0;
+    }
+  }
+  ctl[w].flags = f, ctl[w].pad = 0, ctl[w].lambda = lam;
+  pol[w] = H;
+}
+
 // ================================================================== host-side lock-step LM driver
 static thread_local hipStream_t g_lba_stream = nullptr;
 static thread_local int g_lba_stream_dev = -1;  // the device the stream was created on
@@ -2899,6 +3012,136 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   auto schur_flops_of = [&](int w) {
     return win[w].skip ? 0.0 : 2.0 * (6 * devs[w].nf_cap) * (6 * devs[w].nf_cap + 1) * 3.0 * devs[w].n_mp;
   };
+  // ---- the LM policy on the device (local BAs without an exchange step): VIEO_LBA_DEVICE_POLICY=1.  Off by default: it
+  // passes the same parity tests, and it measured the SAME time as the host loop below (one window beside the tracker
+  // 5.2 vs 5.2 ms, alone 3.56 vs 3.54): what it saves between two rounds (copy back, synchronise, copy up: ~35 us) the blind
+  // round's extra kernels cost again (restore + classification + the stage-start group in the rounds where a stage may
+  // end: 6-8 launches that find nothing to do, ~4 us each).  A round is 12 dependent launches of 5-26 us; fewer, fused
+  // launches are what would shorten it.  The host loop keeps glibc's pow() in the damping update.
+  static const bool dev_policy_env = [] {
+    const char* e = getenv("VIEO_LBA_DEVICE_POLICY");
+    return e && atoi(e) != 0;
+  }();
+  const bool dev_policy = dev_policy_env && !sh && !gba && !KT.on;
+  if (dev_policy) {
+    static thread_local DevBuf g_pol;
+    static thread_local PinnedBuf g_pol_h;
+    if ((rc = g_pol.ensure((size_t)W * sizeof(WinPol))) != VIEO_OK || (rc = g_pol_h.ensure((size_t)W * (sizeof(WinPol) + sizeof(WinCtl)))) != VIEO_OK)
+      return rc;
+    WinPol* hp = (WinPol*)g_pol_h.p;
+    WinCtl* hc = (WinCtl*)(hp + W);
+    WinPol* dP = g_pol.as<WinPol>();
+    int min_first_stage_rounds = 1 << 30;
+    for (int w = 0; w < W; w++) {
+      const WinHost& H = win[w];
+      WinPol& Q = hp[w];
+      memset(&Q, 0, sizeof(Q));
+      Q.stage = H.stage, Q.phase = H.phase, Q.iters = H.iters, Q.its1 = H.P->its1, Q.prelevel_pending = H.prelevel_pending ? 1 : 0;
+      Q.vio = vio ? 1 : 0, Q.robust0 = 1, Q.lambda = H.lambda, Q.ni = 2;
+      Q.lambda_init = vio ? H.VP->lambda_init : 0.0;
+      if (!H.skip) min_first_stage_rounds = std::min(min_first_stage_rounds, std::max(1, std::min(H.iters, 3)));
+    }
+    VIEO_HIP_CHECK(hipMemcpyAsync(dP, hp, (size_t)W * sizeof(WinPol), hipMemcpyHostToDevice, st));
+    // One round = the superset of what a window can ask for at that point: the kernels read the windows' flags and leave at
+    // once where they have nothing to do.  The stage-start kernels (classification, active sets, initial chi2, lambda) are
+    // in round 1 and in every round from the first one in which an optimize() can end (three iterations, or its0 of them)
+    // until the host has seen every window inside its second optimize(); the policy kernel is told whether the round it
+    // prepares has them and lets a window that needs them wait a round otherwise.  The classification kernel alone (final
+    // erase flags) is in every round.
+    auto begin_allowed = [&](int round, bool all_in_second) { return round == 1 || (!all_in_second && round > min_first_stage_rounds); };
+    auto launch_round = [&](int round, bool with_begin) -> int {
+      hipLaunchKernelGGL(k_lba_restore, dim3(gr, W), dim3(256), 0, st, dD, dC);
+      hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC);
+      if (round == 1 && vio)
+        for (int ph = 0; ph < 3; ph++) hipLaunchKernelGGL(k_lba_prelevel, dim3(ge, W), dim3(256), 0, st, dD, dC, ph);
+      if (with_begin) {
+        hipLaunchKernelGGL(k_lba_zero, dim3(64, W), dim3(256), 0, st, dD, dC);
+        hipLaunchKernelGGL(k_lba_begin, dim3(W), dim3(1024), 0, st, dD, dC, dO);
+        hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 0);
+      }
+      auto build2 = [&](auto mc, auto sc) {  // point half, key-frame half
+        constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
+        hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC);
+        hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(std::max(1, max_nf), W), dim3(256), 0, st, dD, dC);
+      };
+      if (any_multicam)
+        build2(std::true_type(), std::false_type());
+      else
+        build2(std::false_type(), std::false_type());
+      if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0);
+      if (with_begin) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_schur<false>, dim3(std::max(1, schur_grid), W), dim3(256), 0, st, dD, dC, dO);
+      if (schur_grid_off > 0) hipLaunchKernelGGL(k_lba_schur<true>, dim3(schur_grid_off, W), dim3(256), 0, st, dD, dC, dO);
+      for (int c = 0; c < 3; c++) {
+        const int nw = cls_first[c + 1] - cls_first[c];
+        if (nw <= 0) continue;
+        const unsigned gx = (unsigned)(((size_t)cls_max[c] * cls_max[c] + 255) / 256);
+        hipLaunchKernelGGL(k_lba_assemble, dim3(gx, nw), dim3(256), 0, st, dD, dC, dO, dWins + cls_first[c]);
+      }
+      if (big && cls_first[3] > cls_first[2]) {
+        const int nbm = (n_max_b + 1 + kNB - 1) / kNB * kNB, ntm = nbm / kNB;
+        hipLaunchKernelGGL(k_big_init, dim3((unsigned)(((size_t)nbm * nbm + 255) / 256), W), dim3(256), 0, st, dD, dC);
+        for (int k = 0; k < ntm; k++) {
+          const int below = nbm - (k + 1) * kNB, m = ntm - k - 1;
+          hipLaunchKernelGGL(k_big_panel, dim3(1 + (below + 255) / 256, W), dim3(256), 0, st, dD, dC, k);
+          if (m > 0) hipLaunchKernelGGL(k_big_syrk, dim3(m * (m + 1) / 2, W), dim3(256), 0, st, dD, dC, k);
+        }
+        for (int sb = 0; sb < (n_max_b + kNB - 1) / kNB; sb++)
+          hipLaunchKernelGGL(k_big_back_step, dim3(1 + (n_max_b + 255) / 256, W), dim3(256), 0, st, dD, dC, sb);
+        hipLaunchKernelGGL(k_big_finish, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      }
+      if (ldlt16 && cls_first[1] > cls_first[0])
+        hipLaunchKernelGGL(k_lba_ldlt16<kLd16Threads>, dim3(W), dim3(kLd16Threads), ld16_lds_bytes(nb16), st, dD, dC, dO, nb16);
+      if (panels && cls_first[2] > cls_first[1])
+        hipLaunchKernelGGL(k_lba_ldltg<kLdGThreads>, dim3(W), dim3(kLdGThreads), ldg_lds_bytes(nbg), st, dD, dC, dO, nbg);
+      hipLaunchKernelGGL(k_lba_update_points, dim3(gq, W), dim3(256), 0, st, dD, dC, dO);
+      hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
+      if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
+      hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      VIEO_HIP_CHECK(hipGetLastError());
+      return VIEO_OK;
+    };
+    const unsigned pg = (unsigned)((W + 63) / 64);
+    int round = 1;
+    bool all_in_second = false, with_begin = true;  // with_begin: what the policy kernel was told about the round it prepared
+    hipLaunchKernelGGL(k_lba_policy, dim3(pg), dim3(64), 0, st, dP, dC, dO, W, 1, 1, (stop && *stop) ? 1 : 0);
+    constexpr int kBlindRounds = 3;
+    for (bool done = false; !done;) {
+      for (int k = 0; k < kBlindRounds; k++, round++) {
+        if ((rc = launch_round(round, with_begin)) != VIEO_OK) return rc;
+        with_begin = begin_allowed(round + 1, all_in_second);
+        hipLaunchKernelGGL(k_lba_policy, dim3(pg), dim3(64), 0, st, dP, dC, dO, W, 0, with_begin ? 1 : 0, (stop && *stop) ? 1 : 0);
+        n_rounds++;
+      }
+      VIEO_HIP_CHECK(hipMemcpyAsync(hp, dP, (size_t)W * sizeof(WinPol), hipMemcpyDeviceToHost, st));
+      VIEO_HIP_CHECK(hipMemcpyAsync(hc, dC, (size_t)W * sizeof(WinCtl), hipMemcpyDeviceToHost, st));
+      {
+        const auto t_w = std::chrono::steady_clock::now();
+        VIEO_HIP_CHECK(hipStreamSynchronize(st));
+        ms_wait += ms_since(t_w);
+      }
+      done = true, all_in_second = true;
+      for (int w = 0; w < W; w++) {
+        if (win[w].skip) continue;
+        if (hp[w].stage < 2 || hc[w].flags != 0) done = false;
+        if (hp[w].stage == 0 || (hp[w].stage == 1 && hp[w].phase != 1)) all_in_second = false;
+      }
+      if (round > 4000) {
+        set_error("local BA: the device policy did not finish in %d rounds", round);
+        return VIEO_E_HIP;
+      }
+    }
+    for (int w = 0; w < W; w++) {
+      WinHost& H = win[w];
+      if (H.skip) continue;
+      const WinPol& Q = hp[w];
+      H.R->lm_iterations += Q.lm_iterations, H.R->lm_trials += Q.lm_trials;
+      H.R->chi2_initial = Q.chi2_initial, H.R->chi2_final = Q.chi2_final;
+      H.lastTrialChi = Q.lastTrialChi;
+      if (Q.aborted) H.R->status = VIEO_LBA_ABORTED;
+      H.stage = 2;
+    }
+  } else
   for (;;) {
     n_rounds++;
     const bool stop_now = sh ? shard_stop : (stop && *stop);
