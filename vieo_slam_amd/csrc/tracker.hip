@@ -20,7 +20,6 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
-#include <functional>
 #include <vector>
 
 #include "imu_device.h"
@@ -641,11 +640,14 @@ static int track_project(vieo_tracker* t, hipStream_t s) {
                                                   d_q1, s);
 }
 
+}  // extern "C" (a template cannot have C linkage)
+
 // projected: the first search's queries are there already (the prediction, the projection of the last frame's points and,
 // for rigs, their compaction ran on the second stream beside the extraction); false for the repeat with the wider window
 // side_rest: what the caller still has to hand to the second stream (recorded into ev_tab / ev_kd / ev_fe there); called
 // behind the first optimisation's launch
-static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, const std::function<int()>* side_rest = nullptr) {
+template <class SideRest>
+static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, SideRest&& side_rest) {
   const vieo_tracker_params& P = t->P;
   const int kc = t->kc, nc = t->nc;
   hipStream_t st = t->st;
@@ -717,7 +719,7 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, const
   TRK(build_obs(f1));
   TRK(pose(f1, r1));
   // a changed local map travels on the second stream; nothing before this line reads it
-  if (side_rest) TRK((*side_rest)());
+  TRK(side_rest());
   if (t->tab_pending) {
     if (hipStreamWaitEvent(st, t->ev_tab, 0) != hipSuccess) return VIEO_E_HIP;
     t->tab_pending = false;
@@ -744,6 +746,8 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, const
   if (nc_local > 0) VIEO_HIP_CHECK(hipMemcpyAsync(t->h_out + t->q_cdep, d_dep + kc, (size_t)nc_local * 4, hipMemcpyDeviceToHost, st));
   return VIEO_OK;
 }
+
+extern "C" {
 
 // an error in the middle of the chain: work queued on the two streams still reads the pinned blocks, which the next
 // call would overwrite -- wait for it before handing the error back
@@ -936,7 +940,7 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   // it over AFTER that kernel's launch.  (Once the frame was extracted ahead the host's launches are the head of the
   // critical path: twenty runtime calls at 2-5 us each used to stand between k_track_adopt and the first search kernel;
   // the first optimisation's 0.25 ms is where the host gets ahead again.)
-  const std::function<int()> side_rest = [&]() -> int {
+  const auto side_rest = [&]() -> int {
     if (new_local) {
       TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cpt, t->h_loc + t->l_cpt, (size_t)nc * sizeof(vieo_frustum_point), hipMemcpyHostToDevice, t->st_imu));
       TRK_HIP(hipMemcpyAsync(t->d_loc + t->l_cdesc, t->h_loc + t->l_cdesc, (size_t)nc * 32, hipMemcpyHostToDevice, t->st_imu));
@@ -975,7 +979,7 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     return VIEO_OK;
   };
   TRK_HIP(hipStreamWaitEvent(st, t->ev_imu, 0));  // the prediction and the first search's queries (second stream)
-  if ((rc = track_chain_tail(t, nc, true, &side_rest)) != VIEO_OK) return track_fail(t, rc);
+  if ((rc = track_chain_tail(t, nc, true, side_rest)) != VIEO_OK) return track_fail(t, rc);
   TRK_HIP(hipStreamWaitEvent(st, t->ev_kd, 0));  // (the keys' / descriptors' copies)
   TRK_HIP(hipEventRecord(t->ev_t1, st));
   if (n_next) {
@@ -1024,7 +1028,7 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     widened = 1;
     const float th2 = 2 * P.th_last;
     TRK_HIP(hipMemcpyAsync(&dH->cam.th, &th2, 4, hipMemcpyHostToDevice, st));
-    if ((rc = track_chain_tail(t, nc, false)) != VIEO_OK) return track_fail(t, rc);
+    if ((rc = track_chain_tail(t, nc, false, [] { return (int)VIEO_OK; })) != VIEO_OK) return track_fail(t, rc);
     TRK_HIP(hipEventRecord(t->ev_t1, st));
     TRK_HIP(hipStreamSynchronize(st));
   }
@@ -1032,7 +1036,7 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     // a replica of one of the two optimisations never became resident (vieo_pose_set_replicas in include/vieo_hot.h: the
     // device is shared with other work): the tail again with one workgroup per optimisation -- the frame is late, not lost
     const int was = vieo_pose_set_replicas(0);
-    rc = track_chain_tail(t, nc, false);
+    rc = track_chain_tail(t, nc, false, [] { return (int)VIEO_OK; });
     (void)vieo_pose_set_replicas(was);
     if (rc != VIEO_OK) return track_fail(t, rc);
     TRK_HIP(hipEventRecord(t->ev_t1, st));
