@@ -213,6 +213,11 @@ struct ReplayBase {
       f.twc[r] = f.nav.p[r] + (Rwb[r * 3] * S.Tbc[3] + Rwb[r * 3 + 1] * S.Tbc[7] + Rwb[r * 3 + 2] * S.Tbc[11]);
     }
   }
+  void centre_of(const vieo_navstate& nav, double* twc) const {  // (pose_of's translation, for a state not written back yet)
+    double Rwb[9];
+    quat_to_R(nav.q, Rwb);
+    for (int r = 0; r < 3; r++) twc[r] = nav.p[r] + (Rwb[r * 3] * S.Tbc[3] + Rwb[r * 3 + 1] * S.Tbc[7] + Rwb[r * 3 + 2] * S.Tbc[11]);
+  }
 
   // Frame::Frame of the first frame: the two extractions and ComputeStereoMatches through the stage entries
   FramePtr make_frame0() {
@@ -315,6 +320,11 @@ struct ReplayBase {
     std::vector<float> X, Xo;
     std::vector<uint8_t> close, erase;
     std::vector<vieo_navstate> navs;
+    // LocalMapping's work around the solve, on its thread: the window is flattened there (deferred) and
+    // MapPoint::UpdateNormalAndDepth of its points is computed there from the results; the write-back only copies
+    bool deferred = false;
+    std::vector<long> nd_ids;
+    std::vector<float> nd_nrm, nd_mx, nd_mn;
     vieo_lba_result res;
     double ms = 0;
     int rc = 0;
@@ -328,7 +338,12 @@ struct ReplayBase {
   };
   std::unique_ptr<LbaJob> lba_build() {
     std::unique_ptr<LbaJob> Jp(new LbaJob());
-    LbaJob& J = *Jp;
+    lba_build_into(*Jp);
+    return Jp;
+  }
+  // (reads the map: on the LocalMapping thread only between a key frame's insertion and its write-back, when the tracking
+  // thread does not write to it)
+  void lba_build_into(LbaJob& J) {
     const int nk = (int)kfs.size(), first = std::max(0, nk - n_local);
     std::vector<int>& local = J.local;
     for (int k = first; k < nk; k++) local.push_back(k);
@@ -398,7 +413,49 @@ struct ReplayBase {
     for (const vieo_lba_keyframe& k : K) n_fixed += k.fixed != 0;
     win_kfs += (long)K.size(), win_fixed += n_fixed, win_points += (long)pts.size(), win_obs += (long)J.obs.size();
     win_max_kfs = std::max(win_max_kfs, (int)K.size()), win_max_fixed = std::max(win_max_fixed, n_fixed);
-    return Jp;
+  }
+  // MapPoint::UpdateNormalAndDepth of the window's points from the solve's results, before they are written back: the
+  // observations that survive the erase flags (a point's rows are contiguous, key frames ascending like the map's
+  // std::map), the key frames' centres with the optimised states in place
+  void lba_post(LbaJob& J) {
+    J.nd_ids.clear();
+    if (J.rc != 0 || J.res.status != 0) return;
+    std::vector<float> centres(kfs.size() * 3);
+    for (size_t k = 0; k < kfs.size(); k++)
+      for (int r = 0; r < 3; r++) centres[3 * k + r] = (float)kfs[k]->twc[r];
+    for (size_t i = 0; i < J.local.size(); i++)
+      if (!J.K[i].fixed) {
+        double twc[3];
+        centre_of(J.navs[i], twc);
+        for (int r = 0; r < 3; r++) centres[3 * J.local[i] + r] = (float)twc[r];
+      }
+    std::vector<int32_t> first(1, 0), obs_centre, ref;
+    std::vector<float> pts, ref_scale;
+    for (size_t r0 = 0; r0 < J.obs.size();) {
+      const int j = J.obs[r0].mp;
+      size_t r1 = r0;
+      const size_t before = obs_centre.size();
+      int ref_row = -1;
+      for (; r1 < J.obs.size() && J.obs[r1].mp == j; r1++)
+        if (!J.erase[r1]) {
+          if (ref_row < 0) ref_row = (int)r1;
+          obs_centre.push_back(J.rows[r1].kid);
+        }
+      r0 = r1;
+      if (obs_centre.size() == before) continue;  // every observation erased: the point goes bad at the write-back
+      J.nd_ids.push_back(J.pts[j]);
+      first.push_back((int32_t)obs_centre.size());
+      ref.push_back(J.rows[ref_row].kid);
+      ref_scale.push_back(scale[kfs[J.rows[ref_row].kid]->keys[J.rows[ref_row].key].octave]);
+      for (int r = 0; r < 3; r++) pts.push_back(J.Xo[3 * j + r]);
+    }
+    const size_t n = J.nd_ids.size();
+    if (n == 0) return;
+    J.nd_nrm.resize(n * 3), J.nd_mx.resize(n), J.nd_mn.resize(n);
+    const int rc = vieo_update_normal_and_depth_batch(pts.data(), first.data(), obs_centre.data(), centres.data(), (int)kfs.size(), ref.data(),
+                                                      ref_scale.data(), scale[NLEVELS - 1], (int)n, J.nd_nrm.data(), J.nd_mx.data(),
+                                                      J.nd_mn.data());
+    if (rc != 0) J.rc = rc;
   }
   static void lba_solve(LbaJob* J) {  // (any host thread)
     const auto t0 = std::chrono::steady_clock::now();
@@ -439,11 +496,16 @@ struct ReplayBase {
       }
     for (size_t j = 0; j < J.pts.size(); j++)
       for (int r = 0; r < 3; r++) mp_X[3 * J.pts[j] + r] = J.Xo[3 * j + r];
-    update_normal_depth(J.pts);
+    for (size_t j = 0; j < J.nd_ids.size(); j++) {  // (lba_post computed them on the LocalMapping thread)
+      const long m = J.nd_ids[j];
+      for (int r = 0; r < 3; r++) mp_normal[3 * m + r] = J.nd_nrm[3 * j + r];
+      mp_maxd[m] = J.nd_mx[j], mp_mind[m] = J.nd_mn[j];
+    }
   }
   void local_ba() {  // inline: LocalMapping before the next frame
     std::unique_ptr<LbaJob> J = lba_build();
     lba_solve(J.get());
+    lba_post(*J);
     n_lba++;
     lba_apply(*J);
   }
@@ -456,7 +518,9 @@ struct ReplayBase {
         if (lba_quit) return;
         J = lba_todo, lba_todo = nullptr;
       }
+      if (J->deferred) lba_build_into(*J);
       lba_solve(J);
+      lba_post(*J);
       {
         std::lock_guard<std::mutex> g(lba_m);
         lba_busy = false;
@@ -548,7 +612,8 @@ struct ReplayBase {
         std::memset(&placeholder, 0, sizeof(placeholder));
         insert_keyframe(f, f->nav, &placeholder);
         before_frame(k + lba_lag + kf_every);  // (a job still pending is applied first)
-        job = lba_build();
+        job.reset(new LbaJob());
+        job->deferred = true;  // (flattened on the LocalMapping thread: nothing writes to the map until the write-back)
         job->need_edge = true, job->edge_kf = (int)kfs.size() - 1;
         job->samples.assign(S.imu.begin() + i0, S.imu.begin() + i0 + ni);
         job->noise = S.noise, job->ti = kp_t, job->tj = t;
