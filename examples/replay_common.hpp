@@ -510,6 +510,7 @@ struct ReplayBase {
     lba_apply(*J);
   }
   void lba_worker() {
+    CHECK(vieo_lba_set_stream_priority(0));  // one window beside the tracker: not behind everything else on the device
     for (;;) {
       LbaJob* J;
       {

@@ -676,6 +676,12 @@ int vieo_local_bundle_adjustment(const vieo_lba_params* params, const vieo_lba_k
                                  vieo_navstate* h_navs_out, float* h_points_out, uint8_t* h_erase,
                                  vieo_lba_result* h_result);
 
+/* Priority of the calling host thread's bundle-adjustment stream from its next call on: -1 lowest (the default, or
+ * VIEO_LBA_PRIORITY: batches of windows beside a batched front end fill what it leaves free), 0 default priority (one
+ * window beside a tracker: the LocalMapping thread of a sequential host -- examples/replay_common.hpp -- asks for this;
+ * 1.03 against 1.08 ms per frame), 1 highest. */
+int vieo_lba_set_stream_priority(int priority);
+
 /* Several independent windows (one per map / per LocalMapping thread of a multi-session server)
  * advanced in lock step: every kernel launch covers all windows and the host reads one small
  * record per window and LM trial.  Each array argument has n_windows entries; per-window results

@@ -138,6 +138,7 @@ _SIGS = {
     "vieo_local_bundle_adjustment_vio_batch": (c_i, [c_i] + [c_p] * 15),
     "vieo_lba_sharded_buffer_doubles": (ctypes.c_size_t, [c_i, c_p]),
     "vieo_lba_enable_timing": (None, [c_i]),
+    "vieo_lba_set_stream_priority": (c_i, [c_i]),
     "vieo_lba_kernel_classes": (c_i, []),
     "vieo_lba_kernel_class_name": (ctypes.c_char_p, [c_i]),
     "vieo_lba_kernel_times": (None, [c_p, c_p, c_p]),

@@ -2165,6 +2165,7 @@ k_lba_policy(WinPol* __restrict__ pol, WinCtl* __restrict__ ctl, const WinOut* _
 // ================================================================== host-side lock-step LM driver
 static thread_local hipStream_t g_lba_stream = nullptr;
 static thread_local int g_lba_stream_dev = -1;  // the device the stream was created on
+static thread_local int g_lba_priority = -2;    // vieo_lba_set_stream_priority of this host thread (-2: VIEO_LBA_PRIORITY / -1)
 static thread_local DevBuf g_arena, g_small;
 static thread_local PinnedBuf g_stage, g_small_h;
 
@@ -2503,9 +2504,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     // highest 48.9 k frames/s with k_fast at 9.3 ms per launch and 0.17 ms per window; default 50.1 k / 7.6 / 0.79;
     // lowest 53.0 k / 7.7 (what k_fast takes alone) / 0.73 -- the windows' kernels are short and many and fill what the
     // front end leaves free instead of taking CUs from it.
+    // One window beside a tracker is the other case: the sequential replay measured 1.03 ms per frame with the stream at
+    // the DEFAULT priority against 1.08 at the lowest and 1.07 at the highest (the solve finishes sooner and the tracker
+    // waits less for its write-back): the LocalMapping thread of such a host asks for it with vieo_lba_set_stream_priority(0).
     int lo = 0, hi = 0;
     const char* e = getenv("VIEO_LBA_PRIORITY");
-    const int want = e ? atoi(e) : -1;
+    const int want = g_lba_priority != -2 ? g_lba_priority : (e ? atoi(e) : -1);
     const char* cm = getenv("VIEO_LBA_CU_MASK");  // experiment: "first,count" -> the engine's stream on those CUs only
     int cu_first = 0, cu_count = 0;
     if (cm && sscanf(cm, "%d,%d", &cu_first, &cu_count) == 2 && cu_count > 0) {
@@ -3380,6 +3384,17 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
 using namespace vieo;
 
 extern "C" {
+
+int vieo_lba_set_stream_priority(int priority) {
+  if (priority < -1 || priority > 1) return VIEO_E_INVALID;
+  if (priority != g_lba_priority && g_lba_stream) {  // the next call creates the stream again
+    (void)hipStreamSynchronize(g_lba_stream);
+    (void)hipStreamDestroy(g_lba_stream);
+    g_lba_stream = nullptr;
+  }
+  g_lba_priority = priority;
+  return VIEO_OK;
+}
 
 int vieo_local_bundle_adjustment_batch(int n_windows, const vieo_lba_params* const* params,
                                        const vieo_lba_keyframe* const* h_kfs, const int* n_kf,
