@@ -222,6 +222,7 @@ struct vieo_tracker {
   hipStream_t st = nullptr, st_imu = nullptr, st_pref = nullptr;
   hipEvent_t ev_up = nullptr, ev_imu = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_ext = nullptr, ev_fe = nullptr, ev_kd = nullptr;
   hipEvent_t ev_head = nullptr, ev_pref = nullptr;  // this frame's stereo stage is done / the next frame is extracted
+  hipEvent_t ev_spec = nullptr;                     // the pre-integration run ahead (second stream) is done
   hipEvent_t ev_h2d = nullptr;                      // the prefetched images have left the pinned planes
   bool h2d_pending = false;
   hipEvent_t ev_tab = nullptr;                      // a changed local map (second stream) is in place
@@ -351,7 +352,7 @@ void vieo_tracker_destroy(vieo_tracker* t) {
   if (t->st) (void)hipStreamSynchronize(t->st);
   if (t->st_imu) (void)hipStreamSynchronize(t->st_imu), (void)hipStreamDestroy(t->st_imu);
   if (t->st_pref) (void)hipStreamSynchronize(t->st_pref), (void)hipStreamDestroy(t->st_pref);
-  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe, t->ev_kd, t->ev_head, t->ev_pref, t->ev_tab, t->ev_h2d})
+  for (hipEvent_t e : {t->ev_up, t->ev_imu, t->ev_t0, t->ev_t1, t->ev_ext, t->ev_fe, t->ev_kd, t->ev_head, t->ev_pref, t->ev_tab, t->ev_h2d, t->ev_spec})
     if (e) (void)hipEventDestroy(e);
   for (uint8_t* p : {t->h_up, t->h_loc, t->h_out, t->h_next, t->h_spec})
     if (p) (void)hipHostFree(p);
@@ -474,6 +475,7 @@ int vieo_tracker_create_rig(vieo_tracker** out, const vieo_tracker_params* P, co
             create_prefetch_stream(&t->st_pref) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_pref, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_h2d, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&t->ev_spec, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_head, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t->ev_tab, hipEventDisableTiming) == hipSuccess &&
             create_side_stream(&t->st_imu, t->st, &t->side_ratio) == hipSuccess &&
@@ -886,6 +888,9 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   // launches: those are the head of the critical path (the host spends 20-30 us on the second stream's five to eight
   // launches, and the first pyramid level used to wait for them).
   const TrkTables tables{(const float*)(t->d_up + t->o_xyz), (const float*)(t->d_up + t->o_dep), (float*)(Wk + t->w_xyz), (float*)(Wk + t->w_dep)};
+  // (a frame extracted ahead: there is no extraction to run beside, the prediction and the projection are the next links of
+  // the chain itself -- on this stream, without the two event hops to the second one and back: ~12 us)
+  const hipStream_t s_head = pref ? st : t->st_imu;
   if (!t->vision) {
     // the pre-integration beside the extraction -- or, run ahead by the previous call (next_imu), if what that call
     // integrated is bit for bit what this call asks for
@@ -896,23 +901,24 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     const uint8_t* pre_at = ahead ? t->d_spec + t->sp_pre : Wk + t->w_pre;
     const uint8_t* prv_at = ahead ? t->d_spec + t->sp_prv : Wk + t->w_prv;
     const uint8_t* pst_at = ahead ? t->d_spec + t->sp_pst : Wk + t->w_pst;
-    TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
-    if (ahead)
+    if (!pref) TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
+    if (ahead) {
       t->spec_used++;
-    else if ((rc = vieo_imu_preintegrate_batch_device(&dH->noise, (const vieo_imu_sample*)(t->d_up + t->o_imu), dH->first, &dH->ti,
-                                                      &dH->tj, dH->bg, dH->ba, 1, (vieo_imu_preint*)(Wk + t->w_pre),
-                                                      (double*)(Wk + t->w_prv), (int32_t*)(Wk + t->w_pst), t->st_imu)) != VIEO_OK)
+      if (pref) TRK_HIP(hipStreamWaitEvent(st, t->ev_spec, 0));  // (it ran on the second stream)
+    } else if ((rc = vieo_imu_preintegrate_batch_device(&dH->noise, (const vieo_imu_sample*)(t->d_up + t->o_imu), dH->first, &dH->ti,
+                                                        &dH->tj, dH->bg, dH->ba, 1, (vieo_imu_preint*)(Wk + t->w_pre),
+                                                        (double*)(Wk + t->w_prv), (int32_t*)(Wk + t->w_pst), s_head)) != VIEO_OK)
       return track_fail(t, rc);
-    hipLaunchKernelGGL(k_track_predict, dim3(1 + kTableBlocks), dim3(64), 0, t->st_imu, dH, dO, (const vieo_imu_preint*)pre_at,
+    hipLaunchKernelGGL(k_track_predict, dim3(1 + kTableBlocks), dim3(64), 0, s_head, dH, dO, (const vieo_imu_preint*)pre_at,
                        (const double*)prv_at, (const int32_t*)pst_at, (double*)(t->d_spec + t->sp_bias), tables);
   } else {
-    TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
-    hipLaunchKernelGGL(k_track_set_pose, dim3(1 + kTableBlocks), dim3(64), 0, t->st_imu, dH, dO, tables);
+    if (!pref) TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
+    hipLaunchKernelGGL(k_track_set_pose, dim3(1 + kTableBlocks), dim3(64), 0, s_head, dH, dO, tables);
   }
   // PredictNavStateByIMU and the projection of the last frame's points need nothing of the new images: beside the extraction
   TRK_HIP(hipGetLastError());
-  if ((rc = track_project(t, t->st_imu)) != VIEO_OK) return track_fail(t, rc);
-  TRK_HIP(hipEventRecord(t->ev_imu, t->st_imu));  // the prediction and the first search's queries: what the search waits for
+  if ((rc = track_project(t, s_head)) != VIEO_OK) return track_fail(t, rc);
+  if (!pref) TRK_HIP(hipEventRecord(t->ev_imu, t->st_imu));  // the prediction and the first search's queries: what the search waits for
   // ComputeStereoFishEyeMatches (Frame.cc:613-779) into mvKeys order: keys / descriptors in the work block, the tables in
   // the download block.
   // What tracking reads of it -- the concatenated keys and descriptors, the cameras' ranges, uright = -1 -- does not
@@ -973,12 +979,13 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
                                                             &dS->ti, &dS->tj, bias, bias + 3, 1, (vieo_imu_preint*)(t->d_spec + t->sp_pre),
                                                             (double*)(t->d_spec + t->sp_prv), (int32_t*)(t->d_spec + t->sp_pst), t->st_imu);
       if (rc_pre != VIEO_OK) return rc_pre;
+      TRK_HIP(hipEventRecord(t->ev_spec, t->st_imu));
       t->spec_samples.assign(in->next_imu, in->next_imu + in->next_n_imu);
       t->spec_n = in->next_n_imu, t->spec_ti = in->t_cur, t->spec_tj = in->next_t_cur;
     }
     return VIEO_OK;
   };
-  TRK_HIP(hipStreamWaitEvent(st, t->ev_imu, 0));  // the prediction and the first search's queries (second stream)
+  if (!pref) TRK_HIP(hipStreamWaitEvent(st, t->ev_imu, 0));  // the prediction and the first search's queries (second stream)
   if ((rc = track_chain_tail(t, nc, true, side_rest)) != VIEO_OK) return track_fail(t, rc);
   TRK_HIP(hipStreamWaitEvent(st, t->ev_kd, 0));  // (the keys' / descriptors' copies)
   TRK_HIP(hipEventRecord(t->ev_t1, st));
