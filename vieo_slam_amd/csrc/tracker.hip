@@ -904,7 +904,8 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     if (!pref) TRK_HIP(hipStreamWaitEvent(t->st_imu, t->ev_up, 0));
     if (ahead) {
       t->spec_used++;
-      if (pref) TRK_HIP(hipStreamWaitEvent(st, t->ev_spec, 0));  // (it ran on the second stream)
+      // (it ran on the second stream -- which vieo_tracker_reprobe may have replaced since: wait for it by its event either way)
+      TRK_HIP(hipStreamWaitEvent(s_head, t->ev_spec, 0));
     } else if ((rc = vieo_imu_preintegrate_batch_device(&dH->noise, (const vieo_imu_sample*)(t->d_up + t->o_imu), dH->first, &dH->ti,
                                                         &dH->tj, dH->bg, dH->ba, 1, (vieo_imu_preint*)(Wk + t->w_pre),
                                                         (double*)(Wk + t->w_prv), (int32_t*)(Wk + t->w_pst), s_head)) != VIEO_OK)
