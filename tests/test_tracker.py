@@ -324,6 +324,12 @@ def test_gpu_tracker_frame_pipelining_is_bit_identical(tmp_path):
     sb = Rb.trk.stats()
     assert sb["frames_prefetched"] == n - 2 and 0 < sb["preints_ahead_used"] <= n - 2
     assert Ra.trk.stats()["preints_ahead_used"] == 0
+    # the pre-integration alone run ahead (next_imu without next images): same bytes again
+    Rd = TrackerReplay(seq, replay.HipStages(), preint_ahead=True)
+    td = Rd.run(n)
+    sd = Rd.trk.stats()
+    assert td.tobytes() == ta.tobytes() and sd["frames_prefetched"] == 0 and sd["preints_ahead_used"] > 0
+    Rd.close()
     # a pending prefetch is discarded by a call that brings its own images; use_prefetched without one is an error
     Rb2 = TrackerReplay(seq, replay.HipStages(), prefetch=True)
     Rb2.initialise()

@@ -243,8 +243,9 @@ class Tracker:
 class TrackerReplay(rp.Replay):
     """The sequential replay with every frame's tracking as ONE vieo_track_frame call."""
 
-    def __init__(self, seq, stages, max_local_points=16384, prefetch=False, **kw):
+    def __init__(self, seq, stages, max_local_points=16384, prefetch=False, preint_ahead=False, **kw):
         super().__init__(seq, stages, **kw)
+        self.preint_ahead = bool(preint_ahead)  # next_imu without next images (the run-ahead pre-integration alone)
         self.trk = Tracker(euroc_params(max_local_points, self.th_last, self.th_local, seq.noise[0]))
         self._lv = 0
         # frame pipelining: frame k + 1's images go along with frame k's call (vieo_track_input.next_left / next_right)
@@ -302,7 +303,7 @@ class TrackerReplay(rp.Replay):
         nxt = self.seq.images(k + 1) if (self.prefetch and k + 1 < self._n_run) else None
         self._prefetched = nxt is not None
         nxt_imu = None
-        if nxt is not None:
+        if nxt is not None or (self.preint_ahead and k + 1 < self._n_run):
             t_next = self.seq.time(k + 1)
             nxt_imu = (self.seq.imu_between(t, t_next), t_next)
         o, v = self.trk.track(Li, Ri, self.seq.imu_between(t_ref, t), t_ref, t, ref_nav, last.nav, prior, pts,
