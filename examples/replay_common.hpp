@@ -510,7 +510,9 @@ struct ReplayBase {
     lba_apply(*J);
   }
   void lba_worker() {
-    CHECK(vieo_lba_set_stream_priority(0));  // one window beside the tracker: not behind everything else on the device
+    // one window beside the tracker: not behind everything else on the device (VIEO_REPLAY_LBA_PRIORITY=-1 / 1: A/B runs)
+    const char* pe = std::getenv("VIEO_REPLAY_LBA_PRIORITY");
+    CHECK(vieo_lba_set_stream_priority(pe ? std::atoi(pe) : 0));
     for (;;) {
       LbaJob* J;
       {

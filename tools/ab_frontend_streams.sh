@@ -1,4 +1,5 @@
 #!/bin/bash
+# the batched bench step with the front end on 1 / 2 / 4 streams (with and without the local BA)
 cd "$(dirname "$0")/.."
 q() { python -c "
 import json,sys

@@ -1,4 +1,5 @@
 #!/bin/bash
+# the batched bench step with the bundle-adjustment streams at the lowest / default / highest priority x 2 / 4 / 8 issuing threads
 cd "$(dirname "$0")/.."
 q() { python -c "
 import json,sys

@@ -1,4 +1,5 @@
 #!/bin/bash
+# frame pipelining with the prefetch stream at normal / low / high priority (VIEO_PREFETCH_PRIORITY) + a kernel timeline
 cd "$(dirname "$0")/.."
 python tools/write_sequence.py /tmp/seq.vseq --frames 200 > /dev/null
 q() { python -c "

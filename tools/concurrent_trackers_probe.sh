@@ -1,4 +1,5 @@
 #!/bin/bash
+# N concurrent trackers on one GPU (examples/replay_main --trackers N)
 cd "$(dirname "$0")/.."
 python tools/write_sequence.py /tmp/seq.vseq --frames 60 > /dev/null
 q() { python -c "

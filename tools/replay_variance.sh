@@ -1,4 +1,5 @@
 #!/bin/bash
+# run-to-run spread of the sequential replay (six runs per write-back lag) with the caller's own time per frame
 cd "$(dirname "$0")/.."
 python tools/write_sequence.py /tmp/seq.vseq --frames 400 > /dev/null
 for lag in 8 9; do for rep in 1 2 3 4 5 6; do timeout 120 ./examples/replay_main /tmp/seq.vseq --warmup 16 --quiet --lba-lag $lag --prefetch 1 | python -c "
