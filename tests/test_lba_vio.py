@@ -536,3 +536,20 @@ def test_gpu_lba_device_policy_parity():
                         "tests/test_lba_vio.py::test_gpu_vio_lba_solver_classes_parity"],
                        cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+@pytest.mark.gpu
+def test_gpu_lba_stream_priority_changes_nothing_but_the_stream():
+    """vieo_lba_set_stream_priority: -1 / 0 / 1 are accepted (anything else is VIEO_E_INVALID), the calling thread's stream is
+    made again at the next call, and the solve returns the same bytes whatever its stream's priority."""
+    from vieo_slam_amd._lib import lib
+    from vieo_slam_amd.optimizer import Optimizer
+    L = lib()
+    win = synth_ba.make_lba_vio_problem(31, n_local=6, n_fixed=3, n_points=500)[:6]
+    assert L.vieo_lba_set_stream_priority(2) != 0 and L.vieo_lba_set_stream_priority(-2) != 0
+    outs = []
+    for pr in (-1, 0, 1, -1):
+        assert L.vieo_lba_set_stream_priority(pr) == 0
+        n, p, e, r = Optimizer.LocalBundleAdjustmentNavStatePRV(*win)
+        outs.append((n.tobytes(), p.tobytes(), e.tobytes(), int(r["lm_trials"])))
+    assert all(o == outs[0] for o in outs[1:])
