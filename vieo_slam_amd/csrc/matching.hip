@@ -133,10 +133,16 @@ __device__ __forceinline__ knn_v4i knn_spread16(unsigned h) {
   return r;
 }
 
+#ifndef VIEO_KNN2_TILE_ROWS
+#define VIEO_KNN2_TILE_ROWS 32  // train rows per barrier (32 or 64).  64 halves the barriers but needs four accumulators: 210 registers,
+                                // two wavefronts per SIMD instead of three -- 1.00 against 0.92 ms per 1536 searches (tools/ab_knn2_tile.sh)
+#endif
 __global__ void __launch_bounds__(256)
 k_knn2_mfma(Knn2Src S, int32_t* __restrict__ idx, int32_t* __restrict__ dist) {
-  __shared__ knn_v4i s_a[2][512];  // chunk (m * 2 + g) * 32 + i = the 16 expanded bytes of train row i for MFMA m, half g
-  __shared__ __attribute__((aligned(16))) unsigned s_L[2][32];
+  constexpr int TR = VIEO_KNN2_TILE_ROWS, NSUB = TR / 32, CH = TR * 16;  // chunks of 16 expanded bytes per tile
+  // chunk ((sub * 8 + m) * 2 + g) * 32 + i = the 16 expanded bytes of train row sub * 32 + i for MFMA m, half g
+  __shared__ knn_v4i s_a[2][CH];
+  __shared__ __attribute__((aligned(16))) unsigned s_L[2][TR];
   Knn2Job J;
   if (S.jobs)
     J = S.jobs[blockIdx.y];
@@ -169,27 +175,28 @@ k_knn2_mfma(Knn2Src S, int32_t* __restrict__ idx, int32_t* __restrict__ dist) {
     for (int m = 0; m < 8; m++) B[s][m] = knn_spread16((w[m >> 1] >> (16 * (m & 1))) & 0xFFFFu);
   }
   unsigned k0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, k1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-  // ---- staging roles: thread t expands chunks t and t + 256 of a tile; threads 0..31 its rows' words
-  const int n_tiles = (J.nt + 31) >> 5;
-  unsigned h16[2] = {0, 0};
+  // ---- staging roles: thread t expands chunks t + 256 u of a tile; threads 0 .. TR - 1 its rows' words
+  const int n_tiles = (J.nt + TR - 1) / TR;
+  constexpr int NU = CH / 256;
+  unsigned h16[NU];
   uint4 ra = {0, 0, 0, 0}, rb = ra;
   auto fetch = [&](int T) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const int cc = tid + 256 * u, m = cc >> 6, gg = (cc >> 5) & 1, row = T * 32 + (cc & 31);
+    for (int u = 0; u < NU; u++) {
+      const int cc = tid + 256 * u, sub = cc >> 9, m = (cc >> 6) & 7, gg = (cc >> 5) & 1, row = T * TR + sub * 32 + (cc & 31);
       h16[u] = row < J.nt ? (unsigned)*(const unsigned short*)(J.t + (size_t)row * 32 + 16 * gg + 2 * m) : 0u;
     }
-    if (tid < 32) {
-      const int row = T * 32 + tid;
+    if (tid < TR) {
+      const int row = T * TR + tid;
       ra = rb = make_uint4(0, 0, 0, 0);
       if (row < J.nt) ra = ((const uint4*)(J.t + (size_t)row * 32))[0], rb = ((const uint4*)(J.t + (size_t)row * 32))[1];
     }
   };
   auto stage = [&](int T, int b) {
-    s_a[b][tid] = knn_spread16(h16[0]);
-    s_a[b][tid + 256] = knn_spread16(h16[1]);
-    if (tid < 32) {
-      const int row = T * 32 + tid;
+#pragma unroll
+    for (int u = 0; u < NU; u++) s_a[b][tid + 256 * u] = knn_spread16(h16[u]);
+    if (tid < TR) {
+      const int row = T * TR + tid;
       const unsigned pa = __popc(ra.x) + __popc(ra.y) + __popc(ra.z) + __popc(ra.w) + __popc(rb.x) + __popc(rb.y) + __popc(rb.z) + __popc(rb.w);
       s_L[b][tid] = row < J.nt ? ((pa + 512u) << 16) | (unsigned)row : 0xFFFFFFFFu;
     }
@@ -200,22 +207,25 @@ k_knn2_mfma(Knn2Src S, int32_t* __restrict__ idx, int32_t* __restrict__ dist) {
   for (int T = 0; T < n_tiles; T++) {
     const int b = T & 1;
     if (T + 1 < n_tiles) fetch(T + 1);  // (in flight during this tile's MFMAs)
-    knn_v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const knn_v4i a = s_a[b][(m * 2 + g) * 32 + j];
-      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[0][m], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[1][m], acc1, 0, 0, 0);
-    }
+    for (int sub = 0; sub < NSUB; sub++) {
+      knn_v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
 #pragma unroll
-    for (int q4 = 0; q4 < 4; q4++) {
-      const uint4 Lw = *(const uint4*)&s_L[b][8 * q4 + 4 * g];
-      const unsigned L[4] = {Lw.x, Lw.y, Lw.z, Lw.w};
+      for (int m = 0; m < 8; m++) {
+        const knn_v4i a = s_a[b][((sub * 8 + m) * 2 + g) * 32 + j];
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[0][m], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[1][m], acc1, 0, 0, 0);
+      }
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const unsigned ka = L[e] - ((unsigned)acc0[4 * q4 + e] << 17), kb = L[e] - ((unsigned)acc1[4 * q4 + e] << 17);
-        k1[0] = min(max(ka, k0[0]), k1[0]), k0[0] = min(k0[0], ka);
-        k1[1] = min(max(kb, k0[1]), k1[1]), k0[1] = min(k0[1], kb);
+      for (int q4 = 0; q4 < 4; q4++) {
+        const uint4 Lw = *(const uint4*)&s_L[b][sub * 32 + 8 * q4 + 4 * g];
+        const unsigned L[4] = {Lw.x, Lw.y, Lw.z, Lw.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const unsigned ka = L[e] - ((unsigned)acc0[4 * q4 + e] << 17), kb = L[e] - ((unsigned)acc1[4 * q4 + e] << 17);
+          k1[0] = min(max(ka, k0[0]), k1[0]), k0[0] = min(k0[0], ka);
+          k1[1] = min(max(kb, k0[1]), k1[1]), k0[1] = min(k0[1], kb);
+        }
       }
     }
     if (T + 1 < n_tiles) stage(T + 1, b ^ 1);
