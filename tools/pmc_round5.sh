@@ -69,7 +69,7 @@ if cd_:
 json.dump(fast, open(R + "/gpurun_out/r5_pmc_fast.json", "w"), indent=1)
 rb, rd = read("rig_b"), read("rig_d")
 ker = {}
-for name, sub, src, sha in (("k_knn2", "k_knn2", "matching.hip", s_match), ("k_sbp_assign_cam", "k_sbp_assign_cam", "proj_search.hip", s_sbp),
+for name, sub, src, sha in (("k_knn2_mfma", "k_knn2_mfma", "matching.hip", s_match), ("k_sbp_assign_cam", "k_sbp_assign_cam", "proj_search.hip", s_sbp),
                             ("k_pose_opt_vio<256, rig>", "k_pose_opt_vio", "pose_opt_vio.hip", s_pose), ("k_fe_fill", "k_fe_fill", "fisheye_stereo.hip", "")):
     c = dict(pick(rb, sub)); c.update(pick(rd, sub))
     if not c:
