@@ -19,7 +19,7 @@
                    ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                           \
                    ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                           \
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)  \
-                   : "v"(b), "v"(c));                                                                \
+                   : "v"(b), "v"(c) : "vcc", "s10", "s11");                                          \
     }                                                                                                \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;              \
   }
@@ -47,6 +47,12 @@
 #define A_MAXF32(k) "v_max_f32 %" #k ", %" #k ", %8\n"
 #define A_MINU16(k) "v_min_u16 %" #k ", %" #k ", %8\n"
 #define A_CNDMASK(k) "v_cndmask_b32 %" #k ", %" #k ", %8, vcc\n"
+#define A_CNDMASK64(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %8, s[10:11]\n"
+#define A_CMPCND(k) "v_cmp_le_u32_e32 vcc, %8, %" #k "\n v_cndmask_b32_e32 %" #k ", %" #k ", %9, vcc\n"
+#define A_CMPCND64(k) "v_cmp_le_u32_e64 s[10:11], %8, %" #k "\n v_cndmask_b32_e64 %" #k ", %" #k ", %9, s[10:11]\n"
+#define A_ASHR(k) "v_ashrrev_i32 %" #k ", 31, %" #k "\n"
+#define A_LSHL(k) "v_lshlrev_b32 %" #k ", 3, %" #k "\n"
+#define A_SUB(k) "v_sub_u32 %" #k ", %" #k ", %8\n"
 #define A_BITOP3(k) "v_bitop3_b32 %" #k ", %" #k ", %8, %9 bitop3:0xcf\n"
 #define A_OR3(k) "v_or3_b32 %" #k ", %" #k ", %8, %9\n"
 #define A_XAD(k) "v_add3_u32 %" #k ", %" #k ", %8, %9\n"
@@ -80,6 +86,12 @@ OP_KERNEL(k_add_f32, A_PKADDF32)
 OP_KERNEL(k_max_f32, A_MAXF32)
 OP_KERNEL(k_min_u16, A_MINU16)
 OP_KERNEL(k_cndmask, A_CNDMASK)
+OP_KERNEL(k_cndmask64, A_CNDMASK64)
+OP_KERNEL(k_cmpcnd, A_CMPCND)
+OP_KERNEL(k_cmpcnd64, A_CMPCND64)
+OP_KERNEL(k_ashr, A_ASHR)
+OP_KERNEL(k_lshl, A_LSHL)
+OP_KERNEL(k_sub, A_SUB)
 OP_KERNEL(k_bitop3, A_BITOP3)
 OP_KERNEL(k_or3, A_OR3)
 OP_KERNEL(k_add3, A_XAD)
@@ -98,6 +110,8 @@ int main() {
       {"v_fma_f32", k_fma_f32}, {"v_add_f32", k_add_f32}, {"v_max_f32", k_max_f32}, {"v_mov_b32", k_mov},
       {"v_add_u32", k_add_u32}, {"v_and_b32", k_and_b32}, {"v_max_i32", k_max_i32}, {"v_min3_i32", k_min3_i32},
       {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3}, {"v_bitop3_b32", k_bitop3}, {"v_cndmask_b32", k_cndmask},
+      {"v_cndmask_b32_e64 (sgpr pair)", k_cndmask64}, {"v_cmp + v_cndmask (vcc), 2 instr", k_cmpcnd},
+      {"v_cmp + v_cndmask (sgpr pair), 2 instr", k_cmpcnd64}, {"v_ashrrev_i32", k_ashr}, {"v_lshlrev_b32", k_lshl}, {"v_sub_u32", k_sub},
       {"v_lshl_add_u32", k_lshl_add}, {"v_bfe_u32", k_bfe}, {"v_bcnt_u32_b32", k_bcnt},
       {"v_perm_b32", k_perm_b32}, {"v_alignbyte_b32", k_alignbyte}, {"v_min_u16", k_min_u16},
       {"v_pk_max_i16", k_pk_max_i16}, {"v_pk_sub_i16", k_pk_sub_i16}, {"v_pk_mad_i16", k_pk_mad_i16},
