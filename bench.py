@@ -163,7 +163,8 @@ def mfma_busy():
     path = _latest_profile("_pmc_lba_schur.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            d = json.load(f)
+        return d if _counters_match_source(d) else None  # counters of another lba.hip are not evidence about this one
     except (OSError, TypeError, ValueError):
         return None
 
@@ -245,6 +246,8 @@ def cpu_baseline(P, lba_problems, lba_every, budget_s=20.0):
         lm_thread.join()
     dt = time.perf_counter() - t0
     return {"value": n_done / dt, "unit": "frames/s", "cores": 3, "kind": "port",
+            "sample_short": "%d stereo frames of the timed batch + 1 local BA per %d frames, CPU oracle -O3 -march=native, threads as in "
+                            "the reference (2 extraction + tracking + LocalMapping), %.0f s" % (n_done, lba_every, dt),
             "sample": "%d of the benchmark's stereo frames through the same chain with the CPU oracle "
                       "(-O3 -march=native), threaded like the reference: extraction on 1 thread per "
                       "camera, stereo match / projection searches / 2x PoseOptimization on the tracking "
@@ -841,6 +844,122 @@ def pcie_leg(P, steps, warmup, lba=None):
                      "double-buffered against the step's kernels")}
 
 
+
+# ---------------------------------------------------------------- the ONE line the driver parses
+LINE_BUDGET = 4000   # characters; BENCH_r04's 19 KB line parsed, BENCH_r05's 27 KB line did not: stay far from the edge
+
+
+def _num(v, digits=6):
+    """Numbers of the compact line: floats to `digits` significant digits, numpy scalars to Python's."""
+    if isinstance(v, (bool, np.bool_)):
+        return bool(v)
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    if isinstance(v, (float, np.floating)):
+        v = float(v)
+        return float("%.*g" % (digits, v)) if np.isfinite(v) else None
+    return v
+
+
+def _pick(d, keys):
+    return {k: _num(d.get(k)) for k in keys if isinstance(d, dict) and k in d}
+
+
+def failed_legs(out):
+    """Names of the legs whose record is an {"error": ...}: a broken leg must be visible in the line, not buried."""
+    bad = []
+    for k, v in out.items():
+        if isinstance(v, dict):
+            if "error" in v:
+                bad.append(k)
+            bad += ["%s.%s" % (k, k2) for k2, v2 in v.items() if isinstance(v2, dict) and "error" in v2]
+    return bad
+
+
+def compact_line(out, detail_path=None):
+    """The contract's JSON line from the full record: headline, config (names the workload, <= 300 characters), roofline
+    of the dominant kernel, the MFMA roofline of the Schur contraction, the CPU baseline, the parity sample's verdicts and
+    the single-stream figures.  Everything else (stage tables, rig / vision legs, drop_in, pcie, multi_gpu, notes) is the
+    detail record: bench_detail.json beside this script, echoed to stderr."""
+    c = out.get("config", {})
+    line = {k: _num(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                           "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    wl = "BASELINE configs[2]: EuRoC MH05 stereo-VIO 752x480, 1200 feats; per frame ORBextractor x2 + ComputeStereoMatches + " \
+         "SearchByProjection x2 + PoseOptimization(VIO) x2; + 1 LocalBundleAdjustmentNavStatePRV per %s frames; frames resident in HBM" \
+         % c.get("lba_every", 10)
+    line["config"] = dict(_pick(c, ("workload_id", "stereo_frames_per_gpu_per_step", "local_ba_windows_per_step", "hip_streams_per_gpu",
+                                    "mean_keypoints_per_image", "ate_rmse_vs_truth_m")), workload=wl[:300])
+    r = out.get("roofline") or {}
+    line["roofline"] = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                 "avg_launch_ms"))
+    if isinstance(r.get("alone"), dict):
+        line["roofline"]["frac_alone"] = _num(r["alone"].get("frac"))
+    if isinstance(r.get("valu_issue"), dict) and r["valu_issue"].get("issue_fraction") is not None:
+        line["roofline"]["valu_issue_frac"] = _num(r["valu_issue"]["issue_fraction"])
+    m = out.get("roofline_mfma") or {}
+    line["roofline_mfma"] = dict(_pick(m, ("achieved", "peak", "unit", "frac", "frac_useful", "avg_launch_ms")), kernel="k_lba_schur")
+    if isinstance(m.get("alone"), dict):
+        line["roofline_mfma"]["alone"] = _pick(m["alone"], ("achieved", "frac", "frac_useful", "avg_launch_ms"))
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample_short") or cb.get("sample", ""))[:200]
+        if isinstance(cb.get("single_stream"), dict):
+            line["cpu_baseline"]["single_stream_value"] = _num(cb["single_stream"].get("value"))
+        if line.get("value") and cb.get("value"):
+            line["vs_cpu_baseline"] = _num(out["value"] / cb["value"], 4)
+    ps = out.get("parity_sample")
+    if isinstance(ps, dict) and "error" not in ps:
+        lw = ps.get("local_ba_windows", [])
+        line["parity_sample"] = dict(_pick(ps, ("keypoint_bytes_equal", "matches_equal", "inliers_equal", "max_se3_error")),
+                                     frames_checked=len(ps.get("frames_checked", [])),
+                                     lba_erase_flags_equal=all(w["erase_flags_equal"] for w in lw) if lw else None,
+                                     lba_lm_trials_equal=all(w["lm_trials"][0] == w["lm_trials"][1] for w in lw) if lw else None,
+                                     lba_max_se3_error=_num(max(w["max_se3_error"] for w in lw)) if lw else None)
+    ss = out.get("single_stream")
+    if isinstance(ss, dict) and "error" not in ss:
+        line["single_stream"] = _pick(ss, ("frames", "ms_per_frame", "ms_per_frame_tracking_call", "ms_per_local_ba_mean",
+                                           "ate_vs_oracle_m", "max_position_difference_vs_oracle_m", "vs_cpu_single_stream",
+                                           "vs_cpu_threaded"))
+        if isinstance(ss.get("drop_in"), dict):
+            line["single_stream"]["drop_in_ms_per_frame"] = _num(ss["drop_in"].get("ms_per_frame"))
+    line["legs_failed"] = failed_legs(out)
+    line["detail"] = detail_path
+    return line
+
+
+def emit(out, stream=None):
+    """Rank 0: the detail record to bench_detail.json (+ gpurun_out/ when that directory exists) and to stderr, then the
+    compact line as the LAST line of stdout."""
+    import ctypes
+    stream = stream or sys.stdout
+    detail = json.dumps(out)
+    paths = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                f.write(detail + "\n")
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            pass
+    line = json.dumps(compact_line(out, written), separators=(",", ":"))
+    if len(line) > LINE_BUDGET:
+        raise RuntimeError("bench line is %d characters (budget %d): trim compact_line()" % (len(line), LINE_BUDGET))
+    try:
+        ctypes.CDLL(None).fflush(None)  # (RCCL's version banner sits in C stdio's buffer: out with it BEFORE the line)
+    except OSError:
+        pass
+    sys.stderr.write("bench_detail: " + detail + "\n")
+    sys.stderr.flush()
+    stream.flush()
+    stream.write(line + "\n")
+    stream.flush()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1088,7 +1207,7 @@ def main():
                             % (a.lba_every, " + ".join(str(len(c)) for c in chunks),
                                "" if (a.lba_mixed or a.lba_batch > 0 or a.workload != "r3") else
                                ": one call per solver class, i.e. ordinary / bLarge windows apart", a.lba_threads),
-                "workload_id": a.workload,
+                "workload_id": a.workload, "lba_every": a.lba_every,
                 "local_ba_windows_per_step": n_lba,
                 "local_ba_ms_per_window_mean": float(np.mean(lba_ms)) if lba_ms else None,
                 "local_ba_lm_iterations_mean": float(np.mean([r["lm_iterations"] for r in lba_res])) if lba_res else None,
@@ -1245,10 +1364,7 @@ def main():
                 out["single_stream_rig"] = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
         if oracle_runs:
             oracle_runs.close()
-        import ctypes
-        ctypes.CDLL(None).fflush(None)  # (RCCL's version banner sits in C stdio's buffer: out with it BEFORE the line)
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 
