@@ -80,7 +80,10 @@ struct HotBinding {
   std::vector<MapPoint*> stage2_points;  // per key: the map point after the local-map search (nullptr: none)
   std::vector<uint8_t> stage2_outlier;
   std::vector<float> stage2_depth;       // per key: mTrackDepth of a point found in the local map (NaN: keep)
+  std::vector<MapPoint*> stage1_points;  // the points the first search + optimisation left on the keys (SearchLocalPoints' head)
+  std::vector<uint8_t> local_seen;       // per candidate of `local`: Frame::isInFrustum said yes (IncreaseVisible, Tracking.cc:2342)
   vieo_vio_result second;
+  int map_change_idx = -1;               // Map::GetLastChangeIdx() the candidate table was flattened at
 
   ~HotBinding() { vieo_tracker_destroy(trk); }
 
@@ -152,18 +155,33 @@ struct HotBinding {
     key_cap = vieo_tracker_key_capacity(trk);
   }
 
-  // mvpLocalMapPoints -> the candidate table (re-uploaded by the tracker only when local_version changes)
-  void set_local_map(const std::vector<MapPoint*>& pts) {
+  // One tracker per mode: a vision-only tracker integrates no IMU samples and applies no inertial edge or prior, an IMU
+  // tracker without samples reports PREINT_FAILED -- a Tracking object that crosses the IMU initialisation (or a
+  // relocalisation's bias recomputation) hands its frames to the other member, and the tracker follows.
+  void ensure_mode(bool no_imu) {
+    if (trk && vision_only != no_imu) {
+      vieo_tracker_destroy(trk);
+      trk = nullptr;
+      local.clear();  // the new tracker has seen no candidate table: the next set_local_map uploads
+      map_change_idx = -1;
+      parked = false;
+    }
+  }
+
+  // mvpLocalMapPoints -> the candidate table (re-uploaded by the tracker only when local_version changes).  The table
+  // holds VALUES (positions, normals, distance limits, descriptors): it is rebuilt when the pointer list differs and
+  // whenever the map changed since it was flattened (a local BA / loop correction moved the points, Map::InformNewChange;
+  // the reference reads GetWorldPos() afresh in every frame).
+  void set_local_map(const std::vector<MapPoint*>& pts, int change_idx) {
     std::vector<MapPoint*> live;
     live.reserve(pts.size());
     for (MapPoint* p : pts)
       if (p && !p->isBad()) live.push_back(p);
     if (live.size() > 16384) live.resize(16384);
-    bool same = live.size() == local.size();
+    bool same = live.size() == local.size() && change_idx == map_change_idx;
     for (size_t i = 0; same && i < live.size(); ++i) same = live[i] == local[i];
-    // (positions move with every local BA: the table is rebuilt whenever the map says it changed; the caller passes
-    // `force` through by clearing `local`)
     if (same) return;
+    map_change_idx = change_idx;
     local.swap(live);
     local_pts.resize(local.size()), local_desc.resize(local.size() * 32);
     for (size_t j = 0; j < local.size(); ++j) {
@@ -304,14 +322,18 @@ struct HotBinding {
     };
     stage2_points.assign(N, nullptr), stage2_outlier.assign(out.outlier, out.outlier + N);
     stage2_depth.assign(N, std::numeric_limits<float>::quiet_NaN());
+    stage1_points.assign(N, nullptr);
     auto& cmps = cur.GetMapPointsRef();
     for (int i = 0; i < N; ++i) {
       const int ref = out.point_ref[i];
       MapPoint* mp = point_of(ref);
       stage2_points[i] = mp;
-      if (mp && ref < out.key_cap) cmps[i] = mp;  // held since the first search and still held: TrackWithIMU's survivors
+      if (mp && ref < out.key_cap) cmps[i] = mp, stage1_points[i] = mp;  // held since the first search and still held: TrackWithIMU's survivors
       if (mp && ref >= out.key_cap) stage2_depth[i] = out.local_track_depth[ref - out.key_cap];
     }
+    // Frame::isInFrustum's verdict per candidate (the device evaluated it for every one: depth < 0 = outside every camera)
+    local_seen.assign(local.size(), 0);
+    for (size_t j = 0; j < local.size(); ++j) local_seen[j] = out.local_track_depth[j] >= 0.f;
     second = out.second;
     parked = out.status == VIEO_TRACK_OK;
     if (out.status == VIEO_TRACK_OK) {
@@ -327,6 +349,25 @@ struct HotBinding {
   void apply_second_stage(Frame& cur) {
     auto& cmps = cur.GetMapPointsRef();
     const int N = cur.N;
+    // SearchLocalPoints' bookkeeping (src/Tracking.cc:2308-2345): the points the frame already holds are visible and
+    // marked as seen in this frame; every other live candidate inside the frustum is visible.  (GetFoundRatio() =
+    // found / visible feeds LocalMapping::MapPointCulling: without these calls the ratio only grows.)
+    for (int i = 0; i < N && i < (int)stage1_points.size(); ++i) {
+      MapPoint* mp = stage1_points[i];
+      if (!mp) continue;
+      if (mp->isBad()) {
+        cur.EraseMapPointMatch(i);
+        continue;
+      }
+      mp->IncreaseVisible();
+      mp->GetTrackInfoRef().Reset(&cur);
+    }
+    for (size_t j = 0; j < local.size() && j < local_seen.size(); ++j) {
+      MapPoint* mp = local[j];
+      if (mp->GetTrackInfoRef().last_seen_frameid_ == cur.nid_) continue;  // held by the frame: counted above
+      if (mp->isBad()) continue;
+      if (local_seen[j]) mp->IncreaseVisible();
+    }
     for (int i = 0; i < N && i < (int)stage2_points.size(); ++i) {
       MapPoint* mp = stage2_points[i];
       if (mp && !cmps[i]) {
@@ -399,12 +440,13 @@ bool Tracking::TrackWithIMU(bool bMapUpdated) {
       if (ok) mCurrentFrame.UpdateNavStatePVRFromTcw();
       return ok;
     }
+    H.ensure_mode(false);
     if (!H.trk) {
       const cv::Mat& im = mpORBextractors[0]->DeferredImage();
       H.create(mLastFrame, mpORBextractors, im.cols, im.rows, false, mpLocalMapper->th_far_pts_, mpIMUInitiator->GetGravityVec(), (float)th,
                mSensor == System::RGBD ? 3.f : 2.f);
-      H.set_local_map(mvpLocalMapPoints);
     }
+    H.set_local_map(mvpLocalMapPoints, mpMap->GetLastChangeIdx());  // (no-op unless the list or the map changed)
     const bool prior = !bMapUpdated && mLastFrame.mbPrior;
     const int st = H.run(mCurrentFrame, mLastFrame, mpORBextractors, ns_ref, ref->ftimestamp_, prior ? &mLastFrame.mNavStatePrior : nullptr,
                          prior ? &mLastFrame.mMargCovInv : nullptr, nullptr, &nmatches);
@@ -460,7 +502,7 @@ bool Tracking::TrackLocalMapWithIMU(bool bMapUpdated) {
   if (H.parked) {
     H.apply_second_stage(mCurrentFrame);
     UpdateLocalMap();  // for the next frame's call
-    H.set_local_map(mvpLocalMapPoints);
+    H.set_local_map(mvpLocalMapPoints, mpMap->GetLastChangeIdx());
   } else {
     UpdateLocalMap();
     SearchLocalPoints();
@@ -484,7 +526,11 @@ bool Tracking::TrackLocalMapWithIMU(bool bMapUpdated) {
       mCurrentFrame.EraseMapPointMatch(i);
   }
   // steady state again?  the next Frame::Frame may then skip its extraction
-  const bool steady = mpIMUInitiator->GetVINSInited() && HotBinding::supported(mpORBextractors, mpCameras) && mSensor == System::STEREO;
+  // (Track() sends the next frame to TrackWithIMU only when the IMU is initialised AND no bias recomputation after a
+  // relocalisation is pending, src/Tracking.cc:1020,1164: otherwise it goes to TrackWithMotionModel, which has no
+  // samples for an IMU tracker)
+  const bool steady = mpIMUInitiator->GetVINSInited() && !mbRelocBiasPrepare && HotBinding::supported(mpORBextractors, mpCameras) &&
+                      mSensor == System::STEREO;
   bool ok;
   if (mCurrentFrame.nid_ < mnLastRelocFrameId + mMaxFrames && mnMatchesInliers < 50)
     ok = false;
@@ -509,11 +555,12 @@ bool Tracking::TrackWithMotionModel() {
     mCurrentFrame.SetPose(mVelocity * mLastFrame.GetTcwRef());
     mCurrentFrame.UpdateNavStatePVRFromTcw();  // the predicted pose as a body state: what the vision-only call starts from
     const NavState pred = mCurrentFrame.GetNavState();
+    H.ensure_mode(true);
     if (!H.trk) {
       const cv::Mat& im = mpORBextractors[0]->DeferredImage();
       H.create(mLastFrame, mpORBextractors, im.cols, im.rows, true, 0.f, cv::Mat(), (float)th, mSensor == System::RGBD ? 3.f : 1.f);
-      H.set_local_map(mvpLocalMapPoints);
     }
+    H.set_local_map(mvpLocalMapPoints, mpMap->GetLastChangeIdx());  // (no-op unless the list or the map changed)
     const int st = H.run(mCurrentFrame, mLastFrame, mpORBextractors, pred, mLastFrame.ftimestamp_, nullptr, nullptr, &pred, &nmatches);
     if (st != VIEO_TRACK_OK) {  // fewer than 20 matches after the wider window (:1878)
       defer_all(mpORBextractors, false);
@@ -558,7 +605,7 @@ bool Tracking::TrackLocalMap() {
   if (H.parked) {
     H.apply_second_stage(mCurrentFrame);
     UpdateLocalMap();
-    H.set_local_map(mvpLocalMapPoints);
+    H.set_local_map(mvpLocalMapPoints, mpMap->GetLastChangeIdx());
   } else {
     UpdateLocalMap();
     SearchLocalPoints();
@@ -581,7 +628,7 @@ bool Tracking::TrackLocalMap() {
   else
     ok = mnMatchesInliers >= 15;
   const bool steady = mSensor == System::STEREO && !Frame::usedistort_ && HotBinding::supported(mpORBextractors, mpCameras) &&
-                      !mpIMUInitiator->GetVINSInited() && !mVelocity.empty();
+                      (!mpIMUInitiator->GetVINSInited() || mbRelocBiasPrepare) && !mVelocity.empty();
   defer_all(mpORBextractors, ok && steady);
   return ok;
 }

@@ -220,6 +220,7 @@ class MapPoint {
     std::list<size_t> vtrack_cami_;
     std::list<float> vtrack_viewcos_;
     std::list<int> vtrack_scalelevel_;
+    unsigned long track_ref_frameid_, last_seen_frameid_;  // (FrameId = unsigned long, include/FrameBase.h:126)
     void Reset(Frame* pf = nullptr);
   } TrackFastMatchInfo;
   TrackFastMatchInfo trackinfo_;
@@ -241,6 +242,7 @@ class MapPoint {
   cv::Mat GetDescriptor();
   TrackFastMatchInfo& GetTrackInfoRef();
   void IncreaseFound(int n = 1);
+  void IncreaseVisible(int n = 1);
   unsigned long mnId, mnBALocalForKF;
   static std::mutex mGlobalMutex;
 
@@ -251,6 +253,7 @@ class MapPoint {
 class Map {
  public:
   void InformNewChange();
+  int GetLastChangeIdx();
   std::mutex mMutexMapUpdate;
 };
 
@@ -348,6 +351,8 @@ class Tracking {
   Frame mLastFrame;
   unsigned int mnLastRelocFrameId = 0;
   cv::Mat mVelocity;
+  Map* mpMap;
+  bool mbRelocBiasPrepare;
 };
 
 }  // namespace VIEO_SLAM
