@@ -23,7 +23,7 @@
 #define B6144 B4096; B2048
 #define B8192 B4096; B4096
 #define B16384 B8192; B8192
-#define BODY(NINST) B##NINST
+#define BODY(NINST) { B##NINST; }
 
 // KB of code per pass = NINST pairs * 16 bytes / 1024.  DIFF: every wavefront runs its own copy of the body.
 template <int KB, bool DIFF>
@@ -34,41 +34,41 @@ __global__ void __launch_bounds__(256) k(double* out, unsigned long long* t, int
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int r = 0; r < rep; r++) {
     if (!DIFF || wave == 0) {
-      if constexpr (KB == 8) BODY(512);
-      if constexpr (KB == 16) BODY(1024);
-      if constexpr (KB == 32) BODY(2048);
-      if constexpr (KB == 48) BODY(3072);
-      if constexpr (KB == 64) BODY(4096);
-      if constexpr (KB == 96) BODY(6144);
-      if constexpr (KB == 128) BODY(8192);
-      if constexpr (KB == 256) BODY(16384);
+      if constexpr (KB == 8) BODY(512)
+      if constexpr (KB == 16) BODY(1024)
+      if constexpr (KB == 32) BODY(2048)
+      if constexpr (KB == 48) BODY(3072)
+      if constexpr (KB == 64) BODY(4096)
+      if constexpr (KB == 96) BODY(6144)
+      if constexpr (KB == 128) BODY(8192)
+      if constexpr (KB == 256) BODY(16384)
     } else if (wave == 1) {
-      if constexpr (KB == 8) BODY(512);
-      if constexpr (KB == 16) BODY(1024);
-      if constexpr (KB == 32) BODY(2048);
-      if constexpr (KB == 48) BODY(3072);
-      if constexpr (KB == 64) BODY(4096);
-      if constexpr (KB == 96) BODY(6144);
-      if constexpr (KB == 128) BODY(8192);
-      if constexpr (KB == 256) BODY(16384);
+      if constexpr (KB == 8) BODY(512)
+      if constexpr (KB == 16) BODY(1024)
+      if constexpr (KB == 32) BODY(2048)
+      if constexpr (KB == 48) BODY(3072)
+      if constexpr (KB == 64) BODY(4096)
+      if constexpr (KB == 96) BODY(6144)
+      if constexpr (KB == 128) BODY(8192)
+      if constexpr (KB == 256) BODY(16384)
     } else if (wave == 2) {
-      if constexpr (KB == 8) BODY(512);
-      if constexpr (KB == 16) BODY(1024);
-      if constexpr (KB == 32) BODY(2048);
-      if constexpr (KB == 48) BODY(3072);
-      if constexpr (KB == 64) BODY(4096);
-      if constexpr (KB == 96) BODY(6144);
-      if constexpr (KB == 128) BODY(8192);
-      if constexpr (KB == 256) BODY(16384);
+      if constexpr (KB == 8) BODY(512)
+      if constexpr (KB == 16) BODY(1024)
+      if constexpr (KB == 32) BODY(2048)
+      if constexpr (KB == 48) BODY(3072)
+      if constexpr (KB == 64) BODY(4096)
+      if constexpr (KB == 96) BODY(6144)
+      if constexpr (KB == 128) BODY(8192)
+      if constexpr (KB == 256) BODY(16384)
     } else {
-      if constexpr (KB == 8) BODY(512);
-      if constexpr (KB == 16) BODY(1024);
-      if constexpr (KB == 32) BODY(2048);
-      if constexpr (KB == 48) BODY(3072);
-      if constexpr (KB == 64) BODY(4096);
-      if constexpr (KB == 96) BODY(6144);
-      if constexpr (KB == 128) BODY(8192);
-      if constexpr (KB == 256) BODY(16384);
+      if constexpr (KB == 8) BODY(512)
+      if constexpr (KB == 16) BODY(1024)
+      if constexpr (KB == 32) BODY(2048)
+      if constexpr (KB == 48) BODY(3072)
+      if constexpr (KB == 64) BODY(4096)
+      if constexpr (KB == 96) BODY(6144)
+      if constexpr (KB == 128) BODY(8192)
+      if constexpr (KB == 256) BODY(16384)
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();

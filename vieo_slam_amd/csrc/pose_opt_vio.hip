@@ -24,33 +24,311 @@
 
 namespace vieo {
 
+// ---- the single-lane edges, round 6: what an error evaluation has computed is not computed again by the linearisation
+// that follows it at the same state (the LM loop linearises at the state of the last accepted -- i.e. last -- evaluation).
+// A lane's time here is the latency of its transcendental chains (sincos 374 cycles, atan 211, sqrt 101, a division 76,
+// tools/micro/lat_bench.hip), so the rules are: (1) a quaternion that is a product of unit quaternions is re-normalised
+// by the series of 1 / sqrt(1 + e) (|e| ~ 1e-16: exact to rounding) instead of sqrt + division; (2) Exp(-Log(q)) is
+// conj(q); (3) JrInv(Log(q)) and Jr(w) take sin / cos of the angle from the half-angle values the quaternion / the
+// exponential already hold (sin t = 2 s c, 1 + cos t = 2 c^2, 1 - cos t = 2 s^2); (4) constants of the call (the
+// quaternion of the pre-integrated rotation) are formed once.  Values agree with the plain forms (imu_device.h, kept
+// for the local BA) to rounding; the optimiser's parity bar is 1e-4 on SE(3).
+// (5) Inside |angle| < ~0.5 rad -- every increment, bias correction and edge error of a tracked frame -- Exp, Log, Jr and
+// JrInv are polynomials in the squared angle (Taylor series to double rounding: the remainders are below 1e-17 on the
+// stated domains): no sqrt, no sincos, no atan, one or two reciprocals.  Outside the domain the plain forms run.
+//   cos(t/2) = sum (-1)^k u^k / (4^k (2k)!),  sin(t/2) / t = sum (-1)^k u^k / (2 4^k (2k+1)!),  u = t^2 < 1/4
+//   Jr(w) = I - A hat(w) + B hat(w)^2,  A = (1 - cos t) / t^2 = sum (-1)^k u^k / (2k+2)!,  B = (t - sin t) / t^3 = sum (-1)^k u^k / (2k+3)!
+//   Log(w, v) = (2 P / w) v with x^2 = |v|^2 / w^2 < 1/16, P = atan(x) / x = 1 - x^2 Q, Q = 1/3 - x^2/5 + x^4/7 - ...
+//   JrInv(Log q) = I + hat(e) / 2 + g hat(e)^2,  g = (1 - t (1 + cos t) / (2 sin t)) / t^2 = Q / (4 P^2)   (-> 1/12 at 0)
+constexpr double kCosH[9] = {1.0, -0.125, 0.0026041666666666665, -2.170138888888889e-05, 9.68812003968254e-08, -2.691144455467372e-10, 5.096864498991235e-13, -7.001187498614334e-16, 7.292903644389931e-19};
+constexpr double kSinHT[9] = {0.5, -0.020833333333333332, 0.00026041666666666666, -1.5500992063492063e-06, 5.382288910934745e-09, -1.2232474797578965e-11, 1.9603324996120133e-14, -2.333729166204778e-17, 2.1449716601146855e-20};
+constexpr double kJrA[9] = {0.5, -0.041666666666666664, 0.001388888888888889, -2.48015873015873e-05, 2.755731922398589e-07, -2.08767569878681e-09, 1.1470745597729725e-11, -4.779477332387385e-14, 1.5619206968586225e-16};
+constexpr double kJrB[9] = {0.16666666666666666, -0.008333333333333333, 0.0001984126984126984, -2.7557319223985893e-06, 2.505210838544172e-08, -1.6059043836821613e-10, 7.647163731819816e-13, -2.8114572543455206e-15, 8.22063524662433e-18};
+constexpr double kAtanQ[16] = {0.3333333333333333, -0.2, 0.14285714285714285, -0.1111111111111111, 0.09090909090909091, -0.07692307692307693, 0.06666666666666667, -0.058823529411764705, 0.05263157894736842, -0.047619047619047616, 0.043478260869565216, -0.04, 0.037037037037037035, -0.034482758620689655, 0.03225806451612903, -0.030303030303030304};
+// (6) The hot forms are STRAIGHT-LINE code: a lane's error evaluation is one basic block in which the scheduler
+// interleaves the independent chains (position / velocity rows beside the quaternion chain of the rotation rows) --
+// with a branch per domain test each piece was a block of its own and the lane ran them one dependent instruction at a
+// time.  Every polynomial is evaluated unconditionally, the domain tests only clear `ok`, and a caller whose evaluation
+// ends with ok == false (angles beyond the domains, a quaternion that is not unit: never in a tracked sequence) runs
+// the plain forms of imu_device.h after it.
+__device__ __forceinline__ Qd q_renorm(const Qd& q, bool& ok) {
+  const double e = (q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z) - 1.0;
+  ok = ok && fabs(e) < 1e-5;
+  const double r = 1.0 - e * (0.5 - 0.375 * e);
+  return Qd{q.w * r, q.x * r, q.y * r, q.z * r};
+}
+template <int N>
+__device__ __forceinline__ double horner(const double (&c)[N], double u) {
+  double r = c[N - 1];
+#pragma unroll
+  for (int k = N - 2; k >= 0; k--) r = __builtin_fma(r, u, c[k]);
+  return r;
+}
+__device__ __forceinline__ double rcp_nr(double d) {  // 1 / d: v_rcp_f64 + two Newton steps (as the solver's pivots)
+  double inv = __builtin_amdgcn_rcp(d);
+  inv = __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+  return __builtin_fma(__builtin_fma(-d, inv, 1.0), inv, inv);
+}
+// SO3ex::exp (so3_extra.h:121-142) as a unit quaternion; domain |w|^2 < 1/4
+__device__ __forceinline__ Qd so3_exp_unit(const double* w, bool& ok) {
+  const double u = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  ok = ok && u < 0.25;
+  const double real = horner(kCosH, u), imag = horner(kSinHT, u);
+  return q_renorm(Qd{real, imag * w[0], imag * w[1], imag * w[2]}, ok);
+}
+// SO3ex::log (so3_extra.h:144-190) of a unit quaternion, and g of JacobianRInv(log) = I + hat / 2 + g hat^2;
+// domain tan^2(half angle) < 1/16
+__device__ __forceinline__ void so3_log_unit(const Qd& q, double* out, double* g, bool& ok) {
+  const double n2 = q.x * q.x + q.y * q.y + q.z * q.z, w2 = q.w * q.w;
+  ok = ok && n2 < 0.0625 * w2;
+  const double iw = rcp_nr(q.w), x2 = n2 * (iw * iw);
+  const double Q = horner(kAtanQ, x2), P = __builtin_fma(-x2, Q, 1.0);
+  const double f = 2.0 * P * iw;
+  out[0] = f * q.x, out[1] = f * q.y, out[2] = f * q.z;
+  *g = Q * rcp_nr(4.0 * P * P);
+}
+// g of JacobianRInv for an angle outside the polynomial's domain (the plain forms' fallback)
+__device__ __noinline__ double so3_JrInv_g_of(const double* e) {
+  const double th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2], th = sqrt(th2);
+  if (th < 1e-5) return 1. / 12.;
+  double sth, cth;
+  sincos(th, &sth, &cth);
+  return (1.0 - (1.0 + cth) * th / (2.0 * sth)) / th2;
+}
+__device__ __forceinline__ void so3_JrInv_g(const double* e, double g, double* J) {
+  // hat(e)^2 = e e^T - |e|^2 I
+  const double xx = e[0] * e[0], yy = e[1] * e[1], zz = e[2] * e[2];
+  const double xy = g * e[0] * e[1], xz = g * e[0] * e[2], yz = g * e[1] * e[2];
+  J[0] = 1.0 - g * (yy + zz), J[1] = xy - 0.5 * e[2], J[2] = xz + 0.5 * e[1];
+  J[3] = xy + 0.5 * e[2], J[4] = 1.0 - g * (xx + zz), J[5] = yz - 0.5 * e[0];
+  J[6] = xz - 0.5 * e[1], J[7] = yz + 0.5 * e[0], J[8] = 1.0 - g * (xx + yy);
+}
+// JacobianR(w) (so3_extra.h:254-270); domain |w|^2 < 1/4 (the caller knows from the cache)
+__device__ __forceinline__ void so3_Jr_unit(const double* w, double* J) {
+  const double u = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double A = horner(kJrA, u), B = horner(kJrB, u);
+  const double xx = w[0] * w[0], yy = w[1] * w[1], zz = w[2] * w[2];
+  const double xy = B * w[0] * w[1], xz = B * w[0] * w[2], yz = B * w[1] * w[2];
+  J[0] = 1.0 - B * (yy + zz), J[1] = xy + A * w[2], J[2] = xz - A * w[1];
+  J[3] = xy - A * w[2], J[4] = 1.0 - B * (xx + zz), J[5] = yz + A * w[0];
+  J[6] = xz + A * w[1], J[7] = yz - A * w[0], J[8] = 1.0 - B * (xx + yy);
+}
+struct RotCache {  // written by an error evaluation, read by the linearisation at the same state
+  Qd qe, qb;        // inertial edge: the error quaternion (err_R = Log qe) and conj(q_i) q_j
+  double g_e;       // JrInv(err_R) = I + hat / 2 + g_e hat^2
+  double w[3];      // JgR dbg_i
+  Qd qp;            // prior edge: conj(q_prior) q_i, err_P[6..9) = Log qp
+  double g_p;
+  int w_small;      // |w|^2 < 1/4: Jr(w) by its polynomial
+};
+
 // EdgeNavStatePriorPVRBias (g2otypes.cpp:84-124); J is 15 x 15: cols 0..8 PVR_i, 9..14 Bias_i
-__device__ void prior_error(const NSd& pr, const NSd& si, double* err) {
+__device__ __forceinline__ void prior_error(const NSd& pr, const NSd& si, double* err, RotCache& C) {
   double Rb[9], d[3];
   q_to_R(q_of(pr), Rb);
   for (int k = 0; k < 3; k++) d[k] = si.p[k] - pr.p[k];
   mTv3(Rb, d, err);
-  so3_log_q(q_norm(q_mul(q_conj(q_of(pr)), q_of(si))), err + 6);
+  bool ok = true;
+  Qd q = q_renorm(q_mul(q_conj(q_of(pr)), q_of(si)), ok);
+  double g;
+  so3_log_unit(q, err + 6, &g, ok);
   for (int k = 0; k < 3; k++) {
     err[3 + k] = si.v[k] - pr.v[k];
     err[9 + k] = si.bg[k] + si.dbg[k] - (pr.bg[k] + pr.dbg[k]);
     err[12 + k] = si.ba[k] + si.dba[k] - (pr.ba[k] + pr.dba[k]);
   }
+  if (!ok) {  // the plain forms
+    q = q_norm(q_mul(q_conj(q_of(pr)), q_of(si)));
+    so3_log_q(q, err + 6);
+    g = so3_JrInv_g_of(err + 6);
+  }
+  C.qp = q, C.g_p = g;
 }
-__device__ void prior_linearize(const NSd& pr, const NSd& si, const double* err, double* J) {
-  for (int i = 0; i < 225; i++) J[i] = 0;
-  double Rb[9], Ri[9], RbT[9], tmp[9], I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Jrinv[9];
-  q_to_R(q_of(pr), Rb);
+// The Jacobian's constant part (zeros, the three identity blocks) is written once per call (prior_jacobian_init, all
+// threads); a linearisation writes the two blocks that depend on the state: R_prior^T R_i = R(conj(q_prior) q_i), the
+// quaternion the error evaluation formed, and JrInv of the rotation error.
+__device__ __forceinline__ void prior_jacobian_init(double* J, int tid, int nthreads) {
+  for (int e = tid; e < 225; e += nthreads) {
+    const int r = e / 15, c = e - r * 15;
+    J[e] = (r == c && ((r >= 3 && r < 6) || r >= 9)) ? 1.0 : 0.0;
+  }
+}
+__device__ __forceinline__ void prior_linearize(const double* err, double* J, const RotCache& C) {
+  double tmp[9], Jrinv[9];
+  q_to_R(C.qp, tmp);
+  set3(J, 15, 0, 0, tmp, 1.0);
+  so3_JrInv_g(err + 6, C.g_p, Jrinv);
+  set3(J, 15, 6, 6, Jrinv, 1.0);
+}
+
+// EdgeNavStateI computeError, rotation rows (imu_device.h imu_error part 2) with the intermediates kept; qRij = the
+// quaternion of the pre-integrated rotation (R_to_q(M.Rij), once per call)
+__device__ __forceinline__ void imu_error_rot(const vieo_imu_preint& M, const Qd& qRij, const NSd& si, const NSd& sj, double* err, RotCache& C) {
+  double w[3];
+  mv3(M.JgR, si.dbg, w);
+  bool ok = true;
+  const Qd qx = so3_exp_unit(w, ok);
+  const bool w_small = ok;
+  Qd qb = q_renorm(q_mul(q_conj(q_of(si)), q_of(sj)), ok);  // (independent of the chain through qx)
+  const Qd qa = q_renorm(q_mul(qRij, qx), ok);
+  Qd qe = q_renorm(q_mul(q_conj(qa), qb), ok);
+  double g;
+  so3_log_unit(qe, err + 6, &g, ok);
+  if (!ok) {  // the plain forms
+    qb = q_norm(q_mul(q_conj(q_of(si)), q_of(sj)));
+    qe = q_norm(q_mul(q_conj(q_norm(q_mul(qRij, so3_exp_q(w)))), qb));
+    so3_log_q(qe, err + 6);
+    g = so3_JrInv_g_of(err + 6);
+  }
+  C.qe = qe, C.qb = qb, C.g_e = g;
+  C.w[0] = w[0], C.w[1] = w[1], C.w[2] = w[2], C.w_small = w_small ? 1 : 0;
+}
+// The inertial Jacobian (9 x 24, imu_device.h imu_linearize with (idR, idV) = (6, 3)) has 14 non-zero 3 x 3 blocks, five
+// of them constants of the call (-I and the four bias Jacobians of the pre-integration): those and the zeros are
+// written once (imu_jacobian_init, all threads); a linearisation writes the nine blocks that depend on the states.
+__device__ __forceinline__ void imu_jacobian_init(const vieo_imu_preint& M, double* J, int tid, int nthreads) {
+  for (int e = tid; e < 9 * 24; e += nthreads) {
+    const int r = e / 24, c = e - r * 24;
+    double v = 0.0;
+    if (r < 3) {
+      if (c >= 9 && c < 12) v = (c - 9 == r) ? -1.0 : 0.0;
+      if (c >= 18 && c < 21) v = -M.Jgp[r * 3 + c - 18];
+      if (c >= 21) v = -M.Jap[r * 3 + c - 21];
+    } else if (r < 6) {
+      if (c >= 18 && c < 21) v = -M.Jgv[(r - 3) * 3 + c - 18];
+      if (c >= 21) v = -M.Jav[(r - 3) * 3 + c - 21];
+    }
+    J[e] = v;
+  }
+}
+// position and velocity rows (imu_linearize part 1 without its constant blocks)
+__device__ __forceinline__ void imu_linearize_pv(const vieo_imu_preint& M, const double* gw, const NSd& si, const NSd& sj, double* J) {
+  const int ld = 24, cj = 0, ci = 9, idR = 6, idV = 3;
+  double Ri[9], RiT[9], Rj[9], t[3], r[3], Hm[9], tmp[9];
   q_to_R(q_of(si), Ri);
   for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) RbT[i * 3 + j] = Rb[j * 3 + i];
-  mm3(RbT, Ri, tmp);
-  set3(J, 15, 0, 0, tmp, 1.0);
-  set3(J, 15, 3, 3, I3, 1.0);
-  so3_JrInv_d(err + 6, Jrinv);
-  set3(J, 15, 6, 6, Jrinv, 1.0);
-  set3(J, 15, 9, 9, I3, 1.0);
-  set3(J, 15, 12, 12, I3, 1.0);
+    for (int j = 0; j < 3; j++) RiT[i * 3 + j] = Ri[j * 3 + i];
+  q_to_R(q_of(sj), Rj);
+  const double dt = M.dt;
+  for (int k = 0; k < 3; k++) t[k] = sj.p[k] - si.p[k] - si.v[k] * dt - gw[k] * (dt * dt / 2);
+  mv3(RiT, t, r);
+  hat3(r, Hm);
+  set3(J, ld, 0, ci + idR, Hm, 1.0);
+  set3(J, ld, 0, ci + idV, RiT, -dt);
+  mm3(RiT, Rj, tmp);
+  set3(J, ld, 0, cj + 0, tmp, 1.0);
+  for (int k = 0; k < 3; k++) t[k] = sj.v[k] - si.v[k] - gw[k] * dt;
+  mv3(RiT, t, r);
+  hat3(r, Hm);
+  set3(J, ld, idV, ci + idR, Hm, 1.0);
+  set3(J, ld, idV, ci + idV, RiT, -1.0);
+  set3(J, ld, idV, cj + idV, RiT, 1.0);
+}
+// EdgeNavStateI linearizeOplus, rotation rows (imu_device.h imu_linearize part 2; the caller has cleared J) from the
+// cache of the error evaluation at the same state
+__device__ __forceinline__ void imu_linearize_rot(const vieo_imu_preint& M, const double* err, double* J, const RotCache& C) {
+  const int ld = 24, cj = 0, ci = 9, cb = 18, idR = 6;
+  double Jrinv[9], Rji[9], tmp[9], tmp2[9], E[9], Jr[9];
+  so3_JrInv_g(err + idR, C.g_e, Jrinv);
+  q_to_R(q_conj(C.qb), Rji);                    // R_j^T R_i
+  mm3(Jrinv, Rji, tmp);
+  set3(J, ld, idR, ci + idR, tmp, -1.0);
+  q_to_R(q_conj(C.qe), E);                      // Exp(-err_R)
+  so3_Jr_unit(C.w, Jr);
+  if (!C.w_small) so3_Jr_d(C.w, Jr);
+  mm3(Jrinv, E, tmp);
+  mm3(tmp, Jr, tmp2);
+  mm3(tmp2, M.JgR, tmp);
+  set3(J, ld, idR, cb + 0, tmp, -1.0);
+  set3(J, ld, idR, cj + idR, Jrinv, 1.0);
+}
+// NavState::IncSmall(dPVR) + IncSmallBias (imu_device.h ns_inc)
+__device__ __forceinline__ void ns_inc_unit(NSd& s, const double* d, const double* db) {
+  double R[9], Rd[3];
+  q_to_R(q_of(s), R);
+  mv3(R, d, Rd);
+  bool ok = true;
+  Qd q = q_renorm(q_mul(q_of(s), so3_exp_unit(d + 6, ok)), ok);
+  if (!ok) q = q_norm(q_mul(q_of(s), so3_exp_q(d + 6)));
+  for (int i = 0; i < 3; i++) s.p[i] += Rd[i], s.v[i] += d[3 + i];
+  s.qw = q.w, s.qx = q.x, s.qy = q.y, s.qz = q.z;
+  for (int i = 0; i < 3; i++) s.dbg[i] += db[i], s.dba[i] += db[3 + i];
+}
+
+// ---- the visual edges of a one-camera frame as STRAIGHT-LINE code (round 6).  A pass over the edges was a loop with a
+// `continue` for the edges of the wrong level, a branch for the stereo row and one inside the Huber kernel: every edge a
+// chain of basic blocks in which one wavefront per SIMD runs its ~320 double-precision instructions one dependent link
+// after the other (~9 cycles each against 4 of issue).  Here an edge is evaluated unconditionally -- a masked or
+// out-of-range slot with weight 0, the stereo row of a monocular edge as zeros, the Huber kernel by selection -- so that
+// TWO edges form one block and the scheduler interleaves their chains.  A valid edge goes through the operations of
+// edge_error / visual_jacobian / visual_accumulate (ba_device.h) in their order; the zeros added for the other slots do
+// not change a sum.
+struct VisFlat {
+  double err[3], Pc[3], info, chi2;
+  bool stereo;
+};
+__device__ __forceinline__ void vis_error_flat(const CamD& c, const PoseXf& X, const vieo_pose_obs& o, bool valid, VisFlat& E) {
+  const double Xw0 = o.Xw[0], Xw1 = o.Xw[1], Xw2 = o.Xw[2];
+  for (int i = 0; i < 3; i++) E.Pc[i] = X.Rcw[i * 3] * Xw0 + X.Rcw[i * 3 + 1] * Xw1 + X.Rcw[i * 3 + 2] * Xw2 + X.tcw[i];
+  if (!valid) E.Pc[2] = 1.0;  // (a slot that does not count must not divide by a zero depth: inf x weight 0 = NaN)
+  const double invz = 1. / E.Pc[2];
+  const double u = (double)(float)(c.fx * E.Pc[0] * invz + c.cx);
+  const double v = (double)(float)(c.fy * E.Pc[1] * invz + c.cy);
+  E.err[0] = (double)o.u - u;
+  E.err[1] = (double)o.v - v;
+  E.info = (double)o.inv_sigma2;
+  E.stereo = o.ur >= 0;
+  const double e2 = (double)o.ur - (u - c.bf / E.Pc[2]);
+  E.err[2] = E.stereo ? e2 : 0.0;
+  const double chi = E.err[0] * (E.info * E.err[0]) + E.err[1] * (E.info * E.err[1]);
+  const double chis = chi + E.err[2] * (E.info * E.err[2]);
+  E.chi2 = E.stereo ? chis : chi;
+}
+// RobustKernelHuber::robustify by selection (huber() of ba_device.h: same values)
+__device__ __forceinline__ void huber_flat(double e, double delta, double dsqr, bool robust, double* r0, double* r1) {
+  const bool big = robust && !(e <= dsqr);
+  const double sq = sqrt(big ? e : dsqr);
+  *r0 = big ? 2 * sq * delta - dsqr : e;
+  *r1 = big ? delta / sq : 1.;
+}
+// visual_jacobian with the stereo row of a monocular edge as zeros
+__device__ __forceinline__ void vis_jacobian_flat(const CamD& c, const PoseXf& X, const double* p, const vieo_pose_obs& o,
+                                                  const VisFlat& E, double* J) {
+  const double invz = 1 / E.Pc[2], invz2 = invz * invz;
+  double Jp[9];
+  Jp[0] = -(c.fx * invz), Jp[1] = 0, Jp[2] = -(-c.fx * E.Pc[0] * invz2);
+  Jp[3] = 0, Jp[4] = -(c.fy * invz), Jp[5] = -(-c.fy * E.Pc[1] * invz2);
+  Jp[6] = E.stereo ? Jp[0] : 0.0, Jp[7] = 0, Jp[8] = E.stereo ? Jp[2] - c.bf * invz2 : 0.0;
+  const double dP0 = (double)o.Xw[0] - p[0], dP1 = (double)o.Xw[1] - p[1], dP2 = (double)o.Xw[2] - p[2];
+  double Pa[3];
+  for (int m = 0; m < 3; m++) Pa[m] = X.Rwb[m] * dP0 + X.Rwb[3 + m] * dP1 + X.Rwb[6 + m] * dP2;
+  double RH[9];  // Rcb * hat(Rwb^T (Xw - pwb))
+  for (int m = 0; m < 3; m++) {
+    const double a = c.Rcb[m * 3], b = c.Rcb[m * 3 + 1], d = c.Rcb[m * 3 + 2];
+    RH[m * 3 + 0] = b * Pa[2] - d * Pa[1];
+    RH[m * 3 + 1] = -a * Pa[2] + d * Pa[0];
+    RH[m * 3 + 2] = a * Pa[1] - b * Pa[0];
+  }
+  for (int r = 0; r < 3; r++)
+    for (int q = 0; q < 3; q++) {
+      J[r * 6 + q] = -(Jp[r * 3] * c.Rcb[q] + Jp[r * 3 + 1] * c.Rcb[3 + q] + Jp[r * 3 + 2] * c.Rcb[6 + q]);
+      J[r * 6 + 3 + q] = Jp[r * 3] * RH[q] + Jp[r * 3 + 1] * RH[3 + q] + Jp[r * 3 + 2] * RH[6 + q];
+    }
+}
+// visual_accumulate with all three rows (the third is zero for a monocular edge) and the weight of the slot
+__device__ __forceinline__ void vis_accumulate_flat(const double* J, const double* err, double info, double r1, double* acc) {
+  const double w = r1 * info;
+  int t = 0;
+  for (int a = 0; a < 6; a++) {
+    for (int b = a; b < 6; b++, t++) {
+      double s = J[a] * w * J[b] + J[6 + a] * w * J[6 + b];
+      s += J[12 + a] * w * J[12 + b];
+      acc[t] += s;
+    }
+    double s = J[a] * (-(info * err[0]) * r1) + J[6 + a] * (-(info * err[1]) * r1);
+    s += J[12 + a] * (-(info * err[2]) * r1);
+    acc[21 + a] += s;
+  }
 }
 
 // LDS hand-over between the lanes of one wavefront
@@ -250,6 +528,8 @@ struct VioShared {
   double JI[9 * 24], JP[225], InfoI[81], T[225], TP[225], Hp[225];  // Hp: the frame's H_prior, staged once
   double xv[4];         // a scalar on its way through PoseXchg
   int xfail;            // an exchange timed out (a replica never arrived): the frame is reported as failed
+  RotCache rc;          // intermediates of the last error evaluation (inertial edge's rotation rows, prior edge)
+  double qRij[4];       // quaternion of the pre-integrated rotation (constant of the call)
   double gw[4];         // gravity (a pointer into LDS for the out-of-line edge functions; a local array would sit in scratch)
   vieo_imu_preint imu;  // the frame's pre-integration without Sigma, staged once: the single-lane edge evaluations of
                         // every trial read it, and a trip to L2 per dependent batch of loads was a fifth of their time
@@ -388,6 +668,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   CamD* s_cams = reinterpret_cast<CamD*>(s_cam_store);
   __shared__ __align__(8) unsigned char s_enc_store[ENC ? sizeof(VioEncShared) : 8];
   VioEncShared* SE = reinterpret_cast<VioEncShared*>(s_enc_store);
+  // The observations of a one-camera frame of up to kVioSplitObs edges, staged once (24 KB): every pass over the visual
+  // edges -- two per LM iteration, ~35 per call -- started with a trip to L2 for its first record and kept one more in
+  // flight per edge; from LDS a record is two ds_read_b128.
+  __shared__ __align__(16) vieo_pose_obs s_obs[(BS == 256 && !MC) ? 768 : 1];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T1 = BS > 64 ? 64 : 0, T2 = BS > 128 ? 128 : 0;  // lanes of the second / third serial role
   const int T3 = BS > 192 ? 192 : 0;  // fourth: the rotation rows of the inertial Jacobian (its two halves are independent)
@@ -491,9 +775,21 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   if (!fixedLast)
     for (int e = tid; e < 225; e += BS) S.Hp[e] = F.H_prior[e];
   if (tid < 3) S.gw[tid] = F.gw[tid];
+  prior_jacobian_init(S.JP, tid, BS);
+  if (hasImu) imu_jacobian_init(F.imu, S.JI, tid, BS);
+  if (tid == BS - 1 && hasImu) {
+    const Qd q = R_to_q(F.imu.Rij);
+    S.qRij[0] = q.w, S.qRij[1] = q.x, S.qRij[2] = q.y, S.qRij[3] = q.z;
+  }
   for (int e = tid; e < (int)(offsetof(vieo_imu_preint, Sigma) / 8); e += BS)
     reinterpret_cast<double*>(&S.imu)[e] = reinterpret_cast<const double*>(&F.imu)[e];
   __syncthreads();
+  // the system's entries that no linearisation writes (right of the diagonal; see the assembly) stay zero from here on
+  // (the information matrix's elimination above used this memory)
+  if (BS == 256) {
+    for (int i = tid; i < 900; i += BS) S.H[i] = 0.0;
+    __syncthreads();
+  }
   const double deltatij = F.imu.dt ? F.imu.dt : F.dt_frames;
   const double infoBg = F.inv_sigma_bg2 / deltatij * (fixedLast ? 1e-2 : 1.0);
   const double infoBa = F.inv_sigma_ba2 / deltatij * (fixedLast ? 1e-2 : 1.0);
@@ -508,6 +804,23 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   const int i0 = g * VT + tid;       // this thread's first visual edge; the next ones GV further
   constexpr int GV = G * VT;
   PoseXchg* xb = G > 1 ? xchg + f : nullptr;
+  // the prior edge's lane: on the third wavefront (behind its visual edges when it carries some: on the fourth, behind
+  // the inertial edge, it measured 4 % slower -- that wavefront is the last to arrive as it is)
+  const int TPr = T2;
+  constexpr bool kObsLds = BS == 256 && !MC && VT == 192 && G == 1;  // (N <= kVioSplitObs = the array's size)
+  if constexpr (kObsLds) {
+    static_assert(sizeof(vieo_pose_obs) == 32, "two 16-byte halves per record");
+    const uint4* src = reinterpret_cast<const uint4*>(obs);
+    uint4* dst = reinterpret_cast<uint4*>(s_obs);
+    for (int i = tid; i < 2 * N; i += BS) dst[i] = src[i];
+    __syncthreads();
+  }
+  auto ld_obs = [&](int i) -> vieo_pose_obs {
+    if constexpr (kObsLds)
+      return s_obs[i];
+    else
+      return obs[i];
+  };
   // Rig: the cameras' transforms at the estimate of a pass.  All threads on the visual edges: lanes 0 .. n_cams - 1 of
   // the workgroup form them between two barriers.  Visual edges on wavefronts 0-1 only (replicas): every wavefront
   // forms its own copy between wavefront barriers -- the other wavefronts are busy with the single-lane edges and cannot
@@ -602,10 +915,34 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       make_xf(c, e, X);
       rig_xf(X, e.p);
       double tc = 0;
-      vieo_pose_obs o_next = obs[min(i0, N - 1)];  // the next edge's record is in flight while this one is evaluated
+      if constexpr (kObsLds) {  // straight-line form, two edges per block (see vis_error_flat)
+        const int K = (N + VT - 1) / VT;  // slots per lane (uniform)
+        auto slots = [&](int k0, auto u_c) __attribute__((always_inline)) {
+          constexpr int U = decltype(u_c)::value;
+          VisFlat E[U];
+          bool valid[U];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int i = tid + (k0 + u) * VT;
+            valid[u] = i < N && !((levelmask >> (k0 + u)) & 1);
+            vis_error_flat(c, X, s_obs[min(i, N - 1)], valid[u], E[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            double r0, r1;
+            const double dl = E[u].stereo ? deltaStereo : deltaMono;
+            huber_flat(E[u].chi2, dl, dl * dl, vis_robust, &r0, &r1);
+            tc += valid[u] ? r0 : 0.0;
+          }
+        };
+        int k = 0;
+        for (; k + 1 < K; k += 2) slots(k, std::integral_constant<int, 2>{});
+        if (k < K) slots(k, std::integral_constant<int, 1>{});
+      } else {
+      vieo_pose_obs o_next = ld_obs(min(i0, N - 1));  // the next edge's record is in flight while this one is evaluated
       for (int k = 0, i = i0; i < Nv; k++, i += GV) {
         const vieo_pose_obs o = o_next;
-        if (i + GV < N) o_next = obs[i + GV];
+        if (i + GV < N) o_next = ld_obs(i + GV);
         if ((levelmask >> k) & 1) continue;
         double err[3], Pc[3];
         const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf + (VT == BS ? 0 : 48 * wave) : nullptr);
@@ -616,16 +953,28 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         }
         tc += r0;
       }
+      }
       tc = BS == 64 ? wave_sum_d_bfly(tc) : wave_sum_d(tc);
       if (lane == 0) S.red[wave] = tc;  // (S.red's last readers are barriers away)
     }
     if (BS > 192) {
-      if (tid == T3 && hasImu) RT(17, imu_error(S.imu, S.gw, S.nsi, S.nsj, S.errI, 6, 2));
-      if (tid == T2 && hasImu) RT(18, imu_error(S.imu, S.gw, S.nsi, S.nsj, S.errI, 6, 1));
-    } else if (tid == 0 && hasImu)
-      imu_error(S.imu, S.gw, S.nsi, S.nsj, S.errI);
+      // (three visual wavefronts: the third also carries the prior's lane, so both halves of the inertial edge sit on
+      // the fourth; two visual wavefronts: its position / velocity rows go with the prior on the third)
+      if (VT > 128) {  // one lane, one block: the scheduler interleaves the two halves' chains
+        if (tid == T3 && hasImu) {
+          RT(17, imu_error(S.imu, S.gw, S.nsi, S.nsj, S.errI, 6, 1);
+             imu_error_rot(S.imu, Qd{S.qRij[0], S.qRij[1], S.qRij[2], S.qRij[3]}, S.nsi, S.nsj, S.errI, S.rc));
+        }
+      } else {
+        if (tid == T3 && hasImu) RT(17, imu_error_rot(S.imu, Qd{S.qRij[0], S.qRij[1], S.qRij[2], S.qRij[3]}, S.nsi, S.nsj, S.errI, S.rc));
+        if (tid == T2 && hasImu) RT(18, imu_error(S.imu, S.gw, S.nsi, S.nsj, S.errI, 6, 1));
+      }
+    } else if (tid == 0 && hasImu) {
+      imu_error(S.imu, S.gw, S.nsi, S.nsj, S.errI, 6, 1);
+      imu_error_rot(S.imu, Qd{S.qRij[0], S.qRij[1], S.qRij[2], S.qRij[3]}, S.nsi, S.nsj, S.errI, S.rc);
+    }
+    if (tid == TPr && !fixedLast) RT(19, prior_error(S.prior, S.nsi, S.errP, S.rc));
     if (tid == T2) {
-      if (!fixedLast) RT(19, prior_error(S.prior, S.nsi, S.errP));
       for (int k = 0; k < 3; k++) {
         S.errB[k] = (S.nsj.bg[k] + S.nsj.dbg[k]) - (S.nsi.bg[k] + S.nsi.dbg[k]);
         S.errB[3 + k] = (S.nsj.ba[k] + S.nsj.dba[k]) - (S.nsi.ba[k] + S.nsi.dba[k]);
@@ -659,26 +1008,27 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     PP(15);
     double chi = 0;
     *rhoI = *rhoB = *rhoP = 1.0;
+    // the three quadratic forms first (independent chains the scheduler can interleave), then the kernels
+    double eI = 0, eB = 0, eP = 0;
+    if (hasImu)
+      for (int i = 0; i < 9; i++) eI += S.errI[i] * S.wI[i];
+    for (int i = 0; i < 3; i++) eB += S.errB[i] * (infoBg * S.errB[i]);
+    for (int i = 3; i < 6; i++) eB += S.errB[i] * (infoBa * S.errB[i]);
+    if (!fixedLast)
+      for (int i = 0; i < 15; i++) eP += S.errP[i] * S.wP[i];
     if (hasImu) {
-      double e = 0;
-      for (int i = 0; i < 9; i++) e += S.errI[i] * S.wI[i];
-      double r0 = e;
-      if (fixedLast) huber(e, dI, dI * dI, &r0, rhoI);
+      double r0 = eI;
+      if (fixedLast) huber(eI, dI, dI * dI, &r0, rhoI);
       chi += r0;
     }
     {
-      double e = 0;
-      for (int i = 0; i < 3; i++) e += S.errB[i] * (infoBg * S.errB[i]);
-      for (int i = 3; i < 6; i++) e += S.errB[i] * (infoBa * S.errB[i]);
-      double r0 = e;
-      if (fixedLast) huber(e, dB, dB * dB, &r0, rhoB);
+      double r0 = eB;
+      if (fixedLast) huber(eB, dB, dB * dB, &r0, rhoB);
       chi += r0;
     }
     if (!fixedLast) {
-      double e = 0;
-      for (int i = 0; i < 15; i++) e += S.errP[i] * S.wP[i];
-      double r0 = e;
-      huber(e, dP, dP * dP, &r0, rhoP);
+      double r0 = eP;
+      huber(eP, dP, dP * dP, &r0, rhoP);
       chi += r0;
     }
     if (ENC) {
@@ -728,10 +1078,38 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       PoseXf X;
       make_xf(c, e, X);
       rig_xf(X, e.p);
-      vieo_pose_obs o_next = obs[min(i0, N - 1)];  // the next edge's record is in flight while this one is evaluated
+      if constexpr (kObsLds) {  // straight-line form, two edges per block (see vis_error_flat)
+        const int K = (N + VT - 1) / VT;  // slots per lane (uniform)
+        auto slots = [&](int k0, auto u_c) __attribute__((always_inline)) {
+          constexpr int U = decltype(u_c)::value;
+          VisFlat E[U];
+          bool valid[U];
+          double J[U][18];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int i = tid + (k0 + u) * VT;
+            valid[u] = i < N && !((levelmask >> (k0 + u)) & 1);
+            const vieo_pose_obs o = s_obs[min(i, N - 1)];
+            vis_error_flat(c, X, o, valid[u], E[u]);
+            vis_jacobian_flat(c, X, e.p, o, E[u], J[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            double r0, r1;
+            const double dl = E[u].stereo ? deltaStereo : deltaMono;
+            huber_flat(E[u].chi2, dl, dl * dl, vis_robust, &r0, &r1);
+            acc[27] += valid[u] ? r0 : 0.0;
+            vis_accumulate_flat(J[u], E[u].err, valid[u] ? E[u].info : 0.0, r1, acc);
+          }
+        };
+        int k = 0;
+        for (; k + 1 < K; k += 2) slots(k, std::integral_constant<int, 2>{});
+        if (k < K) slots(k, std::integral_constant<int, 1>{});
+      } else {
+      vieo_pose_obs o_next = ld_obs(min(i0, N - 1));  // the next edge's record is in flight while this one is evaluated
       for (int k = 0, i = i0; i < Nv; k++, i += GV) {
         const vieo_pose_obs o = o_next;
-        if (i + GV < N) o_next = obs[i + GV];
+        if (i + GV < N) o_next = ld_obs(i + GV);
         if ((levelmask >> k) & 1) continue;
         double err[3], Pc[3];
         double J[18];
@@ -746,22 +1124,135 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
       }
       }
+      }
       // the single-lane Jacobians, on the wavefronts without visual edges, meanwhile
+      // (round 6) ... and what follows from them alone: the inertial edge's (rho' Info) J and J^T T -- i.e. every entry of
+      // the system before the other edges add to it -- on the inertial edge's wavefront, the prior's (rho' H_prior) J and
+      // J^T T' (parked in the solver's column buffer, dead between two solves) on the prior's wavefront, both WHILE
+      // wavefronts 0-1 go through the visual edges and their sums.  What is left behind the sums' barrier is one phase of
+      // additions (C below).  The entries and the order of their terms are those of the three-phase form (kept for the
+      // one-wavefront instances, where the phases are the same wavefront anyway): same bits.
+      constexpr bool kOverlap = BS == 256;
       if (BS > 192) {
-        if (wave == 3 && hasImu) {  // both halves of the inertial Jacobian: the wavefront clears it, lane 0 fills it
-          for (int i = lane; i < 9 * 24; i += 64) S.JI[i] = 0;
-          wave_sync();
-          if (lane == 0) {
-            RT(20, imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1));
-            RT(21, imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2));
+        if (wave == 3) {
+          if (hasImu) {  // lane 0 writes the inertial Jacobian's state-dependent blocks (the others are constants of the call)
+            if (lane == 0) {
+              RT(20, imu_linearize_pv(S.imu, S.gw, S.nsi, S.nsj, S.JI);
+                 imu_linearize_rot(S.imu, S.errI, S.JI, S.rc));
+            }
+            wave_sync();
+          }
+          // The inertial edge's part of the system, J^T (rho' Info) J and its gradient, on the FP64 matrix cores of this
+          // wavefront (v_mfma_f64_16x16x4_f64; lane l supplies A[l & 15][4 ks + (l >> 4)] and B[4 ks + (l >> 4)][l & 15],
+          // accumulator register r is D[(l >> 4) + 4 r][l & 15]):
+          //   T = (rho' Info) J, 9 x 24 as one 16-row tile by two 16-column tiles, K = 9 in three steps of 4 -- its
+          //   accumulator registers r = 0..2 are, as they stand, the B operands (rows 4 r + (l >> 4)) of
+          //   H = J^T T, whose A operands are the J values already loaded as B operands of the first product;
+          //   column 24 of T (padding) carries -rho' w, so column 24 of H is the gradient J^T (-rho' Info e).
+          // The solver reads the diagonal and the entries below it only, so tile (0, 1) serves the gradient alone.
+          // Entries receive the sum of their nine terms in the matrix core's order instead of the scalar loop's: same
+          // value up to the last bits (parity bar 1e-4).  The rest of the system is zero-filled first.
+          if (!hasImu) {  // no inertial edge: nothing overwrites the entries the other edges add to
+            for (int i = lane; i < n * n; i += 64) S.H[i] = 0.0;
+            if (lane < n) S.b[lane] = 0.0;
+          }
+          if (hasImu) {
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            const int l15 = lane & 15, l4 = lane >> 4;
+            double aI[3], bJ[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+              const int k = 4 * ks + l4;
+              aI[ks] = (l15 < 9 && k < 9) ? rhoI * S.InfoI[l15 * 9 + k] : 0.0;
+              bJ[0][ks] = k < 9 ? S.JI[k * 24 + l15] : 0.0;
+              bJ[1][ks] = (k < 9 && l15 < 8) ? S.JI[k * 24 + 16 + l15] : 0.0;
+            }
+            v4d T0 = {0, 0, 0, 0}, T1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+              T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[ks], bJ[0][ks], T0, 0, 0, 0);
+              T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[ks], bJ[1][ks], T1, 0, 0, 0);
+            }
+            if (l15 == 8) {  // column 24: -rho' w_k, k = 4 r + (l >> 4)
+#pragma unroll
+              for (int r = 0; r < 3; r++) {
+                const int k = 4 * r + l4;
+                T1[r] = k < 9 ? -S.wI[k] * rhoI : 0.0;
+              }
+            }
+            v4d H00 = {0, 0, 0, 0}, H01 = {0, 0, 0, 0}, H10 = {0, 0, 0, 0}, H11 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+              H00 = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[0][ks], T0[ks], H00, 0, 0, 0);
+              H01 = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[0][ks], T1[ks], H01, 0, 0, 0);
+              H10 = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[1][ks], T0[ks], H10, 0, 0, 0);
+              H11 = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[1][ks], T1[ks], H11, 0, 0, 0);
+            }
+            const int m = fixedLast ? 9 : 24;  // reduced unknowns of the inertial edge
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int row = l4 + 4 * r;
+              // tiles (0, 0), (1, 0), (1, 1): reduced (c1, c2) with c2 <= c1; tiles (0, 1), (1, 1) column 8: the gradient
+              {
+                const int c1 = row, c2 = l15;
+                if (c1 < m && c2 <= c1) S.H[(c1 < 9 ? c1 : c1 + 6) * n + (c2 < 9 ? c2 : c2 + 6)] = 0.0 + H00[r];
+                if (c1 < m && l15 == 8) S.b[c1 < 9 ? c1 : c1 + 6] = 0.0 + H01[r];
+              }
+              if (!fixedLast) {
+                const int c1 = 16 + row;
+                if (c1 < 24) {
+                  S.H[(c1 + 6) * n + (l15 < 9 ? l15 : l15 + 6)] = 0.0 + H10[r];
+                  if (l15 < 8 && 16 + l15 <= c1) S.H[(c1 + 6) * n + 16 + l15 + 6] = 0.0 + H11[r];
+                  if (l15 == 8) S.b[c1 + 6] = 0.0 + H11[r];
+                }
+              }
+            }
           }
         }
-      } else if (tid == 0 && hasImu)
-        imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI);
-      if (tid == T2 && !fixedLast) RT(22, prior_linearize(S.prior, S.nsi, S.errP, S.JP));
+      } else if (hasImu) {  // one wavefront per frame: it clears the Jacobian, lane 0 fills it
+        for (int i = lane; i < 9 * 24; i += 64) S.JI[i] = 0;
+        wave_sync();
+        if (tid == 0) {
+          imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
+          imu_linearize_rot(S.imu, S.errI, S.JI, S.rc);
+        }
+      }
+      if (tid == TPr && !fixedLast) RT(22, prior_linearize(S.errP, S.JP, S.rc));
+      if (kOverlap && wave == (TPr >> 6) && !fixedLast) {
+        wave_sync();
+        // the prior's J^T (rho' H_prior) J and gradient the same way: one 16 x 16 tile, K = 15 in four steps; column 15 of
+        // T' (padding) carries -rho' w'.  Parked in L[0 .. 225) and L[225 .. 240).
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int l15 = lane & 15, l4 = lane >> 4;
+        double aP[4], bP[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+          const int k = 4 * ks + l4;
+          aP[ks] = (l15 < 15 && k < 15) ? rhoP * S.Hp[l15 * 15 + k] : 0.0;
+          bP[ks] = (l15 < 15 && k < 15) ? S.JP[k * 15 + l15] : 0.0;
+        }
+        v4d TPv = {0, 0, 0, 0}, HPv = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) TPv = __builtin_amdgcn_mfma_f64_16x16x4f64(aP[ks], bP[ks], TPv, 0, 0, 0);
+        if (l15 == 15) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int k = 4 * r + l4;
+            TPv[r] = k < 15 ? -S.wP[k] * rhoP : 0.0;
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) HPv = __builtin_amdgcn_mfma_f64_16x16x4f64(bP[ks], TPv[ks], HPv, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = l4 + 4 * r;
+          if (row < 15) S.L[l15 < 15 ? row * 15 + l15 : 225 + row] = HPv[r];
+        }
+      }
       if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
       PP(2);
-      // the 28 sums land in S.vis (the system's visual block) straight from the transpose; H .. tr_tail are dead here.
+      // the 28 sums land in S.vis (the system's visual block) straight from the transpose; H .. tr_tail are dead here
+      // (the four-wavefront instances transpose through s_tr: H is being written meanwhile).
       // Its barriers are also where the Jacobians above meet the threads that assemble the system.
       block_sum_lds<28, BS>(acc, BS == 64 ? S.H : s_tr, S.vis, tid);
       grid_sum(S.vis, 28);
@@ -770,13 +1261,15 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       const double iniChi = currentChi;
       const double rhoE0 = rhoE;  // the trial evaluations below overwrite rhoE
       PP(4);
-      // Three more barriers (were seven): (A) the products (rho' Info) J of the inertial, prior and encoder edges side by side;
+      // One-wavefront instances: three more barriers (were seven): (A) the products (rho' Info) J of the inertial, prior and
+      // encoder edges side by side;
       // (B) every entry of the system is WRITTEN once -- J^T T of the inertial edge over its 24 (9) unknowns, zero on
       // the rows and columns of the current bias -- so nothing is cleared first; (C) the visual block, the prior and
       // the bias edge add to entries no other role of this phase touches (the one shared diagonal, prior + bias of the
       // last state, stays with the prior's thread).  Each entry receives its terms in the order inertial, visual |
       // prior, bias, i.e. the sums are those of the one-edge-after-the-other form, bit for bit.
-      if (hasImu) {  // T = (rho' Info) J  (9 x 24)
+      // Four-wavefront instances: (A) and (B) are done (above); only the encoder edge's product is formed here.
+      if (!kOverlap && hasImu) {  // T = (rho' Info) J  (9 x 24)
         const int cnt = fixedLast ? 81 : 216;
         for (int eidx = tid; eidx < cnt; eidx += BS) {
           const int a = fixedLast ? eidx / 9 : eidx / 24, cc = eidx - a * (fixedLast ? 9 : 24);
@@ -786,7 +1279,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           S.T[a * 24 + cc] = t;
         }
       }
-      if (!fixedLast)  // T' = (rho' H_prior) J (15 x 15)
+      if (!kOverlap && !fixedLast)  // T' = (rho' H_prior) J (15 x 15)
         for (int eidx = tid; eidx < 225; eidx += BS) {
           const int a = eidx / 15, cc = eidx % 15;
           double t = 0;
@@ -801,36 +1294,38 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           for (int q = 0; q < 6; q++) t += (rhoE0 * SE->Info[a * 6 + q]) * SE->J[q * 12 + cc];
           SE->T[eidx] = t;
         }
-      __syncthreads();
-      for (int i = tid; i < n * n; i += BS) {
-        const int s1 = fixedLast ? i / 15 : i / 30, s2 = i - s1 * n;
-        const bool bias = (s1 >= 9 && s1 < 15) || (s2 >= 9 && s2 < 15);
-        double t = 0;
-        if (hasImu && !bias) {
-          const int c1 = s1 < 9 ? s1 : s1 - 6, c2 = s2 < 9 ? s2 : s2 - 6;
+      if (!kOverlap) {
+        __syncthreads();
+        for (int i = tid; i < n * n; i += BS) {
+          const int s1 = fixedLast ? i / 15 : i / 30, s2 = i - s1 * n;
+          const bool bias = (s1 >= 9 && s1 < 15) || (s2 >= 9 && s2 < 15);
+          double t = 0;
+          if (hasImu && !bias) {
+            const int c1 = s1 < 9 ? s1 : s1 - 6, c2 = s2 < 9 ? s2 : s2 - 6;
 #pragma unroll
-          for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c1] * S.T[a * 24 + c2];
+            for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c1] * S.T[a * 24 + c2];
+          }
+          S.H[i] = 0.0 + t;  // (0 + t: the sign of a zero sum as before)
         }
-        S.H[i] = 0.0 + t;  // (0 + t: the sign of a zero sum as before)
-      }
-      if (tid < n) {
-        const bool bias = tid >= 9 && tid < 15;
-        double t = 0;
-        if (hasImu && !bias) {
-          const int c = tid < 9 ? tid : tid - 6;
+        if (tid < n) {
+          const bool bias = tid >= 9 && tid < 15;
+          double t = 0;
+          if (hasImu && !bias) {
+            const int c = tid < 9 ? tid : tid - 6;
 #pragma unroll
-          for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c] * (-S.wI[a] * rhoI);
+            for (int a = 0; a < 9; a++) t += S.JI[a * 24 + c] * (-S.wI[a] * rhoI);
+          }
+          S.b[tid] = 0.0 + t;
         }
-        S.b[tid] = 0.0 + t;
+        __syncthreads();
       }
-      __syncthreads();
       // visual block: (dp, dphi) -> system rows/cols {0,1,2,6,7,8}
       if (tid < 36) {
         const int a = tid / 6, bq = tid % 6;
         const int lo = a < bq ? a : bq, hi = a < bq ? bq : a;
         const int t = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
         const int ra = a < 3 ? a : a + 3, rb = bq < 3 ? bq : bq + 3;
-        S.H[ra * n + rb] += S.vis[t];
+        if (!kOverlap || ra >= rb) S.H[ra * n + rb] += S.vis[t];  // (the solver reads the diagonal and below)
       }
       if (tid >= T1 && tid < T1 + 6) {
         const int a = tid - T1;
@@ -840,16 +1335,25 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         for (int eidx = tid; eidx < 225; eidx += BS) {
           const int c1 = eidx / 15, c2 = eidx % 15;
           double t = 0;
+          if (kOverlap)
+            t = S.L[eidx];
+          else {
 #pragma unroll
-          for (int a = 0; a < 15; a++) t += S.JP[a * 15 + c1] * S.TP[a * 15 + c2];
+            for (int a = 0; a < 15; a++) t += S.JP[a * 15 + c1] * S.TP[a * 15 + c2];
+          }
+          if (kOverlap && c1 < c2) continue;
           double h = S.H[(15 + c1) * n + 15 + c2] + t;
           if (c1 == c2 && c1 >= 9) h += (c1 < 12 ? infoBg : infoBa) * rhoB;
           S.H[(15 + c1) * n + 15 + c2] = h;
         }
         if (tid < 15) {
           double t = 0;
+          if (kOverlap)
+            t = S.L[225 + tid];
+          else {
 #pragma unroll
-          for (int a = 0; a < 15; a++) t += S.JP[a * 15 + tid] * (-S.wP[a] * rhoP);
+            for (int a = 0; a < 15; a++) t += S.JP[a * 15 + tid] * (-S.wP[a] * rhoP);
+          }
           double h = S.b[15 + tid] + t;
           if (tid >= 9) h += (tid < 12 ? infoBg : infoBa) * S.errB[tid - 9] * rhoB;
           S.b[15 + tid] = h;
@@ -859,11 +1363,12 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         const int k = tid - T2;
         const double w = (k < 3 ? infoBg : infoBa) * rhoB;
         const double we = (k < 3 ? infoBg : infoBa) * S.errB[k] * rhoB;
-        S.H[(9 + k) * n + 9 + k] += w;
-        S.b[9 + k] += -we;
+        // (this thread is the only writer of these entries: rows / columns of the current bias)
+        S.H[(9 + k) * n + 9 + k] = 0.0 + w;
+        S.b[9 + k] = 0.0 + -we;
         if (!fixedLast) {
-          S.H[(9 + k) * n + 24 + k] -= w;
-          S.H[(24 + k) * n + 9 + k] -= w;
+          S.H[(9 + k) * n + 24 + k] = 0.0 - w;
+          S.H[(24 + k) * n + 9 + k] = 0.0 - w;
         }
       }
       __syncthreads();
@@ -874,7 +1379,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           double t = 0;
           for (int a = 0; a < 6; a++) t += SE->J[a * 12 + c1] * SE->T[a * 12 + c2];
           const int s1 = (c1 < 6 ? 0 : 9) + c1 + (c1 % 6 < 3 ? 0 : 3), s2 = (c2 < 6 ? 0 : 9) + c2 + (c2 % 6 < 3 ? 0 : 3);
-          S.H[s1 * n + s2] += t;
+          if (!kOverlap || s1 >= s2) S.H[s1 * n + s2] += t;
         }
         if (tid < nc) {
           double t = 0;
@@ -918,8 +1423,8 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           __syncthreads();
         }
         // the two states are retracted side by side on different wavefronts (one lane each)
-        if (tid == 0) ns_inc(S.nsj, S.x, S.x + 9);
-        if (tid == T1 && !fixedLast) ns_inc(S.nsi, S.x + 15, S.x + 24);
+        if (tid == 0) ns_inc_unit(S.nsj, S.x, S.x + 9);
+        if (tid == T1 && !fixedLast) ns_inc_unit(S.nsi, S.x + 15, S.x + 24);
         __syncthreads();
         PP(7);
         double r1, r2, r3, visChi;
@@ -972,7 +1477,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     const float chi2close = (float)(1.5 * (double)chi2Mono);
     double nb[1] = {0};
     for (int k = 0, i = i0; i < Nv; k++, i += GV) {
-      const vieo_pose_obs o = obs[i];
+      const vieo_pose_obs o = ld_obs(i);
       double err[3], Pc[3];
       const float chi2 = (float)edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf + (VT == BS ? 0 : 48 * wave) : nullptr);
       bool bad;
@@ -1008,7 +1513,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     rig_xf(X, e.p);
     double nb[1] = {0};
     for (int k = 0, i = i0; i < Nv; k++, i += GV) {
-      const vieo_pose_obs o = obs[i];
+      const vieo_pose_obs o = ld_obs(i);
       double err[3], Pc[3];
       const double chi2 = edge_eval<MC>(c, s_cams, X, e.p, o, err, Pc, nullptr, MC ? s_xf + (VT == BS ? 0 : 48 * wave) : nullptr);
       if (chi2 < (double)(o.ur < 0 ? 18.f : 24.f)) {
@@ -1041,10 +1546,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
-    vieo_pose_obs o_next = obs[min(i0, N - 1)];  // the next edge's record is in flight while this one is evaluated
+    vieo_pose_obs o_next = ld_obs(min(i0, N - 1));  // the next edge's record is in flight while this one is evaluated
     for (int k = 0, i = i0; i < Nv; k++, i += GV) {
       const vieo_pose_obs o = o_next;
-      if (i + GV < N) o_next = obs[i + GV];
+      if (i + GV < N) o_next = ld_obs(i + GV);
       if ((levelmask >> k) & 1) continue;
       double err[3], Pc[3];
       double J[18];
@@ -1058,8 +1563,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       visual_accumulate(J, err, (double)o.inv_sigma2, r1, stereo, acc);
     }
     block_sum_bs<27, BS>(acc, S.red, tid);
-    if (BS > 192)
-      for (int i = tid; i < 9 * 24; i += BS) S.JI[i] = 0;
+    for (int i = tid; i < 9 * 24; i += BS) S.JI[i] = 0;
     __syncthreads();
     if (tid < 27) {
       double v = 0;
@@ -1070,10 +1574,12 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     }
     if (BS > 192) {
       if (tid == 0 && hasImu) imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
-      if (tid == T3 && hasImu) imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 2);
-    } else if (tid == 0 && hasImu)
-      imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI);
-    if (tid == T1 && !fixedLast) prior_linearize(S.prior, S.nsi, S.errP, S.JP);
+      if (tid == T3 && hasImu) imu_linearize_rot(S.imu, S.errI, S.JI, S.rc);
+    } else if (tid == 0 && hasImu) {
+      imu_linearize(S.imu, S.gw, S.nsi, S.nsj, S.errI, S.JI, 6, 3, 1);
+      imu_linearize_rot(S.imu, S.errI, S.JI, S.rc);
+    }
+    if (tid == T1 && !fixedLast) prior_linearize(S.errP, S.JP, S.rc);
     if (ENC && tid == T2) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 1);
     for (int i = tid; i < 225; i += BS) S.cov[i] = 0, S.C[i] = 0, S.E[i] = 0;
     __syncthreads();
@@ -1217,7 +1723,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   using one_c = std::integral_constant<int, 1>;
   if constexpr (BS == 256 && !MC) {
     if (N <= kVioSplitObs)
-      optimise(std::integral_constant<int, 128>{}, one_c{});
+      optimise(std::integral_constant<int, 192>{}, one_c{});
     else
       optimise(std::integral_constant<int, BS>{}, one_c{});
   } else if constexpr (BS == 256 && MC) {
