@@ -526,6 +526,7 @@ struct VioShared {
   double red[4 * 28], vis[28];
   double errI[9], errB[6], errP[15], wI[9], wP[15];
   double JI[9 * 24], JP[225], InfoI[81], T[225], TP[225], Hp[225];  // Hp: the frame's H_prior, staged once
+  double chiq[8];       // the generic edges' quadratic forms after the robust kernel and rho': (I, B, P) x (rho0, rho1)
   double xv[4];         // a scalar on its way through PoseXchg
   int xfail;            // an exchange timed out (a replica never arrived): the frame is reported as failed
   RotCache rc;          // intermediates of the last error evaluation (inertial edge's rotation rows, prior edge)
@@ -672,6 +673,10 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   // edges -- two per LM iteration, ~35 per call -- started with a trip to L2 for its first record and kept one more in
   // flight per edge; from LDS a record is two ds_read_b128.
   __shared__ __align__(16) vieo_pose_obs s_obs[(BS == 256 && !MC) ? 768 : 1];
+  // ... and their level (1: an outlier of the last classification, not an active edge) as bytes beside the lanes' bit
+  // masks: the error pass of a trial runs the edges over TWO wavefronts (the third then carries the prior edge alone and
+  // is not the last to arrive), i.e. in another edge -> lane mapping than the passes that own the masks
+  __shared__ uint8_t s_lvl[(BS == 256 && !MC) ? 768 : 4];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T1 = BS > 64 ? 64 : 0, T2 = BS > 128 ? 128 : 0;  // lanes of the second / third serial role
   const int T3 = BS > 192 ? 192 : 0;  // fourth: the rotation rows of the inertial Jacobian (its two halves are independent)
@@ -813,6 +818,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     const uint4* src = reinterpret_cast<const uint4*>(obs);
     uint4* dst = reinterpret_cast<uint4*>(s_obs);
     for (int i = tid; i < 2 * N; i += BS) dst[i] = src[i];
+    for (int i = tid; i < N; i += BS) s_lvl[i] = 0;
     __syncthreads();
   }
   auto ld_obs = [&](int i) -> vieo_pose_obs {
@@ -906,8 +912,9 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   // bias and the encoder edge on the third) and are evaluated while the first two wavefronts go through the visual edges
   // (with_visual: a trial; without: the first linearisation of an optimize(), which sums the visual edges itself).
   // Returns the robust chi2 of the generic edges (and rho' of I, B, P); *vis = that of the active visual edges.
+  constexpr int VTE = kObsLds ? 128 : VT;  // visual threads of the error pass
   auto all_errors = [&](double* rhoI, double* rhoB, double* rhoP, bool with_visual, double* vis) -> double {
-    if (with_visual && tid < VT) {  // (whole wavefronts)
+    if (with_visual && tid < VTE) {  // (whole wavefronts)
       Est e;
       e.p[0] = S.nsj.p[0], e.p[1] = S.nsj.p[1], e.p[2] = S.nsj.p[2];
       e.qw = S.nsj.qw, e.qx = S.nsj.qx, e.qy = S.nsj.qy, e.qz = S.nsj.qz;
@@ -916,16 +923,16 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       rig_xf(X, e.p);
       double tc = 0;
       if constexpr (kObsLds) {  // straight-line form, two edges per block (see vis_error_flat)
-        const int K = (N + VT - 1) / VT;  // slots per lane (uniform)
+        const int K = (N + VTE - 1) / VTE;  // slots per lane (uniform)
         auto slots = [&](int k0, auto u_c) __attribute__((always_inline)) {
           constexpr int U = decltype(u_c)::value;
           VisFlat E[U];
           bool valid[U];
 #pragma unroll
           for (int u = 0; u < U; u++) {
-            const int i = tid + (k0 + u) * VT;
-            valid[u] = i < N && !((levelmask >> (k0 + u)) & 1);
-            vis_error_flat(c, X, s_obs[min(i, N - 1)], valid[u], E[u]);
+            const int i = min(tid + (k0 + u) * VTE, N - 1);
+            valid[u] = tid + (k0 + u) * VTE < N && !s_lvl[i];
+            vis_error_flat(c, X, s_obs[i], valid[u], E[u]);
           }
 #pragma unroll
           for (int u = 0; u < U; u++) {
@@ -981,13 +988,79 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       }
       if (ENC) vio_enc_eval(pe, SE, &S.nsi, &S.nsj, 0);
     }
+    // Four wavefronts with both halves of the inertial edge on the fourth (kTail): the information products, the
+    // quadratic forms and the robust kernels of the inertial / prior / bias edges are formed by their own wavefronts
+    // right behind the errors -- the products lane-parallel, each form by one lane in the order of the loop further
+    // down (same bits) -- instead of by every thread behind a second barrier.
+    constexpr bool kTail = BS == 256 && VT == 192 && !ENC;
+    if (kTail) {
+      if (wave == 3 && hasImu) {
+        wave_sync();
+        if (lane < 9) {
+          double t = 0;
+#pragma unroll
+          for (int j = 0; j < 9; j++) t += S.InfoI[lane * 9 + j] * S.errI[j];
+          S.wI[lane] = t;
+        }
+        wave_sync();
+        if (lane == 0) {
+          double eI = 0;
+#pragma unroll
+          for (int i = 0; i < 9; i++) eI += S.errI[i] * S.wI[i];
+          double r0 = eI, r1 = 1.0;
+          if (fixedLast) huber(eI, dI, dI * dI, &r0, &r1);
+          S.chiq[0] = r0, S.chiq[1] = r1;
+        }
+      }
+      if (wave == 2) {
+        wave_sync();
+        if (!fixedLast && lane < 15) {
+          double t = 0;
+#pragma unroll
+          for (int j = 0; j < 15; j++) t += S.Hp[lane * 15 + j] * S.errP[j];
+          S.wP[lane] = t;
+        }
+        wave_sync();
+        if (lane == 0) {
+          double eB = 0;
+#pragma unroll
+          for (int i = 0; i < 3; i++) eB += S.errB[i] * (infoBg * S.errB[i]);
+#pragma unroll
+          for (int i = 3; i < 6; i++) eB += S.errB[i] * (infoBa * S.errB[i]);
+          double r0 = eB, r1 = 1.0;
+          if (fixedLast) huber(eB, dB, dB * dB, &r0, &r1);
+          S.chiq[2] = r0, S.chiq[3] = r1;
+          if (!fixedLast) {
+            double eP = 0;
+#pragma unroll
+            for (int i = 0; i < 15; i++) eP += S.errP[i] * S.wP[i];
+            huber(eP, dP, dP * dP, &r0, &r1);
+            S.chiq[4] = r0, S.chiq[5] = r1;
+          }
+        }
+      }
+    }
     PP(13);
     __syncthreads();
     PP(14);
+    if (kTail) {
+      PP(15);
+      double chi = 0;
+      *rhoI = *rhoB = *rhoP = 1.0;
+      if (hasImu) chi += S.chiq[0], *rhoI = S.chiq[1];
+      chi += S.chiq[2], *rhoB = S.chiq[3];
+      if (!fixedLast) chi += S.chiq[4], *rhoP = S.chiq[5];
+      if (with_visual) {
+        double v = S.red[0];
+        for (int w = 1; w < VTE / 64; w++) v += S.red[w];
+        *vis = v;
+      }
+      return chi;
+    }
     if (G > 1 && with_visual) {  // the replicas' shares of the visual chi2
       if (tid == 0) {
         double v = S.red[0];
-        for (int w = 1; w < VT / 64; w++) v += S.red[w];
+        for (int w = 1; w < VTE / 64; w++) v += S.red[w];
         S.xv[0] = v;
       }
       __syncthreads();
@@ -1038,7 +1111,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     }
     if (with_visual) {
       double v = S.red[0];
-      for (int w = 1; w < VT / 64; w++) v += S.red[w];
+      for (int w = 1; w < VTE / 64; w++) v += S.red[w];
       *vis = G > 1 ? S.xv[0] : v;
     }
     return chi;
@@ -1425,6 +1498,17 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         // the two states are retracted side by side on different wavefronts (one lane each)
         if (tid == 0) ns_inc_unit(S.nsj, S.x, S.x + 9);
         if (tid == T1 && !fixedLast) ns_inc_unit(S.nsi, S.x + 15, S.x + 24);
+        if (tid == T2) {  // the gain ratio's denominator, beside the retractions (it was every thread's loop behind the trial)
+          double sc = 0;  // (all loads up front: trip count known per branch)
+          if (fixedLast) {
+#pragma unroll
+            for (int j = 0; j < 15; j++) sc += S.x[j] * (lambda * S.x[j] + S.b[j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 30; j++) sc += S.x[j] * (lambda * S.x[j] + S.b[j]);
+          }
+          S.chiq[6] = sc;
+        }
         __syncthreads();
         PP(7);
         double r1, r2, r3, visChi;
@@ -1433,8 +1517,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         PP(9);
         if (!ok2) tempChi = DBL_MAX;
         rho = currentChi - tempChi;
-        double scale = 0;
-        for (int j = 0; j < n; j++) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
+        double scale = S.chiq[6];
         scale += 1e-3;
         rho /= scale;
         if (rho > 0 && isfinite(tempChi)) {
@@ -1490,6 +1573,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
         nb[0] += 1;
       } else
         levelmask &= ~(1ull << k);
+      if constexpr (kObsLds) s_lvl[i] = bad ? 1 : 0;
     }
     block_sum_bs<1, BS>(nb, S.red, tid);
     if (G > 1) {
@@ -1519,6 +1603,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
       if (chi2 < (double)(o.ur < 0 ? 18.f : 24.f)) {
         levelmask &= ~(1ull << k);
         outmask &= ~(1ull << k);
+        if constexpr (kObsLds) s_lvl[i] = 0;
       } else
         nb[0] += 1;
     }
