@@ -125,6 +125,8 @@ struct LbaDev {
   int* big_fail;                  //   and its "not positive definite" flag
   int nb;
   double *part0, *part, *part_m, *pmax;  // per-block partials
+  double* part_t;                 // [blocks of 64 points] robust chi2 of a trial, summed per point block (k_lba_tail)
+  int* tail_cnt;                  // arrival counter of k_lba_tail's workgroups (the last one folds the partials)
   CamD cam;                       // the single rectified pinhole camera (n_cams == 0) ...
   CamD cams[4];                   // ... or the physical cameras of a distorted multi-camera rig
   int n_cams;
@@ -338,6 +340,7 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
     if (D.scale_opt) np += 1;  // id_scale = maxKFid + 1: after every key-frame vertex
     D.np = np, D.n_free = nf, D.npv = 6 * nf + (D.scale_opt ? 1 : 0);
     out[w].np = np;
+    *D.tail_cnt = 0;  // (scratch memory: k_lba_tail's arrival counter starts an optimize() at zero)
   }
   __syncthreads();
   for (int i = tid; i < n_obs; i += 1024)
@@ -380,17 +383,17 @@ k_lba_error(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
 }
 
 // one workgroup per window: fold the per-block partials into the window's output record
-__global__ void __launch_bounds__(256)
-k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
-  __shared__ double s_red[4 * 3];
-  const int w = blockIdx.x, fl = ctl[w].flags;
-  if (!(fl & (LBA_TRIAL | LBA_BEGIN))) return;
-  const LbaDev& D = devs[w];
+// per_point: the trial's chi2 partials are k_lba_tail's (one per block of 64 points) instead of k_lba_error's
+__device__ __forceinline__ void lba_reduce_dev(const LbaDev& D, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out, int w,
+                                               int fl, bool per_point, double* s_red) {
   double v[3] = {0, 0, 0};
   if ((fl & LBA_BEGIN) && D.np > 0)
     for (int i = threadIdx.x; i < (D.n_obs + 255) / 256; i += 256) v[0] += D.part0[i];
   if ((fl & LBA_TRIAL) && D.np > 0) {
-    for (int i = threadIdx.x; i < (D.n_obs + 255) / 256; i += 256) v[1] += D.part[i];
+    if (per_point)
+      for (int i = threadIdx.x; i < (D.n_mp + 63) / 64; i += 256) v[1] += D.part_t[i];
+    else
+      for (int i = threadIdx.x; i < (D.n_obs + 255) / 256; i += 256) v[1] += D.part[i];
     for (int i = threadIdx.x; i < (D.n_mp + 63) / 64; i += 256) v[2] += D.part_m[i];
   }
   block_sum<3>(v, s_red, threadIdx.x);
@@ -405,6 +408,13 @@ k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
     } else
       out[w].chi0 = v[0] + g0, out[w].chi2 = v[1] + ((fl & LBA_TRIAL) ? g1 : 0.0), out[w].scale_l = v[2];
   }
+}
+__global__ void __launch_bounds__(256)
+k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+  __shared__ double s_red[4 * 3];
+  const int w = blockIdx.x, fl = ctl[w].flags;
+  if (!(fl & (LBA_TRIAL | LBA_BEGIN))) return;
+  lba_reduce_dev(devs[w], ctl, out, w, fl, false, s_red);
 }
 
 // 6x3 block Jp^T (rho' Omega) Jx of one active edge (multi-camera rigs: a key frame can see a point in
@@ -1139,15 +1149,10 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
 // ---- inertial edges of a visual-inertial window: one wavefront per key-frame pair.
 // mode 0: linearise at the current state (30x30 block J^T (rho' Omega) J and gradient, both edges of the
 // pair) and robust chi2 -> gchi0; mode 1: robust chi2 after a trial -> gchi.
-__global__ void __launch_bounds__(64)
-k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int mode) {
+// (the body, for one wavefront: k_lba_generic's workgroups and the pair workgroups of k_lba_tail)
+__device__ __forceinline__ void lba_generic_dev(const LbaDev& D, int e, int lane, int mode) {
   __shared__ double sJ[9 * 30], sT[9 * 30], sErr[9 + 6], sWe[9], sRho[3];
   __shared__ double sJE[6 * 30], sTE[6 * 30], sWeE[6];  // encoder edge: J in the local order, (rho' Info) J, Info e
-  const int w = blockIdx.y, fl = ctl[w].flags;
-  if (!(fl & (mode ? LBA_TRIAL : LBA_BUILD))) return;
-  const LbaDev& D = devs[w];
-  const int e = blockIdx.x, lane = threadIdx.x;
-  if (e >= D.n_imu) return;
   const LbaImu& E = D.imu[e];
   const double dI = (double)(float)sqrt(16.919), dB = (double)(float)sqrt(12.592);  // Optimizer.cc:219-222
   if (lane == 0) {
@@ -1273,6 +1278,14 @@ k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, i
     }
     A[900 + lane] = u;
   }
+}
+__global__ void __launch_bounds__(64)
+k_lba_generic(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int mode) {
+  const int w = blockIdx.y, fl = ctl[w].flags;
+  if (!(fl & (mode ? LBA_TRIAL : LBA_BUILD))) return;
+  const LbaDev& D = devs[w];
+  if ((int)blockIdx.x >= D.n_imu) return;
+  lba_generic_dev(D, blockIdx.x, threadIdx.x, mode);
 }
 
 // ---- dense LDL^T solve of the reduced system + pose update.
@@ -1999,19 +2012,13 @@ k_big_finish(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, Wi
 }
 
 // ---- back-substitution + update of the points, landmark part of the LM gain-ratio scale
-__global__ void __launch_bounds__(256)
-k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl,
-                    const WinOut* __restrict__ out) {
-  __shared__ double s_red[4];
-  const int w = blockIdx.y;
-  if (!(ctl[w].flags & LBA_TRIAL)) return;
-  const LbaDev& D = devs[w];
-  if (blockIdx.x * 64 >= D.n_mp || D.np == 0) return;
-  const double lambda = win_lambda(ctl[w], out[w]);
+// (the body: k_lba_update_points, and k_lba_tail which goes on with the points' edges)
+// Xn (optional): the updated point on the quad's lane 0, zeros on the other lanes and for an inactive point
+__device__ __forceinline__ void lba_update_points_dev(const LbaDev& D, double lambda, int blk, double* s_red, double* Xn = nullptr) {
   // FOUR lanes per point, each over every fourth free key frame: a point's chain was one dependent `tab` -> block round
   // trip per free key frame (10 .. 25 of them, 73 us per launch whatever the batch); the quad's partial sums are added
   // in a fixed order
-  const int m = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const int m = blk * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
   const bool act = m < D.n_mp && D.mp_act[m];
   double sc[1] = {0};
   double cl[3] = {0, 0, 0};
@@ -2042,11 +2049,22 @@ k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ 
       const double old = D.X[3 * (size_t)m + a];
       D.X_bak[3 * (size_t)m + a] = old;
       D.X[3 * (size_t)m + a] = old + x;
+      if (Xn) Xn[a] = old + x;
       sc[0] += x * (lambda * x + D.bl[3 * (size_t)m + a]);
     }
   }
   block_sum<1>(sc, s_red, threadIdx.x);
-  if (threadIdx.x == 0) D.part_m[blockIdx.x] = sc[0];  // one partial per 64 points (k_lba_reduce)
+  if (threadIdx.x == 0) D.part_m[blk] = sc[0];  // one partial per 64 points (k_lba_reduce)
+}
+__global__ void __launch_bounds__(256)
+k_lba_update_points(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl,
+                    const WinOut* __restrict__ out) {
+  __shared__ double s_red[4];
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_TRIAL)) return;
+  const LbaDev& D = devs[w];
+  if (blockIdx.x * 64 >= D.n_mp || D.np == 0) return;
+  lba_update_points_dev(D, win_lambda(ctl[w], out[w]), blockIdx.x, s_red);
 }
 
 // ================================================================== g2o's LM policy, per window, on the device
@@ -2064,12 +2082,14 @@ struct WinPol {
 
 // first: only the next round's flags (the first round).  allow_begin: the round being prepared contains the kernels of a
 // stage start (classification, active sets, initial chi2, lambda); a window that needs them in a round without waits.
-__global__ void __launch_bounds__(64)
-k_lba_policy(WinPol* __restrict__ pol, WinCtl* __restrict__ ctl, const WinOut* __restrict__ out, int W, int first,
-             int allow_begin, int stop_now) {
-  const int w = blockIdx.x * 64 + threadIdx.x;
-  if (w >= W) return;
+// restore_here: the caller rolls a rejected trial back itself, at once (k_lba_tail's last workgroup) -- returns 1 then --
+// instead of a LBA_RESTORE flag for the next round's k_lba_restore.
+// ctl: the flags of the round that has just run; ctl_next: where the next round's go (the same array for k_lba_policy, which
+// is a launch of its own; the other of two for k_lba_tail, whose workgroups read the current flags while one of them decides).
+__device__ __forceinline__ int lba_policy_dev(WinPol* __restrict__ pol, const WinCtl* ctl, WinCtl* ctl_next, const WinOut* __restrict__ out, int w,
+                                              int first, int allow_begin, int stop_now, bool restore_here) {
   WinPol H = pol[w];
+  int restore_now = 0;
   const int fl = first ? 0 : ctl[w].flags;
   if (fl & LBA_TRIAL) {
     bool run = true;
@@ -2105,7 +2125,10 @@ k_lba_policy(WinPol* __restrict__ pol, WinCtl* __restrict__ ctl, const WinOut* _
       } else {
         H.lambda *= H.ni;
         H.ni *= 2;
-        H.need_restore = 1;
+        if (restore_here)
+          restore_now = 1;
+        else
+          H.need_restore = 1;
       }
       H.qmax++;
       H.chi2_final = H.currentChi;
@@ -2158,8 +2181,110 @@ k_lba_policy(WinPol* __restrict__ pol, WinCtl* __restrict__ ctl, const WinOut* _
       if (H.need_restore) f |= LBA_RESTORE, H.need_restore = 0;
     }
   }
-  ctl[w].flags = f, ctl[w].pad = 0, ctl[w].lambda = lam;
+  ctl_next[w].flags = f, ctl_next[w].pad = 0, ctl_next[w].lambda = lam;
   pol[w] = H;
+  return restore_now;
+}
+__global__ void __launch_bounds__(64)
+k_lba_policy(WinPol* __restrict__ pol, WinCtl* __restrict__ ctl, const WinOut* __restrict__ out, int W, int first,
+             int allow_begin, int stop_now) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= W) return;
+  (void)lba_policy_dev(pol, ctl, ctl, out, w, first, allow_begin, stop_now, false);
+}
+
+// ---- the tail of a trial as ONE launch (round 6; were k_lba_update_points, k_lba_error(1), k_lba_generic(1),
+// k_lba_reduce: four dependent launches of 5-6 us each that are mostly launch ramp).
+//   workgroups [0, gq): 64 points each -- back-substitution and update of the points as above, then the residuals and the
+//     robust chi2 of THOSE points' edges (a point's observations are contiguous; the quad of a point takes every fourth;
+//     the key-frame poses were updated by the solve kernel before this launch): no workgroup waits for another;
+//   workgroups [gq, gq + pairs): the inertial / encoder pair edges' chi2 after the trial (one wavefront each);
+//   the LAST workgroup of a window to arrive (a counter in global memory behind a device-scope fence) folds the
+//     partials into the window's output record in k_lba_reduce's fixed order -- and, when the LM policy runs on the
+//     device (pol != null), takes the window's decision right there (lba_policy_dev: the next round's flags and
+//     damping) and rolls a rejected trial back at once: no policy launch, no restore launch, no host round trip.
+// The trial's visual chi2 is summed per block of 64 points instead of per block of 256 edges: another (fixed)
+// association order than the four-launch form, same terms.
+__global__ void __launch_bounds__(256)
+k_lba_tail(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out, int gq, WinPol* __restrict__ pol,
+           WinCtl* __restrict__ ctl_next, int allow_begin, int stop_now) {
+  __shared__ double s_red[4 * 3];
+  __shared__ int s_last;
+  const int w = blockIdx.y, fl = ctl[w].flags;
+  if (!(fl & LBA_TRIAL)) {  // (a window between two stages, waiting for a round with the stage-start kernels, or done)
+    if (pol && blockIdx.x == 0 && threadIdx.x == 0) (void)lba_policy_dev(pol, ctl, ctl_next, out, w, 0, allow_begin, stop_now, true);
+    return;
+  }
+  const LbaDev& D = devs[w];
+  const int nblk = max((D.n_mp + 63) / 64, 1);  // (block 0 of an empty landmark shard still arrives)
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < gq) {
+    if ((int)blockIdx.x >= nblk) return;
+    if (D.np > 0 && (int)blockIdx.x * 64 < D.n_mp) {
+      double Xn[3] = {0, 0, 0};
+      lba_update_points_dev(D, win_lambda(ctl[w], out[w]), blockIdx.x, s_red, Xn);
+      // the edges of the block's points at the trial state (the new point travels from the quad's lane 0 in registers:
+      // x + 0 + 0 + 0 is exact)
+      const int m = blockIdx.x * 64 + (tid >> 2), sub = tid & 3;
+#pragma unroll
+      for (int a = 0; a < 3; a++) Xn[a] = quad_sum_f64(Xn[a]);
+      double v[1] = {0};
+      if (m < D.n_mp && D.mp_act[m]) {  // (a point without an active edge has nothing to evaluate)
+        const int first = D.mp_first[m], cnt = D.mp_count[m];
+        const double scl = win_scale(D);
+        const double Xs[3] = {Xn[0] * scl, Xn[1] * scl, Xn[2] * scl};
+        for (int k = sub; k < cnt; k += 4) {
+          const int i = first + k;
+          if (D.level[i] != 0) continue;
+          const vieo_lba_obs o = D.obs[i];
+          PoseXf X;
+          const CamD& C = obs_cam(D, i);
+          kf_xf(C, D.kf[o.kf], X);
+          double err[3], Pc[3];
+          const double chi2 = lba_edge_error(C, X, o, Xs, err, Pc);
+          D.err[3 * (size_t)i] = err[0], D.err[3 * (size_t)i + 1] = err[1], D.err[3 * (size_t)i + 2] = err[2];
+          double r0 = chi2, r1;
+          if (fl & LBA_ROBUST) {
+            const double dl = o.ur >= 0 ? D.dStereo : D.dMono;
+            huber(chi2, dl, dl * dl, &r0, &r1);
+          }
+          v[0] += r0;
+        }
+      }
+      v[0] = quad_sum_f64(v[0]);
+      if (sub != 0) v[0] = 0;
+      block_sum<1>(v, s_red, tid);
+      if (tid == 0) D.part_t[blockIdx.x] = v[0];
+    }
+  } else {
+    const int e = blockIdx.x - gq;
+    if (e >= D.n_imu) return;
+    if (tid < 64) lba_generic_dev(D, e, tid, 1);
+  }
+  // arrival: this workgroup's results are visible device-wide before its count is
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const int total = nblk + D.n_imu;
+    const int old = atomicAdd(D.tail_cnt, 1);
+    s_last = old == total - 1;
+    if (s_last) *D.tail_cnt = 0;  // (for the next launch: nobody else touches it any more)
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  lba_reduce_dev(D, ctl, out, w, fl, true, s_red);
+  if (!pol) return;
+  // (every workgroup of the window has read its flags -- they all arrived -- so the control word can change now)
+  if (tid == 0) s_last = lba_policy_dev(pol, ctl, ctl_next, out, w, 0, allow_begin, stop_now, true);
+  __syncthreads();
+  if (!s_last) return;
+  for (int i = tid; i < D.n_mp; i += 256)  // k_lba_restore
+    if (D.mp_act[i])
+      for (int a = 0; a < 3; a++) D.X[3 * (size_t)i + a] = D.X_bak[3 * (size_t)i + a];
+  for (int i = tid; i < D.n_kf; i += 256)
+    if (D.kf[i].col >= 0) D.kf[i] = D.kf_bak[i];
+  if (tid == 0 && D.scale_opt) D.scl[0] = D.scl[1];
 }
 
 // ================================================================== host-side lock-step LM driver
@@ -2672,7 +2797,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   std::vector<size_t> scratch_off(W);
   struct Scr {
     size_t kf_bak, X_bak, mp_act, BB, Bs, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
-        gchi, bfull, Hb, Wp, big_fail, kf_act, occ, sc_sys, psc;
+        gchi, bfull, Hb, Wp, big_fail, kf_act, occ, sc_sys, psc, part_t, tail_cnt;
     int nb;
   };
   std::vector<Scr> scr(W);
@@ -2715,6 +2840,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     s.gchi0 = take((size_t)std::max(H.n_imu, 1) * 8), s.gchi = take((size_t)std::max(H.n_imu, 1) * 8);
     s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
     s.part_m = take((size_t)((H.n_mp + 63) / 64) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
+    s.part_t = take((size_t)std::max((H.n_mp + 63) / 64, 1) * 8), s.tail_cnt = take(256);
     s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)std::max(nf, 1) * H.n_mp * 4);
     s.sc_sys = take((size_t)(6 * nf + 2) * 8), s.psc = take((size_t)((H.n_mp + 63) / 64) * 16);
     s.kf_act = take((size_t)H.n_kf * 4);
@@ -2930,6 +3056,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.bs = (double*)(base + s.bs), D.xp = (double*)(base + s.xp);
     D.part0 = (double*)(base + s.part0), D.part = (double*)(base + s.part);
     D.part_m = (double*)(base + s.part_m), D.pmax = (double*)(base + s.pmax);
+    D.part_t = (double*)(base + s.part_t), D.tail_cnt = (int*)(base + s.tail_cnt);
     D.kf_list = (int*)(base + s.kf_list), D.tab = (int*)(base + s.tab);
     D.kf_act = (int*)(base + s.kf_act), D.occ = base + s.occ;
     D.bfull = (double*)(base + s.bfull), D.Ae = (double*)(base + s.Ae);
@@ -3020,8 +3147,21 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   // passes the same parity tests, and it measured the SAME time as the host loop below (one window beside the tracker
   // 5.2 vs 5.2 ms, alone 3.56 vs 3.54): what it saves between two rounds (copy back, synchronise, copy up: ~35 us) the blind
   // round's extra kernels cost again (restore + classification + the stage-start group in the rounds where a stage may
-  // end: 6-8 launches that find nothing to do, ~4 us each).  A round is 12 dependent launches of 5-26 us; fewer, fused
-  // launches are what would shorten it.  The host loop keeps glibc's pow() in the damping update.
+  // end: 6-8 launches that find nothing to do, ~4 us each).  Round 6 put the decision and the rollback INSIDE the trial's
+  // last launch (k_lba_tail's last workgroup: no policy launch, no restore launch, control words double-buffered by round
+  // parity) -- and it still measured 5.1-5.2 ms against the host loop's 4.9 beside the tracker (tools/r6_lba_check.sh):
+  // the rounds queued blind behind a finished stage and the stage-start groups cost more than the round trip they save.
+  // The host loop keeps glibc's pow() in the damping update.
+  // k_lba_tail (one launch for the tail of a trial) for calls of a few windows: one window beside the tracker 5.0 -> 4.9 ms,
+  // W = 4 equal, but W = 16 / 64 windows 2.80 -> 3.02 / 5.07 -> 6.47 ms per call -- its residual pass runs four lanes per
+  // point over the point's edges (that is what makes it independent of the other workgroups), which is latency-bound and
+  // loses to k_lba_error's lane per edge once the launch ramps are amortised over many windows.
+  // VIEO_LBA_FUSED_TAIL=0 / 1 forces the four-launch / one-launch form (A/B runs, tests of both forms).
+  static const int fused_tail_env = [] {
+    const char* e = getenv("VIEO_LBA_FUSED_TAIL");
+    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+  }();
+  const bool fused_tail = fused_tail_env >= 0 ? fused_tail_env != 0 : W <= 4;
   static const bool dev_policy_env = [] {
     const char* e = getenv("VIEO_LBA_DEVICE_POLICY");
     return e && atoi(e) != 0;
@@ -3030,11 +3170,13 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   if (dev_policy) {
     static thread_local DevBuf g_pol;
     static thread_local PinnedBuf g_pol_h;
-    if ((rc = g_pol.ensure((size_t)W * sizeof(WinPol))) != VIEO_OK || (rc = g_pol_h.ensure((size_t)W * (sizeof(WinPol) + sizeof(WinCtl)))) != VIEO_OK)
+    if ((rc = g_pol.ensure((size_t)W * (sizeof(WinPol) + sizeof(WinCtl)))) != VIEO_OK || (rc = g_pol_h.ensure((size_t)W * (sizeof(WinPol) + sizeof(WinCtl)))) != VIEO_OK)
       return rc;
     WinPol* hp = (WinPol*)g_pol_h.p;
     WinCtl* hc = (WinCtl*)(hp + W);
     WinPol* dP = g_pol.as<WinPol>();
+    // (k_lba_tail decides inside the round: the flags of a round and of the next one live in two arrays, by round parity)
+    WinCtl* const cbuf[2] = {dC, (WinCtl*)(dP + W)};
     int min_first_stage_rounds = 1 << 30;
     for (int w = 0; w < W; w++) {
       const WinHost& H = win[w];
@@ -3053,8 +3195,10 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     // prepares has them and lets a window that needs them wait a round otherwise.  The classification kernel alone (final
     // erase flags) is in every round.
     auto begin_allowed = [&](int round, bool all_in_second) { return round == 1 || (!all_in_second && round > min_first_stage_rounds); };
-    auto launch_round = [&](int round, bool with_begin) -> int {
-      hipLaunchKernelGGL(k_lba_restore, dim3(gr, W), dim3(256), 0, st, dD, dC);
+    auto launch_round = [&](int round, bool with_begin, bool next_begin) -> int {
+      WinCtl* const dC = fused_tail ? cbuf[round & 1] : cbuf[0];  // (shadows the one-array name used by the launches below)
+      WinCtl* const dCn = cbuf[(round + 1) & 1];
+      if (!fused_tail) hipLaunchKernelGGL(k_lba_restore, dim3(gr, W), dim3(256), 0, st, dD, dC);
       hipLaunchKernelGGL(k_lba_classify, dim3(ge, W), dim3(256), 0, st, dD, dC);
       if (round == 1 && vio)
         for (int ph = 0; ph < 3; ph++) hipLaunchKernelGGL(k_lba_prelevel, dim3(ge, W), dim3(256), 0, st, dD, dC, ph);
@@ -3098,27 +3242,33 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         hipLaunchKernelGGL(k_lba_ldlt16<kLd16Threads>, dim3(W), dim3(kLd16Threads), ld16_lds_bytes(nb16), st, dD, dC, dO, nb16);
       if (panels && cls_first[2] > cls_first[1])
         hipLaunchKernelGGL(k_lba_ldltg<kLdGThreads>, dim3(W), dim3(kLdGThreads), ldg_lds_bytes(nbg), st, dD, dC, dO, nbg);
-      hipLaunchKernelGGL(k_lba_update_points, dim3(gq, W), dim3(256), 0, st, dD, dC, dO);
-      hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
-      if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
-      hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      if (fused_tail)  // ... with the window's LM decision and the rollback of a rejected trial in its last workgroup
+        hipLaunchKernelGGL(k_lba_tail, dim3(gq + max_imu, W), dim3(256), 0, st, dD, dC, dO, gq, dP, dCn, next_begin ? 1 : 0, (stop && *stop) ? 1 : 0);
+      else {
+        hipLaunchKernelGGL(k_lba_update_points, dim3(gq, W), dim3(256), 0, st, dD, dC, dO);
+        hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
+        if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
+        hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
+      }
       VIEO_HIP_CHECK(hipGetLastError());
       return VIEO_OK;
     };
     const unsigned pg = (unsigned)((W + 63) / 64);
     int round = 1;
     bool all_in_second = false, with_begin = true;  // with_begin: what the policy kernel was told about the round it prepared
-    hipLaunchKernelGGL(k_lba_policy, dim3(pg), dim3(64), 0, st, dP, dC, dO, W, 1, 1, (stop && *stop) ? 1 : 0);
+    hipLaunchKernelGGL(k_lba_policy, dim3(pg), dim3(64), 0, st, dP, fused_tail ? cbuf[1] : cbuf[0], dO, W, 1, 1, (stop && *stop) ? 1 : 0);
     constexpr int kBlindRounds = 3;
     for (bool done = false; !done;) {
       for (int k = 0; k < kBlindRounds; k++, round++) {
-        if ((rc = launch_round(round, with_begin)) != VIEO_OK) return rc;
-        with_begin = begin_allowed(round + 1, all_in_second);
-        hipLaunchKernelGGL(k_lba_policy, dim3(pg), dim3(64), 0, st, dP, dC, dO, W, 0, with_begin ? 1 : 0, (stop && *stop) ? 1 : 0);
+        const bool next_begin = begin_allowed(round + 1, all_in_second);
+        if ((rc = launch_round(round, with_begin, next_begin)) != VIEO_OK) return rc;
+        with_begin = next_begin;
+        if (!fused_tail)
+          hipLaunchKernelGGL(k_lba_policy, dim3(pg), dim3(64), 0, st, dP, dC, dO, W, 0, with_begin ? 1 : 0, (stop && *stop) ? 1 : 0);
         n_rounds++;
       }
       VIEO_HIP_CHECK(hipMemcpyAsync(hp, dP, (size_t)W * sizeof(WinPol), hipMemcpyDeviceToHost, st));
-      VIEO_HIP_CHECK(hipMemcpyAsync(hc, dC, (size_t)W * sizeof(WinCtl), hipMemcpyDeviceToHost, st));
+      VIEO_HIP_CHECK(hipMemcpyAsync(hc, fused_tail ? cbuf[round & 1] : cbuf[0], (size_t)W * sizeof(WinCtl), hipMemcpyDeviceToHost, st));
       {
         const auto t_w = std::chrono::steady_clock::now();
         VIEO_HIP_CHECK(hipStreamSynchronize(st));
@@ -3246,10 +3396,14 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldlt16<kLd16Threads>, dim3(W), dim3(kLd16Threads), ld16_lds_bytes(nb16), st, dD, dC, dO, nb16); });
       if (panels && cls_trial[1])
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldltg<kLdGThreads>, dim3(W), dim3(kLdGThreads), ldg_lds_bytes(nbg), st, dD, dC, dO, nbg); });
-      KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_update_points, dim3(gq, W), dim3(256), 0, st, dD, dC, dO); });
-      KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1); });
-      if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1); });
-      KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO); });
+      if (fused_tail)
+        KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_tail, dim3(gq + max_imu, W), dim3(256), 0, st, dD, dC, dO, gq, (WinPol*)nullptr, (WinCtl*)nullptr, 0, 0); });
+      else {
+        KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_update_points, dim3(gq, W), dim3(256), 0, st, dD, dC, dO); });
+        KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1); });
+        if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1); });
+        KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO); });
+      }
       if (sh) {  // chi2 and the landmark part of the gain-ratio scale
         if ((rc = shard_exchange(sh, sh->d_buf + shard_sys, 4 * (size_t)W, st)) != VIEO_OK) return rc;
         VIEO_HIP_CHECK(hipMemcpyAsync(h_sc, sh->d_buf + shard_sys, 32 * (size_t)W, hipMemcpyDeviceToHost, st));
