@@ -143,7 +143,13 @@ def valu_issue(kernel, n_img, launch_ms):
         insts = d["valu_insts_per_simd"] * n_img / d["images_per_launch"]
         cyc = launch_ms * 1e-3 * 2.4e9
         c = d["issue_cycles_per_valu_inst"]
-        return {"valu_insts_per_simd_per_launch": insts, "launch_cycles_at_2p4_ghz": cyc,
+        # round 6 (tools/fast_issue.py): the loops' instruction classes weighted by measured trip counts give the half-rate
+        # share of the kernel's vector instructions, hence ONE issue fraction instead of the bracket below
+        half = (d.get("instruction_classes") or {}).get("valu_half_rate_share")
+        frac = insts * ((1 - half) * c["full_rate"] + half * c["half_rate"]) / cyc if half is not None else None
+        return {"issue_fraction": frac, "valu_half_rate_share": half,
+                "wave_cycle_accounting": {k: v for k, v in (d.get("wave_cycle_accounting") or {}).items() if isinstance(v, float)},
+                "valu_insts_per_simd_per_launch": insts, "launch_cycles_at_2p4_ghz": cyc,
                 "valu_insts_per_cycle_per_simd": insts / cyc,
                 "issue_fraction_if_all_full_rate": insts * c["full_rate"] / cyc,
                 "issue_fraction_if_all_half_rate": insts * c["half_rate"] / cyc,
