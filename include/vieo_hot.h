@@ -548,7 +548,7 @@ typedef struct vieo_pose_result {
   int32_t n_inliers;  /* return value of the reference: nInitialCorrespondences - nBad */
   int32_t status;     /* VIEO_POSE_* */
   int32_t lm_iterations; /* total LM iterations executed over the 4 rounds (diagnostic) */
-  int32_t reserved;
+  int32_t reserved;   /* visual-inertial variant: total lambda trials over the 4 rounds (diagnostic); else 0 */
 } vieo_pose_result;
 
 /* int Optimizer::PoseOptimization(Frame* pFrame, Frame* pLastF = NULL) (src/Optimizer.cc:1611-1874),

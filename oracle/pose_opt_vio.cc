@@ -441,6 +441,7 @@ static void accumulate(Problem& P, const GEdge& e, std::vector<double>& H, std::
 struct LM2 {
   double lambda = -1, ni = 2;
   int nBad = 0;
+  int trials = 0;  // lambda trials of this optimize() (diagnostic: vieo_pose_result.reserved)
 };
 
 static int lm_solve_vio(Problem& P, std::vector<VisEdge*>& active, int iteration, LM2& lm) {
@@ -531,6 +532,7 @@ static int lm_solve_vio(Problem& P, std::vector<VisEdge*>& active, int iteration
       P.nsj = bj, P.nsi = bi;
     }
     qmax++;
+    lm.trials++;
   } while (rho < 0 && qmax < 10);
   if (qmax == 10 || rho == 0) return 1;
   if ((iniChi - currentChi) * 1e3 < iniChi)
@@ -697,6 +699,7 @@ static void pose_optimization_vio(const vieo_vio_frame& F, const vieo_pose_obs* 
       R.base.lm_iterations++;
       if (res != 0) break;
     }
+    R.base.reserved += lm.trials;
     float chi2close = 1.5 * chi2Mono[it];
     nBad = 0;
     for (int pass = 0; pass < 2; pass++)

@@ -108,3 +108,42 @@ def test_gpu_vision_only_replay_staged_and_one_call_vs_oracle(oracle):
     ms = np.array(Rt.stats["ms_chain"])
     print("vision-only replay: ATE vs oracle staged %.2e / one call %.2e m; tracking call %.2f ms (GPU %.2f)"
           % (replay.ate_between(th, to), replay.ate_between(tt, to), ms[8:, 0].mean(), ms[8:, 1].mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+@pytest.mark.parametrize("rig,nc,nfeat,seed", [("radtan", 2, 1200, 3), ("kb8", 2, 1500, 4), ("kb8", 4, 1500, 5)])
+def test_gpu_rig_replay_at_bench_length_vs_oracle(oracle, rig, nc, nfeat, seed):
+    """The sequence legs of bench.py run 100 frames with the write-back 8 frames behind; this is that run as a test, with bounds
+    its own numbers satisfy and a reason for each.
+      * Up to the first frame whose integer decisions differ from the oracle's the two replays work on the same map:
+        <= 1e-4 (BASELINE's bar; measured 3e-13 .. 2e-6).  The float difference is NOT flat before that frame: the reference's
+        estimator turns a position difference dp between two consecutive frames into an accelerometer-bias difference of
+        ~ 2 dp / dt^2 (dt = 50 ms: x 800; with the marginal prior's weight on the last state up to x 3e4 -- tools/rig_call_gain.py
+        shows it on the ORACLE alone: last state + 1e-10 m -> dba + 3e-7), so rounding-level differences of the optimised
+        positions (1e-13) reach 1e-6 within ten frames on the 4-camera rig (tools/rig_drift_stages.py; every stage agrees with
+        the oracle to 1e-12 on identical inputs: tools/rig_pose_same_inputs.py, tools/rig_stage_same_inputs.py).
+      * Behind the first flipped decision the runs track different maps.  Both are realisations of the same estimator, whose
+        own error against the truth is E (computed here): the difference between them is asked to stay below E / 2 at its
+        worst frame and below E_rmse / 2 as an RMSE -- i.e. the HIP path is closer to the oracle than either is to the truth --
+        and below 3 mm / 1.2 mm absolutely (round-5 bench: 1.65 mm / 0.69 mm on the 4-camera rig, 89 frames behind its flip)."""
+    from tests.replay_oracle import OracleRigStages
+    n, lag = 100, 8
+    seq = rm.RigSequence(seed, n, rig, nc)
+    Ro = rm.RigReplay(seq, OracleRigStages(oracle, nfeat, nc), nfeat, lba_lag=lag)
+    to = Ro.run(n)
+    Rt = rm.RigTrackerReplay(seq, rm.HipRigStages(nfeat, nc), nfeat, lba_lag=lag, prefetch=True)
+    tt = Rt.run(n)
+    Rt.close()
+    flip = replay.first_decision_flip(Rt.stats, Ro.stats)
+    upto = n if flip is None else flip
+    d = np.linalg.norm(tt["p"] - to["p"], axis=1)
+    rot = np.array([synth_ba.pose_error(tt[k], to[k])[1] for k in range(n)])
+    e_truth = np.array([synth_ba.pose_error(to[k], seq.truth(k))[0] for k in range(n)])
+    ate = replay.ate_between(tt, to)
+    print("rig replay %s x%d, %d frames: first flipped decision at frame %s, max |dp| before it %.2e; behind it max %.2e, ATE %.2e; "
+          "oracle vs truth max %.2e rmse %.2e" % (rig, nc, n, flip, d[:upto].max(), d.max(), ate, e_truth.max(), np.sqrt((e_truth ** 2).mean())))
+    assert d[:upto].max() <= 1e-4 and rot[:upto].max() <= 1e-4, (flip, d[:upto].max())
+    assert d.max() <= min(3e-3, 0.5 * e_truth.max()) and rot.max() <= 3e-3, (flip, d.max(), e_truth.max())
+    assert ate <= min(1.2e-3, 0.5 * np.sqrt((e_truth ** 2).mean())), (ate, np.sqrt((e_truth ** 2).mean()))
+    assert Rt.stats["lba"] == Ro.stats["lba"] == 9

@@ -900,7 +900,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
   };
   unsigned long long levelmask = 0;
   bool vis_robust = true;
-  int nBad = 0, total_iters = 0;
+  int nBad = 0, total_iters = 0, total_trials = 0;
   const int n_edges_total = N + (hasImu ? 1 : 0) + 1 + (fixedLast ? 0 : 1) + (ENC ? 1 : 0);
   double rhoE = 1.0;  // rho' of the encoder edge at the last all_errors()
 
@@ -1539,6 +1539,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
           }
         }
         qmax++;
+        total_trials++;
       } while (rho < 0 && qmax < 10);
       __syncthreads();
       if (qmax == 10 || rho == 0) break;
@@ -1800,7 +1801,7 @@ k_pose_opt_vio(const vieo_vio_frame* __restrict__ frames, const vieo_pose_obs* _
     R->base.n_inliers = N - nBad;
     R->base.status = (G > 1 && S.xfail) ? VIEO_E_HIP : VIEO_POSE_OK;
     R->base.lm_iterations = total_iters;
-    R->base.reserved = 0;
+    R->base.reserved = total_trials;  // lambda trials over the four rounds (diagnostic)
     R->has_marg = F.compute_marg ? 1 : 0;
     R->reserved = 0;
   }

@@ -17,6 +17,7 @@ a key frame every `kf_every` frames and its local bundle adjustment applied with
 tests: tests/replay_oracle.py); *TrackerReplay runs a frame's tracking as ONE vieo_track_frame call (the map, the key
 frames and the local BA are the driver's, shared with the staged class).  Same simplifications as replay.Replay."""
 import time
+import zlib
 
 import numpy as np
 
@@ -359,6 +360,13 @@ class RigReplay(replay.Replay):
         self.map_updated = False
         self.stats["n_matches"].append((int(n1), int(n2)))
         self.stats["n_inliers"].append(int(r2["base"]["n_inliers"]))
+        # (LM iteration counts of the two optimisations: near convergence the sign of a gain ratio is rounding noise, and a
+        # trial more or less moves the result by its last step -- the float divergence tools/rig_drift.py traces)
+        self.stats.setdefault("lm_iterations", []).append((int(r1["base"]["lm_iterations"]), int(r2["base"]["lm_iterations"])))
+        # (which key holds which point, which observations were kept: the counts above can agree while the sets differ)
+        self.stats.setdefault("assignment_crc", []).append((zlib.crc32(np.ascontiguousarray(f.mp_ref).tobytes()), zlib.crc32(np.ascontiguousarray(f.outlier).tobytes())))
+        if self.stats.get("keep_marg"):  # (diagnosis only: tools/rig_drift.py)
+            self.stats.setdefault("H_marg", []).append(r2["H_marg"].copy() if int(r2["has_marg"]) else None)
         return self._finish_frame(k, f, t0)
 
 
@@ -463,6 +471,13 @@ class RigTrackerReplay(RigReplay):
         self.map_updated = False
         self.stats["n_matches"].append((int(o["n_matches_last"]), int(o["n_matches_local"])))
         self.stats["n_inliers"].append(int(r2["base"]["n_inliers"]))
+        # (LM iteration counts of the two optimisations: near convergence the sign of a gain ratio is rounding noise, and a
+        # trial more or less moves the result by its last step -- the float divergence tools/rig_drift.py traces)
+        self.stats.setdefault("lm_iterations", []).append((int(r1["base"]["lm_iterations"]), int(r2["base"]["lm_iterations"])))
+        # (which key holds which point, which observations were kept: the counts above can agree while the sets differ)
+        self.stats.setdefault("assignment_crc", []).append((zlib.crc32(np.ascontiguousarray(f.mp_ref).tobytes()), zlib.crc32(np.ascontiguousarray(f.outlier).tobytes())))
+        if self.stats.get("keep_marg"):  # (diagnosis only: tools/rig_drift.py)
+            self.stats.setdefault("H_marg", []).append(r2["H_marg"].copy() if int(r2["has_marg"]) else None)
         return self._finish_frame(k, f, t0)
 
 
