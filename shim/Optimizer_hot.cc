@@ -7,6 +7,8 @@
 //   int  PoseOptimization<Frame|KeyFrame>(Frame*, T*, gw, bComputeMarg, bNoMPs)         Optimizer.h:208-816
 //   void LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int Nlocal)           Optimizer.cc:1876-2307
 //   void LocalBundleAdjustmentNavStatePRV(KeyFrame*, Nlocal, bool*, Map*, gw, bLarge, bRecInit, th_dist_far)  :21-769
+//   int  GlobalBundleAdjustmentNavStatePRV(Map*, gw, nIterations, bool*, nLoopKF, bRobust, bScaleOpt, pimu_initator)  :771-1345
+//   void BundleAdjustment(vpKF, vpMP, nIterations, bool*, nLoopKF, bRobust, bEnc) / GlobalBundleAdjustment(Map*, ...)  :1346-1609
 //
 // Everything that touches caller objects keeps the reference's order and locks: MapPoint::mGlobalMutex while the
 // point positions of a frame are read (Optimizer.cc:1700, Optimizer.h:403), pMap->mMutexMapUpdate around the local-BA
@@ -14,6 +16,7 @@
 // C-ABI reads by a watcher: see StopMirror).
 #include "Optimizer.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -280,6 +283,82 @@ void fill_lba_params(KeyFrame* pKF, int its0, int its1, Window& W, vieo_lba_para
   }
 }
 
+// protected members of MapPoint the batched UpdateNormalAndDepth writes (as MapPointAccess in ORBmatcher_hot.cc reads two)
+struct MapPointWrite : public MapPoint {
+  static float MapPoint::*max_distance() { return &MapPointWrite::mfMaxDistance; }
+  static float MapPoint::*min_distance() { return &MapPointWrite::mfMinDistance; }
+  static MapPoint::Vector3data MapPoint::*normal() { return &MapPointWrite::mNormalVector; }
+  static std::mutex MapPoint::*mutex_pos() { return &MapPointWrite::mMutexPos; }
+};
+
+// void MapPoint::UpdateNormalAndDepth() (src/MapPoint.cc:424-480) for all points of a write-back as ONE call
+// (vieo_update_normal_and_depth_batch) instead of one host call per point: the observations' camera centres
+// (GetCameraCenter() + Rcrw^T Trc.translation() of the observing camera, :447-451) are gathered once per (key frame,
+// camera), the mean viewing direction and the two scale-invariance distances come back, and the members are written
+// under the point's own lock as the reference does (:474-479).  Points that are bad or have no observation are skipped
+// as there (:431,:437).
+void update_normal_and_depth(const std::vector<MapPoint*>& pts) {
+  std::vector<MapPoint*> live;
+  std::vector<float> X, centres, ref_scale;
+  std::vector<int32_t> first(1, 0), obs_centre, ref_centre;
+  std::map<std::pair<KeyFrame*, size_t>, int> centre_of;
+  auto centre = [&](KeyFrame* pKF, size_t cami) -> int {
+    auto it = centre_of.find(std::make_pair(pKF, cami));
+    if (it != centre_of.end()) return it->second;
+    const cv::Mat Ow = pKF->GetCameraCenter();
+    double c[3] = {Ow.at<float>(0, 0), Ow.at<float>(1, 0), Ow.at<float>(2, 0)};
+    if (pKF->mpCameras.size() > cami) {  // twc += Rcrw^T * Trc.translation()
+      const cv::Mat R = pKF->GetRotation();
+      const auto t = pKF->mpCameras[cami]->GetTrc().translation();
+      for (int r = 0; r < 3; ++r)
+        c[r] += (double)R.at<float>(0, r) * t(0) + (double)R.at<float>(1, r) * t(1) + (double)R.at<float>(2, r) * t(2);
+    }
+    const int id = (int)(centres.size() / 3);
+    for (int r = 0; r < 3; ++r) centres.push_back((float)c[r]);
+    centre_of[std::make_pair(pKF, cami)] = id;
+    return id;
+  };
+  float scale_last = 1.f;
+  for (MapPoint* pMP : pts) {
+    if (!pMP || pMP->isBad()) continue;
+    const std::map<KeyFrame*, std::set<size_t>> observations = pMP->GetObservations();
+    KeyFrame* pRef = pMP->GetReferenceKeyFrame();
+    if (observations.empty() || !pRef) continue;
+    auto ref_it = observations.find(pRef);
+    if (ref_it == observations.end() || ref_it->second.empty()) continue;  // (CV_Assert in the reference, :466)
+    for (auto mit = observations.begin(); mit != observations.end(); ++mit)
+      for (size_t idx : mit->second) {
+        KeyFrame* pKF = mit->first;
+        const size_t cami = pKF->mapn2in_.size() <= idx ? 0 : std::get<0>(pKF->mapn2in_[idx]);
+        obs_centre.push_back(centre(pKF, cami));
+      }
+    first.push_back((int32_t)obs_centre.size());
+    const auto P = pMP->GetWorldPos();
+    X.push_back(P(0)), X.push_back(P(1)), X.push_back(P(2));
+    // the reference key frame's own centre (camera 0: GetCameraCenter(), :461) and the scale of the key's level (:467-468)
+    ref_centre.push_back(centre(pRef, (size_t)-1));
+    const int level = pRef->mvKeys[*ref_it->second.begin()].octave;
+    ref_scale.push_back(pRef->scalepyrinfo_.vscalefactor_[level]);
+    scale_last = pRef->scalepyrinfo_.vscalefactor_.back();
+    live.push_back(pMP);
+  }
+  if (live.empty()) return;
+  const int n = (int)live.size();
+  std::vector<float> nrm(3 * (size_t)n), dmax(n), dmin(n);
+  HOT_CHECK(vieo_update_normal_and_depth_batch(X.data(), first.data(), obs_centre.data(), centres.data(), (int)(centres.size() / 3),
+                                               ref_centre.data(), ref_scale.data(), scale_last, n, nrm.data(), dmax.data(), dmin.data()));
+  for (int i = 0; i < n; ++i) {
+    MapPoint* pMP = live[i];
+    auto& ti = pMP->GetTrackInfoRef();
+    if (INFINITY == ti.track_depth_) ti.track_depth_ = dmax[i] / ref_scale[i];  // dist (:463-464)
+    std::unique_lock<std::mutex> lock(pMP->*MapPointWrite::mutex_pos());
+    MapPoint::Vector3data& N = pMP->*MapPointWrite::normal();
+    N(0) = nrm[3 * i], N(1) = nrm[3 * i + 1], N(2) = nrm[3 * i + 2];
+    pMP->*MapPointWrite::max_distance() = dmax[i];
+    pMP->*MapPointWrite::min_distance() = dmin[i];
+  }
+}
+
 // Optimizer.cc:704-768 / :2251-2300 with the map lock held by the caller
 void write_back(Window& W, const std::vector<vieo_navstate>& navs, const std::vector<float>& Xo,
                 const std::vector<uint8_t>& erase, bool vio) {
@@ -300,8 +379,8 @@ void write_back(Window& W, const std::vector<vieo_navstate>& navs, const std::ve
     MapPoint::Vector3data Pos;
     Pos(0) = Xo[3 * m], Pos(1) = Xo[3 * m + 1], Pos(2) = Xo[3 * m + 2];
     W.mp_ptr[m]->SetWorldPos(Pos);
-    W.mp_ptr[m]->UpdateNormalAndDepth();
   }
+  update_normal_and_depth(W.mp_ptr);
 }
 
 }  // namespace
@@ -519,6 +598,247 @@ void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap
   std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);  // :2270
   write_back(W, navs, Xo, erase, false);
   pMap->InformNewChange();
+}
+
+// ================================================================ the full bundle adjustments
+namespace {
+
+// every good key frame (vertex order = nid_ order, as g2o's ids give it), every good point with an observation in one of
+// them, the observations in the reference's insertion order (point by point, std::map order over the key frames, key
+// index order): Optimizer.cc:808-842,1060-1222 / :1375-1535
+struct FullMap {
+  Window W;
+  std::vector<size_t> mp_index;  // point m of the flattened problem is vpMP[mp_index[m]]
+  std::map<KeyFrame*, int> kf_index;
+  bool bdimPoses = false;
+};
+
+void flatten_map(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, bool vio, FullMap& M) {
+  std::vector<KeyFrame*> kfs;
+  for (KeyFrame* k : vpKFs)
+    if (k && !k->isBad()) kfs.push_back(k);
+  std::sort(kfs.begin(), kfs.end(), [](KeyFrame* a, KeyFrame* b) { return a->nid_ < b->nid_; });
+  for (KeyFrame* k : kfs) {
+    vieo_lba_keyframe r;
+    std::memset(&r, 0, sizeof(r));
+    if (!vio) k->UpdateNavStatePVRFromTcw();  // :1386
+    vieo_shim::to_pod(k->GetNavState(), r.nav);
+    r.fixed = k->nid_ == 0;
+    if (!r.fixed) M.bdimPoses = true;
+    M.kf_index[k] = (int)M.W.kfs.size();
+    M.W.kfs.push_back(r), M.W.kf_ptr.push_back(k);
+  }
+  M.W.n_local = M.W.kfs.size();
+  const bool distort = Frame::usedistort_;
+  for (size_t i = 0; i < vpMP.size(); ++i) {
+    MapPoint* pMP = vpMP[i];
+    if (!pMP || pMP->isBad()) continue;
+    const std::map<KeyFrame*, std::set<size_t>> observations = pMP->GetObservations();
+    const size_t obs0 = M.W.obs.size();
+    const int m = (int)M.W.mp_ptr.size();
+    for (auto mit = observations.begin(); mit != observations.end(); ++mit) {
+      KeyFrame* pKFi = mit->first;
+      auto it = M.kf_index.find(pKFi);
+      if (it == M.kf_index.end()) continue;  // bad key frame / not part of this problem
+      for (size_t idx : mit->second) {
+        const cv::KeyPoint& kp = !distort ? pKFi->mvKeysUn[idx] : pKFi->mvKeys[idx];
+        vieo_lba_obs o;
+        o.kf = it->second, o.mp = m;
+        if (distort && pKFi->mapn2in_.size() > idx) o.kf |= (int)std::get<0>(pKFi->mapn2in_[idx]) << 24;
+        o.u = kp.pt.x, o.v = kp.pt.y, o.ur = pKFi->stereoinfo_.vuright_[idx];
+        o.inv_sigma2 = pKFi->scalepyrinfo_.vinvlevelsigma2_[kp.octave];
+        M.W.obs.push_back(o), M.W.obs_kf.push_back(pKFi), M.W.obs_mp.push_back(pMP);
+      }
+    }
+    if (M.W.obs.size() == obs0) continue;  // nEdges == 0: the vertex is removed, vbNotIncludedMP (:1225-1231)
+    M.W.mp_ptr.push_back(pMP), M.mp_index.push_back(i);
+    const auto Xw = pMP->GetWorldPos();
+    M.W.X.push_back(Xw(0)), M.W.X.push_back(Xw(1)), M.W.X.push_back(Xw(2));
+  }
+}
+
+// Tcw (4 x 4, CV_32F) of a body state: Tcb * Twb^-1 (Optimizer.cc:1284-1296 / :1569-1577)
+cv::Mat tcw_of(const vieo_navstate& n) {
+  const double w = n.q[0], x = n.q[1], y = n.q[2], z = n.q[3];
+  const double Rwb[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
+                         2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+  cv::Mat T(4, 4, CV_32F);
+  for (int r = 0; r < 3; ++r) {
+    double t = Frame::meigtcb(r);
+    for (int c = 0; c < 3; ++c) {
+      double v = 0;
+      for (int k = 0; k < 3; ++k) v += Frame::meigRcb(r, k) * Rwb[c * 3 + k];  // Rcw = Rcb * Rwb^T
+      T.at<float>(r, c) = (float)v;
+      t -= v * n.p[c];
+    }
+    T.at<float>(r, 3) = (float)t;
+  }
+  for (int c = 0; c < 4; ++c) T.at<float>(3, c) = c == 3 ? 1.f : 0.f;
+  return T;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- Optimizer.cc:771-1345
+int Optimizer::GlobalBundleAdjustmentNavStatePRV(Map* pMap, const cv::Mat& cvgw, int nIterations, bool* pbStopFlag,
+                                                 const unsigned long nLoopKF, const bool bRobust, bool bScaleOpt,
+                                                 IMUInitialization* pimu_initiator) {
+  if (pimu_initiator) {
+    // The IMU initialiser's form adds a gravity-direction vertex (VertexGThetaXYRwI, EdgeNavStatePRVG, a bias prior:
+    // Optimizer.cc:852-905,954-972) that the C-ABI does not carry (IMU initialisation is out of scope).
+    // INTEGRATION.md 4 keeps the reference's definition for that caller under the name below.
+#ifdef VIEO_HOT_KEEPS_INIT_GBA
+    return GlobalBundleAdjustmentNavStatePRVInit(pMap, cvgw, nIterations, pbStopFlag, nLoopKF, bRobust, bScaleOpt, pimu_initiator);
+#else
+    hot_fail("GlobalBundleAdjustmentNavStatePRV with pimu_initiator (build with VIEO_HOT_KEEPS_INIT_GBA, INTEGRATION.md 4)", VIEO_E_INVALID);
+#endif
+  }
+  const std::vector<KeyFrame*> vpKFs = pMap->GetAllKeyFrames();
+  const std::vector<MapPoint*> vpMP = pMap->GetAllMapPoints();
+  FullMap M;
+  flatten_map(vpKFs, vpMP, true, M);
+  Window& W = M.W;
+  const int nInitialCorrespondences = (int)W.obs.size();
+  // inertial + bias (+ encoder) edges between consecutive good key frames (:923-1057)
+  std::vector<vieo_lba_imu_edge> imu;
+  for (KeyFrame* pKF1 : W.kf_ptr) {
+    KeyFrame* pKF0 = pKF1->GetPrevKeyFrame();
+    if (!pKF0) continue;
+    auto it0 = M.kf_index.find(pKF0);
+    if (it0 == M.kf_index.end()) continue;
+    vieo_lba_imu_edge e;
+    std::memset(&e, 0, sizeof(e));
+    e.kf_i = it0->second, e.kf_j = M.kf_index[pKF1];
+    e.dt_kf = pKF1->ftimestamp_ - pKF0->ftimestamp_;
+    vieo_shim::to_pod(pKF1->GetIMUPreInt(), true, e.imu);
+    vieo_shim::to_pod(pKF1->GetEncPreInt(), e.enc);
+    imu.push_back(e);
+  }
+  std::vector<vieo_navstate> navs(W.kfs.size());
+  std::vector<float> Xo(W.X.size());
+  double scale = 1.0;
+  if ((M.bdimPoses || bScaleOpt) && !W.kfs.empty()) {  // :850, :1236
+    vieo_lba_vio_params P;
+    std::memset(&P, 0, sizeof(P));
+    fill_lba_params(W.kf_ptr[0], 0, 0, W, P.base);
+    for (int i = 0; i < 3; ++i) P.gw[i] = cvgw.at<float>(i, 0);
+    P.inv_sigma_bg2 = IMUDataBase::mInvSigmabg2, P.inv_sigma_ba2 = IMUDataBase::mInvSigmaba2;
+    vieo_shim::tbe_to_pod(Frame::mTbc, Frame::mTce, P.qRbe, P.pbe);
+    vieo_lba_result r;
+    StopMirror stop(pbStopFlag);
+    HOT_CHECK(vieo_global_bundle_adjustment_vio_scale(&P, nIterations, bRobust ? 1 : 0, bScaleOpt ? 1 : 0, W.kfs.data(), (int)W.kfs.size(),
+                                                      W.X.data(), (int)W.mp_ptr.size(), W.obs.data(), (int)W.obs.size(), imu.data(),
+                                                      (int)imu.size(), stop.ptr(), navs.data(), Xo.data(), &r, &scale));
+  } else {  // nothing to optimise: the estimates are written back as they are
+    for (size_t k = 0; k < W.kfs.size(); ++k) navs[k] = W.kfs[k].nav;
+    Xo = W.X;
+  }
+  std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate, std::defer_lock);
+  if (nLoopKF == 0) lock.lock();  // :1238-1241
+  for (size_t k = 0; k < W.kf_ptr.size(); ++k) {
+    KeyFrame* pKFi = W.kf_ptr[k];
+    NavState ns = pKFi->GetNavState();
+    vieo_shim::from_pod(navs[k], ns);  // PR, V, dbg / dba (ns_recov, :1270-1276)
+    if (nLoopKF == 0)
+      pKFi->SetNavState(ns);
+    else {
+      pKFi->mNavStateGBA = ns;
+      pKFi->mTcwGBA = tcw_of(navs[k]);
+      pKFi->mnBAGlobalForKF = nLoopKF;
+    }
+  }
+  std::vector<MapPoint*> moved;
+  for (size_t m = 0; m < W.mp_ptr.size(); ++m) {  // (the points come back as (float)scale * (float)Xh already, :1321)
+    MapPoint* pMP = W.mp_ptr[m];
+    if (pMP->isBad()) continue;
+    MapPoint::Vector3data Pos;
+    Pos(0) = Xo[3 * m], Pos(1) = Xo[3 * m + 1], Pos(2) = Xo[3 * m + 2];
+    if (nLoopKF == 0) {
+      pMP->SetWorldPos(Pos);
+      moved.push_back(pMP);
+    } else {
+      pMP->mPosGBA = Pos;
+      pMP->mnBAGlobalForKF = nLoopKF;
+    }
+  }
+  update_normal_and_depth(moved);
+  return nInitialCorrespondences;
+}
+
+// ---------------------------------------------------------------- Optimizer.cc:1353-1609
+void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations,
+                                 bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust, const bool bEnc) {
+  FullMap M;
+  flatten_map(vpKFs, vpMP, false, M);
+  Window& W = M.W;
+  if (W.kfs.empty()) return;
+  std::vector<vieo_lba_enc_edge> enc_edges;
+  if (bEnc)  // EdgeEncNavStatePR between consecutive key frames (:1400-1445)
+    for (KeyFrame* pKF1 : W.kf_ptr) {
+      KeyFrame* pKF0 = pKF1->GetPrevKeyFrame();
+      if (!pKF0) continue;
+      auto it0 = M.kf_index.find(pKF0);
+      if (it0 == M.kf_index.end()) continue;
+      vieo_lba_enc_edge e;
+      std::memset(&e, 0, sizeof(e));
+      e.kf_i = it0->second, e.kf_j = M.kf_index[pKF1];
+      vieo_shim::to_pod(pKF1->GetEncPreInt(), e.enc);
+      if (e.enc.dt != 0) enc_edges.push_back(e);
+    }
+  std::vector<vieo_navstate> navs(W.kfs.size());
+  std::vector<float> Xo(W.X.size());
+  if (M.bdimPoses) {  // :1550
+    vieo_lba_params P;
+    fill_lba_params(W.kf_ptr[0], 0, 0, W, P);
+    vieo_lba_enc E;
+    std::memset(&E, 0, sizeof(E));
+    E.n_edges = (int)enc_edges.size(), E.edges = enc_edges.data();
+    vieo_shim::tbe_to_pod(Frame::mTbc, Frame::mTce, E.qRbe, E.pbe);
+    vieo_lba_result r;
+    StopMirror stop(pbStopFlag);
+    HOT_CHECK(vieo_bundle_adjustment_enc(&P, nIterations, bRobust ? 1 : 0, W.kfs.data(), (int)W.kfs.size(), W.X.data(), (int)W.mp_ptr.size(),
+                                         W.obs.data(), (int)W.obs.size(), enc_edges.empty() ? nullptr : &E, stop.ptr(), navs.data(), Xo.data(),
+                                         &r));
+  } else {
+    for (size_t k = 0; k < W.kfs.size(); ++k) navs[k] = W.kfs[k].nav;
+    Xo = W.X;
+  }
+  for (size_t k = 0; k < W.kf_ptr.size(); ++k) {  // :1555-1580 (no map lock in the reference)
+    KeyFrame* pKF = W.kf_ptr[k];
+    if (nLoopKF == 0) {
+      NavState ns = pKF->GetNavState();
+      NavState pr = ns;
+      vieo_shim::from_pod(navs[k], pr);
+      ns.mpwb = pr.mpwb, ns.mRwb = pr.mRwb;  // VertexNavStatePR: pose only
+      pKF->SetNavState(ns);
+    } else {
+      pKF->mTcwGBA = tcw_of(navs[k]);
+      pKF->mnBAGlobalForKF = nLoopKF;
+    }
+  }
+  std::vector<MapPoint*> moved;
+  for (size_t m = 0; m < W.mp_ptr.size(); ++m) {
+    MapPoint* pMP = W.mp_ptr[m];
+    if (pMP->isBad()) continue;
+    MapPoint::Vector3data Pos;
+    Pos(0) = Xo[3 * m], Pos(1) = Xo[3 * m + 1], Pos(2) = Xo[3 * m + 2];
+    if (nLoopKF == 0) {
+      pMP->SetWorldPos(Pos);
+      moved.push_back(pMP);
+    } else {
+      pMP->mPosGBA = Pos;
+      pMP->mnBAGlobalForKF = nLoopKF;
+    }
+  }
+  update_normal_and_depth(moved);
+}
+
+// ---------------------------------------------------------------- Optimizer.cc:1346-1351
+void Optimizer::GlobalBundleAdjustment(Map* pMap, int nIterations, bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust,
+                                       const bool bEnc) {
+  const std::vector<KeyFrame*> vpKFs = pMap->GetAllKeyFrames();
+  const std::vector<MapPoint*> vpMP = pMap->GetAllMapPoints();
+  BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust, bEnc);
 }
 
 }  // namespace VIEO_SLAM

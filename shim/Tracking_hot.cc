@@ -6,6 +6,8 @@
 //   bool Tracking::TrackLocalMapWithIMU(bool bMapUpdated)   src/Tracking.cc:453-547
 //   bool Tracking::TrackWithMotionModel()                   src/Tracking.cc:1843-1922   (stereo without IMU, configs[0])
 //   bool Tracking::TrackLocalMap()                          src/Tracking.cc:1924-2008
+//   void Tracking::SearchLocalPoints()                      src/Tracking.cc:2308-2370   (the member-by-member path: Frame::isInFrustum
+//                                                                                        of all local points as ONE call)
 //
 // compiled inside the reference tree against its own include/Tracking.h (declarations untouched; the four members are
 // compiled out of src/Tracking.cc with `#ifndef VIEO_HOT`).  This is the path that changes the
@@ -631,6 +633,109 @@ bool Tracking::TrackLocalMap() {
                       (!mpIMUInitiator->GetVINSInited() || mbRelocBiasPrepare) && !mVelocity.empty();
   defer_all(mpORBextractors, ok && steady);
   return ok;
+}
+
+// ---------------------------------------------------------------- src/Tracking.cc:2308-2370
+// The loop `for (pMP : mvpLocalMapPoints) if (mCurrentFrame.isInFrustum(pMP, 0.5)) ...` as one vieo_is_in_frustum_batch call
+// (Frame::isInFrustum, src/Frame.cc:335-416, per point on the device); what the member writes into the point's
+// TrackFastMatchInfo is written here from the call's records, in the same push order.
+void Tracking::SearchLocalPoints() {
+  const auto& curfmps = mCurrentFrame.GetMapPointMatches();
+  for (size_t i = 0; i < curfmps.size(); ++i) {  // :2313-2327
+    MapPoint* pMP = curfmps[i];
+    if (!pMP) continue;
+    if (pMP->isBad())
+      mCurrentFrame.EraseMapPointMatch(i);
+    else {
+      pMP->IncreaseVisible();
+      pMP->GetTrackInfoRef().Reset(&mCurrentFrame);
+    }
+  }
+  std::vector<MapPoint*> cand;
+  cand.reserve(mvpLocalMapPoints.size());
+  for (MapPoint* pMP : mvpLocalMapPoints) {  // :2332-2337
+    if (pMP->GetTrackInfoRef().last_seen_frameid_ == mCurrentFrame.nid_) continue;
+    if (pMP->isBad()) continue;
+    cand.push_back(pMP);
+  }
+  int nToMatch = 0;
+  if (!cand.empty()) {
+    Frame& F = mCurrentFrame;
+    const int nc = F.mpCameras.empty() ? 1 : (int)F.mpCameras.size();
+    if (nc > 4) hot_fail("SearchLocalPoints: at most 4 cameras", VIEO_E_INVALID);
+    vieo_frustum_frame B;
+    std::memset(&B, 0, sizeof(B));
+    const cv::Mat& Tcw = F.GetTcwRef();  // CV_32F (Frame.cc:346-349 reads it through double and back: the same floats)
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) B.Rcrw[r * 3 + c] = Tcw.at<float>(r, c);
+      B.tcrw[r] = Tcw.at<float>(r, 3);
+    }
+    const cv::Mat Ow = F.GetCameraCenter();
+    for (int r = 0; r < 3; ++r) B.Ow[r] = Ow.at<float>(r, 0);
+    B.n_cams = nc, B.use_distort = Frame::usedistort_ ? 1 : 0;
+    vieo_camera cams[4];
+    const Eigen::Matrix3d I = Eigen::Matrix3d::Identity();
+    const Eigen::Vector3d z = Eigen::Vector3d::Zero();
+    for (int c = 0; c < nc; ++c) {
+      if (!vieo_shim::to_pod(F.mpCameras[c].get(), I, z, cams[c])) hot_fail("camera model", VIEO_E_INVALID);
+      {
+        const auto Tcr = F.mpCameras[c]->GetTcr();
+        const auto R = Tcr.rotationMatrix();
+        const auto t = Tcr.translation();
+        for (int r = 0; r < 3; ++r) {
+          for (int k = 0; k < 3; ++k) B.Tcr[c][r * 4 + k] = R(r, k);
+          B.Tcr[c][r * 4 + 3] = t(r);
+        }
+      }
+      const auto trc = F.mpCameras[c]->GetTrc().translation();
+      for (int k = 0; k < 3; ++k) B.trc[c][k] = trc(k);
+      for (int k = 0; k < 4; ++k) B.bounds[c][k] = vieo_shim::GridAccess::bounds()[c][k];
+    }
+    B.cams = cams;
+    B.bf = F.stereoinfo_.baseline_bf_[1];
+    B.log_scale_factor = F.scalepyrinfo_.flogscalefactor_;
+    B.n_levels = (int)F.scalepyrinfo_.vscalefactor_.size();
+    B.viewing_cos_limit = 0.5f;
+    std::vector<vieo_frustum_point> pts(cand.size());
+    for (size_t j = 0; j < cand.size(); ++j) {
+      MapPoint* p = cand[j];
+      const auto X = p->GetWorldPos();
+      const auto nrm = p->GetNormal();
+      for (int r = 0; r < 3; ++r) pts[j].Xw[r] = X(r), pts[j].normal[r] = nrm(r);
+      pts[j].max_distance = p->*MapPointAccess::max_distance();
+      pts[j].min_distance = p->*MapPointAccess::min_distance();
+    }
+    std::vector<vieo_track_info> info(cand.size());
+    HOT_CHECK(vieo_is_in_frustum_batch(&B, pts.data(), (int)pts.size(), info.data()));
+    for (size_t j = 0; j < cand.size(); ++j) {
+      auto& ti = cand[j]->GetTrackInfoRef();
+      ti.Reset();
+      const vieo_track_info& T = info[j];
+      for (int k = 0; k < T.n; ++k) {  // Frame.cc:399-406
+        ti.vtrack_proj_[0].push_back(T.u[k]);
+        ti.vtrack_proj_[1].push_back(T.v[k]);
+        ti.vtrack_proj_[2].push_back(T.ur[k]);
+        ti.vtrack_scalelevel_.push_back(T.level[k]);
+        ti.vtrack_viewcos_.push_back(T.viewcos[k]);
+        ti.vtrack_cami_.push_back((size_t)T.cam[k]);
+      }
+      if (T.n > 0) ti.track_depth_ = T.track_depth;
+      ti.btrack_inview_ = T.n > 0;
+      if (T.n > 0) {
+        cand[j]->IncreaseVisible();
+        ++nToMatch;
+      }
+    }
+  }
+  if (nToMatch > 0) {  // :2346-2367
+    ORBmatcher matcher(0.8);
+    int th = 1;
+    if (mSensor == System::RGBD) th = 3;
+    if (mpIMUInitiator->GetVINSInited()) th = 2;
+    if (mCurrentFrame.nid_ < mnLastRelocFrameId + 2) th = 5;
+    if (ODOMOK == mState) th = 15;
+    nToMatch = matcher.SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th, mpLocalMapper->th_far_pts_);
+  }
 }
 
 }  // namespace VIEO_SLAM

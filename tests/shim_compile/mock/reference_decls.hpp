@@ -35,6 +35,7 @@ namespace VIEO_SLAM {
 using std::set;
 using std::vector;
 using Eigen::aligned_list;
+#define listeig(EncData) Eigen::aligned_list<EncData>
 using Eigen::aligned_vector;
 using Eigen::Vector3d;
 class ORBVocabulary;
@@ -65,16 +66,27 @@ class EncPreIntegrator {
   Vector6d mdelxEij;
   Matrix6d mSigmaEij;
 };
-class IMUPreintegrator {
+// src/Odom/OdomPreIntegrator.h, reduced: the pre-integrator is a class template over the sample type
+template <class _OdomData>
+class OdomPreIntegratorBase {
  public:
-  aligned_list<IMUData>& GetRawDataRef();
-  const aligned_list<IMUData>& GetRawDataRef() const;
+  aligned_list<_OdomData>& GetRawDataRef();
+  const aligned_list<_OdomData>& GetRawDataRef() const;
   double mdeltatij;
+};
+template <class IMUDataBase>
+class IMUPreIntegratorBase : public OdomPreIntegratorBase<IMUDataBase> {
+ public:
   Eigen::Matrix3d mRij;
   Eigen::Vector3d mvij, mpij;
   Matrix9d mSigmaijPRV, mSigmaij;
   Eigen::Matrix3d mJgpij, mJapij, mJgvij, mJavij, mJgRij;
+  int PreIntegration(const double& timeStampi, const double& timeStampj, const Eigen::Vector3d& bgi_bar, const Eigen::Vector3d& bai_bar,
+                     const typename listeig(IMUDataBase)::const_iterator& iterBegin,
+                     const typename listeig(IMUDataBase)::const_iterator& iterEnd, bool breset = true);
+  void reset();
 };
+typedef IMUPreIntegratorBase<IMUDataBase> IMUPreintegrator;
 
 namespace camm {
 class GeometricCamera {
@@ -179,6 +191,7 @@ class Frame : public FrameBase {
   const IMUPreintegrator& GetIMUPreInt(void) const;
   void UpdatePoseFromNS();
   void UpdateNavStatePVRFromTcw();
+  cv::Mat GetCameraCenter();
   vector<MapPoint*>& GetMapPointsRef();
   vector<bool> mvbOutlier;
   cv::Mat& GetTcwRef();
@@ -208,6 +221,10 @@ class KeyFrame : public FrameBase {
   void FuseMP(size_t idx, MapPoint* pMP);
   vector<KeyFrame*> GetVectorCovisibleKeyFrames();
   unsigned long mnBALocalForKF, mnBAFixedForKF;
+  void UpdateNavStatePVRFromTcw();
+  NavState mNavStateGBA;
+  cv::Mat mTcwGBA;
+  unsigned long mnBAGlobalForKF;
 };
 
 class MapPoint {
@@ -243,17 +260,24 @@ class MapPoint {
   TrackFastMatchInfo& GetTrackInfoRef();
   void IncreaseFound(int n = 1);
   void IncreaseVisible(int n = 1);
+  KeyFrame* GetReferenceKeyFrame();
+  Vector3data mPosGBA;
+  unsigned long mnBAGlobalForKF;
   unsigned long mnId, mnBALocalForKF;
   static std::mutex mGlobalMutex;
 
  protected:
   float mfMinDistance, mfMaxDistance;
+  Vector3data mNormalVector;
+  std::mutex mMutexPos;
 };
 
 class Map {
  public:
   void InformNewChange();
   int GetLastChangeIdx();
+  std::vector<KeyFrame*> GetAllKeyFrames();
+  std::vector<MapPoint*> GetAllMapPoints();
   std::mutex mMutexMapUpdate;
 };
 
@@ -286,6 +310,7 @@ class ORBmatcher {
   bool mbCheckOrientation;
 };
 
+class IMUInitialization;
 class Optimizer {
  public:
   template <class KeyFrame>
@@ -296,6 +321,14 @@ class Optimizer {
                                                float th_dist_far = INFINITY);
   void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int Nlocal = 0);
   int static PoseOptimization(Frame* pFrame, Frame* pLastF = NULL);
+  int static GlobalBundleAdjustmentNavStatePRV(Map* pMap, const cv::Mat& gw, int nIterations = 5, bool* pbStopFlag = NULL,
+                                               const unsigned long nLoopKF = 0, const bool bRobust = true, bool bScaleOpt = false,
+                                               IMUInitialization* pimu_initator = nullptr);
+  void static BundleAdjustment(const std::vector<KeyFrame*>& vpKF, const std::vector<MapPoint*>& vpMP, int nIterations = 5,
+                               bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true,
+                               const bool bEnc = false);
+  void static GlobalBundleAdjustment(Map* pMap, int nIterations = 5, bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0,
+                                     const bool bRobust = true, const bool bEnc = false);
 };
 // what INTEGRATION.md section 4 adds to include/Optimizer.h in place of the template's body
 template <>

@@ -14,7 +14,7 @@ INC = ["-I" + MOCK, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(RO
 
 
 @pytest.mark.parametrize("src", ["shim/ORBmatcher_hot.cc", "shim/Optimizer_hot.cc", "shim/Frame_hot.cc", "shim/Tracking_hot.cc",
-                                 "tests/shim_compile/use_extractor_shim.cc"])
+                                 "shim/OdomPreIntegrator_hot.cc", "tests/shim_compile/use_extractor_shim.cc"])
 def test_shim_translation_unit_type_checks(src):
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror"] + INC + [os.path.join(ROOT, src)],
                        capture_output=True, text=True)
@@ -35,8 +35,14 @@ def test_shims_define_every_replaced_member():
                 "int Optimizer::PoseOptimization<Frame>(", "int Optimizer::PoseOptimization<KeyFrame>(",
                 "void Optimizer::LocalBundleAdjustmentNavStatePRV(KeyFrame* pKF, int Nlocal, bool* pbStopFlag, Map* pMap",
                 "void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int Nlocal)",
-                "MapPoint::mGlobalMutex", "pMap->mMutexMapUpdate", "pbStopFlag"):
+                "MapPoint::mGlobalMutex", "pMap->mMutexMapUpdate", "pbStopFlag",
+                # round 6: the full BAs and the batched UpdateNormalAndDepth of every write-back (8f-3)
+                "int Optimizer::GlobalBundleAdjustmentNavStatePRV(Map* pMap, const cv::Mat& cvgw, int nIterations, bool* pbStopFlag",
+                "void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations",
+                "void Optimizer::GlobalBundleAdjustment(Map* pMap, int nIterations, bool* pbStopFlag",
+                "vieo_global_bundle_adjustment_vio_scale", "vieo_bundle_adjustment_enc", "vieo_update_normal_and_depth_batch"):
         assert sig in o, sig
+    assert "->UpdateNormalAndDepth()" not in o  # (no per-point host call is left in a write-back)
     f = open(os.path.join(ROOT, "shim", "Frame_hot.cc")).read()
     for sig in ("void Frame::ComputeStereoMatches()", "void Frame::ComputeStereoFishEyeMatches(const float th_far_pts)",
                 "vieo_stereo_match_rectified_resident", "vieo_stereo_fisheye_match", "vieo_orb_holds"):
@@ -44,8 +50,13 @@ def test_shims_define_every_replaced_member():
     t = open(os.path.join(ROOT, "shim", "Tracking_hot.cc")).read()
     for sig in ("bool Tracking::TrackWithIMU(bool bMapUpdated)", "bool Tracking::TrackLocalMapWithIMU(bool bMapUpdated)",
                 "bool Tracking::TrackWithMotionModel()", "bool Tracking::TrackLocalMap()", "vieo_track_frame",
-                "vieo_tracker_create_rig", "P.vision_only"):
+                "vieo_tracker_create_rig", "P.vision_only",
+                "void Tracking::SearchLocalPoints()", "vieo_is_in_frustum_batch", "IncreaseVisible", "GetLastChangeIdx", "ensure_mode"):
         assert sig in t, sig
+    pi = open(os.path.join(ROOT, "shim", "OdomPreIntegrator_hot.cc")).read()
+    for sig in ("int IMUPreIntegratorBase<IMUDataBase>::PreIntegration(const double& timeStampi, const double& timeStampj",
+                "vieo_imu_preintegrate_batch", "VIEO_PREINT_GAP"):
+        assert sig in pi, sig
     # the resident frame is what the matcher shim tries first
     for sig in ("vieo_search_by_projection_last_frame_resident", "vieo_search_by_projection_resident", "vieo_orb_holds"):
         assert sig in m, sig
