@@ -1879,6 +1879,11 @@ static PoseXchg* vio_xchg_records(hipStream_t stream, int n_frames, unsigned* la
   for (Rec& r : recs.v)
     if (r.st == stream && r.dev == dev) {
       *launch_id = ++r.launches;
+      // A granule's tag carries 20 bits of the launch number, and not every slot is rewritten by every launch (the records
+      // of frames a call does not have, launches whose frames stay below kVioReplicaMinObs): before the number wraps, the
+      // records are zeroed on the launch stream -- tag 0 is never used -- so a granule left 2^20 launches ago cannot be
+      // taken for a fresh one.
+      if ((r.launches & 0x7FFFFu) == 0 && r.p) (void)hipMemsetAsync(r.p, 0, sizeof(PoseXchg) * r.n, stream);
       if (r.n >= n_frames) return r.p;
       (void)hipStreamSynchronize(stream);
       (void)hipFree(r.p);

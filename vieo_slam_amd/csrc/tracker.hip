@@ -769,8 +769,12 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   const uint8_t* imgs[4] = {in->left, in->right, nullptr, nullptr};
   if (t->rig)
     for (int c = 0; c < 4; c++) imgs[c] = in->images[c];
-  for (int c = 0; c < t->n_img; c++)
-    if (!imgs[c]) return VIEO_E_INVALID;
+  if (!in->use_prefetched)  // (a prefetched frame's images are not read: vieo_hot.h says they may be null then)
+    for (int c = 0; c < t->n_img; c++)
+      if (!imgs[c]) {
+        set_error("vieo_track_frame: image %d is null (only a call with use_prefetched = 1 may leave the images out)", c);
+        return VIEO_E_INVALID;
+      }
   const auto t_enter = std::chrono::steady_clock::now();
   const vieo_tracker_params& P = t->P;
   const int cap = t->cap, kc = t->kc, W = P.width, Hh = P.height;
@@ -1096,7 +1100,10 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     t->slow_run = (med > 0 && out->ms_gpu > 1.3f * med && !widened) ? t->slow_run + 1 : 0;
     t->gpu_ring[t->gpu_n % 32] = out->ms_gpu, t->gpu_n++;
     t->frames_since_check++;
-    if (t->slow_run >= 8 && t->frames_since_check >= 64) {
+    // (not while the next frame's extraction is still running on the prefetch stream: the probe's spin kernels would
+    // share the device with it, the ratio would be skewed and the side stream swapped for nothing -- it waits for a frame
+    // without a prefetch in flight)
+    if (t->slow_run >= 8 && t->frames_since_check >= 64 && !t->pref_valid) {
       (void)vieo_tracker_reprobe(t);
       t->frames_since_check = 0, t->slow_run = 0, t->gpu_n = 0;
     }
