@@ -192,3 +192,120 @@ def test_oracle_matches_committed_golden(oracle):
         assert mono == int(g[tag + "_mono"])
         assert np.array_equal(kps.view(np.uint8), g[tag + "_kps"].view(np.uint8))
         assert np.array_equal(desc, g[tag + "_desc"])
+
+
+# ---------------------------------------------------------------- round 6: the unpinned oracle tightened from the inside
+# (VERDICT r5 item 10).  None of this pins the oracle against a real OpenCV -- there is none in the image -- but it takes
+# "a typo in a constant" off the list: the constants are DERIVED here, not asserted as literals.
+
+def test_gaussian_taps_follow_from_sigma_by_error_diffusion(oracle):
+    """cv::GaussianBlur(8U, 7 x 7, sigma = 2) uses a Q8.8 kernel whose coefficients sum to exactly 256: the real-valued
+    kernel exp(-x^2 / (2 sigma^2)) / sum, scaled by 256 and rounded WITH the rounding error carried to the next tap
+    (plain rounding gives 18 34 49 55 49 34 18 = 257).  The oracle's impulse response must be that kernel's outer product
+    with the vertical pass's round-to-nearest."""
+    sigma, n = 2.0, 7
+    x = np.arange(n) - (n - 1) / 2
+    k = np.exp(-x * x / (2 * sigma * sigma))
+    k /= k.sum()
+    taps, err = [], 0.0
+    for i in range(n):
+        v = k[i] * 256 + err
+        t = int(math.floor(v + 0.5))
+        err = v - t
+        taps.append(t)
+    assert sum(taps) == 256 and taps == taps[::-1]
+    plain = [int(math.floor(v * 256 + 0.5)) for v in k]
+    assert sum(plain) != 256  # (the diffusion is what makes a constant image come out unchanged)
+    img = np.zeros((23, 23), np.uint8)
+    img[11, 11] = 200
+    out = oracle.blur(img)
+    for dy in range(-3, 4):
+        for dx in range(-3, 4):
+            assert out[11 + dy, 11 + dx] == (taps[dy + 3] * (200 * taps[dx + 3]) + 32768) >> 16, (dy, dx)
+
+
+def _resize_linear_8u(src, dw, dh):
+    """cv::resize(INTER_LINEAR, CV_8UC1) written out independently of oracle/ocv_prims.hpp from SURVEY.md Appendix A: float
+    source coordinates, 11-bit coefficients by round-half-even, the horizontal pass in int, the vertical pass
+    ((b0 (r0 >> 4)) >> 16) + ((b1 (r1 >> 4)) >> 16) + 2 >> 2."""
+    sh, sw = src.shape
+    def coeffs(sn, dn):
+        scale = sn / dn
+        idx, w0, w1 = [], [], []
+        for d in range(dn):
+            f = np.float32((d + 0.5) * scale - 0.5)
+            s = int(math.floor(f))
+            f = np.float32(f - s)
+            if s < 0:
+                s, f = 0, np.float32(0)
+            if s >= sn - 1:
+                s, f = sn - 1, np.float32(0)
+            idx.append(s)
+            w1.append(int(np.rint(np.float32(f * np.float32(2048)))))
+            w0.append(int(np.rint(np.float32((np.float32(1) - f) * np.float32(2048)))))
+        return idx, w0, w1
+    xi, xa, xb = coeffs(sw, dw)
+    yi, ya, yb = coeffs(sh, dh)
+    s = src.astype(np.int64)
+    rows = np.zeros((sh, dw), np.int64)
+    for d in range(dw):
+        rows[:, d] = s[:, xi[d]] * xa[d] + s[:, min(xi[d] + 1, sw - 1)] * xb[d]
+    out = np.zeros((dh, dw), np.uint8)
+    for d in range(dh):
+        r0, r1 = rows[yi[d]], rows[min(yi[d] + 1, sh - 1)]
+        out[d] = ((((ya[d] * (r0 >> 4)) >> 16) + ((yb[d] * (r1 >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+    return out
+
+
+def test_resize_ramps_at_the_seven_euroc_level_ratios(oracle):
+    """Level l + 1 is resized from level l (ORBextractor.cc:1070): the seven (source, destination) size pairs of a 752 x 480
+    image at scale 1.2.  On a linear ramp bilinear interpolation is exact up to the fixed-point rounding, and the whole plane
+    must equal the independent restatement above byte for byte (ramps in x, in y, and a random plane)."""
+    s, sizes = np.float32(1.0), []
+    for _ in range(8):
+        inv = np.float32(1.0) / s
+        sizes.append((int(np.rint(np.float32(752) * inv)), int(np.rint(np.float32(480) * inv))))
+        s = np.float32(s * np.float64(np.float32(1.2)))
+    assert sizes[0] == (752, 480) and sizes[-1] == (210, 134)
+    rng = np.random.default_rng(11)
+    for (sw, sh), (dw, dh) in zip(sizes[:-1], sizes[1:]):
+        rx = np.tile((np.arange(sw) * 255.0 / (sw - 1)).astype(np.uint8), (sh, 1))
+        ry = np.tile((np.arange(sh) * 255.0 / (sh - 1)).astype(np.uint8)[:, None], (1, sw))
+        rnd = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        for name, img in (("x ramp", rx), ("y ramp", ry), ("random", rnd)):
+            got = oracle.resize(img, dw, dh)
+            assert np.array_equal(got, _resize_linear_8u(img, dw, dh)), (name, sw, sh, dw, dh)
+        # the ramp itself: within one grey level of the real-valued interpolation of the (quantised) source ramp
+        xs = np.clip((np.arange(dw) + 0.5) * (sw / dw) - 0.5, 0, sw - 1)
+        expect = np.interp(xs, np.arange(sw), rx[0].astype(float))
+        assert np.abs(oracle.resize(rx, dw, dh)[dh // 2].astype(float) - expect).max() <= 1.0
+
+
+def test_fast_atan2_within_its_documented_accuracy_over_the_moment_range(oracle):
+    """IC_Angle feeds fastAtan2((float)m_01, (float)m_10) with integer moments of the radius-15 disc (|m| <= 255 x sum |u| over
+    the disc ~ 1.2e6).  cv::fastAtan2's documented accuracy is 0.3 degrees; the restated polynomial has to stay inside it on a
+    dense grid of small moments (where the quantisation is coarsest), on the same grid scaled up to the largest moments, and
+    along the octant boundaries where the polynomial's branches meet."""
+    def err(y, x):
+        ref = math.degrees(math.atan2(y, x)) % 360.0
+        d = abs(oracle.fast_atan2(float(y), float(x)) - ref)
+        return min(d, 360 - d)
+    worst = 0.0
+    for y in range(-120, 121):
+        for x in range(-120, 121):
+            if x == 0 and y == 0:
+                continue
+            worst = max(worst, err(y, x))
+    for scale in (97, 9973):  # up to ~1.2e6
+        for y in range(-120, 121, 3):
+            for x in range(-120, 121, 3):
+                if x or y:
+                    worst = max(worst, err(y * scale, x * scale + (y % 7)))
+    for m in (1, 2, 1000, 1199999):  # |x| = |y| and the axes: the branch boundaries
+        for sy in (-1, 1):
+            for sx in (-1, 1):
+                worst = max(worst, err(sy * m, sx * m), err(sy * m, sx * (m + 1)), err(sy * (m + 1), sx * m))
+        worst = max(worst, err(0, m), err(0, -m), err(m, 0), err(-m, 0))
+    assert worst < 0.3, worst
+    assert worst < 0.02, worst  # (what the polynomial actually achieves: an order of magnitude inside the documented bound)
+    assert oracle.fast_atan2(0.0, 0.0) == 0.0  # OpenCV returns 0 for the null vector
