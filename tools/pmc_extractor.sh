@@ -24,15 +24,19 @@ def read(c):
                 out[k] = (float(m.group(1)), int(m.group(2)))
     return out
 F, W = read("FETCH_SIZE"), read("WRITE_SIZE")
-names = {"fast": "k_fast", "blur": "k_blur", "pyramid": "k_resize", "describe": "k_describe", "quadtree": "k_quadtree"}
-launches = {"pyramid": 7, "quadtree": 2}  # k_quadtree: level 0 and the other levels are two launches (batches)
-# one counter row per launch (rocprofv3 sums the instances): the average over the rows is KB per launch
+names = {"fast": ["k_fast"], "blur": ["k_blur"], "pyramid": ["k_resize2", "k_resize"], "describe": ["k_describe_fused", "k_describe"], "quadtree": ["k_quadtree"]}
+CALLS = 3  # run_extract.py B 3: three extractions per run
+# one counter row per launch (rocprofv3 sums the instances): a kernel's average x its launches per extraction, summed over the
+# kernels of a stage (the pyramid is k_resize2 x 3 + k_resize x 1 since round 6) = KB per extraction
+def match(k, subs):  # (rocpd_pmc.py prints "vieo::k_name": the base name decides, exactly)
+    return k.split("::")[-1].split("<")[0].strip() in subs
 kern = {}
-for short, kn in names.items():
-    f = [v for k, v in F.items() if kn in k]
-    w = [v for k, v in W.items() if kn in k]
-    if f and w:
-        kern[short] = {"fetch_kb": f[0][0], "write_kb": w[0][0], "launches": launches.get(short, 1)}
+for short, subs in names.items():
+    f = sum(v[0] * v[1] / CALLS for k, v in F.items() if match(k, subs))
+    w = sum(v[0] * v[1] / CALLS for k, v in W.items() if match(k, subs))
+    n = sum(v[1] / CALLS for k, v in F.items() if match(k, subs))
+    if f or w:
+        kern[short] = {"fetch_kb": f, "write_kb": w, "launches": 1, "launches_per_extraction": n}
 out = {"how": "tools/pmc_extractor.sh: rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate "
               "passes) -- python tools/run_extract.py %d 3; per-kernel averages over the launches; KB per "
               "launch of %d images 752x480; HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024" % (B, B),

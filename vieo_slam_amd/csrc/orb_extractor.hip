@@ -115,6 +115,130 @@ k_resize(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab,
   }
 }
 
+// ---- two pyramid levels per launch (round 6).  The resize chain was 47 % of the extractor's HBM traffic: every level is
+// written, then read again as the next resize's source.  Here a workgroup produces a tile of level l + 1 (l = the second
+// level of the pair) from the tile of level l it has just computed and still holds in LDS: level l is read from HBM by
+// FAST and the descriptor kernel only, no longer by the resize, and the chain is 4 launches instead of 7.
+//   tile     kR2W x kR2H pixels of level l + 1;
+//   region   the level-l pixels its taps touch (rows [yt2[dy0].x, yt2[dy1 - 1].y], columns likewise, the left edge rounded
+//            down to a dword): at most 256 x kR2Rows, computed from level l - 1 exactly as k_resize does (same table-driven
+//            fixed point, same bytes) into LDS;
+//   owned    the part of the region that THIS workgroup writes to level l in HBM: from its region's start to the next
+//            tile's region start (dword-aligned in x, so no dword of the plane has two writers); neighbouring regions overlap
+//            by one or two rows / up to five columns, which are computed twice and written once.
+// The host plans the pairs (orb_plan) and keeps k_resize for a last odd level and for geometries whose regions do not fit.
+static const int kR2W = 200, kR2H = 26, kR2Rows = 36;
+__global__ void __launch_bounds__(256, 4)
+k_resize2(OrbParams P, int l, ImgSet I, const short4* __restrict__ xtab, const short4* __restrict__ ytab, int lds_pitch,
+          int l1_off) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* l1 = smem + l1_off;  // the level-l region: kR2Rows rows of 256 bytes (+ 4 of padding per row)
+  constexpr int kL1P = 260;
+  const LevelDesc& D1 = P.lv[l];
+  const LevelDesc& D2 = P.lv[l + 1];
+  const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const short4* xt1 = xtab + D1.xtab_off;
+  const short4* yt1 = ytab + D1.ytab_off;
+  const short4* xt2 = xtab + D2.xtab_off;
+  const short4* yt2 = ytab + D2.ytab_off;
+  // ---- the tile of level l + 1, its region of level l and what of it this workgroup owns
+  const int ex0 = blockIdx.x * kR2W, ex1 = min(ex0 + kR2W, D2.w);
+  const int ey0 = blockIdx.y * kR2H, ey1 = min(ey0 + kR2H, D2.h);
+  const bool last_x = ex1 == D2.w, last_y = ey1 == D2.h;
+  const int rx0 = blockIdx.x == 0 ? 0 : (xt2[ex0].x & ~3), rx1 = last_x ? D1.w : min((int)xt2[ex1 - 1].y + 1, D1.w);
+  const int ry0 = blockIdx.y == 0 ? 0 : (int)yt2[ey0].x, ry1 = last_y ? D1.h : min((int)yt2[ey1 - 1].y + 1, D1.h);
+  const int ox1 = last_x ? D1.w : (xt2[ex1].x & ~3), oy1 = last_y ? D1.h : (int)yt2[ey1].x;
+  // ---- level l - 1 rows of the region into LDS (as k_resize)
+  int spitch;
+  const uint8_t* src = plane_ptr(P, I, b, l - 1, &spitch);
+  const int sy_lo = yt1[ry0].x, nrows = yt1[ry1 - 1].y - sy_lo + 1;
+  const int sx_lo = xt1[rx0].x & ~3, ndw = ((xt1[rx1 - 1].y + 4) >> 2) - (sx_lo >> 2);
+  {
+    unsigned v[12][2];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const int r = wave + 4 * k;
+      const unsigned* row = (const unsigned*)(src + (size_t)(sy_lo + r) * spitch + sx_lo);
+      if (r < nrows && lane < ndw) v[k][0] = row[lane];
+      if (r < nrows && lane + 64 < ndw) v[k][1] = row[lane + 64];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const int r = wave + 4 * k;
+      if (r < nrows && lane < ndw) *(unsigned*)(smem + r * lds_pitch + 4 * lane) = v[k][0];
+      if (r < nrows && lane + 64 < ndw) *(unsigned*)(smem + r * lds_pitch + 4 * (lane + 64)) = v[k][1];
+    }
+    for (int r = wave; r < nrows; r += 4) {
+      const unsigned* row = (const unsigned*)(src + (size_t)(sy_lo + r) * spitch + sx_lo);
+      for (int c = lane + (r < 48 ? 128 : 0); c < ndw; c += 64) *(unsigned*)(smem + r * lds_pitch + 4 * c) = row[c];
+    }
+  }
+  __syncthreads();
+  // ---- level l: the region into LDS, its owned part to HBM
+  {
+    const int dx4 = rx0 + lane * 4;
+    if (dx4 < rx1) {
+      int x0[4], x1[4], a0[4], a1[4];
+      unsigned keep = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const short4 t = xt1[min(dx4 + j, D1.w - 1)];
+        x0[j] = t.x - sx_lo, x1[j] = t.y - sx_lo, a0[j] = t.z, a1[j] = t.w;
+        if (dx4 + j < D1.w) keep |= 0xFFu << (8 * j);
+      }
+      uint8_t* dst = I.pyr + (size_t)b * I.pyr_img + D1.off;
+      const bool own_x = dx4 < ox1;  // (ox1 is a multiple of 4 or the plane's width: whole dwords)
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+      for (int dy = ry0 + wave_u; dy < ry1; dy += 4) {
+        const short4 y = yt1[dy];
+        const uint8_t* r0 = smem + (y.x - sy_lo) * lds_pitch;
+        const uint8_t* r1 = smem + (y.y - sy_lo) * lds_pitch;
+        const int b0 = y.z, b1 = y.w;
+        unsigned out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int h0 = r0[x0[j]] * a0[j] + r0[x1[j]] * a1[j];
+          const int h1 = r1[x0[j]] * a0[j] + r1[x1[j]] * a1[j];
+          const int v = (((b0 * (int)(unsigned short)(h0 >> 4)) >> 16) + ((b1 * (int)(unsigned short)(h1 >> 4)) >> 16) + 2) >> 2;
+          out |= (unsigned)(v & 0xFF) << (8 * j);
+        }
+        out &= keep;
+        *(unsigned*)(l1 + (dy - ry0) * kL1P + 4 * lane) = out;
+        if (own_x && dy < oy1) *(unsigned*)(dst + (size_t)dy * D1.pitch + dx4) = out;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- level l + 1: the tile from the region in LDS
+  const int dx4 = ex0 + lane * 4;
+  if (dx4 >= ex1) return;
+  int x0[4], x1[4], a0[4], a1[4];
+  unsigned keep = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const short4 t = xt2[min(dx4 + j, D2.w - 1)];
+    x0[j] = t.x - rx0, x1[j] = t.y - rx0, a0[j] = t.z, a1[j] = t.w;
+    if (dx4 + j < D2.w) keep |= 0xFFu << (8 * j);
+  }
+  uint8_t* dst2 = I.pyr + (size_t)b * I.pyr_img + D2.off;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  for (int dy = ey0 + wave_u; dy < ey1; dy += 4) {
+    const short4 y = yt2[dy];
+    const uint8_t* r0 = l1 + (y.x - ry0) * kL1P;
+    const uint8_t* r1 = l1 + (y.y - ry0) * kL1P;
+    const int b0 = y.z, b1 = y.w;
+    unsigned out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int h0 = r0[x0[j]] * a0[j] + r0[x1[j]] * a1[j];
+      const int h1 = r1[x0[j]] * a0[j] + r1[x1[j]] * a1[j];
+      const int v = (((b0 * (int)(unsigned short)(h0 >> 4)) >> 16) + ((b1 * (int)(unsigned short)(h1 >> 4)) >> 16) + 2) >> 2;
+      out |= (unsigned)(v & 0xFF) << (8 * j);
+    }
+    *(unsigned*)(dst2 + (size_t)dy * D2.pitch + dx4) = out & keep;
+  }
+}
+
 // Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Neighbouring
 // cells / tiles share 128-byte lines of the plane, so they should share an L2: the launch index is
 // mapped so that runs of G consecutive items stay on one XCD while the runs themselves are still
@@ -1391,6 +1515,37 @@ static int plan_geometry(vieo_orb* e, int w, int h, int B) {
   e->blur_img = align_up_sz(blur_off, 256);
   e->resize_pitch = 4 * resize_dw + 4;  // bytes; +4 keeps consecutive rows on different banks
   e->resize_lds = resize_rows * e->resize_pitch;
+  {  // k_resize2: the (l, l + 1) pairs l = 1, 3, 5, ...: every tile's level-l region and its source band must fit the kernel
+    bool ok = e->nlevels >= 3;
+    int rows2 = 1, dw2 = 1;
+    for (int l = 1; ok && l + 1 < e->nlevels; l += 2) {
+      const LevelDesc &D1 = P.lv[l], &D2 = P.lv[l + 1];
+      const short* xt1 = xtab.data() + 4 * (size_t)D1.xtab_off;
+      const short* yt1 = ytab.data() + 4 * (size_t)D1.ytab_off;
+      const short* xt2 = xtab.data() + 4 * (size_t)D2.xtab_off;
+      const short* yt2 = ytab.data() + 4 * (size_t)D2.ytab_off;
+      for (int ex0 = 0; ok && ex0 < D2.w; ex0 += kR2W) {
+        const int ex1 = std::min(ex0 + kR2W, D2.w);
+        const int rx0 = ex0 == 0 ? 0 : (xt2[4 * ex0] & ~3), rx1 = ex1 == D2.w ? D1.w : std::min(xt2[4 * (ex1 - 1) + 1] + 1, D1.w);
+        const int ox1 = ex1 == D2.w ? D1.w : (xt2[4 * ex1] & ~3);
+        const int ndw = ((xt1[4 * (rx1 - 1) + 1] + 4) >> 2) - ((xt1[4 * rx0] & ~3) >> 2);
+        ok = rx1 - rx0 <= 256 && ox1 <= rx1 && ox1 > rx0 && ndw <= 128;
+        dw2 = std::max(dw2, ndw);
+      }
+      for (int ey0 = 0; ok && ey0 < D2.h; ey0 += kR2H) {
+        const int ey1 = std::min(ey0 + kR2H, D2.h);
+        const int ry0 = ey0 == 0 ? 0 : yt2[4 * ey0], ry1 = ey1 == D2.h ? D1.h : std::min(yt2[4 * (ey1 - 1) + 1] + 1, D1.h);
+        const int oy1 = ey1 == D2.h ? D1.h : yt2[4 * ey1];
+        const int nrows = yt1[4 * (ry1 - 1) + 1] - yt1[4 * ry0] + 1;
+        ok = ry1 - ry0 <= kR2Rows && oy1 <= ry1 && oy1 > ry0 && nrows <= 48;
+        rows2 = std::max(rows2, nrows);
+      }
+    }
+    e->resize2_ok = ok;
+    e->resize2_pitch = 4 * dw2 + 4;
+    e->resize2_l1_off = (rows2 * e->resize2_pitch + 15) & ~15;
+    e->resize2_lds = e->resize2_l1_off + kR2Rows * 260;
+  }
   // FAST LDS: cell tile (dword-aligned columns) + strength tile
   e->tpitch = align_up(max_cw + 3, 4) + 4;
   e->tile_bytes = align_up(e->tpitch * max_ch, 16);
@@ -1479,11 +1634,25 @@ static int run_batch(vieo_orb* e, const uint8_t* d_images, int B, int w, int h, 
 #define STAMP()                                                  \
   if (T.on) VIEO_HIP_CHECK(hipEventRecord(evs[evi++], st))
   STAMP();
-  for (int l = 1; l < P.nlevels; l++) {
+  // two levels per launch where the geometry allows (k_resize2; VIEO_RESIZE_PAIRS=0: one level per launch, A/B runs)
+  static const bool resize_pairs = [] {
+    const char* v = getenv("VIEO_RESIZE_PAIRS");
+    return !(v && atoi(v) == 0);
+  }();
+  for (int l = 1; l < P.nlevels;) {
+    if (resize_pairs && e->resize2_ok && (l & 1) && l + 1 < P.nlevels) {
+      const LevelDesc& D2 = P.lv[l + 1];
+      dim3 grd((D2.w + kR2W - 1) / kR2W, (D2.h + kR2H - 1) / kR2H, B);
+      hipLaunchKernelGGL(k_resize2, grd, dim3(256), e->resize2_lds, st, P, l, I, e->d_xtab.as<short4>(), e->d_ytab.as<short4>(),
+                         e->resize2_pitch, e->resize2_l1_off);
+      l += 2;
+      continue;
+    }
     const LevelDesc& D = P.lv[l];
     dim3 grd((D.w + 255) / 256, (D.h + kResizeRows - 1) / kResizeRows, B);
     hipLaunchKernelGGL(k_resize, grd, dim3(256), e->resize_lds, st, P, l, I, e->d_xtab.as<short4>(),
                        e->d_ytab.as<short4>(), e->resize_pitch);
+    l++;
   }
   STAMP();
   const auto xcd_grid = [](long long items) {

@@ -90,6 +90,8 @@ struct vieo_orb {  // global-scope tag declared in include/vieo_hot.h
   std::vector<vieo::BlurTile> tiles;
   int tpitch = 0, fast_cand_cap = 0, tile_bytes = 0, score_bytes = 0, fast_lds = 0, qt_lds = 0, ncap_max = 0, scap_max = 0;
   int resize_pitch = 0, resize_lds = 0;
+  int resize2_pitch = 0, resize2_l1_off = 0, resize2_lds = 0;  // k_resize2: source band pitch, offset of the level-l region, LDS bytes
+  bool resize2_ok = false;                                     // the pairs' regions fit (else: one level per launch)
   size_t pyr_img = 0, blur_img = 0;
   vieo::DevBuf d_pyr, d_blur, d_cells, d_tiles, d_xtab, d_ytab, d_cell_keys, d_cell_counts, d_keys,
       d_kslot, d_kq, d_sel, d_sel_count, d_pattern, d_in, d_kp, d_desc, d_counts, d_tmp_kp,
