@@ -633,6 +633,7 @@ def sequence_leg(kind, orc, n, lag, rig=None, nc=None, nfeat=None, seed=1):
     th = R.run(n)
     dt = time.perf_counter() - t0
     R.close()
+    cpp = cpp_sequence_leg(kind, seq, n, lag, nfeat, th)
     to = orc["traj"]
     # 1e-4 is the bar "for the same inputs": up to the first frame whose integer decisions (matches, inliers) differ from
     # the oracle's run the two work on the same map; behind it a flipped decision has changed the inputs
@@ -647,6 +648,7 @@ def sequence_leg(kind, orc, n, lag, rig=None, nc=None, nfeat=None, seed=1):
         "ms_per_frame_tracking_call_last_half": float(ms[len(ms) // 2:, 0].mean()),
         "frame_pipelining": {"on": True, "ms_per_frame_tracking_call_without": float(ms_plain[:, 0].mean()),
                              "trajectory_bytes_identical_without": bool(th.tobytes() == tn.tobytes())},
+        "ms_per_frame": cpp.get("ms_per_frame"), "cpp": cpp,
         "ms_per_frame_python_loop": 1e3 * dt / (n - 1),
         "ms_per_local_ba_mean": float(np.mean(R.stats["ms_lba"])) if R.stats["ms_lba"] else None,
         "lba_windows": {"mean_key_frames": float(shapes[:, 0].mean()), "max_key_frames": int(shapes[:, 0].max()),
@@ -662,9 +664,41 @@ def sequence_leg(kind, orc, n, lag, rig=None, nc=None, nfeat=None, seed=1):
         "oracle_replay_frames_per_s": (n - 1) / orc["seconds"], "oracle_over_tracking_call": orc["seconds"] / (n - 1) * 1e3 / float(ms[:, 0].mean()),
         "max_position_error_vs_truth_m": float(err), "host_syncs_per_frame": 1,
         "note": "ms_per_frame_tracking_call = wall time of the ONE vieo_track_frame call per frame (the C entry's own clock); "
-                "ms_per_frame_python_loop adds this driver's numpy map bookkeeping and the local BAs issued from Python "
-                "(the rectified configuration has a C++ driver, examples/replay_main: single_stream)",
+                "ms_per_frame = the WHOLE loop of examples/replay_modes (C++, no Python: map bookkeeping on the host, the "
+                "local BA on its LocalMapping thread; median of 3 runs, details under cpp); ms_per_frame_python_loop = the same "
+                "replay driven from Python (numpy map bookkeeping, local BAs issued from Python)",
     }
+
+
+def cpp_sequence_leg(kind, seq, n, lag, nfeat, th):
+    """The same sequence replay as a C++ program (examples/replay_modes.cc: rig / --vision): whole-loop ms per frame with
+    frame pipelining, LocalMapping on its own host thread; its trajectory against the Python tracker replay's (th)."""
+    import subprocess
+    import tempfile
+    from tools.write_sequence import write_rig_sequence, write_sequence
+    from vieo_slam_amd.ba_types import NAVSTATE_DTYPE
+    exe = os.path.join(ROOT, "examples", "replay_modes")
+    if not os.path.exists(exe):
+        return {"error": "examples/replay_modes missing: run __graft_entry__.build()"}
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path, traj = os.path.join(tmp, "seq.vseq"), os.path.join(tmp, "traj.bin")
+            if kind == "vision":
+                write_sequence(path, seq.seed, n, seq)
+            else:
+                write_rig_sequence(path, seq, nfeat)
+            cmd = [exe, path, traj, "--warmup", "14", "--quiet", "--lba-lag", str(lag), "--prefetch", "1"] + (["--vision"] if kind == "vision" else [])
+            runs = [json.loads(subprocess.check_output(cmd, timeout=1800).decode().strip().splitlines()[-1]) for _ in range(3)]
+            tc = np.fromfile(traj, NAVSTATE_DTYPE)
+        r = sorted(runs, key=lambda x: x["ms_per_frame"])[1]
+        d = np.linalg.norm(tc["p"] - th["p"], axis=1)
+        return dict(r, ms_per_frame_runs=[x["ms_per_frame"] for x in runs],
+                    max_position_difference_vs_python_tracker_replay_m=float(d.max()),
+                    max_position_difference_vs_python_first_16_frames_m=float(d[:16].max()),
+                    path="examples/replay_modes (C++, no Python): per frame ONE vieo_track_frame call, the next frame's extraction "
+                         "queued beside it; per key frame the local BA on the LocalMapping thread, applied %d frames later" % lag)
+    except Exception as e:  # (the Python leg's numbers stand on their own)
+        return {"error": repr(e)}
 
 
 def concurrent_trackers_leg(path, n_list=(8, 32), frames=60):
@@ -929,7 +963,18 @@ def compact_line(out, detail_path=None):
                                            "vs_cpu_threaded"))
         if isinstance(ss.get("drop_in"), dict):
             line["single_stream"]["drop_in_ms_per_frame"] = _num(ss["drop_in"].get("ms_per_frame"))
-    line["legs_failed"] = failed_legs(out)
+    # the other BASELINE configurations as sequences: whole-loop ms per frame of the C++ replays (examples/replay_modes)
+    oc, bad_cpp = {}, []
+    legs = dict(out.get("single_stream_rig") or {}, configs0_vision_only=out.get("single_stream_vision_only"))
+    for name, leg in legs.items():
+        if isinstance(leg, dict) and isinstance(leg.get("cpp"), dict):
+            if "error" in leg["cpp"]:
+                bad_cpp.append("%s.cpp" % name)
+            else:
+                oc[name] = _num(leg["cpp"].get("ms_per_frame"))
+    if oc:
+        line["other_configs_ms_per_frame"] = oc
+    line["legs_failed"] = failed_legs(out) + bad_cpp
     line["detail"] = detail_path
     return line
 

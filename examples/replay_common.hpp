@@ -47,8 +47,13 @@ struct Sequence {
   std::vector<vieo_imu_sample> imu;
   std::vector<double> truth;  // [n][10]
   std::vector<uint8_t> images;
+  // "VSEQ0002" (tools/write_sequence.py write_rig_sequence): a rig of n_cams distorted cameras and its tracker's parameters
+  int n_cams = 2, nfeatures = NFEAT;
+  bool has_rig = false;
+  vieo_tracker_params trk_params;
+  vieo_tracker_rig rig;
   double time(int k) const { return t0 + k * dt; }
-  const uint8_t* image(int k, int cam) const { return images.data() + ((size_t)k * 2 + cam) * W * H; }
+  const uint8_t* image(int k, int cam) const { return images.data() + ((size_t)k * n_cams + cam) * W * H; }
   // the samples PreIntegration gets for [ti, tj]: from the last one at or before ti to the first one at or after tj
   void imu_between(double ti, double tj, int* first, int* count) const {
     int a = 0, b = n_imu - 1;
@@ -76,7 +81,8 @@ inline bool load_sequence(const char* path, Sequence& S) {
   FILE* f = std::fopen(path, "rb");
   if (!f) return false;
   char magic[8];
-  bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "VSEQ0001", 8) == 0;
+  bool ok = std::fread(magic, 1, 8, f) == 8 && (std::memcmp(magic, "VSEQ0001", 8) == 0 || std::memcmp(magic, "VSEQ0002", 8) == 0);
+  S.has_rig = ok && magic[7] == '2';
   int hdr[4];
   ok = ok && std::fread(hdr, 4, 4, f) == 4;
   S.n_frames = hdr[0], S.W = hdr[1], S.H = hdr[2], S.n_imu = hdr[3];
@@ -88,7 +94,14 @@ inline bool load_sequence(const char* path, Sequence& S) {
   if (!ok) return std::fclose(f), false;
   S.fx = (float)S.intr[0], S.fy = (float)S.intr[1], S.cx = (float)S.intr[2], S.cy = (float)S.intr[3];
   S.bf = (float)S.intr[4], S.baseline = (float)S.intr[5], S.th_depth = (float)S.intr[6];
-  S.imu.resize(S.n_imu), S.truth.resize((size_t)S.n_frames * 10), S.images.resize((size_t)S.n_frames * 2 * S.W * S.H);
+  if (S.has_rig) {
+    int32_t h2[2];
+    ok = std::fread(h2, 4, 2, f) == 2 && std::fread(&S.trk_params, sizeof(S.trk_params), 1, f) == 1 &&
+         std::fread(&S.rig, sizeof(S.rig), 1, f) == 1 && h2[0] >= 2 && h2[0] <= 4 && S.rig.n_cams == h2[0];
+    if (!ok) return std::fclose(f), false;
+    S.n_cams = h2[0], S.nfeatures = h2[1];
+  }
+  S.imu.resize(S.n_imu), S.truth.resize((size_t)S.n_frames * 10), S.images.resize((size_t)S.n_frames * S.n_cams * S.W * S.H);
   ok = std::fread(S.imu.data(), sizeof(vieo_imu_sample), S.n_imu, f) == (size_t)S.n_imu;
   ok = ok && std::fread(S.truth.data(), 8, S.truth.size(), f) == S.truth.size();
   ok = ok && std::fread(S.images.data(), 1, S.images.size(), f) == S.images.size();
