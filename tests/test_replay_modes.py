@@ -229,7 +229,7 @@ def test_gpu_cpp_vision_only_replay_equals_the_python_tracker_replay(tmp_path):
     # within 20 frames, all integer decisions unchanged).  Tight over the first frames, the oracle comparisons' bar over the run.
     d = np.linalg.norm(tc["p"] - tt["p"], axis=1)
     rot = np.array([synth_ba.pose_error(tc[k], tt[k])[1] for k in range(n)])
-    assert d[:16].max() <= 1e-9 and rot[:16].max() <= 1e-9, (d[:16].max(), rot[:16].max())
+    assert d[:16].max() <= 1e-9 and rot[:16].max() <= 1e-7, (d[:16].max(), rot[:16].max())  # (pose_error's arccos resolves 3e-8)
     assert d.max() <= 1e-4 and rot.max() <= 1e-4 and replay.ate_between(tc, tt) <= 3e-5, (d.max(), rot.max())
     R0 = rm.VisionTrackerReplay(seq, rm.HipVisionStages())
     t0 = R0.run(n)
