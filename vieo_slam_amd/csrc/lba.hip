@@ -84,6 +84,8 @@ struct WinOut {
   double chig0, chig;  // landmark-sharded windows: the (replicated) inertial part, kept out of the reduction
 };
 
+static const int kBuildChunk = 512;  // edges of a key frame per workgroup of k_lba_build's key-frame half (2 per thread)
+
 struct LbaDev {
   const vieo_lba_obs* obs;
   int n_obs, n_mp, n_kf, nf_cap;  // nf_cap: non-fixed key frames = rows of `tab`
@@ -127,6 +129,11 @@ struct LbaDev {
   double *part0, *part, *part_m, *pmax;  // per-block partials
   double* part_t;                 // [blocks of 64 points] robust chi2 of a trial, summed per point block (k_lba_tail)
   int* tail_cnt;                  // arrival counter of k_lba_tail's workgroups (the last one folds the partials)
+  // key-frame half of k_lba_build: a key frame's edge list in chunks of kBuildChunk edges, one workgroup each
+  int n_chunks;                   // written by k_lba_begin: chunks of the free + active key frames
+  int *chunk_first, *chunk_kf;    // [n_free + 1] first chunk of kf_list[a]; [n_chunks] the a of a chunk
+  int* chunk_cnt;                 // [n_free] arrival counters (the last workgroup of a key frame folds its chunks' partials)
+  double* chunk_part;             // [n_chunks][33] H_pp (21) + b_p (6) + H_ps (6) of a chunk
   CamD cam;                       // the single rectified pinhole camera (n_cams == 0) ...
   CamD cams[4];                   // ... or the physical cameras of a distorted multi-camera rig
   int n_cams;
@@ -341,8 +348,17 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
     D.np = np, D.n_free = nf, D.npv = 6 * nf + (D.scale_opt ? 1 : 0);
     out[w].np = np;
     *D.tail_cnt = 0;  // (scratch memory: k_lba_tail's arrival counter starts an optimize() at zero)
+    int nchk = 0;
+    for (int a = 0; a < nf; a++) {
+      const int k = D.kf_list[a];
+      D.chunk_first[a] = nchk, D.chunk_cnt[a] = 0;
+      nchk += max(1, (D.kf_edge_first[k + 1] - D.kf_edge_first[k] + kBuildChunk - 1) / kBuildChunk);
+    }
+    D.chunk_first[nf] = nchk, D.n_chunks = nchk;
   }
   __syncthreads();
+  for (int a = tid; a < D.n_free; a += 1024)
+    for (int c = D.chunk_first[a]; c < D.chunk_first[a + 1]; c++) D.chunk_kf[c] = a;
   for (int i = tid; i < n_obs; i += 1024)
     if (D.level[i] == 0) {
       const vieo_lba_obs o = D.obs[i];
@@ -457,6 +473,10 @@ __device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& 
 // half H_ps = sum Jp^T W Js.
 // The two halves are two launches (KFHALF): the point half needs 162 registers, the key-frame half 254, and in one
 // kernel the point half's 64 % of the workgroups ran at the key-frame half's two wavefronts per SIMD.
+// The key-frame half takes a key frame's edge list in chunks of kBuildChunk edges, one workgroup per chunk (a rig key
+// frame has thousands of edges -- 4 cameras x 1500 features: one workgroup per key frame was 1.08 ms of a trial's 1.4);
+// a chunk's sums go to chunk_part, the workgroup that arrives last at the key frame's counter adds the chunks in chunk
+// order.  A key frame of one chunk (<= 512 edges) writes its sums directly, as before.
 template <bool MULTICAM, bool SCALE, bool KFHALF>
 __global__ void __launch_bounds__(256, 2)
 k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
@@ -583,11 +603,12 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
     if (threadIdx.x == 0) D.pmax[bx] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
     return;
   }
-  const int a = bx;
-  if (a >= D.n_free) return;
+  if (bx >= D.n_chunks) return;
+  const int a = D.chunk_kf[bx], chunk0 = D.chunk_first[a], nchunk = D.chunk_first[a + 1] - chunk0;
   const int kfi = D.kf_list[a];
   const LbaKf k = D.kf[kfi];
   const int first = D.kf_edge_first[kfi], cnt = D.kf_edge_first[kfi + 1] - first;
+  const int j_lo = (bx - chunk0) * kBuildChunk, j_hi = min(cnt, j_lo + kBuildChunk);
   double acc[27];
 #pragma unroll
   for (int t = 0; t < 27; t++) acc[t] = 0;
@@ -600,7 +621,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
   // A thread's edges two at a time: both list entries, then both records and level bytes, then both points are loaded
   // before the arithmetic (three dependent round trips per PAIR of edges instead of per edge; a key frame's ~600 edges are
   // 2.3 per thread).  Same edges in the same order per thread: the sums are bit-identical.
-  for (int j0 = threadIdx.x; j0 < cnt; j0 += 512) {
+  for (int j0 = j_lo + threadIdx.x; j0 < j_hi; j0 += 512) {  // (one trip: a chunk is 2 edges per thread)
     int ii[2];
     vieo_lba_obs oo[2];
     unsigned char lvv[2];
@@ -617,7 +638,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
 #pragma unroll
     for (int u = 0; u < 2; u++) {
     const int j = j0 + 256 * u;
-    if (j >= cnt) continue;
+    if (j >= j_hi) continue;
     const int i = ii[u];
     const vieo_lba_obs o = oo[u];
     const bool active = !lvv[u];
@@ -700,6 +721,40 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
     }
   }
   block_sum<27>(acc, s_red, threadIdx.x);
+  if (scl) block_sum<6>(aps, s_red, threadIdx.x);
+  __shared__ int s_last;
+  if (nchunk > 1) {  // this chunk's sums; the last workgroup of the key frame adds the chunks in order
+    if (threadIdx.x < 33) {
+      double v = 0;
+#pragma unroll
+      for (int t = 0; t < 27; t++)
+        if ((int)threadIdx.x == t) v = acc[t];
+#pragma unroll
+      for (int t = 0; t < 6; t++)
+        if ((int)threadIdx.x == 27 + t) v = aps[t];
+      D.chunk_part[33 * (size_t)bx + threadIdx.x] = v;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int old = atomicAdd(&D.chunk_cnt[a], 1);
+      s_last = old == nchunk - 1;
+      if (s_last) D.chunk_cnt[a] = 0;  // (for the next launch: nobody else touches it any more)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < 33) {
+      double v = 0;
+      for (int c = 0; c < nchunk; c++) v += D.chunk_part[33 * (size_t)(chunk0 + c) + threadIdx.x];
+#pragma unroll
+      for (int t = 0; t < 27; t++)
+        if ((int)threadIdx.x == t) acc[t] = v;
+#pragma unroll
+      for (int t = 0; t < 6; t++)
+        if ((int)threadIdx.x == 27 + t) aps[t] = v;
+    }
+  }
   if (threadIdx.x < 27) {
     double v = 0;
 #pragma unroll
@@ -714,15 +769,12 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
     } else
       D.bp[6 * a + threadIdx.x - 21] = v;
   }
-  if (scl) {
-    block_sum<6>(aps, s_red, threadIdx.x);
-    if (threadIdx.x < 6) {
-      double v = 0;
+  if (scl && threadIdx.x >= 27 && threadIdx.x < 33) {
+    double v = 0;
 #pragma unroll
-      for (int t = 0; t < 6; t++)
-        if ((int)threadIdx.x == t) v = aps[t];
-      D.sc_sys[6 * a + threadIdx.x] = v;
-    }
+    for (int t = 0; t < 6; t++)
+      if ((int)threadIdx.x == 27 + t) v = aps[t];
+    D.sc_sys[6 * a + threadIdx.x - 27] = v;
   }
 }
 
@@ -2765,7 +2817,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   const size_t zero_end = arena;
   if ((rc = g_stage.ensure(res_end)) != VIEO_OK) return rc;
   uint8_t* hs = (uint8_t*)g_stage.p;
-  int max_obs = 0, max_mp = 0, max_kf = 0, max_nf = 0, max_imu = 0;
+  int max_obs = 0, max_mp = 0, max_kf = 0, max_nf = 0, max_imu = 0, max_chunks = 1;
   bool any_multicam = false;
   for (int w = 0; w < W; w++) {
     if (win[w].skip) continue;
@@ -2797,7 +2849,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   std::vector<size_t> scratch_off(W);
   struct Scr {
     size_t kf_bak, X_bak, mp_act, BB, Bs, Sp, Hll, bl, Hpp, Hs, bp, bs, xp, part0, part, part_m, pmax, kf_list, tab, Ae, gchi0,
-        gchi, bfull, Hb, Wp, big_fail, kf_act, occ, sc_sys, psc, part_t, tail_cnt;
+        gchi, bfull, Hb, Wp, big_fail, kf_act, occ, sc_sys, psc, part_t, tail_cnt, chunk_first, chunk_kf, chunk_cnt, chunk_part;
     int nb;
   };
   std::vector<Scr> scr(W);
@@ -2841,6 +2893,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     s.part0 = take((size_t)((H.n_obs + 255) / 256) * 8), s.part = take((size_t)((H.n_obs + 255) / 256) * 8);
     s.part_m = take((size_t)((H.n_mp + 63) / 64) * 8), s.pmax = take((size_t)((H.n_mp + 63) / 64) * 8);
     s.part_t = take((size_t)std::max((H.n_mp + 63) / 64, 1) * 8), s.tail_cnt = take(256);
+    {  // chunks of the key frames' edge lists: sum over the free key frames of ceil(edges / kBuildChunk) <= this bound
+      const size_t nchk = (size_t)H.n_obs / kBuildChunk + nf + 1;
+      s.chunk_first = take((size_t)(nf + 1) * 4), s.chunk_cnt = take((size_t)(nf + 1) * 4);
+      s.chunk_kf = take(nchk * 4), s.chunk_part = take(nchk * 33 * 8);
+      max_chunks = std::max(max_chunks, (int)nchk);
+    }
     s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)std::max(nf, 1) * H.n_mp * 4);
     s.sc_sys = take((size_t)(6 * nf + 2) * 8), s.psc = take((size_t)((H.n_mp + 63) / 64) * 16);
     s.kf_act = take((size_t)H.n_kf * 4);
@@ -3057,6 +3115,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.part0 = (double*)(base + s.part0), D.part = (double*)(base + s.part);
     D.part_m = (double*)(base + s.part_m), D.pmax = (double*)(base + s.pmax);
     D.part_t = (double*)(base + s.part_t), D.tail_cnt = (int*)(base + s.tail_cnt);
+    D.chunk_first = (int*)(base + s.chunk_first), D.chunk_cnt = (int*)(base + s.chunk_cnt);
+    D.chunk_kf = (int*)(base + s.chunk_kf), D.chunk_part = (double*)(base + s.chunk_part);
     D.kf_list = (int*)(base + s.kf_list), D.tab = (int*)(base + s.tab);
     D.kf_act = (int*)(base + s.kf_act), D.occ = base + s.occ;
     D.bfull = (double*)(base + s.bfull), D.Ae = (double*)(base + s.Ae);
@@ -3210,7 +3270,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       auto build2 = [&](auto mc, auto sc) {  // point half, key-frame half
         constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
         hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC);
-        hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(std::max(1, max_nf), W), dim3(256), 0, st, dD, dC);
+        hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(max_chunks, W), dim3(256), 0, st, dD, dC);
       };
       if (any_multicam)
         build2(std::true_type(), std::false_type());
@@ -3348,7 +3408,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       auto build2 = [&](auto mc, auto sc) {  // point half, key-frame half
         constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
         KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC); });
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(std::max(1, max_nf), W), dim3(256), 0, st, dD, dC); });
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(max_chunks, W), dim3(256), 0, st, dD, dC); });
       };
       if (sco) {
         if (any_multicam)
