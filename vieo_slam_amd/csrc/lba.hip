@@ -477,14 +477,23 @@ __device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& 
 // frame has thousands of edges -- 4 cameras x 1500 features: one workgroup per key frame was 1.08 ms of a trial's 1.4);
 // a chunk's sums go to chunk_part, the workgroup that arrives last at the key frame's counter adds the chunks in chunk
 // order.  A key frame of one chunk (<= 512 edges) writes its sums directly, as before.
+// The key-frame half's launch also carries the generic (inertial / encoder) edges' linearisation, one workgroup per edge
+// behind the gk chunk workgroups (it was a launch of its own, k_lba_generic(0): 44 us of single-lane chains that now run
+// beside the chunks instead of behind them).
+__device__ __forceinline__ void lba_generic_dev(const LbaDev& D, int e, int lane, int mode);
 template <bool MULTICAM, bool SCALE, bool KFHALF>
 __global__ void __launch_bounds__(256, 2)
-k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int gk) {
   const int bx = blockIdx.x;
   __shared__ double s_red[4 * 27];
   const int w = blockIdx.y, fl = ctl[w].flags;
   if (!(fl & LBA_BUILD)) return;
   const LbaDev& D = devs[w];
+  if (KFHALF && bx >= gk) {
+    const int e = bx - gk;
+    if (e < D.n_imu && threadIdx.x < 64) lba_generic_dev(D, e, threadIdx.x, 0);
+    return;
+  }
   if (D.np == 0) return;
   const bool robust = fl & LBA_ROBUST;
   if (!KFHALF) {
@@ -3269,14 +3278,13 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       }
       auto build2 = [&](auto mc, auto sc) {  // point half, key-frame half
         constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
-        hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC);
-        hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(max_chunks, W), dim3(256), 0, st, dD, dC);
+        hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0);
+        hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks);
       };
       if (any_multicam)
         build2(std::true_type(), std::false_type());
       else
         build2(std::false_type(), std::false_type());
-      if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0);
       if (with_begin) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);
       hipLaunchKernelGGL(k_lba_schur<false>, dim3(std::max(1, schur_grid), W), dim3(256), 0, st, dD, dC, dO);
       if (schur_grid_off > 0) hipLaunchKernelGGL(k_lba_schur<true>, dim3(schur_grid_off, W), dim3(256), 0, st, dD, dC, dO);
@@ -3407,8 +3415,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (any & LBA_BUILD) {
       auto build2 = [&](auto mc, auto sc) {  // point half, key-frame half
         constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC); });
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(max_chunks, W), dim3(256), 0, st, dD, dC); });
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0); });
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks); });
       };
       if (sco) {
         if (any_multicam)
@@ -3420,7 +3428,6 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         build2(std::true_type(), std::false_type());
       else
         build2(std::false_type(), std::false_type());
-      if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0); });
     }
     if (any & LBA_BEGIN) KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO); });
     if (any & LBA_TRIAL) {
