@@ -481,22 +481,27 @@ __device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& 
 // behind the gk chunk workgroups (it was a launch of its own, k_lba_generic(0): 44 us of single-lane chains that now run
 // beside the chunks instead of behind them).
 __device__ __forceinline__ void lba_generic_dev(const LbaDev& D, int e, int lane, int mode);
-template <bool MULTICAM, bool SCALE, bool KFHALF>
+// HALF = 0: the point half, 1: the key-frame half (+ the generic edges), 2: both in one launch -- gp point workgroups, then
+// the key-frame half's (calls of a few windows: the register-rich instance's occupancy does not matter there, a launch
+// less does).
+template <bool MULTICAM, bool SCALE, int HALF>
 __global__ void __launch_bounds__(256, 2)
-k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int gk) {
-  const int bx = blockIdx.x;
+k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int gk, int gp) {
+  int bx = blockIdx.x;
   __shared__ double s_red[4 * 27];
   const int w = blockIdx.y, fl = ctl[w].flags;
   if (!(fl & LBA_BUILD)) return;
   const LbaDev& D = devs[w];
-  if (KFHALF && bx >= gk) {
+  const bool point_half = HALF == 0 || (HALF == 2 && bx < gp);
+  if (HALF == 2 && !point_half) bx -= gp;
+  if (!point_half && bx >= gk) {
     const int e = bx - gk;
     if (e < D.n_imu && threadIdx.x < 64) lba_generic_dev(D, e, threadIdx.x, 0);
     return;
   }
   if (D.np == 0) return;
   const bool robust = fl & LBA_ROBUST;
-  if (!KFHALF) {
+  if (point_half) {
     if (bx * 64 >= D.n_mp) return;
     const int m = bx * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;  // 4 lanes per point
     const bool act = m < D.n_mp && D.mp_act[m];
@@ -3231,6 +3236,11 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     return e ? (atoi(e) != 0 ? 1 : 0) : -1;
   }();
   const bool fused_tail = fused_tail_env >= 0 ? fused_tail_env != 0 : W <= 4;
+  static const int fused_build_env = [] {  // VIEO_LBA_FUSED_BUILD=0 / 1: both halves of k_lba_build in one launch (A/B runs)
+    const char* e = getenv("VIEO_LBA_FUSED_BUILD");
+    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+  }();
+  const bool fused_build = fused_build_env >= 0 ? fused_build_env != 0 : W <= 4;
   static const bool dev_policy_env = [] {
     const char* e = getenv("VIEO_LBA_DEVICE_POLICY");
     return e && atoi(e) != 0;
@@ -3278,8 +3288,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       }
       auto build2 = [&](auto mc, auto sc) {  // point half, key-frame half
         constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
-        hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0);
-        hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks);
+        hipLaunchKernelGGL((k_lba_build<MC, SC, 0>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0, 0);
+        hipLaunchKernelGGL((k_lba_build<MC, SC, 1>), dim3(max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks, 0);
       };
       if (any_multicam)
         build2(std::true_type(), std::false_type());
@@ -3415,8 +3425,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     if (any & LBA_BUILD) {
       auto build2 = [&](auto mc, auto sc) {  // point half, key-frame half
         constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, false>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0); });
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, true>), dim3(max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks); });
+        if (fused_build) {  // one launch for both halves
+          KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, 2>), dim3(gq + max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks, gq); });
+          return;
+        }
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, 0>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0, 0); });
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, 1>), dim3(max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks, 0); });
       };
       if (sco) {
         if (any_multicam)
