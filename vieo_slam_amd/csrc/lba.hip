@@ -3288,6 +3288,10 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       }
       auto build2 = [&](auto mc, auto sc) {  // point half, key-frame half
         constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
+        if (fused_build) {
+          hipLaunchKernelGGL((k_lba_build<MC, SC, 2>), dim3(gq + max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks, gq);
+          return;
+        }
         hipLaunchKernelGGL((k_lba_build<MC, SC, 0>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0, 0);
         hipLaunchKernelGGL((k_lba_build<MC, SC, 1>), dim3(max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks, 0);
       };
