@@ -84,7 +84,7 @@ struct WinOut {
   double chig0, chig;  // landmark-sharded windows: the (replicated) inertial part, kept out of the reduction
 };
 
-static const int kBuildChunk = 512;  // edges of a key frame per workgroup of k_lba_build's key-frame half (2 per thread)
+static const int kBuildChunk = 1024;  // edges of a key frame per run of k_lba_build's key-frame half (4 per thread: two trips of two)
 
 struct LbaDev {
   const vieo_lba_obs* obs;
@@ -131,6 +131,9 @@ struct LbaDev {
   int* tail_cnt;                  // arrival counter of k_lba_tail's workgroups (the last one folds the partials)
   // key-frame half of k_lba_build: a key frame's edge list in chunks of kBuildChunk edges, one workgroup each
   int n_chunks;                   // written by k_lba_begin: chunks of the free + active key frames
+  int chunk_edges;                // kBuildChunk in calls of a few windows; batches keep one chunk per key frame -- the fold's
+                                  // device-scope fence (an L2 write-back per workgroup on this multi-XCD part) cost a
+                                  // 205-window step 3.2 -> 13.6 ms of k_lba_build, and a batch fills the device anyway
   int *chunk_first, *chunk_kf;    // [n_free + 1] first chunk of kf_list[a]; [n_chunks] the a of a chunk
   int* chunk_cnt;                 // [n_free] arrival counters (the last workgroup of a key frame folds its chunks' partials)
   double* chunk_part;             // [n_chunks][33] H_pp (21) + b_p (6) + H_ps (6) of a chunk
@@ -352,7 +355,7 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
     for (int a = 0; a < nf; a++) {
       const int k = D.kf_list[a];
       D.chunk_first[a] = nchk, D.chunk_cnt[a] = 0;
-      nchk += max(1, (D.kf_edge_first[k + 1] - D.kf_edge_first[k] + kBuildChunk - 1) / kBuildChunk);
+      nchk += max(1, (D.kf_edge_first[k + 1] - D.kf_edge_first[k] + D.chunk_edges - 1) / D.chunk_edges);
     }
     D.chunk_first[nf] = nchk, D.n_chunks = nchk;
   }
@@ -476,10 +479,10 @@ __device__ __forceinline__ void lba_edge_B(const LbaDev& D, int i, const LbaKf& 
 // The key-frame half takes a key frame's edge list in chunks of kBuildChunk edges, one workgroup per chunk (a rig key
 // frame has thousands of edges -- 4 cameras x 1500 features: one workgroup per key frame was 1.08 ms of a trial's 1.4);
 // a chunk's sums go to chunk_part, the workgroup that arrives last at the key frame's counter adds the chunks in chunk
-// order.  A key frame of one chunk (<= 512 edges) writes its sums directly, as before.
-// The key-frame half's launch also carries the generic (inertial / encoder) edges' linearisation, one workgroup per edge
-// behind the gk chunk workgroups (it was a launch of its own, k_lba_generic(0): 44 us of single-lane chains that now run
-// beside the chunks instead of behind them).
+// order.  A key frame of one chunk (<= kBuildChunk edges) writes its sums directly, as before.
+// The one-launch instance (HALF = 2, calls of a few windows) also carries the generic (inertial / encoder) edges'
+// linearisation, one workgroup per edge behind the gk chunk workgroups (k_lba_generic(0) otherwise: 44 us of single-lane
+// chains that then run beside the chunks instead of behind them).
 __device__ __forceinline__ void lba_generic_dev(const LbaDev& D, int e, int lane, int mode);
 // HALF = 0: the point half, 1: the key-frame half (+ the generic edges), 2: both in one launch -- gp point workgroups, then
 // the key-frame half's (calls of a few windows: the register-rich instance's occupancy does not matter there, a launch
@@ -494,8 +497,8 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   const LbaDev& D = devs[w];
   const bool point_half = HALF == 0 || (HALF == 2 && bx < gp);
   if (HALF == 2 && !point_half) bx -= gp;
-  if (!point_half && bx >= gk) {
-    const int e = bx - gk;
+  if (HALF == 2 && !point_half && bx >= gk) {  // (this instance only: the generic path's 1.7 KB of scratch per lane would
+    const int e = bx - gk;                     //  cost the batched key-frame half its occupancy: 3.2 -> 15.6 ms per step)
     if (e < D.n_imu && threadIdx.x < 64) lba_generic_dev(D, e, threadIdx.x, 0);
     return;
   }
@@ -622,12 +625,22 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   const int kfi = D.kf_list[a];
   const LbaKf k = D.kf[kfi];
   const int first = D.kf_edge_first[kfi], cnt = D.kf_edge_first[kfi + 1] - first;
-  const int j_lo = (bx - chunk0) * kBuildChunk, j_hi = min(cnt, j_lo + kBuildChunk);
-  double acc[27];
+  // The sums are formed per run of kBuildChunk edges and the runs' sums added in run order -- by the last workgroup of the
+  // key frame when the runs are workgroups of their own (calls of a few windows), by this workgroup one run after the
+  // other otherwise (batches): the same association either way, the result does not depend on what a window is batched with.
+  const bool own_chunks = D.chunk_edges == kBuildChunk;
+  const int nsub = own_chunks ? 1 : max(1, (cnt + kBuildChunk - 1) / kBuildChunk);
+  double acc[27], tot[27];
+  double aps[6] = {0, 0, 0, 0, 0, 0}, tps[6] = {0, 0, 0, 0, 0, 0};  // SCALE: H_ps = sum Jp^T W Js
+#pragma unroll
+  for (int t = 0; t < 27; t++) tot[t] = 0;
+  const bool scl = SCALE && D.scale_opt;
+  for (int sub = 0; sub < nsub; sub++) {
+  const int j_lo = (own_chunks ? bx - chunk0 : sub) * kBuildChunk, j_hi = min(cnt, j_lo + kBuildChunk);
 #pragma unroll
   for (int t = 0; t < 27; t++) acc[t] = 0;
-  double aps[6] = {0, 0, 0, 0, 0, 0};  // SCALE: H_ps = sum Jp^T W Js
-  const bool scl = SCALE && D.scale_opt;
+#pragma unroll
+  for (int t = 0; t < 6; t++) aps[t] = 0;
   const double sc = scl ? D.scl[0] : 1.0;
   PoseXf X;
   kf_xf(D.cam, k, X);  // one camera: the transform is the same for all edges of the key frame
@@ -635,7 +648,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   // A thread's edges two at a time: both list entries, then both records and level bytes, then both points are loaded
   // before the arithmetic (three dependent round trips per PAIR of edges instead of per edge; a key frame's ~600 edges are
   // 2.3 per thread).  Same edges in the same order per thread: the sums are bit-identical.
-  for (int j0 = j_lo + threadIdx.x; j0 < j_hi; j0 += 512) {  // (one trip: a chunk is 2 edges per thread)
+  for (int j0 = j_lo + threadIdx.x; j0 < j_hi; j0 += 512) {  // (a run is at most two trips)
     int ii[2];
     vieo_lba_obs oo[2];
     unsigned char lvv[2];
@@ -736,6 +749,19 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   }
   block_sum<27>(acc, s_red, threadIdx.x);
   if (scl) block_sum<6>(aps, s_red, threadIdx.x);
+  if (nsub > 1) {
+#pragma unroll
+    for (int t = 0; t < 27; t++) tot[t] += acc[t];
+#pragma unroll
+    for (int t = 0; t < 6; t++) tps[t] += aps[t];
+  }
+  }
+  if (nsub > 1) {
+#pragma unroll
+    for (int t = 0; t < 27; t++) acc[t] = tot[t];
+#pragma unroll
+    for (int t = 0; t < 6; t++) aps[t] = tps[t];
+  }
   __shared__ int s_last;
   if (nchunk > 1) {  // this chunk's sums; the last workgroup of the key frame adds the chunks in order
     if (threadIdx.x < 33) {
@@ -2911,7 +2937,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       const size_t nchk = (size_t)H.n_obs / kBuildChunk + nf + 1;
       s.chunk_first = take((size_t)(nf + 1) * 4), s.chunk_cnt = take((size_t)(nf + 1) * 4);
       s.chunk_kf = take(nchk * 4), s.chunk_part = take(nchk * 33 * 8);
-      max_chunks = std::max(max_chunks, (int)nchk);
+      max_chunks = std::max(max_chunks, W <= 4 ? (int)nchk : nf);
     }
     s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)std::max(nf, 1) * H.n_mp * 4);
     s.sc_sys = take((size_t)(6 * nf + 2) * 8), s.psc = take((size_t)((H.n_mp + 63) / 64) * 16);
@@ -3129,6 +3155,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.part0 = (double*)(base + s.part0), D.part = (double*)(base + s.part);
     D.part_m = (double*)(base + s.part_m), D.pmax = (double*)(base + s.pmax);
     D.part_t = (double*)(base + s.part_t), D.tail_cnt = (int*)(base + s.tail_cnt);
+    D.chunk_edges = W <= 4 ? kBuildChunk : (1 << 30);
     D.chunk_first = (int*)(base + s.chunk_first), D.chunk_cnt = (int*)(base + s.chunk_cnt);
     D.chunk_kf = (int*)(base + s.chunk_kf), D.chunk_part = (double*)(base + s.chunk_part);
     D.kf_list = (int*)(base + s.kf_list), D.tab = (int*)(base + s.tab);
@@ -3293,12 +3320,13 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
           return;
         }
         hipLaunchKernelGGL((k_lba_build<MC, SC, 0>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0, 0);
-        hipLaunchKernelGGL((k_lba_build<MC, SC, 1>), dim3(max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks, 0);
+        hipLaunchKernelGGL((k_lba_build<MC, SC, 1>), dim3(max_chunks, W), dim3(256), 0, st, dD, dC, max_chunks, 0);
       };
       if (any_multicam)
         build2(std::true_type(), std::false_type());
       else
         build2(std::false_type(), std::false_type());
+      if (!fused_build && max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0);
       if (with_begin) hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO);
       hipLaunchKernelGGL(k_lba_schur<false>, dim3(std::max(1, schur_grid), W), dim3(256), 0, st, dD, dC, dO);
       if (schur_grid_off > 0) hipLaunchKernelGGL(k_lba_schur<true>, dim3(schur_grid_off, W), dim3(256), 0, st, dD, dC, dO);
@@ -3434,7 +3462,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
           return;
         }
         KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, 0>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0, 0); });
-        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, 1>), dim3(max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks, 0); });
+        KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, 1>), dim3(max_chunks, W), dim3(256), 0, st, dD, dC, max_chunks, 0); });
       };
       if (sco) {
         if (any_multicam)
@@ -3446,6 +3474,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         build2(std::true_type(), std::false_type());
       else
         build2(std::false_type(), std::false_type());
+      if (!fused_build && max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 0); });
     }
     if (any & LBA_BEGIN) KT.launch(KC_BEGIN, [&] { hipLaunchKernelGGL(k_lba_lambda, dim3(W), dim3(256), 0, st, dD, dC, dO); });
     if (any & LBA_TRIAL) {
