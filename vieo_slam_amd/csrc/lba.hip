@@ -84,7 +84,7 @@ struct WinOut {
   double chig0, chig;  // landmark-sharded windows: the (replicated) inertial part, kept out of the reduction
 };
 
-static const int kBuildChunk = 1024;  // edges of a key frame per run of k_lba_build's key-frame half (4 per thread: two trips of two)
+static const int kBuildChunk = 512;  // edges of a key frame per run (= workgroup) of k_lba_build's key-frame half (2 per thread)
 
 struct LbaDev {
   const vieo_lba_obs* obs;
@@ -131,9 +131,9 @@ struct LbaDev {
   int* tail_cnt;                  // arrival counter of k_lba_tail's workgroups (the last one folds the partials)
   // key-frame half of k_lba_build: a key frame's edge list in chunks of kBuildChunk edges, one workgroup each
   int n_chunks;                   // written by k_lba_begin: chunks of the free + active key frames
-  int chunk_edges;                // kBuildChunk in calls of a few windows; batches keep one chunk per key frame -- the fold's
-                                  // device-scope fence (an L2 write-back per workgroup on this multi-XCD part) cost a
-                                  // 205-window step 3.2 -> 13.6 ms of k_lba_build, and a batch fills the device anyway
+  int fold_kernel;                // batches: the runs' sums are added by k_lba_build_fold, not by the last workgroup to arrive
+                                  // (its device-scope fence, an L2 write-back per workgroup on this multi-XCD part, cost a
+                                  // 205-window step 3.2 -> 13.6 ms of k_lba_build)
   int *chunk_first, *chunk_kf;    // [n_free + 1] first chunk of kf_list[a]; [n_chunks] the a of a chunk
   int* chunk_cnt;                 // [n_free] arrival counters (the last workgroup of a key frame folds its chunks' partials)
   double* chunk_part;             // [n_chunks][33] H_pp (21) + b_p (6) + H_ps (6) of a chunk
@@ -355,7 +355,7 @@ k_lba_begin(LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* _
     for (int a = 0; a < nf; a++) {
       const int k = D.kf_list[a];
       D.chunk_first[a] = nchk, D.chunk_cnt[a] = 0;
-      nchk += max(1, (D.kf_edge_first[k + 1] - D.kf_edge_first[k] + D.chunk_edges - 1) / D.chunk_edges);
+      nchk += max(1, (D.kf_edge_first[k + 1] - D.kf_edge_first[k] + kBuildChunk - 1) / kBuildChunk);
     }
     D.chunk_first[nf] = nchk, D.n_chunks = nchk;
   }
@@ -625,22 +625,16 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   const int kfi = D.kf_list[a];
   const LbaKf k = D.kf[kfi];
   const int first = D.kf_edge_first[kfi], cnt = D.kf_edge_first[kfi + 1] - first;
-  // The sums are formed per run of kBuildChunk edges and the runs' sums added in run order -- by the last workgroup of the
-  // key frame when the runs are workgroups of their own (calls of a few windows), by this workgroup one run after the
-  // other otherwise (batches): the same association either way, the result does not depend on what a window is batched with.
-  const bool own_chunks = D.chunk_edges == kBuildChunk;
-  const int nsub = own_chunks ? 1 : max(1, (cnt + kBuildChunk - 1) / kBuildChunk);
-  double acc[27], tot[27];
-  double aps[6] = {0, 0, 0, 0, 0, 0}, tps[6] = {0, 0, 0, 0, 0, 0};  // SCALE: H_ps = sum Jp^T W Js
-#pragma unroll
-  for (int t = 0; t < 27; t++) tot[t] = 0;
-  const bool scl = SCALE && D.scale_opt;
-  for (int sub = 0; sub < nsub; sub++) {
-  const int j_lo = (own_chunks ? bx - chunk0 : sub) * kBuildChunk, j_hi = min(cnt, j_lo + kBuildChunk);
+  // The sums are formed per run of kBuildChunk edges (a workgroup each) and the runs' sums added in run order: by the last
+  // workgroup of the key frame to arrive in calls of a few windows, by k_lba_build_fold in batches (D.fold_kernel: a
+  // device-scope fence per workgroup does not scale) -- the same association either way, a window's result does not depend
+  // on what it is batched with.
+  const int j_lo = (bx - chunk0) * kBuildChunk, j_hi = min(cnt, j_lo + kBuildChunk);
+  double acc[27];
+  double aps[6] = {0, 0, 0, 0, 0, 0};  // SCALE: H_ps = sum Jp^T W Js
 #pragma unroll
   for (int t = 0; t < 27; t++) acc[t] = 0;
-#pragma unroll
-  for (int t = 0; t < 6; t++) aps[t] = 0;
+  const bool scl = SCALE && D.scale_opt;
   const double sc = scl ? D.scl[0] : 1.0;
   PoseXf X;
   kf_xf(D.cam, k, X);  // one camera: the transform is the same for all edges of the key frame
@@ -648,7 +642,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   // A thread's edges two at a time: both list entries, then both records and level bytes, then both points are loaded
   // before the arithmetic (three dependent round trips per PAIR of edges instead of per edge; a key frame's ~600 edges are
   // 2.3 per thread).  Same edges in the same order per thread: the sums are bit-identical.
-  for (int j0 = j_lo + threadIdx.x; j0 < j_hi; j0 += 512) {  // (a run is at most two trips)
+  for (int j0 = j_lo + threadIdx.x; j0 < j_hi; j0 += 512) {  // (one trip: a run is 2 edges per thread)
     int ii[2];
     vieo_lba_obs oo[2];
     unsigned char lvv[2];
@@ -749,19 +743,6 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
   }
   block_sum<27>(acc, s_red, threadIdx.x);
   if (scl) block_sum<6>(aps, s_red, threadIdx.x);
-  if (nsub > 1) {
-#pragma unroll
-    for (int t = 0; t < 27; t++) tot[t] += acc[t];
-#pragma unroll
-    for (int t = 0; t < 6; t++) tps[t] += aps[t];
-  }
-  }
-  if (nsub > 1) {
-#pragma unroll
-    for (int t = 0; t < 27; t++) acc[t] = tot[t];
-#pragma unroll
-    for (int t = 0; t < 6; t++) aps[t] = tps[t];
-  }
   __shared__ int s_last;
   if (nchunk > 1) {  // this chunk's sums; the last workgroup of the key frame adds the chunks in order
     if (threadIdx.x < 33) {
@@ -774,6 +755,7 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
         if ((int)threadIdx.x == 27 + t) v = aps[t];
       D.chunk_part[33 * (size_t)bx + threadIdx.x] = v;
     }
+    if (D.fold_kernel) return;  // (batches: k_lba_build_fold adds the runs)
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -816,6 +798,30 @@ k_lba_build(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, int
       if ((int)threadIdx.x == 27 + t) v = aps[t];
     D.sc_sys[6 * a + threadIdx.x - 27] = v;
   }
+}
+
+// The runs' sums of a key frame added in run order (batches; see k_lba_build): one wavefront per free key frame
+__global__ void __launch_bounds__(64)
+k_lba_build_fold(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl) {
+  const int w = blockIdx.y;
+  if (!(ctl[w].flags & LBA_BUILD)) return;
+  const LbaDev& D = devs[w];
+  const int a = blockIdx.x;
+  if (D.np == 0 || a >= D.n_free) return;
+  const int chunk0 = D.chunk_first[a], nchunk = D.chunk_first[a + 1] - chunk0;
+  if (nchunk <= 1 || threadIdx.x >= 33) return;
+  double v = 0;
+  for (int c = 0; c < nchunk; c++) v += D.chunk_part[33 * (size_t)(chunk0 + c) + threadIdx.x];
+  if (threadIdx.x < 21) {
+    int r = 0, t = threadIdx.x;
+    while (t >= 6 - r) t -= 6 - r, r++;
+    const int c = r + t;
+    D.Hpp[36 * (size_t)a + r * 6 + c] = v;
+    D.Hpp[36 * (size_t)a + c * 6 + r] = v;
+  } else if (threadIdx.x < 27)
+    D.bp[6 * a + threadIdx.x - 21] = v;
+  else if (D.scale_opt)
+    D.sc_sys[6 * a + threadIdx.x - 27] = v;
 }
 
 // H_ss, b_s of the scale vertex: the per-block partials of k_lba_build in fixed order (one workgroup per window)
@@ -2937,7 +2943,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
       const size_t nchk = (size_t)H.n_obs / kBuildChunk + nf + 1;
       s.chunk_first = take((size_t)(nf + 1) * 4), s.chunk_cnt = take((size_t)(nf + 1) * 4);
       s.chunk_kf = take(nchk * 4), s.chunk_part = take(nchk * 33 * 8);
-      max_chunks = std::max(max_chunks, W <= 4 ? (int)nchk : nf);
+      max_chunks = std::max(max_chunks, (int)nchk);
     }
     s.kf_list = take((size_t)H.n_kf * 4), s.tab = take((size_t)std::max(nf, 1) * H.n_mp * 4);
     s.sc_sys = take((size_t)(6 * nf + 2) * 8), s.psc = take((size_t)((H.n_mp + 63) / 64) * 16);
@@ -3155,7 +3161,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
     D.part0 = (double*)(base + s.part0), D.part = (double*)(base + s.part);
     D.part_m = (double*)(base + s.part_m), D.pmax = (double*)(base + s.pmax);
     D.part_t = (double*)(base + s.part_t), D.tail_cnt = (int*)(base + s.tail_cnt);
-    D.chunk_edges = W <= 4 ? kBuildChunk : (1 << 30);
+    D.fold_kernel = W <= 4 ? 0 : 1;
     D.chunk_first = (int*)(base + s.chunk_first), D.chunk_cnt = (int*)(base + s.chunk_cnt);
     D.chunk_kf = (int*)(base + s.chunk_kf), D.chunk_part = (double*)(base + s.chunk_part);
     D.kf_list = (int*)(base + s.kf_list), D.tab = (int*)(base + s.tab);
@@ -3317,10 +3323,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
         if (fused_build) {
           hipLaunchKernelGGL((k_lba_build<MC, SC, 2>), dim3(gq + max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks, gq);
+          if (W > 4) hipLaunchKernelGGL(k_lba_build_fold, dim3(std::max(1, max_nf), W), dim3(64), 0, st, dD, dC);
           return;
         }
         hipLaunchKernelGGL((k_lba_build<MC, SC, 0>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0, 0);
         hipLaunchKernelGGL((k_lba_build<MC, SC, 1>), dim3(max_chunks, W), dim3(256), 0, st, dD, dC, max_chunks, 0);
+        if (W > 4) hipLaunchKernelGGL(k_lba_build_fold, dim3(std::max(1, max_nf), W), dim3(64), 0, st, dD, dC);
       };
       if (any_multicam)
         build2(std::true_type(), std::false_type());
@@ -3459,10 +3467,12 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         constexpr bool MC = decltype(mc)::value, SC = decltype(sc)::value;
         if (fused_build) {  // one launch for both halves
           KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, 2>), dim3(gq + max_chunks + max_imu, W), dim3(256), 0, st, dD, dC, max_chunks, gq); });
+          if (W > 4) KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL(k_lba_build_fold, dim3(std::max(1, max_nf), W), dim3(64), 0, st, dD, dC); });
           return;
         }
         KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, 0>), dim3(gq, W), dim3(256), 0, st, dD, dC, 0, 0); });
         KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL((k_lba_build<MC, SC, 1>), dim3(max_chunks, W), dim3(256), 0, st, dD, dC, max_chunks, 0); });
+        if (W > 4) KT.launch(KC_BUILD, [&] { hipLaunchKernelGGL(k_lba_build_fold, dim3(std::max(1, max_nf), W), dim3(64), 0, st, dD, dC); });
       };
       if (sco) {
         if (any_multicam)
