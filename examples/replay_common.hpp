@@ -171,7 +171,7 @@ struct ReplayBase {
   std::vector<uint8_t> lp_desc;
   size_t lp_key_kfs = (size_t)-1;
   int lp_key_lba = -1;
-  double ms_track = 0, ms_gpu = 0, ms_lba = 0, ms_frames = 0;
+  double ms_track = 0, ms_gpu = 0, ms_lba = 0, ms_lba_job = 0, ms_frames = 0;
   int n_tracked = 0;
   // what the run looked like: wall time of every frame of the timed loop (main() fills it), and the local-BA windows'
   // shapes (key frames, fixed ones among them, points, observations) -- a steady-state run has 10 free key frames plus
@@ -339,7 +339,7 @@ struct ReplayBase {
     std::vector<long> nd_ids;
     std::vector<float> nd_nrm, nd_mx, nd_mn;
     vieo_lba_result res;
-    double ms = 0;
+    double ms = 0, ms_job = 0;  // the solve (pre-integration + local BA call); the whole job on the LocalMapping thread
     int rc = 0;
     // the newest key frame's inertial edge, pre-integrated on the LocalMapping thread too (only the local BA reads it)
     bool need_edge = false;
@@ -492,7 +492,7 @@ struct ReplayBase {
   void lba_apply(LbaJob& J) {
     if (J.rc != 0) std::fprintf(stderr, "local BA / key-frame pre-integration failed: %s\n", vieo_last_error()), std::exit(1);
     if (J.need_edge) kfs[J.edge_kf]->edge = J.edge;
-    ms_lba += J.ms;
+    ms_lba += J.ms, ms_lba_job += J.ms_job;
     n_lba_applied++;
     if (J.res.status != 0) return;
     for (size_t r = 0; r < J.obs.size(); r++)  // ErasePairObs
@@ -534,9 +534,11 @@ struct ReplayBase {
         if (lba_quit) return;
         J = lba_todo, lba_todo = nullptr;
       }
+      const auto tj = std::chrono::steady_clock::now();
       if (J->deferred) lba_build_into(*J);
       lba_solve(J);
       lba_post(*J);
+      J->ms_job = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count();
       {
         std::lock_guard<std::mutex> g(lba_m);
         lba_busy = false;
