@@ -1314,7 +1314,7 @@ __device__ __forceinline__ void lba_generic_dev(const LbaDev& D, int e, int lane
     sRho[0] = rI, sRho[1] = rB, sRho[2] = rE;
     if (mode == 0 && E.has_imu) {
       // J (9 x 24, [PRV_j | PRV_i | Bias_i]) -> local order [i: PR V Bias | j: PR V Bias]
-      double J24[9 * 24];
+      double* J24 = sT;  // (LDS, free until the products below: as a local array it lived in scratch, 1.7 KB per lane)
       imu_linearize(E.M, D.gw, si, sj, sErr, J24, 3, 6);
       for (int a = 0; a < 9; a++) {
         for (int c = 0; c < 30; c++) sJ[a * 30 + c] = 0;
