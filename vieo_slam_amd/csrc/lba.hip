@@ -1251,7 +1251,17 @@ k_lba_assemble(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, 
 __device__ __forceinline__ void lba_generic_dev(const LbaDev& D, int e, int lane, int mode) {
   __shared__ double sJ[9 * 30], sT[9 * 30], sErr[9 + 6], sWe[9], sRho[3];
   __shared__ double sJE[6 * 30], sTE[6 * 30], sWeE[6];  // encoder edge: J in the local order, (rho' Info) J, Info e
-  const LbaImu& E = D.imu[e];
+  // the edge's record staged in LDS by the whole wavefront: lane 0's chains below read it field by field, and every
+  // dependent batch of those reads was a trip to L2
+  static_assert(sizeof(LbaImu) % 8 == 0, "staged in 8-byte words");
+  __shared__ __align__(16) double sE_store[sizeof(LbaImu) / 8];
+  {
+    const double* src = reinterpret_cast<const double*>(&D.imu[e]);
+    for (int i = lane; i < (int)(sizeof(LbaImu) / 8); i += 64) sE_store[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const LbaImu& E = *reinterpret_cast<const LbaImu*>(sE_store);
   const double dI = (double)(float)sqrt(16.919), dB = (double)(float)sqrt(12.592);  // Optimizer.cc:219-222
   if (lane == 0) {
     NSd si, sj;
