@@ -429,11 +429,11 @@ __device__ __forceinline__ void lba_reduce_dev(const LbaDev& D, const WinCtl* __
   }
 }
 __global__ void __launch_bounds__(256)
-k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out) {
+k_lba_reduce(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinOut* __restrict__ out, int tail) {
   __shared__ double s_red[4 * 3];
   const int w = blockIdx.x, fl = ctl[w].flags;
   if (!(fl & (LBA_TRIAL | LBA_BEGIN))) return;
-  lba_reduce_dev(devs[w], ctl, out, w, fl, false, s_red);
+  lba_reduce_dev(devs[w], ctl, out, w, fl, tail != 0, s_red);  // tail: the trial's chi2 comes from k_lba_tail's partials
 }
 
 // 6x3 block Jp^T (rho' Omega) Jx of one active edge (multi-camera rigs: a key frame can see a point in
@@ -2369,6 +2369,7 @@ k_lba_tail(const LbaDev* __restrict__ devs, const WinCtl* __restrict__ ctl, WinO
     if (e >= D.n_imu) return;
     if (tid < 64) lba_generic_dev(D, e, tid, 1);
   }
+  if (D.fold_kernel) return;  // (batches: k_lba_reduce(tail) folds the partials -- no device-scope fence per workgroup)
   // arrival: this workgroup's results are visible device-wide before its count is
   __threadfence();
   __syncthreads();
@@ -3273,12 +3274,16 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   // W = 4 equal, but W = 16 / 64 windows 2.80 -> 3.02 / 5.07 -> 6.47 ms per call -- its residual pass runs four lanes per
   // point over the point's edges (that is what makes it independent of the other workgroups), which is latency-bound and
   // loses to k_lba_error's lane per edge once the launch ramps are amortised over many windows.
-  // VIEO_LBA_FUSED_TAIL=0 / 1 forces the four-launch / one-launch form (A/B runs, tests of both forms).
+  // VIEO_LBA_FUSED_TAIL=0 forces the four-launch form everywhere (A/B runs, tests of both forms).
   static const int fused_tail_env = [] {
     const char* e = getenv("VIEO_LBA_FUSED_TAIL");
-    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    return e ? atoi(e) : -1;
   }();
-  const bool fused_tail = fused_tail_env >= 0 ? fused_tail_env != 0 : W <= 4;
+  // calls of a few windows: the tail's last workgroup folds (fused_tail); batches: the four-launch form (its per-edge
+  // residual kernel has four times the tail's parallelism: the tail without the fold + k_lba_reduce over its partials,
+  // VIEO_LBA_FUSED_TAIL=2, measured 3.9 against 2.9 ms of kernel time per 205-window step); =0: four launches everywhere
+  const bool fused_tail = fused_tail_env != 0 && W <= 4;
+  const bool split_tail = fused_tail_env == 2 && W > 4;
   static const int fused_build_env = [] {  // VIEO_LBA_FUSED_BUILD=0 / 1: both halves of k_lba_build in one launch (A/B runs)
     const char* e = getenv("VIEO_LBA_FUSED_BUILD");
     return e ? (atoi(e) != 0 ? 1 : 0) : -1;
@@ -3376,7 +3381,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         hipLaunchKernelGGL(k_lba_update_points, dim3(gq, W), dim3(256), 0, st, dD, dC, dO);
         hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1);
         if (max_imu > 0) hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1);
-        hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO);
+        hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO, 0);
       }
       VIEO_HIP_CHECK(hipGetLastError());
       return VIEO_OK;
@@ -3532,11 +3537,14 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         KT.launch(KC_LDLT, [&] { hipLaunchKernelGGL(k_lba_ldltg<kLdGThreads>, dim3(W), dim3(kLdGThreads), ldg_lds_bytes(nbg), st, dD, dC, dO, nbg); });
       if (fused_tail)
         KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_tail, dim3(gq + max_imu, W), dim3(256), 0, st, dD, dC, dO, gq, (WinPol*)nullptr, (WinCtl*)nullptr, 0, 0); });
-      else {
+      else if (split_tail) {
+        KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_tail, dim3(gq + max_imu, W), dim3(256), 0, st, dD, dC, dO, gq, (WinPol*)nullptr, (WinCtl*)nullptr, 0, 0); });
+        KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO, 1); });
+      } else {
         KT.launch(KC_UPDATE, [&] { hipLaunchKernelGGL(k_lba_update_points, dim3(gq, W), dim3(256), 0, st, dD, dC, dO); });
         KT.launch(KC_ERROR, [&] { hipLaunchKernelGGL(k_lba_error, dim3(ge, W), dim3(256), 0, st, dD, dC, 1); });
         if (max_imu > 0) KT.launch(KC_GENERIC, [&] { hipLaunchKernelGGL(k_lba_generic, dim3(max_imu, W), dim3(64), 0, st, dD, dC, 1); });
-        KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO); });
+        KT.launch(KC_OTHER, [&] { hipLaunchKernelGGL(k_lba_reduce, dim3(W), dim3(256), 0, st, dD, dC, dO, 0); });
       }
       if (sh) {  // chi2 and the landmark part of the gain-ratio scale
         if ((rc = shard_exchange(sh, sh->d_buf + shard_sys, 4 * (size_t)W, st)) != VIEO_OK) return rc;
