@@ -67,6 +67,9 @@ class ORBextractor {
     // mvImagePyramid (ORBextractor.h:54) is read by Frame::ComputeStereoMatches only (src/Frame.cc:457,536-557), and
     // shim/Frame_hot.cc runs that on the device where the planes already are: the eight bordered planes (1.4 MB for a
     // 752 x 480 image) are copied back only on request -- FetchImagePyramid(), or always with VIEO_SHIM_EAGER_PYRAMID.
+    // CONTRACT CHANGE against the reference's operator(): after the call mvImagePyramid holds EMPTY cv::Mat's unless one
+    // of the two is used.  No other reader exists in the reference today (grep mvImagePyramid: ORBextractor.cc itself and
+    // the two places in Frame.cc named above); code added later that reads the member must ask for the planes.
 #ifdef VIEO_SHIM_EAGER_PYRAMID
     FetchImagePyramid();
 #else
