@@ -524,6 +524,11 @@ def single_stream_leg(seq, n_frames):
         "ms_per_frame_tracking_call": float(np.mean([x["ms_track_call"] for x in runs])),
         "ms_per_frame_tracking_call_gpu": float(np.mean([x["ms_track_gpu"] for x in runs])),
         "ms_per_frame_without_local_ba": r["ms_frame_without_local_ba"], "ms_per_local_ba_mean": r["ms_per_local_ba"],
+        # the vieo_local_bundle_adjustment_vio call alone (as the Python replays time it); the key-frame pair's pre-integration
+        # (LocalMapping::ProcessNewKeyFrame's in the reference) and the whole LocalMapping job (flattening the window +
+        # pre-integration + the call + MapPoint::UpdateNormalAndDepth) beside it
+        "ms_per_key_frame_preintegration": r.get("ms_per_key_frame_preintegration"),
+        "ms_per_local_mapping_job": r.get("ms_per_local_mapping_job"),
         "host_syncs_per_frame": 1, "frames_with_the_wider_search_window": r["widened"],
         "key_frames": r["key_frames"], "map_points": r["map_points"],
         "ate_vs_oracle_m": None, "max_position_difference_vs_oracle_m": None, "vs_cpu_single_stream": None,

@@ -171,7 +171,7 @@ struct ReplayBase {
   std::vector<uint8_t> lp_desc;
   size_t lp_key_kfs = (size_t)-1;
   int lp_key_lba = -1;
-  double ms_track = 0, ms_gpu = 0, ms_lba = 0, ms_lba_job = 0, ms_frames = 0;
+  double ms_track = 0, ms_gpu = 0, ms_lba = 0, ms_kf_preint = 0, ms_lba_job = 0, ms_frames = 0;
   int n_tracked = 0;
   // what the run looked like: wall time of every frame of the timed loop (main() fills it), and the local-BA windows'
   // shapes (key frames, fixed ones among them, points, observations) -- a steady-state run has 10 free key frames plus
@@ -339,7 +339,7 @@ struct ReplayBase {
     std::vector<long> nd_ids;
     std::vector<float> nd_nrm, nd_mx, nd_mn;
     vieo_lba_result res;
-    double ms = 0, ms_job = 0;  // the solve (pre-integration + local BA call); the whole job on the LocalMapping thread
+    double ms = 0, ms_preint = 0, ms_job = 0;  // the local BA call; the key-frame pair's pre-integration; the whole job on the LocalMapping thread
     int rc = 0;
     // the newest key frame's inertial edge, pre-integrated on the LocalMapping thread too (only the local BA reads it)
     bool need_edge = false;
@@ -471,7 +471,7 @@ struct ReplayBase {
     if (rc != 0) J.rc = rc;
   }
   static void lba_solve(LbaJob* J) {  // (any host thread)
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
     if (J->need_edge) {
       const int32_t first[2] = {0, (int32_t)J->samples.size()};
       double prv[81];
@@ -483,6 +483,10 @@ struct ReplayBase {
       }
       std::memcpy(J->edge.Sigma, prv, sizeof(prv));  // mSigmaijPRV for the local BA
       J->edges.back().imu = J->edge;                 // (the newest key frame's edge is the last one built)
+      // (the key frame's pre-integration is LocalMapping::ProcessNewKeyFrame's in the reference, not the optimiser's: timed apart)
+      const auto t1 = std::chrono::steady_clock::now();
+      J->ms_preint = std::chrono::duration<double, std::milli>(t1 - t0).count();
+      t0 = t1;
     }
     J->rc = vieo_local_bundle_adjustment_vio(&J->P, J->K.data(), (int)J->K.size(), J->X.data(), J->close.data(), (int)J->pts.size(),
                                              J->obs.data(), (int)J->obs.size(), J->edges.data(), (int)J->edges.size(), nullptr,
@@ -492,7 +496,7 @@ struct ReplayBase {
   void lba_apply(LbaJob& J) {
     if (J.rc != 0) std::fprintf(stderr, "local BA / key-frame pre-integration failed: %s\n", vieo_last_error()), std::exit(1);
     if (J.need_edge) kfs[J.edge_kf]->edge = J.edge;
-    ms_lba += J.ms, ms_lba_job += J.ms_job;
+    ms_lba += J.ms, ms_kf_preint += J.ms_preint, ms_lba_job += J.ms_job;
     n_lba_applied++;
     if (J.res.status != 0) return;
     for (size_t r = 0; r < J.obs.size(); r++)  // ErasePairObs

@@ -122,7 +122,7 @@ struct LbaJob {
   std::vector<long> nd_ids;
   std::vector<float> nd_nrm, nd_mx, nd_mn;
   vieo_lba_result res;
-  double ms = 0;
+  double ms = 0, ms_preint = 0;
   int rc = 0;
   bool need_edge = false;
   int edge_kf = -1;
@@ -165,7 +165,7 @@ struct Replay {
   int lp_key_lba = -1;
   bool prefetch = false, prefetched = false;
   int last_frame = -1;
-  double ms_track = 0, ms_gpu = 0, ms_lba = 0;
+  double ms_track = 0, ms_gpu = 0, ms_lba = 0, ms_kf_preint = 0;
   std::vector<double> frame_ms;
   long win_kfs = 0, win_fixed = 0, win_points = 0, win_obs = 0;
   int win_max_kfs = 0, win_max_fixed = 0;
@@ -432,7 +432,7 @@ struct Replay {
     if (rc != 0) J.rc = rc;
   }
   static void lba_solve(LbaJob* J) {  // (any host thread)
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
     if (J->need_edge) {
       const int32_t first[2] = {0, (int32_t)J->samples.size()};
       double prv[81];
@@ -444,6 +444,10 @@ struct Replay {
       }
       std::memcpy(J->edge.Sigma, prv, sizeof(prv));  // mSigmaijPRV for the local BA
       J->edges.back().imu = J->edge;                 // (the newest key frame's edge is the last one built)
+      // (the key frame's pre-integration is LocalMapping::ProcessNewKeyFrame's in the reference, not the optimiser's: timed apart)
+      const auto t1 = std::chrono::steady_clock::now();
+      J->ms_preint = std::chrono::duration<double, std::milli>(t1 - t0).count();
+      t0 = t1;
     }
     if (J->vision)
       J->rc = vieo_local_bundle_adjustment(&J->P.base, J->K.data(), (int)J->K.size(), J->X.data(), (int)J->pts.size(), J->obs.data(),
@@ -457,7 +461,7 @@ struct Replay {
   void lba_apply(LbaJob& J) {
     if (J.rc != 0) std::fprintf(stderr, "local BA / key-frame pre-integration failed: %s\n", vieo_last_error()), std::exit(1);
     if (J.need_edge) kfs[J.edge_kf]->edge = J.edge;
-    ms_lba += J.ms;
+    ms_lba += J.ms, ms_kf_preint += J.ms_preint;
     n_lba_applied++;
     if (J.res.status != 0) return;
     for (size_t r = 0; r < J.obs.size(); r++)  // ErasePairObs: this key's observation of the point
@@ -860,10 +864,10 @@ int main(int argc, char** argv) {
   }
   const int nf = n - 1;
   std::printf("{\"mode\": \"%s\", \"cameras\": %d, \"frames\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"ms_track_call\": %.4f, "
-              "\"ms_track_gpu\": %.4f, \"local_bas\": %d, \"ms_per_local_ba\": %.4f, \"key_frames\": %zu, \"map_points\": %zu, "
+              "\"ms_track_gpu\": %.4f, \"local_bas\": %d, \"ms_per_local_ba\": %.4f, \"ms_per_key_frame_preintegration\": %.4f, \"key_frames\": %zu, \"map_points\": %zu, "
               "\"widened\": %d, \"lba_lag\": %d, \"prefetch\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e, %s}\n",
               vision ? "vision" : "rig", vision ? 2 : S.n_cams, nf, ms_total / nf, 1e3 * nf / ms_total, R.ms_track / nf, R.ms_gpu / nf, R.n_lba,
-              R.n_lba_applied ? R.ms_lba / R.n_lba_applied : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, lba_lag, prefetch, std::sqrt(e2 / n),
+              R.n_lba_applied ? R.ms_lba / R.n_lba_applied : 0.0, R.n_lba_applied ? R.ms_kf_preint / R.n_lba_applied : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, lba_lag, prefetch, std::sqrt(e2 / n),
               emax, R.run_shape_json().c_str());
   return 0;
 }

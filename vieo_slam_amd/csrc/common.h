@@ -40,7 +40,13 @@ struct DevBuf {
       p = nullptr, cap = 0;
     }
     if (bytes <= cap) return VIEO_OK;
-    if (p) (void)hipFree(p);
+    // a buffer that GROWS gets half as much again (at most 64 MB of slack): a local-BA arena grows with its map, and an
+    // exact fit was a hipFree (a device synchronisation) + hipMalloc on every call, 0.4 ms of a 3.6 ms window
+    if (p) {
+      const size_t slack = bytes / 2;
+      bytes += slack < ((size_t)64 << 20) ? slack : ((size_t)64 << 20);
+      (void)hipFree(p);
+    }
     p = nullptr;
     cap = 0;
     VIEO_HIP_CHECK(hipMalloc(&p, bytes));

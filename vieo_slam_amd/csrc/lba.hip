@@ -3006,6 +3006,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   // ---- staging, part 2: the inputs of every window into the pinned copy of the arena (index structures, key frames,
   // inertial edges with their information matrices, points).  Windows are independent and the work is memory copies,
   // so a large batch is split over a few host threads (6.6 ms on one thread for the 103 windows of a bench step).
+  const double ms_layout = ms_since(t_enter);
   auto fill_window = [&](int w) -> int {
     WinHost& H = win[w];
     const Off& o = off[w];
@@ -3146,6 +3147,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
         if (rcs[i] != VIEO_OK) return fill_window(live[i]);  // again on this thread: the error text is thread-local
     }
   }
+  const double ms_filled = ms_since(t_enter);
   const size_t small_bytes = (size_t)W * (sizeof(LbaDev) + sizeof(WinCtl) + sizeof(WinOut) + sizeof(int));
   if ((rc = g_arena.ensure(arena)) != VIEO_OK) return rc;
   if ((rc = g_small.ensure(small_bytes)) != VIEO_OK) return rc;
@@ -3205,6 +3207,7 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   WinCtl* ctl = (WinCtl*)g_small_h.p;
   WinOut* out = (WinOut*)(ctl + W);
   double* h_sc = (double*)(out + W);  // reduced scalars of a sharded run
+  const double ms_described = ms_since(t_enter);
   VIEO_HIP_CHECK(hipMemcpyAsync(base, hs, res_end, hipMemcpyHostToDevice, st));
   VIEO_HIP_CHECK(hipMemsetAsync(base + res_end, 0, zero_end - res_end, st));
   VIEO_HIP_CHECK(hipMemcpyAsync(dD, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
@@ -3638,7 +3641,8 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   VIEO_HIP_CHECK(hipStreamSynchronize(st));
   if (host_timing)
     fprintf(stderr, "lba_run: %d windows, staging %.3f ms, %d rounds %.3f ms (of which waiting for the stream %.3f), "
-                    "results copy %.3f ms\n", W, ms_staged, n_rounds, ms_rounds, ms_wait, ms_since(t_res));
+                    "results copy %.3f ms; staging: layout %.3f, windows filled %.3f, descriptors %.3f, enqueued %.3f\n", W, ms_staged,
+            n_rounds, ms_rounds, ms_wait, ms_since(t_res), ms_layout, ms_filled, ms_described, ms_staged);
   for (int w = 0; w < W; w++) {
     WinHost& H = win[w];
     if (H.skip) continue;
