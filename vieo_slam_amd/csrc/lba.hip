@@ -3212,7 +3212,6 @@ static int lba_run(const LbaShard* sh, const GbaMode* gba, int n_windows, const 
   VIEO_HIP_CHECK(hipMemsetAsync(base + res_end, 0, zero_end - res_end, st));
   VIEO_HIP_CHECK(hipMemcpyAsync(dD, devs.data(), (size_t)W * sizeof(LbaDev), hipMemcpyHostToDevice, st));
   VIEO_HIP_CHECK(hipMemsetAsync(dO, 0, (size_t)W * sizeof(WinOut), st));
-  const int n_max = pd * max_nf + sco;
   const int occ_max = ((6 * max_nf + sco + 64) / 64) * ((max_mp + kChunkLm - 1) / kChunkLm);
   // per solver class: the largest system of the class in this batch (0: the class is empty)
   int cls_max[3] = {0, 0, 0};

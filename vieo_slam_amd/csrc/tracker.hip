@@ -672,7 +672,6 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, SideR
   uint8_t* d_outl = W + t->w_outl;
   float* d_xyz = (float*)(W + t->w_xyz);
   float* d_dep = (float*)(W + t->w_dep);
-  const vieo_sbp_rig* d_rig = (const vieo_sbp_rig*)t->d_const;
   const float close = std::max(10.0f, P.th_depth);
   const int vio = t->vision ? 0 : 1;
   void* f1 = t->vision ? (void*)&dH->f1.base : (void*)&dH->f1;
