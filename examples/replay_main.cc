@@ -30,6 +30,7 @@ struct Replay : ReplayBase {
   bool prefetch = false, prefetched = false;
   int last_frame = -1;
   double ms_prep = 0, ms_post = 0, ms_finish = 0;  // the caller's own work per frame: before / after the call, bookkeeping
+  double next_bias[6];
 
   explicit Replay(const Sequence& s) : ReplayBase(s) {
     vieo_tracker_params P;
@@ -63,10 +64,31 @@ struct Replay : ReplayBase {
       prefetched = k + 1 <= last_frame;
       if (prefetched) {
         in.next_left = S.image(k + 1, 0), in.next_right = S.image(k + 1, 1);
-        // ... and its pre-integration, which starts at this frame unless the map is updated in between
+        // ... and its pre-integration, which starts at this frame -- unless LocalMapping's write-back is applied in between:
+        // then the next prediction starts at the newest key frame, with the bias the local BA gave it.  When that solve has
+        // finished by now its result is known and the run-ahead integration is told its reference (next_ref_bias); when it
+        // has not, the next call integrates on its own (either way its outputs are the same bits).
         int j0, nj;
-        S.imu_between(t, S.time(k + 1), &j0, &nj);
-        in.next_imu = S.imu.data() + j0, in.next_n_imu = nj, in.next_t_cur = S.time(k + 1);
+        if (job && k + 1 >= lba_due) {
+          bool done;
+          {
+            std::lock_guard<std::mutex> g(lba_m);
+            done = !lba_busy;
+          }
+          if (done && job->rc == 0 && job->res.status == 0) {
+            const Frame& kf = *kfs.back();
+            const vieo_navstate* nav = &kf.nav;
+            for (size_t i = 0; i < job->local.size(); i++)
+              if (job->local[i] == kf.id && !job->K[i].fixed) nav = &job->navs[i];
+            std::memcpy(next_bias, nav->bg, 48);  // bg[3], ba[3] are adjacent in vieo_navstate
+            S.imu_between(kf.t, S.time(k + 1), &j0, &nj);
+            in.next_ref_bias = next_bias, in.next_t_ref = kf.t;
+            in.next_imu = S.imu.data() + j0, in.next_n_imu = nj, in.next_t_cur = S.time(k + 1);
+          }
+        } else {
+          S.imu_between(t, S.time(k + 1), &j0, &nj);
+          in.next_imu = S.imu.data() + j0, in.next_n_imu = nj, in.next_t_cur = S.time(k + 1);
+        }
       }
     }
     int i0, ni;

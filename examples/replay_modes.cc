@@ -165,6 +165,7 @@ struct Replay {
   int lp_key_lba = -1;
   bool prefetch = false, prefetched = false;
   int last_frame = -1;
+  double next_bias[6];
   double ms_track = 0, ms_gpu = 0, ms_lba = 0, ms_kf_preint = 0;
   std::vector<double> frame_ms;
   long win_kfs = 0, win_fixed = 0, win_points = 0, win_obs = 0;
@@ -652,9 +653,29 @@ struct Replay {
       if (prefetched) {
         set_images(in, k + 1, true);
         if (!vision) {
+          // (as in examples/replay_main.cc: when LocalMapping's write-back comes in between, the next prediction starts at
+          // the newest key frame with the bias the local BA gave it -- known once that solve has finished)
           int j0, nj;
-          S.imu_between(t, S.time(k + 1), &j0, &nj);
-          in.next_imu = S.imu.data() + j0, in.next_n_imu = nj, in.next_t_cur = S.time(k + 1);
+          if (job && k + 1 >= lba_due) {
+            bool done;
+            {
+              std::lock_guard<std::mutex> g(lba_m);
+              done = !lba_busy;
+            }
+            if (done && job->rc == 0 && job->res.status == 0) {
+              const MFrame& kf = *kfs.back();
+              const vieo_navstate* nav = &kf.nav;
+              for (size_t i = 0; i < job->local.size(); i++)
+                if (job->local[i] == kf.id && !job->K[i].fixed) nav = &job->navs[i];
+              std::memcpy(next_bias, nav->bg, 48);  // bg[3], ba[3] are adjacent in vieo_navstate
+              S.imu_between(kf.t, S.time(k + 1), &j0, &nj);
+              in.next_ref_bias = next_bias, in.next_t_ref = kf.t;
+              in.next_imu = S.imu.data() + j0, in.next_n_imu = nj, in.next_t_cur = S.time(k + 1);
+            }
+          } else {
+            S.imu_between(t, S.time(k + 1), &j0, &nj);
+            in.next_imu = S.imu.data() + j0, in.next_n_imu = nj, in.next_t_cur = S.time(k + 1);
+          }
         }
       }
     }

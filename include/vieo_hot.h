@@ -1213,6 +1213,14 @@ typedef struct vieo_track_input {
   double next_t_cur;
   const uint8_t* next_images[4];        /* rig trackers: the next frame's camera images instead of next_left / next_right
                                          * (all of them or none); its extraction runs ahead, its stereo stage in its call */
+  /* ... and when the NEXT call's reference will not be this frame: the caller is about to apply a local-BA write-back, so
+   * the next prediction starts at the last key frame (Tracking.cc:392-409) and integrates every sample since -- 0.5 ms at
+   * the head of that frame's chain.  The run-ahead integration can be told its reference: next_imu = the samples for
+   * [next_t_ref, next_t_cur], next_ref_bias = that key frame's (bg, ba) as they will be AFTER the write-back.  Same rule:
+   * the next call uses the result only if its own t_ref / t_cur / samples / nav_ref.bg / nav_ref.ba are bit for bit what was
+   * integrated.  NULL: the reference is this frame (above). */
+  const double* next_ref_bias;          /* [6] bg, ba */
+  double next_t_ref;
 } vieo_track_input;
 
 #define VIEO_TRACK_OK 0

@@ -357,3 +357,23 @@ def test_gpu_tracker_frame_pipelining_is_bit_identical(tmp_path):
         out[pf] = (json.loads(line), open(traj, "rb").read())
     assert out[0][1] == out[1][1] and out[1][0]["prefetch"] == 1
     print("frame pipelining: C++ replay %.3f -> %.3f ms per frame" % (out[0][0]["ms_per_frame"], out[1][0]["ms_per_frame"]))
+
+
+@pytest.mark.gpu
+def test_gpu_cpp_replay_pipelined_equals_unpipelined_bytes(tmp_path):
+    """Frame pipelining in the C++ replay -- the next frame's extraction, stereo stage and pre-integration run ahead, the
+    latter also when the next call's reference is the newest key frame behind a local-BA write-back
+    (vieo_track_input.next_ref_bias: the caller names the reference's bias once LocalMapping's solve has finished) -- changes
+    no output: the trajectories of --prefetch 1 and --prefetch 0 are the same bytes."""
+    from tools.write_sequence import write_sequence
+    exe = os.path.join(ROOT, "examples", "replay_main")
+    n = 60
+    seq = replay.Sequence(1, n)
+    path = str(tmp_path / "seq.vseq")
+    write_sequence(path, 1, n, seq)
+    out = {}
+    for pf in (0, 1):
+        traj = str(tmp_path / ("traj%d.bin" % pf))
+        subprocess.check_output([exe, path, traj, "--quiet", "--lba-lag", "8", "--prefetch", str(pf)], timeout=600)
+        out[pf] = open(traj, "rb").read()
+    assert len(out[0]) == n * 176 and out[0] == out[1]

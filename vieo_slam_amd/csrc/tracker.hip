@@ -46,6 +46,7 @@ struct SpecImu {
   vieo_imu_noise noise;
   double ti, tj;
   int32_t first[2];
+  double xbias[6];  // next_ref_bias: the reference's bias when it is not this frame's predicted one
 };
 
 // download header
@@ -894,6 +895,27 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   // (a frame extracted ahead: there is no extraction to run beside, the prediction and the projection are the next links of
   // the chain itself -- on this stream, without the two event hops to the second one and back: ~12 us)
   const hipStream_t s_head = pref ? st : t->st_imu;
+  // the next frame's pre-integration run ahead: with this frame as its reference (behind this frame's prediction, in
+  // side_rest below) or with a reference the caller names (spec_ref, started right behind the prediction's launch)
+  const bool spec_any = !t->vision && in->next_imu && in->next_n_imu > 0 && in->next_n_imu <= t->imu_cap;
+  const bool spec_ref = spec_any && in->next_ref_bias != nullptr, spec = spec_any && !spec_ref;
+  const auto spec_launch = [&](double t_ref, const double* ref_bias) -> int {  // ref_bias: null = this frame's predicted bias
+    SpecImu& S = *(SpecImu*)t->h_spec;
+    S.noise = H.noise, S.ti = t_ref, S.tj = in->next_t_cur, S.first[0] = 0, S.first[1] = in->next_n_imu;
+    for (int k = 0; k < 6; k++) S.xbias[k] = ref_bias ? ref_bias[k] : 0.0;
+    memcpy(t->h_spec + t->sp_samples, in->next_imu, (size_t)in->next_n_imu * sizeof(vieo_imu_sample));
+    VIEO_HIP_CHECK(hipMemcpyAsync(t->d_spec, t->h_spec, t->sp_samples + (size_t)in->next_n_imu * sizeof(vieo_imu_sample), hipMemcpyHostToDevice, t->st_imu));
+    SpecImu* dS = (SpecImu*)t->d_spec;
+    const double* bias = ref_bias ? dS->xbias : (const double*)(t->d_spec + t->sp_bias);
+    const int rc_pre = vieo_imu_preintegrate_batch_device(&dS->noise, (const vieo_imu_sample*)(t->d_spec + t->sp_samples), dS->first, &dS->ti,
+                                                          &dS->tj, bias, bias + 3, 1, (vieo_imu_preint*)(t->d_spec + t->sp_pre),
+                                                          (double*)(t->d_spec + t->sp_prv), (int32_t*)(t->d_spec + t->sp_pst), t->st_imu);
+    if (rc_pre != VIEO_OK) return rc_pre;
+    VIEO_HIP_CHECK(hipEventRecord(t->ev_spec, t->st_imu));
+    t->spec_samples.assign(in->next_imu, in->next_imu + in->next_n_imu);
+    t->spec_n = in->next_n_imu, t->spec_ti = t_ref, t->spec_tj = in->next_t_cur;
+    return VIEO_OK;
+  };
   if (!t->vision) {
     // the pre-integration beside the extraction -- or, run ahead by the previous call (next_imu), if what that call
     // integrated is bit for bit what this call asks for
@@ -945,7 +967,6 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
   // the frame's keys / descriptors (mvKeys / mDescriptors: the left image's, or the rig's concatenation) are final here:
   // what the second stream reads of this one (the rig's groups, the keys' / descriptors' copies back)
   TRK_HIP(hipEventRecord(t->ev_ext, st));
-  const bool spec = !t->vision && in->next_imu && in->next_n_imu > 0 && in->next_n_imu <= t->imu_cap;
   // The rest of the second stream's work is read by the tail behind the first optimisation at the earliest: the host hands
   // it over AFTER that kernel's launch.  (Once the frame was extracted ahead the host's launches are the head of the
   // critical path: twenty runtime calls at 2-5 us each used to stand between k_track_adopt and the first search kernel;
@@ -986,6 +1007,14 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
       TRK_HIP(hipEventRecord(t->ev_spec, t->st_imu));
       t->spec_samples.assign(in->next_imu, in->next_imu + in->next_n_imu);
       t->spec_n = in->next_n_imu, t->spec_ti = in->t_cur, t->spec_tj = in->next_t_cur;
+    }
+    // ... or of [next_t_ref, next_t_cur] with the bias the caller names (next_ref_bias: the next call's reference is a key
+    // frame).  Measured and dropped: starting this one right behind the prediction -- nothing of this frame enters it -- on
+    // the second stream (tracking call 0.730 against 0.717 ms here) or on a stream of its own (a fourth stream of the
+    // tracker shares a hardware queue with somebody: the local BA beside it went from 3.2 to 3.9 ms).
+    if (spec_ref) {
+      const int rc_pre = spec_launch(in->next_t_ref, in->next_ref_bias);
+      if (rc_pre != VIEO_OK) return rc_pre;
     }
     return VIEO_OK;
   };
@@ -1055,8 +1084,10 @@ int vieo_track_frame(vieo_tracker* t, const vieo_track_input* in, vieo_track_out
     t->replica_repeats++;
   }
 #undef TRK_HIP
-  if (spec) {  // (the bias the run-ahead integration used: the next call's nav_ref must carry exactly it)
+  if (spec || spec_ref) {  // (the bias the run-ahead integration used: the next call's nav_ref must carry exactly it)
     for (int k = 0; k < 3; k++) t->spec_bias[k] = O->nav_pred.bg[k], t->spec_bias[3 + k] = O->nav_pred.ba[k];
+    if (spec_ref)
+      for (int k = 0; k < 6; k++) t->spec_bias[k] = in->next_ref_bias[k];
     t->spec_valid = true;
   }
   memset(out, 0, sizeof(*out));

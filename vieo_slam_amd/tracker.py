@@ -31,7 +31,8 @@ TRACK_INPUT_DTYPE = np.dtype([
     ("t_cur", "<f8"), ("nav_ref", NAVSTATE_DTYPE), ("nav_last", NAVSTATE_DTYPE), ("nav_prior", "<u8"), ("H_prior", "<u8"),
     ("n_last", "<i4"), ("last_points", "<u8"), ("last_track_depth", "<u8"), ("n_local", "<i4"), ("local_version", "<i4"),
     ("local_points", "<u8"), ("local_desc", "<u8"), ("local_alias", "<u8"), ("images", "<u8", 4), ("next_left", "<u8"),
-    ("next_right", "<u8"), ("use_prefetched", "<i4"), ("next_n_imu", "<i4"), ("next_imu", "<u8"), ("next_t_cur", "<f8"), ("next_images", "<u8", 4)],
+    ("next_right", "<u8"), ("use_prefetched", "<i4"), ("next_n_imu", "<i4"), ("next_imu", "<u8"), ("next_t_cur", "<f8"), ("next_images", "<u8", 4), ("next_ref_bias", "<u8"),
+    ("next_t_ref", "<f8")],
     align=True)
 TRACK_OUTPUT_DTYPE = np.dtype([
     ("status", "<i4"), ("n_keys", "<i4"), ("key_cap", "<i4"), ("keys", "<u8"), ("desc", "<u8"), ("uright", "<u8"),
