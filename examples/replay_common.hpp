@@ -172,6 +172,7 @@ struct ReplayBase {
   size_t lp_key_kfs = (size_t)-1;
   int lp_key_lba = -1;
   double ms_track = 0, ms_gpu = 0, ms_lba = 0, ms_kf_preint = 0, ms_lba_job = 0, ms_frames = 0;
+  double ms_wait_lm = 0, ms_apply = 0;  // the write-back on the tracking thread: waiting for LocalMapping / copying its results
   int n_tracked = 0;
   // what the run looked like: wall time of every frame of the timed loop (main() fills it), and the local-BA windows'
   // shapes (key frames, fixed ones among them, points, observations) -- a steady-state run has 10 free key frames plus
@@ -561,13 +562,17 @@ struct ReplayBase {
   // the pending write-back reaches the tracker before frame k
   void before_frame(int k) {
     if (job && k >= lba_due) {
+      const auto t0 = std::chrono::steady_clock::now();
       {
         std::unique_lock<std::mutex> g(lba_m);
         lba_cv.wait(g, [&] { return !lba_busy; });
       }
+      const auto t1 = std::chrono::steady_clock::now();
       lba_apply(*job);
-      job.reset();
+      job.reset();  // (frees the job's arrays)
       map_updated = true;
+      ms_wait_lm += std::chrono::duration<double, std::milli>(t1 - t0).count();
+      ms_apply += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     }
   }
 

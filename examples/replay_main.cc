@@ -305,9 +305,9 @@ int main(int argc, char** argv) {
   std::printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"ms_track_call\": %.4f, \"ms_track_gpu\": %.4f, "
               "\"ms_frame_without_local_ba\": %.4f, \"local_bas\": %d, \"ms_per_local_ba\": %.4f, \"ms_per_key_frame_preintegration\": %.4f, \"ms_per_local_mapping_job\": %.4f, \"key_frames\": %zu, "
               "\"map_points\": %zu, \"widened\": %d, \"lba_lag\": %d, \"prefetch\": %d, \"ate_rmse_vs_truth_m\": %.6e, \"max_err_vs_truth_m\": %.6e, "
-              "\"caller_ms_per_frame\": {\"map_write_back\": %.4f, \"before_call\": %.4f, \"after_call\": %.4f, \"key_frame_bookkeeping\": %.4f}, %s}\n",
+              "\"caller_ms_per_frame\": {\"map_write_back\": %.4f, \"of_which_waiting_for_local_mapping\": %.4f, \"before_call\": %.4f, \"after_call\": %.4f, \"key_frame_bookkeeping\": %.4f}, %s}\n",
               nf, ms_total / nf, 1e3 * nf / ms_total, R.ms_track / nf, R.ms_gpu / nf, R.ms_frames / nf, R.n_lba,
               R.n_lba ? R.ms_lba / R.n_lba : 0.0, R.n_lba ? R.ms_kf_preint / R.n_lba : 0.0, R.n_lba ? R.ms_lba_job / R.n_lba : 0.0, R.kfs.size(), R.mp_bad.size(), R.widened, lba_lag, prefetch, std::sqrt(e2 / n), emax,
-              ms_before / nf, R.ms_prep / nf, R.ms_post / nf, R.ms_finish / nf, R.run_shape_json().c_str());
+              ms_before / nf, R.ms_wait_lm / nf, R.ms_prep / nf, R.ms_post / nf, R.ms_finish / nf, R.run_shape_json().c_str());
   return 0;
 }
