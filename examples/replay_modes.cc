@@ -124,7 +124,7 @@ struct LbaJob {
   vieo_lba_result res;
   double ms = 0, ms_preint = 0;
   int rc = 0;
-  bool need_edge = false;
+  bool need_edge = false, edge_done = false;  // edge_done: the pre-integration has run (on the helper thread)
   int edge_kf = -1;
   std::vector<vieo_imu_sample> samples;
   vieo_imu_noise noise;
@@ -158,6 +158,11 @@ struct Replay {
   std::condition_variable lba_cv;
   LbaJob* lba_todo = nullptr;
   bool lba_busy = false, lba_quit = false;
+  std::thread pre_thread;  // its helper: the key-frame pair's pre-integration beside the window's flattening
+  std::mutex pre_m;
+  std::condition_variable pre_cv;
+  LbaJob* pre_todo = nullptr;
+  bool pre_busy = false, pre_quit = false;
   std::vector<long> lp;
   std::vector<vieo_frustum_point> lp_pts;
   std::vector<uint8_t> lp_desc;
@@ -208,6 +213,14 @@ struct Replay {
       }
       lba_cv.notify_all();
       lba_thread.join();
+    }
+    if (pre_thread.joinable()) {
+      {
+        std::lock_guard<std::mutex> g(pre_m);
+        pre_quit = true;
+      }
+      pre_cv.notify_all();
+      pre_thread.join();
     }
     vieo_tracker_destroy(trk);
   }
@@ -432,24 +445,25 @@ struct Replay {
                                                       J.nd_mn.data());
     if (rc != 0) J.rc = rc;
   }
+  // the key-frame pair's pre-integration (LocalMapping::ProcessNewKeyFrame's in the reference, not the optimiser's: timed apart)
+  static void lba_preintegrate(LbaJob* J) {  // (any host thread)
+    const auto t0 = std::chrono::steady_clock::now();
+    const int32_t first[2] = {0, (int32_t)J->samples.size()};
+    double prv[81];
+    int32_t st = 0;
+    J->rc = vieo_imu_preintegrate_batch(&J->noise, J->samples.data(), first, &J->ti, &J->tj, J->bg, J->ba, 1, &J->edge, prv, &st);
+    if (J->rc != 0 || st != 0) J->rc = J->rc ? J->rc : -1;
+    std::memcpy(J->edge.Sigma, prv, sizeof(prv));  // mSigmaijPRV for the local BA
+    J->ms_preint = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    J->edge_done = true;
+  }
   static void lba_solve(LbaJob* J) {  // (any host thread)
-    auto t0 = std::chrono::steady_clock::now();
     if (J->need_edge) {
-      const int32_t first[2] = {0, (int32_t)J->samples.size()};
-      double prv[81];
-      int32_t st = 0;
-      J->rc = vieo_imu_preintegrate_batch(&J->noise, J->samples.data(), first, &J->ti, &J->tj, J->bg, J->ba, 1, &J->edge, prv, &st);
-      if (J->rc != 0 || st != 0) {
-        J->rc = J->rc ? J->rc : -1;
-        return;
-      }
-      std::memcpy(J->edge.Sigma, prv, sizeof(prv));  // mSigmaijPRV for the local BA
-      J->edges.back().imu = J->edge;                 // (the newest key frame's edge is the last one built)
-      // (the key frame's pre-integration is LocalMapping::ProcessNewKeyFrame's in the reference, not the optimiser's: timed apart)
-      const auto t1 = std::chrono::steady_clock::now();
-      J->ms_preint = std::chrono::duration<double, std::milli>(t1 - t0).count();
-      t0 = t1;
+      if (!J->edge_done) lba_preintegrate(J);
+      if (J->rc != 0) return;
+      J->edges.back().imu = J->edge;  // (the newest key frame's edge is the last one built)
     }
+    const auto t0 = std::chrono::steady_clock::now();
     if (J->vision)
       J->rc = vieo_local_bundle_adjustment(&J->P.base, J->K.data(), (int)J->K.size(), J->X.data(), (int)J->pts.size(), J->obs.data(),
                                            (int)J->obs.size(), nullptr, J->navs.data(), J->Xo.data(), J->erase.data(), &J->res);
@@ -508,7 +522,19 @@ struct Replay {
         if (lba_quit) return;
         J = lba_todo, lba_todo = nullptr;
       }
+      if (J->need_edge && J->deferred) {  // the pre-integration on the helper thread, beside the flattening
+        if (!pre_thread.joinable()) pre_thread = std::thread(&Replay::pre_worker, this);
+        {
+          std::lock_guard<std::mutex> g(pre_m);
+          pre_todo = J, pre_busy = true;
+        }
+        pre_cv.notify_all();
+      }
       if (J->deferred) lba_build_into(*J);
+      if (J->need_edge && J->deferred) {
+        std::unique_lock<std::mutex> g(pre_m);
+        pre_cv.wait(g, [&] { return !pre_busy; });
+      }
       lba_solve(J);
       lba_post(*J);
       {
@@ -516,6 +542,23 @@ struct Replay {
         lba_busy = false;
       }
       lba_cv.notify_all();
+    }
+  }
+  void pre_worker() {
+    for (;;) {
+      LbaJob* J;
+      {
+        std::unique_lock<std::mutex> g(pre_m);
+        pre_cv.wait(g, [&] { return pre_todo || pre_quit; });
+        if (pre_quit) return;
+        J = pre_todo, pre_todo = nullptr;
+      }
+      lba_preintegrate(J);
+      {
+        std::lock_guard<std::mutex> g(pre_m);
+        pre_busy = false;
+      }
+      pre_cv.notify_all();
     }
   }
   void lba_submit(LbaJob* J) {
