@@ -922,6 +922,22 @@ int vieo_track_after_pose_batch_device(int32_t* d_mp_ref, const int32_t* d_obs_k
                                        const void* d_results, int frames_are_vio, int key_cap,
                                        int n_frames, void* d_next_frames, uint8_t* d_taken,
                                        void* stream);
+/* ... and vieo_track_mark_held_batch_device (below) in the same launch: d_held[f][p_cap] from the entries left. */
+int vieo_track_after_pose_held_batch_device(int32_t* d_mp_ref, const int32_t* d_obs_key, const uint8_t* d_outlier,
+                                            const void* d_frames, const void* d_results, int frames_are_vio, int key_cap,
+                                            int n_frames, void* d_next_frames, uint8_t* d_taken, const int32_t* d_counts,
+                                            int img_first, int img_step, uint8_t* d_held, int p_cap, void* stream);
+/* vieo_track_merge_assign[_rig]_batch_device + vieo_track_build_obs[_depth | _rig]_batch_device as ONE launch (the one-call
+ * tracker's chain is a launch shorter per search): the assignment is merged into d_mp_ref key by key and the observations
+ * are gathered from the merged entries.  d_same_point / d_query_src / d_point_depth / d_cam_first may be NULL (the plain
+ * forms); same outputs as the two calls. */
+int vieo_track_merge_build_obs_batch_device(const int32_t* d_assign, int32_t* d_mp_ref, int point_offset, int reset, int query_div,
+                                            const vieo_last_frame_point* d_same_point, const int32_t* d_query_src, int q_cap,
+                                            const float* d_point_xyz, const float* d_point_depth, float close_depth, int p_cap,
+                                            const vieo_keypoint* d_keys, const float* d_uright, const int32_t* d_counts,
+                                            const int32_t* d_cam_first, int n_cams, int key_cap, int n_frames, int img_first,
+                                            int img_step, const float* d_inv_sigma2, vieo_pose_obs* d_obs, int32_t* d_obs_key,
+                                            void* d_frames, int frames_are_vio, void* stream);
 /* The same with the `close` bit of the observations (vieo_pose_obs.flags bit 0) taken from the depth at which the
  * point was tracked: d_point_depth[f][p_cap] < close_depth (Frame::mvpMapPoints[i]->mTrackDepth against
  * max(10, ThDepth), the stereo chi2 gate of the visual-inertial PoseOptimization, include/Optimizer.h:406-490). */

@@ -128,6 +128,9 @@ _SIGS = {
     "vieo_track_build_obs_depth_batch_device": (c_i, [c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p,
                                                        c_p, c_i, c_p]),
     "vieo_track_mark_held_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "vieo_track_after_pose_held_batch_device": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "vieo_track_merge_build_obs_batch_device": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_i,
+                                                       c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
     "vieo_track_local_queries_device": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "vieo_orb_stream": (c_p, [c_p]),
     "vieo_local_bundle_adjustment": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -11,6 +11,29 @@
 namespace vieo {
 
 // mp_ref[f][key_cap]: index of the point held by keypoint i in the frame's point table, -1 none
+// what a search's assignment makes of key i's entry (AddMapPoint / EraseMapPointMatch)
+struct MergeArgs {
+  const int* assign;  // null: no merge
+  int point_offset, reset, query_div, q_cap;
+  const vieo_last_frame_point* pts;
+  const int* query_src;
+};
+__device__ __forceinline__ int merged_entry(const MergeArgs& M, int f, int i, int key_cap, int cur_in) {
+  int cur = M.reset ? -1 : cur_in;
+  const int a = M.assign[(size_t)f * key_cap + i];
+  if (a >= 0) {
+    const int q = M.query_src ? M.query_src[(size_t)f * M.q_cap + a] : a;  // compacted query list: back to (point, camera)
+    int pi = M.query_div > 1 ? q / M.query_div : q;  // a rig's query (point i, camera c) is i * n_cams + c
+    // a rig frame's map point is held by one key per camera: all of them stand for the first one's table entry
+    if (M.pts) {
+      const int rep = M.pts[(size_t)f * key_cap + pi].reserved[0];
+      if (rep > 0) pi = rep - 1;
+    }
+    cur = M.point_offset + pi;
+  } else if (a == VIEO_SBP_ERASED)
+    cur = -1;
+  return cur;
+}
 __global__ void __launch_bounds__(256)
 k_track_merge_assign(const int* __restrict__ assign, int* __restrict__ mp_ref,
                      const int* __restrict__ counts, int key_cap, int img_first, int img_step,
@@ -24,26 +47,13 @@ k_track_merge_assign(const int* __restrict__ assign, int* __restrict__ mp_ref,
     *m = -1;
     return;
   }
-  int cur = reset ? -1 : *m;
-  const int a = assign[(size_t)f * key_cap + i];
-  if (a >= 0) {
-    const int q = query_src ? query_src[(size_t)f * q_cap + a] : a;  // compacted query list: back to (point, camera)
-    int pi = query_div > 1 ? q / query_div : q;  // a rig's query (point i, camera c) is i * n_cams + c
-    // a rig frame's map point is held by one key per camera: all of them stand for the first one's table entry
-    if (pts) {
-      const int rep = pts[(size_t)f * key_cap + pi].reserved[0];
-      if (rep > 0) pi = rep - 1;
-    }
-    cur = point_offset + pi;
-  }
-  else if (a == VIEO_SBP_ERASED)
-    cur = -1;
-  *m = cur;
+  const MergeArgs M{assign, point_offset, reset, query_div, q_cap, pts, query_src};
+  *m = merged_entry(M, f, i, key_cap, *m);
 }
 
 // one workgroup per frame: compact the held points into observations, in keypoint order
 __global__ void __launch_bounds__(1024)
-k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ point_xyz, int p_cap,
+k_track_build_obs(int* mp_ref, MergeArgs MG, const float* __restrict__ point_xyz, int p_cap,
                   const vieo_keypoint* __restrict__ keys, const float* __restrict__ uright,
                   const int* __restrict__ counts, int key_cap, int img_first, int img_step,
                   const float* __restrict__ inv_sigma2, const float* __restrict__ point_depth, float close_depth,
@@ -54,7 +64,7 @@ k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ poin
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int img = img_first + f * img_step;
   const int N = min(counts[2 * img], key_cap);
-  const int* m = mp_ref + (size_t)f * key_cap;
+  int* m = mp_ref + (size_t)f * key_cap;
   const vieo_keypoint* K = keys + (size_t)img * key_cap;
   const float* ur = uright + (size_t)f * key_cap;
   // A thread owns E consecutive keys, so the order of the edges is the order of the keys with ONE scan over the
@@ -62,8 +72,18 @@ k_track_build_obs(const int* __restrict__ mp_ref, const float* __restrict__ poin
   // for the 6 000 keys of a 4-camera frame.)
   const int nt = (int)blockDim.x, E = (N + nt - 1) / nt, i_lo = tid * E, i_hi = min(i_lo + E, N);
   int cnt = 0;
+  if (MG.assign) {  // k_track_merge_assign in the same launch: a thread's keys are its own, before and after
+    for (int i = N + tid; i < key_cap; i += nt) m[i] = -1;
+#pragma unroll 4
+    for (int i = i_lo; i < i_hi; i++) {
+      const int v = merged_entry(MG, f, i, key_cap, m[i]);
+      m[i] = v;
+      cnt += v >= 0 ? 1 : 0;
+    }
+  } else {
 #pragma unroll 8
-  for (int i = i_lo; i < i_hi; i++) cnt += m[i] >= 0 ? 1 : 0;
+    for (int i = i_lo; i < i_hi; i++) cnt += m[i] >= 0 ? 1 : 0;
+  }
   int inc = cnt;
   for (int o = 1; o < 64; o <<= 1) {
     const int t = __shfl_up(inc, o);
@@ -126,7 +146,8 @@ k_track_after_pose(int* __restrict__ mp_ref, const int* __restrict__ obs_key,
                    const uint8_t* __restrict__ outlier, const uint8_t* frames_base,
                    size_t frame_stride, size_t nobs_offset, int key_cap,
                    const uint8_t* results_base, size_t result_stride, uint8_t* next_frames_base,
-                   size_t next_frame_stride, uint8_t* __restrict__ taken) {
+                   size_t next_frame_stride, uint8_t* __restrict__ taken, uint8_t* __restrict__ held, int p_cap,
+                   const int* __restrict__ counts, int img_first, int img_step) {
   const int f = blockIdx.x, tid = threadIdx.x;
   const int n = *(const int*)(frames_base + (size_t)f * frame_stride + nobs_offset);
   int* m = mp_ref + (size_t)f * key_cap;
@@ -139,6 +160,14 @@ k_track_after_pose(int* __restrict__ mp_ref, const int* __restrict__ obs_key,
     const double* src = (const double*)(results_base + (size_t)f * result_stride);
     double* dst = (double*)(next_frames_base + (size_t)f * next_frame_stride);
     for (int i = tid; i < (int)(sizeof(vieo_navstate) / 8); i += 256) dst[i] = src[i];
+  }
+  if (held) {  // k_track_mark_held in the same launch (the one-call tracker: a launch less on its chain)
+    uint8_t* h = held + (size_t)f * p_cap;
+    for (int i = tid; i < p_cap; i += 256) h[i] = 0;
+    __syncthreads();
+    const int N = min(counts[2 * (img_first + f * img_step)], key_cap);
+    for (int i = tid; i < N; i += 256)
+      if (m[i] >= 0 && m[i] < p_cap) h[m[i]] = 1;
   }
 }
 
@@ -260,8 +289,8 @@ int vieo_track_build_obs_batch_device(const int32_t* d_mp_ref, const float* d_po
     return VIEO_E_INVALID;
   const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
   const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
-  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, d_mp_ref,
-                     d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, const_cast<int32_t*>(d_mp_ref),
+                     MergeArgs{nullptr, 0, 0, 1, 0, nullptr, nullptr}, d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
                      d_inv_sigma2, (const float*)nullptr, 0.f, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
                      base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
                      (const int*)nullptr, 0);
@@ -281,8 +310,8 @@ int vieo_track_build_obs_depth_batch_device(const int32_t* d_mp_ref, const float
     return VIEO_E_INVALID;
   const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
   const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
-  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, d_mp_ref,
-                     d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, const_cast<int32_t*>(d_mp_ref),
+                     MergeArgs{nullptr, 0, 0, 1, 0, nullptr, nullptr}, d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, img_first, img_step,
                      d_inv_sigma2, d_point_depth, close_depth, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
                      base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
                      (const int*)nullptr, 0);
@@ -301,11 +330,32 @@ int vieo_track_build_obs_rig_batch_device(const int32_t* d_mp_ref, const float* 
     return VIEO_E_INVALID;
   const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
   const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
-  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, d_mp_ref,
-                     d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, 0, 1,
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, const_cast<int32_t*>(d_mp_ref),
+                     MergeArgs{nullptr, 0, 0, 1, 0, nullptr, nullptr}, d_point_xyz, p_cap, d_keys, d_uright, d_counts, key_cap, 0, 1,
                      d_inv_sigma2, d_point_depth, close_depth, d_obs, d_obs_key, (uint8_t*)d_frames, stride,
                      base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
                      d_cam_first, n_cams);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_merge_build_obs_batch_device(const int32_t* d_assign, int32_t* d_mp_ref, int point_offset, int reset, int query_div,
+                                            const vieo_last_frame_point* d_same_point, const int32_t* d_query_src, int q_cap,
+                                            const float* d_point_xyz, const float* d_point_depth, float close_depth, int p_cap,
+                                            const vieo_keypoint* d_keys, const float* d_uright, const int32_t* d_counts,
+                                            const int32_t* d_cam_first, int n_cams, int key_cap, int n_frames, int img_first,
+                                            int img_step, const float* d_inv_sigma2, vieo_pose_obs* d_obs, int32_t* d_obs_key,
+                                            void* d_frames, int frames_are_vio, void* stream) {
+  if (!d_assign || !d_mp_ref || query_div < 1 || !d_point_xyz || !d_keys || !d_uright || !d_counts || (d_cam_first && (n_cams < 1 || n_cams > 4)) ||
+      !d_inv_sigma2 || !d_obs || !d_obs_key || !d_frames || key_cap <= 0 || n_frames <= 0)
+    return VIEO_E_INVALID;
+  const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
+  const size_t base = frames_are_vio ? offsetof(vieo_vio_frame, base) : 0;
+  hipLaunchKernelGGL(k_track_build_obs, dim3(n_frames), dim3(key_cap > 2048 ? 1024 : 256), 0, (hipStream_t)stream, d_mp_ref,
+                     MergeArgs{d_assign, point_offset, reset, query_div, q_cap, d_same_point, d_query_src}, d_point_xyz, p_cap, d_keys,
+                     d_uright, d_counts, key_cap, img_first, img_step, d_inv_sigma2, d_point_depth, close_depth, d_obs, d_obs_key,
+                     (uint8_t*)d_frames, stride, base + offsetof(vieo_pose_frame, n_obs), base + offsetof(vieo_pose_frame, obs_begin),
+                     d_cam_first, d_cam_first ? n_cams : 0);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }
@@ -333,7 +383,25 @@ int vieo_track_after_pose_batch_device(int32_t* d_mp_ref, const int32_t* d_obs_k
                      d_obs_key, d_outlier, (const uint8_t*)d_frames, stride,
                      (frames_are_vio ? offsetof(vieo_vio_frame, base) : 0) + offsetof(vieo_pose_frame, n_obs),
                      key_cap, (const uint8_t*)d_results, rstride, (uint8_t*)d_next_frames, stride,
-                     d_taken);
+                     d_taken, (uint8_t*)nullptr, 0, (const int*)nullptr, 0, 0);
+  VIEO_HIP_CHECK(hipGetLastError());
+  return VIEO_OK;
+}
+
+int vieo_track_after_pose_held_batch_device(int32_t* d_mp_ref, const int32_t* d_obs_key, const uint8_t* d_outlier,
+                                            const void* d_frames, const void* d_results, int frames_are_vio, int key_cap,
+                                            int n_frames, void* d_next_frames, uint8_t* d_taken, const int32_t* d_counts,
+                                            int img_first, int img_step, uint8_t* d_held, int p_cap, void* stream) {
+  if (!d_mp_ref || !d_obs_key || !d_outlier || !d_frames || !d_results || key_cap <= 0 || n_frames <= 0 || !d_counts || !d_held ||
+      p_cap <= 0)
+    return VIEO_E_INVALID;
+  const size_t stride = frames_are_vio ? sizeof(vieo_vio_frame) : sizeof(vieo_pose_frame);
+  const size_t rstride = frames_are_vio ? sizeof(vieo_vio_result) : sizeof(vieo_pose_result);
+  hipLaunchKernelGGL(k_track_after_pose, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_mp_ref, d_obs_key, d_outlier,
+                     (const uint8_t*)d_frames, stride,
+                     (frames_are_vio ? offsetof(vieo_vio_frame, base) : 0) + offsetof(vieo_pose_frame, n_obs), key_cap,
+                     (const uint8_t*)d_results, rstride, (uint8_t*)d_next_frames, stride, d_taken, d_held, p_cap, d_counts,
+                     img_first, img_step);
   VIEO_HIP_CHECK(hipGetLastError());
   return VIEO_OK;
 }

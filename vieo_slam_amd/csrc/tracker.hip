@@ -690,15 +690,13 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, SideR
     return vieo_search_by_projection_batch_device(mode, q, d_nq, q_cap, 1, d_kp, d_ur, d_desc, taken, d_cnt, kc, 0, 2,
                                                   t->bounds[0], nn, 1, d_assign, d_nm, st);
   };
-  auto build_obs = [&](void* frame) {
-    if (t->rig)
-      return vieo_track_build_obs_rig_batch_device(d_mpref, d_xyz, d_dep, close, t->pcap, d_kp, d_ur, d_cnt, dO->cam_first, nc, kc,
-                                                   1, dH->consts, d_obs, d_obskey, frame, vio, st);
-    if (t->vision)  // (the vision-only optimisation has no close-point gate)
-      return vieo_track_build_obs_batch_device(d_mpref, d_xyz, t->pcap, d_kp, d_ur, d_cnt, kc, 1, 0, 2, dH->consts, d_obs, d_obskey,
-                                               frame, 0, st);
-    return vieo_track_build_obs_depth_batch_device(d_mpref, d_xyz, d_dep, close, t->pcap, d_kp, d_ur, d_cnt, kc, 1, 0, 2, dH->consts,
-                                                   d_obs, d_obskey, frame, 1, st);
+  // the search's assignment merged into the frame's point table and the observations gathered from it: one launch
+  auto merge_build_obs = [&](void* frame, int point_offset, int reset, const vieo_last_frame_point* same_point, const int32_t* query_src,
+                             int q_cap) {
+    return vieo_track_merge_build_obs_batch_device(d_assign, d_mpref, point_offset, reset, nc, same_point, query_src, q_cap, d_xyz,
+                                                   t->vision ? nullptr : d_dep, close, t->pcap, d_kp, d_ur, d_cnt,
+                                                   t->rig ? dO->cam_first : nullptr, nc, kc, 1, 0, t->rig ? 1 : 2, dH->consts, d_obs,
+                                                   d_obskey, frame, vio, st);
   };
   auto pose = [&](void* frame, void* result) {
     if (t->vision)
@@ -712,13 +710,11 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, SideR
     vieo_proj_query* d_q1c = (vieo_proj_query*)(W + t->w_q1c);
     int32_t* d_qsrc = (int32_t*)(W + t->w_qsrc);
     TRK(search(VIEO_SBP_LAST_FRAME, d_q1c, dO->nq + 1, kc * nc, nullptr, P.nn_last, dO->nm));
-    TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, 0, 1, nc,
-                                                 (const vieo_last_frame_point*)(t->d_up + t->o_pts), d_qsrc, kc * nc, st));
+    TRK(merge_build_obs(f1, 0, 1, (const vieo_last_frame_point*)(t->d_up + t->o_pts), d_qsrc, kc * nc));
   } else {
     TRK(search(VIEO_SBP_LAST_FRAME, d_q1, dH->npts + 1, kc * nc, nullptr, P.nn_last, dO->nm));
-    TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, 0, 1, nc, nullptr, nullptr, 0, st));
+    TRK(merge_build_obs(f1, 0, 1, nullptr, nullptr, 0));
   }
-  TRK(build_obs(f1));
   TRK(pose(f1, r1));
   // a changed local map travels on the second stream; nothing before this line reads it
   TRK(side_rest());
@@ -726,8 +722,7 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, SideR
     if (hipStreamWaitEvent(st, t->ev_tab, 0) != hipSuccess) return VIEO_E_HIP;
     t->tab_pending = false;
   }
-  TRK(vieo_track_after_pose_batch_device(d_mpref, d_obskey, d_outl, f1, r1, vio, kc, 1, f2, d_taken, st));
-  TRK(vieo_track_mark_held_batch_device(d_mpref, d_cnt, kc, 1, 0, 2, d_held, t->pcap, st));
+  TRK(vieo_track_after_pose_held_batch_device(d_mpref, d_obskey, d_outl, f1, r1, vio, kc, 1, f2, d_taken, d_cnt, 0, 2, d_held, t->pcap, st));
   // (the kernel reads only the leading vieo_pose_frame / vieo_pose_result of its two arguments)
   TRK(vieo_track_local_queries_device(&t->ff, (const vieo_vio_frame*)f1, (const vieo_vio_result*)r1,
                                       (const vieo_frustum_point*)(t->d_loc + t->l_cpt), t->d_loc + t->l_cdesc,
@@ -735,8 +730,7 @@ static int track_chain_tail(vieo_tracker* t, int nc_local, bool projected, SideR
                                       t->rig ? t->R.th_far_pts : 0.f, dH->consts + 16, d_q2, d_dep + kc, dO->nq, st));
   (void)vieo_sbp_keep_grid(1);  // the frame's keys have not changed since the first search
   TRK(search(VIEO_SBP_LOCAL_MAP, d_q2, dO->nq, t->ccap * nc, d_taken, P.nn_local, dO->nm + 1));
-  TRK(vieo_track_merge_assign_rig_batch_device(d_assign, d_mpref, d_cnt, kc, 1, 0, 2, kc, 0, nc, nullptr, nullptr, 0, st));
-  TRK(build_obs(f2));
+  TRK(merge_build_obs(f2, kc, 0, nullptr, nullptr, 0));
   TRK(pose(f2, t->vision ? (void*)&dO->r2.base : (void*)&dO->r2));
 #undef TRK
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(256), 0, st, d_obskey, d_outl, &dH->f2, t->d_out + t->q_outl, kc, dO);
